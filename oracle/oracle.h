@@ -1,0 +1,186 @@
+/*
+ * oracle.h -- CPU restatement of the guisongchen/vo_slam_test hot path.
+ *
+ * THIS IS TEST INFRASTRUCTURE, NOT PRODUCT CODE.  Only tests/, the smoke check in
+ * __graft_entry__.py and bench.py's cpu_baseline leg may load liboracle.so.  The
+ * product path (vo_slam_test_amd/, include/vo_hip.h) never includes, links or calls
+ * anything in this directory.
+ *
+ * PARITY UNPINNED: the reference has no tests, golden vectors or fixtures, and
+ * cannot be compiled in this image (OpenCV, Ceres, Sophus, Eigen, DBoW3 absent;
+ * SURVEY.md section 8c).  Every function below cites the reference file:line it
+ * follows; third-party arithmetic (OpenCV 3.x FAST / resize / GaussianBlur /
+ * fastAtan2 / cvRound, Ceres 1.x LM + Schur, old Sophus SE3) is restated from the
+ * published algorithms and the exact variant chosen is written next to it.
+ */
+#ifndef VO_ORACLE_H
+#define VO_ORACLE_H
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* cv::KeyPoint layout (28 bytes): pt.x pt.y size angle response octave class_id */
+typedef struct {
+  float x, y, size, angle, response;
+  int32_t octave, class_id;
+} orc_keypoint;
+
+/* ---------------- ORB extractor (reference src/ORBextractor.cpp) -------------- */
+
+#define ORC_MAX_LEVELS 16
+
+typedef struct {
+  int nfeatures, nlevels, ini_th, min_th;
+  float scale_factor;
+  float scale[ORC_MAX_LEVELS];      /* mvScaleFactor      ORBextractor.cpp:421-427 */
+  float inv_scale[ORC_MAX_LEVELS];  /* mvInvScaleFactor   :430-436 */
+  int quota[ORC_MAX_LEVELS];        /* mnFeaturesPerLevel :440-451 */
+  int umax[16];                     /* circular patch     :457-475 */
+  int8_t pattern[1024];             /* bit_pattern_31_    :154-412 (fed from fixture) */
+} orc_orb_params;
+
+void orc_orb_params_init(orc_orb_params *p, int nfeatures, float scale_factor, int nlevels,
+                         int ini_th, int min_th, const int8_t *pattern1024);
+void orc_level_size(const orc_orb_params *p, int w, int h, int level, int *lw, int *lh);
+
+/* cv::resize(INTER_LINEAR) for CV_8UC1, OpenCV 3.x fixed-point path. */
+void orc_resize_linear_u8(const uint8_t *src, int sw, int sh, int sstride, uint8_t *dst, int dw,
+                          int dh, int dstride);
+/* cv::GaussianBlur(7x7, sigma 2, BORDER_REFLECT_101) for CV_8UC1, OpenCV <=3.4.0 8-bit kernel. */
+void orc_gaussian7_u8(const uint8_t *src, int w, int h, int sstride, uint8_t *dst, int dstride);
+/* cv::FAST(img, kps, threshold, nms=true), TYPE_9_16.  Returns count; x,y,score arrays sized cap. */
+int orc_fast9_16(const uint8_t *img, int cols, int rows, int stride, int threshold, int nms,
+                 int *xs, int *ys, int *scores, int cap);
+float orc_fast_atan2(float y, float x);
+int orc_cv_round_f(float v);
+/* cos/sin of a float angle [rad] as used by the descriptor: deterministic double polynomial,
+ * rounded to float (spec in DESIGN.md "steered BRIEF trig").  *_libm = glibc cosf/sinf. */
+void orc_cos_sin_f(float angle_rad, float *c, float *s);
+void orc_cos_sin_f_libm(float angle_rad, float *c, float *s);
+
+/* ComputeKeyPointsOctTree cell loop for one level (:771-837): candidates in reference order,
+ * coordinates relative to (minBorderX, minBorderY) exactly like vToDistributeKeys. */
+int orc_level_candidates(const orc_orb_params *p, const uint8_t *img, int w, int h, int stride,
+                         float *cx, float *cy, float *cresp, int cap);
+/* DistributeOctTree (:545-769).  Returns number of kept keys, indices into the candidate arrays in
+ * list order.  Tie rule for equal-size nodes = creation order (Q-E3). */
+int orc_distribute_octtree(const float *cx, const float *cy, const float *cresp, int n, int minX,
+                           int maxX, int minY, int maxY, int N, int *out_idx, int cap);
+float orc_ic_angle(const uint8_t *img, int stride, int px, int py, const int *umax);
+void orc_orb_descriptor(const uint8_t *blur, int stride, int px, int py, float angle_deg,
+                        const int8_t *pattern, uint8_t *desc32);
+
+/* Full ORBextractor::operator() (:1051-1112).  kps/desc sized for `cap` key-points.
+ * If pyr_out != NULL it receives nlevels pointers to malloc'ed unpadded level images (caller frees)
+ * and blur_out likewise.  Returns number of key-points or <0 on error. */
+int orc_orb_extract(const orc_orb_params *p, const uint8_t *img, int w, int h, int stride,
+                    orc_keypoint *kps, uint8_t *desc, int cap, int *n_per_level);
+
+/* ---------------- Matcher (reference src/matcher.cpp, src/frame.cpp) ---------- */
+
+int orc_hamming256(const uint8_t *a, const uint8_t *b); /* matcher.cpp:1240-1256 */
+void orc_hamming_matrix(const uint8_t *A, int na, const uint8_t *B, int nb, uint16_t *D);
+void orc_three_max(const int *hist_sizes, int L, int *i1, int *i2, int *i3); /* :1258-1304 */
+
+#define ORC_GRID_COLS 64
+#define ORC_GRID_ROWS 48
+typedef struct {
+  int n;
+  const float *x, *y;      /* unKeypoints_ pt */
+  const int32_t *octave;
+  const float *angle;
+  const float *uright;     /* uRight_ (<=0: no depth) */
+  const uint8_t *desc;     /* n x 32 */
+  float xmin, ymin, xmax, ymax, grid_per_px_w, grid_per_px_h;
+  /* CSR grid built by orc_frame_build_grid: cell (ix,iy) -> [start[ix*48+iy], start[..+1]) */
+  int *cell_start;         /* 64*48+1 */
+  int *cell_items;         /* n */
+} orc_frame;
+
+void orc_frame_build_grid(orc_frame *f); /* frame.cpp:72-89 */
+int orc_features_in_area(const orc_frame *f, float u, float v, float radius, int min_level,
+                         int max_level, int *out, int cap); /* frame.cpp:199-247 */
+
+/* Matcher::searchByProjection(Frame*,Frame*,radius,checkRot) matcher.cpp:18-148 on flat arrays.
+ * Query i carries what the reference reads from frame_last/map point i (already projected):
+ * valid[i], u,v (float pixel), invz, last octave, last angle, descriptor, claimed-feature mask is
+ * in/out: assigned[idx] = query index or -1; `blocked[idx]` = feature already holds an observed
+ * point (mappoints_[idx]->observe_cnt_>0). */
+int orc_match_frame_projection(const orc_frame *cur, int nq, const uint8_t *q_valid,
+                               const float *q_u, const float *q_v, const float *q_invz,
+                               const int32_t *q_octave, const float *q_angle,
+                               const uint8_t *q_desc, float radius, float bf, int direction,
+                               int check_rot, int n_levels, const float *scale_factors,
+                               const uint8_t *blocked, int32_t *assigned);
+/* Matcher::searchByProjection(Frame*, vector<MapPoint*>, thRadius) matcher.cpp:274-353. */
+int orc_match_local_map(const orc_frame *cur, int nq, const uint8_t *q_valid, const float *q_u,
+                        const float *q_v, const float *q_ur, const int32_t *q_level,
+                        const float *q_viewcos, const uint8_t *q_desc, float th_radius,
+                        float ratio, const float *scale_factors, const uint8_t *blocked,
+                        int32_t *assigned);
+
+/* ---------------- Optimizer (reference optimizer_ceres.{h,cpp}) --------------- */
+
+void orc_se3_exp(const double xi[6], double q[4] /*w,x,y,z*/, double t[3]); /* Sophus SE3::exp */
+void orc_se3_log(const double q[4], const double t[3], double xi[6]);       /* Sophus SE3::log */
+void orc_se3_plus(const double x[6], const double delta[6], double out[6]); /* :44-53 */
+void orc_se3_trans_point(const double se3[6], const double pt[3], double out[3]); /* .h:29-95 */
+void orc_se3_apply(const double q[4], const double t[3], const double p[3], double out[3]);
+void orc_angle_axis_to_R(const double aa[3], double R[9] /*column-major*/);
+
+/* residual + Jacobians of one edge; uR<0 => mono (2 rows) else stereo (3 rows).  Returns rows.
+ * Jp row-major rows x 6, Jl row-major rows x 3 (either may be NULL). cam = fx,fy,cx,cy,bf. */
+int orc_edge_eval(const double pose[6], const double pt[3], const double obs[3], double inv_sigma,
+                  const double cam[5], double r[3], double *Jp, double *Jl);
+
+typedef struct {
+  int max_iterations;
+  int iterations;          /* iterations actually run (iteration 0 excluded) */
+  int accepted;
+  double initial_cost, final_cost;
+  double final_radius;
+  int termination;         /* 0 max-iter, 1 function tol, 2 parameter tol, 3 gradient tol, 4 failure */
+  /* optional per-iteration trace (caller supplies arrays of max_iterations+1 or NULL) */
+  double *trace_cost, *trace_radius;
+  int *trace_accepted;
+} orc_lm_summary;
+
+/* Optimizer::solvePoseOnlySE3 (:157-314) on flat arrays.  pose in/out = se3 log [upsilon;omega].
+ * outlier[n] out.  Returns inlier count.  sums: optional [2] LM summaries (round 0, round 1). */
+int orc_pose_only_solve(int n, const double *pts /*n x 3*/, const double *obs /*n x 3*/,
+                        const double *inv_sigma, const double cam[5], double pose[6],
+                        uint8_t *outlier, orc_lm_summary *sums);
+
+/* one Ceres-style LM solve of a BA problem with point-block Schur elimination.
+ * huber_mono/huber_stereo <= 0 => no loss.  edge_active: NULL or mask.  Edges may come in any
+ * order; the oracle processes them in the given order. */
+int orc_ba_lm(int n_cams, double *poses /*n_cams x 6 in/out*/, const uint8_t *cam_fixed,
+              int n_pts, double *points /*n_pts x 3 in/out*/, int n_edges, const int32_t *e_cam,
+              const int32_t *e_pt, const double *e_obs /*n_edges x 3*/, const double *e_inv_sigma,
+              const uint8_t *edge_active, const double cam[5], double huber_mono,
+              double huber_stereo, int max_iterations, orc_lm_summary *sum);
+
+/* Optimizer::solveLocalBAPoseAndPoint (:446-808) numerics on flat arrays: problem 1 (Huber, 5 it),
+ * float chi2 classification, problem 2 (no loss, 10 it), final chi2 pass.  edge_erase[n_edges] out.
+ * stop: polled exactly where the reference polls stopFlag (:594, :612).  Returns 0, or 1 if the
+ * first poll aborted (no write-back, Q-B8). */
+int orc_local_ba(int n_cams, double *poses, const uint8_t *cam_fixed, int n_pts, double *points,
+                 int n_edges, const int32_t *e_cam, const int32_t *e_pt, const double *e_obs,
+                 const double *e_inv_sigma, const double cam[5], const volatile int *stop,
+                 uint8_t *edge_erase, orc_lm_summary *sums /*[2] or NULL*/);
+
+/* Linearisation products at the current point, for K8/K9 checks: Schur S (6nf x 6nf, row-major,
+ * nf = number of free cams in index order), rhs b (6nf), cost.  No LM damping, no Jacobi scaling,
+ * loss applied if huber>0. */
+int orc_ba_schur(int n_cams, const double *poses, const uint8_t *cam_fixed, int n_pts,
+                 const double *points, int n_edges, const int32_t *e_cam, const int32_t *e_pt,
+                 const double *e_obs, const double *e_inv_sigma, const uint8_t *edge_active,
+                 const double cam[5], double huber_mono, double huber_stereo, double point_damping,
+                 double *S, double *b, double *cost);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,174 @@
+"""Seeded synthetic inputs: frames, frame pairs, descriptor sets,
+pose-only and local-BA problems.  No TUM data exists in this environment, so every test,
+fixture and bench line is driven from here.  Pure numpy; no GPU, no oracle, no reference."""
+from __future__ import annotations
+
+import numpy as np
+
+# intrinsics of reference config/example.yaml:20-23,40 (as float32, like Camera::Camera reads them)
+CAM = np.array([np.float32(517.306408), np.float32(516.469215), np.float32(318.643040),
+                np.float32(255.313989), np.float32(40.0)], dtype=np.float64)
+QUOTAS = np.array([217, 181, 151, 126, 105, 87, 73, 60], dtype=np.float64)
+
+
+def _rng(seed: int) -> np.random.Generator:
+    return np.random.Generator(np.random.PCG64(seed))
+
+
+def make_frame(idx: int = 0, w: int = 640, h: int = 480, n_rect: int = 600, n_blob: int = 150,
+               noise: int = 6) -> np.ndarray:
+    """One textured grey frame: rectangles in painter's order, small blobs, uniform noise."""
+    rng = _rng(0x5EED0000 + idx)
+    img = np.full((h, w), 110, dtype=np.int16)
+    for _ in range(n_rect):
+        rw, rh = rng.integers(8, 121, size=2)
+        x0 = int(rng.integers(-rw // 2, w - rw // 2))
+        y0 = int(rng.integers(-rh // 2, h - rh // 2))
+        img[max(y0, 0):max(y0 + rh, 0), max(x0, 0):max(x0 + rw, 0)] = int(rng.integers(20, 236))
+    for _ in range(n_blob):
+        s = int(rng.integers(3, 8))
+        x0 = int(rng.integers(0, w - s))
+        y0 = int(rng.integers(0, h - s))
+        img[y0:y0 + s, x0:x0 + s] = 240 if rng.integers(0, 2) else 15
+    img += rng.integers(-noise, noise + 1, size=img.shape, dtype=np.int16)
+    return np.clip(img, 0, 255).astype(np.uint8)
+
+
+def make_shifted(frame: np.ndarray, idx: int, max_shift: int = 12, noise: int = 6):
+    """Frame k+1 of a pair: integer shift of frame k (edge-replicated) with fresh noise."""
+    rng = _rng(0x5EED8000 + idx)
+    dx, dy = (int(v) for v in rng.integers(-max_shift, max_shift + 1, size=2))
+    h, w = frame.shape
+    ys = np.clip(np.arange(h) - dy, 0, h - 1)
+    xs = np.clip(np.arange(w) - dx, 0, w - 1)
+    out = frame[np.ix_(ys, xs)].astype(np.int16)
+    out += rng.integers(-noise, noise + 1, size=out.shape, dtype=np.int16)
+    return np.clip(out, 0, 255).astype(np.uint8), dx, dy
+
+
+def make_frames(n: int, start: int = 0, **kw) -> np.ndarray:
+    return np.stack([make_frame(start + i, **kw) for i in range(n)])
+
+
+def random_descriptors(n: int, seed: int = 0) -> np.ndarray:
+    return _rng(0xDE5C0000 + seed).integers(0, 256, size=(n, 32), dtype=np.uint8)
+
+
+# --------------------------------------------------------------------------- SE3 helpers
+def _hat(w):
+    return np.array([[0, -w[2], w[1]], [w[2], 0, -w[0]], [-w[1], w[0], 0.0]])
+
+
+def se3_exp(xi):
+    """Reference tangent order [upsilon; omega] -> (R, t)."""
+    ups, om = np.asarray(xi[:3], float), np.asarray(xi[3:], float)
+    th = np.linalg.norm(om)
+    Om = _hat(om)
+    if th < 1e-10:
+        R = np.eye(3) + Om
+        V = np.eye(3) + 0.5 * Om
+    else:
+        R = np.eye(3) + np.sin(th) / th * Om + (1 - np.cos(th)) / th**2 * Om @ Om
+        V = np.eye(3) + (1 - np.cos(th)) / th**2 * Om + (th - np.sin(th)) / th**3 * Om @ Om
+    return R, V @ ups
+
+
+def se3_log(R, t):
+    from scipy.spatial.transform import Rotation
+    om = Rotation.from_matrix(R).as_rotvec()
+    th = np.linalg.norm(om)
+    Om = _hat(om)
+    if th < 1e-10:
+        Vinv = np.eye(3) - 0.5 * Om
+    else:
+        Vinv = np.eye(3) - 0.5 * Om + (1 - th / (2 * np.tan(th / 2))) / th**2 * Om @ Om
+    return np.concatenate([Vinv @ t, om])
+
+
+def project(R, t, P, cam=CAM):
+    pc = P @ R.T + t
+    u = cam[0] * pc[:, 0] / pc[:, 2] + cam[2]
+    v = cam[1] * pc[:, 1] / pc[:, 2] + cam[3]
+    ur = u - cam[4] / pc[:, 2]
+    return u, v, ur, pc[:, 2]
+
+
+def _octaves(rng, n):
+    return rng.choice(8, size=n, p=QUOTAS / QUOTAS.sum())
+
+
+def make_pose_problem(i: int = 0, n: int = 1000, outlier_frac: float = 0.10, mono_frac: float = 0.10):
+    """Config 2: 1 frame x n observations; true pose identity, perturbed initial guess."""
+    rng = _rng(42 + i)
+    z = rng.uniform(0.5, 6.0, n)
+    u = rng.uniform(20, 620, n)
+    v = rng.uniform(20, 460, n)
+    P = np.stack([(u - CAM[2]) * z / CAM[0], (v - CAM[3]) * z / CAM[1], z], axis=1)
+    octv = _octaves(rng, n)
+    sigma = 1.2 ** octv
+    obs = np.stack([u, v, u - CAM[4] / z], axis=1) + rng.normal(0, 1, (n, 3)) * sigma[:, None]
+    mono = rng.random(n) < mono_frac
+    obs[mono, 2] = -1.0
+    out = rng.random(n) < outlier_frac
+    obs[out, 0] = rng.uniform(0, 640, out.sum())
+    obs[out, 1] = rng.uniform(0, 480, out.sum())
+    # observations are float32 pixel coordinates in the reference (cv::KeyPoint, uRight_)
+    obs = obs.astype(np.float32).astype(np.float64)
+    xi0 = np.concatenate([rng.uniform(-0.05, 0.05, 3), rng.uniform(-0.05, 0.05, 3)])
+    inv_sigma = 1.0 / (np.float32(1.2) ** octv.astype(np.float32)).astype(np.float64)
+    return dict(pts=np.ascontiguousarray(P), obs=np.ascontiguousarray(obs), inv_sigma=inv_sigma,
+                cam=CAM.copy(), pose0=xi0)
+
+
+def make_lba_problem(i: int = 0, n_kf: int = 10, n_pts: int = 3000, n_fixed: int = 4,
+                     outlier_frac: float = 0.05, fixed_seen: float = 0.30):
+    """Config 3: n_kf key-frames on a 1 m arc looking at a box of points, KF 0 constant, plus
+    n_fixed extra fixed key-frames each seeing a random 30 % of the points."""
+    rng = _rng(1000 + i)
+    P = np.stack([rng.uniform(-2, 2, n_pts), rng.uniform(-1.5, 1.5, n_pts), rng.uniform(2, 5, n_pts)], 1)
+    n_cam = n_kf + n_fixed
+    poses_true = np.zeros((n_cam, 6))
+    Rs, ts = [], []
+    for c in range(n_cam):
+        if c < n_kf:
+            ang = np.deg2rad(-18 + 36.0 * c / max(n_kf - 1, 1))
+        else:
+            ang = np.deg2rad(rng.uniform(-25, 25))
+        centre = np.array([np.sin(ang) * 1.0, rng.uniform(-0.05, 0.05), -np.cos(ang) * 1.0 + 1.0])
+        yaw = -ang * 0.6
+        Rwc = np.array([[np.cos(yaw), 0, np.sin(yaw)], [0, 1, 0], [-np.sin(yaw), 0, np.cos(yaw)]])
+        Rcw = Rwc.T
+        tcw = -Rcw @ centre
+        Rs.append(Rcw), ts.append(tcw)
+        poses_true[c] = se3_log(Rcw, tcw)
+    e_cam, e_pt, e_obs, e_is = [], [], [], []
+    for j in range(n_pts):
+        for c in range(n_cam):
+            if c >= n_kf and rng.random() > fixed_seen:
+                continue
+            u, v, ur, z = project(Rs[c], ts[c], P[j:j + 1])
+            if z[0] <= 0.2 or not (19 <= u[0] <= 621 and 19 <= v[0] <= 461):
+                continue
+            octv = int(_octaves(rng, 1)[0])
+            sg = 1.2 ** octv
+            o = np.array([u[0], v[0], ur[0]]) + rng.normal(0, 1, 3) * sg
+            if rng.random() < 0.10:
+                o[2] = -1.0
+            if rng.random() < outlier_frac:
+                o[0], o[1] = rng.uniform(0, 640), rng.uniform(0, 480)
+            e_cam.append(c), e_pt.append(j), e_obs.append(o)
+            e_is.append(float(np.float64(1.0) / np.float64(np.float32(1.2) ** np.float32(octv))))
+    fixed = np.zeros(n_cam, np.uint8)
+    fixed[0] = 1
+    fixed[n_kf:] = 1
+    poses0 = poses_true.copy()
+    for c in range(n_cam):
+        if not fixed[c]:
+            poses0[c, :3] += rng.normal(0, 0.01, 3)
+            poses0[c, 3:] += rng.normal(0, np.deg2rad(0.5), 3)
+    pts0 = P + rng.normal(0, 0.02, P.shape)
+    e_obs = np.asarray(e_obs).astype(np.float32).astype(np.float64)
+    return dict(poses=poses0, poses_true=poses_true, fixed=fixed, points=pts0, points_true=P,
+                e_cam=np.asarray(e_cam, np.int32), e_pt=np.asarray(e_pt, np.int32),
+                e_obs=np.ascontiguousarray(e_obs), e_inv_sigma=np.asarray(e_is, np.float64),
+                cam=CAM.copy())
