@@ -1,0 +1,241 @@
+/*
+ * vo_hip.h -- C-ABI of the MI355X (gfx950) implementation of the ORB front end and the
+ * bundle-adjustment back end of guisongchen/vo_slam_test.
+ *
+ * This is the drop-in boundary: the reference has no plugin/FFI interface (its hot path is three
+ * C++ classes inside libvo.so), so each entry point below names the reference member it replaces.
+ * C++ shims with the reference's class names live in include/myslam_shim/ and call only this
+ * header.  Plain pointers and sizes; no C++, torch, OpenCV, Eigen or Ceres types.
+ *
+ * Conventions
+ *   - every function returns VO_OK (0) or a negative vo_status; nothing throws.
+ *   - "host" pointers are ordinary CPU memory, "dev" pointers are HIP device memory (HBM).
+ *   - handles are not re-entrant (like ORBextractor, which mutates mvImagePyramid); use one
+ *     handle per host thread.  Each handle owns one HIP stream unless one is supplied.
+ *   - the library fails loudly (VO_ERR_NO_DEVICE) when no gfx950 device is usable; there is no
+ *     CPU fallback.
+ */
+#ifndef VO_HIP_H
+#define VO_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef enum {
+  VO_OK = 0,
+  VO_ERR_INVALID = -1,   /* bad argument */
+  VO_ERR_NO_DEVICE = -2, /* no usable HIP device */
+  VO_ERR_HIP = -3,       /* a HIP runtime call failed (vo_last_error() has the text) */
+  VO_ERR_CAPACITY = -4,  /* an internal or caller buffer is too small */
+  VO_ERR_STOPPED = -5    /* local BA aborted by the stop flag before the first solve */
+} vo_status;
+
+const char *vo_last_error(void);
+int vo_device_count(void);
+const char *vo_version(void);
+
+/* cv::KeyPoint memory layout (28 bytes) so that the shim can reinterpret the output array. */
+typedef struct {
+  float x, y;     /* pt, level-0 pixel coordinates */
+  float size;     /* 31 * scale[octave], truncated (ORBextractor.cpp:842) */
+  float angle;    /* degrees [0,360) from the intensity centroid */
+  float response; /* FAST score */
+  int32_t octave;
+  int32_t class_id; /* -1 */
+} vo_keypoint;
+
+/* ------------------------------------------------------------------------------------------
+ * ORB extractor  --  replaces ORB_SLAM2::ORBextractor (include/myslam/ORBextractor.h:45-111,
+ * src/ORBextractor.cpp).
+ * ------------------------------------------------------------------------------------------ */
+typedef struct vo_orb vo_orb;
+
+/* ORBextractor::ORBextractor(nfeatures, scaleFactor, nlevels, iniThFAST, minThFAST)
+ * (ORBextractor.cpp:414-476; constructed once at visualOdometry.cpp:31 with 1000,1.2,8,20,7). */
+int vo_orb_create(vo_orb **out, int nfeatures, float scale_factor, int nlevels, int ini_th_fast,
+                  int min_th_fast);
+void vo_orb_destroy(vo_orb *h);
+/* run on a caller-owned hipStream_t instead of the handle's own stream (NULL = default stream) */
+int vo_orb_set_stream(vo_orb *h, void *hip_stream);
+
+/* GetLevels / GetScaleFactor / GetScaleFactors / GetInverseScaleFactors (ORBextractor.h:61-76) */
+int vo_orb_levels(const vo_orb *h);
+float vo_orb_scale_factor(const vo_orb *h);
+int vo_orb_scale_factors(const vo_orb *h, float *scale /*nlevels*/, float *inv_scale /*nlevels or NULL*/);
+int vo_orb_features_per_level(const vo_orb *h, int *quota /*nlevels*/);
+/* upper bound on key-points per frame (the oct-tree may return a few more than nfeatures) */
+int vo_orb_max_keypoints(const vo_orb *h);
+
+/* ORBextractor::operator()(image, mask [ignored], keypoints, descriptors)
+ * (ORBextractor.cpp:1051-1112; called from Frame::Frame, frame.cpp:22).
+ * Host 8-bit grey image in, host key-points (level-major, oct-tree order) and 32-byte descriptors
+ * out.  image == NULL or width/height <= 0 returns VO_OK without touching the outputs (:1054). */
+int vo_orb_extract(vo_orb *h, const uint8_t *image, int width, int height, int stride,
+                   vo_keypoint *keypoints, uint8_t *descriptors, int capacity, int *n_keypoints);
+
+/* The same operator over a batch of frames that is already resident in HBM (bench / pipelines
+ * that keep frames on the device).  Frame f starts at dev_images + f*frame_stride_bytes.
+ * Outputs are device arrays: key-points [n_frames][capacity], descriptors [n_frames][capacity][32],
+ * counts [n_frames].  Asynchronous on the handle's stream; call vo_orb_sync before reading. */
+int vo_orb_extract_batch_dev(vo_orb *h, const uint8_t *dev_images, int n_frames, int width,
+                             int height, int stride, size_t frame_stride_bytes,
+                             vo_keypoint *dev_keypoints, uint8_t *dev_descriptors, int capacity,
+                             int32_t *dev_counts);
+int vo_orb_sync(vo_orb *h);
+
+/* mvImagePyramid[level] of frame `frame` of the last call (ORBextractor.h:85), unpadded, to host.
+ * blurred != 0 returns the 7x7 Gaussian-blurred plane the descriptors were sampled from. */
+int vo_orb_get_level(vo_orb *h, int frame, int level, int blurred, uint8_t *dst, int dst_stride,
+                     int *width, int *height);
+/* FAST candidates of one level of one frame after the per-cell NMS, in reference order
+ * (vToDistributeKeys, ORBextractor.cpp:826-833): x,y relative to the (16,16) border, score. */
+int vo_orb_get_candidates(vo_orb *h, int frame, int level, float *x, float *y, float *response,
+                          int capacity, int *n);
+/* per-level key-point counts of one frame of the last call */
+int vo_orb_get_level_counts(vo_orb *h, int frame, int32_t *counts /*nlevels*/);
+
+/* ------------------------------------------------------------------------------------------
+ * Matcher  --  replaces the arithmetic of myslam::Matcher (include/myslam/matcher.h:9-45,
+ * src/matcher.cpp).  The pointer-graph gather/scatter stays in the C++ shim.
+ * ------------------------------------------------------------------------------------------ */
+
+/* Matcher::computeDistance (matcher.cpp:1240-1256) for all pairs: D[i*nb + j] = Hamming(A_i,B_j).
+ * Device pointers; descriptors are 32 bytes each, 4-byte aligned. */
+int vo_hamming_matrix_dev(const uint8_t *dev_a, int na, const uint8_t *dev_b, int nb,
+                          uint16_t *dev_d, void *hip_stream);
+/* batched: pair p uses A + p*a_stride, B + p*b_stride, D + p*d_stride (strides in elements of
+ * the respective arrays' rows: descriptors / descriptors / uint16) */
+int vo_hamming_matrix_batch_dev(const uint8_t *dev_a, int na, size_t a_stride, const uint8_t *dev_b,
+                                int nb, size_t b_stride, uint16_t *dev_d, size_t d_stride,
+                                int n_pairs, void *hip_stream);
+/* host convenience wrapper (copies in/out) -- also what MapPoint::computeDescriptor's N x N
+ * median selection (mappoint.cpp:140-151) consumes */
+int vo_hamming_matrix(const uint8_t *a, int na, const uint8_t *b, int nb, uint16_t *d);
+
+/* one frame's features as the matcher sees them (Frame members, frame.h:26-45) */
+typedef struct {
+  int32_t n;
+  const float *x, *y;       /* unKeypoints_[i].pt */
+  const int32_t *octave;    /* unKeypoints_[i].octave */
+  const float *angle;       /* unKeypoints_[i].angle */
+  const float *uright;      /* uRight_[i] */
+  const uint8_t *desc;      /* descriptors_ (n x 32) */
+  float xmin, ymin, xmax, ymax; /* Camera::xMin_.. (camera.cpp:40-43) */
+} vo_frame_view;
+
+/* q_flags bit 0: query valid (map point exists, not outlier, projects inside the image);
+ *         bit 1: its map point has observe_cnt_ > 0 (claims the feature for later queries). */
+
+/* Matcher::searchByProjection(Frame* cur, Frame* last, radius, checkRot) (matcher.cpp:18-148).
+ * direction: 1 = forward, 2 = backward, 0 = neither (:47-48,:70-75).  assigned[cur.n] in/out:
+ * query index matched to each feature or -1.  blocked[cur.n]: feature already holds an observed
+ * map point.  Distances come from the device Hamming matrix; the greedy replay is host code.
+ * Returns the match count in *n_matches. */
+int vo_match_frame_projection(const vo_frame_view *cur, int nq, const uint8_t *q_flags,
+                              const float *q_u, const float *q_v, const float *q_invz,
+                              const int32_t *q_octave, const float *q_angle, const uint8_t *q_desc,
+                              float radius, float bf, int direction, int check_rot, int n_levels,
+                              const float *scale_factors, const uint8_t *blocked,
+                              int32_t *assigned, int *n_matches);
+
+/* Matcher::searchByProjection(Frame*, const vector<MapPoint*>&, thRadius) (matcher.cpp:274-353);
+ * ratio = Matcher::ratio_. */
+int vo_match_local_map(const vo_frame_view *cur, int nq, const uint8_t *q_flags, const float *q_u,
+                       const float *q_v, const float *q_ur, const int32_t *q_level,
+                       const float *q_viewcos, const uint8_t *q_desc, float th_radius, float ratio,
+                       const float *scale_factors, const uint8_t *blocked, int32_t *assigned,
+                       int *n_matches);
+
+/* ------------------------------------------------------------------------------------------
+ * Optimizer  --  replaces myslam::Optimizer (include/myslam/optimizer_ceres.h:12-97,
+ * src/optimizer_ceres.cpp) including the Ceres solve it delegates to.
+ * Poses are se3 tangent vectors [upsilon(3); omega(3)] = Sophus SE3::log(Tcw); cam = fx,fy,cx,cy,bf.
+ * ------------------------------------------------------------------------------------------ */
+typedef struct {
+  int32_t iterations;  /* LM iterations run (successful or not) */
+  int32_t accepted;
+  int32_t termination; /* 0 max iterations, 1 function tol., 2 parameter tol., 3 gradient tol., 4 failure */
+  int32_t reserved;
+  double initial_cost, final_cost, final_radius;
+} vo_lm_summary;
+
+/* Optimizer::solvePoseOnlySE3(Frame*) (optimizer_ceres.cpp:157-314) for `n_problems` independent
+ * frames in one launch (one workgroup per frame).  Problem p owns observations
+ * [offsets[p], offsets[p+1]).  obs = (u, v, uR) with uR < 0 for monocular observations.
+ * pose [n_problems][6] in/out, outlier[total obs] out, n_inliers[n_problems] out.
+ * summaries: NULL or [n_problems][2] (Huber round, plain round).  Host pointers. */
+int vo_pose_only_solve(int n_problems, const int32_t *offsets, const double *points,
+                       const double *obs, const double *inv_sigma, const double cam[5],
+                       double *poses, uint8_t *outlier, int32_t *n_inliers,
+                       vo_lm_summary *summaries);
+/* device-resident variant (all pointers device memory, asynchronous on hip_stream) */
+int vo_pose_only_solve_dev(int n_problems, const int32_t *dev_offsets, int max_obs,
+                           const double *dev_points, const double *dev_obs,
+                           const double *dev_inv_sigma, const double *dev_cam5, double *dev_poses,
+                           uint8_t *dev_outlier, int32_t *dev_n_inliers,
+                           vo_lm_summary *dev_summaries, void *hip_stream);
+
+/* Bundle-adjustment problem handle (the arrays Optimizer::solveLocalBAPoseAndPoint gathers at
+ * optimizer_ceres.cpp:446-592).  Edges may be given in any order; they are grouped by point
+ * internally (stable).  cam_fixed[c] != 0 <=> SetParameterBlockConstant (:578-579). */
+typedef struct vo_ba vo_ba;
+int vo_ba_create(vo_ba **out, int n_cams, const double *poses, const uint8_t *cam_fixed, int n_points,
+                 const double *points, int n_edges, const int32_t *edge_cam,
+                 const int32_t *edge_point, const double *edge_obs, const double *edge_inv_sigma,
+                 const double cam[5]);
+void vo_ba_destroy(vo_ba *h);
+int vo_ba_set_stream(vo_ba *h, void *hip_stream);
+/* restrict this handle to the points p with p % n_shards == shard (multi-GPU: one process per
+ * GPU, each owning a shard; cameras replicated).  Must precede any solve. */
+int vo_ba_set_shard(vo_ba *h, int shard, int n_shards);
+int vo_ba_set_state(vo_ba *h, const double *poses, const double *points);
+int vo_ba_get_state(vo_ba *h, double *poses, double *points);
+int vo_ba_n_free_cams(const vo_ba *h);
+
+/* Full Optimizer::solveLocalBAPoseAndPoint numerics (:530-755): Huber LM (5 iterations), float
+ * chi2 classification, plain LM (10 iterations) on the inliers, final chi2 pass.
+ * stop: NULL or the reference's stopFlag, polled exactly at :594 and :612.
+ * edge_erase[n_edges] (host) out in the caller's edge order.  summaries: NULL or [2]. */
+int vo_ba_local_ba(vo_ba *h, const volatile int *stop, uint8_t *edge_erase,
+                   vo_lm_summary *summaries);
+/* One Ceres-style LM solve (ceres::Solve with DENSE_SCHUR at :604 / :699) on the current state.
+ * huber_* <= 0 disables the loss.  edge_active: NULL or host mask in caller's edge order. */
+int vo_ba_solve(vo_ba *h, double huber_mono, double huber_stereo, int max_iterations,
+                const uint8_t *edge_active, vo_lm_summary *summary);
+
+/* Split-phase interface used by the multi-GPU driver and the kernel-level tests:
+ *   vo_ba_linearize   evaluate residuals/Jacobians at the current state, assemble the point
+ *                     blocks and this shard's contribution to the reduced camera system into the
+ *                     device buffer returned by vo_ba_reduced_system(): packed doubles
+ *                     [ S (6nf x 6nf row-major) | b (6nf) | cost | |x|^2 ... ] -- the buffer that is
+ *                     all-reduced (sum) across shards each LM iteration.
+ *   vo_ba_step        Cholesky-solve the (already reduced) system, back-substitute, form the
+ *                     candidate state, evaluate its cost -> second small reduced buffer.
+ *   vo_ba_update      accept / reject, trust-region radius update, convergence flags.
+ * All three are asynchronous on the handle's stream; no host synchronisation inside. */
+int vo_ba_lm_begin(vo_ba *h, double huber_mono, double huber_stereo, int max_iterations,
+                   const uint8_t *edge_active);
+int vo_ba_linearize(vo_ba *h);
+int vo_ba_step(vo_ba *h);
+int vo_ba_update(vo_ba *h);
+int vo_ba_lm_end(vo_ba *h, vo_lm_summary *summary);
+/* device pointers + element counts of the two all-reduce payloads */
+int vo_ba_reduced_system(vo_ba *h, double **dev_ptr, size_t *n_doubles);
+int vo_ba_reduced_cost(vo_ba *h, double **dev_ptr, size_t *n_doubles);
+/* copy out the undamped reduced camera system of the current linearisation (tests):
+ * S [6nf*6nf], b [6nf], cost.  point_damping is added to every point-block diagonal. */
+int vo_ba_debug_schur(vo_ba *h, double huber_mono, double huber_stereo, double point_damping,
+                      const uint8_t *edge_active, double *S, double *b, double *cost);
+
+/* SE3 helpers the shims need (Sophus SE3::exp / log as used at :163,:257,:474,:787) */
+int vo_se3_exp(const double xi[6], double R_rowmajor[9], double t[3]);
+int vo_se3_log(const double R_rowmajor[9], const double t[3], double xi[6]);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* VO_HIP_H */

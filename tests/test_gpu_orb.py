@@ -1,0 +1,114 @@
+"""GPU parity: ORB extractor (HIP, through the C-ABI) vs the CPU oracle, bit-exact."""
+import numpy as np
+import pytest
+
+from vo_slam_test_amd import synth
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ext(vo):
+    e = vo.OrbExtractor(1000, 1.2, 8, 20, 7)
+    yield e
+    e.close()
+
+
+def test_tables_match_oracle(ext, orc):
+    p = orc.orb_params()
+    assert np.array_equal(ext.GetScaleFactors(), np.array(list(p.scale)[:8], np.float32))
+    assert np.array_equal(ext.GetInverseScaleFactors(), np.array(list(p.inv_scale)[:8], np.float32))
+    assert list(ext.features_per_level()) == list(p.quota)[:8]
+    assert ext.GetLevels() == 8
+
+
+@pytest.mark.parametrize("idx", [0, 1, 2])
+def test_stages_bit_exact(ext, orc, idx):
+    """pyramid, blur, FAST candidates (order included), oct-tree selection per level"""
+    img = synth.make_frame(idx)
+    p = orc.orb_params()
+    kps, desc = ext(img)
+    lev = orc.pyramid(p, img)
+    for l in range(8):
+        g = ext.get_level(0, l)
+        assert g.shape == lev[l].shape
+        assert np.array_equal(g, lev[l]), f"pyramid level {l}"
+        assert np.array_equal(ext.get_level(0, l, blurred=True), orc.blur(lev[l])), f"blur level {l}"
+        cx, cy, cr = orc.level_candidates(p, lev[l])
+        gx, gy, gr = ext.get_candidates(0, l)
+        assert len(gx) == len(cx), f"candidate count level {l}: {len(gx)} vs {len(cx)}"
+        assert np.array_equal(gx, cx) and np.array_equal(gy, cy) and np.array_equal(gr, cr), f"candidates {l}"
+
+
+@pytest.mark.parametrize("idx", [0, 1, 2, 3, 4, 5, 6, 7])
+def test_extract_bit_exact(ext, orc, idx):
+    img = synth.make_frame(idx)
+    p = orc.orb_params()
+    okp, odesc, onpl = orc.extract(p, img)
+    kps, desc = ext(img)
+    assert list(ext.get_level_counts(0)) == list(onpl)
+    assert len(kps) == len(okp) >= 1000
+    for name in ("x", "y", "size", "angle", "response", "octave", "class_id"):
+        assert np.array_equal(kps[name], okp[name]), name
+    assert np.array_equal(desc, odesc)
+
+
+def test_other_sizes_and_params(vo, orc):
+    """ragged sizes (non-multiple-of-64 widths, tiny top levels) and a different feature budget"""
+    for (w, h, nf, nl) in [(320, 240, 500, 8), (752, 480, 1500, 8), (401, 301, 300, 5), (128, 96, 200, 4)]:
+        img = synth.make_frame(11, w=w, h=h, n_rect=200, n_blob=60)
+        e = vo.OrbExtractor(nf, 1.2, nl, 20, 7)
+        p = orc.orb_params(nf, 1.2, nl, 20, 7)
+        okp, odesc, _ = orc.extract(p, img, cap=nf + 64)
+        kps, desc = e(img)
+        e.close()
+        assert len(kps) == len(okp), (w, h)
+        assert np.array_equal(kps, okp) and np.array_equal(desc, odesc), (w, h)
+
+
+def test_flat_image_gives_no_keypoints(ext):
+    kps, desc = ext(np.full((480, 640), 100, np.uint8))
+    assert len(kps) == 0 and desc.shape == (0, 32)
+
+
+def test_empty_image_is_noop(ext):
+    kps, desc = ext(np.zeros((0, 0), np.uint8))
+    assert len(kps) == 0
+
+
+def test_strided_input(ext, orc):
+    big = np.zeros((480, 700), np.uint8)
+    big[:, :640] = synth.make_frame(3)
+    view = big[:, :640]
+    import ctypes as C
+    from vo_slam_test_amd import _lib
+    cap = ext.max_keypoints()
+    kps = np.zeros(cap, _lib.KP_DTYPE)
+    desc = np.zeros((cap, 32), np.uint8)
+    n = C.c_int()
+    _lib.check(_lib.lib().vo_orb_extract(ext._h, C.c_void_p(big.ctypes.data), 640, 480, 700,
+                                         C.c_void_p(kps.ctypes.data), C.c_void_p(desc.ctypes.data), cap, C.byref(n)))
+    okp, odesc, _ = orc.extract(orc.orb_params(), np.ascontiguousarray(view))
+    assert n.value == len(okp) and np.array_equal(kps[:n.value], okp) and np.array_equal(desc[:n.value], odesc)
+
+
+def test_batch_device_matches_single(ext, orc):
+    import torch
+    frames = synth.make_frames(6, start=20)
+    dev = torch.from_numpy(frames).cuda()
+    cap = ext.max_keypoints()
+    kps = torch.zeros((6, cap, 28), dtype=torch.uint8, device="cuda")
+    desc = torch.zeros((6, cap, 32), dtype=torch.uint8, device="cuda")
+    cnt = torch.zeros(6, dtype=torch.int32, device="cuda")
+    torch.cuda.synchronize()
+    ext.extract_batch_dev(dev, kps, desc, cnt)
+    ext.sync()
+    from vo_slam_test_amd import _lib
+    p = orc.orb_params()
+    for f in range(6):
+        okp, odesc, _ = orc.extract(p, frames[f])
+        n = int(cnt[f])
+        assert n == len(okp)
+        got = np.frombuffer(kps[f, :n].cpu().numpy().tobytes(), dtype=_lib.KP_DTYPE)
+        assert np.array_equal(got, okp)
+        assert np.array_equal(desc[f, :n].cpu().numpy(), odesc)

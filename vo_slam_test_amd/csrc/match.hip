@@ -1,0 +1,298 @@
+// match.hip -- Hamming distance matrix on gfx950 and the guided greedy matchers that consume it.
+// Replaces the arithmetic of myslam::Matcher (reference src/matcher.cpp): computeDistance
+// (:1240-1256) becomes one all-pairs kernel; the sequential, order-dependent assignment logic of
+// searchByProjection (:18-148, :274-353) is replayed on the host over the device-computed matrix
+// so that match pairs stay identical to the reference's visiting order.
+#include "vo_common.h"
+
+#include <cmath>
+#include <vector>
+
+namespace {
+
+using namespace vo;
+
+// K6: D[i][j] = popcount(A_i xor B_j) over 256 bits.  Each thread keeps two B descriptors in
+// registers (16 VGPRs) and streams a 32-row A tile from LDS (all lanes read the same address:
+// a broadcast, no bank conflict); results leave as one 4-byte store per lane per row, i.e. 256
+// contiguous bytes per wavefront -- the kernel is bound by the 2 bytes/pair it writes.
+__global__ __launch_bounds__(256) void k_hamming(const uint32_t *A, int na, long long a_stride,
+                                                 const uint32_t *B, int nb, long long b_stride,
+                                                 uint16_t *D, long long d_stride) {
+  __shared__ uint32_t a[32][8];
+  const int tid = threadIdx.x;
+  const long long p = blockIdx.z;
+  A += p * a_stride * 8;
+  B += p * b_stride * 8;
+  D += p * d_stride;
+  const int i0 = blockIdx.y * 32;
+  const int j0 = (blockIdx.x * 256 + tid) * 2;
+  {
+    const int r = tid >> 3, w = tid & 7;
+    a[r][w] = (i0 + r < na) ? A[(long long)(i0 + r) * 8 + w] : 0u;
+  }
+  uint32_t b0[8], b1[8];
+#pragma unroll
+  for (int w = 0; w < 8; w++) {
+    b0[w] = j0 < nb ? B[(long long)j0 * 8 + w] : 0u;
+    b1[w] = j0 + 1 < nb ? B[(long long)(j0 + 1) * 8 + w] : 0u;
+  }
+  __syncthreads();
+  if (j0 >= nb) return;
+  const bool pair_store = ((nb & 1) == 0);
+  const int rows = min(32, na - i0);
+  for (int r = 0; r < rows; r++) {
+    int d0 = 0, d1 = 0;
+#pragma unroll
+    for (int w = 0; w < 8; w++) {
+      const uint32_t av = a[r][w];
+      d0 += __popc(av ^ b0[w]);
+      d1 += __popc(av ^ b1[w]);
+    }
+    uint16_t *o = D + (long long)(i0 + r) * nb + j0;
+    if (pair_store) {
+      *reinterpret_cast<uint32_t *>(o) = (uint32_t)d0 | ((uint32_t)d1 << 16);
+    } else {
+      o[0] = (uint16_t)d0;
+      if (j0 + 1 < nb) o[1] = (uint16_t)d1;
+    }
+  }
+}
+
+int launch_hamming(const uint8_t *a, int na, size_t as, const uint8_t *b, int nb, size_t bs, uint16_t *d,
+                   size_t ds, int n_pairs, hipStream_t st) {
+  if (na <= 0 || nb <= 0 || n_pairs <= 0) return VO_OK;
+  dim3 grid((nb + 511) / 512, (na + 31) / 32, n_pairs);
+  hipLaunchKernelGGL(k_hamming, grid, dim3(256), 0, st, reinterpret_cast<const uint32_t *>(a), na, (long long)as,
+                     reinterpret_cast<const uint32_t *>(b), nb, (long long)bs, d, (long long)ds);
+  VO_HIP_CHECK(hipGetLastError());
+  return VO_OK;
+}
+
+// ---- host replay helpers -----------------------------------------------------------------
+constexpr int kGridCols = 64, kGridRows = 48;  // FRAME_GRID_COLS/ROWS, camera.h:8-9
+constexpr int TH_HIGH = 100;                   // matcher.cpp:11
+constexpr int HISTO_LENGTH = 30;               // :13
+
+struct Grid {  // Frame::assignFeaturesToGrid, frame.cpp:72-89
+  std::vector<int> start, items;
+  float gw, gh, xmin, ymin;
+  explicit Grid(const vo_frame_view &f) : start(kGridCols * kGridRows + 1, 0), items(f.n > 0 ? f.n : 0) {
+    xmin = f.xmin, ymin = f.ymin;
+    gw = (float)kGridCols / (f.xmax - f.xmin);  // camera.cpp:45-46
+    gh = (float)kGridRows / (f.ymax - f.ymin);
+    std::vector<int> cell(f.n, -1);
+    for (int i = 0; i < f.n; i++) {
+      const int gx = (int)roundf((f.x[i] - xmin) * gw), gy = (int)roundf((f.y[i] - ymin) * gh);
+      if (gx < 0 || gx >= kGridCols || gy < 0 || gy >= kGridRows) continue;
+      cell[i] = gx * kGridRows + gy;
+      start[cell[i] + 1]++;
+    }
+    for (size_t c = 1; c < start.size(); c++) start[c] += start[c - 1];
+    std::vector<int> fill(start.begin(), start.end() - 1);
+    for (int i = 0; i < f.n; i++)
+      if (cell[i] >= 0) items[fill[cell[i]]++] = i;
+  }
+  // Frame::getFeaturesInArea, frame.cpp:199-247
+  void query(const vo_frame_view &f, float u, float v, float r, int lmin, int lmax, std::vector<int> &out) const {
+    out.clear();
+    const int x0 = std::max(0, (int)floorf((u - xmin - r) * gw));
+    if (x0 >= kGridCols) return;
+    const int x1 = std::min(kGridCols - 1, (int)floorf((u - xmin + r) * gw));
+    if (x1 < 0) return;
+    const int y0 = std::max(0, (int)floorf((v - ymin - r) * gh));
+    if (y0 >= kGridRows) return;
+    const int y1 = std::min(kGridRows - 1, (int)floorf((v - ymin + r) * gh));
+    if (y1 < 0) return;
+    for (int ix = x0; ix <= x1; ix++)
+      for (int iy = y0; iy <= y1; iy++) {
+        const int c = ix * kGridRows + iy;
+        for (int t = start[c]; t < start[c + 1]; t++) {
+          const int k = items[t];
+          if (f.octave[k] < lmin || f.octave[k] > lmax) continue;
+          if (fabsf(f.x[k] - u) < r && fabsf(f.y[k] - v) < r) out.push_back(k);
+        }
+      }
+  }
+};
+
+// device all-pairs distances for (queries x features), back on the host
+int distance_matrix(const uint8_t *q_desc, int nq, const uint8_t *f_desc, int nf, std::vector<uint16_t> &D) {
+  D.assign((size_t)nq * nf, 0);
+  if (nq <= 0 || nf <= 0) return VO_OK;
+  return vo_hamming_matrix(q_desc, nq, f_desc, nf, D.data());
+}
+
+void three_max(const std::vector<std::vector<int>> &h, int &i1, int &i2, int &i3) {  // matcher.cpp:1258-1304
+  int m1 = 0, m2 = 0, m3 = 0;
+  i1 = i2 = i3 = -1;
+  for (int i = 0; i < (int)h.size(); i++) {
+    const int s = (int)h[i].size();
+    if (s > m1) {
+      m3 = m2, i3 = i2, m2 = m1, i2 = i1, m1 = s, i1 = i;
+    } else if (s > m2) {
+      m3 = m2, i3 = i2, m2 = s, i2 = i;
+    } else if (s > m3) {
+      m3 = s, i3 = i;
+    }
+  }
+  if (m2 < 0.1f * (float)m1)
+    i2 = i3 = -1;
+  else if (m3 < 0.1f * (float)m1)
+    i3 = -1;
+}
+
+}  // namespace
+
+extern "C" {
+
+int vo_hamming_matrix_dev(const uint8_t *a, int na, const uint8_t *b, int nb, uint16_t *d, void *stream) {
+  if ((na > 0 && !a) || (nb > 0 && !b) || (na > 0 && nb > 0 && !d) || na < 0 || nb < 0) return VO_ERR_INVALID;
+  VO_CHECK(vo::ensure_device());
+  return launch_hamming(a, na, 0, b, nb, 0, d, 0, 1, (hipStream_t)stream);
+}
+
+int vo_hamming_matrix_batch_dev(const uint8_t *a, int na, size_t as, const uint8_t *b, int nb, size_t bs,
+                                uint16_t *d, size_t ds, int n_pairs, void *stream) {
+  if (!a || !b || !d || na < 0 || nb < 0 || n_pairs < 0) return VO_ERR_INVALID;
+  VO_CHECK(vo::ensure_device());
+  return launch_hamming(a, na, as, b, nb, bs, d, ds, n_pairs, (hipStream_t)stream);
+}
+
+int vo_hamming_matrix(const uint8_t *a, int na, const uint8_t *b, int nb, uint16_t *d) {
+  if (na < 0 || nb < 0) return VO_ERR_INVALID;
+  if (na == 0 || nb == 0) return VO_OK;
+  if (!a || !b || !d) return VO_ERR_INVALID;
+  VO_CHECK(vo::ensure_device());
+  vo::DevBuf da, db, dd;
+  int rc = VO_OK;
+  do {
+    if ((rc = da.reserve((size_t)na * 32)) != VO_OK) break;
+    if ((rc = db.reserve((size_t)nb * 32)) != VO_OK) break;
+    if ((rc = dd.reserve((size_t)na * nb * 2)) != VO_OK) break;
+    if (hipMemcpy(da.p, a, (size_t)na * 32, hipMemcpyHostToDevice) != hipSuccess ||
+        hipMemcpy(db.p, b, (size_t)nb * 32, hipMemcpyHostToDevice) != hipSuccess) {
+      vo::set_error("hipMemcpy H2D failed");
+      rc = VO_ERR_HIP;
+      break;
+    }
+    if ((rc = launch_hamming(da.as<uint8_t>(), na, 0, db.as<uint8_t>(), nb, 0, dd.as<uint16_t>(), 0, 1, nullptr)) != VO_OK)
+      break;
+    if (hipMemcpy(d, dd.p, (size_t)na * nb * 2, hipMemcpyDeviceToHost) != hipSuccess) {
+      vo::set_error("hipMemcpy D2H failed");
+      rc = VO_ERR_HIP;
+    }
+  } while (0);
+  da.release(), db.release(), dd.release();
+  return rc;
+}
+
+int vo_match_frame_projection(const vo_frame_view *cur, int nq, const uint8_t *q_flags, const float *q_u,
+                              const float *q_v, const float *q_invz, const int32_t *q_octave,
+                              const float *q_angle, const uint8_t *q_desc, float radius, float bf, int direction,
+                              int check_rot, int n_levels, const float *scale_factors, const uint8_t *blocked_in,
+                              int32_t *assigned, int *n_matches) {
+  if (!cur || nq < 0 || !assigned || !n_matches || !scale_factors) return VO_ERR_INVALID;
+  *n_matches = 0;
+  if (nq == 0 || cur->n == 0) return VO_OK;
+  std::vector<uint16_t> D;
+  VO_CHECK(distance_matrix(q_desc, nq, cur->desc, cur->n, D));
+  const Grid grid(*cur);
+  const float pdf = HISTO_LENGTH / 360.0f;
+  std::vector<std::vector<int>> rot(HISTO_LENGTH);
+  std::vector<uint8_t> blocked(cur->n, 0);
+  if (blocked_in) blocked.assign(blocked_in, blocked_in + cur->n);
+  std::vector<int> cand;
+  int cnt = 0;
+  for (int i = 0; i < nq; i++) {
+    if (!(q_flags[i] & 1)) continue;
+    const int oct = q_octave[i];
+    const float rs = radius * scale_factors[oct];
+    if (direction == 1)
+      grid.query(*cur, q_u[i], q_v[i], rs, oct, n_levels, cand);
+    else if (direction == 2)
+      grid.query(*cur, q_u[i], q_v[i], rs, 0, oct, cand);
+    else
+      grid.query(*cur, q_u[i], q_v[i], rs, oct - 1, oct + 1, cand);
+    int best = 256, best_idx = -1;
+    for (int idx : cand) {
+      if (blocked[idx]) continue;
+      if (cur->uright[idx] > 0) {
+        const float ur = q_u[i] - bf * q_invz[i];
+        if (fabsf(ur - cur->uright[idx]) > rs) continue;
+      }
+      const int d = D[(size_t)i * cur->n + idx];
+      if (d < best) best = d, best_idx = idx;
+    }
+    if (best <= TH_HIGH) {
+      assigned[best_idx] = i;
+      blocked[best_idx] = (q_flags[i] >> 1) & 1;
+      cnt++;
+      if (check_rot) {
+        float r = q_angle[i] - cur->angle[best_idx];
+        if (r < 0) r += 360.0f;
+        int bin = (int)lrintf(r * pdf);
+        if (bin == HISTO_LENGTH) bin = 0;
+        rot[bin].push_back(best_idx);
+      }
+    }
+  }
+  if (check_rot) {
+    int i1, i2, i3;
+    three_max(rot, i1, i2, i3);
+    for (int b = 0; b < HISTO_LENGTH; b++)
+      if (b != i1 && b != i2 && b != i3)
+        for (int idx : rot[b]) {
+          assigned[idx] = -1;
+          cnt--;
+        }
+  }
+  *n_matches = cnt;
+  return VO_OK;
+}
+
+int vo_match_local_map(const vo_frame_view *cur, int nq, const uint8_t *q_flags, const float *q_u, const float *q_v,
+                       const float *q_ur, const int32_t *q_level, const float *q_viewcos, const uint8_t *q_desc,
+                       float th_radius, float ratio, const float *scale_factors, const uint8_t *blocked_in,
+                       int32_t *assigned, int *n_matches) {
+  if (!cur || nq < 0 || !assigned || !n_matches || !scale_factors) return VO_ERR_INVALID;
+  *n_matches = 0;
+  if (nq == 0 || cur->n == 0) return VO_OK;
+  std::vector<uint16_t> D;
+  VO_CHECK(distance_matrix(q_desc, nq, cur->desc, cur->n, D));
+  const Grid grid(*cur);
+  std::vector<uint8_t> blocked(cur->n, 0);
+  if (blocked_in) blocked.assign(blocked_in, blocked_in + cur->n);
+  std::vector<int> cand;
+  int cnt = 0;
+  for (int i = 0; i < nq; i++) {
+    if (!(q_flags[i] & 1)) continue;
+    float radius = q_viewcos[i] > 0.998 ? 2.5f : 4.0f;  // :288-291
+    radius *= th_radius;
+    const int lv = q_level[i];
+    const float rs = radius * scale_factors[lv];
+    grid.query(*cur, q_u[i], q_v[i], rs, lv - 1, lv, cand);
+    int best = 256, best_lv = -1, second = 256, second_lv = -1, best_idx = -1;
+    for (int idx : cand) {
+      if (blocked[idx]) continue;
+      if (cur->uright[idx] > 0 && fabsf(q_ur[i] - cur->uright[idx]) > rs) continue;
+      const int d = D[(size_t)i * cur->n + idx];
+      if (d < best) {
+        second = best, second_lv = best_lv;
+        best = d, best_lv = cur->octave[idx], best_idx = idx;
+      } else if (d < second) {
+        second = d, second_lv = cur->octave[idx];
+      }
+    }
+    if (best <= TH_HIGH) {
+      if (best_lv == second_lv && (float)best > ratio * (float)second) continue;
+      assigned[best_idx] = i;
+      blocked[best_idx] = (q_flags[i] >> 1) & 1;
+      cnt++;
+    }
+  }
+  *n_matches = cnt;
+  return VO_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,1177 @@
+// orb.hip -- ORB extractor for gfx950 (MI355X): image pyramid, per-cell FAST-9-16 + NMS,
+// oct-tree key-point distribution, intensity-centroid orientation, 7x7 Gaussian blur and steered
+// BRIEF, all device-resident and batched over frames.  Replaces ORB_SLAM2::ORBextractor
+// (reference src/ORBextractor.cpp); every kernel cites the lines it stands in for.
+//
+// Compiled with -ffp-contract=off: the float expressions that decide integer results
+// (fastAtan2 polynomial, x*b + y*a sample coordinates, pt *= scale) must round exactly like the
+// x86-64 reference build, which has no FMA.
+#include "vo_common.h"
+
+#include <cmath>
+#include <mutex>
+#include <vector>
+
+namespace {
+
+using namespace vo;
+
+constexpr int kMaxLevels = 16;
+constexpr int kEdge = 19;          // EDGE_THRESHOLD  ORBextractor.cpp:76
+constexpr int kBorder = kEdge - 3; // minBorderX/Y    :778-779
+constexpr int kHalfPatch = 15;     // HALF_PATCH_SIZE :75
+constexpr int kTileP = 72;         // LDS pitch of a FAST cell tile (cell <= 66 px incl. 6 px overlap)
+constexpr int kMaxList = 1024;     // oct-tree node list capacity per level (quota <= kMaxList-4)
+
+__constant__ int8_t c_pattern[1024] = {
+#include "orb_pattern.inc"
+};
+
+struct LevelGeom {
+  int w, h, pitch;
+  long long pyr_off;   // byte offset in the per-frame pyramid block (levels >= 1)
+  long long blur_off;  // byte offset in the per-frame blurred block
+  int nCols, nRows, wCell, hCell, maxBX, maxBY;
+  int cellBase, nCells, capCell;
+  long long slotBase;  // u32 offset in the per-frame cell-slot block
+  int quota, capSel, selBase;
+  int candCap, candBase;
+  int nIni;
+  float hX;
+  float scale;
+  int patchSize;
+  int tileBase, tilesX, tilesY;
+};
+
+struct OrbDev {
+  int nlevels, ini_th, min_th, pad;
+  int umax[16];
+  LevelGeom lv[kMaxLevels];
+};
+
+struct FrameSrc {  // where level 0 lives (caller memory) and where levels >= 1 live (ours)
+  const uint8_t *img0;
+  long long img0_frame_stride;
+  int img0_pitch;
+  uint8_t *pyr;
+  long long pyr_frame_stride;
+  uint8_t *blur;
+  long long blur_frame_stride;
+};
+
+__device__ __forceinline__ const uint8_t *level_plane(const OrbDev &P, const FrameSrc &S, int l, int f,
+                                                      int &pitch) {
+  if (l == 0) {
+    pitch = S.img0_pitch;
+    return S.img0 + (long long)f * S.img0_frame_stride;
+  }
+  pitch = P.lv[l].pitch;
+  return S.pyr + (long long)f * S.pyr_frame_stride + P.lv[l].pyr_off;
+}
+
+// ------------------------------------------------------------------------------------------
+// K1  cv::resize(INTER_LINEAR, CV_8U) -- ComputePyramid, ORBextractor.cpp:1129.
+// OpenCV 3.x fixed point: 11-bit coefficients (tables built on the host, orb_resize_tables()),
+// horizontal pass in int32, vertical pass ((b0*(r0>>4))>>16) + ((b1*(r1>>4))>>16) + 2) >> 2.
+// One thread per output pixel; source rows come through L1/L2 (each source byte is touched by
+// <= 4 neighbouring threads).
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_resize(const uint8_t *src, long long s_frame_stride, int s_pitch,
+                                                int sw, int sh, uint8_t *dst, long long d_frame_stride,
+                                                int d_pitch, int dw, int dh, const int *xofs,
+                                                const int *xab, const int *yofs, const int *yab) {
+  const int dx = blockIdx.x * 64 + threadIdx.x;
+  const int dy = blockIdx.y * 4 + threadIdx.y;
+  if (dx >= dw || dy >= dh) return;
+  const uint8_t *S = src + (long long)blockIdx.z * s_frame_stride;
+  const int sx = xofs[dx];
+  const int sx1 = min(sx + 1, sw - 1);
+  const int ab = xab[dx];
+  const int a0 = (short)(ab & 0xffff), a1 = ab >> 16;
+  const int sy = yofs[dy];
+  const int sy0 = min(max(sy, 0), sh - 1), sy1 = min(max(sy + 1, 0), sh - 1);
+  const int bb = yab[dy];
+  const int b0 = (short)(bb & 0xffff), b1 = bb >> 16;
+  const uint8_t *R0 = S + (long long)sy0 * s_pitch, *R1 = S + (long long)sy1 * s_pitch;
+  const int r0 = R0[sx] * a0 + R0[sx1] * a1;
+  const int r1 = R1[sx] * a0 + R1[sx1] * a1;
+  int v = (((b0 * (r0 >> 4)) >> 16) + ((b1 * (r1 >> 4)) >> 16) + 2) >> 2;
+  v = min(max(v, 0), 255);
+  dst[(long long)blockIdx.z * d_frame_stride + (long long)dy * d_pitch + dx] = (uint8_t)v;
+}
+
+// ------------------------------------------------------------------------------------------
+// K2  cv::FAST(cell, threshold, nms=true) per 30-px grid cell with the 20 -> 7 threshold fallback
+// -- ComputeKeyPointsOctTree cell loop, ORBextractor.cpp:796-837.
+// One 256-thread workgroup per (cell, frame).  The cell sub-image (<= 66x66 incl. the 6-px
+// overlap) is staged in LDS; every interior pixel gets S = max over the 16 nine-pixel arcs of the
+// minimum |centre - ring| (bright or dark), so "corner at threshold t" <=> S > t and the OpenCV
+// cornerScore is S-1, independent of t.  NMS runs on the LDS score tile with scores below the
+// cell's current threshold read as 0 and pixels outside the cell interior as 0 (Q-E2).  Survivors
+// are written in raster order (ballot + prefix) to the cell's slot: x | y<<12 | score<<24 with
+// x,y already shifted by (j*wCell, i*hCell) like :830-831.
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ int fast_arc_score(const uint8_t *t, int min_th) {
+  const int TP = kTileP;
+  const int v = t[0];
+  int d[16];
+  d[0] = v - t[3 * TP];
+  d[1] = v - t[3 * TP + 1];
+  d[2] = v - t[2 * TP + 2];
+  d[3] = v - t[TP + 3];
+  d[4] = v - t[3];
+  d[5] = v - t[-TP + 3];
+  d[6] = v - t[-2 * TP + 2];
+  d[7] = v - t[-3 * TP + 1];
+  d[8] = v - t[-3 * TP];
+  d[9] = v - t[-3 * TP - 1];
+  d[10] = v - t[-2 * TP - 2];
+  d[11] = v - t[-TP - 3];
+  d[12] = v - t[-3];
+  d[13] = v - t[TP - 3];
+  d[14] = v - t[2 * TP - 2];
+  d[15] = v - t[3 * TP - 1];
+  int mn3[16], mx3[16];
+#pragma unroll
+  for (int k = 0; k < 16; k++) {
+    mn3[k] = min(d[k], min(d[(k + 1) & 15], d[(k + 2) & 15]));
+    mx3[k] = max(d[k], max(d[(k + 1) & 15], d[(k + 2) & 15]));
+  }
+  int sd = -1000, sb = 1000;
+#pragma unroll
+  for (int k = 0; k < 16; k++) {
+    sd = max(sd, min(mn3[k], min(mn3[(k + 3) & 15], mn3[(k + 6) & 15])));
+    sb = min(sb, max(mx3[k], max(mx3[(k + 3) & 15], mx3[(k + 6) & 15])));
+  }
+  const int S = max(sd, -sb);
+  return S > min_th ? S - 1 : 0;
+}
+
+__global__ __launch_bounds__(256) void k_fast_cells(OrbDev P, FrameSrc src, uint32_t *cell_slots,
+                                                    long long slots_frame_stride, int *cell_count,
+                                                    int cells_per_frame) {
+  __shared__ uint8_t tile[kTileP * kTileP];
+  __shared__ uint8_t score[kTileP * kTileP];
+  __shared__ int wcnt[4];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int cell = blockIdx.x, f = blockIdx.y;
+  int l = 0;
+  while (l + 1 < P.nlevels && cell >= P.lv[l + 1].cellBase) l++;
+  const LevelGeom &L = P.lv[l];
+  const int ci = cell - L.cellBase;
+  const int ci_i = ci / L.nCols, ci_j = ci - ci_i * L.nCols;
+  const int iniX = kBorder + ci_j * L.wCell, iniY = kBorder + ci_i * L.hCell;
+  int *out_count = cell_count + (long long)f * cells_per_frame + cell;
+  if (iniX >= L.maxBX - 6 || iniY >= L.maxBY - 3) {  // :801, :811
+    if (tid == 0) *out_count = 0;
+    return;
+  }
+  const int maxX = min(iniX + L.wCell + 6, L.maxBX), maxY = min(iniY + L.hCell + 6, L.maxBY);
+  const int cw = maxX - iniX, ch = maxY - iniY;
+  int pitch;
+  const uint8_t *img = level_plane(P, src, l, f, pitch);
+  for (int idx = tid; idx < cw * ch; idx += 256) {
+    const int y = idx / cw, x = idx - y * cw;
+    tile[y * kTileP + x] = img[(long long)(iniY + y) * pitch + iniX + x];
+    score[y * kTileP + x] = 0;
+  }
+  __syncthreads();
+  const int iw = cw - 6, ih = ch - 6;
+  const int ni = (iw > 0 && ih > 0) ? iw * ih : 0;
+  for (int idx = tid; idx < ni; idx += 256) {
+    const int y = 3 + idx / iw, x = 3 + idx % iw;
+    score[y * kTileP + x] = (uint8_t)fast_arc_score(&tile[y * kTileP + x], P.min_th);
+  }
+  __syncthreads();
+  uint32_t *slot = cell_slots + (long long)f * slots_frame_stride + L.slotBase + (long long)ci * L.capCell;
+  int running = 0;
+  for (int pass = 0; pass < 2; pass++) {
+    const int th = pass == 0 ? P.ini_th : P.min_th;
+    running = 0;
+    for (int base = 0; base < ni; base += 256) {
+      const int idx = base + tid;
+      bool keep = false;
+      int x = 0, y = 0, s = 0;
+      if (idx < ni) {
+        y = 3 + idx / iw, x = 3 + idx % iw;
+        const uint8_t *c = &score[y * kTileP + x];
+        s = c[0];
+        if (s >= th) {
+          int nb = 0;
+#define NBR(o) nb = max(nb, (int)c[o] >= th ? (int)c[o] : 0)
+          NBR(-kTileP - 1); NBR(-kTileP); NBR(-kTileP + 1);
+          NBR(-1); NBR(1);
+          NBR(kTileP - 1); NBR(kTileP); NBR(kTileP + 1);
+#undef NBR
+          keep = s > nb;
+        }
+      }
+      const unsigned long long mask = __ballot(keep);
+      if (lane == 0) wcnt[wave] = __popcll(mask);
+      __syncthreads();
+      int off = running + __popcll(mask & ((1ull << lane) - 1ull));
+      int tot = 0;
+      for (int w2 = 0; w2 < 4; w2++) {
+        if (w2 < wave) off += wcnt[w2];
+        tot += wcnt[w2];
+      }
+      if (keep && off < L.capCell)
+        slot[off] = (uint32_t)(x + ci_j * L.wCell) | ((uint32_t)(y + ci_i * L.hCell) << 12) | ((uint32_t)s << 24);
+      running += tot;
+      __syncthreads();
+    }
+    if (running > 0) break;  // :820 `if(vKeysCell.empty())` retry with minThFAST
+  }
+  if (tid == 0) *out_count = min(running, L.capCell);
+}
+
+// ------------------------------------------------------------------------------------------
+// E3/E4  ExtractorNode::DivideNode + ORBextractor::DistributeOctTree, ORBextractor.cpp:487-769.
+// One 256-thread workgroup per (level, frame).  The std::list of nodes is an LDS array in list
+// order; keys never move -- each key carries the list position of its node.  One pass =
+//   (1) order the expandable nodes (count > 1): list order in the breadth phase (:599-657), by
+//       (size desc, creation order desc) in the "careful" phase (:679-744; Q-E3 tie rule),
+//   (2) count keys per child with LDS atomics, (3) prefix sums give the cut-off where the list
+//       reaches N and every node's new list position (children are push_front'ed, so later-
+//       processed parents come first and n4,n3,n2,n1 within a parent), (4) relabel keys.
+// The best-response key of each final node (first wins on ties, :748-766) is an atomicMax over
+// (response, -candidate index).
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ int block_excl_scan(int v, int *wsum /*LDS[5]*/, int *total) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  int x = v;
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) {
+    int y = __shfl_up(x, o);
+    if (lane >= o) x += y;
+  }
+  __syncthreads();  // protect wsum reuse
+  if (lane == 63) wsum[wave] = x;
+  __syncthreads();
+  int base = 0, tot = 0;
+  for (int w = 0; w < 4; w++) {
+    if (w < wave) base += wsum[w];
+    tot += wsum[w];
+  }
+  *total = tot;
+  return base + x - v;
+}
+
+struct OctLds {
+  unsigned short x0[2][kMaxList], y0[2][kMaxList], x1[2][kMaxList], y1[2][kMaxList];
+  unsigned short cnt[2][kMaxList], seq[2][kMaxList];
+  unsigned short prank[kMaxList];   // processing rank of an expandable node, 0xffff otherwise
+  unsigned short order[kMaxList];   // rank -> list position
+  unsigned short newpos_old[kMaxList];
+  unsigned short newpos_child[kMaxList * 4];
+  int ccount[kMaxList * 4];
+  int cprefix[kMaxList];            // inclusive prefix over ranks of nonempty-children counts
+  unsigned int best[kMaxList];
+  int wsum[8];
+  int s_m, s_cutoff, s_newsize, s_nexp, s_total;
+};
+
+__device__ __forceinline__ int quadrant_of(int kx, int ky, int x0, int y0, int x1, int y1) {
+  const int midx = x0 + ((x1 - x0 + 1) >> 1);  // UL.x + ceil((UR.x-UL.x)/2)   :489
+  const int midy = y0 + ((y1 - y0 + 1) >> 1);
+  return (kx < midx ? 0 : 1) + (ky < midy ? 0 : 2);  // n1,n2,n3,n4            :522-534
+}
+
+__global__ __launch_bounds__(256) void k_octree(OrbDev P, const uint32_t *cell_slots,
+                                                long long slots_frame_stride, const int *cell_count,
+                                                int cells_per_frame, uint32_t *key_data,
+                                                unsigned short *key_label, int keys_per_frame,
+                                                int *cand_count, uint32_t *sel, int sel_per_frame,
+                                                int *nk, int *err_flag) {
+  __shared__ OctLds S;
+  const int tid = threadIdx.x;
+  const int l = blockIdx.x, f = blockIdx.y;
+  const LevelGeom &L = P.lv[l];
+  uint32_t *kd = key_data + (long long)f * keys_per_frame + L.candBase;
+  unsigned short *kl = key_label + (long long)f * keys_per_frame + L.candBase;
+  const int *cc = cell_count + (long long)f * cells_per_frame + L.cellBase;
+  const uint32_t *slots = cell_slots + (long long)f * slots_frame_stride + L.slotBase;
+  const int N = L.quota;
+
+  // ---- gather the per-cell lists in reference order (cell row-major, raster inside a cell)
+  int n = 0;
+  for (int base = 0; base < L.nCells; base += 256) {
+    const int c = base + tid;
+    const int cnt = c < L.nCells ? cc[c] : 0;
+    int tot;
+    const int off = n + block_excl_scan(cnt, S.wsum, &tot);
+    for (int e = 0; e < cnt; e++)
+      if (off + e < L.candCap) kd[off + e] = slots[(long long)c * L.capCell + e];
+    n += tot;
+  }
+  if (n > L.candCap) {
+    if (tid == 0) atomicExch(err_flag, 1);
+    n = L.candCap;
+  }
+  if (tid == 0) cand_count[f * P.nlevels + l] = n;
+  __syncthreads();
+  __threadfence_block();
+
+  // ---- root nodes (:549-590)
+  int cur = 0;
+  const int nIni = L.nIni;
+  const int H = L.maxBY - kBorder;
+  for (int i = tid; i < kMaxList * 4; i += 256) S.ccount[i] = 0;
+  __syncthreads();
+  for (int k = tid; k < n; k += 256) {
+    const int kx = kd[k] & 0xfff;
+    int b = (int)((float)kx / L.hX);
+    b = min(max(b, 0), nIni - 1);
+    kl[k] = (unsigned short)b;  // provisional: root index
+    atomicAdd(&S.ccount[b], 1);
+  }
+  __syncthreads();
+  int size = 0;
+  {
+    // compact non-empty roots (nIni is tiny: serial on thread 0)
+    if (tid == 0) {
+      int s = 0;
+      for (int i = 0; i < nIni && s < kMaxList; i++) {
+        const int c = S.ccount[i];
+        S.newpos_old[i] = 0xffff;
+        if (c == 0) continue;
+        S.x0[0][s] = (unsigned short)(int)(L.hX * (float)i);
+        S.x1[0][s] = (unsigned short)(int)(L.hX * (float)(i + 1));
+        S.y0[0][s] = 0;
+        S.y1[0][s] = (unsigned short)H;
+        S.cnt[0][s] = (unsigned short)min(c, 65535);
+        S.seq[0][s] = (unsigned short)s;
+        S.newpos_old[i] = (unsigned short)s;
+        s++;
+      }
+      S.s_newsize = s;
+    }
+    __syncthreads();
+    size = S.s_newsize;
+    for (int k = tid; k < n; k += 256) kl[k] = S.newpos_old[kl[k]];
+    __syncthreads();
+  }
+
+  bool careful = false;
+  bool finish = (n == 0);
+  int guard = 0;
+  while (!finish && guard++ < 64) {
+    const int prevSize = size;
+    // (1) expandable nodes and their processing order
+    //     list-order rank first (also the creation order of the candidate array)
+    int myflag[4], myrank[4];
+    int local = 0;
+    for (int e = 0; e < 4; e++) {
+      const int pos = tid * 4 + e;
+      myflag[e] = (pos < size && S.cnt[cur][pos] > 1) ? 1 : 0;
+      local += myflag[e];
+    }
+    int m;
+    int ex = block_excl_scan(local, S.wsum, &m);
+    for (int e = 0; e < 4; e++) {
+      const int pos = tid * 4 + e;
+      myrank[e] = ex;
+      ex += myflag[e];
+      if (pos < kMaxList) S.prank[pos] = myflag[e] ? (unsigned short)myrank[e] : 0xffff;
+      if (myflag[e]) S.order[myrank[e]] = (unsigned short)pos;
+    }
+    __syncthreads();
+    if (careful && m > 1) {
+      // rank by (count desc, seq desc): :690 sorts ascending and walks from the back
+      unsigned short newrank[4];
+      for (int e = 0; e < 4; e++) {
+        newrank[e] = 0xffff;
+        if (!myflag[e]) continue;
+        const int pos = tid * 4 + e;
+        const unsigned int mykey = ((unsigned int)S.cnt[cur][pos] << 16) | S.seq[cur][pos];
+        int r = 0;
+        for (int j = 0; j < m; j++) {
+          const int p2 = S.order[j];
+          const unsigned int k2 = ((unsigned int)S.cnt[cur][p2] << 16) | S.seq[cur][p2];
+          r += (k2 > mykey) ? 1 : 0;
+        }
+        newrank[e] = (unsigned short)r;
+      }
+      __syncthreads();
+      for (int e = 0; e < 4; e++)
+        if (myflag[e]) {
+          S.prank[tid * 4 + e] = newrank[e];
+          S.order[newrank[e]] = (unsigned short)(tid * 4 + e);
+        }
+      __syncthreads();
+    }
+    // (2) key pass 1: child occupancy
+    for (int i = tid; i < m * 4; i += 256) S.ccount[i] = 0;
+    __syncthreads();
+    for (int k = tid; k < n; k += 256) {
+      const int pos = kl[k];
+      const int r = S.prank[pos];
+      if (r == 0xffff) continue;
+      const uint32_t kv = kd[k];
+      const int q = quadrant_of(kv & 0xfff, (kv >> 12) & 0xfff, S.x0[cur][pos], S.y0[cur][pos], S.x1[cur][pos],
+                                S.y1[cur][pos]);
+      atomicAdd(&S.ccount[r * 4 + q], 1);
+    }
+    __syncthreads();
+    // (3) prefix over processing ranks: nonempty children, cut-off
+    {
+      int run_c = 0;  // running inclusive prefix carried across chunks
+      int cutoff = m - 1;
+      bool found = false;
+      for (int base = 0; base < m; base += 256) {
+        const int r = base + tid;
+        int c = 0;
+        if (r < m)
+          for (int q = 0; q < 4; q++) c += S.ccount[r * 4 + q] > 0;
+        int tot;
+        const int exs = block_excl_scan(c, S.wsum, &tot);
+        const int inc = run_c + exs + c;
+        if (r < m) S.cprefix[r] = inc;
+        run_c += tot;
+      }
+      __syncthreads();
+      if (careful) {
+        // first rank where the list reaches N (:741 break): size + (children - parents) >= N
+        if (tid == 0) S.s_cutoff = m - 1;
+        __syncthreads();
+        for (int r = tid; r < m; r += 256) {
+          const int sz = prevSize + S.cprefix[r] - (r + 1);
+          if (sz >= N) atomicMin(&S.s_cutoff, r);
+        }
+        __syncthreads();
+        cutoff = S.s_cutoff;
+        found = true;
+      }
+      (void)found;
+      const int totalChildren = m > 0 ? S.cprefix[cutoff] : 0;
+      // (4) new list: children first
+      const int nxt = cur ^ 1;
+      if (tid == 0) S.s_nexp = 0;
+      __syncthreads();
+      int nexp_local = 0;
+      for (int r = tid; r <= cutoff && r < m; r += 256) {
+        const int pos = S.order[r];
+        const int base_r = totalChildren - S.cprefix[r];  // children of later-processed parents precede
+        const int px0 = S.x0[cur][pos], py0 = S.y0[cur][pos], px1 = S.x1[cur][pos], py1 = S.y1[cur][pos];
+        const int midx = px0 + ((px1 - px0 + 1) >> 1), midy = py0 + ((py1 - py0 + 1) >> 1);
+        int after = 0;  // nonempty children with a higher quadrant come first (n4 pushed last)
+        for (int q = 3; q >= 0; q--) {
+          const int c = S.ccount[r * 4 + q];
+          if (c == 0) {
+            S.newpos_child[r * 4 + q] = 0xffff;
+            continue;
+          }
+          const int np = base_r + after;
+          after++;
+          S.newpos_child[r * 4 + q] = (unsigned short)np;
+          S.x0[nxt][np] = (unsigned short)((q & 1) ? midx : px0);
+          S.x1[nxt][np] = (unsigned short)((q & 1) ? px1 : midx);
+          S.y0[nxt][np] = (unsigned short)((q & 2) ? midy : py0);
+          S.y1[nxt][np] = (unsigned short)((q & 2) ? py1 : midy);
+          S.cnt[nxt][np] = (unsigned short)min(c, 65535);
+          S.seq[nxt][np] = (unsigned short)(r * 4 + q);
+          nexp_local += c > 1;
+        }
+      }
+      if (nexp_local) atomicAdd(&S.s_nexp, nexp_local);
+      // kept old nodes follow, in their old order
+      int keptlocal = 0, kf[4];
+      for (int e = 0; e < 4; e++) {
+        const int pos = tid * 4 + e;
+        const int r = pos < size ? S.prank[pos] : 0xffff;
+        kf[e] = (pos < size && (r == 0xffff || r > cutoff)) ? 1 : 0;
+        keptlocal += kf[e];
+      }
+      int keptTotal;
+      int kex = block_excl_scan(keptlocal, S.wsum, &keptTotal);
+      for (int e = 0; e < 4; e++) {
+        const int pos = tid * 4 + e;
+        if (!kf[e]) {
+          if (pos < kMaxList) S.newpos_old[pos] = 0xffff;
+          continue;
+        }
+        const int np = totalChildren + kex;
+        kex++;
+        S.newpos_old[pos] = (unsigned short)np;
+        if (np < kMaxList) {
+          S.x0[nxt][np] = S.x0[cur][pos];
+          S.x1[nxt][np] = S.x1[cur][pos];
+          S.y0[nxt][np] = S.y0[cur][pos];
+          S.y1[nxt][np] = S.y1[cur][pos];
+          S.cnt[nxt][np] = S.cnt[cur][pos];
+          S.seq[nxt][np] = S.seq[cur][pos];
+        }
+      }
+      __syncthreads();
+      const int newsize = totalChildren + keptTotal;
+      // (5) key pass 2: relabel
+      for (int k = tid; k < n; k += 256) {
+        const int pos = kl[k];
+        const int r = S.prank[pos];
+        if (r != 0xffff && r <= cutoff) {
+          const uint32_t kv = kd[k];
+          const int q = quadrant_of(kv & 0xfff, (kv >> 12) & 0xfff, S.x0[cur][pos], S.y0[cur][pos],
+                                    S.x1[cur][pos], S.y1[cur][pos]);
+          kl[k] = S.newpos_child[r * 4 + q];
+        } else {
+          kl[k] = S.newpos_old[pos];
+        }
+      }
+      __syncthreads();
+      const int nToExpand = S.s_nexp;
+      cur = nxt;
+      size = newsize;
+      if (size > kMaxList - 4) {
+        if (tid == 0) atomicExch(err_flag, 2);
+        finish = true;
+      }
+      if (size >= N || size == prevSize)
+        finish = true;  // :662-665 / :746-747
+      else if (!careful && size + nToExpand * 3 > N)
+        careful = true;  // :667
+    }
+    __syncthreads();
+  }
+
+  // ---- best response per node, first key wins ties (:748-766)
+  for (int i = tid; i < kMaxList; i += 256) S.best[i] = 0;
+  __syncthreads();
+  for (int k = tid; k < n; k += 256) {
+    const int pos = kl[k];
+    if (pos >= kMaxList) continue;
+    const unsigned int v = ((kd[k] >> 24) << 16) | (unsigned int)(65535 - k);
+    atomicMax(&S.best[pos], v);
+  }
+  __syncthreads();
+  uint32_t *out = sel + (long long)f * sel_per_frame + L.selBase;
+  const int nout = min(size, L.capSel);
+  for (int i = tid; i < nout; i += 256) out[i] = kd[65535 - (S.best[i] & 0xffff)];
+  if (tid == 0) nk[f * P.nlevels + l] = (n == 0) ? 0 : nout;
+}
+
+__global__ void k_offsets(int nlevels, int n_frames, const int *nk, int *off, int capacity, int *counts) {
+  const int f = blockIdx.x * blockDim.x + threadIdx.x;
+  if (f >= n_frames) return;
+  int acc = 0;
+  for (int l = 0; l < nlevels; l++) {
+    off[f * (nlevels + 1) + l] = acc;
+    acc += nk[f * nlevels + l];
+  }
+  off[f * (nlevels + 1) + nlevels] = acc;
+  if (counts) counts[f] = min(acc, capacity);
+}
+
+// ------------------------------------------------------------------------------------------
+// K4  cv::GaussianBlur(7x7, sigma 2, BORDER_REFLECT_101) on the unpadded level (:1093-1094).
+// OpenCV <= 3.4.0 8-bit path: kernel quantised to {18,34,49,55,49,34,18}/256 per pass, row pass
+// in int32, column pass (v + 2^15) >> 16 saturated.  64x16 output tile per workgroup; the
+// (64+6)x(16+6) source tile and the 22x64 row sums live in LDS.
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ int reflect101(int i, int n) {
+  if (n == 1) return 0;
+  while (i < 0 || i >= n) i = i < 0 ? -i : 2 * n - 2 - i;
+  return i;
+}
+
+__global__ __launch_bounds__(256) void k_blur(OrbDev P, FrameSrc src, int tiles_per_frame) {
+  __shared__ uint8_t t[22][72];
+  __shared__ int hs[22][64];
+  const int kq[7] = {18, 34, 49, 55, 49, 34, 18};
+  const int tid = threadIdx.x, f = blockIdx.y;
+  int tile = blockIdx.x;
+  int l = 0;
+  while (l + 1 < P.nlevels && tile >= P.lv[l + 1].tileBase) l++;
+  const LevelGeom &L = P.lv[l];
+  tile -= L.tileBase;
+  const int ty = tile / L.tilesX, tx = tile - ty * L.tilesX;
+  const int x0 = tx * 64, y0 = ty * 16;
+  int pitch;
+  const uint8_t *img = level_plane(P, src, l, f, pitch);
+  for (int idx = tid; idx < 22 * 70; idx += 256) {
+    const int r = idx / 70, c = idx - r * 70;
+    const int sy = reflect101(y0 + r - 3, L.h), sx = reflect101(x0 + c - 3, L.w);
+    t[r][c] = img[(long long)sy * pitch + sx];
+  }
+  __syncthreads();
+  for (int idx = tid; idx < 22 * 64; idx += 256) {
+    const int r = idx >> 6, c = idx & 63;
+    int acc = 0;
+#pragma unroll
+    for (int i = 0; i < 7; i++) acc += kq[i] * t[r][c + i];
+    hs[r][c] = acc;
+  }
+  __syncthreads();
+  uint8_t *dst = src.blur + (long long)f * src.blur_frame_stride + L.blur_off;
+  for (int idx = tid; idx < 16 * 64; idx += 256) {
+    const int r = idx >> 6, c = idx & 63;
+    if (x0 + c >= L.w || y0 + r >= L.h) continue;
+    int acc = 0;
+#pragma unroll
+    for (int j = 0; j < 7; j++) acc += kq[j] * hs[r + j][c];
+    const int v = (acc + (1 << 15)) >> 16;
+    dst[(long long)(y0 + r) * L.pitch + x0 + c] = (uint8_t)min(v, 255);
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// K3 + K5  IC_Angle (:79-107) + computeOrbDescriptor (:110-151) + the coordinate bookkeeping of
+// :845-855 and :1102-1108.  One wavefront per key-point: the 749-pixel disc is reduced with
+// cross-lane adds (two 31-wide rows per step), lane 0's fastAtan2 is evaluated by every lane,
+// then lane t evaluates tests t, t+64, t+128, t+192 and four 64-bit ballots are the descriptor.
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ float fast_atan2_deg(float y, float x) {  // cv::fastAtan2, OpenCV 3.x
+  const float p1 = 0.9997878412794807f * (float)(180 / 3.14159265358979323846);
+  const float p3 = -0.3258083974640975f * (float)(180 / 3.14159265358979323846);
+  const float p5 = 0.1555786518463281f * (float)(180 / 3.14159265358979323846);
+  const float p7 = -0.04432655554792128f * (float)(180 / 3.14159265358979323846);
+  const float ax = fabsf(x), ay = fabsf(y);
+  float a, c, c2;
+  if (ax >= ay) {
+    c = ay / (ax + (float)2.2204460492503131e-16);
+    c2 = c * c;
+    a = (((p7 * c2 + p5) * c2 + p3) * c2 + p1) * c;
+  } else {
+    c = ax / (ay + (float)2.2204460492503131e-16);
+    c2 = c * c;
+    a = 90.f - (((p7 * c2 + p5) * c2 + p3) * c2 + p1) * c;
+  }
+  if (x < 0) a = 180.f - a;
+  if (y < 0) a = 360.f - a;
+  return a;
+}
+
+// cos/sin of the descriptor steering angle: double Cody-Waite reduction + fixed-order minimax
+// polynomials, rounded once to float (DESIGN.md "steered BRIEF trig").
+__device__ __forceinline__ void cos_sin_f(float angle_rad, float &cs, float &sn) {
+  const double x = (double)angle_rad;
+  const double kd = floor(x * 6.36619772367581382433e-01 + 0.5);
+  const int k = (int)kd;
+  const double r = (x - kd * 1.57079632673412561417e+00) - kd * 6.07710050650619224932e-11;
+  const double z = r * r;
+  double ps = 1.58969099521155010221e-10;
+  ps = ps * z + -2.50507602534068634195e-08;
+  ps = ps * z + 2.75573137070700676789e-06;
+  ps = ps * z + -1.98412698298579493134e-04;
+  ps = ps * z + 8.33333333332248946124e-03;
+  ps = ps * z + -1.66666666666666324348e-01;
+  const double s = r + r * (z * ps);
+  double pc = -1.13596475577881948265e-11;
+  pc = pc * z + 2.08757232129817482790e-09;
+  pc = pc * z + -2.75573143513906633035e-07;
+  pc = pc * z + 2.48015872894767294178e-05;
+  pc = pc * z + -1.38888888888741095749e-03;
+  pc = pc * z + 4.16666666666666019037e-02;
+  const double c = (1.0 - 0.5 * z) + z * (z * pc);
+  double co, si;
+  switch (k & 3) {
+    case 0: co = c, si = s; break;
+    case 1: co = -s, si = c; break;
+    case 2: co = -c, si = -s; break;
+    default: co = s, si = -c; break;
+  }
+  cs = (float)co;
+  sn = (float)si;
+}
+
+__global__ __launch_bounds__(256) void k_describe(OrbDev P, FrameSrc src, const uint32_t *sel,
+                                                  int sel_per_frame, const int *off, int capacity,
+                                                  vo_keypoint *kps, uint8_t *desc) {
+  const int lane = threadIdx.x & 63;
+  const int g = blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int f = blockIdx.y;
+  const int *o = off + f * (P.nlevels + 1);
+  if (g >= o[P.nlevels] || g >= capacity) return;
+  int l = 0;
+  while (l + 1 < P.nlevels && g >= o[l + 1]) l++;
+  const LevelGeom &L = P.lv[l];
+  const uint32_t kv = sel[(long long)f * sel_per_frame + L.selBase + (g - o[l])];
+  const int px = (int)(kv & 0xfff) + kBorder, py = (int)((kv >> 12) & 0xfff) + kBorder;  // :849-850
+  int pitch;
+  const uint8_t *img = level_plane(P, src, l, f, pitch);
+  const uint8_t *center = img + (long long)py * pitch + px;
+  // intensity centroid: rows v = -15..15, two rows per step (lane>>5 picks the row)
+  int m10 = 0, m01 = 0;
+  const int u = (lane & 31) - kHalfPatch;
+  for (int step = 0; step < 16; step++) {
+    const int v = -kHalfPatch + step * 2 + (lane >> 5);
+    if (v <= kHalfPatch) {
+      const int d = P.umax[v < 0 ? -v : v];
+      if (u >= -d && u <= d) {
+        const int val = center[(long long)v * pitch + u];
+        m10 += u * val;
+        m01 += v * val;
+      }
+    }
+  }
+#pragma unroll
+  for (int o2 = 32; o2 >= 1; o2 >>= 1) {
+    m10 += __shfl_xor(m10, o2);
+    m01 += __shfl_xor(m01, o2);
+  }
+  const float angle = fast_atan2_deg((float)m01, (float)m10);
+  const float factorPI = (float)(3.14159265358979323846 / 180.f);  // :109
+  float a, b;
+  cos_sin_f(angle * factorPI, a, b);
+  const uint8_t *bc = src.blur + (long long)f * src.blur_frame_stride + L.blur_off + (long long)py * L.pitch + px;
+  unsigned long long words[4];
+#pragma unroll
+  for (int k = 0; k < 4; k++) {
+    const int t = lane + 64 * k;
+    const float x0 = (float)c_pattern[4 * t], y0 = (float)c_pattern[4 * t + 1];
+    const float x1 = (float)c_pattern[4 * t + 2], y1 = (float)c_pattern[4 * t + 3];
+    const int r0 = __float2int_rn(x0 * b + y0 * a), q0 = __float2int_rn(x0 * a - y0 * b);
+    const int r1 = __float2int_rn(x1 * b + y1 * a), q1 = __float2int_rn(x1 * a - y1 * b);
+    const int t0 = bc[(long long)r0 * L.pitch + q0], t1 = bc[(long long)r1 * L.pitch + q1];
+    words[k] = __ballot(t0 < t1);
+  }
+  const long long oi = (long long)f * capacity + g;
+  if (lane < 4) reinterpret_cast<unsigned long long *>(desc + oi * 32)[lane] = words[lane];
+  if (lane == 0) {
+    vo_keypoint kp;
+    float fx = (float)px, fy = (float)py;
+    if (l != 0) {  // :1102-1108
+      fx *= L.scale;
+      fy *= L.scale;
+    }
+    kp.x = fx;
+    kp.y = fy;
+    kp.size = (float)L.patchSize;
+    kp.angle = angle;
+    kp.response = (float)(kv >> 24);
+    kp.octave = l;
+    kp.class_id = -1;
+    kps[oi] = kp;
+  }
+}
+
+}  // namespace
+
+// ============================================================================================
+// host side
+// ============================================================================================
+struct vo_orb {
+  int nfeatures = 0, nlevels = 0, ini_th = 0, min_th = 0;
+  float scale_factor = 0;
+  float scale[kMaxLevels], inv_scale[kMaxLevels];
+  int quota[kMaxLevels];
+  int umax[16];
+  hipStream_t stream = nullptr;
+  bool own_stream = false;
+  // geometry (valid for cfg_w x cfg_h)
+  int cfg_w = 0, cfg_h = 0;
+  OrbDev dev;
+  long long pyr_frame = 0, blur_frame = 0, slots_frame = 0;
+  int cells_frame = 0, keys_frame = 0, sel_frame = 0, tiles_frame = 0, max_kp = 0;
+  std::vector<int> tab_off;  // per level: offsets of xofs,xab,yofs,yab in tables
+  vo::DevBuf tables, pyr, blur, slots, cellcnt, keydata, keylabel, candcnt, sel, nk, off, err;
+  vo::DevBuf in_img, out_kp, out_desc, out_cnt;
+  int batch_cap = 0;
+  // last call
+  FrameSrc last_src{};
+  int last_frames = 0;
+};
+
+namespace {
+
+int cv_round_f(float v) { return (int)lrintf(v); }
+int cv_floor_f(float v) {
+  int i = (int)v;
+  return i - (i > v);
+}
+
+// coefficient tables of cv::resize(INTER_LINEAR) for CV_8U (OpenCV 3.x resize.cpp): per output
+// column the left source column and two 11-bit weights, same per row.
+void orb_resize_tables(int sw, int sh, int dw, int dh, std::vector<int> &xofs, std::vector<int> &xab,
+                       std::vector<int> &yofs, std::vector<int> &yab) {
+  const double scale_x = 1. / ((double)dw / sw), scale_y = 1. / ((double)dh / sh);
+  auto sat16 = [](float v) {
+    int i = cv_round_f(v);
+    return std::min(32767, std::max(-32768, i));
+  };
+  xofs.resize(dw), xab.resize(dw), yofs.resize(dh), yab.resize(dh);
+  for (int dx = 0; dx < dw; dx++) {
+    float fx = (float)((dx + 0.5) * scale_x - 0.5);
+    int sx = cv_floor_f(fx);
+    fx -= sx;
+    if (sx < 0) fx = 0, sx = 0;
+    if (sx >= sw - 1) fx = 0, sx = sw - 1;
+    xofs[dx] = sx;
+    xab[dx] = (sat16((1.f - fx) * 2048) & 0xffff) | (sat16(fx * 2048) << 16);
+  }
+  for (int dy = 0; dy < dh; dy++) {
+    float fy = (float)((dy + 0.5) * scale_y - 0.5);
+    int sy = cv_floor_f(fy);
+    fy -= sy;
+    yofs[dy] = sy;
+    yab[dy] = (sat16((1.f - fy) * 2048) & 0xffff) | (sat16(fy * 2048) << 16);
+  }
+}
+
+int align_up(int v, int a) { return (v + a - 1) / a * a; }
+
+int configure(vo_orb *h, int w, int h_img, int n_frames) {
+  if (w != h->cfg_w || h_img != h->cfg_h) {
+    OrbDev &D = h->dev;
+    memset(&D, 0, sizeof(D));
+    D.nlevels = h->nlevels;
+    D.ini_th = h->ini_th;
+    D.min_th = h->min_th;
+    memcpy(D.umax, h->umax, sizeof(D.umax));
+    long long pyr = 0, blur = 0, slots = 0;
+    int cells = 0, keys = 0, sel = 0, tiles = 0, maxkp = 0;
+    std::vector<int> tables;
+    h->tab_off.assign(h->nlevels * 4, 0);
+    int pw = w, ph = h_img;
+    for (int l = 0; l < h->nlevels; l++) {
+      LevelGeom &L = D.lv[l];
+      L.w = cv_round_f((float)w * h->inv_scale[l]);  // ORBextractor.cpp:1120
+      L.h = cv_round_f((float)h_img * h->inv_scale[l]);
+      if (L.w > 4095 || L.h > 4095) {
+        vo::set_error("image level %d is %dx%d; the packed key format supports <= 4095", l, L.w, L.h);
+        return VO_ERR_INVALID;
+      }
+      L.pitch = align_up(L.w, 64);
+      L.pyr_off = pyr;
+      if (l > 0) pyr += (long long)L.pitch * L.h;
+      L.blur_off = blur;
+      blur += (long long)L.pitch * L.h;
+      L.scale = h->scale[l];
+      L.patchSize = (int)(31 * h->scale[l]);  // :842
+      L.maxBX = L.w - kEdge + 3;
+      L.maxBY = L.h - kEdge + 3;
+      const float width = (float)(L.maxBX - kBorder), height = (float)(L.maxBY - kBorder);
+      L.nCols = width > 0 ? (int)(width / 30.f) : 0;  // :791-794
+      L.nRows = height > 0 ? (int)(height / 30.f) : 0;
+      if (L.nCols < 1 || L.nRows < 1) {
+        L.nCols = L.nRows = 0;
+        L.wCell = L.hCell = 1;
+      } else {
+        L.wCell = (int)ceilf(width / L.nCols);
+        L.hCell = (int)ceilf(height / L.nRows);
+        if (L.wCell + 6 > kTileP - 6 || L.hCell + 6 > kTileP - 6) {
+          vo::set_error("FAST cell %dx%d exceeds the LDS tile", L.wCell, L.hCell);
+          return VO_ERR_INVALID;
+        }
+      }
+      L.cellBase = cells;
+      L.nCells = L.nCols * L.nRows;
+      cells += L.nCells;
+      L.capCell = ((L.wCell + 1) / 2) * ((L.hCell + 1) / 2);  // strict-> NMS: no two kept pixels touch
+      L.slotBase = slots;
+      slots += (long long)L.nCells * L.capCell;
+      L.quota = h->quota[l];
+      const float ratio = (L.maxBY - kBorder) > 0 ? (float)(L.maxBX - kBorder) / (L.maxBY - kBorder) : 0.f;
+      L.nIni = (int)roundf(ratio);  // :549
+      if (L.nCells > 0 && L.nIni < 1) {
+        vo::set_error("level %d is taller than wide (nIni = 0): the reference divides by zero here", l);
+        return VO_ERR_INVALID;
+      }
+      if (L.nIni < 1) L.nIni = 1;
+      L.hX = (float)(L.maxBX - kBorder) / L.nIni;
+      L.capSel = std::max(L.quota + 4, 4 * L.nIni);
+      if (L.capSel > kMaxList - 4) {
+        vo::set_error("level %d quota %d exceeds the oct-tree list capacity %d", l, L.quota, kMaxList - 8);
+        return VO_ERR_CAPACITY;
+      }
+      L.selBase = sel;
+      sel += L.capSel;
+      maxkp += L.capSel;
+      long long cc = (long long)L.nCells * L.capCell;
+      L.candCap = (int)std::min<long long>(cc, 65535);
+      L.candBase = keys;
+      keys += L.candCap;
+      L.tilesX = (L.w + 63) / 64;
+      L.tilesY = (L.h + 15) / 16;
+      L.tileBase = tiles;
+      tiles += L.tilesX * L.tilesY;
+      if (l > 0) {
+        std::vector<int> xo, xa, yo, ya;
+        orb_resize_tables(pw, ph, L.w, L.h, xo, xa, yo, ya);
+        h->tab_off[l * 4 + 0] = (int)tables.size();
+        tables.insert(tables.end(), xo.begin(), xo.end());
+        h->tab_off[l * 4 + 1] = (int)tables.size();
+        tables.insert(tables.end(), xa.begin(), xa.end());
+        h->tab_off[l * 4 + 2] = (int)tables.size();
+        tables.insert(tables.end(), yo.begin(), yo.end());
+        h->tab_off[l * 4 + 3] = (int)tables.size();
+        tables.insert(tables.end(), ya.begin(), ya.end());
+      }
+      pw = L.w, ph = L.h;
+    }
+    h->pyr_frame = align_up((int)std::max<long long>(pyr, 64), 256);
+    h->blur_frame = align_up((int)blur, 256);
+    h->slots_frame = slots;
+    h->cells_frame = cells;
+    h->keys_frame = align_up(keys, 64);
+    h->sel_frame = sel;
+    h->tiles_frame = tiles;
+    h->max_kp = maxkp;
+    VO_CHECK(h->tables.reserve(std::max<size_t>(tables.size() * sizeof(int), 64)));
+    if (!tables.empty())
+      VO_HIP_CHECK(hipMemcpy(h->tables.p, tables.data(), tables.size() * sizeof(int), hipMemcpyHostToDevice));
+    h->cfg_w = w;
+    h->cfg_h = h_img;
+    h->batch_cap = 0;
+  }
+  if (n_frames > h->batch_cap) {
+    const size_t B = (size_t)n_frames;
+    VO_CHECK(h->pyr.reserve(B * h->pyr_frame));
+    VO_CHECK(h->blur.reserve(B * h->blur_frame));
+    VO_CHECK(h->slots.reserve(std::max<size_t>(B * h->slots_frame * 4, 64)));
+    VO_CHECK(h->cellcnt.reserve(std::max<size_t>(B * h->cells_frame * 4, 64)));
+    VO_CHECK(h->keydata.reserve(B * h->keys_frame * 4));
+    VO_CHECK(h->keylabel.reserve(B * h->keys_frame * 2));
+    VO_CHECK(h->candcnt.reserve(B * kMaxLevels * 4));
+    VO_CHECK(h->sel.reserve(B * h->sel_frame * 4));
+    VO_CHECK(h->nk.reserve(B * kMaxLevels * 4));
+    VO_CHECK(h->off.reserve(B * (kMaxLevels + 1) * 4));
+    VO_CHECK(h->err.reserve(64));
+    h->batch_cap = n_frames;
+  }
+  return VO_OK;
+}
+
+int run_pipeline(vo_orb *h, const uint8_t *dev_images, int n_frames, int w, int hh, int stride,
+                 size_t frame_stride, vo_keypoint *dkp, uint8_t *ddesc, int capacity, int32_t *dcounts) {
+  VO_CHECK(configure(h, w, hh, n_frames));
+  const OrbDev &D = h->dev;
+  hipStream_t st = h->stream;
+  FrameSrc S;
+  S.img0 = dev_images;
+  S.img0_frame_stride = (long long)frame_stride;
+  S.img0_pitch = stride;
+  S.pyr = h->pyr.as<uint8_t>();
+  S.pyr_frame_stride = h->pyr_frame;
+  S.blur = h->blur.as<uint8_t>();
+  S.blur_frame_stride = h->blur_frame;
+  h->last_src = S;
+  h->last_frames = n_frames;
+  VO_HIP_CHECK(hipMemsetAsync(h->err.p, 0, 4, st));
+  // pyramid: level l from level l-1 (sequential by construction, :1129)
+  for (int l = 1; l < D.nlevels; l++) {
+    const LevelGeom &L = D.lv[l], &Pv = D.lv[l - 1];
+    const uint8_t *sp = l == 1 ? dev_images : S.pyr + Pv.pyr_off;
+    const long long sfs = l == 1 ? (long long)frame_stride : h->pyr_frame;
+    const int spitch = l == 1 ? stride : Pv.pitch;
+    const int *T = h->tables.as<int>();
+    dim3 grid((L.w + 63) / 64, (L.h + 3) / 4, n_frames), block(64, 4);
+    hipLaunchKernelGGL(k_resize, grid, block, 0, st, sp, sfs, spitch, Pv.w, Pv.h, S.pyr + L.pyr_off,
+                       (long long)h->pyr_frame, L.pitch, L.w, L.h, T + h->tab_off[l * 4 + 0],
+                       T + h->tab_off[l * 4 + 1], T + h->tab_off[l * 4 + 2], T + h->tab_off[l * 4 + 3]);
+  }
+  if (h->cells_frame > 0)
+    hipLaunchKernelGGL(k_fast_cells, dim3(h->cells_frame, n_frames), dim3(256), 0, st, D, S,
+                       h->slots.as<uint32_t>(), h->slots_frame, h->cellcnt.as<int>(), h->cells_frame);
+  hipLaunchKernelGGL(k_octree, dim3(D.nlevels, n_frames), dim3(256), 0, st, D, h->slots.as<uint32_t>(),
+                     h->slots_frame, h->cellcnt.as<int>(), h->cells_frame, h->keydata.as<uint32_t>(),
+                     h->keylabel.as<unsigned short>(), h->keys_frame, h->candcnt.as<int>(),
+                     h->sel.as<uint32_t>(), h->sel_frame, h->nk.as<int>(), h->err.as<int>());
+  hipLaunchKernelGGL(k_offsets, dim3((n_frames + 63) / 64), dim3(64), 0, st, D.nlevels, n_frames,
+                     h->nk.as<int>(), h->off.as<int>(), capacity, dcounts);
+  hipLaunchKernelGGL(k_blur, dim3(h->tiles_frame, n_frames), dim3(256), 0, st, D, S, h->tiles_frame);
+  const int kp_blocks = (std::min(capacity, h->max_kp) + 3) / 4;
+  if (kp_blocks > 0)
+    hipLaunchKernelGGL(k_describe, dim3(kp_blocks, n_frames), dim3(256), 0, st, D, S, h->sel.as<uint32_t>(),
+                       h->sel_frame, h->off.as<int>(), capacity, dkp, ddesc);
+  VO_HIP_CHECK(hipGetLastError());
+  return VO_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int vo_orb_create(vo_orb **out, int nfeatures, float scale_factor, int nlevels, int ini_th, int min_th) {
+  if (!out || nfeatures < 1 || nlevels < 1 || nlevels > kMaxLevels || !(scale_factor > 1.0f) || ini_th < 0 ||
+      min_th < 0 || ini_th > 255 || min_th > 255) {
+    vo::set_error("vo_orb_create: invalid argument");
+    return VO_ERR_INVALID;
+  }
+  VO_CHECK(vo::ensure_device());
+  vo_orb *h = new vo_orb();
+  h->nfeatures = nfeatures;
+  h->nlevels = nlevels;
+  h->ini_th = ini_th;
+  h->min_th = min_th;
+  h->scale_factor = scale_factor;
+  // ORBextractor::ORBextractor, ORBextractor.cpp:414-476.  `scaleFactor` is a double member
+  // initialised from the float argument (ORBextractor.h:101).
+  const double sf = (double)scale_factor;
+  h->scale[0] = 1.0f;
+  for (int i = 1; i < nlevels; i++) h->scale[i] = (float)(h->scale[i - 1] * sf);
+  for (int i = 0; i < nlevels; i++) h->inv_scale[i] = 1.0f / h->scale[i];
+  const float factor = (float)(1.0f / sf);
+  float desired = nfeatures * (1 - factor) / (1 - (float)pow((double)factor, (double)nlevels));
+  int sum = 0;
+  for (int l = 0; l < nlevels - 1; l++) {
+    h->quota[l] = cv_round_f(desired);
+    sum += h->quota[l];
+    desired *= factor;
+  }
+  h->quota[nlevels - 1] = std::max(nfeatures - sum, 0);
+  // circular patch rows, :457-475
+  const int vmax = cv_floor_f(kHalfPatch * sqrtf(2.f) / 2 + 1);
+  const int vmin = (int)ceilf(kHalfPatch * sqrtf(2.f) / 2);
+  for (int v = 0; v <= vmax; ++v) h->umax[v] = (int)lrint(sqrt((double)kHalfPatch * kHalfPatch - v * v));
+  for (int v = kHalfPatch, v0 = 0; v >= vmin; --v) {
+    while (h->umax[v0] == h->umax[v0 + 1]) ++v0;
+    h->umax[v] = v0;
+    ++v0;
+  }
+  if (hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking) != hipSuccess) {
+    vo::set_error("hipStreamCreate failed");
+    delete h;
+    return VO_ERR_HIP;
+  }
+  h->own_stream = true;
+  *out = h;
+  return VO_OK;
+}
+
+void vo_orb_destroy(vo_orb *h) {
+  if (!h) return;
+  (void)hipStreamSynchronize(h->stream);
+  for (vo::DevBuf *b : {&h->tables, &h->pyr, &h->blur, &h->slots, &h->cellcnt, &h->keydata, &h->keylabel,
+                        &h->candcnt, &h->sel, &h->nk, &h->off, &h->err, &h->in_img, &h->out_kp, &h->out_desc,
+                        &h->out_cnt})
+    b->release();
+  if (h->own_stream) (void)hipStreamDestroy(h->stream);
+  delete h;
+}
+
+int vo_orb_set_stream(vo_orb *h, void *s) {
+  if (!h) return VO_ERR_INVALID;
+  (void)hipStreamSynchronize(h->stream);
+  if (h->own_stream) (void)hipStreamDestroy(h->stream);
+  h->own_stream = false;
+  h->stream = (hipStream_t)s;
+  return VO_OK;
+}
+
+int vo_orb_levels(const vo_orb *h) { return h ? h->nlevels : 0; }
+float vo_orb_scale_factor(const vo_orb *h) { return h ? h->scale_factor : 0.f; }
+int vo_orb_scale_factors(const vo_orb *h, float *s, float *is) {
+  if (!h || !s) return VO_ERR_INVALID;
+  for (int i = 0; i < h->nlevels; i++) {
+    s[i] = h->scale[i];
+    if (is) is[i] = h->inv_scale[i];
+  }
+  return VO_OK;
+}
+int vo_orb_features_per_level(const vo_orb *h, int *q) {
+  if (!h || !q) return VO_ERR_INVALID;
+  for (int i = 0; i < h->nlevels; i++) q[i] = h->quota[i];
+  return VO_OK;
+}
+int vo_orb_max_keypoints(const vo_orb *h) {
+  if (!h) return 0;
+  int s = 0;
+  for (int i = 0; i < h->nlevels; i++) s += h->quota[i] + 4;
+  return s;
+}
+
+int vo_orb_sync(vo_orb *h) {
+  if (!h) return VO_ERR_INVALID;
+  VO_HIP_CHECK(hipStreamSynchronize(h->stream));
+  int e = 0;
+  if (h->err.p) VO_HIP_CHECK(hipMemcpy(&e, h->err.p, 4, hipMemcpyDeviceToHost));
+  if (e) {
+    vo::set_error(e == 1 ? "more FAST candidates on one level than the 65535-key scratch holds"
+                         : "oct-tree node list overflow");
+    return VO_ERR_CAPACITY;
+  }
+  return VO_OK;
+}
+
+int vo_orb_extract_batch_dev(vo_orb *h, const uint8_t *dev_images, int n_frames, int width, int height,
+                             int stride, size_t frame_stride_bytes, vo_keypoint *dev_keypoints,
+                             uint8_t *dev_descriptors, int capacity, int32_t *dev_counts) {
+  if (!h || !dev_images || n_frames < 1 || width < 1 || height < 1 || stride < width || !dev_keypoints ||
+      !dev_descriptors || capacity < 1) {
+    vo::set_error("vo_orb_extract_batch_dev: invalid argument");
+    return VO_ERR_INVALID;
+  }
+  return run_pipeline(h, dev_images, n_frames, width, height, stride, frame_stride_bytes, dev_keypoints,
+                      dev_descriptors, capacity, dev_counts);
+}
+
+int vo_orb_extract(vo_orb *h, const uint8_t *image, int width, int height, int stride, vo_keypoint *keypoints,
+                   uint8_t *descriptors, int capacity, int *n_keypoints) {
+  if (!h) return VO_ERR_INVALID;
+  if (!image || width <= 0 || height <= 0) return VO_OK;  // `if(_image.empty()) return;` :1054-1055
+  if (!keypoints || !descriptors || !n_keypoints || capacity < 1 || stride < width) {
+    vo::set_error("vo_orb_extract: invalid argument");
+    return VO_ERR_INVALID;
+  }
+  const int pitch = align_up(width, 64);
+  VO_CHECK(h->in_img.reserve((size_t)pitch * height));
+  VO_CHECK(h->out_kp.reserve((size_t)capacity * sizeof(vo_keypoint)));
+  VO_CHECK(h->out_desc.reserve((size_t)capacity * 32));
+  VO_CHECK(h->out_cnt.reserve(64));
+  VO_HIP_CHECK(hipMemcpy2DAsync(h->in_img.p, pitch, image, stride, width, height, hipMemcpyHostToDevice, h->stream));
+  VO_CHECK(run_pipeline(h, h->in_img.as<uint8_t>(), 1, width, height, pitch, (size_t)pitch * height,
+                        h->out_kp.as<vo_keypoint>(), h->out_desc.as<uint8_t>(), capacity, h->out_cnt.as<int32_t>()));
+  int n = 0;
+  VO_HIP_CHECK(hipMemcpyAsync(&n, h->out_cnt.p, 4, hipMemcpyDeviceToHost, h->stream));
+  VO_CHECK(vo_orb_sync(h));
+  if (n > 0) {
+    VO_HIP_CHECK(hipMemcpy(keypoints, h->out_kp.p, (size_t)n * sizeof(vo_keypoint), hipMemcpyDeviceToHost));
+    VO_HIP_CHECK(hipMemcpy(descriptors, h->out_desc.p, (size_t)n * 32, hipMemcpyDeviceToHost));
+  }
+  *n_keypoints = n;
+  return VO_OK;
+}
+
+int vo_orb_get_level(vo_orb *h, int frame, int level, int blurred, uint8_t *dst, int dst_stride, int *width,
+                     int *height) {
+  if (!h || frame < 0 || frame >= h->last_frames || level < 0 || level >= h->nlevels) return VO_ERR_INVALID;
+  VO_HIP_CHECK(hipStreamSynchronize(h->stream));
+  const LevelGeom &L = h->dev.lv[level];
+  if (width) *width = L.w;
+  if (height) *height = L.h;
+  if (!dst) return VO_OK;
+  const uint8_t *sp;
+  int pitch;
+  if (blurred) {
+    sp = h->last_src.blur + (long long)frame * h->last_src.blur_frame_stride + L.blur_off;
+    pitch = L.pitch;
+  } else if (level == 0) {
+    sp = h->last_src.img0 + (long long)frame * h->last_src.img0_frame_stride;
+    pitch = h->last_src.img0_pitch;
+  } else {
+    sp = h->last_src.pyr + (long long)frame * h->last_src.pyr_frame_stride + L.pyr_off;
+    pitch = L.pitch;
+  }
+  VO_HIP_CHECK(hipMemcpy2D(dst, dst_stride, sp, pitch, L.w, L.h, hipMemcpyDeviceToHost));
+  return VO_OK;
+}
+
+int vo_orb_get_candidates(vo_orb *h, int frame, int level, float *x, float *y, float *response, int capacity,
+                          int *n) {
+  if (!h || frame < 0 || frame >= h->last_frames || level < 0 || level >= h->nlevels || !n) return VO_ERR_INVALID;
+  VO_HIP_CHECK(hipStreamSynchronize(h->stream));
+  int cnt = 0;
+  VO_HIP_CHECK(hipMemcpy(&cnt, h->candcnt.as<int>() + frame * h->nlevels + level, 4, hipMemcpyDeviceToHost));
+  *n = cnt;
+  const int m = std::min(cnt, capacity);
+  if (m <= 0 || !x || !y || !response) return VO_OK;
+  std::vector<uint32_t> tmp(m);
+  VO_HIP_CHECK(hipMemcpy(tmp.data(),
+                         h->keydata.as<uint32_t>() + (long long)frame * h->keys_frame + h->dev.lv[level].candBase,
+                         (size_t)m * 4, hipMemcpyDeviceToHost));
+  for (int i = 0; i < m; i++) {
+    x[i] = (float)(tmp[i] & 0xfff);
+    y[i] = (float)((tmp[i] >> 12) & 0xfff);
+    response[i] = (float)(tmp[i] >> 24);
+  }
+  return VO_OK;
+}
+
+int vo_orb_get_level_counts(vo_orb *h, int frame, int32_t *counts) {
+  if (!h || frame < 0 || frame >= h->last_frames || !counts) return VO_ERR_INVALID;
+  VO_HIP_CHECK(hipStreamSynchronize(h->stream));
+  VO_HIP_CHECK(hipMemcpy(counts, h->nk.as<int>() + frame * h->nlevels, (size_t)h->nlevels * 4, hipMemcpyDeviceToHost));
+  return VO_OK;
+}
+
+}  // extern "C"

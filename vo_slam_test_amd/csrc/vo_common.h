@@ -1,0 +1,58 @@
+// vo_common.h -- shared host/device helpers for the gfx950 library (not part of the C-ABI).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+
+#include "../../include/vo_hip.h"
+
+namespace vo {
+
+void set_error(const char *fmt, ...);
+int ensure_device();  // VO_OK or VO_ERR_NO_DEVICE
+
+#define VO_HIP_CHECK(expr)                                                                 \
+  do {                                                                                     \
+    hipError_t _e = (expr);                                                                \
+    if (_e != hipSuccess) {                                                                \
+      vo::set_error("%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e), __FILE__, __LINE__); \
+      return VO_ERR_HIP;                                                                   \
+    }                                                                                      \
+  } while (0)
+
+#define VO_CHECK(expr)           \
+  do {                           \
+    int _s = (expr);             \
+    if (_s != VO_OK) return _s;  \
+  } while (0)
+
+// growable device buffer
+struct DevBuf {
+  void *p = nullptr;
+  size_t bytes = 0;
+  int reserve(size_t n) {
+    if (n <= bytes) return VO_OK;
+    if (p) (void)hipFree(p);
+    p = nullptr;
+    bytes = 0;
+    VO_HIP_CHECK(hipMalloc(&p, n));
+    bytes = n;
+    return VO_OK;
+  }
+  void release() {
+    if (p) (void)hipFree(p);
+    p = nullptr;
+    bytes = 0;
+  }
+  template <class T>
+  T *as() const {
+    return reinterpret_cast<T *>(p);
+  }
+};
+
+constexpr int kWave = 64;
+
+}  // namespace vo
