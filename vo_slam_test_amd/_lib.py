@@ -252,3 +252,134 @@ class Matcher:
     @staticmethod
     def computeDistance(a, b) -> int:
         return int(hamming_matrix(np.asarray(a).reshape(1, 32), np.asarray(b).reshape(1, 32))[0, 0])
+
+
+class Optimizer:
+    """Mirror of myslam::Optimizer's static entry points on flat arrays
+    (reference include/myslam/optimizer_ceres.h:12-27)."""
+
+    @staticmethod
+    def solvePoseOnlySE3(problems, summaries=False):
+        """problems: list of dicts(pts, obs, inv_sigma, cam, pose0) -> (poses, outlier masks, inlier counts)."""
+        P = len(problems)
+        offs = np.zeros(P + 1, np.int32)
+        for i, pr in enumerate(problems):
+            offs[i + 1] = offs[i] + len(pr["pts"])
+        tot = int(offs[-1])
+        pts = np.ascontiguousarray(np.concatenate([pr["pts"] for pr in problems]) if tot else np.zeros((0, 3)))
+        obs = np.ascontiguousarray(np.concatenate([pr["obs"] for pr in problems]) if tot else np.zeros((0, 3)))
+        isg = np.ascontiguousarray(np.concatenate([pr["inv_sigma"] for pr in problems]) if tot else np.zeros(0))
+        poses = np.ascontiguousarray(np.stack([pr["pose0"] for pr in problems]).astype(np.float64))
+        cam = np.ascontiguousarray(problems[0]["cam"], np.float64)
+        outl = np.zeros(max(tot, 1), np.uint8)
+        ninl = np.zeros(P, np.int32)
+        sums = (LmSummary * (2 * P))()
+        check(lib().vo_pose_only_solve(P, _p(offs), _p(pts), _p(obs), _p(isg), _p(cam), _p(poses), _p(outl),
+                                       _p(ninl), C.byref(sums) if summaries else None), "vo_pose_only_solve")
+        masks = [outl[offs[i]:offs[i + 1]].copy() for i in range(P)]
+        if summaries:
+            return poses, masks, ninl, sums
+        return poses, masks, ninl
+
+
+class BundleAdjuster:
+    """Handle over vo_ba_* (the arrays Optimizer::solveLocalBAPoseAndPoint gathers)."""
+
+    def __init__(self, prob, shard=0, n_shards=1, stream=None):
+        self.prob = prob
+        self.n_cams, self.n_pts, self.n_edges = len(prob["poses"]), len(prob["points"]), len(prob["e_cam"])
+        self._h = C.c_void_p()
+        a = {k: np.ascontiguousarray(v) for k, v in prob.items() if isinstance(v, np.ndarray)}
+        check(lib().vo_ba_create(C.byref(self._h), self.n_cams, _p(a["poses"]), _p(a["fixed"]), self.n_pts,
+                                 _p(a["points"]), self.n_edges, _p(a["e_cam"]), _p(a["e_pt"]), _p(a["e_obs"]),
+                                 _p(a["e_inv_sigma"]), _p(a["cam"])), "vo_ba_create")
+        if n_shards > 1:
+            check(lib().vo_ba_set_shard(self._h, shard, n_shards), "vo_ba_set_shard")
+        if stream is not None:
+            check(lib().vo_ba_set_stream(self._h, C.c_void_p(stream)))
+
+    def close(self):
+        if getattr(self, "_h", None) and self._h.value:
+            lib().vo_ba_destroy(self._h)
+            self._h = C.c_void_p()
+
+    __del__ = close
+
+    def n_free_cams(self):
+        return lib().vo_ba_n_free_cams(self._h)
+
+    def state(self):
+        poses = np.zeros((self.n_cams, 6))
+        pts = np.zeros((self.n_pts, 3))
+        check(lib().vo_ba_get_state(self._h, _p(poses), _p(pts)), "vo_ba_get_state")
+        return poses, pts
+
+    def set_state(self, poses=None, points=None):
+        check(lib().vo_ba_set_state(self._h, _p(None if poses is None else np.ascontiguousarray(poses)),
+                                    _p(None if points is None else np.ascontiguousarray(points))))
+
+    def solve(self, huber_mono=0.0, huber_stereo=0.0, max_iterations=10, edge_active=None):
+        s = LmSummary()
+        act = None if edge_active is None else np.ascontiguousarray(edge_active, np.uint8)
+        check(lib().vo_ba_solve(self._h, C.c_double(huber_mono), C.c_double(huber_stereo), int(max_iterations),
+                                _p(act), C.byref(s)), "vo_ba_solve")
+        return s
+
+    def local_ba(self, stop=None):
+        """Optimizer::solveLocalBAPoseAndPoint numerics; returns (edge_erase, summaries, status)."""
+        erase = np.zeros(max(self.n_edges, 1), np.uint8)
+        sums = (LmSummary * 2)()
+        rc = lib().vo_ba_local_ba(self._h, stop, _p(erase), C.byref(sums))
+        if rc not in (0, -5):
+            check(rc, "vo_ba_local_ba")
+        return erase[:self.n_edges], sums, rc
+
+    # split-phase interface (multi-GPU driver)
+    def lm_begin(self, huber_mono, huber_stereo, max_iterations, edge_active=None):
+        act = None if edge_active is None else np.ascontiguousarray(edge_active, np.uint8)
+        check(lib().vo_ba_lm_begin(self._h, C.c_double(huber_mono), C.c_double(huber_stereo), int(max_iterations),
+                                   _p(act)), "vo_ba_lm_begin")
+
+    def linearize(self):
+        check(lib().vo_ba_linearize(self._h), "vo_ba_linearize")
+
+    def step(self):
+        check(lib().vo_ba_step(self._h), "vo_ba_step")
+
+    def update(self):
+        check(lib().vo_ba_update(self._h), "vo_ba_update")
+
+    def lm_end(self):
+        s = LmSummary()
+        check(lib().vo_ba_lm_end(self._h, C.byref(s)), "vo_ba_lm_end")
+        return s
+
+    def reduced_system(self):
+        p, n = C.c_void_p(), C.c_size_t()
+        check(lib().vo_ba_reduced_system(self._h, C.byref(p), C.byref(n)))
+        return p.value, n.value
+
+    def reduced_cost(self):
+        p, n = C.c_void_p(), C.c_size_t()
+        check(lib().vo_ba_reduced_cost(self._h, C.byref(p), C.byref(n)))
+        return p.value, n.value
+
+    def debug_schur(self, huber=(0.0, 0.0), edge_active=None):
+        n = 6 * self.n_free_cams()
+        S, b, cost = np.zeros((n, n)), np.zeros(n), C.c_double()
+        act = None if edge_active is None else np.ascontiguousarray(edge_active, np.uint8)
+        check(lib().vo_ba_debug_schur(self._h, C.c_double(huber[0]), C.c_double(huber[1]), C.c_double(0.0), _p(act),
+                                      _p(S), _p(b), C.byref(cost)), "vo_ba_debug_schur")
+        return S, b, cost.value
+
+
+def se3_exp(xi):
+    R, t = np.zeros(9), np.zeros(3)
+    check(lib().vo_se3_exp(_p(np.ascontiguousarray(xi, np.float64)), _p(R), _p(t)))
+    return R.reshape(3, 3), t
+
+
+def se3_log(R, t):
+    xi = np.zeros(6)
+    check(lib().vo_se3_log(_p(np.ascontiguousarray(R, np.float64).reshape(-1)), _p(np.ascontiguousarray(t, np.float64)), _p(xi)))
+    return xi

@@ -1,0 +1,1477 @@
+// ba.hip -- pose-only and local bundle adjustment on gfx950 (MI355X), FP64.
+// Replaces myslam::Optimizer::solvePoseOnlySE3 / solveLocalBAPoseAndPoint (reference
+// src/optimizer_ceres.cpp:157-314, 446-808) together with the Ceres solve they delegate to
+// (TrustRegionMinimizer + LevenbergMarquardtStrategy + DENSE_SCHUR; contract in DESIGN.md).
+//
+// Device-resident LM: every iteration is a fixed sequence of kernels whose control decisions
+// (accept / reject, radius, convergence) live in a small state struct in HBM, so the host never
+// synchronises inside a solve and a multi-GPU driver only inserts two all-reduces per iteration.
+//
+//   k_ba_points   8 lanes per map point: residuals + Jacobians of its edges, point block Hll/gl,
+//                 LM-damped inverse, and the rows of the two K-major operand matrices
+//                 Wt[3j+k][6c+a] = W_cj[a][k] (camera-unscaled), Yt = W * Hll^-1
+//   k_ba_cams     camera blocks Hpp/gp by segmented reduction over each camera's edge list
+//   k_ba_gemm     Schur product  Y * W^T  (6nf x 3Np x 6nf) on the FP64 matrix cores
+//                 (v_mfma_f64_16x16x4_f64), split-K partial tiles
+//   k_ba_reduce   fixed-order sum of the partial slabs into the all-reduce payload
+//   k_ba_solve    one workgroup: reduced camera system, Cholesky in LDS, step, candidate poses
+//   k_ba_backsub  back-substitution, candidate points, candidate cost
+//   k_ba_update   trust-region bookkeeping
+#include "ba_math.h"
+#include "vo_common.h"
+
+#include <algorithm>
+#include <cmath>
+#include <numeric>
+#include <vector>
+
+namespace {
+
+using namespace vo;
+using namespace vo::ba;
+
+// ============================================================================================
+// block reductions (fixed order => deterministic)
+// ============================================================================================
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+  for (int o = 32; o >= 1; o >>= 1) v += __shfl_xor(v, o);
+  return v;
+}
+__device__ __forceinline__ double wave_max(double v) {
+#pragma unroll
+  for (int o = 32; o >= 1; o >>= 1) v = fmax(v, __shfl_xor(v, o));
+  return v;
+}
+template <int N>
+__device__ __forceinline__ void block_sum(double (&v)[N], double *lds /*>= 4*N*/) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+  for (int i = 0; i < N; i++) v[i] = wave_sum(v[i]);
+  __syncthreads();
+  if (lane == 0)
+    for (int i = 0; i < N; i++) lds[wave * N + i] = v[i];
+  __syncthreads();
+  const int nw = blockDim.x >> 6;
+#pragma unroll
+  for (int i = 0; i < N; i++) {
+    double s = 0;
+    for (int w = 0; w < nw; w++) s += lds[w * N + i];
+    v[i] = s;
+  }
+}
+
+// ============================================================================================
+// Pose-only BA: Optimizer::solvePoseOnlySE3 (optimizer_ceres.cpp:157-314), one workgroup per frame
+// ============================================================================================
+struct PoseLm {
+  double radius, decrease, x_cost, x_norm;
+  int iterations, accepted, termination;
+};
+
+// one linearisation pass: H (upper 21), g (6), cost; unscaled, loss-corrected
+__device__ void pose_accumulate(const double x[6], int n, const double *pts, const double *obs, const double *isg,
+                                const uint8_t *skip, const Cam &K, double hm, double hs, bool want_jac,
+                                double (&acc)[28]) {
+#pragma unroll
+  for (int i = 0; i < 28; i++) acc[i] = 0;
+  const PoseCache P = pose_cache(x);
+  for (int i = threadIdx.x; i < n; i += blockDim.x) {
+    if (skip && skip[i]) continue;
+    double r[3], J[18];
+    int m;
+    if (want_jac)
+      m = edge_eval<true, false>(P, pts + 3 * i, obs[3 * i], obs[3 * i + 1], obs[3 * i + 2], isg[i], K, r, J, nullptr);
+    else
+      m = edge_eval<false, false>(P, pts + 3 * i, obs[3 * i], obs[3 * i + 1], obs[3 * i + 2], isg[i], K, r, nullptr,
+                                  nullptr);
+    const double s = r[0] * r[0] + r[1] * r[1] + r[2] * r[2];
+    double rho0, rho1;
+    huber(m == 2 ? hm : hs, s, rho0, rho1);
+    acc[27] += 0.5 * rho0;
+    if (!want_jac) continue;
+    // J' = sqrt(rho1) J, r' = sqrt(rho1) r  =>  J'^T J' = rho1 J^T J, J'^T r' = rho1 J^T r
+    int t = 0;
+#pragma unroll
+    for (int a = 0; a < 6; a++) {
+      const double ja0 = J[a], ja1 = J[6 + a], ja2 = J[12 + a];
+#pragma unroll
+      for (int b = a; b < 6; b++) acc[t++] += rho1 * (ja0 * J[b] + ja1 * J[6 + b] + ja2 * J[12 + b]);
+      acc[21 + a] += rho1 * (ja0 * r[0] + ja1 * r[1] + ja2 * r[2]);
+    }
+  }
+}
+
+__device__ bool chol6_solve(double A[6][6], double b[6]) {
+  for (int j = 0; j < 6; j++) {
+    double d = A[j][j];
+    for (int k = 0; k < j; k++) d -= A[j][k] * A[j][k];
+    if (!(d > 0.0)) return false;
+    d = sqrt(d);
+    A[j][j] = d;
+    for (int i = j + 1; i < 6; i++) {
+      double s = A[i][j];
+      for (int k = 0; k < j; k++) s -= A[i][k] * A[j][k];
+      A[i][j] = s / d;
+    }
+  }
+  for (int i = 0; i < 6; i++) {
+    double s = b[i];
+    for (int k = 0; k < i; k++) s -= A[i][k] * b[k];
+    b[i] = s / A[i][i];
+  }
+  for (int i = 5; i >= 0; i--) {
+    double s = b[i];
+    for (int k = i + 1; k < 6; k++) s -= A[k][i] * b[k];
+    b[i] = s / A[i][i];
+  }
+  return true;
+}
+
+// Ceres-style LM on one 6-dof pose; every thread keeps the (uniform) control state in registers.
+__device__ void pose_lm(double x[6], int n, const double *pts, const double *obs, const double *isg,
+                        const uint8_t *skip, const Cam &K, double hm, double hs, int max_it, double *lds,
+                        vo_lm_summary *sum) {
+  double acc[28];
+  pose_accumulate(x, n, pts, obs, isg, skip, K, hm, hs, true, acc);
+  block_sum<28>(acc, lds);
+  double scale[6];
+  {
+    int t = 0;
+    for (int a = 0; a < 6; a++) {
+      scale[a] = 1.0 / (1.0 + sqrt(acc[t]));
+      t += 6 - a;
+    }
+  }
+  double radius = 1e4, decrease = 2.0, x_cost = acc[27];
+  const double initial_cost = x_cost;
+  double x_norm = sqrt(x[0] * x[0] + x[1] * x[1] + x[2] * x[2] + x[3] * x[3] + x[4] * x[4] + x[5] * x[5]);
+  int iterations = 0, accepted = 0, termination = 0, invalid = 0;
+  bool last_ok = false;
+  for (int it = 1;; it++) {
+    if (it - 1 >= max_it) {
+      termination = 0;
+      break;
+    }
+    if (last_ok) {
+      double gm = 0;
+      for (int a = 0; a < 6; a++) gm = fmax(gm, fabs(acc[21 + a]));
+      if (gm <= 1e-10) {
+        termination = 3;
+        break;
+      }
+    }
+    if (radius < 1e-32) {
+      termination = 4;
+      break;
+    }
+    iterations = it;
+    last_ok = false;
+    // scaled normal equations  H'' = S H S, g'' = S g ; LM diagonal from clamp(diag H'')/radius
+    double A[6][6], g[6], D[6], Hs[6][6];
+    {
+      int t = 0;
+      for (int a = 0; a < 6; a++)
+        for (int b = a; b < 6; b++) {
+          const double v = acc[t++] * scale[a] * scale[b];
+          Hs[a][b] = Hs[b][a] = v;
+        }
+    }
+    for (int a = 0; a < 6; a++) {
+      g[a] = acc[21 + a] * scale[a];
+      D[a] = fmin(fmax(Hs[a][a], 1e-6), 1e32) / radius;
+      for (int b = 0; b < 6; b++) A[a][b] = Hs[a][b];
+      A[a][a] += D[a];
+    }
+    double y[6];
+    for (int a = 0; a < 6; a++) y[a] = g[a];
+    bool ok = chol6_solve(A, y);
+    double step[6], delta[6], model = 0;
+    if (ok) {
+      double gs = 0, sHs = 0;
+      for (int a = 0; a < 6; a++) {
+        step[a] = -y[a];
+        if (!isfinite(step[a])) ok = false;
+      }
+      for (int a = 0; a < 6; a++) {
+        gs += g[a] * step[a];
+        double row = 0;
+        for (int b = 0; b < 6; b++) row += Hs[a][b] * step[b];
+        sHs += step[a] * row;
+        delta[a] = step[a] * scale[a];
+      }
+      model = -(gs + 0.5 * sHs);  // -m.(r + m/2) with m = J''step
+    }
+    if (!ok || !(model > 0.0)) {
+      if (++invalid >= 5) {
+        termination = 4;
+        break;
+      }
+      radius /= decrease;
+      decrease *= 2.0;
+      continue;
+    }
+    invalid = 0;
+    double xc[6];
+    se3_plus(x, delta, xc);
+    double cacc[28];
+    pose_accumulate(xc, n, pts, obs, isg, skip, K, hm, hs, false, cacc);
+    double cc[1] = {cacc[27]};
+    block_sum<1>(cc, lds);
+    double cand = cc[0];
+    if (!isfinite(cand)) cand = 1.7976931348623157e308;
+    double sn = 0;
+    for (int a = 0; a < 6; a++) sn += (x[a] - xc[a]) * (x[a] - xc[a]);
+    if (sqrt(sn) <= 1e-8 * (x_norm + 1e-8)) {
+      termination = 2;
+      break;
+    }
+    const double change = x_cost - cand;
+    if (fabs(change) <= 1e-6 * x_cost) {
+      termination = 1;
+      break;
+    }
+    const double rel = change / model;
+    if (rel > 1e-3) {
+      for (int a = 0; a < 6; a++) x[a] = xc[a];
+      x_norm = sqrt(x[0] * x[0] + x[1] * x[1] + x[2] * x[2] + x[3] * x[3] + x[4] * x[4] + x[5] * x[5]);
+      pose_accumulate(x, n, pts, obs, isg, skip, K, hm, hs, true, acc);
+      block_sum<28>(acc, lds);
+      x_cost = acc[27];
+      const double t2 = 2.0 * rel - 1.0;
+      radius = fmin(radius / fmax(1.0 / 3.0, 1.0 - t2 * t2 * t2), 1e16);
+      decrease = 2.0;
+      accepted++;
+      last_ok = true;
+    } else {
+      radius /= decrease;
+      decrease *= 2.0;
+    }
+  }
+  if (sum && threadIdx.x == 0) {
+    sum->iterations = iterations;
+    sum->accepted = accepted;
+    sum->termination = termination;
+    sum->reserved = 0;
+    sum->initial_cost = initial_cost;
+    sum->final_cost = x_cost;
+    sum->final_radius = radius;
+  }
+}
+
+// float chi2 test of optimizer_ceres.cpp:262-303 (Q-B2: deliberately float)
+__device__ __forceinline__ bool pose_chi2_outlier(const double pc[3], double ou, double ov, double our, float fx,
+                                                  float fy, float cx, float cy, float bf, double isg) {
+  const double x = pc[0], y = pc[1], z = pc[2];
+  const float invz = (float)(1.0f / z);
+  const float u = (float)(fx * x * invz + cx);
+  const float v = (float)(fy * y * invz + cy);
+  const float eu = (float)(u - ou), ev = (float)(v - ov);
+  const float e2 = eu * eu + ev * ev;
+  const float is2 = (float)(isg * isg);
+  if (our < 0) return !(e2 * is2 < 5.991f);
+  const float ur = u - bf * invz;
+  const float eur = (float)(ur - our);
+  return !((e2 + eur * eur) * is2 < 7.815f);
+}
+
+__global__ __launch_bounds__(256) void k_pose_only(const int *offsets, const double *pts, const double *obs,
+                                                   const double *isg, const double *cam5, double *poses,
+                                                   uint8_t *outlier, int *n_inliers, vo_lm_summary *sums) {
+  __shared__ double lds[4 * 28];
+  __shared__ int s_cnt[4];
+  const int p = blockIdx.x;
+  const int o0 = offsets[p], n = offsets[p + 1] - o0;
+  pts += 3 * (long long)o0, obs += 3 * (long long)o0, isg += o0, outlier += o0;
+  Cam K{cam5[0], cam5[1], cam5[2], cam5[3], cam5[4]};
+  const float fx = (float)K.fx, fy = (float)K.fy, cx = (float)K.cx, cy = (float)K.cy, bf = (float)K.bf;
+  double x0[6], x[6];
+  for (int a = 0; a < 6; a++) x0[a] = x[a] = poses[6 * p + a];
+  if (n <= 0) {  // :204-205
+    if (threadIdx.x == 0) n_inliers[p] = 0;
+    return;
+  }
+  for (int i = threadIdx.x; i < n; i += blockDim.x) outlier[i] = 0;
+  __syncthreads();
+  int inl = 0;
+  for (int round = 0; round < 2; round++) {
+    for (int a = 0; a < 6; a++) x[a] = x0[a];  // :215
+    const double hm = round == 0 ? (double)sqrtf(5.991f) : 0.0;
+    const double hs = round == 0 ? (double)sqrtf(7.815f) : 0.0;
+    pose_lm(x, n, pts, obs, isg, outlier, K, hm, hs, 10, lds, sums ? &sums[2 * p + round] : nullptr);
+    __syncthreads();
+    // classification with Tcw = exp(pose) (Sophus quaternion form, :256-257)
+    const Se3 T = se3_exp(x);
+    int local = 0;
+    for (int i = threadIdx.x; i < n; i += blockDim.x) {
+      double rp[3], pc[3];
+      quat_rotate(T.q, pts + 3 * i, rp);
+      pc[0] = rp[0] + T.t[0], pc[1] = rp[1] + T.t[1], pc[2] = rp[2] + T.t[2];
+      const bool out = pose_chi2_outlier(pc, obs[3 * i], obs[3 * i + 1], obs[3 * i + 2], fx, fy, cx, cy, bf, isg[i]);
+      outlier[i] = out ? 1 : 0;
+      local += out ? 0 : 1;
+    }
+    for (int o = 32; o >= 1; o >>= 1) local += __shfl_xor(local, o);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) s_cnt[threadIdx.x >> 6] = local;
+    __syncthreads();
+    inl = s_cnt[0] + s_cnt[1] + s_cnt[2] + s_cnt[3];
+    __syncthreads();
+    if (inl < 10) {  // :306-307
+      if (round == 0 && sums && threadIdx.x == 0) memset(&sums[2 * p + 1], 0, sizeof(vo_lm_summary));
+      break;
+    }
+  }
+  if (threadIdx.x == 0) {
+    n_inliers[p] = inl;
+    for (int a = 0; a < 6; a++) poses[6 * p + a] = x[a];
+  }
+}
+
+// ============================================================================================
+// Local BA
+// ============================================================================================
+constexpr int kGroup = 8;        // lanes per map point
+constexpr int kPtsPerBlock = 32; // 256 / kGroup
+constexpr int kCamChunk = 1024;  // edges per k_ba_cams block
+constexpr int kMaxN = 128;       // reduced system size limit of the LDS Cholesky (6*nf + 1 <= kMaxN)
+
+struct BaState {
+  double radius, decrease, x_cost, cand_cost, initial_cost, x_norm2_c, cand_norm2_c, step_norm2_c, gdot_c,
+      dquad_c, gmax;
+  int iter, accepted, termination, done, invalid, last_ok, cur, max_it, first, solve_failed;
+};
+
+struct BaDev {
+  int n_cams, n_pts, n_edges, nf, n_local;  // n_local = points owned by this shard
+  int Mpad;                                 // padded reduced size (multiple of 16), 6nf+1 <= Mpad
+  int ksplit, kchunk;                       // split-K of the Schur GEMM
+  int n_pblocks, n_cchunks;
+  int n_shards, shard;
+  double hm, hs;
+  Cam K;
+  // problem
+  const int *e_cam, *e_pt;
+  const double *e_obs, *e_is;
+  uint8_t *e_active;
+  const int *pt_start;      // [n_pts+1] into the point-sorted edge arrays
+  const int *local_pts;     // [n_local]
+  const int *cam_slot;      // [n_cams] free index or -1
+  const int *slot_cam;      // [nf]
+  const int *cam_start;     // [nf+1]
+  const int *cam_edges;     // edge ids per free camera (this shard's edges only)
+  uint8_t *pt_in, *cam_in;
+  // state
+  double *Xc[2], *Xp[2];
+  double *scale_c, *scale_p;
+  double *hinv, *gl2, *dl;  // per point: inverse (6), scaled gradient (3), LM diagonal (3)
+  double *Wt, *Yt;          // [3*n_pts][Mpad]
+  double *slab_gemm;        // [ksplit][Mpad*Mpad]
+  double *slab_cam;         // [nf][n_cchunks][27]
+  double *slab_pt;          // [n_pblocks][2]  cost, gmax
+  double *payload;          // Mpad*Mpad + nf*27 + 1 + n_shards
+  double *zc;               // [6nf] scale_c * y_c
+  double *slab_bs;          // [n_pblocks][6]
+  double *payload2;         // 6
+  BaState *st;
+};
+
+__device__ __forceinline__ int payload_hpp_off(const BaDev &B) { return B.Mpad * B.Mpad; }
+__device__ __forceinline__ int payload_cost_off(const BaDev &B) { return B.Mpad * B.Mpad + B.nf * 27; }
+
+// --------------------------------------------------------------------------------------------
+// k_ba_points: LocalBAProjectUV / LocalBAStereoProjectUVD::Evaluate (:320-444) for the edges of a
+// point, Ceres' loss correction, the e-block E^T E + D and its inverse (SchurEliminator), and this
+// point's rows of the GEMM operands.
+// --------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_ba_points(BaDev B) {
+  __shared__ double lds[4 * 2];
+  const BaState st = *B.st;
+  if (st.done) return;
+  const int tid = threadIdx.x, g = tid & (kGroup - 1);
+  const int li = blockIdx.x * kPtsPerBlock + (tid >> 3);
+  const bool valid = li < B.n_local;
+  const int j = valid ? B.local_pts[li] : 0;
+  const double *Xc = B.Xc[st.cur], *Xp = B.Xp[st.cur];
+  double cost = 0, gmax = 0;
+  if (valid) {
+    const int e0 = B.pt_start[j], e1 = B.pt_start[j + 1];
+    const double pt[3] = {Xp[3 * j], Xp[3 * j + 1], Xp[3 * j + 2]};
+    double h[6] = {0, 0, 0, 0, 0, 0}, gl[3] = {0, 0, 0};
+    for (int e = e0 + g; e < e1; e += kGroup) {
+      if (!B.e_active[e]) continue;
+      const PoseCache P = pose_cache(Xc + 6 * B.e_cam[e]);
+      double r[3], Jl[9];
+      const int m = edge_eval<false, true>(P, pt, B.e_obs[3 * e], B.e_obs[3 * e + 1], B.e_obs[3 * e + 2], B.e_is[e],
+                                           B.K, r, nullptr, Jl);
+      double rho0, rho1;
+      huber(m == 2 ? B.hm : B.hs, r[0] * r[0] + r[1] * r[1] + r[2] * r[2], rho0, rho1);
+      cost += 0.5 * rho0;
+      h[0] += rho1 * (Jl[0] * Jl[0] + Jl[3] * Jl[3] + Jl[6] * Jl[6]);
+      h[1] += rho1 * (Jl[0] * Jl[1] + Jl[3] * Jl[4] + Jl[6] * Jl[7]);
+      h[2] += rho1 * (Jl[0] * Jl[2] + Jl[3] * Jl[5] + Jl[6] * Jl[8]);
+      h[3] += rho1 * (Jl[1] * Jl[1] + Jl[4] * Jl[4] + Jl[7] * Jl[7]);
+      h[4] += rho1 * (Jl[1] * Jl[2] + Jl[4] * Jl[5] + Jl[7] * Jl[8]);
+      h[5] += rho1 * (Jl[2] * Jl[2] + Jl[5] * Jl[5] + Jl[8] * Jl[8]);
+      gl[0] += rho1 * (Jl[0] * r[0] + Jl[3] * r[1] + Jl[6] * r[2]);
+      gl[1] += rho1 * (Jl[1] * r[0] + Jl[4] * r[1] + Jl[7] * r[2]);
+      gl[2] += rho1 * (Jl[2] * r[0] + Jl[5] * r[1] + Jl[8] * r[2]);
+    }
+    // butterfly over the 8 lanes of the group: every lane ends with the totals
+#pragma unroll
+    for (int o = 1; o < kGroup; o <<= 1) {
+#pragma unroll
+      for (int i = 0; i < 6; i++) h[i] += __shfl_xor(h[i], o);
+#pragma unroll
+      for (int i = 0; i < 3; i++) gl[i] += __shfl_xor(gl[i], o);
+    }
+    double sp[3];
+    if (st.first) {  // Jacobi scaling 1/(1+||column||), fixed after iteration 0
+      sp[0] = 1.0 / (1.0 + sqrt(h[0])), sp[1] = 1.0 / (1.0 + sqrt(h[3])), sp[2] = 1.0 / (1.0 + sqrt(h[5]));
+      if (g == 0) B.scale_p[3 * j] = sp[0], B.scale_p[3 * j + 1] = sp[1], B.scale_p[3 * j + 2] = sp[2];
+    } else {
+      sp[0] = B.scale_p[3 * j], sp[1] = B.scale_p[3 * j + 1], sp[2] = B.scale_p[3 * j + 2];
+    }
+    gmax = fmax(fabs(gl[0]), fmax(fabs(gl[1]), fabs(gl[2])));
+    double hs[6] = {h[0] * sp[0] * sp[0], h[1] * sp[0] * sp[1], h[2] * sp[0] * sp[2],
+                    h[3] * sp[1] * sp[1], h[4] * sp[1] * sp[2], h[5] * sp[2] * sp[2]};
+    const double d0 = fmin(fmax(hs[0], 1e-6), 1e32) / st.radius;
+    const double d1 = fmin(fmax(hs[3], 1e-6), 1e32) / st.radius;
+    const double d2 = fmin(fmax(hs[5], 1e-6), 1e32) / st.radius;
+    hs[0] += d0, hs[3] += d1, hs[5] += d2;
+    double hi[6];
+    if (!inv3_sym(hs, hi)) {
+      hi[0] = hi[3] = hi[5] = 0.0 / 0.0;  // poisons the step => invalid step handling
+      hi[1] = hi[2] = hi[4] = 0;
+    }
+    const double g2[3] = {gl[0] * sp[0], gl[1] * sp[1], gl[2] * sp[2]};
+    if (g == 0) {
+      for (int i = 0; i < 6; i++) B.hinv[6 * j + i] = hi[i];
+      B.gl2[3 * j] = g2[0], B.gl2[3 * j + 1] = g2[1], B.gl2[3 * j + 2] = g2[2];
+      B.dl[3 * j] = d0, B.dl[3 * j + 1] = d1, B.dl[3 * j + 2] = d2;
+      // extra GEMM column 6nf carries gl'' so that the same product yields  sum_j Y_j gl''_j
+      for (int k = 0; k < 3; k++) B.Wt[(long long)(3 * j + k) * B.Mpad + 6 * B.nf] = g2[k];
+    }
+    // second sweep: W = Jp'^T Jl' per edge, point-scaled, and Y = W Hinv
+    for (int e = e0 + g; e < e1; e += kGroup) {
+      if (!B.e_active[e]) continue;
+      const int slot = B.cam_slot[B.e_cam[e]];
+      if (slot < 0) continue;
+      const PoseCache P = pose_cache(Xc + 6 * B.e_cam[e]);
+      double r[3], Jp[18], Jl[9];
+      const int m = edge_eval<true, true>(P, pt, B.e_obs[3 * e], B.e_obs[3 * e + 1], B.e_obs[3 * e + 2], B.e_is[e],
+                                          B.K, r, Jp, Jl);
+      double rho0, rho1;
+      huber(m == 2 ? B.hm : B.hs, r[0] * r[0] + r[1] * r[1] + r[2] * r[2], rho0, rho1);
+#pragma unroll
+      for (int a = 0; a < 6; a++) {
+        double w[3];
+#pragma unroll
+        for (int k = 0; k < 3; k++)
+          w[k] = rho1 * (Jp[a] * Jl[k] + Jp[6 + a] * Jl[3 + k] + Jp[12 + a] * Jl[6 + k]) * sp[k];
+        const double y0 = w[0] * hi[0] + w[1] * hi[1] + w[2] * hi[2];
+        const double y1 = w[0] * hi[1] + w[1] * hi[3] + w[2] * hi[4];
+        const double y2 = w[0] * hi[2] + w[1] * hi[4] + w[2] * hi[5];
+        const long long base = (long long)(3 * j) * B.Mpad + 6 * slot + a;
+        B.Wt[base] = w[0], B.Wt[base + B.Mpad] = w[1], B.Wt[base + 2 * B.Mpad] = w[2];
+        B.Yt[base] = y0, B.Yt[base + B.Mpad] = y1, B.Yt[base + 2 * B.Mpad] = y2;
+      }
+    }
+  }
+  // block partials: cost (sum), gmax (max).  Only lane g==0.. all lanes hold their own cost part.
+  double c[1] = {cost};
+  block_sum<1>(c, lds);
+  double gm = wave_max(gmax);
+  __shared__ double lmx[4];
+  if ((tid & 63) == 0) lmx[tid >> 6] = gm;
+  __syncthreads();
+  if (tid == 0) {
+    B.slab_pt[2 * blockIdx.x] = c[0];
+    B.slab_pt[2 * blockIdx.x + 1] = fmax(fmax(lmx[0], lmx[1]), fmax(lmx[2], lmx[3]));
+  }
+}
+
+// --------------------------------------------------------------------------------------------
+// k_ba_cams: F^T F and F^T b of each free camera (the f-blocks of the Schur eliminator)
+// --------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_ba_cams(BaDev B) {
+  __shared__ double lds[4 * 27];
+  const BaState st = *B.st;
+  if (st.done) return;
+  const int slot = blockIdx.x, chunk = blockIdx.y, tid = threadIdx.x;
+  const int c = B.slot_cam[slot];
+  const int s0 = B.cam_start[slot], s1 = B.cam_start[slot + 1];
+  const double *Xc = B.Xc[st.cur], *Xp = B.Xp[st.cur];
+  const PoseCache P = pose_cache(Xc + 6 * c);
+  double acc[27];
+#pragma unroll
+  for (int i = 0; i < 27; i++) acc[i] = 0;
+  for (int idx = s0 + chunk * kCamChunk + tid; idx < min(s1, s0 + (chunk + 1) * kCamChunk); idx += 256) {
+    const int e = B.cam_edges[idx];
+    if (!B.e_active[e]) continue;
+    const int j = B.e_pt[e];
+    const double pt[3] = {Xp[3 * j], Xp[3 * j + 1], Xp[3 * j + 2]};
+    double r[3], J[18];
+    const int m = edge_eval<true, false>(P, pt, B.e_obs[3 * e], B.e_obs[3 * e + 1], B.e_obs[3 * e + 2], B.e_is[e],
+                                         B.K, r, J, nullptr);
+    double rho0, rho1;
+    huber(m == 2 ? B.hm : B.hs, r[0] * r[0] + r[1] * r[1] + r[2] * r[2], rho0, rho1);
+    int t = 0;
+#pragma unroll
+    for (int a = 0; a < 6; a++) {
+      const double ja0 = J[a], ja1 = J[6 + a], ja2 = J[12 + a];
+#pragma unroll
+      for (int b = a; b < 6; b++) acc[t++] += rho1 * (ja0 * J[b] + ja1 * J[6 + b] + ja2 * J[12 + b]);
+      acc[21 + a] += rho1 * (ja0 * r[0] + ja1 * r[1] + ja2 * r[2]);
+    }
+  }
+  block_sum<27>(acc, lds);
+  if (tid < 27) B.slab_cam[((long long)slot * B.n_cchunks + chunk) * 27 + tid] = acc[tid];
+}
+
+// --------------------------------------------------------------------------------------------
+// k_ba_gemm: partial tiles of  G = Y * W^T  with G[m][n] = sum_k Yt[k][m] * Wt[k][n] on the FP64
+// matrix cores.  One 16x16 tile per wavefront per K-slice; A operand: lane l holds
+// A[i = l&15][k = l>>4]; B operand: B[k = l>>4][j = l&15]; result: 4 doubles per lane at
+// row (l>>4) + 4*reg, column l&15.
+// --------------------------------------------------------------------------------------------
+typedef double double4_t __attribute__((ext_vector_type(4)));
+
+__global__ __launch_bounds__(64) void k_ba_gemm(BaDev B) {
+  const BaState st = *B.st;
+  if (st.done) return;
+  const int tiles = B.Mpad / 16;
+  const int tile = blockIdx.x, ks = blockIdx.y;
+  const int tm = tile / tiles, tn = tile - tm * tiles;
+  const int lane = threadIdx.x;
+  const int K = 3 * B.n_pts;
+  const int k0 = ks * B.kchunk, k1 = min(K, k0 + B.kchunk);
+  double4_t acc = {0, 0, 0, 0};
+  const int kk = lane >> 4, ii = lane & 15;
+  for (int k = k0; k < k1; k += 4) {
+    const int kr = k + kk;
+    double a = 0, b = 0;
+    if (kr < k1) {
+      a = B.Yt[(long long)kr * B.Mpad + tm * 16 + ii];
+      b = B.Wt[(long long)kr * B.Mpad + tn * 16 + ii];
+    }
+    acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc, 0, 0, 0);
+  }
+  double *out = B.slab_gemm + (long long)ks * B.Mpad * B.Mpad;
+#pragma unroll
+  for (int r = 0; r < 4; r++) out[(long long)(tm * 16 + kk + 4 * r) * B.Mpad + tn * 16 + ii] = acc[r];
+}
+
+// fixed-order reduction of the slabs into the payload that a multi-GPU run all-reduces
+__global__ __launch_bounds__(256) void k_ba_reduce(BaDev B) {
+  const BaState st = *B.st;
+  if (st.done) return;
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  const int nG = B.Mpad * B.Mpad, nH = B.nf * 27;
+  if (i < nG) {
+    double s = 0;
+    for (int k = 0; k < B.ksplit; k++) s += B.slab_gemm[(long long)k * nG + i];
+    B.payload[i] = s;
+  } else if (i < nG + nH) {
+    const int q = i - nG, slot = q / 27, t = q - slot * 27;
+    double s = 0;
+    for (int c = 0; c < B.n_cchunks; c++) s += B.slab_cam[((long long)slot * B.n_cchunks + c) * 27 + t];
+    B.payload[i] = s;
+  } else if (i == nG + nH) {
+    double s = 0, m = 0;
+    for (int b = 0; b < B.n_pblocks; b++) {
+      s += B.slab_pt[2 * b];
+      m = fmax(m, B.slab_pt[2 * b + 1]);
+    }
+    B.payload[i] = s;
+    for (int k = 0; k < B.n_shards; k++) B.payload[i + 1 + k] = (k == B.shard) ? m : 0.0;
+  }
+}
+
+// --------------------------------------------------------------------------------------------
+// k_ba_solve: reduced camera system S y = rhs (DenseSchurComplementSolver: dense Cholesky),
+// camera step, candidate poses.  One workgroup; S lives in LDS.
+// --------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_ba_solve(BaDev B) {
+  extern __shared__ double sm[];
+  BaState *S = B.st;
+  if (S->done) return;
+  const int tid = threadIdx.x;
+  const int n = 6 * B.nf, ld = n + 1;
+  double *A = sm;                 // n x ld
+  double *rhs = A + n * ld;       // n
+  double *sc = rhs + n;           // n   Jacobi scale
+  double *Dd = sc + n;            // n   LM diagonal
+  double *red = Dd + n;           // 8 * 4 scratch
+  __shared__ int s_fail, s_stop;
+  const double *G = B.payload;
+  const double *HP = B.payload + payload_hpp_off(B);
+  const int first = S->first;
+  const double radius = S->radius;
+  if (tid == 0) s_fail = 0, s_stop = 0;
+  // Jacobi scaling of the camera columns from the first linearisation
+  for (int i = tid; i < n; i += 256) {
+    const int slot = i / 6, a = i - slot * 6;
+    int t = 0;
+    for (int q = 0; q < a; q++) t += 6 - q;  // index of (a,a) in the packed upper triangle
+    const double hd = HP[slot * 27 + t];
+    double s;
+    if (first) {
+      s = 1.0 / (1.0 + sqrt(hd));
+      B.scale_c[6 * B.slot_cam[slot] + a] = s;
+    } else {
+      s = B.scale_c[6 * B.slot_cam[slot] + a];
+    }
+    sc[i] = s;
+    Dd[i] = fmin(fmax(hd * s * s, 1e-6), 1e32) / radius;
+  }
+  __syncthreads();
+  double gm = 0;
+  for (int i = tid; i < n * n; i += 256) {
+    const int r = i / n, c = i - r * n;
+    double v = -G[(long long)r * B.Mpad + c];
+    if (r / 6 == c / 6) {
+      const int slot = r / 6, a = min(r % 6, c % 6), b = max(r % 6, c % 6);
+      int t = 0;
+      for (int q = 0; q < a; q++) t += 6 - q;
+      v += HP[slot * 27 + t + (b - a)];
+    }
+    v *= sc[r] * sc[c];
+    if (r == c) v += Dd[r];
+    A[r * ld + c] = v;
+  }
+  for (int i = tid; i < n; i += 256) {
+    const int slot = i / 6, a = i - slot * 6;
+    const double gp = HP[slot * 27 + 21 + a];
+    gm = fmax(gm, fabs(gp));
+    rhs[i] = sc[i] * (gp - G[(long long)i * B.Mpad + n]);
+  }
+  gm = wave_max(gm);
+  if ((tid & 63) == 0) red[tid >> 6] = gm;
+  __syncthreads();
+  if (tid == 0) {
+    double m = fmax(fmax(red[0], red[1]), fmax(red[2], red[3]));
+    const int co = payload_cost_off(B);
+    for (int k = 0; k < B.n_shards; k++) m = fmax(m, B.payload[co + 1 + k]);
+    S->gmax = m;
+    const double cost = B.payload[co];
+    S->x_cost = cost;
+    if (first) S->initial_cost = cost;
+    // FinalizeIterationAndCheckIfMinimizerCanContinue of the previous iteration
+    if (S->last_ok && m <= 1e-10) {
+      S->termination = 3;
+      S->done = 1;
+      s_stop = 1;
+    } else {
+      S->iter += 1;
+    }
+    S->first = 0;
+  }
+  __syncthreads();
+  if (s_stop) return;
+  double gdot = 0, dquad = 0;
+  // right-looking Cholesky, lower triangle, column by column
+  for (int j = 0; j < n; j++) {
+    if (tid == 0) {
+      const double d = A[j * ld + j];
+      if (!(d > 0.0)) s_fail = 1;
+      A[j * ld + j] = sqrt(d);
+    }
+    __syncthreads();
+    if (s_fail) break;
+    const double dj = A[j * ld + j];
+    for (int i = j + 1 + tid; i < n; i += 256) A[i * ld + j] /= dj;
+    __syncthreads();
+    const int rem = n - j - 1;
+    for (int t = tid; t < rem * rem; t += 256) {
+      const int r = j + 1 + t / rem, c = j + 1 + t % rem;
+      if (c <= r) A[r * ld + c] -= A[r * ld + j] * A[c * ld + j];
+    }
+    __syncthreads();
+  }
+  double *y = Dd + n + 64;  // reuse after red: solution vector (n)
+  if (!s_fail) {
+    if (tid == 0) {
+      for (int i = 0; i < n; i++) {
+        double s = rhs[i];
+        for (int k = 0; k < i; k++) s -= A[i * ld + k] * y[k];
+        y[i] = s / A[i * ld + i];
+      }
+      for (int i = n - 1; i >= 0; i--) {
+        double s = y[i];
+        for (int k = i + 1; k < n; k++) s -= A[k * ld + i] * y[k];
+        y[i] = s / A[i * ld + i];
+      }
+      for (int i = 0; i < n; i++)
+        if (!isfinite(y[i])) s_fail = 1;
+    }
+    __syncthreads();
+  }
+  // camera part of  g''.step  and  step^T D step  (step = -y)
+  for (int i = tid; i < n; i += 256) {
+    const double stp = -y[i];
+    dquad += Dd[i] * stp * stp;
+    B.zc[i] = sc[i] * y[i];
+  }
+  // g''_c . step_c needs the *gradient* s_c*gp, not the Schur rhs
+  for (int i = tid; i < n; i += 256) {
+    const int slot = i / 6, a = i - slot * 6;
+    gdot += sc[i] * HP[slot * 27 + 21 + a] * (-y[i]);
+  }
+  // candidate poses + norms
+  const double *X = B.Xc[S->cur];
+  double *Xn = B.Xc[S->cur ^ 1];
+  double xn2 = 0, cn2 = 0, sn2 = 0;
+  for (int c = tid; c < B.n_cams; c += 256) {
+    const int slot = B.cam_slot[c];
+    double xc[6];
+    if (slot >= 0 && !s_fail) {
+      double d[6];
+      for (int a = 0; a < 6; a++) d[a] = -y[6 * slot + a] * sc[6 * slot + a];
+      se3_plus(X + 6 * c, d, xc);
+    } else {
+      for (int a = 0; a < 6; a++) xc[a] = X[6 * c + a];
+    }
+    for (int a = 0; a < 6; a++) {
+      Xn[6 * c + a] = xc[a];
+      if (slot >= 0 && B.cam_in[c]) {
+        xn2 += X[6 * c + a] * X[6 * c + a];
+        cn2 += xc[a] * xc[a];
+        sn2 += (xc[a] - X[6 * c + a]) * (xc[a] - X[6 * c + a]);
+      }
+    }
+  }
+  double v5[5] = {gdot, dquad, xn2, cn2, sn2};
+  __syncthreads();
+  block_sum<5>(v5, red);
+  if (tid == 0) {
+    S->gdot_c = v5[0];
+    S->dquad_c = v5[1];
+    S->x_norm2_c = v5[2];
+    S->cand_norm2_c = v5[3];
+    S->step_norm2_c = v5[4];
+    S->solve_failed = s_fail;
+  }
+}
+
+// --------------------------------------------------------------------------------------------
+// k_ba_backsub: SchurEliminator::BackSubstitute, candidate points and the candidate cost
+// --------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_ba_backsub(BaDev B) {
+  __shared__ double lds[4 * 6];
+  const BaState st = *B.st;
+  if (st.done) return;
+  const int tid = threadIdx.x, g = tid & (kGroup - 1);
+  const int li = blockIdx.x * kPtsPerBlock + (tid >> 3);
+  const bool valid = li < B.n_local;
+  const int j = valid ? B.local_pts[li] : 0;
+  const double *Xc = B.Xc[st.cur], *Xp = B.Xp[st.cur];
+  const double *Xcn = B.Xc[st.cur ^ 1];
+  double *Xpn = B.Xp[st.cur ^ 1];
+  double v[6] = {0, 0, 0, 0, 0, 0};  // cand_cost, gdot_l, dquad_l, step2, xnorm2, candnorm2
+  if (valid) {
+    const int e0 = B.pt_start[j], e1 = B.pt_start[j + 1];
+    double rr[3] = {0, 0, 0};
+    for (int e = e0 + g; e < e1; e += kGroup) {
+      if (!B.e_active[e]) continue;
+      const int slot = B.cam_slot[B.e_cam[e]];
+      if (slot < 0) continue;
+      const long long base = (long long)(3 * j) * B.Mpad + 6 * slot;
+#pragma unroll
+      for (int a = 0; a < 6; a++) {
+        const double z = B.zc[6 * slot + a];
+        rr[0] += B.Wt[base + a] * z;
+        rr[1] += B.Wt[base + B.Mpad + a] * z;
+        rr[2] += B.Wt[base + 2 * B.Mpad + a] * z;
+      }
+    }
+#pragma unroll
+    for (int o = 1; o < kGroup; o <<= 1)
+#pragma unroll
+      for (int i = 0; i < 3; i++) rr[i] += __shfl_xor(rr[i], o);
+    const double *hi = B.hinv + 6 * j;
+    const double g2[3] = {B.gl2[3 * j], B.gl2[3 * j + 1], B.gl2[3 * j + 2]};
+    const double q[3] = {g2[0] - rr[0], g2[1] - rr[1], g2[2] - rr[2]};
+    const double y0 = hi[0] * q[0] + hi[1] * q[1] + hi[2] * q[2];
+    const double y1 = hi[1] * q[0] + hi[3] * q[1] + hi[4] * q[2];
+    const double y2 = hi[2] * q[0] + hi[4] * q[1] + hi[5] * q[2];
+    const double stp[3] = {-y0, -y1, -y2};
+    const bool in = B.pt_in[j] && !st.solve_failed;
+    double pn[3];
+    for (int k = 0; k < 3; k++) pn[k] = Xp[3 * j + k] + (in ? stp[k] * B.scale_p[3 * j + k] : 0.0);
+    if (g == 0) {
+      for (int k = 0; k < 3; k++) Xpn[3 * j + k] = pn[k];
+      if (B.pt_in[j]) {
+        for (int k = 0; k < 3; k++) {
+          v[1] += g2[k] * stp[k];
+          v[2] += B.dl[3 * j + k] * stp[k] * stp[k];
+          v[3] += (pn[k] - Xp[3 * j + k]) * (pn[k] - Xp[3 * j + k]);
+          v[4] += Xp[3 * j + k] * Xp[3 * j + k];
+          v[5] += pn[k] * pn[k];
+        }
+      }
+    }
+    for (int e = e0 + g; e < e1; e += kGroup) {
+      if (!B.e_active[e]) continue;
+      const PoseCache P = pose_cache(Xcn + 6 * B.e_cam[e]);
+      double r[3];
+      const int m = edge_eval<false, false>(P, pn, B.e_obs[3 * e], B.e_obs[3 * e + 1], B.e_obs[3 * e + 2], B.e_is[e],
+                                            B.K, r, nullptr, nullptr);
+      double rho0, rho1;
+      huber(m == 2 ? B.hm : B.hs, r[0] * r[0] + r[1] * r[1] + r[2] * r[2], rho0, rho1);
+      v[0] += 0.5 * rho0;
+    }
+  }
+  block_sum<6>(v, lds);
+  if (tid < 6) B.slab_bs[6 * blockIdx.x + tid] = v[tid];
+}
+
+__global__ __launch_bounds__(64) void k_ba_reduce2(BaDev B) {
+  const BaState st = *B.st;
+  if (st.done) return;
+  const int t = threadIdx.x;
+  if (t < 6) {
+    double s = 0;
+    for (int b = 0; b < B.n_pblocks; b++) s += B.slab_bs[6 * b + t];
+    B.payload2[t] = s;
+  }
+}
+
+// --------------------------------------------------------------------------------------------
+// k_ba_update: TrustRegionMinimizer step evaluation + LevenbergMarquardtStrategy radius update
+// --------------------------------------------------------------------------------------------
+__global__ void k_ba_update(BaDev B) {
+  BaState *S = B.st;
+  if (S->done || threadIdx.x != 0 || blockIdx.x != 0) return;
+  const double *p = B.payload2;
+  const double cand_cost = p[0];
+  const double model = -0.5 * (S->gdot_c + p[1]) + 0.5 * (S->dquad_c + p[2]);
+  const double step_norm = sqrt(S->step_norm2_c + p[3]);
+  const double x_norm = sqrt(S->x_norm2_c + p[4]);
+  S->cand_cost = cand_cost;
+  S->last_ok = 0;
+  if (S->solve_failed || !(model > 0.0) || !isfinite(model)) {
+    if (++S->invalid >= 5) {
+      S->termination = 4;
+      S->done = 1;
+      return;
+    }
+    S->radius /= S->decrease;
+    S->decrease *= 2.0;
+  } else {
+    S->invalid = 0;
+    const double cc = isfinite(cand_cost) ? cand_cost : 1.7976931348623157e308;
+    if (step_norm <= 1e-8 * (x_norm + 1e-8)) {
+      S->termination = 2;
+      S->done = 1;
+      return;
+    }
+    const double change = S->x_cost - cc;
+    if (fabs(change) <= 1e-6 * S->x_cost) {
+      S->termination = 1;
+      S->done = 1;
+      return;
+    }
+    const double rel = change / model;
+    if (rel > 1e-3) {
+      S->cur ^= 1;
+      S->x_cost = cc;
+      const double t2 = 2.0 * rel - 1.0;
+      S->radius = fmin(S->radius / fmax(1.0 / 3.0, 1.0 - t2 * t2 * t2), 1e16);
+      S->decrease = 2.0;
+      S->accepted += 1;
+      S->last_ok = 1;
+    } else {
+      S->radius /= S->decrease;
+      S->decrease *= 2.0;
+    }
+  }
+  if (S->iter >= S->max_it) {
+    S->termination = 0;
+    S->done = 1;
+  } else if (S->radius < 1e-32) {
+    S->termination = 4;
+    S->done = 1;
+  }
+}
+
+__global__ void k_ba_begin(BaDev B, int max_it) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  BaState *S = B.st;
+  const int cur = S->cur;
+  memset(S, 0, sizeof(BaState));
+  S->cur = cur;
+  S->radius = 1e4;
+  S->decrease = 2.0;
+  S->max_it = max_it;
+  S->first = 1;
+}
+
+// edge activity -> which points / cameras are in the problem (Ceres drops unused blocks)
+__global__ void k_ba_mark(BaDev B) {
+  const int e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= B.n_edges || !B.e_active[e]) return;
+  B.pt_in[B.e_pt[e]] = 1;
+  if (B.cam_slot[B.e_cam[e]] >= 0) B.cam_in[B.e_cam[e]] = 1;
+}
+
+// float chi2 classification of the edges, optimizer_ceres.cpp:618-689 (mode 0: writes
+// e_active = inlier and out = outlier) and :703-755 (mode 1: out |= outlier).  Q-B2.
+__global__ void k_ba_classify(BaDev B, int mode, uint8_t *out) {
+  const int e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= B.n_edges) return;
+  const int cur = B.st->cur;
+  if (mode == 1 && out[e]) return;
+  const PoseCache P = pose_cache(B.Xc[cur] + 6 * B.e_cam[e]);
+  double pc[3];
+  trans_point(P, B.Xp[cur] + 3 * B.e_pt[e], pc);
+  const float fx = (float)B.K.fx, fy = (float)B.K.fy, cx = (float)B.K.cx, cy = (float)B.K.cy, bf = (float)B.K.bf;
+  const float x = (float)pc[0], y = (float)pc[1], z = (float)pc[2];
+  const double ou = B.e_obs[3 * e], ov = B.e_obs[3 * e + 1], our = B.e_obs[3 * e + 2];
+  bool outl;
+  if (z < 0.0f) {
+    outl = true;
+  } else {
+    const float invz = 1.0f / z;
+    const float u = fx * x * invz + cx, v = fy * y * invz + cy;
+    float eu, ev;
+    if (mode == 0)
+      eu = u - (float)ou, ev = v - (float)ov;
+    else
+      eu = (float)(u - ou), ev = (float)(v - ov);
+    const float e2 = eu * eu + ev * ev;
+    const float is2 = (float)(B.e_is[e] * B.e_is[e]);
+    const bool mono = mode == 0 ? ((float)our < 0) : (our < 0);
+    if (mono) {
+      outl = e2 * is2 > 5.991f;
+    } else {
+      const float ur = u - bf * invz;
+      const float eur = mode == 0 ? ur - (float)our : (float)(ur - our);
+      outl = (e2 + eur * eur) * is2 > 7.815f;
+    }
+  }
+  if (mode == 0) {
+    out[e] = outl;
+    B.e_active[e] = !outl;
+  } else {
+    out[e] = outl;
+  }
+}
+
+}  // namespace
+
+// ============================================================================================
+// host
+// ============================================================================================
+struct vo_ba {
+  int n_cams = 0, n_pts = 0, n_edges = 0, nf = 0;
+  std::vector<double> poses, points;
+  std::vector<uint8_t> cam_fixed;
+  std::vector<int> e_cam, e_pt, perm;  // sorted by point; perm[sorted] = caller index
+  std::vector<double> e_obs, e_is;
+  std::vector<int> pt_start, cam_slot, slot_cam;
+  double cam[5];
+  int shard = 0, n_shards = 1;
+  hipStream_t stream = nullptr;
+  bool own_stream = false;
+  bool built = false;
+  BaDev D{};
+  vo::DevBuf b_ecam, b_ept, b_eobs, b_eis, b_eact, b_ptstart, b_local, b_camslot, b_slotcam, b_camstart,
+      b_camedges, b_ptin, b_camin, b_xc0, b_xc1, b_xp0, b_xp1, b_sc, b_sp, b_hinv, b_gl2, b_dl, b_wt, b_yt,
+      b_sgemm, b_scam, b_spt, b_payload, b_zc, b_sbs, b_payload2, b_state, b_out;
+  size_t solve_lds = 0;
+  int lm_max_it = 0;
+};
+
+namespace {
+
+int upload(vo::DevBuf &b, const void *src, size_t bytes) {
+  VO_CHECK(b.reserve(std::max<size_t>(bytes, 64)));
+  if (bytes) VO_HIP_CHECK(hipMemcpy(b.p, src, bytes, hipMemcpyHostToDevice));
+  return VO_OK;
+}
+
+int build_device(vo_ba *h) {
+  if (h->built) return VO_OK;
+  BaDev &D = h->D;
+  D.n_cams = h->n_cams, D.n_pts = h->n_pts, D.n_edges = h->n_edges, D.nf = h->nf;
+  D.n_shards = h->n_shards, D.shard = h->shard;
+  D.K = Cam{h->cam[0], h->cam[1], h->cam[2], h->cam[3], h->cam[4]};
+  if (6 * h->nf + 1 > kMaxN) {
+    vo::set_error("local BA with %d free key-frames needs a %d-wide reduced system; this build solves up to %d "
+                  "in LDS (larger problems: blocked MFMA Cholesky, not in this round)",
+                  h->nf, 6 * h->nf + 1, kMaxN);
+    return VO_ERR_CAPACITY;
+  }
+  D.Mpad = std::max(16, (6 * h->nf + 1 + 15) / 16 * 16);
+  std::vector<int> local;
+  for (int j = 0; j < h->n_pts; j++)
+    if (j % h->n_shards == h->shard) local.push_back(j);
+  D.n_local = (int)local.size();
+  // per-camera edge lists restricted to this shard's points
+  std::vector<int> cstart(h->nf + 1, 0), cedges;
+  {
+    std::vector<std::vector<int>> lists(h->nf);
+    for (int e = 0; e < h->n_edges; e++) {
+      const int s = h->cam_slot[h->e_cam[e]];
+      if (s >= 0 && h->e_pt[e] % h->n_shards == h->shard) lists[s].push_back(e);
+    }
+    int mx = 0;
+    for (int s = 0; s < h->nf; s++) {
+      cstart[s + 1] = cstart[s] + (int)lists[s].size();
+      cedges.insert(cedges.end(), lists[s].begin(), lists[s].end());
+      mx = std::max(mx, (int)lists[s].size());
+    }
+    D.n_cchunks = std::max(1, (mx + kCamChunk - 1) / kCamChunk);
+  }
+  D.n_pblocks = std::max(1, (D.n_local + kPtsPerBlock - 1) / kPtsPerBlock);
+  const int K = 3 * h->n_pts;
+  const int tiles = (D.Mpad / 16) * (D.Mpad / 16);
+  int ks = std::max(1, std::min(64, 1024 / tiles));
+  ks = std::min(ks, std::max(1, K / 64));
+  D.kchunk = ((K + ks - 1) / ks + 3) / 4 * 4;
+  D.ksplit = std::max(1, (K + D.kchunk - 1) / D.kchunk);
+  VO_CHECK(upload(h->b_ecam, h->e_cam.data(), h->e_cam.size() * 4));
+  VO_CHECK(upload(h->b_ept, h->e_pt.data(), h->e_pt.size() * 4));
+  VO_CHECK(upload(h->b_eobs, h->e_obs.data(), h->e_obs.size() * 8));
+  VO_CHECK(upload(h->b_eis, h->e_is.data(), h->e_is.size() * 8));
+  VO_CHECK(h->b_eact.reserve(std::max<size_t>(h->n_edges, 64)));
+  VO_CHECK(h->b_out.reserve(std::max<size_t>(h->n_edges, 64)));
+  VO_CHECK(upload(h->b_ptstart, h->pt_start.data(), h->pt_start.size() * 4));
+  VO_CHECK(upload(h->b_local, local.data(), local.size() * 4));
+  VO_CHECK(upload(h->b_camslot, h->cam_slot.data(), h->cam_slot.size() * 4));
+  VO_CHECK(upload(h->b_slotcam, h->slot_cam.data(), h->slot_cam.size() * 4));
+  VO_CHECK(upload(h->b_camstart, cstart.data(), cstart.size() * 4));
+  VO_CHECK(upload(h->b_camedges, cedges.data(), cedges.size() * 4));
+  VO_CHECK(h->b_ptin.reserve(std::max<size_t>(h->n_pts, 64)));
+  VO_CHECK(h->b_camin.reserve(std::max<size_t>(h->n_cams, 64)));
+  VO_CHECK(upload(h->b_xc0, h->poses.data(), h->poses.size() * 8));
+  VO_CHECK(upload(h->b_xc1, h->poses.data(), h->poses.size() * 8));
+  VO_CHECK(upload(h->b_xp0, h->points.data(), h->points.size() * 8));
+  VO_CHECK(upload(h->b_xp1, h->points.data(), h->points.size() * 8));
+  VO_CHECK(h->b_sc.reserve((size_t)std::max(1, h->n_cams) * 6 * 8));
+  VO_CHECK(h->b_sp.reserve((size_t)std::max(1, h->n_pts) * 3 * 8));
+  VO_CHECK(h->b_hinv.reserve((size_t)std::max(1, h->n_pts) * 6 * 8));
+  VO_CHECK(h->b_gl2.reserve((size_t)std::max(1, h->n_pts) * 3 * 8));
+  VO_CHECK(h->b_dl.reserve((size_t)std::max(1, h->n_pts) * 3 * 8));
+  VO_CHECK(h->b_wt.reserve((size_t)std::max(1, K) * D.Mpad * 8));
+  VO_CHECK(h->b_yt.reserve((size_t)std::max(1, K) * D.Mpad * 8));
+  VO_CHECK(h->b_sgemm.reserve((size_t)D.ksplit * D.Mpad * D.Mpad * 8));
+  VO_CHECK(h->b_scam.reserve((size_t)std::max(1, h->nf) * D.n_cchunks * 27 * 8));
+  VO_CHECK(h->b_spt.reserve((size_t)D.n_pblocks * 2 * 8));
+  VO_CHECK(h->b_payload.reserve(((size_t)D.Mpad * D.Mpad + (size_t)h->nf * 27 + 1 + h->n_shards) * 8));
+  VO_CHECK(h->b_zc.reserve((size_t)std::max(1, 6 * h->nf) * 8));
+  VO_CHECK(h->b_sbs.reserve((size_t)D.n_pblocks * 6 * 8));
+  VO_CHECK(h->b_payload2.reserve(64));
+  VO_CHECK(h->b_state.reserve(sizeof(BaState)));
+  VO_HIP_CHECK(hipMemset(h->b_state.p, 0, sizeof(BaState)));
+  D.e_cam = h->b_ecam.as<int>(), D.e_pt = h->b_ept.as<int>();
+  D.e_obs = h->b_eobs.as<double>(), D.e_is = h->b_eis.as<double>();
+  D.e_active = h->b_eact.as<uint8_t>();
+  D.pt_start = h->b_ptstart.as<int>(), D.local_pts = h->b_local.as<int>();
+  D.cam_slot = h->b_camslot.as<int>(), D.slot_cam = h->b_slotcam.as<int>();
+  D.cam_start = h->b_camstart.as<int>(), D.cam_edges = h->b_camedges.as<int>();
+  D.pt_in = h->b_ptin.as<uint8_t>(), D.cam_in = h->b_camin.as<uint8_t>();
+  D.Xc[0] = h->b_xc0.as<double>(), D.Xc[1] = h->b_xc1.as<double>();
+  D.Xp[0] = h->b_xp0.as<double>(), D.Xp[1] = h->b_xp1.as<double>();
+  D.scale_c = h->b_sc.as<double>(), D.scale_p = h->b_sp.as<double>();
+  D.hinv = h->b_hinv.as<double>(), D.gl2 = h->b_gl2.as<double>(), D.dl = h->b_dl.as<double>();
+  D.Wt = h->b_wt.as<double>(), D.Yt = h->b_yt.as<double>();
+  D.slab_gemm = h->b_sgemm.as<double>(), D.slab_cam = h->b_scam.as<double>(), D.slab_pt = h->b_spt.as<double>();
+  D.payload = h->b_payload.as<double>(), D.zc = h->b_zc.as<double>();
+  D.slab_bs = h->b_sbs.as<double>(), D.payload2 = h->b_payload2.as<double>();
+  D.st = h->b_state.as<BaState>();
+  const int n = 6 * h->nf;
+  h->solve_lds = ((size_t)n * (n + 1) + 3 * n + 64 + n + 64) * 8;
+  if (h->solve_lds > 64 * 1024)
+    VO_HIP_CHECK(hipFuncSetAttribute((const void *)k_ba_solve, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                     (int)h->solve_lds));
+  h->built = true;
+  return VO_OK;
+}
+
+int lm_begin(vo_ba *h, double hm, double hs, int max_it, const uint8_t *active_caller, bool keep_device_mask) {
+  VO_CHECK(build_device(h));
+  BaDev &D = h->D;
+  D.hm = hm, D.hs = hs;
+  hipStream_t st = h->stream;
+  if (!keep_device_mask) {
+    std::vector<uint8_t> act(std::max(1, h->n_edges), 1);
+    if (active_caller)
+      for (int e = 0; e < h->n_edges; e++) act[e] = active_caller[h->perm[e]] ? 1 : 0;
+    VO_HIP_CHECK(hipMemcpyAsync(D.e_active, act.data(), h->n_edges, hipMemcpyHostToDevice, st));
+    VO_HIP_CHECK(hipStreamSynchronize(st));  // act is a stack-lifetime buffer
+  }
+  VO_HIP_CHECK(hipMemsetAsync(D.pt_in, 0, std::max(1, h->n_pts), st));
+  VO_HIP_CHECK(hipMemsetAsync(D.cam_in, 0, std::max(1, h->n_cams), st));
+  VO_HIP_CHECK(hipMemsetAsync(D.Wt, 0, (size_t)std::max(1, 3 * h->n_pts) * D.Mpad * 8, st));
+  VO_HIP_CHECK(hipMemsetAsync(D.Yt, 0, (size_t)std::max(1, 3 * h->n_pts) * D.Mpad * 8, st));
+  if (h->n_edges > 0)
+    hipLaunchKernelGGL(k_ba_mark, dim3((h->n_edges + 255) / 256), dim3(256), 0, st, D);
+  hipLaunchKernelGGL(k_ba_begin, dim3(1), dim3(1), 0, st, D, max_it);
+  VO_HIP_CHECK(hipGetLastError());
+  h->lm_max_it = max_it;
+  return VO_OK;
+}
+
+int launch_linearize(vo_ba *h) {
+  BaDev &D = h->D;
+  hipStream_t st = h->stream;
+  hipLaunchKernelGGL(k_ba_points, dim3(D.n_pblocks), dim3(256), 0, st, D);
+  if (h->nf > 0) hipLaunchKernelGGL(k_ba_cams, dim3(h->nf, D.n_cchunks), dim3(256), 0, st, D);
+  const int tiles = (D.Mpad / 16) * (D.Mpad / 16);
+  hipLaunchKernelGGL(k_ba_gemm, dim3(tiles, D.ksplit), dim3(64), 0, st, D);
+  const int np = D.Mpad * D.Mpad + h->nf * 27 + 1;
+  hipLaunchKernelGGL(k_ba_reduce, dim3((np + 255) / 256), dim3(256), 0, st, D);
+  VO_HIP_CHECK(hipGetLastError());
+  return VO_OK;
+}
+int launch_step(vo_ba *h) {
+  BaDev &D = h->D;
+  hipStream_t st = h->stream;
+  hipLaunchKernelGGL(k_ba_solve, dim3(1), dim3(256), h->solve_lds, st, D);
+  hipLaunchKernelGGL(k_ba_backsub, dim3(D.n_pblocks), dim3(256), 0, st, D);
+  hipLaunchKernelGGL(k_ba_reduce2, dim3(1), dim3(64), 0, st, D);
+  VO_HIP_CHECK(hipGetLastError());
+  return VO_OK;
+}
+int launch_update(vo_ba *h) {
+  hipLaunchKernelGGL(k_ba_update, dim3(1), dim3(1), 0, h->stream, h->D);
+  VO_HIP_CHECK(hipGetLastError());
+  return VO_OK;
+}
+
+int lm_end(vo_ba *h, vo_lm_summary *sum) {
+  VO_HIP_CHECK(hipStreamSynchronize(h->stream));
+  BaState s;
+  VO_HIP_CHECK(hipMemcpy(&s, h->D.st, sizeof(s), hipMemcpyDeviceToHost));
+  if (sum) {
+    sum->iterations = s.iter;
+    sum->accepted = s.accepted;
+    sum->termination = s.termination;
+    sum->reserved = 0;
+    sum->initial_cost = s.initial_cost;
+    sum->final_cost = s.x_cost;
+    sum->final_radius = s.radius;
+  }
+  return VO_OK;
+}
+
+int run_lm(vo_ba *h, int max_it) {
+  for (int it = 0; it < max_it; it++) {
+    VO_CHECK(launch_linearize(h));
+    VO_CHECK(launch_step(h));
+    VO_CHECK(launch_update(h));
+  }
+  return VO_OK;
+}
+
+int current_index(vo_ba *h, int *cur) {
+  BaState s;
+  VO_HIP_CHECK(hipStreamSynchronize(h->stream));
+  VO_HIP_CHECK(hipMemcpy(&s, h->D.st, sizeof(s), hipMemcpyDeviceToHost));
+  *cur = s.cur;
+  return VO_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int vo_pose_only_solve_dev(int n_problems, const int32_t *dev_offsets, int max_obs, const double *dev_points,
+                           const double *dev_obs, const double *dev_inv_sigma, const double *dev_cam5,
+                           double *dev_poses, uint8_t *dev_outlier, int32_t *dev_n_inliers,
+                           vo_lm_summary *dev_summaries, void *hip_stream) {
+  (void)max_obs;
+  if (n_problems < 0 || (n_problems > 0 && (!dev_offsets || !dev_poses || !dev_outlier || !dev_n_inliers || !dev_cam5)))
+    return VO_ERR_INVALID;
+  if (n_problems == 0) return VO_OK;
+  VO_CHECK(vo::ensure_device());
+  hipLaunchKernelGGL(k_pose_only, dim3(n_problems), dim3(256), 0, (hipStream_t)hip_stream, dev_offsets, dev_points,
+                     dev_obs, dev_inv_sigma, dev_cam5, dev_poses, dev_outlier, dev_n_inliers, dev_summaries);
+  VO_HIP_CHECK(hipGetLastError());
+  return VO_OK;
+}
+
+int vo_pose_only_solve(int n_problems, const int32_t *offsets, const double *points, const double *obs,
+                       const double *inv_sigma, const double cam[5], double *poses, uint8_t *outlier,
+                       int32_t *n_inliers, vo_lm_summary *summaries) {
+  if (n_problems < 0 || (n_problems > 0 && (!offsets || !poses || !n_inliers || !cam))) return VO_ERR_INVALID;
+  if (n_problems == 0) return VO_OK;
+  VO_CHECK(vo::ensure_device());
+  const int total = offsets[n_problems];
+  if (total > 0 && (!points || !obs || !inv_sigma || !outlier)) return VO_ERR_INVALID;
+  vo::DevBuf d_off, d_pts, d_obs, d_is, d_cam, d_pose, d_out, d_inl, d_sum;
+  int rc = VO_OK;
+  auto fail = [&](int r) {
+    for (vo::DevBuf *b : {&d_off, &d_pts, &d_obs, &d_is, &d_cam, &d_pose, &d_out, &d_inl, &d_sum}) b->release();
+    return r;
+  };
+  if ((rc = upload(d_off, offsets, (size_t)(n_problems + 1) * 4)) != VO_OK) return fail(rc);
+  if ((rc = upload(d_pts, points, (size_t)total * 24)) != VO_OK) return fail(rc);
+  if ((rc = upload(d_obs, obs, (size_t)total * 24)) != VO_OK) return fail(rc);
+  if ((rc = upload(d_is, inv_sigma, (size_t)total * 8)) != VO_OK) return fail(rc);
+  if ((rc = upload(d_cam, cam, 40)) != VO_OK) return fail(rc);
+  if ((rc = upload(d_pose, poses, (size_t)n_problems * 48)) != VO_OK) return fail(rc);
+  if ((rc = d_out.reserve(std::max(64, total))) != VO_OK) return fail(rc);
+  if ((rc = d_inl.reserve((size_t)n_problems * 4)) != VO_OK) return fail(rc);
+  if ((rc = d_sum.reserve((size_t)n_problems * 2 * sizeof(vo_lm_summary))) != VO_OK) return fail(rc);
+  (void)hipMemset(d_sum.p, 0, (size_t)n_problems * 2 * sizeof(vo_lm_summary));
+  rc = vo_pose_only_solve_dev(n_problems, d_off.as<int32_t>(), 0, d_pts.as<double>(), d_obs.as<double>(),
+                              d_is.as<double>(), d_cam.as<double>(), d_pose.as<double>(), d_out.as<uint8_t>(),
+                              d_inl.as<int32_t>(), d_sum.as<vo_lm_summary>(), nullptr);
+  if (rc != VO_OK) return fail(rc);
+  if (hipDeviceSynchronize() != hipSuccess) {
+    vo::set_error("pose-only kernel failed: %s", hipGetErrorString(hipGetLastError()));
+    return fail(VO_ERR_HIP);
+  }
+  (void)hipMemcpy(poses, d_pose.p, (size_t)n_problems * 48, hipMemcpyDeviceToHost);
+  if (total > 0) (void)hipMemcpy(outlier, d_out.p, total, hipMemcpyDeviceToHost);
+  (void)hipMemcpy(n_inliers, d_inl.p, (size_t)n_problems * 4, hipMemcpyDeviceToHost);
+  if (summaries)
+    (void)hipMemcpy(summaries, d_sum.p, (size_t)n_problems * 2 * sizeof(vo_lm_summary), hipMemcpyDeviceToHost);
+  return fail(VO_OK);
+}
+
+int vo_ba_create(vo_ba **out, int n_cams, const double *poses, const uint8_t *cam_fixed, int n_points,
+                 const double *points, int n_edges, const int32_t *edge_cam, const int32_t *edge_point,
+                 const double *edge_obs, const double *edge_inv_sigma, const double cam[5]) {
+  if (!out || n_cams < 1 || n_points < 0 || n_edges < 0 || !poses || !cam_fixed || !cam ||
+      (n_points > 0 && !points) || (n_edges > 0 && (!edge_cam || !edge_point || !edge_obs || !edge_inv_sigma))) {
+    vo::set_error("vo_ba_create: invalid argument");
+    return VO_ERR_INVALID;
+  }
+  for (int e = 0; e < n_edges; e++)
+    if (edge_cam[e] < 0 || edge_cam[e] >= n_cams || edge_point[e] < 0 || edge_point[e] >= n_points) {
+      vo::set_error("vo_ba_create: edge %d references camera %d / point %d out of range", e, edge_cam[e],
+                    edge_point[e]);
+      return VO_ERR_INVALID;
+    }
+  VO_CHECK(vo::ensure_device());
+  vo_ba *h = new vo_ba();
+  h->n_cams = n_cams, h->n_pts = n_points, h->n_edges = n_edges;
+  h->poses.assign(poses, poses + 6 * (size_t)n_cams);
+  h->points.assign(points, points + 3 * (size_t)n_points);
+  h->cam_fixed.assign(cam_fixed, cam_fixed + n_cams);
+  memcpy(h->cam, cam, sizeof(h->cam));
+  // stable grouping of the edges by point (the order Ceres' Schur eliminator walks its chunks)
+  h->perm.resize(n_edges);
+  std::iota(h->perm.begin(), h->perm.end(), 0);
+  std::stable_sort(h->perm.begin(), h->perm.end(), [&](int a, int b) { return edge_point[a] < edge_point[b]; });
+  h->e_cam.resize(n_edges), h->e_pt.resize(n_edges), h->e_obs.resize(3 * (size_t)n_edges), h->e_is.resize(n_edges);
+  h->pt_start.assign(n_points + 1, 0);
+  for (int s = 0; s < n_edges; s++) {
+    const int e = h->perm[s];
+    h->e_cam[s] = edge_cam[e], h->e_pt[s] = edge_point[e], h->e_is[s] = edge_inv_sigma[e];
+    for (int k = 0; k < 3; k++) h->e_obs[3 * (size_t)s + k] = edge_obs[3 * (size_t)e + k];
+    h->pt_start[edge_point[e] + 1]++;
+  }
+  for (int j = 0; j < n_points; j++) h->pt_start[j + 1] += h->pt_start[j];
+  h->cam_slot.assign(n_cams, -1);
+  for (int c = 0; c < n_cams; c++)
+    if (!cam_fixed[c]) {
+      h->cam_slot[c] = h->nf++;
+      h->slot_cam.push_back(c);
+    }
+  if (hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking) != hipSuccess) {
+    delete h;
+    vo::set_error("hipStreamCreate failed");
+    return VO_ERR_HIP;
+  }
+  h->own_stream = true;
+  *out = h;
+  return VO_OK;
+}
+
+void vo_ba_destroy(vo_ba *h) {
+  if (!h) return;
+  (void)hipStreamSynchronize(h->stream);
+  for (vo::DevBuf *b : {&h->b_ecam, &h->b_ept, &h->b_eobs, &h->b_eis, &h->b_eact, &h->b_ptstart, &h->b_local,
+                        &h->b_camslot, &h->b_slotcam, &h->b_camstart, &h->b_camedges, &h->b_ptin, &h->b_camin,
+                        &h->b_xc0, &h->b_xc1, &h->b_xp0, &h->b_xp1, &h->b_sc, &h->b_sp, &h->b_hinv, &h->b_gl2,
+                        &h->b_dl, &h->b_wt, &h->b_yt, &h->b_sgemm, &h->b_scam, &h->b_spt, &h->b_payload, &h->b_zc,
+                        &h->b_sbs, &h->b_payload2, &h->b_state, &h->b_out})
+    b->release();
+  if (h->own_stream) (void)hipStreamDestroy(h->stream);
+  delete h;
+}
+
+int vo_ba_set_stream(vo_ba *h, void *s) {
+  if (!h) return VO_ERR_INVALID;
+  (void)hipStreamSynchronize(h->stream);
+  if (h->own_stream) (void)hipStreamDestroy(h->stream);
+  h->own_stream = false;
+  h->stream = (hipStream_t)s;
+  return VO_OK;
+}
+
+int vo_ba_set_shard(vo_ba *h, int shard, int n_shards) {
+  if (!h || n_shards < 1 || shard < 0 || shard >= n_shards || h->built) {
+    vo::set_error("vo_ba_set_shard: invalid argument or called after the first solve");
+    return VO_ERR_INVALID;
+  }
+  h->shard = shard, h->n_shards = n_shards;
+  return VO_OK;
+}
+
+int vo_ba_n_free_cams(const vo_ba *h) { return h ? h->nf : 0; }
+
+int vo_ba_set_state(vo_ba *h, const double *poses, const double *points) {
+  if (!h) return VO_ERR_INVALID;
+  VO_CHECK(build_device(h));
+  int cur;
+  VO_CHECK(current_index(h, &cur));
+  if (poses) VO_HIP_CHECK(hipMemcpy(h->D.Xc[cur], poses, (size_t)h->n_cams * 48, hipMemcpyHostToDevice));
+  if (points && h->n_pts) VO_HIP_CHECK(hipMemcpy(h->D.Xp[cur], points, (size_t)h->n_pts * 24, hipMemcpyHostToDevice));
+  return VO_OK;
+}
+
+int vo_ba_get_state(vo_ba *h, double *poses, double *points) {
+  if (!h) return VO_ERR_INVALID;
+  VO_CHECK(build_device(h));
+  int cur;
+  VO_CHECK(current_index(h, &cur));
+  if (poses) VO_HIP_CHECK(hipMemcpy(poses, h->D.Xc[cur], (size_t)h->n_cams * 48, hipMemcpyDeviceToHost));
+  if (points && h->n_pts) VO_HIP_CHECK(hipMemcpy(points, h->D.Xp[cur], (size_t)h->n_pts * 24, hipMemcpyDeviceToHost));
+  return VO_OK;
+}
+
+int vo_ba_lm_begin(vo_ba *h, double hm, double hs, int max_it, const uint8_t *edge_active) {
+  if (!h || max_it < 0) return VO_ERR_INVALID;
+  return lm_begin(h, hm, hs, max_it, edge_active, false);
+}
+int vo_ba_linearize(vo_ba *h) { return h && h->built ? launch_linearize(h) : VO_ERR_INVALID; }
+int vo_ba_step(vo_ba *h) { return h && h->built ? launch_step(h) : VO_ERR_INVALID; }
+int vo_ba_update(vo_ba *h) { return h && h->built ? launch_update(h) : VO_ERR_INVALID; }
+int vo_ba_lm_end(vo_ba *h, vo_lm_summary *s) { return h && h->built ? lm_end(h, s) : VO_ERR_INVALID; }
+
+int vo_ba_reduced_system(vo_ba *h, double **p, size_t *n) {
+  if (!h || !p || !n) return VO_ERR_INVALID;
+  VO_CHECK(build_device(h));
+  *p = h->D.payload;
+  *n = (size_t)h->D.Mpad * h->D.Mpad + (size_t)h->nf * 27 + 1 + h->n_shards;
+  return VO_OK;
+}
+int vo_ba_reduced_cost(vo_ba *h, double **p, size_t *n) {
+  if (!h || !p || !n) return VO_ERR_INVALID;
+  VO_CHECK(build_device(h));
+  *p = h->D.payload2;
+  *n = 6;
+  return VO_OK;
+}
+
+int vo_ba_solve(vo_ba *h, double hm, double hs, int max_it, const uint8_t *edge_active, vo_lm_summary *sum) {
+  if (!h || max_it < 0) return VO_ERR_INVALID;
+  VO_CHECK(lm_begin(h, hm, hs, max_it, edge_active, false));
+  VO_CHECK(run_lm(h, max_it));
+  return lm_end(h, sum);
+}
+
+int vo_ba_local_ba(vo_ba *h, const volatile int *stop, uint8_t *edge_erase, vo_lm_summary *sums) {
+  if (!h || !edge_erase) return VO_ERR_INVALID;
+  for (int e = 0; e < h->n_edges; e++) edge_erase[e] = 0;
+  if (stop && *stop) return VO_ERR_STOPPED;  // :594-595 (no write-back, Q-B8)
+  VO_CHECK(lm_begin(h, (double)sqrtf(5.991f), (double)sqrtf(7.815f), 5, nullptr, false));
+  VO_CHECK(run_lm(h, 5));
+  VO_CHECK(lm_end(h, sums ? &sums[0] : nullptr));
+  uint8_t *out = h->b_out.as<uint8_t>();
+  VO_HIP_CHECK(hipMemsetAsync(out, 0, std::max(1, h->n_edges), h->stream));
+  const dim3 eg((std::max(1, h->n_edges) + 255) / 256);
+  if (!(stop && *stop)) {  // :612
+    hipLaunchKernelGGL(k_ba_classify, eg, dim3(256), 0, h->stream, h->D, 0, out);
+    VO_CHECK(lm_begin(h, 0.0, 0.0, 10, nullptr, true));
+    VO_CHECK(run_lm(h, 10));
+    VO_CHECK(lm_end(h, sums ? &sums[1] : nullptr));
+  } else if (sums) {
+    memset(&sums[1], 0, sizeof(vo_lm_summary));
+  }
+  hipLaunchKernelGGL(k_ba_classify, eg, dim3(256), 0, h->stream, h->D, 1, out);
+  VO_HIP_CHECK(hipGetLastError());
+  std::vector<uint8_t> tmp(std::max(1, h->n_edges));
+  VO_HIP_CHECK(hipMemcpyAsync(tmp.data(), out, h->n_edges, hipMemcpyDeviceToHost, h->stream));
+  VO_HIP_CHECK(hipStreamSynchronize(h->stream));
+  for (int s = 0; s < h->n_edges; s++) edge_erase[h->perm[s]] = tmp[s];
+  return VO_OK;
+}
+
+int vo_ba_debug_schur(vo_ba *h, double hm, double hs, double point_damping, const uint8_t *edge_active, double *S,
+                      double *b, double *cost) {
+  // undamped reduced system: run the linearisation kernels with a huge radius (D -> clamp/1e300 ~ 0)
+  // and no Jacobi scaling effect removed on the host.
+  if (!h || !S || !b || !cost) return VO_ERR_INVALID;
+  (void)point_damping;
+  VO_CHECK(lm_begin(h, hm, hs, 1, edge_active, false));
+  BaState s;
+  VO_HIP_CHECK(hipStreamSynchronize(h->stream));
+  VO_HIP_CHECK(hipMemcpy(&s, h->D.st, sizeof(s), hipMemcpyDeviceToHost));
+  s.radius = 1e300;
+  VO_HIP_CHECK(hipMemcpy(h->D.st, &s, sizeof(s), hipMemcpyHostToDevice));
+  VO_CHECK(launch_linearize(h));
+  VO_HIP_CHECK(hipStreamSynchronize(h->stream));
+  const int n = 6 * h->nf, M = h->D.Mpad;
+  std::vector<double> pay((size_t)M * M + (size_t)h->nf * 27 + 1 + h->n_shards);
+  VO_HIP_CHECK(hipMemcpy(pay.data(), h->D.payload, pay.size() * 8, hipMemcpyDeviceToHost));
+  const double *HP = pay.data() + (size_t)M * M;
+  for (int r = 0; r < n; r++) {
+    for (int c = 0; c < n; c++) {
+      double v = -pay[(size_t)r * M + c];
+      if (r / 6 == c / 6) {
+        const int slot = r / 6, a = std::min(r % 6, c % 6), bb = std::max(r % 6, c % 6);
+        int t = 0;
+        for (int q = 0; q < a; q++) t += 6 - q;
+        v += HP[slot * 27 + t + (bb - a)];
+      }
+      S[(size_t)r * n + c] = v;
+    }
+    b[r] = HP[(r / 6) * 27 + 21 + r % 6] - pay[(size_t)r * M + n];
+  }
+  *cost = pay[(size_t)M * M + (size_t)h->nf * 27];
+  return VO_OK;
+}
+
+int vo_se3_exp(const double xi[6], double R[9], double t[3]) {
+  if (!xi || !R || !t) return VO_ERR_INVALID;
+  const Se3 T = se3_exp(xi);
+  const double *q = T.q;
+  const double tx = 2 * q[1], ty = 2 * q[2], tz = 2 * q[3];
+  const double twx = tx * q[0], twy = ty * q[0], twz = tz * q[0];
+  const double txx = tx * q[1], txy = ty * q[1], txz = tz * q[1];
+  const double tyy = ty * q[2], tyz = tz * q[2], tzz = tz * q[3];
+  R[0] = 1 - (tyy + tzz), R[1] = txy - twz, R[2] = txz + twy;
+  R[3] = txy + twz, R[4] = 1 - (txx + tzz), R[5] = tyz - twx;
+  R[6] = txz - twy, R[7] = tyz + twx, R[8] = 1 - (txx + tyy);
+  t[0] = T.t[0], t[1] = T.t[1], t[2] = T.t[2];
+  return VO_OK;
+}
+
+int vo_se3_log(const double R[9], const double t[3], double xi[6]) {
+  if (!xi || !R || !t) return VO_ERR_INVALID;
+  // rotation matrix -> unit quaternion (Eigen's Quaternion(Matrix3) branch structure)
+  Se3 T;
+  const double tr = R[0] + R[4] + R[8];
+  if (tr > 0) {
+    double s = sqrt(tr + 1.0);
+    T.q[0] = 0.5 * s;
+    s = 0.5 / s;
+    T.q[1] = (R[7] - R[5]) * s, T.q[2] = (R[2] - R[6]) * s, T.q[3] = (R[3] - R[1]) * s;
+  } else {
+    int i = 0;
+    if (R[4] > R[0]) i = 1;
+    if (R[8] > R[i * 4]) i = 2;
+    const int j = (i + 1) % 3, k = (j + 1) % 3;
+    double s = sqrt(R[i * 4] - R[j * 4] - R[k * 4] + 1.0);
+    double q[4];
+    q[1 + i] = 0.5 * s;
+    s = 0.5 / s;
+    q[0] = (R[k * 3 + j] - R[j * 3 + k]) * s;
+    q[1 + j] = (R[j * 3 + i] + R[i * 3 + j]) * s;
+    q[1 + k] = (R[k * 3 + i] + R[i * 3 + k]) * s;
+    for (int a = 0; a < 4; a++) T.q[a] = q[a];
+  }
+  quat_normalize(T.q);
+  T.t[0] = t[0], T.t[1] = t[1], T.t[2] = t[2];
+  se3_log(T, xi);
+  return VO_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,241 @@
+// ba_math.h -- FP64 device/host math for the optimizer kernels: Sophus-style SE3 exp/log/compose,
+// the reference's se3TransPoint and reprojection residual/Jacobians, Huber weights.
+// Reference: include/myslam/optimizer_ceres.h:29-95, src/optimizer_ceres.cpp:44-154, 320-444.
+#pragma once
+#include <hip/hip_runtime.h>
+
+namespace vo {
+namespace ba {
+
+#define VO_HD __host__ __device__ __forceinline__
+
+constexpr double kSmallEps = 1e-10;          // Sophus SMALL_EPS
+constexpr double kDblEps = 2.2204460492503131e-16;
+
+struct Se3 {  // unit quaternion (w,x,y,z) + translation, like Sophus::SE3
+  double q[4];
+  double t[3];
+};
+
+VO_HD void quat_normalize(double q[4]) {
+  const double n = sqrt(q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3]);
+  q[0] /= n, q[1] /= n, q[2] /= n, q[3] /= n;
+}
+
+VO_HD void quat_rotate(const double q[4], const double v[3], double o[3]) {
+  double uv0 = q[2] * v[2] - q[3] * v[1], uv1 = q[3] * v[0] - q[1] * v[2], uv2 = q[1] * v[1] - q[2] * v[0];
+  uv0 += uv0, uv1 += uv1, uv2 += uv2;
+  o[0] = v[0] + q[0] * uv0 + (q[2] * uv2 - q[3] * uv1);
+  o[1] = v[1] + q[0] * uv1 + (q[3] * uv0 - q[1] * uv2);
+  o[2] = v[2] + q[0] * uv2 + (q[1] * uv1 - q[2] * uv0);
+}
+
+// Sophus SE3::exp: tangent [upsilon; omega]
+VO_HD Se3 se3_exp(const double xi[6]) {
+  Se3 T;
+  const double wx = xi[3], wy = xi[4], wz = xi[5];
+  const double theta = sqrt(wx * wx + wy * wy + wz * wz);
+  const double half = 0.5 * theta;
+  double imag;
+  if (theta < kSmallEps) {
+    const double t2 = theta * theta;
+    imag = 0.5 - 0.0208333 * t2 + 0.000260417 * t2 * t2;
+  } else {
+    imag = sin(half) / theta;
+  }
+  T.q[0] = cos(half), T.q[1] = imag * wx, T.q[2] = imag * wy, T.q[3] = imag * wz;
+  quat_normalize(T.q);
+  // V = I + a*Om + b*Om^2 ;  V*u = u + a (w x u) + b (w x (w x u))
+  const double u[3] = {xi[0], xi[1], xi[2]};
+  const double wxu[3] = {wy * u[2] - wz * u[1], wz * u[0] - wx * u[2], wx * u[1] - wy * u[0]};
+  const double wwxu[3] = {wy * wxu[2] - wz * wxu[1], wz * wxu[0] - wx * wxu[2], wx * wxu[1] - wy * wxu[0]};
+  if (theta < kSmallEps) {
+    quat_rotate(T.q, u, T.t);  // V = R in the small-angle branch
+  } else {
+    const double t2 = theta * theta;
+    const double a = (1 - cos(theta)) / t2, b = (theta - sin(theta)) / (t2 * theta);
+    T.t[0] = u[0] + a * wxu[0] + b * wwxu[0];
+    T.t[1] = u[1] + a * wxu[1] + b * wwxu[1];
+    T.t[2] = u[2] + a * wxu[2] + b * wwxu[2];
+  }
+  return T;
+}
+
+// Sophus SE3::log
+VO_HD void se3_log(const Se3 &T, double xi[6]) {
+  const double n = sqrt(T.q[1] * T.q[1] + T.q[2] * T.q[2] + T.q[3] * T.q[3]);
+  const double w = T.q[0];
+  double f;
+  if (n < kSmallEps)
+    f = 2. / w - 2. * (n * n) / (w * w * w);
+  else
+    f = 2 * atan(n / w) / n;
+  const double theta = f * n;
+  const double wx = f * T.q[1], wy = f * T.q[2], wz = f * T.q[3];
+  const double c = (theta < kSmallEps) ? (1. / 12.) : (1 - theta / (2 * tan(theta / 2))) / (theta * theta);
+  const double *t = T.t;
+  const double wxt[3] = {wy * t[2] - wz * t[1], wz * t[0] - wx * t[2], wx * t[1] - wy * t[0]};
+  const double wwxt[3] = {wy * wxt[2] - wz * wxt[1], wz * wxt[0] - wx * wxt[2], wx * wxt[1] - wy * wxt[0]};
+  xi[0] = t[0] - 0.5 * wxt[0] + c * wwxt[0];
+  xi[1] = t[1] - 0.5 * wxt[1] + c * wwxt[1];
+  xi[2] = t[2] - 0.5 * wxt[2] + c * wwxt[2];
+  xi[3] = wx, xi[4] = wy, xi[5] = wz;
+}
+
+// PoseLocalParameterization::Plus (optimizer_ceres.cpp:44-53): log(exp(delta) * exp(x))
+VO_HD void se3_plus(const double x[6], const double d[6], double out[6]) {
+  const Se3 A = se3_exp(d), B = se3_exp(x);
+  Se3 Cc;
+  double rt[3];
+  quat_rotate(A.q, B.t, rt);
+  Cc.t[0] = A.t[0] + rt[0], Cc.t[1] = A.t[1] + rt[1], Cc.t[2] = A.t[2] + rt[2];
+  Cc.q[0] = A.q[0] * B.q[0] - A.q[1] * B.q[1] - A.q[2] * B.q[2] - A.q[3] * B.q[3];
+  Cc.q[1] = A.q[0] * B.q[1] + A.q[1] * B.q[0] + A.q[2] * B.q[3] - A.q[3] * B.q[2];
+  Cc.q[2] = A.q[0] * B.q[2] + A.q[2] * B.q[0] + A.q[3] * B.q[1] - A.q[1] * B.q[3];
+  Cc.q[3] = A.q[0] * B.q[3] + A.q[3] * B.q[0] + A.q[1] * B.q[2] - A.q[2] * B.q[1];
+  quat_normalize(Cc.q);
+  se3_log(Cc, out);
+}
+
+// Optimizer::se3TransPoint<double> (optimizer_ceres.h:29-95) plus the rotation matrix of
+// ceres::AngleAxisToRotationMatrix (same theta^2 > eps branch), R row-major here.
+struct PoseCache {
+  double R[9];  // row-major rotation
+  double t[3];  // V * upsilon
+};
+
+VO_HD PoseCache pose_cache(const double se3[6]) {
+  PoseCache P;
+  const double a0 = se3[3], a1 = se3[4], a2 = se3[5];
+  const double u0 = se3[0], u1 = se3[1], u2 = se3[2];
+  const double theta2 = a0 * a0 + a1 * a1 + a2 * a2;
+  if (theta2 > kDblEps) {
+    const double theta = sqrt(theta2);
+    const double c = cos(theta), s = sin(theta);
+    const double wx = a0 / theta, wy = a1 / theta, wz = a2 / theta;
+    P.R[0] = c + wx * wx * (1.0 - c);
+    P.R[3] = wz * s + wx * wy * (1.0 - c);
+    P.R[6] = -wy * s + wx * wz * (1.0 - c);
+    P.R[1] = wx * wy * (1.0 - c) - wz * s;
+    P.R[4] = c + wy * wy * (1.0 - c);
+    P.R[7] = wx * s + wy * wz * (1.0 - c);
+    P.R[2] = wy * s + wx * wz * (1.0 - c);
+    P.R[5] = -wx * s + wy * wz * (1.0 - c);
+    P.R[8] = c + wz * wz * (1.0 - c);
+    const double wxu0 = wy * u2 - wz * u1, wxu1 = wz * u0 - wx * u2, wxu2 = wx * u1 - wy * u0;
+    const double ww0 = wy * wxu2 - wz * wxu1, ww1 = wz * wxu0 - wx * wxu2, ww2 = wx * wxu1 - wy * wxu0;
+    const double A = (1.0 - c) / theta, B = (theta - s) / theta;
+    P.t[0] = u0 + A * wxu0 + B * ww0;
+    P.t[1] = u1 + A * wxu1 + B * ww1;
+    P.t[2] = u2 + A * wxu2 + B * ww2;
+  } else {
+    P.R[0] = 1, P.R[1] = -a2, P.R[2] = a1;
+    P.R[3] = a2, P.R[4] = 1, P.R[5] = -a0;
+    P.R[6] = -a1, P.R[7] = a0, P.R[8] = 1;
+    P.t[0] = u0 + (a1 * u2 - a2 * u1);
+    P.t[1] = u1 + (a2 * u0 - a0 * u2);
+    P.t[2] = u2 + (a0 * u1 - a1 * u0);
+  }
+  return P;
+}
+
+VO_HD void trans_point(const PoseCache &P, const double p[3], double o[3]) {
+  o[0] = P.R[0] * p[0] + P.R[1] * p[1] + P.R[2] * p[2] + P.t[0];
+  o[1] = P.R[3] * p[0] + P.R[4] * p[1] + P.R[5] * p[2] + P.t[1];
+  o[2] = P.R[6] * p[0] + P.R[7] * p[1] + P.R[8] * p[2] + P.t[2];
+}
+
+struct Cam {
+  double fx, fy, cx, cy, bf;
+};
+
+// residual (with inv_sigma) and the reference's Jacobians (without it: Q-B1).
+// rows: 2 mono (uR < 0) / 3 stereo.  Jp row-major rows x 6, Jl rows x 3.
+template <bool WANT_JP, bool WANT_JL>
+VO_HD int edge_eval(const PoseCache &P, const double pt[3], double ou, double ov, double our, double inv_sigma,
+                    const Cam &K, double r[3], double *Jp, double *Jl) {
+  double pc[3];
+  trans_point(P, pt, pc);
+  const double x = pc[0], y = pc[1], z = pc[2];
+  const double invz = 1.0 / z, invz2 = invz * invz;
+  const bool stereo = !(our < 0);
+  const double uhat = K.fx * x * invz + K.cx;
+  r[0] = (ou - uhat) * inv_sigma;
+  r[1] = (ov - (K.fy * y * invz + K.cy)) * inv_sigma;
+  r[2] = stereo ? (our - (uhat - K.bf * invz)) * inv_sigma : 0.0;
+  if (WANT_JP) {
+    Jp[0] = -invz * K.fx, Jp[1] = 0, Jp[2] = x * invz2 * K.fx;
+    Jp[3] = x * y * invz2 * K.fx, Jp[4] = -(1 + (x * x * invz2)) * K.fx, Jp[5] = y * invz * K.fx;
+    Jp[6] = 0, Jp[7] = -invz * K.fy, Jp[8] = y * invz2 * K.fy;
+    Jp[9] = (1 + y * y * invz2) * K.fy, Jp[10] = -x * y * invz2 * K.fy, Jp[11] = -x * invz * K.fy;
+    if (stereo) {
+      Jp[12] = Jp[0], Jp[13] = 0, Jp[14] = Jp[2] - K.bf * invz2;
+      Jp[15] = Jp[3] - K.bf * y * invz2, Jp[16] = Jp[4] + K.bf * x * invz2, Jp[17] = Jp[5];
+    } else {
+      Jp[12] = Jp[13] = Jp[14] = Jp[15] = Jp[16] = Jp[17] = 0;
+    }
+  }
+  if (WANT_JL) {
+    // column-major R of the reference indexed R[0],R[3],R[6] = first ROW of the rotation
+    Jl[0] = -K.fx * P.R[0] * invz + K.fx * x * P.R[6] * invz2;
+    Jl[1] = -K.fx * P.R[1] * invz + K.fx * x * P.R[7] * invz2;
+    Jl[2] = -K.fx * P.R[2] * invz + K.fx * x * P.R[8] * invz2;
+    Jl[3] = -K.fy * P.R[3] * invz + K.fy * y * P.R[6] * invz2;
+    Jl[4] = -K.fy * P.R[4] * invz + K.fy * y * P.R[7] * invz2;
+    Jl[5] = -K.fy * P.R[5] * invz + K.fy * y * P.R[8] * invz2;
+    if (stereo) {
+      Jl[6] = Jl[0] - K.bf * P.R[6] * invz2;
+      Jl[7] = Jl[1] - K.bf * P.R[7] * invz2;
+      Jl[8] = Jl[2] - K.bf * P.R[8] * invz2;
+    } else {
+      Jl[6] = Jl[7] = Jl[8] = 0;
+    }
+  }
+  return stereo ? 3 : 2;
+}
+
+// ceres::HuberLoss: rho(s) and rho'(s); a <= 0 disables the loss.  Corrector: rho'' <= 0 for Huber,
+// so residual and Jacobian are scaled by sqrt(rho') only.
+VO_HD void huber(double a, double s, double &rho0, double &rho1) {
+  const double b = a * a;
+  if (a > 0 && s > b) {
+    const double r = sqrt(s);
+    rho0 = 2 * a * r - b;
+    rho1 = a / r;
+    if (rho1 < 2.2250738585072014e-308) rho1 = 2.2250738585072014e-308;
+  } else {
+    rho0 = s;
+    rho1 = 1;
+  }
+}
+
+// 3x3 SPD inverse from the packed upper triangle h = {00,01,02,11,12,22}; returns packed inverse.
+VO_HD bool inv3_sym(const double h[6], double o[6]) {
+  // Cholesky h = L L^T
+  const double l00 = sqrt(h[0]);
+  if (!(h[0] > 0)) return false;
+  const double l10 = h[1] / l00, l20 = h[2] / l00;
+  const double d1 = h[3] - l10 * l10;
+  if (!(d1 > 0)) return false;
+  const double l11 = sqrt(d1);
+  const double l21 = (h[4] - l20 * l10) / l11;
+  const double d2 = h[5] - l20 * l20 - l21 * l21;
+  if (!(d2 > 0)) return false;
+  const double l22 = sqrt(d2);
+  // inverse of L (lower)
+  const double i00 = 1.0 / l00, i11 = 1.0 / l11, i22 = 1.0 / l22;
+  const double i10 = -l10 * i00 * i11;
+  const double i21 = -l21 * i11 * i22;
+  const double i20 = -(l20 * i00 + l21 * i10) * i22;
+  // H^-1 = L^-T L^-1
+  o[0] = i00 * i00 + i10 * i10 + i20 * i20;
+  o[1] = i10 * i11 + i20 * i21;
+  o[2] = i20 * i22;
+  o[3] = i11 * i11 + i21 * i21;
+  o[4] = i21 * i22;
+  o[5] = i22 * i22;
+  return true;
+}
+
+}  // namespace ba
+}  // namespace vo
