@@ -98,6 +98,15 @@ int vo_orb_get_candidates(vo_orb *h, int frame, int level, float *x, float *y, f
 /* per-level key-point counts of one frame of the last call */
 int vo_orb_get_level_counts(vo_orb *h, int frame, int32_t *counts /*nlevels*/);
 
+/* Per-stage timing with HIP events recorded on the handle's stream around each stage of every
+ * subsequent call (bench.py's live roofline measurement).  Stages: 0 pyramid (all resize launches),
+ * 1 FAST cells, 2 oct-tree, 3 offsets, 4 blur, 5 orientation+descriptor.  vo_orb_get_timing
+ * synchronises, adds the elapsed times of the calls since the last reset to ms[VO_ORB_STAGES],
+ * returns the number of timed calls in *n_calls and resets the accumulators. */
+#define VO_ORB_STAGES 6
+int vo_orb_set_timing(vo_orb *h, int enabled);
+int vo_orb_get_timing(vo_orb *h, double *ms /*VO_ORB_STAGES*/, int *n_calls);
+
 /* ------------------------------------------------------------------------------------------
  * Matcher  --  replaces the arithmetic of myslam::Matcher (include/myslam/matcher.h:9-45,
  * src/matcher.cpp).  The pointer-graph gather/scatter stays in the C++ shim.
@@ -223,9 +232,22 @@ int vo_ba_linearize(vo_ba *h);
 int vo_ba_step(vo_ba *h);
 int vo_ba_update(vo_ba *h);
 int vo_ba_lm_end(vo_ba *h, vo_lm_summary *summary);
+/* let the caller own the two all-reduce payload buffers (e.g. torch tensors handed to
+ * torch.distributed); sizes as reported by vo_ba_reduced_system / vo_ba_reduced_cost.
+ * Must precede vo_ba_lm_begin. */
+int vo_ba_set_reduce_buffers(vo_ba *h, double *dev_system, double *dev_cost);
 /* device pointers + element counts of the two all-reduce payloads */
 int vo_ba_reduced_system(vo_ba *h, double **dev_ptr, size_t *n_doubles);
 int vo_ba_reduced_cost(vo_ba *h, double **dev_ptr, size_t *n_doubles);
+/* pieces of the local-BA schedule for drivers that run the LM loop themselves (multi-GPU):
+ *   vo_ba_classify(h, 0)  float chi2 test of optimizer_ceres.cpp:618-689 on the current state; the
+ *                         device-side edge mask becomes "inlier", outliers are remembered
+ *   vo_ba_lm_begin_inliers  like vo_ba_lm_begin but keeps that device-side mask (problem 2, :691-699)
+ *   vo_ba_classify(h, 1)  final pass :703-755 (adds to the remembered outliers)
+ *   vo_ba_get_edge_outliers  the remembered mask in the caller's edge order (edgeErase) */
+int vo_ba_classify(vo_ba *h, int final_pass);
+int vo_ba_lm_begin_inliers(vo_ba *h, double huber_mono, double huber_stereo, int max_iterations);
+int vo_ba_get_edge_outliers(vo_ba *h, uint8_t *edge_erase);
 /* copy out the undamped reduced camera system of the current linearisation (tests):
  * S [6nf*6nf], b [6nf], cost.  point_damping is added to every point-block diagonal. */
 int vo_ba_debug_schur(vo_ba *h, double huber_mono, double huber_stereo, double point_damping,

@@ -112,3 +112,27 @@ def test_batch_device_matches_single(ext, orc):
         got = np.frombuffer(kps[f, :n].cpu().numpy().tobytes(), dtype=_lib.KP_DTYPE)
         assert np.array_equal(got, okp)
         assert np.array_equal(desc[f, :n].cpu().numpy(), odesc)
+
+
+def test_batch_device_unaligned_rows(ext, orc):
+    """row stride 641 (not a multiple of 4): level-0 blur takes the generic LDS kernel"""
+    import torch
+    from vo_slam_test_amd import _lib
+    frames = synth.make_frames(2, start=40)
+    buf = torch.zeros((2, 480, 641), dtype=torch.uint8, device="cuda")
+    buf[:, :, :640] = torch.from_numpy(frames).cuda()
+    view = buf[:, :, :640]
+    cap = ext.max_keypoints()
+    kps = torch.zeros((2, cap, 28), dtype=torch.uint8, device="cuda")
+    desc = torch.zeros((2, cap, 32), dtype=torch.uint8, device="cuda")
+    cnt = torch.zeros(2, dtype=torch.int32, device="cuda")
+    torch.cuda.synchronize()
+    ext.extract_batch_dev(view, kps, desc, cnt)
+    ext.sync()
+    p = orc.orb_params()
+    for f in range(2):
+        okp, odesc, _ = orc.extract(p, frames[f])
+        n = int(cnt[f])
+        assert n == len(okp)
+        assert np.array_equal(np.frombuffer(kps[f, :n].cpu().numpy().tobytes(), dtype=_lib.KP_DTYPE), okp)
+        assert np.array_equal(desc[f, :n].cpu().numpy(), odesc)

@@ -38,14 +38,15 @@ SYMBOLS = [
     "vo_orb_create", "vo_orb_destroy", "vo_orb_set_stream", "vo_orb_levels", "vo_orb_scale_factor",
     "vo_orb_scale_factors", "vo_orb_features_per_level", "vo_orb_max_keypoints", "vo_orb_extract",
     "vo_orb_extract_batch_dev", "vo_orb_sync", "vo_orb_get_level", "vo_orb_get_candidates",
-    "vo_orb_get_level_counts",
+    "vo_orb_get_level_counts", "vo_orb_set_timing", "vo_orb_get_timing",
     "vo_hamming_matrix_dev", "vo_hamming_matrix_batch_dev", "vo_hamming_matrix",
     "vo_match_frame_projection", "vo_match_local_map",
     "vo_pose_only_solve", "vo_pose_only_solve_dev",
     "vo_ba_create", "vo_ba_destroy", "vo_ba_set_stream", "vo_ba_set_shard", "vo_ba_set_state",
     "vo_ba_get_state", "vo_ba_n_free_cams", "vo_ba_local_ba", "vo_ba_solve", "vo_ba_lm_begin",
     "vo_ba_linearize", "vo_ba_step", "vo_ba_update", "vo_ba_lm_end", "vo_ba_reduced_system",
-    "vo_ba_reduced_cost", "vo_ba_debug_schur", "vo_se3_exp", "vo_se3_log",
+    "vo_ba_reduced_cost", "vo_ba_set_reduce_buffers", "vo_ba_classify",
+    "vo_ba_lm_begin_inliers", "vo_ba_get_edge_outliers", "vo_ba_debug_schur", "vo_se3_exp", "vo_se3_log",
 ]
 
 
@@ -177,6 +178,17 @@ class OrbExtractor:
         n = C.c_int()
         check(lib().vo_orb_get_candidates(self._h, frame, level, _p(x), _p(y), _p(r), cap, C.byref(n)))
         return x[:n.value].copy(), y[:n.value].copy(), r[:n.value].copy()
+
+    STAGES = ("pyramid", "fast", "octree", "offsets", "blur", "describe")
+
+    def set_timing(self, enabled: bool):
+        check(lib().vo_orb_set_timing(self._h, int(enabled)))
+
+    def get_timing(self):
+        ms = np.zeros(len(self.STAGES))
+        n = C.c_int()
+        check(lib().vo_orb_get_timing(self._h, _p(ms), C.byref(n)))
+        return dict(zip(self.STAGES, ms.tolist())), n.value
 
     def get_level_counts(self, frame=0):
         c = np.zeros(self.nlevels, np.int32)
@@ -363,6 +375,21 @@ class BundleAdjuster:
         p, n = C.c_void_p(), C.c_size_t()
         check(lib().vo_ba_reduced_cost(self._h, C.byref(p), C.byref(n)))
         return p.value, n.value
+
+    def classify(self, final_pass: bool):
+        check(lib().vo_ba_classify(self._h, int(final_pass)), "vo_ba_classify")
+
+    def lm_begin_inliers(self, huber_mono, huber_stereo, max_iterations):
+        check(lib().vo_ba_lm_begin_inliers(self._h, C.c_double(huber_mono), C.c_double(huber_stereo),
+                                           int(max_iterations)), "vo_ba_lm_begin_inliers")
+
+    def edge_outliers(self):
+        out = np.zeros(max(self.n_edges, 1), np.uint8)
+        check(lib().vo_ba_get_edge_outliers(self._h, _p(out)), "vo_ba_get_edge_outliers")
+        return out[:self.n_edges]
+
+    def set_reduce_buffers(self, system, cost):
+        check(lib().vo_ba_set_reduce_buffers(self._h, _p(system), _p(cost)))
 
     def debug_schur(self, huber=(0.0, 0.0), edge_active=None):
         n = 6 * self.n_free_cams()

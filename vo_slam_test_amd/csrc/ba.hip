@@ -333,7 +333,7 @@ __global__ __launch_bounds__(256) void k_pose_only(const int *offsets, const dou
 // ============================================================================================
 constexpr int kGroup = 8;        // lanes per map point
 constexpr int kPtsPerBlock = 32; // 256 / kGroup
-constexpr int kCamChunk = 1024;  // edges per k_ba_cams block
+constexpr int kCamChunk = 256;   // edges per camera-role block (one per thread)
 constexpr int kMaxN = 128;       // reduced system size limit of the LDS Cholesky (6*nf + 1 <= kMaxN)
 
 struct BaState {
@@ -363,6 +363,7 @@ struct BaDev {
   uint8_t *pt_in, *cam_in;
   // state
   double *Xc[2], *Xp[2];
+  double *PC[2];            // pose caches (R row-major 9 + t 3) of Xc[0/1], one per camera
   double *scale_c, *scale_p;
   double *hinv, *gl2, *dl;  // per point: inverse (6), scaled gradient (3), LM diagonal (3)
   double *Wt, *Yt;          // [3*n_pts][Mpad]
@@ -376,6 +377,21 @@ struct BaDev {
   BaState *st;
 };
 
+__device__ __forceinline__ PoseCache load_pc(const double *pc, int c) {
+  PoseCache P;
+  const double *q = pc + 12 * c;
+#pragma unroll
+  for (int i = 0; i < 9; i++) P.R[i] = q[i];
+  P.t[0] = q[9], P.t[1] = q[10], P.t[2] = q[11];
+  return P;
+}
+__device__ __forceinline__ void store_pc(double *pc, int c, const PoseCache &P) {
+  double *q = pc + 12 * c;
+#pragma unroll
+  for (int i = 0; i < 9; i++) q[i] = P.R[i];
+  q[9] = P.t[0], q[10] = P.t[1], q[11] = P.t[2];
+}
+
 __device__ __forceinline__ int payload_hpp_off(const BaDev &B) { return B.Mpad * B.Mpad; }
 __device__ __forceinline__ int payload_cost_off(const BaDev &B) { return B.Mpad * B.Mpad + B.nf * 27; }
 
@@ -384,15 +400,12 @@ __device__ __forceinline__ int payload_cost_off(const BaDev &B) { return B.Mpad 
 // point, Ceres' loss correction, the e-block E^T E + D and its inverse (SchurEliminator), and this
 // point's rows of the GEMM operands.
 // --------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_ba_points(BaDev B) {
-  __shared__ double lds[4 * 2];
-  const BaState st = *B.st;
-  if (st.done) return;
+__device__ __forceinline__ void ba_points_role(const BaDev &B, const BaState &st, double *lds, double *lmx) {
   const int tid = threadIdx.x, g = tid & (kGroup - 1);
   const int li = blockIdx.x * kPtsPerBlock + (tid >> 3);
   const bool valid = li < B.n_local;
   const int j = valid ? B.local_pts[li] : 0;
-  const double *Xc = B.Xc[st.cur], *Xp = B.Xp[st.cur];
+  const double *PCc = B.PC[st.cur], *Xp = B.Xp[st.cur];
   double cost = 0, gmax = 0;
   if (valid) {
     const int e0 = B.pt_start[j], e1 = B.pt_start[j + 1];
@@ -400,7 +413,7 @@ __global__ __launch_bounds__(256) void k_ba_points(BaDev B) {
     double h[6] = {0, 0, 0, 0, 0, 0}, gl[3] = {0, 0, 0};
     for (int e = e0 + g; e < e1; e += kGroup) {
       if (!B.e_active[e]) continue;
-      const PoseCache P = pose_cache(Xc + 6 * B.e_cam[e]);
+      const PoseCache P = load_pc(PCc, B.e_cam[e]);
       double r[3], Jl[9];
       const int m = edge_eval<false, true>(P, pt, B.e_obs[3 * e], B.e_obs[3 * e + 1], B.e_obs[3 * e + 2], B.e_is[e],
                                            B.K, r, nullptr, Jl);
@@ -457,7 +470,7 @@ __global__ __launch_bounds__(256) void k_ba_points(BaDev B) {
       if (!B.e_active[e]) continue;
       const int slot = B.cam_slot[B.e_cam[e]];
       if (slot < 0) continue;
-      const PoseCache P = pose_cache(Xc + 6 * B.e_cam[e]);
+      const PoseCache P = load_pc(PCc, B.e_cam[e]);
       double r[3], Jp[18], Jl[9];
       const int m = edge_eval<true, true>(P, pt, B.e_obs[3 * e], B.e_obs[3 * e + 1], B.e_obs[3 * e + 2], B.e_is[e],
                                           B.K, r, Jp, Jl);
@@ -482,7 +495,6 @@ __global__ __launch_bounds__(256) void k_ba_points(BaDev B) {
   double c[1] = {cost};
   block_sum<1>(c, lds);
   double gm = wave_max(gmax);
-  __shared__ double lmx[4];
   if ((tid & 63) == 0) lmx[tid >> 6] = gm;
   __syncthreads();
   if (tid == 0) {
@@ -494,15 +506,12 @@ __global__ __launch_bounds__(256) void k_ba_points(BaDev B) {
 // --------------------------------------------------------------------------------------------
 // k_ba_cams: F^T F and F^T b of each free camera (the f-blocks of the Schur eliminator)
 // --------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_ba_cams(BaDev B) {
-  __shared__ double lds[4 * 27];
-  const BaState st = *B.st;
-  if (st.done) return;
-  const int slot = blockIdx.x, chunk = blockIdx.y, tid = threadIdx.x;
+__device__ __forceinline__ void ba_cams_role(const BaDev &B, const BaState &st, int slot, int chunk, double *lds) {
+  const int tid = threadIdx.x;
   const int c = B.slot_cam[slot];
   const int s0 = B.cam_start[slot], s1 = B.cam_start[slot + 1];
-  const double *Xc = B.Xc[st.cur], *Xp = B.Xp[st.cur];
-  const PoseCache P = pose_cache(Xc + 6 * c);
+  const double *Xp = B.Xp[st.cur];
+  const PoseCache P = load_pc(B.PC[st.cur], c);
   double acc[27];
 #pragma unroll
   for (int i = 0; i < 27; i++) acc[i] = 0;
@@ -529,6 +538,21 @@ __global__ __launch_bounds__(256) void k_ba_cams(BaDev B) {
   if (tid < 27) B.slab_cam[((long long)slot * B.n_cchunks + chunk) * 27 + tid] = acc[tid];
 }
 
+// one launch for the whole linearisation: blocks [0, n_pblocks) work on points, the rest on
+// (camera, chunk) pairs -- the two roles are independent and overlap on the chip
+__global__ __launch_bounds__(256) void k_ba_linearize(BaDev B) {
+  __shared__ double lds[4 * 27];
+  __shared__ double lmx[4];
+  const BaState st = *B.st;
+  if (st.done) return;
+  if ((int)blockIdx.x < B.n_pblocks) {
+    ba_points_role(B, st, lds, lmx);
+  } else {
+    const int q = blockIdx.x - B.n_pblocks;
+    ba_cams_role(B, st, q / B.n_cchunks, q % B.n_cchunks, lds);
+  }
+}
+
 // --------------------------------------------------------------------------------------------
 // k_ba_gemm: partial tiles of  G = Y * W^T  with G[m][n] = sum_k Yt[k][m] * Wt[k][n] on the FP64
 // matrix cores.  One 16x16 tile per wavefront per K-slice; A operand: lane l holds
@@ -548,12 +572,25 @@ __global__ __launch_bounds__(64) void k_ba_gemm(BaDev B) {
   const int k0 = ks * B.kchunk, k1 = min(K, k0 + B.kchunk);
   double4_t acc = {0, 0, 0, 0};
   const int kk = lane >> 4, ii = lane & 15;
-  for (int k = k0; k < k1; k += 4) {
+  const double *Ya = B.Yt + tm * 16 + ii, *Wb = B.Wt + tn * 16 + ii;
+  int k = k0;
+  for (; k + 32 <= k1; k += 32) {  // 8 independent load pairs in flight per lane
+    double a[8], b[8];
+#pragma unroll
+    for (int u = 0; u < 8; u++) {
+      const long long row = (long long)(k + 4 * u + kk) * B.Mpad;
+      a[u] = Ya[row];
+      b[u] = Wb[row];
+    }
+#pragma unroll
+    for (int u = 0; u < 8; u++) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a[u], b[u], acc, 0, 0, 0);
+  }
+  for (; k < k1; k += 4) {
     const int kr = k + kk;
     double a = 0, b = 0;
     if (kr < k1) {
-      a = B.Yt[(long long)kr * B.Mpad + tm * 16 + ii];
-      b = B.Wt[(long long)kr * B.Mpad + tn * 16 + ii];
+      a = Ya[(long long)kr * B.Mpad];
+      b = Wb[(long long)kr * B.Mpad];
     }
     acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc, 0, 0, 0);
   }
@@ -570,7 +607,15 @@ __global__ __launch_bounds__(256) void k_ba_reduce(BaDev B) {
   const int nG = B.Mpad * B.Mpad, nH = B.nf * 27;
   if (i < nG) {
     double s = 0;
-    for (int k = 0; k < B.ksplit; k++) s += B.slab_gemm[(long long)k * nG + i];
+    int k = 0;
+    for (; k + 8 <= B.ksplit; k += 8) {
+      double v[8];
+#pragma unroll
+      for (int u = 0; u < 8; u++) v[u] = B.slab_gemm[(long long)(k + u) * nG + i];
+#pragma unroll
+      for (int u = 0; u < 8; u++) s += v[u];
+    }
+    for (; k < B.ksplit; k++) s += B.slab_gemm[(long long)k * nG + i];
     B.payload[i] = s;
   } else if (i < nG + nH) {
     const int q = i - nG, slot = q / 27, t = q - slot * 27;
@@ -598,25 +643,26 @@ __global__ __launch_bounds__(256) void k_ba_solve(BaDev B) {
   if (S->done) return;
   const int tid = threadIdx.x;
   const int n = 6 * B.nf, ld = n + 1;
-  double *A = sm;                 // n x ld
-  double *rhs = A + n * ld;       // n
-  double *sc = rhs + n;           // n   Jacobi scale
-  double *Dd = sc + n;            // n   LM diagonal
-  double *red = Dd + n;           // 8 * 4 scratch
+  double *A = sm;               // (n+1) x ld: lower triangle of S'' in rows 0..n-1, rhs'' in row n
+  double *sc = A + (n + 1) * ld;  // Jacobi scale
+  double *Dd = sc + n;            // LM diagonal
+  double *gpp = Dd + n;           // scaled gradient g''
+  double *y = gpp + n;            // solution
+  double *red = y + n;            // 64 scratch
   __shared__ int s_fail, s_stop;
   const double *G = B.payload;
   const double *HP = B.payload + payload_hpp_off(B);
   const int first = S->first;
   const double radius = S->radius;
   if (tid == 0) s_fail = 0, s_stop = 0;
-  // Jacobi scaling of the camera columns from the first linearisation
+  double gm = 0;
   for (int i = tid; i < n; i += 256) {
     const int slot = i / 6, a = i - slot * 6;
     int t = 0;
     for (int q = 0; q < a; q++) t += 6 - q;  // index of (a,a) in the packed upper triangle
     const double hd = HP[slot * 27 + t];
     double s;
-    if (first) {
+    if (first) {  // Jacobi scaling of the camera columns from the first linearisation
       s = 1.0 / (1.0 + sqrt(hd));
       B.scale_c[6 * B.slot_cam[slot] + a] = s;
     } else {
@@ -624,14 +670,17 @@ __global__ __launch_bounds__(256) void k_ba_solve(BaDev B) {
     }
     sc[i] = s;
     Dd[i] = fmin(fmax(hd * s * s, 1e-6), 1e32) / radius;
+    const double gp = HP[slot * 27 + 21 + a];
+    gm = fmax(gm, fabs(gp));
+    gpp[i] = s * gp;
   }
   __syncthreads();
-  double gm = 0;
   for (int i = tid; i < n * n; i += 256) {
     const int r = i / n, c = i - r * n;
+    if (c > r) continue;
     double v = -G[(long long)r * B.Mpad + c];
     if (r / 6 == c / 6) {
-      const int slot = r / 6, a = min(r % 6, c % 6), b = max(r % 6, c % 6);
+      const int slot = r / 6, a = c % 6, b = r % 6;  // a <= b
       int t = 0;
       for (int q = 0; q < a; q++) t += 6 - q;
       v += HP[slot * 27 + t + (b - a)];
@@ -640,12 +689,7 @@ __global__ __launch_bounds__(256) void k_ba_solve(BaDev B) {
     if (r == c) v += Dd[r];
     A[r * ld + c] = v;
   }
-  for (int i = tid; i < n; i += 256) {
-    const int slot = i / 6, a = i - slot * 6;
-    const double gp = HP[slot * 27 + 21 + a];
-    gm = fmax(gm, fabs(gp));
-    rhs[i] = sc[i] * (gp - G[(long long)i * B.Mpad + n]);
-  }
+  for (int i = tid; i < n; i += 256) A[n * ld + i] = gpp[i] - sc[i] * G[(long long)i * B.Mpad + n];
   gm = wave_max(gm);
   if ((tid & 63) == 0) red[tid >> 6] = gm;
   __syncthreads();
@@ -669,68 +713,63 @@ __global__ __launch_bounds__(256) void k_ba_solve(BaDev B) {
   }
   __syncthreads();
   if (s_stop) return;
-  double gdot = 0, dquad = 0;
-  // right-looking Cholesky, lower triangle, column by column
+  // Square-root-free Cholesky (L D L^T) of the damped reduced camera system with the rhs carried as
+  // row n, i.e. the forward substitution happens inside the elimination.  One barrier per column.
   for (int j = 0; j < n; j++) {
-    if (tid == 0) {
-      const double d = A[j * ld + j];
-      if (!(d > 0.0)) s_fail = 1;
-      A[j * ld + j] = sqrt(d);
+    const double pv = A[j * ld + j];
+    if (!(pv > 0.0) || !isfinite(pv)) {  // uniform: every thread reads the same pivot
+      if (tid == 0) s_fail = 1;
+      break;
     }
-    __syncthreads();
-    if (s_fail) break;
-    const double dj = A[j * ld + j];
-    for (int i = j + 1 + tid; i < n; i += 256) A[i * ld + j] /= dj;
-    __syncthreads();
-    const int rem = n - j - 1;
-    for (int t = tid; t < rem * rem; t += 256) {
-      const int r = j + 1 + t / rem, c = j + 1 + t % rem;
-      if (c <= r) A[r * ld + c] -= A[r * ld + j] * A[c * ld + j];
+    const double ip = 1.0 / pv;
+    const int cols = n - 1 - j, rows = n - j;  // columns j+1..n-1, rows j+1..n
+    for (int t = tid; t < rows * cols; t += 256) {
+      const int r = j + 1 + t / cols, c = j + 1 + t % cols;
+      if (c <= r) A[r * ld + c] -= A[r * ld + j] * A[c * ld + j] * ip;
     }
     __syncthreads();
   }
-  double *y = Dd + n + 64;  // reuse after red: solution vector (n)
-  if (!s_fail) {
-    if (tid == 0) {
-      for (int i = 0; i < n; i++) {
-        double s = rhs[i];
-        for (int k = 0; k < i; k++) s -= A[i * ld + k] * y[k];
-        y[i] = s / A[i * ld + i];
-      }
-      for (int i = n - 1; i >= 0; i--) {
-        double s = y[i];
-        for (int k = i + 1; k < n; k++) s -= A[k * ld + i] * y[k];
-        y[i] = s / A[i * ld + i];
-      }
-      for (int i = 0; i < n; i++)
-        if (!isfinite(y[i])) s_fail = 1;
+  __syncthreads();
+  const int fail = s_fail;
+  if (!fail) {
+    for (int j = n - 1; j >= 0; j--) {  // back substitution, column oriented
+      const double yj = A[n * ld + j] / A[j * ld + j];
+      if (tid == 0) y[j] = yj;
+      for (int i = tid; i < j; i += 256) A[n * ld + i] -= A[j * ld + i] * yj;
+      __syncthreads();
     }
+  } else {
+    for (int i = tid; i < n; i += 256) y[i] = 0.0;
     __syncthreads();
   }
   // camera part of  g''.step  and  step^T D step  (step = -y)
+  double gdot = 0, dquad = 0;
+  int bad = 0;
   for (int i = tid; i < n; i += 256) {
     const double stp = -y[i];
+    if (!isfinite(stp)) bad = 1;
+    gdot += gpp[i] * stp;
     dquad += Dd[i] * stp * stp;
     B.zc[i] = sc[i] * y[i];
   }
-  // g''_c . step_c needs the *gradient* s_c*gp, not the Schur rhs
-  for (int i = tid; i < n; i += 256) {
-    const int slot = i / 6, a = i - slot * 6;
-    gdot += sc[i] * HP[slot * 27 + 21 + a] * (-y[i]);
-  }
-  // candidate poses + norms
+  if (bad) s_fail = 1;
+  __syncthreads();
+  const int failed = s_fail;
+  // candidate poses (PoseLocalParameterization::Plus) + their caches + norms
   const double *X = B.Xc[S->cur];
   double *Xn = B.Xc[S->cur ^ 1];
   double xn2 = 0, cn2 = 0, sn2 = 0;
   for (int c = tid; c < B.n_cams; c += 256) {
     const int slot = B.cam_slot[c];
     double xc[6];
-    if (slot >= 0 && !s_fail) {
+    if (slot >= 0 && !failed) {
       double d[6];
       for (int a = 0; a < 6; a++) d[a] = -y[6 * slot + a] * sc[6 * slot + a];
       se3_plus(X + 6 * c, d, xc);
+      store_pc(B.PC[S->cur ^ 1], c, pose_cache(xc));
     } else {
       for (int a = 0; a < 6; a++) xc[a] = X[6 * c + a];
+      store_pc(B.PC[S->cur ^ 1], c, load_pc(B.PC[S->cur], c));
     }
     for (int a = 0; a < 6; a++) {
       Xn[6 * c + a] = xc[a];
@@ -742,7 +781,6 @@ __global__ __launch_bounds__(256) void k_ba_solve(BaDev B) {
     }
   }
   double v5[5] = {gdot, dquad, xn2, cn2, sn2};
-  __syncthreads();
   block_sum<5>(v5, red);
   if (tid == 0) {
     S->gdot_c = v5[0];
@@ -750,7 +788,7 @@ __global__ __launch_bounds__(256) void k_ba_solve(BaDev B) {
     S->x_norm2_c = v5[2];
     S->cand_norm2_c = v5[3];
     S->step_norm2_c = v5[4];
-    S->solve_failed = s_fail;
+    S->solve_failed = failed;
   }
 }
 
@@ -765,8 +803,7 @@ __global__ __launch_bounds__(256) void k_ba_backsub(BaDev B) {
   const int li = blockIdx.x * kPtsPerBlock + (tid >> 3);
   const bool valid = li < B.n_local;
   const int j = valid ? B.local_pts[li] : 0;
-  const double *Xc = B.Xc[st.cur], *Xp = B.Xp[st.cur];
-  const double *Xcn = B.Xc[st.cur ^ 1];
+  const double *Xp = B.Xp[st.cur];
   double *Xpn = B.Xp[st.cur ^ 1];
   double v[6] = {0, 0, 0, 0, 0, 0};  // cand_cost, gdot_l, dquad_l, step2, xnorm2, candnorm2
   if (valid) {
@@ -813,7 +850,7 @@ __global__ __launch_bounds__(256) void k_ba_backsub(BaDev B) {
     }
     for (int e = e0 + g; e < e1; e += kGroup) {
       if (!B.e_active[e]) continue;
-      const PoseCache P = pose_cache(Xcn + 6 * B.e_cam[e]);
+      const PoseCache P = load_pc(B.PC[st.cur ^ 1], B.e_cam[e]);
       double r[3];
       const int m = edge_eval<false, false>(P, pn, B.e_obs[3 * e], B.e_obs[3 * e + 1], B.e_obs[3 * e + 2], B.e_is[e],
                                             B.K, r, nullptr, nullptr);
@@ -830,11 +867,13 @@ __global__ __launch_bounds__(64) void k_ba_reduce2(BaDev B) {
   const BaState st = *B.st;
   if (st.done) return;
   const int t = threadIdx.x;
-  if (t < 6) {
-    double s = 0;
-    for (int b = 0; b < B.n_pblocks; b++) s += B.slab_bs[6 * b + t];
-    B.payload2[t] = s;
-  }
+  double v[6] = {0, 0, 0, 0, 0, 0};
+  for (int b = t; b < B.n_pblocks; b += 64)
+#pragma unroll
+    for (int i = 0; i < 6; i++) v[i] += B.slab_bs[6 * b + i];
+#pragma unroll
+  for (int i = 0; i < 6; i++) v[i] = wave_sum(v[i]);
+  if (t < 6) B.payload2[t] = v[t];
 }
 
 // --------------------------------------------------------------------------------------------
@@ -907,6 +946,13 @@ __global__ void k_ba_begin(BaDev B, int max_it) {
   S->first = 1;
 }
 
+__global__ void k_ba_posecache(BaDev B) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= B.n_cams) return;
+  const int cur = B.st->cur;
+  store_pc(B.PC[cur], c, pose_cache(B.Xc[cur] + 6 * c));
+}
+
 // edge activity -> which points / cameras are in the problem (Ceres drops unused blocks)
 __global__ void k_ba_mark(BaDev B) {
   const int e = blockIdx.x * blockDim.x + threadIdx.x;
@@ -977,10 +1023,11 @@ struct vo_ba {
   bool built = false;
   BaDev D{};
   vo::DevBuf b_ecam, b_ept, b_eobs, b_eis, b_eact, b_ptstart, b_local, b_camslot, b_slotcam, b_camstart,
-      b_camedges, b_ptin, b_camin, b_xc0, b_xc1, b_xp0, b_xp1, b_sc, b_sp, b_hinv, b_gl2, b_dl, b_wt, b_yt,
+      b_camedges, b_ptin, b_camin, b_xc0, b_xc1, b_xp0, b_xp1, b_pc0, b_pc1, b_sc, b_sp, b_hinv, b_gl2, b_dl, b_wt, b_yt,
       b_sgemm, b_scam, b_spt, b_payload, b_zc, b_sbs, b_payload2, b_state, b_out;
   size_t solve_lds = 0;
   int lm_max_it = 0;
+  double *ext_payload = nullptr, *ext_payload2 = nullptr;
 };
 
 namespace {
@@ -1027,7 +1074,7 @@ int build_device(vo_ba *h) {
   D.n_pblocks = std::max(1, (D.n_local + kPtsPerBlock - 1) / kPtsPerBlock);
   const int K = 3 * h->n_pts;
   const int tiles = (D.Mpad / 16) * (D.Mpad / 16);
-  int ks = std::max(1, std::min(64, 1024 / tiles));
+  int ks = std::max(1, std::min(16, 512 / tiles));
   ks = std::min(ks, std::max(1, K / 64));
   D.kchunk = ((K + ks - 1) / ks + 3) / 4 * 4;
   D.ksplit = std::max(1, (K + D.kchunk - 1) / D.kchunk);
@@ -1049,6 +1096,8 @@ int build_device(vo_ba *h) {
   VO_CHECK(upload(h->b_xc1, h->poses.data(), h->poses.size() * 8));
   VO_CHECK(upload(h->b_xp0, h->points.data(), h->points.size() * 8));
   VO_CHECK(upload(h->b_xp1, h->points.data(), h->points.size() * 8));
+  VO_CHECK(h->b_pc0.reserve((size_t)h->n_cams * 12 * 8));
+  VO_CHECK(h->b_pc1.reserve((size_t)h->n_cams * 12 * 8));
   VO_CHECK(h->b_sc.reserve((size_t)std::max(1, h->n_cams) * 6 * 8));
   VO_CHECK(h->b_sp.reserve((size_t)std::max(1, h->n_pts) * 3 * 8));
   VO_CHECK(h->b_hinv.reserve((size_t)std::max(1, h->n_pts) * 6 * 8));
@@ -1074,15 +1123,18 @@ int build_device(vo_ba *h) {
   D.pt_in = h->b_ptin.as<uint8_t>(), D.cam_in = h->b_camin.as<uint8_t>();
   D.Xc[0] = h->b_xc0.as<double>(), D.Xc[1] = h->b_xc1.as<double>();
   D.Xp[0] = h->b_xp0.as<double>(), D.Xp[1] = h->b_xp1.as<double>();
+  D.PC[0] = h->b_pc0.as<double>(), D.PC[1] = h->b_pc1.as<double>();
   D.scale_c = h->b_sc.as<double>(), D.scale_p = h->b_sp.as<double>();
   D.hinv = h->b_hinv.as<double>(), D.gl2 = h->b_gl2.as<double>(), D.dl = h->b_dl.as<double>();
   D.Wt = h->b_wt.as<double>(), D.Yt = h->b_yt.as<double>();
   D.slab_gemm = h->b_sgemm.as<double>(), D.slab_cam = h->b_scam.as<double>(), D.slab_pt = h->b_spt.as<double>();
-  D.payload = h->b_payload.as<double>(), D.zc = h->b_zc.as<double>();
-  D.slab_bs = h->b_sbs.as<double>(), D.payload2 = h->b_payload2.as<double>();
+  D.payload = h->ext_payload ? h->ext_payload : h->b_payload.as<double>();
+  D.zc = h->b_zc.as<double>();
+  D.slab_bs = h->b_sbs.as<double>();
+  D.payload2 = h->ext_payload2 ? h->ext_payload2 : h->b_payload2.as<double>();
   D.st = h->b_state.as<BaState>();
   const int n = 6 * h->nf;
-  h->solve_lds = ((size_t)n * (n + 1) + 3 * n + 64 + n + 64) * 8;
+  h->solve_lds = ((size_t)(n + 1) * (n + 1) + 4 * n + 64) * 8;
   if (h->solve_lds > 64 * 1024)
     VO_HIP_CHECK(hipFuncSetAttribute((const void *)k_ba_solve, hipFuncAttributeMaxDynamicSharedMemorySize,
                                      (int)h->solve_lds));
@@ -1109,6 +1161,7 @@ int lm_begin(vo_ba *h, double hm, double hs, int max_it, const uint8_t *active_c
   if (h->n_edges > 0)
     hipLaunchKernelGGL(k_ba_mark, dim3((h->n_edges + 255) / 256), dim3(256), 0, st, D);
   hipLaunchKernelGGL(k_ba_begin, dim3(1), dim3(1), 0, st, D, max_it);
+  hipLaunchKernelGGL(k_ba_posecache, dim3((h->n_cams + 63) / 64), dim3(64), 0, st, D);
   VO_HIP_CHECK(hipGetLastError());
   h->lm_max_it = max_it;
   return VO_OK;
@@ -1117,8 +1170,7 @@ int lm_begin(vo_ba *h, double hm, double hs, int max_it, const uint8_t *active_c
 int launch_linearize(vo_ba *h) {
   BaDev &D = h->D;
   hipStream_t st = h->stream;
-  hipLaunchKernelGGL(k_ba_points, dim3(D.n_pblocks), dim3(256), 0, st, D);
-  if (h->nf > 0) hipLaunchKernelGGL(k_ba_cams, dim3(h->nf, D.n_cchunks), dim3(256), 0, st, D);
+  hipLaunchKernelGGL(k_ba_linearize, dim3(D.n_pblocks + h->nf * D.n_cchunks), dim3(256), 0, st, D);
   const int tiles = (D.Mpad / 16) * (D.Mpad / 16);
   hipLaunchKernelGGL(k_ba_gemm, dim3(tiles, D.ksplit), dim3(64), 0, st, D);
   const int np = D.Mpad * D.Mpad + h->nf * 27 + 1;
@@ -1288,7 +1340,7 @@ void vo_ba_destroy(vo_ba *h) {
   (void)hipStreamSynchronize(h->stream);
   for (vo::DevBuf *b : {&h->b_ecam, &h->b_ept, &h->b_eobs, &h->b_eis, &h->b_eact, &h->b_ptstart, &h->b_local,
                         &h->b_camslot, &h->b_slotcam, &h->b_camstart, &h->b_camedges, &h->b_ptin, &h->b_camin,
-                        &h->b_xc0, &h->b_xc1, &h->b_xp0, &h->b_xp1, &h->b_sc, &h->b_sp, &h->b_hinv, &h->b_gl2,
+                        &h->b_xc0, &h->b_xc1, &h->b_xp0, &h->b_xp1, &h->b_pc0, &h->b_pc1, &h->b_sc, &h->b_sp, &h->b_hinv, &h->b_gl2,
                         &h->b_dl, &h->b_wt, &h->b_yt, &h->b_sgemm, &h->b_scam, &h->b_spt, &h->b_payload, &h->b_zc,
                         &h->b_sbs, &h->b_payload2, &h->b_state, &h->b_out})
     b->release();
@@ -1345,6 +1397,16 @@ int vo_ba_step(vo_ba *h) { return h && h->built ? launch_step(h) : VO_ERR_INVALI
 int vo_ba_update(vo_ba *h) { return h && h->built ? launch_update(h) : VO_ERR_INVALID; }
 int vo_ba_lm_end(vo_ba *h, vo_lm_summary *s) { return h && h->built ? lm_end(h, s) : VO_ERR_INVALID; }
 
+int vo_ba_set_reduce_buffers(vo_ba *h, double *dev_system, double *dev_cost) {
+  if (!h) return VO_ERR_INVALID;
+  h->ext_payload = dev_system, h->ext_payload2 = dev_cost;
+  if (h->built) {
+    h->D.payload = dev_system ? dev_system : h->b_payload.as<double>();
+    h->D.payload2 = dev_cost ? dev_cost : h->b_payload2.as<double>();
+  }
+  return VO_OK;
+}
+
 int vo_ba_reduced_system(vo_ba *h, double **p, size_t *n) {
   if (!h || !p || !n) return VO_ERR_INVALID;
   VO_CHECK(build_device(h));
@@ -1389,6 +1451,32 @@ int vo_ba_local_ba(vo_ba *h, const volatile int *stop, uint8_t *edge_erase, vo_l
   VO_HIP_CHECK(hipGetLastError());
   std::vector<uint8_t> tmp(std::max(1, h->n_edges));
   VO_HIP_CHECK(hipMemcpyAsync(tmp.data(), out, h->n_edges, hipMemcpyDeviceToHost, h->stream));
+  VO_HIP_CHECK(hipStreamSynchronize(h->stream));
+  for (int s = 0; s < h->n_edges; s++) edge_erase[h->perm[s]] = tmp[s];
+  return VO_OK;
+}
+
+int vo_ba_classify(vo_ba *h, int final_pass) {
+  if (!h) return VO_ERR_INVALID;
+  VO_CHECK(build_device(h));
+  uint8_t *out = h->b_out.as<uint8_t>();
+  if (!final_pass) VO_HIP_CHECK(hipMemsetAsync(out, 0, std::max(1, h->n_edges), h->stream));
+  hipLaunchKernelGGL(k_ba_classify, dim3((std::max(1, h->n_edges) + 255) / 256), dim3(256), 0, h->stream, h->D,
+                     final_pass ? 1 : 0, out);
+  VO_HIP_CHECK(hipGetLastError());
+  return VO_OK;
+}
+
+int vo_ba_lm_begin_inliers(vo_ba *h, double hm, double hs, int max_it) {
+  if (!h || max_it < 0) return VO_ERR_INVALID;
+  return lm_begin(h, hm, hs, max_it, nullptr, true);
+}
+
+int vo_ba_get_edge_outliers(vo_ba *h, uint8_t *edge_erase) {
+  if (!h || !edge_erase) return VO_ERR_INVALID;
+  VO_CHECK(build_device(h));
+  std::vector<uint8_t> tmp(std::max(1, h->n_edges));
+  VO_HIP_CHECK(hipMemcpyAsync(tmp.data(), h->b_out.p, h->n_edges, hipMemcpyDeviceToHost, h->stream));
   VO_HIP_CHECK(hipStreamSynchronize(h->stream));
   for (int s = 0; s < h->n_edges; s++) edge_erase[h->perm[s]] = tmp[s];
   return VO_OK;

@@ -41,6 +41,8 @@ struct LevelGeom {
   float scale;
   int patchSize;
   int tileBase, tilesX, tilesY;
+  // fast blur: 4-pixel groups at x = 4 + 4*g, g < blurGroups; wave strips of 64 groups x 32 rows
+  int blurGroups, stripsX, stripsY, stripBase, borderRowBase;
 };
 
 struct OrbDev {
@@ -152,7 +154,9 @@ __global__ __launch_bounds__(256) void k_fast_cells(OrbDev P, FrameSrc src, uint
                                                     int cells_per_frame) {
   __shared__ uint8_t tile[kTileP * kTileP];
   __shared__ uint8_t score[kTileP * kTileP];
+  __shared__ unsigned short plist[kTileP * kTileP];
   __shared__ int wcnt[4];
+  __shared__ int pcount;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int cell = blockIdx.x, f = blockIdx.y;
   int l = 0;
@@ -178,9 +182,38 @@ __global__ __launch_bounds__(256) void k_fast_cells(OrbDev P, FrameSrc src, uint
   __syncthreads();
   const int iw = cw - 6, ih = ch - 6;
   const int ni = (iw > 0 && ih > 0) ? iw * ih : 0;
-  for (int idx = tid; idx < ni; idx += 256) {
-    const int y = 3 + idx / iw, x = 3 + idx % iw;
-    score[y * kTileP + x] = (uint8_t)fast_arc_score(&tile[y * kTileP + x], P.min_th);
+  // phase 1: a 9-arc always contains two neighbouring compass pixels (ring 0,4,8,12), so a pixel can
+  // only be a corner at the lowest threshold if one such pair is brighter or darker together.
+  // Survivors are compacted into an LDS list (order is irrelevant here).
+  if (tid == 0) pcount = 0;
+  __syncthreads();
+  for (int base = 0; base < ni; base += 256) {
+    const int idx = base + tid;
+    bool pass = false;
+    int pos = 0;
+    if (idx < ni) {
+      const int y = 3 + idx / iw, x = 3 + idx % iw;
+      pos = y * kTileP + x;
+      const uint8_t *t = &tile[pos];
+      const int v = t[0], hi = v + P.min_th, lo = v - P.min_th;
+      const int p0 = t[3 * kTileP], p4 = t[3], p8 = t[-3 * kTileP], p12 = t[-3];
+      const int b = (p0 > hi) | ((p4 > hi) << 1) | ((p8 > hi) << 2) | ((p12 > hi) << 3);
+      const int d = (p0 < lo) | ((p4 < lo) << 1) | ((p8 < lo) << 2) | ((p12 < lo) << 3);
+      const int bb = b & ((b >> 1) | (b << 3)), dd = d & ((d >> 1) | (d << 3));
+      pass = ((bb | dd) & 15) != 0;
+    }
+    const unsigned long long mask = __ballot(pass);
+    int wbase = 0;
+    if (lane == 0 && mask) wbase = atomicAdd(&pcount, __popcll(mask));
+    wbase = __shfl(wbase, 0);
+    if (pass) plist[wbase + __popcll(mask & ((1ull << lane) - 1ull))] = (unsigned short)pos;
+  }
+  __syncthreads();
+  // phase 2: full arc score only for the survivors
+  const int np = pcount;
+  for (int i = tid; i < np; i += 256) {
+    const int pos = plist[i];
+    score[pos] = (uint8_t)fast_arc_score(&tile[pos], P.min_th);
   }
   __syncthreads();
   uint32_t *slot = cell_slots + (long long)f * slots_frame_stride + L.slotBase + (long long)ci * L.capCell;
@@ -573,7 +606,7 @@ __device__ __forceinline__ int reflect101(int i, int n) {
   return i;
 }
 
-__global__ __launch_bounds__(256) void k_blur(OrbDev P, FrameSrc src, int tiles_per_frame) {
+__global__ __launch_bounds__(256) void k_blur(OrbDev P, FrameSrc src, int only_level) {
   __shared__ uint8_t t[22][72];
   __shared__ int hs[22][64];
   const int kq[7] = {18, 34, 49, 55, 49, 34, 18};
@@ -582,6 +615,7 @@ __global__ __launch_bounds__(256) void k_blur(OrbDev P, FrameSrc src, int tiles_
   int l = 0;
   while (l + 1 < P.nlevels && tile >= P.lv[l + 1].tileBase) l++;
   const LevelGeom &L = P.lv[l];
+  if (only_level >= 0 && l != only_level) return;
   tile -= L.tileBase;
   const int ty = tile / L.tilesX, tx = tile - ty * L.tilesX;
   const int x0 = tx * 64, y0 = ty * 16;
@@ -611,6 +645,94 @@ __global__ __launch_bounds__(256) void k_blur(OrbDev P, FrameSrc src, int tiles_
     const int v = (acc + (1 << 15)) >> 16;
     dst[(long long)(y0 + r) * L.pitch + x0 + c] = (uint8_t)min(v, 255);
   }
+}
+
+// Fast path of the same filter.  One wavefront owns a strip of 64 four-pixel groups x 32 rows and
+// walks it top to bottom: per source row every lane loads the three aligned dwords around its
+// group, forms the four 7-tap row sums with v_alignbyte + v_dot4_u32_u8, keeps a 7-row sliding
+// window of row sums in registers and emits one packed dword of output per row.  No LDS, 4-byte
+// coalesced loads and stores.  Groups need x-4 >= 0 and x+7 <= w-1; the remaining <= 15 border
+// columns per row go through k_blur_border (direct 49-tap form, identical integer result because
+// the row pass is exact).
+__global__ __launch_bounds__(256) void k_blur_strips(OrbDev P, FrameSrc src, int lv0_generic) {
+  const int lane = threadIdx.x & 63, f = blockIdx.y;
+  int job = blockIdx.x * 4 + (threadIdx.x >> 6);
+  int l = 0;
+  while (l + 1 < P.nlevels && job >= P.lv[l + 1].stripBase) l++;
+  const LevelGeom &L = P.lv[l];
+  job -= L.stripBase;
+  if (job >= L.stripsX * L.stripsY) return;
+  if (l == 0 && lv0_generic) return;
+  const int sy = job / L.stripsX, sx = job - sy * L.stripsX;
+  const int g = sx * 64 + lane;
+  const bool active = g < L.blurGroups;
+  const int x = 4 + 4 * (active ? g : 0);
+  int pitch;
+  const uint8_t *img = level_plane(P, src, l, f, pitch);
+  uint8_t *dst = src.blur + (long long)f * src.blur_frame_stride + L.blur_off;
+  const int y0 = sy * 32, y1 = min(L.h, y0 + 32);
+  const unsigned K0 = 18u | (34u << 8) | (49u << 16) | (55u << 24);
+  const unsigned K1 = 49u | (34u << 8) | (18u << 16);
+  int hw[7][4];
+#pragma unroll
+  for (int j = 0; j < 7; j++)
+#pragma unroll
+    for (int q = 0; q < 4; q++) hw[j][q] = 0;
+  for (int yy = y0 - 3; yy < y1 + 3; yy++) {
+    const int ry = reflect101(yy, L.h);
+    const uint8_t *row = img + (long long)ry * pitch + x;
+    const unsigned Lw = *reinterpret_cast<const unsigned *>(row - 4);
+    const unsigned Cw = *reinterpret_cast<const unsigned *>(row);
+    const unsigned Rw = *reinterpret_cast<const unsigned *>(row + 4);
+#pragma unroll
+    for (int j = 0; j < 6; j++)
+#pragma unroll
+      for (int q = 0; q < 4; q++) hw[j][q] = hw[j + 1][q];
+    // pixel q sits at byte 4+q of (L,C,R); its taps are bytes q+1 .. q+7
+    hw[6][0] = __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(Cw, Lw, 1), K0, __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(Rw, Cw, 1), K1, 0u, false), false);
+    hw[6][1] = __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(Cw, Lw, 2), K0, __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(Rw, Cw, 2), K1, 0u, false), false);
+    hw[6][2] = __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(Cw, Lw, 3), K0, __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(Rw, Cw, 3), K1, 0u, false), false);
+    hw[6][3] = __builtin_amdgcn_udot4(Cw, K0, __builtin_amdgcn_udot4(Rw, K1, 0u, false), false);
+    if (yy >= y0 + 3) {
+      unsigned outw = 0;
+#pragma unroll
+      for (int q = 0; q < 4; q++) {
+        const int acc = 18 * (hw[0][q] + hw[6][q]) + 34 * (hw[1][q] + hw[5][q]) + 49 * (hw[2][q] + hw[4][q]) + 55 * hw[3][q];
+        const unsigned v = (unsigned)min((acc + (1 << 15)) >> 16, 255);
+        outw |= v << (8 * q);
+      }
+      if (active) *reinterpret_cast<unsigned *>(dst + (long long)(yy - 3) * L.pitch + x) = outw;
+    }
+  }
+}
+
+// border columns of the blur: x in [0,4) and [4 + 4*blurGroups, w); 16 rows x 16 columns per block
+__global__ __launch_bounds__(256) void k_blur_border(OrbDev P, FrameSrc src, int lv0_generic) {
+  const int kq[7] = {18, 34, 49, 55, 49, 34, 18};
+  const int f = blockIdx.y;
+  int rb = blockIdx.x;
+  int l = 0;
+  while (l + 1 < P.nlevels && rb >= P.lv[l + 1].borderRowBase) l++;
+  const LevelGeom &L = P.lv[l];
+  rb -= L.borderRowBase;
+  if (l == 0 && lv0_generic) return;
+  const int y = rb * 16 + (threadIdx.x >> 4), ci = threadIdx.x & 15;
+  const int xr = 4 + 4 * L.blurGroups;
+  const int x = ci < 4 ? ci : xr + (ci - 4);
+  if (y >= L.h || x >= L.w || (ci < 4 && x >= xr)) return;
+  int pitch;
+  const uint8_t *img = level_plane(P, src, l, f, pitch);
+  int acc = 0;
+#pragma unroll
+  for (int j = 0; j < 7; j++) {
+    const uint8_t *row = img + (long long)reflect101(y + j - 3, L.h) * pitch;
+    int hsum = 0;
+#pragma unroll
+    for (int i = 0; i < 7; i++) hsum += kq[i] * row[reflect101(x + i - 3, L.w)];
+    acc += kq[j] * hsum;
+  }
+  uint8_t *dst = src.blur + (long long)f * src.blur_frame_stride + L.blur_off;
+  dst[(long long)y * L.pitch + x] = (uint8_t)min((acc + (1 << 15)) >> 16, 255);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -762,6 +884,7 @@ struct vo_orb {
   OrbDev dev;
   long long pyr_frame = 0, blur_frame = 0, slots_frame = 0;
   int cells_frame = 0, keys_frame = 0, sel_frame = 0, tiles_frame = 0, max_kp = 0;
+  int strips_frame = 0, border_rows_frame = 0;
   std::vector<int> tab_off;  // per level: offsets of xofs,xab,yofs,yab in tables
   vo::DevBuf tables, pyr, blur, slots, cellcnt, keydata, keylabel, candcnt, sel, nk, off, err;
   vo::DevBuf in_img, out_kp, out_desc, out_cnt;
@@ -769,6 +892,10 @@ struct vo_orb {
   // last call
   FrameSrc last_src{};
   int last_frames = 0;
+  // per-stage event timing
+  bool timing = false;
+  std::vector<hipEvent_t> ev;       // (VO_ORB_STAGES + 1) events per timed call
+  int timed_calls = 0;
 };
 
 namespace {
@@ -818,7 +945,7 @@ int configure(vo_orb *h, int w, int h_img, int n_frames) {
     D.min_th = h->min_th;
     memcpy(D.umax, h->umax, sizeof(D.umax));
     long long pyr = 0, blur = 0, slots = 0;
-    int cells = 0, keys = 0, sel = 0, tiles = 0, maxkp = 0;
+    int cells = 0, keys = 0, sel = 0, tiles = 0, maxkp = 0, strips = 0, brows = 0;
     std::vector<int> tables;
     h->tab_off.assign(h->nlevels * 4, 0);
     int pw = w, ph = h_img;
@@ -884,6 +1011,13 @@ int configure(vo_orb *h, int w, int h_img, int n_frames) {
       L.tilesY = (L.h + 15) / 16;
       L.tileBase = tiles;
       tiles += L.tilesX * L.tilesY;
+      L.blurGroups = L.w >= 12 ? (L.w - 12) / 4 + 1 : 0;
+      L.stripsX = (L.blurGroups + 63) / 64;
+      L.stripsY = (L.h + 31) / 32;
+      L.stripBase = strips;
+      strips += L.stripsX * L.stripsY;
+      L.borderRowBase = brows;
+      brows += (L.h + 15) / 16;
       if (l > 0) {
         std::vector<int> xo, xa, yo, ya;
         orb_resize_tables(pw, ph, L.w, L.h, xo, xa, yo, ya);
@@ -906,6 +1040,8 @@ int configure(vo_orb *h, int w, int h_img, int n_frames) {
     h->sel_frame = sel;
     h->tiles_frame = tiles;
     h->max_kp = maxkp;
+    h->strips_frame = strips;
+    h->border_rows_frame = brows;
     VO_CHECK(h->tables.reserve(std::max<size_t>(tables.size() * sizeof(int), 64)));
     if (!tables.empty())
       VO_HIP_CHECK(hipMemcpy(h->tables.p, tables.data(), tables.size() * sizeof(int), hipMemcpyHostToDevice));
@@ -947,6 +1083,20 @@ int run_pipeline(vo_orb *h, const uint8_t *dev_images, int n_frames, int w, int 
   h->last_src = S;
   h->last_frames = n_frames;
   VO_HIP_CHECK(hipMemsetAsync(h->err.p, 0, 4, st));
+  hipEvent_t *ev = nullptr;
+  if (h->timing) {
+    const size_t need = (size_t)(h->timed_calls + 1) * (VO_ORB_STAGES + 1);
+    while (h->ev.size() < need) {
+      hipEvent_t e;
+      VO_HIP_CHECK(hipEventCreate(&e));
+      h->ev.push_back(e);
+    }
+    ev = h->ev.data() + (size_t)h->timed_calls * (VO_ORB_STAGES + 1);
+    h->timed_calls++;
+  }
+#define VO_STAGE_MARK(i) \
+  if (ev) VO_HIP_CHECK(hipEventRecord(ev[i], st))
+  VO_STAGE_MARK(0);
   // pyramid: level l from level l-1 (sequential by construction, :1129)
   for (int l = 1; l < D.nlevels; l++) {
     const LevelGeom &L = D.lv[l], &Pv = D.lv[l - 1];
@@ -959,20 +1109,35 @@ int run_pipeline(vo_orb *h, const uint8_t *dev_images, int n_frames, int w, int 
                        (long long)h->pyr_frame, L.pitch, L.w, L.h, T + h->tab_off[l * 4 + 0],
                        T + h->tab_off[l * 4 + 1], T + h->tab_off[l * 4 + 2], T + h->tab_off[l * 4 + 3]);
   }
+  VO_STAGE_MARK(1);
   if (h->cells_frame > 0)
     hipLaunchKernelGGL(k_fast_cells, dim3(h->cells_frame, n_frames), dim3(256), 0, st, D, S,
                        h->slots.as<uint32_t>(), h->slots_frame, h->cellcnt.as<int>(), h->cells_frame);
+  VO_STAGE_MARK(2);
   hipLaunchKernelGGL(k_octree, dim3(D.nlevels, n_frames), dim3(256), 0, st, D, h->slots.as<uint32_t>(),
                      h->slots_frame, h->cellcnt.as<int>(), h->cells_frame, h->keydata.as<uint32_t>(),
                      h->keylabel.as<unsigned short>(), h->keys_frame, h->candcnt.as<int>(),
                      h->sel.as<uint32_t>(), h->sel_frame, h->nk.as<int>(), h->err.as<int>());
+  VO_STAGE_MARK(3);
   hipLaunchKernelGGL(k_offsets, dim3((n_frames + 63) / 64), dim3(64), 0, st, D.nlevels, n_frames,
                      h->nk.as<int>(), h->off.as<int>(), capacity, dcounts);
-  hipLaunchKernelGGL(k_blur, dim3(h->tiles_frame, n_frames), dim3(256), 0, st, D, S, h->tiles_frame);
+  VO_STAGE_MARK(4);
+  {
+    // the strip kernel reads aligned dwords; a caller image that is not 4-byte aligned falls back
+    // to the generic LDS kernel for level 0 only
+    const int lv0_generic = ((reinterpret_cast<uintptr_t>(dev_images) | (uintptr_t)stride | (uintptr_t)frame_stride) & 3) ? 1 : 0;
+    if (h->strips_frame > 0)
+      hipLaunchKernelGGL(k_blur_strips, dim3((h->strips_frame + 3) / 4, n_frames), dim3(256), 0, st, D, S, lv0_generic);
+    hipLaunchKernelGGL(k_blur_border, dim3(h->border_rows_frame, n_frames), dim3(256), 0, st, D, S, lv0_generic);
+    if (lv0_generic) hipLaunchKernelGGL(k_blur, dim3(h->tiles_frame, n_frames), dim3(256), 0, st, D, S, 0);
+  }
+  VO_STAGE_MARK(5);
   const int kp_blocks = (std::min(capacity, h->max_kp) + 3) / 4;
   if (kp_blocks > 0)
     hipLaunchKernelGGL(k_describe, dim3(kp_blocks, n_frames), dim3(256), 0, st, D, S, h->sel.as<uint32_t>(),
                        h->sel_frame, h->off.as<int>(), capacity, dkp, ddesc);
+  VO_STAGE_MARK(6);
+#undef VO_STAGE_MARK
   VO_HIP_CHECK(hipGetLastError());
   return VO_OK;
 }
@@ -1035,6 +1200,7 @@ void vo_orb_destroy(vo_orb *h) {
                         &h->candcnt, &h->sel, &h->nk, &h->off, &h->err, &h->in_img, &h->out_kp, &h->out_desc,
                         &h->out_cnt})
     b->release();
+  for (hipEvent_t e : h->ev) (void)hipEventDestroy(e);
   if (h->own_stream) (void)hipStreamDestroy(h->stream);
   delete h;
 }
@@ -1119,6 +1285,30 @@ int vo_orb_extract(vo_orb *h, const uint8_t *image, int width, int height, int s
     VO_HIP_CHECK(hipMemcpy(descriptors, h->out_desc.p, (size_t)n * 32, hipMemcpyDeviceToHost));
   }
   *n_keypoints = n;
+  return VO_OK;
+}
+
+int vo_orb_set_timing(vo_orb *h, int enabled) {
+  if (!h) return VO_ERR_INVALID;
+  VO_HIP_CHECK(hipStreamSynchronize(h->stream));
+  h->timing = enabled != 0;
+  h->timed_calls = 0;
+  return VO_OK;
+}
+
+int vo_orb_get_timing(vo_orb *h, double *ms, int *n_calls) {
+  if (!h || !ms || !n_calls) return VO_ERR_INVALID;
+  VO_HIP_CHECK(hipStreamSynchronize(h->stream));
+  for (int c = 0; c < h->timed_calls; c++) {
+    hipEvent_t *ev = h->ev.data() + (size_t)c * (VO_ORB_STAGES + 1);
+    for (int s = 0; s < VO_ORB_STAGES; s++) {
+      float t = 0;
+      VO_HIP_CHECK(hipEventElapsedTime(&t, ev[s], ev[s + 1]));
+      ms[s] += t;
+    }
+  }
+  *n_calls = h->timed_calls;
+  h->timed_calls = 0;
   return VO_OK;
 }
 
