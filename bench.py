@@ -177,33 +177,32 @@ def main():
     if not args.no_ba:
         lb = synth.make_lba_problem(0)
         n_edges = len(lb["e_cam"])
-        reps = 8
+        reps = 20
         if world == 1:
             ba = vo.BundleAdjuster(lb)
             ba.local_ba()  # warm-up (allocations, code load)
-            iters = 0
-            torch.cuda.synchronize()
-            tb0 = time.perf_counter()
+            iters, tb = 0, 0.0
             for _ in range(reps):
-                ba.set_state(lb["poses"], lb["points"])
-                _, sums, _ = ba.local_ba()
+                ba.set_state(lb["poses"], lb["points"])  # reset to the initial guess (not timed)
+                torch.cuda.synchronize()
+                tb0 = time.perf_counter()
+                _, sums, _ = ba.local_ba()               # returns after its own final synchronisation
+                tb += time.perf_counter() - tb0
                 iters += sums[0].iterations + sums[1].iterations
-            torch.cuda.synchronize()
-            tb = time.perf_counter() - tb0
             ba.close()
         else:
             from vo_slam_test_amd.dist_ba import ShardedBundleAdjuster
             sba = ShardedBundleAdjuster(lb, rank, world)
             sba.local_ba()
-            iters = 0
-            barrier()
-            tb0 = time.perf_counter()
+            iters, tb = 0, 0.0
             for _ in range(reps):
                 sba.ba.set_state(lb["poses"], lb["points"])
+                barrier()
+                tb0 = time.perf_counter()
                 _, _, _, (s1, s2) = sba.local_ba()
+                barrier()
+                tb += time.perf_counter() - tb0
                 iters += s1.iterations + s2.iterations
-            barrier()
-            tb = time.perf_counter() - tb0
             sba.close()
         out["local_ba"] = {"workload": f"10 KF + 4 fixed x 3000 pts, {n_edges} edges, 5 Huber + 10 plain LM iterations",
                            "lm_iters_per_s": round(iters / tb, 1), "ms_per_solve": round(tb / reps * 1e3, 3),

@@ -49,8 +49,10 @@ __device__ __forceinline__ void block_sum(double (&v)[N], double *lds /*>= 4*N*/
 #pragma unroll
   for (int i = 0; i < N; i++) v[i] = wave_sum(v[i]);
   __syncthreads();
-  if (lane == 0)
+  if (lane == 0) {
+#pragma unroll
     for (int i = 0; i < N; i++) lds[wave * N + i] = v[i];
+  }
   __syncthreads();
   const int nw = blockDim.x >> 6;
 #pragma unroll
@@ -374,7 +376,9 @@ struct BaDev {
   double *zc;               // [6nf] scale_c * y_c
   double *slab_bs;          // [n_pblocks][6]
   double *payload2;         // 6
+  unsigned long long *dbg;  // optional stamps (VO_BA_STAMPS builds)
   BaState *st;
+  BaState *hist;            // [2] states of earlier solves of the same schedule
 };
 
 __device__ __forceinline__ PoseCache load_pc(const double *pc, int c) {
@@ -467,9 +471,19 @@ __device__ __forceinline__ void ba_points_role(const BaDev &B, const BaState &st
     }
     // second sweep: W = Jp'^T Jl' per edge, point-scaled, and Y = W Hinv
     for (int e = e0 + g; e < e1; e += kGroup) {
-      if (!B.e_active[e]) continue;
       const int slot = B.cam_slot[B.e_cam[e]];
       if (slot < 0) continue;
+      if (!B.e_active[e]) {  // keep the operand rows of a deactivated edge at zero (no per-solve memset)
+        if (st.first) {
+          const long long base = (long long)(3 * j) * B.Mpad + 6 * slot;
+#pragma unroll
+          for (int a = 0; a < 6; a++) {
+            B.Wt[base + a] = 0, B.Wt[base + B.Mpad + a] = 0, B.Wt[base + 2 * B.Mpad + a] = 0;
+            B.Yt[base + a] = 0, B.Yt[base + B.Mpad + a] = 0, B.Yt[base + 2 * B.Mpad + a] = 0;
+          }
+        }
+        continue;
+      }
       const PoseCache P = load_pc(PCc, B.e_cam[e]);
       double r[3], Jp[18], Jl[9];
       const int m = edge_eval<true, true>(P, pt, B.e_obs[3 * e], B.e_obs[3 * e + 1], B.e_obs[3 * e + 2], B.e_is[e],
@@ -535,7 +549,11 @@ __device__ __forceinline__ void ba_cams_role(const BaDev &B, const BaState &st, 
     }
   }
   block_sum<27>(acc, lds);
-  if (tid < 27) B.slab_cam[((long long)slot * B.n_cchunks + chunk) * 27 + tid] = acc[tid];
+  if (tid == 0) {  // static indices only (a runtime-indexed acc[] would live in scratch memory)
+    double *o = B.slab_cam + ((long long)slot * B.n_cchunks + chunk) * 27;
+#pragma unroll
+    for (int i = 0; i < 27; i++) o[i] = acc[i];
+  }
 }
 
 // one launch for the whole linearisation: blocks [0, n_pblocks) work on points, the rest on
@@ -561,15 +579,23 @@ __global__ __launch_bounds__(256) void k_ba_linearize(BaDev B) {
 // --------------------------------------------------------------------------------------------
 typedef double double4_t __attribute__((ext_vector_type(4)));
 
-__global__ __launch_bounds__(64) void k_ba_gemm(BaDev B) {
+__global__ __launch_bounds__(256) void k_ba_gemm(BaDev B) {
+  __shared__ double part[4][256];
   const BaState st = *B.st;
   if (st.done) return;
   const int tiles = B.Mpad / 16;
-  const int tile = blockIdx.x, ks = blockIdx.y;
-  const int tm = tile / tiles, tn = tile - tm * tiles;
-  const int lane = threadIdx.x;
+  // upper-triangular tile index -> (tm <= tn)
+  int tile = blockIdx.x, tm = 0;
+  while (tile >= tiles - tm) {
+    tile -= tiles - tm;
+    tm++;
+  }
+  const int tn = tm + tile;
+  const int ks = blockIdx.y, wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int K = 3 * B.n_pts;
-  const int k0 = ks * B.kchunk, k1 = min(K, k0 + B.kchunk);
+  const int kb0 = ks * B.kchunk, kb1 = min(K, kb0 + B.kchunk);
+  const int q = ((kb1 - kb0 + 15) / 16) * 4;  // rows per wave, multiple of 4
+  const int k0 = kb0 + wave * q, k1 = min(kb1, k0 + q);
   double4_t acc = {0, 0, 0, 0};
   const int kk = lane >> 4, ii = lane & 15;
   const double *Ya = B.Yt + tm * 16 + ii, *Wb = B.Wt + tn * 16 + ii;
@@ -594,41 +620,49 @@ __global__ __launch_bounds__(64) void k_ba_gemm(BaDev B) {
     }
     acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc, 0, 0, 0);
   }
-  double *out = B.slab_gemm + (long long)ks * B.Mpad * B.Mpad;
 #pragma unroll
-  for (int r = 0; r < 4; r++) out[(long long)(tm * 16 + kk + 4 * r) * B.Mpad + tn * 16 + ii] = acc[r];
+  for (int r = 0; r < 4; r++) part[wave][(kk + 4 * r) * 16 + ii] = acc[r];
+  __syncthreads();
+  const int t = threadIdx.x;  // element (t>>4, t&15) of the tile, fixed summation order
+  const double v = (part[0][t] + part[1][t]) + (part[2][t] + part[3][t]);
+  B.slab_gemm[(long long)ks * B.Mpad * B.Mpad + (long long)(tm * 16 + (t >> 4)) * B.Mpad + tn * 16 + (t & 15)] = v;
 }
 
 // fixed-order reduction of the slabs into the payload that a multi-GPU run all-reduces
 __global__ __launch_bounds__(256) void k_ba_reduce(BaDev B) {
   const BaState st = *B.st;
   if (st.done) return;
-  const int i = blockIdx.x * 256 + threadIdx.x;
+  const int gid = blockIdx.x * 256 + threadIdx.x;
+  const int i = gid >> 2, sub = gid & 3;  // 4 lanes share one payload entry
   const int nG = B.Mpad * B.Mpad, nH = B.nf * 27;
+  double s = 0;
   if (i < nG) {
-    double s = 0;
-    int k = 0;
-    for (; k + 8 <= B.ksplit; k += 8) {
+    const int r = i / B.Mpad, c = i - r * B.Mpad;
+    if ((c >> 4) >= (r >> 4)) {  // upper tiles only
       double v[8];
 #pragma unroll
-      for (int u = 0; u < 8; u++) v[u] = B.slab_gemm[(long long)(k + u) * nG + i];
+      for (int u = 0; u < 8; u++) {  // ksplit <= 32: up to 8 slabs per lane, all loads in flight together
+        const int k = sub + 4 * u;
+        v[u] = k < B.ksplit ? B.slab_gemm[(long long)k * nG + i] : 0.0;
+      }
 #pragma unroll
       for (int u = 0; u < 8; u++) s += v[u];
     }
-    for (; k < B.ksplit; k++) s += B.slab_gemm[(long long)k * nG + i];
-    B.payload[i] = s;
   } else if (i < nG + nH) {
     const int q = i - nG, slot = q / 27, t = q - slot * 27;
-    double s = 0;
-    for (int c = 0; c < B.n_cchunks; c++) s += B.slab_cam[((long long)slot * B.n_cchunks + c) * 27 + t];
-    B.payload[i] = s;
-  } else if (i == nG + nH) {
-    double s = 0, m = 0;
+    for (int c = sub; c < B.n_cchunks; c += 4) s += B.slab_cam[((long long)slot * B.n_cchunks + c) * 27 + t];
+  }
+  s += __shfl_xor(s, 1);
+  s += __shfl_xor(s, 2);
+  if (i < nG + nH) {
+    if (sub == 0) B.payload[i] = s;
+  } else if (i == nG + nH && sub == 0) {
+    double cs = 0, m = 0;
     for (int b = 0; b < B.n_pblocks; b++) {
-      s += B.slab_pt[2 * b];
+      cs += B.slab_pt[2 * b];
       m = fmax(m, B.slab_pt[2 * b + 1]);
     }
-    B.payload[i] = s;
+    B.payload[i] = cs;
     for (int k = 0; k < B.n_shards; k++) B.payload[i + 1 + k] = (k == B.shard) ? m : 0.0;
   }
 }
@@ -637,18 +671,62 @@ __global__ __launch_bounds__(256) void k_ba_reduce(BaDev B) {
 // k_ba_solve: reduced camera system S y = rhs (DenseSchurComplementSolver: dense Cholesky),
 // camera step, candidate poses.  One workgroup; S lives in LDS.
 // --------------------------------------------------------------------------------------------
+// fast FP64 reciprocal: hardware estimate + two Newton steps (dependent chain of ~5 instructions
+// instead of the ~12 of an IEEE division; relative error < 2^-50, far below the LM tolerances)
+__device__ __forceinline__ double fast_rcp(double d) {
+  double r = __builtin_amdgcn_rcp(d);
+  r = r * (2.0 - d * r);
+  r = r * (2.0 - d * r);
+  return r;
+}
+
+// 6x6 L D L^T of a diagonal block held in registers (packed lower triangle, row-major, 21).
+// On return the strict lower part holds the unit-lower factor, the diagonal holds d_j and
+// rd[j] = 1/d_j.  Returns false on a non-positive pivot.  Square-root free: the pivot chain is
+// the latency floor of the whole solve.
+__device__ __forceinline__ bool ldl6_packed(double L[21], double rd[6]) {
+  bool ok = true;
+  double u[21];  // u_ij = l_ij d_j
+#pragma unroll
+  for (int j = 0; j < 6; j++) {
+    double d = L[j * (j + 1) / 2 + j];
+#pragma unroll
+    for (int k = 0; k < j; k++) d -= u[j * (j + 1) / 2 + k] * L[j * (j + 1) / 2 + k];
+    ok = ok && (d > 0.0) && isfinite(d);
+    const double r = fast_rcp(d);
+    L[j * (j + 1) / 2 + j] = d;
+    rd[j] = r;
+#pragma unroll
+    for (int i = j + 1; i < 6; i++) {
+      double v = L[i * (i + 1) / 2 + j];
+#pragma unroll
+      for (int k = 0; k < j; k++) v -= u[i * (i + 1) / 2 + k] * L[j * (j + 1) / 2 + k];
+      u[i * (i + 1) / 2 + j] = v;
+      L[i * (i + 1) / 2 + j] = v * r;
+    }
+  }
+  return ok;
+}
+
+#ifdef VO_BA_STAMPS
+#define STAMP(i) do { if (threadIdx.x == 0) B.dbg[i] = __builtin_amdgcn_s_memrealtime(); } while (0)
+#else
+#define STAMP(i)
+#endif
 __global__ __launch_bounds__(256) void k_ba_solve(BaDev B) {
   extern __shared__ double sm[];
   BaState *S = B.st;
   if (S->done) return;
   const int tid = threadIdx.x;
-  const int n = 6 * B.nf, ld = n + 1;
-  double *A = sm;               // (n+1) x ld: lower triangle of S'' in rows 0..n-1, rhs'' in row n
-  double *sc = A + (n + 1) * ld;  // Jacobi scale
-  double *Dd = sc + n;            // LM diagonal
-  double *gpp = Dd + n;           // scaled gradient g''
-  double *y = gpp + n;            // solution
-  double *red = y + n;            // 64 scratch
+  STAMP(0);
+  const int nb = B.nf, n = 6 * nb, ld = n + 1;
+  double *A = sm;                   // (n+1) x ld: lower triangle of S'' in rows 0..n-1, rhs'' in row n
+  double *sc = A + (n + 1) * ld;    // Jacobi scale
+  double *Dd = sc + n;              // LM diagonal
+  double *gpp = Dd + n;             // scaled gradient g''
+  double *y = gpp + n;              // solution
+  double *Ldg = y + n;              // nb x 21 factored diagonal blocks
+  double *red = Ldg + nb * 21 + n;  // 64 scratch (after the n reciprocal pivots)
   __shared__ int s_fail, s_stop;
   const double *G = B.payload;
   const double *HP = B.payload + payload_hpp_off(B);
@@ -675,19 +753,24 @@ __global__ __launch_bounds__(256) void k_ba_solve(BaDev B) {
     gpp[i] = s * gp;
   }
   __syncthreads();
-  for (int i = tid; i < n * n; i += 256) {
-    const int r = i / n, c = i - r * n;
-    if (c > r) continue;
-    double v = -G[(long long)r * B.Mpad + c];
-    if (r / 6 == c / 6) {
-      const int slot = r / 6, a = c % 6, b = r % 6;  // a <= b
-      int t = 0;
-      for (int q = 0; q < a; q++) t += 6 - q;
-      v += HP[slot * 27 + t + (b - a)];
-    }
-    v *= sc[r] * sc[c];
-    if (r == c) v += Dd[r];
-    A[r * ld + c] = v;
+  STAMP(1);
+  // S'' = diag(sc) (Hpp - Y W^T) diag(sc) + D, lower triangle; the GEMM delivers the upper tiles
+  {
+    const int tx = tid & 15, ty = tid >> 4;  // lanes run along r: contiguous reads of G[c][r..]
+    for (int c = ty; c < n; c += 16)
+      for (int r = c - (c & 15) + tx; r < n; r += 16) {
+        if (r < c) continue;
+        double v = -G[(long long)c * B.Mpad + r];
+        if (r / 6 == c / 6) {
+          const int slot = r / 6, a = c % 6, b = r % 6;  // a <= b
+          int t = 0;
+          for (int q = 0; q < a; q++) t += 6 - q;
+          v += HP[slot * 27 + t + (b - a)];
+        }
+        v *= sc[r] * sc[c];
+        if (r == c) v += Dd[r];
+        A[r * ld + c] = v;
+      }
   }
   for (int i = tid; i < n; i += 256) A[n * ld + i] = gpp[i] - sc[i] * G[(long long)i * B.Mpad + n];
   gm = wave_max(gm);
@@ -713,35 +796,87 @@ __global__ __launch_bounds__(256) void k_ba_solve(BaDev B) {
   }
   __syncthreads();
   if (s_stop) return;
-  // Square-root-free Cholesky (L D L^T) of the damped reduced camera system with the rhs carried as
-  // row n, i.e. the forward substitution happens inside the elimination.  One barrier per column.
-  for (int j = 0; j < n; j++) {
-    const double pv = A[j * ld + j];
-    if (!(pv > 0.0) || !isfinite(pv)) {  // uniform: every thread reads the same pivot
-      if (tid == 0) s_fail = 1;
-      break;
+  STAMP(2);
+  // Blocked (6x6) right-looking L D L^T with the rhs carried as row n (forward substitution for
+  // free).  Rows below the diagonal block store u_rt = l_rt d_t.  Per block column: every thread
+  // factors the diagonal block redundantly in registers (no barrier needed for it), one thread per
+  // panel row does its substitution, barrier, rank-6 trailing update, barrier.
+  double *rdv = Ldg + nb * 21;  // 1/d_j of all n pivots
+  bool ok_all = true;
+  for (int k = 0; k < nb; k++) {
+    const int K0 = 6 * k;
+    double L[21], rd[6];
+#pragma unroll
+    for (int i = 0; i < 6; i++)
+#pragma unroll
+      for (int j = 0; j <= i; j++) L[i * (i + 1) / 2 + j] = A[(K0 + i) * ld + K0 + j];
+    ok_all = ldl6_packed(L, rd) && ok_all;
+    // static indices only: a runtime-indexed register array would be demoted to scratch memory
+    if (tid == 0) {
+#pragma unroll
+      for (int i = 0; i < 21; i++) Ldg[k * 21 + i] = L[i];
+#pragma unroll
+      for (int i = 0; i < 6; i++) rdv[K0 + i] = rd[i];
     }
-    const double ip = 1.0 / pv;
-    const int cols = n - 1 - j, rows = n - j;  // columns j+1..n-1, rows j+1..n
-    for (int t = tid; t < rows * cols; t += 256) {
-      const int r = j + 1 + t / cols, c = j + 1 + t % cols;
-      if (c <= r) A[r * ld + c] -= A[r * ld + j] * A[c * ld + j] * ip;
+    for (int r = K0 + 6 + tid; r <= n; r += 256) {  // u_rt = A[r][t] - sum_{q<t} u_rq l_tq
+      double x[6];
+#pragma unroll
+      for (int t = 0; t < 6; t++) {
+        double v = A[r * ld + K0 + t];
+#pragma unroll
+        for (int q = 0; q < t; q++) v -= x[q] * L[t * (t + 1) / 2 + q];
+        x[t] = v;
+      }
+#pragma unroll
+      for (int t = 0; t < 6; t++) A[r * ld + K0 + t] = x[t];
+    }
+    __syncthreads();
+    {
+      const int tx = tid & 15, ty = tid >> 4;
+      for (int r = K0 + 6 + ty; r <= n; r += 16) {
+        double w[6];
+#pragma unroll
+        for (int t = 0; t < 6; t++) w[t] = A[r * ld + K0 + t] * rd[t];
+        for (int c = K0 + 6 + tx; c <= r && c < n; c += 16) {
+          double acc = 0;
+#pragma unroll
+          for (int t = 0; t < 6; t++) acc += w[t] * A[c * ld + K0 + t];
+          A[r * ld + c] -= acc;
+        }
+      }
     }
     __syncthreads();
   }
+  if (!ok_all && tid == 0) s_fail = 1;  // every thread saw the same pivots
   __syncthreads();
-  const int fail = s_fail;
-  if (!fail) {
-    for (int j = n - 1; j >= 0; j--) {  // back substitution, column oriented
-      const double yj = A[n * ld + j] / A[j * ld + j];
-      if (tid == 0) y[j] = yj;
-      for (int i = tid; i < j; i += 256) A[n * ld + i] -= A[j * ld + i] * yj;
-      __syncthreads();
+  STAMP(3);
+  // back substitution  L^T y = D^-1 w  (w = row n), block by block from the bottom; row n keeps
+  // w_i - sum_{r>i} u_ri y_r and is scaled by 1/d_i when its block is solved
+  for (int k = nb - 1; k >= 0; k--) {
+    const int K0 = 6 * k;
+    double L[21], yk[6];
+#pragma unroll
+    for (int i = 0; i < 21; i++) L[i] = Ldg[k * 21 + i];
+#pragma unroll
+    for (int t = 5; t >= 0; t--) {
+      double v = A[n * ld + K0 + t] * rdv[K0 + t];
+#pragma unroll
+      for (int q = t + 1; q < 6; q++) v -= L[q * (q + 1) / 2 + t] * yk[q];
+      yk[t] = v;
     }
-  } else {
-    for (int i = tid; i < n; i += 256) y[i] = 0.0;
+    if (tid == 0) {
+#pragma unroll
+      for (int i = 0; i < 6; i++) y[K0 + i] = yk[i];
+    }
+    for (int i = tid; i < K0; i += 256) {
+      double acc = 0;
+#pragma unroll
+      for (int t = 0; t < 6; t++) acc += A[(K0 + t) * ld + i] * yk[t];
+      A[n * ld + i] -= acc;
+    }
     __syncthreads();
   }
+  STAMP(4);
   // camera part of  g''.step  and  step^T D step  (step = -y)
   double gdot = 0, dquad = 0;
   int bad = 0;
@@ -755,6 +890,7 @@ __global__ __launch_bounds__(256) void k_ba_solve(BaDev B) {
   if (bad) s_fail = 1;
   __syncthreads();
   const int failed = s_fail;
+  STAMP(5);
   // candidate poses (PoseLocalParameterization::Plus) + their caches + norms
   const double *X = B.Xc[S->cur];
   double *Xn = B.Xc[S->cur ^ 1];
@@ -780,6 +916,7 @@ __global__ __launch_bounds__(256) void k_ba_solve(BaDev B) {
       }
     }
   }
+  STAMP(6);
   double v5[5] = {gdot, dquad, xn2, cn2, sn2};
   block_sum<5>(v5, red);
   if (tid == 0) {
@@ -790,6 +927,7 @@ __global__ __launch_bounds__(256) void k_ba_solve(BaDev B) {
     S->step_norm2_c = v5[4];
     S->solve_failed = failed;
   }
+  STAMP(7);
 }
 
 // --------------------------------------------------------------------------------------------
@@ -860,7 +998,10 @@ __global__ __launch_bounds__(256) void k_ba_backsub(BaDev B) {
     }
   }
   block_sum<6>(v, lds);
-  if (tid < 6) B.slab_bs[6 * blockIdx.x + tid] = v[tid];
+  if (tid == 0) {
+#pragma unroll
+    for (int i = 0; i < 6; i++) B.slab_bs[6 * blockIdx.x + i] = v[i];
+  }
 }
 
 __global__ __launch_bounds__(64) void k_ba_reduce2(BaDev B) {
@@ -879,9 +1020,25 @@ __global__ __launch_bounds__(64) void k_ba_reduce2(BaDev B) {
 // --------------------------------------------------------------------------------------------
 // k_ba_update: TrustRegionMinimizer step evaluation + LevenbergMarquardtStrategy radius update
 // --------------------------------------------------------------------------------------------
-__global__ void k_ba_update(BaDev B) {
+__global__ __launch_bounds__(64) void k_ba_update(BaDev B, int fused_reduce) {
   BaState *S = B.st;
-  if (S->done || threadIdx.x != 0 || blockIdx.x != 0) return;
+  if (S->done) return;
+  if (fused_reduce) {  // single shard: sum the back-substitution slabs here instead of k_ba_reduce2
+    const int t = threadIdx.x;
+    double v[6] = {0, 0, 0, 0, 0, 0};
+    for (int b = t; b < B.n_pblocks; b += 64)
+#pragma unroll
+      for (int i = 0; i < 6; i++) v[i] += B.slab_bs[6 * b + i];
+#pragma unroll
+    for (int i = 0; i < 6; i++) v[i] = wave_sum(v[i]);
+    if (t == 0) {
+#pragma unroll
+      for (int i = 0; i < 6; i++) B.payload2[i] = v[i];
+    }
+    __threadfence_block();
+    __syncthreads();
+  }
+  if (threadIdx.x != 0) return;
   const double *p = B.payload2;
   const double cand_cost = p[0];
   const double model = -0.5 * (S->gdot_c + p[1]) + 0.5 * (S->dquad_c + p[2]);
@@ -934,9 +1091,10 @@ __global__ void k_ba_update(BaDev B) {
   }
 }
 
-__global__ void k_ba_begin(BaDev B, int max_it) {
+__global__ void k_ba_begin(BaDev B, int max_it, int archive_slot) {
   if (threadIdx.x != 0 || blockIdx.x != 0) return;
   BaState *S = B.st;
+  if (archive_slot >= 0) B.hist[archive_slot] = *S;
   const int cur = S->cur;
   memset(S, 0, sizeof(BaState));
   S->cur = cur;
@@ -1024,10 +1182,11 @@ struct vo_ba {
   BaDev D{};
   vo::DevBuf b_ecam, b_ept, b_eobs, b_eis, b_eact, b_ptstart, b_local, b_camslot, b_slotcam, b_camstart,
       b_camedges, b_ptin, b_camin, b_xc0, b_xc1, b_xp0, b_xp1, b_pc0, b_pc1, b_sc, b_sp, b_hinv, b_gl2, b_dl, b_wt, b_yt,
-      b_sgemm, b_scam, b_spt, b_payload, b_zc, b_sbs, b_payload2, b_state, b_out;
+      b_sgemm, b_scam, b_spt, b_payload, b_zc, b_sbs, b_payload2, b_state, b_out, b_dbg;
   size_t solve_lds = 0;
   int lm_max_it = 0;
   double *ext_payload = nullptr, *ext_payload2 = nullptr;
+  int archive_slot = -1;
 };
 
 namespace {
@@ -1073,10 +1232,10 @@ int build_device(vo_ba *h) {
   }
   D.n_pblocks = std::max(1, (D.n_local + kPtsPerBlock - 1) / kPtsPerBlock);
   const int K = 3 * h->n_pts;
-  const int tiles = (D.Mpad / 16) * (D.Mpad / 16);
-  int ks = std::max(1, std::min(16, 512 / tiles));
-  ks = std::min(ks, std::max(1, K / 64));
-  D.kchunk = ((K + ks - 1) / ks + 3) / 4 * 4;
+  const int tiles = (D.Mpad / 16) * (D.Mpad / 16 + 1) / 2;
+  int ks = std::max(1, std::min(8, 128 / tiles));  // <= 8 slabs: one load batch in k_ba_reduce
+  ks = std::min(ks, std::max(1, K / 128));
+  D.kchunk = ((K + ks - 1) / ks + 15) / 16 * 16;
   D.ksplit = std::max(1, (K + D.kchunk - 1) / D.kchunk);
   VO_CHECK(upload(h->b_ecam, h->e_cam.data(), h->e_cam.size() * 4));
   VO_CHECK(upload(h->b_ept, h->e_pt.data(), h->e_pt.size() * 4));
@@ -1105,6 +1264,9 @@ int build_device(vo_ba *h) {
   VO_CHECK(h->b_dl.reserve((size_t)std::max(1, h->n_pts) * 3 * 8));
   VO_CHECK(h->b_wt.reserve((size_t)std::max(1, K) * D.Mpad * 8));
   VO_CHECK(h->b_yt.reserve((size_t)std::max(1, K) * D.Mpad * 8));
+  // operand matrices start out all-zero; only (point, camera) pairs that have an edge are ever written
+  VO_HIP_CHECK(hipMemset(h->b_wt.p, 0, (size_t)std::max(1, K) * D.Mpad * 8));
+  VO_HIP_CHECK(hipMemset(h->b_yt.p, 0, (size_t)std::max(1, K) * D.Mpad * 8));
   VO_CHECK(h->b_sgemm.reserve((size_t)D.ksplit * D.Mpad * D.Mpad * 8));
   VO_CHECK(h->b_scam.reserve((size_t)std::max(1, h->nf) * D.n_cchunks * 27 * 8));
   VO_CHECK(h->b_spt.reserve((size_t)D.n_pblocks * 2 * 8));
@@ -1112,8 +1274,10 @@ int build_device(vo_ba *h) {
   VO_CHECK(h->b_zc.reserve((size_t)std::max(1, 6 * h->nf) * 8));
   VO_CHECK(h->b_sbs.reserve((size_t)D.n_pblocks * 6 * 8));
   VO_CHECK(h->b_payload2.reserve(64));
-  VO_CHECK(h->b_state.reserve(sizeof(BaState)));
-  VO_HIP_CHECK(hipMemset(h->b_state.p, 0, sizeof(BaState)));
+  VO_CHECK(h->b_state.reserve(3 * sizeof(BaState)));
+  VO_CHECK(h->b_dbg.reserve(64 * 8));
+  D.dbg = h->b_dbg.as<unsigned long long>();
+  VO_HIP_CHECK(hipMemset(h->b_state.p, 0, 3 * sizeof(BaState)));
   D.e_cam = h->b_ecam.as<int>(), D.e_pt = h->b_ept.as<int>();
   D.e_obs = h->b_eobs.as<double>(), D.e_is = h->b_eis.as<double>();
   D.e_active = h->b_eact.as<uint8_t>();
@@ -1133,8 +1297,9 @@ int build_device(vo_ba *h) {
   D.slab_bs = h->b_sbs.as<double>();
   D.payload2 = h->ext_payload2 ? h->ext_payload2 : h->b_payload2.as<double>();
   D.st = h->b_state.as<BaState>();
+  D.hist = D.st + 1;
   const int n = 6 * h->nf;
-  h->solve_lds = ((size_t)(n + 1) * (n + 1) + 4 * n + 64) * 8;
+  h->solve_lds = ((size_t)(n + 1) * (n + 1) + 5 * n + (size_t)h->nf * 21 + 64) * 8;
   if (h->solve_lds > 64 * 1024)
     VO_HIP_CHECK(hipFuncSetAttribute((const void *)k_ba_solve, hipFuncAttributeMaxDynamicSharedMemorySize,
                                      (int)h->solve_lds));
@@ -1148,19 +1313,20 @@ int lm_begin(vo_ba *h, double hm, double hs, int max_it, const uint8_t *active_c
   D.hm = hm, D.hs = hs;
   hipStream_t st = h->stream;
   if (!keep_device_mask) {
-    std::vector<uint8_t> act(std::max(1, h->n_edges), 1);
-    if (active_caller)
+    if (!active_caller) {
+      VO_HIP_CHECK(hipMemsetAsync(D.e_active, 1, std::max(1, h->n_edges), st));
+    } else {
+      std::vector<uint8_t> act(std::max(1, h->n_edges), 1);
       for (int e = 0; e < h->n_edges; e++) act[e] = active_caller[h->perm[e]] ? 1 : 0;
-    VO_HIP_CHECK(hipMemcpyAsync(D.e_active, act.data(), h->n_edges, hipMemcpyHostToDevice, st));
-    VO_HIP_CHECK(hipStreamSynchronize(st));  // act is a stack-lifetime buffer
+      VO_HIP_CHECK(hipMemcpyAsync(D.e_active, act.data(), h->n_edges, hipMemcpyHostToDevice, st));
+      VO_HIP_CHECK(hipStreamSynchronize(st));  // act is a stack-lifetime buffer
+    }
   }
   VO_HIP_CHECK(hipMemsetAsync(D.pt_in, 0, std::max(1, h->n_pts), st));
   VO_HIP_CHECK(hipMemsetAsync(D.cam_in, 0, std::max(1, h->n_cams), st));
-  VO_HIP_CHECK(hipMemsetAsync(D.Wt, 0, (size_t)std::max(1, 3 * h->n_pts) * D.Mpad * 8, st));
-  VO_HIP_CHECK(hipMemsetAsync(D.Yt, 0, (size_t)std::max(1, 3 * h->n_pts) * D.Mpad * 8, st));
   if (h->n_edges > 0)
     hipLaunchKernelGGL(k_ba_mark, dim3((h->n_edges + 255) / 256), dim3(256), 0, st, D);
-  hipLaunchKernelGGL(k_ba_begin, dim3(1), dim3(1), 0, st, D, max_it);
+  hipLaunchKernelGGL(k_ba_begin, dim3(1), dim3(1), 0, st, D, max_it, h->archive_slot);
   hipLaunchKernelGGL(k_ba_posecache, dim3((h->n_cams + 63) / 64), dim3(64), 0, st, D);
   VO_HIP_CHECK(hipGetLastError());
   h->lm_max_it = max_it;
@@ -1171,9 +1337,9 @@ int launch_linearize(vo_ba *h) {
   BaDev &D = h->D;
   hipStream_t st = h->stream;
   hipLaunchKernelGGL(k_ba_linearize, dim3(D.n_pblocks + h->nf * D.n_cchunks), dim3(256), 0, st, D);
-  const int tiles = (D.Mpad / 16) * (D.Mpad / 16);
-  hipLaunchKernelGGL(k_ba_gemm, dim3(tiles, D.ksplit), dim3(64), 0, st, D);
-  const int np = D.Mpad * D.Mpad + h->nf * 27 + 1;
+  const int tdim = D.Mpad / 16, tiles = tdim * (tdim + 1) / 2;
+  hipLaunchKernelGGL(k_ba_gemm, dim3(tiles, D.ksplit), dim3(256), 0, st, D);
+  const int np = (D.Mpad * D.Mpad + h->nf * 27 + 1) * 4;
   hipLaunchKernelGGL(k_ba_reduce, dim3((np + 255) / 256), dim3(256), 0, st, D);
   VO_HIP_CHECK(hipGetLastError());
   return VO_OK;
@@ -1183,12 +1349,12 @@ int launch_step(vo_ba *h) {
   hipStream_t st = h->stream;
   hipLaunchKernelGGL(k_ba_solve, dim3(1), dim3(256), h->solve_lds, st, D);
   hipLaunchKernelGGL(k_ba_backsub, dim3(D.n_pblocks), dim3(256), 0, st, D);
-  hipLaunchKernelGGL(k_ba_reduce2, dim3(1), dim3(64), 0, st, D);
+  if (h->n_shards > 1) hipLaunchKernelGGL(k_ba_reduce2, dim3(1), dim3(64), 0, st, D);
   VO_HIP_CHECK(hipGetLastError());
   return VO_OK;
 }
 int launch_update(vo_ba *h) {
-  hipLaunchKernelGGL(k_ba_update, dim3(1), dim3(1), 0, h->stream, h->D);
+  hipLaunchKernelGGL(k_ba_update, dim3(1), dim3(64), 0, h->stream, h->D, h->n_shards > 1 ? 0 : 1);
   VO_HIP_CHECK(hipGetLastError());
   return VO_OK;
 }
@@ -1342,7 +1508,7 @@ void vo_ba_destroy(vo_ba *h) {
                         &h->b_camslot, &h->b_slotcam, &h->b_camstart, &h->b_camedges, &h->b_ptin, &h->b_camin,
                         &h->b_xc0, &h->b_xc1, &h->b_xp0, &h->b_xp1, &h->b_pc0, &h->b_pc1, &h->b_sc, &h->b_sp, &h->b_hinv, &h->b_gl2,
                         &h->b_dl, &h->b_wt, &h->b_yt, &h->b_sgemm, &h->b_scam, &h->b_spt, &h->b_payload, &h->b_zc,
-                        &h->b_sbs, &h->b_payload2, &h->b_state, &h->b_out})
+                        &h->b_sbs, &h->b_payload2, &h->b_state, &h->b_out, &h->b_dbg})
     b->release();
   if (h->own_stream) (void)hipStreamDestroy(h->stream);
   delete h;
@@ -1429,30 +1595,54 @@ int vo_ba_solve(vo_ba *h, double hm, double hs, int max_it, const uint8_t *edge_
   return lm_end(h, sum);
 }
 
+static void summary_from_state(const BaState &s, vo_lm_summary *sum) {
+  sum->iterations = s.iter;
+  sum->accepted = s.accepted;
+  sum->termination = s.termination;
+  sum->reserved = 0;
+  sum->initial_cost = s.initial_cost;
+  sum->final_cost = s.x_cost;
+  sum->final_radius = s.radius;
+}
+
 int vo_ba_local_ba(vo_ba *h, const volatile int *stop, uint8_t *edge_erase, vo_lm_summary *sums) {
   if (!h || !edge_erase) return VO_ERR_INVALID;
   for (int e = 0; e < h->n_edges; e++) edge_erase[e] = 0;
   if (stop && *stop) return VO_ERR_STOPPED;  // :594-595 (no write-back, Q-B8)
+  // The whole schedule is queued without a host synchronisation in between; the stop flag is
+  // polled where the reference polls it (:612), which here is at enqueue time of problem 2.
+  h->archive_slot = -1;
   VO_CHECK(lm_begin(h, (double)sqrtf(5.991f), (double)sqrtf(7.815f), 5, nullptr, false));
   VO_CHECK(run_lm(h, 5));
-  VO_CHECK(lm_end(h, sums ? &sums[0] : nullptr));
   uint8_t *out = h->b_out.as<uint8_t>();
   VO_HIP_CHECK(hipMemsetAsync(out, 0, std::max(1, h->n_edges), h->stream));
   const dim3 eg((std::max(1, h->n_edges) + 255) / 256);
+  bool second = false;
   if (!(stop && *stop)) {  // :612
     hipLaunchKernelGGL(k_ba_classify, eg, dim3(256), 0, h->stream, h->D, 0, out);
+    h->archive_slot = 0;  // problem 1's final state is archived by problem 2's begin kernel
     VO_CHECK(lm_begin(h, 0.0, 0.0, 10, nullptr, true));
+    h->archive_slot = -1;
     VO_CHECK(run_lm(h, 10));
-    VO_CHECK(lm_end(h, sums ? &sums[1] : nullptr));
-  } else if (sums) {
-    memset(&sums[1], 0, sizeof(vo_lm_summary));
+    second = true;
   }
   hipLaunchKernelGGL(k_ba_classify, eg, dim3(256), 0, h->stream, h->D, 1, out);
   VO_HIP_CHECK(hipGetLastError());
   std::vector<uint8_t> tmp(std::max(1, h->n_edges));
+  BaState st[3];
   VO_HIP_CHECK(hipMemcpyAsync(tmp.data(), out, h->n_edges, hipMemcpyDeviceToHost, h->stream));
+  VO_HIP_CHECK(hipMemcpyAsync(st, h->D.st, 3 * sizeof(BaState), hipMemcpyDeviceToHost, h->stream));
   VO_HIP_CHECK(hipStreamSynchronize(h->stream));
   for (int s = 0; s < h->n_edges; s++) edge_erase[h->perm[s]] = tmp[s];
+  if (sums) {
+    if (second) {
+      summary_from_state(st[1], &sums[0]);
+      summary_from_state(st[0], &sums[1]);
+    } else {
+      summary_from_state(st[0], &sums[0]);
+      memset(&sums[1], 0, sizeof(vo_lm_summary));
+    }
+  }
   return VO_OK;
 }
 
@@ -1482,6 +1672,13 @@ int vo_ba_get_edge_outliers(vo_ba *h, uint8_t *edge_erase) {
   return VO_OK;
 }
 
+int vo_ba_debug_stamps(vo_ba *h, unsigned long long *out /*8*/) {
+  if (!h || !h->built) return VO_ERR_INVALID;
+  VO_HIP_CHECK(hipStreamSynchronize(h->stream));
+  VO_HIP_CHECK(hipMemcpy(out, h->b_dbg.p, 64, hipMemcpyDeviceToHost));
+  return VO_OK;
+}
+
 int vo_ba_debug_schur(vo_ba *h, double hm, double hs, double point_damping, const uint8_t *edge_active, double *S,
                       double *b, double *cost) {
   // undamped reduced system: run the linearisation kernels with a huge radius (D -> clamp/1e300 ~ 0)
@@ -1502,7 +1699,7 @@ int vo_ba_debug_schur(vo_ba *h, double hm, double hs, double point_damping, cons
   const double *HP = pay.data() + (size_t)M * M;
   for (int r = 0; r < n; r++) {
     for (int c = 0; c < n; c++) {
-      double v = -pay[(size_t)r * M + c];
+      double v = -pay[(size_t)std::min(r, c) * M + std::max(r, c)];  // only upper tiles are produced
       if (r / 6 == c / 6) {
         const int slot = r / 6, a = std::min(r % 6, c % 6), bb = std::max(r % 6, c % 6);
         int t = 0;

@@ -36,14 +36,16 @@ VO_HD Se3 se3_exp(const double xi[6]) {
   const double wx = xi[3], wy = xi[4], wz = xi[5];
   const double theta = sqrt(wx * wx + wy * wy + wz * wz);
   const double half = 0.5 * theta;
+  double sh, ch;
+  sincos(half, &sh, &ch);  // one range reduction for both; sin/cos(theta) follow from the half angle
   double imag;
   if (theta < kSmallEps) {
     const double t2 = theta * theta;
     imag = 0.5 - 0.0208333 * t2 + 0.000260417 * t2 * t2;
   } else {
-    imag = sin(half) / theta;
+    imag = sh / theta;
   }
-  T.q[0] = cos(half), T.q[1] = imag * wx, T.q[2] = imag * wy, T.q[3] = imag * wz;
+  T.q[0] = ch, T.q[1] = imag * wx, T.q[2] = imag * wy, T.q[3] = imag * wz;
   quat_normalize(T.q);
   // V = I + a*Om + b*Om^2 ;  V*u = u + a (w x u) + b (w x (w x u))
   const double u[3] = {xi[0], xi[1], xi[2]};
@@ -53,7 +55,7 @@ VO_HD Se3 se3_exp(const double xi[6]) {
     quat_rotate(T.q, u, T.t);  // V = R in the small-angle branch
   } else {
     const double t2 = theta * theta;
-    const double a = (1 - cos(theta)) / t2, b = (theta - sin(theta)) / (t2 * theta);
+    const double a = (2.0 * sh * sh) / t2, b = (theta - 2.0 * sh * ch) / (t2 * theta);  // 1-cos = 2 sin^2(t/2)
     T.t[0] = u[0] + a * wxu[0] + b * wwxu[0];
     T.t[1] = u[1] + a * wxu[1] + b * wwxu[1];
     T.t[2] = u[2] + a * wxu[2] + b * wwxu[2];
@@ -72,7 +74,8 @@ VO_HD void se3_log(const Se3 &T, double xi[6]) {
     f = 2 * atan(n / w) / n;
   const double theta = f * n;
   const double wx = f * T.q[1], wy = f * T.q[2], wz = f * T.q[3];
-  const double c = (theta < kSmallEps) ? (1. / 12.) : (1 - theta / (2 * tan(theta / 2))) / (theta * theta);
+  // theta/2 = atan(n/w)  =>  tan(theta/2) = n/w: no second transcendental
+  const double c = (theta < kSmallEps) ? (1. / 12.) : (1 - theta * w / (2 * n)) / (theta * theta);
   const double *t = T.t;
   const double wxt[3] = {wy * t[2] - wz * t[1], wz * t[0] - wx * t[2], wx * t[1] - wy * t[0]};
   const double wwxt[3] = {wy * wxt[2] - wz * wxt[1], wz * wxt[0] - wx * wxt[2], wx * wxt[1] - wy * wxt[0]};
@@ -111,7 +114,8 @@ VO_HD PoseCache pose_cache(const double se3[6]) {
   const double theta2 = a0 * a0 + a1 * a1 + a2 * a2;
   if (theta2 > kDblEps) {
     const double theta = sqrt(theta2);
-    const double c = cos(theta), s = sin(theta);
+    double s, c;
+    sincos(theta, &s, &c);
     const double wx = a0 / theta, wy = a1 / theta, wz = a2 / theta;
     P.R[0] = c + wx * wx * (1.0 - c);
     P.R[3] = wz * s + wx * wy * (1.0 - c);
