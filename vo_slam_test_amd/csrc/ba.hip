@@ -63,6 +63,33 @@ __device__ __forceinline__ void block_sum(double (&v)[N], double *lds /*>= 4*N*/
   }
 }
 
+// Inter-workgroup hand-off ("last block reduces") without fences, MI355X guide Guideline 16 form
+// R1: EVERY handed-off byte is stored write-through (agent-scope relaxed atomic store = `sc1`) and
+// loaded with an agent-scope relaxed atomic load (`sc1`, bypasses this CU's L1); every storing wave
+// drains its stores (s_waitcnt vmcnt(0)), the block barriers, one lane takes a ticket with a relaxed
+// agent-scope add.  The block that draws the last ticket reads the others' data.  Placement
+// independent: per-XCD L2s are not coherent and a CU's L1 is never refreshed by other CUs.
+__device__ __forceinline__ void st_sc1(double *p, double v) {
+  __hip_atomic_store(reinterpret_cast<unsigned long long *>(p), __double_as_longlong(v), __ATOMIC_RELAXED,
+                     __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ double ld_sc1(const double *p) {
+  return __longlong_as_double(__hip_atomic_load(reinterpret_cast<const unsigned long long *>(p), __ATOMIC_RELAXED,
+                                                __HIP_MEMORY_SCOPE_AGENT));
+}
+__device__ __forceinline__ bool arrive_and_check_last(unsigned int *counter, unsigned int expected, int *s_flag) {
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const unsigned int t = __hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const int last = (t == expected - 1u);
+    if (last) __hip_atomic_store(counter, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // re-arm
+    *s_flag = last;
+  }
+  __syncthreads();
+  return *s_flag != 0;
+}
+
 // ============================================================================================
 // Pose-only BA: Optimizer::solvePoseOnlySE3 (optimizer_ceres.cpp:157-314), one workgroup per frame
 // ============================================================================================
@@ -379,6 +406,8 @@ struct BaDev {
   unsigned long long *dbg;  // optional stamps (VO_BA_STAMPS builds)
   BaState *st;
   BaState *hist;            // [2] states of earlier solves of the same schedule
+  unsigned int *counters;   // [0] back-substitution arrivals, [1 + tile] GEMM K-slice arrivals
+  int fused;                // single shard: in-kernel reductions replace k_ba_reduce / k_ba_reduce2
 };
 
 __device__ __forceinline__ PoseCache load_pc(const double *pc, int c) {
@@ -625,7 +654,21 @@ __global__ __launch_bounds__(256) void k_ba_gemm(BaDev B) {
   __syncthreads();
   const int t = threadIdx.x;  // element (t>>4, t&15) of the tile, fixed summation order
   const double v = (part[0][t] + part[1][t]) + (part[2][t] + part[3][t]);
-  B.slab_gemm[(long long)ks * B.Mpad * B.Mpad + (long long)(tm * 16 + (t >> 4)) * B.Mpad + tn * 16 + (t & 15)] = v;
+  const long long eoff = (long long)(tm * 16 + (t >> 4)) * B.Mpad + tn * 16 + (t & 15);
+  if (!B.fused) {
+    B.slab_gemm[(long long)ks * B.Mpad * B.Mpad + eoff] = v;
+    return;
+  }
+  st_sc1(&B.slab_gemm[(long long)ks * B.Mpad * B.Mpad + eoff], v);
+  __shared__ int s_last;
+  if (!arrive_and_check_last(&B.counters[1 + blockIdx.x], gridDim.y, &s_last)) return;
+  double sv[8];
+#pragma unroll
+  for (int u = 0; u < 8; u++) sv[u] = u < B.ksplit ? ld_sc1(&B.slab_gemm[(long long)u * B.Mpad * B.Mpad + eoff]) : 0.0;
+  double sum = 0;
+#pragma unroll
+  for (int u = 0; u < 8; u++) sum += sv[u];  // slab order: deterministic
+  B.payload[eoff] = sum;
 }
 
 // fixed-order reduction of the slabs into the payload that a multi-GPU run all-reduces
@@ -729,7 +772,52 @@ __global__ __launch_bounds__(256) void k_ba_solve(BaDev B) {
   double *red = Ldg + nb * 21 + n;  // 64 scratch (after the n reciprocal pivots)
   __shared__ int s_fail, s_stop;
   const double *G = B.payload;
-  const double *HP = B.payload + payload_hpp_off(B);
+  double *HPw = B.payload + payload_hpp_off(B);
+  // issue this thread's loads of the Schur product early (they only depend on k_ba_gemm); they are
+  // consumed after the slab sums and the scale setup, hiding one memory round trip
+  constexpr int kPref = 8;
+  double gpre[kPref];
+  {
+    const int tx = tid & 15, ty = tid >> 4;
+    int q = 0;
+    for (int c = ty; c < n && q < kPref; c += 16)
+      for (int r = c - (c & 15) + tx; r < n && q < kPref; r += 16) {
+        if (r < c) continue;
+        gpre[q++] = G[(long long)c * B.Mpad + r];
+      }
+    for (; q < kPref; q++) gpre[q] = 0;
+  }
+  if (B.fused) {  // no k_ba_reduce in this mode: sum the camera-block and cost slabs here
+    for (int i = tid; i < B.nf * 27; i += 256) {
+      const int slot = i / 27, t = i - slot * 27;
+      const double *sp = B.slab_cam + (long long)slot * B.n_cchunks * 27 + t;
+      double a = 0;
+      int c = 0;
+      for (; c + 4 <= B.n_cchunks; c += 4) {  // four loads in flight, summed in chunk order
+        const double v0 = sp[c * 27], v1 = sp[(c + 1) * 27], v2 = sp[(c + 2) * 27], v3 = sp[(c + 3) * 27];
+        a += v0, a += v1, a += v2, a += v3;
+      }
+      for (; c < B.n_cchunks; c++) a += sp[c * 27];
+      HPw[i] = a;
+    }
+    if (tid >= 192) {  // last wave: cost (sum) and gradient max over the point blocks
+      const int l = tid - 192;
+      double cs = 0, m = 0;
+      for (int b = l; b < B.n_pblocks; b += 64) {
+        cs += B.slab_pt[2 * b];
+        m = fmax(m, B.slab_pt[2 * b + 1]);
+      }
+      cs = wave_sum(cs);
+      m = wave_max(m);
+      if (l == 0) {
+        HPw[B.nf * 27] = cs;
+        HPw[B.nf * 27 + 1] = m;
+      }
+    }
+    __threadfence_block();
+    __syncthreads();
+  }
+  const double *HP = HPw;
   const int first = S->first;
   const double radius = S->radius;
   if (tid == 0) s_fail = 0, s_stop = 0;
@@ -757,10 +845,12 @@ __global__ __launch_bounds__(256) void k_ba_solve(BaDev B) {
   // S'' = diag(sc) (Hpp - Y W^T) diag(sc) + D, lower triangle; the GEMM delivers the upper tiles
   {
     const int tx = tid & 15, ty = tid >> 4;  // lanes run along r: contiguous reads of G[c][r..]
+    int q = 0;
     for (int c = ty; c < n; c += 16)
       for (int r = c - (c & 15) + tx; r < n; r += 16) {
         if (r < c) continue;
-        double v = -G[(long long)c * B.Mpad + r];
+        double v = q < kPref ? -gpre[q] : -G[(long long)c * B.Mpad + r];
+        q++;
         if (r / 6 == c / 6) {
           const int slot = r / 6, a = c % 6, b = r % 6;  // a <= b
           int t = 0;
@@ -930,6 +1020,61 @@ __global__ __launch_bounds__(256) void k_ba_solve(BaDev B) {
   STAMP(7);
 }
 
+// TrustRegionMinimizer step evaluation + LevenbergMarquardtStrategy radius update (one thread)
+__device__ void ba_update_logic(const BaDev &B) {
+  BaState *S = B.st;
+  const double *p = B.payload2;
+  const double cand_cost = p[0];
+  const double model = -0.5 * (S->gdot_c + p[1]) + 0.5 * (S->dquad_c + p[2]);
+  const double step_norm = sqrt(S->step_norm2_c + p[3]);
+  const double x_norm = sqrt(S->x_norm2_c + p[4]);
+  S->cand_cost = cand_cost;
+  S->last_ok = 0;
+  if (S->solve_failed || !(model > 0.0) || !isfinite(model)) {
+    if (++S->invalid >= 5) {
+      S->termination = 4;
+      S->done = 1;
+      return;
+    }
+    S->radius /= S->decrease;
+    S->decrease *= 2.0;
+  } else {
+    S->invalid = 0;
+    const double cc = isfinite(cand_cost) ? cand_cost : 1.7976931348623157e308;
+    if (step_norm <= 1e-8 * (x_norm + 1e-8)) {
+      S->termination = 2;
+      S->done = 1;
+      return;
+    }
+    const double change = S->x_cost - cc;
+    if (fabs(change) <= 1e-6 * S->x_cost) {
+      S->termination = 1;
+      S->done = 1;
+      return;
+    }
+    const double rel = change / model;
+    if (rel > 1e-3) {
+      S->cur ^= 1;
+      S->x_cost = cc;
+      const double t2 = 2.0 * rel - 1.0;
+      S->radius = fmin(S->radius / fmax(1.0 / 3.0, 1.0 - t2 * t2 * t2), 1e16);
+      S->decrease = 2.0;
+      S->accepted += 1;
+      S->last_ok = 1;
+    } else {
+      S->radius /= S->decrease;
+      S->decrease *= 2.0;
+    }
+  }
+  if (S->iter >= S->max_it) {
+    S->termination = 0;
+    S->done = 1;
+  } else if (S->radius < 1e-32) {
+    S->termination = 4;
+    S->done = 1;
+  }
+}
+
 // --------------------------------------------------------------------------------------------
 // k_ba_backsub: SchurEliminator::BackSubstitute, candidate points and the candidate cost
 // --------------------------------------------------------------------------------------------
@@ -1000,7 +1145,30 @@ __global__ __launch_bounds__(256) void k_ba_backsub(BaDev B) {
   block_sum<6>(v, lds);
   if (tid == 0) {
 #pragma unroll
-    for (int i = 0; i < 6; i++) B.slab_bs[6 * blockIdx.x + i] = v[i];
+    for (int i = 0; i < 6; i++) {
+      if (B.fused)
+        st_sc1(&B.slab_bs[6 * blockIdx.x + i], v[i]);
+      else
+        B.slab_bs[6 * blockIdx.x + i] = v[i];
+    }
+  }
+  if (!B.fused) return;
+  // single shard: the last block to arrive sums the slabs (fixed order) and runs the update
+  __shared__ int s_last;
+  if (!arrive_and_check_last(&B.counters[0], gridDim.x, &s_last)) return;
+  if (tid < 64) {
+    double a[6] = {0, 0, 0, 0, 0, 0};
+    for (int b = tid; b < B.n_pblocks; b += 64)
+#pragma unroll
+      for (int i = 0; i < 6; i++) a[i] += ld_sc1(&B.slab_bs[6 * b + i]);
+#pragma unroll
+    for (int i = 0; i < 6; i++) a[i] = wave_sum(a[i]);
+    if (tid == 0) {
+#pragma unroll
+      for (int i = 0; i < 6; i++) B.payload2[i] = a[i];
+      __threadfence_block();
+      ba_update_logic(B);
+    }
   }
 }
 
@@ -1020,82 +1188,19 @@ __global__ __launch_bounds__(64) void k_ba_reduce2(BaDev B) {
 // --------------------------------------------------------------------------------------------
 // k_ba_update: TrustRegionMinimizer step evaluation + LevenbergMarquardtStrategy radius update
 // --------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(64) void k_ba_update(BaDev B, int fused_reduce) {
-  BaState *S = B.st;
-  if (S->done) return;
-  if (fused_reduce) {  // single shard: sum the back-substitution slabs here instead of k_ba_reduce2
-    const int t = threadIdx.x;
-    double v[6] = {0, 0, 0, 0, 0, 0};
-    for (int b = t; b < B.n_pblocks; b += 64)
-#pragma unroll
-      for (int i = 0; i < 6; i++) v[i] += B.slab_bs[6 * b + i];
-#pragma unroll
-    for (int i = 0; i < 6; i++) v[i] = wave_sum(v[i]);
-    if (t == 0) {
-#pragma unroll
-      for (int i = 0; i < 6; i++) B.payload2[i] = v[i];
-    }
-    __threadfence_block();
-    __syncthreads();
-  }
-  if (threadIdx.x != 0) return;
-  const double *p = B.payload2;
-  const double cand_cost = p[0];
-  const double model = -0.5 * (S->gdot_c + p[1]) + 0.5 * (S->dquad_c + p[2]);
-  const double step_norm = sqrt(S->step_norm2_c + p[3]);
-  const double x_norm = sqrt(S->x_norm2_c + p[4]);
-  S->cand_cost = cand_cost;
-  S->last_ok = 0;
-  if (S->solve_failed || !(model > 0.0) || !isfinite(model)) {
-    if (++S->invalid >= 5) {
-      S->termination = 4;
-      S->done = 1;
-      return;
-    }
-    S->radius /= S->decrease;
-    S->decrease *= 2.0;
-  } else {
-    S->invalid = 0;
-    const double cc = isfinite(cand_cost) ? cand_cost : 1.7976931348623157e308;
-    if (step_norm <= 1e-8 * (x_norm + 1e-8)) {
-      S->termination = 2;
-      S->done = 1;
-      return;
-    }
-    const double change = S->x_cost - cc;
-    if (fabs(change) <= 1e-6 * S->x_cost) {
-      S->termination = 1;
-      S->done = 1;
-      return;
-    }
-    const double rel = change / model;
-    if (rel > 1e-3) {
-      S->cur ^= 1;
-      S->x_cost = cc;
-      const double t2 = 2.0 * rel - 1.0;
-      S->radius = fmin(S->radius / fmax(1.0 / 3.0, 1.0 - t2 * t2 * t2), 1e16);
-      S->decrease = 2.0;
-      S->accepted += 1;
-      S->last_ok = 1;
-    } else {
-      S->radius /= S->decrease;
-      S->decrease *= 2.0;
-    }
-  }
-  if (S->iter >= S->max_it) {
-    S->termination = 0;
-    S->done = 1;
-  } else if (S->radius < 1e-32) {
-    S->termination = 4;
-    S->done = 1;
-  }
+__global__ __launch_bounds__(64) void k_ba_update(BaDev B) {
+  if (B.st->done || threadIdx.x != 0) return;
+  ba_update_logic(B);
 }
 
+// one block: reset the LM state (keeping the ping-pong index) and refresh the pose caches
 __global__ void k_ba_begin(BaDev B, int max_it, int archive_slot) {
-  if (threadIdx.x != 0 || blockIdx.x != 0) return;
   BaState *S = B.st;
-  if (archive_slot >= 0) B.hist[archive_slot] = *S;
   const int cur = S->cur;
+  __syncthreads();
+  for (int c = threadIdx.x; c < B.n_cams; c += blockDim.x) store_pc(B.PC[cur], c, pose_cache(B.Xc[cur] + 6 * c));
+  if (threadIdx.x != 0) return;
+  if (archive_slot >= 0) B.hist[archive_slot] = *S;
   memset(S, 0, sizeof(BaState));
   S->cur = cur;
   S->radius = 1e4;
@@ -1104,11 +1209,15 @@ __global__ void k_ba_begin(BaDev B, int max_it, int archive_slot) {
   S->first = 1;
 }
 
-__global__ void k_ba_posecache(BaDev B) {
-  const int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= B.n_cams) return;
-  const int cur = B.st->cur;
-  store_pc(B.PC[cur], c, pose_cache(B.Xc[cur] + 6 * c));
+// flags reset for a new solve (replaces three hipMemsetAsync calls, each ~50 us of host time)
+__global__ void k_ba_clear(BaDev B, int set_active, uint8_t *out_or_null) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < B.n_pts) B.pt_in[i] = 0;
+  if (i < B.n_cams) B.cam_in[i] = 0;
+  if (i < B.n_edges) {
+    if (set_active) B.e_active[i] = 1;
+    if (out_or_null) out_or_null[i] = 0;
+  }
 }
 
 // edge activity -> which points / cameras are in the problem (Ceres drops unused blocks)
@@ -1182,7 +1291,7 @@ struct vo_ba {
   BaDev D{};
   vo::DevBuf b_ecam, b_ept, b_eobs, b_eis, b_eact, b_ptstart, b_local, b_camslot, b_slotcam, b_camstart,
       b_camedges, b_ptin, b_camin, b_xc0, b_xc1, b_xp0, b_xp1, b_pc0, b_pc1, b_sc, b_sp, b_hinv, b_gl2, b_dl, b_wt, b_yt,
-      b_sgemm, b_scam, b_spt, b_payload, b_zc, b_sbs, b_payload2, b_state, b_out, b_dbg;
+      b_sgemm, b_scam, b_spt, b_payload, b_zc, b_sbs, b_payload2, b_state, b_out, b_dbg, b_cnt;
   size_t solve_lds = 0;
   int lm_max_it = 0;
   double *ext_payload = nullptr, *ext_payload2 = nullptr;
@@ -1276,6 +1385,10 @@ int build_device(vo_ba *h) {
   VO_CHECK(h->b_payload2.reserve(64));
   VO_CHECK(h->b_state.reserve(3 * sizeof(BaState)));
   VO_CHECK(h->b_dbg.reserve(64 * 8));
+  VO_CHECK(h->b_cnt.reserve(4096));
+  VO_HIP_CHECK(hipMemset(h->b_cnt.p, 0, 4096));
+  D.counters = h->b_cnt.as<unsigned int>();
+  D.fused = h->n_shards == 1 ? 1 : 0;
   D.dbg = h->b_dbg.as<unsigned long long>();
   VO_HIP_CHECK(hipMemset(h->b_state.p, 0, 3 * sizeof(BaState)));
   D.e_cam = h->b_ecam.as<int>(), D.e_pt = h->b_ept.as<int>();
@@ -1312,9 +1425,10 @@ int lm_begin(vo_ba *h, double hm, double hs, int max_it, const uint8_t *active_c
   BaDev &D = h->D;
   D.hm = hm, D.hs = hs;
   hipStream_t st = h->stream;
+  int set_active = 0;
   if (!keep_device_mask) {
     if (!active_caller) {
-      VO_HIP_CHECK(hipMemsetAsync(D.e_active, 1, std::max(1, h->n_edges), st));
+      set_active = 1;
     } else {
       std::vector<uint8_t> act(std::max(1, h->n_edges), 1);
       for (int e = 0; e < h->n_edges; e++) act[e] = active_caller[h->perm[e]] ? 1 : 0;
@@ -1322,12 +1436,11 @@ int lm_begin(vo_ba *h, double hm, double hs, int max_it, const uint8_t *active_c
       VO_HIP_CHECK(hipStreamSynchronize(st));  // act is a stack-lifetime buffer
     }
   }
-  VO_HIP_CHECK(hipMemsetAsync(D.pt_in, 0, std::max(1, h->n_pts), st));
-  VO_HIP_CHECK(hipMemsetAsync(D.cam_in, 0, std::max(1, h->n_cams), st));
+  const int nmax = std::max(std::max(h->n_edges, h->n_pts), h->n_cams);
+  hipLaunchKernelGGL(k_ba_clear, dim3((nmax + 255) / 256), dim3(256), 0, st, D, set_active, (uint8_t *)nullptr);
   if (h->n_edges > 0)
     hipLaunchKernelGGL(k_ba_mark, dim3((h->n_edges + 255) / 256), dim3(256), 0, st, D);
-  hipLaunchKernelGGL(k_ba_begin, dim3(1), dim3(1), 0, st, D, max_it, h->archive_slot);
-  hipLaunchKernelGGL(k_ba_posecache, dim3((h->n_cams + 63) / 64), dim3(64), 0, st, D);
+  hipLaunchKernelGGL(k_ba_begin, dim3(1), dim3(64), 0, st, D, max_it, h->archive_slot);
   VO_HIP_CHECK(hipGetLastError());
   h->lm_max_it = max_it;
   return VO_OK;
@@ -1339,8 +1452,10 @@ int launch_linearize(vo_ba *h) {
   hipLaunchKernelGGL(k_ba_linearize, dim3(D.n_pblocks + h->nf * D.n_cchunks), dim3(256), 0, st, D);
   const int tdim = D.Mpad / 16, tiles = tdim * (tdim + 1) / 2;
   hipLaunchKernelGGL(k_ba_gemm, dim3(tiles, D.ksplit), dim3(256), 0, st, D);
-  const int np = (D.Mpad * D.Mpad + h->nf * 27 + 1) * 4;
-  hipLaunchKernelGGL(k_ba_reduce, dim3((np + 255) / 256), dim3(256), 0, st, D);
+  if (!D.fused) {
+    const int np = (D.Mpad * D.Mpad + h->nf * 27 + 1) * 4;
+    hipLaunchKernelGGL(k_ba_reduce, dim3((np + 255) / 256), dim3(256), 0, st, D);
+  }
   VO_HIP_CHECK(hipGetLastError());
   return VO_OK;
 }
@@ -1354,7 +1469,8 @@ int launch_step(vo_ba *h) {
   return VO_OK;
 }
 int launch_update(vo_ba *h) {
-  hipLaunchKernelGGL(k_ba_update, dim3(1), dim3(64), 0, h->stream, h->D, h->n_shards > 1 ? 0 : 1);
+  if (h->D.fused) return VO_OK;  // done by the last block of k_ba_backsub
+  hipLaunchKernelGGL(k_ba_update, dim3(1), dim3(64), 0, h->stream, h->D);
   VO_HIP_CHECK(hipGetLastError());
   return VO_OK;
 }
@@ -1508,7 +1624,7 @@ void vo_ba_destroy(vo_ba *h) {
                         &h->b_camslot, &h->b_slotcam, &h->b_camstart, &h->b_camedges, &h->b_ptin, &h->b_camin,
                         &h->b_xc0, &h->b_xc1, &h->b_xp0, &h->b_xp1, &h->b_pc0, &h->b_pc1, &h->b_sc, &h->b_sp, &h->b_hinv, &h->b_gl2,
                         &h->b_dl, &h->b_wt, &h->b_yt, &h->b_sgemm, &h->b_scam, &h->b_spt, &h->b_payload, &h->b_zc,
-                        &h->b_sbs, &h->b_payload2, &h->b_state, &h->b_out, &h->b_dbg})
+                        &h->b_sbs, &h->b_payload2, &h->b_state, &h->b_out, &h->b_dbg, &h->b_cnt})
     b->release();
   if (h->own_stream) (void)hipStreamDestroy(h->stream);
   delete h;
@@ -1615,7 +1731,6 @@ int vo_ba_local_ba(vo_ba *h, const volatile int *stop, uint8_t *edge_erase, vo_l
   VO_CHECK(lm_begin(h, (double)sqrtf(5.991f), (double)sqrtf(7.815f), 5, nullptr, false));
   VO_CHECK(run_lm(h, 5));
   uint8_t *out = h->b_out.as<uint8_t>();
-  VO_HIP_CHECK(hipMemsetAsync(out, 0, std::max(1, h->n_edges), h->stream));
   const dim3 eg((std::max(1, h->n_edges) + 255) / 256);
   bool second = false;
   if (!(stop && *stop)) {  // :612
@@ -1626,6 +1741,7 @@ int vo_ba_local_ba(vo_ba *h, const volatile int *stop, uint8_t *edge_erase, vo_l
     VO_CHECK(run_lm(h, 10));
     second = true;
   }
+  if (!second) hipLaunchKernelGGL(k_ba_clear, eg, dim3(256), 0, h->stream, h->D, 0, out);  // no outliers known yet
   hipLaunchKernelGGL(k_ba_classify, eg, dim3(256), 0, h->stream, h->D, 1, out);
   VO_HIP_CHECK(hipGetLastError());
   std::vector<uint8_t> tmp(std::max(1, h->n_edges));
@@ -1650,7 +1766,6 @@ int vo_ba_classify(vo_ba *h, int final_pass) {
   if (!h) return VO_ERR_INVALID;
   VO_CHECK(build_device(h));
   uint8_t *out = h->b_out.as<uint8_t>();
-  if (!final_pass) VO_HIP_CHECK(hipMemsetAsync(out, 0, std::max(1, h->n_edges), h->stream));
   hipLaunchKernelGGL(k_ba_classify, dim3((std::max(1, h->n_edges) + 255) / 256), dim3(256), 0, h->stream, h->D,
                      final_pass ? 1 : 0, out);
   VO_HIP_CHECK(hipGetLastError());
@@ -1691,7 +1806,11 @@ int vo_ba_debug_schur(vo_ba *h, double hm, double hs, double point_damping, cons
   VO_HIP_CHECK(hipMemcpy(&s, h->D.st, sizeof(s), hipMemcpyDeviceToHost));
   s.radius = 1e300;
   VO_HIP_CHECK(hipMemcpy(h->D.st, &s, sizeof(s), hipMemcpyHostToDevice));
-  VO_CHECK(launch_linearize(h));
+  const int fused_saved = h->D.fused;
+  h->D.fused = 0;  // materialise the complete payload with k_ba_reduce
+  const int lrc = launch_linearize(h);
+  h->D.fused = fused_saved;
+  VO_CHECK(lrc);
   VO_HIP_CHECK(hipStreamSynchronize(h->stream));
   const int n = 6 * h->nf, M = h->D.Mpad;
   std::vector<double> pay((size_t)M * M + (size_t)h->nf * 27 + 1 + h->n_shards);

@@ -23,7 +23,10 @@ constexpr int kHalfPatch = 15;     // HALF_PATCH_SIZE :75
 constexpr int kTileP = 72;         // LDS pitch of a FAST cell tile (cell <= 66 px incl. 6 px overlap)
 constexpr int kMaxList = 1024;     // oct-tree node list capacity per level (quota <= kMaxList-4)
 
-__constant__ int8_t c_pattern[1024] = {
+// (u,v) of the 749 pixels of the orientation disc (filled by vo_orb_create from umax), padded to 768
+__constant__ __attribute__((aligned(16))) int8_t c_disc[768 * 2];
+
+__constant__ __attribute__((aligned(16))) int8_t c_pattern[1024] = {
 #include "orb_pattern.inc"
 };
 
@@ -102,6 +105,79 @@ __global__ __launch_bounds__(256) void k_resize(const uint8_t *src, long long s_
   dst[(long long)blockIdx.z * d_frame_stride + (long long)dy * d_pitch + dx] = (uint8_t)v;
 }
 
+// Vectorised form used when source rows are 4-byte aligned: one thread makes 4 adjacent output
+// pixels of one row.  The row index (hence the vertical weights and the two source rows) is uniform
+// per wavefront; the 4 outputs draw on at most 7 consecutive source columns, fetched as three
+// aligned dwords per source row; the result leaves as one dword.
+__device__ __forceinline__ int byte_at(unsigned w0, unsigned w1, unsigned w2, int i) {  // i in [0,12)
+  const unsigned w = i < 4 ? w0 : (i < 8 ? w1 : w2);
+  return (w >> (8 * (i & 3))) & 0xff;
+}
+
+__global__ __launch_bounds__(256) void k_resize4(const uint8_t *src, long long s_frame_stride, int s_pitch,
+                                                 int sw, int sh, uint8_t *dst, long long d_frame_stride,
+                                                 int d_pitch, int dw, int dh, const int *xofs,
+                                                 const int *xab, const int *yofs, const int *yab) {
+  constexpr int R = 4;  // output rows per thread: column tables are loaded once, 24 image loads in flight
+  const int gx = blockIdx.x * 64 + threadIdx.x;  // group of 4 output columns
+  const int dy0 = (blockIdx.y * 4 + threadIdx.y) * R;
+  const int dx = 4 * gx;
+  if (dx >= dw || dy0 >= dh) return;
+  const uint8_t *S = src + (long long)blockIdx.z * s_frame_stride;
+  int sx[4], a0[4], a1[4];
+#pragma unroll
+  for (int q = 0; q < 4; q++) {
+    const int d = min(dx + q, dw - 1);
+    sx[q] = xofs[d];
+    const int ab = xab[d];
+    a0[q] = (short)(ab & 0xffff), a1[q] = ab >> 16;
+  }
+  const int base = sx[0] & ~3;  // aligned start; columns needed: sx[0] .. sx[3]+1 <= base + 10
+  const int last = ((sw - 1) & ~3);
+  const int o1 = min(base + 4, last), o2 = min(base + 8, last);
+  // o1/o2 are only clamped when base+4 / base+8 lie beyond the last aligned dword of the row, and
+  // then every column this thread needs (<= sw-1) sits in an earlier dword, so indices stay valid
+  int i0[4], i1[4];
+#pragma unroll
+  for (int q = 0; q < 4; q++) i0[q] = sx[q] - base, i1[q] = min(sx[q] + 1, sw - 1) - base;
+  unsigned p[R][3], qv[R][3];
+  int b0[R], b1[R];
+#pragma unroll
+  for (int r = 0; r < R; r++) {
+    const int dy = min(dy0 + r, dh - 1);
+    const int sy = yofs[dy];
+    const int sy0 = min(max(sy, 0), sh - 1), sy1 = min(max(sy + 1, 0), sh - 1);
+    const int bb = yab[dy];
+    b0[r] = (short)(bb & 0xffff), b1[r] = bb >> 16;
+    const uint8_t *R0 = S + (long long)sy0 * s_pitch, *R1 = S + (long long)sy1 * s_pitch;
+    p[r][0] = *reinterpret_cast<const unsigned *>(R0 + base);
+    p[r][1] = *reinterpret_cast<const unsigned *>(R0 + o1);
+    p[r][2] = *reinterpret_cast<const unsigned *>(R0 + o2);
+    qv[r][0] = *reinterpret_cast<const unsigned *>(R1 + base);
+    qv[r][1] = *reinterpret_cast<const unsigned *>(R1 + o1);
+    qv[r][2] = *reinterpret_cast<const unsigned *>(R1 + o2);
+  }
+#pragma unroll
+  for (int r = 0; r < R; r++) {
+    if (dy0 + r >= dh) break;
+    unsigned outw = 0;
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+      const int r0 = byte_at(p[r][0], p[r][1], p[r][2], i0[q]) * a0[q] + byte_at(p[r][0], p[r][1], p[r][2], i1[q]) * a1[q];
+      const int r1 = byte_at(qv[r][0], qv[r][1], qv[r][2], i0[q]) * a0[q] + byte_at(qv[r][0], qv[r][1], qv[r][2], i1[q]) * a1[q];
+      int v = (((b0[r] * (r0 >> 4)) >> 16) + ((b1[r] * (r1 >> 4)) >> 16) + 2) >> 2;
+      v = min(max(v, 0), 255);
+      outw |= (unsigned)v << (8 * q);
+    }
+    uint8_t *o = dst + (long long)blockIdx.z * d_frame_stride + (long long)(dy0 + r) * d_pitch + dx;
+    if (dx + 3 < dw) {
+      *reinterpret_cast<unsigned *>(o) = outw;
+    } else {
+      for (int q = 0; q < 4 && dx + q < dw; q++) o[q] = (uint8_t)(outw >> (8 * q));
+    }
+  }
+}
+
 // ------------------------------------------------------------------------------------------
 // K2  cv::FAST(cell, threshold, nms=true) per 30-px grid cell with the 20 -> 7 threshold fallback
 // -- ComputeKeyPointsOctTree cell loop, ORBextractor.cpp:796-837.
@@ -151,8 +227,8 @@ __device__ __forceinline__ int fast_arc_score(const uint8_t *t, int min_th) {
 
 __global__ __launch_bounds__(256) void k_fast_cells(OrbDev P, FrameSrc src, uint32_t *cell_slots,
                                                     long long slots_frame_stride, int *cell_count,
-                                                    int cells_per_frame) {
-  __shared__ uint8_t tile[kTileP * kTileP];
+                                                    int cells_per_frame, int lv0_unaligned) {
+  __shared__ __attribute__((aligned(16))) uint8_t tile_raw[kTileP * kTileP + 16];
   __shared__ uint8_t score[kTileP * kTileP];
   __shared__ unsigned short plist[kTileP * kTileP];
   __shared__ int wcnt[4];
@@ -174,10 +250,46 @@ __global__ __launch_bounds__(256) void k_fast_cells(OrbDev P, FrameSrc src, uint
   const int cw = maxX - iniX, ch = maxY - iniY;
   int pitch;
   const uint8_t *img = level_plane(P, src, l, f, pitch);
-  for (int idx = tid; idx < cw * ch; idx += 256) {
-    const int y = idx / cw, x = idx - y * cw;
-    tile[y * kTileP + x] = img[(long long)(iniY + y) * pitch + iniX + x];
-    score[y * kTileP + x] = 0;
+  // The tile keeps the source's dword alignment: LDS column 0 is image column iniX - (iniX & 3), so a
+  // row is a run of aligned dwords copied verbatim.  Every thread first issues all of its global
+  // loads (<= 5 dwords, independent), then writes LDS: one memory round trip per tile, not one per
+  // element.
+  const int ox = (l == 0 && lv0_unaligned) ? 0 : (iniX & 3);
+  const uint8_t *tile = tile_raw + ox;
+  for (int idx = tid; idx < kTileP * kTileP / 4; idx += 256) reinterpret_cast<uint32_t *>(score)[idx] = 0;
+  if (l == 0 && lv0_unaligned) {  // caller image rows are not 4-byte aligned: byte path
+    const float inv = 1.0f / (float)cw;
+    for (int base = 0; base < cw * ch; base += 256 * 4) {
+      uint8_t v[4];
+      int pos[4];
+#pragma unroll
+      for (int q = 0; q < 4; q++) {
+        const int idx = base + q * 256 + tid;
+        const int y = min((int)(((float)idx + 0.5f) * inv), ch - 1), x = idx - y * cw;
+        pos[q] = idx < cw * ch ? y * kTileP + x : -1;
+        v[q] = idx < cw * ch ? img[(long long)(iniY + y) * pitch + iniX + x] : 0;
+      }
+#pragma unroll
+      for (int q = 0; q < 4; q++)
+        if (pos[q] >= 0) tile_raw[pos[q]] = v[q];
+    }
+  } else {
+    const int ndw = (ox + cw + 3) >> 2;  // dwords per tile row (<= kTileP/4)
+    const float inv = 1.0f / (float)ndw;
+    const uint8_t *g0 = img + (long long)iniY * pitch + (iniX - ox);
+    uint32_t v[5];
+    int pos[5];
+#pragma unroll
+    for (int q = 0; q < 5; q++) {
+      const int idx = q * 256 + tid;
+      const int y = min((int)(((float)idx + 0.5f) * inv), ch), x4 = idx - y * ndw;
+      const bool ok = idx < ndw * ch;
+      pos[q] = ok ? y * (kTileP / 4) + x4 : -1;
+      v[q] = ok ? *reinterpret_cast<const uint32_t *>(g0 + (long long)y * pitch + 4 * x4) : 0u;
+    }
+#pragma unroll
+    for (int q = 0; q < 5; q++)
+      if (pos[q] >= 0) reinterpret_cast<uint32_t *>(tile_raw)[pos[q]] = v[q];
   }
   __syncthreads();
   const int iw = cw - 6, ih = ch - 6;
@@ -186,13 +298,15 @@ __global__ __launch_bounds__(256) void k_fast_cells(OrbDev P, FrameSrc src, uint
   // only be a corner at the lowest threshold if one such pair is brighter or darker together.
   // Survivors are compacted into an LDS list (order is irrelevant here).
   if (tid == 0) pcount = 0;
+  const float inv_iw = 1.0f / (float)max(iw, 1);
   __syncthreads();
   for (int base = 0; base < ni; base += 256) {
     const int idx = base + tid;
     bool pass = false;
     int pos = 0;
     if (idx < ni) {
-      const int y = 3 + idx / iw, x = 3 + idx % iw;
+      const int yq = min((int)(((float)idx + 0.5f) * inv_iw), ih - 1);
+      const int y = 3 + yq, x = 3 + idx - yq * iw;
       pos = y * kTileP + x;
       const uint8_t *t = &tile[pos];
       const int v = t[0], hi = v + P.min_th, lo = v - P.min_th;
@@ -226,7 +340,8 @@ __global__ __launch_bounds__(256) void k_fast_cells(OrbDev P, FrameSrc src, uint
       bool keep = false;
       int x = 0, y = 0, s = 0;
       if (idx < ni) {
-        y = 3 + idx / iw, x = 3 + idx % iw;
+        const int yq = min((int)(((float)idx + 0.5f) * inv_iw), ih - 1);
+        y = 3 + yq, x = 3 + idx - yq * iw;
         const uint8_t *c = &score[y * kTileP + x];
         s = c[0];
         if (s >= th) {
@@ -678,6 +793,7 @@ __global__ __launch_bounds__(256) void k_blur_strips(OrbDev P, FrameSrc src, int
   for (int j = 0; j < 7; j++)
 #pragma unroll
     for (int q = 0; q < 4; q++) hw[j][q] = 0;
+#pragma unroll 4
   for (int yy = y0 - 3; yy < y1 + 3; yy++) {
     const int ry = reflect101(yy, L.h);
     const uint8_t *row = img + (long long)ry * pitch + x;
@@ -706,33 +822,40 @@ __global__ __launch_bounds__(256) void k_blur_strips(OrbDev P, FrameSrc src, int
   }
 }
 
-// border columns of the blur: x in [0,4) and [4 + 4*blurGroups, w); 16 rows x 16 columns per block
+// border columns of the blur: x in [0,4) and [4 + 4*blurGroups, w), at most 4 + 11 per row.  One
+// lane owns one border column over a 32-row band and walks down it with the same 7-row sliding
+// window as the strip kernel (7 reflected column indices are fixed per lane).
 __global__ __launch_bounds__(256) void k_blur_border(OrbDev P, FrameSrc src, int lv0_generic) {
-  const int kq[7] = {18, 34, 49, 55, 49, 34, 18};
   const int f = blockIdx.y;
-  int rb = blockIdx.x;
+  int band = blockIdx.x * 16 + (threadIdx.x >> 4);  // 16 bands per block, 16 column slots per band
+  const int ci = threadIdx.x & 15;
   int l = 0;
-  while (l + 1 < P.nlevels && rb >= P.lv[l + 1].borderRowBase) l++;
+  while (l + 1 < P.nlevels && band >= P.lv[l + 1].borderRowBase) l++;
   const LevelGeom &L = P.lv[l];
-  rb -= L.borderRowBase;
-  if (l == 0 && lv0_generic) return;
-  const int y = rb * 16 + (threadIdx.x >> 4), ci = threadIdx.x & 15;
+  band -= L.borderRowBase;
+  if (band >= L.stripsY || (l == 0 && lv0_generic)) return;
   const int xr = 4 + 4 * L.blurGroups;
   const int x = ci < 4 ? ci : xr + (ci - 4);
-  if (y >= L.h || x >= L.w || (ci < 4 && x >= xr)) return;
+  if (x >= L.w || (ci < 4 && x >= xr)) return;
   int pitch;
   const uint8_t *img = level_plane(P, src, l, f, pitch);
-  int acc = 0;
-#pragma unroll
-  for (int j = 0; j < 7; j++) {
-    const uint8_t *row = img + (long long)reflect101(y + j - 3, L.h) * pitch;
-    int hsum = 0;
-#pragma unroll
-    for (int i = 0; i < 7; i++) hsum += kq[i] * row[reflect101(x + i - 3, L.w)];
-    acc += kq[j] * hsum;
-  }
   uint8_t *dst = src.blur + (long long)f * src.blur_frame_stride + L.blur_off;
-  dst[(long long)y * L.pitch + x] = (uint8_t)min((acc + (1 << 15)) >> 16, 255);
+  int xi[7];
+#pragma unroll
+  for (int i = 0; i < 7; i++) xi[i] = reflect101(x + i - 3, L.w);
+  const int y0 = band * 32, y1 = min(L.h, y0 + 32);
+  int hw[7] = {0, 0, 0, 0, 0, 0, 0};
+  for (int yy = y0 - 3; yy < y1 + 3; yy++) {
+    const uint8_t *row = img + (long long)reflect101(yy, L.h) * pitch;
+    const int hsum = 18 * (row[xi[0]] + row[xi[6]]) + 34 * (row[xi[1]] + row[xi[5]]) + 49 * (row[xi[2]] + row[xi[4]]) + 55 * row[xi[3]];
+#pragma unroll
+    for (int j = 0; j < 6; j++) hw[j] = hw[j + 1];
+    hw[6] = hsum;
+    if (yy >= y0 + 3) {
+      const int acc = 18 * (hw[0] + hw[6]) + 34 * (hw[1] + hw[5]) + 49 * (hw[2] + hw[4]) + 55 * hw[3];
+      dst[(long long)(yy - 3) * L.pitch + x] = (uint8_t)min((acc + (1 << 15)) >> 16, 255);
+    }
+  }
 }
 
 // ------------------------------------------------------------------------------------------
@@ -801,28 +924,38 @@ __global__ __launch_bounds__(256) void k_describe(OrbDev P, FrameSrc src, const 
   const int lane = threadIdx.x & 63;
   const int g = blockIdx.x * 4 + (threadIdx.x >> 6);
   const int f = blockIdx.y;
-  const int *o = off + f * (P.nlevels + 1);
-  if (g >= o[P.nlevels] || g >= capacity) return;
-  int l = 0;
-  while (l + 1 < P.nlevels && g >= o[l + 1]) l++;
+  const int *op = off + f * (P.nlevels + 1);
+  int o[kMaxLevels + 1];  // all level offsets in flight at once (a dependent scan costs a round trip per level)
+#pragma unroll
+  for (int i = 0; i <= kMaxLevels; i++) o[i] = i <= P.nlevels ? op[i] : 0x7fffffff;
+  int total = 0, l = 0, obase = 0;
+#pragma unroll
+  for (int i = 0; i <= kMaxLevels; i++) {
+    if (i == P.nlevels) total = o[i];
+    if (i >= 1 && i < P.nlevels && g >= o[i]) l = i, obase = o[i];
+  }
+  if (g >= total || g >= capacity) return;
   const LevelGeom &L = P.lv[l];
-  const uint32_t kv = sel[(long long)f * sel_per_frame + L.selBase + (g - o[l])];
+  const uint32_t kv = sel[(long long)f * sel_per_frame + L.selBase + (g - obase)];
   const int px = (int)(kv & 0xfff) + kBorder, py = (int)((kv >> 12) & 0xfff) + kBorder;  // :849-850
   int pitch;
   const uint8_t *img = level_plane(P, src, l, f, pitch);
   const uint8_t *center = img + (long long)py * pitch + px;
   // intensity centroid: rows v = -15..15, two rows per step (lane>>5 picks the row)
   int m10 = 0, m01 = 0;
-  const int u = (lane & 31) - kHalfPatch;
-  for (int step = 0; step < 16; step++) {
-    const int v = -kHalfPatch + step * 2 + (lane >> 5);
-    if (v <= kHalfPatch) {
-      const int d = P.umax[v < 0 ? -v : v];
-      if (u >= -d && u <= d) {
-        const int val = center[(long long)v * pitch + u];
-        m10 += u * val;
-        m01 += v * val;
-      }
+  {
+    int uu[12], vv[12], val[12];
+#pragma unroll
+    for (int i = 0; i < 12; i++) {  // disc pixel lane + 64 i; entries >= n_disc are (0,0) with weight 0
+      const unsigned short w = reinterpret_cast<const unsigned short *>(c_disc)[lane + 64 * i];
+      uu[i] = (int8_t)(w & 0xff), vv[i] = (int8_t)(w >> 8);
+    }
+#pragma unroll
+    for (int i = 0; i < 12; i++) val[i] = center[(long long)vv[i] * pitch + uu[i]];
+#pragma unroll
+    for (int i = 0; i < 12; i++) {
+      m10 += uu[i] * val[i];
+      m01 += vv[i] * val[i];
     }
   }
 #pragma unroll
@@ -839,8 +972,9 @@ __global__ __launch_bounds__(256) void k_describe(OrbDev P, FrameSrc src, const 
 #pragma unroll
   for (int k = 0; k < 4; k++) {
     const int t = lane + 64 * k;
-    const float x0 = (float)c_pattern[4 * t], y0 = (float)c_pattern[4 * t + 1];
-    const float x1 = (float)c_pattern[4 * t + 2], y1 = (float)c_pattern[4 * t + 3];
+    const uint32_t pw = reinterpret_cast<const uint32_t *>(c_pattern)[t];  // x0,y0,x1,y1 as int8
+    const float x0 = (float)(int8_t)(pw & 0xff), y0 = (float)(int8_t)((pw >> 8) & 0xff);
+    const float x1 = (float)(int8_t)((pw >> 16) & 0xff), y1 = (float)(int8_t)(pw >> 24);
     const int r0 = __float2int_rn(x0 * b + y0 * a), q0 = __float2int_rn(x0 * a - y0 * b);
     const int r1 = __float2int_rn(x1 * b + y1 * a), q1 = __float2int_rn(x1 * a - y1 * b);
     const int t0 = bc[(long long)r0 * L.pitch + q0], t1 = bc[(long long)r1 * L.pitch + q1];
@@ -975,7 +1109,7 @@ int configure(vo_orb *h, int w, int h_img, int n_frames) {
       } else {
         L.wCell = (int)ceilf(width / L.nCols);
         L.hCell = (int)ceilf(height / L.nRows);
-        if (L.wCell + 6 > kTileP - 6 || L.hCell + 6 > kTileP - 6) {
+        if (L.wCell + 6 > kTileP - 6 || L.hCell + 6 > kTileP - 6 || ((L.wCell + 6 + 3 + 3) / 4) * (L.hCell + 6) > 1280) {
           vo::set_error("FAST cell %dx%d exceeds the LDS tile", L.wCell, L.hCell);
           return VO_ERR_INVALID;
         }
@@ -1016,8 +1150,8 @@ int configure(vo_orb *h, int w, int h_img, int n_frames) {
       L.stripsY = (L.h + 31) / 32;
       L.stripBase = strips;
       strips += L.stripsX * L.stripsY;
-      L.borderRowBase = brows;
-      brows += (L.h + 15) / 16;
+      L.borderRowBase = brows;  // 32-row bands, same count as stripsY
+      brows += L.stripsY;
       if (l > 0) {
         std::vector<int> xo, xa, yo, ya;
         orb_resize_tables(pw, ph, L.w, L.h, xo, xa, yo, ya);
@@ -1083,6 +1217,9 @@ int run_pipeline(vo_orb *h, const uint8_t *dev_images, int n_frames, int w, int 
   h->last_src = S;
   h->last_frames = n_frames;
   VO_HIP_CHECK(hipMemsetAsync(h->err.p, 0, 4, st));
+  // kernels that read aligned dwords need 4-byte aligned caller rows; otherwise level 0 takes byte paths
+  const int lv0_unaligned =
+      ((reinterpret_cast<uintptr_t>(dev_images) | (uintptr_t)stride | (uintptr_t)frame_stride) & 3) ? 1 : 0;
   hipEvent_t *ev = nullptr;
   if (h->timing) {
     const size_t need = (size_t)(h->timed_calls + 1) * (VO_ORB_STAGES + 1);
@@ -1104,15 +1241,26 @@ int run_pipeline(vo_orb *h, const uint8_t *dev_images, int n_frames, int w, int 
     const long long sfs = l == 1 ? (long long)frame_stride : h->pyr_frame;
     const int spitch = l == 1 ? stride : Pv.pitch;
     const int *T = h->tables.as<int>();
-    dim3 grid((L.w + 63) / 64, (L.h + 3) / 4, n_frames), block(64, 4);
-    hipLaunchKernelGGL(k_resize, grid, block, 0, st, sp, sfs, spitch, Pv.w, Pv.h, S.pyr + L.pyr_off,
-                       (long long)h->pyr_frame, L.pitch, L.w, L.h, T + h->tab_off[l * 4 + 0],
-                       T + h->tab_off[l * 4 + 1], T + h->tab_off[l * 4 + 2], T + h->tab_off[l * 4 + 3]);
+    // 4 outputs span <= 3*scale + 2 source columns; with the aligned start that fits 12 bytes for
+    // scale factors below 2 and needs 4-byte aligned source rows with readable padding to the pitch
+    const bool aligned = ((reinterpret_cast<uintptr_t>(sp) | (uintptr_t)spitch | (uintptr_t)sfs) & 3) == 0 &&
+                         (double)Pv.w / L.w < 1.99 && ((Pv.w + 3) & ~3) <= spitch;
+    if (aligned) {
+      dim3 grid(((L.w + 3) / 4 + 63) / 64, (L.h + 15) / 16, n_frames), block(64, 4);
+      hipLaunchKernelGGL(k_resize4, grid, block, 0, st, sp, sfs, spitch, Pv.w, Pv.h, S.pyr + L.pyr_off,
+                         (long long)h->pyr_frame, L.pitch, L.w, L.h, T + h->tab_off[l * 4 + 0],
+                         T + h->tab_off[l * 4 + 1], T + h->tab_off[l * 4 + 2], T + h->tab_off[l * 4 + 3]);
+    } else {
+      dim3 grid((L.w + 63) / 64, (L.h + 3) / 4, n_frames), block(64, 4);
+      hipLaunchKernelGGL(k_resize, grid, block, 0, st, sp, sfs, spitch, Pv.w, Pv.h, S.pyr + L.pyr_off,
+                         (long long)h->pyr_frame, L.pitch, L.w, L.h, T + h->tab_off[l * 4 + 0],
+                         T + h->tab_off[l * 4 + 1], T + h->tab_off[l * 4 + 2], T + h->tab_off[l * 4 + 3]);
+    }
   }
   VO_STAGE_MARK(1);
   if (h->cells_frame > 0)
     hipLaunchKernelGGL(k_fast_cells, dim3(h->cells_frame, n_frames), dim3(256), 0, st, D, S,
-                       h->slots.as<uint32_t>(), h->slots_frame, h->cellcnt.as<int>(), h->cells_frame);
+                       h->slots.as<uint32_t>(), h->slots_frame, h->cellcnt.as<int>(), h->cells_frame, lv0_unaligned);
   VO_STAGE_MARK(2);
   hipLaunchKernelGGL(k_octree, dim3(D.nlevels, n_frames), dim3(256), 0, st, D, h->slots.as<uint32_t>(),
                      h->slots_frame, h->cellcnt.as<int>(), h->cells_frame, h->keydata.as<uint32_t>(),
@@ -1125,10 +1273,10 @@ int run_pipeline(vo_orb *h, const uint8_t *dev_images, int n_frames, int w, int 
   {
     // the strip kernel reads aligned dwords; a caller image that is not 4-byte aligned falls back
     // to the generic LDS kernel for level 0 only
-    const int lv0_generic = ((reinterpret_cast<uintptr_t>(dev_images) | (uintptr_t)stride | (uintptr_t)frame_stride) & 3) ? 1 : 0;
+    const int lv0_generic = lv0_unaligned;
     if (h->strips_frame > 0)
       hipLaunchKernelGGL(k_blur_strips, dim3((h->strips_frame + 3) / 4, n_frames), dim3(256), 0, st, D, S, lv0_generic);
-    hipLaunchKernelGGL(k_blur_border, dim3(h->border_rows_frame, n_frames), dim3(256), 0, st, D, S, lv0_generic);
+    hipLaunchKernelGGL(k_blur_border, dim3((h->border_rows_frame + 15) / 16, n_frames), dim3(256), 0, st, D, S, lv0_generic);
     if (lv0_generic) hipLaunchKernelGGL(k_blur, dim3(h->tiles_frame, n_frames), dim3(256), 0, st, D, S, 0);
   }
   VO_STAGE_MARK(5);
@@ -1182,6 +1330,27 @@ int vo_orb_create(vo_orb **out, int nfeatures, float scale_factor, int nlevels, 
     while (h->umax[v0] == h->umax[v0 + 1]) ++v0;
     h->umax[v] = v0;
     ++v0;
+  }
+  {
+    // disc pixels of IC_Angle (:79-107) as an explicit list; padding entries (0,0) contribute u*I = v*I = 0
+    int8_t disc[768 * 2];
+    memset(disc, 0, sizeof(disc));
+    int nd = 0;
+    for (int v = -kHalfPatch; v <= kHalfPatch; v++)
+      for (int u = -h->umax[v < 0 ? -v : v]; u <= h->umax[v < 0 ? -v : v]; u++) {
+        disc[2 * nd] = (int8_t)u, disc[2 * nd + 1] = (int8_t)v;
+        nd++;
+      }
+    if (nd > 768) {
+      vo::set_error("orientation disc has %d pixels (table holds 768)", nd);
+      delete h;
+      return VO_ERR_INVALID;
+    }
+    if (hipMemcpyToSymbol(HIP_SYMBOL(c_disc), disc, sizeof(disc)) != hipSuccess) {
+      vo::set_error("hipMemcpyToSymbol(c_disc) failed");
+      delete h;
+      return VO_ERR_HIP;
+    }
   }
   if (hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking) != hipSuccess) {
     vo::set_error("hipStreamCreate failed");
