@@ -231,8 +231,7 @@ __global__ __launch_bounds__(256) void k_fast_cells(OrbDev P, FrameSrc src, uint
   __shared__ __attribute__((aligned(16))) uint8_t tile_raw[kTileP * kTileP + 16];
   __shared__ uint8_t score[kTileP * kTileP];
   __shared__ unsigned short plist[kTileP * kTileP];
-  __shared__ int wcnt[4];
-  __shared__ int pcount;
+  __shared__ int wcnt[4][4];  // double-buffered per-wave counts (phase 1: 0/1, phase 3: 2/3)
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int cell = blockIdx.x, f = blockIdx.y;
   int l = 0;
@@ -294,20 +293,19 @@ __global__ __launch_bounds__(256) void k_fast_cells(OrbDev P, FrameSrc src, uint
   __syncthreads();
   const int iw = cw - 6, ih = ch - 6;
   const int ni = (iw > 0 && ih > 0) ? iw * ih : 0;
+  const float inv_iw = 1.0f / (float)max(iw, 1);
   // phase 1: a 9-arc always contains two neighbouring compass pixels (ring 0,4,8,12), so a pixel can
   // only be a corner at the lowest threshold if one such pair is brighter or darker together.
-  // Survivors are compacted into an LDS list (order is irrelevant here).
-  if (tid == 0) pcount = 0;
-  const float inv_iw = 1.0f / (float)max(iw, 1);
-  __syncthreads();
-  for (int base = 0; base < ni; base += 256) {
+  // Survivors are compacted IN RASTER ORDER into an LDS list (ballot + per-wave counts, one barrier
+  // per 256-pixel chunk); everything after this phase touches survivors only.
+  int np = 0;
+  for (int base = 0, it = 0; base < ni; base += 256, it++) {
     const int idx = base + tid;
     bool pass = false;
     int pos = 0;
     if (idx < ni) {
       const int yq = min((int)(((float)idx + 0.5f) * inv_iw), ih - 1);
-      const int y = 3 + yq, x = 3 + idx - yq * iw;
-      pos = y * kTileP + x;
+      pos = (3 + yq) * kTileP + 3 + idx - yq * iw;
       const uint8_t *t = &tile[pos];
       const int v = t[0], hi = v + P.min_th, lo = v - P.min_th;
       const int p0 = t[3 * kTileP], p4 = t[3], p8 = t[-3 * kTileP], p12 = t[-3];
@@ -317,56 +315,69 @@ __global__ __launch_bounds__(256) void k_fast_cells(OrbDev P, FrameSrc src, uint
       pass = ((bb | dd) & 15) != 0;
     }
     const unsigned long long mask = __ballot(pass);
-    int wbase = 0;
-    if (lane == 0 && mask) wbase = atomicAdd(&pcount, __popcll(mask));
-    wbase = __shfl(wbase, 0);
-    if (pass) plist[wbase + __popcll(mask & ((1ull << lane) - 1ull))] = (unsigned short)pos;
+    int *wc = wcnt[it & 1];
+    if (lane == 0) wc[wave] = __popcll(mask);
+    __syncthreads();
+    int off = np + __popcll(mask & ((1ull << lane) - 1ull));
+    int tot = 0;
+#pragma unroll
+    for (int w2 = 0; w2 < 4; w2++) {
+      if (w2 < wave) off += wc[w2];
+      tot += wc[w2];
+    }
+    if (pass) plist[off] = (unsigned short)pos;
+    np += tot;
   }
   __syncthreads();
   // phase 2: full arc score only for the survivors
-  const int np = pcount;
   for (int i = tid; i < np; i += 256) {
     const int pos = plist[i];
     score[pos] = (uint8_t)fast_arc_score(&tile[pos], P.min_th);
   }
   __syncthreads();
+  // phase 3: 3x3 non-maximum suppression at the cell's threshold over the (raster-ordered) survivors;
+  // kept pixels are written in the same order.  A cell with no key-point at iniThFAST is redone at
+  // minThFAST (:820-824).
   uint32_t *slot = cell_slots + (long long)f * slots_frame_stride + L.slotBase + (long long)ci * L.capCell;
   int running = 0;
+  int it2 = 0;
   for (int pass = 0; pass < 2; pass++) {
     const int th = pass == 0 ? P.ini_th : P.min_th;
     running = 0;
-    for (int base = 0; base < ni; base += 256) {
-      const int idx = base + tid;
+    for (int base = 0; base < np; base += 256, it2++) {
+      const int i = base + tid;
       bool keep = false;
-      int x = 0, y = 0, s = 0;
-      if (idx < ni) {
-        const int yq = min((int)(((float)idx + 0.5f) * inv_iw), ih - 1);
-        y = 3 + yq, x = 3 + idx - yq * iw;
-        const uint8_t *c = &score[y * kTileP + x];
-        s = c[0];
-        if (s >= th) {
+      int pos = 0, sc0 = 0;
+      if (i < np) {
+        pos = plist[i];
+        const uint8_t *c = &score[pos];
+        sc0 = c[0];
+        if (sc0 >= th) {
           int nb = 0;
 #define NBR(o) nb = max(nb, (int)c[o] >= th ? (int)c[o] : 0)
           NBR(-kTileP - 1); NBR(-kTileP); NBR(-kTileP + 1);
           NBR(-1); NBR(1);
           NBR(kTileP - 1); NBR(kTileP); NBR(kTileP + 1);
 #undef NBR
-          keep = s > nb;
+          keep = sc0 > nb;
         }
       }
       const unsigned long long mask = __ballot(keep);
-      if (lane == 0) wcnt[wave] = __popcll(mask);
+      int *wc = wcnt[2 + (it2 & 1)];
+      if (lane == 0) wc[wave] = __popcll(mask);
       __syncthreads();
       int off = running + __popcll(mask & ((1ull << lane) - 1ull));
       int tot = 0;
+#pragma unroll
       for (int w2 = 0; w2 < 4; w2++) {
-        if (w2 < wave) off += wcnt[w2];
-        tot += wcnt[w2];
+        if (w2 < wave) off += wc[w2];
+        tot += wc[w2];
       }
-      if (keep && off < L.capCell)
-        slot[off] = (uint32_t)(x + ci_j * L.wCell) | ((uint32_t)(y + ci_i * L.hCell) << 12) | ((uint32_t)s << 24);
+      if (keep && off < L.capCell) {
+        const int y = pos / kTileP, x = pos - y * kTileP;
+        slot[off] = (uint32_t)(x + ci_j * L.wCell) | ((uint32_t)(y + ci_i * L.hCell) << 12) | ((uint32_t)sc0 << 24);
+      }
       running += tot;
-      __syncthreads();
     }
     if (running > 0) break;  // :820 `if(vKeysCell.empty())` retry with minThFAST
   }
