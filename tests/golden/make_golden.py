@@ -1,0 +1,126 @@
+#!/usr/bin/env python3
+"""Generate the golden fixtures under tests/golden/ (inputs AND expected outputs).
+
+The reference (guisongchen/vo_slam_test) has no tests, golden vectors or fixtures and cannot be
+built in this image, so these vectors come from the CPU restatement in oracle/ on seeded synthetic
+inputs ("parity unpinned").  They pin (a) the oracle against regressions and
+(b) the HIP path on the GPU box, where neither /root/reference nor this script's inputs are needed.
+
+    python tests/golden/make_golden.py          # rewrites tests/golden/*.npz
+"""
+import ctypes as C
+import pathlib
+import sys
+
+import numpy as np
+
+HERE = pathlib.Path(__file__).resolve().parent
+sys.path.insert(0, str(HERE.parent))
+sys.path.insert(0, str(HERE.parent.parent))
+import oracle_lib as O  # noqa: E402
+from vo_slam_test_amd import synth  # noqa: E402
+
+
+def g1_extract():
+    out = {}
+    for tag, (w, h, nf, nl, idx) in {"vga": (640, 480, 1000, 8, 0), "qvga": (320, 240, 500, 6, 5)}.items():
+        img = synth.make_frame(idx, w=w, h=h, n_rect=600 if w == 640 else 200, n_blob=150 if w == 640 else 60)
+        p = O.orb_params(nf, 1.2, nl, 20, 7)
+        kps, desc, npl = O.extract(p, img, cap=nf + 64)
+        out[f"{tag}_image"] = img
+        out[f"{tag}_params"] = np.array([nf, nl, 20, 7], np.int32)
+        out[f"{tag}_kps"] = kps
+        out[f"{tag}_desc"] = desc
+        out[f"{tag}_per_level"] = npl
+    np.savez_compressed(HERE / "g1_extract.npz", **out)
+
+
+def g2_fast():
+    img = synth.make_frame(2)
+    out = {}
+    for k, (x0, y0) in enumerate([(100, 80), (400, 300)]):
+        crop = np.ascontiguousarray(img[y0:y0 + 64, x0:x0 + 64])
+        out[f"crop{k}"] = crop
+        for th in (20, 7):
+            xs, ys, sc = O.fast(crop, th, True)
+            out[f"crop{k}_th{th}"] = np.stack([xs, ys, sc], 1).astype(np.int32)
+    p = O.orb_params()
+    lev = O.pyramid(p, img)
+    out["level3"] = lev[3]
+    cx, cy, cr = O.level_candidates(p, lev[3])
+    out["level3_candidates"] = np.stack([cx, cy, cr], 1)
+    sel = O.octtree(cx, cy, cr, lev[3].shape[1], lev[3].shape[0], int(p.quota[3]))
+    out["level3_octtree_sel"] = sel
+    out["level3_blur"] = O.blur(lev[3])
+    np.savez_compressed(HERE / "g2_fast_octtree.npz", **out)
+
+
+def g3_match():
+    p = O.orb_params()
+    f0 = synth.make_frame(7)
+    f1, dx, dy = synth.make_shifted(f0, 7)
+    k0, d0, _ = O.extract(p, f0)
+    k1, d1, _ = O.extract(p, f1)
+    n = 400
+    k0, d0, k1, d1 = k0[:n], d0[:n], k1[:n], d1[:n]
+    D = O.hamming_matrix(d0, d1)
+    rng = np.random.default_rng(7)
+    z1 = rng.uniform(0.8, 4.5, n).astype(np.float32)
+    ur1 = (k1["x"] - np.float32(40.0) / z1).astype(np.float32)
+    sf = np.array(list(p.scale)[:8], np.float32)
+    q = dict(flags=np.full(n, 3, np.uint8), u=(k0["x"] + dx).astype(np.float32), v=(k0["y"] + dy).astype(np.float32),
+             invz=np.full(n, 0.5, np.float32), octave=k0["octave"].astype(np.int32), angle=k0["angle"].astype(np.float32))
+    of = O.FrameData(k1["x"], k1["y"], k1["octave"], k1["angle"], ur1, d1)
+    assigned = np.full(n, -1, np.int32)
+    cnt = O.lib().orc_match_frame_projection(C.byref(of.c), n, q["flags"], q["u"], q["v"], q["invz"], q["octave"],
+                                             q["angle"], np.ascontiguousarray(d0), 15.0, 40.0, 0, 1, 8, sf,
+                                             np.zeros(n, np.uint8), assigned)
+    np.savez_compressed(HERE / "g3_match.npz", d0=d0, d1=d1, D=D, kx=k1["x"], ky=k1["y"], koct=k1["octave"],
+                        kang=k1["angle"], ur=ur1, q_u=q["u"], q_v=q["v"], q_oct=q["octave"], q_ang=q["angle"],
+                        scale=sf, assigned=assigned, count=np.int32(cnt))
+
+
+def g4_pose():
+    pr = synth.make_pose_problem(3, n=300)
+    pose, outl, ninl, sums, keep = O.pose_only(pr, trace=True)
+    np.savez_compressed(HERE / "g4_pose_only.npz", pts=pr["pts"], obs=pr["obs"], inv_sigma=pr["inv_sigma"], cam=pr["cam"],
+                        pose0=pr["pose0"], pose=pose, outlier=outl, n_inlier=np.int32(ninl),
+                        iters=np.array([sums[0].iterations, sums[1].iterations], np.int32),
+                        accepted=np.array([sums[0].accepted, sums[1].accepted], np.int32),
+                        cost0=np.array([keep[0][0][i] for i in range(sums[0].iterations + 1)]),
+                        cost1=np.array([keep[1][0][i] for i in range(sums[1].iterations + 1)]),
+                        radius0=np.array([keep[0][1][i] for i in range(sums[0].iterations + 1)]))
+
+
+def g5_lba():
+    pr = synth.make_lba_problem(11, n_kf=3, n_pts=50, n_fixed=1)
+    deg = np.bincount(pr["e_pt"], minlength=len(pr["points"]))
+    active = (deg[pr["e_pt"]] >= 2).astype(np.uint8)
+    S, b, cost, nf = O.ba_schur(pr, active=active, point_damping=1e-3)
+    poses, pts, erase, sums, rc = O.local_ba(pr)
+    arrays = {k: v for k, v in pr.items() if isinstance(v, np.ndarray)}
+    np.savez_compressed(HERE / "g5_local_ba.npz", **arrays, schur_active=active, S=S, b=b, cost=cost,
+                        out_poses=poses, out_points=pts, edge_erase=erase,
+                        iters=np.array([sums[0].iterations, sums[1].iterations], np.int32),
+                        final_cost=np.array([sums[0].final_cost, sums[1].final_cost]))
+
+
+def g7_se3():
+    rng = np.random.default_rng(1)
+    xi = np.concatenate([rng.uniform(-2, 2, (12, 6)), np.array([[0.1, 0.2, 0.3, 0, 0, 0], [0.1, 0.2, 0.3, 1e-12, 0, 0],
+                                                                 [1, 2, 3, 3.1, 0.0, 0.0], [0, 0, 0, 0, 3.14159, 0]])])
+    q, t, tp = np.zeros((len(xi), 4)), np.zeros((len(xi), 3)), np.zeros((len(xi), 3))
+    p0 = np.array([0.3, -0.7, 2.5])
+    for i, x in enumerate(xi):
+        O.lib().orc_se3_exp(np.ascontiguousarray(x), q[i], t[i])
+        O.lib().orc_se3_trans_point(np.ascontiguousarray(x), p0, tp[i])
+    np.savez_compressed(HERE / "g7_se3.npz", xi=xi, quat_wxyz=q, trans=t, point=p0, transformed=tp)
+
+
+if __name__ == "__main__":
+    for fn in (g1_extract, g2_fast, g3_match, g4_pose, g5_lba, g7_se3):
+        fn()
+        print("wrote", fn.__name__)
+    import os
+    for f in sorted(HERE.glob("*.npz")):
+        print(f.name, os.path.getsize(f))

@@ -1,0 +1,79 @@
+"""World-size-2 test of the N>1 path on CPU (gloo): the sharding rule and the all-reduce payload
+handling of vo_slam_test_amd.dist_ba, with the CPU oracle standing in for the per-shard HIP
+linearisation (the oracle is the checker here, never the product path)."""
+import os
+import pathlib
+import socket
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = pathlib.Path(__file__).resolve().parent.parent
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    sys.path.insert(0, str(ROOT))
+    sys.path.insert(0, str(ROOT / "tests"))
+    import torch
+    import torch.distributed as dist
+    import oracle_lib as orc
+    from vo_slam_test_amd import dist_ba, synth
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    pr = synth.make_lba_problem(12, n_kf=4, n_pts=120, n_fixed=1)
+    mask = dist_ba.shard_edge_mask(pr["e_pt"], rank, world)
+    S, b, cost, nf = orc.ba_schur(pr, active=mask, point_damping=1e-3)
+    payload = torch.from_numpy(np.concatenate([S.ravel(), b, [cost]]))
+    dist_ba.allreduce_sum_(payload, dist)
+    # every rank updates only the points it owns; the merge restores the full array on all ranks
+    pts = pr["points"].copy()
+    own = dist_ba.shard_of_point(np.arange(len(pts)), world) == rank
+    pts[own] += 1.0 + rank
+    merged = dist_ba.merge_owned_points(
+        pts, rank, world, lambda a: dist_ba.allreduce_sum_(torch.from_numpy(a.copy()), dist).numpy())
+    q.put((rank, payload.numpy(), merged, int(mask.sum())))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(180)
+def test_two_rank_gloo_allreduce_of_shard_partials(orc):
+    import torch.multiprocessing as mp
+    from vo_slam_test_amd import dist_ba, synth
+    world, port = 2, _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=150) for _ in range(world)], key=lambda t: t[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    pr = synth.make_lba_problem(12, n_kf=4, n_pts=120, n_fixed=1)
+    S, b, cost, nf = orc.ba_schur(pr, point_damping=1e-3)
+    ref = np.concatenate([S.ravel(), b, [cost]])
+    assert np.array_equal(res[0][1], res[1][1])              # all ranks hold identical reduced systems
+    assert np.abs(res[0][1] - ref).max() <= 1e-9 * np.abs(ref).max()
+    assert res[0][3] + res[1][3] == len(pr["e_pt"])           # every edge belongs to exactly one shard
+    expect = pr["points"].copy()
+    expect[0::2] += 1.0
+    expect[1::2] += 2.0
+    assert np.array_equal(res[0][2], res[1][2]) and np.allclose(res[0][2], expect)
+
+
+def test_sharding_rule():
+    from vo_slam_test_amd import dist_ba
+    e_pt = np.arange(20) % 7
+    masks = [dist_ba.shard_edge_mask(e_pt, r, 3) for r in range(3)]
+    assert (np.sum(masks, 0) == 1).all()
+    assert np.array_equal(dist_ba.shard_of_point(np.arange(6), 1), np.zeros(6, int))

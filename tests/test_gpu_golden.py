@@ -1,0 +1,66 @@
+"""GPU: the HIP path against the committed golden fixtures (tests/golden/*.npz) -- no oracle call,
+nothing read from outside the repository."""
+import pathlib
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+G = pathlib.Path(__file__).resolve().parent / "golden"
+
+
+def test_g1_extract(vo):
+    g = np.load(G / "g1_extract.npz")
+    for tag in ("vga", "qvga"):
+        nf, nl, it, mt = (int(v) for v in g[f"{tag}_params"])
+        e = vo.OrbExtractor(nf, 1.2, nl, it, mt)
+        kps, desc = e(g[f"{tag}_image"])
+        assert list(e.get_level_counts(0)) == list(g[f"{tag}_per_level"])
+        e.close()
+        exp = g[f"{tag}_kps"]
+        assert len(kps) == len(exp)
+        for name in kps.dtype.names:
+            assert np.array_equal(kps[name], exp[name]), (tag, name)
+        assert np.array_equal(desc, g[f"{tag}_desc"])
+
+
+def test_g3_hamming_and_match(vo):
+    g = np.load(G / "g3_match.npz")
+    assert np.array_equal(vo.hamming_matrix(g["d0"], g["d1"]), g["D"])
+    n = len(g["d0"])
+    cur = vo.FrameArrays(g["kx"], g["ky"], g["koct"], g["kang"], g["ur"], g["d1"])
+    q = dict(flags=np.full(n, 3, np.uint8), u=g["q_u"], v=g["q_v"], invz=np.full(n, 0.5, np.float32),
+             octave=g["q_oct"], angle=g["q_ang"], desc=np.ascontiguousarray(g["d0"]))
+    cnt, assigned = vo.Matcher(0.8).searchByProjection_frame(cur, q, 15.0, 40.0, 0, True, g["scale"])
+    assert cnt == int(g["count"]) and np.array_equal(assigned, g["assigned"])
+
+
+def test_g4_pose_only(vo):
+    g = np.load(G / "g4_pose_only.npz")
+    pr = {k: g[k] for k in ("pts", "obs", "inv_sigma", "cam", "pose0")}
+    poses, masks, ninl, sums = vo.Optimizer.solvePoseOnlySE3([pr], summaries=True)
+    assert ninl[0] == int(g["n_inlier"]) and np.array_equal(masks[0], g["outlier"])
+    assert np.abs(poses[0] - g["pose"]).max() < 1e-9
+    assert [sums[0].iterations, sums[1].iterations] == g["iters"].tolist()
+    assert abs(sums[0].final_cost - g["cost0"][-1]) <= 1e-9 * g["cost0"][-1]
+
+
+def test_g5_local_ba(vo):
+    g = np.load(G / "g5_local_ba.npz")
+    pr = {k: g[k] for k in ("poses", "fixed", "points", "e_cam", "e_pt", "e_obs", "e_inv_sigma", "cam")}
+    ba = vo.BundleAdjuster(pr)
+    erase, sums, rc = ba.local_ba()
+    poses, pts = ba.state()
+    ba.close()
+    assert rc == 0 and np.array_equal(erase, g["edge_erase"])
+    assert [sums[0].iterations, sums[1].iterations] == g["iters"].tolist()
+    assert np.abs(poses - g["out_poses"]).max() < 1e-7
+    assert np.allclose([sums[0].final_cost, sums[1].final_cost], g["final_cost"], rtol=1e-7)
+
+
+def test_g7_se3(vo):
+    g = np.load(G / "g7_se3.npz")
+    for i, xi in enumerate(g["xi"]):
+        R, t = vo.se3_exp(xi)
+        assert np.abs(t - g["trans"][i]).max() < 1e-13
+        assert np.abs(R @ g["point"] + t - g["transformed"][i]).max() < 1e-12
