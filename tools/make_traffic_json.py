@@ -1,0 +1,39 @@
+#!/usr/bin/env python3
+"""Turn two rocprofv3 --pmc runs (FETCH_SIZE, WRITE_SIZE) into profiles/traffic.json:
+HBM-side bytes per launch for every bench stage.  Counter unit is KiB (x1024).  On gfx950
+FETCH_SIZE under-reports wide streaming reads by 2x (MI355X_MICROARCH.md, HBM section); the
+4-byte-per-lane reads used here are uncalibrated, so both the raw and the doubled read figure are
+kept and `traffic` uses raw read + write (a lower bound)."""
+import collections, csv, glob, json, sys
+fetch_dir, write_dir, out = sys.argv[1], sys.argv[2], sys.argv[3]
+STAGE = {"k_resize4": "pyramid", "k_resize": "pyramid", "k_fast_cells": "fast", "k_octree": "octree",
+         "k_blur_strips": "blur", "k_blur_border": "blur", "k_blur": "blur", "k_describe": "describe",
+         "k_hamming": "hamming"}
+def load(d, counter):
+    f = glob.glob(d + "/**/*counter_collection.csv", recursive=True)[0]
+    acc = collections.defaultdict(list)
+    for r in csv.DictReader(open(f)):
+        if r["Counter_Name"] != counter:
+            continue
+        name = r["Kernel_Name"].replace("(anonymous namespace)::", "").split("(")[0]
+        acc[name].append(float(r["Counter_Value"]) * 1024.0)
+    return acc
+fe, wr = load(fetch_dir, "FETCH_SIZE"), load(write_dir, "WRITE_SIZE")
+steps = len(fe.get("k_fast_cells", [1]))
+res = {"_note": "bytes per bench step (one launch of each stage over the whole batch); read figure raw",
+       "_steps_profiled": steps}
+detail = {}
+for k in set(fe) | set(wr):
+    if k not in STAGE:
+        continue
+    st = STAGE[k]
+    rd = sum(fe.get(k, [0])) / steps
+    w = sum(wr.get(k, [0])) / steps
+    d = detail.setdefault(st, {"read": 0.0, "write": 0.0})
+    d["read"] += rd
+    d["write"] += w
+for st, d in detail.items():
+    res[st] = round(d["read"] + d["write"])
+res["_detail"] = {k: {a: round(b) for a, b in v.items()} for k, v in detail.items()}
+json.dump(res, open(out, "w"), indent=1, sort_keys=True)
+print(json.dumps(res))
