@@ -211,6 +211,10 @@ int vo_ba_n_free_cams(const vo_ba *h);
  * edge_erase[n_edges] (host) out in the caller's edge order.  summaries: NULL or [2]. */
 int vo_ba_local_ba(vo_ba *h, const volatile int *stop, uint8_t *edge_erase,
                    vo_lm_summary *summaries);
+/* The same schedule split into "queue everything on the handle's stream" and "wait + fetch results",
+ * so that several independent problems (handles) overlap on one GPU. */
+int vo_ba_local_ba_enqueue(vo_ba *h, const volatile int *stop);
+int vo_ba_local_ba_finish(vo_ba *h, uint8_t *edge_erase, vo_lm_summary *summaries);
 /* One Ceres-style LM solve (ceres::Solve with DENSE_SCHUR at :604 / :699) on the current state.
  * huber_* <= 0 disables the loss.  edge_active: NULL or host mask in caller's edge order. */
 int vo_ba_solve(vo_ba *h, double huber_mono, double huber_stereo, int max_iterations,

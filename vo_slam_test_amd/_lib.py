@@ -43,7 +43,8 @@ SYMBOLS = [
     "vo_match_frame_projection", "vo_match_local_map",
     "vo_pose_only_solve", "vo_pose_only_solve_dev",
     "vo_ba_create", "vo_ba_destroy", "vo_ba_set_stream", "vo_ba_set_shard", "vo_ba_set_state",
-    "vo_ba_get_state", "vo_ba_n_free_cams", "vo_ba_local_ba", "vo_ba_solve", "vo_ba_lm_begin",
+    "vo_ba_get_state", "vo_ba_n_free_cams", "vo_ba_local_ba", "vo_ba_local_ba_enqueue",
+    "vo_ba_local_ba_finish", "vo_ba_solve", "vo_ba_lm_begin",
     "vo_ba_linearize", "vo_ba_step", "vo_ba_update", "vo_ba_lm_end", "vo_ba_reduced_system",
     "vo_ba_reduced_cost", "vo_ba_set_reduce_buffers", "vo_ba_classify",
     "vo_ba_lm_begin_inliers", "vo_ba_get_edge_outliers", "vo_ba_debug_schur", "vo_se3_exp", "vo_se3_log",
@@ -345,6 +346,15 @@ class BundleAdjuster:
         if rc not in (0, -5):
             check(rc, "vo_ba_local_ba")
         return erase[:self.n_edges], sums, rc
+
+    def local_ba_enqueue(self, stop=None):
+        return lib().vo_ba_local_ba_enqueue(self._h, stop)
+
+    def local_ba_finish(self):
+        erase = np.zeros(max(self.n_edges, 1), np.uint8)
+        sums = (LmSummary * 2)()
+        check(lib().vo_ba_local_ba_finish(self._h, _p(erase), C.byref(sums)), "vo_ba_local_ba_finish")
+        return erase[:self.n_edges], sums
 
     # split-phase interface (multi-GPU driver)
     def lm_begin(self, huber_mono, huber_stereo, max_iterations, edge_active=None):

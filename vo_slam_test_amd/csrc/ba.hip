@@ -22,6 +22,7 @@
 
 #include <algorithm>
 #include <cmath>
+#include <map>
 #include <numeric>
 #include <vector>
 
@@ -362,12 +363,13 @@ __global__ __launch_bounds__(256) void k_pose_only(const int *offsets, const dou
 // ============================================================================================
 constexpr int kGroup = 8;        // lanes per map point
 constexpr int kPtsPerBlock = 32; // 256 / kGroup
-constexpr int kCamChunk = 256;   // edges per camera-role block (one per thread)
+constexpr int kCamChunk = 1024;  // edges per camera-role block (four per thread; the role is off the critical path)
 constexpr int kMaxN = 128;       // reduced system size limit of the LDS Cholesky (6*nf + 1 <= kMaxN)
 
 struct BaState {
   double radius, decrease, x_cost, cand_cost, initial_cost, x_norm2_c, cand_norm2_c, step_norm2_c, gdot_c,
       dquad_c, gmax;
+  double hm, hs;  // Huber thresholds of the running solve (<= 0: no loss)
   int iter, accepted, termination, done, invalid, last_ok, cur, max_it, first, solve_failed;
 };
 
@@ -377,7 +379,6 @@ struct BaDev {
   int ksplit, kchunk;                       // split-K of the Schur GEMM
   int n_pblocks, n_cchunks;
   int n_shards, shard;
-  double hm, hs;
   Cam K;
   // problem
   const int *e_cam, *e_pt;
@@ -451,7 +452,7 @@ __device__ __forceinline__ void ba_points_role(const BaDev &B, const BaState &st
       const int m = edge_eval<false, true>(P, pt, B.e_obs[3 * e], B.e_obs[3 * e + 1], B.e_obs[3 * e + 2], B.e_is[e],
                                            B.K, r, nullptr, Jl);
       double rho0, rho1;
-      huber(m == 2 ? B.hm : B.hs, r[0] * r[0] + r[1] * r[1] + r[2] * r[2], rho0, rho1);
+      huber(m == 2 ? st.hm : st.hs, r[0] * r[0] + r[1] * r[1] + r[2] * r[2], rho0, rho1);
       cost += 0.5 * rho0;
       h[0] += rho1 * (Jl[0] * Jl[0] + Jl[3] * Jl[3] + Jl[6] * Jl[6]);
       h[1] += rho1 * (Jl[0] * Jl[1] + Jl[3] * Jl[4] + Jl[6] * Jl[7]);
@@ -518,7 +519,7 @@ __device__ __forceinline__ void ba_points_role(const BaDev &B, const BaState &st
       const int m = edge_eval<true, true>(P, pt, B.e_obs[3 * e], B.e_obs[3 * e + 1], B.e_obs[3 * e + 2], B.e_is[e],
                                           B.K, r, Jp, Jl);
       double rho0, rho1;
-      huber(m == 2 ? B.hm : B.hs, r[0] * r[0] + r[1] * r[1] + r[2] * r[2], rho0, rho1);
+      huber(m == 2 ? st.hm : st.hs, r[0] * r[0] + r[1] * r[1] + r[2] * r[2], rho0, rho1);
 #pragma unroll
       for (int a = 0; a < 6; a++) {
         double w[3];
@@ -567,7 +568,7 @@ __device__ __forceinline__ void ba_cams_role(const BaDev &B, const BaState &st, 
     const int m = edge_eval<true, false>(P, pt, B.e_obs[3 * e], B.e_obs[3 * e + 1], B.e_obs[3 * e + 2], B.e_is[e],
                                          B.K, r, J, nullptr);
     double rho0, rho1;
-    huber(m == 2 ? B.hm : B.hs, r[0] * r[0] + r[1] * r[1] + r[2] * r[2], rho0, rho1);
+    huber(m == 2 ? st.hm : st.hs, r[0] * r[0] + r[1] * r[1] + r[2] * r[2], rho0, rho1);
     int t = 0;
 #pragma unroll
     for (int a = 0; a < 6; a++) {
@@ -1138,7 +1139,7 @@ __global__ __launch_bounds__(256) void k_ba_backsub(BaDev B) {
       const int m = edge_eval<false, false>(P, pn, B.e_obs[3 * e], B.e_obs[3 * e + 1], B.e_obs[3 * e + 2], B.e_is[e],
                                             B.K, r, nullptr, nullptr);
       double rho0, rho1;
-      huber(m == 2 ? B.hm : B.hs, r[0] * r[0] + r[1] * r[1] + r[2] * r[2], rho0, rho1);
+      huber(m == 2 ? st.hm : st.hs, r[0] * r[0] + r[1] * r[1] + r[2] * r[2], rho0, rho1);
       v[0] += 0.5 * rho0;
     }
   }
@@ -1194,7 +1195,7 @@ __global__ __launch_bounds__(64) void k_ba_update(BaDev B) {
 }
 
 // one block: reset the LM state (keeping the ping-pong index) and refresh the pose caches
-__global__ void k_ba_begin(BaDev B, int max_it, int archive_slot) {
+__global__ void k_ba_begin(BaDev B, int max_it, int archive_slot, double hm, double hs) {
   BaState *S = B.st;
   const int cur = S->cur;
   __syncthreads();
@@ -1207,6 +1208,8 @@ __global__ void k_ba_begin(BaDev B, int max_it, int archive_slot) {
   S->decrease = 2.0;
   S->max_it = max_it;
   S->first = 1;
+  S->hm = hm;
+  S->hs = hs;
 }
 
 // flags reset for a new solve (replaces three hipMemsetAsync calls, each ~50 us of host time)
@@ -1296,6 +1299,8 @@ struct vo_ba {
   int lm_max_it = 0;
   double *ext_payload = nullptr, *ext_payload2 = nullptr;
   int archive_slot = -1;
+  bool lba_second = false;
+  std::map<int, hipGraphExec_t> graphs;  // LM iteration sequences captured per iteration count
 };
 
 namespace {
@@ -1423,7 +1428,6 @@ int build_device(vo_ba *h) {
 int lm_begin(vo_ba *h, double hm, double hs, int max_it, const uint8_t *active_caller, bool keep_device_mask) {
   VO_CHECK(build_device(h));
   BaDev &D = h->D;
-  D.hm = hm, D.hs = hs;
   hipStream_t st = h->stream;
   int set_active = 0;
   if (!keep_device_mask) {
@@ -1440,7 +1444,7 @@ int lm_begin(vo_ba *h, double hm, double hs, int max_it, const uint8_t *active_c
   hipLaunchKernelGGL(k_ba_clear, dim3((nmax + 255) / 256), dim3(256), 0, st, D, set_active, (uint8_t *)nullptr);
   if (h->n_edges > 0)
     hipLaunchKernelGGL(k_ba_mark, dim3((h->n_edges + 255) / 256), dim3(256), 0, st, D);
-  hipLaunchKernelGGL(k_ba_begin, dim3(1), dim3(64), 0, st, D, max_it, h->archive_slot);
+  hipLaunchKernelGGL(k_ba_begin, dim3(1), dim3(64), 0, st, D, max_it, h->archive_slot, hm, hs);
   VO_HIP_CHECK(hipGetLastError());
   h->lm_max_it = max_it;
   return VO_OK;
@@ -1491,12 +1495,45 @@ int lm_end(vo_ba *h, vo_lm_summary *sum) {
   return VO_OK;
 }
 
-int run_lm(vo_ba *h, int max_it) {
+void drop_graphs(vo_ba *h) {
+  for (auto &g : h->graphs) (void)hipGraphExecDestroy(g.second);
+  h->graphs.clear();
+}
+
+int run_lm_eager(vo_ba *h, int max_it) {
   for (int it = 0; it < max_it; it++) {
     VO_CHECK(launch_linearize(h));
     VO_CHECK(launch_step(h));
     VO_CHECK(launch_update(h));
   }
+  return VO_OK;
+}
+
+// The iteration sequence has fixed launch parameters (everything that varies lives in BaState), so
+// on a library-owned stream it is captured once into a hipGraph and replayed: one host call per
+// solve instead of 4 launches per iteration.
+int run_lm(vo_ba *h, int max_it) {
+  if (!h->own_stream || max_it < 1) return run_lm_eager(h, max_it);
+  auto it = h->graphs.find(max_it);
+  if (it == h->graphs.end()) {
+    hipGraph_t graph = nullptr;
+    hipGraphExec_t exec = nullptr;
+    if (hipStreamBeginCapture(h->stream, hipStreamCaptureModeThreadLocal) != hipSuccess) return run_lm_eager(h, max_it);
+    const int rc = run_lm_eager(h, max_it);
+    if (hipStreamEndCapture(h->stream, &graph) != hipSuccess || rc != VO_OK || !graph) {
+      (void)hipGetLastError();
+      if (graph) (void)hipGraphDestroy(graph);
+      return run_lm_eager(h, max_it);
+    }
+    if (hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0) != hipSuccess) {
+      (void)hipGraphDestroy(graph);
+      (void)hipGetLastError();
+      return run_lm_eager(h, max_it);
+    }
+    (void)hipGraphDestroy(graph);
+    it = h->graphs.emplace(max_it, exec).first;
+  }
+  VO_HIP_CHECK(hipGraphLaunch(it->second, h->stream));
   return VO_OK;
 }
 
@@ -1620,6 +1657,7 @@ int vo_ba_create(vo_ba **out, int n_cams, const double *poses, const uint8_t *ca
 void vo_ba_destroy(vo_ba *h) {
   if (!h) return;
   (void)hipStreamSynchronize(h->stream);
+  drop_graphs(h);
   for (vo::DevBuf *b : {&h->b_ecam, &h->b_ept, &h->b_eobs, &h->b_eis, &h->b_eact, &h->b_ptstart, &h->b_local,
                         &h->b_camslot, &h->b_slotcam, &h->b_camstart, &h->b_camedges, &h->b_ptin, &h->b_camin,
                         &h->b_xc0, &h->b_xc1, &h->b_xp0, &h->b_xp1, &h->b_pc0, &h->b_pc1, &h->b_sc, &h->b_sp, &h->b_hinv, &h->b_gl2,
@@ -1633,6 +1671,7 @@ void vo_ba_destroy(vo_ba *h) {
 int vo_ba_set_stream(vo_ba *h, void *s) {
   if (!h) return VO_ERR_INVALID;
   (void)hipStreamSynchronize(h->stream);
+  drop_graphs(h);
   if (h->own_stream) (void)hipStreamDestroy(h->stream);
   h->own_stream = false;
   h->stream = (hipStream_t)s;
@@ -1681,6 +1720,7 @@ int vo_ba_lm_end(vo_ba *h, vo_lm_summary *s) { return h && h->built ? lm_end(h, 
 
 int vo_ba_set_reduce_buffers(vo_ba *h, double *dev_system, double *dev_cost) {
   if (!h) return VO_ERR_INVALID;
+  drop_graphs(h);
   h->ext_payload = dev_system, h->ext_payload2 = dev_cost;
   if (h->built) {
     h->D.payload = dev_system ? dev_system : h->b_payload.as<double>();
@@ -1721,9 +1761,9 @@ static void summary_from_state(const BaState &s, vo_lm_summary *sum) {
   sum->final_radius = s.radius;
 }
 
-int vo_ba_local_ba(vo_ba *h, const volatile int *stop, uint8_t *edge_erase, vo_lm_summary *sums) {
-  if (!h || !edge_erase) return VO_ERR_INVALID;
-  for (int e = 0; e < h->n_edges; e++) edge_erase[e] = 0;
+int vo_ba_local_ba_enqueue(vo_ba *h, const volatile int *stop) {
+  if (!h) return VO_ERR_INVALID;
+  h->lba_second = false;
   if (stop && *stop) return VO_ERR_STOPPED;  // :594-595 (no write-back, Q-B8)
   // The whole schedule is queued without a host synchronisation in between; the stop flag is
   // polled where the reference polls it (:612), which here is at enqueue time of problem 2.
@@ -1732,26 +1772,30 @@ int vo_ba_local_ba(vo_ba *h, const volatile int *stop, uint8_t *edge_erase, vo_l
   VO_CHECK(run_lm(h, 5));
   uint8_t *out = h->b_out.as<uint8_t>();
   const dim3 eg((std::max(1, h->n_edges) + 255) / 256);
-  bool second = false;
   if (!(stop && *stop)) {  // :612
     hipLaunchKernelGGL(k_ba_classify, eg, dim3(256), 0, h->stream, h->D, 0, out);
     h->archive_slot = 0;  // problem 1's final state is archived by problem 2's begin kernel
     VO_CHECK(lm_begin(h, 0.0, 0.0, 10, nullptr, true));
     h->archive_slot = -1;
     VO_CHECK(run_lm(h, 10));
-    second = true;
+    h->lba_second = true;
   }
-  if (!second) hipLaunchKernelGGL(k_ba_clear, eg, dim3(256), 0, h->stream, h->D, 0, out);  // no outliers known yet
+  if (!h->lba_second) hipLaunchKernelGGL(k_ba_clear, eg, dim3(256), 0, h->stream, h->D, 0, out);  // no outliers known yet
   hipLaunchKernelGGL(k_ba_classify, eg, dim3(256), 0, h->stream, h->D, 1, out);
   VO_HIP_CHECK(hipGetLastError());
+  return VO_OK;
+}
+
+int vo_ba_local_ba_finish(vo_ba *h, uint8_t *edge_erase, vo_lm_summary *sums) {
+  if (!h || !edge_erase || !h->built) return VO_ERR_INVALID;
   std::vector<uint8_t> tmp(std::max(1, h->n_edges));
   BaState st[3];
-  VO_HIP_CHECK(hipMemcpyAsync(tmp.data(), out, h->n_edges, hipMemcpyDeviceToHost, h->stream));
+  VO_HIP_CHECK(hipMemcpyAsync(tmp.data(), h->b_out.p, h->n_edges, hipMemcpyDeviceToHost, h->stream));
   VO_HIP_CHECK(hipMemcpyAsync(st, h->D.st, 3 * sizeof(BaState), hipMemcpyDeviceToHost, h->stream));
   VO_HIP_CHECK(hipStreamSynchronize(h->stream));
   for (int s = 0; s < h->n_edges; s++) edge_erase[h->perm[s]] = tmp[s];
   if (sums) {
-    if (second) {
+    if (h->lba_second) {
       summary_from_state(st[1], &sums[0]);
       summary_from_state(st[0], &sums[1]);
     } else {
@@ -1760,6 +1804,14 @@ int vo_ba_local_ba(vo_ba *h, const volatile int *stop, uint8_t *edge_erase, vo_l
     }
   }
   return VO_OK;
+}
+
+int vo_ba_local_ba(vo_ba *h, const volatile int *stop, uint8_t *edge_erase, vo_lm_summary *sums) {
+  if (!h || !edge_erase) return VO_ERR_INVALID;
+  for (int e = 0; e < h->n_edges; e++) edge_erase[e] = 0;
+  const int rc = vo_ba_local_ba_enqueue(h, stop);
+  if (rc != VO_OK) return rc;
+  return vo_ba_local_ba_finish(h, edge_erase, sums);
 }
 
 int vo_ba_classify(vo_ba *h, int final_pass) {
