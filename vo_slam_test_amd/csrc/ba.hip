@@ -395,11 +395,13 @@ struct BaDev {
   double *Xc[2], *Xp[2];
   double *PC[2];            // pose caches (R row-major 9 + t 3) of Xc[0/1], one per camera
   double *scale_c, *scale_p;
-  double *hinv, *gl2, *dl;  // per point: inverse (6), scaled gradient (3), LM diagonal (3)
-  double *Wt, *Yt;          // [3*n_pts][Mpad]
+  double *hinv, *gl2, *dl;  // per point, for the current radius: inverse (6), scaled gradient (3), LM diagonal (3)
+  // linearisation products, double-buffered like the state ([cur] = at x, [cur^1] = at the candidate)
+  double *Wt[2];            // [3*n_pts][Mpad]  W_cj[a][k] * sp[k] at row 3j+k, column 6c+a; column 6nf = sp*gl
+  double *hll[2];           // [n_pts][6] packed upper triangle of sum Jl^T Jl (unscaled)
+  double *slab_pt[2];       // [n_pblocks][2]  cost, gmax
   double *slab_gemm;        // [ksplit][Mpad*Mpad]
   double *slab_cam;         // [nf][n_cchunks][27]
-  double *slab_pt;          // [n_pblocks][2]  cost, gmax
   double *payload;          // Mpad*Mpad + nf*27 + 1 + n_shards
   double *zc;               // [6nf] scale_c * y_c
   double *slab_bs;          // [n_pblocks][6]
@@ -434,117 +436,124 @@ __device__ __forceinline__ int payload_cost_off(const BaDev &B) { return B.Mpad 
 // point, Ceres' loss correction, the e-block E^T E + D and its inverse (SchurEliminator), and this
 // point's rows of the GEMM operands.
 // --------------------------------------------------------------------------------------------
-__device__ __forceinline__ void ba_points_role(const BaDev &B, const BaState &st, double *lds, double *lmx) {
-  const int tid = threadIdx.x, g = tid & (kGroup - 1);
-  const int li = blockIdx.x * kPtsPerBlock + (tid >> 3);
-  const bool valid = li < B.n_local;
-  const int j = valid ? B.local_pts[li] : 0;
-  const double *PCc = B.PC[st.cur], *Xp = B.Xp[st.cur];
-  double cost = 0, gmax = 0;
-  if (valid) {
-    const int e0 = B.pt_start[j], e1 = B.pt_start[j + 1];
-    const double pt[3] = {Xp[3 * j], Xp[3 * j + 1], Xp[3 * j + 2]};
-    double h[6] = {0, 0, 0, 0, 0, 0}, gl[3] = {0, 0, 0};
-    for (int e = e0 + g; e < e1; e += kGroup) {
-      if (!B.e_active[e]) continue;
-      const PoseCache P = load_pc(PCc, B.e_cam[e]);
-      double r[3], Jl[9];
-      const int m = edge_eval<false, true>(P, pt, B.e_obs[3 * e], B.e_obs[3 * e + 1], B.e_obs[3 * e + 2], B.e_is[e],
-                                           B.K, r, nullptr, Jl);
-      double rho0, rho1;
-      huber(m == 2 ? st.hm : st.hs, r[0] * r[0] + r[1] * r[1] + r[2] * r[2], rho0, rho1);
-      cost += 0.5 * rho0;
-      h[0] += rho1 * (Jl[0] * Jl[0] + Jl[3] * Jl[3] + Jl[6] * Jl[6]);
-      h[1] += rho1 * (Jl[0] * Jl[1] + Jl[3] * Jl[4] + Jl[6] * Jl[7]);
-      h[2] += rho1 * (Jl[0] * Jl[2] + Jl[3] * Jl[5] + Jl[6] * Jl[8]);
-      h[3] += rho1 * (Jl[1] * Jl[1] + Jl[4] * Jl[4] + Jl[7] * Jl[7]);
-      h[4] += rho1 * (Jl[1] * Jl[2] + Jl[4] * Jl[5] + Jl[7] * Jl[8]);
-      h[5] += rho1 * (Jl[2] * Jl[2] + Jl[5] * Jl[5] + Jl[8] * Jl[8]);
-      gl[0] += rho1 * (Jl[0] * r[0] + Jl[3] * r[1] + Jl[6] * r[2]);
-      gl[1] += rho1 * (Jl[1] * r[0] + Jl[4] * r[1] + Jl[7] * r[2]);
-      gl[2] += rho1 * (Jl[2] * r[0] + Jl[5] * r[1] + Jl[8] * r[2]);
-    }
-    // butterfly over the 8 lanes of the group: every lane ends with the totals
+// Linearisation of one map point at (point position `pt`, camera caches `PCs`) by the 8 lanes of
+// its group: point block Hll (unscaled) and gradient, Jacobi scale (first linearisation of a
+// solve), and the point's rows of the K-major operand matrix W (point-scaled).  Nothing here
+// depends on the trust-region radius, so the same routine linearises the *candidate* inside the
+// back-substitution kernel; the radius-dependent inverse is formed later by k_ba_gemm.
+__device__ __forceinline__ void point_linearize(const BaDev &B, const BaState &st, int j, int g, const double pt[3],
+                                                const double *PCs, int buf, double &cost, double &gmax) {
+  const int e0 = B.pt_start[j], e1 = B.pt_start[j + 1];
+  double *Wt = B.Wt[buf];
+  double h[6] = {0, 0, 0, 0, 0, 0}, gl[3] = {0, 0, 0};
+  double sp[3] = {1, 1, 1};
+  const bool first = st.first != 0;
+  if (!first) sp[0] = B.scale_p[3 * j], sp[1] = B.scale_p[3 * j + 1], sp[2] = B.scale_p[3 * j + 2];
+  for (int e = e0 + g; e < e1; e += kGroup) {
+    const int slot = B.cam_slot[B.e_cam[e]];
+    if (!B.e_active[e]) {  // rows of a deactivated edge stay zero
+      if (slot >= 0) {
+        const long long base = (long long)(3 * j) * B.Mpad + 6 * slot;
 #pragma unroll
-    for (int o = 1; o < kGroup; o <<= 1) {
+        for (int a = 0; a < 6; a++) Wt[base + a] = 0, Wt[base + B.Mpad + a] = 0, Wt[base + 2 * B.Mpad + a] = 0;
+      }
+      continue;
+    }
+    const PoseCache P = load_pc(PCs, B.e_cam[e]);
+    double r[3], Jp[18], Jl[9];
+    const int m = edge_eval<true, true>(P, pt, B.e_obs[3 * e], B.e_obs[3 * e + 1], B.e_obs[3 * e + 2], B.e_is[e],
+                                        B.K, r, Jp, Jl);
+    double rho0, rho1;
+    huber(m == 2 ? st.hm : st.hs, r[0] * r[0] + r[1] * r[1] + r[2] * r[2], rho0, rho1);
+    cost += 0.5 * rho0;
+    h[0] += rho1 * (Jl[0] * Jl[0] + Jl[3] * Jl[3] + Jl[6] * Jl[6]);
+    h[1] += rho1 * (Jl[0] * Jl[1] + Jl[3] * Jl[4] + Jl[6] * Jl[7]);
+    h[2] += rho1 * (Jl[0] * Jl[2] + Jl[3] * Jl[5] + Jl[6] * Jl[8]);
+    h[3] += rho1 * (Jl[1] * Jl[1] + Jl[4] * Jl[4] + Jl[7] * Jl[7]);
+    h[4] += rho1 * (Jl[1] * Jl[2] + Jl[4] * Jl[5] + Jl[7] * Jl[8]);
+    h[5] += rho1 * (Jl[2] * Jl[2] + Jl[5] * Jl[5] + Jl[8] * Jl[8]);
+    gl[0] += rho1 * (Jl[0] * r[0] + Jl[3] * r[1] + Jl[6] * r[2]);
+    gl[1] += rho1 * (Jl[1] * r[0] + Jl[4] * r[1] + Jl[7] * r[2]);
+    gl[2] += rho1 * (Jl[2] * r[0] + Jl[5] * r[1] + Jl[8] * r[2]);
+    if (!first && slot >= 0) {  // the scale is known: W rows can be written in the same sweep
+      const long long base = (long long)(3 * j) * B.Mpad + 6 * slot;
 #pragma unroll
-      for (int i = 0; i < 6; i++) h[i] += __shfl_xor(h[i], o);
+      for (int a = 0; a < 6; a++)
 #pragma unroll
-      for (int i = 0; i < 3; i++) gl[i] += __shfl_xor(gl[i], o);
+        for (int k = 0; k < 3; k++)
+          Wt[base + k * B.Mpad + a] = rho1 * (Jp[a] * Jl[k] + Jp[6 + a] * Jl[3 + k] + Jp[12 + a] * Jl[6 + k]) * sp[k];
     }
-    double sp[3];
-    if (st.first) {  // Jacobi scaling 1/(1+||column||), fixed after iteration 0
-      sp[0] = 1.0 / (1.0 + sqrt(h[0])), sp[1] = 1.0 / (1.0 + sqrt(h[3])), sp[2] = 1.0 / (1.0 + sqrt(h[5]));
-      if (g == 0) B.scale_p[3 * j] = sp[0], B.scale_p[3 * j + 1] = sp[1], B.scale_p[3 * j + 2] = sp[2];
-    } else {
-      sp[0] = B.scale_p[3 * j], sp[1] = B.scale_p[3 * j + 1], sp[2] = B.scale_p[3 * j + 2];
-    }
-    gmax = fmax(fabs(gl[0]), fmax(fabs(gl[1]), fabs(gl[2])));
-    double hs[6] = {h[0] * sp[0] * sp[0], h[1] * sp[0] * sp[1], h[2] * sp[0] * sp[2],
-                    h[3] * sp[1] * sp[1], h[4] * sp[1] * sp[2], h[5] * sp[2] * sp[2]};
-    const double d0 = fmin(fmax(hs[0], 1e-6), 1e32) / st.radius;
-    const double d1 = fmin(fmax(hs[3], 1e-6), 1e32) / st.radius;
-    const double d2 = fmin(fmax(hs[5], 1e-6), 1e32) / st.radius;
-    hs[0] += d0, hs[3] += d1, hs[5] += d2;
-    double hi[6];
-    if (!inv3_sym(hs, hi)) {
-      hi[0] = hi[3] = hi[5] = 0.0 / 0.0;  // poisons the step => invalid step handling
-      hi[1] = hi[2] = hi[4] = 0;
-    }
-    const double g2[3] = {gl[0] * sp[0], gl[1] * sp[1], gl[2] * sp[2]};
-    if (g == 0) {
-      for (int i = 0; i < 6; i++) B.hinv[6 * j + i] = hi[i];
-      B.gl2[3 * j] = g2[0], B.gl2[3 * j + 1] = g2[1], B.gl2[3 * j + 2] = g2[2];
-      B.dl[3 * j] = d0, B.dl[3 * j + 1] = d1, B.dl[3 * j + 2] = d2;
-      // extra GEMM column 6nf carries gl'' so that the same product yields  sum_j Y_j gl''_j
-      for (int k = 0; k < 3; k++) B.Wt[(long long)(3 * j + k) * B.Mpad + 6 * B.nf] = g2[k];
-    }
-    // second sweep: W = Jp'^T Jl' per edge, point-scaled, and Y = W Hinv
+  }
+  // butterfly over the 8 lanes of the group: every lane ends with the totals
+#pragma unroll
+  for (int o = 1; o < kGroup; o <<= 1) {
+#pragma unroll
+    for (int i = 0; i < 6; i++) h[i] += __shfl_xor(h[i], o);
+#pragma unroll
+    for (int i = 0; i < 3; i++) gl[i] += __shfl_xor(gl[i], o);
+  }
+  if (first) {  // Jacobi scaling 1/(1+||column||), fixed for the rest of the solve
+    sp[0] = 1.0 / (1.0 + sqrt(h[0])), sp[1] = 1.0 / (1.0 + sqrt(h[3])), sp[2] = 1.0 / (1.0 + sqrt(h[5]));
+    if (g == 0) B.scale_p[3 * j] = sp[0], B.scale_p[3 * j + 1] = sp[1], B.scale_p[3 * j + 2] = sp[2];
+  }
+  gmax = fmax(gmax, fmax(fabs(gl[0]), fmax(fabs(gl[1]), fabs(gl[2]))));
+  if (g == 0) {
+#pragma unroll
+    for (int i = 0; i < 6; i++) B.hll[buf][6 * j + i] = h[i];
+    // extra GEMM column 6nf carries the scaled gradient so that the same product yields sum_j Y_j gl''_j
+#pragma unroll
+    for (int k = 0; k < 3; k++) Wt[(long long)(3 * j + k) * B.Mpad + 6 * B.nf] = gl[k] * sp[k];
+  }
+  if (first) {  // second sweep, now that the scale exists
     for (int e = e0 + g; e < e1; e += kGroup) {
       const int slot = B.cam_slot[B.e_cam[e]];
-      if (slot < 0) continue;
-      if (!B.e_active[e]) {  // keep the operand rows of a deactivated edge at zero (no per-solve memset)
-        if (st.first) {
-          const long long base = (long long)(3 * j) * B.Mpad + 6 * slot;
-#pragma unroll
-          for (int a = 0; a < 6; a++) {
-            B.Wt[base + a] = 0, B.Wt[base + B.Mpad + a] = 0, B.Wt[base + 2 * B.Mpad + a] = 0;
-            B.Yt[base + a] = 0, B.Yt[base + B.Mpad + a] = 0, B.Yt[base + 2 * B.Mpad + a] = 0;
-          }
-        }
-        continue;
-      }
-      const PoseCache P = load_pc(PCc, B.e_cam[e]);
+      if (slot < 0 || !B.e_active[e]) continue;
+      const PoseCache P = load_pc(PCs, B.e_cam[e]);
       double r[3], Jp[18], Jl[9];
       const int m = edge_eval<true, true>(P, pt, B.e_obs[3 * e], B.e_obs[3 * e + 1], B.e_obs[3 * e + 2], B.e_is[e],
                                           B.K, r, Jp, Jl);
       double rho0, rho1;
       huber(m == 2 ? st.hm : st.hs, r[0] * r[0] + r[1] * r[1] + r[2] * r[2], rho0, rho1);
+      const long long base = (long long)(3 * j) * B.Mpad + 6 * slot;
 #pragma unroll
-      for (int a = 0; a < 6; a++) {
-        double w[3];
+      for (int a = 0; a < 6; a++)
 #pragma unroll
         for (int k = 0; k < 3; k++)
-          w[k] = rho1 * (Jp[a] * Jl[k] + Jp[6 + a] * Jl[3 + k] + Jp[12 + a] * Jl[6 + k]) * sp[k];
-        const double y0 = w[0] * hi[0] + w[1] * hi[1] + w[2] * hi[2];
-        const double y1 = w[0] * hi[1] + w[1] * hi[3] + w[2] * hi[4];
-        const double y2 = w[0] * hi[2] + w[1] * hi[4] + w[2] * hi[5];
-        const long long base = (long long)(3 * j) * B.Mpad + 6 * slot + a;
-        B.Wt[base] = w[0], B.Wt[base + B.Mpad] = w[1], B.Wt[base + 2 * B.Mpad] = w[2];
-        B.Yt[base] = y0, B.Yt[base + B.Mpad] = y1, B.Yt[base + 2 * B.Mpad] = y2;
-      }
+          Wt[base + k * B.Mpad + a] = rho1 * (Jp[a] * Jl[k] + Jp[6 + a] * Jl[3 + k] + Jp[12 + a] * Jl[6 + k]) * sp[k];
     }
   }
-  // block partials: cost (sum), gmax (max).  Only lane g==0.. all lanes hold their own cost part.
+}
+
+// block partials of a point pass: cost (sum) and gradient max-norm
+__device__ __forceinline__ void store_point_partials(const BaDev &B, int buf, double cost, double gmax, double *lds,
+                                                     double *lmx) {
+  const int tid = threadIdx.x;
   double c[1] = {cost};
   block_sum<1>(c, lds);
-  double gm = wave_max(gmax);
+  const double gm = wave_max(gmax);
   if ((tid & 63) == 0) lmx[tid >> 6] = gm;
   __syncthreads();
   if (tid == 0) {
-    B.slab_pt[2 * blockIdx.x] = c[0];
-    B.slab_pt[2 * blockIdx.x + 1] = fmax(fmax(lmx[0], lmx[1]), fmax(lmx[2], lmx[3]));
+    B.slab_pt[buf][2 * blockIdx.x] = c[0];
+    B.slab_pt[buf][2 * blockIdx.x + 1] = fmax(fmax(lmx[0], lmx[1]), fmax(lmx[2], lmx[3]));
   }
+}
+
+// first linearisation of a solve, at the current state
+__global__ __launch_bounds__(256) void k_ba_lin0(BaDev B) {
+  __shared__ double lds[4];
+  __shared__ double lmx[4];
+  const BaState st = *B.st;
+  const int tid = threadIdx.x, g = tid & (kGroup - 1);
+  const int li = blockIdx.x * kPtsPerBlock + (tid >> 3);
+  double cost = 0, gmax = 0;
+  if (li < B.n_local) {
+    const int j = B.local_pts[li];
+    const double *Xp = B.Xp[st.cur];
+    const double pt[3] = {Xp[3 * j], Xp[3 * j + 1], Xp[3 * j + 2]};
+    point_linearize(B, st, j, g, pt, B.PC[st.cur], st.cur, cost, gmax);
+  }
+  store_point_partials(B, st.cur, cost, gmax, lds, lmx);
 }
 
 // --------------------------------------------------------------------------------------------
@@ -586,21 +595,6 @@ __device__ __forceinline__ void ba_cams_role(const BaDev &B, const BaState &st, 
   }
 }
 
-// one launch for the whole linearisation: blocks [0, n_pblocks) work on points, the rest on
-// (camera, chunk) pairs -- the two roles are independent and overlap on the chip
-__global__ __launch_bounds__(256) void k_ba_linearize(BaDev B) {
-  __shared__ double lds[4 * 27];
-  __shared__ double lmx[4];
-  const BaState st = *B.st;
-  if (st.done) return;
-  if ((int)blockIdx.x < B.n_pblocks) {
-    ba_points_role(B, st, lds, lmx);
-  } else {
-    const int q = blockIdx.x - B.n_pblocks;
-    ba_cams_role(B, st, q / B.n_cchunks, q % B.n_cchunks, lds);
-  }
-}
-
 // --------------------------------------------------------------------------------------------
 // k_ba_gemm: partial tiles of  G = Y * W^T  with G[m][n] = sum_k Yt[k][m] * Wt[k][n] on the FP64
 // matrix cores.  One 16x16 tile per wavefront per K-slice; A operand: lane l holds
@@ -609,43 +603,95 @@ __global__ __launch_bounds__(256) void k_ba_linearize(BaDev B) {
 // --------------------------------------------------------------------------------------------
 typedef double double4_t __attribute__((ext_vector_type(4)));
 
+constexpr int kChunkPts = 512;  // points per K-slice (LDS table of their damped inverses)
+
 __global__ __launch_bounds__(256) void k_ba_gemm(BaDev B) {
   __shared__ double part[4][256];
+  __shared__ double hinvL[kChunkPts * 6];
+  __shared__ double lds27[4 * 27];
   const BaState st = *B.st;
   if (st.done) return;
-  const int tiles = B.Mpad / 16;
-  // upper-triangular tile index -> (tm <= tn)
-  int tile = blockIdx.x, tm = 0;
-  while (tile >= tiles - tm) {
-    tile -= tiles - tm;
+  const int tdim = B.Mpad / 16, ntiles = tdim * (tdim + 1) / 2;
+  if ((int)blockIdx.x >= ntiles * B.ksplit) {  // camera-block role (independent of the tiles)
+    const int q = blockIdx.x - ntiles * B.ksplit;
+    ba_cams_role(B, st, q / B.n_cchunks, q % B.n_cchunks, lds27);
+    return;
+  }
+  const int ks = blockIdx.x / ntiles;
+  int tile = blockIdx.x - ks * ntiles, tm = 0;
+  while (tile >= tdim - tm) {  // upper-triangular tile index -> (tm <= tn)
+    tile -= tdim - tm;
     tm++;
   }
   const int tn = tm + tile;
-  const int ks = blockIdx.y, wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   const int K = 3 * B.n_pts;
-  const int kb0 = ks * B.kchunk, kb1 = min(K, kb0 + B.kchunk);
+  const int kb0 = ks * B.kchunk, kb1 = min(K, kb0 + B.kchunk);  // kchunk is a multiple of 48: whole points
+  // ---- damped inverse of every point block of this K-slice (SchurEliminator: (E^T E + D)^-1).
+  // Each tile block needs them for its own A operand; the tile-0 block also publishes them for the
+  // back-substitution.
+  const int j0 = kb0 / 3, npts = (kb1 - kb0) / 3;
+  const double *hl = B.hll[st.cur];
+  const double *W = B.Wt[st.cur];
+  for (int t = tid; t < npts; t += 256) {
+    const int j = j0 + t;
+    const double sp0 = B.scale_p[3 * j], sp1 = B.scale_p[3 * j + 1], sp2 = B.scale_p[3 * j + 2];
+    double hs[6] = {hl[6 * j] * sp0 * sp0, hl[6 * j + 1] * sp0 * sp1, hl[6 * j + 2] * sp0 * sp2,
+                    hl[6 * j + 3] * sp1 * sp1, hl[6 * j + 4] * sp1 * sp2, hl[6 * j + 5] * sp2 * sp2};
+    const double d0 = fmin(fmax(hs[0], 1e-6), 1e32) / st.radius;
+    const double d1 = fmin(fmax(hs[3], 1e-6), 1e32) / st.radius;
+    const double d2 = fmin(fmax(hs[5], 1e-6), 1e32) / st.radius;
+    hs[0] += d0, hs[3] += d1, hs[5] += d2;
+    double hi[6];
+    if (!inv3_sym(hs, hi)) {
+      hi[0] = hi[3] = hi[5] = 0.0 / 0.0;  // poisons the step => invalid step handling
+      hi[1] = hi[2] = hi[4] = 0;
+    }
+#pragma unroll
+    for (int i = 0; i < 6; i++) hinvL[6 * t + i] = hi[i];
+    if (tm == 0 && tn == 0) {
+#pragma unroll
+      for (int i = 0; i < 6; i++) B.hinv[6 * j + i] = hi[i];
+      B.dl[3 * j] = d0, B.dl[3 * j + 1] = d1, B.dl[3 * j + 2] = d2;
+#pragma unroll
+      for (int k = 0; k < 3; k++) B.gl2[3 * j + k] = W[(long long)(3 * j + k) * B.Mpad + 6 * B.nf];
+    }
+  }
+  __syncthreads();
   const int q = ((kb1 - kb0 + 15) / 16) * 4;  // rows per wave, multiple of 4
   const int k0 = kb0 + wave * q, k1 = min(kb1, k0 + q);
   double4_t acc = {0, 0, 0, 0};
   const int kk = lane >> 4, ii = lane & 15;
-  const double *Ya = B.Yt + tm * 16 + ii, *Wb = B.Wt + tn * 16 + ii;
+  const double *Wa = W + tm * 16 + ii, *Wb = W + tn * 16 + ii;
+  // A[m][3j+c] = sum_c' W[3j+c'][m] * Hinv_j[c'][c]  is formed on the fly (Y is never stored)
+  auto sym = [](const double *hv, int r, int c) {  // packed upper {00,01,02,11,12,22}
+    const int a = r < c ? r : c, b = r < c ? c : r;
+    return hv[a == 0 ? b : (a == 1 ? 2 + b : 5)];
+  };
   int k = k0;
-  for (; k + 32 <= k1; k += 32) {  // 8 independent load pairs in flight per lane
-    double a[8], b[8];
+  for (; k + 16 <= k1; k += 16) {  // 4 MFMA steps: 16 independent loads in flight per lane
+    double a[4], b[4];
 #pragma unroll
-    for (int u = 0; u < 8; u++) {
-      const long long row = (long long)(k + 4 * u + kk) * B.Mpad;
-      a[u] = Ya[row];
-      b[u] = Wb[row];
+    for (int u = 0; u < 4; u++) {
+      const int kr = k + 4 * u + kk;
+      const int j = kr / 3, c = kr - 3 * j;
+      const double *hv = &hinvL[6 * (j - j0)];
+      const long long r3 = (long long)(3 * j) * B.Mpad;
+      const double w0 = Wa[r3], w1 = Wa[r3 + B.Mpad], w2 = Wa[r3 + 2 * B.Mpad];
+      a[u] = w0 * sym(hv, 0, c) + w1 * sym(hv, 1, c) + w2 * sym(hv, 2, c);
+      b[u] = Wb[(long long)kr * B.Mpad];
     }
 #pragma unroll
-    for (int u = 0; u < 8; u++) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a[u], b[u], acc, 0, 0, 0);
+    for (int u = 0; u < 4; u++) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a[u], b[u], acc, 0, 0, 0);
   }
   for (; k < k1; k += 4) {
     const int kr = k + kk;
     double a = 0, b = 0;
     if (kr < k1) {
-      a = Ya[(long long)kr * B.Mpad];
+      const int j = kr / 3, c = kr - 3 * j;
+      const double *hv = &hinvL[6 * (j - j0)];
+      const long long r3 = (long long)(3 * j) * B.Mpad;
+      a = Wa[r3] * sym(hv, 0, c) + Wa[r3 + B.Mpad] * sym(hv, 1, c) + Wa[r3 + 2 * B.Mpad] * sym(hv, 2, c);
       b = Wb[(long long)kr * B.Mpad];
     }
     acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc, 0, 0, 0);
@@ -662,7 +708,7 @@ __global__ __launch_bounds__(256) void k_ba_gemm(BaDev B) {
   }
   st_sc1(&B.slab_gemm[(long long)ks * B.Mpad * B.Mpad + eoff], v);
   __shared__ int s_last;
-  if (!arrive_and_check_last(&B.counters[1 + blockIdx.x], gridDim.y, &s_last)) return;
+  if (!arrive_and_check_last(&B.counters[1 + (tm * tdim + tn)], (unsigned)B.ksplit, &s_last)) return;
   double sv[8];
 #pragma unroll
   for (int u = 0; u < 8; u++) sv[u] = u < B.ksplit ? ld_sc1(&B.slab_gemm[(long long)u * B.Mpad * B.Mpad + eoff]) : 0.0;
@@ -702,9 +748,10 @@ __global__ __launch_bounds__(256) void k_ba_reduce(BaDev B) {
     if (sub == 0) B.payload[i] = s;
   } else if (i == nG + nH && sub == 0) {
     double cs = 0, m = 0;
+    const double *sp = B.slab_pt[st.cur];
     for (int b = 0; b < B.n_pblocks; b++) {
-      cs += B.slab_pt[2 * b];
-      m = fmax(m, B.slab_pt[2 * b + 1]);
+      cs += sp[2 * b];
+      m = fmax(m, sp[2 * b + 1]);
     }
     B.payload[i] = cs;
     for (int k = 0; k < B.n_shards; k++) B.payload[i + 1 + k] = (k == B.shard) ? m : 0.0;
@@ -804,9 +851,10 @@ __global__ __launch_bounds__(256) void k_ba_solve(BaDev B) {
     if (tid >= 192) {  // last wave: cost (sum) and gradient max over the point blocks
       const int l = tid - 192;
       double cs = 0, m = 0;
+      const double *spt = B.slab_pt[S->cur];
       for (int b = l; b < B.n_pblocks; b += 64) {
-        cs += B.slab_pt[2 * b];
-        m = fmax(m, B.slab_pt[2 * b + 1]);
+        cs += spt[2 * b];
+        m = fmax(m, spt[2 * b + 1]);
       }
       cs = wave_sum(cs);
       m = wave_max(m);
@@ -1081,6 +1129,7 @@ __device__ void ba_update_logic(const BaDev &B) {
 // --------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_ba_backsub(BaDev B) {
   __shared__ double lds[4 * 6];
+  __shared__ double lmx[4];
   const BaState st = *B.st;
   if (st.done) return;
   const int tid = threadIdx.x, g = tid & (kGroup - 1);
@@ -1089,7 +1138,9 @@ __global__ __launch_bounds__(256) void k_ba_backsub(BaDev B) {
   const int j = valid ? B.local_pts[li] : 0;
   const double *Xp = B.Xp[st.cur];
   double *Xpn = B.Xp[st.cur ^ 1];
+  const double *W = B.Wt[st.cur];
   double v[6] = {0, 0, 0, 0, 0, 0};  // cand_cost, gdot_l, dquad_l, step2, xnorm2, candnorm2
+  double ccost = 0, cgmax = 0;
   if (valid) {
     const int e0 = B.pt_start[j], e1 = B.pt_start[j + 1];
     double rr[3] = {0, 0, 0};
@@ -1101,9 +1152,9 @@ __global__ __launch_bounds__(256) void k_ba_backsub(BaDev B) {
 #pragma unroll
       for (int a = 0; a < 6; a++) {
         const double z = B.zc[6 * slot + a];
-        rr[0] += B.Wt[base + a] * z;
-        rr[1] += B.Wt[base + B.Mpad + a] * z;
-        rr[2] += B.Wt[base + 2 * B.Mpad + a] * z;
+        rr[0] += W[base + a] * z;
+        rr[1] += W[base + B.Mpad + a] * z;
+        rr[2] += W[base + 2 * B.Mpad + a] * z;
       }
     }
 #pragma unroll
@@ -1132,17 +1183,13 @@ __global__ __launch_bounds__(256) void k_ba_backsub(BaDev B) {
         }
       }
     }
-    for (int e = e0 + g; e < e1; e += kGroup) {
-      if (!B.e_active[e]) continue;
-      const PoseCache P = load_pc(B.PC[st.cur ^ 1], B.e_cam[e]);
-      double r[3];
-      const int m = edge_eval<false, false>(P, pn, B.e_obs[3 * e], B.e_obs[3 * e + 1], B.e_obs[3 * e + 2], B.e_is[e],
-                                            B.K, r, nullptr, nullptr);
-      double rho0, rho1;
-      huber(m == 2 ? st.hm : st.hs, r[0] * r[0] + r[1] * r[1] + r[2] * r[2], rho0, rho1);
-      v[0] += 0.5 * rho0;
-    }
+    // candidate cost and, in the same sweep, the complete (radius-independent) linearisation at the
+    // candidate into the other buffer set: if the step is accepted the next iteration starts from it
+    point_linearize(B, st, j, g, pn, B.PC[st.cur ^ 1], st.cur ^ 1, ccost, cgmax);
+    v[0] = ccost;
   }
+  store_point_partials(B, st.cur ^ 1, ccost, cgmax, lds, lmx);
+  __syncthreads();
   block_sum<6>(v, lds);
   if (tid == 0) {
 #pragma unroll
@@ -1293,7 +1340,7 @@ struct vo_ba {
   bool built = false;
   BaDev D{};
   vo::DevBuf b_ecam, b_ept, b_eobs, b_eis, b_eact, b_ptstart, b_local, b_camslot, b_slotcam, b_camstart,
-      b_camedges, b_ptin, b_camin, b_xc0, b_xc1, b_xp0, b_xp1, b_pc0, b_pc1, b_sc, b_sp, b_hinv, b_gl2, b_dl, b_wt, b_yt,
+      b_camedges, b_ptin, b_camin, b_xc0, b_xc1, b_xp0, b_xp1, b_pc0, b_pc1, b_sc, b_sp, b_hinv, b_gl2, b_dl, b_wt, b_wt1, b_hll0, b_hll1, b_spt1,
       b_sgemm, b_scam, b_spt, b_payload, b_zc, b_sbs, b_payload2, b_state, b_out, b_dbg, b_cnt;
   size_t solve_lds = 0;
   int lm_max_it = 0;
@@ -1347,10 +1394,15 @@ int build_device(vo_ba *h) {
   D.n_pblocks = std::max(1, (D.n_local + kPtsPerBlock - 1) / kPtsPerBlock);
   const int K = 3 * h->n_pts;
   const int tiles = (D.Mpad / 16) * (D.Mpad / 16 + 1) / 2;
-  int ks = std::max(1, std::min(8, 128 / tiles));  // <= 8 slabs: one load batch in k_ba_reduce
+  int ks = std::max(1, std::min(8, 128 / tiles));  // <= 8 slabs: one load batch per reduction
   ks = std::min(ks, std::max(1, K / 128));
-  D.kchunk = ((K + ks - 1) / ks + 15) / 16 * 16;
+  D.kchunk = ((K + ks - 1) / ks + 47) / 48 * 48;  // multiple of 16 (MFMA slices) and of 3 (whole points)
   D.ksplit = std::max(1, (K + D.kchunk - 1) / D.kchunk);
+  if (D.kchunk / 3 > kChunkPts || D.ksplit > 8) {
+    vo::set_error("local BA with %d points exceeds this round's dense Schur path (%d points per K slice, 8 slices)",
+                  h->n_pts, kChunkPts);
+    return VO_ERR_CAPACITY;
+  }
   VO_CHECK(upload(h->b_ecam, h->e_cam.data(), h->e_cam.size() * 4));
   VO_CHECK(upload(h->b_ept, h->e_pt.data(), h->e_pt.size() * 4));
   VO_CHECK(upload(h->b_eobs, h->e_obs.data(), h->e_obs.size() * 8));
@@ -1377,13 +1429,18 @@ int build_device(vo_ba *h) {
   VO_CHECK(h->b_gl2.reserve((size_t)std::max(1, h->n_pts) * 3 * 8));
   VO_CHECK(h->b_dl.reserve((size_t)std::max(1, h->n_pts) * 3 * 8));
   VO_CHECK(h->b_wt.reserve((size_t)std::max(1, K) * D.Mpad * 8));
-  VO_CHECK(h->b_yt.reserve((size_t)std::max(1, K) * D.Mpad * 8));
+  VO_CHECK(h->b_wt1.reserve((size_t)std::max(1, K) * D.Mpad * 8));
+  VO_CHECK(h->b_hll0.reserve((size_t)std::max(1, h->n_pts) * 6 * 8));
+  VO_CHECK(h->b_hll1.reserve((size_t)std::max(1, h->n_pts) * 6 * 8));
+  VO_HIP_CHECK(hipMemset(h->b_hll0.p, 0, (size_t)std::max(1, h->n_pts) * 6 * 8));
+  VO_HIP_CHECK(hipMemset(h->b_hll1.p, 0, (size_t)std::max(1, h->n_pts) * 6 * 8));
   // operand matrices start out all-zero; only (point, camera) pairs that have an edge are ever written
   VO_HIP_CHECK(hipMemset(h->b_wt.p, 0, (size_t)std::max(1, K) * D.Mpad * 8));
-  VO_HIP_CHECK(hipMemset(h->b_yt.p, 0, (size_t)std::max(1, K) * D.Mpad * 8));
+  VO_HIP_CHECK(hipMemset(h->b_wt1.p, 0, (size_t)std::max(1, K) * D.Mpad * 8));
   VO_CHECK(h->b_sgemm.reserve((size_t)D.ksplit * D.Mpad * D.Mpad * 8));
   VO_CHECK(h->b_scam.reserve((size_t)std::max(1, h->nf) * D.n_cchunks * 27 * 8));
   VO_CHECK(h->b_spt.reserve((size_t)D.n_pblocks * 2 * 8));
+  VO_CHECK(h->b_spt1.reserve((size_t)D.n_pblocks * 2 * 8));
   VO_CHECK(h->b_payload.reserve(((size_t)D.Mpad * D.Mpad + (size_t)h->nf * 27 + 1 + h->n_shards) * 8));
   VO_CHECK(h->b_zc.reserve((size_t)std::max(1, 6 * h->nf) * 8));
   VO_CHECK(h->b_sbs.reserve((size_t)D.n_pblocks * 6 * 8));
@@ -1408,8 +1465,10 @@ int build_device(vo_ba *h) {
   D.PC[0] = h->b_pc0.as<double>(), D.PC[1] = h->b_pc1.as<double>();
   D.scale_c = h->b_sc.as<double>(), D.scale_p = h->b_sp.as<double>();
   D.hinv = h->b_hinv.as<double>(), D.gl2 = h->b_gl2.as<double>(), D.dl = h->b_dl.as<double>();
-  D.Wt = h->b_wt.as<double>(), D.Yt = h->b_yt.as<double>();
-  D.slab_gemm = h->b_sgemm.as<double>(), D.slab_cam = h->b_scam.as<double>(), D.slab_pt = h->b_spt.as<double>();
+  D.Wt[0] = h->b_wt.as<double>(), D.Wt[1] = h->b_wt1.as<double>();
+  D.hll[0] = h->b_hll0.as<double>(), D.hll[1] = h->b_hll1.as<double>();
+  D.slab_pt[0] = h->b_spt.as<double>(), D.slab_pt[1] = h->b_spt1.as<double>();
+  D.slab_gemm = h->b_sgemm.as<double>(), D.slab_cam = h->b_scam.as<double>();
   D.payload = h->ext_payload ? h->ext_payload : h->b_payload.as<double>();
   D.zc = h->b_zc.as<double>();
   D.slab_bs = h->b_sbs.as<double>();
@@ -1445,6 +1504,7 @@ int lm_begin(vo_ba *h, double hm, double hs, int max_it, const uint8_t *active_c
   if (h->n_edges > 0)
     hipLaunchKernelGGL(k_ba_mark, dim3((h->n_edges + 255) / 256), dim3(256), 0, st, D);
   hipLaunchKernelGGL(k_ba_begin, dim3(1), dim3(64), 0, st, D, max_it, h->archive_slot, hm, hs);
+  hipLaunchKernelGGL(k_ba_lin0, dim3(D.n_pblocks), dim3(256), 0, st, D);  // first linearisation of the solve
   VO_HIP_CHECK(hipGetLastError());
   h->lm_max_it = max_it;
   return VO_OK;
@@ -1453,9 +1513,9 @@ int lm_begin(vo_ba *h, double hm, double hs, int max_it, const uint8_t *active_c
 int launch_linearize(vo_ba *h) {
   BaDev &D = h->D;
   hipStream_t st = h->stream;
-  hipLaunchKernelGGL(k_ba_linearize, dim3(D.n_pblocks + h->nf * D.n_cchunks), dim3(256), 0, st, D);
   const int tdim = D.Mpad / 16, tiles = tdim * (tdim + 1) / 2;
-  hipLaunchKernelGGL(k_ba_gemm, dim3(tiles, D.ksplit), dim3(256), 0, st, D);
+  // Schur product tiles and the camera blocks in one launch (independent roles)
+  hipLaunchKernelGGL(k_ba_gemm, dim3(tiles * D.ksplit + h->nf * D.n_cchunks), dim3(256), 0, st, D);
   if (!D.fused) {
     const int np = (D.Mpad * D.Mpad + h->nf * 27 + 1) * 4;
     hipLaunchKernelGGL(k_ba_reduce, dim3((np + 255) / 256), dim3(256), 0, st, D);
@@ -1661,7 +1721,7 @@ void vo_ba_destroy(vo_ba *h) {
   for (vo::DevBuf *b : {&h->b_ecam, &h->b_ept, &h->b_eobs, &h->b_eis, &h->b_eact, &h->b_ptstart, &h->b_local,
                         &h->b_camslot, &h->b_slotcam, &h->b_camstart, &h->b_camedges, &h->b_ptin, &h->b_camin,
                         &h->b_xc0, &h->b_xc1, &h->b_xp0, &h->b_xp1, &h->b_pc0, &h->b_pc1, &h->b_sc, &h->b_sp, &h->b_hinv, &h->b_gl2,
-                        &h->b_dl, &h->b_wt, &h->b_yt, &h->b_sgemm, &h->b_scam, &h->b_spt, &h->b_payload, &h->b_zc,
+                        &h->b_dl, &h->b_wt, &h->b_wt1, &h->b_hll0, &h->b_hll1, &h->b_spt1, &h->b_sgemm, &h->b_scam, &h->b_spt, &h->b_payload, &h->b_zc,
                         &h->b_sbs, &h->b_payload2, &h->b_state, &h->b_out, &h->b_dbg, &h->b_cnt})
     b->release();
   if (h->own_stream) (void)hipStreamDestroy(h->stream);
