@@ -363,7 +363,7 @@ __global__ __launch_bounds__(256) void k_pose_only(const int *offsets, const dou
 // ============================================================================================
 constexpr int kGroup = 8;        // lanes per map point
 constexpr int kPtsPerBlock = 32; // 256 / kGroup
-constexpr int kCamChunk = 1024;  // edges per camera-role block (four per thread; the role is off the critical path)
+constexpr int kCamChunk = 256;   // edges per camera-role block (one per thread: the role shares a launch with the Schur tiles)
 constexpr int kMaxN = 128;       // reduced system size limit of the LDS Cholesky (6*nf + 1 <= kMaxN)
 
 struct BaState {
@@ -1573,7 +1573,14 @@ int run_lm_eager(vo_ba *h, int max_it) {
 // on a library-owned stream it is captured once into a hipGraph and replayed: one host call per
 // solve instead of 4 launches per iteration.
 int run_lm(vo_ba *h, int max_it) {
-  if (!h->own_stream || max_it < 1) return run_lm_eager(h, max_it);
+  // Measured on MI355X / ROCm 7.2: replaying a 30-45 node graph costs ~100-200 us of host time before
+  // the first node starts, while eager launches (~4 us each) stay ahead of ~20 us kernels.  Graph
+  // replay is therefore opt-in (VO_BA_GRAPH=1), for hosts whose launch path is the bottleneck.
+  static const bool use_graph = [] {
+    const char *e = getenv("VO_BA_GRAPH");
+    return e && e[0] == '1';
+  }();
+  if (!use_graph || !h->own_stream || max_it < 1) return run_lm_eager(h, max_it);
   auto it = h->graphs.find(max_it);
   if (it == h->graphs.end()) {
     hipGraph_t graph = nullptr;
