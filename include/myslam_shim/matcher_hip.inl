@@ -1,8 +1,9 @@
 // include/myslam_shim/matcher_hip.inl -- replacement bodies for the hot members of myslam::Matcher
 // (reference src/matcher.cpp).  #include this file at the bottom of a copy of matcher.cpp from which
-// computeDistance (:1240-1256) and the two projection searches (:18-148, :274-353) were removed; the
-// remaining members (BoW / Sim3 / fuse) keep calling Matcher::computeDistance, which now goes to the
-// device for batches and stays scalar for single pairs.
+// computeDistance (:1240-1256), the projection searches (:18-148, :150-272, :274-353), the two
+// searchByBoW overloads (:449-559, :561-677), searchForTriangulation (:867-1010) and fuseMapPoints
+// (:1012-1133) were removed; the Sim3 members (:356-447, :679-865, :1135-1238) keep calling
+// Matcher::computeDistance.
 //
 // Needs the reference's headers (Frame, MapPoint, Camera): compile inside the reference tree.
 #include <vector>
@@ -16,7 +17,8 @@ struct FrameFlat {
   std::vector<float> x, y, angle;
   std::vector<int32_t> octave;
   vo_frame_view view;
-  explicit FrameFlat(Frame *f) {
+  template <class F>  // Frame and KeyFrame expose the same members (frame.h:26-45, keyframe.h)
+  explicit FrameFlat(F *f) {
     const int n = (int)f->unKeypoints_.size();
     x.resize(n), y.resize(n), angle.resize(n), octave.resize(n);
     for (int i = 0; i < n; i++) {
@@ -104,6 +106,173 @@ int Matcher::searchByProjection(Frame *frame, const vector<MapPoint *> &mappoint
   for (int k = 0; k < nf; k++)
     if (assigned[k] >= 0) frame->mappoints_[k] = mappoints[assigned[k]];
   return n;
+}
+
+// DBoW3::FeatureVector (std::map<NodeId, std::vector<unsigned>>) -> CSR view
+struct BowFlat {
+  std::vector<uint32_t> node, feat;
+  std::vector<int32_t> start;
+  vo_bow_view view;
+  explicit BowFlat(const DBoW3::FeatureVector &fv) {
+    start.push_back(0);
+    for (const auto &kv : fv) {
+      node.push_back(kv.first);
+      feat.insert(feat.end(), kv.second.begin(), kv.second.end());
+      start.push_back((int32_t)feat.size());
+    }
+    view.n_nodes = (int32_t)node.size();
+    view.node_id = node.data(), view.start = start.data(), view.feat = feat.data();
+  }
+};
+
+// Matcher::searchByProjection(Frame*, KeyFrame*, radius, distThreshold, found, checkRot), :150-272
+int Matcher::searchByProjection(Frame *cur, KeyFrame *kf, const float radius, const float distThreshold,
+                                const set<MapPoint *> &found, bool checkRot) {
+  Camera *cam = cur->camera_;
+  const int xMax = cur->xMax_, xMin = cur->xMin_, yMax = cur->yMax_, yMin = cur->yMin_;
+  const SE3 Tcw = cur->Tcw_;
+  const Vector3d Ow = Tcw.inverse().translation();
+  const vector<MapPoint *> mps = kf->getMapPoints();
+  const int nq = (int)mps.size();
+  std::vector<uint8_t> flags(nq, 0), qdesc((size_t)nq * 32, 0);
+  std::vector<float> u(nq), v(nq), ang(nq);
+  std::vector<int32_t> lvl(nq);
+  for (int i = 0; i < nq; i++) {
+    MapPoint *mp = mps[i];
+    if (!mp || mp->isBad() || found.count(mp)) continue;
+    const Vector3d pc = Tcw * mp->getPose();
+    if (static_cast<float>(pc[2]) <= 0) continue;
+    const Vector2d px = cam->camera2pixel(pc);
+    const float uu = px[0], vv = px[1];
+    if (uu > xMax || uu < xMin || vv > yMax || vv < yMin) continue;
+    const float dist = (mp->getPose() - Ow).norm();
+    if (dist < mp->getMinDistanceThreshold() || dist > mp->getMaxDistanceThreshold()) continue;
+    flags[i] = 1, u[i] = uu, v[i] = vv, lvl[i] = mp->predictScale(dist, cur);
+    ang[i] = kf->unKeypoints_[i].angle;
+    memcpy(&qdesc[(size_t)i * 32], mp->getDescriptor().data, 32);
+  }
+  FrameFlat ff(cur);
+  std::vector<uint8_t> has(ff.view.n);
+  std::vector<int32_t> assigned(ff.view.n, -1);
+  for (int k = 0; k < ff.view.n; k++) has[k] = cur->mappoints_[k] != nullptr;
+  int n = 0;
+  vo_match_frame_keyframe(&ff.view, nq, flags.data(), u.data(), v.data(), lvl.data(), ang.data(), qdesc.data(), radius,
+                          distThreshold, checkRot ? 1 : 0, kf->scaleFactors_.data(), has.data(), assigned.data(), &n);
+  for (int k = 0; k < ff.view.n; k++)
+    if (assigned[k] >= 0) cur->mappoints_[k] = mps[assigned[k]];
+  return n;
+}
+
+// Matcher::searchByBoW(KeyFrame*, Frame*, matches, checkRot), :449-559
+int Matcher::searchByBoW(KeyFrame *kf, Frame *frame, vector<MapPoint *> &matches, bool checkRot) {
+  matches.assign(frame->N_, static_cast<MapPoint *>(nullptr));
+  const vector<MapPoint *> mps = kf->getMapPoints();
+  std::vector<uint8_t> valid(mps.size());
+  for (size_t i = 0; i < mps.size(); i++) valid[i] = mps[i] && !mps[i]->isBad();
+  FrameFlat a(kf), b(frame);
+  BowFlat an(kf->featVec_), bn(frame->featVec_);
+  std::vector<int32_t> m(frame->N_, -1);
+  int n = 0;
+  vo_match_bow(&a.view, valid.data(), &an.view, &b.view, nullptr, &bn.view, 0, ratio_, checkRot ? 1 : 0, m.data(), &n);
+  for (int k = 0; k < frame->N_; k++)
+    if (m[k] >= 0) matches[k] = mps[m[k]];
+  return n;
+}
+
+// Matcher::searchByBoW(KeyFrame*, KeyFrame*, matches, checkRot), :561-677
+int Matcher::searchByBoW(KeyFrame *kf1, KeyFrame *kf2, vector<MapPoint *> &matches12, bool checkRot) {
+  const vector<MapPoint *> mps1 = kf1->getMapPoints(), mps2 = kf2->getMapPoints();
+  matches12.assign(mps1.size(), static_cast<MapPoint *>(nullptr));
+  std::vector<uint8_t> v1(mps1.size()), v2(mps2.size());
+  for (size_t i = 0; i < mps1.size(); i++) v1[i] = mps1[i] && !mps1[i]->isBad();
+  for (size_t i = 0; i < mps2.size(); i++) v2[i] = mps2[i] && !mps2[i]->isBad();
+  FrameFlat a(kf1), b(kf2);
+  BowFlat an(kf1->featVec_), bn(kf2->featVec_);
+  std::vector<int32_t> m(mps1.size(), -1);
+  int n = 0;
+  vo_match_bow(&a.view, v1.data(), &an.view, &b.view, v2.data(), &bn.view, 1, ratio_, checkRot ? 1 : 0, m.data(), &n);
+  for (size_t k = 0; k < m.size(); k++)
+    if (m[k] >= 0) matches12[k] = mps2[m[k]];
+  return n;
+}
+
+// Matcher::searchForTriangulation(kf1, kf2, matchIdxs, F12, checkRot), :867-1010
+int Matcher::searchForTriangulation(KeyFrame *kf1, KeyFrame *kf2, vector<pair<int, int>> &matchIdxs,
+                                    Eigen::Matrix3d &F12, bool checkRot) {
+  const vector<MapPoint *> mps1 = kf1->getMapPoints(), mps2 = kf2->getMapPoints();
+  std::vector<uint8_t> h1(mps1.size()), h2(mps2.size());
+  for (size_t i = 0; i < mps1.size(); i++) h1[i] = mps1[i] != nullptr;
+  for (size_t i = 0; i < mps2.size(); i++) h2[i] = mps2[i] != nullptr;
+  const Vector3d C2 = kf2->getPose() * kf1->getCamCenter();
+  const Vector2d e = kf2->camera_->camera2pixel(C2);
+  double F[9];
+  for (int r = 0; r < 3; r++)
+    for (int c = 0; c < 3; c++) F[3 * r + c] = F12(r, c);
+  FrameFlat a(kf1), b(kf2);
+  BowFlat an(kf1->featVec_), bn(kf2->featVec_);
+  std::vector<int32_t> m(kf1->N_, -1);
+  int n = 0;
+  vo_match_triangulation(&a.view, h1.data(), &an.view, &b.view, h2.data(), &bn.view, F, (float)e[0], (float)e[1],
+                         kf2->scaleFactors_.data(), checkRot ? 1 : 0, m.data(), &n);
+  matchIdxs.clear();
+  matchIdxs.reserve(n);
+  for (int i = 0; i < kf1->N_; i++)
+    if (m[i] >= 0) matchIdxs.push_back(make_pair(i, m[i]));
+  return n;
+}
+
+// Matcher::fuseMapPoints(KeyFrame*, mappoints, threshold), :1012-1133.  Matching is a pure function of the
+// projections and descriptors, so it runs as one batch; the map mutation (:1108-1127) is replayed in
+// list order with the two gates an earlier merge can flip (isBad, beObserved) re-evaluated.
+int Matcher::fuseMapPoints(KeyFrame *kf, vector<MapPoint *> &mappoints, const float &threshold) {
+  Camera *cam = kf->camera_;
+  const SE3 Tcw = kf->getPose();
+  const Vector3d Ow = kf->getCamCenter();
+  const int nq = (int)mappoints.size();
+  std::vector<uint8_t> flags(nq, 0), qdesc((size_t)nq * 32, 0);
+  std::vector<float> u(nq), v(nq), ur(nq);
+  std::vector<int32_t> lvl(nq);
+  for (int i = 0; i < nq; i++) {
+    MapPoint *mp = mappoints[i];
+    if (!mp || mp->isBad() || mp->beObserved(kf)) continue;
+    const Vector3d pw = mp->getPose(), pc = Tcw * pw;
+    const float z = static_cast<float>(pc[2]);
+    if (z < 0.0f) continue;
+    const float invz = 1.0f / z;
+    const float uu = cam->fx_ * (static_cast<float>(pc[0]) * invz) + cam->cx_;
+    const float vv = cam->fy_ * (static_cast<float>(pc[1]) * invz) + cam->cy_;
+    if (!kf->isInImg(uu, vv)) continue;
+    const Vector3d line = pw - Ow;
+    const float dist = line.norm();
+    if (dist < mp->getMinDistanceThreshold() || dist > mp->getMaxDistanceThreshold()) continue;
+    if (line.dot(mp->getNormalVector()) < 0.5 * dist) continue;
+    flags[i] = 1, u[i] = uu, v[i] = vv, ur[i] = uu - cam->bf_ * invz, lvl[i] = mp->predictScale(dist, kf);
+    memcpy(&qdesc[(size_t)i * 32], mp->getDescriptor().data, 32);
+  }
+  FrameFlat ff(kf);
+  std::vector<int32_t> best(nq, -1);
+  int n = 0, cnt = 0;
+  vo_match_fuse(&ff.view, nq, flags.data(), u.data(), v.data(), ur.data(), lvl.data(), qdesc.data(), threshold,
+                kf->scaleFactors_.data(), best.data(), &n);
+  for (int i = 0; i < nq; i++) {
+    if (best[i] < 0) continue;
+    MapPoint *mp = mappoints[i];
+    if (mp->isBad() || mp->beObserved(kf)) continue;
+    MapPoint *org = kf->mappoints_[best[i]];
+    if (org) {
+      if (!org->isBad()) {
+        if (org->getObsCnt() > mp->getObsCnt())
+          mp->replaceMapPoint(org);
+        else
+          org->replaceMapPoint(mp);
+      }
+    } else {
+      mp->addObservation(kf, best[i]);
+      kf->addMapPoint(mp, best[i]);
+    }
+    cnt++;
+  }
+  return cnt;
 }
 
 }  // namespace myslam

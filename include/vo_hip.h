@@ -159,6 +159,50 @@ int vo_match_local_map(const vo_frame_view *cur, int nq, const uint8_t *q_flags,
                        const float *scale_factors, const uint8_t *blocked, int32_t *assigned,
                        int *n_matches);
 
+/* Matcher::searchByProjection(Frame*, KeyFrame*, radius, distThreshold, found, checkRot)
+ * (matcher.cpp:150-272, relocalisation top-up).  Query i = key-frame map point i, already projected
+ * (flag bit 0: exists, not bad, not in `found`, z > 0, inside the image and its distance range);
+ * q_level = MapPoint::predictScale.  has_map_point[cur.n]: the feature holds any map point (:218);
+ * features assigned earlier in the call are skipped as well. */
+int vo_match_frame_keyframe(const vo_frame_view *cur, int nq, const uint8_t *q_flags, const float *q_u,
+                            const float *q_v, const int32_t *q_level, const float *q_angle,
+                            const uint8_t *q_desc, float radius, float dist_threshold, int check_rot,
+                            const float *scale_factors, const uint8_t *has_map_point, int32_t *assigned,
+                            int *n_matches);
+
+/* DBoW3::FeatureVector of one frame as CSR: node ids ascending, node k owns
+ * feat[start[k] .. start[k+1]) (frame.h:50, keyframe.h). */
+typedef struct {
+  int32_t n_nodes;
+  const uint32_t *node_id;
+  const int32_t *start;
+  const uint32_t *feat;
+} vo_bow_view;
+
+/* Matcher::searchByBoW(KeyFrame*, Frame*, matches, checkRot) (matcher.cpp:449-559; mode 0:
+ * match[b.n] = A index held by each B feature) and searchByBoW(KeyFrame*, KeyFrame*, ...)
+ * (:561-677; mode 1: match[a.n] = B index of each A feature).  a_valid / b_valid: the feature has
+ * a good map point.  ratio = Matcher::ratio_. */
+int vo_match_bow(const vo_frame_view *a, const uint8_t *a_valid, const vo_bow_view *a_nodes,
+                 const vo_frame_view *b, const uint8_t *b_valid, const vo_bow_view *b_nodes, int mode,
+                 float ratio, int check_rot, int32_t *match, int *n_matches);
+
+/* Matcher::searchForTriangulation(kf1, kf2, matchIdxs, F12, checkRot) (matcher.cpp:867-1010,
+ * called at localMapping.cpp:187).  *_has_map_point: feature already triangulated (skipped).
+ * F12 row-major; (ex, ey) = camera centre 1 projected into key-frame 2 (:887-891).
+ * match12[a.n] = B index or -1. */
+int vo_match_triangulation(const vo_frame_view *a, const uint8_t *a_has_map_point, const vo_bow_view *a_nodes,
+                           const vo_frame_view *b, const uint8_t *b_has_map_point, const vo_bow_view *b_nodes,
+                           const double F12[9], float ex, float ey, const float *scale_factors,
+                           int check_rot, int32_t *match12, int *n_matches);
+
+/* matching part of Matcher::fuseMapPoints (matcher.cpp:1012-1133; the map mutation :1108-1127
+ * stays in the shim).  Query = candidate map point projected into the key-frame (flag bit 0:
+ * passes the gates of :1029-1062); best_idx[nq] = feature to fuse with or -1. */
+int vo_match_fuse(const vo_frame_view *kf, int nq, const uint8_t *q_flags, const float *q_u,
+                  const float *q_v, const float *q_ur, const int32_t *q_level, const uint8_t *q_desc,
+                  float threshold, const float *scale_factors, int32_t *best_idx, int *n_matches);
+
 /* ------------------------------------------------------------------------------------------
  * Optimizer  --  replaces myslam::Optimizer (include/myslam/optimizer_ceres.h:12-97,
  * src/optimizer_ceres.cpp) including the Ceres solve it delegates to.

@@ -252,3 +252,253 @@ int orc_match_local_map(const orc_frame *cur, int nq, const uint8_t *q_valid, co
   free(blocked);
   return match_cnt;
 }
+
+/* ---------------------------------------------------------------------------------------------
+ * Matcher::searchByProjection(Frame*, KeyFrame*, radius, distThreshold, found, checkRot),
+ * matcher.cpp:150-272 (relocalisation top-up).  Query i = key-frame map point i already projected
+ * (valid: exists, not bad, not in `found`, z>0, inside the image, inside its distance range);
+ * q_level = predictScale.  A feature that holds ANY map point is skipped (:218), including the ones
+ * assigned earlier in this call.
+ * ------------------------------------------------------------------------------------------- */
+int orc_match_frame_keyframe(const orc_frame *cur, int nq, const uint8_t *q_valid, const float *q_u,
+                             const float *q_v, const int32_t *q_level, const float *q_angle,
+                             const uint8_t *q_desc, float radius, float dist_threshold, int check_rot,
+                             const float *scale_factors, const uint8_t *has_mp_in, int32_t *assigned) {
+  const float pdf = HISTO_LENGTH / 360.0f;
+  int match_cnt = 0;
+  int *hist = (int *)malloc(sizeof(int) * HISTO_LENGTH * (size_t)(nq > 0 ? nq : 1));
+  int hist_n[HISTO_LENGTH];
+  memset(hist_n, 0, sizeof(hist_n));
+  int *cand = (int *)malloc(sizeof(int) * (cur->n > 0 ? cur->n : 1));
+  uint8_t *has = (uint8_t *)malloc(cur->n > 0 ? cur->n : 1);
+  for (int k = 0; k < cur->n; k++) has[k] = has_mp_in ? has_mp_in[k] : 0;
+  for (int i = 0; i < nq; i++) {
+    if (!(q_valid[i] & 1)) continue;
+    const int lp = q_level[i];
+    const float rs = radius * scale_factors[lp];
+    const int nc = orc_features_in_area(cur, q_u[i], q_v[i], rs, lp - 1, lp + 1, cand, cur->n);
+    if (nc == 0) continue;
+    int bestDist = 256, bestIdx = -1;
+    for (int j = 0; j < nc; j++) {
+      const int idx = cand[j];
+      if (has[idx]) continue;
+      const int dist = orc_hamming256(q_desc + (size_t)i * 32, cur->desc + (size_t)idx * 32);
+      if (dist < bestDist) bestDist = dist, bestIdx = idx;
+    }
+    if ((float)bestDist <= dist_threshold) { /* int <= float comparison of the reference */
+      assigned[bestIdx] = i;
+      has[bestIdx] = 1;
+      match_cnt++;
+      if (check_rot) {
+        float rot = q_angle[i] - cur->angle[bestIdx];
+        if (rot < 0) rot += 360.0f;
+        int bin = orc_cv_round_f(rot * pdf);
+        if (bin == HISTO_LENGTH) bin = 0;
+        hist[bin * nq + hist_n[bin]++] = bestIdx;
+      }
+    }
+  }
+  if (check_rot) {
+    int i1 = -1, i2 = -1, i3 = -1;
+    orc_three_max(hist_n, HISTO_LENGTH, &i1, &i2, &i3);
+    for (int b = 0; b < HISTO_LENGTH; b++)
+      if (b != i1 && b != i2 && b != i3)
+        for (int j = 0; j < hist_n[b]; j++) {
+          assigned[hist[b * nq + j]] = -1;
+          match_cnt--;
+        }
+  }
+  free(hist), free(cand), free(has);
+  return match_cnt;
+}
+
+/* DBoW3::FeatureVector as CSR: node ids ascending, node k owns feat[start[k] .. start[k+1]) */
+static int next_common_node(const orc_bow *a, const orc_bow *b, int *ia, int *ib) {
+  while (*ia < a->n_nodes && *ib < b->n_nodes) {
+    if (a->node_id[*ia] == b->node_id[*ib]) return 1;
+    if (a->node_id[*ia] < b->node_id[*ib]) (*ia)++; /* lower_bound walk, :541-544 */
+    else (*ib)++;
+  }
+  return 0;
+}
+
+/* Matcher::searchByBoW(KeyFrame*, Frame*, matches, checkRot) matcher.cpp:449-559 (mode 0) and
+ * searchByBoW(KeyFrame*, KeyFrame*, ...) :561-677 (mode 1).
+ * mode 0: match[b->n] = A index held by B feature (or -1); a_valid = A feature has a good map point.
+ * mode 1: match[a->n] = B index matched to A feature; b_valid likewise; uses round() for the bin. */
+int orc_match_bow(const orc_frame *a, const uint8_t *a_valid, const orc_bow *an, const orc_frame *b,
+                  const uint8_t *b_valid, const orc_bow *bn, int mode, float ratio, int check_rot,
+                  int32_t *match) {
+  const float pdf = HISTO_LENGTH / 360.0f;
+  const int nout = mode == 0 ? b->n : a->n;
+  for (int i = 0; i < nout; i++) match[i] = -1;
+  uint8_t *matched2 = (uint8_t *)calloc(b->n > 0 ? b->n : 1, 1);
+  int *hist = (int *)malloc(sizeof(int) * HISTO_LENGTH * (size_t)(a->n > 0 ? a->n : 1));
+  int hist_n[HISTO_LENGTH];
+  memset(hist_n, 0, sizeof(hist_n));
+  int cnt = 0, ia = 0, ib = 0;
+  while (next_common_node(an, bn, &ia, &ib)) {
+    for (int s = an->start[ia]; s < an->start[ia + 1]; s++) {
+      const int i1 = (int)an->feat[s];
+      if (!a_valid[i1]) continue;
+      int best1 = 256, best2 = 256, bidx = -1;
+      for (int t = bn->start[ib]; t < bn->start[ib + 1]; t++) {
+        const int i2 = (int)bn->feat[t];
+        if (mode == 0) {
+          if (match[i2] >= 0) continue; /* :487 */
+        } else {
+          if (matched2[i2] || !b_valid[i2]) continue; /* :605-608 */
+        }
+        const int d = orc_hamming256(a->desc + (size_t)i1 * 32, b->desc + (size_t)i2 * 32);
+        if (d < best1) best2 = best1, best1 = d, bidx = i2;
+        else if (d < best2) best2 = d;
+      }
+      if (best1 <= TH_LOW && (float)best1 < ratio * (float)best2) {
+        float rot = a->angle[i1] - b->angle[bidx];
+        if (rot < 0) rot += 360.0f;
+        int bin = mode == 0 ? orc_cv_round_f(rot * pdf) : (int)roundf(rot * pdf); /* :518 vs :637 */
+        if (bin == HISTO_LENGTH) bin = 0;
+        if (mode == 0) {
+          match[bidx] = i1;
+          if (check_rot) hist[bin * a->n + hist_n[bin]++] = bidx;
+        } else {
+          match[i1] = bidx;
+          matched2[bidx] = 1;
+          if (check_rot) hist[bin * a->n + hist_n[bin]++] = i1;
+        }
+        cnt++;
+      }
+    }
+    ia++, ib++;
+  }
+  if (check_rot) {
+    int i1 = -1, i2 = -1, i3 = -1;
+    orc_three_max(hist_n, HISTO_LENGTH, &i1, &i2, &i3);
+    for (int bb = 0; bb < HISTO_LENGTH; bb++)
+      if (bb != i1 && bb != i2 && bb != i3)
+        for (int j = 0; j < hist_n[bb]; j++) {
+          match[hist[bb * a->n + j]] = -1;
+          cnt--;
+        }
+  }
+  free(matched2), free(hist);
+  return cnt;
+}
+
+/* Matcher::checkEpipolarConstrain, matcher.cpp:1306-1324 (float arithmetic on a double line) */
+static int epipolar_ok(float x1, float y1, float x2, float y2, const double F[9], float sigma) {
+  const double l0 = x1 * F[0] + y1 * F[3] + F[6], l1 = x1 * F[1] + y1 * F[4] + F[7],
+               l2 = x1 * F[2] + y1 * F[5] + F[8]; /* (p1^T F12)^T */
+  const float num = (float)(l0 * x2 + l1 * y2 + l2);
+  const float den = (float)(l0 * l0 + l1 * l1);
+  if (den == 0) return 0;
+  const float d2 = num * num / den;
+  return d2 < 3.84f * sigma * sigma;
+}
+
+/* Matcher::searchForTriangulation(kf1, kf2, matchIdxs, F12, checkRot) matcher.cpp:867-1010.
+ * a_has_mp / b_has_mp: the feature already has a map point (then it is skipped).  F12 row-major.
+ * match12[a->n] = B index or -1.  (ex, ey) = projection of camera centre 1 into key-frame 2. */
+int orc_match_triangulation(const orc_frame *a, const uint8_t *a_has_mp, const orc_bow *an,
+                            const orc_frame *b, const uint8_t *b_has_mp, const orc_bow *bn,
+                            const double F12[9], float ex, float ey, const float *scale_factors,
+                            int check_rot, int32_t *match12) {
+  const float pdf = HISTO_LENGTH / 360.0f;
+  for (int i = 0; i < a->n; i++) match12[i] = -1;
+  uint8_t *matched2 = (uint8_t *)calloc(b->n > 0 ? b->n : 1, 1);
+  int *hist = (int *)malloc(sizeof(int) * HISTO_LENGTH * (size_t)(a->n > 0 ? a->n : 1));
+  int hist_n[HISTO_LENGTH];
+  memset(hist_n, 0, sizeof(hist_n));
+  int cnt = 0, ia = 0, ib = 0;
+  while (next_common_node(an, bn, &ia, &ib)) {
+    for (int s = an->start[ia]; s < an->start[ia + 1]; s++) {
+      const int i1 = (int)an->feat[s];
+      if (a_has_mp[i1]) continue;
+      const int stereo1 = a->uright[i1] >= 0;
+      int bestDist = TH_LOW, bidx = -1;
+      for (int t = bn->start[ib]; t < bn->start[ib + 1]; t++) {
+        const int i2 = (int)bn->feat[t];
+        if (matched2[i2] || b_has_mp[i2]) continue;
+        const int stereo2 = b->uright[i2] >= 0;
+        const int d = orc_hamming256(a->desc + (size_t)i1 * 32, b->desc + (size_t)i2 * 32);
+        if (d > TH_LOW || d > bestDist) continue; /* later equal distances replace earlier ones */
+        if (!stereo1 && !stereo2) {
+          const float dx = ex - b->x[i2], dy = ey - b->y[i2];
+          if (dx * dx + dy * dy < 100 * scale_factors[b->octave[i2]]) continue;
+        }
+        if (epipolar_ok(a->x[i1], a->y[i1], b->x[i2], b->y[i2], F12, scale_factors[b->octave[i2]])) {
+          bestDist = d;
+          bidx = i2;
+        }
+      }
+      if (bidx >= 0) {
+        match12[i1] = bidx;
+        matched2[bidx] = 1;
+        if (check_rot) {
+          float rot = a->angle[i1] - b->angle[bidx];
+          if (rot < 0) rot += 360.0f;
+          int bin = (int)roundf(rot * pdf);
+          if (bin == HISTO_LENGTH) bin = 0;
+          hist[bin * a->n + hist_n[bin]++] = i1;
+        }
+        cnt++;
+      }
+    }
+    ia++, ib++;
+  }
+  if (check_rot) {
+    int i1 = -1, i2 = -1, i3 = -1;
+    orc_three_max(hist_n, HISTO_LENGTH, &i1, &i2, &i3);
+    for (int bb = 0; bb < HISTO_LENGTH; bb++)
+      if (bb != i1 && bb != i2 && bb != i3)
+        for (int j = 0; j < hist_n[bb]; j++) {
+          match12[hist[bb * a->n + j]] = -1;
+          cnt--;
+        }
+  }
+  free(matched2), free(hist);
+  return cnt;
+}
+
+/* matching part of Matcher::fuseMapPoints (matcher.cpp:1012-1133; the map mutation at :1108-1127
+ * stays in the caller).  Query = candidate map point already projected into the key-frame (valid:
+ * good, not observed by it, z>=0, inside the image and its distance / viewing-angle range).
+ * best_idx[nq] = feature index with the smallest Hamming distance <= TH_LOW after the level and
+ * chi2 gates, or -1.  Queries are independent of each other. */
+int orc_match_fuse(const orc_frame *kf, int nq, const uint8_t *q_valid, const float *q_u,
+                   const float *q_v, const float *q_ur, const int32_t *q_level, const uint8_t *q_desc,
+                   float threshold, const float *scale_factors, int32_t *best_idx) {
+  int cnt = 0;
+  int *cand = (int *)malloc(sizeof(int) * (kf->n > 0 ? kf->n : 1));
+  for (int i = 0; i < nq; i++) {
+    best_idx[i] = -1;
+    if (!(q_valid[i] & 1)) continue;
+    const int lp = q_level[i];
+    const float radius = threshold * scale_factors[lp];
+    /* KeyFrame::getFeaturesInArea(u,v,r) has no level filter (keyframe.cpp:268-312) */
+    const int nc = orc_features_in_area(kf, q_u[i], q_v[i], radius, -1000, 1000, cand, kf->n);
+    int bestDist = 256, bidx = -1;
+    for (int j = 0; j < nc; j++) {
+      const int idx = cand[j];
+      if (kf->octave[idx] < lp - 1 || kf->octave[idx] > lp) continue;
+      const float exx = q_u[i] - kf->x[idx], eyy = q_v[i] - kf->y[idx];
+      const float invSigma = 1.0f / scale_factors[kf->octave[idx]];
+      if (kf->uright[idx] >= 0) {
+        const float er = q_ur[i] - kf->uright[idx];
+        const float e2 = exx * exx + eyy * eyy + er * er;
+        if (e2 * invSigma * invSigma > 7.815f) continue;
+      } else {
+        const float e2 = exx * exx + eyy * eyy;
+        if (e2 * invSigma * invSigma > 5.991f) continue;
+      }
+      const int d = orc_hamming256(q_desc + (size_t)i * 32, kf->desc + (size_t)idx * 32);
+      if (d < bestDist) bestDist = d, bidx = idx;
+    }
+    if (bestDist <= TH_LOW) {
+      best_idx[i] = bidx;
+      cnt++;
+    }
+  }
+  free(cand);
+  return cnt;
+}

@@ -121,6 +121,29 @@ int orc_match_local_map(const orc_frame *cur, int nq, const uint8_t *q_valid, co
                         float ratio, const float *scale_factors, const uint8_t *blocked,
                         int32_t *assigned);
 
+/* DBoW3::FeatureVector of one frame as CSR (node ids ascending) */
+typedef struct {
+  int32_t n_nodes;
+  const uint32_t *node_id;
+  const int32_t *start; /* n_nodes + 1 */
+  const uint32_t *feat;
+} orc_bow;
+
+int orc_match_frame_keyframe(const orc_frame *cur, int nq, const uint8_t *q_valid, const float *q_u,
+                             const float *q_v, const int32_t *q_level, const float *q_angle,
+                             const uint8_t *q_desc, float radius, float dist_threshold, int check_rot,
+                             const float *scale_factors, const uint8_t *has_mp, int32_t *assigned);
+int orc_match_bow(const orc_frame *a, const uint8_t *a_valid, const orc_bow *an, const orc_frame *b,
+                  const uint8_t *b_valid, const orc_bow *bn, int mode, float ratio, int check_rot,
+                  int32_t *match);
+int orc_match_triangulation(const orc_frame *a, const uint8_t *a_has_mp, const orc_bow *an,
+                            const orc_frame *b, const uint8_t *b_has_mp, const orc_bow *bn,
+                            const double F12[9], float ex, float ey, const float *scale_factors,
+                            int check_rot, int32_t *match12);
+int orc_match_fuse(const orc_frame *kf, int nq, const uint8_t *q_valid, const float *q_u,
+                   const float *q_v, const float *q_ur, const int32_t *q_level, const uint8_t *q_desc,
+                   float threshold, const float *scale_factors, int32_t *best_idx);
+
 /* ---------------- Optimizer (reference optimizer_ceres.{h,cpp}) --------------- */
 
 void orc_se3_exp(const double xi[6], double q[4] /*w,x,y,z*/, double t[3]); /* Sophus SE3::exp */

@@ -80,6 +80,51 @@ def g3_match():
                         scale=sf, assigned=assigned, count=np.int32(cnt))
 
 
+def g6_match_kf():
+    """M2 / M5 / M6 / M8 / M9 on g3's frame pair (descriptors etc. are read from g3_match.npz)."""
+    g = np.load(HERE / "g3_match.npz")
+    n = len(g["d0"])
+    p = O.orb_params()
+    f0 = synth.make_frame(7)
+    f1, dx, dy = synth.make_shifted(f0, 7)
+    k0, _, _ = O.extract(p, f0)
+    k0 = k0[:n]
+    rng = np.random.default_rng(70)
+    sf = g["scale"]
+    ur0 = np.where(rng.random(n) < 0.5, -1.0, k0["x"] - 12.0).astype(np.float32)
+    ur1 = np.where(rng.random(n) < 0.5, -1.0, g["ur"]).astype(np.float32)
+    A = O.FrameData(k0["x"], k0["y"], k0["octave"], k0["angle"], ur0, g["d0"])
+    B = O.FrameData(g["kx"], g["ky"], g["koct"], g["kang"], ur1, g["d1"])
+    node = lambda x, y: (np.floor(x / 64.0).astype(np.int64) + 16 * np.floor(y / 64.0).astype(np.int64)).astype(np.uint32)
+    na, nb = node(k0["x"], k0["y"]), node(g["kx"] - dx, g["ky"] - dy)
+    ba, bb = O.BowData(na), O.BowData(nb)
+    fa, fb = (rng.random(n) < 0.25).astype(np.uint8), (rng.random(n) < 0.25).astype(np.uint8)
+    out = dict(ax=k0["x"], ay=k0["y"], aoct=k0["octave"], aang=k0["angle"], aur=ur0, bur=ur1, node_a=na, node_b=nb,
+               flag_a=fa, flag_b=fb)
+    L = O.lib()
+    for mode in (0, 1):
+        m = np.full(n, -1, np.int32)
+        out[f"bow{mode}_n"] = np.int32(L.orc_match_bow(C.byref(A.c), 1 - fa, C.byref(ba.c), C.byref(B.c), 1 - fb,
+                                                       C.byref(bb.c), mode, 0.75, 1, m))
+        out[f"bow{mode}"] = m
+    F = np.array([[0, 0, dy], [0, 0, -dx], [-dy, dx, 0]], np.float64)
+    m = np.full(n, -1, np.int32)
+    out["tri_n"] = np.int32(L.orc_match_triangulation(C.byref(A.c), fa, C.byref(ba.c), C.byref(B.c), fb, C.byref(bb.c),
+                                                      np.ascontiguousarray(F.reshape(-1)), 300.0, 200.0, sf, 1, m))
+    out["tri"], out["F12"] = m, F
+    q_lvl = np.clip(k0["octave"] + rng.integers(0, 2, n), 0, 7).astype(np.int32)
+    q_ur = (g["q_u"] - 15.0).astype(np.float32)
+    m = np.full(n, -1, np.int32)
+    out["fuse_n"] = np.int32(L.orc_match_fuse(C.byref(B.c), n, 1 - fa, g["q_u"], g["q_v"], q_ur, q_lvl,
+                                              np.ascontiguousarray(g["d0"]), 3.0, sf, m))
+    out["fuse"], out["q_level"], out["q_ur"] = m, q_lvl, q_ur
+    m = np.full(n, -1, np.int32)
+    out["kfproj_n"] = np.int32(L.orc_match_frame_keyframe(C.byref(B.c), n, 1 - fa, g["q_u"], g["q_v"], q_lvl, g["q_ang"],
+                                                          np.ascontiguousarray(g["d0"]), 10.0, 64.0, 1, sf, fb, m))
+    out["kfproj"] = m
+    np.savez_compressed(HERE / "g6_match_kf.npz", **out)
+
+
 def g4_pose():
     pr = synth.make_pose_problem(3, n=300)
     pose, outl, ninl, sums, keep = O.pose_only(pr, trace=True)
@@ -118,7 +163,7 @@ def g7_se3():
 
 
 if __name__ == "__main__":
-    for fn in (g1_extract, g2_fast, g3_match, g4_pose, g5_lba, g7_se3):
+    for fn in (g1_extract, g2_fast, g3_match, g6_match_kf, g4_pose, g5_lba, g7_se3):
         fn()
         print("wrote", fn.__name__)
     import os

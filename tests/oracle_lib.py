@@ -50,6 +50,24 @@ class Frame(C.Structure):
                 ("cell_start", C.c_void_p), ("cell_items", C.c_void_p)]
 
 
+class Bow(C.Structure):
+    _fields_ = [("n_nodes", C.c_int32), ("node_id", C.c_void_p), ("start", C.c_void_p), ("feat", C.c_void_p)]
+
+
+class BowData:
+    def __init__(self, node_of_feature):
+        node_of_feature = np.asarray(node_of_feature)
+        order = np.argsort(node_of_feature, kind="stable")
+        ids, counts = np.unique(node_of_feature, return_counts=True)
+        self.node_id = np.ascontiguousarray(ids, np.uint32)
+        self.start = np.ascontiguousarray(np.concatenate([[0], np.cumsum(counts)]), np.int32)
+        self.feat = np.ascontiguousarray(order, np.uint32)
+        b = Bow()
+        b.n_nodes = len(self.node_id)
+        b.node_id, b.start, b.feat = self.node_id.ctypes.data, self.start.ctypes.data, self.feat.ctypes.data
+        self.c = b
+
+
 def build(force: bool = False) -> pathlib.Path:
     srcs = [ORACLE_DIR / n for n in ("orb_oracle.c", "match_oracle.c", "ba_oracle.c", "oracle.h")]
     if force or not SO.exists() or any(s.stat().st_mtime > SO.stat().st_mtime for s in srcs if s.exists()):
@@ -101,6 +119,17 @@ def lib():
     L.orc_match_local_map.argtypes = [C.POINTER(Frame), C.c_int, _u8p, _f32p, _f32p, _f32p, _i32p, _f32p, _u8p,
                                       C.c_float, C.c_float, _f32p, _u8p, _i32p]
     L.orc_match_local_map.restype = C.c_int
+    L.orc_match_frame_keyframe.argtypes = [C.POINTER(Frame), C.c_int, _u8p, _f32p, _f32p, _i32p, _f32p, _u8p, C.c_float,
+                                           C.c_float, C.c_int, _f32p, _u8p, _i32p]
+    L.orc_match_frame_keyframe.restype = C.c_int
+    L.orc_match_bow.argtypes = [C.POINTER(Frame), _u8p, C.POINTER(Bow), C.POINTER(Frame), _u8p, C.POINTER(Bow), C.c_int,
+                                C.c_float, C.c_int, _i32p]
+    L.orc_match_bow.restype = C.c_int
+    L.orc_match_triangulation.argtypes = [C.POINTER(Frame), _u8p, C.POINTER(Bow), C.POINTER(Frame), _u8p, C.POINTER(Bow),
+                                          _f64p, C.c_float, C.c_float, _f32p, C.c_int, _i32p]
+    L.orc_match_triangulation.restype = C.c_int
+    L.orc_match_fuse.argtypes = [C.POINTER(Frame), C.c_int, _u8p, _f32p, _f32p, _f32p, _i32p, _u8p, C.c_float, _f32p, _i32p]
+    L.orc_match_fuse.restype = C.c_int
     L.orc_se3_exp.argtypes = [_f64p, _f64p, _f64p]
     L.orc_se3_log.argtypes = [_f64p, _f64p, _f64p]
     L.orc_se3_plus.argtypes = [_f64p, _f64p, _f64p]

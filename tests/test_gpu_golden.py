@@ -35,6 +35,25 @@ def test_g3_hamming_and_match(vo):
     assert cnt == int(g["count"]) and np.array_equal(assigned, g["assigned"])
 
 
+def test_g6_keyframe_matchers(vo):
+    g3, g = np.load(G / "g3_match.npz"), np.load(G / "g6_match_kf.npz")
+    A = vo.FrameArrays(g["ax"], g["ay"], g["aoct"], g["aang"], g["aur"], g3["d0"])
+    B = vo.FrameArrays(g3["kx"], g3["ky"], g3["koct"], g3["kang"], g["bur"], g3["d1"])
+    na, nb, fa, fb = vo.BowNodes(g["node_a"]), vo.BowNodes(g["node_b"]), g["flag_a"], g["flag_b"]
+    m = vo.Matcher(0.75)
+    for mode in (0, 1):
+        cnt, match = m.searchByBoW(A, 1 - fa, na, B, 1 - fb, nb, bool(mode), True)
+        assert cnt == int(g[f"bow{mode}_n"]) and np.array_equal(match, g[f"bow{mode}"])
+    cnt, match = m.searchForTriangulation(A, fa, na, B, fb, nb, g["F12"], 300.0, 200.0, g3["scale"], True)
+    assert cnt == int(g["tri_n"]) and np.array_equal(match, g["tri"])
+    q = dict(flags=(1 - fa).astype(np.uint8), u=g3["q_u"], v=g3["q_v"], ur=g["q_ur"], level=g["q_level"],
+             angle=g3["q_ang"], desc=np.ascontiguousarray(g3["d0"]))
+    cnt, best = m.fuseMapPoints_match(B, q, 3.0, g3["scale"])
+    assert cnt == int(g["fuse_n"]) and np.array_equal(best, g["fuse"])
+    cnt, assigned = m.searchByProjection_keyframe(B, q, 10.0, 64.0, True, g3["scale"], np.ascontiguousarray(fb))
+    assert cnt == int(g["kfproj_n"]) and np.array_equal(assigned, g["kfproj"])
+
+
 def test_g4_pose_only(vo):
     g = np.load(G / "g4_pose_only.npz")
     pr = {k: g[k] for k in ("pts", "obs", "inv_sigma", "cam", "pose0")}

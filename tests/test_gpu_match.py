@@ -100,3 +100,126 @@ def test_search_local_map(vo, orc, idx):
                                        q["viewcos"], q["desc"], 3.0, 0.8, sf, np.zeros(len(k1), np.uint8), oa)
     assert n == on and n > 100
     assert np.array_equal(assigned, oa)
+
+
+# ------------------------------------------------------------------ M2 / M5 / M6 / M8 / M9
+
+def _nodes(k, dx=0.0, dy=0.0):
+    """synthetic vocabulary node of a feature: coarse cell of its (shift-compensated) position"""
+    return (np.floor((k["x"] - dx) / 64.0).astype(np.int64) + 16 * np.floor((k["y"] - dy) / 64.0).astype(np.int64)
+            + 1000).astype(np.uint32)
+
+
+@pytest.mark.parametrize("idx,check_rot", [(0, 1), (1, 0), (2, 1)])
+def test_search_by_projection_keyframe(vo, orc, idx, check_rot):
+    import ctypes as C
+    k0, d0, k1, d1, dx, dy = _frame_pair(orc, idx)
+    ur1, _ = _uright(k1, idx)
+    sf = np.array(list(orc.orb_params().scale)[:8], np.float32)
+    rng = np.random.default_rng(idx + 7)
+    flags = (rng.random(len(k0)) > 0.1).astype(np.uint8)
+    q = dict(flags=flags, u=(k0["x"] + dx + rng.normal(0, 1.5, len(k0))).astype(np.float32),
+             v=(k0["y"] + dy + rng.normal(0, 1.5, len(k0))).astype(np.float32),
+             level=np.clip(k0["octave"] + rng.integers(-1, 2, len(k0)), 0, 7).astype(np.int32),
+             angle=k0["angle"].astype(np.float32), desc=np.ascontiguousarray(d0))
+    has = (rng.random(len(k1)) < 0.2).astype(np.uint8)
+    cur = vo.FrameArrays(k1["x"], k1["y"], k1["octave"], k1["angle"], ur1, d1)
+    n, assigned = vo.Matcher(0.8).searchByProjection_keyframe(cur, q, 10.0, 64.0, check_rot, sf, has)
+    of = orc.FrameData(k1["x"], k1["y"], k1["octave"], k1["angle"], ur1, d1)
+    oa = np.full(len(k1), -1, np.int32)
+    on = orc.lib().orc_match_frame_keyframe(C.byref(of.c), len(k0), q["flags"], q["u"], q["v"], q["level"], q["angle"],
+                                            q["desc"], 10.0, 64.0, check_rot, sf, has, oa)
+    assert n == on and n > 150
+    assert np.array_equal(assigned, oa)
+    assert not (assigned[has == 1] >= 0).any()
+
+
+@pytest.mark.parametrize("idx,mode,check_rot", [(0, 0, 1), (1, 1, 1), (2, 0, 0), (3, 1, 0)])
+def test_search_by_bow(vo, orc, idx, mode, check_rot):
+    import ctypes as C
+    k0, d0, k1, d1, dx, dy = _frame_pair(orc, idx)
+    ur0, _ = _uright(k0, idx)
+    ur1, _ = _uright(k1, idx + 1)
+    rng = np.random.default_rng(idx + 11)
+    va, vb = (rng.random(len(k0)) > 0.15).astype(np.uint8), (rng.random(len(k1)) > 0.15).astype(np.uint8)
+    na, nb = _nodes(k0), _nodes(k1, dx, dy)
+    A = vo.FrameArrays(k0["x"], k0["y"], k0["octave"], k0["angle"], ur0, d0)
+    B = vo.FrameArrays(k1["x"], k1["y"], k1["octave"], k1["angle"], ur1, d1)
+    n, match = vo.Matcher(0.75).searchByBoW(A, va, vo.BowNodes(na), B, vb, vo.BowNodes(nb), bool(mode), bool(check_rot))
+    oA = orc.FrameData(k0["x"], k0["y"], k0["octave"], k0["angle"], ur0, d0)
+    oB = orc.FrameData(k1["x"], k1["y"], k1["octave"], k1["angle"], ur1, d1)
+    ba, bb = orc.BowData(na), orc.BowData(nb)
+    om = np.full(len(k0) if mode else len(k1), -1, np.int32)
+    on = orc.lib().orc_match_bow(C.byref(oA.c), va, C.byref(ba.c), C.byref(oB.c), vb, C.byref(bb.c), mode, 0.75,
+                                 check_rot, om)
+    assert n == on and n > 100
+    assert np.array_equal(match, om)
+
+
+@pytest.mark.parametrize("idx,check_rot,epi_inside", [(0, 1, 0), (1, 0, 1), (2, 1, 1)])
+def test_search_for_triangulation(vo, orc, idx, check_rot, epi_inside):
+    import ctypes as C
+    k0, d0, k1, d1, dx, dy = _frame_pair(orc, idx)
+    rng = np.random.default_rng(idx + 13)
+    ur0, _ = _uright(k0, idx)
+    ur1, _ = _uright(k1, idx + 1)
+    ur0[rng.random(len(k0)) < 0.5] = -1.0   # monocular features exercise the epipole gate
+    ur1[rng.random(len(k1)) < 0.5] = -1.0
+    ha, hb = (rng.random(len(k0)) < 0.3).astype(np.uint8), (rng.random(len(k1)) < 0.3).astype(np.uint8)
+    # pure image shift e = (dx, dy, 0): p1^T [e]x p2 = 0 for p2 = p1 + e
+    F = np.array([[0, 0, dy], [0, 0, -dx], [-dy, dx, 0]], np.float64) * 1e-3
+    ex, ey = (320.0, 240.0) if epi_inside else (1e6, 1e6)
+    sf = np.array(list(orc.orb_params().scale)[:8], np.float32)
+    na, nb = _nodes(k0), _nodes(k1, dx, dy)
+    A = vo.FrameArrays(k0["x"], k0["y"], k0["octave"], k0["angle"], ur0, d0)
+    B = vo.FrameArrays(k1["x"], k1["y"], k1["octave"], k1["angle"], ur1, d1)
+    n, match = vo.Matcher(0.6).searchForTriangulation(A, ha, vo.BowNodes(na), B, hb, vo.BowNodes(nb), F, ex, ey, sf,
+                                                      bool(check_rot))
+    oA = orc.FrameData(k0["x"], k0["y"], k0["octave"], k0["angle"], ur0, d0)
+    oB = orc.FrameData(k1["x"], k1["y"], k1["octave"], k1["angle"], ur1, d1)
+    ba, bb = orc.BowData(na), orc.BowData(nb)
+    om = np.full(len(k0), -1, np.int32)
+    on = orc.lib().orc_match_triangulation(C.byref(oA.c), ha, C.byref(ba.c), C.byref(oB.c), hb, C.byref(bb.c),
+                                           np.ascontiguousarray(F.reshape(-1)), ex, ey, sf, check_rot, om)
+    assert n == on and n > 50
+    assert np.array_equal(match, om)
+    m = match >= 0
+    assert not ha[m].any() and not hb[match[m]].any()
+    assert len(np.unique(match[m])) == m.sum()
+
+
+@pytest.mark.parametrize("idx,threshold", [(0, 3.0), (1, 2.5)])
+def test_fuse_matching(vo, orc, idx, threshold):
+    import ctypes as C
+    k0, d0, k1, d1, dx, dy = _frame_pair(orc, idx)
+    ur1, _ = _uright(k1, idx)
+    rng = np.random.default_rng(idx + 17)
+    sf = np.array(list(orc.orb_params().scale)[:8], np.float32)
+    u = (k0["x"] + dx + rng.normal(0, 0.7, len(k0))).astype(np.float32)
+    q = dict(flags=(rng.random(len(k0)) > 0.1).astype(np.uint8), u=u,
+             v=(k0["y"] + dy + rng.normal(0, 0.7, len(k0))).astype(np.float32),
+             ur=(u - rng.uniform(5, 40, len(k0))).astype(np.float32),
+             level=np.clip(k0["octave"] + rng.integers(0, 2, len(k0)), 0, 7).astype(np.int32),
+             desc=np.ascontiguousarray(d0))
+    kf = vo.FrameArrays(k1["x"], k1["y"], k1["octave"], k1["angle"], ur1, d1)
+    n, best = vo.Matcher(0.8).fuseMapPoints_match(kf, q, threshold, sf)
+    of = orc.FrameData(k1["x"], k1["y"], k1["octave"], k1["angle"], ur1, d1)
+    ob = np.full(len(k0), -1, np.int32)
+    on = orc.lib().orc_match_fuse(C.byref(of.c), len(k0), q["flags"], q["u"], q["v"], q["ur"], q["level"], q["desc"],
+                                  threshold, sf, ob)
+    assert n == on and n > 50
+    assert np.array_equal(best, ob)
+
+
+def test_new_matchers_empty_inputs(vo):
+    e = np.zeros(0, np.float32)
+    empty = vo.FrameArrays(e, e, np.zeros(0, np.int32), e, e, np.zeros((0, 32), np.uint8))
+    nodes = vo.BowNodes(np.zeros(0, np.uint32))
+    z8 = np.zeros(0, np.uint8)
+    m = vo.Matcher(0.8)
+    assert m.searchByBoW(empty, z8, nodes, empty, z8, nodes, False)[0] == 0
+    assert m.searchByBoW(empty, z8, nodes, empty, z8, nodes, True)[0] == 0
+    assert m.searchForTriangulation(empty, z8, nodes, empty, z8, nodes, np.eye(3), 0.0, 0.0, np.ones(8, np.float32))[0] == 0
+    q = dict(flags=z8, u=e, v=e, ur=e, level=np.zeros(0, np.int32), angle=e, desc=np.zeros((0, 32), np.uint8))
+    assert m.fuseMapPoints_match(empty, q, 3.0, np.ones(8, np.float32))[0] == 0
+    assert m.searchByProjection_keyframe(empty, q, 10.0, 64.0, True, np.ones(8, np.float32))[0] == 0

@@ -79,3 +79,109 @@ def test_match_fixture(orc):
     # each query claims at most one feature (its map point has observe_cnt_ > 0)
     used = assigned[assigned >= 0]
     assert len(set(used.tolist())) == len(used)
+
+
+# ---- the BoW-guided / key-frame matchers (M2, M5, M6, M8, M9): oracle self-consistency on CPU
+
+def _pair(orc, idx):
+    from vo_slam_test_amd import synth
+    p = orc.orb_params()
+    f0 = synth.make_frame(idx)
+    f1, dx, dy = synth.make_shifted(f0, idx)
+    k0, d0, _ = orc.extract(p, f0)
+    k1, d1, _ = orc.extract(p, f1)
+    return k0, d0, k1, d1, dx, dy
+
+
+def _nodes(k, dx=0.0, dy=0.0):
+    return (np.floor((k["x"] - dx) / 64.0).astype(np.int64) + 16 * np.floor((k["y"] - dy) / 64.0).astype(np.int64)
+            + 1000).astype(np.uint32)
+
+
+def test_oracle_bow_matchers_recover_shift(orc):
+    import ctypes as C
+    k0, d0, k1, d1, dx, dy = _pair(orc, 0)
+    m1 = -np.ones(len(k0), np.float32)
+    A = orc.FrameData(k0["x"], k0["y"], k0["octave"], k0["angle"], m1, d0)
+    B = orc.FrameData(k1["x"], k1["y"], k1["octave"], k1["angle"], -np.ones(len(k1), np.float32), d1)
+    ba, bb = orc.BowData(_nodes(k0)), orc.BowData(_nodes(k1, dx, dy))
+    va, vb = np.ones(len(k0), np.uint8), np.ones(len(k1), np.uint8)
+    for mode in (0, 1):
+        om = np.full(len(k0) if mode else len(k1), -1, np.int32)
+        n = orc.lib().orc_match_bow(C.byref(A.c), va, C.byref(ba.c), C.byref(B.c), vb, C.byref(bb.c), mode, 0.75, 1, om)
+        assert n == (om >= 0).sum() and n > 100
+        sel = np.nonzero(om >= 0)[0]
+        ia, ib = (sel, om[sel]) if mode else (om[sel], sel)
+        err = np.hypot(k1["x"][ib] - k0["x"][ia] - dx, k1["y"][ib] - k0["y"][ia] - dy)
+        assert np.mean(err < 3.0) > 0.9
+        if mode:
+            assert len(np.unique(ib)) == len(ib)     # KF-KF search keeps B features exclusive (:569, :628)
+    # triangulation search: epipolar geometry of the pure shift
+    F = np.array([[0, 0, dy], [0, 0, -dx], [-dy, dx, 0]], np.float64)
+    z = np.zeros(len(k0), np.uint8)
+    sf = np.array(list(orc.orb_params().scale)[:8], np.float32)
+    om = np.full(len(k0), -1, np.int32)
+    n = orc.lib().orc_match_triangulation(C.byref(A.c), z, C.byref(ba.c), C.byref(B.c), np.zeros(len(k1), np.uint8),
+                                          C.byref(bb.c), np.ascontiguousarray(F.reshape(-1)), 1e6, 1e6, sf, 1, om)
+    sel = np.nonzero(om >= 0)[0]
+    assert n == len(sel) and n > 100
+    err = np.hypot(k1["x"][om[sel]] - k0["x"][sel] - dx, k1["y"][om[sel]] - k0["y"][sel] - dy)
+    assert np.mean(err < 3.0) > 0.85
+    # with the epipole in the image centre, monocular pairs near it are rejected (:932-940)
+    om2 = np.full(len(k0), -1, np.int32)
+    orc.lib().orc_match_triangulation(C.byref(A.c), z, C.byref(ba.c), C.byref(B.c), np.zeros(len(k1), np.uint8),
+                                      C.byref(bb.c), np.ascontiguousarray(F.reshape(-1)), 320.0, 240.0, sf, 0, om2)
+    s2 = np.nonzero(om2 >= 0)[0]
+    d2 = (320.0 - k1["x"][om2[s2]]) ** 2 + (240.0 - k1["y"][om2[s2]]) ** 2
+    assert (d2 >= 100 * sf[k1["octave"][om2[s2]]] - 1e-3).all()
+
+
+def test_oracle_fuse_and_keyframe_projection(orc):
+    import ctypes as C
+    k0, d0, k1, d1, dx, dy = _pair(orc, 1)
+    sf = np.array(list(orc.orb_params().scale)[:8], np.float32)
+    ur1 = -np.ones(len(k1), np.float32)
+    F = orc.FrameData(k1["x"], k1["y"], k1["octave"], k1["angle"], ur1, d1)
+    u, v = (k0["x"] + dx).astype(np.float32), (k0["y"] + dy).astype(np.float32)
+    ones = np.ones(len(k0), np.uint8)
+    best = np.full(len(k0), -1, np.int32)
+    n = orc.lib().orc_match_fuse(C.byref(F.c), len(k0), ones, u, v, u - 10, k0["octave"].astype(np.int32),
+                                 np.ascontiguousarray(d0), 3.0, sf, best)
+    sel = np.nonzero(best >= 0)[0]
+    assert n == len(sel) and n > 100
+    # accepted features satisfy the octave gate and the 2-dof chi2 gate
+    oc = k1["octave"][best[sel]]
+    assert ((oc >= k0["octave"][sel] - 1) & (oc <= k0["octave"][sel])).all()
+    e2 = ((u[sel] - k1["x"][best[sel]]) ** 2 + (v[sel] - k1["y"][best[sel]]) ** 2) / sf[oc] ** 2
+    assert (e2 <= 5.991 + 1e-3).all()
+    assigned = np.full(len(k1), -1, np.int32)
+    has = np.zeros(len(k1), np.uint8)
+    has[::5] = 1
+    n = orc.lib().orc_match_frame_keyframe(C.byref(F.c), len(k0), ones, u, v, k0["octave"].astype(np.int32),
+                                           k0["angle"].astype(np.float32), np.ascontiguousarray(d0), 10.0, 64.0, 1, sf,
+                                           has, assigned)
+    assert n == (assigned >= 0).sum() and n > 100
+    assert not (assigned[has == 1] >= 0).any()
+
+
+def test_keyframe_matcher_fixture(orc):
+    """the committed g6 fixture is what the oracle produces today (guards oracle drift)"""
+    g3, g = np.load(G / "g3_match.npz"), np.load(G / "g6_match_kf.npz")
+    n = len(g3["d0"])
+    A = orc.FrameData(g["ax"], g["ay"], g["aoct"], g["aang"], g["aur"], g3["d0"])
+    B = orc.FrameData(g3["kx"], g3["ky"], g3["koct"], g3["kang"], g["bur"], g3["d1"])
+    ba, bb = orc.BowData(g["node_a"]), orc.BowData(g["node_b"])
+    fa, fb = g["flag_a"], g["flag_b"]
+    L = orc.lib()
+    for mode in (0, 1):
+        m = np.full(n, -1, np.int32)
+        cnt = L.orc_match_bow(C.byref(A.c), 1 - fa, C.byref(ba.c), C.byref(B.c), 1 - fb, C.byref(bb.c), mode, 0.75, 1, m)
+        assert cnt == int(g[f"bow{mode}_n"]) and np.array_equal(m, g[f"bow{mode}"])
+    m = np.full(n, -1, np.int32)
+    cnt = L.orc_match_triangulation(C.byref(A.c), fa, C.byref(ba.c), C.byref(B.c), fb, C.byref(bb.c),
+                                    np.ascontiguousarray(g["F12"].reshape(-1)), 300.0, 200.0, g3["scale"], 1, m)
+    assert cnt == int(g["tri_n"]) and np.array_equal(m, g["tri"])
+    m = np.full(n, -1, np.int32)
+    cnt = L.orc_match_fuse(C.byref(B.c), n, 1 - fa, g3["q_u"], g3["q_v"], g["q_ur"], g["q_level"],
+                           np.ascontiguousarray(g3["d0"]), 3.0, g3["scale"], m)
+    assert cnt == int(g["fuse_n"]) and np.array_equal(m, g["fuse"])

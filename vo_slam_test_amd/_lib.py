@@ -40,7 +40,8 @@ SYMBOLS = [
     "vo_orb_extract_batch_dev", "vo_orb_sync", "vo_orb_get_level", "vo_orb_get_candidates",
     "vo_orb_get_level_counts", "vo_orb_set_timing", "vo_orb_get_timing",
     "vo_hamming_matrix_dev", "vo_hamming_matrix_batch_dev", "vo_hamming_matrix",
-    "vo_match_frame_projection", "vo_match_local_map",
+    "vo_match_frame_projection", "vo_match_local_map", "vo_match_frame_keyframe", "vo_match_bow",
+    "vo_match_triangulation", "vo_match_fuse",
     "vo_pose_only_solve", "vo_pose_only_solve_dev",
     "vo_ba_create", "vo_ba_destroy", "vo_ba_set_stream", "vo_ba_set_shard", "vo_ba_set_state",
     "vo_ba_get_state", "vo_ba_n_free_cams", "vo_ba_local_ba", "vo_ba_local_ba_enqueue",
@@ -233,8 +234,28 @@ class FrameArrays:
         self.view = v
 
 
+class BowView(C.Structure):
+    _fields_ = [("n_nodes", C.c_int32), ("node_id", C.c_void_p), ("start", C.c_void_p), ("feat", C.c_void_p)]
+
+
+class BowNodes:
+    """DBoW3::FeatureVector as CSR built from a per-feature node id array (ascending node ids)."""
+
+    def __init__(self, node_of_feature):
+        node_of_feature = np.asarray(node_of_feature)
+        order = np.argsort(node_of_feature, kind="stable")
+        ids, counts = np.unique(node_of_feature, return_counts=True)
+        self.node_id = np.ascontiguousarray(ids, np.uint32)
+        self.start = np.ascontiguousarray(np.concatenate([[0], np.cumsum(counts)]), np.int32)
+        self.feat = np.ascontiguousarray(order, np.uint32)
+        v = BowView()
+        v.n_nodes = len(self.node_id)
+        v.node_id, v.start, v.feat = self.node_id.ctypes.data, self.start.ctypes.data, self.feat.ctypes.data
+        self.view = v
+
+
 class Matcher:
-    """Mirror of myslam::Matcher's projection searches (reference include/myslam/matcher.h:9-45)."""
+    """Mirror of myslam::Matcher's search routines (reference include/myslam/matcher.h:9-45)."""
 
     def __init__(self, ratio: float = 0.8):
         self.ratio_ = ratio
@@ -261,6 +282,50 @@ class Matcher:
             _p(q["viewcos"]), _p(q["desc"]), C.c_float(thRadius), C.c_float(self.ratio_), _p(sf), _p(blocked),
             _p(assigned), C.byref(n)), "vo_match_local_map")
         return n.value, assigned
+
+    def searchByProjection_keyframe(self, cur: FrameArrays, q, radius, distThreshold, checkRot, scale_factors,
+                                    has_map_point=None):
+        nq = len(q["flags"])
+        assigned = np.full(cur.view.n, -1, np.int32)
+        n = C.c_int()
+        sf = np.ascontiguousarray(scale_factors, np.float32)
+        check(lib().vo_match_frame_keyframe(
+            C.byref(cur.view), nq, _p(q["flags"]), _p(q["u"]), _p(q["v"]), _p(q["level"]), _p(q["angle"]),
+            _p(q["desc"]), C.c_float(radius), C.c_float(distThreshold), int(checkRot), _p(sf), _p(has_map_point),
+            _p(assigned), C.byref(n)), "vo_match_frame_keyframe")
+        return n.value, assigned
+
+    def searchByBoW(self, a: FrameArrays, a_valid, a_nodes: BowNodes, b: FrameArrays, b_valid, b_nodes: BowNodes,
+                    keyframe_to_keyframe: bool, checkRot=True):
+        mode = 1 if keyframe_to_keyframe else 0
+        match = np.full((a.view.n if mode else b.view.n), -1, np.int32)
+        n = C.c_int()
+        check(lib().vo_match_bow(C.byref(a.view), _p(np.ascontiguousarray(a_valid, np.uint8)), C.byref(a_nodes.view),
+                                 C.byref(b.view), _p(np.ascontiguousarray(b_valid, np.uint8)), C.byref(b_nodes.view),
+                                 mode, C.c_float(self.ratio_), int(checkRot), _p(match), C.byref(n)), "vo_match_bow")
+        return n.value, match
+
+    def searchForTriangulation(self, a: FrameArrays, a_has, a_nodes, b: FrameArrays, b_has, b_nodes, F12, ex, ey,
+                               scale_factors, checkRot=True):
+        match = np.full(a.view.n, -1, np.int32)
+        n = C.c_int()
+        sf = np.ascontiguousarray(scale_factors, np.float32)
+        F = np.ascontiguousarray(F12, np.float64).reshape(-1)
+        check(lib().vo_match_triangulation(
+            C.byref(a.view), _p(np.ascontiguousarray(a_has, np.uint8)), C.byref(a_nodes.view), C.byref(b.view),
+            _p(np.ascontiguousarray(b_has, np.uint8)), C.byref(b_nodes.view), _p(F), C.c_float(ex), C.c_float(ey),
+            _p(sf), int(checkRot), _p(match), C.byref(n)), "vo_match_triangulation")
+        return n.value, match
+
+    def fuseMapPoints_match(self, kf: FrameArrays, q, threshold, scale_factors):
+        nq = len(q["flags"])
+        best = np.full(nq, -1, np.int32)
+        n = C.c_int()
+        sf = np.ascontiguousarray(scale_factors, np.float32)
+        check(lib().vo_match_fuse(C.byref(kf.view), nq, _p(q["flags"]), _p(q["u"]), _p(q["v"]), _p(q["ur"]),
+                                  _p(q["level"]), _p(q["desc"]), C.c_float(threshold), _p(sf), _p(best), C.byref(n)),
+              "vo_match_fuse")
+        return n.value, best
 
     @staticmethod
     def computeDistance(a, b) -> int:

@@ -296,3 +296,222 @@ int vo_match_local_map(const vo_frame_view *cur, int nq, const uint8_t *q_flags,
 }
 
 }  // extern "C"
+
+namespace {
+
+constexpr int TH_LOW = 50;  // matcher.cpp:12
+
+struct RotHist {  // rotation-consistency filter shared by the search routines (:128-145 and friends)
+  std::vector<std::vector<int>> bins = std::vector<std::vector<int>>(HISTO_LENGTH);
+  void add(float angle_a, float angle_b, int idx, bool cv_round) {
+    const float pdf = HISTO_LENGTH / 360.0f;
+    float r = angle_a - angle_b;
+    if (r < 0) r += 360.0f;
+    int bin = cv_round ? (int)lrintf(r * pdf) : (int)roundf(r * pdf);
+    if (bin == HISTO_LENGTH) bin = 0;
+    bins[bin].push_back(idx);
+  }
+  template <class F>
+  int prune(F &&drop) {  // calls drop(idx) for every entry outside the three dominant bins
+    int i1, i2, i3, removed = 0;
+    three_max(bins, i1, i2, i3);
+    for (int b = 0; b < HISTO_LENGTH; b++)
+      if (b != i1 && b != i2 && b != i3)
+        for (int idx : bins[b]) {
+          drop(idx);
+          removed++;
+        }
+    return removed;
+  }
+};
+
+// walk two ascending node lists, calling f(ia, ib) for every common node id (:541-544 lower_bound walk)
+template <class F>
+void for_common_nodes(const vo_bow_view &a, const vo_bow_view &b, F &&f) {
+  int ia = 0, ib = 0;
+  while (ia < a.n_nodes && ib < b.n_nodes) {
+    if (a.node_id[ia] == b.node_id[ib]) {
+      f(ia, ib);
+      ia++, ib++;
+    } else if (a.node_id[ia] < b.node_id[ib]) {
+      ia++;
+    } else {
+      ib++;
+    }
+  }
+}
+
+}  // namespace
+
+extern "C" {
+
+int vo_match_frame_keyframe(const vo_frame_view *cur, int nq, const uint8_t *q_flags, const float *q_u,
+                            const float *q_v, const int32_t *q_level, const float *q_angle, const uint8_t *q_desc,
+                            float radius, float dist_threshold, int check_rot, const float *scale_factors,
+                            const uint8_t *has_mp_in, int32_t *assigned, int *n_matches) {
+  if (!cur || nq < 0 || !assigned || !n_matches || !scale_factors) return VO_ERR_INVALID;
+  *n_matches = 0;
+  if (nq == 0 || cur->n == 0) return VO_OK;
+  std::vector<uint16_t> D;
+  VO_CHECK(distance_matrix(q_desc, nq, cur->desc, cur->n, D));
+  const Grid grid(*cur);
+  std::vector<uint8_t> has(cur->n, 0);
+  if (has_mp_in) has.assign(has_mp_in, has_mp_in + cur->n);
+  RotHist rot;
+  std::vector<int> cand;
+  int cnt = 0;
+  for (int i = 0; i < nq; i++) {
+    if (!(q_flags[i] & 1)) continue;
+    const int lp = q_level[i];
+    const float rs = radius * scale_factors[lp];
+    grid.query(*cur, q_u[i], q_v[i], rs, lp - 1, lp + 1, cand);
+    int best = 256, best_idx = -1;
+    for (int idx : cand) {
+      if (has[idx]) continue;
+      const int d = D[(size_t)i * cur->n + idx];
+      if (d < best) best = d, best_idx = idx;
+    }
+    if ((float)best <= dist_threshold) {
+      assigned[best_idx] = i;
+      has[best_idx] = 1;
+      cnt++;
+      if (check_rot) rot.add(q_angle[i], cur->angle[best_idx], best_idx, true);
+    }
+  }
+  if (check_rot) cnt -= rot.prune([&](int idx) { assigned[idx] = -1; });
+  *n_matches = cnt;
+  return VO_OK;
+}
+
+int vo_match_bow(const vo_frame_view *a, const uint8_t *a_valid, const vo_bow_view *an, const vo_frame_view *b,
+                 const uint8_t *b_valid, const vo_bow_view *bn, int mode, float ratio, int check_rot, int32_t *match,
+                 int *n_matches) {
+  if (!a || !b || !an || !bn || !a_valid || !match || !n_matches || (mode != 0 && mode != 1) || (mode == 1 && !b_valid))
+    return VO_ERR_INVALID;
+  const int nout = mode == 0 ? b->n : a->n;
+  for (int i = 0; i < nout; i++) match[i] = -1;
+  *n_matches = 0;
+  if (a->n == 0 || b->n == 0) return VO_OK;
+  std::vector<uint16_t> D;
+  VO_CHECK(distance_matrix(a->desc, a->n, b->desc, b->n, D));
+  std::vector<uint8_t> taken(b->n, 0);
+  RotHist rot;
+  int cnt = 0;
+  for_common_nodes(*an, *bn, [&](int ia, int ib) {
+    for (int s = an->start[ia]; s < an->start[ia + 1]; s++) {
+      const int i1 = (int)an->feat[s];
+      if (!a_valid[i1]) continue;
+      int best1 = 256, best2 = 256, bidx = -1;
+      for (int t = bn->start[ib]; t < bn->start[ib + 1]; t++) {
+        const int i2 = (int)bn->feat[t];
+        if (mode == 0 ? match[i2] >= 0 : (taken[i2] || !b_valid[i2])) continue;
+        const int d = D[(size_t)i1 * b->n + i2];
+        if (d < best1)
+          best2 = best1, best1 = d, bidx = i2;
+        else if (d < best2)
+          best2 = d;
+      }
+      if (best1 <= TH_LOW && (float)best1 < ratio * (float)best2) {
+        if (mode == 0) {
+          match[bidx] = i1;
+          if (check_rot) rot.add(a->angle[i1], b->angle[bidx], bidx, true);
+        } else {
+          match[i1] = bidx;
+          taken[bidx] = 1;
+          if (check_rot) rot.add(a->angle[i1], b->angle[bidx], i1, false);  // :637 uses round()
+        }
+        cnt++;
+      }
+    }
+  });
+  if (check_rot) cnt -= rot.prune([&](int idx) { match[idx] = -1; });
+  *n_matches = cnt;
+  return VO_OK;
+}
+
+int vo_match_triangulation(const vo_frame_view *a, const uint8_t *a_has, const vo_bow_view *an, const vo_frame_view *b,
+                           const uint8_t *b_has, const vo_bow_view *bn, const double F[9], float ex, float ey,
+                           const float *scale_factors, int check_rot, int32_t *match12, int *n_matches) {
+  if (!a || !b || !an || !bn || !a_has || !b_has || !F || !scale_factors || !match12 || !n_matches) return VO_ERR_INVALID;
+  for (int i = 0; i < a->n; i++) match12[i] = -1;
+  *n_matches = 0;
+  if (a->n == 0 || b->n == 0) return VO_OK;
+  std::vector<uint16_t> D;
+  VO_CHECK(distance_matrix(a->desc, a->n, b->desc, b->n, D));
+  std::vector<uint8_t> taken(b->n, 0);
+  RotHist rot;
+  int cnt = 0;
+  for_common_nodes(*an, *bn, [&](int ia, int ib) {
+    for (int s = an->start[ia]; s < an->start[ia + 1]; s++) {
+      const int i1 = (int)an->feat[s];
+      if (a_has[i1]) continue;
+      const bool stereo1 = a->uright[i1] >= 0;
+      // epipolar line of feature 1 in image 2: l = F12^T p1 (checkEpipolarConstrain, :1306-1324)
+      const double l0 = a->x[i1] * F[0] + a->y[i1] * F[3] + F[6], l1 = a->x[i1] * F[1] + a->y[i1] * F[4] + F[7],
+                   l2 = a->x[i1] * F[2] + a->y[i1] * F[5] + F[8];
+      const float den = (float)(l0 * l0 + l1 * l1);
+      int best = TH_LOW, bidx = -1;
+      for (int t = bn->start[ib]; t < bn->start[ib + 1]; t++) {
+        const int i2 = (int)bn->feat[t];
+        if (taken[i2] || b_has[i2]) continue;
+        const int d = D[(size_t)i1 * b->n + i2];
+        if (d > TH_LOW || d > best) continue;  // an equal later distance replaces the earlier one (:928)
+        const float sigma = scale_factors[b->octave[i2]];
+        if (!stereo1 && !(b->uright[i2] >= 0)) {
+          const float dx = ex - b->x[i2], dy = ey - b->y[i2];
+          if (dx * dx + dy * dy < 100 * sigma) continue;  // too close to the epipole (:932-940)
+        }
+        if (den == 0) continue;
+        const float num = (float)(l0 * b->x[i2] + l1 * b->y[i2] + l2);
+        if (num * num / den < 3.84f * sigma * sigma) best = d, bidx = i2;
+      }
+      if (bidx >= 0) {
+        match12[i1] = bidx;
+        taken[bidx] = 1;
+        cnt++;
+        if (check_rot) rot.add(a->angle[i1], b->angle[bidx], i1, false);
+      }
+    }
+  });
+  if (check_rot) cnt -= rot.prune([&](int idx) { match12[idx] = -1; });
+  *n_matches = cnt;
+  return VO_OK;
+}
+
+int vo_match_fuse(const vo_frame_view *kf, int nq, const uint8_t *q_flags, const float *q_u, const float *q_v,
+                  const float *q_ur, const int32_t *q_level, const uint8_t *q_desc, float threshold,
+                  const float *scale_factors, int32_t *best_idx, int *n_matches) {
+  if (!kf || nq < 0 || !best_idx || !n_matches || !scale_factors) return VO_ERR_INVALID;
+  for (int i = 0; i < nq; i++) best_idx[i] = -1;
+  *n_matches = 0;
+  if (nq == 0 || kf->n == 0) return VO_OK;
+  std::vector<uint16_t> D;
+  VO_CHECK(distance_matrix(q_desc, nq, kf->desc, kf->n, D));
+  const Grid grid(*kf);
+  std::vector<int> cand;
+  int cnt = 0;
+  for (int i = 0; i < nq; i++) {
+    if (!(q_flags[i] & 1)) continue;
+    const int lp = q_level[i];
+    grid.query(*kf, q_u[i], q_v[i], threshold * scale_factors[lp], -(1 << 30), 1 << 30, cand);
+    int best = 256, bidx = -1;
+    for (int idx : cand) {
+      if (kf->octave[idx] < lp - 1 || kf->octave[idx] > lp) continue;
+      const float dx = q_u[i] - kf->x[idx], dy = q_v[i] - kf->y[idx];
+      const float is = 1.0f / scale_factors[kf->octave[idx]];
+      if (kf->uright[idx] >= 0) {  // chi2 gates of :1084-1099
+        const float er = q_ur[i] - kf->uright[idx];
+        if ((dx * dx + dy * dy + er * er) * is * is > 7.815f) continue;
+      } else if ((dx * dx + dy * dy) * is * is > 5.991f) {
+        continue;
+      }
+      const int d = D[(size_t)i * kf->n + idx];
+      if (d < best) best = d, bidx = idx;
+    }
+    if (best <= TH_LOW) best_idx[i] = bidx, cnt++;
+  }
+  *n_matches = cnt;
+  return VO_OK;
+}
+
+}  // extern "C"
