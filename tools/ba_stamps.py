@@ -1,0 +1,46 @@
+"""Developer tool: phase breakdown of k_ba_solve from s_memrealtime stamps.
+
+Builds a VO_BA_STAMPS variant of the library into tools/_stamp/libvo_stamp.so (git-ignored, ships
+with gpurun), then on the GPU box:  python tools/ba_stamps.py run
+"""
+import ctypes as C
+import pathlib
+import subprocess
+import sys
+
+import numpy as np
+
+ROOT = pathlib.Path(__file__).resolve().parent.parent
+OUT = ROOT / "tools" / "_stamp" / "libvo_stamp.so"
+sys.path.insert(0, str(ROOT))
+
+
+def build():
+    OUT.parent.mkdir(exist_ok=True)
+    srcs = [ROOT / "vo_slam_test_amd" / "csrc" / n for n in ("vo_common.hip", "orb.hip", "match.hip", "ba.hip")]
+    cmd = ["/opt/rocm/bin/hipcc", "-O3", "-std=c++17", "--offload-arch=gfx950", "-fPIC", "-shared", "-DVO_BA_STAMPS",
+           "-ffp-contract=fast", "-Wno-unused-function", *map(str, srcs), "-o", str(OUT)]
+    subprocess.run(cmd, check=True)
+    print("built", OUT)
+
+
+def run():
+    import torch  # noqa: F401  (HIP runtime first)
+    from vo_slam_test_amd import _lib, synth
+    _lib.SO = OUT
+    L = _lib.lib()
+    pr = synth.make_lba_problem(0)
+    ba = _lib.BundleAdjuster(pr)
+    ba.local_ba()
+    st = np.zeros(8, np.uint64)
+    L.vo_ba_debug_stamps(ba._h, st.ctypes.data_as(C.c_void_p))
+    d = np.diff(st.astype(np.int64)) / 100.0  # s_memrealtime ticks at 100 MHz -> us
+    names = ["slab sums+scale", "assemble+gmax", "LDLt", "back-subst", "dots", "cand poses", "block_sum"]
+    for nm, v in zip(names, d):
+        print(f"{nm:18s} {v:8.2f} us")
+    print(f"{'total':18s} {(int(st[7]) - int(st[0])) / 100.0:8.2f} us")
+    ba.close()
+
+
+if __name__ == "__main__":
+    build() if len(sys.argv) < 2 or sys.argv[1] == "build" else run()

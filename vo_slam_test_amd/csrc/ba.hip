@@ -820,7 +820,8 @@ __global__ __launch_bounds__(256) void k_ba_solve(BaDev B) {
   double *red = Ldg + nb * 21 + n;  // 64 scratch (after the n reciprocal pivots)
   __shared__ int s_fail, s_stop;
   const double *G = B.payload;
-  double *HPw = B.payload + payload_hpp_off(B);
+  // camera blocks / cost / gradient-max: all-reduced payload in the sharded mode, summed into LDS here otherwise
+  double *HPw = B.fused ? red + 64 : B.payload + payload_hpp_off(B);
   // issue this thread's loads of the Schur product early (they only depend on k_ba_gemm); they are
   // consumed after the slab sums and the scale setup, hiding one memory round trip
   constexpr int kPref = 8;
@@ -835,23 +836,36 @@ __global__ __launch_bounds__(256) void k_ba_solve(BaDev B) {
       }
     for (; q < kPref; q++) gpre[q] = 0;
   }
+  // this thread's camera for the candidate-pose phase: pose and cache are read now, used after the solve
+  const int cur0 = S->cur;
+  const int first = S->first;
+  const double radius = S->radius;
+  const int pc_cam = tid < B.n_cams ? tid : 0;
+  double xpre[6];
+#pragma unroll
+  for (int a = 0; a < 6; a++) xpre[a] = B.Xc[cur0][6 * pc_cam + a];
+  const PoseCache pcpre = load_pc(B.PC[cur0], pc_cam);
+  const int slotpre = B.cam_slot[pc_cam], cinpre = B.cam_in[pc_cam];
+  const int sc_idx = tid < n ? 6 * B.slot_cam[tid / 6] + tid % 6 : 0;
+  const double sc_pre = first ? 0.0 : B.scale_c[sc_idx];
   if (B.fused) {  // no k_ba_reduce in this mode: sum the camera-block and cost slabs here
     for (int i = tid; i < B.nf * 27; i += 256) {
       const int slot = i / 27, t = i - slot * 27;
       const double *sp = B.slab_cam + (long long)slot * B.n_cchunks * 27 + t;
       double a = 0;
-      int c = 0;
-      for (; c + 4 <= B.n_cchunks; c += 4) {  // four loads in flight, summed in chunk order
-        const double v0 = sp[c * 27], v1 = sp[(c + 1) * 27], v2 = sp[(c + 2) * 27], v3 = sp[(c + 3) * 27];
-        a += v0, a += v1, a += v2, a += v3;
+      for (int c0 = 0; c0 < B.n_cchunks; c0 += 16) {  // sixteen loads in flight, summed in chunk order
+        double v[16];
+#pragma unroll
+        for (int q = 0; q < 16; q++) v[q] = c0 + q < B.n_cchunks ? sp[(c0 + q) * 27] : 0.0;
+#pragma unroll
+        for (int q = 0; q < 16; q++) a += v[q];
       }
-      for (; c < B.n_cchunks; c++) a += sp[c * 27];
       HPw[i] = a;
     }
     if (tid >= 192) {  // last wave: cost (sum) and gradient max over the point blocks
       const int l = tid - 192;
       double cs = 0, m = 0;
-      const double *spt = B.slab_pt[S->cur];
+      const double *spt = B.slab_pt[cur0];
       for (int b = l; b < B.n_pblocks; b += 64) {
         cs += spt[2 * b];
         m = fmax(m, spt[2 * b + 1]);
@@ -863,12 +877,9 @@ __global__ __launch_bounds__(256) void k_ba_solve(BaDev B) {
         HPw[B.nf * 27 + 1] = m;
       }
     }
-    __threadfence_block();
     __syncthreads();
   }
   const double *HP = HPw;
-  const int first = S->first;
-  const double radius = S->radius;
   if (tid == 0) s_fail = 0, s_stop = 0;
   double gm = 0;
   for (int i = tid; i < n; i += 256) {
@@ -881,7 +892,7 @@ __global__ __launch_bounds__(256) void k_ba_solve(BaDev B) {
       s = 1.0 / (1.0 + sqrt(hd));
       B.scale_c[6 * B.slot_cam[slot] + a] = s;
     } else {
-      s = B.scale_c[6 * B.slot_cam[slot] + a];
+      s = i == tid ? sc_pre : B.scale_c[6 * B.slot_cam[slot] + a];
     }
     sc[i] = s;
     Dd[i] = fmin(fmax(hd * s * s, 1e-6), 1e32) / radius;
@@ -917,10 +928,10 @@ __global__ __launch_bounds__(256) void k_ba_solve(BaDev B) {
   __syncthreads();
   if (tid == 0) {
     double m = fmax(fmax(red[0], red[1]), fmax(red[2], red[3]));
-    const int co = payload_cost_off(B);
-    for (int k = 0; k < B.n_shards; k++) m = fmax(m, B.payload[co + 1 + k]);
+    const double *CP = HP + B.nf * 27;  // cost, then one gradient-max slot per shard
+    for (int k = 0; k < B.n_shards; k++) m = fmax(m, CP[1 + k]);
     S->gmax = m;
-    const double cost = B.payload[co];
+    const double cost = CP[0];
     S->x_cost = cost;
     if (first) S->initial_cost = cost;
     // FinalizeIterationAndCheckIfMinimizerCanContinue of the previous iteration
@@ -1031,27 +1042,34 @@ __global__ __launch_bounds__(256) void k_ba_solve(BaDev B) {
   const int failed = s_fail;
   STAMP(5);
   // candidate poses (PoseLocalParameterization::Plus) + their caches + norms
-  const double *X = B.Xc[S->cur];
-  double *Xn = B.Xc[S->cur ^ 1];
+  const double *X = B.Xc[cur0];
+  double *Xn = B.Xc[cur0 ^ 1];
   double xn2 = 0, cn2 = 0, sn2 = 0;
   for (int c = tid; c < B.n_cams; c += 256) {
-    const int slot = B.cam_slot[c];
-    double xc[6];
+    const bool pre = c == tid;  // first round: operands were prefetched at the top of the kernel
+    const int slot = pre ? slotpre : B.cam_slot[c];
+    const int cin = pre ? cinpre : (int)B.cam_in[c];
+    double x0[6], xc[6];
+#pragma unroll
+    for (int a = 0; a < 6; a++) x0[a] = pre ? xpre[a] : X[6 * c + a];
     if (slot >= 0 && !failed) {
       double d[6];
+#pragma unroll
       for (int a = 0; a < 6; a++) d[a] = -y[6 * slot + a] * sc[6 * slot + a];
-      se3_plus(X + 6 * c, d, xc);
-      store_pc(B.PC[S->cur ^ 1], c, pose_cache(xc));
+      se3_plus(x0, d, xc);
+      store_pc(B.PC[cur0 ^ 1], c, pose_cache(xc));
     } else {
-      for (int a = 0; a < 6; a++) xc[a] = X[6 * c + a];
-      store_pc(B.PC[S->cur ^ 1], c, load_pc(B.PC[S->cur], c));
+#pragma unroll
+      for (int a = 0; a < 6; a++) xc[a] = x0[a];
+      store_pc(B.PC[cur0 ^ 1], c, pre ? pcpre : load_pc(B.PC[cur0], c));
     }
+#pragma unroll
     for (int a = 0; a < 6; a++) {
       Xn[6 * c + a] = xc[a];
-      if (slot >= 0 && B.cam_in[c]) {
-        xn2 += X[6 * c + a] * X[6 * c + a];
+      if (slot >= 0 && cin) {
+        xn2 += x0[a] * x0[a];
         cn2 += xc[a] * xc[a];
-        sn2 += (xc[a] - X[6 * c + a]) * (xc[a] - X[6 * c + a]);
+        sn2 += (xc[a] - x0[a]) * (xc[a] - x0[a]);
       }
     }
   }
@@ -1476,7 +1494,7 @@ int build_device(vo_ba *h) {
   D.st = h->b_state.as<BaState>();
   D.hist = D.st + 1;
   const int n = 6 * h->nf;
-  h->solve_lds = ((size_t)(n + 1) * (n + 1) + 5 * n + (size_t)h->nf * 21 + 64) * 8;
+  h->solve_lds = ((size_t)(n + 1) * (n + 1) + 5 * n + (size_t)h->nf * 21 + 64 + (size_t)h->nf * 27 + 8) * 8;
   if (h->solve_lds > 64 * 1024)
     VO_HIP_CHECK(hipFuncSetAttribute((const void *)k_ba_solve, hipFuncAttributeMaxDynamicSharedMemorySize,
                                      (int)h->solve_lds));

@@ -181,16 +181,23 @@ __global__ __launch_bounds__(256) void k_resize4(const uint8_t *src, long long s
 // ------------------------------------------------------------------------------------------
 // K2  cv::FAST(cell, threshold, nms=true) per 30-px grid cell with the 20 -> 7 threshold fallback
 // -- ComputeKeyPointsOctTree cell loop, ORBextractor.cpp:796-837.
-// One 256-thread workgroup per (cell, frame).  The cell sub-image (<= 66x66 incl. the 6-px
-// overlap) is staged in LDS; every interior pixel gets S = max over the 16 nine-pixel arcs of the
+// One WAVEFRONT per (cell, frame), four cells per 256-thread workgroup, no workgroup barrier
+// anywhere: the kernel is instruction-issue bound, and ballot/mbcnt compaction inside one wave
+// needs neither LDS counters nor barriers.  The cell sub-image (incl. the 6-px overlap) is staged
+// in the wave's LDS region; every interior pixel gets S = max over the 16 nine-pixel arcs of the
 // minimum |centre - ring| (bright or dark), so "corner at threshold t" <=> S > t and the OpenCV
 // cornerScore is S-1, independent of t.  NMS runs on the LDS score tile with scores below the
 // cell's current threshold read as 0 and pixels outside the cell interior as 0 (Q-E2).  Survivors
-// are written in raster order (ballot + prefix) to the cell's slot: x | y<<12 | score<<24 with
-// x,y already shifted by (j*wCell, i*hCell) like :830-831.
+// are written in raster order to the cell's slot: x | y<<12 | score<<24 with x,y already shifted
+// by (j*wCell, i*hCell) like :830-831.
 // ------------------------------------------------------------------------------------------
+__device__ __forceinline__ void wave_sync() {  // LDS hand-off between lanes of one wavefront
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+}
+
+template <int TP>
 __device__ __forceinline__ int fast_arc_score(const uint8_t *t, int min_th) {
-  const int TP = kTileP;
   const int v = t[0];
   int d[16];
   d[0] = v - t[3 * TP];
@@ -225,15 +232,22 @@ __device__ __forceinline__ int fast_arc_score(const uint8_t *t, int min_th) {
   return S > min_th ? S - 1 : 0;
 }
 
-__global__ __launch_bounds__(256) void k_fast_cells(OrbDev P, FrameSrc src, uint32_t *cell_slots,
-                                                    long long slots_frame_stride, int *cell_count,
-                                                    int cells_per_frame, int lv0_unaligned) {
-  __shared__ __attribute__((aligned(16))) uint8_t tile_raw[kTileP * kTileP + 16];
-  __shared__ uint8_t score[kTileP * kTileP];
-  __shared__ unsigned short plist[kTileP * kTileP];
-  __shared__ int wcnt[4][4];  // double-buffered per-wave counts (phase 1: 0/1, phase 3: 2/3)
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int cell = blockIdx.x, f = blockIdx.y;
+__host__ __device__ __forceinline__ int fast_align16(int v) { return (v + 15) & ~15; }
+
+template <int TP>  // LDS tile pitch in bytes: 48 for the usual 30..39-px cells, 72 for the largest legal cell
+__global__ __launch_bounds__(256) void k_fast_wave(OrbDev P, FrameSrc src, uint32_t *cell_slots,
+                                                   long long slots_frame_stride, int *cell_count,
+                                                   int cells_per_frame, int lv0_unaligned, int tile_rows,
+                                                   int max_interior) {
+  extern __shared__ __attribute__((aligned(16))) uint8_t fast_lds[];
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
+  const int cell = blockIdx.x * 4 + wave, f = blockIdx.y;
+  if (cell >= cells_per_frame) return;  // wave-uniform; the kernel has no workgroup barrier
+  const int tileB = fast_align16(TP * tile_rows + 16), scoreB = fast_align16(TP * tile_rows);
+  uint8_t *tile_raw = fast_lds + (size_t)wave * (tileB + scoreB + fast_align16(2 * max_interior));
+  uint8_t *score = tile_raw + tileB;
+  unsigned short *plist = reinterpret_cast<unsigned short *>(score + scoreB);
   int l = 0;
   while (l + 1 < P.nlevels && cell >= P.lv[l + 1].cellBase) l++;
   const LevelGeom &L = P.lv[l];
@@ -242,7 +256,7 @@ __global__ __launch_bounds__(256) void k_fast_cells(OrbDev P, FrameSrc src, uint
   const int iniX = kBorder + ci_j * L.wCell, iniY = kBorder + ci_i * L.hCell;
   int *out_count = cell_count + (long long)f * cells_per_frame + cell;
   if (iniX >= L.maxBX - 6 || iniY >= L.maxBY - 3) {  // :801, :811
-    if (tid == 0) *out_count = 0;
+    if (lane == 0) *out_count = 0;
     return;
   }
   const int maxX = min(iniX + L.wCell + 6, L.maxBX), maxY = min(iniY + L.hCell + 6, L.maxBY);
@@ -250,102 +264,89 @@ __global__ __launch_bounds__(256) void k_fast_cells(OrbDev P, FrameSrc src, uint
   int pitch;
   const uint8_t *img = level_plane(P, src, l, f, pitch);
   // The tile keeps the source's dword alignment: LDS column 0 is image column iniX - (iniX & 3), so a
-  // row is a run of aligned dwords copied verbatim.  Every thread first issues all of its global
-  // loads (<= 5 dwords, independent), then writes LDS: one memory round trip per tile, not one per
-  // element.
-  const int ox = (l == 0 && lv0_unaligned) ? 0 : (iniX & 3);
+  // row is a run of aligned dwords copied verbatim, four independent loads in flight per lane.
+  const bool bytewise = l == 0 && lv0_unaligned;  // caller image rows are not 4-byte aligned
+  const int ox = bytewise ? 0 : (iniX & 3);
   const uint8_t *tile = tile_raw + ox;
-  for (int idx = tid; idx < kTileP * kTileP / 4; idx += 256) reinterpret_cast<uint32_t *>(score)[idx] = 0;
-  if (l == 0 && lv0_unaligned) {  // caller image rows are not 4-byte aligned: byte path
-    const float inv = 1.0f / (float)cw;
-    for (int base = 0; base < cw * ch; base += 256 * 4) {
-      uint8_t v[4];
+  for (int i = lane; i < scoreB / 16; i += 64) reinterpret_cast<uint4 *>(score)[i] = make_uint4(0, 0, 0, 0);
+  {
+    const int unit = bytewise ? 1 : 4;                       // bytes per element copied
+    const int npr = bytewise ? cw : (ox + cw + 3) >> 2;      // elements per tile row
+    const int total = npr * ch;
+    const uint8_t *g0 = img + (long long)iniY * pitch + (iniX - ox);
+    int y = (int)(((float)lane + 0.5f) / (float)npr), x = lane - y * npr;
+    const int sdy = 64 / npr, sdx = 64 - sdy * npr;
+    for (int base = 0; base < total; base += 256) {
+      uint32_t v[4];
       int pos[4];
 #pragma unroll
       for (int q = 0; q < 4; q++) {
-        const int idx = base + q * 256 + tid;
-        const int y = min((int)(((float)idx + 0.5f) * inv), ch - 1), x = idx - y * cw;
-        pos[q] = idx < cw * ch ? y * kTileP + x : -1;
-        v[q] = idx < cw * ch ? img[(long long)(iniY + y) * pitch + iniX + x] : 0;
+        const bool ok = base + q * 64 + lane < total;
+        pos[q] = ok ? y * TP + unit * x : -1;
+        const uint8_t *g = g0 + (long long)y * pitch + unit * x;
+        v[q] = !ok ? 0u : bytewise ? (uint32_t)*g : *reinterpret_cast<const uint32_t *>(g);
+        x += sdx, y += sdy;
+        if (x >= npr) x -= npr, y++;
       }
 #pragma unroll
       for (int q = 0; q < 4; q++)
-        if (pos[q] >= 0) tile_raw[pos[q]] = v[q];
+        if (pos[q] >= 0) {
+          if (bytewise)
+            tile_raw[pos[q]] = (uint8_t)v[q];
+          else
+            *reinterpret_cast<uint32_t *>(tile_raw + pos[q]) = v[q];
+        }
     }
-  } else {
-    const int ndw = (ox + cw + 3) >> 2;  // dwords per tile row (<= kTileP/4)
-    const float inv = 1.0f / (float)ndw;
-    const uint8_t *g0 = img + (long long)iniY * pitch + (iniX - ox);
-    uint32_t v[5];
-    int pos[5];
-#pragma unroll
-    for (int q = 0; q < 5; q++) {
-      const int idx = q * 256 + tid;
-      const int y = min((int)(((float)idx + 0.5f) * inv), ch), x4 = idx - y * ndw;
-      const bool ok = idx < ndw * ch;
-      pos[q] = ok ? y * (kTileP / 4) + x4 : -1;
-      v[q] = ok ? *reinterpret_cast<const uint32_t *>(g0 + (long long)y * pitch + 4 * x4) : 0u;
-    }
-#pragma unroll
-    for (int q = 0; q < 5; q++)
-      if (pos[q] >= 0) reinterpret_cast<uint32_t *>(tile_raw)[pos[q]] = v[q];
   }
-  __syncthreads();
+  wave_sync();
   const int iw = cw - 6, ih = ch - 6;
   const int ni = (iw > 0 && ih > 0) ? iw * ih : 0;
-  const float inv_iw = 1.0f / (float)max(iw, 1);
   // phase 1: a 9-arc always contains two neighbouring compass pixels (ring 0,4,8,12), so a pixel can
-  // only be a corner at the lowest threshold if one such pair is brighter or darker together.
-  // Survivors are compacted IN RASTER ORDER into an LDS list (ballot + per-wave counts, one barrier
-  // per 256-pixel chunk); everything after this phase touches survivors only.
+  // only be a corner at the lowest threshold if one such pair is brighter or darker together:
+  // max over the four pairs of min(pair) > v + t, or min over the pairs of max(pair) < v - t.
+  // Survivors are compacted IN RASTER ORDER into the wave's LDS list; everything after this phase
+  // touches survivors only.
   int np = 0;
-  for (int base = 0, it = 0; base < ni; base += 256, it++) {
-    const int idx = base + tid;
-    bool pass = false;
-    int pos = 0;
-    if (idx < ni) {
-      const int yq = min((int)(((float)idx + 0.5f) * inv_iw), ih - 1);
-      pos = (3 + yq) * kTileP + 3 + idx - yq * iw;
-      const uint8_t *t = &tile[pos];
-      const int v = t[0], hi = v + P.min_th, lo = v - P.min_th;
-      const int p0 = t[3 * kTileP], p4 = t[3], p8 = t[-3 * kTileP], p12 = t[-3];
-      const int b = (p0 > hi) | ((p4 > hi) << 1) | ((p8 > hi) << 2) | ((p12 > hi) << 3);
-      const int d = (p0 < lo) | ((p4 < lo) << 1) | ((p8 < lo) << 2) | ((p12 < lo) << 3);
-      const int bb = b & ((b >> 1) | (b << 3)), dd = d & ((d >> 1) | (d << 3));
-      pass = ((bb | dd) & 15) != 0;
+  {
+    const int iwd = max(iw, 1);
+    int y = (int)(((float)lane + 0.5f) / (float)iwd), x = lane - y * iwd;
+    const int sdy = 64 / iwd, sdx = 64 - sdy * iwd;
+    for (int base = 0; base < ni; base += 64) {
+      bool pass = false;
+      const int pos = (3 + y) * TP + 3 + x;
+      if (base + lane < ni) {
+        const uint8_t *t = &tile[pos];
+        const int v = t[0];
+        const int p0 = t[3 * TP], p4 = t[3], p8 = t[-3 * TP], p12 = t[-3];
+        const int mb = max(max(min(p0, p4), min(p4, p8)), max(min(p8, p12), min(p12, p0)));
+        const int md = min(min(max(p0, p4), max(p4, p8)), min(max(p8, p12), max(p12, p0)));
+        pass = (mb > v + P.min_th) | (md < v - P.min_th);
+      }
+      const unsigned long long mask = __ballot(pass);
+      if (pass) plist[np + __builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0u))] =
+          (unsigned short)pos;
+      np += __popcll(mask);
+      x += sdx, y += sdy;
+      if (x >= iwd) x -= iwd, y++;
     }
-    const unsigned long long mask = __ballot(pass);
-    int *wc = wcnt[it & 1];
-    if (lane == 0) wc[wave] = __popcll(mask);
-    __syncthreads();
-    int off = np + __popcll(mask & ((1ull << lane) - 1ull));
-    int tot = 0;
-#pragma unroll
-    for (int w2 = 0; w2 < 4; w2++) {
-      if (w2 < wave) off += wc[w2];
-      tot += wc[w2];
-    }
-    if (pass) plist[off] = (unsigned short)pos;
-    np += tot;
   }
-  __syncthreads();
+  wave_sync();
   // phase 2: full arc score only for the survivors
-  for (int i = tid; i < np; i += 256) {
+  for (int i = lane; i < np; i += 64) {
     const int pos = plist[i];
-    score[pos] = (uint8_t)fast_arc_score(&tile[pos], P.min_th);
+    score[pos] = (uint8_t)fast_arc_score<TP>(&tile[pos], P.min_th);
   }
-  __syncthreads();
+  wave_sync();
   // phase 3: 3x3 non-maximum suppression at the cell's threshold over the (raster-ordered) survivors;
   // kept pixels are written in the same order.  A cell with no key-point at iniThFAST is redone at
   // minThFAST (:820-824).
   uint32_t *slot = cell_slots + (long long)f * slots_frame_stride + L.slotBase + (long long)ci * L.capCell;
   int running = 0;
-  int it2 = 0;
   for (int pass = 0; pass < 2; pass++) {
     const int th = pass == 0 ? P.ini_th : P.min_th;
     running = 0;
-    for (int base = 0; base < np; base += 256, it2++) {
-      const int i = base + tid;
+    for (int base = 0; base < np; base += 64) {
+      const int i = base + lane;
       bool keep = false;
       int pos = 0, sc0 = 0;
       if (i < np) {
@@ -355,33 +356,24 @@ __global__ __launch_bounds__(256) void k_fast_cells(OrbDev P, FrameSrc src, uint
         if (sc0 >= th) {
           int nb = 0;
 #define NBR(o) nb = max(nb, (int)c[o] >= th ? (int)c[o] : 0)
-          NBR(-kTileP - 1); NBR(-kTileP); NBR(-kTileP + 1);
+          NBR(-TP - 1); NBR(-TP); NBR(-TP + 1);
           NBR(-1); NBR(1);
-          NBR(kTileP - 1); NBR(kTileP); NBR(kTileP + 1);
+          NBR(TP - 1); NBR(TP); NBR(TP + 1);
 #undef NBR
           keep = sc0 > nb;
         }
       }
       const unsigned long long mask = __ballot(keep);
-      int *wc = wcnt[2 + (it2 & 1)];
-      if (lane == 0) wc[wave] = __popcll(mask);
-      __syncthreads();
-      int off = running + __popcll(mask & ((1ull << lane) - 1ull));
-      int tot = 0;
-#pragma unroll
-      for (int w2 = 0; w2 < 4; w2++) {
-        if (w2 < wave) off += wc[w2];
-        tot += wc[w2];
-      }
+      const int off = running + __builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0u));
       if (keep && off < L.capCell) {
-        const int y = pos / kTileP, x = pos - y * kTileP;
+        const int y = pos / TP, x = pos - y * TP;
         slot[off] = (uint32_t)(x + ci_j * L.wCell) | ((uint32_t)(y + ci_i * L.hCell) << 12) | ((uint32_t)sc0 << 24);
       }
-      running += tot;
+      running += __popcll(mask);
     }
     if (running > 0) break;  // :820 `if(vKeysCell.empty())` retry with minThFAST
   }
-  if (tid == 0) *out_count = min(running, L.capCell);
+  if (lane == 0) *out_count = min(running, L.capCell);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -1029,6 +1021,8 @@ struct vo_orb {
   OrbDev dev;
   long long pyr_frame = 0, blur_frame = 0, slots_frame = 0;
   int cells_frame = 0, keys_frame = 0, sel_frame = 0, tiles_frame = 0, max_kp = 0;
+  int fast_tp = 48, fast_rows = 0, fast_interior = 0;  // k_fast_wave: LDS pitch, tile rows, list capacity
+  size_t fast_lds = 0;
   int strips_frame = 0, border_rows_frame = 0;
   std::vector<int> tab_off;  // per level: offsets of xofs,xab,yofs,yab in tables
   vo::DevBuf tables, pyr, blur, slots, cellcnt, keydata, keylabel, candcnt, sel, nk, off, err;
@@ -1120,7 +1114,7 @@ int configure(vo_orb *h, int w, int h_img, int n_frames) {
       } else {
         L.wCell = (int)ceilf(width / L.nCols);
         L.hCell = (int)ceilf(height / L.nRows);
-        if (L.wCell + 6 > kTileP - 6 || L.hCell + 6 > kTileP - 6 || ((L.wCell + 6 + 3 + 3) / 4) * (L.hCell + 6) > 1280) {
+        if (L.wCell + 9 > kTileP || L.hCell + 6 > kTileP - 6) {
           vo::set_error("FAST cell %dx%d exceeds the LDS tile", L.wCell, L.hCell);
           return VO_ERR_INVALID;
         }
@@ -1181,6 +1175,24 @@ int configure(vo_orb *h, int w, int h_img, int n_frames) {
     h->blur_frame = align_up((int)blur, 256);
     h->slots_frame = slots;
     h->cells_frame = cells;
+    {
+      int mw = 1, mh = 1;
+      for (int l = 0; l < h->nlevels; l++)
+        if (D.lv[l].nCols > 0) mw = std::max(mw, D.lv[l].wCell), mh = std::max(mh, D.lv[l].hCell);
+      h->fast_tp = mw + 9 <= 48 ? 48 : kTileP;
+      h->fast_rows = mh + 6;
+      h->fast_interior = mw * mh;
+      h->fast_lds = 4 * (size_t)(fast_align16(h->fast_tp * h->fast_rows + 16) + fast_align16(h->fast_tp * h->fast_rows) +
+                                 fast_align16(2 * h->fast_interior));
+      if (h->fast_lds > 64 * 1024) {
+        if (h->fast_tp == 48)
+          VO_HIP_CHECK(hipFuncSetAttribute((const void *)k_fast_wave<48>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                           (int)h->fast_lds));
+        else
+          VO_HIP_CHECK(hipFuncSetAttribute((const void *)k_fast_wave<kTileP>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                           (int)h->fast_lds));
+      }
+    }
     h->keys_frame = align_up(keys, 64);
     h->sel_frame = sel;
     h->tiles_frame = tiles;
@@ -1269,9 +1281,16 @@ int run_pipeline(vo_orb *h, const uint8_t *dev_images, int n_frames, int w, int 
     }
   }
   VO_STAGE_MARK(1);
-  if (h->cells_frame > 0)
-    hipLaunchKernelGGL(k_fast_cells, dim3(h->cells_frame, n_frames), dim3(256), 0, st, D, S,
-                       h->slots.as<uint32_t>(), h->slots_frame, h->cellcnt.as<int>(), h->cells_frame, lv0_unaligned);
+  if (h->cells_frame > 0) {
+    const dim3 grid((h->cells_frame + 3) / 4, n_frames);
+    if (h->fast_tp == 48)
+      hipLaunchKernelGGL(k_fast_wave<48>, grid, dim3(256), h->fast_lds, st, D, S, h->slots.as<uint32_t>(), h->slots_frame,
+                         h->cellcnt.as<int>(), h->cells_frame, lv0_unaligned, h->fast_rows, h->fast_interior);
+    else
+      hipLaunchKernelGGL(k_fast_wave<kTileP>, grid, dim3(256), h->fast_lds, st, D, S, h->slots.as<uint32_t>(),
+                         h->slots_frame, h->cellcnt.as<int>(), h->cells_frame, lv0_unaligned, h->fast_rows,
+                         h->fast_interior);
+  }
   VO_STAGE_MARK(2);
   hipLaunchKernelGGL(k_octree, dim3(D.nlevels, n_frames), dim3(256), 0, st, D, h->slots.as<uint32_t>(),
                      h->slots_frame, h->cellcnt.as<int>(), h->cells_frame, h->keydata.as<uint32_t>(),
