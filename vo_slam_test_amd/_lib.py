@@ -3,6 +3,7 @@ without the HIP library / a gfx950 device raises."""
 from __future__ import annotations
 
 import ctypes as C
+import os
 import pathlib
 
 import numpy as np
@@ -56,8 +57,9 @@ def lib():
     global _lib
     if _lib is not None:
         return _lib
-    if not SO.exists():
-        raise VoError(f"{SO} is missing: run `python -m vo_slam_test_amd.build` (hipcc, gfx950). "
+    so = pathlib.Path(os.environ.get("VO_HIP_LIB", SO))  # alternative install location / developer builds
+    if not so.exists():
+        raise VoError(f"{so} is missing: run `python -m vo_slam_test_amd.build` (hipcc, gfx950). "
                       "There is no CPU fallback.")
     # PyTorch-ROCm bundles its own libamdhip64.so.7 / libhsa-runtime64; two HIP runtimes in one
     # process cannot both open the GPU.  Importing torch first makes the loader resolve our
@@ -67,7 +69,7 @@ def lib():
         import torch  # noqa: F401
     except Exception:  # pragma: no cover - torch is plumbing only
         pass
-    L = C.CDLL(str(SO))
+    L = C.CDLL(str(so))
     L.vo_last_error.restype = C.c_char_p
     L.vo_version.restype = C.c_char_p
     L.vo_orb_scale_factor.restype = C.c_float

@@ -105,76 +105,155 @@ __global__ __launch_bounds__(256) void k_resize(const uint8_t *src, long long s_
   dst[(long long)blockIdx.z * d_frame_stride + (long long)dy * d_pitch + dx] = (uint8_t)v;
 }
 
-// Vectorised form used when source rows are 4-byte aligned: one thread makes 4 adjacent output
-// pixels of one row.  The row index (hence the vertical weights and the two source rows) is uniform
-// per wavefront; the 4 outputs draw on at most 7 consecutive source columns, fetched as three
-// aligned dwords per source row; the result leaves as one dword.
-__device__ __forceinline__ int byte_at(unsigned w0, unsigned w1, unsigned w2, int i) {  // i in [0,12)
-  const unsigned w = i < 4 ? w0 : (i < 8 ? w1 : w2);
-  return (w >> (8 * (i & 3))) & 0xff;
+// Tiled form used when source rows are 4-byte aligned.  A 256-thread workgroup walks a strip of
+// 256 x 16 output tiles: the source rectangle of a tile (about 309 x 21 bytes at scale 1.2) travels
+// HBM -> registers (coalesced dwords, all in flight) while the previous tile is consumed from LDS,
+// then registers -> LDS; every thread makes 4 adjacent pixels of 4 rows from LDS.  The kernel is
+// instruction-bound, so it is written branch-free: loads use clamped rows instead of predicates,
+// tile copies run under a uniform trip count, outputs leave as whole dwords (row padding absorbs
+// the tail).  The 4 outputs draw on at most 8 consecutive source bytes starting at column sx[0]
+// (scale < 2): two v_alignbyte_b32 build that window from three aligned dwords, one v_perm_b32 per
+// output spreads its two taps into 16-bit lanes (selector precomputed per column, shared by all
+// rows) and v_dot2_i32_i16 against the packed coefficient pair (exactly the table word:
+// a0 | a1 << 16) gives tap0*a0 + tap1*a1 in one instruction.
+typedef short short2_t __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ int dot2_i16(unsigned taps, unsigned coef) {
+  return __builtin_amdgcn_sdot2(__builtin_bit_cast(short2_t, taps), __builtin_bit_cast(short2_t, coef), 0, false);
 }
 
+#ifndef VO_RZ_ABLATE
+#define VO_RZ_ABLATE 0  // developer ablation switch (tools/rz_ablate.py); 0 in the product build
+#endif
+constexpr int kRzW = 256, kRzH = 16;  // output tile of k_resize4
+constexpr int kRzTiles = 4;           // vertically consecutive tiles per workgroup (software pipeline)
+constexpr int kRzNQ = 10;             // source rectangle <= 2560 dwords (scale 1.2: 78 x 22); else the generic kernel
+
+template <int NQ>  // dwords of a source rectangle per thread (rectangle <= NQ x 256 dwords)
 __global__ __launch_bounds__(256) void k_resize4(const uint8_t *src, long long s_frame_stride, int s_pitch,
                                                  int sw, int sh, uint8_t *dst, long long d_frame_stride,
                                                  int d_pitch, int dw, int dh, const int *xofs,
                                                  const int *xab, const int *yofs, const int *yab) {
-  constexpr int R = 4;  // output rows per thread: column tables are loaded once, 24 image loads in flight
-  const int gx = blockIdx.x * 64 + threadIdx.x;  // group of 4 output columns
-  const int dy0 = (blockIdx.y * 4 + threadIdx.y) * R;
-  const int dx = 4 * gx;
-  if (dx >= dw || dy0 >= dh) return;
+  extern __shared__ __attribute__((aligned(16))) uint8_t rz_tile[];
+  constexpr int R = 4;
+  const int tid = threadIdx.x, gx = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int dx0 = blockIdx.x * kRzW;
+  const int dx = min(dx0 + 4 * gx, ((dw - 1) & ~3));  // lanes past the row repeat its last group
   const uint8_t *S = src + (long long)blockIdx.z * s_frame_stride;
-  int sx[4], a0[4], a1[4];
+  uint8_t *Dst = dst + (long long)blockIdx.z * d_frame_stride;
+  // column tables of this thread: the same for every tile of the strip
+  int sx[4];
+  unsigned ab[4];
 #pragma unroll
   for (int q = 0; q < 4; q++) {
     const int d = min(dx + q, dw - 1);
     sx[q] = xofs[d];
-    const int ab = xab[d];
-    a0[q] = (short)(ab & 0xffff), a1[q] = ab >> 16;
+    ab[q] = (unsigned)xab[d];
   }
-  const int base = sx[0] & ~3;  // aligned start; columns needed: sx[0] .. sx[3]+1 <= base + 10
-  const int last = ((sw - 1) & ~3);
-  const int o1 = min(base + 4, last), o2 = min(base + 8, last);
-  // o1/o2 are only clamped when base+4 / base+8 lie beyond the last aligned dword of the row, and
-  // then every column this thread needs (<= sw-1) sits in an earlier dword, so indices stay valid
-  int i0[4], i1[4];
+  const int c0 = xofs[dx0] & ~3, c1 = min(xofs[min(dx0 + kRzW, dw) - 1] + 1, sw - 1);
+  const int ndw = ((c1 - c0) >> 2) + 1;  // dwords per source row of the strip
+  const int lds_pitch = 4 * ndw + 4;     // one pad dword skews the LDS banks of consecutive rows
+  const int ytiles = (dh + kRzH - 1) / kRzH;
+  const int ty0 = blockIdx.y * kRzTiles, ty1 = min(ty0 + kRzTiles, ytiles);
+  // element e = tid + 256 q of a rectangle sits at (row yq[q], dword xq4[q] / 4); independent of the tile
+  int lpos[NQ], xq4[NQ], yq[NQ];
+  {
+    int y = (int)(((float)tid + 0.5f) / (float)ndw), x = tid - y * ndw;
+    const int sdy = 256 / ndw, sdx = 256 - sdy * ndw;
 #pragma unroll
-  for (int q = 0; q < 4; q++) i0[q] = sx[q] - base, i1[q] = min(sx[q] + 1, sw - 1) - base;
-  unsigned p[R][3], qv[R][3];
-  int b0[R], b1[R];
-#pragma unroll
-  for (int r = 0; r < R; r++) {
-    const int dy = min(dy0 + r, dh - 1);
-    const int sy = yofs[dy];
-    const int sy0 = min(max(sy, 0), sh - 1), sy1 = min(max(sy + 1, 0), sh - 1);
-    const int bb = yab[dy];
-    b0[r] = (short)(bb & 0xffff), b1[r] = bb >> 16;
-    const uint8_t *R0 = S + (long long)sy0 * s_pitch, *R1 = S + (long long)sy1 * s_pitch;
-    p[r][0] = *reinterpret_cast<const unsigned *>(R0 + base);
-    p[r][1] = *reinterpret_cast<const unsigned *>(R0 + o1);
-    p[r][2] = *reinterpret_cast<const unsigned *>(R0 + o2);
-    qv[r][0] = *reinterpret_cast<const unsigned *>(R1 + base);
-    qv[r][1] = *reinterpret_cast<const unsigned *>(R1 + o1);
-    qv[r][2] = *reinterpret_cast<const unsigned *>(R1 + o2);
+    for (int q = 0; q < NQ; q++) {
+      yq[q] = y;
+      xq4[q] = 4 * x;
+      lpos[q] = __mul24(y, lds_pitch) + 4 * x;
+      x += sdx, y += sdy;
+      if (x >= ndw) x -= ndw, y++;
+    }
   }
+  const int base = sx[0] & ~3;  // three aligned dwords from here hold columns sx[0] .. sx[0] + 7
+  const int lastT = c0 + 4 * (ndw - 1);
+  // o1/o2 are only clamped when base+4 / base+8 lie beyond the strip's last dword, and then every
+  // column this thread needs (<= c1) sits in an earlier dword, so the bytes it selects stay valid
+  const int o0 = base - c0, o1 = min(base + 4, lastT) - c0, o2 = min(base + 8, lastT) - c0;
+  const unsigned woff = (unsigned)(sx[0] & 3);  // byte offset of the 8-byte window in {w2,w1,w0}
+  unsigned sel[4];
 #pragma unroll
-  for (int r = 0; r < R; r++) {
-    if (dy0 + r >= dh) break;
-    unsigned outw = 0;
+  for (int q = 0; q < 4; q++) {
+    const int i0 = sx[q] - sx[0], i1 = min(sx[q] + 1, sw - 1) - sx[0];  // 0 <= i0 <= i1 <= 7 for scale < 2
+    sel[q] = (unsigned)i0 | 0x0c00u | ((unsigned)i1 << 16) | 0x0c000000u;  // 0x0c: constant 0
+  }
+  // software pipeline over the strip's tiles
+  unsigned v[NQ];
+  int r0 = 0, nq = 0, syr[R], bbr[R];
+  auto fetch = [&](int ty) {
+    const int dy0 = ty * kRzH;
+    r0 = min(max(yofs[dy0], 0), sh - 1);
+    const int r1 = min(max(yofs[min(dy0 + kRzH, dh) - 1] + 1, 0), sh - 1);
+    nq = (ndw * (r1 - r0 + 1) + 255) >> 8;
+    const uint8_t *g0 = S + (long long)r0 * s_pitch + c0;
+    const int ymax = sh - 1 - r0;
 #pragma unroll
-    for (int q = 0; q < 4; q++) {
-      const int r0 = byte_at(p[r][0], p[r][1], p[r][2], i0[q]) * a0[q] + byte_at(p[r][0], p[r][1], p[r][2], i1[q]) * a1[q];
-      const int r1 = byte_at(qv[r][0], qv[r][1], qv[r][2], i0[q]) * a0[q] + byte_at(qv[r][0], qv[r][1], qv[r][2], i1[q]) * a1[q];
-      int v = (((b0[r] * (r0 >> 4)) >> 16) + ((b1[r] * (r1 >> 4)) >> 16) + 2) >> 2;
-      v = min(max(v, 0), 255);
-      outw |= (unsigned)v << (8 * q);
+    for (int q = 0; q < NQ; q++)
+      if (q < nq) {  // uniform
+#if VO_RZ_ABLATE == 2
+        v[q] = (unsigned)(xq4[q] + r0);
+        (void)g0;
+#else
+        v[q] = *reinterpret_cast<const unsigned *>(g0 + (__mul24(min(yq[q], ymax), s_pitch) + xq4[q]));
+#endif
+      }
+#pragma unroll
+    for (int r = 0; r < R; r++) {
+      const int dy = min(dy0 + wave * R + r, dh - 1);  // uniform per wave: scalar loads
+      syr[r] = yofs[dy];
+      bbr[r] = yab[dy];
     }
-    uint8_t *o = dst + (long long)blockIdx.z * d_frame_stride + (long long)(dy0 + r) * d_pitch + dx;
-    if (dx + 3 < dw) {
-      *reinterpret_cast<unsigned *>(o) = outw;
-    } else {
-      for (int q = 0; q < 4 && dx + q < dw; q++) o[q] = (uint8_t)(outw >> (8 * q));
+  };
+  fetch(ty0);
+  for (int ty = ty0; ty < ty1; ty++) {
+    const int rr0 = r0, nqc = nq;
+    int sy_[R], bb_[R];
+#pragma unroll
+    for (int r = 0; r < R; r++) sy_[r] = syr[r], bb_[r] = bbr[r];
+#pragma unroll
+    for (int q = 0; q < NQ; q++)
+      if (q < nqc) *reinterpret_cast<unsigned *>(rz_tile + lpos[q]) = v[q];
+    __syncthreads();
+    if (ty + 1 < ty1) fetch(ty + 1);
+    const int dyw = ty * kRzH + wave * R;
+    uint8_t *orow = Dst + (long long)dyw * d_pitch + dx;
+#pragma unroll
+    for (int r = 0; r < R; r++) {
+      if (dyw + r >= dh) break;  // uniform per wave
+      const int sy0 = min(max(sy_[r], 0), sh - 1) - rr0, sy1 = min(max(sy_[r] + 1, 0), sh - 1) - rr0;
+      const int b0 = (short)(bb_[r] & 0xffff), b1 = bb_[r] >> 16;
+      const uint8_t *R0 = rz_tile + __mul24(sy0, lds_pitch), *R1 = rz_tile + __mul24(sy1, lds_pitch);
+      const unsigned p0 = *reinterpret_cast<const unsigned *>(R0 + o0), p1 = *reinterpret_cast<const unsigned *>(R0 + o1),
+                     p2 = *reinterpret_cast<const unsigned *>(R0 + o2);
+      const unsigned q0 = *reinterpret_cast<const unsigned *>(R1 + o0), q1 = *reinterpret_cast<const unsigned *>(R1 + o1),
+                     q2 = *reinterpret_cast<const unsigned *>(R1 + o2);
+      unsigned outw = 0;
+#if VO_RZ_ABLATE == 1
+      outw = p0 ^ p1 ^ p2 ^ q0 ^ q1 ^ q2 ^ (unsigned)(b0 + b1);
+#else
+      // the 8 bytes from column sx[0] on, of both source rows
+      const unsigned pl = __builtin_amdgcn_alignbyte(p1, p0, woff), ph = __builtin_amdgcn_alignbyte(p2, p1, woff);
+      const unsigned ql = __builtin_amdgcn_alignbyte(q1, q0, woff), qh = __builtin_amdgcn_alignbyte(q2, q1, woff);
+#pragma unroll
+      for (int q = 0; q < 4; q++) {
+        const int h0 = dot2_i16(__builtin_amdgcn_perm(ph, pl, sel[q]), ab[q]);
+        const int h1 = dot2_i16(__builtin_amdgcn_perm(qh, ql, sel[q]), ab[q]);
+        // 24-bit multiplies are exact here: |b| <= 2048, |h >> 4| <= 255 * 2048 / 16
+        int val = ((__mul24(b0, h0 >> 4) >> 16) + (__mul24(b1, h1 >> 4) >> 16) + 2) >> 2;
+        val = min(max(val, 0), 255);
+        outw |= (unsigned)val << (8 * q);
+      }
+#endif
+#if VO_RZ_ABLATE == 3
+      if (outw == 0x12345678u)
+#endif
+      *reinterpret_cast<unsigned *>(orow + (long long)r * d_pitch) = outw;  // the tail lands in the row padding
     }
+    __syncthreads();  // the tile is overwritten by the next iteration
   }
 }
 
@@ -408,16 +487,17 @@ __device__ __forceinline__ int block_excl_scan(int v, int *wsum /*LDS[5]*/, int 
   return base + x - v;
 }
 
+template <int CAP>  // node-list capacity: 256 when every level's quota fits (16 KB of LDS), else 1024
 struct OctLds {
-  unsigned short x0[2][kMaxList], y0[2][kMaxList], x1[2][kMaxList], y1[2][kMaxList];
-  unsigned short cnt[2][kMaxList], seq[2][kMaxList];
-  unsigned short prank[kMaxList];   // processing rank of an expandable node, 0xffff otherwise
-  unsigned short order[kMaxList];   // rank -> list position
-  unsigned short newpos_old[kMaxList];
-  unsigned short newpos_child[kMaxList * 4];
-  int ccount[kMaxList * 4];
-  int cprefix[kMaxList];            // inclusive prefix over ranks of nonempty-children counts
-  unsigned int best[kMaxList];
+  unsigned short x0[2][CAP], y0[2][CAP], x1[2][CAP], y1[2][CAP];
+  unsigned short cnt[2][CAP], seq[2][CAP];
+  unsigned short prank[CAP];   // processing rank of an expandable node, 0xffff otherwise
+  unsigned short order[CAP];   // rank -> list position
+  unsigned short newpos_old[CAP];
+  unsigned short newpos_child[CAP * 4];
+  int ccount[CAP * 4];
+  int cprefix[CAP];            // inclusive prefix over ranks of nonempty-children counts
+  unsigned int best[CAP];
   int wsum[8];
   int s_m, s_cutoff, s_newsize, s_nexp, s_total;
 };
@@ -428,13 +508,14 @@ __device__ __forceinline__ int quadrant_of(int kx, int ky, int x0, int y0, int x
   return (kx < midx ? 0 : 1) + (ky < midy ? 0 : 2);  // n1,n2,n3,n4            :522-534
 }
 
+template <int CAP>
 __global__ __launch_bounds__(256) void k_octree(OrbDev P, const uint32_t *cell_slots,
                                                 long long slots_frame_stride, const int *cell_count,
                                                 int cells_per_frame, uint32_t *key_data,
                                                 unsigned short *key_label, int keys_per_frame,
                                                 int *cand_count, uint32_t *sel, int sel_per_frame,
                                                 int *nk, int *err_flag) {
-  __shared__ OctLds S;
+  __shared__ OctLds<CAP> S;
   const int tid = threadIdx.x;
   const int l = blockIdx.x, f = blockIdx.y;
   const LevelGeom &L = P.lv[l];
@@ -467,7 +548,7 @@ __global__ __launch_bounds__(256) void k_octree(OrbDev P, const uint32_t *cell_s
   int cur = 0;
   const int nIni = L.nIni;
   const int H = L.maxBY - kBorder;
-  for (int i = tid; i < kMaxList * 4; i += 256) S.ccount[i] = 0;
+  for (int i = tid; i < CAP * 4; i += 256) S.ccount[i] = 0;
   __syncthreads();
   for (int k = tid; k < n; k += 256) {
     const int kx = kd[k] & 0xfff;
@@ -482,7 +563,7 @@ __global__ __launch_bounds__(256) void k_octree(OrbDev P, const uint32_t *cell_s
     // compact non-empty roots (nIni is tiny: serial on thread 0)
     if (tid == 0) {
       int s = 0;
-      for (int i = 0; i < nIni && s < kMaxList; i++) {
+      for (int i = 0; i < nIni && s < CAP; i++) {
         const int c = S.ccount[i];
         S.newpos_old[i] = 0xffff;
         if (c == 0) continue;
@@ -523,7 +604,7 @@ __global__ __launch_bounds__(256) void k_octree(OrbDev P, const uint32_t *cell_s
       const int pos = tid * 4 + e;
       myrank[e] = ex;
       ex += myflag[e];
-      if (pos < kMaxList) S.prank[pos] = myflag[e] ? (unsigned short)myrank[e] : 0xffff;
+      if (pos < CAP) S.prank[pos] = myflag[e] ? (unsigned short)myrank[e] : 0xffff;
       if (myflag[e]) S.order[myrank[e]] = (unsigned short)pos;
     }
     __syncthreads();
@@ -638,13 +719,13 @@ __global__ __launch_bounds__(256) void k_octree(OrbDev P, const uint32_t *cell_s
       for (int e = 0; e < 4; e++) {
         const int pos = tid * 4 + e;
         if (!kf[e]) {
-          if (pos < kMaxList) S.newpos_old[pos] = 0xffff;
+          if (pos < CAP) S.newpos_old[pos] = 0xffff;
           continue;
         }
         const int np = totalChildren + kex;
         kex++;
         S.newpos_old[pos] = (unsigned short)np;
-        if (np < kMaxList) {
+        if (np < CAP) {
           S.x0[nxt][np] = S.x0[cur][pos];
           S.x1[nxt][np] = S.x1[cur][pos];
           S.y0[nxt][np] = S.y0[cur][pos];
@@ -672,7 +753,7 @@ __global__ __launch_bounds__(256) void k_octree(OrbDev P, const uint32_t *cell_s
       const int nToExpand = S.s_nexp;
       cur = nxt;
       size = newsize;
-      if (size > kMaxList - 4) {
+      if (size > CAP - 4) {
         if (tid == 0) atomicExch(err_flag, 2);
         finish = true;
       }
@@ -685,11 +766,11 @@ __global__ __launch_bounds__(256) void k_octree(OrbDev P, const uint32_t *cell_s
   }
 
   // ---- best response per node, first key wins ties (:748-766)
-  for (int i = tid; i < kMaxList; i += 256) S.best[i] = 0;
+  for (int i = tid; i < CAP; i += 256) S.best[i] = 0;
   __syncthreads();
   for (int k = tid; k < n; k += 256) {
     const int pos = kl[k];
-    if (pos >= kMaxList) continue;
+    if (pos >= CAP) continue;
     const unsigned int v = ((kd[k] >> 24) << 16) | (unsigned int)(65535 - k);
     atomicMax(&S.best[pos], v);
   }
@@ -1023,6 +1104,9 @@ struct vo_orb {
   int cells_frame = 0, keys_frame = 0, sel_frame = 0, tiles_frame = 0, max_kp = 0;
   int fast_tp = 48, fast_rows = 0, fast_interior = 0;  // k_fast_wave: LDS pitch, tile rows, list capacity
   size_t fast_lds = 0;
+  bool oct_small = false;
+  size_t rz_lds[kMaxLevels] = {0};
+  int rz_dwords[kMaxLevels] = {0};  // every level's node list fits k_octree<256>
   int strips_frame = 0, border_rows_frame = 0;
   std::vector<int> tab_off;  // per level: offsets of xofs,xab,yofs,yab in tables
   vo::DevBuf tables, pyr, blur, slots, cellcnt, keydata, keylabel, candcnt, sel, nk, off, err;
@@ -1168,6 +1252,19 @@ int configure(vo_orb *h, int w, int h_img, int n_frames) {
         tables.insert(tables.end(), yo.begin(), yo.end());
         h->tab_off[l * 4 + 3] = (int)tables.size();
         tables.insert(tables.end(), ya.begin(), ya.end());
+        int mdw = 1, mrows = 1;  // largest source rectangle of a 256 x 16 output tile
+        for (int x0 = 0; x0 < L.w; x0 += kRzW) {
+          const int c0 = xo[x0] & ~3, c1 = std::min(xo[std::min(x0 + kRzW, L.w) - 1] + 1, pw - 1);
+          mdw = std::max(mdw, ((c1 - c0) >> 2) + 1);
+        }
+        for (int y0 = 0; y0 < L.h; y0 += kRzH) {
+          const int r0 = std::min(std::max(yo[y0], 0), ph - 1);
+          const int r1 = std::min(std::max(yo[std::min(y0 + kRzH, L.h) - 1] + 1, 0), ph - 1);
+          mrows = std::max(mrows, r1 - r0 + 1);
+        }
+        // the copy runs in whole 256-dword rounds at the strip's own pitch (4 ndw + 4): round up generously
+        h->rz_lds[l] = 4 * ((size_t)mdw * mrows + 256 + 2 * (size_t)(mdw + mrows) + 64) + 1024;
+        h->rz_dwords[l] = mdw * mrows;
       }
       pw = L.w, ph = L.h;
     }
@@ -1179,6 +1276,9 @@ int configure(vo_orb *h, int w, int h_img, int n_frames) {
       int mw = 1, mh = 1;
       for (int l = 0; l < h->nlevels; l++)
         if (D.lv[l].nCols > 0) mw = std::max(mw, D.lv[l].wCell), mh = std::max(mh, D.lv[l].hCell);
+      int mcap = 0;
+      for (int l = 0; l < h->nlevels; l++) mcap = std::max(mcap, std::max(D.lv[l].capSel, D.lv[l].nIni));
+      h->oct_small = mcap <= 256 - 4;
       h->fast_tp = mw + 9 <= 48 ? 48 : kTileP;
       h->fast_rows = mh + 6;
       h->fast_interior = mw * mh;
@@ -1267,10 +1367,11 @@ int run_pipeline(vo_orb *h, const uint8_t *dev_images, int n_frames, int w, int 
     // 4 outputs span <= 3*scale + 2 source columns; with the aligned start that fits 12 bytes for
     // scale factors below 2 and needs 4-byte aligned source rows with readable padding to the pitch
     const bool aligned = ((reinterpret_cast<uintptr_t>(sp) | (uintptr_t)spitch | (uintptr_t)sfs) & 3) == 0 &&
-                         (double)Pv.w / L.w < 1.99 && ((Pv.w + 3) & ~3) <= spitch;
+                         (double)Pv.w / L.w < 1.99 && ((Pv.w + 3) & ~3) <= spitch && h->rz_dwords[l] <= 256 * kRzNQ && L.pitch >= ((L.w + 3) & ~3);
     if (aligned) {
-      dim3 grid(((L.w + 3) / 4 + 63) / 64, (L.h + 15) / 16, n_frames), block(64, 4);
-      hipLaunchKernelGGL(k_resize4, grid, block, 0, st, sp, sfs, spitch, Pv.w, Pv.h, S.pyr + L.pyr_off,
+      const int ytiles = (L.h + kRzH - 1) / kRzH;
+      dim3 grid((L.w + kRzW - 1) / kRzW, (ytiles + kRzTiles - 1) / kRzTiles, n_frames);
+      hipLaunchKernelGGL(k_resize4<kRzNQ>, grid, dim3(256), h->rz_lds[l], st, sp, sfs, spitch, Pv.w, Pv.h, S.pyr + L.pyr_off,
                          (long long)h->pyr_frame, L.pitch, L.w, L.h, T + h->tab_off[l * 4 + 0],
                          T + h->tab_off[l * 4 + 1], T + h->tab_off[l * 4 + 2], T + h->tab_off[l * 4 + 3]);
     } else {
@@ -1292,10 +1393,16 @@ int run_pipeline(vo_orb *h, const uint8_t *dev_images, int n_frames, int w, int 
                          h->fast_interior);
   }
   VO_STAGE_MARK(2);
-  hipLaunchKernelGGL(k_octree, dim3(D.nlevels, n_frames), dim3(256), 0, st, D, h->slots.as<uint32_t>(),
-                     h->slots_frame, h->cellcnt.as<int>(), h->cells_frame, h->keydata.as<uint32_t>(),
-                     h->keylabel.as<unsigned short>(), h->keys_frame, h->candcnt.as<int>(),
-                     h->sel.as<uint32_t>(), h->sel_frame, h->nk.as<int>(), h->err.as<int>());
+  if (h->oct_small)
+    hipLaunchKernelGGL(k_octree<256>, dim3(D.nlevels, n_frames), dim3(256), 0, st, D, h->slots.as<uint32_t>(),
+                       h->slots_frame, h->cellcnt.as<int>(), h->cells_frame, h->keydata.as<uint32_t>(),
+                       h->keylabel.as<unsigned short>(), h->keys_frame, h->candcnt.as<int>(),
+                       h->sel.as<uint32_t>(), h->sel_frame, h->nk.as<int>(), h->err.as<int>());
+  else
+    hipLaunchKernelGGL(k_octree<kMaxList>, dim3(D.nlevels, n_frames), dim3(256), 0, st, D, h->slots.as<uint32_t>(),
+                       h->slots_frame, h->cellcnt.as<int>(), h->cells_frame, h->keydata.as<uint32_t>(),
+                       h->keylabel.as<unsigned short>(), h->keys_frame, h->candcnt.as<int>(),
+                       h->sel.as<uint32_t>(), h->sel_frame, h->nk.as<int>(), h->err.as<int>());
   VO_STAGE_MARK(3);
   hipLaunchKernelGGL(k_offsets, dim3((n_frames + 63) / 64), dim3(64), 0, st, D.nlevels, n_frames,
                      h->nk.as<int>(), h->off.as<int>(), capacity, dcounts);
