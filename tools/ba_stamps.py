@@ -32,9 +32,14 @@ def run():
     pr = synth.make_lba_problem(0)
     ba = _lib.BundleAdjuster(pr)
     ba.local_ba()
-    st = np.zeros(8, np.uint64)
+    st = np.zeros(32, np.uint64)
     L.vo_ba_debug_stamps(ba._h, st.ctypes.data_as(C.c_void_p))
-    d = np.diff(st.astype(np.int64)) / 100.0  # s_memrealtime ticks at 100 MHz -> us
+    d = np.diff(st[:8].astype(np.int64)) / 100.0  # s_memrealtime ticks at 100 MHz -> us
+    rel = lambda i: (int(st[i]) - int(st[16])) / 100.0
+    print("gemm block 0 (us from its entry): hinv table %.2f, MFMA loop done %.2f, end %.2f; solve kernel starts at %.2f"
+          % (rel(17), rel(18), rel(20), rel(0)))
+    print("  G prefetch +%.2f, pose prefetch +%.2f" % ((int(st[10]) - int(st[0])) / 100.0, (int(st[11]) - int(st[0])) / 100.0))
+    print(f"  prefetch drained at +{(int(st[8]) - int(st[0])) / 100.0:.2f} us, slab sums done at +{(int(st[9]) - int(st[0])) / 100.0:.2f} us")
     names = ["slab sums+scale", "assemble+gmax", "LDLt", "back-subst", "dots", "cand poses", "block_sum"]
     for nm, v in zip(names, d):
         print(f"{nm:18s} {v:8.2f} us")

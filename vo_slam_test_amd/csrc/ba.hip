@@ -605,18 +605,45 @@ typedef double double4_t __attribute__((ext_vector_type(4)));
 
 constexpr int kChunkPts = 512;  // points per K-slice (LDS table of their damped inverses)
 
+#ifdef VO_BA_STAMPS
+#define STAMP(i) do { if (threadIdx.x == 0) B.dbg[i] = __builtin_amdgcn_s_memrealtime(); } while (0)
+#define STAMP_DRAIN(i) do { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); STAMP(i); } while (0)
+#else
+#define STAMP(i)
+#define STAMP_DRAIN(i)
+#endif
+#ifdef VO_BA_STAMPS
+#define STAMP0(i) do { if (threadIdx.x == 0 && blockIdx.x == 0) B.dbg[i] = __builtin_amdgcn_s_memrealtime(); } while (0)
+#else
+#define STAMP0(i)
+#endif
+constexpr int kGemmLdsDoubles = 4 * 256 + kChunkPts * 6 + 4 * 27;  // part, hinvL, lds27
+
+__device__ __forceinline__ void ba_gemm_tile_role(const BaDev &B, const BaState &st, double *sm, int ntiles, int tdim);
+
+// Schur product tiles and camera blocks in one launch (independent roles).  Every block writes its
+// partial result to a slab; the consumer sits behind the kernel boundary (k_ba_solve when the problem
+// lives on one GPU, k_ba_reduce + all-reduce when it is sharded).  In-kernel hand-offs were measured
+// and lose: an sc1 store -> ticket -> sc1 load chain costs ~8 us on MI355X and a single block pulls
+// coherent loads at only ~12 GB/s, against ~5 us for a kernel boundary followed by cached loads.
 __global__ __launch_bounds__(256) void k_ba_gemm(BaDev B) {
-  __shared__ double part[4][256];
-  __shared__ double hinvL[kChunkPts * 6];
-  __shared__ double lds27[4 * 27];
+  extern __shared__ double sm[];  // part | hinvL | lds27
   const BaState st = *B.st;
   if (st.done) return;
+  STAMP0(16);
   const int tdim = B.Mpad / 16, ntiles = tdim * (tdim + 1) / 2;
   if ((int)blockIdx.x >= ntiles * B.ksplit) {  // camera-block role (independent of the tiles)
     const int q = blockIdx.x - ntiles * B.ksplit;
-    ba_cams_role(B, st, q / B.n_cchunks, q % B.n_cchunks, lds27);
-    return;
+    ba_cams_role(B, st, q / B.n_cchunks, q % B.n_cchunks, sm + 4 * 256 + kChunkPts * 6);
+  } else {
+    ba_gemm_tile_role(B, st, sm, ntiles, tdim);
   }
+  STAMP0(20);
+}
+
+__device__ __forceinline__ void ba_gemm_tile_role(const BaDev &B, const BaState &st, double *sm, int ntiles, int tdim) {
+  double(*part)[256] = reinterpret_cast<double(*)[256]>(sm);
+  double *hinvL = sm + 4 * 256;
   const int ks = blockIdx.x / ntiles;
   int tile = blockIdx.x - ks * ntiles, tm = 0;
   while (tile >= tdim - tm) {  // upper-triangular tile index -> (tm <= tn)
@@ -658,6 +685,7 @@ __global__ __launch_bounds__(256) void k_ba_gemm(BaDev B) {
     }
   }
   __syncthreads();
+  STAMP0(17);
   const int q = ((kb1 - kb0 + 15) / 16) * 4;  // rows per wave, multiple of 4
   const int k0 = kb0 + wave * q, k1 = min(kb1, k0 + q);
   double4_t acc = {0, 0, 0, 0};
@@ -669,6 +697,26 @@ __global__ __launch_bounds__(256) void k_ba_gemm(BaDev B) {
     return hv[a == 0 ? b : (a == 1 ? 2 + b : 5)];
   };
   int k = k0;
+  // The loop is latency-bound (one wave per SIMD): 12 MFMA steps per trip keep 48 independent loads
+  // in flight per lane; all loads of a trip are issued before the first multiply.
+  for (; k + 48 <= k1; k += 48) {
+    double w0[12], w1[12], w2[12], b[12];
+#pragma unroll
+    for (int u = 0; u < 12; u++) {
+      const int kr = k + 4 * u + kk;
+      const long long r3 = (long long)(3 * (kr / 3)) * B.Mpad;
+      w0[u] = Wa[r3], w1[u] = Wa[r3 + B.Mpad], w2[u] = Wa[r3 + 2 * B.Mpad];
+      b[u] = Wb[(long long)kr * B.Mpad];
+    }
+#pragma unroll
+    for (int u = 0; u < 12; u++) {
+      const int kr = k + 4 * u + kk;
+      const int j = kr / 3, c = kr - 3 * j;
+      const double *hv = &hinvL[6 * (j - j0)];
+      const double a = w0[u] * sym(hv, 0, c) + w1[u] * sym(hv, 1, c) + w2[u] * sym(hv, 2, c);
+      acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b[u], acc, 0, 0, 0);
+    }
+  }
   for (; k + 16 <= k1; k += 16) {  // 4 MFMA steps: 16 independent loads in flight per lane
     double a[4], b[4];
 #pragma unroll
@@ -696,25 +744,31 @@ __global__ __launch_bounds__(256) void k_ba_gemm(BaDev B) {
     }
     acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc, 0, 0, 0);
   }
+  STAMP0(18);
 #pragma unroll
   for (int r = 0; r < 4; r++) part[wave][(kk + 4 * r) * 16 + ii] = acc[r];
   __syncthreads();
   const int t = threadIdx.x;  // element (t>>4, t&15) of the tile, fixed summation order
   const double v = (part[0][t] + part[1][t]) + (part[2][t] + part[3][t]);
   const long long eoff = (long long)(tm * 16 + (t >> 4)) * B.Mpad + tn * 16 + (t & 15);
-  if (!B.fused) {
+  if (!B.fused) {  // sharded: k_ba_reduce sums the slabs into the payload that is all-reduced
     B.slab_gemm[(long long)ks * B.Mpad * B.Mpad + eoff] = v;
     return;
   }
+  // One GPU: the last K-slice block of a tile to arrive sums the tile's slabs (slab order:
+  // deterministic) into the payload.  This hand-off (~8 us: write-through stores, ticket, coherent
+  // loads) runs in parallel over the tiles and overlaps the longer camera-block role; the single
+  // solving block behind the kernel boundary then reads 12 KB instead of ksplit x 12 KB.
   st_sc1(&B.slab_gemm[(long long)ks * B.Mpad * B.Mpad + eoff], v);
   __shared__ int s_last;
   if (!arrive_and_check_last(&B.counters[1 + (tm * tdim + tn)], (unsigned)B.ksplit, &s_last)) return;
-  double sv[8];
+  const long long M2 = (long long)B.Mpad * B.Mpad;
+  double sv[32];
 #pragma unroll
-  for (int u = 0; u < 8; u++) sv[u] = u < B.ksplit ? ld_sc1(&B.slab_gemm[(long long)u * B.Mpad * B.Mpad + eoff]) : 0.0;
+  for (int u = 0; u < 32; u++) sv[u] = ld_sc1(&B.slab_gemm[min(u, B.ksplit - 1) * M2 + eoff]);  // all in flight
   double sum = 0;
 #pragma unroll
-  for (int u = 0; u < 8; u++) sum += sv[u];  // slab order: deterministic
+  for (int u = 0; u < 32; u++) sum += u < B.ksplit ? sv[u] : 0.0;
   B.payload[eoff] = sum;
 }
 
@@ -799,15 +853,9 @@ __device__ __forceinline__ bool ldl6_packed(double L[21], double rd[6]) {
   return ok;
 }
 
-#ifdef VO_BA_STAMPS
-#define STAMP(i) do { if (threadIdx.x == 0) B.dbg[i] = __builtin_amdgcn_s_memrealtime(); } while (0)
-#else
-#define STAMP(i)
-#endif
-__global__ __launch_bounds__(256) void k_ba_solve(BaDev B) {
-  extern __shared__ double sm[];
+__device__ __forceinline__ void ba_solve_body(const BaDev &B, const BaState &st0, double *sm) {
   BaState *S = B.st;
-  if (S->done) return;
+  if (st0.done) return;
   const int tid = threadIdx.x;
   STAMP(0);
   const int nb = B.nf, n = 6 * nb, ld = n + 1;
@@ -822,33 +870,46 @@ __global__ __launch_bounds__(256) void k_ba_solve(BaDev B) {
   const double *G = B.payload;
   // camera blocks / cost / gradient-max: all-reduced payload in the sharded mode, summed into LDS here otherwise
   double *HPw = B.fused ? red + 64 : B.payload + payload_hpp_off(B);
-  // issue this thread's loads of the Schur product early (they only depend on k_ba_gemm); they are
-  // consumed after the slab sums and the scale setup, hiding one memory round trip
-  constexpr int kPref = 8;
-  double gpre[kPref];
+  // Raw Schur product into A (lower triangle, rhs in row n): entry (c, r >= c) of the payload --
+  // all-reduced across GPUs (sharded) or summed over the K slices by k_ba_gemm's tile blocks (fused).
+  // Unconditional loads, eight in flight per lane: lanes without an entry read the all-zero slab.
+  // (A `cond ? load : 0` form is sunk into a branch by the compiler and followed by
+  // s_waitcnt vmcnt(0): every load of the round would be serialised.)
   {
-    const int tx = tid & 15, ty = tid >> 4;
-    int q = 0;
-    for (int c = ty; c < n && q < kPref; c += 16)
-      for (int r = c - (c & 15) + tx; r < n && q < kPref; r += 16) {
-        if (r < c) continue;
-        gpre[q++] = G[(long long)c * B.Mpad + r];
+    const double *zero_slab = B.slab_gemm + (long long)B.ksplit * B.Mpad * B.Mpad;  // never written after creation
+    const int ne = n * (n + 1);  // entry e = c * (n + 1) + r, r in [c, n]
+    for (int e0 = 0; e0 < ne; e0 += 256 * 8) {
+      double v[8];
+      int pos[8];
+#pragma unroll
+      for (int un = 0; un < 8; un++) {
+        const int e = e0 + un * 256 + tid;
+        const int c = e / (n + 1), r = e - c * (n + 1);
+        const bool valid = e < ne && r >= c;
+        pos[un] = valid ? r * ld + c : -1;
+        v[un] = *(valid ? G + (long long)c * B.Mpad + r : zero_slab);
       }
-    for (; q < kPref; q++) gpre[q] = 0;
+#pragma unroll
+      for (int un = 0; un < 8; un++)
+        if (pos[un] >= 0) A[pos[un]] = v[un];
+    }
   }
+  STAMP_DRAIN(10);
   // this thread's camera for the candidate-pose phase: pose and cache are read now, used after the solve
-  const int cur0 = S->cur;
-  const int first = S->first;
-  const double radius = S->radius;
+  const int cur0 = st0.cur;
+  const int first = st0.first;
+  const double radius = st0.radius;
   const int pc_cam = tid < B.n_cams ? tid : 0;
   double xpre[6];
 #pragma unroll
   for (int a = 0; a < 6; a++) xpre[a] = B.Xc[cur0][6 * pc_cam + a];
   const PoseCache pcpre = load_pc(B.PC[cur0], pc_cam);
   const int slotpre = B.cam_slot[pc_cam], cinpre = B.cam_in[pc_cam];
-  const int sc_idx = tid < n ? 6 * B.slot_cam[tid / 6] + tid % 6 : 0;
-  const double sc_pre = first ? 0.0 : B.scale_c[sc_idx];
+  STAMP_DRAIN(11);
+  const double sc_pre = (first || tid >= n) ? 0.0 : B.scale_c[tid];  // per reduced-system column
+  STAMP_DRAIN(8);  // debug builds only: the prefetch round trip
   if (B.fused) {  // no k_ba_reduce in this mode: sum the camera-block and cost slabs here
+    const double *zslab = B.slab_gemm + (long long)B.ksplit * B.Mpad * B.Mpad;
     for (int i = tid; i < B.nf * 27; i += 256) {
       const int slot = i / 27, t = i - slot * 27;
       const double *sp = B.slab_cam + (long long)slot * B.n_cchunks * 27 + t;
@@ -856,7 +917,7 @@ __global__ __launch_bounds__(256) void k_ba_solve(BaDev B) {
       for (int c0 = 0; c0 < B.n_cchunks; c0 += 16) {  // sixteen loads in flight, summed in chunk order
         double v[16];
 #pragma unroll
-        for (int q = 0; q < 16; q++) v[q] = c0 + q < B.n_cchunks ? sp[(c0 + q) * 27] : 0.0;
+        for (int q = 0; q < 16; q++) v[q] = *(c0 + q < B.n_cchunks ? sp + (c0 + q) * 27 : zslab);
 #pragma unroll
         for (int q = 0; q < 16; q++) a += v[q];
       }
@@ -879,6 +940,7 @@ __global__ __launch_bounds__(256) void k_ba_solve(BaDev B) {
     }
     __syncthreads();
   }
+  STAMP(9);
   const double *HP = HPw;
   if (tid == 0) s_fail = 0, s_stop = 0;
   double gm = 0;
@@ -890,9 +952,9 @@ __global__ __launch_bounds__(256) void k_ba_solve(BaDev B) {
     double s;
     if (first) {  // Jacobi scaling of the camera columns from the first linearisation
       s = 1.0 / (1.0 + sqrt(hd));
-      B.scale_c[6 * B.slot_cam[slot] + a] = s;
+      B.scale_c[i] = s;
     } else {
-      s = i == tid ? sc_pre : B.scale_c[6 * B.slot_cam[slot] + a];
+      s = i == tid ? sc_pre : B.scale_c[i];
     }
     sc[i] = s;
     Dd[i] = fmin(fmax(hd * s * s, 1e-6), 1e32) / radius;
@@ -902,15 +964,13 @@ __global__ __launch_bounds__(256) void k_ba_solve(BaDev B) {
   }
   __syncthreads();
   STAMP(1);
-  // S'' = diag(sc) (Hpp - Y W^T) diag(sc) + D, lower triangle; the GEMM delivers the upper tiles
+  // S'' = diag(sc) (Hpp - Y W^T) diag(sc) + D in place on the raw product; rhs'' = g'' - sc * (Y g_l)
   {
-    const int tx = tid & 15, ty = tid >> 4;  // lanes run along r: contiguous reads of G[c][r..]
-    int q = 0;
+    const int tx = tid & 15, ty = tid >> 4;
     for (int c = ty; c < n; c += 16)
       for (int r = c - (c & 15) + tx; r < n; r += 16) {
         if (r < c) continue;
-        double v = q < kPref ? -gpre[q] : -G[(long long)c * B.Mpad + r];
-        q++;
+        double v = -A[r * ld + c];
         if (r / 6 == c / 6) {
           const int slot = r / 6, a = c % 6, b = r % 6;  // a <= b
           int t = 0;
@@ -922,7 +982,7 @@ __global__ __launch_bounds__(256) void k_ba_solve(BaDev B) {
         A[r * ld + c] = v;
       }
   }
-  for (int i = tid; i < n; i += 256) A[n * ld + i] = gpp[i] - sc[i] * G[(long long)i * B.Mpad + n];
+  for (int i = tid; i < n; i += 256) A[n * ld + i] = gpp[i] - sc[i] * A[n * ld + i];
   gm = wave_max(gm);
   if ((tid & 63) == 0) red[tid >> 6] = gm;
   __syncthreads();
@@ -935,12 +995,12 @@ __global__ __launch_bounds__(256) void k_ba_solve(BaDev B) {
     S->x_cost = cost;
     if (first) S->initial_cost = cost;
     // FinalizeIterationAndCheckIfMinimizerCanContinue of the previous iteration
-    if (S->last_ok && m <= 1e-10) {
+    if (st0.last_ok && m <= 1e-10) {
       S->termination = 3;
       S->done = 1;
       s_stop = 1;
     } else {
-      S->iter += 1;
+      S->iter = st0.iter + 1;
     }
     S->first = 0;
   }
@@ -1085,6 +1145,12 @@ __global__ __launch_bounds__(256) void k_ba_solve(BaDev B) {
     S->solve_failed = failed;
   }
   STAMP(7);
+}
+
+__global__ __launch_bounds__(256) void k_ba_solve(BaDev B) {
+  extern __shared__ double sm[];
+  const BaState st = *B.st;
+  ba_solve_body(B, st, sm);
 }
 
 // TrustRegionMinimizer step evaluation + LevenbergMarquardtStrategy radius update (one thread)
@@ -1360,7 +1426,7 @@ struct vo_ba {
   vo::DevBuf b_ecam, b_ept, b_eobs, b_eis, b_eact, b_ptstart, b_local, b_camslot, b_slotcam, b_camstart,
       b_camedges, b_ptin, b_camin, b_xc0, b_xc1, b_xp0, b_xp1, b_pc0, b_pc1, b_sc, b_sp, b_hinv, b_gl2, b_dl, b_wt, b_wt1, b_hll0, b_hll1, b_spt1,
       b_sgemm, b_scam, b_spt, b_payload, b_zc, b_sbs, b_payload2, b_state, b_out, b_dbg, b_cnt;
-  size_t solve_lds = 0;
+  size_t solve_lds = 0, gemm_lds = 0;
   int lm_max_it = 0;
   double *ext_payload = nullptr, *ext_payload2 = nullptr;
   int archive_slot = -1;
@@ -1412,12 +1478,13 @@ int build_device(vo_ba *h) {
   D.n_pblocks = std::max(1, (D.n_local + kPtsPerBlock - 1) / kPtsPerBlock);
   const int K = 3 * h->n_pts;
   const int tiles = (D.Mpad / 16) * (D.Mpad / 16 + 1) / 2;
-  int ks = std::max(1, std::min(8, 128 / tiles));  // <= 8 slabs: one load batch per reduction
+  // the MFMA loop is latency-bound per wave (~1.5 us per 48-row trip): many short K slices, <= 32 slabs
+  int ks = std::max(1, std::min(32, 256 / tiles));
   ks = std::min(ks, std::max(1, K / 128));
   D.kchunk = ((K + ks - 1) / ks + 47) / 48 * 48;  // multiple of 16 (MFMA slices) and of 3 (whole points)
   D.ksplit = std::max(1, (K + D.kchunk - 1) / D.kchunk);
-  if (D.kchunk / 3 > kChunkPts || D.ksplit > 8) {
-    vo::set_error("local BA with %d points exceeds this round's dense Schur path (%d points per K slice, 8 slices)",
+  if (D.kchunk / 3 > kChunkPts || D.ksplit > 32) {
+    vo::set_error("local BA with %d points exceeds this round's dense Schur path (%d points per K slice, 32 slices)",
                   h->n_pts, kChunkPts);
     return VO_ERR_CAPACITY;
   }
@@ -1455,7 +1522,8 @@ int build_device(vo_ba *h) {
   // operand matrices start out all-zero; only (point, camera) pairs that have an edge are ever written
   VO_HIP_CHECK(hipMemset(h->b_wt.p, 0, (size_t)std::max(1, K) * D.Mpad * 8));
   VO_HIP_CHECK(hipMemset(h->b_wt1.p, 0, (size_t)std::max(1, K) * D.Mpad * 8));
-  VO_CHECK(h->b_sgemm.reserve((size_t)D.ksplit * D.Mpad * D.Mpad * 8));
+  VO_CHECK(h->b_sgemm.reserve((size_t)(D.ksplit + 1) * D.Mpad * D.Mpad * 8));  // + one all-zero slab
+  VO_HIP_CHECK(hipMemset(h->b_sgemm.as<double>() + (size_t)D.ksplit * D.Mpad * D.Mpad, 0, (size_t)D.Mpad * D.Mpad * 8));
   VO_CHECK(h->b_scam.reserve((size_t)std::max(1, h->nf) * D.n_cchunks * 27 * 8));
   VO_CHECK(h->b_spt.reserve((size_t)D.n_pblocks * 2 * 8));
   VO_CHECK(h->b_spt1.reserve((size_t)D.n_pblocks * 2 * 8));
@@ -1498,6 +1566,10 @@ int build_device(vo_ba *h) {
   if (h->solve_lds > 64 * 1024)
     VO_HIP_CHECK(hipFuncSetAttribute((const void *)k_ba_solve, hipFuncAttributeMaxDynamicSharedMemorySize,
                                      (int)h->solve_lds));
+  h->gemm_lds = (size_t)kGemmLdsDoubles * 8;
+  if (h->gemm_lds > 64 * 1024)
+    VO_HIP_CHECK(hipFuncSetAttribute((const void *)k_ba_gemm, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                     (int)h->gemm_lds));
   h->built = true;
   return VO_OK;
 }
@@ -1533,7 +1605,7 @@ int launch_linearize(vo_ba *h) {
   hipStream_t st = h->stream;
   const int tdim = D.Mpad / 16, tiles = tdim * (tdim + 1) / 2;
   // Schur product tiles and the camera blocks in one launch (independent roles)
-  hipLaunchKernelGGL(k_ba_gemm, dim3(tiles * D.ksplit + h->nf * D.n_cchunks), dim3(256), 0, st, D);
+  hipLaunchKernelGGL(k_ba_gemm, dim3(tiles * D.ksplit + h->nf * D.n_cchunks), dim3(256), h->gemm_lds, st, D);
   if (!D.fused) {
     const int np = (D.Mpad * D.Mpad + h->nf * 27 + 1) * 4;
     hipLaunchKernelGGL(k_ba_reduce, dim3((np + 255) / 256), dim3(256), 0, st, D);
@@ -1924,10 +1996,10 @@ int vo_ba_get_edge_outliers(vo_ba *h, uint8_t *edge_erase) {
   return VO_OK;
 }
 
-int vo_ba_debug_stamps(vo_ba *h, unsigned long long *out /*8*/) {
+int vo_ba_debug_stamps(vo_ba *h, unsigned long long *out /*32*/) {
   if (!h || !h->built) return VO_ERR_INVALID;
   VO_HIP_CHECK(hipStreamSynchronize(h->stream));
-  VO_HIP_CHECK(hipMemcpy(out, h->b_dbg.p, 64, hipMemcpyDeviceToHost));
+  VO_HIP_CHECK(hipMemcpy(out, h->b_dbg.p, 256, hipMemcpyDeviceToHost));
   return VO_OK;
 }
 
