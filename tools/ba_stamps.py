@@ -32,12 +32,16 @@ def run():
     pr = synth.make_lba_problem(0)
     ba = _lib.BundleAdjuster(pr)
     ba.local_ba()
-    st = np.zeros(32, np.uint64)
+    st = np.zeros(48, np.uint64)
     L.vo_ba_debug_stamps(ba._h, st.ctypes.data_as(C.c_void_p))
     d = np.diff(st[:8].astype(np.int64)) / 100.0  # s_memrealtime ticks at 100 MHz -> us
     rel = lambda i: (int(st[i]) - int(st[16])) / 100.0
     print("gemm block 0 (us from its entry): hinv table %.2f, MFMA loop done %.2f, end %.2f; solve kernel starts at %.2f"
           % (rel(17), rel(18), rel(20), rel(0)))
+    print("  camera role, first block (us from gemm block 0 entry): start %.2f, edges done %.2f, block sum done %.2f" % (rel(32), rel(33), rel(34)))
+    print("  shader clock during the solve: %.0f MHz" % ((int(st[31]) - int(st[30])) / ((int(st[7]) - int(st[0])) / 100.0)))
+    l = [(int(st[i]) - int(st[2])) / 100.0 for i in range(24, 30)]
+    print("  LDLt step 0 (us from LDLt start): diag loaded %.2f, ldl6 %.2f, panel %.2f, barrier %.2f, trailing %.2f, barrier %.2f" % tuple(l))
     print("  G prefetch +%.2f, pose prefetch +%.2f" % ((int(st[10]) - int(st[0])) / 100.0, (int(st[11]) - int(st[0])) / 100.0))
     print(f"  prefetch drained at +{(int(st[8]) - int(st[0])) / 100.0:.2f} us, slab sums done at +{(int(st[9]) - int(st[0])) / 100.0:.2f} us")
     names = ["slab sums+scale", "assemble+gmax", "LDLt", "back-subst", "dots", "cand poses", "block_sum"]

@@ -390,7 +390,8 @@ struct BaDev {
   const int *slot_cam;      // [nf]
   const int *cam_start;     // [nf+1]
   const int *cam_edges;     // edge ids per free camera (this shard's edges only)
-  uint8_t *pt_in, *cam_in;
+  uint8_t *pt_in, *cam_in;  // == epoch: the block is in the current problem (no clearing pass between solves)
+  int epoch;
   // state
   double *Xc[2], *Xp[2];
   double *PC[2];            // pose caches (R row-major 9 + t 3) of Xc[0/1], one per camera
@@ -565,6 +566,9 @@ __device__ __forceinline__ void ba_cams_role(const BaDev &B, const BaState &st, 
   const int s0 = B.cam_start[slot], s1 = B.cam_start[slot + 1];
   const double *Xp = B.Xp[st.cur];
   const PoseCache P = load_pc(B.PC[st.cur], c);
+#ifdef VO_BA_STAMPS
+  if (tid == 0 && slot == 0 && chunk == 0) B.dbg[32] = __builtin_amdgcn_s_memrealtime();
+#endif
   double acc[27];
 #pragma unroll
   for (int i = 0; i < 27; i++) acc[i] = 0;
@@ -587,7 +591,13 @@ __device__ __forceinline__ void ba_cams_role(const BaDev &B, const BaState &st, 
       acc[21 + a] += rho1 * (ja0 * r[0] + ja1 * r[1] + ja2 * r[2]);
     }
   }
+#ifdef VO_BA_STAMPS
+  if (tid == 0 && slot == 0 && chunk == 0) B.dbg[33] = __builtin_amdgcn_s_memrealtime();
+#endif
   block_sum<27>(acc, lds);
+#ifdef VO_BA_STAMPS
+  if (tid == 0 && slot == 0 && chunk == 0) B.dbg[34] = __builtin_amdgcn_s_memrealtime();
+#endif
   if (tid == 0) {  // static indices only (a runtime-indexed acc[] would live in scratch memory)
     double *o = B.slab_cam + ((long long)slot * B.n_cchunks + chunk) * 27;
 #pragma unroll
@@ -858,6 +868,9 @@ __device__ __forceinline__ void ba_solve_body(const BaDev &B, const BaState &st0
   if (st0.done) return;
   const int tid = threadIdx.x;
   STAMP(0);
+#ifdef VO_BA_STAMPS
+  if (tid == 0) B.dbg[30] = __builtin_readcyclecounter();
+#endif
   const int nb = B.nf, n = 6 * nb, ld = n + 1;
   double *A = sm;                   // (n+1) x ld: lower triangle of S'' in rows 0..n-1, rhs'' in row n
   double *sc = A + (n + 1) * ld;    // Jacobi scale
@@ -904,7 +917,7 @@ __device__ __forceinline__ void ba_solve_body(const BaDev &B, const BaState &st0
 #pragma unroll
   for (int a = 0; a < 6; a++) xpre[a] = B.Xc[cur0][6 * pc_cam + a];
   const PoseCache pcpre = load_pc(B.PC[cur0], pc_cam);
-  const int slotpre = B.cam_slot[pc_cam], cinpre = B.cam_in[pc_cam];
+  const int slotpre = B.cam_slot[pc_cam], cinpre = B.cam_in[pc_cam] == B.epoch;
   STAMP_DRAIN(11);
   const double sc_pre = (first || tid >= n) ? 0.0 : B.scale_c[tid];  // per reduced-system column
   STAMP_DRAIN(8);  // debug builds only: the prefetch round trip
@@ -1011,6 +1024,11 @@ __device__ __forceinline__ void ba_solve_body(const BaDev &B, const BaState &st0
   // free).  Rows below the diagonal block store u_rt = l_rt d_t.  Per block column: every thread
   // factors the diagonal block redundantly in registers (no barrier needed for it), one thread per
   // panel row does its substitution, barrier, rank-6 trailing update, barrier.
+  // (Measured alternative: the trailing update as 16x16 tiles on the FP64 matrix cores, K = 6 padded
+  // to two v_mfma_f64_16x16x4 steps.  At n = 54 it is slower -- 15.0 us against 11.3 us for the whole
+  // factorisation: whole tiles do not shrink with the trailing matrix and the panel rows must be
+  // published twice -- so the scalar form stays; the pivot chain and the panel substitution, not the
+  // update, are the latency floor.)
   double *rdv = Ldg + nb * 21;  // 1/d_j of all n pivots
   bool ok_all = true;
   for (int k = 0; k < nb; k++) {
@@ -1040,7 +1058,9 @@ __device__ __forceinline__ void ba_solve_body(const BaDev &B, const BaState &st0
 #pragma unroll
       for (int t = 0; t < 6; t++) A[r * ld + K0 + t] = x[t];
     }
+    if (k == 0) STAMP(26);
     __syncthreads();
+    if (k == 0) STAMP(27);
     {
       const int tx = tid & 15, ty = tid >> 4;
       for (int r = K0 + 6 + ty; r <= n; r += 16) {
@@ -1055,7 +1075,9 @@ __device__ __forceinline__ void ba_solve_body(const BaDev &B, const BaState &st0
         }
       }
     }
+    if (k == 0) STAMP(28);
     __syncthreads();
+    if (k == 0) STAMP(29);
   }
   if (!ok_all && tid == 0) s_fail = 1;  // every thread saw the same pivots
   __syncthreads();
@@ -1108,7 +1130,7 @@ __device__ __forceinline__ void ba_solve_body(const BaDev &B, const BaState &st0
   for (int c = tid; c < B.n_cams; c += 256) {
     const bool pre = c == tid;  // first round: operands were prefetched at the top of the kernel
     const int slot = pre ? slotpre : B.cam_slot[c];
-    const int cin = pre ? cinpre : (int)B.cam_in[c];
+    const int cin = pre ? cinpre : (int)(B.cam_in[c] == B.epoch);
     double x0[6], xc[6];
 #pragma unroll
     for (int a = 0; a < 6; a++) x0[a] = pre ? xpre[a] : X[6 * c + a];
@@ -1135,7 +1157,14 @@ __device__ __forceinline__ void ba_solve_body(const BaDev &B, const BaState &st0
   }
   STAMP(6);
   double v5[5] = {gdot, dquad, xn2, cn2, sn2};
-  block_sum<5>(v5, red);
+  if (n <= 64 && B.n_cams <= 64) {  // only wavefront 0 holds non-zero terms: no LDS pass, no barrier
+    if (tid < 64) {
+#pragma unroll
+      for (int i = 0; i < 5; i++) v5[i] = wave_sum(v5[i]);
+    }
+  } else {
+    block_sum<5>(v5, red);
+  }
   if (tid == 0) {
     S->gdot_c = v5[0];
     S->dquad_c = v5[1];
@@ -1145,6 +1174,9 @@ __device__ __forceinline__ void ba_solve_body(const BaDev &B, const BaState &st0
     S->solve_failed = failed;
   }
   STAMP(7);
+#ifdef VO_BA_STAMPS
+  if (tid == 0) B.dbg[31] = __builtin_readcyclecounter();
+#endif
 }
 
 __global__ __launch_bounds__(256) void k_ba_solve(BaDev B) {
@@ -1252,12 +1284,13 @@ __global__ __launch_bounds__(256) void k_ba_backsub(BaDev B) {
     const double y1 = hi[1] * q[0] + hi[3] * q[1] + hi[4] * q[2];
     const double y2 = hi[2] * q[0] + hi[4] * q[1] + hi[5] * q[2];
     const double stp[3] = {-y0, -y1, -y2};
-    const bool in = B.pt_in[j] && !st.solve_failed;
+    const bool ptin = B.pt_in[j] == B.epoch;
+    const bool in = ptin && !st.solve_failed;
     double pn[3];
     for (int k = 0; k < 3; k++) pn[k] = Xp[3 * j + k] + (in ? stp[k] * B.scale_p[3 * j + k] : 0.0);
     if (g == 0) {
       for (int k = 0; k < 3; k++) Xpn[3 * j + k] = pn[k];
-      if (B.pt_in[j]) {
+      if (ptin) {
         for (int k = 0; k < 3; k++) {
           v[1] += g2[k] * stp[k];
           v[2] += B.dl[3 * j + k] * stp[k] * stp[k];
@@ -1325,25 +1358,7 @@ __global__ __launch_bounds__(64) void k_ba_update(BaDev B) {
   ba_update_logic(B);
 }
 
-// one block: reset the LM state (keeping the ping-pong index) and refresh the pose caches
-__global__ void k_ba_begin(BaDev B, int max_it, int archive_slot, double hm, double hs) {
-  BaState *S = B.st;
-  const int cur = S->cur;
-  __syncthreads();
-  for (int c = threadIdx.x; c < B.n_cams; c += blockDim.x) store_pc(B.PC[cur], c, pose_cache(B.Xc[cur] + 6 * c));
-  if (threadIdx.x != 0) return;
-  if (archive_slot >= 0) B.hist[archive_slot] = *S;
-  memset(S, 0, sizeof(BaState));
-  S->cur = cur;
-  S->radius = 1e4;
-  S->decrease = 2.0;
-  S->max_it = max_it;
-  S->first = 1;
-  S->hm = hm;
-  S->hs = hs;
-}
-
-// flags reset for a new solve (replaces three hipMemsetAsync calls, each ~50 us of host time)
+// flags reset (epoch wrap-around, and the outlier mask of a local BA stopped before problem 2)
 __global__ void k_ba_clear(BaDev B, int set_active, uint8_t *out_or_null) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i < B.n_pts) B.pt_in[i] = 0;
@@ -1354,20 +1369,9 @@ __global__ void k_ba_clear(BaDev B, int set_active, uint8_t *out_or_null) {
   }
 }
 
-// edge activity -> which points / cameras are in the problem (Ceres drops unused blocks)
-__global__ void k_ba_mark(BaDev B) {
-  const int e = blockIdx.x * blockDim.x + threadIdx.x;
-  if (e >= B.n_edges || !B.e_active[e]) return;
-  B.pt_in[B.e_pt[e]] = 1;
-  if (B.cam_slot[B.e_cam[e]] >= 0) B.cam_in[B.e_cam[e]] = 1;
-}
-
-// float chi2 classification of the edges, optimizer_ceres.cpp:618-689 (mode 0: writes
+// float chi2 classification of one edge, optimizer_ceres.cpp:618-689 (mode 0: writes
 // e_active = inlier and out = outlier) and :703-755 (mode 1: out |= outlier).  Q-B2.
-__global__ void k_ba_classify(BaDev B, int mode, uint8_t *out) {
-  const int e = blockIdx.x * blockDim.x + threadIdx.x;
-  if (e >= B.n_edges) return;
-  const int cur = B.st->cur;
+__device__ __forceinline__ void classify_edge(const BaDev &B, int cur, int mode, int e, uint8_t *out) {
   if (mode == 1 && out[e]) return;
   const PoseCache P = pose_cache(B.Xc[cur] + 6 * B.e_cam[e]);
   double pc[3];
@@ -1397,12 +1401,47 @@ __global__ void k_ba_classify(BaDev B, int mode, uint8_t *out) {
       outl = (e2 + eur * eur) * is2 > 7.815f;
     }
   }
-  if (mode == 0) {
-    out[e] = outl;
-    B.e_active[e] = !outl;
-  } else {
-    out[e] = outl;
+  out[e] = outl;
+  if (mode == 0) B.e_active[e] = !outl;
+}
+
+__global__ void k_ba_classify(BaDev B, int mode, uint8_t *out) {
+  const int e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e < B.n_edges) classify_edge(B, B.st->cur, mode, e, out);
+}
+
+// Start of an LM solve in ONE launch (was clear / mark / begin, ~5 us of dispatch gap each):
+//  * per edge: optional first-pass classification (local BA, between its two problems) or "all edges
+//    active"; then edge activity -> which points / cameras are in the problem (Ceres drops unused
+//    blocks), stamped with this solve's epoch so nothing has to be cleared first;
+//  * block 0: reset the LM state (keeping the ping-pong index) and refresh the pose caches.
+__global__ __launch_bounds__(256) void k_ba_setup(BaDev B, int set_active, uint8_t *classify0_out, int max_it,
+                                                  int archive_slot, double hm, double hs) {
+  BaState *S = B.st;
+  const int cur = S->cur;  // never changes during this launch (the reset below keeps it)
+  const int e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e < B.n_edges) {
+    if (classify0_out) classify_edge(B, cur, 0, e, classify0_out);
+    else if (set_active) B.e_active[e] = 1;
+    if (B.e_active[e]) {
+      B.pt_in[B.e_pt[e]] = (uint8_t)B.epoch;
+      if (B.cam_slot[B.e_cam[e]] >= 0) B.cam_in[B.e_cam[e]] = (uint8_t)B.epoch;
+    }
   }
+  if (blockIdx.x != 0) return;
+  for (int c = threadIdx.x; c < B.n_cams; c += blockDim.x) store_pc(B.PC[cur], c, pose_cache(B.Xc[cur] + 6 * c));
+  if (threadIdx.x != 0) return;
+  if (archive_slot >= 0) B.hist[archive_slot] = *S;
+  BaState z;
+  memset(&z, 0, sizeof(BaState));
+  z.cur = cur;
+  z.radius = 1e4;
+  z.decrease = 2.0;
+  z.max_it = max_it;
+  z.first = 1;
+  z.hm = hm;
+  z.hs = hs;
+  *S = z;  // `cur` is rewritten with its own value: readers in other blocks never see a different one
 }
 
 }  // namespace
@@ -1502,6 +1541,9 @@ int build_device(vo_ba *h) {
   VO_CHECK(upload(h->b_camedges, cedges.data(), cedges.size() * 4));
   VO_CHECK(h->b_ptin.reserve(std::max<size_t>(h->n_pts, 64)));
   VO_CHECK(h->b_camin.reserve(std::max<size_t>(h->n_cams, 64)));
+  VO_HIP_CHECK(hipMemset(h->b_ptin.p, 0, std::max<size_t>(h->n_pts, 64)));  // epoch stamps start below epoch 1
+  VO_HIP_CHECK(hipMemset(h->b_camin.p, 0, std::max<size_t>(h->n_cams, 64)));
+  D.epoch = 0;
   VO_CHECK(upload(h->b_xc0, h->poses.data(), h->poses.size() * 8));
   VO_CHECK(upload(h->b_xc1, h->poses.data(), h->poses.size() * 8));
   VO_CHECK(upload(h->b_xp0, h->points.data(), h->points.size() * 8));
@@ -1574,7 +1616,8 @@ int build_device(vo_ba *h) {
   return VO_OK;
 }
 
-int lm_begin(vo_ba *h, double hm, double hs, int max_it, const uint8_t *active_caller, bool keep_device_mask) {
+int lm_begin(vo_ba *h, double hm, double hs, int max_it, const uint8_t *active_caller, bool keep_device_mask,
+             uint8_t *classify0_out = nullptr) {
   VO_CHECK(build_device(h));
   BaDev &D = h->D;
   hipStream_t st = h->stream;
@@ -1589,11 +1632,13 @@ int lm_begin(vo_ba *h, double hm, double hs, int max_it, const uint8_t *active_c
       VO_HIP_CHECK(hipStreamSynchronize(st));  // act is a stack-lifetime buffer
     }
   }
-  const int nmax = std::max(std::max(h->n_edges, h->n_pts), h->n_cams);
-  hipLaunchKernelGGL(k_ba_clear, dim3((nmax + 255) / 256), dim3(256), 0, st, D, set_active, (uint8_t *)nullptr);
-  if (h->n_edges > 0)
-    hipLaunchKernelGGL(k_ba_mark, dim3((h->n_edges + 255) / 256), dim3(256), 0, st, D);
-  hipLaunchKernelGGL(k_ba_begin, dim3(1), dim3(64), 0, st, D, max_it, h->archive_slot, hm, hs);
+  if (++D.epoch > 255) {  // the membership stamps are bytes: clear them when the epoch wraps
+    const int nmax = std::max(std::max(h->n_edges, h->n_pts), h->n_cams);
+    hipLaunchKernelGGL(k_ba_clear, dim3((nmax + 255) / 256), dim3(256), 0, st, D, 0, (uint8_t *)nullptr);
+    D.epoch = 1;
+  }
+  hipLaunchKernelGGL(k_ba_setup, dim3((std::max(1, h->n_edges) + 255) / 256), dim3(256), 0, st, D, set_active,
+                     classify0_out, max_it, h->archive_slot, hm, hs);
   hipLaunchKernelGGL(k_ba_lin0, dim3(D.n_pblocks), dim3(256), 0, st, D);  // first linearisation of the solve
   VO_HIP_CHECK(hipGetLastError());
   h->lm_max_it = max_it;
@@ -1930,9 +1975,9 @@ int vo_ba_local_ba_enqueue(vo_ba *h, const volatile int *stop) {
   uint8_t *out = h->b_out.as<uint8_t>();
   const dim3 eg((std::max(1, h->n_edges) + 255) / 256);
   if (!(stop && *stop)) {  // :612
-    hipLaunchKernelGGL(k_ba_classify, eg, dim3(256), 0, h->stream, h->D, 0, out);
-    h->archive_slot = 0;  // problem 1's final state is archived by problem 2's begin kernel
-    VO_CHECK(lm_begin(h, 0.0, 0.0, 10, nullptr, true));
+    h->archive_slot = 0;  // problem 1's final state is archived by problem 2's setup kernel, which also
+                          // classifies the edges at problem 1's solution (:618-689) before marking
+    VO_CHECK(lm_begin(h, 0.0, 0.0, 10, nullptr, true, out));
     h->archive_slot = -1;
     VO_CHECK(run_lm(h, 10));
     h->lba_second = true;
@@ -1996,10 +2041,10 @@ int vo_ba_get_edge_outliers(vo_ba *h, uint8_t *edge_erase) {
   return VO_OK;
 }
 
-int vo_ba_debug_stamps(vo_ba *h, unsigned long long *out /*32*/) {
+int vo_ba_debug_stamps(vo_ba *h, unsigned long long *out /*48*/) {
   if (!h || !h->built) return VO_ERR_INVALID;
   VO_HIP_CHECK(hipStreamSynchronize(h->stream));
-  VO_HIP_CHECK(hipMemcpy(out, h->b_dbg.p, 256, hipMemcpyDeviceToHost));
+  VO_HIP_CHECK(hipMemcpy(out, h->b_dbg.p, 384, hipMemcpyDeviceToHost));
   return VO_OK;
 }
 
