@@ -39,6 +39,8 @@ def run():
     print("gemm block 0 (us from its entry): hinv table %.2f, MFMA loop done %.2f, end %.2f; solve kernel starts at %.2f"
           % (rel(17), rel(18), rel(20), rel(0)))
     print("  camera role, first block (us from gemm block 0 entry): start %.2f, edges done %.2f, block sum done %.2f" % (rel(32), rel(33), rel(34)))
+    rb = lambda i: (int(st[i]) - int(st[36])) / 100.0
+    print("  back-substitution kernel, block 0 (us from its entry): point steps %.2f, candidate linearised %.2f, block sums %.2f; last block: ticket %.2f, update done %.2f" % (rb(37), rb(38), rb(39), rb(40), rb(41)))
     print("  shader clock during the solve: %.0f MHz" % ((int(st[31]) - int(st[30])) / ((int(st[7]) - int(st[0])) / 100.0)))
     l = [(int(st[i]) - int(st[2])) / 100.0 for i in range(24, 30)]
     print("  LDLt step 0 (us from LDLt start): diag loaded %.2f, ldl6 %.2f, panel %.2f, barrier %.2f, trailing %.2f, barrier %.2f" % tuple(l))

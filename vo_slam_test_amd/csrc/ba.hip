@@ -361,9 +361,13 @@ __global__ __launch_bounds__(256) void k_pose_only(const int *offsets, const dou
 // ============================================================================================
 // Local BA
 // ============================================================================================
-constexpr int kGroup = 8;        // lanes per map point
-constexpr int kPtsPerBlock = 32; // 256 / kGroup
+constexpr int kGroupLog = 4;
+constexpr int kGroup = 1 << kGroupLog;  // lanes per map point: one edge per lane at the usual <= 16 observations,
+                                        // and twice the workgroups -- the point kernels are FP64-latency bound
+                                        // with one wavefront per SIMD
+constexpr int kPtsPerBlock = 256 / kGroup;
 constexpr int kCamChunk = 256;   // edges per camera-role block (one per thread: the role shares a launch with the Schur tiles)
+constexpr int kPcLds = 128;     // pose caches staged in LDS by the point kernels (12 KB)
 constexpr int kMaxN = 128;       // reduced system size limit of the LDS Cholesky (6*nf + 1 <= kMaxN)
 
 struct BaState {
@@ -544,15 +548,20 @@ __device__ __forceinline__ void store_point_partials(const BaDev &B, int buf, do
 __global__ __launch_bounds__(256) void k_ba_lin0(BaDev B) {
   __shared__ double lds[4];
   __shared__ double lmx[4];
+  __shared__ double pcL[kPcLds * 12];
   const BaState st = *B.st;
   const int tid = threadIdx.x, g = tid & (kGroup - 1);
-  const int li = blockIdx.x * kPtsPerBlock + (tid >> 3);
+  const bool pc_lds = B.n_cams <= kPcLds;
+  if (pc_lds)
+    for (int i = tid; i < 12 * B.n_cams; i += 256) pcL[i] = B.PC[st.cur][i];
+  __syncthreads();
+  const int li = blockIdx.x * kPtsPerBlock + (tid >> kGroupLog);
   double cost = 0, gmax = 0;
   if (li < B.n_local) {
     const int j = B.local_pts[li];
     const double *Xp = B.Xp[st.cur];
     const double pt[3] = {Xp[3 * j], Xp[3 * j + 1], Xp[3 * j + 2]};
-    point_linearize(B, st, j, g, pt, B.PC[st.cur], st.cur, cost, gmax);
+    point_linearize(B, st, j, g, pt, pc_lds ? pcL : B.PC[st.cur], st.cur, cost, gmax);
   }
   store_point_partials(B, st.cur, cost, gmax, lds, lmx);
 }
@@ -883,6 +892,17 @@ __device__ __forceinline__ void ba_solve_body(const BaDev &B, const BaState &st0
   const double *G = B.payload;
   // camera blocks / cost / gradient-max: all-reduced payload in the sharded mode, summed into LDS here otherwise
   double *HPw = B.fused ? red + 64 : B.payload + payload_hpp_off(B);
+  const int cur0 = st0.cur;
+  const int first = st0.first;
+  const double radius = st0.radius;
+  // this thread's camera for the candidate-pose phase: pose and cache are read now, used after the solve
+  const int pc_cam = tid < B.n_cams ? tid : 0;
+  double xpre[6];
+#pragma unroll
+  for (int a = 0; a < 6; a++) xpre[a] = B.Xc[cur0][6 * pc_cam + a];
+  const PoseCache pcpre = load_pc(B.PC[cur0], pc_cam);
+  const int slotpre = B.cam_slot[pc_cam], cinpre = B.cam_in[pc_cam] == B.epoch;
+  Se3 expx;
   // Raw Schur product into A (lower triangle, rhs in row n): entry (c, r >= c) of the payload --
   // all-reduced across GPUs (sharded) or summed over the K slices by k_ba_gemm's tile blocks (fused).
   // Unconditional loads, eight in flight per lane: lanes without an entry read the all-zero slab.
@@ -891,9 +911,7 @@ __device__ __forceinline__ void ba_solve_body(const BaDev &B, const BaState &st0
   {
     const double *zero_slab = B.slab_gemm + (long long)B.ksplit * B.Mpad * B.Mpad;  // never written after creation
     const int ne = n * (n + 1);  // entry e = c * (n + 1) + r, r in [c, n]
-    for (int e0 = 0; e0 < ne; e0 += 256 * 8) {
-      double v[8];
-      int pos[8];
+    auto issue = [&](int e0, double (&v)[8], int (&pos)[8]) {
 #pragma unroll
       for (int un = 0; un < 8; un++) {
         const int e = e0 + un * 256 + tid;
@@ -902,22 +920,27 @@ __device__ __forceinline__ void ba_solve_body(const BaDev &B, const BaState &st0
         pos[un] = valid ? r * ld + c : -1;
         v[un] = *(valid ? G + (long long)c * B.Mpad + r : zero_slab);
       }
+    };
+    auto commit = [&](const double (&v)[8], const int (&pos)[8]) {
 #pragma unroll
       for (int un = 0; un < 8; un++)
         if (pos[un] >= 0) A[pos[un]] = v[un];
+    };
+    double v0[8];
+    int pos0[8];
+    issue(0, v0, pos0);
+    // exp(x) of this thread's camera while the first round is in flight (the pose loads were issued
+    // before it and return first); se3_plus only has exp(delta), the product and the log left to do
+    expx = se3_exp(xpre);
+    commit(v0, pos0);
+    for (int e0 = 256 * 8; e0 < ne; e0 += 256 * 8) {
+      double v[8];
+      int pos[8];
+      issue(e0, v, pos);
+      commit(v, pos);
     }
   }
   STAMP_DRAIN(10);
-  // this thread's camera for the candidate-pose phase: pose and cache are read now, used after the solve
-  const int cur0 = st0.cur;
-  const int first = st0.first;
-  const double radius = st0.radius;
-  const int pc_cam = tid < B.n_cams ? tid : 0;
-  double xpre[6];
-#pragma unroll
-  for (int a = 0; a < 6; a++) xpre[a] = B.Xc[cur0][6 * pc_cam + a];
-  const PoseCache pcpre = load_pc(B.PC[cur0], pc_cam);
-  const int slotpre = B.cam_slot[pc_cam], cinpre = B.cam_in[pc_cam] == B.epoch;
   STAMP_DRAIN(11);
   const double sc_pre = (first || tid >= n) ? 0.0 : B.scale_c[tid];  // per reduced-system column
   STAMP_DRAIN(8);  // debug builds only: the prefetch round trip
@@ -1138,7 +1161,10 @@ __device__ __forceinline__ void ba_solve_body(const BaDev &B, const BaState &st0
       double d[6];
 #pragma unroll
       for (int a = 0; a < 6; a++) d[a] = -y[6 * slot + a] * sc[6 * slot + a];
-      se3_plus(x0, d, xc);
+      if (pre)
+        se3_plus_exp(expx, d, xc);
+      else
+        se3_plus(x0, d, xc);
       store_pc(B.PC[cur0 ^ 1], c, pose_cache(xc));
     } else {
 #pragma unroll
@@ -1186,9 +1212,10 @@ __global__ __launch_bounds__(256) void k_ba_solve(BaDev B) {
 }
 
 // TrustRegionMinimizer step evaluation + LevenbergMarquardtStrategy radius update (one thread)
-__device__ void ba_update_logic(const BaDev &B) {
-  BaState *S = B.st;
-  const double *p = B.payload2;
+// Works on a register copy of the state (`s`, as read at the start of the launch: nothing else writes it
+// in between) and the six reduced sums `p`; the caller stores the result back in one piece.
+__device__ __forceinline__ void ba_update_logic(BaState &s, const double p[6]) {
+  BaState *S = &s;
   const double cand_cost = p[0];
   const double model = -0.5 * (S->gdot_c + p[1]) + 0.5 * (S->dquad_c + p[2]);
   const double step_norm = sqrt(S->step_norm2_c + p[3]);
@@ -1246,10 +1273,21 @@ __device__ void ba_update_logic(const BaDev &B) {
 __global__ __launch_bounds__(256) void k_ba_backsub(BaDev B) {
   __shared__ double lds[4 * 6];
   __shared__ double lmx[4];
+  __shared__ double pcL[kPcLds * 12];  // pose caches of the candidate poses
+  __shared__ double zcL[kMaxN];        // camera step
   const BaState st = *B.st;
   if (st.done) return;
+  STAMP0(36);
   const int tid = threadIdx.x, g = tid & (kGroup - 1);
-  const int li = blockIdx.x * kPtsPerBlock + (tid >> 3);
+  // every edge evaluation reads a 12-double pose cache: from LDS it costs one level of the load
+  // chain less and no global traffic (falls back to HBM for more cameras than the table holds)
+  const bool pc_lds = B.n_cams <= kPcLds;
+  if (pc_lds)
+    for (int i = tid; i < 12 * B.n_cams; i += 256) pcL[i] = B.PC[st.cur ^ 1][i];
+  for (int i = tid; i < 6 * B.nf; i += 256) zcL[i] = B.zc[i];
+  __syncthreads();
+  const double *PCcand = pc_lds ? pcL : B.PC[st.cur ^ 1];
+  const int li = blockIdx.x * kPtsPerBlock + (tid >> kGroupLog);
   const bool valid = li < B.n_local;
   const int j = valid ? B.local_pts[li] : 0;
   const double *Xp = B.Xp[st.cur];
@@ -1267,7 +1305,7 @@ __global__ __launch_bounds__(256) void k_ba_backsub(BaDev B) {
       const long long base = (long long)(3 * j) * B.Mpad + 6 * slot;
 #pragma unroll
       for (int a = 0; a < 6; a++) {
-        const double z = B.zc[6 * slot + a];
+        const double z = zcL[6 * slot + a];
         rr[0] += W[base + a] * z;
         rr[1] += W[base + B.Mpad + a] * z;
         rr[2] += W[base + 2 * B.Mpad + a] * z;
@@ -1302,37 +1340,74 @@ __global__ __launch_bounds__(256) void k_ba_backsub(BaDev B) {
     }
     // candidate cost and, in the same sweep, the complete (radius-independent) linearisation at the
     // candidate into the other buffer set: if the step is accepted the next iteration starts from it
-    point_linearize(B, st, j, g, pn, B.PC[st.cur ^ 1], st.cur ^ 1, ccost, cgmax);
+#ifdef VO_BA_STAMPS
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
+    STAMP0(37);
+    point_linearize(B, st, j, g, pn, PCcand, st.cur ^ 1, ccost, cgmax);
     v[0] = ccost;
   }
-  store_point_partials(B, st.cur ^ 1, ccost, cgmax, lds, lmx);
-  __syncthreads();
-  block_sum<6>(v, lds);
-  if (tid == 0) {
+#ifdef VO_BA_STAMPS
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
+  STAMP0(38);
+  // one pass for everything the block hands on: the six step sums, and (v[0] doubles as it) the
+  // candidate cost and gradient max-norm of the candidate linearisation
+  {
+    const int lane = tid & 63, wave = tid >> 6;
 #pragma unroll
-    for (int i = 0; i < 6; i++) {
+    for (int i = 0; i < 6; i++) v[i] = wave_sum(v[i]);
+    const double gm = wave_max(cgmax);
+    if (lane == 0) {
+#pragma unroll
+      for (int i = 0; i < 6; i++) lds[wave * 6 + i] = v[i];
+      lmx[wave] = gm;
+    }
+    __syncthreads();
+    if (tid < 6) {
+      const double t = ((lds[tid] + lds[6 + tid]) + lds[12 + tid]) + lds[18 + tid];
       if (B.fused)
-        st_sc1(&B.slab_bs[6 * blockIdx.x + i], v[i]);
+        st_sc1(&B.slab_bs[6 * blockIdx.x + tid], t);
       else
-        B.slab_bs[6 * blockIdx.x + i] = v[i];
+        B.slab_bs[6 * blockIdx.x + tid] = t;
+      if (tid == 0) {
+        B.slab_pt[st.cur ^ 1][2 * blockIdx.x] = t;
+        B.slab_pt[st.cur ^ 1][2 * blockIdx.x + 1] = fmax(fmax(lmx[0], lmx[1]), fmax(lmx[2], lmx[3]));
+      }
     }
   }
+  STAMP0(39);
   if (!B.fused) return;
   // single shard: the last block to arrive sums the slabs (fixed order) and runs the update
   __shared__ int s_last;
   if (!arrive_and_check_last(&B.counters[0], gridDim.x, &s_last)) return;
+#ifdef VO_BA_STAMPS
+  if (tid == 0) B.dbg[40] = __builtin_amdgcn_s_memrealtime();
+#endif
   if (tid < 64) {
     double a[6] = {0, 0, 0, 0, 0, 0};
-    for (int b = tid; b < B.n_pblocks; b += 64)
+    for (int b0 = 0; b0 < B.n_pblocks; b0 += 256) {  // 24 coherent loads in flight per lane, added in block order
+      double w[4][6];
 #pragma unroll
-      for (int i = 0; i < 6; i++) a[i] += ld_sc1(&B.slab_bs[6 * b + i]);
+      for (int q = 0; q < 4; q++)
+#pragma unroll
+        for (int i = 0; i < 6; i++) w[q][i] = ld_sc1(&B.slab_bs[6 * min(b0 + 64 * q + tid, B.n_pblocks - 1) + i]);
+#pragma unroll
+      for (int q = 0; q < 4; q++)
+#pragma unroll
+        for (int i = 0; i < 6; i++) a[i] += b0 + 64 * q + tid < B.n_pblocks ? w[q][i] : 0.0;
+    }
 #pragma unroll
     for (int i = 0; i < 6; i++) a[i] = wave_sum(a[i]);
     if (tid == 0) {
 #pragma unroll
       for (int i = 0; i < 6; i++) B.payload2[i] = a[i];
-      __threadfence_block();
-      ba_update_logic(B);
+      BaState ns = st;  // the solve kernel's fields (gdot_c, ...) are in the launch-time copy
+      ba_update_logic(ns, a);
+      *B.st = ns;
+#ifdef VO_BA_STAMPS
+      B.dbg[41] = __builtin_amdgcn_s_memrealtime();
+#endif
     }
   }
 }
@@ -1355,7 +1430,11 @@ __global__ __launch_bounds__(64) void k_ba_reduce2(BaDev B) {
 // --------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(64) void k_ba_update(BaDev B) {
   if (B.st->done || threadIdx.x != 0) return;
-  ba_update_logic(B);
+  BaState ns = *B.st;
+  double p[6];
+  for (int i = 0; i < 6; i++) p[i] = B.payload2[i];
+  ba_update_logic(ns, p);
+  *B.st = ns;
 }
 
 // flags reset (epoch wrap-around, and the outlier mask of a local BA stopped before problem 2)

@@ -85,9 +85,11 @@ VO_HD void se3_log(const Se3 &T, double xi[6]) {
   xi[3] = wx, xi[4] = wy, xi[5] = wz;
 }
 
-// PoseLocalParameterization::Plus (optimizer_ceres.cpp:44-53): log(exp(delta) * exp(x))
-VO_HD void se3_plus(const double x[6], const double d[6], double out[6]) {
-  const Se3 A = se3_exp(d), B = se3_exp(x);
+// PoseLocalParameterization::Plus (optimizer_ceres.cpp:44-53): log(exp(delta) * exp(x)).
+// The two-argument form takes exp(x) ready-made: the solve kernel forms it while the reduced
+// system is still in flight, off the critical path behind the factorisation.
+VO_HD void se3_plus_exp(const Se3 &B, const double d[6], double out[6]) {
+  const Se3 A = se3_exp(d);
   Se3 Cc;
   double rt[3];
   quat_rotate(A.q, B.t, rt);
@@ -99,6 +101,7 @@ VO_HD void se3_plus(const double x[6], const double d[6], double out[6]) {
   quat_normalize(Cc.q);
   se3_log(Cc, out);
 }
+VO_HD void se3_plus(const double x[6], const double d[6], double out[6]) { se3_plus_exp(se3_exp(x), d, out); }
 
 // Optimizer::se3TransPoint<double> (optimizer_ceres.h:29-95) plus the rotation matrix of
 // ceres::AngleAxisToRotationMatrix (same theta^2 > eps branch), R row-major here.
