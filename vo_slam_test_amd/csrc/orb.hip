@@ -362,8 +362,10 @@ __global__ __launch_bounds__(256) void k_fast_wave(OrbDev P, FrameSrc src, uint3
       for (int q = 0; q < 4; q++) {
         const bool ok = base + q * 64 + lane < total;
         pos[q] = ok ? y * TP + unit * x : -1;
-        const uint8_t *g = g0 + (long long)y * pitch + unit * x;
-        v[q] = !ok ? 0u : bytewise ? (uint32_t)*g : *reinterpret_cast<const uint32_t *>(g);
+        // unconditional load (lanes past the tile re-read its first element): a `ok ? load : 0` form is
+        // turned into a branch per load with a full s_waitcnt behind it, serialising the batch
+        const uint8_t *g = ok ? g0 + (long long)y * pitch + unit * x : g0;
+        v[q] = bytewise ? (uint32_t)*g : *reinterpret_cast<const uint32_t *>(g);
         x += sdx, y += sdy;
         if (x >= npr) x -= npr, y++;
       }
@@ -804,6 +806,8 @@ __device__ __forceinline__ int reflect101(int i, int n) {
   while (i < 0 || i >= n) i = i < 0 ? -i : 2 * n - 2 - i;
   return i;
 }
+// same result for -n < i < 2n - 1 (the blur apron of 3 with n >= 4), without the loop
+__device__ __forceinline__ int reflect101_near(int i, int n) { return i < 0 ? -i : (i >= n ? 2 * n - 2 - i : i); }
 
 __global__ __launch_bounds__(256) void k_blur(OrbDev P, FrameSrc src, int only_level) {
   __shared__ uint8_t t[22][72];
@@ -855,13 +859,16 @@ __global__ __launch_bounds__(256) void k_blur(OrbDev P, FrameSrc src, int only_l
 // the row pass is exact).
 __global__ __launch_bounds__(256) void k_blur_strips(OrbDev P, FrameSrc src, int lv0_generic) {
   const int lane = threadIdx.x & 63, f = blockIdx.y;
-  int job = blockIdx.x * 4 + (threadIdx.x >> 6);
+  // wave-uniform job: the level's geometry then sits in scalar registers for the whole walk (left
+  // lane-dependent, its fields are re-fetched through vector memory around every store)
+  int job = blockIdx.x * 4 + __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
   int l = 0;
   while (l + 1 < P.nlevels && job >= P.lv[l + 1].stripBase) l++;
   const LevelGeom &L = P.lv[l];
   job -= L.stripBase;
   if (job >= L.stripsX * L.stripsY) return;
   if (l == 0 && lv0_generic) return;
+  const int Lh = L.h, Lpitch = L.pitch;
   const int sy = job / L.stripsX, sx = job - sy * L.stripsX;
   const int g = sx * 64 + lane;
   const bool active = g < L.blurGroups;
@@ -869,7 +876,8 @@ __global__ __launch_bounds__(256) void k_blur_strips(OrbDev P, FrameSrc src, int
   int pitch;
   const uint8_t *img = level_plane(P, src, l, f, pitch);
   uint8_t *dst = src.blur + (long long)f * src.blur_frame_stride + L.blur_off;
-  const int y0 = sy * 32, y1 = min(L.h, y0 + 32);
+  const int y0 = sy * 32, y1 = min(Lh, y0 + 32);
+  const bool near = Lh >= 4;
   const unsigned K0 = 18u | (34u << 8) | (49u << 16) | (55u << 24);
   const unsigned K1 = 49u | (34u << 8) | (18u << 16);
   int hw[7][4];
@@ -877,31 +885,45 @@ __global__ __launch_bounds__(256) void k_blur_strips(OrbDev P, FrameSrc src, int
   for (int j = 0; j < 7; j++)
 #pragma unroll
     for (int q = 0; q < 4; q++) hw[j][q] = 0;
-#pragma unroll 4
-  for (int yy = y0 - 3; yy < y1 + 3; yy++) {
-    const int ry = reflect101(yy, L.h);
-    const uint8_t *row = img + (long long)ry * pitch + x;
-    const unsigned Lw = *reinterpret_cast<const unsigned *>(row - 4);
-    const unsigned Cw = *reinterpret_cast<const unsigned *>(row);
-    const unsigned Rw = *reinterpret_cast<const unsigned *>(row + 4);
+  // Rows are taken eight at a time: all 24 loads of a batch are issued before the first result is
+  // stored.  (Written row by row, every load waits behind the previous row's store -- the compiler
+  // cannot prove that `dst` and `img` do not alias -- and a wave pays one memory round trip per row.)
+  constexpr int RB = 8;
+  for (int yb = y0 - 3; yb < y1 + 3; yb += RB) {
+    unsigned Lr[RB], Cr[RB], Rr[RB];
 #pragma unroll
-    for (int j = 0; j < 6; j++)
+    for (int u = 0; u < RB; u++) {
+      const int yq = min(yb + u, y1 + 2);  // rows past the strip repeat its last one (unused)
+      const int ry = near ? reflect101_near(yq, Lh) : reflect101(yq, Lh);
+      const uint8_t *row = img + (long long)ry * pitch + x;
+      Lr[u] = *reinterpret_cast<const unsigned *>(row - 4);
+      Cr[u] = *reinterpret_cast<const unsigned *>(row);
+      Rr[u] = *reinterpret_cast<const unsigned *>(row + 4);
+    }
 #pragma unroll
-      for (int q = 0; q < 4; q++) hw[j][q] = hw[j + 1][q];
-    // pixel q sits at byte 4+q of (L,C,R); its taps are bytes q+1 .. q+7
-    hw[6][0] = __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(Cw, Lw, 1), K0, __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(Rw, Cw, 1), K1, 0u, false), false);
-    hw[6][1] = __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(Cw, Lw, 2), K0, __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(Rw, Cw, 2), K1, 0u, false), false);
-    hw[6][2] = __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(Cw, Lw, 3), K0, __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(Rw, Cw, 3), K1, 0u, false), false);
-    hw[6][3] = __builtin_amdgcn_udot4(Cw, K0, __builtin_amdgcn_udot4(Rw, K1, 0u, false), false);
-    if (yy >= y0 + 3) {
-      unsigned outw = 0;
+    for (int u = 0; u < RB; u++) {
+      const int yy = yb + u;
+      if (yy >= y1 + 3) break;  // uniform
+      const unsigned Lw = Lr[u], Cw = Cr[u], Rw = Rr[u];
 #pragma unroll
-      for (int q = 0; q < 4; q++) {
-        const int acc = 18 * (hw[0][q] + hw[6][q]) + 34 * (hw[1][q] + hw[5][q]) + 49 * (hw[2][q] + hw[4][q]) + 55 * hw[3][q];
-        const unsigned v = (unsigned)min((acc + (1 << 15)) >> 16, 255);
-        outw |= v << (8 * q);
+      for (int j = 0; j < 6; j++)
+#pragma unroll
+        for (int q = 0; q < 4; q++) hw[j][q] = hw[j + 1][q];
+      // pixel q sits at byte 4+q of (L,C,R); its taps are bytes q+1 .. q+7
+      hw[6][0] = __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(Cw, Lw, 1), K0, __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(Rw, Cw, 1), K1, 0u, false), false);
+      hw[6][1] = __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(Cw, Lw, 2), K0, __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(Rw, Cw, 2), K1, 0u, false), false);
+      hw[6][2] = __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(Cw, Lw, 3), K0, __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(Rw, Cw, 3), K1, 0u, false), false);
+      hw[6][3] = __builtin_amdgcn_udot4(Cw, K0, __builtin_amdgcn_udot4(Rw, K1, 0u, false), false);
+      if (yy >= y0 + 3) {
+        unsigned outw = 0;
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+          const int acc = 18 * (hw[0][q] + hw[6][q]) + 34 * (hw[1][q] + hw[5][q]) + 49 * (hw[2][q] + hw[4][q]) + 55 * hw[3][q];
+          const unsigned v = (unsigned)min((acc + (1 << 15)) >> 16, 255);
+          outw |= v << (8 * q);
+        }
+        if (active) *reinterpret_cast<unsigned *>(dst + (long long)(yy - 3) * Lpitch + x) = outw;
       }
-      if (active) *reinterpret_cast<unsigned *>(dst + (long long)(yy - 3) * L.pitch + x) = outw;
     }
   }
 }
@@ -927,17 +949,32 @@ __global__ __launch_bounds__(256) void k_blur_border(OrbDev P, FrameSrc src, int
   int xi[7];
 #pragma unroll
   for (int i = 0; i < 7; i++) xi[i] = reflect101(x + i - 3, L.w);
-  const int y0 = band * 32, y1 = min(L.h, y0 + 32);
+  const int Lh = L.h, Lpitch = L.pitch;  // read once: the stores below would force a re-fetch
+  const bool near = Lh >= 4;
+  const int y0 = band * 32, y1 = min(Lh, y0 + 32);
   int hw[7] = {0, 0, 0, 0, 0, 0, 0};
-  for (int yy = y0 - 3; yy < y1 + 3; yy++) {
-    const uint8_t *row = img + (long long)reflect101(yy, L.h) * pitch;
-    const int hsum = 18 * (row[xi[0]] + row[xi[6]]) + 34 * (row[xi[1]] + row[xi[5]]) + 49 * (row[xi[2]] + row[xi[4]]) + 55 * row[xi[3]];
+  constexpr int RB = 6;  // rows per batch: all 42 loads are issued before the first store (see k_blur_strips)
+  for (int yb = y0 - 3; yb < y1 + 3; yb += RB) {
+    int px[RB][7];
 #pragma unroll
-    for (int j = 0; j < 6; j++) hw[j] = hw[j + 1];
-    hw[6] = hsum;
-    if (yy >= y0 + 3) {
-      const int acc = 18 * (hw[0] + hw[6]) + 34 * (hw[1] + hw[5]) + 49 * (hw[2] + hw[4]) + 55 * hw[3];
-      dst[(long long)(yy - 3) * L.pitch + x] = (uint8_t)min((acc + (1 << 15)) >> 16, 255);
+    for (int u = 0; u < RB; u++) {
+      const int yq = min(yb + u, y1 + 2);
+      const uint8_t *row = img + (long long)(near ? reflect101_near(yq, Lh) : reflect101(yq, Lh)) * pitch;
+#pragma unroll
+      for (int i = 0; i < 7; i++) px[u][i] = row[xi[i]];
+    }
+#pragma unroll
+    for (int u = 0; u < RB; u++) {
+      const int yy = yb + u;
+      if (yy >= y1 + 3) break;
+      const int hsum = 18 * (px[u][0] + px[u][6]) + 34 * (px[u][1] + px[u][5]) + 49 * (px[u][2] + px[u][4]) + 55 * px[u][3];
+#pragma unroll
+      for (int j = 0; j < 6; j++) hw[j] = hw[j + 1];
+      hw[6] = hsum;
+      if (yy >= y0 + 3) {
+        const int acc = 18 * (hw[0] + hw[6]) + 34 * (hw[1] + hw[5]) + 49 * (hw[2] + hw[4]) + 55 * hw[3];
+        dst[(long long)(yy - 3) * Lpitch + x] = (uint8_t)min((acc + (1 << 15)) >> 16, 255);
+      }
     }
   }
 }
