@@ -6,9 +6,13 @@ FETCH_SIZE under-reports wide streaming reads by 2x (MI355X_MICROARCH.md, HBM se
 kept and `traffic` uses raw read + write (a lower bound)."""
 import collections, csv, glob, json, sys
 fetch_dir, write_dir, out = sys.argv[1], sys.argv[2], sys.argv[3]
-STAGE = {"k_resize4": "pyramid", "k_resize": "pyramid", "k_fast_cells": "fast", "k_octree": "octree",
-         "k_blur_strips": "blur", "k_blur_border": "blur", "k_blur": "blur", "k_describe": "describe",
-         "k_hamming": "hamming"}
+STAGES = (("k_resize", "pyramid"), ("k_fast", "fast"), ("k_octree", "octree"), ("k_blur", "blur"),
+          ("k_describe", "describe"), ("k_hamming", "hamming"))
+def stage_of(kernel):  # template instances appear as "void k_fast_wave<48>"
+    for key, st in STAGES:
+        if key in kernel:
+            return st
+    return None
 def load(d, counter):
     f = glob.glob(d + "/**/*counter_collection.csv", recursive=True)[0]
     acc = collections.defaultdict(list)
@@ -19,14 +23,14 @@ def load(d, counter):
         acc[name].append(float(r["Counter_Value"]) * 1024.0)
     return acc
 fe, wr = load(fetch_dir, "FETCH_SIZE"), load(write_dir, "WRITE_SIZE")
-steps = len(fe.get("k_fast_cells", [1]))
+steps = max([len(v) for k, v in fe.items() if "k_describe" in k] + [1])
 res = {"_note": "bytes per bench step (one launch of each stage over the whole batch); read figure raw",
        "_steps_profiled": steps}
 detail = {}
 for k in set(fe) | set(wr):
-    if k not in STAGE:
+    st = stage_of(k)
+    if st is None:
         continue
-    st = STAGE[k]
     rd = sum(fe.get(k, [0])) / steps
     w = sum(wr.get(k, [0])) / steps
     d = detail.setdefault(st, {"read": 0.0, "write": 0.0})

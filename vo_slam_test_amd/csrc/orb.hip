@@ -1043,8 +1043,18 @@ __global__ __launch_bounds__(256) void k_describe(OrbDev P, FrameSrc src, const 
                                                   int sel_per_frame, const int *off, int capacity,
                                                   vo_keypoint *kps, uint8_t *desc) {
   const int lane = threadIdx.x & 63;
-  const int g = blockIdx.x * 4 + (threadIdx.x >> 6);
+  // wave-uniform key-point index: level search, geometry and the selected key all stay in scalar
+  // registers / scalar loads
+  const int g = blockIdx.x * 4 + __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
   const int f = blockIdx.y;
+  // the two per-lane tables do not depend on the key-point: fetch them first, under the offset / key
+  // round trips (the disc: pixel lane + 64 i, entries >= n_disc are (0,0) with weight 0)
+  unsigned short dw[12];
+#pragma unroll
+  for (int i = 0; i < 12; i++) dw[i] = reinterpret_cast<const unsigned short *>(c_disc)[lane + 64 * i];
+  uint32_t pat[4];
+#pragma unroll
+  for (int k = 0; k < 4; k++) pat[k] = reinterpret_cast<const uint32_t *>(c_pattern)[lane + 64 * k];  // x0,y0,x1,y1 as int8
   const int *op = off + f * (P.nlevels + 1);
   int o[kMaxLevels + 1];  // all level offsets in flight at once (a dependent scan costs a round trip per level)
 #pragma unroll
@@ -1067,10 +1077,7 @@ __global__ __launch_bounds__(256) void k_describe(OrbDev P, FrameSrc src, const 
   {
     int uu[12], vv[12], val[12];
 #pragma unroll
-    for (int i = 0; i < 12; i++) {  // disc pixel lane + 64 i; entries >= n_disc are (0,0) with weight 0
-      const unsigned short w = reinterpret_cast<const unsigned short *>(c_disc)[lane + 64 * i];
-      uu[i] = (int8_t)(w & 0xff), vv[i] = (int8_t)(w >> 8);
-    }
+    for (int i = 0; i < 12; i++) uu[i] = (int8_t)(dw[i] & 0xff), vv[i] = (int8_t)(dw[i] >> 8);
 #pragma unroll
     for (int i = 0; i < 12; i++) val[i] = center[(long long)vv[i] * pitch + uu[i]];
 #pragma unroll
@@ -1088,19 +1095,21 @@ __global__ __launch_bounds__(256) void k_describe(OrbDev P, FrameSrc src, const 
   const float factorPI = (float)(3.14159265358979323846 / 180.f);  // :109
   float a, b;
   cos_sin_f(angle * factorPI, a, b);
-  const uint8_t *bc = src.blur + (long long)f * src.blur_frame_stride + L.blur_off + (long long)py * L.pitch + px;
+  const int Lpitch = L.pitch;
+  const uint8_t *bc = src.blur + (long long)f * src.blur_frame_stride + L.blur_off + (long long)py * Lpitch + px;
   unsigned long long words[4];
+  int t0[4], t1[4];
 #pragma unroll
   for (int k = 0; k < 4; k++) {
-    const int t = lane + 64 * k;
-    const uint32_t pw = reinterpret_cast<const uint32_t *>(c_pattern)[t];  // x0,y0,x1,y1 as int8
+    const uint32_t pw = pat[k];
     const float x0 = (float)(int8_t)(pw & 0xff), y0 = (float)(int8_t)((pw >> 8) & 0xff);
     const float x1 = (float)(int8_t)((pw >> 16) & 0xff), y1 = (float)(int8_t)(pw >> 24);
     const int r0 = __float2int_rn(x0 * b + y0 * a), q0 = __float2int_rn(x0 * a - y0 * b);
     const int r1 = __float2int_rn(x1 * b + y1 * a), q1 = __float2int_rn(x1 * a - y1 * b);
-    const int t0 = bc[(long long)r0 * L.pitch + q0], t1 = bc[(long long)r1 * L.pitch + q1];
-    words[k] = __ballot(t0 < t1);
+    t0[k] = bc[r0 * Lpitch + q0], t1[k] = bc[r1 * Lpitch + q1];  // all eight loads in flight
   }
+#pragma unroll
+  for (int k = 0; k < 4; k++) words[k] = __ballot(t0[k] < t1[k]);
   const long long oi = (long long)f * capacity + g;
   if (lane < 4) reinterpret_cast<unsigned long long *>(desc + oi * 32)[lane] = words[lane];
   if (lane == 0) {
