@@ -7,16 +7,17 @@
 // (accept / reject, radius, convergence) live in a small state struct in HBM, so the host never
 // synchronises inside a solve and a multi-GPU driver only inserts two all-reduces per iteration.
 //
-//   k_ba_points   8 lanes per map point: residuals + Jacobians of its edges, point block Hll/gl,
-//                 LM-damped inverse, and the rows of the two K-major operand matrices
-//                 Wt[3j+k][6c+a] = W_cj[a][k] (camera-unscaled), Yt = W * Hll^-1
-//   k_ba_cams     camera blocks Hpp/gp by segmented reduction over each camera's edge list
-//   k_ba_gemm     Schur product  Y * W^T  (6nf x 3Np x 6nf) on the FP64 matrix cores
-//                 (v_mfma_f64_16x16x4_f64), split-K partial tiles
-//   k_ba_reduce   fixed-order sum of the partial slabs into the all-reduce payload
-//   k_ba_solve    one workgroup: reduced camera system, Cholesky in LDS, step, candidate poses
-//   k_ba_backsub  back-substitution, candidate points, candidate cost
-//   k_ba_update   trust-region bookkeeping
+//   k_ba_setup    start of a solve: edge activity -> problem membership (epoch stamps), optional
+//                 chi2 classification, LM state reset, pose caches
+//   k_ba_lin0     first linearisation: 16 lanes per map point evaluate its edges -> point block
+//                 Hll/gl, Jacobi scale, rows of the K-major operand matrix Wt[3j+k][6c+a]
+//   k_ba_gemm     Schur product  (W Hll^-1) W^T  (6nf x 3Np x 6nf) on the FP64 matrix cores
+//                 (v_mfma_f64_16x16x4_f64), short K slices; extra blocks: camera blocks Hpp/gp
+//   k_ba_reduce   (sharded) fixed-order sum of the partial slabs into the all-reduce payload
+//   k_ba_solve    one workgroup: reduced camera system, blocked LDL^T in LDS, step, candidate poses
+//   k_ba_backsub  back-substitution, candidate points, linearisation at the candidate, its cost;
+//                 single GPU: the last block also runs the trust-region update
+//   k_ba_reduce2 / k_ba_update  (sharded) second payload and trust-region bookkeeping
 #include "ba_math.h"
 #include "vo_common.h"
 
@@ -441,7 +442,7 @@ __device__ __forceinline__ int payload_cost_off(const BaDev &B) { return B.Mpad 
 // point, Ceres' loss correction, the e-block E^T E + D and its inverse (SchurEliminator), and this
 // point's rows of the GEMM operands.
 // --------------------------------------------------------------------------------------------
-// Linearisation of one map point at (point position `pt`, camera caches `PCs`) by the 8 lanes of
+// Linearisation of one map point at (point position `pt`, camera caches `PCs`) by the kGroup lanes of
 // its group: point block Hll (unscaled) and gradient, Jacobi scale (first linearisation of a
 // solve), and the point's rows of the K-major operand matrix W (point-scaled).  Nothing here
 // depends on the trust-region radius, so the same routine linearises the *candidate* inside the
@@ -489,7 +490,7 @@ __device__ __forceinline__ void point_linearize(const BaDev &B, const BaState &s
           Wt[base + k * B.Mpad + a] = rho1 * (Jp[a] * Jl[k] + Jp[6 + a] * Jl[3 + k] + Jp[12 + a] * Jl[6 + k]) * sp[k];
     }
   }
-  // butterfly over the 8 lanes of the group: every lane ends with the totals
+  // butterfly over the lanes of the group: every lane ends with the totals
 #pragma unroll
   for (int o = 1; o < kGroup; o <<= 1) {
 #pragma unroll
