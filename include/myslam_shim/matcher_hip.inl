@@ -1,9 +1,9 @@
 // include/myslam_shim/matcher_hip.inl -- replacement bodies for the hot members of myslam::Matcher
 // (reference src/matcher.cpp).  #include this file at the bottom of a copy of matcher.cpp from which
 // computeDistance (:1240-1256), the projection searches (:18-148, :150-272, :274-353), the two
-// searchByBoW overloads (:449-559, :561-677), searchForTriangulation (:867-1010) and fuseMapPoints
-// (:1012-1133) were removed; the Sim3 members (:356-447, :679-865, :1135-1238) keep calling
-// Matcher::computeDistance.
+// searchByBoW overloads (:449-559, :561-677), searchForTriangulation (:867-1010), fuseMapPoints
+// (:1012-1133) and the loop-closure members (:356-447, :679-865, :1135-1238) were removed, i.e. every
+// member of Matcher except the constructor and computeThreeMax.
 //
 // Needs the reference's headers (Frame, MapPoint, Camera): compile inside the reference tree.
 #include <vector>
@@ -273,6 +273,156 @@ int Matcher::fuseMapPoints(KeyFrame *kf, vector<MapPoint *> &mappoints, const fl
     cnt++;
   }
   return cnt;
+}
+
+// projection of a map point under a similarity / rigid pose with the gates shared by the loop-closure
+// members (:380-406, :1163-1187): z >= 0, inside the image, distance range, viewing angle
+struct LoopQuery {
+  std::vector<uint8_t> flags, desc;
+  std::vector<float> u, v;
+  std::vector<int32_t> level;
+  explicit LoopQuery(int n) : flags(n, 0), desc((size_t)n * 32, 0), u(n), v(n), level(n) {}
+  void set(int i, MapPoint *mp, float uu, float vv, int lvl) {
+    flags[i] = 1, u[i] = uu, v[i] = vv, level[i] = lvl;
+    memcpy(&desc[(size_t)i * 32], mp->getDescriptor().data, 32);
+  }
+};
+
+// Matcher::searchByProjection(KeyFrame*, Sim3&, loopMapPoints, matchMapPoints, th), :356-447
+int Matcher::searchByProjection(KeyFrame *kf, Sophus::Sim3 &Scw, vector<MapPoint *> &loopMapPoints,
+                                vector<MapPoint *> &matchMapPoints, int th) {
+  Camera *cam = kf->camera_;
+  const double scale = Scw.scale();
+  const Eigen::Matrix3d Rcw = Scw.rotation_matrix() / scale;
+  const Vector3d tcw = Scw.translation() / scale, Ow = -Rcw.transpose() * tcw;
+  set<MapPoint *> found(matchMapPoints.begin(), matchMapPoints.end());
+  found.erase(static_cast<MapPoint *>(nullptr));
+  const int nq = (int)loopMapPoints.size();
+  LoopQuery q(nq);
+  for (int i = 0; i < nq; i++) {
+    MapPoint *mp = loopMapPoints[i];
+    if (!mp || mp->isBad() || found.count(mp)) continue;
+    const Vector3d pc = Rcw * mp->getPose() + tcw;
+    const float z = static_cast<float>(pc[2]);
+    if (z < 0) continue;
+    const float invz = 1.0f / z;
+    const float uu = cam->fx_ * (static_cast<float>(pc[0]) * invz) + cam->cx_;
+    const float vv = cam->fy_ * (static_cast<float>(pc[1]) * invz) + cam->cy_;
+    if (!kf->isInImg(uu, vv)) continue;
+    const Vector3d line = mp->getPose() - Ow;
+    const float dist = line.norm();
+    if (dist < mp->getMinDistanceThreshold() || dist > mp->getMaxDistanceThreshold()) continue;
+    if (line.dot(mp->getNormalVector()) < 0.5 * dist) continue;
+    q.set(i, mp, uu, vv, mp->predictScale(dist, kf));
+  }
+  FrameFlat ff(kf);
+  std::vector<uint8_t> occupied(ff.view.n);
+  for (int k = 0; k < ff.view.n; k++) occupied[k] = matchMapPoints[k] != nullptr;
+  std::vector<int32_t> assigned(ff.view.n, -1);
+  int n = 0;
+  vo_match_sim3_projection(&ff.view, nq, q.flags.data(), q.u.data(), q.v.data(), q.level.data(), q.desc.data(), th,
+                           kf->scaleFactors_.data(), occupied.data(), assigned.data(), &n);
+  for (int k = 0; k < ff.view.n; k++)
+    if (assigned[k] >= 0) matchMapPoints[k] = loopMapPoints[assigned[k]];
+  return n;
+}
+
+// Matcher::searchBySim3, :679-865
+int Matcher::searchBySim3(KeyFrame *kf1, KeyFrame *kf2, vector<MapPoint *> &matches12, Sophus::Sim3 &S12,
+                          const float th) {
+  Camera *cam = kf1->camera_;
+  const vector<MapPoint *> mps1 = kf1->getMapPoints(), mps2 = kf2->getMapPoints();
+  const int N1 = (int)mps1.size(), N2 = (int)mps2.size();
+  std::vector<bool> matched1(N1, false), matched2(N2, false);
+  const SE3 Tcw1 = kf1->getPose(), Tcw2 = kf2->getPose();
+  const Sophus::Sim3 S21 = S12.inverse();
+  for (int i = 0; i < N1; i++)
+    if (MapPoint *mp = matches12[i]) {
+      matched1[i] = true;
+      const int idx2 = mp->getIndexInKeyFrame(kf2);
+      if (idx2 >= 0 && idx2 < N2) matched2[idx2] = true;
+    }
+  LoopQuery q1(N1), q2(N2);
+  auto project = [&](const Vector3d &p, KeyFrame *into, bool strict, float &uu, float &vv, float &dist) {
+    const float z = static_cast<float>(p[2]);
+    if (strict ? z <= 0 : z < 0) return false;  // :729 uses `<`, :797 uses `<=`
+    const float invz = 1.0f / z;
+    uu = cam->fx_ * (static_cast<float>(p[0]) * invz) + cam->cx_;
+    vv = cam->fy_ * (static_cast<float>(p[1]) * invz) + cam->cy_;
+    dist = p.norm();
+    return into->isInImg(uu, vv);
+  };
+  for (int i = 0; i < N1; i++) {
+    MapPoint *mp = mps1[i];
+    if (!mp || matched1[i] || mp->isBad()) continue;
+    float uu, vv, d;
+    if (!project(S21 * (Tcw1 * mp->pos_), kf2, false, uu, vv, d)) continue;
+    if (d < mp->getMinDistanceThreshold() || d > mp->getMaxDistanceThreshold()) continue;
+    q1.set(i, mp, uu, vv, mp->predictScale(d, kf2));
+  }
+  for (int j = 0; j < N2; j++) {
+    MapPoint *mp = mps2[j];
+    if (!mp || matched2[j]) continue;
+    float uu, vv, d;
+    if (!project(S12 * (Tcw2 * mp->pos_), kf1, true, uu, vv, d)) continue;
+    if (d < mp->getMinDistanceThreshold() || d > mp->getMaxDistanceThreshold()) continue;
+    q2.set(j, mp, uu, vv, mp->predictScale(d, kf1));
+  }
+  FrameFlat f1(kf1), f2(kf2);
+  std::vector<int32_t> m12(N1, -1);
+  int n = 0;
+  vo_match_sim3_mutual(&f1.view, &f2.view, q1.flags.data(), q1.u.data(), q1.v.data(), q1.level.data(), q1.desc.data(),
+                       q2.flags.data(), q2.u.data(), q2.v.data(), q2.level.data(), q2.desc.data(), th,
+                       kf1->scaleFactors_.data(), kf2->scaleFactors_.data(), m12.data(), &n);
+  for (int i = 0; i < N1; i++)
+    if (m12[i] >= 0) matches12[i] = mps2[m12[i]];
+  return n;
+}
+
+// Matcher::fuseByPose, :1135-1238 (matching as one batch, mutation :1215-1230 replayed in list order)
+int Matcher::fuseByPose(KeyFrame *kf, Sophus::Sim3 &Scw, vector<MapPoint *> &loopMapPoints,
+                        vector<MapPoint *> &replaceMapPoints, const float th) {
+  Camera *cam = kf->camera_;
+  const SE3 Tcw(Scw.rotation_matrix(), Scw.translation());
+  const Vector3d Ow = -Tcw.rotation_matrix().transpose() * Tcw.translation();
+  set<MapPoint *> found;
+  for (MapPoint *mp : kf->mappoints_)
+    if (mp && !mp->isBad()) found.insert(mp);
+  const int nq = (int)loopMapPoints.size();
+  LoopQuery q(nq);
+  for (int i = 0; i < nq; i++) {
+    MapPoint *mp = loopMapPoints[i];
+    if (!mp || mp->isBad() || found.count(mp)) continue;
+    const Vector3d pc = Tcw * mp->getPose();
+    const float z = static_cast<float>(pc[2]);
+    if (z < 0) continue;
+    const float invz = 1.0f / z;
+    const float uu = cam->fx_ * (static_cast<float>(pc[0]) * invz) + cam->cx_;
+    const float vv = cam->fy_ * (static_cast<float>(pc[1]) * invz) + cam->cy_;
+    if (!kf->isInImg(uu, vv)) continue;
+    const Vector3d line = mp->getPose() - Ow;
+    const float dist = line.norm();
+    if (dist < mp->getMinDistanceThreshold() || dist > mp->getMaxDistanceThreshold()) continue;
+    if (line.dot(mp->getNormalVector()) < 0.5 * dist) continue;
+    q.set(i, mp, uu, vv, mp->predictScale(dist, kf));
+  }
+  FrameFlat ff(kf);
+  std::vector<int32_t> best(nq, -1);
+  int n = 0, fused = 0;
+  vo_match_area_best(&ff.view, nq, q.flags.data(), q.u.data(), q.v.data(), q.level.data(), q.desc.data(), th,
+                     kf->scaleFactors_.data(), 50, best.data(), &n);
+  for (int i = 0; i < nq; i++) {
+    if (best[i] < 0) continue;
+    MapPoint *mp = loopMapPoints[i], *mpKF = kf->mappoints_[best[i]];
+    if (mpKF) {
+      if (!mpKF->isBad()) replaceMapPoints[i] = mpKF;
+    } else {
+      mp->addObservation(kf, best[i]);
+      kf->addMapPoint(mp, best[i]);
+    }
+    fused++;
+  }
+  return fused;
 }
 
 }  // namespace myslam

@@ -203,6 +203,36 @@ int vo_match_fuse(const vo_frame_view *kf, int nq, const uint8_t *q_flags, const
                   const float *q_v, const float *q_ur, const int32_t *q_level, const uint8_t *q_desc,
                   float threshold, const float *scale_factors, int32_t *best_idx, int *n_matches);
 
+/* Loop-closure searches.  All three project map points into a key-frame and take, per point, the
+ * best Hamming match among KeyFrame::getFeaturesInArea(u, v, th * scale[level]) with octave in
+ * [level - 1, level]; flag bit 0 of a query = it passed the projection gates of the routine.
+ *
+ * vo_match_area_best: queries independent -- the inner search of Matcher::searchBySim3
+ * (matcher.cpp:756-786, 821-851; max_dist = 100) and of Matcher::fuseByPose (:1196-1213;
+ * max_dist = 50; the map mutation :1215-1230 stays in the shim). */
+int vo_match_area_best(const vo_frame_view *kf, int nq, const uint8_t *q_flags, const float *q_u,
+                       const float *q_v, const int32_t *q_level, const uint8_t *q_desc, float th,
+                       const float *scale_factors, int max_dist, int32_t *best_idx, int *n_matches);
+
+/* Matcher::searchByProjection(KeyFrame*, Sim3&, loopMapPoints, matchMapPoints, th)
+ * (matcher.cpp:356-447).  occupied[kf.n]: matchMapPoints[k] non-null on entry; assigned[kf.n] =
+ * query that claimed the feature, or -1.  The reference's skip test `matchMapPoints[j]` (:422)
+ * indexes with the candidate counter, not the feature index; reproduced. */
+int vo_match_sim3_projection(const vo_frame_view *kf, int nq, const uint8_t *q_flags, const float *q_u,
+                             const float *q_v, const int32_t *q_level, const uint8_t *q_desc, int th,
+                             const float *scale_factors, const uint8_t *occupied, int32_t *assigned,
+                             int *n_matches);
+
+/* Matcher::searchBySim3 (matcher.cpp:679-865): q1 = map point of feature i of key-frame 1 projected
+ * into key-frame 2 (flag 0 also for features without a usable point or already matched, :722-727),
+ * q2 the reverse; match12[kf1.n] = feature of key-frame 2, kept only when both directions agree. */
+int vo_match_sim3_mutual(const vo_frame_view *kf1, const vo_frame_view *kf2, const uint8_t *q1_flags,
+                         const float *q1_u, const float *q1_v, const int32_t *q1_level, const uint8_t *q1_desc,
+                         const uint8_t *q2_flags, const float *q2_u, const float *q2_v,
+                         const int32_t *q2_level, const uint8_t *q2_desc, float th,
+                         const float *scale_factors1, const float *scale_factors2, int32_t *match12,
+                         int *n_matches);
+
 /* ------------------------------------------------------------------------------------------
  * Optimizer  --  replaces myslam::Optimizer (include/myslam/optimizer_ceres.h:12-97,
  * src/optimizer_ceres.cpp) including the Ceres solve it delegates to.

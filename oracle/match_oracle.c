@@ -502,3 +502,96 @@ int orc_match_fuse(const orc_frame *kf, int nq, const uint8_t *q_valid, const fl
   free(cand);
   return cnt;
 }
+
+/* ---- Sim3 / loop-closure searches (M4, M7, M10) ------------------------------------------------
+ * All three project map points into a key-frame and take, per point, the best Hamming match among
+ * the features of KeyFrame::getFeaturesInArea(u, v, th * scale[level_predict]) whose octave is in
+ * [level_predict - 1, level_predict].  The caller supplies the projections (flag bit 0 = the gates
+ * of matcher.cpp:380-406 / 728-754 / 1163-1187 passed). */
+
+/* best feature per query, queries independent: the inner search of searchBySim3 (matcher.cpp:756-786,
+ * 821-851; max_dist = TH_HIGH) and of fuseByPose (:1196-1213; max_dist = TH_LOW) */
+int orc_match_area_best(const orc_frame *kf, int nq, const uint8_t *q_valid, const float *q_u,
+                        const float *q_v, const int32_t *q_level, const uint8_t *q_desc, float th,
+                        const float *scale_factors, int max_dist, int32_t *best_idx) {
+  int cnt = 0;
+  int *cand = (int *)malloc(sizeof(int) * (kf->n > 0 ? kf->n : 1));
+  for (int i = 0; i < nq; i++) {
+    best_idx[i] = -1;
+    if (!(q_valid[i] & 1)) continue;
+    const int lp = q_level[i];
+    const float radius = th * scale_factors[lp];
+    const int nc = orc_features_in_area(kf, q_u[i], q_v[i], radius, -1000, 1000, cand, kf->n);
+    int bestDist = 256, bidx = -1;
+    for (int j = 0; j < nc; j++) {
+      const int idx = cand[j];
+      if (kf->octave[idx] < lp - 1 || kf->octave[idx] > lp) continue;
+      const int d = orc_hamming256(q_desc + (size_t)i * 32, kf->desc + (size_t)idx * 32);
+      if (d < bestDist) bestDist = d, bidx = idx;
+    }
+    if (bestDist <= max_dist) {
+      best_idx[i] = bidx;
+      cnt++;
+    }
+  }
+  free(cand);
+  return cnt;
+}
+
+/* Matcher::searchByProjection(KeyFrame*, Sim3&, loopMapPoints, matchMapPoints, th), matcher.cpp:356-447.
+ * occupied[k] != 0 <=> matchMapPoints[k] is non-null on entry; assigned[k] = query that claimed
+ * feature k during the call.  Q-M1 (:422): the skip test indexes matchMapPoints with the
+ * CANDIDATE COUNTER j, not with the feature index -- reproduced literally. */
+int orc_match_sim3_projection(const orc_frame *kf, int nq, const uint8_t *q_valid, const float *q_u,
+                              const float *q_v, const int32_t *q_level, const uint8_t *q_desc, int th,
+                              const float *scale_factors, const uint8_t *occupied, int32_t *assigned) {
+  int cnt = 0;
+  int *cand = (int *)malloc(sizeof(int) * (kf->n > 0 ? kf->n : 1));
+  uint8_t *occ = (uint8_t *)malloc(kf->n > 0 ? kf->n : 1);
+  for (int k = 0; k < kf->n; k++) occ[k] = occupied ? occupied[k] : 0, assigned[k] = -1;
+  for (int i = 0; i < nq; i++) {
+    if (!(q_valid[i] & 1)) continue;
+    const int lp = q_level[i];
+    const float radius = (float)th * scale_factors[lp];
+    const int nc = orc_features_in_area(kf, q_u[i], q_v[i], radius, -1000, 1000, cand, kf->n);
+    int bestDist = 256, bidx = -1;
+    for (int j = 0; j < nc; j++) {
+      const int idx = cand[j];
+      if (occ[j]) continue; /* Q-M1 */
+      if (kf->octave[idx] < lp - 1 || kf->octave[idx] > lp) continue;
+      const int d = orc_hamming256(q_desc + (size_t)i * 32, kf->desc + (size_t)idx * 32);
+      if (d < bestDist) bestDist = d, bidx = idx;
+    }
+    if (bestDist <= TH_LOW) {
+      occ[bidx] = 1; /* matchMapPoints[bestIdx] = mp (:439); a second claim overwrites the first */
+      assigned[bidx] = i;
+      cnt++;
+    }
+  }
+  free(cand);
+  free(occ);
+  return cnt;
+}
+
+/* Matcher::searchBySim3, matcher.cpp:679-865: q1 = map points of key-frame 1 projected into key-frame
+ * 2 (:722-754), q2 the reverse (:790-819); a pair survives when both directions agree (:853-864).
+ * match12[i] = feature of key-frame 2 matched to feature i of key-frame 1, or -1. */
+int orc_match_sim3_mutual(const orc_frame *kf1, const orc_frame *kf2, const uint8_t *q1_valid,
+                          const float *q1_u, const float *q1_v, const int32_t *q1_level,
+                          const uint8_t *q1_desc, const uint8_t *q2_valid, const float *q2_u,
+                          const float *q2_v, const int32_t *q2_level, const uint8_t *q2_desc, float th, const float *scale_factors1,
+                          const float *scale_factors2, int32_t *match12) {
+  int32_t *m1 = (int32_t *)malloc(sizeof(int32_t) * (kf1->n > 0 ? kf1->n : 1));
+  int32_t *m2 = (int32_t *)malloc(sizeof(int32_t) * (kf2->n > 0 ? kf2->n : 1));
+  orc_match_area_best(kf2, kf1->n, q1_valid, q1_u, q1_v, q1_level, q1_desc, th, scale_factors2, TH_HIGH, m1);
+  orc_match_area_best(kf1, kf2->n, q2_valid, q2_u, q2_v, q2_level, q2_desc, th, scale_factors1, TH_HIGH, m2);
+  int found = 0;
+  for (int i = 0; i < kf1->n; i++) {
+    match12[i] = -1;
+    const int idx2 = m1[i];
+    if (idx2 >= 0 && m2[idx2] == i) match12[i] = idx2, found++;
+  }
+  free(m1);
+  free(m2);
+  return found;
+}

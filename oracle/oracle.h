@@ -144,6 +144,18 @@ int orc_match_fuse(const orc_frame *kf, int nq, const uint8_t *q_valid, const fl
                    const float *q_v, const float *q_ur, const int32_t *q_level, const uint8_t *q_desc,
                    float threshold, const float *scale_factors, int32_t *best_idx);
 
+int orc_match_area_best(const orc_frame *kf, int nq, const uint8_t *q_valid, const float *q_u,
+                        const float *q_v, const int32_t *q_level, const uint8_t *q_desc, float th,
+                        const float *scale_factors, int max_dist, int32_t *best_idx);
+int orc_match_sim3_projection(const orc_frame *kf, int nq, const uint8_t *q_valid, const float *q_u,
+                              const float *q_v, const int32_t *q_level, const uint8_t *q_desc, int th,
+                              const float *scale_factors, const uint8_t *occupied, int32_t *assigned);
+int orc_match_sim3_mutual(const orc_frame *kf1, const orc_frame *kf2, const uint8_t *q1_valid,
+                          const float *q1_u, const float *q1_v, const int32_t *q1_level,
+                          const uint8_t *q1_desc, const uint8_t *q2_valid, const float *q2_u,
+                          const float *q2_v, const int32_t *q2_level, const uint8_t *q2_desc, float th, const float *scale_factors1,
+                          const float *scale_factors2, int32_t *match12);
+
 /* ---------------- Optimizer (reference optimizer_ceres.{h,cpp}) --------------- */
 
 void orc_se3_exp(const double xi[6], double q[4] /*w,x,y,z*/, double t[3]); /* Sophus SE3::exp */

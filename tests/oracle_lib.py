@@ -130,6 +130,13 @@ def lib():
     L.orc_match_triangulation.restype = C.c_int
     L.orc_match_fuse.argtypes = [C.POINTER(Frame), C.c_int, _u8p, _f32p, _f32p, _f32p, _i32p, _u8p, C.c_float, _f32p, _i32p]
     L.orc_match_fuse.restype = C.c_int
+    L.orc_match_area_best.argtypes = [C.POINTER(Frame), C.c_int, _u8p, _f32p, _f32p, _i32p, _u8p, C.c_float, _f32p, C.c_int, _i32p]
+    L.orc_match_area_best.restype = C.c_int
+    L.orc_match_sim3_projection.argtypes = [C.POINTER(Frame), C.c_int, _u8p, _f32p, _f32p, _i32p, _u8p, C.c_int, _f32p, _u8p, _i32p]
+    L.orc_match_sim3_projection.restype = C.c_int
+    L.orc_match_sim3_mutual.argtypes = [C.POINTER(Frame), C.POINTER(Frame), _u8p, _f32p, _f32p, _i32p, _u8p, _u8p, _f32p, _f32p,
+                                        _i32p, _u8p, C.c_float, _f32p, _f32p, _i32p]
+    L.orc_match_sim3_mutual.restype = C.c_int
     L.orc_se3_exp.argtypes = [_f64p, _f64p, _f64p]
     L.orc_se3_log.argtypes = [_f64p, _f64p, _f64p]
     L.orc_se3_plus.argtypes = [_f64p, _f64p, _f64p]

@@ -223,3 +223,73 @@ def test_new_matchers_empty_inputs(vo):
     q = dict(flags=z8, u=e, v=e, ur=e, level=np.zeros(0, np.int32), angle=e, desc=np.zeros((0, 32), np.uint8))
     assert m.fuseMapPoints_match(empty, q, 3.0, np.ones(8, np.float32))[0] == 0
     assert m.searchByProjection_keyframe(empty, q, 10.0, 64.0, True, np.ones(8, np.float32))[0] == 0
+
+
+# ------------------------------------------------------------------ M4 / M7 / M10 (loop closure)
+
+def _loop_queries(k_from, d_from, dx, dy, seed, drop=0.1, jitter=1.0):
+    rng = np.random.default_rng(seed)
+    n = len(k_from)
+    return dict(flags=(rng.random(n) > drop).astype(np.uint8),
+                u=(k_from["x"] + dx + rng.normal(0, jitter, n)).astype(np.float32),
+                v=(k_from["y"] + dy + rng.normal(0, jitter, n)).astype(np.float32),
+                level=np.clip(k_from["octave"] + rng.integers(0, 2, n), 0, 7).astype(np.int32),
+                desc=np.ascontiguousarray(d_from))
+
+
+@pytest.mark.parametrize("idx,max_dist,th", [(0, 100, 7.5), (1, 50, 4.0), (2, 50, 3.0)])
+def test_area_best(vo, orc, idx, max_dist, th):
+    import ctypes as C
+    k0, d0, k1, d1, dx, dy = _frame_pair(orc, idx)
+    ur1, _ = _uright(k1, idx)
+    sf = np.array(list(orc.orb_params().scale)[:8], np.float32)
+    q = _loop_queries(k0, d0, dx, dy, idx + 21)
+    kf = vo.FrameArrays(k1["x"], k1["y"], k1["octave"], k1["angle"], ur1, d1)
+    n, best = vo.Matcher(0.8).areaBest(kf, q, th, sf, max_dist)
+    of = orc.FrameData(k1["x"], k1["y"], k1["octave"], k1["angle"], ur1, d1)
+    ob = np.full(len(k0), -1, np.int32)
+    on = orc.lib().orc_match_area_best(C.byref(of.c), len(k0), q["flags"], q["u"], q["v"], q["level"], q["desc"], th, sf,
+                                       max_dist, ob)
+    assert n == on and n > 100
+    assert np.array_equal(best, ob)
+
+
+@pytest.mark.parametrize("idx,th", [(0, 10), (1, 3), (3, 5)])
+def test_search_by_projection_sim3(vo, orc, idx, th):
+    import ctypes as C
+    k0, d0, k1, d1, dx, dy = _frame_pair(orc, idx)
+    ur1, _ = _uright(k1, idx)
+    sf = np.array(list(orc.orb_params().scale)[:8], np.float32)
+    q = _loop_queries(k0, d0, dx, dy, idx + 23)
+    occ = (np.random.default_rng(idx + 29).random(len(k1)) < 0.15).astype(np.uint8)   # exercises the :422 quirk
+    kf = vo.FrameArrays(k1["x"], k1["y"], k1["octave"], k1["angle"], ur1, d1)
+    n, assigned = vo.Matcher(0.8).searchByProjection_sim3(kf, q, th, sf, occ)
+    of = orc.FrameData(k1["x"], k1["y"], k1["octave"], k1["angle"], ur1, d1)
+    oa = np.full(len(k1), -1, np.int32)
+    on = orc.lib().orc_match_sim3_projection(C.byref(of.c), len(k0), q["flags"], q["u"], q["v"], q["level"], q["desc"],
+                                             th, sf, occ, oa)
+    assert n == on and n > 100
+    assert np.array_equal(assigned, oa)
+
+
+@pytest.mark.parametrize("idx", [0, 2])
+def test_search_by_sim3(vo, orc, idx):
+    import ctypes as C
+    k0, d0, k1, d1, dx, dy = _frame_pair(orc, idx)
+    ur0, _ = _uright(k0, idx)
+    ur1, _ = _uright(k1, idx + 1)
+    sf = np.array(list(orc.orb_params().scale)[:8], np.float32)
+    q1 = _loop_queries(k0, d0, dx, dy, idx + 31)       # points of key-frame 1 seen from key-frame 2
+    q2 = _loop_queries(k1, d1, -dx, -dy, idx + 37)     # and the reverse
+    A = vo.FrameArrays(k0["x"], k0["y"], k0["octave"], k0["angle"], ur0, d0)
+    B = vo.FrameArrays(k1["x"], k1["y"], k1["octave"], k1["angle"], ur1, d1)
+    n, m12 = vo.Matcher(0.8).searchBySim3(A, B, q1, q2, 7.5, sf, sf)
+    oA = orc.FrameData(k0["x"], k0["y"], k0["octave"], k0["angle"], ur0, d0)
+    oB = orc.FrameData(k1["x"], k1["y"], k1["octave"], k1["angle"], ur1, d1)
+    om = np.full(len(k0), -1, np.int32)
+    on = orc.lib().orc_match_sim3_mutual(C.byref(oA.c), C.byref(oB.c), q1["flags"], q1["u"], q1["v"], q1["level"], q1["desc"],
+                                         q2["flags"], q2["u"], q2["v"], q2["level"], q2["desc"], 7.5, sf, sf, om)
+    assert n == on and n > 100
+    assert np.array_equal(m12, om)
+    sel = np.nonzero(m12 >= 0)[0]
+    assert len(np.unique(m12[sel])) == len(sel)      # mutual agreement makes the map injective

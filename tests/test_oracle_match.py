@@ -185,3 +185,35 @@ def test_keyframe_matcher_fixture(orc):
     cnt = L.orc_match_fuse(C.byref(B.c), n, 1 - fa, g3["q_u"], g3["q_v"], g["q_ur"], g["q_level"],
                            np.ascontiguousarray(g3["d0"]), 3.0, g3["scale"], m)
     assert cnt == int(g["fuse_n"]) and np.array_equal(m, g["fuse"])
+
+
+def test_oracle_loop_closure_searches(orc):
+    """M4 / M7 / M10 restatements: the shift is recovered; the candidate-counter skip of :422 is live"""
+    import ctypes as C
+    k0, d0, k1, d1, dx, dy = _pair(orc, 2)
+    sf = np.array(list(orc.orb_params().scale)[:8], np.float32)
+    n0, n1 = len(k0), len(k1)
+    F1 = orc.FrameData(k1["x"], k1["y"], k1["octave"], k1["angle"], -np.ones(n1, np.float32), d1)
+    F0 = orc.FrameData(k0["x"], k0["y"], k0["octave"], k0["angle"], -np.ones(n0, np.float32), d0)
+    ones0, ones1 = np.ones(n0, np.uint8), np.ones(n1, np.uint8)
+    u01, v01 = (k0["x"] + dx).astype(np.float32), (k0["y"] + dy).astype(np.float32)
+    u10, v10 = (k1["x"] - dx).astype(np.float32), (k1["y"] - dy).astype(np.float32)
+    l0, l1 = k0["octave"].astype(np.int32), k1["octave"].astype(np.int32)
+    L = orc.lib()
+    m12 = np.full(n0, -1, np.int32)
+    n = L.orc_match_sim3_mutual(C.byref(F0.c), C.byref(F1.c), ones0, u01, v01, l0, np.ascontiguousarray(d0), ones1, u10, v10,
+                                l1, np.ascontiguousarray(d1), 7.5, sf, sf, m12)
+    sel = np.nonzero(m12 >= 0)[0]
+    assert n == len(sel) > 200
+    err = np.hypot(k1["x"][m12[sel]] - k0["x"][sel] - dx, k1["y"][m12[sel]] - k0["y"][sel] - dy)
+    assert np.mean(err < 5.0) > 0.9   # window 7.5 px x level scale; neighbouring octaves see the same corner
+    a_free = np.full(n1, -1, np.int32)
+    nf = L.orc_match_sim3_projection(C.byref(F1.c), n0, ones0, u01, v01, l0, np.ascontiguousarray(d0), 5, sf,
+                                     np.zeros(n1, np.uint8), a_free)
+    occ = np.zeros(n1, np.uint8)
+    occ[:3] = 1                      # non-null matchMapPoints[0..2]: hides the first three CANDIDATES of every window
+    a_occ = np.full(n1, -1, np.int32)
+    no = L.orc_match_sim3_projection(C.byref(F1.c), n0, ones0, u01, v01, l0, np.ascontiguousarray(d0), 5, sf, occ, a_occ)
+    # the count is per accepted query: a feature can be claimed again (the :422 test does not protect it)
+    assert nf >= (a_free >= 0).sum() > 200 and no <= nf
+    assert not np.array_equal(a_free, a_occ)

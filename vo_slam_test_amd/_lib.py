@@ -42,7 +42,8 @@ SYMBOLS = [
     "vo_orb_get_level_counts", "vo_orb_set_timing", "vo_orb_get_timing",
     "vo_hamming_matrix_dev", "vo_hamming_matrix_batch_dev", "vo_hamming_matrix",
     "vo_match_frame_projection", "vo_match_local_map", "vo_match_frame_keyframe", "vo_match_bow",
-    "vo_match_triangulation", "vo_match_fuse",
+    "vo_match_triangulation", "vo_match_fuse", "vo_match_area_best", "vo_match_sim3_projection",
+    "vo_match_sim3_mutual",
     "vo_pose_only_solve", "vo_pose_only_solve_dev",
     "vo_ba_create", "vo_ba_destroy", "vo_ba_set_stream", "vo_ba_set_shard", "vo_ba_set_state",
     "vo_ba_get_state", "vo_ba_n_free_cams", "vo_ba_local_ba", "vo_ba_local_ba_enqueue",
@@ -328,6 +329,39 @@ class Matcher:
                                   _p(q["level"]), _p(q["desc"]), C.c_float(threshold), _p(sf), _p(best), C.byref(n)),
               "vo_match_fuse")
         return n.value, best
+
+    def areaBest(self, kf: FrameArrays, q, th, scale_factors, max_dist):
+        """inner search of searchBySim3 / fuseByPose"""
+        nq = len(q["flags"])
+        best = np.full(nq, -1, np.int32)
+        n = C.c_int()
+        sf = np.ascontiguousarray(scale_factors, np.float32)
+        check(lib().vo_match_area_best(C.byref(kf.view), nq, _p(q["flags"]), _p(q["u"]), _p(q["v"]), _p(q["level"]),
+                                       _p(q["desc"]), C.c_float(th), _p(sf), int(max_dist), _p(best), C.byref(n)),
+              "vo_match_area_best")
+        return n.value, best
+
+    def searchByProjection_sim3(self, kf: FrameArrays, q, th, scale_factors, occupied=None):
+        nq = len(q["flags"])
+        assigned = np.full(kf.view.n, -1, np.int32)
+        n = C.c_int()
+        sf = np.ascontiguousarray(scale_factors, np.float32)
+        occ = None if occupied is None else np.ascontiguousarray(occupied, np.uint8)
+        check(lib().vo_match_sim3_projection(C.byref(kf.view), nq, _p(q["flags"]), _p(q["u"]), _p(q["v"]), _p(q["level"]),
+                                             _p(q["desc"]), int(th), _p(sf), _p(occ), _p(assigned), C.byref(n)),
+              "vo_match_sim3_projection")
+        return n.value, assigned
+
+    def searchBySim3(self, kf1: FrameArrays, kf2: FrameArrays, q1, q2, th, sf1, sf2):
+        match12 = np.full(kf1.view.n, -1, np.int32)
+        n = C.c_int()
+        sf1 = np.ascontiguousarray(sf1, np.float32)
+        sf2 = np.ascontiguousarray(sf2, np.float32)
+        check(lib().vo_match_sim3_mutual(C.byref(kf1.view), C.byref(kf2.view), _p(q1["flags"]), _p(q1["u"]), _p(q1["v"]),
+                                         _p(q1["level"]), _p(q1["desc"]), _p(q2["flags"]), _p(q2["u"]), _p(q2["v"]),
+                                         _p(q2["level"]), _p(q2["desc"]), C.c_float(th), _p(sf1), _p(sf2), _p(match12),
+                                         C.byref(n)), "vo_match_sim3_mutual")
+        return n.value, match12
 
     @staticmethod
     def computeDistance(a, b) -> int:

@@ -514,4 +514,97 @@ int vo_match_fuse(const vo_frame_view *kf, int nq, const uint8_t *q_flags, const
   return VO_OK;
 }
 
+
+// ---- loop-closure searches (matcher.cpp:356-447, 679-865, 1135-1238)
+namespace {
+// best feature of the window around (u, v) with octave in [lp - 1, lp]; `skip` (optional) is the
+// occupancy array of the Sim3 projection search, consulted per CANDIDATE RANK (reference :422)
+inline int area_best(const vo_frame_view &kf, const Grid &grid, const uint16_t *drow, float u, float v, float radius,
+                     int lp, const uint8_t *skip, std::vector<int> &cand, int &best) {
+  grid.query(kf, u, v, radius, -(1 << 30), 1 << 30, cand);
+  best = 256;
+  int bidx = -1;
+  for (size_t j = 0; j < cand.size(); j++) {
+    const int idx = cand[j];
+    if (skip && skip[j]) continue;
+    if (kf.octave[idx] < lp - 1 || kf.octave[idx] > lp) continue;
+    const int d = drow[idx];
+    if (d < best) best = d, bidx = idx;
+  }
+  return bidx;
+}
+}  // namespace
+
+int vo_match_area_best(const vo_frame_view *kf, int nq, const uint8_t *q_flags, const float *q_u, const float *q_v,
+                       const int32_t *q_level, const uint8_t *q_desc, float th, const float *scale_factors,
+                       int max_dist, int32_t *best_idx, int *n_matches) {
+  if (!kf || nq < 0 || !best_idx || !n_matches || !scale_factors) return VO_ERR_INVALID;
+  for (int i = 0; i < nq; i++) best_idx[i] = -1;
+  *n_matches = 0;
+  if (nq == 0 || kf->n == 0) return VO_OK;
+  std::vector<uint16_t> D;
+  VO_CHECK(distance_matrix(q_desc, nq, kf->desc, kf->n, D));
+  const Grid grid(*kf);
+  std::vector<int> cand;
+  int cnt = 0;
+  for (int i = 0; i < nq; i++) {
+    if (!(q_flags[i] & 1)) continue;
+    int best;
+    const int bidx = area_best(*kf, grid, &D[(size_t)i * kf->n], q_u[i], q_v[i], th * scale_factors[q_level[i]],
+                               q_level[i], nullptr, cand, best);
+    if (best <= max_dist) best_idx[i] = bidx, cnt++;
+  }
+  *n_matches = cnt;
+  return VO_OK;
+}
+
+int vo_match_sim3_projection(const vo_frame_view *kf, int nq, const uint8_t *q_flags, const float *q_u,
+                             const float *q_v, const int32_t *q_level, const uint8_t *q_desc, int th,
+                             const float *scale_factors, const uint8_t *occupied, int32_t *assigned, int *n_matches) {
+  if (!kf || nq < 0 || !assigned || !n_matches || !scale_factors) return VO_ERR_INVALID;
+  for (int k = 0; k < kf->n; k++) assigned[k] = -1;
+  *n_matches = 0;
+  if (nq == 0 || kf->n == 0) return VO_OK;
+  std::vector<uint16_t> D;
+  VO_CHECK(distance_matrix(q_desc, nq, kf->desc, kf->n, D));
+  const Grid grid(*kf);
+  std::vector<uint8_t> occ(kf->n, 0);
+  if (occupied) occ.assign(occupied, occupied + kf->n);
+  std::vector<int> cand;
+  int cnt = 0;
+  for (int i = 0; i < nq; i++) {
+    if (!(q_flags[i] & 1)) continue;
+    int best;
+    const int bidx = area_best(*kf, grid, &D[(size_t)i * kf->n], q_u[i], q_v[i], (float)th * scale_factors[q_level[i]],
+                               q_level[i], occ.data(), cand, best);
+    if (best <= TH_LOW) {
+      occ[bidx] = 1;
+      assigned[bidx] = i;
+      cnt++;
+    }
+  }
+  *n_matches = cnt;
+  return VO_OK;
+}
+
+int vo_match_sim3_mutual(const vo_frame_view *kf1, const vo_frame_view *kf2, const uint8_t *q1_flags, const float *q1_u,
+                         const float *q1_v, const int32_t *q1_level, const uint8_t *q1_desc, const uint8_t *q2_flags,
+                         const float *q2_u, const float *q2_v, const int32_t *q2_level, const uint8_t *q2_desc, float th,
+                         const float *scale_factors1, const float *scale_factors2, int32_t *match12, int *n_matches) {
+  if (!kf1 || !kf2 || !match12 || !n_matches) return VO_ERR_INVALID;
+  std::vector<int32_t> m1(std::max(1, kf1->n)), m2(std::max(1, kf2->n));
+  int n1 = 0, n2 = 0;
+  VO_CHECK(vo_match_area_best(kf2, kf1->n, q1_flags, q1_u, q1_v, q1_level, q1_desc, th, scale_factors2, TH_HIGH,
+                              m1.data(), &n1));
+  VO_CHECK(vo_match_area_best(kf1, kf2->n, q2_flags, q2_u, q2_v, q2_level, q2_desc, th, scale_factors1, TH_HIGH,
+                              m2.data(), &n2));
+  int found = 0;
+  for (int i = 0; i < kf1->n; i++) {
+    match12[i] = -1;
+    if (m1[i] >= 0 && m2[m1[i]] == i) match12[i] = m1[i], found++;  // :853-864
+  }
+  *n_matches = found;
+  return VO_OK;
+}
+
 }  // extern "C"
