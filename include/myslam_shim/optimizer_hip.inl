@@ -140,4 +140,47 @@ void Optimizer::solveLocalBAPoseAndPoint(KeyFrame *keyframe, bool &stopFlag, Map
   }
 }
 
+// Optimizer::solveLoopSim3, reference optimizer_ceres.cpp:810-1030
+int Optimizer::solveLoopSim3(KeyFrame *kf_curr, KeyFrame *kf_match, vector<MapPoint *> &inlierMappoints,
+                             Sophus::Sim3 &Scm, const bool &fixScaleFlag) {
+  const SE3 Tcw = kf_curr->getPose(), Tmw = kf_match->getPose();
+  const vector<MapPoint *> mps1 = kf_curr->getMapPoints();
+  double pose[6], scale = Scm.scale();
+  const Matrix3d Rcm = Scm.rotation_matrix();
+  const Vector3d tcm = Scm.translation();
+  ceres::RotationMatrixToAngleAxis(Rcm.data(), pose);  // any log map of SO(3) will do here
+  memcpy(pose + 3, tcm.data(), 3 * sizeof(double));
+  Camera *c = kf_curr->camera_;
+  const double camera[4] = {c->fx_, c->fy_, c->cx_, c->cy_};
+  std::vector<double> cam_m, pix_c, is_c, cam_c, pix_m, is_m;
+  std::vector<int> index;
+  for (int i = 0, N = (int)inlierMappoints.size(); i < N; i++) {  // :846-878
+    MapPoint *mpm = inlierMappoints[i], *mpc = mps1[i];
+    if (!mpm || mpm->isBad() || !mpc || mpc->isBad()) continue;
+    const int im = mpm->getIndexInKeyFrame(kf_match);
+    if (im < 0) continue;
+    const Vector3d pm = Tmw * mpm->getPose(), pc = Tcw * mpc->getPose();
+    const cv::KeyPoint &km = kf_match->unKeypoints_[im], &kc = kf_curr->unKeypoints_[i];
+    cam_m.insert(cam_m.end(), {pm[0], pm[1], pm[2]});
+    pix_m.insert(pix_m.end(), {(double)km.pt.x, (double)km.pt.y});
+    is_m.push_back(1.0 / static_cast<double>(kf_match->scaleFactors_[km.octave]));
+    cam_c.insert(cam_c.end(), {pc[0], pc[1], pc[2]});
+    pix_c.insert(pix_c.end(), {(double)kc.pt.x, (double)kc.pt.y});
+    is_c.push_back(1.0 / static_cast<double>(kf_curr->scaleFactors_[kc.octave]));
+    index.push_back(i);
+  }
+  const int32_t offsets[2] = {0, (int32_t)index.size()};
+  std::vector<uint8_t> outlier(index.size() + 1, 0);
+  int32_t inliers = 0;
+  vo_sim3_solve(1, offsets, cam_m.data(), pix_c.data(), is_c.data(), cam_c.data(), pix_m.data(), is_m.data(), camera,
+                fixScaleFlag ? 1 : 0, pose, &scale, outlier.data(), &inliers, nullptr);
+  for (size_t k = 0; k < index.size(); k++)
+    if (outlier[k]) inlierMappoints[index[k]] = static_cast<MapPoint *>(nullptr);
+  if (inliers == 0 && (int)index.size() - (int)std::count(outlier.begin(), outlier.end(), 1) < 10) return 0;  // :950-951
+  double R[9];
+  ceres::AngleAxisToRotationMatrix(pose, R);
+  Scm = Sophus::Sim3(Sophus::ScSO3(scale, Eigen::Map<const Matrix3d>(R)), Eigen::Map<const Vector3d>(pose + 3));
+  return inliers;
+}
+
 }  // namespace myslam

@@ -262,6 +262,22 @@ int vo_pose_only_solve_dev(int n_problems, const int32_t *dev_offsets, int max_o
                            uint8_t *dev_outlier, int32_t *dev_n_inliers,
                            vo_lm_summary *dev_summaries, void *hip_stream);
 
+/* Optimizer::solveLoopSim3(keyframe_curr, keyframe_match, inlierMappoints, Scm, fixScaleFlag)
+ * (optimizer_ceres.cpp:810-1030) with PoseOnlySim3 / PoseOnlyInverseSim3 (optimizer_ceres.h:211-267):
+ * problem 1 (Huber sqrt(10), <= 10 iterations), chi2 > 10 rejection in both images, then 10 (or 5
+ * when nothing was rejected) more iterations on the survivors and a final test of every match.
+ * Batched: problem p owns matches offsets[p] .. offsets[p+1].  Per match: the map point in the
+ * matched key-frame's camera frame (cam_match) with the current key-frame's pixel and 1/sigma, and
+ * the current key-frame's camera-frame point (cam_curr) with the matched key-frame's pixel and
+ * 1/sigma (:846-878).  poses[6p..] in/out = [angle-axis; t] of Scm, scales[p] its scale
+ * (fix_scale: constant, loopClosing.cpp:15).  outlier[i] = 1: inlierMappoints entry nulled.
+ * n_inliers[p] = return value; 0 with pose and scale untouched when fewer than 10 matches survive
+ * problem 1 (:950-951). */
+int vo_sim3_solve(int n_problems, const int32_t *offsets, const double *cam_match, const double *pix_curr,
+                  const double *inv_sigma_curr, const double *cam_curr, const double *pix_match,
+                  const double *inv_sigma_match, const double camera[4], int fix_scale, double *poses,
+                  double *scales, uint8_t *outlier, int32_t *n_inliers, vo_lm_summary *summaries /*2 per problem or NULL*/);
+
 /* Bundle-adjustment problem handle (the arrays Optimizer::solveLocalBAPoseAndPoint gathers at
  * optimizer_ceres.cpp:446-592).  Edges may be given in any order; they are grouped by point
  * internally (stable).  cam_fixed[c] != 0 <=> SetParameterBlockConstant (:578-579). */

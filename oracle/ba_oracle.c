@@ -1037,3 +1037,288 @@ int orc_local_ba(int n_cams, double *poses, const uint8_t *cam_fixed, int n_pts,
   free(active);
   return 0;
 }
+
+/* ------------------------------------------------------------------ Sim3 (loop closure) ----
+ * Optimizer::solveLoopSim3, optimizer_ceres.cpp:810-1030, with PoseOnlySim3 / PoseOnlyInverseSim3
+ * (optimizer_ceres.h:211-267) over IntrinsicProjectionUV (optimizer_ceres.cpp:8-42).
+ * Parameters: pose = [angle-axis(3); t(3)] and the scale s, both with the plain additive update
+ * (no local parameterisation); points constant.  Per match two 2-row residual blocks, each with
+ * its own Huber(sqrt(10)) loss:
+ *   forward  r = (pix_curr  - K pi(s R P_match + t)) / sigma_curr
+ *   inverse  r = (pix_match - K pi(R^T (P_curr - t) / s)) / sigma_match
+ * Jacobians: the autodiff chain through CostFunctionToFunctor = (analytic d r/d p of
+ * IntrinsicProjectionUV, which LACKS the 1/sigma factor -- same inconsistency as Q-B1) times the
+ * exact derivative of the camera-frame point, here in closed form:
+ *   d(R(w) p)/dw = -R [p]x Jr(w),   d(R(w)^T v)/dw = R^T [v]x Jl(w). */
+static void aa_to_R_rowmajor(const double aa[3], double R[9]) {
+  double C[9];
+  orc_angle_axis_to_R(aa, C); /* column-major like ceres */
+  for (int i = 0; i < 3; i++)
+    for (int j = 0; j < 3; j++) R[3 * i + j] = C[3 * j + i];
+}
+static void so3_jacobians(const double w[3], double Jr[9], double Jl[9]) {
+  const double t2 = w[0] * w[0] + w[1] * w[1] + w[2] * w[2];
+  double W[9], W2[9];
+  hat(w, W);
+  mat3_mul(W, W, W2);
+  double a, b;
+  if (t2 > DBL_EPSILON) { /* same branch point as ceres::AngleAxisToRotationMatrix */
+    const double th = sqrt(t2);
+    a = (1.0 - cos(th)) / t2;
+    b = (th - sin(th)) / (t2 * th);
+  } else {
+    a = 0.0, b = 0.0; /* R = I + [w]x there: the derivative of that first-order form */
+  }
+  for (int i = 0; i < 9; i++) {
+    const double id = (i % 4 == 0) ? 1.0 : 0.0;
+    Jr[i] = id - a * W[i] + b * W2[i];
+    Jl[i] = id + a * W[i] + b * W2[i];
+  }
+}
+
+/* IntrinsicProjectionUV::Evaluate */
+static void intrinsic_uv(const double p[3], const double pix[2], const double cam[4], double isig,
+                         double r[2], double J[6]) {
+  const double x = p[0], y = p[1], z = p[2];
+  const double invz = 1.0 / z, invz2 = invz * invz;
+  r[0] = (pix[0] - (cam[0] * x * invz + cam[2])) * isig;
+  r[1] = (pix[1] - (cam[1] * y * invz + cam[3])) * isig;
+  if (J) {
+    J[0] = -invz * cam[0], J[1] = 0, J[2] = x * invz2 * cam[0];
+    J[3] = 0, J[4] = -invz * cam[1], J[5] = y * invz2 * cam[1];
+  }
+}
+
+/* both residual blocks of one match at x = [aa, t, s]; J blocks are 2 x 7 row-major (column 6 = s) */
+void orc_sim3_eval(const double x[7], const double cam_match[3], const double pix_curr[2], double isig_c,
+                   const double cam_curr[3], const double pix_match[2], double isig_m,
+                   const double cam[4], double r_fwd[2], double J_fwd[14], double r_inv[2], double J_inv[14]) {
+  double R[9], Jr[9], Jl[9];
+  aa_to_R_rowmajor(x, R);
+  const double s = x[6];
+  double Rp[3];
+  for (int i = 0; i < 3; i++) Rp[i] = R[3 * i] * cam_match[0] + R[3 * i + 1] * cam_match[1] + R[3 * i + 2] * cam_match[2];
+  const double p[3] = {s * Rp[0] + x[3], s * Rp[1] + x[4], s * Rp[2] + x[5]};
+  double Juv[6];
+  intrinsic_uv(p, pix_curr, cam, isig_c, r_fwd, J_fwd ? Juv : NULL);
+  if (J_fwd || J_inv) so3_jacobians(x, Jr, Jl);
+  if (J_fwd) {
+    double P[9], RP[9], D[9]; /* dp/dw = -s R [Pm]x Jr */
+    hat(cam_match, P);
+    mat3_mul(R, P, RP);
+    mat3_mul(RP, Jr, D);
+    for (int k = 0; k < 2; k++) {
+      for (int a = 0; a < 3; a++)
+        J_fwd[7 * k + a] = -s * (Juv[3 * k] * D[a] + Juv[3 * k + 1] * D[3 + a] + Juv[3 * k + 2] * D[6 + a]);
+      for (int a = 0; a < 3; a++) J_fwd[7 * k + 3 + a] = Juv[3 * k + a];
+      J_fwd[7 * k + 6] = Juv[3 * k] * Rp[0] + Juv[3 * k + 1] * Rp[1] + Juv[3 * k + 2] * Rp[2];
+    }
+  }
+  const double v[3] = {(cam_curr[0] - x[3]) / s, (cam_curr[1] - x[4]) / s, (cam_curr[2] - x[5]) / s};
+  double q[3];
+  for (int i = 0; i < 3; i++) q[i] = R[i] * v[0] + R[3 + i] * v[1] + R[6 + i] * v[2]; /* R^T v */
+  intrinsic_uv(q, pix_match, cam, isig_m, r_inv, J_inv ? Juv : NULL);
+  if (J_inv) {
+    double V[9], VJ[9], D[9], Rt[9]; /* dq/dw = R^T [v]x Jl */
+    hat(v, V);
+    mat3_mul(V, Jl, VJ);
+    for (int i = 0; i < 3; i++)
+      for (int j = 0; j < 3; j++) Rt[3 * i + j] = R[3 * j + i];
+    mat3_mul(Rt, VJ, D);
+    for (int k = 0; k < 2; k++) {
+      for (int a = 0; a < 3; a++)
+        J_inv[7 * k + a] = Juv[3 * k] * D[a] + Juv[3 * k + 1] * D[3 + a] + Juv[3 * k + 2] * D[6 + a];
+      for (int a = 0; a < 3; a++) /* dq/dt = -R^T / s */
+        J_inv[7 * k + 3 + a] = -(Juv[3 * k] * Rt[a] + Juv[3 * k + 1] * Rt[3 + a] + Juv[3 * k + 2] * Rt[6 + a]) / s;
+      J_inv[7 * k + 6] = -(Juv[3 * k] * q[0] + Juv[3 * k + 1] * q[1] + Juv[3 * k + 2] * q[2]) / s; /* dq/ds = -q/s */
+    }
+  }
+}
+
+typedef struct {
+  int n, np; /* np = 6 (scale fixed) or 7 */
+  const double *cam_match, *pix_curr, *isig_c, *cam_curr, *pix_match, *isig_m, *cam;
+  const uint8_t *active;
+  double huber;
+  double *J, *r; /* per match: 2 blocks x 2 rows x 7, 4 residuals; corrected + scaled */
+  double scale[7];
+} sim3_ctx;
+
+static int sim3_linearize(void *vc, const double *x, int first, double *cost, double *gmax) {
+  sim3_ctx *c = (sim3_ctx *)vc;
+  double total = 0, g[7] = {0}, cn[7] = {0};
+  for (int i = 0; i < c->n; i++) {
+    if (c->active && !c->active[i]) continue;
+    double *J = c->J + (size_t)i * 28, *r = c->r + (size_t)i * 4;
+    orc_sim3_eval(x, c->cam_match + 3 * i, c->pix_curr + 2 * i, c->isig_c[i], c->cam_curr + 3 * i,
+                  c->pix_match + 2 * i, c->isig_m[i], c->cam, r, J, r + 2, J + 14);
+    for (int blk = 0; blk < 2; blk++) {
+      double *rb = r + 2 * blk, *Jb = J + 14 * blk, rho[3];
+      huber(c->huber, rb[0] * rb[0] + rb[1] * rb[1], rho);
+      total += 0.5 * rho[0];
+      const double w = sqrt(rho[1]);
+      rb[0] *= w, rb[1] *= w;
+      for (int k = 0; k < 14; k++) Jb[k] *= w;
+      for (int k = 0; k < 2; k++)
+        for (int a = 0; a < c->np; a++) {
+          g[a] += Jb[7 * k + a] * rb[k];
+          cn[a] += Jb[7 * k + a] * Jb[7 * k + a];
+        }
+    }
+  }
+  if (first)
+    for (int a = 0; a < c->np; a++) c->scale[a] = 1.0 / (1.0 + sqrt(cn[a]));
+  for (int i = 0; i < c->n; i++) {
+    if (c->active && !c->active[i]) continue;
+    for (int k = 0; k < 4; k++)
+      for (int a = 0; a < c->np; a++) c->J[(size_t)i * 28 + 7 * k + a] *= c->scale[a];
+  }
+  double m = 0;
+  for (int a = 0; a < c->np; a++)
+    if (fabs(g[a]) > m) m = fabs(g[a]);
+  *cost = total;
+  *gmax = m;
+  return isfinite(total);
+}
+static int sim3_step(void *vc, double radius, double *delta, double *model_change) {
+  sim3_ctx *c = (sim3_ctx *)vc;
+  const int np = c->np;
+  double H[49], b[7];
+  memset(H, 0, sizeof(H));
+  memset(b, 0, sizeof(b));
+  for (int i = 0; i < c->n; i++) {
+    if (c->active && !c->active[i]) continue;
+    const double *J = c->J + (size_t)i * 28, *r = c->r + (size_t)i * 4;
+    for (int k = 0; k < 4; k++)
+      for (int a = 0; a < np; a++) {
+        b[a] += J[7 * k + a] * r[k];
+        for (int bb = 0; bb < np; bb++) H[a * np + bb] += J[7 * k + a] * J[7 * k + bb];
+      }
+  }
+  for (int a = 0; a < np; a++) {
+    double d = H[a * np + a];
+    d = d < 1e-6 ? 1e-6 : (d > 1e32 ? 1e32 : d);
+    H[a * np + a] += d / radius;
+  }
+  if (!chol_solve(H, b, np)) return 0;
+  double step[7];
+  for (int a = 0; a < np; a++) {
+    if (!isfinite(b[a])) return 0;
+    step[a] = -b[a];
+  }
+  double mc = 0;
+  for (int i = 0; i < c->n; i++) {
+    if (c->active && !c->active[i]) continue;
+    const double *J = c->J + (size_t)i * 28, *r = c->r + (size_t)i * 4;
+    for (int k = 0; k < 4; k++) {
+      double mr = 0;
+      for (int a = 0; a < np; a++) mr += J[7 * k + a] * step[a];
+      mc += mr * (r[k] + mr / 2.0);
+    }
+  }
+  *model_change = -mc;
+  for (int a = 0; a < 7; a++) delta[a] = a < np ? step[a] * c->scale[a] : 0.0;
+  return 1;
+}
+static void sim3_plus(void *vc, const double *x, const double *d, double *xn) {
+  (void)vc;
+  for (int a = 0; a < 7; a++) xn[a] = x[a] + d[a];
+}
+static int sim3_cost(void *vc, const double *x, double *cost) {
+  sim3_ctx *c = (sim3_ctx *)vc;
+  double total = 0;
+  for (int i = 0; i < c->n; i++) {
+    if (c->active && !c->active[i]) continue;
+    double r[4], rho[3];
+    orc_sim3_eval(x, c->cam_match + 3 * i, c->pix_curr + 2 * i, c->isig_c[i], c->cam_curr + 3 * i,
+                  c->pix_match + 2 * i, c->isig_m[i], c->cam, r, NULL, r + 2, NULL);
+    huber(c->huber, r[0] * r[0] + r[1] * r[1], rho);
+    total += 0.5 * rho[0];
+    huber(c->huber, r[2] * r[2] + r[3] * r[3], rho);
+    total += 0.5 * rho[0];
+  }
+  *cost = total;
+  return isfinite(total);
+}
+static double sim3_norm(void *vc, const double *x, const double *y) {
+  sim3_ctx *c = (sim3_ctx *)vc;
+  double s = 0;
+  for (int a = 0; a < c->np; a++) { /* the free parameter blocks only */
+    const double d = y ? x[a] - y[a] : x[a];
+    s += d * d;
+  }
+  return sqrt(s);
+}
+
+/* chi2 > 10 tests of :916-948 / :996-1022 (double arithmetic; camera2pixel = fx x / z + cx) */
+static int sim3_outlier(const double x[7], const double cam_match[3], const double pix_curr[2], double isig_c,
+                        const double cam_curr[3], const double pix_match[2], double isig_m, const double cam[4]) {
+  double R[9];
+  aa_to_R_rowmajor(x, R);
+  const double s = x[6];
+  double p[3];
+  for (int i = 0; i < 3; i++)
+    p[i] = s * (R[3 * i] * cam_match[0] + R[3 * i + 1] * cam_match[1] + R[3 * i + 2] * cam_match[2]) + x[3 + i];
+  const double eu = cam[0] * p[0] / p[2] + cam[2] - pix_curr[0], ev = cam[1] * p[1] / p[2] + cam[3] - pix_curr[1];
+  if ((eu * eu + ev * ev) * isig_c * isig_c > 10.0) return 1;
+  /* Smc = Scm^-1: rotation R^T, scale 1/s, translation -R^T t / s */
+  double q[3];
+  for (int i = 0; i < 3; i++) {
+    const double Rtp = R[i] * cam_curr[0] + R[3 + i] * cam_curr[1] + R[6 + i] * cam_curr[2];
+    const double Rtt = R[i] * x[3] + R[3 + i] * x[4] + R[6 + i] * x[5];
+    q[i] = Rtp / s - Rtt / s;
+  }
+  const double fu = cam[0] * q[0] / q[2] + cam[2] - pix_match[0], fv = cam[1] * q[1] / q[2] + cam[3] - pix_match[1];
+  return (fu * fu + fv * fv) * isig_m * isig_m > 10.0;
+}
+
+int orc_sim3_solve(int n, const double *cam_match, const double *pix_curr, const double *isig_curr,
+                   const double *cam_curr, const double *pix_match, const double *isig_match,
+                   const double cam[4], int fix_scale, double pose[6], double *scale, uint8_t *outlier,
+                   orc_lm_summary *sums) {
+  double x[7], x_in[7];
+  memcpy(x, pose, 6 * sizeof(double));
+  x[6] = *scale;
+  memcpy(x_in, x, sizeof(x));
+  for (int i = 0; i < n; i++) outlier[i] = 0;
+  sim3_ctx c;
+  memset(&c, 0, sizeof(c));
+  c.n = n, c.np = fix_scale ? 6 : 7;
+  c.cam_match = cam_match, c.pix_curr = pix_curr, c.isig_c = isig_curr, c.cam_curr = cam_curr;
+  c.pix_match = pix_match, c.isig_m = isig_match, c.cam = cam;
+  c.huber = (double)sqrtf(10.0f); /* sqrt(10.0f) is a float expression (:880) */
+  c.J = (double *)malloc(sizeof(double) * 28 * (size_t)(n > 0 ? n : 1));
+  c.r = (double *)malloc(sizeof(double) * 4 * (size_t)(n > 0 ? n : 1));
+  uint8_t *active = (uint8_t *)malloc(n > 0 ? n : 1);
+  c.active = active;
+  for (int i = 0; i < n; i++) active[i] = 1;
+  lm_problem P = {&c, 7, sim3_linearize, sim3_step, sim3_plus, sim3_cost, sim3_norm};
+  if (sums) memset(sums, 0, 2 * sizeof(orc_lm_summary));
+  if (n > 0) lm_minimize(&P, x, 10, sums ? &sums[0] : NULL);
+  int outlier_cnt = 0;
+  for (int i = 0; i < n; i++) {
+    outlier[i] = (uint8_t)sim3_outlier(x, cam_match + 3 * i, pix_curr + 2 * i, isig_curr[i], cam_curr + 3 * i,
+                                       pix_match + 2 * i, isig_match[i], cam);
+    outlier_cnt += outlier[i];
+  }
+  int inliers = 0;
+  if (n - outlier_cnt < 10) { /* :950-951: returns before Scm is written */
+    memcpy(x, x_in, sizeof(x));
+  } else {
+    for (int i = 0; i < n; i++) active[i] = !outlier[i];
+    lm_minimize(&P, x, outlier_cnt > 0 ? 10 : 5, sums ? &sums[1] : NULL);
+    for (int i = 0; i < n; i++) {
+      /* :996-1022 tests every match again, including those excluded from problem 2 */
+      const int o = sim3_outlier(x, cam_match + 3 * i, pix_curr + 2 * i, isig_curr[i], cam_curr + 3 * i,
+                                 pix_match + 2 * i, isig_match[i], cam);
+      if (o) outlier[i] = 1;
+      inliers += !o;
+    }
+  }
+  memcpy(pose, x, 6 * sizeof(double));
+  *scale = x[6];
+  free(c.J);
+  free(c.r);
+  free(active);
+  return inliers;
+}

@@ -215,6 +215,20 @@ int orc_ba_schur(int n_cams, const double *poses, const uint8_t *cam_fixed, int 
                  const double cam[5], double huber_mono, double huber_stereo, double point_damping,
                  double *S, double *b, double *cost);
 
+/* PoseOnlySim3 / PoseOnlyInverseSim3 residual blocks of one match at x = [angle-axis, t, s]
+ * (optimizer_ceres.h:211-267); Jacobians 2 x 7 row-major or NULL. */
+void orc_sim3_eval(const double x[7], const double cam_match[3], const double pix_curr[2], double isig_c,
+                   const double cam_curr[3], const double pix_match[2], double isig_m,
+                   const double cam[4], double r_fwd[2], double J_fwd[14], double r_inv[2], double J_inv[14]);
+
+/* Optimizer::solveLoopSim3 (optimizer_ceres.cpp:810-1030) on flat arrays.  pose in/out =
+ * [angle-axis; t] of Scm, *scale its scale; outlier[n]: inlierMappoints entry nulled.  Returns the
+ * inlier count (0 with pose/scale untouched when fewer than 10 matches survive problem 1). */
+int orc_sim3_solve(int n, const double *cam_match, const double *pix_curr, const double *isig_curr,
+                   const double *cam_curr, const double *pix_match, const double *isig_match,
+                   const double cam[4], int fix_scale, double pose[6], double *scale, uint8_t *outlier,
+                   orc_lm_summary *sums /*[2] or NULL*/);
+
 #ifdef __cplusplus
 }
 #endif

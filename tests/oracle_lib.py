@@ -137,6 +137,11 @@ def lib():
     L.orc_match_sim3_mutual.argtypes = [C.POINTER(Frame), C.POINTER(Frame), _u8p, _f32p, _f32p, _i32p, _u8p, _u8p, _f32p, _f32p,
                                         _i32p, _u8p, C.c_float, _f32p, _f32p, _i32p]
     L.orc_match_sim3_mutual.restype = C.c_int
+    L.orc_sim3_eval.argtypes = [_f64p, _f64p, _f64p, C.c_double, _f64p, _f64p, C.c_double, _f64p, _f64p, C.c_void_p, _f64p,
+                                C.c_void_p]
+    L.orc_sim3_solve.argtypes = [C.c_int, _f64p, _f64p, _f64p, _f64p, _f64p, _f64p, _f64p, C.c_int, _f64p, _f64p, _u8p,
+                                 C.c_void_p]
+    L.orc_sim3_solve.restype = C.c_int
     L.orc_se3_exp.argtypes = [_f64p, _f64p, _f64p]
     L.orc_se3_log.argtypes = [_f64p, _f64p, _f64p]
     L.orc_se3_plus.argtypes = [_f64p, _f64p, _f64p]
@@ -311,3 +316,16 @@ def ba_schur(prob, huber=(0.0, 0.0), point_damping=0.0, active=None):
                             ne, prob["e_cam"], prob["e_pt"], prob["e_obs"], prob["e_inv_sigma"], act, prob["cam"],
                             huber[0], huber[1], point_damping, S, b, C.byref(cost))
     return S[:6 * nf, :6 * nf], b[:6 * nf], cost.value, nf
+
+
+def sim3_solve(prob, fix_scale=True, trace=False):
+    """Optimizer::solveLoopSim3 on a synth.make_sim3_problem dict -> (pose[6], scale, outlier, inliers, sums)"""
+    pose = prob["pose0"].copy()
+    scale = np.array([prob["scale0"]], np.float64)
+    n = len(prob["cam_match"])
+    outl = np.zeros(max(n, 1), np.uint8)
+    sums = (LmSummary * 2)()
+    inl = lib().orc_sim3_solve(n, prob["cam_match"], prob["pix_curr"], prob["isig_curr"], prob["cam_curr"],
+                               prob["pix_match"], prob["isig_match"], prob["cam"][:4].copy(), int(fix_scale), pose, scale,
+                               outl, C.cast(sums, C.c_void_p))
+    return pose, float(scale[0]), outl[:n], inl, sums

@@ -218,3 +218,33 @@ def test_sharded_driver_world1(vo, orc):
     assert s1.iterations == osums[0].iterations and s2.iterations == osums[1].iterations
     assert np.abs(poses - oposes).max() < 1e-7
     assert np.array_equal(erase, oerase)
+
+
+# ------------------------------------------------------------------ Sim3 (loop closure, B10/B11)
+
+@pytest.mark.parametrize("fix_scale", [True, False])
+def test_sim3_solve_matches_oracle(vo, orc, fix_scale):
+    from vo_slam_test_amd import synth
+    probs = [synth.make_sim3_problem(i, n=80 + 40 * i, outliers=0.05 * i, scale=1.0 + 0.02 * i) for i in range(4)]
+    poses, scales, masks, ninl, sums = vo.Optimizer.solveLoopSim3(probs, fixScaleFlag=fix_scale, summaries=True)
+    for i, pr in enumerate(probs):
+        op, osc, oout, oinl, osums = orc.sim3_solve(pr, fix_scale=fix_scale)
+        # tolerance: FP64 both sides, different summation order (block reduction vs serial)
+        assert np.abs(poses[i] - op).max() < 1e-8, i
+        assert abs(scales[i] - osc) < 1e-8
+        assert np.array_equal(masks[i], oout) and ninl[i] == oinl
+        assert [sums[2 * i].iterations, sums[2 * i + 1].iterations] == [osums[0].iterations, osums[1].iterations]
+        assert abs(sums[2 * i + 1].final_cost - osums[1].final_cost) <= 1e-9 * max(1.0, osums[1].final_cost)
+        if fix_scale:
+            assert scales[i] == pr["scale0"]
+        assert np.abs(poses[i] - pr["pose_true"]).max() < np.abs(pr["pose0"] - pr["pose_true"]).max()
+
+
+def test_sim3_too_few_inliers_leaves_pose(vo, orc):
+    from vo_slam_test_amd import synth
+    pr = synth.make_sim3_problem(9, n=12, outliers=0.0)
+    pr["pix_curr"] = pr["pix_curr"] + 500.0          # every match fails the forward chi2 test
+    poses, scales, masks, ninl = vo.Optimizer.solveLoopSim3([pr])
+    op, osc, oout, oinl, _ = orc.sim3_solve(pr)
+    assert ninl[0] == 0 == oinl and masks[0].all() and oout.all()
+    assert np.array_equal(poses[0], pr["pose0"]) and np.array_equal(op, pr["pose0"])   # :950-951 returns before Scm = Scm2

@@ -44,7 +44,7 @@ SYMBOLS = [
     "vo_match_frame_projection", "vo_match_local_map", "vo_match_frame_keyframe", "vo_match_bow",
     "vo_match_triangulation", "vo_match_fuse", "vo_match_area_best", "vo_match_sim3_projection",
     "vo_match_sim3_mutual",
-    "vo_pose_only_solve", "vo_pose_only_solve_dev",
+    "vo_pose_only_solve", "vo_sim3_solve", "vo_pose_only_solve_dev",
     "vo_ba_create", "vo_ba_destroy", "vo_ba_set_stream", "vo_ba_set_shard", "vo_ba_set_state",
     "vo_ba_get_state", "vo_ba_n_free_cams", "vo_ba_local_ba", "vo_ba_local_ba_enqueue",
     "vo_ba_local_ba_finish", "vo_ba_solve", "vo_ba_lm_begin",
@@ -303,8 +303,9 @@ class Matcher:
         mode = 1 if keyframe_to_keyframe else 0
         match = np.full((a.view.n if mode else b.view.n), -1, np.int32)
         n = C.c_int()
-        check(lib().vo_match_bow(C.byref(a.view), _p(np.ascontiguousarray(a_valid, np.uint8)), C.byref(a_nodes.view),
-                                 C.byref(b.view), _p(np.ascontiguousarray(b_valid, np.uint8)), C.byref(b_nodes.view),
+        av, bv = np.ascontiguousarray(a_valid, np.uint8), np.ascontiguousarray(b_valid, np.uint8)  # alive across the call
+        check(lib().vo_match_bow(C.byref(a.view), _p(av), C.byref(a_nodes.view),
+                                 C.byref(b.view), _p(bv), C.byref(b_nodes.view),
                                  mode, C.c_float(self.ratio_), int(checkRot), _p(match), C.byref(n)), "vo_match_bow")
         return n.value, match
 
@@ -314,9 +315,10 @@ class Matcher:
         n = C.c_int()
         sf = np.ascontiguousarray(scale_factors, np.float32)
         F = np.ascontiguousarray(F12, np.float64).reshape(-1)
+        ah, bh = np.ascontiguousarray(a_has, np.uint8), np.ascontiguousarray(b_has, np.uint8)
         check(lib().vo_match_triangulation(
-            C.byref(a.view), _p(np.ascontiguousarray(a_has, np.uint8)), C.byref(a_nodes.view), C.byref(b.view),
-            _p(np.ascontiguousarray(b_has, np.uint8)), C.byref(b_nodes.view), _p(F), C.c_float(ex), C.c_float(ey),
+            C.byref(a.view), _p(ah), C.byref(a_nodes.view), C.byref(b.view),
+            _p(bh), C.byref(b_nodes.view), _p(F), C.c_float(ex), C.c_float(ey),
             _p(sf), int(checkRot), _p(match), C.byref(n)), "vo_match_triangulation")
         return n.value, match
 
@@ -396,6 +398,33 @@ class Optimizer:
         return poses, masks, ninl
 
 
+    @staticmethod
+    def solveLoopSim3(problems, fixScaleFlag=True, summaries=False):
+        """problems: list of synth.make_sim3_problem-style dicts -> (poses[P,6], scales[P], outlier masks, inliers)."""
+        P = len(problems)
+        offs = np.zeros(P + 1, np.int32)
+        for i, pr in enumerate(problems):
+            offs[i + 1] = offs[i] + len(pr["cam_match"])
+        cat = lambda k, w: np.ascontiguousarray(np.concatenate([pr[k].reshape(-1, w) for pr in problems]).astype(np.float64))
+        tot = int(offs[-1])
+        poses = np.ascontiguousarray(np.stack([pr["pose0"] for pr in problems]).astype(np.float64))
+        scales = np.ascontiguousarray([float(pr["scale0"]) for pr in problems], np.float64)
+        cam = np.ascontiguousarray(problems[0]["cam"][:4], np.float64)
+        outl = np.zeros(max(tot, 1), np.uint8)
+        ninl = np.zeros(P, np.int32)
+        sums = (LmSummary * (2 * P))()
+        # keep the packed arrays alive across the call (_p only takes their addresses)
+        a_pm, a_pc, a_ic = cat("cam_match", 3), cat("pix_curr", 2), cat("isig_curr", 1)
+        a_Pc, a_xm, a_im = cat("cam_curr", 3), cat("pix_match", 2), cat("isig_match", 1)
+        check(lib().vo_sim3_solve(P, _p(offs), _p(a_pm), _p(a_pc), _p(a_ic), _p(a_Pc), _p(a_xm), _p(a_im), _p(cam),
+                                  int(bool(fixScaleFlag)), _p(poses), _p(scales), _p(outl), _p(ninl),
+                                  C.byref(sums) if summaries else None), "vo_sim3_solve")
+        masks = [outl[offs[i]:offs[i + 1]].copy() for i in range(P)]
+        if summaries:
+            return poses, scales, masks, ninl, sums
+        return poses, scales, masks, ninl
+
+
 class BundleAdjuster:
     """Handle over vo_ba_* (the arrays Optimizer::solveLocalBAPoseAndPoint gathers)."""
 
@@ -429,8 +458,9 @@ class BundleAdjuster:
         return poses, pts
 
     def set_state(self, poses=None, points=None):
-        check(lib().vo_ba_set_state(self._h, _p(None if poses is None else np.ascontiguousarray(poses)),
-                                    _p(None if points is None else np.ascontiguousarray(points))))
+        po = None if poses is None else np.ascontiguousarray(poses, np.float64)
+        pt = None if points is None else np.ascontiguousarray(points, np.float64)
+        check(lib().vo_ba_set_state(self._h, _p(po), _p(pt)))
 
     def solve(self, huber_mono=0.0, huber_stereo=0.0, max_iterations=10, edge_active=None):
         s = LmSummary()
@@ -513,11 +543,13 @@ class BundleAdjuster:
 
 def se3_exp(xi):
     R, t = np.zeros(9), np.zeros(3)
-    check(lib().vo_se3_exp(_p(np.ascontiguousarray(xi, np.float64)), _p(R), _p(t)))
+    xi = np.ascontiguousarray(xi, np.float64)
+    check(lib().vo_se3_exp(_p(xi), _p(R), _p(t)))
     return R.reshape(3, 3), t
 
 
 def se3_log(R, t):
     xi = np.zeros(6)
-    check(lib().vo_se3_log(_p(np.ascontiguousarray(R, np.float64).reshape(-1)), _p(np.ascontiguousarray(t, np.float64)), _p(xi)))
+    Rf, tf = np.ascontiguousarray(R, np.float64).reshape(-1), np.ascontiguousarray(t, np.float64)
+    check(lib().vo_se3_log(_p(Rf), _p(tf), _p(xi)))
     return xi

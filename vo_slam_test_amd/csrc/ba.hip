@@ -360,6 +360,292 @@ __global__ __launch_bounds__(256) void k_pose_only(const int *offsets, const dou
 }
 
 // ============================================================================================
+// Sim3 optimisation of a loop candidate: Optimizer::solveLoopSim3 (optimizer_ceres.cpp:810-1030),
+// one workgroup per problem, same structure as k_pose_only.  NP = 6 (scale fixed, the only mode the
+// reference uses: loopClosing.cpp:15) or 7.
+// ============================================================================================
+struct Sim3Prob {
+  int n;
+  const double *Pm, *pc, *isc, *Pc, *pm, *ism;  // cam_match(3n), pix_curr(2n), 1/sigma, cam_curr(3n), pix_match(2n), 1/sigma
+  const uint8_t *skip;
+  double cam[4];
+  double huber;
+};
+
+template <int NP>
+__device__ void sim3_accumulate(const double x[7], const Sim3Prob &Q, bool want_jac,
+                                double (&acc)[NP * (NP + 1) / 2 + NP + 1]) {
+  constexpr int NH = NP * (NP + 1) / 2;
+#pragma unroll
+  for (int i = 0; i < NH + NP + 1; i++) acc[i] = 0;
+  const Sim3Frame F = sim3_frame(x, want_jac);
+  for (int i = threadIdx.x; i < Q.n; i += blockDim.x) {
+    if (Q.skip && Q.skip[i]) continue;
+    double r[4], J[28];
+    if (want_jac)
+      sim3_eval<true>(F, Q.Pm + 3 * i, Q.pc[2 * i], Q.pc[2 * i + 1], Q.isc[i], Q.Pc + 3 * i, Q.pm[2 * i], Q.pm[2 * i + 1],
+                      Q.ism[i], Q.cam, r, J);
+    else
+      sim3_eval<false>(F, Q.Pm + 3 * i, Q.pc[2 * i], Q.pc[2 * i + 1], Q.isc[i], Q.Pc + 3 * i, Q.pm[2 * i], Q.pm[2 * i + 1],
+                       Q.ism[i], Q.cam, r, nullptr);
+#pragma unroll
+    for (int blk = 0; blk < 2; blk++) {  // each 2-row block has its own loss (two AddResidualBlock calls, :888-895)
+      const double *rb = r + 2 * blk, *Jb = J + 14 * blk;
+      double rho0, rho1;
+      huber(Q.huber, rb[0] * rb[0] + rb[1] * rb[1], rho0, rho1);
+      acc[NH + NP] += 0.5 * rho0;
+      if (!want_jac) continue;
+      int t = 0;
+#pragma unroll
+      for (int a = 0; a < NP; a++) {
+#pragma unroll
+        for (int b = a; b < NP; b++) acc[t++] += rho1 * (Jb[a] * Jb[b] + Jb[7 + a] * Jb[7 + b]);
+        acc[NH + a] += rho1 * (Jb[a] * rb[0] + Jb[7 + a] * rb[1]);
+      }
+    }
+  }
+}
+
+template <int N>
+__device__ bool chol_solve_n(double (&A)[N][N], double (&b)[N]) {
+#pragma unroll
+  for (int j = 0; j < N; j++) {
+    double d = A[j][j];
+#pragma unroll
+    for (int k = 0; k < j; k++) d -= A[j][k] * A[j][k];
+    if (!(d > 0.0)) return false;
+    d = sqrt(d);
+    A[j][j] = d;
+#pragma unroll
+    for (int i = j + 1; i < N; i++) {
+      double v = A[i][j];
+#pragma unroll
+      for (int k = 0; k < j; k++) v -= A[i][k] * A[j][k];
+      A[i][j] = v / d;
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < N; i++) {
+    double v = b[i];
+#pragma unroll
+    for (int k = 0; k < i; k++) v -= A[i][k] * b[k];
+    b[i] = v / A[i][i];
+  }
+#pragma unroll
+  for (int i = N - 1; i >= 0; i--) {
+    double v = b[i];
+#pragma unroll
+    for (int k = i + 1; k < N; k++) v -= A[k][i] * b[k];
+    b[i] = v / A[i][i];
+  }
+  return true;
+}
+
+// Ceres-style LM (same contract as pose_lm) on the first NP entries of x with the plain additive update
+template <int NP>
+__device__ void sim3_lm(double x[7], const Sim3Prob &Q, int max_it, double *lds, vo_lm_summary *sum) {
+  constexpr int NH = NP * (NP + 1) / 2, NA = NH + NP + 1;
+  double acc[NA];
+  sim3_accumulate<NP>(x, Q, true, acc);
+  block_sum<NA>(acc, lds);
+  double scale[NP];
+  {
+    int t = 0;
+#pragma unroll
+    for (int a = 0; a < NP; a++) {
+      scale[a] = 1.0 / (1.0 + sqrt(acc[t]));
+      t += NP - a;
+    }
+  }
+  auto norm_free = [](const double *v) {
+    double q = 0;
+#pragma unroll
+    for (int a = 0; a < NP; a++) q += v[a] * v[a];
+    return sqrt(q);
+  };
+  double radius = 1e4, decrease = 2.0, x_cost = acc[NH + NP];
+  const double initial_cost = x_cost;
+  double x_norm = norm_free(x);
+  int iterations = 0, accepted = 0, termination = 0, invalid = 0;
+  bool last_ok = false;
+  for (int it = 1;; it++) {
+    if (it - 1 >= max_it) {
+      termination = 0;
+      break;
+    }
+    if (last_ok) {
+      double gm = 0;
+#pragma unroll
+      for (int a = 0; a < NP; a++) gm = fmax(gm, fabs(acc[NH + a]));
+      if (gm <= 1e-10) {
+        termination = 3;
+        break;
+      }
+    }
+    if (radius < 1e-32) {
+      termination = 4;
+      break;
+    }
+    iterations = it;
+    last_ok = false;
+    double A[NP][NP], Hs[NP][NP], g[NP], y[NP];
+    {
+      int t = 0;
+#pragma unroll
+      for (int a = 0; a < NP; a++)
+#pragma unroll
+        for (int b = a; b < NP; b++) {
+          const double v = acc[t++] * scale[a] * scale[b];
+          Hs[a][b] = Hs[b][a] = v;
+        }
+    }
+#pragma unroll
+    for (int a = 0; a < NP; a++) {
+      g[a] = acc[NH + a] * scale[a];
+#pragma unroll
+      for (int b = 0; b < NP; b++) A[a][b] = Hs[a][b];
+      A[a][a] += fmin(fmax(Hs[a][a], 1e-6), 1e32) / radius;
+      y[a] = g[a];
+    }
+    bool ok = chol_solve_n<NP>(A, y);
+    double delta[7] = {0, 0, 0, 0, 0, 0, 0}, model = 0;
+    if (ok) {
+      double gs = 0, sHs = 0;
+#pragma unroll
+      for (int a = 0; a < NP; a++)
+        if (!isfinite(y[a])) ok = false;
+#pragma unroll
+      for (int a = 0; a < NP; a++) {
+        gs -= g[a] * y[a];
+        double row = 0;
+#pragma unroll
+        for (int b = 0; b < NP; b++) row -= Hs[a][b] * y[b];
+        sHs -= y[a] * row;
+        delta[a] = -y[a] * scale[a];
+      }
+      model = -(gs + 0.5 * sHs);
+    }
+    if (!ok || !(model > 0.0)) {
+      if (++invalid >= 5) {
+        termination = 4;
+        break;
+      }
+      radius /= decrease;
+      decrease *= 2.0;
+      continue;
+    }
+    invalid = 0;
+    double xc[7];
+#pragma unroll
+    for (int a = 0; a < 7; a++) xc[a] = x[a] + delta[a];
+    double cacc[NA];
+    sim3_accumulate<NP>(xc, Q, false, cacc);
+    double cc[1] = {cacc[NH + NP]};
+    block_sum<1>(cc, lds);
+    double cand = cc[0];
+    if (!isfinite(cand)) cand = 1.7976931348623157e308;
+    double sn = 0;
+#pragma unroll
+    for (int a = 0; a < NP; a++) sn += (x[a] - xc[a]) * (x[a] - xc[a]);
+    if (sqrt(sn) <= 1e-8 * (x_norm + 1e-8)) {
+      termination = 2;
+      break;
+    }
+    const double change = x_cost - cand;
+    if (fabs(change) <= 1e-6 * x_cost) {
+      termination = 1;
+      break;
+    }
+    const double rel = change / model;
+    if (rel > 1e-3) {
+#pragma unroll
+      for (int a = 0; a < 7; a++) x[a] = xc[a];
+      x_norm = norm_free(x);
+      sim3_accumulate<NP>(x, Q, true, acc);
+      block_sum<NA>(acc, lds);
+      x_cost = acc[NH + NP];
+      const double t2 = 2.0 * rel - 1.0;
+      radius = fmin(radius / fmax(1.0 / 3.0, 1.0 - t2 * t2 * t2), 1e16);
+      decrease = 2.0;
+      accepted++;
+      last_ok = true;
+    } else {
+      radius /= decrease;
+      decrease *= 2.0;
+    }
+  }
+  if (sum && threadIdx.x == 0) {
+    sum->iterations = iterations;
+    sum->accepted = accepted;
+    sum->termination = termination;
+    sum->reserved = 0;
+    sum->initial_cost = initial_cost;
+    sum->final_cost = x_cost;
+    sum->final_radius = radius;
+  }
+}
+
+template <int NP>
+__global__ __launch_bounds__(256) void k_sim3(const int *offsets, const double *Pm, const double *pc, const double *isc,
+                                              const double *Pc, const double *pm, const double *ism, const double *cam4,
+                                              double *poses, double *scales, uint8_t *outlier, int *n_inliers,
+                                              vo_lm_summary *sums) {
+  __shared__ double lds[4 * 36];
+  __shared__ int s_cnt[4];
+  const int p = blockIdx.x;
+  const int o0 = offsets[p], n = offsets[p + 1] - o0;
+  Sim3Prob Q;
+  Q.n = n, Q.Pm = Pm + 3 * (long long)o0, Q.pc = pc + 2 * (long long)o0, Q.isc = isc + o0;
+  Q.Pc = Pc + 3 * (long long)o0, Q.pm = pm + 2 * (long long)o0, Q.ism = ism + o0;
+  Q.skip = nullptr;
+  for (int a = 0; a < 4; a++) Q.cam[a] = cam4[a];
+  Q.huber = (double)sqrtf(10.0f);  // :880
+  outlier += o0;
+  double x[7], x_in[7];
+  for (int a = 0; a < 6; a++) x[a] = x_in[a] = poses[6 * p + a];
+  x[6] = x_in[6] = scales[p];
+  for (int i = threadIdx.x; i < n; i += blockDim.x) outlier[i] = 0;
+  __syncthreads();
+  if (sums && threadIdx.x == 0) {
+    vo_lm_summary z = {};
+    sums[2 * p] = z, sums[2 * p + 1] = z;
+  }
+  if (n > 0) sim3_lm<NP>(x, Q, 10, lds, sums ? &sums[2 * p] : nullptr);
+  auto classify = [&](bool keep_old) {  // returns the number of matches passing both chi2 tests now
+    const Sim3Frame F = sim3_frame(x, false);
+    int cnt = 0;
+    for (int i = threadIdx.x; i < n; i += blockDim.x) {
+      const bool o = sim3_outlier(F, Q.Pm + 3 * i, Q.pc[2 * i], Q.pc[2 * i + 1], Q.isc[i], Q.Pc + 3 * i, Q.pm[2 * i],
+                                  Q.pm[2 * i + 1], Q.ism[i], Q.cam);
+      if (o || !keep_old) outlier[i] = o ? 1 : 0;
+      cnt += o ? 0 : 1;
+    }
+#pragma unroll
+    for (int o2 = 32; o2 >= 1; o2 >>= 1) cnt += __shfl_xor(cnt, o2);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) s_cnt[threadIdx.x >> 6] = cnt;
+    __syncthreads();
+    return s_cnt[0] + s_cnt[1] + s_cnt[2] + s_cnt[3];
+  };
+  const int ok1 = classify(false);
+  int inliers = 0;
+  if (ok1 < 10) {  // :950-951 returns before Scm is written
+    for (int a = 0; a < 7; a++) x[a] = x_in[a];
+  } else {
+    Q.skip = outlier;  // problem 2: survivors only (:958-960); continues from problem 1's estimate
+    __syncthreads();
+    sim3_lm<NP>(x, Q, ok1 < n ? 10 : 5, lds, sums ? &sums[2 * p + 1] : nullptr);
+    __syncthreads();
+    inliers = classify(true);  // :996-1022 tests every match again
+  }
+  if (threadIdx.x == 0) {
+    for (int a = 0; a < 6; a++) poses[6 * p + a] = x[a];
+    scales[p] = x[6];
+    n_inliers[p] = inliers;
+  }
+}
+
+// ============================================================================================
 // Local BA
 // ============================================================================================
 constexpr int kGroupLog = 4;
@@ -1879,6 +2165,59 @@ int vo_pose_only_solve(int n_problems, const int32_t *offsets, const double *poi
     return fail(VO_ERR_HIP);
   }
   (void)hipMemcpy(poses, d_pose.p, (size_t)n_problems * 48, hipMemcpyDeviceToHost);
+  if (total > 0) (void)hipMemcpy(outlier, d_out.p, total, hipMemcpyDeviceToHost);
+  (void)hipMemcpy(n_inliers, d_inl.p, (size_t)n_problems * 4, hipMemcpyDeviceToHost);
+  if (summaries)
+    (void)hipMemcpy(summaries, d_sum.p, (size_t)n_problems * 2 * sizeof(vo_lm_summary), hipMemcpyDeviceToHost);
+  return fail(VO_OK);
+}
+
+int vo_sim3_solve(int n_problems, const int32_t *offsets, const double *cam_match, const double *pix_curr,
+                  const double *inv_sigma_curr, const double *cam_curr, const double *pix_match,
+                  const double *inv_sigma_match, const double camera[4], int fix_scale, double *poses, double *scales,
+                  uint8_t *outlier, int32_t *n_inliers, vo_lm_summary *summaries) {
+  if (n_problems < 0 || (n_problems > 0 && (!offsets || !poses || !scales || !n_inliers || !camera))) return VO_ERR_INVALID;
+  if (n_problems == 0) return VO_OK;
+  VO_CHECK(vo::ensure_device());
+  const int total = offsets[n_problems];
+  if (total > 0 && (!cam_match || !pix_curr || !inv_sigma_curr || !cam_curr || !pix_match || !inv_sigma_match || !outlier))
+    return VO_ERR_INVALID;
+  vo::DevBuf d_off, d_pm, d_pc, d_isc, d_Pc, d_pxm, d_ism, d_cam, d_pose, d_sc, d_out, d_inl, d_sum;
+  int rc = VO_OK;
+  auto fail = [&](int r) {
+    for (vo::DevBuf *b : {&d_off, &d_pm, &d_pc, &d_isc, &d_Pc, &d_pxm, &d_ism, &d_cam, &d_pose, &d_sc, &d_out, &d_inl, &d_sum})
+      b->release();
+    return r;
+  };
+  if ((rc = upload(d_off, offsets, (size_t)(n_problems + 1) * 4)) != VO_OK) return fail(rc);
+  if ((rc = upload(d_pm, cam_match, (size_t)total * 24)) != VO_OK) return fail(rc);
+  if ((rc = upload(d_pc, pix_curr, (size_t)total * 16)) != VO_OK) return fail(rc);
+  if ((rc = upload(d_isc, inv_sigma_curr, (size_t)total * 8)) != VO_OK) return fail(rc);
+  if ((rc = upload(d_Pc, cam_curr, (size_t)total * 24)) != VO_OK) return fail(rc);
+  if ((rc = upload(d_pxm, pix_match, (size_t)total * 16)) != VO_OK) return fail(rc);
+  if ((rc = upload(d_ism, inv_sigma_match, (size_t)total * 8)) != VO_OK) return fail(rc);
+  if ((rc = upload(d_cam, camera, 32)) != VO_OK) return fail(rc);
+  if ((rc = upload(d_pose, poses, (size_t)n_problems * 48)) != VO_OK) return fail(rc);
+  if ((rc = upload(d_sc, scales, (size_t)n_problems * 8)) != VO_OK) return fail(rc);
+  if ((rc = d_out.reserve(std::max(64, total))) != VO_OK) return fail(rc);
+  if ((rc = d_inl.reserve((size_t)n_problems * 4)) != VO_OK) return fail(rc);
+  if ((rc = d_sum.reserve((size_t)n_problems * 2 * sizeof(vo_lm_summary))) != VO_OK) return fail(rc);
+  if (fix_scale)
+    hipLaunchKernelGGL(k_sim3<6>, dim3(n_problems), dim3(256), 0, nullptr, d_off.as<int>(), d_pm.as<double>(),
+                       d_pc.as<double>(), d_isc.as<double>(), d_Pc.as<double>(), d_pxm.as<double>(), d_ism.as<double>(),
+                       d_cam.as<double>(), d_pose.as<double>(), d_sc.as<double>(), d_out.as<uint8_t>(), d_inl.as<int>(),
+                       d_sum.as<vo_lm_summary>());
+  else
+    hipLaunchKernelGGL(k_sim3<7>, dim3(n_problems), dim3(256), 0, nullptr, d_off.as<int>(), d_pm.as<double>(),
+                       d_pc.as<double>(), d_isc.as<double>(), d_Pc.as<double>(), d_pxm.as<double>(), d_ism.as<double>(),
+                       d_cam.as<double>(), d_pose.as<double>(), d_sc.as<double>(), d_out.as<uint8_t>(), d_inl.as<int>(),
+                       d_sum.as<vo_lm_summary>());
+  if (hipDeviceSynchronize() != hipSuccess) {
+    vo::set_error("Sim3 kernel failed: %s", hipGetErrorString(hipGetLastError()));
+    return fail(VO_ERR_HIP);
+  }
+  (void)hipMemcpy(poses, d_pose.p, (size_t)n_problems * 48, hipMemcpyDeviceToHost);
+  (void)hipMemcpy(scales, d_sc.p, (size_t)n_problems * 8, hipMemcpyDeviceToHost);
   if (total > 0) (void)hipMemcpy(outlier, d_out.p, total, hipMemcpyDeviceToHost);
   (void)hipMemcpy(n_inliers, d_inl.p, (size_t)n_problems * 4, hipMemcpyDeviceToHost);
   if (summaries)

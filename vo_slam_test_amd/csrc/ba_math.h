@@ -244,5 +244,134 @@ VO_HD bool inv3_sym(const double h[6], double o[6]) {
   return true;
 }
 
+
+// ---- Sim3 residual blocks of the loop-closure optimisation (reference optimizer_ceres.h:211-267 over
+// IntrinsicProjectionUV, optimizer_ceres.cpp:8-42).  x = [angle-axis(3); t(3); s].
+struct Sim3Frame {  // quantities of x shared by all matches
+  double R[9];      // row-major rotation (ceres::AngleAxisToRotationMatrix, same theta^2 > eps branch)
+  double Jr[9], Jl[9];  // right / left Jacobian of SO(3):  d(R p)/dw = -R [p]x Jr,  d(R^T v)/dw = R^T [v]x Jl
+  double t[3], s;
+};
+
+VO_HD void mat3_mul_rm(const double A[9], const double B[9], double C[9]) {
+#pragma unroll
+  for (int i = 0; i < 3; i++)
+#pragma unroll
+    for (int j = 0; j < 3; j++) C[3 * i + j] = A[3 * i] * B[j] + A[3 * i + 1] * B[3 + j] + A[3 * i + 2] * B[6 + j];
+}
+
+VO_HD Sim3Frame sim3_frame(const double x[7], bool want_jac) {
+  Sim3Frame F;
+  const double se3[6] = {0, 0, 0, x[0], x[1], x[2]};
+  const PoseCache P = pose_cache(se3);
+#pragma unroll
+  for (int i = 0; i < 9; i++) F.R[i] = P.R[i];
+  F.t[0] = x[3], F.t[1] = x[4], F.t[2] = x[5], F.s = x[6];
+  if (want_jac) {
+    const double w0 = x[0], w1 = x[1], w2 = x[2];
+    const double t2 = w0 * w0 + w1 * w1 + w2 * w2;
+    const double W[9] = {0, -w2, w1, w2, 0, -w0, -w1, w0, 0};
+    double W2[9];
+    mat3_mul_rm(W, W, W2);
+    double a = 0, b = 0;
+    if (t2 > kDblEps) {
+      const double th = sqrt(t2);
+      a = (1.0 - cos(th)) / t2;
+      b = (th - sin(th)) / (t2 * th);
+    }
+#pragma unroll
+    for (int i = 0; i < 9; i++) {
+      const double id = (i % 4 == 0) ? 1.0 : 0.0;
+      F.Jr[i] = id - a * W[i] + b * W2[i];
+      F.Jl[i] = id + a * W[i] + b * W2[i];
+    }
+  }
+  return F;
+}
+
+// IntrinsicProjectionUV::Evaluate: residual with 1/sigma, Jacobian without it
+template <bool WANT_J>
+VO_HD void intrinsic_uv(const double p[3], double pu, double pv, const double cam[4], double isig, double r[2],
+                        double J[6]) {
+  const double x = p[0], y = p[1], z = p[2];
+  const double invz = 1.0 / z, invz2 = invz * invz;
+  r[0] = (pu - (cam[0] * x * invz + cam[2])) * isig;
+  r[1] = (pv - (cam[1] * y * invz + cam[3])) * isig;
+  if (WANT_J) {
+    J[0] = -invz * cam[0], J[1] = 0, J[2] = x * invz2 * cam[0];
+    J[3] = 0, J[4] = -invz * cam[1], J[5] = y * invz2 * cam[1];
+  }
+}
+
+// r = [forward(2); inverse(2)], J = 4 x 7 row-major (column 6 = scale)
+template <bool WANT_J>
+VO_HD void sim3_eval(const Sim3Frame &F, const double Pm[3], double pcu, double pcv, double isc, const double Pc[3],
+                     double pmu, double pmv, double ism, const double cam[4], double r[4], double *J) {
+  const double *R = F.R;
+  const double s = F.s;
+  const double Rp[3] = {R[0] * Pm[0] + R[1] * Pm[1] + R[2] * Pm[2], R[3] * Pm[0] + R[4] * Pm[1] + R[5] * Pm[2],
+                        R[6] * Pm[0] + R[7] * Pm[1] + R[8] * Pm[2]};
+  const double p[3] = {s * Rp[0] + F.t[0], s * Rp[1] + F.t[1], s * Rp[2] + F.t[2]};
+  double Juv[6];
+  intrinsic_uv<WANT_J>(p, pcu, pcv, cam, isc, r, Juv);
+  if (WANT_J) {
+    const double Px[9] = {0, -Pm[2], Pm[1], Pm[2], 0, -Pm[0], -Pm[1], Pm[0], 0};
+    double RP[9], D[9];
+    mat3_mul_rm(R, Px, RP);
+    mat3_mul_rm(RP, F.Jr, D);
+#pragma unroll
+    for (int k = 0; k < 2; k++) {
+#pragma unroll
+      for (int a = 0; a < 3; a++)
+        J[7 * k + a] = -s * (Juv[3 * k] * D[a] + Juv[3 * k + 1] * D[3 + a] + Juv[3 * k + 2] * D[6 + a]);
+#pragma unroll
+      for (int a = 0; a < 3; a++) J[7 * k + 3 + a] = Juv[3 * k + a];
+      J[7 * k + 6] = Juv[3 * k] * Rp[0] + Juv[3 * k + 1] * Rp[1] + Juv[3 * k + 2] * Rp[2];
+    }
+  }
+  const double v[3] = {(Pc[0] - F.t[0]) / s, (Pc[1] - F.t[1]) / s, (Pc[2] - F.t[2]) / s};
+  const double q[3] = {R[0] * v[0] + R[3] * v[1] + R[6] * v[2], R[1] * v[0] + R[4] * v[1] + R[7] * v[2],
+                       R[2] * v[0] + R[5] * v[1] + R[8] * v[2]};  // R^T v
+  intrinsic_uv<WANT_J>(q, pmu, pmv, cam, ism, r + 2, Juv);
+  if (WANT_J) {
+    const double V[9] = {0, -v[2], v[1], v[2], 0, -v[0], -v[1], v[0], 0};
+    const double Rt[9] = {R[0], R[3], R[6], R[1], R[4], R[7], R[2], R[5], R[8]};
+    double VJ[9], D[9];
+    mat3_mul_rm(V, F.Jl, VJ);
+    mat3_mul_rm(Rt, VJ, D);
+#pragma unroll
+    for (int k = 0; k < 2; k++) {
+      double *Jk = J + 14 + 7 * k;
+#pragma unroll
+      for (int a = 0; a < 3; a++) Jk[a] = Juv[3 * k] * D[a] + Juv[3 * k + 1] * D[3 + a] + Juv[3 * k + 2] * D[6 + a];
+#pragma unroll
+      for (int a = 0; a < 3; a++)
+        Jk[3 + a] = -(Juv[3 * k] * Rt[a] + Juv[3 * k + 1] * Rt[3 + a] + Juv[3 * k + 2] * Rt[6 + a]) / s;
+      Jk[6] = -(Juv[3 * k] * q[0] + Juv[3 * k + 1] * q[1] + Juv[3 * k + 2] * q[2]) / s;
+    }
+  }
+}
+
+// chi2 > 10 tests of optimizer_ceres.cpp:916-948 / :996-1022 (double; camera2pixel = fx x / z + cx)
+VO_HD bool sim3_outlier(const Sim3Frame &F, const double Pm[3], double pcu, double pcv, double isc, const double Pc[3],
+                        double pmu, double pmv, double ism, const double cam[4]) {
+  const double *R = F.R;
+  const double s = F.s;
+  double p[3];
+#pragma unroll
+  for (int i = 0; i < 3; i++) p[i] = s * (R[3 * i] * Pm[0] + R[3 * i + 1] * Pm[1] + R[3 * i + 2] * Pm[2]) + F.t[i];
+  const double eu = cam[0] * p[0] / p[2] + cam[2] - pcu, ev = cam[1] * p[1] / p[2] + cam[3] - pcv;
+  if ((eu * eu + ev * ev) * isc * isc > 10.0) return true;
+  double q[3];
+#pragma unroll
+  for (int i = 0; i < 3; i++) {
+    const double Rtp = R[i] * Pc[0] + R[3 + i] * Pc[1] + R[6 + i] * Pc[2];
+    const double Rtt = R[i] * F.t[0] + R[3 + i] * F.t[1] + R[6 + i] * F.t[2];
+    q[i] = Rtp / s - Rtt / s;
+  }
+  const double fu = cam[0] * q[0] / q[2] + cam[2] - pmu, fv = cam[1] * q[1] / q[2] + cam[3] - pmv;
+  return (fu * fu + fv * fv) * ism * ism > 10.0;
+}
+
 }  // namespace ba
 }  // namespace vo

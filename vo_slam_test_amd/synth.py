@@ -172,3 +172,43 @@ def make_lba_problem(i: int = 0, n_kf: int = 10, n_pts: int = 3000, n_fixed: int
                 e_cam=np.asarray(e_cam, np.int32), e_pt=np.asarray(e_pt, np.int32),
                 e_obs=np.ascontiguousarray(e_obs), e_inv_sigma=np.asarray(e_is, np.float64),
                 cam=CAM.copy())
+
+
+# --------------------------------------------------------------------------- Sim3 (loop closure)
+def _rodrigues(w):
+    th = np.linalg.norm(w)
+    if th < 1e-12:
+        return np.eye(3) + _hat(w)
+    k = w / th
+    K = _hat(k)
+    return np.eye(3) + np.sin(th) * K + (1 - np.cos(th)) * K @ K
+
+
+def make_sim3_problem(seed: int, n: int = 150, outliers: float = 0.1, scale: float = 1.0):
+    """Matched map points seen from the current and the loop key-frame (solveLoopSim3's inputs,
+    optimizer_ceres.cpp:846-878): true Scm = (s, R, t), initial guess perturbed."""
+    rng = _rng(0x51300000 + seed)
+    fx, fy, cx, cy = CAM[:4]
+    w_true = rng.uniform(-0.3, 0.3, 3)
+    t_true = rng.uniform(-0.5, 0.5, 3)
+    R = _rodrigues(w_true)
+    Pm = np.column_stack([rng.uniform(-2, 2, n), rng.uniform(-1.5, 1.5, n), rng.uniform(2, 6, n)])
+    Pc = scale * (Pm @ R.T) + t_true
+    ok = Pc[:, 2] > 0.5
+    Pm, Pc = Pm[ok], Pc[ok]
+    n = len(Pm)
+    octs = rng.integers(0, 8, (2, n))
+    sig = 1.2 ** octs
+    pix_m = np.column_stack([fx * Pm[:, 0] / Pm[:, 2] + cx, fy * Pm[:, 1] / Pm[:, 2] + cy]) + rng.normal(0, 1, (n, 2)) * sig[0][:, None]
+    pix_c = np.column_stack([fx * Pc[:, 0] / Pc[:, 2] + cx, fy * Pc[:, 1] / Pc[:, 2] + cy]) + rng.normal(0, 1, (n, 2)) * sig[1][:, None]
+    bad = rng.random(n) < outliers
+    pix_c[bad] += rng.uniform(-60, 60, (int(bad.sum()), 2))
+    # the stored 3-D points carry some triangulation noise
+    Pm_n = Pm + rng.normal(0, 0.01, Pm.shape)
+    Pc_n = Pc + rng.normal(0, 0.01, Pc.shape)
+    pose0 = np.concatenate([w_true + rng.uniform(-0.03, 0.03, 3), t_true + rng.uniform(-0.05, 0.05, 3)])
+    return dict(cam_match=np.ascontiguousarray(Pm_n), pix_curr=np.ascontiguousarray(pix_c),
+                isig_curr=np.ascontiguousarray(1.0 / sig[1]), cam_curr=np.ascontiguousarray(Pc_n),
+                pix_match=np.ascontiguousarray(pix_m), isig_match=np.ascontiguousarray(1.0 / sig[0]),
+                cam=np.array(CAM, np.float64), pose0=pose0, scale0=float(scale), pose_true=np.concatenate([w_true, t_true]),
+                is_outlier=bad)
