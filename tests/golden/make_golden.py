@@ -150,6 +150,32 @@ def g5_lba():
                         final_cost=np.array([sums[0].final_cost, sums[1].final_cost]))
 
 
+def g8_sim3():
+    """solveLoopSim3 (B10/B11) on one synthetic loop candidate + the loop-closure searches on g3's frames"""
+    pr = synth.make_sim3_problem(5, n=120, outliers=0.1)
+    pose, scale, outl, inl, sums = O.sim3_solve(pr)
+    arrays = {k: v for k, v in pr.items() if isinstance(v, np.ndarray)}
+    out = dict(**arrays, scale0=np.float64(pr["scale0"]), out_pose=pose, out_scale=np.float64(scale), outlier=outl,
+               n_inlier=np.int32(inl), iters=np.array([sums[0].iterations, sums[1].iterations], np.int32),
+               final_cost=np.array([sums[0].final_cost, sums[1].final_cost]))
+    g = np.load(HERE / "g3_match.npz")
+    n = len(g["d0"])
+    B = O.FrameData(g["kx"], g["ky"], g["koct"], g["kang"], g["ur"], g["d1"])
+    flags = np.ones(n, np.uint8)
+    lvl = g["q_oct"].astype(np.int32)
+    best = np.full(n, -1, np.int32)
+    out["area_n"] = np.int32(O.lib().orc_match_area_best(C.byref(B.c), n, flags, g["q_u"], g["q_v"], lvl,
+                                                         np.ascontiguousarray(g["d0"]), 7.5, g["scale"], 100, best))
+    out["area_best"] = best
+    occ = np.zeros(n, np.uint8)
+    occ[:2] = 1
+    assigned = np.full(n, -1, np.int32)
+    out["sim3proj_n"] = np.int32(O.lib().orc_match_sim3_projection(C.byref(B.c), n, flags, g["q_u"], g["q_v"], lvl,
+                                                                   np.ascontiguousarray(g["d0"]), 5, g["scale"], occ, assigned))
+    out["sim3proj"], out["sim3proj_occ"] = assigned, occ
+    np.savez_compressed(HERE / "g8_sim3.npz", **out)
+
+
 def g7_se3():
     rng = np.random.default_rng(1)
     xi = np.concatenate([rng.uniform(-2, 2, (12, 6)), np.array([[0.1, 0.2, 0.3, 0, 0, 0], [0.1, 0.2, 0.3, 1e-12, 0, 0],
@@ -163,7 +189,7 @@ def g7_se3():
 
 
 if __name__ == "__main__":
-    for fn in (g1_extract, g2_fast, g3_match, g6_match_kf, g4_pose, g5_lba, g7_se3):
+    for fn in (g1_extract, g2_fast, g3_match, g6_match_kf, g4_pose, g5_lba, g7_se3, g8_sim3):
         fn()
         print("wrote", fn.__name__)
     import os

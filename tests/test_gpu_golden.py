@@ -83,3 +83,23 @@ def test_g7_se3(vo):
         R, t = vo.se3_exp(xi)
         assert np.abs(t - g["trans"][i]).max() < 1e-13
         assert np.abs(R @ g["point"] + t - g["transformed"][i]).max() < 1e-12
+
+
+def test_g8_sim3_and_loop_searches(vo):
+    g, g3 = np.load(G / "g8_sim3.npz"), np.load(G / "g3_match.npz")
+    pr = {k: g[k] for k in ("cam_match", "pix_curr", "isig_curr", "cam_curr", "pix_match", "isig_match", "cam", "pose0")}
+    pr["scale0"] = float(g["scale0"])
+    poses, scales, masks, ninl, sums = vo.Optimizer.solveLoopSim3([pr], summaries=True)
+    assert ninl[0] == int(g["n_inlier"]) and np.array_equal(masks[0], g["outlier"])
+    assert np.abs(poses[0] - g["out_pose"]).max() < 1e-9 and scales[0] == float(g["out_scale"])
+    assert [sums[0].iterations, sums[1].iterations] == g["iters"].tolist()
+    assert np.allclose([sums[0].final_cost, sums[1].final_cost], g["final_cost"], rtol=1e-9)
+    n = len(g3["d0"])
+    kf = vo.FrameArrays(g3["kx"], g3["ky"], g3["koct"], g3["kang"], g3["ur"], g3["d1"])
+    q = dict(flags=np.ones(n, np.uint8), u=g3["q_u"], v=g3["q_v"], level=g3["q_oct"].astype(np.int32),
+             desc=np.ascontiguousarray(g3["d0"]))
+    m = vo.Matcher(0.8)
+    cnt, best = m.areaBest(kf, q, 7.5, g3["scale"], 100)
+    assert cnt == int(g["area_n"]) and np.array_equal(best, g["area_best"])
+    cnt, assigned = m.searchByProjection_sim3(kf, q, 5, g3["scale"], g["sim3proj_occ"])
+    assert cnt == int(g["sim3proj_n"]) and np.array_equal(assigned, g["sim3proj"])

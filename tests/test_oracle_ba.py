@@ -212,3 +212,14 @@ def test_sim3_jacobians_and_convergence(orc):
     assert outl[pr["is_outlier"]].mean() > 0.9          # gross outliers are rejected
     pose7, s7, _, inl7, _ = orc.sim3_solve(pr, fix_scale=False)
     assert abs(s7 - 1.0) < 0.05 and inl7 > 0.6 * len(outl)
+
+
+def test_sim3_fixture(orc):
+    """the committed g8 fixture is what the oracle produces today"""
+    import pathlib
+    g = np.load(pathlib.Path(__file__).parent / "golden" / "g8_sim3.npz")
+    pr = {k: g[k] for k in ("cam_match", "pix_curr", "isig_curr", "cam_curr", "pix_match", "isig_match", "cam", "pose0")}
+    pr["scale0"] = float(g["scale0"])
+    pose, scale, outl, inl, sums = orc.sim3_solve(pr)
+    assert inl == int(g["n_inlier"]) and np.array_equal(outl, g["outlier"])
+    assert np.array_equal(pose, g["out_pose"]) and scale == float(g["out_scale"])
