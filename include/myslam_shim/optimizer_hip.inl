@@ -183,4 +183,37 @@ int Optimizer::solveLoopSim3(KeyFrame *kf_curr, KeyFrame *kf_match, vector<MapPo
   return inliers;
 }
 
+// The solve and the map-point re-anchoring inside Optimizer::solvePoseGraphLoop, reference
+// optimizer_ceres.cpp:1036-1305.  The edge construction (:1094-1236) is the reference's own code with
+// `problem.AddResidualBlock(...)` replaced by `pg.add(id1, id2, Sji)`; only what changes is shown.
+struct PoseGraphArrays {
+  std::vector<double> quats, trans, scales, q_meas, t_meas, s_meas;
+  std::vector<int32_t> e_i, e_j;
+  explicit PoseGraphArrays(size_t n_ids) : quats(4 * n_ids, 0.0), trans(3 * n_ids, 0.0), scales(n_ids, 1.0) {
+    for (size_t i = 0; i < n_ids; i++) quats[4 * i + 3] = 1.0;
+  }
+  void set_node(unsigned long id, const Sophus::Sim3 &S) {  // :1074-1076
+    const Eigen::Quaterniond q = S.quaternion().normalized();
+    memcpy(&quats[4 * id], q.coeffs().data(), 32);          // x, y, z, w
+    memcpy(&trans[3 * id], S.translation().data(), 24);
+    scales[id] = S.scale();
+  }
+  void add(unsigned long id1, unsigned long id2, const Sophus::Sim3 &Sji) {
+    const Eigen::Quaterniond q = Sji.quaternion().normalized();
+    e_i.push_back((int32_t)id1), e_j.push_back((int32_t)id2);
+    q_meas.insert(q_meas.end(), q.coeffs().data(), q.coeffs().data() + 4);
+    t_meas.insert(t_meas.end(), Sji.translation().data(), Sji.translation().data() + 3);
+    s_meas.push_back(Sji.scale());
+  }
+  int solve(unsigned long fixed_id, bool fixScaleFlag) {  // :1238-1258
+    return vo_pose_graph_solve((int)scales.size(), quats.data(), trans.data(), scales.data(), (int)fixed_id,
+                               (int)e_i.size(), e_i.data(), e_j.data(), q_meas.data(), t_meas.data(), s_meas.data(),
+                               fixScaleFlag ? 1 : 0, 20, nullptr);
+  }
+};
+// After pg.solve(keyframe_match->id_, fixScaleFlag): key-frame poses are written as at :1264-1278
+// (SE3(uq, t / s)), the Sim3 pairs (Scw[idm], optimizedSwc[idm]) are packed 8 doubles each and
+// vo_sim3_reanchor_points() produces every corrected map-point position of :1281-1301 in one call
+// (ref = correctReference_ or keyFrame_ref_->id_, -1 for bad points).
+
 }  // namespace myslam

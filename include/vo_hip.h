@@ -278,6 +278,29 @@ int vo_sim3_solve(int n_problems, const int32_t *offsets, const double *cam_matc
                   const double *inv_sigma_match, const double camera[4], int fix_scale, double *poses,
                   double *scales, uint8_t *outlier, int32_t *n_inliers, vo_lm_summary *summaries /*2 per problem or NULL*/);
 
+/* The solve inside Optimizer::solvePoseGraphLoop (optimizer_ceres.cpp:1036-1305; cost functor
+ * PoseGraphLoop, optimizer_ceres.h:269-325): key-frame i = Sim3 S_iw as unit quaternion quats[4i..]
+ * (Eigen coefficient order x, y, z, w; ceres::EigenQuaternionParameterization), translation
+ * trans[3i..], scale scales[i] (constant: fix_scale must be 1, as loopClosing.cpp:15 always passes);
+ * edge e (edge_i -> edge_j) measures S_ji = (q_meas, t_meas, s_meas) (:1094-1236).  fixed_node is
+ * keyframe_match (:1238-1240).  No loss, LM, exact solve of the normal equations
+ * (SPARSE_NORMAL_CHOLESKY in the reference; here a dense blocked Cholesky with the trailing update on
+ * the FP64 matrix cores), max_iterations = 20 in the reference (:1253).  6 * (nodes - 1) <= 4096. */
+int vo_pose_graph_solve(int n_nodes, double *quats, double *trans, const double *scales, int fixed_node,
+                        int n_edges, const int32_t *edge_i, const int32_t *edge_j, const double *q_meas,
+                        const double *t_meas, const double *s_meas, int fix_scale, int max_iterations,
+                        vo_lm_summary *summary);
+
+/* Map-point re-anchoring after the pose graph (optimizer_ceres.cpp:1281-1301):
+ * out = S_wr[ref] * (S_rw[ref] * p); a Sim3 is 8 doubles: quaternion (x, y, z, w), translation, scale.
+ * ref_node[i] < 0 leaves the point unchanged (bad points are skipped, :1284-1285). */
+int vo_sim3_reanchor_points(int n_points, const double *points_in, const int32_t *ref_node, int n_nodes,
+                            const double *S_rw, const double *S_wr, double *points_out);
+
+/* Dense symmetric positive definite solve on the device (the blocked Cholesky behind
+ * vo_pose_graph_solve): A row-major, lower triangle read and overwritten by its factor, b -> x. */
+int vo_chol_solve(int n, double *A_rowmajor_lower, double *b);
+
 /* Bundle-adjustment problem handle (the arrays Optimizer::solveLocalBAPoseAndPoint gathers at
  * optimizer_ceres.cpp:446-592).  Edges may be given in any order; they are grouped by point
  * internally (stable).  cam_fixed[c] != 0 <=> SetParameterBlockConstant (:578-579). */

@@ -1322,3 +1322,274 @@ int orc_sim3_solve(int n, const double *cam_match, const double *pix_curr, const
   free(active);
   return inliers;
 }
+
+/* ------------------------------------------------------------- pose graph (loop closure) ----
+ * Optimizer::solvePoseGraphLoop numerics, optimizer_ceres.cpp:1036-1305, cost functor PoseGraphLoop
+ * (optimizer_ceres.h:269-325).  Node = Sim3 as unit quaternion (Eigen coefficient order x,y,z,w),
+ * translation, scale; edge (1 -> 2) with measurement S21 = (q21, t21, s21):
+ *   r[0:3] = 2 vec(q21 * q1 * q2^-1),  r[3:6] = s21 (q21 * t12) + t21,  r[6] = s21 s1 / s2   (Q-B4)
+ *   with t12 = s1 (q1 * (-(q2^-1 * (t2 / s2)))) + t1.
+ * Quaternions move by ceres::EigenQuaternionParameterization (x' = dq(delta) * x, dq = [sin|d| d/|d|,
+ * cos|d|]), translations additively, scales are constant (fixScaleFlag is always true,
+ * loopClosing.cpp:15); no loss; LM with an exact solve of the normal equations
+ * (SPARSE_NORMAL_CHOLESKY), <= 20 iterations.  Jacobians (tangent, 7 x 6 per node = [rotation,
+ * translation]) in closed form; they equal autodiff-ambient x ComputeJacobian because the
+ * parameterisation's columns are tangent to the unit sphere. */
+static void q_mul(const double a[4], const double b[4], double o[4]) { /* x,y,z,w */
+  o[0] = a[3] * b[0] + a[0] * b[3] + a[1] * b[2] - a[2] * b[1];
+  o[1] = a[3] * b[1] - a[0] * b[2] + a[1] * b[3] + a[2] * b[0];
+  o[2] = a[3] * b[2] + a[0] * b[1] - a[1] * b[0] + a[2] * b[3];
+  o[3] = a[3] * b[3] - a[0] * b[0] - a[1] * b[1] - a[2] * b[2];
+}
+static void q_conj(const double a[4], double o[4]) { o[0] = -a[0], o[1] = -a[1], o[2] = -a[2], o[3] = a[3]; }
+static void q_rot(const double q[4], const double v[3], double o[3]) { /* Eigen _transformVector */
+  const double uv[3] = {2 * (q[1] * v[2] - q[2] * v[1]), 2 * (q[2] * v[0] - q[0] * v[2]), 2 * (q[0] * v[1] - q[1] * v[0])};
+  o[0] = v[0] + q[3] * uv[0] + (q[1] * uv[2] - q[2] * uv[1]);
+  o[1] = v[1] + q[3] * uv[1] + (q[2] * uv[0] - q[0] * uv[2]);
+  o[2] = v[2] + q[3] * uv[2] + (q[0] * uv[1] - q[1] * uv[0]);
+}
+static void q_to_R(const double q[4], double R[9]) { /* row-major, unit quaternion */
+  const double x = q[0], y = q[1], z = q[2], w = q[3];
+  R[0] = 1 - 2 * (y * y + z * z), R[1] = 2 * (x * y - z * w), R[2] = 2 * (x * z + y * w);
+  R[3] = 2 * (x * y + z * w), R[4] = 1 - 2 * (x * x + z * z), R[5] = 2 * (y * z - x * w);
+  R[6] = 2 * (x * z - y * w), R[7] = 2 * (y * z + x * w), R[8] = 1 - 2 * (x * x + y * y);
+}
+/* ceres::EigenQuaternionParameterization::Plus */
+void orc_quat_plus(const double q[4], const double d[3], double o[4]) {
+  const double n = sqrt(d[0] * d[0] + d[1] * d[1] + d[2] * d[2]);
+  if (n > 0.0) {
+    const double s = sin(n) / n;
+    const double dq[4] = {s * d[0], s * d[1], s * d[2], cos(n)};
+    q_mul(dq, q, o);
+  } else {
+    o[0] = q[0], o[1] = q[1], o[2] = q[2], o[3] = q[3];
+  }
+}
+
+/* one edge: residual r[7]; J1, J2 (7 x 6 row-major: d/d[delta_rot, t]) or NULL */
+void orc_pose_graph_edge(const double q1[4], const double t1[3], double s1, const double q2[4], const double t2[3],
+                         double s2, const double qm[4], const double tm[3], double sm, double r[7], double *J1,
+                         double *J2) {
+  double q2i[4], q12[4], dq[4], t2s[3], w[3], t2inv[3], rq[3], t12[3], rt[3];
+  q_conj(q2, q2i);
+  q_mul(q1, q2i, q12);
+  q_mul(qm, q12, dq);
+  for (int k = 0; k < 3; k++) t2s[k] = (1.0 / s2) * t2[k];
+  q_rot(q2i, t2s, w);
+  for (int k = 0; k < 3; k++) t2inv[k] = -w[k];
+  q_rot(q1, t2inv, rq);
+  for (int k = 0; k < 3; k++) t12[k] = s1 * rq[k] + t1[k];
+  q_rot(qm, t12, rt);
+  for (int k = 0; k < 3; k++) r[k] = 2.0 * dq[k], r[3 + k] = sm * rt[k] + tm[k];
+  r[6] = sm * s1 * (1.0 / s2);
+  if (!J1 && !J2) return;
+  double Rm[9], R1[9], R2[9];
+  q_to_R(qm, Rm), q_to_R(q1, R1), q_to_R(q2, R2);
+  if (J1) {
+    memset(J1, 0, 42 * sizeof(double));
+    /* d(2 vec(qm (1 + d^) q12))/dd: column a = 2 vec(qm * e_a * q12), e_a pure unit quaternion */
+    for (int a = 0; a < 3; a++) {
+      double e[4] = {0, 0, 0, 0}, tmp[4], col[4];
+      e[a] = 1;
+      q_mul(qm, e, tmp);
+      q_mul(tmp, q12, col);
+      for (int k = 0; k < 3; k++) J1[6 * k + a] = 2.0 * col[k];
+    }
+    /* d r_t / d delta1 = sm Rm s1 (-2 [R1 t2inv]x);  d r_t / d t1 = sm Rm */
+    const double X[9] = {0, -rq[2], rq[1], rq[2], 0, -rq[0], -rq[1], rq[0], 0};
+    double M[9];
+    mat3_mul(Rm, X, M);
+    for (int k = 0; k < 3; k++)
+      for (int a = 0; a < 3; a++) {
+        J1[6 * (3 + k) + a] = -2.0 * sm * s1 * M[3 * k + a];
+        J1[6 * (3 + k) + 3 + a] = sm * Rm[3 * k + a];
+      }
+  }
+  if (J2) {
+    memset(J2, 0, 42 * sizeof(double));
+    /* q2'^-1 = q2^-1 (1 - d^):  column a = -2 vec(dq0 * e_a), dq0 = qm q1 q2^-1 */
+    for (int a = 0; a < 3; a++) {
+      double e[4] = {0, 0, 0, 0}, col[4];
+      e[a] = 1;
+      q_mul(dq, e, col);
+      for (int k = 0; k < 3; k++) J2[6 * k + a] = -2.0 * col[k];
+    }
+    /* t2inv' = t2inv - 2 R2^T [t2/s2]x d  =>  d r_t/d delta2 = sm Rm s1 R1 (-2 R2^T [t2/s2]x);
+     * d r_t / d t2 = sm Rm s1 R1 (-R2^T / s2) */
+    const double X[9] = {0, -t2s[2], t2s[1], t2s[2], 0, -t2s[0], -t2s[1], t2s[0], 0};
+    double R2t[9], A[9], Bm[9], Cm[9];
+    for (int i = 0; i < 3; i++)
+      for (int j = 0; j < 3; j++) R2t[3 * i + j] = R2[3 * j + i];
+    mat3_mul(Rm, R1, A);    /* Rm R1 */
+    mat3_mul(A, R2t, Bm);   /* Rm R1 R2^T */
+    mat3_mul(Bm, X, Cm);    /* Rm R1 R2^T [t2/s2]x */
+    for (int k = 0; k < 3; k++)
+      for (int a = 0; a < 3; a++) {
+        J2[6 * (3 + k) + a] = -2.0 * sm * s1 * Cm[3 * k + a];
+        J2[6 * (3 + k) + 3 + a] = -sm * s1 * (1.0 / s2) * Bm[3 * k + a];
+      }
+  }
+}
+
+typedef struct {
+  int n_nodes, n_edges, fixed, nfree;
+  const int32_t *e_i, *e_j;
+  const double *qm, *tm, *sm; /* per edge 4, 3, 1 */
+  const double *scales;       /* constant */
+  int *slot;                  /* node -> free index or -1 */
+  double *J, *r;              /* per edge 2 x 42, 7 */
+  double *colscale;           /* 6 nfree */
+  double *H, *g;              /* dense normal equations (scaled) */
+} pg_ctx;
+
+/* x = [q(4) t(3)] per node */
+static int pg_linearize(void *vc, const double *x, int first, double *cost, double *gmax) {
+  pg_ctx *c = (pg_ctx *)vc;
+  const int n = 6 * c->nfree;
+  double total = 0;
+  double *cn = (double *)calloc(n, sizeof(double)), *g = (double *)calloc(n, sizeof(double));
+  for (int e = 0; e < c->n_edges; e++) {
+    const int a = c->e_i[e], b = c->e_j[e];
+    double *J1 = c->J + (size_t)e * 84, *J2 = J1 + 42, *r = c->r + (size_t)e * 7;
+    orc_pose_graph_edge(x + 7 * a, x + 7 * a + 4, c->scales[a], x + 7 * b, x + 7 * b + 4, c->scales[b], c->qm + 4 * e,
+                        c->tm + 3 * e, c->sm[e], r, J1, J2);
+    for (int k = 0; k < 7; k++) total += 0.5 * r[k] * r[k];
+    const int sa = c->slot[a], sb = c->slot[b];
+    for (int k = 0; k < 7; k++)
+      for (int p = 0; p < 6; p++) {
+        if (sa >= 0) g[6 * sa + p] += J1[6 * k + p] * r[k], cn[6 * sa + p] += J1[6 * k + p] * J1[6 * k + p];
+        if (sb >= 0) g[6 * sb + p] += J2[6 * k + p] * r[k], cn[6 * sb + p] += J2[6 * k + p] * J2[6 * k + p];
+      }
+  }
+  if (first)
+    for (int i = 0; i < n; i++) c->colscale[i] = 1.0 / (1.0 + sqrt(cn[i]));
+  double m = 0;
+  for (int i = 0; i < n; i++)
+    if (fabs(g[i]) > m) m = fabs(g[i]);
+  /* scaled dense normal equations */
+  memset(c->H, 0, sizeof(double) * (size_t)n * n);
+  for (int i = 0; i < n; i++) c->g[i] = g[i] * c->colscale[i];
+  for (int e = 0; e < c->n_edges; e++) {
+    const int sl[2] = {c->slot[c->e_i[e]], c->slot[c->e_j[e]]};
+    const double *Jb[2] = {c->J + (size_t)e * 84, c->J + (size_t)e * 84 + 42};
+    for (int u = 0; u < 2; u++)
+      for (int v = 0; v < 2; v++) {
+        if (sl[u] < 0 || sl[v] < 0) continue;
+        for (int p = 0; p < 6; p++)
+          for (int q = 0; q < 6; q++) {
+            double acc = 0;
+            for (int k = 0; k < 7; k++) acc += Jb[u][6 * k + p] * Jb[v][6 * k + q];
+            const int ip = 6 * sl[u] + p, iq = 6 * sl[v] + q;
+            c->H[(size_t)ip * n + iq] += acc * c->colscale[ip] * c->colscale[iq];
+          }
+      }
+  }
+  free(cn);
+  free(g);
+  *cost = total;
+  *gmax = m;
+  return isfinite(total);
+}
+static int pg_step(void *vc, double radius, double *delta, double *model_change) {
+  pg_ctx *c = (pg_ctx *)vc;
+  const int n = 6 * c->nfree;
+  double *A = (double *)malloc(sizeof(double) * (size_t)n * n), *b = (double *)malloc(sizeof(double) * n);
+  memcpy(A, c->H, sizeof(double) * (size_t)n * n);
+  memcpy(b, c->g, sizeof(double) * n);
+  for (int i = 0; i < n; i++) {
+    double d = c->H[(size_t)i * n + i];
+    d = d < 1e-6 ? 1e-6 : (d > 1e32 ? 1e32 : d);
+    A[(size_t)i * n + i] += d / radius;
+  }
+  int ok = chol_solve(A, b, n);
+  if (ok)
+    for (int i = 0; i < n; i++)
+      if (!isfinite(b[i])) ok = 0;
+  if (ok) {
+    /* model cost change = -(g''.s + 0.5 s^T H'' s), s = -b */
+    double gs = 0, sHs = 0;
+    for (int i = 0; i < n; i++) {
+      double row = 0;
+      for (int j = 0; j < n; j++) row += c->H[(size_t)i * n + j] * b[j];
+      sHs += b[i] * row;
+      gs -= c->g[i] * b[i];
+    }
+    *model_change = -(gs + 0.5 * sHs);
+    memset(delta, 0, sizeof(double) * 6 * c->n_nodes);
+    for (int a = 0; a < c->n_nodes; a++)
+      if (c->slot[a] >= 0)
+        for (int p = 0; p < 6; p++) delta[6 * a + p] = -b[6 * c->slot[a] + p] * c->colscale[6 * c->slot[a] + p];
+  }
+  free(A);
+  free(b);
+  return ok;
+}
+static void pg_plus(void *vc, const double *x, const double *d, double *xn) {
+  pg_ctx *c = (pg_ctx *)vc;
+  for (int a = 0; a < c->n_nodes; a++) {
+    orc_quat_plus(x + 7 * a, d + 6 * a, xn + 7 * a);
+    for (int k = 0; k < 3; k++) xn[7 * a + 4 + k] = x[7 * a + 4 + k] + d[6 * a + 3 + k];
+  }
+}
+static int pg_cost(void *vc, const double *x, double *cost) {
+  pg_ctx *c = (pg_ctx *)vc;
+  double total = 0;
+  for (int e = 0; e < c->n_edges; e++) {
+    const int a = c->e_i[e], b = c->e_j[e];
+    double r[7];
+    orc_pose_graph_edge(x + 7 * a, x + 7 * a + 4, c->scales[a], x + 7 * b, x + 7 * b + 4, c->scales[b], c->qm + 4 * e,
+                        c->tm + 3 * e, c->sm[e], r, NULL, NULL);
+    for (int k = 0; k < 7; k++) total += 0.5 * r[k] * r[k];
+  }
+  *cost = total;
+  return isfinite(total);
+}
+static double pg_norm(void *vc, const double *x, const double *y) {
+  pg_ctx *c = (pg_ctx *)vc;
+  double s = 0;
+  for (int a = 0; a < c->n_nodes; a++) {
+    if (c->slot[a] < 0) continue; /* constant blocks are not part of the reduced program */
+    for (int k = 0; k < 7; k++) {
+      const double d = y ? x[7 * a + k] - y[7 * a + k] : x[7 * a + k];
+      s += d * d;
+    }
+  }
+  return sqrt(s);
+}
+
+/* nodes: quats (4n, x y z w), trans (3n) in/out; scales (n) constant.  Node `fixed` is constant. */
+int orc_pose_graph_solve(int n_nodes, double *quats, double *trans, const double *scales, int fixed, int n_edges,
+                         const int32_t *e_i, const int32_t *e_j, const double *q_meas, const double *t_meas,
+                         const double *s_meas, int max_iterations, orc_lm_summary *sum) {
+  pg_ctx c;
+  memset(&c, 0, sizeof(c));
+  c.n_nodes = n_nodes, c.n_edges = n_edges, c.fixed = fixed;
+  c.e_i = e_i, c.e_j = e_j, c.qm = q_meas, c.tm = t_meas, c.sm = s_meas, c.scales = scales;
+  c.slot = (int *)malloc(sizeof(int) * n_nodes);
+  /* a node is in the problem when an edge touches it (parameter blocks are added by AddResidualBlock) */
+  uint8_t *used = (uint8_t *)calloc(n_nodes, 1);
+  for (int e = 0; e < n_edges; e++) used[e_i[e]] = used[e_j[e]] = 1;
+  c.nfree = 0;
+  for (int a = 0; a < n_nodes; a++) c.slot[a] = (used[a] && a != fixed) ? c.nfree++ : -1;
+  const int n = 6 * c.nfree;
+  c.J = (double *)malloc(sizeof(double) * 84 * (size_t)(n_edges > 0 ? n_edges : 1));
+  c.r = (double *)malloc(sizeof(double) * 7 * (size_t)(n_edges > 0 ? n_edges : 1));
+  c.colscale = (double *)malloc(sizeof(double) * (n > 0 ? n : 1));
+  c.H = (double *)malloc(sizeof(double) * (size_t)(n > 0 ? n : 1) * (n > 0 ? n : 1));
+  c.g = (double *)malloc(sizeof(double) * (n > 0 ? n : 1));
+  double *x = (double *)malloc(sizeof(double) * 7 * n_nodes);
+  for (int a = 0; a < n_nodes; a++) {
+    memcpy(x + 7 * a, quats + 4 * a, 4 * sizeof(double));
+    memcpy(x + 7 * a + 4, trans + 3 * a, 3 * sizeof(double));
+  }
+  /* lm_minimize works on an ambient vector and a tangent delta of possibly different sizes: nx is
+   * the larger (ambient) one */
+  lm_problem P = {&c, 7 * n_nodes, pg_linearize, pg_step, pg_plus, pg_cost, pg_norm};
+  if (n > 0 && n_edges > 0) lm_minimize(&P, x, max_iterations, sum);
+  for (int a = 0; a < n_nodes; a++) {
+    memcpy(quats + 4 * a, x + 7 * a, 4 * sizeof(double));
+    memcpy(trans + 3 * a, x + 7 * a + 4, 3 * sizeof(double));
+  }
+  free(c.slot), free(used), free(c.J), free(c.r), free(c.colscale), free(c.H), free(c.g), free(x);
+  return 0;
+}

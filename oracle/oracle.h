@@ -229,6 +229,19 @@ int orc_sim3_solve(int n, const double *cam_match, const double *pix_curr, const
                    const double cam[4], int fix_scale, double pose[6], double *scale, uint8_t *outlier,
                    orc_lm_summary *sums /*[2] or NULL*/);
 
+/* ceres::EigenQuaternionParameterization::Plus (quaternion order x, y, z, w) */
+void orc_quat_plus(const double q[4], const double d[3], double o[4]);
+/* PoseGraphLoop residual (optimizer_ceres.h:269-325) of one edge and its tangent Jacobians
+ * (7 x 6 row-major per node: [rotation delta, translation]) or NULL */
+void orc_pose_graph_edge(const double q1[4], const double t1[3], double s1, const double q2[4], const double t2[3],
+                         double s2, const double qm[4], const double tm[3], double sm, double r[7], double *J1,
+                         double *J2);
+/* Optimizer::solvePoseGraphLoop's solve (optimizer_ceres.cpp:1238-1258) on flat arrays: scales
+ * constant (fixScaleFlag), node `fixed` constant, no loss, LM with exact normal-equation solves. */
+int orc_pose_graph_solve(int n_nodes, double *quats /*4n: x y z w*/, double *trans /*3n*/, const double *scales,
+                         int fixed, int n_edges, const int32_t *e_i, const int32_t *e_j, const double *q_meas,
+                         const double *t_meas, const double *s_meas, int max_iterations, orc_lm_summary *sum);
+
 #ifdef __cplusplus
 }
 #endif

@@ -142,6 +142,11 @@ def lib():
     L.orc_sim3_solve.argtypes = [C.c_int, _f64p, _f64p, _f64p, _f64p, _f64p, _f64p, _f64p, C.c_int, _f64p, _f64p, _u8p,
                                  C.c_void_p]
     L.orc_sim3_solve.restype = C.c_int
+    L.orc_quat_plus.argtypes = [_f64p, _f64p, _f64p]
+    L.orc_pose_graph_edge.argtypes = [_f64p, _f64p, C.c_double, _f64p, _f64p, C.c_double, _f64p, _f64p, C.c_double, _f64p,
+                                      C.c_void_p, C.c_void_p]
+    L.orc_pose_graph_solve.argtypes = [C.c_int, _f64p, _f64p, _f64p, C.c_int, C.c_int, _i32p, _i32p, _f64p, _f64p, _f64p,
+                                       C.c_int, C.c_void_p]
     L.orc_se3_exp.argtypes = [_f64p, _f64p, _f64p]
     L.orc_se3_log.argtypes = [_f64p, _f64p, _f64p]
     L.orc_se3_plus.argtypes = [_f64p, _f64p, _f64p]
@@ -329,3 +334,13 @@ def sim3_solve(prob, fix_scale=True, trace=False):
                                prob["pix_match"], prob["isig_match"], prob["cam"][:4].copy(), int(fix_scale), pose, scale,
                                outl, C.cast(sums, C.c_void_p))
     return pose, float(scale[0]), outl[:n], inl, sums
+
+
+def pose_graph_solve(g, max_iterations=20):
+    """Optimizer::solvePoseGraphLoop's solve on a synth.make_pose_graph dict -> (quats, trans, summary)"""
+    q, t = g["quats"].copy(), g["trans"].copy()
+    s = make_summary(max_iterations)
+    lib().orc_pose_graph_solve(len(q), q, t, np.ascontiguousarray(g["scales"], np.float64), int(g["fixed"]), len(g["e_i"]),
+                               g["e_i"], g["e_j"], g["q_meas"], g["t_meas"], np.ascontiguousarray(g["s_meas"], np.float64),
+                               max_iterations, C.cast(C.pointer(s), C.c_void_p))
+    return q, t, s

@@ -223,3 +223,41 @@ def test_sim3_fixture(orc):
     pose, scale, outl, inl, sums = orc.sim3_solve(pr)
     assert inl == int(g["n_inlier"]) and np.array_equal(outl, g["outlier"])
     assert np.array_equal(pose, g["out_pose"]) and scale == float(g["out_scale"])
+
+
+def test_pose_graph_jacobians_and_convergence(orc):
+    """closed-form tangent Jacobians of the PoseGraphLoop residual = finite differences through
+    EigenQuaternionParameterization::Plus; the solve reduces the non-constant part of the cost"""
+    from vo_slam_test_amd import synth
+    g = synth.make_pose_graph(0, n_kf=30)
+    L = orc.lib()
+    e = 7
+    a, b = g["e_i"][e], g["e_j"][e]
+    q1 = np.empty(4)
+    L.orc_quat_plus(g["quats"][a].copy(), np.array([0.03, -0.02, 0.05]), q1)
+    t1, q2, t2 = g["trans"][a] + 0.1, g["quats"][b].copy(), g["trans"][b].copy()
+    qm, tm = g["q_meas"][e].copy(), g["t_meas"][e].copy()
+
+    def ev(qa, ta, qb, tb, jac):
+        r, J1, J2 = np.zeros(7), np.zeros(42), np.zeros(42)
+        L.orc_pose_graph_edge(np.ascontiguousarray(qa), np.ascontiguousarray(ta), 1.0, np.ascontiguousarray(qb),
+                              np.ascontiguousarray(tb), 1.0, qm, tm, 1.0, r, J1.ctypes.data if jac else None,
+                              J2.ctypes.data if jac else None)
+        return r, J1.reshape(7, 6), J2.reshape(7, 6)
+
+    _, J1, J2 = ev(q1, t1, q2, t2, True)
+    N1, N2, h = np.zeros((7, 6)), np.zeros((7, 6)), 1e-6
+    for p in range(6):
+        for sg in (1.0, -1.0):
+            d = np.zeros(6)
+            d[p] = sg * h
+            qa, qb = np.empty(4), np.empty(4)
+            L.orc_quat_plus(q1, d[:3].copy(), qa)
+            L.orc_quat_plus(q2, d[:3].copy(), qb)
+            N1[:, p] += sg * ev(qa, t1 + d[3:], q2, t2, False)[0] / (2 * h)
+            N2[:, p] += sg * ev(q1, t1, qb, t2 + d[3:], False)[0] / (2 * h)
+    assert np.abs(J1 - N1).max() < 1e-7 and np.abs(J2 - N2).max() < 1e-7
+    q, t, s = orc.pose_graph_solve(g)
+    const = 0.5 * len(g["e_i"])            # r[6] = s21 s1 / s2 = 1 on every edge (Q-B4)
+    assert s.final_cost - const < 0.05 * (s.initial_cost - const)
+    assert np.abs(t - g["true_trans"]).max() < np.abs(g["trans"] - g["true_trans"]).max()

@@ -44,7 +44,7 @@ SYMBOLS = [
     "vo_match_frame_projection", "vo_match_local_map", "vo_match_frame_keyframe", "vo_match_bow",
     "vo_match_triangulation", "vo_match_fuse", "vo_match_area_best", "vo_match_sim3_projection",
     "vo_match_sim3_mutual",
-    "vo_pose_only_solve", "vo_sim3_solve", "vo_pose_only_solve_dev",
+    "vo_pose_only_solve", "vo_sim3_solve", "vo_pose_graph_solve", "vo_sim3_reanchor_points", "vo_chol_solve", "vo_pose_only_solve_dev",
     "vo_ba_create", "vo_ba_destroy", "vo_ba_set_stream", "vo_ba_set_shard", "vo_ba_set_state",
     "vo_ba_get_state", "vo_ba_n_free_cams", "vo_ba_local_ba", "vo_ba_local_ba_enqueue",
     "vo_ba_local_ba_finish", "vo_ba_solve", "vo_ba_lm_begin",
@@ -423,6 +423,39 @@ class Optimizer:
         if summaries:
             return poses, scales, masks, ninl, sums
         return poses, scales, masks, ninl
+
+
+    @staticmethod
+    def solvePoseGraphLoop(g, max_iterations=20):
+        """g: synth.make_pose_graph-style dict -> (quats, trans, summary)"""
+        q = np.ascontiguousarray(g["quats"], np.float64).copy()
+        t = np.ascontiguousarray(g["trans"], np.float64).copy()
+        sc = np.ascontiguousarray(g["scales"], np.float64)
+        ei, ej = np.ascontiguousarray(g["e_i"], np.int32), np.ascontiguousarray(g["e_j"], np.int32)
+        qm, tm = np.ascontiguousarray(g["q_meas"], np.float64), np.ascontiguousarray(g["t_meas"], np.float64)
+        sm = np.ascontiguousarray(g["s_meas"], np.float64)
+        s = LmSummary()
+        check(lib().vo_pose_graph_solve(len(q), _p(q), _p(t), _p(sc), int(g["fixed"]), len(ei), _p(ei), _p(ej), _p(qm),
+                                        _p(tm), _p(sm), 1, int(max_iterations), C.byref(s)), "vo_pose_graph_solve")
+        return q, t, s
+
+
+def chol_solve(A, b):
+    """dense SPD solve through the device Cholesky kernels -> (x, L)"""
+    A = np.ascontiguousarray(A, np.float64).copy()
+    x = np.ascontiguousarray(b, np.float64).copy()
+    check(lib().vo_chol_solve(len(x), _p(A), _p(x)), "vo_chol_solve")
+    return x, np.tril(A)
+
+
+def sim3_reanchor_points(points, ref, S_rw, S_wr):
+    points = np.ascontiguousarray(points, np.float64)
+    ref = np.ascontiguousarray(ref, np.int32)
+    S_rw, S_wr = np.ascontiguousarray(S_rw, np.float64), np.ascontiguousarray(S_wr, np.float64)
+    out = np.zeros_like(points)
+    check(lib().vo_sim3_reanchor_points(len(points), _p(points), _p(ref), len(S_rw), _p(S_rw), _p(S_wr), _p(out)),
+          "vo_sim3_reanchor_points")
+    return out
 
 
 class BundleAdjuster:

@@ -23,6 +23,7 @@ SOURCES = [
     ("orb.hip", ["-ffp-contract=off"]),
     ("match.hip", ["-ffp-contract=off"]),
     ("ba.hip", ["-ffp-contract=fast"]),
+    ("pose_graph.hip", ["-ffp-contract=fast"]),
 ]
 COMMON = ["-O3", "-std=c++17", f"--offload-arch={ARCH}", "-fPIC", "-Wall", "-Wno-unused-function"]
 

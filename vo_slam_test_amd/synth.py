@@ -212,3 +212,64 @@ def make_sim3_problem(seed: int, n: int = 150, outliers: float = 0.1, scale: flo
                 pix_match=np.ascontiguousarray(pix_m), isig_match=np.ascontiguousarray(1.0 / sig[0]),
                 cam=np.array(CAM, np.float64), pose0=pose0, scale0=float(scale), pose_true=np.concatenate([w_true, t_true]),
                 is_outlier=bad)
+
+
+# --------------------------------------------------------------------------- pose graph (loop closure)
+def _quat_from_R(R):
+    """unit quaternion (x, y, z, w) of a rotation matrix"""
+    w = np.sqrt(max(0.0, 1 + R[0, 0] + R[1, 1] + R[2, 2])) / 2
+    x = np.sqrt(max(0.0, 1 + R[0, 0] - R[1, 1] - R[2, 2])) / 2
+    y = np.sqrt(max(0.0, 1 - R[0, 0] + R[1, 1] - R[2, 2])) / 2
+    z = np.sqrt(max(0.0, 1 - R[0, 0] - R[1, 1] + R[2, 2])) / 2
+    x, y, z = np.copysign(x, R[2, 1] - R[1, 2]), np.copysign(y, R[0, 2] - R[2, 0]), np.copysign(z, R[1, 0] - R[0, 1])
+    q = np.array([x, y, z, w])
+    return q / np.linalg.norm(q)
+
+
+def _R_from_quat(q):
+    x, y, z, w = q
+    return np.array([[1 - 2 * (y * y + z * z), 2 * (x * y - z * w), 2 * (x * z + y * w)],
+                     [2 * (x * y + z * w), 1 - 2 * (x * x + z * z), 2 * (y * z - x * w)],
+                     [2 * (x * z - y * w), 2 * (y * z + x * w), 1 - 2 * (x * x + y * y)]])
+
+
+def make_pose_graph(seed: int, n_kf: int = 40, drift: float = 0.01, extra_edges: int = 2):
+    """Key-frames on a closed loop (world -> camera Sim3 with unit scale), odometry edges measured on a
+    drifted copy of the trajectory (what the map holds before the loop closes), covisibility edges
+    between near neighbours, and one loop edge carrying the true relative pose (the corrected side of
+    solvePoseGraphLoop, optimizer_ceres.cpp:1094-1125).  Edge (i -> j) measures S_ji = S_jw * S_wi."""
+    rng = _rng(0x9C0000 + seed)
+    ang = np.linspace(0, 2 * np.pi, n_kf, endpoint=False)
+    Rs, ts = [], []
+    for a in ang:
+        Rwc = _rodrigues(np.array([0, a + np.pi / 2, 0])) @ _rodrigues(rng.normal(0, 0.02, 3))
+        c = np.array([5 * np.cos(a), 0.1 * np.sin(3 * a), 5 * np.sin(a)])
+        Rcw = Rwc.T
+        Rs.append(Rcw), ts.append(-Rcw @ c)
+    # drifted estimate: accumulate small errors along the chain
+    Rd, td = [Rs[0]], [ts[0]]
+    for i in range(1, n_kf):
+        Rrel = Rs[i] @ Rs[i - 1].T
+        trel = ts[i] - Rrel @ ts[i - 1]
+        Rrel = _rodrigues(rng.normal(0, drift, 3)) @ Rrel
+        trel = trel + rng.normal(0, drift, 3)
+        Rd.append(Rrel @ Rd[-1]), td.append(Rrel @ td[-1] + trel)
+
+    def rel(Ra, ta, Rb, tb):  # S_ba = S_bw * S_wa
+        Rba = Rb @ Ra.T
+        return _quat_from_R(Rba), tb - Rba @ ta
+
+    e_i, e_j, qm, tm = [], [], [], []
+    for i in range(1, n_kf):                       # spanning tree: child -> parent, measured on the drifted map
+        q, t_ = rel(Rd[i], td[i], Rd[i - 1], td[i - 1])
+        e_i.append(i), e_j.append(i - 1), qm.append(q), tm.append(t_)
+        for k in range(2, 2 + extra_edges):        # covisibility edges to older neighbours
+            if i - k >= 0:
+                q, t_ = rel(Rd[i], td[i], Rd[i - k], td[i - k])
+                e_i.append(i), e_j.append(i - k), qm.append(q), tm.append(t_)
+    q, t_ = rel(Rs[n_kf - 1], ts[n_kf - 1], Rs[0], ts[0])   # loop edge: true relative pose
+    e_i.append(n_kf - 1), e_j.append(0), qm.append(q), tm.append(t_)
+    return dict(quats=np.ascontiguousarray([_quat_from_R(R) for R in Rd]), trans=np.ascontiguousarray(td),
+                scales=np.ones(n_kf), fixed=0, e_i=np.array(e_i, np.int32), e_j=np.array(e_j, np.int32),
+                q_meas=np.ascontiguousarray(qm), t_meas=np.ascontiguousarray(tm), s_meas=np.ones(len(e_i)),
+                true_quats=np.ascontiguousarray([_quat_from_R(R) for R in Rs]), true_trans=np.ascontiguousarray(ts))
