@@ -338,3 +338,25 @@ def test_pose_graph_config4_size_properties(vo):
     #  solve after a few iterations -- Q-B4; the drift is reduced, not removed)
     assert np.abs(t - g["true_trans"]).max() < np.abs(g["trans"] - g["true_trans"]).max()
     print(f"pose graph 500 KF / {len(g['e_i'])} edges: {s.iterations} LM iterations in {dt * 1e3:.1f} ms")
+
+
+# ------------------------------------------------------------------ large reduced systems (global-BA path)
+
+@pytest.mark.parametrize("n_kf,n_pts,seed", [(23, 600, 3), (30, 900, 4)])
+def test_large_system_local_ba_matches_oracle(vo, orc, n_kf, n_pts, seed):
+    """more than 21 free key-frames: per-edge W blocks, pair-gathered Schur complement, HBM-resident
+    reduced system through the blocked Cholesky -- same schedule and tolerances as the LDS path"""
+    from vo_slam_test_amd import synth
+    pr = synth.make_lba_problem(seed, n_kf=n_kf, n_pts=n_pts, n_fixed=2)
+    ba = vo.BundleAdjuster(pr)
+    assert 6 * ba.n_free_cams() + 1 > 128
+    erase, sums, rc = ba.local_ba()
+    poses, pts = ba.state()
+    ba.close()
+    oposes, opts, oerase, osums, orc_rc = orc.local_ba(pr)
+    assert rc == 0 == orc_rc
+    assert [sums[0].iterations, sums[1].iterations] == [osums[0].iterations, osums[1].iterations]
+    assert [sums[0].accepted, sums[1].accepted] == [osums[0].accepted, osums[1].accepted]
+    assert np.array_equal(erase, oerase)
+    assert np.abs(poses - oposes).max() < 1e-7 and np.abs(pts - opts).max() < 1e-6
+    assert np.allclose([sums[0].final_cost, sums[1].final_cost], [osums[0].final_cost, osums[1].final_cost], rtol=1e-8)

@@ -103,3 +103,22 @@ def test_g8_sim3_and_loop_searches(vo):
     assert cnt == int(g["area_n"]) and np.array_equal(best, g["area_best"])
     cnt, assigned = m.searchByProjection_sim3(kf, q, 5, g3["scale"], g["sim3proj_occ"])
     assert cnt == int(g["sim3proj_n"]) and np.array_equal(assigned, g["sim3proj"])
+
+
+def test_g9_global_ba_config4(vo):
+    """BASELINE config 4 size (500 key-frames, 50 000 points, ~620 k edges, 2994 x 2994 reduced system):
+    two LM iterations against the CPU oracle's result (tests/golden/make_g9_global_ba.py)."""
+    from vo_slam_test_amd import synth
+    g = np.load(G / "g9_global_ba.npz")
+    pr = synth.make_global_ba_problem(0)
+    assert len(pr["e_cam"]) == int(g["n_edges"])
+    assert pr["e_obs"].sum() + pr["poses"].sum() + pr["points"].sum() == float(g["input_checksum"])
+    ba = vo.BundleAdjuster(pr)
+    s = ba.solve(float(np.sqrt(np.float32(5.991))), float(np.sqrt(np.float32(7.815))), int(g["iters"]))
+    poses, pts = ba.state()
+    ba.close()
+    assert (s.iterations, s.accepted) == (int(g["iters"]), int(g["accepted"]))
+    assert abs(s.initial_cost - float(g["initial_cost"])) <= 1e-10 * float(g["initial_cost"])
+    assert abs(s.final_cost - float(g["final_cost"])) <= 1e-8 * float(g["final_cost"])
+    assert np.abs(poses - g["poses"]).max() < 1e-7
+    assert np.abs(pts[g["point_idx"]] - g["points"]).max() < 1e-6

@@ -703,7 +703,25 @@ struct BaDev {
   BaState *hist;            // [2] states of earlier solves of the same schedule
   unsigned int *counters;   // [0] back-substitution arrivals, [1 + tile] GEMM K-slice arrivals
   int fused;                // single shard: in-kernel reductions replace k_ba_reduce / k_ba_reduce2
+  // ---- large reduced systems (6 nf + 1 > kMaxN, e.g. a global BA over hundreds of key-frames): no dense
+  // operand matrix; the camera-point blocks live per edge and the reduced system is a dense ld x ld
+  // matrix in HBM, factored by the blocked Cholesky of csrc/pose_graph.hip
+  int large, ld;
+  double *We[2];            // [n_edges][3][6]  W_cj[a][k] * sp[k] at [k][a]
+  double *glsc[2];          // [n_pts][3] scaled point gradient
+  double *Sd, *rhs;         // reduced system (lower triangle used) and right-hand side / solution
+  double *sc_v, *Dd_v, *gpp_v;  // per reduced column: Jacobi scale, LM diagonal, scaled gradient
+  int *chol_fail;
+  const int *pair_start;    // [n_pairs + 1] into pair_e
+  const int *pair_cc;       // [n_pairs][2] camera slots (c <= c')
+  const int *pair_e;        // [..][2] edge of c, edge of c' at a shared point, in point order
+  int n_pairs;
 };
+
+// address of the W block row k of edge e (point j, camera slot): dense operand matrix or per-edge store
+__device__ __forceinline__ double *w_row(const BaDev &B, int buf, int e, int j, int slot, int k) {
+  return B.large ? B.We[buf] + 18LL * e + 6 * k : B.Wt[buf] + (long long)(3 * j + k) * B.Mpad + 6 * slot;
+}
 
 __device__ __forceinline__ PoseCache load_pc(const double *pc, int c) {
   PoseCache P;
@@ -736,7 +754,6 @@ __device__ __forceinline__ int payload_cost_off(const BaDev &B) { return B.Mpad 
 __device__ __forceinline__ void point_linearize(const BaDev &B, const BaState &st, int j, int g, const double pt[3],
                                                 const double *PCs, int buf, double &cost, double &gmax) {
   const int e0 = B.pt_start[j], e1 = B.pt_start[j + 1];
-  double *Wt = B.Wt[buf];
   double h[6] = {0, 0, 0, 0, 0, 0}, gl[3] = {0, 0, 0};
   double sp[3] = {1, 1, 1};
   const bool first = st.first != 0;
@@ -745,9 +762,12 @@ __device__ __forceinline__ void point_linearize(const BaDev &B, const BaState &s
     const int slot = B.cam_slot[B.e_cam[e]];
     if (!B.e_active[e]) {  // rows of a deactivated edge stay zero
       if (slot >= 0) {
-        const long long base = (long long)(3 * j) * B.Mpad + 6 * slot;
 #pragma unroll
-        for (int a = 0; a < 6; a++) Wt[base + a] = 0, Wt[base + B.Mpad + a] = 0, Wt[base + 2 * B.Mpad + a] = 0;
+        for (int k = 0; k < 3; k++) {
+          double *w = w_row(B, buf, e, j, slot, k);
+#pragma unroll
+          for (int a = 0; a < 6; a++) w[a] = 0;
+        }
       }
       continue;
     }
@@ -768,12 +788,12 @@ __device__ __forceinline__ void point_linearize(const BaDev &B, const BaState &s
     gl[1] += rho1 * (Jl[1] * r[0] + Jl[4] * r[1] + Jl[7] * r[2]);
     gl[2] += rho1 * (Jl[2] * r[0] + Jl[5] * r[1] + Jl[8] * r[2]);
     if (!first && slot >= 0) {  // the scale is known: W rows can be written in the same sweep
-      const long long base = (long long)(3 * j) * B.Mpad + 6 * slot;
 #pragma unroll
-      for (int a = 0; a < 6; a++)
+      for (int k = 0; k < 3; k++) {
+        double *w = w_row(B, buf, e, j, slot, k);
 #pragma unroll
-        for (int k = 0; k < 3; k++)
-          Wt[base + k * B.Mpad + a] = rho1 * (Jp[a] * Jl[k] + Jp[6 + a] * Jl[3 + k] + Jp[12 + a] * Jl[6 + k]) * sp[k];
+        for (int a = 0; a < 6; a++) w[a] = rho1 * (Jp[a] * Jl[k] + Jp[6 + a] * Jl[3 + k] + Jp[12 + a] * Jl[6 + k]) * sp[k];
+      }
     }
   }
   // butterfly over the lanes of the group: every lane ends with the totals
@@ -794,7 +814,12 @@ __device__ __forceinline__ void point_linearize(const BaDev &B, const BaState &s
     for (int i = 0; i < 6; i++) B.hll[buf][6 * j + i] = h[i];
     // extra GEMM column 6nf carries the scaled gradient so that the same product yields sum_j Y_j gl''_j
 #pragma unroll
-    for (int k = 0; k < 3; k++) Wt[(long long)(3 * j + k) * B.Mpad + 6 * B.nf] = gl[k] * sp[k];
+    for (int k = 0; k < 3; k++) {
+      if (B.large)
+        B.glsc[buf][3 * j + k] = gl[k] * sp[k];
+      else
+        B.Wt[buf][(long long)(3 * j + k) * B.Mpad + 6 * B.nf] = gl[k] * sp[k];
+    }
   }
   if (first) {  // second sweep, now that the scale exists
     for (int e = e0 + g; e < e1; e += kGroup) {
@@ -806,12 +831,12 @@ __device__ __forceinline__ void point_linearize(const BaDev &B, const BaState &s
                                           B.K, r, Jp, Jl);
       double rho0, rho1;
       huber(m == 2 ? st.hm : st.hs, r[0] * r[0] + r[1] * r[1] + r[2] * r[2], rho0, rho1);
-      const long long base = (long long)(3 * j) * B.Mpad + 6 * slot;
 #pragma unroll
-      for (int a = 0; a < 6; a++)
+      for (int k = 0; k < 3; k++) {
+        double *w = w_row(B, buf, e, j, slot, k);
 #pragma unroll
-        for (int k = 0; k < 3; k++)
-          Wt[base + k * B.Mpad + a] = rho1 * (Jp[a] * Jl[k] + Jp[6 + a] * Jl[3 + k] + Jp[12 + a] * Jl[6 + k]) * sp[k];
+        for (int a = 0; a < 6; a++) w[a] = rho1 * (Jp[a] * Jl[k] + Jp[6 + a] * Jl[3 + k] + Jp[12 + a] * Jl[6 + k]) * sp[k];
+      }
     }
   }
 }
@@ -1498,6 +1523,261 @@ __global__ __launch_bounds__(256) void k_ba_solve(BaDev B) {
   ba_solve_body(B, st, sm);
 }
 
+// ============================================================================================
+// Large reduced camera systems (6 nf + 1 > kMaxN: a global BA over hundreds of key-frames).
+// The linearisation and the back-substitution are the kernels above (per-edge W blocks instead of
+// the dense operand matrix); the Schur complement is gathered per camera pair and the dense ld x ld
+// system goes through the blocked Cholesky of csrc/pose_graph.hip.
+//   k_ba_hinv_large  damped inverses of the point blocks for the current radius
+//   k_ba_cams_large  camera blocks Hpp / gp (same role as inside k_ba_gemm)
+//   k_ba_pairs       one wavefront per covisible camera pair (c <= c'): the 6x6 block
+//                    sum_j (W_cj Hll_j^-1) W_c'j^T over the shared points, lanes run over the points,
+//                    fixed-shape butterfly at the end (deterministic, no atomics)
+//   k_ba_prestep_large / k_ba_assemble_large / k_ba_poststep_large   what k_ba_solve does around
+//                    its factorisation, split around the grid-wide Cholesky
+// ============================================================================================
+__global__ __launch_bounds__(256) void k_ba_hinv_large(BaDev B) {
+  const BaState st = *B.st;
+  if (st.done) return;
+  const int li = blockIdx.x * 256 + threadIdx.x;
+  if (li >= B.n_local) return;
+  const int j = B.local_pts[li];
+  const double *hl = B.hll[st.cur];
+  const double sp0 = B.scale_p[3 * j], sp1 = B.scale_p[3 * j + 1], sp2 = B.scale_p[3 * j + 2];
+  double hs[6] = {hl[6 * j] * sp0 * sp0, hl[6 * j + 1] * sp0 * sp1, hl[6 * j + 2] * sp0 * sp2,
+                  hl[6 * j + 3] * sp1 * sp1, hl[6 * j + 4] * sp1 * sp2, hl[6 * j + 5] * sp2 * sp2};
+  const double d0 = fmin(fmax(hs[0], 1e-6), 1e32) / st.radius;
+  const double d1 = fmin(fmax(hs[3], 1e-6), 1e32) / st.radius;
+  const double d2 = fmin(fmax(hs[5], 1e-6), 1e32) / st.radius;
+  hs[0] += d0, hs[3] += d1, hs[5] += d2;
+  double hi[6];
+  if (!inv3_sym(hs, hi)) {
+    hi[0] = hi[3] = hi[5] = 0.0 / 0.0;  // poisons the step => invalid step handling
+    hi[1] = hi[2] = hi[4] = 0;
+  }
+#pragma unroll
+  for (int i = 0; i < 6; i++) B.hinv[6 * j + i] = hi[i];
+  B.dl[3 * j] = d0, B.dl[3 * j + 1] = d1, B.dl[3 * j + 2] = d2;
+#pragma unroll
+  for (int k = 0; k < 3; k++) B.gl2[3 * j + k] = B.glsc[st.cur][3 * j + k];
+}
+
+__global__ __launch_bounds__(256) void k_ba_cams_large(BaDev B) {
+  __shared__ double lds27[4 * 27];
+  const BaState st = *B.st;
+  if (st.done) return;
+  ba_cams_role(B, st, blockIdx.x / B.n_cchunks, blockIdx.x % B.n_cchunks, lds27);
+}
+
+__global__ __launch_bounds__(256) void k_ba_pairs(BaDev B) {
+  const BaState st = *B.st;
+  if (st.done) return;
+  const int lane = threadIdx.x & 63;
+  const int pr = blockIdx.x * 4 + __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
+  if (pr >= B.n_pairs) return;
+  const int c = B.pair_cc[2 * pr], cp = B.pair_cc[2 * pr + 1];
+  const double *We = B.We[st.cur], *gls = B.glsc[st.cur];
+  double acc[36], rh[6];
+#pragma unroll
+  for (int i = 0; i < 36; i++) acc[i] = 0;
+#pragma unroll
+  for (int i = 0; i < 6; i++) rh[i] = 0;
+  for (int t = B.pair_start[pr] + lane; t < B.pair_start[pr + 1]; t += 64) {
+    const int e = B.pair_e[2 * t], ep = B.pair_e[2 * t + 1];
+    if (!B.e_active[e] || !B.e_active[ep]) continue;
+    const int j = B.e_pt[e];
+    const double *hv = B.hinv + 6 * j;
+    const double h00 = hv[0], h01 = hv[1], h02 = hv[2], h11 = hv[3], h12 = hv[4], h22 = hv[5];
+    const double *w = We + 18LL * e, *wp = We + 18LL * ep;
+    double Y[6][3];  // (W_e Hinv)[a][k'] with W_e[a][k] = w[6 k + a]
+#pragma unroll
+    for (int a = 0; a < 6; a++) {
+      const double w0 = w[a], w1 = w[6 + a], w2 = w[12 + a];
+      Y[a][0] = w0 * h00 + w1 * h01 + w2 * h02;
+      Y[a][1] = w0 * h01 + w1 * h11 + w2 * h12;
+      Y[a][2] = w0 * h02 + w1 * h12 + w2 * h22;
+    }
+#pragma unroll
+    for (int a = 0; a < 6; a++)
+#pragma unroll
+      for (int b = 0; b < 6; b++) acc[6 * a + b] += Y[a][0] * wp[b] + Y[a][1] * wp[6 + b] + Y[a][2] * wp[12 + b];
+    if (c == cp) {  // diagonal pair: the camera's own edges -> its part of the right-hand side
+      const double g0 = gls[3 * j], g1 = gls[3 * j + 1], g2 = gls[3 * j + 2];
+#pragma unroll
+      for (int a = 0; a < 6; a++) rh[a] += Y[a][0] * g0 + Y[a][1] * g1 + Y[a][2] * g2;
+    }
+  }
+#pragma unroll
+  for (int o = 32; o >= 1; o >>= 1) {
+#pragma unroll
+    for (int i = 0; i < 36; i++) acc[i] += __shfl_xor(acc[i], o);
+  }
+  // block (row c', column c) of the lower triangle: entry (6c'+b, 6c+a) = -G[a][b]
+  double mine = 0;
+#pragma unroll
+  for (int i = 0; i < 36; i++) mine = (lane == i) ? acc[i] : mine;  // static indices only
+  if (lane < 36) {
+    const int a = lane / 6, b = lane - 6 * a;
+    B.Sd[(long long)(6 * cp + b) * B.ld + 6 * c + a] = -mine;
+  }
+  if (c == cp) {
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) {
+#pragma unroll
+      for (int i = 0; i < 6; i++) rh[i] += __shfl_xor(rh[i], o);
+    }
+    double r1 = 0;
+#pragma unroll
+    for (int i = 0; i < 6; i++) r1 = (lane == i) ? rh[i] : r1;
+    if (lane < 6) B.rhs[6 * c + lane] = -r1;  // -(sum_e Y_e gl''_j); completed by k_ba_assemble_large
+  }
+}
+
+// one workgroup: camera-block sums, Jacobi scale, LM diagonal, cost / gradient-max bookkeeping
+__global__ __launch_bounds__(256) void k_ba_prestep_large(BaDev B, double *hp /*[nf][27]*/) {
+  __shared__ double red[8];
+  __shared__ int s_stop;
+  BaState *S = B.st;
+  const BaState st0 = *S;
+  if (st0.done) return;
+  const int tid = threadIdx.x, n = 6 * B.nf;
+  if (tid == 0) *B.chol_fail = 0, s_stop = 0;
+  for (int i = tid; i < B.nf * 27; i += 256) {
+    const int slot = i / 27, t = i - slot * 27;
+    const double *sp = B.slab_cam + (long long)slot * B.n_cchunks * 27 + t;
+    double a = 0;
+    for (int cchunk = 0; cchunk < B.n_cchunks; cchunk++) a += sp[cchunk * 27];  // chunk order
+    hp[i] = a;
+  }
+  double cs = 0, m = 0;
+  const double *spt = B.slab_pt[st0.cur];
+  for (int b = tid; b < B.n_pblocks; b += 256) cs += spt[2 * b], m = fmax(m, spt[2 * b + 1]);
+  __syncthreads();
+  double gm = 0;
+  for (int i = tid; i < n; i += 256) {
+    const int slot = i / 6, a = i - slot * 6;
+    int t = 0;
+    for (int q = 0; q < a; q++) t += 6 - q;
+    const double hd = hp[slot * 27 + t];
+    double sc;
+    if (st0.first) {
+      sc = 1.0 / (1.0 + sqrt(hd));
+      B.scale_c[i] = sc;
+    } else {
+      sc = B.scale_c[i];
+    }
+    B.sc_v[i] = sc;
+    B.Dd_v[i] = fmin(fmax(hd * sc * sc, 1e-6), 1e32) / st0.radius;
+    const double gp = hp[slot * 27 + 21 + a];
+    gm = fmax(gm, fabs(gp));
+    B.gpp_v[i] = sc * gp;
+  }
+  double v2[2] = {cs, 0};
+  block_sum<2>(v2, red);
+  m = fmax(wave_max(m), wave_max(gm));
+  __syncthreads();
+  if ((tid & 63) == 0) red[tid >> 6] = m;
+  __syncthreads();
+  if (tid == 0) {
+    const double gmax = fmax(fmax(red[0], red[1]), fmax(red[2], red[3]));
+    S->gmax = gmax;
+    S->x_cost = v2[0];
+    if (st0.first) S->initial_cost = v2[0];
+    if (st0.last_ok && gmax <= 1e-10) {
+      S->termination = 3;
+      S->done = 1;
+    } else {
+      S->iter = st0.iter + 1;
+    }
+    S->first = 0;
+  }
+}
+
+// A = sc_r (Hpp - G) sc_c + D on the lower triangle (identity on the padding), rhs'' = g'' - sc (Y gl'')
+__global__ __launch_bounds__(256) void k_ba_assemble_large(BaDev B, const double *hp) {
+  if (B.st->done) return;
+  const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
+  const int r = (int)(idx / B.ld), c = (int)(idx - (long long)r * B.ld);
+  const int n = 6 * B.nf;
+  if (r >= B.ld || c > r) return;
+  double v;
+  if (r < n) {
+    v = B.Sd[idx];
+    if (r / 6 == c / 6) {
+      const int slot = r / 6, a = c % 6, b = r % 6;  // a <= b
+      int t = 0;
+      for (int q = 0; q < a; q++) t += 6 - q;
+      v += hp[slot * 27 + t + (b - a)];
+    }
+    v *= B.sc_v[r] * B.sc_v[c];
+    if (r == c) v += B.Dd_v[r];
+  } else {
+    v = r == c ? 1.0 : 0.0;
+  }
+  B.Sd[idx] = v;
+  if (c == 0) B.rhs[r] = r < n ? B.gpp_v[r] + B.sc_v[r] * B.rhs[r] : 0.0;
+}
+
+// one workgroup: step, candidate poses and the camera part of the trust-region quantities
+__global__ __launch_bounds__(256) void k_ba_poststep_large(BaDev B) {
+  __shared__ double red[4 * 5];
+  BaState *S = B.st;
+  const BaState st0 = *S;
+  if (st0.done) return;
+  const int tid = threadIdx.x, n = 6 * B.nf;
+  const double *y = B.rhs;
+  int bad = *B.chol_fail;
+  double gdot = 0, dquad = 0;
+  for (int i = tid; i < n; i += 256) {
+    const double stp = -y[i];
+    if (!isfinite(stp)) bad = 1;
+    gdot += B.gpp_v[i] * stp;
+    dquad += B.Dd_v[i] * stp * stp;
+    B.zc[i] = B.sc_v[i] * y[i];
+  }
+  const int failed = __syncthreads_or(bad);
+  const int cur0 = st0.cur;
+  const double *X = B.Xc[cur0];
+  double *Xn = B.Xc[cur0 ^ 1];
+  double xn2 = 0, cn2 = 0, sn2 = 0;
+  for (int c = tid; c < B.n_cams; c += 256) {
+    const int slot = B.cam_slot[c];
+    double x0[6], xc[6];
+#pragma unroll
+    for (int a = 0; a < 6; a++) x0[a] = X[6 * c + a];
+    if (slot >= 0 && !failed) {
+      double d[6];
+#pragma unroll
+      for (int a = 0; a < 6; a++) d[a] = -y[6 * slot + a] * B.sc_v[6 * slot + a];
+      se3_plus(x0, d, xc);
+      store_pc(B.PC[cur0 ^ 1], c, pose_cache(xc));
+    } else {
+#pragma unroll
+      for (int a = 0; a < 6; a++) xc[a] = x0[a];
+      store_pc(B.PC[cur0 ^ 1], c, load_pc(B.PC[cur0], c));
+    }
+#pragma unroll
+    for (int a = 0; a < 6; a++) {
+      Xn[6 * c + a] = xc[a];
+      if (slot >= 0 && B.cam_in[c] == B.epoch) {
+        xn2 += x0[a] * x0[a];
+        cn2 += xc[a] * xc[a];
+        sn2 += (xc[a] - x0[a]) * (xc[a] - x0[a]);
+      }
+    }
+  }
+  double v5[5] = {gdot, dquad, xn2, cn2, sn2};
+  block_sum<5>(v5, red);
+  if (tid == 0) {
+    S->gdot_c = v5[0];
+    S->dquad_c = v5[1];
+    S->x_norm2_c = v5[2];
+    S->cand_norm2_c = v5[3];
+    S->step_norm2_c = v5[4];
+    S->solve_failed = failed;
+  }
+}
+
 // TrustRegionMinimizer step evaluation + LevenbergMarquardtStrategy radius update (one thread)
 // Works on a register copy of the state (`s`, as read at the start of the launch: nothing else writes it
 // in between) and the six reduced sums `p`; the caller stores the result back in one piece.
@@ -1571,15 +1851,17 @@ __global__ __launch_bounds__(256) void k_ba_backsub(BaDev B) {
   const bool pc_lds = B.n_cams <= kPcLds;
   if (pc_lds)
     for (int i = tid; i < 12 * B.n_cams; i += 256) pcL[i] = B.PC[st.cur ^ 1][i];
-  for (int i = tid; i < 6 * B.nf; i += 256) zcL[i] = B.zc[i];
+  const bool zc_lds = 6 * B.nf <= kMaxN;
+  if (zc_lds)
+    for (int i = tid; i < 6 * B.nf; i += 256) zcL[i] = B.zc[i];
   __syncthreads();
   const double *PCcand = pc_lds ? pcL : B.PC[st.cur ^ 1];
+  const double *zcv = zc_lds ? zcL : B.zc;
   const int li = blockIdx.x * kPtsPerBlock + (tid >> kGroupLog);
   const bool valid = li < B.n_local;
   const int j = valid ? B.local_pts[li] : 0;
   const double *Xp = B.Xp[st.cur];
   double *Xpn = B.Xp[st.cur ^ 1];
-  const double *W = B.Wt[st.cur];
   double v[6] = {0, 0, 0, 0, 0, 0};  // cand_cost, gdot_l, dquad_l, step2, xnorm2, candnorm2
   double ccost = 0, cgmax = 0;
   if (valid) {
@@ -1589,13 +1871,14 @@ __global__ __launch_bounds__(256) void k_ba_backsub(BaDev B) {
       if (!B.e_active[e]) continue;
       const int slot = B.cam_slot[B.e_cam[e]];
       if (slot < 0) continue;
-      const long long base = (long long)(3 * j) * B.Mpad + 6 * slot;
+      const double *w0 = w_row(B, st.cur, e, j, slot, 0), *w1 = w_row(B, st.cur, e, j, slot, 1),
+                   *w2 = w_row(B, st.cur, e, j, slot, 2);
 #pragma unroll
       for (int a = 0; a < 6; a++) {
-        const double z = zcL[6 * slot + a];
-        rr[0] += W[base + a] * z;
-        rr[1] += W[base + B.Mpad + a] * z;
-        rr[2] += W[base + 2 * B.Mpad + a] * z;
+        const double z = zcv[6 * slot + a];
+        rr[0] += w0[a] * z;
+        rr[1] += w1[a] * z;
+        rr[2] += w2[a] * z;
       }
     }
 #pragma unroll
@@ -1832,6 +2115,8 @@ struct vo_ba {
       b_camedges, b_ptin, b_camin, b_xc0, b_xc1, b_xp0, b_xp1, b_pc0, b_pc1, b_sc, b_sp, b_hinv, b_gl2, b_dl, b_wt, b_wt1, b_hll0, b_hll1, b_spt1,
       b_sgemm, b_scam, b_spt, b_payload, b_zc, b_sbs, b_payload2, b_state, b_out, b_dbg, b_cnt;
   size_t solve_lds = 0, gemm_lds = 0;
+  vo::DevBuf b_we0, b_we1, b_glsc0, b_glsc1, b_Sd, b_rhs, b_scv, b_ddv, b_gppv, b_cholfail, b_pairstart, b_paircc, b_paire,
+      b_hp;  // large reduced systems
   int lm_max_it = 0;
   double *ext_payload = nullptr, *ext_payload2 = nullptr;
   int archive_slot = -1;
@@ -1853,13 +2138,13 @@ int build_device(vo_ba *h) {
   D.n_cams = h->n_cams, D.n_pts = h->n_pts, D.n_edges = h->n_edges, D.nf = h->nf;
   D.n_shards = h->n_shards, D.shard = h->shard;
   D.K = Cam{h->cam[0], h->cam[1], h->cam[2], h->cam[3], h->cam[4]};
-  if (6 * h->nf + 1 > kMaxN) {
-    vo::set_error("local BA with %d free key-frames needs a %d-wide reduced system; this build solves up to %d "
-                  "in LDS (larger problems: blocked MFMA Cholesky, not in this round)",
-                  h->nf, 6 * h->nf + 1, kMaxN);
+  D.large = 6 * h->nf + 1 > kMaxN ? 1 : 0;
+  D.ld = (6 * h->nf + vo::kCholPanel - 1) / vo::kCholPanel * vo::kCholPanel;
+  if (D.large && (h->n_shards > 1 || D.ld > 4096)) {
+    vo::set_error("BA with %d free key-frames: the large-system path handles one shard and 6 nf <= 4096", h->nf);
     return VO_ERR_CAPACITY;
   }
-  D.Mpad = std::max(16, (6 * h->nf + 1 + 15) / 16 * 16);
+  D.Mpad = D.large ? 16 : std::max(16, (6 * h->nf + 1 + 15) / 16 * 16);  // large: no dense operand matrix
   std::vector<int> local;
   for (int j = 0; j < h->n_pts; j++)
     if (j % h->n_shards == h->shard) local.push_back(j);
@@ -1888,7 +2173,7 @@ int build_device(vo_ba *h) {
   ks = std::min(ks, std::max(1, K / 128));
   D.kchunk = ((K + ks - 1) / ks + 47) / 48 * 48;  // multiple of 16 (MFMA slices) and of 3 (whole points)
   D.ksplit = std::max(1, (K + D.kchunk - 1) / D.kchunk);
-  if (D.kchunk / 3 > kChunkPts || D.ksplit > 32) {
+  if (!D.large && (D.kchunk / 3 > kChunkPts || D.ksplit > 32)) {
     vo::set_error("local BA with %d points exceeds this round's dense Schur path (%d points per K slice, 32 slices)",
                   h->n_pts, kChunkPts);
     return VO_ERR_CAPACITY;
@@ -1921,17 +2206,73 @@ int build_device(vo_ba *h) {
   VO_CHECK(h->b_hinv.reserve((size_t)std::max(1, h->n_pts) * 6 * 8));
   VO_CHECK(h->b_gl2.reserve((size_t)std::max(1, h->n_pts) * 3 * 8));
   VO_CHECK(h->b_dl.reserve((size_t)std::max(1, h->n_pts) * 3 * 8));
-  VO_CHECK(h->b_wt.reserve((size_t)std::max(1, K) * D.Mpad * 8));
-  VO_CHECK(h->b_wt1.reserve((size_t)std::max(1, K) * D.Mpad * 8));
+  const size_t wt_rows = D.large ? 1 : (size_t)std::max(1, K);
+  VO_CHECK(h->b_wt.reserve(wt_rows * D.Mpad * 8));
+  VO_CHECK(h->b_wt1.reserve(wt_rows * D.Mpad * 8));
   VO_CHECK(h->b_hll0.reserve((size_t)std::max(1, h->n_pts) * 6 * 8));
   VO_CHECK(h->b_hll1.reserve((size_t)std::max(1, h->n_pts) * 6 * 8));
   VO_HIP_CHECK(hipMemset(h->b_hll0.p, 0, (size_t)std::max(1, h->n_pts) * 6 * 8));
   VO_HIP_CHECK(hipMemset(h->b_hll1.p, 0, (size_t)std::max(1, h->n_pts) * 6 * 8));
   // operand matrices start out all-zero; only (point, camera) pairs that have an edge are ever written
-  VO_HIP_CHECK(hipMemset(h->b_wt.p, 0, (size_t)std::max(1, K) * D.Mpad * 8));
-  VO_HIP_CHECK(hipMemset(h->b_wt1.p, 0, (size_t)std::max(1, K) * D.Mpad * 8));
+  VO_HIP_CHECK(hipMemset(h->b_wt.p, 0, wt_rows * D.Mpad * 8));
+  VO_HIP_CHECK(hipMemset(h->b_wt1.p, 0, wt_rows * D.Mpad * 8));
+  if (D.large) D.ksplit = 1;
   VO_CHECK(h->b_sgemm.reserve((size_t)(D.ksplit + 1) * D.Mpad * D.Mpad * 8));  // + one all-zero slab
   VO_HIP_CHECK(hipMemset(h->b_sgemm.as<double>() + (size_t)D.ksplit * D.Mpad * D.Mpad, 0, (size_t)D.Mpad * D.Mpad * 8));
+  if (D.large) {
+    // covisible camera pairs (c <= c') and, per pair, the (edge of c, edge of c') couples at their shared
+    // points in point order: the gather lists of k_ba_pairs
+    struct Couple {
+      long long key;
+      int e, ep;
+    };
+    std::vector<Couple> cp;
+    for (int j : local) {
+      for (int a = h->pt_start[j]; a < h->pt_start[j + 1]; a++) {
+        const int sa = h->cam_slot[h->e_cam[a]];
+        if (sa < 0) continue;
+        for (int b = h->pt_start[j]; b < h->pt_start[j + 1]; b++) {
+          const int sb = h->cam_slot[h->e_cam[b]];
+          if (sb < sa || (sb == sa && b != a)) continue;  // c <= c'; a camera sees a point once
+          cp.push_back({(long long)sa * h->nf + sb, a, b});
+        }
+      }
+    }
+    std::stable_sort(cp.begin(), cp.end(), [](const Couple &x, const Couple &y) { return x.key < y.key; });
+    std::vector<int> pstart, pcc, pe;
+    pe.reserve(2 * cp.size());
+    for (size_t i = 0; i < cp.size(); i++) {
+      if (i == 0 || cp[i].key != cp[i - 1].key) {
+        pstart.push_back((int)i);
+        pcc.push_back((int)(cp[i].key / h->nf)), pcc.push_back((int)(cp[i].key % h->nf));
+      }
+      pe.push_back(cp[i].e), pe.push_back(cp[i].ep);
+    }
+    pstart.push_back((int)cp.size());
+    D.n_pairs = (int)pstart.size() - 1;
+    VO_CHECK(upload(h->b_pairstart, pstart.data(), pstart.size() * 4));
+    VO_CHECK(upload(h->b_paircc, pcc.data(), pcc.size() * 4));
+    VO_CHECK(upload(h->b_paire, pe.data(), pe.size() * 4));
+    VO_CHECK(h->b_we0.reserve((size_t)std::max(1, h->n_edges) * 18 * 8));
+    VO_CHECK(h->b_we1.reserve((size_t)std::max(1, h->n_edges) * 18 * 8));
+    VO_HIP_CHECK(hipMemset(h->b_we0.p, 0, (size_t)std::max(1, h->n_edges) * 18 * 8));
+    VO_HIP_CHECK(hipMemset(h->b_we1.p, 0, (size_t)std::max(1, h->n_edges) * 18 * 8));
+    VO_CHECK(h->b_glsc0.reserve((size_t)std::max(1, h->n_pts) * 3 * 8));
+    VO_CHECK(h->b_glsc1.reserve((size_t)std::max(1, h->n_pts) * 3 * 8));
+    VO_CHECK(h->b_Sd.reserve((size_t)D.ld * D.ld * 8));
+    VO_CHECK(h->b_rhs.reserve((size_t)D.ld * 8));
+    VO_CHECK(h->b_scv.reserve((size_t)D.ld * 8));
+    VO_CHECK(h->b_ddv.reserve((size_t)D.ld * 8));
+    VO_CHECK(h->b_gppv.reserve((size_t)D.ld * 8));
+    VO_CHECK(h->b_cholfail.reserve(64));
+    VO_CHECK(h->b_hp.reserve((size_t)h->nf * 27 * 8));
+    D.We[0] = h->b_we0.as<double>(), D.We[1] = h->b_we1.as<double>();
+    D.glsc[0] = h->b_glsc0.as<double>(), D.glsc[1] = h->b_glsc1.as<double>();
+    D.Sd = h->b_Sd.as<double>(), D.rhs = h->b_rhs.as<double>();
+    D.sc_v = h->b_scv.as<double>(), D.Dd_v = h->b_ddv.as<double>(), D.gpp_v = h->b_gppv.as<double>();
+    D.chol_fail = h->b_cholfail.as<int>();
+    D.pair_start = h->b_pairstart.as<int>(), D.pair_cc = h->b_paircc.as<int>(), D.pair_e = h->b_paire.as<int>();
+  }
   VO_CHECK(h->b_scam.reserve((size_t)std::max(1, h->nf) * D.n_cchunks * 27 * 8));
   VO_CHECK(h->b_spt.reserve((size_t)D.n_pblocks * 2 * 8));
   VO_CHECK(h->b_spt1.reserve((size_t)D.n_pblocks * 2 * 8));
@@ -1969,9 +2310,9 @@ int build_device(vo_ba *h) {
   D.payload2 = h->ext_payload2 ? h->ext_payload2 : h->b_payload2.as<double>();
   D.st = h->b_state.as<BaState>();
   D.hist = D.st + 1;
-  const int n = 6 * h->nf;
+  const int n = D.large ? 6 : 6 * h->nf;
   h->solve_lds = ((size_t)(n + 1) * (n + 1) + 5 * n + (size_t)h->nf * 21 + 64 + (size_t)h->nf * 27 + 8) * 8;
-  if (h->solve_lds > 64 * 1024)
+  if (!D.large && h->solve_lds > 64 * 1024)
     VO_HIP_CHECK(hipFuncSetAttribute((const void *)k_ba_solve, hipFuncAttributeMaxDynamicSharedMemorySize,
                                      (int)h->solve_lds));
   h->gemm_lds = (size_t)kGemmLdsDoubles * 8;
@@ -2011,9 +2352,28 @@ int lm_begin(vo_ba *h, double hm, double hs, int max_it, const uint8_t *active_c
   return VO_OK;
 }
 
+// one LM iteration of the large-system path up to the candidate poses (k_ba_backsub follows)
+int launch_large(vo_ba *h) {
+  BaDev &D = h->D;
+  hipStream_t st = h->stream;
+  double *hp = h->b_hp.as<double>();
+  hipLaunchKernelGGL(k_ba_hinv_large, dim3((D.n_local + 255) / 256), dim3(256), 0, st, D);
+  hipLaunchKernelGGL(k_ba_cams_large, dim3(std::max(1, h->nf * D.n_cchunks)), dim3(256), 0, st, D);
+  VO_HIP_CHECK(hipMemsetAsync(D.Sd, 0, (size_t)D.ld * D.ld * 8, st));
+  VO_HIP_CHECK(hipMemsetAsync(D.rhs, 0, (size_t)D.ld * 8, st));
+  if (D.n_pairs > 0) hipLaunchKernelGGL(k_ba_pairs, dim3((D.n_pairs + 3) / 4), dim3(256), 0, st, D);
+  hipLaunchKernelGGL(k_ba_prestep_large, dim3(1), dim3(256), 0, st, D, hp);
+  hipLaunchKernelGGL(k_ba_assemble_large, dim3((unsigned)(((long long)D.ld * D.ld + 255) / 256)), dim3(256), 0, st, D, hp);
+  vo::chol_factor_solve(D.Sd, D.ld, D.rhs, D.chol_fail, st);
+  hipLaunchKernelGGL(k_ba_poststep_large, dim3(1), dim3(256), 0, st, D);
+  VO_HIP_CHECK(hipGetLastError());
+  return VO_OK;
+}
+
 int launch_linearize(vo_ba *h) {
   BaDev &D = h->D;
   hipStream_t st = h->stream;
+  if (D.large) return launch_large(h);
   const int tdim = D.Mpad / 16, tiles = tdim * (tdim + 1) / 2;
   // Schur product tiles and the camera blocks in one launch (independent roles)
   hipLaunchKernelGGL(k_ba_gemm, dim3(tiles * D.ksplit + h->nf * D.n_cchunks), dim3(256), h->gemm_lds, st, D);
@@ -2027,7 +2387,7 @@ int launch_linearize(vo_ba *h) {
 int launch_step(vo_ba *h) {
   BaDev &D = h->D;
   hipStream_t st = h->stream;
-  hipLaunchKernelGGL(k_ba_solve, dim3(1), dim3(256), h->solve_lds, st, D);
+  if (!D.large) hipLaunchKernelGGL(k_ba_solve, dim3(1), dim3(256), h->solve_lds, st, D);
   hipLaunchKernelGGL(k_ba_backsub, dim3(D.n_pblocks), dim3(256), 0, st, D);
   if (h->n_shards > 1) hipLaunchKernelGGL(k_ba_reduce2, dim3(1), dim3(64), 0, st, D);
   VO_HIP_CHECK(hipGetLastError());
@@ -2283,7 +2643,9 @@ void vo_ba_destroy(vo_ba *h) {
                         &h->b_camslot, &h->b_slotcam, &h->b_camstart, &h->b_camedges, &h->b_ptin, &h->b_camin,
                         &h->b_xc0, &h->b_xc1, &h->b_xp0, &h->b_xp1, &h->b_pc0, &h->b_pc1, &h->b_sc, &h->b_sp, &h->b_hinv, &h->b_gl2,
                         &h->b_dl, &h->b_wt, &h->b_wt1, &h->b_hll0, &h->b_hll1, &h->b_spt1, &h->b_sgemm, &h->b_scam, &h->b_spt, &h->b_payload, &h->b_zc,
-                        &h->b_sbs, &h->b_payload2, &h->b_state, &h->b_out, &h->b_dbg, &h->b_cnt})
+                        &h->b_sbs, &h->b_payload2, &h->b_state, &h->b_out, &h->b_dbg, &h->b_cnt, &h->b_we0, &h->b_we1,
+                        &h->b_glsc0, &h->b_glsc1, &h->b_Sd, &h->b_rhs, &h->b_scv, &h->b_ddv, &h->b_gppv, &h->b_cholfail,
+                        &h->b_pairstart, &h->b_paircc, &h->b_paire, &h->b_hp})
     b->release();
   if (h->own_stream) (void)hipStreamDestroy(h->stream);
   delete h;
@@ -2472,6 +2834,11 @@ int vo_ba_debug_schur(vo_ba *h, double hm, double hs, double point_damping, cons
   // undamped reduced system: run the linearisation kernels with a huge radius (D -> clamp/1e300 ~ 0)
   // and no Jacobi scaling effect removed on the host.
   if (!h || !S || !b || !cost) return VO_ERR_INVALID;
+  VO_CHECK(build_device(h));
+  if (h->D.large) {
+    vo::set_error("vo_ba_debug_schur: only for the LDS-sized reduced systems");
+    return VO_ERR_CAPACITY;
+  }
   (void)point_damping;
   VO_CHECK(lm_begin(h, hm, hs, 1, edge_active, false));
   BaState s;

@@ -27,7 +27,7 @@ namespace {
 
 using namespace vo;
 
-constexpr int NB = 64;  // Cholesky panel width
+constexpr int NB = vo::kCholPanel;  // Cholesky panel width
 
 // ---------------------------------------------------------------- quaternion helpers (x, y, z, w)
 __host__ __device__ __forceinline__ void q_mul(const double a[4], const double b[4], double o[4]) {
@@ -413,6 +413,19 @@ double sum_device(const vo::DevBuf &b, int n, int stride = 1, int offset = 0) { 
 
 }  // namespace
 
+void vo::chol_factor_solve(double *A, int ld, double *rhs, int *fail, hipStream_t st) {
+  for (int K0 = 0; K0 < ld; K0 += NB) {
+    hipLaunchKernelGGL(k_chol_diag, dim3(1), dim3(256), 0, st, A, ld, K0, fail);
+    const int rem = ld - K0 - NB;
+    if (rem > 0) {
+      hipLaunchKernelGGL(k_chol_trsm, dim3((rem + 255) / 256), dim3(256), 0, st, A, ld, K0, fail);
+      const int m = rem / NB;
+      hipLaunchKernelGGL(k_chol_syrk, dim3(m * (m + 1) / 2), dim3(256), 0, st, A, ld, K0, fail);
+    }
+  }
+  hipLaunchKernelGGL(k_chol_solve, dim3(1), dim3(256), (size_t)ld * 8, st, A, ld, rhs, fail);
+}
+
 extern "C" {
 
 int vo_chol_solve(int n, double *A_rowmajor_lower, double *b) {
@@ -443,16 +456,7 @@ int vo_chol_solve(int n, double *A_rowmajor_lower, double *b) {
   if ((rc = upload(db, bp.data(), bp.size() * 8)) != VO_OK) return done(rc);
   int zero = 0;
   if ((rc = upload(dfail, &zero, 4)) != VO_OK) return done(rc);
-  for (int K0 = 0; K0 < ld; K0 += NB) {
-    hipLaunchKernelGGL(k_chol_diag, dim3(1), dim3(256), 0, nullptr, dA.as<double>(), ld, K0, dfail.as<int>());
-    const int rem = ld - K0 - NB;
-    if (rem > 0) {
-      hipLaunchKernelGGL(k_chol_trsm, dim3((rem + 255) / 256), dim3(256), 0, nullptr, dA.as<double>(), ld, K0, dfail.as<int>());
-      const int m = rem / NB;
-      hipLaunchKernelGGL(k_chol_syrk, dim3(m * (m + 1) / 2), dim3(256), 0, nullptr, dA.as<double>(), ld, K0, dfail.as<int>());
-    }
-  }
-  hipLaunchKernelGGL(k_chol_solve, dim3(1), dim3(256), (size_t)ld * 8, nullptr, dA.as<double>(), ld, db.as<double>(), dfail.as<int>());
+  vo::chol_factor_solve(dA.as<double>(), ld, db.as<double>(), dfail.as<int>(), nullptr);
   if (hipDeviceSynchronize() != hipSuccess) {
     vo::set_error("Cholesky kernels failed: %s", hipGetErrorString(hipGetLastError()));
     return done(VO_ERR_HIP);
@@ -601,19 +605,7 @@ int vo_pose_graph_solve(int n_nodes, double *quats, double *trans, const double 
     (void)hipMemcpy(d_fail.p, &zero, 4, hipMemcpyHostToDevice);
     hipLaunchKernelGGL(k_pg_damp, dim3((unsigned)(((long long)ld * ld + 255) / 256)), dim3(256), 0, nullptr, P,
                        d_A.as<double>(), d_rhs.as<double>(), radius);
-    for (int K0 = 0; K0 < ld; K0 += NB) {
-      hipLaunchKernelGGL(k_chol_diag, dim3(1), dim3(256), 0, nullptr, d_A.as<double>(), ld, K0, d_fail.as<int>());
-      const int rem = ld - K0 - NB;
-      if (rem > 0) {
-        hipLaunchKernelGGL(k_chol_trsm, dim3((rem + 255) / 256), dim3(256), 0, nullptr, d_A.as<double>(), ld, K0,
-                           d_fail.as<int>());
-        const int m = rem / NB;
-        hipLaunchKernelGGL(k_chol_syrk, dim3(m * (m + 1) / 2), dim3(256), 0, nullptr, d_A.as<double>(), ld, K0,
-                           d_fail.as<int>());
-      }
-    }
-    hipLaunchKernelGGL(k_chol_solve, dim3(1), dim3(256), (size_t)ld * 8, nullptr, d_A.as<double>(), ld, d_rhs.as<double>(),
-                       d_fail.as<int>());
+    vo::chol_factor_solve(d_A.as<double>(), ld, d_rhs.as<double>(), d_fail.as<int>(), nullptr);
     hipLaunchKernelGGL(k_pg_model, dim3(n), dim3(256), 0, nullptr, P, d_rhs.as<double>(), d_part.as<double>());
     hipLaunchKernelGGL(k_pg_candidate, dim3((n_nodes + 127) / 128), dim3(128), 0, nullptr, P, dx, d_rhs.as<double>(), dxc,
                        d_norm.as<double>());

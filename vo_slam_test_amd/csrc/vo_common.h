@@ -55,4 +55,11 @@ struct DevBuf {
 
 constexpr int kWave = 64;
 
+// Dense SPD solve on the device (csrc/pose_graph.hip): A is ld x ld row-major with ld a multiple of 64
+// (identity on the padding diagonal), lower triangle factored in place (L L^T, 64-wide panels,
+// trailing update on the FP64 matrix cores), rhs -> solution.  *fail (device int, zeroed by the
+// caller) is set when a pivot is not positive.  Enqueues kernels only; no synchronisation.
+constexpr int kCholPanel = 64;
+void chol_factor_solve(double *A, int ld, double *rhs, int *fail, hipStream_t st);
+
 }  // namespace vo

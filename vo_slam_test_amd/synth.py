@@ -273,3 +273,62 @@ def make_pose_graph(seed: int, n_kf: int = 40, drift: float = 0.01, extra_edges:
                 scales=np.ones(n_kf), fixed=0, e_i=np.array(e_i, np.int32), e_j=np.array(e_j, np.int32),
                 q_meas=np.ascontiguousarray(qm), t_meas=np.ascontiguousarray(tm), s_meas=np.ones(len(e_i)),
                 true_quats=np.ascontiguousarray([_quat_from_R(R) for R in Rs]), true_trans=np.ascontiguousarray(ts))
+
+
+# --------------------------------------------------------------------------- global BA (config 4)
+def make_global_ba_problem(seed: int = 0, n_kf: int = 500, n_pts: int = 50000, radius: float = 20.0 / (2 * np.pi),
+                           view_dist: float = 2.5, noise: bool = True, obs_keep: float = 0.37):
+    """BASELINE config 4: key-frames on a closed loop (circumference 2 pi radius = 20 m by default)
+    looking outwards at a 3 m shell of points; a point is observed by the key-frames within `view_dist`
+    whose frustum contains it (about 12-18 per point at the default sizes); one fixed key-frame.
+    Vectorised; edges come sorted by point."""
+    rng = _rng(0x6BA0000 + seed)
+    fx, fy, cx, cy, bf = CAM
+    ang = np.linspace(0, 2 * np.pi, n_kf, endpoint=False)
+    centres = np.stack([radius * np.cos(ang), 0.05 * np.sin(5 * ang), radius * np.sin(ang)], 1)
+    Rcw = np.zeros((n_kf, 3, 3))
+    for c in range(n_kf):  # camera z axis points outwards, y down
+        z = np.array([np.cos(ang[c]), 0.0, np.sin(ang[c])])
+        y = np.array([0.0, 1.0, 0.0])
+        x = np.cross(y, z)
+        Rcw[c] = np.stack([x, y, z])
+    tcw = -np.einsum("cij,cj->ci", Rcw, centres)
+    pa = rng.uniform(0, 2 * np.pi, n_pts)
+    pr = radius + rng.uniform(1.0, 4.0, n_pts)
+    P = np.stack([pr * np.cos(pa), rng.uniform(-1.0, 1.0, n_pts), pr * np.sin(pa)], 1)
+    e_cam, e_pt, e_obs, e_is = [], [], [], []
+    order = np.argsort(pa)
+    win = max(2, int(np.ceil(view_dist / (2 * np.pi * radius / n_kf))) + 1)
+    for c in range(n_kf):
+        d = np.abs(((pa - ang[c] + np.pi) % (2 * np.pi)) - np.pi)
+        cand = np.nonzero(d < (win * 2 * np.pi / n_kf))[0]
+        pc = P[cand] @ Rcw[c].T + tcw[c]
+        z = pc[:, 2]
+        u, v = fx * pc[:, 0] / z + cx, fy * pc[:, 1] / z + cy
+        ok = (z > 0.3) & (u >= 19) & (u <= 621) & (v >= 19) & (v <= 461) & (np.linalg.norm(P[cand] - centres[c], axis=1) < view_dist + 3.0)
+        ok &= rng.random(len(cand)) < obs_keep   # a feature is matched in a fraction of the frames that could see it
+        idx = cand[ok]
+        e_cam.append(np.full(len(idx), c, np.int32)), e_pt.append(idx.astype(np.int32))
+        e_obs.append(np.stack([u[ok], v[ok], u[ok] - bf / z[ok]], 1))
+    e_cam, e_pt, e_obs = np.concatenate(e_cam), np.concatenate(e_pt), np.concatenate(e_obs)
+    octv = rng.integers(0, 8, len(e_cam))
+    sg = 1.2 ** octv
+    if noise:
+        e_obs = e_obs + rng.normal(0, 1, e_obs.shape) * sg[:, None]
+    e_obs[rng.random(len(e_cam)) < 0.10, 2] = -1.0
+    srt = np.argsort(e_pt, kind="stable")
+    e_cam, e_pt, e_obs, sg = e_cam[srt], e_pt[srt], e_obs[srt], sg[srt]
+    keep = np.bincount(e_pt, minlength=n_pts) >= 2            # a landmark needs two views
+    m = keep[e_pt]
+    e_cam, e_pt, e_obs, sg = e_cam[m], e_pt[m], e_obs[m], sg[m]
+    poses_true = np.stack([se3_log(Rcw[c], tcw[c]) for c in range(n_kf)])
+    fixed = np.zeros(n_kf, np.uint8)
+    fixed[0] = 1
+    poses0 = poses_true.copy()
+    poses0[1:, :3] += rng.normal(0, 0.01, (n_kf - 1, 3))
+    poses0[1:, 3:] += rng.normal(0, np.deg2rad(0.3), (n_kf - 1, 3))
+    points0 = P + rng.normal(0, 0.02, P.shape)
+    return dict(poses=np.ascontiguousarray(poses0), fixed=fixed, points=np.ascontiguousarray(points0),
+                e_cam=np.ascontiguousarray(e_cam, np.int32), e_pt=np.ascontiguousarray(e_pt, np.int32),
+                e_obs=np.ascontiguousarray(e_obs), e_inv_sigma=np.ascontiguousarray(1.0 / sg),
+                cam=np.array(CAM, np.float64), poses_true=poses_true, points_true=P)
