@@ -1715,7 +1715,7 @@ __global__ __launch_bounds__(256) void k_ba_assemble_large(BaDev B, const double
     v = r == c ? 1.0 : 0.0;
   }
   B.Sd[idx] = v;
-  if (c == 0) B.rhs[r] = r < n ? B.gpp_v[r] + B.sc_v[r] * B.rhs[r] : 0.0;
+  if (c == 0) B.Sd[(long long)B.ld * B.ld + r] = r < n ? B.gpp_v[r] + B.sc_v[r] * B.rhs[r] : 0.0;  // right-hand side: row ld
 }
 
 // one workgroup: step, candidate poses and the camera part of the trust-region quantities
@@ -1725,7 +1725,7 @@ __global__ __launch_bounds__(256) void k_ba_poststep_large(BaDev B) {
   const BaState st0 = *S;
   if (st0.done) return;
   const int tid = threadIdx.x, n = 6 * B.nf;
-  const double *y = B.rhs;
+  const double *y = B.Sd + (long long)(B.ld + 1) * B.ld;  // solution row of the Cholesky storage
   int bad = *B.chol_fail;
   double gdot = 0, dquad = 0;
   for (int i = tid; i < n; i += 256) {
@@ -2259,7 +2259,7 @@ int build_device(vo_ba *h) {
     VO_HIP_CHECK(hipMemset(h->b_we1.p, 0, (size_t)std::max(1, h->n_edges) * 18 * 8));
     VO_CHECK(h->b_glsc0.reserve((size_t)std::max(1, h->n_pts) * 3 * 8));
     VO_CHECK(h->b_glsc1.reserve((size_t)std::max(1, h->n_pts) * 3 * 8));
-    VO_CHECK(h->b_Sd.reserve((size_t)D.ld * D.ld * 8));
+    VO_CHECK(h->b_Sd.reserve((size_t)(D.ld + vo::kCholPanel) * D.ld * 8));  // + right-hand side / solution rows
     VO_CHECK(h->b_rhs.reserve((size_t)D.ld * 8));
     VO_CHECK(h->b_scv.reserve((size_t)D.ld * 8));
     VO_CHECK(h->b_ddv.reserve((size_t)D.ld * 8));
@@ -2359,12 +2359,12 @@ int launch_large(vo_ba *h) {
   double *hp = h->b_hp.as<double>();
   hipLaunchKernelGGL(k_ba_hinv_large, dim3((D.n_local + 255) / 256), dim3(256), 0, st, D);
   hipLaunchKernelGGL(k_ba_cams_large, dim3(std::max(1, h->nf * D.n_cchunks)), dim3(256), 0, st, D);
-  VO_HIP_CHECK(hipMemsetAsync(D.Sd, 0, (size_t)D.ld * D.ld * 8, st));
+  VO_HIP_CHECK(hipMemsetAsync(D.Sd, 0, (size_t)(D.ld + vo::kCholPanel) * D.ld * 8, st));
   VO_HIP_CHECK(hipMemsetAsync(D.rhs, 0, (size_t)D.ld * 8, st));
   if (D.n_pairs > 0) hipLaunchKernelGGL(k_ba_pairs, dim3((D.n_pairs + 3) / 4), dim3(256), 0, st, D);
   hipLaunchKernelGGL(k_ba_prestep_large, dim3(1), dim3(256), 0, st, D, hp);
   hipLaunchKernelGGL(k_ba_assemble_large, dim3((unsigned)(((long long)D.ld * D.ld + 255) / 256)), dim3(256), 0, st, D, hp);
-  vo::chol_factor_solve(D.Sd, D.ld, D.rhs, D.chol_fail, st);
+  vo::chol_factor_solve(D.Sd, D.ld, D.chol_fail, st);
   hipLaunchKernelGGL(k_ba_poststep_large, dim3(1), dim3(256), 0, st, D);
   VO_HIP_CHECK(hipGetLastError());
   return VO_OK;

@@ -10,7 +10,8 @@
 //   k_chol_diag / k_chol_trsm / k_chol_syrk   blocked right-looking Cholesky of the dense
 //                   6(N-1) x 6(N-1) system, 64-wide panels, trailing update on the FP64 matrix cores
 //                   (v_mfma_f64_16x16x4_f64) from LDS-staged panels
-//   k_chol_solve    forward / backward substitution, one workgroup, rhs in LDS
+//   k_chol_back     backward substitution, one launch per panel (the forward one rides along with the
+//                   factorisation: the right-hand side is an extra row of the matrix)
 //   k_pg_model      model cost change  -(g''.s + s^T H'' s / 2)
 //   k_pg_candidate  x (+) delta  (EigenQuaternionParameterization::Plus, additive translation)
 //   k_pg_cost       sum of squared residuals over the edges
@@ -178,39 +179,56 @@ __global__ __launch_bounds__(256) void k_pg_damp(PgDev P, double *A, double *rhs
     v = 1.0;  // padding: identity keeps the factorisation well defined
   }
   A[idx] = v;
-  if (j == 0) rhs[i] = i < P.n ? P.g[i] * P.colscale[i] : 0.0;
+  if (j == 0) A[(long long)P.ld * P.ld + i] = i < P.n ? P.g[i] * P.colscale[i] : 0.0;  // right-hand side: row ld
+  (void)rhs;
 }
 
 // ---------------------------------------------------------------- dense Cholesky, lower, in place
-__global__ __launch_bounds__(256) void k_chol_diag(double *A, int ld, int K0, int *fail) {
-  __shared__ double T[NB][NB + 1];
-  const int tid = threadIdx.x;
-  for (int i = tid; i < NB * NB; i += 256) T[i / NB][i % NB] = A[(long long)(K0 + i / NB) * ld + K0 + i % NB];
-  __syncthreads();
-  for (int j = 0; j < NB; j++) {
-    const double d = T[j][j];
-    if (!(d > 0.0) || !isfinite(d)) {  // uniform: every thread reads the same value
-      if (tid == 0) *fail = 1;
-      return;
-    }
-    const double sd = sqrt(d);
-    __syncthreads();
-    if (tid == 0) T[j][j] = sd;
-    if (tid > j && tid < NB) T[tid][j] = T[tid][j] / sd;
-    __syncthreads();
-    // trailing update of the block: (i, c) with j < c <= i
-    const int m = NB - 1 - j;
-    for (int t = tid; t < m * m; t += 256) {
-      const int i = j + 1 + t / m, c = j + 1 + t % m;
-      if (c <= i) T[i][c] -= T[i][j] * T[c][j];
-    }
-    __syncthreads();
-  }
-  for (int i = tid; i < NB * NB; i += 256)
-    if (i % NB <= i / NB) A[(long long)(K0 + i / NB) * ld + K0 + i % NB] = T[i / NB][i % NB];
+// Storage: (ld + NB) rows x ld columns, row-major.  Rows 0..ld-1: the matrix (identity on the padding
+// diagonal).  Row ld: the right-hand side; it takes part in the panel substitution and in the trailing
+// update like any other row, so when the factorisation ends it holds L^-1 b (forward substitution for
+// free).  Rows ld+1.. are zero.
+
+// 64 x 64 diagonal block, one wavefront: lane i keeps row i in registers, column j of the factor is
+// broadcast with v_readlane (no LDS, no barrier); the pivot chain is the latency floor.
+__device__ __forceinline__ double lane_bcast(double v, int src_lane) {
+  const unsigned long long u = __double_as_longlong(v);
+  const unsigned lo = __builtin_amdgcn_readlane((int)(unsigned)u, src_lane);
+  const unsigned hi = __builtin_amdgcn_readlane((int)(unsigned)(u >> 32), src_lane);
+  return __longlong_as_double(((unsigned long long)hi << 32) | lo);
 }
 
-// rows below the diagonal block: X L11^T = A21, one thread per row
+__global__ __launch_bounds__(64) void k_chol_diag(double *A, int ld, int K0, int *fail) {
+  const int i = threadIdx.x;
+  double row[NB];
+  const double *src = A + (long long)(K0 + i) * ld + K0;
+#pragma unroll
+  for (int c = 0; c < NB; c++) row[c] = src[c];  // entries right of the diagonal are never used by another lane
+  bool bad = false;
+#pragma unroll
+  for (int j = 0; j < NB; j++) {
+    const double d = lane_bcast(row[j], j);
+    if (!(d > 0.0) || !isfinite(d)) bad = true;  // uniform
+    const double sd = sqrt(d);
+    const double a = i == j ? sd : row[j] / sd;  // L[i][j] (meaningful for i >= j)
+    row[j] = a;
+#pragma unroll
+    for (int c = j + 1; c < NB; c++) {
+      const double lcj = lane_bcast(a, c);  // L[c][j]
+      row[c] -= a * lcj;                    // rows i < c carry garbage in column c; never stored
+    }
+  }
+  if (bad) {
+    if (i == 0) *fail = 1;
+    return;
+  }
+  double *dst = A + (long long)(K0 + i) * ld + K0;
+#pragma unroll
+  for (int c = 0; c < NB; c++)
+    if (c <= i) dst[c] = row[c];
+}
+
+// rows below the diagonal block (including the right-hand-side row): X L11^T = A21, one thread per row
 __global__ __launch_bounds__(256) void k_chol_trsm(double *A, int ld, int K0, const int *fail) {
   __shared__ double L[NB][NB + 1];
   if (*fail) return;
@@ -218,7 +236,7 @@ __global__ __launch_bounds__(256) void k_chol_trsm(double *A, int ld, int K0, co
   for (int i = tid; i < NB * NB; i += 256) L[i / NB][i % NB] = A[(long long)(K0 + i / NB) * ld + K0 + i % NB];
   __syncthreads();
   const int r = K0 + NB + blockIdx.x * 256 + tid;
-  if (r >= ld) return;
+  if (r > ld) return;  // row ld = right-hand side
   double *row = A + (long long)r * ld + K0;
   double xr[NB];
 #pragma unroll
@@ -236,17 +254,22 @@ __global__ __launch_bounds__(256) void k_chol_trsm(double *A, int ld, int K0, co
 
 typedef double double4_t __attribute__((ext_vector_type(4)));
 
-// trailing update  A22 -= L21 L21^T  (lower tiles): one 64x64 tile per workgroup, each wavefront a
-// 32x32 quadrant = 2x2 MFMA tiles, K = 64 in 16 steps; both panels staged in LDS.
+// trailing update  A22 -= L21 L21^T  (lower tiles, plus the tile row that holds the right-hand side):
+// one 64x64 tile per workgroup, each wavefront a 32x32 quadrant = 2x2 MFMA tiles, K = 64 in 16 steps;
+// both panels staged in LDS.
 // MFMA operands: A: lane l holds A[i = l & 15][k = l >> 4];  B: B[k = l >> 4][j = l & 15];
 // C/D: column l & 15, rows (l >> 4) + 4 reg.
 __global__ __launch_bounds__(256) void k_chol_syrk(double *A, int ld, int K0, const int *fail) {
   __shared__ double Pr[NB][NB + 1], Pc[NB][NB + 1];
   if (*fail) return;
-  // linear tile index -> (tr >= tc)
-  int t = blockIdx.x, tr = 0;
-  while (t > tr) t -= tr + 1, tr++;
-  const int tc = t;
+  const int m = (ld - K0 - NB) / NB;  // square tiles per side; tile row m = the right-hand-side rows
+  int t = blockIdx.x, tr = 0, tc;
+  if (t < m * (m + 1) / 2) {  // linear index -> (tr >= tc)
+    while (t > tr) t -= tr + 1, tr++;
+    tc = t;
+  } else {
+    tr = m, tc = t - m * (m + 1) / 2;
+  }
   const int R0 = K0 + NB + tr * NB, C0 = K0 + NB + tc * NB;
   const int tid = threadIdx.x;
   for (int i = tid; i < NB * NB; i += 256) {
@@ -271,52 +294,37 @@ __global__ __launch_bounds__(256) void k_chol_syrk(double *A, int ld, int K0, co
     }
 }
 
-// L y = b, L^T x = y; one workgroup, vector in LDS (ld <= 4096)
-__global__ __launch_bounds__(256) void k_chol_solve(const double *A, int ld, double *b, const int *fail) {
-  extern __shared__ double v[];
-  __shared__ double blk[NB];
+// One step of the backward substitution L^T x = y (y = row ld), blocks from the bottom: every workgroup
+// solves the 64 x 64 triangle of block K0 redundantly in its first wavefront (lane i holds y_i, column
+// broadcasts by v_readlane), then updates its own 256-column slice of y to the left of the block.
+__global__ __launch_bounds__(256) void k_chol_back(double *A, int ld, int K0, const int *fail) {
+  __shared__ double Lk[NB][NB + 1];
+  __shared__ double xk[NB];
   if (*fail) return;
   const int tid = threadIdx.x;
-  for (int i = tid; i < ld; i += 256) v[i] = b[i];
+  double *y = A + (long long)ld * ld;
+  for (int i = tid; i < NB * NB; i += 256) Lk[i / NB][i % NB] = A[(long long)(K0 + i / NB) * ld + K0 + i % NB];
   __syncthreads();
-  const int nb = ld / NB;
-  for (int k = 0; k < nb; k++) {  // forward
-    const int K0 = k * NB;
-    for (int j = 0; j < NB; j++) {  // within the diagonal block: column-oriented, 64 threads
-      if (tid == 0) v[K0 + j] = v[K0 + j] / A[(long long)(K0 + j) * ld + K0 + j];
-      __syncthreads();
-      if (tid > j && tid < NB) v[K0 + tid] -= A[(long long)(K0 + tid) * ld + K0 + j] * v[K0 + j];
-      __syncthreads();
-    }
-    if (tid < NB) blk[tid] = v[K0 + tid];
-    __syncthreads();
-    for (int r = K0 + NB + tid; r < ld; r += 256) {
-      const double *row = A + (long long)r * ld + K0;
-      double acc = 0;
-#pragma unroll 8
-      for (int c = 0; c < NB; c++) acc += row[c] * blk[c];
-      v[r] -= acc;
-    }
-    __syncthreads();
-  }
-  for (int k = nb - 1; k >= 0; k--) {  // backward: L^T x = y
-    const int K0 = k * NB;
+  if (tid < NB) {
+    double yi = y[K0 + tid];
+#pragma unroll
     for (int j = NB - 1; j >= 0; j--) {
-      if (tid == 0) v[K0 + j] = v[K0 + j] / A[(long long)(K0 + j) * ld + K0 + j];
-      __syncthreads();
-      if (tid < j) v[K0 + tid] -= A[(long long)(K0 + j) * ld + K0 + tid] * v[K0 + j];
-      __syncthreads();
+      const double xj = lane_bcast(yi, j) / Lk[j][j];
+      if (tid == j) yi = xj;
+      if (tid < j) yi -= Lk[j][tid] * xj;
     }
-    if (tid < NB) blk[tid] = v[K0 + tid];
-    __syncthreads();
-    for (int c = tid; c < K0; c += 256) {  // x[c] -= sum_r L[r][c] x[r], r in this block
-      double acc = 0;
-      for (int rr = 0; rr < NB; rr++) acc += A[(long long)(K0 + rr) * ld + c] * blk[rr];
-      v[c] -= acc;
-    }
-    __syncthreads();
+    xk[tid] = yi;
   }
-  for (int i = tid; i < ld; i += 256) b[i] = v[i];
+  __syncthreads();
+  const int c = blockIdx.x * 256 + tid;
+  if (c < K0) {
+    double acc = 0;
+#pragma unroll 8
+    for (int r = 0; r < NB; r++) acc += A[(long long)(K0 + r) * ld + c] * xk[r];
+    y[c] -= acc;
+  }
+  // the solution goes to row ld + 1: y_k itself must stay intact for workgroups that start later
+  if (blockIdx.x == 0 && tid < NB) A[(long long)(ld + 1) * ld + K0 + tid] = xk[tid];
 }
 
 // model cost change of step s = -y:  -(g''.s + s^T H'' s / 2), H'' = S H S (undamped); out[0] += partial
@@ -413,17 +421,16 @@ double sum_device(const vo::DevBuf &b, int n, int stride = 1, int offset = 0) { 
 
 }  // namespace
 
-void vo::chol_factor_solve(double *A, int ld, double *rhs, int *fail, hipStream_t st) {
+void vo::chol_factor_solve(double *A, int ld, int *fail, hipStream_t st) {
   for (int K0 = 0; K0 < ld; K0 += NB) {
-    hipLaunchKernelGGL(k_chol_diag, dim3(1), dim3(256), 0, st, A, ld, K0, fail);
-    const int rem = ld - K0 - NB;
-    if (rem > 0) {
-      hipLaunchKernelGGL(k_chol_trsm, dim3((rem + 255) / 256), dim3(256), 0, st, A, ld, K0, fail);
-      const int m = rem / NB;
-      hipLaunchKernelGGL(k_chol_syrk, dim3(m * (m + 1) / 2), dim3(256), 0, st, A, ld, K0, fail);
-    }
+    hipLaunchKernelGGL(k_chol_diag, dim3(1), dim3(64), 0, st, A, ld, K0, fail);
+    const int rem = ld - K0 - NB;  // matrix rows below the block; the right-hand-side row comes on top
+    hipLaunchKernelGGL(k_chol_trsm, dim3((rem + 1 + 255) / 256), dim3(256), 0, st, A, ld, K0, fail);
+    const int m = rem / NB;
+    if (m > 0) hipLaunchKernelGGL(k_chol_syrk, dim3(m * (m + 1) / 2 + m), dim3(256), 0, st, A, ld, K0, fail);
   }
-  hipLaunchKernelGGL(k_chol_solve, dim3(1), dim3(256), (size_t)ld * 8, st, A, ld, rhs, fail);
+  for (int K0 = ld - NB; K0 >= 0; K0 -= NB)
+    hipLaunchKernelGGL(k_chol_back, dim3(std::max(1, (K0 + 255) / 256)), dim3(256), 0, st, A, ld, K0, fail);
 }
 
 extern "C" {
@@ -437,26 +444,25 @@ int vo_chol_solve(int n, double *A_rowmajor_lower, double *b) {
     vo::set_error("vo_chol_solve: n = %d exceeds 4096", n);
     return VO_ERR_CAPACITY;
   }
-  std::vector<double> Ap((size_t)ld * ld, 0.0), bp(ld, 0.0);
+  std::vector<double> Ap((size_t)(ld + NB) * ld, 0.0), bp(ld, 0.0);
   for (int i = 0; i < ld; i++) {
     if (i < n) {
       for (int j = 0; j <= i; j++) Ap[(size_t)i * ld + j] = A_rowmajor_lower[(size_t)i * n + j];
-      bp[i] = b[i];
+      Ap[(size_t)ld * ld + i] = b[i];  // right-hand side: row ld
     } else {
       Ap[(size_t)i * ld + i] = 1.0;
     }
   }
-  vo::DevBuf dA, db, dfail;
+  vo::DevBuf dA, dfail;
   int rc = VO_OK;
   auto done = [&](int r) {
-    dA.release(), db.release(), dfail.release();
+    dA.release(), dfail.release();
     return r;
   };
   if ((rc = upload(dA, Ap.data(), Ap.size() * 8)) != VO_OK) return done(rc);
-  if ((rc = upload(db, bp.data(), bp.size() * 8)) != VO_OK) return done(rc);
   int zero = 0;
   if ((rc = upload(dfail, &zero, 4)) != VO_OK) return done(rc);
-  vo::chol_factor_solve(dA.as<double>(), ld, db.as<double>(), dfail.as<int>(), nullptr);
+  vo::chol_factor_solve(dA.as<double>(), ld, dfail.as<int>(), nullptr);
   if (hipDeviceSynchronize() != hipSuccess) {
     vo::set_error("Cholesky kernels failed: %s", hipGetErrorString(hipGetLastError()));
     return done(VO_ERR_HIP);
@@ -467,9 +473,8 @@ int vo_chol_solve(int n, double *A_rowmajor_lower, double *b) {
     vo::set_error("vo_chol_solve: matrix is not positive definite");
     return done(VO_ERR_INVALID);
   }
-  (void)hipMemcpy(bp.data(), db.p, (size_t)ld * 8, hipMemcpyDeviceToHost);
-  for (int i = 0; i < n; i++) b[i] = bp[i];
   (void)hipMemcpy(Ap.data(), dA.p, Ap.size() * 8, hipMemcpyDeviceToHost);
+  for (int i = 0; i < n; i++) b[i] = Ap[(size_t)(ld + 1) * ld + i];  // solution: row ld + 1
   for (int i = 0; i < n; i++)
     for (int j = 0; j <= i; j++) A_rowmajor_lower[(size_t)i * n + j] = Ap[(size_t)i * ld + j];
   return done(VO_OK);
@@ -540,7 +545,7 @@ int vo_pose_graph_solve(int n_nodes, double *quats, double *trans, const double 
   PG_TRY(upload(d_x, x.data(), x.size() * 8));
   PG_TRY(d_xc.reserve(x.size() * 8));
   PG_TRY(d_H.reserve((size_t)ld * ld * 8));
-  PG_TRY(d_A.reserve((size_t)ld * ld * 8));
+  PG_TRY(d_A.reserve((size_t)(ld + NB) * ld * 8));
   PG_TRY(d_g.reserve((size_t)ld * 8));
   PG_TRY(d_cs.reserve((size_t)ld * 8));
   PG_TRY(d_rhs.reserve((size_t)ld * 8));
@@ -605,9 +610,11 @@ int vo_pose_graph_solve(int n_nodes, double *quats, double *trans, const double 
     (void)hipMemcpy(d_fail.p, &zero, 4, hipMemcpyHostToDevice);
     hipLaunchKernelGGL(k_pg_damp, dim3((unsigned)(((long long)ld * ld + 255) / 256)), dim3(256), 0, nullptr, P,
                        d_A.as<double>(), d_rhs.as<double>(), radius);
-    vo::chol_factor_solve(d_A.as<double>(), ld, d_rhs.as<double>(), d_fail.as<int>(), nullptr);
-    hipLaunchKernelGGL(k_pg_model, dim3(n), dim3(256), 0, nullptr, P, d_rhs.as<double>(), d_part.as<double>());
-    hipLaunchKernelGGL(k_pg_candidate, dim3((n_nodes + 127) / 128), dim3(128), 0, nullptr, P, dx, d_rhs.as<double>(), dxc,
+    (void)hipMemsetAsync(d_A.as<double>() + (size_t)(ld + 1) * ld, 0, (size_t)(NB - 1) * ld * 8, nullptr);  // rows below the rhs
+    vo::chol_factor_solve(d_A.as<double>(), ld, d_fail.as<int>(), nullptr);
+    const double *ysol = d_A.as<double>() + (size_t)(ld + 1) * ld;
+    hipLaunchKernelGGL(k_pg_model, dim3(n), dim3(256), 0, nullptr, P, ysol, d_part.as<double>());
+    hipLaunchKernelGGL(k_pg_candidate, dim3((n_nodes + 127) / 128), dim3(128), 0, nullptr, P, dx, ysol, dxc,
                        d_norm.as<double>());
     PG_TRY(sync());
     int failed = 0;

@@ -55,11 +55,13 @@ struct DevBuf {
 
 constexpr int kWave = 64;
 
-// Dense SPD solve on the device (csrc/pose_graph.hip): A is ld x ld row-major with ld a multiple of 64
-// (identity on the padding diagonal), lower triangle factored in place (L L^T, 64-wide panels,
-// trailing update on the FP64 matrix cores), rhs -> solution.  *fail (device int, zeroed by the
-// caller) is set when a pivot is not positive.  Enqueues kernels only; no synchronisation.
+// Dense SPD solve on the device (csrc/pose_graph.hip).  A: (ld + 64) rows x ld columns, row-major, ld a
+// multiple of 64.  Rows 0..ld-1: the matrix, lower triangle used (identity on the padding diagonal);
+// row ld: the right-hand side; rows ld+1..: zero on entry.  The lower triangle is factored in place
+// (L L^T, 64-wide panels, trailing update on the FP64 matrix cores); the solution ends up in row
+// ld + 1.  *fail (device int, zeroed by the caller) is set when a pivot is not positive.  Enqueues
+// kernels only; no synchronisation.
 constexpr int kCholPanel = 64;
-void chol_factor_solve(double *A, int ld, double *rhs, int *fail, hipStream_t st);
+void chol_factor_solve(double *A, int ld, int *fail, hipStream_t st);
 
 }  // namespace vo
