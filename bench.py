@@ -17,6 +17,7 @@ reports them as extra keys of the same JSON line.
 from __future__ import annotations
 
 import argparse
+import ctypes
 import json
 import os
 import pathlib
@@ -239,6 +240,35 @@ def main():
             out["pose_only_ba"] = {"workload": f"{len(probs)} frames x 1000 obs, 2 x <=10 LM iterations, one launch "
                                                "(host buffers in/out, PCIe included)",
                                    "solves_per_s": round(len(probs) / tp, 1), "lm_iters_per_s": round(pit / tp, 1)}
+            # config 4: loop-closure sized problems (global BA through the large-system path, pose graph, Sim3)
+            gb = synth.make_global_ba_problem(0)
+            gba = vo.BundleAdjuster(gb)
+            hm, hs = float(np.sqrt(np.float32(5.991))), float(np.sqrt(np.float32(7.815)))
+            gba.solve(hm, hs, 1)                                   # builds the device structures
+            gba.set_state(gb["poses"], gb["points"])
+            torch.cuda.synchronize()
+            tg0 = time.perf_counter()
+            gs = gba.solve(hm, hs, 10)
+            tg = time.perf_counter() - tg0
+            gba.close()
+            out["global_ba"] = {"workload": f"{len(gb['poses'])} KF x {len(gb['points'])} pts, {len(gb['e_cam'])} edges, "
+                                            f"{6 * (len(gb['poses']) - 1)}-wide reduced system, 10 LM iterations",
+                                "lm_iters_per_s": round(gs.iterations / tg, 1), "ms_per_iter": round(tg / gs.iterations * 1e3, 3),
+                                "dtype": "f64", "sharding": "single GPU"}
+            pg = synth.make_pose_graph(7, n_kf=500, drift=0.004, extra_edges=4)
+            vo.Optimizer.solvePoseGraphLoop(synth.make_pose_graph(0, n_kf=12))
+            tq0 = time.perf_counter()
+            _, _, ps = vo.Optimizer.solvePoseGraphLoop(pg)
+            tq = time.perf_counter() - tq0
+            out["pose_graph"] = {"workload": f"500 KF, {len(pg['e_i'])} Sim3 edges, scales fixed", "ms_per_solve": round(tq * 1e3, 2),
+                                 "lm_iterations": ps.iterations, "ms_per_iter": round(tq / max(ps.iterations, 1) * 1e3, 2)}
+            sp = [synth.make_sim3_problem(i, n=200, outliers=0.1) for i in range(256)]
+            vo.Optimizer.solveLoopSim3(sp[:8])
+            ts0 = time.perf_counter()
+            vo.Optimizer.solveLoopSim3(sp)
+            ts = time.perf_counter() - ts0
+            out["sim3"] = {"workload": "256 loop candidates x 200 matches, one launch (host buffers in/out)",
+                           "solves_per_s": round(len(sp) / ts, 1)}
 
     # ------------------------------------------------------------------ CPU baseline (oracle)
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
@@ -274,6 +304,17 @@ def main():
             if "aggregate_lm_iters_per_s" in out["local_ba"]:
                 out["local_ba"]["aggregate_speedup_vs_cpu_port"] = round(
                     out["local_ba"]["aggregate_lm_iters_per_s"] / (its / tl), 1)
+            if "global_ba" in out:
+                gp, gpt = gb["poses"].copy(), gb["points"].copy()
+                gsum = orc.make_summary(1)
+                tgc0 = time.perf_counter()
+                orc.lib().orc_ba_lm(len(gp), gp, gb["fixed"], len(gpt), gpt, len(gb["e_cam"]), gb["e_cam"], gb["e_pt"],
+                                    gb["e_obs"], gb["e_inv_sigma"], None, gb["cam"], hm, hs, 1,
+                                    ctypes.cast(ctypes.pointer(gsum), ctypes.c_void_p))
+                tgc = time.perf_counter() - tgc0
+                cpu["global_ba_lm_iters_per_s"] = round(1.0 / tgc, 3)
+                cpu["global_ba_sample"] = f"1 LM iteration of the same 500-KF problem, {tgc:.1f} s, 1 thread"
+                out["global_ba"]["speedup_vs_cpu_port"] = round(out["global_ba"]["lm_iters_per_s"] * tgc, 1)
         cpu["host"] = {"cpu_count": os.cpu_count()}
         out["cpu_baseline"] = cpu
     ext.close()
