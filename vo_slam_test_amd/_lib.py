@@ -113,8 +113,8 @@ class OrbExtractor:
         self.nlevels = nlevels
 
     def close(self):
-        if getattr(self, "_h", None) and self._h.value:
-            lib().vo_orb_destroy(self._h)
+        if getattr(self, "_h", None) and self._h.value and _lib is not None:   # (_lib is gone at interpreter exit)
+            _lib.vo_orb_destroy(self._h)
             self._h = C.c_void_p()
 
     __del__ = close
@@ -475,8 +475,8 @@ class BundleAdjuster:
             check(lib().vo_ba_set_stream(self._h, C.c_void_p(stream)))
 
     def close(self):
-        if getattr(self, "_h", None) and self._h.value:
-            lib().vo_ba_destroy(self._h)
+        if getattr(self, "_h", None) and self._h.value and _lib is not None:
+            _lib.vo_ba_destroy(self._h)
             self._h = C.c_void_p()
 
     __del__ = close

@@ -2500,12 +2500,10 @@ int vo_pose_only_solve(int n_problems, const int32_t *offsets, const double *poi
   VO_CHECK(vo::ensure_device());
   const int total = offsets[n_problems];
   if (total > 0 && (!points || !obs || !inv_sigma || !outlier)) return VO_ERR_INVALID;
-  vo::DevBuf d_off, d_pts, d_obs, d_is, d_cam, d_pose, d_out, d_inl, d_sum;
+  // per host thread, grow-only scratch: no allocation after the first call at a size
+  thread_local vo::DevBuf d_off, d_pts, d_obs, d_is, d_cam, d_pose, d_out, d_inl, d_sum;
   int rc = VO_OK;
-  auto fail = [&](int r) {
-    for (vo::DevBuf *b : {&d_off, &d_pts, &d_obs, &d_is, &d_cam, &d_pose, &d_out, &d_inl, &d_sum}) b->release();
-    return r;
-  };
+  auto fail = [&](int r) { return r; };
   if ((rc = upload(d_off, offsets, (size_t)(n_problems + 1) * 4)) != VO_OK) return fail(rc);
   if ((rc = upload(d_pts, points, (size_t)total * 24)) != VO_OK) return fail(rc);
   if ((rc = upload(d_obs, obs, (size_t)total * 24)) != VO_OK) return fail(rc);
@@ -2542,13 +2540,9 @@ int vo_sim3_solve(int n_problems, const int32_t *offsets, const double *cam_matc
   const int total = offsets[n_problems];
   if (total > 0 && (!cam_match || !pix_curr || !inv_sigma_curr || !cam_curr || !pix_match || !inv_sigma_match || !outlier))
     return VO_ERR_INVALID;
-  vo::DevBuf d_off, d_pm, d_pc, d_isc, d_Pc, d_pxm, d_ism, d_cam, d_pose, d_sc, d_out, d_inl, d_sum;
+  thread_local vo::DevBuf d_off, d_pm, d_pc, d_isc, d_Pc, d_pxm, d_ism, d_cam, d_pose, d_sc, d_out, d_inl, d_sum;
   int rc = VO_OK;
-  auto fail = [&](int r) {
-    for (vo::DevBuf *b : {&d_off, &d_pm, &d_pc, &d_isc, &d_Pc, &d_pxm, &d_ism, &d_cam, &d_pose, &d_sc, &d_out, &d_inl, &d_sum})
-      b->release();
-    return r;
-  };
+  auto fail = [&](int r) { return r; };
   if ((rc = upload(d_off, offsets, (size_t)(n_problems + 1) * 4)) != VO_OK) return fail(rc);
   if ((rc = upload(d_pm, cam_match, (size_t)total * 24)) != VO_OK) return fail(rc);
   if ((rc = upload(d_pc, pix_curr, (size_t)total * 16)) != VO_OK) return fail(rc);

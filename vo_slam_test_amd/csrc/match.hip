@@ -164,7 +164,9 @@ int vo_hamming_matrix(const uint8_t *a, int na, const uint8_t *b, int nb, uint16
   if (na == 0 || nb == 0) return VO_OK;
   if (!a || !b || !d) return VO_ERR_INVALID;
   VO_CHECK(vo::ensure_device());
-  vo::DevBuf da, db, dd;
+  // per host thread, grow-only: the stateless entry points do not allocate after the first call at a size
+  // (never freed: a few MB per calling thread for the life of the process)
+  thread_local vo::DevBuf da, db, dd;
   int rc = VO_OK;
   do {
     if ((rc = da.reserve((size_t)na * 32)) != VO_OK) break;
@@ -183,7 +185,6 @@ int vo_hamming_matrix(const uint8_t *a, int na, const uint8_t *b, int nb, uint16
       rc = VO_ERR_HIP;
     }
   } while (0);
-  da.release(), db.release(), dd.release();
   return rc;
 }
 
