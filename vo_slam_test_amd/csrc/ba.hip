@@ -245,11 +245,12 @@ __device__ void pose_lm(double x[6], int n, const double *pts, const double *obs
     invalid = 0;
     double xc[6];
     se3_plus(x, delta, xc);
+    // The candidate is linearised completely in the same pass (its cost is one of the 28 sums): an
+    // accepted step -- the common case -- then needs no second sweep over the observations.
     double cacc[28];
-    pose_accumulate(xc, n, pts, obs, isg, skip, K, hm, hs, false, cacc);
-    double cc[1] = {cacc[27]};
-    block_sum<1>(cc, lds);
-    double cand = cc[0];
+    pose_accumulate(xc, n, pts, obs, isg, skip, K, hm, hs, true, cacc);
+    block_sum<28>(cacc, lds);
+    double cand = cacc[27];
     if (!isfinite(cand)) cand = 1.7976931348623157e308;
     double sn = 0;
     for (int a = 0; a < 6; a++) sn += (x[a] - xc[a]) * (x[a] - xc[a]);
@@ -266,8 +267,8 @@ __device__ void pose_lm(double x[6], int n, const double *pts, const double *obs
     if (rel > 1e-3) {
       for (int a = 0; a < 6; a++) x[a] = xc[a];
       x_norm = sqrt(x[0] * x[0] + x[1] * x[1] + x[2] * x[2] + x[3] * x[3] + x[4] * x[4] + x[5] * x[5]);
-      pose_accumulate(x, n, pts, obs, isg, skip, K, hm, hs, true, acc);
-      block_sum<28>(acc, lds);
+#pragma unroll
+      for (int i = 0; i < 28; i++) acc[i] = cacc[i];
       x_cost = acc[27];
       const double t2 = 2.0 * rel - 1.0;
       radius = fmin(radius / fmax(1.0 / 3.0, 1.0 - t2 * t2 * t2), 1e16);
@@ -538,11 +539,10 @@ __device__ void sim3_lm(double x[7], const Sim3Prob &Q, int max_it, double *lds,
     double xc[7];
 #pragma unroll
     for (int a = 0; a < 7; a++) xc[a] = x[a] + delta[a];
-    double cacc[NA];
-    sim3_accumulate<NP>(xc, Q, false, cacc);
-    double cc[1] = {cacc[NH + NP]};
-    block_sum<1>(cc, lds);
-    double cand = cc[0];
+    double cacc[NA];  // complete linearisation at the candidate (see pose_lm)
+    sim3_accumulate<NP>(xc, Q, true, cacc);
+    block_sum<NA>(cacc, lds);
+    double cand = cacc[NH + NP];
     if (!isfinite(cand)) cand = 1.7976931348623157e308;
     double sn = 0;
 #pragma unroll
@@ -561,8 +561,8 @@ __device__ void sim3_lm(double x[7], const Sim3Prob &Q, int max_it, double *lds,
 #pragma unroll
       for (int a = 0; a < 7; a++) x[a] = xc[a];
       x_norm = norm_free(x);
-      sim3_accumulate<NP>(x, Q, true, acc);
-      block_sum<NA>(acc, lds);
+#pragma unroll
+      for (int i = 0; i < NA; i++) acc[i] = cacc[i];
       x_cost = acc[NH + NP];
       const double t2 = 2.0 * rel - 1.0;
       radius = fmin(radius / fmax(1.0 / 3.0, 1.0 - t2 * t2 * t2), 1e16);
@@ -2500,34 +2500,48 @@ int vo_pose_only_solve(int n_problems, const int32_t *offsets, const double *poi
   VO_CHECK(vo::ensure_device());
   const int total = offsets[n_problems];
   if (total > 0 && (!points || !obs || !inv_sigma || !outlier)) return VO_ERR_INVALID;
-  // per host thread, grow-only scratch: no allocation after the first call at a size
-  thread_local vo::DevBuf d_off, d_pts, d_obs, d_is, d_cam, d_pose, d_out, d_inl, d_sum;
-  int rc = VO_OK;
-  auto fail = [&](int r) { return r; };
-  if ((rc = upload(d_off, offsets, (size_t)(n_problems + 1) * 4)) != VO_OK) return fail(rc);
-  if ((rc = upload(d_pts, points, (size_t)total * 24)) != VO_OK) return fail(rc);
-  if ((rc = upload(d_obs, obs, (size_t)total * 24)) != VO_OK) return fail(rc);
-  if ((rc = upload(d_is, inv_sigma, (size_t)total * 8)) != VO_OK) return fail(rc);
-  if ((rc = upload(d_cam, cam, 40)) != VO_OK) return fail(rc);
-  if ((rc = upload(d_pose, poses, (size_t)n_problems * 48)) != VO_OK) return fail(rc);
-  if ((rc = d_out.reserve(std::max(64, total))) != VO_OK) return fail(rc);
-  if ((rc = d_inl.reserve((size_t)n_problems * 4)) != VO_OK) return fail(rc);
-  if ((rc = d_sum.reserve((size_t)n_problems * 2 * sizeof(vo_lm_summary))) != VO_OK) return fail(rc);
-  (void)hipMemset(d_sum.p, 0, (size_t)n_problems * 2 * sizeof(vo_lm_summary));
-  rc = vo_pose_only_solve_dev(n_problems, d_off.as<int32_t>(), 0, d_pts.as<double>(), d_obs.as<double>(),
-                              d_is.as<double>(), d_cam.as<double>(), d_pose.as<double>(), d_out.as<uint8_t>(),
-                              d_inl.as<int32_t>(), d_sum.as<vo_lm_summary>(), nullptr);
-  if (rc != VO_OK) return fail(rc);
-  if (hipDeviceSynchronize() != hipSuccess) {
-    vo::set_error("pose-only kernel failed: %s", hipGetErrorString(hipGetLastError()));
-    return fail(VO_ERR_HIP);
+  // One staging block each way (a tracking thread calls this once or twice per frame: eleven small
+  // copies cost more than the kernel's first LM iterations).  Per host thread, grow-only.
+  auto up8 = [](size_t v) { return (v + 7) & ~(size_t)7; };
+  const size_t o_pts = 0, o_obs = o_pts + (size_t)total * 24, o_is = o_obs + (size_t)total * 24,
+               o_cam = o_is + (size_t)total * 8, o_pose = o_cam + 40, o_off = o_pose + (size_t)n_problems * 48,
+               in_bytes = up8(o_off + (size_t)(n_problems + 1) * 4);
+  const size_t r_pose = 0, r_sum = r_pose + (size_t)n_problems * 48,
+               r_inl = r_sum + (size_t)n_problems * 2 * sizeof(vo_lm_summary), r_out = up8(r_inl + (size_t)n_problems * 4),
+               out_bytes = up8(r_out + (size_t)std::max(total, 1));
+  thread_local std::vector<uint8_t> stage;
+  thread_local vo::DevBuf d_in, d_out;
+  stage.resize(std::max(in_bytes, out_bytes));
+  if (total > 0) {
+    memcpy(&stage[o_pts], points, (size_t)total * 24);
+    memcpy(&stage[o_obs], obs, (size_t)total * 24);
+    memcpy(&stage[o_is], inv_sigma, (size_t)total * 8);
   }
-  (void)hipMemcpy(poses, d_pose.p, (size_t)n_problems * 48, hipMemcpyDeviceToHost);
-  if (total > 0) (void)hipMemcpy(outlier, d_out.p, total, hipMemcpyDeviceToHost);
-  (void)hipMemcpy(n_inliers, d_inl.p, (size_t)n_problems * 4, hipMemcpyDeviceToHost);
-  if (summaries)
-    (void)hipMemcpy(summaries, d_sum.p, (size_t)n_problems * 2 * sizeof(vo_lm_summary), hipMemcpyDeviceToHost);
-  return fail(VO_OK);
+  memcpy(&stage[o_cam], cam, 40);
+  memcpy(&stage[o_pose], poses, (size_t)n_problems * 48);
+  memcpy(&stage[o_off], offsets, (size_t)(n_problems + 1) * 4);
+  VO_CHECK(d_in.reserve(in_bytes));
+  VO_CHECK(d_out.reserve(out_bytes));
+  VO_HIP_CHECK(hipMemcpy(d_in.p, stage.data(), in_bytes, hipMemcpyHostToDevice));
+  uint8_t *di = d_in.as<uint8_t>(), *dout = d_out.as<uint8_t>();
+  // the kernel updates poses in place: give it the output block's copy
+  VO_HIP_CHECK(hipMemcpyAsync(dout + r_pose, di + o_pose, (size_t)n_problems * 48, hipMemcpyDeviceToDevice, nullptr));
+  VO_HIP_CHECK(hipMemsetAsync(dout + r_sum, 0, (size_t)n_problems * 2 * sizeof(vo_lm_summary), nullptr));
+  VO_CHECK(vo_pose_only_solve_dev(n_problems, reinterpret_cast<const int32_t *>(di + o_off), 0,
+                                  reinterpret_cast<const double *>(di + o_pts), reinterpret_cast<const double *>(di + o_obs),
+                                  reinterpret_cast<const double *>(di + o_is), reinterpret_cast<const double *>(di + o_cam),
+                                  reinterpret_cast<double *>(dout + r_pose), dout + r_out,
+                                  reinterpret_cast<int32_t *>(dout + r_inl),
+                                  reinterpret_cast<vo_lm_summary *>(dout + r_sum), nullptr));
+  if (hipMemcpy(stage.data(), dout, out_bytes, hipMemcpyDeviceToHost) != hipSuccess) {  // synchronises with the kernel
+    vo::set_error("pose-only kernel failed: %s", hipGetErrorString(hipGetLastError()));
+    return VO_ERR_HIP;
+  }
+  memcpy(poses, &stage[r_pose], (size_t)n_problems * 48);
+  if (total > 0) memcpy(outlier, &stage[r_out], total);
+  memcpy(n_inliers, &stage[r_inl], (size_t)n_problems * 4);
+  if (summaries) memcpy(summaries, &stage[r_sum], (size_t)n_problems * 2 * sizeof(vo_lm_summary));
+  return VO_OK;
 }
 
 int vo_sim3_solve(int n_problems, const int32_t *offsets, const double *cam_match, const double *pix_curr,
