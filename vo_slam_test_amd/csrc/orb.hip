@@ -1143,6 +1143,8 @@ struct vo_orb {
   int umax[16];
   hipStream_t stream = nullptr;
   bool own_stream = false;
+  hipStream_t side = nullptr;          // blur runs here, concurrently with FAST / oct-tree (no data dependence)
+  hipEvent_t ev_fork = nullptr, ev_join = nullptr;
   // geometry (valid for cfg_w x cfg_h)
   int cfg_w = 0, cfg_h = 0;
   OrbDev dev;
@@ -1428,6 +1430,23 @@ int run_pipeline(vo_orb *h, const uint8_t *dev_images, int n_frames, int w, int 
     }
   }
   VO_STAGE_MARK(1);
+  // The blur reads the pyramid only; FAST -> oct-tree -> offsets do not touch the blurred planes.  Outside
+  // the instrumented mode the blur therefore runs on a side stream next to them (the oct-tree kernel is
+  // latency-bound and leaves most of the machine idle) and joins before the descriptors.
+  const bool overlap = !ev && h->side != nullptr;
+  auto launch_blur = [&](hipStream_t bs) {
+    const int lv0_generic = lv0_unaligned;
+    if (h->strips_frame > 0)
+      hipLaunchKernelGGL(k_blur_strips, dim3((h->strips_frame + 3) / 4, n_frames), dim3(256), 0, bs, D, S, lv0_generic);
+    hipLaunchKernelGGL(k_blur_border, dim3((h->border_rows_frame + 15) / 16, n_frames), dim3(256), 0, bs, D, S, lv0_generic);
+    if (lv0_generic) hipLaunchKernelGGL(k_blur, dim3(h->tiles_frame, n_frames), dim3(256), 0, bs, D, S, 0);
+  };
+  if (overlap) {
+    VO_HIP_CHECK(hipEventRecord(h->ev_fork, st));
+    VO_HIP_CHECK(hipStreamWaitEvent(h->side, h->ev_fork, 0));
+    launch_blur(h->side);
+    VO_HIP_CHECK(hipEventRecord(h->ev_join, h->side));
+  }
   if (h->cells_frame > 0) {
     const dim3 grid((h->cells_frame + 3) / 4, n_frames);
     if (h->fast_tp == 48)
@@ -1453,15 +1472,12 @@ int run_pipeline(vo_orb *h, const uint8_t *dev_images, int n_frames, int w, int 
   hipLaunchKernelGGL(k_offsets, dim3((n_frames + 63) / 64), dim3(64), 0, st, D.nlevels, n_frames,
                      h->nk.as<int>(), h->off.as<int>(), capacity, dcounts);
   VO_STAGE_MARK(4);
-  {
-    // the strip kernel reads aligned dwords; a caller image that is not 4-byte aligned falls back
-    // to the generic LDS kernel for level 0 only
-    const int lv0_generic = lv0_unaligned;
-    if (h->strips_frame > 0)
-      hipLaunchKernelGGL(k_blur_strips, dim3((h->strips_frame + 3) / 4, n_frames), dim3(256), 0, st, D, S, lv0_generic);
-    hipLaunchKernelGGL(k_blur_border, dim3((h->border_rows_frame + 15) / 16, n_frames), dim3(256), 0, st, D, S, lv0_generic);
-    if (lv0_generic) hipLaunchKernelGGL(k_blur, dim3(h->tiles_frame, n_frames), dim3(256), 0, st, D, S, 0);
-  }
+  // (the strip kernel reads aligned dwords; a caller image that is not 4-byte aligned falls back to the
+  // generic LDS kernel for level 0 only)
+  if (overlap)
+    VO_HIP_CHECK(hipStreamWaitEvent(st, h->ev_join, 0));
+  else
+    launch_blur(st);
   VO_STAGE_MARK(5);
   const int kp_blocks = (std::min(capacity, h->max_kp) + 3) / 4;
   if (kp_blocks > 0)
@@ -1541,6 +1557,12 @@ int vo_orb_create(vo_orb **out, int nfeatures, float scale_factor, int nlevels, 
     return VO_ERR_HIP;
   }
   h->own_stream = true;
+  if (hipStreamCreateWithFlags(&h->side, hipStreamNonBlocking) != hipSuccess ||
+      hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming) != hipSuccess ||
+      hipEventCreateWithFlags(&h->ev_join, hipEventDisableTiming) != hipSuccess) {
+    (void)hipGetLastError();
+    h->side = nullptr;  // no overlap then
+  }
   *out = h;
   return VO_OK;
 }
@@ -1553,6 +1575,9 @@ void vo_orb_destroy(vo_orb *h) {
                         &h->out_cnt})
     b->release();
   for (hipEvent_t e : h->ev) (void)hipEventDestroy(e);
+  if (h->ev_fork) (void)hipEventDestroy(h->ev_fork);
+  if (h->ev_join) (void)hipEventDestroy(h->ev_join);
+  if (h->side) (void)hipStreamDestroy(h->side);
   if (h->own_stream) (void)hipStreamDestroy(h->stream);
   delete h;
 }
