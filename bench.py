@@ -205,6 +205,12 @@ def main():
                 tb += time.perf_counter() - tb0
                 iters += s1.iterations + s2.iterations
             sba.close()
+            # every rank took the same decisions: identical iteration counts are part of the contract
+            chk = torch.tensor([iters], dtype=torch.int64, device="cuda")
+            lo, hi = chk.clone(), chk.clone()
+            dist.all_reduce(lo, op=dist.ReduceOp.MIN)
+            dist.all_reduce(hi, op=dist.ReduceOp.MAX)
+            assert int(lo.item()) == int(hi.item()), "ranks diverged in the sharded LM loop"
         out["local_ba"] = {"workload": f"10 KF + 4 fixed x 3000 pts, {n_edges} edges, 5 Huber + 10 plain LM iterations",
                            "lm_iters_per_s": round(iters / tb, 1), "ms_per_solve": round(tb / reps * 1e3, 3),
                            "iterations_per_solve": iters / reps, "dtype": "f64",

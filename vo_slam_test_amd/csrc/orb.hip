@@ -361,7 +361,7 @@ __global__ __launch_bounds__(256) void k_fast_wave(OrbDev P, FrameSrc src, uint3
 #pragma unroll
       for (int q = 0; q < 4; q++) {
         const bool ok = base + q * 64 + lane < total;
-        pos[q] = ok ? y * TP + unit * x : -1;
+        pos[q] = ok ? __mul24(y, TP) + unit * x : -1;
         // unconditional load (lanes past the tile re-read its first element): a `ok ? load : 0` form is
         // turned into a branch per load with a full s_waitcnt behind it, serialising the batch
         const uint8_t *g = ok ? g0 + (long long)y * pitch + unit * x : g0;
@@ -394,7 +394,7 @@ __global__ __launch_bounds__(256) void k_fast_wave(OrbDev P, FrameSrc src, uint3
     const int sdy = 64 / iwd, sdx = 64 - sdy * iwd;
     for (int base = 0; base < ni; base += 64) {
       bool pass = false;
-      const int pos = (3 + y) * TP + 3 + x;
+      const int pos = __mul24(3 + y, TP) + 3 + x;  // 24-bit multiply: full rate (v_mul_lo_u32 is quarter rate)
       if (base + lane < ni) {
         const uint8_t *t = &tile[pos];
         const int v = t[0];
