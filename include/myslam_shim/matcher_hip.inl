@@ -425,4 +425,25 @@ int Matcher::fuseByPose(KeyFrame *kf, Sophus::Sim3 &Scw, vector<MapPoint *> &loo
   return fused;
 }
 
+// Frame::computeBow / KeyFrame::computeBow (frame.cpp:248-253, keyframe.cpp:394-398):
+// voc_->transform(descriptors, bowVec_, featVec_, 3).  The tree descent runs on the device; filling the
+// two std::maps is what DBoW3::Vocabulary::transform does after it (word weights summed per word, L1
+// normalisation for the TF-IDF / L1 vocabulary shipped with ORB-SLAM2, features listed per node).
+// `voc_dev` is created once from the parsed vocabulary with vo_vocab_create.
+template <class F>
+void computeBowHip(F *f, const vo_vocab *voc_dev) {
+  if (!f->featVec_.empty() && !f->bowVec_.empty()) return;
+  const int n = f->descriptors_.rows;
+  std::vector<int32_t> word(n), node(n);
+  std::vector<double> weight(n);
+  vo_bow_transform(voc_dev, n, f->descriptors_.data, 3, word.data(), weight.data(), node.data());
+  f->bowVec_.clear(), f->featVec_.clear();
+  for (int i = 0; i < n; i++)
+    if (weight[i] > 0) {
+      f->bowVec_.addWeight(word[i], weight[i]);
+      f->featVec_.addFeature(node[i], i);
+    }
+  f->bowVec_.normalize(DBoW3::L1);
+}
+
 }  // namespace myslam

@@ -203,6 +203,22 @@ int vo_match_fuse(const vo_frame_view *kf, int nq, const uint8_t *q_flags, const
                   const float *q_v, const float *q_ur, const int32_t *q_level, const uint8_t *q_desc,
                   float threshold, const float *scale_factors, int32_t *best_idx, int *n_matches);
 
+/* Bag-of-words transform: DBoW3::Vocabulary::transform(features, bowVec, featVec, levelsup) as called by
+ * Frame::computeBow (frame.cpp:248-253) and KeyFrame::computeBow (keyframe.cpp:394-398), levelsup = 3.
+ * The vocabulary tree (parsed on the host from the DBoW3 file) is uploaded once as flat arrays: the
+ * children of node i are children[child_start[i] .. child_start[i+1]), node 0 is the root,
+ * word_id[i] >= 0 marks a leaf (a word) with weight node_weight[i], node_desc holds one 32-byte ORB
+ * descriptor per node.  Per feature: the word, its weight, and the node reached at level
+ * depth_L - levelsup (the key of the FeatureVector that searchByBoW / searchForTriangulation walk).
+ * The (word -> summed weight) map, its L1 normalisation and the (node -> feature list) map stay in
+ * the shim: they are std::map insertions. */
+typedef struct vo_vocab vo_vocab;
+int vo_vocab_create(vo_vocab **out, int n_nodes, int depth_L, const int32_t *child_start, const int32_t *children,
+                    const uint8_t *node_desc, const double *node_weight, const int32_t *word_id);
+void vo_vocab_destroy(vo_vocab *v);
+int vo_bow_transform(const vo_vocab *v, int n, const uint8_t *desc, int levelsup, int32_t *word_id, double *weight,
+                     int32_t *node_id);
+
 /* Loop-closure searches.  All three project map points into a key-frame and take, per point, the
  * best Hamming match among KeyFrame::getFeaturesInArea(u, v, th * scale[level]) with octave in
  * [level - 1, level]; flag bit 0 of a query = it passed the projection gates of the routine.

@@ -595,3 +595,52 @@ int orc_match_sim3_mutual(const orc_frame *kf1, const orc_frame *kf2, const uint
   free(m2);
   return found;
 }
+
+/* ---- N2: DBoW3::Vocabulary::transform(features, BowVector&, FeatureVector&, levelsup) as called by
+ * Frame::computeBow / KeyFrame::computeBow (frame.cpp:248-253, keyframe.cpp:394-398; levelsup = 3).
+ * DBoW3 0.0.1 is an external, unpinned dependency: its published algorithm is restated -- from the root,
+ * at every level take the child with the smallest Hamming distance (first wins ties), remember the node
+ * reached at level L - levelsup, stop at a leaf; the leaf's word id and weight go to the BoW vector, the
+ * remembered node to the feature vector.  Tree as flat arrays: children of node i are
+ * children[child_start[i] .. child_start[i+1]); word_id[i] >= 0 marks a leaf; node 0 is the root. */
+void orc_bow_transform(int depth_L, const int32_t *child_start, const int32_t *children, const uint8_t *node_desc,
+                       const double *node_weight, const int32_t *word_id, int n, const uint8_t *desc, int levelsup,
+                       int32_t *out_word, double *out_weight, int32_t *out_node) {
+  const int nid_level = depth_L - levelsup;
+  for (int i = 0; i < n; i++) {
+    const uint8_t *f = desc + (size_t)i * 32;
+    int final_id = 0, level = 0, nid = 0; /* nid_level <= 0: the root */
+    while (word_id[final_id] < 0 && child_start[final_id + 1] > child_start[final_id]) {
+      level++;
+      const int c0 = child_start[final_id], c1 = child_start[final_id + 1];
+      int best = children[c0], bestd = orc_hamming256(f, node_desc + (size_t)best * 32);
+      for (int c = c0 + 1; c < c1; c++) {
+        const int id = children[c];
+        const int d = orc_hamming256(f, node_desc + (size_t)id * 32);
+        if (d < bestd) bestd = d, best = id;
+      }
+      final_id = best;
+      if (level == nid_level) nid = final_id;
+    }
+    out_word[i] = word_id[final_id];
+    out_weight[i] = node_weight[final_id];
+    out_node[i] = nid;
+  }
+}
+
+/* Map::score (map.cpp:335-376): L1 score of two BoW vectors given as ascending (word, value) lists */
+double orc_bow_score(int n1, const int32_t *w1, const double *v1, int n2, const int32_t *w2, const double *v2) {
+  double score = 0;
+  int i = 0, j = 0;
+  while (i < n1 && j < n2) {
+    if (w1[i] == w2[j]) {
+      score += fabs(v1[i] - v2[j]) - fabs(v1[i]) - fabs(v2[j]);
+      i++, j++;
+    } else if (w1[i] < w2[j]) {
+      i++;
+    } else {
+      j++;
+    }
+  }
+  return -score / 2.0;
+}

@@ -156,6 +156,12 @@ int orc_match_sim3_mutual(const orc_frame *kf1, const orc_frame *kf2, const uint
                           const float *q2_v, const int32_t *q2_level, const uint8_t *q2_desc, float th, const float *scale_factors1,
                           const float *scale_factors2, int32_t *match12);
 
+/* DBoW3::Vocabulary::transform as used by computeBow (frame.cpp:248-253, keyframe.cpp:394-398) */
+void orc_bow_transform(int depth_L, const int32_t *child_start, const int32_t *children, const uint8_t *node_desc,
+                       const double *node_weight, const int32_t *word_id, int n, const uint8_t *desc, int levelsup,
+                       int32_t *out_word, double *out_weight, int32_t *out_node);
+double orc_bow_score(int n1, const int32_t *w1, const double *v1, int n2, const int32_t *w2, const double *v2);
+
 /* ---------------- Optimizer (reference optimizer_ceres.{h,cpp}) --------------- */
 
 void orc_se3_exp(const double xi[6], double q[4] /*w,x,y,z*/, double t[3]); /* Sophus SE3::exp */

@@ -147,6 +147,9 @@ def lib():
                                       C.c_void_p, C.c_void_p]
     L.orc_pose_graph_solve.argtypes = [C.c_int, _f64p, _f64p, _f64p, C.c_int, C.c_int, _i32p, _i32p, _f64p, _f64p, _f64p,
                                        C.c_int, C.c_void_p]
+    L.orc_bow_transform.argtypes = [C.c_int, _i32p, _i32p, _u8p, _f64p, _i32p, C.c_int, _u8p, C.c_int, _i32p, _f64p, _i32p]
+    L.orc_bow_score.argtypes = [C.c_int, _i32p, _f64p, C.c_int, _i32p, _f64p]
+    L.orc_bow_score.restype = C.c_double
     L.orc_se3_exp.argtypes = [_f64p, _f64p, _f64p]
     L.orc_se3_log.argtypes = [_f64p, _f64p, _f64p]
     L.orc_se3_plus.argtypes = [_f64p, _f64p, _f64p]

@@ -217,3 +217,33 @@ def test_oracle_loop_closure_searches(orc):
     # the count is per accepted query: a feature can be claimed again (the :422 test does not protect it)
     assert nf >= (a_free >= 0).sum() > 200 and no <= nf
     assert not np.array_equal(a_free, a_occ)
+
+
+def test_oracle_bow_transform_and_score(orc):
+    """the descent picks the nearest child at every level (checked against a numpy walk) and the L1 score
+    of Map::score is 1 for identical normalised vectors, 0 for disjoint ones"""
+    from vo_slam_test_amd import synth
+    voc = synth.make_vocabulary(0, k=5, L=3)
+    rng = np.random.default_rng(0)
+    desc = rng.integers(0, 256, (200, 32), dtype=np.uint8)
+    n = len(desc)
+    w, wt, nd = np.zeros(n, np.int32), np.zeros(n, np.float64), np.zeros(n, np.int32)
+    orc.lib().orc_bow_transform(voc["L"], voc["child_start"], voc["children"], np.ascontiguousarray(voc["node_desc"]),
+                                voc["node_weight"], voc["word_id"], n, desc, 1, w, wt, nd)
+    bits = np.unpackbits(voc["node_desc"], axis=1).astype(np.int32)
+    for i in range(n):
+        node, level, rem = 0, 0, -1
+        fb = np.unpackbits(desc[i]).astype(np.int32)
+        while voc["word_id"][node] < 0:
+            ch = voc["children"][voc["child_start"][node]:voc["child_start"][node + 1]]
+            d = np.abs(bits[ch] - fb).sum(1)
+            node = int(ch[np.argmin(d)])          # argmin: first minimum
+            level += 1
+            if level == voc["L"] - 1:
+                rem = node
+        assert w[i] == voc["word_id"][node] and wt[i] == voc["node_weight"][node] and nd[i] == rem
+    a_w = np.array([1, 5, 9], np.int32)
+    a_v = np.array([0.2, 0.3, 0.5])
+    assert abs(orc.lib().orc_bow_score(3, a_w, a_v, 3, a_w, a_v) - 1.0) < 1e-15
+    b_w = np.array([2, 6, 10], np.int32)
+    assert orc.lib().orc_bow_score(3, a_w, a_v, 3, b_w, a_v) == 0.0

@@ -36,3 +36,21 @@ for i in range(50):
     vo.Optimizer.solvePoseOnlySE3([pr])
     ts.append(time.perf_counter() - t0)
 print(f"vo_pose_only_solve (1 frame x {len(pr['pts'])} obs, host in/out): median {np.median(ts) * 1e3:.3f} ms")
+# guided matchers (what tracking calls once or twice per frame)
+k0, d0 = ext(f0)
+k1, d1 = ext(f1)
+sf = np.array([1.2 ** i for i in range(8)], np.float32)
+rng = np.random.default_rng(0)
+z = rng.uniform(0.8, 4.5, len(k1)).astype(np.float32)
+ur1 = (k1["x"] - np.float32(40.0) / z).astype(np.float32)
+cur = vo.FrameArrays(k1["x"], k1["y"], k1["octave"], k1["angle"], ur1, d1)
+q = dict(flags=np.full(len(k0), 3, np.uint8), u=(k0["x"] + dx).astype(np.float32), v=(k0["y"] + dy).astype(np.float32),
+         invz=np.full(len(k0), 0.5, np.float32), octave=k0["octave"].astype(np.int32), angle=k0["angle"].astype(np.float32),
+         desc=np.ascontiguousarray(d0))
+m = vo.Matcher(0.8)
+ts = []
+for i in range(30):
+    t0 = time.perf_counter()
+    n, assigned = m.searchByProjection_frame(cur, q, 15.0, 40.0, 0, True, sf)
+    ts.append(time.perf_counter() - t0)
+print(f"vo_match_frame_projection ({len(k0)} map points -> {len(k1)} features, {n} matches): median {np.median(ts) * 1e3:.3f} ms")

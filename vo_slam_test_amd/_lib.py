@@ -43,7 +43,7 @@ SYMBOLS = [
     "vo_hamming_matrix_dev", "vo_hamming_matrix_batch_dev", "vo_hamming_matrix",
     "vo_match_frame_projection", "vo_match_local_map", "vo_match_frame_keyframe", "vo_match_bow",
     "vo_match_triangulation", "vo_match_fuse", "vo_match_area_best", "vo_match_sim3_projection",
-    "vo_match_sim3_mutual",
+    "vo_match_sim3_mutual", "vo_vocab_create", "vo_vocab_destroy", "vo_bow_transform",
     "vo_pose_only_solve", "vo_sim3_solve", "vo_pose_graph_solve", "vo_sim3_reanchor_points", "vo_chol_solve", "vo_pose_only_solve_dev",
     "vo_ba_create", "vo_ba_destroy", "vo_ba_set_stream", "vo_ba_set_shard", "vo_ba_set_state",
     "vo_ba_get_state", "vo_ba_n_free_cams", "vo_ba_local_ba", "vo_ba_local_ba_enqueue",
@@ -81,6 +81,8 @@ def lib():
     L.vo_orb_destroy.restype = None
     if hasattr(L, "vo_ba_destroy"):
         L.vo_ba_destroy.restype = None
+    if hasattr(L, "vo_vocab_destroy"):
+        L.vo_vocab_destroy.restype = None
     _lib = L
     return L
 
@@ -255,6 +257,32 @@ class BowNodes:
         v.n_nodes = len(self.node_id)
         v.node_id, v.start, v.feat = self.node_id.ctypes.data, self.start.ctypes.data, self.feat.ctypes.data
         self.view = v
+
+
+class Vocabulary:
+    """Device copy of a DBoW3 vocabulary tree; transform() = DBoW3::Vocabulary::transform's per-feature part."""
+
+    def __init__(self, depth_L, child_start, children, node_desc, node_weight, word_id):
+        self._h = C.c_void_p()
+        cs, ch = np.ascontiguousarray(child_start, np.int32), np.ascontiguousarray(children, np.int32)
+        nd, nw = np.ascontiguousarray(node_desc, np.uint8), np.ascontiguousarray(node_weight, np.float64)
+        wi = np.ascontiguousarray(word_id, np.int32)
+        check(lib().vo_vocab_create(C.byref(self._h), len(wi), int(depth_L), _p(cs), _p(ch), _p(nd), _p(nw), _p(wi)),
+              "vo_vocab_create")
+
+    def close(self):
+        if getattr(self, "_h", None) and self._h.value and _lib is not None:
+            _lib.vo_vocab_destroy(self._h)
+            self._h = C.c_void_p()
+
+    __del__ = close
+
+    def transform(self, desc, levelsup=3):
+        desc = np.ascontiguousarray(desc, np.uint8)
+        n = len(desc)
+        word, weight, node = np.zeros(n, np.int32), np.zeros(n, np.float64), np.zeros(n, np.int32)
+        check(lib().vo_bow_transform(self._h, n, _p(desc), int(levelsup), _p(word), _p(weight), _p(node)), "vo_bow_transform")
+        return word, weight, node
 
 
 class Matcher:

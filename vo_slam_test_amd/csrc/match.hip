@@ -608,4 +608,115 @@ int vo_match_sim3_mutual(const vo_frame_view *kf1, const vo_frame_view *kf2, con
   return VO_OK;
 }
 
+
+// ---- BoW transform (DBoW3::Vocabulary::transform as called by computeBow, frame.cpp:248-253,
+// keyframe.cpp:394-398).  The vocabulary tree lives in HBM as flat arrays; one lane per feature
+// walks it: at every level the child with the smallest Hamming distance (first wins ties).
+}  // extern "C" (kernels below)
+
+namespace {
+
+struct VocabDev {
+  int n_nodes, depth;
+  const int *child_start, *children, *word_id;
+  const uint32_t *desc;  // 8 dwords per node
+  const double *weight;
+};
+
+__global__ __launch_bounds__(256) void k_bow_transform(VocabDev V, int n, const uint32_t *feat, int levelsup, int *out_word,
+                                                       double *out_weight, int *out_node) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  uint32_t f[8];
+#pragma unroll
+  for (int k = 0; k < 8; k++) f[k] = feat[8LL * i + k];
+  const int nid_level = V.depth - levelsup;
+  int id = 0, level = 0, nid = 0;
+  while (V.word_id[id] < 0 && V.child_start[id + 1] > V.child_start[id]) {
+    level++;
+    const int c0 = V.child_start[id], c1 = V.child_start[id + 1];
+    int best = -1, bestd = 1 << 30;
+    for (int c = c0; c < c1; c++) {
+      const int ch = V.children[c];
+      const uint32_t *d = V.desc + 8LL * ch;
+      int dist = 0;
+#pragma unroll
+      for (int k = 0; k < 8; k++) dist += __popc(f[k] ^ d[k]);
+      if (dist < bestd) bestd = dist, best = ch;  // strict: the first minimum wins
+    }
+    id = best;
+    if (level == nid_level) nid = id;
+  }
+  out_word[i] = V.word_id[id];
+  out_weight[i] = V.weight[id];
+  out_node[i] = nid;
+}
+
+}  // namespace
+
+struct vo_vocab {
+  VocabDev V{};
+  vo::DevBuf b_cs, b_ch, b_wid, b_desc, b_w;
+};
+
+extern "C" {
+
+int vo_vocab_create(vo_vocab **out, int n_nodes, int depth_L, const int32_t *child_start, const int32_t *children,
+                    const uint8_t *node_desc, const double *node_weight, const int32_t *word_id) {
+  if (!out || n_nodes < 1 || depth_L < 0 || !child_start || !node_desc || !node_weight || !word_id) return VO_ERR_INVALID;
+  const int n_children = child_start[n_nodes];
+  if (n_children < 0 || (n_children > 0 && !children)) return VO_ERR_INVALID;
+  for (int i = 0; i < n_nodes; i++)
+    if (child_start[i] > child_start[i + 1]) return VO_ERR_INVALID;
+  for (int c = 0; c < n_children; c++)
+    if (children[c] <= 0 || children[c] >= n_nodes) {  // a child is never the root: guarantees termination
+      vo::set_error("vo_vocab_create: child %d out of range", children[c]);
+      return VO_ERR_INVALID;
+    }
+  VO_CHECK(vo::ensure_device());
+  vo_vocab *v = new vo_vocab();
+  auto up = [](vo::DevBuf &b, const void *src, size_t bytes) -> int {
+    VO_CHECK(b.reserve(std::max<size_t>(bytes, 64)));
+    if (bytes) VO_HIP_CHECK(hipMemcpy(b.p, src, bytes, hipMemcpyHostToDevice));
+    return VO_OK;
+  };
+  int rc;
+  if ((rc = up(v->b_cs, child_start, (size_t)(n_nodes + 1) * 4)) != VO_OK || (rc = up(v->b_ch, children, (size_t)n_children * 4)) != VO_OK ||
+      (rc = up(v->b_wid, word_id, (size_t)n_nodes * 4)) != VO_OK || (rc = up(v->b_desc, node_desc, (size_t)n_nodes * 32)) != VO_OK ||
+      (rc = up(v->b_w, node_weight, (size_t)n_nodes * 8)) != VO_OK) {
+    for (vo::DevBuf *b : {&v->b_cs, &v->b_ch, &v->b_wid, &v->b_desc, &v->b_w}) b->release();
+    delete v;
+    return rc;
+  }
+  v->V.n_nodes = n_nodes, v->V.depth = depth_L;
+  v->V.child_start = v->b_cs.as<int>(), v->V.children = v->b_ch.as<int>(), v->V.word_id = v->b_wid.as<int>();
+  v->V.desc = v->b_desc.as<uint32_t>(), v->V.weight = v->b_w.as<double>();
+  *out = v;
+  return VO_OK;
+}
+
+void vo_vocab_destroy(vo_vocab *v) {
+  if (!v) return;
+  for (vo::DevBuf *b : {&v->b_cs, &v->b_ch, &v->b_wid, &v->b_desc, &v->b_w}) b->release();
+  delete v;
+}
+
+int vo_bow_transform(const vo_vocab *v, int n, const uint8_t *desc, int levelsup, int32_t *word_id, double *weight,
+                     int32_t *node_id) {
+  if (!v || n < 0 || (n > 0 && (!desc || !word_id || !weight || !node_id))) return VO_ERR_INVALID;
+  if (n == 0) return VO_OK;
+  thread_local vo::DevBuf d_f, d_w, d_wt, d_n;
+  VO_CHECK(d_f.reserve((size_t)n * 32));
+  VO_CHECK(d_w.reserve((size_t)n * 4));
+  VO_CHECK(d_wt.reserve((size_t)n * 8));
+  VO_CHECK(d_n.reserve((size_t)n * 4));
+  VO_HIP_CHECK(hipMemcpy(d_f.p, desc, (size_t)n * 32, hipMemcpyHostToDevice));
+  hipLaunchKernelGGL(k_bow_transform, dim3((n + 255) / 256), dim3(256), 0, nullptr, v->V, n, d_f.as<uint32_t>(), levelsup,
+                     d_w.as<int>(), d_wt.as<double>(), d_n.as<int>());
+  VO_HIP_CHECK(hipMemcpy(word_id, d_w.p, (size_t)n * 4, hipMemcpyDeviceToHost));
+  VO_HIP_CHECK(hipMemcpy(weight, d_wt.p, (size_t)n * 8, hipMemcpyDeviceToHost));
+  VO_HIP_CHECK(hipMemcpy(node_id, d_n.p, (size_t)n * 4, hipMemcpyDeviceToHost));
+  return VO_OK;
+}
+
 }  // extern "C"

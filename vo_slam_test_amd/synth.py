@@ -332,3 +332,41 @@ def make_global_ba_problem(seed: int = 0, n_kf: int = 500, n_pts: int = 50000, r
                 e_cam=np.ascontiguousarray(e_cam, np.int32), e_pt=np.ascontiguousarray(e_pt, np.int32),
                 e_obs=np.ascontiguousarray(e_obs), e_inv_sigma=np.ascontiguousarray(1.0 / sg),
                 cam=np.array(CAM, np.float64), poses_true=poses_true, points_true=P)
+
+
+# --------------------------------------------------------------------------- vocabulary tree (BoW)
+def make_vocabulary(seed: int = 0, k: int = 10, L: int = 4, flip: int = 24):
+    """A k-ary tree of depth L over 256-bit descriptors: every child is its parent with `flip` random
+    bits toggled (so the descent is meaningful), leaves are words with idf-like weights.  Flat arrays in
+    the layout vo_vocab_create takes (node 0 = root, breadth-first)."""
+    rng = _rng(0xB0C0000 + seed)
+    desc = [rng.integers(0, 256, 32, dtype=np.uint8)]
+    child_start, children, level_of = [0], [], [0]
+    frontier = [0]
+    for lvl in range(1, L + 1):
+        nxt = []
+        for node in frontier:
+            first = len(desc)
+            for _ in range(k):
+                bits = np.unpackbits(desc[node])
+                idx = rng.choice(256, flip, replace=False)
+                bits[idx] ^= 1
+                desc.append(np.packbits(bits))
+                level_of.append(lvl)
+                nxt.append(len(desc) - 1)
+            children.extend(range(first, first + k))
+        frontier = nxt
+    n = len(desc)
+    # child_start in node order (breadth-first numbering makes the child lists consecutive)
+    cs = np.zeros(n + 1, np.int32)
+    inner = [i for i in range(n) if level_of[i] < L]
+    for i in inner:
+        cs[i + 1] = k
+    cs = np.cumsum(cs).astype(np.int32)
+    word_id = np.full(n, -1, np.int32)
+    leaves = [i for i in range(n) if level_of[i] == L]
+    word_id[leaves] = np.arange(len(leaves), dtype=np.int32)
+    weight = np.zeros(n)
+    weight[leaves] = rng.uniform(0.5, 8.0, len(leaves))
+    return dict(k=k, L=L, child_start=cs, children=np.array(children, np.int32), node_desc=np.ascontiguousarray(desc),
+                node_weight=weight, word_id=word_id)
