@@ -199,6 +199,7 @@ __device__ __forceinline__ double lane_bcast(double v, int src_lane) {
 }
 
 __global__ __launch_bounds__(64) void k_chol_diag(double *A, int ld, int K0, int *fail) {
+  __shared__ __attribute__((aligned(16))) double col[NB];  // column j of the factor, broadcast to every lane
   const int i = threadIdx.x;
   double row[NB];
   const double *src = A + (long long)(K0 + i) * ld + K0;
@@ -212,11 +213,11 @@ __global__ __launch_bounds__(64) void k_chol_diag(double *A, int ld, int K0, int
     const double sd = sqrt(d);
     const double a = i == j ? sd : row[j] / sd;  // L[i][j] (meaningful for i >= j)
     row[j] = a;
+    // one LDS write, then (63 - j) / 2 broadcast ds_read_b128: half the instructions of a readlane pair per
+    // element.  A single wavefront issues its LDS operations in order, so no barrier is needed.
+    col[i] = a;
 #pragma unroll
-    for (int c = j + 1; c < NB; c++) {
-      const double lcj = lane_bcast(a, c);  // L[c][j]
-      row[c] -= a * lcj;                    // rows i < c carry garbage in column c; never stored
-    }
+    for (int c = j + 1; c < NB; c++) row[c] -= a * col[c];  // rows i < c carry garbage in column c; never stored
   }
   if (bad) {
     if (i == 0) *fail = 1;
@@ -230,7 +231,7 @@ __global__ __launch_bounds__(64) void k_chol_diag(double *A, int ld, int K0, int
 
 // rows below the diagonal block (including the right-hand-side row): X L11^T = A21, one thread per row
 __global__ __launch_bounds__(256) void k_chol_trsm(double *A, int ld, int K0, const int *fail) {
-  __shared__ double L[NB][NB + 1];
+  __shared__ __attribute__((aligned(16))) double L[NB][NB + 2];  // even pitch: the unrolled broadcast reads pair into ds_read_b128
   if (*fail) return;
   const int tid = threadIdx.x;
   for (int i = tid; i < NB * NB; i += 256) L[i / NB][i % NB] = A[(long long)(K0 + i / NB) * ld + K0 + i % NB];
