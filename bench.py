@@ -233,6 +233,33 @@ def main():
                            "lm_iters_per_s": round(iters / tb, 1), "ms_per_solve": round(tb / reps * 1e3, 3),
                            "iterations_per_solve": iters / reps, "dtype": "f64",
                            "sharding": f"points % {world}, 2 all-reduces per LM iteration" if world > 1 else "single GPU"}
+        if world > 1:
+            # replicas: every GPU works on its own set of independent 10-KF problems (several local-mapping
+            # sessions / map regions); no exchange.  Aggregate LM-iterations/s over the node.
+            nconc = 8
+            handles = [vo.BundleAdjuster(lb) for _ in range(nconc)]
+            for hd in handles:
+                hd.local_ba()
+            r_iters, r_t = 0, 0.0
+            for _ in range(5):
+                for hd in handles:
+                    hd.set_state(lb["poses"], lb["points"])
+                barrier()
+                tr0 = time.perf_counter()
+                for hd in handles:
+                    hd.local_ba_enqueue()
+                res = [hd.local_ba_finish() for hd in handles]
+                barrier()
+                r_t += time.perf_counter() - tr0
+                r_iters += sum(sr[0].iterations + sr[1].iterations for _, sr in res)
+            for hd in handles:
+                hd.close()
+            tot = torch.tensor([r_iters], dtype=torch.float64, device="cuda")
+            tmax = torch.tensor([r_t], dtype=torch.float64, device="cuda")
+            dist.all_reduce(tot, op=dist.ReduceOp.SUM)
+            dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+            out["local_ba"]["replicas"] = {"problems_per_gpu": nconc, "aggregate_lm_iters_per_s": round(float(tot.item()) / float(tmax.item()), 1),
+                                           "sharding": "independent problems per GPU, no collective"}
         if world == 1:
             # aggregate throughput: independent problems (one handle + stream each) overlapped on the GPU
             nconc = 8
