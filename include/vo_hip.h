@@ -386,6 +386,10 @@ int vo_ba_get_edge_outliers(vo_ba *h, uint8_t *edge_erase);
 int vo_ba_debug_schur(vo_ba *h, double huber_mono, double huber_stereo, double point_damping,
                       const uint8_t *edge_active, double *S, double *b, double *cost);
 
+/* Developer instrumentation: s_memrealtime stamps (100 MHz ticks) written by the BA kernels of a
+ * -DVO_BA_STAMPS build (tools/ba_stamps.py); all zero in the product build.  out[48]. */
+int vo_ba_debug_stamps(vo_ba *h, unsigned long long *out);
+
 /* SE3 helpers the shims need (Sophus SE3::exp / log as used at :163,:257,:474,:787) */
 int vo_se3_exp(const double xi[6], double R_rowmajor[9], double t[3]);
 int vo_se3_log(const double R_rowmajor[9], const double t[3], double xi[6]);

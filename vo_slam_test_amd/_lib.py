@@ -50,7 +50,7 @@ SYMBOLS = [
     "vo_ba_local_ba_finish", "vo_ba_solve", "vo_ba_lm_begin",
     "vo_ba_linearize", "vo_ba_step", "vo_ba_update", "vo_ba_lm_end", "vo_ba_reduced_system",
     "vo_ba_reduced_cost", "vo_ba_set_reduce_buffers", "vo_ba_classify",
-    "vo_ba_lm_begin_inliers", "vo_ba_get_edge_outliers", "vo_ba_debug_schur", "vo_se3_exp", "vo_se3_log",
+    "vo_ba_lm_begin_inliers", "vo_ba_get_edge_outliers", "vo_ba_debug_schur", "vo_ba_debug_stamps", "vo_se3_exp", "vo_se3_log",
 ]
 
 
