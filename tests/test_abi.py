@@ -28,6 +28,7 @@ def test_library_exports_every_declared_symbol(vo):
     out = subprocess.run(["nm", "-D", "--defined-only", str(vo.SO)], capture_output=True, text=True).stdout
     exported = set(re.findall(r" T (vo_[a-z0-9_]+)", out))
     assert set(_header_symbols()) <= exported
+    assert exported <= set(_header_symbols()), f"exported but not declared in include/vo_hip.h: {sorted(exported - set(_header_symbols()))}"
     assert lib.vo_version().decode().startswith("vo_slam_test_amd")
 
 
