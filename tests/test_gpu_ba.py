@@ -406,3 +406,21 @@ def test_ba_all_cameras_fixed_is_refused_or_trivial(vo):
         pass
     finally:
         ba.close()
+
+
+@pytest.mark.parametrize("n_kf,n_pts,n_fixed,seed", [(2, 60, 0, 20), (3, 40, 2, 21), (8, 700, 0, 22), (21, 300, 1, 23),
+                                                     (22, 300, 1, 24), (23, 250, 0, 25)])
+def test_local_ba_size_sweep(vo, orc, n_kf, n_pts, n_fixed, seed):
+    """both sides of the LDS-path limit (21 free key-frames = 20/21/22 key-frames with id 0 fixed), tiny
+    problems, no fixed observers"""
+    from vo_slam_test_amd import synth
+    pr = synth.make_lba_problem(seed, n_kf=n_kf, n_pts=n_pts, n_fixed=n_fixed)
+    ba = vo.BundleAdjuster(pr)
+    erase, sums, rc = ba.local_ba()
+    poses, pts = ba.state()
+    ba.close()
+    oposes, opts, oerase, osums, orc_rc = orc.local_ba(pr)
+    assert rc == 0 == orc_rc
+    assert [sums[0].iterations, sums[1].iterations] == [osums[0].iterations, osums[1].iterations]
+    assert np.array_equal(erase, oerase)
+    assert np.abs(poses - oposes).max() < 1e-7 and np.abs(pts - opts).max() < 1e-6

@@ -136,3 +136,18 @@ def test_batch_device_unaligned_rows(ext, orc):
         assert n == len(okp)
         assert np.array_equal(np.frombuffer(kps[f, :n].cpu().numpy().tobytes(), dtype=_lib.KP_DTYPE), okp)
         assert np.array_equal(desc[f, :n].cpu().numpy(), odesc)
+
+
+@pytest.mark.parametrize("w,h,nf,sf,nl", [(1280, 720, 2000, 1.2, 8), (640, 480, 1000, 1.1, 8), (640, 480, 800, 1.5, 5),
+                                         (500, 375, 600, 1.33, 6), (640, 480, 700, 2.0, 4), (203, 151, 150, 1.25, 3)])
+def test_scale_factors_and_large_images(vo, orc, w, h, nf, sf, nl):
+    """other pyramid scale factors (the tiled resize covers ratios below 2, the generic kernel the rest),
+    a 720p frame, and odd small sizes"""
+    img = synth.make_frame(21, w=w, h=h, n_rect=max(150, w * h // 600), n_blob=80)
+    e = vo.OrbExtractor(nf, sf, nl, 20, 7)
+    p = orc.orb_params(nf, sf, nl, 20, 7)
+    okp, odesc, _ = orc.extract(p, img, cap=nf + 256)
+    kps, desc = e(img)
+    e.close()
+    assert len(kps) == len(okp) > 0, (w, h, sf)
+    assert np.array_equal(kps, okp) and np.array_equal(desc, odesc), (w, h, sf)
