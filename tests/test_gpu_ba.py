@@ -160,12 +160,14 @@ def test_ba_degenerate_inputs(vo):
     assert np.array_equal(pts, pr["points"])
 
 
-def test_two_shard_emulation_matches_single(vo, orc):
+@pytest.mark.parametrize("n_kf,n_pts", [(6, 600), (30, 2400)], ids=["lds", "large"])
+def test_two_shard_emulation_matches_single(vo, orc, n_kf, n_pts):
     """Multi-GPU path on one GPU: two shard handles (points % 2), their all-reduce payloads summed by
     hand each LM iteration.  Must reproduce the unsharded solve (same math, different summation order)
-    and leave both shards with identical poses."""
+    and leave both shards with identical poses.  Both reduced-system paths: the LDS one and the
+    large-system one (6 nf + 1 > 128), whose payload is the Cholesky storage itself."""
     import torch
-    pr = synth.make_lba_problem(9, n_kf=6, n_pts=600, n_fixed=2)
+    pr = synth.make_lba_problem(9, n_kf=n_kf, n_pts=n_pts, n_fixed=2)
     ref = vo.BundleAdjuster(pr)
     rs = ref.solve(HM, HS, 5)
     rposes, rpts = ref.state()

@@ -709,7 +709,7 @@ struct BaDev {
   int large, ld;
   double *We[2];            // [n_edges][3][6]  W_cj[a][k] * sp[k] at [k][a]
   double *glsc[2];          // [n_pts][3] scaled point gradient
-  double *Sd, *rhs;         // reduced system (lower triangle used) and right-hand side / solution
+  double *Sd;               // Cholesky storage: reduced system, rhs row, solution row, extras (large_ext_off)
   double *sc_v, *Dd_v, *gpp_v;  // per reduced column: Jacobi scale, LM diagonal, scaled gradient
   int *chol_fail;
   const int *pair_start;    // [n_pairs + 1] into pair_e
@@ -717,6 +717,11 @@ struct BaDev {
   const int *pair_e;        // [..][2] edge of c, edge of c' at a shared point, in point order
   int n_pairs;
 };
+
+// large path: what rides along with the reduced system in the same buffer (so that one all-reduce carries
+// everything): row ld = right-hand side, row ld + 1 = solution, from row ld + 2 on: camera blocks
+// [nf][27], cost, one gradient-max slot per shard
+__device__ __host__ __forceinline__ long long large_ext_off(int ld) { return (long long)(ld + 2) * ld; }
 
 // address of the W block row k of edge e (point j, camera slot): dense operand matrix or per-edge store
 __device__ __forceinline__ double *w_row(const BaDev &B, int buf, int e, int j, int slot, int k) {
@@ -1629,30 +1634,50 @@ __global__ __launch_bounds__(256) void k_ba_pairs(BaDev B) {
     double r1 = 0;
 #pragma unroll
     for (int i = 0; i < 6; i++) r1 = (lane == i) ? rh[i] : r1;
-    if (lane < 6) B.rhs[6 * c + lane] = -r1;  // -(sum_e Y_e gl''_j); completed by k_ba_assemble_large
+    if (lane < 6) B.Sd[(long long)B.ld * B.ld + 6 * c + lane] = -r1;  // row ld: -(sum_e Y_e gl''_j); completed by k_ba_assemble_large
   }
 }
 
-// one workgroup: camera-block sums, Jacobi scale, LM diagonal, cost / gradient-max bookkeeping
-__global__ __launch_bounds__(256) void k_ba_prestep_large(BaDev B, double *hp /*[nf][27]*/) {
+// one workgroup: this shard's camera-block sums, cost and gradient max into the extras of the reduced-system
+// buffer (summed over the shards by the all-reduce when the problem is sharded)
+__global__ __launch_bounds__(256) void k_ba_partials_large(BaDev B) {
   __shared__ double red[8];
-  __shared__ int s_stop;
-  BaState *S = B.st;
-  const BaState st0 = *S;
+  const BaState st0 = *B.st;
   if (st0.done) return;
-  const int tid = threadIdx.x, n = 6 * B.nf;
-  if (tid == 0) *B.chol_fail = 0, s_stop = 0;
+  const int tid = threadIdx.x;
+  double *ext = B.Sd + large_ext_off(B.ld);
   for (int i = tid; i < B.nf * 27; i += 256) {
     const int slot = i / 27, t = i - slot * 27;
     const double *sp = B.slab_cam + (long long)slot * B.n_cchunks * 27 + t;
     double a = 0;
     for (int cchunk = 0; cchunk < B.n_cchunks; cchunk++) a += sp[cchunk * 27];  // chunk order
-    hp[i] = a;
+    ext[i] = a;
   }
   double cs = 0, m = 0;
   const double *spt = B.slab_pt[st0.cur];
   for (int b = tid; b < B.n_pblocks; b += 256) cs += spt[2 * b], m = fmax(m, spt[2 * b + 1]);
+  double v2[2] = {cs, 0};
+  block_sum<2>(v2, red);
+  m = wave_max(m);
   __syncthreads();
+  if ((tid & 63) == 0) red[tid >> 6] = m;
+  __syncthreads();
+  if (tid == 0) {
+    ext[B.nf * 27] = v2[0];
+    const double gm = fmax(fmax(red[0], red[1]), fmax(red[2], red[3]));
+    for (int k = 0; k < B.n_shards; k++) ext[B.nf * 27 + 1 + k] = (k == B.shard) ? gm : 0.0;
+  }
+}
+
+// one workgroup: Jacobi scale, LM diagonal, cost / gradient-max bookkeeping from the (all-reduced) extras
+__global__ __launch_bounds__(256) void k_ba_prestep_large(BaDev B) {
+  __shared__ double red[4];
+  BaState *S = B.st;
+  const BaState st0 = *S;
+  if (st0.done) return;
+  const int tid = threadIdx.x, n = 6 * B.nf;
+  const double *hp = B.Sd + large_ext_off(B.ld);
+  if (tid == 0) *B.chol_fail = 0;
   double gm = 0;
   for (int i = tid; i < n; i += 256) {
     const int slot = i / 6, a = i - slot * 6;
@@ -1672,17 +1697,16 @@ __global__ __launch_bounds__(256) void k_ba_prestep_large(BaDev B, double *hp /*
     gm = fmax(gm, fabs(gp));
     B.gpp_v[i] = sc * gp;
   }
-  double v2[2] = {cs, 0};
-  block_sum<2>(v2, red);
-  m = fmax(wave_max(m), wave_max(gm));
-  __syncthreads();
-  if ((tid & 63) == 0) red[tid >> 6] = m;
+  gm = wave_max(gm);
+  if ((tid & 63) == 0) red[tid >> 6] = gm;
   __syncthreads();
   if (tid == 0) {
-    const double gmax = fmax(fmax(red[0], red[1]), fmax(red[2], red[3]));
+    double gmax = fmax(fmax(red[0], red[1]), fmax(red[2], red[3]));
+    for (int k = 0; k < B.n_shards; k++) gmax = fmax(gmax, hp[B.nf * 27 + 1 + k]);
+    const double cost = hp[B.nf * 27];
     S->gmax = gmax;
-    S->x_cost = v2[0];
-    if (st0.first) S->initial_cost = v2[0];
+    S->x_cost = cost;
+    if (st0.first) S->initial_cost = cost;
     if (st0.last_ok && gmax <= 1e-10) {
       S->termination = 3;
       S->done = 1;
@@ -1694,8 +1718,9 @@ __global__ __launch_bounds__(256) void k_ba_prestep_large(BaDev B, double *hp /*
 }
 
 // A = sc_r (Hpp - G) sc_c + D on the lower triangle (identity on the padding), rhs'' = g'' - sc (Y gl'')
-__global__ __launch_bounds__(256) void k_ba_assemble_large(BaDev B, const double *hp) {
+__global__ __launch_bounds__(256) void k_ba_assemble_large(BaDev B) {
   if (B.st->done) return;
+  const double *hp = B.Sd + large_ext_off(B.ld);
   const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
   const int r = (int)(idx / B.ld), c = (int)(idx - (long long)r * B.ld);
   const int n = 6 * B.nf;
@@ -1715,7 +1740,10 @@ __global__ __launch_bounds__(256) void k_ba_assemble_large(BaDev B, const double
     v = r == c ? 1.0 : 0.0;
   }
   B.Sd[idx] = v;
-  if (c == 0) B.Sd[(long long)B.ld * B.ld + r] = r < n ? B.gpp_v[r] + B.sc_v[r] * B.rhs[r] : 0.0;  // right-hand side: row ld
+  if (c == 0) {  // right-hand side, row ld: in place on this shard-summed -(Y gl'')
+    double *rh = B.Sd + (long long)B.ld * B.ld + r;
+    *rh = r < n ? B.gpp_v[r] + B.sc_v[r] * *rh : 0.0;
+  }
 }
 
 // one workgroup: step, candidate poses and the camera part of the trust-region quantities
@@ -2115,8 +2143,7 @@ struct vo_ba {
       b_camedges, b_ptin, b_camin, b_xc0, b_xc1, b_xp0, b_xp1, b_pc0, b_pc1, b_sc, b_sp, b_hinv, b_gl2, b_dl, b_wt, b_wt1, b_hll0, b_hll1, b_spt1,
       b_sgemm, b_scam, b_spt, b_payload, b_zc, b_sbs, b_payload2, b_state, b_out, b_dbg, b_cnt;
   size_t solve_lds = 0, gemm_lds = 0;
-  vo::DevBuf b_we0, b_we1, b_glsc0, b_glsc1, b_Sd, b_rhs, b_scv, b_ddv, b_gppv, b_cholfail, b_pairstart, b_paircc, b_paire,
-      b_hp;  // large reduced systems
+  vo::DevBuf b_we0, b_we1, b_glsc0, b_glsc1, b_Sd, b_scv, b_ddv, b_gppv, b_cholfail, b_pairstart, b_paircc, b_paire;  // large reduced systems
   int lm_max_it = 0;
   double *ext_payload = nullptr, *ext_payload2 = nullptr;
   int archive_slot = -1;
@@ -2140,8 +2167,8 @@ int build_device(vo_ba *h) {
   D.K = Cam{h->cam[0], h->cam[1], h->cam[2], h->cam[3], h->cam[4]};
   D.large = 6 * h->nf + 1 > kMaxN ? 1 : 0;
   D.ld = (6 * h->nf + vo::kCholPanel - 1) / vo::kCholPanel * vo::kCholPanel;
-  if (D.large && (h->n_shards > 1 || D.ld > 4096)) {
-    vo::set_error("BA with %d free key-frames: the large-system path handles one shard and 6 nf <= 4096", h->nf);
+  if (D.large && D.ld > 4096) {
+    vo::set_error("BA with %d free key-frames: the large-system path handles 6 nf <= 4096", h->nf);
     return VO_ERR_CAPACITY;
   }
   D.Mpad = D.large ? 16 : std::max(16, (6 * h->nf + 1 + 15) / 16 * 16);  // large: no dense operand matrix
@@ -2260,15 +2287,13 @@ int build_device(vo_ba *h) {
     VO_CHECK(h->b_glsc0.reserve((size_t)std::max(1, h->n_pts) * 3 * 8));
     VO_CHECK(h->b_glsc1.reserve((size_t)std::max(1, h->n_pts) * 3 * 8));
     VO_CHECK(h->b_Sd.reserve((size_t)(D.ld + vo::kCholPanel) * D.ld * 8));  // + right-hand side / solution rows
-    VO_CHECK(h->b_rhs.reserve((size_t)D.ld * 8));
     VO_CHECK(h->b_scv.reserve((size_t)D.ld * 8));
     VO_CHECK(h->b_ddv.reserve((size_t)D.ld * 8));
     VO_CHECK(h->b_gppv.reserve((size_t)D.ld * 8));
     VO_CHECK(h->b_cholfail.reserve(64));
-    VO_CHECK(h->b_hp.reserve((size_t)h->nf * 27 * 8));
     D.We[0] = h->b_we0.as<double>(), D.We[1] = h->b_we1.as<double>();
     D.glsc[0] = h->b_glsc0.as<double>(), D.glsc[1] = h->b_glsc1.as<double>();
-    D.Sd = h->b_Sd.as<double>(), D.rhs = h->b_rhs.as<double>();
+    D.Sd = h->ext_payload ? h->ext_payload : h->b_Sd.as<double>();
     D.sc_v = h->b_scv.as<double>(), D.Dd_v = h->b_ddv.as<double>(), D.gpp_v = h->b_gppv.as<double>();
     D.chol_fail = h->b_cholfail.as<int>();
     D.pair_start = h->b_pairstart.as<int>(), D.pair_cc = h->b_paircc.as<int>(), D.pair_e = h->b_paire.as<int>();
@@ -2352,18 +2377,25 @@ int lm_begin(vo_ba *h, double hm, double hs, int max_it, const uint8_t *active_c
   return VO_OK;
 }
 
-// one LM iteration of the large-system path up to the candidate poses (k_ba_backsub follows)
-int launch_large(vo_ba *h) {
+// large-system path, first half of an LM iteration: this shard's part of the reduced system (and of the
+// camera blocks / cost) into the buffer a multi-GPU driver all-reduces
+int launch_linearize_large(vo_ba *h) {
   BaDev &D = h->D;
   hipStream_t st = h->stream;
-  double *hp = h->b_hp.as<double>();
   hipLaunchKernelGGL(k_ba_hinv_large, dim3((D.n_local + 255) / 256), dim3(256), 0, st, D);
   hipLaunchKernelGGL(k_ba_cams_large, dim3(std::max(1, h->nf * D.n_cchunks)), dim3(256), 0, st, D);
   VO_HIP_CHECK(hipMemsetAsync(D.Sd, 0, (size_t)(D.ld + vo::kCholPanel) * D.ld * 8, st));
-  VO_HIP_CHECK(hipMemsetAsync(D.rhs, 0, (size_t)D.ld * 8, st));
   if (D.n_pairs > 0) hipLaunchKernelGGL(k_ba_pairs, dim3((D.n_pairs + 3) / 4), dim3(256), 0, st, D);
-  hipLaunchKernelGGL(k_ba_prestep_large, dim3(1), dim3(256), 0, st, D, hp);
-  hipLaunchKernelGGL(k_ba_assemble_large, dim3((unsigned)(((long long)D.ld * D.ld + 255) / 256)), dim3(256), 0, st, D, hp);
+  hipLaunchKernelGGL(k_ba_partials_large, dim3(1), dim3(256), 0, st, D);
+  VO_HIP_CHECK(hipGetLastError());
+  return VO_OK;
+}
+// second half: damped system, factorisation, step, candidate poses (k_ba_backsub follows)
+int launch_step_large(vo_ba *h) {
+  BaDev &D = h->D;
+  hipStream_t st = h->stream;
+  hipLaunchKernelGGL(k_ba_prestep_large, dim3(1), dim3(256), 0, st, D);
+  hipLaunchKernelGGL(k_ba_assemble_large, dim3((unsigned)(((long long)D.ld * D.ld + 255) / 256)), dim3(256), 0, st, D);
   vo::chol_factor_solve(D.Sd, D.ld, D.chol_fail, st);
   hipLaunchKernelGGL(k_ba_poststep_large, dim3(1), dim3(256), 0, st, D);
   VO_HIP_CHECK(hipGetLastError());
@@ -2373,7 +2405,7 @@ int launch_large(vo_ba *h) {
 int launch_linearize(vo_ba *h) {
   BaDev &D = h->D;
   hipStream_t st = h->stream;
-  if (D.large) return launch_large(h);
+  if (D.large) return launch_linearize_large(h);
   const int tdim = D.Mpad / 16, tiles = tdim * (tdim + 1) / 2;
   // Schur product tiles and the camera blocks in one launch (independent roles)
   hipLaunchKernelGGL(k_ba_gemm, dim3(tiles * D.ksplit + h->nf * D.n_cchunks), dim3(256), h->gemm_lds, st, D);
@@ -2387,7 +2419,10 @@ int launch_linearize(vo_ba *h) {
 int launch_step(vo_ba *h) {
   BaDev &D = h->D;
   hipStream_t st = h->stream;
-  if (!D.large) hipLaunchKernelGGL(k_ba_solve, dim3(1), dim3(256), h->solve_lds, st, D);
+  if (D.large)
+    VO_CHECK(launch_step_large(h));
+  else
+    hipLaunchKernelGGL(k_ba_solve, dim3(1), dim3(256), h->solve_lds, st, D);
   hipLaunchKernelGGL(k_ba_backsub, dim3(D.n_pblocks), dim3(256), 0, st, D);
   if (h->n_shards > 1) hipLaunchKernelGGL(k_ba_reduce2, dim3(1), dim3(64), 0, st, D);
   VO_HIP_CHECK(hipGetLastError());
@@ -2652,8 +2687,8 @@ void vo_ba_destroy(vo_ba *h) {
                         &h->b_xc0, &h->b_xc1, &h->b_xp0, &h->b_xp1, &h->b_pc0, &h->b_pc1, &h->b_sc, &h->b_sp, &h->b_hinv, &h->b_gl2,
                         &h->b_dl, &h->b_wt, &h->b_wt1, &h->b_hll0, &h->b_hll1, &h->b_spt1, &h->b_sgemm, &h->b_scam, &h->b_spt, &h->b_payload, &h->b_zc,
                         &h->b_sbs, &h->b_payload2, &h->b_state, &h->b_out, &h->b_dbg, &h->b_cnt, &h->b_we0, &h->b_we1,
-                        &h->b_glsc0, &h->b_glsc1, &h->b_Sd, &h->b_rhs, &h->b_scv, &h->b_ddv, &h->b_gppv, &h->b_cholfail,
-                        &h->b_pairstart, &h->b_paircc, &h->b_paire, &h->b_hp})
+                        &h->b_glsc0, &h->b_glsc1, &h->b_Sd, &h->b_scv, &h->b_ddv, &h->b_gppv, &h->b_cholfail,
+                        &h->b_pairstart, &h->b_paircc, &h->b_paire})
     b->release();
   if (h->own_stream) (void)hipStreamDestroy(h->stream);
   delete h;
@@ -2716,6 +2751,7 @@ int vo_ba_set_reduce_buffers(vo_ba *h, double *dev_system, double *dev_cost) {
   if (h->built) {
     h->D.payload = dev_system ? dev_system : h->b_payload.as<double>();
     h->D.payload2 = dev_cost ? dev_cost : h->b_payload2.as<double>();
+    if (h->D.large) h->D.Sd = dev_system ? dev_system : h->b_Sd.as<double>();  // the Cholesky storage is the payload
   }
   return VO_OK;
 }
@@ -2723,6 +2759,11 @@ int vo_ba_set_reduce_buffers(vo_ba *h, double *dev_system, double *dev_cost) {
 int vo_ba_reduced_system(vo_ba *h, double **p, size_t *n) {
   if (!h || !p || !n) return VO_ERR_INVALID;
   VO_CHECK(build_device(h));
+  if (h->D.large) {  // matrix, right-hand side row, solution row, extras: the whole Cholesky storage
+    *p = h->D.Sd;
+    *n = (size_t)(h->D.ld + vo::kCholPanel) * h->D.ld;
+    return VO_OK;
+  }
   *p = h->D.payload;
   *n = (size_t)h->D.Mpad * h->D.Mpad + (size_t)h->nf * 27 + 1 + h->n_shards;
   return VO_OK;
