@@ -263,10 +263,11 @@ __global__ __launch_bounds__(256) void k_resize4(const uint8_t *src, long long s
 // One WAVEFRONT per (cell, frame), four cells per 256-thread workgroup, no workgroup barrier
 // anywhere: the kernel is instruction-issue bound, and ballot/mbcnt compaction inside one wave
 // needs neither LDS counters nor barriers.  The cell sub-image (incl. the 6-px overlap) is staged
-// in the wave's LDS region; every interior pixel gets S = max over the 16 nine-pixel arcs of the
-// minimum |centre - ring| (bright or dark), so "corner at threshold t" <=> S > t and the OpenCV
-// cornerScore is S-1, independent of t.  NMS runs on the LDS score tile with scores below the
-// cell's current threshold read as 0 and pixels outside the cell interior as 0 (Q-E2).  Survivors
+// in the wave's LDS region.  With S = max over the 16 nine-pixel arcs of the minimum |centre - ring|
+// (bright or dark), "corner at threshold t" <=> S > t and the OpenCV cornerScore is S-1, independent of
+// t.  S is only evaluated for pixels whose compass margin (an upper bound of S) exceeds the threshold in
+// force.  NMS runs on the LDS score tile with entries below the cell's current threshold read as 0 and
+// pixels outside the cell interior as 0 (Q-E2).  Survivors
 // are written in raster order to the cell's slot: x | y<<12 | score<<24 with x,y already shifted
 // by (j*wCell, i*hCell) like :830-831.
 // ------------------------------------------------------------------------------------------
@@ -275,58 +276,70 @@ __device__ __forceinline__ void wave_sync() {  // LDS hand-off between lanes of 
   __builtin_amdgcn_wave_barrier();
 }
 
-template <int TP>
-__device__ __forceinline__ int fast_arc_score(const uint8_t *t, int min_th) {
-  const int v = t[0];
-  int d[16];
-  d[0] = v - t[3 * TP];
-  d[1] = v - t[3 * TP + 1];
-  d[2] = v - t[2 * TP + 2];
-  d[3] = v - t[TP + 3];
-  d[4] = v - t[3];
-  d[5] = v - t[-TP + 3];
-  d[6] = v - t[-2 * TP + 2];
-  d[7] = v - t[-3 * TP + 1];
-  d[8] = v - t[-3 * TP];
-  d[9] = v - t[-3 * TP - 1];
-  d[10] = v - t[-2 * TP - 2];
-  d[11] = v - t[-TP - 3];
-  d[12] = v - t[-3];
-  d[13] = v - t[TP - 3];
-  d[14] = v - t[2 * TP - 2];
-  d[15] = v - t[3 * TP - 1];
+typedef __attribute__((address_space(3))) uint8_t lds_u8;  // explicit LDS pointers: 32-bit address arithmetic
+typedef __attribute__((address_space(3))) unsigned short lds_u16;
+
+// Arc score of one pixel.  With A = min over the 16 nine-pixel arcs of the arc's maximum and B = max over
+// the arcs of the arc's minimum (ring values, not differences), S = max(v - A, B - v); a nine-arc extremum
+// is a 3-extremum of 3-extrema.  `ring` points at the tile pixel (-3, -3) from the centre so that every
+// LDS offset is a non-negative immediate.  RP: row pitch of the tile in LDS.
+template <int RP>
+__device__ __forceinline__ int fast_arc_score(const lds_u8 *ring, int min_th) {
+  constexpr int C = 3 * RP + 3;
+  const int v = ring[C];
+  int r[16];
+  r[0] = ring[C + 3 * RP];
+  r[1] = ring[C + 3 * RP + 1];
+  r[2] = ring[C + 2 * RP + 2];
+  r[3] = ring[C + RP + 3];
+  r[4] = ring[C + 3];
+  r[5] = ring[C - RP + 3];
+  r[6] = ring[C - 2 * RP + 2];
+  r[7] = ring[C - 3 * RP + 1];
+  r[8] = ring[C - 3 * RP];
+  r[9] = ring[C - 3 * RP - 1];
+  r[10] = ring[C - 2 * RP - 2];
+  r[11] = ring[C - RP - 3];
+  r[12] = ring[C - 3];
+  r[13] = ring[C + RP - 3];
+  r[14] = ring[C + 2 * RP - 2];
+  r[15] = ring[C + 3 * RP - 1];
   int mn3[16], mx3[16];
 #pragma unroll
   for (int k = 0; k < 16; k++) {
-    mn3[k] = min(d[k], min(d[(k + 1) & 15], d[(k + 2) & 15]));
-    mx3[k] = max(d[k], max(d[(k + 1) & 15], d[(k + 2) & 15]));
+    mn3[k] = min(r[k], min(r[(k + 1) & 15], r[(k + 2) & 15]));
+    mx3[k] = max(r[k], max(r[(k + 1) & 15], r[(k + 2) & 15]));
   }
-  int sd = -1000, sb = 1000;
+  int A = 1000, B = -1000;
 #pragma unroll
   for (int k = 0; k < 16; k++) {
-    sd = max(sd, min(mn3[k], min(mn3[(k + 3) & 15], mn3[(k + 6) & 15])));
-    sb = min(sb, max(mx3[k], max(mx3[(k + 3) & 15], mx3[(k + 6) & 15])));
+    A = min(A, max(mx3[k], max(mx3[(k + 3) & 15], mx3[(k + 6) & 15])));
+    B = max(B, min(mn3[k], min(mn3[(k + 3) & 15], mn3[(k + 6) & 15])));
   }
-  const int S = max(sd, -sb);
+  const int S = max(v - A, B - v);
   return S > min_th ? S - 1 : 0;
 }
 
 __host__ __device__ __forceinline__ int fast_align16(int v) { return (v + 15) & ~15; }
+// LDS bytes of one wave of k_fast_wave: image rows and score rows interleaved (row pitch 2 TP), survivor list
+__host__ __device__ __forceinline__ int fast_wave_lds(int tp, int tile_rows, int max_interior) {
+  return fast_align16(2 * tp * tile_rows + 16) + fast_align16(2 * max_interior);
+}
 
-template <int TP>  // LDS tile pitch in bytes: 48 for the usual 30..39-px cells, 72 for the largest legal cell
+// TP: width of a tile row in bytes, 48 for the usual 30..39-px cells, 72 for the largest legal cell.
+// BYTEWISE: the caller's level-0 rows are not 4-byte aligned (level 0 is then copied byte by byte).
+template <int TP, bool BYTEWISE>
 __global__ __launch_bounds__(256) void k_fast_wave(OrbDev P, FrameSrc src, uint32_t *cell_slots,
                                                    long long slots_frame_stride, int *cell_count,
-                                                   int cells_per_frame, int lv0_unaligned, int tile_rows,
-                                                   int max_interior) {
+                                                   int cells_per_frame, int tile_rows, int max_interior) {
   extern __shared__ __attribute__((aligned(16))) uint8_t fast_lds[];
+  constexpr int RP = 2 * TP;  // LDS row pitch: image row (TP bytes), then the score row of the same pixels
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
   const int cell = blockIdx.x * 4 + wave, f = blockIdx.y;
   if (cell >= cells_per_frame) return;  // wave-uniform; the kernel has no workgroup barrier
-  const int tileB = fast_align16(TP * tile_rows + 16), scoreB = fast_align16(TP * tile_rows);
-  uint8_t *tile_raw = fast_lds + (size_t)wave * (tileB + scoreB + fast_align16(2 * max_interior));
-  uint8_t *score = tile_raw + tileB;
-  unsigned short *plist = reinterpret_cast<unsigned short *>(score + scoreB);
+  lds_u8 *tile_raw = (lds_u8 *)fast_lds + wave * fast_wave_lds(TP, tile_rows, max_interior);
+  lds_u16 *plist = (lds_u16 *)(tile_raw + fast_align16(RP * tile_rows + 16));
   int l = 0;
   while (l + 1 < P.nlevels && cell >= P.lv[l + 1].cellBase) l++;
   const LevelGeom &L = P.lv[l];
@@ -334,121 +347,157 @@ __global__ __launch_bounds__(256) void k_fast_wave(OrbDev P, FrameSrc src, uint3
   const int ci_i = ci / L.nCols, ci_j = ci - ci_i * L.nCols;
   const int iniX = kBorder + ci_j * L.wCell, iniY = kBorder + ci_i * L.hCell;
   int *out_count = cell_count + (long long)f * cells_per_frame + cell;
-  if (iniX >= L.maxBX - 6 || iniY >= L.maxBY - 3) {  // :801, :811
+  const int maxX = min(iniX + L.wCell + 6, L.maxBX), maxY = min(iniY + L.hCell + 6, L.maxBY);
+  const int cw = maxX - iniX, ch = maxY - iniY;
+  const int iw = cw - 6, ih = ch - 6;
+  if (iniX >= L.maxBX - 6 || iniY >= L.maxBY - 3 || iw <= 0 || ih <= 0) {  // :801, :811; no interior pixel
     if (lane == 0) *out_count = 0;
     return;
   }
-  const int maxX = min(iniX + L.wCell + 6, L.maxBX), maxY = min(iniY + L.hCell + 6, L.maxBY);
-  const int cw = maxX - iniX, ch = maxY - iniY;
   int pitch;
   const uint8_t *img = level_plane(P, src, l, f, pitch);
-  // The tile keeps the source's dword alignment: LDS column 0 is image column iniX - (iniX & 3), so a
-  // row is a run of aligned dwords copied verbatim, four independent loads in flight per lane.
-  const bool bytewise = l == 0 && lv0_unaligned;  // caller image rows are not 4-byte aligned
+  // score rows start at 0: the 3-px margin around the interior is read by the NMS and never written
+  for (int i = lane; i < ch * (TP / 8); i += 64) {
+    const int r = i / (TP / 8), k = i - r * (TP / 8);
+    *(__attribute__((address_space(3))) unsigned long long *)(tile_raw + r * RP + TP + 8 * k) = 0ull;
+  }
+  // ---- stage the cell (incl. the 6-px overlap) in LDS.  The tile keeps the source's dword alignment: LDS
+  // column 0 is image column iniX - (iniX & 3), so a row is a run of aligned dwords copied verbatim.  A lane
+  // owns one dword column of a group of RG rows; group after group is fetched with the row base in scalar
+  // registers (no per-load address arithmetic), all loads of a batch in flight before the first LDS store.
+  // The last group is shifted up to end at the tile's last row (overlapping rows carry identical data), so
+  // there is no row predicate at all.
+  const bool bytewise = BYTEWISE && l == 0;
   const int ox = bytewise ? 0 : (iniX & 3);
-  const uint8_t *tile = tile_raw + ox;
-  for (int i = lane; i < scoreB / 16; i += 64) reinterpret_cast<uint4 *>(score)[i] = make_uint4(0, 0, 0, 0);
-  {
-    const int unit = bytewise ? 1 : 4;                       // bytes per element copied
-    const int npr = bytewise ? cw : (ox + cw + 3) >> 2;      // elements per tile row
-    const int total = npr * ch;
-    const uint8_t *g0 = img + (long long)iniY * pitch + (iniX - ox);
-    int y = (int)(((float)lane + 0.5f) / (float)npr), x = lane - y * npr;
-    const int sdy = 64 / npr, sdx = 64 - sdy * npr;
-    for (int base = 0; base < total; base += 256) {
-      uint32_t v[4];
-      int pos[4];
+  lds_u8 *tile = tile_raw + ox;
+  const uint8_t *g0 = img + (long long)iniY * pitch + (iniX - ox);
+  if (!bytewise) {
+    constexpr int LW = TP <= 64 ? 16 : 32, RG = 64 / LW, NB = 6;  // dword columns, rows per group, groups per batch
+    const int npr = (ox + cw + 3) >> 2;                            // dwords per tile row (<= TP / 4 <= LW)
+    const int d = lane & (LW - 1), r = lane / LW;
+    if (d < npr) {
+      const unsigned goff = (unsigned)(r * pitch + 4 * d);
+      lds_u8 *lt = tile_raw + r * RP + 4 * d;
+      const int ng = (ch + RG - 1) / RG, last0 = max(ch - RG, 0);
+      for (int gb = 0; gb < ng; gb += NB) {
+        uint32_t v[NB];
+        int row0[NB];
 #pragma unroll
-      for (int q = 0; q < 4; q++) {
-        const bool ok = base + q * 64 + lane < total;
-        pos[q] = ok ? __mul24(y, TP) + unit * x : -1;
-        // unconditional load (lanes past the tile re-read its first element): a `ok ? load : 0` form is
-        // turned into a branch per load with a full s_waitcnt behind it, serialising the batch
-        const uint8_t *g = ok ? g0 + (long long)y * pitch + unit * x : g0;
-        v[q] = bytewise ? (uint32_t)*g : *reinterpret_cast<const uint32_t *>(g);
-        x += sdx, y += sdy;
-        if (x >= npr) x -= npr, y++;
-      }
-#pragma unroll
-      for (int q = 0; q < 4; q++)
-        if (pos[q] >= 0) {
-          if (bytewise)
-            tile_raw[pos[q]] = (uint8_t)v[q];
-          else
-            *reinterpret_cast<uint32_t *>(tile_raw + pos[q]) = v[q];
+        for (int q = 0; q < NB; q++) {
+          row0[q] = min(min(gb + q, ng - 1) * RG, last0);  // scalar; groups past the end repeat the last one
+          long long ro = (long long)row0[q] * pitch;
+          asm("" : "+s"(ro));  // keep the row base in scalar registers: the load is saddr + lane offset
+          v[q] = *reinterpret_cast<const uint32_t *>(g0 + ro + goff);
         }
-    }
-  }
-  wave_sync();
-  const int iw = cw - 6, ih = ch - 6;
-  const int ni = (iw > 0 && ih > 0) ? iw * ih : 0;
-  // phase 1: a 9-arc always contains two neighbouring compass pixels (ring 0,4,8,12), so a pixel can
-  // only be a corner at the lowest threshold if one such pair is brighter or darker together:
-  // max over the four pairs of min(pair) > v + t, or min over the pairs of max(pair) < v - t.
-  // Survivors are compacted IN RASTER ORDER into the wave's LDS list; everything after this phase
-  // touches survivors only.
-  int np = 0;
-  {
-    const int iwd = max(iw, 1);
-    int y = (int)(((float)lane + 0.5f) / (float)iwd), x = lane - y * iwd;
-    const int sdy = 64 / iwd, sdx = 64 - sdy * iwd;
-    for (int base = 0; base < ni; base += 64) {
-      bool pass = false;
-      const int pos = __mul24(3 + y, TP) + 3 + x;  // 24-bit multiply: full rate (v_mul_lo_u32 is quarter rate)
-      if (base + lane < ni) {
-        const uint8_t *t = &tile[pos];
-        const int v = t[0];
-        const int p0 = t[3 * TP], p4 = t[3], p8 = t[-3 * TP], p12 = t[-3];
-        const int mb = max(max(min(p0, p4), min(p4, p8)), max(min(p8, p12), min(p12, p0)));
-        const int md = min(min(max(p0, p4), max(p4, p8)), min(max(p8, p12), max(p12, p0)));
-        pass = (mb > v + P.min_th) | (md < v - P.min_th);
+#pragma unroll
+        for (int q = 0; q < NB; q++) {
+          int lo = row0[q] * RP;
+          asm("" : "+s"(lo));
+          *(__attribute__((address_space(3))) uint32_t *)(lt + lo) = v[q];
+        }
       }
-      const unsigned long long mask = __ballot(pass);
-      if (pass) plist[np + __builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0u))] =
-          (unsigned short)pos;
-      np += __popcll(mask);
-      x += sdx, y += sdy;
-      if (x >= iwd) x -= iwd, y++;
+    }
+  } else {
+    constexpr int NB = 8;
+    for (int col = lane; col < cw; col += 64) {  // one tile row per load
+      for (int rb = 0; rb < ch; rb += NB) {
+        uint8_t v[NB];
+        int row[NB];
+#pragma unroll
+        for (int q = 0; q < NB; q++) {
+          row[q] = min(rb + q, ch - 1);
+          v[q] = g0[(long long)row[q] * pitch + col];
+        }
+#pragma unroll
+        for (int q = 0; q < NB; q++) tile_raw[row[q] * RP + col] = v[q];
+      }
     }
   }
   wave_sync();
-  // phase 2: full arc score only for the survivors
-  for (int i = lane; i < np; i += 64) {
-    const int pos = plist[i];
-    score[pos] = (uint8_t)fast_arc_score<TP>(&tile[pos], P.min_th);
-  }
-  wave_sync();
-  // phase 3: 3x3 non-maximum suppression at the cell's threshold over the (raster-ordered) survivors;
-  // kept pixels are written in the same order.  A cell with no key-point at iniThFAST is redone at
-  // minThFAST (:820-824).
+  // ---- phase 1.  A 9-arc always contains two neighbouring compass pixels (ring 0,4,8,12), so the arc score
+  // S is bounded by the compass margin m = max(mb - v, v - md), mb = max over the four neighbouring pairs of
+  // min(pair) = min(max(p0,p8), max(p4,p12)), md = min over the pairs of max(pair) = max(min(p0,p8),
+  // min(p4,p12)): a pixel can only be a corner at threshold t if m > t.  Every interior pixel leaves
+  // max(m - 1, 0) in the score tile (an upper bound of its score S - 1, replaced by the score once computed),
+  // and the pixels with m > iniThFAST are compacted IN RASTER ORDER into the wave's LDS list: cells that yield
+  // a key-point at iniThFAST (almost all) never score the 4x larger minThFAST survivor set.
+  // Lane mapping: 32 columns x 2 rows per step (64 x 1 for cells wider than 32), so that a lane's LDS
+  // address advances by a wave-uniform constant and the only per-step predicate is the row count.  The
+  // list holds the LDS address of the pixel's (-3, -3) neighbour: every later access is that register plus
+  // an immediate.
+  const int lw = iw <= 32 ? 5 : 6;  // uniform
+  const int lx = lane & ((1 << lw) - 1), ly = lane >> lw, ri = 64 >> lw;
+  lds_u8 *const b0 = tile + ly * RP + lx;
+  // Walk the interior: lanes beyond the cell's width sit out the whole walk, full steps need no predicate,
+  // and an odd last row (two-row steps) is a separate step for the lanes of the first row.  `body` returns
+  // the lane's hit; hits are appended in lane order = raster order.
+  int np = 0;
+  auto walk = [&](auto body) {
+    int n = 0;
+    if (lx < iw) {
+      lds_u8 *b = b0;
+      asm("" : "+v"(b));  // one address register, advanced by a scalar: the accesses below are register + immediate
+      int row = 0;
+      auto step = [&]() {
+        const bool hit = body(b);
+        const unsigned long long mask = __builtin_amdgcn_ballot_w64(hit);
+        if (hit) plist[n + __builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0u))] =
+            (unsigned short)(unsigned)(uintptr_t)b;
+        n += __popcll(mask);
+      };
+      for (; row + ri <= ih; row += ri, b += ri * RP) step();
+      if (row < ih && ly == 0) step();
+    }
+    return __builtin_amdgcn_readlane(n, 0);  // lane 0 always takes part
+  };
+  np = walk([&](lds_u8 *b) {
+    const int v = b[3 * RP + 3];
+    const int p0 = b[6 * RP + 3], p4 = b[3 * RP + 6], p8 = b[3], p12 = b[3 * RP];
+    const int mb = min(max(p0, p8), max(p4, p12));
+    const int md = max(min(p0, p8), min(p4, p12));
+    const int m1 = max(max(mb + ~v, v + ~md), 0);  // max(m - 1, 0)
+    b[3 * RP + 3 + TP] = (uint8_t)m1;
+    return m1 >= P.ini_th;
+  });
   uint32_t *slot = cell_slots + (long long)f * slots_frame_stride + L.slotBase + (long long)ci * L.capCell;
   int running = 0;
-  for (int pass = 0; pass < 2; pass++) {
-    const int th = pass == 0 ? P.ini_th : P.min_th;
+  for (int round = 0; round < 2; round++) {
+    const int th = round == 0 ? P.ini_th : P.min_th;
+    if (round == 1) {
+      // A cell with no key-point at iniThFAST is redone at minThFAST (:820-824): the survivors are the
+      // pixels whose tile entry (margin bound, or score where already computed) reaches minThFAST.
+      np = walk([&](lds_u8 *b) { return (int)b[3 * RP + 3 + TP] >= th; });
+    }
+    wave_sync();
+    // ---- phase 2: full arc score only for the survivors
+    for (int i = lane; i < np; i += 64) {
+      lds_u8 *b = (lds_u8 *)(uintptr_t)(unsigned)plist[i];
+      b[3 * RP + 3 + TP] = (uint8_t)fast_arc_score<RP>(b, P.min_th);
+    }
+    wave_sync();
+    // ---- phase 3: 3x3 non-maximum suppression at the threshold over the (raster-ordered) survivors; kept
+    // pixels are written in the same order.  A survivor's score only has to exceed the raw neighbouring tile
+    // entries: an entry below the threshold (a score, or the margin bound of a pixel that cannot be a corner
+    // at it; OpenCV reads those as 0) is below the survivor's score anyway.
     running = 0;
     for (int base = 0; base < np; base += 64) {
       const int i = base + lane;
       bool keep = false;
       int pos = 0, sc0 = 0;
       if (i < np) {
-        pos = plist[i];
-        const uint8_t *c = &score[pos];
-        sc0 = c[0];
-        if (sc0 >= th) {
-          int nb = 0;
-#define NBR(o) nb = max(nb, (int)c[o] >= th ? (int)c[o] : 0)
-          NBR(-TP - 1); NBR(-TP); NBR(-TP + 1);
-          NBR(-1); NBR(1);
-          NBR(TP - 1); NBR(TP); NBR(TP + 1);
-#undef NBR
-          keep = sc0 > nb;
-        }
+        const lds_u8 *b = (const lds_u8 *)(uintptr_t)(unsigned)plist[i];
+        pos = (int)(b - tile);  // (row * RP + column) of the (-3, -3) neighbour = of the pixel, minus the margin
+        const lds_u8 *c = b + 2 * RP + 2 + TP;  // score entry (-1, -1) from the pixel
+        sc0 = c[RP + 1];
+        const int nb = max(max(max((int)c[0], (int)c[1]), max((int)c[2], (int)c[RP])),
+                           max(max((int)c[RP + 2], (int)c[2 * RP]), max((int)c[2 * RP + 1], (int)c[2 * RP + 2])));
+        keep = sc0 >= th && sc0 > nb;
       }
-      const unsigned long long mask = __ballot(keep);
+      const unsigned long long mask = __builtin_amdgcn_ballot_w64(keep);
       const int off = running + __builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0u));
       if (keep && off < L.capCell) {
-        const int y = pos / TP, x = pos - y * TP;
-        slot[off] = (uint32_t)(x + ci_j * L.wCell) | ((uint32_t)(y + ci_i * L.hCell) << 12) | ((uint32_t)sc0 << 24);
+        const int y = pos / RP, x = pos - y * RP;  // interior coordinates; the cell-local ones are +3
+        slot[off] = (uint32_t)(x + 3 + ci_j * L.wCell) | ((uint32_t)(y + 3 + ci_i * L.hCell) << 12) | ((uint32_t)sc0 << 24);
       }
       running += __popcll(mask);
     }
@@ -1330,15 +1379,11 @@ int configure(vo_orb *h, int w, int h_img, int n_frames) {
       h->fast_tp = mw + 9 <= 48 ? 48 : kTileP;
       h->fast_rows = mh + 6;
       h->fast_interior = mw * mh;
-      h->fast_lds = 4 * (size_t)(fast_align16(h->fast_tp * h->fast_rows + 16) + fast_align16(h->fast_tp * h->fast_rows) +
-                                 fast_align16(2 * h->fast_interior));
+      h->fast_lds = 4 * (size_t)fast_wave_lds(h->fast_tp, h->fast_rows, h->fast_interior);
       if (h->fast_lds > 64 * 1024) {
-        if (h->fast_tp == 48)
-          VO_HIP_CHECK(hipFuncSetAttribute((const void *)k_fast_wave<48>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                           (int)h->fast_lds));
-        else
-          VO_HIP_CHECK(hipFuncSetAttribute((const void *)k_fast_wave<kTileP>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                           (int)h->fast_lds));
+        for (const void *fn : {(const void *)k_fast_wave<48, false>, (const void *)k_fast_wave<48, true>,
+                               (const void *)k_fast_wave<kTileP, false>, (const void *)k_fast_wave<kTileP, true>})
+          VO_HIP_CHECK(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->fast_lds));
       }
     }
     h->keys_frame = align_up(keys, 64);
@@ -1449,13 +1494,10 @@ int run_pipeline(vo_orb *h, const uint8_t *dev_images, int n_frames, int w, int 
   }
   if (h->cells_frame > 0) {
     const dim3 grid((h->cells_frame + 3) / 4, n_frames);
-    if (h->fast_tp == 48)
-      hipLaunchKernelGGL(k_fast_wave<48>, grid, dim3(256), h->fast_lds, st, D, S, h->slots.as<uint32_t>(), h->slots_frame,
-                         h->cellcnt.as<int>(), h->cells_frame, lv0_unaligned, h->fast_rows, h->fast_interior);
-    else
-      hipLaunchKernelGGL(k_fast_wave<kTileP>, grid, dim3(256), h->fast_lds, st, D, S, h->slots.as<uint32_t>(),
-                         h->slots_frame, h->cellcnt.as<int>(), h->cells_frame, lv0_unaligned, h->fast_rows,
-                         h->fast_interior);
+    auto fast = h->fast_tp == 48 ? (lv0_unaligned ? k_fast_wave<48, true> : k_fast_wave<48, false>)
+                                 : (lv0_unaligned ? k_fast_wave<kTileP, true> : k_fast_wave<kTileP, false>);
+    hipLaunchKernelGGL(fast, grid, dim3(256), h->fast_lds, st, D, S, h->slots.as<uint32_t>(), h->slots_frame,
+                       h->cellcnt.as<int>(), h->cells_frame, h->fast_rows, h->fast_interior);
   }
   VO_STAGE_MARK(2);
   if (h->oct_small)
