@@ -23,10 +23,13 @@ constexpr int kHalfPatch = 15;     // HALF_PATCH_SIZE :75
 constexpr int kTileP = 72;         // LDS pitch of a FAST cell tile (cell <= 66 px incl. 6 px overlap)
 constexpr int kMaxList = 1024;     // oct-tree node list capacity per level (quota <= kMaxList-4)
 
-// (u,v) of the 749 pixels of the orientation disc (filled by vo_orb_create from umax), padded to 768
-__constant__ __attribute__((aligned(16))) int8_t c_disc[768 * 2];
-
-__constant__ __attribute__((aligned(16))) int8_t c_pattern[1024] = {
+// Per-lane constants of k_describe, lane-major so that a lane fetches them with nine 16-byte loads:
+//  [0..11]  the lane's 12 pixels of the 749-pixel orientation disc (filled by vo_orb_create from umax; pixel
+//           lane + 64 i, padded to 768 with the centre) as offsets (v + 15) * 64 + (u + 15) in the staged window
+//  [12..14] their u as signed bytes, four pixels per dword; [15..17] their v (padding entries weigh 0)
+//  [18..33] steered-BRIEF pattern as floats, [word k][x0, y0, x1, y1] = test 64 k + lane
+__constant__ __attribute__((aligned(16))) uint32_t c_desc_tab[64][36];
+const int8_t h_pattern[1024] = {  // host copy: 256 x (x0, y0, x1, y1)
 #include "orb_pattern.inc"
 };
 
@@ -1088,83 +1091,196 @@ __device__ __forceinline__ void cos_sin_f(float angle_rad, float &cs, float &sn)
   sn = (float)si;
 }
 
+typedef float v2f __attribute__((ext_vector_type(2)));
+
+// per key-point record of a k_describe batch (LDS)
+struct DescRec {
+  unsigned long long disc_base;  // level plane, pixel (px - 15, py - 15)
+  unsigned long long blur_base;  // blurred plane, pixel (px - 19, py - 19)
+  int pitch, bpitch;             // row pitch of the two planes
+  int m10, m01;                  // intensity-centroid moments
+  float a, b;                    // cos, sin of the steering angle
+  int bytewise, pad;             // level-0 rows of the caller's image are not 16-byte aligned
+};
+
+// LDS values every lane reads from the same address, moved to scalar registers
+__device__ __forceinline__ int uni_i32(int v) { return __builtin_amdgcn_readfirstlane(v); }
+__device__ __forceinline__ float uni_f32(float v) { return __uint_as_float((unsigned)__builtin_amdgcn_readfirstlane((int)__float_as_uint(v))); }
+typedef const __attribute__((address_space(1))) uint8_t gmem_u8;  // global memory: loads are scalar base + lane offset
+__device__ __forceinline__ gmem_u8 *uni_ptr(unsigned long long v) {
+  const unsigned lo = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)v);
+  const unsigned hi = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(v >> 32));
+  return (gmem_u8 *)(uintptr_t)(((unsigned long long)hi << 32) | lo);
+}
+
+__device__ __forceinline__ int wave_sum_i32(int x) {  // sum over the 64 lanes, result uniform (SGPR)
+  x += __builtin_amdgcn_update_dpp(0, x, 0xB1, 0xf, 0xf, false);   // quad_perm [1,0,3,2]
+  x += __builtin_amdgcn_update_dpp(0, x, 0x4E, 0xf, 0xf, false);   // quad_perm [2,3,0,1]
+  x += __builtin_amdgcn_update_dpp(0, x, 0x141, 0xf, 0xf, false);  // row_half_mirror
+  x += __builtin_amdgcn_update_dpp(0, x, 0x140, 0xf, 0xf, false);  // row_mirror: every lane holds its row's sum
+  return __builtin_amdgcn_readlane(x, 0) + __builtin_amdgcn_readlane(x, 16) + __builtin_amdgcn_readlane(x, 32) +
+         __builtin_amdgcn_readlane(x, 48);
+}
+
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+constexpr int kWinPitch = 64;       // LDS row pitch of a staged window: four 16-byte chunks
+constexpr int kWinBytes = 40 * 64;  // 39 rows, rounded up to a multiple of 4 lanes x 16 bytes
+
+// Stage the ROWS x (<= 64 - 15) byte window whose top-left pixel is `origin` (row pitch `pitch`, rows 16-byte
+// aligned) into LDS with 16-byte loads: lane + 64 j -> row (lane >> 2) + 16 j, chunk lane & 3, so the LDS
+// address is simply 16 lane + 1024 j.  Rows past the window repeat its last row.  Returns the column of
+// `origin` in the staged rows (0..15).  The memory pipe spends the same 16 cycles on a wavefront's byte
+// gather as on these 1 KB loads: staging cuts its work per key-point by 4x.
+template <int ROWS>
+__device__ __forceinline__ void window_issue(unsigned long long origin, int pitch, int lane, u32x4 (&v)[(ROWS + 15) / 16], int &ox) {
+  constexpr int NJ = (ROWS + 15) / 16;
+  ox = uni_i32((int)(unsigned)origin & 15);
+  gmem_u8 *base = uni_ptr(origin) - ox;
+#pragma unroll
+  for (int j = 0; j < NJ; j++) {
+    const int row = (j + 1) * 16 <= ROWS ? (lane >> 2) + 16 * j : min((lane >> 2) + 16 * j, ROWS - 1);
+    const unsigned goff = (unsigned)(row * pitch + 16 * (lane & 3));
+    v[j] = *reinterpret_cast<const __attribute__((address_space(1))) u32x4 *>(base + goff);
+  }
+}
+template <int NJ>
+__device__ __forceinline__ void window_store(lds_u8 *slot, int lane, const u32x4 (&v)[NJ]) {
+#pragma unroll
+  for (int j = 0; j < NJ; j++)
+    if (16 * lane + 1024 * j < kWinBytes)  // the slot ends after row 39 (a predicate on the last store only)
+      *(__attribute__((address_space(3))) u32x4 *)(slot + 16 * lane + 1024 * j) = v[j];
+}
+
+#ifndef VO_DESC_NK
+#define VO_DESC_NK 2
+#endif
+
+// One workgroup per batch of 64 key-points of a frame, four phases separated by workgroup barriers:
+//  0  lane = key-point: level search, selected key, plane addresses -> LDS records
+//  1  wave = key-point (16 per wave, NK in flight): the 31 x 31 window around the key-point is staged in LDS,
+//     the lane's 12 pixels of the 749-pixel disc are LDS byte reads at constant offsets, moments as signed
+//     byte dot products (pixel - 128; the disc's u and v sum to zero, so the offset cancels exactly), DPP row
+//     reduction
+//  2  lane = key-point: fastAtan2, cos / sin (one evaluation for 64 key-points instead of one per wave),
+//     key-point record out
+//  3  wave = key-point: the 39 x 39 window of the blurred plane is staged in LDS (the rotated pattern points
+//     scatter over it); lane t rotates the pattern points of tests t, t+64, t+128, t+192 (packed FP32
+//     multiplies and adds, rounding by the 1.5 * 2^23 constant so that the integer falls out of the mantissa
+//     and feeds the address arithmetic), eight LDS byte gathers, four 64-bit ballots are the descriptor.
+template <int NK>  // key-points a wave keeps in flight in phases 1 and 3
 __global__ __launch_bounds__(256) void k_describe(OrbDev P, FrameSrc src, const uint32_t *sel,
                                                   int sel_per_frame, const int *off, int capacity,
-                                                  vo_keypoint *kps, uint8_t *desc) {
-  const int lane = threadIdx.x & 63;
-  // wave-uniform key-point index: level search, geometry and the selected key all stay in scalar
-  // registers / scalar loads
-  const int g = blockIdx.x * 4 + __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
-  const int f = blockIdx.y;
-  // the two per-lane tables do not depend on the key-point: fetch them first, under the offset / key
-  // round trips (the disc: pixel lane + 64 i, entries >= n_disc are (0,0) with weight 0)
-  unsigned short dw[12];
-#pragma unroll
-  for (int i = 0; i < 12; i++) dw[i] = reinterpret_cast<const unsigned short *>(c_disc)[lane + 64 * i];
-  uint32_t pat[4];
-#pragma unroll
-  for (int k = 0; k < 4; k++) pat[k] = reinterpret_cast<const uint32_t *>(c_pattern)[lane + 64 * k];  // x0,y0,x1,y1 as int8
+                                                  vo_keypoint *kps, uint8_t *desc, int lv0_bytewise,
+                                                  int batches_per_frame, int n_frames) {
+  __shared__ DescRec rec[64];
+  __shared__ __attribute__((aligned(16))) uint8_t win_lds[4][NK][kWinBytes];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  // Workgroups go round-robin over the 8 XCDs (each with its own L2): all batches of a frame run on one XCD
+  // so that the windows of its key-points, which overlap line by line, are served by that L2.
+  const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+  const int f = (slot / batches_per_frame) * 8 + xcd, g0 = (slot % batches_per_frame) * 64;
+  if (f >= n_frames) return;
   const int *op = off + f * (P.nlevels + 1);
-  int o[kMaxLevels + 1];  // all level offsets in flight at once (a dependent scan costs a round trip per level)
+  const int total = min(op[P.nlevels], capacity);
+  const int nv = min(total - g0, 64);  // key-points of this batch (uniform)
+  if (nv <= 0) return;
+  // per-lane constants of phase 1 (disc offsets and weights), independent of the key-point: in flight under phase 0
+  u32x4 tab[9];
 #pragma unroll
-  for (int i = 0; i <= kMaxLevels; i++) o[i] = i <= P.nlevels ? op[i] : 0x7fffffff;
-  int total = 0, l = 0, obase = 0;
-#pragma unroll
-  for (int i = 0; i <= kMaxLevels; i++) {
-    if (i == P.nlevels) total = o[i];
-    if (i >= 1 && i < P.nlevels && g >= o[i]) l = i, obase = o[i];
-  }
-  if (g >= total || g >= capacity) return;
-  const LevelGeom &L = P.lv[l];
-  const uint32_t kv = sel[(long long)f * sel_per_frame + L.selBase + (g - obase)];
-  const int px = (int)(kv & 0xfff) + kBorder, py = (int)((kv >> 12) & 0xfff) + kBorder;  // :849-850
-  int pitch;
-  const uint8_t *img = level_plane(P, src, l, f, pitch);
-  const uint8_t *center = img + (long long)py * pitch + px;
-  // intensity centroid: rows v = -15..15, two rows per step (lane>>5 picks the row)
-  int m10 = 0, m01 = 0;
-  {
-    int uu[12], vv[12], val[12];
-#pragma unroll
-    for (int i = 0; i < 12; i++) uu[i] = (int8_t)(dw[i] & 0xff), vv[i] = (int8_t)(dw[i] >> 8);
-#pragma unroll
-    for (int i = 0; i < 12; i++) val[i] = center[(long long)vv[i] * pitch + uu[i]];
-#pragma unroll
-    for (int i = 0; i < 12; i++) {
-      m10 += uu[i] * val[i];
-      m01 += vv[i] * val[i];
+  for (int i = 0; i < 5; i++) tab[i] = reinterpret_cast<const u32x4 *>(c_desc_tab[lane])[i];
+  uint32_t kv_own = 0;
+  int l_own = 0, px_own = 0, py_own = 0;
+  if (tid < nv) {
+    const int g = g0 + tid;
+    int l = 0, obase = 0;
+    for (int i = 1; i < P.nlevels; i++) {
+      const int oi = op[i];
+      if (g >= oi) l = i, obase = oi;
     }
+    const LevelGeom &L = P.lv[l];  // lane-dependent level: vector loads, once per 64 key-points
+    const uint32_t kv = sel[(long long)f * sel_per_frame + L.selBase + (g - obase)];
+    const int px = (int)(kv & 0xfff) + kBorder, py = (int)((kv >> 12) & 0xfff) + kBorder;  // :849-850
+    int pitch;
+    const uint8_t *img = level_plane(P, src, l, f, pitch);
+    const int bp = L.pitch;
+    const uint8_t *bl = src.blur + (long long)f * src.blur_frame_stride + L.blur_off;
+    DescRec r;
+    r.disc_base = (unsigned long long)(uintptr_t)(img + (long long)(py - kHalfPatch) * pitch + (px - kHalfPatch));
+    r.blur_base = (unsigned long long)(uintptr_t)(bl + (long long)(py - kEdge) * bp + (px - kEdge));
+    r.pitch = pitch, r.bpitch = bp;
+    r.m10 = r.m01 = 0;
+    r.a = r.b = 0.f;
+    r.bytewise = l == 0 && lv0_bytewise, r.pad = 0;
+    rec[tid] = r;
+    kv_own = kv, l_own = l, px_own = px, py_own = py;
   }
+  __syncthreads();
+  // ---- phase 1: moments
+  const int k0 = wave * 16, k1 = min(k0 + 16, nv);
+  for (int k = k0; k < k1; k += NK) {
+    uint32_t va[NK][12];
+    bool staged[NK];
+    u32x4 wv[NK][2];
+    int ox[NK];
 #pragma unroll
-  for (int o2 = 32; o2 >= 1; o2 >>= 1) {
-    m10 += __shfl_xor(m10, o2);
-    m01 += __shfl_xor(m01, o2);
+    for (int s = 0; s < NK; s++) {
+      const int kk = min(k + s, k1 - 1);  // uniform; past the end the last key-point is redone (not stored)
+      staged[s] = uni_i32(rec[kk].bytewise) == 0;
+      if (staged[s]) {
+        window_issue<2 * kHalfPatch + 1>(rec[kk].disc_base, uni_i32(rec[kk].pitch), lane, wv[s], ox[s]);
+      } else {  // byte gathers straight from the caller's image
+        gmem_u8 *base = uni_ptr(rec[kk].disc_base);
+        const int pp = uni_i32(rec[kk].pitch);
+#pragma unroll
+        for (int i = 0; i < 12; i++) {
+          const uint32_t c = tab[i >> 2][i & 3];
+          va[s][i] = base[__umul24(c >> 6, (unsigned)pp) + (c & 63)];
+        }
+      }
+    }
+#pragma unroll
+    for (int s = 0; s < NK; s++)
+      if (staged[s]) window_store<2>((lds_u8 *)win_lds[wave][s], lane, wv[s]);
+    wave_sync();
+#pragma unroll
+    for (int s = 0; s < NK; s++)
+      if (staged[s]) {
+        const lds_u8 *w0 = (const lds_u8 *)win_lds[wave][s] + ox[s];
+#pragma unroll
+        for (int i = 0; i < 12; i++) va[s][i] = w0[tab[i >> 2][i & 3]];
+      }
+#pragma unroll
+    for (int s = 0; s < NK; s++) {
+      int s10 = 0, s01 = 0;
+#pragma unroll
+      for (int j = 0; j < 3; j++) {
+        // four pixels per dword (two byte permutes and one OR-XOR), minus 128
+        const uint32_t w = (__builtin_amdgcn_perm(va[s][4 * j + 1], va[s][4 * j], 0x0c0c0400u) |
+                            __builtin_amdgcn_perm(va[s][4 * j + 3], va[s][4 * j + 2], 0x04000c0cu)) ^ 0x80808080u;
+        s10 = __builtin_amdgcn_sdot4((int)tab[3][j], (int)w, s10, false);
+        s01 = __builtin_amdgcn_sdot4((int)(j == 0 ? tab[3][3] : tab[4][j - 1]), (int)w, s01, false);
+      }
+      const int m10 = wave_sum_i32(s10), m01 = wave_sum_i32(s01);
+      if (lane == 0 && k + s < k1) rec[k + s].m10 = m10, rec[k + s].m01 = m01;
+    }
+    wave_sync();  // the windows are overwritten by the next group
   }
-  const float angle = fast_atan2_deg((float)m01, (float)m10);
-  const float factorPI = (float)(3.14159265358979323846 / 180.f);  // :109
-  float a, b;
-  cos_sin_f(angle * factorPI, a, b);
-  const int Lpitch = L.pitch;
-  const uint8_t *bc = src.blur + (long long)f * src.blur_frame_stride + L.blur_off + (long long)py * Lpitch + px;
-  unsigned long long words[4];
-  int t0[4], t1[4];
+  // the lane's pattern rows (phase 3): in flight under phase 2; the registers of the disc constants are free now
 #pragma unroll
-  for (int k = 0; k < 4; k++) {
-    const uint32_t pw = pat[k];
-    const float x0 = (float)(int8_t)(pw & 0xff), y0 = (float)(int8_t)((pw >> 8) & 0xff);
-    const float x1 = (float)(int8_t)((pw >> 16) & 0xff), y1 = (float)(int8_t)(pw >> 24);
-    const int r0 = __float2int_rn(x0 * b + y0 * a), q0 = __float2int_rn(x0 * a - y0 * b);
-    const int r1 = __float2int_rn(x1 * b + y1 * a), q1 = __float2int_rn(x1 * a - y1 * b);
-    t0[k] = bc[r0 * Lpitch + q0], t1[k] = bc[r1 * Lpitch + q1];  // all eight loads in flight
-  }
-#pragma unroll
-  for (int k = 0; k < 4; k++) words[k] = __ballot(t0[k] < t1[k]);
-  const long long oi = (long long)f * capacity + g;
-  if (lane < 4) reinterpret_cast<unsigned long long *>(desc + oi * 32)[lane] = words[lane];
-  if (lane == 0) {
+  for (int i = 4; i < 9; i++) tab[i] = reinterpret_cast<const u32x4 *>(c_desc_tab[lane])[i];
+  __syncthreads();
+  // ---- phase 2: angle, cos / sin, key-point record
+  if (tid < nv) {
+    const float angle = fast_atan2_deg((float)rec[tid].m01, (float)rec[tid].m10);
+    const float factorPI = (float)(3.14159265358979323846 / 180.f);  // :109
+    float a, b;
+    cos_sin_f(angle * factorPI, a, b);
+    rec[tid].a = a, rec[tid].b = b;
+    const LevelGeom &L = P.lv[l_own];
     vo_keypoint kp;
-    float fx = (float)px, fy = (float)py;
-    if (l != 0) {  // :1102-1108
+    float fx = (float)px_own, fy = (float)py_own;
+    if (l_own != 0) {  // :1102-1108
       fx *= L.scale;
       fy *= L.scale;
     }
@@ -1172,10 +1288,56 @@ __global__ __launch_bounds__(256) void k_describe(OrbDev P, FrameSrc src, const 
     kp.y = fy;
     kp.size = (float)L.patchSize;
     kp.angle = angle;
-    kp.response = (float)(kv >> 24);
-    kp.octave = l;
+    kp.response = (float)(kv_own >> 24);
+    kp.octave = l_own;
     kp.class_id = -1;
-    kps[oi] = kp;
+    kps[(long long)f * capacity + g0 + tid] = kp;
+  }
+  __syncthreads();
+  // ---- phase 3: descriptors
+  constexpr float kMagic = 12582912.f;  // 1.5 * 2^23: x + kMagic has rint(x) + 0x400000 in its low 24 bits
+  for (int k = k0; k < k1; k += NK) {
+    u32x4 wv[NK][3];
+    int ox[NK];
+#pragma unroll
+    for (int s = 0; s < NK; s++) {
+      const int kk = min(k + s, k1 - 1);
+      window_issue<2 * kEdge + 1>(rec[kk].blur_base, uni_i32(rec[kk].bpitch), lane, wv[s], ox[s]);
+    }
+#pragma unroll
+    for (int s = 0; s < NK; s++) window_store<3>((lds_u8 *)win_lds[wave][s], lane, wv[s]);
+    wave_sync();
+    uint32_t t[NK][8];
+#pragma unroll
+    for (int s = 0; s < NK; s++) {
+      const int kk = min(k + s, k1 - 1);
+      const float a = uni_f32(rec[kk].a), b = uni_f32(rec[kk].b);
+      // (r + 19) * 64 + (q + 19 + ox) from the raw bit patterns 0x4B400000 + integer (arithmetic mod 2^32)
+      const unsigned fold = (unsigned)(kEdge * kWinPitch + kEdge + ox[s]) - (0x4B400000u * (unsigned)kWinPitch + 0x4B400000u);
+      const lds_u8 *wl = (const lds_u8 *)win_lds[wave][s];
+      const v2f ba = {b, a}, anb = {a, -b}, mg = {kMagic, kMagic};
+#pragma unroll
+      for (int w = 0; w < 4; w++)
+#pragma unroll
+        for (int e = 0; e < 2; e++) {
+          const int c = 18 + 4 * w + 2 * e;
+          const float x = __uint_as_float(tab[c >> 2][c & 3]), y = __uint_as_float(tab[(c + 1) >> 2][(c + 1) & 3]);
+          const v2f xx = {x, x}, yy = {y, y};
+          const v2f rq = (xx * ba + yy * anb) + mg;  // (x b + y a, x a - y b), each rounded to nearest even
+          const unsigned o = (__float_as_uint(rq.x) << 6) + __float_as_uint(rq.y) + fold;
+          t[s][2 * w + e] = wl[o];
+        }
+    }
+#pragma unroll
+    for (int s = 0; s < NK; s++) {
+      unsigned long long wd[4];
+#pragma unroll
+      for (int w = 0; w < 4; w++) wd[w] = __builtin_amdgcn_ballot_w64(t[s][2 * w] < t[s][2 * w + 1]);
+      // lane w < 4 stores word w
+      const unsigned long long mine = lane == 0 ? wd[0] : lane == 1 ? wd[1] : lane == 2 ? wd[2] : wd[3];
+      if (lane < 4 && k + s < k1) reinterpret_cast<unsigned long long *>(desc + ((long long)f * capacity + g0 + k + s) * 32)[lane] = mine;
+    }
+    wave_sync();  // the windows are overwritten by the next group
   }
 }
 
@@ -1436,6 +1598,9 @@ int run_pipeline(vo_orb *h, const uint8_t *dev_images, int n_frames, int w, int 
   // kernels that read aligned dwords need 4-byte aligned caller rows; otherwise level 0 takes byte paths
   const int lv0_unaligned =
       ((reinterpret_cast<uintptr_t>(dev_images) | (uintptr_t)stride | (uintptr_t)frame_stride) & 3) ? 1 : 0;
+  // k_describe stages level-0 windows with 16-byte loads when the caller's rows allow it
+  const int lv0_not16 =
+      ((reinterpret_cast<uintptr_t>(dev_images) | (uintptr_t)stride | (uintptr_t)frame_stride) & 15) ? 1 : 0;
   hipEvent_t *ev = nullptr;
   if (h->timing) {
     const size_t need = (size_t)(h->timed_calls + 1) * (VO_ORB_STAGES + 1);
@@ -1521,10 +1686,11 @@ int run_pipeline(vo_orb *h, const uint8_t *dev_images, int n_frames, int w, int 
   else
     launch_blur(st);
   VO_STAGE_MARK(5);
-  const int kp_blocks = (std::min(capacity, h->max_kp) + 3) / 4;
+  const int kp_blocks = (std::min(capacity, h->max_kp) + 63) / 64;
   if (kp_blocks > 0)
-    hipLaunchKernelGGL(k_describe, dim3(kp_blocks, n_frames), dim3(256), 0, st, D, S, h->sel.as<uint32_t>(),
-                       h->sel_frame, h->off.as<int>(), capacity, dkp, ddesc);
+    hipLaunchKernelGGL(k_describe<VO_DESC_NK>, dim3(kp_blocks * ((n_frames + 7) / 8) * 8), dim3(256), 0, st, D, S,
+                       h->sel.as<uint32_t>(), h->sel_frame, h->off.as<int>(), capacity, dkp, ddesc, lv0_not16, kp_blocks,
+                       n_frames);
   VO_STAGE_MARK(6);
 #undef VO_STAGE_MARK
   VO_HIP_CHECK(hipGetLastError());
@@ -1587,8 +1753,23 @@ int vo_orb_create(vo_orb **out, int nfeatures, float scale_factor, int nlevels, 
       delete h;
       return VO_ERR_INVALID;
     }
-    if (hipMemcpyToSymbol(HIP_SYMBOL(c_disc), disc, sizeof(disc)) != hipSuccess) {
-      vo::set_error("hipMemcpyToSymbol(c_disc) failed");
+    static uint32_t tab[64][36];
+    memset(tab, 0, sizeof(tab));
+    for (int ln = 0; ln < 64; ln++) {
+      for (int i = 0; i < 12; i++) {
+        const int u = disc[2 * (ln + 64 * i)], v = disc[2 * (ln + 64 * i) + 1];
+        tab[ln][i] = (uint32_t)((v + kHalfPatch) * 64 + (u + kHalfPatch));
+        tab[ln][12 + i / 4] |= (uint32_t)(uint8_t)(int8_t)u << (8 * (i % 4));
+        tab[ln][15 + i / 4] |= (uint32_t)(uint8_t)(int8_t)v << (8 * (i % 4));
+      }
+      for (int k = 0; k < 4; k++)
+        for (int c = 0; c < 4; c++) {
+          const float fv = (float)h_pattern[4 * (64 * k + ln) + c];
+          memcpy(&tab[ln][18 + 4 * k + c], &fv, 4);
+        }
+    }
+    if (hipMemcpyToSymbol(HIP_SYMBOL(c_desc_tab), tab, sizeof(tab)) != hipSuccess) {
+      vo::set_error("hipMemcpyToSymbol(orientation / pattern table) failed");
       delete h;
       return VO_ERR_HIP;
     }
