@@ -334,7 +334,8 @@ __host__ __device__ __forceinline__ int fast_wave_lds(int tp, int tile_rows, int
 template <int TP, bool BYTEWISE>
 __global__ __launch_bounds__(256) void k_fast_wave(OrbDev P, FrameSrc src, uint32_t *cell_slots,
                                                    long long slots_frame_stride, int *cell_count,
-                                                   int cells_per_frame, int tile_rows, int max_interior) {
+                                                   int cells_per_frame, int tile_rows, int max_interior,
+                                                   const int *__restrict__ cell_tab) {
   extern __shared__ __attribute__((aligned(16))) uint8_t fast_lds[];
   constexpr int RP = 2 * TP;  // LDS row pitch: image row (TP bytes), then the score row of the same pixels
   const int lane = threadIdx.x & 63;
@@ -343,22 +344,26 @@ __global__ __launch_bounds__(256) void k_fast_wave(OrbDev P, FrameSrc src, uint3
   if (cell >= cells_per_frame) return;  // wave-uniform; the kernel has no workgroup barrier
   lds_u8 *tile_raw = (lds_u8 *)fast_lds + wave * fast_wave_lds(TP, tile_rows, max_interior);
   lds_u16 *plist = (lds_u16 *)(tile_raw + fast_align16(RP * tile_rows + 16));
-  int l = 0;
-  while (l + 1 < P.nlevels && cell >= P.lv[l + 1].cellBase) l++;
-  const LevelGeom &L = P.lv[l];
-  const int ci = cell - L.cellBase;
-  const int ci_i = ci / L.nCols, ci_j = ci - ci_i * L.nCols;
-  const int iniX = kBorder + ci_j * L.wCell, iniY = kBorder + ci_i * L.hCell;
+  // the cell's geometry comes from a table built with the handle (12 dwords by scalar loads) instead of a
+  // level search over the kernel arguments, which is a chain of dependent scalar round trips per wavefront
+  const int *cd = cell_tab + 16 * cell;
+  const int l = cd[0], iniX = cd[1], iniY = cd[2], cw = cd[3], ch = cd[4], xoff = cd[5], yoff = cd[6];
+  const int slot_off = cd[7], cap_cell = cd[8];
   int *out_count = cell_count + (long long)f * cells_per_frame + cell;
-  const int maxX = min(iniX + L.wCell + 6, L.maxBX), maxY = min(iniY + L.hCell + 6, L.maxBY);
-  const int cw = maxX - iniX, ch = maxY - iniY;
   const int iw = cw - 6, ih = ch - 6;
-  if (iniX >= L.maxBX - 6 || iniY >= L.maxBY - 3 || iw <= 0 || ih <= 0) {  // :801, :811; no interior pixel
+  if (iw <= 0 || ih <= 0) {  // :801, :811 (cw = 0 in the table), or no interior pixel
     if (lane == 0) *out_count = 0;
     return;
   }
   int pitch;
-  const uint8_t *img = level_plane(P, src, l, f, pitch);
+  const uint8_t *img;
+  if (l == 0) {
+    pitch = src.img0_pitch;
+    img = src.img0 + (long long)f * src.img0_frame_stride;
+  } else {
+    pitch = cd[9];
+    img = src.pyr + (long long)f * src.pyr_frame_stride + (((long long)cd[11] << 32) | (unsigned)cd[10]);
+  }
   // score rows start at 0: the 3-px margin around the interior is read by the NMS and never written
   for (int i = lane; i < ch * (TP / 8); i += 64) {
     const int r = i / (TP / 8), k = i - r * (TP / 8);
@@ -462,7 +467,7 @@ __global__ __launch_bounds__(256) void k_fast_wave(OrbDev P, FrameSrc src, uint3
     b[3 * RP + 3 + TP] = (uint8_t)m1;
     return m1 >= P.ini_th;
   });
-  uint32_t *slot = cell_slots + (long long)f * slots_frame_stride + L.slotBase + (long long)ci * L.capCell;
+  uint32_t *slot = cell_slots + (long long)f * slots_frame_stride + slot_off;
   int running = 0;
   for (int round = 0; round < 2; round++) {
     const int th = round == 0 ? P.ini_th : P.min_th;
@@ -498,15 +503,15 @@ __global__ __launch_bounds__(256) void k_fast_wave(OrbDev P, FrameSrc src, uint3
       }
       const unsigned long long mask = __builtin_amdgcn_ballot_w64(keep);
       const int off = running + __builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0u));
-      if (keep && off < L.capCell) {
+      if (keep && off < cap_cell) {
         const int y = pos / RP, x = pos - y * RP;  // interior coordinates; the cell-local ones are +3
-        slot[off] = (uint32_t)(x + 3 + ci_j * L.wCell) | ((uint32_t)(y + 3 + ci_i * L.hCell) << 12) | ((uint32_t)sc0 << 24);
+        slot[off] = (uint32_t)(x + 3 + xoff) | ((uint32_t)(y + 3 + yoff) << 12) | ((uint32_t)sc0 << 24);
       }
       running += __popcll(mask);
     }
     if (running > 0) break;  // :820 `if(vKeysCell.empty())` retry with minThFAST
   }
-  if (lane == 0) *out_count = min(running, L.capCell);
+  if (lane == 0) *out_count = min(running, cap_cell);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -909,25 +914,29 @@ __global__ __launch_bounds__(256) void k_blur(OrbDev P, FrameSrc src, int only_l
 // coalesced loads and stores.  Groups need x-4 >= 0 and x+7 <= w-1; the remaining <= 15 border
 // columns per row go through k_blur_border (direct 49-tap form, identical integer result because
 // the row pass is exact).
-__global__ __launch_bounds__(256) void k_blur_strips(OrbDev P, FrameSrc src, int lv0_generic) {
+__global__ __launch_bounds__(256) void k_blur_strips(FrameSrc src, int lv0_generic, const int *__restrict__ strip_tab,
+                                                     int n_strips) {
   const int lane = threadIdx.x & 63, f = blockIdx.y;
-  // wave-uniform job: the level's geometry then sits in scalar registers for the whole walk (left
-  // lane-dependent, its fields are re-fetched through vector memory around every store)
-  int job = blockIdx.x * 4 + __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
-  int l = 0;
-  while (l + 1 < P.nlevels && job >= P.lv[l + 1].stripBase) l++;
-  const LevelGeom &L = P.lv[l];
-  job -= L.stripBase;
-  if (job >= L.stripsX * L.stripsY) return;
+  // wave-uniform job whose geometry comes from a table built with the handle (scalar loads, no level search):
+  // it sits in scalar registers for the whole walk
+  const int job = blockIdx.x * 4 + __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
+  if (job >= n_strips) return;
+  const int *sd = strip_tab + 16 * job;
+  const int l = sd[0], sx = sd[1], sy = sd[2], Lh = sd[3], Lpitch = sd[4], groups = sd[5];
   if (l == 0 && lv0_generic) return;
-  const int Lh = L.h, Lpitch = L.pitch;
-  const int sy = job / L.stripsX, sx = job - sy * L.stripsX;
   const int g = sx * 64 + lane;
-  const bool active = g < L.blurGroups;
+  const bool active = g < groups;
   const int x = 4 + 4 * (active ? g : 0);
   int pitch;
-  const uint8_t *img = level_plane(P, src, l, f, pitch);
-  uint8_t *dst = src.blur + (long long)f * src.blur_frame_stride + L.blur_off;
+  const uint8_t *img;
+  if (l == 0) {
+    pitch = src.img0_pitch;
+    img = src.img0 + (long long)f * src.img0_frame_stride;
+  } else {
+    pitch = sd[8];
+    img = src.pyr + (long long)f * src.pyr_frame_stride + (((long long)sd[10] << 32) | (unsigned)sd[9]);
+  }
+  uint8_t *dst = src.blur + (long long)f * src.blur_frame_stride + (((long long)sd[7] << 32) | (unsigned)sd[6]);
   const int y0 = sy * 32, y1 = min(Lh, y0 + 32);
   const bool near = Lh >= 4;
   const unsigned K0 = 18u | (34u << 8) | (49u << 16) | (55u << 24);
@@ -1362,6 +1371,7 @@ struct vo_orb {
   long long pyr_frame = 0, blur_frame = 0, slots_frame = 0;
   int cells_frame = 0, keys_frame = 0, sel_frame = 0, tiles_frame = 0, max_kp = 0;
   int fast_tp = 48, fast_rows = 0, fast_interior = 0;  // k_fast_wave: LDS pitch, tile rows, list capacity
+  int cell_tab_off = 0, strip_tab_off = 0;             // per-cell / per-strip geometry tables (ints into `tables`)
   size_t fast_lds = 0;
   bool oct_small = false;
   size_t rz_lds[kMaxLevels] = {0};
@@ -1532,6 +1542,40 @@ int configure(vo_orb *h, int w, int h_img, int n_frames) {
     h->slots_frame = slots;
     h->cells_frame = cells;
     {
+      // k_fast_wave's per-cell geometry (16 ints per cell): level, cell origin and size incl. the 6-px overlap
+      // (size 0: the cell is skipped, :801 / :811), key offset of the cell, slot block, plane pitch / offset
+      while (tables.size() % 16) tables.push_back(0);
+      h->strip_tab_off = (int)tables.size();  // k_blur_strips: 16 ints per 64-group x 32-row strip
+      for (int l = 0; l < h->nlevels; l++) {
+        const LevelGeom &L = D.lv[l];
+        for (int j = 0; j < L.stripsX * L.stripsY; j++) {
+          const int e[16] = {l, j % L.stripsX, j / L.stripsX, L.h, L.pitch, L.blurGroups,
+                             (int)(unsigned)(L.blur_off & 0xffffffffLL), (int)(L.blur_off >> 32), L.pitch,
+                             (int)(unsigned)(L.pyr_off & 0xffffffffLL), (int)(L.pyr_off >> 32), 0, 0, 0, 0, 0};
+          tables.insert(tables.end(), e, e + 16);
+        }
+      }
+      h->cell_tab_off = (int)tables.size();
+      for (int l = 0; l < h->nlevels; l++) {
+        const LevelGeom &L = D.lv[l];
+        for (int ci = 0; ci < L.nCells; ci++) {
+          const int ci_i = ci / L.nCols, ci_j = ci - ci_i * L.nCols;
+          const int iniX = kBorder + ci_j * L.wCell, iniY = kBorder + ci_i * L.hCell;
+          const bool skip = iniX >= L.maxBX - 6 || iniY >= L.maxBY - 3;
+          const int maxX = std::min(iniX + L.wCell + 6, L.maxBX), maxY = std::min(iniY + L.hCell + 6, L.maxBY);
+          const long long so = L.slotBase + (long long)ci * L.capCell;
+          if (so > 0x7fffffffLL) {
+            vo::set_error("cell slot block of %lld entries per frame exceeds the 32-bit cell table", so);
+            return VO_ERR_CAPACITY;
+          }
+          const int e[16] = {l, iniX, iniY, skip ? 0 : maxX - iniX, skip ? 0 : maxY - iniY, ci_j * L.wCell, ci_i * L.hCell,
+                             (int)so, L.capCell, L.pitch, (int)(unsigned)(L.pyr_off & 0xffffffffLL), (int)(L.pyr_off >> 32),
+                             0, 0, 0, 0};
+          tables.insert(tables.end(), e, e + 16);
+        }
+      }
+    }
+    {
       int mw = 1, mh = 1;
       for (int l = 0; l < h->nlevels; l++)
         if (D.lv[l].nCols > 0) mw = std::max(mw, D.lv[l].wCell), mh = std::max(mh, D.lv[l].hCell);
@@ -1647,7 +1691,8 @@ int run_pipeline(vo_orb *h, const uint8_t *dev_images, int n_frames, int w, int 
   auto launch_blur = [&](hipStream_t bs) {
     const int lv0_generic = lv0_unaligned;
     if (h->strips_frame > 0)
-      hipLaunchKernelGGL(k_blur_strips, dim3((h->strips_frame + 3) / 4, n_frames), dim3(256), 0, bs, D, S, lv0_generic);
+      hipLaunchKernelGGL(k_blur_strips, dim3((h->strips_frame + 3) / 4, n_frames), dim3(256), 0, bs, S, lv0_generic,
+                         h->tables.as<int>() + h->strip_tab_off, h->strips_frame);
     hipLaunchKernelGGL(k_blur_border, dim3((h->border_rows_frame + 15) / 16, n_frames), dim3(256), 0, bs, D, S, lv0_generic);
     if (lv0_generic) hipLaunchKernelGGL(k_blur, dim3(h->tiles_frame, n_frames), dim3(256), 0, bs, D, S, 0);
   };
@@ -1662,7 +1707,8 @@ int run_pipeline(vo_orb *h, const uint8_t *dev_images, int n_frames, int w, int 
     auto fast = h->fast_tp == 48 ? (lv0_unaligned ? k_fast_wave<48, true> : k_fast_wave<48, false>)
                                  : (lv0_unaligned ? k_fast_wave<kTileP, true> : k_fast_wave<kTileP, false>);
     hipLaunchKernelGGL(fast, grid, dim3(256), h->fast_lds, st, D, S, h->slots.as<uint32_t>(), h->slots_frame,
-                       h->cellcnt.as<int>(), h->cells_frame, h->fast_rows, h->fast_interior);
+                       h->cellcnt.as<int>(), h->cells_frame, h->fast_rows, h->fast_interior,
+                       h->tables.as<int>() + h->cell_tab_off);
   }
   VO_STAGE_MARK(2);
   if (h->oct_small)
