@@ -440,33 +440,43 @@ __global__ __launch_bounds__(256) void k_fast_wave(OrbDev P, FrameSrc src, uint3
   // and an odd last row (two-row steps) is a separate step for the lanes of the first row.  `body` returns
   // the lane's hit; hits are appended in lane order = raster order.
   int np = 0;
-  auto walk = [&](auto body) {
+  // `load` fetches a step's tile bytes, `eval` turns them into the lane's hit (and may store): two steps are
+  // loaded before either is evaluated, which halves the LDS round trips a wave waits for.
+  auto walk = [&](auto load, auto eval) {
     int n = 0;
     if (lx < iw) {
       lds_u8 *b = b0;
       asm("" : "+v"(b));  // one address register, advanced by a scalar: the accesses below are register + immediate
       int row = 0;
-      auto step = [&]() {
-        const bool hit = body(b);
+      auto append = [&](bool hit, lds_u8 *bb) {
         const unsigned long long mask = __builtin_amdgcn_ballot_w64(hit);
         if (hit) plist[n + __builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0u))] =
-            (unsigned short)(unsigned)(uintptr_t)b;
+            (unsigned short)(unsigned)(uintptr_t)bb;
         n += __popcll(mask);
       };
-      for (; row + ri <= ih; row += ri, b += ri * RP) step();
-      if (row < ih && ly == 0) step();
+      for (; row + 2 * ri <= ih; row += 2 * ri, b += 2 * ri * RP) {
+        lds_u8 *b1 = b + ri * RP;
+        const auto va = load(b), vb = load(b1);
+        append(eval(b, va), b);
+        append(eval(b1, vb), b1);
+      }
+      if (row + ri <= ih) {
+        append(eval(b, load(b)), b);
+        row += ri, b += ri * RP;
+      }
+      if (row < ih && ly == 0) append(eval(b, load(b)), b);
     }
     return __builtin_amdgcn_readlane(n, 0);  // lane 0 always takes part
   };
-  np = walk([&](lds_u8 *b) {
-    const int v = b[3 * RP + 3];
-    const int p0 = b[6 * RP + 3], p4 = b[3 * RP + 6], p8 = b[3], p12 = b[3 * RP];
-    const int mb = min(max(p0, p8), max(p4, p12));
-    const int md = max(min(p0, p8), min(p4, p12));
-    const int m1 = max(max(mb + ~v, v + ~md), 0);  // max(m - 1, 0)
-    b[3 * RP + 3 + TP] = (uint8_t)m1;
-    return m1 >= P.ini_th;
-  });
+  struct Ring5 { int v, p0, p4, p8, p12; };
+  np = walk([&](lds_u8 *b) { return Ring5{b[3 * RP + 3], b[6 * RP + 3], b[3 * RP + 6], b[3], b[3 * RP]}; },
+            [&](lds_u8 *b, const Ring5 &r) {
+              const int mb = min(max(r.p0, r.p8), max(r.p4, r.p12));
+              const int md = max(min(r.p0, r.p8), min(r.p4, r.p12));
+              const int m1 = max(max(mb + ~r.v, r.v + ~md), 0);  // max(m - 1, 0)
+              b[3 * RP + 3 + TP] = (uint8_t)m1;
+              return m1 >= P.ini_th;
+            });
   uint32_t *slot = cell_slots + (long long)f * slots_frame_stride + slot_off;
   int running = 0;
   for (int round = 0; round < 2; round++) {
@@ -474,7 +484,7 @@ __global__ __launch_bounds__(256) void k_fast_wave(OrbDev P, FrameSrc src, uint3
     if (round == 1) {
       // A cell with no key-point at iniThFAST is redone at minThFAST (:820-824): the survivors are the
       // pixels whose tile entry (margin bound, or score where already computed) reaches minThFAST.
-      np = walk([&](lds_u8 *b) { return (int)b[3 * RP + 3 + TP] >= th; });
+      np = walk([&](lds_u8 *b) { return (int)b[3 * RP + 3 + TP]; }, [&](lds_u8 *, int e) { return e >= th; });
     }
     wave_sync();
     // ---- phase 2: full arc score only for the survivors
