@@ -12,36 +12,59 @@ namespace {
 
 using namespace vo;
 
-// K6: D[i][j] = popcount(A_i xor B_j) over 256 bits.  Each thread keeps two B descriptors in
-// registers (16 VGPRs) and streams a 32-row A tile from LDS (all lanes read the same address:
-// a broadcast, no bank conflict); results leave as one 4-byte store per lane per row, i.e. 256
-// contiguous bytes per wavefront -- the kernel is bound by the 2 bytes/pair it writes.
+// K6: D[i][j] = popcount(A_i xor B_j) over 256 bits.  A workgroup owns 512 columns x 128 rows: each thread
+// keeps two B descriptors in registers (fetched as four 16-byte loads: a wavefront reads 4 KB contiguous) and
+// streams the 128-row A tile from LDS (all lanes read the same address: a broadcast, no bank conflict);
+// results leave as one 4-byte store per lane per row, i.e. 256 contiguous bytes per wavefront -- the kernel
+// is bound by the 2 bytes/pair it writes and by the 16 vector instructions a distance costs.
+constexpr int kHamRows = 128;
+typedef uint32_t ham_u32x4 __attribute__((ext_vector_type(4)));
+
 __global__ __launch_bounds__(256) void k_hamming(const uint32_t *A, int na, long long a_stride,
                                                  const uint32_t *B, int nb, long long b_stride,
                                                  uint16_t *D, long long d_stride) {
-  __shared__ uint32_t a[32][8];
+  __shared__ __attribute__((aligned(16))) uint32_t a[kHamRows][8];
   const int tid = threadIdx.x;
   const long long p = blockIdx.z;
   A += p * a_stride * 8;
   B += p * b_stride * 8;
   D += p * d_stride;
-  const int i0 = blockIdx.y * 32;
+  const int i0 = blockIdx.y * kHamRows;
   const int j0 = (blockIdx.x * 256 + tid) * 2;
-  {
-    const int r = tid >> 3, w = tid & 7;
-    a[r][w] = (i0 + r < na) ? A[(long long)(i0 + r) * 8 + w] : 0u;
+  const bool wide = ((reinterpret_cast<uintptr_t>(A) | reinterpret_cast<uintptr_t>(B)) & 15) == 0;  // uniform
+  for (int c = tid; c < kHamRows * 2; c += 256) {  // 16-byte chunk c of the tile: row c / 2, half c & 1
+    const int r = c >> 1;
+    ham_u32x4 v = {0u, 0u, 0u, 0u};
+    if (i0 + r < na) {
+      const uint32_t *src = A + (long long)(i0 + r) * 8 + 4 * (c & 1);
+      if (wide)
+        v = *reinterpret_cast<const ham_u32x4 *>(src);
+      else
+        v = ham_u32x4{src[0], src[1], src[2], src[3]};
+    }
+    *reinterpret_cast<ham_u32x4 *>(&a[r][4 * (c & 1)]) = v;
   }
   uint32_t b0[8], b1[8];
+  {
+    ham_u32x4 q[4] = {{0u, 0u, 0u, 0u}, {0u, 0u, 0u, 0u}, {0u, 0u, 0u, 0u}, {0u, 0u, 0u, 0u}};
+    // the last column of an odd nb is clamped, not predicated (a predicated load becomes a branch)
+    const uint32_t *s0 = B + (long long)min(j0, nb - 1) * 8, *s1 = B + (long long)min(j0 + 1, nb - 1) * 8;
+    if (wide) {
+      q[0] = reinterpret_cast<const ham_u32x4 *>(s0)[0], q[1] = reinterpret_cast<const ham_u32x4 *>(s0)[1];
+      q[2] = reinterpret_cast<const ham_u32x4 *>(s1)[0], q[3] = reinterpret_cast<const ham_u32x4 *>(s1)[1];
+    } else {
 #pragma unroll
-  for (int w = 0; w < 8; w++) {
-    b0[w] = j0 < nb ? B[(long long)j0 * 8 + w] : 0u;
-    b1[w] = j0 + 1 < nb ? B[(long long)(j0 + 1) * 8 + w] : 0u;
+      for (int w = 0; w < 4; w++) q[0][w] = s0[w], q[1][w] = s0[4 + w], q[2][w] = s1[w], q[3][w] = s1[4 + w];
+    }
+#pragma unroll
+    for (int w = 0; w < 4; w++) b0[w] = q[0][w], b0[4 + w] = q[1][w], b1[w] = q[2][w], b1[4 + w] = q[3][w];
   }
   __syncthreads();
   if (j0 >= nb) return;
   const bool pair_store = ((nb & 1) == 0);
-  const int rows = min(32, na - i0);
-  for (int r = 0; r < rows; r++) {
+  const int rows = min(kHamRows, na - i0);
+  uint16_t *o = D + (long long)i0 * nb + j0;
+  for (int r = 0; r < rows; r++, o += nb) {
     int d0 = 0, d1 = 0;
 #pragma unroll
     for (int w = 0; w < 8; w++) {
@@ -49,7 +72,6 @@ __global__ __launch_bounds__(256) void k_hamming(const uint32_t *A, int na, long
       d0 += __popc(av ^ b0[w]);
       d1 += __popc(av ^ b1[w]);
     }
-    uint16_t *o = D + (long long)(i0 + r) * nb + j0;
     if (pair_store) {
       *reinterpret_cast<uint32_t *>(o) = (uint32_t)d0 | ((uint32_t)d1 << 16);
     } else {
@@ -62,7 +84,7 @@ __global__ __launch_bounds__(256) void k_hamming(const uint32_t *A, int na, long
 int launch_hamming(const uint8_t *a, int na, size_t as, const uint8_t *b, int nb, size_t bs, uint16_t *d,
                    size_t ds, int n_pairs, hipStream_t st) {
   if (na <= 0 || nb <= 0 || n_pairs <= 0) return VO_OK;
-  dim3 grid((nb + 511) / 512, (na + 31) / 32, n_pairs);
+  dim3 grid((nb + 511) / 512, (na + kHamRows - 1) / kHamRows, n_pairs);
   hipLaunchKernelGGL(k_hamming, grid, dim3(256), 0, st, reinterpret_cast<const uint32_t *>(a), na, (long long)as,
                      reinterpret_cast<const uint32_t *>(b), nb, (long long)bs, d, (long long)ds);
   VO_HIP_CHECK(hipGetLastError());
