@@ -612,6 +612,35 @@ __global__ __launch_bounds__(256) void k_octree(OrbDev P, const uint32_t *cell_s
   if (tid == 0) cand_count[f * P.nlevels + l] = n;
   __syncthreads();
   __threadfence_block();
+  // Keys and their node labels stay in registers for the passes below when the level has at most 256 x 8
+  // candidates (the usual case by far): a pass is then LDS traffic and barriers only, instead of two global
+  // round trips per key.  `for_keys(body)`: body(k, key, label) may change the label.
+  constexpr int KR = 8;
+  const bool inreg = n <= 256 * KR;  // uniform
+  uint32_t kreg[KR];
+  int lreg[KR];
+#pragma unroll
+  for (int e = 0; e < KR; e++) {
+    const int k = tid + 256 * e;
+    kreg[e] = (inreg && k < n) ? kd[k] : 0u;
+    lreg[e] = 0;
+  }
+  auto for_keys = [&](auto body) {
+    if (inreg) {
+#pragma unroll
+      for (int e = 0; e < KR; e++) {
+        const int k = tid + 256 * e;
+        if (k < n) body(k, kreg[e], lreg[e]);
+      }
+    } else {
+      for (int k = tid; k < n; k += 256) {
+        int lab = kl[k];
+        const int lab0 = lab;
+        body(k, kd[k], lab);
+        if (lab != lab0) kl[k] = (unsigned short)lab;
+      }
+    }
+  };
 
   // ---- root nodes (:549-590)
   int cur = 0;
@@ -619,13 +648,15 @@ __global__ __launch_bounds__(256) void k_octree(OrbDev P, const uint32_t *cell_s
   const int H = L.maxBY - kBorder;
   for (int i = tid; i < CAP * 4; i += 256) S.ccount[i] = 0;
   __syncthreads();
-  for (int k = tid; k < n; k += 256) {
-    const int kx = kd[k] & 0xfff;
+  if (!inreg)
+    for (int k = tid; k < n; k += 256) kl[k] = 0xffff;  // for_keys stores a label only when it changes
+  for_keys([&](int, uint32_t kv, int &lab) {
+    const int kx = kv & 0xfff;
     int b = (int)((float)kx / L.hX);
     b = min(max(b, 0), nIni - 1);
-    kl[k] = (unsigned short)b;  // provisional: root index
+    lab = b;  // provisional: root index
     atomicAdd(&S.ccount[b], 1);
-  }
+  });
   __syncthreads();
   int size = 0;
   {
@@ -649,7 +680,7 @@ __global__ __launch_bounds__(256) void k_octree(OrbDev P, const uint32_t *cell_s
     }
     __syncthreads();
     size = S.s_newsize;
-    for (int k = tid; k < n; k += 256) kl[k] = S.newpos_old[kl[k]];
+    for_keys([&](int, uint32_t, int &lab) { lab = S.newpos_old[lab]; });
     __syncthreads();
   }
 
@@ -704,15 +735,14 @@ __global__ __launch_bounds__(256) void k_octree(OrbDev P, const uint32_t *cell_s
     // (2) key pass 1: child occupancy
     for (int i = tid; i < m * 4; i += 256) S.ccount[i] = 0;
     __syncthreads();
-    for (int k = tid; k < n; k += 256) {
-      const int pos = kl[k];
+    for_keys([&](int, uint32_t kv, int &lab) {
+      const int pos = lab;
       const int r = S.prank[pos];
-      if (r == 0xffff) continue;
-      const uint32_t kv = kd[k];
+      if (r == 0xffff) return;
       const int q = quadrant_of(kv & 0xfff, (kv >> 12) & 0xfff, S.x0[cur][pos], S.y0[cur][pos], S.x1[cur][pos],
                                 S.y1[cur][pos]);
       atomicAdd(&S.ccount[r * 4 + q], 1);
-    }
+    });
     __syncthreads();
     // (3) prefix over processing ranks: nonempty children, cut-off
     {
@@ -806,18 +836,17 @@ __global__ __launch_bounds__(256) void k_octree(OrbDev P, const uint32_t *cell_s
       __syncthreads();
       const int newsize = totalChildren + keptTotal;
       // (5) key pass 2: relabel
-      for (int k = tid; k < n; k += 256) {
-        const int pos = kl[k];
+      for_keys([&](int, uint32_t kv, int &lab) {
+        const int pos = lab;
         const int r = S.prank[pos];
         if (r != 0xffff && r <= cutoff) {
-          const uint32_t kv = kd[k];
           const int q = quadrant_of(kv & 0xfff, (kv >> 12) & 0xfff, S.x0[cur][pos], S.y0[cur][pos],
                                     S.x1[cur][pos], S.y1[cur][pos]);
-          kl[k] = S.newpos_child[r * 4 + q];
+          lab = S.newpos_child[r * 4 + q];
         } else {
-          kl[k] = S.newpos_old[pos];
+          lab = S.newpos_old[pos];
         }
-      }
+      });
       __syncthreads();
       const int nToExpand = S.s_nexp;
       cur = nxt;
@@ -837,12 +866,12 @@ __global__ __launch_bounds__(256) void k_octree(OrbDev P, const uint32_t *cell_s
   // ---- best response per node, first key wins ties (:748-766)
   for (int i = tid; i < CAP; i += 256) S.best[i] = 0;
   __syncthreads();
-  for (int k = tid; k < n; k += 256) {
-    const int pos = kl[k];
-    if (pos >= CAP) continue;
-    const unsigned int v = ((kd[k] >> 24) << 16) | (unsigned int)(65535 - k);
+  for_keys([&](int k, uint32_t kv, int &lab) {
+    const int pos = lab;
+    if (pos >= CAP) return;
+    const unsigned int v = ((kv >> 24) << 16) | (unsigned int)(65535 - k);
     atomicMax(&S.best[pos], v);
-  }
+  });
   __syncthreads();
   uint32_t *out = sel + (long long)f * sel_per_frame + L.selBase;
   const int nout = min(size, L.capSel);
