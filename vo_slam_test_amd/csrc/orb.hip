@@ -601,8 +601,16 @@ __global__ __launch_bounds__(256) void k_octree(OrbDev P, const uint32_t *cell_s
     const int cnt = c < L.nCells ? cc[c] : 0;
     int tot;
     const int off = n + block_excl_scan(cnt, S.wsum, &tot);
-    for (int e = 0; e < cnt; e++)
-      if (off + e < L.candCap) kd[off + e] = slots[(long long)c * L.capCell + e];
+    // four entries per round trip: written one by one, every load would wait behind the previous store
+    // (the compiler cannot prove that `kd` and `slots` do not alias)
+    for (int e0 = 0; e0 < cnt; e0 += 4) {
+      uint32_t v[4];
+#pragma unroll
+      for (int u = 0; u < 4; u++) v[u] = slots[(long long)c * L.capCell + min(e0 + u, cnt - 1)];
+#pragma unroll
+      for (int u = 0; u < 4; u++)
+        if (e0 + u < cnt && off + e0 + u < L.candCap) kd[off + e0 + u] = v[u];
+    }
     n += tot;
   }
   if (n > L.candCap) {
