@@ -717,26 +717,31 @@ __global__ __launch_bounds__(256) void k_octree(OrbDev P, const uint32_t *cell_s
     }
     __syncthreads();
     if (careful && m > 1) {
-      // rank by (count desc, seq desc): :690 sorts ascending and walks from the back
-      unsigned short newrank[4];
-      for (int e = 0; e < 4; e++) {
-        newrank[e] = 0xffff;
-        if (!myflag[e]) continue;
-        const int pos = tid * 4 + e;
-        const unsigned int mykey = ((unsigned int)S.cnt[cur][pos] << 16) | S.seq[cur][pos];
-        int r = 0;
-        for (int j = 0; j < m; j++) {
-          const int p2 = S.order[j];
-          const unsigned int k2 = ((unsigned int)S.cnt[cur][p2] << 16) | S.seq[cur][p2];
-          r += (k2 > mykey) ? 1 : 0;
-        }
-        newrank[e] = (unsigned short)r;
+      // rank by (count desc, seq desc): :690 sorts ascending and walks from the back.  One expandable node per
+      // thread (in list-order rank j), its packed key compared with all m keys through broadcast LDS reads.
+      for (int j = tid; j < m; j += 256) {
+        const int p2 = S.order[j];
+        S.cprefix[j] = (int)(((unsigned int)S.cnt[cur][p2] << 16) | S.seq[cur][p2]);  // scratch until step (3)
       }
       __syncthreads();
-      for (int e = 0; e < 4; e++)
-        if (myflag[e]) {
-          S.prank[tid * 4 + e] = newrank[e];
-          S.order[newrank[e]] = (unsigned short)(tid * 4 + e);
+      int mypos[CAP / 256], myr[CAP / 256];
+#pragma unroll
+      for (int u = 0; u < CAP / 256; u++) {
+        const int j = tid + 256 * u;
+        mypos[u] = -1, myr[u] = 0;
+        if (j >= m) continue;
+        mypos[u] = S.order[j];
+        const unsigned int mykey = (unsigned int)S.cprefix[j];
+        int r = 0;
+        for (int i = 0; i < m; i++) r += ((unsigned int)S.cprefix[i] > mykey) ? 1 : 0;
+        myr[u] = r;
+      }
+      __syncthreads();
+#pragma unroll
+      for (int u = 0; u < CAP / 256; u++)
+        if (mypos[u] >= 0) {
+          S.prank[mypos[u]] = (unsigned short)myr[u];
+          S.order[myr[u]] = (unsigned short)mypos[u];
         }
       __syncthreads();
     }
