@@ -47,8 +47,7 @@ struct LevelGeom {
   float scale;
   int patchSize;
   int tileBase, tilesX, tilesY;
-  // fast blur: 4-pixel groups at x = 4 + 4*g, g < blurGroups; wave strips of 64 groups x 32 rows
-  int blurGroups, stripsX, stripsY, stripBase, borderRowBase;
+  int pad_[5];  // (formerly blur strip bookkeeping; kept so that the argument layout is unchanged)
 };
 
 struct OrbDev {
@@ -918,7 +917,7 @@ __device__ __forceinline__ int reflect101(int i, int n) {
 // same result for -n < i < 2n - 1 (the blur apron of 3 with n >= 4), without the loop
 __device__ __forceinline__ int reflect101_near(int i, int n) { return i < 0 ? -i : (i >= n ? 2 * n - 2 - i : i); }
 
-__global__ __launch_bounds__(256) void k_blur(OrbDev P, FrameSrc src, int only_level) {
+__global__ __launch_bounds__(256) void k_blur(OrbDev P, FrameSrc src, unsigned level_mask) {
   __shared__ uint8_t t[22][72];
   __shared__ int hs[22][64];
   const int kq[7] = {18, 34, 49, 55, 49, 34, 18};
@@ -927,7 +926,7 @@ __global__ __launch_bounds__(256) void k_blur(OrbDev P, FrameSrc src, int only_l
   int l = 0;
   while (l + 1 < P.nlevels && tile >= P.lv[l + 1].tileBase) l++;
   const LevelGeom &L = P.lv[l];
-  if (only_level >= 0 && l != only_level) return;
+  if (!((level_mask >> l) & 1u)) return;
   tile -= L.tileBase;
   const int ty = tile / L.tilesX, tx = tile - ty * L.tilesX;
   const int x0 = tx * 64, y0 = ty * 16;
@@ -959,38 +958,74 @@ __global__ __launch_bounds__(256) void k_blur(OrbDev P, FrameSrc src, int only_l
   }
 }
 
-// Fast path of the same filter.  One wavefront owns a strip of 64 four-pixel groups x 32 rows and
-// walks it top to bottom: per source row every lane loads the three aligned dwords around its
-// group, forms the four 7-tap row sums with v_alignbyte + v_dot4_u32_u8, keeps a 7-row sliding
-// window of row sums in registers and emits one packed dword of output per row.  No LDS, 4-byte
-// coalesced loads and stores.  Groups need x-4 >= 0 and x+7 <= w-1; the remaining <= 15 border
-// columns per row go through k_blur_border (direct 49-tap form, identical integer result because
-// the row pass is exact).
-__global__ __launch_bounds__(256) void k_blur_strips(FrameSrc src, int lv0_generic, const int *__restrict__ strip_tab,
-                                                     int n_strips) {
-  const int lane = threadIdx.x & 63, f = blockIdx.y;
-  // wave-uniform job whose geometry comes from a table built with the handle (scalar loads, no level search):
-  // it sits in scalar registers for the whole walk
+// Fast path of the same filter.  A wavefront owns 16 four-pixel groups x 32 rows of FOUR consecutive frames
+// (lane = frame * 16 + group: the level geometry, hence the row walk, is the same for all of them, and 16-group
+// blocks fit the level widths far better than 64-group ones) and walks them top to bottom: per source row
+// every lane loads the three aligned dwords around its group (row base in scalar registers, the lane's frame
+// and column in a constant register offset), forms the four 7-tap row sums with v_alignbyte + v_dot4_u32_u8,
+// keeps a 7-row sliding window of row sums in registers and emits one packed dword of output per row.  No
+// LDS, 4-byte coalesced loads and stores.  The groups at the two ends of a row need pixels reflected about
+// the first / last column (BORDER_REFLECT_101): blocks that contain them (wave-uniform) rebuild the affected
+// dwords with byte permutes whose selectors are constant per lane.
+constexpr int kBlurB = 16;                   // groups per block
+constexpr int kBlurF = 64 / kBlurB;          // frames per wavefront
+constexpr int kBlurMinW = 24, kBlurMinH = 4; // smaller levels take the generic kernel
+
+__global__ __launch_bounds__(256) void k_blur_groups(FrameSrc src, int lv0_generic, const int *__restrict__ job_tab,
+                                                     int n_jobs, int n_frames) {
+  const int lane = threadIdx.x & 63;
   const int job = blockIdx.x * 4 + __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
-  if (job >= n_strips) return;
-  const int *sd = strip_tab + 16 * job;
-  const int l = sd[0], sx = sd[1], sy = sd[2], Lh = sd[3], Lpitch = sd[4], groups = sd[5];
+  if (job >= n_jobs) return;
+  // wave-uniform job whose geometry comes from a table built with the handle: scalar registers for the whole walk
+  const int *sd = job_tab + 16 * job;
+  const int l = sd[0], cb = sd[1], sy = sd[2], Lh = sd[3], Lpitch = sd[4], ngroups = sd[5], w = sd[11];
   if (l == 0 && lv0_generic) return;
-  const int g = sx * 64 + lane;
-  const bool active = g < groups;
-  const int x = 4 + 4 * (active ? g : 0);
+  const int f0 = blockIdx.y * kBlurF, fo = lane / kBlurB;
+  const bool fvalid = f0 + fo < n_frames;
+  const int fl = fvalid ? fo : 0;  // lanes past the batch repeat its first frame (not stored)
+  const int G = min(cb * kBlurB + (lane & (kBlurB - 1)), ngroups - 1), x = 4 * G;
+  const bool active = fvalid && cb * kBlurB + (lane & (kBlurB - 1)) < ngroups;
   int pitch;
   const uint8_t *img;
+  unsigned fsrc;
   if (l == 0) {
     pitch = src.img0_pitch;
-    img = src.img0 + (long long)f * src.img0_frame_stride;
+    img = src.img0 + (long long)f0 * src.img0_frame_stride;
+    fsrc = (unsigned)(fl * src.img0_frame_stride);
   } else {
     pitch = sd[8];
-    img = src.pyr + (long long)f * src.pyr_frame_stride + (((long long)sd[10] << 32) | (unsigned)sd[9]);
+    img = src.pyr + (long long)f0 * src.pyr_frame_stride + (((long long)sd[10] << 32) | (unsigned)sd[9]);
+    fsrc = (unsigned)(fl * src.pyr_frame_stride);
   }
-  uint8_t *dst = src.blur + (long long)f * src.blur_frame_stride + (((long long)sd[7] << 32) | (unsigned)sd[6]);
+  uint8_t *dst = src.blur + (long long)f0 * src.blur_frame_stride + (((long long)sd[7] << 32) | (unsigned)sd[6]) +
+                 (long long)fl * src.blur_frame_stride + x;
+  // the three dwords of the lane: columns x-4.., x.., x+4..; at the row ends the neighbour is replaced by the
+  // group itself (never read outside the row) and rebuilt below
+  const unsigned vC = fsrc + (unsigned)x, vL = vC - (G > 0 ? 4u : 0u), vR = vC + (x + 4 < pitch ? 4u : 0u);
+  // edge blocks: window byte k = 0..11 is pixel x - 4 + k; beyond the row it is the pixel reflected about the
+  // last column, which lies at window byte k' >= 1 whenever a stored pixel needs it
+  const bool edge_job = cb == 0 || (cb + 1) * kBlurB * 4 + 4 > w;  // uniform
+  unsigned selC = 0x07060504u, selRA = 0x07060504u, selRB = 0u, selL = 0x03020100u;
+  bool caseB = false, left = false;
+  if (edge_job) {
+    auto srck = [&](int k) {
+      int i = x - 4 + k;
+      if (i > w - 1) i = 2 * (w - 1) - i;
+      return min(max(i - (x - 4), 0), 11);
+    };
+    selC = 0, selRA = 0, selRB = 0;
+#pragma unroll
+    for (int b = 0; b < 4; b++) {
+      const int kc = srck(4 + b), kr = srck(8 + b);
+      selC |= (unsigned)min(kc, 7) << (8 * b);           // perm(C, L): 0..3 = L, 4..7 = C
+      selRA |= (unsigned)min(max(kr - 4, 0), 7) << (8 * b);  // perm(R, C): 0..3 = C, 4..7 = R
+      selRB |= (unsigned)min(kr, 7) << (8 * b);          // perm(C, L)
+    }
+    caseB = x + 4 > w - 1;  // the right neighbour lies entirely beyond the row
+    left = G == 0;          // pixels -4..-1 are pixels 4..1: bytes R0, C3, C2, C1 of perm(R, C)
+    selL = 0x01020304u;
+  }
   const int y0 = sy * 32, y1 = min(Lh, y0 + 32);
-  const bool near = Lh >= 4;
   const unsigned K0 = 18u | (34u << 8) | (49u << 16) | (55u << 24);
   const unsigned K1 = 49u | (34u << 8) | (18u << 16);
   int hw[7][4];
@@ -1007,17 +1042,24 @@ __global__ __launch_bounds__(256) void k_blur_strips(FrameSrc src, int lv0_gener
 #pragma unroll
     for (int u = 0; u < RB; u++) {
       const int yq = min(yb + u, y1 + 2);  // rows past the strip repeat its last one (unused)
-      const int ry = near ? reflect101_near(yq, Lh) : reflect101(yq, Lh);
-      const uint8_t *row = img + (long long)ry * pitch + x;
-      Lr[u] = *reinterpret_cast<const unsigned *>(row - 4);
-      Cr[u] = *reinterpret_cast<const unsigned *>(row);
-      Rr[u] = *reinterpret_cast<const unsigned *>(row + 4);
+      const uint8_t *row = img + (long long)reflect101_near(yq, Lh) * pitch;  // scalar
+      Lr[u] = *reinterpret_cast<const unsigned *>(row + vL);
+      Cr[u] = *reinterpret_cast<const unsigned *>(row + vC);
+      Rr[u] = *reinterpret_cast<const unsigned *>(row + vR);
     }
 #pragma unroll
     for (int u = 0; u < RB; u++) {
       const int yy = yb + u;
       if (yy >= y1 + 3) break;  // uniform
-      const unsigned Lw = Lr[u], Cw = Cr[u], Rw = Rr[u];
+      unsigned Lw = Lr[u], Cw = Cr[u], Rw = Rr[u];
+      if (edge_job) {  // uniform
+        const unsigned l2 = __builtin_amdgcn_perm(Rw, Cw, selL);
+        const unsigned c2 = __builtin_amdgcn_perm(Cw, Lw, selC);
+        const unsigned ra = __builtin_amdgcn_perm(Rw, Cw, selRA), rb = __builtin_amdgcn_perm(Cw, Lw, selRB);
+        Lw = left ? l2 : Lw;
+        Rw = caseB ? rb : ra;
+        Cw = c2;
+      }
 #pragma unroll
       for (int j = 0; j < 6; j++)
 #pragma unroll
@@ -1035,58 +1077,7 @@ __global__ __launch_bounds__(256) void k_blur_strips(FrameSrc src, int lv0_gener
           const unsigned v = (unsigned)min((acc + (1 << 15)) >> 16, 255);
           outw |= v << (8 * q);
         }
-        if (active) *reinterpret_cast<unsigned *>(dst + (long long)(yy - 3) * Lpitch + x) = outw;
-      }
-    }
-  }
-}
-
-// border columns of the blur: x in [0,4) and [4 + 4*blurGroups, w), at most 4 + 11 per row.  One
-// lane owns one border column over a 32-row band and walks down it with the same 7-row sliding
-// window as the strip kernel (7 reflected column indices are fixed per lane).
-__global__ __launch_bounds__(256) void k_blur_border(OrbDev P, FrameSrc src, int lv0_generic) {
-  const int f = blockIdx.y;
-  int band = blockIdx.x * 16 + (threadIdx.x >> 4);  // 16 bands per block, 16 column slots per band
-  const int ci = threadIdx.x & 15;
-  int l = 0;
-  while (l + 1 < P.nlevels && band >= P.lv[l + 1].borderRowBase) l++;
-  const LevelGeom &L = P.lv[l];
-  band -= L.borderRowBase;
-  if (band >= L.stripsY || (l == 0 && lv0_generic)) return;
-  const int xr = 4 + 4 * L.blurGroups;
-  const int x = ci < 4 ? ci : xr + (ci - 4);
-  if (x >= L.w || (ci < 4 && x >= xr)) return;
-  int pitch;
-  const uint8_t *img = level_plane(P, src, l, f, pitch);
-  uint8_t *dst = src.blur + (long long)f * src.blur_frame_stride + L.blur_off;
-  int xi[7];
-#pragma unroll
-  for (int i = 0; i < 7; i++) xi[i] = reflect101(x + i - 3, L.w);
-  const int Lh = L.h, Lpitch = L.pitch;  // read once: the stores below would force a re-fetch
-  const bool near = Lh >= 4;
-  const int y0 = band * 32, y1 = min(Lh, y0 + 32);
-  int hw[7] = {0, 0, 0, 0, 0, 0, 0};
-  constexpr int RB = 6;  // rows per batch: all 42 loads are issued before the first store (see k_blur_strips)
-  for (int yb = y0 - 3; yb < y1 + 3; yb += RB) {
-    int px[RB][7];
-#pragma unroll
-    for (int u = 0; u < RB; u++) {
-      const int yq = min(yb + u, y1 + 2);
-      const uint8_t *row = img + (long long)(near ? reflect101_near(yq, Lh) : reflect101(yq, Lh)) * pitch;
-#pragma unroll
-      for (int i = 0; i < 7; i++) px[u][i] = row[xi[i]];
-    }
-#pragma unroll
-    for (int u = 0; u < RB; u++) {
-      const int yy = yb + u;
-      if (yy >= y1 + 3) break;
-      const int hsum = 18 * (px[u][0] + px[u][6]) + 34 * (px[u][1] + px[u][5]) + 49 * (px[u][2] + px[u][4]) + 55 * px[u][3];
-#pragma unroll
-      for (int j = 0; j < 6; j++) hw[j] = hw[j + 1];
-      hw[6] = hsum;
-      if (yy >= y0 + 3) {
-        const int acc = 18 * (hw[0] + hw[6]) + 34 * (hw[1] + hw[5]) + 49 * (hw[2] + hw[4]) + 55 * hw[3];
-        dst[(long long)(yy - 3) * Lpitch + x] = (uint8_t)min((acc + (1 << 15)) >> 16, 255);
+        if (active) *reinterpret_cast<unsigned *>(dst + (long long)(yy - 3) * Lpitch) = outw;  // the tail lands in the row padding
       }
     }
   }
@@ -1428,7 +1419,8 @@ struct vo_orb {
   bool oct_small = false;
   size_t rz_lds[kMaxLevels] = {0};
   int rz_dwords[kMaxLevels] = {0};  // every level's node list fits k_octree<256>
-  int strips_frame = 0, border_rows_frame = 0;
+  int blur_jobs = 0;               // k_blur_groups jobs per frame quad
+  unsigned blur_generic_mask = 0;  // levels blurred by the generic kernel
   std::vector<int> tab_off;  // per level: offsets of xofs,xab,yofs,yab in tables
   vo::DevBuf tables, pyr, blur, slots, cellcnt, keydata, keylabel, candcnt, sel, nk, off, err;
   vo::DevBuf in_img, out_kp, out_desc, out_cnt;
@@ -1555,13 +1547,6 @@ int configure(vo_orb *h, int w, int h_img, int n_frames) {
       L.tilesY = (L.h + 15) / 16;
       L.tileBase = tiles;
       tiles += L.tilesX * L.tilesY;
-      L.blurGroups = L.w >= 12 ? (L.w - 12) / 4 + 1 : 0;
-      L.stripsX = (L.blurGroups + 63) / 64;
-      L.stripsY = (L.h + 31) / 32;
-      L.stripBase = strips;
-      strips += L.stripsX * L.stripsY;
-      L.borderRowBase = brows;  // 32-row bands, same count as stripsY
-      brows += L.stripsY;
       if (l > 0) {
         std::vector<int> xo, xa, yo, ya;
         orb_resize_tables(pw, ph, L.w, L.h, xo, xa, yo, ya);
@@ -1597,15 +1582,25 @@ int configure(vo_orb *h, int w, int h_img, int n_frames) {
       // k_fast_wave's per-cell geometry (16 ints per cell): level, cell origin and size incl. the 6-px overlap
       // (size 0: the cell is skipped, :801 / :811), key offset of the cell, slot block, plane pitch / offset
       while (tables.size() % 16) tables.push_back(0);
-      h->strip_tab_off = (int)tables.size();  // k_blur_strips: 16 ints per 64-group x 32-row strip
+      // k_blur_groups: 16 ints per job of 16 groups x 32 rows; levels too small for it go to the generic kernel
+      h->strip_tab_off = (int)tables.size();
+      h->blur_jobs = 0;
+      h->blur_generic_mask = 0;
       for (int l = 0; l < h->nlevels; l++) {
         const LevelGeom &L = D.lv[l];
-        for (int j = 0; j < L.stripsX * L.stripsY; j++) {
-          const int e[16] = {l, j % L.stripsX, j / L.stripsX, L.h, L.pitch, L.blurGroups,
-                             (int)(unsigned)(L.blur_off & 0xffffffffLL), (int)(L.blur_off >> 32), L.pitch,
-                             (int)(unsigned)(L.pyr_off & 0xffffffffLL), (int)(L.pyr_off >> 32), 0, 0, 0, 0, 0};
-          tables.insert(tables.end(), e, e + 16);
+        if (L.w < kBlurMinW || L.h < kBlurMinH) {
+          h->blur_generic_mask |= 1u << l;
+          continue;
         }
+        const int ng = (L.w + 3) / 4, ncb = (ng + kBlurB - 1) / kBlurB;
+        for (int sy = 0; sy < (L.h + 31) / 32; sy++)
+          for (int cb = 0; cb < ncb; cb++) {
+            const int e[16] = {l, cb, sy, L.h, L.pitch, ng,
+                               (int)(unsigned)(L.blur_off & 0xffffffffLL), (int)(L.blur_off >> 32), L.pitch,
+                               (int)(unsigned)(L.pyr_off & 0xffffffffLL), (int)(L.pyr_off >> 32), L.w, 0, 0, 0, 0};
+            tables.insert(tables.end(), e, e + 16);
+            h->blur_jobs++;
+          }
       }
       h->cell_tab_off = (int)tables.size();
       for (int l = 0; l < h->nlevels; l++) {
@@ -1648,8 +1643,6 @@ int configure(vo_orb *h, int w, int h_img, int n_frames) {
     h->sel_frame = sel;
     h->tiles_frame = tiles;
     h->max_kp = maxkp;
-    h->strips_frame = strips;
-    h->border_rows_frame = brows;
     VO_CHECK(h->tables.reserve(std::max<size_t>(tables.size() * sizeof(int), 64)));
     if (!tables.empty())
       VO_HIP_CHECK(hipMemcpy(h->tables.p, tables.data(), tables.size() * sizeof(int), hipMemcpyHostToDevice));
@@ -1742,11 +1735,11 @@ int run_pipeline(vo_orb *h, const uint8_t *dev_images, int n_frames, int w, int 
   const bool overlap = !ev && h->side != nullptr;
   auto launch_blur = [&](hipStream_t bs) {
     const int lv0_generic = lv0_unaligned;
-    if (h->strips_frame > 0)
-      hipLaunchKernelGGL(k_blur_strips, dim3((h->strips_frame + 3) / 4, n_frames), dim3(256), 0, bs, S, lv0_generic,
-                         h->tables.as<int>() + h->strip_tab_off, h->strips_frame);
-    hipLaunchKernelGGL(k_blur_border, dim3((h->border_rows_frame + 15) / 16, n_frames), dim3(256), 0, bs, D, S, lv0_generic);
-    if (lv0_generic) hipLaunchKernelGGL(k_blur, dim3(h->tiles_frame, n_frames), dim3(256), 0, bs, D, S, 0);
+    if (h->blur_jobs > 0)
+      hipLaunchKernelGGL(k_blur_groups, dim3((h->blur_jobs + 3) / 4, (n_frames + kBlurF - 1) / kBlurF), dim3(256), 0, bs, S,
+                         lv0_generic, h->tables.as<int>() + h->strip_tab_off, h->blur_jobs, n_frames);
+    const unsigned gmask = h->blur_generic_mask | (lv0_generic ? 1u : 0u);
+    if (gmask) hipLaunchKernelGGL(k_blur, dim3(h->tiles_frame, n_frames), dim3(256), 0, bs, D, S, gmask);
   };
   if (overlap) {
     VO_HIP_CHECK(hipEventRecord(h->ev_fork, st));
