@@ -126,23 +126,32 @@ __device__ __forceinline__ int dot2_i16(unsigned taps, unsigned coef) {
 #ifndef VO_RZ_ABLATE
 #define VO_RZ_ABLATE 0  // developer ablation switch (tools/rz_ablate.py); 0 in the product build
 #endif
-constexpr int kRzW = 256, kRzH = 16;  // output tile of k_resize4
-constexpr int kRzTiles = 4;           // vertically consecutive tiles per workgroup (software pipeline)
-constexpr int kRzNQ = 10;             // source rectangle <= 2560 dwords (scale 1.2: 78 x 22); else the generic kernel
+constexpr int kRzL = 16;               // lanes (four-pixel groups) per tile row
+constexpr int kRzF = 64 / kRzL;        // frames a wavefront works on side by side
+constexpr int kRzW = 4 * kRzL, kRzH = 16;  // output tile of k_resize4: 64 x 16 pixels of kRzF frames
+constexpr int kRzTiles = 1;           // vertically consecutive tiles per workgroup (see the launch)
+constexpr int kRzNQ = 10;             // source rectangles <= 2560 dwords (scale 1.2: 4 x 21 x 22); else the generic kernel
 
-template <int NQ>  // dwords of a source rectangle per thread (rectangle <= NQ x 256 dwords)
+// Lane = frame * 16 + group: a 256-pixel-wide tile wastes up to half of its lanes on the narrow levels, a
+// 64-pixel one at most a fifth, and with four frames side by side the row bookkeeping (source rows, vertical
+// coefficients) stays wave-uniform.  The source rectangles of the four frames are stacked in LDS row by row
+// (LDS row 4 y + frame).
+template <int NQ>  // dwords of the source rectangles per thread (rectangles <= NQ x 256 dwords)
 __global__ __launch_bounds__(256) void k_resize4(const uint8_t *src, long long s_frame_stride, int s_pitch,
                                                  int sw, int sh, uint8_t *dst, long long d_frame_stride,
                                                  int d_pitch, int dw, int dh, const int *xofs,
-                                                 const int *xab, const int *yofs, const int *yab) {
+                                                 const int *xab, const int *yofs, const int *yab, int n_frames,
+                                                 int tiles_per_wg) {
   extern __shared__ __attribute__((aligned(16))) uint8_t rz_tile[];
   constexpr int R = 4;
-  const int tid = threadIdx.x, gx = tid & 63;
+  const int tid = threadIdx.x, gx = tid & (kRzL - 1), fo = (tid & 63) / kRzL;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int dx0 = blockIdx.x * kRzW;
   const int dx = min(dx0 + 4 * gx, ((dw - 1) & ~3));  // lanes past the row repeat its last group
-  const uint8_t *S = src + (long long)blockIdx.z * s_frame_stride;
-  uint8_t *Dst = dst + (long long)blockIdx.z * d_frame_stride;
+  const int f0 = blockIdx.z * kRzF, nfr = min(kRzF, n_frames - f0);  // frames of this workgroup (uniform)
+  const uint8_t *S = src + (long long)f0 * s_frame_stride;
+  uint8_t *Dst = dst + (long long)(f0 + min(fo, nfr - 1)) * d_frame_stride;  // lanes past the batch repeat its last frame
+  const bool store_ok = fo < nfr;
   // column tables of this thread: the same for every tile of the strip
   int sx[4];
   unsigned ab[4];
@@ -156,26 +165,28 @@ __global__ __launch_bounds__(256) void k_resize4(const uint8_t *src, long long s
   const int ndw = ((c1 - c0) >> 2) + 1;  // dwords per source row of the strip
   const int lds_pitch = 4 * ndw + 4;     // one pad dword skews the LDS banks of consecutive rows
   const int ytiles = (dh + kRzH - 1) / kRzH;
-  const int ty0 = blockIdx.y * kRzTiles, ty1 = min(ty0 + kRzTiles, ytiles);
-  // element e = tid + 256 q of a rectangle sits at (row yq[q], dword xq4[q] / 4); independent of the tile
+  const int ty0 = blockIdx.y * tiles_per_wg, ty1 = min(ty0 + tiles_per_wg, ytiles);
+  // element e = tid + 256 q of the stacked rectangles sits at (LDS row tq = 4 y + frame, dword xq4 / 4);
+  // independent of the tile
   int lpos[NQ], xq4[NQ], yq[NQ];
   {
-    int y = (int)(((float)tid + 0.5f) / (float)ndw), x = tid - y * ndw;
+    int t = (int)(((float)tid + 0.5f) / (float)ndw), x = tid - t * ndw;
     const int sdy = 256 / ndw, sdx = 256 - sdy * ndw;
 #pragma unroll
     for (int q = 0; q < NQ; q++) {
-      yq[q] = y;
-      xq4[q] = 4 * x;
-      lpos[q] = __mul24(y, lds_pitch) + 4 * x;
-      x += sdx, y += sdy;
-      if (x >= ndw) x -= ndw, y++;
+      yq[q] = t >> 2;
+      xq4[q] = 4 * x + min(t & 3, nfr - 1) * (int)s_frame_stride;  // column and frame: one lane offset
+      lpos[q] = __mul24(t, lds_pitch) + 4 * x;
+      x += sdx, t += sdy;
+      if (x >= ndw) x -= ndw, t++;
     }
   }
   const int base = sx[0] & ~3;  // three aligned dwords from here hold columns sx[0] .. sx[0] + 7
   const int lastT = c0 + 4 * (ndw - 1);
   // o1/o2 are only clamped when base+4 / base+8 lie beyond the strip's last dword, and then every
   // column this thread needs (<= c1) sits in an earlier dword, so the bytes it selects stay valid
-  const int o0 = base - c0, o1 = min(base + 4, lastT) - c0, o2 = min(base + 8, lastT) - c0;
+  const int lf = fo * lds_pitch;  // the lane's frame within a stacked LDS row group
+  const int o0 = base - c0 + lf, o1 = min(base + 4, lastT) - c0 + lf, o2 = min(base + 8, lastT) - c0 + lf;
   const unsigned woff = (unsigned)(sx[0] & 3);  // byte offset of the 8-byte window in {w2,w1,w0}
   unsigned sel[4];
 #pragma unroll
@@ -190,7 +201,7 @@ __global__ __launch_bounds__(256) void k_resize4(const uint8_t *src, long long s
     const int dy0 = ty * kRzH;
     r0 = min(max(yofs[dy0], 0), sh - 1);
     const int r1 = min(max(yofs[min(dy0 + kRzH, dh) - 1] + 1, 0), sh - 1);
-    nq = (ndw * (r1 - r0 + 1) + 255) >> 8;
+    nq = (ndw * (r1 - r0 + 1) * kRzF + 255) >> 8;
     const uint8_t *g0 = S + (long long)r0 * s_pitch + c0;
     const int ymax = sh - 1 - r0;
 #pragma unroll
@@ -228,7 +239,7 @@ __global__ __launch_bounds__(256) void k_resize4(const uint8_t *src, long long s
       if (dyw + r >= dh) break;  // uniform per wave
       const int sy0 = min(max(sy_[r], 0), sh - 1) - rr0, sy1 = min(max(sy_[r] + 1, 0), sh - 1) - rr0;
       const int b0 = (short)(bb_[r] & 0xffff), b1 = bb_[r] >> 16;
-      const uint8_t *R0 = rz_tile + __mul24(sy0, lds_pitch), *R1 = rz_tile + __mul24(sy1, lds_pitch);
+      const uint8_t *R0 = rz_tile + __mul24(sy0 * kRzF, lds_pitch), *R1 = rz_tile + __mul24(sy1 * kRzF, lds_pitch);
       const unsigned p0 = *reinterpret_cast<const unsigned *>(R0 + o0), p1 = *reinterpret_cast<const unsigned *>(R0 + o1),
                      p2 = *reinterpret_cast<const unsigned *>(R0 + o2);
       const unsigned q0 = *reinterpret_cast<const unsigned *>(R1 + o0), q1 = *reinterpret_cast<const unsigned *>(R1 + o1),
@@ -253,7 +264,7 @@ __global__ __launch_bounds__(256) void k_resize4(const uint8_t *src, long long s
 #if VO_RZ_ABLATE == 3
       if (outw == 0x12345678u)
 #endif
-      *reinterpret_cast<unsigned *>(orow + (long long)r * d_pitch) = outw;  // the tail lands in the row padding
+      if (store_ok) *reinterpret_cast<unsigned *>(orow + (long long)r * d_pitch) = outw;  // the tail lands in the row padding
     }
     __syncthreads();  // the tile is overwritten by the next iteration
   }
@@ -1558,7 +1569,7 @@ int configure(vo_orb *h, int w, int h_img, int n_frames) {
         tables.insert(tables.end(), yo.begin(), yo.end());
         h->tab_off[l * 4 + 3] = (int)tables.size();
         tables.insert(tables.end(), ya.begin(), ya.end());
-        int mdw = 1, mrows = 1;  // largest source rectangle of a 256 x 16 output tile
+        int mdw = 1, mrows = 1;  // largest source rectangle of a 64 x 16 output tile
         for (int x0 = 0; x0 < L.w; x0 += kRzW) {
           const int c0 = xo[x0] & ~3, c1 = std::min(xo[std::min(x0 + kRzW, L.w) - 1] + 1, pw - 1);
           mdw = std::max(mdw, ((c1 - c0) >> 2) + 1);
@@ -1569,8 +1580,9 @@ int configure(vo_orb *h, int w, int h_img, int n_frames) {
           mrows = std::max(mrows, r1 - r0 + 1);
         }
         // the copy runs in whole 256-dword rounds at the strip's own pitch (4 ndw + 4): round up generously
-        h->rz_lds[l] = 4 * ((size_t)mdw * mrows + 256 + 2 * (size_t)(mdw + mrows) + 64) + 1024;
-        h->rz_dwords[l] = mdw * mrows;
+        // kRzF stacked rectangles at the strip's own pitch (4 ndw + 4); the copy runs in whole 256-dword rounds
+        h->rz_lds[l] = (size_t)(4 * mdw + 4) * ((size_t)mrows * kRzF + 256 / mdw + 3) + 4 * 256 + 1024;
+        h->rz_dwords[l] = mdw * mrows * kRzF;
       }
       pw = L.w, ph = L.h;
     }
@@ -1717,10 +1729,15 @@ int run_pipeline(vo_orb *h, const uint8_t *dev_images, int n_frames, int w, int 
                          (double)Pv.w / L.w < 1.99 && ((Pv.w + 3) & ~3) <= spitch && h->rz_dwords[l] <= 256 * kRzNQ && L.pitch >= ((L.w + 3) & ~3);
     if (aligned) {
       const int ytiles = (L.h + kRzH - 1) / kRzH;
-      dim3 grid((L.w + kRzW - 1) / kRzW, (ytiles + kRzTiles - 1) / kRzTiles, n_frames);
+      // One tile per workgroup measured fastest (0.196 ms per 256 frames against 0.214 / 0.221 / 0.240 with 2 / 4 /
+      // 8 vertically consecutive tiles software-pipelined in one workgroup): many small workgroups overlap
+      // their loads and arithmetic across each other better than the in-kernel pipeline does.
+      const int gx = (L.w + kRzW - 1) / kRzW, gz = (n_frames + kRzF - 1) / kRzF;
+      const int tpw = kRzTiles;
+      dim3 grid(gx, (ytiles + tpw - 1) / tpw, gz);
       hipLaunchKernelGGL(k_resize4<kRzNQ>, grid, dim3(256), h->rz_lds[l], st, sp, sfs, spitch, Pv.w, Pv.h, S.pyr + L.pyr_off,
                          (long long)h->pyr_frame, L.pitch, L.w, L.h, T + h->tab_off[l * 4 + 0],
-                         T + h->tab_off[l * 4 + 1], T + h->tab_off[l * 4 + 2], T + h->tab_off[l * 4 + 3]);
+                         T + h->tab_off[l * 4 + 1], T + h->tab_off[l * 4 + 2], T + h->tab_off[l * 4 + 3], n_frames, tpw);
     } else {
       dim3 grid((L.w + 63) / 64, (L.h + 3) / 4, n_frames), block(64, 4);
       hipLaunchKernelGGL(k_resize, grid, block, 0, st, sp, sfs, spitch, Pv.w, Pv.h, S.pyr + L.pyr_off,
