@@ -969,7 +969,7 @@ __global__ __launch_bounds__(256) void k_blur(OrbDev P, FrameSrc src, unsigned l
   }
 }
 
-// Fast path of the same filter.  A wavefront owns 16 four-pixel groups x 32 rows of FOUR consecutive frames
+// Fast path of the same filter.  A wavefront owns 16 four-pixel groups x 36 rows of FOUR consecutive frames
 // (lane = frame * 16 + group: the level geometry, hence the row walk, is the same for all of them, and 16-group
 // blocks fit the level widths far better than 64-group ones) and walks them top to bottom: per source row
 // every lane loads the three aligned dwords around its group (row base in scalar registers, the lane's frame
@@ -981,6 +981,7 @@ __global__ __launch_bounds__(256) void k_blur(OrbDev P, FrameSrc src, unsigned l
 constexpr int kBlurB = 16;                   // groups per block
 constexpr int kBlurF = 64 / kBlurB;          // frames per wavefront
 constexpr int kBlurMinW = 24, kBlurMinH = 4; // smaller levels take the generic kernel
+constexpr int kBlurRows = 36;                // rows per job: 36 + 6 apron rows = six batches of seven
 
 __global__ __launch_bounds__(256) void k_blur_groups(FrameSrc src, int lv0_generic, const int *__restrict__ job_tab,
                                                      int n_jobs, int n_frames) {
@@ -1036,18 +1037,20 @@ __global__ __launch_bounds__(256) void k_blur_groups(FrameSrc src, int lv0_gener
     left = G == 0;          // pixels -4..-1 are pixels 4..1: bytes R0, C3, C2, C1 of perm(R, C)
     selL = 0x01020304u;
   }
-  const int y0 = sy * 32, y1 = min(Lh, y0 + 32);
+  const int y0 = sy * kBlurRows, y1 = min(Lh, y0 + kBlurRows);
   const unsigned K0 = 18u | (34u << 8) | (49u << 16) | (55u << 24);
   const unsigned K1 = 49u | (34u << 8) | (18u << 16);
+  // Row sums of the last seven rows, as a ring: rows are taken seven at a time, so row u of a batch always
+  // lands in slot u and the taps of an output row are slots (u + 1 + k) mod 7 -- all compile-time indices, no
+  // register shuffling.  All 21 loads of a batch are issued before the first result is stored.  (Written row
+  // by row, every load waits behind the previous row's store -- the compiler cannot prove that `dst` and
+  // `img` do not alias -- and a wave pays one memory round trip per row.)
   int hw[7][4];
 #pragma unroll
   for (int j = 0; j < 7; j++)
 #pragma unroll
     for (int q = 0; q < 4; q++) hw[j][q] = 0;
-  // Rows are taken eight at a time: all 24 loads of a batch are issued before the first result is
-  // stored.  (Written row by row, every load waits behind the previous row's store -- the compiler
-  // cannot prove that `dst` and `img` do not alias -- and a wave pays one memory round trip per row.)
-  constexpr int RB = 8;
+  constexpr int RB = 7;
   for (int yb = y0 - 3; yb < y1 + 3; yb += RB) {
     unsigned Lr[RB], Cr[RB], Rr[RB];
 #pragma unroll
@@ -1071,20 +1074,19 @@ __global__ __launch_bounds__(256) void k_blur_groups(FrameSrc src, int lv0_gener
         Rw = caseB ? rb : ra;
         Cw = c2;
       }
-#pragma unroll
-      for (int j = 0; j < 6; j++)
-#pragma unroll
-        for (int q = 0; q < 4; q++) hw[j][q] = hw[j + 1][q];
       // pixel q sits at byte 4+q of (L,C,R); its taps are bytes q+1 .. q+7
-      hw[6][0] = __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(Cw, Lw, 1), K0, __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(Rw, Cw, 1), K1, 0u, false), false);
-      hw[6][1] = __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(Cw, Lw, 2), K0, __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(Rw, Cw, 2), K1, 0u, false), false);
-      hw[6][2] = __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(Cw, Lw, 3), K0, __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(Rw, Cw, 3), K1, 0u, false), false);
-      hw[6][3] = __builtin_amdgcn_udot4(Cw, K0, __builtin_amdgcn_udot4(Rw, K1, 0u, false), false);
+      hw[u][0] = __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(Cw, Lw, 1), K0, __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(Rw, Cw, 1), K1, 0u, false), false);
+      hw[u][1] = __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(Cw, Lw, 2), K0, __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(Rw, Cw, 2), K1, 0u, false), false);
+      hw[u][2] = __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(Cw, Lw, 3), K0, __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(Rw, Cw, 3), K1, 0u, false), false);
+      hw[u][3] = __builtin_amdgcn_udot4(Cw, K0, __builtin_amdgcn_udot4(Rw, K1, 0u, false), false);
       if (yy >= y0 + 3) {
         unsigned outw = 0;
 #pragma unroll
         for (int q = 0; q < 4; q++) {
-          const int acc = 18 * (hw[0][q] + hw[6][q]) + 34 * (hw[1][q] + hw[5][q]) + 49 * (hw[2][q] + hw[4][q]) + 55 * hw[3][q];
+          // row sums are <= 255 * 257 and their pair sums < 2^17: 24-bit multiplies are exact (and full rate)
+          const int t0 = hw[(u + 1) % 7][q] + hw[u][q], t1 = hw[(u + 2) % 7][q] + hw[(u + 6) % 7][q];
+          const int t2 = hw[(u + 3) % 7][q] + hw[(u + 5) % 7][q];
+          const int acc = __mul24(18, t0) + __mul24(34, t1) + __mul24(49, t2) + __mul24(55, hw[(u + 4) % 7][q]);
           const unsigned v = (unsigned)min((acc + (1 << 15)) >> 16, 255);
           outw |= v << (8 * q);
         }
@@ -1492,7 +1494,7 @@ int configure(vo_orb *h, int w, int h_img, int n_frames) {
     D.min_th = h->min_th;
     memcpy(D.umax, h->umax, sizeof(D.umax));
     long long pyr = 0, blur = 0, slots = 0;
-    int cells = 0, keys = 0, sel = 0, tiles = 0, maxkp = 0, strips = 0, brows = 0;
+    int cells = 0, keys = 0, sel = 0, tiles = 0, maxkp = 0;
     std::vector<int> tables;
     h->tab_off.assign(h->nlevels * 4, 0);
     int pw = w, ph = h_img;
@@ -1605,7 +1607,7 @@ int configure(vo_orb *h, int w, int h_img, int n_frames) {
           continue;
         }
         const int ng = (L.w + 3) / 4, ncb = (ng + kBlurB - 1) / kBlurB;
-        for (int sy = 0; sy < (L.h + 31) / 32; sy++)
+        for (int sy = 0; sy < (L.h + kBlurRows - 1) / kBlurRows; sy++)
           for (int cb = 0; cb < ncb; cb++) {
             const int e[16] = {l, cb, sy, L.h, L.pitch, ng,
                                (int)(unsigned)(L.blur_off & 0xffffffffLL), (int)(L.blur_off >> 32), L.pitch,
