@@ -604,24 +604,76 @@ __global__ __launch_bounds__(256) void k_octree(OrbDev P, const uint32_t *cell_s
   const uint32_t *slots = cell_slots + (long long)f * slots_frame_stride + L.slotBase;
   const int N = L.quota;
 
-  // ---- gather the per-cell lists in reference order (cell row-major, raster inside a cell)
+  // ---- gather the per-cell lists in reference order (cell row-major, raster inside a cell).  The cells'
+  // exclusive offsets go to LDS (the child counters double as scratch); then thread t takes candidates t,
+  // t + 256, ...: a binary search finds the cell of each, so all of a thread's slot loads are independent and
+  // in flight together (walking a cell's list entry by entry costs a global round trip per entry), and the
+  // first 8 stay in registers for the passes below.
+  constexpr int KR = 8;
+  uint32_t kreg[KR];
+  int lreg[KR];
   int n = 0;
-  for (int base = 0; base < L.nCells; base += 256) {
-    const int c = base + tid;
-    const int cnt = c < L.nCells ? cc[c] : 0;
-    int tot;
-    const int off = n + block_excl_scan(cnt, S.wsum, &tot);
-    // four entries per round trip: written one by one, every load would wait behind the previous store
-    // (the compiler cannot prove that `kd` and `slots` do not alias)
-    for (int e0 = 0; e0 < cnt; e0 += 4) {
-      uint32_t v[4];
-#pragma unroll
-      for (int u = 0; u < 4; u++) v[u] = slots[(long long)c * L.capCell + min(e0 + u, cnt - 1)];
-#pragma unroll
-      for (int u = 0; u < 4; u++)
-        if (e0 + u < cnt && off + e0 + u < L.candCap) kd[off + e0 + u] = v[u];
+  bool inreg;
+  if (L.nCells <= CAP * 4) {
+    int *coff = S.ccount;  // [nCells]: exclusive offsets
+    for (int base = 0; base < L.nCells; base += 256) {
+      const int c = base + tid;
+      const int cnt = c < L.nCells ? cc[c] : 0;
+      int tot;
+      const int off = n + block_excl_scan(cnt, S.wsum, &tot);
+      if (c < L.nCells) coff[c] = off;
+      n += tot;
     }
-    n += tot;
+    __syncthreads();
+    const int ncand = min(n, L.candCap);
+    inreg = ncand <= 256 * KR;
+    auto slot_of = [&](int k) {  // last cell whose offset is <= k (empty cells share offsets with their successor)
+      int lo = 0, hi = L.nCells - 1;
+      while (lo < hi) {
+        const int mid = (lo + hi + 1) >> 1;
+        if (coff[mid] <= k) lo = mid; else hi = mid - 1;
+      }
+      return (long long)lo * L.capCell + (k - coff[lo]);
+    };
+#pragma unroll
+    for (int e = 0; e < KR; e++) {
+      const int k = tid + 256 * e;
+      kreg[e] = k < ncand ? slots[slot_of(k)] : 0u;
+      lreg[e] = 0;
+    }
+#pragma unroll
+    for (int e = 0; e < KR; e++) {
+      const int k = tid + 256 * e;
+      if (k < ncand) kd[k] = kreg[e];
+    }
+    for (int k = tid + 256 * KR; k < ncand; k += 256) kd[k] = slots[slot_of(k)];
+  } else {
+    for (int base = 0; base < L.nCells; base += 256) {
+      const int c = base + tid;
+      const int cnt = c < L.nCells ? cc[c] : 0;
+      int tot;
+      const int off = n + block_excl_scan(cnt, S.wsum, &tot);
+      // four entries per round trip: written one by one, every load would wait behind the previous store
+      // (the compiler cannot prove that `kd` and `slots` do not alias)
+      for (int e0 = 0; e0 < cnt; e0 += 4) {
+        uint32_t v[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) v[u] = slots[(long long)c * L.capCell + min(e0 + u, cnt - 1)];
+#pragma unroll
+        for (int u = 0; u < 4; u++)
+          if (e0 + u < cnt && off + e0 + u < L.candCap) kd[off + e0 + u] = v[u];
+      }
+      n += tot;
+    }
+    __syncthreads();
+    __threadfence_block();
+    inreg = min(n, L.candCap) <= 256 * KR;
+#pragma unroll
+    for (int e = 0; e < KR; e++) {
+      const int k = tid + 256 * e;
+      kreg[e] = (inreg && k < min(n, L.candCap)) ? kd[k] : 0u;
+      lreg[e] = 0;
+    }
   }
   if (n > L.candCap) {
     if (tid == 0) atomicExch(err_flag, 1);
@@ -633,16 +685,6 @@ __global__ __launch_bounds__(256) void k_octree(OrbDev P, const uint32_t *cell_s
   // Keys and their node labels stay in registers for the passes below when the level has at most 256 x 8
   // candidates (the usual case by far): a pass is then LDS traffic and barriers only, instead of two global
   // round trips per key.  `for_keys(body)`: body(k, key, label) may change the label.
-  constexpr int KR = 8;
-  const bool inreg = n <= 256 * KR;  // uniform
-  uint32_t kreg[KR];
-  int lreg[KR];
-#pragma unroll
-  for (int e = 0; e < KR; e++) {
-    const int k = tid + 256 * e;
-    kreg[e] = (inreg && k < n) ? kd[k] : 0u;
-    lreg[e] = 0;
-  }
   auto for_keys = [&](auto body) {
     if (inreg) {
 #pragma unroll
