@@ -66,6 +66,23 @@ def test_other_sizes_and_params(vo, orc):
         assert np.array_equal(kps, okp) and np.array_equal(desc, odesc), (w, h)
 
 
+@pytest.mark.parametrize("w,h", [(96, 80), (80, 64), (77, 61)])
+def test_tiny_pyramid_levels(vo, orc, w, h):
+    """top levels narrower than 24 px take the generic blur kernel, levels without a FAST cell yield nothing:
+    every level's pyramid and blurred plane, and the final key-points, still match"""
+    img = synth.make_frame(11, w=w, h=h, n_rect=40, n_blob=10)
+    e = vo.OrbExtractor(100, 1.2, 8, 20, 7)
+    p = orc.orb_params(100, 1.2, 8, 20, 7)
+    okp, odesc, _ = orc.extract(p, img, cap=164)
+    kps, desc = e(img)
+    lev = orc.pyramid(p, img)
+    for l in range(8):
+        assert np.array_equal(e.get_level(0, l), lev[l]), f"pyramid level {l}"
+        assert np.array_equal(e.get_level(0, l, blurred=True), orc.blur(lev[l])), f"blur level {l}"
+    e.close()
+    assert np.array_equal(kps, okp) and np.array_equal(desc, odesc)
+
+
 def test_flat_image_gives_no_keypoints(ext):
     kps, desc = ext(np.full((480, 640), 100, np.uint8))
     assert len(kps) == 0 and desc.shape == (0, 32)
