@@ -109,20 +109,23 @@ def test_strided_input(ext, orc):
     assert n.value == len(okp) and np.array_equal(kps[:n.value], okp) and np.array_equal(desc[:n.value], odesc)
 
 
-def test_batch_device_matches_single(ext, orc):
+@pytest.mark.parametrize("nb", [6, 13])
+def test_batch_device_matches_single(ext, orc, nb):
+    """batch sizes that are not multiples of the four frames a wavefront of the pyramid / blur kernels works on,
+    nor of the eight XCDs the descriptor batches are dealt to"""
     import torch
-    frames = synth.make_frames(6, start=20)
+    frames = synth.make_frames(nb, start=20)
     dev = torch.from_numpy(frames).cuda()
     cap = ext.max_keypoints()
-    kps = torch.zeros((6, cap, 28), dtype=torch.uint8, device="cuda")
-    desc = torch.zeros((6, cap, 32), dtype=torch.uint8, device="cuda")
-    cnt = torch.zeros(6, dtype=torch.int32, device="cuda")
+    kps = torch.zeros((nb, cap, 28), dtype=torch.uint8, device="cuda")
+    desc = torch.zeros((nb, cap, 32), dtype=torch.uint8, device="cuda")
+    cnt = torch.zeros(nb, dtype=torch.int32, device="cuda")
     torch.cuda.synchronize()
     ext.extract_batch_dev(dev, kps, desc, cnt)
     ext.sync()
     from vo_slam_test_amd import _lib
     p = orc.orb_params()
-    for f in range(6):
+    for f in range(nb):
         okp, odesc, _ = orc.extract(p, frames[f])
         n = int(cnt[f])
         assert n == len(okp)
