@@ -129,19 +129,27 @@ __device__ __forceinline__ int dot2_i16(unsigned taps, unsigned coef) {
 constexpr int kRzL = 16;               // lanes (four-pixel groups) per tile row
 constexpr int kRzF = 64 / kRzL;        // frames a wavefront works on side by side
 constexpr int kRzW = 4 * kRzL, kRzH = 16;  // output tile of k_resize4: 64 x 16 pixels of kRzF frames
-constexpr int kRzTiles = 1;           // vertically consecutive tiles per workgroup (see the launch)
-constexpr int kRzNQ = 10;             // source rectangles <= 2560 dwords (scale 1.2: 4 x 21 x 22); else the generic kernel
+constexpr int kRzMaxDw = 32;           // dwords per source row of a tile (scale factors up to ~1.8)
+constexpr int kRzPitch = 4 * kRzMaxDw + 4;  // LDS row pitch: constant, so staged rows sit at immediate offsets
+constexpr int kRzMaxRows = 32;         // source rows of a tile
+constexpr int kRzNQ = kRzMaxRows * kRzF / 8;  // staging loads per thread: 8 stacked rows (2 source rows x 4 frames) each
 
-// Lane = frame * 16 + group: a 256-pixel-wide tile wastes up to half of its lanes on the narrow levels, a
-// 64-pixel one at most a fifth, and with four frames side by side the row bookkeeping (source rows, vertical
-// coefficients) stays wave-uniform.  The source rectangles of the four frames are stacked in LDS row by row
-// (LDS row 4 y + frame).
-template <int NQ>  // dwords of the source rectangles per thread (rectangles <= NQ x 256 dwords)
+// One workgroup per 64 x 16 output tile of four consecutive frames; lane = frame * 16 + four-pixel group: a
+// 256-pixel-wide tile wastes up to half of its lanes on the narrow levels, a 64-pixel one at most a fifth, and
+// with four frames side by side the row bookkeeping (source rows, vertical coefficients) stays wave-uniform.
+// Everything that depends only on the output column is precomputed per level with the handle (`gtab`: per
+// four-pixel group the aligned source column, the byte offset of its 8-byte window, the four tap selectors and
+// coefficient pairs; `btab`: per column block the first source dword and the dwords per row), and the source
+// rectangles are staged without index arithmetic: thread (x = tid & 31, tr = tid >> 5) copies dword x of
+// stacked row 8 q + tr (source row 2 q + (tr >> 2) of frame tr & 3) for q = 0, 1, ... into LDS row 8 q + tr.
+// One tile per workgroup measured fastest (0.196 ms per 256 frames against 0.214 / 0.221 / 0.240 with 2 / 4 /
+// 8 vertically consecutive tiles software-pipelined in one workgroup): many small workgroups overlap their
+// loads and arithmetic across each other better than an in-kernel pipeline does.
 __global__ __launch_bounds__(256) void k_resize4(const uint8_t *src, long long s_frame_stride, int s_pitch,
                                                  int sw, int sh, uint8_t *dst, long long d_frame_stride,
-                                                 int d_pitch, int dw, int dh, const int *xofs,
-                                                 const int *xab, const int *yofs, const int *yab, int n_frames,
-                                                 int tiles_per_wg) {
+                                                 int d_pitch, int dw, int dh, const int *__restrict__ gtab,
+                                                 const int *__restrict__ btab, const int *__restrict__ yofs,
+                                                 const int *__restrict__ yab, int n_frames) {
   extern __shared__ __attribute__((aligned(16))) uint8_t rz_tile[];
   constexpr int R = 4;
   const int tid = threadIdx.x, gx = tid & (kRzL - 1), fo = (tid & 63) / kRzL;
@@ -152,121 +160,88 @@ __global__ __launch_bounds__(256) void k_resize4(const uint8_t *src, long long s
   const uint8_t *S = src + (long long)f0 * s_frame_stride;
   uint8_t *Dst = dst + (long long)(f0 + min(fo, nfr - 1)) * d_frame_stride;  // lanes past the batch repeat its last frame
   const bool store_ok = fo < nfr;
-  // column tables of this thread: the same for every tile of the strip
-  int sx[4];
-  unsigned ab[4];
-#pragma unroll
-  for (int q = 0; q < 4; q++) {
-    const int d = min(dx + q, dw - 1);
-    sx[q] = xofs[d];
-    ab[q] = (unsigned)xab[d];
-  }
-  const int c0 = xofs[dx0] & ~3, c1 = min(xofs[min(dx0 + kRzW, dw) - 1] + 1, sw - 1);
-  const int ndw = ((c1 - c0) >> 2) + 1;  // dwords per source row of the strip
-  const int lds_pitch = 4 * ndw + 4;     // one pad dword skews the LDS banks of consecutive rows
-  const int ytiles = (dh + kRzH - 1) / kRzH;
-  const int ty0 = blockIdx.y * tiles_per_wg, ty1 = min(ty0 + tiles_per_wg, ytiles);
-  // element e = tid + 256 q of the stacked rectangles sits at (LDS row tq = 4 y + frame, dword xq4 / 4);
-  // independent of the tile
-  int lpos[NQ], xq4[NQ], yq[NQ];
-  {
-    int t = (int)(((float)tid + 0.5f) / (float)ndw), x = tid - t * ndw;
-    const int sdy = 256 / ndw, sdx = 256 - sdy * ndw;
-#pragma unroll
-    for (int q = 0; q < NQ; q++) {
-      yq[q] = t >> 2;
-      xq4[q] = 4 * x + min(t & 3, nfr - 1) * (int)s_frame_stride;  // column and frame: one lane offset
-      lpos[q] = __mul24(t, lds_pitch) + 4 * x;
-      x += sdx, t += sdy;
-      if (x >= ndw) x -= ndw, t++;
-    }
-  }
-  const int base = sx[0] & ~3;  // three aligned dwords from here hold columns sx[0] .. sx[0] + 7
+  // column constants of this thread's group
+  const int4 *gt = reinterpret_cast<const int4 *>(gtab + 12 * (dx >> 2));
+  const int4 g0v = gt[0], g1v = gt[1], g2v = gt[2];
+  const int base = g0v.x;                 // aligned source column: three dwords from here hold the group's 8-byte window
+  const unsigned woff = (unsigned)g0v.y;  // byte offset of the window in {w2,w1,w0}
+  const unsigned sel[4] = {(unsigned)g0v.z, (unsigned)g0v.w, (unsigned)g1v.x, (unsigned)g1v.y};
+  const unsigned ab[4] = {(unsigned)g1v.z, (unsigned)g1v.w, (unsigned)g2v.x, (unsigned)g2v.y};
+  const int c0 = btab[2 * blockIdx.x], ndw = btab[2 * blockIdx.x + 1];  // first source column (aligned), dwords per row
   const int lastT = c0 + 4 * (ndw - 1);
   // o1/o2 are only clamped when base+4 / base+8 lie beyond the strip's last dword, and then every
-  // column this thread needs (<= c1) sits in an earlier dword, so the bytes it selects stay valid
-  const int lf = fo * lds_pitch;  // the lane's frame within a stacked LDS row group
+  // column this thread needs sits in an earlier dword, so the bytes it selects stay valid
+  const int lf = fo * kRzPitch;  // the lane's frame within a stacked LDS row group
   const int o0 = base - c0 + lf, o1 = min(base + 4, lastT) - c0 + lf, o2 = min(base + 8, lastT) - c0 + lf;
-  const unsigned woff = (unsigned)(sx[0] & 3);  // byte offset of the 8-byte window in {w2,w1,w0}
-  unsigned sel[4];
+  // source rows of the tile
+  const int dy0 = blockIdx.y * kRzH;
+  const int r0 = min(max(yofs[dy0], 0), sh - 1);
+  const int r1 = min(max(yofs[min(dy0 + kRzH, dh) - 1] + 1, 0), sh - 1);
+  const int nq = ((r1 - r0 + 1) * kRzF + 7) >> 3;  // staging rounds (uniform)
+  int sy_[R], bb_[R];
 #pragma unroll
-  for (int q = 0; q < 4; q++) {
-    const int i0 = sx[q] - sx[0], i1 = min(sx[q] + 1, sw - 1) - sx[0];  // 0 <= i0 <= i1 <= 7 for scale < 2
-    sel[q] = (unsigned)i0 | 0x0c00u | ((unsigned)i1 << 16) | 0x0c000000u;  // 0x0c: constant 0
+  for (int r = 0; r < R; r++) {
+    const int dy = min(dy0 + wave * R + r, dh - 1);  // uniform per wave: scalar loads
+    sy_[r] = yofs[dy];
+    bb_[r] = yab[dy];
   }
-  // software pipeline over the strip's tiles
-  unsigned v[NQ];
-  int r0 = 0, nq = 0, syr[R], bbr[R];
-  auto fetch = [&](int ty) {
-    const int dy0 = ty * kRzH;
-    r0 = min(max(yofs[dy0], 0), sh - 1);
-    const int r1 = min(max(yofs[min(dy0 + kRzH, dh) - 1] + 1, 0), sh - 1);
-    nq = (ndw * (r1 - r0 + 1) * kRzF + 255) >> 8;
-    const uint8_t *g0 = S + (long long)r0 * s_pitch + c0;
+  {
+    const int x = min(tid & 31, ndw - 1), tr = tid >> 5;  // lanes past the row's last dword repeat it
     const int ymax = sh - 1 - r0;
+    const uint8_t *g0 = S + (long long)r0 * s_pitch + c0 + (long long)min(tr & 3, nfr - 1) * s_frame_stride + 4 * x;
+    uint8_t *lt = rz_tile + tr * kRzPitch + 4 * x;
+    const bool hi = (tr >> 2) != 0;
+    unsigned v[kRzNQ];
 #pragma unroll
-    for (int q = 0; q < NQ; q++)
+    for (int q = 0; q < kRzNQ; q++)
       if (q < nq) {  // uniform
+        // source row 2 q + (tr >> 2), clamped to the image: both candidates are scalar
+        const int ra = __mul24(min(2 * q, ymax), s_pitch), rb = __mul24(min(2 * q + 1, ymax), s_pitch);
 #if VO_RZ_ABLATE == 2
-        v[q] = (unsigned)(xq4[q] + r0);
+        v[q] = (unsigned)(ra + rb);
         (void)g0;
 #else
-        v[q] = *reinterpret_cast<const unsigned *>(g0 + (__mul24(min(yq[q], ymax), s_pitch) + xq4[q]));
+        v[q] = *reinterpret_cast<const unsigned *>(g0 + (hi ? rb : ra));
 #endif
       }
 #pragma unroll
-    for (int r = 0; r < R; r++) {
-      const int dy = min(dy0 + wave * R + r, dh - 1);  // uniform per wave: scalar loads
-      syr[r] = yofs[dy];
-      bbr[r] = yab[dy];
-    }
-  };
-  fetch(ty0);
-  for (int ty = ty0; ty < ty1; ty++) {
-    const int rr0 = r0, nqc = nq;
-    int sy_[R], bb_[R];
+    for (int q = 0; q < kRzNQ; q++)
+      if (q < nq) *reinterpret_cast<unsigned *>(lt + q * 8 * kRzPitch) = v[q];
+  }
+  __syncthreads();
+  const int dyw = dy0 + wave * R;
+  uint8_t *orow = Dst + (long long)dyw * d_pitch + dx;
 #pragma unroll
-    for (int r = 0; r < R; r++) sy_[r] = syr[r], bb_[r] = bbr[r];
-#pragma unroll
-    for (int q = 0; q < NQ; q++)
-      if (q < nqc) *reinterpret_cast<unsigned *>(rz_tile + lpos[q]) = v[q];
-    __syncthreads();
-    if (ty + 1 < ty1) fetch(ty + 1);
-    const int dyw = ty * kRzH + wave * R;
-    uint8_t *orow = Dst + (long long)dyw * d_pitch + dx;
-#pragma unroll
-    for (int r = 0; r < R; r++) {
-      if (dyw + r >= dh) break;  // uniform per wave
-      const int sy0 = min(max(sy_[r], 0), sh - 1) - rr0, sy1 = min(max(sy_[r] + 1, 0), sh - 1) - rr0;
-      const int b0 = (short)(bb_[r] & 0xffff), b1 = bb_[r] >> 16;
-      const uint8_t *R0 = rz_tile + __mul24(sy0 * kRzF, lds_pitch), *R1 = rz_tile + __mul24(sy1 * kRzF, lds_pitch);
-      const unsigned p0 = *reinterpret_cast<const unsigned *>(R0 + o0), p1 = *reinterpret_cast<const unsigned *>(R0 + o1),
-                     p2 = *reinterpret_cast<const unsigned *>(R0 + o2);
-      const unsigned q0 = *reinterpret_cast<const unsigned *>(R1 + o0), q1 = *reinterpret_cast<const unsigned *>(R1 + o1),
-                     q2 = *reinterpret_cast<const unsigned *>(R1 + o2);
-      unsigned outw = 0;
+  for (int r = 0; r < R; r++) {
+    if (dyw + r >= dh) break;  // uniform per wave
+    const int sy0 = min(max(sy_[r], 0), sh - 1) - r0, sy1 = min(max(sy_[r] + 1, 0), sh - 1) - r0;
+    const int b0 = (short)(bb_[r] & 0xffff), b1 = bb_[r] >> 16;
+    const uint8_t *R0 = rz_tile + __mul24(sy0 * kRzF, kRzPitch), *R1 = rz_tile + __mul24(sy1 * kRzF, kRzPitch);
+    const unsigned p0 = *reinterpret_cast<const unsigned *>(R0 + o0), p1 = *reinterpret_cast<const unsigned *>(R0 + o1),
+                   p2 = *reinterpret_cast<const unsigned *>(R0 + o2);
+    const unsigned q0 = *reinterpret_cast<const unsigned *>(R1 + o0), q1 = *reinterpret_cast<const unsigned *>(R1 + o1),
+                   q2 = *reinterpret_cast<const unsigned *>(R1 + o2);
+    unsigned outw = 0;
 #if VO_RZ_ABLATE == 1
-      outw = p0 ^ p1 ^ p2 ^ q0 ^ q1 ^ q2 ^ (unsigned)(b0 + b1);
+    outw = p0 ^ p1 ^ p2 ^ q0 ^ q1 ^ q2 ^ (unsigned)(b0 + b1);
 #else
-      // the 8 bytes from column sx[0] on, of both source rows
-      const unsigned pl = __builtin_amdgcn_alignbyte(p1, p0, woff), ph = __builtin_amdgcn_alignbyte(p2, p1, woff);
-      const unsigned ql = __builtin_amdgcn_alignbyte(q1, q0, woff), qh = __builtin_amdgcn_alignbyte(q2, q1, woff);
+    // the 8 bytes from column sx[0] on, of both source rows
+    const unsigned pl = __builtin_amdgcn_alignbyte(p1, p0, woff), ph = __builtin_amdgcn_alignbyte(p2, p1, woff);
+    const unsigned ql = __builtin_amdgcn_alignbyte(q1, q0, woff), qh = __builtin_amdgcn_alignbyte(q2, q1, woff);
 #pragma unroll
-      for (int q = 0; q < 4; q++) {
-        const int h0 = dot2_i16(__builtin_amdgcn_perm(ph, pl, sel[q]), ab[q]);
-        const int h1 = dot2_i16(__builtin_amdgcn_perm(qh, ql, sel[q]), ab[q]);
-        // 24-bit multiplies are exact here: |b| <= 2048, |h >> 4| <= 255 * 2048 / 16
-        int val = ((__mul24(b0, h0 >> 4) >> 16) + (__mul24(b1, h1 >> 4) >> 16) + 2) >> 2;
-        val = min(max(val, 0), 255);
-        outw |= (unsigned)val << (8 * q);
-      }
+    for (int q = 0; q < 4; q++) {
+      const int h0 = dot2_i16(__builtin_amdgcn_perm(ph, pl, sel[q]), ab[q]);
+      const int h1 = dot2_i16(__builtin_amdgcn_perm(qh, ql, sel[q]), ab[q]);
+      // 24-bit multiplies are exact here: |b| <= 2048, |h >> 4| <= 255 * 2048 / 16
+      int val = ((__mul24(b0, h0 >> 4) >> 16) + (__mul24(b1, h1 >> 4) >> 16) + 2) >> 2;
+      val = min(max(val, 0), 255);
+      outw |= (unsigned)val << (8 * q);
+    }
 #endif
 #if VO_RZ_ABLATE == 3
-      if (outw == 0x12345678u)
+    if (outw == 0x12345678u)
 #endif
-      if (store_ok) *reinterpret_cast<unsigned *>(orow + (long long)r * d_pitch) = outw;  // the tail lands in the row padding
-    }
-    __syncthreads();  // the tile is overwritten by the next iteration
+    if (store_ok) *reinterpret_cast<unsigned *>(orow + (long long)r * d_pitch) = outw;  // the tail lands in the row padding
   }
 }
 
@@ -1473,7 +1448,8 @@ struct vo_orb {
   size_t fast_lds = 0;
   bool oct_small = false;
   size_t rz_lds[kMaxLevels] = {0};
-  int rz_dwords[kMaxLevels] = {0};  // every level's node list fits k_octree<256>
+  bool rz_tiled[kMaxLevels] = {false};                             // the level's tiles fit k_resize4's LDS layout
+  int rz_gtab_off[kMaxLevels] = {0}, rz_btab_off[kMaxLevels] = {0};  // its column tables (ints into `tables`)
   int blur_jobs = 0;               // k_blur_groups jobs per frame quad
   unsigned blur_generic_mask = 0;  // levels blurred by the generic kernel
   std::vector<int> tab_off;  // per level: offsets of xofs,xab,yofs,yab in tables
@@ -1614,19 +1590,39 @@ int configure(vo_orb *h, int w, int h_img, int n_frames) {
         h->tab_off[l * 4 + 3] = (int)tables.size();
         tables.insert(tables.end(), ya.begin(), ya.end());
         int mdw = 1, mrows = 1;  // largest source rectangle of a 64 x 16 output tile
+        // k_resize4's column tables: per column block the first source dword and the dwords per row ...
+        while (tables.size() % 4) tables.push_back(0);
+        h->rz_btab_off[l] = (int)tables.size();
         for (int x0 = 0; x0 < L.w; x0 += kRzW) {
           const int c0 = xo[x0] & ~3, c1 = std::min(xo[std::min(x0 + kRzW, L.w) - 1] + 1, pw - 1);
-          mdw = std::max(mdw, ((c1 - c0) >> 2) + 1);
+          const int ndw = ((c1 - c0) >> 2) + 1;
+          mdw = std::max(mdw, ndw);
+          tables.push_back(c0);
+          tables.push_back(ndw);
+        }
+        // ... and per four-pixel group: aligned source column, byte offset of the 8-byte window, four byte-permute
+        // selectors (tap 0 / tap 1 of each output into 16-bit lanes; 0x0c = constant 0) and coefficient pairs
+        while (tables.size() % 4) tables.push_back(0);
+        h->rz_gtab_off[l] = (int)tables.size();
+        for (int g = 0; g < (L.w + 3) / 4; g++) {
+          int sx[4];
+          for (int q = 0; q < 4; q++) sx[q] = xo[std::min(4 * g + q, L.w - 1)];
+          int e[12] = {sx[0] & ~3, sx[0] & 3, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+          for (int q = 0; q < 4; q++) {
+            const int i0 = sx[q] - sx[0], i1 = std::min(sx[q] + 1, pw - 1) - sx[0];  // 0 <= i0 <= i1 <= 7 for scale < 2
+            e[2 + q] = (int)((unsigned)i0 | 0x0c00u | ((unsigned)i1 << 16) | 0x0c000000u);
+            e[6 + q] = xa[std::min(4 * g + q, L.w - 1)];
+          }
+          tables.insert(tables.end(), e, e + 12);
         }
         for (int y0 = 0; y0 < L.h; y0 += kRzH) {
           const int r0 = std::min(std::max(yo[y0], 0), ph - 1);
           const int r1 = std::min(std::max(yo[std::min(y0 + kRzH, L.h) - 1] + 1, 0), ph - 1);
           mrows = std::max(mrows, r1 - r0 + 1);
         }
-        // the copy runs in whole 256-dword rounds at the strip's own pitch (4 ndw + 4): round up generously
-        // kRzF stacked rectangles at the strip's own pitch (4 ndw + 4); the copy runs in whole 256-dword rounds
-        h->rz_lds[l] = (size_t)(4 * mdw + 4) * ((size_t)mrows * kRzF + 256 / mdw + 3) + 4 * 256 + 1024;
-        h->rz_dwords[l] = mdw * mrows * kRzF;
+        // kRzF stacked rectangles at the constant pitch, staged in whole rounds of 8 stacked rows
+        h->rz_lds[l] = (size_t)kRzPitch * (((size_t)mrows * kRzF + 7) / 8 * 8) + 64;
+        h->rz_tiled[l] = mdw <= kRzMaxDw && mrows <= kRzMaxRows;
       }
       pw = L.w, ph = L.h;
     }
@@ -1770,18 +1766,12 @@ int run_pipeline(vo_orb *h, const uint8_t *dev_images, int n_frames, int w, int 
     // 4 outputs span <= 3*scale + 2 source columns; with the aligned start that fits 12 bytes for
     // scale factors below 2 and needs 4-byte aligned source rows with readable padding to the pitch
     const bool aligned = ((reinterpret_cast<uintptr_t>(sp) | (uintptr_t)spitch | (uintptr_t)sfs) & 3) == 0 &&
-                         (double)Pv.w / L.w < 1.99 && ((Pv.w + 3) & ~3) <= spitch && h->rz_dwords[l] <= 256 * kRzNQ && L.pitch >= ((L.w + 3) & ~3);
+                         (double)Pv.w / L.w < 1.99 && ((Pv.w + 3) & ~3) <= spitch && h->rz_tiled[l] && L.pitch >= ((L.w + 3) & ~3);
     if (aligned) {
-      const int ytiles = (L.h + kRzH - 1) / kRzH;
-      // One tile per workgroup measured fastest (0.196 ms per 256 frames against 0.214 / 0.221 / 0.240 with 2 / 4 /
-      // 8 vertically consecutive tiles software-pipelined in one workgroup): many small workgroups overlap
-      // their loads and arithmetic across each other better than the in-kernel pipeline does.
-      const int gx = (L.w + kRzW - 1) / kRzW, gz = (n_frames + kRzF - 1) / kRzF;
-      const int tpw = kRzTiles;
-      dim3 grid(gx, (ytiles + tpw - 1) / tpw, gz);
-      hipLaunchKernelGGL(k_resize4<kRzNQ>, grid, dim3(256), h->rz_lds[l], st, sp, sfs, spitch, Pv.w, Pv.h, S.pyr + L.pyr_off,
-                         (long long)h->pyr_frame, L.pitch, L.w, L.h, T + h->tab_off[l * 4 + 0],
-                         T + h->tab_off[l * 4 + 1], T + h->tab_off[l * 4 + 2], T + h->tab_off[l * 4 + 3], n_frames, tpw);
+      dim3 grid((L.w + kRzW - 1) / kRzW, (L.h + kRzH - 1) / kRzH, (n_frames + kRzF - 1) / kRzF);
+      hipLaunchKernelGGL(k_resize4, grid, dim3(256), h->rz_lds[l], st, sp, sfs, spitch, Pv.w, Pv.h, S.pyr + L.pyr_off,
+                         (long long)h->pyr_frame, L.pitch, L.w, L.h, T + h->rz_gtab_off[l], T + h->rz_btab_off[l],
+                         T + h->tab_off[l * 4 + 2], T + h->tab_off[l * 4 + 3], n_frames);
     } else {
       dim3 grid((L.w + 63) / 64, (L.h + 3) / 4, n_frames), block(64, 4);
       hipLaunchKernelGGL(k_resize, grid, block, 0, st, sp, sfs, spitch, Pv.w, Pv.h, S.pyr + L.pyr_off,
