@@ -1638,7 +1638,7 @@ __global__ __launch_bounds__(256) void k_ba_pairs(BaDev B) {
   }
 }
 
-// one workgroup: this shard's camera-block sums, cost and gradient max into the extras of the reduced-system
+// this shard's camera-block sums, cost and gradient max into the extras of the reduced-system
 // buffer (summed over the shards by the all-reduce when the problem is sharded)
 __global__ __launch_bounds__(256) void k_ba_partials_large(BaDev B) {
   __shared__ double red[8];
@@ -1646,13 +1646,15 @@ __global__ __launch_bounds__(256) void k_ba_partials_large(BaDev B) {
   if (st0.done) return;
   const int tid = threadIdx.x;
   double *ext = B.Sd + large_ext_off(B.ld);
-  for (int i = tid; i < B.nf * 27; i += 256) {
+  // camera-block sums: one entry per thread over the whole grid; the cost / gradient part on workgroup 0
+  for (int i = blockIdx.x * 256 + tid; i < B.nf * 27; i += gridDim.x * 256) {
     const int slot = i / 27, t = i - slot * 27;
     const double *sp = B.slab_cam + (long long)slot * B.n_cchunks * 27 + t;
     double a = 0;
     for (int cchunk = 0; cchunk < B.n_cchunks; cchunk++) a += sp[cchunk * 27];  // chunk order
     ext[i] = a;
   }
+  if (blockIdx.x != 0) return;
   double cs = 0, m = 0;
   const double *spt = B.slab_pt[st0.cur];
   for (int b = tid; b < B.n_pblocks; b += 256) cs += spt[2 * b], m = fmax(m, spt[2 * b + 1]);
@@ -2386,7 +2388,7 @@ int launch_linearize_large(vo_ba *h) {
   hipLaunchKernelGGL(k_ba_cams_large, dim3(std::max(1, h->nf * D.n_cchunks)), dim3(256), 0, st, D);
   VO_HIP_CHECK(hipMemsetAsync(D.Sd, 0, (size_t)(D.ld + vo::kCholPanel) * D.ld * 8, st));
   if (D.n_pairs > 0) hipLaunchKernelGGL(k_ba_pairs, dim3((D.n_pairs + 3) / 4), dim3(256), 0, st, D);
-  hipLaunchKernelGGL(k_ba_partials_large, dim3(1), dim3(256), 0, st, D);
+  hipLaunchKernelGGL(k_ba_partials_large, dim3(std::max(1, (h->nf * 27 + 255) / 256)), dim3(256), 0, st, D);
   VO_HIP_CHECK(hipGetLastError());
   return VO_OK;
 }
