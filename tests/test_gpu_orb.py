@@ -83,6 +83,33 @@ def test_tiny_pyramid_levels(vo, orc, w, h):
     assert np.array_equal(kps, okp) and np.array_equal(desc, odesc)
 
 
+@pytest.mark.parametrize("kind", ["uniform", "salt"])
+def test_noise_images_overflow_the_survivor_list(vo, orc, kind):
+    """white noise: most pixels pass the FAST pre-test, far more than the per-cell survivor list holds, so
+    the cells take the chunked path; sparse salt noise mixes both paths"""
+    rng = np.random.default_rng(5)
+    if kind == "uniform":
+        img = rng.integers(0, 256, (240, 320), dtype=np.uint8)
+    else:
+        img = np.full((240, 320), 90, np.uint8)
+        m = rng.random((240, 320)) < 0.08
+        img[m] = rng.integers(150, 256, int(m.sum()), dtype=np.uint8)
+        img[:, 160:] = rng.integers(0, 256, (240, 160), dtype=np.uint8)
+    e = vo.OrbExtractor(800, 1.2, 8, 20, 7)
+    p = orc.orb_params(800, 1.2, 8, 20, 7)
+    okp, odesc, _ = orc.extract(p, img, cap=800 + 256)
+    kps, desc = e(img)
+    lev = orc.pyramid(p, img)
+    for l in range(3):
+        cx, cy, cr = orc.level_candidates(p, lev[l])
+        gx, gy, gr = e.get_candidates(0, l)
+        assert len(gx) == len(cx), f"candidate count level {l}: {len(gx)} vs {len(cx)}"
+        assert np.array_equal(gx, cx) and np.array_equal(gy, cy) and np.array_equal(gr, cr), f"candidates {l}"
+    e.close()
+    assert len(kps) == len(okp) > 0
+    assert np.array_equal(kps, okp) and np.array_equal(desc, odesc)
+
+
 def test_flat_image_gives_no_keypoints(ext):
     kps, desc = ext(np.full((480, 640), 100, np.uint8))
     assert len(kps) == 0 and desc.shape == (0, 32)

@@ -310,8 +310,8 @@ __device__ __forceinline__ int fast_arc_score(const lds_u8 *ring, int min_th) {
 
 __host__ __device__ __forceinline__ int fast_align16(int v) { return (v + 15) & ~15; }
 // LDS bytes of one wave of k_fast_wave: image rows and score rows interleaved (row pitch 2 TP), survivor list
-__host__ __device__ __forceinline__ int fast_wave_lds(int tp, int tile_rows, int max_interior) {
-  return fast_align16(2 * tp * tile_rows + 16) + fast_align16(2 * max_interior);
+__host__ __device__ __forceinline__ int fast_wave_lds(int tp, int tile_rows, int list_cap) {
+  return fast_align16(2 * tp * tile_rows + 16) + fast_align16(2 * list_cap);
 }
 
 // TP: width of a tile row in bytes, 48 for the usual 30..39-px cells, 72 for the largest legal cell.
@@ -319,7 +319,7 @@ __host__ __device__ __forceinline__ int fast_wave_lds(int tp, int tile_rows, int
 template <int TP, bool BYTEWISE>
 __global__ __launch_bounds__(256) void k_fast_wave(OrbDev P, FrameSrc src, uint32_t *cell_slots,
                                                    long long slots_frame_stride, int *cell_count,
-                                                   int cells_per_frame, int tile_rows, int max_interior,
+                                                   int cells_per_frame, int tile_rows, int list_cap,
                                                    const int *__restrict__ cell_tab) {
   extern __shared__ __attribute__((aligned(16))) uint8_t fast_lds[];
   constexpr int RP = 2 * TP;  // LDS row pitch: image row (TP bytes), then the score row of the same pixels
@@ -327,7 +327,7 @@ __global__ __launch_bounds__(256) void k_fast_wave(OrbDev P, FrameSrc src, uint3
   const int wave = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
   const int cell = blockIdx.x * 4 + wave, f = blockIdx.y;
   if (cell >= cells_per_frame) return;  // wave-uniform; the kernel has no workgroup barrier
-  lds_u8 *tile_raw = (lds_u8 *)fast_lds + wave * fast_wave_lds(TP, tile_rows, max_interior);
+  lds_u8 *tile_raw = (lds_u8 *)fast_lds + wave * fast_wave_lds(TP, tile_rows, list_cap);
   lds_u16 *plist = (lds_u16 *)(tile_raw + fast_align16(RP * tile_rows + 16));
   // the cell's geometry comes from a table built with the handle (12 dwords by scalar loads) instead of a
   // level search over the kernel arguments, which is a chain of dependent scalar round trips per wavefront
@@ -435,7 +435,9 @@ __global__ __launch_bounds__(256) void k_fast_wave(OrbDev P, FrameSrc src, uint3
       int row = 0;
       auto append = [&](bool hit, lds_u8 *bb) {
         const unsigned long long mask = __builtin_amdgcn_ballot_w64(hit);
-        if (hit) plist[n + __builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0u))] =
+        // the list holds list_cap entries (half the cell's pixels: the LDS saved is one more resident workgroup
+        // per CU); entries past it pile up on the last slot and the count tells the caller to take the chunked path
+        if (hit) plist[min(n + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0u)), list_cap - 1)] =
             (unsigned short)(unsigned)(uintptr_t)bb;
         n += __popcll(mask);
       };
@@ -463,6 +465,61 @@ __global__ __launch_bounds__(256) void k_fast_wave(OrbDev P, FrameSrc src, uint3
               return m1 >= P.ini_th;
             });
   uint32_t *slot = cell_slots + (long long)f * slots_frame_stride + slot_off;
+  // Rare path for cells with more survivors than the list holds (noise-like texture).  Every interior pixel
+  // already has its tile entry (margin bound or score), so the survivors at threshold `th` are the entries
+  // >= th: they are scored chunk by chunk (a chunk = as many rows as fit the list even if every pixel hits),
+  // then -- all scores final -- suppressed chunk by chunk; chunks follow each other in raster order.
+  auto chunked_round = [&](int th) {
+    const int chunk_rows = max(list_cap / 64, 1) * ri;
+    auto collect = [&](int r0, int r1) {
+      int n = 0;
+      for (int r = r0; r < r1; r += ri) {
+        lds_u8 *b = b0 + r * RP;
+        const bool hit = lx < iw && r + ly < r1 && (int)b[3 * RP + 3 + TP] >= th;
+        const unsigned long long mask = __builtin_amdgcn_ballot_w64(hit);
+        if (hit) plist[n + __builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0u))] =
+            (unsigned short)(unsigned)(uintptr_t)b;
+        n += __popcll(mask);
+      }
+      wave_sync();
+      return n;
+    };
+    for (int r0 = 0; r0 < ih; r0 += chunk_rows) {
+      const int n = collect(r0, min(r0 + chunk_rows, ih));
+      for (int i = lane; i < n; i += 64) {
+        lds_u8 *b = (lds_u8 *)(uintptr_t)(unsigned)plist[i];
+        b[3 * RP + 3 + TP] = (uint8_t)fast_arc_score<RP>(b, P.min_th);
+      }
+      wave_sync();
+    }
+    int kept = 0;
+    for (int r0 = 0; r0 < ih; r0 += chunk_rows) {
+      const int n = collect(r0, min(r0 + chunk_rows, ih));
+      for (int base = 0; base < n; base += 64) {
+        const int i = base + lane;
+        bool keep = false;
+        int pos = 0, sc0 = 0;
+        if (i < n) {
+          const lds_u8 *b = (const lds_u8 *)(uintptr_t)(unsigned)plist[i];
+          pos = (int)(b - tile);
+          const lds_u8 *c = b + 2 * RP + 2 + TP;
+          sc0 = c[RP + 1];
+          const int nb = max(max(max((int)c[0], (int)c[1]), max((int)c[2], (int)c[RP])),
+                             max(max((int)c[RP + 2], (int)c[2 * RP]), max((int)c[2 * RP + 1], (int)c[2 * RP + 2])));
+          keep = sc0 >= th && sc0 > nb;
+        }
+        const unsigned long long mask = __builtin_amdgcn_ballot_w64(keep);
+        const int off = kept + __builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0u));
+        if (keep && off < cap_cell) {
+          const int y = pos / RP, x = pos - y * RP;
+          slot[off] = (uint32_t)(x + 3 + xoff) | ((uint32_t)(y + 3 + yoff) << 12) | ((uint32_t)sc0 << 24);
+        }
+        kept += __popcll(mask);
+      }
+      wave_sync();
+    }
+    return kept;
+  };
   int running = 0;
   for (int round = 0; round < 2; round++) {
     const int th = round == 0 ? P.ini_th : P.min_th;
@@ -470,6 +527,12 @@ __global__ __launch_bounds__(256) void k_fast_wave(OrbDev P, FrameSrc src, uint3
       // A cell with no key-point at iniThFAST is redone at minThFAST (:820-824): the survivors are the
       // pixels whose tile entry (margin bound, or score where already computed) reaches minThFAST.
       np = walk([&](lds_u8 *b) { return (int)b[3 * RP + 3 + TP]; }, [&](lds_u8 *, int e) { return e >= th; });
+    }
+    if (np > list_cap) {  // uniform, rare
+      wave_sync();
+      running = chunked_round(th);
+      if (running > 0) break;
+      continue;
     }
     wave_sync();
     // ---- phase 2: full arc score only for the survivors
@@ -1683,7 +1746,7 @@ int configure(vo_orb *h, int w, int h_img, int n_frames) {
       h->oct_small = mcap <= 256 - 4;
       h->fast_tp = mw + 9 <= 48 ? 48 : kTileP;
       h->fast_rows = mh + 6;
-      h->fast_interior = mw * mh;
+      h->fast_interior = std::max(128, (mw * mh + 1) / 2);  // survivor-list entries: half the cell's pixels (see k_fast_wave)
       h->fast_lds = 4 * (size_t)fast_wave_lds(h->fast_tp, h->fast_rows, h->fast_interior);
       if (h->fast_lds > 64 * 1024) {
         for (const void *fn : {(const void *)k_fast_wave<48, false>, (const void *)k_fast_wave<48, true>,
