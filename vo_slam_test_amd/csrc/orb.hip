@@ -1120,16 +1120,20 @@ __global__ __launch_bounds__(256) void k_blur_groups(FrameSrc src, int lv0_gener
   const int y0 = sy * kBlurRows, y1 = min(Lh, y0 + kBlurRows);
   const unsigned K0 = 18u | (34u << 8) | (49u << 16) | (55u << 24);
   const unsigned K1 = 49u | (34u << 8) | (18u << 16);
-  // Row sums of the last seven rows, as a ring: rows are taken seven at a time, so row u of a batch always
-  // lands in slot u and the taps of an output row are slots (u + 1 + k) mod 7 -- all compile-time indices, no
-  // register shuffling.  All 21 loads of a batch are issued before the first result is stored.  (Written row
-  // by row, every load waits behind the previous row's store -- the compiler cannot prove that `dst` and
+  // Row sums (< 2^16) of the last seven rows, as a ring of PAIRS of consecutive rows packed into one register
+  // (slot s = rows s and s + 1): rows are taken seven at a time, so row u of a batch always closes slot u - 1
+  // and the taps of an output row are slots u + 1, u + 3, u + 5 (mod 7) plus the new row itself -- all
+  // compile-time indices, no register shuffling, and the column pass is three v_dot2_u32_u16 and one 24-bit
+  // multiply-add per pixel.  All 21 loads of a batch are issued before the first result is stored.  (Written
+  // row by row, every load waits behind the previous row's store -- the compiler cannot prove that `dst` and
   // `img` do not alias -- and a wave pays one memory round trip per row.)
-  int hw[7][4];
+  typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
+  const u16x2 W01 = {18, 34}, W23 = {49, 55}, W45 = {49, 34};
+  unsigned pr[7][4], prev[4] = {0u, 0u, 0u, 0u};
 #pragma unroll
   for (int j = 0; j < 7; j++)
 #pragma unroll
-    for (int q = 0; q < 4; q++) hw[j][q] = 0;
+    for (int q = 0; q < 4; q++) pr[j][q] = 0;
   constexpr int RB = 7;
   for (int yb = y0 - 3; yb < y1 + 3; yb += RB) {
     unsigned Lr[RB], Cr[RB], Rr[RB];
@@ -1155,23 +1159,24 @@ __global__ __launch_bounds__(256) void k_blur_groups(FrameSrc src, int lv0_gener
         Cw = c2;
       }
       // pixel q sits at byte 4+q of (L,C,R); its taps are bytes q+1 .. q+7
-      hw[u][0] = __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(Cw, Lw, 1), K0, __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(Rw, Cw, 1), K1, 0u, false), false);
-      hw[u][1] = __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(Cw, Lw, 2), K0, __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(Rw, Cw, 2), K1, 0u, false), false);
-      hw[u][2] = __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(Cw, Lw, 3), K0, __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(Rw, Cw, 3), K1, 0u, false), false);
-      hw[u][3] = __builtin_amdgcn_udot4(Cw, K0, __builtin_amdgcn_udot4(Rw, K1, 0u, false), false);
-      if (yy >= y0 + 3) {
-        unsigned outw = 0;
+      unsigned hn[4];
+      hn[0] = __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(Cw, Lw, 1), K0, __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(Rw, Cw, 1), K1, 0u, false), false);
+      hn[1] = __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(Cw, Lw, 2), K0, __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(Rw, Cw, 2), K1, 0u, false), false);
+      hn[2] = __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(Cw, Lw, 3), K0, __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(Rw, Cw, 3), K1, 0u, false), false);
+      hn[3] = __builtin_amdgcn_udot4(Cw, K0, __builtin_amdgcn_udot4(Rw, K1, 0u, false), false);
+      unsigned outw = 0;
 #pragma unroll
-        for (int q = 0; q < 4; q++) {
-          // row sums are <= 255 * 257 and their pair sums < 2^17: 24-bit multiplies are exact (and full rate)
-          const int t0 = hw[(u + 1) % 7][q] + hw[u][q], t1 = hw[(u + 2) % 7][q] + hw[(u + 6) % 7][q];
-          const int t2 = hw[(u + 3) % 7][q] + hw[(u + 5) % 7][q];
-          const int acc = __mul24(18, t0) + __mul24(34, t1) + __mul24(49, t2) + __mul24(55, hw[(u + 4) % 7][q]);
-          const unsigned v = (unsigned)min((acc + (1 << 15)) >> 16, 255);
-          outw |= v << (8 * q);
-        }
-        if (active) *reinterpret_cast<unsigned *>(dst + (long long)(yy - 3) * Lpitch) = outw;  // the tail lands in the row padding
+      for (int q = 0; q < 4; q++) {
+        pr[(u + 6) % 7][q] = prev[q] | (hn[q] << 16);  // rows (u - 1, u)
+        prev[q] = hn[q];
+        // taps: rows u-6, u-5 | u-4, u-3 | u-2, u-1 | u with weights 18, 34 | 49, 55 | 49, 34 | 18
+        unsigned acc = (unsigned)__mul24(18, (int)hn[q]) + (1u << 15);
+        acc = __builtin_amdgcn_udot2(__builtin_bit_cast(u16x2, pr[(u + 5) % 7][q]), W45, acc, false);
+        acc = __builtin_amdgcn_udot2(__builtin_bit_cast(u16x2, pr[(u + 3) % 7][q]), W23, acc, false);
+        acc = __builtin_amdgcn_udot2(__builtin_bit_cast(u16x2, pr[(u + 1) % 7][q]), W01, acc, false);
+        outw |= min(acc >> 16, 255u) << (8 * q);
       }
+      if (yy >= y0 + 3 && active) *reinterpret_cast<unsigned *>(dst + (long long)(yy - 3) * Lpitch) = outw;  // the tail lands in the row padding
     }
   }
 }
