@@ -100,7 +100,8 @@ int vo_orb_get_level_counts(vo_orb *h, int frame, int32_t *counts /*nlevels*/);
 
 /* Per-stage timing with HIP events recorded on the handle's stream around each stage of every
  * subsequent call (bench.py's live roofline measurement).  Stages: 0 pyramid (all resize launches),
- * 1 FAST cells, 2 oct-tree, 3 offsets, 4 blur, 5 orientation+descriptor.  vo_orb_get_timing
+ * 1 FAST cells, 2 oct-tree, 3 offsets (always 0: folded into the descriptor kernel), 4 blur,
+ * 5 orientation+descriptor.  vo_orb_get_timing
  * synchronises, adds the elapsed times of the calls since the last reset to ms[VO_ORB_STAGES],
  * returns the number of timed calls in *n_calls and resets the accumulators. */
 #define VO_ORB_STAGES 6

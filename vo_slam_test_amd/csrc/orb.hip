@@ -982,18 +982,6 @@ __global__ __launch_bounds__(256) void k_octree(OrbDev P, const uint32_t *cell_s
   if (tid == 0) nk[f * P.nlevels + l] = (n == 0) ? 0 : nout;
 }
 
-__global__ void k_offsets(int nlevels, int n_frames, const int *nk, int *off, int capacity, int *counts) {
-  const int f = blockIdx.x * blockDim.x + threadIdx.x;
-  if (f >= n_frames) return;
-  int acc = 0;
-  for (int l = 0; l < nlevels; l++) {
-    off[f * (nlevels + 1) + l] = acc;
-    acc += nk[f * nlevels + l];
-  }
-  off[f * (nlevels + 1) + nlevels] = acc;
-  if (counts) counts[f] = min(acc, capacity);
-}
-
 // ------------------------------------------------------------------------------------------
 // K4  cv::GaussianBlur(7x7, sigma 2, BORDER_REFLECT_101) on the unpadded level (:1093-1094).
 // OpenCV <= 3.4.0 8-bit path: kernel quantised to {18,34,49,55,49,34,18}/256 per pass, row pass
@@ -1319,7 +1307,7 @@ __device__ __forceinline__ void window_store(lds_u8 *slot, int lane, const u32x4
 //     and feeds the address arithmetic), eight LDS byte gathers, four 64-bit ballots are the descriptor.
 template <int NK>  // key-points a wave keeps in flight in phases 1 and 3
 __global__ __launch_bounds__(256) void k_describe(OrbDev P, FrameSrc src, const uint32_t *sel,
-                                                  int sel_per_frame, const int *off, int capacity,
+                                                  int sel_per_frame, const int *nk, int *counts, int capacity,
                                                   vo_keypoint *kps, uint8_t *desc, int lv0_bytewise,
                                                   int batches_per_frame, int n_frames) {
   __shared__ DescRec rec[64];
@@ -1331,8 +1319,20 @@ __global__ __launch_bounds__(256) void k_describe(OrbDev P, FrameSrc src, const 
   const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
   const int f = (slot / batches_per_frame) * 8 + xcd, g0 = (slot % batches_per_frame) * 64;
   if (f >= n_frames) return;
-  const int *op = off + f * (P.nlevels + 1);
-  const int total = min(op[P.nlevels], capacity);
+  // the frame's per-level key-point offsets: a prefix sum over its (at most 8) level counts, scalar
+  int op[kMaxLevels + 1];
+  {
+    const int *nkp = nk + f * P.nlevels;
+    int acc = 0;
+#pragma unroll
+    for (int i = 0; i < kMaxLevels; i++) {
+      op[i] = acc;
+      if (i < P.nlevels) acc += nkp[i];
+    }
+    op[kMaxLevels] = acc;
+  }
+  const int total = min(op[kMaxLevels], capacity);
+  if (g0 == 0 && tid == 0 && counts) counts[f] = total;
   const int nv = min(total - g0, 64);  // key-points of this batch (uniform)
   if (nv <= 0) return;
   // per-lane constants of phase 1 (disc offsets and weights), independent of the key-point: in flight under phase 0
@@ -1344,10 +1344,9 @@ __global__ __launch_bounds__(256) void k_describe(OrbDev P, FrameSrc src, const 
   if (tid < nv) {
     const int g = g0 + tid;
     int l = 0, obase = 0;
-    for (int i = 1; i < P.nlevels; i++) {
-      const int oi = op[i];
-      if (g >= oi) l = i, obase = oi;
-    }
+#pragma unroll
+    for (int i = 1; i < kMaxLevels; i++)
+      if (i < P.nlevels && g >= op[i]) l = i, obase = op[i];
     const LevelGeom &L = P.lv[l];  // lane-dependent level: vector loads, once per 64 key-points
     const uint32_t kv = sel[(long long)f * sel_per_frame + L.selBase + (g - obase)];
     const int px = (int)(kv & 0xfff) + kBorder, py = (int)((kv >> 12) & 0xfff) + kBorder;  // :849-850
@@ -1521,7 +1520,7 @@ struct vo_orb {
   int blur_jobs = 0;               // k_blur_groups jobs per frame quad
   unsigned blur_generic_mask = 0;  // levels blurred by the generic kernel
   std::vector<int> tab_off;  // per level: offsets of xofs,xab,yofs,yab in tables
-  vo::DevBuf tables, pyr, blur, slots, cellcnt, keydata, keylabel, candcnt, sel, nk, off, err;
+  vo::DevBuf tables, pyr, blur, slots, cellcnt, keydata, keylabel, candcnt, sel, nk, err;
   vo::DevBuf in_img, out_kp, out_desc, out_cnt;
   int batch_cap = 0;
   // last call
@@ -1781,7 +1780,6 @@ int configure(vo_orb *h, int w, int h_img, int n_frames) {
     VO_CHECK(h->candcnt.reserve(B * kMaxLevels * 4));
     VO_CHECK(h->sel.reserve(B * h->sel_frame * 4));
     VO_CHECK(h->nk.reserve(B * kMaxLevels * 4));
-    VO_CHECK(h->off.reserve(B * (kMaxLevels + 1) * 4));
     VO_CHECK(h->err.reserve(64));
     h->batch_cap = n_frames;
   }
@@ -1886,9 +1884,7 @@ int run_pipeline(vo_orb *h, const uint8_t *dev_images, int n_frames, int w, int 
                        h->keylabel.as<unsigned short>(), h->keys_frame, h->candcnt.as<int>(),
                        h->sel.as<uint32_t>(), h->sel_frame, h->nk.as<int>(), h->err.as<int>());
   VO_STAGE_MARK(3);
-  hipLaunchKernelGGL(k_offsets, dim3((n_frames + 63) / 64), dim3(64), 0, st, D.nlevels, n_frames,
-                     h->nk.as<int>(), h->off.as<int>(), capacity, dcounts);
-  VO_STAGE_MARK(4);
+  // (stage 3, the per-frame offsets and counts, is computed by k_describe itself: no launch and no event here)
   // (the strip kernel reads aligned dwords; a caller image that is not 4-byte aligned falls back to the
   // generic LDS kernel for level 0 only)
   if (overlap)
@@ -1897,9 +1893,10 @@ int run_pipeline(vo_orb *h, const uint8_t *dev_images, int n_frames, int w, int 
     launch_blur(st);
   VO_STAGE_MARK(5);
   const int kp_blocks = (std::min(capacity, h->max_kp) + 63) / 64;
+  if (kp_blocks == 0 && dcounts) VO_HIP_CHECK(hipMemsetAsync(dcounts, 0, (size_t)n_frames * sizeof(int), st));
   if (kp_blocks > 0)
     hipLaunchKernelGGL(k_describe<VO_DESC_NK>, dim3(kp_blocks * ((n_frames + 7) / 8) * 8), dim3(256), 0, st, D, S,
-                       h->sel.as<uint32_t>(), h->sel_frame, h->off.as<int>(), capacity, dkp, ddesc, lv0_not16, kp_blocks,
+                       h->sel.as<uint32_t>(), h->sel_frame, h->nk.as<int>(), dcounts, capacity, dkp, ddesc, lv0_not16, kp_blocks,
                        n_frames);
   VO_STAGE_MARK(6);
 #undef VO_STAGE_MARK
@@ -2004,7 +2001,7 @@ void vo_orb_destroy(vo_orb *h) {
   if (!h) return;
   (void)hipStreamSynchronize(h->stream);
   for (vo::DevBuf *b : {&h->tables, &h->pyr, &h->blur, &h->slots, &h->cellcnt, &h->keydata, &h->keylabel,
-                        &h->candcnt, &h->sel, &h->nk, &h->off, &h->err, &h->in_img, &h->out_kp, &h->out_desc,
+                        &h->candcnt, &h->sel, &h->nk, &h->err, &h->in_img, &h->out_kp, &h->out_desc,
                         &h->out_cnt})
     b->release();
   for (hipEvent_t e : h->ev) (void)hipEventDestroy(e);
@@ -2112,8 +2109,9 @@ int vo_orb_get_timing(vo_orb *h, double *ms, int *n_calls) {
   for (int c = 0; c < h->timed_calls; c++) {
     hipEvent_t *ev = h->ev.data() + (size_t)c * (VO_ORB_STAGES + 1);
     for (int s = 0; s < VO_ORB_STAGES; s++) {
+      if (s == 3) continue;  // folded into the descriptor kernel; event 4 is not recorded
       float t = 0;
-      VO_HIP_CHECK(hipEventElapsedTime(&t, ev[s], ev[s + 1]));
+      VO_HIP_CHECK(hipEventElapsedTime(&t, ev[s == 4 ? 3 : s], ev[s + 1]));
       ms[s] += t;
     }
   }
