@@ -334,6 +334,12 @@ __global__ __launch_bounds__(256) void k_fast_wave(OrbDev P, FrameSrc src, uint3
   const int *cd = cell_tab + 16 * cell;
   const int l = cd[0], iniX = cd[1], iniY = cd[2], cw = cd[3], ch = cd[4], xoff = cd[5], yoff = cd[6];
   const int slot_off = cd[7], cap_cell = cd[8];
+  // score rows start at 0: the 3-px margin around the interior is read by the NMS and never written (all rows
+  // of the buffer, not just the cell's: the loop then does not wait for the table entry)
+  for (int i = lane; i < tile_rows * (TP / 8); i += 64) {
+    const int r = i / (TP / 8), k = i - r * (TP / 8);
+    *(__attribute__((address_space(3))) unsigned long long *)(tile_raw + r * RP + TP + 8 * k) = 0ull;
+  }
   int *out_count = cell_count + (long long)f * cells_per_frame + cell;
   const int iw = cw - 6, ih = ch - 6;
   if (iw <= 0 || ih <= 0) {  // :801, :811 (cw = 0 in the table), or no interior pixel
@@ -348,11 +354,6 @@ __global__ __launch_bounds__(256) void k_fast_wave(OrbDev P, FrameSrc src, uint3
   } else {
     pitch = cd[9];
     img = src.pyr + (long long)f * src.pyr_frame_stride + (((long long)cd[11] << 32) | (unsigned)cd[10]);
-  }
-  // score rows start at 0: the 3-px margin around the interior is read by the NMS and never written
-  for (int i = lane; i < ch * (TP / 8); i += 64) {
-    const int r = i / (TP / 8), k = i - r * (TP / 8);
-    *(__attribute__((address_space(3))) unsigned long long *)(tile_raw + r * RP + TP + 8 * k) = 0ull;
   }
   // ---- stage the cell (incl. the 6-px overlap) in LDS.  The tile keeps the source's dword alignment: LDS
   // column 0 is image column iniX - (iniX & 3), so a row is a run of aligned dwords copied verbatim.  A lane
