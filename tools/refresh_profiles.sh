@@ -8,7 +8,7 @@ O=$R/gpurun_out/refresh
 rm -rf $O; mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
 # 1. kernel trace + stats of the bench command
-rocprofv3 --kernel-trace --stats -d $O/kt --output-format csv -- python3 $R/bench.py --steps 10 --warmup 2 --no-cpu-baseline > $O/kt.log 2>&1
+rocprofv3 --kernel-trace --stats -d $O/kt --output-format csv -- python3 $R/bench.py --steps 40 --warmup 2 --no-cpu-baseline > $O/kt.log 2>&1
 f=$(find $O/kt -name "*kernel_stats.csv" | head -1)
 cp "$f" $O/r${NN}_kernel_stats.csv
 python3 $R/tools/prof_summary.py $O/kt 30 > $O/r${NN}_kernel_stats_summary.txt 2>&1
