@@ -2546,9 +2546,10 @@ int vo_pose_only_solve(int n_problems, const int32_t *offsets, const double *poi
   const size_t r_pose = 0, r_sum = r_pose + (size_t)n_problems * 48,
                r_inl = r_sum + (size_t)n_problems * 2 * sizeof(vo_lm_summary), r_out = up8(r_inl + (size_t)n_problems * 4),
                out_bytes = up8(r_out + (size_t)std::max(total, 1));
-  thread_local std::vector<uint8_t> stage;
+  thread_local vo::PinnedBuf pinned;
   thread_local vo::DevBuf d_in, d_out;
-  stage.resize(std::max(in_bytes, out_bytes));
+  VO_CHECK(pinned.reserve(std::max(in_bytes, out_bytes)));
+  uint8_t *stage = pinned.data();
   if (total > 0) {
     memcpy(&stage[o_pts], points, (size_t)total * 24);
     memcpy(&stage[o_obs], obs, (size_t)total * 24);
@@ -2559,7 +2560,7 @@ int vo_pose_only_solve(int n_problems, const int32_t *offsets, const double *poi
   memcpy(&stage[o_off], offsets, (size_t)(n_problems + 1) * 4);
   VO_CHECK(d_in.reserve(in_bytes));
   VO_CHECK(d_out.reserve(out_bytes));
-  VO_HIP_CHECK(hipMemcpy(d_in.p, stage.data(), in_bytes, hipMemcpyHostToDevice));
+  VO_HIP_CHECK(hipMemcpyAsync(d_in.p, stage, in_bytes, hipMemcpyHostToDevice, nullptr));
   uint8_t *di = d_in.as<uint8_t>(), *dout = d_out.as<uint8_t>();
   // the kernel updates poses in place: give it the output block's copy
   VO_HIP_CHECK(hipMemcpyAsync(dout + r_pose, di + o_pose, (size_t)n_problems * 48, hipMemcpyDeviceToDevice, nullptr));
@@ -2570,7 +2571,9 @@ int vo_pose_only_solve(int n_problems, const int32_t *offsets, const double *poi
                                   reinterpret_cast<double *>(dout + r_pose), dout + r_out,
                                   reinterpret_cast<int32_t *>(dout + r_inl),
                                   reinterpret_cast<vo_lm_summary *>(dout + r_sum), nullptr));
-  if (hipMemcpy(stage.data(), dout, out_bytes, hipMemcpyDeviceToHost) != hipSuccess) {  // synchronises with the kernel
+  // the inputs have left the staging block once the kernel has run: it takes the results back
+  if (hipMemcpyAsync(stage, dout, out_bytes, hipMemcpyDeviceToHost, nullptr) != hipSuccess ||
+      hipStreamSynchronize(nullptr) != hipSuccess) {
     vo::set_error("pose-only kernel failed: %s", hipGetErrorString(hipGetLastError()));
     return VO_ERR_HIP;
   }

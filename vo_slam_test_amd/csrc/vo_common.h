@@ -53,6 +53,24 @@ struct DevBuf {
   }
 };
 
+// Grow-only page-locked host staging (per host thread where used): copies to and from it run at full PCIe
+// rate and without the runtime's own bounce buffer.  Never freed (thread-exit order vs. runtime teardown).
+struct PinnedBuf {
+  void *p = nullptr;
+  size_t bytes = 0;
+  int reserve(size_t n) {
+    if (n <= bytes) return VO_OK;
+    if (p) (void)hipHostFree(p);
+    p = nullptr;
+    bytes = 0;
+    const size_t want = n + n / 2 + 4096;
+    VO_HIP_CHECK(hipHostMalloc(&p, want, hipHostMallocDefault));
+    bytes = want;
+    return VO_OK;
+  }
+  uint8_t *data() const { return reinterpret_cast<uint8_t *>(p); }
+};
+
 constexpr int kWave = 64;
 
 // Dense SPD solve on the device (csrc/pose_graph.hip).  A: (ld + 64) rows x ld columns, row-major, ld a
