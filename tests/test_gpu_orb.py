@@ -198,3 +198,38 @@ def test_scale_factors_and_large_images(vo, orc, w, h, nf, sf, nl):
     e.close()
     assert len(kps) == len(okp) > 0, (w, h, sf)
     assert np.array_equal(kps, okp) and np.array_equal(desc, odesc), (w, h, sf)
+
+
+def test_large_batch_is_deterministic_and_matches_oracle(ext, orc):
+    """bench-sized batch (256 frames = 32 distinct ones, 8 times): identical frames give identical outputs
+    wherever they sit in the batch (frame quads of the pyramid / blur kernels, XCD dealing of the descriptor
+    batches), a second run reproduces the first bit for bit, and sampled frames equal the oracle"""
+    import torch
+    from vo_slam_test_amd import _lib
+    base = synth.make_frames(32, start=100)
+    dev = torch.from_numpy(base).cuda().repeat(8, 1, 1).contiguous()
+    nb = dev.shape[0]
+    cap = ext.max_keypoints()
+    outs = []
+    for _ in range(2):
+        kps = torch.zeros((nb, cap, 28), dtype=torch.uint8, device="cuda")
+        desc = torch.zeros((nb, cap, 32), dtype=torch.uint8, device="cuda")
+        cnt = torch.zeros(nb, dtype=torch.int32, device="cuda")
+        torch.cuda.synchronize()
+        ext.extract_batch_dev(dev, kps, desc, cnt)
+        ext.sync()
+        outs.append((kps.cpu().numpy(), desc.cpu().numpy(), cnt.cpu().numpy()))
+    for a, b in zip(outs[0], outs[1]):
+        assert np.array_equal(a, b)
+    kps, desc, cnt = outs[0]
+    for f in range(32, nb):
+        n = int(cnt[f])
+        assert n == int(cnt[f - 32])
+        assert np.array_equal(kps[f, :n], kps[f - 32, :n]) and np.array_equal(desc[f, :n], desc[f - 32, :n]), f
+    p = orc.orb_params()
+    for f in (0, 77, 255):
+        okp, odesc, _ = orc.extract(p, base[f % 32])
+        n = int(cnt[f])
+        assert n == len(okp)
+        assert np.array_equal(np.frombuffer(kps[f, :n].tobytes(), dtype=_lib.KP_DTYPE), okp)
+        assert np.array_equal(desc[f, :n], odesc)
