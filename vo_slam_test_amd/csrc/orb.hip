@@ -626,8 +626,10 @@ __device__ __forceinline__ int quadrant_of(int kx, int ky, int x0, int y0, int x
   return (kx < midx ? 0 : 1) + (ky < midy ? 0 : 2);  // n1,n2,n3,n4            :522-534
 }
 
+// (7 waves per SIMD = 7 workgroups per CU: the kernel is a chain of latencies, co-resident workgroups are its
+// throughput; 0.326 -> 0.283 ms per 1024 frames against the compiler's own choice of 88 registers / 5 waves)
 template <int CAP>
-__global__ __launch_bounds__(256) void k_octree(OrbDev P, const uint32_t *cell_slots,
+__attribute__((amdgpu_waves_per_eu(7, 7))) __global__ __launch_bounds__(256) void k_octree(OrbDev P, const uint32_t *cell_slots,
                                                 long long slots_frame_stride, const int *cell_count,
                                                 int cells_per_frame, uint32_t *key_data,
                                                 unsigned short *key_label, int keys_per_frame,
