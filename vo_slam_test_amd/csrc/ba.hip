@@ -2140,6 +2140,7 @@ struct vo_ba {
   hipStream_t stream = nullptr;
   bool own_stream = false;
   bool built = false;
+  vo::PinnedBuf pin;  // page-locked landing block of vo_ba_local_ba_finish (results of a solve)
   BaDev D{};
   vo::DevBuf b_ecam, b_ept, b_eobs, b_eis, b_eact, b_ptstart, b_local, b_camslot, b_slotcam, b_camstart,
       b_camedges, b_ptin, b_camin, b_xc0, b_xc1, b_xp0, b_xp1, b_pc0, b_pc1, b_sc, b_sp, b_hinv, b_gl2, b_dl, b_wt, b_wt1, b_hll0, b_hll1, b_spt1,
@@ -2695,6 +2696,7 @@ void vo_ba_destroy(vo_ba *h) {
                         &h->b_glsc0, &h->b_glsc1, &h->b_Sd, &h->b_scv, &h->b_ddv, &h->b_gppv, &h->b_cholfail,
                         &h->b_pairstart, &h->b_paircc, &h->b_paire})
     b->release();
+  if (h->pin.p) (void)hipHostFree(h->pin.p);
   if (h->own_stream) (void)hipStreamDestroy(h->stream);
   delete h;
 }
@@ -2825,9 +2827,12 @@ int vo_ba_local_ba_enqueue(vo_ba *h, const volatile int *stop) {
 
 int vo_ba_local_ba_finish(vo_ba *h, uint8_t *edge_erase, vo_lm_summary *sums) {
   if (!h || !edge_erase || !h->built) return VO_ERR_INVALID;
-  std::vector<uint8_t> tmp(std::max(1, h->n_edges));
-  BaState st[3];
-  VO_HIP_CHECK(hipMemcpyAsync(tmp.data(), h->b_out.p, h->n_edges, hipMemcpyDeviceToHost, h->stream));
+  // both results land in one page-locked block: a copy into pageable memory costs ~20 us apiece
+  const size_t st_off = ((size_t)std::max(1, h->n_edges) + 15) & ~(size_t)15;
+  VO_CHECK(h->pin.reserve(st_off + 3 * sizeof(BaState)));
+  uint8_t *tmp = h->pin.data();
+  BaState *st = reinterpret_cast<BaState *>(tmp + st_off);
+  VO_HIP_CHECK(hipMemcpyAsync(tmp, h->b_out.p, h->n_edges, hipMemcpyDeviceToHost, h->stream));
   VO_HIP_CHECK(hipMemcpyAsync(st, h->D.st, 3 * sizeof(BaState), hipMemcpyDeviceToHost, h->stream));
   VO_HIP_CHECK(hipStreamSynchronize(h->stream));
   for (int s = 0; s < h->n_edges; s++) edge_erase[h->perm[s]] = tmp[s];
