@@ -14,6 +14,7 @@
 #include <opencv2/core/core.hpp>
 
 #include <stdexcept>
+#include <string>
 #include <vector>
 
 #include "vo_hip.h"

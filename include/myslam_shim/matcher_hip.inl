@@ -6,6 +6,7 @@
 // member of Matcher except the constructor and computeThreeMax.
 //
 // Needs the reference's headers (Frame, MapPoint, Camera): compile inside the reference tree.
+#include <cstring>
 #include <vector>
 
 #include "vo_hip.h"
@@ -33,9 +34,17 @@ struct FrameFlat {
   }
 };
 
+// Matcher::computeDistance (matcher.cpp:1240-1256): ONE pair is eight host popcounts -- a GPU round trip per
+// 256-bit distance would turn microseconds into milliseconds.  Its only N x N caller, MapPoint::computeDescriptor,
+// has its own shim (mappoint_hip.inl: one kernel launch per map point or per batch of map points).
 int Matcher::computeDistance(const Mat &a, const Mat &b) {
-  uint16_t d = 0;
-  vo_hamming_matrix(a.ptr<uint8_t>(), 1, b.ptr<uint8_t>(), 1, &d);
+  const uint8_t *pa = a.ptr<uint8_t>(), *pb = b.ptr<uint8_t>();
+  int d = 0;
+  for (int w = 0; w < 4; w++) {
+    unsigned long long x, y;
+    memcpy(&x, pa + 8 * w, 8), memcpy(&y, pb + 8 * w, 8);
+    d += __builtin_popcountll(x ^ y);
+  }
   return d;
 }
 

@@ -1,11 +1,14 @@
-// include/myslam_shim/optimizer_hip.inl -- replacement bodies for Optimizer::solvePoseOnlySE3 and
-// Optimizer::solveLocalBAPoseAndPoint (reference src/optimizer_ceres.cpp:157-314, 446-808).
-// #include at the bottom of a copy of optimizer_ceres.cpp from which those two functions were
-// removed (the Sim3 / pose-graph functions keep using Ceres).  Only the pointer-graph gather and the
-// write-back stay on the host; the Ceres solves, the chi2 tests and the LM loop run on the GPU.
+// include/myslam_shim/optimizer_hip.inl -- replacement bodies for every member of myslam::Optimizer:
+// solvePoseOnlySE3, solveLocalBAPoseAndPoint, solveLoopSim3 and solvePoseGraphLoop (reference
+// src/optimizer_ceres.cpp:157-314, 446-808, 810-1030, 1036-1305).  #include at the bottom of a copy of
+// optimizer_ceres.cpp from which those functions and the cost-function classes were removed: Ceres is no
+// longer needed at all (only Eigen and Sophus, which the reference's own headers pull in).  The pointer-graph
+// gather and the write-back stay on the host; the solves, the chi2 tests and the LM loops run on the GPU.
 //
-// Needs the reference's headers (Frame, KeyFrame, MapPoint, Map, Sophus): compile inside the
-// reference tree.
+// Needs the reference's headers (Frame, KeyFrame, MapPoint, Map, LoopClosing, Sophus): compile inside the
+// reference tree.  tests/test_shims_compile.py checks the syntax against stub declarations of those types.
+#include <algorithm>
+#include <cstring>
 #include <map>
 #include <set>
 #include <vector>
@@ -108,13 +111,12 @@ void Optimizer::solveLocalBAPoseAndPoint(KeyFrame *keyframe, bool &stopFlag, Map
   if (vo_ba_create(&h, (int)cams.size(), poses.data(), fixed.data(), (int)points.size(), pts.data(),
                    (int)edges.size(), e_cam.data(), e_pt.data(), e_obs.data(), e_is.data(), cam) != VO_OK)
     return;
-  // ---- solve (problem 1, chi2, problem 2, chi2) with the reference's stopFlag polling points
-  // The reference polls `stopFlag` (a bool written by the tracking thread) at :594 and :612.  The
-  // device schedule lasts about a millisecond, so both polls collapse into this one; the C-ABI takes
-  // an int flag for callers that want the second poll as well.
+  // ---- solve (problem 1, chi2, problem 2, chi2) with the reference's stopFlag polling points: the library
+  // reads the caller's LIVE flag (a bool written by the tracking thread, localMapping.cpp:72,540) as a byte at
+  // :594 and again at :612, so a stop raised while problem 1 is being queued is still seen
   std::vector<uint8_t> erase(edges.size() + 1, 0);
-  volatile int stop = stopFlag ? 1 : 0;
-  const int rc = vo_ba_local_ba(h, &stop, erase.data(), nullptr);
+  static_assert(sizeof(bool) == 1, "stopFlag is polled as a byte");
+  const int rc = vo_ba_local_ba(h, reinterpret_cast<const volatile unsigned char *>(&stopFlag), erase.data(), nullptr);
   if (rc != VO_OK) {  // VO_ERR_STOPPED mirrors the early return at :594-595 (no write-back)
     vo_ba_destroy(h);
     return;
@@ -148,7 +150,13 @@ int Optimizer::solveLoopSim3(KeyFrame *kf_curr, KeyFrame *kf_match, vector<MapPo
   double pose[6], scale = Scm.scale();
   const Matrix3d Rcm = Scm.rotation_matrix();
   const Vector3d tcm = Scm.translation();
-  ceres::RotationMatrixToAngleAxis(Rcm.data(), pose);  // any log map of SO(3) will do here
+  {  // angle-axis of Rcm (:826 uses ceres::RotationMatrixToAngleAxis; any log map of SO(3) gives the same vector)
+    double R[9], t0[3] = {0, 0, 0}, xi[6];
+    for (int r = 0; r < 3; r++)
+      for (int cc = 0; cc < 3; cc++) R[3 * r + cc] = Rcm(r, cc);
+    vo_se3_log(R, t0, xi);
+    pose[0] = xi[3], pose[1] = xi[4], pose[2] = xi[5];
+  }
   memcpy(pose + 3, tcm.data(), 3 * sizeof(double));
   Camera *c = kf_curr->camera_;
   const double camera[4] = {c->fx_, c->fy_, c->cx_, c->cy_};
@@ -172,48 +180,138 @@ int Optimizer::solveLoopSim3(KeyFrame *kf_curr, KeyFrame *kf_match, vector<MapPo
   const int32_t offsets[2] = {0, (int32_t)index.size()};
   std::vector<uint8_t> outlier(index.size() + 1, 0);
   int32_t inliers = 0;
-  vo_sim3_solve(1, offsets, cam_m.data(), pix_c.data(), is_c.data(), cam_c.data(), pix_m.data(), is_m.data(), camera,
-                fixScaleFlag ? 1 : 0, pose, &scale, outlier.data(), &inliers, nullptr);
+  vo_lm_summary sums[2];
+  if (vo_sim3_solve(1, offsets, cam_m.data(), pix_c.data(), is_c.data(), cam_c.data(), pix_m.data(), is_m.data(), camera,
+                    fixScaleFlag ? 1 : 0, pose, &scale, outlier.data(), &inliers, sums) != VO_OK)
+    return 0;  // no error channel in the reference: "no inliers", Scm untouched
   for (size_t k = 0; k < index.size(); k++)
     if (outlier[k]) inlierMappoints[index[k]] = static_cast<MapPoint *>(nullptr);
-  if (inliers == 0 && (int)index.size() - (int)std::count(outlier.begin(), outlier.end(), 1) < 10) return 0;  // :950-951
-  double R[9];
-  ceres::AngleAxisToRotationMatrix(pose, R);
-  Scm = Sophus::Sim3(Sophus::ScSO3(scale, Eigen::Map<const Matrix3d>(R)), Eigen::Map<const Vector3d>(pose + 3));
+  if (sums[0].reserved != 2) return 0;  // fewer than 10 survivors of problem 1: :950-951 returns before Scm is written
+  // both problems ran: Scm = Scm2 even when the final test leaves no inlier (:1024-1027)
+  double R[9], t0[3];
+  const double xi[6] = {0, 0, 0, pose[0], pose[1], pose[2]};
+  vo_se3_exp(xi, R, t0);
+  Matrix3d Rm;
+  for (int r = 0; r < 3; r++)
+    for (int cc = 0; cc < 3; cc++) Rm(r, cc) = R[3 * r + cc];
+  Scm = Sophus::Sim3(Sophus::ScSO3(scale, Rm), Vector3d(pose[3], pose[4], pose[5]));
   return inliers;
 }
 
-// The solve and the map-point re-anchoring inside Optimizer::solvePoseGraphLoop, reference
-// optimizer_ceres.cpp:1036-1305.  The edge construction (:1094-1236) is the reference's own code with
-// `problem.AddResidualBlock(...)` replaced by `pg.add(id1, id2, Sji)`; only what changes is shown.
-struct PoseGraphArrays {
-  std::vector<double> quats, trans, scales, q_meas, t_meas, s_meas;
+// Optimizer::solvePoseGraphLoop, reference optimizer_ceres.cpp:1036-1305: pose collection (:1062-1083), the four
+// edge families (:1094-1236: loop connections, spanning tree, earlier loop edges, covisibility >= 100), the solve
+// (:1238-1258), key-frame write-back (:1264-1278) and map-point re-anchoring (:1281-1301).
+int Optimizer::solvePoseGraphLoop(Map *map_curr, KeyFrame *keyframe_match, KeyFrame *keyframe_curr,
+                                  const LoopClosing::KeyFrameAndPose &uncorrectPose,
+                                  const LoopClosing::KeyFrameAndPose &correctPose,
+                                  const map<KeyFrame *, set<KeyFrame *>> &loopConnections, const bool &fixScaleFlag) {
+  vector<KeyFrame *> allKeyFrames = map_curr->getAllKeyFrames();
+  vector<MapPoint *> allMapPoints = map_curr->getAllMapPoints();
+  const unsigned long maxKFId = map_curr->maxKFId_;
+  const size_t n_ids = maxKFId + 1;
+  vector<Sophus::Sim3, Eigen::aligned_allocator<Sophus::Sim3>> Scw(n_ids);
+  std::vector<double> quats(4 * n_ids, 0.0), trans(3 * n_ids, 0.0), scales(n_ids, 1.0), q_meas, t_meas, s_meas;
   std::vector<int32_t> e_i, e_j;
-  explicit PoseGraphArrays(size_t n_ids) : quats(4 * n_ids, 0.0), trans(3 * n_ids, 0.0), scales(n_ids, 1.0) {
-    for (size_t i = 0; i < n_ids; i++) quats[4 * i + 3] = 1.0;
+  for (size_t i = 0; i < n_ids; i++) quats[4 * i + 3] = 1.0;  // ids without a key-frame: identity, no edge touches them
+  for (KeyFrame *kf : allKeyFrames) {  // :1062-1083
+    const unsigned long idx = kf->id_;
+    LoopClosing::KeyFrameAndPose::const_iterator it = correctPose.find(kf);
+    if (it != correctPose.end()) {
+      Scw[idx] = it->second;
+    } else {
+      SE3 Tiw = kf->getPose();
+      Scw[idx] = Sophus::Sim3(Sophus::ScSO3(Tiw.unit_quaternion()), Tiw.translation());
+    }
+    const Quaterniond q = Scw[idx].quaternion().normalized();
+    memcpy(&quats[4 * idx], q.coeffs().data(), 32);  // Eigen coefficient order x, y, z, w
+    const Vector3d t = Scw[idx].translation();
+    memcpy(&trans[3 * idx], t.data(), 24);
+    scales[idx] = Scw[idx].scale();
   }
-  void set_node(unsigned long id, const Sophus::Sim3 &S) {  // :1074-1076
-    const Eigen::Quaterniond q = S.quaternion().normalized();
-    memcpy(&quats[4 * id], q.coeffs().data(), 32);          // x, y, z, w
-    memcpy(&trans[3 * id], S.translation().data(), 24);
-    scales[id] = S.scale();
-  }
-  void add(unsigned long id1, unsigned long id2, const Sophus::Sim3 &Sji) {
-    const Eigen::Quaterniond q = Sji.quaternion().normalized();
+  auto add_edge = [&](unsigned long id1, unsigned long id2, const Sophus::Sim3 &Sji) {  // one AddResidualBlock
+    const Quaterniond q = Sji.quaternion().normalized();
+    const Vector3d t = Sji.translation();
     e_i.push_back((int32_t)id1), e_j.push_back((int32_t)id2);
     q_meas.insert(q_meas.end(), q.coeffs().data(), q.coeffs().data() + 4);
-    t_meas.insert(t_meas.end(), Sji.translation().data(), Sji.translation().data() + 3);
+    t_meas.insert(t_meas.end(), t.data(), t.data() + 3);
     s_meas.push_back(Sji.scale());
+  };
+  auto pose_or = [&](const LoopClosing::KeyFrameAndPose &m, KeyFrame *kf) -> Sophus::Sim3 {
+    LoopClosing::KeyFrameAndPose::const_iterator it = m.find(kf);
+    return it != m.end() ? it->second : Scw[kf->id_];
+  };
+  const int minFeat = 100;
+  set<pair<unsigned long, unsigned long>> insertedLoopEdges;
+  for (auto it = loopConnections.begin(); it != loopConnections.end(); it++) {  // :1094-1125, corrected poses
+    KeyFrame *kf = it->first;
+    const unsigned long id1 = kf->id_;
+    const Sophus::Sim3 Swi = Scw[id1].inverse();
+    for (KeyFrame *kc : it->second) {
+      const unsigned long id2 = kc->id_;
+      // Q-B5: `id2 != curr || id2 != match` is always true, so only the weight gate acts (:1105)
+      if ((id2 != keyframe_curr->id_ || id2 != keyframe_match->id_) && kf->getWeight(kc) < minFeat) continue;
+      add_edge(id1, id2, Scw[id2] * Swi);
+      insertedLoopEdges.insert(make_pair(min(id1, id2), max(id1, id2)));
+    }
   }
-  int solve(unsigned long fixed_id, bool fixScaleFlag) {  // :1238-1258
-    return vo_pose_graph_solve((int)scales.size(), quats.data(), trans.data(), scales.data(), (int)fixed_id,
-                               (int)e_i.size(), e_i.data(), e_j.data(), q_meas.data(), t_meas.data(), s_meas.data(),
-                               fixScaleFlag ? 1 : 0, 20, nullptr);
+  for (KeyFrame *kf : allKeyFrames) {  // :1128-1236, uncorrected poses
+    const unsigned long id1 = kf->id_;
+    const Sophus::Sim3 Swi = pose_or(uncorrectPose, kf).inverse();
+    KeyFrame *parentKF = kf->getParent();
+    if (parentKF) add_edge(id1, parentKF->id_, pose_or(uncorrectPose, parentKF) * Swi);  // spanning tree :1141-1166
+    const set<KeyFrame *> loopEdges = kf->loopEdges_;
+    for (KeyFrame *kfl : loopEdges)  // loop edges found before this closure :1168-1198
+      if (kfl->id_ < keyframe_curr->id_) add_edge(id1, kfl->id_, pose_or(uncorrectPose, kfl) * Swi);
+    for (KeyFrame *kfw : kf->getCovisiblesByWeight(minFeat)) {  // covisibility >= 100 :1200-1236
+      if (!kfw || kfw == parentKF || kf->children_.count(kfw) || loopEdges.count(kfw)) continue;
+      if (kfw->isBad() || !(kfw->id_ < kf->id_)) continue;
+      if (insertedLoopEdges.count(make_pair(kfw->id_, kf->id_))) continue;
+      add_edge(id1, kfw->id_, pose_or(uncorrectPose, kfw) * Swi);
+    }
   }
-};
-// After pg.solve(keyframe_match->id_, fixScaleFlag): key-frame poses are written as at :1264-1278
-// (SE3(uq, t / s)), the Sim3 pairs (Scw[idm], optimizedSwc[idm]) are packed 8 doubles each and
-// vo_sim3_reanchor_points() produces every corrected map-point position of :1281-1301 in one call
-// (ref = correctReference_ or keyFrame_ref_->id_, -1 for bad points).
+  // :1238-1258: key-frame `match` constant, quaternion parameterisation, scales constant, <= 20 iterations
+  vo_pose_graph_solve((int)n_ids, quats.data(), trans.data(), scales.data(), (int)keyframe_match->id_, (int)e_i.size(),
+                      e_i.data(), e_j.data(), q_meas.data(), t_meas.data(), s_meas.data(), fixScaleFlag ? 1 : 0, 20,
+                      nullptr);
+  {
+    unique_lock<mutex> lock(map_curr->mutexMapUpdate_);
+    std::vector<double> S_rw(8 * n_ids, 0.0), S_wr(8 * n_ids, 0.0);  // Sim3 as quaternion (x y z w), translation, scale
+    auto pack = [](const Sophus::Sim3 &S, double *o) {
+      const Quaterniond q = S.quaternion().normalized();
+      const Vector3d t = S.translation();
+      memcpy(o, q.coeffs().data(), 32), memcpy(o + 4, t.data(), 24);
+      o[7] = S.scale();
+    };
+    for (KeyFrame *kf : allKeyFrames) {  // :1264-1278
+      const unsigned long id = kf->id_;
+      const Quaterniond uq(quats[4 * id + 3], quats[4 * id], quats[4 * id + 1], quats[4 * id + 2]);  // (w, x, y, z)
+      const Vector3d t(trans[3 * id], trans[3 * id + 1], trans[3 * id + 2]);
+      const double s = scales[id];
+      SE3 Tiw(uq, t / s);
+      kf->setPose(Tiw);
+      const Sophus::Sim3 Siw(Sophus::ScSO3(s, Tiw.rotation_matrix()), t);
+      pack(Scw[id], &S_rw[8 * id]);
+      pack(Siw.inverse(), &S_wr[8 * id]);
+    }
+    const size_t np = allMapPoints.size();  // :1281-1301, all points in one call
+    std::vector<double> pin(3 * np + 3), pout(3 * np + 3);
+    std::vector<int32_t> ref(np + 1, -1);
+    for (size_t i = 0; i < np; i++) {
+      MapPoint *mp = allMapPoints[i];
+      if (mp->isBad()) continue;
+      ref[i] = (int32_t)(mp->loopCorrectByKF_ == keyframe_curr->id_ ? mp->correctReference_ : mp->keyFrame_ref_->id_);
+      const Vector3d p = mp->getPose();
+      pin[3 * i] = p[0], pin[3 * i + 1] = p[1], pin[3 * i + 2] = p[2];
+    }
+    if (np > 0 && vo_sim3_reanchor_points((int)np, pin.data(), ref.data(), (int)n_ids, S_rw.data(), S_wr.data(),
+                                          pout.data()) == VO_OK)
+      for (size_t i = 0; i < np; i++)
+        if (ref[i] >= 0) {
+          allMapPoints[i]->setPose(Vector3d(pout[3 * i], pout[3 * i + 1], pout[3 * i + 2]));
+          allMapPoints[i]->updateNormalAndDepth();
+        }
+  }
+  return 0;  // Q-B6: the reference falls off the end of an int function; its callers ignore the value
+}
 
 }  // namespace myslam

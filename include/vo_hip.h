@@ -126,8 +126,18 @@ int vo_hamming_matrix_batch_dev(const uint8_t *dev_a, int na, size_t a_stride, c
  * median selection (mappoint.cpp:140-151) consumes */
 int vo_hamming_matrix(const uint8_t *a, int na, const uint8_t *b, int nb, uint16_t *d);
 
+/* MapPoint::computeDescriptor (mappoint.cpp:118-179): for each set s (one map point) of
+ * descriptors desc[offsets[s] .. offsets[s+1]) -- the rows kf->descriptors_.row(idx) of its good
+ * observers -- the index (within the set) of the descriptor with the smallest median Hamming
+ * distance to all members (:140-172); -1 for an empty set (:136-137 returns without choosing).
+ * ONE kernel launch for the whole batch (the N x N distances never leave the GPU); at most 1024
+ * observations per map point.  Host pointers.  (The scalar Matcher::computeDistance of two
+ * descriptors is a host inline popcount in the shim: a GPU round trip per pair would be absurd.) */
+int vo_median_descriptor(const uint8_t *desc, int n_sets, const int32_t *offsets, int32_t *best_idx);
+
+
 /* one frame's features as the matcher sees them (Frame members, frame.h:26-45) */
-typedef struct {
+typedef struct vo_frame_view_s {
   int32_t n;
   const float *x, *y;       /* unKeypoints_[i].pt */
   const int32_t *octave;    /* unKeypoints_[i].octave */
@@ -137,14 +147,85 @@ typedef struct {
   float xmin, ymin, xmax, ymax; /* Camera::xMin_.. (camera.cpp:40-43) */
 } vo_frame_view;
 
+/* ------------------------------------------------------------------------------------------
+ * Device-resident frames  --  Frame::undistortKeyPoints / findDepth / assignFeaturesToGrid
+ * (frame.cpp:36-133) and Frame/KeyFrame::getFeaturesInArea (frame.cpp:199-247,
+ * keyframe.cpp:268-312) on the GPU: key-points stay in HBM between the extractor and the matcher.
+ * A vo_frames handle stores up to max_frames frames of up to max_features (<= 16384) features:
+ * undistorted key-points, octave, angle, uRight, depth, descriptors and the 64 x 48 grid as CSR.
+ * ------------------------------------------------------------------------------------------ */
+typedef struct vo_frames vo_frames;
+int vo_frames_create(vo_frames **out, int max_frames, int max_features);
+void vo_frames_destroy(vo_frames *h);
+int vo_frames_capacity(const vo_frames *h, int *max_frames, int *max_features);
+/* Camera (camera.cpp:8-47): intrinsics = fx, fy, cx, cy, bf; dist_coef = k1, k2, p1, p2, k3 (NULL or
+ * k1 == 0: no undistortion, frame.cpp:41-45); image bounds xMin = yMin = 0, xMax = width, yMax = height. */
+int vo_frames_set_camera(vo_frames *h, const float intrinsics[5], const float dist_coef[5], float width,
+                         float height);
+/* Frame::Frame post-processing (frame.cpp:27-32) of n_frames extractor outputs into slots
+ * slot0 ..: dev_keypoints [n_frames][capacity], dev_descriptors [n_frames][capacity][32], dev_counts
+ * [n_frames] exactly as vo_orb_extract_batch_dev wrote them.  depth_kind 0: no depth (uRight = depth
+ * = -1); 1: float32 metres [h][depth_pitch_bytes]; 2: uint16 raw, metres = raw * inv_depth_scale
+ * (Mat::convertTo, visualOdometry.cpp:162-163).  cv::undistortPoints = OpenCV 3.x: 5 fixed-point
+ * iterations in double.  Asynchronous on hip_stream. */
+int vo_frames_build_dev(vo_frames *h, int slot0, int n_frames, const vo_keypoint *dev_keypoints,
+                        const uint8_t *dev_descriptors, const int32_t *dev_counts, int capacity,
+                        const void *dev_depth, int depth_kind, size_t depth_frame_stride_bytes,
+                        int depth_pitch_bytes, float inv_depth_scale, void *hip_stream);
+/* one already post-processed frame from host arrays (builds the grid); depth may be NULL */
+int vo_frames_upload(vo_frames *h, int slot, const vo_frame_view *view, const float *depth,
+                     void *hip_stream);
+/* copy a slot back (tests / shims): any output may be NULL; cell_start has 64*48+1 entries
+ * (cell = ix * 48 + iy), cell_items n entries (feature indices in push_back order). */
+int vo_frames_download(vo_frames *h, int slot, int *n, float *x, float *y, int32_t *octave, float *angle,
+                       float *uright, float *depth, uint8_t *desc, int32_t *cell_start,
+                       uint16_t *cell_items, void *hip_stream);
+
+/* Guided (window) matching on device-resident frames, batched over frames: frame f of the call
+ * searches slot slot0 + f with its own block of queries (query q of frame f at index
+ * f * stride + q of every array; all device pointers).
+ *   mode 0  searchByProjection(Frame*, Frame*)     matcher.cpp:18-148   aux = 1/z, level = last octave
+ *   mode 1  searchByProjection(Frame*, MapPoints)  :274-353             aux = trackProj_uR_, viewcos
+ *   mode 2  searchByProjection(Frame*, KeyFrame*)  :150-272             radius, dist_threshold
+ *   mode 3  fuseMapPoints candidate search         :1064-1106           aux = projected uR; radius = threshold
+ *   mode 4  searchBySim3 / fuseByPose inner search :756-786, :1196-1213 max_dist
+ *   mode 5  searchByProjection(KeyFrame*, Sim3&)   :356-447 (Q-M1)      radius = th
+ * Modes 0, 1, 2, 5 claim features: dev_assigned [n_frames][max_features] in/out (query index per
+ * feature or -1; mode 5 starts from -1), dev_feature_mask [n_frames][max_features] or NULL =
+ * blocked / holds-a-map-point / occupied on entry.  Modes 3, 4: dev_best_idx [n_frames][stride].
+ * dev_n_matches [n_frames].  pool_per_frame: candidate records per frame (0 = 64 per query);
+ * vo_match_guided_status reports an overflow after the stream has been synchronised. */
+typedef struct {
+  int32_t n_queries;          /* queries per frame (upper bound when n_per_frame is given) */
+  int32_t stride;             /* distance between the query blocks of consecutive frames (>= n_queries) */
+  const int32_t *n_per_frame; /* device, or NULL */
+  const uint8_t *flags;       /* bit 0 valid, bit 1 the query's map point has observations (see below) */
+  const float *u, *v, *aux;
+  const int32_t *level;
+  const float *angle, *viewcos; /* modes 0, 2 (checkRot) / mode 1 */
+  const uint8_t *desc;
+} vo_guided_queries;
+typedef struct {
+  int32_t mode;
+  float radius, bf, ratio, dist_threshold;
+  int32_t direction, check_rot, n_levels, max_dist;
+  const float *scale_factors; /* host, n_levels entries */
+} vo_guided_params;
+int vo_match_guided_dev(vo_frames *h, int slot0, int n_frames, const vo_guided_queries *q,
+                        const vo_guided_params *p, const uint8_t *dev_feature_mask, int32_t *dev_assigned,
+                        int32_t *dev_best_idx, int32_t *dev_n_matches, size_t pool_per_frame,
+                        void *hip_stream);
+int vo_match_guided_status(vo_frames *h, void *hip_stream);
+
 /* q_flags bit 0: query valid (map point exists, not outlier, projects inside the image);
  *         bit 1: its map point has observe_cnt_ > 0 (claims the feature for later queries). */
 
 /* Matcher::searchByProjection(Frame* cur, Frame* last, radius, checkRot) (matcher.cpp:18-148).
  * direction: 1 = forward, 2 = backward, 0 = neither (:47-48,:70-75).  assigned[cur.n] in/out:
  * query index matched to each feature or -1.  blocked[cur.n]: feature already holds an observed
- * map point.  Distances come from the device Hamming matrix; the greedy replay is host code.
- * Returns the match count in *n_matches. */
+ * map point.  Host-array form of vo_match_guided_dev mode 0: the frame view and the queries are
+ * uploaded in one block, window search, gates, Hamming distances and the ordered claim replay run on
+ * the device, only assigned[] comes back.  Returns the match count in *n_matches. */
 int vo_match_frame_projection(const vo_frame_view *cur, int nq, const uint8_t *q_flags,
                               const float *q_u, const float *q_v, const float *q_invz,
                               const int32_t *q_octave, const float *q_angle, const uint8_t *q_desc,
@@ -289,7 +370,8 @@ int vo_pose_only_solve_dev(int n_problems, const int32_t *dev_offsets, int max_o
  * 1/sigma (:846-878).  poses[6p..] in/out = [angle-axis; t] of Scm, scales[p] its scale
  * (fix_scale: constant, loopClosing.cpp:15).  outlier[i] = 1: inlierMappoints entry nulled.
  * n_inliers[p] = return value; 0 with pose and scale untouched when fewer than 10 matches survive
- * problem 1 (:950-951). */
+ * problem 1 (:950-951).  summaries[2p].reserved reports the phase reached: 1 = returned after problem 1
+ * (Scm must not be written), 2 = both problems ran (Scm = the result, even with 0 inliers). */
 int vo_sim3_solve(int n_problems, const int32_t *offsets, const double *cam_match, const double *pix_curr,
                   const double *inv_sigma_curr, const double *cam_curr, const double *pix_match,
                   const double *inv_sigma_match, const double camera[4], int fix_scale, double *poses,
@@ -331,19 +413,29 @@ int vo_ba_set_stream(vo_ba *h, void *hip_stream);
 /* restrict this handle to the points p with p % n_shards == shard (multi-GPU: one process per
  * GPU, each owning a shard; cameras replicated).  Must precede any solve. */
 int vo_ba_set_shard(vo_ba *h, int shard, int n_shards);
+/* Multi-GPU from C/C++: the all-reduce the sharded LM loop needs (sum of n doubles at dev_buf over all
+ * shards, in place, ordered on hip_stream; returns 0).  With RCCL this is
+ *   ncclAllReduce(buf, buf, n, ncclDouble, ncclSum, comm, (hipStream_t)stream)
+ * over xGMI.  Once set, vo_ba_solve / vo_ba_local_ba[_enqueue] on a sharded handle run the whole LM
+ * schedule with exactly two calls of it per iteration (the reduced camera system, 6 scalars); every
+ * rank must make the same calls.  Without it those entry points reject a sharded handle
+ * (VO_ERR_INVALID) instead of solving from partial sums. */
+typedef int (*vo_allreduce_fn)(void *user, double *dev_buf, size_t n_doubles, void *hip_stream);
+int vo_ba_set_allreduce(vo_ba *h, vo_allreduce_fn fn, void *user);
 int vo_ba_set_state(vo_ba *h, const double *poses, const double *points);
 int vo_ba_get_state(vo_ba *h, double *poses, double *points);
 int vo_ba_n_free_cams(const vo_ba *h);
 
 /* Full Optimizer::solveLocalBAPoseAndPoint numerics (:530-755): Huber LM (5 iterations), float
  * chi2 classification, plain LM (10 iterations) on the inliers, final chi2 pass.
- * stop: NULL or the reference's stopFlag, polled exactly at :594 and :612.
+ * stop: NULL or the address of the reference's LIVE `bool stopFlag` (read as a byte, so a C++ caller passes
+ * reinterpret_cast<const volatile unsigned char *>(&stopFlag)), polled exactly at :594 and :612.
  * edge_erase[n_edges] (host) out in the caller's edge order.  summaries: NULL or [2]. */
-int vo_ba_local_ba(vo_ba *h, const volatile int *stop, uint8_t *edge_erase,
+int vo_ba_local_ba(vo_ba *h, const volatile unsigned char *stop, uint8_t *edge_erase,
                    vo_lm_summary *summaries);
 /* The same schedule split into "queue everything on the handle's stream" and "wait + fetch results",
  * so that several independent problems (handles) overlap on one GPU. */
-int vo_ba_local_ba_enqueue(vo_ba *h, const volatile int *stop);
+int vo_ba_local_ba_enqueue(vo_ba *h, const volatile unsigned char *stop);
 int vo_ba_local_ba_finish(vo_ba *h, uint8_t *edge_erase, vo_lm_summary *summaries);
 /* One Ceres-style LM solve (ceres::Solve with DENSE_SCHUR at :604 / :699) on the current state.
  * huber_* <= 0 disables the loss.  edge_active: NULL or host mask in caller's edge order. */

@@ -103,6 +103,16 @@ void orc_frame_build_grid(orc_frame *f); /* frame.cpp:72-89 */
 int orc_features_in_area(const orc_frame *f, float u, float v, float radius, int min_level,
                          int max_level, int *out, int cap); /* frame.cpp:199-247 */
 
+/* Frame post-processing (frame_oracle.c): undistortKeyPoints frame.cpp:36-70 (cv::undistortPoints,
+ * OpenCV 3.x: 5 iterations in double), findDepth :108-133, depth Mat::convertTo visualOdometry.cpp:162-163 */
+void orc_undistort_points(int n, const float *x, const float *y, const float intr[4], const float dist[5],
+                          float *ux, float *uy);
+void orc_find_depth(int n, const float *x, const float *y, const float *ux, const float *depth_img, int w, int h,
+                    int stride, float bf, float *uright, float *depth);
+void orc_depth_to_float(const uint16_t *raw, int n, float inv_scale, float *out);
+/* MapPoint::computeDescriptor mappoint.cpp:118-179: index of the median-best descriptor, -1 if n == 0 */
+int orc_median_descriptor(const uint8_t *desc, int n);
+
 /* Matcher::searchByProjection(Frame*,Frame*,radius,checkRot) matcher.cpp:18-148 on flat arrays.
  * Query i carries what the reference reads from frame_last/map point i (already projected):
  * valid[i], u,v (float pixel), invz, last octave, last angle, descriptor, claimed-feature mask is

@@ -1,0 +1,81 @@
+"""Worker of tests/test_gpu_dist.py: one rank of a 2-process sharded bundle adjustment through the C-ABI.
+
+Launched by torch.distributed.run (gloo on a one-GPU box: both ranks share GPU 0; nccl = RCCL when every rank has
+its own GPU).  The LM loop runs INSIDE libvo_hip.so (vo_ba_local_ba / vo_ba_solve on a sharded handle); this
+process only supplies the all-reduce callback (vo_ba_set_allreduce), exactly what a C++ host would do with
+ncclAllReduce.  Each rank checks the sharded result against the unsharded device solve of the same problem."""
+import argparse
+import os
+import pathlib
+import sys
+
+import numpy as np
+
+ROOT = pathlib.Path(__file__).resolve().parent.parent
+sys.path.insert(0, str(ROOT))
+
+
+class _DevView:
+    def __init__(self, ptr, n):
+        self.__cuda_array_interface__ = {"shape": (n,), "typestr": "<f8", "data": (ptr, False), "version": 2}
+
+
+def main():
+    import faulthandler
+    faulthandler.enable()
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--backend", default="gloo")
+    a = ap.parse_args()
+    import torch
+    import torch.distributed as dist
+    from vo_slam_test_amd import _lib as vo
+    from vo_slam_test_amd import synth
+    rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+    ndev = torch.cuda.device_count()
+    torch.cuda.set_device(rank % max(ndev, 1))
+    dist.init_process_group(a.backend, rank=rank, world_size=world)
+    calls = {"n": 0}
+
+    def allreduce(ptr, n, stream):
+        calls["n"] += 1
+        t = torch.as_tensor(_DevView(ptr, n), device="cuda")
+        if a.backend == "gloo":
+            h = t.cpu()  # synchronises the (current = handle) stream
+            dist.all_reduce(h)
+            t.copy_(h)
+        else:
+            dist.all_reduce(t)
+        return 0
+
+    st = torch.cuda.current_stream().cuda_stream
+    ok = True
+    for name, prob, tol in (("lds-path", synth.make_lba_problem(3, n_kf=6, n_pts=800, n_fixed=2), 1e-9),
+                            ("large-path", synth.make_lba_problem(4, n_kf=26, n_pts=1500, n_fixed=2), 1e-8)):
+        ref = vo.BundleAdjuster(prob, stream=st)
+        e0, s0, rc0 = ref.local_ba()
+        p0, x0 = ref.state()
+        ref.close()
+        sh = vo.BundleAdjuster(prob, shard=rank, n_shards=world, stream=st)
+        # without the callback the single-call entry points must refuse a sharded handle
+        scratch = np.zeros(sh.n_edges, np.uint8)  # (kept alive across the call: _p only takes its address)
+        rc_bad = vo.lib().vo_ba_local_ba(sh._h, None, vo._p(scratch), None)
+        assert rc_bad == -1, rc_bad
+        sh.set_allreduce(allreduce)
+        calls["n"] = 0
+        e1, s1, rc1 = sh.local_ba()
+        p1, x1 = sh.state()
+        sh.close()
+        its = [(s.iterations, s.accepted, s.termination) for s in s0], [(s.iterations, s.accepted, s.termination) for s in s1]
+        dp, dx = np.abs(p0 - p1).max(), np.abs(x0 - x1).max()
+        good = rc0 == rc1 == 0 and its[0] == its[1] and np.array_equal(e0, e1) and dp < tol and dx < 100 * tol
+        n_it = sum(s.iterations for s in s1)
+        print(f"rank {rank} {name}: iterations {its[1]} collectives {calls['n']} (2 per LM iteration + merges) "
+              f"dpose {dp:.2e} dpoint {dx:.2e} erase {int(e1.sum())} -> {'OK' if good else 'MISMATCH'}", flush=True)
+        ok = ok and good and calls["n"] >= 2 * n_it
+    dist.barrier()
+    dist.destroy_process_group()
+    sys.exit(0 if ok else 1)
+
+
+if __name__ == "__main__":
+    main()

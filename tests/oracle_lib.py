@@ -69,7 +69,7 @@ class BowData:
 
 
 def build(force: bool = False) -> pathlib.Path:
-    srcs = [ORACLE_DIR / n for n in ("orb_oracle.c", "match_oracle.c", "ba_oracle.c", "oracle.h")]
+    srcs = [ORACLE_DIR / n for n in ("orb_oracle.c", "match_oracle.c", "ba_oracle.c", "frame_oracle.c", "oracle.h")]
     if force or not SO.exists() or any(s.stat().st_mtime > SO.stat().st_mtime for s in srcs if s.exists()):
         if all(s.exists() for s in srcs):
             subprocess.run(["make", "-C", str(ORACLE_DIR)], check=True, capture_output=True)
@@ -137,6 +137,11 @@ def lib():
     L.orc_match_sim3_mutual.argtypes = [C.POINTER(Frame), C.POINTER(Frame), _u8p, _f32p, _f32p, _i32p, _u8p, _u8p, _f32p, _f32p,
                                         _i32p, _u8p, C.c_float, _f32p, _f32p, _i32p]
     L.orc_match_sim3_mutual.restype = C.c_int
+    L.orc_undistort_points.argtypes = [C.c_int, _f32p, _f32p, _f32p, C.c_void_p, _f32p, _f32p]
+    L.orc_find_depth.argtypes = [C.c_int, _f32p, _f32p, _f32p, _f32p, C.c_int, C.c_int, C.c_int, C.c_float, _f32p, _f32p]
+    L.orc_depth_to_float.argtypes = [_u16p, C.c_int, C.c_float, _f32p]
+    L.orc_median_descriptor.argtypes = [_u8p, C.c_int]
+    L.orc_median_descriptor.restype = C.c_int
     L.orc_sim3_eval.argtypes = [_f64p, _f64p, _f64p, C.c_double, _f64p, _f64p, C.c_double, _f64p, _f64p, C.c_void_p, _f64p,
                                 C.c_void_p]
     L.orc_sim3_solve.argtypes = [C.c_int, _f64p, _f64p, _f64p, _f64p, _f64p, _f64p, _f64p, C.c_int, _f64p, _f64p, _u8p,

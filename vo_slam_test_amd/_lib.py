@@ -40,12 +40,14 @@ SYMBOLS = [
     "vo_orb_scale_factors", "vo_orb_features_per_level", "vo_orb_max_keypoints", "vo_orb_extract",
     "vo_orb_extract_batch_dev", "vo_orb_sync", "vo_orb_get_level", "vo_orb_get_candidates",
     "vo_orb_get_level_counts", "vo_orb_set_timing", "vo_orb_get_timing",
-    "vo_hamming_matrix_dev", "vo_hamming_matrix_batch_dev", "vo_hamming_matrix",
+    "vo_hamming_matrix_dev", "vo_hamming_matrix_batch_dev", "vo_hamming_matrix", "vo_median_descriptor",
+    "vo_frames_create", "vo_frames_destroy", "vo_frames_capacity", "vo_frames_set_camera", "vo_frames_build_dev",
+    "vo_frames_upload", "vo_frames_download", "vo_match_guided_dev", "vo_match_guided_status",
     "vo_match_frame_projection", "vo_match_local_map", "vo_match_frame_keyframe", "vo_match_bow",
     "vo_match_triangulation", "vo_match_fuse", "vo_match_area_best", "vo_match_sim3_projection",
     "vo_match_sim3_mutual", "vo_vocab_create", "vo_vocab_destroy", "vo_bow_transform",
     "vo_pose_only_solve", "vo_sim3_solve", "vo_pose_graph_solve", "vo_sim3_reanchor_points", "vo_chol_solve", "vo_pose_only_solve_dev",
-    "vo_ba_create", "vo_ba_destroy", "vo_ba_set_stream", "vo_ba_set_shard", "vo_ba_set_state",
+    "vo_ba_create", "vo_ba_destroy", "vo_ba_set_stream", "vo_ba_set_shard", "vo_ba_set_allreduce", "vo_ba_set_state",
     "vo_ba_get_state", "vo_ba_n_free_cams", "vo_ba_local_ba", "vo_ba_local_ba_enqueue",
     "vo_ba_local_ba_finish", "vo_ba_solve", "vo_ba_lm_begin",
     "vo_ba_linearize", "vo_ba_step", "vo_ba_update", "vo_ba_lm_end", "vo_ba_reduced_system",
@@ -223,6 +225,109 @@ def hamming_matrix_batch_dev(a, b, d, stream=0):
                                             C.c_void_p(stream)))
 
 
+def median_descriptor(sets):
+    """MapPoint::computeDescriptor for a batch of map points: sets = list of [n_i, 32] uint8 arrays -> best index per set
+    (one kernel launch for the whole batch)."""
+    offs = np.zeros(len(sets) + 1, np.int32)
+    for i, d in enumerate(sets):
+        offs[i + 1] = offs[i] + len(d)
+    cat = np.ascontiguousarray(np.concatenate([np.asarray(d, np.uint8).reshape(-1, 32) for d in sets])
+                               if offs[-1] else np.zeros((0, 32), np.uint8))
+    best = np.zeros(max(len(sets), 1), np.int32)
+    check(lib().vo_median_descriptor(_p(cat), len(sets), _p(offs), _p(best)), "vo_median_descriptor")
+    return best[:len(sets)]
+
+
+class GuidedQueries(C.Structure):
+    _fields_ = [("n_queries", C.c_int32), ("stride", C.c_int32), ("n_per_frame", C.c_void_p), ("flags", C.c_void_p),
+                ("u", C.c_void_p), ("v", C.c_void_p), ("aux", C.c_void_p), ("level", C.c_void_p), ("angle", C.c_void_p),
+                ("viewcos", C.c_void_p), ("desc", C.c_void_p)]
+
+
+class GuidedParams(C.Structure):
+    _fields_ = [("mode", C.c_int32), ("radius", C.c_float), ("bf", C.c_float), ("ratio", C.c_float),
+                ("dist_threshold", C.c_float), ("direction", C.c_int32), ("check_rot", C.c_int32),
+                ("n_levels", C.c_int32), ("max_dist", C.c_int32), ("scale_factors", C.c_void_p)]
+
+
+class Frames:
+    """Device-resident frame store (vo_frames): Frame::Frame post-processing + grid on the GPU, guided matching."""
+
+    MODE_FRAME, MODE_LOCAL_MAP, MODE_KEYFRAME, MODE_FUSE, MODE_AREA, MODE_SIM3 = range(6)
+
+    def __init__(self, max_frames, max_features=2048, intrinsics=None, dist_coef=None, width=640.0, height=480.0):
+        self._h = C.c_void_p()
+        check(lib().vo_frames_create(C.byref(self._h), int(max_frames), int(max_features)), "vo_frames_create")
+        self.max_frames, self.cap = max_frames, max_features
+        if intrinsics is not None:
+            self.set_camera(intrinsics, dist_coef, width, height)
+
+    def close(self):
+        if getattr(self, "_h", None) and self._h.value and _lib is not None:
+            _lib.vo_frames_destroy(self._h)
+            self._h = C.c_void_p()
+
+    __del__ = close
+
+    def set_camera(self, intrinsics, dist_coef=None, width=640.0, height=480.0):
+        k = np.ascontiguousarray(intrinsics, np.float32)
+        d = None if dist_coef is None else np.ascontiguousarray(dist_coef, np.float32)
+        check(lib().vo_frames_set_camera(self._h, _p(k), _p(d), C.c_float(width), C.c_float(height)), "vo_frames_set_camera")
+
+    def build_dev(self, kps, desc, counts, depth=None, inv_depth_scale=1.0, slot0=0, stream=0):
+        """torch device tensors as written by OrbExtractor.extract_batch_dev; depth: float32 [B,H,W] metres or
+        uint16/int16 [B,H,W] raw."""
+        B, cap = kps.shape[0], kps.shape[1]
+        kind, fs, pitch = 0, 0, 0
+        if depth is not None:
+            kind = 1 if depth.element_size() == 4 else 2
+            fs, pitch = depth.stride(0) * depth.element_size(), depth.stride(1) * depth.element_size()
+        check(lib().vo_frames_build_dev(self._h, int(slot0), B, _p(kps), _p(desc), _p(counts), cap, _p(depth), kind,
+                                        C.c_size_t(fs), pitch, C.c_float(inv_depth_scale), C.c_void_p(stream)),
+              "vo_frames_build_dev")
+
+    def upload(self, slot, fa: "FrameArrays", depth=None, stream=0):
+        dp = None if depth is None else np.ascontiguousarray(depth, np.float32)
+        check(lib().vo_frames_upload(self._h, int(slot), C.byref(fa.view), _p(dp), C.c_void_p(stream)), "vo_frames_upload")
+
+    def download(self, slot, stream=0):
+        n = C.c_int()
+        cap = self.cap
+        out = dict(x=np.zeros(cap, np.float32), y=np.zeros(cap, np.float32), octave=np.zeros(cap, np.int32),
+                   angle=np.zeros(cap, np.float32), uright=np.zeros(cap, np.float32), depth=np.zeros(cap, np.float32),
+                   desc=np.zeros((cap, 32), np.uint8), cell_start=np.zeros(64 * 48 + 1, np.int32),
+                   cell_items=np.zeros(cap, np.uint16))
+        check(lib().vo_frames_download(self._h, int(slot), C.byref(n), _p(out["x"]), _p(out["y"]), _p(out["octave"]),
+                                       _p(out["angle"]), _p(out["uright"]), _p(out["depth"]), _p(out["desc"]),
+                                       _p(out["cell_start"]), _p(out["cell_items"]), C.c_void_p(stream)), "vo_frames_download")
+        k = n.value
+        for key in ("x", "y", "octave", "angle", "uright", "depth", "desc", "cell_items"):
+            out[key] = out[key][:k].copy()
+        out["n"] = k
+        return out
+
+    def match_dev(self, n_frames, q, mode, scale_factors, radius=0.0, bf=0.0, ratio=0.0, dist_threshold=0.0, direction=0,
+                  check_rot=0, max_dist=0, feature_mask=None, assigned=None, best_idx=None, n_matches=None, slot0=0,
+                  pool_per_frame=0, stream=0):
+        """q: dict of torch device tensors [n_frames, stride(, 32)] (flags,u,v,aux,level,angle,viewcos,desc; missing
+        ones None) + optional 'n_per_frame'; outputs are torch device tensors."""
+        sf = np.ascontiguousarray(scale_factors, np.float32)
+        gq = GuidedQueries()
+        stride = q["flags"].shape[1]
+        gq.n_queries, gq.stride = int(q.get("n_queries", stride)), int(stride)
+        for k in ("n_per_frame", "flags", "u", "v", "aux", "level", "angle", "viewcos", "desc"):
+            t = q.get(k)
+            setattr(gq, k, 0 if t is None else t.data_ptr())
+        gp = GuidedParams(int(mode), float(radius), float(bf), float(ratio), float(dist_threshold), int(direction),
+                          int(check_rot), len(sf), int(max_dist), sf.ctypes.data)
+        check(lib().vo_match_guided_dev(self._h, int(slot0), int(n_frames), C.byref(gq), C.byref(gp), _p(feature_mask),
+                                        _p(assigned), _p(best_idx), _p(n_matches), C.c_size_t(pool_per_frame),
+                                        C.c_void_p(stream)), "vo_match_guided_dev")
+
+    def match_status(self, stream=0):
+        check(lib().vo_match_guided_status(self._h, C.c_void_p(stream)), "vo_match_guided_status")
+
+
 class FrameArrays:
     def __init__(self, x, y, octave, angle, uright, desc, w=640.0, h=480.0):
         self.x = np.ascontiguousarray(x, np.float32)
@@ -395,7 +500,11 @@ class Matcher:
 
     @staticmethod
     def computeDistance(a, b) -> int:
-        return int(hamming_matrix(np.asarray(a).reshape(1, 32), np.asarray(b).reshape(1, 32))[0, 0])
+        """Matcher::computeDistance (matcher.cpp:1240-1256) of ONE pair: a host popcount, like the inline in the C++
+        shim (a GPU round trip per 256-bit popcount would turn microseconds into milliseconds); sets of
+        descriptors go through hamming_matrix / median_descriptor."""
+        x = np.bitwise_xor(np.asarray(a, np.uint8).reshape(32), np.asarray(b, np.uint8).reshape(32))
+        return int(np.unpackbits(x).sum())
 
 
 class Optimizer:
@@ -508,6 +617,14 @@ class BundleAdjuster:
             self._h = C.c_void_p()
 
     __del__ = close
+
+    ALLREDUCE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p)
+
+    def set_allreduce(self, fn):
+        """fn(dev_ptr, n_doubles, stream_ptr) -> 0: sums the buffer over the shards, ordered on the stream.  The
+        C-ABI drives the sharded LM loop itself once this is set (vo_ba_set_allreduce)."""
+        self._ar = self.ALLREDUCE_FN(lambda user, buf, n, st: int(fn(buf, n, st) or 0))  # keep the thunk alive
+        check(lib().vo_ba_set_allreduce(self._h, self._ar, None), "vo_ba_set_allreduce")
 
     def n_free_cams(self):
         return lib().vo_ba_n_free_cams(self._h)

@@ -22,6 +22,7 @@ SOURCES = [
     ("vo_common.hip", []),
     ("orb.hip", ["-ffp-contract=off"]),
     ("match.hip", ["-ffp-contract=off"]),
+    ("guided.hip", ["-ffp-contract=off"]),
     ("ba.hip", ["-ffp-contract=fast"]),
     ("pose_graph.hip", ["-ffp-contract=fast"]),
 ]

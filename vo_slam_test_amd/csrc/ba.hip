@@ -642,6 +642,7 @@ __global__ __launch_bounds__(256) void k_sim3(const int *offsets, const double *
     for (int a = 0; a < 6; a++) poses[6 * p + a] = x[a];
     scales[p] = x[6];
     n_inliers[p] = inliers;
+    if (sums) sums[2 * p].reserved = ok1 < 10 ? 1 : 2;  // phase reached: the shim writes Scm only after phase 2
   }
 }
 
@@ -2146,11 +2147,14 @@ struct vo_ba {
       b_camedges, b_ptin, b_camin, b_xc0, b_xc1, b_xp0, b_xp1, b_pc0, b_pc1, b_sc, b_sp, b_hinv, b_gl2, b_dl, b_wt, b_wt1, b_hll0, b_hll1, b_spt1,
       b_sgemm, b_scam, b_spt, b_payload, b_zc, b_sbs, b_payload2, b_state, b_out, b_dbg, b_cnt;
   size_t solve_lds = 0, gemm_lds = 0;
+  vo::DevBuf b_merge;  // sharded handles: payload of the closing point / erase-mask all-reduce
   vo::DevBuf b_we0, b_we1, b_glsc0, b_glsc1, b_Sd, b_scv, b_ddv, b_gppv, b_cholfail, b_pairstart, b_paircc, b_paire;  // large reduced systems
   int lm_max_it = 0;
   double *ext_payload = nullptr, *ext_payload2 = nullptr;
   int archive_slot = -1;
   bool lba_second = false;
+  vo_allreduce_fn allreduce = nullptr;  // sums a device buffer over the shards, ordered on the handle's stream
+  void *allreduce_user = nullptr;
   std::map<int, hipGraphExec_t> graphs;  // LM iteration sequences captured per iteration count
 };
 
@@ -2459,10 +2463,30 @@ void drop_graphs(vo_ba *h) {
   h->graphs.clear();
 }
 
+// one collective of the sharded LM loop: the caller's all-reduce (RCCL over xGMI in production) on the handle's stream
+int shard_allreduce(vo_ba *h, double *buf, size_t n) {
+  const int rc = h->allreduce(h->allreduce_user, buf, n, (void *)h->stream);
+  if (rc != 0) {
+    vo::set_error("BA all-reduce callback failed with status %d", rc);
+    return VO_ERR_HIP;
+  }
+  return VO_OK;
+}
+
 int run_lm_eager(vo_ba *h, int max_it) {
+  const bool sharded = h->n_shards > 1;
+  double *p1 = nullptr, *p2 = nullptr;
+  size_t n1 = 0, n2 = 0;
+  if (sharded) {  // exactly two collectives per LM iteration; every control decision is a
+                  // function of all-reduced values, so the shards stay in lock-step without a host sync
+    VO_CHECK(vo_ba_reduced_system(h, &p1, &n1));
+    VO_CHECK(vo_ba_reduced_cost(h, &p2, &n2));
+  }
   for (int it = 0; it < max_it; it++) {
     VO_CHECK(launch_linearize(h));
+    if (sharded) VO_CHECK(shard_allreduce(h, p1, n1));
     VO_CHECK(launch_step(h));
+    if (sharded) VO_CHECK(shard_allreduce(h, p2, n2));
     VO_CHECK(launch_update(h));
   }
   return VO_OK;
@@ -2479,7 +2503,7 @@ int run_lm(vo_ba *h, int max_it) {
     const char *e = getenv("VO_BA_GRAPH");
     return e && e[0] == '1';
   }();
-  if (!use_graph || !h->own_stream || max_it < 1) return run_lm_eager(h, max_it);
+  if (!use_graph || !h->own_stream || max_it < 1 || h->n_shards > 1) return run_lm_eager(h, max_it);
   auto it = h->graphs.find(max_it);
   if (it == h->graphs.end()) {
     hipGraph_t graph = nullptr;
@@ -2547,6 +2571,7 @@ int vo_pose_only_solve(int n_problems, const int32_t *offsets, const double *poi
   const size_t r_pose = 0, r_sum = r_pose + (size_t)n_problems * 48,
                r_inl = r_sum + (size_t)n_problems * 2 * sizeof(vo_lm_summary), r_out = up8(r_inl + (size_t)n_problems * 4),
                out_bytes = up8(r_out + (size_t)std::max(total, 1));
+  hipStream_t st = vo::thread_stream();  // the calling thread's own stream: never queues behind another thread's solve
   thread_local vo::PinnedBuf pinned;
   thread_local vo::DevBuf d_in, d_out;
   VO_CHECK(pinned.reserve(std::max(in_bytes, out_bytes)));
@@ -2561,20 +2586,20 @@ int vo_pose_only_solve(int n_problems, const int32_t *offsets, const double *poi
   memcpy(&stage[o_off], offsets, (size_t)(n_problems + 1) * 4);
   VO_CHECK(d_in.reserve(in_bytes));
   VO_CHECK(d_out.reserve(out_bytes));
-  VO_HIP_CHECK(hipMemcpyAsync(d_in.p, stage, in_bytes, hipMemcpyHostToDevice, nullptr));
+  VO_HIP_CHECK(hipMemcpyAsync(d_in.p, stage, in_bytes, hipMemcpyHostToDevice, st));
   uint8_t *di = d_in.as<uint8_t>(), *dout = d_out.as<uint8_t>();
   // the kernel updates poses in place: give it the output block's copy
-  VO_HIP_CHECK(hipMemcpyAsync(dout + r_pose, di + o_pose, (size_t)n_problems * 48, hipMemcpyDeviceToDevice, nullptr));
-  VO_HIP_CHECK(hipMemsetAsync(dout + r_sum, 0, (size_t)n_problems * 2 * sizeof(vo_lm_summary), nullptr));
+  VO_HIP_CHECK(hipMemcpyAsync(dout + r_pose, di + o_pose, (size_t)n_problems * 48, hipMemcpyDeviceToDevice, st));
+  VO_HIP_CHECK(hipMemsetAsync(dout + r_sum, 0, (size_t)n_problems * 2 * sizeof(vo_lm_summary), st));
   VO_CHECK(vo_pose_only_solve_dev(n_problems, reinterpret_cast<const int32_t *>(di + o_off), 0,
                                   reinterpret_cast<const double *>(di + o_pts), reinterpret_cast<const double *>(di + o_obs),
                                   reinterpret_cast<const double *>(di + o_is), reinterpret_cast<const double *>(di + o_cam),
                                   reinterpret_cast<double *>(dout + r_pose), dout + r_out,
                                   reinterpret_cast<int32_t *>(dout + r_inl),
-                                  reinterpret_cast<vo_lm_summary *>(dout + r_sum), nullptr));
+                                  reinterpret_cast<vo_lm_summary *>(dout + r_sum), st));
   // the inputs have left the staging block once the kernel has run: it takes the results back
-  if (hipMemcpyAsync(stage, dout, out_bytes, hipMemcpyDeviceToHost, nullptr) != hipSuccess ||
-      hipStreamSynchronize(nullptr) != hipSuccess) {
+  if (hipMemcpyAsync(stage, dout, out_bytes, hipMemcpyDeviceToHost, st) != hipSuccess ||
+      hipStreamSynchronize(st) != hipSuccess) {
     vo::set_error("pose-only kernel failed: %s", hipGetErrorString(hipGetLastError()));
     return VO_ERR_HIP;
   }
@@ -2598,6 +2623,8 @@ int vo_sim3_solve(int n_problems, const int32_t *offsets, const double *cam_matc
   thread_local vo::DevBuf d_off, d_pm, d_pc, d_isc, d_Pc, d_pxm, d_ism, d_cam, d_pose, d_sc, d_out, d_inl, d_sum;
   int rc = VO_OK;
   auto fail = [&](int r) { return r; };
+  hipStream_t st = vo::thread_stream();
+  auto upload = [&](vo::DevBuf &b, const void *src, size_t bytes) { return vo::upload(b, src, bytes, st, "vo_sim3_solve"); };
   if ((rc = upload(d_off, offsets, (size_t)(n_problems + 1) * 4)) != VO_OK) return fail(rc);
   if ((rc = upload(d_pm, cam_match, (size_t)total * 24)) != VO_OK) return fail(rc);
   if ((rc = upload(d_pc, pix_curr, (size_t)total * 16)) != VO_OK) return fail(rc);
@@ -2612,26 +2639,23 @@ int vo_sim3_solve(int n_problems, const int32_t *offsets, const double *cam_matc
   if ((rc = d_inl.reserve((size_t)n_problems * 4)) != VO_OK) return fail(rc);
   if ((rc = d_sum.reserve((size_t)n_problems * 2 * sizeof(vo_lm_summary))) != VO_OK) return fail(rc);
   if (fix_scale)
-    hipLaunchKernelGGL(k_sim3<6>, dim3(n_problems), dim3(256), 0, nullptr, d_off.as<int>(), d_pm.as<double>(),
+    hipLaunchKernelGGL(k_sim3<6>, dim3(n_problems), dim3(256), 0, st, d_off.as<int>(), d_pm.as<double>(),
                        d_pc.as<double>(), d_isc.as<double>(), d_Pc.as<double>(), d_pxm.as<double>(), d_ism.as<double>(),
                        d_cam.as<double>(), d_pose.as<double>(), d_sc.as<double>(), d_out.as<uint8_t>(), d_inl.as<int>(),
                        d_sum.as<vo_lm_summary>());
   else
-    hipLaunchKernelGGL(k_sim3<7>, dim3(n_problems), dim3(256), 0, nullptr, d_off.as<int>(), d_pm.as<double>(),
+    hipLaunchKernelGGL(k_sim3<7>, dim3(n_problems), dim3(256), 0, st, d_off.as<int>(), d_pm.as<double>(),
                        d_pc.as<double>(), d_isc.as<double>(), d_Pc.as<double>(), d_pxm.as<double>(), d_ism.as<double>(),
                        d_cam.as<double>(), d_pose.as<double>(), d_sc.as<double>(), d_out.as<uint8_t>(), d_inl.as<int>(),
                        d_sum.as<vo_lm_summary>());
-  if (hipDeviceSynchronize() != hipSuccess) {
-    vo::set_error("Sim3 kernel failed: %s", hipGetErrorString(hipGetLastError()));
-    return fail(VO_ERR_HIP);
-  }
-  (void)hipMemcpy(poses, d_pose.p, (size_t)n_problems * 48, hipMemcpyDeviceToHost);
-  (void)hipMemcpy(scales, d_sc.p, (size_t)n_problems * 8, hipMemcpyDeviceToHost);
-  if (total > 0) (void)hipMemcpy(outlier, d_out.p, total, hipMemcpyDeviceToHost);
-  (void)hipMemcpy(n_inliers, d_inl.p, (size_t)n_problems * 4, hipMemcpyDeviceToHost);
+  VO_HIP_CHECK(hipGetLastError());
+  VO_CHECK(vo::copy_d2h(poses, d_pose.p, (size_t)n_problems * 48, st, "vo_sim3_solve"));
+  VO_CHECK(vo::copy_d2h(scales, d_sc.p, (size_t)n_problems * 8, st, "vo_sim3_solve"));
+  if (total > 0) VO_CHECK(vo::copy_d2h(outlier, d_out.p, total, st, "vo_sim3_solve"));
+  VO_CHECK(vo::copy_d2h(n_inliers, d_inl.p, (size_t)n_problems * 4, st, "vo_sim3_solve"));
   if (summaries)
-    (void)hipMemcpy(summaries, d_sum.p, (size_t)n_problems * 2 * sizeof(vo_lm_summary), hipMemcpyDeviceToHost);
-  return fail(VO_OK);
+    VO_CHECK(vo::copy_d2h(summaries, d_sum.p, (size_t)n_problems * 2 * sizeof(vo_lm_summary), st, "vo_sim3_solve"));
+  return vo::stream_sync(st, "vo_sim3_solve");
 }
 
 int vo_ba_create(vo_ba **out, int n_cams, const double *poses, const uint8_t *cam_fixed, int n_points,
@@ -2694,7 +2718,7 @@ void vo_ba_destroy(vo_ba *h) {
                         &h->b_dl, &h->b_wt, &h->b_wt1, &h->b_hll0, &h->b_hll1, &h->b_spt1, &h->b_sgemm, &h->b_scam, &h->b_spt, &h->b_payload, &h->b_zc,
                         &h->b_sbs, &h->b_payload2, &h->b_state, &h->b_out, &h->b_dbg, &h->b_cnt, &h->b_we0, &h->b_we1,
                         &h->b_glsc0, &h->b_glsc1, &h->b_Sd, &h->b_scv, &h->b_ddv, &h->b_gppv, &h->b_cholfail,
-                        &h->b_pairstart, &h->b_paircc, &h->b_paire})
+                        &h->b_pairstart, &h->b_paircc, &h->b_paire, &h->b_merge})
     b->release();
   if (h->pin.p) (void)hipHostFree(h->pin.p);
   if (h->own_stream) (void)hipStreamDestroy(h->stream);
@@ -2732,11 +2756,38 @@ int vo_ba_set_state(vo_ba *h, const double *poses, const double *points) {
   return VO_OK;
 }
 
+// Sharded handle with an all-reduce callback: every shard holds the up-to-date coordinates of ITS points only
+// (and classifies ITS edges only).  One more collective -- outside the LM loop -- leaves the full point array
+// (and the full erase mask) on every rank: owners contribute their values, everybody else zeros.
+static int merge_shards(vo_ba *h, int cur, uint8_t *erase_sorted /*n_edges, in/out, or NULL*/) {
+  if (h->n_shards <= 1 || !h->allreduce) return VO_OK;
+  const size_t np3 = (size_t)h->n_pts * 3, n = np3 + (erase_sorted ? (size_t)h->n_edges : 0);
+  if (n == 0) return VO_OK;
+  std::vector<double> buf(n, 0.0);
+  VO_HIP_CHECK(hipStreamSynchronize(h->stream));
+  if (np3) VO_HIP_CHECK(hipMemcpy(buf.data(), h->D.Xp[cur], np3 * 8, hipMemcpyDeviceToHost));
+  for (int j = 0; j < h->n_pts; j++)
+    if (j % h->n_shards != h->shard) buf[3 * j] = buf[3 * j + 1] = buf[3 * j + 2] = 0.0;
+  if (erase_sorted)
+    for (int e = 0; e < h->n_edges; e++)
+      buf[np3 + e] = (h->e_pt[e] % h->n_shards == h->shard && erase_sorted[e]) ? 1.0 : 0.0;
+  VO_CHECK(h->b_merge.reserve(n * 8));
+  VO_HIP_CHECK(hipMemcpyAsync(h->b_merge.p, buf.data(), n * 8, hipMemcpyHostToDevice, h->stream));
+  VO_CHECK(shard_allreduce(h, h->b_merge.as<double>(), n));
+  VO_HIP_CHECK(hipMemcpyAsync(buf.data(), h->b_merge.p, n * 8, hipMemcpyDeviceToHost, h->stream));
+  if (np3) VO_HIP_CHECK(hipMemcpyAsync(h->D.Xp[cur], h->b_merge.p, np3 * 8, hipMemcpyDeviceToDevice, h->stream));
+  VO_HIP_CHECK(hipStreamSynchronize(h->stream));
+  if (erase_sorted)
+    for (int e = 0; e < h->n_edges; e++) erase_sorted[e] = buf[np3 + e] != 0.0;
+  return VO_OK;
+}
+
 int vo_ba_get_state(vo_ba *h, double *poses, double *points) {
   if (!h) return VO_ERR_INVALID;
   VO_CHECK(build_device(h));
   int cur;
   VO_CHECK(current_index(h, &cur));
+  VO_CHECK(merge_shards(h, cur, nullptr));
   if (poses) VO_HIP_CHECK(hipMemcpy(poses, h->D.Xc[cur], (size_t)h->n_cams * 48, hipMemcpyDeviceToHost));
   if (points && h->n_pts) VO_HIP_CHECK(hipMemcpy(points, h->D.Xp[cur], (size_t)h->n_pts * 24, hipMemcpyDeviceToHost));
   return VO_OK;
@@ -2750,6 +2801,12 @@ int vo_ba_linearize(vo_ba *h) { return h && h->built ? launch_linearize(h) : VO_
 int vo_ba_step(vo_ba *h) { return h && h->built ? launch_step(h) : VO_ERR_INVALID; }
 int vo_ba_update(vo_ba *h) { return h && h->built ? launch_update(h) : VO_ERR_INVALID; }
 int vo_ba_lm_end(vo_ba *h, vo_lm_summary *s) { return h && h->built ? lm_end(h, s) : VO_ERR_INVALID; }
+
+int vo_ba_set_allreduce(vo_ba *h, vo_allreduce_fn fn, void *user) {
+  if (!h) return VO_ERR_INVALID;
+  h->allreduce = fn, h->allreduce_user = user;
+  return VO_OK;
+}
 
 int vo_ba_set_reduce_buffers(vo_ba *h, double *dev_system, double *dev_cost) {
   if (!h) return VO_ERR_INVALID;
@@ -2783,8 +2840,20 @@ int vo_ba_reduced_cost(vo_ba *h, double **p, size_t *n) {
   return VO_OK;
 }
 
+// A sharded handle (vo_ba_set_shard, n_shards > 1) holds partial sums only: without the two all-reduces per LM
+// iteration the camera step would silently be solved from one shard's partial system.
+static int reject_unreduced_shards(const vo_ba *h, const char *fn) {
+  if (h->n_shards > 1 && !h->allreduce) {
+    vo::set_error("%s: handle is shard %d of %d and has no all-reduce callback (vo_ba_set_allreduce); drive it through "
+                  "vo_ba_lm_begin / linearize / step / update with the caller's all-reduce in between", fn, h->shard, h->n_shards);
+    return VO_ERR_INVALID;
+  }
+  return VO_OK;
+}
+
 int vo_ba_solve(vo_ba *h, double hm, double hs, int max_it, const uint8_t *edge_active, vo_lm_summary *sum) {
   if (!h || max_it < 0) return VO_ERR_INVALID;
+  VO_CHECK(reject_unreduced_shards(h, "vo_ba_solve"));
   VO_CHECK(lm_begin(h, hm, hs, max_it, edge_active, false));
   VO_CHECK(run_lm(h, max_it));
   return lm_end(h, sum);
@@ -2800,8 +2869,9 @@ static void summary_from_state(const BaState &s, vo_lm_summary *sum) {
   sum->final_radius = s.radius;
 }
 
-int vo_ba_local_ba_enqueue(vo_ba *h, const volatile int *stop) {
+int vo_ba_local_ba_enqueue(vo_ba *h, const volatile unsigned char *stop) {
   if (!h) return VO_ERR_INVALID;
+  VO_CHECK(reject_unreduced_shards(h, "vo_ba_local_ba"));
   h->lba_second = false;
   if (stop && *stop) return VO_ERR_STOPPED;  // :594-595 (no write-back, Q-B8)
   // The whole schedule is queued without a host synchronisation in between; the stop flag is
@@ -2835,6 +2905,7 @@ int vo_ba_local_ba_finish(vo_ba *h, uint8_t *edge_erase, vo_lm_summary *sums) {
   VO_HIP_CHECK(hipMemcpyAsync(tmp, h->b_out.p, h->n_edges, hipMemcpyDeviceToHost, h->stream));
   VO_HIP_CHECK(hipMemcpyAsync(st, h->D.st, 3 * sizeof(BaState), hipMemcpyDeviceToHost, h->stream));
   VO_HIP_CHECK(hipStreamSynchronize(h->stream));
+  VO_CHECK(merge_shards(h, st[0].cur, tmp));  // no-op for an unsharded handle
   for (int s = 0; s < h->n_edges; s++) edge_erase[h->perm[s]] = tmp[s];
   if (sums) {
     if (h->lba_second) {
@@ -2848,7 +2919,7 @@ int vo_ba_local_ba_finish(vo_ba *h, uint8_t *edge_erase, vo_lm_summary *sums) {
   return VO_OK;
 }
 
-int vo_ba_local_ba(vo_ba *h, const volatile int *stop, uint8_t *edge_erase, vo_lm_summary *sums) {
+int vo_ba_local_ba(vo_ba *h, const volatile unsigned char *stop, uint8_t *edge_erase, vo_lm_summary *sums) {
   if (!h || !edge_erase) return VO_ERR_INVALID;
   for (int e = 0; e < h->n_edges; e++) edge_erase[e] = 0;
   const int rc = vo_ba_local_ba_enqueue(h, stop);

@@ -1,0 +1,1045 @@
+// guided.hip -- device-resident frame features and the guided (window) matchers on gfx950.
+//
+// Replaces, on the device:
+//   Frame::undistortKeyPoints / findDepth / assignFeaturesToGrid   reference src/frame.cpp:36-133
+//   Frame::getFeaturesInArea / KeyFrame::getFeaturesInArea          frame.cpp:199-247, keyframe.cpp:268-312
+//   the candidate loops of Matcher::searchByProjection (x4), fuseMapPoints, fuseByPose, searchBySim3
+//                                                                   src/matcher.cpp:18-447, 679-865, 1012-1238
+//
+// A `vo_frames` object keeps the features of a batch of frames in HBM (undistorted key-points, uRight,
+// depth, descriptors and the 64 x 48 grid as CSR), so key-points never leave the device between
+// vo_orb_extract_batch_dev and the matcher.  Matching is two kernels:
+//   k_guided_cand    one WAVEFRONT per query: the grid columns of the search window are contiguous item
+//                    ranges of the CSR (cell = ix * 48 + iy), so a lane per column fetches (start, end), a wave
+//                    prefix sum lays the window's items out in reference order, every lane gates one item
+//                    (level range, |dx| < r, |dy| < r, stereo / chi2 gates) and computes its 256-bit Hamming
+//                    distance (v_xor + v_bcnt), survivors are compacted in order by ballot/mbcnt into the
+//                    frame's candidate pool.  Searches without a claim step (fuse, area-best) finish here with
+//                    a wave-wide arg-min.
+//   k_guided_replay  one wavefront per frame walks the queries in the reference's order and replays the
+//                    order-dependent part -- "features claimed earlier in the call are skipped" (:87, :218,
+//                    :314, :422) -- over the compact records: lanes = candidates, blocked[] in LDS, best and
+//                    second by two DPP wave minima of (distance, position), then the rotation histogram and
+//                    its three-maxima pruning (:128-145, computeThreeMax :1258-1304).
+// Match pairs are bit-identical to the sequential reference loop for any input.
+//
+// Compiled with -ffp-contract=off: the float gates must round like the x86-64 reference build.
+#include "vo_common.h"
+
+#include <algorithm>
+#include <cmath>
+#include <vector>
+
+namespace {
+
+using namespace vo;
+
+constexpr int kGridCols = 64, kGridRows = 48;  // FRAME_GRID_COLS/ROWS, camera.h:8-9
+constexpr int kCells = kGridCols * kGridRows;
+constexpr int TH_HIGH = 100, TH_LOW = 50;      // matcher.cpp:11-12
+constexpr int HISTO_LENGTH = 30;               // :13
+constexpr int kMaxFeat = 16384;                // features per frame (LDS arrays of the replay kernel)
+
+enum GuidedMode {
+  kModeFrame = 0,     // searchByProjection(Frame*, Frame*)        :18-148
+  kModeLocalMap = 1,  // searchByProjection(Frame*, MapPoints)     :274-353
+  kModeKeyFrame = 2,  // searchByProjection(Frame*, KeyFrame*)     :150-272
+  kModeFuse = 3,      // fuseMapPoints candidate search            :1064-1106
+  kModeArea = 4,      // searchBySim3 / fuseByPose inner search    :756-786, :1196-1213
+  kModeSim3 = 5       // searchByProjection(KeyFrame*, Sim3&)      :356-447 (Q-M1)
+};
+
+struct FramesDev {
+  int cap;  // feature slots per frame
+  float *x, *y, *angle, *uright, *depth;
+  int *octave;
+  uint8_t *desc;
+  int *n;              // [frames]
+  int *cell_start;     // [frames][kCells + 1]
+  unsigned short *cell_items;  // [frames][cap]
+  float xmin, ymin, gw, gh;
+};
+
+struct CamDev {
+  float fx, fy, cx, cy, bf;
+  double k[5];  // k1 k2 p1 p2 k3
+  int distorted;
+};
+
+// ------------------------------------------------------------------------------------------
+// N1  frame post-processing.  One thread per key-point:
+//   undistortKeyPoints (frame.cpp:36-70): cv::undistortPoints(mat, mat, K, distCoef, Mat(), K) -- OpenCV 3.x
+//     cvUndistortPoints: normalise with 1/fx, 1/fy, five fixed-point iterations of the inverse distortion
+//     model in double, re-project with K, round to float; skipped when k1 == 0 (:41-45)
+//   findDepth (:108-133): d = depthImg.at<float>(v, u) at the ORIGINAL key-point (float -> int truncation),
+//     uRight = undistorted x - bf / d when d > 0
+//   grid cell of assignFeaturesToGrid (:72-89): round((x - xMin) * gridPerPixelWidth)
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_frame_post(FramesDev F, CamDev C, const vo_keypoint *kps, const uint8_t *desc,
+                                                    const int *counts, int kp_capacity, const void *depth, int depth_kind,
+                                                    long long depth_frame_stride, int depth_pitch, float inv_depth_scale,
+                                                    int img_w, int img_h, int slot0) {
+  const int f = blockIdx.y, i = blockIdx.x * 256 + threadIdx.x;
+  const int n = min(counts[f], min(kp_capacity, F.cap));
+  if (i == 0) F.n[slot0 + f] = n;
+  if (i >= n) return;
+  const vo_keypoint kp = kps[(long long)f * kp_capacity + i];
+  float ux = kp.x, uy = kp.y;
+  if (C.distorted) {
+    const double fx = (double)C.fx, fy = (double)C.fy, cx = (double)C.cx, cy = (double)C.cy;
+    const double ifx = 1. / fx, ify = 1. / fy;
+    double x = ((double)kp.x - cx) * ifx, y = ((double)kp.y - cy) * ify;
+    const double x0 = x, y0 = y;
+    for (int j = 0; j < 5; j++) {
+      const double r2 = x * x + y * y;
+      const double icdist = (1 + ((0 * r2 + 0) * r2 + 0) * r2) / (1 + ((C.k[4] * r2 + C.k[1]) * r2 + C.k[0]) * r2);
+      const double deltaX = 2 * C.k[2] * x * y + C.k[3] * (r2 + 2 * x * x);
+      const double deltaY = C.k[2] * (r2 + 2 * y * y) + 2 * C.k[3] * x * y;
+      x = (x0 - deltaX) * icdist;
+      y = (y0 - deltaY) * icdist;
+    }
+    const double xx = fx * x + 0 * y + cx, yy = 0 * x + fy * y + cy, ww = 1. / (0 * x + 0 * y + 1.0);
+    ux = (float)(xx * ww);
+    uy = (float)(yy * ww);
+  }
+  const long long o = (long long)(slot0 + f) * F.cap + i;
+  float d = -1.f, ur = -1.f;
+  if (depth_kind) {
+    const int px = min(max((int)kp.x, 0), img_w - 1), py = min(max((int)kp.y, 0), img_h - 1);
+    float dv;
+    if (depth_kind == 1)
+      dv = reinterpret_cast<const float *>(reinterpret_cast<const uint8_t *>(depth) + f * depth_frame_stride + (long long)py * depth_pitch)[px];
+    else  // 16-bit raw depth, Mat::convertTo(CV_32F, 1 / depthScale) (visualOdometry.cpp:162-163): float multiply
+      dv = (float)reinterpret_cast<const unsigned short *>(reinterpret_cast<const uint8_t *>(depth) + f * depth_frame_stride + (long long)py * depth_pitch)[px] * inv_depth_scale;
+    if (dv > 0) {
+      d = dv;
+      ur = ux - C.bf / dv;
+    }
+  }
+  F.x[o] = ux, F.y[o] = uy, F.angle[o] = kp.angle, F.octave[o] = kp.octave, F.uright[o] = ur, F.depth[o] = d;
+  const uint4 *ds = reinterpret_cast<const uint4 *>(desc + ((long long)f * kp_capacity + i) * 32);
+  uint4 *dd = reinterpret_cast<uint4 *>(F.desc + o * 32);
+  dd[0] = ds[0], dd[1] = ds[1];
+}
+
+// assignFeaturesToGrid (frame.cpp:72-89) as CSR: one workgroup per frame.  Cell lists keep feature-index order
+// (push_back order): slots are handed out by LDS atomics, then every cell with more than one item is sorted.
+__global__ __launch_bounds__(256) void k_frame_grid(FramesDev F, int slot0) {
+  __shared__ int cnt[kCells];
+  __shared__ int wsum[4];
+  const int s = slot0 + blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int n = F.n[s];
+  const float *X = F.x + (long long)s * F.cap, *Y = F.y + (long long)s * F.cap;
+  int *start = F.cell_start + (long long)s * (kCells + 1);
+  unsigned short *items = F.cell_items + (long long)s * F.cap;
+  for (int c = tid; c < kCells; c += 256) cnt[c] = 0;
+  __syncthreads();
+  auto cell_of = [&](int i) {
+    const int gx = (int)roundf((X[i] - F.xmin) * F.gw), gy = (int)roundf((Y[i] - F.ymin) * F.gh);
+    return (gx < 0 || gx >= kGridCols || gy < 0 || gy >= kGridRows) ? -1 : gx * kGridRows + gy;
+  };
+  for (int i = tid; i < n; i += 256) {
+    const int c = cell_of(i);
+    if (c >= 0) atomicAdd(&cnt[c], 1);
+  }
+  __syncthreads();
+  // exclusive scan of the 3072 counts: 12 per thread
+  constexpr int PER = kCells / 256;
+  int loc[PER], sum = 0;
+#pragma unroll
+  for (int k = 0; k < PER; k++) loc[k] = cnt[tid * PER + k], sum += loc[k];
+  int incl = sum;
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) {
+    const int v = __shfl_up(incl, o);
+    if (lane >= o) incl += v;
+  }
+  if (lane == 63) wsum[wave] = incl;
+  __syncthreads();
+  int base = incl - sum;
+  for (int w = 0; w < wave; w++) base += wsum[w];
+  __syncthreads();
+#pragma unroll
+  for (int k = 0; k < PER; k++) {
+    start[tid * PER + k] = base;
+    cnt[tid * PER + k] = base;  // fill cursor
+    base += loc[k];
+  }
+  if (tid == 255) start[kCells] = base;
+  __syncthreads();
+  for (int i = tid; i < n; i += 256) {
+    const int c = cell_of(i);
+    if (c >= 0) items[atomicAdd(&cnt[c], 1)] = (unsigned short)i;
+  }
+  __syncthreads();
+  __threadfence_block();
+  for (int c = tid; c < kCells; c += 256) {
+    const int e = cnt[c];
+    // s0 = start of the cell: the exclusive offset written above
+    const int s0 = start[c];
+    for (int a = s0 + 1; a < e; a++) {  // insertion sort, lists of a handful of entries
+      const unsigned short v = items[a];
+      int b = a - 1;
+      while (b >= s0 && items[b] > v) items[b + 1] = items[b], b--;
+      items[b + 1] = v;
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// guided matching
+// ------------------------------------------------------------------------------------------
+struct Queries {  // device arrays, query q of frame f at f * stride + q
+  const uint8_t *flags;
+  const float *u, *v, *aux;   // aux: 1/z (frame search) or projected uRight (local map, fuse)
+  const int *level;           // last octave (frame search) or predicted level
+  const float *angle, *viewcos;
+  const uint8_t *desc;
+  const int *nq;              // per frame, or NULL: nq_all
+  int nq_all, stride;
+};
+
+struct GuidedParams {
+  int mode;
+  float radius, bf, ratio, dist_threshold;
+  int direction, check_rot, n_levels, max_dist;
+  float sf[16];
+};
+
+struct GuidedOut {
+  unsigned *pool;           // [frames][pool_stride] candidate records: idx | dist << 16 | octave << 25
+  unsigned short *rank;     // [frames][pool_stride] position in the raw window list (Sim3 search only)
+  uint2 *qrec;              // [frames][stride] (offset, count) of every query's records
+  int *pool_used;           // [frames]
+  int pool_stride;
+  int *best_idx;            // [frames][stride]   (fuse / area searches)
+  int *assigned;            // [frames][cap]      (claiming searches), in/out
+  const uint8_t *fmask;     // [frames][cap] or NULL: blocked / has-map-point / occupied on entry
+  unsigned *pushes;         // [frames][stride] rotation-histogram entries idx | bin << 16
+  int *n_matches;           // [frames]
+  int *err;                 // 1: candidate pool overflow
+};
+
+__device__ __forceinline__ unsigned wave_min_u32(unsigned x) {  // minimum over the 64 lanes, uniform
+  x = min(x, (unsigned)__builtin_amdgcn_update_dpp((int)x, (int)x, 0xB1, 0xf, 0xf, false));
+  x = min(x, (unsigned)__builtin_amdgcn_update_dpp((int)x, (int)x, 0x4E, 0xf, 0xf, false));
+  x = min(x, (unsigned)__builtin_amdgcn_update_dpp((int)x, (int)x, 0x141, 0xf, 0xf, false));
+  x = min(x, (unsigned)__builtin_amdgcn_update_dpp((int)x, (int)x, 0x140, 0xf, 0xf, false));
+  return min(min((unsigned)__builtin_amdgcn_readlane((int)x, 0), (unsigned)__builtin_amdgcn_readlane((int)x, 16)),
+             min((unsigned)__builtin_amdgcn_readlane((int)x, 32), (unsigned)__builtin_amdgcn_readlane((int)x, 48)));
+}
+__device__ __forceinline__ int lane_rank(unsigned long long mask) {  // set bits of `mask` below this lane
+  return (int)__builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0u));
+}
+
+// One wavefront per (query, frame); four queries per workgroup, no workgroup barrier.
+__global__ __launch_bounds__(256) void k_guided_cand(FramesDev F, Queries Q, GuidedParams P, GuidedOut O, int slot0) {
+  __shared__ int s_pre[4][64], s_base[4][64];
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
+  const int f = blockIdx.y, q = blockIdx.x * 4 + wave;
+  const int nq = Q.nq ? Q.nq[f] : Q.nq_all;
+  if (q >= nq) return;
+  const long long qo = (long long)f * Q.stride + q;
+  const int s = slot0 + f;
+  const bool claims = P.mode == kModeFrame || P.mode == kModeLocalMap || P.mode == kModeKeyFrame || P.mode == kModeSim3;
+  auto finish_empty = [&]() {
+    if (lane == 0) {
+      if (claims) O.qrec[qo] = make_uint2(0u, 0u);
+      else O.best_idx[qo] = -1;
+    }
+  };
+  const unsigned flags = Q.flags[qo];
+  if (!(flags & 1u)) return finish_empty();
+  const float u = Q.u[qo], v = Q.v[qo];
+  const int lv = Q.level[qo];
+  // search radius and level range of the routine
+  float rs;
+  int lmin, lmax;
+  if (P.mode == kModeFrame) {
+    rs = P.radius * P.sf[lv];  // :66-68
+    if (P.direction == 1) lmin = lv, lmax = P.n_levels;       // :70-71
+    else if (P.direction == 2) lmin = 0, lmax = lv;           // :72-73
+    else lmin = lv - 1, lmax = lv + 1;                        // :74-75
+  } else if (P.mode == kModeLocalMap) {
+    float r = Q.viewcos[qo] > 0.998 ? 2.5f : 4.0f;            // :288-291 (float vs double literal compare)
+    r *= P.radius;
+    rs = r * P.sf[lv];
+    lmin = lv - 1, lmax = lv;
+  } else if (P.mode == kModeKeyFrame) {
+    rs = P.radius * P.sf[lv];
+    lmin = lv - 1, lmax = lv + 1;
+  } else {  // KeyFrame::getFeaturesInArea has no level filter (keyframe.cpp:268-312); the octave gate follows
+    rs = P.radius * P.sf[lv];
+    lmin = -(1 << 30), lmax = 1 << 30;
+  }
+  // window -> grid columns / rows, frame.cpp:205-223
+  const int x0 = max(0, (int)floorf((u - F.xmin - rs) * F.gw));
+  const int x1 = min(kGridCols - 1, (int)floorf((u - F.xmin + rs) * F.gw));
+  const int y0 = max(0, (int)floorf((v - F.ymin - rs) * F.gh));
+  const int y1 = min(kGridRows - 1, (int)floorf((v - F.ymin + rs) * F.gh));
+  if (x0 >= kGridCols || x1 < 0 || y0 >= kGridRows || y1 < 0 || x1 < x0 || y1 < y0) return finish_empty();
+  const int *start = F.cell_start + (long long)s * (kCells + 1);
+  const unsigned short *items = F.cell_items + (long long)s * F.cap;
+  const long long fo = (long long)s * F.cap, mo = (long long)f * F.cap;  // frame-store slot / this call's frame
+  // lane c = grid column x0 + c: its window cells y0..y1 are one contiguous run of the CSR
+  int cbeg = 0, ccnt = 0;
+  if (x0 + lane <= x1) {
+    cbeg = start[(x0 + lane) * kGridRows + y0];
+    ccnt = start[(x0 + lane) * kGridRows + y1 + 1] - cbeg;
+  }
+  int incl = ccnt;
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) {
+    const int t = __shfl_up(incl, o);
+    if (lane >= o) incl += t;
+  }
+  const int T = __builtin_amdgcn_readlane(incl, 63);
+  if (T == 0) return finish_empty();
+  s_pre[wave][lane] = incl - ccnt;
+  s_base[wave][lane] = cbeg;
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  const int ncol = x1 - x0 + 1;
+  // query descriptor: uniform address
+  const uint4 *qd4 = reinterpret_cast<const uint4 *>(Q.desc + qo * 32);
+  const uint4 qa = qd4[0], qb = qd4[1];
+  const float aux = Q.aux ? Q.aux[qo] : 0.f;
+  const float ur_q = P.mode == kModeFrame ? u - P.bf * aux : aux;  // :92 / trackProj_uR_
+
+  // evaluate item t of the window: returns pass, fills idx / dist / octave / rawpos
+  struct Item { bool inraw, pass; int idx, dist, oct; };
+  auto eval = [&](int t, bool want_dist) {
+    Item it{false, false, 0, 256, 0};
+    if (t >= T) return it;
+    int lo = 0, hi = ncol - 1;  // last column whose prefix is <= t
+    while (lo < hi) {
+      const int mid = (lo + hi + 1) >> 1;
+      if (s_pre[wave][mid] <= t) lo = mid; else hi = mid - 1;
+    }
+    const int idx = items[s_base[wave][lo] + (t - s_pre[wave][lo])];
+    const float fx = F.x[fo + idx], fy = F.y[fo + idx];
+    const int oct = F.octave[fo + idx];
+    it.idx = idx, it.oct = oct;
+    if (oct < lmin || oct > lmax) return it;
+    if (!(fabsf(fx - u) < rs && fabsf(fy - v) < rs)) return it;  // frame.cpp:238-241
+    it.inraw = true;
+    bool ok = true;
+    if (P.mode == kModeFrame || P.mode == kModeLocalMap) {
+      if (O.fmask && O.fmask[mo + idx]) ok = false;  // already blocked on entry: stays blocked (:87, :314)
+      const float fur = F.uright[fo + idx];
+      if (fur > 0 && fabsf(ur_q - fur) > rs) ok = false;  // :90-96, :317-322
+    } else if (P.mode == kModeKeyFrame) {
+      if (O.fmask && O.fmask[mo + idx]) ok = false;  // :218
+    } else {
+      if (oct < lv - 1 || oct > lv) ok = false;  // :1077, :769, :425
+      if (P.mode == kModeFuse && ok) {  // chi2 gates :1084-1099
+        const float ex = u - fx, ey = v - fy;
+        const float is = 1.0f / P.sf[oct];
+        const float fur = F.uright[fo + idx];
+        if (fur >= 0) {
+          const float er = aux - fur;
+          const float e2 = ex * ex + ey * ey + er * er;
+          if (e2 * is * is > 7.815f) ok = false;
+        } else {
+          const float e2 = ex * ex + ey * ey;
+          if (e2 * is * is > 5.991f) ok = false;
+        }
+      }
+    }
+    it.pass = ok;
+    if (ok && want_dist) {
+      const uint4 *fd = reinterpret_cast<const uint4 *>(F.desc + (fo + idx) * 32);
+      const uint4 a = fd[0], b = fd[1];
+      it.dist = __popc(a.x ^ qa.x) + __popc(a.y ^ qa.y) + __popc(a.z ^ qa.z) + __popc(a.w ^ qa.w) + __popc(b.x ^ qb.x) +
+                __popc(b.y ^ qb.y) + __popc(b.z ^ qb.z) + __popc(b.w ^ qb.w);
+    }
+    return it;
+  };
+
+  if (!claims) {  // independent queries: arg-min in candidate order, strict < keeps the first minimum
+    unsigned best = 0xffffffffu;
+    int best_idx = -1;
+    for (int base = 0; base < T; base += 64) {
+      const Item it = eval(base + lane, true);
+      const unsigned key = it.pass ? ((unsigned)it.dist << 20) | (unsigned)(base + lane) : 0xffffffffu;
+      const unsigned m = wave_min_u32(key);
+      if (m < best) {
+        best = m;
+        const int src = (int)(m & 0xfffffu) - base;
+        best_idx = __builtin_amdgcn_readlane(it.idx, src);
+      }
+    }
+    const int limit = P.mode == kModeFuse ? TH_LOW : P.max_dist;
+    if (lane == 0) O.best_idx[qo] = (best != 0xffffffffu && (int)(best >> 20) <= limit) ? best_idx : -1;
+    return;
+  }
+
+  // claiming searches: records of the gated candidates, in order, into the frame's pool
+  Item first = eval(lane, true);
+  int npass = __popcll(__builtin_amdgcn_ballot_w64(first.pass));
+  for (int base = 64; base < T; base += 64) npass += __popcll(__builtin_amdgcn_ballot_w64(eval(base + lane, false).pass));
+  if (npass == 0) return finish_empty();
+  int off = 0;
+  if (lane == 0) off = atomicAdd(&O.pool_used[f], npass);
+  off = __builtin_amdgcn_readfirstlane(off);
+  if (off + npass > O.pool_stride) {
+    if (lane == 0) {
+      atomicExch(O.err, 1);
+      O.qrec[qo] = make_uint2(0u, 0u);
+    }
+    return;
+  }
+  unsigned *pool = O.pool + (long long)f * O.pool_stride + off;
+  unsigned short *rk = O.rank ? O.rank + (long long)f * O.pool_stride + off : nullptr;
+  int written = 0, rawbase = 0;
+  for (int base = 0; base < T; base += 64) {
+    const Item it = base == 0 ? first : eval(base + lane, true);
+    const unsigned long long pm = __builtin_amdgcn_ballot_w64(it.pass), rm = __builtin_amdgcn_ballot_w64(it.inraw);
+    if (it.pass) {
+      const int p = written + lane_rank(pm);
+      pool[p] = (unsigned)it.idx | ((unsigned)it.dist << 16) | ((unsigned)it.oct << 25);
+      if (rk) rk[p] = (unsigned short)min(rawbase + lane_rank(rm), 65535);
+    }
+    written += __popcll(pm);
+    rawbase += __popcll(rm);
+  }
+  if (lane == 0) O.qrec[qo] = make_uint2((unsigned)off, (unsigned)npass);
+}
+
+// One wavefront per frame: the sequential claim replay.  LDS: blocked[cap] bytes, assigned[cap] u16.
+__global__ __launch_bounds__(64) void k_guided_replay(FramesDev F, Queries Q, GuidedParams P, GuidedOut O, int slot0) {
+  extern __shared__ __attribute__((aligned(16))) uint8_t rp_lds[];
+  __shared__ int hist[32];
+  const int lane = threadIdx.x, f = blockIdx.x, s = slot0 + f;
+  const int nf = F.n[s];
+  const int nq = Q.nq ? Q.nq[f] : Q.nq_all;
+  uint8_t *blocked = rp_lds;                                                       // [capA]
+  const int capA = (F.cap + 15) & ~15;
+  unsigned short *asg = reinterpret_cast<unsigned short *>(rp_lds + capA);          // [cap]: query + 1, 0 = none
+  const long long fo = (long long)s * F.cap;
+  int *assigned = O.assigned + (long long)f * F.cap;
+  const bool sim3 = P.mode == kModeSim3;
+  for (int i = lane; i < nf; i += 64) {
+    blocked[i] = O.fmask ? O.fmask[(long long)f * F.cap + i] : 0;
+    const int a = sim3 ? -1 : assigned[i];
+    asg[i] = (unsigned short)(a + 1);
+  }
+  if (lane < 32) hist[lane] = 0;
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  const uint2 *qrec = O.qrec + (long long)f * Q.stride;
+  const unsigned *pool = O.pool + (long long)f * O.pool_stride;
+  const unsigned short *rkp = O.rank ? O.rank + (long long)f * O.pool_stride : nullptr;
+  unsigned *pushes = O.pushes + (long long)f * Q.stride;
+  const float pdf = HISTO_LENGTH / 360.0f;
+  int cnt = 0, npush = 0;
+  constexpr int G = 8;  // queries whose first record chunk is in flight together
+  for (int qb = 0; qb < nq; qb += 64) {
+    // (offset, count) of 64 queries: one vector load, then scalar reads
+    const uint2 mine = qb + lane < nq ? qrec[qb + lane] : make_uint2(0u, 0u);
+    const int qe = min(64, nq - qb);
+    for (int g0 = 0; g0 < qe; g0 += G) {
+      unsigned rec0[G];
+      unsigned short rk0[G];
+      int off[G], cn[G];
+#pragma unroll
+      for (int g = 0; g < G; g++) {
+        const int ql = min(g0 + g, 63);
+        off[g] = __builtin_amdgcn_readlane((int)mine.x, ql);
+        cn[g] = g0 + g < qe ? __builtin_amdgcn_readlane((int)mine.y, ql) : 0;
+        rec0[g] = lane < cn[g] ? pool[off[g] + lane] : 0u;
+        rk0[g] = (rkp && lane < cn[g]) ? rkp[off[g] + lane] : (unsigned short)0;
+      }
+#pragma unroll
+      for (int g = 0; g < G; g++) {
+        if (cn[g] == 0) continue;  // uniform
+        const int q = qb + g0 + g;
+        // best and second over the unblocked records by (distance, position)
+        unsigned k1 = 0xffffffffu, k2 = 0xffffffffu, r1 = 0, r2 = 0;
+        for (int base = 0; base < cn[g]; base += 64) {
+          unsigned rec = rec0[g];
+          unsigned short rk = rk0[g];
+          if (base > 0) {
+            rec = base + lane < cn[g] ? pool[off[g] + base + lane] : 0u;
+            rk = (rkp && base + lane < cn[g]) ? rkp[off[g] + base + lane] : (unsigned short)0;
+          }
+          const bool have = base + lane < cn[g];
+          const int idx = rec & 0xffffu;
+          const bool skip = !have || (sim3 ? (rk < nf && blocked[rk]) : blocked[idx]);  // :422 indexes by the candidate counter
+          unsigned key = skip ? 0xffffffffu : (((rec >> 16) & 0x1ffu) << 16) | (unsigned)(base + lane);
+          const unsigned m1 = wave_min_u32(key);
+          if (m1 == 0xffffffffu) continue;
+          const int l1 = (int)(m1 & 0xffffu) - base;
+          const unsigned rr1 = (unsigned)__builtin_amdgcn_readlane((int)rec, l1);
+          if (lane == l1) key = 0xffffffffu;
+          const unsigned m2 = wave_min_u32(key);
+          unsigned rr2 = 0;
+          if (m2 != 0xffffffffu) rr2 = (unsigned)__builtin_amdgcn_readlane((int)rec, (int)(m2 & 0xffffu) - base);
+          // merge (k1, k2) with (m1, m2): all keys distinct by position
+          if (m1 < k1) {
+            if (k1 < m2) k2 = k1, r2 = r1; else k2 = m2, r2 = rr2;
+            k1 = m1, r1 = rr1;
+          } else {
+            if (m1 < k2) k2 = m1, r2 = rr1;
+          }
+        }
+        if (k1 == 0xffffffffu) continue;
+        const int best = (int)(k1 >> 16), bidx = (int)(r1 & 0xffffu);
+        bool accept;
+        if (P.mode == kModeFrame) accept = best <= TH_HIGH;
+        else if (P.mode == kModeLocalMap) {
+          accept = best <= TH_HIGH;
+          if (accept && k2 != 0xffffffffu) {
+            const int second = (int)(k2 >> 16);
+            const int lv1 = (int)((r1 >> 25) & 0xfu), lv2 = (int)((r2 >> 25) & 0xfu);
+            if (lv1 == lv2 && (float)best > P.ratio * (float)second) accept = false;  // :344
+          }
+        } else if (P.mode == kModeKeyFrame) accept = (float)best <= P.dist_threshold;  // :238
+        else accept = best <= TH_LOW;                                                  // :437
+        if (!accept) continue;
+        const unsigned qflags = Q.flags[(long long)f * Q.stride + q];
+        if (lane == 0) {
+          asg[bidx] = (unsigned short)(q + 1);
+          if (P.mode == kModeFrame || P.mode == kModeLocalMap) blocked[bidx] = (uint8_t)((qflags >> 1) & 1u);  // :110-113
+          else blocked[bidx] = 1;
+        }
+        cnt++;
+        if (P.check_rot && (P.mode == kModeFrame || P.mode == kModeKeyFrame)) {  // :115-125
+          float rot = Q.angle[(long long)f * Q.stride + q] - F.angle[fo + bidx];
+          if (rot < 0) rot += 360.0f;
+          int bin = (int)rintf(rot * pdf);
+          if (bin == HISTO_LENGTH) bin = 0;
+          bin = min(max(bin, 0), 31);
+          if (lane == 0) {
+            pushes[npush] = (unsigned)bidx | ((unsigned)bin << 16);
+            hist[bin]++;
+          }
+          npush++;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+      }
+    }
+  }
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  if (npush > 0) {  // computeThreeMax (:1258-1304) + pruning (:128-145)
+    int m1 = 0, m2 = 0, m3 = 0, i1 = -1, i2 = -1, i3 = -1;
+    for (int i = 0; i < HISTO_LENGTH; i++) {
+      const int sz = hist[i];
+      if (sz > m1) m3 = m2, i3 = i2, m2 = m1, i2 = i1, m1 = sz, i1 = i;
+      else if (sz > m2) m3 = m2, i3 = i2, m2 = sz, i2 = i;
+      else if (sz > m3) m3 = sz, i3 = i;
+    }
+    if (m2 < 0.1f * (float)m1) i2 = i3 = -1;
+    else if (m3 < 0.1f * (float)m1) i3 = -1;
+    __threadfence_block();
+    for (int base = 0; base < npush; base += 64) {
+      bool drop = false;
+      if (base + lane < npush) {
+        const unsigned p = pushes[base + lane];
+        const int bin = (int)(p >> 16);
+        if (bin != i1 && bin != i2 && bin != i3) {
+          drop = true;
+          asg[p & 0xffffu] = 0;
+        }
+      }
+      cnt -= __popcll(__builtin_amdgcn_ballot_w64(drop));
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+  }
+  for (int i = lane; i < nf; i += 64) assigned[i] = (int)asg[i] - 1;
+  if (lane == 0) O.n_matches[f] = cnt;
+}
+
+// number of accepted queries of the searches without a claim step
+__global__ __launch_bounds__(256) void k_guided_count(Queries Q, const int *best_idx, int *n_matches) {
+  __shared__ int tot;
+  const int f = blockIdx.x;
+  const int nq = Q.nq ? Q.nq[f] : Q.nq_all;
+  if (threadIdx.x == 0) tot = 0;
+  __syncthreads();
+  int c = 0;
+  for (int q = threadIdx.x; q < nq; q += 256) c += best_idx[(long long)f * Q.stride + q] >= 0;
+  if (c) atomicAdd(&tot, c);
+  __syncthreads();
+  if (threadIdx.x == 0) n_matches[f] = tot;
+}
+
+}  // namespace
+
+// ============================================================================================
+// host side
+// ============================================================================================
+struct vo_frames {
+  int max_frames = 0, cap = 0;
+  FramesDev D{};
+  CamDev cam{};
+  float width = 640.f, height = 480.f;
+  vo::DevBuf b_x, b_y, b_angle, b_ur, b_depth, b_oct, b_desc, b_n, b_cs, b_ci;
+  // matcher scratch (grow-only)
+  vo::DevBuf b_pool, b_rank, b_qrec, b_used, b_best, b_asg, b_push, b_nm, b_err;
+  size_t pool_stride = 0;
+};
+
+namespace {
+
+int frames_alloc(vo_frames *h) {
+  const size_t N = (size_t)h->max_frames * h->cap;
+  VO_CHECK(h->b_x.reserve(N * 4));
+  VO_CHECK(h->b_y.reserve(N * 4));
+  VO_CHECK(h->b_angle.reserve(N * 4));
+  VO_CHECK(h->b_ur.reserve(N * 4));
+  VO_CHECK(h->b_depth.reserve(N * 4));
+  VO_CHECK(h->b_oct.reserve(N * 4));
+  VO_CHECK(h->b_desc.reserve(N * 32));
+  VO_CHECK(h->b_n.reserve((size_t)h->max_frames * 4 + 64));
+  VO_CHECK(h->b_cs.reserve((size_t)h->max_frames * (kCells + 1) * 4));
+  VO_CHECK(h->b_ci.reserve(N * 2 + 64));
+  FramesDev &D = h->D;
+  D.cap = h->cap;
+  D.x = h->b_x.as<float>(), D.y = h->b_y.as<float>(), D.angle = h->b_angle.as<float>();
+  D.uright = h->b_ur.as<float>(), D.depth = h->b_depth.as<float>(), D.octave = h->b_oct.as<int>();
+  D.desc = h->b_desc.as<uint8_t>(), D.n = h->b_n.as<int>(), D.cell_start = h->b_cs.as<int>();
+  D.cell_items = h->b_ci.as<unsigned short>();
+  return VO_OK;
+}
+
+void frames_set_bounds(vo_frames *h, float xmin, float ymin, float xmax, float ymax) {
+  h->D.xmin = xmin, h->D.ymin = ymin;
+  h->D.gw = (float)kGridCols / (xmax - xmin);  // camera.cpp:45-46
+  h->D.gh = (float)kGridRows / (ymax - ymin);
+}
+
+struct GuidedCall {
+  int mode;
+  float radius, bf, ratio, dist_threshold;
+  int direction, check_rot, n_levels, max_dist;
+  const float *scale_factors;
+  int n_scale;
+};
+
+// Enqueue the matcher kernels for frames [slot0, slot0 + n_frames) on `st`.  All pointers are device memory.
+int guided_launch(vo_frames *h, int slot0, int n_frames, const Queries &Q, const GuidedCall &c, const uint8_t *fmask,
+                  int *assigned, int *best_idx, int *n_matches, size_t pool_per_frame, hipStream_t st) {
+  GuidedParams P{};
+  P.mode = c.mode, P.radius = c.radius, P.bf = c.bf, P.ratio = c.ratio, P.dist_threshold = c.dist_threshold;
+  P.direction = c.direction, P.check_rot = c.check_rot, P.n_levels = c.n_levels, P.max_dist = c.max_dist;
+  for (int i = 0; i < 16; i++) P.sf[i] = i < c.n_scale ? c.scale_factors[i] : (c.n_scale > 0 ? c.scale_factors[c.n_scale - 1] : 1.f);
+  const bool claims = c.mode == kModeFrame || c.mode == kModeLocalMap || c.mode == kModeKeyFrame || c.mode == kModeSim3;
+  GuidedOut O{};
+  O.best_idx = best_idx, O.assigned = assigned, O.fmask = fmask, O.n_matches = n_matches;
+  VO_CHECK(h->b_err.reserve(64));
+  O.err = h->b_err.as<int>();
+  if (claims) {
+    VO_CHECK(h->b_pool.reserve((size_t)n_frames * pool_per_frame * 4));
+    if (c.mode == kModeSim3) VO_CHECK(h->b_rank.reserve((size_t)n_frames * pool_per_frame * 2));
+    VO_CHECK(h->b_qrec.reserve((size_t)n_frames * Q.stride * 8 + 64));
+    VO_CHECK(h->b_used.reserve((size_t)n_frames * 4 + 64));
+    VO_CHECK(h->b_push.reserve((size_t)n_frames * Q.stride * 4 + 64));
+    O.pool = h->b_pool.as<unsigned>();
+    O.rank = c.mode == kModeSim3 ? h->b_rank.as<unsigned short>() : nullptr;
+    O.qrec = h->b_qrec.as<uint2>(), O.pool_used = h->b_used.as<int>(), O.pushes = h->b_push.as<unsigned>();
+    O.pool_stride = (int)pool_per_frame;
+    VO_HIP_CHECK(hipMemsetAsync(O.pool_used, 0, (size_t)n_frames * 4, st));
+  }
+  VO_HIP_CHECK(hipMemsetAsync(O.err, 0, 4, st));
+  const int nq_max = Q.nq_all;
+  if (nq_max > 0)
+    hipLaunchKernelGGL(k_guided_cand, dim3((nq_max + 3) / 4, n_frames), dim3(256), 0, st, h->D, Q, P, O, slot0);
+  if (claims) {
+    const size_t lds = (size_t)((h->cap + 15) & ~15) + (size_t)h->cap * 2;
+    hipLaunchKernelGGL(k_guided_replay, dim3(n_frames), dim3(64), lds, st, h->D, Q, P, O, slot0);
+  } else {
+    hipLaunchKernelGGL(k_guided_count, dim3(n_frames), dim3(256), 0, st, Q, best_idx, n_matches);
+  }
+  VO_HIP_CHECK(hipGetLastError());
+  return VO_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int vo_frames_create(vo_frames **out, int max_frames, int max_features) {
+  if (!out || max_frames < 1 || max_features < 1 || max_features > kMaxFeat) {
+    vo::set_error("vo_frames_create: 1 <= max_features <= %d", kMaxFeat);
+    return VO_ERR_INVALID;
+  }
+  VO_CHECK(vo::ensure_device());
+  vo_frames *h = new vo_frames();
+  h->max_frames = max_frames, h->cap = max_features;
+  const int rc = frames_alloc(h);
+  if (rc != VO_OK) {
+    vo_frames_destroy(h);
+    return rc;
+  }
+  frames_set_bounds(h, 0.f, 0.f, 640.f, 480.f);
+  const size_t lds = (size_t)((h->cap + 15) & ~15) + (size_t)h->cap * 2;
+  if (lds > 48 * 1024)
+    VO_HIP_CHECK(hipFuncSetAttribute((const void *)k_guided_replay, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  *out = h;
+  return VO_OK;
+}
+
+void vo_frames_destroy(vo_frames *h) {
+  if (!h) return;
+  for (vo::DevBuf *b : {&h->b_x, &h->b_y, &h->b_angle, &h->b_ur, &h->b_depth, &h->b_oct, &h->b_desc, &h->b_n, &h->b_cs,
+                        &h->b_ci, &h->b_pool, &h->b_rank, &h->b_qrec, &h->b_used, &h->b_best, &h->b_asg, &h->b_push,
+                        &h->b_nm, &h->b_err})
+    b->release();
+  delete h;
+}
+
+int vo_frames_set_camera(vo_frames *h, const float intrinsics[5], const float dist_coef[5], float width, float height) {
+  if (!h || !intrinsics || !(width > 0) || !(height > 0)) return VO_ERR_INVALID;
+  h->cam.fx = intrinsics[0], h->cam.fy = intrinsics[1], h->cam.cx = intrinsics[2], h->cam.cy = intrinsics[3];
+  h->cam.bf = intrinsics[4];
+  for (int i = 0; i < 5; i++) h->cam.k[i] = dist_coef ? (double)dist_coef[i] : 0.0;
+  h->cam.distorted = dist_coef && dist_coef[0] != 0.0f;  // frame.cpp:41
+  h->width = width, h->height = height;
+  frames_set_bounds(h, 0.f, 0.f, width, height);  // camera.cpp:40-46
+  return VO_OK;
+}
+
+int vo_frames_capacity(const vo_frames *h, int *max_frames, int *max_features) {
+  if (!h) return VO_ERR_INVALID;
+  if (max_frames) *max_frames = h->max_frames;
+  if (max_features) *max_features = h->cap;
+  return VO_OK;
+}
+
+int vo_frames_build_dev(vo_frames *h, int slot0, int n_frames, const vo_keypoint *dev_keypoints,
+                        const uint8_t *dev_descriptors, const int32_t *dev_counts, int capacity, const void *dev_depth,
+                        int depth_kind, size_t depth_frame_stride_bytes, int depth_pitch_bytes, float inv_depth_scale,
+                        void *hip_stream) {
+  if (!h || slot0 < 0 || n_frames < 1 || slot0 + n_frames > h->max_frames || !dev_keypoints || !dev_descriptors ||
+      !dev_counts || capacity < 1 || depth_kind < 0 || depth_kind > 2 || (depth_kind && !dev_depth)) {
+    vo::set_error("vo_frames_build_dev: invalid argument");
+    return VO_ERR_INVALID;
+  }
+  hipStream_t st = (hipStream_t)hip_stream;
+  const int nmax = std::min(capacity, h->cap);
+  hipLaunchKernelGGL(k_frame_post, dim3((nmax + 255) / 256, n_frames), dim3(256), 0, st, h->D, h->cam, dev_keypoints,
+                     dev_descriptors, dev_counts, capacity, dev_depth, depth_kind, (long long)depth_frame_stride_bytes,
+                     depth_pitch_bytes, inv_depth_scale, (int)h->width, (int)h->height, slot0);
+  hipLaunchKernelGGL(k_frame_grid, dim3(n_frames), dim3(256), 0, st, h->D, slot0);
+  VO_HIP_CHECK(hipGetLastError());
+  return VO_OK;
+}
+
+int vo_frames_upload(vo_frames *h, int slot, const vo_frame_view *view, const float *depth, void *hip_stream) {
+  if (!h || slot < 0 || slot >= h->max_frames || !view || view->n < 0) return VO_ERR_INVALID;
+  if (view->n > h->cap) {
+    vo::set_error("vo_frames_upload: %d features exceed the handle's %d slots", view->n, h->cap);
+    return VO_ERR_CAPACITY;
+  }
+  hipStream_t st = (hipStream_t)hip_stream;
+  const int n = view->n;
+  const size_t o = (size_t)slot * h->cap;
+  frames_set_bounds(h, view->xmin, view->ymin, view->xmax, view->ymax);
+  if (n > 0) {
+    if (!view->x || !view->y || !view->octave || !view->desc) return VO_ERR_INVALID;
+    VO_CHECK(vo::copy_h2d(h->D.x + o, view->x, (size_t)n * 4, st, "vo_frames_upload"));
+    VO_CHECK(vo::copy_h2d(h->D.y + o, view->y, (size_t)n * 4, st, "vo_frames_upload"));
+    VO_CHECK(vo::copy_h2d(h->D.octave + o, view->octave, (size_t)n * 4, st, "vo_frames_upload"));
+    if (view->angle) VO_CHECK(vo::copy_h2d(h->D.angle + o, view->angle, (size_t)n * 4, st, "vo_frames_upload"));
+    else VO_HIP_CHECK(hipMemsetAsync(h->D.angle + o, 0, (size_t)n * 4, st));
+    if (view->uright) VO_CHECK(vo::copy_h2d(h->D.uright + o, view->uright, (size_t)n * 4, st, "vo_frames_upload"));
+    else VO_HIP_CHECK(hipMemsetAsync(h->D.uright + o, 0xbf, (size_t)n * 4, st));  // 0xbfbfbfbf = -1.498...: "no depth"
+    if (depth) VO_CHECK(vo::copy_h2d(h->D.depth + o, depth, (size_t)n * 4, st, "vo_frames_upload"));
+    VO_CHECK(vo::copy_h2d(h->D.desc + o * 32, view->desc, (size_t)n * 32, st, "vo_frames_upload"));
+  }
+  VO_CHECK(vo::copy_h2d(h->D.n + slot, &n, 4, st, "vo_frames_upload"));
+  hipLaunchKernelGGL(k_frame_grid, dim3(1), dim3(256), 0, st, h->D, slot);
+  VO_HIP_CHECK(hipGetLastError());
+  // `n` lives on this stack frame: the copy above must have left it before we return
+  return vo::stream_sync(st, "vo_frames_upload");
+}
+
+int vo_frames_download(vo_frames *h, int slot, int *n, float *x, float *y, int32_t *octave, float *angle, float *uright,
+                       float *depth, uint8_t *desc, int32_t *cell_start, uint16_t *cell_items, void *hip_stream) {
+  if (!h || slot < 0 || slot >= h->max_frames || !n) return VO_ERR_INVALID;
+  hipStream_t st = (hipStream_t)hip_stream;
+  int cnt = 0;
+  VO_CHECK(vo::copy_d2h(&cnt, h->D.n + slot, 4, st, "vo_frames_download"));
+  VO_CHECK(vo::stream_sync(st, "vo_frames_download"));
+  *n = cnt;
+  const size_t o = (size_t)slot * h->cap;
+  if (x) VO_CHECK(vo::copy_d2h(x, h->D.x + o, (size_t)cnt * 4, st, "vo_frames_download"));
+  if (y) VO_CHECK(vo::copy_d2h(y, h->D.y + o, (size_t)cnt * 4, st, "vo_frames_download"));
+  if (octave) VO_CHECK(vo::copy_d2h(octave, h->D.octave + o, (size_t)cnt * 4, st, "vo_frames_download"));
+  if (angle) VO_CHECK(vo::copy_d2h(angle, h->D.angle + o, (size_t)cnt * 4, st, "vo_frames_download"));
+  if (uright) VO_CHECK(vo::copy_d2h(uright, h->D.uright + o, (size_t)cnt * 4, st, "vo_frames_download"));
+  if (depth) VO_CHECK(vo::copy_d2h(depth, h->D.depth + o, (size_t)cnt * 4, st, "vo_frames_download"));
+  if (desc) VO_CHECK(vo::copy_d2h(desc, h->D.desc + o * 32, (size_t)cnt * 32, st, "vo_frames_download"));
+  if (cell_start)
+    VO_CHECK(vo::copy_d2h(cell_start, h->D.cell_start + (size_t)slot * (kCells + 1), (size_t)(kCells + 1) * 4, st, "vo_frames_download"));
+  if (cell_items) VO_CHECK(vo::copy_d2h(cell_items, h->D.cell_items + o, (size_t)cnt * 2, st, "vo_frames_download"));
+  return vo::stream_sync(st, "vo_frames_download");
+}
+
+int vo_match_guided_dev(vo_frames *h, int slot0, int n_frames, const vo_guided_queries *q, const vo_guided_params *p,
+                        const uint8_t *dev_feature_mask, int32_t *dev_assigned, int32_t *dev_best_idx,
+                        int32_t *dev_n_matches, size_t pool_per_frame, void *hip_stream) {
+  if (!h || !q || !p || slot0 < 0 || n_frames < 1 || slot0 + n_frames > h->max_frames || q->n_queries < 0 ||
+      q->stride < q->n_queries || !dev_n_matches || p->mode < 0 || p->mode > 5 || !p->scale_factors || p->n_levels < 1 ||
+      p->n_levels > 16) {
+    vo::set_error("vo_match_guided_dev: invalid argument");
+    return VO_ERR_INVALID;
+  }
+  const bool claims = p->mode == kModeFrame || p->mode == kModeLocalMap || p->mode == kModeKeyFrame || p->mode == kModeSim3;
+  if ((claims && !dev_assigned) || (!claims && !dev_best_idx) || q->n_queries > 65534) {
+    vo::set_error("vo_match_guided_dev: missing output array or more than 65534 queries per frame");
+    return VO_ERR_INVALID;
+  }
+  Queries Q{};
+  Q.flags = q->flags, Q.u = q->u, Q.v = q->v, Q.aux = q->aux, Q.level = q->level, Q.angle = q->angle;
+  Q.viewcos = q->viewcos, Q.desc = q->desc, Q.nq = q->n_per_frame, Q.nq_all = q->n_queries, Q.stride = q->stride;
+  GuidedCall c{p->mode, p->radius, p->bf, p->ratio, p->dist_threshold, p->direction, p->check_rot, p->n_levels,
+               p->max_dist, p->scale_factors, p->n_levels};
+  if (pool_per_frame == 0) pool_per_frame = (size_t)std::max(q->n_queries, 1) * 64;
+  return guided_launch(h, slot0, n_frames, Q, c, dev_feature_mask, dev_assigned, dev_best_idx, dev_n_matches,
+                       pool_per_frame, (hipStream_t)hip_stream);
+}
+
+int vo_match_guided_status(vo_frames *h, void *hip_stream) {
+  if (!h) return VO_ERR_INVALID;
+  if (!h->b_err.p) return VO_OK;
+  int e = 0;
+  hipStream_t st = (hipStream_t)hip_stream;
+  VO_CHECK(vo::copy_d2h(&e, h->b_err.p, 4, st, "vo_match_guided_status"));
+  VO_CHECK(vo::stream_sync(st, "vo_match_guided_status"));
+  if (e) {
+    vo::set_error("guided matcher: candidate pool overflow (raise pool_per_frame)");
+    return VO_ERR_CAPACITY;
+  }
+  return VO_OK;
+}
+
+}  // extern "C"
+
+// ---- host-array entry points (the reference's call shape: one frame, everything in host memory) ----------
+namespace {
+
+struct HostCtx {  // per host thread: one-slot frame store + staging, grow-only
+  vo_frames *fr = nullptr;
+  vo::DevBuf dq, dout;
+  vo::PinnedBuf pin;
+};
+
+HostCtx &host_ctx() {
+  thread_local HostCtx c;
+  return c;
+}
+
+struct HostQueries {
+  int nq;
+  const uint8_t *flags;
+  const float *u, *v, *aux;
+  const int32_t *level;
+  const float *angle, *viewcos;
+  const uint8_t *desc;
+};
+
+// One frame through the device matcher: upload the frame view and the queries (one staging block), run, fetch
+// the result.  mask_in: blocked / has-map-point / occupied [cur.n] or NULL.  assigned in/out or best_idx out.
+int guided_host(const vo_frame_view *cur, const HostQueries &hq, const GuidedCall &c, const uint8_t *mask_in,
+                int32_t *assigned, int32_t *best_idx, int *n_matches) {
+  VO_CHECK(vo::ensure_device());
+  HostCtx &C = host_ctx();
+  const int nf = cur->n, nq = hq.nq;
+  if (nf > kMaxFeat || nq > 65534) {
+    vo::set_error("guided matcher: %d features / %d queries exceed %d / 65534", nf, nq, kMaxFeat);
+    return VO_ERR_CAPACITY;
+  }
+  if (!C.fr || C.fr->cap < nf) {
+    if (C.fr) vo_frames_destroy(C.fr);
+    C.fr = nullptr;
+    int cap = 2048;
+    while (cap < nf) cap *= 2;
+    VO_CHECK(vo_frames_create(&C.fr, 1, cap));
+  }
+  vo_frames *h = C.fr;
+  hipStream_t st = vo::thread_stream();
+  // staging layout (4-byte aligned blocks)
+  auto up = [](size_t v) { return (v + 15) & ~(size_t)15; };
+  const size_t o_x = 0, o_y = o_x + up((size_t)nf * 4), o_oct = o_y + up((size_t)nf * 4), o_ang = o_oct + up((size_t)nf * 4),
+               o_ur = o_ang + up((size_t)nf * 4), o_fd = o_ur + up((size_t)nf * 4), o_mask = o_fd + up((size_t)nf * 32),
+               o_asg = o_mask + up((size_t)nf), o_qf = o_asg + up((size_t)nf * 4), o_qu = o_qf + up((size_t)nq),
+               o_qv = o_qu + up((size_t)nq * 4), o_qa = o_qv + up((size_t)nq * 4), o_ql = o_qa + up((size_t)nq * 4),
+               o_qang = o_ql + up((size_t)nq * 4), o_qvc = o_qang + up((size_t)nq * 4), o_qd = o_qvc + up((size_t)nq * 4),
+               o_n = o_qd + up((size_t)nq * 32), in_bytes = o_n + 16;
+  const size_t r_asg = 0, r_best = r_asg + up((size_t)nf * 4), r_nm = r_best + up((size_t)nq * 4), r_err = r_nm + 16,
+               out_bytes = r_err + 16;
+  VO_CHECK(C.pin.reserve(std::max(in_bytes, out_bytes)));
+  VO_CHECK(C.dq.reserve(in_bytes));
+  VO_CHECK(C.dout.reserve(out_bytes));
+  uint8_t *sg = C.pin.data();
+  memset(sg, 0, in_bytes);
+  auto put = [&](size_t off, const void *src, size_t bytes) {
+    if (src && bytes) memcpy(sg + off, src, bytes);
+  };
+  put(o_x, cur->x, (size_t)nf * 4), put(o_y, cur->y, (size_t)nf * 4), put(o_oct, cur->octave, (size_t)nf * 4);
+  put(o_ang, cur->angle, (size_t)nf * 4), put(o_fd, cur->desc, (size_t)nf * 32), put(o_mask, mask_in, (size_t)nf);
+  if (cur->uright) put(o_ur, cur->uright, (size_t)nf * 4);
+  else for (int i = 0; i < nf; i++) reinterpret_cast<float *>(sg + o_ur)[i] = -1.f;
+  if (assigned) put(o_asg, assigned, (size_t)nf * 4);
+  put(o_qf, hq.flags, (size_t)nq), put(o_qu, hq.u, (size_t)nq * 4), put(o_qv, hq.v, (size_t)nq * 4);
+  put(o_qa, hq.aux, (size_t)nq * 4), put(o_ql, hq.level, (size_t)nq * 4), put(o_qang, hq.angle, (size_t)nq * 4);
+  put(o_qvc, hq.viewcos, (size_t)nq * 4), put(o_qd, hq.desc, (size_t)nq * 32);
+  memcpy(sg + o_n, &nf, 4);
+  VO_CHECK(vo::copy_h2d(C.dq.p, sg, in_bytes, st, "guided matcher"));
+  uint8_t *d = C.dq.as<uint8_t>(), *r = C.dout.as<uint8_t>();
+  // frame slot 0 <- the staged view (device-to-device), then its grid
+  FramesDev &D = h->D;
+  frames_set_bounds(h, cur->xmin, cur->ymin, cur->xmax, cur->ymax);
+  auto d2d = [&](void *dst, size_t off, size_t bytes) -> int {
+    if (bytes) VO_HIP_CHECK(hipMemcpyAsync(dst, d + off, bytes, hipMemcpyDeviceToDevice, st));
+    return VO_OK;
+  };
+  VO_CHECK(d2d(D.x, o_x, (size_t)nf * 4));
+  VO_CHECK(d2d(D.y, o_y, (size_t)nf * 4));
+  VO_CHECK(d2d(D.octave, o_oct, (size_t)nf * 4));
+  VO_CHECK(d2d(D.angle, o_ang, (size_t)nf * 4));
+  VO_CHECK(d2d(D.uright, o_ur, (size_t)nf * 4));
+  VO_CHECK(d2d(D.desc, o_fd, (size_t)nf * 32));
+  VO_CHECK(d2d(D.n, o_n, 4));
+  hipLaunchKernelGGL(k_frame_grid, dim3(1), dim3(256), 0, st, D, 0);
+  Queries Q{};
+  Q.flags = d + o_qf, Q.u = reinterpret_cast<const float *>(d + o_qu), Q.v = reinterpret_cast<const float *>(d + o_qv);
+  Q.aux = reinterpret_cast<const float *>(d + o_qa), Q.level = reinterpret_cast<const int *>(d + o_ql);
+  Q.angle = reinterpret_cast<const float *>(d + o_qang), Q.viewcos = reinterpret_cast<const float *>(d + o_qvc);
+  Q.desc = d + o_qd, Q.nq = nullptr, Q.nq_all = nq, Q.stride = std::max(nq, 1);
+  int *d_asg = reinterpret_cast<int *>(r + r_asg), *d_best = reinterpret_cast<int *>(r + r_best);
+  int *d_nm = reinterpret_cast<int *>(r + r_nm);
+  const bool claims = c.mode == kModeFrame || c.mode == kModeLocalMap || c.mode == kModeKeyFrame || c.mode == kModeSim3;
+  if (claims) VO_CHECK(d2d(d_asg, o_asg, (size_t)nf * 4));
+  // the cap of the frame store may exceed nf: assigned / mask arrays are indexed with the store's stride for
+  // frame 0 only, so the staged [nf] arrays serve as they are
+  size_t pool = std::max<size_t>((size_t)nq * 48, 4096);
+  for (int attempt = 0;; attempt++) {
+    VO_CHECK(guided_launch(h, 0, 1, Q, c, mask_in ? d + o_mask : nullptr, d_asg, d_best, d_nm, pool, st));
+    VO_HIP_CHECK(hipMemcpyAsync(r + r_err, h->b_err.p, 4, hipMemcpyDeviceToDevice, st));
+    VO_CHECK(vo::copy_d2h(sg, r, out_bytes, st, "guided matcher"));
+    VO_CHECK(vo::stream_sync(st, "guided matcher"));
+    int e;
+    memcpy(&e, sg + r_err, 4);
+    if (!e) break;
+    if (attempt >= 6) {
+      vo::set_error("guided matcher: candidate pool overflow");
+      return VO_ERR_CAPACITY;
+    }
+    pool *= 4;  // rare (dense windows): redo with a larger pool
+    if (claims) VO_CHECK(d2d(d_asg, o_asg, (size_t)nf * 4));
+  }
+  if (claims && assigned) memcpy(assigned, sg + r_asg, (size_t)nf * 4);
+  if (!claims && best_idx) memcpy(best_idx, sg + r_best, (size_t)nq * 4);
+  memcpy(n_matches, sg + r_nm, 4);
+  return VO_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int vo_match_frame_projection(const vo_frame_view *cur, int nq, const uint8_t *q_flags, const float *q_u,
+                              const float *q_v, const float *q_invz, const int32_t *q_octave, const float *q_angle,
+                              const uint8_t *q_desc, float radius, float bf, int direction, int check_rot, int n_levels,
+                              const float *scale_factors, const uint8_t *blocked_in, int32_t *assigned, int *n_matches) {
+  if (!cur || nq < 0 || !assigned || !n_matches || !scale_factors || n_levels < 1 || n_levels > 16) return VO_ERR_INVALID;
+  *n_matches = 0;
+  if (nq == 0 || cur->n == 0) return VO_OK;
+  if (!q_flags || !q_u || !q_v || !q_invz || !q_octave || !q_desc || (check_rot && !q_angle)) return VO_ERR_INVALID;
+  const HostQueries hq{nq, q_flags, q_u, q_v, q_invz, q_octave, q_angle, nullptr, q_desc};
+  const GuidedCall c{kModeFrame, radius, bf, 0.f, 0.f, direction, check_rot, n_levels, 0, scale_factors, n_levels};
+  return guided_host(cur, hq, c, blocked_in, assigned, nullptr, n_matches);
+}
+
+int vo_match_local_map(const vo_frame_view *cur, int nq, const uint8_t *q_flags, const float *q_u, const float *q_v,
+                       const float *q_ur, const int32_t *q_level, const float *q_viewcos, const uint8_t *q_desc,
+                       float th_radius, float ratio, const float *scale_factors, const uint8_t *blocked_in,
+                       int32_t *assigned, int *n_matches) {
+  if (!cur || nq < 0 || !assigned || !n_matches || !scale_factors) return VO_ERR_INVALID;
+  *n_matches = 0;
+  if (nq == 0 || cur->n == 0) return VO_OK;
+  if (!q_flags || !q_u || !q_v || !q_ur || !q_level || !q_viewcos || !q_desc) return VO_ERR_INVALID;
+  const HostQueries hq{nq, q_flags, q_u, q_v, q_ur, q_level, nullptr, q_viewcos, q_desc};
+  const GuidedCall c{kModeLocalMap, th_radius, 0.f, ratio, 0.f, 0, 0, 16, 0, scale_factors, 16};
+  return guided_host(cur, hq, c, blocked_in, assigned, nullptr, n_matches);
+}
+
+int vo_match_frame_keyframe(const vo_frame_view *cur, int nq, const uint8_t *q_flags, const float *q_u,
+                            const float *q_v, const int32_t *q_level, const float *q_angle, const uint8_t *q_desc,
+                            float radius, float dist_threshold, int check_rot, const float *scale_factors,
+                            const uint8_t *has_mp_in, int32_t *assigned, int *n_matches) {
+  if (!cur || nq < 0 || !assigned || !n_matches || !scale_factors) return VO_ERR_INVALID;
+  *n_matches = 0;
+  if (nq == 0 || cur->n == 0) return VO_OK;
+  if (!q_flags || !q_u || !q_v || !q_level || !q_desc || (check_rot && !q_angle)) return VO_ERR_INVALID;
+  const HostQueries hq{nq, q_flags, q_u, q_v, nullptr, q_level, q_angle, nullptr, q_desc};
+  const GuidedCall c{kModeKeyFrame, radius, 0.f, 0.f, dist_threshold, 0, check_rot, 16, 0, scale_factors, 16};
+  return guided_host(cur, hq, c, has_mp_in, assigned, nullptr, n_matches);
+}
+
+int vo_match_fuse(const vo_frame_view *kf, int nq, const uint8_t *q_flags, const float *q_u, const float *q_v,
+                  const float *q_ur, const int32_t *q_level, const uint8_t *q_desc, float threshold,
+                  const float *scale_factors, int32_t *best_idx, int *n_matches) {
+  if (!kf || nq < 0 || !best_idx || !n_matches || !scale_factors) return VO_ERR_INVALID;
+  for (int i = 0; i < nq; i++) best_idx[i] = -1;
+  *n_matches = 0;
+  if (nq == 0 || kf->n == 0) return VO_OK;
+  if (!q_flags || !q_u || !q_v || !q_ur || !q_level || !q_desc) return VO_ERR_INVALID;
+  const HostQueries hq{nq, q_flags, q_u, q_v, q_ur, q_level, nullptr, nullptr, q_desc};
+  const GuidedCall c{kModeFuse, threshold, 0.f, 0.f, 0.f, 0, 0, 16, TH_LOW, scale_factors, 16};
+  return guided_host(kf, hq, c, nullptr, nullptr, best_idx, n_matches);
+}
+
+int vo_match_area_best(const vo_frame_view *kf, int nq, const uint8_t *q_flags, const float *q_u, const float *q_v,
+                       const int32_t *q_level, const uint8_t *q_desc, float th, const float *scale_factors,
+                       int max_dist, int32_t *best_idx, int *n_matches) {
+  if (!kf || nq < 0 || !best_idx || !n_matches || !scale_factors) return VO_ERR_INVALID;
+  for (int i = 0; i < nq; i++) best_idx[i] = -1;
+  *n_matches = 0;
+  if (nq == 0 || kf->n == 0) return VO_OK;
+  if (!q_flags || !q_u || !q_v || !q_level || !q_desc) return VO_ERR_INVALID;
+  const HostQueries hq{nq, q_flags, q_u, q_v, nullptr, q_level, nullptr, nullptr, q_desc};
+  const GuidedCall c{kModeArea, th, 0.f, 0.f, 0.f, 0, 0, 16, max_dist, scale_factors, 16};
+  return guided_host(kf, hq, c, nullptr, nullptr, best_idx, n_matches);
+}
+
+int vo_match_sim3_projection(const vo_frame_view *kf, int nq, const uint8_t *q_flags, const float *q_u,
+                             const float *q_v, const int32_t *q_level, const uint8_t *q_desc, int th,
+                             const float *scale_factors, const uint8_t *occupied, int32_t *assigned, int *n_matches) {
+  if (!kf || nq < 0 || !assigned || !n_matches || !scale_factors) return VO_ERR_INVALID;
+  for (int k = 0; k < kf->n; k++) assigned[k] = -1;
+  *n_matches = 0;
+  if (nq == 0 || kf->n == 0) return VO_OK;
+  if (!q_flags || !q_u || !q_v || !q_level || !q_desc) return VO_ERR_INVALID;
+  const HostQueries hq{nq, q_flags, q_u, q_v, nullptr, q_level, nullptr, nullptr, q_desc};
+  const GuidedCall c{kModeSim3, (float)th, 0.f, 0.f, 0.f, 0, 0, 16, TH_LOW, scale_factors, 16};
+  return guided_host(kf, hq, c, occupied, assigned, nullptr, n_matches);
+}
+
+int vo_match_sim3_mutual(const vo_frame_view *kf1, const vo_frame_view *kf2, const uint8_t *q1_flags, const float *q1_u,
+                         const float *q1_v, const int32_t *q1_level, const uint8_t *q1_desc, const uint8_t *q2_flags,
+                         const float *q2_u, const float *q2_v, const int32_t *q2_level, const uint8_t *q2_desc, float th,
+                         const float *scale_factors1, const float *scale_factors2, int32_t *match12, int *n_matches) {
+  if (!kf1 || !kf2 || !match12 || !n_matches) return VO_ERR_INVALID;
+  std::vector<int32_t> m1(std::max(1, kf1->n)), m2(std::max(1, kf2->n));
+  int n1 = 0, n2 = 0;
+  VO_CHECK(vo_match_area_best(kf2, kf1->n, q1_flags, q1_u, q1_v, q1_level, q1_desc, th, scale_factors2, TH_HIGH,
+                              m1.data(), &n1));
+  VO_CHECK(vo_match_area_best(kf1, kf2->n, q2_flags, q2_u, q2_v, q2_level, q2_desc, th, scale_factors1, TH_HIGH,
+                              m2.data(), &n2));
+  int found = 0;
+  for (int i = 0; i < kf1->n; i++) {
+    match12[i] = -1;
+    if (m1[i] >= 0 && m2[m1[i]] == i) match12[i] = m1[i], found++;  // :853-864
+  }
+  *n_matches = found;
+  return VO_OK;
+}
+
+}  // extern "C"

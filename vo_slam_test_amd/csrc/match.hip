@@ -5,6 +5,7 @@
 // so that match pairs stay identical to the reference's visiting order.
 #include "vo_common.h"
 
+#include <algorithm>
 #include <cmath>
 #include <vector>
 
@@ -91,52 +92,59 @@ int launch_hamming(const uint8_t *a, int na, size_t as, const uint8_t *b, int nb
   return VO_OK;
 }
 
-// ---- host replay helpers -----------------------------------------------------------------
-constexpr int kGridCols = 64, kGridRows = 48;  // FRAME_GRID_COLS/ROWS, camera.h:8-9
-constexpr int TH_HIGH = 100;                   // matcher.cpp:11
-constexpr int HISTO_LENGTH = 30;               // :13
-
-struct Grid {  // Frame::assignFeaturesToGrid, frame.cpp:72-89
-  std::vector<int> start, items;
-  float gw, gh, xmin, ymin;
-  explicit Grid(const vo_frame_view &f) : start(kGridCols * kGridRows + 1, 0), items(f.n > 0 ? f.n : 0) {
-    xmin = f.xmin, ymin = f.ymin;
-    gw = (float)kGridCols / (f.xmax - f.xmin);  // camera.cpp:45-46
-    gh = (float)kGridRows / (f.ymax - f.ymin);
-    std::vector<int> cell(f.n, -1);
-    for (int i = 0; i < f.n; i++) {
-      const int gx = (int)roundf((f.x[i] - xmin) * gw), gy = (int)roundf((f.y[i] - ymin) * gh);
-      if (gx < 0 || gx >= kGridCols || gy < 0 || gy >= kGridRows) continue;
-      cell[i] = gx * kGridRows + gy;
-      start[cell[i] + 1]++;
-    }
-    for (size_t c = 1; c < start.size(); c++) start[c] += start[c - 1];
-    std::vector<int> fill(start.begin(), start.end() - 1);
-    for (int i = 0; i < f.n; i++)
-      if (cell[i] >= 0) items[fill[cell[i]]++] = i;
+// MapPoint::computeDescriptor (mappoint.cpp:118-179): among the N descriptors observing one map point, the one
+// whose MEDIAN Hamming distance to all N (itself included, sorted row entry int(0.5 * (N - 1))) is smallest;
+// strict < keeps the first.  One workgroup per map point (a batch of points per launch): descriptors staged in
+// LDS at a 36-byte pitch (conflict-free column reads), one wavefront per row -- lanes are columns, the row's k-th
+// smallest distance by a 9-step bisection over ballot counts -- and an LDS atomicMin over (median << 16 | row).
+constexpr int kMedianMax = 1024;  // observations per map point (36 KB of LDS)
+__global__ __launch_bounds__(256) void k_median_desc(const uint32_t *desc, const int *offsets, int *best_idx) {
+  extern __shared__ uint32_t md_lds[];  // [n][9]
+  __shared__ unsigned s_best;
+  const int set = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int o = offsets[set], n = offsets[set + 1] - o;
+  if (n <= 0) {  // `if (desp.empty()) return;` :136-137 -- nothing selected
+    if (tid == 0) best_idx[set] = -1;
+    return;
   }
-  // Frame::getFeaturesInArea, frame.cpp:199-247
-  void query(const vo_frame_view &f, float u, float v, float r, int lmin, int lmax, std::vector<int> &out) const {
-    out.clear();
-    const int x0 = std::max(0, (int)floorf((u - xmin - r) * gw));
-    if (x0 >= kGridCols) return;
-    const int x1 = std::min(kGridCols - 1, (int)floorf((u - xmin + r) * gw));
-    if (x1 < 0) return;
-    const int y0 = std::max(0, (int)floorf((v - ymin - r) * gh));
-    if (y0 >= kGridRows) return;
-    const int y1 = std::min(kGridRows - 1, (int)floorf((v - ymin + r) * gh));
-    if (y1 < 0) return;
-    for (int ix = x0; ix <= x1; ix++)
-      for (int iy = y0; iy <= y1; iy++) {
-        const int c = ix * kGridRows + iy;
-        for (int t = start[c]; t < start[c + 1]; t++) {
-          const int k = items[t];
-          if (f.octave[k] < lmin || f.octave[k] > lmax) continue;
-          if (fabsf(f.x[k] - u) < r && fabsf(f.y[k] - v) < r) out.push_back(k);
-        }
+  for (int i = tid; i < n * 8; i += 256) md_lds[(i >> 3) * 9 + (i & 7)] = desc[(long long)o * 8 + i];
+  if (tid == 0) s_best = 256u << 16;  // bestMid = 256, bestIdx = 0  :159-160
+  __syncthreads();
+  const int k = (n - 1) / 2;  // int(0.5 * (N - 1))  :166
+  constexpr int NC = kMedianMax / 64;
+  for (int row = wave; row < n; row += 4) {
+    uint32_t a[8];
+#pragma unroll
+    for (int w = 0; w < 8; w++) a[w] = md_lds[row * 9 + w];
+    int d[NC];
+#pragma unroll
+    for (int c = 0; c < NC; c++) {
+      d[c] = 0x7fff;
+      const int j = lane + 64 * c;
+      if (64 * c < n && j < n) {
+        int s = 0;
+#pragma unroll
+        for (int w = 0; w < 8; w++) s += __popc(a[w] ^ md_lds[j * 9 + w]);
+        d[c] = s;
       }
+    }
+    int lo = 0, hi = 256;  // smallest v with #(d <= v) >= k + 1
+    while (lo < hi) {
+      const int mid = (lo + hi) >> 1;
+      int cnt = 0;
+#pragma unroll
+      for (int c = 0; c < NC; c++)
+        if (64 * c < n) cnt += __popcll(__builtin_amdgcn_ballot_w64(d[c] <= mid));
+      if (cnt >= k + 1) hi = mid; else lo = mid + 1;
+    }
+    if (lane == 0) atomicMin(&s_best, ((unsigned)lo << 16) | (unsigned)row);
   }
-};
+  __syncthreads();
+  if (tid == 0) best_idx[set] = (int)(s_best & 0xffffu);
+}
+
+// ---- host replay helpers (BoW-node searches: the candidate sets are vocabulary nodes, not grid windows) ----
+constexpr int HISTO_LENGTH = 30;               // matcher.cpp:13
 
 // device all-pairs distances for (queries x features), back on the host
 int distance_matrix(const uint8_t *q_desc, int nq, const uint8_t *f_desc, int nf, std::vector<uint16_t> &D) {
@@ -187,135 +195,43 @@ int vo_hamming_matrix(const uint8_t *a, int na, const uint8_t *b, int nb, uint16
   if (!a || !b || !d) return VO_ERR_INVALID;
   VO_CHECK(vo::ensure_device());
   // per host thread, grow-only: the stateless entry points do not allocate after the first call at a size
-  // (never freed: a few MB per calling thread for the life of the process)
+  // (never freed: a few MB per calling thread for the life of the process); the calling thread's own stream
   thread_local vo::DevBuf da, db, dd;
-  int rc = VO_OK;
-  do {
-    if ((rc = da.reserve((size_t)na * 32)) != VO_OK) break;
-    if ((rc = db.reserve((size_t)nb * 32)) != VO_OK) break;
-    if ((rc = dd.reserve((size_t)na * nb * 2)) != VO_OK) break;
-    if (hipMemcpy(da.p, a, (size_t)na * 32, hipMemcpyHostToDevice) != hipSuccess ||
-        hipMemcpy(db.p, b, (size_t)nb * 32, hipMemcpyHostToDevice) != hipSuccess) {
-      vo::set_error("hipMemcpy H2D failed");
-      rc = VO_ERR_HIP;
-      break;
-    }
-    if ((rc = launch_hamming(da.as<uint8_t>(), na, 0, db.as<uint8_t>(), nb, 0, dd.as<uint16_t>(), 0, 1, nullptr)) != VO_OK)
-      break;
-    if (hipMemcpy(d, dd.p, (size_t)na * nb * 2, hipMemcpyDeviceToHost) != hipSuccess) {
-      vo::set_error("hipMemcpy D2H failed");
-      rc = VO_ERR_HIP;
-    }
-  } while (0);
-  return rc;
+  hipStream_t st = vo::thread_stream();
+  VO_CHECK(vo::upload(da, a, (size_t)na * 32, st, "vo_hamming_matrix"));
+  VO_CHECK(vo::upload(db, b, (size_t)nb * 32, st, "vo_hamming_matrix"));
+  VO_CHECK(dd.reserve((size_t)na * nb * 2));
+  VO_CHECK(launch_hamming(da.as<uint8_t>(), na, 0, db.as<uint8_t>(), nb, 0, dd.as<uint16_t>(), 0, 1, st));
+  VO_CHECK(vo::copy_d2h(d, dd.p, (size_t)na * nb * 2, st, "vo_hamming_matrix"));
+  return vo::stream_sync(st, "vo_hamming_matrix");
 }
 
-int vo_match_frame_projection(const vo_frame_view *cur, int nq, const uint8_t *q_flags, const float *q_u,
-                              const float *q_v, const float *q_invz, const int32_t *q_octave,
-                              const float *q_angle, const uint8_t *q_desc, float radius, float bf, int direction,
-                              int check_rot, int n_levels, const float *scale_factors, const uint8_t *blocked_in,
-                              int32_t *assigned, int *n_matches) {
-  if (!cur || nq < 0 || !assigned || !n_matches || !scale_factors) return VO_ERR_INVALID;
-  *n_matches = 0;
-  if (nq == 0 || cur->n == 0) return VO_OK;
-  std::vector<uint16_t> D;
-  VO_CHECK(distance_matrix(q_desc, nq, cur->desc, cur->n, D));
-  const Grid grid(*cur);
-  const float pdf = HISTO_LENGTH / 360.0f;
-  std::vector<std::vector<int>> rot(HISTO_LENGTH);
-  std::vector<uint8_t> blocked(cur->n, 0);
-  if (blocked_in) blocked.assign(blocked_in, blocked_in + cur->n);
-  std::vector<int> cand;
-  int cnt = 0;
-  for (int i = 0; i < nq; i++) {
-    if (!(q_flags[i] & 1)) continue;
-    const int oct = q_octave[i];
-    const float rs = radius * scale_factors[oct];
-    if (direction == 1)
-      grid.query(*cur, q_u[i], q_v[i], rs, oct, n_levels, cand);
-    else if (direction == 2)
-      grid.query(*cur, q_u[i], q_v[i], rs, 0, oct, cand);
-    else
-      grid.query(*cur, q_u[i], q_v[i], rs, oct - 1, oct + 1, cand);
-    int best = 256, best_idx = -1;
-    for (int idx : cand) {
-      if (blocked[idx]) continue;
-      if (cur->uright[idx] > 0) {
-        const float ur = q_u[i] - bf * q_invz[i];
-        if (fabsf(ur - cur->uright[idx]) > rs) continue;
-      }
-      const int d = D[(size_t)i * cur->n + idx];
-      if (d < best) best = d, best_idx = idx;
-    }
-    if (best <= TH_HIGH) {
-      assigned[best_idx] = i;
-      blocked[best_idx] = (q_flags[i] >> 1) & 1;
-      cnt++;
-      if (check_rot) {
-        float r = q_angle[i] - cur->angle[best_idx];
-        if (r < 0) r += 360.0f;
-        int bin = (int)lrintf(r * pdf);
-        if (bin == HISTO_LENGTH) bin = 0;
-        rot[bin].push_back(best_idx);
-      }
-    }
+int vo_median_descriptor(const uint8_t *desc, int n_sets, const int32_t *offsets, int32_t *best_idx) {
+  if (n_sets < 0 || (n_sets > 0 && (!offsets || !best_idx))) return VO_ERR_INVALID;
+  if (n_sets == 0) return VO_OK;
+  const int total = offsets[n_sets];
+  if (total < 0 || (total > 0 && !desc)) return VO_ERR_INVALID;
+  int nmax = 0;
+  for (int s = 0; s < n_sets; s++) {
+    const int n = offsets[s + 1] - offsets[s];
+    if (n < 0) return VO_ERR_INVALID;
+    nmax = std::max(nmax, n);
   }
-  if (check_rot) {
-    int i1, i2, i3;
-    three_max(rot, i1, i2, i3);
-    for (int b = 0; b < HISTO_LENGTH; b++)
-      if (b != i1 && b != i2 && b != i3)
-        for (int idx : rot[b]) {
-          assigned[idx] = -1;
-          cnt--;
-        }
+  if (nmax > kMedianMax) {
+    vo::set_error("vo_median_descriptor: %d observations of one map point exceed %d", nmax, kMedianMax);
+    return VO_ERR_CAPACITY;
   }
-  *n_matches = cnt;
-  return VO_OK;
-}
-
-int vo_match_local_map(const vo_frame_view *cur, int nq, const uint8_t *q_flags, const float *q_u, const float *q_v,
-                       const float *q_ur, const int32_t *q_level, const float *q_viewcos, const uint8_t *q_desc,
-                       float th_radius, float ratio, const float *scale_factors, const uint8_t *blocked_in,
-                       int32_t *assigned, int *n_matches) {
-  if (!cur || nq < 0 || !assigned || !n_matches || !scale_factors) return VO_ERR_INVALID;
-  *n_matches = 0;
-  if (nq == 0 || cur->n == 0) return VO_OK;
-  std::vector<uint16_t> D;
-  VO_CHECK(distance_matrix(q_desc, nq, cur->desc, cur->n, D));
-  const Grid grid(*cur);
-  std::vector<uint8_t> blocked(cur->n, 0);
-  if (blocked_in) blocked.assign(blocked_in, blocked_in + cur->n);
-  std::vector<int> cand;
-  int cnt = 0;
-  for (int i = 0; i < nq; i++) {
-    if (!(q_flags[i] & 1)) continue;
-    float radius = q_viewcos[i] > 0.998 ? 2.5f : 4.0f;  // :288-291
-    radius *= th_radius;
-    const int lv = q_level[i];
-    const float rs = radius * scale_factors[lv];
-    grid.query(*cur, q_u[i], q_v[i], rs, lv - 1, lv, cand);
-    int best = 256, best_lv = -1, second = 256, second_lv = -1, best_idx = -1;
-    for (int idx : cand) {
-      if (blocked[idx]) continue;
-      if (cur->uright[idx] > 0 && fabsf(q_ur[i] - cur->uright[idx]) > rs) continue;
-      const int d = D[(size_t)i * cur->n + idx];
-      if (d < best) {
-        second = best, second_lv = best_lv;
-        best = d, best_lv = cur->octave[idx], best_idx = idx;
-      } else if (d < second) {
-        second = d, second_lv = cur->octave[idx];
-      }
-    }
-    if (best <= TH_HIGH) {
-      if (best_lv == second_lv && (float)best > ratio * (float)second) continue;
-      assigned[best_idx] = i;
-      blocked[best_idx] = (q_flags[i] >> 1) & 1;
-      cnt++;
-    }
-  }
-  *n_matches = cnt;
-  return VO_OK;
+  VO_CHECK(vo::ensure_device());
+  thread_local vo::DevBuf dd, doff, dbest;
+  hipStream_t st = vo::thread_stream();
+  VO_CHECK(vo::upload(dd, desc, (size_t)total * 32, st, "vo_median_descriptor"));
+  VO_CHECK(vo::upload(doff, offsets, (size_t)(n_sets + 1) * 4, st, "vo_median_descriptor"));
+  VO_CHECK(dbest.reserve((size_t)n_sets * 4));
+  const size_t lds = (size_t)std::max(nmax, 1) * 36;
+  hipLaunchKernelGGL(k_median_desc, dim3(n_sets), dim3(256), lds, st, dd.as<uint32_t>(), doff.as<int>(), dbest.as<int>());
+  VO_HIP_CHECK(hipGetLastError());
+  VO_CHECK(vo::copy_d2h(best_idx, dbest.p, (size_t)n_sets * 4, st, "vo_median_descriptor"));
+  return vo::stream_sync(st, "vo_median_descriptor");
 }
 
 }  // extern "C"
@@ -367,44 +283,6 @@ void for_common_nodes(const vo_bow_view &a, const vo_bow_view &b, F &&f) {
 }  // namespace
 
 extern "C" {
-
-int vo_match_frame_keyframe(const vo_frame_view *cur, int nq, const uint8_t *q_flags, const float *q_u,
-                            const float *q_v, const int32_t *q_level, const float *q_angle, const uint8_t *q_desc,
-                            float radius, float dist_threshold, int check_rot, const float *scale_factors,
-                            const uint8_t *has_mp_in, int32_t *assigned, int *n_matches) {
-  if (!cur || nq < 0 || !assigned || !n_matches || !scale_factors) return VO_ERR_INVALID;
-  *n_matches = 0;
-  if (nq == 0 || cur->n == 0) return VO_OK;
-  std::vector<uint16_t> D;
-  VO_CHECK(distance_matrix(q_desc, nq, cur->desc, cur->n, D));
-  const Grid grid(*cur);
-  std::vector<uint8_t> has(cur->n, 0);
-  if (has_mp_in) has.assign(has_mp_in, has_mp_in + cur->n);
-  RotHist rot;
-  std::vector<int> cand;
-  int cnt = 0;
-  for (int i = 0; i < nq; i++) {
-    if (!(q_flags[i] & 1)) continue;
-    const int lp = q_level[i];
-    const float rs = radius * scale_factors[lp];
-    grid.query(*cur, q_u[i], q_v[i], rs, lp - 1, lp + 1, cand);
-    int best = 256, best_idx = -1;
-    for (int idx : cand) {
-      if (has[idx]) continue;
-      const int d = D[(size_t)i * cur->n + idx];
-      if (d < best) best = d, best_idx = idx;
-    }
-    if ((float)best <= dist_threshold) {
-      assigned[best_idx] = i;
-      has[best_idx] = 1;
-      cnt++;
-      if (check_rot) rot.add(q_angle[i], cur->angle[best_idx], best_idx, true);
-    }
-  }
-  if (check_rot) cnt -= rot.prune([&](int idx) { assigned[idx] = -1; });
-  *n_matches = cnt;
-  return VO_OK;
-}
 
 int vo_match_bow(const vo_frame_view *a, const uint8_t *a_valid, const vo_bow_view *an, const vo_frame_view *b,
                  const uint8_t *b_valid, const vo_bow_view *bn, int mode, float ratio, int check_rot, int32_t *match,
@@ -498,135 +376,6 @@ int vo_match_triangulation(const vo_frame_view *a, const uint8_t *a_has, const v
   });
   if (check_rot) cnt -= rot.prune([&](int idx) { match12[idx] = -1; });
   *n_matches = cnt;
-  return VO_OK;
-}
-
-int vo_match_fuse(const vo_frame_view *kf, int nq, const uint8_t *q_flags, const float *q_u, const float *q_v,
-                  const float *q_ur, const int32_t *q_level, const uint8_t *q_desc, float threshold,
-                  const float *scale_factors, int32_t *best_idx, int *n_matches) {
-  if (!kf || nq < 0 || !best_idx || !n_matches || !scale_factors) return VO_ERR_INVALID;
-  for (int i = 0; i < nq; i++) best_idx[i] = -1;
-  *n_matches = 0;
-  if (nq == 0 || kf->n == 0) return VO_OK;
-  std::vector<uint16_t> D;
-  VO_CHECK(distance_matrix(q_desc, nq, kf->desc, kf->n, D));
-  const Grid grid(*kf);
-  std::vector<int> cand;
-  int cnt = 0;
-  for (int i = 0; i < nq; i++) {
-    if (!(q_flags[i] & 1)) continue;
-    const int lp = q_level[i];
-    grid.query(*kf, q_u[i], q_v[i], threshold * scale_factors[lp], -(1 << 30), 1 << 30, cand);
-    int best = 256, bidx = -1;
-    for (int idx : cand) {
-      if (kf->octave[idx] < lp - 1 || kf->octave[idx] > lp) continue;
-      const float dx = q_u[i] - kf->x[idx], dy = q_v[i] - kf->y[idx];
-      const float is = 1.0f / scale_factors[kf->octave[idx]];
-      if (kf->uright[idx] >= 0) {  // chi2 gates of :1084-1099
-        const float er = q_ur[i] - kf->uright[idx];
-        if ((dx * dx + dy * dy + er * er) * is * is > 7.815f) continue;
-      } else if ((dx * dx + dy * dy) * is * is > 5.991f) {
-        continue;
-      }
-      const int d = D[(size_t)i * kf->n + idx];
-      if (d < best) best = d, bidx = idx;
-    }
-    if (best <= TH_LOW) best_idx[i] = bidx, cnt++;
-  }
-  *n_matches = cnt;
-  return VO_OK;
-}
-
-
-// ---- loop-closure searches (matcher.cpp:356-447, 679-865, 1135-1238)
-namespace {
-// best feature of the window around (u, v) with octave in [lp - 1, lp]; `skip` (optional) is the
-// occupancy array of the Sim3 projection search, consulted per CANDIDATE RANK (reference :422)
-inline int area_best(const vo_frame_view &kf, const Grid &grid, const uint16_t *drow, float u, float v, float radius,
-                     int lp, const uint8_t *skip, std::vector<int> &cand, int &best) {
-  grid.query(kf, u, v, radius, -(1 << 30), 1 << 30, cand);
-  best = 256;
-  int bidx = -1;
-  for (size_t j = 0; j < cand.size(); j++) {
-    const int idx = cand[j];
-    if (skip && skip[j]) continue;
-    if (kf.octave[idx] < lp - 1 || kf.octave[idx] > lp) continue;
-    const int d = drow[idx];
-    if (d < best) best = d, bidx = idx;
-  }
-  return bidx;
-}
-}  // namespace
-
-int vo_match_area_best(const vo_frame_view *kf, int nq, const uint8_t *q_flags, const float *q_u, const float *q_v,
-                       const int32_t *q_level, const uint8_t *q_desc, float th, const float *scale_factors,
-                       int max_dist, int32_t *best_idx, int *n_matches) {
-  if (!kf || nq < 0 || !best_idx || !n_matches || !scale_factors) return VO_ERR_INVALID;
-  for (int i = 0; i < nq; i++) best_idx[i] = -1;
-  *n_matches = 0;
-  if (nq == 0 || kf->n == 0) return VO_OK;
-  std::vector<uint16_t> D;
-  VO_CHECK(distance_matrix(q_desc, nq, kf->desc, kf->n, D));
-  const Grid grid(*kf);
-  std::vector<int> cand;
-  int cnt = 0;
-  for (int i = 0; i < nq; i++) {
-    if (!(q_flags[i] & 1)) continue;
-    int best;
-    const int bidx = area_best(*kf, grid, &D[(size_t)i * kf->n], q_u[i], q_v[i], th * scale_factors[q_level[i]],
-                               q_level[i], nullptr, cand, best);
-    if (best <= max_dist) best_idx[i] = bidx, cnt++;
-  }
-  *n_matches = cnt;
-  return VO_OK;
-}
-
-int vo_match_sim3_projection(const vo_frame_view *kf, int nq, const uint8_t *q_flags, const float *q_u,
-                             const float *q_v, const int32_t *q_level, const uint8_t *q_desc, int th,
-                             const float *scale_factors, const uint8_t *occupied, int32_t *assigned, int *n_matches) {
-  if (!kf || nq < 0 || !assigned || !n_matches || !scale_factors) return VO_ERR_INVALID;
-  for (int k = 0; k < kf->n; k++) assigned[k] = -1;
-  *n_matches = 0;
-  if (nq == 0 || kf->n == 0) return VO_OK;
-  std::vector<uint16_t> D;
-  VO_CHECK(distance_matrix(q_desc, nq, kf->desc, kf->n, D));
-  const Grid grid(*kf);
-  std::vector<uint8_t> occ(kf->n, 0);
-  if (occupied) occ.assign(occupied, occupied + kf->n);
-  std::vector<int> cand;
-  int cnt = 0;
-  for (int i = 0; i < nq; i++) {
-    if (!(q_flags[i] & 1)) continue;
-    int best;
-    const int bidx = area_best(*kf, grid, &D[(size_t)i * kf->n], q_u[i], q_v[i], (float)th * scale_factors[q_level[i]],
-                               q_level[i], occ.data(), cand, best);
-    if (best <= TH_LOW) {
-      occ[bidx] = 1;
-      assigned[bidx] = i;
-      cnt++;
-    }
-  }
-  *n_matches = cnt;
-  return VO_OK;
-}
-
-int vo_match_sim3_mutual(const vo_frame_view *kf1, const vo_frame_view *kf2, const uint8_t *q1_flags, const float *q1_u,
-                         const float *q1_v, const int32_t *q1_level, const uint8_t *q1_desc, const uint8_t *q2_flags,
-                         const float *q2_u, const float *q2_v, const int32_t *q2_level, const uint8_t *q2_desc, float th,
-                         const float *scale_factors1, const float *scale_factors2, int32_t *match12, int *n_matches) {
-  if (!kf1 || !kf2 || !match12 || !n_matches) return VO_ERR_INVALID;
-  std::vector<int32_t> m1(std::max(1, kf1->n)), m2(std::max(1, kf2->n));
-  int n1 = 0, n2 = 0;
-  VO_CHECK(vo_match_area_best(kf2, kf1->n, q1_flags, q1_u, q1_v, q1_level, q1_desc, th, scale_factors2, TH_HIGH,
-                              m1.data(), &n1));
-  VO_CHECK(vo_match_area_best(kf1, kf2->n, q2_flags, q2_u, q2_v, q2_level, q2_desc, th, scale_factors1, TH_HIGH,
-                              m2.data(), &n2));
-  int found = 0;
-  for (int i = 0; i < kf1->n; i++) {
-    match12[i] = -1;
-    if (m1[i] >= 0 && m2[m1[i]] == i) match12[i] = m1[i], found++;  // :853-864
-  }
-  *n_matches = found;
   return VO_OK;
 }
 
@@ -732,13 +481,15 @@ int vo_bow_transform(const vo_vocab *v, int n, const uint8_t *desc, int levelsup
   VO_CHECK(d_w.reserve((size_t)n * 4));
   VO_CHECK(d_wt.reserve((size_t)n * 8));
   VO_CHECK(d_n.reserve((size_t)n * 4));
-  VO_HIP_CHECK(hipMemcpy(d_f.p, desc, (size_t)n * 32, hipMemcpyHostToDevice));
-  hipLaunchKernelGGL(k_bow_transform, dim3((n + 255) / 256), dim3(256), 0, nullptr, v->V, n, d_f.as<uint32_t>(), levelsup,
+  hipStream_t st = vo::thread_stream();
+  VO_CHECK(vo::copy_h2d(d_f.p, desc, (size_t)n * 32, st, "vo_bow_transform"));
+  hipLaunchKernelGGL(k_bow_transform, dim3((n + 255) / 256), dim3(256), 0, st, v->V, n, d_f.as<uint32_t>(), levelsup,
                      d_w.as<int>(), d_wt.as<double>(), d_n.as<int>());
-  VO_HIP_CHECK(hipMemcpy(word_id, d_w.p, (size_t)n * 4, hipMemcpyDeviceToHost));
-  VO_HIP_CHECK(hipMemcpy(weight, d_wt.p, (size_t)n * 8, hipMemcpyDeviceToHost));
-  VO_HIP_CHECK(hipMemcpy(node_id, d_n.p, (size_t)n * 4, hipMemcpyDeviceToHost));
-  return VO_OK;
+  VO_HIP_CHECK(hipGetLastError());
+  VO_CHECK(vo::copy_d2h(word_id, d_w.p, (size_t)n * 4, st, "vo_bow_transform"));
+  VO_CHECK(vo::copy_d2h(weight, d_wt.p, (size_t)n * 8, st, "vo_bow_transform"));
+  VO_CHECK(vo::copy_d2h(node_id, d_n.p, (size_t)n * 4, st, "vo_bow_transform"));
+  return vo::stream_sync(st, "vo_bow_transform");
 }
 
 }  // extern "C"

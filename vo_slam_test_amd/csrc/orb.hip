@@ -1312,7 +1312,7 @@ template <int NK>  // key-points a wave keeps in flight in phases 1 and 3
 __global__ __launch_bounds__(256) void k_describe(OrbDev P, FrameSrc src, const uint32_t *sel,
                                                   int sel_per_frame, const int *nk, int *counts, int capacity,
                                                   vo_keypoint *kps, uint8_t *desc, int lv0_bytewise,
-                                                  int batches_per_frame, int n_frames) {
+                                                  int batches_per_frame, int n_frames, int *err_flag) {
   __shared__ DescRec rec[64];
   __shared__ __attribute__((aligned(16))) uint8_t win_lds[4][NK][kWinBytes];
   const int tid = threadIdx.x, lane = tid & 63;
@@ -1336,6 +1336,7 @@ __global__ __launch_bounds__(256) void k_describe(OrbDev P, FrameSrc src, const 
   }
   const int total = min(op[kMaxLevels], capacity);
   if (g0 == 0 && tid == 0 && counts) counts[f] = total;
+  if (g0 == 0 && tid == 0 && op[kMaxLevels] > capacity) atomicExch(err_flag, 3);  // key-points dropped: reported by vo_orb_sync
   const int nv = min(total - g0, 64);  // key-points of this batch (uniform)
   if (nv <= 0) return;
   // per-lane constants of phase 1 (disc offsets and weights), independent of the key-point: in flight under phase 0
@@ -1575,6 +1576,8 @@ int align_up(int v, int a) { return (v + a - 1) / a * a; }
 
 int configure(vo_orb *h, int w, int h_img, int n_frames) {
   if (w != h->cfg_w || h_img != h->cfg_h) {
+    // kernels of the previous call may still be reading the tables on the (non-blocking) handle stream
+    VO_HIP_CHECK(hipStreamSynchronize(h->stream));
     OrbDev &D = h->dev;
     memset(&D, 0, sizeof(D));
     D.nlevels = h->nlevels;
@@ -1767,7 +1770,7 @@ int configure(vo_orb *h, int w, int h_img, int n_frames) {
     h->max_kp = maxkp;
     VO_CHECK(h->tables.reserve(std::max<size_t>(tables.size() * sizeof(int), 64)));
     if (!tables.empty())
-      VO_HIP_CHECK(hipMemcpy(h->tables.p, tables.data(), tables.size() * sizeof(int), hipMemcpyHostToDevice));
+      VO_HIP_CHECK(hipMemcpy(h->tables.p, tables.data(), tables.size() * sizeof(int), hipMemcpyHostToDevice));  // synchronous: `tables` is a local
     h->cfg_w = w;
     h->cfg_h = h_img;
     h->batch_cap = 0;
@@ -1783,7 +1786,10 @@ int configure(vo_orb *h, int w, int h_img, int n_frames) {
     VO_CHECK(h->candcnt.reserve(B * kMaxLevels * 4));
     VO_CHECK(h->sel.reserve(B * h->sel_frame * 4));
     VO_CHECK(h->nk.reserve(B * kMaxLevels * 4));
-    VO_CHECK(h->err.reserve(64));
+    if (!h->err.p) {
+      VO_CHECK(h->err.reserve(64));
+      VO_HIP_CHECK(hipMemsetAsync(h->err.p, 0, 64, h->stream));
+    }
     h->batch_cap = n_frames;
   }
   return VO_OK;
@@ -1804,7 +1810,8 @@ int run_pipeline(vo_orb *h, const uint8_t *dev_images, int n_frames, int w, int 
   S.blur_frame_stride = h->blur_frame;
   h->last_src = S;
   h->last_frames = n_frames;
-  VO_HIP_CHECK(hipMemsetAsync(h->err.p, 0, 4, st));
+  // (the device error flag is sticky across calls: vo_orb_sync reads and clears it, so an overflow inside an
+  // asynchronous batch is never lost between two syncs)
   // kernels that read aligned dwords need 4-byte aligned caller rows; otherwise level 0 takes byte paths
   const int lv0_unaligned =
       ((reinterpret_cast<uintptr_t>(dev_images) | (uintptr_t)stride | (uintptr_t)frame_stride) & 3) ? 1 : 0;
@@ -1900,7 +1907,7 @@ int run_pipeline(vo_orb *h, const uint8_t *dev_images, int n_frames, int w, int 
   if (kp_blocks > 0)
     hipLaunchKernelGGL(k_describe<VO_DESC_NK>, dim3(kp_blocks * ((n_frames + 7) / 8) * 8), dim3(256), 0, st, D, S,
                        h->sel.as<uint32_t>(), h->sel_frame, h->nk.as<int>(), dcounts, capacity, dkp, ddesc, lv0_not16, kp_blocks,
-                       n_frames);
+                       n_frames, h->err.as<int>());
   VO_STAGE_MARK(6);
 #undef VO_STAGE_MARK
   VO_HIP_CHECK(hipGetLastError());
@@ -2041,8 +2048,11 @@ int vo_orb_features_per_level(const vo_orb *h, int *q) {
 }
 int vo_orb_max_keypoints(const vo_orb *h) {
   if (!h) return 0;
+  // after the first call the exact per-level capacities are known (max(quota + 4, 4 * nIni), configure());
+  // before it the bound covers root-node counts up to nIni = 8 (images up to ~8.5 : 1)
+  if (h->cfg_w > 0) return h->max_kp;
   int s = 0;
-  for (int i = 0; i < h->nlevels; i++) s += h->quota[i] + 4;
+  for (int i = 0; i < h->nlevels; i++) s += std::max(h->quota[i] + 4, 32);
   return s;
 }
 
@@ -2050,10 +2060,14 @@ int vo_orb_sync(vo_orb *h) {
   if (!h) return VO_ERR_INVALID;
   VO_HIP_CHECK(hipStreamSynchronize(h->stream));
   int e = 0;
-  if (h->err.p) VO_HIP_CHECK(hipMemcpy(&e, h->err.p, 4, hipMemcpyDeviceToHost));
+  if (h->err.p) {
+    VO_HIP_CHECK(hipMemcpy(&e, h->err.p, 4, hipMemcpyDeviceToHost));
+    if (e) VO_HIP_CHECK(hipMemset(h->err.p, 0, 4));  // reported once
+  }
   if (e) {
-    vo::set_error(e == 1 ? "more FAST candidates on one level than the 65535-key scratch holds"
-                         : "oct-tree node list overflow");
+    vo::set_error(e == 1   ? "more FAST candidates on one level than the 65535-key scratch holds"
+                  : e == 2 ? "oct-tree node list overflow"
+                           : "more key-points in a frame than the caller's capacity (see vo_orb_max_keypoints)");
     return VO_ERR_CAPACITY;
   }
   return VO_OK;

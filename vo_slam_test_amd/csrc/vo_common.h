@@ -73,6 +73,19 @@ struct PinnedBuf {
 
 constexpr int kWave = 64;
 
+// Per host thread: a non-blocking stream for the stateless entry points (vo_hamming_matrix, vo_pose_only_solve,
+// vo_sim3_solve, vo_pose_graph_solve, ...).  The reference calls them concurrently from the tracking, local-
+// mapping and loop-closing threads: on the legacy NULL stream a 0.4 ms pose-only solve would queue behind a
+// 500-key-frame pose graph, and every hipDeviceSynchronize would stall the other threads' streams.  Created on
+// first use, never destroyed (thread-exit order vs. runtime teardown).
+hipStream_t thread_stream();
+// checked copies on a stream (error text names `what`)
+int copy_h2d(void *dst, const void *src, size_t bytes, hipStream_t st, const char *what);
+int copy_d2h(void *dst, const void *src, size_t bytes, hipStream_t st, const char *what);
+int stream_sync(hipStream_t st, const char *what);
+// reserve + copy
+int upload(DevBuf &b, const void *src, size_t bytes, hipStream_t st, const char *what);
+
 // Dense SPD solve on the device (csrc/pose_graph.hip).  A: (ld + 64) rows x ld columns, row-major, ld a
 // multiple of 64.  Rows 0..ld-1: the matrix, lower triangle used (identity on the padding diagonal);
 // row ld: the right-hand side; rows ld+1..: zero on entry.  The lower triangle is factored in place

@@ -30,6 +30,53 @@ int ensure_device() {
   return status;
 }
 
+hipStream_t thread_stream() {
+  thread_local hipStream_t st = nullptr;
+  thread_local bool tried = false;
+  if (!tried) {
+    tried = true;
+    if (hipStreamCreateWithFlags(&st, hipStreamNonBlocking) != hipSuccess) {
+      (void)hipGetLastError();
+      st = nullptr;  // the NULL stream still gives correct results
+    }
+  }
+  return st;
+}
+
+int copy_h2d(void *dst, const void *src, size_t bytes, hipStream_t st, const char *what) {
+  if (!bytes) return VO_OK;
+  const hipError_t e = hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, st);
+  if (e != hipSuccess) {
+    set_error("%s: host-to-device copy of %zu bytes failed: %s", what, bytes, hipGetErrorString(e));
+    return VO_ERR_HIP;
+  }
+  return VO_OK;
+}
+
+int copy_d2h(void *dst, const void *src, size_t bytes, hipStream_t st, const char *what) {
+  if (!bytes) return VO_OK;
+  const hipError_t e = hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, st);
+  if (e != hipSuccess) {
+    set_error("%s: device-to-host copy of %zu bytes failed: %s", what, bytes, hipGetErrorString(e));
+    return VO_ERR_HIP;
+  }
+  return VO_OK;
+}
+
+int stream_sync(hipStream_t st, const char *what) {
+  const hipError_t e = hipStreamSynchronize(st);
+  if (e != hipSuccess) {
+    set_error("%s: kernel or copy failed: %s", what, hipGetErrorString(e));
+    return VO_ERR_HIP;
+  }
+  return VO_OK;
+}
+
+int upload(DevBuf &b, const void *src, size_t bytes, hipStream_t st, const char *what) {
+  VO_CHECK(b.reserve(bytes > 64 ? bytes : 64));
+  return copy_h2d(b.p, src, bytes, st, what);
+}
+
 }  // namespace vo
 
 extern "C" {

@@ -46,6 +46,24 @@ def make_shifted(frame: np.ndarray, idx: int, max_shift: int = 12, noise: int = 
     return np.clip(out, 0, 255).astype(np.uint8), dx, dy
 
 
+# distortion coefficients of reference config/example.yaml:25-29 (k1, k2, p1, p2, k3) as float32
+DIST = np.array([0.262383, -0.953104, -0.005358, 0.002628, 1.163314], dtype=np.float32)
+DEPTH_SCALE = 5000.0  # camera_depthScale, example.yaml:31
+
+
+def make_depth(idx: int = 0, w: int = 640, h: int = 480, holes: float = 0.08) -> np.ndarray:
+    """16-bit raw depth image: a tilted plane 0.8 .. 4.5 m plus noise, x 5000, with invalid (0) holes."""
+    rng = _rng(0x5EEDD000 + idx)
+    yy, xx = np.mgrid[0:h, 0:w]
+    a, b = rng.uniform(-1.5, 1.5, 2)
+    z = 2.6 + a * (xx / w - 0.5) + b * (yy / h - 0.5) + rng.normal(0, 0.02, (h, w))
+    z = np.clip(z, 0.8, 4.5)
+    raw = np.round(z * DEPTH_SCALE).astype(np.uint16)
+    hole = rng.random((h // 8 + 1, w // 8 + 1)) < holes
+    raw[np.kron(hole, np.ones((8, 8), bool))[:h, :w]] = 0
+    return raw
+
+
 def make_frames(n: int, start: int = 0, **kw) -> np.ndarray:
     return np.stack([make_frame(start + i, **kw) for i in range(n)])
 
