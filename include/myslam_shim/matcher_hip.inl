@@ -183,7 +183,7 @@ int Matcher::searchByBoW(KeyFrame *kf, Frame *frame, vector<MapPoint *> &matches
   std::vector<int32_t> m(frame->N_, -1);
   int n = 0;
   vo_match_bow(&a.view, valid.data(), &an.view, &b.view, nullptr, &bn.view, 0, ratio_, checkRot ? 1 : 0, m.data(), &n);
-  for (int k = 0; k < frame->N_; k++)
+  for (int k = 0; k < (int)frame->N_; k++)
     if (m[k] >= 0) matches[k] = mps[m[k]];
   return n;
 }
@@ -225,7 +225,7 @@ int Matcher::searchForTriangulation(KeyFrame *kf1, KeyFrame *kf2, vector<pair<in
                          kf2->scaleFactors_.data(), checkRot ? 1 : 0, m.data(), &n);
   matchIdxs.clear();
   matchIdxs.reserve(n);
-  for (int i = 0; i < kf1->N_; i++)
+  for (int i = 0; i < (int)kf1->N_; i++)
     if (m[i] >= 0) matchIdxs.push_back(make_pair(i, m[i]));
   return n;
 }

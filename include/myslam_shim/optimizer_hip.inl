@@ -134,7 +134,8 @@ void Optimizer::solveLocalBAPoseAndPoint(KeyFrame *keyframe, bool &stopFlag, Map
   for (size_t k = 0; k < cams.size(); k++) {
     if (fixed[k]) continue;
     Eigen::Map<const Eigen::Matrix<double, 6, 1>> se3(&poses[6 * k]);
-    cams[k]->setPose(SE3::exp(se3));
+    SE3 Tcw = SE3::exp(se3);  // KeyFrame::setPose takes a non-const reference (keyframe.h)
+    cams[k]->setPose(Tcw);
   }
   for (size_t j = 0; j < points.size(); j++) {
     points[j]->setPose(Vector3d(pts[3 * j], pts[3 * j + 1], pts[3 * j + 2]));

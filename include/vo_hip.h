@@ -360,6 +360,39 @@ int vo_pose_only_solve_dev(int n_problems, const int32_t *dev_offsets, int max_o
                            uint8_t *dev_outlier, int32_t *dev_n_inliers,
                            vo_lm_summary *dev_summaries, void *hip_stream);
 
+/* the same with explicit ranges: problem p owns observations [ranges[2p], ranges[2p] + ranges[2p+1])
+ * (frames laid out at a fixed stride by vo_track_gather_dev) */
+int vo_pose_only_solve_ranges_dev(int n_problems, const int32_t *dev_ranges, const double *dev_points,
+                                  const double *dev_obs, const double *dev_inv_sigma, const double *dev_cam5,
+                                  double *dev_poses, uint8_t *dev_outlier, int32_t *dev_n_inliers,
+                                  vo_lm_summary *dev_summaries, void *hip_stream);
+
+/* Tracking glue on the device (a tracked frame stays in HBM from the extractor to the pose):
+ *   vo_track_project_dev  projection prologue of searchByProjection(Frame*, Frame*) (matcher.cpp:41-64):
+ *       dev_Tcw [n_frames][12] = rotation row-major + translation of the current pose estimate,
+ *       dev_points [n_frames][stride][3] the last frame's map points, dev_point_flags bit 0 = point
+ *       exists and is no outlier, bit 1 = observe_cnt_ > 0; writes the mode-0 query arrays
+ *       (flags, u, v, 1/z) of vo_match_guided_dev.  xmin .. ymax are the int-truncated image bounds.
+ *   vo_track_scatter_dev  frame->mappoints_[k] = the query that claimed feature k: copies its world
+ *       point into dev_feature_points [n_frames][max_features][3], sets dev_feature_has (and
+ *       dev_feature_observed = flag bit 1, the `blocked` mask of the next search).
+ *   vo_track_gather_dev   the gather of solvePoseOnlySE3 (optimizer_ceres.cpp:181-202): features that
+ *       hold a map point, in feature order, into points / obs (x, y, uRight) / 1/sigma at
+ *       [f * max_features ...) with dev_ranges [n_frames][2] = (start, count) for
+ *       vo_pose_only_solve_ranges_dev; dev_index (or NULL) = the feature index of every observation. */
+int vo_track_project_dev(int n_frames, int n_queries, int stride, const double *dev_Tcw, const double *dev_points,
+                         const uint8_t *dev_point_flags, const float cam4[4], int xmin, int xmax, int ymin,
+                         int ymax, uint8_t *dev_q_flags, float *dev_u, float *dev_v, float *dev_invz,
+                         void *hip_stream);
+int vo_track_scatter_dev(vo_frames *h, int slot0, int n_frames, const int32_t *dev_assigned,
+                         const double *dev_query_points, const uint8_t *dev_query_flags, int stride,
+                         double *dev_feature_points, uint8_t *dev_feature_has, uint8_t *dev_feature_observed,
+                         void *hip_stream);
+int vo_track_gather_dev(vo_frames *h, int slot0, int n_frames, const double *dev_feature_points,
+                        const uint8_t *dev_feature_has, const float *scale_factors, int n_levels,
+                        double *dev_points, double *dev_obs, double *dev_inv_sigma, int32_t *dev_ranges,
+                        int32_t *dev_index, void *hip_stream);
+
 /* Optimizer::solveLoopSim3(keyframe_curr, keyframe_match, inlierMappoints, Scm, fixScaleFlag)
  * (optimizer_ceres.cpp:810-1030) with PoseOnlySim3 / PoseOnlyInverseSim3 (optimizer_ceres.h:211-267):
  * problem 1 (Huber sqrt(10), <= 10 iterations), chi2 > 10 rejection in both images, then 10 (or 5

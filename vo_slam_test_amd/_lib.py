@@ -43,6 +43,7 @@ SYMBOLS = [
     "vo_hamming_matrix_dev", "vo_hamming_matrix_batch_dev", "vo_hamming_matrix", "vo_median_descriptor",
     "vo_frames_create", "vo_frames_destroy", "vo_frames_capacity", "vo_frames_set_camera", "vo_frames_build_dev",
     "vo_frames_upload", "vo_frames_download", "vo_match_guided_dev", "vo_match_guided_status",
+    "vo_track_project_dev", "vo_track_scatter_dev", "vo_track_gather_dev", "vo_pose_only_solve_ranges_dev",
     "vo_match_frame_projection", "vo_match_local_map", "vo_match_frame_keyframe", "vo_match_bow",
     "vo_match_triangulation", "vo_match_fuse", "vo_match_area_best", "vo_match_sim3_projection",
     "vo_match_sim3_mutual", "vo_vocab_create", "vo_vocab_destroy", "vo_bow_transform",

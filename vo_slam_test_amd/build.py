@@ -23,6 +23,7 @@ SOURCES = [
     ("orb.hip", ["-ffp-contract=off"]),
     ("match.hip", ["-ffp-contract=off"]),
     ("guided.hip", ["-ffp-contract=off"]),
+    ("track.hip", ["-ffp-contract=off"]),
     ("ba.hip", ["-ffp-contract=fast"]),
     ("pose_graph.hip", ["-ffp-contract=fast"]),
 ]

@@ -307,13 +307,15 @@ __device__ __forceinline__ bool pose_chi2_outlier(const double pc[3], double ou,
   return !((e2 + eur * eur) * is2 < 7.815f);
 }
 
+// ranges != 0: problem p owns observations [offsets[2p], offsets[2p] + offsets[2p+1]) (frames at a fixed stride,
+// vo_track_gather_dev); otherwise [offsets[p], offsets[p+1]).
 __global__ __launch_bounds__(256) void k_pose_only(const int *offsets, const double *pts, const double *obs,
                                                    const double *isg, const double *cam5, double *poses,
-                                                   uint8_t *outlier, int *n_inliers, vo_lm_summary *sums) {
+                                                   uint8_t *outlier, int *n_inliers, vo_lm_summary *sums, int ranges) {
   __shared__ double lds[4 * 28];
   __shared__ int s_cnt[4];
   const int p = blockIdx.x;
-  const int o0 = offsets[p], n = offsets[p + 1] - o0;
+  const int o0 = ranges ? offsets[2 * p] : offsets[p], n = ranges ? offsets[2 * p + 1] : offsets[p + 1] - o0;
   pts += 3 * (long long)o0, obs += 3 * (long long)o0, isg += o0, outlier += o0;
   Cam K{cam5[0], cam5[1], cam5[2], cam5[3], cam5[4]};
   const float fx = (float)K.fx, fy = (float)K.fy, cx = (float)K.cx, cy = (float)K.cy, bf = (float)K.bf;
@@ -2549,7 +2551,21 @@ int vo_pose_only_solve_dev(int n_problems, const int32_t *dev_offsets, int max_o
   if (n_problems == 0) return VO_OK;
   VO_CHECK(vo::ensure_device());
   hipLaunchKernelGGL(k_pose_only, dim3(n_problems), dim3(256), 0, (hipStream_t)hip_stream, dev_offsets, dev_points,
-                     dev_obs, dev_inv_sigma, dev_cam5, dev_poses, dev_outlier, dev_n_inliers, dev_summaries);
+                     dev_obs, dev_inv_sigma, dev_cam5, dev_poses, dev_outlier, dev_n_inliers, dev_summaries, 0);
+  VO_HIP_CHECK(hipGetLastError());
+  return VO_OK;
+}
+
+int vo_pose_only_solve_ranges_dev(int n_problems, const int32_t *dev_ranges, const double *dev_points, const double *dev_obs,
+                                  const double *dev_inv_sigma, const double *dev_cam5, double *dev_poses,
+                                  uint8_t *dev_outlier, int32_t *dev_n_inliers, vo_lm_summary *dev_summaries,
+                                  void *hip_stream) {
+  if (n_problems < 0 || (n_problems > 0 && (!dev_ranges || !dev_poses || !dev_outlier || !dev_n_inliers || !dev_cam5)))
+    return VO_ERR_INVALID;
+  if (n_problems == 0) return VO_OK;
+  VO_CHECK(vo::ensure_device());
+  hipLaunchKernelGGL(k_pose_only, dim3(n_problems), dim3(256), 0, (hipStream_t)hip_stream, dev_ranges, dev_points,
+                     dev_obs, dev_inv_sigma, dev_cam5, dev_poses, dev_outlier, dev_n_inliers, dev_summaries, 1);
   VO_HIP_CHECK(hipGetLastError());
   return VO_OK;
 }

@@ -572,6 +572,15 @@ __global__ __launch_bounds__(256) void k_guided_count(Queries Q, const int *best
 // ============================================================================================
 // host side
 // ============================================================================================
+namespace vo {  // csrc/track.hip
+void track_scatter_launch(int n_frames, int cap, int stride, const int *fn, int slot0, const int *assigned,
+                          const double *qpoints, const uint8_t *qflags, double *fpoint, uint8_t *fhas, uint8_t *fobserved,
+                          hipStream_t st);
+void track_gather_launch(int n_frames, int cap, const int *fn, int slot0, const float *X, const float *Y, const float *UR,
+                         const int *OCT, const double *fpoint, const uint8_t *fhas, const float *sf, double *pts, double *obs,
+                         double *isg, int *ranges, int *index, hipStream_t st);
+}  // namespace vo
+
 struct vo_frames {
   int max_frames = 0, cap = 0;
   FramesDev D{};
@@ -579,8 +588,9 @@ struct vo_frames {
   float width = 640.f, height = 480.f;
   vo::DevBuf b_x, b_y, b_angle, b_ur, b_depth, b_oct, b_desc, b_n, b_cs, b_ci;
   // matcher scratch (grow-only)
-  vo::DevBuf b_pool, b_rank, b_qrec, b_used, b_best, b_asg, b_push, b_nm, b_err;
+  vo::DevBuf b_pool, b_rank, b_qrec, b_used, b_best, b_asg, b_push, b_nm, b_err, b_sf;
   size_t pool_stride = 0;
+  float sf_host[16] = {0};  // scale factors last uploaded for vo_track_gather_dev
 };
 
 namespace {
@@ -687,7 +697,7 @@ void vo_frames_destroy(vo_frames *h) {
   if (!h) return;
   for (vo::DevBuf *b : {&h->b_x, &h->b_y, &h->b_angle, &h->b_ur, &h->b_depth, &h->b_oct, &h->b_desc, &h->b_n, &h->b_cs,
                         &h->b_ci, &h->b_pool, &h->b_rank, &h->b_qrec, &h->b_used, &h->b_best, &h->b_asg, &h->b_push,
-                        &h->b_nm, &h->b_err})
+                        &h->b_nm, &h->b_err, &h->b_sf})
     b->release();
   delete h;
 }
@@ -802,6 +812,36 @@ int vo_match_guided_dev(vo_frames *h, int slot0, int n_frames, const vo_guided_q
   if (pool_per_frame == 0) pool_per_frame = (size_t)std::max(q->n_queries, 1) * 64;
   return guided_launch(h, slot0, n_frames, Q, c, dev_feature_mask, dev_assigned, dev_best_idx, dev_n_matches,
                        pool_per_frame, (hipStream_t)hip_stream);
+}
+
+int vo_track_scatter_dev(vo_frames *h, int slot0, int n_frames, const int32_t *dev_assigned, const double *dev_query_points,
+                         const uint8_t *dev_query_flags, int stride, double *dev_feature_points, uint8_t *dev_feature_has,
+                         uint8_t *dev_feature_observed, void *hip_stream) {
+  if (!h || slot0 < 0 || n_frames < 1 || slot0 + n_frames > h->max_frames || !dev_assigned || !dev_query_points ||
+      !dev_query_flags || stride < 1 || !dev_feature_points || !dev_feature_has)
+    return VO_ERR_INVALID;
+  vo::track_scatter_launch(n_frames, h->cap, stride, h->D.n, slot0, dev_assigned, dev_query_points, dev_query_flags,
+                           dev_feature_points, dev_feature_has, dev_feature_observed, (hipStream_t)hip_stream);
+  VO_HIP_CHECK(hipGetLastError());
+  return VO_OK;
+}
+
+int vo_track_gather_dev(vo_frames *h, int slot0, int n_frames, const double *dev_feature_points,
+                        const uint8_t *dev_feature_has, const float *scale_factors, int n_levels, double *dev_points,
+                        double *dev_obs, double *dev_inv_sigma, int32_t *dev_ranges, int32_t *dev_index, void *hip_stream) {
+  if (!h || slot0 < 0 || n_frames < 1 || slot0 + n_frames > h->max_frames || !dev_feature_points || !dev_feature_has ||
+      !scale_factors || n_levels < 1 || n_levels > 16 || !dev_points || !dev_obs || !dev_inv_sigma || !dev_ranges)
+    return VO_ERR_INVALID;
+  hipStream_t st = (hipStream_t)hip_stream;
+  if (!h->b_sf.p) VO_CHECK(h->b_sf.reserve(64));
+  if (memcmp(h->sf_host, scale_factors, (size_t)n_levels * 4) != 0) {  // uploaded when it changes (once per extractor)
+    memcpy(h->sf_host, scale_factors, (size_t)n_levels * 4);
+    VO_HIP_CHECK(hipMemcpyAsync(h->b_sf.p, h->sf_host, 64, hipMemcpyHostToDevice, st));
+  }
+  vo::track_gather_launch(n_frames, h->cap, h->D.n, slot0, h->D.x, h->D.y, h->D.uright, h->D.octave, dev_feature_points,
+                          dev_feature_has, h->b_sf.as<float>(), dev_points, dev_obs, dev_inv_sigma, dev_ranges, dev_index, st);
+  VO_HIP_CHECK(hipGetLastError());
+  return VO_OK;
 }
 
 int vo_match_guided_status(vo_frames *h, void *hip_stream) {

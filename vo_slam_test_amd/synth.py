@@ -388,3 +388,45 @@ def make_vocabulary(seed: int = 0, k: int = 10, L: int = 4, flip: int = 24):
     weight[leaves] = rng.uniform(0.5, 8.0, len(leaves))
     return dict(k=k, L=L, child_start=cs, children=np.array(children, np.int32), node_desc=np.ascontiguousarray(desc),
                 node_weight=weight, word_id=word_id)
+
+
+# --------------------------------------------------------------------------- tracked-frame map (bench / tests)
+def make_tracking_map(kx, ky, octave, angle, desc, depth_m, seed: int, n_local_rep: int = 2, cam=CAM):
+    """Synthetic map seen by ONE frame whose (distorted-free) key-points are (kx, ky): the last frame's map points =
+    the frame's own features back-projected with their depth (2.5 m where the depth image has a hole), the local
+    map = `n_local_rep` noisy copies of them; the current pose estimate is a small perturbation of the true pose
+    (identity).  Returns (Tcw12, pose6, last, local) in the layout of tracking.BatchTracker.set_map; projections of
+    the local map points are pre-computed in float32 like Frame::isInFrame leaves them (frame.cpp:145-190)."""
+    rng = _rng(0x7AC40000 + seed)
+    n = len(kx)
+    fx, fy, cx, cy, bf = [float(c) for c in cam]
+    z = np.where(depth_m > 0, depth_m, 2.5).astype(np.float64)
+    P = np.stack([(kx.astype(np.float64) - cx) * z / fx, (ky.astype(np.float64) - cy) * z / fy, z], axis=1)
+    xi = np.concatenate([rng.uniform(-0.02, 0.02, 3), rng.uniform(-0.01, 0.01, 3)])
+    R, t = se3_exp(xi)
+    Tcw12 = np.concatenate([R.reshape(-1), t])
+    flags = (1 | ((rng.random(n) < 0.7).astype(np.uint8) << 1)).astype(np.uint8)
+    flags[rng.random(n) < 0.05] = 0
+    d0 = desc.copy()
+    flip = rng.random(d0.shape) < 0.01
+    d0[flip] ^= rng.integers(1, 256, int(flip.sum()), dtype=np.uint8)
+    last = dict(points=P + rng.normal(0, 0.005, P.shape), flags=flags, octave=octave.astype(np.int32),
+                angle=angle.astype(np.float32), desc=d0)
+    idx = np.tile(np.arange(n), n_local_rep)
+    rng.shuffle(idx)
+    m = len(idx)
+    Pl = P[idx] + rng.normal(0, 0.01, (m, 3))
+    pc = Pl @ R.T + t
+    u = (fx * pc[:, 0] / pc[:, 2] + cx).astype(np.float32)
+    v = (fy * pc[:, 1] / pc[:, 2] + cy).astype(np.float32)
+    zf = pc[:, 2].astype(np.float32)
+    ur = (u - np.float32(bf) / zf).astype(np.float32)
+    lflags = np.where(rng.random(m) < 0.6, 3, 1).astype(np.uint8)
+    lflags[(u < 0) | (u > 640) | (v < 0) | (v > 480) | (rng.random(m) < 0.05)] = 0
+    dl = desc[idx].copy()
+    flip = rng.random(dl.shape) < 0.02
+    dl[flip] ^= rng.integers(1, 256, int(flip.sum()), dtype=np.uint8)
+    local = dict(points=Pl, flags=lflags, u=u, v=v, ur=ur,
+                 level=np.clip(octave[idx] + rng.integers(0, 2, m), 0, 7).astype(np.int32),
+                 viewcos=rng.uniform(0.99, 1.0, m).astype(np.float32), desc=dl)
+    return Tcw12, se3_log(R, t), last, local
