@@ -1,14 +1,16 @@
 #!/usr/bin/env python3
 """bench.py -- throughput of the MI355X hot path on synthetic inputs.
 
-One "step" = one pass of the ORB front end over a batch of B synthetic 640x480 frames that is
-already resident in HBM: 8-level pyramid, per-cell FAST + NMS, oct-tree, orientation, blur,
-steered BRIEF (vo_orb_extract_batch_dev) followed by the all-pairs 1000x1000 Hamming matrix of
-every frame against its successor (vo_hamming_matrix_batch_dev) -- BASELINE.json configs[1].
-`value` = frames/s over all ranks (weak scaling: every rank owns its own batch; no collective on
-this path).  After the timed region the same process measures local BA (configs[3], sharded over
-the ranks with two all-reduces per LM iteration) and batched pose-only BA (configs[2]) and
-reports them as extra keys of the same JSON line.
+One "step" = B synthetic 640x480 frames (already resident in HBM, with their depth images and the map they are tracked
+against) through the whole per-frame tracking path: ORB extraction (8-level pyramid, per-cell FAST + NMS, oct-tree,
+orientation, blur, steered BRIEF), frame post-processing (undistort, depth, 64x48 grid), searchByProjection against the
+last frame's map points, solvePoseOnlySE3, searchByProjection against the local map, solvePoseOnlySE3 -- what
+VisualOdometry::trackWithMotionModel + trackLocalMap do per frame (visualOdometry.cpp:228-251, 745-775).
+`value` = tracked frames/s over all ranks (weak scaling: every rank owns its own batch of independent camera streams;
+no collective on this path).  The same JSON line carries BASELINE configs[1] as written (extract + brute-force
+1000x1000 Hamming, `extract_bruteforce_match`), local BA (configs[3]: one problem sharded over the ranks with two
+all-reduces per LM iteration, and independent problems per GPU), pose-only BA (configs[2]) and the loop-closure sized
+problems (configs[4]).
 
   python bench.py --gpus 1 --steps 20 --warmup 3
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \\
@@ -57,21 +59,93 @@ def stage_bytes_per_frame(w, h, nkp, ncand):
     }
 
 
+def tracking_bytes_per_frame(nkp, n_q0, n_q1, n_obs):
+    """Algorithmic bytes of the tracking stages per frame: key-points + descriptors in and the feature store out; per
+    query its descriptor and projection plus ~12 gated candidates (feature record 16 B + descriptor 32 B) and the 4-byte
+    assignment per feature; pose-only reads 56 B per observation per evaluation."""
+    return {
+        "frame_post": nkp * (28 + 32 + 2) + nkp * (20 + 32 + 2) + 4 * 3073,
+        "match_last_frame": n_q0 * (32 + 16 + 12 * 48) + 8 * nkp,
+        "match_local_map": n_q1 * (32 + 20 + 12 * 48) + 8 * nkp,
+        "pose_only_1": n_obs * 56, "pose_only_2": n_obs * 56,
+    }
+
+
+def cpu_track_one(orc, p, sf, img, raw_depth, mp, cam5, dist_coef, inv_depth):
+    """The oracle's tracked frame (the same stages as BatchTracker.track, one frame, one thread): returns pose inliers."""
+    import ctypes as C
+    H, W = img.shape
+    k, d, _ = orc.extract(p, img)
+    n = len(k)
+    x, y = np.ascontiguousarray(k["x"]), np.ascontiguousarray(k["y"])
+    ux, uy = np.zeros(n, np.float32), np.zeros(n, np.float32)
+    orc.lib().orc_undistort_points(n, x, y, cam5[:4].copy(), dist_coef.ctypes.data, ux, uy)
+    dimg = np.zeros((H, W), np.float32)
+    orc.lib().orc_depth_to_float(np.ascontiguousarray(raw_depth).reshape(-1), H * W, inv_depth, dimg.reshape(-1))
+    ur, dep = np.zeros(n, np.float32), np.zeros(n, np.float32)
+    orc.lib().orc_find_depth(n, x, y, ux, dimg, W, H, W, float(cam5[4]), ur, dep)
+    of = orc.FrameData(ux, uy, k["octave"], k["angle"], ur, d)   # builds the 64 x 48 grid
+    T, pose6, la, lo = mp
+    P = la["points"]
+    xc = T[0] * P[:, 0] + T[1] * P[:, 1] + T[2] * P[:, 2] + T[9]
+    yc = T[3] * P[:, 0] + T[4] * P[:, 1] + T[5] * P[:, 2] + T[10]
+    zc = T[6] * P[:, 0] + T[7] * P[:, 1] + T[8] * P[:, 2] + T[11]
+    z = zc.astype(np.float32)
+    with np.errstate(divide="ignore", invalid="ignore"):
+        qz = (np.float32(1.0) / z).astype(np.float32)
+        qu = (np.float64(cam5[0]) * xc / zc + np.float64(cam5[2])).astype(np.float32)
+        qv = (np.float64(cam5[1]) * yc / zc + np.float64(cam5[3])).astype(np.float32)
+    ok = ((la["flags"] & 1) == 1) & ~(z < 0) & ~((qu < 0) | (qu > W)) & ~((qv < 0) | (qv > H))
+    qf = np.where(ok, 1 | (la["flags"] & 2), 0).astype(np.uint8)
+    nq = min(len(qf), n + 64)
+    a0 = np.full(n, -1, np.int32)
+    orc.lib().orc_match_frame_projection(C.byref(of.c), len(qf), qf, np.nan_to_num(qu), np.nan_to_num(qv), np.nan_to_num(qz),
+                                         la["octave"], la["angle"], np.ascontiguousarray(la["desc"]), 15.0, float(cam5[4]),
+                                         0, 1, 8, sf, np.zeros(n, np.uint8), a0)
+    fpt, has, fobs = np.zeros((n, 3)), a0 >= 0, np.zeros(n, np.uint8)
+    fpt[has] = P[a0[has]]
+    fobs[has] = (qf[a0[has]] >> 1) & 1
+    cam_d = cam5.astype(np.float64)
+
+    def solve(pose_in):
+        idx = np.nonzero(has)[0]
+        pr = dict(pts=np.ascontiguousarray(fpt[idx]),
+                  obs=np.ascontiguousarray(np.stack([ux[idx], uy[idx], ur[idx]], 1).astype(np.float64)),
+                  inv_sigma=np.ascontiguousarray(1.0 / sf[k["octave"][idx]].astype(np.float64)), cam=cam_d, pose0=pose_in)
+        return orc.pose_only(pr)
+
+    p1, _, _, _, _ = solve(pose6)
+    a1 = np.full(n, -1, np.int32)
+    orc.lib().orc_match_local_map(C.byref(of.c), len(lo["flags"]), lo["flags"], lo["u"], lo["v"], lo["ur"], lo["level"],
+                                  lo["viewcos"], np.ascontiguousarray(lo["desc"]), 3.0, 0.8, sf, fobs, a1)
+    new = a1 >= 0
+    fpt[new] = lo["points"][a1[new]]
+    has = has | new
+    _, _, ninl, _, _ = solve(p1)
+    return ninl, (k, d, ux, uy, dep)
+
+
 def _cpu_worker(arg):
-    """one host core: the oracle's extract + 1000x1000 Hamming on `n` synthetic frames (spawned process)"""
+    """one host core: the oracle's tracked frame on `n` synthetic frames (spawned process)"""
     seed, n = arg
     sys.path.insert(0, str(ROOT / "tests"))
     import oracle_lib as orc
     from vo_slam_test_amd import synth
     p = orc.orb_params()
+    sf = np.array(list(p.scale)[:8], np.float32)
+    cam5 = synth.CAM.astype(np.float32)
+    inv = float(np.float32(1.0) / np.float32(synth.DEPTH_SCALE))
     frames = synth.make_frames(2, start=seed * 7)
-    orc.extract(p, frames[0])                      # first touch: library load, page-in
+    depth = [synth.make_depth(seed * 7 + i) for i in range(2)]
+    maps = []
+    for i in range(2):   # first touch (library load, page-in) + the map the frames are tracked against
+        k, d, _ = orc.extract(p, frames[i])
+        dep = np.where(depth[i][np.clip(k["y"].astype(int), 0, 479), np.clip(k["x"].astype(int), 0, 639)] > 0,
+                       depth[i][np.clip(k["y"].astype(int), 0, 479), np.clip(k["x"].astype(int), 0, 639)] * inv, -1).astype(np.float32)
+        maps.append(synth.make_tracking_map(k["x"], k["y"], k["octave"], k["angle"], d, dep, seed=i))
     t0 = time.perf_counter()
-    prev = None
     for i in range(n):
-        k, d, _ = orc.extract(p, frames[i & 1])
-        orc.hamming_matrix((prev if prev is not None else d)[:1000], d[:1000])
-        prev = d
+        cpu_track_one(orc, p, sf, frames[i & 1], depth[i & 1], maps[i & 1], cam5, synth.DIST, inv)
     return time.perf_counter() - t0
 
 
@@ -84,6 +158,7 @@ def main():
                                                              "188 k frames/s at 64, 246 k at 256, 268 k at 512, 275 k at 1024, 278 k at 2048)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-ba", action="store_true")
+    ap.add_argument("--no-bruteforce", action="store_true", help="skip the extract + all-pairs Hamming measurement (configs[1] as written)")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo lets two ranks "
                     "share one GPU to exercise the N > 1 code path on a single-GPU box)")
@@ -117,38 +192,66 @@ def main():
     W, H, B = 640, 480, args.batch
     n_unique = min(B, 32)
     uniq = synth.make_frames(n_unique, start=rank * 1000)
+    uniq_depth = np.stack([synth.make_depth(rank * 1000 + i) for i in range(n_unique)])
     frames_np = np.stack([uniq[i % n_unique] for i in range(B)])
+    inv_depth = float(np.float32(1.0) / np.float32(synth.DEPTH_SCALE))
+    cam5 = synth.CAM.astype(np.float32)
     stream = torch.cuda.Stream()
     ext = vo.OrbExtractor(1000, 1.2, 8, 20, 7)
     ext.set_stream(stream.cuda_stream)
     cap = ext.max_keypoints()
     NM = 1000
+    from vo_slam_test_amd.tracking import BatchTracker
     with torch.cuda.stream(stream):
         frames = torch.from_numpy(frames_np).cuda()
-        kps = torch.zeros((B, cap, 28), dtype=torch.uint8, device="cuda")
-        desc = torch.zeros((B + 1, cap, 32), dtype=torch.uint8, device="cuda")
-        cnt = torch.zeros(B, dtype=torch.int32, device="cuda")
-        dmat = torch.zeros((B, NM, NM), dtype=torch.int16, device="cuda")
-    ham_ev = []
+        depth = torch.from_numpy(np.stack([uniq_depth[i % n_unique] for i in range(B)]).view(np.int16)).cuda()
+    # ---- the map every frame is tracked against (resident in HBM, like the frames): built once from the features of the
+    # unique frames -- last frame's map points = the frame's own features back-projected with their depth, local map = two
+    # noisy copies of them (synth.make_tracking_map); TUM fr1 distortion coefficients (example.yaml:25-29)
+    trk = BatchTracker(B, ext, cam5, synth.DIST, W, H, n_last=1100, n_local=2200, stream=stream)
+    with torch.cuda.stream(stream):
+        ext.extract_batch_dev(frames[:n_unique], trk.kps[:n_unique], trk.desc[:n_unique], trk.cnt[:n_unique])
+        trk.frames.build_dev(trk.kps[:n_unique], trk.desc[:n_unique], trk.cnt[:n_unique], depth[:n_unique], inv_depth,
+                             stream=stream.cuda_stream)
+    torch.cuda.synchronize()
+    ext.sync()
+    maps = []
+    for i in range(n_unique):
+        fr = trk.frames.download(i, stream=stream.cuda_stream)
+        maps.append(synth.make_tracking_map(fr["x"], fr["y"], fr["octave"], fr["angle"], fr["desc"], fr["depth"], seed=i))
+
+    def stack(which, key, n, tail=()):
+        o = np.zeros((B, n) + tail, maps[0][which][key].dtype)
+        for f in range(B):
+            a = maps[f % n_unique][which][key]
+            o[f, :len(a)] = a[:n]
+        return o
+
+    last = dict(points=stack(2, "points", 1100, (3,)), flags=stack(2, "flags", 1100), octave=stack(2, "octave", 1100),
+                angle=stack(2, "angle", 1100), desc=stack(2, "desc", 1100, (32,)))
+    local = {k: stack(3, k, 2200, (3,) if k == "points" else (32,) if k == "desc" else ())
+             for k in ("points", "flags", "u", "v", "ur", "level", "viewcos", "desc")}
+    with torch.cuda.stream(stream):
+        trk.set_map(np.stack([maps[f % n_unique][0] for f in range(B)]), np.stack([maps[f % n_unique][1] for f in range(B)]),
+                    last, local)
+    n_q0 = float(np.mean([(m[2]["flags"] & 1).sum() for m in maps]))
+    n_q1 = float(np.mean([(m[3]["flags"] & 1).sum() for m in maps]))
+    trk_ev = []
 
     def step(timed=False):
-        with torch.cuda.stream(stream):
-            ext.extract_batch_dev(frames, kps, desc[:B], cnt)
-            desc[B].copy_(desc[0])
-            if timed:
-                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-                e0.record(stream)
-            vo.hamming_matrix_batch_dev(desc[:B, :NM], desc[1:, :NM], dmat, stream=stream.cuda_stream)
-            if timed:
-                e1.record(stream)
-                ham_ev.append((e0, e1))
+        evs = trk.track(frames, depth, inv_depth, events=timed, keep_first=not timed)
+        if timed:
+            trk_ev.append(evs)
 
     for _ in range(args.warmup):
         step()
     barrier()
     ext.sync()
-    counts = cnt.cpu().numpy()
+    trk.frames.match_status(stream=stream.cuda_stream)
+    counts = trk.cnt.cpu().numpy()
     assert counts.min() >= NM, f"synthetic frames must yield >= {NM} key-points, got {counts.min()}"
+    ninl = trk.ninl.cpu().numpy()
+    assert ninl.min() >= 100, f"tracking must keep >= 100 pose inliers per frame, got {ninl.min()}"
     ncand = sum(len(ext.get_candidates(0, l)[0]) for l in range(8))
     ext.set_timing(True)
     barrier()
@@ -164,11 +267,17 @@ def main():
     stage_ms, ncalls = ext.get_timing()
     ext.set_timing(False)
     stage_ms = {k: v / max(ncalls, 1) for k, v in stage_ms.items()}
-    stage_ms["hamming"] = float(np.mean([a.elapsed_time(b) for a, b in ham_ev]))
+    for name in ("frame_post", "match_last_frame", "pose_only_1", "match_local_map", "pose_only_2"):
+        stage_ms[name] = float(np.mean([e[name][0].elapsed_time(e[name][1]) for e in trk_ev]))
     frames_per_s = world * B * args.steps / elapsed
+    n_match0 = float((trk.assigned0 >= 0).sum().item()) / B if trk.assigned0 is not None else 0.0
+    n_obs2 = float(trk.ranges[:, 1].double().mean().item())
 
-    sb = stage_bytes_per_frame(W, H, int(counts.mean()), ncand)
-    dom = max((k for k in stage_ms if k != "offsets"), key=lambda k: stage_ms[k])
+    nkp = int(counts.mean())
+    sb = stage_bytes_per_frame(W, H, nkp, ncand)
+    sb.update(tracking_bytes_per_frame(nkp, n_q0, n_q1, n_obs2))
+    hbm_stages = [k for k in stage_ms if k not in ("offsets", "pose_only_1", "pose_only_2")]
+    dom = max(hbm_stages, key=lambda k: stage_ms[k])
     achieved = sb[dom] * B / (stage_ms[dom] * 1e-3) / 1e9
     traffic = None
     tf = ROOT / "profiles" / "traffic.json"
@@ -180,24 +289,79 @@ def main():
     roofline = {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
                 "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
                 "bytes_per_launch": sb[dom] * B, "avg_launch_ms": round(stage_ms[dom], 4)}
-    stage_gbs = {k: round(sb[k] * B / (stage_ms[k] * 1e-3) / 1e9, 1) for k in stage_ms if stage_ms[k] > 0}
-    total_alg = sum(sb[k] for k in sb if k != "offsets")
-    e2e_gbs = total_alg * frames_per_s / world / 1e9
+    stage_gbs = {k: round(sb[k] * B / (stage_ms[k] * 1e-3) / 1e9, 1) for k in hbm_stages if stage_ms[k] > 0}
+    # pose-only stages are FP64-latency bound: report their flop rate (~270 flop per observation and iteration)
+    po_iters = 20.0
+    pose_flops = 270.0 * n_obs2 * po_iters
+    ext_keys = ("pyramid", "fast", "octree", "blur", "describe")
+    ext_ms = sum(stage_ms[k] for k in ext_keys)
+    match_ms = stage_ms["frame_post"] + stage_ms["match_last_frame"] + stage_ms["match_local_map"]
+    em_bytes = sum(sb[k] for k in ext_keys) + sb["frame_post"] + sb["match_last_frame"] + sb["match_local_map"]
+    em_gbs = em_bytes * B / ((ext_ms + match_ms) * 1e-3) / 1e9
 
     out = {
-        "metric": "tracked frames/sec + local-BA LM-iters/sec (synthetic 640x480; value = ORB extract+match frames/sec)",
+        "metric": "tracked frames/sec + local-BA LM-iters/sec (synthetic 640x480; value = tracked frames/sec: ORB extraction, "
+                  "frame post-processing, two guided searches and two pose-only solves per frame)",
         "value": round(frames_per_s, 1), "unit": "frames/s", "n_gpus": world, "steps": args.steps,
         "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True,
         "scaling": "weak", "vs_baseline": None, "dtype": "u8", "data": "synthetic",
-        "config": {"workload": "ORB extract+match: 640x480, 8-level pyramid, 1000 kpts/frame, all-pairs "
-                               "1000x1000 Hamming vs next frame; frames resident in HBM",
+        "config": {"workload": "tracked frame: ORB extract (640x480, 8-level pyramid, 1000 kpts) + undistort/depth/grid + "
+                               "searchByProjection vs last frame + solvePoseOnlySE3 + searchByProjection vs local map + "
+                               "solvePoseOnlySE3; frames, depth and map resident in HBM",
                    "frames_per_gpu_per_step": B, "keypoints_per_frame": float(counts.mean()),
-                   "fast_candidates_per_frame": ncand, "parallelism": f"frames sharded x{world}, no collective"},
+                   "fast_candidates_per_frame": ncand, "last_frame_queries": round(n_q0, 1), "local_map_queries": round(n_q1, 1),
+                   "matches_last_frame": round(n_match0, 1), "pose_observations": round(n_obs2, 1),
+                   "pose_inliers": float(ninl.mean()), "parallelism": f"frames sharded x{world}, no collective"},
         "roofline": roofline,
         "stage_ms_per_launch": {k: round(v, 4) for k, v in stage_ms.items()},
         "stage_algorithmic_GBps": stage_gbs,
-        "end_to_end_algorithmic_GBps_per_gpu": round(e2e_gbs, 1),
+        "extract_match_algorithmic_GBps_per_gpu": round(em_gbs, 1),
+        "extract_match_frac_of_hbm_peak": round(em_gbs / HBM_PEAK_GBS, 4),
+        "pose_only_in_path": {"ms_per_launch": round(stage_ms["pose_only_1"] + stage_ms["pose_only_2"], 4),
+                              "fp64_GFLOPs": round(2 * pose_flops * B / ((stage_ms["pose_only_1"] + stage_ms["pose_only_2"]) * 1e-3) / 1e9, 1),
+                              "bound": "fp64 latency (one workgroup per frame, <= 20 dependent LM iterations)"},
     }
+
+    # ---- BASELINE config 1 as written: extract + brute-force 1000 x 1000 Hamming against the next frame (SURVEY 8d bytes)
+    if not args.no_bruteforce:
+        with torch.cuda.stream(stream):
+            bdesc = torch.zeros((B + 1, cap, 32), dtype=torch.uint8, device="cuda")
+            dmat = torch.zeros((B, NM, NM), dtype=torch.int16, device="cuda")
+        ham_ev = []
+
+        def bf_step():
+            with torch.cuda.stream(stream):
+                ext.extract_batch_dev(frames, trk.kps, bdesc[:B], trk.cnt)
+                bdesc[B].copy_(bdesc[0])
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record(stream)
+                vo.hamming_matrix_batch_dev(bdesc[:B, :NM], bdesc[1:, :NM], dmat, stream=stream.cuda_stream)
+                e1.record(stream)
+                ham_ev.append((e0, e1))
+
+        bf_step()
+        torch.cuda.synchronize()
+        ham_ev.clear()
+        ext.set_timing(True)
+        tb0 = time.perf_counter()
+        nbf = max(3, args.steps // 2)
+        for _ in range(nbf):
+            bf_step()
+        torch.cuda.synchronize()
+        tbf = time.perf_counter() - tb0
+        bms, bn = ext.get_timing()
+        ext.set_timing(False)
+        bms = {k: v / max(bn, 1) for k, v in bms.items()}
+        bms["hamming"] = float(np.mean([a.elapsed_time(b) for a, b in ham_ev]))
+        sb8 = 5123128 + 2064000  # B_ext + B_match per frame
+        out["extract_bruteforce_match"] = {
+            "workload": "BASELINE configs[1]: extract + all-pairs 1000x1000 Hamming vs next frame (u16 matrix written)",
+            "frames_per_s": round(B * nbf / tbf, 1), "ms_per_step": round(tbf / nbf * 1e3, 4),
+            "stage_ms_per_launch": {k: round(v, 4) for k, v in bms.items() if k != "offsets"},
+            "survey_8d_bytes_per_frame": sb8,
+            "end_to_end_algorithmic_GBps_per_gpu": round(sb8 * B * nbf / tbf / 1e9, 1),
+            "frac_of_hbm_peak": round(sb8 * B * nbf / tbf / 1e9 / HBM_PEAK_GBS, 4)}
+        del dmat, bdesc
 
     # ------------------------------------------------------------------ BA (configs 2 and 3)
     if not args.no_ba:
@@ -333,20 +497,19 @@ def main():
         sys.path.insert(0, str(ROOT / "tests"))
         import oracle_lib as orc
         p = orc.orb_params()
+        sfo = np.array(list(p.scale)[:8], np.float32)
+        cpu_track_one(orc, p, sfo, uniq[0], uniq_depth[0], maps[0], cam5, synth.DIST, inv_depth)   # first touch
         tc0 = time.perf_counter()
-        nfr = 0
-        prev = None
+        nfr, cpu_inl = 0, 0
         while time.perf_counter() - tc0 < args.cpu_seconds * 0.6 and nfr < 400:
-            k, d, _ = orc.extract(p, uniq[nfr % n_unique])
-            if prev is not None:
-                orc.hamming_matrix(prev[:NM], d[:NM])
-            else:
-                orc.hamming_matrix(d[:NM], d[:NM])
-            prev = d
+            ni, _ = cpu_track_one(orc, p, sfo, uniq[nfr % n_unique], uniq_depth[nfr % n_unique], maps[nfr % n_unique], cam5,
+                                  synth.DIST, inv_depth)
+            cpu_inl += ni
             nfr += 1
         tc = time.perf_counter() - tc0
         cpu = {"value": round(nfr / tc, 2), "unit": "frames/s", "cores": 1, "kind": "port",
-               "sample": f"{nfr} frames of the same synthetic workload (extract + 1000x1000 Hamming), "
+               "sample": f"{nfr} tracked frames of the same synthetic workload (extract, undistort/depth/grid, two guided "
+                         f"searches, two pose-only solves; {cpu_inl / max(nfr, 1):.0f} pose inliers per frame), "
                          f"{tc:.1f} s, oracle/ C restatement, gcc -O3 -ffp-contract=off, 1 thread"}
         if not args.no_ba:
             tl0 = time.perf_counter()

@@ -193,8 +193,9 @@ int vo_frames_download(vo_frames *h, int slot, int *n, float *x, float *y, int32
  * Modes 0, 1, 2, 5 claim features: dev_assigned [n_frames][max_features] in/out (query index per
  * feature or -1; mode 5 starts from -1), dev_feature_mask [n_frames][max_features] or NULL =
  * blocked / holds-a-map-point / occupied on entry.  Modes 3, 4: dev_best_idx [n_frames][stride].
- * dev_n_matches [n_frames].  pool_per_frame: candidate records per frame (0 = 64 per query);
- * vo_match_guided_status reports an overflow after the stream has been synchronised. */
+ * dev_n_matches [n_frames].  Every query owns 32 candidate records; pool_per_frame sizes the per-frame
+ * overflow area that windows with more gated candidates spill into (0 = 16 per query);
+ * vo_match_guided_status reports an exhausted overflow area after the stream has been synchronised. */
 typedef struct {
   int32_t n_queries;          /* queries per frame (upper bound when n_per_frame is given) */
   int32_t stride;             /* distance between the query blocks of consecutive frames (>= n_queries) */

@@ -223,7 +223,8 @@ def test_guided_pool_overflow_is_reported(vo, orc):
     dq = _to_dev([q], n0, ("flags", "u", "v", "aux", "level", "angle", "desc"))
     assigned = torch.full((1, 2048), -1, dtype=torch.int32, device="cuda")
     nm = torch.zeros(1, dtype=torch.int32, device="cuda")
-    fr.match_dev(1, dq, vo.Frames.MODE_FRAME, sf, radius=15.0, bf=40.0, assigned=assigned, n_matches=nm, pool_per_frame=64)
+    # radius 200: every window holds hundreds of gated candidates, far beyond the 32 records a query owns
+    fr.match_dev(1, dq, vo.Frames.MODE_FRAME, sf, radius=200.0, bf=1e-3, assigned=assigned, n_matches=nm, pool_per_frame=64)
     torch.cuda.synchronize()
     with pytest.raises(vo.VoError):
         fr.match_status()
@@ -248,3 +249,32 @@ def test_median_descriptor_one_launch(vo, orc):
     assert vo.Matcher.computeDistance(a, b) == orc.lib().orc_hamming256(a, b)
     with pytest.raises(vo.VoError):
         vo.median_descriptor([np.zeros((1025, 32), np.uint8)])
+
+
+def test_guided_dense_windows_use_the_overflow_area(vo, orc):
+    """windows with far more than 32 gated candidates (radius 60 px at every level): records spill into the overflow
+    area and the result still equals the sequential oracle"""
+    import torch
+    sf = _sf(orc)
+    k0, d0, k1, d1, dx, dy = _pair(orc, 51)
+    ur1 = np.full(len(k1), -1.0, np.float32)
+    fr = vo.Frames(1, 2048, synth.CAM.astype(np.float32))
+    fr.upload(0, vo.FrameArrays(k1["x"], k1["y"], k1["octave"], k1["angle"], ur1, d1))
+    n0 = len(k0)
+    rng = np.random.default_rng(9)
+    q = dict(flags=np.where(rng.random(n0) < 0.5, 3, 1).astype(np.uint8), u=(k0["x"] + dx).astype(np.float32),
+             v=(k0["y"] + dy).astype(np.float32), aux=np.full(n0, 0.5, np.float32), level=k0["octave"].astype(np.int32),
+             angle=k0["angle"].astype(np.float32), desc=np.ascontiguousarray(d0))
+    dq = _to_dev([q], n0, ("flags", "u", "v", "aux", "level", "angle", "desc"))
+    assigned = torch.full((1, 2048), -1, dtype=torch.int32, device="cuda")
+    nm = torch.zeros(1, dtype=torch.int32, device="cuda")
+    fr.match_dev(1, dq, vo.Frames.MODE_FRAME, sf, radius=60.0, bf=40.0, direction=2, check_rot=1, assigned=assigned,
+                 n_matches=nm, pool_per_frame=n0 * 600)
+    torch.cuda.synchronize()
+    fr.match_status()
+    of = orc.FrameData(k1["x"], k1["y"], k1["octave"], k1["angle"], ur1, d1)
+    oa = np.full(len(k1), -1, np.int32)
+    on = orc.lib().orc_match_frame_projection(C.byref(of.c), n0, q["flags"], q["u"], q["v"], q["aux"], q["level"], q["angle"],
+                                              q["desc"], 60.0, 40.0, 2, 1, 8, sf, np.zeros(len(k1), np.uint8), oa)
+    assert int(nm.item()) == on and np.array_equal(assigned.cpu().numpy()[0, :len(k1)], oa)
+    fr.close()

@@ -3,7 +3,7 @@
 cd /tmp && export TMPDIR=/tmp
 R=${GRAFT_REPO_ROOT:-/root/repo}
 d=$R/gpurun_out/ktrace; rm -rf $d; mkdir -p $d
-rocprofv3 --kernel-trace -d $d --output-format csv -- python3 $R/bench.py --steps 3 --warmup 1 --no-ba --no-cpu-baseline > $d/log.txt 2>&1
+rocprofv3 --kernel-trace -d $d --output-format csv -- python3 $R/bench.py --steps 3 --warmup 1 --no-ba --no-cpu-baseline --no-bruteforce "$@" > $d/log.txt 2>&1
 python3 - <<PY
 import csv, glob, collections
 f = glob.glob("$d/**/*kernel_trace.csv", recursive=True)[0]

@@ -35,10 +35,27 @@ using namespace vo::ba;
 // ============================================================================================
 // block reductions (fixed order => deterministic)
 // ============================================================================================
+// 64-lane sum, same value in every lane.  The four in-row steps are DPP moves of the two 32-bit halves (no LDS
+// crossbar, a fraction of a ds_bpermute's latency); the cross-row steps use v_readlane of the row sums.  Fixed order.
+template <int CTRL>
+__device__ __forceinline__ double dpp_f64(double v) {
+  const unsigned long long u = __double_as_longlong(v);
+  const unsigned lo = (unsigned)__builtin_amdgcn_update_dpp(0, (int)(unsigned)u, CTRL, 0xf, 0xf, false);
+  const unsigned hi = (unsigned)__builtin_amdgcn_update_dpp(0, (int)(unsigned)(u >> 32), CTRL, 0xf, 0xf, false);
+  return __longlong_as_double(((unsigned long long)hi << 32) | lo);
+}
+__device__ __forceinline__ double readlane_f64(double v, int l) {
+  const unsigned long long u = __double_as_longlong(v);
+  const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)u, l);
+  const unsigned hi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(u >> 32), l);
+  return __longlong_as_double(((unsigned long long)hi << 32) | lo);
+}
 __device__ __forceinline__ double wave_sum(double v) {
-#pragma unroll
-  for (int o = 32; o >= 1; o >>= 1) v += __shfl_xor(v, o);
-  return v;
+  v += dpp_f64<0xB1>(v);   // quad_perm [1,0,3,2]
+  v += dpp_f64<0x4E>(v);   // quad_perm [2,3,0,1]
+  v += dpp_f64<0x141>(v);  // row_half_mirror
+  v += dpp_f64<0x140>(v);  // row_mirror: every lane holds its row's sum
+  return (readlane_f64(v, 0) + readlane_f64(v, 16)) + (readlane_f64(v, 32) + readlane_f64(v, 48));
 }
 __device__ __forceinline__ double wave_max(double v) {
 #pragma unroll
@@ -315,6 +332,7 @@ __global__ __launch_bounds__(256) void k_pose_only(const int *offsets, const dou
   __shared__ double lds[4 * 28];
   __shared__ int s_cnt[4];
   const int p = blockIdx.x;
+  if (threadIdx.x < 4) s_cnt[threadIdx.x] = 0;  // (workgroups of one wavefront leave three of the four slots unused)
   const int o0 = ranges ? offsets[2 * p] : offsets[p], n = ranges ? offsets[2 * p + 1] : offsets[p + 1] - o0;
   pts += 3 * (long long)o0, obs += 3 * (long long)o0, isg += o0, outlier += o0;
   Cam K{cam5[0], cam5[1], cam5[2], cam5[3], cam5[4]};
@@ -2541,6 +2559,19 @@ int current_index(vo_ba *h, int *cur) {
 
 extern "C" {
 
+// The kernel is a chain of ~20 dependent LM iterations whose fixed part (6 x 6 solve, exp / log, reductions) every
+// wavefront of a workgroup repeats, and it needs all 256 registers (one wavefront per SIMD).  A single frame is
+// fastest with four wavefronts sharing its observations; a batch is fastest with ONE wavefront per frame, so that a
+// CU works on four frames at once instead of four times on one (1024 frames x 1000 observations: 1.45 -> see DESIGN).
+static inline int pose_block_width(int n_problems) {
+  static const int forced = [] {
+    const char *e = getenv("VO_POSE_BLOCK");
+    return e ? atoi(e) : 0;
+  }();
+  if (forced == 64 || forced == 128 || forced == 256) return forced;
+  return n_problems >= 512 ? 64 : 256;
+}
+
 int vo_pose_only_solve_dev(int n_problems, const int32_t *dev_offsets, int max_obs, const double *dev_points,
                            const double *dev_obs, const double *dev_inv_sigma, const double *dev_cam5,
                            double *dev_poses, uint8_t *dev_outlier, int32_t *dev_n_inliers,
@@ -2550,7 +2581,7 @@ int vo_pose_only_solve_dev(int n_problems, const int32_t *dev_offsets, int max_o
     return VO_ERR_INVALID;
   if (n_problems == 0) return VO_OK;
   VO_CHECK(vo::ensure_device());
-  hipLaunchKernelGGL(k_pose_only, dim3(n_problems), dim3(256), 0, (hipStream_t)hip_stream, dev_offsets, dev_points,
+  hipLaunchKernelGGL(k_pose_only, dim3(n_problems), dim3(pose_block_width(n_problems)), 0, (hipStream_t)hip_stream, dev_offsets, dev_points,
                      dev_obs, dev_inv_sigma, dev_cam5, dev_poses, dev_outlier, dev_n_inliers, dev_summaries, 0);
   VO_HIP_CHECK(hipGetLastError());
   return VO_OK;
@@ -2564,7 +2595,7 @@ int vo_pose_only_solve_ranges_dev(int n_problems, const int32_t *dev_ranges, con
     return VO_ERR_INVALID;
   if (n_problems == 0) return VO_OK;
   VO_CHECK(vo::ensure_device());
-  hipLaunchKernelGGL(k_pose_only, dim3(n_problems), dim3(256), 0, (hipStream_t)hip_stream, dev_ranges, dev_points,
+  hipLaunchKernelGGL(k_pose_only, dim3(n_problems), dim3(pose_block_width(n_problems)), 0, (hipStream_t)hip_stream, dev_ranges, dev_points,
                      dev_obs, dev_inv_sigma, dev_cam5, dev_poses, dev_outlier, dev_n_inliers, dev_summaries, 1);
   VO_HIP_CHECK(hipGetLastError());
   return VO_OK;

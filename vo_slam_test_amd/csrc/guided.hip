@@ -57,6 +57,10 @@ struct FramesDev {
   int *n;              // [frames]
   int *cell_start;     // [frames][kCells + 1]
   unsigned short *cell_items;  // [frames][cap]
+  // the same features in CELL ORDER (the order of cell_items): the window of a query is a handful of contiguous runs
+  // of these arrays, so the matcher reads its candidates with coalesced loads and one round trip
+  uint4 *srec;         // [frames][cap]  x, y, uRight (float bits), octave | index << 8
+  uint4 *sdesc;        // [frames][cap][2]
   float xmin, ymin, gw, gh;
 };
 
@@ -184,6 +188,18 @@ __global__ __launch_bounds__(256) void k_frame_grid(FramesDev F, int slot0) {
       items[b + 1] = v;
     }
   }
+  __syncthreads();
+  __threadfence_block();
+  // cell-ordered copies for the matcher
+  const int total = start[kCells];
+  const long long fo = (long long)s * F.cap;
+  for (int t = tid; t < total; t += 256) {
+    const int i = items[t];
+    F.srec[fo + t] = make_uint4(__float_as_uint(X[i]), __float_as_uint(Y[i]), __float_as_uint(F.uright[fo + i]),
+                                (unsigned)(F.octave[fo + i] & 0xff) | ((unsigned)i << 8));
+    const uint4 *d = reinterpret_cast<const uint4 *>(F.desc + (fo + i) * 32);
+    F.sdesc[2 * (fo + t)] = d[0], F.sdesc[2 * (fo + t) + 1] = d[1];
+  }
 }
 
 // ------------------------------------------------------------------------------------------
@@ -206,52 +222,60 @@ struct GuidedParams {
   float sf[16];
 };
 
+constexpr int kSlot = 32;  // candidate records every query owns in the pool; the (rare) rest goes to the overflow area
+
 struct GuidedOut {
-  unsigned *pool;           // [frames][pool_stride] candidate records: idx | dist << 16 | octave << 25
-  unsigned short *rank;     // [frames][pool_stride] position in the raw window list (Sim3 search only)
-  uint2 *qrec;              // [frames][stride] (offset, count) of every query's records
-  int *pool_used;           // [frames]
-  int pool_stride;
+  unsigned *pool;           // [frames][stride][kSlot] candidate records: idx | dist << 14 | octave << 23 | rot bin << 27
+  unsigned short *rank;     // same shape: position in the raw window list (Sim3 search only)
+  unsigned *ovf;            // [frames][ovf_stride] records beyond a query's slot
+  unsigned short *ovf_rank;
+  uint2 *qrec;              // [frames][stride] (count | observed << 31, overflow offset) of every query
+  int *ovf_used;            // [frames]
+  int ovf_stride;
   int *best_idx;            // [frames][stride]   (fuse / area searches)
   int *assigned;            // [frames][cap]      (claiming searches), in/out
   const uint8_t *fmask;     // [frames][cap] or NULL: blocked / has-map-point / occupied on entry
   unsigned *pushes;         // [frames][stride] rotation-histogram entries idx | bin << 16
   int *n_matches;           // [frames]
-  int *err;                 // 1: candidate pool overflow
+  int *err;                 // 1: overflow area exhausted
 };
 
-__device__ __forceinline__ unsigned wave_min_u32(unsigned x) {  // minimum over the 64 lanes, uniform
+__device__ __forceinline__ unsigned row_min_u32(unsigned x) {  // minimum over the 16 lanes of a DPP row, in every lane
   x = min(x, (unsigned)__builtin_amdgcn_update_dpp((int)x, (int)x, 0xB1, 0xf, 0xf, false));
   x = min(x, (unsigned)__builtin_amdgcn_update_dpp((int)x, (int)x, 0x4E, 0xf, 0xf, false));
   x = min(x, (unsigned)__builtin_amdgcn_update_dpp((int)x, (int)x, 0x141, 0xf, 0xf, false));
   x = min(x, (unsigned)__builtin_amdgcn_update_dpp((int)x, (int)x, 0x140, 0xf, 0xf, false));
+  return x;
+}
+__device__ __forceinline__ unsigned wave_min_u32(unsigned x) {  // minimum over the 64 lanes, uniform
+  x = row_min_u32(x);
   return min(min((unsigned)__builtin_amdgcn_readlane((int)x, 0), (unsigned)__builtin_amdgcn_readlane((int)x, 16)),
              min((unsigned)__builtin_amdgcn_readlane((int)x, 32), (unsigned)__builtin_amdgcn_readlane((int)x, 48)));
 }
-__device__ __forceinline__ int lane_rank(unsigned long long mask) {  // set bits of `mask` below this lane
-  return (int)__builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0u));
-}
 
-// One wavefront per (query, frame); four queries per workgroup, no workgroup barrier.
+// SIXTEEN LANES per (query, frame): a window holds a dozen items on average, so a 64-lane wavefront per query
+// would idle three quarters of its lanes and -- the kernel is a chain of dependent memory round trips -- need four
+// times the wavefronts.  Sixteen queries per workgroup, no workgroup barrier.  Round trips per query: its fields
+// -> the (start, end) of its grid columns -> the cell-ordered feature records and descriptors (coalesced: the
+// window cells of one grid column are one contiguous run) -> the records out.
 __global__ __launch_bounds__(256) void k_guided_cand(FramesDev F, Queries Q, GuidedParams P, GuidedOut O, int slot0) {
-  __shared__ int s_pre[4][64], s_base[4][64];
-  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
-  const int f = blockIdx.y, q = blockIdx.x * 4 + wave;
+  constexpr int kMaxCol = 64;
+  __shared__ int s_pre[16][kMaxCol], s_base[16][kMaxCol];
+  const int lane = threadIdx.x & 63, l16 = threadIdx.x & 15, grp = threadIdx.x >> 4, sub = lane >> 4;
+  const int f = blockIdx.y, q = blockIdx.x * 16 + grp;
   const int nq = Q.nq ? Q.nq[f] : Q.nq_all;
-  if (q >= nq) return;
-  const long long qo = (long long)f * Q.stride + q;
+  const bool live = q < nq;  // (groups past the end idle through the loops: the wave's ballots need every lane)
+  const long long qo = (long long)f * Q.stride + (live ? q : 0);
   const int s = slot0 + f;
   const bool claims = P.mode == kModeFrame || P.mode == kModeLocalMap || P.mode == kModeKeyFrame || P.mode == kModeSim3;
-  auto finish_empty = [&]() {
-    if (lane == 0) {
-      if (claims) O.qrec[qo] = make_uint2(0u, 0u);
-      else O.best_idx[qo] = -1;
-    }
-  };
-  const unsigned flags = Q.flags[qo];
-  if (!(flags & 1u)) return finish_empty();
+  const unsigned flags = live ? Q.flags[qo] : 0u;
+  const bool valid = (flags & 1u) != 0;
   const float u = Q.u[qo], v = Q.v[qo];
-  const int lv = Q.level[qo];
+  const int lv = min(max(Q.level[qo], 0), 15);
+  const float aux = Q.aux ? Q.aux[qo] : 0.f;
+  const float q_angle = (P.check_rot && Q.angle) ? Q.angle[qo] : 0.f;
+  const uint4 *qd4 = reinterpret_cast<const uint4 *>(Q.desc + qo * 32);
+  const uint4 qa = qd4[0], qb = qd4[1];
   // search radius and level range of the routine
   float rs;
   int lmin, lmax;
@@ -261,7 +285,7 @@ __global__ __launch_bounds__(256) void k_guided_cand(FramesDev F, Queries Q, Gui
     else if (P.direction == 2) lmin = 0, lmax = lv;           // :72-73
     else lmin = lv - 1, lmax = lv + 1;                        // :74-75
   } else if (P.mode == kModeLocalMap) {
-    float r = Q.viewcos[qo] > 0.998 ? 2.5f : 4.0f;            // :288-291 (float vs double literal compare)
+    float r = (Q.viewcos ? Q.viewcos[qo] : 1.f) > 0.998 ? 2.5f : 4.0f;  // :288-291 (float vs double literal compare)
     r *= P.radius;
     rs = r * P.sf[lv];
     lmin = lv - 1, lmax = lv;
@@ -277,48 +301,49 @@ __global__ __launch_bounds__(256) void k_guided_cand(FramesDev F, Queries Q, Gui
   const int x1 = min(kGridCols - 1, (int)floorf((u - F.xmin + rs) * F.gw));
   const int y0 = max(0, (int)floorf((v - F.ymin - rs) * F.gh));
   const int y1 = min(kGridRows - 1, (int)floorf((v - F.ymin + rs) * F.gh));
-  if (x0 >= kGridCols || x1 < 0 || y0 >= kGridRows || y1 < 0 || x1 < x0 || y1 < y0) return finish_empty();
+  const bool window = valid && !(x0 >= kGridCols || x1 < 0 || y0 >= kGridRows || y1 < 0 || x1 < x0 || y1 < y0);
   const int *start = F.cell_start + (long long)s * (kCells + 1);
-  const unsigned short *items = F.cell_items + (long long)s * F.cap;
   const long long fo = (long long)s * F.cap, mo = (long long)f * F.cap;  // frame-store slot / this call's frame
-  // lane c = grid column x0 + c: its window cells y0..y1 are one contiguous run of the CSR
-  int cbeg = 0, ccnt = 0;
-  if (x0 + lane <= x1) {
-    cbeg = start[(x0 + lane) * kGridRows + y0];
-    ccnt = start[(x0 + lane) * kGridRows + y1 + 1] - cbeg;
-  }
-  int incl = ccnt;
+  // grid column x0 + c: its window cells y0..y1 are one contiguous run of the cell-ordered arrays
+  const int ncol = window ? x1 - x0 + 1 : 0;
+  int T = 0;
+  for (int cb = 0; cb < kMaxCol; cb += 16) {
+    const int c = cb + l16;
+    int cbeg = 0, ccnt = 0;
+    if (c < ncol) {
+      cbeg = start[(x0 + c) * kGridRows + y0];
+      ccnt = start[(x0 + c) * kGridRows + y1 + 1] - cbeg;
+    }
+    int incl = ccnt;
 #pragma unroll
-  for (int o = 1; o < 64; o <<= 1) {
-    const int t = __shfl_up(incl, o);
-    if (lane >= o) incl += t;
+    for (int o = 1; o < 16; o <<= 1) {
+      const int t = __shfl_up(incl, o, 16);
+      if (l16 >= o) incl += t;
+    }
+    s_pre[grp][c] = T + incl - ccnt;
+    s_base[grp][c] = cbeg;
+    T += __shfl(incl, 15, 16);
+    if (__builtin_amdgcn_ballot_w64(cb + 16 < ncol) == 0ull) break;  // no group of the wave has more columns
   }
-  const int T = __builtin_amdgcn_readlane(incl, 63);
-  if (T == 0) return finish_empty();
-  s_pre[wave][lane] = incl - ccnt;
-  s_base[wave][lane] = cbeg;
   __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
   __builtin_amdgcn_wave_barrier();
-  const int ncol = x1 - x0 + 1;
-  // query descriptor: uniform address
-  const uint4 *qd4 = reinterpret_cast<const uint4 *>(Q.desc + qo * 32);
-  const uint4 qa = qd4[0], qb = qd4[1];
-  const float aux = Q.aux ? Q.aux[qo] : 0.f;
   const float ur_q = P.mode == kModeFrame ? u - P.bf * aux : aux;  // :92 / trackProj_uR_
+  const float pdf = HISTO_LENGTH / 360.0f;
 
-  // evaluate item t of the window: returns pass, fills idx / dist / octave / rawpos
-  struct Item { bool inraw, pass; int idx, dist, oct; };
-  auto eval = [&](int t, bool want_dist) {
-    Item it{false, false, 0, 256, 0};
+  struct Item { bool inraw, pass; int idx, dist, oct, bin; };
+  auto eval = [&](int t) {
+    Item it{false, false, 0, 511, 0, 0};
     if (t >= T) return it;
     int lo = 0, hi = ncol - 1;  // last column whose prefix is <= t
     while (lo < hi) {
       const int mid = (lo + hi + 1) >> 1;
-      if (s_pre[wave][mid] <= t) lo = mid; else hi = mid - 1;
+      if (s_pre[grp][mid] <= t) lo = mid; else hi = mid - 1;
     }
-    const int idx = items[s_base[wave][lo] + (t - s_pre[wave][lo])];
-    const float fx = F.x[fo + idx], fy = F.y[fo + idx];
-    const int oct = F.octave[fo + idx];
+    const long long pos = fo + s_base[grp][lo] + (t - s_pre[grp][lo]);
+    const uint4 r = F.srec[pos];
+    const uint4 da = F.sdesc[2 * pos], db = F.sdesc[2 * pos + 1];
+    const float fx = __uint_as_float(r.x), fy = __uint_as_float(r.y), fur = __uint_as_float(r.z);
+    const int oct = (int)(r.w & 0xffu), idx = (int)(r.w >> 8);
     it.idx = idx, it.oct = oct;
     if (oct < lmin || oct > lmax) return it;
     if (!(fabsf(fx - u) < rs && fabsf(fy - v) < rs)) return it;  // frame.cpp:238-241
@@ -326,7 +351,6 @@ __global__ __launch_bounds__(256) void k_guided_cand(FramesDev F, Queries Q, Gui
     bool ok = true;
     if (P.mode == kModeFrame || P.mode == kModeLocalMap) {
       if (O.fmask && O.fmask[mo + idx]) ok = false;  // already blocked on entry: stays blocked (:87, :314)
-      const float fur = F.uright[fo + idx];
       if (fur > 0 && fabsf(ur_q - fur) > rs) ok = false;  // :90-96, :317-322
     } else if (P.mode == kModeKeyFrame) {
       if (O.fmask && O.fmask[mo + idx]) ok = false;  // :218
@@ -334,8 +358,7 @@ __global__ __launch_bounds__(256) void k_guided_cand(FramesDev F, Queries Q, Gui
       if (oct < lv - 1 || oct > lv) ok = false;  // :1077, :769, :425
       if (P.mode == kModeFuse && ok) {  // chi2 gates :1084-1099
         const float ex = u - fx, ey = v - fy;
-        const float is = 1.0f / P.sf[oct];
-        const float fur = F.uright[fo + idx];
+        const float is = 1.0f / P.sf[min(oct, 15)];
         if (fur >= 0) {
           const float er = aux - fur;
           const float e2 = ex * ex + ey * ey + er * er;
@@ -347,66 +370,87 @@ __global__ __launch_bounds__(256) void k_guided_cand(FramesDev F, Queries Q, Gui
       }
     }
     it.pass = ok;
-    if (ok && want_dist) {
-      const uint4 *fd = reinterpret_cast<const uint4 *>(F.desc + (fo + idx) * 32);
-      const uint4 a = fd[0], b = fd[1];
-      it.dist = __popc(a.x ^ qa.x) + __popc(a.y ^ qa.y) + __popc(a.z ^ qa.z) + __popc(a.w ^ qa.w) + __popc(b.x ^ qb.x) +
-                __popc(b.y ^ qb.y) + __popc(b.z ^ qb.z) + __popc(b.w ^ qb.w);
+    it.dist = __popc(da.x ^ qa.x) + __popc(da.y ^ qa.y) + __popc(da.z ^ qa.z) + __popc(da.w ^ qa.w) + __popc(db.x ^ qb.x) +
+              __popc(db.y ^ qb.y) + __popc(db.z ^ qb.z) + __popc(db.w ^ qb.w);
+    if (ok && P.check_rot && (P.mode == kModeFrame || P.mode == kModeKeyFrame)) {  // the bin this pair would vote for (:115-125)
+      float rot = q_angle - F.angle[fo + idx];
+      if (rot < 0) rot += 360.0f;
+      int bin = (int)rintf(rot * pdf);
+      if (bin == HISTO_LENGTH) bin = 0;
+      it.bin = min(max(bin, 0), 31);
     }
     return it;
   };
+  const int Tmax = (int)(~wave_min_u32(~(unsigned)T));  // max over the wave (uniform trip count)
 
   if (!claims) {  // independent queries: arg-min in candidate order, strict < keeps the first minimum
-    unsigned best = 0xffffffffu;
-    int best_idx = -1;
-    for (int base = 0; base < T; base += 64) {
-      const Item it = eval(base + lane, true);
-      const unsigned key = it.pass ? ((unsigned)it.dist << 20) | (unsigned)(base + lane) : 0xffffffffu;
-      const unsigned m = wave_min_u32(key);
-      if (m < best) {
-        best = m;
-        const int src = (int)(m & 0xfffffu) - base;
-        best_idx = __builtin_amdgcn_readlane(it.idx, src);
-      }
+    unsigned best = 0xffffffffu, best_idx = 0;
+    for (int base = 0; base < Tmax; base += 16) {
+      const Item it = eval(base + l16);
+      const unsigned key = it.pass ? ((unsigned)it.dist << 14) | (unsigned)(base + l16) : 0xffffffffu;  // T <= 16384
+      const unsigned m = row_min_u32(key);
+      const unsigned widx = row_min_u32(key == m ? (unsigned)it.idx : 0xffffffffu);  // the winner's feature index
+      if (m < best) best = m, best_idx = widx;
     }
     const int limit = P.mode == kModeFuse ? TH_LOW : P.max_dist;
-    if (lane == 0) O.best_idx[qo] = (best != 0xffffffffu && (int)(best >> 20) <= limit) ? best_idx : -1;
+    if (live && l16 == 0) O.best_idx[qo] = (best != 0xffffffffu && (int)(best >> 14) <= limit) ? (int)best_idx : -1;
     return;
   }
 
-  // claiming searches: records of the gated candidates, in order, into the frame's pool
-  Item first = eval(lane, true);
-  int npass = __popcll(__builtin_amdgcn_ballot_w64(first.pass));
-  for (int base = 64; base < T; base += 64) npass += __popcll(__builtin_amdgcn_ballot_w64(eval(base + lane, false).pass));
-  if (npass == 0) return finish_empty();
-  int off = 0;
-  if (lane == 0) off = atomicAdd(&O.pool_used[f], npass);
-  off = __builtin_amdgcn_readfirstlane(off);
-  if (off + npass > O.pool_stride) {
-    if (lane == 0) {
-      atomicExch(O.err, 1);
-      O.qrec[qo] = make_uint2(0u, 0u);
-    }
-    return;
-  }
-  unsigned *pool = O.pool + (long long)f * O.pool_stride + off;
-  unsigned short *rk = O.rank ? O.rank + (long long)f * O.pool_stride + off : nullptr;
+  // claiming searches: records of the gated candidates, in window order, into the query's pool slot
+  unsigned *slot = O.pool + ((long long)f * Q.stride + (live ? q : 0)) * kSlot;
+  unsigned short *rslot = O.rank ? O.rank + ((long long)f * Q.stride + (live ? q : 0)) * kSlot : nullptr;
   int written = 0, rawbase = 0;
-  for (int base = 0; base < T; base += 64) {
-    const Item it = base == 0 ? first : eval(base + lane, true);
-    const unsigned long long pm = __builtin_amdgcn_ballot_w64(it.pass), rm = __builtin_amdgcn_ballot_w64(it.inraw);
+  for (int base = 0; base < Tmax; base += 16) {
+    const Item it = eval(base + l16);
+    const unsigned pm = (unsigned)(__builtin_amdgcn_ballot_w64(it.pass) >> (16 * sub)) & 0xffffu;
+    const unsigned rm = (unsigned)(__builtin_amdgcn_ballot_w64(it.inraw) >> (16 * sub)) & 0xffffu;
+    const unsigned below = (1u << l16) - 1u;
     if (it.pass) {
-      const int p = written + lane_rank(pm);
-      pool[p] = (unsigned)it.idx | ((unsigned)it.dist << 16) | ((unsigned)it.oct << 25);
-      if (rk) rk[p] = (unsigned short)min(rawbase + lane_rank(rm), 65535);
+      const int p = written + __popc(pm & below);
+      if (p < kSlot) {
+        slot[p] = (unsigned)it.idx | ((unsigned)it.dist << 14) | ((unsigned)(it.oct & 15) << 23) | ((unsigned)it.bin << 27);
+        if (rslot) rslot[p] = (unsigned short)min(rawbase + __popc(rm & below), 65535);
+      }
     }
-    written += __popcll(pm);
-    rawbase += __popcll(rm);
+    written += __popc(pm);
+    rawbase += __popc(rm);
   }
-  if (lane == 0) O.qrec[qo] = make_uint2((unsigned)off, (unsigned)npass);
+  int ovf_off = 0;
+  if (__builtin_amdgcn_ballot_w64(written > kSlot) != 0ull) {  // rare: dense windows.  The tail goes to the overflow area
+    if (written > kSlot) {
+      if (l16 == 0) ovf_off = atomicAdd(&O.ovf_used[f], written - kSlot);
+      ovf_off = __shfl(ovf_off, 0, 16);
+      if (ovf_off + written - kSlot > O.ovf_stride) {
+        if (l16 == 0) atomicExch(O.err, 1);
+        written = kSlot;  // truncated: reported through vo_match_guided_status
+      }
+    }
+    unsigned *ov = O.ovf + (long long)f * O.ovf_stride + ovf_off - kSlot;
+    unsigned short *orv = O.ovf_rank ? O.ovf_rank + (long long)f * O.ovf_stride + ovf_off - kSlot : nullptr;
+    int w2 = 0, r2 = 0;
+    for (int base = 0; base < Tmax; base += 16) {
+      const Item it = eval(base + l16);
+      const unsigned pm = (unsigned)(__builtin_amdgcn_ballot_w64(it.pass) >> (16 * sub)) & 0xffffu;
+      const unsigned rm = (unsigned)(__builtin_amdgcn_ballot_w64(it.inraw) >> (16 * sub)) & 0xffffu;
+      const unsigned below = (1u << l16) - 1u;
+      if (it.pass) {
+        const int p = w2 + __popc(pm & below);
+        if (p >= kSlot && p < written) {
+          ov[p] = (unsigned)it.idx | ((unsigned)it.dist << 14) | ((unsigned)(it.oct & 15) << 23) | ((unsigned)it.bin << 27);
+          if (orv) orv[p] = (unsigned short)min(r2 + __popc(rm & below), 65535);
+        }
+      }
+      w2 += __popc(pm);
+      r2 += __popc(rm);
+    }
+  }
+  if (live && l16 == 0) O.qrec[qo] = make_uint2((unsigned)written | ((flags >> 1) & 1u) << 31, (unsigned)ovf_off);
 }
 
-// One wavefront per frame: the sequential claim replay.  LDS: blocked[cap] bytes, assigned[cap] u16.
+// One wavefront per frame: the sequential claim replay.  LDS: blocked[cap] bytes, assigned[cap] u16.  Everything a
+// decision needs rides in the records (distance, octave, rotation bin) and in the query record (count, observed flag):
+// the only memory round trips are the record loads, prefetched G queries ahead.
 __global__ __launch_bounds__(64) void k_guided_replay(FramesDev F, Queries Q, GuidedParams P, GuidedOut O, int slot0) {
   extern __shared__ __attribute__((aligned(16))) uint8_t rp_lds[];
   __shared__ int hist[32];
@@ -416,7 +460,6 @@ __global__ __launch_bounds__(64) void k_guided_replay(FramesDev F, Queries Q, Gu
   uint8_t *blocked = rp_lds;                                                       // [capA]
   const int capA = (F.cap + 15) & ~15;
   unsigned short *asg = reinterpret_cast<unsigned short *>(rp_lds + capA);          // [cap]: query + 1, 0 = none
-  const long long fo = (long long)s * F.cap;
   int *assigned = O.assigned + (long long)f * F.cap;
   const bool sim3 = P.mode == kModeSim3;
   for (int i = lane; i < nf; i += 64) {
@@ -428,53 +471,68 @@ __global__ __launch_bounds__(64) void k_guided_replay(FramesDev F, Queries Q, Gu
   __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
   __builtin_amdgcn_wave_barrier();
   const uint2 *qrec = O.qrec + (long long)f * Q.stride;
-  const unsigned *pool = O.pool + (long long)f * O.pool_stride;
-  const unsigned short *rkp = O.rank ? O.rank + (long long)f * O.pool_stride : nullptr;
+  const unsigned *pool = O.pool + (long long)f * Q.stride * kSlot;
+  const unsigned short *rkp = O.rank ? O.rank + (long long)f * Q.stride * kSlot : nullptr;
+  const unsigned *ovf = O.ovf + (long long)f * O.ovf_stride;
+  const unsigned short *ovr = O.ovf_rank ? O.ovf_rank + (long long)f * O.ovf_stride : nullptr;
   unsigned *pushes = O.pushes + (long long)f * Q.stride;
-  const float pdf = HISTO_LENGTH / 360.0f;
+  const bool rot_on = P.check_rot && (P.mode == kModeFrame || P.mode == kModeKeyFrame);
   int cnt = 0, npush = 0;
-  constexpr int G = 8;  // queries whose first record chunk is in flight together
+  // Software pipeline: the records of the NEXT group of G queries (and the query records of the next 64-query block)
+  // are in flight while the current group is replayed -- one wavefront per SIMD has nothing else to hide the memory
+  // round trip behind.
+  constexpr int G = 8;
+  struct Group { unsigned rec[G]; unsigned short rk[G]; int cn[G], oo[G], ob[G]; };
+  auto fetch = [&](Group &g, const uint2 &mine, int qb, int g0, int qe) {
+#pragma unroll
+    for (int k = 0; k < G; k++) {
+      const int ql = min(g0 + k, 63);
+      const unsigned cw = (unsigned)__builtin_amdgcn_readlane((int)mine.x, ql);
+      g.cn[k] = g0 + k < qe ? (int)(cw & 0x7fffffffu) : 0;
+      g.ob[k] = (int)(cw >> 31);
+      g.oo[k] = __builtin_amdgcn_readlane((int)mine.y, ql);
+      // records 0..31 sit in the query's slot, the rest in the overflow area
+      const long long sb = (long long)(qb + g0 + k) * kSlot;
+      g.rec[k] = lane < g.cn[k] ? (lane < kSlot ? pool[sb + lane] : ovf[g.oo[k] + lane - kSlot]) : 0u;
+      g.rk[k] = (rkp && lane < g.cn[k]) ? (lane < kSlot ? rkp[sb + lane] : ovr[g.oo[k] + lane - kSlot]) : (unsigned short)0;
+    }
+  };
+  uint2 mine = lane < nq ? qrec[lane] : make_uint2(0u, 0u);
+  Group cur, nxt;
+  fetch(cur, mine, 0, 0, min(64, nq));
   for (int qb = 0; qb < nq; qb += 64) {
-    // (offset, count) of 64 queries: one vector load, then scalar reads
-    const uint2 mine = qb + lane < nq ? qrec[qb + lane] : make_uint2(0u, 0u);
     const int qe = min(64, nq - qb);
-    for (int g0 = 0; g0 < qe; g0 += G) {
-      unsigned rec0[G];
-      unsigned short rk0[G];
-      int off[G], cn[G];
+    const uint2 mine_next = qb + 64 + lane < nq ? qrec[qb + 64 + lane] : make_uint2(0u, 0u);
+    for (int g0 = 0; g0 < 64; g0 += G) {
+      if (g0 + G < 64) fetch(nxt, mine, qb, g0 + G, qe);
+      else fetch(nxt, mine_next, qb + 64, 0, min(64, max(nq - qb - 64, 0)));
 #pragma unroll
       for (int g = 0; g < G; g++) {
-        const int ql = min(g0 + g, 63);
-        off[g] = __builtin_amdgcn_readlane((int)mine.x, ql);
-        cn[g] = g0 + g < qe ? __builtin_amdgcn_readlane((int)mine.y, ql) : 0;
-        rec0[g] = lane < cn[g] ? pool[off[g] + lane] : 0u;
-        rk0[g] = (rkp && lane < cn[g]) ? rkp[off[g] + lane] : (unsigned short)0;
-      }
-#pragma unroll
-      for (int g = 0; g < G; g++) {
-        if (cn[g] == 0) continue;  // uniform
+        if (cur.cn[g] == 0) continue;  // uniform
         const int q = qb + g0 + g;
         // best and second over the unblocked records by (distance, position)
         unsigned k1 = 0xffffffffu, k2 = 0xffffffffu, r1 = 0, r2 = 0;
-        for (int base = 0; base < cn[g]; base += 64) {
-          unsigned rec = rec0[g];
-          unsigned short rk = rk0[g];
+        for (int base = 0; base < cur.cn[g]; base += 64) {
+          unsigned rec = cur.rec[g];
+          unsigned short rk = cur.rk[g];
           if (base > 0) {
-            rec = base + lane < cn[g] ? pool[off[g] + base + lane] : 0u;
-            rk = (rkp && base + lane < cn[g]) ? rkp[off[g] + base + lane] : (unsigned short)0;
+            rec = base + lane < cur.cn[g] ? ovf[cur.oo[g] + base + lane - kSlot] : 0u;
+            rk = (ovr && base + lane < cur.cn[g]) ? ovr[cur.oo[g] + base + lane - kSlot] : (unsigned short)0;
           }
-          const bool have = base + lane < cn[g];
-          const int idx = rec & 0xffffu;
+          const bool have = base + lane < cur.cn[g];
+          const int idx = rec & 0x3fffu;
           const bool skip = !have || (sim3 ? (rk < nf && blocked[rk]) : blocked[idx]);  // :422 indexes by the candidate counter
-          unsigned key = skip ? 0xffffffffu : (((rec >> 16) & 0x1ffu) << 16) | (unsigned)(base + lane);
+          unsigned key = skip ? 0xffffffffu : (((rec >> 14) & 0x1ffu) << 16) | (unsigned)(base + lane);
           const unsigned m1 = wave_min_u32(key);
           if (m1 == 0xffffffffu) continue;
           const int l1 = (int)(m1 & 0xffffu) - base;
           const unsigned rr1 = (unsigned)__builtin_amdgcn_readlane((int)rec, l1);
-          if (lane == l1) key = 0xffffffffu;
-          const unsigned m2 = wave_min_u32(key);
-          unsigned rr2 = 0;
-          if (m2 != 0xffffffffu) rr2 = (unsigned)__builtin_amdgcn_readlane((int)rec, (int)(m2 & 0xffffu) - base);
+          unsigned m2 = 0xffffffffu, rr2 = 0;
+          if (P.mode == kModeLocalMap) {  // only the ratio test looks at the runner-up
+            if (lane == l1) key = 0xffffffffu;
+            m2 = wave_min_u32(key);
+            if (m2 != 0xffffffffu) rr2 = (unsigned)__builtin_amdgcn_readlane((int)rec, (int)(m2 & 0xffffu) - base);
+          }
           // merge (k1, k2) with (m1, m2): all keys distinct by position
           if (m1 < k1) {
             if (k1 < m2) k2 = k1, r2 = r1; else k2 = m2, r2 = rr2;
@@ -484,32 +542,27 @@ __global__ __launch_bounds__(64) void k_guided_replay(FramesDev F, Queries Q, Gu
           }
         }
         if (k1 == 0xffffffffu) continue;
-        const int best = (int)(k1 >> 16), bidx = (int)(r1 & 0xffffu);
+        const int best = (int)(k1 >> 16), bidx = (int)(r1 & 0x3fffu);
         bool accept;
         if (P.mode == kModeFrame) accept = best <= TH_HIGH;
         else if (P.mode == kModeLocalMap) {
           accept = best <= TH_HIGH;
           if (accept && k2 != 0xffffffffu) {
             const int second = (int)(k2 >> 16);
-            const int lv1 = (int)((r1 >> 25) & 0xfu), lv2 = (int)((r2 >> 25) & 0xfu);
+            const int lv1 = (int)((r1 >> 23) & 0xfu), lv2 = (int)((r2 >> 23) & 0xfu);
             if (lv1 == lv2 && (float)best > P.ratio * (float)second) accept = false;  // :344
           }
         } else if (P.mode == kModeKeyFrame) accept = (float)best <= P.dist_threshold;  // :238
         else accept = best <= TH_LOW;                                                  // :437
         if (!accept) continue;
-        const unsigned qflags = Q.flags[(long long)f * Q.stride + q];
         if (lane == 0) {
           asg[bidx] = (unsigned short)(q + 1);
-          if (P.mode == kModeFrame || P.mode == kModeLocalMap) blocked[bidx] = (uint8_t)((qflags >> 1) & 1u);  // :110-113
+          if (P.mode == kModeFrame || P.mode == kModeLocalMap) blocked[bidx] = (uint8_t)cur.ob[g];  // :110-113
           else blocked[bidx] = 1;
         }
         cnt++;
-        if (P.check_rot && (P.mode == kModeFrame || P.mode == kModeKeyFrame)) {  // :115-125
-          float rot = Q.angle[(long long)f * Q.stride + q] - F.angle[fo + bidx];
-          if (rot < 0) rot += 360.0f;
-          int bin = (int)rintf(rot * pdf);
-          if (bin == HISTO_LENGTH) bin = 0;
-          bin = min(max(bin, 0), 31);
+        if (rot_on) {  // :115-125
+          const int bin = (int)(r1 >> 27);
           if (lane == 0) {
             pushes[npush] = (unsigned)bidx | ((unsigned)bin << 16);
             hist[bin]++;
@@ -519,7 +572,10 @@ __global__ __launch_bounds__(64) void k_guided_replay(FramesDev F, Queries Q, Gu
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         __builtin_amdgcn_wave_barrier();
       }
+      cur = nxt;
+      if (qb + g0 + G >= nq) break;  // uniform
     }
+    mine = mine_next;
   }
   __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
   __builtin_amdgcn_wave_barrier();
@@ -586,9 +642,9 @@ struct vo_frames {
   FramesDev D{};
   CamDev cam{};
   float width = 640.f, height = 480.f;
-  vo::DevBuf b_x, b_y, b_angle, b_ur, b_depth, b_oct, b_desc, b_n, b_cs, b_ci;
+  vo::DevBuf b_x, b_y, b_angle, b_ur, b_depth, b_oct, b_desc, b_n, b_cs, b_ci, b_srec, b_sdesc;
   // matcher scratch (grow-only)
-  vo::DevBuf b_pool, b_rank, b_qrec, b_used, b_best, b_asg, b_push, b_nm, b_err, b_sf;
+  vo::DevBuf b_pool, b_rank, b_ovf, b_ovfr, b_qrec, b_used, b_best, b_asg, b_push, b_nm, b_err, b_sf;
   size_t pool_stride = 0;
   float sf_host[16] = {0};  // scale factors last uploaded for vo_track_gather_dev
 };
@@ -607,12 +663,15 @@ int frames_alloc(vo_frames *h) {
   VO_CHECK(h->b_n.reserve((size_t)h->max_frames * 4 + 64));
   VO_CHECK(h->b_cs.reserve((size_t)h->max_frames * (kCells + 1) * 4));
   VO_CHECK(h->b_ci.reserve(N * 2 + 64));
+  VO_CHECK(h->b_srec.reserve(N * 16 + 64));
+  VO_CHECK(h->b_sdesc.reserve(N * 32 + 64));
   FramesDev &D = h->D;
   D.cap = h->cap;
   D.x = h->b_x.as<float>(), D.y = h->b_y.as<float>(), D.angle = h->b_angle.as<float>();
   D.uright = h->b_ur.as<float>(), D.depth = h->b_depth.as<float>(), D.octave = h->b_oct.as<int>();
   D.desc = h->b_desc.as<uint8_t>(), D.n = h->b_n.as<int>(), D.cell_start = h->b_cs.as<int>();
   D.cell_items = h->b_ci.as<unsigned short>();
+  D.srec = h->b_srec.as<uint4>(), D.sdesc = h->b_sdesc.as<uint4>();
   return VO_OK;
 }
 
@@ -643,21 +702,28 @@ int guided_launch(vo_frames *h, int slot0, int n_frames, const Queries &Q, const
   VO_CHECK(h->b_err.reserve(64));
   O.err = h->b_err.as<int>();
   if (claims) {
-    VO_CHECK(h->b_pool.reserve((size_t)n_frames * pool_per_frame * 4));
-    if (c.mode == kModeSim3) VO_CHECK(h->b_rank.reserve((size_t)n_frames * pool_per_frame * 2));
+    // every query owns kSlot records; `pool_per_frame` sizes the overflow area dense windows spill into
+    const size_t slots = (size_t)n_frames * Q.stride * kSlot;
+    VO_CHECK(h->b_pool.reserve(slots * 4 + 64));
+    VO_CHECK(h->b_ovf.reserve((size_t)n_frames * pool_per_frame * 4 + 64));
+    if (c.mode == kModeSim3) {
+      VO_CHECK(h->b_rank.reserve(slots * 2 + 64));
+      VO_CHECK(h->b_ovfr.reserve((size_t)n_frames * pool_per_frame * 2 + 64));
+    }
     VO_CHECK(h->b_qrec.reserve((size_t)n_frames * Q.stride * 8 + 64));
     VO_CHECK(h->b_used.reserve((size_t)n_frames * 4 + 64));
     VO_CHECK(h->b_push.reserve((size_t)n_frames * Q.stride * 4 + 64));
-    O.pool = h->b_pool.as<unsigned>();
+    O.pool = h->b_pool.as<unsigned>(), O.ovf = h->b_ovf.as<unsigned>();
     O.rank = c.mode == kModeSim3 ? h->b_rank.as<unsigned short>() : nullptr;
-    O.qrec = h->b_qrec.as<uint2>(), O.pool_used = h->b_used.as<int>(), O.pushes = h->b_push.as<unsigned>();
-    O.pool_stride = (int)pool_per_frame;
-    VO_HIP_CHECK(hipMemsetAsync(O.pool_used, 0, (size_t)n_frames * 4, st));
+    O.ovf_rank = c.mode == kModeSim3 ? h->b_ovfr.as<unsigned short>() : nullptr;
+    O.qrec = h->b_qrec.as<uint2>(), O.ovf_used = h->b_used.as<int>(), O.pushes = h->b_push.as<unsigned>();
+    O.ovf_stride = (int)pool_per_frame;
+    VO_HIP_CHECK(hipMemsetAsync(O.ovf_used, 0, (size_t)n_frames * 4, st));
   }
   VO_HIP_CHECK(hipMemsetAsync(O.err, 0, 4, st));
   const int nq_max = Q.nq_all;
   if (nq_max > 0)
-    hipLaunchKernelGGL(k_guided_cand, dim3((nq_max + 3) / 4, n_frames), dim3(256), 0, st, h->D, Q, P, O, slot0);
+    hipLaunchKernelGGL(k_guided_cand, dim3((nq_max + 15) / 16, n_frames), dim3(256), 0, st, h->D, Q, P, O, slot0);
   if (claims) {
     const size_t lds = (size_t)((h->cap + 15) & ~15) + (size_t)h->cap * 2;
     hipLaunchKernelGGL(k_guided_replay, dim3(n_frames), dim3(64), lds, st, h->D, Q, P, O, slot0);
@@ -696,7 +762,7 @@ int vo_frames_create(vo_frames **out, int max_frames, int max_features) {
 void vo_frames_destroy(vo_frames *h) {
   if (!h) return;
   for (vo::DevBuf *b : {&h->b_x, &h->b_y, &h->b_angle, &h->b_ur, &h->b_depth, &h->b_oct, &h->b_desc, &h->b_n, &h->b_cs,
-                        &h->b_ci, &h->b_pool, &h->b_rank, &h->b_qrec, &h->b_used, &h->b_best, &h->b_asg, &h->b_push,
+                        &h->b_ci, &h->b_srec, &h->b_sdesc, &h->b_pool, &h->b_rank, &h->b_ovf, &h->b_ovfr, &h->b_qrec, &h->b_used, &h->b_best, &h->b_asg, &h->b_push,
                         &h->b_nm, &h->b_err, &h->b_sf})
     b->release();
   delete h;
@@ -809,7 +875,7 @@ int vo_match_guided_dev(vo_frames *h, int slot0, int n_frames, const vo_guided_q
   Q.viewcos = q->viewcos, Q.desc = q->desc, Q.nq = q->n_per_frame, Q.nq_all = q->n_queries, Q.stride = q->stride;
   GuidedCall c{p->mode, p->radius, p->bf, p->ratio, p->dist_threshold, p->direction, p->check_rot, p->n_levels,
                p->max_dist, p->scale_factors, p->n_levels};
-  if (pool_per_frame == 0) pool_per_frame = (size_t)std::max(q->n_queries, 1) * 64;
+  if (pool_per_frame == 0) pool_per_frame = (size_t)std::max(q->n_queries, 1) * 16;
   return guided_launch(h, slot0, n_frames, Q, c, dev_feature_mask, dev_assigned, dev_best_idx, dev_n_matches,
                        pool_per_frame, (hipStream_t)hip_stream);
 }
@@ -958,7 +1024,7 @@ int guided_host(const vo_frame_view *cur, const HostQueries &hq, const GuidedCal
   if (claims) VO_CHECK(d2d(d_asg, o_asg, (size_t)nf * 4));
   // the cap of the frame store may exceed nf: assigned / mask arrays are indexed with the store's stride for
   // frame 0 only, so the staged [nf] arrays serve as they are
-  size_t pool = std::max<size_t>((size_t)nq * 48, 4096);
+  size_t pool = std::max<size_t>((size_t)nq * 16, 4096);
   for (int attempt = 0;; attempt++) {
     VO_CHECK(guided_launch(h, 0, 1, Q, c, mask_in ? d + o_mask : nullptr, d_asg, d_best, d_nm, pool, st));
     VO_HIP_CHECK(hipMemcpyAsync(r + r_err, h->b_err.p, 4, hipMemcpyDeviceToDevice, st));

@@ -87,13 +87,24 @@ class BatchTracker:
                                                  None, C.c_void_p(st)), "vo_pose_only_solve_ranges_dev")
 
     def track(self, images, depth=None, inv_depth_scale=1.0, radius=15.0, th_radius=3.0, ratio=0.8, direction=0,
-              keep_first=False):
+              keep_first=False, events=False):
         """images: uint8 [B,H,W] device tensor, depth: float32 / int16 [B,H,W] device tensor or None.  Asynchronous on the
         tracker's stream; results: self.pose [B,6], self.ninl [B], self.assigned [B,cap]."""
         L, st, B = vo.lib(), self.st, self.B
+        evs = {}
+
+        def mark(name, end=False):  # HIP events on the launching stream around a stage (bench.py's live stage times)
+            if events:
+                e = self.torch.cuda.Event(enable_timing=True)
+                e.record(self.stream)
+                evs.setdefault(name, []).append(e)
+
         with self.torch.cuda.stream(self.stream):
             self.ext.extract_batch_dev(images, self.kps, self.desc, self.cnt)
+            mark("frame_post")
             self.frames.build_dev(self.kps, self.desc, self.cnt, depth, inv_depth_scale, stream=st)
+            mark("frame_post")
+            mark("match_last_frame")
             nq0 = self.q0["n_queries"]
             vo.check(L.vo_track_project_dev(B, nq0, self.n_last, vo._p(self.Tcw), vo._p(self.p0), vo._p(self.pf0),
                                             vo._p(self.cam4), 0, int(self.W), 0, int(self.H), vo._p(self.q0["flags"]),
@@ -106,14 +117,22 @@ class BatchTracker:
             vo.check(L.vo_track_scatter_dev(self.frames._h, 0, B, vo._p(self.assigned), vo._p(self.p0), vo._p(self.q0["flags"]),
                                             self.n_last, vo._p(self.fpoint), vo._p(self.fhas), vo._p(self.fobs), C.c_void_p(st)),
                      "vo_track_scatter_dev")
+            mark("match_last_frame")
+            mark("pose_only_1")
             self._solve_pose()
+            mark("pose_only_1")
             if keep_first:
                 self.assigned0, self.pose_first, self.ninl_first = self.assigned.clone(), self.pose.clone(), self.ninl.clone()
             # local map: features that already hold an observed map point are blocked (:314); new claims are added
+            mark("match_local_map")
             self.assigned.fill_(-1)
             self.frames.match_dev(B, self.q1, vo.Frames.MODE_LOCAL_MAP, self.sf, radius=th_radius, ratio=ratio,
                                   feature_mask=self.fobs, assigned=self.assigned, n_matches=self.nm, stream=st)
             vo.check(L.vo_track_scatter_dev(self.frames._h, 0, B, vo._p(self.assigned), vo._p(self.p1), vo._p(self.q1["flags"]),
                                             self.n_local, vo._p(self.fpoint), vo._p(self.fhas), vo._p(self.fobs), C.c_void_p(st)),
                      "vo_track_scatter_dev")
+            mark("match_local_map")
+            mark("pose_only_2")
             self._solve_pose()
+            mark("pose_only_2")
+        return evs
