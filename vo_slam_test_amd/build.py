@@ -26,6 +26,7 @@ SOURCES = [
     ("track.hip", ["-ffp-contract=off"]),
     ("ba.hip", ["-ffp-contract=fast"]),
     ("pose_graph.hip", ["-ffp-contract=fast"]),
+    ("chol.hip", ["-ffp-contract=fast"]),
 ]
 COMMON = ["-O3", "-std=c++17", f"--offload-arch={ARCH}", "-fPIC", "-Wall", "-Wno-unused-function"]
 

@@ -2317,7 +2317,7 @@ int build_device(vo_ba *h) {
     VO_CHECK(h->b_scv.reserve((size_t)D.ld * 8));
     VO_CHECK(h->b_ddv.reserve((size_t)D.ld * 8));
     VO_CHECK(h->b_gppv.reserve((size_t)D.ld * 8));
-    VO_CHECK(h->b_cholfail.reserve(64));
+    VO_CHECK(h->b_cholfail.reserve(vo::chol_workspace_bytes(D.ld)));
     D.We[0] = h->b_we0.as<double>(), D.We[1] = h->b_we1.as<double>();
     D.glsc[0] = h->b_glsc0.as<double>(), D.glsc[1] = h->b_glsc1.as<double>();
     D.Sd = h->ext_payload ? h->ext_payload : h->b_Sd.as<double>();

@@ -1,0 +1,479 @@
+// chol.hip -- dense SPD factor + solve for the reduced camera system of a global bundle adjustment and for the
+// loop-closure pose graph (6 N unknowns, N up to ~680 key-frames) on gfx950, FP64.
+//
+// What the reference asks of its solver: Ceres DENSE_SCHUR's Cholesky of the reduced camera matrix
+// (src/optimizer_ceres.cpp:248, :600, :695) and SPARSE_NORMAL_CHOLESKY of the pose graph (:1252-1258).
+//
+// ONE launch, persistent workgroups, tile dataflow.  The matrix is cut into 64 x 64 tiles; tile (i, j) -- and the
+// tile row that carries the right-hand side, which rides through the factorisation and comes out as L^-1 b -- is a
+// TASK: its owner keeps the tile in MFMA accumulators, subtracts L(i,k) L(j,k)^T for k < j as those tiles become
+// available (v_mfma_f64_16x16x4_f64 from LDS-staged operands), then finishes it (64 x 64 Cholesky on the diagonal,
+// X L(j,j)^T = T below it) and publishes it.  Tasks are handed out by a ticket counter in column-major order, so
+// everything a task waits for has an earlier ticket and is either finished or running: no deadlock, whatever the
+// number of resident workgroups.  The trailing matrix is never re-read and re-written panel after panel (the round-1
+// kernels did 47 x 4 dependent launches of 16-25 us each: 3.8 ms of launch latency for 9 GFLOP); here every tile is
+// read once and written once, and the only serial chain left is diag(j) -> L(j+1, j) -> diag(j+1).
+// The backward substitution L^T x = y runs in the same launch: one workgroup walks the diagonal from the bottom and
+// takes the three nearest tiles of every column itself, the other workgroups deliver the far partial products.
+//
+// Hand-off between workgroups (MI355X: per-XCD L2s are not coherent with each other, a CU's L1 is never refreshed):
+// every handed-off double is stored and loaded with agent-scope relaxed atomics (sc1: write-through / L1 bypass),
+// the producer drains its stores (s_waitcnt vmcnt(0)), barriers, and one lane raises the tile's flag; consumers
+// poll the flag with agent-scope loads.  Every poll loop is bounded: on expiry the kernel raises `fail` and all
+// workgroups leave (a hang would cost the GPU box).
+#include "vo_common.h"
+
+#include <algorithm>
+
+namespace {
+
+using namespace vo;
+
+constexpr int NB = vo::kCholPanel;  // 64
+#ifndef VO_CHOL_NEWTON
+#define VO_CHOL_NEWTON 2
+#endif
+constexpr int kNewton = VO_CHOL_NEWTON;  // v_rsq_f64 is good to ~2^-26: one step gives ~1e-15, two steps full precision
+constexpr int LP = NB + 1;          // LDS pitch of a staged tile (conflict-free column and row walks)
+typedef double double4_t __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ void st_sc1(double *p, double v) {
+  __hip_atomic_store(reinterpret_cast<unsigned long long *>(p), __double_as_longlong(v), __ATOMIC_RELAXED,
+                     __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ double ld_sc1(const double *p) {
+  return __longlong_as_double(__hip_atomic_load(reinterpret_cast<const unsigned long long *>(p), __ATOMIC_RELAXED,
+                                                __HIP_MEMORY_SCOPE_AGENT));
+}
+__device__ __forceinline__ int ld_flag(const int *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void st_flag(int *p, int v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+
+__device__ __forceinline__ double bcast_lane(double v, int src_lane) {
+  const unsigned long long u = __double_as_longlong(v);
+  const unsigned lo = __builtin_amdgcn_readlane((int)(unsigned)u, src_lane);
+  const unsigned hi = __builtin_amdgcn_readlane((int)(unsigned)(u >> 32), src_lane);
+  return __longlong_as_double(((unsigned long long)hi << 32) | lo);
+}
+
+#ifdef VO_CHOL_STAMPS  // developer build: s_memrealtime stamps (100 MHz) of the critical tasks -> workspace tail
+#define CSTAMP(slot, k) if (threadIdx.x == 0) C.stamps[(slot) * 16 + (k)] = wall_clock64()
+#else
+#define CSTAMP(slot, k)
+#endif
+
+struct CholCtx {
+  double *A;
+  int ld, m;          // m = ld / 64 tile columns; tile row m = the right-hand-side rows
+  int *fail, *ticket, *done, *ready, *xready, *pcount;
+  double *partial;    // [m][m][64] far partial products of the backward substitution
+  int spin_limit;
+  unsigned long long *stamps;  // [2 m][16] (VO_CHOL_STAMPS builds)
+};
+
+// workgroup-wide wait for a flag (bounded).  Returns false when the kernel is being abandoned.
+__device__ __forceinline__ bool wait_flag(const CholCtx &C, const int *flag, int want, int *s_state) {
+  if (threadIdx.x == 0) {
+    int ok = 1;
+    for (int n = 0; ld_flag(flag) < want; n++) {
+      if (n > C.spin_limit || ld_flag(C.fail) != 0) {
+        if (n > C.spin_limit) atomicMax(C.fail, 2);  // dependency never arrived: give up loudly instead of hanging
+        ok = 0;
+        break;
+      }
+      __builtin_amdgcn_s_sleep(2);
+    }
+    *s_state = ok;
+  }
+  __syncthreads();
+  const bool ok = *s_state != 0;
+  __syncthreads();
+  return ok;
+}
+
+// Tiles travel as 16-byte buffer loads / stores with the sc1 bit (agent scope: write-through on the store side,
+// L1 bypass on the load side) -- the 8-byte agent-scope atomics the language offers move a 32 KB tile in 4 us, these
+// in about a third of that.  A thread owns two adjacent doubles of rows r, r + 8, ...
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+constexpr int kSc1 = 1 << 4;  // cache-policy bit of the raw buffer intrinsics on gfx94x / gfx950
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t tile_rsrc(const CholCtx &C) {
+  return __builtin_amdgcn_make_buffer_rsrc((void *)C.A, 0, (int)(((long long)(C.ld + NB) * C.ld * 8) & 0x7fffffff), 0x00020000);
+}
+__device__ __forceinline__ void load_tile(const CholCtx &C, int R0, int C0, double (*T)[LP], bool /*coherent*/) {
+  const int tid = threadIdx.x, c = 2 * (tid & 31), rr = tid >> 5;
+  const __amdgpu_buffer_rsrc_t rs = tile_rsrc(C);
+  u32x4 v[8];
+#pragma unroll
+  for (int q = 0; q < 8; q++)
+    v[q] = __builtin_amdgcn_raw_buffer_load_b128(rs, (int)(((long long)(R0 + rr + 8 * q) * C.ld + C0 + c) * 8), 0, kSc1);
+#pragma unroll
+  for (int q = 0; q < 8; q++) {
+    T[rr + 8 * q][c] = __longlong_as_double(((unsigned long long)v[q].y << 32) | v[q].x);
+    T[rr + 8 * q][c + 1] = __longlong_as_double(((unsigned long long)v[q].w << 32) | v[q].z);
+  }
+}
+__device__ __forceinline__ void store_tile(const CholCtx &C, int R0, int C0, const double (*T)[LP], bool lower_only) {
+  const int tid = threadIdx.x, c = 2 * (tid & 31), rr = tid >> 5;
+  const __amdgpu_buffer_rsrc_t rs = tile_rsrc(C);
+#pragma unroll
+  for (int q = 0; q < 8; q++) {
+    const int r = rr + 8 * q;
+    if (lower_only && c > r) continue;  // (the pair (r, c), (r, c + 1) with c == r also carries one entry above the diagonal: a zero)
+    const unsigned long long lo = __double_as_longlong(T[r][c]), hi = __double_as_longlong(T[r][c + 1]);
+    const u32x4 v = {(unsigned)lo, (unsigned)(lo >> 32), (unsigned)hi, (unsigned)(hi >> 32)};
+    __builtin_amdgcn_raw_buffer_store_b128(v, rs, (int)(((long long)(R0 + r) * C.ld + C0 + c) * 8), 0, kSc1);
+  }
+}
+
+// 64 x 64 Cholesky of the LDS tile T (lower triangle in, factor out), whole workgroup, four panels of 16 columns:
+//  (1) the first wavefront factors the panel -- lane = row, the row's 16 panel entries in registers, the pivot row's
+//      entries broadcast with v_readlane (no LDS round trip on the pivot chain, which is the critical path of the
+//      whole factorisation); the reciprocal square root is a single-precision estimate refined by three Newton
+//      steps in double (full precision at a fraction of v_sqrt_f64 + v_div_f64's latency);
+//  (2) all four wavefronts apply the rank-16 update to the trailing tiles on the matrix cores.
+// (A lane = row version with the whole 64-entry row in registers needs > 512 registers once it is part of this
+// kernel: 7 KB of scratch per lane and 15 ms per factorisation.)
+template <class PanelDone, class UpdateDone>
+__device__ __forceinline__ bool tile_chol(double (*T)[LP], double *rdiag /*[NB]*/, double *colbuf /*[NB]*/, PanelDone &&panel_done,
+                                          UpdateDone &&update_done) {
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, i16 = lane & 15, q4 = lane >> 4;
+  bool bad = false;
+#pragma unroll
+  for (int b = 0; b < 4; b++) {
+    const int c0 = 16 * b;
+    if (wave == 0) {
+      double p[16];
+#pragma unroll
+      for (int c = 0; c < 16; c++) p[c] = T[lane][c0 + c];
+#pragma unroll
+      for (int j = 0; j < 16; j++) {
+        const double d = bcast_lane(p[j], c0 + j);
+        if (!(d > 0.0) || !(d < 1e300)) bad = true;  // uniform
+        // 1 / sqrt(d): hardware estimate + Newton steps (e = 1 - d r^2, r += r e / 2): the pivot chain is the critical
+        // path of the whole factorisation, every dependent FP64 operation on it costs ~47 x 64 x 18 cycles
+        double r = __builtin_amdgcn_rsq(d);
+#pragma unroll
+        for (int nr = 0; nr < kNewton; nr++) r = __builtin_fma(0.5 * r, __builtin_fma(-(d * r), r, 1.0), r);
+        const double a = lane == c0 + j ? d * r : p[j] * r;  // L[lane][c0 + j] (meaningful for lane >= c0 + j)
+        p[j] = a;
+        if (lane == c0 + j) rdiag[c0 + j] = r;
+        if (j < 15) {
+          // the next pivot only needs column j + 1 of this update: its factor comes by v_readlane (no LDS round trip
+          // on the pivot chain); the other columns take theirs from an LDS broadcast, off the chain
+          p[j + 1] -= a * bcast_lane(a, c0 + j + 1);
+          colbuf[lane] = a;
+#pragma unroll
+          for (int c = j + 2; c < 16; c++) p[c] -= a * colbuf[c0 + c];  // one wavefront issues its LDS operations in order
+        }
+      }
+#pragma unroll
+      for (int c = 0; c < 16; c++) T[lane][c0 + c] = (lane >= c0 + c) ? p[c] : 0.0;
+    }
+    __syncthreads();
+    panel_done(b);  // columns c0 .. c0 + 15 are final: the owner ships them while the trailing update runs
+    // trailing tiles (rt >= ct > b): T -= P P^T with P = the panel columns just written
+    const int nt = (3 - b) * (4 - b) / 2;
+    for (int t = wave; t < nt; t += 4) {
+      int rt = b + 1, u = t;
+      while (u > rt - (b + 1)) u -= rt - b, rt++;
+      const int ct = b + 1 + u;
+      const int R = 16 * rt, Cc = 16 * ct;
+      double4_t acc = {T[R + q4][Cc + i16], T[R + q4 + 4][Cc + i16], T[R + q4 + 8][Cc + i16], T[R + q4 + 12][Cc + i16]};
+#pragma unroll
+      for (int s2 = 0; s2 < 4; s2++)
+        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(-T[R + i16][c0 + 4 * s2 + q4], T[Cc + i16][c0 + 4 * s2 + q4], acc, 0, 0, 0);
+      T[R + q4][Cc + i16] = acc[0], T[R + q4 + 4][Cc + i16] = acc[1], T[R + q4 + 8][Cc + i16] = acc[2], T[R + q4 + 12][Cc + i16] = acc[3];
+    }
+    update_done(b);  // (contains the workgroup barrier that closes the panel step)
+  }
+  return !__syncthreads_or(bad ? 1 : 0);
+}
+
+// X L^T = W for the 64 rows of W (in place), L = lower-triangular LDS tile, rdiag = 1 / diag(L).  Rows are
+// independent: every wavefront owns 16 of them and needs no workgroup barrier.  Column blocks of 16: the part of a
+// block that depends on earlier blocks is an MFMA product, the 16 x 16 triangle a per-row substitution.
+__device__ __forceinline__ void tile_trsm_block(double (*W)[LP], const double (*L)[LP], const double *rdiag, int b) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, i16 = lane & 15, q4 = lane >> 4;
+  const int r0 = 16 * wave, c0 = 16 * b;
+  if (b > 0) {
+    double4_t acc = {W[r0 + q4][c0 + i16], W[r0 + q4 + 4][c0 + i16], W[r0 + q4 + 8][c0 + i16], W[r0 + q4 + 12][c0 + i16]};
+    for (int s = 0; s < 4 * b; s++)
+      acc = __builtin_amdgcn_mfma_f64_16x16x4f64(-W[r0 + i16][4 * s + q4], L[c0 + i16][4 * s + q4], acc, 0, 0, 0);
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    W[r0 + q4][c0 + i16] = acc[0], W[r0 + q4 + 4][c0 + i16] = acc[1], W[r0 + q4 + 8][c0 + i16] = acc[2], W[r0 + q4 + 12][c0 + i16] = acc[3];
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+  }
+  if (lane < 16) {
+    double x[16];
+#pragma unroll
+    for (int c = 0; c < 16; c++) x[c] = W[r0 + lane][c0 + c];
+#pragma unroll
+    for (int c = 0; c < 16; c++) {
+      double v = x[c];
+#pragma unroll
+      for (int q = 0; q < c; q++) v -= x[q] * L[c0 + c][c0 + q];
+      x[c] = v * rdiag[c0 + c];
+    }
+#pragma unroll
+    for (int c = 0; c < 16; c++) W[r0 + lane][c0 + c] = x[c];
+  }
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+}
+
+__global__ __launch_bounds__(256) void k_chol_tiles(CholCtx C) {
+  extern __shared__ __attribute__((aligned(16))) double lds[];
+  double(*Pr)[LP] = reinterpret_cast<double(*)[LP]>(lds);
+  double(*Pc)[LP] = reinterpret_cast<double(*)[LP]>(lds + NB * LP);
+  double *col = lds + 2 * NB * LP, *rdiag = col + NB, *xv = rdiag + NB;  // xv[4][NB]: backward-substitution vectors
+  __shared__ int s_ticket, s_state;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, i16 = lane & 15, q4 = lane >> 4;
+  const int m = C.m, ld = C.ld;
+  const int nF = m * (m + 1) / 2 + m;                 // factorisation tasks: tiles (i >= j) and the rhs tile row
+  int nFar = 0;                                       // off-chain tiles of the backward substitution: i >= j + 2
+  for (int i = 2; i < m; i++) nFar += i - 1;
+  const int nB = 1 + nFar;
+  for (;;) {
+    if (tid == 0) s_ticket = atomicAdd(C.ticket, 1);
+    __syncthreads();
+    const int t = s_ticket;
+    __syncthreads();
+    if (t >= nF + nB) return;
+    if (tid == 0) s_state = ld_flag(C.fail);
+    __syncthreads();
+    if (s_state != 0) return;  // abandoned (not positive definite, or a dependency timed out)
+    __syncthreads();
+    if (t < nF) {
+      // ---------------------------------------------------------------- factorisation task: ticket -> (i, j)
+      int j = 0, rem = t;
+      while (rem >= m - j + 1) rem -= m - j + 1, j++;
+      const int i = j + rem;                                 // j <= i <= m  (i == m: right-hand-side rows)
+      const int R0 = i < m ? NB * i : ld, C0 = NB * j;
+      const int qr = (wave >> 1) * 32, qc = (wave & 1) * 32;
+      double4_t acc[2][2];
+#pragma unroll
+      for (int a = 0; a < 2; a++)
+#pragma unroll
+        for (int b = 0; b < 2; b++) {
+          const double *p = C.A + (long long)(R0 + qr + 16 * a + q4) * ld + C0 + qc + 16 * b + i16;
+          acc[a][b] = double4_t{p[0], p[4LL * ld], p[8LL * ld], p[12LL * ld]};
+        }
+      bool alive = true;
+      const int stamp_slot = i == j ? 2 * j : (i == j + 1 ? 2 * j + 1 : -1);
+      for (int k = 0; k < j && alive; k++) {
+        if (stamp_slot >= 0 && k == j - 1) CSTAMP(stamp_slot, 0);
+        alive = wait_flag(C, C.ready + i * m + k, 1, &s_state);
+        if (alive && i != j) alive = wait_flag(C, C.ready + j * m + k, 1, &s_state);
+        if (!alive) break;
+        if (stamp_slot >= 0 && k == j - 1) CSTAMP(stamp_slot, 1);
+        load_tile(C, R0, NB * k, Pr, true);
+        if (i != j) load_tile(C, NB * j, NB * k, Pc, true);
+        __syncthreads();
+        double(*Pb)[LP] = i != j ? Pc : Pr;
+#pragma unroll
+        for (int a = 0; a < 2; a++)
+#pragma unroll
+          for (int b = 0; b < 2; b++) {
+            const int r0 = qr + 16 * a, c0 = qc + 16 * b;
+#pragma unroll
+            for (int s = 0; s < NB / 4; s++)
+              acc[a][b] = __builtin_amdgcn_mfma_f64_16x16x4f64(-Pr[r0 + i16][4 * s + q4], Pb[c0 + i16][4 * s + q4], acc[a][b], 0, 0, 0);
+          }
+        __syncthreads();
+      }
+      if (!alive) return;
+      if (stamp_slot >= 0) CSTAMP(stamp_slot, 2);
+      // accumulators -> LDS working tile
+#pragma unroll
+      for (int a = 0; a < 2; a++)
+#pragma unroll
+        for (int b = 0; b < 2; b++)
+#pragma unroll
+          for (int g = 0; g < 4; g++) Pr[qr + 16 * a + q4 + 4 * g][qc + 16 * b + i16] = acc[a][b][g];
+      __syncthreads();
+      if (i == j) {
+        // The diagonal tile is published PANEL BY PANEL (flag = panels shipped): the tile below it starts its
+        // triangular solve on the first 16 columns while the pivots of the next panel are still being computed.
+        const __amdgpu_buffer_rsrc_t rs = tile_rsrc(C);
+        double *rd_out = C.partial + (long long)m * m * NB + NB * j;
+        const bool ok = tile_chol(
+            Pr, rdiag, col,
+            [&](int b) {  // panel b: rows 16 b .. 63 x 16 columns = 2 doubles per thread and row group
+              const int c = 16 * b + 2 * (tid & 7), rr = tid >> 3;  // 8 threads per row, 32 rows per pass
+#pragma unroll
+              for (int q = 0; q < 2; q++) {
+                const int r = rr + 32 * q;
+                if (r < 16 * b) continue;
+                const unsigned long long lo = __double_as_longlong(Pr[r][c]), hi = __double_as_longlong(Pr[r][c + 1]);
+                const u32x4 v = {(unsigned)lo, (unsigned)(lo >> 32), (unsigned)hi, (unsigned)(hi >> 32)};
+                __builtin_amdgcn_raw_buffer_store_b128(v, rs, (int)(((long long)(R0 + r) * ld + C0 + c) * 8), 0, kSc1);
+              }
+              if (tid < 16) st_sc1(rd_out + 16 * b + tid, rdiag[16 * b + tid]);
+            },
+            [&](int b) {  // (flagging a panel one pivot phase later, when its stores have long landed, was measured: the
+                          // tile below falls behind by as much and the column period grows from 22.9 to 25.4 us)
+              asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+              __syncthreads();
+              if (tid == 0) st_flag(C.ready + i * m + j, b + 1);
+            });
+        if (!ok && tid == 0) atomicMax(C.fail, 1);  // not positive definite
+        if (stamp_slot >= 0) CSTAMP(stamp_slot, 3);
+        if (stamp_slot >= 0) CSTAMP(stamp_slot, 6);
+        if (tid == 0) atomicAdd(C.done, 1);
+        continue;
+      } else {
+        // X L(j,j)^T = T, panel by panel as the diagonal tile's owner ships them
+        const __amdgpu_buffer_rsrc_t rs = tile_rsrc(C);
+        const double *rd_in = C.partial + (long long)m * m * NB + NB * j;
+        for (int b = 0; b < 4; b++) {
+          if (!wait_flag(C, C.ready + j * m + j, b + 1, &s_state)) return;
+          if (stamp_slot >= 0 && b == 3) CSTAMP(stamp_slot, 3);
+          {  // panel b of L(j,j): rows 16 b .. 63, columns 16 b .. 16 b + 15
+            const int c = 16 * b + 2 * (tid & 7), rr = tid >> 3;
+            u32x4 v[2];
+#pragma unroll
+            for (int q = 0; q < 2; q++)
+              v[q] = __builtin_amdgcn_raw_buffer_load_b128(rs, (int)(((long long)(NB * j + rr + 32 * q) * ld + C0 + c) * 8), 0, kSc1);
+#pragma unroll
+            for (int q = 0; q < 2; q++) {
+              Pc[rr + 32 * q][c] = __longlong_as_double(((unsigned long long)v[q].y << 32) | v[q].x);
+              Pc[rr + 32 * q][c + 1] = __longlong_as_double(((unsigned long long)v[q].w << 32) | v[q].z);
+            }
+            if (tid < 16) rdiag[16 * b + tid] = ld_sc1(rd_in + 16 * b + tid);
+          }
+          __syncthreads();
+          if (stamp_slot >= 0 && b == 3) CSTAMP(stamp_slot, 4);
+          tile_trsm_block(Pr, Pc, rdiag, b);
+        }
+        __syncthreads();
+        if (stamp_slot >= 0) CSTAMP(stamp_slot, 5);
+        store_tile(C, R0, C0, Pr, false);
+      }
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+      if (tid == 0) st_flag(C.ready + i * m + j, 1);
+      if (stamp_slot >= 0) CSTAMP(stamp_slot, 6);
+      if (tid == 0) atomicAdd(C.done, 1);
+      continue;
+    }
+    const double *y = C.A + (long long)ld * ld;          // L^-1 b after the factorisation
+    double *xsol = C.A + (long long)(ld + 1) * ld;       // solution row
+    const double *rd_all = C.partial + (long long)m * m * NB;
+    double *Sacc = C.partial;                             // [m][NB]: running sum_{i >= j + 2} L(i,j)^T x_i of column j
+    double *red = xv;                                     // [4][NB] partial dot products of the four wavefronts
+    // L(i,j)^T x for the staged tile T and the vector in `vec`: thread (g, c) takes rows r = g, g + 4, ...;
+    // returns the complete sum in threads 0..63 (fixed order)
+    auto tile_matvec_t = [&](double (*T)[LP], const double *vec) {
+      const int c = tid & 63, g = tid >> 6;
+      double acc = 0;
+#pragma unroll
+      for (int r = 0; r < NB / 4; r++) acc += T[g + 4 * r][c] * vec[g + 4 * r];
+      red[g * NB + c] = acc;
+      __syncthreads();
+      const double tot = (red[c] + red[NB + c]) + (red[2 * NB + c] + red[3 * NB + c]);
+      __syncthreads();
+      return tot;
+    };
+    if (t == nF) {
+      // ---------------------------------------------------------------- backward substitution, the chain:
+      // x_j = L(j,j)^-T (y_j - L(j+1,j)^T x_{j+1} - S_j), S_j delivered by the other workgroups
+      CSTAMP(0, 8);
+      if (!wait_flag(C, C.done, nF, &s_state)) return;  // every tile of L (and y = L^-1 b) is published
+      for (int j = m - 1; j >= 0; j--) {
+        if (j == 0) CSTAMP(0, 9);
+        const bool near = j + 1 < m;
+        if (near) load_tile(C, NB * (j + 1), NB * j, Pr, true);
+        load_tile(C, NB * j, NB * j, Pc, true);
+        const int links = max(0, m - 2 - j);
+        if (links > 0 && !wait_flag(C, C.pcount + j, links, &s_state)) return;
+        __syncthreads();
+        double sj = 0;
+        if (tid < NB) {
+          rdiag[tid] = ld_sc1(rd_all + NB * j + tid);
+          sj = ld_sc1(y + NB * j + tid) - (links > 0 ? ld_sc1(Sacc + NB * j + tid) : 0.0);
+        }
+        if (near) {
+          const double nv = tile_matvec_t(Pr, col);  // col = x_{j+1}
+          sj -= nv;
+        }
+        if (wave == 0) {  // L(j,j)^T x = rhs: lane i holds rhs_i, columns from the bottom
+          double yi = sj;
+#pragma unroll
+          for (int c = NB - 1; c >= 0; c--) {
+            const double xc = bcast_lane(yi, c) * rdiag[c];
+            if (lane == c) yi = xc;
+            if (lane < c) yi -= Pc[c][lane] * xc;
+          }
+          col[lane] = yi;
+          st_sc1(xsol + NB * j + lane, yi);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (tid == 0) st_flag(C.xready + j, 1);
+        if (j == 0) CSTAMP(0, 10);
+      }
+      continue;
+    }
+    {
+      // ---------------------------------------------------------------- S_j += L(i,j)^T x_i for i >= j + 2, one link
+      // of column j's chain per task: links run i = m-1, m-2, ... (fixed order: deterministic sums)
+      int u = t - nF - 1, i = m - 1;        // ticket order: i descending, then j descending (closest to the chain first)
+      while (u >= i - 1) u -= i - 1, i--;
+      const int j = i - 2 - u;
+      if (!wait_flag(C, C.xready + i, 1, &s_state)) return;
+      load_tile(C, NB * i, NB * j, Pr, true);
+      if (tid < NB) col[tid] = ld_sc1(xsol + NB * i + tid);
+      __syncthreads();
+      const double pv = tile_matvec_t(Pr, col);
+      const int link = m - 1 - i;
+      if (link > 0 && !wait_flag(C, C.pcount + j, link, &s_state)) return;
+      if (tid < NB) st_sc1(Sacc + NB * j + tid, (link > 0 ? ld_sc1(Sacc + NB * j + tid) : 0.0) + pv);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+      if (tid == 0) st_flag(C.pcount + j, link + 1);
+    }
+  }
+}
+
+int chol_ws_ints(int m) { return 16 + (m + 1) * m + 2 * m; }
+
+}  // namespace
+
+size_t vo::chol_workspace_bytes(int ld) {
+  const int m = ld / NB;
+  const size_t ints = ((size_t)chol_ws_ints(m) * 4 + 255) & ~(size_t)255;
+  return ints + ((size_t)m * m * NB + (size_t)m * NB) * 8 + (size_t)2 * m * 16 * 8;
+}
+
+void vo::chol_factor_solve(double *A, int ld, void *workspace, hipStream_t st) {
+  const int m = ld / NB;
+  int *wsI = reinterpret_cast<int *>(workspace);
+  const size_t ints = ((size_t)chol_ws_ints(m) * 4 + 255) & ~(size_t)255;
+  // everything but the fail flag (word 0, owned by the caller) starts at zero
+  (void)hipMemsetAsync(wsI + 1, 0, ints - 4, st);
+  CholCtx C;
+  C.A = A, C.ld = ld, C.m = m;
+  C.fail = wsI, C.ticket = wsI + 1, C.done = wsI + 2, C.ready = wsI + 16, C.xready = C.ready + (m + 1) * m, C.pcount = C.xready + m;
+  C.partial = reinterpret_cast<double *>(reinterpret_cast<uint8_t *>(workspace) + ints);
+  C.stamps = reinterpret_cast<unsigned long long *>(C.partial + (size_t)m * m * NB + (size_t)m * NB);
+  C.spin_limit = 4000000;  // ~ a second of polling: far beyond any healthy wait (a factorisation lasts ~1 ms)
+  static int n_cu = 0;
+  if (!n_cu) {
+    hipDeviceProp_t prop;
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    n_cu = hipGetDeviceProperties(&prop, dev) == hipSuccess ? prop.multiProcessorCount : 256;
+  }
+  const size_t lds = (size_t)(2 * NB * LP + 2 * NB + 4 * NB) * 8;
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute((const void *)k_chol_tiles, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    attr_set = true;
+  }
+  int nFar = 0;
+  for (int i = 2; i < m; i++) nFar += i - 1;
+  const int tasks = m * (m + 1) / 2 + m + 1 + nFar;
+  const int grid = std::max(1, std::min(tasks, 2 * n_cu));
+  hipLaunchKernelGGL(k_chol_tiles, dim3(grid), dim3(256), lds, st, C);
+}

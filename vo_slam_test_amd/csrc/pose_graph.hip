@@ -7,11 +7,8 @@
 //                   incident edges, its 6x6 diagonal block, gradient and one 6x6 off-diagonal block per
 //                   neighbour, gathered in adjacency order (deterministic, no atomics)
 //   k_pg_damp       A = S H S + D(radius) (lower triangle), rhs = S g        (Jacobi scaling S)
-//   k_chol_diag / k_chol_trsm / k_chol_syrk   blocked right-looking Cholesky of the dense
-//                   6(N-1) x 6(N-1) system, 64-wide panels, trailing update on the FP64 matrix cores
-//                   (v_mfma_f64_16x16x4_f64) from LDS-staged panels
-//   k_chol_back     backward substitution, one launch per panel (the forward one rides along with the
-//                   factorisation: the right-hand side is an extra row of the matrix)
+//   vo::chol_factor_solve (csrc/chol.hip)  dense tile Cholesky + both substitutions of the
+//                   6(N-1) x 6(N-1) system in one persistent dataflow kernel on the FP64 matrix cores
 //   k_pg_model      model cost change  -(g''.s + s^T H'' s / 2)
 //   k_pg_candidate  x (+) delta  (EigenQuaternionParameterization::Plus, additive translation)
 //   k_pg_cost       sum of squared residuals over the edges
@@ -183,151 +180,6 @@ __global__ __launch_bounds__(256) void k_pg_damp(PgDev P, double *A, double *rhs
   (void)rhs;
 }
 
-// ---------------------------------------------------------------- dense Cholesky, lower, in place
-// Storage: (ld + NB) rows x ld columns, row-major.  Rows 0..ld-1: the matrix (identity on the padding
-// diagonal).  Row ld: the right-hand side; it takes part in the panel substitution and in the trailing
-// update like any other row, so when the factorisation ends it holds L^-1 b (forward substitution for
-// free).  Rows ld+1.. are zero.
-
-// 64 x 64 diagonal block, one wavefront: lane i keeps row i in registers, column j of the factor is
-// broadcast with v_readlane (no LDS, no barrier); the pivot chain is the latency floor.
-__device__ __forceinline__ double lane_bcast(double v, int src_lane) {
-  const unsigned long long u = __double_as_longlong(v);
-  const unsigned lo = __builtin_amdgcn_readlane((int)(unsigned)u, src_lane);
-  const unsigned hi = __builtin_amdgcn_readlane((int)(unsigned)(u >> 32), src_lane);
-  return __longlong_as_double(((unsigned long long)hi << 32) | lo);
-}
-
-__global__ __launch_bounds__(64) void k_chol_diag(double *A, int ld, int K0, int *fail) {
-  __shared__ __attribute__((aligned(16))) double col[NB];  // column j of the factor, broadcast to every lane
-  const int i = threadIdx.x;
-  double row[NB];
-  const double *src = A + (long long)(K0 + i) * ld + K0;
-#pragma unroll
-  for (int c = 0; c < NB; c++) row[c] = src[c];  // entries right of the diagonal are never used by another lane
-  bool bad = false;
-#pragma unroll
-  for (int j = 0; j < NB; j++) {
-    const double d = lane_bcast(row[j], j);
-    if (!(d > 0.0) || !isfinite(d)) bad = true;  // uniform
-    const double sd = sqrt(d);
-    const double a = i == j ? sd : row[j] / sd;  // L[i][j] (meaningful for i >= j)
-    row[j] = a;
-    // one LDS write, then (63 - j) / 2 broadcast ds_read_b128: half the instructions of a readlane pair per
-    // element.  A single wavefront issues its LDS operations in order, so no barrier is needed.
-    col[i] = a;
-#pragma unroll
-    for (int c = j + 1; c < NB; c++) row[c] -= a * col[c];  // rows i < c carry garbage in column c; never stored
-  }
-  if (bad) {
-    if (i == 0) *fail = 1;
-    return;
-  }
-  double *dst = A + (long long)(K0 + i) * ld + K0;
-#pragma unroll
-  for (int c = 0; c < NB; c++)
-    if (c <= i) dst[c] = row[c];
-}
-
-// rows below the diagonal block (including the right-hand-side row): X L11^T = A21, one thread per row
-__global__ __launch_bounds__(256) void k_chol_trsm(double *A, int ld, int K0, const int *fail) {
-  __shared__ __attribute__((aligned(16))) double L[NB][NB + 2];  // even pitch: the unrolled broadcast reads pair into ds_read_b128
-  if (*fail) return;
-  const int tid = threadIdx.x;
-  for (int i = tid; i < NB * NB; i += 256) L[i / NB][i % NB] = A[(long long)(K0 + i / NB) * ld + K0 + i % NB];
-  __syncthreads();
-  const int r = K0 + NB + blockIdx.x * 256 + tid;
-  if (r > ld) return;  // row ld = right-hand side
-  double *row = A + (long long)r * ld + K0;
-  double xr[NB];
-#pragma unroll
-  for (int c = 0; c < NB; c++) xr[c] = row[c];
-#pragma unroll
-  for (int c = 0; c < NB; c++) {
-    double v = xr[c];
-#pragma unroll
-    for (int q = 0; q < c; q++) v -= xr[q] * L[c][q];
-    xr[c] = v / L[c][c];
-  }
-#pragma unroll
-  for (int c = 0; c < NB; c++) row[c] = xr[c];
-}
-
-typedef double double4_t __attribute__((ext_vector_type(4)));
-
-// trailing update  A22 -= L21 L21^T  (lower tiles, plus the tile row that holds the right-hand side):
-// one 64x64 tile per workgroup, each wavefront a 32x32 quadrant = 2x2 MFMA tiles, K = 64 in 16 steps;
-// both panels staged in LDS.
-// MFMA operands: A: lane l holds A[i = l & 15][k = l >> 4];  B: B[k = l >> 4][j = l & 15];
-// C/D: column l & 15, rows (l >> 4) + 4 reg.
-__global__ __launch_bounds__(256) void k_chol_syrk(double *A, int ld, int K0, const int *fail) {
-  __shared__ double Pr[NB][NB + 1], Pc[NB][NB + 1];
-  if (*fail) return;
-  const int m = (ld - K0 - NB) / NB;  // square tiles per side; tile row m = the right-hand-side rows
-  int t = blockIdx.x, tr = 0, tc;
-  if (t < m * (m + 1) / 2) {  // linear index -> (tr >= tc)
-    while (t > tr) t -= tr + 1, tr++;
-    tc = t;
-  } else {
-    tr = m, tc = t - m * (m + 1) / 2;
-  }
-  const int R0 = K0 + NB + tr * NB, C0 = K0 + NB + tc * NB;
-  const int tid = threadIdx.x;
-  for (int i = tid; i < NB * NB; i += 256) {
-    const int rr = i / NB, kk = i % NB;
-    Pr[rr][kk] = A[(long long)(R0 + rr) * ld + K0 + kk];
-    Pc[rr][kk] = A[(long long)(C0 + rr) * ld + K0 + kk];
-  }
-  __syncthreads();
-  const int wave = tid >> 6, lane = tid & 63, i16 = lane & 15, q4 = lane >> 4;
-  const int qr = (wave >> 1) * 32, qc = (wave & 1) * 32;
-#pragma unroll
-  for (int a = 0; a < 2; a++)
-#pragma unroll
-    for (int b = 0; b < 2; b++) {
-      const int r0 = qr + 16 * a, c0 = qc + 16 * b;
-      double *C = A + (long long)(R0 + r0 + q4) * ld + C0 + c0 + i16;
-      double4_t acc = {C[0], C[4LL * ld], C[8LL * ld], C[12LL * ld]};
-#pragma unroll
-      for (int s = 0; s < NB / 4; s++)
-        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(-Pr[r0 + i16][4 * s + q4], Pc[c0 + i16][4 * s + q4], acc, 0, 0, 0);
-      C[0] = acc[0], C[4LL * ld] = acc[1], C[8LL * ld] = acc[2], C[12LL * ld] = acc[3];
-    }
-}
-
-// One step of the backward substitution L^T x = y (y = row ld), blocks from the bottom: every workgroup
-// solves the 64 x 64 triangle of block K0 redundantly in its first wavefront (lane i holds y_i, column
-// broadcasts by v_readlane), then updates its own 256-column slice of y to the left of the block.
-__global__ __launch_bounds__(256) void k_chol_back(double *A, int ld, int K0, const int *fail) {
-  __shared__ double Lk[NB][NB + 1];
-  __shared__ double xk[NB];
-  if (*fail) return;
-  const int tid = threadIdx.x;
-  double *y = A + (long long)ld * ld;
-  for (int i = tid; i < NB * NB; i += 256) Lk[i / NB][i % NB] = A[(long long)(K0 + i / NB) * ld + K0 + i % NB];
-  __syncthreads();
-  if (tid < NB) {
-    double yi = y[K0 + tid];
-#pragma unroll
-    for (int j = NB - 1; j >= 0; j--) {
-      const double xj = lane_bcast(yi, j) / Lk[j][j];
-      if (tid == j) yi = xj;
-      if (tid < j) yi -= Lk[j][tid] * xj;
-    }
-    xk[tid] = yi;
-  }
-  __syncthreads();
-  const int c = blockIdx.x * 256 + tid;
-  if (c < K0) {
-    double acc = 0;
-#pragma unroll 8
-    for (int r = 0; r < NB; r++) acc += A[(long long)(K0 + r) * ld + c] * xk[r];
-    y[c] -= acc;
-  }
-  // the solution goes to row ld + 1: y_k itself must stay intact for workgroups that start later
-  if (blockIdx.x == 0 && tid < NB) A[(long long)(ld + 1) * ld + K0 + tid] = xk[tid];
-}
-
 // model cost change of step s = -y:  -(g''.s + s^T H'' s / 2), H'' = S H S (undamped); out[0] += partial
 __global__ __launch_bounds__(256) void k_pg_model(PgDev P, const double *y, double *partial) {
   __shared__ double red[4];
@@ -422,18 +274,6 @@ double sum_device(const vo::DevBuf &b, int n, int stride = 1, int offset = 0) { 
 
 }  // namespace
 
-void vo::chol_factor_solve(double *A, int ld, int *fail, hipStream_t st) {
-  for (int K0 = 0; K0 < ld; K0 += NB) {
-    hipLaunchKernelGGL(k_chol_diag, dim3(1), dim3(64), 0, st, A, ld, K0, fail);
-    const int rem = ld - K0 - NB;  // matrix rows below the block; the right-hand-side row comes on top
-    hipLaunchKernelGGL(k_chol_trsm, dim3((rem + 1 + 255) / 256), dim3(256), 0, st, A, ld, K0, fail);
-    const int m = rem / NB;
-    if (m > 0) hipLaunchKernelGGL(k_chol_syrk, dim3(m * (m + 1) / 2 + m), dim3(256), 0, st, A, ld, K0, fail);
-  }
-  for (int K0 = ld - NB; K0 >= 0; K0 -= NB)
-    hipLaunchKernelGGL(k_chol_back, dim3(std::max(1, (K0 + 255) / 256)), dim3(256), 0, st, A, ld, K0, fail);
-}
-
 extern "C" {
 
 int vo_chol_solve(int n, double *A_rowmajor_lower, double *b) {
@@ -461,9 +301,9 @@ int vo_chol_solve(int n, double *A_rowmajor_lower, double *b) {
     return r;
   };
   if ((rc = upload(dA, Ap.data(), Ap.size() * 8)) != VO_OK) return done(rc);
-  int zero = 0;
-  if ((rc = upload(dfail, &zero, 4)) != VO_OK) return done(rc);
-  vo::chol_factor_solve(dA.as<double>(), ld, dfail.as<int>(), nullptr);
+  if ((rc = dfail.reserve(vo::chol_workspace_bytes(ld))) != VO_OK) return done(rc);
+  if (hipMemset(dfail.p, 0, 4) != hipSuccess) return done(VO_ERR_HIP);
+  vo::chol_factor_solve(dA.as<double>(), ld, dfail.p, nullptr);
   if (hipDeviceSynchronize() != hipSuccess) {
     vo::set_error("Cholesky kernels failed: %s", hipGetErrorString(hipGetLastError()));
     return done(VO_ERR_HIP);
@@ -471,8 +311,8 @@ int vo_chol_solve(int n, double *A_rowmajor_lower, double *b) {
   int failed = 0;
   (void)hipMemcpy(&failed, dfail.p, 4, hipMemcpyDeviceToHost);
   if (failed) {
-    vo::set_error("vo_chol_solve: matrix is not positive definite");
-    return done(VO_ERR_INVALID);
+    vo::set_error(failed == 1 ? "vo_chol_solve: matrix is not positive definite" : "vo_chol_solve: the factorisation kernel abandoned a wait");
+    return done(failed == 1 ? VO_ERR_INVALID : VO_ERR_HIP);
   }
   (void)hipMemcpy(Ap.data(), dA.p, Ap.size() * 8, hipMemcpyDeviceToHost);
   for (int i = 0; i < n; i++) b[i] = Ap[(size_t)(ld + 1) * ld + i];  // solution: row ld + 1
@@ -480,6 +320,38 @@ int vo_chol_solve(int n, double *A_rowmajor_lower, double *b) {
     for (int j = 0; j <= i; j++) A_rowmajor_lower[(size_t)i * n + j] = Ap[(size_t)i * ld + j];
   return done(VO_OK);
 }
+
+#ifdef VO_CHOL_STAMPS
+// developer entry (tools/chol_stamps.py): vo_chol_solve + the stamp block of the workspace
+int vo_chol_debug_solve(int n, double *A_rowmajor_lower, double *b, unsigned long long *stamps, int n_stamps) {
+  const int ld = (n + NB - 1) / NB * NB;
+  std::vector<double> Ap((size_t)(ld + NB) * ld, 0.0);
+  for (int i = 0; i < ld; i++) {
+    if (i < n) {
+      for (int j = 0; j <= i; j++) Ap[(size_t)i * ld + j] = A_rowmajor_lower[(size_t)i * n + j];
+      Ap[(size_t)ld * ld + i] = b[i];
+    } else {
+      Ap[(size_t)i * ld + i] = 1.0;
+    }
+  }
+  vo::DevBuf dA, dws;
+  VO_CHECK(upload(dA, Ap.data(), Ap.size() * 8));
+  const size_t wsb = vo::chol_workspace_bytes(ld);
+  VO_CHECK(dws.reserve(wsb));
+  VO_HIP_CHECK(hipMemset(dws.p, 0, wsb));
+  vo::chol_factor_solve(dA.as<double>(), ld, dws.p, nullptr);
+  VO_HIP_CHECK(hipDeviceSynchronize());
+  VO_HIP_CHECK(hipMemcpy(Ap.data(), dA.p, Ap.size() * 8, hipMemcpyDeviceToHost));
+  for (int i = 0; i < n; i++) b[i] = Ap[(size_t)(ld + 1) * ld + i];
+  const int m = ld / NB;
+  const size_t soff = wsb - (size_t)2 * m * 16 * 8;
+  VO_HIP_CHECK(hipMemcpy(stamps, reinterpret_cast<uint8_t *>(dws.p) + soff, std::min<size_t>((size_t)n_stamps, (size_t)2 * m * 16) * 8, hipMemcpyDeviceToHost));
+  int failed = 0;
+  VO_HIP_CHECK(hipMemcpy(&failed, dws.p, 4, hipMemcpyDeviceToHost));
+  dA.release(), dws.release();
+  return failed;
+}
+#endif
 
 int vo_pose_graph_solve(int n_nodes, double *quats, double *trans, const double *scales, int fixed_node, int n_edges,
                         const int32_t *edge_i, const int32_t *edge_j, const double *q_meas, const double *t_meas,
@@ -554,7 +426,7 @@ int vo_pose_graph_solve(int n_nodes, double *quats, double *trans, const double 
   PG_TRY(d_norm.reserve((size_t)n_nodes * 16));
   const int cost_blocks = (n_edges + 255) / 256;
   PG_TRY(d_cost.reserve((size_t)cost_blocks * 8));
-  PG_TRY(d_fail.reserve(64));
+  PG_TRY(d_fail.reserve(vo::chol_workspace_bytes(ld)));
   PgDev P;
   P.n_nodes = n_nodes, P.n_edges = n_edges, P.n = n, P.ld = ld;
   P.e_i = d_ei.as<int>(), P.e_j = d_ej.as<int>(), P.qm = d_qm.as<double>(), P.tm = d_tm.as<double>();
@@ -612,7 +484,7 @@ int vo_pose_graph_solve(int n_nodes, double *quats, double *trans, const double 
     hipLaunchKernelGGL(k_pg_damp, dim3((unsigned)(((long long)ld * ld + 255) / 256)), dim3(256), 0, nullptr, P,
                        d_A.as<double>(), d_rhs.as<double>(), radius);
     (void)hipMemsetAsync(d_A.as<double>() + (size_t)(ld + 1) * ld, 0, (size_t)(NB - 1) * ld * 8, nullptr);  // rows below the rhs
-    vo::chol_factor_solve(d_A.as<double>(), ld, d_fail.as<int>(), nullptr);
+    vo::chol_factor_solve(d_A.as<double>(), ld, d_fail.p, nullptr);
     const double *ysol = d_A.as<double>() + (size_t)(ld + 1) * ld;
     hipLaunchKernelGGL(k_pg_model, dim3(n), dim3(256), 0, nullptr, P, ysol, d_part.as<double>());
     hipLaunchKernelGGL(k_pg_candidate, dim3((n_nodes + 127) / 128), dim3(128), 0, nullptr, P, dx, ysol, dxc,

@@ -86,13 +86,14 @@ int stream_sync(hipStream_t st, const char *what);
 // reserve + copy
 int upload(DevBuf &b, const void *src, size_t bytes, hipStream_t st, const char *what);
 
-// Dense SPD solve on the device (csrc/pose_graph.hip).  A: (ld + 64) rows x ld columns, row-major, ld a
-// multiple of 64.  Rows 0..ld-1: the matrix, lower triangle used (identity on the padding diagonal);
-// row ld: the right-hand side; rows ld+1..: zero on entry.  The lower triangle is factored in place
-// (L L^T, 64-wide panels, trailing update on the FP64 matrix cores); the solution ends up in row
-// ld + 1.  *fail (device int, zeroed by the caller) is set when a pivot is not positive.  Enqueues
-// kernels only; no synchronisation.
+// Dense SPD solve on the device (csrc/chol.hip).  A: (ld + 64) rows x ld columns, row-major, ld a multiple of 64.
+// Rows 0..ld-1: the matrix, lower triangle used (identity on the padding diagonal); row ld: the right-hand side;
+// rows ld+1.. are spare.  The lower triangle is factored in place (L L^T, 64 x 64 tiles, one persistent dataflow
+// kernel on the FP64 matrix cores); the solution ends up in row ld + 1.  `workspace`: chol_workspace_bytes(ld) bytes
+// of device memory; its first int is the fail flag -- zeroed by the caller, set to 1 when a pivot is not positive,
+// 2 when the kernel abandoned a wait.  Enqueues one memset and one kernel; no synchronisation.
 constexpr int kCholPanel = 64;
-void chol_factor_solve(double *A, int ld, int *fail, hipStream_t st);
+size_t chol_workspace_bytes(int ld);
+void chol_factor_solve(double *A, int ld, void *workspace, hipStream_t st);
 
 }  // namespace vo
