@@ -59,6 +59,15 @@ def stage_bytes_per_frame(w, h, nkp, ncand):
     }
 
 
+def ba_flops_per_iteration(prob):
+    """F_ba of SURVEY 8d for one LM iteration of a BA problem dict (synth.make_lba_problem layout)."""
+    ne, npts = len(prob["e_cam"]), len(prob["points"])
+    nc = int((np.asarray(prob["fixed"]) == 0).sum())
+    k = np.bincount(prob["e_pt"], minlength=npts).astype(np.float64)
+    m = np.where(prob["e_obs"][:, 2] >= 0, 3, 2).astype(np.float64)
+    return float((150 + 108 * m).sum() + (50 + 144 * k + 216 * k * (k + 1) / 2).sum() + (6 * nc) ** 3 / 3 + 2 * (6 * nc) ** 2 + 60 * ne)
+
+
 def tracking_bytes_per_frame(nkp, n_q0, n_q1, n_obs):
     """Algorithmic bytes of the tracking stages per frame: key-points + descriptors in and the feature store out; per
     query its descriptor and projection plus ~12 gated candidates (feature record 16 B + descriptor 32 B) and the 4-byte
@@ -381,15 +390,31 @@ def main():
                 iters += sums[0].iterations + sums[1].iterations
             ba.close()
         else:
-            from vo_slam_test_amd.dist_ba import ShardedBundleAdjuster
-            sba = ShardedBundleAdjuster(lb, rank, world)
+            # one problem, points sharded over the ranks; the LM loop runs inside libvo_hip.so and calls back for its
+            # two all-reduces per iteration (RCCL over xGMI with the nccl backend)
+            class _DevView:
+                def __init__(self, ptr, n):
+                    self.__cuda_array_interface__ = {"shape": (n,), "typestr": "<f8", "data": (ptr, False), "version": 2}
+
+            def _allreduce(ptr, n, _stream):
+                t = torch.as_tensor(_DevView(ptr, n), device="cuda")
+                if args.backend == "nccl":
+                    dist.all_reduce(t)
+                else:
+                    hbuf = t.cpu()
+                    dist.all_reduce(hbuf)
+                    t.copy_(hbuf)
+                return 0
+
+            sba = vo.BundleAdjuster(lb, shard=rank, n_shards=world, stream=torch.cuda.current_stream().cuda_stream)
+            sba.set_allreduce(_allreduce)
             sba.local_ba()
             iters, tb = 0, 0.0
             for _ in range(reps):
-                sba.ba.set_state(lb["poses"], lb["points"])
+                sba.set_state(lb["poses"], lb["points"])
                 barrier()
                 tb0 = time.perf_counter()
-                _, _, _, (s1, s2) = sba.local_ba()
+                _, (s1, s2), _ = sba.local_ba()
                 barrier()
                 tb += time.perf_counter() - tb0
                 iters += s1.iterations + s2.iterations
@@ -403,7 +428,13 @@ def main():
         out["local_ba"] = {"workload": f"10 KF + 4 fixed x 3000 pts, {n_edges} edges, 5 Huber + 10 plain LM iterations",
                            "lm_iters_per_s": round(iters / tb, 1), "ms_per_solve": round(tb / reps * 1e3, 3),
                            "iterations_per_solve": iters / reps, "dtype": "f64",
-                           "sharding": f"points % {world}, 2 all-reduces per LM iteration" if world > 1 else "single GPU"}
+                           "sharding": f"points % {world}, 2 all-reduces per LM iteration inside the C-ABI (vo_ba_set_allreduce)"
+                           if world > 1 else "single GPU"}
+        f_lba = ba_flops_per_iteration(lb)
+        out["local_ba"]["roofline"] = {"bound": "fp64 (latency-bound: 3 dependent launches per LM iteration)",
+                                       "flops_per_iteration": round(f_lba), "achieved": round(f_lba * iters / tb / 1e12, 4),
+                                       "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s",
+                                       "frac": round(f_lba * iters / tb / 1e12 / FP64_PEAK_TFLOPS, 5)}
         if world > 1:
             # replicas: every GPU works on its own set of independent 10-KF problems (several local-mapping
             # sessions / map regions); no exchange.  Aggregate LM-iterations/s over the node.
@@ -462,6 +493,33 @@ def main():
             out["pose_only_ba"] = {"workload": f"{len(probs)} frames x 1000 obs, 2 x <=10 LM iterations, one launch "
                                                "(host buffers in/out, PCIe included)",
                                    "solves_per_s": round(len(probs) / tp, 1), "lm_iters_per_s": round(pit / tp, 1)}
+            # the same batch with everything resident in HBM (kernel time between two events)
+            offs = np.arange(len(probs) + 1, dtype=np.int32) * 1000
+            cat = lambda k: torch.from_numpy(np.ascontiguousarray(np.concatenate([pr[k] for pr in probs]))).cuda()
+            d_off, d_pts, d_obs, d_isg = torch.from_numpy(offs).cuda(), cat("pts"), cat("obs"), cat("inv_sigma")
+            d_cam = torch.from_numpy(np.ascontiguousarray(probs[0]["cam"], np.float64)).cuda()
+            pose0 = torch.from_numpy(np.stack([pr["pose0"] for pr in probs])).cuda()
+            d_pose, d_out = pose0.clone(), torch.zeros(len(probs) * 1000, dtype=torch.uint8, device="cuda")
+            d_inl = torch.zeros(len(probs), dtype=torch.int32, device="cuda")
+            cs = torch.cuda.current_stream()
+            ev = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
+            for rep in range(3):
+                d_pose.copy_(pose0)
+                if rep == 2:
+                    ev[0].record(cs)
+                vo.check(vo.lib().vo_pose_only_solve_dev(len(probs), vo._p(d_off), 1000, vo._p(d_pts), vo._p(d_obs), vo._p(d_isg),
+                                                         vo._p(d_cam), vo._p(d_pose), vo._p(d_out), vo._p(d_inl), None,
+                                                         ctypes.c_void_p(cs.cuda_stream)), "vo_pose_only_solve_dev")
+            ev[1].record(cs)
+            torch.cuda.synchronize()
+            tk = ev[0].elapsed_time(ev[1]) * 1e-3
+            f_po = 270.0 * 1000 * pit  # ~150 + 120 flop per observation and LM iteration
+            out["pose_only_ba"]["device_resident"] = {"solves_per_s": round(len(probs) / tk, 1), "lm_iters_per_s": round(pit / tk, 1),
+                                                      "ms_per_launch": round(tk * 1e3, 3)}
+            out["pose_only_ba"]["roofline"] = {"bound": "fp64 (latency-bound: <= 20 dependent LM iterations per frame)",
+                                               "achieved": round(f_po / tk / 1e12, 4), "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s",
+                                               "frac": round(f_po / tk / 1e12 / FP64_PEAK_TFLOPS, 5)}
+            pose_probs, pose_iters_dev = probs, pit
             # config 4: loop-closure sized problems (global BA through the large-system path, pose graph, Sim3)
             gb = synth.make_global_ba_problem(0)
             gba = vo.BundleAdjuster(gb)
@@ -477,6 +535,11 @@ def main():
                                             f"{6 * (len(gb['poses']) - 1)}-wide reduced system, 10 LM iterations",
                                 "lm_iters_per_s": round(gs.iterations / tg, 1), "ms_per_iter": round(tg / gs.iterations * 1e3, 3),
                                 "dtype": "f64", "sharding": "single GPU"}
+            f_gba = ba_flops_per_iteration(gb)
+            out["global_ba"]["roofline"] = {"bound": "fp64 mfma (dense tile Cholesky: the serial pivot chain bounds it)",
+                                            "flops_per_iteration": round(f_gba), "achieved": round(f_gba * gs.iterations / tg / 1e12, 3),
+                                            "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s",
+                                            "frac": round(f_gba * gs.iterations / tg / 1e12 / FP64_PEAK_TFLOPS, 4)}
             pg = synth.make_pose_graph(7, n_kf=500, drift=0.004, extra_edges=4)
             vo.Optimizer.solvePoseGraphLoop(synth.make_pose_graph(0, n_kf=12))
             tq0 = time.perf_counter()
@@ -525,6 +588,18 @@ def main():
             if "aggregate_lm_iters_per_s" in out["local_ba"]:
                 out["local_ba"]["aggregate_speedup_vs_cpu_port"] = round(
                     out["local_ba"]["aggregate_lm_iters_per_s"] / (its / tl), 1)
+            if "pose_only_ba" in out:
+                tq0 = time.perf_counter()
+                nps, pits = 0, 0
+                while time.perf_counter() - tq0 < 2.0 and nps < 64:
+                    _, _, _, ps_, _ = orc.pose_only(pose_probs[nps])
+                    pits += ps_[0].iterations + ps_[1].iterations
+                    nps += 1
+                tq = time.perf_counter() - tq0
+                cpu["pose_only_solves_per_s"] = round(nps / tq, 1)
+                cpu["pose_only_lm_iters_per_s"] = round(pits / tq, 1)
+                cpu["pose_only_sample"] = f"{nps} of the same 1000-observation problems, {tq:.1f} s, 1 thread"
+                out["pose_only_ba"]["speedup_vs_cpu_port"] = round(out["pose_only_ba"]["device_resident"]["solves_per_s"] / (nps / tq), 1)
             if "global_ba" in out:
                 gp, gpt = gb["poses"].copy(), gb["points"].copy()
                 gsum = orc.make_summary(1)

@@ -302,6 +302,56 @@ void vo_vocab_destroy(vo_vocab *v);
 int vo_bow_transform(const vo_vocab *v, int n, const uint8_t *desc, int levelsup, int32_t *word_id, double *weight,
                      int32_t *node_id);
 
+/* The vocabulary file itself (DBoW3::Vocabulary(path), vo_run.cpp:87): DBoW3 0.0.1 binary layout
+ * (Vocabulary::toStream, uncompressed) or the ORB-SLAM2 text format; builds the device tree. */
+int vo_vocab_load(const char *path, vo_vocab **out, int *n_nodes, int *n_words, int *branching_k, int *depth_L);
+/* Map::score (map.cpp:335-376): L1 similarity of the query BoW vector (ascending word ids) with every
+ * candidate's (CSR: candidate c owns cand_words / cand_values [cand_start[c], cand_start[c+1])); one
+ * launch for all candidates of detectLoopCandidates / detectRelocalizationCandidates (:210-333). */
+int vo_bow_score(int n_query, const int32_t *query_words, const double *query_values, int n_candidates,
+                 const int32_t *cand_start, const int32_t *cand_words, const double *cand_values, double *scores);
+
+/* Sim3Solver (src/sim3Solver.cpp): every RANSAC hypothesis of Sim3Solver::iterate in one launch -- Horn's
+ * closed form (computeSim3 :179-252) for the three sampled correspondences triplets[3k..3k+2] and
+ * checkInliers (:254-280) over all n correspondences.  The random triplets come from the caller (the
+ * reference draws them with rand(), :119-137), as does the sequential pick "first hypothesis whose
+ * inlier count beats the threshold" (:141-160).  max_err = the reference's INTEGER thresholds
+ * (vector<int>, 9.210 sigma^2 truncated).  Per hypothesis: counts[k], inlier_flags[k * n ..] (or NULL),
+ * sims[13 k ..] = R12 row-major (9), t12 (3), s12. */
+int vo_sim3_ransac_eval(int n, const double *cam1_points, const double *cam2_points, const double *pixels1,
+                        const double *pixels2, const int32_t *max_err1, const int32_t *max_err2,
+                        const float cam4[4], int n_hypotheses, const int32_t *triplets, int fix_scale,
+                        int32_t *counts, uint8_t *inlier_flags, double *sims);
+
+/* LocalMapping::createNewMapPoints' linear triangulation (localMapping.cpp:234-251), batched: normalised
+ * observations xn1 / xn2 [n][2], Tcw1 (3 x 4 float, row-major) of the current key-frame, Tcw2 one pose or
+ * one per pair.  points [n][3]; ok[i] = 0 where |x_3| < 1e-8 (:245-246 skips the pair).  The right
+ * singular vector is taken from the eigen-decomposition of A^T A in double: agreement with cv::SVD's
+ * float Jacobi is to float rounding (stated tolerance 1e-4 relative), not bit-exact. */
+int vo_triangulate(int n, const float *xn1, const float *xn2, const float Tcw1[12], const float *Tcw2,
+                   int per_pair_pose2, float *points, uint8_t *ok);
+
+/* cv::cvtColor(CV_RGB2GRAY / CV_BGR2GRAY [/ RGBA / BGRA]) of VisualOdometry::createFrame
+ * (visualOdometry.cpp:146-159), OpenCV 3.x fixed point. */
+int vo_rgb_to_gray(const uint8_t *src, long long n_pixels, int channels, int first_is_red, uint8_t *dst);
+int vo_rgb_to_gray_dev(const uint8_t *dev_src, long long n_pixels, int channels, int first_is_red,
+                       uint8_t *dev_dst, void *hip_stream);
+
+/* The reference harness's I/O (test/vo_run.cpp): associate.txt (:24-58), cv::imread of 8-bit colour
+ * / 16-bit depth PNGs (:108-109; zlib + PNG filters, non-interlaced), the trajectory files (:154-232,
+ * Twc7 = translation + quaternion x y z w per pose, Eigen's default stream format) and the tracking-
+ * time report (:138-151). */
+typedef struct vo_dataset vo_dataset;
+int vo_dataset_open(vo_dataset **out, const char *dataset_dir, int max_frames);
+int vo_dataset_size(const vo_dataset *d);
+int vo_dataset_entry(const vo_dataset *d, int i, const char **rgb_time, const char **rgb_path,
+                     const char **depth_time, const char **depth_path);
+void vo_dataset_close(vo_dataset *d);
+int vo_png_info(const char *path, int *width, int *height, int *channels, int *bit_depth);
+int vo_png_read(const char *path, int as_bgr, void *dst, size_t dst_bytes);
+int vo_trajectory_write(const char *path, int n, const char *const *timestamps, const double *Twc7);
+int vo_tracking_time_stats(const double *seconds, int n_tracked, double *median, double *mean);
+
 /* Loop-closure searches.  All three project map points into a key-frame and take, per point, the
  * best Hamming match among KeyFrame::getFeaturesInArea(u, v, th * scale[level]) with octave in
  * [level - 1, level]; flag bit 0 of a query = it passed the projection gates of the routine.

@@ -90,3 +90,173 @@ int orc_median_descriptor(const uint8_t *desc, int n) {
   free(dist), free(row);
   return bestIdx;
 }
+
+/* ---- N3: Sim3Solver (reference src/sim3Solver.cpp) ------------------------------------------------------- */
+
+/* symmetric 4 x 4 eigen-decomposition by cyclic Jacobi rotations (the reference calls Eigen::EigenSolver on the
+ * symmetric matrix N, :211-213: same eigenvectors up to sign and rounding) */
+static void sym4_eigen(double A[4][4], double V[4][4], double w[4]) {
+  for (int i = 0; i < 4; i++)
+    for (int j = 0; j < 4; j++) V[i][j] = i == j;
+  for (int sweep = 0; sweep < 60; sweep++) {
+    double off = 0;
+    for (int p = 0; p < 4; p++)
+      for (int q = p + 1; q < 4; q++) off += A[p][q] * A[p][q];
+    if (off < 1e-300) break;
+    for (int p = 0; p < 4; p++)
+      for (int q = p + 1; q < 4; q++) {
+        if (fabs(A[p][q]) < 1e-300) continue;
+        const double theta = (A[q][q] - A[p][p]) / (2.0 * A[p][q]);
+        const double t = (theta >= 0 ? 1.0 : -1.0) / (fabs(theta) + sqrt(theta * theta + 1.0));
+        const double c = 1.0 / sqrt(t * t + 1.0), s = t * c;
+        for (int k = 0; k < 4; k++) {
+          const double akp = A[k][p], akq = A[k][q];
+          A[k][p] = c * akp - s * akq, A[k][q] = s * akp + c * akq;
+        }
+        for (int k = 0; k < 4; k++) {
+          const double apk = A[p][k], aqk = A[q][k];
+          A[p][k] = c * apk - s * aqk, A[q][k] = s * apk + c * aqk;
+        }
+        for (int k = 0; k < 4; k++) {
+          const double vkp = V[k][p], vkq = V[k][q];
+          V[k][p] = c * vkp - s * vkq, V[k][q] = s * vkp + c * vkq;
+        }
+      }
+  }
+  for (int i = 0; i < 4; i++) w[i] = A[i][i];
+}
+
+/* Sim3Solver::computeSim3, sim3Solver.cpp:179-252 (Horn 1987).  P1, P2: three points each, point i = P[3 i .. 3 i + 2].
+ * Out: R12 row-major, t12, s12 (1 when fix_scale). */
+void orc_sim3_horn(const double P1[9], const double P2[9], int fix_scale, double R[9], double t[3], double *s) {
+  double O1[3] = {0, 0, 0}, O2[3] = {0, 0, 0}, Pr1[3][3], Pr2[3][3], M[3][3];
+  for (int i = 0; i < 3; i++)
+    for (int k = 0; k < 3; k++) O1[k] += P1[3 * i + k], O2[k] += P2[3 * i + k];
+  for (int k = 0; k < 3; k++) O1[k] /= 3.0, O2[k] /= 3.0;
+  for (int i = 0; i < 3; i++)
+    for (int k = 0; k < 3; k++) Pr1[k][i] = P1[3 * i + k] - O1[k], Pr2[k][i] = P2[3 * i + k] - O2[k]; /* 3 x 3, column = point */
+  for (int a = 0; a < 3; a++)
+    for (int b = 0; b < 3; b++) {
+      M[a][b] = 0;
+      for (int i = 0; i < 3; i++) M[a][b] += Pr2[a][i] * Pr1[b][i]; /* M = Pr2 Pr1^T */
+    }
+  double N[4][4], V[4][4], w[4];
+  N[0][0] = M[0][0] + M[1][1] + M[2][2];
+  N[0][1] = N[1][0] = M[1][2] - M[2][1];
+  N[0][2] = N[2][0] = M[2][0] - M[0][2];
+  N[0][3] = N[3][0] = M[0][1] - M[1][0];
+  N[1][1] = M[0][0] - M[1][1] - M[2][2];
+  N[1][2] = N[2][1] = M[0][1] + M[1][0];
+  N[1][3] = N[3][1] = M[2][0] + M[0][2];
+  N[2][2] = -M[0][0] + M[1][1] - M[2][2];
+  N[2][3] = N[3][2] = M[1][2] + M[2][1];
+  N[3][3] = -M[0][0] - M[1][1] + M[2][2];
+  sym4_eigen(N, V, w);
+  int best = 0;
+  for (int i = 1; i < 4; i++)
+    if (w[i] > w[best]) best = i;
+  double q0 = V[0][best], q1 = V[1][best], q2 = V[2][best], q3 = V[3][best]; /* (w, x, y, z) */
+  const double nq = sqrt(q0 * q0 + q1 * q1 + q2 * q2 + q3 * q3);
+  q0 /= nq, q1 /= nq, q2 /= nq, q3 /= nq;
+  /* Eigen::Quaterniond::toRotationMatrix */
+  R[0] = 1 - 2 * (q2 * q2 + q3 * q3), R[1] = 2 * (q1 * q2 - q0 * q3), R[2] = 2 * (q1 * q3 + q0 * q2);
+  R[3] = 2 * (q1 * q2 + q0 * q3), R[4] = 1 - 2 * (q1 * q1 + q3 * q3), R[5] = 2 * (q2 * q3 - q0 * q1);
+  R[6] = 2 * (q1 * q3 - q0 * q2), R[7] = 2 * (q2 * q3 + q0 * q1), R[8] = 1 - 2 * (q1 * q1 + q2 * q2);
+  double sc = 1.0;
+  if (!fix_scale) { /* :236-242 */
+    double nom = 0, den = 0;
+    for (int i = 0; i < 3; i++)
+      for (int a = 0; a < 3; a++) {
+        const double p3 = R[3 * a] * Pr2[0][i] + R[3 * a + 1] * Pr2[1][i] + R[3 * a + 2] * Pr2[2][i];
+        nom += Pr1[a][i] * p3, den += p3 * p3;
+      }
+    sc = nom / den;
+  }
+  *s = sc;
+  for (int a = 0; a < 3; a++) t[a] = O1[a] - sc * (R[3 * a] * O2[0] + R[3 * a + 1] * O2[1] + R[3 * a + 2] * O2[2]);
+}
+
+/* Sim3Solver::project (:290-313): float pixel arithmetic on a double camera-frame point */
+static void sim3_project(const double R[9], const double t[3], double s, const double p[3], const float cam[4], double uv[2]) {
+  const double x = s * (R[0] * p[0] + R[1] * p[1] + R[2] * p[2]) + t[0];
+  const double y = s * (R[3] * p[0] + R[4] * p[1] + R[5] * p[2]) + t[1];
+  const double z = s * (R[6] * p[0] + R[7] * p[1] + R[8] * p[2]) + t[2];
+  const double invz = 1.0 / z;
+  const float u = (float)(x * invz) * cam[0] + cam[2], v = (float)(y * invz) * cam[1] + cam[3];
+  uv[0] = u, uv[1] = v;
+}
+
+/* One RANSAC hypothesis per sample triplet (:119-137) + checkInliers (:254-280) over all n correspondences.
+ * pc1 / pc2: camera-frame points, px1 / px2: their pixels (Camera::camera2pixel, doubles), maxerr1 / maxerr2: the
+ * reference's INTEGER thresholds (vector<int>, 9.210 sigma^2 truncated; sim3Solver.h).  Out per hypothesis k:
+ * counts[k], flags[k * n ..], sims[k * 13 ..] = R12 (9), t12 (3), s12.  The sequential pick (first hypothesis whose
+ * count beats the threshold, :141-160) is the caller's loop. */
+void orc_sim3_ransac_eval(int n, const double *pc1, const double *pc2, const double *px1, const double *px2,
+                          const int32_t *maxerr1, const int32_t *maxerr2, const float cam[4], int K, const int32_t *triplets,
+                          int fix_scale, int32_t *counts, uint8_t *flags, double *sims) {
+  for (int k = 0; k < K; k++) {
+    double P1[9], P2[9], R[9], t[3], s;
+    for (int i = 0; i < 3; i++)
+      for (int a = 0; a < 3; a++) P1[3 * i + a] = pc1[3 * triplets[3 * k + i] + a], P2[3 * i + a] = pc2[3 * triplets[3 * k + i] + a];
+    orc_sim3_horn(P1, P2, fix_scale, R, t, &s);
+    /* T21 = T12^-1 (:250): s^-1 R^T, -s^-1 R^T t */
+    double Ri[9], ti[3];
+    const double si = 1.0 / s;
+    for (int a = 0; a < 3; a++)
+      for (int b = 0; b < 3; b++) Ri[3 * a + b] = R[3 * b + a];
+    for (int a = 0; a < 3; a++) ti[a] = -si * (Ri[3 * a] * t[0] + Ri[3 * a + 1] * t[1] + Ri[3 * a + 2] * t[2]);
+    int cnt = 0;
+    for (int i = 0; i < n; i++) {
+      double a1[2], a2[2];
+      sim3_project(R, t, s, pc2 + 3 * i, cam, a1);    /* points of frame 2 into image 1 */
+      sim3_project(Ri, ti, si, pc1 + 3 * i, cam, a2); /* points of frame 1 into image 2 */
+      const double d1x = px1[2 * i] - a1[0], d1y = px1[2 * i + 1] - a1[1];
+      const double d2x = px2[2 * i] - a2[0], d2y = px2[2 * i + 1] - a2[1];
+      const float err1 = (float)(d1x * d1x + d1y * d1y), err2 = (float)(d2x * d2x + d2y * d2y);
+      const int in = err1 < (float)maxerr1[i] && err2 < (float)maxerr2[i];
+      flags[(size_t)k * n + i] = (uint8_t)in;
+      cnt += in;
+    }
+    counts[k] = cnt;
+    memcpy(sims + 13 * (size_t)k, R, 72), memcpy(sims + 13 * (size_t)k + 9, t, 24), sims[13 * (size_t)k + 12] = s;
+  }
+}
+
+/* ---- N4: linear triangulation of localMapping.cpp:234-251: A (4 x 4, float) from the two normalised
+ * observations and the two 3 x 4 float poses, x = right singular vector of the smallest singular value
+ * (cv::SVD::compute(A, w, u, vt, MODIFY_A | FULL_UV); vt.row(3)), divided by its last entry.  The SVD is restated as
+ * the eigen-decomposition of A^T A in double (OpenCV's float one-sided Jacobi agrees to float rounding; parity is
+ * stated as a tolerance, not bit-exact).  Returns 0 when |x[3]| < 1e-8 (:245-246 `continue`). */
+int orc_triangulate(const float xn1[2], const float xn2[2], const float T1[12], const float T2[12], float out[3]) {
+  float A[4][4];
+  for (int c = 0; c < 4; c++) {
+    A[0][c] = xn1[0] * T1[8 + c] - T1[c];
+    A[1][c] = xn1[1] * T1[8 + c] - T1[4 + c];
+    A[2][c] = xn2[0] * T2[8 + c] - T2[c];
+    A[3][c] = xn2[1] * T2[8 + c] - T2[4 + c];
+  }
+  double G[4][4], V[4][4], w[4];
+  for (int a = 0; a < 4; a++)
+    for (int b = 0; b < 4; b++) {
+      G[a][b] = 0;
+      for (int r = 0; r < 4; r++) G[a][b] += (double)A[r][a] * (double)A[r][b];
+    }
+  sym4_eigen(G, V, w);
+  int best = 0;
+  for (int i = 1; i < 4; i++)
+    if (w[i] < w[best]) best = i;
+  const float x3 = (float)V[3][best];
+  if (fabsf(x3) < 1e-8f) return 0;
+  for (int a = 0; a < 3; a++) out[a] = (float)V[a][best] / x3;
+  return 1;
+}
+
+/* cv::cvtColor(CV_RGB2GRAY / CV_BGR2GRAY) for 8-bit images, OpenCV 3.x fixed point (visualOdometry.cpp:146-159):
+ * Y = (R * 4899 + G * 9617 + B * 1868 + 8192) >> 14.  `first_is_red` = the code was CV_RGB2GRAY. */
+void orc_rgb_to_gray(const uint8_t *src, int n_px, int channels, int first_is_red, uint8_t *dst) {
+  for (int i = 0; i < n_px; i++) {
+    const int c0 = src[(size_t)i * channels], c1 = src[(size_t)i * channels + 1], c2 = src[(size_t)i * channels + 2];
+    const int r = first_is_red ? c0 : c2, b = first_is_red ? c2 : c0;
+    dst[i] = (uint8_t)((r * 4899 + c1 * 9617 + b * 1868 + (1 << 13)) >> 14);
+  }
+}

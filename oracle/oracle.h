@@ -113,6 +113,16 @@ void orc_depth_to_float(const uint16_t *raw, int n, float inv_scale, float *out)
 /* MapPoint::computeDescriptor mappoint.cpp:118-179: index of the median-best descriptor, -1 if n == 0 */
 int orc_median_descriptor(const uint8_t *desc, int n);
 
+/* Sim3Solver (sim3Solver.cpp): Horn's closed form :179-252 and one RANSAC hypothesis per sample triplet with
+ * checkInliers :254-280 (integer thresholds, float pixel arithmetic); the sequential pick :141-160 is the caller's */
+void orc_sim3_horn(const double P1[9], const double P2[9], int fix_scale, double R[9], double t[3], double *s);
+void orc_sim3_ransac_eval(int n, const double *pc1, const double *pc2, const double *px1, const double *px2,
+                          const int32_t *maxerr1, const int32_t *maxerr2, const float cam[4], int K, const int32_t *triplets,
+                          int fix_scale, int32_t *counts, uint8_t *flags, double *sims);
+/* localMapping.cpp:234-251 (4 x 4 float SVD triangulation); visualOdometry.cpp:146-159 (cvtColor to grey) */
+int orc_triangulate(const float xn1[2], const float xn2[2], const float T1[12], const float T2[12], float out[3]);
+void orc_rgb_to_gray(const uint8_t *src, int n_px, int channels, int first_is_red, uint8_t *dst);
+
 /* Matcher::searchByProjection(Frame*,Frame*,radius,checkRot) matcher.cpp:18-148 on flat arrays.
  * Query i carries what the reference reads from frame_last/map point i (already projected):
  * valid[i], u,v (float pixel), invz, last octave, last angle, descriptor, claimed-feature mask is

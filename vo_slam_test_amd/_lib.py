@@ -43,6 +43,9 @@ SYMBOLS = [
     "vo_hamming_matrix_dev", "vo_hamming_matrix_batch_dev", "vo_hamming_matrix", "vo_median_descriptor",
     "vo_frames_create", "vo_frames_destroy", "vo_frames_capacity", "vo_frames_set_camera", "vo_frames_build_dev",
     "vo_frames_upload", "vo_frames_download", "vo_match_guided_dev", "vo_match_guided_status",
+    "vo_vocab_load", "vo_bow_score", "vo_sim3_ransac_eval", "vo_triangulate", "vo_rgb_to_gray", "vo_rgb_to_gray_dev",
+    "vo_dataset_open", "vo_dataset_size", "vo_dataset_entry", "vo_dataset_close", "vo_png_info", "vo_png_read",
+    "vo_trajectory_write", "vo_tracking_time_stats",
     "vo_track_project_dev", "vo_track_scatter_dev", "vo_track_gather_dev", "vo_pose_only_solve_ranges_dev",
     "vo_match_frame_projection", "vo_match_local_map", "vo_match_frame_keyframe", "vo_match_bow",
     "vo_match_triangulation", "vo_match_fuse", "vo_match_area_best", "vo_match_sim3_projection",
@@ -82,6 +85,10 @@ def lib():
         if f is not None and f.restype is C.c_int:
             f.restype = C.c_int
     L.vo_orb_destroy.restype = None
+    if hasattr(L, "vo_dataset_close"):
+        L.vo_dataset_close.restype = None
+    if hasattr(L, "vo_frames_destroy"):
+        L.vo_frames_destroy.restype = None
     if hasattr(L, "vo_ba_destroy"):
         L.vo_ba_destroy.restype = None
     if hasattr(L, "vo_vocab_destroy"):
@@ -732,3 +739,102 @@ def se3_log(R, t):
     Rf, tf = np.ascontiguousarray(R, np.float64).reshape(-1), np.ascontiguousarray(t, np.float64)
     check(lib().vo_se3_log(_p(Rf), _p(tf), _p(xi)))
     return xi
+
+
+# ----------------------------------------------------------------------------- loop closing / local mapping / harness I/O
+def sim3_ransac_eval(pc1, pc2, px1, px2, maxerr1, maxerr2, cam4, triplets, fix_scale=True, want_flags=True):
+    """Sim3Solver hypotheses (sim3Solver.cpp:98-280) in one launch -> (counts [K], flags [K, n], sims [K, 13])."""
+    a = [np.ascontiguousarray(v, np.float64) for v in (pc1, pc2, px1, px2)]
+    e1, e2 = np.ascontiguousarray(maxerr1, np.int32), np.ascontiguousarray(maxerr2, np.int32)
+    tr = np.ascontiguousarray(triplets, np.int32).reshape(-1, 3)
+    cam = np.ascontiguousarray(cam4, np.float32)
+    n, K = len(a[0]), len(tr)
+    counts, flags, sims = np.zeros(K, np.int32), np.zeros((K, max(n, 1)), np.uint8), np.zeros((K, 13))
+    check(lib().vo_sim3_ransac_eval(n, _p(a[0]), _p(a[1]), _p(a[2]), _p(a[3]), _p(e1), _p(e2), _p(cam), K, _p(tr),
+                                    int(bool(fix_scale)), _p(counts), _p(flags) if want_flags else None, _p(sims)),
+          "vo_sim3_ransac_eval")
+    return counts, flags[:, :n], sims
+
+
+def triangulate(xn1, xn2, Tcw1, Tcw2):
+    xn1, xn2 = np.ascontiguousarray(xn1, np.float32), np.ascontiguousarray(xn2, np.float32)
+    T1, T2 = np.ascontiguousarray(Tcw1, np.float32).reshape(12), np.ascontiguousarray(Tcw2, np.float32)
+    per_pair = T2.size > 12
+    n = len(xn1)
+    pts, ok = np.zeros((n, 3), np.float32), np.zeros(max(n, 1), np.uint8)
+    check(lib().vo_triangulate(n, _p(xn1), _p(xn2), _p(T1), _p(T2), int(per_pair), _p(pts), _p(ok)), "vo_triangulate")
+    return pts, ok[:n]
+
+
+def bow_score(query_words, query_values, cand_words_list, cand_values_list):
+    qw, qv = np.ascontiguousarray(query_words, np.int32), np.ascontiguousarray(query_values, np.float64)
+    start = np.zeros(len(cand_words_list) + 1, np.int32)
+    for i, w in enumerate(cand_words_list):
+        start[i + 1] = start[i] + len(w)
+    cw = np.ascontiguousarray(np.concatenate(cand_words_list) if start[-1] else np.zeros(0), np.int32)
+    cv = np.ascontiguousarray(np.concatenate(cand_values_list) if start[-1] else np.zeros(0), np.float64)
+    out = np.zeros(max(len(cand_words_list), 1))
+    check(lib().vo_bow_score(len(qw), _p(qw), _p(qv), len(cand_words_list), _p(start), _p(cw), _p(cv), _p(out)), "vo_bow_score")
+    return out[:len(cand_words_list)]
+
+
+def rgb_to_gray(img, first_is_red=True):
+    img = np.ascontiguousarray(img, np.uint8)
+    out = np.zeros(img.shape[:2], np.uint8)
+    check(lib().vo_rgb_to_gray(_p(img), C.c_longlong(out.size), img.shape[2], int(first_is_red), _p(out)), "vo_rgb_to_gray")
+    return out
+
+
+def load_vocabulary(path):
+    """DBoW3::Vocabulary(path) -> (Vocabulary handle wrapper, info dict)"""
+    h = C.c_void_p()
+    nn, nw, k, L = C.c_int(), C.c_int(), C.c_int(), C.c_int()
+    check(lib().vo_vocab_load(str(path).encode(), C.byref(h), C.byref(nn), C.byref(nw), C.byref(k), C.byref(L)), "vo_vocab_load")
+    v = Vocabulary.__new__(Vocabulary)
+    v._h = h
+    return v, dict(n_nodes=nn.value, n_words=nw.value, k=k.value, L=L.value)
+
+
+class Dataset:
+    """associate.txt of a TUM RGB-D sequence as test/vo_run.cpp:24-58 reads it."""
+
+    def __init__(self, dataset_dir, max_frames):
+        self._h = C.c_void_p()
+        check(lib().vo_dataset_open(C.byref(self._h), str(dataset_dir).encode(), int(max_frames)), "vo_dataset_open")
+
+    def __len__(self):
+        return lib().vo_dataset_size(self._h)
+
+    def __getitem__(self, i):
+        s = [C.c_char_p() for _ in range(4)]
+        check(lib().vo_dataset_entry(self._h, int(i), *[C.byref(x) for x in s]), "vo_dataset_entry")
+        return tuple(x.value.decode() for x in s)
+
+    def close(self):
+        if getattr(self, "_h", None) and self._h.value and _lib is not None:
+            _lib.vo_dataset_close(self._h)
+            self._h = C.c_void_p()
+
+    __del__ = close
+
+
+def read_png(path, as_bgr=False):
+    w, h, ch, bd = C.c_int(), C.c_int(), C.c_int(), C.c_int()
+    check(lib().vo_png_info(str(path).encode(), C.byref(w), C.byref(h), C.byref(ch), C.byref(bd)), "vo_png_info")
+    shape = (h.value, w.value) if ch.value == 1 else (h.value, w.value, ch.value)
+    out = np.zeros(shape, np.uint16 if bd.value == 16 else np.uint8)
+    check(lib().vo_png_read(str(path).encode(), int(as_bgr), _p(out), C.c_size_t(out.nbytes)), "vo_png_read")
+    return out
+
+
+def write_trajectory(path, timestamps, Twc7):
+    T = np.ascontiguousarray(Twc7, np.float64).reshape(-1, 7)
+    arr = (C.c_char_p * len(T))(*[str(t).encode() for t in timestamps])
+    check(lib().vo_trajectory_write(str(path).encode(), len(T), arr, _p(T)), "vo_trajectory_write")
+
+
+def tracking_time_stats(seconds):
+    s = np.ascontiguousarray(seconds, np.float64)
+    med, mean = C.c_double(), C.c_double()
+    check(lib().vo_tracking_time_stats(_p(s), len(s), C.byref(med), C.byref(mean)), "vo_tracking_time_stats")
+    return med.value, mean.value

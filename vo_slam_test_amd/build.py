@@ -27,6 +27,8 @@ SOURCES = [
     ("ba.hip", ["-ffp-contract=fast"]),
     ("pose_graph.hip", ["-ffp-contract=fast"]),
     ("chol.hip", ["-ffp-contract=fast"]),
+    ("loop.hip", ["-ffp-contract=off"]),
+    ("dataset_io.cpp", []),
 ]
 COMMON = ["-O3", "-std=c++17", f"--offload-arch={ARCH}", "-fPIC", "-Wall", "-Wno-unused-function"]
 
@@ -65,7 +67,7 @@ def build(force: bool = False, verbose: bool = False) -> pathlib.Path:
         if r.returncode != 0:
             raise RuntimeError(f"hipcc failed on {src}:\n{r.stdout}\n{r.stderr}")
         objs.append(str(o))
-    cmd = [cc, f"--offload-arch={ARCH}", "-shared", "-fPIC", "-o", str(OUT), *objs]
+    cmd = [cc, f"--offload-arch={ARCH}", "-shared", "-fPIC", "-o", str(OUT), *objs, "-lz"]
     r = subprocess.run(cmd, capture_output=True, text=True)
     if r.returncode != 0:
         raise RuntimeError(f"link failed:\n{r.stdout}\n{r.stderr}")

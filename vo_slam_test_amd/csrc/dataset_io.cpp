@@ -1,0 +1,375 @@
+// dataset_io.cpp -- the I/O contract of the reference's harness (test/vo_run.cpp) and its vocabulary file, as plain
+// host C++ behind the C-ABI (no OpenCV / DBoW3 in this image: PNG decoding is zlib + the five scan-line filters):
+//   associate.txt          vo_run.cpp:24-58   (`fin >> rgb_time >> rgb_file >> depth_time >> depth_file`, data_num records)
+//   cv::imread(rgb, 1) / cv::imread(depth, -1)  :108-109  8-bit colour as B, G, R / 16-bit depth as stored
+//   trajectory files       :154-232   `timestamp tx ty tz qx qy qz qw`, Eigen's default stream format
+//   tracking-time report   :138-151   median = sorted[tracked / 2], mean = total / tracked
+//   DBoW3::Vocabulary(path) :87       binary (.bin / .dbow3, DBoW3 0.0.1 Vocabulary::toStream layout) or the ORB-SLAM2
+//                                     text format -> flat tree arrays -> vo_vocab_create
+#include <zlib.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <fstream>
+#include <sstream>
+#include <string>
+#include <vector>
+
+#include "../../include/vo_hip.h"
+
+namespace vo {
+void set_error(const char *fmt, ...);
+}
+
+struct vo_dataset {
+  std::vector<std::string> rgb_time, rgb_path, depth_time, depth_path;
+};
+
+namespace {
+
+uint32_t be32(const uint8_t *p) { return ((uint32_t)p[0] << 24) | ((uint32_t)p[1] << 16) | ((uint32_t)p[2] << 8) | p[3]; }
+
+struct Png {
+  int w = 0, h = 0, depth = 0, color = 0, channels = 0;
+  std::vector<uint8_t> pixels;  // h * w * channels * (depth / 8), 16-bit samples big-endian as in the file
+  std::vector<uint8_t> palette;
+};
+
+int png_decode(const char *path, Png &P, bool header_only) {
+  std::ifstream f(path, std::ios::binary);
+  if (!f) {
+    vo::set_error("cannot open %s", path);
+    return VO_ERR_INVALID;
+  }
+  std::vector<uint8_t> buf((std::istreambuf_iterator<char>(f)), std::istreambuf_iterator<char>());
+  static const uint8_t sig[8] = {0x89, 'P', 'N', 'G', 0x0d, 0x0a, 0x1a, 0x0a};
+  if (buf.size() < 33 || memcmp(buf.data(), sig, 8) != 0) {
+    vo::set_error("%s is not a PNG file", path);
+    return VO_ERR_INVALID;
+  }
+  std::vector<uint8_t> idat;
+  size_t pos = 8;
+  int interlace = 0;
+  while (pos + 12 <= buf.size()) {
+    const uint32_t len = be32(&buf[pos]);
+    const char *type = reinterpret_cast<const char *>(&buf[pos + 4]);
+    if (pos + 12 + len > buf.size()) break;
+    const uint8_t *d = &buf[pos + 8];
+    if (!memcmp(type, "IHDR", 4)) {
+      P.w = (int)be32(d), P.h = (int)be32(d + 4), P.depth = d[8], P.color = d[9], interlace = d[12];
+      P.channels = P.color == 0 ? 1 : P.color == 2 ? 3 : P.color == 3 ? 1 : P.color == 4 ? 2 : 4;
+      if (header_only) return VO_OK;
+    } else if (!memcmp(type, "PLTE", 4)) {
+      P.palette.assign(d, d + len);
+    } else if (!memcmp(type, "IDAT", 4)) {
+      idat.insert(idat.end(), d, d + len);
+    } else if (!memcmp(type, "IEND", 4)) {
+      break;
+    }
+    pos += 12 + len;
+  }
+  const bool packed = P.depth < 8 && (P.color == 0 || P.color == 3);  // 1 / 2 / 4-bit grey or palette indices
+  if (P.w <= 0 || P.h <= 0 || interlace != 0 || (!packed && P.depth != 8 && P.depth != 16) ||
+      (packed && P.depth != 1 && P.depth != 2 && P.depth != 4) || (P.color == 3 && P.depth > 8)) {
+    vo::set_error("%s: unsupported PNG (interlaced, or bit depth %d)", path, P.depth);
+    return VO_ERR_INVALID;
+  }
+  const int bpp = packed ? 1 : P.channels * P.depth / 8;
+  const size_t stride = packed ? ((size_t)P.w * P.depth + 7) / 8 : (size_t)P.w * bpp;
+  std::vector<uint8_t> raw((stride + 1) * P.h);
+  uLongf out_len = (uLongf)raw.size();
+  if (uncompress(raw.data(), &out_len, idat.data(), (uLong)idat.size()) != Z_OK || out_len != raw.size()) {
+    vo::set_error("%s: corrupt PNG data stream", path);
+    return VO_ERR_INVALID;
+  }
+  P.pixels.assign(stride * P.h, 0);
+  std::vector<uint8_t> zero(stride, 0);
+  for (int y = 0; y < P.h; y++) {
+    const uint8_t ft = raw[(stride + 1) * y];
+    const uint8_t *in = &raw[(stride + 1) * y + 1];
+    uint8_t *cur = &P.pixels[stride * y];
+    const uint8_t *up = y ? cur - stride : zero.data();
+    for (size_t x = 0; x < stride; x++) {
+      const int a = x >= (size_t)bpp ? cur[x - bpp] : 0, b = up[x], c = x >= (size_t)bpp ? up[x - bpp] : 0;
+      int pred = 0;
+      switch (ft) {
+        case 0: pred = 0; break;
+        case 1: pred = a; break;
+        case 2: pred = b; break;
+        case 3: pred = (a + b) >> 1; break;
+        case 4: {
+          const int p = a + b - c, pa = std::abs(p - a), pb = std::abs(p - b), pc = std::abs(p - c);
+          pred = (pa <= pb && pa <= pc) ? a : (pb <= pc ? b : c);
+          break;
+        }
+        default:
+          vo::set_error("%s: bad PNG filter type %d", path, ft);
+          return VO_ERR_INVALID;
+      }
+      cur[x] = (uint8_t)(in[x] + pred);
+    }
+  }
+  if (packed) {  // unpack to one byte per sample (most significant bits first); grey is scaled to 0..255 like libpng's expansion
+    std::vector<uint8_t> un((size_t)P.w * P.h);
+    const int maxv = (1 << P.depth) - 1;
+    for (int y = 0; y < P.h; y++)
+      for (int x = 0; x < P.w; x++) {
+        const size_t bit = (size_t)x * P.depth;
+        const int v = (P.pixels[stride * y + bit / 8] >> (8 - P.depth - (int)(bit % 8))) & maxv;
+        un[(size_t)y * P.w + x] = (uint8_t)(P.color == 0 ? v * 255 / maxv : v);
+      }
+    P.pixels.swap(un);
+    P.depth = 8;
+  }
+  return VO_OK;
+}
+
+// `os << eigen_row_vector` with Eigen's default IOFormat: every coefficient printed with the stream's default
+// precision (6 significant digits, %g), padded on the left to the widest one, separated by one space
+std::string eigen_row(const double *v, int n) {
+  std::vector<std::string> s(n);
+  size_t w = 0;
+  for (int i = 0; i < n; i++) {
+    std::ostringstream o;
+    o << v[i];
+    s[i] = o.str();
+    w = std::max(w, s[i].size());
+  }
+  std::string out;
+  for (int i = 0; i < n; i++) {
+    if (i) out += " ";
+    out += std::string(w - s[i].size(), ' ') + s[i];
+  }
+  return out;
+}
+
+struct VocNode {
+  uint32_t id = 0, parent = 0, word_id = 0;
+  double weight = 0;
+  uint8_t desc[32];
+  std::vector<uint32_t> children;
+};
+
+int vocab_to_handle(std::vector<VocNode> &nodes, int L, vo_vocab **out, int *n_nodes, int *n_words) {
+  const int N = (int)nodes.size();
+  std::vector<int32_t> cs(N + 1, 0), ch, wid(N, -1);
+  std::vector<uint8_t> desc((size_t)N * 32, 0);
+  std::vector<double> wt(N, 0.0);
+  int words = 0;
+  for (int i = 0; i < N; i++) {
+    cs[i] = (int32_t)ch.size();
+    for (uint32_t c : nodes[i].children) ch.push_back((int32_t)c);
+    memcpy(&desc[(size_t)i * 32], nodes[i].desc, 32);
+    wt[i] = nodes[i].weight;
+    if (nodes[i].children.empty() && i > 0) wid[i] = (int32_t)nodes[i].word_id, words++;  // Node::isLeaf()
+  }
+  cs[N] = (int32_t)ch.size();
+  if (n_nodes) *n_nodes = N;
+  if (n_words) *n_words = words;
+  return vo_vocab_create(out, N, L, cs.data(), ch.data(), desc.data(), wt.data(), wid.data());
+}
+
+}  // namespace
+
+extern "C" {
+
+int vo_dataset_open(vo_dataset **out, const char *dataset_dir, int max_frames) {
+  if (!out || !dataset_dir) return VO_ERR_INVALID;
+  const std::string dir(dataset_dir);
+  std::ifstream fin(dir + "/associate.txt");
+  if (fin.fail()) {
+    vo::set_error("can't find associate file in %s", dataset_dir);  // vo_run.cpp:33-37
+    return VO_ERR_INVALID;
+  }
+  vo_dataset *d = new vo_dataset();
+  for (int i = 0; i < max_frames; i++) {  // :43-57, including its quirk: eof is only noticed before a read, so a file that
+    if (fin.eof()) break;                 // ends with a newline yields one last record of empty strings
+    std::string rt, rf, dt, df;
+    fin >> rt >> rf >> dt >> df;
+    d->rgb_time.push_back(rt), d->rgb_path.push_back(dir + rf);
+    d->depth_time.push_back(dt), d->depth_path.push_back(dir + df);
+  }
+  *out = d;
+  return VO_OK;
+}
+int vo_dataset_size(const vo_dataset *d) { return d ? (int)d->rgb_time.size() : 0; }
+int vo_dataset_entry(const vo_dataset *d, int i, const char **rgb_time, const char **rgb_path, const char **depth_time,
+                     const char **depth_path) {
+  if (!d || i < 0 || i >= (int)d->rgb_time.size()) return VO_ERR_INVALID;
+  if (rgb_time) *rgb_time = d->rgb_time[i].c_str();
+  if (rgb_path) *rgb_path = d->rgb_path[i].c_str();
+  if (depth_time) *depth_time = d->depth_time[i].c_str();
+  if (depth_path) *depth_path = d->depth_path[i].c_str();
+  return VO_OK;
+}
+void vo_dataset_close(vo_dataset *d) { delete d; }
+
+int vo_png_info(const char *path, int *width, int *height, int *channels, int *bit_depth) {
+  if (!path) return VO_ERR_INVALID;
+  Png P;
+  const int rc = png_decode(path, P, true);
+  if (rc != VO_OK) return rc;
+  if (width) *width = P.w;
+  if (height) *height = P.h;
+  if (channels) *channels = P.color == 3 ? 3 : P.channels;
+  if (bit_depth) *bit_depth = P.depth < 8 ? 8 : P.depth;
+  return VO_OK;
+}
+
+int vo_png_read(const char *path, int as_bgr, void *dst, size_t dst_bytes) {
+  if (!path || !dst) return VO_ERR_INVALID;
+  Png P;
+  const int rc = png_decode(path, P, false);
+  if (rc != VO_OK) return rc;
+  const size_t npx = (size_t)P.w * P.h;
+  if (P.depth == 16) {  // cv::imread(path, -1): samples as stored, host byte order
+    if (dst_bytes < npx * P.channels * 2) return VO_ERR_CAPACITY;
+    uint16_t *o = static_cast<uint16_t *>(dst);
+    for (size_t i = 0; i < npx * P.channels; i++) o[i] = (uint16_t)((P.pixels[2 * i] << 8) | P.pixels[2 * i + 1]);
+    return VO_OK;
+  }
+  uint8_t *o = static_cast<uint8_t *>(dst);
+  if (P.color == 3) {  // palette -> colour
+    if (dst_bytes < npx * 3) return VO_ERR_CAPACITY;
+    for (size_t i = 0; i < npx; i++) {
+      const uint8_t *c = &P.palette[3 * std::min<size_t>(P.pixels[i], P.palette.size() / 3 - 1)];
+      o[3 * i] = as_bgr ? c[2] : c[0], o[3 * i + 1] = c[1], o[3 * i + 2] = as_bgr ? c[0] : c[2];
+    }
+    return VO_OK;
+  }
+  if (dst_bytes < npx * P.channels) return VO_ERR_CAPACITY;
+  if (P.channels >= 3 && as_bgr) {  // cv::imread(path, 1) hands out B, G, R
+    for (size_t i = 0; i < npx; i++) {
+      const uint8_t *c = &P.pixels[i * P.channels];
+      o[i * P.channels] = c[2], o[i * P.channels + 1] = c[1], o[i * P.channels + 2] = c[0];
+      if (P.channels == 4) o[i * 4 + 3] = c[3];
+    }
+  } else {
+    memcpy(o, P.pixels.data(), npx * P.channels);
+  }
+  return VO_OK;
+}
+
+int vo_trajectory_write(const char *path, int n, const char *const *timestamps, const double *Twc7) {
+  if (!path || n < 0 || (n > 0 && (!timestamps || !Twc7))) return VO_ERR_INVALID;
+  std::ofstream f(path);
+  if (!f) {
+    vo::set_error("cannot write %s", path);
+    return VO_ERR_INVALID;
+  }
+  for (int i = 0; i < n; i++)  // :171-172 / :227-228: translation, then quaternion coefficients x y z w
+    f << timestamps[i] << " " << eigen_row(Twc7 + 7 * i, 3) << " " << eigen_row(Twc7 + 7 * i + 3, 4) << std::endl;
+  return VO_OK;
+}
+
+int vo_tracking_time_stats(const double *seconds, int n_tracked, double *median, double *mean) {
+  if (n_tracked < 1 || !seconds || !median || !mean) return VO_ERR_INVALID;
+  std::vector<double> t(seconds, seconds + n_tracked);
+  std::sort(t.begin(), t.end());  // :138-151
+  double total = 0;
+  for (double v : t) total += v;
+  *median = t[n_tracked / 2];
+  *mean = total / n_tracked;
+  return VO_OK;
+}
+
+int vo_vocab_load(const char *path, vo_vocab **out, int *n_nodes, int *n_words, int *branching_k, int *depth_L) {
+  if (!path || !out) return VO_ERR_INVALID;
+  std::ifstream f(path, std::ios::binary);
+  if (!f) {
+    vo::set_error("vocabulary file not exist: %s", path);  // vo_run.cpp:80-84
+    return VO_ERR_INVALID;
+  }
+  uint64_t sig = 0;
+  f.read(reinterpret_cast<char *>(&sig), 8);
+  std::vector<VocNode> nodes;
+  int k = 0, L = 0;
+  if (f && sig == 88877711233ULL) {
+    // DBoW3 0.0.1 Vocabulary::toStream: magic, bool compressed, uint32 node count; then k, L, scoring, weighting (ints)
+    // and per node: id, parent (uint32), weight (double), word id (uint32), descriptor (cols, rows, type, bytes)
+    char compressed = 0;
+    uint32_t nn = 0;
+    f.read(&compressed, 1);
+    f.read(reinterpret_cast<char *>(&nn), 4);
+    if (compressed) {
+      vo::set_error("%s: compressed DBoW3 vocabularies are not supported", path);
+      return VO_ERR_INVALID;
+    }
+    int32_t hdr[4];
+    f.read(reinterpret_cast<char *>(hdr), 16);
+    k = hdr[0], L = hdr[1];
+    nodes.resize(nn);
+    for (uint32_t i = 0; i < nn && f; i++) {
+      VocNode n;
+      int32_t cols = 0, rows = 0, type = 0;
+      f.read(reinterpret_cast<char *>(&n.id), 4);
+      f.read(reinterpret_cast<char *>(&n.parent), 4);
+      f.read(reinterpret_cast<char *>(&n.weight), 8);
+      f.read(reinterpret_cast<char *>(&n.word_id), 4);
+      f.read(reinterpret_cast<char *>(&cols), 4);
+      f.read(reinterpret_cast<char *>(&rows), 4);
+      f.read(reinterpret_cast<char *>(&type), 4);
+      memset(n.desc, 0, 32);
+      if (cols > 0) {
+        if ((type & 7) != 0 || cols != 32) {  // CV_8U, 32 bytes: ORB
+          vo::set_error("%s: node %u has a %d-column descriptor of type %d (need 32 x CV_8U)", path, n.id, cols, type);
+          return VO_ERR_INVALID;
+        }
+        f.read(reinterpret_cast<char *>(n.desc), 32);
+      }
+      if (n.id >= nn) {
+        vo::set_error("%s: node id %u out of range", path, n.id);
+        return VO_ERR_INVALID;
+      }
+      nodes[n.id] = n;
+    }
+    if (!f) {
+      vo::set_error("%s: truncated vocabulary", path);
+      return VO_ERR_INVALID;
+    }
+    for (uint32_t i = 1; i < nn; i++) nodes[nodes[i].parent].children.push_back(i);  // file order = id order
+  } else {
+    // ORB-SLAM2 text vocabulary: "k L scoring weighting", then one line per node: parent is_leaf 32 bytes weight
+    f.clear();
+    f.seekg(0);
+    int scoring = 0, weighting = 0;
+    std::string line;
+    if (!std::getline(f, line)) return VO_ERR_INVALID;
+    std::istringstream h(line);
+    if (!(h >> k >> L >> scoring >> weighting) || k < 1 || k > 20 || L < 1 || L > 10) {
+      vo::set_error("%s: neither a DBoW3 binary nor an ORB-SLAM2 text vocabulary", path);
+      return VO_ERR_INVALID;
+    }
+    nodes.resize(1);
+    uint32_t words = 0;
+    while (std::getline(f, line)) {
+      if (line.empty()) continue;
+      std::istringstream s(line);
+      VocNode n;
+      int parent = 0, leaf = 0;
+      s >> parent >> leaf;
+      for (int b = 0; b < 32; b++) {
+        int v = 0;
+        s >> v;
+        n.desc[b] = (uint8_t)v;
+      }
+      s >> n.weight;
+      if (!s || parent < 0 || parent >= (int)nodes.size()) {
+        vo::set_error("%s: malformed node line %zu", path, nodes.size());
+        return VO_ERR_INVALID;
+      }
+      n.id = (uint32_t)nodes.size(), n.parent = (uint32_t)parent;
+      if (leaf) n.word_id = words++;
+      nodes[parent].children.push_back(n.id);
+      nodes.push_back(n);
+    }
+  }
+  if (nodes.empty()) return VO_ERR_INVALID;
+  if (branching_k) *branching_k = k;
+  if (depth_L) *depth_L = L;
+  return vocab_to_handle(nodes, L, out, n_nodes, n_words);
+}
+
+}  // extern "C"
