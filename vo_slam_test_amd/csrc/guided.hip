@@ -449,12 +449,24 @@ __global__ __launch_bounds__(256) void k_guided_cand(FramesDev F, Queries Q, Gui
 }
 
 // One wavefront per frame: the sequential claim replay.  LDS: blocked[cap] bytes, assigned[cap] u16.  Everything a
-// decision needs rides in the records (distance, octave, rotation bin) and in the query record (count, observed flag):
-// the only memory round trips are the record loads, prefetched G queries ahead.
+// decision needs rides in the records (distance, octave, rotation bin) and in the query record (count, observed flag).
+// FOUR consecutive queries are replayed per step, one per 16-lane row (a query has a dozen gated candidates): each
+// row finds its best (and runner-up) under the blocked state at the start of the step; a later row whose candidate
+// list contains a feature that an earlier row of the same step claims is evaluated again after that claim -- so the
+// result is exactly the sequential loop's, while the common step costs two DPP row minima instead of four passes.
+// Claims are committed row by row in query order (assignments of a feature overwrite each other in that order).
+// LDS hand-off between the lanes of ONE wavefront: its LDS operations execute in order, so all that is needed is
+// that the compiler keeps them in order and that the writes have been issued.  (A wavefront-scope fence also waits
+// for vmcnt(0), i.e. for every prefetched global load in flight -- that alone made the replay memory-latency bound.)
+__device__ __forceinline__ void lds_handoff() {
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_wave_barrier();
+}
+
 __global__ __launch_bounds__(64) void k_guided_replay(FramesDev F, Queries Q, GuidedParams P, GuidedOut O, int slot0) {
   extern __shared__ __attribute__((aligned(16))) uint8_t rp_lds[];
   __shared__ int hist[32];
-  const int lane = threadIdx.x, f = blockIdx.x, s = slot0 + f;
+  const int lane = threadIdx.x, row = lane >> 4, l16 = lane & 15, f = blockIdx.x, s = slot0 + f;
   const int nf = F.n[s];
   const int nq = Q.nq ? Q.nq[f] : Q.nq_all;
   uint8_t *blocked = rp_lds;                                                       // [capA]
@@ -468,8 +480,7 @@ __global__ __launch_bounds__(64) void k_guided_replay(FramesDev F, Queries Q, Gu
     asg[i] = (unsigned short)(a + 1);
   }
   if (lane < 32) hist[lane] = 0;
-  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-  __builtin_amdgcn_wave_barrier();
+  lds_handoff();
   const uint2 *qrec = O.qrec + (long long)f * Q.stride;
   const unsigned *pool = O.pool + (long long)f * Q.stride * kSlot;
   const unsigned short *rkp = O.rank ? O.rank + (long long)f * Q.stride * kSlot : nullptr;
@@ -477,108 +488,135 @@ __global__ __launch_bounds__(64) void k_guided_replay(FramesDev F, Queries Q, Gu
   const unsigned short *ovr = O.ovf_rank ? O.ovf_rank + (long long)f * O.ovf_stride : nullptr;
   unsigned *pushes = O.pushes + (long long)f * Q.stride;
   const bool rot_on = P.check_rot && (P.mode == kModeFrame || P.mode == kModeKeyFrame);
+  const bool want2 = P.mode == kModeLocalMap;  // only the ratio test looks at the runner-up
   int cnt = 0, npush = 0;
-  // Software pipeline: the records of the NEXT group of G queries (and the query records of the next 64-query block)
-  // are in flight while the current group is replayed -- one wavefront per SIMD has nothing else to hide the memory
-  // round trip behind.
-  constexpr int G = 8;
-  struct Group { unsigned rec[G]; unsigned short rk[G]; int cn[G], oo[G], ob[G]; };
-  auto fetch = [&](Group &g, const uint2 &mine, int qb, int g0, int qe) {
-#pragma unroll
-    for (int k = 0; k < G; k++) {
-      const int ql = min(g0 + k, 63);
-      const unsigned cw = (unsigned)__builtin_amdgcn_readlane((int)mine.x, ql);
-      g.cn[k] = g0 + k < qe ? (int)(cw & 0x7fffffffu) : 0;
-      g.ob[k] = (int)(cw >> 31);
-      g.oo[k] = __builtin_amdgcn_readlane((int)mine.y, ql);
-      // records 0..31 sit in the query's slot, the rest in the overflow area
-      const long long sb = (long long)(qb + g0 + k) * kSlot;
-      g.rec[k] = lane < g.cn[k] ? (lane < kSlot ? pool[sb + lane] : ovf[g.oo[k] + lane - kSlot]) : 0u;
-      g.rk[k] = (rkp && lane < g.cn[k]) ? (lane < kSlot ? rkp[sb + lane] : ovr[g.oo[k] + lane - kSlot]) : (unsigned short)0;
-    }
+  constexpr unsigned kNone = 0xffffffffu;
+  // the records of a group: row r = query g0 + r, lane l16 = records l16 and 16 + l16 of its slot
+  struct Group { unsigned cw, oo, rec0, rec1; unsigned short rk0, rk1; };
+  auto fetch = [&](int g0) {
+    // every load is issued unconditionally (clamped addresses): the record loads must not wait for the count in the
+    // query record, or each fetch would cost two dependent round trips; entries past the count are masked at use
+    Group g{0u, 0u, 0u, 0u, 0, 0};
+    const int q = min(g0 + row, max(nq - 1, 0));
+    const uint2 qr = qrec[q];
+    const long long sb = (long long)q * kSlot;
+    g.rec0 = pool[sb + l16], g.rec1 = pool[sb + 16 + l16];
+    if (rkp) g.rk0 = rkp[sb + l16], g.rk1 = rkp[sb + 16 + l16];
+    g.cw = g0 + row < nq ? qr.x : 0u, g.oo = qr.y;
+    return g;
   };
-  uint2 mine = lane < nq ? qrec[lane] : make_uint2(0u, 0u);
-  Group cur, nxt;
-  fetch(cur, mine, 0, 0, min(64, nq));
-  for (int qb = 0; qb < nq; qb += 64) {
-    const int qe = min(64, nq - qb);
-    const uint2 mine_next = qb + 64 + lane < nq ? qrec[qb + 64 + lane] : make_uint2(0u, 0u);
-    for (int g0 = 0; g0 < 64; g0 += G) {
-      if (g0 + G < 64) fetch(nxt, mine, qb, g0 + G, qe);
-      else fetch(nxt, mine_next, qb + 64, 0, min(64, max(nq - qb - 64, 0)));
-#pragma unroll
-      for (int g = 0; g < G; g++) {
-        if (cur.cn[g] == 0) continue;  // uniform
-        const int q = qb + g0 + g;
-        // best and second over the unblocked records by (distance, position)
-        unsigned k1 = 0xffffffffu, k2 = 0xffffffffu, r1 = 0, r2 = 0;
-        for (int base = 0; base < cur.cn[g]; base += 64) {
-          unsigned rec = cur.rec[g];
-          unsigned short rk = cur.rk[g];
-          if (base > 0) {
-            rec = base + lane < cur.cn[g] ? ovf[cur.oo[g] + base + lane - kSlot] : 0u;
-            rk = (ovr && base + lane < cur.cn[g]) ? ovr[cur.oo[g] + base + lane - kSlot] : (unsigned short)0;
-          }
-          const bool have = base + lane < cur.cn[g];
-          const int idx = rec & 0x3fffu;
-          const bool skip = !have || (sim3 ? (rk < nf && blocked[rk]) : blocked[idx]);  // :422 indexes by the candidate counter
-          unsigned key = skip ? 0xffffffffu : (((rec >> 14) & 0x1ffu) << 16) | (unsigned)(base + lane);
-          const unsigned m1 = wave_min_u32(key);
-          if (m1 == 0xffffffffu) continue;
-          const int l1 = (int)(m1 & 0xffffu) - base;
-          const unsigned rr1 = (unsigned)__builtin_amdgcn_readlane((int)rec, l1);
-          unsigned m2 = 0xffffffffu, rr2 = 0;
-          if (P.mode == kModeLocalMap) {  // only the ratio test looks at the runner-up
-            if (lane == l1) key = 0xffffffffu;
-            m2 = wave_min_u32(key);
-            if (m2 != 0xffffffffu) rr2 = (unsigned)__builtin_amdgcn_readlane((int)rec, (int)(m2 & 0xffffu) - base);
-          }
-          // merge (k1, k2) with (m1, m2): all keys distinct by position
-          if (m1 < k1) {
-            if (k1 < m2) k2 = k1, r2 = r1; else k2 = m2, r2 = rr2;
-            k1 = m1, r1 = rr1;
-          } else {
-            if (m1 < k2) k2 = m1, r2 = rr1;
-          }
+  // D groups (16 queries) are in flight while D others are replayed: with one wavefront per SIMD nothing else hides
+  // the ~1.5 us of a record fetch, and a group takes a fraction of that to replay
+  constexpr int D = 4;
+  auto replay_group = [&](const Group &g, int g0) {
+    const int cn = (int)(g.cw & 0x7fffffffu), ob = (int)(g.cw >> 31);
+    const int cmax = ~(int)wave_min_u32(~(unsigned)cn);
+    if (cmax == 0) return;  // uniform
+    const int nch = (cmax + 15) >> 4;
+    unsigned pending;
+    {
+      const unsigned long long m = __builtin_amdgcn_ballot_w64(cn > 0);
+      pending = (unsigned)((m & 1ull) | ((m >> 15) & 2ull) | ((m >> 30) & 4ull) | ((m >> 45) & 8ull));
+    }
+    while (pending != 0u) {  // uniform
+      const bool mine = (pending >> row) & 1u;
+      unsigned k1 = kNone, k2 = kNone, r1 = 0, r2 = 0;
+      for (int c = 0; c < nch; c++) {
+        unsigned rec = c == 0 ? g.rec0 : g.rec1;
+        unsigned short rk = c == 0 ? g.rk0 : g.rk1;
+        const int pos = 16 * c + l16;
+        if (c >= 2) {  // beyond the query's slot: the overflow area (dense windows only)
+          rec = pos < cn ? ovf[g.oo + pos - kSlot] : 0u;
+          rk = (ovr && pos < cn) ? ovr[g.oo + pos - kSlot] : (unsigned short)0;
         }
-        if (k1 == 0xffffffffu) continue;
-        const int best = (int)(k1 >> 16), bidx = (int)(r1 & 0x3fffu);
-        bool accept;
+        const int idx = rec & 0x3fffu;
+        const bool skip = !mine || pos >= cn || (sim3 ? (rk < nf && blocked[rk]) : blocked[idx]);  // :422 indexes by the candidate counter
+        unsigned key = skip ? kNone : (((rec >> 14) & 0x1ffu) << 16) | (unsigned)pos;
+        const unsigned m1 = row_min_u32(key);
+        const unsigned rr1 = (unsigned)__shfl((int)rec, (lane & 48) | (int)(m1 & 15u));
+        unsigned m2 = kNone, rr2 = 0;
+        if (want2) {
+          if (key == m1) key = kNone;
+          m2 = row_min_u32(key);
+          rr2 = (unsigned)__shfl((int)rec, (lane & 48) | (int)(m2 & 15u));
+        }
+        if (m1 < k1) {  // merge (k1, k2) with (m1, m2): all keys distinct by position
+          if (k1 < m2) k2 = k1, r2 = r1; else k2 = m2, r2 = rr2;
+          k1 = m1, r1 = rr1;
+        } else if (m1 < k2) {
+          k2 = m1, r2 = rr1;
+        }
+      }
+      const int best = (int)(k1 >> 16), bidx = (int)(r1 & 0x3fffu);
+      bool accept = k1 != kNone;
+      if (accept) {
         if (P.mode == kModeFrame) accept = best <= TH_HIGH;
         else if (P.mode == kModeLocalMap) {
           accept = best <= TH_HIGH;
-          if (accept && k2 != 0xffffffffu) {
+          if (accept && k2 != kNone) {
             const int second = (int)(k2 >> 16);
             const int lv1 = (int)((r1 >> 23) & 0xfu), lv2 = (int)((r2 >> 23) & 0xfu);
             if (lv1 == lv2 && (float)best > P.ratio * (float)second) accept = false;  // :344
           }
         } else if (P.mode == kModeKeyFrame) accept = (float)best <= P.dist_threshold;  // :238
         else accept = best <= TH_LOW;                                                  // :437
-        if (!accept) continue;
-        if (lane == 0) {
-          asg[bidx] = (unsigned short)(q + 1);
-          if (P.mode == kModeFrame || P.mode == kModeLocalMap) blocked[bidx] = (uint8_t)cur.ob[g];  // :110-113
-          else blocked[bidx] = 1;
-        }
-        cnt++;
-        if (rot_on) {  // :115-125
-          const int bin = (int)(r1 >> 27);
-          if (lane == 0) {
-            pushes[npush] = (unsigned)bidx | ((unsigned)bin << 16);
-            hist[bin]++;
-          }
-          npush++;
-        }
-        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-        __builtin_amdgcn_wave_barrier();
       }
-      cur = nxt;
-      if (qb + g0 + G >= nq) break;  // uniform
+      const int blocks = (P.mode == kModeFrame || P.mode == kModeLocalMap) ? ob : 1;  // what the claim writes into blocked[] (:110-113)
+      // a later pending row is stale if an earlier pending row of this step blocks a feature on its list
+      bool stale = false;
+#pragma unroll
+      for (int r = 0; r < 3; r++) {
+        const int a_r = __builtin_amdgcn_readlane((int)(accept && mine), 16 * r);
+        const int b_r = __builtin_amdgcn_readlane(bidx, 16 * r), bl_r = __builtin_amdgcn_readlane(blocks, 16 * r);
+        if (!(a_r && bl_r)) continue;  // uniform
+        if (row > r && mine) {
+          const unsigned key0 = sim3 ? g.rk0 : (g.rec0 & 0x3fffu), key1 = sim3 ? g.rk1 : (g.rec1 & 0x3fffu);
+          if ((l16 < cn && key0 == (unsigned)b_r) || (16 + l16 < cn && key1 == (unsigned)b_r) || cn > 32) stale = true;
+        }
+      }
+      const unsigned long long sm = __builtin_amdgcn_ballot_w64(stale);
+      int first_stale = 4;
+      if (sm & 0xffff000000000000ull) first_stale = 3;
+      if (sm & 0x0000ffff00000000ull) first_stale = 2;
+      if (sm & 0x00000000ffff0000ull) first_stale = 1;
+      // commit the rows in front of the first stale one, in query order
+#pragma unroll
+      for (int r = 0; r < 4; r++) {
+        if (r >= first_stale || !((pending >> r) & 1u)) continue;  // uniform
+        const int a_r = __builtin_amdgcn_readlane((int)accept, 16 * r);
+        if (a_r) {
+          const int b_r = __builtin_amdgcn_readlane(bidx, 16 * r), bl_r = __builtin_amdgcn_readlane(blocks, 16 * r);
+          const int bin = (int)((unsigned)__builtin_amdgcn_readlane((int)r1, 16 * r) >> 27);
+          if (lane == 0) {
+            asg[b_r] = (unsigned short)(g0 + r + 1);
+            blocked[b_r] = (uint8_t)bl_r;
+            if (rot_on) {  // :115-125
+              pushes[npush] = (unsigned)b_r | ((unsigned)bin << 16);
+              hist[bin]++;
+            }
+          }
+          cnt++;
+          if (rot_on) npush++;
+        }
+        pending &= ~(1u << r);
+      }
+      lds_handoff();
     }
-    mine = mine_next;
+  };
+  Group nxt[D];
+#pragma unroll
+  for (int d = 0; d < D; d++) nxt[d] = fetch(4 * d);
+  for (int gb = 0; gb < nq; gb += 4 * D) {
+    Group cur[D];
+#pragma unroll
+    for (int d = 0; d < D; d++) cur[d] = nxt[d];
+#pragma unroll
+    for (int d = 0; d < D; d++) nxt[d] = fetch(gb + 4 * D + 4 * d);
+#pragma unroll
+    for (int d = 0; d < D; d++)
+      if (gb + 4 * d < nq) replay_group(cur[d], gb + 4 * d);  // uniform
   }
-  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-  __builtin_amdgcn_wave_barrier();
+  lds_handoff();
   if (npush > 0) {  // computeThreeMax (:1258-1304) + pruning (:128-145)
     int m1 = 0, m2 = 0, m3 = 0, i1 = -1, i2 = -1, i3 = -1;
     for (int i = 0; i < HISTO_LENGTH; i++) {
@@ -602,8 +640,7 @@ __global__ __launch_bounds__(64) void k_guided_replay(FramesDev F, Queries Q, Gu
       }
       cnt -= __popcll(__builtin_amdgcn_ballot_w64(drop));
     }
-    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-    __builtin_amdgcn_wave_barrier();
+    lds_handoff();
   }
   for (int i = lane; i < nf; i += 64) assigned[i] = (int)asg[i] - 1;
   if (lane == 0) O.n_matches[f] = cnt;

@@ -1272,24 +1272,32 @@ constexpr int kWinBytes = 40 * 64;  // 39 rows, rounded up to a multiple of 4 la
 // address is simply 16 lane + 1024 j.  Rows past the window repeat its last row.  Returns the column of
 // `origin` in the staged rows (0..15).  The memory pipe spends the same 16 cycles on a wavefront's byte
 // gather as on these 1 KB loads: staging cuts its work per key-point by 4x.
-template <int ROWS>
-__device__ __forceinline__ void window_issue(unsigned long long origin, int pitch, int lane, u32x4 (&v)[(ROWS + 15) / 16], int &ox) {
-  constexpr int NJ = (ROWS + 15) / 16;
+// CH: 16-byte chunks fetched per row.  Three cover 48 bytes: enough for the 31-pixel orientation window at any
+// alignment (15 + 31 <= 48) and for the 39-pixel descriptor window when it starts in the first ten bytes of its
+// chunk (9 + 39 <= 48) -- the kernel is bound by the bytes its loads pull through the texture path (TA busy ~80 %),
+// so the fourth chunk is only fetched when a window needs it.
+template <int ROWS, int CH>
+__device__ __forceinline__ void window_issue(unsigned long long origin, int pitch, int lane, u32x4 (&v)[(ROWS * CH + 63) / 64], int &ox) {
+  constexpr int NJ = (ROWS * CH + 63) / 64;
   ox = uni_i32((int)(unsigned)origin & 15);
   gmem_u8 *base = uni_ptr(origin) - ox;
 #pragma unroll
   for (int j = 0; j < NJ; j++) {
-    const int row = (j + 1) * 16 <= ROWS ? (lane >> 2) + 16 * j : min((lane >> 2) + 16 * j, ROWS - 1);
-    const unsigned goff = (unsigned)(row * pitch + 16 * (lane & 3));
+    const int idx = lane + 64 * j;
+    const int row = min(CH == 4 ? idx >> 2 : idx / 3, ROWS - 1), chunk = CH == 4 ? idx & 3 : idx % 3;
+    const unsigned goff = (unsigned)(row * pitch + 16 * chunk);
     v[j] = *reinterpret_cast<const __attribute__((address_space(1))) u32x4 *>(base + goff);
   }
 }
-template <int NJ>
+template <int ROWS, int CH, int NJ>
 __device__ __forceinline__ void window_store(lds_u8 *slot, int lane, const u32x4 (&v)[NJ]) {
 #pragma unroll
-  for (int j = 0; j < NJ; j++)
-    if (16 * lane + 1024 * j < kWinBytes)  // the slot ends after row 39 (a predicate on the last store only)
-      *(__attribute__((address_space(3))) u32x4 *)(slot + 16 * lane + 1024 * j) = v[j];
+  for (int j = 0; j < (ROWS * CH + 63) / 64; j++) {
+    const int idx = lane + 64 * j;
+    const int row = CH == 4 ? idx >> 2 : idx / 3, chunk = CH == 4 ? idx & 3 : idx % 3;
+    if (row < kWinBytes / kWinPitch)  // the slot ends after row 39 (lanes past the window repeat its last row: harmless)
+      *(__attribute__((address_space(3))) u32x4 *)(slot + kWinPitch * row + 16 * chunk) = v[j];
+  }
 }
 
 #ifndef VO_DESC_NK
@@ -1381,7 +1389,7 @@ __global__ __launch_bounds__(256) void k_describe(OrbDev P, FrameSrc src, const 
       const int kk = min(k + s, k1 - 1);  // uniform; past the end the last key-point is redone (not stored)
       staged[s] = uni_i32(rec[kk].bytewise) == 0;
       if (staged[s]) {
-        window_issue<2 * kHalfPatch + 1>(rec[kk].disc_base, uni_i32(rec[kk].pitch), lane, wv[s], ox[s]);
+        window_issue<2 * kHalfPatch + 1, 3>(rec[kk].disc_base, uni_i32(rec[kk].pitch), lane, wv[s], ox[s]);
       } else {  // byte gathers straight from the caller's image
         gmem_u8 *base = uni_ptr(rec[kk].disc_base);
         const int pp = uni_i32(rec[kk].pitch);
@@ -1394,7 +1402,7 @@ __global__ __launch_bounds__(256) void k_describe(OrbDev P, FrameSrc src, const 
     }
 #pragma unroll
     for (int s = 0; s < NK; s++)
-      if (staged[s]) window_store<2>((lds_u8 *)win_lds[wave][s], lane, wv[s]);
+      if (staged[s]) window_store<2 * kHalfPatch + 1, 3>((lds_u8 *)win_lds[wave][s], lane, wv[s]);
     wave_sync();
 #pragma unroll
     for (int s = 0; s < NK; s++)
@@ -1452,13 +1460,29 @@ __global__ __launch_bounds__(256) void k_describe(OrbDev P, FrameSrc src, const 
   for (int k = k0; k < k1; k += NK) {
     u32x4 wv[NK][3];
     int ox[NK];
+    bool narrow[NK];
 #pragma unroll
     for (int s = 0; s < NK; s++) {
       const int kk = min(k + s, k1 - 1);
-      window_issue<2 * kEdge + 1>(rec[kk].blur_base, uni_i32(rec[kk].bpitch), lane, wv[s], ox[s]);
+      const unsigned long long bb = rec[kk].blur_base;
+      narrow[s] = uni_i32((int)(unsigned)bb & 15) <= 48 - (2 * kEdge + 1);  // uniform: three chunks per row suffice
+      if (narrow[s]) {
+        u32x4 w2[2];
+        window_issue<2 * kEdge + 1, 3>(bb, uni_i32(rec[kk].bpitch), lane, w2, ox[s]);
+        wv[s][0] = w2[0], wv[s][1] = w2[1];
+      } else {
+        window_issue<2 * kEdge + 1, 4>(bb, uni_i32(rec[kk].bpitch), lane, wv[s], ox[s]);
+      }
     }
 #pragma unroll
-    for (int s = 0; s < NK; s++) window_store<3>((lds_u8 *)win_lds[wave][s], lane, wv[s]);
+    for (int s = 0; s < NK; s++) {
+      if (narrow[s]) {
+        const u32x4 w2[2] = {wv[s][0], wv[s][1]};
+        window_store<2 * kEdge + 1, 3>((lds_u8 *)win_lds[wave][s], lane, w2);
+      } else {
+        window_store<2 * kEdge + 1, 4>((lds_u8 *)win_lds[wave][s], lane, wv[s]);
+      }
+    }
     wave_sync();
     uint32_t t[NK][8];
 #pragma unroll
