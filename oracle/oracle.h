@@ -72,6 +72,9 @@ float orc_ic_angle(const uint8_t *img, int stride, int px, int py, const int *um
 void orc_orb_descriptor(const uint8_t *blur, int stride, int px, int py, float angle_deg,
                         const int8_t *pattern, uint8_t *desc32);
 
+void orc_orb_descriptor_libm(const uint8_t *blur, int stride, int px, int py, float angle_deg,
+                             const int8_t *pattern, uint8_t *desc32); /* glibc cosf / sinf variant (measurement only) */
+
 /* Full ORBextractor::operator() (:1051-1112).  kps/desc sized for `cap` key-points.
  * If pyr_out != NULL it receives nlevels pointers to malloc'ed unpadded level images (caller frees)
  * and blur_out likewise.  Returns number of key-points or <0 on error. */

@@ -744,6 +744,28 @@ void orc_orb_descriptor(const uint8_t *blur, int stride, int px, int py, float a
   }
 }
 
+/* the same with glibc's cosf / sinf, what a reference binary calls (:114-115): used to MEASURE how many descriptor
+ * bytes the correctly-rounded contract above can change (tests/test_oracle_orb.py) */
+void orc_orb_descriptor_libm(const uint8_t *blur, int stride, int px, int py, float angle_deg,
+                             const int8_t *pattern, uint8_t *desc32) {
+  const float factorPI = (float)(3.1415926535897932384626433832795 / 180.f);
+  float angle = angle_deg * factorPI;
+  float a, b;
+  orc_cos_sin_f_libm(angle, &a, &b);
+  const uint8_t *center = blur + (size_t)py * stride + px;
+  for (int i = 0; i < 32; ++i) {
+    int val = 0;
+    for (int t = 0; t < 8; t++) {
+      const int8_t *pp = pattern + (i * 16 + t * 2) * 2;
+      float x0 = (float)pp[0], y0 = (float)pp[1], x1 = (float)pp[2], y1 = (float)pp[3];
+      int t0 = center[orc_cv_round_f(x0 * b + y0 * a) * stride + orc_cv_round_f(x0 * a - y0 * b)];
+      int t1 = center[orc_cv_round_f(x1 * b + y1 * a) * stride + orc_cv_round_f(x1 * a - y1 * b)];
+      val |= (t0 < t1) << t;
+    }
+    desc32[i] = (uint8_t)val;
+  }
+}
+
 /* ------------------------------------------------------------------ E9 ---- */
 /* ORBextractor::operator(), ORBextractor.cpp:1051-1112 (+ComputePyramid :1115-1142,
  * ComputeKeyPointsOctTree :771-861).  The 19-px REFLECT_101 padding of each level is never read by

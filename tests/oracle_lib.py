@@ -104,6 +104,7 @@ def lib():
     L.orc_ic_angle.argtypes = [_u8p, C.c_int, C.c_int, C.c_int, _i32p]
     L.orc_ic_angle.restype = C.c_float
     L.orc_orb_descriptor.argtypes = [_u8p, C.c_int, C.c_int, C.c_int, C.c_float, _i8p, _u8p]
+    L.orc_orb_descriptor_libm.argtypes = [_u8p, C.c_int, C.c_int, C.c_int, C.c_float, _i8p, _u8p]
     L.orc_orb_extract.argtypes = [C.POINTER(OrbParams), _u8p, C.c_int, C.c_int, C.c_int, C.c_void_p, _u8p, C.c_int, _i32p]
     L.orc_orb_extract.restype = C.c_int
     L.orc_hamming256.argtypes = [_u8p, _u8p]
