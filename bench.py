@@ -165,6 +165,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch", type=int, default=1024, help="frames per GPU per step (resident in HBM; throughput saturates near 1024: "
                                                              "188 k frames/s at 64, 246 k at 256, 268 k at 512, 275 k at 1024, 278 k at 2048)")
+    ap.add_argument("--pipeline", type=int, default=2, help="batches in flight: the issue-bound extraction of one batch runs on a "
+                    "shared stream next to the latency-bound searches / pose solves (one wavefront per frame, high-priority "
+                    "streams) of the previous ones; 1 = everything on one stream")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-ba", action="store_true")
     ap.add_argument("--no-bruteforce", action="store_true", help="skip the extract + all-pairs Hamming measurement (configs[1] as written)")
@@ -205,8 +208,10 @@ def main():
     frames_np = np.stack([uniq[i % n_unique] for i in range(B)])
     inv_depth = float(np.float32(1.0) / np.float32(synth.DEPTH_SCALE))
     cam5 = synth.CAM.astype(np.float32)
-    stream = torch.cuda.Stream()
-    ext = vo.OrbExtractor(1000, 1.2, 8, 20, 7)
+    n_pipe = max(1, args.pipeline)
+    stream = torch.cuda.Stream()           # extraction (shared by the batches in flight); also the brute-force leg
+    exts = [vo.OrbExtractor(1000, 1.2, 8, 20, 7) for _ in range(n_pipe)]
+    ext = exts[0]
     ext.set_stream(stream.cuda_stream)
     cap = ext.max_keypoints()
     NM = 1000
@@ -217,9 +222,16 @@ def main():
     # ---- the map every frame is tracked against (resident in HBM, like the frames): built once from the features of the
     # unique frames -- last frame's map points = the frame's own features back-projected with their depth, local map = two
     # noisy copies of them (synth.make_tracking_map); TUM fr1 distortion coefficients (example.yaml:25-29)
-    trk = BatchTracker(B, ext, cam5, synth.DIST, W, H, n_last=1100, n_local=2200, stream=stream)
+    if n_pipe == 1:
+        trks = [BatchTracker(B, ext, cam5, synth.DIST, W, H, n_last=1100, n_local=2200, stream=stream)]
+    else:
+        trks = [BatchTracker(B, e, cam5, synth.DIST, W, H, n_last=1100, n_local=2200, stream=torch.cuda.Stream(priority=-1),
+                             extract_stream=stream) for e in exts]
+    trk = trks[0]
     with torch.cuda.stream(stream):
         ext.extract_batch_dev(frames[:n_unique], trk.kps[:n_unique], trk.desc[:n_unique], trk.cnt[:n_unique])
+    torch.cuda.synchronize()
+    with torch.cuda.stream(stream):
         trk.frames.build_dev(trk.kps[:n_unique], trk.desc[:n_unique], trk.cnt[:n_unique], depth[:n_unique], inv_depth,
                              stream=stream.cuda_stream)
     torch.cuda.synchronize()
@@ -240,29 +252,54 @@ def main():
                 angle=stack(2, "angle", 1100), desc=stack(2, "desc", 1100, (32,)))
     local = {k: stack(3, k, 2200, (3,) if k == "points" else (32,) if k == "desc" else ())
              for k in ("points", "flags", "u", "v", "ur", "level", "viewcos", "desc")}
-    with torch.cuda.stream(stream):
-        trk.set_map(np.stack([maps[f % n_unique][0] for f in range(B)]), np.stack([maps[f % n_unique][1] for f in range(B)]),
-                    last, local)
+    Tcw_all = np.stack([maps[f % n_unique][0] for f in range(B)])
+    pose_all = np.stack([maps[f % n_unique][1] for f in range(B)])
+    for t in trks:
+        with torch.cuda.stream(t.stream):
+            t.set_map(Tcw_all, pose_all, last, local)
+    torch.cuda.synchronize()
     n_q0 = float(np.mean([(m[2]["flags"] & 1).sum() for m in maps]))
     n_q1 = float(np.mean([(m[3]["flags"] & 1).sum() for m in maps]))
     trk_ev = []
+    n_steps_done = [0]
 
-    def step(timed=False):
-        evs = trk.track(frames, depth, inv_depth, events=timed, keep_first=not timed)
+    def step(timed=False, only=None, sink=None):
+        """one batch of B frames through the tracked-frame path; consecutive steps alternate between the batches in flight"""
+        t = trks[n_steps_done[0] % n_pipe] if only is None else only
+        n_steps_done[0] += 1
+        evs = t.track(frames, depth, inv_depth, events=timed, keep_first=not timed)
         if timed:
-            trk_ev.append(evs)
+            (trk_ev if sink is None else sink).append(evs)
 
-    for _ in range(args.warmup):
+    for _ in range(max(args.warmup, n_pipe)):
         step()
     barrier()
-    ext.sync()
-    trk.frames.match_status(stream=stream.cuda_stream)
-    counts = trk.cnt.cpu().numpy()
-    assert counts.min() >= NM, f"synthetic frames must yield >= {NM} key-points, got {counts.min()}"
-    ninl = trk.ninl.cpu().numpy()
-    assert ninl.min() >= 100, f"tracking must keep >= 100 pose inliers per frame, got {ninl.min()}"
+    for t in trks:
+        t.ext.sync()
+        t.frames.match_status(stream=t.st)
+        counts = t.cnt.cpu().numpy()
+        assert counts.min() >= NM, f"synthetic frames must yield >= {NM} key-points, got {counts.min()}"
+        ninl = t.ninl.cpu().numpy()
+        assert ninl.min() >= 100, f"tracking must keep >= 100 pose inliers per frame, got {ninl.min()}"
     ncand = sum(len(ext.get_candidates(0, l)[0]) for l in range(8))
+    # reference point: the same step with nothing overlapped (one batch in flight)
+    barrier()
     ext.set_timing(True)
+    ts0 = time.perf_counter()
+    n_serial = max(3, args.steps // 4)
+    serial_ev = []
+    for _ in range(n_serial):
+        step(timed=True, only=trk, sink=serial_ev)
+        torch.cuda.synchronize()
+    serial_ms = (time.perf_counter() - ts0) / n_serial * 1e3
+    sm, nc = ext.get_timing()
+    ext.set_timing(False)
+    serial_stage_ms = {k: v / max(nc, 1) for k, v in sm.items()}
+    for name in ("frame_post", "match_last_frame", "pose_only_1", "match_local_map", "pose_only_2"):
+        serial_stage_ms[name] = float(np.mean([e[name][0].elapsed_time(e[name][1]) for e in serial_ev]))
+    for e in exts:
+        e.set_timing(True)
+    n_steps_done[0] = 0
     barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
@@ -273,8 +310,13 @@ def main():
     if dist is not None:
         dist.all_reduce(el, op=dist.ReduceOp.MAX)
     elapsed = float(el.item())
-    stage_ms, ncalls = ext.get_timing()
-    ext.set_timing(False)
+    stage_ms, ncalls = {}, 0
+    for e in exts:
+        sm, nc = e.get_timing()
+        e.set_timing(False)
+        ncalls += nc
+        for k, v in sm.items():
+            stage_ms[k] = stage_ms.get(k, 0.0) + v
     stage_ms = {k: v / max(ncalls, 1) for k, v in stage_ms.items()}
     for name in ("frame_post", "match_last_frame", "pose_only_1", "match_local_map", "pose_only_2"):
         stage_ms[name] = float(np.mean([e[name][0].elapsed_time(e[name][1]) for e in trk_ev]))
@@ -295,9 +337,14 @@ def main():
             traffic = json.loads(tf.read_text()).get(dom)
         except Exception:
             traffic = None
+    alone = sb[dom] * B / (serial_stage_ms[dom] * 1e-3) / 1e9
     roofline = {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
                 "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
-                "bytes_per_launch": sb[dom] * B, "avg_launch_ms": round(stage_ms[dom], 4)}
+                "bytes_per_launch": sb[dom] * B, "avg_launch_ms": round(stage_ms[dom], 4),
+                "alone": {"avg_launch_ms": round(serial_stage_ms[dom], 4), "achieved": round(alone, 2),
+                          "frac": round(alone / HBM_PEAK_GBS, 5),
+                          "note": "the same stage with one batch in flight; in the timed region the other batch's kernels share "
+                                  "the CUs with it, which stretches every launch while the step gets shorter"}}
     stage_gbs = {k: round(sb[k] * B / (stage_ms[k] * 1e-3) / 1e9, 1) for k in hbm_stages if stage_ms[k] > 0}
     # pose-only stages are FP64-latency bound: report their flop rate (~270 flop per observation and iteration)
     po_iters = 20.0
@@ -320,7 +367,13 @@ def main():
                    "frames_per_gpu_per_step": B, "keypoints_per_frame": float(counts.mean()),
                    "fast_candidates_per_frame": ncand, "last_frame_queries": round(n_q0, 1), "local_map_queries": round(n_q1, 1),
                    "matches_last_frame": round(n_match0, 1), "pose_observations": round(n_obs2, 1),
-                   "pose_inliers": float(ninl.mean()), "parallelism": f"frames sharded x{world}, no collective"},
+                   "pose_inliers": float(ninl.mean()), "parallelism": f"frames sharded x{world}, no collective",
+                   "batches_in_flight": n_pipe},
+        "one_batch_in_flight": {"ms_per_step": round(serial_ms, 4), "frames_per_s": round(B / serial_ms * 1e3, 1),
+                                "stage_ms_per_launch": {k: round(v, 4) for k, v in serial_stage_ms.items()},
+                                "note": "the same step with a host synchronisation after every batch (nothing overlapped); "
+                                        "stage_ms_per_launch at the top level is measured inside the timed region, i.e. with the "
+                                        "other batch's kernels running next to each launch when batches_in_flight > 1"},
         "roofline": roofline,
         "stage_ms_per_launch": {k: round(v, 4) for k, v in stage_ms.items()},
         "stage_algorithmic_GBps": stage_gbs,
@@ -634,7 +687,10 @@ def main():
             cpu["all_cores"] = {"error": repr(exc)}
         cpu["host"] = {"cpu_count": os.cpu_count()}
         out["cpu_baseline"] = cpu
-    ext.close()
+    for t in trks:
+        t.close()
+    for e in exts:
+        e.close()
     if rank == 0:
         print(json.dumps(out))
     if dist is not None:

@@ -15,13 +15,17 @@ from . import _lib as vo
 
 class BatchTracker:
     def __init__(self, batch, extractor, intrinsics5, dist_coef=None, width=640, height=480, n_last=1024, n_local=2048,
-                 max_features=None, stream=None):
+                 max_features=None, stream=None, extract_stream=None):
         import torch
         self.torch = torch
         self.B, self.ext = batch, extractor
         self.stream = stream if stream is not None else torch.cuda.current_stream()
         self.st = self.stream.cuda_stream
-        extractor.set_stream(self.st)  # one stream for the whole path: extraction -> frames -> matches -> pose
+        # one stream for the whole path (extraction -> frames -> matches -> pose) unless the caller gives the extraction a
+        # stream of its own (shared by several trackers: their extractions then take turns on it, in call order)
+        self.ext_stream = extract_stream if extract_stream is not None else self.stream
+        extractor.set_stream(self.ext_stream.cuda_stream)
+        self.build_done = None
         self.cap = max_features or 2048
         self.kcap = extractor.max_keypoints()
         self.W, self.H = width, height
@@ -87,9 +91,12 @@ class BatchTracker:
                                                  None, C.c_void_p(st)), "vo_pose_only_solve_ranges_dev")
 
     def track(self, images, depth=None, inv_depth_scale=1.0, radius=15.0, th_radius=3.0, ratio=0.8, direction=0,
-              keep_first=False, events=False):
+              keep_first=False, events=False, after=None):
         """images: uint8 [B,H,W] device tensor, depth: float32 / int16 [B,H,W] device tensor or None.  Asynchronous on the
-        tracker's stream; results: self.pose [B,6], self.ninl [B], self.assigned [B,cap]."""
+        tracker's stream; results: self.pose [B,6], self.ninl [B], self.assigned [B,cap].  after: an event the extraction
+        waits for; self.extract_done is recorded behind the extraction -- two trackers on two streams chained this way take
+        turns on the issue-bound extraction while the other's latency-bound searches and pose solves (one wavefront per
+        frame) run next to it."""
         L, st, B = vo.lib(), self.st, self.B
         evs = {}
 
@@ -100,10 +107,21 @@ class BatchTracker:
                 evs.setdefault(name, []).append(e)
 
         with self.torch.cuda.stream(self.stream):
+            if after is not None:
+                self.ext_stream.wait_event(after)
+            if self.ext_stream is not self.stream and self.build_done is not None:
+                self.ext_stream.wait_event(self.build_done)  # the previous batch's key-points have been consumed
             self.ext.extract_batch_dev(images, self.kps, self.desc, self.cnt)
+            self.extract_done = self.torch.cuda.Event()
+            self.extract_done.record(self.ext_stream)
+            if self.ext_stream is not self.stream:
+                self.stream.wait_event(self.extract_done)
             mark("frame_post")
             self.frames.build_dev(self.kps, self.desc, self.cnt, depth, inv_depth_scale, stream=st)
             mark("frame_post")
+            if self.ext_stream is not self.stream:
+                self.build_done = self.torch.cuda.Event()
+                self.build_done.record(self.stream)
             mark("match_last_frame")
             nq0 = self.q0["n_queries"]
             vo.check(L.vo_track_project_dev(B, nq0, self.n_last, vo._p(self.Tcw), vo._p(self.p0), vo._p(self.pf0),
