@@ -62,18 +62,37 @@ __device__ __forceinline__ double wave_max(double v) {
   for (int o = 32; o >= 1; o >>= 1) v = fmax(v, __shfl_xor(v, o));
   return v;
 }
+#ifdef VO_BA_STAMPS
+// time stamp that cannot move above the computation of `dep`
+__device__ __forceinline__ unsigned long long stamp_after(double &dep) {
+  unsigned long long t;
+  asm volatile("s_memrealtime %0\n s_waitcnt lgkmcnt(0)" : "=s"(t), "+v"(dep)::"memory");
+  return t;
+}
+#endif
 template <int N>
 __device__ __forceinline__ void block_sum(double (&v)[N], double *lds /*>= 4*N*/) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
 #pragma unroll
   for (int i = 0; i < N; i++) v[i] = wave_sum(v[i]);
+  const int nw = blockDim.x >> 6;
+  if (nw == 1) return;  // one wavefront: the wave sum is the block sum (no LDS, no barrier)
   __syncthreads();
   if (lane == 0) {
 #pragma unroll
     for (int i = 0; i < N; i++) lds[wave * N + i] = v[i];
   }
   __syncthreads();
-  const int nw = blockDim.x >> 6;
+  if (nw == 4) {  // the usual block: all reads issued together, summed in wave order
+    double p[4][N];
+#pragma unroll
+    for (int w = 0; w < 4; w++)
+#pragma unroll
+      for (int i = 0; i < N; i++) p[w][i] = lds[w * N + i];
+#pragma unroll
+    for (int i = 0; i < N; i++) v[i] = (((0.0 + p[0][i]) + p[1][i]) + p[2][i]) + p[3][i];
+    return;
+  }
 #pragma unroll
   for (int i = 0; i < N; i++) {
     double s = 0;
@@ -723,6 +742,7 @@ struct BaDev {
   BaState *st;
   BaState *hist;            // [2] states of earlier solves of the same schedule
   unsigned int *counters;   // [0] back-substitution arrivals, [1 + tile] GEMM K-slice arrivals
+  unsigned div_np1;         // ceil(2^32 / (6 nf + 1)): e / (n + 1) = umulhi(e, div_np1) for e (n + 1) < 2^32
   int fused;                // single shard: in-kernel reductions replace k_ba_reduce / k_ba_reduce2
   // ---- large reduced systems (6 nf + 1 > kMaxN, e.g. a global BA over hundreds of key-frames): no dense
   // operand matrix; the camera-point blocks live per edge and the reduced system is a dense ld x ld
@@ -915,6 +935,7 @@ __device__ __forceinline__ void ba_cams_role(const BaDev &B, const BaState &st, 
   const PoseCache P = load_pc(B.PC[st.cur], c);
 #ifdef VO_BA_STAMPS
   if (tid == 0 && slot == 0 && chunk == 0) B.dbg[32] = __builtin_amdgcn_s_memrealtime();
+  if (tid == 0) atomicMax(&B.dbg[42], (unsigned long long)__builtin_amdgcn_s_memrealtime());
 #endif
   double acc[27];
 #pragma unroll
@@ -939,16 +960,31 @@ __device__ __forceinline__ void ba_cams_role(const BaDev &B, const BaState &st, 
     }
   }
 #ifdef VO_BA_STAMPS
-  if (tid == 0 && slot == 0 && chunk == 0) B.dbg[33] = __builtin_amdgcn_s_memrealtime();
+  {
+    double dep = acc[0] + acc[26];
+    const unsigned long long t = stamp_after(dep);
+    if (dep == 1.2345e-300) acc[0] = 0;
+    if (tid == 0 && slot == 0 && chunk == 0) B.dbg[33] = t;
+    if ((tid & 63) == 0) atomicMax(&B.dbg[43], t);
+  }
 #endif
   block_sum<27>(acc, lds);
 #ifdef VO_BA_STAMPS
-  if (tid == 0 && slot == 0 && chunk == 0) B.dbg[34] = __builtin_amdgcn_s_memrealtime();
+  {
+    double dep = acc[0] + acc[26];
+    const unsigned long long t = stamp_after(dep);
+    if (dep == 1.2345e-300) acc[0] = 0;
+    if (tid == 0 && slot == 0 && chunk == 0) B.dbg[34] = t;
+    if (tid == 0) atomicMax(&B.dbg[44], t);
+  }
 #endif
   if (tid == 0) {  // static indices only (a runtime-indexed acc[] would live in scratch memory)
     double *o = B.slab_cam + ((long long)slot * B.n_cchunks + chunk) * 27;
 #pragma unroll
     for (int i = 0; i < 27; i++) o[i] = acc[i];
+#ifdef VO_BA_STAMPS
+    atomicMax(&B.dbg[35], (unsigned long long)__builtin_amdgcn_s_memrealtime());
+#endif
   }
 }
 
@@ -971,7 +1007,14 @@ constexpr int kChunkPts = 512;  // points per K-slice (LDS table of their damped
 #endif
 #ifdef VO_BA_STAMPS
 #define STAMP0(i) do { if (threadIdx.x == 0 && blockIdx.x == 0) B.dbg[i] = __builtin_amdgcn_s_memrealtime(); } while (0)
+// phase accumulators kept in registers (no store inside the timed loop)
+#define PHASE_DECL unsigned long long ph_acc[5] = {0, 0, 0, 0, 0}, ph_prev = __builtin_amdgcn_s_memrealtime()
+#define PHASE(i) do { const unsigned long long ph_t = __builtin_amdgcn_s_memrealtime(); ph_acc[i] += ph_t - ph_prev; ph_prev = ph_t; } while (0)
+#define PHASE_STORE(base) do { if (threadIdx.x == 0) for (int ph_i = 0; ph_i < 5; ph_i++) B.dbg[(base) + ph_i] = ph_acc[ph_i]; } while (0)
 #else
+#define PHASE_DECL
+#define PHASE(i)
+#define PHASE_STORE(base)
 #define STAMP0(i)
 #endif
 constexpr int kGemmLdsDoubles = 4 * 256 + kChunkPts * 6 + 4 * 27;  // part, hinvL, lds27
@@ -1102,6 +1145,9 @@ __device__ __forceinline__ void ba_gemm_tile_role(const BaDev &B, const BaState 
     acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc, 0, 0, 0);
   }
   STAMP0(18);
+#ifdef VO_BA_STAMPS
+  if (threadIdx.x == 0) atomicMax(&B.dbg[23], (unsigned long long)__builtin_amdgcn_s_memrealtime());
+#endif
 #pragma unroll
   for (int r = 0; r < 4; r++) part[wave][(kk + 4 * r) * 16 + ii] = acc[r];
   __syncthreads();
@@ -1119,6 +1165,9 @@ __device__ __forceinline__ void ba_gemm_tile_role(const BaDev &B, const BaState 
   st_sc1(&B.slab_gemm[(long long)ks * B.Mpad * B.Mpad + eoff], v);
   __shared__ int s_last;
   if (!arrive_and_check_last(&B.counters[1 + (tm * tdim + tn)], (unsigned)B.ksplit, &s_last)) return;
+#ifdef VO_BA_STAMPS
+  if (threadIdx.x == 0) atomicMax(&B.dbg[22], (unsigned long long)__builtin_amdgcn_s_memrealtime());
+#endif
   const long long M2 = (long long)B.Mpad * B.Mpad;
   double sv[32];
 #pragma unroll
@@ -1127,6 +1176,9 @@ __device__ __forceinline__ void ba_gemm_tile_role(const BaDev &B, const BaState 
 #pragma unroll
   for (int u = 0; u < 32; u++) sum += u < B.ksplit ? sv[u] : 0.0;
   B.payload[eoff] = sum;
+#ifdef VO_BA_STAMPS
+  if (threadIdx.x == 0) atomicMax(&B.dbg[21], (unsigned long long)__builtin_amdgcn_s_memrealtime());
+#endif
 }
 
 // fixed-order reduction of the slabs into the payload that a multi-GPU run all-reduces
@@ -1210,10 +1262,13 @@ __device__ __forceinline__ bool ldl6_packed(double L[21], double rd[6]) {
   return ok;
 }
 
+constexpr int kSolveThreads = 512;  // two wavefronts per SIMD: a lone wavefront issues one instruction per ~8 cycles
+constexpr int kSolveRed = 16 * 5 + 48;  // block_sum<5> of up to 16 wavefronts
 __device__ __forceinline__ void ba_solve_body(const BaDev &B, const BaState &st0, double *sm) {
   BaState *S = B.st;
   if (st0.done) return;
   const int tid = threadIdx.x;
+  constexpr int NT = kSolveThreads;
   STAMP(0);
 #ifdef VO_BA_STAMPS
   if (tid == 0) B.dbg[30] = __builtin_readcyclecounter();
@@ -1225,11 +1280,11 @@ __device__ __forceinline__ void ba_solve_body(const BaDev &B, const BaState &st0
   double *gpp = Dd + n;             // scaled gradient g''
   double *y = gpp + n;              // solution
   double *Ldg = y + n;              // nb x 21 factored diagonal blocks
-  double *red = Ldg + nb * 21 + n;  // 64 scratch (after the n reciprocal pivots)
+  double *red = Ldg + nb * 21 + n;  // kSolveRed scratch (after the n reciprocal pivots)
   __shared__ int s_fail, s_stop;
   const double *G = B.payload;
   // camera blocks / cost / gradient-max: all-reduced payload in the sharded mode, summed into LDS here otherwise
-  double *HPw = B.fused ? red + 64 : B.payload + payload_hpp_off(B);
+  double *HPw = B.fused ? red + kSolveRed : B.payload + payload_hpp_off(B);
   const int cur0 = st0.cur;
   const int first = st0.first;
   const double radius = st0.radius;
@@ -1252,8 +1307,8 @@ __device__ __forceinline__ void ba_solve_body(const BaDev &B, const BaState &st0
     auto issue = [&](int e0, double (&v)[8], int (&pos)[8]) {
 #pragma unroll
       for (int un = 0; un < 8; un++) {
-        const int e = e0 + un * 256 + tid;
-        const int c = e / (n + 1), r = e - c * (n + 1);
+        const int e = e0 + un * NT + tid;
+        const int c = (int)__umulhi((unsigned)e, B.div_np1), r = e - c * (n + 1);  // c = e / (n + 1) without the divide
         const bool valid = e < ne && r >= c;
         pos[un] = valid ? r * ld + c : -1;
         v[un] = *(valid ? G + (long long)c * B.Mpad + r : zero_slab);
@@ -1267,38 +1322,55 @@ __device__ __forceinline__ void ba_solve_body(const BaDev &B, const BaState &st0
     double v0[8];
     int pos0[8];
     issue(0, v0, pos0);
+    // single shard (no k_ba_reduce): the camera-block slabs of k_ba_gemm's camera role are summed here, one entry
+    // per thread, sixteen chunk loads in flight together with the round above
+    const double *zslab = zero_slab;
+    const int ci = tid < B.nf * 27 ? tid : 0;
+    const int cslot = ci / 27;
+    const double *sp = B.slab_cam + (long long)cslot * B.n_cchunks * 27 + (ci - cslot * 27);
+    double cv[16];
+    if (B.fused) {
+#pragma unroll
+      for (int q = 0; q < 16; q++) cv[q] = *(q < B.n_cchunks ? sp + q * 27 : zslab);
+    }
     // exp(x) of this thread's camera while the first round is in flight (the pose loads were issued
     // before it and return first); se3_plus only has exp(delta), the product and the log left to do
     expx = se3_exp(xpre);
     commit(v0, pos0);
-    for (int e0 = 256 * 8; e0 < ne; e0 += 256 * 8) {
+    for (int e0 = NT * 8; e0 < ne; e0 += NT * 8) {
       double v[8];
       int pos[8];
       issue(e0, v, pos);
       commit(v, pos);
     }
-  }
-  STAMP_DRAIN(10);
-  STAMP_DRAIN(11);
-  const double sc_pre = (first || tid >= n) ? 0.0 : B.scale_c[tid];  // per reduced-system column
-  STAMP_DRAIN(8);  // debug builds only: the prefetch round trip
-  if (B.fused) {  // no k_ba_reduce in this mode: sum the camera-block and cost slabs here
-    const double *zslab = B.slab_gemm + (long long)B.ksplit * B.Mpad * B.Mpad;
-    for (int i = tid; i < B.nf * 27; i += 256) {
-      const int slot = i / 27, t = i - slot * 27;
-      const double *sp = B.slab_cam + (long long)slot * B.n_cchunks * 27 + t;
+    if (B.fused) {
       double a = 0;
-      for (int c0 = 0; c0 < B.n_cchunks; c0 += 16) {  // sixteen loads in flight, summed in chunk order
+#pragma unroll
+      for (int q = 0; q < 16; q++) a += cv[q];
+      for (int c0 = 16; c0 < B.n_cchunks; c0 += 16) {  // more than 16 chunks per camera: further rounds, chunk order
         double v[16];
 #pragma unroll
         for (int q = 0; q < 16; q++) v[q] = *(c0 + q < B.n_cchunks ? sp + (c0 + q) * 27 : zslab);
 #pragma unroll
         for (int q = 0; q < 16; q++) a += v[q];
       }
+      if (tid < B.nf * 27) HPw[tid] = a;
+    }
+  }
+  STAMP_DRAIN(10);
+  STAMP_DRAIN(11);
+  const double sc_pre = (first || tid >= n) ? 0.0 : B.scale_c[tid];  // per reduced-system column
+  STAMP_DRAIN(8);  // debug builds only: the prefetch round trip
+  if (B.fused) {
+    for (int i = tid + NT; i < B.nf * 27; i += NT) {  // nf * 27 > NT never happens (nf <= 21): kept for safety
+      const int slot = i / 27, t = i - slot * 27;
+      const double *sp2 = B.slab_cam + (long long)slot * B.n_cchunks * 27 + t;
+      double a = 0;
+      for (int c0 = 0; c0 < B.n_cchunks; c0++) a += sp2[c0 * 27];
       HPw[i] = a;
     }
-    if (tid >= 192) {  // last wave: cost (sum) and gradient max over the point blocks
-      const int l = tid - 192;
+    if (tid >= NT - 64) {  // last wave: cost (sum) and gradient max over the point blocks
+      const int l = tid - (NT - 64);
       double cs = 0, m = 0;
       const double *spt = B.slab_pt[cur0];
       for (int b = l; b < B.n_pblocks; b += 64) {
@@ -1318,7 +1390,7 @@ __device__ __forceinline__ void ba_solve_body(const BaDev &B, const BaState &st0
   const double *HP = HPw;
   if (tid == 0) s_fail = 0, s_stop = 0;
   double gm = 0;
-  for (int i = tid; i < n; i += 256) {
+  for (int i = tid; i < n; i += NT) {
     const int slot = i / 6, a = i - slot * 6;
     int t = 0;
     for (int q = 0; q < a; q++) t += 6 - q;  // index of (a,a) in the packed upper triangle
@@ -1341,7 +1413,7 @@ __device__ __forceinline__ void ba_solve_body(const BaDev &B, const BaState &st0
   // S'' = diag(sc) (Hpp - Y W^T) diag(sc) + D in place on the raw product; rhs'' = g'' - sc * (Y g_l)
   {
     const int tx = tid & 15, ty = tid >> 4;
-    for (int c = ty; c < n; c += 16)
+    for (int c = ty; c < n; c += NT / 16)
       for (int r = c - (c & 15) + tx; r < n; r += 16) {
         if (r < c) continue;
         double v = -A[r * ld + c];
@@ -1356,12 +1428,13 @@ __device__ __forceinline__ void ba_solve_body(const BaDev &B, const BaState &st0
         A[r * ld + c] = v;
       }
   }
-  for (int i = tid; i < n; i += 256) A[n * ld + i] = gpp[i] - sc[i] * A[n * ld + i];
+  for (int i = tid; i < n; i += NT) A[n * ld + i] = gpp[i] - sc[i] * A[n * ld + i];
   gm = wave_max(gm);
   if ((tid & 63) == 0) red[tid >> 6] = gm;
   __syncthreads();
   if (tid == 0) {
-    double m = fmax(fmax(red[0], red[1]), fmax(red[2], red[3]));
+    double m = 0;
+    for (int w = 0; w < NT / 64; w++) m = fmax(m, red[w]);
     const double *CP = HP + B.nf * 27;  // cost, then one gradient-max slot per shard
     for (int k = 0; k < B.n_shards; k++) m = fmax(m, CP[1 + k]);
     S->gmax = m;
@@ -1392,6 +1465,7 @@ __device__ __forceinline__ void ba_solve_body(const BaDev &B, const BaState &st0
   // update, are the latency floor.)
   double *rdv = Ldg + nb * 21;  // 1/d_j of all n pivots
   bool ok_all = true;
+  PHASE_DECL;
   for (int k = 0; k < nb; k++) {
     const int K0 = 6 * k;
     double L[21], rd[6];
@@ -1399,7 +1473,9 @@ __device__ __forceinline__ void ba_solve_body(const BaDev &B, const BaState &st0
     for (int i = 0; i < 6; i++)
 #pragma unroll
       for (int j = 0; j <= i; j++) L[i * (i + 1) / 2 + j] = A[(K0 + i) * ld + K0 + j];
+    PHASE(0);
     ok_all = ldl6_packed(L, rd) && ok_all;
+    PHASE(1);
     // static indices only: a runtime-indexed register array would be demoted to scratch memory
     if (tid == 0) {
 #pragma unroll
@@ -1407,7 +1483,7 @@ __device__ __forceinline__ void ba_solve_body(const BaDev &B, const BaState &st0
 #pragma unroll
       for (int i = 0; i < 6; i++) rdv[K0 + i] = rd[i];
     }
-    for (int r = K0 + 6 + tid; r <= n; r += 256) {  // u_rt = A[r][t] - sum_{q<t} u_rq l_tq
+    for (int r = K0 + 6 + tid; r <= n; r += NT) {  // u_rt = A[r][t] - sum_{q<t} u_rq l_tq
       double x[6];
 #pragma unroll
       for (int t = 0; t < 6; t++) {
@@ -1419,12 +1495,12 @@ __device__ __forceinline__ void ba_solve_body(const BaDev &B, const BaState &st0
 #pragma unroll
       for (int t = 0; t < 6; t++) A[r * ld + K0 + t] = x[t];
     }
-    if (k == 0) STAMP(26);
+    PHASE(2);
     __syncthreads();
-    if (k == 0) STAMP(27);
+    PHASE(3);
     {
       const int tx = tid & 15, ty = tid >> 4;
-      for (int r = K0 + 6 + ty; r <= n; r += 16) {
+      for (int r = K0 + 6 + ty; r <= n; r += NT / 16) {
         double w[6];
 #pragma unroll
         for (int t = 0; t < 6; t++) w[t] = A[r * ld + K0 + t] * rd[t];
@@ -1436,10 +1512,11 @@ __device__ __forceinline__ void ba_solve_body(const BaDev &B, const BaState &st0
         }
       }
     }
-    if (k == 0) STAMP(28);
+    PHASE(4);
     __syncthreads();
-    if (k == 0) STAMP(29);
+    PHASE(3);
   }
+  PHASE_STORE(48);
   if (!ok_all && tid == 0) s_fail = 1;  // every thread saw the same pivots
   __syncthreads();
   STAMP(3);
@@ -1461,7 +1538,7 @@ __device__ __forceinline__ void ba_solve_body(const BaDev &B, const BaState &st0
 #pragma unroll
       for (int i = 0; i < 6; i++) y[K0 + i] = yk[i];
     }
-    for (int i = tid; i < K0; i += 256) {
+    for (int i = tid; i < K0; i += NT) {
       double acc = 0;
 #pragma unroll
       for (int t = 0; t < 6; t++) acc += A[(K0 + t) * ld + i] * yk[t];
@@ -1473,7 +1550,7 @@ __device__ __forceinline__ void ba_solve_body(const BaDev &B, const BaState &st0
   // camera part of  g''.step  and  step^T D step  (step = -y)
   double gdot = 0, dquad = 0;
   int bad = 0;
-  for (int i = tid; i < n; i += 256) {
+  for (int i = tid; i < n; i += NT) {
     const double stp = -y[i];
     if (!isfinite(stp)) bad = 1;
     gdot += gpp[i] * stp;
@@ -1488,7 +1565,7 @@ __device__ __forceinline__ void ba_solve_body(const BaDev &B, const BaState &st0
   const double *X = B.Xc[cur0];
   double *Xn = B.Xc[cur0 ^ 1];
   double xn2 = 0, cn2 = 0, sn2 = 0;
-  for (int c = tid; c < B.n_cams; c += 256) {
+  for (int c = tid; c < B.n_cams; c += NT) {
     const bool pre = c == tid;  // first round: operands were prefetched at the top of the kernel
     const int slot = pre ? slotpre : B.cam_slot[c];
     const int cin = pre ? cinpre : (int)(B.cam_in[c] == B.epoch);
@@ -1543,7 +1620,7 @@ __device__ __forceinline__ void ba_solve_body(const BaDev &B, const BaState &st0
 #endif
 }
 
-__global__ __launch_bounds__(256) void k_ba_solve(BaDev B) {
+__global__ __launch_bounds__(kSolveThreads) void k_ba_solve(BaDev B) {
   extern __shared__ double sm[];
   const BaState st = *B.st;
   ba_solve_body(B, st, sm);
@@ -2338,6 +2415,7 @@ int build_device(vo_ba *h) {
   VO_HIP_CHECK(hipMemset(h->b_cnt.p, 0, 4096));
   D.counters = h->b_cnt.as<unsigned int>();
   D.fused = h->n_shards == 1 ? 1 : 0;
+  D.div_np1 = (unsigned)((0x100000000ull + (unsigned)(6 * h->nf)) / (unsigned)(6 * h->nf + 1));
   D.dbg = h->b_dbg.as<unsigned long long>();
   VO_HIP_CHECK(hipMemset(h->b_state.p, 0, 3 * sizeof(BaState)));
   D.e_cam = h->b_ecam.as<int>(), D.e_pt = h->b_ept.as<int>();
@@ -2363,7 +2441,7 @@ int build_device(vo_ba *h) {
   D.st = h->b_state.as<BaState>();
   D.hist = D.st + 1;
   const int n = D.large ? 6 : 6 * h->nf;
-  h->solve_lds = ((size_t)(n + 1) * (n + 1) + 5 * n + (size_t)h->nf * 21 + 64 + (size_t)h->nf * 27 + 8) * 8;
+  h->solve_lds = ((size_t)(n + 1) * (n + 1) + 5 * n + (size_t)h->nf * 21 + kSolveRed + (size_t)h->nf * 27 + 8) * 8;
   if (!D.large && h->solve_lds > 64 * 1024)
     VO_HIP_CHECK(hipFuncSetAttribute((const void *)k_ba_solve, hipFuncAttributeMaxDynamicSharedMemorySize,
                                      (int)h->solve_lds));
@@ -2449,7 +2527,7 @@ int launch_step(vo_ba *h) {
   if (D.large)
     VO_CHECK(launch_step_large(h));
   else
-    hipLaunchKernelGGL(k_ba_solve, dim3(1), dim3(256), h->solve_lds, st, D);
+    hipLaunchKernelGGL(k_ba_solve, dim3(1), dim3(kSolveThreads), h->solve_lds, st, D);
   hipLaunchKernelGGL(k_ba_backsub, dim3(D.n_pblocks), dim3(256), 0, st, D);
   if (h->n_shards > 1) hipLaunchKernelGGL(k_ba_reduce2, dim3(1), dim3(64), 0, st, D);
   VO_HIP_CHECK(hipGetLastError());
@@ -2999,10 +3077,10 @@ int vo_ba_get_edge_outliers(vo_ba *h, uint8_t *edge_erase) {
   return VO_OK;
 }
 
-int vo_ba_debug_stamps(vo_ba *h, unsigned long long *out /*48*/) {
+int vo_ba_debug_stamps(vo_ba *h, unsigned long long *out /*64*/) {
   if (!h || !h->built) return VO_ERR_INVALID;
   VO_HIP_CHECK(hipStreamSynchronize(h->stream));
-  VO_HIP_CHECK(hipMemcpy(out, h->b_dbg.p, 384, hipMemcpyDeviceToHost));
+  VO_HIP_CHECK(hipMemcpy(out, h->b_dbg.p, 512, hipMemcpyDeviceToHost));
   return VO_OK;
 }
 
