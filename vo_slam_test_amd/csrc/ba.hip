@@ -25,6 +25,7 @@
 #include <cmath>
 #include <map>
 #include <numeric>
+#include <type_traits>
 #include <vector>
 
 namespace {
@@ -70,12 +71,12 @@ __device__ __forceinline__ unsigned long long stamp_after(double &dep) {
   return t;
 }
 #endif
-template <int N>
-__device__ __forceinline__ void block_sum(double (&v)[N], double *lds /*>= 4*N*/) {
+template <int N, int NW = 0>  // NW: wavefronts per block when known at compile time (0: blockDim.x / 64)
+__device__ __forceinline__ void block_sum(double (&v)[N], double *lds /*>= nw*N*/) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
 #pragma unroll
   for (int i = 0; i < N; i++) v[i] = wave_sum(v[i]);
-  const int nw = blockDim.x >> 6;
+  const int nw = NW ? NW : (int)(blockDim.x >> 6);
   if (nw == 1) return;  // one wavefront: the wave sum is the block sum (no LDS, no barrier)
   __syncthreads();
   if (lane == 0) {
@@ -83,7 +84,20 @@ __device__ __forceinline__ void block_sum(double (&v)[N], double *lds /*>= 4*N*/
     for (int i = 0; i < N; i++) lds[wave * N + i] = v[i];
   }
   __syncthreads();
-  if (nw == 4) {  // the usual block: all reads issued together, summed in wave order
+  // all partials are read in one batch and summed in wave order (a runtime loop over the waves waits for LDS once
+  // per term: 4 us for 27 sums)
+  if (NW == 8 || (NW == 0 && nw == 8)) {
+    double p[8][N];
+#pragma unroll
+    for (int w = 0; w < 8; w++)
+#pragma unroll
+      for (int i = 0; i < N; i++) p[w][i] = lds[w * N + i];
+#pragma unroll
+    for (int i = 0; i < N; i++)
+      v[i] = (((((((0.0 + p[0][i]) + p[1][i]) + p[2][i]) + p[3][i]) + p[4][i]) + p[5][i]) + p[6][i]) + p[7][i];
+    return;
+  }
+  if (NW == 4 || (NW == 0 && nw == 4)) {
     double p[4][N];
 #pragma unroll
     for (int w = 0; w < 4; w++)
@@ -693,7 +707,9 @@ constexpr int kGroup = 1 << kGroupLog;  // lanes per map point: one edge per lan
                                         // and twice the workgroups -- the point kernels are FP64-latency bound
                                         // with one wavefront per SIMD
 constexpr int kPtsPerBlock = 256 / kGroup;
-constexpr int kCamChunk = 256;   // edges per camera-role block (one per thread: the role shares a launch with the Schur tiles)
+constexpr int kGemmThreads = 512;  // k_ba_gemm / k_ba_cams_large: two wavefronts per SIMD (each wave's K-slice is one 48-row trip)
+constexpr int kCamChunk = 256;  // edges per camera-role block, one per thread of its first four wavefronts (the role shares a
+                                // launch with the Schur tiles; 27 wave sums per wavefront are its cost, so the other four retire)
 constexpr int kPcLds = 128;     // pose caches staged in LDS by the point kernels (12 KB)
 constexpr int kMaxN = 128;       // reduced system size limit of the LDS Cholesky (6*nf + 1 <= kMaxN)
 
@@ -940,7 +956,7 @@ __device__ __forceinline__ void ba_cams_role(const BaDev &B, const BaState &st, 
   double acc[27];
 #pragma unroll
   for (int i = 0; i < 27; i++) acc[i] = 0;
-  for (int idx = s0 + chunk * kCamChunk + tid; idx < min(s1, s0 + (chunk + 1) * kCamChunk); idx += 256) {
+  for (int idx = s0 + chunk * kCamChunk + tid; idx < min(s1, s0 + (chunk + 1) * kCamChunk); idx += kCamChunk) {
     const int e = B.cam_edges[idx];
     if (!B.e_active[e]) continue;
     const int j = B.e_pt[e];
@@ -968,7 +984,7 @@ __device__ __forceinline__ void ba_cams_role(const BaDev &B, const BaState &st, 
     if ((tid & 63) == 0) atomicMax(&B.dbg[43], t);
   }
 #endif
-  block_sum<27>(acc, lds);
+  block_sum<27, kCamChunk / 64>(acc, lds);
 #ifdef VO_BA_STAMPS
   {
     double dep = acc[0] + acc[26];
@@ -1017,7 +1033,8 @@ constexpr int kChunkPts = 512;  // points per K-slice (LDS table of their damped
 #define PHASE_STORE(base)
 #define STAMP0(i)
 #endif
-constexpr int kGemmLdsDoubles = 4 * 256 + kChunkPts * 6 + 4 * 27;  // part, hinvL, lds27
+constexpr int kGemmWaves = kGemmThreads / 64;
+constexpr int kGemmLdsDoubles = kGemmWaves * 256 + kChunkPts * 6 + kGemmWaves * 27;  // part, hinvL, lds27
 
 __device__ __forceinline__ void ba_gemm_tile_role(const BaDev &B, const BaState &st, double *sm, int ntiles, int tdim);
 
@@ -1026,15 +1043,16 @@ __device__ __forceinline__ void ba_gemm_tile_role(const BaDev &B, const BaState 
 // lives on one GPU, k_ba_reduce + all-reduce when it is sharded).  In-kernel hand-offs were measured
 // and lose: an sc1 store -> ticket -> sc1 load chain costs ~8 us on MI355X and a single block pulls
 // coherent loads at only ~12 GB/s, against ~5 us for a kernel boundary followed by cached loads.
-__global__ __launch_bounds__(256) void k_ba_gemm(BaDev B) {
+__global__ __launch_bounds__(kGemmThreads) void k_ba_gemm(BaDev B) {
   extern __shared__ double sm[];  // part | hinvL | lds27
   const BaState st = *B.st;
   if (st.done) return;
   STAMP0(16);
   const int tdim = B.Mpad / 16, ntiles = tdim * (tdim + 1) / 2;
   if ((int)blockIdx.x >= ntiles * B.ksplit) {  // camera-block role (independent of the tiles)
+    if (threadIdx.x >= kCamChunk) return;  // retired wavefronts do not take part in the role's barriers
     const int q = blockIdx.x - ntiles * B.ksplit;
-    ba_cams_role(B, st, q / B.n_cchunks, q % B.n_cchunks, sm + 4 * 256 + kChunkPts * 6);
+    ba_cams_role(B, st, q / B.n_cchunks, q % B.n_cchunks, sm + kGemmWaves * 256 + kChunkPts * 6);
   } else {
     ba_gemm_tile_role(B, st, sm, ntiles, tdim);
   }
@@ -1043,7 +1061,7 @@ __global__ __launch_bounds__(256) void k_ba_gemm(BaDev B) {
 
 __device__ __forceinline__ void ba_gemm_tile_role(const BaDev &B, const BaState &st, double *sm, int ntiles, int tdim) {
   double(*part)[256] = reinterpret_cast<double(*)[256]>(sm);
-  double *hinvL = sm + 4 * 256;
+  double *hinvL = sm + kGemmWaves * 256;
   const int ks = blockIdx.x / ntiles;
   int tile = blockIdx.x - ks * ntiles, tm = 0;
   while (tile >= tdim - tm) {  // upper-triangular tile index -> (tm <= tn)
@@ -1060,7 +1078,7 @@ __device__ __forceinline__ void ba_gemm_tile_role(const BaDev &B, const BaState 
   const int j0 = kb0 / 3, npts = (kb1 - kb0) / 3;
   const double *hl = B.hll[st.cur];
   const double *W = B.Wt[st.cur];
-  for (int t = tid; t < npts; t += 256) {
+  for (int t = tid; t < npts; t += kGemmThreads) {
     const int j = j0 + t;
     const double sp0 = B.scale_p[3 * j], sp1 = B.scale_p[3 * j + 1], sp2 = B.scale_p[3 * j + 2];
     double hs[6] = {hl[6 * j] * sp0 * sp0, hl[6 * j + 1] * sp0 * sp1, hl[6 * j + 2] * sp0 * sp2,
@@ -1086,7 +1104,7 @@ __device__ __forceinline__ void ba_gemm_tile_role(const BaDev &B, const BaState 
   }
   __syncthreads();
   STAMP0(17);
-  const int q = ((kb1 - kb0 + 15) / 16) * 4;  // rows per wave, multiple of 4
+  const int q = ((kb1 - kb0 + 4 * kGemmWaves - 1) / (4 * kGemmWaves)) * 4;  // rows per wave, multiple of 4
   const int k0 = kb0 + wave * q, k1 = min(kb1, k0 + q);
   double4_t acc = {0, 0, 0, 0};
   const int kk = lane >> 4, ii = lane & 15;
@@ -1097,26 +1115,29 @@ __device__ __forceinline__ void ba_gemm_tile_role(const BaDev &B, const BaState 
     return hv[a == 0 ? b : (a == 1 ? 2 + b : 5)];
   };
   int k = k0;
-  // The loop is latency-bound (one wave per SIMD): 12 MFMA steps per trip keep 48 independent loads
-  // in flight per lane; all loads of a trip are issued before the first multiply.
-  for (; k + 48 <= k1; k += 48) {
-    double w0[12], w1[12], w2[12], b[12];
+  // The loop is latency-bound (one wave per SIMD): 12 MFMA steps per trip keep 48 independent loads in flight per
+  // lane, all issued before the first multiply.  (96-row trips are slower, 16.7 against 14.2 us for the kernel: vmcnt
+  // counts at most 63 outstanding vector-memory operations per wave.)
+  auto trip = [&](auto uc, int kt) {
+    constexpr int U = decltype(uc)::value;
+    double w0[U], w1[U], w2[U], b[U];
 #pragma unroll
-    for (int u = 0; u < 12; u++) {
-      const int kr = k + 4 * u + kk;
+    for (int u = 0; u < U; u++) {
+      const int kr = kt + 4 * u + kk;
       const long long r3 = (long long)(3 * (kr / 3)) * B.Mpad;
       w0[u] = Wa[r3], w1[u] = Wa[r3 + B.Mpad], w2[u] = Wa[r3 + 2 * B.Mpad];
       b[u] = Wb[(long long)kr * B.Mpad];
     }
 #pragma unroll
-    for (int u = 0; u < 12; u++) {
-      const int kr = k + 4 * u + kk;
+    for (int u = 0; u < U; u++) {
+      const int kr = kt + 4 * u + kk;
       const int j = kr / 3, c = kr - 3 * j;
       const double *hv = &hinvL[6 * (j - j0)];
       const double a = w0[u] * sym(hv, 0, c) + w1[u] * sym(hv, 1, c) + w2[u] * sym(hv, 2, c);
       acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b[u], acc, 0, 0, 0);
     }
-  }
+  };
+  for (; k + 48 <= k1; k += 48) trip(std::integral_constant<int, 12>{}, k);
   for (; k + 16 <= k1; k += 16) {  // 4 MFMA steps: 16 independent loads in flight per lane
     double a[4], b[4];
 #pragma unroll
@@ -1151,23 +1172,27 @@ __device__ __forceinline__ void ba_gemm_tile_role(const BaDev &B, const BaState 
 #pragma unroll
   for (int r = 0; r < 4; r++) part[wave][(kk + 4 * r) * 16 + ii] = acc[r];
   __syncthreads();
-  const int t = threadIdx.x;  // element (t>>4, t&15) of the tile, fixed summation order
-  const double v = (part[0][t] + part[1][t]) + (part[2][t] + part[3][t]);
+  const int t = threadIdx.x & 255;  // element (t>>4, t&15) of the tile, fixed summation order (the upper half of the
+                                    // block computes the same value and stores nothing)
+  double v = (part[0][t] + part[1][t]) + (part[2][t] + part[3][t]);
+  if (kGemmWaves == 8) v += (part[4][t] + part[5][t]) + (part[6][t] + part[7][t]);
+  const bool writer = threadIdx.x < 256;
   const long long eoff = (long long)(tm * 16 + (t >> 4)) * B.Mpad + tn * 16 + (t & 15);
   if (!B.fused) {  // sharded: k_ba_reduce sums the slabs into the payload that is all-reduced
-    B.slab_gemm[(long long)ks * B.Mpad * B.Mpad + eoff] = v;
+    if (writer) B.slab_gemm[(long long)ks * B.Mpad * B.Mpad + eoff] = v;
     return;
   }
   // One GPU: the last K-slice block of a tile to arrive sums the tile's slabs (slab order:
   // deterministic) into the payload.  This hand-off (~8 us: write-through stores, ticket, coherent
   // loads) runs in parallel over the tiles and overlaps the longer camera-block role; the single
   // solving block behind the kernel boundary then reads 12 KB instead of ksplit x 12 KB.
-  st_sc1(&B.slab_gemm[(long long)ks * B.Mpad * B.Mpad + eoff], v);
+  if (writer) st_sc1(&B.slab_gemm[(long long)ks * B.Mpad * B.Mpad + eoff], v);
   __shared__ int s_last;
   if (!arrive_and_check_last(&B.counters[1 + (tm * tdim + tn)], (unsigned)B.ksplit, &s_last)) return;
 #ifdef VO_BA_STAMPS
   if (threadIdx.x == 0) atomicMax(&B.dbg[22], (unsigned long long)__builtin_amdgcn_s_memrealtime());
 #endif
+  if (!writer) return;  // no barrier below
   const long long M2 = (long long)B.Mpad * B.Mpad;
   double sv[32];
 #pragma unroll
@@ -1175,7 +1200,7 @@ __device__ __forceinline__ void ba_gemm_tile_role(const BaDev &B, const BaState 
   double sum = 0;
 #pragma unroll
   for (int u = 0; u < 32; u++) sum += u < B.ksplit ? sv[u] : 0.0;
-  B.payload[eoff] = sum;
+  if (writer) B.payload[eoff] = sum;
 #ifdef VO_BA_STAMPS
   if (threadIdx.x == 0) atomicMax(&B.dbg[21], (unsigned long long)__builtin_amdgcn_s_memrealtime());
 #endif
@@ -1604,7 +1629,7 @@ __device__ __forceinline__ void ba_solve_body(const BaDev &B, const BaState &st0
       for (int i = 0; i < 5; i++) v5[i] = wave_sum(v5[i]);
     }
   } else {
-    block_sum<5>(v5, red);
+    block_sum<5, kSolveThreads / 64>(v5, red);
   }
   if (tid == 0) {
     S->gdot_c = v5[0];
@@ -1665,7 +1690,7 @@ __global__ __launch_bounds__(256) void k_ba_hinv_large(BaDev B) {
   for (int k = 0; k < 3; k++) B.gl2[3 * j + k] = B.glsc[st.cur][3 * j + k];
 }
 
-__global__ __launch_bounds__(256) void k_ba_cams_large(BaDev B) {
+__global__ __launch_bounds__(kCamChunk) void k_ba_cams_large(BaDev B) {
   __shared__ double lds27[4 * 27];
   const BaState st = *B.st;
   if (st.done) return;
@@ -2488,7 +2513,7 @@ int launch_linearize_large(vo_ba *h) {
   BaDev &D = h->D;
   hipStream_t st = h->stream;
   hipLaunchKernelGGL(k_ba_hinv_large, dim3((D.n_local + 255) / 256), dim3(256), 0, st, D);
-  hipLaunchKernelGGL(k_ba_cams_large, dim3(std::max(1, h->nf * D.n_cchunks)), dim3(256), 0, st, D);
+  hipLaunchKernelGGL(k_ba_cams_large, dim3(std::max(1, h->nf * D.n_cchunks)), dim3(kCamChunk), 0, st, D);
   VO_HIP_CHECK(hipMemsetAsync(D.Sd, 0, (size_t)(D.ld + vo::kCholPanel) * D.ld * 8, st));
   if (D.n_pairs > 0) hipLaunchKernelGGL(k_ba_pairs, dim3((D.n_pairs + 3) / 4), dim3(256), 0, st, D);
   hipLaunchKernelGGL(k_ba_partials_large, dim3(std::max(1, (h->nf * 27 + 255) / 256)), dim3(256), 0, st, D);
@@ -2513,7 +2538,7 @@ int launch_linearize(vo_ba *h) {
   if (D.large) return launch_linearize_large(h);
   const int tdim = D.Mpad / 16, tiles = tdim * (tdim + 1) / 2;
   // Schur product tiles and the camera blocks in one launch (independent roles)
-  hipLaunchKernelGGL(k_ba_gemm, dim3(tiles * D.ksplit + h->nf * D.n_cchunks), dim3(256), h->gemm_lds, st, D);
+  hipLaunchKernelGGL(k_ba_gemm, dim3(tiles * D.ksplit + h->nf * D.n_cchunks), dim3(kGemmThreads), h->gemm_lds, st, D);
   if (!D.fused) {
     const int np = (D.Mpad * D.Mpad + h->nf * 27 + 1) * 4;
     hipLaunchKernelGGL(k_ba_reduce, dim3((np + 255) / 256), dim3(256), 0, st, D);
