@@ -943,6 +943,11 @@ __global__ __launch_bounds__(256) void k_ba_lin0(BaDev B) {
 // --------------------------------------------------------------------------------------------
 // k_ba_cams: F^T F and F^T b of each free camera (the f-blocks of the Schur eliminator)
 // --------------------------------------------------------------------------------------------
+constexpr int kCamPitch = 265;  // LDS row pitch (doubles) of the transposed camera-block reduction
+// kLdsReduce: the 27 block sums go through LDS transposed (lds >= 27 * kCamPitch doubles): 27 stores, then 216 threads
+// add 32 terms each and finish over 8 lanes by DPP -- ~110 instructions per wavefront against ~700 for 27 butterfly
+// wave sums, which is what the role's run time was made of.  Fixed order either way.
+template <bool kLdsReduce>
 __device__ __forceinline__ void ba_cams_role(const BaDev &B, const BaState &st, int slot, int chunk, double *lds) {
   const int tid = threadIdx.x;
   const int c = B.slot_cam[slot];
@@ -984,24 +989,36 @@ __device__ __forceinline__ void ba_cams_role(const BaDev &B, const BaState &st, 
     if ((tid & 63) == 0) atomicMax(&B.dbg[43], t);
   }
 #endif
-  block_sum<27, kCamChunk / 64>(acc, lds);
-#ifdef VO_BA_STAMPS
-  {
-    double dep = acc[0] + acc[26];
-    const unsigned long long t = stamp_after(dep);
-    if (dep == 1.2345e-300) acc[0] = 0;
-    if (tid == 0 && slot == 0 && chunk == 0) B.dbg[34] = t;
-    if (tid == 0) atomicMax(&B.dbg[44], t);
-  }
-#endif
-  if (tid == 0) {  // static indices only (a runtime-indexed acc[] would live in scratch memory)
-    double *o = B.slab_cam + ((long long)slot * B.n_cchunks + chunk) * 27;
+  double *o = B.slab_cam + ((long long)slot * B.n_cchunks + chunk) * 27;
+  if (kLdsReduce) {
+    const int col = tid + (tid >> 5);  // one pad per 32 columns: the 8 partial sums of an entry start in different banks
 #pragma unroll
-    for (int i = 0; i < 27; i++) o[i] = acc[i];
-#ifdef VO_BA_STAMPS
-    atomicMax(&B.dbg[35], (unsigned long long)__builtin_amdgcn_s_memrealtime());
-#endif
+    for (int i = 0; i < 27; i++) lds[i * kCamPitch + col] = acc[i];
+    __syncthreads();
+    if (tid < 27 * 8) {
+      const int i = tid >> 3, part = tid & 7;
+      const double *src = lds + i * kCamPitch + part * 33;
+      double v[32];
+#pragma unroll
+      for (int j = 0; j < 32; j++) v[j] = src[j];
+      double sum = 0;
+#pragma unroll
+      for (int j = 0; j < 32; j++) sum += v[j];
+      sum += dpp_f64<0xB1>(sum);   // quad_perm [1,0,3,2]
+      sum += dpp_f64<0x4E>(sum);   // quad_perm [2,3,0,1]
+      sum += dpp_f64<0x141>(sum);  // row_half_mirror: the other quad of the 8 lanes
+      if (part == 0) o[i] = sum;
+    }
+  } else {
+    block_sum<27, kCamChunk / 64>(acc, lds);
+    if (tid == 0) {  // static indices only (a runtime-indexed acc[] would live in scratch memory)
+#pragma unroll
+      for (int i = 0; i < 27; i++) o[i] = acc[i];
+    }
   }
+#ifdef VO_BA_STAMPS
+  if (tid == 0) atomicMax(&B.dbg[35], (unsigned long long)__builtin_amdgcn_s_memrealtime());
+#endif
 }
 
 // --------------------------------------------------------------------------------------------
@@ -1034,7 +1051,8 @@ constexpr int kChunkPts = 512;  // points per K-slice (LDS table of their damped
 #define STAMP0(i)
 #endif
 constexpr int kGemmWaves = kGemmThreads / 64;
-constexpr int kGemmLdsDoubles = kGemmWaves * 256 + kChunkPts * 6 + kGemmWaves * 27;  // part, hinvL, lds27
+constexpr int kGemmLdsTile = kGemmWaves * 256 + kChunkPts * 6;  // part, hinvL
+constexpr int kGemmLdsDoubles = kGemmLdsTile > 27 * kCamPitch ? kGemmLdsTile : 27 * kCamPitch;  // or the camera role's 27 rows
 
 __device__ __forceinline__ void ba_gemm_tile_role(const BaDev &B, const BaState &st, double *sm, int ntiles, int tdim);
 
@@ -1052,7 +1070,7 @@ __global__ __launch_bounds__(kGemmThreads) void k_ba_gemm(BaDev B) {
   if ((int)blockIdx.x >= ntiles * B.ksplit) {  // camera-block role (independent of the tiles)
     if (threadIdx.x >= kCamChunk) return;  // retired wavefronts do not take part in the role's barriers
     const int q = blockIdx.x - ntiles * B.ksplit;
-    ba_cams_role(B, st, q / B.n_cchunks, q % B.n_cchunks, sm + kGemmWaves * 256 + kChunkPts * 6);
+    ba_cams_role<true>(B, st, q / B.n_cchunks, q % B.n_cchunks, sm);  // the role's blocks use none of the tile buffers
   } else {
     ba_gemm_tile_role(B, st, sm, ntiles, tdim);
   }
@@ -1489,26 +1507,38 @@ __device__ __forceinline__ void ba_solve_body(const BaDev &B, const BaState &st0
   // published twice -- so the scalar form stays; the pivot chain and the panel substitution, not the
   // update, are the latency floor.)
   double *rdv = Ldg + nb * 21;  // 1/d_j of all n pivots
-  bool ok_all = true;
+  // Look-ahead: while wavefronts 1.. update the trailing matrix with block column k, wavefront 0 updates only the next
+  // diagonal block, factors it and publishes L / 1/d in LDS, so the ~0.4 us pivot chain of ldl6 is off the critical
+  // path of every block column but the first.  Same operations on the same operands as the plain right-looking form.
   PHASE_DECL;
-  for (int k = 0; k < nb; k++) {
-    const int K0 = 6 * k;
-    double L[21], rd[6];
+  const int wave = tid >> 6;
+  if (nb > 0) {  // (all cameras fixed: a points-only problem has no reduced system)
+    double L0[21], rd0[6];
 #pragma unroll
     for (int i = 0; i < 6; i++)
 #pragma unroll
-      for (int j = 0; j <= i; j++) L[i * (i + 1) / 2 + j] = A[(K0 + i) * ld + K0 + j];
-    PHASE(0);
-    ok_all = ldl6_packed(L, rd) && ok_all;
-    PHASE(1);
-    // static indices only: a runtime-indexed register array would be demoted to scratch memory
+      for (int j = 0; j <= i; j++) L0[i * (i + 1) / 2 + j] = A[i * ld + j];
+    const bool ok0 = ldl6_packed(L0, rd0);  // every thread, redundantly: nothing to wait for
     if (tid == 0) {
+      if (!ok0) s_fail = 1;
 #pragma unroll
-      for (int i = 0; i < 21; i++) Ldg[k * 21 + i] = L[i];
+      for (int i = 0; i < 21; i++) Ldg[i] = L0[i];
 #pragma unroll
-      for (int i = 0; i < 6; i++) rdv[K0 + i] = rd[i];
+      for (int i = 0; i < 6; i++) rdv[i] = rd0[i];
     }
-    for (int r = K0 + 6 + tid; r <= n; r += NT) {  // u_rt = A[r][t] - sum_{q<t} u_rq l_tq
+    __syncthreads();
+  }
+  for (int k = 0; k < nb; k++) {
+    const int K0 = 6 * k, R0 = K0 + 6;
+    double L[21], rd[6];
+    if (R0 + (tid & ~63) <= n) {  // wavefronts that own a panel row (LDS bandwidth is per CU: no redundant loads)
+#pragma unroll
+      for (int i = 0; i < 21; i++) L[i] = Ldg[k * 21 + i];
+    }
+#pragma unroll
+    for (int i = 0; i < 6; i++) rd[i] = rdv[K0 + i];
+    PHASE(0);
+    for (int r = R0 + tid; r <= n; r += NT) {  // u_rt = A[r][t] - sum_{q<t} u_rq l_tq
       double x[6];
 #pragma unroll
       for (int t = 0; t < 6; t++) {
@@ -1523,13 +1553,43 @@ __device__ __forceinline__ void ba_solve_body(const BaDev &B, const BaState &st0
     PHASE(2);
     __syncthreads();
     PHASE(3);
-    {
-      const int tx = tid & 15, ty = tid >> 4;
-      for (int r = K0 + 6 + ty; r <= n; r += NT / 16) {
+    if (wave == 0) {
+      if (k + 1 < nb) {  // rows R0 .. R0+5 of the trailing matrix are exactly the next diagonal block
+        int i = 0, j = 0;  // lane e < 21 -> (i, j), j <= i
+        {
+          int e = tid < 21 ? tid : 0;
+          while (e > i) e -= ++i;
+          j = e;
+        }
+        const int r = R0 + i, c = R0 + j;
+        double acc = 0;
+#pragma unroll
+        for (int t = 0; t < 6; t++) acc += (A[r * ld + K0 + t] * rd[t]) * A[c * ld + K0 + t];
+        if (tid < 21) A[r * ld + c] -= acc;
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_wave_barrier();
+        double Ln[21], rdn[6];
+#pragma unroll
+        for (int a = 0; a < 6; a++)
+#pragma unroll
+          for (int bq = 0; bq <= a; bq++) Ln[a * (a + 1) / 2 + bq] = A[(R0 + a) * ld + R0 + bq];
+        PHASE(1);
+        const bool okn = ldl6_packed(Ln, rdn);
+        if (tid == 0) {
+          if (!okn) s_fail = 1;
+#pragma unroll
+          for (int a = 0; a < 21; a++) Ldg[(k + 1) * 21 + a] = Ln[a];
+#pragma unroll
+          for (int a = 0; a < 6; a++) rdv[R0 + a] = rdn[a];
+        }
+      }
+    } else {
+      const int tt = tid - 64, tx = tt & 15, ty = tt >> 4;
+      for (int r = R0 + 6 + ty; r <= n; r += (NT - 64) / 16) {
         double w[6];
 #pragma unroll
         for (int t = 0; t < 6; t++) w[t] = A[r * ld + K0 + t] * rd[t];
-        for (int c = K0 + 6 + tx; c <= r && c < n; c += 16) {
+        for (int c = R0 + tx; c <= r && c < n; c += 16) {
           double acc = 0;
 #pragma unroll
           for (int t = 0; t < 6; t++) acc += w[t] * A[c * ld + K0 + t];
@@ -1542,11 +1602,56 @@ __device__ __forceinline__ void ba_solve_body(const BaDev &B, const BaState &st0
     PHASE(3);
   }
   PHASE_STORE(48);
-  if (!ok_all && tid == 0) s_fail = 1;  // every thread saw the same pivots
-  __syncthreads();
   STAMP(3);
   // back substitution  L^T y = D^-1 w  (w = row n), block by block from the bottom; row n keeps
   // w_i - sum_{r>i} u_ri y_r and is scaled by 1/d_i when its block is solved
+  if (n < 64) {
+    // One wavefront, lane = column, no barrier: w_i lives in a register, the pivots' entries come by v_readlane, and the
+    // next block's operands (L, 1/d, the six u_ri of this lane) are in flight while the current block is solved.
+    if (wave == 0) {
+      const int i = tid;
+      double wi = A[n * ld + (i < n ? i : 0)], yi = 0;
+      auto loadblk = [&](int kb, double (&Lb)[21], double (&rb)[6], double (&ab)[6]) {
+        const int Kb = 6 * kb, ii = i < Kb ? i : 0;
+#pragma unroll
+        for (int q = 0; q < 21; q++) Lb[q] = Ldg[kb * 21 + q];
+#pragma unroll
+        for (int t = 0; t < 6; t++) rb[t] = rdv[Kb + t], ab[t] = A[(Kb + t) * ld + ii];
+      };
+      auto step = [&](int kb, const double (&Lc)[21], const double (&rc)[6], const double (&ac)[6], double (&Ln)[21],
+                      double (&rn)[6], double (&an)[6]) {
+        const int Kb = 6 * kb;
+        loadblk(kb > 0 ? kb - 1 : 0, Ln, rn, an);
+        double yk[6];
+#pragma unroll
+        for (int t = 5; t >= 0; t--) {
+          double v = readlane_f64(wi, Kb + t) * rc[t];
+#pragma unroll
+          for (int q = t + 1; q < 6; q++) v -= Lc[q * (q + 1) / 2 + t] * yk[q];
+          yk[t] = v;
+        }
+#pragma unroll
+        for (int t = 0; t < 6; t++) yi = i == Kb + t ? yk[t] : yi;
+        double acc = 0;
+#pragma unroll
+        for (int t = 0; t < 6; t++) acc += ac[t] * yk[t];
+        wi = i < Kb ? wi - acc : wi;
+      };
+      double LA[21], rA[6], aA[6], LB[21], rB[6], aB[6];
+      int kb = nb - 1;
+      if (kb >= 0) {
+        loadblk(kb, LA, rA, aA);
+        for (;;) {
+          step(kb, LA, rA, aA, LB, rB, aB);
+          if (--kb < 0) break;
+          step(kb, LB, rB, aB, LA, rA, aA);
+          if (--kb < 0) break;
+        }
+      }
+      if (i < n) y[i] = yi;
+    }
+    __syncthreads();
+  } else
   for (int k = nb - 1; k >= 0; k--) {
     const int K0 = 6 * k;
     double L[21], yk[6];
@@ -1694,7 +1799,7 @@ __global__ __launch_bounds__(kCamChunk) void k_ba_cams_large(BaDev B) {
   __shared__ double lds27[4 * 27];
   const BaState st = *B.st;
   if (st.done) return;
-  ba_cams_role(B, st, blockIdx.x / B.n_cchunks, blockIdx.x % B.n_cchunks, lds27);
+  ba_cams_role<false>(B, st, blockIdx.x / B.n_cchunks, blockIdx.x % B.n_cchunks, lds27);
 }
 
 __global__ __launch_bounds__(256) void k_ba_pairs(BaDev B) {
