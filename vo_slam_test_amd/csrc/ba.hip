@@ -1307,11 +1307,14 @@ __device__ __forceinline__ bool ldl6_packed(double L[21], double rd[6]) {
 
 constexpr int kSolveThreads = 512;  // two wavefronts per SIMD: a lone wavefront issues one instruction per ~8 cycles
 constexpr int kSolveRed = 16 * 5 + 48;  // block_sum<5> of up to 16 wavefronts
-__device__ __forceinline__ void ba_solve_body(const BaDev &B, const BaState &st0, double *sm) {
+__device__ __forceinline__ void ba_solve_body(const BaDev &B, double *sm) {
   BaState *S = B.st;
-  if (st0.done) return;
   const int tid = threadIdx.x;
   constexpr int NT = kSolveThreads;
+  // The state and everything whose address does not depend on it (the reduced system, the camera-block slabs) are
+  // requested together: one round trip instead of two before the first barrier (~1.3 us).  The state's load is issued
+  // first, so waiting for it (vmcnt counts in order) leaves the others in flight; only the poses need st.cur.
+  const BaState st0 = *S;
   STAMP(0);
 #ifdef VO_BA_STAMPS
   if (tid == 0) B.dbg[30] = __builtin_readcyclecounter();
@@ -1328,17 +1331,14 @@ __device__ __forceinline__ void ba_solve_body(const BaDev &B, const BaState &st0
   const double *G = B.payload;
   // camera blocks / cost / gradient-max: all-reduced payload in the sharded mode, summed into LDS here otherwise
   double *HPw = B.fused ? red + kSolveRed : B.payload + payload_hpp_off(B);
-  const int cur0 = st0.cur;
-  const int first = st0.first;
-  const double radius = st0.radius;
-  // this thread's camera for the candidate-pose phase: pose and cache are read now, used after the solve
+  // this thread's camera for the candidate-pose phase: pose and cache are read early, used after the solve
   const int pc_cam = tid < B.n_cams ? tid : 0;
-  double xpre[6];
-#pragma unroll
-  for (int a = 0; a < 6; a++) xpre[a] = B.Xc[cur0][6 * pc_cam + a];
-  const PoseCache pcpre = load_pc(B.PC[cur0], pc_cam);
   const int slotpre = B.cam_slot[pc_cam], cinpre = B.cam_in[pc_cam] == B.epoch;
   Se3 expx;
+  double xpre[6];
+  PoseCache pcpre;
+  int cur0, first;
+  double radius;
   // Raw Schur product into A (lower triangle, rhs in row n): entry (c, r >= c) of the payload --
   // all-reduced across GPUs (sharded) or summed over the K slices by k_ba_gemm's tile blocks (fused).
   // Unconditional loads, eight in flight per lane: lanes without an entry read the all-zero slab.
@@ -1346,24 +1346,31 @@ __device__ __forceinline__ void ba_solve_body(const BaDev &B, const BaState &st0
   // s_waitcnt vmcnt(0): every load of the round would be serialised.)
   {
     const double *zero_slab = B.slab_gemm + (long long)B.ksplit * B.Mpad * B.Mpad;  // never written after creation
-    const int ne = n * (n + 1);  // entry e = c * (n + 1) + r, r in [c, n]
-    auto issue = [&](int e0, double (&v)[8], int (&pos)[8]) {
+    // Only the entries that exist are enumerated (instruction issue, not latency, bounds this prologue): the packed
+    // lower triangle row by row, e = r (r + 1) / 2 + c for r < n, then the rhs row n.
+    const int ntri = n * (n + 1) / 2, ne = ntri + n;
+    constexpr int RU = 4;  // entries per thread and round
+    auto issue = [&](int e0, double (&v)[RU], int (&pos)[RU]) {
 #pragma unroll
-      for (int un = 0; un < 8; un++) {
+      for (int un = 0; un < RU; un++) {
         const int e = e0 + un * NT + tid;
-        const int c = (int)__umulhi((unsigned)e, B.div_np1), r = e - c * (n + 1);  // c = e / (n + 1) without the divide
-        const bool valid = e < ne && r >= c;
+        int r = (int)((__fsqrt_rn(8.0f * (float)e + 1.0f) - 1.0f) * 0.5f);
+        r += ((r + 1) * (r + 2) / 2 <= e) ? 1 : 0;
+        r -= (r * (r + 1) / 2 > e) ? 1 : 0;
+        int c = e - r * (r + 1) / 2;
+        if (e >= ntri) r = n, c = e - ntri;
+        const bool valid = e < ne;
         pos[un] = valid ? r * ld + c : -1;
         v[un] = *(valid ? G + (long long)c * B.Mpad + r : zero_slab);
       }
     };
-    auto commit = [&](const double (&v)[8], const int (&pos)[8]) {
+    auto commit = [&](const double (&v)[RU], const int (&pos)[RU]) {
 #pragma unroll
-      for (int un = 0; un < 8; un++)
+      for (int un = 0; un < RU; un++)
         if (pos[un] >= 0) A[pos[un]] = v[un];
     };
-    double v0[8];
-    int pos0[8];
+    double v0[RU];
+    int pos0[RU];
     issue(0, v0, pos0);
     // single shard (no k_ba_reduce): the camera-block slabs of k_ba_gemm's camera role are summed here, one entry
     // per thread, sixteen chunk loads in flight together with the round above
@@ -1372,21 +1379,24 @@ __device__ __forceinline__ void ba_solve_body(const BaDev &B, const BaState &st0
     const int cslot = ci / 27;
     const double *sp = B.slab_cam + (long long)cslot * B.n_cchunks * 27 + (ci - cslot * 27);
     double cv[16];
-    if (B.fused) {
+    const bool slab_thread = B.fused && tid < B.nf * 27;  // whole wavefronts without an entry skip the sixteen loads
+    if (slab_thread) {
 #pragma unroll
       for (int q = 0; q < 16; q++) cv[q] = *(q < B.n_cchunks ? sp + q * 27 : zslab);
     }
-    // exp(x) of this thread's camera while the first round is in flight (the pose loads were issued
-    // before it and return first); se3_plus only has exp(delta), the product and the log left to do
-    expx = se3_exp(xpre);
+    if (st0.done) return;  // (nothing has been written yet)
+    cur0 = st0.cur, first = st0.first, radius = st0.radius;
+#pragma unroll
+    for (int a = 0; a < 6; a++) xpre[a] = B.Xc[cur0][6 * pc_cam + a];
+    pcpre = load_pc(B.PC[cur0], pc_cam);
     commit(v0, pos0);
-    for (int e0 = NT * 8; e0 < ne; e0 += NT * 8) {
-      double v[8];
-      int pos[8];
+    for (int e0 = NT * RU; e0 < ne; e0 += NT * RU) {
+      double v[RU];
+      int pos[RU];
       issue(e0, v, pos);
       commit(v, pos);
     }
-    if (B.fused) {
+    if (slab_thread) {
       double a = 0;
 #pragma unroll
       for (int q = 0; q < 16; q++) a += cv[q];
@@ -1397,8 +1407,10 @@ __device__ __forceinline__ void ba_solve_body(const BaDev &B, const BaState &st0
 #pragma unroll
         for (int q = 0; q < 16; q++) a += v[q];
       }
-      if (tid < B.nf * 27) HPw[tid] = a;
+      HPw[tid] = a;
     }
+    // exp(x) of this thread's camera: se3_plus then only has exp(delta), the product and the log left to do
+    if (tid < B.n_cams) expx = se3_exp(xpre);
   }
   STAMP_DRAIN(10);
   STAMP_DRAIN(11);
@@ -1752,8 +1764,7 @@ __device__ __forceinline__ void ba_solve_body(const BaDev &B, const BaState &st0
 
 __global__ __launch_bounds__(kSolveThreads) void k_ba_solve(BaDev B) {
   extern __shared__ double sm[];
-  const BaState st = *B.st;
-  ba_solve_body(B, st, sm);
+  ba_solve_body(B, sm);
 }
 
 // ============================================================================================
