@@ -37,6 +37,12 @@ typedef enum {
 const char *vo_last_error(void);
 int vo_device_count(void);
 const char *vo_version(void);
+/* The stateless entry points (vo_hamming_matrix, vo_match_*, vo_pose_only_solve, vo_sim3_solve, vo_pose_graph_solve,
+ * vo_chol_solve, ...) keep grow-only device scratch per calling host thread, so that the hot path neither allocates
+ * nor frees (the reference's Matcher / Optimizer are called from three threads).  This
+ * frees what the calling thread holds and returns the number of bytes; the buffers grow again on the next call.
+ * Call it before a worker thread exits, or after a one-off large problem (a 500-key-frame pose graph holds 150 MB). */
+size_t vo_release_thread_scratch(void);
 
 /* cv::KeyPoint memory layout (28 bytes) so that the shim can reinterpret the output array. */
 typedef struct {

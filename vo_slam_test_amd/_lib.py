@@ -35,7 +35,7 @@ _lib = None
 
 # every symbol include/vo_hip.h declares (tests check the .so exports all of them)
 SYMBOLS = [
-    "vo_last_error", "vo_device_count", "vo_version",
+    "vo_last_error", "vo_device_count", "vo_version", "vo_release_thread_scratch",
     "vo_orb_create", "vo_orb_destroy", "vo_orb_set_stream", "vo_orb_levels", "vo_orb_scale_factor",
     "vo_orb_scale_factors", "vo_orb_features_per_level", "vo_orb_max_keypoints", "vo_orb_extract",
     "vo_orb_extract_batch_dev", "vo_orb_sync", "vo_orb_get_level", "vo_orb_get_candidates",
@@ -79,6 +79,7 @@ def lib():
     L = C.CDLL(str(so))
     L.vo_last_error.restype = C.c_char_p
     L.vo_version.restype = C.c_char_p
+    L.vo_release_thread_scratch.restype = C.c_size_t
     L.vo_orb_scale_factor.restype = C.c_float
     for name in SYMBOLS:
         f = getattr(L, name, None)

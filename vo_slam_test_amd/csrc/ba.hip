@@ -2839,7 +2839,7 @@ int vo_pose_only_solve(int n_problems, const int32_t *offsets, const double *poi
                out_bytes = up8(r_out + (size_t)std::max(total, 1));
   hipStream_t st = vo::thread_stream();  // the calling thread's own stream: never queues behind another thread's solve
   thread_local vo::PinnedBuf pinned;
-  thread_local vo::DevBuf d_in, d_out;
+  thread_local vo::ScratchBuf d_in, d_out;
   VO_CHECK(pinned.reserve(std::max(in_bytes, out_bytes)));
   uint8_t *stage = pinned.data();
   if (total > 0) {
@@ -2886,7 +2886,7 @@ int vo_sim3_solve(int n_problems, const int32_t *offsets, const double *cam_matc
   const int total = offsets[n_problems];
   if (total > 0 && (!cam_match || !pix_curr || !inv_sigma_curr || !cam_curr || !pix_match || !inv_sigma_match || !outlier))
     return VO_ERR_INVALID;
-  thread_local vo::DevBuf d_off, d_pm, d_pc, d_isc, d_Pc, d_pxm, d_ism, d_cam, d_pose, d_sc, d_out, d_inl, d_sum;
+  thread_local vo::ScratchBuf d_off, d_pm, d_pc, d_isc, d_Pc, d_pxm, d_ism, d_cam, d_pose, d_sc, d_out, d_inl, d_sum;
   int rc = VO_OK;
   auto fail = [&](int r) { return r; };
   hipStream_t st = vo::thread_stream();

@@ -968,7 +968,7 @@ namespace {
 
 struct HostCtx {  // per host thread: one-slot frame store + staging, grow-only
   vo_frames *fr = nullptr;
-  vo::DevBuf dq, dout;
+  vo::ScratchBuf dq, dout;
   vo::PinnedBuf pin;
 };
 

@@ -219,7 +219,7 @@ int vo_sim3_ransac_eval(int n, const double *cam1_points, const double *cam2_poi
       return VO_ERR_INVALID;
     }
   VO_CHECK(vo::ensure_device());
-  thread_local vo::DevBuf d1, d2, p1, p2, e1, e2, tr, cn, fl, sm;
+  thread_local vo::ScratchBuf d1, d2, p1, p2, e1, e2, tr, cn, fl, sm;
   hipStream_t st = vo::thread_stream();
   const char *W = "vo_sim3_ransac_eval";
   VO_CHECK(vo::upload(d1, cam1_points, (size_t)n * 24, st, W));
@@ -247,7 +247,7 @@ int vo_triangulate(int n, const float *xn1, const float *xn2, const float Tcw1[1
   if (n < 0 || (n > 0 && (!xn1 || !xn2 || !Tcw1 || !Tcw2 || !points || !ok))) return VO_ERR_INVALID;
   if (n == 0) return VO_OK;
   VO_CHECK(vo::ensure_device());
-  thread_local vo::DevBuf a, b, t1, t2, o, k;
+  thread_local vo::ScratchBuf a, b, t1, t2, o, k;
   hipStream_t st = vo::thread_stream();
   const char *W = "vo_triangulate";
   VO_CHECK(vo::upload(a, xn1, (size_t)n * 8, st, W));
@@ -273,7 +273,7 @@ int vo_bow_score(int n_query, const int32_t *query_words, const double *query_va
   const int total = cand_start[n_candidates];
   if (total < 0 || (total > 0 && (!cand_words || !cand_values))) return VO_ERR_INVALID;
   VO_CHECK(vo::ensure_device());
-  thread_local vo::DevBuf qw, qv, cs, cw, cv, sc;
+  thread_local vo::ScratchBuf qw, qv, cs, cw, cv, sc;
   hipStream_t st = vo::thread_stream();
   const char *W = "vo_bow_score";
   VO_CHECK(vo::upload(qw, query_words, (size_t)n_query * 4, st, W));
@@ -304,7 +304,7 @@ int vo_rgb_to_gray(const uint8_t *src, long long n_pixels, int channels, int fir
   if (!src || !dst || n_pixels < 0 || (channels != 3 && channels != 4)) return VO_ERR_INVALID;
   if (n_pixels == 0) return VO_OK;
   VO_CHECK(vo::ensure_device());
-  thread_local vo::DevBuf a, b;
+  thread_local vo::ScratchBuf a, b;
   hipStream_t st = vo::thread_stream();
   VO_CHECK(vo::upload(a, src, (size_t)n_pixels * channels, st, "vo_rgb_to_gray"));
   VO_CHECK(b.reserve((size_t)n_pixels));

@@ -196,7 +196,7 @@ int vo_hamming_matrix(const uint8_t *a, int na, const uint8_t *b, int nb, uint16
   VO_CHECK(vo::ensure_device());
   // per host thread, grow-only: the stateless entry points do not allocate after the first call at a size
   // (never freed: a few MB per calling thread for the life of the process); the calling thread's own stream
-  thread_local vo::DevBuf da, db, dd;
+  thread_local vo::ScratchBuf da, db, dd;
   hipStream_t st = vo::thread_stream();
   VO_CHECK(vo::upload(da, a, (size_t)na * 32, st, "vo_hamming_matrix"));
   VO_CHECK(vo::upload(db, b, (size_t)nb * 32, st, "vo_hamming_matrix"));
@@ -222,7 +222,7 @@ int vo_median_descriptor(const uint8_t *desc, int n_sets, const int32_t *offsets
     return VO_ERR_CAPACITY;
   }
   VO_CHECK(vo::ensure_device());
-  thread_local vo::DevBuf dd, doff, dbest;
+  thread_local vo::ScratchBuf dd, doff, dbest;
   hipStream_t st = vo::thread_stream();
   VO_CHECK(vo::upload(dd, desc, (size_t)total * 32, st, "vo_median_descriptor"));
   VO_CHECK(vo::upload(doff, offsets, (size_t)(n_sets + 1) * 4, st, "vo_median_descriptor"));
@@ -476,7 +476,7 @@ int vo_bow_transform(const vo_vocab *v, int n, const uint8_t *desc, int levelsup
                      int32_t *node_id) {
   if (!v || n < 0 || (n > 0 && (!desc || !word_id || !weight || !node_id))) return VO_ERR_INVALID;
   if (n == 0) return VO_OK;
-  thread_local vo::DevBuf d_f, d_w, d_wt, d_n;
+  thread_local vo::ScratchBuf d_f, d_w, d_wt, d_n;
   VO_CHECK(d_f.reserve((size_t)n * 32));
   VO_CHECK(d_w.reserve((size_t)n * 4));
   VO_CHECK(d_wt.reserve((size_t)n * 8));

@@ -258,18 +258,20 @@ __global__ void k_sim3_reanchor(int n, const double *pts_in, const int *ref, con
   pts_out[3 * i] = p[0], pts_out[3 * i + 1] = p[1], pts_out[3 * i + 2] = p[2];
 }
 
-int upload(vo::DevBuf &b, const void *src, size_t bytes) {
-  VO_CHECK(b.reserve(std::max<size_t>(bytes, 64)));
-  if (bytes) VO_HIP_CHECK(hipMemcpy(b.p, src, bytes, hipMemcpyHostToDevice));
-  return VO_OK;
+// All entry points of this file run on the calling host thread's stream with that thread's grow-only scratch
+// (vo_common.h): no hipMalloc / hipFree / hipDeviceSynchronize per call, nothing on the NULL stream.
+int upload(vo::DevBuf &b, const void *src, size_t bytes, hipStream_t st) {
+  return vo::upload(b, src, bytes, st, "pose graph");
 }
 
-double sum_device(const vo::DevBuf &b, int n, int stride = 1, int offset = 0) {  // fixed order, on the host
+int sum_device(const vo::DevBuf &b, int n, hipStream_t st, double &out, int stride = 1, int offset = 0) {  // fixed order, on the host
   std::vector<double> h((size_t)n * stride);
-  (void)hipMemcpy(h.data(), b.p, h.size() * 8, hipMemcpyDeviceToHost);
+  VO_CHECK(vo::copy_d2h(h.data(), b.p, h.size() * 8, st, "pose graph"));
+  VO_CHECK(vo::stream_sync(st, "pose graph"));
   double s = 0;
   for (int i = 0; i < n; i++) s += h[(size_t)i * stride + offset];
-  return s;
+  out = s;
+  return VO_OK;
 }
 
 }  // namespace
@@ -294,27 +296,22 @@ int vo_chol_solve(int n, double *A_rowmajor_lower, double *b) {
       Ap[(size_t)i * ld + i] = 1.0;
     }
   }
-  vo::DevBuf dA, dfail;
-  int rc = VO_OK;
-  auto done = [&](int r) {
-    dA.release(), dfail.release();
-    return r;
-  };
-  if ((rc = upload(dA, Ap.data(), Ap.size() * 8)) != VO_OK) return done(rc);
-  if ((rc = dfail.reserve(vo::chol_workspace_bytes(ld))) != VO_OK) return done(rc);
-  if (hipMemset(dfail.p, 0, 4) != hipSuccess) return done(VO_ERR_HIP);
-  vo::chol_factor_solve(dA.as<double>(), ld, dfail.p, nullptr);
-  if (hipDeviceSynchronize() != hipSuccess) {
-    vo::set_error("Cholesky kernels failed: %s", hipGetErrorString(hipGetLastError()));
-    return done(VO_ERR_HIP);
-  }
+  thread_local vo::ScratchBuf dA, dfail;
+  hipStream_t st = vo::thread_stream();
+  auto done = [&](int r) { return r; };
+  VO_CHECK(upload(dA, Ap.data(), Ap.size() * 8, st));
+  VO_CHECK(dfail.reserve(vo::chol_workspace_bytes(ld)));
+  VO_HIP_CHECK(hipMemsetAsync(dfail.p, 0, 4, st));
+  vo::chol_factor_solve(dA.as<double>(), ld, dfail.p, st);
   int failed = 0;
-  (void)hipMemcpy(&failed, dfail.p, 4, hipMemcpyDeviceToHost);
+  VO_CHECK(vo::copy_d2h(&failed, dfail.p, 4, st, "vo_chol_solve"));
+  VO_CHECK(vo::stream_sync(st, "vo_chol_solve"));
   if (failed) {
     vo::set_error(failed == 1 ? "vo_chol_solve: matrix is not positive definite" : "vo_chol_solve: the factorisation kernel abandoned a wait");
     return done(failed == 1 ? VO_ERR_INVALID : VO_ERR_HIP);
   }
-  (void)hipMemcpy(Ap.data(), dA.p, Ap.size() * 8, hipMemcpyDeviceToHost);
+  VO_CHECK(vo::copy_d2h(Ap.data(), dA.p, Ap.size() * 8, st, "vo_chol_solve"));
+  VO_CHECK(vo::stream_sync(st, "vo_chol_solve"));
   for (int i = 0; i < n; i++) b[i] = Ap[(size_t)(ld + 1) * ld + i];  // solution: row ld + 1
   for (int i = 0; i < n; i++)
     for (int j = 0; j <= i; j++) A_rowmajor_lower[(size_t)i * n + j] = Ap[(size_t)i * ld + j];
@@ -335,7 +332,8 @@ int vo_chol_debug_solve(int n, double *A_rowmajor_lower, double *b, unsigned lon
     }
   }
   vo::DevBuf dA, dws;
-  VO_CHECK(upload(dA, Ap.data(), Ap.size() * 8));
+  VO_CHECK(upload(dA, Ap.data(), Ap.size() * 8, nullptr));
+  VO_HIP_CHECK(hipDeviceSynchronize());
   const size_t wsb = vo::chol_workspace_bytes(ld);
   VO_CHECK(dws.reserve(wsb));
   VO_HIP_CHECK(hipMemset(dws.p, 0, wsb));
@@ -395,27 +393,22 @@ int vo_pose_graph_solve(int n_nodes, double *quats, double *trans, const double 
     memcpy(&x[7 * a], quats + 4 * a, 32);
     memcpy(&x[7 * a + 4], trans + 3 * a, 24);
   }
-  vo::DevBuf d_ei, d_ej, d_qm, d_tm, d_sm, d_sc, d_slot, d_as, d_ae, d_H, d_g, d_cs, d_A, d_rhs, d_x, d_xc, d_part, d_norm,
-      d_fail, d_cost;
-  std::vector<vo::DevBuf *> all = {&d_ei, &d_ej, &d_qm, &d_tm, &d_sm, &d_sc, &d_slot, &d_as, &d_ae, &d_H, &d_g,
-                                   &d_cs, &d_A, &d_rhs, &d_x, &d_xc, &d_part, &d_norm, &d_fail, &d_cost};
-  int rc = VO_OK;
-  auto done = [&](int r) {
-    for (auto *b : all) b->release();
-    return r;
-  };
-#define PG_TRY(expr)                         \
-  if ((rc = (expr)) != VO_OK) return done(rc)
-  PG_TRY(upload(d_ei, edge_i, (size_t)n_edges * 4));
-  PG_TRY(upload(d_ej, edge_j, (size_t)n_edges * 4));
-  PG_TRY(upload(d_qm, q_meas, (size_t)n_edges * 32));
-  PG_TRY(upload(d_tm, t_meas, (size_t)n_edges * 24));
-  PG_TRY(upload(d_sm, s_meas, (size_t)n_edges * 8));
-  PG_TRY(upload(d_sc, scales, (size_t)n_nodes * 8));
-  PG_TRY(upload(d_slot, slot.data(), (size_t)n_nodes * 4));
-  PG_TRY(upload(d_as, adj_start.data(), adj_start.size() * 4));
-  PG_TRY(upload(d_ae, adj_edge.data(), adj_edge.size() * 4));
-  PG_TRY(upload(d_x, x.data(), x.size() * 8));
+  // grow-only, per host thread (150 MB at 500 key-frames; vo_release_thread_scratch() gives it back)
+  thread_local vo::ScratchBuf d_ei, d_ej, d_qm, d_tm, d_sm, d_sc, d_slot, d_as, d_ae, d_H, d_g, d_cs, d_A, d_rhs, d_x,
+      d_xc, d_part, d_norm, d_fail, d_cost;
+  hipStream_t st = vo::thread_stream();
+  auto done = [&](int r) { return r; };
+#define PG_TRY(expr) VO_CHECK(expr)
+  PG_TRY(upload(d_ei, edge_i, (size_t)n_edges * 4, st));
+  PG_TRY(upload(d_ej, edge_j, (size_t)n_edges * 4, st));
+  PG_TRY(upload(d_qm, q_meas, (size_t)n_edges * 32, st));
+  PG_TRY(upload(d_tm, t_meas, (size_t)n_edges * 24, st));
+  PG_TRY(upload(d_sm, s_meas, (size_t)n_edges * 8, st));
+  PG_TRY(upload(d_sc, scales, (size_t)n_nodes * 8, st));
+  PG_TRY(upload(d_slot, slot.data(), (size_t)n_nodes * 4, st));
+  PG_TRY(upload(d_as, adj_start.data(), adj_start.size() * 4, st));
+  PG_TRY(upload(d_ae, adj_edge.data(), adj_edge.size() * 4, st));
+  PG_TRY(upload(d_x, x.data(), x.size() * 8, st));
   PG_TRY(d_xc.reserve(x.size() * 8));
   PG_TRY(d_H.reserve((size_t)ld * ld * 8));
   PG_TRY(d_A.reserve((size_t)(ld + NB) * ld * 8));
@@ -433,24 +426,15 @@ int vo_pose_graph_solve(int n_nodes, double *quats, double *trans, const double 
   P.sm = d_sm.as<double>(), P.scales = d_sc.as<double>(), P.slot = d_slot.as<int>();
   P.adj_start = d_as.as<int>(), P.adj_edge = d_ae.as<int>(), P.H = d_H.as<double>(), P.g = d_g.as<double>();
   P.colscale = d_cs.as<double>();
-  auto sync = [&]() -> int {
-    if (hipDeviceSynchronize() != hipSuccess) {
-      vo::set_error("pose-graph kernel failed: %s", hipGetErrorString(hipGetLastError()));
-      return VO_ERR_HIP;
-    }
-    return VO_OK;
-  };
   auto cost_of = [&](const double *dx, double &c) -> int {
-    hipLaunchKernelGGL(k_pg_cost, dim3(cost_blocks), dim3(256), 0, nullptr, P, dx, d_cost.as<double>());
-    VO_CHECK(sync());
-    c = sum_device(d_cost, cost_blocks);
-    return VO_OK;
+    hipLaunchKernelGGL(k_pg_cost, dim3(cost_blocks), dim3(256), 0, st, P, dx, d_cost.as<double>());
+    return sum_device(d_cost, cost_blocks, st, c);
   };
   auto linearize = [&](const double *dx, int first, double &gmax) -> int {
-    hipLaunchKernelGGL(k_pg_linearize, dim3(n_nodes), dim3(64), 0, nullptr, P, dx, first);
-    VO_CHECK(sync());
+    hipLaunchKernelGGL(k_pg_linearize, dim3(n_nodes), dim3(64), 0, st, P, dx, first);
     std::vector<double> g(n);
-    (void)hipMemcpy(g.data(), d_g.p, (size_t)n * 8, hipMemcpyDeviceToHost);
+    VO_CHECK(vo::copy_d2h(g.data(), d_g.p, (size_t)n * 8, st, "pose graph"));
+    VO_CHECK(vo::stream_sync(st, "pose graph"));
     gmax = 0;
     for (double v : g) gmax = std::max(gmax, std::fabs(v));
     return VO_OK;
@@ -479,20 +463,27 @@ int vo_pose_graph_solve(int n_nodes, double *quats, double *trans, const double 
     iterations = it;
     last_ok = false;
     // damped system, factorisation, solve
-    int zero = 0;
-    (void)hipMemcpy(d_fail.p, &zero, 4, hipMemcpyHostToDevice);
-    hipLaunchKernelGGL(k_pg_damp, dim3((unsigned)(((long long)ld * ld + 255) / 256)), dim3(256), 0, nullptr, P,
+    VO_HIP_CHECK(hipMemsetAsync(d_fail.p, 0, 4, st));
+    hipLaunchKernelGGL(k_pg_damp, dim3((unsigned)(((long long)ld * ld + 255) / 256)), dim3(256), 0, st, P,
                        d_A.as<double>(), d_rhs.as<double>(), radius);
-    (void)hipMemsetAsync(d_A.as<double>() + (size_t)(ld + 1) * ld, 0, (size_t)(NB - 1) * ld * 8, nullptr);  // rows below the rhs
-    vo::chol_factor_solve(d_A.as<double>(), ld, d_fail.p, nullptr);
+    VO_HIP_CHECK(hipMemsetAsync(d_A.as<double>() + (size_t)(ld + 1) * ld, 0, (size_t)(NB - 1) * ld * 8, st));  // rows below the rhs
+    vo::chol_factor_solve(d_A.as<double>(), ld, d_fail.p, st);
     const double *ysol = d_A.as<double>() + (size_t)(ld + 1) * ld;
-    hipLaunchKernelGGL(k_pg_model, dim3(n), dim3(256), 0, nullptr, P, ysol, d_part.as<double>());
-    hipLaunchKernelGGL(k_pg_candidate, dim3((n_nodes + 127) / 128), dim3(128), 0, nullptr, P, dx, ysol, dxc,
+    hipLaunchKernelGGL(k_pg_model, dim3(n), dim3(256), 0, st, P, ysol, d_part.as<double>());
+    hipLaunchKernelGGL(k_pg_candidate, dim3((n_nodes + 127) / 128), dim3(128), 0, st, P, dx, ysol, dxc,
                        d_norm.as<double>());
-    PG_TRY(sync());
+    hipLaunchKernelGGL(k_pg_cost, dim3(cost_blocks), dim3(256), 0, st, P, dxc, d_cost.as<double>());  // the candidate's cost
+    // one synchronisation per LM iteration: fail flag, model partials, norms and candidate cost come back together
     int failed = 0;
-    (void)hipMemcpy(&failed, d_fail.p, 4, hipMemcpyDeviceToHost);
-    double model = failed ? 0.0 : sum_device(d_part, n);
+    std::vector<double> h_part(n), h_norm(2 * (size_t)n_nodes), h_cost(cost_blocks);
+    PG_TRY(vo::copy_d2h(&failed, d_fail.p, 4, st, "pose graph"));
+    PG_TRY(vo::copy_d2h(h_part.data(), d_part.p, h_part.size() * 8, st, "pose graph"));
+    PG_TRY(vo::copy_d2h(h_norm.data(), d_norm.p, h_norm.size() * 8, st, "pose graph"));
+    PG_TRY(vo::copy_d2h(h_cost.data(), d_cost.p, h_cost.size() * 8, st, "pose graph"));
+    PG_TRY(vo::stream_sync(st, "pose graph"));
+    double model = 0;
+    if (!failed)
+      for (double v : h_part) model += v;
     if (failed || !(model > 0.0) || !std::isfinite(model)) {
       if (++invalid >= 5) {
         termination = 4;
@@ -503,10 +494,11 @@ int vo_pose_graph_solve(int n_nodes, double *quats, double *trans, const double 
       continue;
     }
     invalid = 0;
-    double cand = 0;
-    PG_TRY(cost_of(dxc, cand));
+    double cand = 0, xn2 = 0, sn2 = 0;
+    for (double v : h_cost) cand += v;
     if (!std::isfinite(cand)) cand = 1.7976931348623157e308;
-    const double x_norm = std::sqrt(sum_device(d_norm, n_nodes, 2, 0)), step_norm = std::sqrt(sum_device(d_norm, n_nodes, 2, 1));
+    for (int a = 0; a < n_nodes; a++) xn2 += h_norm[2 * (size_t)a], sn2 += h_norm[2 * (size_t)a + 1];
+    const double x_norm = std::sqrt(xn2), step_norm = std::sqrt(sn2);
     if (step_norm <= 1e-8 * (x_norm + 1e-8)) {
       termination = 2;
       break;
@@ -533,7 +525,8 @@ int vo_pose_graph_solve(int n_nodes, double *quats, double *trans, const double 
   }
   summary->iterations = iterations, summary->accepted = accepted, summary->termination = termination;
   summary->final_cost = x_cost, summary->final_radius = radius;
-  (void)hipMemcpy(x.data(), dx, x.size() * 8, hipMemcpyDeviceToHost);
+  PG_TRY(vo::copy_d2h(x.data(), dx, x.size() * 8, st, "pose graph"));
+  PG_TRY(vo::stream_sync(st, "pose graph"));
   for (int a = 0; a < n_nodes; a++) {
     memcpy(quats + 4 * a, &x[7 * a], 32);
     memcpy(trans + 3 * a, &x[7 * a + 4], 24);
@@ -548,25 +541,17 @@ int vo_sim3_reanchor_points(int n_points, const double *points_in, const int32_t
     return VO_ERR_INVALID;
   if (n_points == 0) return VO_OK;
   VO_CHECK(vo::ensure_device());
-  vo::DevBuf dp, dr, d1, d2, dout;
-  int rc = VO_OK;
-  auto done = [&](int r) {
-    dp.release(), dr.release(), d1.release(), d2.release(), dout.release();
-    return r;
-  };
-  if ((rc = upload(dp, points_in, (size_t)n_points * 24)) != VO_OK) return done(rc);
-  if ((rc = upload(dr, ref_node, (size_t)n_points * 4)) != VO_OK) return done(rc);
-  if ((rc = upload(d1, S_rw, (size_t)n_nodes * 64)) != VO_OK) return done(rc);
-  if ((rc = upload(d2, S_wr, (size_t)n_nodes * 64)) != VO_OK) return done(rc);
-  if ((rc = dout.reserve((size_t)n_points * 24)) != VO_OK) return done(rc);
-  hipLaunchKernelGGL(k_sim3_reanchor, dim3((n_points + 255) / 256), dim3(256), 0, nullptr, n_points, dp.as<double>(),
+  thread_local vo::ScratchBuf dp, dr, d1, d2, dout;
+  hipStream_t st = vo::thread_stream();
+  VO_CHECK(upload(dp, points_in, (size_t)n_points * 24, st));
+  VO_CHECK(upload(dr, ref_node, (size_t)n_points * 4, st));
+  VO_CHECK(upload(d1, S_rw, (size_t)n_nodes * 64, st));
+  VO_CHECK(upload(d2, S_wr, (size_t)n_nodes * 64, st));
+  VO_CHECK(dout.reserve((size_t)n_points * 24));
+  hipLaunchKernelGGL(k_sim3_reanchor, dim3((n_points + 255) / 256), dim3(256), 0, st, n_points, dp.as<double>(),
                      dr.as<int>(), d1.as<double>(), d2.as<double>(), dout.as<double>());
-  if (hipDeviceSynchronize() != hipSuccess) {
-    vo::set_error("re-anchor kernel failed: %s", hipGetErrorString(hipGetLastError()));
-    return done(VO_ERR_HIP);
-  }
-  (void)hipMemcpy(points_out, dout.p, (size_t)n_points * 24, hipMemcpyDeviceToHost);
-  return done(VO_OK);
+  VO_CHECK(vo::copy_d2h(points_out, dout.p, (size_t)n_points * 24, st, "vo_sim3_reanchor_points"));
+  return vo::stream_sync(st, "vo_sim3_reanchor_points");
 }
 
 }  // extern "C"

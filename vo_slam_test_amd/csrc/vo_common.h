@@ -53,6 +53,15 @@ struct DevBuf {
   }
 };
 
+// Grow-only device scratch of the stateless entry points: one set per host thread (`thread_local ScratchBuf`), kept
+// between calls so that the hot path neither allocates nor frees (hipFree synchronises the whole device).  Every
+// ScratchBuf registers itself with its thread; vo_release_thread_scratch() frees what the calling thread holds (the
+// buffers grow again on the next call), e.g. before a worker thread exits or after a one-off 150 MB pose graph.
+struct ScratchBuf : DevBuf {
+  ScratchBuf();
+};
+size_t release_thread_scratch();  // bytes freed
+
 // Grow-only page-locked host staging (per host thread where used): copies to and from it run at full PCIe
 // rate and without the runtime's own bounce buffer.  Never freed (thread-exit order vs. runtime teardown).
 struct PinnedBuf {

@@ -1,6 +1,8 @@
 // vo_common.hip -- error reporting and device bring-up shared by every C-ABI entry point.
 #include "vo_common.h"
 
+#include <vector>
+
 #include <mutex>
 
 namespace vo {
@@ -28,6 +30,18 @@ int ensure_device() {
   if (status != VO_OK)
     set_error("no usable HIP device: this library has no CPU fallback (build target gfx950 / MI355X)");
   return status;
+}
+
+static thread_local std::vector<DevBuf *> *g_scratch = nullptr;  // heap: no destructor order issues at thread exit
+ScratchBuf::ScratchBuf() {
+  if (!g_scratch) g_scratch = new std::vector<DevBuf *>();
+  g_scratch->push_back(this);
+}
+size_t release_thread_scratch() {
+  size_t freed = 0;
+  if (g_scratch)
+    for (DevBuf *b : *g_scratch) freed += b->bytes, b->release();
+  return freed;
 }
 
 hipStream_t thread_stream() {
@@ -87,4 +101,5 @@ int vo_device_count(void) {
   return n;
 }
 const char *vo_version(void) { return "vo_slam_test_amd 0.1 (gfx950)"; }
+size_t vo_release_thread_scratch(void) { return vo::release_thread_scratch(); }
 }
