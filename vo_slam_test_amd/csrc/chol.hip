@@ -64,8 +64,9 @@ __device__ __forceinline__ double bcast_lane(double v, int src_lane) {
 struct CholCtx {
   double *A;
   int ld, m;          // m = ld / 64 tile columns; tile row m = the right-hand-side rows
-  int *fail, *ticket, *done, *ready, *xready, *pcount;
+  int *fail, *ticket, *done, *ready, *xready, *pcount, *invready;
   double *partial;    // [m][m][64] far partial products of the backward substitution
+  double *linv;       // [m][64][64] inverses of the diagonal tiles (backward substitution by products, not by 64 pivots)
   int spin_limit;
   unsigned long long *stamps;  // [2 m][16] (VO_CHOL_STAMPS builds)
 };
@@ -97,6 +98,21 @@ typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 constexpr int kSc1 = 1 << 4;  // cache-policy bit of the raw buffer intrinsics on gfx94x / gfx950
 __device__ __forceinline__ __amdgpu_buffer_rsrc_t tile_rsrc(const CholCtx &C) {
   return __builtin_amdgcn_make_buffer_rsrc((void *)C.A, 0, (int)(((long long)(C.ld + NB) * C.ld * 8) & 0x7fffffff), 0x00020000);
+}
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t linv_rsrc(const CholCtx &C) {
+  return __builtin_amdgcn_make_buffer_rsrc((void *)C.linv, 0, (int)((long long)C.m * NB * NB * 8), 0x00020000);
+}
+__device__ __forceinline__ void load_tile_rs(const __amdgpu_buffer_rsrc_t rs, int pitch, int R0, int C0, double (*T)[LP]) {
+  const int tid = threadIdx.x, c = 2 * (tid & 31), rr = tid >> 5;
+  u32x4 v[8];
+#pragma unroll
+  for (int q = 0; q < 8; q++)
+    v[q] = __builtin_amdgcn_raw_buffer_load_b128(rs, (int)(((long long)(R0 + rr + 8 * q) * pitch + C0 + c) * 8), 0, kSc1);
+#pragma unroll
+  for (int q = 0; q < 8; q++) {
+    T[rr + 8 * q][c] = __longlong_as_double(((unsigned long long)v[q].y << 32) | v[q].x);
+    T[rr + 8 * q][c + 1] = __longlong_as_double(((unsigned long long)v[q].w << 32) | v[q].z);
+  }
 }
 __device__ __forceinline__ void load_tile(const CholCtx &C, int R0, int C0, double (*T)[LP], bool /*coherent*/) {
   const int tid = threadIdx.x, c = 2 * (tid & 31), rr = tid >> 5;
@@ -233,21 +249,34 @@ __global__ __launch_bounds__(256) void k_chol_tiles(CholCtx C) {
   const int nF = m * (m + 1) / 2 + m;                 // factorisation tasks: tiles (i >= j) and the rhs tile row
   int nFar = 0;                                       // off-chain tiles of the backward substitution: i >= j + 2
   for (int i = 2; i < m; i++) nFar += i - 1;
+  const int nI = m;                                   // inverses of the diagonal tiles (off the factorisation's chain)
   const int nB = 1 + nFar;
   for (;;) {
     if (tid == 0) s_ticket = atomicAdd(C.ticket, 1);
     __syncthreads();
     const int t = s_ticket;
     __syncthreads();
-    if (t >= nF + nB) return;
+    if (t >= nF + nI + nB) return;
     if (tid == 0) s_state = ld_flag(C.fail);
     __syncthreads();
     if (s_state != 0) return;  // abandoned (not positive definite, or a dependency timed out)
     __syncthreads();
-    if (t < nF) {
+    // Ticket order: column by column (i = j .. m), and behind column j's tasks the inverse of diagonal tile j - 2, which
+    // is complete by then (a task that polls for a long time costs the chain memory bandwidth on the flag lines); the
+    // last two inverses follow the last column.
+    int tj = 0, trem = t, inv_j = -1;
+    if (t < nF + nI) {
+      for (; tj < m; tj++) {
+        const int cnt = m - tj + 1 + (tj >= 2 ? 1 : 0);
+        if (trem < cnt) break;
+        trem -= cnt;
+      }
+      if (tj == m) inv_j = (m >= 2 ? m - 2 : 0) + trem;
+      else if (trem == m - tj + 1) inv_j = tj - 2;
+    }
+    if (t < nF + nI && inv_j < 0) {
       // ---------------------------------------------------------------- factorisation task: ticket -> (i, j)
-      int j = 0, rem = t;
-      while (rem >= m - j + 1) rem -= m - j + 1, j++;
+      const int j = tj, rem = trem;
       const int i = j + rem;                                 // j <= i <= m  (i == m: right-hand-side rows)
       const int R0 = i < m ? NB * i : ld, C0 = NB * j;
       const int qr = (wave >> 1) * 32, qc = (wave & 1) * 32;
@@ -375,50 +404,86 @@ __global__ __launch_bounds__(256) void k_chol_tiles(CholCtx C) {
       __syncthreads();
       return tot;
     };
-    if (t == nF) {
+    if (inv_j >= 0) {
+      // ---------------------------------------------------------------- X = L(j,j)^-1 for the backward substitution.
+      // One wavefront, lane = column of X, L's entries broadcast from LDS: 2016 multiply-adds per lane (~10 us) -- on
+      // nobody's critical path except for the last tile, and it turns the 64 sequential pivots of every backward
+      // step into one tile product.
+      const int j = inv_j;
+      if (!wait_flag(C, C.ready + j * m + j, 4, &s_state)) return;
+      load_tile(C, NB * j, NB * j, Pr, true);
+      if (tid < NB) rdiag[tid] = ld_sc1(rd_all + NB * j + tid);
+      __syncthreads();
+      if (wave == 0) {
+        // X is built row by row in the second LDS tile (a column in 64 registers would cost the whole kernel its second
+        // workgroup per CU): X[r][c] = (delta_rc - sum_{k<r} L[r][k] X[k][c]) / L[r][r], lane = c
+        for (int r = 0; r < NB; r++) {
+          double s0 = lane == r ? 1.0 : 0.0, s1 = 0, s2 = 0, s3 = 0;
+          int k = 0;
+          for (; k + 4 <= r; k += 4) {
+            s0 -= Pr[r][k] * Pc[k][lane];
+            s1 -= Pr[r][k + 1] * Pc[k + 1][lane];
+            s2 -= Pr[r][k + 2] * Pc[k + 2][lane];
+            s3 -= Pr[r][k + 3] * Pc[k + 3][lane];
+          }
+          for (; k < r; k++) s0 -= Pr[r][k] * Pc[k][lane];
+          Pc[r][lane] = ((s0 + s1) + (s2 + s3)) * rdiag[r];
+        }
+        double *out = C.linv + (long long)j * NB * NB;
+        for (int r = 0; r < NB; r++) st_sc1(out + r * NB + lane, Pc[r][lane]);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (lane == 0) atomicAdd(C.invready, 1);  // a counter: the chain waits for all of them at once
+      }
+      continue;
+    }
+    if (t == nF + nI) {
       // ---------------------------------------------------------------- backward substitution, the chain:
-      // x_j = L(j,j)^-T (y_j - L(j+1,j)^T x_{j+1} - S_j), S_j delivered by the other workgroups
+      // x_j = L(j,j)^-T (y_j - L(j+1,j)^T x_{j+1} - S_j), S_j delivered by the other workgroups.  Per column: two
+      // tile products (no pivot loop); x_j is flagged for the far links one step later, when its write-through
+      // store has landed behind the next column's tile loads, so the chain itself never waits for a store.
       CSTAMP(0, 8);
       if (!wait_flag(C, C.done, nF, &s_state)) return;  // every tile of L (and y = L^-1 b) is published
+      if (!wait_flag(C, C.invready, m, &s_state)) return;  // and every inverse
+      const __amdgpu_buffer_rsrc_t rsi = linv_rsrc(C);
+      double *svec = rdiag;  // right-hand side of the column (rdiag is free here)
       for (int j = m - 1; j >= 0; j--) {
         if (j == 0) CSTAMP(0, 9);
         const bool near = j + 1 < m;
         if (near) load_tile(C, NB * (j + 1), NB * j, Pr, true);
-        load_tile(C, NB * j, NB * j, Pc, true);
+        load_tile_rs(rsi, NB, NB * j, 0, Pc);
+        double yj = 0;
+        if (tid < NB) yj = ld_sc1(y + NB * j + tid);
+        // (all vector-memory operations issued so far have completed once the tiles are in LDS: x_{j+1} is visible)
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (near && tid == 0) st_flag(C.xready + j + 1, 1);
         const int links = max(0, m - 2 - j);
         if (links > 0 && !wait_flag(C, C.pcount + j, links, &s_state)) return;
         __syncthreads();
-        double sj = 0;
-        if (tid < NB) {
-          rdiag[tid] = ld_sc1(rd_all + NB * j + tid);
-          sj = ld_sc1(y + NB * j + tid) - (links > 0 ? ld_sc1(Sacc + NB * j + tid) : 0.0);
-        }
+        double sj = yj;
+        if (tid < NB && links > 0) sj -= ld_sc1(Sacc + NB * j + tid);
         if (near) {
           const double nv = tile_matvec_t(Pr, col);  // col = x_{j+1}
           sj -= nv;
         }
-        if (wave == 0) {  // L(j,j)^T x = rhs: lane i holds rhs_i, columns from the bottom
-          double yi = sj;
-#pragma unroll
-          for (int c = NB - 1; c >= 0; c--) {
-            const double xc = bcast_lane(yi, c) * rdiag[c];
-            if (lane == c) yi = xc;
-            if (lane < c) yi -= Pc[c][lane] * xc;
-          }
-          col[lane] = yi;
-          st_sc1(xsol + NB * j + lane, yi);
-        }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (tid < NB) svec[tid] = sj;
         __syncthreads();
-        if (tid == 0) st_flag(C.xready + j, 1);
+        const double xj = tile_matvec_t(Pc, svec);  // X^T s: X is lower triangular, zeros above
+        if (tid < NB) {
+          col[tid] = xj;
+          st_sc1(xsol + NB * j + tid, xj);
+        }
+        __syncthreads();
         if (j == 0) CSTAMP(0, 10);
       }
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+      if (tid == 0) st_flag(C.xready + 0, 1);
       continue;
     }
     {
       // ---------------------------------------------------------------- S_j += L(i,j)^T x_i for i >= j + 2, one link
       // of column j's chain per task: links run i = m-1, m-2, ... (fixed order: deterministic sums)
-      int u = t - nF - 1, i = m - 1;        // ticket order: i descending, then j descending (closest to the chain first)
+      int u = t - nF - nI - 1, i = m - 1;   // ticket order: i descending, then j descending (closest to the chain first)
       while (u >= i - 1) u -= i - 1, i--;
       const int j = i - 2 - u;
       if (!wait_flag(C, C.xready + i, 1, &s_state)) return;
@@ -436,14 +501,14 @@ __global__ __launch_bounds__(256) void k_chol_tiles(CholCtx C) {
   }
 }
 
-int chol_ws_ints(int m) { return 16 + (m + 1) * m + 2 * m; }
+int chol_ws_ints(int m) { return 16 + (m + 1) * m + 3 * m; }
 
 }  // namespace
 
 size_t vo::chol_workspace_bytes(int ld) {
   const int m = ld / NB;
   const size_t ints = ((size_t)chol_ws_ints(m) * 4 + 255) & ~(size_t)255;
-  return ints + ((size_t)m * m * NB + (size_t)m * NB) * 8 + (size_t)2 * m * 16 * 8;
+  return ints + ((size_t)m * m * NB + (size_t)m * NB + (size_t)m * NB * NB) * 8 + (size_t)2 * m * 16 * 8;
 }
 
 void vo::chol_factor_solve(double *A, int ld, void *workspace, hipStream_t st) {
@@ -454,9 +519,10 @@ void vo::chol_factor_solve(double *A, int ld, void *workspace, hipStream_t st) {
   (void)hipMemsetAsync(wsI + 1, 0, ints - 4, st);
   CholCtx C;
   C.A = A, C.ld = ld, C.m = m;
-  C.fail = wsI, C.ticket = wsI + 1, C.done = wsI + 2, C.ready = wsI + 16, C.xready = C.ready + (m + 1) * m, C.pcount = C.xready + m;
+  C.fail = wsI, C.ticket = wsI + 1, C.done = wsI + 2, C.ready = wsI + 16, C.xready = C.ready + (m + 1) * m, C.pcount = C.xready + m, C.invready = C.pcount + m;
   C.partial = reinterpret_cast<double *>(reinterpret_cast<uint8_t *>(workspace) + ints);
-  C.stamps = reinterpret_cast<unsigned long long *>(C.partial + (size_t)m * m * NB + (size_t)m * NB);
+  C.linv = C.partial + (size_t)m * m * NB + (size_t)m * NB;
+  C.stamps = reinterpret_cast<unsigned long long *>(C.linv + (size_t)m * NB * NB);
   C.spin_limit = 4000000;  // ~ a second of polling: far beyond any healthy wait (a factorisation lasts ~1 ms)
   static int n_cu = 0;
   if (!n_cu) {
@@ -473,7 +539,7 @@ void vo::chol_factor_solve(double *A, int ld, void *workspace, hipStream_t st) {
   }
   int nFar = 0;
   for (int i = 2; i < m; i++) nFar += i - 1;
-  const int tasks = m * (m + 1) / 2 + m + 1 + nFar;
+  const int tasks = m * (m + 1) / 2 + m + m + 1 + nFar;
   const int grid = std::max(1, std::min(tasks, 2 * n_cu));
   hipLaunchKernelGGL(k_chol_tiles, dim3(grid), dim3(256), lds, st, C);
 }
