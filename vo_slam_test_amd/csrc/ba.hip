@@ -769,9 +769,10 @@ struct BaDev {
   double *Sd;               // Cholesky storage: reduced system, rhs row, solution row, extras (large_ext_off)
   double *sc_v, *Dd_v, *gpp_v;  // per reduced column: Jacobi scale, LM diagonal, scaled gradient
   int *chol_fail;
-  const int *pair_start;    // [n_pairs + 1] into pair_e
+  const int *pair_start;    // [n_pairs][2] begin / end in pair_e; pairs in work order (below), padded with empty ones
+  int pair_diag_blocks;     // leading workgroups (4 pairs each) that hold the (c, c) pairs
   const int *pair_cc;       // [n_pairs][2] camera slots (c <= c')
-  const int *pair_e;        // [..][2] edge of c, edge of c' at a shared point, in point order
+  const int4 *pair_e;       // [..] (edge of c, edge of c', point, 0) at a shared point, in point order
   int n_pairs;
 };
 
@@ -1813,26 +1814,79 @@ __global__ __launch_bounds__(kCamChunk) void k_ba_cams_large(BaDev B) {
   ba_cams_role<false>(B, st, blockIdx.x / B.n_cchunks, blockIdx.x % B.n_cchunks, lds27);
 }
 
+typedef double double2_t __attribute__((ext_vector_type(2)));
+
+// 36 per-lane partial sums -> their 64-lane totals, one per lane: a reduce-scatter butterfly (each level halves the
+// number of values a lane carries: 38 exchanges instead of the 216 of 36 full butterflies).  Lane l ends up with the
+// total of entry bitreverse6(l) when that is < 36.  Fixed order.
+__device__ __forceinline__ double reduce_scatter36(const double (&v0)[36], int lane, int &index) {
+  auto level = [&](auto nin, const double *in, double *out, int bit, int width) {
+    constexpr int N = decltype(nin)::value;
+#pragma unroll
+    for (int i = 0; i < (N + 1) / 2; i++) {
+      const double lo = in[2 * i], hi = 2 * i + 1 < N ? in[2 * i + 1] : 0.0;
+      const double keep = bit ? hi : lo, send = bit ? lo : hi;
+      out[i] = keep + __shfl_xor(send, width);
+    }
+  };
+  double v1[18], v2[9], v3[5], v4[3], v5[2], v6[1];
+  level(std::integral_constant<int, 36>{}, v0, v1, lane & 32, 32);
+  level(std::integral_constant<int, 18>{}, v1, v2, lane & 16, 16);
+  level(std::integral_constant<int, 9>{}, v2, v3, lane & 8, 8);
+  level(std::integral_constant<int, 5>{}, v3, v4, lane & 4, 4);
+  level(std::integral_constant<int, 3>{}, v4, v5, lane & 2, 2);
+  level(std::integral_constant<int, 2>{}, v5, v6, lane & 1, 1);
+  index = (int)(__brev((unsigned)lane) >> 26);
+  return v6[0];
+}
+
 __global__ __launch_bounds__(256) void k_ba_pairs(BaDev B) {
   const BaState st = *B.st;
   if (st.done) return;
   const int lane = threadIdx.x & 63;
-  const int pr = blockIdx.x * 4 + __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
-  if (pr >= B.n_pairs) return;
+  // Workgroups are dealt round-robin to the 8 XCDs, each with its own L2: behind the diagonal pairs every XCD takes one
+  // contiguous eighth of the list, so the W blocks of the cameras it is working on are fetched into one L2, not eight.
+  int blk = blockIdx.x;
+  if (blk >= B.pair_diag_blocks) {
+    const int q = blk - B.pair_diag_blocks, per_xcd = ((int)gridDim.x - B.pair_diag_blocks) >> 3;
+    blk = B.pair_diag_blocks + (q & 7) * per_xcd + (q >> 3);
+  }
+  const int pr = blk * 4 + __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
   const int c = B.pair_cc[2 * pr], cp = B.pair_cc[2 * pr + 1];
+  const int t0 = B.pair_start[2 * pr], t1 = B.pair_start[2 * pr + 1];
+  if (t1 <= t0) return;  // padding
   const double *We = B.We[st.cur], *gls = B.glsc[st.cur];
   double acc[36], rh[6];
 #pragma unroll
   for (int i = 0; i < 36; i++) acc[i] = 0;
 #pragma unroll
   for (int i = 0; i < 6; i++) rh[i] = 0;
-  for (int t = B.pair_start[pr] + lane; t < B.pair_start[pr + 1]; t += 64) {
-    const int e = B.pair_e[2 * t], ep = B.pair_e[2 * t + 1];
-    if (!B.e_active[e] || !B.e_active[ep]) continue;
-    const int j = B.e_pt[e];
-    const double *hv = B.hinv + 6 * j;
-    const double h00 = hv[0], h01 = hv[1], h02 = hv[2], h11 = hv[3], h12 = hv[4], h22 = hv[5];
-    const double *w = We + 18LL * e, *wp = We + 18LL * ep;
+  // The walk is a chain of dependent loads (couple -> flags, point block, two W blocks); the kernel is bound by that
+  // latency, not by arithmetic or bandwidth.  The couple carries its point index (one load instead of two dependent
+  // ones), the next couple is requested before the current one is used, and every load is unconditional (clamped
+  // index; an inactive or out-of-range couple gets a zero point block, so it adds exact zeros).
+  int4 rec = B.pair_e[min(t0 + lane, t1 - 1)];
+  for (int t = t0 + lane; t - lane < t1; t += 64) {
+    const int4 nxt = B.pair_e[min(t + 64, t1 - 1)];
+    const int e = rec.x, ep = rec.y, j = rec.z;
+    const int act = (int)B.e_active[e] & (int)B.e_active[ep];  // (no short-circuit: both loads are issued now)
+    const bool ok = (t < t1) & (act != 0);
+    // 16-byte loads: the texture-address unit spends ~1.5 cycles per lane and instruction on these scattered blocks
+    // and was busy 91 % of the kernel with 8-byte loads (TA_TA_BUSY); the blocks are 48 and 144 bytes, 16-byte aligned
+    const double2_t *hv2 = reinterpret_cast<const double2_t *>(B.hinv + 6 * j);
+    const double2_t ha = hv2[0], hb = hv2[1], hc = hv2[2];
+    const double h00 = ok ? ha.x : 0.0, h01 = ok ? ha.y : 0.0, h02 = ok ? hb.x : 0.0, h11 = ok ? hb.y : 0.0,
+                 h12 = ok ? hc.x : 0.0, h22 = ok ? hc.y : 0.0;
+    double w[18], wp[18];
+    {
+      const double2_t *w2 = reinterpret_cast<const double2_t *>(We + 18LL * e);
+      const double2_t *wp2 = reinterpret_cast<const double2_t *>(We + 18LL * ep);
+#pragma unroll
+      for (int q = 0; q < 9; q++) {
+        const double2_t a2 = w2[q], b2 = wp2[q];
+        w[2 * q] = a2.x, w[2 * q + 1] = a2.y, wp[2 * q] = b2.x, wp[2 * q + 1] = b2.y;
+      }
+    }
     double Y[6][3];  // (W_e Hinv)[a][k'] with W_e[a][k] = w[6 k + a]
 #pragma unroll
     for (int a = 0; a < 6; a++) {
@@ -1850,18 +1904,13 @@ __global__ __launch_bounds__(256) void k_ba_pairs(BaDev B) {
 #pragma unroll
       for (int a = 0; a < 6; a++) rh[a] += Y[a][0] * g0 + Y[a][1] * g1 + Y[a][2] * g2;
     }
-  }
-#pragma unroll
-  for (int o = 32; o >= 1; o >>= 1) {
-#pragma unroll
-    for (int i = 0; i < 36; i++) acc[i] += __shfl_xor(acc[i], o);
+    rec = nxt;
   }
   // block (row c', column c) of the lower triangle: entry (6c'+b, 6c+a) = -G[a][b]
-  double mine = 0;
-#pragma unroll
-  for (int i = 0; i < 36; i++) mine = (lane == i) ? acc[i] : mine;  // static indices only
-  if (lane < 36) {
-    const int a = lane / 6, b = lane - 6 * a;
+  int idx;
+  const double mine = reduce_scatter36(acc, lane, idx);
+  if (idx < 36) {
+    const int a = idx / 6, b = idx - 6 * a;
     B.Sd[(long long)(6 * cp + b) * B.ld + 6 * c + a] = -mine;
   }
   if (c == cp) {
@@ -1877,8 +1926,6 @@ __global__ __launch_bounds__(256) void k_ba_pairs(BaDev B) {
   }
 }
 
-// this shard's camera-block sums, cost and gradient max into the extras of the reduced-system
-// buffer (summed over the shards by the all-reduce when the problem is sharded)
 __global__ __launch_bounds__(256) void k_ba_partials_large(BaDev B) {
   __shared__ double red[8];
   const BaState st0 = *B.st;
@@ -2511,17 +2558,38 @@ int build_device(vo_ba *h) {
       }
     }
     std::stable_sort(cp.begin(), cp.end(), [](const Couple &x, const Couple &y) { return x.key < y.key; });
-    std::vector<int> pstart, pcc, pe;
-    pe.reserve(2 * cp.size());
+    std::vector<int> pstart, pcc, pe, first;
+    pe.reserve(4 * cp.size());
     for (size_t i = 0; i < cp.size(); i++) {
-      if (i == 0 || cp[i].key != cp[i - 1].key) {
-        pstart.push_back((int)i);
-        pcc.push_back((int)(cp[i].key / h->nf)), pcc.push_back((int)(cp[i].key % h->nf));
-      }
-      pe.push_back(cp[i].e), pe.push_back(cp[i].ep);
+      if (i == 0 || cp[i].key != cp[i - 1].key) first.push_back((int)i);
+      pe.push_back(cp[i].e), pe.push_back(cp[i].ep), pe.push_back(h->e_pt[cp[i].e]), pe.push_back(0);
     }
-    pstart.push_back((int)cp.size());
-    D.n_pairs = (int)pstart.size() - 1;
+    first.push_back((int)cp.size());
+    D.n_pairs = (int)first.size() - 1;
+    // Work order.  First the cameras' own "pairs" (c, c): 5-10 x longer lists than the rest, they must not be what
+    // the kernel ends on.  Then the covisible pairs in list order (c, then c'): neighbouring cameras share their
+    // points, so consecutive pairs read the same W blocks -- measured 322 us in this order against 377 us sorted by
+    // length and 427 us with the diagonal pairs in place.  Both parts are padded with empty pairs to whole groups of
+    // 8 workgroups; the kernel deals the second part to the XCDs in contiguous eighths.
+    std::vector<int> order;
+    auto is_diag = [&](int w) { return cp[first[w]].key / h->nf == cp[first[w]].key % h->nf; };
+    for (int w = 0; w < D.n_pairs; w++)
+      if (is_diag(w)) order.push_back(w);
+    while (order.size() % 32) order.push_back(-1);
+    D.pair_diag_blocks = (int)order.size() / 4;
+    for (int w = 0; w < D.n_pairs; w++)
+      if (!is_diag(w)) order.push_back(w);
+    while (order.size() % 32) order.push_back(-1);
+    D.n_pairs = (int)order.size();
+    for (int w : order) {
+      if (w < 0) {
+        pstart.push_back(0), pstart.push_back(0), pcc.push_back(0), pcc.push_back(0);
+        continue;
+      }
+      pstart.push_back(first[w]), pstart.push_back(first[w + 1]);
+      pcc.push_back((int)(cp[first[w]].key / h->nf)), pcc.push_back((int)(cp[first[w]].key % h->nf));
+    }
+    if (pe.empty()) pe.assign(4, 0);
     VO_CHECK(upload(h->b_pairstart, pstart.data(), pstart.size() * 4));
     VO_CHECK(upload(h->b_paircc, pcc.data(), pcc.size() * 4));
     VO_CHECK(upload(h->b_paire, pe.data(), pe.size() * 4));
@@ -2541,7 +2609,7 @@ int build_device(vo_ba *h) {
     D.Sd = h->ext_payload ? h->ext_payload : h->b_Sd.as<double>();
     D.sc_v = h->b_scv.as<double>(), D.Dd_v = h->b_ddv.as<double>(), D.gpp_v = h->b_gppv.as<double>();
     D.chol_fail = h->b_cholfail.as<int>();
-    D.pair_start = h->b_pairstart.as<int>(), D.pair_cc = h->b_paircc.as<int>(), D.pair_e = h->b_paire.as<int>();
+    D.pair_start = h->b_pairstart.as<int>(), D.pair_cc = h->b_paircc.as<int>(), D.pair_e = h->b_paire.as<int4>();
   }
   VO_CHECK(h->b_scam.reserve((size_t)std::max(1, h->nf) * D.n_cchunks * 27 * 8));
   VO_CHECK(h->b_spt.reserve((size_t)D.n_pblocks * 2 * 8));
@@ -2631,7 +2699,7 @@ int launch_linearize_large(vo_ba *h) {
   hipLaunchKernelGGL(k_ba_hinv_large, dim3((D.n_local + 255) / 256), dim3(256), 0, st, D);
   hipLaunchKernelGGL(k_ba_cams_large, dim3(std::max(1, h->nf * D.n_cchunks)), dim3(kCamChunk), 0, st, D);
   VO_HIP_CHECK(hipMemsetAsync(D.Sd, 0, (size_t)(D.ld + vo::kCholPanel) * D.ld * 8, st));
-  if (D.n_pairs > 0) hipLaunchKernelGGL(k_ba_pairs, dim3((D.n_pairs + 3) / 4), dim3(256), 0, st, D);
+  if (D.n_pairs > 0) hipLaunchKernelGGL(k_ba_pairs, dim3(D.n_pairs / 4), dim3(256), 0, st, D);  // n_pairs: a multiple of 32
   hipLaunchKernelGGL(k_ba_partials_large, dim3(std::max(1, (h->nf * 27 + 255) / 256)), dim3(256), 0, st, D);
   VO_HIP_CHECK(hipGetLastError());
   return VO_OK;
