@@ -114,3 +114,82 @@ def test_tracked_frames_match_the_oracle(vo, orc, distorted):
         assert ninl2[f] == oi2 and np.abs(pose2[f] - op2).max() < 1e-9
         assert oi2 >= 200
     trk.close(), ext.close()
+
+
+@pytest.mark.timeout(300)
+def test_pipelined_trackers_lifecycle(vo):
+    """Two batches in flight (shared extraction stream, high-priority search / pose streams -- bench.py's regime) give
+    exactly the single-stream results, and handles can be closed and re-created while others live on the same streams."""
+    import torch
+    from vo_slam_test_amd.tracking import BatchTracker
+    B, W, H = 8, 640, 480
+    imgs = synth.make_frames(B, start=20)
+    raw = np.stack([synth.make_depth(20 + i) for i in range(B)])
+    inv = float(np.float32(1.0) / np.float32(synth.DEPTH_SCALE))
+    cam5 = synth.CAM.astype(np.float32)
+    t_img = torch.from_numpy(imgs).cuda()
+    t_dep = torch.from_numpy(raw.view(np.int16)).cuda()
+
+    def make(stream, ext_stream):
+        ext = vo.OrbExtractor(1000, 1.2, 8, 20, 7)
+        trk = BatchTracker(B, ext, cam5, synth.DIST, W, H, n_last=1100, n_local=2200, stream=stream, extract_stream=ext_stream)
+        return trk
+
+    def load_map(trk, maps):
+        def stack(which, key, n, tail=()):
+            o = np.zeros((B, n) + tail, maps[0][which][key].dtype)
+            for f in range(B):
+                a = maps[f][which][key]
+                o[f, :len(a)] = a[:n]
+            return o
+        last = dict(points=stack(2, "points", 1100, (3,)), flags=stack(2, "flags", 1100), octave=stack(2, "octave", 1100),
+                    angle=stack(2, "angle", 1100), desc=stack(2, "desc", 1100, (32,)))
+        local = {k: stack(3, k, 2200, (3,) if k == "points" else (32,) if k == "desc" else ())
+                 for k in ("points", "flags", "u", "v", "ur", "level", "viewcos", "desc")}
+        with torch.cuda.stream(trk.stream):
+            trk.set_map(np.stack([m[0] for m in maps]), np.stack([m[1] for m in maps]), last, local)
+        torch.cuda.synchronize()
+
+    # reference: everything on one stream
+    s0 = torch.cuda.Stream()
+    ref = make(s0, None)
+    with torch.cuda.stream(s0):
+        ref.ext.extract_batch_dev(t_img, ref.kps, ref.desc, ref.cnt)
+        ref.frames.build_dev(ref.kps, ref.desc, ref.cnt, t_dep, inv, stream=s0.cuda_stream)
+    torch.cuda.synchronize()
+    maps = []
+    for i in range(B):
+        fr = ref.frames.download(i, stream=s0.cuda_stream)
+        maps.append(synth.make_tracking_map(fr["x"], fr["y"], fr["octave"], fr["angle"], fr["desc"], fr["depth"], seed=i))
+    load_map(ref, maps)
+    ref.track(t_img, t_dep, inv)
+    torch.cuda.synchronize()
+    want = (ref.pose.cpu().numpy().copy(), ref.ninl.cpu().numpy().copy(), ref.assigned.cpu().numpy().copy())
+    assert want[1].min() >= 100
+
+    es = torch.cuda.Stream()
+    for generation in range(3):
+        trks = [make(torch.cuda.Stream(priority=-1), es) for _ in range(2)]
+        for t in trks:
+            load_map(t, maps)
+        for step in range(6):
+            trks[step % 2].track(t_img, t_dep, inv)
+        torch.cuda.synchronize()
+        for t in trks:
+            t.ext.sync()
+            t.frames.match_status(stream=t.st)
+            assert np.array_equal(t.pose.cpu().numpy(), want[0])
+            assert np.array_equal(t.ninl.cpu().numpy(), want[1])
+            assert np.array_equal(t.assigned.cpu().numpy(), want[2])
+        # close one now, the other after its successor has been created on the same extraction stream
+        trks[0].close(), trks[0].ext.close()
+        keep = trks[1]
+        nxt = make(torch.cuda.Stream(priority=-1), es)
+        load_map(nxt, maps)
+        nxt.track(t_img, t_dep, inv)
+        keep.track(t_img, t_dep, inv)
+        torch.cuda.synchronize()
+        assert np.array_equal(nxt.pose.cpu().numpy(), want[0]) and np.array_equal(keep.pose.cpu().numpy(), want[0])
+        for t in (keep, nxt):
+            t.close(), t.ext.close()
+    ref.close(), ref.ext.close()
