@@ -491,6 +491,118 @@ __global__ __launch_bounds__(64) void k_guided_replay(FramesDev F, Queries Q, Gu
   const bool want2 = P.mode == kModeLocalMap;  // only the ratio test looks at the runner-up
   int cnt = 0, npush = 0;
   constexpr unsigned kNone = 0xffffffffu;
+  // ------------------------------------------------------------------------------------------------------------
+  // Batched replay (every mode but Sim3, frames whose windows all fit their slots): 64 queries per step, lane = query.
+  // Every lane proposes its claim from the blocked[] state left by the previous steps; a proposal is final unless an
+  // EARLIER lane of the same step proposes a blocking claim on a feature of its list (then its best / runner-up may
+  // change) -- the first such lane and everything behind it is re-proposed after the lanes in front have committed.
+  // Conflicts are rare (a handful per frame), so a step is usually one round: ~25 steps instead of ~450 four-query
+  // steps, with the same result as the one-query-at-a-time order of matcher.cpp:76-128.
+  if (!sim3 && O.ovf_used[f] == 0) {
+    int *tmpb = reinterpret_cast<int *>(rp_lds + capA + 2 * (size_t)capA);  // [cap] first blocking lane of the round
+    int *tmpw = tmpb + capA;                                                  // [cap] last final claimant + 1
+    for (int i = lane; i < capA; i += 64) tmpb[i] = 64, tmpw[i] = 0;
+    lds_handoff();
+    constexpr int R = kSlot;  // 32 records per query, all in registers
+    auto fetch64 = [&](int gb, unsigned (&rc)[R], unsigned &cw) {
+      const int q = min(gb + lane, max(nq - 1, 0));
+      cw = gb + lane < nq ? qrec[q].x : 0u;
+      const uint4 *p4 = reinterpret_cast<const uint4 *>(pool + (long long)q * kSlot);
+#pragma unroll
+      for (int k = 0; k < R / 4; k++) {
+        const uint4 v = p4[k];
+        rc[4 * k] = v.x, rc[4 * k + 1] = v.y, rc[4 * k + 2] = v.z, rc[4 * k + 3] = v.w;
+      }
+    };
+    unsigned recN[R], cwN;
+    fetch64(0, recN, cwN);
+    for (int gb = 0; gb < nq; gb += 64) {
+      unsigned rec[R];
+#pragma unroll
+      for (int k = 0; k < R; k++) rec[k] = recN[k];
+      const unsigned cw = cwN;
+      fetch64(gb + 64, recN, cwN);  // in flight while this step is replayed
+      const int cn = (int)(cw & 0x7fffffffu), ob = (int)(cw >> 31);
+      const int cmax = ~(int)wave_min_u32(~(unsigned)cn);  // uniform: chunks of 4 records beyond it are skipped
+      const int blocks = (P.mode == kModeFrame || P.mode == kModeLocalMap) ? ob : 1;
+      bool unresolved = cn > 0;
+      while (__builtin_amdgcn_ballot_w64(unresolved) != 0ull) {  // uniform
+        // 1. proposal: best (and runner-up) among the unblocked records, ties to the earlier position
+        unsigned d1 = kNone, d2 = kNone, r1 = 0, r2 = 0;
+#pragma unroll
+        for (int c4 = 0; c4 < R / 4; c4++) {
+          if (4 * c4 >= cmax) break;  // uniform
+#pragma unroll
+          for (int u = 0; u < 4; u++) {
+            const int pos = 4 * c4 + u;
+            const unsigned rcd = rec[pos];
+            const int idx = min((int)(rcd & 0x3fffu), capA - 1);  // records past the count hold anything
+            const bool valid = unresolved & (pos < cn) & (blocked[idx] == 0);
+            const unsigned d = valid ? ((rcd >> 14) & 0x1ffu) : kNone;
+            const bool lt1 = d < d1, lt2 = d < d2;
+            d2 = lt1 ? d1 : (lt2 ? d : d2), r2 = lt1 ? r1 : (lt2 ? rcd : r2);
+            d1 = lt1 ? d : d1, r1 = lt1 ? rcd : r1;
+          }
+        }
+        const int best = (int)d1, bidx = (int)(r1 & 0x3fffu);
+        bool accept = unresolved && d1 != kNone;
+        if (accept) {
+          if (P.mode == kModeFrame) accept = best <= TH_HIGH;
+          else if (P.mode == kModeLocalMap) {
+            accept = best <= TH_HIGH;
+            if (accept && d2 != kNone) {
+              const int lv1 = (int)((r1 >> 23) & 0xfu), lv2 = (int)((r2 >> 23) & 0xfu);
+              if (lv1 == lv2 && (float)best > P.ratio * (float)(int)d2) accept = false;  // :344
+            }
+          } else if (P.mode == kModeKeyFrame) accept = (float)best <= P.dist_threshold;  // :238
+          else accept = best <= TH_LOW;                                                  // :437
+        }
+        // 2. blocking proposals, earliest lane per feature
+        const bool blocker = accept && blocks != 0;
+        if (blocker) atomicMin(&tmpb[bidx], lane);
+        lds_handoff();
+        // 3. a lane is stale when an earlier lane blocks a feature of its list
+        bool stale = false;
+#pragma unroll
+        for (int c4 = 0; c4 < R / 4; c4++) {
+          if (4 * c4 >= cmax) break;  // uniform
+#pragma unroll
+          for (int u = 0; u < 4; u++) {
+            const int pos = 4 * c4 + u;
+            const int idx = min((int)(rec[pos] & 0x3fffu), capA - 1);
+            stale |= unresolved & (pos < cn) & (tmpb[idx] < lane);
+          }
+        }
+        const unsigned long long sm = __builtin_amdgcn_ballot_w64(stale);
+        const int first_stale = sm ? (int)__builtin_ctzll(sm) : 64;
+        const bool fin = unresolved && lane < first_stale, claim = fin && accept;
+        // 4. several final lanes may claim one feature (non-blocking claims): the last one in query order owns it
+        if (claim) atomicMax(&tmpw[bidx], lane + 1);
+        lds_handoff();
+        const unsigned long long cm = __builtin_amdgcn_ballot_w64(claim);
+        if (claim) {
+          if (tmpw[bidx] == lane + 1) {
+            asg[bidx] = (unsigned short)(gb + lane + 1);
+            blocked[bidx] = (uint8_t)blocks;
+          }
+          if (rot_on) {  // :115-125, in query order
+            const int bin = (int)(r1 >> 27);
+            const int below = (int)__builtin_amdgcn_mbcnt_hi((unsigned)(cm >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)cm, 0u));
+            pushes[npush + below] = (unsigned)bidx | ((unsigned)bin << 16);
+            atomicAdd(&hist[bin], 1);
+          }
+        }
+        const int ncl = (int)__popcll(cm);
+        cnt += ncl;
+        if (rot_on) npush += ncl;
+        lds_handoff();
+        if (blocker) tmpb[bidx] = 64;  // scratch back to its idle state
+        if (claim) tmpw[bidx] = 0;
+        unresolved = unresolved && !fin;
+        lds_handoff();
+      }
+    }
+  } else {
   // the records of a group: row r = query g0 + r, lane l16 = records l16 and 16 + l16 of its slot
   struct Group { unsigned cw, oo, rec0, rec1; unsigned short rk0, rk1; };
   auto fetch = [&](int g0) {
@@ -616,6 +728,7 @@ __global__ __launch_bounds__(64) void k_guided_replay(FramesDev F, Queries Q, Gu
     for (int d = 0; d < D; d++)
       if (gb + 4 * d < nq) replay_group(cur[d], gb + 4 * d);  // uniform
   }
+  }  // serial replay
   lds_handoff();
   if (npush > 0) {  // computeThreeMax (:1258-1304) + pruning (:128-145)
     int m1 = 0, m2 = 0, m3 = 0, i1 = -1, i2 = -1, i3 = -1;
@@ -762,7 +875,8 @@ int guided_launch(vo_frames *h, int slot0, int n_frames, const Queries &Q, const
   if (nq_max > 0)
     hipLaunchKernelGGL(k_guided_cand, dim3((nq_max + 15) / 16, n_frames), dim3(256), 0, st, h->D, Q, P, O, slot0);
   if (claims) {
-    const size_t lds = (size_t)((h->cap + 15) & ~15) + (size_t)h->cap * 2;
+    const size_t capA = (size_t)((h->cap + 15) & ~15);
+    const size_t lds = capA + capA * 2 + capA * 8;  // blocked, asg, and the batched replay's two int arrays
     hipLaunchKernelGGL(k_guided_replay, dim3(n_frames), dim3(64), lds, st, h->D, Q, P, O, slot0);
   } else {
     hipLaunchKernelGGL(k_guided_count, dim3(n_frames), dim3(256), 0, st, Q, best_idx, n_matches);
