@@ -222,6 +222,7 @@ struct GuidedParams {
   float sf[16];
 };
 
+constexpr float kNarrowRadius = 20.f;  // search radius (before the level scale) up to which a query gets 8 lanes, not 16
 constexpr int kSlot = 32;  // candidate records every query owns in the pool; the (rare) rest goes to the overflow area
 
 struct GuidedOut {
@@ -253,16 +254,27 @@ __device__ __forceinline__ unsigned wave_min_u32(unsigned x) {  // minimum over 
              min((unsigned)__builtin_amdgcn_readlane((int)x, 32), (unsigned)__builtin_amdgcn_readlane((int)x, 48)));
 }
 
+template <int G>
+__device__ __forceinline__ unsigned group_min_u32(unsigned x) {  // minimum over the G lanes of a query, in every lane
+  if (G == 16) return row_min_u32(x);
+#pragma unroll
+  for (int o = G / 2; o >= 1; o >>= 1) x = min(x, (unsigned)__shfl_xor((int)x, o, G));
+  return x;
+}
+
 // SIXTEEN LANES per (query, frame): a window holds a dozen items on average, so a 64-lane wavefront per query
 // would idle three quarters of its lanes and -- the kernel is a chain of dependent memory round trips -- need four
 // times the wavefronts.  Sixteen queries per workgroup, no workgroup barrier.  Round trips per query: its fields
 // -> the (start, end) of its grid columns -> the cell-ordered feature records and descriptors (coalesced: the
 // window cells of one grid column are one contiguous run) -> the records out.
+template <int G>  // lanes per query: 16 (wide windows) or 8 (the tracking searches: a handful of features per window;
+                   // measured per 1024 frames, frame / local-map search stage: 16 lanes 0.60 / 0.61 ms, 8: 0.57 / 0.52, 4: 0.67 / 0.73,
+                   // one lane per query 0.85 / 0.72 -- fewer lanes save set-up instructions but scatter the record loads)
 __global__ __launch_bounds__(256) void k_guided_cand(FramesDev F, Queries Q, GuidedParams P, GuidedOut O, int slot0) {
-  constexpr int kMaxCol = 64;
-  __shared__ int s_pre[16][kMaxCol], s_base[16][kMaxCol];
-  const int lane = threadIdx.x & 63, l16 = threadIdx.x & 15, grp = threadIdx.x >> 4, sub = lane >> 4;
-  const int f = blockIdx.y, q = blockIdx.x * 16 + grp;
+  constexpr int kMaxCol = 64, QPB = 256 / G;
+  __shared__ int s_pre[QPB][kMaxCol], s_base[QPB][kMaxCol];
+  const int lane = threadIdx.x & 63, l16 = threadIdx.x & (G - 1), grp = threadIdx.x / G, sub = lane / G;
+  const int f = blockIdx.y, q = blockIdx.x * QPB + grp;
   const int nq = Q.nq ? Q.nq[f] : Q.nq_all;
   const bool live = q < nq;  // (groups past the end idle through the loops: the wave's ballots need every lane)
   const long long qo = (long long)f * Q.stride + (live ? q : 0);
@@ -307,7 +319,7 @@ __global__ __launch_bounds__(256) void k_guided_cand(FramesDev F, Queries Q, Gui
   // grid column x0 + c: its window cells y0..y1 are one contiguous run of the cell-ordered arrays
   const int ncol = window ? x1 - x0 + 1 : 0;
   int T = 0;
-  for (int cb = 0; cb < kMaxCol; cb += 16) {
+  for (int cb = 0; cb < kMaxCol; cb += G) {
     const int c = cb + l16;
     int cbeg = 0, ccnt = 0;
     if (c < ncol) {
@@ -316,14 +328,14 @@ __global__ __launch_bounds__(256) void k_guided_cand(FramesDev F, Queries Q, Gui
     }
     int incl = ccnt;
 #pragma unroll
-    for (int o = 1; o < 16; o <<= 1) {
-      const int t = __shfl_up(incl, o, 16);
+    for (int o = 1; o < G; o <<= 1) {
+      const int t = __shfl_up(incl, o, G);
       if (l16 >= o) incl += t;
     }
     s_pre[grp][c] = T + incl - ccnt;
     s_base[grp][c] = cbeg;
-    T += __shfl(incl, 15, 16);
-    if (__builtin_amdgcn_ballot_w64(cb + 16 < ncol) == 0ull) break;  // no group of the wave has more columns
+    T += __shfl(incl, G - 1, G);
+    if (__builtin_amdgcn_ballot_w64(cb + G < ncol) == 0ull) break;  // no group of the wave has more columns
   }
   __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
   __builtin_amdgcn_wave_barrier();
@@ -382,14 +394,15 @@ __global__ __launch_bounds__(256) void k_guided_cand(FramesDev F, Queries Q, Gui
     return it;
   };
   const int Tmax = (int)(~wave_min_u32(~(unsigned)T));  // max over the wave (uniform trip count)
+  constexpr unsigned kGroupMask = (1u << G) - 1u;
 
   if (!claims) {  // independent queries: arg-min in candidate order, strict < keeps the first minimum
     unsigned best = 0xffffffffu, best_idx = 0;
-    for (int base = 0; base < Tmax; base += 16) {
+    for (int base = 0; base < Tmax; base += G) {
       const Item it = eval(base + l16);
       const unsigned key = it.pass ? ((unsigned)it.dist << 14) | (unsigned)(base + l16) : 0xffffffffu;  // T <= 16384
-      const unsigned m = row_min_u32(key);
-      const unsigned widx = row_min_u32(key == m ? (unsigned)it.idx : 0xffffffffu);  // the winner's feature index
+      const unsigned m = group_min_u32<G>(key);
+      const unsigned widx = group_min_u32<G>(key == m ? (unsigned)it.idx : 0xffffffffu);  // the winner's feature index
       if (m < best) best = m, best_idx = widx;
     }
     const int limit = P.mode == kModeFuse ? TH_LOW : P.max_dist;
@@ -401,10 +414,10 @@ __global__ __launch_bounds__(256) void k_guided_cand(FramesDev F, Queries Q, Gui
   unsigned *slot = O.pool + ((long long)f * Q.stride + (live ? q : 0)) * kSlot;
   unsigned short *rslot = O.rank ? O.rank + ((long long)f * Q.stride + (live ? q : 0)) * kSlot : nullptr;
   int written = 0, rawbase = 0;
-  for (int base = 0; base < Tmax; base += 16) {
+  for (int base = 0; base < Tmax; base += G) {
     const Item it = eval(base + l16);
-    const unsigned pm = (unsigned)(__builtin_amdgcn_ballot_w64(it.pass) >> (16 * sub)) & 0xffffu;
-    const unsigned rm = (unsigned)(__builtin_amdgcn_ballot_w64(it.inraw) >> (16 * sub)) & 0xffffu;
+    const unsigned pm = (unsigned)(__builtin_amdgcn_ballot_w64(it.pass) >> (G * sub)) & kGroupMask;
+    const unsigned rm = (unsigned)(__builtin_amdgcn_ballot_w64(it.inraw) >> (G * sub)) & kGroupMask;
     const unsigned below = (1u << l16) - 1u;
     if (it.pass) {
       const int p = written + __popc(pm & below);
@@ -420,7 +433,7 @@ __global__ __launch_bounds__(256) void k_guided_cand(FramesDev F, Queries Q, Gui
   if (__builtin_amdgcn_ballot_w64(written > kSlot) != 0ull) {  // rare: dense windows.  The tail goes to the overflow area
     if (written > kSlot) {
       if (l16 == 0) ovf_off = atomicAdd(&O.ovf_used[f], written - kSlot);
-      ovf_off = __shfl(ovf_off, 0, 16);
+      ovf_off = __shfl(ovf_off, 0, G);
       if (ovf_off + written - kSlot > O.ovf_stride) {
         if (l16 == 0) atomicExch(O.err, 1);
         written = kSlot;  // truncated: reported through vo_match_guided_status
@@ -429,10 +442,10 @@ __global__ __launch_bounds__(256) void k_guided_cand(FramesDev F, Queries Q, Gui
     unsigned *ov = O.ovf + (long long)f * O.ovf_stride + ovf_off - kSlot;
     unsigned short *orv = O.ovf_rank ? O.ovf_rank + (long long)f * O.ovf_stride + ovf_off - kSlot : nullptr;
     int w2 = 0, r2 = 0;
-    for (int base = 0; base < Tmax; base += 16) {
+    for (int base = 0; base < Tmax; base += G) {
       const Item it = eval(base + l16);
-      const unsigned pm = (unsigned)(__builtin_amdgcn_ballot_w64(it.pass) >> (16 * sub)) & 0xffffu;
-      const unsigned rm = (unsigned)(__builtin_amdgcn_ballot_w64(it.inraw) >> (16 * sub)) & 0xffffu;
+      const unsigned pm = (unsigned)(__builtin_amdgcn_ballot_w64(it.pass) >> (G * sub)) & kGroupMask;
+      const unsigned rm = (unsigned)(__builtin_amdgcn_ballot_w64(it.inraw) >> (G * sub)) & kGroupMask;
       const unsigned below = (1u << l16) - 1u;
       if (it.pass) {
         const int p = w2 + __popc(pm & below);
@@ -872,8 +885,14 @@ int guided_launch(vo_frames *h, int slot0, int n_frames, const Queries &Q, const
   }
   VO_HIP_CHECK(hipMemsetAsync(O.err, 0, 4, st));
   const int nq_max = Q.nq_all;
-  if (nq_max > 0)
-    hipLaunchKernelGGL(k_guided_cand, dim3((nq_max + 15) / 16, n_frames), dim3(256), 0, st, h->D, Q, P, O, slot0);
+  if (nq_max > 0) {
+    // narrow windows (the tracking searches: 15 px, 2.5-4 px times the level scale: 1-5 features) -> eight lanes per
+    // query; wide ones (relocalisation, fuse by pose: tens of features) -> sixteen
+    if (c.radius <= kNarrowRadius)
+      hipLaunchKernelGGL(k_guided_cand<8>, dim3((nq_max + 31) / 32, n_frames), dim3(256), 0, st, h->D, Q, P, O, slot0);
+    else
+      hipLaunchKernelGGL(k_guided_cand<16>, dim3((nq_max + 15) / 16, n_frames), dim3(256), 0, st, h->D, Q, P, O, slot0);
+  }
   if (claims) {
     const size_t capA = (size_t)((h->cap + 15) & ~15);
     const size_t lds = capA + capA * 2 + capA * 8;  // blocked, asg, and the batched replay's two int arrays
