@@ -111,9 +111,15 @@ class BatchTracker:
                 self.ext_stream.wait_event(after)
             if self.ext_stream is not self.stream and self.build_done is not None:
                 self.ext_stream.wait_event(self.build_done)  # the previous batch's key-points have been consumed
+            if events:  # on the extraction's stream: the whole extraction of this batch
+                e0 = self.torch.cuda.Event(enable_timing=True)
+                e0.record(self.ext_stream)
+                evs["extract"] = [e0]
             self.ext.extract_batch_dev(images, self.kps, self.desc, self.cnt)
-            self.extract_done = self.torch.cuda.Event()
+            self.extract_done = self.torch.cuda.Event(enable_timing=events)
             self.extract_done.record(self.ext_stream)
+            if events:
+                evs["extract"].append(self.extract_done)
             if self.ext_stream is not self.stream:
                 self.stream.wait_event(self.extract_done)
             mark("frame_post")
