@@ -209,7 +209,8 @@ def main():
     inv_depth = float(np.float32(1.0) / np.float32(synth.DEPTH_SCALE))
     cam5 = synth.CAM.astype(np.float32)
     n_pipe = max(1, args.pipeline)
-    stream = torch.cuda.Stream()           # extraction (shared by the batches in flight); also the brute-force leg
+    prio_ext, prio_tail = (int(x) for x in os.environ.get("VO_BENCH_PRIO", "0,-1").split(","))
+    stream = torch.cuda.Stream(priority=prio_ext)  # extraction (shared by the batches in flight); also the brute-force leg
     exts = [vo.OrbExtractor(1000, 1.2, 8, 20, 7) for _ in range(n_pipe)]
     ext = exts[0]
     ext.set_stream(stream.cuda_stream)
@@ -225,7 +226,7 @@ def main():
     if n_pipe == 1:
         trks = [BatchTracker(B, ext, cam5, synth.DIST, W, H, n_last=1100, n_local=2200, stream=stream)]
     else:
-        trks = [BatchTracker(B, e, cam5, synth.DIST, W, H, n_last=1100, n_local=2200, stream=torch.cuda.Stream(priority=-1),
+        trks = [BatchTracker(B, e, cam5, synth.DIST, W, H, n_last=1100, n_local=2200, stream=torch.cuda.Stream(priority=prio_tail),
                              extract_stream=stream) for e in exts]
     trk = trks[0]
     with torch.cuda.stream(stream):
