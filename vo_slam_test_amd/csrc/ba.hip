@@ -1053,9 +1053,10 @@ constexpr int kChunkPts = 512;  // points per K-slice (LDS table of their damped
 #endif
 constexpr int kGemmWaves = kGemmThreads / 64;
 constexpr int kGemmLdsTile = kGemmWaves * 256 + kChunkPts * 6;  // part, hinvL
+static_assert(kChunkPts <= kGemmThreads, "ba_gemm_tile_role takes one point per thread");
 constexpr int kGemmLdsDoubles = kGemmLdsTile > 27 * kCamPitch ? kGemmLdsTile : 27 * kCamPitch;  // or the camera role's 27 rows
 
-__device__ __forceinline__ void ba_gemm_tile_role(const BaDev &B, const BaState &st, double *sm, int ntiles, int tdim);
+__device__ __forceinline__ void ba_gemm_tile_role(const BaDev &B, double *sm, int ntiles, int tdim, int bid);
 
 // Schur product tiles and camera blocks in one launch (independent roles).  Every block writes its
 // partial result to a slab; the consumer sits behind the kernel boundary (k_ba_solve when the problem
@@ -1064,25 +1065,29 @@ __device__ __forceinline__ void ba_gemm_tile_role(const BaDev &B, const BaState 
 // coherent loads at only ~12 GB/s, against ~5 us for a kernel boundary followed by cached loads.
 __global__ __launch_bounds__(kGemmThreads) void k_ba_gemm(BaDev B) {
   extern __shared__ double sm[];  // part | hinvL | lds27
-  const BaState st = *B.st;
-  if (st.done) return;
   STAMP0(16);
   const int tdim = B.Mpad / 16, ntiles = tdim * (tdim + 1) / 2;
-  if ((int)blockIdx.x >= ntiles * B.ksplit) {  // camera-block role (independent of the tiles)
+  // The camera-block role (independent of the tiles, and the longer of the two) takes the FIRST workgroup indices: with
+  // it behind the 240 tile blocks its last workgroup was observed to start 8.7 us into the kernel.
+  const int ncam = B.nf * B.n_cchunks;
+  if ((int)blockIdx.x < ncam) {
+    const BaState st = *B.st;
+    if (st.done) return;
     if (threadIdx.x >= kCamChunk) return;  // retired wavefronts do not take part in the role's barriers
-    const int q = blockIdx.x - ntiles * B.ksplit;
+    const int q = blockIdx.x;
     ba_cams_role<true>(B, st, q / B.n_cchunks, q % B.n_cchunks, sm);  // the role's blocks use none of the tile buffers
   } else {
-    ba_gemm_tile_role(B, st, sm, ntiles, tdim);
+    ba_gemm_tile_role(B, sm, ntiles, tdim, (int)blockIdx.x - ncam);  // reads the state itself, together with what does not depend on it
   }
   STAMP0(20);
 }
 
-__device__ __forceinline__ void ba_gemm_tile_role(const BaDev &B, const BaState &st, double *sm, int ntiles, int tdim) {
+__device__ __forceinline__ void ba_gemm_tile_role(const BaDev &B, double *sm, int ntiles, int tdim, int bid) {
+  const BaState st = *B.st;  // issued first: waiting for it leaves the loads below in flight
   double(*part)[256] = reinterpret_cast<double(*)[256]>(sm);
   double *hinvL = sm + kGemmWaves * 256;
-  const int ks = blockIdx.x / ntiles;
-  int tile = blockIdx.x - ks * ntiles, tm = 0;
+  const int ks = bid / ntiles;
+  int tile = bid - ks * ntiles, tm = 0;
   while (tile >= tdim - tm) {  // upper-triangular tile index -> (tm <= tn)
     tile -= tdim - tm;
     tm++;
@@ -1094,14 +1099,25 @@ __device__ __forceinline__ void ba_gemm_tile_role(const BaDev &B, const BaState 
   // ---- damped inverse of every point block of this K-slice (SchurEliminator: (E^T E + D)^-1).
   // Each tile block needs them for its own A operand; the tile-0 block also publishes them for the
   // back-substitution.
-  const int j0 = kb0 / 3, npts = (kb1 - kb0) / 3;
-  const double *hl = B.hll[st.cur];
+  const int j0 = kb0 / 3, npts = (kb1 - kb0) / 3;  // <= kChunkPts = kGemmThreads: one point per thread
+  // The point blocks of BOTH linearisation buffers and the scales are requested before the state is looked at (which
+  // buffer is current is the only thing the state decides here): one round trip instead of two.
+  const int jp = j0 + min(tid, max(npts - 1, 0));
+  double hb[2][6], spv[3];
+#pragma unroll
+  for (int i = 0; i < 6; i++) hb[0][i] = B.hll[0][6 * jp + i], hb[1][i] = B.hll[1][6 * jp + i];
+#pragma unroll
+  for (int i = 0; i < 3; i++) spv[i] = B.scale_p[3 * jp + i];
+  if (st.done) return;
   const double *W = B.Wt[st.cur];
-  for (int t = tid; t < npts; t += kGemmThreads) {
-    const int j = j0 + t;
-    const double sp0 = B.scale_p[3 * j], sp1 = B.scale_p[3 * j + 1], sp2 = B.scale_p[3 * j + 2];
-    double hs[6] = {hl[6 * j] * sp0 * sp0, hl[6 * j + 1] * sp0 * sp1, hl[6 * j + 2] * sp0 * sp2,
-                    hl[6 * j + 3] * sp1 * sp1, hl[6 * j + 4] * sp1 * sp2, hl[6 * j + 5] * sp2 * sp2};
+  if (tid < npts) {
+    const int t = tid, j = j0 + t;
+    const double sp0 = spv[0], sp1 = spv[1], sp2 = spv[2];
+    double hl6[6];
+#pragma unroll
+    for (int i = 0; i < 6; i++) hl6[i] = st.cur ? hb[1][i] : hb[0][i];
+    double hs[6] = {hl6[0] * sp0 * sp0, hl6[1] * sp0 * sp1, hl6[2] * sp0 * sp2,
+                    hl6[3] * sp1 * sp1, hl6[4] * sp1 * sp2, hl6[5] * sp2 * sp2};
     const double d0 = fmin(fmax(hs[0], 1e-6), 1e32) / st.radius;
     const double d1 = fmin(fmax(hs[3], 1e-6), 1e32) / st.radius;
     const double d2 = fmin(fmax(hs[5], 1e-6), 1e32) / st.radius;
