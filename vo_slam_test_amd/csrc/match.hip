@@ -143,33 +143,241 @@ __global__ __launch_bounds__(256) void k_median_desc(const uint32_t *desc, const
   if (tid == 0) best_idx[set] = (int)(s_best & 0xffffu);
 }
 
-// ---- host replay helpers (BoW-node searches: the candidate sets are vocabulary nodes, not grid windows) ----
-constexpr int HISTO_LENGTH = 30;               // matcher.cpp:13
+// ---- BoW-node searches on the device: searchByBoW x 2 (matcher.cpp:449-559, :561-677) and searchForTriangulation
+// (:867-1010).  The candidate set of a query (a feature of frame A) is the list of B's features in the same vocabulary
+// node; the reference walks the nodes and their features in order and a claimed B feature is out for every later query.
+// One wavefront replays that loop 64 queries at a time, lane = query: every lane walks its node list (a handful of
+// entries; distances are computed on the fly, there is no all-pairs matrix), proposes its claim from the taken[] state
+// of the previous steps, and a lane is re-proposed after the lanes in front of it have committed iff an earlier lane of
+// the step claims a feature of its list -- the scheme of k_guided_replay (csrc/guided.hip).
+constexpr int HISTO_LENGTH = 30;  // matcher.cpp:13
+constexpr int kNodeBow0 = 0, kNodeBow1 = 1, kNodeTri = 2;
 
-// device all-pairs distances for (queries x features), back on the host
-int distance_matrix(const uint8_t *q_desc, int nq, const uint8_t *f_desc, int nf, std::vector<uint16_t> &D) {
-  D.assign((size_t)nq * nf, 0);
-  if (nq <= 0 || nf <= 0) return VO_OK;
-  return vo_hamming_matrix(q_desc, nq, f_desc, nf, D.data());
-}
+struct NodeArgs {
+  int mode, nq, nA, nB, check_rot;
+  float ratio, ex, ey;
+  double F[9];
+  float sf[16];
+  const int4 *queries;          // (A feature, begin, end in bfeat, 0) in the reference's visiting order
+  const uint32_t *bfeat;
+  const uint4 *descA, *descB;   // 2 per feature
+  const float *angA, *angB, *xA, *yA, *urA, *xB, *yB, *urB;
+  const int *octB;
+  const uint8_t *b_ok;          // B features that may be claimed at all (KF-KF: valid map point; triangulation: none yet)
+  int4 *claims;                 // scratch [nq]: (A feature, B feature, rotation bin, 0) in claim order
+  int *match, *n_matches;       // out: [nB] (mode 0: A index per B feature) or [nA] (B index per A feature)
+};
 
-void three_max(const std::vector<std::vector<int>> &h, int &i1, int &i2, int &i3) {  // matcher.cpp:1258-1304
-  int m1 = 0, m2 = 0, m3 = 0;
-  i1 = i2 = i3 = -1;
-  for (int i = 0; i < (int)h.size(); i++) {
-    const int s = (int)h[i].size();
-    if (s > m1) {
-      m3 = m2, i3 = i2, m2 = m1, i2 = i1, m1 = s, i1 = i;
-    } else if (s > m2) {
-      m3 = m2, i3 = i2, m2 = s, i2 = i;
-    } else if (s > m3) {
-      m3 = s, i3 = i;
+__global__ __launch_bounds__(64) void k_node_replay(NodeArgs P) {
+  extern __shared__ __attribute__((aligned(16))) uint8_t nr_lds[];
+  __shared__ int hist[32];
+  const int lane = threadIdx.x;
+  const int nBa = (P.nB + 15) & ~15;
+  uint8_t *taken = nr_lds;                                  // [nB]
+  int *tmpb = reinterpret_cast<int *>(nr_lds + nBa);         // [nB] first claiming lane of the round
+  for (int i = lane; i < nBa; i += 64) taken[i] = 0, tmpb[i] = 64;
+  if (lane < 32) hist[lane] = 0;
+  const int nout = P.mode == kNodeBow0 ? P.nB : P.nA;
+  for (int i = lane; i < nout; i += 64) P.match[i] = -1;
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_wave_barrier();
+  const float pdf = HISTO_LENGTH / 360.0f;
+  int nclaims = 0;
+  for (int gb = 0; gb < P.nq; gb += 64) {
+    const bool live = gb + lane < P.nq;
+    const int4 q = P.queries[min(gb + lane, P.nq - 1)];
+    const int i1 = q.x, b0 = q.y, b1 = live ? q.z : q.y;
+    const uint4 da = P.descA[2 * i1], db = P.descA[2 * i1 + 1];
+    double l0 = 0, l1 = 0, l2 = 0;
+    float den = 0;
+    bool stereo1 = false;
+    if (P.mode == kNodeTri) {  // epipolar line of feature 1 in image 2: l = F12^T p1 (checkEpipolarConstrain, :1306-1324)
+      const double x1 = P.xA[i1], y1 = P.yA[i1];
+      l0 = x1 * P.F[0] + y1 * P.F[3] + P.F[6], l1 = x1 * P.F[1] + y1 * P.F[4] + P.F[7], l2 = x1 * P.F[2] + y1 * P.F[5] + P.F[8];
+      den = (float)(l0 * l0 + l1 * l1);
+      stereo1 = P.urA[i1] >= 0;
+    }
+    const int len = b1 - b0;
+    int lmax = len;
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) lmax = max(lmax, __shfl_xor(lmax, o));
+    bool unresolved = len > 0;
+    while (__builtin_amdgcn_ballot_w64(unresolved) != 0ull) {  // uniform
+      int best1 = P.mode == kNodeTri ? 50 /*TH_LOW*/ : 256, best2 = 256, bidx = -1;
+      for (int t = 0; t < lmax; t++) {
+        if (!(unresolved && t < len)) continue;
+        const int i2 = (int)P.bfeat[b0 + t];
+        if (taken[i2] || !P.b_ok[i2]) continue;  // :494 / :603 / :916-917
+        const uint4 ea = P.descB[2 * i2], eb = P.descB[2 * i2 + 1];
+        const int d = __popc(da.x ^ ea.x) + __popc(da.y ^ ea.y) + __popc(da.z ^ ea.z) + __popc(da.w ^ ea.w) +
+                      __popc(db.x ^ eb.x) + __popc(db.y ^ eb.y) + __popc(db.z ^ eb.z) + __popc(db.w ^ eb.w);
+        if (P.mode != kNodeTri) {
+          if (d < best1) best2 = best1, best1 = d, bidx = i2;
+          else if (d < best2) best2 = d;
+        } else {
+          if (d > 50 || d > best1) continue;  // an equal later distance replaces the earlier one (:928)
+          const float sigma = P.sf[min(max(P.octB[i2], 0), 15)];
+          if (!stereo1 && !(P.urB[i2] >= 0)) {
+            const float dx = P.ex - P.xB[i2], dy = P.ey - P.yB[i2];
+            if (dx * dx + dy * dy < 100 * sigma) continue;  // too close to the epipole (:932-940)
+          }
+          if (den == 0) continue;
+          const float num = (float)(l0 * P.xB[i2] + l1 * P.yB[i2] + l2);
+          if (num * num / den < 3.84f * sigma * sigma) best1 = d, bidx = i2;
+        }
+      }
+      bool accept = unresolved && bidx >= 0;
+      if (accept && P.mode != kNodeTri) accept = best1 <= 50 && (float)best1 < P.ratio * (float)best2;  // :520 / :628
+      if (accept) atomicMin(&tmpb[bidx], lane);
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_wave_barrier();
+      bool stale = false;
+      for (int t = 0; t < lmax; t++)
+        if (unresolved && t < len) stale |= tmpb[P.bfeat[b0 + t]] < lane;
+      const unsigned long long sm = __builtin_amdgcn_ballot_w64(stale);
+      const int first_stale = sm ? (int)__builtin_ctzll(sm) : 64;
+      const bool fin = unresolved && lane < first_stale, claim = fin && accept;
+      const unsigned long long cm = __builtin_amdgcn_ballot_w64(claim);
+      if (claim) {
+        taken[bidx] = 1;
+        int bin = 0;
+        if (P.check_rot) {  // :524-533 (cvRound), :633-641 / :958-966 (round)
+          float r = P.angA[i1] - P.angB[bidx];
+          if (r < 0) r += 360.0f;
+          bin = P.mode == kNodeBow0 ? (int)rintf(r * pdf) : (int)roundf(r * pdf);
+          if (bin == HISTO_LENGTH) bin = 0;
+          atomicAdd(&hist[bin], 1);
+        }
+        const int below = (int)__builtin_amdgcn_mbcnt_hi((unsigned)(cm >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)cm, 0u));
+        P.claims[nclaims + below] = make_int4(i1, bidx, bin, 0);
+      }
+      nclaims += (int)__popcll(cm);
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_wave_barrier();
+      if (accept) tmpb[bidx] = 64;
+      unresolved = unresolved && !fin;
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_wave_barrier();
     }
   }
-  if (m2 < 0.1f * (float)m1)
-    i2 = i3 = -1;
-  else if (m3 < 0.1f * (float)m1)
-    i3 = -1;
+  // computeThreeMax (:1258-1304) and the pruning of the other bins
+  int i1m = -1, i2m = -1, i3m = -1;
+  if (P.check_rot) {
+    int m1 = 0, m2 = 0, m3 = 0;
+    for (int i = 0; i < HISTO_LENGTH; i++) {
+      const int sz = hist[i];
+      if (sz > m1) m3 = m2, i3m = i2m, m2 = m1, i2m = i1m, m1 = sz, i1m = i;
+      else if (sz > m2) m3 = m2, i3m = i2m, m2 = sz, i2m = i;
+      else if (sz > m3) m3 = sz, i3m = i;
+    }
+    if (m2 < 0.1f * (float)m1) i2m = i3m = -1;
+    else if (m3 < 0.1f * (float)m1) i3m = -1;
+  }
+  __threadfence_block();
+  int kept = 0;
+  for (int base = 0; base < nclaims; base += 64) {
+    bool keep = false;
+    if (base + lane < nclaims) {
+      const int4 c = P.claims[base + lane];
+      keep = !P.check_rot || c.z == i1m || c.z == i2m || c.z == i3m;
+      if (keep) {
+        if (P.mode == kNodeBow0) P.match[c.y] = c.x;
+        else P.match[c.x] = c.y;
+      }
+    }
+    kept += (int)__popcll(__builtin_amdgcn_ballot_w64(keep));
+  }
+  if (lane == 0) *P.n_matches = kept;
+}
+
+// walk two ascending node lists, calling f(ia, ib) for every common node id (:541-544 lower_bound walk)
+template <class F>
+void for_common_nodes(const vo_bow_view &a, const vo_bow_view &b, F &&f) {
+  int ia = 0, ib = 0;
+  while (ia < a.n_nodes && ib < b.n_nodes) {
+    if (a.node_id[ia] == b.node_id[ib]) {
+      f(ia, ib);
+      ia++, ib++;
+    } else if (a.node_id[ia] < b.node_id[ib]) {
+      ia++;
+    } else {
+      ib++;
+    }
+  }
+}
+
+constexpr int kNodeMaxB = 16384;  // B features (LDS: 5 bytes each)
+
+// gather (the reference's pointer walk, flattened), upload, one launch, fetch
+int node_search(int mode, const vo_frame_view *a, const uint8_t *a_skip_or_valid, bool a_flag_is_skip, const vo_bow_view *an,
+                const vo_frame_view *b, const uint8_t *b_ok_or_null, bool b_flag_is_blocked, const vo_bow_view *bn,
+                float ratio, int check_rot, const double *F, float ex, float ey, const float *scale_factors,
+                int32_t *match, int *n_matches) {
+  const int nout = mode == kNodeBow0 ? b->n : a->n;
+  for (int i = 0; i < nout; i++) match[i] = -1;
+  *n_matches = 0;
+  if (a->n == 0 || b->n == 0) return VO_OK;
+  if (b->n > kNodeMaxB) {
+    vo::set_error("BoW-node search: %d features in the second frame exceed %d", b->n, kNodeMaxB);
+    return VO_ERR_CAPACITY;
+  }
+  VO_CHECK(vo::ensure_device());
+  std::vector<int> queries;
+  queries.reserve(4 * (size_t)a->n);
+  for_common_nodes(*an, *bn, [&](int ia, int ib) {
+    for (int s = an->start[ia]; s < an->start[ia + 1]; s++) {
+      const int i1 = (int)an->feat[s];
+      if (a_flag_is_skip ? a_skip_or_valid[i1] != 0 : a_skip_or_valid[i1] == 0) continue;  // :488 / :597 / :905
+      queries.push_back(i1), queries.push_back(bn->start[ib]), queries.push_back(bn->start[ib + 1]), queries.push_back(0);
+    }
+  });
+  const int nq = (int)queries.size() / 4;
+  if (nq == 0) return VO_OK;
+  const int nbf = bn->n_nodes > 0 ? bn->start[bn->n_nodes] : 0;
+  std::vector<uint8_t> bok(b->n, 1);
+  if (b_ok_or_null)
+    for (int i = 0; i < b->n; i++) bok[i] = b_flag_is_blocked ? (b_ok_or_null[i] ? 0 : 1) : (b_ok_or_null[i] ? 1 : 0);
+  thread_local vo::ScratchBuf dq, dbf, dda, ddb, daa, dab, dxa, dya, dua, dxb, dyb, dub, dob, dok, dcl, dm, dn;
+  hipStream_t st = vo::thread_stream();
+  const char *what = "BoW-node search";
+  VO_CHECK(vo::upload(dq, queries.data(), queries.size() * 4, st, what));
+  VO_CHECK(vo::upload(dbf, bn->feat, (size_t)std::max(nbf, 1) * 4, st, what));
+  VO_CHECK(vo::upload(dda, a->desc, (size_t)a->n * 32, st, what));
+  VO_CHECK(vo::upload(ddb, b->desc, (size_t)b->n * 32, st, what));
+  VO_CHECK(vo::upload(daa, a->angle, (size_t)a->n * 4, st, what));
+  VO_CHECK(vo::upload(dab, b->angle, (size_t)b->n * 4, st, what));
+  VO_CHECK(vo::upload(dxa, a->x, (size_t)a->n * 4, st, what));
+  VO_CHECK(vo::upload(dya, a->y, (size_t)a->n * 4, st, what));
+  VO_CHECK(vo::upload(dua, a->uright, (size_t)a->n * 4, st, what));
+  VO_CHECK(vo::upload(dxb, b->x, (size_t)b->n * 4, st, what));
+  VO_CHECK(vo::upload(dyb, b->y, (size_t)b->n * 4, st, what));
+  VO_CHECK(vo::upload(dub, b->uright, (size_t)b->n * 4, st, what));
+  VO_CHECK(vo::upload(dob, b->octave, (size_t)b->n * 4, st, what));
+  VO_CHECK(vo::upload(dok, bok.data(), (size_t)b->n, st, what));
+  VO_CHECK(dcl.reserve((size_t)nq * 16));
+  VO_CHECK(dm.reserve((size_t)std::max(nout, 1) * 4));
+  VO_CHECK(dn.reserve(64));
+  NodeArgs P{};
+  P.mode = mode, P.nq = nq, P.nA = a->n, P.nB = b->n, P.check_rot = check_rot, P.ratio = ratio, P.ex = ex, P.ey = ey;
+  for (int i = 0; i < 9; i++) P.F[i] = F ? F[i] : 0.0;
+  for (int i = 0; i < 16; i++) P.sf[i] = scale_factors ? scale_factors[std::min(i, 7)] : 1.f;
+  P.queries = dq.as<int4>(), P.bfeat = dbf.as<uint32_t>(), P.descA = dda.as<uint4>(), P.descB = ddb.as<uint4>();
+  P.angA = daa.as<float>(), P.angB = dab.as<float>(), P.xA = dxa.as<float>(), P.yA = dya.as<float>(), P.urA = dua.as<float>();
+  P.xB = dxb.as<float>(), P.yB = dyb.as<float>(), P.urB = dub.as<float>(), P.octB = dob.as<int>(), P.b_ok = dok.as<uint8_t>();
+  P.claims = dcl.as<int4>(), P.match = dm.as<int>(), P.n_matches = dn.as<int>();
+  const size_t lds = (size_t)((b->n + 15) & ~15) * 5;
+  if (lds > 64 * 1024) {
+    static bool attr_set = false;
+    if (!attr_set) {
+      (void)hipFuncSetAttribute((const void *)k_node_replay, hipFuncAttributeMaxDynamicSharedMemorySize, kNodeMaxB * 5);
+      attr_set = true;
+    }
+  }
+  hipLaunchKernelGGL(k_node_replay, dim3(1), dim3(64), lds, st, P);
+  VO_HIP_CHECK(hipGetLastError());
+  VO_CHECK(vo::copy_d2h(match, dm.p, (size_t)nout * 4, st, what));
+  VO_CHECK(vo::copy_d2h(n_matches, dn.p, 4, st, what));
+  return vo::stream_sync(st, what);
 }
 
 }  // namespace
@@ -236,52 +444,6 @@ int vo_median_descriptor(const uint8_t *desc, int n_sets, const int32_t *offsets
 
 }  // extern "C"
 
-namespace {
-
-constexpr int TH_LOW = 50;  // matcher.cpp:12
-
-struct RotHist {  // rotation-consistency filter shared by the search routines (:128-145 and friends)
-  std::vector<std::vector<int>> bins = std::vector<std::vector<int>>(HISTO_LENGTH);
-  void add(float angle_a, float angle_b, int idx, bool cv_round) {
-    const float pdf = HISTO_LENGTH / 360.0f;
-    float r = angle_a - angle_b;
-    if (r < 0) r += 360.0f;
-    int bin = cv_round ? (int)lrintf(r * pdf) : (int)roundf(r * pdf);
-    if (bin == HISTO_LENGTH) bin = 0;
-    bins[bin].push_back(idx);
-  }
-  template <class F>
-  int prune(F &&drop) {  // calls drop(idx) for every entry outside the three dominant bins
-    int i1, i2, i3, removed = 0;
-    three_max(bins, i1, i2, i3);
-    for (int b = 0; b < HISTO_LENGTH; b++)
-      if (b != i1 && b != i2 && b != i3)
-        for (int idx : bins[b]) {
-          drop(idx);
-          removed++;
-        }
-    return removed;
-  }
-};
-
-// walk two ascending node lists, calling f(ia, ib) for every common node id (:541-544 lower_bound walk)
-template <class F>
-void for_common_nodes(const vo_bow_view &a, const vo_bow_view &b, F &&f) {
-  int ia = 0, ib = 0;
-  while (ia < a.n_nodes && ib < b.n_nodes) {
-    if (a.node_id[ia] == b.node_id[ib]) {
-      f(ia, ib);
-      ia++, ib++;
-    } else if (a.node_id[ia] < b.node_id[ib]) {
-      ia++;
-    } else {
-      ib++;
-    }
-  }
-}
-
-}  // namespace
-
 extern "C" {
 
 int vo_match_bow(const vo_frame_view *a, const uint8_t *a_valid, const vo_bow_view *an, const vo_frame_view *b,
@@ -289,100 +451,18 @@ int vo_match_bow(const vo_frame_view *a, const uint8_t *a_valid, const vo_bow_vi
                  int *n_matches) {
   if (!a || !b || !an || !bn || !a_valid || !match || !n_matches || (mode != 0 && mode != 1) || (mode == 1 && !b_valid))
     return VO_ERR_INVALID;
-  const int nout = mode == 0 ? b->n : a->n;
-  for (int i = 0; i < nout; i++) match[i] = -1;
-  *n_matches = 0;
-  if (a->n == 0 || b->n == 0) return VO_OK;
-  std::vector<uint16_t> D;
-  VO_CHECK(distance_matrix(a->desc, a->n, b->desc, b->n, D));
-  std::vector<uint8_t> taken(b->n, 0);
-  RotHist rot;
-  int cnt = 0;
-  for_common_nodes(*an, *bn, [&](int ia, int ib) {
-    for (int s = an->start[ia]; s < an->start[ia + 1]; s++) {
-      const int i1 = (int)an->feat[s];
-      if (!a_valid[i1]) continue;
-      int best1 = 256, best2 = 256, bidx = -1;
-      for (int t = bn->start[ib]; t < bn->start[ib + 1]; t++) {
-        const int i2 = (int)bn->feat[t];
-        if (mode == 0 ? match[i2] >= 0 : (taken[i2] || !b_valid[i2])) continue;
-        const int d = D[(size_t)i1 * b->n + i2];
-        if (d < best1)
-          best2 = best1, best1 = d, bidx = i2;
-        else if (d < best2)
-          best2 = d;
-      }
-      if (best1 <= TH_LOW && (float)best1 < ratio * (float)best2) {
-        if (mode == 0) {
-          match[bidx] = i1;
-          if (check_rot) rot.add(a->angle[i1], b->angle[bidx], bidx, true);
-        } else {
-          match[i1] = bidx;
-          taken[bidx] = 1;
-          if (check_rot) rot.add(a->angle[i1], b->angle[bidx], i1, false);  // :637 uses round()
-        }
-        cnt++;
-      }
-    }
-  });
-  if (check_rot) cnt -= rot.prune([&](int idx) { match[idx] = -1; });
-  *n_matches = cnt;
-  return VO_OK;
+  return node_search(mode == 0 ? kNodeBow0 : kNodeBow1, a, a_valid, false, an, b, mode == 1 ? b_valid : nullptr, false, bn,
+                     ratio, check_rot, nullptr, 0.f, 0.f, nullptr, match, n_matches);
 }
 
 int vo_match_triangulation(const vo_frame_view *a, const uint8_t *a_has, const vo_bow_view *an, const vo_frame_view *b,
                            const uint8_t *b_has, const vo_bow_view *bn, const double F[9], float ex, float ey,
                            const float *scale_factors, int check_rot, int32_t *match12, int *n_matches) {
   if (!a || !b || !an || !bn || !a_has || !b_has || !F || !scale_factors || !match12 || !n_matches) return VO_ERR_INVALID;
-  for (int i = 0; i < a->n; i++) match12[i] = -1;
-  *n_matches = 0;
-  if (a->n == 0 || b->n == 0) return VO_OK;
-  std::vector<uint16_t> D;
-  VO_CHECK(distance_matrix(a->desc, a->n, b->desc, b->n, D));
-  std::vector<uint8_t> taken(b->n, 0);
-  RotHist rot;
-  int cnt = 0;
-  for_common_nodes(*an, *bn, [&](int ia, int ib) {
-    for (int s = an->start[ia]; s < an->start[ia + 1]; s++) {
-      const int i1 = (int)an->feat[s];
-      if (a_has[i1]) continue;
-      const bool stereo1 = a->uright[i1] >= 0;
-      // epipolar line of feature 1 in image 2: l = F12^T p1 (checkEpipolarConstrain, :1306-1324)
-      const double l0 = a->x[i1] * F[0] + a->y[i1] * F[3] + F[6], l1 = a->x[i1] * F[1] + a->y[i1] * F[4] + F[7],
-                   l2 = a->x[i1] * F[2] + a->y[i1] * F[5] + F[8];
-      const float den = (float)(l0 * l0 + l1 * l1);
-      int best = TH_LOW, bidx = -1;
-      for (int t = bn->start[ib]; t < bn->start[ib + 1]; t++) {
-        const int i2 = (int)bn->feat[t];
-        if (taken[i2] || b_has[i2]) continue;
-        const int d = D[(size_t)i1 * b->n + i2];
-        if (d > TH_LOW || d > best) continue;  // an equal later distance replaces the earlier one (:928)
-        const float sigma = scale_factors[b->octave[i2]];
-        if (!stereo1 && !(b->uright[i2] >= 0)) {
-          const float dx = ex - b->x[i2], dy = ey - b->y[i2];
-          if (dx * dx + dy * dy < 100 * sigma) continue;  // too close to the epipole (:932-940)
-        }
-        if (den == 0) continue;
-        const float num = (float)(l0 * b->x[i2] + l1 * b->y[i2] + l2);
-        if (num * num / den < 3.84f * sigma * sigma) best = d, bidx = i2;
-      }
-      if (bidx >= 0) {
-        match12[i1] = bidx;
-        taken[bidx] = 1;
-        cnt++;
-        if (check_rot) rot.add(a->angle[i1], b->angle[bidx], i1, false);
-      }
-    }
-  });
-  if (check_rot) cnt -= rot.prune([&](int idx) { match12[idx] = -1; });
-  *n_matches = cnt;
-  return VO_OK;
+  return node_search(kNodeTri, a, a_has, true, an, b, b_has, true, bn, 0.f, check_rot, F, ex, ey, scale_factors, match12,
+                     n_matches);
 }
 
-
-// ---- BoW transform (DBoW3::Vocabulary::transform as called by computeBow, frame.cpp:248-253,
-// keyframe.cpp:394-398).  The vocabulary tree lives in HBM as flat arrays; one lane per feature
-// walks it: at every level the child with the smallest Hamming distance (first wins ties).
 }  // extern "C" (kernels below)
 
 namespace {
