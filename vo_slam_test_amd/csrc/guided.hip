@@ -507,8 +507,9 @@ __global__ __launch_bounds__(64) void k_guided_replay(FramesDev F, Queries Q, Gu
   // ------------------------------------------------------------------------------------------------------------
   // Batched replay (every mode but Sim3, frames whose windows all fit their slots): 64 queries per step, lane = query.
   // Every lane proposes its claim from the blocked[] state left by the previous steps; a proposal is final unless an
-  // EARLIER lane of the same step proposes a blocking claim on a feature of its list (then its best / runner-up may
-  // change) -- the first such lane and everything behind it is re-proposed after the lanes in front have committed.
+  // EARLIER lane of the same step proposes a blocking claim on the feature it chose (or on its runner-up, where the
+  // ratio test looks at it) -- the first such lane and everything behind it is re-proposed after the lanes in front
+  // have committed.
   // Conflicts are rare (a handful per frame), so a step is usually one round: ~25 steps instead of ~450 four-query
   // steps, with the same result as the one-query-at-a-time order of matcher.cpp:76-128.
   if (!sim3 && O.ovf_used[f] == 0) {
@@ -574,17 +575,14 @@ __global__ __launch_bounds__(64) void k_guided_replay(FramesDev F, Queries Q, Gu
         const bool blocker = accept && blocks != 0;
         if (blocker) atomicMin(&tmpb[bidx], lane);
         lds_handoff();
-        // 3. a lane is stale when an earlier lane blocks a feature of its list
+        // 3. a lane is stale when an earlier lane of the step blocks the feature it chose -- or, where the ratio test
+        //    looks at it, its runner-up: blocking any other record of its list leaves (best, runner-up) as they are.
+        //    (Testing the whole list instead is also correct but makes half of the lanes stale in the frame search:
+        //    ~8 records per query, 63 earlier claims among ~1000 features -- 8 rounds per step instead of 1-2.)
         bool stale = false;
-#pragma unroll
-        for (int c4 = 0; c4 < R / 4; c4++) {
-          if (4 * c4 >= cmax) break;  // uniform
-#pragma unroll
-          for (int u = 0; u < 4; u++) {
-            const int pos = 4 * c4 + u;
-            const int idx = min((int)(rec[pos] & 0x3fffu), capA - 1);
-            stale |= unresolved & (pos < cn) & (tmpb[idx] < lane);
-          }
+        if (unresolved && d1 != kNone) {
+          stale = tmpb[bidx] < lane;
+          if (want2 && d2 != kNone) stale |= tmpb[(int)(r2 & 0x3fffu)] < lane;
         }
         const unsigned long long sm = __builtin_amdgcn_ballot_w64(stale);
         const int first_stale = sm ? (int)__builtin_ctzll(sm) : 64;

@@ -203,7 +203,7 @@ __global__ __launch_bounds__(64) void k_node_replay(NodeArgs P) {
     for (int o = 32; o >= 1; o >>= 1) lmax = max(lmax, __shfl_xor(lmax, o));
     bool unresolved = len > 0;
     while (__builtin_amdgcn_ballot_w64(unresolved) != 0ull) {  // uniform
-      int best1 = P.mode == kNodeTri ? 50 /*TH_LOW*/ : 256, best2 = 256, bidx = -1;
+      int best1 = P.mode == kNodeTri ? 50 /*TH_LOW*/ : 256, best2 = 256, bidx = -1, bidx2 = -1;
       for (int t = 0; t < lmax; t++) {
         if (!(unresolved && t < len)) continue;
         const int i2 = (int)P.bfeat[b0 + t];
@@ -212,8 +212,8 @@ __global__ __launch_bounds__(64) void k_node_replay(NodeArgs P) {
         const int d = __popc(da.x ^ ea.x) + __popc(da.y ^ ea.y) + __popc(da.z ^ ea.z) + __popc(da.w ^ ea.w) +
                       __popc(db.x ^ eb.x) + __popc(db.y ^ eb.y) + __popc(db.z ^ eb.z) + __popc(db.w ^ eb.w);
         if (P.mode != kNodeTri) {
-          if (d < best1) best2 = best1, best1 = d, bidx = i2;
-          else if (d < best2) best2 = d;
+          if (d < best1) best2 = best1, bidx2 = bidx, best1 = d, bidx = i2;
+          else if (d < best2) best2 = d, bidx2 = i2;
         } else {
           if (d > 50 || d > best1) continue;  // an equal later distance replaces the earlier one (:928)
           const float sigma = P.sf[min(max(P.octB[i2], 0), 15)];
@@ -231,9 +231,13 @@ __global__ __launch_bounds__(64) void k_node_replay(NodeArgs P) {
       if (accept) atomicMin(&tmpb[bidx], lane);
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       __builtin_amdgcn_wave_barrier();
+      // stale: an earlier lane of the step claims the feature this lane chose, or the one its runner-up distance comes
+      // from (the ratio test's operand); any other feature of its list leaves the decision as it is
       bool stale = false;
-      for (int t = 0; t < lmax; t++)
-        if (unresolved && t < len) stale |= tmpb[P.bfeat[b0 + t]] < lane;
+      if (unresolved && bidx >= 0) {
+        stale = tmpb[bidx] < lane;
+        if (P.mode != kNodeTri && bidx2 >= 0) stale |= tmpb[bidx2] < lane;
+      }
       const unsigned long long sm = __builtin_amdgcn_ballot_w64(stale);
       const int first_stale = sm ? (int)__builtin_ctzll(sm) : 64;
       const bool fin = unresolved && lane < first_stale, claim = fin && accept;
