@@ -97,6 +97,16 @@ __device__ __forceinline__ void block_sum(double (&v)[N], double *lds /*>= nw*N*
       v[i] = (((((((0.0 + p[0][i]) + p[1][i]) + p[2][i]) + p[3][i]) + p[4][i]) + p[5][i]) + p[6][i]) + p[7][i];
     return;
   }
+  if (NW == 2 || (NW == 0 && nw == 2)) {
+    double p[2][N];
+#pragma unroll
+    for (int w = 0; w < 2; w++)
+#pragma unroll
+      for (int i = 0; i < N; i++) p[w][i] = lds[w * N + i];
+#pragma unroll
+    for (int i = 0; i < N; i++) v[i] = (0.0 + p[0][i]) + p[1][i];
+    return;
+  }
   if (NW == 4 || (NW == 0 && nw == 4)) {
     double p[4][N];
 #pragma unroll
