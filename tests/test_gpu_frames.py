@@ -278,3 +278,53 @@ def test_guided_dense_windows_use_the_overflow_area(vo, orc):
                                               q["desc"], 60.0, 40.0, 2, 1, 8, sf, np.zeros(len(k1), np.uint8), oa)
     assert int(nm.item()) == on and np.array_equal(assigned.cpu().numpy()[0, :len(k1)], oa)
     fr.close()
+
+
+@pytest.mark.parametrize("mode", ["frame", "local_map"])
+def test_guided_replay_under_heavy_conflicts(vo, orc, mode):
+    """Crowded queries: every feature is the target of ~6 queries that carry (nearly) its descriptor, all of them
+    observed (= blocking) -- most lanes of a 64-query step lose their chosen feature to an earlier lane and are
+    re-proposed, several rounds per step.  The assignments must still be the sequential loop's."""
+    import torch
+    sf = _sf(orc)
+    k0, d0, k1, d1, dx, dy = _pair(orc, 44)
+    ur1, _ = _uright(k1, 3)
+    n1 = len(k1)
+    rng = np.random.default_rng(5)
+    tgt = rng.integers(0, n1, 6 * n1 // 1 if False else 3000)          # query -> feature it sits on
+    desc = d1[tgt].copy()
+    flip = rng.random(len(tgt)) < 0.5                                   # half of them one bit off: distinct distances
+    desc[flip, rng.integers(0, 32, flip.sum())] ^= (1 << rng.integers(0, 8, flip.sum())).astype(np.uint8)
+    q = dict(flags=np.full(len(tgt), 3, np.uint8),
+             u=(k1["x"][tgt] + rng.normal(0, 0.7, len(tgt))).astype(np.float32),
+             v=(k1["y"][tgt] + rng.normal(0, 0.7, len(tgt))).astype(np.float32),
+             level=k1["octave"][tgt].astype(np.int32), desc=np.ascontiguousarray(desc))
+    fr = vo.Frames(1, 2048, synth.CAM.astype(np.float32))
+    fr.upload(0, vo.FrameArrays(k1["x"], k1["y"], k1["octave"], k1["angle"], ur1, d1))
+    of = orc.FrameData(k1["x"], k1["y"], k1["octave"], k1["angle"], ur1, d1)
+    oa = np.full(n1, -1, np.int32)
+    mask = np.zeros(n1, np.uint8)
+    assigned = torch.full((1, 2048), -1, dtype=torch.int32, device="cuda")
+    nm = torch.zeros(1, dtype=torch.int32, device="cuda")
+    st = torch.cuda.current_stream().cuda_stream
+    if mode == "frame":
+        q["aux"] = np.full(len(tgt), 0.2, np.float32)
+        q["angle"] = k1["angle"][tgt].astype(np.float32)
+        dq = _to_dev([q], len(tgt), ("flags", "u", "v", "aux", "level", "angle", "desc"))
+        fr.match_dev(1, dq, vo.Frames.MODE_FRAME, sf, radius=15.0, bf=40.0, direction=0, check_rot=1,
+                     feature_mask=torch.zeros((1, 2048), dtype=torch.uint8, device="cuda"), assigned=assigned, n_matches=nm, stream=st)
+        on = orc.lib().orc_match_frame_projection(C.byref(of.c), len(tgt), q["flags"], q["u"], q["v"], q["aux"], q["level"],
+                                                  q["angle"], q["desc"], 15.0, 40.0, 0, 1, 8, sf, mask, oa)
+    else:
+        q["aux"] = np.where(ur1[tgt] >= 0, ur1[tgt], -1.0).astype(np.float32)
+        q["viewcos"] = np.full(len(tgt), 0.9, np.float32)
+        dq = _to_dev([q], len(tgt), ("flags", "u", "v", "aux", "level", "viewcos", "desc"))
+        fr.match_dev(1, dq, vo.Frames.MODE_LOCAL_MAP, sf, radius=3.0, ratio=0.8,
+                     feature_mask=torch.zeros((1, 2048), dtype=torch.uint8, device="cuda"), assigned=assigned, n_matches=nm, stream=st)
+        on = orc.lib().orc_match_local_map(C.byref(of.c), len(tgt), q["flags"], q["u"], q["v"], q["aux"], q["level"],
+                                           q["viewcos"], q["desc"], 3.0, 0.8, sf, mask, oa)
+    torch.cuda.synchronize()
+    fr.match_status()
+    assert int(nm[0]) == on and on > 300
+    assert np.array_equal(assigned[0, :n1].cpu().numpy(), oa)
+    fr.close()

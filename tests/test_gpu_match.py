@@ -342,3 +342,33 @@ def test_bow_feature_vector_feeds_search_by_bow(vo, orc):
     om = np.full(len(k0), -1, np.int32)
     on = orc.lib().orc_match_bow(C.byref(oA.c), ones0, C.byref(ba.c), C.byref(oB.c), ones1, C.byref(bb.c), 1, 0.75, 1, om)
     assert n == on and np.array_equal(match, om) and n > 50
+
+
+@pytest.mark.parametrize("mode", [0, 1])
+def test_search_by_bow_under_heavy_conflicts(vo, orc, mode):
+    """Frame A holds every feature three times (two of the copies one descriptor bit off) in coarse vocabulary nodes of
+    ~50 features: most lanes of a 64-query step want a feature an earlier lane takes, so the device replay runs many
+    conflict rounds per step -- and must still give the node-by-node sequential result."""
+    import ctypes as C
+    k0, d0, k1, d1, dx, dy = _frame_pair(orc, 3)
+    rng = np.random.default_rng(23)
+    rep = np.concatenate([np.arange(len(k0))] * 3)
+    rng.shuffle(rep)
+    kA, dA = k0[rep], d0[rep].copy()
+    off = rng.random(len(rep)) < 0.66
+    dA[off, rng.integers(0, 32, off.sum())] ^= (1 << rng.integers(0, 8, off.sum())).astype(np.uint8)
+    urA, _ = _uright(kA, 1)
+    ur1, _ = _uright(k1, 2)
+    va, vb = np.ones(len(kA), np.uint8), (rng.random(len(k1)) > 0.1).astype(np.uint8)
+    coarse = lambda k, sx=0.0, sy=0.0: (np.floor((k["x"] - sx) / 160.0).astype(np.int64) + 8 * np.floor((k["y"] - sy) / 160.0).astype(np.int64) + 7).astype(np.uint32)
+    na, nb = coarse(kA), coarse(k1, dx, dy)
+    A = vo.FrameArrays(kA["x"], kA["y"], kA["octave"], kA["angle"], urA, dA)
+    B = vo.FrameArrays(k1["x"], k1["y"], k1["octave"], k1["angle"], ur1, d1)
+    n, match = vo.Matcher(0.9).searchByBoW(A, va, vo.BowNodes(na), B, vb, vo.BowNodes(nb), bool(mode), True)
+    oA = orc.FrameData(kA["x"], kA["y"], kA["octave"], kA["angle"], urA, dA)
+    oB = orc.FrameData(k1["x"], k1["y"], k1["octave"], k1["angle"], ur1, d1)
+    ba, bb = orc.BowData(na), orc.BowData(nb)
+    om = np.full(len(kA) if mode else len(k1), -1, np.int32)
+    on = orc.lib().orc_match_bow(C.byref(oA.c), va, C.byref(ba.c), C.byref(oB.c), vb, C.byref(bb.c), mode, 0.9, 1, om)
+    assert n == on and n > 50
+    assert np.array_equal(match, om)
