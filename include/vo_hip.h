@@ -187,6 +187,18 @@ int vo_frames_download(vo_frames *h, int slot, int *n, float *x, float *y, int32
                        float *uright, float *depth, uint8_t *desc, int32_t *cell_start,
                        uint16_t *cell_items, void *hip_stream);
 
+/* Frame::getFeaturesInArea(u, v, radius, minLevel, maxLevel) (frame.cpp:199-247) and
+ * KeyFrame::getFeaturesInArea(u, v, radius) (keyframe.cpp:268-312; min_level = max_level = NULL) for
+ * n_queries windows of one stored frame: out_idx[q * max_out + k] = k-th feature index of window q in
+ * the reference's order (grid column by column, cells top to bottom, insertion order inside a cell),
+ * out_count[q] = number of features in the window (may exceed max_out: the list is then truncated).
+ * Host arrays in and out; runs on the calling thread's stream.  The searches above do not go through
+ * this list -- they walk the same windows inside their candidate kernel -- it is the reference's
+ * accessor for other callers and the direct test of the grid. */
+int vo_frames_features_in_area(vo_frames *h, int slot, int n_queries, const float *u, const float *v,
+                               const float *radius, const int32_t *min_level, const int32_t *max_level,
+                               int32_t *out_idx, int max_out, int32_t *out_count);
+
 /* Guided (window) matching on device-resident frames, batched over frames: frame f of the call
  * searches slot slot0 + f with its own block of queries (query q of frame f at index
  * f * stride + q of every array; all device pointers).

@@ -328,3 +328,35 @@ def test_guided_replay_under_heavy_conflicts(vo, orc, mode):
     assert int(nm[0]) == on and on > 300
     assert np.array_equal(assigned[0, :n1].cpu().numpy(), oa)
     fr.close()
+
+
+@pytest.mark.parametrize("with_levels", [True, False])
+def test_features_in_area_matches_the_reference_order(vo, orc, with_levels):
+    """Frame::getFeaturesInArea (with a level range) / KeyFrame::getFeaturesInArea (without) on the device grid: the
+    same indices in the same order as the oracle's walk, for windows inside, across and outside the image."""
+    k0, d0, k1, d1, dx, dy = _pair(orc, 12)
+    ur1, _ = _uright(k1, 1)
+    fr = vo.Frames(1, 2048, synth.CAM.astype(np.float32))
+    fr.upload(0, vo.FrameArrays(k1["x"], k1["y"], k1["octave"], k1["angle"], ur1, d1))
+    of = orc.FrameData(k1["x"], k1["y"], k1["octave"], k1["angle"], ur1, d1)
+    rng = np.random.default_rng(3)
+    nq = 700
+    u = rng.uniform(-60, 700, nq).astype(np.float32)
+    v = rng.uniform(-60, 540, nq).astype(np.float32)
+    r = rng.choice([3.0, 7.5, 15.0, 40.0, 200.0], nq).astype(np.float32)
+    lo = rng.integers(0, 6, nq).astype(np.int32) if with_levels else None
+    hi = (lo + rng.integers(0, 3, nq)).astype(np.int32) if with_levels else None
+    lists, cnt = fr.getFeaturesInArea(0, u, v, r, lo, hi, max_out=1100)
+    out = np.zeros(len(k1), np.int32)
+    total = 0
+    for i in range(nq):
+        m = orc.lib().orc_features_in_area(C.byref(of.c), float(u[i]), float(v[i]), float(r[i]),
+                                           int(lo[i]) if with_levels else -(1 << 30), int(hi[i]) if with_levels else 1 << 30,
+                                           out, len(k1))
+        assert cnt[i] == m and np.array_equal(lists[i], out[:m]), i
+        total += m
+    assert total > 5000
+    # truncation is reported through the count
+    lists, cnt2 = fr.getFeaturesInArea(0, u[:50], v[:50], np.full(50, 200.0, np.float32), max_out=4)
+    assert all(len(l) <= 4 for l in lists) and (cnt2 > 4).any()
+    fr.close()

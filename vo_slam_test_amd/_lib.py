@@ -42,7 +42,7 @@ SYMBOLS = [
     "vo_orb_get_level_counts", "vo_orb_set_timing", "vo_orb_get_timing",
     "vo_hamming_matrix_dev", "vo_hamming_matrix_batch_dev", "vo_hamming_matrix", "vo_median_descriptor",
     "vo_frames_create", "vo_frames_destroy", "vo_frames_capacity", "vo_frames_set_camera", "vo_frames_build_dev",
-    "vo_frames_upload", "vo_frames_download", "vo_match_guided_dev", "vo_match_guided_status",
+    "vo_frames_upload", "vo_frames_download", "vo_frames_features_in_area", "vo_match_guided_dev", "vo_match_guided_status",
     "vo_vocab_load", "vo_bow_score", "vo_sim3_ransac_eval", "vo_triangulate", "vo_rgb_to_gray", "vo_rgb_to_gray_dev",
     "vo_dataset_open", "vo_dataset_size", "vo_dataset_entry", "vo_dataset_close", "vo_png_info", "vo_png_read",
     "vo_trajectory_write", "vo_tracking_time_stats",
@@ -314,6 +314,19 @@ class Frames:
             out[key] = out[key][:k].copy()
         out["n"] = k
         return out
+
+    def getFeaturesInArea(self, slot, u, v, radius, min_level=None, max_level=None, max_out=256):
+        """Frame::getFeaturesInArea / KeyFrame::getFeaturesInArea for arrays of windows -> list of index arrays
+        (reference order), one per window"""
+        u, v = np.ascontiguousarray(u, np.float32), np.ascontiguousarray(v, np.float32)
+        r = np.ascontiguousarray(np.broadcast_to(np.asarray(radius, np.float32), u.shape))
+        lo = None if min_level is None else np.ascontiguousarray(np.broadcast_to(np.asarray(min_level, np.int32), u.shape))
+        hi = None if max_level is None else np.ascontiguousarray(np.broadcast_to(np.asarray(max_level, np.int32), u.shape))
+        out = np.full((len(u), max_out), -1, np.int32)
+        cnt = np.zeros(len(u), np.int32)
+        check(lib().vo_frames_features_in_area(self._h, int(slot), len(u), _p(u), _p(v), _p(r), _p(lo), _p(hi), _p(out),
+                                               int(max_out), _p(cnt)), "vo_frames_features_in_area")
+        return [out[i, :min(int(cnt[i]), max_out)].copy() for i in range(len(u))], cnt
 
     def match_dev(self, n_frames, q, mode, scale_factors, radius=0.0, bf=0.0, ratio=0.0, dist_threshold=0.0, direction=0,
                   check_rot=0, max_dist=0, feature_mask=None, assigned=None, best_idx=None, n_matches=None, slot0=0,

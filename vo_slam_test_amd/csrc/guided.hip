@@ -461,6 +461,58 @@ __global__ __launch_bounds__(256) void k_guided_cand(FramesDev F, Queries Q, Gui
   if (live && l16 == 0) O.qrec[qo] = make_uint2((unsigned)written | ((flags >> 1) & 1u) << 31, (unsigned)ovf_off);
 }
 
+// Frame / KeyFrame::getFeaturesInArea (frame.cpp:199-247, keyframe.cpp:268-312) as an entry point of its own: the
+// feature indices of a window in the reference's order (grid column by column, cells top to bottom, push_back order
+// inside a cell).  Sixteen lanes per query walk the cell-ordered records; ballot compaction keeps the order.
+__global__ __launch_bounds__(256) void k_features_in_area(FramesDev F, int slot, int nq, const float *qu, const float *qv,
+                                                          const float *qr, const int *qlo, const int *qhi, int *out,
+                                                          int max_out, int *count) {
+  const int lane = threadIdx.x & 63, l16 = threadIdx.x & 15, sub = lane >> 4;
+  const int q = blockIdx.x * 16 + (threadIdx.x >> 4);
+  const bool live = q < nq;
+  const int qq = live ? q : 0;
+  const float u = qu[qq], v = qv[qq], rs = qr[qq];
+  const int lmin = qlo ? qlo[qq] : -(1 << 30), lmax = qhi ? qhi[qq] : (1 << 30);
+  const int x0 = max(0, (int)floorf((u - F.xmin - rs) * F.gw));
+  const int x1 = min(kGridCols - 1, (int)floorf((u - F.xmin + rs) * F.gw));
+  const int y0 = max(0, (int)floorf((v - F.ymin - rs) * F.gh));
+  const int y1 = min(kGridRows - 1, (int)floorf((v - F.ymin + rs) * F.gh));
+  const bool window = live && !(x0 >= kGridCols || x1 < 0 || y0 >= kGridRows || y1 < 0);
+  const int *start = F.cell_start + (long long)slot * (kCells + 1);
+  const long long fo = (long long)slot * F.cap;
+  int written = 0;
+  const int ncol = window ? x1 - x0 + 1 : 0;
+  int ncmax = ncol;
+#pragma unroll
+  for (int o = 32; o >= 1; o >>= 1) ncmax = max(ncmax, __shfl_xor(ncmax, o));
+  for (int c = 0; c < ncmax; c++) {  // uniform trip count; a grid column's window cells are one contiguous run
+    int cbeg = 0, cend = 0;
+    if (c < ncol && y1 >= y0) cbeg = start[(x0 + c) * kGridRows + y0], cend = start[(x0 + c) * kGridRows + y1 + 1];
+    int len = cend - cbeg, lenmax = len;
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) lenmax = max(lenmax, __shfl_xor(lenmax, o));
+    for (int base = 0; base < lenmax; base += 16) {
+      const int t = base + l16;
+      bool hit = false;
+      int idx = 0;
+      if (t < len) {
+        const uint4 r = F.srec[fo + cbeg + t];
+        const float fx = __uint_as_float(r.x), fy = __uint_as_float(r.y);
+        const int oct = (int)(r.w & 0xffu);
+        idx = (int)(r.w >> 8);
+        hit = !(oct < lmin || oct > lmax) && fabsf(fx - u) < rs && fabsf(fy - v) < rs;
+      }
+      const unsigned m = (unsigned)(__builtin_amdgcn_ballot_w64(hit) >> (16 * sub)) & 0xffffu;
+      if (hit) {
+        const int p = written + __popc(m & ((1u << l16) - 1u));
+        if (p < max_out) out[(long long)q * max_out + p] = idx;
+      }
+      written += __popc(m);
+    }
+  }
+  if (live && l16 == 0) count[q] = written;
+}
+
 // One wavefront per frame: the sequential claim replay.  LDS: blocked[cap] bytes, assigned[cap] u16.  Everything a
 // decision needs rides in the records (distance, octave, rotation bin) and in the query record (count, observed flag).
 // FOUR consecutive queries are replayed per step, one per 16-lane row (a query has a dozen gated candidates): each
@@ -1022,6 +1074,32 @@ int vo_frames_download(vo_frames *h, int slot, int *n, float *x, float *y, int32
     VO_CHECK(vo::copy_d2h(cell_start, h->D.cell_start + (size_t)slot * (kCells + 1), (size_t)(kCells + 1) * 4, st, "vo_frames_download"));
   if (cell_items) VO_CHECK(vo::copy_d2h(cell_items, h->D.cell_items + o, (size_t)cnt * 2, st, "vo_frames_download"));
   return vo::stream_sync(st, "vo_frames_download");
+}
+
+int vo_frames_features_in_area(vo_frames *h, int slot, int n_queries, const float *u, const float *v, const float *radius,
+                               const int32_t *min_level, const int32_t *max_level, int32_t *out_idx, int max_out,
+                               int32_t *out_count) {
+  if (!h || slot < 0 || slot >= h->max_frames || n_queries < 0 || max_out < 0 ||
+      (n_queries > 0 && (!u || !v || !radius || !out_count || (max_out > 0 && !out_idx))))
+    return VO_ERR_INVALID;
+  if (n_queries == 0) return VO_OK;
+  thread_local vo::ScratchBuf du, dv, dr, dlo, dhi, dout, dcnt;
+  hipStream_t st = vo::thread_stream();
+  const char *what = "vo_frames_features_in_area";
+  VO_CHECK(vo::upload(du, u, (size_t)n_queries * 4, st, what));
+  VO_CHECK(vo::upload(dv, v, (size_t)n_queries * 4, st, what));
+  VO_CHECK(vo::upload(dr, radius, (size_t)n_queries * 4, st, what));
+  if (min_level) VO_CHECK(vo::upload(dlo, min_level, (size_t)n_queries * 4, st, what));
+  if (max_level) VO_CHECK(vo::upload(dhi, max_level, (size_t)n_queries * 4, st, what));
+  VO_CHECK(dout.reserve(std::max<size_t>((size_t)n_queries * max_out * 4, 64)));
+  VO_CHECK(dcnt.reserve((size_t)n_queries * 4));
+  hipLaunchKernelGGL(k_features_in_area, dim3((n_queries + 15) / 16), dim3(256), 0, st, h->D, slot, n_queries, du.as<float>(),
+                     dv.as<float>(), dr.as<float>(), min_level ? dlo.as<int>() : nullptr, max_level ? dhi.as<int>() : nullptr,
+                     dout.as<int>(), max_out, dcnt.as<int>());
+  VO_HIP_CHECK(hipGetLastError());
+  if (max_out > 0) VO_CHECK(vo::copy_d2h(out_idx, dout.p, (size_t)n_queries * max_out * 4, st, what));
+  VO_CHECK(vo::copy_d2h(out_count, dcnt.p, (size_t)n_queries * 4, st, what));
+  return vo::stream_sync(st, what);
 }
 
 int vo_match_guided_dev(vo_frames *h, int slot0, int n_frames, const vo_guided_queries *q, const vo_guided_params *p,
