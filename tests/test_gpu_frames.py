@@ -360,3 +360,34 @@ def test_features_in_area_matches_the_reference_order(vo, orc, with_levels):
     lists, cnt2 = fr.getFeaturesInArea(0, u[:50], v[:50], np.full(50, 200.0, np.float32), max_out=4)
     assert all(len(l) <= 4 for l in lists) and (cnt2 > 4).any()
     fr.close()
+
+
+def test_guided_search_with_the_largest_frame_capacity(vo, orc):
+    """max_features = 16384 (the documented limit): the replay's LDS layout switches to the serial form (the batched
+    one needs 11 bytes per feature slot) and 8192 takes the batched form with an enlarged LDS allocation; same result."""
+    import torch
+    sf = _sf(orc)
+    k0, d0, k1, d1, dx, dy = _pair(orc, 31)
+    ur1, _ = _uright(k1, 2)
+    _, z0 = _uright(k0, 7)
+    q = dict(flags=np.full(len(k0), 3, np.uint8), u=(k0["x"] + dx).astype(np.float32), v=(k0["y"] + dy).astype(np.float32),
+             aux=(1.0 / z0).astype(np.float32), level=k0["octave"].astype(np.int32), angle=k0["angle"].astype(np.float32),
+             desc=np.ascontiguousarray(d0))
+    of = orc.FrameData(k1["x"], k1["y"], k1["octave"], k1["angle"], ur1, d1)
+    oa = np.full(len(k1), -1, np.int32)
+    on = orc.lib().orc_match_frame_projection(C.byref(of.c), len(k0), q["flags"], q["u"], q["v"], q["aux"], q["level"],
+                                              q["angle"], q["desc"], 15.0, 40.0, 0, 1, 8, sf, np.zeros(len(k1), np.uint8), oa)
+    for cap in (8192, 16384):
+        fr = vo.Frames(1, cap, synth.CAM.astype(np.float32))
+        fr.upload(0, vo.FrameArrays(k1["x"], k1["y"], k1["octave"], k1["angle"], ur1, d1))
+        dq = _to_dev([q], len(k0), ("flags", "u", "v", "aux", "level", "angle", "desc"))
+        assigned = torch.full((1, cap), -1, dtype=torch.int32, device="cuda")
+        nm = torch.zeros(1, dtype=torch.int32, device="cuda")
+        fr.match_dev(1, dq, vo.Frames.MODE_FRAME, sf, radius=15.0, bf=40.0, direction=0, check_rot=1,
+                     feature_mask=torch.zeros((1, cap), dtype=torch.uint8, device="cuda"), assigned=assigned, n_matches=nm,
+                     stream=torch.cuda.current_stream().cuda_stream)
+        torch.cuda.synchronize()
+        fr.match_status()
+        assert int(nm[0]) == on and on > 300
+        assert np.array_equal(assigned[0, :len(k1)].cpu().numpy(), oa)
+        fr.close()

@@ -528,7 +528,8 @@ __device__ __forceinline__ void lds_handoff() {
   __builtin_amdgcn_wave_barrier();
 }
 
-__global__ __launch_bounds__(64) void k_guided_replay(FramesDev F, Queries Q, GuidedParams P, GuidedOut O, int slot0) {
+__global__ __launch_bounds__(64) void k_guided_replay(FramesDev F, Queries Q, GuidedParams P, GuidedOut O, int slot0,
+                                                      int batched_lds) {
   extern __shared__ __attribute__((aligned(16))) uint8_t rp_lds[];
   __shared__ int hist[32];
   const int lane = threadIdx.x, row = lane >> 4, l16 = lane & 15, f = blockIdx.x, s = slot0 + f;
@@ -564,7 +565,7 @@ __global__ __launch_bounds__(64) void k_guided_replay(FramesDev F, Queries Q, Gu
   // have committed.
   // Conflicts are rare (a handful per frame), so a step is usually one round: ~25 steps instead of ~450 four-query
   // steps, with the same result as the one-query-at-a-time order of matcher.cpp:76-128.
-  if (!sim3 && O.ovf_used[f] == 0) {
+  if (batched_lds && !sim3 && O.ovf_used[f] == 0) {
     int *tmpb = reinterpret_cast<int *>(rp_lds + capA + 2 * (size_t)capA);  // [cap] first blocking lane of the round
     int *tmpw = tmpb + capA;                                                  // [cap] last final claimant + 1
     for (int i = lane; i < capA; i += 64) tmpb[i] = 64, tmpw[i] = 0;
@@ -858,7 +859,7 @@ struct vo_frames {
   vo::DevBuf b_x, b_y, b_angle, b_ur, b_depth, b_oct, b_desc, b_n, b_cs, b_ci, b_srec, b_sdesc;
   // matcher scratch (grow-only)
   vo::DevBuf b_pool, b_rank, b_ovf, b_ovfr, b_qrec, b_used, b_best, b_asg, b_push, b_nm, b_err, b_sf;
-  size_t pool_stride = 0;
+  size_t pool_stride = 0, replay_lds_attr = 0;
   float sf_host[16] = {0};  // scale factors last uploaded for vo_track_gather_dev
 };
 
@@ -944,9 +945,16 @@ int guided_launch(vo_frames *h, int slot0, int n_frames, const Queries &Q, const
       hipLaunchKernelGGL(k_guided_cand<16>, dim3((nq_max + 15) / 16, n_frames), dim3(256), 0, st, h->D, Q, P, O, slot0);
   }
   if (claims) {
+    // LDS per frame: blocked (1 B per feature slot), asg (2 B), and the batched replay's two int arrays (8 B) where
+    // they fit (up to 14 k features per frame; beyond that the four-query serial replay runs)
     const size_t capA = (size_t)((h->cap + 15) & ~15);
-    const size_t lds = capA + capA * 2 + capA * 8;  // blocked, asg, and the batched replay's two int arrays
-    hipLaunchKernelGGL(k_guided_replay, dim3(n_frames), dim3(64), lds, st, h->D, Q, P, O, slot0);
+    const int batched = capA * 11 <= 160 * 1024 - 256 ? 1 : 0;
+    const size_t lds = capA * 3 + (batched ? capA * 8 : 0);
+    if (lds > 64 * 1024 && lds > h->replay_lds_attr) {
+      VO_HIP_CHECK(hipFuncSetAttribute((const void *)k_guided_replay, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+      h->replay_lds_attr = lds;
+    }
+    hipLaunchKernelGGL(k_guided_replay, dim3(n_frames), dim3(64), lds, st, h->D, Q, P, O, slot0, batched);
   } else {
     hipLaunchKernelGGL(k_guided_count, dim3(n_frames), dim3(256), 0, st, Q, best_idx, n_matches);
   }
