@@ -26,8 +26,11 @@ class BatchTracker:
         self.ext_stream = extract_stream if extract_stream is not None else self.stream
         extractor.set_stream(self.ext_stream.cuda_stream)
         self.build_done = None
-        self.cap = max_features or 2048
         self.kcap = extractor.max_keypoints()
+        # feature slots per frame: what the extractor can emit, rounded up (the searches' LDS -- 11 bytes per slot and
+        # frame -- and every per-feature buffer scale with it; 2048 slots for 1005 features cost the kernels that run
+        # next to the replay a third of their LDS)
+        self.cap = max_features or max(256, (self.kcap + 63) // 64 * 64)
         self.W, self.H = width, height
         self.cam5 = np.ascontiguousarray(intrinsics5, np.float32)
         self.frames = vo.Frames(batch, self.cap, self.cam5, dist_coef, float(width), float(height))
