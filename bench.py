@@ -336,7 +336,7 @@ def main():
     # stream around every kernel; with two batches in flight the other batch's kernels share the CUs with it, which
     # stretches every launch while the step gets shorter -- the same kernel with one batch in flight is under "alone")
     kernel_stages = [k for k in serial_stage_ms if k not in ("offsets", "pose_only_1", "pose_only_2")]
-    dom = max(kernel_stages, key=lambda k: stage_ms[k])
+    dom = max(kernel_stages, key=lambda k: serial_stage_ms[k])  # by the undisturbed durations: the in-region ranking flips between runs
     achieved = sb[dom] * B / (stage_ms[dom] * 1e-3) / 1e9
     traffic = None
     tf = ROOT / "profiles" / "traffic.json"
