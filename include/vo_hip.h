@@ -283,7 +283,8 @@ typedef struct {
 /* Matcher::searchByBoW(KeyFrame*, Frame*, matches, checkRot) (matcher.cpp:449-559; mode 0:
  * match[b.n] = A index held by each B feature) and searchByBoW(KeyFrame*, KeyFrame*, ...)
  * (:561-677; mode 1: match[a.n] = B index of each A feature).  a_valid / b_valid: the feature has
- * a good map point.  ratio = Matcher::ratio_. */
+ * a good map point.  ratio = Matcher::ratio_.  Runs on the device (k_node_replay: the node-by-node
+ * claims in the reference's order, distances computed on the fly); b.n <= 16384, else VO_ERR_CAPACITY. */
 int vo_match_bow(const vo_frame_view *a, const uint8_t *a_valid, const vo_bow_view *a_nodes,
                  const vo_frame_view *b, const uint8_t *b_valid, const vo_bow_view *b_nodes, int mode,
                  float ratio, int check_rot, int32_t *match, int *n_matches);
@@ -291,7 +292,8 @@ int vo_match_bow(const vo_frame_view *a, const uint8_t *a_valid, const vo_bow_vi
 /* Matcher::searchForTriangulation(kf1, kf2, matchIdxs, F12, checkRot) (matcher.cpp:867-1010,
  * called at localMapping.cpp:187).  *_has_map_point: feature already triangulated (skipped).
  * F12 row-major; (ex, ey) = camera centre 1 projected into key-frame 2 (:887-891).
- * match12[a.n] = B index or -1. */
+ * match12[a.n] = B index or -1.  Same device kernel as vo_match_bow (epipole / epipolar-line gates per
+ * candidate); scale_factors: 8 entries. */
 int vo_match_triangulation(const vo_frame_view *a, const uint8_t *a_has_map_point, const vo_bow_view *a_nodes,
                            const vo_frame_view *b, const uint8_t *b_has_map_point, const vo_bow_view *b_nodes,
                            const double F12[9], float ex, float ey, const float *scale_factors,
