@@ -117,7 +117,7 @@ def test_g9_global_ba_config4(vo):
     s = ba.solve(float(np.sqrt(np.float32(5.991))), float(np.sqrt(np.float32(7.815))), int(g["iters"]))
     poses, pts = ba.state()
     ba.close()
-    assert (s.iterations, s.accepted) == (int(g["iters"]), int(g["accepted"]))
+    assert (s.iterations, s.accepted) == (int(g["iters"]), int(g["accepted"])), (s.iterations, s.accepted, s.termination, s.initial_cost, s.final_cost, s.final_radius, vo.lib().vo_last_error())
     assert abs(s.initial_cost - float(g["initial_cost"])) <= 1e-10 * float(g["initial_cost"])
     assert abs(s.final_cost - float(g["final_cost"])) <= 1e-8 * float(g["final_cost"])
     assert np.abs(poses - g["poses"]).max() < 1e-7

@@ -2495,6 +2495,9 @@ int upload(vo::DevBuf &b, const void *src, size_t bytes) {
   return VO_OK;
 }
 
+// Every device-side initialisation below is enqueued on the handle's own (non-blocking) stream: a hipMemset on the NULL
+// stream is asynchronous for device memory and does not order with that stream -- the zeroing of the LM state was seen
+// to land after k_ba_setup had initialised it (a fresh handle whose allocations reuse recently freed memory).
 int build_device(vo_ba *h) {
   if (h->built) return VO_OK;
   BaDev &D = h->D;
@@ -2555,8 +2558,8 @@ int build_device(vo_ba *h) {
   VO_CHECK(upload(h->b_camedges, cedges.data(), cedges.size() * 4));
   VO_CHECK(h->b_ptin.reserve(std::max<size_t>(h->n_pts, 64)));
   VO_CHECK(h->b_camin.reserve(std::max<size_t>(h->n_cams, 64)));
-  VO_HIP_CHECK(hipMemset(h->b_ptin.p, 0, std::max<size_t>(h->n_pts, 64)));  // epoch stamps start below epoch 1
-  VO_HIP_CHECK(hipMemset(h->b_camin.p, 0, std::max<size_t>(h->n_cams, 64)));
+  VO_HIP_CHECK(hipMemsetAsync(h->b_ptin.p, 0, std::max<size_t>(h->n_pts, 64), h->stream));  // epoch stamps start below epoch 1
+  VO_HIP_CHECK(hipMemsetAsync(h->b_camin.p, 0, std::max<size_t>(h->n_cams, 64), h->stream));
   D.epoch = 0;
   VO_CHECK(upload(h->b_xc0, h->poses.data(), h->poses.size() * 8));
   VO_CHECK(upload(h->b_xc1, h->poses.data(), h->poses.size() * 8));
@@ -2574,14 +2577,14 @@ int build_device(vo_ba *h) {
   VO_CHECK(h->b_wt1.reserve(wt_rows * D.Mpad * 8));
   VO_CHECK(h->b_hll0.reserve((size_t)std::max(1, h->n_pts) * 6 * 8));
   VO_CHECK(h->b_hll1.reserve((size_t)std::max(1, h->n_pts) * 6 * 8));
-  VO_HIP_CHECK(hipMemset(h->b_hll0.p, 0, (size_t)std::max(1, h->n_pts) * 6 * 8));
-  VO_HIP_CHECK(hipMemset(h->b_hll1.p, 0, (size_t)std::max(1, h->n_pts) * 6 * 8));
+  VO_HIP_CHECK(hipMemsetAsync(h->b_hll0.p, 0, (size_t)std::max(1, h->n_pts) * 6 * 8, h->stream));
+  VO_HIP_CHECK(hipMemsetAsync(h->b_hll1.p, 0, (size_t)std::max(1, h->n_pts) * 6 * 8, h->stream));
   // operand matrices start out all-zero; only (point, camera) pairs that have an edge are ever written
-  VO_HIP_CHECK(hipMemset(h->b_wt.p, 0, wt_rows * D.Mpad * 8));
-  VO_HIP_CHECK(hipMemset(h->b_wt1.p, 0, wt_rows * D.Mpad * 8));
+  VO_HIP_CHECK(hipMemsetAsync(h->b_wt.p, 0, wt_rows * D.Mpad * 8, h->stream));
+  VO_HIP_CHECK(hipMemsetAsync(h->b_wt1.p, 0, wt_rows * D.Mpad * 8, h->stream));
   if (D.large) D.ksplit = 1;
   VO_CHECK(h->b_sgemm.reserve((size_t)(D.ksplit + 1) * D.Mpad * D.Mpad * 8));  // + one all-zero slab
-  VO_HIP_CHECK(hipMemset(h->b_sgemm.as<double>() + (size_t)D.ksplit * D.Mpad * D.Mpad, 0, (size_t)D.Mpad * D.Mpad * 8));
+  VO_HIP_CHECK(hipMemsetAsync(h->b_sgemm.as<double>() + (size_t)D.ksplit * D.Mpad * D.Mpad, 0, (size_t)D.Mpad * D.Mpad * 8, h->stream));
   if (D.large) {
     // covisible camera pairs (c <= c') and, per pair, the (edge of c, edge of c') couples at their shared
     // points in point order: the gather lists of k_ba_pairs
@@ -2639,8 +2642,8 @@ int build_device(vo_ba *h) {
     VO_CHECK(upload(h->b_paire, pe.data(), pe.size() * 4));
     VO_CHECK(h->b_we0.reserve((size_t)std::max(1, h->n_edges) * 18 * 8));
     VO_CHECK(h->b_we1.reserve((size_t)std::max(1, h->n_edges) * 18 * 8));
-    VO_HIP_CHECK(hipMemset(h->b_we0.p, 0, (size_t)std::max(1, h->n_edges) * 18 * 8));
-    VO_HIP_CHECK(hipMemset(h->b_we1.p, 0, (size_t)std::max(1, h->n_edges) * 18 * 8));
+    VO_HIP_CHECK(hipMemsetAsync(h->b_we0.p, 0, (size_t)std::max(1, h->n_edges) * 18 * 8, h->stream));
+    VO_HIP_CHECK(hipMemsetAsync(h->b_we1.p, 0, (size_t)std::max(1, h->n_edges) * 18 * 8, h->stream));
     VO_CHECK(h->b_glsc0.reserve((size_t)std::max(1, h->n_pts) * 3 * 8));
     VO_CHECK(h->b_glsc1.reserve((size_t)std::max(1, h->n_pts) * 3 * 8));
     VO_CHECK(h->b_Sd.reserve((size_t)(D.ld + vo::kCholPanel) * D.ld * 8));  // + right-hand side / solution rows
@@ -2665,12 +2668,12 @@ int build_device(vo_ba *h) {
   VO_CHECK(h->b_state.reserve(3 * sizeof(BaState)));
   VO_CHECK(h->b_dbg.reserve(64 * 8));
   VO_CHECK(h->b_cnt.reserve(4096));
-  VO_HIP_CHECK(hipMemset(h->b_cnt.p, 0, 4096));
+  VO_HIP_CHECK(hipMemsetAsync(h->b_cnt.p, 0, 4096, h->stream));
   D.counters = h->b_cnt.as<unsigned int>();
   D.fused = h->n_shards == 1 ? 1 : 0;
   D.div_np1 = (unsigned)((0x100000000ull + (unsigned)(6 * h->nf)) / (unsigned)(6 * h->nf + 1));
   D.dbg = h->b_dbg.as<unsigned long long>();
-  VO_HIP_CHECK(hipMemset(h->b_state.p, 0, 3 * sizeof(BaState)));
+  VO_HIP_CHECK(hipMemsetAsync(h->b_state.p, 0, 3 * sizeof(BaState), h->stream));
   D.e_cam = h->b_ecam.as<int>(), D.e_pt = h->b_ept.as<int>();
   D.e_obs = h->b_eobs.as<double>(), D.e_is = h->b_eis.as<double>();
   D.e_active = h->b_eact.as<uint8_t>();

@@ -2086,7 +2086,7 @@ int vo_orb_sync(vo_orb *h) {
   int e = 0;
   if (h->err.p) {
     VO_HIP_CHECK(hipMemcpy(&e, h->err.p, 4, hipMemcpyDeviceToHost));
-    if (e) VO_HIP_CHECK(hipMemset(h->err.p, 0, 4));  // reported once
+    if (e) VO_HIP_CHECK(hipMemsetAsync(h->err.p, 0, 4, h->stream));  // reported once (on the handle's stream: ordered with its kernels)
   }
   if (e) {
     vo::set_error(e == 1   ? "more FAST candidates on one level than the 65535-key scratch holds"
