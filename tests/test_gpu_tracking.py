@@ -193,3 +193,62 @@ def test_pipelined_trackers_lifecycle(vo):
         for t in (keep, nxt):
             t.close(), t.ext.close()
     ref.close(), ref.ext.close()
+
+
+def test_batch_of_replicated_frames_is_consistent(vo):
+    """A batch of 160 frames built from 8 distinct ones (the shape of bench.py's workload): every replica of a frame
+    gets bit-identical key-points, assignments, poses and inlier counts -- whatever its position in the batch -- and the
+    results differ between distinct frames."""
+    import torch
+    from vo_slam_test_amd.tracking import BatchTracker
+    NU, REP, W, H = 8, 20, 640, 480
+    B = NU * REP
+    uniq = synth.make_frames(NU, start=300)
+    udep = np.stack([synth.make_depth(300 + i) for i in range(NU)])
+    order = np.arange(B) % NU
+    np.random.default_rng(1).shuffle(order)
+    imgs = torch.from_numpy(uniq[order]).cuda()
+    dep = torch.from_numpy(udep[order].view(np.int16)).cuda()
+    inv = float(np.float32(1.0) / np.float32(synth.DEPTH_SCALE))
+    cam5 = synth.CAM.astype(np.float32)
+    ext = vo.OrbExtractor(1000, 1.2, 8, 20, 7)
+    trk = BatchTracker(B, ext, cam5, synth.DIST, W, H, n_last=1100, n_local=2200)
+    with torch.cuda.stream(trk.stream):
+        ext.extract_batch_dev(imgs, trk.kps, trk.desc, trk.cnt)
+        trk.frames.build_dev(trk.kps, trk.desc, trk.cnt, dep, inv, stream=trk.st)
+    torch.cuda.synchronize()
+    first = {int(u): int(np.nonzero(order == u)[0][0]) for u in range(NU)}
+    maps = {}
+    for u, f in first.items():
+        fr = trk.frames.download(f, stream=trk.st)
+        maps[u] = synth.make_tracking_map(fr["x"], fr["y"], fr["octave"], fr["angle"], fr["desc"], fr["depth"], seed=u)
+
+    def stack(which, key, n, tail=()):
+        o = np.zeros((B, n) + tail, maps[0][which][key].dtype)
+        for f in range(B):
+            a = maps[int(order[f])][which][key]
+            o[f, :len(a)] = a[:n]
+        return o
+    last = dict(points=stack(2, "points", 1100, (3,)), flags=stack(2, "flags", 1100), octave=stack(2, "octave", 1100),
+                angle=stack(2, "angle", 1100), desc=stack(2, "desc", 1100, (32,)))
+    local = {k: stack(3, k, 2200, (3,) if k == "points" else (32,) if k == "desc" else ())
+             for k in ("points", "flags", "u", "v", "ur", "level", "viewcos", "desc")}
+    with torch.cuda.stream(trk.stream):
+        trk.set_map(np.stack([maps[int(order[f])][0] for f in range(B)]), np.stack([maps[int(order[f])][1] for f in range(B)]),
+                    last, local)
+    trk.track(imgs, dep, inv)
+    torch.cuda.synchronize()
+    ext.sync()
+    trk.frames.match_status(stream=trk.st)
+    cnt, pose, ninl = trk.cnt.cpu().numpy(), trk.pose.cpu().numpy(), trk.ninl.cpu().numpy()
+    asg, kps = trk.assigned.cpu().numpy(), trk.kps.cpu().numpy()
+    for u in range(NU):
+        idx = np.nonzero(order == u)[0]
+        r = idx[0]
+        assert ninl[r] >= 100
+        for f in idx[1:]:
+            assert cnt[f] == cnt[r] and ninl[f] == ninl[r]
+            assert np.array_equal(kps[f, :cnt[r]], kps[r, :cnt[r]])
+            assert np.array_equal(asg[f], asg[r]) and np.array_equal(pose[f], pose[r])
+    assert len({tuple(pose[first[u]]) for u in range(NU)}) == NU
+    trk.close(), ext.close()
