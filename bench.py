@@ -354,7 +354,7 @@ def main():
     stage_gbs = {k: round(sb[k] * B / (serial_stage_ms[k] * 1e-3) / 1e9, 1) for k in kernel_stages if serial_stage_ms[k] > 0}
     stage_gbs_region = {k: round(sb[k] * B / (stage_ms[k] * 1e-3) / 1e9, 1) for k in stage_ms
                         if k in sb and stage_ms[k] > 0}
-    # pose-only stages are FP64-latency bound: report their flop rate (~270 flop per observation and iteration)
+    # pose-only stages are bound by FP64 instruction issue: report their flop rate (~270 flop per observation and iteration)
     po_iters = 20.0
     pose_flops = 270.0 * n_obs2 * po_iters
     ext_ms = stage_ms["extract"]
@@ -389,7 +389,7 @@ def main():
         "extract_match_frac_of_hbm_peak": round(em_gbs / HBM_PEAK_GBS, 4),
         "pose_only_in_path": {"ms_per_launch": round(stage_ms["pose_only_1"] + stage_ms["pose_only_2"], 4),
                               "fp64_GFLOPs": round(2 * pose_flops * B / ((stage_ms["pose_only_1"] + stage_ms["pose_only_2"]) * 1e-3) / 1e9, 1),
-                              "bound": "fp64 latency (one workgroup per frame, <= 20 dependent LM iterations)"},
+                              "bound": "fp64 VALU issue (one wavefront per frame; twice the frames take twice as long: ~10 cycles per FP64 wave-instruction per SIMD)"},
     }
 
     # ---- BASELINE config 1 as written: extract + brute-force 1000 x 1000 Hamming against the next frame (SURVEY 8d bytes)
@@ -577,7 +577,7 @@ def main():
             f_po = 270.0 * 1000 * pit  # ~150 + 120 flop per observation and LM iteration
             out["pose_only_ba"]["device_resident"] = {"solves_per_s": round(len(probs) / tk, 1), "lm_iters_per_s": round(pit / tk, 1),
                                                       "ms_per_launch": round(tk * 1e3, 3)}
-            out["pose_only_ba"]["roofline"] = {"bound": "fp64 (latency-bound: <= 20 dependent LM iterations per frame)",
+            out["pose_only_ba"]["roofline"] = {"bound": "fp64 VALU issue (one wavefront per frame and SIMD, ~10 cycles per FP64 wave-instruction; most instructions are not multiply-adds)",
                                                "achieved": round(f_po / tk / 1e12, 4), "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s",
                                                "frac": round(f_po / tk / 1e12 / FP64_PEAK_TFLOPS, 5)}
             pose_probs, pose_iters_dev = probs, pit
