@@ -160,24 +160,56 @@ struct PoseLm {
   int iterations, accepted, termination;
 };
 
+// Where a frame's observations are read from during a solve.  A solve makes ~20 passes over them; with one wavefront
+// per frame (the batched mode) a pass re-reads 56 bytes per observation from HBM -- the batch does not fit the L2s (PMC:
+// 93 % L2 misses, TCP stalled on pending misses 40 % of the kernel) -- so the first `nc` observations of the frame are
+// kept in LDS in a compact, LOSSLESS form: the point in double, (u, v, uR) as the floats they came from, 1/sigma as an
+// index into a table of the frame's distinct values (one per pyramid level), and the outlier flag.  38 bytes per
+// observation, for the first 768 observations of each of the four frames that share a CU.  A frame whose observations are not
+// float-representable, or with more than 16 distinct 1/sigma, is read from memory as before (nc = 0).
+struct ObsView {
+  const double *pts, *obs, *isg;
+  uint8_t *outlier;  // global flags: the result, and the skip mask of what is not cached
+  int nc;
+  const double *lx, *ly, *lz, *tab;
+  const float *lu, *lv, *lr;
+  const uint8_t *li;
+  uint8_t *lsk;
+  __device__ __forceinline__ void get(int i, double (&p)[3], double &ou, double &ov, double &our, double &is) const {
+    if (i < nc) {  // wave-uniform: nc is a multiple of 64 or the whole frame
+      p[0] = lx[i], p[1] = ly[i], p[2] = lz[i];
+      ou = (double)lu[i], ov = (double)lv[i], our = (double)lr[i];
+      is = tab[li[i]];
+    } else {
+      p[0] = pts[3 * i], p[1] = pts[3 * i + 1], p[2] = pts[3 * i + 2];
+      ou = obs[3 * i], ov = obs[3 * i + 1], our = obs[3 * i + 2];
+      is = isg[i];
+    }
+  }
+  __device__ __forceinline__ bool skip(int i) const { return i < nc ? lsk[i] != 0 : outlier[i] != 0; }
+  __device__ __forceinline__ void set_skip(int i, bool v) const {
+    if (i < nc) lsk[i] = v ? 1 : 0;
+    outlier[i] = v ? 1 : 0;
+  }
+};
+
 // one linearisation pass: H (upper 21), g (6), cost; unscaled, loss-corrected
-__device__ void pose_accumulate(const double x[6], int n, const double *pts, const double *obs, const double *isg,
-                                const uint8_t *skip, const Cam &K, double hm, double hs, bool want_jac,
-                                double (&acc)[28]) {
+__device__ void pose_accumulate(const double x[6], int n, const ObsView &V, bool use_skip, const Cam &K, double hm, double hs,
+                                bool want_jac, double (&acc)[28]) {
 #pragma unroll
   for (int i = 0; i < 28; i++) acc[i] = 0;
   const PoseCache P = pose_cache(x);
   // (Requesting the next observation of the lane before the current one is used was measured: the kernel sits at its
   // 256-register limit, the extra live values spill, 0.52 -> 0.56 ms per 1024 frames.)
   for (int i = threadIdx.x; i < n; i += blockDim.x) {
-    if (skip && skip[i]) continue;
-    double r[3], J[18];
+    if (use_skip && V.skip(i)) continue;
+    double r[3], J[18], pw[3], ou, ov, our, is;
+    V.get(i, pw, ou, ov, our, is);
     int m;
     if (want_jac)
-      m = edge_eval<true, false>(P, pts + 3 * i, obs[3 * i], obs[3 * i + 1], obs[3 * i + 2], isg[i], K, r, J, nullptr);
+      m = edge_eval<true, false>(P, pw, ou, ov, our, is, K, r, J, nullptr);
     else
-      m = edge_eval<false, false>(P, pts + 3 * i, obs[3 * i], obs[3 * i + 1], obs[3 * i + 2], isg[i], K, r, nullptr,
-                                  nullptr);
+      m = edge_eval<false, false>(P, pw, ou, ov, our, is, K, r, nullptr, nullptr);
     const double s = r[0] * r[0] + r[1] * r[1] + r[2] * r[2];
     double rho0, rho1;
     huber(m == 2 ? hm : hs, s, rho0, rho1);
@@ -238,11 +270,10 @@ __device__ bool chol6_solve(double A[6][6], double b[6]) {
 }
 
 // Ceres-style LM on one 6-dof pose; every thread keeps the (uniform) control state in registers.
-__device__ void pose_lm(double x[6], int n, const double *pts, const double *obs, const double *isg,
-                        const uint8_t *skip, const Cam &K, double hm, double hs, int max_it, double *lds,
+__device__ void pose_lm(double x[6], int n, const ObsView &V, const Cam &K, double hm, double hs, int max_it, double *lds,
                         vo_lm_summary *sum) {
   double acc[28];
-  pose_accumulate(x, n, pts, obs, isg, skip, K, hm, hs, true, acc);
+  pose_accumulate(x, n, V, true, K, hm, hs, true, acc);
   block_sum<28>(acc, lds);
   double scale[6];
   {
@@ -326,7 +357,7 @@ __device__ void pose_lm(double x[6], int n, const double *pts, const double *obs
     // The candidate is linearised completely in the same pass (its cost is one of the 28 sums): an
     // accepted step -- the common case -- then needs no second sweep over the observations.
     double cacc[28];
-    pose_accumulate(xc, n, pts, obs, isg, skip, K, hm, hs, true, cacc);
+    pose_accumulate(xc, n, V, true, K, hm, hs, true, cacc);
     block_sum<28>(cacc, lds);
     double cand = cacc[27];
     if (!isfinite(cand)) cand = 1.7976931348623157e308;
@@ -389,7 +420,9 @@ __device__ __forceinline__ bool pose_chi2_outlier(const double pc[3], double ou,
 // vo_track_gather_dev); otherwise [offsets[p], offsets[p+1]).
 __global__ __launch_bounds__(256) void k_pose_only(const int *offsets, const double *pts, const double *obs,
                                                    const double *isg, const double *cam5, double *poses,
-                                                   uint8_t *outlier, int *n_inliers, vo_lm_summary *sums, int ranges) {
+                                                   uint8_t *outlier, int *n_inliers, vo_lm_summary *sums, int ranges,
+                                                   int cache_cap) {
+  extern __shared__ __attribute__((aligned(16))) uint8_t pose_dyn[];  // the observation cache (cache_cap > 0)
   __shared__ double lds[4 * 28];
   __shared__ int s_cnt[4];
   const int p = blockIdx.x;
@@ -404,6 +437,47 @@ __global__ __launch_bounds__(256) void k_pose_only(const int *offsets, const dou
     if (threadIdx.x == 0) n_inliers[p] = 0;
     return;
   }
+  ObsView V{pts, obs, isg, outlier, 0, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+  if (cache_cap > 0) {  // one wavefront per frame (blockDim.x == 64): fill the cache, verify that it is lossless
+    const int lane = threadIdx.x, nfill = min(n, cache_cap);
+    double *lx = reinterpret_cast<double *>(pose_dyn), *ly = lx + cache_cap, *lz = ly + cache_cap, *tab = lz + cache_cap;
+    float *lu = reinterpret_cast<float *>(tab + 16), *lv = lu + cache_cap, *lr = lv + cache_cap;
+    uint8_t *li = reinterpret_cast<uint8_t *>(lr + cache_cap), *lsk = li + cache_cap;
+    int ntab = 0;
+    bool good = true;
+    for (int base = 0; base < nfill; base += 64) {
+      const int i = base + lane;
+      const bool valid = i < nfill;
+      const int j = valid ? i : nfill - 1;
+      const double px = pts[3 * j], py = pts[3 * j + 1], pz = pts[3 * j + 2];
+      const double ou = obs[3 * j], ov = obs[3 * j + 1], our = obs[3 * j + 2], is = isg[j];
+      const float fu = (float)ou, fv = (float)ov, fr = (float)our;
+      const bool lossless = (double)fu == ou && (double)fv == ov && (double)fr == our;
+      int idx = -1;
+      for (int k = 0; k < ntab; k++)
+        if (tab[k] == is) idx = k;
+      unsigned long long miss = __builtin_amdgcn_ballot_w64(valid && idx < 0);
+      while (miss != 0ull && ntab < 16) {  // uniform: one new table entry per trip
+        const double v = readlane_f64(is, (int)__builtin_ctzll(miss));
+        if (lane == 0) tab[ntab] = v;
+        if (idx < 0 && is == v) idx = ntab;
+        ntab++;
+        miss = __builtin_amdgcn_ballot_w64(valid && idx < 0);
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_wave_barrier();
+      if (miss != 0ull || __builtin_amdgcn_ballot_w64(valid && !lossless) != 0ull) good = false;  // uniform
+      if (valid) {
+        lx[i] = px, ly[i] = py, lz[i] = pz;
+        lu[i] = fu, lv[i] = fv, lr[i] = fr;
+        li[i] = (uint8_t)max(idx, 0);
+        lsk[i] = 0;
+      }
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_wave_barrier();
+    if (good) V = ObsView{pts, obs, isg, outlier, nfill, lx, ly, lz, tab, lu, lv, lr, li, lsk};
+  }
   for (int i = threadIdx.x; i < n; i += blockDim.x) outlier[i] = 0;
   __syncthreads();
   int inl = 0;
@@ -411,17 +485,18 @@ __global__ __launch_bounds__(256) void k_pose_only(const int *offsets, const dou
     for (int a = 0; a < 6; a++) x[a] = x0[a];  // :215
     const double hm = round == 0 ? (double)sqrtf(5.991f) : 0.0;
     const double hs = round == 0 ? (double)sqrtf(7.815f) : 0.0;
-    pose_lm(x, n, pts, obs, isg, outlier, K, hm, hs, 10, lds, sums ? &sums[2 * p + round] : nullptr);
+    pose_lm(x, n, V, K, hm, hs, 10, lds, sums ? &sums[2 * p + round] : nullptr);
     __syncthreads();
     // classification with Tcw = exp(pose) (Sophus quaternion form, :256-257)
     const Se3 T = se3_exp(x);
     int local = 0;
     for (int i = threadIdx.x; i < n; i += blockDim.x) {
-      double rp[3], pc[3];
-      quat_rotate(T.q, pts + 3 * i, rp);
+      double rp[3], pc[3], pw[3], ou, ov, our, is;
+      V.get(i, pw, ou, ov, our, is);
+      quat_rotate(T.q, pw, rp);
       pc[0] = rp[0] + T.t[0], pc[1] = rp[1] + T.t[1], pc[2] = rp[2] + T.t[2];
-      const bool out = pose_chi2_outlier(pc, obs[3 * i], obs[3 * i + 1], obs[3 * i + 2], fx, fy, cx, cy, bf, isg[i]);
-      outlier[i] = out ? 1 : 0;
+      const bool out = pose_chi2_outlier(pc, ou, ov, our, fx, fy, cx, cy, bf, is);
+      V.set_skip(i, out);
       local += out ? 0 : 1;
     }
     for (int o = 32; o >= 1; o >>= 1) local += __shfl_xor(local, o);
@@ -2906,6 +2981,21 @@ static inline int pose_block_width(int n_problems) {
   return n_problems >= 512 ? 64 : 256;
 }
 
+// Observation cache of the one-wavefront-per-frame mode: 768 observations x 38 bytes + the 1/sigma table = 29 KB per
+// frame, four frames per CU; a frame's observations beyond that are read from memory.  Measured per 1024 frames x ~1000
+// observations (pose solve alone / tracked step with two batches in flight): no cache 0.55 ms / 4.72 ms, 512: 0.47 / 4.58,
+// 768: 0.42 / 4.52, 1024: 0.44 / 5.00 -- the full cache takes the CU's whole LDS away from the extraction kernels that
+// run next to the solve.  VO_POSE_CACHE overrides.
+static inline int pose_cache_cap(int block_width) {
+  static const int forced = [] {
+    const char *e = getenv("VO_POSE_CACHE");
+    return e ? atoi(e) : -1;
+  }();
+  const int cap = forced >= 0 ? (forced / 64) * 64 : 768;
+  return block_width == 64 ? cap : 0;
+}
+static inline size_t pose_cache_bytes(int cap) { return cap > 0 ? (size_t)cap * 38 + 16 * 8 : 0; }
+
 int vo_pose_only_solve_dev(int n_problems, const int32_t *dev_offsets, int max_obs, const double *dev_points,
                            const double *dev_obs, const double *dev_inv_sigma, const double *dev_cam5,
                            double *dev_poses, uint8_t *dev_outlier, int32_t *dev_n_inliers,
@@ -2915,8 +3005,9 @@ int vo_pose_only_solve_dev(int n_problems, const int32_t *dev_offsets, int max_o
     return VO_ERR_INVALID;
   if (n_problems == 0) return VO_OK;
   VO_CHECK(vo::ensure_device());
-  hipLaunchKernelGGL(k_pose_only, dim3(n_problems), dim3(pose_block_width(n_problems)), 0, (hipStream_t)hip_stream, dev_offsets, dev_points,
-                     dev_obs, dev_inv_sigma, dev_cam5, dev_poses, dev_outlier, dev_n_inliers, dev_summaries, 0);
+  const int bw = pose_block_width(n_problems), cc = pose_cache_cap(bw);
+  hipLaunchKernelGGL(k_pose_only, dim3(n_problems), dim3(bw), pose_cache_bytes(cc), (hipStream_t)hip_stream, dev_offsets, dev_points,
+                     dev_obs, dev_inv_sigma, dev_cam5, dev_poses, dev_outlier, dev_n_inliers, dev_summaries, 0, cc);
   VO_HIP_CHECK(hipGetLastError());
   return VO_OK;
 }
@@ -2929,8 +3020,9 @@ int vo_pose_only_solve_ranges_dev(int n_problems, const int32_t *dev_ranges, con
     return VO_ERR_INVALID;
   if (n_problems == 0) return VO_OK;
   VO_CHECK(vo::ensure_device());
-  hipLaunchKernelGGL(k_pose_only, dim3(n_problems), dim3(pose_block_width(n_problems)), 0, (hipStream_t)hip_stream, dev_ranges, dev_points,
-                     dev_obs, dev_inv_sigma, dev_cam5, dev_poses, dev_outlier, dev_n_inliers, dev_summaries, 1);
+  const int bw = pose_block_width(n_problems), cc = pose_cache_cap(bw);
+  hipLaunchKernelGGL(k_pose_only, dim3(n_problems), dim3(bw), pose_cache_bytes(cc), (hipStream_t)hip_stream, dev_ranges, dev_points,
+                     dev_obs, dev_inv_sigma, dev_cam5, dev_poses, dev_outlier, dev_n_inliers, dev_summaries, 1, cc);
   VO_HIP_CHECK(hipGetLastError());
   return VO_OK;
 }
