@@ -468,3 +468,31 @@ def test_stateless_entry_points_from_three_threads_and_scratch_release(vo):
     assert vo.lib().vo_release_thread_scratch() == 0
     again = vo.Optimizer.solvePoseGraphLoop(g)
     assert np.array_equal(again[0], ref_pg[0])
+
+
+@pytest.mark.parametrize("kind", ["float_obs", "double_obs", "many_sigmas", "long"])
+def test_pose_only_batched_mode_with_observation_cache(vo, orc, kind):
+    """>= 512 problems in one call: one wavefront per frame with the observations cached in LDS.  float_obs: the cache is
+    used (observations are float pixel coordinates, as in the reference); double_obs: observations that are not
+    float-representable must bypass it; many_sigmas: more than 16 distinct 1/sigma values must bypass it; long: frames
+    with more observations than the cache holds (the tail is read from memory).  Each against the oracle."""
+    from vo_slam_test_amd import synth
+    nprob, nobs = 520, (1500 if kind == "long" else 90)
+    if kind == "long":
+        nprob = 512
+    probs = []
+    for i in range(nprob):
+        pr = synth.make_pose_problem(100 + (i % 7), n=nobs)
+        pr = dict(pr)
+        rng = np.random.default_rng(i)
+        pr["pose0"] = pr["pose0"] + rng.uniform(-0.01, 0.01, 6)
+        if kind == "double_obs":
+            pr["obs"] = pr["obs"] + np.where(pr["obs"] >= 0, 1e-9, 0.0)       # no longer float32 values (mono uR = -1 kept)
+        if kind == "many_sigmas":
+            pr["inv_sigma"] = pr["inv_sigma"] * (1.0 + 1e-3 * rng.integers(0, 40, nobs))
+        probs.append(pr)
+    poses, masks, ninl = vo.Optimizer.solvePoseOnlySE3(probs)
+    for i in list(range(0, nprob, 37)) + [nprob - 1]:
+        op, oout, oinl, _, _ = orc.pose_only(probs[i])
+        assert ninl[i] == oinl and np.array_equal(masks[i], oout), (kind, i)
+        assert np.abs(poses[i] - op).max() < 1e-9, (kind, i)
