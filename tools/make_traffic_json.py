@@ -9,7 +9,7 @@ fetch_dir, write_dir, out = sys.argv[1], sys.argv[2], sys.argv[3]
 STAGES = (("k_resize", "pyramid"), ("k_fast", "fast"), ("k_octree", "octree"), ("k_blur", "blur"),
           ("k_describe", "describe"), ("k_hamming", "hamming"), ("k_frame_", "frame_post"),
           ("k_guided_", "match"), ("k_track_", "match"), ("k_pose_only", "pose_only"))
-def stage_of(kernel):  # template instances appear as "void k_fast_wave<48>"
+def stage_of(kernel):  # template instances appear as "void k_fast_cell<48, false>"
     for key, st in STAGES:
         if key in kernel:
             return st

@@ -266,6 +266,8 @@ __device__ __forceinline__ void wave_sync() {  // LDS hand-off between lanes of 
 
 typedef __attribute__((address_space(3))) uint8_t lds_u8;  // explicit LDS pointers: 32-bit address arithmetic
 typedef __attribute__((address_space(3))) unsigned short lds_u16;
+typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));
+typedef const __attribute__((address_space(1))) uint8_t gmem_u8;  // global memory: loads are scalar base + lane offset
 
 // Arc score of one pixel.  With A = min over the 16 nine-pixel arcs of the arc's maximum and B = max over
 // the arcs of the arc's minimum (ring values, not differences), S = max(v - A, B - v); a nine-arc extremum
@@ -309,37 +311,56 @@ __device__ __forceinline__ int fast_arc_score(const lds_u8 *ring, int min_th) {
 }
 
 __host__ __device__ __forceinline__ int fast_align16(int v) { return (v + 15) & ~15; }
-// LDS bytes of one wave of k_fast_wave: image rows and score rows interleaved (row pitch 2 TP), survivor list
-__host__ __device__ __forceinline__ int fast_wave_lds(int tp, int tile_rows, int list_cap) {
-  return fast_align16(2 * tp * tile_rows + 16) + fast_align16(2 * list_cap);
+// ------------------------------------------------------------------------------------------
+// K2  k_fast_cell: per-cell FAST-9-16 + NMS, one wavefront per (cell, frame), four cells per workgroup, no
+// workgroup barrier.  Round 3 rebuilt round 2's k_fast_wave around what the issue-rate calibration of this chip shows
+// (profiles/r03_valu_issue_calibration.txt): 32-bit min / max, three-operand and packed integer forms issue at
+// 4.2 cycles per wave64, 16-bit VOP2 forms at 2.2 (>= 4 waves per SIMD) -- and around the LDS pipe, which the
+// round-2 kernel kept 64 % busy:
+//  * the tile goes global memory -> LDS by LDS-DMA (global_load_lds_dwordx4, lane = 16-byte chunk of a 48-byte
+//    tile row): two or three instructions per cell instead of 12 loads + 12 LDS stores and their addressing;
+//  * the compass-margin pass runs on 16-bit VOP2 min / max / sub and does NOT leave its bound in the score
+//    tile: the tile is zero except for the arc scores of the survivors, which is all the NMS needs (a pixel
+//    whose margin does not exceed the threshold cannot score above it); the rare second round at minThFAST and
+//    the rare overflow path recompute the margins instead of reading them back;
+// Results are bit-identical to round 2's kernel and to the oracle (tests/test_gpu_orb.py); 0.253 -> 0.210 ms per 256
+// frames.  Early-exit builds split the 0.213 ms into staging 0.074, margin walk 0.048, arc scores 0.057, NMS + output
+// 0.035: the phases add up, i.e. the staging latency (table entry, then the tile: two dependent memory round trips
+// of ~3 us per cell with 32 waves per CU in flight) is not hidden by the other waves' compute.
+// ------------------------------------------------------------------------------------------
+#define VO_OP16(name, ins)                                                   \
+  __device__ __forceinline__ unsigned name(unsigned a, unsigned b) {          \
+    unsigned r;                                                               \
+    asm(ins " %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));                        \
+    return r;                                                                 \
+  }
+VO_OP16(max_u16, "v_max_u16")
+VO_OP16(min_u16, "v_min_u16")
+#undef VO_OP16
+
+// LDS bytes of one wave of k_fast_cell: image tile, score tile (same geometry), survivor list
+__host__ __device__ __forceinline__ int fast_cell_lds(int tp, int tile_rows, int list_cap) {
+  return 2 * fast_align16(tp * tile_rows) + fast_align16(2 * list_cap);
 }
 
-// TP: width of a tile row in bytes, 48 for the usual 30..39-px cells, 72 for the largest legal cell.
-// BYTEWISE: the caller's level-0 rows are not 4-byte aligned (level 0 is then copied byte by byte).
+// TP: tile row pitch in bytes (48: three 16-byte chunks, the LDS-DMA path; 72: the largest legal cell, staged
+// through registers).  BYTEWISE: the caller's level-0 rows are not 4-byte aligned (copied byte by byte).
 template <int TP, bool BYTEWISE>
-__global__ __launch_bounds__(256) void k_fast_wave(OrbDev P, FrameSrc src, uint32_t *cell_slots,
+__global__ __launch_bounds__(256) void k_fast_cell(OrbDev P, FrameSrc src, uint32_t *cell_slots,
                                                    long long slots_frame_stride, int *cell_count,
                                                    int cells_per_frame, int tile_rows, int list_cap,
                                                    const int *__restrict__ cell_tab) {
   extern __shared__ __attribute__((aligned(16))) uint8_t fast_lds[];
-  constexpr int RP = 2 * TP;  // LDS row pitch: image row (TP bytes), then the score row of the same pixels
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
   const int cell = blockIdx.x * 4 + wave, f = blockIdx.y;
   if (cell >= cells_per_frame) return;  // wave-uniform; the kernel has no workgroup barrier
-  lds_u8 *tile_raw = (lds_u8 *)fast_lds + wave * fast_wave_lds(TP, tile_rows, list_cap);
-  lds_u16 *plist = (lds_u16 *)(tile_raw + fast_align16(RP * tile_rows + 16));
-  // the cell's geometry comes from a table built with the handle (12 dwords by scalar loads) instead of a
-  // level search over the kernel arguments, which is a chain of dependent scalar round trips per wavefront
+  const int tile_bytes = fast_align16(TP * tile_rows);  // uniform
+  lds_u8 *tile_raw = (lds_u8 *)fast_lds + wave * fast_cell_lds(TP, tile_rows, list_cap);
+  lds_u16 *plist = (lds_u16 *)(tile_raw + 2 * tile_bytes);
   const int *cd = cell_tab + 16 * cell;
   const int l = cd[0], iniX = cd[1], iniY = cd[2], cw = cd[3], ch = cd[4], xoff = cd[5], yoff = cd[6];
   const int slot_off = cd[7], cap_cell = cd[8];
-  // score rows start at 0: the 3-px margin around the interior is read by the NMS and never written (all rows
-  // of the buffer, not just the cell's: the loop then does not wait for the table entry)
-  for (int i = lane; i < tile_rows * (TP / 8); i += 64) {
-    const int r = i / (TP / 8), k = i - r * (TP / 8);
-    *(__attribute__((address_space(3))) unsigned long long *)(tile_raw + r * RP + TP + 8 * k) = 0ull;
-  }
   int *out_count = cell_count + (long long)f * cells_per_frame + cell;
   const int iw = cw - 6, ih = ch - 6;
   if (iw <= 0 || ih <= 0) {  // :801, :811 (cw = 0 in the table), or no interior pixel
@@ -355,37 +376,45 @@ __global__ __launch_bounds__(256) void k_fast_wave(OrbDev P, FrameSrc src, uint3
     pitch = cd[9];
     img = src.pyr + (long long)f * src.pyr_frame_stride + (((long long)cd[11] << 32) | (unsigned)cd[10]);
   }
-  // ---- stage the cell (incl. the 6-px overlap) in LDS.  The tile keeps the source's dword alignment: LDS
-  // column 0 is image column iniX - (iniX & 3), so a row is a run of aligned dwords copied verbatim.  A lane
-  // owns one dword column of a group of RG rows; group after group is fetched with the row base in scalar
-  // registers (no per-load address arithmetic), all loads of a batch in flight before the first LDS store.
-  // The last group is shifted up to end at the tile's last row (overlapping rows carry identical data), so
-  // there is no row predicate at all.
+  // ---- stage the cell (incl. the 6-px overlap).  The tile keeps the source's dword alignment: LDS column 0 is
+  // image column iniX - (iniX & 3).
   const bool bytewise = BYTEWISE && l == 0;
   const int ox = bytewise ? 0 : (iniX & 3);
   lds_u8 *tile = tile_raw + ox;
   const uint8_t *g0 = img + (long long)iniY * pitch + (iniX - ox);
-  if (!bytewise) {
+  if (!bytewise && TP == 48) {
+    // LDS-DMA: lane + 64 k <-> 16-byte chunk (row = idx / 3, chunk = idx % 3), LDS address 16 idx.  A row's 48
+    // bytes may reach past the cell (into the next cell's pixels or the row padding; the plane has at least 13
+    // more rows behind the last tile row, so never past the allocation).
+    gmem_u8 *gb = (gmem_u8 *)g0;
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+      const int idx = lane + 64 * k;
+      const unsigned row = (unsigned)idx / 3u, chunk = (unsigned)idx - 3u * row;
+      if (64 * k < 3 * ch && idx < 3 * ch)
+        __builtin_amdgcn_global_load_lds(gb + (row * (unsigned)pitch + 16u * chunk), tile_raw + 1024 * k, 16, 0, 0);
+    }
+  } else if (!bytewise) {
     constexpr int LW = TP <= 64 ? 16 : 32, RG = 64 / LW, NB = 6;  // dword columns, rows per group, groups per batch
-    const int npr = (ox + cw + 3) >> 2;                            // dwords per tile row (<= TP / 4 <= LW)
+    const int npr = (ox + cw + 3) >> 2;
     const int d = lane & (LW - 1), r = lane / LW;
     if (d < npr) {
       const unsigned goff = (unsigned)(r * pitch + 4 * d);
-      lds_u8 *lt = tile_raw + r * RP + 4 * d;
+      lds_u8 *lt = tile_raw + r * TP + 4 * d;
       const int ng = (ch + RG - 1) / RG, last0 = max(ch - RG, 0);
       for (int gb = 0; gb < ng; gb += NB) {
         uint32_t v[NB];
         int row0[NB];
 #pragma unroll
         for (int q = 0; q < NB; q++) {
-          row0[q] = min(min(gb + q, ng - 1) * RG, last0);  // scalar; groups past the end repeat the last one
+          row0[q] = min(min(gb + q, ng - 1) * RG, last0);
           long long ro = (long long)row0[q] * pitch;
-          asm("" : "+s"(ro));  // keep the row base in scalar registers: the load is saddr + lane offset
+          asm("" : "+s"(ro));
           v[q] = *reinterpret_cast<const uint32_t *>(g0 + ro + goff);
         }
 #pragma unroll
         for (int q = 0; q < NB; q++) {
-          int lo = row0[q] * RP;
+          int lo = row0[q] * TP;
           asm("" : "+s"(lo));
           *(__attribute__((address_space(3))) uint32_t *)(lt + lo) = v[q];
         }
@@ -393,7 +422,7 @@ __global__ __launch_bounds__(256) void k_fast_wave(OrbDev P, FrameSrc src, uint3
     }
   } else {
     constexpr int NB = 8;
-    for (int col = lane; col < cw; col += 64) {  // one tile row per load
+    for (int col = lane; col < cw; col += 64) {
       for (int rb = 0; rb < ch; rb += NB) {
         uint8_t v[NB];
         int row[NB];
@@ -403,172 +432,141 @@ __global__ __launch_bounds__(256) void k_fast_wave(OrbDev P, FrameSrc src, uint3
           v[q] = g0[(long long)row[q] * pitch + col];
         }
 #pragma unroll
-        for (int q = 0; q < NB; q++) tile_raw[row[q] * RP + col] = v[q];
+        for (int q = 0; q < NB; q++) tile_raw[row[q] * TP + col] = v[q];
       }
     }
   }
+  // the score tile starts at zero (under the loads' latency): only survivors ever get an entry
+  for (int i = lane; i < tile_bytes / 16; i += 64)
+    *(__attribute__((address_space(3))) u32x4_t *)(tile_raw + tile_bytes + 16 * i) = u32x4_t{0u, 0u, 0u, 0u};
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   wave_sync();
-  // ---- phase 1.  A 9-arc always contains two neighbouring compass pixels (ring 0,4,8,12), so the arc score
-  // S is bounded by the compass margin m = max(mb - v, v - md), mb = max over the four neighbouring pairs of
-  // min(pair) = min(max(p0,p8), max(p4,p12)), md = min over the pairs of max(pair) = max(min(p0,p8),
-  // min(p4,p12)): a pixel can only be a corner at threshold t if m > t.  Every interior pixel leaves
-  // max(m - 1, 0) in the score tile (an upper bound of its score S - 1, replaced by the score once computed),
-  // and the pixels with m > iniThFAST are compacted IN RASTER ORDER into the wave's LDS list: cells that yield
-  // a key-point at iniThFAST (almost all) never score the 4x larger minThFAST survivor set.
-  // Lane mapping: 32 columns x 2 rows per step (64 x 1 for cells wider than 32), so that a lane's LDS
-  // address advances by a wave-uniform constant and the only per-step predicate is the row count.  The
-  // list holds the LDS address of the pixel's (-3, -3) neighbour: every later access is that register plus
-  // an immediate.
+  // ---- margin walk.  A 9-arc always contains two neighbouring compass pixels (ring 0, 4, 8, 12), so the arc
+  // score S is bounded by the compass margin m = max(mb - v, v - md), mb = min(max(p0,p8), max(p4,p12)),
+  // md = max(min(p0,p8), min(p4,p12)): a pixel can only be a corner at threshold t if m > t.  Pixels with m > th
+  // are compacted IN RASTER ORDER into the wave's LDS list as the LDS address of their (-3, -3) neighbour.
+  // Lane mapping: 32 columns x 2 rows per step (64 x 1 for cells wider than 32).
   const int lw = iw <= 32 ? 5 : 6;  // uniform
   const int lx = lane & ((1 << lw) - 1), ly = lane >> lw, ri = 64 >> lw;
-  lds_u8 *const b0 = tile + ly * RP + lx;
-  // Walk the interior: lanes beyond the cell's width sit out the whole walk, full steps need no predicate,
-  // and an odd last row (two-row steps) is a separate step for the lanes of the first row.  `body` returns
-  // the lane's hit; hits are appended in lane order = raster order.
-  int np = 0;
-  // `load` fetches a step's tile bytes, `eval` turns them into the lane's hit (and may store): two steps are
-  // loaded before either is evaluated, which halves the LDS round trips a wave waits for.
-  auto walk = [&](auto load, auto eval) {
+  lds_u8 *const b0 = tile + ly * TP + lx;
+  struct Ring5 { unsigned v, p0, p4, p8, p12; };
+  auto load5 = [&](const lds_u8 *b) { return Ring5{b[3 * TP + 3], b[6 * TP + 3], b[3 * TP + 6], b[3], b[3 * TP]}; };
+  // lanes with m > th as a wave mask: nine 16-bit VOP2 instructions and the compare, in one block (no register
+  // moves, no hazard padding between the dependent instructions: none of them writes a partial register)
+  auto margin_gt = [&](const Ring5 &r, unsigned thv) {
+    unsigned long long mask;
+    unsigned t0, t1, t2, t3;
+    asm("v_max_u16 %1, %6, %8\n\t"
+        "v_max_u16 %2, %7, %9\n\t"
+        "v_min_u16 %3, %6, %8\n\t"
+        "v_min_u16 %4, %7, %9\n\t"
+        "v_min_u16 %1, %1, %2\n\t"
+        "v_max_u16 %3, %3, %4\n\t"
+        "v_sub_u16 %1, %1, %5\n\t"
+        "v_sub_u16 %3, %5, %3\n\t"
+        "v_max_i16 %1, %1, %3\n\t"
+        "v_cmp_gt_i16 %0, %1, %10"
+        : "=s"(mask), "=&v"(t0), "=&v"(t1), "=&v"(t2), "=&v"(t3)
+        : "v"(r.v), "v"(r.p0), "v"(r.p4), "v"(r.p8), "v"(r.p12), "v"(thv));
+    return mask;
+  };
+  // rows [r0, r1) of the interior; returns the number of survivors (uniform); entries past the list's capacity
+  // pile up on its last 64 slots and the count tells the caller to take the chunked path
+  auto walk = [&](int th, int r0, int r1) {
     int n = 0;
+    const unsigned thv = (unsigned)th;
     if (lx < iw) {
-      lds_u8 *b = b0;
-      asm("" : "+v"(b));  // one address register, advanced by a scalar: the accesses below are register + immediate
-      int row = 0;
-      auto append = [&](bool hit, lds_u8 *bb) {
-        const unsigned long long mask = __builtin_amdgcn_ballot_w64(hit);
-        // the list holds list_cap entries (half the cell's pixels: the LDS saved is one more resident workgroup
-        // per CU); entries past it pile up on the last slot and the count tells the caller to take the chunked path
-        if (hit) plist[min(n + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0u)), list_cap - 1)] =
-            (unsigned short)(unsigned)(uintptr_t)bb;
+      lds_u8 *b = b0 + r0 * TP;
+      asm("" : "+v"(b));
+      int row = r0;
+      auto append = [&](unsigned long long mask, lds_u8 *bb) {
+        const int base = min(n, list_cap - 64);  // scalar
+        const int pos = (int)__builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mask, (unsigned)base));
+        if (__builtin_amdgcn_inverse_ballot_w64(mask)) plist[pos] = (unsigned short)(unsigned)(uintptr_t)bb;
         n += __popcll(mask);
       };
-      for (; row + 2 * ri <= ih; row += 2 * ri, b += 2 * ri * RP) {
-        lds_u8 *b1 = b + ri * RP;
-        const auto va = load(b), vb = load(b1);
-        append(eval(b, va), b);
-        append(eval(b1, vb), b1);
+      for (; row + 2 * ri <= r1; row += 2 * ri, b += 2 * ri * TP) {
+        lds_u8 *b1 = b + ri * TP;
+        const Ring5 va = load5(b), vb = load5(b1);
+        const unsigned long long ma = margin_gt(va, thv), mb = margin_gt(vb, thv);
+        append(ma, b);
+        append(mb, b1);
       }
-      if (row + ri <= ih) {
-        append(eval(b, load(b)), b);
-        row += ri, b += ri * RP;
+      if (row + ri <= r1) {
+        append(margin_gt(load5(b), thv), b);
+        row += ri, b += ri * TP;
       }
-      if (row < ih && ly == 0) append(eval(b, load(b)), b);
+      if (row < r1) {  // odd last row of a two-row step: the lanes of the first row only
+        const unsigned long long m = margin_gt(load5(b), thv);
+        append(ly == 0 ? m & 0xffffffffull : 0ull, b);
+      }
     }
     return __builtin_amdgcn_readlane(n, 0);  // lane 0 always takes part
   };
-  struct Ring5 { int v, p0, p4, p8, p12; };
-  np = walk([&](lds_u8 *b) { return Ring5{b[3 * RP + 3], b[6 * RP + 3], b[3 * RP + 6], b[3], b[3 * RP]}; },
-            [&](lds_u8 *b, const Ring5 &r) {
-              const int mb = min(max(r.p0, r.p8), max(r.p4, r.p12));
-              const int md = max(min(r.p0, r.p8), min(r.p4, r.p12));
-              const int m1 = max(max(mb + ~r.v, r.v + ~md), 0);  // max(m - 1, 0)
-              b[3 * RP + 3 + TP] = (uint8_t)m1;
-              return m1 >= P.ini_th;
-            });
   uint32_t *slot = cell_slots + (long long)f * slots_frame_stride + slot_off;
-  // Rare path for cells with more survivors than the list holds (noise-like texture).  Every interior pixel
-  // already has its tile entry (margin bound or score), so the survivors at threshold `th` are the entries
-  // >= th: they are scored chunk by chunk (a chunk = as many rows as fit the list even if every pixel hits),
-  // then -- all scores final -- suppressed chunk by chunk; chunks follow each other in raster order.
-  auto chunked_round = [&](int th) {
-    const int chunk_rows = max(list_cap / 64, 1) * ri;
-    auto collect = [&](int r0, int r1) {
-      int n = 0;
-      for (int r = r0; r < r1; r += ri) {
-        lds_u8 *b = b0 + r * RP;
-        const bool hit = lx < iw && r + ly < r1 && (int)b[3 * RP + 3 + TP] >= th;
-        const unsigned long long mask = __builtin_amdgcn_ballot_w64(hit);
-        if (hit) plist[n + __builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0u))] =
-            (unsigned short)(unsigned)(uintptr_t)b;
-        n += __popcll(mask);
-      }
-      wave_sync();
-      return n;
-    };
-    for (int r0 = 0; r0 < ih; r0 += chunk_rows) {
-      const int n = collect(r0, min(r0 + chunk_rows, ih));
-      for (int i = lane; i < n; i += 64) {
-        lds_u8 *b = (lds_u8 *)(uintptr_t)(unsigned)plist[i];
-        b[3 * RP + 3 + TP] = (uint8_t)fast_arc_score<RP>(b, P.min_th);
-      }
-      wave_sync();
+  auto score_list = [&](int n) {
+    for (int i = lane; i < n; i += 64) {
+      lds_u8 *b = (lds_u8 *)(uintptr_t)(unsigned)plist[i];
+      b[tile_bytes + 3 * TP + 3] = (uint8_t)fast_arc_score<TP>(b, P.min_th);  // cornerScore, defined from minThFAST up
     }
-    int kept = 0;
-    for (int r0 = 0; r0 < ih; r0 += chunk_rows) {
-      const int n = collect(r0, min(r0 + chunk_rows, ih));
-      for (int base = 0; base < n; base += 64) {
-        const int i = base + lane;
-        bool keep = false;
-        int pos = 0, sc0 = 0;
-        if (i < n) {
-          const lds_u8 *b = (const lds_u8 *)(uintptr_t)(unsigned)plist[i];
-          pos = (int)(b - tile);
-          const lds_u8 *c = b + 2 * RP + 2 + TP;
-          sc0 = c[RP + 1];
-          const int nb = max(max(max((int)c[0], (int)c[1]), max((int)c[2], (int)c[RP])),
-                             max(max((int)c[RP + 2], (int)c[2 * RP]), max((int)c[2 * RP + 1], (int)c[2 * RP + 2])));
-          keep = sc0 >= th && sc0 > nb;
-        }
-        const unsigned long long mask = __builtin_amdgcn_ballot_w64(keep);
-        const int off = kept + __builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0u));
-        if (keep && off < cap_cell) {
-          const int y = pos / RP, x = pos - y * RP;
-          slot[off] = (uint32_t)(x + 3 + xoff) | ((uint32_t)(y + 3 + yoff) << 12) | ((uint32_t)sc0 << 24);
-        }
-        kept += __popcll(mask);
+  };
+  // 3x3 non-maximum suppression at threshold th over the raster-ordered list; kept pixels go out in the same
+  // order behind the `kept` already written.  Entries that are not survivors are 0, as OpenCV reads them.
+  auto nms_list = [&](int n, int th, int kept) {
+    for (int base = 0; base < n; base += 64) {
+      const int i = base + lane;
+      bool keep = false;
+      int pos = 0, sc0 = 0;
+      if (i < n) {
+        const lds_u8 *b = (const lds_u8 *)(uintptr_t)(unsigned)plist[i];
+        pos = (int)(b - tile);
+        const lds_u8 *c = b + tile_bytes + 2 * TP + 2;  // score entry (-1, -1) from the pixel
+        sc0 = c[TP + 1];
+        const unsigned nb = max_u16(max_u16(max_u16(c[0], c[1]), max_u16(c[2], c[TP])),
+                                    max_u16(max_u16(c[TP + 2], c[2 * TP]), max_u16(c[2 * TP + 1], c[2 * TP + 2])));
+        keep = sc0 >= th && sc0 > (int)nb;
       }
-      wave_sync();
+      const unsigned long long mask = __builtin_amdgcn_ballot_w64(keep);
+      const int off = kept + __builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0u));
+      if (keep && off < cap_cell) {
+        const int y = pos / TP, x = pos - y * TP;  // interior coordinates; the cell-local ones are +3
+        slot[off] = (uint32_t)(x + 3 + xoff) | ((uint32_t)(y + 3 + yoff) << 12) | ((uint32_t)sc0 << 24);
+      }
+      kept += __popcll(mask);
     }
     return kept;
   };
   int running = 0;
   for (int round = 0; round < 2; round++) {
+    // a cell with no key-point at iniThFAST is redone at minThFAST (:820-824)
     const int th = round == 0 ? P.ini_th : P.min_th;
-    if (round == 1) {
-      // A cell with no key-point at iniThFAST is redone at minThFAST (:820-824): the survivors are the
-      // pixels whose tile entry (margin bound, or score where already computed) reaches minThFAST.
-      np = walk([&](lds_u8 *b) { return (int)b[3 * RP + 3 + TP]; }, [&](lds_u8 *, int e) { return e >= th; });
-    }
-    if (np > list_cap) {  // uniform, rare
+    const int np = walk(th, 0, ih);
+    wave_sync();
+    if (np <= list_cap - 64) {  // uniform, the usual case (the walk's appends clamp their base 64 entries before the end)
+      score_list(np);
       wave_sync();
-      running = chunked_round(th);
-      if (running > 0) break;
-      continue;
-    }
-    wave_sync();
-    // ---- phase 2: full arc score only for the survivors
-    for (int i = lane; i < np; i += 64) {
-      lds_u8 *b = (lds_u8 *)(uintptr_t)(unsigned)plist[i];
-      b[3 * RP + 3 + TP] = (uint8_t)fast_arc_score<RP>(b, P.min_th);
-    }
-    wave_sync();
-    // ---- phase 3: 3x3 non-maximum suppression at the threshold over the (raster-ordered) survivors; kept
-    // pixels are written in the same order.  A survivor's score only has to exceed the raw neighbouring tile
-    // entries: an entry below the threshold (a score, or the margin bound of a pixel that cannot be a corner
-    // at it; OpenCV reads those as 0) is below the survivor's score anyway.
-    running = 0;
-    for (int base = 0; base < np; base += 64) {
-      const int i = base + lane;
-      bool keep = false;
-      int pos = 0, sc0 = 0;
-      if (i < np) {
-        const lds_u8 *b = (const lds_u8 *)(uintptr_t)(unsigned)plist[i];
-        pos = (int)(b - tile);  // (row * RP + column) of the (-3, -3) neighbour = of the pixel, minus the margin
-        const lds_u8 *c = b + 2 * RP + 2 + TP;  // score entry (-1, -1) from the pixel
-        sc0 = c[RP + 1];
-        const int nb = max(max(max((int)c[0], (int)c[1]), max((int)c[2], (int)c[RP])),
-                           max(max((int)c[RP + 2], (int)c[2 * RP]), max((int)c[2 * RP + 1], (int)c[2 * RP + 2])));
-        keep = sc0 >= th && sc0 > nb;
+      running = nms_list(np, th, 0);
+    } else {
+      // Rare: more survivors than the list holds (noise-like texture).  Chunks of as many rows as fit the list
+      // even if every pixel hits are scored one after the other, then -- all scores final -- suppressed one after
+      // the other; chunks follow each other in raster order.
+      const int chunk_rows = max((list_cap - 64) / 64, 1) * ri;
+      for (int r0 = 0; r0 < ih; r0 += chunk_rows) {
+        const int n = walk(th, r0, min(r0 + chunk_rows, ih));
+        wave_sync();
+        score_list(n);
+        wave_sync();
       }
-      const unsigned long long mask = __builtin_amdgcn_ballot_w64(keep);
-      const int off = running + __builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0u));
-      if (keep && off < cap_cell) {
-        const int y = pos / RP, x = pos - y * RP;  // interior coordinates; the cell-local ones are +3
-        slot[off] = (uint32_t)(x + 3 + xoff) | ((uint32_t)(y + 3 + yoff) << 12) | ((uint32_t)sc0 << 24);
+      running = 0;
+      for (int r0 = 0; r0 < ih; r0 += chunk_rows) {
+        const int n = walk(th, r0, min(r0 + chunk_rows, ih));
+        wave_sync();
+        running = nms_list(n, th, running);
+        wave_sync();
       }
-      running += __popcll(mask);
     }
     if (running > 0) break;  // :820 `if(vKeysCell.empty())` retry with minThFAST
+    wave_sync();
   }
   if (lane == 0) *out_count = min(running, cap_cell);
 }
@@ -1247,7 +1245,6 @@ struct DescRec {
 // LDS values every lane reads from the same address, moved to scalar registers
 __device__ __forceinline__ int uni_i32(int v) { return __builtin_amdgcn_readfirstlane(v); }
 __device__ __forceinline__ float uni_f32(float v) { return __uint_as_float((unsigned)__builtin_amdgcn_readfirstlane((int)__float_as_uint(v))); }
-typedef const __attribute__((address_space(1))) uint8_t gmem_u8;  // global memory: loads are scalar base + lane offset
 __device__ __forceinline__ gmem_u8 *uni_ptr(unsigned long long v) {
   const unsigned lo = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)v);
   const unsigned hi = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(v >> 32));
@@ -1538,7 +1535,7 @@ struct vo_orb {
   OrbDev dev;
   long long pyr_frame = 0, blur_frame = 0, slots_frame = 0;
   int cells_frame = 0, keys_frame = 0, sel_frame = 0, tiles_frame = 0, max_kp = 0;
-  int fast_tp = 48, fast_rows = 0, fast_interior = 0;  // k_fast_wave: LDS pitch, tile rows, list capacity
+  int fast_tp = 48, fast_rows = 0, fast_interior = 0;  // k_fast_cell: LDS pitch, tile rows, list capacity
   int cell_tab_off = 0, strip_tab_off = 0;             // per-cell / per-strip geometry tables (ints into `tables`)
   size_t fast_lds = 0;
   bool oct_small = false;
@@ -1728,7 +1725,7 @@ int configure(vo_orb *h, int w, int h_img, int n_frames) {
     h->slots_frame = slots;
     h->cells_frame = cells;
     {
-      // k_fast_wave's per-cell geometry (16 ints per cell): level, cell origin and size incl. the 6-px overlap
+      // k_fast_cell's per-cell geometry (16 ints per cell): level, cell origin and size incl. the 6-px overlap
       // (size 0: the cell is skipped, :801 / :811), key offset of the cell, slot block, plane pitch / offset
       while (tables.size() % 16) tables.push_back(0);
       // k_blur_groups: 16 ints per job of 16 groups x 32 rows; levels too small for it go to the generic kernel
@@ -1780,11 +1777,11 @@ int configure(vo_orb *h, int w, int h_img, int n_frames) {
       h->oct_small = mcap <= 256 - 4;
       h->fast_tp = mw + 9 <= 48 ? 48 : kTileP;
       h->fast_rows = mh + 6;
-      h->fast_interior = std::max(128, (mw * mh + 1) / 2);  // survivor-list entries: half the cell's pixels (see k_fast_wave)
-      h->fast_lds = 4 * (size_t)fast_wave_lds(h->fast_tp, h->fast_rows, h->fast_interior);
+      h->fast_interior = std::max(128, (mw * mh + 1) / 2);  // survivor-list entries: half the cell's pixels (see k_fast_cell)
+      h->fast_lds = 4 * (size_t)fast_cell_lds(h->fast_tp, h->fast_rows, h->fast_interior);
       if (h->fast_lds > 64 * 1024) {
-        for (const void *fn : {(const void *)k_fast_wave<48, false>, (const void *)k_fast_wave<48, true>,
-                               (const void *)k_fast_wave<kTileP, false>, (const void *)k_fast_wave<kTileP, true>})
+        for (const void *fn : {(const void *)k_fast_cell<48, false>, (const void *)k_fast_cell<48, true>,
+                               (const void *)k_fast_cell<kTileP, false>, (const void *)k_fast_cell<kTileP, true>})
           VO_HIP_CHECK(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->fast_lds));
       }
     }
@@ -1900,8 +1897,8 @@ int run_pipeline(vo_orb *h, const uint8_t *dev_images, int n_frames, int w, int 
   }
   if (h->cells_frame > 0) {
     const dim3 grid((h->cells_frame + 3) / 4, n_frames);
-    auto fast = h->fast_tp == 48 ? (lv0_unaligned ? k_fast_wave<48, true> : k_fast_wave<48, false>)
-                                 : (lv0_unaligned ? k_fast_wave<kTileP, true> : k_fast_wave<kTileP, false>);
+    auto fast = h->fast_tp == 48 ? (lv0_unaligned ? k_fast_cell<48, true> : k_fast_cell<48, false>)
+                                 : (lv0_unaligned ? k_fast_cell<kTileP, true> : k_fast_cell<kTileP, false>);
     hipLaunchKernelGGL(fast, grid, dim3(256), h->fast_lds, st, D, S, h->slots.as<uint32_t>(), h->slots_frame,
                        h->cellcnt.as<int>(), h->cells_frame, h->fast_rows, h->fast_interior,
                        h->tables.as<int>() + h->cell_tab_off);
