@@ -167,123 +167,238 @@ struct PoseLm {
 // index into a table of the frame's distinct values (one per pyramid level), and the outlier flag.  38 bytes per
 // observation, for the first 768 observations of each of the four frames that share a CU.  A frame whose observations are not
 // float-representable, or with more than 16 distinct 1/sigma, is read from memory as before (nc = 0).
-struct ObsView {
-  const double *pts, *obs, *isg;
-  uint8_t *outlier;  // global flags: the result, and the skip mask of what is not cached
+#define VO_GLOBAL __attribute__((address_space(1)))
+#define VO_LDS __attribute__((address_space(3)))
+struct ObsView {  // explicit address spaces: as generic pointers in a struct every access becomes a flat load
+  const VO_GLOBAL double *pts, *obs, *isg;
+  VO_GLOBAL uint8_t *outlier;  // global flags: the result, and the skip mask of what is not cached
   int nc;
-  const double *lx, *ly, *lz, *tab;
-  const float *lu, *lv, *lr;
-  const uint8_t *li;
-  uint8_t *lsk;
-  __device__ __forceinline__ void get(int i, double (&p)[3], double &ou, double &ov, double &our, double &is) const {
-    if (i < nc) {  // wave-uniform: nc is a multiple of 64 or the whole frame
-      p[0] = lx[i], p[1] = ly[i], p[2] = lz[i];
-      ou = (double)lu[i], ov = (double)lv[i], our = (double)lr[i];
-      is = tab[li[i]];
-    } else {
-      p[0] = pts[3 * i], p[1] = pts[3 * i + 1], p[2] = pts[3 * i + 2];
-      ou = obs[3 * i], ov = obs[3 * i + 1], our = obs[3 * i + 2];
-      is = isg[i];
-    }
+  const VO_LDS double *lx, *ly, *lz, *tab;
+  const VO_LDS float *lu, *lv, *lr;
+  const VO_LDS uint8_t *li;
+  VO_LDS uint8_t *lsk;
+  __device__ __forceinline__ void get_cached(int i, double (&p)[3], double &ou, double &ov, double &our, double &is) const {
+    p[0] = lx[i], p[1] = ly[i], p[2] = lz[i];
+    ou = (double)lu[i], ov = (double)lv[i], our = (double)lr[i];
+    is = tab[li[i]];
   }
-  __device__ __forceinline__ bool skip(int i) const { return i < nc ? lsk[i] != 0 : outlier[i] != 0; }
-  __device__ __forceinline__ void set_skip(int i, bool v) const {
-    if (i < nc) lsk[i] = v ? 1 : 0;
-    outlier[i] = v ? 1 : 0;
+  __device__ __forceinline__ void get_global(int i, double (&p)[3], double &ou, double &ov, double &our, double &is) const {
+    p[0] = pts[3 * i], p[1] = pts[3 * i + 1], p[2] = pts[3 * i + 2];
+    ou = obs[3 * i], ov = obs[3 * i + 1], our = obs[3 * i + 2];
+    is = isg[i];
   }
 };
 
-// one linearisation pass: H (upper 21), g (6), cost; unscaled, loss-corrected
-__device__ void pose_accumulate(const double x[6], int n, const ObsView &V, bool use_skip, const Cam &K, double hm, double hs,
-                                bool want_jac, double (&acc)[28]) {
+// One observation's contribution to H (upper 21), g (6) and the cost; unscaled, loss-corrected.
+__device__ __forceinline__ void pose_obs_term(const PoseCache &P, const double (&pw)[3], double ou, double ov, double our,
+                                              double is, const Cam &K, double hm, double hs, double (&acc)[28]) {
+  double r[3], J[18];
+  const int m = edge_eval<true, false>(P, pw, ou, ov, our, is, K, r, J, nullptr);
+  const double s = r[0] * r[0] + r[1] * r[1] + r[2] * r[2];
+  double rho0, rho1;
+  huber(m == 2 ? hm : hs, s, rho0, rho1);
+  acc[27] += 0.5 * rho0;
+  // J' = sqrt(rho1) J, r' = sqrt(rho1) r  =>  J'^T J' = rho1 J^T J, J'^T r' = rho1 J^T r.  The rows of edge_eval's pose
+  // Jacobian have fixed zeros -- u row [a0 0 a2 a3 a4 a5], v row [0 b1 b2 b3 b4 b5], uR row [c0 0 c2 c3 c4 c5] (all
+  // zero for a monocular observation) -- so the products that involve them are left out (60 multiply-adds and 15
+  // scalings per observation instead of 108).  acc: packed upper triangle row by row (00 01 02 03 04 05 11 12 ...),
+  // then the gradient, then the cost.  Every sum is one chain of multiply-adds onto its accumulator
+  // (acc += a b + c d + e f costs a multiply, two multiply-adds and an add).
+  double w0[6], w1[6], w2[6];
+#pragma unroll
+  for (int k = 0; k < 6; k++) w0[k] = rho1 * J[k], w1[k] = rho1 * J[6 + k], w2[k] = rho1 * J[12 + k];
+  acc[0] = __builtin_fma(w0[0], J[0], __builtin_fma(w2[0], J[12], acc[0]));  // (0,0); (0,1) is identically zero
+#pragma unroll
+  for (int b = 2; b < 6; b++) acc[b] = __builtin_fma(w0[0], J[b], __builtin_fma(w2[0], J[12 + b], acc[b]));  // (0,b)
+  acc[6] = __builtin_fma(w1[1], J[7], acc[6]);                                                               // (1,1)
+#pragma unroll
+  for (int b = 2; b < 6; b++) acc[5 + b] = __builtin_fma(w1[1], J[6 + b], acc[5 + b]);  // (1,b): index 6 + (b - 1)
+  {
+    int t = 11;  // (2,2)
+#pragma unroll
+    for (int a = 2; a < 6; a++)
+#pragma unroll
+      for (int b = a; b < 6; b++, t++)
+        acc[t] = __builtin_fma(w0[a], J[b], __builtin_fma(w1[a], J[6 + b], __builtin_fma(w2[a], J[12 + b], acc[t])));
+  }
+  acc[21] = __builtin_fma(w0[0], r[0], __builtin_fma(w2[0], r[2], acc[21]));
+  acc[22] = __builtin_fma(w1[1], r[1], acc[22]);
+#pragma unroll
+  for (int a = 2; a < 6; a++)
+    acc[21 + a] = __builtin_fma(w0[a], r[0], __builtin_fma(w1[a], r[1], __builtin_fma(w2[a], r[2], acc[21 + a])));
+}
+
+// One linearisation pass over the observations that are not flagged.  WAVE (one wavefront per frame): the cached
+// observations and the ones read from memory are two loops, each with one kind of address (a select between an LDS
+// and a global pointer inside one loop turns every load into a flat load that waits for both counters).
+template <bool WAVE>
+__device__ __forceinline__ void pose_accumulate(const PoseCache &P, int n, const ObsView &V, const Cam &K, double hm, double hs,
+                                                double (&acc)[28]) {
 #pragma unroll
   for (int i = 0; i < 28; i++) acc[i] = 0;
-  const PoseCache P = pose_cache(x);
-  // (Requesting the next observation of the lane before the current one is used was measured: the kernel sits at its
-  // 256-register limit, the extra live values spill, 0.52 -> 0.56 ms per 1024 frames.)
-  for (int i = threadIdx.x; i < n; i += blockDim.x) {
-    if (use_skip && V.skip(i)) continue;
-    double r[3], J[18], pw[3], ou, ov, our, is;
-    V.get(i, pw, ou, ov, our, is);
-    int m;
-    if (want_jac)
-      m = edge_eval<true, false>(P, pw, ou, ov, our, is, K, r, J, nullptr);
-    else
-      m = edge_eval<false, false>(P, pw, ou, ov, our, is, K, r, nullptr, nullptr);
-    const double s = r[0] * r[0] + r[1] * r[1] + r[2] * r[2];
-    double rho0, rho1;
-    huber(m == 2 ? hm : hs, s, rho0, rho1);
-    acc[27] += 0.5 * rho0;
-    if (!want_jac) continue;
-    // J' = sqrt(rho1) J, r' = sqrt(rho1) r  =>  J'^T J' = rho1 J^T J, J'^T r' = rho1 J^T r.  The rows of edge_eval's pose
-    // Jacobian have fixed zeros -- u row [a0 0 a2 a3 a4 a5], v row [0 b1 b2 b3 b4 b5], uR row [c0 0 c2 c3 c4 c5] (all
-    // zero for a monocular observation) -- so the products that involve them are left out (60 multiply-adds and 15
-    // scalings per observation instead of 108; this loop is a third of the kernel's instructions).  acc: packed upper
-    // triangle row by row (00 01 02 03 04 05 11 12 ...), then the gradient, then the cost.
-    double w0[6], w1[6], w2[6];
+  if (WAVE) {
+    // One wavefront per SIMD has nothing else to run while a load is in flight: the cached observations are read one
+    // trip ahead (LDS latency), the ones in memory four trips at a time with all their loads issued before the first
+    // use (at ~1000 observations and a 768-entry cache that is the whole tail in one batch, in flight under the cached
+    // part).
+    const int lane = threadIdx.x;
+    struct Ob { double pw[3], ou, ov, our, is; bool skip; };
+    auto ld_cached = [&](int i) {
+      Ob o;
+      V.get_cached(i, o.pw, o.ou, o.ov, o.our, o.is);
+      o.skip = V.lsk[i] != 0;
+      return o;
+    };
+    // the first four trips of the part in memory are requested before the cached part is walked
+    Ob o[4];
+    auto ld_tail = [&](int base) {
 #pragma unroll
-    for (int k = 0; k < 6; k++) w0[k] = rho1 * J[k], w1[k] = rho1 * J[6 + k], w2[k] = rho1 * J[12 + k];
-    acc[0] += w0[0] * J[0] + w2[0] * J[12];  // (0,0); (0,1) is identically zero
-#pragma unroll
-    for (int b = 2; b < 6; b++) acc[b] += w0[0] * J[b] + w2[0] * J[12 + b];  // (0,b)
-    acc[6] += w1[1] * J[7];                                                  // (1,1)
-#pragma unroll
-    for (int b = 2; b < 6; b++) acc[5 + b] += w1[1] * J[6 + b];              // (1,b): index 6 + (b - 1)
-    {
-      int t = 11;  // (2,2)
-#pragma unroll
-      for (int a = 2; a < 6; a++)
-#pragma unroll
-        for (int b = a; b < 6; b++) acc[t++] += w0[a] * J[b] + w1[a] * J[6 + b] + w2[a] * J[12 + b];
+      for (int k = 0; k < 4; k++) {
+        const int i = min(base + 64 * k + lane, n - 1);
+        V.get_global(i, o[k].pw, o[k].ou, o[k].ov, o[k].our, o[k].is);
+        o[k].skip = V.outlier[i] != 0;
+      }
+    };
+    if (V.nc < n) ld_tail(V.nc);
+    if (lane < V.nc) {
+      Ob cur = ld_cached(lane);
+#pragma unroll 1
+      for (int i = lane; i < V.nc; i += 64) {
+        const int in = min(i + 64, V.nc - 1);  // past the end: a harmless re-read
+        const Ob nxt = ld_cached(in);
+        if (!cur.skip) pose_obs_term(P, cur.pw, cur.ou, cur.ov, cur.our, cur.is, K, hm, hs, acc);
+        cur = nxt;
+      }
     }
-    acc[21] += w0[0] * r[0] + w2[0] * r[2];
-    acc[22] += w1[1] * r[1];
+#pragma unroll 1
+    for (int base = V.nc; base < n; base += 4 * 64) {
+      if (base != V.nc) ld_tail(base);
 #pragma unroll
-    for (int a = 2; a < 6; a++) acc[21 + a] += w0[a] * r[0] + w1[a] * r[1] + w2[a] * r[2];
+      for (int k = 0; k < 4; k++)
+        if (base + 64 * k + lane < n && !o[k].skip) pose_obs_term(P, o[k].pw, o[k].ou, o[k].ov, o[k].our, o[k].is, K, hm, hs, acc);
+    }
+    return;
+  }
+#pragma unroll 1
+  for (int i = threadIdx.x; i < n; i += (int)blockDim.x) {
+    if (V.outlier[i]) continue;
+    double pw[3], ou, ov, our, is;
+    V.get_global(i, pw, ou, ov, our, is);
+    pose_obs_term(P, pw, ou, ov, our, is, K, hm, hs, acc);
   }
 }
 
-__device__ bool chol6_solve(double A[6][6], double b[6]) {
+// 6 x 6 SPD solve on the packed lower triangle (row by row: 00 10 11 20 21 22 ...), in place; b := A^-1 b.  Fully
+// unrolled (every index a compile-time constant: the 21 + 6 + 6 values stay in registers); no divide and no square
+// root: per column one Newton-refined v_rsq_f64 (an ulp or two from 1 / sqrt(d), like the per-observation arithmetic),
+// the column and both substitutions multiply by it -- 6 reciprocal square roots instead of 6 IEEE square roots and 33 IEEE
+// divides (about 1000 of the 3600 instructions an LM iteration spent outside the observation loop).
+__device__ __forceinline__ constexpr int tri_l(int i, int j) { return i * (i + 1) / 2 + j; }            // j <= i
+__device__ __forceinline__ constexpr int tri_u(int a, int b) { return a * 6 - a * (a - 1) / 2 + (b - a); }  // a <= b
+__device__ __forceinline__ bool chol6_packed(double (&L)[21], double (&b)[6]) {
+  double ri[6];  // 1 / L[j][j]
+#pragma unroll
   for (int j = 0; j < 6; j++) {
-    double d = A[j][j];
-    for (int k = 0; k < j; k++) d -= A[j][k] * A[j][k];
+    double d = L[tri_l(j, j)];
+#pragma unroll
+    for (int k = 0; k < j; k++) d -= L[tri_l(j, k)] * L[tri_l(j, k)];
     if (!(d > 0.0)) return false;
-    d = sqrt(d);
-    A[j][j] = d;
+    ri[j] = rsqrt_fast(d);
+#pragma unroll
     for (int i = j + 1; i < 6; i++) {
-      double s = A[i][j];
-      for (int k = 0; k < j; k++) s -= A[i][k] * A[j][k];
-      A[i][j] = s / d;
+      double t = L[tri_l(i, j)];
+#pragma unroll
+      for (int k = 0; k < j; k++) t -= L[tri_l(i, k)] * L[tri_l(j, k)];
+      L[tri_l(i, j)] = t * ri[j];
     }
   }
+#pragma unroll
   for (int i = 0; i < 6; i++) {
-    double s = b[i];
-    for (int k = 0; k < i; k++) s -= A[i][k] * b[k];
-    b[i] = s / A[i][i];
+    double t = b[i];
+#pragma unroll
+    for (int k = 0; k < i; k++) t -= L[tri_l(i, k)] * b[k];
+    b[i] = t * ri[i];
   }
+#pragma unroll
   for (int i = 5; i >= 0; i--) {
-    double s = b[i];
-    for (int k = i + 1; k < 6; k++) s -= A[k][i] * b[k];
-    b[i] = s / A[i][i];
+    double t = b[i];
+#pragma unroll
+    for (int k = i + 1; k < 6; k++) t -= L[tri_l(k, i)] * b[k];
+    b[i] = t * ri[i];
   }
   return true;
 }
 
-// Ceres-style LM on one 6-dof pose; every thread keeps the (uniform) control state in registers.
-__device__ void pose_lm(double x[6], int n, const ObsView &V, const Cam &K, double hm, double hs, int max_it, double *lds,
-                        vo_lm_summary *sum) {
-  double acc[28];
-  pose_accumulate(x, n, V, true, K, hm, hs, true, acc);
-  block_sum<28>(acc, lds);
-  double scale[6];
-  {
-    int t = 0;
-    for (int a = 0; a < 6; a++) {
-      scale[a] = 1.0 / (1.0 + sqrt(acc[t]));
-      t += 6 - a;
+__device__ __forceinline__ void wave_lds_sync() {  // LDS hand-off between lanes of one wavefront
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+}
+
+// 64 lanes x 28 partial sums -> 28 totals at dst (LDS), in a fixed order.  Two passes of 14 values through a
+// [64][15] scratch: lane l stores its 14 values as row l, lane 4 v + q sums rows q, q + 4, ... of column v, the four
+// quarter sums meet by two quad permutes.  About 110 instructions for what 28 DPP / readlane wave sums did in 1000
+// (a third of the instructions the round-2 kernel executed per LM iteration).
+constexpr int kPoseRedScratch = 64 * 15;
+__device__ __forceinline__ void wave_reduce28(const double (&v)[28], double *scratch, double *dst) {
+  const int lane = threadIdx.x & 63, vi = lane >> 2, q = lane & 3;
+#pragma unroll
+  for (int c = 0; c < 2; c++) {
+#pragma unroll
+    for (int k = 0; k < 14; k++) scratch[lane * 15 + k] = v[14 * c + k];
+    wave_lds_sync();
+    double t = 0;
+    if (lane < 56) {
+#pragma unroll
+      for (int j = 0; j < 16; j++) t += scratch[(4 * j + q) * 15 + vi];
     }
+    t += dpp_f64<0xB1>(t);  // quad_perm [1,0,3,2]
+    t += dpp_f64<0x4E>(t);  // quad_perm [2,3,0,1]
+    if (lane < 56 && q == 0) dst[14 * c + vi] = t;
+    wave_lds_sync();
   }
-  double radius = 1e4, decrease = 2.0, x_cost = acc[27];
+}
+
+// LDS doubles of a pose-only workgroup behind the observation cache: the reduction scratch, the linearisation at x
+// and at the candidate
+template <bool WAVE>
+struct PoseLds {
+  static constexpr int kRed = WAVE ? kPoseRedScratch : 4 * 28;
+  double red[kRed];
+  double acc[28];   // linearisation at x: 21 + 6 + 1 sums, uniform over the workgroup
+  double cand[28];  // ... at the trial point
+};
+
+// Ceres-style LM on one 6-dof pose.  The linearisations -- 21 + 6 + 1 sums each -- live in LDS, not in registers: a
+// trial step accumulates the candidate's sums while the solve's temporaries are dead and vice versa (round 2 kept
+// two sets of 28 accumulators next to a 6 x 6 system in every lane: 256 VGPR + 251 AGPR).  Every thread carries the
+// (uniform) trust-region scalars in registers.
+template <bool WAVE>
+__device__ void pose_lm(double x[6], int n, const ObsView &V, const Cam &K, double hm, double hs, int max_it, PoseLds<WAVE> &S,
+                        vo_lm_summary *sum) {
+  // exp(x) is kept across the iterations (an accepted candidate's exp is the product se3_plus forms anyway) and the
+  // residuals are evaluated from it: rotation matrix from the unit quaternion, t = V * upsilon -- what
+  // se3TransPoint(x) computes through sin / cos of |omega|, up to rounding; no trigonometry per evaluation.
+  Se3 Tx = se3_exp<true>(x);
+  auto linearize = [&](const Se3 &T, double *dst) {  // sums of the linearisation at T -> dst (LDS)
+    double v[28];
+    pose_accumulate<WAVE>(pose_cache_se3(T), n, V, K, hm, hs, v);
+    if (WAVE) {
+      wave_reduce28(v, S.red, dst);
+    } else {
+      block_sum<28>(v, S.red);
+      __syncthreads();
+      if (threadIdx.x == 0) {
+#pragma unroll
+        for (int i = 0; i < 28; i++) dst[i] = v[i];
+      }
+      __syncthreads();
+    }
+  };
+  linearize(Tx, S.acc);
+  double scale[6];
+#pragma unroll
+  for (int a = 0; a < 6; a++) scale[a] = 1.0 / (1.0 + sqrt(S.acc[tri_u(a, a)]));
+  double radius = 1e4, decrease = 2.0, x_cost = S.acc[27];
   const double initial_cost = x_cost;
   double x_norm = sqrt(x[0] * x[0] + x[1] * x[1] + x[2] * x[2] + x[3] * x[3] + x[4] * x[4] + x[5] * x[5]);
   int iterations = 0, accepted = 0, termination = 0, invalid = 0;
@@ -295,7 +410,8 @@ __device__ void pose_lm(double x[6], int n, const ObsView &V, const Cam &K, doub
     }
     if (last_ok) {
       double gm = 0;
-      for (int a = 0; a < 6; a++) gm = fmax(gm, fabs(acc[21 + a]));
+#pragma unroll
+      for (int a = 0; a < 6; a++) gm = fmax(gm, fabs(S.acc[21 + a]));
       if (gm <= 1e-10) {
         termination = 3;
         break;
@@ -308,60 +424,60 @@ __device__ void pose_lm(double x[6], int n, const ObsView &V, const Cam &K, doub
     iterations = it;
     last_ok = false;
     // scaled normal equations  H'' = S H S, g'' = S g ; LM diagonal from clamp(diag H'')/radius
-    double A[6][6], g[6], D[6], Hs[6][6];
-    {
-      int t = 0;
-      for (int a = 0; a < 6; a++)
-        for (int b = a; b < 6; b++) {
-          const double v = acc[t++] * scale[a] * scale[b];
-          Hs[a][b] = Hs[b][a] = v;
-        }
-    }
+    double L[21], g[6], y[6];
+#pragma unroll
     for (int a = 0; a < 6; a++) {
-      g[a] = acc[21 + a] * scale[a];
-      D[a] = fmin(fmax(Hs[a][a], 1e-6), 1e32) / radius;
-      for (int b = 0; b < 6; b++) A[a][b] = Hs[a][b];
-      A[a][a] += D[a];
+#pragma unroll
+      for (int b2 = 0; b2 <= a; b2++) L[tri_l(a, b2)] = S.acc[tri_u(b2, a)] * scale[b2] * scale[a];
+      g[a] = S.acc[21 + a] * scale[a];
+      y[a] = g[a];
     }
-    double y[6];
-    for (int a = 0; a < 6; a++) y[a] = g[a];
-    bool ok = chol6_solve(A, y);
-    double step[6], delta[6], model = 0;
-    if (ok) {
-      double gs = 0, sHs = 0;
-      for (int a = 0; a < 6; a++) {
-        step[a] = -y[a];
-        if (!isfinite(step[a])) ok = false;
+    double model = 0, delta[6];
+    {
+      // step^T H'' step from the undamped matrix, before the factorisation overwrites it
+      double Hs[21];
+#pragma unroll
+      for (int i = 0; i < 21; i++) Hs[i] = L[i];
+#pragma unroll
+      for (int a = 0; a < 6; a++) L[tri_l(a, a)] += fmin(fmax(L[tri_l(a, a)], 1e-6), 1e32) / radius;
+      bool ok = chol6_packed(L, y);
+      if (ok) {
+        double gs = 0, sHs = 0;
+#pragma unroll
+        for (int a = 0; a < 6; a++)
+          if (!isfinite(y[a])) ok = false;
+#pragma unroll
+        for (int a = 0; a < 6; a++) {
+          gs -= g[a] * y[a];  // step = -y
+          double row = 0;
+#pragma unroll
+          for (int b2 = 0; b2 < 6; b2++) row += Hs[a >= b2 ? tri_l(a, b2) : tri_l(b2, a)] * y[b2];
+          sHs += y[a] * row;
+          delta[a] = -y[a] * scale[a];
+        }
+        model = -(gs + 0.5 * sHs);  // -m.(r + m/2) with m = J''step
       }
-      for (int a = 0; a < 6; a++) {
-        gs += g[a] * step[a];
-        double row = 0;
-        for (int b = 0; b < 6; b++) row += Hs[a][b] * step[b];
-        sHs += step[a] * row;
-        delta[a] = step[a] * scale[a];
+      if (!ok || !(model > 0.0)) {
+        if (++invalid >= 5) {
+          termination = 4;
+          break;
+        }
+        radius /= decrease;
+        decrease *= 2.0;
+        continue;
       }
-      model = -(gs + 0.5 * sHs);  // -m.(r + m/2) with m = J''step
-    }
-    if (!ok || !(model > 0.0)) {
-      if (++invalid >= 5) {
-        termination = 4;
-        break;
-      }
-      radius /= decrease;
-      decrease *= 2.0;
-      continue;
     }
     invalid = 0;
     double xc[6];
-    se3_plus(x, delta, xc);
+    Se3 Tc;
+    se3_plus_keep(Tx, delta, xc, Tc);
     // The candidate is linearised completely in the same pass (its cost is one of the 28 sums): an
     // accepted step -- the common case -- then needs no second sweep over the observations.
-    double cacc[28];
-    pose_accumulate(xc, n, V, true, K, hm, hs, true, cacc);
-    block_sum<28>(cacc, lds);
-    double cand = cacc[27];
+    linearize(Tc, S.cand);
+    double cand = S.cand[27];
     if (!isfinite(cand)) cand = 1.7976931348623157e308;
     double sn = 0;
+#pragma unroll
     for (int a = 0; a < 6; a++) sn += (x[a] - xc[a]) * (x[a] - xc[a]);
     if (sqrt(sn) <= 1e-8 * (x_norm + 1e-8)) {
       termination = 2;
@@ -374,11 +490,15 @@ __device__ void pose_lm(double x[6], int n, const ObsView &V, const Cam &K, doub
     }
     const double rel = change / model;
     if (rel > 1e-3) {
-      for (int a = 0; a < 6; a++) x[a] = xc[a];
-      x_norm = sqrt(x[0] * x[0] + x[1] * x[1] + x[2] * x[2] + x[3] * x[3] + x[4] * x[4] + x[5] * x[5]);
 #pragma unroll
-      for (int i = 0; i < 28; i++) acc[i] = cacc[i];
-      x_cost = acc[27];
+      for (int a = 0; a < 6; a++) x[a] = xc[a];
+      Tx = Tc;
+      x_norm = sqrt(x[0] * x[0] + x[1] * x[1] + x[2] * x[2] + x[3] * x[3] + x[4] * x[4] + x[5] * x[5]);
+      // the candidate's linearisation becomes the current one
+      if (WAVE) wave_lds_sync(); else __syncthreads();
+      if (threadIdx.x < 28) S.acc[threadIdx.x] = S.cand[threadIdx.x];
+      if (WAVE) wave_lds_sync(); else __syncthreads();
+      x_cost = cand;
       const double t2 = 2.0 * rel - 1.0;
       radius = fmin(radius / fmax(1.0 / 3.0, 1.0 - t2 * t2 * t2), 1e16);
       decrease = 2.0;
@@ -417,13 +537,15 @@ __device__ __forceinline__ bool pose_chi2_outlier(const double pc[3], double ou,
 }
 
 // ranges != 0: problem p owns observations [offsets[2p], offsets[2p] + offsets[2p+1]) (frames at a fixed stride,
-// vo_track_gather_dev); otherwise [offsets[p], offsets[p+1]).
-__global__ __launch_bounds__(256) void k_pose_only(const int *offsets, const double *pts, const double *obs,
-                                                   const double *isg, const double *cam5, double *poses,
-                                                   uint8_t *outlier, int *n_inliers, vo_lm_summary *sums, int ranges,
-                                                   int cache_cap) {
+// vo_track_gather_dev); otherwise [offsets[p], offsets[p+1]).  WAVE: one wavefront per problem (batches), with the
+// observation cache; otherwise 128 or 256 threads per problem (a few problems: the observations are shared out).
+template <bool WAVE>
+__global__ __launch_bounds__(WAVE ? 64 : 256) void k_pose_only(const int *offsets, const double *pts, const double *obs,
+                                                               const double *isg, const double *cam5, double *poses,
+                                                               uint8_t *outlier, int *n_inliers, vo_lm_summary *sums,
+                                                               int ranges, int cache_cap) {
   extern __shared__ __attribute__((aligned(16))) uint8_t pose_dyn[];  // the observation cache (cache_cap > 0)
-  __shared__ double lds[4 * 28];
+  __shared__ PoseLds<WAVE> S;
   __shared__ int s_cnt[4];
   const int p = blockIdx.x;
   if (threadIdx.x < 4) s_cnt[threadIdx.x] = 0;  // (workgroups of one wavefront leave three of the four slots unused)
@@ -437,8 +559,9 @@ __global__ __launch_bounds__(256) void k_pose_only(const int *offsets, const dou
     if (threadIdx.x == 0) n_inliers[p] = 0;
     return;
   }
-  ObsView V{pts, obs, isg, outlier, 0, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
-  if (cache_cap > 0) {  // one wavefront per frame (blockDim.x == 64): fill the cache, verify that it is lossless
+  ObsView V{(const VO_GLOBAL double *)pts, (const VO_GLOBAL double *)obs, (const VO_GLOBAL double *)isg, (VO_GLOBAL uint8_t *)outlier, 0,
+            nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+  if (WAVE && cache_cap > 0) {  // fill the cache, verify that it is lossless
     const int lane = threadIdx.x, nfill = min(n, cache_cap);
     double *lx = reinterpret_cast<double *>(pose_dyn), *ly = lx + cache_cap, *lz = ly + cache_cap, *tab = lz + cache_cap;
     float *lu = reinterpret_cast<float *>(tab + 16), *lv = lu + cache_cap, *lr = lv + cache_cap;
@@ -476,28 +599,47 @@ __global__ __launch_bounds__(256) void k_pose_only(const int *offsets, const dou
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_wave_barrier();
-    if (good) V = ObsView{pts, obs, isg, outlier, nfill, lx, ly, lz, tab, lu, lv, lr, li, lsk};
+    if (good)
+      V = ObsView{V.pts, V.obs, V.isg, V.outlier, nfill, (const VO_LDS double *)lx, (const VO_LDS double *)ly, (const VO_LDS double *)lz,
+                  (const VO_LDS double *)tab, (const VO_LDS float *)lu, (const VO_LDS float *)lv, (const VO_LDS float *)lr,
+                  (const VO_LDS uint8_t *)li, (VO_LDS uint8_t *)lsk};
   }
-  for (int i = threadIdx.x; i < n; i += blockDim.x) outlier[i] = 0;
+  const int stride = WAVE ? 64 : (int)blockDim.x;
+  for (int i = threadIdx.x; i < n; i += stride) outlier[i] = 0;
   __syncthreads();
   int inl = 0;
   for (int round = 0; round < 2; round++) {
     for (int a = 0; a < 6; a++) x[a] = x0[a];  // :215
     const double hm = round == 0 ? (double)sqrtf(5.991f) : 0.0;
     const double hs = round == 0 ? (double)sqrtf(7.815f) : 0.0;
-    pose_lm(x, n, V, K, hm, hs, 10, lds, sums ? &sums[2 * p + round] : nullptr);
+    pose_lm<WAVE>(x, n, V, K, hm, hs, 10, S, sums ? &sums[2 * p + round] : nullptr);
     __syncthreads();
     // classification with Tcw = exp(pose) (Sophus quaternion form, :256-257)
     const Se3 T = se3_exp(x);
     int local = 0;
-    for (int i = threadIdx.x; i < n; i += blockDim.x) {
-      double rp[3], pc[3], pw[3], ou, ov, our, is;
-      V.get(i, pw, ou, ov, our, is);
+    auto classify = [&](int i, const double (&pw)[3], double ou, double ov, double our, double is) {
+      double rp[3], pc[3];
       quat_rotate(T.q, pw, rp);
       pc[0] = rp[0] + T.t[0], pc[1] = rp[1] + T.t[1], pc[2] = rp[2] + T.t[2];
       const bool out = pose_chi2_outlier(pc, ou, ov, our, fx, fy, cx, cy, bf, is);
-      V.set_skip(i, out);
       local += out ? 0 : 1;
+      return out;
+    };
+    if (WAVE) {
+#pragma unroll 1
+      for (int i = threadIdx.x; i < V.nc; i += 64) {
+        double pw[3], ou, ov, our, is;
+        V.get_cached(i, pw, ou, ov, our, is);
+        const bool out = classify(i, pw, ou, ov, our, is);
+        V.lsk[i] = out ? 1 : 0;
+        outlier[i] = out ? 1 : 0;
+      }
+    }
+#pragma unroll 1
+    for (int i = (WAVE ? V.nc : 0) + threadIdx.x; i < n; i += stride) {
+      double pw[3], ou, ov, our, is;
+      V.get_global(i, pw, ou, ov, our, is);
+      outlier[i] = classify(i, pw, ou, ov, our, is) ? 1 : 0;
     }
     for (int o = 32; o >= 1; o >>= 1) local += __shfl_xor(local, o);
     __syncthreads();
@@ -3006,8 +3148,9 @@ int vo_pose_only_solve_dev(int n_problems, const int32_t *dev_offsets, int max_o
   if (n_problems == 0) return VO_OK;
   VO_CHECK(vo::ensure_device());
   const int bw = pose_block_width(n_problems), cc = pose_cache_cap(bw);
-  hipLaunchKernelGGL(k_pose_only, dim3(n_problems), dim3(bw), pose_cache_bytes(cc), (hipStream_t)hip_stream, dev_offsets, dev_points,
-                     dev_obs, dev_inv_sigma, dev_cam5, dev_poses, dev_outlier, dev_n_inliers, dev_summaries, 0, cc);
+  hipLaunchKernelGGL(bw == 64 ? k_pose_only<true> : k_pose_only<false>, dim3(n_problems), dim3(bw), pose_cache_bytes(cc),
+                     (hipStream_t)hip_stream, dev_offsets, dev_points, dev_obs, dev_inv_sigma, dev_cam5, dev_poses, dev_outlier,
+                     dev_n_inliers, dev_summaries, 0, cc);
   VO_HIP_CHECK(hipGetLastError());
   return VO_OK;
 }
@@ -3021,8 +3164,9 @@ int vo_pose_only_solve_ranges_dev(int n_problems, const int32_t *dev_ranges, con
   if (n_problems == 0) return VO_OK;
   VO_CHECK(vo::ensure_device());
   const int bw = pose_block_width(n_problems), cc = pose_cache_cap(bw);
-  hipLaunchKernelGGL(k_pose_only, dim3(n_problems), dim3(bw), pose_cache_bytes(cc), (hipStream_t)hip_stream, dev_ranges, dev_points,
-                     dev_obs, dev_inv_sigma, dev_cam5, dev_poses, dev_outlier, dev_n_inliers, dev_summaries, 1, cc);
+  hipLaunchKernelGGL(bw == 64 ? k_pose_only<true> : k_pose_only<false>, dim3(n_problems), dim3(bw), pose_cache_bytes(cc),
+                     (hipStream_t)hip_stream, dev_ranges, dev_points, dev_obs, dev_inv_sigma, dev_cam5, dev_poses, dev_outlier,
+                     dev_n_inliers, dev_summaries, 1, cc);
   VO_HIP_CHECK(hipGetLastError());
   return VO_OK;
 }

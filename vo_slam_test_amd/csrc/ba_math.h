@@ -54,23 +54,53 @@ VO_HD void quat_rotate(const double q[4], const double v[3], double o[3]) {
   o[2] = v[2] + q[0] * uv2 + (q[1] * uv1 - q[2] * uv0);
 }
 
-// Sophus SE3::exp: tangent [upsilon; omega]
+// sin and cos of a small argument without the range reduction of the library call: the fdlibm kernels (k_sin.c,
+// k_cos.c: minimax polynomials on [-pi/4, pi/4], < 1 ulp), ~25 multiply-adds instead of ~250 instructions.  The
+// arguments here are half rotation angles of LM steps and of camera poses; anything larger takes the library call.
+VO_HD void sincos_small(double x, double *s, double *c) {
+  if (fabs(x) > 0.78539816339744830962) {
+    sincos(x, s, c);
+    return;
+  }
+  const double z = x * x;
+  const double rs = 8.33333333332248946124e-03 +
+                    z * (-1.98412698298579493134e-04 +
+                         z * (2.75573137070700676789e-06 + z * (-2.50507602534068634195e-08 + z * 1.58969099521155010221e-10)));
+  *s = x + (z * x) * (-1.66666666666666324348e-01 + z * rs);
+  const double rc = z * (4.16666666666666019037e-02 +
+                         z * (-1.38888888888741095749e-03 +
+                              z * (2.48015872894767294178e-05 +
+                                   z * (-2.75573143513906633035e-07 + z * (2.08757232129817482790e-09 + z * -1.13596475577881948265e-11)))));
+  *c = 1.0 - (0.5 * z - z * rc);
+}
+
+// Sophus SE3::exp: tangent [upsilon; omega].  FAST (device, pose-only LM): polynomial sincos for small angles and
+// Newton-refined reciprocals instead of IEEE divides -- an ulp or two from the plain form.
+template <bool FAST = false>
 VO_HD Se3 se3_exp(const double xi[6]) {
   Se3 T;
   const double wx = xi[3], wy = xi[4], wz = xi[5];
   const double theta = sqrt(wx * wx + wy * wy + wz * wz);
   const double half = 0.5 * theta;
   double sh, ch;
-  sincos(half, &sh, &ch);  // one range reduction for both; sin/cos(theta) follow from the half angle
+  if (FAST)
+    sincos_small(half, &sh, &ch);
+  else
+    sincos(half, &sh, &ch);  // one range reduction for both; sin/cos(theta) follow from the half angle
   double imag;
   if (theta < kSmallEps) {
     const double t2 = theta * theta;
     imag = 0.5 - 0.0208333 * t2 + 0.000260417 * t2 * t2;
   } else {
-    imag = sh / theta;
+    imag = FAST ? sh * inv_fast(theta) : sh / theta;
   }
   T.q[0] = ch, T.q[1] = imag * wx, T.q[2] = imag * wy, T.q[3] = imag * wz;
-  quat_normalize(T.q);
+  if (FAST) {
+    const double rn = rsqrt_fast(T.q[0] * T.q[0] + T.q[1] * T.q[1] + T.q[2] * T.q[2] + T.q[3] * T.q[3]);
+    T.q[0] *= rn, T.q[1] *= rn, T.q[2] *= rn, T.q[3] *= rn;
+  } else {
+    quat_normalize(T.q);
+  }
   // V = I + a*Om + b*Om^2 ;  V*u = u + a (w x u) + b (w x (w x u))
   const double u[3] = {xi[0], xi[1], xi[2]};
   const double wxu[3] = {wy * u[2] - wz * u[1], wz * u[0] - wx * u[2], wx * u[1] - wy * u[0]};
@@ -79,7 +109,13 @@ VO_HD Se3 se3_exp(const double xi[6]) {
     quat_rotate(T.q, u, T.t);  // V = R in the small-angle branch
   } else {
     const double t2 = theta * theta;
-    const double a = (2.0 * sh * sh) / t2, b = (theta - 2.0 * sh * ch) / (t2 * theta);  // 1-cos = 2 sin^2(t/2)
+    double a, b;  // 1-cos = 2 sin^2(t/2)
+    if (FAST) {
+      const double it2 = inv_fast(t2);
+      a = (2.0 * sh * sh) * it2, b = (theta - 2.0 * sh * ch) * (it2 * inv_fast(theta));
+    } else {
+      a = (2.0 * sh * sh) / t2, b = (theta - 2.0 * sh * ch) / (t2 * theta);
+    }
     T.t[0] = u[0] + a * wxu[0] + b * wwxu[0];
     T.t[1] = u[1] + a * wxu[1] + b * wwxu[1];
     T.t[2] = u[2] + a * wxu[2] + b * wwxu[2];
@@ -126,6 +162,21 @@ VO_HD void se3_plus_exp(const Se3 &B, const double d[6], double out[6]) {
   se3_log(Cc, out);
 }
 VO_HD void se3_plus(const double x[6], const double d[6], double out[6]) { se3_plus_exp(se3_exp(x), d, out); }
+// The same with exp(delta) * B handed back as well (C) and the FAST forms: the pose-only LM keeps exp(x) across its
+// iterations -- the accepted candidate's C is the next B -- and evaluates residuals from C directly (pose_cache_se3).
+VO_HD void se3_plus_keep(const Se3 &B, const double d[6], double out[6], Se3 &C) {
+  const Se3 A = se3_exp<true>(d);
+  double rt[3];
+  quat_rotate(A.q, B.t, rt);
+  C.t[0] = A.t[0] + rt[0], C.t[1] = A.t[1] + rt[1], C.t[2] = A.t[2] + rt[2];
+  C.q[0] = A.q[0] * B.q[0] - A.q[1] * B.q[1] - A.q[2] * B.q[2] - A.q[3] * B.q[3];
+  C.q[1] = A.q[0] * B.q[1] + A.q[1] * B.q[0] + A.q[2] * B.q[3] - A.q[3] * B.q[2];
+  C.q[2] = A.q[0] * B.q[2] + A.q[2] * B.q[0] + A.q[3] * B.q[1] - A.q[1] * B.q[3];
+  C.q[3] = A.q[0] * B.q[3] + A.q[3] * B.q[0] + A.q[1] * B.q[2] - A.q[2] * B.q[1];
+  const double rn = rsqrt_fast(C.q[0] * C.q[0] + C.q[1] * C.q[1] + C.q[2] * C.q[2] + C.q[3] * C.q[3]);
+  C.q[0] *= rn, C.q[1] *= rn, C.q[2] *= rn, C.q[3] *= rn;
+  se3_log(C, out);
+}
 
 // Optimizer::se3TransPoint<double> (optimizer_ceres.h:29-95) plus the rotation matrix of
 // ceres::AngleAxisToRotationMatrix (same theta^2 > eps branch), R row-major here.
@@ -167,6 +218,19 @@ VO_HD PoseCache pose_cache(const double se3[6]) {
     P.t[1] = u1 + (a2 * u0 - a0 * u2);
     P.t[2] = u2 + (a0 * u1 - a1 * u0);
   }
+  return P;
+}
+
+// The same quantities from T = exp(se3) (unit quaternion, t = V * upsilon): no trigonometry.  Equal to
+// pose_cache(log(T)) up to rounding (a few 1e-16).
+VO_HD PoseCache pose_cache_se3(const Se3 &T) {
+  PoseCache P;
+  const double w = T.q[0], x = T.q[1], y = T.q[2], z = T.q[3];
+  const double xx = x * x, yy = y * y, zz = z * z, xy = x * y, xz = x * z, yz = y * z, wx = w * x, wy = w * y, wz = w * z;
+  P.R[0] = 1.0 - 2.0 * (yy + zz), P.R[1] = 2.0 * (xy - wz), P.R[2] = 2.0 * (xz + wy);
+  P.R[3] = 2.0 * (xy + wz), P.R[4] = 1.0 - 2.0 * (xx + zz), P.R[5] = 2.0 * (yz - wx);
+  P.R[6] = 2.0 * (xz - wy), P.R[7] = 2.0 * (yz + wx), P.R[8] = 1.0 - 2.0 * (xx + yy);
+  P.t[0] = T.t[0], P.t[1] = T.t[1], P.t[2] = T.t[2];
   return P;
 }
 
