@@ -231,9 +231,11 @@ __device__ __forceinline__ void pose_obs_term(const PoseCache &P, const double (
 // One linearisation pass over the observations that are not flagged.  WAVE (one wavefront per frame): the cached
 // observations and the ones read from memory are two loops, each with one kind of address (a select between an LDS
 // and a global pointer inside one loop turns every load into a flat load that waits for both counters).
-template <bool WAVE>
-__device__ __forceinline__ void pose_accumulate(const PoseCache &P, int n, const ObsView &V, const Cam &K, double hm, double hs,
+template <bool WAVE, bool CACHE>
+__device__ __forceinline__ void pose_accumulate(const PoseCache &P, int n, const ObsView &V0, const Cam &K, double hm, double hs,
                                                 double (&acc)[28]) {
+  ObsView V = V0;
+  if (!CACHE) V.nc = 0;  // compile-time: the cached loops fold away
 #pragma unroll
   for (int i = 0; i < 28; i++) acc[i] = 0;
   if (WAVE) {
@@ -242,21 +244,24 @@ __device__ __forceinline__ void pose_accumulate(const PoseCache &P, int n, const
     // use (at ~1000 observations and a 768-entry cache that is the whole tail in one batch, in flight under the cached
     // part).
     const int lane = threadIdx.x;
-    struct Ob { double pw[3], ou, ov, our, is; bool skip; };
+    struct Ob { double pw[3], ou, ov, our, is; unsigned skip; };  // skip: the raw flag byte (a bool would be compared, i.e. waited for, where it is loaded)
     auto ld_cached = [&](int i) {
       Ob o;
       V.get_cached(i, o.pw, o.ou, o.ov, o.our, o.is);
-      o.skip = V.lsk[i] != 0;
+      o.skip = V.lsk[i];
       return o;
     };
-    // the first four trips of the part in memory are requested before the cached part is walked
-    Ob o[4];
+    // the first trips of the part in memory are requested before the cached part is walked (four with the cache:
+    // the whole tail of a ~1000-observation frame; two without it, where a second wavefront on the SIMD covers the
+    // latency and the registers are needed to let it in)
+    constexpr int ND = CACHE ? 4 : 2;
+    Ob o[ND];
     auto ld_tail = [&](int base) {
 #pragma unroll
-      for (int k = 0; k < 4; k++) {
+      for (int k = 0; k < ND; k++) {
         const int i = min(base + 64 * k + lane, n - 1);
         V.get_global(i, o[k].pw, o[k].ou, o[k].ov, o[k].our, o[k].is);
-        o[k].skip = V.outlier[i] != 0;
+        o[k].skip = V.outlier[i];
       }
     };
     if (V.nc < n) ld_tail(V.nc);
@@ -271,10 +276,10 @@ __device__ __forceinline__ void pose_accumulate(const PoseCache &P, int n, const
       }
     }
 #pragma unroll 1
-    for (int base = V.nc; base < n; base += 4 * 64) {
+    for (int base = V.nc; base < n; base += ND * 64) {
       if (base != V.nc) ld_tail(base);
 #pragma unroll
-      for (int k = 0; k < 4; k++)
+      for (int k = 0; k < ND; k++)
         if (base + 64 * k + lane < n && !o[k].skip) pose_obs_term(P, o[k].pw, o[k].ou, o[k].ov, o[k].our, o[k].is, K, hm, hs, acc);
     }
     return;
@@ -348,8 +353,16 @@ __device__ __forceinline__ void wave_reduce28(const double (&v)[28], double *scr
     wave_lds_sync();
     double t = 0;
     if (lane < 56) {
+      // all sixteen loads in flight before the first add (a running sum over loads waits for LDS once per term),
+      // summed pairwise in a fixed order
+      double u[16];
 #pragma unroll
-      for (int j = 0; j < 16; j++) t += scratch[(4 * j + q) * 15 + vi];
+      for (int j = 0; j < 16; j++) u[j] = scratch[(4 * j + q) * 15 + vi];
+#pragma unroll
+      for (int w = 8; w >= 1; w >>= 1)
+#pragma unroll
+        for (int j = 0; j < w; j++) u[j] += u[j + w];
+      t = u[0];
     }
     t += dpp_f64<0xB1>(t);  // quad_perm [1,0,3,2]
     t += dpp_f64<0x4E>(t);  // quad_perm [2,3,0,1]
@@ -366,13 +379,14 @@ struct PoseLds {
   double red[kRed];
   double acc[28];   // linearisation at x: 21 + 6 + 1 sums, uniform over the workgroup
   double cand[28];  // ... at the trial point
+  double stash[32];  // uniform LM state parked across a pass over the observations (two-wavefronts-per-SIMD instance)
 };
 
 // Ceres-style LM on one 6-dof pose.  The linearisations -- 21 + 6 + 1 sums each -- live in LDS, not in registers: a
 // trial step accumulates the candidate's sums while the solve's temporaries are dead and vice versa (round 2 kept
 // two sets of 28 accumulators next to a 6 x 6 system in every lane: 256 VGPR + 251 AGPR).  Every thread carries the
 // (uniform) trust-region scalars in registers.
-template <bool WAVE>
+template <bool WAVE, bool CACHE>
 __device__ void pose_lm(double x[6], int n, const ObsView &V, const Cam &K, double hm, double hs, int max_it, PoseLds<WAVE> &S,
                         vo_lm_summary *sum) {
   // exp(x) is kept across the iterations (an accepted candidate's exp is the product se3_plus forms anyway) and the
@@ -381,7 +395,7 @@ __device__ void pose_lm(double x[6], int n, const ObsView &V, const Cam &K, doub
   Se3 Tx = se3_exp<true>(x);
   auto linearize = [&](const Se3 &T, double *dst) {  // sums of the linearisation at T -> dst (LDS)
     double v[28];
-    pose_accumulate<WAVE>(pose_cache_se3(T), n, V, K, hm, hs, v);
+    pose_accumulate<WAVE, CACHE>(pose_cache_se3(T), n, V, K, hm, hs, v);
     if (WAVE) {
       wave_reduce28(v, S.red, dst);
     } else {
@@ -409,9 +423,11 @@ __device__ void pose_lm(double x[6], int n, const ObsView &V, const Cam &K, doub
       break;
     }
     if (last_ok) {
-      double gm = 0;
+      double gm = 0, gr[6];
 #pragma unroll
-      for (int a = 0; a < 6; a++) gm = fmax(gm, fabs(S.acc[21 + a]));
+      for (int a = 0; a < 6; a++) gr[a] = S.acc[21 + a];
+#pragma unroll
+      for (int a = 0; a < 6; a++) gm = fmax(gm, fabs(gr[a]));
       if (gm <= 1e-10) {
         termination = 3;
         break;
@@ -425,12 +441,17 @@ __device__ void pose_lm(double x[6], int n, const ObsView &V, const Cam &K, doub
     last_ok = false;
     // scaled normal equations  H'' = S H S, g'' = S g ; LM diagonal from clamp(diag H'')/radius
     double L[21], g[6], y[6];
+    {
+      double h[27];  // one batch of LDS reads
 #pragma unroll
-    for (int a = 0; a < 6; a++) {
+      for (int i = 0; i < 27; i++) h[i] = S.acc[i];
 #pragma unroll
-      for (int b2 = 0; b2 <= a; b2++) L[tri_l(a, b2)] = S.acc[tri_u(b2, a)] * scale[b2] * scale[a];
-      g[a] = S.acc[21 + a] * scale[a];
-      y[a] = g[a];
+      for (int a = 0; a < 6; a++) {
+#pragma unroll
+        for (int b2 = 0; b2 <= a; b2++) L[tri_l(a, b2)] = h[tri_u(b2, a)] * scale[b2] * scale[a];
+        g[a] = h[21 + a] * scale[a];
+        y[a] = g[a];
+      }
     }
     double model = 0, delta[6];
     {
@@ -473,7 +494,26 @@ __device__ void pose_lm(double x[6], int n, const ObsView &V, const Cam &K, doub
     se3_plus_keep(Tx, delta, xc, Tc);
     // The candidate is linearised completely in the same pass (its cost is one of the 28 sums): an
     // accepted step -- the common case -- then needs no second sweep over the observations.
+    constexpr bool kPark = WAVE && !CACHE;  // the register budget of two wavefronts per SIMD: park what the pass does not use
+    if (kPark) {
+#pragma unroll
+      for (int a = 0; a < 6; a++) S.stash[a] = x[a], S.stash[6 + a] = scale[a], S.stash[12 + a] = xc[a];
+#pragma unroll
+      for (int a = 0; a < 4; a++) S.stash[18 + a] = Tx.q[a];
+#pragma unroll
+      for (int a = 0; a < 3; a++) S.stash[22 + a] = Tx.t[a];
+      S.stash[25] = x_norm, S.stash[26] = radius, S.stash[27] = decrease, S.stash[28] = x_cost, S.stash[29] = model;
+    }
     linearize(Tc, S.cand);
+    if (kPark) {
+#pragma unroll
+      for (int a = 0; a < 6; a++) x[a] = S.stash[a], scale[a] = S.stash[6 + a], xc[a] = S.stash[12 + a];
+#pragma unroll
+      for (int a = 0; a < 4; a++) Tx.q[a] = S.stash[18 + a];
+#pragma unroll
+      for (int a = 0; a < 3; a++) Tx.t[a] = S.stash[22 + a];
+      x_norm = S.stash[25], radius = S.stash[26], decrease = S.stash[27], x_cost = S.stash[28], model = S.stash[29];
+    }
     double cand = S.cand[27];
     if (!isfinite(cand)) cand = 1.7976931348623157e308;
     double sn = 0;
@@ -539,11 +579,10 @@ __device__ __forceinline__ bool pose_chi2_outlier(const double pc[3], double ou,
 // ranges != 0: problem p owns observations [offsets[2p], offsets[2p] + offsets[2p+1]) (frames at a fixed stride,
 // vo_track_gather_dev); otherwise [offsets[p], offsets[p+1]).  WAVE: one wavefront per problem (batches), with the
 // observation cache; otherwise 128 or 256 threads per problem (a few problems: the observations are shared out).
-template <bool WAVE>
-__global__ __launch_bounds__(WAVE ? 64 : 256) void k_pose_only(const int *offsets, const double *pts, const double *obs,
-                                                               const double *isg, const double *cam5, double *poses,
-                                                               uint8_t *outlier, int *n_inliers, vo_lm_summary *sums,
-                                                               int ranges, int cache_cap) {
+template <bool WAVE, bool CACHE>
+__device__ __forceinline__ void pose_only_body(const int *offsets, const double *pts, const double *obs, const double *isg,
+                                               const double *cam5, double *poses, uint8_t *outlier, int *n_inliers,
+                                               vo_lm_summary *sums, int ranges, int cache_cap) {
   extern __shared__ __attribute__((aligned(16))) uint8_t pose_dyn[];  // the observation cache (cache_cap > 0)
   __shared__ PoseLds<WAVE> S;
   __shared__ int s_cnt[4];
@@ -561,7 +600,7 @@ __global__ __launch_bounds__(WAVE ? 64 : 256) void k_pose_only(const int *offset
   }
   ObsView V{(const VO_GLOBAL double *)pts, (const VO_GLOBAL double *)obs, (const VO_GLOBAL double *)isg, (VO_GLOBAL uint8_t *)outlier, 0,
             nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
-  if (WAVE && cache_cap > 0) {  // fill the cache, verify that it is lossless
+  if (WAVE && CACHE && cache_cap > 0) {  // fill the cache, verify that it is lossless
     const int lane = threadIdx.x, nfill = min(n, cache_cap);
     double *lx = reinterpret_cast<double *>(pose_dyn), *ly = lx + cache_cap, *lz = ly + cache_cap, *tab = lz + cache_cap;
     float *lu = reinterpret_cast<float *>(tab + 16), *lv = lu + cache_cap, *lr = lv + cache_cap;
@@ -612,7 +651,7 @@ __global__ __launch_bounds__(WAVE ? 64 : 256) void k_pose_only(const int *offset
     for (int a = 0; a < 6; a++) x[a] = x0[a];  // :215
     const double hm = round == 0 ? (double)sqrtf(5.991f) : 0.0;
     const double hs = round == 0 ? (double)sqrtf(7.815f) : 0.0;
-    pose_lm<WAVE>(x, n, V, K, hm, hs, 10, S, sums ? &sums[2 * p + round] : nullptr);
+    pose_lm<WAVE, CACHE>(x, n, V, K, hm, hs, 10, S, sums ? &sums[2 * p + round] : nullptr);
     __syncthreads();
     // classification with Tcw = exp(pose) (Sophus quaternion form, :256-257)
     const Se3 T = se3_exp(x);
@@ -625,7 +664,7 @@ __global__ __launch_bounds__(WAVE ? 64 : 256) void k_pose_only(const int *offset
       local += out ? 0 : 1;
       return out;
     };
-    if (WAVE) {
+    if (WAVE && CACHE) {
 #pragma unroll 1
       for (int i = threadIdx.x; i < V.nc; i += 64) {
         double pw[3], ou, ov, our, is;
@@ -636,7 +675,7 @@ __global__ __launch_bounds__(WAVE ? 64 : 256) void k_pose_only(const int *offset
       }
     }
 #pragma unroll 1
-    for (int i = (WAVE ? V.nc : 0) + threadIdx.x; i < n; i += stride) {
+    for (int i = (WAVE && CACHE ? V.nc : 0) + threadIdx.x; i < n; i += stride) {
       double pw[3], ou, ov, our, is;
       V.get_global(i, pw, ou, ov, our, is);
       outlier[i] = classify(i, pw, ou, ov, our, is) ? 1 : 0;
@@ -657,6 +696,21 @@ __global__ __launch_bounds__(WAVE ? 64 : 256) void k_pose_only(const int *offset
     for (int a = 0; a < 6; a++) poses[6 * p + a] = x[a];
   }
 }
+
+#define VO_POSE_ARGS                                                                                                  \
+  const int *offsets, const double *pts, const double *obs, const double *isg, const double *cam5, double *poses,    \
+      uint8_t *outlier, int *n_inliers, vo_lm_summary *sums, int ranges, int cache_cap
+__global__ __launch_bounds__(256) void k_pose_only_block(VO_POSE_ARGS) {
+  pose_only_body<false, false>(offsets, pts, obs, isg, cam5, poses, outlier, n_inliers, sums, ranges, cache_cap);
+}
+__global__ __launch_bounds__(64) void k_pose_only_wave_cached(VO_POSE_ARGS) {
+  pose_only_body<true, true>(offsets, pts, obs, isg, cam5, poses, outlier, n_inliers, sums, ranges, cache_cap);
+}
+// no observation cache: 8.6 KB of LDS per wavefront, two wavefronts per SIMD when the registers allow
+__attribute__((amdgpu_waves_per_eu(2, 2))) __global__ __launch_bounds__(64) void k_pose_only_wave(VO_POSE_ARGS) {
+  pose_only_body<true, false>(offsets, pts, obs, isg, cam5, poses, outlier, n_inliers, sums, ranges, cache_cap);
+}
+#undef VO_POSE_ARGS
 
 // ============================================================================================
 // Sim3 optimisation of a loop candidate: Optimizer::solveLoopSim3 (optimizer_ceres.cpp:810-1030),
@@ -3148,7 +3202,7 @@ int vo_pose_only_solve_dev(int n_problems, const int32_t *dev_offsets, int max_o
   if (n_problems == 0) return VO_OK;
   VO_CHECK(vo::ensure_device());
   const int bw = pose_block_width(n_problems), cc = pose_cache_cap(bw);
-  hipLaunchKernelGGL(bw == 64 ? k_pose_only<true> : k_pose_only<false>, dim3(n_problems), dim3(bw), pose_cache_bytes(cc),
+  hipLaunchKernelGGL(bw != 64 ? k_pose_only_block : cc > 0 ? k_pose_only_wave_cached : k_pose_only_wave, dim3(n_problems), dim3(bw), pose_cache_bytes(cc),
                      (hipStream_t)hip_stream, dev_offsets, dev_points, dev_obs, dev_inv_sigma, dev_cam5, dev_poses, dev_outlier,
                      dev_n_inliers, dev_summaries, 0, cc);
   VO_HIP_CHECK(hipGetLastError());
@@ -3164,7 +3218,7 @@ int vo_pose_only_solve_ranges_dev(int n_problems, const int32_t *dev_ranges, con
   if (n_problems == 0) return VO_OK;
   VO_CHECK(vo::ensure_device());
   const int bw = pose_block_width(n_problems), cc = pose_cache_cap(bw);
-  hipLaunchKernelGGL(bw == 64 ? k_pose_only<true> : k_pose_only<false>, dim3(n_problems), dim3(bw), pose_cache_bytes(cc),
+  hipLaunchKernelGGL(bw != 64 ? k_pose_only_block : cc > 0 ? k_pose_only_wave_cached : k_pose_only_wave, dim3(n_problems), dim3(bw), pose_cache_bytes(cc),
                      (hipStream_t)hip_stream, dev_ranges, dev_points, dev_obs, dev_inv_sigma, dev_cam5, dev_poses, dev_outlier,
                      dev_n_inliers, dev_summaries, 1, cc);
   VO_HIP_CHECK(hipGetLastError());
