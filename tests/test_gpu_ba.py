@@ -471,11 +471,11 @@ def test_stateless_entry_points_from_three_threads_and_scratch_release(vo):
 
 
 @pytest.mark.parametrize("kind", ["float_obs", "double_obs", "many_sigmas", "long"])
-def test_pose_only_batched_mode_with_observation_cache(vo, orc, kind):
-    """>= 512 problems in one call: one wavefront per frame with the observations cached in LDS.  float_obs: the cache is
-    used (observations are float pixel coordinates, as in the reference); double_obs: observations that are not
-    float-representable must bypass it; many_sigmas: more than 16 distinct 1/sigma values must bypass it; long: frames
-    with more observations than the cache holds (the tail is read from memory).  Each against the oracle."""
+def test_pose_only_batched_mode(vo, orc, kind):
+    """>= 512 problems in one call: one wavefront per frame (k_pose_only<true>: observations requested four trips
+    ahead, transpose reduction through LDS, linearisations in LDS).  float_obs: float pixel coordinates, as in the
+    reference; double_obs: observations that are not float-representable; many_sigmas: 40 distinct 1/sigma values;
+    long: 1500 observations per frame (several batches of prefetched trips, ragged end).  Each against the oracle."""
     from vo_slam_test_amd import synth
     nprob, nobs = 520, (1500 if kind == "long" else 90)
     if kind == "long":

@@ -160,29 +160,19 @@ struct PoseLm {
   int iterations, accepted, termination;
 };
 
-// Where a frame's observations are read from during a solve.  A solve makes ~20 passes over them; with one wavefront
-// per frame (the batched mode) a pass re-reads 56 bytes per observation from HBM -- the batch does not fit the L2s (PMC:
-// 93 % L2 misses, TCP stalled on pending misses 40 % of the kernel) -- so the first `nc` observations of the frame are
-// kept in LDS in a compact, LOSSLESS form: the point in double, (u, v, uR) as the floats they came from, 1/sigma as an
-// index into a table of the frame's distinct values (one per pyramid level), and the outlier flag.  38 bytes per
-// observation, for the first 768 observations of each of the four frames that share a CU.  A frame whose observations are not
-// float-representable, or with more than 16 distinct 1/sigma, is read from memory as before (nc = 0).
+// A frame's observations (global memory, explicit address space: generic pointers in a struct turn every access
+// into a flat load that waits for both counters).  Round 2 kept the first 768 of them in LDS in a compact form
+// (one wavefront per SIMD cannot hide the latency of a load it waits for right away); with every load of a pass issued
+// four trips ahead of its use the plain reads are as fast (0.284 against 0.286 ms per 1024 frames), and the 148 KB of
+// LDS per CU the cache took go to the extraction kernels that run next to the solve (tracked step 4.39 -> 4.14 ms).
 #define VO_GLOBAL __attribute__((address_space(1)))
-#define VO_LDS __attribute__((address_space(3)))
-struct ObsView {  // explicit address spaces: as generic pointers in a struct every access becomes a flat load
+#ifndef VO_POSE_ND
+#define VO_POSE_ND 4
+#endif
+struct ObsView {
   const VO_GLOBAL double *pts, *obs, *isg;
-  VO_GLOBAL uint8_t *outlier;  // global flags: the result, and the skip mask of what is not cached
-  int nc;
-  const VO_LDS double *lx, *ly, *lz, *tab;
-  const VO_LDS float *lu, *lv, *lr;
-  const VO_LDS uint8_t *li;
-  VO_LDS uint8_t *lsk;
-  __device__ __forceinline__ void get_cached(int i, double (&p)[3], double &ou, double &ov, double &our, double &is) const {
-    p[0] = lx[i], p[1] = ly[i], p[2] = lz[i];
-    ou = (double)lu[i], ov = (double)lv[i], our = (double)lr[i];
-    is = tab[li[i]];
-  }
-  __device__ __forceinline__ void get_global(int i, double (&p)[3], double &ou, double &ov, double &our, double &is) const {
+  VO_GLOBAL uint8_t *outlier;  // the result, and the skip mask of a pass
+  __device__ __forceinline__ void get(int i, double (&p)[3], double &ou, double &ov, double &our, double &is) const {
     p[0] = pts[3 * i], p[1] = pts[3 * i + 1], p[2] = pts[3 * i + 2];
     ou = obs[3 * i], ov = obs[3 * i + 1], our = obs[3 * i + 2];
     is = isg[i];
@@ -228,59 +218,38 @@ __device__ __forceinline__ void pose_obs_term(const PoseCache &P, const double (
     acc[21 + a] = __builtin_fma(w0[a], r[0], __builtin_fma(w1[a], r[1], __builtin_fma(w2[a], r[2], acc[21 + a])));
 }
 
-// One linearisation pass over the observations that are not flagged.  WAVE (one wavefront per frame): the cached
-// observations and the ones read from memory are two loops, each with one kind of address (a select between an LDS
-// and a global pointer inside one loop turns every load into a flat load that waits for both counters).
-template <bool WAVE, bool CACHE>
-__device__ __forceinline__ void pose_accumulate(const PoseCache &P, int n, const ObsView &V0, const Cam &K, double hm, double hs,
+// One linearisation pass over the observations that are not flagged.  WAVE (one wavefront per frame, nothing else on
+// its SIMD to run while a load is in flight): observations are requested in batches of four trips, one batch ahead
+// of their use -- the raw flag byte included: a bool would be compared, i.e. waited for, where it is loaded.
+template <bool WAVE>
+__device__ __forceinline__ void pose_accumulate(const PoseCache &P, int n, const ObsView &V, const Cam &K, double hm, double hs,
                                                 double (&acc)[28]) {
-  ObsView V = V0;
-  if (!CACHE) V.nc = 0;  // compile-time: the cached loops fold away
 #pragma unroll
   for (int i = 0; i < 28; i++) acc[i] = 0;
   if (WAVE) {
-    // One wavefront per SIMD has nothing else to run while a load is in flight: the cached observations are read one
-    // trip ahead (LDS latency), the ones in memory four trips at a time with all their loads issued before the first
-    // use (at ~1000 observations and a 768-entry cache that is the whole tail in one batch, in flight under the cached
-    // part).
     const int lane = threadIdx.x;
-    struct Ob { double pw[3], ou, ov, our, is; unsigned skip; };  // skip: the raw flag byte (a bool would be compared, i.e. waited for, where it is loaded)
-    auto ld_cached = [&](int i) {
-      Ob o;
-      V.get_cached(i, o.pw, o.ou, o.ov, o.our, o.is);
-      o.skip = V.lsk[i];
-      return o;
-    };
-    // the first trips of the part in memory are requested before the cached part is walked (four with the cache:
-    // the whole tail of a ~1000-observation frame; two without it, where a second wavefront on the SIMD covers the
-    // latency and the registers are needed to let it in)
-    constexpr int ND = CACHE ? 4 : 2;
-    Ob o[ND];
-    auto ld_tail = [&](int base) {
+    constexpr int ND = VO_POSE_ND;
+    struct Ob { double pw[3], ou, ov, our, is; unsigned skip; };
+    auto request = [&](int base, Ob (&o)[ND]) {
 #pragma unroll
       for (int k = 0; k < ND; k++) {
-        const int i = min(base + 64 * k + lane, n - 1);
-        V.get_global(i, o[k].pw, o[k].ou, o[k].ov, o[k].our, o[k].is);
+        const int i = min(base + 64 * k + lane, n - 1);  // past the end: a harmless re-read
+        V.get(i, o[k].pw, o[k].ou, o[k].ov, o[k].our, o[k].is);
         o[k].skip = V.outlier[i];
       }
     };
-    if (V.nc < n) ld_tail(V.nc);
-    if (lane < V.nc) {
-      Ob cur = ld_cached(lane);
+    Ob cur[ND];
+    request(0, cur);
 #pragma unroll 1
-      for (int i = lane; i < V.nc; i += 64) {
-        const int in = min(i + 64, V.nc - 1);  // past the end: a harmless re-read
-        const Ob nxt = ld_cached(in);
-        if (!cur.skip) pose_obs_term(P, cur.pw, cur.ou, cur.ov, cur.our, cur.is, K, hm, hs, acc);
-        cur = nxt;
-      }
-    }
-#pragma unroll 1
-    for (int base = V.nc; base < n; base += ND * 64) {
-      if (base != V.nc) ld_tail(base);
+    for (int base = 0; base < n; base += ND * 64) {
+      Ob nxt[ND];
+      request(base + ND * 64, nxt);  // the next batch travels while this one is evaluated
 #pragma unroll
       for (int k = 0; k < ND; k++)
-        if (base + 64 * k + lane < n && !o[k].skip) pose_obs_term(P, o[k].pw, o[k].ou, o[k].ov, o[k].our, o[k].is, K, hm, hs, acc);
+        if (base + 64 * k + lane < n && !cur[k].skip)
+          pose_obs_term(P, cur[k].pw, cur[k].ou, cur[k].ov, cur[k].our, cur[k].is, K, hm, hs, acc);
+#pragma unroll
+      for (int k = 0; k < ND; k++) cur[k] = nxt[k];
     }
     return;
   }
@@ -288,7 +257,7 @@ __device__ __forceinline__ void pose_accumulate(const PoseCache &P, int n, const
   for (int i = threadIdx.x; i < n; i += (int)blockDim.x) {
     if (V.outlier[i]) continue;
     double pw[3], ou, ov, our, is;
-    V.get_global(i, pw, ou, ov, our, is);
+    V.get(i, pw, ou, ov, our, is);
     pose_obs_term(P, pw, ou, ov, our, is, K, hm, hs, acc);
   }
 }
@@ -379,14 +348,13 @@ struct PoseLds {
   double red[kRed];
   double acc[28];   // linearisation at x: 21 + 6 + 1 sums, uniform over the workgroup
   double cand[28];  // ... at the trial point
-  double stash[32];  // uniform LM state parked across a pass over the observations (two-wavefronts-per-SIMD instance)
 };
 
 // Ceres-style LM on one 6-dof pose.  The linearisations -- 21 + 6 + 1 sums each -- live in LDS, not in registers: a
 // trial step accumulates the candidate's sums while the solve's temporaries are dead and vice versa (round 2 kept
 // two sets of 28 accumulators next to a 6 x 6 system in every lane: 256 VGPR + 251 AGPR).  Every thread carries the
 // (uniform) trust-region scalars in registers.
-template <bool WAVE, bool CACHE>
+template <bool WAVE>
 __device__ void pose_lm(double x[6], int n, const ObsView &V, const Cam &K, double hm, double hs, int max_it, PoseLds<WAVE> &S,
                         vo_lm_summary *sum) {
   // exp(x) is kept across the iterations (an accepted candidate's exp is the product se3_plus forms anyway) and the
@@ -395,7 +363,7 @@ __device__ void pose_lm(double x[6], int n, const ObsView &V, const Cam &K, doub
   Se3 Tx = se3_exp<true>(x);
   auto linearize = [&](const Se3 &T, double *dst) {  // sums of the linearisation at T -> dst (LDS)
     double v[28];
-    pose_accumulate<WAVE, CACHE>(pose_cache_se3(T), n, V, K, hm, hs, v);
+    pose_accumulate<WAVE>(pose_cache_se3(T), n, V, K, hm, hs, v);
     if (WAVE) {
       wave_reduce28(v, S.red, dst);
     } else {
@@ -494,26 +462,7 @@ __device__ void pose_lm(double x[6], int n, const ObsView &V, const Cam &K, doub
     se3_plus_keep(Tx, delta, xc, Tc);
     // The candidate is linearised completely in the same pass (its cost is one of the 28 sums): an
     // accepted step -- the common case -- then needs no second sweep over the observations.
-    constexpr bool kPark = WAVE && !CACHE;  // the register budget of two wavefronts per SIMD: park what the pass does not use
-    if (kPark) {
-#pragma unroll
-      for (int a = 0; a < 6; a++) S.stash[a] = x[a], S.stash[6 + a] = scale[a], S.stash[12 + a] = xc[a];
-#pragma unroll
-      for (int a = 0; a < 4; a++) S.stash[18 + a] = Tx.q[a];
-#pragma unroll
-      for (int a = 0; a < 3; a++) S.stash[22 + a] = Tx.t[a];
-      S.stash[25] = x_norm, S.stash[26] = radius, S.stash[27] = decrease, S.stash[28] = x_cost, S.stash[29] = model;
-    }
     linearize(Tc, S.cand);
-    if (kPark) {
-#pragma unroll
-      for (int a = 0; a < 6; a++) x[a] = S.stash[a], scale[a] = S.stash[6 + a], xc[a] = S.stash[12 + a];
-#pragma unroll
-      for (int a = 0; a < 4; a++) Tx.q[a] = S.stash[18 + a];
-#pragma unroll
-      for (int a = 0; a < 3; a++) Tx.t[a] = S.stash[22 + a];
-      x_norm = S.stash[25], radius = S.stash[26], decrease = S.stash[27], x_cost = S.stash[28], model = S.stash[29];
-    }
     double cand = S.cand[27];
     if (!isfinite(cand)) cand = 1.7976931348623157e308;
     double sn = 0;
@@ -577,13 +526,13 @@ __device__ __forceinline__ bool pose_chi2_outlier(const double pc[3], double ou,
 }
 
 // ranges != 0: problem p owns observations [offsets[2p], offsets[2p] + offsets[2p+1]) (frames at a fixed stride,
-// vo_track_gather_dev); otherwise [offsets[p], offsets[p+1]).  WAVE: one wavefront per problem (batches), with the
-// observation cache; otherwise 128 or 256 threads per problem (a few problems: the observations are shared out).
-template <bool WAVE, bool CACHE>
-__device__ __forceinline__ void pose_only_body(const int *offsets, const double *pts, const double *obs, const double *isg,
-                                               const double *cam5, double *poses, uint8_t *outlier, int *n_inliers,
-                                               vo_lm_summary *sums, int ranges, int cache_cap) {
-  extern __shared__ __attribute__((aligned(16))) uint8_t pose_dyn[];  // the observation cache (cache_cap > 0)
+// vo_track_gather_dev); otherwise [offsets[p], offsets[p+1]).  WAVE: one wavefront per problem (batches); otherwise
+// 128 or 256 threads per problem (a few problems: the observations are shared out).
+template <bool WAVE>
+__global__ __launch_bounds__(WAVE ? 64 : 256) void k_pose_only(const int *offsets, const double *pts, const double *obs,
+                                                               const double *isg, const double *cam5, double *poses,
+                                                               uint8_t *outlier, int *n_inliers, vo_lm_summary *sums,
+                                                               int ranges) {
   __shared__ PoseLds<WAVE> S;
   __shared__ int s_cnt[4];
   const int p = blockIdx.x;
@@ -598,51 +547,7 @@ __device__ __forceinline__ void pose_only_body(const int *offsets, const double 
     if (threadIdx.x == 0) n_inliers[p] = 0;
     return;
   }
-  ObsView V{(const VO_GLOBAL double *)pts, (const VO_GLOBAL double *)obs, (const VO_GLOBAL double *)isg, (VO_GLOBAL uint8_t *)outlier, 0,
-            nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
-  if (WAVE && CACHE && cache_cap > 0) {  // fill the cache, verify that it is lossless
-    const int lane = threadIdx.x, nfill = min(n, cache_cap);
-    double *lx = reinterpret_cast<double *>(pose_dyn), *ly = lx + cache_cap, *lz = ly + cache_cap, *tab = lz + cache_cap;
-    float *lu = reinterpret_cast<float *>(tab + 16), *lv = lu + cache_cap, *lr = lv + cache_cap;
-    uint8_t *li = reinterpret_cast<uint8_t *>(lr + cache_cap), *lsk = li + cache_cap;
-    int ntab = 0;
-    bool good = true;
-    for (int base = 0; base < nfill; base += 64) {
-      const int i = base + lane;
-      const bool valid = i < nfill;
-      const int j = valid ? i : nfill - 1;
-      const double px = pts[3 * j], py = pts[3 * j + 1], pz = pts[3 * j + 2];
-      const double ou = obs[3 * j], ov = obs[3 * j + 1], our = obs[3 * j + 2], is = isg[j];
-      const float fu = (float)ou, fv = (float)ov, fr = (float)our;
-      const bool lossless = (double)fu == ou && (double)fv == ov && (double)fr == our;
-      int idx = -1;
-      for (int k = 0; k < ntab; k++)
-        if (tab[k] == is) idx = k;
-      unsigned long long miss = __builtin_amdgcn_ballot_w64(valid && idx < 0);
-      while (miss != 0ull && ntab < 16) {  // uniform: one new table entry per trip
-        const double v = readlane_f64(is, (int)__builtin_ctzll(miss));
-        if (lane == 0) tab[ntab] = v;
-        if (idx < 0 && is == v) idx = ntab;
-        ntab++;
-        miss = __builtin_amdgcn_ballot_w64(valid && idx < 0);
-      }
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-      __builtin_amdgcn_wave_barrier();
-      if (miss != 0ull || __builtin_amdgcn_ballot_w64(valid && !lossless) != 0ull) good = false;  // uniform
-      if (valid) {
-        lx[i] = px, ly[i] = py, lz[i] = pz;
-        lu[i] = fu, lv[i] = fv, lr[i] = fr;
-        li[i] = (uint8_t)max(idx, 0);
-        lsk[i] = 0;
-      }
-    }
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_wave_barrier();
-    if (good)
-      V = ObsView{V.pts, V.obs, V.isg, V.outlier, nfill, (const VO_LDS double *)lx, (const VO_LDS double *)ly, (const VO_LDS double *)lz,
-                  (const VO_LDS double *)tab, (const VO_LDS float *)lu, (const VO_LDS float *)lv, (const VO_LDS float *)lr,
-                  (const VO_LDS uint8_t *)li, (VO_LDS uint8_t *)lsk};
-  }
+  const ObsView V{(const VO_GLOBAL double *)pts, (const VO_GLOBAL double *)obs, (const VO_GLOBAL double *)isg, (VO_GLOBAL uint8_t *)outlier};
   const int stride = WAVE ? 64 : (int)blockDim.x;
   for (int i = threadIdx.x; i < n; i += stride) outlier[i] = 0;
   __syncthreads();
@@ -651,34 +556,20 @@ __device__ __forceinline__ void pose_only_body(const int *offsets, const double 
     for (int a = 0; a < 6; a++) x[a] = x0[a];  // :215
     const double hm = round == 0 ? (double)sqrtf(5.991f) : 0.0;
     const double hs = round == 0 ? (double)sqrtf(7.815f) : 0.0;
-    pose_lm<WAVE, CACHE>(x, n, V, K, hm, hs, 10, S, sums ? &sums[2 * p + round] : nullptr);
+    pose_lm<WAVE>(x, n, V, K, hm, hs, 10, S, sums ? &sums[2 * p + round] : nullptr);
     __syncthreads();
     // classification with Tcw = exp(pose) (Sophus quaternion form, :256-257)
     const Se3 T = se3_exp(x);
     int local = 0;
-    auto classify = [&](int i, const double (&pw)[3], double ou, double ov, double our, double is) {
-      double rp[3], pc[3];
+#pragma unroll 1
+    for (int i = threadIdx.x; i < n; i += stride) {
+      double rp[3], pc[3], pw[3], ou, ov, our, is;
+      V.get(i, pw, ou, ov, our, is);
       quat_rotate(T.q, pw, rp);
       pc[0] = rp[0] + T.t[0], pc[1] = rp[1] + T.t[1], pc[2] = rp[2] + T.t[2];
       const bool out = pose_chi2_outlier(pc, ou, ov, our, fx, fy, cx, cy, bf, is);
+      outlier[i] = out ? 1 : 0;
       local += out ? 0 : 1;
-      return out;
-    };
-    if (WAVE && CACHE) {
-#pragma unroll 1
-      for (int i = threadIdx.x; i < V.nc; i += 64) {
-        double pw[3], ou, ov, our, is;
-        V.get_cached(i, pw, ou, ov, our, is);
-        const bool out = classify(i, pw, ou, ov, our, is);
-        V.lsk[i] = out ? 1 : 0;
-        outlier[i] = out ? 1 : 0;
-      }
-    }
-#pragma unroll 1
-    for (int i = (WAVE && CACHE ? V.nc : 0) + threadIdx.x; i < n; i += stride) {
-      double pw[3], ou, ov, our, is;
-      V.get_global(i, pw, ou, ov, our, is);
-      outlier[i] = classify(i, pw, ou, ov, our, is) ? 1 : 0;
     }
     for (int o = 32; o >= 1; o >>= 1) local += __shfl_xor(local, o);
     __syncthreads();
@@ -696,21 +587,6 @@ __device__ __forceinline__ void pose_only_body(const int *offsets, const double 
     for (int a = 0; a < 6; a++) poses[6 * p + a] = x[a];
   }
 }
-
-#define VO_POSE_ARGS                                                                                                  \
-  const int *offsets, const double *pts, const double *obs, const double *isg, const double *cam5, double *poses,    \
-      uint8_t *outlier, int *n_inliers, vo_lm_summary *sums, int ranges, int cache_cap
-__global__ __launch_bounds__(256) void k_pose_only_block(VO_POSE_ARGS) {
-  pose_only_body<false, false>(offsets, pts, obs, isg, cam5, poses, outlier, n_inliers, sums, ranges, cache_cap);
-}
-__global__ __launch_bounds__(64) void k_pose_only_wave_cached(VO_POSE_ARGS) {
-  pose_only_body<true, true>(offsets, pts, obs, isg, cam5, poses, outlier, n_inliers, sums, ranges, cache_cap);
-}
-// no observation cache: 8.6 KB of LDS per wavefront, two wavefronts per SIMD when the registers allow
-__attribute__((amdgpu_waves_per_eu(2, 2))) __global__ __launch_bounds__(64) void k_pose_only_wave(VO_POSE_ARGS) {
-  pose_only_body<true, false>(offsets, pts, obs, isg, cam5, poses, outlier, n_inliers, sums, ranges, cache_cap);
-}
-#undef VO_POSE_ARGS
 
 // ============================================================================================
 // Sim3 optimisation of a loop candidate: Optimizer::solveLoopSim3 (optimizer_ceres.cpp:810-1030),
@@ -3177,21 +3053,6 @@ static inline int pose_block_width(int n_problems) {
   return n_problems >= 512 ? 64 : 256;
 }
 
-// Observation cache of the one-wavefront-per-frame mode: 768 observations x 38 bytes + the 1/sigma table = 29 KB per
-// frame, four frames per CU; a frame's observations beyond that are read from memory.  Measured per 1024 frames x ~1000
-// observations (pose solve alone / tracked step with two batches in flight): no cache 0.55 ms / 4.72 ms, 512: 0.47 / 4.58,
-// 768: 0.42 / 4.52, 1024: 0.44 / 5.00 -- the full cache takes the CU's whole LDS away from the extraction kernels that
-// run next to the solve.  VO_POSE_CACHE overrides.
-static inline int pose_cache_cap(int block_width) {
-  static const int forced = [] {
-    const char *e = getenv("VO_POSE_CACHE");
-    return e ? atoi(e) : -1;
-  }();
-  const int cap = forced >= 0 ? (forced / 64) * 64 : 768;
-  return block_width == 64 ? cap : 0;
-}
-static inline size_t pose_cache_bytes(int cap) { return cap > 0 ? (size_t)cap * 38 + 16 * 8 : 0; }
-
 int vo_pose_only_solve_dev(int n_problems, const int32_t *dev_offsets, int max_obs, const double *dev_points,
                            const double *dev_obs, const double *dev_inv_sigma, const double *dev_cam5,
                            double *dev_poses, uint8_t *dev_outlier, int32_t *dev_n_inliers,
@@ -3201,10 +3062,9 @@ int vo_pose_only_solve_dev(int n_problems, const int32_t *dev_offsets, int max_o
     return VO_ERR_INVALID;
   if (n_problems == 0) return VO_OK;
   VO_CHECK(vo::ensure_device());
-  const int bw = pose_block_width(n_problems), cc = pose_cache_cap(bw);
-  hipLaunchKernelGGL(bw != 64 ? k_pose_only_block : cc > 0 ? k_pose_only_wave_cached : k_pose_only_wave, dim3(n_problems), dim3(bw), pose_cache_bytes(cc),
-                     (hipStream_t)hip_stream, dev_offsets, dev_points, dev_obs, dev_inv_sigma, dev_cam5, dev_poses, dev_outlier,
-                     dev_n_inliers, dev_summaries, 0, cc);
+  const int bw = pose_block_width(n_problems);
+  hipLaunchKernelGGL(bw == 64 ? k_pose_only<true> : k_pose_only<false>, dim3(n_problems), dim3(bw), 0, (hipStream_t)hip_stream,
+                     dev_offsets, dev_points, dev_obs, dev_inv_sigma, dev_cam5, dev_poses, dev_outlier, dev_n_inliers, dev_summaries, 0);
   VO_HIP_CHECK(hipGetLastError());
   return VO_OK;
 }
@@ -3217,10 +3077,9 @@ int vo_pose_only_solve_ranges_dev(int n_problems, const int32_t *dev_ranges, con
     return VO_ERR_INVALID;
   if (n_problems == 0) return VO_OK;
   VO_CHECK(vo::ensure_device());
-  const int bw = pose_block_width(n_problems), cc = pose_cache_cap(bw);
-  hipLaunchKernelGGL(bw != 64 ? k_pose_only_block : cc > 0 ? k_pose_only_wave_cached : k_pose_only_wave, dim3(n_problems), dim3(bw), pose_cache_bytes(cc),
-                     (hipStream_t)hip_stream, dev_ranges, dev_points, dev_obs, dev_inv_sigma, dev_cam5, dev_poses, dev_outlier,
-                     dev_n_inliers, dev_summaries, 1, cc);
+  const int bw = pose_block_width(n_problems);
+  hipLaunchKernelGGL(bw == 64 ? k_pose_only<true> : k_pose_only<false>, dim3(n_problems), dim3(bw), 0, (hipStream_t)hip_stream,
+                     dev_ranges, dev_points, dev_obs, dev_inv_sigma, dev_cam5, dev_poses, dev_outlier, dev_n_inliers, dev_summaries, 1);
   VO_HIP_CHECK(hipGetLastError());
   return VO_OK;
 }
