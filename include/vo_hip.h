@@ -464,6 +464,104 @@ int vo_track_gather_dev(vo_frames *h, int slot0, int n_frames, const double *dev
                         double *dev_points, double *dev_obs, double *dev_inv_sigma, int32_t *dev_ranges,
                         int32_t *dev_index, void *hip_stream);
 
+/* ------------------------------------------------------------------------------------------
+ * The tracked-frame pipeline as one object  --  VisualOdometry::trackWithMotion + trackLocalMap
+ * (visualOdometry.cpp:228-251, 286-300, 745-775, 864-886) for a batch of `batch` independent camera
+ * streams resident in HBM: extraction, Frame::Frame post-processing, searchByProjection against the last
+ * frame's map points (radius 15), solvePoseOnlySE3, cullingOutliersBeforeLocalMap, Frame::isInFrame +
+ * MapPoint::predictScale for the local map points WITH THE REFINED POSE, searchByProjection against
+ * them (thRadius 3, ratio 0.8), solvePoseOnlySE3, inlier count.  One call enqueues the whole sequence
+ * (23 launches) without host synchronisation; batch = 1 with host images is the single-stream form
+ * (Frame construction to pose in one call).
+ *
+ * Streams: the searches and pose solves run on `stream` (NULL: a high-priority stream of the tracker),
+ * the extraction on `extract_stream` (NULL: a stream of the tracker, or `stream` itself when
+ * single_stream != 0).  Several trackers that share one extract_stream take turns on the extraction
+ * while each other's searches and solves run next to it (two batches in flight: bench.py's regime).
+ *
+ * Not covered (the caller's control flow): the retry with 2 x radius when fewer than 20 matches are
+ * found (:241-245), trackRefKeyFrame and relocalisation; status bit VO_TRACK_FEW_MATCHES /
+ * VO_TRACK_FEW_INLIERS tell the caller that the reference would have left trackWithMotion (:247, :253).
+ * ------------------------------------------------------------------------------------------ */
+typedef struct vo_tracker vo_tracker;
+typedef struct {
+  int32_t batch, width, height;
+  int32_t nfeatures, nlevels, ini_th_fast, min_th_fast; /* 0: 1000, 8, 20, 7 (visualOdometry.cpp:31) */
+  float scale_factor;                                   /* <= 1: 1.2 */
+  float intrinsics[5];                                  /* fx, fy, cx, cy, bf */
+  float dist_coef[5];                                   /* k1, k2, p1, p2, k3 */
+  int32_t has_distortion;
+  float inv_depth_scale;                                /* metres = raw * inv_depth_scale (depth_kind 2) */
+  int32_t max_last, max_local;                          /* capacity: last-frame / local map points per frame */
+  int32_t max_features;                                 /* feature slots per frame; 0: the extractor's bound */
+  int32_t single_stream;
+  void *stream, *extract_stream;                        /* hipStream_t or NULL */
+} vo_tracker_config;
+typedef struct {
+  float radius;     /* searchByProjection(frame, last frame): 15 */
+  float th_radius;  /* searchByProjection(frame, local points): 3 (5 just after relocalisation, :793-794) */
+  float ratio;      /* Matcher(0.8) */
+  int32_t direction; /* matcher.cpp:70-75: 0 none, 1 forward, 2 backward */
+} vo_tracker_params;
+enum { VO_TRACK_FEW_MATCHES = 1, VO_TRACK_FEW_INLIERS = 2 };
+int vo_tracker_create(vo_tracker **out, const vo_tracker_config *cfg);
+void vo_tracker_destroy(vo_tracker *t);
+int vo_tracker_info(const vo_tracker *t, int *batch, int *max_features, int *max_keypoints, int *n_levels);
+vo_orb *vo_tracker_extractor(vo_tracker *t); /* the handles the tracker owns (accessors, tests) */
+vo_frames *vo_tracker_frames(vo_tracker *t);
+void *vo_tracker_stream(vo_tracker *t);
+/* State of the map as the next batch sees it; host arrays [batch][n][...], copied before the call
+ * returns.  Last frame (frame_last_->mappoints_, visualOdometry.cpp:232-238): Tcw12 [batch][12] =
+ * rotation row-major + translation of frame_curr_->Tcw_ = Tcl_ * frame_last_->Tcw_; per map point its
+ * world position, flags (bit 0: exists and is no outlier, bit 1: observe_cnt_ > 0), the octave, angle
+ * and descriptor of the last frame's feature.  Local map (localMappoints_, :745-775): world position,
+ * normal vector, minDistance_ / maxDistance_ (mappoint.h), flags (bit 0: exists and is not bad, bit 1:
+ * observe_cnt_ > 0), descriptor; link[i] = index of the same MapPoint in the last-frame list or -1
+ * (NULL: none) -- a point the first search matched carries visualIdxOfFrame_ == frame id and is
+ * skipped (:765). */
+int vo_tracker_set_last_frame(vo_tracker *t, int n, const double *Tcw12, const double *points, const uint8_t *flags,
+                              const int32_t *octave, const float *angle, const uint8_t *desc);
+int vo_tracker_set_local_map(vo_tracker *t, int n, const double *points, const double *normals,
+                             const float *min_distance, const float *max_distance, const uint8_t *flags,
+                             const int32_t *link, const uint8_t *desc);
+/* One batch.  _dev: 8-bit grey images [batch] in device memory (row pitch, frame stride in bytes), depth as
+ * in vo_frames_build_dev (depth_kind 0 none, 1 float32 metres, 2 uint16 raw).  vo_tracker_track: the same
+ * from host memory (width x height, tightly packed; uploads included).  Asynchronous; params NULL: 15,
+ * 3, 0.8, 0. */
+int vo_tracker_track_dev(vo_tracker *t, const uint8_t *dev_images, int image_pitch, size_t image_frame_stride,
+                         const void *dev_depth, int depth_kind, size_t depth_frame_stride, int depth_pitch,
+                         const vo_tracker_params *params);
+int vo_tracker_track(vo_tracker *t, const uint8_t *images, const void *depth, int depth_kind,
+                     const vo_tracker_params *params);
+/* Waits for the batch and copies out (any pointer may be NULL): poses as se3 [batch][6] and as Tcw
+ * [batch][12]; n_tracked = inliers of the second solve whose map point has observations (inliers_num_,
+ * :289-300); n_inliers = the second solve's return value; the two searches' match counts; status bits.
+ * Reports sticky stage errors (dropped key-points, exhausted candidate pools) as VO_ERR_CAPACITY. */
+int vo_tracker_results(vo_tracker *t, double *poses6, double *Tcw12, int32_t *n_tracked, int32_t *n_inliers,
+                       int32_t *n_matches_last, int32_t *n_matches_local, int32_t *status);
+/* intermediate state of the last batch (tests, shims): [batch][max_features] / [batch][max_local] arrays */
+enum {
+  VO_TRACKER_ASSIGNED_LAST = 0,      /* int32: last-frame point index per feature after search 1, or -1 */
+  VO_TRACKER_ASSIGNED_LOCAL = 1,     /* int32: local point index per feature claimed by search 2, or -1 */
+  VO_TRACKER_POSE_FIRST = 2,         /* double [batch][6]: pose after the first solve */
+  VO_TRACKER_INLIERS_FIRST = 3,      /* int32 [batch]: return value of the first solve */
+  VO_TRACKER_OBSERVED_INLIERS_FIRST = 4, /* int32 [batch]: cullingOutliersBeforeLocalMap's return value */
+  VO_TRACKER_FEATURE_HAS_POINT = 5,  /* uint8: frame->mappoints_[i] != nullptr at the end */
+  VO_TRACKER_FEATURE_POINTS = 6,     /* double [..][3]: that map point's position */
+  VO_TRACKER_LOCAL_FLAGS = 7, VO_TRACKER_LOCAL_U = 8, VO_TRACKER_LOCAL_V = 9, VO_TRACKER_LOCAL_UR = 10,
+  VO_TRACKER_LOCAL_LEVEL = 11, VO_TRACKER_LOCAL_VIEWCOS = 12, /* Frame::isInFrame's outputs per local point */
+  VO_TRACKER_KEYPOINT_COUNTS = 13    /* int32 [batch] */
+};
+int vo_tracker_get(vo_tracker *t, int what, void *dst, size_t dst_bytes);
+int vo_tracker_sync(vo_tracker *t);
+/* HIP events on the launching streams around the six stages of every subsequent batch (bench.py):
+ * 0 extraction, 1 frame post-processing, 2 search vs last frame, 3 pose solve + culling, 4 isInFrame +
+ * search vs local map, 5 pose solve + count.  vo_tracker_get_timing synchronises, returns the summed
+ * milliseconds since the last call and the number of timed batches, and resets. */
+#define VO_TRACKER_STAGES 6
+int vo_tracker_set_timing(vo_tracker *t, int enabled);
+int vo_tracker_get_timing(vo_tracker *t, double *ms /*VO_TRACKER_STAGES*/, int *n_calls);
+
 /* Optimizer::solveLoopSim3(keyframe_curr, keyframe_match, inlierMappoints, Scm, fixScaleFlag)
  * (optimizer_ceres.cpp:810-1030) with PoseOnlySim3 / PoseOnlyInverseSim3 (optimizer_ceres.h:211-267):
  * problem 1 (Huber sqrt(10), <= 10 iterations), chi2 > 10 rejection in both images, then 10 (or 5

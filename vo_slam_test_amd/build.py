@@ -24,6 +24,7 @@ SOURCES = [
     ("match.hip", ["-ffp-contract=off"]),
     ("guided.hip", ["-ffp-contract=off"]),
     ("track.hip", ["-ffp-contract=off"]),
+    ("tracker.hip", ["-ffp-contract=off"]),
     ("ba.hip", ["-ffp-contract=fast"]),
     ("pose_graph.hip", ["-ffp-contract=fast"]),
     ("chol.hip", ["-ffp-contract=fast"]),

@@ -1,0 +1,639 @@
+// tracker.hip -- the tracked-frame pipeline behind the C-ABI (vo_tracker_*): what VisualOdometry::trackWithMotion +
+// trackLocalMap do per frame (reference src/visualOdometry.cpp:228-251, 286-300, 745-775, 864-886), for a batch of
+// independent camera streams that stay in HBM from the image to the pose:
+//
+//   ORB extraction (frame.cpp:22)                    vo_orb_extract_batch_dev          extraction stream
+//   Frame::Frame post-processing, grid (:27-32)      vo_frames_build_dev               tracking stream from here on
+//   searchByProjection(frame, last frame, 15)        k_track_project + vo_match_guided_dev mode 0 + k_track_scatter
+//   solvePoseOnlySE3                                 k_track_gather + k_pose_only
+//   cullingOutliersBeforeLocalMap (:864-886)         k_track_cull: outliers of the solve lose their map point
+//   searchLocalMapPoints: Frame::isInFrame (frame.cpp:145-190, with the REFINED pose) + MapPoint::predictScale
+//                                                    k_track_in_frame
+//   searchByProjection(frame, local points, 3)       vo_match_guided_dev mode 1 + k_track_scatter
+//   solvePoseOnlySE3, inlier count (:289-300)        k_track_gather + k_pose_only + k_track_count
+//
+// 23 launches per batch, no host synchronisation in between.  The extraction may run on a stream shared by several
+// trackers (vo_tracker_config.extract_stream): batch i + 1's extraction then overlaps batch i's searches and pose
+// solves (two events order them).  Round 2 kept this sequence in Python (vo_slam_test_amd/tracking.py) without the
+// culling step and with the local-map projections fixed before the first solve; host code is now C++
+// throughout, as the reference's callers are.
+#include "vo_common.h"
+
+#include <cmath>
+#include <new>
+#include <vector>
+
+#include "ba_math.h"
+
+namespace {
+
+using namespace vo;
+using namespace vo::ba;
+
+// cullingOutliersBeforeLocalMap (visualOdometry.cpp:864-886) on the pose solver's observation list: an outlier's
+// feature loses its map point (`mappoints_[i] = nullptr`, and with it the "holds an observed point" mark the local-map
+// search tests at matcher.cpp:314); inliers whose point has observations are counted (the function's return value).
+// Also marks the last-frame points that were matched at all: matched points -- kept or culled -- carry
+// visualIdxOfFrame_ == frame id (:752, :881) and are skipped by searchLocalMapPoints (:765).
+__global__ __launch_bounds__(256) void k_track_cull(int cap, const int *ranges, const int *index, const uint8_t *outlier,
+                                                    const int *assigned, int last_stride, uint8_t *fhas, uint8_t *fobs,
+                                                    uint8_t *last_matched, int *n_observed_inliers) {
+  __shared__ int s_cnt[4];
+  const int f = blockIdx.x, tid = threadIdx.x;
+  const long long o = (long long)f * cap;
+  const int start = ranges[2 * f], count = ranges[2 * f + 1];
+  for (int i = tid; i < cap; i += 256) {
+    const int a = assigned[o + i];
+    if (a >= 0) last_matched[(long long)f * last_stride + a] = 1;
+  }
+  int local = 0;
+  for (int d = tid; d < count; d += 256) {
+    const int i = index[start + d];
+    if (outlier[start + d]) {
+      fhas[o + i] = 0;
+      fobs[o + i] = 0;
+    } else if (fobs[o + i]) {
+      local++;
+    }
+  }
+  for (int s = 32; s >= 1; s >>= 1) local += __shfl_xor(local, s);
+  if ((tid & 63) == 0) s_cnt[tid >> 6] = local;
+  __syncthreads();
+  if (tid == 0) n_observed_inliers[f] = s_cnt[0] + s_cnt[1] + s_cnt[2] + s_cnt[3];
+}
+
+// Frame::isInFrame (frame.cpp:145-190) and MapPoint::predictScale (mappoint.cpp:182-196) for the local map points of
+// every frame, with Tcw = exp(pose) of the first solve (frame->setPose, optimizer_ceres.cpp:311).  Arithmetic as the
+// reference has it: the transform in double (Sophus SE3 * Vector3d = Eigen's quaternion rotation), z, u, v, the
+// distance and the view cosine narrowed to float where the reference narrows them, logf as the correctly rounded
+// float of the double logarithm (the reference calls glibc's logf: DESIGN section 3).
+// pflags bit 0: the point exists, is not bad and is not already in the frame; bit 1: it has observations.
+__global__ __launch_bounds__(256) void k_track_in_frame(int nq, int stride, const double *pose6, const double *points,
+                                                        const double *normals, const float *min_dist, const float *max_dist,
+                                                        const uint8_t *pflags, const int *link, const uint8_t *last_matched,
+                                                        int last_stride, float fx, float fy, float cx, float cy, float bf,
+                                                        float xmin, float xmax, float ymin, float ymax, float log_sf1,
+                                                        int n_levels, uint8_t *qflags, float *qu, float *qv, float *qur,
+                                                        int *qlevel, float *qviewcos) {
+  __shared__ double s_T[10];  // q (w, x, y, z), t, Ow
+  const int f = blockIdx.y, q = blockIdx.x * 256 + threadIdx.x;
+  if (threadIdx.x == 0) {
+    const Se3 T = se3_exp(pose6 + 6 * (long long)f);
+    // Ow_ = Tcw.inverse().translation() (frame.cpp:103): the conjugate rotation of -t
+    const double qc[4] = {T.q[0], -T.q[1], -T.q[2], -T.q[3]}, nt[3] = {-T.t[0], -T.t[1], -T.t[2]};
+    double ow[3];
+    quat_rotate(qc, nt, ow);
+    for (int k = 0; k < 4; k++) s_T[k] = T.q[k];
+    for (int k = 0; k < 3; k++) s_T[4 + k] = T.t[k], s_T[7 + k] = ow[k];
+  }
+  __syncthreads();
+  if (q >= nq) return;
+  const long long o = (long long)f * stride + q;
+  const unsigned pf = pflags[o];
+  uint8_t out = 0;
+  float u = 0.f, v = 0.f, ur = 0.f, vc = 0.f;
+  int level = 0;
+  const int lk = link ? link[o] : -1;
+  const bool in_frame_already = lk >= 0 && last_matched[(long long)f * last_stride + lk] != 0;  // :765
+  if ((pf & 1u) && !in_frame_already) {
+    const double *p = points + 3 * o, *nv = normals + 3 * o;
+    const double qq[4] = {s_T[0], s_T[1], s_T[2], s_T[3]};
+    double rp[3];
+    quat_rotate(qq, p, rp);
+    const double x = rp[0] + s_T[4], y = rp[1] + s_T[5], zc = rp[2] + s_T[6];
+    const float z = (float)zc;
+    if (!(z < 0.0f)) {  // :153-154
+      u = (float)((double)fx * x / zc + (double)cx);  // Camera::camera2pixel, camera.cpp:72-75 (float members widened)
+      v = (float)((double)fy * y / zc + (double)cy);
+      if (!(u < xmin || u > xmax) && !(v < ymin || v > ymax)) {  // :159-164
+        const double l0 = p[0] - s_T[7], l1 = p[1] - s_T[8], l2 = p[2] - s_T[9];
+        const float dist = (float)sqrt(l0 * l0 + l1 * l1 + l2 * l2);  // :167
+        const float mind = 0.8f * min_dist[o], maxd = 1.2f * max_dist[o];  // mappoint.cpp:391-401
+        if (!(dist < mind || dist > maxd)) {
+          vc = (float)(l0 * nv[0] + l1 * nv[1] + l2 * nv[2]) / dist;  // :176
+          if (!(vc < 0.5f)) {
+            out = (uint8_t)(1u | (pf & 2u));
+            ur = u - bf / z;  // :184
+            const float ratio = max_dist[o] / dist;  // mappoint.cpp:187
+            const float lg = (float)log((double)ratio);
+            const int s = (int)ceilf(lg / log_sf1);
+            level = s < 0 ? 0 : (s >= n_levels ? n_levels - 1 : s);
+          }
+        }
+      }
+    }
+  }
+  if (!out) u = v = ur = vc = 0.f, level = 0;
+  qflags[o] = out, qu[o] = u, qv[o] = v, qur[o] = ur, qlevel[o] = level, qviewcos[o] = vc;
+}
+
+// trackLocalMap's inlier count (visualOdometry.cpp:289-300): features that hold a map point with observations and are
+// no outlier of the second solve; and the per-frame status word.
+__global__ __launch_bounds__(256) void k_track_count(int cap, const int *ranges, const int *index, const uint8_t *outlier,
+                                                     const uint8_t *fobs, const int *n_first, const int *n_observed_first,
+                                                     const int *ninl_first, int *n_tracked, int *status) {
+  __shared__ int s_cnt[4];
+  const int f = blockIdx.x, tid = threadIdx.x;
+  const long long o = (long long)f * cap;
+  const int start = ranges[2 * f], count = ranges[2 * f + 1];
+  int local = 0;
+  for (int d = tid; d < count; d += 256)
+    if (!outlier[start + d] && fobs[o + index[start + d]]) local++;
+  for (int s = 32; s >= 1; s >>= 1) local += __shfl_xor(local, s);
+  if ((tid & 63) == 0) s_cnt[tid >> 6] = local;
+  __syncthreads();
+  if (tid == 0) {
+    const int n = s_cnt[0] + s_cnt[1] + s_cnt[2] + s_cnt[3];
+    n_tracked[f] = n;
+    int st = 0;
+    if (n_first[f] < 20) st |= VO_TRACK_FEW_MATCHES;               // visualOdometry.cpp:247-248
+    if (n_observed_first[f] < 10) st |= VO_TRACK_FEW_INLIERS;      // :253
+    (void)ninl_first;
+    status[f] = st;
+  }
+}
+
+constexpr int kStages = VO_TRACKER_STAGES;
+
+}  // namespace
+
+struct vo_tracker {
+  vo_tracker_config cfg{};
+  vo_orb *orb = nullptr;
+  vo_frames *frames = nullptr;
+  hipStream_t st = nullptr, est = nullptr;
+  bool own_st = false, own_est = false;
+  hipEvent_t ev_extract = nullptr, ev_build = nullptr;
+  bool have_build = false;
+  int B = 0, kcap = 0, cap = 0, n_levels = 0, n_last = 0, n_local = 0, nq_last = 0, nq_local = 0;
+  float sf[16] = {0};
+  // device state
+  DevBuf kps, desc, cnt, images, depth;
+  DevBuf q0_flags, q0_u, q0_v, q0_aux, q0_level, q0_angle, q0_desc, p0, pf0, last_matched;
+  DevBuf q1_flags, q1_u, q1_v, q1_aux, q1_level, q1_viewcos, q1_desc, p1, nrm1, mind1, maxd1, pf1, link1;
+  DevBuf Tcw, pose0, pose, pose_first;
+  DevBuf assigned, assigned_first, nm, nm_first, fpoint, fhas, fobs, pts, obs, isg, ranges, index, outlier, ninl, ninl_first,
+      nobs_first, ntracked, status;
+  PinnedBuf stage;
+  bool have_link = false;
+  // timing
+  bool timing = false;
+  std::vector<hipEvent_t> tev;  // 2 per stage
+  double tms[kStages] = {0};
+  int tcalls = 0;
+  bool tpending = false;
+};
+
+namespace {
+
+int alloc_all(vo_tracker *t) {
+  const size_t B = t->B, nl = (size_t)t->n_last, nm = (size_t)t->n_local, cap = t->cap, kc = t->kcap;
+  VO_CHECK(t->kps.reserve(B * kc * sizeof(vo_keypoint)));
+  VO_CHECK(t->desc.reserve(B * kc * 32));
+  VO_CHECK(t->cnt.reserve(B * 4 + 64));
+  VO_CHECK(t->q0_flags.reserve(B * nl));
+  VO_CHECK(t->q0_u.reserve(B * nl * 4));
+  VO_CHECK(t->q0_v.reserve(B * nl * 4));
+  VO_CHECK(t->q0_aux.reserve(B * nl * 4));
+  VO_CHECK(t->q0_level.reserve(B * nl * 4));
+  VO_CHECK(t->q0_angle.reserve(B * nl * 4));
+  VO_CHECK(t->q0_desc.reserve(B * nl * 32));
+  VO_CHECK(t->p0.reserve(B * nl * 24));
+  VO_CHECK(t->pf0.reserve(B * nl));
+  VO_CHECK(t->last_matched.reserve(B * nl + 64));
+  VO_CHECK(t->q1_flags.reserve(B * nm));
+  VO_CHECK(t->q1_u.reserve(B * nm * 4));
+  VO_CHECK(t->q1_v.reserve(B * nm * 4));
+  VO_CHECK(t->q1_aux.reserve(B * nm * 4));
+  VO_CHECK(t->q1_level.reserve(B * nm * 4));
+  VO_CHECK(t->q1_viewcos.reserve(B * nm * 4));
+  VO_CHECK(t->q1_desc.reserve(B * nm * 32));
+  VO_CHECK(t->p1.reserve(B * nm * 24));
+  VO_CHECK(t->nrm1.reserve(B * nm * 24));
+  VO_CHECK(t->mind1.reserve(B * nm * 4));
+  VO_CHECK(t->maxd1.reserve(B * nm * 4));
+  VO_CHECK(t->pf1.reserve(B * nm));
+  VO_CHECK(t->link1.reserve(B * nm * 4));
+  VO_CHECK(t->Tcw.reserve(B * 96 + 64));
+  VO_CHECK(t->pose0.reserve(B * 48));
+  VO_CHECK(t->pose.reserve(B * 48));  // Tcw, then the intrinsics as doubles
+  VO_CHECK(t->pose_first.reserve(B * 48));
+  VO_CHECK(t->assigned.reserve(B * cap * 4));
+  VO_CHECK(t->assigned_first.reserve(B * cap * 4));
+  VO_CHECK(t->nm.reserve(B * 4 + 64));
+  VO_CHECK(t->nm_first.reserve(B * 4 + 64));
+  VO_CHECK(t->fpoint.reserve(B * cap * 24));
+  VO_CHECK(t->fhas.reserve(B * cap));
+  VO_CHECK(t->fobs.reserve(B * cap));
+  VO_CHECK(t->pts.reserve(B * cap * 24));
+  VO_CHECK(t->obs.reserve(B * cap * 24));
+  VO_CHECK(t->isg.reserve(B * cap * 8));
+  VO_CHECK(t->ranges.reserve(B * 8 + 64));
+  VO_CHECK(t->index.reserve(B * cap * 4));
+  VO_CHECK(t->outlier.reserve(B * cap));
+  VO_CHECK(t->ninl.reserve(B * 4 + 64));
+  VO_CHECK(t->ninl_first.reserve(B * 4 + 64));
+  VO_CHECK(t->nobs_first.reserve(B * 4 + 64));
+  VO_CHECK(t->ntracked.reserve(B * 4 + 64));
+  VO_CHECK(t->status.reserve(B * 4 + 64));
+  return VO_OK;
+}
+
+// host [B][n][elem] -> device [B][stride][elem], zero padding behind n
+int put_rows(vo_tracker *t, DevBuf &dst, const void *src, int n, int stride, size_t elem, const char *what) {
+  const size_t B = t->B;
+  VO_HIP_CHECK(hipMemsetAsync(dst.p, 0, B * stride * elem, t->st));
+  if (n > 0 && src)
+    VO_HIP_CHECK(hipMemcpy2DAsync(dst.p, (size_t)stride * elem, src, (size_t)n * elem, (size_t)n * elem, B,
+                                  hipMemcpyHostToDevice, t->st));
+  (void)what;
+  return VO_OK;
+}
+
+struct StageTimer {
+  vo_tracker *t;
+  int stage;
+  hipStream_t s;
+  StageTimer(vo_tracker *t_, int stage_, hipStream_t s_) : t(t_), stage(stage_), s(s_) {
+    if (t->timing) (void)hipEventRecord(t->tev[2 * stage], s);
+  }
+  ~StageTimer() {
+    if (t->timing) (void)hipEventRecord(t->tev[2 * stage + 1], s);
+  }
+};
+
+int collect_timing(vo_tracker *t) {
+  if (!t->tpending) return VO_OK;
+  VO_HIP_CHECK(hipStreamSynchronize(t->st));
+  if (t->est != t->st) VO_HIP_CHECK(hipStreamSynchronize(t->est));
+  for (int s = 0; s < kStages; s++) {
+    float ms = 0.f;
+    if (hipEventElapsedTime(&ms, t->tev[2 * s], t->tev[2 * s + 1]) == hipSuccess) t->tms[s] += ms;
+  }
+  t->tcalls++;
+  t->tpending = false;
+  return VO_OK;
+}
+
+int solve_pose(vo_tracker *t) {
+  VO_CHECK(vo_track_gather_dev(t->frames, 0, t->B, t->fpoint.as<double>(), t->fhas.as<uint8_t>(), t->sf, t->n_levels,
+                               t->pts.as<double>(), t->obs.as<double>(), t->isg.as<double>(), t->ranges.as<int32_t>(),
+                               t->index.as<int32_t>(), t->st));
+  return vo_pose_only_solve_ranges_dev(t->B, t->ranges.as<int32_t>(), t->pts.as<double>(), t->obs.as<double>(),
+                                       t->isg.as<double>(), t->Tcw.as<double>() + (size_t)t->B * 12, t->pose.as<double>(),
+                                       t->outlier.as<uint8_t>(), t->ninl.as<int32_t>(), nullptr, t->st);
+}
+
+int run_pipeline(vo_tracker *t, const uint8_t *dev_images, int img_pitch, size_t img_frame_stride, const void *dev_depth,
+                 int depth_kind, size_t depth_frame_stride, int depth_pitch, const vo_tracker_params *prm) {
+  if (t->timing) VO_CHECK(collect_timing(t));
+  const int B = t->B;
+  hipStream_t st = t->st, est = t->est;
+  const vo_tracker_config &c = t->cfg;
+  vo_tracker_params P;
+  if (prm) {
+    P = *prm;
+  } else {
+    P.radius = 15.f, P.th_radius = 3.f, P.ratio = 0.8f, P.direction = 0;
+  }
+  // ---- extraction (its stream may be shared with other trackers)
+  if (est != st && t->have_build) VO_HIP_CHECK(hipStreamWaitEvent(est, t->ev_build, 0));  // last batch's key-points consumed
+  {
+    StageTimer tm(t, 0, est);
+    VO_CHECK(vo_orb_extract_batch_dev(t->orb, dev_images, B, c.width, c.height, img_pitch, img_frame_stride,
+                                      t->kps.as<vo_keypoint>(), t->desc.as<uint8_t>(), t->kcap, t->cnt.as<int32_t>()));
+  }
+  VO_HIP_CHECK(hipEventRecord(t->ev_extract, est));
+  if (est != st) VO_HIP_CHECK(hipStreamWaitEvent(st, t->ev_extract, 0));
+  // ---- Frame::Frame post-processing
+  {
+    StageTimer tm(t, 1, st);
+    VO_CHECK(vo_frames_build_dev(t->frames, 0, B, t->kps.as<vo_keypoint>(), t->desc.as<uint8_t>(), t->cnt.as<int32_t>(),
+                                 t->kcap, dev_depth, depth_kind, depth_frame_stride, depth_pitch, c.inv_depth_scale, st));
+  }
+  if (est != st) {
+    VO_HIP_CHECK(hipEventRecord(t->ev_build, st));
+    t->have_build = true;
+  }
+  // ---- searchByProjection against the last frame
+  const size_t capB = (size_t)B * t->cap;
+  vo_guided_queries q{};
+  vo_guided_params gp{};
+  gp.n_levels = t->n_levels, gp.scale_factors = t->sf;
+  {
+    StageTimer tm(t, 2, st);
+    const float cam4[4] = {c.intrinsics[0], c.intrinsics[1], c.intrinsics[2], c.intrinsics[3]};
+    VO_CHECK(vo_track_project_dev(B, t->nq_last, t->n_last, t->Tcw.as<double>(), t->p0.as<double>(), t->pf0.as<uint8_t>(),
+                                  cam4, 0, c.width, 0, c.height, t->q0_flags.as<uint8_t>(), t->q0_u.as<float>(),
+                                  t->q0_v.as<float>(), t->q0_aux.as<float>(), st));
+    VO_HIP_CHECK(hipMemsetAsync(t->assigned.p, 0xff, capB * 4, st));
+    VO_HIP_CHECK(hipMemsetAsync(t->fhas.p, 0, capB, st));
+    VO_HIP_CHECK(hipMemsetAsync(t->fobs.p, 0, capB, st));
+    VO_HIP_CHECK(hipMemsetAsync(t->last_matched.p, 0, (size_t)B * t->n_last, st));
+    VO_HIP_CHECK(hipMemcpyAsync(t->pose.p, t->pose0.p, (size_t)B * 48, hipMemcpyDeviceToDevice, st));
+    q.n_queries = t->nq_last, q.stride = t->n_last, q.flags = t->q0_flags.as<uint8_t>(), q.u = t->q0_u.as<float>();
+    q.v = t->q0_v.as<float>(), q.aux = t->q0_aux.as<float>(), q.level = t->q0_level.as<int32_t>();
+    q.angle = t->q0_angle.as<float>(), q.desc = t->q0_desc.as<uint8_t>();
+    gp.mode = 0, gp.radius = P.radius, gp.bf = c.intrinsics[4], gp.direction = P.direction, gp.check_rot = 1;
+    VO_CHECK(vo_match_guided_dev(t->frames, 0, B, &q, &gp, nullptr, t->assigned.as<int32_t>(), nullptr,
+                                 t->nm_first.as<int32_t>(), 0, st));
+    VO_CHECK(vo_track_scatter_dev(t->frames, 0, B, t->assigned.as<int32_t>(), t->p0.as<double>(), t->q0_flags.as<uint8_t>(),
+                                  t->n_last, t->fpoint.as<double>(), t->fhas.as<uint8_t>(), t->fobs.as<uint8_t>(), st));
+  }
+  // ---- solvePoseOnlySE3, cullingOutliersBeforeLocalMap
+  {
+    StageTimer tm(t, 3, st);
+    VO_CHECK(solve_pose(t));
+    hipLaunchKernelGGL(k_track_cull, dim3(B), dim3(256), 0, st, t->cap, t->ranges.as<int>(), t->index.as<int>(),
+                       t->outlier.as<uint8_t>(), t->assigned.as<int>(), t->n_last, t->fhas.as<uint8_t>(), t->fobs.as<uint8_t>(),
+                       t->last_matched.as<uint8_t>(), t->nobs_first.as<int>());
+    VO_HIP_CHECK(hipMemcpyAsync(t->assigned_first.p, t->assigned.p, capB * 4, hipMemcpyDeviceToDevice, st));
+    VO_HIP_CHECK(hipMemcpyAsync(t->pose_first.p, t->pose.p, (size_t)B * 48, hipMemcpyDeviceToDevice, st));
+    VO_HIP_CHECK(hipMemcpyAsync(t->ninl_first.p, t->ninl.p, (size_t)B * 4, hipMemcpyDeviceToDevice, st));
+  }
+  // ---- searchLocalMapPoints: isInFrame with the refined pose, then the search; occupied = holds an observed point
+  {
+    StageTimer tm(t, 4, st);
+    if (t->nq_local > 0) {
+      hipLaunchKernelGGL(k_track_in_frame, dim3((t->nq_local + 255) / 256, B), dim3(256), 0, st, t->nq_local, t->n_local,
+                         t->pose.as<double>(), t->p1.as<double>(), t->nrm1.as<double>(), t->mind1.as<float>(),
+                         t->maxd1.as<float>(), t->pf1.as<uint8_t>(), t->have_link ? t->link1.as<int>() : (const int *)nullptr,
+                         t->last_matched.as<uint8_t>(), t->n_last, c.intrinsics[0], c.intrinsics[1], c.intrinsics[2],
+                         c.intrinsics[3], c.intrinsics[4], 0.f, (float)c.width, 0.f, (float)c.height,
+                         (float)log((double)t->sf[1]), t->n_levels, t->q1_flags.as<uint8_t>(), t->q1_u.as<float>(),
+                         t->q1_v.as<float>(), t->q1_aux.as<float>(), t->q1_level.as<int>(), t->q1_viewcos.as<float>());
+      VO_HIP_CHECK(hipMemsetAsync(t->assigned.p, 0xff, capB * 4, st));
+      q = vo_guided_queries{};
+      q.n_queries = t->nq_local, q.stride = t->n_local, q.flags = t->q1_flags.as<uint8_t>(), q.u = t->q1_u.as<float>();
+      q.v = t->q1_v.as<float>(), q.aux = t->q1_aux.as<float>(), q.level = t->q1_level.as<int32_t>();
+      q.viewcos = t->q1_viewcos.as<float>(), q.desc = t->q1_desc.as<uint8_t>();
+      gp.mode = 1, gp.radius = P.th_radius, gp.ratio = P.ratio, gp.bf = 0.f, gp.direction = 0, gp.check_rot = 0;
+      VO_CHECK(vo_match_guided_dev(t->frames, 0, B, &q, &gp, t->fobs.as<uint8_t>(), t->assigned.as<int32_t>(), nullptr,
+                                   t->nm.as<int32_t>(), 0, st));
+      VO_CHECK(vo_track_scatter_dev(t->frames, 0, B, t->assigned.as<int32_t>(), t->p1.as<double>(), t->q1_flags.as<uint8_t>(),
+                                    t->n_local, t->fpoint.as<double>(), t->fhas.as<uint8_t>(), t->fobs.as<uint8_t>(), st));
+    } else {
+      VO_HIP_CHECK(hipMemsetAsync(t->assigned.p, 0xff, capB * 4, st));
+      VO_HIP_CHECK(hipMemsetAsync(t->nm.p, 0, (size_t)B * 4, st));
+    }
+  }
+  // ---- second solvePoseOnlySE3 and the inlier count of trackLocalMap
+  {
+    StageTimer tm(t, 5, st);
+    VO_CHECK(solve_pose(t));
+    hipLaunchKernelGGL(k_track_count, dim3(B), dim3(256), 0, st, t->cap, t->ranges.as<int>(), t->index.as<int>(),
+                       t->outlier.as<uint8_t>(), t->fobs.as<uint8_t>(), t->nm_first.as<int>(), t->nobs_first.as<int>(),
+                       t->ninl_first.as<int>(), t->ntracked.as<int>(), t->status.as<int>());
+  }
+  VO_HIP_CHECK(hipGetLastError());
+  t->tpending = t->timing;
+  return VO_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int vo_tracker_create(vo_tracker **out, const vo_tracker_config *cfg) {
+  if (!out || !cfg || cfg->batch < 1 || cfg->width < 64 || cfg->height < 64 || cfg->max_last < 1 || cfg->max_local < 0)
+    return VO_ERR_INVALID;
+  VO_CHECK(vo::ensure_device());
+  vo_tracker *t = new (std::nothrow) vo_tracker();
+  if (!t) {
+    vo::set_error("vo_tracker_create: out of host memory");
+    return VO_ERR_HIP;
+  }
+  t->cfg = *cfg;
+  t->B = cfg->batch;
+  int rc = vo_orb_create(&t->orb, cfg->nfeatures > 0 ? cfg->nfeatures : 1000, cfg->scale_factor > 1.f ? cfg->scale_factor : 1.2f,
+                         cfg->nlevels > 0 ? cfg->nlevels : 8, cfg->ini_th_fast > 0 ? cfg->ini_th_fast : 20,
+                         cfg->min_th_fast > 0 ? cfg->min_th_fast : 7);
+  if (rc != VO_OK) {
+    delete t;
+    return rc;
+  }
+  auto fail = [&](int code) {
+    vo_tracker_destroy(t);
+    return code;
+  };
+  if (cfg->stream) {
+    t->st = (hipStream_t)cfg->stream;
+  } else {
+    int lo = 0, hi = 0;
+    (void)hipDeviceGetStreamPriorityRange(&lo, &hi);
+    if (hipStreamCreateWithPriority(&t->st, hipStreamNonBlocking, hi) != hipSuccess) return fail(VO_ERR_HIP);
+    t->own_st = true;
+  }
+  if (cfg->extract_stream) {
+    t->est = (hipStream_t)cfg->extract_stream;
+  } else if (cfg->single_stream) {
+    t->est = t->st;
+  } else {
+    if (hipStreamCreateWithFlags(&t->est, hipStreamNonBlocking) != hipSuccess) return fail(VO_ERR_HIP);
+    t->own_est = true;
+  }
+  if ((rc = vo_orb_set_stream(t->orb, t->est)) != VO_OK) return fail(rc);
+  if (hipEventCreateWithFlags(&t->ev_extract, hipEventDisableTiming) != hipSuccess ||
+      hipEventCreateWithFlags(&t->ev_build, hipEventDisableTiming) != hipSuccess)
+    return fail(VO_ERR_HIP);
+  t->n_levels = vo_orb_levels(t->orb);
+  if ((rc = vo_orb_scale_factors(t->orb, t->sf, nullptr)) != VO_OK) return fail(rc);
+  t->kcap = vo_orb_max_keypoints(t->orb);
+  t->cap = cfg->max_features > 0 ? cfg->max_features : std::max(256, (t->kcap + 63) / 64 * 64);
+  t->n_last = cfg->max_last, t->n_local = std::max(cfg->max_local, 1);
+  if ((rc = vo_frames_create(&t->frames, t->B, t->cap)) != VO_OK) return fail(rc);
+  if ((rc = vo_frames_set_camera(t->frames, cfg->intrinsics, cfg->has_distortion ? cfg->dist_coef : nullptr, (float)cfg->width,
+                                 (float)cfg->height)) != VO_OK)
+    return fail(rc);
+  if ((rc = alloc_all(t)) != VO_OK) return fail(rc);
+  // the intrinsics as doubles behind the Tcw block (the pose solver reads them from device memory)
+  {
+    double cam5d[5];
+    for (int i = 0; i < 5; i++) cam5d[i] = (double)cfg->intrinsics[i];
+    if (hipMemcpy(t->Tcw.as<double>() + (size_t)t->B * 12, cam5d, sizeof(cam5d), hipMemcpyHostToDevice) != hipSuccess)
+      return fail(VO_ERR_HIP);
+  }
+  t->tev.resize(2 * kStages, nullptr);
+  *out = t;
+  return VO_OK;
+}
+
+void vo_tracker_destroy(vo_tracker *t) {
+  if (!t) return;
+  if (t->st) (void)hipStreamSynchronize(t->st);
+  if (t->est && t->est != t->st) (void)hipStreamSynchronize(t->est);
+  for (hipEvent_t e : t->tev)
+    if (e) (void)hipEventDestroy(e);
+  if (t->ev_extract) (void)hipEventDestroy(t->ev_extract);
+  if (t->ev_build) (void)hipEventDestroy(t->ev_build);
+  if (t->frames) vo_frames_destroy(t->frames);
+  if (t->orb) vo_orb_destroy(t->orb);
+  for (DevBuf *b : {&t->kps, &t->desc, &t->cnt, &t->images, &t->depth, &t->q0_flags, &t->q0_u, &t->q0_v, &t->q0_aux, &t->q0_level,
+                    &t->q0_angle, &t->q0_desc, &t->p0, &t->pf0, &t->last_matched, &t->q1_flags, &t->q1_u, &t->q1_v, &t->q1_aux,
+                    &t->q1_level, &t->q1_viewcos, &t->q1_desc, &t->p1, &t->nrm1, &t->mind1, &t->maxd1, &t->pf1, &t->link1, &t->Tcw,
+                    &t->pose0, &t->pose, &t->pose_first, &t->assigned, &t->assigned_first, &t->nm, &t->nm_first, &t->fpoint,
+                    &t->fhas, &t->fobs, &t->pts, &t->obs, &t->isg, &t->ranges, &t->index, &t->outlier, &t->ninl, &t->ninl_first,
+                    &t->nobs_first, &t->ntracked, &t->status})
+    b->release();
+  if (t->own_st && t->st) (void)hipStreamDestroy(t->st);
+  if (t->own_est && t->est) (void)hipStreamDestroy(t->est);
+  delete t;
+}
+
+int vo_tracker_info(const vo_tracker *t, int *batch, int *max_features, int *max_keypoints, int *n_levels) {
+  if (!t) return VO_ERR_INVALID;
+  if (batch) *batch = t->B;
+  if (max_features) *max_features = t->cap;
+  if (max_keypoints) *max_keypoints = t->kcap;
+  if (n_levels) *n_levels = t->n_levels;
+  return VO_OK;
+}
+
+vo_orb *vo_tracker_extractor(vo_tracker *t) { return t ? t->orb : nullptr; }
+vo_frames *vo_tracker_frames(vo_tracker *t) { return t ? t->frames : nullptr; }
+void *vo_tracker_stream(vo_tracker *t) { return t ? (void *)t->st : nullptr; }
+
+int vo_tracker_set_last_frame(vo_tracker *t, int n, const double *Tcw12, const double *points, const uint8_t *flags,
+                              const int32_t *octave, const float *angle, const uint8_t *desc) {
+  if (!t || n < 0 || n > t->n_last || !Tcw12 || (n > 0 && (!points || !flags || !octave || !angle || !desc)))
+    return VO_ERR_INVALID;
+  const int B = t->B;
+  // pose6 = log(Tcw) on the host (the solver's start value; Frame::setPose keeps the SE3 itself)
+  std::vector<double> p6((size_t)B * 6);
+  for (int f = 0; f < B; f++) VO_CHECK(vo_se3_log(Tcw12 + 12 * f, Tcw12 + 12 * f + 9, p6.data() + 6 * f));
+  VO_CHECK(t->stage.reserve((size_t)B * 144));
+  memcpy(t->stage.data(), Tcw12, (size_t)B * 96);
+  memcpy(t->stage.data() + (size_t)B * 96, p6.data(), (size_t)B * 48);
+  VO_HIP_CHECK(hipMemcpyAsync(t->Tcw.p, t->stage.data(), (size_t)B * 96, hipMemcpyHostToDevice, t->st));
+  VO_HIP_CHECK(hipMemcpyAsync(t->pose0.p, t->stage.data() + (size_t)B * 96, (size_t)B * 48, hipMemcpyHostToDevice, t->st));
+  VO_CHECK(put_rows(t, t->p0, points, n, t->n_last, 24, "points"));
+  VO_CHECK(put_rows(t, t->pf0, flags, n, t->n_last, 1, "flags"));
+  VO_CHECK(put_rows(t, t->q0_level, octave, n, t->n_last, 4, "octave"));
+  VO_CHECK(put_rows(t, t->q0_angle, angle, n, t->n_last, 4, "angle"));
+  VO_CHECK(put_rows(t, t->q0_desc, desc, n, t->n_last, 32, "desc"));
+  t->nq_last = n;
+  VO_HIP_CHECK(hipStreamSynchronize(t->st));  // the caller's arrays and the staging block are free again
+  return VO_OK;
+}
+
+int vo_tracker_set_local_map(vo_tracker *t, int n, const double *points, const double *normals, const float *min_distance,
+                             const float *max_distance, const uint8_t *flags, const int32_t *link, const uint8_t *desc) {
+  if (!t || n < 0 || n > t->n_local || (n > 0 && (!points || !normals || !min_distance || !max_distance || !flags || !desc)))
+    return VO_ERR_INVALID;
+  VO_CHECK(put_rows(t, t->p1, points, n, t->n_local, 24, "points"));
+  VO_CHECK(put_rows(t, t->nrm1, normals, n, t->n_local, 24, "normals"));
+  VO_CHECK(put_rows(t, t->mind1, min_distance, n, t->n_local, 4, "min_distance"));
+  VO_CHECK(put_rows(t, t->maxd1, max_distance, n, t->n_local, 4, "max_distance"));
+  VO_CHECK(put_rows(t, t->pf1, flags, n, t->n_local, 1, "flags"));
+  VO_CHECK(put_rows(t, t->q1_desc, desc, n, t->n_local, 32, "desc"));
+  t->have_link = link != nullptr;
+  if (link) VO_CHECK(put_rows(t, t->link1, link, n, t->n_local, 4, "link"));
+  t->nq_local = n;
+  VO_HIP_CHECK(hipStreamSynchronize(t->st));
+  return VO_OK;
+}
+
+int vo_tracker_track_dev(vo_tracker *t, const uint8_t *dev_images, int image_pitch, size_t image_frame_stride,
+                         const void *dev_depth, int depth_kind, size_t depth_frame_stride, int depth_pitch,
+                         const vo_tracker_params *params) {
+  if (!t || !dev_images || image_pitch < t->cfg.width || depth_kind < 0 || depth_kind > 2 || (depth_kind && !dev_depth))
+    return VO_ERR_INVALID;
+  return run_pipeline(t, dev_images, image_pitch, image_frame_stride, dev_depth, depth_kind, depth_frame_stride, depth_pitch,
+                      params);
+}
+
+int vo_tracker_track(vo_tracker *t, const uint8_t *images, const void *depth, int depth_kind, const vo_tracker_params *params) {
+  if (!t || !images || depth_kind < 0 || depth_kind > 2 || (depth_kind && !depth)) return VO_ERR_INVALID;
+  const size_t B = t->B, npx = (size_t)t->cfg.width * t->cfg.height, dsz = depth_kind == 1 ? 4 : depth_kind == 2 ? 2 : 0;
+  VO_CHECK(t->images.reserve(B * npx));
+  if (dsz) VO_CHECK(t->depth.reserve(B * npx * dsz));
+  // uploads on the extraction stream (the depth is first read behind the extraction, which the tracking stream waits for)
+  if (t->est != t->st && t->have_build) VO_HIP_CHECK(hipStreamWaitEvent(t->est, t->ev_build, 0));
+  VO_HIP_CHECK(hipMemcpyAsync(t->images.p, images, B * npx, hipMemcpyHostToDevice, t->est));
+  if (dsz) VO_HIP_CHECK(hipMemcpyAsync(t->depth.p, depth, B * npx * dsz, hipMemcpyHostToDevice, t->est));
+  return run_pipeline(t, t->images.as<uint8_t>(), t->cfg.width, npx, dsz ? t->depth.p : nullptr, depth_kind, npx * dsz,
+                      t->cfg.width * (int)dsz, params);
+}
+
+int vo_tracker_results(vo_tracker *t, double *poses6, double *Tcw12, int32_t *n_tracked, int32_t *n_inliers,
+                       int32_t *n_matches_last, int32_t *n_matches_local, int32_t *status) {
+  if (!t) return VO_ERR_INVALID;
+  const size_t B = t->B;
+  VO_CHECK(t->stage.reserve(B * (48 + 5 * 4) + 64));
+  uint8_t *h = t->stage.data();
+  VO_HIP_CHECK(hipMemcpyAsync(h, t->pose.p, B * 48, hipMemcpyDeviceToHost, t->st));
+  const DevBuf *src[5] = {&t->ntracked, &t->ninl, &t->nm_first, &t->nm, &t->status};
+  for (int k = 0; k < 5; k++) VO_HIP_CHECK(hipMemcpyAsync(h + B * 48 + k * B * 4, src[k]->p, B * 4, hipMemcpyDeviceToHost, t->st));
+  VO_HIP_CHECK(hipStreamSynchronize(t->st));
+  const double *p6 = reinterpret_cast<const double *>(h);
+  if (poses6) memcpy(poses6, p6, B * 48);
+  if (Tcw12)
+    for (size_t f = 0; f < B; f++) VO_CHECK(vo_se3_exp(p6 + 6 * f, Tcw12 + 12 * f, Tcw12 + 12 * f + 9));
+  int32_t *dst[5] = {n_tracked, n_inliers, n_matches_last, n_matches_local, status};
+  for (int k = 0; k < 5; k++)
+    if (dst[k]) memcpy(dst[k], h + B * 48 + k * B * 4, B * 4);
+  // sticky error flags of the stages (dropped key-points, exhausted candidate pools)
+  VO_CHECK(vo_orb_sync(t->orb));
+  VO_CHECK(vo_match_guided_status(t->frames, t->st));
+  return VO_OK;
+}
+
+int vo_tracker_get(vo_tracker *t, int what, void *dst, size_t dst_bytes) {
+  if (!t || !dst) return VO_ERR_INVALID;
+  const size_t B = t->B, cap = t->cap;
+  const DevBuf *b = nullptr;
+  size_t bytes = 0;
+  switch (what) {
+    case VO_TRACKER_ASSIGNED_LAST: b = &t->assigned_first, bytes = B * cap * 4; break;
+    case VO_TRACKER_ASSIGNED_LOCAL: b = &t->assigned, bytes = B * cap * 4; break;
+    case VO_TRACKER_POSE_FIRST: b = &t->pose_first, bytes = B * 48; break;
+    case VO_TRACKER_INLIERS_FIRST: b = &t->ninl_first, bytes = B * 4; break;
+    case VO_TRACKER_OBSERVED_INLIERS_FIRST: b = &t->nobs_first, bytes = B * 4; break;
+    case VO_TRACKER_FEATURE_HAS_POINT: b = &t->fhas, bytes = B * cap; break;
+    case VO_TRACKER_FEATURE_POINTS: b = &t->fpoint, bytes = B * cap * 24; break;
+    case VO_TRACKER_LOCAL_FLAGS: b = &t->q1_flags, bytes = B * (size_t)t->n_local; break;
+    case VO_TRACKER_LOCAL_U: b = &t->q1_u, bytes = B * (size_t)t->n_local * 4; break;
+    case VO_TRACKER_LOCAL_V: b = &t->q1_v, bytes = B * (size_t)t->n_local * 4; break;
+    case VO_TRACKER_LOCAL_UR: b = &t->q1_aux, bytes = B * (size_t)t->n_local * 4; break;
+    case VO_TRACKER_LOCAL_LEVEL: b = &t->q1_level, bytes = B * (size_t)t->n_local * 4; break;
+    case VO_TRACKER_LOCAL_VIEWCOS: b = &t->q1_viewcos, bytes = B * (size_t)t->n_local * 4; break;
+    case VO_TRACKER_KEYPOINT_COUNTS: b = &t->cnt, bytes = B * 4; break;
+    default: return VO_ERR_INVALID;
+  }
+  if (dst_bytes < bytes) {
+    vo::set_error("vo_tracker_get(%d): destination holds %zu bytes, %zu needed", what, dst_bytes, bytes);
+    return VO_ERR_CAPACITY;
+  }
+  VO_HIP_CHECK(hipMemcpyAsync(dst, b->p, bytes, hipMemcpyDeviceToHost, t->st));
+  VO_HIP_CHECK(hipStreamSynchronize(t->st));
+  return VO_OK;
+}
+
+int vo_tracker_sync(vo_tracker *t) {
+  if (!t) return VO_ERR_INVALID;
+  VO_HIP_CHECK(hipStreamSynchronize(t->st));
+  return VO_OK;
+}
+
+int vo_tracker_set_timing(vo_tracker *t, int enabled) {
+  if (!t) return VO_ERR_INVALID;
+  if (enabled)
+    for (hipEvent_t &e : t->tev)
+      if (!e) VO_HIP_CHECK(hipEventCreate(&e));
+  t->timing = enabled != 0;
+  t->tpending = false;
+  for (double &m : t->tms) m = 0;
+  t->tcalls = 0;
+  return VO_OK;
+}
+
+int vo_tracker_get_timing(vo_tracker *t, double *ms, int *n_calls) {
+  if (!t || !ms) return VO_ERR_INVALID;
+  VO_CHECK(collect_timing(t));
+  for (int s = 0; s < kStages; s++) ms[s] = t->tms[s], t->tms[s] = 0;
+  if (n_calls) *n_calls = t->tcalls;
+  t->tcalls = 0;
+  return VO_OK;
+}
+
+}  // extern "C"
