@@ -81,8 +81,9 @@ def tracking_bytes_per_frame(nkp, n_q0, n_q1, n_obs):
 
 
 def cpu_track_one(orc, p, sf, img, raw_depth, mp, cam5, dist_coef, inv_depth):
-    """The oracle's tracked frame (the same stages as BatchTracker.track, one frame, one thread): returns pose inliers."""
-    import ctypes as C
+    """The oracle's tracked frame (the same stages as vo_tracker, one frame, one thread; tests/track_ref.py): returns the
+    second solve's inlier count."""
+    from track_ref import track_frame
     H, W = img.shape
     k, d, _ = orc.extract(p, img)
     n = len(k)
@@ -93,45 +94,9 @@ def cpu_track_one(orc, p, sf, img, raw_depth, mp, cam5, dist_coef, inv_depth):
     orc.lib().orc_depth_to_float(np.ascontiguousarray(raw_depth).reshape(-1), H * W, inv_depth, dimg.reshape(-1))
     ur, dep = np.zeros(n, np.float32), np.zeros(n, np.float32)
     orc.lib().orc_find_depth(n, x, y, ux, dimg, W, H, W, float(cam5[4]), ur, dep)
-    of = orc.FrameData(ux, uy, k["octave"], k["angle"], ur, d)   # builds the 64 x 48 grid
     T, pose6, la, lo = mp
-    P = la["points"]
-    xc = T[0] * P[:, 0] + T[1] * P[:, 1] + T[2] * P[:, 2] + T[9]
-    yc = T[3] * P[:, 0] + T[4] * P[:, 1] + T[5] * P[:, 2] + T[10]
-    zc = T[6] * P[:, 0] + T[7] * P[:, 1] + T[8] * P[:, 2] + T[11]
-    z = zc.astype(np.float32)
-    with np.errstate(divide="ignore", invalid="ignore"):
-        qz = (np.float32(1.0) / z).astype(np.float32)
-        qu = (np.float64(cam5[0]) * xc / zc + np.float64(cam5[2])).astype(np.float32)
-        qv = (np.float64(cam5[1]) * yc / zc + np.float64(cam5[3])).astype(np.float32)
-    ok = ((la["flags"] & 1) == 1) & ~(z < 0) & ~((qu < 0) | (qu > W)) & ~((qv < 0) | (qv > H))
-    qf = np.where(ok, 1 | (la["flags"] & 2), 0).astype(np.uint8)
-    nq = min(len(qf), n + 64)
-    a0 = np.full(n, -1, np.int32)
-    orc.lib().orc_match_frame_projection(C.byref(of.c), len(qf), qf, np.nan_to_num(qu), np.nan_to_num(qv), np.nan_to_num(qz),
-                                         la["octave"], la["angle"], np.ascontiguousarray(la["desc"]), 15.0, float(cam5[4]),
-                                         0, 1, 8, sf, np.zeros(n, np.uint8), a0)
-    fpt, has, fobs = np.zeros((n, 3)), a0 >= 0, np.zeros(n, np.uint8)
-    fpt[has] = P[a0[has]]
-    fobs[has] = (qf[a0[has]] >> 1) & 1
-    cam_d = cam5.astype(np.float64)
-
-    def solve(pose_in):
-        idx = np.nonzero(has)[0]
-        pr = dict(pts=np.ascontiguousarray(fpt[idx]),
-                  obs=np.ascontiguousarray(np.stack([ux[idx], uy[idx], ur[idx]], 1).astype(np.float64)),
-                  inv_sigma=np.ascontiguousarray(1.0 / sf[k["octave"][idx]].astype(np.float64)), cam=cam_d, pose0=pose_in)
-        return orc.pose_only(pr)
-
-    p1, _, _, _, _ = solve(pose6)
-    a1 = np.full(n, -1, np.int32)
-    orc.lib().orc_match_local_map(C.byref(of.c), len(lo["flags"]), lo["flags"], lo["u"], lo["v"], lo["ur"], lo["level"],
-                                  lo["viewcos"], np.ascontiguousarray(lo["desc"]), 3.0, 0.8, sf, fobs, a1)
-    new = a1 >= 0
-    fpt[new] = lo["points"][a1[new]]
-    has = has | new
-    _, _, ninl, _, _ = solve(p1)
-    return ninl, (k, d, ux, uy, dep)
+    w = track_frame(orc, k, d, ux, uy, ur, T, pose6, la, lo, cam5, sf, W, H)
+    return w["inliers_2"], (k, d, ux, uy, dep)
 
 
 def _cpu_worker(arg):
@@ -211,102 +176,91 @@ def main():
     n_pipe = max(1, args.pipeline)
     prio_ext, prio_tail = (int(x) for x in os.environ.get("VO_BENCH_PRIO", "0,-1").split(","))
     stream = torch.cuda.Stream(priority=prio_ext)  # extraction (shared by the batches in flight); also the brute-force leg
-    exts = [vo.OrbExtractor(1000, 1.2, 8, 20, 7) for _ in range(n_pipe)]
-    ext = exts[0]
+    ext = vo.OrbExtractor(1000, 1.2, 8, 20, 7)       # set-up and the brute-force leg (the trackers own theirs)
     ext.set_stream(stream.cuda_stream)
     cap = ext.max_keypoints()
     NM = 1000
-    from vo_slam_test_amd.tracking import BatchTracker
+    from vo_slam_test_amd.tracking import load_maps
     with torch.cuda.stream(stream):
         frames = torch.from_numpy(frames_np).cuda()
         depth = torch.from_numpy(np.stack([uniq_depth[i % n_unique] for i in range(B)]).view(np.int16)).cuda()
+        kps0 = torch.zeros((B, cap, 28), dtype=torch.uint8, device="cuda")
+        desc0 = torch.zeros((B, cap, 32), dtype=torch.uint8, device="cuda")
+        cnt0 = torch.zeros(B, dtype=torch.int32, device="cuda")
     # ---- the map every frame is tracked against (resident in HBM, like the frames): built once from the features of the
     # unique frames -- last frame's map points = the frame's own features back-projected with their depth, local map = two
-    # noisy copies of them (synth.make_tracking_map); TUM fr1 distortion coefficients (example.yaml:25-29)
-    if n_pipe == 1:
-        trks = [BatchTracker(B, ext, cam5, synth.DIST, W, H, n_last=1100, n_local=2200, stream=stream)]
-    else:
-        trks = [BatchTracker(B, e, cam5, synth.DIST, W, H, n_last=1100, n_local=2200, stream=torch.cuda.Stream(priority=prio_tail),
-                             extract_stream=stream) for e in exts]
-    trk = trks[0]
+    # noisy copies of them with the normals / distance ranges Frame::isInFrame reads (synth.make_tracking_map); TUM fr1
+    # distortion coefficients (example.yaml:25-29)
+    fstore = vo.Frames(n_unique, max(256, (cap + 63) // 64 * 64), cam5, synth.DIST, float(W), float(H))
     with torch.cuda.stream(stream):
-        ext.extract_batch_dev(frames[:n_unique], trk.kps[:n_unique], trk.desc[:n_unique], trk.cnt[:n_unique])
-    torch.cuda.synchronize()
-    with torch.cuda.stream(stream):
-        trk.frames.build_dev(trk.kps[:n_unique], trk.desc[:n_unique], trk.cnt[:n_unique], depth[:n_unique], inv_depth,
-                             stream=stream.cuda_stream)
+        ext.extract_batch_dev(frames[:n_unique], kps0[:n_unique], desc0[:n_unique], cnt0[:n_unique])
+        fstore.build_dev(kps0[:n_unique], desc0[:n_unique], cnt0[:n_unique], depth[:n_unique], inv_depth, stream=stream.cuda_stream)
     torch.cuda.synchronize()
     ext.sync()
     maps = []
     for i in range(n_unique):
-        fr = trk.frames.download(i, stream=stream.cuda_stream)
+        fr = fstore.download(i, stream=stream.cuda_stream)
         maps.append(synth.make_tracking_map(fr["x"], fr["y"], fr["octave"], fr["angle"], fr["desc"], fr["depth"], seed=i))
-
-    def stack(which, key, n, tail=()):
-        o = np.zeros((B, n) + tail, maps[0][which][key].dtype)
-        for f in range(B):
-            a = maps[f % n_unique][which][key]
-            o[f, :len(a)] = a[:n]
-        return o
-
-    last = dict(points=stack(2, "points", 1100, (3,)), flags=stack(2, "flags", 1100), octave=stack(2, "octave", 1100),
-                angle=stack(2, "angle", 1100), desc=stack(2, "desc", 1100, (32,)))
-    local = {k: stack(3, k, 2200, (3,) if k == "points" else (32,) if k == "desc" else ())
-             for k in ("points", "flags", "u", "v", "ur", "level", "viewcos", "desc")}
-    Tcw_all = np.stack([maps[f % n_unique][0] for f in range(B)])
-    pose_all = np.stack([maps[f % n_unique][1] for f in range(B)])
+    fstore.close()
+    # The trackers: vo_tracker runs the whole tracked-frame path behind the C-ABI (csrc/tracker.hip).  n_pipe of them share
+    # the extraction stream; their searches and pose solves run on high-priority streams of their own.
+    trks = [vo.Tracker(B, cam5, synth.DIST, W, H, max_last=1100, max_local=2200, inv_depth_scale=inv_depth,
+                       extract_stream=stream.cuda_stream if n_pipe > 1 else None, single_stream=(n_pipe == 1))
+            for _ in range(n_pipe)]
+    trk = trks[0]
+    exts = [t.extractor() for t in trks]
+    all_maps = [maps[f % n_unique] for f in range(B)]
     for t in trks:
-        with torch.cuda.stream(t.stream):
-            t.set_map(Tcw_all, pose_all, last, local)
-    torch.cuda.synchronize()
+        load_maps(t, all_maps, 1100, 2200)
     n_q0 = float(np.mean([(m[2]["flags"] & 1).sum() for m in maps]))
-    n_q1 = float(np.mean([(m[3]["flags"] & 1).sum() for m in maps]))
-    trk_ev = []
+    n_q1 = float(np.mean([(m[3]["valid"] & 1).sum() for m in maps]))
     n_steps_done = [0]
 
-    def step(timed=False, only=None, sink=None):
-        """one batch of B frames through the tracked-frame path; consecutive steps alternate between the batches in flight"""
+    def step(only=None):
+        """one batch of B frames through the tracked-frame path (ONE C call: vo_tracker_track_dev); consecutive steps
+        alternate between the batches in flight"""
         t = trks[n_steps_done[0] % n_pipe] if only is None else only
         n_steps_done[0] += 1
-        evs = t.track(frames, depth, inv_depth, events=timed, keep_first=not timed)
-        if timed:
-            (trk_ev if sink is None else sink).append(evs)
+        t.track_dev(frames, depth)
 
     for _ in range(max(args.warmup, n_pipe)):
         step()
     barrier()
     for t in trks:
-        t.ext.sync()
-        t.frames.match_status(stream=t.st)
-        counts = t.cnt.cpu().numpy()
+        res = t.results()   # synchronises; raises on dropped key-points / exhausted candidate pools
+        counts = t.get(t.KEYPOINT_COUNTS)
         assert counts.min() >= NM, f"synthetic frames must yield >= {NM} key-points, got {counts.min()}"
-        ninl = t.ninl.cpu().numpy()
+        ninl = res["n_inliers"]
         assert ninl.min() >= 100, f"tracking must keep >= 100 pose inliers per frame, got {ninl.min()}"
-    ncand = sum(len(ext.get_candidates(0, l)[0]) for l in range(8))
+        assert not res["status"].any(), "every synthetic frame must be tracked (status 0)"
+    ncand = sum(len(exts[0].get_candidates(0, l)[0]) for l in range(8))
     # reference point: the same step with nothing overlapped (one batch in flight)
     barrier()
-    ext.set_timing(True)
+    exts[0].set_timing(True)
+    trk.set_timing(True)
     ts0 = time.perf_counter()
     n_serial = max(3, args.steps // 4)
-    serial_ev = []
     for _ in range(n_serial):
-        step(timed=True, only=trk, sink=serial_ev)
-        torch.cuda.synchronize()
+        step(only=trk)
+        trk.sync()
     serial_ms = (time.perf_counter() - ts0) / n_serial * 1e3
-    sm, nc = ext.get_timing()
-    ext.set_timing(False)
+    sm, nc = exts[0].get_timing()
+    exts[0].set_timing(False)
     serial_stage_ms = {k: v / max(nc, 1) for k, v in sm.items()}
+    tm, tc = trk.get_timing()
     for name in ("frame_post", "match_last_frame", "pose_only_1", "match_local_map", "pose_only_2"):
-        serial_stage_ms[name] = float(np.mean([e[name][0].elapsed_time(e[name][1]) for e in serial_ev]))
+        serial_stage_ms[name] = tm[name] / max(tc, 1)
     # timed region: instrumented as well (per-kernel HIP events on the launching stream; the un-instrumented extractor,
     # whose blur runs on a side stream, measured the same step time with two batches in flight: 4.74 ms either way)
     for e in exts:
         e.set_timing(True)
+    for t in trks:
+        t.set_timing(True)
     n_steps_done[0] = 0
     barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        step(timed=True)
+        step()
     torch.cuda.synchronize()
     t1 = time.perf_counter()
     el = torch.tensor([t1 - t0], dtype=torch.float64, device="cuda")
@@ -321,11 +275,19 @@ def main():
         for k, v in sm.items():
             stage_ms[k] = stage_ms.get(k, 0.0) + v
     stage_ms = {k: v / max(ncalls, 1) for k, v in stage_ms.items()}
+    tsum, tcalls = {}, 0
+    for t in trks:
+        tm, tc = t.get_timing()
+        t.set_timing(False)
+        tcalls += tc
+        for k, v in tm.items():
+            tsum[k] = tsum.get(k, 0.0) + v
     for name in ("extract", "frame_post", "match_last_frame", "pose_only_1", "match_local_map", "pose_only_2"):
-        stage_ms[name] = float(np.mean([e[name][0].elapsed_time(e[name][1]) for e in trk_ev]))
+        stage_ms[name] = tsum[name] / max(tcalls, 1)
     frames_per_s = world * B * args.steps / elapsed
-    n_match0 = float((trk.assigned0 >= 0).sum().item()) / B if trk.assigned0 is not None else 0.0
-    n_obs2 = float(trk.ranges[:, 1].double().mean().item())
+    res = trk.results()
+    n_match0 = float(res["n_matches_last"].mean())
+    n_obs2 = float(trk.get(trk.FEATURE_HAS_POINT).sum()) / B
 
     nkp = int(counts.mean())
     sb = stage_bytes_per_frame(W, H, nkp, ncand)
@@ -364,13 +326,15 @@ def main():
 
     out = {
         "metric": "tracked frames/sec + local-BA LM-iters/sec (synthetic 640x480; value = tracked frames/sec: ORB extraction, "
-                  "frame post-processing, two guided searches and two pose-only solves per frame)",
+                  "frame post-processing, two guided searches with the culling / isInFrame steps between them and two "
+                  "pose-only solves per frame, one vo_tracker C call per batch)",
         "value": round(frames_per_s, 1), "unit": "frames/s", "n_gpus": world, "steps": args.steps,
         "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True,
         "scaling": "weak", "vs_baseline": None, "dtype": "u8", "data": "synthetic",
         "config": {"workload": "tracked frame: ORB extract (640x480, 8-level pyramid, 1000 kpts) + undistort/depth/grid + "
-                               "searchByProjection vs last frame + solvePoseOnlySE3 + searchByProjection vs local map + "
-                               "solvePoseOnlySE3; frames, depth and map resident in HBM",
+                               "searchByProjection vs last frame + solvePoseOnlySE3 + cullingOutliersBeforeLocalMap + "
+                               "isInFrame (refined pose) + searchByProjection vs local map + solvePoseOnlySE3; frames, depth "
+                               "and map resident in HBM",
                    "frames_per_gpu_per_step": B, "keypoints_per_frame": float(counts.mean()),
                    "fast_candidates_per_frame": ncand, "last_frame_queries": round(n_q0, 1), "local_map_queries": round(n_q1, 1),
                    "matches_last_frame": round(n_match0, 1), "pose_observations": round(n_obs2, 1),
@@ -392,6 +356,39 @@ def main():
                               "bound": "fp64 VALU issue (one wavefront per frame; twice the frames take twice as long: ~10 cycles per FP64 wave-instruction per SIMD)"},
     }
 
+    # ---- one camera stream, host buffers: Frame construction to pose in ONE call (vo_tracker_track, batch 1: image and raw
+    # depth uploaded, pose downloaded) -- the drop-in latency of visualOdometry.cpp:228-251 + 745-775 -- and the same call for
+    # a whole batch of host images (PCIe ingest included; never `value`).
+    if rank == 0:
+        t1 = vo.Tracker(1, cam5, synth.DIST, W, H, max_last=1100, max_local=2200, inv_depth_scale=inv_depth, single_stream=True)
+        load_maps(t1, [maps[0]], 1100, 2200)
+        h_img, h_dep = np.ascontiguousarray(uniq[:1]), np.ascontiguousarray(uniq_depth[:1]).view(np.uint16)
+        lat = []
+        for i in range(40):
+            tq = time.perf_counter()
+            t1.track(h_img, h_dep)
+            r1 = t1.results()
+            lat.append(time.perf_counter() - tq)
+        assert r1["n_inliers"][0] >= 100
+        t1.close()
+        out["single_stream"] = {"ms_per_frame": round(float(np.median(lat[5:])) * 1e3, 4),
+                                "frames_per_s": round(1.0 / float(np.median(lat[5:])), 1),
+                                "note": "batch 1, host image + raw depth in, pose out, one C call + results (PCIe and "
+                                        "launch latency of 23 kernels included)"}
+        h_all = np.ascontiguousarray(frames_np)
+        h_dall = np.ascontiguousarray(np.stack([uniq_depth[i % n_unique] for i in range(B)])).view(np.uint16)
+        ing = []
+        for i in range(4):
+            tq = time.perf_counter()
+            trk.track(h_all, h_dall)
+            trk.results()
+            ing.append(time.perf_counter() - tq)
+        out["ingest_inclusive"] = {"ms_per_step": round(float(np.median(ing[1:])) * 1e3, 3),
+                                   "frames_per_s": round(B / float(np.median(ing[1:])), 1),
+                                   "GBps_host_to_device": round(B * W * H * 3 / float(np.median(ing[1:])) / 1e9, 1),
+                                   "note": f"{B} host frames (8-bit image + 16-bit depth, pageable memory) uploaded inside "
+                                           "the call, one batch in flight"}
+
     # ---- BASELINE config 1 as written: extract + brute-force 1000 x 1000 Hamming against the next frame (SURVEY 8d bytes)
     if not args.no_bruteforce:
         with torch.cuda.stream(stream):
@@ -401,7 +398,7 @@ def main():
 
         def bf_step():
             with torch.cuda.stream(stream):
-                ext.extract_batch_dev(frames, trk.kps, bdesc[:B], trk.cnt)
+                ext.extract_batch_dev(frames, kps0, bdesc[:B], cnt0)
                 bdesc[B].copy_(bdesc[0])
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 e0.record(stream)

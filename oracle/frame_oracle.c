@@ -260,3 +260,47 @@ void orc_rgb_to_gray(const uint8_t *src, int n_px, int channels, int first_is_re
     dst[i] = (uint8_t)((r * 4899 + c1 * 9617 + b * 1868 + (1 << 13)) >> 14);
   }
 }
+
+/* Frame::isInFrame, frame.cpp:145-190, with MapPoint::predictScale, mappoint.cpp:182-196, and the distance thresholds
+ * of mappoint.cpp:391-401, for n map points against the pose Tcw = exp(pose6) (Frame::setPose, frame.cpp:100-105: Ow_ =
+ * Tcw_.inverse().translation()).  valid[i] bit 0: the point takes part (exists, not bad, visualIdxOfFrame_ != frame id,
+ * visualOdometry.cpp:762-766), bit 1: it has observations (copied to the output flag).  Outputs = trackInLocalMap_,
+ * trackProj_u_ / _v_ / _uR_, trackScaleLevel_, viewCos_.  `log` on a float argument is std::log(float) = logf through
+ * `using namespace std` (common_include.h:13); restated as the double logarithm rounded to float (glibc's logf is not
+ * correctly rounded everywhere; the quotient only matters when it falls within an ulp of an integer). */
+void orc_is_in_frame(int n, const double pose6[6], const double *pts, const double *normals, const float *min_dist,
+                     const float *max_dist, const uint8_t *valid, const float intr5[5], float xmin, float xmax, float ymin,
+                     float ymax, float scale_factor_1, int n_levels, uint8_t *flags, float *u_out, float *v_out,
+                     float *ur_out, int32_t *level_out, float *viewcos_out) {
+  double q[4], t[3];
+  orc_se3_exp(pose6, q, t);
+  const double qc[4] = {q[0], -q[1], -q[2], -q[3]}, zero[3] = {0, 0, 0}, nt[3] = {-t[0], -t[1], -t[2]};
+  double ow[3];
+  orc_se3_apply(qc, zero, nt, ow); /* SE3::inverse: (q^-1, q^-1 * (-t)) */
+  const float fx = intr5[0], fy = intr5[1], cx = intr5[2], cy = intr5[3], bf = intr5[4];
+  const float log_sf1 = (float)log((double)scale_factor_1);
+  for (int i = 0; i < n; i++) {
+    flags[i] = 0, u_out[i] = v_out[i] = ur_out[i] = viewcos_out[i] = 0.f, level_out[i] = 0;
+    if (!(valid[i] & 1)) continue;
+    double pc[3];
+    orc_se3_apply(q, t, pts + 3 * i, pc);
+    const float z = (float)pc[2];
+    if (z < 0.0f) continue;
+    const float u = (float)((double)fx * pc[0] / pc[2] + (double)cx); /* camera.cpp:72-75, float members */
+    if (u < xmin || u > xmax) continue;
+    const float v = (float)((double)fy * pc[1] / pc[2] + (double)cy);
+    if (v < ymin || v > ymax) continue;
+    const double l0 = pts[3 * i] - ow[0], l1 = pts[3 * i + 1] - ow[1], l2 = pts[3 * i + 2] - ow[2];
+    const float dist = (float)sqrt(l0 * l0 + l1 * l1 + l2 * l2);
+    const float mind = 0.8f * min_dist[i], maxd = 1.2f * max_dist[i];
+    if (dist < mind || dist > maxd) continue;
+    const float viewcos = (float)(l0 * normals[3 * i] + l1 * normals[3 * i + 1] + l2 * normals[3 * i + 2]) / dist;
+    if (viewcos < 0.5f) continue;
+    const float ratio = max_dist[i] / dist;
+    int s = (int)ceilf((float)log((double)ratio) / log_sf1);
+    if (s < 0) s = 0;
+    else if (s >= n_levels) s = n_levels - 1;
+    flags[i] = (uint8_t)(1 | (valid[i] & 2));
+    u_out[i] = u, v_out[i] = v, ur_out[i] = u - bf / z, level_out[i] = s, viewcos_out[i] = viewcos;
+  }
+}

@@ -115,6 +115,11 @@ void orc_find_depth(int n, const float *x, const float *y, const float *ux, cons
 void orc_depth_to_float(const uint16_t *raw, int n, float inv_scale, float *out);
 /* MapPoint::computeDescriptor mappoint.cpp:118-179: index of the median-best descriptor, -1 if n == 0 */
 int orc_median_descriptor(const uint8_t *desc, int n);
+/* Frame::isInFrame + MapPoint::predictScale (frame.cpp:145-190, mappoint.cpp:182-196, 391-401) */
+void orc_is_in_frame(int n, const double pose6[6], const double *pts, const double *normals, const float *min_dist,
+                     const float *max_dist, const uint8_t *valid, const float intr5[5], float xmin, float xmax, float ymin,
+                     float ymax, float scale_factor_1, int n_levels, uint8_t *flags, float *u_out, float *v_out,
+                     float *ur_out, int32_t *level_out, float *viewcos_out);
 
 /* Sim3Solver (sim3Solver.cpp): Horn's closed form :179-252 and one RANSAC hypothesis per sample triplet with
  * checkInliers :254-280 (integer thresholds, float pixel arithmetic); the sequential pick :141-160 is the caller's */

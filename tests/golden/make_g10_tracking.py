@@ -1,7 +1,10 @@
 #!/usr/bin/env python3
-"""Round-2 fixture g10_tracking.npz: one synthetic RGB-D frame through the tracked-frame path of the oracle --
+"""Fixture g10_tracking.npz (round 2, regenerated in round 3 with the culling step and Frame::isInFrame in the path):
+one synthetic RGB-D frame through the tracked-frame path of the oracle (tests/track_ref.py) --
 key-points, undistorted coordinates, uRight / depth (frame.cpp:36-133), the searchByProjection assignments against the
-last frame's points (matcher.cpp:18-148) and against the local map (:274-353), both pose-only solves -- plus a batch of
+last frame's points (matcher.cpp:18-148), the first pose-only solve, cullingOutliersBeforeLocalMap
+(visualOdometry.cpp:864-886), Frame::isInFrame of the local map points with the refined pose (frame.cpp:145-190), the
+search against them (:274-353), the second solve and trackLocalMap's inlier count -- plus a batch of
 Sim3 RANSAC hypotheses (sim3Solver.cpp:98-269) and a median-descriptor query (mappoint.cpp:118-179).  Inputs AND
 expected outputs; the oracle is the source (the reference ships no vectors: "parity unpinned").
 
@@ -39,42 +42,21 @@ def main():
     ur, dep = np.zeros(n, np.float32), np.zeros(n, np.float32)
     O.lib().orc_find_depth(n, x, y, ux, dimg, W, H, W, float(cam5[4]), ur, dep)
     T, pose6, la, lo = synth.make_tracking_map(ux, uy, k["octave"], k["angle"], d, dep, seed=IDX)
-    of = O.FrameData(ux, uy, k["octave"], k["angle"], ur, d)
-    # the test helper of tests/test_gpu_tracking.py projects the same way
-    sys.path.insert(0, str(HERE.parent))
-    from test_gpu_tracking import _project
-    qf, qu, qv, qz = _project(T, la["points"], la["flags"], cam5, W, H)
-    a0 = np.full(n, -1, np.int32)
-    n0 = O.lib().orc_match_frame_projection(C.byref(of.c), len(qf), qf, qu, qv, qz, la["octave"], la["angle"],
-                                            np.ascontiguousarray(la["desc"]), 15.0, float(cam5[4]), 0, 1, 8, sf,
-                                            np.zeros(n, np.uint8), a0)
-    fpt, has, fobs = np.zeros((n, 3)), a0 >= 0, np.zeros(n, np.uint8)
-    fpt[has] = la["points"][a0[has]]
-    fobs[has] = (qf[a0[has]] >> 1) & 1
-
-    def solve(pose_in, has):
-        idx = np.nonzero(has)[0]
-        pr = dict(pts=np.ascontiguousarray(fpt[idx]),
-                  obs=np.ascontiguousarray(np.stack([ux[idx], uy[idx], ur[idx]], 1).astype(np.float64)),
-                  inv_sigma=np.ascontiguousarray(1.0 / sf[k["octave"][idx]].astype(np.float64)), cam=cam5.astype(np.float64),
-                  pose0=pose_in)
-        return O.pose_only(pr)
-
-    p1, _, i1, _, _ = solve(pose6, has)
-    a1 = np.full(n, -1, np.int32)
-    n1 = O.lib().orc_match_local_map(C.byref(of.c), len(lo["flags"]), lo["flags"], lo["u"], lo["v"], lo["ur"], lo["level"],
-                                     lo["viewcos"], np.ascontiguousarray(lo["desc"]), 3.0, 0.8, sf, fobs, a1)
-    new = a1 >= 0
-    fpt[new] = lo["points"][a1[new]]
-    p2, _, i2, _, _ = solve(p1, has | new)
+    from track_ref import track_frame
+    w = track_frame(O, k, d, ux, uy, ur, T, pose6, la, lo, cam5, sf, W, H)
     out.update(image=img, depth_raw=raw, inv_depth_scale=np.float32(inv), cam5=cam5, dist=synth.DIST,
                kp_x=x, kp_y=y, kp_octave=k["octave"], kp_angle=k["angle"], desc=d, ux=ux, uy=uy, uright=ur, depth=dep,
                Tcw=T, pose0=pose6, last_points=la["points"], last_flags=la["flags"], last_octave=la["octave"],
                last_angle=la["angle"], last_desc=la["desc"],
-               local_points=lo["points"], local_flags=lo["flags"], local_u=lo["u"], local_v=lo["v"], local_ur=lo["ur"],
-               local_level=lo["level"], local_viewcos=lo["viewcos"], local_desc=lo["desc"],
-               assigned_last=a0, n_last=np.int32(n0), pose_1=p1, inliers_1=np.int32(i1),
-               assigned_local=a1, n_local=np.int32(n1), pose_2=p2, inliers_2=np.int32(i2))
+               local_points=lo["points"], local_normals=lo["normals"], local_min_dist=lo["min_dist"],
+               local_max_dist=lo["max_dist"], local_valid=lo["valid"], local_link=lo["link"], local_desc=lo["desc"],
+               assigned_last=w["assigned_last"], n_last=np.int32(w["n_last"]), pose_1=w["pose_1"], inliers_1=np.int32(w["inliers_1"]),
+               observed_inliers_1=np.int32(w["observed_inliers_1"]),
+               local_flags=w["local_flags"], local_u=w["local_u"], local_v=w["local_v"], local_ur=w["local_ur"],
+               local_level=w["local_level"], local_viewcos=w["local_viewcos"],
+               assigned_local=w["assigned_local"], n_local=np.int32(w["n_local"]), pose_2=w["pose_2"],
+               inliers_2=np.int32(w["inliers_2"]), n_tracked=np.int32(w["n_tracked"]))
+    n0, n1, i1, i2 = w["n_last"], w["n_local"], w["inliers_1"], w["inliers_2"]
     # Sim3 RANSAC hypotheses
     from test_gpu_loop import _sim3_data
     pc1, pc2, px1, px2, me1, me2, cam, tri, _ = _sim3_data(11, n=200)

@@ -142,6 +142,9 @@ def lib():
     L.orc_find_depth.argtypes = [C.c_int, _f32p, _f32p, _f32p, _f32p, C.c_int, C.c_int, C.c_int, C.c_float, _f32p, _f32p]
     L.orc_depth_to_float.argtypes = [_u16p, C.c_int, C.c_float, _f32p]
     L.orc_median_descriptor.argtypes = [_u8p, C.c_int]
+    L.orc_is_in_frame.argtypes = [C.c_int, _f64p, _f64p, _f64p, _f32p, _f32p, _u8p, _f32p, C.c_float, C.c_float, C.c_float,
+                                  C.c_float, C.c_float, C.c_int, _u8p, _f32p, _f32p, _f32p, _i32p, _f32p]
+    L.orc_is_in_frame.restype = None
     L.orc_median_descriptor.restype = C.c_int
     L.orc_sim3_horn.argtypes = [_f64p, _f64p, C.c_int, _f64p, _f64p, C.POINTER(C.c_double)]
     L.orc_sim3_ransac_eval.argtypes = [C.c_int, _f64p, _f64p, _f64p, _f64p, _i32p, _i32p, _f32p, C.c_int, _i32p, C.c_int,

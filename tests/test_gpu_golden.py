@@ -125,36 +125,37 @@ def test_g9_global_ba_config4(vo):
 
 
 def test_g10_tracked_frame_and_loop_helpers(vo):
-    """Round-2 fixture: one RGB-D frame through the device tracked-frame path (extraction, undistortion / depth / grid,
-    both searches, both pose solves) against the committed vectors; Sim3 hypotheses and the median descriptor too."""
-    import torch
-    from vo_slam_test_amd.tracking import BatchTracker
+    """Fixture g10: one RGB-D frame through vo_tracker (host image and raw depth in: extraction, undistortion / depth /
+    grid, search, solve, culling, isInFrame, search, solve) against the committed vectors; Sim3 hypotheses and the
+    median descriptor too."""
     g = np.load(G / "g10_tracking.npz")
     H, W = g["image"].shape
-    ext = vo.OrbExtractor(1000, 1.2, 8, 20, 7)
-    n_last, n_local = len(g["last_flags"]), len(g["local_flags"])
-    trk = BatchTracker(1, ext, g["cam5"], g["dist"], W, H, n_last=n_last, n_local=n_local)
-    last = dict(points=g["last_points"][None], flags=g["last_flags"][None], octave=g["last_octave"][None],
-                angle=g["last_angle"][None], desc=g["last_desc"][None])
-    local = {k: g["local_" + k][None] for k in ("points", "flags", "u", "v", "ur", "level", "viewcos", "desc")}
-    trk.set_map(g["Tcw"][None], g["pose0"][None], last, local)
-    img = torch.from_numpy(g["image"][None].copy()).cuda()
-    dep = torch.from_numpy(g["depth_raw"][None].view(np.int16).copy()).cuda()
-    trk.track(img, dep, float(g["inv_depth_scale"]), keep_first=True)
-    torch.cuda.synchronize()
-    trk.frames.match_status()
-    fr = trk.frames.download(0)
+    n_last, n_local = len(g["last_flags"]), len(g["local_valid"])
+    trk = vo.Tracker(1, g["cam5"], g["dist"], W, H, max_last=n_last, max_local=n_local, inv_depth_scale=float(g["inv_depth_scale"]))
+    trk.set_last_frame(g["Tcw"][None], g["last_points"][None], g["last_flags"][None], g["last_octave"][None],
+                       g["last_angle"][None], g["last_desc"][None])
+    trk.set_local_map(g["local_points"][None], g["local_normals"][None], g["local_min_dist"][None], g["local_max_dist"][None],
+                      g["local_valid"][None], g["local_desc"][None], link=g["local_link"][None])
+    trk.track(g["image"][None], g["depth_raw"][None].view(np.uint16))
+    r = trk.results()
+    fr = trk.download_frame(0)
     n = len(g["kp_x"])
     assert fr["n"] == n
     assert np.array_equal(fr["x"], g["ux"]) and np.array_equal(fr["y"], g["uy"])          # undistorted key-points
     assert np.array_equal(fr["uright"], g["uright"]) and np.array_equal(fr["depth"], g["depth"])
     assert np.array_equal(fr["desc"], g["desc"]) and np.array_equal(fr["octave"], g["kp_octave"])
-    assert np.array_equal(trk.assigned0[0, :n].cpu().numpy(), g["assigned_last"])
-    assert np.array_equal(trk.assigned[0, :n].cpu().numpy(), g["assigned_local"])
-    assert int(trk.ninl_first[0]) == int(g["inliers_1"]) and int(trk.ninl[0]) == int(g["inliers_2"])
-    assert np.abs(trk.pose_first[0].cpu().numpy() - g["pose_1"]).max() < 1e-9
-    assert np.abs(trk.pose[0].cpu().numpy() - g["pose_2"]).max() < 1e-9
-    trk.close(), ext.close()
+    assert np.array_equal(trk.get(trk.ASSIGNED_LAST)[0, :n], g["assigned_last"])
+    assert int(trk.get(trk.INLIERS_FIRST)[0]) == int(g["inliers_1"])
+    assert int(trk.get(trk.OBSERVED_INLIERS_FIRST)[0]) == int(g["observed_inliers_1"])
+    assert np.abs(trk.get(trk.POSE_FIRST)[0] - g["pose_1"]).max() < 1e-9
+    for what, key in ((trk.LOCAL_FLAGS, "local_flags"), (trk.LOCAL_U, "local_u"), (trk.LOCAL_V, "local_v"),
+                      (trk.LOCAL_UR, "local_ur"), (trk.LOCAL_LEVEL, "local_level"), (trk.LOCAL_VIEWCOS, "local_viewcos")):
+        assert np.array_equal(trk.get(what)[0, :n_local], g[key]), key
+    assert np.array_equal(trk.get(trk.ASSIGNED_LOCAL)[0, :n], g["assigned_local"])
+    assert int(r["n_inliers"][0]) == int(g["inliers_2"]) and int(r["n_tracked"][0]) == int(g["n_tracked"])
+    assert int(r["n_matches_last"][0]) == int(g["n_last"]) and int(r["n_matches_local"][0]) == int(g["n_local"])
+    assert np.abs(r["pose"][0] - g["pose_2"]).max() < 1e-9
+    trk.close()
     counts, flags, sims = vo.sim3_ransac_eval(g["s3_pc1"], g["s3_pc2"], g["s3_px1"], g["s3_px2"], g["s3_me1"], g["s3_me2"],
                                               g["s3_cam"], g["s3_tri"], True)
     assert np.array_equal(counts, g["s3_counts"]) and np.array_equal(np.packbits(flags, axis=1), g["s3_flags"])

@@ -1,9 +1,7 @@
-"""GPU parity of the whole tracked-frame path on device-resident frames (extract -> undistort / depth / grid ->
-searchByProjection vs the last frame -> solvePoseOnlySE3 -> searchByProjection vs the local map ->
-solvePoseOnlySE3) against the CPU oracle run stage by stage on the same inputs: match pairs bit-exact, poses
-within 1e-9, identical inlier counts."""
-import ctypes as C
-
+"""GPU parity of the whole tracked-frame path behind the C-ABI (vo_tracker: extract -> undistort / depth / grid ->
+searchByProjection vs the last frame -> solvePoseOnlySE3 -> cullingOutliersBeforeLocalMap -> isInFrame with the
+refined pose -> searchByProjection vs the local map -> solvePoseOnlySE3) against the CPU oracle run stage by stage on
+the same inputs: match pairs and local-map projections bit-exact, poses within 1e-9, identical inlier counts."""
 import numpy as np
 import pytest
 
@@ -12,116 +10,111 @@ from vo_slam_test_amd import synth
 pytestmark = pytest.mark.gpu
 
 
-def _project(T, P, pf, cam, W, H):
-    x = T[0] * P[:, 0] + T[1] * P[:, 1] + T[2] * P[:, 2] + T[9]
-    y = T[3] * P[:, 0] + T[4] * P[:, 1] + T[5] * P[:, 2] + T[10]
-    zc = T[6] * P[:, 0] + T[7] * P[:, 1] + T[8] * P[:, 2] + T[11]
-    z = zc.astype(np.float32)
-    with np.errstate(divide="ignore", invalid="ignore"):
-        invz = (np.float32(1.0) / z).astype(np.float32)
-        u = (np.float64(cam[0]) * x / zc + np.float64(cam[2])).astype(np.float32)
-        v = (np.float64(cam[1]) * y / zc + np.float64(cam[3])).astype(np.float32)
-    ok = ((pf & 1) == 1) & ~(z < 0) & ~((u < 0) | (u > W)) & ~((v < 0) | (v > H))
-    flags = np.where(ok, 1 | (pf & 2), 0).astype(np.uint8)
-    return flags, np.where(ok, u, 0).astype(np.float32), np.where(ok, v, 0).astype(np.float32), np.where(ok, invz, 0).astype(np.float32)
+from track_ref import project_last as _project  # noqa: E402,F401  (kept under its old name for the g10 generator)
+from track_ref import track_frame  # noqa: E402
+
+
+def _oracle_frames(orc, imgs, raw, inv, cam5, dist, W, H):
+    """the oracle's Frame::Frame for every image: key-points, descriptors, undistorted coordinates, uRight, depth"""
+    p = orc.orb_params()
+    out = []
+    for f in range(len(imgs)):
+        k, d, _ = orc.extract(p, imgs[f])
+        n = len(k)
+        x, y = np.ascontiguousarray(k["x"]), np.ascontiguousarray(k["y"])
+        ux, uy = np.zeros(n, np.float32), np.zeros(n, np.float32)
+        orc.lib().orc_undistort_points(n, x, y, cam5[:4].copy(), dist.ctypes.data if dist is not None else None, ux, uy)
+        dimg = np.zeros((H, W), np.float32)
+        orc.lib().orc_depth_to_float(np.ascontiguousarray(raw[f]).reshape(-1), H * W, inv, dimg.reshape(-1))
+        ur, dep = np.zeros(n, np.float32), np.zeros(n, np.float32)
+        orc.lib().orc_find_depth(n, x, y, ux, dimg, W, H, W, float(cam5[4]), ur, dep)
+        out.append((k, d, ux, uy, ur, dep))
+    return out
 
 
 @pytest.mark.parametrize("distorted", [False, True])
 def test_tracked_frames_match_the_oracle(vo, orc, distorted):
-    import torch
-    from vo_slam_test_amd.tracking import BatchTracker
+    """vo_tracker (one C call per batch) against the oracle run stage by stage: both searches' assignments bit-exact,
+    Frame::isInFrame's outputs for the local map bit-exact, both poses within 1e-9, identical inlier counts -- with the
+    culling of the first solve's outliers and the local-map projections taken with the refined pose."""
+    from vo_slam_test_amd.tracking import load_maps
     B, W, H = 3, 640, 480
     imgs = synth.make_frames(B, start=60)
     raw = np.stack([synth.make_depth(60 + i) for i in range(B)])
     inv = np.float32(1.0) / np.float32(synth.DEPTH_SCALE)
     cam5 = synth.CAM.astype(np.float32)
     dist = synth.DIST if distorted else None
-    p = orc.orb_params()
-    sf = np.array(list(p.scale)[:8], np.float32)
-    # the oracle's frames (and the synthetic map built from them)
-    oracle_frames, maps = [], []
-    for f in range(B):
-        k, d, _ = orc.extract(p, imgs[f])
-        n = len(k)
-        x, y = np.ascontiguousarray(k["x"]), np.ascontiguousarray(k["y"])
-        ux, uy = np.zeros(n, np.float32), np.zeros(n, np.float32)
-        orc.lib().orc_undistort_points(n, x, y, cam5[:4].copy(), dist.ctypes.data if distorted else None, ux, uy)
-        dimg = np.zeros((H, W), np.float32)
-        orc.lib().orc_depth_to_float(np.ascontiguousarray(raw[f]).reshape(-1), H * W, inv, dimg.reshape(-1))
-        ur, dep = np.zeros(n, np.float32), np.zeros(n, np.float32)
-        orc.lib().orc_find_depth(n, x, y, ux, dimg, W, H, W, float(cam5[4]), ur, dep)
-        oracle_frames.append((k, d, ux, uy, ur))
-        maps.append(synth.make_tracking_map(ux, uy, k["octave"], k["angle"], d, dep, seed=f))
+    sf = np.array(list(orc.orb_params().scale)[:8], np.float32)
+    oracle_frames = _oracle_frames(orc, imgs, raw, inv, cam5, dist, W, H)
+    maps = [synth.make_tracking_map(fr[2], fr[3], fr[0]["octave"], fr[0]["angle"], fr[1], fr[5], seed=f)
+            for f, fr in enumerate(oracle_frames)]
     n_last = max(len(m[2]["flags"]) for m in maps)
     n_local = max(len(m[3]["flags"]) for m in maps)
-
-    def stack(key, which, shape_tail=()):
-        out = np.zeros((B, n_last if which == 2 else n_local) + shape_tail, maps[0][which][key].dtype)
-        for f in range(B):
-            a = maps[f][which][key]
-            out[f, :len(a)] = a
-        return out
-
-    last = dict(points=stack("points", 2, (3,)), flags=stack("flags", 2), octave=stack("octave", 2), angle=stack("angle", 2),
-                desc=stack("desc", 2, (32,)))
-    local = {k: stack(k, 3, (3,) if k == "points" else (32,) if k == "desc" else ()) for k in
-             ("points", "flags", "u", "v", "ur", "level", "viewcos", "desc")}
-    ext = vo.OrbExtractor(1000, 1.2, 8, 20, 7)
-    trk = BatchTracker(B, ext, cam5, dist, W, H, n_last=n_last, n_local=n_local)
-    trk.set_map(np.stack([m[0] for m in maps]), np.stack([m[1] for m in maps]), last, local)
-    t_img = torch.from_numpy(imgs).cuda()
-    t_dep = torch.from_numpy(raw.view(np.int16)).cuda()
-    trk.track(t_img, t_dep, float(inv), keep_first=True)
-    torch.cuda.synchronize()
-    trk.frames.match_status()
-    asg0, asg1 = trk.assigned0.cpu().numpy(), trk.assigned.cpu().numpy()
-    pose1, pose2 = trk.pose_first.cpu().numpy(), trk.pose.cpu().numpy()
-    ninl1, ninl2 = trk.ninl_first.cpu().numpy(), trk.ninl.cpu().numpy()
-    cam_d = cam5.astype(np.float64)
+    trk = vo.Tracker(B, cam5, dist, W, H, max_last=n_last, max_local=n_local, inv_depth_scale=float(inv))
+    load_maps(trk, maps)
+    # host images and raw depth in, poses out: the single-call form
+    trk.track(imgs, raw.view(np.uint16))
+    res = trk.results()
+    asg0, asg1 = trk.get(trk.ASSIGNED_LAST), trk.get(trk.ASSIGNED_LOCAL)
+    pose1, ninl1, nobs1 = trk.get(trk.POSE_FIRST), trk.get(trk.INLIERS_FIRST), trk.get(trk.OBSERVED_INLIERS_FIRST)
+    lfl, lu, lv, lur = trk.get(trk.LOCAL_FLAGS), trk.get(trk.LOCAL_U), trk.get(trk.LOCAL_V), trk.get(trk.LOCAL_UR)
+    llev, lvc = trk.get(trk.LOCAL_LEVEL), trk.get(trk.LOCAL_VIEWCOS)
+    culled_any = False
     for f in range(B):
-        k, d, ux, uy, ur = oracle_frames[f]
+        k, d, ux, uy, ur, _ = oracle_frames[f]
         n = len(k)
         T, pose6, la, lo = maps[f]
-        of = orc.FrameData(ux, uy, k["octave"], k["angle"], ur, d)
-        qf, qu, qv, qz = _project(T, la["points"], la["flags"], cam5, W, H)
-        a0 = np.full(n, -1, np.int32)
-        orc.lib().orc_match_frame_projection(C.byref(of.c), len(qf), qf, qu, qv, qz, la["octave"], la["angle"],
-                                             np.ascontiguousarray(la["desc"]), 15.0, float(cam5[4]), 0, 1, 8, sf,
-                                             np.zeros(n, np.uint8), a0)
-        assert np.array_equal(asg0[f, :n], a0) and (a0 >= 0).sum() > 300
-        # frame->mappoints_, then the pose-only solve over the features that hold a point
-        fpt, has, fobs = np.zeros((n, 3)), a0 >= 0, np.zeros(n, np.uint8)
-        fpt[has] = la["points"][a0[has]]
-        fobs[has] = (qf[a0[has]] >> 1) & 1
+        want = track_frame(orc, k, d, ux, uy, ur, T, pose6, la, lo, cam5, sf, W, H)
+        assert np.array_equal(asg0[f, :n], want["assigned_last"]) and (want["assigned_last"] >= 0).sum() > 300
+        assert res["n_matches_last"][f] == want["n_last"]
+        assert ninl1[f] == want["inliers_1"] and np.abs(pose1[f] - want["pose_1"]).max() < 1e-9
+        assert nobs1[f] == want["observed_inliers_1"]
+        m = len(lo["valid"])
+        assert np.array_equal(lfl[f, :m], want["local_flags"]) and (want["local_flags"] > 0).sum() > 500
+        for got, key in ((lu, "local_u"), (lv, "local_v"), (lur, "local_ur"), (lvc, "local_viewcos")):
+            assert np.array_equal(got[f, :m].view(np.uint32), want[key].view(np.uint32)), key
+        assert np.array_equal(llev[f, :m], want["local_level"])
+        assert np.array_equal(asg1[f, :n], want["assigned_local"]) and (want["assigned_local"] >= 0).sum() > 100
+        assert res["n_matches_local"][f] == want["n_local"]
+        assert res["n_inliers"][f] == want["inliers_2"] and np.abs(res["pose"][f] - want["pose_2"]).max() < 1e-9
+        assert res["n_tracked"][f] == want["n_tracked"] and want["n_tracked"] >= 100
+        assert res["status"][f] == 0
+        culled_any |= want["inliers_1"] < (want["assigned_last"] >= 0).sum()
+    assert culled_any  # the synthetic map has outliers the first solve rejects: the culling step is exercised
+    trk.close()
 
-        def solve(pose_in):
-            idx = np.nonzero(has)[0]
-            pr = dict(pts=np.ascontiguousarray(fpt[idx]),
-                      obs=np.ascontiguousarray(np.stack([ux[idx], uy[idx], ur[idx]], 1).astype(np.float64)),
-                      inv_sigma=np.ascontiguousarray(1.0 / sf[k["octave"][idx]].astype(np.float64)), cam=cam_d, pose0=pose_in)
-            return orc.pose_only(pr)
 
-        op1, _, oi1, _, _ = solve(pose6)
-        assert ninl1[f] == oi1 and np.abs(pose1[f] - op1).max() < 1e-9
-        a1 = np.full(n, -1, np.int32)
-        orc.lib().orc_match_local_map(C.byref(of.c), len(lo["flags"]), lo["flags"], lo["u"], lo["v"], lo["ur"], lo["level"],
-                                      lo["viewcos"], np.ascontiguousarray(lo["desc"]), 3.0, 0.8, sf, fobs, a1)
-        assert np.array_equal(asg1[f, :n], a1) and (a1 >= 0).sum() > 100
-        new = a1 >= 0
-        fpt[new] = lo["points"][a1[new]]
-        has = has | new
-        op2, _, oi2, _, _ = solve(op1)
-        assert ninl2[f] == oi2 and np.abs(pose2[f] - op2).max() < 1e-9
-        assert oi2 >= 200
-    trk.close(), ext.close()
+def _device_frames(vo, t_img, t_dep, inv, cam5, dist, W, H):
+    """the frames of a batch as the device builds them (separate extractor / frame store handles) -> list of dicts"""
+    import torch
+    B = t_img.shape[0]
+    ext = vo.OrbExtractor(1000, 1.2, 8, 20, 7)
+    kcap = ext.max_keypoints()
+    cap = max(256, (kcap + 63) // 64 * 64)
+    fr = vo.Frames(B, cap, cam5, dist, float(W), float(H))
+    s0 = torch.cuda.Stream()
+    ext.set_stream(s0.cuda_stream)
+    with torch.cuda.stream(s0):
+        kps = torch.zeros((B, kcap, 28), dtype=torch.uint8, device="cuda")
+        desc = torch.zeros((B, kcap, 32), dtype=torch.uint8, device="cuda")
+        cnt = torch.zeros(B, dtype=torch.int32, device="cuda")
+        ext.extract_batch_dev(t_img, kps, desc, cnt)
+        fr.build_dev(kps, desc, cnt, t_dep, inv, stream=s0.cuda_stream)
+    torch.cuda.synchronize()
+    out = [fr.download(i, stream=s0.cuda_stream) for i in range(B)]
+    for i in range(B):
+        out[i]["kps"] = kps[i, :out[i]["n"]].cpu().numpy()
+    fr.close(), ext.close()
+    return out
 
 
 @pytest.mark.timeout(300)
 def test_pipelined_trackers_lifecycle(vo):
     """Two batches in flight (shared extraction stream, high-priority search / pose streams -- bench.py's regime) give
-    exactly the single-stream results, and handles can be closed and re-created while others live on the same streams."""
+    exactly the single-stream results, and trackers can be destroyed and re-created while others live on the same
+    extraction stream."""
     import torch
-    from vo_slam_test_amd.tracking import BatchTracker
+    from vo_slam_test_amd.tracking import load_maps
     B, W, H = 8, 640, 480
     imgs = synth.make_frames(B, start=20)
     raw = np.stack([synth.make_depth(20 + i) for i in range(B)])
@@ -129,126 +122,73 @@ def test_pipelined_trackers_lifecycle(vo):
     cam5 = synth.CAM.astype(np.float32)
     t_img = torch.from_numpy(imgs).cuda()
     t_dep = torch.from_numpy(raw.view(np.int16)).cuda()
+    frames = _device_frames(vo, t_img, t_dep, inv, cam5, synth.DIST, W, H)
+    maps = [synth.make_tracking_map(fr["x"], fr["y"], fr["octave"], fr["angle"], fr["desc"], fr["depth"], seed=i)
+            for i, fr in enumerate(frames)]
 
-    def make(stream, ext_stream):
-        ext = vo.OrbExtractor(1000, 1.2, 8, 20, 7)
-        trk = BatchTracker(B, ext, cam5, synth.DIST, W, H, n_last=1100, n_local=2200, stream=stream, extract_stream=ext_stream)
-        return trk
+    def make(ext_stream=None, single=False):
+        t = vo.Tracker(B, cam5, synth.DIST, W, H, max_last=1100, max_local=2200, inv_depth_scale=inv,
+                       extract_stream=ext_stream, single_stream=single)
+        load_maps(t, maps, 1100, 2200)
+        return t
 
-    def load_map(trk, maps):
-        def stack(which, key, n, tail=()):
-            o = np.zeros((B, n) + tail, maps[0][which][key].dtype)
-            for f in range(B):
-                a = maps[f][which][key]
-                o[f, :len(a)] = a[:n]
-            return o
-        last = dict(points=stack(2, "points", 1100, (3,)), flags=stack(2, "flags", 1100), octave=stack(2, "octave", 1100),
-                    angle=stack(2, "angle", 1100), desc=stack(2, "desc", 1100, (32,)))
-        local = {k: stack(3, k, 2200, (3,) if k == "points" else (32,) if k == "desc" else ())
-                 for k in ("points", "flags", "u", "v", "ur", "level", "viewcos", "desc")}
-        with torch.cuda.stream(trk.stream):
-            trk.set_map(np.stack([m[0] for m in maps]), np.stack([m[1] for m in maps]), last, local)
-        torch.cuda.synchronize()
-
-    # reference: everything on one stream
-    s0 = torch.cuda.Stream()
-    ref = make(s0, None)
-    with torch.cuda.stream(s0):
-        ref.ext.extract_batch_dev(t_img, ref.kps, ref.desc, ref.cnt)
-        ref.frames.build_dev(ref.kps, ref.desc, ref.cnt, t_dep, inv, stream=s0.cuda_stream)
-    torch.cuda.synchronize()
-    maps = []
-    for i in range(B):
-        fr = ref.frames.download(i, stream=s0.cuda_stream)
-        maps.append(synth.make_tracking_map(fr["x"], fr["y"], fr["octave"], fr["angle"], fr["desc"], fr["depth"], seed=i))
-    load_map(ref, maps)
-    ref.track(t_img, t_dep, inv)
-    torch.cuda.synchronize()
-    want = (ref.pose.cpu().numpy().copy(), ref.ninl.cpu().numpy().copy(), ref.assigned.cpu().numpy().copy())
-    assert want[1].min() >= 100
+    ref = make(single=True)  # reference: everything on one stream
+    ref.track_dev(t_img, t_dep)
+    r = ref.results()
+    want = (r["pose"].copy(), r["n_inliers"].copy(), ref.get(ref.ASSIGNED_LOCAL).copy(), r["n_tracked"].copy())
+    assert want[1].min() >= 100 and want[3].min() >= 50 and not r["status"].any()
 
     es = torch.cuda.Stream()
     for generation in range(3):
-        trks = [make(torch.cuda.Stream(priority=-1), es) for _ in range(2)]
-        for t in trks:
-            load_map(t, maps)
+        trks = [make(es.cuda_stream) for _ in range(2)]
         for step in range(6):
-            trks[step % 2].track(t_img, t_dep, inv)
-        torch.cuda.synchronize()
+            trks[step % 2].track_dev(t_img, t_dep)
         for t in trks:
-            t.ext.sync()
-            t.frames.match_status(stream=t.st)
-            assert np.array_equal(t.pose.cpu().numpy(), want[0])
-            assert np.array_equal(t.ninl.cpu().numpy(), want[1])
-            assert np.array_equal(t.assigned.cpu().numpy(), want[2])
+            r = t.results()
+            assert np.array_equal(r["pose"], want[0]) and np.array_equal(r["n_inliers"], want[1])
+            assert np.array_equal(t.get(t.ASSIGNED_LOCAL), want[2]) and np.array_equal(r["n_tracked"], want[3])
         # close one now, the other after its successor has been created on the same extraction stream
-        trks[0].close(), trks[0].ext.close()
+        trks[0].close()
         keep = trks[1]
-        nxt = make(torch.cuda.Stream(priority=-1), es)
-        load_map(nxt, maps)
-        nxt.track(t_img, t_dep, inv)
-        keep.track(t_img, t_dep, inv)
-        torch.cuda.synchronize()
-        assert np.array_equal(nxt.pose.cpu().numpy(), want[0]) and np.array_equal(keep.pose.cpu().numpy(), want[0])
-        for t in (keep, nxt):
-            t.close(), t.ext.close()
-    ref.close(), ref.ext.close()
+        nxt = make(es.cuda_stream)
+        nxt.track_dev(t_img, t_dep)
+        keep.track_dev(t_img, t_dep)
+        assert np.array_equal(nxt.results()["pose"], want[0]) and np.array_equal(keep.results()["pose"], want[0])
+        keep.close(), nxt.close()
+    ref.close()
 
 
 def test_batch_of_replicated_frames_is_consistent(vo):
     """A batch of 160 frames built from 8 distinct ones (the shape of bench.py's workload): every replica of a frame
-    gets bit-identical key-points, assignments, poses and inlier counts -- whatever its position in the batch -- and the
-    results differ between distinct frames."""
+    gets bit-identical key-point counts, assignments, poses and inlier counts -- whatever its position in the batch --
+    and the results differ between distinct frames."""
     import torch
-    from vo_slam_test_amd.tracking import BatchTracker
+    from vo_slam_test_amd.tracking import load_maps
     NU, REP, W, H = 8, 20, 640, 480
     B = NU * REP
     uniq = synth.make_frames(NU, start=300)
     udep = np.stack([synth.make_depth(300 + i) for i in range(NU)])
     order = np.arange(B) % NU
     np.random.default_rng(1).shuffle(order)
-    imgs = torch.from_numpy(uniq[order]).cuda()
-    dep = torch.from_numpy(udep[order].view(np.int16)).cuda()
     inv = float(np.float32(1.0) / np.float32(synth.DEPTH_SCALE))
     cam5 = synth.CAM.astype(np.float32)
-    ext = vo.OrbExtractor(1000, 1.2, 8, 20, 7)
-    trk = BatchTracker(B, ext, cam5, synth.DIST, W, H, n_last=1100, n_local=2200)
-    with torch.cuda.stream(trk.stream):
-        ext.extract_batch_dev(imgs, trk.kps, trk.desc, trk.cnt)
-        trk.frames.build_dev(trk.kps, trk.desc, trk.cnt, dep, inv, stream=trk.st)
-    torch.cuda.synchronize()
+    ufr = _device_frames(vo, torch.from_numpy(uniq).cuda(), torch.from_numpy(udep.view(np.int16)).cuda(), inv, cam5, synth.DIST, W, H)
+    umaps = [synth.make_tracking_map(fr["x"], fr["y"], fr["octave"], fr["angle"], fr["desc"], fr["depth"], seed=u)
+             for u, fr in enumerate(ufr)]
+    imgs = torch.from_numpy(uniq[order]).cuda()
+    dep = torch.from_numpy(udep[order].view(np.int16)).cuda()
+    trk = vo.Tracker(B, cam5, synth.DIST, W, H, max_last=1100, max_local=2200, inv_depth_scale=inv)
+    load_maps(trk, [umaps[int(order[f])] for f in range(B)], 1100, 2200)
+    trk.track_dev(imgs, dep)
+    r = trk.results()
+    cnt, asg = trk.get(trk.KEYPOINT_COUNTS), trk.get(trk.ASSIGNED_LOCAL)
     first = {int(u): int(np.nonzero(order == u)[0][0]) for u in range(NU)}
-    maps = {}
-    for u, f in first.items():
-        fr = trk.frames.download(f, stream=trk.st)
-        maps[u] = synth.make_tracking_map(fr["x"], fr["y"], fr["octave"], fr["angle"], fr["desc"], fr["depth"], seed=u)
-
-    def stack(which, key, n, tail=()):
-        o = np.zeros((B, n) + tail, maps[0][which][key].dtype)
-        for f in range(B):
-            a = maps[int(order[f])][which][key]
-            o[f, :len(a)] = a[:n]
-        return o
-    last = dict(points=stack(2, "points", 1100, (3,)), flags=stack(2, "flags", 1100), octave=stack(2, "octave", 1100),
-                angle=stack(2, "angle", 1100), desc=stack(2, "desc", 1100, (32,)))
-    local = {k: stack(3, k, 2200, (3,) if k == "points" else (32,) if k == "desc" else ())
-             for k in ("points", "flags", "u", "v", "ur", "level", "viewcos", "desc")}
-    with torch.cuda.stream(trk.stream):
-        trk.set_map(np.stack([maps[int(order[f])][0] for f in range(B)]), np.stack([maps[int(order[f])][1] for f in range(B)]),
-                    last, local)
-    trk.track(imgs, dep, inv)
-    torch.cuda.synchronize()
-    ext.sync()
-    trk.frames.match_status(stream=trk.st)
-    cnt, pose, ninl = trk.cnt.cpu().numpy(), trk.pose.cpu().numpy(), trk.ninl.cpu().numpy()
-    asg, kps = trk.assigned.cpu().numpy(), trk.kps.cpu().numpy()
     for u in range(NU):
         idx = np.nonzero(order == u)[0]
-        r = idx[0]
-        assert ninl[r] >= 100
+        q = idx[0]
+        assert r["n_inliers"][q] >= 100 and cnt[q] == ufr[u]["n"]
         for f in idx[1:]:
-            assert cnt[f] == cnt[r] and ninl[f] == ninl[r]
-            assert np.array_equal(kps[f, :cnt[r]], kps[r, :cnt[r]])
-            assert np.array_equal(asg[f], asg[r]) and np.array_equal(pose[f], pose[r])
-    assert len({tuple(pose[first[u]]) for u in range(NU)}) == NU
-    trk.close(), ext.close()
+            assert cnt[f] == cnt[q] and r["n_inliers"][f] == r["n_inliers"][q] and r["n_tracked"][f] == r["n_tracked"][q]
+            assert np.array_equal(asg[f], asg[q]) and np.array_equal(r["pose"][f], r["pose"][q])
+    assert len({tuple(r["pose"][first[u]]) for u in range(NU)}) == NU
+    trk.close()

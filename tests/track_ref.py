@@ -1,0 +1,84 @@
+"""The tracked-frame path of the reference, stage by stage on the CPU oracle (test infrastructure): what
+VisualOdometry::trackWithMotion + trackLocalMap do to one frame (src/visualOdometry.cpp:228-251, 286-300, 745-775,
+864-886).  Used by tests/test_gpu_tracking.py, tests/golden/make_g10_tracking.py and bench.py's cpu_baseline leg."""
+import ctypes as C
+
+import numpy as np
+
+
+def project_last(T, P, pf, cam, W, H):
+    """the projection prologue of Matcher::searchByProjection(Frame*, Frame*), matcher.cpp:41-64"""
+    x = T[0] * P[:, 0] + T[1] * P[:, 1] + T[2] * P[:, 2] + T[9]
+    y = T[3] * P[:, 0] + T[4] * P[:, 1] + T[5] * P[:, 2] + T[10]
+    zc = T[6] * P[:, 0] + T[7] * P[:, 1] + T[8] * P[:, 2] + T[11]
+    z = zc.astype(np.float32)
+    with np.errstate(divide="ignore", invalid="ignore"):
+        invz = (np.float32(1.0) / z).astype(np.float32)
+        u = (np.float64(cam[0]) * x / zc + np.float64(cam[2])).astype(np.float32)
+        v = (np.float64(cam[1]) * y / zc + np.float64(cam[3])).astype(np.float32)
+    ok = ((pf & 1) == 1) & ~(z < 0) & ~((u < 0) | (u > W)) & ~((v < 0) | (v > H))
+    flags = np.where(ok, 1 | (pf & 2), 0).astype(np.uint8)
+    return flags, np.where(ok, u, 0).astype(np.float32), np.where(ok, v, 0).astype(np.float32), np.where(ok, invz, 0).astype(np.float32)
+
+
+def is_in_frame(orc, pose6, local, valid, cam5, W, H, sf1, n_levels=8):
+    n = len(valid)
+    fl, lv = np.zeros(n, np.uint8), np.zeros(n, np.int32)
+    u, v, ur, vc = (np.zeros(n, np.float32) for _ in range(4))
+    orc.lib().orc_is_in_frame(n, np.ascontiguousarray(pose6, np.float64), np.ascontiguousarray(local["points"], np.float64),
+                              np.ascontiguousarray(local["normals"], np.float64), np.ascontiguousarray(local["min_dist"], np.float32),
+                              np.ascontiguousarray(local["max_dist"], np.float32), np.ascontiguousarray(valid, np.uint8),
+                              np.ascontiguousarray(cam5, np.float32), 0.0, float(W), 0.0, float(H), float(sf1), n_levels,
+                              fl, u, v, ur, lv, vc)
+    return fl, u, v, ur, lv, vc
+
+
+def track_frame(orc, k, d, ux, uy, ur, T, pose6, last, local, cam5, sf, W=640, H=480, radius=15.0, th_radius=3.0, ratio=0.8):
+    """-> dict of every intermediate result of the path for one frame (k, d: the oracle's key-points and descriptors;
+    ux, uy, ur: undistorted coordinates and uRight; T [12], pose6: the pose estimate; last / local: the map as
+    synth.make_tracking_map builds it)"""
+    n = len(k)
+    of = orc.FrameData(ux, uy, k["octave"], k["angle"], ur, d)
+    cam_d = np.asarray(cam5, np.float64)
+    qf, qu, qv, qz = project_last(T, last["points"], last["flags"], cam5, W, H)
+    a0 = np.full(n, -1, np.int32)
+    n0 = orc.lib().orc_match_frame_projection(C.byref(of.c), len(qf), qf, qu, qv, qz, np.ascontiguousarray(last["octave"], np.int32),
+                                              np.ascontiguousarray(last["angle"], np.float32), np.ascontiguousarray(last["desc"]),
+                                              float(radius), float(cam5[4]), 0, 1, 8, sf, np.zeros(n, np.uint8), a0)
+    fpt, has, fobs = np.zeros((n, 3)), a0 >= 0, np.zeros(n, np.uint8)
+    fpt[has] = last["points"][a0[has]]
+    fobs[has] = (qf[a0[has]] >> 1) & 1
+
+    def solve(pose_in):
+        idx = np.nonzero(has)[0]
+        pr = dict(pts=np.ascontiguousarray(fpt[idx]),
+                  obs=np.ascontiguousarray(np.stack([ux[idx], uy[idx], ur[idx]], 1).astype(np.float64)),
+                  inv_sigma=np.ascontiguousarray(1.0 / sf[k["octave"][idx]].astype(np.float64)), cam=cam_d, pose0=pose_in)
+        pose, outl, ninl, _, _ = orc.pose_only(pr)
+        return pose, np.asarray(outl, bool), ninl, idx
+
+    p1, out1, i1, idx1 = solve(np.asarray(pose6, np.float64))
+    # cullingOutliersBeforeLocalMap (:864-886)
+    n_obs1 = int(fobs[idx1[~out1]].sum())
+    has[idx1[out1]] = False
+    fobs[idx1[out1]] = 0
+    last_matched = np.zeros(len(last["flags"]), bool)
+    last_matched[a0[a0 >= 0]] = True
+    # searchLocalMapPoints (:745-775): isInFrame with the refined pose; points already in the frame are skipped
+    valid = np.asarray(local["valid"], np.uint8).copy()
+    lk = np.asarray(local.get("link", np.full(len(valid), -1)), np.int64)
+    skip = (lk >= 0) & last_matched[np.clip(lk, 0, len(last_matched) - 1)]
+    valid[skip] = 0
+    fl, lu, lv_, lur, llev, lvc = is_in_frame(orc, p1, local, valid, cam5, W, H, sf[1])
+    a1 = np.full(n, -1, np.int32)
+    n1 = orc.lib().orc_match_local_map(C.byref(of.c), len(fl), fl, lu, lv_, lur, llev, lvc, np.ascontiguousarray(local["desc"]),
+                                       float(th_radius), float(ratio), sf, fobs, a1)
+    new = a1 >= 0
+    fpt[new] = local["points"][a1[new]]
+    fobs[new] = (fl[a1[new]] >> 1) & 1
+    has = has | new
+    p2, out2, i2, idx2 = solve(p1)
+    n_tracked = int(fobs[idx2[~out2]].sum())
+    return dict(assigned_last=a0, n_last=n0, pose_1=p1, inliers_1=i1, observed_inliers_1=n_obs1, local_flags=fl, local_u=lu,
+                local_v=lv_, local_ur=lur, local_level=llev, local_viewcos=lvc, assigned_local=a1, n_local=n1, pose_2=p2,
+                inliers_2=i2, n_tracked=n_tracked, has=has)

@@ -47,6 +47,9 @@ SYMBOLS = [
     "vo_dataset_open", "vo_dataset_size", "vo_dataset_entry", "vo_dataset_close", "vo_png_info", "vo_png_read",
     "vo_trajectory_write", "vo_tracking_time_stats",
     "vo_track_project_dev", "vo_track_scatter_dev", "vo_track_gather_dev", "vo_pose_only_solve_ranges_dev",
+    "vo_tracker_create", "vo_tracker_destroy", "vo_tracker_info", "vo_tracker_extractor", "vo_tracker_frames",
+    "vo_tracker_stream", "vo_tracker_set_last_frame", "vo_tracker_set_local_map", "vo_tracker_track_dev", "vo_tracker_track",
+    "vo_tracker_results", "vo_tracker_get", "vo_tracker_sync", "vo_tracker_set_timing", "vo_tracker_get_timing",
     "vo_match_frame_projection", "vo_match_local_map", "vo_match_frame_keyframe", "vo_match_bow",
     "vo_match_triangulation", "vo_match_fuse", "vo_match_area_best", "vo_match_sim3_projection",
     "vo_match_sim3_mutual", "vo_vocab_create", "vo_vocab_destroy", "vo_bow_transform",
@@ -94,6 +97,11 @@ def lib():
         L.vo_ba_destroy.restype = None
     if hasattr(L, "vo_vocab_destroy"):
         L.vo_vocab_destroy.restype = None
+    if hasattr(L, "vo_tracker_destroy"):
+        L.vo_tracker_destroy.restype = None
+        L.vo_tracker_extractor.restype = C.c_void_p
+        L.vo_tracker_frames.restype = C.c_void_p
+        L.vo_tracker_stream.restype = C.c_void_p
     _lib = L
     return L
 
@@ -125,7 +133,16 @@ class OrbExtractor:
                                   int(iniThFAST), int(minThFAST)), "vo_orb_create")
         self.nlevels = nlevels
 
+    @classmethod
+    def borrowed(cls, handle, nlevels=8):
+        """a view of an extractor another object owns (vo_tracker_extractor): never destroyed from here"""
+        o = cls.__new__(cls)
+        o._h, o.nlevels, o._borrowed = handle, nlevels, True
+        return o
+
     def close(self):
+        if getattr(self, "_borrowed", False):
+            self._h = C.c_void_p()
         if getattr(self, "_h", None) and self._h.value and _lib is not None:   # (_lib is gone at interpreter exit)
             _lib.vo_orb_destroy(self._h)
             self._h = C.c_void_p()
@@ -348,6 +365,161 @@ class Frames:
 
     def match_status(self, stream=0):
         check(lib().vo_match_guided_status(self._h, C.c_void_p(stream)), "vo_match_guided_status")
+
+
+class TrackerConfig(C.Structure):
+    _fields_ = [("batch", C.c_int32), ("width", C.c_int32), ("height", C.c_int32), ("nfeatures", C.c_int32),
+                ("nlevels", C.c_int32), ("ini_th_fast", C.c_int32), ("min_th_fast", C.c_int32), ("scale_factor", C.c_float),
+                ("intrinsics", C.c_float * 5), ("dist_coef", C.c_float * 5), ("has_distortion", C.c_int32),
+                ("inv_depth_scale", C.c_float), ("max_last", C.c_int32), ("max_local", C.c_int32),
+                ("max_features", C.c_int32), ("single_stream", C.c_int32), ("stream", C.c_void_p),
+                ("extract_stream", C.c_void_p)]
+
+
+class TrackerParams(C.Structure):
+    _fields_ = [("radius", C.c_float), ("th_radius", C.c_float), ("ratio", C.c_float), ("direction", C.c_int32)]
+
+
+class Tracker:
+    """vo_tracker: VisualOdometry::trackWithMotion + trackLocalMap for a batch of camera streams, one C call per
+    batch (include/vo_hip.h).  This class only marshals arrays; torch appears where the caller hands over device
+    tensors (images, depth) or streams."""
+    (ASSIGNED_LAST, ASSIGNED_LOCAL, POSE_FIRST, INLIERS_FIRST, OBSERVED_INLIERS_FIRST, FEATURE_HAS_POINT, FEATURE_POINTS,
+     LOCAL_FLAGS, LOCAL_U, LOCAL_V, LOCAL_UR, LOCAL_LEVEL, LOCAL_VIEWCOS, KEYPOINT_COUNTS) = range(14)
+    STAGES = ("extract", "frame_post", "match_last_frame", "pose_only_1", "match_local_map", "pose_only_2")
+    FEW_MATCHES, FEW_INLIERS = 1, 2
+
+    def __init__(self, batch, intrinsics5, dist_coef=None, width=640, height=480, max_last=1024, max_local=2048,
+                 inv_depth_scale=1.0, nfeatures=1000, scale_factor=1.2, nlevels=8, ini_th=20, min_th=7, max_features=0,
+                 stream=None, extract_stream=None, single_stream=False):
+        cfg = TrackerConfig()
+        cfg.batch, cfg.width, cfg.height = int(batch), int(width), int(height)
+        cfg.nfeatures, cfg.nlevels, cfg.ini_th_fast, cfg.min_th_fast = int(nfeatures), int(nlevels), int(ini_th), int(min_th)
+        cfg.scale_factor = float(scale_factor)
+        cfg.intrinsics = (C.c_float * 5)(*[float(v) for v in intrinsics5])
+        if dist_coef is not None:
+            cfg.dist_coef = (C.c_float * 5)(*[float(v) for v in dist_coef])
+            cfg.has_distortion = 1
+        cfg.inv_depth_scale = float(inv_depth_scale)
+        cfg.max_last, cfg.max_local, cfg.max_features = int(max_last), int(max_local), int(max_features)
+        cfg.single_stream = int(bool(single_stream))
+        cfg.stream = stream if stream is None else int(stream)
+        cfg.extract_stream = extract_stream if extract_stream is None else int(extract_stream)
+        self._h = C.c_void_p()
+        check(lib().vo_tracker_create(C.byref(self._h), C.byref(cfg)), "vo_tracker_create")
+        b, cap, kcap, nl = C.c_int(), C.c_int(), C.c_int(), C.c_int()
+        check(lib().vo_tracker_info(self._h, C.byref(b), C.byref(cap), C.byref(kcap), C.byref(nl)), "vo_tracker_info")
+        self.B, self.cap, self.kcap, self.n_levels = b.value, cap.value, kcap.value, nl.value
+        self.W, self.H, self.max_last, self.max_local = int(width), int(height), int(max_last), int(max_local)
+        self.st = lib().vo_tracker_stream(self._h)
+
+    def close(self):
+        if getattr(self, "_h", None) and self._h.value and _lib is not None:
+            _lib.vo_tracker_destroy(self._h)
+            self._h = C.c_void_p()
+
+    __del__ = close
+
+    @property
+    def frames_handle(self):
+        return C.c_void_p(lib().vo_tracker_frames(self._h))
+
+    @property
+    def extractor_handle(self):
+        return C.c_void_p(lib().vo_tracker_extractor(self._h))
+
+    def extractor(self):
+        """the tracker's extractor as an OrbExtractor view (per-kernel timing, candidates)"""
+        return OrbExtractor.borrowed(self.extractor_handle, self.n_levels)
+
+    def scale_factors(self):
+        sf = np.zeros(self.n_levels, np.float32)
+        check(lib().vo_orb_scale_factors(self.extractor_handle, _p(sf), None), "vo_orb_scale_factors")
+        return sf
+
+    def set_last_frame(self, Tcw12, points, flags, octave, angle, desc):
+        """arrays [B, n, ...] (numpy)"""
+        n = np.asarray(flags).shape[1]
+        a = lambda x, dt: np.ascontiguousarray(x, dt)
+        check(lib().vo_tracker_set_last_frame(self._h, int(n), _p(a(Tcw12, np.float64)), _p(a(points, np.float64)),
+                                              _p(a(flags, np.uint8)), _p(a(octave, np.int32)), _p(a(angle, np.float32)),
+                                              _p(a(desc, np.uint8))), "vo_tracker_set_last_frame")
+
+    def set_local_map(self, points, normals, min_dist, max_dist, flags, desc, link=None):
+        n = np.asarray(flags).shape[1]
+        a = lambda x, dt: np.ascontiguousarray(x, dt)
+        lk = None if link is None else a(link, np.int32)
+        check(lib().vo_tracker_set_local_map(self._h, int(n), _p(a(points, np.float64)), _p(a(normals, np.float64)),
+                                             _p(a(min_dist, np.float32)), _p(a(max_dist, np.float32)), _p(a(flags, np.uint8)),
+                                             _p(lk), _p(a(desc, np.uint8))), "vo_tracker_set_local_map")
+
+    @staticmethod
+    def _params(radius, th_radius, ratio, direction):
+        return TrackerParams(float(radius), float(th_radius), float(ratio), int(direction))
+
+    def track_dev(self, images, depth=None, radius=15.0, th_radius=3.0, ratio=0.8, direction=0):
+        """images: uint8 [B,H,W] device tensor; depth: float32 or (u)int16 [B,H,W] device tensor or None.  Asynchronous."""
+        kind, fs, pitch = 0, 0, 0
+        if depth is not None:
+            kind = 1 if depth.element_size() == 4 else 2
+            fs, pitch = depth.stride(0) * depth.element_size(), depth.stride(1) * depth.element_size()
+        pr = self._params(radius, th_radius, ratio, direction)
+        check(lib().vo_tracker_track_dev(self._h, _p(images), int(images.stride(1)), C.c_size_t(images.stride(0)), _p(depth),
+                                         kind, C.c_size_t(fs), int(pitch), C.byref(pr)), "vo_tracker_track_dev")
+
+    def track(self, images, depth=None, radius=15.0, th_radius=3.0, ratio=0.8, direction=0):
+        """host arrays: images uint8 [B,H,W]; depth float32 / uint16 [B,H,W] or None (uploads included)."""
+        img = np.ascontiguousarray(images, np.uint8)
+        kind, dp = 0, None
+        if depth is not None:
+            dp = np.ascontiguousarray(depth)
+            kind = 1 if dp.dtype == np.float32 else 2
+        pr = self._params(radius, th_radius, ratio, direction)
+        check(lib().vo_tracker_track(self._h, _p(img), _p(dp), kind, C.byref(pr)), "vo_tracker_track")
+
+    def results(self):
+        B = self.B
+        out = dict(pose=np.zeros((B, 6)), Tcw=np.zeros((B, 12)), n_tracked=np.zeros(B, np.int32), n_inliers=np.zeros(B, np.int32),
+                   n_matches_last=np.zeros(B, np.int32), n_matches_local=np.zeros(B, np.int32), status=np.zeros(B, np.int32))
+        check(lib().vo_tracker_results(self._h, _p(out["pose"]), _p(out["Tcw"]), _p(out["n_tracked"]), _p(out["n_inliers"]),
+                                       _p(out["n_matches_last"]), _p(out["n_matches_local"]), _p(out["status"])),
+              "vo_tracker_results")
+        return out
+
+    def get(self, what):
+        B, cap, nl = self.B, self.cap, self.max_local
+        shape, dt = {
+            self.ASSIGNED_LAST: ((B, cap), np.int32), self.ASSIGNED_LOCAL: ((B, cap), np.int32),
+            self.POSE_FIRST: ((B, 6), np.float64), self.INLIERS_FIRST: ((B,), np.int32),
+            self.OBSERVED_INLIERS_FIRST: ((B,), np.int32), self.FEATURE_HAS_POINT: ((B, cap), np.uint8),
+            self.FEATURE_POINTS: ((B, cap, 3), np.float64), self.LOCAL_FLAGS: ((B, max(nl, 1)), np.uint8),
+            self.LOCAL_U: ((B, max(nl, 1)), np.float32), self.LOCAL_V: ((B, max(nl, 1)), np.float32),
+            self.LOCAL_UR: ((B, max(nl, 1)), np.float32), self.LOCAL_LEVEL: ((B, max(nl, 1)), np.int32),
+            self.LOCAL_VIEWCOS: ((B, max(nl, 1)), np.float32), self.KEYPOINT_COUNTS: ((B,), np.int32)}[what]
+        out = np.zeros(shape, dt)
+        check(lib().vo_tracker_get(self._h, int(what), _p(out), C.c_size_t(out.nbytes)), "vo_tracker_get")
+        return out
+
+    def sync(self):
+        check(lib().vo_tracker_sync(self._h), "vo_tracker_sync")
+
+    def set_timing(self, enabled=True):
+        check(lib().vo_tracker_set_timing(self._h, int(bool(enabled))), "vo_tracker_set_timing")
+
+    def get_timing(self):
+        ms = (C.c_double * len(self.STAGES))()
+        n = C.c_int()
+        check(lib().vo_tracker_get_timing(self._h, ms, C.byref(n)), "vo_tracker_get_timing")
+        return {k: ms[i] for i, k in enumerate(self.STAGES)}, n.value
+
+    def download_frame(self, slot):
+        """the frame store's slot (tests): dict of numpy arrays as Frames.download"""
+        fr = Frames.__new__(Frames)
+        fr._h, fr.cap, fr.max_frames = self.frames_handle, self.cap, self.B
+        try:
+            return fr.download(slot, stream=self.st)
+        finally:
+            fr._h = C.c_void_p()  # not ours to destroy
 
 
 class FrameArrays:

@@ -429,4 +429,20 @@ def make_tracking_map(kx, ky, octave, angle, desc, depth_m, seed: int, n_local_r
     local = dict(points=Pl, flags=lflags, u=u, v=v, ur=ur,
                  level=np.clip(octave[idx] + rng.integers(0, 2, m), 0, 7).astype(np.int32),
                  viewcos=rng.uniform(0.99, 1.0, m).astype(np.float32), desc=dl)
+    # what Frame::isInFrame reads of a MapPoint (frame.cpp:145-190): normal vector and distance range as
+    # MapPoint::updateNormalAndDepth leaves them for a reference key-frame near the true camera (maxDistance_ = distance
+    # times the scale of the feature's level, minDistance_ = maxDistance_ / scale of the last level); `link`: the local
+    # point is the same MapPoint as this entry of the last frame's list (-1: it is not in that list); `valid` = flags
+    # before the pre-projection above (bit 0 exists / not bad, bit 1 has observations)
+    r2 = _rng(0x7AC50000 + seed)
+    cref = r2.normal(0, 0.03, (m, 3))
+    line = Pl - cref
+    dref = np.linalg.norm(line, axis=1)
+    sfl = 1.2 ** np.clip(octave[idx] + r2.integers(0, 2, m), 0, 7).astype(np.float64)
+    local["normals"] = line / dref[:, None]
+    local["max_dist"] = (dref * sfl).astype(np.float32)
+    local["min_dist"] = (local["max_dist"] / np.float32(1.2 ** 7)).astype(np.float32)
+    local["valid"] = np.where(r2.random(m) < 0.6, 3, 1).astype(np.uint8)
+    local["valid"][r2.random(m) < 0.05] = 0
+    local["link"] = np.where(r2.random(m) < 0.3, idx, -1).astype(np.int32)
     return Tcw12, se3_log(R, t), last, local
