@@ -344,7 +344,7 @@ __device__ __forceinline__ void wave_reduce28(const double (&v)[28], double *scr
 // and at the candidate
 template <bool WAVE>
 struct PoseLds {
-  static constexpr int kRed = WAVE ? kPoseRedScratch : 4 * 28;
+  static constexpr int kRed = WAVE ? kPoseRedScratch : 4 * kPoseRedScratch + 4 * 28;  // per-wave scratch, then the wave totals
   double red[kRed];
   double acc[28];   // linearisation at x: 21 + 6 + 1 sums, uniform over the workgroup
   double cand[28];  // ... at the trial point
@@ -367,11 +367,18 @@ __device__ void pose_lm(double x[6], int n, const ObsView &V, const Cam &K, doub
     if (WAVE) {
       wave_reduce28(v, S.red, dst);
     } else {
-      block_sum<28>(v, S.red);
+      // every wavefront reduces its lanes through its own scratch (the same transpose as the one-wavefront kernel: a
+      // tenth of the instructions of 28 DPP / readlane sums -- this path is the latency of ONE frame), then 28 threads add
+      // the wave totals in wave order
+      const int wave = threadIdx.x >> 6, nw = (int)blockDim.x >> 6;
+      double *tot = S.red + 4 * kPoseRedScratch;
+      __syncthreads();  // the previous pass's totals have been read
+      wave_reduce28(v, S.red + wave * kPoseRedScratch, tot + wave * 28);
       __syncthreads();
-      if (threadIdx.x == 0) {
-#pragma unroll
-        for (int i = 0; i < 28; i++) dst[i] = v[i];
+      if (threadIdx.x < 28) {
+        double t = 0;
+        for (int w = 0; w < nw; w++) t += tot[w * 28 + threadIdx.x];
+        dst[threadIdx.x] = t;
       }
       __syncthreads();
     }
