@@ -9,6 +9,7 @@
 // reference tree.  tests/test_shims_compile.py checks the syntax against stub declarations of those types.
 #include <algorithm>
 #include <cstring>
+#include <iostream>
 #include <map>
 #include <set>
 #include <vector>
@@ -271,9 +272,17 @@ int Optimizer::solvePoseGraphLoop(Map *map_curr, KeyFrame *keyframe_match, KeyFr
     }
   }
   // :1238-1258: key-frame `match` constant, quaternion parameterisation, scales constant, <= 20 iterations
-  vo_pose_graph_solve((int)n_ids, quats.data(), trans.data(), scales.data(), (int)keyframe_match->id_, (int)e_i.size(),
-                      e_i.data(), e_j.data(), q_meas.data(), t_meas.data(), s_meas.data(), fixScaleFlag ? 1 : 0, 20,
-                      nullptr);
+  const int pg_rc = vo_pose_graph_solve((int)n_ids, quats.data(), trans.data(), scales.data(), (int)keyframe_match->id_,
+                                        (int)e_i.size(), e_i.data(), e_j.data(), q_meas.data(), t_meas.data(), s_meas.data(),
+                                        fixScaleFlag ? 1 : 0, 20, nullptr);
+  if (pg_rc != VO_OK) {
+    // The reference never inspects Ceres' summary (:1258), but a solver that did not run must not write anything back:
+    // `quats` / `trans` still hold the uncorrected poses, and re-anchoring the map points through them would apply the
+    // loop correction to the points and not to the key-frames.  Leave the map as it is and say why.
+    std::cerr << "solvePoseGraphLoop: vo_pose_graph_solve failed (" << pg_rc << "): " << vo_last_error()
+              << " -- loop closure not applied" << std::endl;
+    return 0;
+  }
   {
     unique_lock<mutex> lock(map_curr->mutexMapUpdate_);
     std::vector<double> S_rw(8 * n_ids, 0.0), S_wr(8 * n_ids, 0.0);  // Sim3 as quaternion (x y z w), translation, scale

@@ -103,19 +103,36 @@ def test_rgb_to_gray(vo, orc):
     assert np.abs(vo.rgb_to_gray(img, True).astype(float) - y).max() <= 1.0   # the fixed-point weights of cv::cvtColor
 
 
-def _write_dbow3_binary(path, k, L, parent, weight, word_id, desc):
+def _write_dbow3_binary(path, k, L, parent, weight, word_id, desc, children=None, compressed=False, truncate=None, bad_parent=False):
+    """DBoW3 Vocabulary::toStream as published (the library is not vendored under the reference): magic, bool compressed,
+    uint32 nnodes, k, L, scoring, weighting; nnodes - 1 node records -- NO root record -- in the writer's depth-first
+    order (a stack of parents; the children of a popped parent are written in order, non-leaf children pushed): id,
+    parent, weight (double), descriptor (cols, rows, type, bytes); then the word table (count; node id, word id)."""
     n = len(parent)
+    if children is None:
+        children = [[] for _ in range(n)]
+        for i in range(1, n):
+            children[int(parent[i])].append(i)
+    body = struct.pack("<iiii", k, L, 0, 0)
+    stack, written = [0], 0
+    while stack:
+        pid = stack.pop()
+        for c in children[pid]:
+            par = n + 5 if (bad_parent and written == 3) else pid
+            body += struct.pack("<IId", c, par, float(weight[c])) + struct.pack("<iii", 32, 1, 0) + bytes(desc[c])
+            written += 1
+            if children[c]:
+                stack.append(c)
+    words = [i for i in range(n) if word_id[i] >= 0]
+    body += struct.pack("<I", len(words))
+    for i in words:
+        body += struct.pack("<II", i, int(word_id[i]))
+    if truncate is not None:
+        body = body[:truncate]
     with open(path, "wb") as f:
         f.write(struct.pack("<Q", 88877711233))
-        f.write(struct.pack("<?I", False, n))
-        f.write(struct.pack("<iiii", k, L, 0, 0))
-        for i in range(n):
-            f.write(struct.pack("<IIdI", i, int(parent[i]), float(weight[i]), int(max(word_id[i], 0))))
-            if i == 0:
-                f.write(struct.pack("<iii", 0, 0, 0))             # the root carries no descriptor
-            else:
-                f.write(struct.pack("<iii", 32, 1, 0))
-                f.write(bytes(desc[i]))
+        f.write(struct.pack("<?I", compressed, n))
+        f.write(body)
 
 
 def _write_orbslam_text(path, k, L, parent, weight, word_id, desc):
@@ -150,3 +167,9 @@ def test_vocabulary_file_loader(vo, orc, fmt, tmp_path):
     (tmp_path / "junk.bin").write_bytes(b"\x00" * 64)
     with pytest.raises(vo.VoError):
         vo.load_vocabulary(tmp_path / "junk.bin")
+    if fmt == "binary":  # malformed streams are refused, not trusted: compressed, truncated, a parent id out of range
+        args = (6, 3, parent, V["node_weight"], V["word_id"], V["node_desc"])
+        for name, kw in (("z", dict(compressed=True)), ("t", dict(truncate=1000)), ("p", dict(bad_parent=True))):
+            _write_dbow3_binary(tmp_path / name, *args, **kw)
+            with pytest.raises(vo.VoError):
+                vo.load_vocabulary(tmp_path / name)

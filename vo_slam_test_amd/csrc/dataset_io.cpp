@@ -287,49 +287,80 @@ int vo_vocab_load(const char *path, vo_vocab **out, int *n_nodes, int *n_words, 
   std::vector<VocNode> nodes;
   int k = 0, L = 0;
   if (f && sig == 88877711233ULL) {
-    // DBoW3 0.0.1 Vocabulary::toStream: magic, bool compressed, uint32 node count; then k, L, scoring, weighting (ints)
-    // and per node: id, parent (uint32), weight (double), word id (uint32), descriptor (cols, rows, type, bytes)
+    // DBoW3 Vocabulary::toStream (the library is not vendored under the reference; layout restated from its published
+    // source): magic, bool compressed, uint32 node count nn; then k, L, scoring, weighting (ints); then nn - 1 records --
+    // the root is implicit -- in the writer's depth-first order: node id, parent id (uint32), weight (double), descriptor
+    // (int cols, rows, type, then cols x elemSize bytes); then uint32 word count and per word (node id, word id).
+    // Children are attached to their parent in FILE order (fromStream does `m_nodes[parent].children.push_back(id)` per
+    // record), which is the order Vocabulary::transform visits them in -- ties in the Hamming distance go to the first.
+    // Compressed streams (QuickLZ chunks; what `Vocabulary::save(path)` writes by default) are not decoded: re-save with
+    // `save(path, false)`.
     char compressed = 0;
     uint32_t nn = 0;
     f.read(&compressed, 1);
     f.read(reinterpret_cast<char *>(&nn), 4);
+    if (!f || nn == 0 || nn > 50u * 1000 * 1000) {
+      vo::set_error("%s: implausible node count %u", path, nn);
+      return VO_ERR_INVALID;
+    }
     if (compressed) {
-      vo::set_error("%s: compressed DBoW3 vocabularies are not supported", path);
+      vo::set_error("%s: compressed DBoW3 vocabulary (QuickLZ): re-save it with Vocabulary::save(path, false)", path);
       return VO_ERR_INVALID;
     }
     int32_t hdr[4];
     f.read(reinterpret_cast<char *>(hdr), 16);
     k = hdr[0], L = hdr[1];
+    if (!f || k < 1 || k > 64 || L < 1 || L > 16) {
+      vo::set_error("%s: implausible branching factor / depth %d / %d", path, k, L);
+      return VO_ERR_INVALID;
+    }
     nodes.resize(nn);
-    for (uint32_t i = 0; i < nn && f; i++) {
+    nodes[0].id = 0, nodes[0].parent = 0, nodes[0].weight = 0;
+    memset(nodes[0].desc, 0, 32);
+    std::vector<uint8_t> seen(nn, 0);
+    seen[0] = 1;
+    for (uint32_t i = 1; i < nn; i++) {
       VocNode n;
       int32_t cols = 0, rows = 0, type = 0;
       f.read(reinterpret_cast<char *>(&n.id), 4);
       f.read(reinterpret_cast<char *>(&n.parent), 4);
       f.read(reinterpret_cast<char *>(&n.weight), 8);
-      f.read(reinterpret_cast<char *>(&n.word_id), 4);
       f.read(reinterpret_cast<char *>(&cols), 4);
       f.read(reinterpret_cast<char *>(&rows), 4);
       f.read(reinterpret_cast<char *>(&type), 4);
-      memset(n.desc, 0, 32);
-      if (cols > 0) {
-        if ((type & 7) != 0 || cols != 32) {  // CV_8U, 32 bytes: ORB
-          vo::set_error("%s: node %u has a %d-column descriptor of type %d (need 32 x CV_8U)", path, n.id, cols, type);
-          return VO_ERR_INVALID;
-        }
-        f.read(reinterpret_cast<char *>(n.desc), 32);
-      }
-      if (n.id >= nn) {
-        vo::set_error("%s: node id %u out of range", path, n.id);
+      if (!f) break;
+      if (n.id == 0 || n.id >= nn || n.parent >= nn || seen[n.id]) {
+        vo::set_error("%s: record %u names node %u / parent %u (of %u nodes%s)", path, i, n.id, n.parent, nn,
+                      n.id < nn && seen[n.id] ? ", twice" : "");
         return VO_ERR_INVALID;
       }
+      memset(n.desc, 0, 32);
+      if ((type & 7) != 0 || cols != 32 || rows != 1) {  // CV_8U, 1 x 32: ORB
+        vo::set_error("%s: node %u has a %d x %d descriptor of type %d (need 1 x 32 CV_8U)", path, n.id, rows, cols, type);
+        return VO_ERR_INVALID;
+      }
+      f.read(reinterpret_cast<char *>(n.desc), 32);
+      seen[n.id] = 1;
+      n.children.clear();
       nodes[n.id] = n;
+      nodes[n.parent].children.push_back(n.id);
     }
-    if (!f) {
+    uint32_t nw = 0;
+    f.read(reinterpret_cast<char *>(&nw), 4);
+    if (!f || nw > nn) {
       vo::set_error("%s: truncated vocabulary", path);
       return VO_ERR_INVALID;
     }
-    for (uint32_t i = 1; i < nn; i++) nodes[nodes[i].parent].children.push_back(i);  // file order = id order
+    for (uint32_t i = 0; i < nw; i++) {
+      uint32_t nid = 0, wid = 0;
+      f.read(reinterpret_cast<char *>(&nid), 4);
+      f.read(reinterpret_cast<char *>(&wid), 4);
+      if (!f || nid >= nn || wid >= nw) {
+        vo::set_error("%s: malformed word table (entry %u: node %u, word %u)", path, i, nid, wid);
+        return VO_ERR_INVALID;
+      }
+      nodes[nid].word_id = wid;
+    }
   } else {
     // ORB-SLAM2 text vocabulary: "k L scoring weighting", then one line per node: parent is_leaf 32 bytes weight
     f.clear();

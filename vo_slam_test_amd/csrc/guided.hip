@@ -913,7 +913,12 @@ int guided_launch(vo_frames *h, int slot0, int n_frames, const Queries &Q, const
   const bool claims = c.mode == kModeFrame || c.mode == kModeLocalMap || c.mode == kModeKeyFrame || c.mode == kModeSim3;
   GuidedOut O{};
   O.best_idx = best_idx, O.assigned = assigned, O.fmask = fmask, O.n_matches = n_matches;
-  VO_CHECK(h->b_err.reserve(64));
+  // the overflow flag is sticky (like the extractor's): kernels only ever set it, vo_match_guided_status reads and clears
+  // it -- two searches launched back to back on one handle (the tracked path) cannot erase each other's report
+  if (!h->b_err.p) {
+    VO_CHECK(h->b_err.reserve(64));
+    VO_HIP_CHECK(hipMemsetAsync(h->b_err.p, 0, 64, st));
+  }
   O.err = h->b_err.as<int>();
   if (claims) {
     // every query owns kSlot records; `pool_per_frame` sizes the overflow area dense windows spill into
@@ -934,7 +939,6 @@ int guided_launch(vo_frames *h, int slot0, int n_frames, const Queries &Q, const
     O.ovf_stride = (int)pool_per_frame;
     VO_HIP_CHECK(hipMemsetAsync(O.ovf_used, 0, (size_t)n_frames * 4, st));
   }
-  VO_HIP_CHECK(hipMemsetAsync(O.err, 0, 4, st));
   const int nq_max = Q.nq_all;
   if (nq_max > 0) {
     // narrow windows (the tracking searches: 15 px, 2.5-4 px times the level scale: 1-5 features) -> eight lanes per
@@ -1172,7 +1176,8 @@ int vo_match_guided_status(vo_frames *h, void *hip_stream) {
   VO_CHECK(vo::copy_d2h(&e, h->b_err.p, 4, st, "vo_match_guided_status"));
   VO_CHECK(vo::stream_sync(st, "vo_match_guided_status"));
   if (e) {
-    vo::set_error("guided matcher: candidate pool overflow (raise pool_per_frame)");
+    VO_HIP_CHECK(hipMemsetAsync(h->b_err.p, 0, 4, st));  // reported once
+    vo::set_error("guided matcher: candidate pool overflow in a search since the last status call (raise pool_per_frame)");
     return VO_ERR_CAPACITY;
   }
   return VO_OK;
@@ -1287,6 +1292,7 @@ int guided_host(const vo_frame_view *cur, const HostQueries &hq, const GuidedCal
     int e;
     memcpy(&e, sg + r_err, 4);
     if (!e) break;
+    VO_HIP_CHECK(hipMemsetAsync(h->b_err.p, 0, 4, st));  // the flag is sticky: this retry loop consumes it
     if (attempt >= 6) {
       vo::set_error("guided matcher: candidate pool overflow");
       return VO_ERR_CAPACITY;

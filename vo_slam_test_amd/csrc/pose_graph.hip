@@ -445,7 +445,7 @@ int vo_pose_graph_solve(int n_nodes, double *quats, double *trans, const double 
   PG_TRY(linearize(dx, 1, gmax));
   PG_TRY(cost_of(dx, x_cost));
   summary->initial_cost = x_cost;
-  int iterations = 0, accepted = 0, termination = 0, invalid = 0;
+  int iterations = 0, accepted = 0, termination = 0, invalid = 0, chol_retries = 0;
   bool last_ok = false;
   for (int it = 1;; it++) {
     if (it - 1 >= max_iterations) {
@@ -481,6 +481,17 @@ int vo_pose_graph_solve(int n_nodes, double *quats, double *trans, const double 
     PG_TRY(vo::copy_d2h(h_norm.data(), d_norm.p, h_norm.size() * 8, st, "pose graph"));
     PG_TRY(vo::copy_d2h(h_cost.data(), d_cost.p, h_cost.size() * 8, st, "pose graph"));
     PG_TRY(vo::stream_sync(st, "pose graph"));
+    if (failed == 2) {
+      // the factorisation kernel gave up waiting for a tile (a GPU shared with other work can starve it): that is not
+      // "the matrix is not positive definite" -- treating it as an invalid step would shrink the trust region and change
+      // the LM path from run to run.  Same radius, same system, once more; a second abandonment is an error.
+      if (++chol_retries > 2) {
+        vo::set_error("pose graph: the factorisation kernel abandoned a wait three times (GPU oversubscribed?)");
+        return VO_ERR_HIP;
+      }
+      it--;
+      continue;
+    }
     double model = 0;
     if (!failed)
       for (double v : h_part) model += v;
