@@ -315,8 +315,21 @@ int run_pipeline(vo_tracker *t, const uint8_t *dev_images, int img_pitch, size_t
     VO_HIP_CHECK(hipEventRecord(t->ev_build, st));
     t->have_build = true;
   }
-  // ---- searchByProjection against the last frame
   const size_t capB = (size_t)B * t->cap;
+  if (t->nq_last == 0) {
+    // no last frame (the first frame of a sequence, visualOdometry.cpp:170-214): Frame construction only; the pose is
+    // the one handed in, every count zero
+    VO_HIP_CHECK(hipMemcpyAsync(t->pose.p, t->pose0.p, (size_t)B * 48, hipMemcpyDeviceToDevice, st));
+    VO_HIP_CHECK(hipMemcpyAsync(t->pose_first.p, t->pose0.p, (size_t)B * 48, hipMemcpyDeviceToDevice, st));
+    VO_HIP_CHECK(hipMemsetAsync(t->assigned.p, 0xff, capB * 4, st));
+    VO_HIP_CHECK(hipMemsetAsync(t->assigned_first.p, 0xff, capB * 4, st));
+    VO_HIP_CHECK(hipMemsetAsync(t->fhas.p, 0, capB, st));
+    for (DevBuf *b : {&t->nm, &t->nm_first, &t->ninl, &t->ninl_first, &t->nobs_first, &t->ntracked, &t->status})
+      VO_HIP_CHECK(hipMemsetAsync(b->p, 0, (size_t)B * 4, st));
+    t->tpending = false;
+    return VO_OK;
+  }
+  // ---- searchByProjection against the last frame
   vo_guided_queries q{};
   vo_guided_params gp{};
   gp.n_levels = t->n_levels, gp.scale_factors = t->sf;
