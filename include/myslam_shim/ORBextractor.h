@@ -13,6 +13,7 @@
 
 #include <opencv2/core/core.hpp>
 
+#include <list>
 #include <stdexcept>
 #include <string>
 #include <vector>
@@ -20,6 +21,19 @@
 #include "vo_hip.h"
 
 namespace ORB_SLAM2 {
+
+// The reference declares the oct-tree node publicly (ORBextractor.h:31-43) although nothing outside ORBextractor.cpp
+// uses it; kept so that code naming the type still compiles.  DistributeOctTree itself runs on the device (k_octree):
+// DivideNode is declared, as there, and deliberately not defined here.
+class ExtractorNode {
+ public:
+  ExtractorNode() : bNoMore(false) {}
+  void DivideNode(ExtractorNode &n1, ExtractorNode &n2, ExtractorNode &n3, ExtractorNode &n4);
+  std::vector<cv::KeyPoint> vKeys;
+  cv::Point2i UL, UR, BL, BR;
+  std::list<ExtractorNode>::iterator lit;
+  bool bNoMore;
+};
 
 class ORBextractor {
  public:
@@ -59,6 +73,9 @@ class ORBextractor {
       desc.rowRange(0, n).copyTo(descriptors);
     pyramid_valid_ = false;
   }
+
+  // the C-ABI handle, for the shims that keep a frame on the device behind the extraction (frame_hip.inl)
+  vo_orb *handle() { return h_; }
 
   int inline GetLevels() { return nlevels_; }
   float inline GetScaleFactor() { return scaleFactor_; }

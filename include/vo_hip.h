@@ -178,6 +178,14 @@ int vo_frames_build_dev(vo_frames *h, int slot0, int n_frames, const vo_keypoint
                         const uint8_t *dev_descriptors, const int32_t *dev_counts, int capacity,
                         const void *dev_depth, int depth_kind, size_t depth_frame_stride_bytes,
                         int depth_pitch_bytes, float inv_depth_scale, void *hip_stream);
+/* Frame::Frame (frame.cpp:14-34) for one host image in one call: ORB extraction (:22), undistortKeyPoints,
+ * findDepth, assignFeaturesToGrid (:27-31) on the device -- the image goes up once, nothing comes back but
+ * the raw key-points (Frame::keypoints_, written here) and what vo_frames_download then returns for the slot
+ * (unKeypoints_, uRight_, depth_, descriptors_, the grid).  The extractor handle is switched to the calling
+ * thread's stream.  depth as in vo_frames_build_dev (host pointer). */
+int vo_frames_construct(vo_frames *h, int slot, vo_orb *orb, const uint8_t *image, int width, int height, int stride,
+                        const void *depth, int depth_kind, int depth_pitch_bytes, float inv_depth_scale,
+                        vo_keypoint *keypoints, int capacity, int *n_keypoints);
 /* one already post-processed frame from host arrays (builds the grid); depth may be NULL */
 int vo_frames_upload(vo_frames *h, int slot, const vo_frame_view *view, const float *depth,
                      void *hip_stream);

@@ -9,6 +9,7 @@
 #define CV_Assert(x) ((void)(x))
 namespace cv {
 struct Point2f { float x, y; };
+struct Point2i { int x, y; };
 struct KeyPoint { Point2f pt; float size, angle, response; int octave, class_id; };
 class Mat;
 class _InputArray { public: _InputArray(); _InputArray(const Mat &); bool empty() const; Mat getMat() const; };

@@ -391,3 +391,32 @@ def test_guided_search_with_the_largest_frame_capacity(vo, orc):
         assert int(nm[0]) == on and on > 300
         assert np.array_equal(assigned[0, :len(k1)].cpu().numpy(), oa)
         fr.close()
+
+
+@pytest.mark.parametrize("depth_kind", ["u16", "f32", None])
+def test_frame_construct_in_one_call(vo, orc, depth_kind):
+    """vo_frames_construct = Frame::Frame (frame.cpp:14-34) for one host image: the raw key-points equal the extractor's,
+    the stored frame equals the oracle's undistortKeyPoints / findDepth / descriptors"""
+    idx, W, H = 33, 640, 480
+    img, raw = synth.make_frame(idx), synth.make_depth(idx)
+    inv = np.float32(1.0) / np.float32(synth.DEPTH_SCALE)
+    cam5 = synth.CAM.astype(np.float32)
+    ext = vo.OrbExtractor(1000, 1.2, 8, 20, 7)
+    k_ref, d_ref = ext(img)
+    fr = vo.Frames(1, 2048, cam5, synth.DIST, float(W), float(H))
+    dimg = np.zeros((H, W), np.float32)
+    orc.lib().orc_depth_to_float(np.ascontiguousarray(raw).reshape(-1), H * W, float(inv), dimg.reshape(-1))
+    depth = None if depth_kind is None else (raw.view(np.uint16) if depth_kind == "u16" else dimg)
+    kps = fr.construct(0, ext, img, depth, float(inv) if depth_kind == "u16" else 1.0)
+    assert np.array_equal(kps, k_ref)
+    got = fr.download(0)
+    n = len(k_ref)
+    x, y = np.ascontiguousarray(k_ref["x"]), np.ascontiguousarray(k_ref["y"])
+    ux, uy = np.zeros(n, np.float32), np.zeros(n, np.float32)
+    orc.lib().orc_undistort_points(n, x, y, cam5[:4].copy(), synth.DIST.ctypes.data, ux, uy)
+    assert got["n"] == n and np.array_equal(got["x"], ux) and np.array_equal(got["y"], uy) and np.array_equal(got["desc"], d_ref)
+    ur, dep = np.full(n, -1, np.float32), np.full(n, -1, np.float32)
+    if depth_kind is not None:
+        orc.lib().orc_find_depth(n, x, y, ux, dimg, W, H, W, float(cam5[4]), ur, dep)
+    assert np.array_equal(got["uright"], ur) and np.array_equal(got["depth"], dep)
+    fr.close(), ext.close()

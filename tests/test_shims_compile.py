@@ -12,7 +12,7 @@ ROOT = pathlib.Path(__file__).resolve().parent.parent
 STUBS = ROOT / "tests" / "shim_stubs"
 
 
-@pytest.mark.parametrize("tu", ["orbextractor", "matcher", "optimizer", "mappoint"])
+@pytest.mark.parametrize("tu", ["orbextractor", "matcher", "optimizer", "mappoint", "frame", "sim3solver", "localmapping", "map"])
 def test_shim_parses(tu):
     gxx = shutil.which("g++")
     assert gxx, "g++ is part of the image"

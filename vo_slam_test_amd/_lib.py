@@ -42,7 +42,7 @@ SYMBOLS = [
     "vo_orb_get_level_counts", "vo_orb_set_timing", "vo_orb_get_timing",
     "vo_hamming_matrix_dev", "vo_hamming_matrix_batch_dev", "vo_hamming_matrix", "vo_median_descriptor",
     "vo_frames_create", "vo_frames_destroy", "vo_frames_capacity", "vo_frames_set_camera", "vo_frames_build_dev",
-    "vo_frames_upload", "vo_frames_download", "vo_frames_features_in_area", "vo_match_guided_dev", "vo_match_guided_status",
+    "vo_frames_upload", "vo_frames_construct", "vo_frames_download", "vo_frames_features_in_area", "vo_match_guided_dev", "vo_match_guided_status",
     "vo_vocab_load", "vo_bow_score", "vo_sim3_ransac_eval", "vo_triangulate", "vo_rgb_to_gray", "vo_rgb_to_gray_dev",
     "vo_dataset_open", "vo_dataset_size", "vo_dataset_entry", "vo_dataset_close", "vo_png_info", "vo_png_read",
     "vo_trajectory_write", "vo_tracking_time_stats",
@@ -311,6 +311,21 @@ class Frames:
         check(lib().vo_frames_build_dev(self._h, int(slot0), B, _p(kps), _p(desc), _p(counts), cap, _p(depth), kind,
                                         C.c_size_t(fs), pitch, C.c_float(inv_depth_scale), C.c_void_p(stream)),
               "vo_frames_build_dev")
+
+    def construct(self, slot, ext: "OrbExtractor", image, depth=None, inv_depth_scale=1.0):
+        """Frame::Frame for one host image (vo_frames_construct): -> raw key-points (KP_DTYPE); the rest via download()"""
+        image = np.ascontiguousarray(image, np.uint8)
+        kind, dp, pitch = 0, None, 0
+        if depth is not None:
+            dp = np.ascontiguousarray(depth)
+            kind, pitch = (1 if dp.dtype == np.float32 else 2), dp.strides[0]
+        cap = ext.max_keypoints()
+        kps = np.zeros(cap, KP_DTYPE)
+        n = C.c_int()
+        check(lib().vo_frames_construct(self._h, int(slot), ext._h, _p(image), image.shape[1], image.shape[0], image.strides[0],
+                                        _p(dp), kind, int(pitch), C.c_float(inv_depth_scale), _p(kps), cap, C.byref(n)),
+              "vo_frames_construct")
+        return kps[:n.value].copy()
 
     def upload(self, slot, fa: "FrameArrays", depth=None, stream=0):
         dp = None if depth is None else np.ascontiguousarray(depth, np.float32)

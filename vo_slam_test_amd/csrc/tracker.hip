@@ -622,6 +622,46 @@ int vo_tracker_get(vo_tracker *t, int what, void *dst, size_t dst_bytes) {
   return VO_OK;
 }
 
+int vo_frames_construct(vo_frames *h, int slot, vo_orb *orb, const uint8_t *image, int width, int height, int stride,
+                        const void *depth, int depth_kind, int depth_pitch_bytes, float inv_depth_scale,
+                        vo_keypoint *keypoints, int capacity, int *n_keypoints) {
+  if (!h || !orb || !image || width < 1 || height < 1 || stride < width || depth_kind < 0 || depth_kind > 2 ||
+      (depth_kind && (!depth || depth_pitch_bytes < width * (depth_kind == 1 ? 4 : 2))) || !n_keypoints || capacity < 0)
+    return VO_ERR_INVALID;
+  VO_CHECK(vo::ensure_device());
+  hipStream_t st = vo::thread_stream();
+  thread_local vo::ScratchBuf d_img, d_dep, d_kp, d_desc, d_cnt;
+  thread_local vo::PinnedBuf stage;
+  const int kcap = vo_orb_max_keypoints(orb);
+  const size_t img_bytes = (size_t)stride * height, dep_bytes = depth_kind ? (size_t)depth_pitch_bytes * height : 0;
+  VO_CHECK(d_img.reserve(img_bytes));
+  VO_CHECK(d_dep.reserve(std::max<size_t>(dep_bytes, 64)));
+  VO_CHECK(d_kp.reserve((size_t)kcap * sizeof(vo_keypoint)));
+  VO_CHECK(d_desc.reserve((size_t)kcap * 32));
+  VO_CHECK(d_cnt.reserve(64));
+  VO_CHECK(vo_orb_set_stream(orb, st));
+  VO_CHECK(vo::copy_h2d(d_img.p, image, img_bytes, st, "vo_frames_construct"));
+  if (dep_bytes) VO_CHECK(vo::copy_h2d(d_dep.p, depth, dep_bytes, st, "vo_frames_construct"));
+  VO_CHECK(vo_orb_extract_batch_dev(orb, d_img.as<uint8_t>(), 1, width, height, stride, img_bytes, d_kp.as<vo_keypoint>(),
+                                    d_desc.as<uint8_t>(), kcap, d_cnt.as<int32_t>()));
+  VO_CHECK(vo_frames_build_dev(h, slot, 1, d_kp.as<vo_keypoint>(), d_desc.as<uint8_t>(), d_cnt.as<int32_t>(), kcap,
+                               dep_bytes ? d_dep.p : nullptr, depth_kind, dep_bytes, depth_pitch_bytes, inv_depth_scale, st));
+  VO_CHECK(stage.reserve((size_t)kcap * sizeof(vo_keypoint) + 64));
+  VO_CHECK(vo::copy_d2h(stage.data(), d_cnt.p, 4, st, "vo_frames_construct"));
+  VO_CHECK(vo::copy_d2h(stage.data() + 64, d_kp.p, (size_t)kcap * sizeof(vo_keypoint), st, "vo_frames_construct"));
+  VO_CHECK(vo::stream_sync(st, "vo_frames_construct"));
+  VO_CHECK(vo_orb_sync(orb));
+  int n = 0;
+  memcpy(&n, stage.data(), 4);
+  if (n > capacity) {
+    vo::set_error("vo_frames_construct: %d key-points, capacity %d", n, capacity);
+    return VO_ERR_CAPACITY;
+  }
+  if (keypoints && n > 0) memcpy(keypoints, stage.data() + 64, (size_t)n * sizeof(vo_keypoint));
+  *n_keypoints = n;
+  return VO_OK;
+}
+
 int vo_tracker_sync(vo_tracker *t) {
   if (!t) return VO_ERR_INVALID;
   VO_HIP_CHECK(hipStreamSynchronize(t->st));
