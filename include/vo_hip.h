@@ -297,6 +297,15 @@ int vo_match_bow(const vo_frame_view *a, const uint8_t *a_valid, const vo_bow_vi
                  const vo_frame_view *b, const uint8_t *b_valid, const vo_bow_view *b_nodes, int mode,
                  float ratio, int check_rot, int32_t *match, int *n_matches);
 
+/* The same search for n_pairs pairs in ONE launch (one workgroup per pair; frames that appear in several pairs are
+ * uploaded once): the searchByBoW calls over the relocalisation candidates (visualOdometry.cpp:354-371) or the loop
+ * candidates (loopClosing.cpp:182).  Arrays of n_pairs pointers; match[p] has b[p]->n (mode 0) or a[p]->n (mode 1)
+ * entries; results identical to n_pairs single calls. */
+int vo_match_bow_batch(int n_pairs, const vo_frame_view *const *a, const uint8_t *const *a_valid,
+                       const vo_bow_view *const *a_nodes, const vo_frame_view *const *b, const uint8_t *const *b_valid,
+                       const vo_bow_view *const *b_nodes, int mode, float ratio, int check_rot, int32_t *const *match,
+                       int *n_matches);
+
 /* Matcher::searchForTriangulation(kf1, kf2, matchIdxs, F12, checkRot) (matcher.cpp:867-1010,
  * called at localMapping.cpp:187).  *_has_map_point: feature already triangulated (skipped).
  * F12 row-major; (ex, ey) = camera centre 1 projected into key-frame 2 (:887-891).
@@ -358,6 +367,16 @@ int vo_sim3_ransac_eval(int n, const double *cam1_points, const double *cam2_poi
  * float Jacobi is to float rounding (stated tolerance 1e-4 relative), not bit-exact. */
 int vo_triangulate(int n, const float *xn1, const float *xn2, const float Tcw1[12], const float *Tcw2,
                    int per_pair_pose2, float *points, uint8_t *ok);
+
+/* searchForTriangulation of the current key-frame `a` against ALL its neighbours in one launch (the loop of
+ * LocalMapping::createNewMapPoints, localMapping.cpp:160-190: <= 10 neighbours, one call each in the reference): pair p
+ * searches b[p] with F12 = F[9p .. 9p+8] and the epipole (ex[p], ey[p]); match12[p] has a->n entries.  The calls are
+ * independent in the reference (matchIdxs is local to a neighbour), so the results equal n_pairs single calls. */
+int vo_match_triangulation_batch(int n_pairs, const vo_frame_view *a, const uint8_t *a_has_map_point,
+                                 const vo_bow_view *a_nodes, const vo_frame_view *const *b,
+                                 const uint8_t *const *b_has_map_point, const vo_bow_view *const *b_nodes, const double *F,
+                                 const float *ex, const float *ey, const float *scale_factors, int check_rot,
+                                 int32_t *const *match12, int *n_matches);
 
 /* cv::cvtColor(CV_RGB2GRAY / CV_BGR2GRAY [/ RGBA / BGRA]) of VisualOdometry::createFrame
  * (visualOdometry.cpp:146-159), OpenCV 3.x fixed point. */

@@ -46,6 +46,14 @@ def _frame_pair(orc, idx):
     return k0, d0, k1, d1, dx, dy
 
 
+def _shifted_frame(orc, idx, j):
+    """neighbour j of frame idx: the frame shifted by a neighbour-specific integer offset with fresh noise"""
+    f0 = synth.make_frame(idx)
+    f1, dx, dy = synth.make_shifted(f0, 1000 * (idx + 1) + j)
+    k1, d1, _ = orc.extract(orc.orb_params(), f1)
+    return k1, d1, dx, dy
+
+
 def _uright(k, seed):
     rng = np.random.default_rng(seed)
     z = rng.uniform(0.8, 4.5, len(k)).astype(np.float32)
@@ -186,6 +194,58 @@ def test_search_for_triangulation(vo, orc, idx, check_rot, epi_inside):
     m = match >= 0
     assert not ha[m].any() and not hb[match[m]].any()
     assert len(np.unique(match[m])) == m.sum()
+
+
+def test_triangulation_and_bow_searches_batched(vo, orc):
+    """createNewMapPoints searches the current key-frame against <= 10 neighbours (localMapping.cpp:160-190): ten
+    searchForTriangulation calls as ONE launch (a workgroup per neighbour) equal ten sequential oracle calls bit for bit;
+    the same for searchByBoW over several candidates (KF-KF and KF-frame)."""
+    import ctypes as C
+    sf = np.array(list(orc.orb_params().scale)[:8], np.float32)
+    k0, d0, _, _, _, _ = _frame_pair(orc, 0)
+    rng = np.random.default_rng(77)
+    ur0, _ = _uright(k0, 0)
+    ur0[rng.random(len(k0)) < 0.5] = -1.0
+    ha = (rng.random(len(k0)) < 0.3).astype(np.uint8)
+    na = _nodes(k0)
+    A = vo.FrameArrays(k0["x"], k0["y"], k0["octave"], k0["angle"], ur0, d0)
+    oA, ba = orc.FrameData(k0["x"], k0["y"], k0["octave"], k0["angle"], ur0, d0), orc.BowData(na)
+    pairs, want = [], []
+    keep = []
+    for j in range(10):
+        kj, dj, dx, dy = _shifted_frame(orc, 0, j)
+        urj, _ = _uright(kj, 20 + j)
+        urj[rng.random(len(kj)) < 0.5] = -1.0
+        hb = (rng.random(len(kj)) < 0.3).astype(np.uint8)
+        F = np.array([[0, 0, dy], [0, 0, -dx], [-dy, dx, 0]], np.float64) * 1e-3
+        ex, ey = (320.0, 240.0) if j % 2 else (1e6, 1e6)
+        nb = _nodes(kj, dx, dy)
+        B, bn = vo.FrameArrays(kj["x"], kj["y"], kj["octave"], kj["angle"], urj, dj), vo.BowNodes(nb)
+        keep.append((B, bn))
+        pairs.append((B, hb, bn, F, ex, ey))
+        oB, bb = orc.FrameData(kj["x"], kj["y"], kj["octave"], kj["angle"], urj, dj), orc.BowData(nb)
+        om = np.full(len(k0), -1, np.int32)
+        on = orc.lib().orc_match_triangulation(C.byref(oA.c), ha, C.byref(ba.c), C.byref(oB.c), hb, C.byref(bb.c),
+                                               np.ascontiguousarray(F.reshape(-1)), ex, ey, sf, 1, om)
+        want.append((on, om))
+    counts, match = vo.Matcher(0.6).searchForTriangulation_batch(A, ha, vo.BowNodes(na), pairs, sf, True)
+    for j in range(10):
+        assert counts[j] == want[j][0] and np.array_equal(match[j], want[j][1]), j
+    assert counts.sum() > 300 and len({int(c) for c in counts}) > 3
+    # searchByBoW, both modes, over the same candidates
+    va = (rng.random(len(k0)) < 0.8).astype(np.uint8)
+    for k2k in (False, True):
+        bp, bw = [], []
+        for j in range(6):
+            B, bn = keep[j]
+            vb = (rng.random(B.view.n) < 0.8).astype(np.uint8)
+            bp.append((A, va, vo.BowNodes(na), B, vb, bn))
+            n1, m1 = vo.Matcher(0.7).searchByBoW(A, va, vo.BowNodes(na), B, vb, bn, k2k, True)
+            bw.append((n1, m1))
+        c2, m2 = vo.Matcher(0.7).searchByBoW_batch(bp, k2k, True)
+        for j in range(6):
+            assert c2[j] == bw[j][0] and np.array_equal(m2[j], bw[j][1]), (k2k, j)
+        assert c2.sum() > 200
 
 
 @pytest.mark.parametrize("idx,threshold", [(0, 3.0), (1, 2.5)])

@@ -51,7 +51,7 @@ SYMBOLS = [
     "vo_tracker_stream", "vo_tracker_set_last_frame", "vo_tracker_set_local_map", "vo_tracker_track_dev", "vo_tracker_track",
     "vo_tracker_results", "vo_tracker_get", "vo_tracker_sync", "vo_tracker_set_timing", "vo_tracker_get_timing",
     "vo_match_frame_projection", "vo_match_local_map", "vo_match_frame_keyframe", "vo_match_bow",
-    "vo_match_triangulation", "vo_match_fuse", "vo_match_area_best", "vo_match_sim3_projection",
+    "vo_match_triangulation", "vo_match_bow_batch", "vo_match_triangulation_batch", "vo_match_fuse", "vo_match_area_best", "vo_match_sim3_projection",
     "vo_match_sim3_mutual", "vo_vocab_create", "vo_vocab_destroy", "vo_bow_transform",
     "vo_pose_only_solve", "vo_sim3_solve", "vo_pose_graph_solve", "vo_sim3_reanchor_points", "vo_chol_solve", "vo_pose_only_solve_dev",
     "vo_ba_create", "vo_ba_destroy", "vo_ba_set_stream", "vo_ba_set_shard", "vo_ba_set_allreduce", "vo_ba_set_state",
@@ -663,6 +663,42 @@ class Matcher:
             _p(bh), C.byref(b_nodes.view), _p(F), C.c_float(ex), C.c_float(ey),
             _p(sf), int(checkRot), _p(match), C.byref(n)), "vo_match_triangulation")
         return n.value, match
+
+    def searchForTriangulation_batch(self, a: FrameArrays, a_has, a_nodes, pairs, scale_factors, checkRot=True):
+        """pairs: list of (b: FrameArrays, b_has, b_nodes: BowNodes, F12, ex, ey) -- the neighbours of key-frame a
+        (LocalMapping::createNewMapPoints); ONE launch.  -> (counts [n], matches [n][a.n])"""
+        n = len(pairs)
+        sf = np.ascontiguousarray(scale_factors, np.float32)
+        ah = np.ascontiguousarray(a_has, np.uint8)
+        bh = [np.ascontiguousarray(p[1], np.uint8) for p in pairs]
+        F = np.ascontiguousarray(np.stack([np.asarray(p[3], np.float64).reshape(9) for p in pairs]) if n else np.zeros((0, 9)))
+        ex = np.ascontiguousarray([p[4] for p in pairs], np.float32)
+        ey = np.ascontiguousarray([p[5] for p in pairs], np.float32)
+        match = np.full((n, a.view.n), -1, np.int32)
+        counts = np.zeros(max(n, 1), np.int32)
+        bptr = (C.c_void_p * max(n, 1))(*[C.addressof(p[0].view) for p in pairs])
+        hptr = (C.c_void_p * max(n, 1))(*[h.ctypes.data for h in bh])
+        nptr = (C.c_void_p * max(n, 1))(*[C.addressof(p[2].view) for p in pairs])
+        mptr = (C.c_void_p * max(n, 1))(*[match[i].ctypes.data for i in range(n)])
+        check(lib().vo_match_triangulation_batch(n, C.byref(a.view), _p(ah), C.byref(a_nodes.view), bptr, hptr, nptr, _p(F), _p(ex),
+                                                 _p(ey), _p(sf), int(checkRot), mptr, _p(counts)),
+              "vo_match_triangulation_batch")
+        return counts[:n].copy(), match
+
+    def searchByBoW_batch(self, pairs, keyframe_to_keyframe: bool, checkRot=True):
+        """pairs: list of (a, a_valid, a_nodes, b, b_valid, b_nodes); ONE launch -> (counts, list of match arrays)"""
+        n, mode = len(pairs), (1 if keyframe_to_keyframe else 0)
+        av = [np.ascontiguousarray(p[1], np.uint8) for p in pairs]
+        bv = [np.ascontiguousarray(p[4], np.uint8) for p in pairs]
+        match = [np.full((p[0].view.n if mode else p[3].view.n), -1, np.int32) for p in pairs]
+        counts = np.zeros(max(n, 1), np.int32)
+        arr = lambda xs: (C.c_void_p * max(n, 1))(*xs)
+        check(lib().vo_match_bow_batch(n, arr([C.addressof(p[0].view) for p in pairs]), arr([x.ctypes.data for x in av]),
+                                       arr([C.addressof(p[2].view) for p in pairs]), arr([C.addressof(p[3].view) for p in pairs]),
+                                       arr([x.ctypes.data for x in bv]), arr([C.addressof(p[5].view) for p in pairs]), mode,
+                                       C.c_float(self.ratio_), int(checkRot), arr([m.ctypes.data for m in match]), _p(counts)),
+              "vo_match_bow_batch")
+        return counts[:n].copy(), match
 
     def fuseMapPoints_match(self, kf: FrameArrays, q, threshold, scale_factors):
         nq = len(q["flags"])

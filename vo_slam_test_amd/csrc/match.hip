@@ -168,7 +168,11 @@ struct NodeArgs {
   int *match, *n_matches;       // out: [nB] (mode 0: A index per B feature) or [nA] (B index per A feature)
 };
 
-__global__ __launch_bounds__(64) void k_node_replay(NodeArgs P) {
+// One workgroup (a single wavefront) per pair of frames: the arguments of pair p are args[p] (device memory), so that
+// the ~10 searchForTriangulation calls of LocalMapping::createNewMapPoints (localMapping.cpp:187, one per neighbour
+// key-frame) or the searchByBoW calls over the loop / relocalisation candidates are ONE launch.
+__global__ __launch_bounds__(64) void k_node_replay(const NodeArgs *__restrict__ args) {
+  const NodeArgs P = args[blockIdx.x];
   extern __shared__ __attribute__((aligned(16))) uint8_t nr_lds[];
   __shared__ int hist[32];
   const int lane = threadIdx.x;
@@ -312,64 +316,132 @@ void for_common_nodes(const vo_bow_view &a, const vo_bow_view &b, F &&f) {
 
 constexpr int kNodeMaxB = 16384;  // B features (LDS: 5 bytes each)
 
-// gather (the reference's pointer walk, flattened), upload, one launch, fetch
-int node_search(int mode, const vo_frame_view *a, const uint8_t *a_skip_or_valid, bool a_flag_is_skip, const vo_bow_view *an,
-                const vo_frame_view *b, const uint8_t *b_ok_or_null, bool b_flag_is_blocked, const vo_bow_view *bn,
-                float ratio, int check_rot, const double *F, float ex, float ey, const float *scale_factors,
-                int32_t *match, int *n_matches) {
-  const int nout = mode == kNodeBow0 ? b->n : a->n;
-  for (int i = 0; i < nout; i++) match[i] = -1;
-  *n_matches = 0;
-  if (a->n == 0 || b->n == 0) return VO_OK;
-  if (b->n > kNodeMaxB) {
-    vo::set_error("BoW-node search: %d features in the second frame exceed %d", b->n, kNodeMaxB);
-    return VO_ERR_CAPACITY;
+// One pair of a batched search (host pointers)
+struct NodePair {
+  const vo_frame_view *a;
+  const uint8_t *a_flag;  // skip (triangulation: already has a map point) or valid (BoW) per A feature
+  const vo_bow_view *an;
+  const vo_frame_view *b;
+  const uint8_t *b_flag;  // blocked (triangulation) or valid (KF-KF BoW) per B feature, or NULL
+  const vo_bow_view *bn;
+  const double *F;        // triangulation: F12 row-major
+  float ex, ey;
+  int32_t *match;
+  int *n_matches;
+};
+
+// gather (the reference's pointer walk, flattened) for every pair, ONE staged upload, ONE launch (a workgroup per
+// pair), ONE download.  Frames that appear in several pairs (the current key-frame of createNewMapPoints, the current
+// frame of a relocalisation) are staged once.
+int node_search_batch(int mode, int n_pairs, const NodePair *pairs, bool a_flag_is_skip, bool b_flag_is_blocked, float ratio,
+                      int check_rot, const float *scale_factors) {
+  size_t max_b = 0;
+  for (int p = 0; p < n_pairs; p++) {
+    const NodePair &Q = pairs[p];
+    const int nout = mode == kNodeBow0 ? Q.b->n : Q.a->n;
+    for (int i = 0; i < nout; i++) Q.match[i] = -1;
+    *Q.n_matches = 0;
+    if (Q.b->n > kNodeMaxB) {
+      vo::set_error("BoW-node search: %d features in the second frame exceed %d", Q.b->n, kNodeMaxB);
+      return VO_ERR_CAPACITY;
+    }
+    max_b = std::max<size_t>(max_b, (size_t)Q.b->n);
   }
   VO_CHECK(vo::ensure_device());
+  // ---- host staging image: [args][per distinct frame: desc, angle, x, y, uright, octave][per pair: queries, bfeat, ok]
+  std::vector<uint8_t> img;
+  auto put = [&](const void *src, size_t bytes) {
+    const size_t off = (img.size() + 15) & ~(size_t)15;
+    img.resize(off + std::max<size_t>(bytes, 16));
+    if (bytes && src) memcpy(img.data() + off, src, bytes);
+    return off;
+  };
+  struct FrameOff { const vo_frame_view *v; size_t desc, ang, x, y, ur, oct; };
+  std::vector<FrameOff> staged;
+  auto stage_frame = [&](const vo_frame_view *v) {
+    for (const FrameOff &f : staged)
+      if (f.v == v) return f;
+    FrameOff f{v, put(v->desc, (size_t)v->n * 32), put(v->angle, (size_t)v->n * 4), put(v->x, (size_t)v->n * 4),
+               put(v->y, (size_t)v->n * 4), put(v->uright, (size_t)v->n * 4), put(v->octave, (size_t)v->n * 4)};
+    staged.push_back(f);
+    return f;
+  };
+  const size_t args_off = put(nullptr, (size_t)n_pairs * sizeof(NodeArgs));
+  struct PairOff { size_t q, bf, ok, claims, match, nm; int nq, nout; FrameOff fa, fb; bool live; };
+  std::vector<PairOff> po(n_pairs);
+  size_t out_bytes = 0;  // device-only output / scratch area behind the image
   std::vector<int> queries;
-  queries.reserve(4 * (size_t)a->n);
-  for_common_nodes(*an, *bn, [&](int ia, int ib) {
-    for (int s = an->start[ia]; s < an->start[ia + 1]; s++) {
-      const int i1 = (int)an->feat[s];
-      if (a_flag_is_skip ? a_skip_or_valid[i1] != 0 : a_skip_or_valid[i1] == 0) continue;  // :488 / :597 / :905
-      queries.push_back(i1), queries.push_back(bn->start[ib]), queries.push_back(bn->start[ib + 1]), queries.push_back(0);
+  for (int p = 0; p < n_pairs; p++) {
+    const NodePair &Q = pairs[p];
+    PairOff &o = po[p];
+    o.nout = mode == kNodeBow0 ? Q.b->n : Q.a->n;
+    o.live = Q.a->n > 0 && Q.b->n > 0;
+    o.nq = 0;
+    if (!o.live) continue;
+    queries.clear();
+    for_common_nodes(*Q.an, *Q.bn, [&](int ia, int ib) {
+      for (int t = Q.an->start[ia]; t < Q.an->start[ia + 1]; t++) {
+        const int i1 = (int)Q.an->feat[t];
+        if (a_flag_is_skip ? Q.a_flag[i1] != 0 : Q.a_flag[i1] == 0) continue;  // :488 / :597 / :905
+        queries.push_back(i1), queries.push_back(Q.bn->start[ib]), queries.push_back(Q.bn->start[ib + 1]), queries.push_back(0);
+      }
+    });
+    o.nq = (int)queries.size() / 4;
+    if (o.nq == 0) {
+      o.live = false;
+      continue;
     }
-  });
-  const int nq = (int)queries.size() / 4;
-  if (nq == 0) return VO_OK;
-  const int nbf = bn->n_nodes > 0 ? bn->start[bn->n_nodes] : 0;
-  std::vector<uint8_t> bok(b->n, 1);
-  if (b_ok_or_null)
-    for (int i = 0; i < b->n; i++) bok[i] = b_flag_is_blocked ? (b_ok_or_null[i] ? 0 : 1) : (b_ok_or_null[i] ? 1 : 0);
-  thread_local vo::ScratchBuf dq, dbf, dda, ddb, daa, dab, dxa, dya, dua, dxb, dyb, dub, dob, dok, dcl, dm, dn;
+    o.fa = stage_frame(Q.a), o.fb = stage_frame(Q.b);
+    o.q = put(queries.data(), queries.size() * 4);
+    const int nbf = Q.bn->n_nodes > 0 ? Q.bn->start[Q.bn->n_nodes] : 0;
+    o.bf = put(Q.bn->feat, (size_t)std::max(nbf, 1) * 4);
+    std::vector<uint8_t> bok(Q.b->n, 1);
+    if (Q.b_flag)
+      for (int i = 0; i < Q.b->n; i++) bok[i] = b_flag_is_blocked ? (Q.b_flag[i] ? 0 : 1) : (Q.b_flag[i] ? 1 : 0);
+    o.ok = put(bok.data(), (size_t)Q.b->n);
+    auto reserve_out = [&](size_t bytes) {
+      const size_t off = (out_bytes + 15) & ~(size_t)15;
+      out_bytes = off + std::max<size_t>(bytes, 16);
+      return off;
+    };
+    o.claims = reserve_out((size_t)o.nq * 16), o.match = reserve_out((size_t)o.nout * 4), o.nm = reserve_out(16);
+  }
+  std::vector<int> live;
+  for (int p = 0; p < n_pairs; p++)
+    if (po[p].live) live.push_back(p);
+  if (live.empty()) return VO_OK;
+  const size_t img_bytes = (img.size() + 255) & ~(size_t)255;
+  thread_local vo::ScratchBuf dbuf;
+  thread_local vo::PinnedBuf stage;
+  VO_CHECK(dbuf.reserve(img_bytes + out_bytes + 256));
+  uint8_t *d = dbuf.as<uint8_t>(), *dout = d + img_bytes;
+  // the argument blocks (device addresses are known now), one per LIVE pair, packed at the front of the args area
+  NodeArgs *hargs = reinterpret_cast<NodeArgs *>(img.data() + args_off);
+  for (size_t k = 0; k < live.size(); k++) {
+    const NodePair &Q = pairs[live[k]];
+    const PairOff &o = po[live[k]];
+    NodeArgs P{};
+    P.mode = mode, P.nq = o.nq, P.nA = Q.a->n, P.nB = Q.b->n, P.check_rot = check_rot, P.ratio = ratio, P.ex = Q.ex, P.ey = Q.ey;
+    for (int i = 0; i < 9; i++) P.F[i] = Q.F ? Q.F[i] : 0.0;
+    for (int i = 0; i < 16; i++) P.sf[i] = scale_factors ? scale_factors[std::min(i, 7)] : 1.f;
+    P.queries = reinterpret_cast<const int4 *>(d + o.q), P.bfeat = reinterpret_cast<const uint32_t *>(d + o.bf);
+    P.descA = reinterpret_cast<const uint4 *>(d + o.fa.desc), P.descB = reinterpret_cast<const uint4 *>(d + o.fb.desc);
+    P.angA = reinterpret_cast<const float *>(d + o.fa.ang), P.angB = reinterpret_cast<const float *>(d + o.fb.ang);
+    P.xA = reinterpret_cast<const float *>(d + o.fa.x), P.yA = reinterpret_cast<const float *>(d + o.fa.y);
+    P.urA = reinterpret_cast<const float *>(d + o.fa.ur);
+    P.xB = reinterpret_cast<const float *>(d + o.fb.x), P.yB = reinterpret_cast<const float *>(d + o.fb.y);
+    P.urB = reinterpret_cast<const float *>(d + o.fb.ur), P.octB = reinterpret_cast<const int *>(d + o.fb.oct);
+    P.b_ok = d + o.ok;
+    P.claims = reinterpret_cast<int4 *>(dout + o.claims), P.match = reinterpret_cast<int *>(dout + o.match);
+    P.n_matches = reinterpret_cast<int *>(dout + o.nm);
+    hargs[k] = P;
+  }
   hipStream_t st = vo::thread_stream();
   const char *what = "BoW-node search";
-  VO_CHECK(vo::upload(dq, queries.data(), queries.size() * 4, st, what));
-  VO_CHECK(vo::upload(dbf, bn->feat, (size_t)std::max(nbf, 1) * 4, st, what));
-  VO_CHECK(vo::upload(dda, a->desc, (size_t)a->n * 32, st, what));
-  VO_CHECK(vo::upload(ddb, b->desc, (size_t)b->n * 32, st, what));
-  VO_CHECK(vo::upload(daa, a->angle, (size_t)a->n * 4, st, what));
-  VO_CHECK(vo::upload(dab, b->angle, (size_t)b->n * 4, st, what));
-  VO_CHECK(vo::upload(dxa, a->x, (size_t)a->n * 4, st, what));
-  VO_CHECK(vo::upload(dya, a->y, (size_t)a->n * 4, st, what));
-  VO_CHECK(vo::upload(dua, a->uright, (size_t)a->n * 4, st, what));
-  VO_CHECK(vo::upload(dxb, b->x, (size_t)b->n * 4, st, what));
-  VO_CHECK(vo::upload(dyb, b->y, (size_t)b->n * 4, st, what));
-  VO_CHECK(vo::upload(dub, b->uright, (size_t)b->n * 4, st, what));
-  VO_CHECK(vo::upload(dob, b->octave, (size_t)b->n * 4, st, what));
-  VO_CHECK(vo::upload(dok, bok.data(), (size_t)b->n, st, what));
-  VO_CHECK(dcl.reserve((size_t)nq * 16));
-  VO_CHECK(dm.reserve((size_t)std::max(nout, 1) * 4));
-  VO_CHECK(dn.reserve(64));
-  NodeArgs P{};
-  P.mode = mode, P.nq = nq, P.nA = a->n, P.nB = b->n, P.check_rot = check_rot, P.ratio = ratio, P.ex = ex, P.ey = ey;
-  for (int i = 0; i < 9; i++) P.F[i] = F ? F[i] : 0.0;
-  for (int i = 0; i < 16; i++) P.sf[i] = scale_factors ? scale_factors[std::min(i, 7)] : 1.f;
-  P.queries = dq.as<int4>(), P.bfeat = dbf.as<uint32_t>(), P.descA = dda.as<uint4>(), P.descB = ddb.as<uint4>();
-  P.angA = daa.as<float>(), P.angB = dab.as<float>(), P.xA = dxa.as<float>(), P.yA = dya.as<float>(), P.urA = dua.as<float>();
-  P.xB = dxb.as<float>(), P.yB = dyb.as<float>(), P.urB = dub.as<float>(), P.octB = dob.as<int>(), P.b_ok = dok.as<uint8_t>();
-  P.claims = dcl.as<int4>(), P.match = dm.as<int>(), P.n_matches = dn.as<int>();
-  const size_t lds = (size_t)((b->n + 15) & ~15) * 5;
+  VO_CHECK(stage.reserve(std::max(img.size(), out_bytes)));
+  memcpy(stage.data(), img.data(), img.size());
+  VO_CHECK(vo::copy_h2d(d, stage.data(), img.size(), st, what));
+  const size_t lds = ((max_b + 15) & ~(size_t)15) * 5;
   if (lds > 64 * 1024) {
     static bool attr_set = false;
     if (!attr_set) {
@@ -377,11 +449,15 @@ int node_search(int mode, const vo_frame_view *a, const uint8_t *a_skip_or_valid
       attr_set = true;
     }
   }
-  hipLaunchKernelGGL(k_node_replay, dim3(1), dim3(64), lds, st, P);
+  hipLaunchKernelGGL(k_node_replay, dim3((unsigned)live.size()), dim3(64), lds, st, reinterpret_cast<const NodeArgs *>(d + args_off));
   VO_HIP_CHECK(hipGetLastError());
-  VO_CHECK(vo::copy_d2h(match, dm.p, (size_t)nout * 4, st, what));
-  VO_CHECK(vo::copy_d2h(n_matches, dn.p, 4, st, what));
-  return vo::stream_sync(st, what);
+  VO_CHECK(vo::copy_d2h(stage.data(), dout, out_bytes, st, what));
+  VO_CHECK(vo::stream_sync(st, what));
+  for (int p : live) {
+    memcpy(pairs[p].match, stage.data() + po[p].match, (size_t)po[p].nout * 4);
+    memcpy(pairs[p].n_matches, stage.data() + po[p].nm, 4);
+  }
+  return VO_OK;
 }
 
 }  // namespace
@@ -455,16 +531,46 @@ int vo_match_bow(const vo_frame_view *a, const uint8_t *a_valid, const vo_bow_vi
                  int *n_matches) {
   if (!a || !b || !an || !bn || !a_valid || !match || !n_matches || (mode != 0 && mode != 1) || (mode == 1 && !b_valid))
     return VO_ERR_INVALID;
-  return node_search(mode == 0 ? kNodeBow0 : kNodeBow1, a, a_valid, false, an, b, mode == 1 ? b_valid : nullptr, false, bn,
-                     ratio, check_rot, nullptr, 0.f, 0.f, nullptr, match, n_matches);
+  const NodePair pr{a, a_valid, an, b, mode == 1 ? b_valid : nullptr, bn, nullptr, 0.f, 0.f, match, n_matches};
+  return node_search_batch(mode == 0 ? kNodeBow0 : kNodeBow1, 1, &pr, false, false, ratio, check_rot, nullptr);
+}
+
+int vo_match_bow_batch(int n_pairs, const vo_frame_view *const *a, const uint8_t *const *a_valid, const vo_bow_view *const *an,
+                       const vo_frame_view *const *b, const uint8_t *const *b_valid, const vo_bow_view *const *bn, int mode,
+                       float ratio, int check_rot, int32_t *const *match, int *n_matches) {
+  if (n_pairs < 0 || (mode != 0 && mode != 1) || (n_pairs > 0 && (!a || !a_valid || !an || !b || !bn || !match || !n_matches)) ||
+      (mode == 1 && n_pairs > 0 && !b_valid))
+    return VO_ERR_INVALID;
+  std::vector<NodePair> pr((size_t)n_pairs);
+  for (int p = 0; p < n_pairs; p++) {
+    if (!a[p] || !a_valid[p] || !an[p] || !b[p] || !bn[p] || !match[p] || (mode == 1 && !b_valid[p])) return VO_ERR_INVALID;
+    pr[p] = NodePair{a[p], a_valid[p], an[p], b[p], mode == 1 ? b_valid[p] : nullptr, bn[p], nullptr, 0.f, 0.f, match[p], &n_matches[p]};
+  }
+  if (n_pairs == 0) return VO_OK;
+  return node_search_batch(mode == 0 ? kNodeBow0 : kNodeBow1, n_pairs, pr.data(), false, false, ratio, check_rot, nullptr);
 }
 
 int vo_match_triangulation(const vo_frame_view *a, const uint8_t *a_has, const vo_bow_view *an, const vo_frame_view *b,
                            const uint8_t *b_has, const vo_bow_view *bn, const double F[9], float ex, float ey,
                            const float *scale_factors, int check_rot, int32_t *match12, int *n_matches) {
   if (!a || !b || !an || !bn || !a_has || !b_has || !F || !scale_factors || !match12 || !n_matches) return VO_ERR_INVALID;
-  return node_search(kNodeTri, a, a_has, true, an, b, b_has, true, bn, 0.f, check_rot, F, ex, ey, scale_factors, match12,
-                     n_matches);
+  const NodePair pr{a, a_has, an, b, b_has, bn, F, ex, ey, match12, n_matches};
+  return node_search_batch(kNodeTri, 1, &pr, true, true, 0.f, check_rot, scale_factors);
+}
+
+int vo_match_triangulation_batch(int n_pairs, const vo_frame_view *a, const uint8_t *a_has, const vo_bow_view *an,
+                                 const vo_frame_view *const *b, const uint8_t *const *b_has, const vo_bow_view *const *bn,
+                                 const double *F /*[n_pairs][9]*/, const float *ex, const float *ey, const float *scale_factors,
+                                 int check_rot, int32_t *const *match12, int *n_matches) {
+  if (n_pairs < 0 || !a || !a_has || !an || !scale_factors || (n_pairs > 0 && (!b || !b_has || !bn || !F || !ex || !ey || !match12 || !n_matches)))
+    return VO_ERR_INVALID;
+  std::vector<NodePair> pr((size_t)n_pairs);
+  for (int p = 0; p < n_pairs; p++) {
+    if (!b[p] || !b_has[p] || !bn[p] || !match12[p]) return VO_ERR_INVALID;
+    pr[p] = NodePair{a, a_has, an, b[p], b_has[p], bn[p], F + 9 * (size_t)p, ex[p], ey[p], match12[p], &n_matches[p]};
+  }
+  if (n_pairs == 0) return VO_OK;
+  return node_search_batch(kNodeTri, n_pairs, pr.data(), true, true, 0.f, check_rot, scale_factors);
 }
 
 }  // extern "C" (kernels below)
