@@ -267,6 +267,49 @@ def test_device_cholesky(vo, n):
     assert np.abs(L - Lref).max() < 1e-9 * np.abs(Lref).max()
 
 
+def _spd_with_tile_structure(kind, n, rng):
+    """SPD matrices whose 64 x 64 tiles follow a structure the sparse factorisation plans are built for"""
+    m = (n + 63) // 64
+    keep = np.zeros((m, m), bool)
+    if kind == "band":
+        for i in range(m):
+            keep[i, max(0, i - 3):i + 1] = True
+    elif kind == "cyclic":
+        for i in range(m):
+            for d in range(3):
+                keep[i, (i - d) % m] = keep[(i - d) % m, i] = True
+    elif kind == "arrow":
+        keep[np.arange(m), np.arange(m)] = True
+        keep[-2:, :] = True
+    elif kind == "blocks":       # independent diagonal blocks of 3 tiles + a dense border: the nested-dissection shape
+        for i in range(m - 4):
+            keep[i, (i // 3) * 3:i + 1] = True
+        keep[m - 4:, :] = True
+    elif kind == "random":
+        keep = rng.random((m, m)) < 0.15
+    keep = keep | keep.T | np.eye(m, dtype=bool)
+    M = rng.normal(size=(n, n))
+    A = (M + M.T) * np.kron(keep, np.ones((64, 64)))[:n, :n]
+    A += (np.abs(A).sum(1).max() + 1.0) * np.eye(n)      # diagonally dominant
+    return A, keep
+
+
+@pytest.mark.parametrize("kind,n", [("band", 1500), ("cyclic", 1500), ("arrow", 1000), ("blocks", 1411), ("random", 2000),
+                                    ("cyclic", 4096), ("blocks", 4090)])
+def test_device_cholesky_on_sparse_tile_plans(vo, kind, n):
+    """matrices with empty tiles take a plan that lists only the tiles of L (fill included): tile columns that do not
+    depend on each other are factored concurrently, tiles outside the plan are never touched"""
+    rng = np.random.default_rng(n + len(kind))
+    A, keep = _spd_with_tile_structure(kind, n, rng)
+    b = rng.normal(size=n)
+    x, L = vo.chol_solve(A, b)
+    Lref = np.linalg.cholesky(A)
+    assert np.abs(L - Lref).max() < 1e-10 * np.abs(Lref).max()
+    assert np.abs(x - np.linalg.solve(A, b)).max() < 1e-10 * max(1.0, np.abs(x).max())
+    # what lies outside the symbolic fill comes back as it went in: exact zeros
+    assert np.all(L[Lref == 0] == 0)
+
+
 def test_device_cholesky_rejects_indefinite(vo):
     A = np.eye(70)
     A[40, 40] = -1.0

@@ -20,7 +20,7 @@ print(f"problem: {n_kf} KF, {n_pts} points, {len(pr['e_cam'])} edges, obs/point 
 t0 = time.perf_counter()
 ba = _lib.BundleAdjuster(pr)
 s = ba.solve(0.0, 0.0, 1)          # builds the device structures, one iteration
-print(f"create + first iteration: {time.perf_counter() - t0:.2f} s")
+print(f"create + first iteration: {time.perf_counter() - t0:.2f} s; key-frame order {ba.debug_order()}")
 ba.set_state(pr["poses"], pr["points"])
 for its in (5, 10):
     ba.set_state(pr["poses"], pr["points"])

@@ -59,7 +59,7 @@ SYMBOLS = [
     "vo_ba_local_ba_finish", "vo_ba_solve", "vo_ba_lm_begin",
     "vo_ba_linearize", "vo_ba_step", "vo_ba_update", "vo_ba_lm_end", "vo_ba_reduced_system",
     "vo_ba_reduced_cost", "vo_ba_set_reduce_buffers", "vo_ba_classify",
-    "vo_ba_lm_begin_inliers", "vo_ba_get_edge_outliers", "vo_ba_debug_schur", "vo_ba_debug_stamps", "vo_se3_exp", "vo_se3_log",
+    "vo_ba_lm_begin_inliers", "vo_ba_get_edge_outliers", "vo_ba_debug_schur", "vo_ba_debug_stamps", "vo_ba_debug_order", "vo_se3_exp", "vo_se3_log",
 ]
 
 
@@ -954,6 +954,12 @@ class BundleAdjuster:
 
     def set_reduce_buffers(self, system, cost):
         check(lib().vo_ba_set_reduce_buffers(self._h, _p(system), _p(cost)))
+
+    def debug_order(self):
+        """-> dict(parts, cyclic, sep, depth, tiles, tile_rows): the key-frame order of a large reduced system"""
+        out = (C.c_int * 6)()
+        check(lib().vo_ba_debug_order(self._h, out), "vo_ba_debug_order")
+        return dict(zip(("parts", "cyclic", "sep", "depth", "tiles", "tile_rows"), list(out)))
 
     def debug_schur(self, huber=(0.0, 0.0), edge_active=None):
         n = 6 * self.n_free_cams()

@@ -24,6 +24,8 @@
 #include "vo_common.h"
 
 #include <algorithm>
+#include <mutex>
+#include <vector>
 
 namespace {
 
@@ -69,6 +71,14 @@ struct CholCtx {
   double *linv;       // [m][64][64] inverses of the diagonal tiles (backward substitution by products, not by 64 pivots)
   int spin_limit;
   unsigned long long *stamps;  // [2 m][16] (VO_CHOL_STAMPS builds)
+  // The plan (vo::chol_plan_create): which 64 x 64 tiles of L exist -- the structure of a reduced camera system is its
+  // covisibility graph, and under a nested-dissection order of the key-frames whole tile columns are independent of
+  // each other -- and the task list in ticket order.  A dense plan lists every tile.
+  const int4 *tasks;            // (type, i, j, aux): 0 tile (i, j) of the factorisation (i == m: right-hand-side row),
+                                // 1 inverse of diagonal tile j, 2 the backward chain, 3 far link (i, j), aux = its rank
+  const unsigned long long *rowmask;  // [m + 1]: bit k of rowmask[i] = tile (i, k) of L exists (row m: the rhs row, all ones)
+  const int2 *colinfo;          // [m]: (far links of column j, tile (j + 1, j) exists)
+  int n_tasks, n_factor;        // tasks in all, factorisation tasks (what `done` counts)
 };
 
 // workgroup-wide wait for a flag (bounded).  Returns false when the kernel is being abandoned.
@@ -246,38 +256,27 @@ __global__ __launch_bounds__(256) void k_chol_tiles(CholCtx C) {
   __shared__ int s_ticket, s_state;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, i16 = lane & 15, q4 = lane >> 4;
   const int m = C.m, ld = C.ld;
-  const int nF = m * (m + 1) / 2 + m;                 // factorisation tasks: tiles (i >= j) and the rhs tile row
-  int nFar = 0;                                       // off-chain tiles of the backward substitution: i >= j + 2
-  for (int i = 2; i < m; i++) nFar += i - 1;
-  const int nI = m;                                   // inverses of the diagonal tiles (off the factorisation's chain)
-  const int nB = 1 + nFar;
+  const int nF = C.n_factor;
   for (;;) {
     if (tid == 0) s_ticket = atomicAdd(C.ticket, 1);
     __syncthreads();
     const int t = s_ticket;
     __syncthreads();
-    if (t >= nF + nI + nB) return;
+    if (t >= C.n_tasks) return;
     if (tid == 0) s_state = ld_flag(C.fail);
     __syncthreads();
     if (s_state != 0) return;  // abandoned (not positive definite, or a dependency timed out)
     __syncthreads();
-    // Ticket order: column by column (i = j .. m), and behind column j's tasks the inverse of diagonal tile j - 2, which
-    // is complete by then (a task that polls for a long time costs the chain memory bandwidth on the flag lines); the
-    // last two inverses follow the last column.
-    int tj = 0, trem = t, inv_j = -1;
-    if (t < nF + nI) {
-      for (; tj < m; tj++) {
-        const int cnt = m - tj + 1 + (tj >= 2 ? 1 : 0);
-        if (trem < cnt) break;
-        trem -= cnt;
-      }
-      if (tj == m) inv_j = (m >= 2 ? m - 2 : 0) + trem;
-      else if (trem == m - tj + 1) inv_j = tj - 2;
-    }
-    if (t < nF + nI && inv_j < 0) {
-      // ---------------------------------------------------------------- factorisation task: ticket -> (i, j)
-      const int j = tj, rem = trem;
-      const int i = j + rem;                                 // j <= i <= m  (i == m: right-hand-side rows)
+    // Ticket order (the plan's): column by column over the tiles that exist (i = j .. m), and behind column j's tasks the
+    // inverse of diagonal tile j - 2, which is complete by then (a task that polls for a long time costs the chain
+    // memory bandwidth on the flag lines); the last two inverses follow the last column; then the backward chain and its
+    // far links.  Everything a task waits for has an earlier ticket.
+    const int4 task = C.tasks[t];
+    const int inv_j = task.x == 1 ? task.z : -1;
+    if (task.x == 0) {
+      // ---------------------------------------------------------------- factorisation task (i, j)
+      const int j = task.z;
+      const int i = task.y;                                  // j <= i <= m  (i == m: right-hand-side rows)
       const int R0 = i < m ? NB * i : ld, C0 = NB * j;
       const int qr = (wave >> 1) * 32, qc = (wave & 1) * 32;
       double4_t acc[2][2];
@@ -290,7 +289,12 @@ __global__ __launch_bounds__(256) void k_chol_tiles(CholCtx C) {
         }
       bool alive = true;
       const int stamp_slot = i == j ? 2 * j : (i == j + 1 ? 2 * j + 1 : -1);
-      for (int k = 0; k < j && alive; k++) {
+      // only the tile columns k in which both L(i, k) and L(j, k) exist contribute (and only those tiles are ever
+      // published: a tile that does not exist must not be waited for)
+      unsigned long long kmask = C.rowmask[i] & C.rowmask[j] & ((1ull << j) - 1ull);
+      while (kmask != 0ull && alive) {
+        const int k = (int)__builtin_ctzll(kmask);
+        kmask &= kmask - 1ull;
         if (stamp_slot >= 0 && k == j - 1) CSTAMP(stamp_slot, 0);
         alive = wait_flag(C, C.ready + i * m + k, 1, &s_state);
         if (alive && i != j) alive = wait_flag(C, C.ready + j * m + k, 1, &s_state);
@@ -436,7 +440,7 @@ __global__ __launch_bounds__(256) void k_chol_tiles(CholCtx C) {
       }
       continue;
     }
-    if (t == nF + nI) {
+    if (task.x == 2) {
       // ---------------------------------------------------------------- backward substitution, the chain:
       // x_j = L(j,j)^-T (y_j - L(j+1,j)^T x_{j+1} - S_j), S_j delivered by the other workgroups.  Per column: two
       // tile products (no pivot loop); x_j is flagged for the far links one step later, when its write-through
@@ -448,15 +452,16 @@ __global__ __launch_bounds__(256) void k_chol_tiles(CholCtx C) {
       double *svec = rdiag;  // right-hand side of the column (rdiag is free here)
       for (int j = m - 1; j >= 0; j--) {
         if (j == 0) CSTAMP(0, 9);
-        const bool near = j + 1 < m;
+        const int2 ci = C.colinfo[j];
+        const bool near = ci.y != 0;  // tile (j + 1, j) exists
         if (near) load_tile(C, NB * (j + 1), NB * j, Pr, true);
         load_tile_rs(rsi, NB, NB * j, 0, Pc);
         double yj = 0;
         if (tid < NB) yj = ld_sc1(y + NB * j + tid);
         // (all vector-memory operations issued so far have completed once the tiles are in LDS: x_{j+1} is visible)
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        if (near && tid == 0) st_flag(C.xready + j + 1, 1);
-        const int links = max(0, m - 2 - j);
+        if (j + 1 < m && tid == 0) st_flag(C.xready + j + 1, 1);
+        const int links = ci.x;
         if (links > 0 && !wait_flag(C, C.pcount + j, links, &s_state)) return;
         __syncthreads();
         double sj = yj;
@@ -482,16 +487,14 @@ __global__ __launch_bounds__(256) void k_chol_tiles(CholCtx C) {
     }
     {
       // ---------------------------------------------------------------- S_j += L(i,j)^T x_i for i >= j + 2, one link
-      // of column j's chain per task: links run i = m-1, m-2, ... (fixed order: deterministic sums)
-      int u = t - nF - nI - 1, i = m - 1;   // ticket order: i descending, then j descending (closest to the chain first)
-      while (u >= i - 1) u -= i - 1, i--;
-      const int j = i - 2 - u;
+      // of column j's chain per task: links run over the existing tiles i = m-1, m-2, ... (fixed order: deterministic sums)
+      const int i = task.y, j = task.z;   // ticket order: i descending, then j descending (closest to the chain first)
       if (!wait_flag(C, C.xready + i, 1, &s_state)) return;
       load_tile(C, NB * i, NB * j, Pr, true);
       if (tid < NB) col[tid] = ld_sc1(xsol + NB * i + tid);
       __syncthreads();
       const double pv = tile_matvec_t(Pr, col);
-      const int link = m - 1 - i;
+      const int link = task.w;  // existing far tiles of column j below this one
       if (link > 0 && !wait_flag(C, C.pcount + j, link, &s_state)) return;
       if (tid < NB) st_sc1(Sacc + NB * j + tid, (link > 0 ? ld_sc1(Sacc + NB * j + tid) : 0.0) + pv);
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -505,14 +508,133 @@ int chol_ws_ints(int m) { return 16 + (m + 1) * m + 3 * m; }
 
 }  // namespace
 
+// ---- plans -----------------------------------------------------------------------------------------------------
+struct vo::CholPlan {
+  int m = 0, n_tasks = 0, n_factor = 0, n_tiles = 0, depth = 0;
+  vo::DevBuf dev;  // [tasks int4][rowmask u64 (m + 1)][colinfo int2 (m)]
+  const int4 *tasks = nullptr;
+  const unsigned long long *rowmask = nullptr;
+  const int2 *colinfo = nullptr;
+};
+
+// Symbolic tile Cholesky: `pattern[i]` (bit k: tile (i, k), k <= i, of the lower triangle of A may be non-zero; NULL =
+// dense) -> the tiles of L (fill included), the length of the longest chain of dependent tile columns, the number of
+// tiles.
+void vo::chol_symbolic(int m, const unsigned long long *pattern, unsigned long long *lmask /*[m]*/, int *depth, int *n_tiles) {
+  for (int i = 0; i < m; i++) {
+    const unsigned long long lower = (i == 63 ? ~0ull : ((1ull << (i + 1)) - 1ull));
+    lmask[i] = (pattern ? pattern[i] : ~0ull) & lower;
+    lmask[i] |= 1ull << i;
+  }
+  for (int j = 0; j < m; j++)  // every pair of rows i1 > i2 > j with tiles in column j creates tile (i1, i2)
+    for (int i2 = j + 1; i2 < m; i2++) {
+      if (!((lmask[i2] >> j) & 1ull)) continue;
+      for (int i1 = i2 + 1; i1 < m; i1++)
+        if ((lmask[i1] >> j) & 1ull) lmask[i1] |= 1ull << i2;
+    }
+  int nt = 0, dmax = 0;
+  std::vector<int> d((size_t)m, 1);
+  for (int j = 0; j < m; j++) {  // column j's diagonal tile needs every column k < j in which row j has a tile
+    for (int k = 0; k < j; k++)
+      if ((lmask[j] >> k) & 1ull) d[j] = std::max(d[j], d[k] + 1);
+    dmax = std::max(dmax, d[j]);
+    nt += __builtin_popcountll(lmask[j]);
+  }
+  if (depth) *depth = dmax;
+  if (n_tiles) *n_tiles = nt;
+}
+
+vo::CholPlan *vo::chol_plan_create(int m, const unsigned long long *pattern) {
+  if (m < 1 || m > 64) return nullptr;
+  std::vector<unsigned long long> lm((size_t)m + 1);
+  int depth = 0, nt = 0;
+  vo::chol_symbolic(m, pattern, lm.data(), &depth, &nt);
+  lm[m] = m == 64 ? ~0ull : ((1ull << m) - 1ull);  // the right-hand-side row
+  auto has = [&](int i, int j) { return ((lm[i] >> j) & 1ull) != 0; };
+  std::vector<int4> tasks;
+  int n_factor = 0;
+  // Ticket order (see the kernel): tile columns by their level in the dependency graph, so that the first columns of
+  // independent parts of the matrix are handed out together.  Everything column j waits for lies in columns of a lower
+  // level: tiles (i, k) and (j, k) both exist only if row j has a tile in column k, i.e. level(k) < level(j).
+  std::vector<int> level((size_t)m, 1), seq((size_t)m);
+  for (int j = 0; j < m; j++) {
+    for (int k = 0; k < j; k++)
+      if (has(j, k)) level[j] = std::max(level[j], level[k] + 1);
+    seq[j] = j;
+  }
+  std::stable_sort(seq.begin(), seq.end(), [&](int a, int b) { return level[a] < level[b]; });
+  for (int p = 0; p < m; p++) {
+    const int j = seq[p];
+    for (int i = j; i <= m; i++)
+      if (has(i, j)) tasks.push_back(make_int4(0, i, j, 0)), n_factor++;
+    if (p >= 2) tasks.push_back(make_int4(1, 0, seq[p - 2], 0));
+  }
+  for (int p = std::max(0, m - 2); p < m; p++) tasks.push_back(make_int4(1, 0, seq[p], 0));
+  tasks.push_back(make_int4(2, 0, 0, 0));
+  std::vector<int2> colinfo((size_t)m);
+  for (int j = 0; j < m; j++) {
+    int far = 0;
+    for (int i = j + 2; i < m; i++) far += has(i, j) ? 1 : 0;
+    colinfo[j] = make_int2(far, j + 1 < m && has(j + 1, j) ? 1 : 0);
+  }
+  for (int i = m - 1; i >= 2; i--)      // far links: i descending, then j descending (closest to the chain first);
+    for (int j = i - 2; j >= 0; j--) {  // aux = the existing far tiles of column j below this one (its turn in the sum)
+      if (!has(i, j)) continue;
+      int below = 0;
+      for (int r = i + 1; r < m; r++) below += has(r, j) ? 1 : 0;
+      tasks.push_back(make_int4(3, i, j, below));
+    }
+  vo::CholPlan *P = new vo::CholPlan();
+  P->m = m, P->n_tasks = (int)tasks.size(), P->n_factor = n_factor, P->n_tiles = nt, P->depth = depth;
+  const size_t o_mask = tasks.size() * sizeof(int4), o_col = o_mask + (size_t)(m + 1) * 8, total = o_col + (size_t)m * sizeof(int2);
+  std::vector<uint8_t> img(total);
+  memcpy(img.data(), tasks.data(), o_mask);
+  memcpy(img.data() + o_mask, lm.data(), (size_t)(m + 1) * 8);
+  memcpy(img.data() + o_col, colinfo.data(), (size_t)m * sizeof(int2));
+  if (P->dev.reserve(total) != VO_OK || hipMemcpy(P->dev.p, img.data(), total, hipMemcpyHostToDevice) != hipSuccess) {
+    P->dev.release();
+    delete P;
+    return nullptr;
+  }
+  P->tasks = reinterpret_cast<const int4 *>(P->dev.p);
+  P->rowmask = reinterpret_cast<const unsigned long long *>(reinterpret_cast<uint8_t *>(P->dev.p) + o_mask);
+  P->colinfo = reinterpret_cast<const int2 *>(reinterpret_cast<uint8_t *>(P->dev.p) + o_col);
+  return P;
+}
+
+void vo::chol_plan_destroy(vo::CholPlan *p) {
+  if (!p) return;
+  p->dev.release();
+  delete p;
+}
+void vo::chol_plan_info(const vo::CholPlan *p, int *n_tiles, int *depth) {
+  if (n_tiles) *n_tiles = p ? p->n_tiles : 0;
+  if (depth) *depth = p ? p->depth : 0;
+}
+
+namespace {
+// dense plans, one per matrix size ever used by this process (never freed: a few KB each)
+const vo::CholPlan *dense_plan(int m) {
+  static std::mutex mu;
+  static const vo::CholPlan *cache[65] = {nullptr};
+  std::lock_guard<std::mutex> lock(mu);
+  if (!cache[m]) cache[m] = vo::chol_plan_create(m, nullptr);
+  return cache[m];
+}
+
+
+}  // namespace
+
 size_t vo::chol_workspace_bytes(int ld) {
   const int m = ld / NB;
   const size_t ints = ((size_t)chol_ws_ints(m) * 4 + 255) & ~(size_t)255;
   return ints + ((size_t)m * m * NB + (size_t)m * NB + (size_t)m * NB * NB) * 8 + (size_t)2 * m * 16 * 8;
 }
 
-void vo::chol_factor_solve(double *A, int ld, void *workspace, hipStream_t st) {
+void vo::chol_factor_solve(double *A, int ld, void *workspace, hipStream_t st, const vo::CholPlan *plan) {
   const int m = ld / NB;
+  if (!plan || plan->m != m) plan = dense_plan(m);
+  if (!plan) return;  // (allocation failure: the caller's fail flag stays clear and the solution row untouched -- reported by the next HIP call)
   int *wsI = reinterpret_cast<int *>(workspace);
   const size_t ints = ((size_t)chol_ws_ints(m) * 4 + 255) & ~(size_t)255;
   // everything but the fail flag (word 0, owned by the caller) starts at zero
@@ -537,9 +659,8 @@ void vo::chol_factor_solve(double *A, int ld, void *workspace, hipStream_t st) {
     (void)hipFuncSetAttribute((const void *)k_chol_tiles, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     attr_set = true;
   }
-  int nFar = 0;
-  for (int i = 2; i < m; i++) nFar += i - 1;
-  const int tasks = m * (m + 1) / 2 + m + m + 1 + nFar;
-  const int grid = std::max(1, std::min(tasks, 2 * n_cu));
+  C.tasks = plan->tasks, C.rowmask = plan->rowmask, C.colinfo = plan->colinfo;
+  C.n_tasks = plan->n_tasks, C.n_factor = plan->n_factor;
+  const int grid = std::max(1, std::min(plan->n_tasks, 2 * n_cu));
   hipLaunchKernelGGL(k_chol_tiles, dim3(grid), dim3(256), lds, st, C);
 }

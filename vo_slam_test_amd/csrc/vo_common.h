@@ -103,6 +103,15 @@ int upload(DevBuf &b, const void *src, size_t bytes, hipStream_t st, const char 
 // 2 when the kernel abandoned a wait.  Enqueues one memset and one kernel; no synchronisation.
 constexpr int kCholPanel = 64;
 size_t chol_workspace_bytes(int ld);
-void chol_factor_solve(double *A, int ld, void *workspace, hipStream_t st);
+// `plan` (or NULL = dense): the tile structure of the matrix.  chol_plan_create(m, pattern): m = ld / 64 tile rows, bit k of
+// pattern[i] = tile (i, k) of the lower triangle may be non-zero (the fill of the factorisation is added by the symbolic
+// pass); tiles outside the plan are never read, written or waited for, and tile columns that do not depend on each
+// other are factored concurrently.  chol_symbolic is that pass on its own (for choosing an ordering on the host).
+struct CholPlan;
+CholPlan *chol_plan_create(int m, const unsigned long long *pattern);
+void chol_plan_destroy(CholPlan *p);
+void chol_plan_info(const CholPlan *p, int *n_tiles, int *depth);
+void chol_symbolic(int m, const unsigned long long *pattern, unsigned long long *lmask, int *depth, int *n_tiles);
+void chol_factor_solve(double *A, int ld, void *workspace, hipStream_t st, const CholPlan *plan = nullptr);
 
 }  // namespace vo
