@@ -32,10 +32,13 @@ namespace {
 using namespace vo;
 
 constexpr int NB = vo::kCholPanel;  // 64
-#ifndef VO_CHOL_NEWTON
-#define VO_CHOL_NEWTON 2
+#ifndef VO_CHOL_POLL_DEPTH
+#define VO_CHOL_POLL_DEPTH 1
 #endif
-constexpr int kNewton = VO_CHOL_NEWTON;  // v_rsq_f64 is good to ~2^-26: one step gives ~1e-15, two steps full precision
+#ifndef VO_CHOL_NEWTON
+#define VO_CHOL_NEWTON 3
+#endif
+constexpr int kNewton = VO_CHOL_NEWTON;  // v_rsq_f64 is good to ~2^-26: 1, 2 = Newton steps (~1e-15, full precision); 3 = one third-order step (full)
 constexpr int LP = NB + 1;          // LDS pitch of a staged tile (conflict-free column and row walks)
 typedef double double4_t __attribute__((ext_vector_type(4)));
 
@@ -66,7 +69,7 @@ __device__ __forceinline__ double bcast_lane(double v, int src_lane) {
 struct CholCtx {
   double *A;
   int ld, m;          // m = ld / 64 tile columns; tile row m = the right-hand-side rows
-  int *fail, *ticket, *done, *ready, *xready, *pcount, *invready;
+  int *fail, *ticket, *ticket2, *done, *ready, *xready, *pcount, *invready;  // (ticket2: k_chol_back's)
   double *partial;    // [m][m][64] far partial products of the backward substitution
   double *linv;       // [m][64][64] inverses of the diagonal tiles (backward substitution by products, not by 64 pivots)
   int spin_limit;
@@ -77,26 +80,55 @@ struct CholCtx {
   const int4 *tasks;            // (type, i, j, aux): 0 tile (i, j) of the factorisation (i == m: right-hand-side row),
                                 // 1 inverse of diagonal tile j, 2 the backward chain, 3 far link (i, j), aux = its rank
   const unsigned long long *rowmask;  // [m + 1]: bit k of rowmask[i] = tile (i, k) of L exists (row m: the rhs row, all ones)
-  const int2 *colinfo;          // [m]: (far links of column j, tile (j + 1, j) exists)
+  const int2 *colinfo;          // [m]: (far links of column j: tiles (i, j) with i >= j + 3; bits 0, 1: tiles (j + 1, j), (j + 2, j) exist)
   int n_tasks, n_factor;        // tasks in all, factorisation tasks (what `done` counts)
+  int n_front;                  // tasks of the first launch (types 0 and 1); the rest is k_chol_back's
 };
 
-// workgroup-wide wait for a flag (bounded).  Returns false when the kernel is being abandoned.
-__device__ __forceinline__ bool wait_flag(const CholCtx &C, const int *flag, int want, int *s_state) {
+// workgroup-wide wait for a flag (bounded).  Returns false when the kernel is being abandoned.  A poll is a trip to
+// memory (~1 us: the loads bypass the caches), so four are kept in flight, a quarter of that apart -- the hand-offs
+// on the factorisation's critical path see a flag ~0.4 us sooner than with one poll at a time; `seen` (optional)
+// receives the value read, which may be ahead of `want` (panel counters: no need to ask again).
+__device__ __forceinline__ bool wait_flag(const CholCtx &C, const int *flag, int want, int *s_state, int *seen = nullptr) {
   if (threadIdx.x == 0) {
     int ok = 1;
-    for (int n = 0; ld_flag(flag) < want; n++) {
+    int v0 = ld_flag(flag);
+#if VO_CHOL_POLL_DEPTH == 4
+    if (v0 < want) {
+      __builtin_amdgcn_s_sleep(4);
+      int v1 = ld_flag(flag);
+      __builtin_amdgcn_s_sleep(4);
+      int v2 = ld_flag(flag);
+      __builtin_amdgcn_s_sleep(4);
+      int v3 = ld_flag(flag);
+      for (int n = 0; v0 < want; n++) {
+        if (n > C.spin_limit || ld_flag(C.fail) != 0) {
+          if (n > C.spin_limit) atomicMax(C.fail, 2);  // dependency never arrived: give up loudly instead of hanging
+          ok = 0;
+          break;
+        }
+        v0 = v1, v1 = v2, v2 = v3;
+        __builtin_amdgcn_s_sleep(4);
+        v3 = ld_flag(flag);
+      }
+    }
+#else
+    for (int n = 0; v0 < want; n++) {
       if (n > C.spin_limit || ld_flag(C.fail) != 0) {
         if (n > C.spin_limit) atomicMax(C.fail, 2);  // dependency never arrived: give up loudly instead of hanging
         ok = 0;
         break;
       }
       __builtin_amdgcn_s_sleep(2);
+      v0 = ld_flag(flag);
     }
-    *s_state = ok;
+#endif
+    s_state[0] = ok;
+    s_state[1] = v0;
   }
   __syncthreads();
-  const bool ok = *s_state != 0;
+  const bool ok = s_state[0] != 0;
+  if (seen) *seen = s_state[1];
   __syncthreads();
   return ok;
 }
@@ -137,62 +169,75 @@ __device__ __forceinline__ void load_tile(const CholCtx &C, int R0, int C0, doub
     T[rr + 8 * q][c + 1] = __longlong_as_double(((unsigned long long)v[q].w << 32) | v[q].z);
   }
 }
-__device__ __forceinline__ void store_tile(const CholCtx &C, int R0, int C0, const double (*T)[LP], bool lower_only) {
-  const int tid = threadIdx.x, c = 2 * (tid & 31), rr = tid >> 5;
-  const __amdgpu_buffer_rsrc_t rs = tile_rsrc(C);
-#pragma unroll
-  for (int q = 0; q < 8; q++) {
-    const int r = rr + 8 * q;
-    if (lower_only && c > r) continue;  // (the pair (r, c), (r, c + 1) with c == r also carries one entry above the diagonal: a zero)
-    const unsigned long long lo = __double_as_longlong(T[r][c]), hi = __double_as_longlong(T[r][c + 1]);
-    const u32x4 v = {(unsigned)lo, (unsigned)(lo >> 32), (unsigned)hi, (unsigned)(hi >> 32)};
-    __builtin_amdgcn_raw_buffer_store_b128(v, rs, (int)(((long long)(R0 + r) * C.ld + C0 + c) * 8), 0, kSc1);
-  }
-}
-
 // 64 x 64 Cholesky of the LDS tile T (lower triangle in, factor out), whole workgroup, four panels of 16 columns:
 //  (1) the first wavefront factors the panel -- lane = row, the row's 16 panel entries in registers, the pivot row's
 //      entries broadcast with v_readlane (no LDS round trip on the pivot chain, which is the critical path of the
-//      whole factorisation); the reciprocal square root is a single-precision estimate refined by three Newton
-//      steps in double (full precision at a fraction of v_sqrt_f64 + v_div_f64's latency);
+//      whole factorisation); the reciprocal square root is the hardware estimate refined by one third-order
+//      step in double (full precision at a fraction of v_sqrt_f64 + v_div_f64's latency);
 //  (2) all four wavefronts apply the rank-16 update to the trailing tiles on the matrix cores.
 // (A lane = row version with the whole 64-entry row in registers needs > 512 registers once it is part of this
 // kernel: 7 KB of scratch per lane and 15 ms per factorisation.)
-template <class PanelDone, class UpdateDone>
-__device__ __forceinline__ bool tile_chol(double (*T)[LP], double *rdiag /*[NB]*/, double *colbuf /*[NB]*/, PanelDone &&panel_done,
-                                          UpdateDone &&update_done) {
+// `side(b)`: what the other three wavefronts do while the first one is on panel b's pivots (they would wait at the barrier).
+template <class PanelDone, class UpdateDone, class Side>
+__device__ __forceinline__ bool tile_chol(double (*T)[LP], double *rdiag /*[NB]*/, double *colbuf /*[2][NB]*/, PanelDone &&panel_done,
+                                          UpdateDone &&update_done, Side &&side) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, i16 = lane & 15, q4 = lane >> 4;
   bool bad = false;
 #pragma unroll
   for (int b = 0; b < 4; b++) {
     const int c0 = 16 * b;
     if (wave == 0) {
-      double p[16];
+      // One wavefront issues in order, so everything between two pivots costs the chain its issue slots and every
+      // wait its latency.  The update of pivot j therefore reaches the columns in three ways: columns j + 1 and j + 2
+      // (needed by the next two pivots) take their factor by v_readlane right away; the columns from j + 3 on take it
+      // from an LDS broadcast ONE PIVOT LATER (double-buffered column, reads issued ahead of the pivot arithmetic), so
+      // no pivot waits for an LDS round trip.
+      // (LDS accesses of the loop: one base register each + immediate offsets -- addresses kept uniform are computed on
+      // the scalar unit, spilled and moved back for every access)
+      typedef __attribute__((address_space(3))) double lds_double;
+      unsigned cb_a = (unsigned)(size_t)colbuf, cbl_a = cb_a + 8u * (unsigned)lane;
+      asm volatile("" : "+v"(cb_a), "+v"(cbl_a));
+      const lds_double *cb = (const lds_double *)(size_t)cb_a;  // factors: uniform address, broadcast reads
+      lds_double *cbl = (lds_double *)(size_t)cbl_a;            // this lane's entry of the column
+      double p[16], rv = 0.0;
 #pragma unroll
       for (int c = 0; c < 16; c++) p[c] = T[lane][c0 + c];
 #pragma unroll
       for (int j = 0; j < 16; j++) {
+        double f[16];  // factors of pivot j - 1 for the columns j + 2 .. 15
+        if (j >= 1) {
+#pragma unroll
+          for (int c = j + 2; c < 16; c++) f[c] = cb[((j - 1) & 1) * NB + c0 + c];
+        }
         const double d = bcast_lane(p[j], c0 + j);
         if (!(d > 0.0) || !(d < 1e300)) bad = true;  // uniform
-        // 1 / sqrt(d): hardware estimate + Newton steps (e = 1 - d r^2, r += r e / 2): the pivot chain is the critical
-        // path of the whole factorisation, every dependent FP64 operation on it costs ~47 x 64 x 18 cycles
+        // 1 / sqrt(d): hardware estimate (~2^-26) + one third-order step, r (1 + e/2 + 3 e^2/8) with e = 1 - d r^2 -- four
+        // dependent operations to full precision (two Newton steps are six); the pivot chain is the critical path of the
+        // whole factorisation
         double r = __builtin_amdgcn_rsq(d);
+        if (kNewton == 3) {
+          const double e = __builtin_fma(-(d * r), r, 1.0);
+          r = __builtin_fma(r * e, __builtin_fma(0.375, e, 0.5), r);
+        } else {
 #pragma unroll
-        for (int nr = 0; nr < kNewton; nr++) r = __builtin_fma(0.5 * r, __builtin_fma(-(d * r), r, 1.0), r);
-        const double a = lane == c0 + j ? d * r : p[j] * r;  // L[lane][c0 + j] (meaningful for lane >= c0 + j)
+          for (int nr = 0; nr < kNewton; nr++) r = __builtin_fma(0.5 * r, __builtin_fma(-(d * r), r, 1.0), r);
+        }
+        const double a = p[j] * r;  // L[lane][c0 + j] (meaningful for lane >= c0 + j; the pivot lane holds d: d r = sqrt(d))
         p[j] = a;
-        if (lane == c0 + j) rdiag[c0 + j] = r;
-        if (j < 15) {
-          // the next pivot only needs column j + 1 of this update: its factor comes by v_readlane (no LDS round trip
-          // on the pivot chain); the other columns take theirs from an LDS broadcast, off the chain
-          p[j + 1] -= a * bcast_lane(a, c0 + j + 1);
-          colbuf[lane] = a;
+        rv = lane == c0 + j ? r : rv;
+        if (j < 15) p[j + 1] -= a * bcast_lane(a, c0 + j + 1);
+        if (j < 14) p[j + 2] -= a * bcast_lane(a, c0 + j + 2);
+        if (j < 13) cbl[(j & 1) * NB] = a;
+        if (j >= 1) {
 #pragma unroll
-          for (int c = j + 2; c < 16; c++) p[c] -= a * colbuf[c0 + c];  // one wavefront issues its LDS operations in order
+          for (int c = j + 2; c < 16; c++) p[c] -= p[j - 1] * f[c];
         }
       }
+      if (lane >= c0 && lane < c0 + 16) rdiag[lane] = rv;
 #pragma unroll
       for (int c = 0; c < 16; c++) T[lane][c0 + c] = (lane >= c0 + c) ? p[c] : 0.0;
+    } else {
+      side(b);
     }
     __syncthreads();
     panel_done(b);  // columns c0 .. c0 + 15 are final: the owner ships them while the trailing update runs
@@ -216,30 +261,50 @@ __device__ __forceinline__ bool tile_chol(double (*T)[LP], double *rdiag /*[NB]*
 
 // X L^T = W for the 64 rows of W (in place), L = lower-triangular LDS tile, rdiag = 1 / diag(L).  Rows are
 // independent: every wavefront owns 16 of them and needs no workgroup barrier.  Column blocks of 16: the part of a
-// block that depends on earlier blocks is an MFMA product, the 16 x 16 triangle a per-row substitution.
-__device__ __forceinline__ void tile_trsm_block(double (*W)[LP], const double (*L)[LP], const double *rdiag, int b) {
+// block that depends on earlier blocks is an MFMA product, the 16 x 16 triangle a per-row substitution.  This runs on
+// the factorisation's critical path (the tile below the diagonal closes a column), so nothing in it may wait for LDS
+// in a dependent position: the product's operands are all requested before the first MFMA and accumulated in
+// independent chains; the substitution fetches row c + 1 of the triangle while row c is being used, and a row's sum
+// takes the newest unknown last (two dependent operations per column).
+template <int B>
+__device__ __forceinline__ void tile_trsm_block(double (*W)[LP], const double (*L)[LP], const double *rdiag) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, i16 = lane & 15, q4 = lane >> 4;
-  const int r0 = 16 * wave, c0 = 16 * b;
-  if (b > 0) {
-    double4_t acc = {W[r0 + q4][c0 + i16], W[r0 + q4 + 4][c0 + i16], W[r0 + q4 + 8][c0 + i16], W[r0 + q4 + 12][c0 + i16]};
-    for (int s = 0; s < 4 * b; s++)
-      acc = __builtin_amdgcn_mfma_f64_16x16x4f64(-W[r0 + i16][4 * s + q4], L[c0 + i16][4 * s + q4], acc, 0, 0, 0);
+  const int r0 = 16 * wave, c0 = 16 * B;
+  if (B > 0) {
+    constexpr int KS = 4 * B, NCH = B == 1 ? 2 : 4;
+    double wa[KS > 0 ? KS : 1], lb[KS > 0 ? KS : 1];
+#pragma unroll
+    for (int s = 0; s < KS; s++) wa[s] = -W[r0 + i16][4 * s + q4], lb[s] = L[c0 + i16][4 * s + q4];
+    double4_t acc[NCH];
+    acc[0] = double4_t{W[r0 + q4][c0 + i16], W[r0 + q4 + 4][c0 + i16], W[r0 + q4 + 8][c0 + i16], W[r0 + q4 + 12][c0 + i16]};
+#pragma unroll
+    for (int h = 1; h < NCH; h++) acc[h] = double4_t{0, 0, 0, 0};
+#pragma unroll
+    for (int s = 0; s < KS; s++) acc[s % NCH] = __builtin_amdgcn_mfma_f64_16x16x4f64(wa[s], lb[s], acc[s % NCH], 0, 0, 0);
+    double4_t tot = NCH == 2 ? acc[0] + acc[1] : (acc[0] + acc[1]) + (acc[2] + acc[3]);
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     __builtin_amdgcn_wave_barrier();
-    W[r0 + q4][c0 + i16] = acc[0], W[r0 + q4 + 4][c0 + i16] = acc[1], W[r0 + q4 + 8][c0 + i16] = acc[2], W[r0 + q4 + 12][c0 + i16] = acc[3];
+    W[r0 + q4][c0 + i16] = tot[0], W[r0 + q4 + 4][c0 + i16] = tot[1], W[r0 + q4 + 8][c0 + i16] = tot[2], W[r0 + q4 + 12][c0 + i16] = tot[3];
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     __builtin_amdgcn_wave_barrier();
   }
   if (lane < 16) {
-    double x[16];
+    double x[16], rd[16], lrow[2][16];
 #pragma unroll
-    for (int c = 0; c < 16; c++) x[c] = W[r0 + lane][c0 + c];
+    for (int c = 0; c < 16; c++) x[c] = W[r0 + lane][c0 + c], rd[c] = rdiag[c0 + c];
+    lrow[1][0] = L[c0 + 1][c0];
+    x[0] *= rd[0];
 #pragma unroll
-    for (int c = 0; c < 16; c++) {
+    for (int c = 1; c < 16; c++) {
+      if (c + 1 < 16) {
+#pragma unroll
+        for (int q = 0; q <= c; q++) lrow[(c + 1) & 1][q] = L[c0 + c + 1][c0 + q];
+      }
       double v = x[c];
 #pragma unroll
-      for (int q = 0; q < c; q++) v -= x[q] * L[c0 + c][c0 + q];
-      x[c] = v * rdiag[c0 + c];
+      for (int q = 0; q + 1 < c; q++) v -= x[q] * lrow[c & 1][q];
+      v -= x[c - 1] * lrow[c & 1][c - 1];
+      x[c] = v * rd[c];
     }
 #pragma unroll
     for (int c = 0; c < 16; c++) W[r0 + lane][c0 + c] = x[c];
@@ -253,19 +318,19 @@ __global__ __launch_bounds__(256) void k_chol_tiles(CholCtx C) {
   double(*Pr)[LP] = reinterpret_cast<double(*)[LP]>(lds);
   double(*Pc)[LP] = reinterpret_cast<double(*)[LP]>(lds + NB * LP);
   double *col = lds + 2 * NB * LP, *rdiag = col + NB, *xv = rdiag + NB;  // xv[4][NB]: backward-substitution vectors
-  __shared__ int s_ticket, s_state;
+  __shared__ int s_ticket, s_state[2], s_stored;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, i16 = lane & 15, q4 = lane >> 4;
   const int m = C.m, ld = C.ld;
-  const int nF = C.n_factor;
+  if (tid == 0) s_stored = 0;
   for (;;) {
     if (tid == 0) s_ticket = atomicAdd(C.ticket, 1);
     __syncthreads();
     const int t = s_ticket;
     __syncthreads();
-    if (t >= C.n_tasks) return;
-    if (tid == 0) s_state = ld_flag(C.fail);
+    if (t >= C.n_front) return;
+    if (tid == 0) s_state[0] = ld_flag(C.fail);
     __syncthreads();
-    if (s_state != 0) return;  // abandoned (not positive definite, or a dependency timed out)
+    if (s_state[0] != 0) return;  // abandoned (not positive definite, or a dependency timed out)
     __syncthreads();
     // Ticket order (the plan's): column by column over the tiles that exist (i = j .. m), and behind column j's tasks the
     // inverse of diagonal tile j - 2, which is complete by then (a task that polls for a long time costs the chain
@@ -275,44 +340,76 @@ __global__ __launch_bounds__(256) void k_chol_tiles(CholCtx C) {
     const int inv_j = task.x == 1 ? task.z : -1;
     if (task.x == 0) {
       // ---------------------------------------------------------------- factorisation task (i, j)
+      // task.w != 0 (i == j + 1): the owner of the tile below the diagonal carries on as the owner of the NEXT diagonal
+      // tile (i, i).  That tile's last update is L(i,j) L(i,j)^T, and L(i,j) is what this workgroup has just produced:
+      // it is applied from LDS, sixteen columns at a time as the triangular solve finishes them (in the time this
+      // workgroup would otherwise spend waiting for the next panel of L(j,j)), instead of travelling to memory and back
+      // (store + flag + load: ~2.5 us of every column's ~17).
       const int j = task.z;
       const int i = task.y;                                  // j <= i <= m  (i == m: right-hand-side rows)
+      const bool fused = task.w != 0;
       const int R0 = i < m ? NB * i : ld, C0 = NB * j;
       const int qr = (wave >> 1) * 32, qc = (wave & 1) * 32;
-      double4_t acc[2][2];
+      double4_t acc[2][2], accd[2][2];
 #pragma unroll
       for (int a = 0; a < 2; a++)
 #pragma unroll
         for (int b = 0; b < 2; b++) {
           const double *p = C.A + (long long)(R0 + qr + 16 * a + q4) * ld + C0 + qc + 16 * b + i16;
           acc[a][b] = double4_t{p[0], p[4LL * ld], p[8LL * ld], p[12LL * ld]};
+          accd[a][b] = double4_t{0, 0, 0, 0};
+          if (fused) {
+            const double *pd = C.A + (long long)(R0 + qr + 16 * a + q4) * ld + R0 + qc + 16 * b + i16;
+            accd[a][b] = double4_t{pd[0], pd[4LL * ld], pd[8LL * ld], pd[12LL * ld]};
+          }
         }
       bool alive = true;
       const int stamp_slot = i == j ? 2 * j : (i == j + 1 ? 2 * j + 1 : -1);
       // only the tile columns k in which both L(i, k) and L(j, k) exist contribute (and only those tiles are ever
-      // published: a tile that does not exist must not be waited for)
-      unsigned long long kmask = C.rowmask[i] & C.rowmask[j] & ((1ull << j) - 1ull);
-      while (kmask != 0ull && alive) {
-        const int k = (int)__builtin_ctzll(kmask);
-        kmask &= kmask - 1ull;
+      // published: a tile that does not exist must not be waited for); the next diagonal tile takes every L(i, k)
+      const unsigned long long below_j = (1ull << j) - 1ull;
+      const unsigned long long kmask = C.rowmask[i] & C.rowmask[j] & below_j;
+      unsigned long long kall = fused ? (C.rowmask[i] & below_j) : kmask;
+      while (kall != 0ull && alive) {
+        const int k = (int)__builtin_ctzll(kall);
+        kall &= kall - 1ull;
+        const bool in_s = ((kmask >> k) & 1ull) != 0;
         if (stamp_slot >= 0 && k == j - 1) CSTAMP(stamp_slot, 0);
-        alive = wait_flag(C, C.ready + i * m + k, 1, &s_state);
-        if (alive && i != j) alive = wait_flag(C, C.ready + j * m + k, 1, &s_state);
+        alive = wait_flag(C, C.ready + i * m + k, 1, s_state);
         if (!alive) break;
-        if (stamp_slot >= 0 && k == j - 1) CSTAMP(stamp_slot, 1);
         load_tile(C, R0, NB * k, Pr, true);
-        if (i != j) load_tile(C, NB * j, NB * k, Pc, true);
         __syncthreads();
-        double(*Pb)[LP] = i != j ? Pc : Pr;
+        // (the last L(j, k) is the tile the previous column has just finished: what does not need it goes first)
+        if (fused) {
 #pragma unroll
-        for (int a = 0; a < 2; a++)
+          for (int a = 0; a < 2; a++)
 #pragma unroll
-          for (int b = 0; b < 2; b++) {
-            const int r0 = qr + 16 * a, c0 = qc + 16 * b;
+            for (int b = 0; b < 2; b++) {
+              const int r0 = qr + 16 * a, c0 = qc + 16 * b;
 #pragma unroll
-            for (int s = 0; s < NB / 4; s++)
-              acc[a][b] = __builtin_amdgcn_mfma_f64_16x16x4f64(-Pr[r0 + i16][4 * s + q4], Pb[c0 + i16][4 * s + q4], acc[a][b], 0, 0, 0);
+              for (int s = 0; s < NB / 4; s++)
+                accd[a][b] = __builtin_amdgcn_mfma_f64_16x16x4f64(-Pr[r0 + i16][4 * s + q4], Pr[c0 + i16][4 * s + q4], accd[a][b], 0, 0, 0);
+            }
+        }
+        if (in_s) {
+          if (i != j) {
+            alive = wait_flag(C, C.ready + j * m + k, 1, s_state);
+            if (!alive) break;
+            if (stamp_slot >= 0 && k == j - 1) CSTAMP(stamp_slot, 1);
+            load_tile(C, NB * j, NB * k, Pc, true);
+            __syncthreads();
           }
+          double(*Pb)[LP] = i != j ? Pc : Pr;
+#pragma unroll
+          for (int a = 0; a < 2; a++)
+#pragma unroll
+            for (int b = 0; b < 2; b++) {
+              const int r0 = qr + 16 * a, c0 = qc + 16 * b;
+#pragma unroll
+              for (int s = 0; s < NB / 4; s++)
+                acc[a][b] = __builtin_amdgcn_mfma_f64_16x16x4f64(-Pr[r0 + i16][4 * s + q4], Pb[c0 + i16][4 * s + q4], acc[a][b], 0, 0, 0);
+            }
+        }
         __syncthreads();
       }
       if (!alive) return;
@@ -325,63 +422,140 @@ __global__ __launch_bounds__(256) void k_chol_tiles(CholCtx C) {
 #pragma unroll
           for (int g = 0; g < 4; g++) Pr[qr + 16 * a + q4 + 4 * g][qc + 16 * b + i16] = acc[a][b][g];
       __syncthreads();
-      if (i == j) {
-        // The diagonal tile is published PANEL BY PANEL (flag = panels shipped): the tile below it starts its
-        // triangular solve on the first 16 columns while the pivots of the next panel are still being computed.
-        const __amdgpu_buffer_rsrc_t rs = tile_rsrc(C);
-        double *rd_out = C.partial + (long long)m * m * NB + NB * j;
+      const __amdgpu_buffer_rsrc_t rs = tile_rsrc(C);
+      // A diagonal tile (working tile T, tile row d) is published PANEL BY PANEL (flag = panels shipped): the tile below
+      // it starts its triangular solve on the first 16 columns while the pivots of the next panel are still being
+      // computed.  `sub` (fused tasks): the flag of the sub-diagonal tile, whose stores are still in flight -- the three
+      // wavefronts that issued them have nothing to do during the first panel's pivots: they drain, count in LDS, and
+      // the last one raises the flag, so the store is on nobody's path.
+      auto factor_diagonal = [&](double(*T)[LP], int d, int dslot, int *sub) {
+        double *rd_out = C.partial + (long long)m * m * NB + NB * d;
         const bool ok = tile_chol(
-            Pr, rdiag, col,
+            T, rdiag, xv,  // (xv: the backward substitution's vectors, free during the factorisation)
             [&](int b) {  // panel b: rows 16 b .. 63 x 16 columns = 2 doubles per thread and row group
+              if (b == 1 && dslot >= 0) CSTAMP(dslot, 11);
               const int c = 16 * b + 2 * (tid & 7), rr = tid >> 3;  // 8 threads per row, 32 rows per pass
 #pragma unroll
               for (int q = 0; q < 2; q++) {
                 const int r = rr + 32 * q;
                 if (r < 16 * b) continue;
-                const unsigned long long lo = __double_as_longlong(Pr[r][c]), hi = __double_as_longlong(Pr[r][c + 1]);
+                const unsigned long long lo = __double_as_longlong(T[r][c]), hi = __double_as_longlong(T[r][c + 1]);
                 const u32x4 v = {(unsigned)lo, (unsigned)(lo >> 32), (unsigned)hi, (unsigned)(hi >> 32)};
-                __builtin_amdgcn_raw_buffer_store_b128(v, rs, (int)(((long long)(R0 + r) * ld + C0 + c) * 8), 0, kSc1);
+                __builtin_amdgcn_raw_buffer_store_b128(v, rs, (int)(((long long)(NB * d + r) * ld + NB * d + c) * 8), 0, kSc1);
               }
               if (tid < 16) st_sc1(rd_out + 16 * b + tid, rdiag[16 * b + tid]);
             },
             [&](int b) {  // (flagging a panel one pivot phase later, when its stores have long landed, was measured: the
                           // tile below falls behind by as much and the column period grows from 22.9 to 25.4 us)
+              if (b == 1 && dslot >= 0) CSTAMP(dslot, 12);
               asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
               __syncthreads();
-              if (tid == 0) st_flag(C.ready + i * m + j, b + 1);
+              if (tid == 0) st_flag(C.ready + d * m + d, b + 1);
+              if (b == 0 && dslot >= 0) CSTAMP(dslot, 14);
+              if (b == 1 && dslot >= 0) CSTAMP(dslot, 13);
+            },
+            [&](int b) {
+              if (b != 0 || !sub) return;
+              asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // (this wavefront's share of the sub-diagonal tile's stores)
+              if (lane == 0 && atomicAdd(&s_stored, 1) == 2) {
+                s_stored = 0;
+                st_flag(sub, 1);
+              }
             });
         if (!ok && tid == 0) atomicMax(C.fail, 1);  // not positive definite
-        if (stamp_slot >= 0) CSTAMP(stamp_slot, 3);
-        if (stamp_slot >= 0) CSTAMP(stamp_slot, 6);
+        if (dslot >= 0) CSTAMP(dslot, 3);
+        if (dslot >= 0) CSTAMP(dslot, 6);
         if (tid == 0) atomicAdd(C.done, 1);
+      };
+      if (i == j) {
+        factor_diagonal(Pr, j, stamp_slot, nullptr);
         continue;
-      } else {
-        // X L(j,j)^T = T, panel by panel as the diagonal tile's owner ships them
-        const __amdgpu_buffer_rsrc_t rs = tile_rsrc(C);
-        const double *rd_in = C.partial + (long long)m * m * NB + NB * j;
-        for (int b = 0; b < 4; b++) {
-          if (!wait_flag(C, C.ready + j * m + j, b + 1, &s_state)) return;
-          if (stamp_slot >= 0 && b == 3) CSTAMP(stamp_slot, 3);
-          {  // panel b of L(j,j): rows 16 b .. 63, columns 16 b .. 16 b + 15
-            const int c = 16 * b + 2 * (tid & 7), rr = tid >> 3;
-            u32x4 v[2];
+      }
+      // X L(j,j)^T = T, panel by panel as the diagonal tile's owner ships them
+      const double *rd_in = C.partial + (long long)m * m * NB + NB * j;
+      // columns 16 b .. 16 b + 15 of X leave for memory as soon as every wavefront has solved its rows (callers: behind a
+      // barrier), from wavefronts 1..3 only: the first one goes on to the next diagonal tile's pivots and must not have
+      // stores of its own to wait for
+      auto store_panel = [&](int b) {
+        if (wave == 0) return;
 #pragma unroll
-            for (int q = 0; q < 2; q++)
-              v[q] = __builtin_amdgcn_raw_buffer_load_b128(rs, (int)(((long long)(NB * j + rr + 32 * q) * ld + C0 + c) * 8), 0, kSc1);
+        for (int t = 0; t < 3; t++) {
+          const int q = (wave - 1) * 64 + lane + 192 * t;
+          if (q >= 512) break;
+          const int r = q >> 3, cc = 16 * b + 2 * (q & 7);
+          const unsigned long long lo = __double_as_longlong(Pr[r][cc]), hi = __double_as_longlong(Pr[r][cc + 1]);
+          const u32x4 v = {(unsigned)lo, (unsigned)(lo >> 32), (unsigned)hi, (unsigned)(hi >> 32)};
+          __builtin_amdgcn_raw_buffer_store_b128(v, rs, (int)(((long long)(R0 + r) * ld + C0 + cc) * 8), 0, kSc1);
+        }
+      };
+      auto diag_rank16 = [&](int b) {  // next diagonal tile -= (columns 16 b .. 16 b + 15 of X) (same)^T
 #pragma unroll
-            for (int q = 0; q < 2; q++) {
-              Pc[rr + 32 * q][c] = __longlong_as_double(((unsigned long long)v[q].y << 32) | v[q].x);
-              Pc[rr + 32 * q][c + 1] = __longlong_as_double(((unsigned long long)v[q].w << 32) | v[q].z);
-            }
-            if (tid < 16) rdiag[16 * b + tid] = ld_sc1(rd_in + 16 * b + tid);
+        for (int a = 0; a < 2; a++)
+#pragma unroll
+          for (int bq = 0; bq < 2; bq++) {
+            const int r0 = qr + 16 * a, c0 = qc + 16 * bq;
+#pragma unroll
+            for (int s = 0; s < 4; s++)
+              accd[a][bq] = __builtin_amdgcn_mfma_f64_16x16x4f64(-Pr[r0 + i16][16 * b + 4 * s + q4], Pr[c0 + i16][16 * b + 4 * s + q4], accd[a][bq], 0, 0, 0);
           }
-          __syncthreads();
-          if (stamp_slot >= 0 && b == 3) CSTAMP(stamp_slot, 4);
-          tile_trsm_block(Pr, Pc, rdiag, b);
+      };
+      int panels = 0;  // panels of L(j,j) known to be published
+      bool have_next = false;
+      u32x4 pv[2];
+      double prd = 0;
+      auto request_panel = [&](int b) {  // panel b of L(j,j): rows 16 b .. 63, columns 16 b .. 16 b + 15 -> registers
+        const int c = 16 * b + 2 * (tid & 7), rr = tid >> 3;
+#pragma unroll
+        for (int q = 0; q < 2; q++)
+          pv[q] = __builtin_amdgcn_raw_buffer_load_b128(rs, (int)(((long long)(NB * j + rr + 32 * q) * ld + C0 + c) * 8), 0, kSc1);
+        if (tid < 16) prd = ld_sc1(rd_in + 16 * b + tid);
+      };
+      for (int b = 0; b < 4; b++) {
+        // (the barriers of the wait -- or the one in its place -- also close the solve of panel b - 1)
+        if (panels >= b + 1) __syncthreads();
+        else if (!wait_flag(C, C.ready + j * m + j, b + 1, s_state, &panels)) return;
+        if (stamp_slot >= 0 && b == 3) CSTAMP(stamp_slot, 3);
+        if (!have_next) request_panel(b);
+        if (b > 0) store_panel(b - 1);
+        if (fused && b > 0) diag_rank16(b - 1);  // (while the panel is on its way)
+        {
+          const int c = 16 * b + 2 * (tid & 7), rr = tid >> 3;
+#pragma unroll
+          for (int q = 0; q < 2; q++) {
+            Pc[rr + 32 * q][c] = __longlong_as_double(((unsigned long long)pv[q].y << 32) | pv[q].x);
+            Pc[rr + 32 * q][c + 1] = __longlong_as_double(((unsigned long long)pv[q].w << 32) | pv[q].z);
+          }
+          if (tid < 16) rdiag[16 * b + tid] = prd;
         }
         __syncthreads();
-        if (stamp_slot >= 0) CSTAMP(stamp_slot, 5);
-        store_tile(C, R0, C0, Pr, false);
+        // a workgroup that has fallen behind the diagonal tile's owner (the usual case: its last update could only start
+        // when the previous column closed) asks for the next panel before it solves this one
+        have_next = b < 3 && panels >= b + 2;
+        if (have_next) request_panel(b + 1);
+        if (stamp_slot >= 0 && b == 3) CSTAMP(stamp_slot, 4);
+        if (b == 0) tile_trsm_block<0>(Pr, Pc, rdiag);
+        else if (b == 1) tile_trsm_block<1>(Pr, Pc, rdiag);
+        else if (b == 2) tile_trsm_block<2>(Pr, Pc, rdiag);
+        else tile_trsm_block<3>(Pr, Pc, rdiag);
+      }
+      __syncthreads();
+      if (stamp_slot >= 0) CSTAMP(stamp_slot, 5);
+      store_panel(3);
+      if (fused) {
+        diag_rank16(3);
+        // the next diagonal tile's working copy goes to the other LDS tile: Pr is the source of the sub-diagonal tile's store
+#pragma unroll
+        for (int a = 0; a < 2; a++)
+#pragma unroll
+          for (int b = 0; b < 2; b++)
+#pragma unroll
+            for (int g = 0; g < 4; g++) Pc[qr + 16 * a + q4 + 4 * g][qc + 16 * b + i16] = accd[a][b][g];
+        __syncthreads();
+        if (tid == 0) atomicAdd(C.done, 1);
+        if (stamp_slot >= 0) CSTAMP(stamp_slot, 6);
+        if (stamp_slot >= 0) CSTAMP(stamp_slot + 1, 2);
+        factor_diagonal(Pc, i, stamp_slot >= 0 ? stamp_slot + 1 : -1, C.ready + i * m + j);
+        continue;
       }
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       __syncthreads();
@@ -390,31 +564,14 @@ __global__ __launch_bounds__(256) void k_chol_tiles(CholCtx C) {
       if (tid == 0) atomicAdd(C.done, 1);
       continue;
     }
-    const double *y = C.A + (long long)ld * ld;          // L^-1 b after the factorisation
-    double *xsol = C.A + (long long)(ld + 1) * ld;       // solution row
     const double *rd_all = C.partial + (long long)m * m * NB;
-    double *Sacc = C.partial;                             // [m][NB]: running sum_{i >= j + 2} L(i,j)^T x_i of column j
-    double *red = xv;                                     // [4][NB] partial dot products of the four wavefronts
-    // L(i,j)^T x for the staged tile T and the vector in `vec`: thread (g, c) takes rows r = g, g + 4, ...;
-    // returns the complete sum in threads 0..63 (fixed order)
-    auto tile_matvec_t = [&](double (*T)[LP], const double *vec) {
-      const int c = tid & 63, g = tid >> 6;
-      double acc = 0;
-#pragma unroll
-      for (int r = 0; r < NB / 4; r++) acc += T[g + 4 * r][c] * vec[g + 4 * r];
-      red[g * NB + c] = acc;
-      __syncthreads();
-      const double tot = (red[c] + red[NB + c]) + (red[2 * NB + c] + red[3 * NB + c]);
-      __syncthreads();
-      return tot;
-    };
-    if (inv_j >= 0) {
+    {
       // ---------------------------------------------------------------- X = L(j,j)^-1 for the backward substitution.
       // One wavefront, lane = column of X, L's entries broadcast from LDS: 2016 multiply-adds per lane (~10 us) -- on
       // nobody's critical path except for the last tile, and it turns the 64 sequential pivots of every backward
       // step into one tile product.
       const int j = inv_j;
-      if (!wait_flag(C, C.ready + j * m + j, 4, &s_state)) return;
+      if (!wait_flag(C, C.ready + j * m + j, 4, s_state)) return;
       load_tile(C, NB * j, NB * j, Pr, true);
       if (tid < NB) rdiag[tid] = ld_sc1(rd_all + NB * j + tid);
       __syncthreads();
@@ -438,64 +595,172 @@ __global__ __launch_bounds__(256) void k_chol_tiles(CholCtx C) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         if (lane == 0) atomicAdd(C.invready, 1);  // a counter: the chain waits for all of them at once
       }
-      continue;
     }
+  }
+}
+
+// The backward substitution L^T x = y: its own launch behind the factorisation (own register allocation: the chain keeps
+// four tiles in registers; as part of k_chol_tiles it pushed that kernel to 442 registers).  Tasks: the plan's types 2
+// (the chain, first ticket) and 3 (far links).
+__global__ __launch_bounds__(256, 2) void k_chol_back(CholCtx C) {
+  extern __shared__ __attribute__((aligned(16))) double lds[];
+  double(*Pr)[LP] = reinterpret_cast<double(*)[LP]>(lds);
+  double *col = lds + 2 * NB * LP, *rdiag = col + NB, *xv = rdiag + NB;
+  __shared__ int s_ticket, s_state[2], s_pc;
+  const int tid = threadIdx.x;
+  const int m = C.m, ld = C.ld;
+  (void)rdiag;
+  for (;;) {
+    if (tid == 0) s_ticket = atomicAdd(C.ticket2, 1);
+    __syncthreads();
+    const int t = s_ticket + C.n_front;
+    __syncthreads();
+    if (t >= C.n_tasks) return;
+    if (tid == 0) s_state[0] = ld_flag(C.fail);
+    __syncthreads();
+    if (s_state[0] != 0) return;  // abandoned (not positive definite, or a dependency timed out)
+    __syncthreads();
+    const int4 task = C.tasks[t];
+    const double *y = C.A + (long long)ld * ld;          // L^-1 b after the factorisation
+    double *xsol = C.A + (long long)(ld + 1) * ld;       // solution row
+    double *Sacc = C.partial;                             // [m][NB]: running sum_{i >= j + 2} L(i,j)^T x_i of column j
+    double *red = xv;                                     // [4][NB] partial dot products of the four wavefronts
+    // L(i,j)^T x for the staged tile T and the vector in `vec`: thread (g, c) takes rows r = g, g + 4, ...;
+    // returns the complete sum in threads 0..63 (fixed order)
+    auto tile_matvec_t = [&](double (*T)[LP], const double *vec) {
+      const int c = tid & 63, g = tid >> 6;
+      double acc = 0;
+#pragma unroll
+      for (int r = 0; r < NB / 4; r++) acc += T[g + 4 * r][c] * vec[g + 4 * r];
+      red[g * NB + c] = acc;
+      __syncthreads();
+      const double tot = (red[c] + red[NB + c]) + (red[2 * NB + c] + red[3 * NB + c]);
+      __syncthreads();
+      return tot;
+    };
     if (task.x == 2) {
       // ---------------------------------------------------------------- backward substitution, the chain:
-      // x_j = L(j,j)^-T (y_j - L(j+1,j)^T x_{j+1} - S_j), S_j delivered by the other workgroups.  Per column: two
-      // tile products (no pivot loop); x_j is flagged for the far links one step later, when its write-through
-      // store has landed behind the next column's tile loads, so the chain itself never waits for a store.
+      // x_j = L(j,j)^-T (y_j - sum_{i = j+1, j+2} L(i,j)^T x_i - S_j), S_j = the far links (i >= j + 3) delivered by the
+      // other workgroups.  A step must not contain a dependent trip to memory (~1 us each, 47 steps): the two near
+      // tiles, the inverse of the diagonal tile, y and the state of the far links of column j - 1 are requested during
+      // step j and stay in REGISTERS -- a thread owns 8 rows x 2 columns of a tile, forms its part of T^T v there, and
+      // the 8 parts of a column meet in LDS (fixed order).  x_i is flagged for the far links one step after it was
+      // computed (its write-through store has landed by then), and a far link has two more steps to deliver (a third near
+      // tile in registers would push the kernel past 256 registers: one workgroup per CU).
       CSTAMP(0, 8);
-      if (!wait_flag(C, C.done, nF, &s_state)) return;  // every tile of L (and y = L^-1 b) is published
-      if (!wait_flag(C, C.invready, m, &s_state)) return;  // and every inverse
-      const __amdgpu_buffer_rsrc_t rsi = linv_rsrc(C);
-      double *svec = rdiag;  // right-hand side of the column (rdiag is free here)
-      for (int j = m - 1; j >= 0; j--) {
+      const __amdgpu_buffer_rsrc_t rsi = linv_rsrc(C), rst = tile_rsrc(C);
+      const int c = 2 * (tid & 31), rr = tid >> 5;
+      double *xs = Pr[0];         // [4][NB] ring of the last solutions x_j (slot j & 3)
+      double *svec = xs + 4 * NB; // [NB] right-hand side of the column
+      double *red8 = svec + NB;   // [8][NB] parts of a product
+      u32x4 n1[8], n2[8], ia[8], ib[8];
+      auto ld8 = [&](const __amdgpu_buffer_rsrc_t rs, int pitch, int R0, int C0, u32x4(&v)[8]) {
+#pragma unroll
+        for (int q = 0; q < 8; q++)
+          v[q] = __builtin_amdgcn_raw_buffer_load_b128(rs, (int)(((long long)(R0 + rr + 8 * q) * pitch + C0 + c) * 8), 0, kSc1);
+      };
+      auto dot8 = [&](const u32x4(&v)[8], const double *vec, double &a0, double &a1) {
+#pragma unroll
+        for (int q = 0; q < 8; q++) {
+          const double x = vec[rr + 8 * q];
+          a0 = __builtin_fma(__longlong_as_double(((unsigned long long)v[q].y << 32) | v[q].x), x, a0);
+          a1 = __builtin_fma(__longlong_as_double(((unsigned long long)v[q].w << 32) | v[q].z), x, a1);
+        }
+      };
+      auto issue_near = [&](int j, int mask) {
+        if (mask & 1) ld8(rst, ld, NB * (j + 1), NB * j, n1);
+        if (mask & 2) ld8(rst, ld, NB * (j + 2), NB * j, n2);
+      };
+      auto sum8 = [&]() {  // thread tid < NB: the complete product of its column
+        double t = 0;
+#pragma unroll
+        for (int g = 0; g < 8; g++) t += red8[g * NB + tid];
+        return t;
+      };
+      // state requested one step ahead: y_j, the far links' counter of column j, the tiles
+      int2 ci = C.colinfo[m - 1];
+      double yj = tid < NB ? ld_sc1(y + NB * (m - 1) + tid) : 0.0;
+      if (tid == 0) s_pc = 0;  // (the last column has no links)
+      __syncthreads();
+      ld8(rsi, NB, NB * (m - 1), 0, ia);
+      auto step = [&](int j, u32x4(&cur)[8], u32x4(&nxt)[8]) -> bool {
         if (j == 0) CSTAMP(0, 9);
-        const int2 ci = C.colinfo[j];
-        const bool near = ci.y != 0;  // tile (j + 1, j) exists
-        if (near) load_tile(C, NB * (j + 1), NB * j, Pr, true);
-        load_tile_rs(rsi, NB, NB * j, 0, Pc);
-        double yj = 0;
-        if (tid < NB) yj = ld_sc1(y + NB * j + tid);
-        // (all vector-memory operations issued so far have completed once the tiles are in LDS: x_{j+1} is visible)
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#ifdef VO_CHOL_STAMPS
+        const unsigned long long w0 = wall_clock64();
+#endif
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this column's tiles are here, and x_{j+1} has landed
+#ifdef VO_CHOL_STAMPS
+        if (tid == 0) C.stamps[1 * 16 + 8] += wall_clock64() - w0;  // time spent waiting for the requested tiles
+#endif
         if (j + 1 < m && tid == 0) st_flag(C.xready + j + 1, 1);
-        const int links = ci.x;
-        if (links > 0 && !wait_flag(C, C.pcount + j, links, &s_state)) return;
-        __syncthreads();
-        double sj = yj;
-        if (tid < NB && links > 0) sj -= ld_sc1(Sacc + NB * j + tid);
-        if (near) {
-          const double nv = tile_matvec_t(Pr, col);  // col = x_{j+1}
-          sj -= nv;
+        const int links = ci.x, near = ci.y;
+        // the far links: normally complete a step ago (pc was read then); S_j is requested first, ahead of the bulk loads
+        const bool fast = links == 0 || s_pc >= links;  // (s_pc: written by thread 0 before the barrier that closed the last step)
+        double sfar = 0;
+        if (links > 0 && fast && tid < NB) sfar = ld_sc1(Sacc + NB * j + tid);
+        int2 cn = ci;
+        int pcn = 0;
+        double yn = 0;
+        if (j >= 1) {
+          cn = C.colinfo[j - 1];
+          if (tid == 0 && cn.x > 0) pcn = ld_flag(C.pcount + j - 1);
+          if (tid < NB) yn = ld_sc1(y + NB * (j - 1) + tid);
         }
-        if (tid < NB) svec[tid] = sj;
+        double a0 = 0, a1 = 0;
+        if (near & 1) dot8(n1, xs + ((j + 1) & 3) * NB, a0, a1);
+        if (near & 2) dot8(n2, xs + ((j + 2) & 3) * NB, a0, a1);
+        if (j >= 1) {
+          issue_near(j - 1, cn.y);
+          ld8(rsi, NB, NB * (j - 1), 0, nxt);
+        }
+        red8[rr * NB + c] = a0, red8[rr * NB + c + 1] = a1;
+#ifdef VO_CHOL_STAMPS
+        if (!fast && tid == 0) C.stamps[1 * 16 + 9] += 1;
+#endif
+        if (!fast) {  // (rare: a far link is late)
+          if (!wait_flag(C, C.pcount + j, links, s_state)) return false;
+          if (tid < NB) sfar = ld_sc1(Sacc + NB * j + tid);
+        }
         __syncthreads();
-        const double xj = tile_matvec_t(Pc, svec);  // X^T s: X is lower triangular, zeros above
+        if (tid < NB) svec[tid] = (yj - sfar) - sum8();
+        __syncthreads();
+        double b0 = 0, b1 = 0;
+        dot8(cur, svec, b0, b1);  // X^T s: X = L(j,j)^-1 is lower triangular, zeros above
+        red8[rr * NB + c] = b0, red8[rr * NB + c + 1] = b1;
+        __syncthreads();
         if (tid < NB) {
-          col[tid] = xj;
+          const double xj = sum8();
+          xs[(j & 3) * NB + tid] = xj;
           st_sc1(xsol + NB * j + tid, xj);
+          if (tid == 0) s_pc = pcn;
         }
         __syncthreads();
+        ci = cn, yj = yn;
         if (j == 0) CSTAMP(0, 10);
+        return true;
+      };
+      bool ok = true;
+      for (int j = m - 1; j >= 0 && ok; j -= 2) {
+        ok = step(j, ia, ib);
+        if (ok && j >= 1) ok = step(j - 1, ib, ia);
       }
+      if (!ok) return;
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       __syncthreads();
       if (tid == 0) st_flag(C.xready + 0, 1);
       continue;
     }
     {
-      // ---------------------------------------------------------------- S_j += L(i,j)^T x_i for i >= j + 2, one link
+      // ---------------------------------------------------------------- S_j += L(i,j)^T x_i for i >= j + 3, one link
       // of column j's chain per task: links run over the existing tiles i = m-1, m-2, ... (fixed order: deterministic sums)
       const int i = task.y, j = task.z;   // ticket order: i descending, then j descending (closest to the chain first)
-      if (!wait_flag(C, C.xready + i, 1, &s_state)) return;
-      load_tile(C, NB * i, NB * j, Pr, true);
+      load_tile(C, NB * i, NB * j, Pr, true);  // the tile first: it is staged while x_i is still on its way
+      if (!wait_flag(C, C.xready + i, 1, s_state)) return;
       if (tid < NB) col[tid] = ld_sc1(xsol + NB * i + tid);
       __syncthreads();
       const double pv = tile_matvec_t(Pr, col);
       const int link = task.w;  // existing far tiles of column j below this one
-      if (link > 0 && !wait_flag(C, C.pcount + j, link, &s_state)) return;
+      if (link > 0 && !wait_flag(C, C.pcount + j, link, s_state)) return;
       if (tid < NB) st_sc1(Sacc + NB * j + tid, (link > 0 ? ld_sc1(Sacc + NB * j + tid) : 0.0) + pv);
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       __syncthreads();
@@ -510,7 +775,7 @@ int chol_ws_ints(int m) { return 16 + (m + 1) * m + 3 * m; }
 
 // ---- plans -----------------------------------------------------------------------------------------------------
 struct vo::CholPlan {
-  int m = 0, n_tasks = 0, n_factor = 0, n_tiles = 0, depth = 0;
+  int m = 0, n_tasks = 0, n_factor = 0, n_front = 0, n_tiles = 0, depth = 0;
   vo::DevBuf dev;  // [tasks int4][rowmask u64 (m + 1)][colinfo int2 (m)]
   const int4 *tasks = nullptr;
   const unsigned long long *rowmask = nullptr;
@@ -565,27 +830,33 @@ vo::CholPlan *vo::chol_plan_create(int m, const unsigned long long *pattern) {
   std::stable_sort(seq.begin(), seq.end(), [&](int a, int b) { return level[a] < level[b]; });
   for (int p = 0; p < m; p++) {
     const int j = seq[p];
-    for (int i = j; i <= m; i++)
-      if (has(i, j)) tasks.push_back(make_int4(0, i, j, 0)), n_factor++;
+    for (int i = j; i <= m; i++) {
+      if (!has(i, j)) continue;
+      n_factor++;
+      if (i == j && j > 0 && has(j, j - 1)) continue;  // this diagonal tile belongs to the task of tile (j, j - 1)
+      tasks.push_back(make_int4(0, i, j, (i == j + 1 && i < m) ? 1 : 0));
+    }
     if (p >= 2) tasks.push_back(make_int4(1, 0, seq[p - 2], 0));
   }
   for (int p = std::max(0, m - 2); p < m; p++) tasks.push_back(make_int4(1, 0, seq[p], 0));
+  const int n_front = (int)tasks.size();
   tasks.push_back(make_int4(2, 0, 0, 0));
   std::vector<int2> colinfo((size_t)m);
   for (int j = 0; j < m; j++) {
-    int far = 0;
-    for (int i = j + 2; i < m; i++) far += has(i, j) ? 1 : 0;
-    colinfo[j] = make_int2(far, j + 1 < m && has(j + 1, j) ? 1 : 0);
+    int far = 0, near = 0;
+    for (int i = j + 3; i < m; i++) far += has(i, j) ? 1 : 0;
+    for (int q = 1; q <= 2; q++) near |= (j + q < m && has(j + q, j)) ? 1 << (q - 1) : 0;
+    colinfo[j] = make_int2(far, near);
   }
-  for (int i = m - 1; i >= 2; i--)      // far links: i descending, then j descending (closest to the chain first);
-    for (int j = i - 2; j >= 0; j--) {  // aux = the existing far tiles of column j below this one (its turn in the sum)
+  for (int i = m - 1; i >= 3; i--)      // far links: i descending, then j descending (closest to the chain first);
+    for (int j = i - 3; j >= 0; j--) {  // aux = the existing far tiles of column j below this one (its turn in the sum)
       if (!has(i, j)) continue;
       int below = 0;
       for (int r = i + 1; r < m; r++) below += has(r, j) ? 1 : 0;
       tasks.push_back(make_int4(3, i, j, below));
     }
   vo::CholPlan *P = new vo::CholPlan();
-  P->m = m, P->n_tasks = (int)tasks.size(), P->n_factor = n_factor, P->n_tiles = nt, P->depth = depth;
+  P->m = m, P->n_tasks = (int)tasks.size(), P->n_factor = n_factor, P->n_front = n_front, P->n_tiles = nt, P->depth = depth;
   const size_t o_mask = tasks.size() * sizeof(int4), o_col = o_mask + (size_t)(m + 1) * 8, total = o_col + (size_t)m * sizeof(int2);
   std::vector<uint8_t> img(total);
   memcpy(img.data(), tasks.data(), o_mask);
@@ -641,7 +912,7 @@ void vo::chol_factor_solve(double *A, int ld, void *workspace, hipStream_t st, c
   (void)hipMemsetAsync(wsI + 1, 0, ints - 4, st);
   CholCtx C;
   C.A = A, C.ld = ld, C.m = m;
-  C.fail = wsI, C.ticket = wsI + 1, C.done = wsI + 2, C.ready = wsI + 16, C.xready = C.ready + (m + 1) * m, C.pcount = C.xready + m, C.invready = C.pcount + m;
+  C.fail = wsI, C.ticket = wsI + 1, C.done = wsI + 2, C.ticket2 = wsI + 3, C.ready = wsI + 16, C.xready = C.ready + (m + 1) * m, C.pcount = C.xready + m, C.invready = C.pcount + m;
   C.partial = reinterpret_cast<double *>(reinterpret_cast<uint8_t *>(workspace) + ints);
   C.linv = C.partial + (size_t)m * m * NB + (size_t)m * NB;
   C.stamps = reinterpret_cast<unsigned long long *>(C.linv + (size_t)m * NB * NB);
@@ -657,10 +928,11 @@ void vo::chol_factor_solve(double *A, int ld, void *workspace, hipStream_t st, c
   static bool attr_set = false;
   if (!attr_set) {
     (void)hipFuncSetAttribute((const void *)k_chol_tiles, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    (void)hipFuncSetAttribute((const void *)k_chol_back, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     attr_set = true;
   }
   C.tasks = plan->tasks, C.rowmask = plan->rowmask, C.colinfo = plan->colinfo;
-  C.n_tasks = plan->n_tasks, C.n_factor = plan->n_factor;
-  const int grid = std::max(1, std::min(plan->n_tasks, 2 * n_cu));
-  hipLaunchKernelGGL(k_chol_tiles, dim3(grid), dim3(256), lds, st, C);
+  C.n_tasks = plan->n_tasks, C.n_factor = plan->n_factor, C.n_front = plan->n_front;
+  hipLaunchKernelGGL(k_chol_tiles, dim3(std::max(1, std::min(plan->n_front, 2 * n_cu))), dim3(256), lds, st, C);
+  hipLaunchKernelGGL(k_chol_back, dim3(std::max(1, std::min(plan->n_tasks - plan->n_front, 2 * n_cu))), dim3(256), lds, st, C);
 }

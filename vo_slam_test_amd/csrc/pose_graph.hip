@@ -278,6 +278,27 @@ int sum_device(const vo::DevBuf &b, int n, hipStream_t st, double &out, int stri
 
 extern "C" {
 
+// the 64 x 64 tiles that hold a non-zero: a matrix with empty tiles is factored on its sparse plan (the plans of the
+// large reduced camera systems go through the same code; this entry point is how the tests reach them).  NULL = dense.
+static vo::CholPlan *plan_of_matrix(const std::vector<double> &Ap, int ld) {
+  const int m = ld / NB;
+  std::vector<unsigned long long> pattern((size_t)m, 0ull);
+  bool dense = true;
+  for (int ti = 0; ti < m; ti++)
+    for (int tj = 0; tj <= ti; tj++) {
+      bool nz = false;
+      for (int r = NB * ti; r < NB * ti + NB && !nz; r++)
+        for (int c = NB * tj; c < NB * tj + NB; c++)
+          if (Ap[(size_t)r * ld + c] != 0.0) {
+            nz = true;
+            break;
+          }
+      if (nz) pattern[ti] |= 1ull << tj;
+      else dense = false;
+    }
+  return dense ? nullptr : vo::chol_plan_create(m, pattern.data());
+}
+
 int vo_chol_solve(int n, double *A_rowmajor_lower, double *b) {
   // dense SPD solve on the device through the same blocked kernels (test / utility entry point)
   if (n <= 0 || !A_rowmajor_lower || !b) return VO_ERR_INVALID;
@@ -302,24 +323,7 @@ int vo_chol_solve(int n, double *A_rowmajor_lower, double *b) {
   VO_CHECK(upload(dA, Ap.data(), Ap.size() * 8, st));
   VO_CHECK(dfail.reserve(vo::chol_workspace_bytes(ld)));
   VO_HIP_CHECK(hipMemsetAsync(dfail.p, 0, 4, st));
-  // the 64 x 64 tiles that hold a non-zero: a matrix with empty tiles is factored on its sparse plan (the plans of
-  // the large reduced camera systems go through the same code; this entry point is how the tests reach them)
-  const int m = ld / NB;
-  std::vector<unsigned long long> pattern((size_t)m, 0ull);
-  bool dense = true;
-  for (int ti = 0; ti < m; ti++)
-    for (int tj = 0; tj <= ti; tj++) {
-      bool nz = false;
-      for (int r = NB * ti; r < NB * ti + NB && !nz; r++)
-        for (int c = NB * tj; c < NB * tj + NB; c++)
-          if (Ap[(size_t)r * ld + c] != 0.0) {
-            nz = true;
-            break;
-          }
-      if (nz) pattern[ti] |= 1ull << tj;
-      else dense = false;
-    }
-  vo::CholPlan *plan = dense ? nullptr : vo::chol_plan_create(m, pattern.data());
+  vo::CholPlan *plan = plan_of_matrix(Ap, ld);
   vo::chol_factor_solve(dA.as<double>(), ld, dfail.p, st, plan);
   int failed = 0;
   const int crc = vo::copy_d2h(&failed, dfail.p, 4, st, "vo_chol_solve");
@@ -358,8 +362,10 @@ int vo_chol_debug_solve(int n, double *A_rowmajor_lower, double *b, unsigned lon
   const size_t wsb = vo::chol_workspace_bytes(ld);
   VO_CHECK(dws.reserve(wsb));
   VO_HIP_CHECK(hipMemset(dws.p, 0, wsb));
-  vo::chol_factor_solve(dA.as<double>(), ld, dws.p, nullptr);
+  vo::CholPlan *plan = plan_of_matrix(Ap, ld);
+  vo::chol_factor_solve(dA.as<double>(), ld, dws.p, nullptr, plan);
   VO_HIP_CHECK(hipDeviceSynchronize());
+  vo::chol_plan_destroy(plan);
   VO_HIP_CHECK(hipMemcpy(Ap.data(), dA.p, Ap.size() * 8, hipMemcpyDeviceToHost));
   for (int i = 0; i < n; i++) b[i] = Ap[(size_t)(ld + 1) * ld + i];
   const int m = ld / NB;
