@@ -4,17 +4,33 @@
 // What the reference asks of its solver: Ceres DENSE_SCHUR's Cholesky of the reduced camera matrix
 // (src/optimizer_ceres.cpp:248, :600, :695) and SPARSE_NORMAL_CHOLESKY of the pose graph (:1252-1258).
 //
-// ONE launch, persistent workgroups, tile dataflow.  The matrix is cut into 64 x 64 tiles; tile (i, j) -- and the
-// tile row that carries the right-hand side, which rides through the factorisation and comes out as L^-1 b -- is a
-// TASK: its owner keeps the tile in MFMA accumulators, subtracts L(i,k) L(j,k)^T for k < j as those tiles become
-// available (v_mfma_f64_16x16x4_f64 from LDS-staged operands), then finishes it (64 x 64 Cholesky on the diagonal,
-// X L(j,j)^T = T below it) and publishes it.  Tasks are handed out by a ticket counter in column-major order, so
+// TWO launches (factorisation, backward substitution), persistent workgroups, tile dataflow, driven by a PLAN
+// (vo::chol_plan_create): the 64 x 64 tiles of L that exist -- the structure of a reduced camera system is its
+// covisibility graph; under a nested-dissection order of the key-frames whole tile columns are independent of each
+// other and are factored concurrently -- and the task tables in ticket order.  A dense plan lists every tile.
+//
+// Factorisation (k_chol_tiles).  Tile (i, j) -- and the tile row that carries the right-hand side, which rides through
+// the factorisation and comes out as L^-1 b -- is a TASK: its owner keeps the tile in MFMA accumulators, subtracts
+// L(i,k) L(j,k)^T for the k < j in which both tiles exist as those become available (v_mfma_f64_16x16x4_f64 from
+// LDS-staged operands), then finishes it (64 x 64 Cholesky on the diagonal, X L(j,j)^T = T below it) and publishes
+// it.  Tasks are handed out by a ticket counter, columns in the order of their level in the dependency graph, so
 // everything a task waits for has an earlier ticket and is either finished or running: no deadlock, whatever the
-// number of resident workgroups.  The trailing matrix is never re-read and re-written panel after panel (the round-1
-// kernels did 47 x 4 dependent launches of 16-25 us each: 3.8 ms of launch latency for 9 GFLOP); here every tile is
-// read once and written once, and the only serial chain left is diag(j) -> L(j+1, j) -> diag(j+1).
-// The backward substitution L^T x = y runs in the same launch: one workgroup walks the diagonal from the bottom and
-// takes the three nearest tiles of every column itself, the other workgroups deliver the far partial products.
+// number of resident workgroups.  Every tile is read once and written once; the serial chain that remains is
+// diag(j) -> L(j+1, j) -> diag(j+1), and it is what the kernel is built around:
+//   * the owner of L(j+1, j) IS the owner of diag(j+1): that tile's last update comes from LDS, sixteen columns at a
+//     time as the triangular solve finishes them, not from memory (store + flag + load);
+//   * the diagonal tile is published panel by panel, the tile below solves against panel b while panel b + 1's pivots
+//     are being computed, and asks for the next panel early when it has fallen behind;
+//   * in the pivot loop nothing waits for LDS (readlane for the next two columns, LDS factors one pivot late), the
+//     reciprocal square root is the hardware estimate + one third-order step;
+//   * stores leave from the wavefronts that idle during the pivots.
+// Measured (BASELINE config 4, 47 tile columns, order chosen by ba.hip: 3 segments + separators, 26 dependent columns):
+// column period 22.9 -> 15.5 us, factorisation 1.08 -> 0.46 ms.
+//
+// Backward substitution L^T x = y (k_chol_back): chains of columns joined by their sub-diagonal tiles walk down with
+// the two nearest tiles of every column and the inverse of its diagonal tile (a type-1 task of the first launch) in
+// registers; the segments of a nested-dissection order are separate chains that run concurrently; all other tiles are
+// far links delivered by the other workgroups as running sums.  0.18 -> 0.07 ms.
 //
 // Hand-off between workgroups (MI355X: per-XCD L2s are not coherent with each other, a CU's L1 is never refreshed):
 // every handed-off double is stored and loaded with agent-scope relaxed atomics (sc1: write-through / L1 bypass),
@@ -32,6 +48,9 @@ namespace {
 using namespace vo;
 
 constexpr int NB = vo::kCholPanel;  // 64
+#ifndef VO_CHOL_SUBFLAG_PANEL
+#define VO_CHOL_SUBFLAG_PANEL 0
+#endif
 #ifndef VO_CHOL_POLL_DEPTH
 #define VO_CHOL_POLL_DEPTH 1
 #endif
@@ -80,7 +99,7 @@ struct CholCtx {
   const int4 *tasks;            // (type, i, j, aux): 0 tile (i, j) of the factorisation (i == m: right-hand-side row),
                                 // 1 inverse of diagonal tile j, 2 the backward chain, 3 far link (i, j), aux = its rank
   const unsigned long long *rowmask;  // [m + 1]: bit k of rowmask[i] = tile (i, k) of L exists (row m: the rhs row, all ones)
-  const int2 *colinfo;          // [m]: (far links of column j: tiles (i, j) with i >= j + 3; bits 0, 1: tiles (j + 1, j), (j + 2, j) exist)
+  const int2 *colinfo;          // [m]: (far links of column j; bits 0, 1: its chain takes the tiles (j + 1, j), (j + 2, j) itself)
   int n_tasks, n_factor;        // tasks in all, factorisation tasks (what `done` counts)
   int n_front;                  // tasks of the first launch (types 0 and 1); the rest is k_chol_back's
 };
@@ -455,7 +474,7 @@ __global__ __launch_bounds__(256) void k_chol_tiles(CholCtx C) {
               if (b == 1 && dslot >= 0) CSTAMP(dslot, 13);
             },
             [&](int b) {
-              if (b != 0 || !sub) return;
+              if (b != VO_CHOL_SUBFLAG_PANEL || !sub) return;
               asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // (this wavefront's share of the sub-diagonal tile's stores)
               if (lane == 0 && atomicAdd(&s_stored, 1) == 2) {
                 s_stored = 0;
@@ -647,7 +666,7 @@ __global__ __launch_bounds__(256, 2) void k_chol_back(CholCtx C) {
       // the 8 parts of a column meet in LDS (fixed order).  x_i is flagged for the far links one step after it was
       // computed (its write-through store has landed by then), and a far link has two more steps to deliver (a third near
       // tile in registers would push the kernel past 256 registers: one workgroup per CU).
-      CSTAMP(0, 8);
+      if (task.y == m - 1) CSTAMP(0, 8);
       const __amdgpu_buffer_rsrc_t rsi = linv_rsrc(C), rst = tile_rsrc(C);
       const int c = 2 * (tid & 31), rr = tid >> 5;
       double *xs = Pr[0];         // [4][NB] ring of the last solutions x_j (slot j & 3)
@@ -678,11 +697,12 @@ __global__ __launch_bounds__(256, 2) void k_chol_back(CholCtx C) {
         return t;
       };
       // state requested one step ahead: y_j, the far links' counter of column j, the tiles
-      int2 ci = C.colinfo[m - 1];
-      double yj = tid < NB ? ld_sc1(y + NB * (m - 1) + tid) : 0.0;
-      if (tid == 0) s_pc = 0;  // (the last column has no links)
+      const int j_hi = task.y, j_lo = task.z;  // this chain's columns
+      int2 ci = C.colinfo[j_hi];
+      double yj = tid < NB ? ld_sc1(y + NB * j_hi + tid) : 0.0;
+      if (tid == 0) s_pc = 0;  // (the first column's links, if any, are waited for)
       __syncthreads();
-      ld8(rsi, NB, NB * (m - 1), 0, ia);
+      ld8(rsi, NB, NB * j_hi, 0, ia);
       auto step = [&](int j, u32x4(&cur)[8], u32x4(&nxt)[8]) -> bool {
         if (j == 0) CSTAMP(0, 9);
 #ifdef VO_CHOL_STAMPS
@@ -692,7 +712,7 @@ __global__ __launch_bounds__(256, 2) void k_chol_back(CholCtx C) {
 #ifdef VO_CHOL_STAMPS
         if (tid == 0) C.stamps[1 * 16 + 8] += wall_clock64() - w0;  // time spent waiting for the requested tiles
 #endif
-        if (j + 1 < m && tid == 0) st_flag(C.xready + j + 1, 1);
+        if (j < j_hi && tid == 0) st_flag(C.xready + j + 1, 1);
         const int links = ci.x, near = ci.y;
         // the far links: normally complete a step ago (pc was read then); S_j is requested first, ahead of the bulk loads
         const bool fast = links == 0 || s_pc >= links;  // (s_pc: written by thread 0 before the barrier that closed the last step)
@@ -701,7 +721,7 @@ __global__ __launch_bounds__(256, 2) void k_chol_back(CholCtx C) {
         int2 cn = ci;
         int pcn = 0;
         double yn = 0;
-        if (j >= 1) {
+        if (j > j_lo) {
           cn = C.colinfo[j - 1];
           if (tid == 0 && cn.x > 0) pcn = ld_flag(C.pcount + j - 1);
           if (tid < NB) yn = ld_sc1(y + NB * (j - 1) + tid);
@@ -709,7 +729,7 @@ __global__ __launch_bounds__(256, 2) void k_chol_back(CholCtx C) {
         double a0 = 0, a1 = 0;
         if (near & 1) dot8(n1, xs + ((j + 1) & 3) * NB, a0, a1);
         if (near & 2) dot8(n2, xs + ((j + 2) & 3) * NB, a0, a1);
-        if (j >= 1) {
+        if (j > j_lo) {
           issue_near(j - 1, cn.y);
           ld8(rsi, NB, NB * (j - 1), 0, nxt);
         }
@@ -740,18 +760,18 @@ __global__ __launch_bounds__(256, 2) void k_chol_back(CholCtx C) {
         return true;
       };
       bool ok = true;
-      for (int j = m - 1; j >= 0 && ok; j -= 2) {
+      for (int j = j_hi; j >= j_lo && ok; j -= 2) {
         ok = step(j, ia, ib);
-        if (ok && j >= 1) ok = step(j - 1, ib, ia);
+        if (ok && j > j_lo) ok = step(j - 1, ib, ia);
       }
       if (!ok) return;
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       __syncthreads();
-      if (tid == 0) st_flag(C.xready + 0, 1);
+      if (tid == 0) st_flag(C.xready + j_lo, 1);
       continue;
     }
     {
-      // ---------------------------------------------------------------- S_j += L(i,j)^T x_i for i >= j + 3, one link
+      // ---------------------------------------------------------------- S_j += L(i,j)^T x_i for the tiles the chains do not take themselves, one link
       // of column j's chain per task: links run over the existing tiles i = m-1, m-2, ... (fixed order: deterministic sums)
       const int i = task.y, j = task.z;   // ticket order: i descending, then j descending (closest to the chain first)
       load_tile(C, NB * i, NB * j, Pr, true);  // the tile first: it is staged while x_i is still on its way
@@ -840,20 +860,36 @@ vo::CholPlan *vo::chol_plan_create(int m, const unsigned long long *pattern) {
   }
   for (int p = std::max(0, m - 2); p < m; p++) tasks.push_back(make_int4(1, 0, seq[p], 0));
   const int n_front = (int)tasks.size();
-  tasks.push_back(make_int4(2, 0, 0, 0));
+  // Backward substitution.  A chain = a run of columns j_hi .. j_lo joined by their sub-diagonal tiles; it walks them
+  // with the tiles (j + 1, j) and (j + 2, j) of its own columns in registers.  Where the sub-diagonal tile is missing
+  // (the first column of a nested-dissection segment) a new chain starts: the segments' chains run concurrently once
+  // the separators' unknowns are there.  Every other tile (i, j) is a far link: S_j += L(i,j)^T x_i by whichever
+  // workgroup takes it, in the order i descending (a running sum: deterministic).
+  std::vector<int> chain_top((size_t)m);
+  for (int j = m - 1; j >= 0; j--) chain_top[j] = (j == m - 1 || !has(j + 1, j)) ? j : chain_top[j + 1];
+  for (int j = m - 1; j >= 0; j--)
+    if (chain_top[j] == j) {
+      int lo = j;
+      while (lo > 0 && chain_top[lo - 1] == j) lo--;
+      tasks.push_back(make_int4(2, j, lo, 0));
+    }
   std::vector<int2> colinfo((size_t)m);
+  auto is_near = [&](int i, int j) { return i - j <= 2 && i <= chain_top[j]; };
   for (int j = 0; j < m; j++) {
     int far = 0, near = 0;
-    for (int i = j + 3; i < m; i++) far += has(i, j) ? 1 : 0;
-    for (int q = 1; q <= 2; q++) near |= (j + q < m && has(j + q, j)) ? 1 << (q - 1) : 0;
+    for (int i = j + 1; i < m; i++) {
+      if (!has(i, j)) continue;
+      if (is_near(i, j)) near |= 1 << (i - j - 1);
+      else far++;
+    }
     colinfo[j] = make_int2(far, near);
   }
-  for (int i = m - 1; i >= 3; i--)      // far links: i descending, then j descending (closest to the chain first);
-    for (int j = i - 3; j >= 0; j--) {  // aux = the existing far tiles of column j below this one (its turn in the sum)
-      if (!has(i, j)) continue;
-      int below = 0;
-      for (int r = i + 1; r < m; r++) below += has(r, j) ? 1 : 0;
-      tasks.push_back(make_int4(3, i, j, below));
+  for (int i = m - 1; i >= 1; i--)      // far links: i descending, then j descending (closest to the chain first);
+    for (int j = i - 1; j >= 0; j--) {  // aux = the far links of column j with a larger i (its turn in the sum)
+      if (!has(i, j) || is_near(i, j)) continue;
+      int before = 0;
+      for (int r = i + 1; r < m; r++) before += (has(r, j) && !is_near(r, j)) ? 1 : 0;
+      tasks.push_back(make_int4(3, i, j, before));
     }
   vo::CholPlan *P = new vo::CholPlan();
   P->m = m, P->n_tasks = (int)tasks.size(), P->n_factor = n_factor, P->n_front = n_front, P->n_tiles = nt, P->depth = depth;
