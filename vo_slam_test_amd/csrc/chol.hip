@@ -41,6 +41,7 @@
 
 #include <algorithm>
 #include <mutex>
+#include <numeric>
 #include <vector>
 
 namespace {
@@ -931,6 +932,97 @@ const vo::CholPlan *dense_plan(int m) {
 
 
 }  // namespace
+
+// ---- block order of a large sparse system -------------------------------------------------------------------------
+// A reduced camera matrix has a 6 x 6 block (c, c') wherever key-frames c and c' share a point; a pose graph's normal
+// matrix one wherever an edge joins them.  Key-frames arrive in time order, so along a trajectory such a matrix is a
+// band (a cyclic band once a loop is closed), and the tile Cholesky of a band is one chain of dependent tile columns
+// however few tiles it has.  Cutting the band into P segments by separators as wide as the band -- segments first,
+// separators last -- makes the segments' columns independent of each other: the chain shrinks to one segment plus the
+// separators.  Candidates (P = 2..8, linear and cyclic cuts) are scored by the symbolic factorisation of their exact
+// tile pattern, so a pattern that is not a band simply keeps the natural order; whichever order is used, the plan lists
+// every tile the factor can touch (correctness never rests on the heuristic).  Segment lengths are multiples of 32
+// blocks (3 tiles at 6 rows per block) so that segments do not share tiles.
+static void tile_pattern(const std::vector<std::pair<int, int>> &pairs, const std::vector<int> &slot_of, int bs, int m,
+                         std::vector<unsigned long long> &pat) {
+  pat.assign((size_t)m, 0ull);
+  for (const auto &pr : pairs) {
+    const int a = slot_of[pr.first], b = slot_of[pr.second];
+    const int hi = std::max(a, b), lo = std::min(a, b);
+    for (int ti = bs * hi / vo::kCholPanel; ti <= (bs * hi + bs - 1) / vo::kCholPanel; ti++)
+      for (int tj = bs * lo / vo::kCholPanel; tj <= (bs * lo + bs - 1) / vo::kCholPanel; tj++)
+        pat[std::max(ti, tj)] |= 1ull << std::min(ti, tj);
+  }
+  for (int i = 0; i < m; i++) pat[i] |= 1ull << i;
+}
+
+vo::CholOrder vo::chol_choose_order(int nf, int bs, const std::vector<std::pair<int, int>> &pairs, int m, int force_parts) {
+  int w_lin = 0, w_cyc = 0;
+  for (const auto &pr : pairs) {
+    const int d = pr.first - pr.second;
+    w_lin = std::max(w_lin, d), w_cyc = std::max(w_cyc, std::min(d, nf - d));
+  }
+  std::vector<unsigned long long> lmask((size_t)m);
+  auto score = [&](vo::CholOrder &o) {
+    tile_pattern(pairs, o.slot_of, bs, m, o.pattern);
+    vo::chol_symbolic(m, o.pattern.data(), lmask.data(), &o.depth, &o.tiles);
+  };
+  vo::CholOrder best;
+  best.slot_of.resize((size_t)nf);
+  std::iota(best.slot_of.begin(), best.slot_of.end(), 0);
+  score(best);
+  if (force_parts == 1) return best;
+  const int natural_depth = best.depth;
+  bool have = false;
+  vo::CholOrder pick = best;
+  // Separators are eliminated in nested order -- every second one first (those are independent of each other: the
+  // segments between them are gone), then every second one of the rest, ... -- and tried at their exact width and
+  // rounded up to whole 32 key-frame units (separators that are eliminated concurrently must not share a tile either).
+  for (int cyclic = 0; cyclic < 2; cyclic++) {
+    const int w = cyclic ? w_cyc : w_lin;
+    if (w < 1) continue;
+    for (int P = 2; P <= 8; P++)
+      for (int wide = 0; wide < 2; wide++)
+        for (int up = 0; up < 2; up++) {
+          if (force_parts > 1 && P != force_parts) continue;
+          const int n_sep = cyclic ? P : P - 1;
+          std::vector<int> rank((size_t)n_sep), sep_len((size_t)n_sep), sep_order((size_t)n_sep);
+          int sep_total = 0;
+          for (int g = 0; g < n_sep; g++) {
+            rank[g] = __builtin_ctz((unsigned)(g + 1));
+            // the last separator of a group that runs concurrently may end anywhere: what follows depends on it
+            sep_len[g] = wide && rank[g] == 0 ? (w + 31) / 32 * 32 : w;
+            sep_total += sep_len[g];
+            sep_order[g] = g;
+          }
+          std::stable_sort(sep_order.begin(), sep_order.end(), [&](int a, int b) { return rank[a] < rank[b]; });
+          const int in_segs = nf - sep_total;
+          if (in_segs < 32 * P) continue;
+          const int base = (in_segs / P / 32 + up) * 32;  // the first P - 1 segments; the last one takes the rest
+          if (base < 32 || in_segs - base * (P - 1) < 1) continue;
+          std::vector<int> sep_start((size_t)n_sep);
+          int at = in_segs;
+          for (int q = 0; q < n_sep; q++) sep_start[sep_order[q]] = at, at += sep_len[sep_order[q]];
+          vo::CholOrder o;
+          o.parts = P, o.cyclic = cyclic, o.sep = w;
+          o.slot_of.assign((size_t)nf, -1);
+          int next_seg = 0, pos = 0;
+          for (int g = 0; g < P; g++) {
+            const int len = g < P - 1 ? base : in_segs - base * (P - 1);
+            for (int q = 0; q < len; q++) o.slot_of[pos++] = next_seg++;
+            if (g < n_sep)
+              for (int q = 0; q < sep_len[g]; q++) o.slot_of[pos++] = sep_start[g] + q;
+          }
+          if (pos != nf) continue;
+          score(o);
+          if (!have || o.depth < pick.depth || (o.depth == pick.depth && o.tiles < pick.tiles)) pick = o, have = true;
+        }
+  }
+  // a shorter chain pays for the extra fill only when it is clearly shorter
+  if (have && (force_parts > 1 || pick.depth * 4 <= natural_depth * 3)) return pick;
+  return best;
+}
+
 
 size_t vo::chol_workspace_bytes(int ld) {
   const int m = ld / NB;

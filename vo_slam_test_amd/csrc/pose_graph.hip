@@ -415,6 +415,25 @@ int vo_pose_graph_solve(int n_nodes, double *quats, double *trans, const double 
     vo::set_error("pose graph with %d free key-frames exceeds the dense solver (6N <= 4096)", nfree);
     return VO_ERR_CAPACITY;
   }
+  // The normal matrix has a block per edge: along a trajectory a narrow band (spanning tree + covisibility neighbours)
+  // plus the loop edges.  Systems of more than a few tiles are factored on the sparse plan of their structure, in the
+  // block order vo::chol_choose_order picks (segments of the band factored concurrently).
+  vo::CholPlan *plan = nullptr;
+  struct PlanGuard {
+    vo::CholPlan *&p;
+    ~PlanGuard() { vo::chol_plan_destroy(p); }
+  } plan_guard{plan};
+  if (ld / NB >= 4) {
+    std::vector<std::pair<int, int>> pairs;
+    for (int e = 0; e < n_edges; e++) {
+      const int sa = slot[edge_i[e]], sb = slot[edge_j[e]];
+      if (sa >= 0 && sb >= 0 && sa != sb) pairs.push_back({std::max(sa, sb), std::min(sa, sb)});
+    }
+    const vo::CholOrder o = vo::chol_choose_order(nfree, 6, pairs, ld / NB);
+    for (int a = 0; a < n_nodes; a++)
+      if (slot[a] >= 0) slot[a] = o.slot_of[slot[a]];
+    plan = vo::chol_plan_create(ld / NB, o.pattern.data());
+  }
   std::vector<double> x(7 * (size_t)n_nodes);
   for (int a = 0; a < n_nodes; a++) {
     memcpy(&x[7 * a], quats + 4 * a, 32);
@@ -494,7 +513,7 @@ int vo_pose_graph_solve(int n_nodes, double *quats, double *trans, const double 
     hipLaunchKernelGGL(k_pg_damp, dim3((unsigned)(((long long)ld * ld + 255) / 256)), dim3(256), 0, st, P,
                        d_A.as<double>(), d_rhs.as<double>(), radius);
     VO_HIP_CHECK(hipMemsetAsync(d_A.as<double>() + (size_t)(ld + 1) * ld, 0, (size_t)(NB - 1) * ld * 8, st));  // rows below the rhs
-    vo::chol_factor_solve(d_A.as<double>(), ld, d_fail.p, st);
+    vo::chol_factor_solve(d_A.as<double>(), ld, d_fail.p, st, plan);
     const double *ysol = d_A.as<double>() + (size_t)(ld + 1) * ld;
     hipLaunchKernelGGL(k_pg_model, dim3(n), dim3(256), 0, st, P, ysol, d_part.as<double>());
     hipLaunchKernelGGL(k_pg_candidate, dim3((n_nodes + 127) / 128), dim3(128), 0, st, P, dx, ysol, dxc,

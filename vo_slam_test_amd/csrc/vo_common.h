@@ -1,6 +1,8 @@
 // vo_common.h -- shared host/device helpers for the gfx950 library (not part of the C-ABI).
 #pragma once
 #include <hip/hip_runtime.h>
+#include <utility>
+#include <vector>
 
 #include <cstdarg>
 #include <cstdio>
@@ -113,5 +115,14 @@ void chol_plan_destroy(CholPlan *p);
 void chol_plan_info(const CholPlan *p, int *n_tiles, int *depth);
 void chol_symbolic(int m, const unsigned long long *pattern, unsigned long long *lmask, int *depth, int *n_tiles);
 void chol_factor_solve(double *A, int ld, void *workspace, hipStream_t st, const CholPlan *plan = nullptr);
+// Order of the nf diagonal blocks (bs rows each; pairs = the off-diagonal blocks (hi, lo) that are non-zero) of a system
+// with m tile rows: natural, or a nested dissection of a (cyclic) band when that shortens the chain of dependent tile
+// columns by a quarter or more (chol.hip).  force_parts: -1 = choose, 1 = natural, P > 1 = P segments.
+struct CholOrder {
+  std::vector<int> slot_of;  // natural block index -> position
+  int parts = 1, cyclic = 0, sep = 0, depth = 0, tiles = 0;
+  std::vector<unsigned long long> pattern;  // tile pattern in the chosen order (chol_plan_create's input)
+};
+CholOrder chol_choose_order(int nf, int bs, const std::vector<std::pair<int, int>> &pairs, int m, int force_parts = -1);
 
 }  // namespace vo
