@@ -136,6 +136,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-ba", action="store_true")
     ap.add_argument("--no-bruteforce", action="store_true", help="skip the extract + all-pairs Hamming measurement (configs[1] as written)")
+    ap.add_argument("--no-single-stream", action="store_true", help="skip the one-frame-at-a-time and ingest-inclusive legs (profiling "
+                    "runs: their batch-1 launches would be averaged into the per-kernel figures of the 1024-frame step)")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo lets two ranks "
                     "share one GPU to exercise the N > 1 code path on a single-GPU box)")
@@ -359,7 +361,7 @@ def main():
     # ---- one camera stream, host buffers: Frame construction to pose in ONE call (vo_tracker_track, batch 1: image and raw
     # depth uploaded, pose downloaded) -- the drop-in latency of visualOdometry.cpp:228-251 + 745-775 -- and the same call for
     # a whole batch of host images (PCIe ingest included; never `value`).
-    if rank == 0:
+    if rank == 0 and not args.no_single_stream:
         t1 = vo.Tracker(1, cam5, synth.DIST, W, H, max_last=1100, max_local=2200, inv_depth_scale=inv_depth, single_stream=True)
         load_maps(t1, [maps[0]], 1100, 2200)
         h_img, h_dep = np.ascontiguousarray(uniq[:1]), np.ascontiguousarray(uniq_depth[:1]).view(np.uint16)
