@@ -655,9 +655,10 @@ int vo_ba_set_state(vo_ba *h, const double *poses, const double *points);
 int vo_ba_get_state(vo_ba *h, double *poses, double *points);
 int vo_ba_n_free_cams(const vo_ba *h);
 /* The key-frame order a large reduced system (6 nf + 1 > 128) is factored in, chosen when the handle is first used:
- * out = {parts, cyclic, separator key-frames, dependent tile columns on the longest chain, tiles of L, tile rows};
- * parts == 1: the natural order.  (Tests and tools; all zero tile rows for LDS-sized systems.) */
-int vo_ba_debug_order(vo_ba *h, int out[6]);
+ * out = {parts, cyclic, separator key-frames, dependent tile columns on the longest chain, tiles of L, tile rows,
+ * tile products L(i,k) L(j,k)^T of the factorisation (2 x 64^3 flop each), 0}; parts == 1: the natural order.
+ * (Tests and tools; all zero tile rows for LDS-sized systems.) */
+int vo_ba_debug_order(vo_ba *h, int out[8]);
 
 /* Full Optimizer::solveLocalBAPoseAndPoint numerics (:530-755): Huber LM (5 iterations), float
  * chi2 classification, plain LM (10 iterations) on the inliers, final chi2 pass.

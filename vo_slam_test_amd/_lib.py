@@ -957,9 +957,9 @@ class BundleAdjuster:
 
     def debug_order(self):
         """-> dict(parts, cyclic, sep, depth, tiles, tile_rows): the key-frame order of a large reduced system"""
-        out = (C.c_int * 6)()
+        out = (C.c_int * 8)()
         check(lib().vo_ba_debug_order(self._h, out), "vo_ba_debug_order")
-        return dict(zip(("parts", "cyclic", "sep", "depth", "tiles", "tile_rows"), list(out)))
+        return dict(zip(("parts", "cyclic", "sep", "depth", "tiles", "tile_rows", "tile_products"), list(out)[:7]))
 
     def debug_schur(self, huber=(0.0, 0.0), edge_active=None):
         n = 6 * self.n_free_cams()

@@ -3325,11 +3325,13 @@ int vo_ba_set_shard(vo_ba *h, int shard, int n_shards) {
 
 int vo_ba_n_free_cams(const vo_ba *h) { return h ? h->nf : 0; }
 
-int vo_ba_debug_order(vo_ba *h, int out[6]) {
+int vo_ba_debug_order(vo_ba *h, int out[8]) {
   if (!h || !out) return VO_ERR_INVALID;
   VO_CHECK(build_device(h));
   out[0] = h->order_parts, out[1] = h->order_cyclic, out[2] = h->order_sep, out[3] = h->order_depth, out[4] = h->order_tiles;
   out[5] = h->D.large ? h->D.ld / vo::kCholPanel : 0;
+  out[6] = out[7] = 0;
+  vo::chol_plan_info(h->chol_plan, nullptr, nullptr, &out[6]);
   return VO_OK;
 }
 

@@ -796,7 +796,7 @@ int chol_ws_ints(int m) { return 16 + (m + 1) * m + 3 * m; }
 
 // ---- plans -----------------------------------------------------------------------------------------------------
 struct vo::CholPlan {
-  int m = 0, n_tasks = 0, n_factor = 0, n_front = 0, n_tiles = 0, depth = 0;
+  int m = 0, n_tasks = 0, n_factor = 0, n_front = 0, n_tiles = 0, depth = 0, n_updates = 0;
   vo::DevBuf dev;  // [tasks int4][rowmask u64 (m + 1)][colinfo int2 (m)]
   const int4 *tasks = nullptr;
   const unsigned long long *rowmask = nullptr;
@@ -892,7 +892,12 @@ vo::CholPlan *vo::chol_plan_create(int m, const unsigned long long *pattern) {
       for (int r = i + 1; r < m; r++) before += (has(r, j) && !is_near(r, j)) ? 1 : 0;
       tasks.push_back(make_int4(3, i, j, before));
     }
+  int n_updates = 0;  // tile products L(i,k) L(j,k)^T of the factorisation (2 x 64^3 flop each)
+  for (int i = 0; i < m; i++)
+    for (int j = 0; j <= i; j++)
+      if (has(i, j)) n_updates += __builtin_popcountll(lm[i] & lm[j] & ((1ull << j) - 1ull));
   vo::CholPlan *P = new vo::CholPlan();
+  P->n_updates = n_updates;
   P->m = m, P->n_tasks = (int)tasks.size(), P->n_factor = n_factor, P->n_front = n_front, P->n_tiles = nt, P->depth = depth;
   const size_t o_mask = tasks.size() * sizeof(int4), o_col = o_mask + (size_t)(m + 1) * 8, total = o_col + (size_t)m * sizeof(int2);
   std::vector<uint8_t> img(total);
@@ -915,9 +920,10 @@ void vo::chol_plan_destroy(vo::CholPlan *p) {
   p->dev.release();
   delete p;
 }
-void vo::chol_plan_info(const vo::CholPlan *p, int *n_tiles, int *depth) {
+void vo::chol_plan_info(const vo::CholPlan *p, int *n_tiles, int *depth, int *n_updates) {
   if (n_tiles) *n_tiles = p ? p->n_tiles : 0;
   if (depth) *depth = p ? p->depth : 0;
+  if (n_updates) *n_updates = p ? p->n_updates : 0;
 }
 
 namespace {

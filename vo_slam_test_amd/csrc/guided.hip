@@ -9,18 +9,26 @@
 // A `vo_frames` object keeps the features of a batch of frames in HBM (undistorted key-points, uRight,
 // depth, descriptors and the 64 x 48 grid as CSR), so key-points never leave the device between
 // vo_orb_extract_batch_dev and the matcher.  Matching is two kernels:
-//   k_guided_cand    one WAVEFRONT per query: the grid columns of the search window are contiguous item
-//                    ranges of the CSR (cell = ix * 48 + iy), so a lane per column fetches (start, end), a wave
-//                    prefix sum lays the window's items out in reference order, every lane gates one item
-//                    (level range, |dx| < r, |dy| < r, stereo / chi2 gates) and computes its 256-bit Hamming
-//                    distance (v_xor + v_bcnt), survivors are compacted in order by ballot/mbcnt into the
-//                    frame's candidate pool.  Searches without a claim step (fuse, area-best) finish here with
-//                    a wave-wide arg-min.
-//   k_guided_replay  one wavefront per frame walks the queries in the reference's order and replays the
-//                    order-dependent part -- "features claimed earlier in the call are skipped" (:87, :218,
-//                    :314, :422) -- over the compact records: lanes = candidates, blocked[] in LDS, best and
-//                    second by two DPP wave minima of (distance, position), then the rotation histogram and
-//                    its three-maxima pruning (:128-145, computeThreeMax :1258-1304).
+//   k_guided_cand<G> G lanes per query (8 for the narrow tracking windows, 16 for wide ones), 256 / G queries per
+//                    workgroup.  The store keeps a second, CELL-ORDERED copy of what a window search reads (16-byte
+//                    records x, y, uright, octave | index << 8, and the descriptors in the same order), so the grid
+//                    columns of a window are contiguous record runs, walked G records at a time: a record that
+//                    passes the radius / octave / stereo gates costs one 32-byte descriptor load and 8 v_xor + v_bcnt,
+//                    and lands -- by ballot / mbcnt within the group -- in the query's fixed 32-record slot as
+//                    index | distance << 14 | octave << 23 | rotation bin << 27.  Queries with more candidates
+//                    continue in a per-frame overflow pool claimed by one atomic per query; an exhausted pool raises
+//                    the handle's sticky error flag (VO_ERR_CAPACITY at the next status call), never truncation.
+//                    Searches without a claim step (fuse, area-best) finish here with a group-wide arg-min.
+//   k_guided_replay  one wavefront per frame replays the order-dependent part of the reference's loop -- "features
+//                    claimed earlier in the call are skipped" (:87, :218, :314, :422), a later non-blocked claim
+//                    overwrites the assignment (:110-128) -- 64 QUERIES PER STEP, lane = query, its 32 records in
+//                    registers: every lane proposes its claim (best and, for the ratio test, runner-up among its
+//                    unblocked records) from the blocked[] state the previous steps left in LDS; blocking proposals
+//                    are published by ds_min (earliest lane per feature); a lane is stale if an earlier lane of the
+//                    step blocks a feature of its list; the lanes in front of the first stale one commit, the rest
+//                    re-propose.  Frames with an overflowing window and the Sim3 search (whose :422 quirk indexes
+//                    blocked[] by candidate rank) take the four-queries-per-step serial form.  Tail: rotation
+//                    histogram and its three-maxima pruning (:128-145, computeThreeMax :1258-1304).
 // Match pairs are bit-identical to the sequential reference loop for any input.
 //
 // Compiled with -ffp-contract=off: the float gates must round like the x86-64 reference build.

@@ -112,7 +112,7 @@ size_t chol_workspace_bytes(int ld);
 struct CholPlan;
 CholPlan *chol_plan_create(int m, const unsigned long long *pattern);
 void chol_plan_destroy(CholPlan *p);
-void chol_plan_info(const CholPlan *p, int *n_tiles, int *depth);
+void chol_plan_info(const CholPlan *p, int *n_tiles, int *depth, int *n_updates = nullptr);
 void chol_symbolic(int m, const unsigned long long *pattern, unsigned long long *lmask, int *depth, int *n_tiles);
 void chol_factor_solve(double *A, int ld, void *workspace, hipStream_t st, const CholPlan *plan = nullptr);
 // Order of the nf diagonal blocks (bs rows each; pairs = the off-diagonal blocks (hi, lo) that are non-zero) of a system

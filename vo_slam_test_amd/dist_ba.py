@@ -1,4 +1,9 @@
-"""Multi-GPU local BA: points (with all their edges) are sharded across ranks, cameras are
+"""TEST-ONLY helpers (tests/test_dist_gloo.py, tests/test_gpu_ba.py): the sharding rule and a Python driver of the
+split-phase entry points, kept as an executable statement of the protocol.  The product path is the sharded LM loop
+INSIDE the C-ABI (vo_ba_set_shard + vo_ba_set_allreduce, then vo_ba_solve / vo_ba_local_ba: tests/dist_worker.py,
+examples/rccl_sharded_ba.cpp, bench.py); nothing in the library, the shims or bench.py imports this module.
+
+Multi-GPU local BA: points (with all their edges) are sharded across ranks, cameras are
 replicated, and each LM iteration exchanges exactly two sum all-reduces over torch.distributed
 (backend "nccl" = RCCL over xGMI on the GPU box, "gloo" in the CPU tests):
 
