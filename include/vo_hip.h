@@ -339,8 +339,9 @@ void vo_vocab_destroy(vo_vocab *v);
 int vo_bow_transform(const vo_vocab *v, int n, const uint8_t *desc, int levelsup, int32_t *word_id, double *weight,
                      int32_t *node_id);
 
-/* The vocabulary file itself (DBoW3::Vocabulary(path), vo_run.cpp:87): DBoW3 0.0.1 binary layout
- * (Vocabulary::toStream, uncompressed) or the ORB-SLAM2 text format; builds the device tree. */
+/* The vocabulary file itself (DBoW3::Vocabulary(path), vo_run.cpp:87): DBoW3's binary stream
+ * (Vocabulary::toStream, uncompressed), its cv::FileStorage form (.yml / .yml.gz: Vocabulary::save(cv::FileStorage&),
+ * what DBoW3::Vocabulary(path) falls back to) or the ORB-SLAM2 text format; builds the device tree. */
 int vo_vocab_load(const char *path, vo_vocab **out, int *n_nodes, int *n_words, int *branching_k, int *depth_L);
 /* Map::score (map.cpp:335-376): L1 similarity of the query BoW vector (ascending word ids) with every
  * candidate's (CSR: candidate c owns cand_words / cand_values [cand_start[c], cand_start[c+1])); one

@@ -192,6 +192,37 @@ def _write_dbow3_binary(path, k, L, parent, weight, word_id, desc, children=None
         f.write(body)
 
 
+def _write_dbow3_yaml(path, k, L, parent, weight, word_id, desc, gz=False, drop_descriptor_of=None):
+    """DBoW3 Vocabulary::save(cv::FileStorage&) as cv::FileStorage lays it out in YAML 1.0 (restated; neither library is
+    here): flow mappings in block sequences, long ones wrapped over lines; nodes in the writer's order (stack of parents)"""
+    import gzip
+    n = len(parent)
+    children = [[] for _ in range(n)]
+    for i in range(1, n):
+        children[int(parent[i])].append(i)
+    out = ["%YAML:1.0", "---", "vocabulary:", "   k: %d" % k, "   L: %d" % L, "   scoringType: 0", "   weightingType: 0", "   nodes:"]
+    stack = [0]
+    while stack:
+        pid = stack.pop()
+        for c in children[pid]:
+            d = "dbw3 0 32 " + " ".join(str(int(b)) for b in desc[c]) + " "
+            rec = "      - { nodeId:%d, parentId:%d, weight:%.17g,\n          " % (c, pid, float(weight[c]))
+            if c != drop_descriptor_of:
+                rec += 'descriptor:"%s" }' % d
+            else:
+                rec += "}"
+            out.append(rec)
+            if children[c]:
+                stack.append(c)
+    out.append("   words:")
+    for i in range(n):
+        if word_id[i] >= 0:
+            out.append("      - { wordId:%d, nodeId:%d }" % (int(word_id[i]), i))
+    data = ("\n".join(out) + "\n").encode()
+    with (gzip.open(path, "wb") if gz else open(path, "wb")) as f:
+        f.write(data)
+
+
 def _write_orbslam_text(path, k, L, parent, weight, word_id, desc):
     with open(path, "w") as f:
         f.write(f"{k} {L} 0 0\n")
@@ -199,7 +230,7 @@ def _write_orbslam_text(path, k, L, parent, weight, word_id, desc):
             f.write(f"{int(parent[i])} {1 if word_id[i] >= 0 else 0} " + " ".join(str(int(b)) for b in desc[i]) + f" {weight[i]:.17g}\n")
 
 
-@pytest.mark.parametrize("fmt", ["binary", "text"])
+@pytest.mark.parametrize("fmt", ["binary", "text", "yaml", "yaml.gz"])
 def test_vocabulary_file_loader(vo, orc, fmt, tmp_path):
     V = synth.make_vocabulary(1, k=6, L=3)
     cs, ch = V["child_start"], V["children"]
@@ -207,8 +238,11 @@ def test_vocabulary_file_loader(vo, orc, fmt, tmp_path):
     parent = np.zeros(n, np.int64)
     for i in range(n):
         parent[ch[cs[i]:cs[i + 1]]] = i
-    path = tmp_path / ("voc.dbow3" if fmt == "binary" else "voc.txt")
-    (_write_dbow3_binary if fmt == "binary" else _write_orbslam_text)(path, 6, 3, parent, V["node_weight"], V["word_id"], V["node_desc"])
+    path = tmp_path / {"binary": "voc.dbow3", "text": "voc.txt", "yaml": "voc.yml", "yaml.gz": "voc.yml.gz"}[fmt]
+    if fmt.startswith("yaml"):
+        _write_dbow3_yaml(path, 6, 3, parent, V["node_weight"], V["word_id"], V["node_desc"], gz=fmt.endswith("gz"))
+    else:
+        (_write_dbow3_binary if fmt == "binary" else _write_orbslam_text)(path, 6, 3, parent, V["node_weight"], V["word_id"], V["node_desc"])
     voc, info = vo.load_vocabulary(path)
     assert info["n_nodes"] == n and info["k"] == 6 and info["L"] == 3 and info["n_words"] == int((V["word_id"] >= 0).sum())
     feats = synth.random_descriptors(500, 9)
@@ -216,7 +250,7 @@ def test_vocabulary_file_loader(vo, orc, fmt, tmp_path):
     w0, wt0, nd0 = ref.transform(feats)
     w1, wt1, nd1 = voc.transform(feats)
     assert np.array_equal(nd0, nd1) and np.array_equal(wt0, wt1)
-    if fmt == "binary":
+    if fmt != "text":
         assert np.array_equal(w0, w1)
     else:  # the text format numbers the words in file order: same leaves, possibly another numbering
         assert len(np.unique(w1)) == len(np.unique(w0))
@@ -224,6 +258,10 @@ def test_vocabulary_file_loader(vo, orc, fmt, tmp_path):
     (tmp_path / "junk.bin").write_bytes(b"\x00" * 64)
     with pytest.raises(vo.VoError):
         vo.load_vocabulary(tmp_path / "junk.bin")
+    if fmt == "yaml":    # a node record without its descriptor is refused
+        _write_dbow3_yaml(tmp_path / "bad.yml", 6, 3, parent, V["node_weight"], V["word_id"], V["node_desc"], drop_descriptor_of=5)
+        with pytest.raises(vo.VoError):
+            vo.load_vocabulary(tmp_path / "bad.yml")
     if fmt == "binary":  # malformed streams are refused, not trusted: compressed, truncated, a parent id out of range
         args = (6, 3, parent, V["node_weight"], V["word_id"], V["node_desc"])
         for name, kw in (("z", dict(compressed=True)), ("t", dict(truncate=1000)), ("p", dict(bad_parent=True))):

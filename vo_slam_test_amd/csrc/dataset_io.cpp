@@ -152,6 +152,155 @@ struct VocNode {
   std::vector<uint32_t> children;
 };
 
+
+// ---- DBoW3 vocabulary as written through cv::FileStorage (Vocabulary::save(cv::FileStorage&), what DBoW3::Vocabulary(path)
+// falls back to for .yml / .yml.gz files; the library is not vendored under the reference: layout restated from its
+// published source).  "%YAML:1.0", a mapping `vocabulary:` with k, L, scoringType, weightingType, a sequence `nodes:` of
+// flow mappings { nodeId, parentId, weight, descriptor:"dbw3 <type> <cols> b0 b1 ..." } (DBoW2 files: 32 plain numbers)
+// in the writer's order -- children are attached to their parent in FILE order, as Vocabulary::load does -- and a
+// sequence `words:` of { wordId, nodeId }.  The reader below is a tolerant scanner of exactly that subset (flow mappings
+// may wrap over lines), not a YAML parser; gzip is handled by zlib (gzread also passes plain files through).
+bool read_all_gz(const char *path, std::string &text) {
+  gzFile g = gzopen(path, "rb");
+  if (!g) return false;
+  char buf[1 << 16];
+  int n;
+  while ((n = gzread(g, buf, sizeof(buf))) > 0) text.append(buf, (size_t)n);
+  gzclose(g);
+  return n == 0;
+}
+
+struct YamlMap {
+  std::vector<std::pair<std::string, std::string>> kv;
+  const std::string *get(const char *k) const {
+    for (const auto &e : kv)
+      if (e.first == k) return &e.second;
+    return nullptr;
+  }
+};
+
+// the flow mappings "{ key:value, key:"string", ... }" between two offsets of the text
+bool yaml_flow_maps(const std::string &t, size_t from, size_t to, std::vector<YamlMap> &out) {
+  size_t i = from;
+  while (true) {
+    i = t.find('{', i);
+    if (i == std::string::npos || i >= to) return true;
+    YamlMap m;
+    i++;
+    while (i < to) {
+      while (i < to && (isspace((unsigned char)t[i]) || t[i] == ',')) i++;
+      if (i < to && t[i] == '}') break;
+      size_t ks = i;
+      while (i < to && t[i] != ':' && t[i] != '}') i++;
+      if (i >= to || t[i] != ':') return false;
+      std::string key = t.substr(ks, i - ks);
+      while (!key.empty() && isspace((unsigned char)key.back())) key.pop_back();
+      i++;
+      while (i < to && isspace((unsigned char)t[i])) i++;
+      std::string val;
+      if (i < to && t[i] == '"') {
+        size_t e = t.find('"', i + 1);
+        if (e == std::string::npos || e >= to) return false;
+        val = t.substr(i + 1, e - i - 1);
+        i = e + 1;
+      } else {
+        size_t vs = i;
+        while (i < to && t[i] != ',' && t[i] != '}' && !isspace((unsigned char)t[i])) i++;
+        val = t.substr(vs, i - vs);
+      }
+      m.kv.push_back({key, val});
+    }
+    if (i >= to) return false;
+    i++;  // '}'
+    out.push_back(std::move(m));
+  }
+}
+
+bool yaml_scalar(const std::string &t, size_t from, size_t to, const char *key, long &v) {
+  const std::string k = std::string(key) + ":";
+  for (size_t i = t.find(k, from); i != std::string::npos && i < to; i = t.find(k, i + 1)) {
+    if (i > 0 && !isspace((unsigned char)t[i - 1])) continue;  // ("%YAML:1.0" holds an "L:")
+    v = strtol(t.c_str() + i + k.size(), nullptr, 10);
+    return true;
+  }
+  return false;
+}
+
+int load_dbow3_yaml(const char *path, const std::string &t, std::vector<VocNode> &nodes, int &k, int &L) {
+  const size_t p_nodes = t.find("nodes:"), p_words = t.find("words:");
+  long lk = 0, lL = 0;
+  if (p_nodes == std::string::npos || p_words == std::string::npos || p_words < p_nodes || !yaml_scalar(t, 0, p_nodes, "k", lk) ||
+      !yaml_scalar(t, 0, p_nodes, "L", lL) || lk < 1 || lk > 64 || lL < 1 || lL > 16) {
+    vo::set_error("%s: not a DBoW3 cv::FileStorage vocabulary (k / L / nodes / words missing or implausible)", path);
+    return VO_ERR_INVALID;
+  }
+  k = (int)lk, L = (int)lL;
+  std::vector<YamlMap> recs, words;
+  if (!yaml_flow_maps(t, p_nodes, p_words, recs) || !yaml_flow_maps(t, p_words, t.size(), words) || recs.empty()) {
+    vo::set_error("%s: malformed node / word records", path);
+    return VO_ERR_INVALID;
+  }
+  const size_t nn = recs.size() + 1;  // + the root, which is not written
+  nodes.assign(nn, VocNode());
+  memset(nodes[0].desc, 0, 32);
+  std::vector<uint8_t> seen(nn, 0);
+  seen[0] = 1;
+  for (size_t r = 0; r < recs.size(); r++) {
+    const std::string *sid = recs[r].get("nodeId"), *spid = recs[r].get("parentId"), *sw = recs[r].get("weight"),
+                      *sd = recs[r].get("descriptor");
+    if (!sid || !spid || !sw || !sd) {
+      vo::set_error("%s: node record %zu lacks nodeId / parentId / weight / descriptor", path, r);
+      return VO_ERR_INVALID;
+    }
+    const long id = strtol(sid->c_str(), nullptr, 10), pid = strtol(spid->c_str(), nullptr, 10);
+    if (id <= 0 || (size_t)id >= nn || pid < 0 || (size_t)pid >= nn || seen[id]) {
+      vo::set_error("%s: record %zu names node %ld / parent %ld (of %zu nodes%s)", path, r, id, pid, nn,
+                    id > 0 && (size_t)id < nn && seen[id] ? ", twice" : "");
+      return VO_ERR_INVALID;
+    }
+    VocNode n;
+    n.id = (uint32_t)id, n.parent = (uint32_t)pid, n.weight = strtod(sw->c_str(), nullptr);
+    memset(n.desc, 0, 32);
+    std::istringstream ds(*sd);
+    std::string first;
+    ds >> first;
+    int cols = 32;
+    if (first == "dbw3") {
+      int type = -1;
+      ds >> type >> cols;
+      if (!ds || (type & 7) != 0 || cols != 32) {  // CV_8U, 32 columns: ORB
+        vo::set_error("%s: node %ld has a descriptor of type %d with %d columns (need CV_8U x 32)", path, id, type, cols);
+        return VO_ERR_INVALID;
+      }
+    } else {
+      ds.clear();
+      ds.str(*sd);  // DBoW2-style: the 32 values alone
+    }
+    for (int b = 0; b < 32; b++) {
+      int v = -1;
+      ds >> v;
+      if (!ds || v < 0 || v > 255) {
+        vo::set_error("%s: node %ld: descriptor byte %d missing or out of range", path, id, b);
+        return VO_ERR_INVALID;
+      }
+      n.desc[b] = (uint8_t)v;
+    }
+    seen[id] = 1;
+    nodes[id] = n;
+    nodes[pid].children.push_back((uint32_t)id);
+  }
+  for (size_t w = 0; w < words.size(); w++) {
+    const std::string *swid = words[w].get("wordId"), *snid = words[w].get("nodeId");
+    const long wid = swid ? strtol(swid->c_str(), nullptr, 10) : -1, nid = snid ? strtol(snid->c_str(), nullptr, 10) : -1;
+    if (wid < 0 || (size_t)wid >= words.size() || nid <= 0 || (size_t)nid >= nn) {
+      vo::set_error("%s: malformed word table (entry %zu: node %ld, word %ld)", path, w, nid, wid);
+      return VO_ERR_INVALID;
+    }
+    nodes[nid].word_id = (uint32_t)wid;
+  }
+  return VO_OK;
+}
+
 int vocab_to_handle(std::vector<VocNode> &nodes, int L, vo_vocab **out, int *n_nodes, int *n_words) {
   const int N = (int)nodes.size();
   std::vector<int32_t> cs(N + 1, 0), ch, wid(N, -1);
@@ -286,7 +435,16 @@ int vo_vocab_load(const char *path, vo_vocab **out, int *n_nodes, int *n_words, 
   f.read(reinterpret_cast<char *>(&sig), 8);
   std::vector<VocNode> nodes;
   int k = 0, L = 0;
-  if (f && sig == 88877711233ULL) {
+  const bool gz = (sig & 0xffff) == 0x8b1f, yaml = memcmp(&sig, "%YAML", 5) == 0;
+  if (f && (gz || yaml)) {
+    std::string text;
+    if (!read_all_gz(path, text) || text.compare(0, 5, "%YAML") != 0) {
+      vo::set_error("%s: %s", path, gz ? "gzip stream that does not hold a cv::FileStorage YAML vocabulary" : "unreadable");
+      return VO_ERR_INVALID;
+    }
+    const int yrc = load_dbow3_yaml(path, text, nodes, k, L);
+    if (yrc != VO_OK) return yrc;
+  } else if (f && sig == 88877711233ULL) {
     // DBoW3 Vocabulary::toStream (the library is not vendored under the reference; layout restated from its published
     // source): magic, bool compressed, uint32 node count nn; then k, L, scoring, weighting (ints); then nn - 1 records --
     // the root is implicit -- in the writer's depth-first order: node id, parent id (uint32), weight (double), descriptor
