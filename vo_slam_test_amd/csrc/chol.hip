@@ -49,6 +49,9 @@ namespace {
 using namespace vo;
 
 constexpr int NB = vo::kCholPanel;  // 64
+#ifndef VO_CHOL_PIVOT_WIDTH
+#define VO_CHOL_PIVOT_WIDTH 16
+#endif
 #ifndef VO_CHOL_SUBFLAG_PANEL
 #define VO_CHOL_SUBFLAG_PANEL 0
 #endif
@@ -203,9 +206,17 @@ __device__ __forceinline__ bool tile_chol(double (*T)[LP], double *rdiag /*[NB]*
                                           UpdateDone &&update_done, Side &&side) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, i16 = lane & 15, q4 = lane >> 4;
   bool bad = false;
+  // Pivot sub-panels of PW columns inside the 16-column panels (publication stays per panel).  A pivot updates the
+  // PW - 1 - j later columns of its sub-panel itself and leaves everything to the right to an MFMA update by all four
+  // wavefronts.  PW = 8 (28 instead of 120 in-loop updates per 16 columns, one more barrier + rank-8 update) was
+  // measured: 11.2 against 10.4 us per diagonal tile -- the pivot loop is bound by the latency of its dependent chain
+  // (~300 cycles per pivot), not by the updates issued next to it; so was forming the next diagonal ahead of the column
+  // (d' = a' - x^2 / d through v_rcp_f64: 2.28 against 2.05 us per 16 pivots).  PW = 16 is the product.
+  constexpr int PW = VO_CHOL_PIVOT_WIDTH, NSP = 16 / PW;
 #pragma unroll
-  for (int b = 0; b < 4; b++) {
-    const int c0 = 16 * b;
+  for (int sp = 0; sp < 4 * NSP; sp++) {
+    const int c0 = PW * sp, b = sp / NSP;
+    const bool last_of_panel = (sp % NSP) == NSP - 1;
     if (wave == 0) {
       // One wavefront issues in order, so everything between two pivots costs the chain its issue slots and every
       // wait its latency.  The update of pivot j therefore reaches the columns in three ways: columns j + 1 and j + 2
@@ -219,15 +230,15 @@ __device__ __forceinline__ bool tile_chol(double (*T)[LP], double *rdiag /*[NB]*
       asm volatile("" : "+v"(cb_a), "+v"(cbl_a));
       const lds_double *cb = (const lds_double *)(size_t)cb_a;  // factors: uniform address, broadcast reads
       lds_double *cbl = (lds_double *)(size_t)cbl_a;            // this lane's entry of the column
-      double p[16], rv = 0.0;
+      double p[PW], rv = 0.0;
 #pragma unroll
-      for (int c = 0; c < 16; c++) p[c] = T[lane][c0 + c];
+      for (int c = 0; c < PW; c++) p[c] = T[lane][c0 + c];
 #pragma unroll
-      for (int j = 0; j < 16; j++) {
-        double f[16];  // factors of pivot j - 1 for the columns j + 2 .. 15
+      for (int j = 0; j < PW; j++) {
+        double f[PW];  // factors of pivot j - 1 for the columns j + 2 .. PW - 1
         if (j >= 1) {
 #pragma unroll
-          for (int c = j + 2; c < 16; c++) f[c] = cb[((j - 1) & 1) * NB + c0 + c];
+          for (int c = j + 2; c < PW; c++) f[c] = cb[((j - 1) & 1) * NB + c0 + c];
         }
         const double d = bcast_lane(p[j], c0 + j);
         if (!(d > 0.0) || !(d < 1e300)) bad = true;  // uniform
@@ -245,36 +256,44 @@ __device__ __forceinline__ bool tile_chol(double (*T)[LP], double *rdiag /*[NB]*
         const double a = p[j] * r;  // L[lane][c0 + j] (meaningful for lane >= c0 + j; the pivot lane holds d: d r = sqrt(d))
         p[j] = a;
         rv = lane == c0 + j ? r : rv;
-        if (j < 15) p[j + 1] -= a * bcast_lane(a, c0 + j + 1);
-        if (j < 14) p[j + 2] -= a * bcast_lane(a, c0 + j + 2);
-        if (j < 13) cbl[(j & 1) * NB] = a;
+        if (j < PW - 1) p[j + 1] -= a * bcast_lane(a, c0 + j + 1);
+        if (j < PW - 2) p[j + 2] -= a * bcast_lane(a, c0 + j + 2);
+        if (j < PW - 3) cbl[(j & 1) * NB] = a;
         if (j >= 1) {
 #pragma unroll
-          for (int c = j + 2; c < 16; c++) p[c] -= p[j - 1] * f[c];
+          for (int c = j + 2; c < PW; c++) p[c] -= p[j - 1] * f[c];
         }
       }
-      if (lane >= c0 && lane < c0 + 16) rdiag[lane] = rv;
+      if (lane >= c0 && lane < c0 + PW) rdiag[lane] = rv;
 #pragma unroll
-      for (int c = 0; c < 16; c++) T[lane][c0 + c] = (lane >= c0 + c) ? p[c] : 0.0;
-    } else {
+      for (int c = 0; c < PW; c++) T[lane][c0 + c] = (lane >= c0 + c) ? p[c] : 0.0;
+    } else if (sp % NSP == 0) {
       side(b);
     }
     __syncthreads();
-    panel_done(b);  // columns c0 .. c0 + 15 are final: the owner ships them while the trailing update runs
-    // trailing tiles (rt >= ct > b): T -= P P^T with P = the panel columns just written
-    const int nt = (3 - b) * (4 - b) / 2;
+    if (last_of_panel) panel_done(b);  // columns 16 b .. 16 b + 15 are final: the owner ships them while the trailing update runs
+    // trailing tiles: T -= P P^T with P = the PW columns just written.  After the last sub-panel of a panel: the 16 x 16
+    // tiles rt >= ct > b; after an earlier one also the panel's own tile column ct = b, of which only the columns to the
+    // right of the sub-panel change (the B operand of the others is zero: they hold finished columns of L).
+    const int cb0 = last_of_panel ? b + 1 : b;
+    const int nrow = 4 - cb0, nt = nrow * (nrow + 1) / 2;
     for (int t = wave; t < nt; t += 4) {
-      int rt = b + 1, u = t;
-      while (u > rt - (b + 1)) u -= rt - b, rt++;
-      const int ct = b + 1 + u;
+      int rt = cb0, u = t;
+      while (u > rt - cb0) u -= rt - cb0 + 1, rt++;
+      const int ct = cb0 + u;
       const int R = 16 * rt, Cc = 16 * ct;
+      const bool own = ct == b;  // (only when !last_of_panel)
       double4_t acc = {T[R + q4][Cc + i16], T[R + q4 + 4][Cc + i16], T[R + q4 + 8][Cc + i16], T[R + q4 + 12][Cc + i16]};
 #pragma unroll
-      for (int s2 = 0; s2 < 4; s2++)
-        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(-T[R + i16][c0 + 4 * s2 + q4], T[Cc + i16][c0 + 4 * s2 + q4], acc, 0, 0, 0);
+      for (int s2 = 0; s2 < PW / 4; s2++) {
+        double bop = T[Cc + i16][c0 + 4 * s2 + q4];
+        if (own && Cc + i16 < c0 + PW) bop = 0.0;
+        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(-T[R + i16][c0 + 4 * s2 + q4], bop, acc, 0, 0, 0);
+      }
       T[R + q4][Cc + i16] = acc[0], T[R + q4 + 4][Cc + i16] = acc[1], T[R + q4 + 8][Cc + i16] = acc[2], T[R + q4 + 12][Cc + i16] = acc[3];
     }
-    update_done(b);  // (contains the workgroup barrier that closes the panel step)
+    if (last_of_panel) update_done(b);  // (contains the workgroup barrier that closes the panel step)
+    else __syncthreads();
   }
   return !__syncthreads_or(bad ? 1 : 0);
 }
