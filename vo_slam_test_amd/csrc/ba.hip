@@ -2155,6 +2155,36 @@ __global__ __launch_bounds__(256) void k_ba_partials_large(BaDev B) {
   }
 }
 
+
+// Sharded large systems: what a shard contributes to the reduced system is the 64 x 64 tiles of the matrix that hold a
+// covisible pair (the plan's input pattern: ~260 of 1128 at config 4), the right-hand-side row and the camera-block
+// extras.  The collective carries exactly that, packed (dir 0: storage -> payload, 1: payload -> storage), instead of the
+// whole Cholesky storage (72 MB -> 8.6 MB at 500 key-frames).
+__global__ __launch_bounds__(256) void k_ba_pack_large(BaDev B, const int2 *tiles, int n_tiles, double *payload, int dir) {
+  const BaState st = *B.st;
+  if (st.done) return;
+  const int tid = threadIdx.x, blk = blockIdx.x;
+  constexpr int T = vo::kCholPanel;
+  if (blk < n_tiles) {
+    const int2 t = tiles[blk];
+    double *pk = payload + (long long)blk * T * T;
+    for (int i = tid; i < T * T; i += 256) {
+      double *a = B.Sd + (long long)(T * t.x + i / T) * B.ld + T * t.y + (i % T);
+      if (dir == 0) pk[i] = *a;
+      else *a = pk[i];
+    }
+    return;
+  }
+  double *pk = payload + (long long)n_tiles * T * T;
+  const int n_ext = B.nf * 27 + 1 + B.n_shards;
+  double *rhs = B.Sd + (long long)B.ld * B.ld, *ext = B.Sd + large_ext_off(B.ld);
+  for (int i = (blk - n_tiles) * 256 + tid; i < B.ld + n_ext; i += (gridDim.x - n_tiles) * 256) {
+    double *a = i < B.ld ? rhs + i : ext + (i - B.ld);
+    if (dir == 0) pk[i] = *a;
+    else *a = pk[i];
+  }
+}
+
 // one workgroup: Jacobi scale, LM diagonal, cost / gradient-max bookkeeping from the (all-reduced) extras
 __global__ __launch_bounds__(256) void k_ba_prestep_large(BaDev B) {
   __shared__ double red[4];
@@ -2640,6 +2670,8 @@ struct vo_ba {
   void *allreduce_user = nullptr;
   std::map<int, hipGraphExec_t> graphs;  // LM iteration sequences captured per iteration count
   vo::CholPlan *chol_plan = nullptr;     // large reduced systems: tile structure under the chosen key-frame order
+  vo::DevBuf b_packtiles, b_pack;        // sharded large systems: tiles of the matrix that exist, packed all-reduce payload
+  int n_pack_tiles = 0;
   int order_parts = 1, order_cyclic = 0, order_sep = 0, order_depth = 0, order_tiles = 0;  // what choose_camera_order picked
 };
 
@@ -2704,6 +2736,15 @@ int build_device(vo_ba *h) {
     if (!h->chol_plan) {
       vo::set_error("BA: could not create the factorisation plan");
       return VO_ERR_HIP;
+    }
+    if (h->n_shards > 1) {
+      std::vector<int2> tiles;
+      for (int i = 0; i < m; i++)
+        for (int j = 0; j <= i; j++)
+          if ((o.pattern[i] >> j) & 1ull) tiles.push_back(make_int2(i, j));
+      h->n_pack_tiles = (int)tiles.size();
+      VO_CHECK(upload(h->b_packtiles, tiles.data(), tiles.size() * sizeof(int2)));
+      VO_CHECK(h->b_pack.reserve(((size_t)tiles.size() * vo::kCholPanel * vo::kCholPanel + D.ld + (size_t)h->nf * 27 + 1 + h->n_shards) * 8));
     }
   }
   std::vector<int> local;
@@ -3031,9 +3072,19 @@ int run_lm_eager(vo_ba *h, int max_it) {
     VO_CHECK(vo_ba_reduced_system(h, &p1, &n1));
     VO_CHECK(vo_ba_reduced_cost(h, &p2, &n2));
   }
+  const bool packed = sharded && h->D.large && h->n_pack_tiles > 0;
+  const size_t n_pack = packed ? (size_t)h->n_pack_tiles * vo::kCholPanel * vo::kCholPanel + h->D.ld + (size_t)h->nf * 27 + 1 + h->n_shards : 0;
   for (int it = 0; it < max_it; it++) {
     VO_CHECK(launch_linearize(h));
-    if (sharded) VO_CHECK(shard_allreduce(h, p1, n1));
+    if (packed) {  // only the tiles that exist, the right-hand side and the extras travel (k_ba_pack_large)
+      const dim3 grid(h->n_pack_tiles + 8);
+      hipLaunchKernelGGL(k_ba_pack_large, grid, dim3(256), 0, h->stream, h->D, h->b_packtiles.as<int2>(), h->n_pack_tiles, h->b_pack.as<double>(), 0);
+      VO_CHECK(shard_allreduce(h, h->b_pack.as<double>(), n_pack));
+      hipLaunchKernelGGL(k_ba_pack_large, grid, dim3(256), 0, h->stream, h->D, h->b_packtiles.as<int2>(), h->n_pack_tiles, h->b_pack.as<double>(), 1);
+      VO_HIP_CHECK(hipGetLastError());
+    } else if (sharded) {
+      VO_CHECK(shard_allreduce(h, p1, n1));
+    }
     VO_CHECK(launch_step(h));
     if (sharded) VO_CHECK(shard_allreduce(h, p2, n2));
     VO_CHECK(launch_update(h));
@@ -3296,7 +3347,7 @@ void vo_ba_destroy(vo_ba *h) {
                         &h->b_dl, &h->b_wt, &h->b_wt1, &h->b_hll0, &h->b_hll1, &h->b_spt1, &h->b_sgemm, &h->b_scam, &h->b_spt, &h->b_payload, &h->b_zc,
                         &h->b_sbs, &h->b_payload2, &h->b_state, &h->b_out, &h->b_dbg, &h->b_cnt, &h->b_we0, &h->b_we1,
                         &h->b_glsc0, &h->b_glsc1, &h->b_Sd, &h->b_scv, &h->b_ddv, &h->b_gppv, &h->b_cholfail,
-                        &h->b_pairstart, &h->b_paircc, &h->b_paire, &h->b_merge})
+                        &h->b_pairstart, &h->b_paircc, &h->b_paire, &h->b_merge, &h->b_packtiles, &h->b_pack})
     b->release();
   vo::chol_plan_destroy(h->chol_plan);
   if (h->pin.p) (void)hipHostFree(h->pin.p);
