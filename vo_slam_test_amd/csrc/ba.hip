@@ -955,6 +955,8 @@ struct BaDev {
   int pair_diag_blocks;     // leading workgroups (4 pairs each) that hold the (c, c) pairs
   const int *pair_cc;       // [n_pairs][2] camera slots (c <= c')
   const int4 *pair_e;       // [..] (edge of c, edge of c', point, 0) at a shared point, in point order
+  const int2 *ltiles;       // large systems: the 64 x 64 tiles (row, column) of the factor that exist (the plan's, fill included)
+  int n_ltiles;
   int n_pairs;
 };
 
@@ -2233,32 +2235,57 @@ __global__ __launch_bounds__(256) void k_ba_prestep_large(BaDev B) {
   }
 }
 
-// A = sc_r (Hpp - G) sc_c + D on the lower triangle (identity on the padding), rhs'' = g'' - sc (Y gl'')
+// Start of a linearisation: zeros in the tiles of the plan (what k_ba_pairs does not write must read as zero: fill
+// tiles, the parts of a tile without a covisible pair) and in the right-hand-side / solution rows.  Tiles outside the
+// plan are never read or written by anything: 15.5 MB instead of the 74 MB memset of the whole storage at config 4.
+__global__ __launch_bounds__(256) void k_ba_zero_large(BaDev B) {
+  if (B.st->done) return;
+  constexpr int T = vo::kCholPanel;
+  const int tid = threadIdx.x, blk = blockIdx.x;
+  if (blk < B.n_ltiles) {
+    const int2 t = B.ltiles[blk];
+    for (int i = tid; i < T * T / 2; i += 256) {
+      const int r = i / (T / 2), c2 = i - r * (T / 2);
+      *reinterpret_cast<double2 *>(B.Sd + (long long)(T * t.x + r) * B.ld + T * t.y + 2 * c2) = make_double2(0.0, 0.0);
+    }
+    return;
+  }
+  for (int i = (blk - B.n_ltiles) * 256 + tid; i < 2 * B.ld; i += (gridDim.x - B.n_ltiles) * 256) B.Sd[(long long)B.ld * B.ld + i] = 0.0;
+}
+
+// A = sc_r (Hpp - G) sc_c + D on the lower triangle of the plan's tiles (identity on the padding), rhs'' = g'' - sc (Y gl'')
 __global__ __launch_bounds__(256) void k_ba_assemble_large(BaDev B) {
   if (B.st->done) return;
+  constexpr int T = vo::kCholPanel;
   const double *hp = B.Sd + large_ext_off(B.ld);
-  const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
-  const int r = (int)(idx / B.ld), c = (int)(idx - (long long)r * B.ld);
-  const int n = 6 * B.nf;
-  if (r >= B.ld || c > r) return;
-  double v;
-  if (r < n) {
-    v = B.Sd[idx];
-    if (r / 6 == c / 6) {
-      const int slot = r / 6, a = c % 6, b = r % 6;  // a <= b
-      int t = 0;
-      for (int q = 0; q < a; q++) t += 6 - q;
-      v += hp[slot * 27 + t + (b - a)];
+  const int n = 6 * B.nf, tid = threadIdx.x, blk = blockIdx.x;
+  if (blk >= B.n_ltiles) {  // right-hand side, row ld: in place on this shard-summed -(Y gl'')
+    for (int r = (blk - B.n_ltiles) * 256 + tid; r < B.ld; r += (gridDim.x - B.n_ltiles) * 256) {
+      double *rh = B.Sd + (long long)B.ld * B.ld + r;
+      *rh = r < n ? B.gpp_v[r] + B.sc_v[r] * *rh : 0.0;
     }
-    v *= B.sc_v[r] * B.sc_v[c];
-    if (r == c) v += B.Dd_v[r];
-  } else {
-    v = r == c ? 1.0 : 0.0;
+    return;
   }
-  B.Sd[idx] = v;
-  if (c == 0) {  // right-hand side, row ld: in place on this shard-summed -(Y gl'')
-    double *rh = B.Sd + (long long)B.ld * B.ld + r;
-    *rh = r < n ? B.gpp_v[r] + B.sc_v[r] * *rh : 0.0;
+  const int2 t = B.ltiles[blk];
+  for (int i = tid; i < T * T; i += 256) {
+    const int r = T * t.x + i / T, c = T * t.y + (i % T);
+    if (c > r) continue;
+    const long long idx = (long long)r * B.ld + c;
+    double v;
+    if (r < n) {
+      v = B.Sd[idx];
+      if (r / 6 == c / 6) {
+        const int slot = r / 6, a = c % 6, b = r % 6;  // a <= b
+        int q0 = 0;
+        for (int q = 0; q < a; q++) q0 += 6 - q;
+        v += hp[slot * 27 + q0 + (b - a)];
+      }
+      v *= B.sc_v[r] * B.sc_v[c];
+      if (r == c) v += B.Dd_v[r];
+    } else {
+      v = r == c ? 1.0 : 0.0;
+    }
+    B.Sd[idx] = v;
   }
 }
 
@@ -2670,6 +2697,7 @@ struct vo_ba {
   void *allreduce_user = nullptr;
   std::map<int, hipGraphExec_t> graphs;  // LM iteration sequences captured per iteration count
   vo::CholPlan *chol_plan = nullptr;     // large reduced systems: tile structure under the chosen key-frame order
+  vo::DevBuf b_ltiles;                   // large systems: tiles of the factor (zeroed / assembled every iteration)
   vo::DevBuf b_packtiles, b_pack;        // sharded large systems: tiles of the matrix that exist, packed all-reduce payload
   int n_pack_tiles = 0;
   int order_parts = 1, order_cyclic = 0, order_sep = 0, order_depth = 0, order_tiles = 0;  // what choose_camera_order picked
@@ -2736,6 +2764,16 @@ int build_device(vo_ba *h) {
     if (!h->chol_plan) {
       vo::set_error("BA: could not create the factorisation plan");
       return VO_ERR_HIP;
+    }
+    {
+      std::vector<unsigned long long> lmask((size_t)m);
+      vo::chol_symbolic(m, o.pattern.data(), lmask.data(), nullptr, nullptr);
+      std::vector<int2> lt;
+      for (int i = 0; i < m; i++)
+        for (int j = 0; j <= i; j++)
+          if ((lmask[i] >> j) & 1ull) lt.push_back(make_int2(i, j));
+      VO_CHECK(upload(h->b_ltiles, lt.data(), lt.size() * sizeof(int2)));
+      D.n_ltiles = (int)lt.size();
     }
     if (h->n_shards > 1) {
       std::vector<int2> tiles;
@@ -2883,6 +2921,9 @@ int build_device(vo_ba *h) {
     VO_CHECK(h->b_glsc0.reserve((size_t)std::max(1, h->n_pts) * 3 * 8));
     VO_CHECK(h->b_glsc1.reserve((size_t)std::max(1, h->n_pts) * 3 * 8));
     VO_CHECK(h->b_Sd.reserve((size_t)(D.ld + vo::kCholPanel) * D.ld * 8));  // + right-hand side / solution rows
+    // (once: the tiles outside the plan are never written again, and a caller's all-reduce of the whole storage -- the
+    // split-phase interface -- must not sum uninitialised memory)
+    VO_HIP_CHECK(hipMemsetAsync(h->b_Sd.p, 0, (size_t)(D.ld + vo::kCholPanel) * D.ld * 8, h->stream));
     VO_CHECK(h->b_scv.reserve((size_t)D.ld * 8));
     VO_CHECK(h->b_ddv.reserve((size_t)D.ld * 8));
     VO_CHECK(h->b_gppv.reserve((size_t)D.ld * 8));
@@ -2893,6 +2934,7 @@ int build_device(vo_ba *h) {
     D.sc_v = h->b_scv.as<double>(), D.Dd_v = h->b_ddv.as<double>(), D.gpp_v = h->b_gppv.as<double>();
     D.chol_fail = h->b_cholfail.as<int>();
     D.pair_start = h->b_pairstart.as<int>(), D.pair_cc = h->b_paircc.as<int>(), D.pair_e = h->b_paire.as<int4>();
+    D.ltiles = h->b_ltiles.as<int2>();
   }
   VO_CHECK(h->b_scam.reserve((size_t)std::max(1, h->nf) * D.n_cchunks * 27 * 8));
   VO_CHECK(h->b_spt.reserve((size_t)D.n_pblocks * 2 * 8));
@@ -2981,7 +3023,7 @@ int launch_linearize_large(vo_ba *h) {
   hipStream_t st = h->stream;
   hipLaunchKernelGGL(k_ba_hinv_large, dim3((D.n_local + 255) / 256), dim3(256), 0, st, D);
   hipLaunchKernelGGL(k_ba_cams_large, dim3(std::max(1, h->nf * D.n_cchunks)), dim3(kCamChunk), 0, st, D);
-  VO_HIP_CHECK(hipMemsetAsync(D.Sd, 0, (size_t)(D.ld + vo::kCholPanel) * D.ld * 8, st));
+  hipLaunchKernelGGL(k_ba_zero_large, dim3(D.n_ltiles + 8), dim3(256), 0, st, D);
   if (D.n_pairs > 0) hipLaunchKernelGGL(k_ba_pairs, dim3(D.n_pairs / 4), dim3(256), 0, st, D);  // n_pairs: a multiple of 32
   hipLaunchKernelGGL(k_ba_partials_large, dim3(std::max(1, (h->nf * 27 + 255) / 256)), dim3(256), 0, st, D);
   VO_HIP_CHECK(hipGetLastError());
@@ -2992,7 +3034,7 @@ int launch_step_large(vo_ba *h) {
   BaDev &D = h->D;
   hipStream_t st = h->stream;
   hipLaunchKernelGGL(k_ba_prestep_large, dim3(1), dim3(256), 0, st, D);
-  hipLaunchKernelGGL(k_ba_assemble_large, dim3((unsigned)(((long long)D.ld * D.ld + 255) / 256)), dim3(256), 0, st, D);
+  hipLaunchKernelGGL(k_ba_assemble_large, dim3(D.n_ltiles + 8), dim3(256), 0, st, D);
   vo::chol_factor_solve(D.Sd, D.ld, D.chol_fail, st, h->chol_plan);
   hipLaunchKernelGGL(k_ba_poststep_large, dim3(1), dim3(256), 0, st, D);
   VO_HIP_CHECK(hipGetLastError());
@@ -3347,7 +3389,7 @@ void vo_ba_destroy(vo_ba *h) {
                         &h->b_dl, &h->b_wt, &h->b_wt1, &h->b_hll0, &h->b_hll1, &h->b_spt1, &h->b_sgemm, &h->b_scam, &h->b_spt, &h->b_payload, &h->b_zc,
                         &h->b_sbs, &h->b_payload2, &h->b_state, &h->b_out, &h->b_dbg, &h->b_cnt, &h->b_we0, &h->b_we1,
                         &h->b_glsc0, &h->b_glsc1, &h->b_Sd, &h->b_scv, &h->b_ddv, &h->b_gppv, &h->b_cholfail,
-                        &h->b_pairstart, &h->b_paircc, &h->b_paire, &h->b_merge, &h->b_packtiles, &h->b_pack})
+                        &h->b_pairstart, &h->b_paircc, &h->b_paire, &h->b_merge, &h->b_packtiles, &h->b_pack, &h->b_ltiles})
     b->release();
   vo::chol_plan_destroy(h->chol_plan);
   if (h->pin.p) (void)hipHostFree(h->pin.p);
