@@ -310,6 +310,34 @@ def test_device_cholesky_on_sparse_tile_plans(vo, kind, n):
     assert np.all(L[Lref == 0] == 0)
 
 
+@pytest.mark.parametrize("seed", range(16))
+def test_device_cholesky_random_plans(vo, seed):
+    """random sizes (2..20 tile rows, ragged last tile), random tile patterns of random density, with and without a
+    sub-diagonal (fused / stand-alone diagonal tasks, several backward chains): the factor, the exact zeros outside the
+    symbolic fill and the solution against numpy"""
+    rng = np.random.default_rng(1000 + seed)
+    m = int(rng.integers(2, 21))
+    n = 64 * (m - 1) + int(rng.integers(1, 65))
+    keep = rng.random((m, m)) < rng.uniform(0.05, 0.6)
+    if seed % 3 == 0:   # break the sub-diagonal somewhere: a second backward chain, a diagonal tile without a fused owner
+        cut = int(rng.integers(1, m))
+        keep[cut, cut - 1] = keep[cut - 1, cut] = False
+        keep[cut:, :cut] = False
+        keep[:cut, cut:] = False
+    else:
+        keep |= np.eye(m, k=1, dtype=bool) & (rng.random((m, m)) < 0.8)
+    keep = keep | keep.T | np.eye(m, dtype=bool)
+    M = rng.normal(size=(n, n))
+    A = (M + M.T) * np.kron(keep, np.ones((64, 64)))[:n, :n]
+    A += (np.abs(A).sum(1).max() + 1.0) * np.eye(n)
+    b = rng.normal(size=n)
+    x, L = vo.chol_solve(A, b)
+    Lref = np.linalg.cholesky(A)
+    assert np.abs(L - Lref).max() < 1e-10 * np.abs(Lref).max()
+    assert np.all(L[Lref == 0] == 0)
+    assert np.abs(x - np.linalg.solve(A, b)).max() < 1e-10 * max(1.0, np.abs(x).max())
+
+
 def test_device_cholesky_rejects_indefinite(vo):
     A = np.eye(70)
     A[40, 40] = -1.0
