@@ -1006,9 +1006,13 @@ vo::CholOrder vo::chol_choose_order(int nf, int bs, const std::vector<std::pair<
   for (int cyclic = 0; cyclic < 2; cyclic++) {
     const int w = cyclic ? w_cyc : w_lin;
     if (w < 1) continue;
+    // Two families per (P, wide): (a) segments of `base` blocks with the last one taking the rest (base = the multiple of
+    // 32 below / above the even share), (b) ALL segments of `base` blocks and the rest added to the separator that is
+    // eliminated last -- then the separators start on a 32-block boundary too, and the ones that run concurrently do not
+    // share a tile (config 4: 4 x 64 key-frames + separators 64 / 48 / 64 / 67: 23 dependent columns against 26).
     for (int P = 2; P <= 8; P++)
       for (int wide = 0; wide < 2; wide++)
-        for (int up = 0; up < 2; up++) {
+        for (int variant = 0; variant < 6; variant++) {
           if (force_parts > 1 && P != force_parts) continue;
           const int n_sep = cyclic ? P : P - 1;
           std::vector<int> rank((size_t)n_sep), sep_len((size_t)n_sep), sep_order((size_t)n_sep);
@@ -1021,10 +1025,21 @@ vo::CholOrder vo::chol_choose_order(int nf, int bs, const std::vector<std::pair<
             sep_order[g] = g;
           }
           std::stable_sort(sep_order.begin(), sep_order.end(), [&](int a, int b) { return rank[a] < rank[b]; });
-          const int in_segs = nf - sep_total;
+          int in_segs = nf - sep_total;
           if (in_segs < 32 * P) continue;
-          const int base = (in_segs / P / 32 + up) * 32;  // the first P - 1 segments; the last one takes the rest
-          if (base < 32 || in_segs - base * (P - 1) < 1) continue;
+          int base, last;
+          if (variant < 2) {  // (a)
+            base = (in_segs / P / 32 + variant) * 32;
+            last = in_segs - base * (P - 1);
+          } else {            // (b): base = the even share rounded down to 32, minus 0 .. 3 units
+            base = (in_segs / P / 32 - (variant - 2)) * 32;
+            last = base;
+            if (base >= 32) {
+              const int rest = in_segs - base * P;
+              sep_len[sep_order[n_sep - 1]] += rest, sep_total += rest, in_segs -= rest;
+            }
+          }
+          if (base < 32 || last < 1) continue;
           std::vector<int> sep_start((size_t)n_sep);
           int at = in_segs;
           for (int q = 0; q < n_sep; q++) sep_start[sep_order[q]] = at, at += sep_len[sep_order[q]];
@@ -1033,7 +1048,7 @@ vo::CholOrder vo::chol_choose_order(int nf, int bs, const std::vector<std::pair<
           o.slot_of.assign((size_t)nf, -1);
           int next_seg = 0, pos = 0;
           for (int g = 0; g < P; g++) {
-            const int len = g < P - 1 ? base : in_segs - base * (P - 1);
+            const int len = g < P - 1 ? base : last;
             for (int q = 0; q < len; q++) o.slot_of[pos++] = next_seg++;
             if (g < n_sep)
               for (int q = 0; q < sep_len[g]; q++) o.slot_of[pos++] = sep_start[g] + q;
