@@ -2069,8 +2069,9 @@ __global__ __launch_bounds__(256) void k_ba_pairs(BaDev B) {
   for (int t = t0 + lane; t - lane < t1; t += 64) {
     const int4 nxt = B.pair_e[min(t + 64, t1 - 1)];
     const int e = rec.x, ep = rec.y, j = rec.z;
-    const int act = (int)B.e_active[e] & (int)B.e_active[ep];  // (no short-circuit: both loads are issued now)
-    const bool ok = (t < t1) & (act != 0);
+    // (no activity test: the linearisation writes all-zero W rows for a deactivated edge -- point_linearize --, so its
+    // couples add exact zeros; the two scattered byte loads it took were two of the ~7 cache lines a couple touches)
+    const bool ok = t < t1;
     // 16-byte loads: the texture-address unit spends ~1.5 cycles per lane and instruction on these scattered blocks
     // and was busy 91 % of the kernel with 8-byte loads (TA_TA_BUSY); the blocks are 48 and 144 bytes, 16-byte aligned
     const double2_t *hv2 = reinterpret_cast<const double2_t *>(B.hinv + 6 * j);
