@@ -90,10 +90,13 @@ struct CamDev {
 __global__ __launch_bounds__(256) void k_frame_post(FramesDev F, CamDev C, const vo_keypoint *kps, const uint8_t *desc,
                                                     const int *counts, int kp_capacity, const void *depth, int depth_kind,
                                                     long long depth_frame_stride, int depth_pitch, float inv_depth_scale,
-                                                    int img_w, int img_h, int slot0) {
+                                                    int img_w, int img_h, int slot0, int *err) {
   const int f = blockIdx.y, i = blockIdx.x * 256 + threadIdx.x;
   const int n = min(counts[f], min(kp_capacity, F.cap));
-  if (i == 0) F.n[slot0 + f] = n;
+  if (i == 0) {
+    F.n[slot0 + f] = n;
+    if (counts[f] > n) atomicOr(err, 2);  // key-points beyond the store's slots are dropped: never silently (sticky flag)
+  }
   if (i >= n) return;
   const vo_keypoint kp = kps[(long long)f * kp_capacity + i];
   float ux = kp.x, uy = kp.y;
@@ -246,7 +249,7 @@ struct GuidedOut {
   const uint8_t *fmask;     // [frames][cap] or NULL: blocked / has-map-point / occupied on entry
   unsigned *pushes;         // [frames][stride] rotation-histogram entries idx | bin << 16
   int *n_matches;           // [frames]
-  int *err;                 // 1: overflow area exhausted
+  int *err;                 // bit 0: overflow area exhausted (bit 1: the frame store dropped key-points, k_frame_post)
 };
 
 __device__ __forceinline__ unsigned row_min_u32(unsigned x) {  // minimum over the 16 lanes of a DPP row, in every lane
@@ -443,7 +446,7 @@ __global__ __launch_bounds__(256) void k_guided_cand(FramesDev F, Queries Q, Gui
       if (l16 == 0) ovf_off = atomicAdd(&O.ovf_used[f], written - kSlot);
       ovf_off = __shfl(ovf_off, 0, G);
       if (ovf_off + written - kSlot > O.ovf_stride) {
-        if (l16 == 0) atomicExch(O.err, 1);
+        if (l16 == 0) atomicOr(O.err, 1);
         written = kSlot;  // truncated: reported through vo_match_guided_status
       }
     }
@@ -1037,9 +1040,13 @@ int vo_frames_build_dev(vo_frames *h, int slot0, int n_frames, const vo_keypoint
   }
   hipStream_t st = (hipStream_t)hip_stream;
   const int nmax = std::min(capacity, h->cap);
+  if (!h->b_err.p) {  // the handle's sticky flag (read and cleared by vo_match_guided_status)
+    VO_CHECK(h->b_err.reserve(64));
+    VO_HIP_CHECK(hipMemsetAsync(h->b_err.p, 0, 64, st));
+  }
   hipLaunchKernelGGL(k_frame_post, dim3((nmax + 255) / 256, n_frames), dim3(256), 0, st, h->D, h->cam, dev_keypoints,
                      dev_descriptors, dev_counts, capacity, dev_depth, depth_kind, (long long)depth_frame_stride_bytes,
-                     depth_pitch_bytes, inv_depth_scale, (int)h->width, (int)h->height, slot0);
+                     depth_pitch_bytes, inv_depth_scale, (int)h->width, (int)h->height, slot0, h->b_err.as<int>());
   hipLaunchKernelGGL(k_frame_grid, dim3(n_frames), dim3(256), 0, st, h->D, slot0);
   VO_HIP_CHECK(hipGetLastError());
   return VO_OK;
@@ -1185,7 +1192,8 @@ int vo_match_guided_status(vo_frames *h, void *hip_stream) {
   VO_CHECK(vo::stream_sync(st, "vo_match_guided_status"));
   if (e) {
     VO_HIP_CHECK(hipMemsetAsync(h->b_err.p, 0, 4, st));  // reported once
-    vo::set_error("guided matcher: candidate pool overflow in a search since the last status call (raise pool_per_frame)");
+    vo::set_error(e & 2 ? "frame store: a frame had more key-points than the store's slots per frame (they were dropped)"
+                        : "guided matcher: candidate pool overflow in a search since the last status call (raise pool_per_frame)");
     return VO_ERR_CAPACITY;
   }
   return VO_OK;
@@ -1299,7 +1307,7 @@ int guided_host(const vo_frame_view *cur, const HostQueries &hq, const GuidedCal
     VO_CHECK(vo::stream_sync(st, "guided matcher"));
     int e;
     memcpy(&e, sg + r_err, 4);
-    if (!e) break;
+    if (!(e & 1)) break;  // (bit 0: pool overflow)
     VO_HIP_CHECK(hipMemsetAsync(h->b_err.p, 0, 4, st));  // the flag is sticky: this retry loop consumes it
     if (attempt >= 6) {
       vo::set_error("guided matcher: candidate pool overflow");
@@ -1417,3 +1425,5 @@ int vo_match_sim3_mutual(const vo_frame_view *kf1, const vo_frame_view *kf2, con
 }
 
 }  // extern "C"
+
+const int *vo::guided_error_flag(const vo_frames *h) { return h ? h->b_err.as<int>() : nullptr; }

@@ -2211,3 +2211,5 @@ int vo_orb_get_level_counts(vo_orb *h, int frame, int32_t *counts) {
 }
 
 }  // extern "C"
+
+const int *vo::orb_error_flag(const vo_orb *h) { return h ? h->err.as<int>() : nullptr; }

@@ -125,4 +125,9 @@ struct CholOrder {
 };
 CholOrder chol_choose_order(int nf, int bs, const std::vector<std::pair<int, int>> &pairs, int m, int force_parts = -1);
 
+// Device addresses of the handles' sticky error flags (NULL before the first use): vo_tracker copies them into its
+// result block so that one download answers "pose + counts + did anything overflow" (orb.hip, guided.hip).
+const int *orb_error_flag(const vo_orb *h);
+const int *guided_error_flag(const vo_frames *h);
+
 }  // namespace vo
