@@ -12,7 +12,7 @@
 //   searchByProjection(frame, local points, 3)       vo_match_guided_dev mode 1 + k_track_scatter
 //   solvePoseOnlySE3, inlier count (:289-300)        k_track_gather + k_pose_only + k_track_count
 //
-// 23 launches per batch, no host synchronisation in between.  The extraction may run on a stream shared by several
+// 29 kernel launches per batch, no host synchronisation in between.  The extraction may run on a stream shared by several
 // trackers (vo_tracker_config.extract_stream): batch i + 1's extraction then overlaps batch i's searches and pose
 // solves (two events order them).  Round 2 kept this sequence in Python (vo_slam_test_amd/tracking.py) without the
 // culling step and with the local-map projections fixed before the first solve; host code is now C++
