@@ -2932,6 +2932,7 @@ int build_device(vo_ba *h) {
     D.We[0] = h->b_we0.as<double>(), D.We[1] = h->b_we1.as<double>();
     D.glsc[0] = h->b_glsc0.as<double>(), D.glsc[1] = h->b_glsc1.as<double>();
     D.Sd = h->ext_payload ? h->ext_payload : h->b_Sd.as<double>();
+    if (h->ext_payload) VO_HIP_CHECK(hipMemsetAsync(h->ext_payload, 0, (size_t)(D.ld + vo::kCholPanel) * D.ld * 8, h->stream));
     D.sc_v = h->b_scv.as<double>(), D.Dd_v = h->b_ddv.as<double>(), D.gpp_v = h->b_gppv.as<double>();
     D.chol_fail = h->b_cholfail.as<int>();
     D.pair_start = h->b_pairstart.as<int>(), D.pair_cc = h->b_paircc.as<int>(), D.pair_e = h->b_paire.as<int4>();
@@ -3498,7 +3499,12 @@ int vo_ba_set_reduce_buffers(vo_ba *h, double *dev_system, double *dev_cost) {
   if (h->built) {
     h->D.payload = dev_system ? dev_system : h->b_payload.as<double>();
     h->D.payload2 = dev_cost ? dev_cost : h->b_payload2.as<double>();
-    if (h->D.large) h->D.Sd = dev_system ? dev_system : h->b_Sd.as<double>();  // the Cholesky storage is the payload
+    if (h->D.large) {
+      h->D.Sd = dev_system ? dev_system : h->b_Sd.as<double>();  // the Cholesky storage is the payload
+      // the caller's all-reduce sums the WHOLE storage, and the tiles outside the factorisation plan are never written:
+      // they must be zeros, not whatever the caller's allocation held
+      if (dev_system) VO_HIP_CHECK(hipMemsetAsync(dev_system, 0, (size_t)(h->D.ld + vo::kCholPanel) * h->D.ld * 8, h->stream));
+    }
   }
   return VO_OK;
 }

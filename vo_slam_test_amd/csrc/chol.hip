@@ -1073,7 +1073,11 @@ size_t vo::chol_workspace_bytes(int ld) {
 void vo::chol_factor_solve(double *A, int ld, void *workspace, hipStream_t st, const vo::CholPlan *plan) {
   const int m = ld / NB;
   if (!plan || plan->m != m) plan = dense_plan(m);
-  if (!plan) return;  // (allocation failure: the caller's fail flag stays clear and the solution row untouched -- reported by the next HIP call)
+  if (!plan) {  // no plan (allocation failure, m outside 1..64): raise the caller's fail flag -- never a silent no-op
+    static const int abandoned = 2;
+    (void)hipMemcpyAsync(workspace, &abandoned, 4, hipMemcpyHostToDevice, st);
+    return;
+  }
   int *wsI = reinterpret_cast<int *>(workspace);
   const size_t ints = ((size_t)chol_ws_ints(m) * 4 + 255) & ~(size_t)255;
   // everything but the fail flag (word 0, owned by the caller) starts at zero
