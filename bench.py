@@ -143,6 +143,21 @@ def main():
                     "share one GPU to exercise the N > 1 code path on a single-GPU box)")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # `python bench.py --gpus N`: start N fresh ranks (one per GPU) BEFORE anything here touches the GPU -- a process that
+        # has initialised HIP must never be replaced by another program -- and relay rank 0's JSON line
+        import socket
+        import subprocess
+        sk = socket.socket()
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+        sk.close()
+        env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", MASTER_ADDR="127.0.0.1")
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
+               "--master-port", str(port), str(pathlib.Path(__file__).resolve()), *sys.argv[1:]]
+        r = subprocess.run(cmd, env=env)
+        raise SystemExit(r.returncode)
+
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -300,7 +315,9 @@ def main():
     # stream around every kernel; with two batches in flight the other batch's kernels share the CUs with it, which
     # stretches every launch while the step gets shorter -- the same kernel with one batch in flight is under "alone")
     kernel_stages = [k for k in serial_stage_ms if k not in ("offsets", "pose_only_1", "pose_only_2")]
-    dom = max(kernel_stages, key=lambda k: serial_stage_ms[k])  # by the undisturbed durations: the in-region ranking flips between runs
+    # ranked by the durations INSIDE the timed region (the undisturbed ranking picked describe over FAST on a
+    # 0.1 % margin); every kernel's fraction is in `per_kernel` below either way
+    dom = max(kernel_stages, key=lambda k: stage_ms.get(k, 0.0))
     achieved = sb[dom] * B / (stage_ms[dom] * 1e-3) / 1e9
     traffic = None
     tf = ROOT / "profiles" / "traffic.json"
@@ -315,6 +332,12 @@ def main():
                 "bytes_per_launch": sb[dom] * B, "avg_launch_ms": round(stage_ms[dom], 4),
                 "alone": {"avg_launch_ms": round(serial_stage_ms[dom], 4), "achieved": round(alone, 2),
                           "frac": round(alone / HBM_PEAK_GBS, 5), "note": "the same kernel with one batch in flight"}}
+    roofline["per_kernel"] = {
+        k: {"bytes_per_launch": sb[k] * B, "avg_launch_ms": round(stage_ms[k], 4),
+            "frac": round(sb[k] * B / (stage_ms[k] * 1e-3) / 1e9 / HBM_PEAK_GBS, 5),
+            "alone_ms": round(serial_stage_ms[k], 4),
+            "alone_frac": round(sb[k] * B / (serial_stage_ms[k] * 1e-3) / 1e9 / HBM_PEAK_GBS, 5)}
+        for k in kernel_stages if stage_ms.get(k, 0.0) > 0 and serial_stage_ms[k] > 0}
     stage_gbs = {k: round(sb[k] * B / (serial_stage_ms[k] * 1e-3) / 1e9, 1) for k in kernel_stages if serial_stage_ms[k] > 0}
     stage_gbs_region = {k: round(sb[k] * B / (stage_ms[k] * 1e-3) / 1e9, 1) for k in stage_ms
                         if k in sb and stage_ms[k] > 0}
@@ -333,6 +356,10 @@ def main():
         "value": round(frames_per_s, 1), "unit": "frames/s", "n_gpus": world, "steps": args.steps,
         "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True,
         "scaling": "weak", "vs_baseline": None, "dtype": "u8", "data": "synthetic",
+        "collective_backend": (args.backend if world > 1 else None),
+        "rccl_note": ("this line's all-reduces went through RCCL (torch.distributed nccl backend)" if (world > 1 and args.backend == "nccl") else
+                      "RCCL has not been exercised by this run: the sharded-BA all-reduce path is covered by gloo tests and an RCCL "
+                      "C++ host that compiles and links (examples/rccl_sharded_ba.cpp); no SCALE record exists yet"),
         "config": {"workload": "tracked frame: ORB extract (640x480, 8-level pyramid, 1000 kpts) + undistort/depth/grid + "
                                "searchByProjection vs last frame + solvePoseOnlySE3 + cullingOutliersBeforeLocalMap + "
                                "isInFrame (refined pose) + searchByProjection vs local map + solvePoseOnlySE3; frames, depth "
@@ -355,7 +382,7 @@ def main():
         "extract_match_frac_of_hbm_peak": round(em_gbs / HBM_PEAK_GBS, 4),
         "pose_only_in_path": {"ms_per_launch": round(stage_ms["pose_only_1"] + stage_ms["pose_only_2"], 4),
                               "fp64_GFLOPs": round(2 * pose_flops * B / ((stage_ms["pose_only_1"] + stage_ms["pose_only_2"]) * 1e-3) / 1e9, 1),
-                              "bound": "fp64 VALU issue (one wavefront per frame; twice the frames take twice as long: ~10 cycles per FP64 wave-instruction per SIMD)"},
+                              "bound": "fp64 VALU issue (one wavefront per frame; twice the frames take twice as long: ~5 cycles per FP64 wave-instruction per SIMD at one wavefront per SIMD, profiles/r03_valu_issue_calibration.txt)"},
     }
 
     # ---- one camera stream, host buffers: Frame construction to pose in ONE call (vo_tracker_track, batch 1: image and raw
@@ -436,58 +463,70 @@ def main():
     if not args.no_ba:
         lb = synth.make_lba_problem(0)
         n_edges = len(lb["e_cam"])
-        reps = 20
+        reps = 30   # >= 30 repetitions, median
+
+        class _DevView:
+            def __init__(self, ptr, n):
+                self.__cuda_array_interface__ = {"shape": (n,), "typestr": "<f8", "data": (ptr, False), "version": 2}
+
+        ar_stats = {"calls": 0, "max_doubles": 0}
+
+        def _allreduce(ptr, n, _stream):
+            # the exchange of the sharded LM loop (vo_ba_set_allreduce): RCCL over xGMI with the nccl backend
+            ar_stats["calls"] += 1
+            ar_stats["max_doubles"] = max(ar_stats["max_doubles"], int(n))
+            t = torch.as_tensor(_DevView(ptr, n), device="cuda")
+            if args.backend == "nccl":
+                dist.all_reduce(t)
+            else:
+                hbuf = t.cpu()
+                dist.all_reduce(hbuf)
+                t.copy_(hbuf)
+            return 0
+
+        def _same_on_all_ranks(v, what):
+            chk = torch.tensor([v], dtype=torch.int64, device="cuda")
+            lo, hi = chk.clone(), chk.clone()
+            dist.all_reduce(lo, op=dist.ReduceOp.MIN)
+            dist.all_reduce(hi, op=dist.ReduceOp.MAX)
+            assert int(lo.item()) == int(hi.item()), f"ranks diverged in the sharded LM loop ({what})"
+
+        solve_s = []
         if world == 1:
             ba = vo.BundleAdjuster(lb)
             ba.local_ba()  # warm-up (allocations, code load)
-            iters, tb = 0, 0.0
+            iters = 0
             for _ in range(reps):
                 ba.set_state(lb["poses"], lb["points"])  # reset to the initial guess (not timed)
                 torch.cuda.synchronize()
                 tb0 = time.perf_counter()
                 _, sums, _ = ba.local_ba()               # returns after its own final synchronisation
-                tb += time.perf_counter() - tb0
+                solve_s.append(time.perf_counter() - tb0)
                 iters += sums[0].iterations + sums[1].iterations
             ba.close()
         else:
             # one problem, points sharded over the ranks; the LM loop runs inside libvo_hip.so and calls back for its
-            # two all-reduces per iteration (RCCL over xGMI with the nccl backend)
-            class _DevView:
-                def __init__(self, ptr, n):
-                    self.__cuda_array_interface__ = {"shape": (n,), "typestr": "<f8", "data": (ptr, False), "version": 2}
-
-            def _allreduce(ptr, n, _stream):
-                t = torch.as_tensor(_DevView(ptr, n), device="cuda")
-                if args.backend == "nccl":
-                    dist.all_reduce(t)
-                else:
-                    hbuf = t.cpu()
-                    dist.all_reduce(hbuf)
-                    t.copy_(hbuf)
-                return 0
-
+            # two all-reduces per iteration
             sba = vo.BundleAdjuster(lb, shard=rank, n_shards=world, stream=torch.cuda.current_stream().cuda_stream)
             sba.set_allreduce(_allreduce)
             sba.local_ba()
-            iters, tb = 0, 0.0
+            iters = 0
             for _ in range(reps):
                 sba.set_state(lb["poses"], lb["points"])
                 barrier()
                 tb0 = time.perf_counter()
                 _, (s1, s2), _ = sba.local_ba()
                 barrier()
-                tb += time.perf_counter() - tb0
+                solve_s.append(time.perf_counter() - tb0)
                 iters += s1.iterations + s2.iterations
             sba.close()
             # every rank took the same decisions: identical iteration counts are part of the contract
-            chk = torch.tensor([iters], dtype=torch.int64, device="cuda")
-            lo, hi = chk.clone(), chk.clone()
-            dist.all_reduce(lo, op=dist.ReduceOp.MIN)
-            dist.all_reduce(hi, op=dist.ReduceOp.MAX)
-            assert int(lo.item()) == int(hi.item()), "ranks diverged in the sharded LM loop"
+            _same_on_all_ranks(iters, "local BA")
+        tb = float(np.median(solve_s)) * reps   # median solve time x repetitions (every solve takes the same LM iterations)
         out["local_ba"] = {"workload": f"10 KF + 4 fixed x 3000 pts, {n_edges} edges, 5 Huber + 10 plain LM iterations",
                            "lm_iters_per_s": round(iters / tb, 1), "ms_per_solve": round(tb / reps * 1e3, 3),
                            "iterations_per_solve": iters / reps, "dtype": "f64",
+                           "timing": f"median of {reps} solves (min {min(solve_s) * 1e3:.3f} ms, max {max(solve_s) * 1e3:.3f} ms)",
                            "sharding": f"points % {world}, 2 all-reduces per LM iteration inside the C-ABI (vo_ba_set_allreduce)"
                            if world > 1 else "single GPU"}
         f_lba = ba_flops_per_iteration(lb)
@@ -522,6 +561,35 @@ def main():
             dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
             out["local_ba"]["replicas"] = {"problems_per_gpu": nconc, "aggregate_lm_iters_per_s": round(float(tot.item()) / float(tmax.item()), 1),
                                            "sharding": "independent problems per GPU, no collective"}
+            # config 4 sharded: ONE 500-key-frame global BA, points % world per rank, the packed reduced camera system
+            # all-reduced once per LM iteration (+ 6 scalars) through the same callback; every rank factors the summed system
+            gb = synth.make_global_ba_problem(0)
+            hm, hs = float(np.sqrt(np.float32(5.991))), float(np.sqrt(np.float32(7.815)))
+            gsh = vo.BundleAdjuster(gb, shard=rank, n_shards=world, stream=torch.cuda.current_stream().cuda_stream)
+            gsh.set_allreduce(_allreduce)
+            gsh.solve(hm, hs, 1)                                   # builds the device structures
+            ar_stats["calls"], ar_stats["max_doubles"] = 0, 0
+            g_s, g_it = [], 0
+            for _ in range(5):
+                gsh.set_state(gb["poses"], gb["points"])
+                barrier()
+                tg0 = time.perf_counter()
+                gs = gsh.solve(hm, hs, 10)
+                barrier()
+                g_s.append(time.perf_counter() - tg0)
+                g_it = gs.iterations
+            g_order = gsh.debug_order()
+            gsh.close()
+            _same_on_all_ranks(g_it, "global BA")
+            tg = float(np.median(g_s))
+            out["global_ba"] = {"workload": f"{len(gb['poses'])} KF x {len(gb['points'])} pts, {len(gb['e_cam'])} edges, "
+                                            f"{6 * (len(gb['poses']) - 1)}-wide reduced system, 10 LM iterations",
+                                "lm_iters_per_s": round(g_it / tg, 1), "ms_per_iter": round(tg / max(g_it, 1) * 1e3, 3), "dtype": "f64",
+                                "timing": f"median of {len(g_s)} solves",
+                                "sharding": f"points % {world}; per LM iteration one all-reduce of the packed reduced system "
+                                            f"({ar_stats['max_doubles'] * 8 / 1e6:.1f} MB) and one of 6 scalars; factorisation replicated",
+                                "allreduce_payload_MB": round(ar_stats["max_doubles"] * 8 / 1e6, 2),
+                                "allreduce_calls_per_solve": ar_stats["calls"] / len(g_s), "key_frame_order": g_order}
         if world == 1:
             # aggregate throughput: independent problems (one handle + stream each) overlapped on the GPU
             nconc = 8
@@ -576,7 +644,7 @@ def main():
             f_po = 270.0 * 1000 * pit  # ~150 + 120 flop per observation and LM iteration
             out["pose_only_ba"]["device_resident"] = {"solves_per_s": round(len(probs) / tk, 1), "lm_iters_per_s": round(pit / tk, 1),
                                                       "ms_per_launch": round(tk * 1e3, 3)}
-            out["pose_only_ba"]["roofline"] = {"bound": "fp64 VALU issue (one wavefront per frame and SIMD, ~10 cycles per FP64 wave-instruction; most instructions are not multiply-adds)",
+            out["pose_only_ba"]["roofline"] = {"bound": "fp64 VALU issue (one wavefront per frame and SIMD, ~5 cycles per FP64 wave-instruction (profiles/r03_valu_issue_calibration.txt); most instructions are not multiply-adds)",
                                                "achieved": round(f_po / tk / 1e12, 4), "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s",
                                                "frac": round(f_po / tk / 1e12 / FP64_PEAK_TFLOPS, 5)}
             pose_probs, pose_iters_dev = probs, pit
@@ -586,16 +654,19 @@ def main():
             hm, hs = float(np.sqrt(np.float32(5.991))), float(np.sqrt(np.float32(7.815)))
             gba.solve(hm, hs, 1)                                   # builds the device structures
             g_order = gba.debug_order()
-            gba.set_state(gb["poses"], gb["points"])
-            torch.cuda.synchronize()
-            tg0 = time.perf_counter()
-            gs = gba.solve(hm, hs, 10)
-            tg = time.perf_counter() - tg0
+            g_s = []
+            for _ in range(5):
+                gba.set_state(gb["poses"], gb["points"])
+                torch.cuda.synchronize()
+                tg0 = time.perf_counter()
+                gs = gba.solve(hm, hs, 10)
+                g_s.append(time.perf_counter() - tg0)
+            tg = float(np.median(g_s))
             gba.close()
             out["global_ba"] = {"workload": f"{len(gb['poses'])} KF x {len(gb['points'])} pts, {len(gb['e_cam'])} edges, "
                                             f"{6 * (len(gb['poses']) - 1)}-wide reduced system, 10 LM iterations",
                                 "lm_iters_per_s": round(gs.iterations / tg, 1), "ms_per_iter": round(tg / gs.iterations * 1e3, 3),
-                                "dtype": "f64", "sharding": "single GPU"}
+                                "dtype": "f64", "sharding": "single GPU", "timing": f"median of {len(g_s)} solves"}
             # SURVEY 8d's F_ba prices the reduced system's factorisation dense ((6 nc)^3 / 3: what Ceres' DENSE_SCHUR does);
             # the device factors it on the plan of its tile structure: flops EXECUTED = F_ba - dense term + tile products
             # (2 x 64^3 each) + one 64^3 solve per sub-diagonal tile + 64^3 / 3 per diagonal tile

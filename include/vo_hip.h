@@ -225,7 +225,8 @@ int vo_frames_features_in_area(vo_frames *h, int slot, int n_queries, const floa
 typedef struct {
   int32_t n_queries;          /* queries per frame (upper bound when n_per_frame is given) */
   int32_t stride;             /* distance between the query blocks of consecutive frames (>= n_queries) */
-  const int32_t *n_per_frame; /* device, or NULL */
+  const int32_t *n_per_frame; /* device, or NULL; a NEGATIVE entry leaves the frame out of the call: nothing of it is
+                                 read or written (assigned, best_idx, n_matches keep their values) */
   const uint8_t *flags;       /* bit 0 valid, bit 1 the query's map point has observations (see below) */
   const float *u, *v, *aux;
   const int32_t *level;
@@ -507,9 +508,16 @@ int vo_track_gather_dev(vo_frames *h, int slot0, int n_frames, const double *dev
  * single_stream != 0).  Several trackers that share one extract_stream take turns on the extraction
  * while each other's searches and solves run next to it (two batches in flight: bench.py's regime).
  *
- * Not covered (the caller's control flow): the retry with 2 x radius when fewer than 20 matches are
- * found (:241-245), trackRefKeyFrame and relocalisation; status bit VO_TRACK_FEW_MATCHES /
- * VO_TRACK_FEW_INLIERS tell the caller that the reference would have left trackWithMotion (:247, :253).
+ * The retry of trackWithMotion -- fewer than 20 matches: clear, search again at 2 x radius (:241-245) -- runs on the
+ * device for the frames that need it (a per-frame flag, a second candidate / replay pass over the flagged frames only).
+ * Status bits VO_TRACK_FEW_MATCHES / VO_TRACK_FEW_INLIERS tell the caller that the reference would have left
+ * trackWithMotion (:247, :253); the route it takes then is vo_tracker_track_ref_keyframe below (trackRefKeyFrame,
+ * :256-277).  Not covered: relocalisation (:307-402, PnP RANSAC over BoW candidates -- control plane around
+ * vo_match_bow / vo_match_frame_keyframe / vo_pose_only_solve), and the map-side steps between the two stages:
+ * trackLocalMap derives localKeyframes_ / localMappoints_ from frame_curr_->mappoints_ AFTER the first stage's culling
+ * (updateLocalKeyFrames / updateLocalMapPoints, :286-291), whereas this call takes the local map BEFORE it starts.  A
+ * caller that needs the reference's order runs the two stages as two calls: vo_tracker_track with an empty local map
+ * (max_local points, n = 0), derives the local map from VO_TRACKER_ASSIGNED_LAST, then vo_tracker_track_local_map.
  * ------------------------------------------------------------------------------------------ */
 typedef struct vo_tracker vo_tracker;
 typedef struct {
@@ -530,6 +538,9 @@ typedef struct {
   float th_radius;  /* searchByProjection(frame, local points): 3 (5 just after relocalisation, :793-794) */
   float ratio;      /* Matcher(0.8) */
   int32_t direction; /* matcher.cpp:70-75: 0 none, 1 forward, 2 backward */
+  float ref_ratio;   /* vo_tracker_track_ref_keyframe: Matcher(0.7) (:262); <= 0: 0.7 */
+  int32_t no_retry;  /* 0: a frame with < 20 matches is cleared and searched again at 2 x radius (:241-245), on the
+                        device, before the solve; 1: no second search (the status bit still reports < 20) */
 } vo_tracker_params;
 enum { VO_TRACK_FEW_MATCHES = 1, VO_TRACK_FEW_INLIERS = 2 };
 int vo_tracker_create(vo_tracker **out, const vo_tracker_config *cfg);
@@ -561,6 +572,37 @@ int vo_tracker_track_dev(vo_tracker *t, const uint8_t *dev_images, int image_pit
                          const vo_tracker_params *params);
 int vo_tracker_track(vo_tracker *t, const uint8_t *images, const void *depth, int depth_kind,
                      const vo_tracker_params *params);
+/* The two stages as two calls (the reference's order: updateLocalKeyFrames / updateLocalMapPoints derive the local map
+ * from the matches of the first stage, visualOdometry.cpp:286-291).  vo_tracker_track_first[_dev]: Frame construction,
+ * trackWithMotion's search (+ retry), solvePoseOnlySE3, cullingOutliersBeforeLocalMap; vo_tracker_results then returns
+ * the first solve's pose, n_tracked = the culling's observed-inlier count (:250), n_inliers = the solve's return value,
+ * the status bits of :247 / :253.  vo_tracker_track_local_map: searchLocalMapPoints, solvePoseOnlySE3 and the inlier
+ * count on the state the first stage left, against the local map set in between (vo_tracker_set_local_map). */
+int vo_tracker_track_first(vo_tracker *t, const uint8_t *images, const void *depth, int depth_kind,
+                           const vo_tracker_params *params);
+int vo_tracker_track_first_dev(vo_tracker *t, const uint8_t *dev_images, int image_pitch, size_t image_frame_stride,
+                               const void *dev_depth, int depth_kind, size_t depth_frame_stride, int depth_pitch,
+                               const vo_tracker_params *params);
+int vo_tracker_track_local_map(vo_tracker *t, const vo_tracker_params *params);
+/* VisualOdometry::trackRefKeyFrame (visualOdometry.cpp:256-277) -- the route taken when trackWithMotion fails --
+ * followed by trackLocalMap (first_stage_only = 0) or on its own (1): Frame construction, Frame::computeBow (vocabulary
+ * transform on the device), Matcher(0.7).searchByBoW(keyframe_trackRef_, frame) (k_node_replay, one workgroup per
+ * frame of the batch), `match_num < 15` -> VO_TRACK_FEW_MATCHES, the key-frame's map points into the frame's slots,
+ * pose = frame_last_->Tcw_, solvePoseOnlySE3, cullingOutliersBeforeLocalMap.  vo_tracker_set_ref_keyframe: per frame of
+ * the batch its reference key-frame's features [batch][n]: the map point of every feature (world position; flags bit 0:
+ * exists and is not bad, bit 1: observe_cnt_ > 0), the feature's angle and descriptor, its DBoW3::FeatureVector
+ * (nodes[batch], levelsup 3) and Tcw12 [batch][12] = frame_last_->Tcw_.  It REPLACES the last-frame state
+ * (vo_tracker_set_last_frame): the key-frame's map points take the place of frame_last_->mappoints_ for the rest of the
+ * pipeline (`link` of vo_tracker_set_local_map then indexes the key-frame's features).  The vocabulary must outlive
+ * the tracker's use of it.  The common-node walk is host work: this route synchronises once inside the call. */
+int vo_tracker_set_ref_keyframe(vo_tracker *t, const vo_vocab *vocab, int n, const double *Tcw12, const double *points,
+                                const uint8_t *flags, const float *angle, const uint8_t *desc,
+                                const vo_bow_view *const *nodes);
+int vo_tracker_track_ref_keyframe(vo_tracker *t, const uint8_t *images, const void *depth, int depth_kind,
+                                  const vo_tracker_params *params, int first_stage_only);
+int vo_tracker_track_ref_keyframe_dev(vo_tracker *t, const uint8_t *dev_images, int image_pitch, size_t image_frame_stride,
+                                      const void *dev_depth, int depth_kind, size_t depth_frame_stride, int depth_pitch,
+                                      const vo_tracker_params *params, int first_stage_only);
 /* Waits for the batch and copies out (any pointer may be NULL): poses as se3 [batch][6] and as Tcw
  * [batch][12]; n_tracked = inliers of the second solve whose map point has observations (inliers_num_,
  * :289-300); n_inliers = the second solve's return value; the two searches' match counts; status bits.

@@ -435,6 +435,33 @@ def test_large_system_local_ba_matches_oracle(vo, orc, n_kf, n_pts, seed):
     assert np.allclose([sums[0].final_cost, sums[1].final_cost], [osums[0].final_cost, osums[1].final_cost], rtol=1e-8)
 
 
+def test_large_system_with_an_isolated_straddling_camera(vo, orc, monkeypatch):
+    """64 is not a multiple of 6, so the 6x6 diagonal block of slot 10 (rows 60..65) lies in tiles (0,0), (1,0)
+    and (1,1).  Here slot 10 is covisible with slot 30 only and no pair joins tiles 0 and 1 otherwise: tile (1,0) must be
+    in the plan all the same, or rows 64-65 x cols 60-63 of that camera block are dropped silently."""
+    from vo_slam_test_amd import synth
+    monkeypatch.setenv("VO_BA_ORDER_PARTS", "1")  # natural order: slot = camera - 1
+    pr = synth.make_lba_problem(7, n_kf=32, n_pts=1600, n_fixed=0, outlier_frac=0.0)
+    pairs = [(10, 30)] + [(a, a + 1) for a in list(range(0, 10, 2)) + list(range(11, 30, 2))]
+    member = {}
+    for g, (a, b) in enumerate(pairs):
+        member[g] = {a + 1, b + 1}
+    grp = pr["e_pt"] % len(pairs)
+    keep = np.array([c == 0 or c in member[g] for c, g in zip(pr["e_cam"], grp)])
+    for k in ("e_cam", "e_pt", "e_obs", "e_inv_sigma"):
+        pr[k] = np.ascontiguousarray(pr[k][keep])
+    ba = vo.BundleAdjuster(pr)
+    assert 6 * ba.n_free_cams() + 1 > 128
+    erase, sums, rc = ba.local_ba()
+    poses, pts = ba.state()
+    ba.close()
+    oposes, opts, oerase, osums, orc_rc = orc.local_ba(pr)
+    assert rc == 0 == orc_rc
+    assert [sums[0].iterations, sums[1].iterations] == [osums[0].iterations, osums[1].iterations]
+    assert np.array_equal(erase, oerase)
+    assert np.abs(poses - oposes).max() < 1e-7
+
+
 def test_loop_closure_edge_cases(vo, orc):
     from vo_slam_test_amd import synth
     # Sim3 with no matches / a batch mixing an empty problem with a real one

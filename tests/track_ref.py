@@ -33,7 +33,72 @@ def is_in_frame(orc, pose6, local, valid, cam5, W, H, sf1, n_levels=8):
     return fl, u, v, ur, lv, vc
 
 
-def track_frame(orc, k, d, ux, uy, ur, T, pose6, last, local, cam5, sf, W=640, H=480, radius=15.0, th_radius=3.0, ratio=0.8):
+def local_map_stage(orc, of, k, ux, uy, ur, fpt, has, fobs, p1, a_first, n_first_list, local, cam5, sf, W, H, th_radius, ratio, solve):
+    """trackLocalMap from searchLocalMapPoints on (visualOdometry.cpp:745-775, :289-300): isInFrame with the refined pose
+    (points the first stage matched are skipped through `link`), the search, the second solve, the inlier count"""
+    n = len(k)
+    last_matched = np.zeros(n_first_list, bool)
+    last_matched[a_first[a_first >= 0]] = True
+    valid = np.asarray(local["valid"], np.uint8).copy()
+    lk = np.asarray(local.get("link", np.full(len(valid), -1)), np.int64)
+    skip = (lk >= 0) & last_matched[np.clip(lk, 0, max(n_first_list - 1, 0))] if n_first_list > 0 else np.zeros(len(valid), bool)
+    valid[skip] = 0
+    fl, lu, lv_, lur, llev, lvc = is_in_frame(orc, p1, local, valid, cam5, W, H, sf[1])
+    a1 = np.full(n, -1, np.int32)
+    n1 = 0
+    if len(fl) > 0:
+        n1 = orc.lib().orc_match_local_map(C.byref(of.c), len(fl), fl, lu, lv_, lur, llev, lvc, np.ascontiguousarray(local["desc"]),
+                                           float(th_radius), float(ratio), sf, fobs, a1)
+    new = a1 >= 0
+    fpt[new] = np.asarray(local["points"])[a1[new]]
+    fobs[new] = (fl[a1[new]] >> 1) & 1
+    has = has | new
+    p2, out2, i2, idx2 = solve(p1, has)
+    n_tracked = int(fobs[idx2[~out2]].sum())
+    return dict(local_flags=fl, local_u=lu, local_v=lv_, local_ur=lur, local_level=llev, local_viewcos=lvc, assigned_local=a1,
+                n_local=n1, pose_2=p2, inliers_2=i2, n_tracked=n_tracked, has=has)
+
+
+def track_frame_ref_keyframe(orc, k, d, ux, uy, ur, pose6_last, kf, node_of_frame_feature, local, cam5, sf, W=640, H=480,
+                             th_radius=3.0, ratio=0.8, ref_ratio=0.7):
+    """VisualOdometry::trackRefKeyFrame (visualOdometry.cpp:256-277) + trackLocalMap on the oracle: searchByBoW(key-frame,
+    frame) with Matcher(0.7), the key-frame's map points into the frame's slots, pose = frame_last_->Tcw_, solve, culling.
+    kf: dict(points, flags, angle, desc, nodes = per-feature node ids); node_of_frame_feature: the frame's FeatureVector."""
+    import oracle_lib as olib
+    n = len(k)
+    of = orc.FrameData(ux, uy, k["octave"], k["angle"], ur, d)
+    nk = len(kf["flags"])
+    okf = orc.FrameData(np.zeros(nk, np.float32), np.zeros(nk, np.float32), np.zeros(nk, np.int32), np.ascontiguousarray(kf["angle"], np.float32),
+                        np.full(nk, -1, np.float32), np.ascontiguousarray(kf["desc"]))
+    ba, bb = olib.BowData(kf["nodes"]), olib.BowData(node_of_frame_feature)
+    a0 = np.full(n, -1, np.int32)
+    va = (np.asarray(kf["flags"]) & 1).astype(np.uint8)
+    n0 = orc.lib().orc_match_bow(C.byref(okf.c), va, C.byref(ba.c), C.byref(of.c), np.ones(n, np.uint8), C.byref(bb.c), 0, float(ref_ratio), 1, a0)
+    fpt, has, fobs = np.zeros((n, 3)), a0 >= 0, np.zeros(n, np.uint8)
+    fpt[has] = np.asarray(kf["points"])[a0[has]]
+    fobs[has] = (np.asarray(kf["flags"])[a0[has]] >> 1) & 1
+    cam_d = np.asarray(cam5, np.float64)
+
+    def solve(pose_in, has_now):
+        idx = np.nonzero(has_now)[0]
+        pr = dict(pts=np.ascontiguousarray(fpt[idx]),
+                  obs=np.ascontiguousarray(np.stack([ux[idx], uy[idx], ur[idx]], 1).astype(np.float64)),
+                  inv_sigma=np.ascontiguousarray(1.0 / sf[k["octave"][idx]].astype(np.float64)), cam=cam_d, pose0=pose_in)
+        pose, outl, ninl, _, _ = orc.pose_only(pr)
+        return pose, np.asarray(outl, bool), ninl, idx
+
+    p1, out1, i1, idx1 = solve(np.asarray(pose6_last, np.float64), has)
+    n_obs1 = int(fobs[idx1[~out1]].sum())
+    has[idx1[out1]] = False
+    fobs[idx1[out1]] = 0
+    # matched points -- kept or culled -- carry visualIdxOfFrame_ == frame id (:752, :881): searchLocalMapPoints skips them
+    out = dict(assigned_first=a0, n_first=n0, pose_1=p1, inliers_1=i1, observed_inliers_1=n_obs1)
+    out.update(local_map_stage(orc, of, k, ux, uy, ur, fpt, has.copy(), fobs, p1, a0, nk, local, cam5, sf, W, H, th_radius, ratio, solve))
+    return out
+
+
+def track_frame(orc, k, d, ux, uy, ur, T, pose6, last, local, cam5, sf, W=640, H=480, radius=15.0, th_radius=3.0, ratio=0.8,
+                retry=True):
     """-> dict of every intermediate result of the path for one frame (k, d: the oracle's key-points and descriptors;
     ux, uy, ur: undistorted coordinates and uRight; T [12], pose6: the pose estimate; last / local: the map as
     synth.make_tracking_map builds it)"""
@@ -45,6 +110,13 @@ def track_frame(orc, k, d, ux, uy, ur, T, pose6, last, local, cam5, sf, W=640, H
     n0 = orc.lib().orc_match_frame_projection(C.byref(of.c), len(qf), qf, qu, qv, qz, np.ascontiguousarray(last["octave"], np.int32),
                                               np.ascontiguousarray(last["angle"], np.float32), np.ascontiguousarray(last["desc"]),
                                               float(radius), float(cam5[4]), 0, 1, 8, sf, np.zeros(n, np.uint8), a0)
+    retried = False
+    if retry and n0 < 20:  # visualOdometry.cpp:241-245: clear, search again at twice the radius
+        retried = True
+        a0 = np.full(n, -1, np.int32)
+        n0 = orc.lib().orc_match_frame_projection(C.byref(of.c), len(qf), qf, qu, qv, qz, np.ascontiguousarray(last["octave"], np.int32),
+                                                  np.ascontiguousarray(last["angle"], np.float32), np.ascontiguousarray(last["desc"]),
+                                                  float(2 * radius), float(cam5[4]), 0, 1, 8, sf, np.zeros(n, np.uint8), a0)
     fpt, has, fobs = np.zeros((n, 3)), a0 >= 0, np.zeros(n, np.uint8)
     fpt[has] = last["points"][a0[has]]
     fobs[has] = (qf[a0[has]] >> 1) & 1
@@ -79,6 +151,6 @@ def track_frame(orc, k, d, ux, uy, ur, T, pose6, last, local, cam5, sf, W=640, H
     has = has | new
     p2, out2, i2, idx2 = solve(p1)
     n_tracked = int(fobs[idx2[~out2]].sum())
-    return dict(assigned_last=a0, n_last=n0, pose_1=p1, inliers_1=i1, observed_inliers_1=n_obs1, local_flags=fl, local_u=lu,
+    return dict(retried=retried, assigned_last=a0, n_last=n0, pose_1=p1, inliers_1=i1, observed_inliers_1=n_obs1, local_flags=fl, local_u=lu,
                 local_v=lv_, local_ur=lur, local_level=llev, local_viewcos=lvc, assigned_local=a1, n_local=n1, pose_2=p2,
                 inliers_2=i2, n_tracked=n_tracked, has=has)

@@ -7,7 +7,6 @@ name=$1; shift
 mkdir -p vo_slam_test_amd/_variants
 C="-O3 -std=c++17 --offload-arch=gfx950 -fPIC -Wall -Wno-unused-function"
 /opt/rocm/bin/hipcc $C -ffp-contract=off "$@" -c vo_slam_test_amd/csrc/orb.hip -o vo_slam_test_amd/_obj/orb_$name.o
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o vo_slam_test_amd/_variants/libvo_$name.so \
-  vo_slam_test_amd/_obj/vo_common.o vo_slam_test_amd/_obj/orb_$name.o vo_slam_test_amd/_obj/match.o \
-  vo_slam_test_amd/_obj/ba.o vo_slam_test_amd/_obj/pose_graph.o vo_slam_test_amd/_obj/chol.o vo_slam_test_amd/_obj/guided.o vo_slam_test_amd/_obj/track.o vo_slam_test_amd/_obj/loop.o vo_slam_test_amd/_obj/dataset_io.o -lz
+others=$(ls vo_slam_test_amd/_obj/*.o | grep -v '/orb' )
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o vo_slam_test_amd/_variants/libvo_$name.so $others vo_slam_test_amd/_obj/orb_$name.o -lz
 echo built vo_slam_test_amd/_variants/libvo_$name.so

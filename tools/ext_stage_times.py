@@ -5,7 +5,8 @@ sys.path.insert(0, str(pathlib.Path(__file__).resolve().parent.parent))
 import torch  # noqa: E402
 from vo_slam_test_amd import _lib as vo, synth  # noqa: E402
 
-B = 256
+import os
+B = int(os.environ.get('VO_EXT_B', '1024'))
 stream = torch.cuda.Stream()
 ext = vo.OrbExtractor(1000, 1.2, 8, 20, 7)
 ext.set_stream(stream.cuda_stream)
@@ -19,7 +20,7 @@ with torch.cuda.stream(stream):
         ext.extract_batch_dev(frames, kps, desc, cnt)
     torch.cuda.synchronize()
     ext.set_timing(True)
-    for _ in range(10):
+    for _ in range(int(os.environ.get('VO_EXT_REPS', '10'))):
         ext.extract_batch_dev(frames, kps, desc, cnt)
     torch.cuda.synchronize()
 ms, n = ext.get_timing()

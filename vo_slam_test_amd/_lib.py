@@ -47,6 +47,8 @@ SYMBOLS = [
     "vo_dataset_open", "vo_dataset_size", "vo_dataset_entry", "vo_dataset_close", "vo_png_info", "vo_png_read",
     "vo_trajectory_write", "vo_tracking_time_stats",
     "vo_track_project_dev", "vo_track_scatter_dev", "vo_track_gather_dev", "vo_pose_only_solve_ranges_dev",
+    "vo_tracker_track_first", "vo_tracker_track_first_dev", "vo_tracker_track_local_map", "vo_tracker_set_ref_keyframe",
+    "vo_tracker_track_ref_keyframe", "vo_tracker_track_ref_keyframe_dev",
     "vo_tracker_create", "vo_tracker_destroy", "vo_tracker_info", "vo_tracker_extractor", "vo_tracker_frames",
     "vo_tracker_stream", "vo_tracker_set_last_frame", "vo_tracker_set_local_map", "vo_tracker_track_dev", "vo_tracker_track",
     "vo_tracker_results", "vo_tracker_get", "vo_tracker_sync", "vo_tracker_set_timing", "vo_tracker_get_timing",
@@ -392,7 +394,8 @@ class TrackerConfig(C.Structure):
 
 
 class TrackerParams(C.Structure):
-    _fields_ = [("radius", C.c_float), ("th_radius", C.c_float), ("ratio", C.c_float), ("direction", C.c_int32)]
+    _fields_ = [("radius", C.c_float), ("th_radius", C.c_float), ("ratio", C.c_float), ("direction", C.c_int32),
+                ("ref_ratio", C.c_float), ("no_retry", C.c_int32)]
 
 
 class Tracker:
@@ -469,28 +472,67 @@ class Tracker:
                                              _p(lk), _p(a(desc, np.uint8))), "vo_tracker_set_local_map")
 
     @staticmethod
-    def _params(radius, th_radius, ratio, direction):
-        return TrackerParams(float(radius), float(th_radius), float(ratio), int(direction))
+    def _params(radius, th_radius, ratio, direction, no_retry=False):
+        return TrackerParams(float(radius), float(th_radius), float(ratio), int(direction), 0.7, int(bool(no_retry)))
 
-    def track_dev(self, images, depth=None, radius=15.0, th_radius=3.0, ratio=0.8, direction=0):
+    def track_dev(self, images, depth=None, radius=15.0, th_radius=3.0, ratio=0.8, direction=0, no_retry=False):
         """images: uint8 [B,H,W] device tensor; depth: float32 or (u)int16 [B,H,W] device tensor or None.  Asynchronous."""
         kind, fs, pitch = 0, 0, 0
         if depth is not None:
             kind = 1 if depth.element_size() == 4 else 2
             fs, pitch = depth.stride(0) * depth.element_size(), depth.stride(1) * depth.element_size()
-        pr = self._params(radius, th_radius, ratio, direction)
+        pr = self._params(radius, th_radius, ratio, direction, no_retry)
         check(lib().vo_tracker_track_dev(self._h, _p(images), int(images.stride(1)), C.c_size_t(images.stride(0)), _p(depth),
                                          kind, C.c_size_t(fs), int(pitch), C.byref(pr)), "vo_tracker_track_dev")
 
-    def track(self, images, depth=None, radius=15.0, th_radius=3.0, ratio=0.8, direction=0):
+    def track(self, images, depth=None, radius=15.0, th_radius=3.0, ratio=0.8, direction=0, no_retry=False):
         """host arrays: images uint8 [B,H,W]; depth float32 / uint16 [B,H,W] or None (uploads included)."""
         img = np.ascontiguousarray(images, np.uint8)
         kind, dp = 0, None
         if depth is not None:
             dp = np.ascontiguousarray(depth)
             kind = 1 if dp.dtype == np.float32 else 2
-        pr = self._params(radius, th_radius, ratio, direction)
+        pr = self._params(radius, th_radius, ratio, direction, no_retry)
         check(lib().vo_tracker_track(self._h, _p(img), _p(dp), kind, C.byref(pr)), "vo_tracker_track")
+
+    def track_first(self, images, depth=None, radius=15.0, direction=0, no_retry=False):
+        """trackWithMotion alone (host arrays): Frame construction, search (+ retry), solve, culling; results() then holds
+        the first solve's pose / counts / status"""
+        img = np.ascontiguousarray(images, np.uint8)
+        kind, dp = 0, None
+        if depth is not None:
+            dp = np.ascontiguousarray(depth)
+            kind = 1 if dp.dtype == np.float32 else 2
+        pr = self._params(radius, 3.0, 0.8, direction, no_retry)
+        check(lib().vo_tracker_track_first(self._h, _p(img), _p(dp), kind, C.byref(pr)), "vo_tracker_track_first")
+
+    def track_local_map(self, th_radius=3.0, ratio=0.8):
+        """trackLocalMap on the state the first stage left, against the local map set in between"""
+        pr = self._params(15.0, th_radius, ratio, 0)
+        check(lib().vo_tracker_track_local_map(self._h, C.byref(pr)), "vo_tracker_track_local_map")
+
+    def set_ref_keyframe(self, vocab, Tcw12, points, flags, angle, desc, node_of_feature):
+        """arrays [B, n, ...]; node_of_feature [B, n]: the key-frame's DBoW3::FeatureVector as per-feature node ids"""
+        n = np.asarray(flags).shape[1]
+        a = lambda x, dt: np.ascontiguousarray(x, dt)
+        nodes = [BowNodes(np.asarray(node_of_feature)[f]) for f in range(self.B)]
+        arr = (C.POINTER(BowView) * self.B)(*[C.pointer(nd.view) for nd in nodes])
+        check(lib().vo_tracker_set_ref_keyframe(self._h, vocab._h, int(n), _p(a(Tcw12, np.float64)), _p(a(points, np.float64)),
+                                                _p(a(flags, np.uint8)), _p(a(angle, np.float32)), _p(a(desc, np.uint8)), arr),
+              "vo_tracker_set_ref_keyframe")
+        self._ref_vocab = vocab  # the C side keeps the pointer
+
+    def track_ref_keyframe(self, images, depth=None, th_radius=3.0, ratio=0.8, ref_ratio=0.7, first_stage_only=False):
+        """trackRefKeyFrame (+ trackLocalMap) from host arrays"""
+        img = np.ascontiguousarray(images, np.uint8)
+        kind, dp = 0, None
+        if depth is not None:
+            dp = np.ascontiguousarray(depth)
+            kind = 1 if dp.dtype == np.float32 else 2
+        pr = self._params(15.0, th_radius, ratio, 0)
+        pr.ref_ratio = float(ref_ratio)
+        check(lib().vo_tracker_track_ref_keyframe(self._h, _p(img), _p(dp), kind, C.byref(pr), int(bool(first_stage_only))),
+              "vo_tracker_track_ref_keyframe")
 
     def results(self):
         B = self.B

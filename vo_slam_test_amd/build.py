@@ -61,13 +61,17 @@ def build(force: bool = False, verbose: bool = False) -> pathlib.Path:
         if not s.exists():
             continue
         o = objdir / (s.stem + ".o")
+        objs.append(str(o))
+        # per-file rebuild: an object is current if it is newer than its source and every header / .inc of csrc/ and include/
+        deps = [s, PKG.parent / "include" / "vo_hip.h", pathlib.Path(__file__)] + [d for d in CSRC.glob("*") if d.suffix in (".h", ".inc")]
+        if not force and o.exists() and all(o.stat().st_mtime > d.stat().st_mtime for d in deps if d.exists()):
+            continue
         cmd = [cc, *COMMON, *extra, "-c", str(s), "-o", str(o)]
         if verbose:
             print(" ".join(cmd))
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:
             raise RuntimeError(f"hipcc failed on {src}:\n{r.stdout}\n{r.stderr}")
-        objs.append(str(o))
     cmd = [cc, f"--offload-arch={ARCH}", "-shared", "-fPIC", "-o", str(OUT), *objs, "-lz"]
     r = subprocess.run(cmd, capture_output=True, text=True)
     if r.returncode != 0:

@@ -979,6 +979,15 @@ static void tile_pattern(const std::vector<std::pair<int, int>> &pairs, const st
         pat[std::max(ti, tj)] |= 1ull << std::min(ti, tj);
   }
   for (int i = 0; i < m; i++) pat[i] |= 1ull << i;
+  // every block's own (s, s) pair: a block that straddles a tile boundary (64 is not a multiple of 6: slots 10, 21, 42,
+  // ...) also has entries in tile (k, k-1), whether or not it pairs with a slot-near neighbour
+  for (size_t s = 0; s < slot_of.size(); s++) {
+    const int a = slot_of[s];
+    if (a < 0) continue;
+    const int t0 = bs * a / vo::kCholPanel, t1 = (bs * a + bs - 1) / vo::kCholPanel;
+    for (int ti = t0; ti <= t1 && ti < m; ti++)
+      for (int tj = t0; tj <= ti; tj++) pat[ti] |= 1ull << tj;
+  }
 }
 
 vo::CholOrder vo::chol_choose_order(int nf, int bs, const std::vector<std::pair<int, int>> &pairs, int m, int force_parts) {

@@ -287,6 +287,7 @@ __global__ __launch_bounds__(256) void k_guided_cand(FramesDev F, Queries Q, Gui
   const int lane = threadIdx.x & 63, l16 = threadIdx.x & (G - 1), grp = threadIdx.x / G, sub = lane / G;
   const int f = blockIdx.y, q = blockIdx.x * QPB + grp;
   const int nq = Q.nq ? Q.nq[f] : Q.nq_all;
+  if (nq < 0) return;        // frame not part of this call (uniform over the workgroup)
   const bool live = q < nq;  // (groups past the end idle through the loops: the wave's ballots need every lane)
   const long long qo = (long long)f * Q.stride + (live ? q : 0);
   const int s = slot0 + f;
@@ -546,6 +547,7 @@ __global__ __launch_bounds__(64) void k_guided_replay(FramesDev F, Queries Q, Gu
   const int lane = threadIdx.x, row = lane >> 4, l16 = lane & 15, f = blockIdx.x, s = slot0 + f;
   const int nf = F.n[s];
   const int nq = Q.nq ? Q.nq[f] : Q.nq_all;
+  if (nq < 0) return;  // n_per_frame[f] < 0: the frame is not part of this call (nothing of it is read or written)
   uint8_t *blocked = rp_lds;                                                       // [capA]
   const int capA = (F.cap + 15) & ~15;
   unsigned short *asg = reinterpret_cast<unsigned short *>(rp_lds + capA);          // [cap]: query + 1, 0 = none
@@ -839,6 +841,7 @@ __global__ __launch_bounds__(256) void k_guided_count(Queries Q, const int *best
   __shared__ int tot;
   const int f = blockIdx.x;
   const int nq = Q.nq ? Q.nq[f] : Q.nq_all;
+  if (nq < 0) return;  // frame not part of this call
   if (threadIdx.x == 0) tot = 0;
   __syncthreads();
   int c = 0;
@@ -1425,5 +1428,9 @@ int vo_match_sim3_mutual(const vo_frame_view *kf1, const vo_frame_view *kf2, con
 }
 
 }  // extern "C"
+
+vo::FrameStoreView vo::frame_store_view(const vo_frames *h) {
+  return vo::FrameStoreView{h->cap, h->D.desc, h->D.angle, h->D.n};
+}
 
 const int *vo::guided_error_flag(const vo_frames *h) { return h ? h->b_err.as<int>() : nullptr; }

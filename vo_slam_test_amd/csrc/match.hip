@@ -683,3 +683,113 @@ int vo_bow_transform(const vo_vocab *v, int n, const uint8_t *desc, int levelsup
 }
 
 }  // extern "C"
+
+// ---- trackRefKeyFrame's search with the current frames resident in a frame store (vo_common.h) --------------------
+int vo::bow_search_resident(const vo_vocab *v, vo_frames *frames, int slot0, int B, const vo::RefKeyFrame *kfs, float ratio,
+                            int check_rot, int levelsup, int32_t *dev_assigned, int cap, int32_t *dev_n_matches, hipStream_t st) {
+  if (!v || !frames || B < 1 || !kfs || !dev_assigned || !dev_n_matches) return VO_ERR_INVALID;
+  const vo::FrameStoreView fs = vo::frame_store_view(frames);
+  if (fs.cap != cap || cap > kNodeMaxB) {
+    vo::set_error("BoW search on resident frames: %d feature slots per frame (the store has %d, the kernel handles %d)", cap, fs.cap, kNodeMaxB);
+    return VO_ERR_CAPACITY;
+  }
+  const char *what = "trackRefKeyFrame search";
+  // Frame::computeBow (frame.cpp:248-253): the node of every feature at level L - levelsup, straight from the store's slots
+  thread_local vo::ScratchBuf d_w, d_wt, d_node, d_img;
+  thread_local vo::PinnedBuf stage;
+  const size_t N = (size_t)B * cap;
+  VO_CHECK(d_w.reserve(N * 4));
+  VO_CHECK(d_wt.reserve(N * 8));
+  VO_CHECK(d_node.reserve(N * 4));
+  hipLaunchKernelGGL(k_bow_transform, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, st, v->V, (int)N,
+                     reinterpret_cast<const uint32_t *>(fs.desc + (size_t)slot0 * cap * 32), levelsup, d_w.as<int>(), d_wt.as<double>(),
+                     d_node.as<int>());
+  VO_HIP_CHECK(hipGetLastError());
+  VO_CHECK(stage.reserve(N * 4 + (size_t)B * 4 + 64));
+  int *h_node = reinterpret_cast<int *>(stage.data()), *h_n = h_node + N;
+  VO_CHECK(vo::copy_d2h(h_node, d_node.p, N * 4, st, what));
+  VO_CHECK(vo::copy_d2h(h_n, fs.n + slot0, (size_t)B * 4, st, what));
+  VO_CHECK(vo::stream_sync(st, what));
+  // host: per frame its FeatureVector (node ids ascending, the features of a node in index order), the walk over the
+  // nodes it shares with its key-frame, the query list in the reference's visiting order (matcher.cpp:465-545)
+  std::vector<uint8_t> img;
+  auto put = [&](const void *src, size_t bytes) {
+    const size_t off = (img.size() + 15) & ~(size_t)15;
+    img.resize(off + std::max<size_t>(bytes, 16));
+    if (bytes && src) memcpy(img.data() + off, src, bytes);
+    return off;
+  };
+  const size_t args_off = put(nullptr, (size_t)B * sizeof(NodeArgs));
+  struct Off { size_t q, bf, ok, adesc, aang, claims; int nq, nB; };
+  std::vector<Off> off((size_t)B);
+  size_t claims_bytes = 0;
+  int max_b = 1;
+  std::vector<int> order, queries;
+  std::vector<uint32_t> bfeat;
+  std::vector<int32_t> bnode, bstart;
+  for (int f = 0; f < B; f++) {
+    const vo::RefKeyFrame &K = kfs[f];
+    const int nB = std::min(std::max(h_n[f], 0), cap);
+    const int *node = h_node + (size_t)f * cap;
+    order.resize((size_t)nB);
+    for (int i = 0; i < nB; i++) order[i] = i;
+    std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return node[a] < node[b]; });
+    bfeat.assign(order.begin(), order.end());
+    bnode.clear(), bstart.clear();
+    for (int i = 0; i < nB; i++)
+      if (i == 0 || node[order[i]] != node[order[i - 1]]) bnode.push_back(node[order[i]]), bstart.push_back(i);
+    bstart.push_back(nB);
+    std::vector<uint32_t> bnode_u(bnode.begin(), bnode.end());
+    const vo_bow_view bv{(int32_t)bnode.size(), bnode_u.data(), bstart.data(), bfeat.data()};
+    queries.clear();
+    if (K.n > 0 && nB > 0 && K.nodes)
+      for_common_nodes(*K.nodes, bv, [&](int ia, int ib) {
+        for (int t = K.nodes->start[ia]; t < K.nodes->start[ia + 1]; t++) {
+          const int i1 = (int)K.nodes->feat[t];
+          if (!K.valid[i1]) continue;  // `if (!mpk || mpk->isBad()) continue;` :475-477
+          queries.push_back(i1), queries.push_back(bstart[ib]), queries.push_back(bstart[ib + 1]), queries.push_back(0);
+        }
+      });
+    Off &o = off[f];
+    o.nq = (int)queries.size() / 4, o.nB = nB;
+    o.q = put(queries.data(), queries.size() * 4);
+    o.bf = put(bfeat.data(), (size_t)nB * 4);
+    std::vector<uint8_t> ok((size_t)std::max(nB, 1), 1);
+    o.ok = put(ok.data(), ok.size());
+    o.adesc = put(K.desc, (size_t)K.n * 32);
+    o.aang = put(K.angle, (size_t)K.n * 4);
+    o.claims = claims_bytes;
+    claims_bytes += ((size_t)std::max(o.nq, 1) * 16 + 15) & ~(size_t)15;
+    max_b = std::max(max_b, nB);
+  }
+  const size_t img_bytes = (img.size() + 255) & ~(size_t)255;
+  VO_CHECK(d_img.reserve(img_bytes + claims_bytes + 256));
+  uint8_t *d = d_img.as<uint8_t>();
+  NodeArgs *hargs = reinterpret_cast<NodeArgs *>(img.data() + args_off);
+  for (int f = 0; f < B; f++) {
+    const Off &o = off[f];
+    NodeArgs P{};
+    P.mode = kNodeBow0, P.nq = o.nq, P.nA = kfs[f].n, P.nB = o.nB, P.check_rot = check_rot, P.ratio = ratio;
+    for (int i = 0; i < 16; i++) P.sf[i] = 1.f;
+    P.queries = reinterpret_cast<const int4 *>(d + o.q), P.bfeat = reinterpret_cast<const uint32_t *>(d + o.bf);
+    P.descA = reinterpret_cast<const uint4 *>(d + o.adesc);
+    P.descB = reinterpret_cast<const uint4 *>(fs.desc + (size_t)(slot0 + f) * cap * 32);
+    P.angA = reinterpret_cast<const float *>(d + o.aang), P.angB = fs.angle + (size_t)(slot0 + f) * cap;
+    P.b_ok = d + o.ok;
+    P.claims = reinterpret_cast<int4 *>(d + img_bytes + o.claims);
+    P.match = dev_assigned + (size_t)f * cap;
+    P.n_matches = dev_n_matches + f;
+    hargs[f] = P;
+  }
+  thread_local vo::PinnedBuf up;
+  VO_CHECK(up.reserve(img.size()));
+  memcpy(up.data(), img.data(), img.size());
+  VO_CHECK(vo::copy_h2d(d, up.data(), img.size(), st, what));
+  const size_t lds = (((size_t)max_b + 15) & ~(size_t)15) * 5;
+  if (lds > 64 * 1024) (void)hipFuncSetAttribute((const void *)k_node_replay, hipFuncAttributeMaxDynamicSharedMemorySize, kNodeMaxB * 5);
+  hipLaunchKernelGGL(k_node_replay, dim3((unsigned)B), dim3(64), lds, st, reinterpret_cast<const NodeArgs *>(d + args_off));
+  VO_HIP_CHECK(hipGetLastError());
+  VO_CHECK(vo::stream_sync(st, what));  // `up` is reused by the calling thread's next call
+  return VO_OK;
+}
+

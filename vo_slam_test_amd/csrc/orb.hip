@@ -123,6 +123,12 @@ __device__ __forceinline__ int dot2_i16(unsigned taps, unsigned coef) {
   return __builtin_amdgcn_sdot2(__builtin_bit_cast(short2_t, taps), __builtin_bit_cast(short2_t, coef), 0, false);
 }
 
+#ifndef VO_FAST_REFINE
+#define VO_FAST_REFINE 2  // developer A/B switches (tools/ab_orb.sh): 0 off, 1 every round, 2 = product: the minThFAST round only
+#endif
+#ifndef VO_FAST_ARC16
+#define VO_FAST_ARC16 1
+#endif
 #ifndef VO_RZ_ABLATE
 #define VO_RZ_ABLATE 0  // developer ablation switch (tools/rz_ablate.py); 0 in the product build
 #endif
@@ -294,18 +300,44 @@ __device__ __forceinline__ int fast_arc_score(const lds_u8 *ring, int min_th) {
   r[13] = ring[C + RP - 3];
   r[14] = ring[C + 2 * RP - 2];
   r[15] = ring[C + 3 * RP - 1];
-  int mn3[16], mx3[16];
+  // three-extrema of consecutive ring pixels on the 16-bit VOP2 min / max (the class that issues at ~2.2 cycles, section 7
+  // of DESIGN.md; the compiler's own v_min_u32 / v_max_u32 issue at 4.2): four ring positions per asm block, 12 operations
+  unsigned mn3[16], mx3[16];
+#if !VO_FAST_ARC16
 #pragma unroll
   for (int k = 0; k < 16; k++) {
-    mn3[k] = min(r[k], min(r[(k + 1) & 15], r[(k + 2) & 15]));
-    mx3[k] = max(r[k], max(r[(k + 1) & 15], r[(k + 2) & 15]));
+    mn3[k] = (unsigned)min(r[k], min(r[(k + 1) & 15], r[(k + 2) & 15]));
+    mx3[k] = (unsigned)max(r[k], max(r[(k + 1) & 15], r[(k + 2) & 15]));
   }
-  int A = 1000, B = -1000;
+#else
 #pragma unroll
-  for (int k = 0; k < 16; k++) {
-    A = min(A, max(mx3[k], max(mx3[(k + 3) & 15], mx3[(k + 6) & 15])));
-    B = max(B, min(mn3[k], min(mn3[(k + 3) & 15], mn3[(k + 6) & 15])));
+  for (int k = 0; k < 16; k += 4) {
+    unsigned t0, t1;
+    asm("v_min_u16 %8, %11, %12\n\t"
+        "v_min_u16 %9, %13, %14\n\t"
+        "v_min_u16 %0, %10, %8\n\t"
+        "v_min_u16 %1, %8, %13\n\t"
+        "v_min_u16 %2, %12, %9\n\t"
+        "v_min_u16 %3, %9, %15\n\t"
+        "v_max_u16 %8, %11, %12\n\t"
+        "v_max_u16 %9, %13, %14\n\t"
+        "v_max_u16 %4, %10, %8\n\t"
+        "v_max_u16 %5, %8, %13\n\t"
+        "v_max_u16 %6, %12, %9\n\t"
+        "v_max_u16 %7, %9, %15"
+        : "=&v"(mn3[k]), "=&v"(mn3[k + 1]), "=&v"(mn3[k + 2]), "=&v"(mn3[k + 3]), "=&v"(mx3[k]), "=&v"(mx3[k + 1]),
+          "=&v"(mx3[k + 2]), "=&v"(mx3[k + 3]), "=&v"(t0), "=&v"(t1)
+        : "v"((unsigned)r[k]), "v"((unsigned)r[(k + 1) & 15]), "v"((unsigned)r[(k + 2) & 15]), "v"((unsigned)r[(k + 3) & 15]),
+          "v"((unsigned)r[(k + 4) & 15]), "v"((unsigned)r[(k + 5) & 15]));
   }
+#endif
+  unsigned Au = max(mx3[0], max(mx3[3], mx3[6])), Bu = min(mn3[0], min(mn3[3], mn3[6]));
+#pragma unroll
+  for (int k = 1; k < 16; k++) {
+    Au = min(Au, max(mx3[k], max(mx3[(k + 3) & 15], mx3[(k + 6) & 15])));
+    Bu = max(Bu, min(mn3[k], min(mn3[(k + 3) & 15], mn3[(k + 6) & 15])));
+  }
+  const int A = (int)Au, B = (int)Bu;
   const int S = max(v - A, B - v);
   return S > min_th ? S - 1 : 0;
 }
@@ -504,6 +536,33 @@ __global__ __launch_bounds__(256) void k_fast_cell(OrbDev P, FrameSrc src, uint3
     return __builtin_amdgcn_readlane(n, 0);  // lane 0 always takes part
   };
   uint32_t *slot = cell_slots + (long long)f * slots_frame_stride + slot_off;
+  // Second-level bound for long lists (a cell redone at minThFAST lists ~1/5 of its pixels, noise for the most part):
+  // the compass argument holds for ANY four ring pixels a quarter turn apart, so S is also bounded by the margin of the
+  // rings (K, K + 4, K + 8, K + 12), K = 1, 2, 3.  Entries whose bound does not exceed th cannot be corners at th and, as
+  // neighbours, score below every kept pixel (S - 1 < th): dropping them -- score entry left at 0 -- changes nothing.
+  // The list is compacted in place, order preserved (a lane writes at or before its own position, after every lane of
+  // the batch has read; LDS operations of one wavefront execute in order).  ~14 fast-class instructions per 64 entries
+  // against ~105 for their arc scores; the second bound halves a minThFAST list, the third takes another third.
+  auto refine_list = [&](int n, int th, auto load_ring) {
+    int kept = 0;
+    const unsigned thv = (unsigned)th;
+    for (int base = 0; base < n; base += 64) {
+      // lanes past the list repeat its last entry (no divergence around the asm block); their mask bits are cleared
+      const unsigned short e = plist[min(base + lane, n - 1)];
+      const int rem = n - base;  // uniform
+      const unsigned long long valid = rem >= 64 ? ~0ull : ((1ull << rem) - 1ull);
+      const unsigned long long mask = margin_gt(load_ring((const lds_u8 *)(uintptr_t)(unsigned)e), thv) & valid;
+      const int pos = (int)__builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mask, (unsigned)kept));
+      if (__builtin_amdgcn_inverse_ballot_w64(mask)) plist[pos] = e;
+      kept += __popcll(mask);
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // LDS operations of one wavefront execute in order: the next batch
+      __builtin_amdgcn_wave_barrier();                    // reads behind these writes (no memory fence needed)
+    }
+    return kept;
+  };
+  auto ring_k2 = [&](const lds_u8 *b) { return Ring5{b[3 * TP + 3], b[5 * TP + 5], b[TP + 5], b[TP + 1], b[5 * TP + 1]}; };
+  auto ring_k1 = [&](const lds_u8 *b) { return Ring5{b[3 * TP + 3], b[6 * TP + 4], b[2 * TP + 6], b[2], b[4 * TP]}; };
+  auto ring_k3 = [&](const lds_u8 *b) { return Ring5{b[3 * TP + 3], b[4 * TP + 6], b[4], b[2 * TP], b[6 * TP + 2]}; };
   auto score_list = [&](int n) {
     for (int i = lane; i < n; i += 64) {
       lds_u8 *b = (lds_u8 *)(uintptr_t)(unsigned)plist[i];
@@ -540,9 +599,19 @@ __global__ __launch_bounds__(256) void k_fast_cell(OrbDev P, FrameSrc src, uint3
   for (int round = 0; round < 2; round++) {
     // a cell with no key-point at iniThFAST is redone at minThFAST (:820-824)
     const int th = round == 0 ? P.ini_th : P.min_th;
-    const int np = walk(th, 0, ih);
+    const int np0 = walk(th, 0, ih);
     wave_sync();
+    int np = np0;
     if (np <= list_cap - 64) {  // uniform, the usual case (the walk's appends clamp their base 64 entries before the end)
+#if VO_FAST_REFINE
+      // (only in the minThFAST round: at iniThFAST the further bounds reject ~15 % of a list -- three passes for nothing,
+      //  measured +3 % on the kernel -- while they take a minThFAST list from ~170 entries to ~55)
+      if (VO_FAST_REFINE == 1 || round == 1) {
+        if (np > 64) np = refine_list(np, th, ring_k2);
+        if (np > 64) np = refine_list(np, th, ring_k1);
+        if (np > 64) np = refine_list(np, th, ring_k3);
+      }
+#endif
       score_list(np);
       wave_sync();
       running = nms_list(np, th, 0);

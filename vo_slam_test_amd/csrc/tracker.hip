@@ -42,6 +42,22 @@ __global__ __launch_bounds__(256) void k_track_prep(int cap, int last_stride, in
   if (tid < 6) pose[6 * f + tid] = pose0[6 * f + tid];
 }
 
+// trackWithMotion's retry (visualOdometry.cpp:241-245): a frame whose first search found fewer than 20 matches has its
+// map-point slots cleared (`fill(mappoints_, nullptr)`) and is searched again at twice the radius.  Per frame: the query
+// count of the second guided call (negative = the frame is left out of it, include/vo_hip.h) and the cleared assignments.
+__global__ __launch_bounds__(256) void k_track_retry_prep(int cap, int nq_last, const int *nm_first, int *assigned, int *retry_nq,
+                                                          int *n_retried) {
+  const int f = blockIdx.x, tid = threadIdx.x;
+  const bool retry = nm_first[f] < 20;
+  if (tid == 0) {
+    retry_nq[f] = retry ? nq_last : -1;
+    if (retry) atomicAdd(n_retried, 1);
+  }
+  if (!retry) return;
+  const long long o = (long long)f * cap;
+  for (int i = tid; i < cap; i += 256) assigned[o + i] = -1;
+}
+
 // End of a batch: everything vo_tracker_results hands back -- pose, the four counts, the status word per frame, and the
 // two stages' sticky overflow flags -- in one block, so that the host needs ONE download (it was eight small ones and
 // three synchronisations: ~60 us of a 0.7 ms frame).  Record: [pose 6 doubles | n_tracked, n_inliers, n_matches_last,
@@ -171,7 +187,7 @@ __global__ __launch_bounds__(256) void k_track_in_frame(int nq, int stride, cons
 // no outlier of the second solve; and the per-frame status word.
 __global__ __launch_bounds__(256) void k_track_count(int cap, const int *ranges, const int *index, const uint8_t *outlier,
                                                      const uint8_t *fobs, const int *n_first, const int *n_observed_first,
-                                                     const int *ninl_first, int *n_tracked, int *status) {
+                                                     const int *ninl_first, int *n_tracked, int *status, int min_matches) {
   __shared__ int s_cnt[4];
   const int f = blockIdx.x, tid = threadIdx.x;
   const long long o = (long long)f * cap;
@@ -186,16 +202,38 @@ __global__ __launch_bounds__(256) void k_track_count(int cap, const int *ranges,
     const int n = s_cnt[0] + s_cnt[1] + s_cnt[2] + s_cnt[3];
     n_tracked[f] = n;
     int st = 0;
-    if (n_first[f] < 20) st |= VO_TRACK_FEW_MATCHES;               // visualOdometry.cpp:247-248
+    if (n_first[f] < min_matches) st |= VO_TRACK_FEW_MATCHES;      // visualOdometry.cpp:247-248 (20) / :268-269 (15)
     if (n_observed_first[f] < 10) st |= VO_TRACK_FEW_INLIERS;      // :253
     (void)ninl_first;
     status[f] = st;
   }
 }
 
+// status word and counts after the first stage alone (vo_tracker_track_first): what trackWithMotion / trackRefKeyFrame
+// return -- enough matches, and at least 10 observed inliers after the culling (:247-253, :268-275)
+__global__ __launch_bounds__(256) void k_track_first_status(int B, const int *n_first, const int *n_observed_first, int *n_tracked,
+                                                            int *status, int min_matches) {
+  const int f = blockIdx.x * 256 + threadIdx.x;
+  if (f >= B) return;
+  int st = 0;
+  if (n_first[f] < min_matches) st |= VO_TRACK_FEW_MATCHES;
+  if (n_observed_first[f] < 10) st |= VO_TRACK_FEW_INLIERS;
+  n_tracked[f] = n_observed_first[f];
+  status[f] = st;
+}
+
 constexpr int kStages = VO_TRACKER_STAGES;
 
 }  // namespace
+
+struct RefKfHost {
+  int n = 0;
+  std::vector<uint8_t> valid, desc;
+  std::vector<float> angle;
+  std::vector<int32_t> node_id, start;
+  std::vector<uint32_t> feat;
+  vo_bow_view view{};
+};
 
 struct vo_tracker {
   vo_tracker_config cfg{};
@@ -211,17 +249,24 @@ struct vo_tracker {
   DevBuf kps, desc, cnt, images, depth;
   DevBuf q0_flags, q0_u, q0_v, q0_aux, q0_level, q0_angle, q0_desc, p0, pf0, last_matched;
   DevBuf q1_flags, q1_u, q1_v, q1_aux, q1_level, q1_viewcos, q1_desc, p1, nrm1, mind1, maxd1, pf1, link1;
-  DevBuf Tcw, pose0, pose, pose_first, resblk;  // resblk: k_track_pack's block (72 bytes per frame + 2 flags)
+  DevBuf Tcw, pose0, pose, pose_first, resblk, retry_nq;  // retry_nq: [B] + the retried-frames counter  // resblk: k_track_pack's block (72 bytes per frame + 2 flags)
   DevBuf assigned, assigned_first, nm, nm_first, fpoint, fhas, fobs, pts, obs, isg, ranges, index, outlier, ninl, ninl_first,
       nobs_first, ntracked, status;
   PinnedBuf stage;
   bool have_link = false;
+  int first_min_matches = 20;
+  // trackRefKeyFrame's reference key-frame per frame of the batch (host copies: the common-node walk is host work)
+  const vo_vocab *ref_vocab = nullptr;
+  std::vector<RefKfHost> ref_kf;
   // timing
   bool timing = false;
-  std::vector<hipEvent_t> tev;  // 2 per stage
+  // 2 events per stage and timed call, in a list that grows with the calls; they are read (after one synchronisation) only
+  // by vo_tracker_get_timing, never inside a track call: a timed call enqueues exactly like an untimed one
+  std::vector<hipEvent_t> tev;
+  int tissued = 0;   // timed calls whose events are recorded and not yet read
+  int tslot = -1;    // event set of the call being enqueued (-1: not timed)
   double tms[kStages] = {0};
   int tcalls = 0;
-  bool tpending = false;
 };
 
 namespace {
@@ -276,6 +321,7 @@ int alloc_all(vo_tracker *t) {
   VO_CHECK(t->nobs_first.reserve(B * 4 + 64));
   VO_CHECK(t->ntracked.reserve(B * 4 + 64));
   VO_CHECK(t->status.reserve(B * 4 + 64));
+  VO_CHECK(t->retry_nq.reserve(B * 4 + 64));
   return VO_OK;
 }
 
@@ -295,23 +341,40 @@ struct StageTimer {
   int stage;
   hipStream_t s;
   StageTimer(vo_tracker *t_, int stage_, hipStream_t s_) : t(t_), stage(stage_), s(s_) {
-    if (t->timing) (void)hipEventRecord(t->tev[2 * stage], s);
+    if (t->tslot >= 0) (void)hipEventRecord(t->tev[(size_t)t->tslot * 2 * kStages + 2 * stage], s);
   }
   ~StageTimer() {
-    if (t->timing) (void)hipEventRecord(t->tev[2 * stage + 1], s);
+    if (t->tslot >= 0) (void)hipEventRecord(t->tev[(size_t)t->tslot * 2 * kStages + 2 * stage + 1], s);
   }
 };
 
 int collect_timing(vo_tracker *t) {
-  if (!t->tpending) return VO_OK;
+  if (t->tissued == 0) return VO_OK;
   VO_HIP_CHECK(hipStreamSynchronize(t->st));
   if (t->est != t->st) VO_HIP_CHECK(hipStreamSynchronize(t->est));
-  for (int s = 0; s < kStages; s++) {
-    float ms = 0.f;
-    if (hipEventElapsedTime(&ms, t->tev[2 * s], t->tev[2 * s + 1]) == hipSuccess) t->tms[s] += ms;
+  for (int c = 0; c < t->tissued; c++) {
+    for (int s = 0; s < kStages; s++) {
+      float ms = 0.f;
+      const size_t e = (size_t)c * 2 * kStages + 2 * s;
+      if (hipEventElapsedTime(&ms, t->tev[e], t->tev[e + 1]) == hipSuccess) t->tms[s] += ms;
+    }
+    t->tcalls++;
   }
-  t->tcalls++;
-  t->tpending = false;
+  t->tissued = 0;
+  return VO_OK;
+}
+
+// the event set of the call about to be enqueued (created on first use)
+int begin_timed_call(vo_tracker *t) {
+  t->tslot = -1;
+  if (!t->timing) return VO_OK;
+  const size_t need = (size_t)(t->tissued + 1) * 2 * kStages;
+  while (t->tev.size() < need) {
+    hipEvent_t e;
+    VO_HIP_CHECK(hipEventCreate(&e));
+    t->tev.push_back(e);
+  }
+  t->tslot = t->tissued;
   return VO_OK;
 }
 
@@ -324,18 +387,15 @@ int solve_pose(vo_tracker *t) {
                                        t->outlier.as<uint8_t>(), t->ninl.as<int32_t>(), nullptr, t->st);
 }
 
-int run_pipeline(vo_tracker *t, const uint8_t *dev_images, int img_pitch, size_t img_frame_stride, const void *dev_depth,
-                 int depth_kind, size_t depth_frame_stride, int depth_pitch, const vo_tracker_params *prm) {
-  if (t->timing) VO_CHECK(collect_timing(t));
+// What a call runs: the front (extraction + Frame::Frame), one of the two first stages -- trackWithMotion's projection
+// search (with its 2 x radius retry) or trackRefKeyFrame's vocabulary-node search --, and the local-map stage.
+enum : unsigned { kRunFront = 1u, kRunMotion = 2u, kRunRefKeyFrame = 4u, kRunLocal = 8u };
+
+int stage_front(vo_tracker *t, const uint8_t *dev_images, int img_pitch, size_t img_frame_stride, const void *dev_depth,
+                int depth_kind, size_t depth_frame_stride, int depth_pitch) {
   const int B = t->B;
   hipStream_t st = t->st, est = t->est;
   const vo_tracker_config &c = t->cfg;
-  vo_tracker_params P;
-  if (prm) {
-    P = *prm;
-  } else {
-    P.radius = 15.f, P.th_radius = 3.f, P.ratio = 0.8f, P.direction = 0;
-  }
   // ---- extraction (its stream may be shared with other trackers)
   if (est != st && t->have_build) VO_HIP_CHECK(hipStreamWaitEvent(est, t->ev_build, 0));  // last batch's key-points consumed
   {
@@ -355,55 +415,104 @@ int run_pipeline(vo_tracker *t, const uint8_t *dev_images, int img_pitch, size_t
     VO_HIP_CHECK(hipEventRecord(t->ev_build, st));
     t->have_build = true;
   }
-  const size_t capB = (size_t)B * t->cap;
-  if (t->nq_last == 0) {
-    // no last frame (the first frame of a sequence, visualOdometry.cpp:170-214): Frame construction only; the pose is
-    // the one handed in, every count zero
-    VO_HIP_CHECK(hipMemcpyAsync(t->pose.p, t->pose0.p, (size_t)B * 48, hipMemcpyDeviceToDevice, st));
-    VO_HIP_CHECK(hipMemcpyAsync(t->pose_first.p, t->pose0.p, (size_t)B * 48, hipMemcpyDeviceToDevice, st));
-    VO_HIP_CHECK(hipMemsetAsync(t->assigned.p, 0xff, capB * 4, st));
-    VO_HIP_CHECK(hipMemsetAsync(t->assigned_first.p, 0xff, capB * 4, st));
-    VO_HIP_CHECK(hipMemsetAsync(t->fhas.p, 0, capB, st));
-    for (DevBuf *b : {&t->nm, &t->nm_first, &t->ninl, &t->ninl_first, &t->nobs_first, &t->ntracked, &t->status})
-      VO_HIP_CHECK(hipMemsetAsync(b->p, 0, (size_t)B * 4, st));
-    VO_CHECK(t->resblk.reserve((size_t)B * 72 + 64));
-    hipLaunchKernelGGL(k_track_pack, dim3((B + 255) / 256), dim3(256), 0, st, B, t->pose.as<double>(), t->ntracked.as<int>(),
-                       t->ninl.as<int>(), t->nm_first.as<int>(), t->nm.as<int>(), t->status.as<int>(), vo::orb_error_flag(t->orb),
-                       vo::guided_error_flag(t->frames), t->resblk.as<uint8_t>());
-    VO_HIP_CHECK(hipGetLastError());
-    t->tpending = false;
-    return VO_OK;
-  }
-  // ---- searchByProjection against the last frame
+  return VO_OK;
+}
+
+int launch_pack(vo_tracker *t) {
+  const int B = t->B;
+  VO_CHECK(t->resblk.reserve((size_t)B * 72 + 64));
+  hipLaunchKernelGGL(k_track_pack, dim3((B + 255) / 256), dim3(256), 0, t->st, B, t->pose.as<double>(), t->ntracked.as<int>(),
+                     t->ninl.as<int>(), t->nm_first.as<int>(), t->nm.as<int>(), t->status.as<int>(), vo::orb_error_flag(t->orb),
+                     vo::guided_error_flag(t->frames), t->resblk.as<uint8_t>());
+  VO_HIP_CHECK(hipGetLastError());
+  return VO_OK;
+}
+
+// trackWithMotion's search (visualOdometry.cpp:238-245): projection, searchByProjection(frame, last frame, radius), the
+// retry at 2 x radius for frames with fewer than 20 matches, the map points of the matches into the frame's slots
+int stage_motion(vo_tracker *t, const vo_tracker_params &P) {
+  const int B = t->B;
+  hipStream_t st = t->st;
+  const vo_tracker_config &c = t->cfg;
   vo_guided_queries q{};
   vo_guided_params gp{};
   gp.n_levels = t->n_levels, gp.scale_factors = t->sf;
-  {
-    StageTimer tm(t, 2, st);
-    const float cam4[4] = {c.intrinsics[0], c.intrinsics[1], c.intrinsics[2], c.intrinsics[3]};
-    VO_CHECK(vo_track_project_dev(B, t->nq_last, t->n_last, t->Tcw.as<double>(), t->p0.as<double>(), t->pf0.as<uint8_t>(),
-                                  cam4, 0, c.width, 0, c.height, t->q0_flags.as<uint8_t>(), t->q0_u.as<float>(),
-                                  t->q0_v.as<float>(), t->q0_aux.as<float>(), st));
-    hipLaunchKernelGGL(k_track_prep, dim3(B), dim3(256), 0, st, t->cap, t->n_last, t->assigned.as<int>(), t->fhas.as<uint8_t>(),
-                       t->fobs.as<uint8_t>(), t->last_matched.as<uint8_t>(), t->pose0.as<double>(), t->pose.as<double>());
-    q.n_queries = t->nq_last, q.stride = t->n_last, q.flags = t->q0_flags.as<uint8_t>(), q.u = t->q0_u.as<float>();
-    q.v = t->q0_v.as<float>(), q.aux = t->q0_aux.as<float>(), q.level = t->q0_level.as<int32_t>();
-    q.angle = t->q0_angle.as<float>(), q.desc = t->q0_desc.as<uint8_t>();
-    gp.mode = 0, gp.radius = P.radius, gp.bf = c.intrinsics[4], gp.direction = P.direction, gp.check_rot = 1;
+  StageTimer tm(t, 2, st);
+  const float cam4[4] = {c.intrinsics[0], c.intrinsics[1], c.intrinsics[2], c.intrinsics[3]};
+  VO_CHECK(vo_track_project_dev(B, t->nq_last, t->n_last, t->Tcw.as<double>(), t->p0.as<double>(), t->pf0.as<uint8_t>(),
+                                cam4, 0, c.width, 0, c.height, t->q0_flags.as<uint8_t>(), t->q0_u.as<float>(),
+                                t->q0_v.as<float>(), t->q0_aux.as<float>(), st));
+  hipLaunchKernelGGL(k_track_prep, dim3(B), dim3(256), 0, st, t->cap, t->n_last, t->assigned.as<int>(), t->fhas.as<uint8_t>(),
+                     t->fobs.as<uint8_t>(), t->last_matched.as<uint8_t>(), t->pose0.as<double>(), t->pose.as<double>());
+  q.n_queries = t->nq_last, q.stride = t->n_last, q.flags = t->q0_flags.as<uint8_t>(), q.u = t->q0_u.as<float>();
+  q.v = t->q0_v.as<float>(), q.aux = t->q0_aux.as<float>(), q.level = t->q0_level.as<int32_t>();
+  q.angle = t->q0_angle.as<float>(), q.desc = t->q0_desc.as<uint8_t>();
+  gp.mode = 0, gp.radius = P.radius, gp.bf = c.intrinsics[4], gp.direction = P.direction, gp.check_rot = 1;
+  VO_CHECK(vo_match_guided_dev(t->frames, 0, B, &q, &gp, nullptr, t->assigned.as<int32_t>(), nullptr,
+                               t->nm_first.as<int32_t>(), 0, st));
+  if (!P.no_retry) {
+    // `if (match_num < 20) { fill(mappoints_, nullptr); match_num = searchByProjection(..., 2*radius); }` (:241-245) for
+    // the frames that need it, on the device: the second call leaves every other frame out (n_per_frame < 0)
+    int *rq = t->retry_nq.as<int>();
+    VO_HIP_CHECK(hipMemsetAsync(rq + B, 0, 4, st));
+    hipLaunchKernelGGL(k_track_retry_prep, dim3(B), dim3(256), 0, st, t->cap, t->nq_last, t->nm_first.as<int>(),
+                       t->assigned.as<int>(), rq, rq + B);
+    q.n_per_frame = rq;
+    gp.radius = 2.f * P.radius;
     VO_CHECK(vo_match_guided_dev(t->frames, 0, B, &q, &gp, nullptr, t->assigned.as<int32_t>(), nullptr,
                                  t->nm_first.as<int32_t>(), 0, st));
-    VO_CHECK(vo_track_scatter_dev(t->frames, 0, B, t->assigned.as<int32_t>(), t->p0.as<double>(), t->q0_flags.as<uint8_t>(),
-                                  t->n_last, t->fpoint.as<double>(), t->fhas.as<uint8_t>(), t->fobs.as<uint8_t>(), st));
   }
-  // ---- solvePoseOnlySE3, cullingOutliersBeforeLocalMap
-  {
-    StageTimer tm(t, 3, st);
-    VO_CHECK(solve_pose(t));
-    hipLaunchKernelGGL(k_track_cull, dim3(B), dim3(256), 0, st, t->cap, t->ranges.as<int>(), t->index.as<int>(),
-                       t->outlier.as<uint8_t>(), t->assigned.as<int>(), t->n_last, t->fhas.as<uint8_t>(), t->fobs.as<uint8_t>(),
-                       t->last_matched.as<uint8_t>(), t->nobs_first.as<int>(), t->assigned_first.as<int>(), t->pose.as<double>(),
-                       t->pose_first.as<double>(), t->ninl.as<int>(), t->ninl_first.as<int>());
+  VO_CHECK(vo_track_scatter_dev(t->frames, 0, B, t->assigned.as<int32_t>(), t->p0.as<double>(), t->q0_flags.as<uint8_t>(),
+                                t->n_last, t->fpoint.as<double>(), t->fhas.as<uint8_t>(), t->fobs.as<uint8_t>(), st));
+  return VO_OK;
+}
+
+// trackRefKeyFrame's search (visualOdometry.cpp:256-270): computeBow of the frames, searchByBoW(reference key-frame,
+// frame) with Matcher(0.7); the key-frame's map points of the matches into the frame's slots, the pose starts at
+// frame_last_->Tcw_ (vo_tracker_set_ref_keyframe).  The common-node walk is host work between two device steps
+// (vo::bow_search_resident synchronises): this is the route of a frame that trackWithMotion has already given up on.
+int stage_ref_keyframe(vo_tracker *t, const vo_tracker_params &P) {
+  const int B = t->B;
+  hipStream_t st = t->st;
+  StageTimer tm(t, 2, st);
+  if (!t->ref_vocab || (int)t->ref_kf.size() != B) {
+    vo::set_error("vo_tracker_track_ref_keyframe: no reference key-frame (vo_tracker_set_ref_keyframe)");
+    return VO_ERR_INVALID;
   }
+  hipLaunchKernelGGL(k_track_prep, dim3(B), dim3(256), 0, st, t->cap, t->n_last, t->assigned.as<int>(), t->fhas.as<uint8_t>(),
+                     t->fobs.as<uint8_t>(), t->last_matched.as<uint8_t>(), t->pose0.as<double>(), t->pose.as<double>());
+  std::vector<vo::RefKeyFrame> kfs((size_t)B);
+  for (int f = 0; f < B; f++) {
+    const RefKfHost &k = t->ref_kf[f];
+    kfs[f] = vo::RefKeyFrame{k.n, k.valid.data(), k.desc.data(), k.angle.data(), &k.view};
+  }
+  VO_CHECK(vo::bow_search_resident(t->ref_vocab, t->frames, 0, B, kfs.data(), P.ref_ratio > 0.f ? P.ref_ratio : 0.7f, 1, 3,
+                                   t->assigned.as<int32_t>(), t->cap, t->nm_first.as<int32_t>(), st));
+  VO_CHECK(vo_track_scatter_dev(t->frames, 0, B, t->assigned.as<int32_t>(), t->p0.as<double>(), t->q0_flags.as<uint8_t>(),
+                                t->n_last, t->fpoint.as<double>(), t->fhas.as<uint8_t>(), t->fobs.as<uint8_t>(), st));
+  return VO_OK;
+}
+
+// solvePoseOnlySE3 + cullingOutliersBeforeLocalMap (:249-250 / :271-272)
+int stage_solve_cull(vo_tracker *t) {
+  hipStream_t st = t->st;
+  StageTimer tm(t, 3, st);
+  VO_CHECK(solve_pose(t));
+  hipLaunchKernelGGL(k_track_cull, dim3(t->B), dim3(256), 0, st, t->cap, t->ranges.as<int>(), t->index.as<int>(),
+                     t->outlier.as<uint8_t>(), t->assigned.as<int>(), t->n_last, t->fhas.as<uint8_t>(), t->fobs.as<uint8_t>(),
+                     t->last_matched.as<uint8_t>(), t->nobs_first.as<int>(), t->assigned_first.as<int>(), t->pose.as<double>(),
+                     t->pose_first.as<double>(), t->ninl.as<int>(), t->ninl_first.as<int>());
+  return VO_OK;
+}
+
+// trackLocalMap from searchLocalMapPoints on (:745-775, :289-300)
+int stage_local(vo_tracker *t, const vo_tracker_params &P) {
+  const int B = t->B;
+  hipStream_t st = t->st;
+  const vo_tracker_config &c = t->cfg;
+  vo_guided_queries q{};
+  vo_guided_params gp{};
+  gp.n_levels = t->n_levels, gp.scale_factors = t->sf;
   // ---- searchLocalMapPoints: isInFrame with the refined pose, then the search; occupied = holds an observed point
   {
     StageTimer tm(t, 4, st);
@@ -415,7 +524,7 @@ int run_pipeline(vo_tracker *t, const uint8_t *dev_images, int img_pitch, size_t
                          c.intrinsics[3], c.intrinsics[4], 0.f, (float)c.width, 0.f, (float)c.height,
                          (float)log((double)t->sf[1]), t->n_levels, t->q1_flags.as<uint8_t>(), t->q1_u.as<float>(),
                          t->q1_v.as<float>(), t->q1_aux.as<float>(), t->q1_level.as<int>(), t->q1_viewcos.as<float>());
-      q = vo_guided_queries{};  // (`assigned` was cleared by k_track_cull)
+      // (`assigned` was cleared by k_track_cull)
       q.n_queries = t->nq_local, q.stride = t->n_local, q.flags = t->q1_flags.as<uint8_t>(), q.u = t->q1_u.as<float>();
       q.v = t->q1_v.as<float>(), q.aux = t->q1_aux.as<float>(), q.level = t->q1_level.as<int32_t>();
       q.viewcos = t->q1_viewcos.as<float>(), q.desc = t->q1_desc.as<uint8_t>();
@@ -434,16 +543,58 @@ int run_pipeline(vo_tracker *t, const uint8_t *dev_images, int img_pitch, size_t
     VO_CHECK(solve_pose(t));
     hipLaunchKernelGGL(k_track_count, dim3(B), dim3(256), 0, st, t->cap, t->ranges.as<int>(), t->index.as<int>(),
                        t->outlier.as<uint8_t>(), t->fobs.as<uint8_t>(), t->nm_first.as<int>(), t->nobs_first.as<int>(),
-                       t->ninl_first.as<int>(), t->ntracked.as<int>(), t->status.as<int>());
+                       t->ninl_first.as<int>(), t->ntracked.as<int>(), t->status.as<int>(), t->first_min_matches);
   }
-  {
-    VO_CHECK(t->resblk.reserve((size_t)B * 72 + 64));
-    hipLaunchKernelGGL(k_track_pack, dim3((B + 255) / 256), dim3(256), 0, st, B, t->pose.as<double>(), t->ntracked.as<int>(),
-                       t->ninl.as<int>(), t->nm_first.as<int>(), t->nm.as<int>(), t->status.as<int>(), vo::orb_error_flag(t->orb),
-                       vo::guided_error_flag(t->frames), t->resblk.as<uint8_t>());
+  return VO_OK;
+}
+
+int run_pipeline(vo_tracker *t, const uint8_t *dev_images, int img_pitch, size_t img_frame_stride, const void *dev_depth,
+                 int depth_kind, size_t depth_frame_stride, int depth_pitch, const vo_tracker_params *prm, unsigned run) {
+  VO_CHECK(begin_timed_call(t));
+  if (!(run == (kRunFront | kRunMotion | kRunLocal))) t->tslot = -1;  // the six stage timers describe the one-call tracked frame
+  const int B = t->B;
+  hipStream_t st = t->st;
+  vo_tracker_params P;
+  if (prm) {
+    P = *prm;
+  } else {
+    P.radius = 15.f, P.th_radius = 3.f, P.ratio = 0.8f, P.direction = 0, P.no_retry = 0, P.ref_ratio = 0.7f;
   }
-  VO_HIP_CHECK(hipGetLastError());
-  t->tpending = t->timing;
+  if (run & kRunFront)
+    VO_CHECK(stage_front(t, dev_images, img_pitch, img_frame_stride, dev_depth, depth_kind, depth_frame_stride, depth_pitch));
+  const size_t capB = (size_t)B * t->cap;
+  if ((run & kRunMotion) && t->nq_last == 0) {
+    // no last frame (the first frame of a sequence, visualOdometry.cpp:170-214): Frame construction only; the pose is
+    // the one handed in, every count zero
+    VO_HIP_CHECK(hipMemcpyAsync(t->pose.p, t->pose0.p, (size_t)B * 48, hipMemcpyDeviceToDevice, st));
+    VO_HIP_CHECK(hipMemcpyAsync(t->pose_first.p, t->pose0.p, (size_t)B * 48, hipMemcpyDeviceToDevice, st));
+    VO_HIP_CHECK(hipMemsetAsync(t->assigned.p, 0xff, capB * 4, st));
+    VO_HIP_CHECK(hipMemsetAsync(t->assigned_first.p, 0xff, capB * 4, st));
+    VO_HIP_CHECK(hipMemsetAsync(t->fhas.p, 0, capB, st));
+    for (DevBuf *b : {&t->nm, &t->nm_first, &t->ninl, &t->ninl_first, &t->nobs_first, &t->ntracked, &t->status})
+      VO_HIP_CHECK(hipMemsetAsync(b->p, 0, (size_t)B * 4, st));
+    VO_CHECK(launch_pack(t));
+    t->tslot = -1;  // Frame construction only: not a timed tracked frame
+    return VO_OK;
+  }
+  if (run & kRunMotion) {
+    t->first_min_matches = 20;  // :247
+    VO_CHECK(stage_motion(t, P));
+  } else if (run & kRunRefKeyFrame) {
+    t->first_min_matches = 15;  // :268
+    VO_CHECK(stage_ref_keyframe(t, P));
+  }
+  if (run & (kRunMotion | kRunRefKeyFrame)) VO_CHECK(stage_solve_cull(t));
+  if (run & kRunLocal) {
+    VO_CHECK(stage_local(t, P));
+  } else {
+    // first stage only: the status word and the counts of trackWithMotion / trackRefKeyFrame
+    VO_HIP_CHECK(hipMemsetAsync(t->nm.p, 0, (size_t)B * 4, st));
+    hipLaunchKernelGGL(k_track_first_status, dim3((B + 255) / 256), dim3(256), 0, st, B, t->nm_first.as<int>(),
+                       t->nobs_first.as<int>(), t->ntracked.as<int>(), t->status.as<int>(), t->first_min_matches);
+  }
+  VO_CHECK(launch_pack(t));
+  if (t->tslot >= 0) t->tissued++, t->tslot = -1;
   return VO_OK;
 }
 
@@ -510,7 +661,6 @@ int vo_tracker_create(vo_tracker **out, const vo_tracker_config *cfg) {
     if (hipMemcpy(t->Tcw.as<double>() + (size_t)t->B * 12, cam5d, sizeof(cam5d), hipMemcpyHostToDevice) != hipSuccess)
       return fail(VO_ERR_HIP);
   }
-  t->tev.resize(2 * kStages, nullptr);
   *out = t;
   return VO_OK;
 }
@@ -596,11 +746,10 @@ int vo_tracker_track_dev(vo_tracker *t, const uint8_t *dev_images, int image_pit
   if (!t || !dev_images || image_pitch < t->cfg.width || depth_kind < 0 || depth_kind > 2 || (depth_kind && !dev_depth))
     return VO_ERR_INVALID;
   return run_pipeline(t, dev_images, image_pitch, image_frame_stride, dev_depth, depth_kind, depth_frame_stride, depth_pitch,
-                      params);
+                      params, kRunFront | kRunMotion | kRunLocal);
 }
 
-int vo_tracker_track(vo_tracker *t, const uint8_t *images, const void *depth, int depth_kind, const vo_tracker_params *params) {
-  if (!t || !images || depth_kind < 0 || depth_kind > 2 || (depth_kind && !depth)) return VO_ERR_INVALID;
+static int upload_host_frames(vo_tracker *t, const uint8_t *images, const void *depth, int depth_kind, size_t *npx_out, size_t *dsz_out) {
   const size_t B = t->B, npx = (size_t)t->cfg.width * t->cfg.height, dsz = depth_kind == 1 ? 4 : depth_kind == 2 ? 2 : 0;
   VO_CHECK(t->images.reserve(B * npx));
   if (dsz) VO_CHECK(t->depth.reserve(B * npx * dsz));
@@ -608,8 +757,98 @@ int vo_tracker_track(vo_tracker *t, const uint8_t *images, const void *depth, in
   if (t->est != t->st && t->have_build) VO_HIP_CHECK(hipStreamWaitEvent(t->est, t->ev_build, 0));
   VO_HIP_CHECK(hipMemcpyAsync(t->images.p, images, B * npx, hipMemcpyHostToDevice, t->est));
   if (dsz) VO_HIP_CHECK(hipMemcpyAsync(t->depth.p, depth, B * npx * dsz, hipMemcpyHostToDevice, t->est));
+  *npx_out = npx, *dsz_out = dsz;
+  return VO_OK;
+}
+
+static int track_host(vo_tracker *t, const uint8_t *images, const void *depth, int depth_kind, const vo_tracker_params *params,
+                      unsigned run) {
+  if (!t || !images || depth_kind < 0 || depth_kind > 2 || (depth_kind && !depth)) return VO_ERR_INVALID;
+  size_t npx = 0, dsz = 0;
+  VO_CHECK(upload_host_frames(t, images, depth, depth_kind, &npx, &dsz));
   return run_pipeline(t, t->images.as<uint8_t>(), t->cfg.width, npx, dsz ? t->depth.p : nullptr, depth_kind, npx * dsz,
-                      t->cfg.width * (int)dsz, params);
+                      t->cfg.width * (int)dsz, params, run);
+}
+
+int vo_tracker_track_first(vo_tracker *t, const uint8_t *images, const void *depth, int depth_kind, const vo_tracker_params *params) {
+  return track_host(t, images, depth, depth_kind, params, kRunFront | kRunMotion);
+}
+
+int vo_tracker_track_first_dev(vo_tracker *t, const uint8_t *dev_images, int image_pitch, size_t image_frame_stride,
+                               const void *dev_depth, int depth_kind, size_t depth_frame_stride, int depth_pitch,
+                               const vo_tracker_params *params) {
+  if (!t || !dev_images || image_pitch < t->cfg.width || depth_kind < 0 || depth_kind > 2 || (depth_kind && !dev_depth))
+    return VO_ERR_INVALID;
+  return run_pipeline(t, dev_images, image_pitch, image_frame_stride, dev_depth, depth_kind, depth_frame_stride, depth_pitch,
+                      params, kRunFront | kRunMotion);
+}
+
+int vo_tracker_track_local_map(vo_tracker *t, const vo_tracker_params *params) {
+  if (!t) return VO_ERR_INVALID;
+  if (!t->resblk.p) {
+    vo::set_error("vo_tracker_track_local_map: no first stage has run (vo_tracker_track_first / _ref_keyframe_first)");
+    return VO_ERR_INVALID;
+  }
+  return run_pipeline(t, nullptr, 0, 0, nullptr, 0, 0, 0, params, kRunLocal);
+}
+
+int vo_tracker_track_ref_keyframe(vo_tracker *t, const uint8_t *images, const void *depth, int depth_kind,
+                                  const vo_tracker_params *params, int first_stage_only) {
+  return track_host(t, images, depth, depth_kind, params, kRunFront | kRunRefKeyFrame | (first_stage_only ? 0u : kRunLocal));
+}
+
+int vo_tracker_track_ref_keyframe_dev(vo_tracker *t, const uint8_t *dev_images, int image_pitch, size_t image_frame_stride,
+                                      const void *dev_depth, int depth_kind, size_t depth_frame_stride, int depth_pitch,
+                                      const vo_tracker_params *params, int first_stage_only) {
+  if (!t || !dev_images || image_pitch < t->cfg.width || depth_kind < 0 || depth_kind > 2 || (depth_kind && !dev_depth))
+    return VO_ERR_INVALID;
+  return run_pipeline(t, dev_images, image_pitch, image_frame_stride, dev_depth, depth_kind, depth_frame_stride, depth_pitch,
+                      params, kRunFront | kRunRefKeyFrame | (first_stage_only ? 0u : kRunLocal));
+}
+
+int vo_tracker_set_ref_keyframe(vo_tracker *t, const vo_vocab *vocab, int n, const double *Tcw12, const double *points,
+                                const uint8_t *flags, const float *angle, const uint8_t *desc, const vo_bow_view *const *nodes) {
+  if (!t || !vocab || n < 0 || n > t->n_last || !Tcw12 || !nodes || (n > 0 && (!points || !flags || !angle || !desc)))
+    return VO_ERR_INVALID;
+  const int B = t->B;
+  std::vector<double> p6((size_t)B * 6);
+  for (int f = 0; f < B; f++) VO_CHECK(vo_se3_log(Tcw12 + 12 * f, Tcw12 + 12 * f + 9, p6.data() + 6 * f));
+  VO_CHECK(t->stage.reserve((size_t)B * 144));
+  memcpy(t->stage.data(), Tcw12, (size_t)B * 96);
+  memcpy(t->stage.data() + (size_t)B * 96, p6.data(), (size_t)B * 48);
+  VO_HIP_CHECK(hipMemcpyAsync(t->Tcw.p, t->stage.data(), (size_t)B * 96, hipMemcpyHostToDevice, t->st));
+  VO_HIP_CHECK(hipMemcpyAsync(t->pose0.p, t->stage.data() + (size_t)B * 96, (size_t)B * 48, hipMemcpyHostToDevice, t->st));
+  // the key-frame's map points take the place of the last frame's list: the tail of the pipeline (scatter, culling, the
+  // `link` test of the local-map stage) indexes them exactly as it indexes frame_last_->mappoints_
+  VO_CHECK(put_rows(t, t->p0, points, n, t->n_last, 24, "points"));
+  VO_CHECK(put_rows(t, t->pf0, flags, n, t->n_last, 1, "flags"));
+  VO_CHECK(put_rows(t, t->q0_flags, flags, n, t->n_last, 1, "flags"));
+  t->ref_vocab = vocab;
+  t->ref_kf.assign((size_t)B, RefKfHost{});
+  for (int f = 0; f < B; f++) {
+    RefKfHost &k = t->ref_kf[f];
+    const vo_bow_view *v = nodes[f];
+    if (!v || v->n_nodes < 0 || (v->n_nodes > 0 && (!v->node_id || !v->start || !v->feat))) return VO_ERR_INVALID;
+    k.n = n;
+    k.valid.resize((size_t)n), k.angle.assign(angle + (size_t)f * n, angle + (size_t)(f + 1) * n);
+    for (int i = 0; i < n; i++) k.valid[i] = flags[(size_t)f * n + i] & 1;
+    k.desc.assign(desc + (size_t)f * n * 32, desc + (size_t)(f + 1) * n * 32);
+    k.node_id.assign(v->node_id, v->node_id + v->n_nodes);
+    k.start.assign(v->start, v->start + v->n_nodes + 1);
+    const int nf = v->n_nodes > 0 ? v->start[v->n_nodes] : 0;
+    k.feat.assign(v->feat, v->feat + nf);
+    for (int i = 0; i < nf; i++)
+      if ((int)k.feat[i] >= n) return VO_ERR_INVALID;
+    k.view.n_nodes = v->n_nodes, k.view.node_id = reinterpret_cast<const uint32_t *>(k.node_id.data()), k.view.start = k.start.data(),
+    k.view.feat = k.feat.data();
+  }
+  t->nq_last = n;
+  VO_HIP_CHECK(hipStreamSynchronize(t->st));
+  return VO_OK;
+}
+
+int vo_tracker_track(vo_tracker *t, const uint8_t *images, const void *depth, int depth_kind, const vo_tracker_params *params) {
+  return track_host(t, images, depth, depth_kind, params, kRunFront | kRunMotion | kRunLocal);
 }
 
 int vo_tracker_results(vo_tracker *t, double *poses6, double *Tcw12, int32_t *n_tracked, int32_t *n_inliers,
@@ -720,11 +959,9 @@ int vo_tracker_sync(vo_tracker *t) {
 
 int vo_tracker_set_timing(vo_tracker *t, int enabled) {
   if (!t) return VO_ERR_INVALID;
-  if (enabled)
-    for (hipEvent_t &e : t->tev)
-      if (!e) VO_HIP_CHECK(hipEventCreate(&e));
+  VO_CHECK(collect_timing(t));  // (synchronises only if timed calls are outstanding)
   t->timing = enabled != 0;
-  t->tpending = false;
+  t->tissued = 0, t->tslot = -1;
   for (double &m : t->tms) m = 0;
   t->tcalls = 0;
   return VO_OK;

@@ -125,6 +125,29 @@ struct CholOrder {
 };
 CholOrder chol_choose_order(int nf, int bs, const std::vector<std::pair<int, int>> &pairs, int m, int force_parts = -1);
 
+// searchByBoW(KeyFrame*, Frame*) (matcher.cpp:449-559) for B (reference key-frame, current frame) pairs whose current
+// frames are resident in a frame store (slots slot0 .. slot0 + B - 1): Frame::computeBow (vocabulary transform, levelsup)
+// on the device, the common-node walk on the host (this call synchronises `st` once), one k_node_replay launch with a
+// workgroup per pair reading the frames' descriptors and angles in place.  dev_assigned [B][cap]: key-frame feature index
+// held by each frame feature or -1; dev_n_matches [B].  (match.hip; the key-frame side is host memory.)
+struct RefKeyFrame {
+  int n;
+  const uint8_t *valid;  // [n] the feature's map point exists and is not bad
+  const uint8_t *desc;   // [n][32]
+  const float *angle;    // [n]
+  const vo_bow_view *nodes;
+};
+int bow_search_resident(const vo_vocab *v, vo_frames *frames, int slot0, int B, const RefKeyFrame *kfs, float ratio, int check_rot,
+                        int levelsup, int32_t *dev_assigned, int cap, int32_t *dev_n_matches, hipStream_t st);
+// device views of a frame store's per-slot arrays (guided.hip)
+struct FrameStoreView {
+  int cap;
+  const uint8_t *desc;  // [slots][cap][32]
+  const float *angle;   // [slots][cap]
+  const int *n;         // [slots]
+};
+FrameStoreView frame_store_view(const vo_frames *h);
+
 // Device addresses of the handles' sticky error flags (NULL before the first use): vo_tracker copies them into its
 // result block so that one download answers "pose + counts + did anything overflow" (orb.hip, guided.hip).
 const int *orb_error_flag(const vo_orb *h);
