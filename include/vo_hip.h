@@ -620,7 +620,8 @@ enum {
   VO_TRACKER_FEATURE_POINTS = 6,     /* double [..][3]: that map point's position */
   VO_TRACKER_LOCAL_FLAGS = 7, VO_TRACKER_LOCAL_U = 8, VO_TRACKER_LOCAL_V = 9, VO_TRACKER_LOCAL_UR = 10,
   VO_TRACKER_LOCAL_LEVEL = 11, VO_TRACKER_LOCAL_VIEWCOS = 12, /* Frame::isInFrame's outputs per local point */
-  VO_TRACKER_KEYPOINT_COUNTS = 13    /* int32 [batch] */
+  VO_TRACKER_KEYPOINT_COUNTS = 13,   /* int32 [batch] */
+  VO_TRACKER_FEATURE_OUTLIER = 14    /* uint8: frame->outliers_[i] after the second solve (valid after the local-map stage) */
 };
 int vo_tracker_get(vo_tracker *t, int what, void *dst, size_t dst_bytes);
 int vo_tracker_sync(vo_tracker *t);

@@ -393,8 +393,8 @@ def test_sim3_reanchor_points(vo):
 
 
 def test_pose_graph_config4_size_properties(vo):
-    """BASELINE config 4: 500 key-frames (2994 x 2994 dense system, 47 Cholesky panels).  Too large for
-    the CPU oracle inside a test; checked through properties: gauge node untouched, unit quaternions,
+    """BASELINE config 4: 500 key-frames (2994 x 2994 system).  Parity with the oracle at this size is the fixture g11
+    (tests/test_gpu_golden.py::test_g11_pose_graph_config4); here the properties: gauge node untouched, unit quaternions,
     the non-constant part of the cost collapses, the drifted loop closes."""
     import time
     from vo_slam_test_amd import synth

@@ -124,6 +124,22 @@ def test_g9_global_ba_config4(vo):
     assert np.abs(pts[g["point_idx"]] - g["points"]).max() < 1e-6
 
 
+def test_g11_pose_graph_config4(vo):
+    """BASELINE config 4's reference-defined solver at full size (Optimizer::solvePoseGraphLoop, optimizer_ceres.cpp:1036-1305;
+    500 key-frames, 2994 x 2994 normal matrix) against the CPU oracle's whole solve (tests/golden/make_g11_pose_graph.py):
+    same LM decisions (the Q-B4 constant makes Ceres' function tolerance fire after a few iterations), poses to 1e-8."""
+    from vo_slam_test_amd import synth
+    g = np.load(G / "g11_pose_graph.npz")
+    pg = synth.make_pose_graph(7, n_kf=500, drift=0.004, extra_edges=4)
+    assert len(pg["e_i"]) == int(g["n_edges"])
+    assert pg["quats"].sum() + pg["trans"].sum() + pg["q_meas"].sum() + pg["t_meas"].sum() == float(g["input_checksum"])
+    q, t, s = vo.Optimizer.solvePoseGraphLoop(pg)
+    assert (s.iterations, s.accepted, s.termination) == (int(g["iters"]), int(g["accepted"]), int(g["termination"]))
+    assert abs(s.initial_cost - float(g["initial_cost"])) <= 1e-10 * float(g["initial_cost"])
+    assert abs(s.final_cost - float(g["final_cost"])) <= 1e-9 * float(g["final_cost"])
+    assert np.abs(q - g["quats"]).max() < 1e-8 and np.abs(t - g["trans"]).max() < 1e-7
+
+
 def test_g10_tracked_frame_and_loop_helpers(vo):
     """Fixture g10: one RGB-D frame through vo_tracker (host image and raw depth in: extraction, undistortion / depth /
     grid, search, solve, culling, isInFrame, search, solve) against the committed vectors; Sim3 hypotheses and the

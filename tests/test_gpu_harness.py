@@ -1,8 +1,10 @@
-"""The harness contract of the reference's test/vo_run.cpp (:24-58, :105-232) end to end: a synthetic TUM-layout
-sequence (rgb/*.png, depth/*.png 16-bit, associate.txt) is written to disk, examples/vo_run_hip.cpp -- plain C++ on
-include/vo_hip.h -- reads it back (vo_dataset_*, vo_png_read, vo_rgb_to_gray), tracks it frame by frame (vo_tracker, batch 1)
-and writes the camera trajectory and the tracking-time report; the same loop run on the CPU oracle gives the same
-poses, and both recover the ground-truth motion of the synthetic camera."""
+"""BASELINE config 0 ("tracking + local BA") end to end behind the C-ABI: a synthetic TUM-layout sequence with rotation
+(rgb/*.png, depth/*.png 16-bit, associate.txt; tests/harness_seq.py) is written to disk, examples/vo_run_hip.cpp -- plain
+C++ on include/vo_hip.h -- reads it back (vo_dataset_*, vo_png_read, vo_rgb_to_gray), tracks every frame in the reference's
+two stages (vo_tracker_track_first, the local map derived in between, vo_tracker_track_local_map) against a NON-EMPTY local
+map, runs the scripted local BA (vo_ba_local_ba over the last 10 frames after every 5th frame) and writes the trajectory
+and the tracking-time report of test/vo_run.cpp.  The same script on the CPU oracle (tests/harness_ref.py) gives the same
+poses to 1e-6, and both recover the ground-truth camera path."""
 import pathlib
 import shutil
 import subprocess
@@ -10,116 +12,83 @@ import subprocess
 import numpy as np
 import pytest
 
+import harness_ref
+import harness_seq
 from vo_slam_test_amd import synth
 
 pytestmark = pytest.mark.gpu
 ROOT = pathlib.Path(__file__).resolve().parent.parent
-W, H, Z = 640, 480, 2.5
-STEP = (7, -4)  # pixels per frame: the camera translates parallel to a textured plane at depth Z
 
 
-def _write_sequence(d, n):
-    from PIL import Image
-    (d / "rgb").mkdir(parents=True), (d / "depth").mkdir()
-    canvas = synth.make_frame(901, w=960, h=720)
-    lines = []
-    for i in range(n):
-        x0, y0 = 100 + i * STEP[0], 140 + i * STEP[1]
-        g = canvas[y0:y0 + H, x0:x0 + W].astype(np.int16)
-        g = np.clip(g + np.random.default_rng(50 + i).integers(-4, 5, g.shape), 0, 255).astype(np.uint8)
-        Image.fromarray(np.stack([g, g, g], 2)).save(d / "rgb" / f"{i}.png")
-        raw = np.full((H, W), int(Z * synth.DEPTH_SCALE), np.uint16)
-        raw[np.random.default_rng(90 + i).random((H, W)) < 0.03] = 0  # holes
-        Image.fromarray(raw).save(d / "depth" / f"{i}.png")
-        lines.append(f"{1305031102.175304 + 0.033 * i:.6f} rgb/{i}.png {1305031102.160407 + 0.033 * i:.6f} depth/{i}.png")
-    (d / "associate.txt").write_text("\n".join(lines))
-    return lines
-
-
-def _inv(T):
-    R, t = T[:9].reshape(3, 3), T[9:]
-    return np.concatenate([R.T.reshape(-1), -R.T @ t])
-
-
-def _mul(A, B):
-    Ra, ta, Rb, tb = A[:9].reshape(3, 3), A[9:], B[:9].reshape(3, 3), B[9:]
-    return np.concatenate([(Ra @ Rb).reshape(-1), Ra @ tb + ta])
-
-
-def _oracle_run(orc, d, n):
-    """the same loop on the CPU oracle (tests/track_ref.py); images read back with Pillow"""
-    from PIL import Image
-    from track_ref import track_frame
-    cam5 = synth.CAM.astype(np.float32)
-    p = orc.orb_params()
-    sf = np.array(list(p.scale)[:8], np.float32)
-    inv = np.float32(1.0) / np.float32(synth.DEPTH_SCALE)
-    eye = np.array([1, 0, 0, 0, 1, 0, 0, 0, 1, 0, 0, 0], np.float64)
-    Tlast, Tcl, last, out = eye.copy(), eye.copy(), None, []
-    for i in range(n):
-        rgb = np.asarray(Image.open(d / "rgb" / f"{i}.png"))
-        raw = np.asarray(Image.open(d / "depth" / f"{i}.png")).astype(np.uint16)
-        gray = np.zeros((H, W), np.uint8)
-        orc.lib().orc_rgb_to_gray(np.ascontiguousarray(rgb[:, :, ::-1]).reshape(-1), H * W, 3, 0, gray.reshape(-1))
-        k, dsc, _ = orc.extract(p, gray)
-        m = len(k)
-        x, y = np.ascontiguousarray(k["x"]), np.ascontiguousarray(k["y"])
-        dimg = np.zeros((H, W), np.float32)
-        orc.lib().orc_depth_to_float(np.ascontiguousarray(raw).reshape(-1), H * W, inv, dimg.reshape(-1))
-        ur, dep = np.zeros(m, np.float32), np.zeros(m, np.float32)
-        orc.lib().orc_find_depth(m, x, y, x, dimg, W, H, W, float(cam5[4]), ur, dep)
-        Tpred = _mul(Tcl, Tlast)
-        if last is None:
-            Tcw = Tpred
-        else:
-            R, t = Tpred[:9].reshape(3, 3), Tpred[9:]
-            empty = dict(points=np.zeros((0, 3)), normals=np.zeros((0, 3)), min_dist=np.zeros(0, np.float32),
-                         max_dist=np.zeros(0, np.float32), valid=np.zeros(0, np.uint8), link=np.zeros(0, np.int32),
-                         desc=np.zeros((0, 32), np.uint8))
-            w = track_frame(orc, k, dsc, x, y, ur, Tpred, synth.se3_log(R, t), last, empty, cam5, sf, W, H)
-            assert w["inliers_2"] >= 200
-            R2, t2 = synth.se3_exp(w["pose_2"])
-            Tcw = np.concatenate([R2.reshape(-1), t2])
-            Tcl = _mul(Tcw, _inv(Tlast))
-        Twc = _inv(Tcw)
-        has = dep > 0
-        z = dep.astype(np.float64)
-        pc = np.stack([(x.astype(np.float64) - float(cam5[2])) * z / float(cam5[0]),
-                       (y.astype(np.float64) - float(cam5[3])) * z / float(cam5[1]), z], 1)
-        pts = np.where(has[:, None], pc @ Twc[:9].reshape(3, 3).T + Twc[9:], 0.0)
-        last = dict(points=pts, flags=np.where(has, 3, 0).astype(np.uint8), octave=k["octave"].astype(np.int32),
-                    angle=k["angle"].astype(np.float32), desc=dsc)
-        Tlast = Tcw
-        out.append(Twc[9:].copy())
-    return np.array(out)
-
-
-def test_vo_run_harness_on_a_synthetic_sequence(vo, orc, tmp_path):
+def _build(tmp_path):
     cxx = shutil.which("g++")
     if cxx is None:
         pytest.skip("no host C++ compiler")
-    n = 6
-    seq = tmp_path / "seq"
-    lines = _write_sequence(seq, n)
     exe = tmp_path / "vo_run_hip"
     so_dir = ROOT / "vo_slam_test_amd"
     r = subprocess.run([cxx, "-O2", "-std=c++17", str(ROOT / "examples" / "vo_run_hip.cpp"), f"-I{ROOT / 'include'}", f"-L{so_dir}",
                         "-lvo_hip", f"-Wl,-rpath,{so_dir}", "-Wl,-rpath-link,/opt/rocm/lib", "-o", str(exe)],
                        capture_output=True, text=True)
     assert r.returncode == 0, r.stderr[-2000:]
-    traj = tmp_path / "camera.txt"
+    return exe
+
+
+@pytest.mark.timeout(600)
+def test_vo_run_harness_tracking_and_local_ba(vo, orc, tmp_path):
+    n = 32
+    grays, raws = harness_seq.render(n)
+    seq = tmp_path / "seq"
+    lines = harness_seq.write(seq, grays, raws)
+    exe = _build(tmp_path)
+    traj, dump = tmp_path / "camera.txt", tmp_path / "poses.txt"
     cam = [str(float(c)) for c in synth.CAM] + [str(float(synth.DEPTH_SCALE))]
-    r = subprocess.run([str(exe), str(seq) + "/", str(traj), "100", *cam], capture_output=True, text=True, timeout=240)
+    r = subprocess.run([str(exe), str(seq) + "/", str(traj), "100", *cam, str(dump)], capture_output=True, text=True, timeout=400)
     assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-1500:])
     assert f"total tracked number: {n}; total lost times: 0" in r.stdout
     assert "median tracking time:" in r.stdout and "mean tracking time:" in r.stdout and "camera trajectory saved !!!" in r.stdout
+    assert r.stdout.count("local BA ") == 6, r.stdout[-3000:]  # after frames 5, 10, ..., 30
     rows = [ln.split() for ln in traj.read_text().strip().splitlines()]
     assert len(rows) == n and [row[0] for row in rows] == [ln.split()[0] for ln in lines]  # time stamps verbatim
-    got = np.array([[float(v) for v in row[1:]] for row in rows])
-    # the oracle's run of the same loop: same positions (the file carries six significant digits)
-    want = _oracle_run(orc, seq, n)
-    assert np.abs(got[:, :3] - want).max() < 2e-5, np.abs(got[:, :3] - want).max()
-    # ... and both are the synthetic camera's motion: STEP pixels per frame at depth Z
-    truth = np.array([[i * STEP[0] * Z / synth.CAM[0], i * STEP[1] * Z / synth.CAM[1], 0.0] for i in range(n)])
-    assert np.abs(got[:, :3] - truth).max() < 0.01, np.abs(got[:, :3] - truth).max()
-    assert np.abs(got[:, 3:6]).max() < 5e-3 and np.abs(got[:, 6] - 1).max() < 1e-4  # no rotation: quaternion (0, 0, 0, 1)
+    got = np.array([[float(v) for v in ln.split()] for ln in dump.read_text().strip().splitlines()])
+    # the oracle's run of the same script (the PNG round trip is lossless: same images)
+    inv = np.float32(1.0) / np.float32(synth.DEPTH_SCALE)
+    ologs = []
+    want, info = harness_ref.run_sequence(orc, synth, list(grays), list(raws), synth.CAM.astype(np.float32), inv, log=ologs.append)
+    want = np.array(want)
+    assert all(i["ok"] for i in info) and len(ologs) == 6
+    # the per-frame counts the harness prints are the oracle's, frame by frame
+    for i, rec in enumerate(info):
+        assert f"\nframe {i}: " in "\n" + r.stdout
+        if i > 0:
+            assert f", {rec['n_last']} / {rec['n_local']} matches, {rec['inliers']} inliers ({rec['tracked']} tracked from the map)" in \
+                ("\n" + r.stdout).split(f"\nframe {i}: ")[1].split("\n")[0], (i, rec)
+    # ... and so are the local BA problems (frames, points, edges, LM iterations, erased edges)
+    for line in ologs:
+        key = line.split("oracle local BA ")[1].replace(" iterations", " LM iterations").replace(" erased", " edges erased")
+        head, tail = key.split(" LM iterations, ")
+        assert head in r.stdout and f", {tail}" in r.stdout, line
+    assert got.shape == want.shape and np.abs(got - want).max() < 1e-6, np.abs(got - want).max()
+    # ... and both are the synthetic camera's path (integer key-point positions at up to 3.6 x scale: a few mm per frame)
+    harness_seq.check_against_truth(list(got), tol_pos=0.05, tol_rot=3e-3)
+    tq = np.array([[float(v) for v in row[1:]] for row in rows])
+    C, th = harness_seq.truth(n)
+    assert np.abs(tq[:, :3] - C).max() < 0.05
+    assert np.abs(tq[:, 5] - np.sin(th / 2)).max() < 2e-3 and np.abs(tq[:, 6] - np.cos(th / 2)).max() < 1e-4  # roll about z
+
+
+def test_vo_run_harness_short_sequence_without_ba(vo, orc, tmp_path):
+    """four frames: no local BA yet (the first runs after frame 5); trajectory = the oracle's"""
+    n = 4
+    grays, raws = harness_seq.render(n)
+    seq = tmp_path / "seq"
+    harness_seq.write(seq, grays, raws)
+    exe = _build(tmp_path)
+    traj, dump = tmp_path / "camera.txt", tmp_path / "poses.txt"
+    cam = [str(float(c)) for c in synth.CAM] + [str(float(synth.DEPTH_SCALE))]
+    r = subprocess.run([str(exe), str(seq) + "/", str(traj), "100", *cam, str(dump)], capture_output=True, text=True, timeout=240)
+    assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-1500:])
+    assert f"total tracked number: {n}; total lost times: 0" in r.stdout and "local BA" not in r.stdout
+    got = np.array([[float(v) for v in ln.split()] for ln in dump.read_text().strip().splitlines()])
+    inv = np.float32(1.0) / np.float32(synth.DEPTH_SCALE)
+    want, _ = harness_ref.run_sequence(orc, synth, list(grays), list(raws), synth.CAM.astype(np.float32), inv)
+    assert np.abs(got - np.array(want)).max() < 1e-8

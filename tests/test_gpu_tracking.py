@@ -236,13 +236,14 @@ def test_motion_model_retry_at_twice_the_radius(vo, orc):
     oracle_frames = _oracle_frames(orc, imgs, raw, inv, cam5, None, W, H)
     maps = [list(synth.make_tracking_map(fr[2], fr[3], fr[0]["octave"], fr[0]["angle"], fr[1], fr[5], seed=f))
             for f, fr in enumerate(oracle_frames)]
-    for f, shift in ((1, 0.12), (2, 1.5)):   # metres of camera translation the motion model did not predict (depth ~2.5 m)
-        xi = synth.se3_log(*synth.se3_exp(maps[f][1]))
-        xi = np.asarray(maps[f][1], np.float64).copy()
-        R, t = synth.se3_exp(xi)
+    for f, shift in ((1, 0.3), (2, 1.5)):   # metres of camera translation the motion model did not predict (depth ~2.5 m)
+        R, t = synth.se3_exp(np.asarray(maps[f][1], np.float64))
         t = t + np.array([shift, 0.0, 0.0])
         maps[f][0] = np.concatenate([R.reshape(-1), t])
         maps[f][1] = synth.se3_log(R, t)
+        # a sparse last frame (15 % of its points): ~8 of them fall into the 15-px windows, ~35 into the 30-px ones
+        keep = np.random.default_rng(40 + f).random(len(maps[f][2]["flags"])) < 0.15
+        maps[f][2] = dict(maps[f][2], flags=np.where(keep, maps[f][2]["flags"], 0).astype(np.uint8))
     n_last = max(len(m[2]["flags"]) for m in maps)
     n_local = max(len(m[3]["flags"]) for m in maps)
     trk = vo.Tracker(B, cam5, None, W, H, max_last=n_last, max_local=n_local, inv_depth_scale=float(inv))
@@ -268,6 +269,7 @@ def test_motion_model_retry_at_twice_the_radius(vo, orc):
     trk.track(imgs, raw.view(np.uint16), no_retry=True)
     r2 = trk.results()
     assert r2["n_matches_last"][1] < 20 and r2["n_matches_last"][0] == res["n_matches_last"][0]
+    assert r2["status"][1] & trk.FEW_MATCHES
     trk.close()
 
 

@@ -18,7 +18,7 @@ def test_shim_parses(tu):
     assert gxx, "g++ is part of the image"
     # gnu++14 like the reference's own build (its KeyFrameAndPose typedef, loopClosing.h, pairs std::map with an
     # allocator of a different value_type, which strict ISO mode rejects)
-    r = subprocess.run([gxx, "-std=gnu++14", "-fsyntax-only", "-Wall", "-Werror", f"-I{STUBS}", f"-I{ROOT / 'include'}",
+    r = subprocess.run([gxx, "-std=gnu++14", "-fsyntax-only", "-Wall", "-Werror", f"-I{STUBS}", f"-I{STUBS / 'thirdparty'}", f"-I{ROOT / 'include'}",
                         str(STUBS / f"tu_{tu}.cpp")], capture_output=True, text=True)
     assert r.returncode == 0, r.stderr[-3000:]
 

@@ -55,7 +55,9 @@ def local_map_stage(orc, of, k, ux, uy, ur, fpt, has, fobs, p1, a_first, n_first
     has = has | new
     p2, out2, i2, idx2 = solve(p1, has)
     n_tracked = int(fobs[idx2[~out2]].sum())
-    return dict(local_flags=fl, local_u=lu, local_v=lv_, local_ur=lur, local_level=llev, local_viewcos=lvc, assigned_local=a1,
+    foutl = np.zeros(n, np.uint8)
+    foutl[idx2[out2]] = 1
+    return dict(feature_outlier=foutl, local_flags=fl, local_u=lu, local_v=lv_, local_ur=lur, local_level=llev, local_viewcos=lvc, assigned_local=a1,
                 n_local=n1, pose_2=p2, inliers_2=i2, n_tracked=n_tracked, has=has)
 
 
@@ -97,60 +99,56 @@ def track_frame_ref_keyframe(orc, k, d, ux, uy, ur, pose6_last, kf, node_of_fram
     return out
 
 
-def track_frame(orc, k, d, ux, uy, ur, T, pose6, last, local, cam5, sf, W=640, H=480, radius=15.0, th_radius=3.0, ratio=0.8,
-                retry=True):
-    """-> dict of every intermediate result of the path for one frame (k, d: the oracle's key-points and descriptors;
-    ux, uy, ur: undistorted coordinates and uRight; T [12], pose6: the pose estimate; last / local: the map as
-    synth.make_tracking_map builds it)"""
+def track_first(orc, k, d, ux, uy, ur, T, pose6, last, cam5, sf, W=640, H=480, radius=15.0, retry=True):
+    """trackWithMotion (visualOdometry.cpp:224-255): projection, searchByProjection against the last frame's points, the
+    2 x radius retry, solvePoseOnlySE3, cullingOutliersBeforeLocalMap -> state dict for local_map_stage"""
     n = len(k)
     of = orc.FrameData(ux, uy, k["octave"], k["angle"], ur, d)
     cam_d = np.asarray(cam5, np.float64)
-    qf, qu, qv, qz = project_last(T, last["points"], last["flags"], cam5, W, H)
+    nl = len(last["flags"])
     a0 = np.full(n, -1, np.int32)
-    n0 = orc.lib().orc_match_frame_projection(C.byref(of.c), len(qf), qf, qu, qv, qz, np.ascontiguousarray(last["octave"], np.int32),
-                                              np.ascontiguousarray(last["angle"], np.float32), np.ascontiguousarray(last["desc"]),
-                                              float(radius), float(cam5[4]), 0, 1, 8, sf, np.zeros(n, np.uint8), a0)
-    retried = False
-    if retry and n0 < 20:  # visualOdometry.cpp:241-245: clear, search again at twice the radius
-        retried = True
-        a0 = np.full(n, -1, np.int32)
-        n0 = orc.lib().orc_match_frame_projection(C.byref(of.c), len(qf), qf, qu, qv, qz, np.ascontiguousarray(last["octave"], np.int32),
-                                                  np.ascontiguousarray(last["angle"], np.float32), np.ascontiguousarray(last["desc"]),
-                                                  float(2 * radius), float(cam5[4]), 0, 1, 8, sf, np.zeros(n, np.uint8), a0)
+    n0, retried = 0, False
+    qf = np.zeros(0, np.uint8)
+    if nl > 0:
+        qf, qu, qv, qz = project_last(T, np.asarray(last["points"]), np.asarray(last["flags"]), cam5, W, H)
+        args = (np.ascontiguousarray(last["octave"], np.int32), np.ascontiguousarray(last["angle"], np.float32), np.ascontiguousarray(last["desc"]))
+        n0 = orc.lib().orc_match_frame_projection(C.byref(of.c), len(qf), qf, qu, qv, qz, *args, float(radius), float(cam5[4]), 0, 1, 8, sf,
+                                                  np.zeros(n, np.uint8), a0)
+        if retry and n0 < 20:  # visualOdometry.cpp:241-245: clear, search again at twice the radius
+            retried = True
+            a0 = np.full(n, -1, np.int32)
+            n0 = orc.lib().orc_match_frame_projection(C.byref(of.c), len(qf), qf, qu, qv, qz, *args, float(2 * radius), float(cam5[4]), 0, 1, 8,
+                                                      sf, np.zeros(n, np.uint8), a0)
     fpt, has, fobs = np.zeros((n, 3)), a0 >= 0, np.zeros(n, np.uint8)
-    fpt[has] = last["points"][a0[has]]
+    fpt[has] = np.asarray(last["points"])[a0[has]]
     fobs[has] = (qf[a0[has]] >> 1) & 1
 
-    def solve(pose_in):
-        idx = np.nonzero(has)[0]
+    def solve(pose_in, has_now):
+        idx = np.nonzero(has_now)[0]
         pr = dict(pts=np.ascontiguousarray(fpt[idx]),
                   obs=np.ascontiguousarray(np.stack([ux[idx], uy[idx], ur[idx]], 1).astype(np.float64)),
                   inv_sigma=np.ascontiguousarray(1.0 / sf[k["octave"][idx]].astype(np.float64)), cam=cam_d, pose0=pose_in)
         pose, outl, ninl, _, _ = orc.pose_only(pr)
         return pose, np.asarray(outl, bool), ninl, idx
 
-    p1, out1, i1, idx1 = solve(np.asarray(pose6, np.float64))
+    p1, out1, i1, idx1 = solve(np.asarray(pose6, np.float64), has)
     # cullingOutliersBeforeLocalMap (:864-886)
     n_obs1 = int(fobs[idx1[~out1]].sum())
     has[idx1[out1]] = False
     fobs[idx1[out1]] = 0
-    last_matched = np.zeros(len(last["flags"]), bool)
-    last_matched[a0[a0 >= 0]] = True
-    # searchLocalMapPoints (:745-775): isInFrame with the refined pose; points already in the frame are skipped
-    valid = np.asarray(local["valid"], np.uint8).copy()
-    lk = np.asarray(local.get("link", np.full(len(valid), -1)), np.int64)
-    skip = (lk >= 0) & last_matched[np.clip(lk, 0, len(last_matched) - 1)]
-    valid[skip] = 0
-    fl, lu, lv_, lur, llev, lvc = is_in_frame(orc, p1, local, valid, cam5, W, H, sf[1])
-    a1 = np.full(n, -1, np.int32)
-    n1 = orc.lib().orc_match_local_map(C.byref(of.c), len(fl), fl, lu, lv_, lur, llev, lvc, np.ascontiguousarray(local["desc"]),
-                                       float(th_radius), float(ratio), sf, fobs, a1)
-    new = a1 >= 0
-    fpt[new] = local["points"][a1[new]]
-    fobs[new] = (fl[a1[new]] >> 1) & 1
-    has = has | new
-    p2, out2, i2, idx2 = solve(p1)
-    n_tracked = int(fobs[idx2[~out2]].sum())
-    return dict(retried=retried, assigned_last=a0, n_last=n0, pose_1=p1, inliers_1=i1, observed_inliers_1=n_obs1, local_flags=fl, local_u=lu,
-                local_v=lv_, local_ur=lur, local_level=llev, local_viewcos=lvc, assigned_local=a1, n_local=n1, pose_2=p2,
-                inliers_2=i2, n_tracked=n_tracked, has=has)
+    status = (1 if n0 < 20 else 0) | (2 if n_obs1 < 10 else 0)
+    return dict(of=of, retried=retried, assigned_last=a0, n_last=n0, pose_1=p1, inliers_1=i1, observed_inliers_1=n_obs1, fpt=fpt, has=has,
+                fobs=fobs, solve=solve, n_last_list=nl, status=status)
+
+
+def track_frame(orc, k, d, ux, uy, ur, T, pose6, last, local, cam5, sf, W=640, H=480, radius=15.0, th_radius=3.0, ratio=0.8,
+                retry=True):
+    """-> dict of every intermediate result of the path for one frame (k, d: the oracle's key-points and descriptors;
+    ux, uy, ur: undistorted coordinates and uRight; T [12], pose6: the pose estimate; last / local: the map as
+    synth.make_tracking_map builds it)"""
+    s1 = track_first(orc, k, d, ux, uy, ur, T, pose6, last, cam5, sf, W, H, radius, retry)
+    out = {kk: s1[kk] for kk in ("retried", "assigned_last", "n_last", "pose_1", "inliers_1", "observed_inliers_1")}
+    # searchLocalMapPoints (:745-775): matched points -- kept or culled -- carry visualIdxOfFrame_ == frame id and are skipped
+    out.update(local_map_stage(orc, s1["of"], k, ux, uy, ur, s1["fpt"], s1["has"].copy(), s1["fobs"], s1["pose_1"], s1["assigned_last"],
+                               s1["n_last_list"], local, cam5, sf, W, H, th_radius, ratio, s1["solve"]))
+    return out

@@ -403,7 +403,7 @@ class Tracker:
     batch (include/vo_hip.h).  This class only marshals arrays; torch appears where the caller hands over device
     tensors (images, depth) or streams."""
     (ASSIGNED_LAST, ASSIGNED_LOCAL, POSE_FIRST, INLIERS_FIRST, OBSERVED_INLIERS_FIRST, FEATURE_HAS_POINT, FEATURE_POINTS,
-     LOCAL_FLAGS, LOCAL_U, LOCAL_V, LOCAL_UR, LOCAL_LEVEL, LOCAL_VIEWCOS, KEYPOINT_COUNTS) = range(14)
+     LOCAL_FLAGS, LOCAL_U, LOCAL_V, LOCAL_UR, LOCAL_LEVEL, LOCAL_VIEWCOS, KEYPOINT_COUNTS, FEATURE_OUTLIER) = range(15)
     STAGES = ("extract", "frame_post", "match_last_frame", "pose_only_1", "match_local_map", "pose_only_2")
     FEW_MATCHES, FEW_INLIERS = 1, 2
 
@@ -552,7 +552,8 @@ class Tracker:
             self.FEATURE_POINTS: ((B, cap, 3), np.float64), self.LOCAL_FLAGS: ((B, max(nl, 1)), np.uint8),
             self.LOCAL_U: ((B, max(nl, 1)), np.float32), self.LOCAL_V: ((B, max(nl, 1)), np.float32),
             self.LOCAL_UR: ((B, max(nl, 1)), np.float32), self.LOCAL_LEVEL: ((B, max(nl, 1)), np.int32),
-            self.LOCAL_VIEWCOS: ((B, max(nl, 1)), np.float32), self.KEYPOINT_COUNTS: ((B,), np.int32)}[what]
+            self.LOCAL_VIEWCOS: ((B, max(nl, 1)), np.float32), self.KEYPOINT_COUNTS: ((B,), np.int32),
+            self.FEATURE_OUTLIER: ((B, cap), np.uint8)}[what]
         out = np.zeros(shape, dt)
         check(lib().vo_tracker_get(self._h, int(what), _p(out), C.c_size_t(out.nbytes)), "vo_tracker_get")
         return out

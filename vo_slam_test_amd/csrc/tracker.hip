@@ -187,14 +187,20 @@ __global__ __launch_bounds__(256) void k_track_in_frame(int nq, int stride, cons
 // no outlier of the second solve; and the per-frame status word.
 __global__ __launch_bounds__(256) void k_track_count(int cap, const int *ranges, const int *index, const uint8_t *outlier,
                                                      const uint8_t *fobs, const int *n_first, const int *n_observed_first,
-                                                     const int *ninl_first, int *n_tracked, int *status, int min_matches) {
+                                                     const int *ninl_first, int *n_tracked, int *status, int min_matches,
+                                                     uint8_t *feature_outlier) {
   __shared__ int s_cnt[4];
   const int f = blockIdx.x, tid = threadIdx.x;
   const long long o = (long long)f * cap;
   const int start = ranges[2 * f], count = ranges[2 * f + 1];
+  // frame_curr_->outliers_[i] after the second solve, per feature (features without a map point: 0)
+  for (int i = tid; i < cap; i += 256) feature_outlier[o + i] = 0;
+  __syncthreads();
   int local = 0;
-  for (int d = tid; d < count; d += 256)
+  for (int d = tid; d < count; d += 256) {
+    if (outlier[start + d]) feature_outlier[o + index[start + d]] = 1;
     if (!outlier[start + d] && fobs[o + index[start + d]]) local++;
+  }
   for (int s = 32; s >= 1; s >>= 1) local += __shfl_xor(local, s);
   if ((tid & 63) == 0) s_cnt[tid >> 6] = local;
   __syncthreads();
@@ -249,7 +255,7 @@ struct vo_tracker {
   DevBuf kps, desc, cnt, images, depth;
   DevBuf q0_flags, q0_u, q0_v, q0_aux, q0_level, q0_angle, q0_desc, p0, pf0, last_matched;
   DevBuf q1_flags, q1_u, q1_v, q1_aux, q1_level, q1_viewcos, q1_desc, p1, nrm1, mind1, maxd1, pf1, link1;
-  DevBuf Tcw, pose0, pose, pose_first, resblk, retry_nq;  // retry_nq: [B] + the retried-frames counter  // resblk: k_track_pack's block (72 bytes per frame + 2 flags)
+  DevBuf Tcw, pose0, pose, pose_first, resblk, retry_nq, foutl;  // retry_nq: [B] + the retried-frames counter  // resblk: k_track_pack's block (72 bytes per frame + 2 flags)
   DevBuf assigned, assigned_first, nm, nm_first, fpoint, fhas, fobs, pts, obs, isg, ranges, index, outlier, ninl, ninl_first,
       nobs_first, ntracked, status;
   PinnedBuf stage;
@@ -322,6 +328,7 @@ int alloc_all(vo_tracker *t) {
   VO_CHECK(t->ntracked.reserve(B * 4 + 64));
   VO_CHECK(t->status.reserve(B * 4 + 64));
   VO_CHECK(t->retry_nq.reserve(B * 4 + 64));
+  VO_CHECK(t->foutl.reserve(B * cap + 64));
   return VO_OK;
 }
 
@@ -543,7 +550,8 @@ int stage_local(vo_tracker *t, const vo_tracker_params &P) {
     VO_CHECK(solve_pose(t));
     hipLaunchKernelGGL(k_track_count, dim3(B), dim3(256), 0, st, t->cap, t->ranges.as<int>(), t->index.as<int>(),
                        t->outlier.as<uint8_t>(), t->fobs.as<uint8_t>(), t->nm_first.as<int>(), t->nobs_first.as<int>(),
-                       t->ninl_first.as<int>(), t->ntracked.as<int>(), t->status.as<int>(), t->first_min_matches);
+                       t->ninl_first.as<int>(), t->ntracked.as<int>(), t->status.as<int>(), t->first_min_matches,
+                       t->foutl.as<uint8_t>());
   }
   return VO_OK;
 }
@@ -900,6 +908,7 @@ int vo_tracker_get(vo_tracker *t, int what, void *dst, size_t dst_bytes) {
     case VO_TRACKER_LOCAL_LEVEL: b = &t->q1_level, bytes = B * (size_t)t->n_local * 4; break;
     case VO_TRACKER_LOCAL_VIEWCOS: b = &t->q1_viewcos, bytes = B * (size_t)t->n_local * 4; break;
     case VO_TRACKER_KEYPOINT_COUNTS: b = &t->cnt, bytes = B * 4; break;
+    case VO_TRACKER_FEATURE_OUTLIER: b = &t->foutl, bytes = B * cap; break;
     default: return VO_ERR_INVALID;
   }
   if (dst_bytes < bytes) {
