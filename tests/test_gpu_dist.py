@@ -45,3 +45,25 @@ def test_two_process_sharded_global_ba_500_keyframes():
     out = r.stdout + r.stderr
     assert r.returncode == 0, out[-4000:]
     assert out.count("-> OK") == 2 and "MISMATCH" not in out, out[-4000:]
+
+
+@pytest.mark.timeout(1500)
+def test_bench_gpus_2_starts_two_ranks_and_reports_the_sharded_legs():
+    """`python bench.py --gpus 2` without a launcher: bench.py itself starts two fresh ranks (before touching the GPU) and relays
+    rank 0's JSON line -- n_gpus = 2, frames sharded without a collective, and under world > 1 the sharded config-3 leg, the
+    replicas leg and the sharded config-4 global BA (payload of its all-reduce reported).  gloo: both ranks share GPU 0."""
+    import json
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", OMP_NUM_THREADS="2")
+    env.pop("WORLD_SIZE", None), env.pop("RANK", None), env.pop("LOCAL_RANK", None)
+    cmd = [sys.executable, str(ROOT / "bench.py"), "--gpus", "2", "--backend", "gloo", "--steps", "2", "--warmup", "1", "--batch", "64",
+           "--no-bruteforce", "--no-single-stream"]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=1400, env=env, cwd=str(ROOT))
+    assert r.returncode == 0, (r.stdout[-2000:], r.stderr[-4000:])
+    line = [ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1]
+    d = json.loads(line)
+    assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["value"] > 0
+    assert d["collective_backend"] == "gloo" and "RCCL has not been exercised" in d["rccl_note"]
+    assert "replicas" in d["local_ba"] and "sharding" in d["local_ba"] and d["local_ba"]["lm_iters_per_s"] > 0
+    g = d["global_ba"]
+    assert g["lm_iters_per_s"] > 0 and 1.0 < g["allreduce_payload_MB"] < 15.0 and g["key_frame_order"]["parts"] > 1
+    assert "cpu_baseline" not in d  # rank 0 at N = 1 only

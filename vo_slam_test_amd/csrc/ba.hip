@@ -19,6 +19,9 @@
 //                 single GPU: the last block also runs the trust-region update
 //   k_ba_reduce2 / k_ba_update  (sharded) second payload and trust-region bookkeeping
 #include "ba_math.h"
+#ifndef VO_POSE_V
+#define VO_POSE_V 7  // developer A/B switches (tools/ab_pose.sh): 1 value-major scratch, 2 LDS-only hand-offs, 4 no prefetch behind the last batch
+#endif
 #include "vo_common.h"
 
 #include <algorithm>
@@ -243,7 +246,8 @@ __device__ __forceinline__ void pose_accumulate(const PoseCache &P, int n, const
 #pragma unroll 1
     for (int base = 0; base < n; base += ND * 64) {
       Ob nxt[ND];
-      request(base + ND * 64, nxt);  // the next batch travels while this one is evaluated
+      // the next batch travels while this one is evaluated (none behind the last one: those loads would only be waited for)
+      if (!(VO_POSE_V & 4) || base + ND * 64 < n) request(base + ND * 64, nxt);
 #pragma unroll
       for (int k = 0; k < ND; k++)
         if (base + 64 * k + lane < n && !cur[k].skip)
@@ -312,21 +316,35 @@ __device__ __forceinline__ void wave_lds_sync() {  // LDS hand-off between lanes
 // [64][15] scratch: lane l stores its 14 values as row l, lane 4 v + q sums rows q, q + 4, ... of column v, the four
 // quarter sums meet by two quad permutes.  About 110 instructions for what 28 DPP / readlane wave sums did in 1000
 // (a third of the instructions the round-2 kernel executed per LM iteration).
-constexpr int kPoseRedScratch = 64 * 15;
+// Layout (round 4): value-major at a pitch of 68 doubles -- scratch[k][lane].  A lane's stores of one value land on
+// consecutive doubles across the wavefront, and the column reads of lane 4 v + q (rows 4 j + q of value v) fall on banks
+// 8 v + 2 q + 8 j (mod 64): distinct inside each half-wave, where the lane-major [64][15] layout of round 3 read two-way
+// conflicted (49 % of the kernel's LDS cycles).  The hand-offs wait for LDS only: a wavefront-scope fence also waits for
+// vmcnt(0), i.e. for whatever the observation prefetch still has in flight.
+constexpr int kPoseRedPitch = 68;
+constexpr int kPoseRedScratch = (VO_POSE_V & 1) ? 14 * kPoseRedPitch : 64 * 15;
+__device__ __forceinline__ void wave_lds_handoff() {
+#if VO_POSE_V & 2
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_wave_barrier();
+#else
+  wave_lds_sync();
+#endif
+}
 __device__ __forceinline__ void wave_reduce28(const double (&v)[28], double *scratch, double *dst) {
   const int lane = threadIdx.x & 63, vi = lane >> 2, q = lane & 3;
 #pragma unroll
   for (int c = 0; c < 2; c++) {
 #pragma unroll
-    for (int k = 0; k < 14; k++) scratch[lane * 15 + k] = v[14 * c + k];
-    wave_lds_sync();
+    for (int k = 0; k < 14; k++) scratch[(VO_POSE_V & 1) ? k * kPoseRedPitch + lane : lane * 15 + k] = v[14 * c + k];
+    wave_lds_handoff();
     double t = 0;
     if (lane < 56) {
       // all sixteen loads in flight before the first add (a running sum over loads waits for LDS once per term),
       // summed pairwise in a fixed order
       double u[16];
 #pragma unroll
-      for (int j = 0; j < 16; j++) u[j] = scratch[(4 * j + q) * 15 + vi];
+      for (int j = 0; j < 16; j++) u[j] = scratch[(VO_POSE_V & 1) ? vi * kPoseRedPitch + 4 * j + q : (4 * j + q) * 15 + vi];
 #pragma unroll
       for (int w = 8; w >= 1; w >>= 1)
 #pragma unroll
@@ -336,7 +354,7 @@ __device__ __forceinline__ void wave_reduce28(const double (&v)[28], double *scr
     t += dpp_f64<0xB1>(t);  // quad_perm [1,0,3,2]
     t += dpp_f64<0x4E>(t);  // quad_perm [2,3,0,1]
     if (lane < 56 && q == 0) dst[14 * c + vi] = t;
-    wave_lds_sync();
+    wave_lds_handoff();
   }
 }
 

@@ -172,7 +172,9 @@ struct NodeArgs {
 // the ~10 searchForTriangulation calls of LocalMapping::createNewMapPoints (localMapping.cpp:187, one per neighbour
 // key-frame) or the searchByBoW calls over the loop / relocalisation candidates are ONE launch.
 __global__ __launch_bounds__(64) void k_node_replay(const NodeArgs *__restrict__ args) {
-  const NodeArgs P = args[blockIdx.x];
+  // (a reference, not a copy: the 300-byte argument block with its dynamically indexed sf[] was copied to scratch memory;
+  //  read in place its fields are scalar loads and sf[i] one global load)
+  const NodeArgs &P = args[blockIdx.x];
   extern __shared__ __attribute__((aligned(16))) uint8_t nr_lds[];
   __shared__ int hist[32];
   const int lane = threadIdx.x;

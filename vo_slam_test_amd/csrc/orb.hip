@@ -66,6 +66,19 @@ struct FrameSrc {  // where level 0 lives (caller memory) and where levels >= 1 
   long long blur_frame_stride;
 };
 
+// The blurred planes are read by nothing but the descriptor windows (39 x 39 pixels around a key-point), and a window row
+// of a row-major plane costs a 128-byte line of its own: ~50 lines pulled through the texture path for 1.5 KB of pixels,
+// which is what k_describe waits for.  They are therefore stored in TILES of 16 x 8 pixels = one
+// 128-byte line each (tile rows of pitch / 16 tiles; the plane's height is padded to 8 rows): a window then touches
+// 3-4 x 5-6 = 15-24 lines.  The blur kernels only change their store address; vo_orb_get_level un-tiles on the host.
+__host__ __device__ __forceinline__ long long blur_tiled_off(int x, int y, int pitch) {
+#if VO_BLUR_TILED
+  return (long long)(y >> 3) * pitch * 8 + (x >> 4) * 128 + (y & 7) * 16 + (x & 15);
+#else
+  return (long long)y * pitch + x;
+#endif
+}
+
 __device__ __forceinline__ const uint8_t *level_plane(const OrbDev &P, const FrameSrc &S, int l, int f,
                                                       int &pitch) {
   if (l == 0) {
@@ -128,6 +141,9 @@ __device__ __forceinline__ int dot2_i16(unsigned taps, unsigned coef) {
 #endif
 #ifndef VO_FAST_ARC16
 #define VO_FAST_ARC16 1
+#endif
+#ifndef VO_BLUR_TILED
+#define VO_BLUR_TILED 1  // 0: blurred planes row-major (rounds 1-3)
 #endif
 #ifndef VO_RZ_ABLATE
 #define VO_RZ_ABLATE 0  // developer ablation switch (tools/rz_ablate.py); 0 in the product build
@@ -1103,7 +1119,7 @@ __global__ __launch_bounds__(256) void k_blur(OrbDev P, FrameSrc src, unsigned l
 #pragma unroll
     for (int j = 0; j < 7; j++) acc += kq[j] * hs[r + j][c];
     const int v = (acc + (1 << 15)) >> 16;
-    dst[(long long)(y0 + r) * L.pitch + x0 + c] = (uint8_t)min(v, 255);
+    dst[blur_tiled_off(x0 + c, y0 + r, L.pitch)] = (uint8_t)min(v, 255);
   }
 }
 
@@ -1147,8 +1163,9 @@ __global__ __launch_bounds__(256) void k_blur_groups(FrameSrc src, int lv0_gener
     img = src.pyr + (long long)f0 * src.pyr_frame_stride + (((long long)sd[10] << 32) | (unsigned)sd[9]);
     fsrc = (unsigned)(fl * src.pyr_frame_stride);
   }
+  // (the lane's part of the store address: its frame and its column -- in the tiled layout tile column and byte in the tile row)
   uint8_t *dst = src.blur + (long long)f0 * src.blur_frame_stride + (((long long)sd[7] << 32) | (unsigned)sd[6]) +
-                 (long long)fl * src.blur_frame_stride + x;
+                 (long long)fl * src.blur_frame_stride + blur_tiled_off(x, 0, 0);
   // the three dwords of the lane: columns x-4.., x.., x+4..; at the row ends the neighbour is replaced by the
   // group itself (never read outside the row) and rebuilt below
   const unsigned vC = fsrc + (unsigned)x, vL = vC - (G > 0 ? 4u : 0u), vR = vC + (x + 4 < pitch ? 4u : 0u);
@@ -1234,7 +1251,8 @@ __global__ __launch_bounds__(256) void k_blur_groups(FrameSrc src, int lv0_gener
         acc = __builtin_amdgcn_udot2(__builtin_bit_cast(u16x2, pr[(u + 1) % 7][q]), W01, acc, false);
         outw |= min(acc >> 16, 255u) << (8 * q);
       }
-      if (yy >= y0 + 3 && active) *reinterpret_cast<unsigned *>(dst + (long long)(yy - 3) * Lpitch) = outw;  // the tail lands in the row padding
+      // (the row's part is scalar; the tail lands in the row padding)
+      if (yy >= y0 + 3 && active) *reinterpret_cast<unsigned *>(dst + blur_tiled_off(0, yy - 3, Lpitch)) = outw;
     }
   }
 }
@@ -1330,7 +1348,10 @@ __device__ __forceinline__ int wave_sum_i32(int x) {  // sum over the 64 lanes, 
 }
 
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
-constexpr int kWinPitch = 64;       // LDS row pitch of a staged window: four 16-byte chunks
+// LDS row pitch of a staged window: four 16-byte chunks.  (Round 4 measured 80 and 96 -- pitches that walk the rows through
+// all 32 banks instead of 16 -- against VERDICT r3's reading of the 48 % bank-conflict cycles: 0.746 / 0.747 / 0.749 ms per
+// 1024 frames for 64 / 80 / 96, i.e. no effect: the LDS pipe is not what the kernel waits for, its window fetches are.)
+constexpr int kWinPitch = 64;
 constexpr int kWinBytes = 40 * 64;  // 39 rows, rounded up to a multiple of 4 lanes x 16 bytes
 
 // Stage the ROWS x (<= 64 - 15) byte window whose top-left pixel is `origin` (row pitch `pitch`, rows 16-byte
@@ -1352,6 +1373,24 @@ __device__ __forceinline__ void window_issue(unsigned long long origin, int pitc
     const int idx = lane + 64 * j;
     const int row = min(CH == 4 ? idx >> 2 : idx / 3, ROWS - 1), chunk = CH == 4 ? idx & 3 : idx % 3;
     const unsigned goff = (unsigned)(row * pitch + 16 * chunk);
+    v[j] = *reinterpret_cast<const __attribute__((address_space(1))) u32x4 *>(base + goff);
+  }
+}
+// the same for a window of a TILED plane (blur_tiled_off): chunk c of window row r is the 16-byte row (y0 + r) & 7 of tile
+// ((x0 >> 4) + c, (y0 + r) >> 3); consecutive lanes walk down the rows of a tile, so a load instruction touches a third
+// of the lines it touched in a row-major plane
+template <int ROWS, int CH>
+__device__ __forceinline__ void window_issue_tiled(unsigned long long plane, int pitch, int xy0, int lane, u32x4 (&v)[(ROWS * CH + 63) / 64], int &ox) {
+  constexpr int NJ = (ROWS * CH + 63) / 64;
+  const int x0 = uni_i32(xy0 & 0xffff), y0 = uni_i32(xy0 >> 16);
+  ox = x0 & 15;
+  gmem_u8 *base = uni_ptr(plane) + (x0 >> 4) * 128;
+#pragma unroll
+  for (int j = 0; j < NJ; j++) {
+    const int idx = lane + 64 * j;
+    const int row = min(CH == 4 ? idx >> 2 : idx / 3, ROWS - 1), chunk = CH == 4 ? idx & 3 : idx % 3;
+    const int y = y0 + row;
+    const unsigned goff = (unsigned)((y >> 3) * (pitch * 8) + (y & 7) * 16 + chunk * 128);
     v[j] = *reinterpret_cast<const __attribute__((address_space(1))) u32x4 *>(base + goff);
   }
 }
@@ -1434,11 +1473,17 @@ __global__ __launch_bounds__(256) void k_describe(OrbDev P, FrameSrc src, const 
     const uint8_t *bl = src.blur + (long long)f * src.blur_frame_stride + L.blur_off;
     DescRec r;
     r.disc_base = (unsigned long long)(uintptr_t)(img + (long long)(py - kHalfPatch) * pitch + (px - kHalfPatch));
+#if VO_BLUR_TILED
+    r.blur_base = (unsigned long long)(uintptr_t)bl;  // the plane; the window's origin (px - 19, py - 19) rides in `pad`
+    r.pad = (px - kEdge) | ((py - kEdge) << 16);
+#else
     r.blur_base = (unsigned long long)(uintptr_t)(bl + (long long)(py - kEdge) * bp + (px - kEdge));
+    r.pad = 0;
+#endif
     r.pitch = pitch, r.bpitch = bp;
     r.m10 = r.m01 = 0;
     r.a = r.b = 0.f;
-    r.bytewise = l == 0 && lv0_bytewise, r.pad = 0;
+    r.bytewise = l == 0 && lv0_bytewise;
     rec[tid] = r;
     kv_own = kv, l_own = l, px_own = px, py_own = py;
   }
@@ -1531,6 +1576,17 @@ __global__ __launch_bounds__(256) void k_describe(OrbDev P, FrameSrc src, const 
     for (int s = 0; s < NK; s++) {
       const int kk = min(k + s, k1 - 1);
       const unsigned long long bb = rec[kk].blur_base;
+#if VO_BLUR_TILED
+      const int xy0 = rec[kk].pad;
+      narrow[s] = uni_i32(xy0 & 15) <= 48 - (2 * kEdge + 1);  // uniform: three chunks per row suffice
+      if (narrow[s]) {
+        u32x4 w2[2];
+        window_issue_tiled<2 * kEdge + 1, 3>(bb, uni_i32(rec[kk].bpitch), xy0, lane, w2, ox[s]);
+        wv[s][0] = w2[0], wv[s][1] = w2[1];
+      } else {
+        window_issue_tiled<2 * kEdge + 1, 4>(bb, uni_i32(rec[kk].bpitch), xy0, lane, wv[s], ox[s]);
+      }
+#else
       narrow[s] = uni_i32((int)(unsigned)bb & 15) <= 48 - (2 * kEdge + 1);  // uniform: three chunks per row suffice
       if (narrow[s]) {
         u32x4 w2[2];
@@ -1539,6 +1595,7 @@ __global__ __launch_bounds__(256) void k_describe(OrbDev P, FrameSrc src, const 
       } else {
         window_issue<2 * kEdge + 1, 4>(bb, uni_i32(rec[kk].bpitch), lane, wv[s], ox[s]);
       }
+#endif
     }
 #pragma unroll
     for (int s = 0; s < NK; s++) {
@@ -1691,7 +1748,7 @@ int configure(vo_orb *h, int w, int h_img, int n_frames) {
       L.pyr_off = pyr;
       if (l > 0) pyr += (long long)L.pitch * L.h;
       L.blur_off = blur;
-      blur += (long long)L.pitch * L.h;
+      blur += (long long)L.pitch * align_up(L.h, 8);  // (tiles of 8 rows)
       L.scale = h->scale[l];
       L.patchSize = (int)(31 * h->scale[l]);  // :842
       L.maxBX = L.w - kEdge + 3;
@@ -2246,6 +2303,13 @@ int vo_orb_get_level(vo_orb *h, int frame, int level, int blurred, uint8_t *dst,
   } else {
     sp = h->last_src.pyr + (long long)frame * h->last_src.pyr_frame_stride + L.pyr_off;
     pitch = L.pitch;
+  }
+  if (blurred && VO_BLUR_TILED) {  // the blurred planes are stored in 16 x 8 tiles: fetch the plane, un-tile on the host
+    std::vector<uint8_t> tmp((size_t)pitch * align_up(L.h, 8));
+    VO_HIP_CHECK(hipMemcpy(tmp.data(), sp, tmp.size(), hipMemcpyDeviceToHost));
+    for (int y = 0; y < L.h; y++)
+      for (int x = 0; x < L.w; x++) dst[(size_t)y * dst_stride + x] = tmp[(size_t)blur_tiled_off(x, y, pitch)];
+    return VO_OK;
   }
   VO_HIP_CHECK(hipMemcpy2D(dst, dst_stride, sp, pitch, L.w, L.h, hipMemcpyDeviceToHost));
   return VO_OK;
