@@ -20,7 +20,7 @@
 //   k_ba_reduce2 / k_ba_update  (sharded) second payload and trust-region bookkeeping
 #include "ba_math.h"
 #ifndef VO_POSE_V
-#define VO_POSE_V 7  // developer A/B switches (tools/ab_pose.sh): 1 value-major scratch, 2 LDS-only hand-offs, 4 no prefetch behind the last batch
+#define VO_POSE_V 1  // developer A/B switches (tools/ab_pose.sh): 1 value-major scratch (product: 0.284 -> 0.280 ms), 2 LDS-only hand-offs (no effect), 4 no prefetch behind the last batch (+6 %: the branch breaks the software pipeline)
 #endif
 #include "vo_common.h"
 

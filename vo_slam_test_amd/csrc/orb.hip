@@ -6,6 +6,9 @@
 // Compiled with -ffp-contract=off: the float expressions that decide integer results
 // (fastAtan2 polynomial, x*b + y*a sample coordinates, pt *= scale) must round exactly like the
 // x86-64 reference build, which has no FMA.
+#ifndef VO_BLUR_TILED
+#define VO_BLUR_TILED 1  // 0: blurred planes row-major (rounds 1-3)
+#endif
 #include "vo_common.h"
 
 #include <cmath>
@@ -141,9 +144,6 @@ __device__ __forceinline__ int dot2_i16(unsigned taps, unsigned coef) {
 #endif
 #ifndef VO_FAST_ARC16
 #define VO_FAST_ARC16 1
-#endif
-#ifndef VO_BLUR_TILED
-#define VO_BLUR_TILED 1  // 0: blurred planes row-major (rounds 1-3)
 #endif
 #ifndef VO_RZ_ABLATE
 #define VO_RZ_ABLATE 0  // developer ablation switch (tools/rz_ablate.py); 0 in the product build
@@ -1163,9 +1163,19 @@ __global__ __launch_bounds__(256) void k_blur_groups(FrameSrc src, int lv0_gener
     img = src.pyr + (long long)f0 * src.pyr_frame_stride + (((long long)sd[10] << 32) | (unsigned)sd[9]);
     fsrc = (unsigned)(fl * src.pyr_frame_stride);
   }
-  // (the lane's part of the store address: its frame and its column -- in the tiled layout tile column and byte in the tile row)
+#if VO_BLUR_TILED
+  // the lane's part of the store address: its frame and the tile column of its quad (lanes 4 t .. 4 t + 3 = the four column
+  // groups of one 16-pixel tile; lanes past the row end keep their own tile column: what they store is row padding)
+  const int Gu = cb * kBlurB + (lane & (kBlurB - 1));
+  const bool tile_ok = fvalid && 4 * (Gu & ~3) < Lpitch && (Gu & ~3) < ngroups;
   uint8_t *dst = src.blur + (long long)f0 * src.blur_frame_stride + (((long long)sd[7] << 32) | (unsigned)sd[6]) +
-                 (long long)fl * src.blur_frame_stride + blur_tiled_off(x, 0, 0);
+                 (long long)fl * src.blur_frame_stride + (Gu >> 2) * 128;
+  __shared__ __attribute__((aligned(16))) unsigned tr_all[4][4][64];
+  unsigned (*tr)[64] = tr_all[threadIdx.x >> 6];
+#else
+  uint8_t *dst = src.blur + (long long)f0 * src.blur_frame_stride + (((long long)sd[7] << 32) | (unsigned)sd[6]) +
+                 (long long)fl * src.blur_frame_stride + x;
+#endif
   // the three dwords of the lane: columns x-4.., x.., x+4..; at the row ends the neighbour is replaced by the
   // group itself (never read outside the row) and rebuilt below
   const unsigned vC = fsrc + (unsigned)x, vL = vC - (G > 0 ? 4u : 0u), vR = vC + (x + 4 < pitch ? 4u : 0u);
@@ -1251,8 +1261,28 @@ __global__ __launch_bounds__(256) void k_blur_groups(FrameSrc src, int lv0_gener
         acc = __builtin_amdgcn_udot2(__builtin_bit_cast(u16x2, pr[(u + 1) % 7][q]), W01, acc, false);
         outw |= min(acc >> 16, 255u) << (8 * q);
       }
+#if VO_BLUR_TILED
+      // Tiled plane: a row's dword per lane would be a 4-byte piece in each of sixteen 128-byte lines (measured: the blur
+      // 50 % slower).  Four output rows are transposed through LDS instead -- lane (tile t, column group j) then holds the
+      // four dwords of row j of its tile and stores them as ONE 16-byte tile row: as many line touches per row as the
+      // row-major layout had.  (Rows come in groups of four aligned to four: a strip starts at a multiple of 36.)
+      if (yy >= y0 + 3) {  // uniform
+        const int y = yy - 3;
+        tr[y & 3][lane] = outw;
+        if ((y & 3) == 3 || y == y1 - 1) {  // uniform: the group is complete (or the strip ends)
+          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+          __builtin_amdgcn_wave_barrier();
+          const int yr = (y & ~3) + (lane & 3);
+          const u32x4_t v = *reinterpret_cast<const u32x4_t *>(&tr[lane & 3][lane & ~3]);
+          if (tile_ok && yr <= y) *reinterpret_cast<u32x4_t *>(dst + blur_tiled_off(0, yr, Lpitch)) = v;
+          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // (the next group's writes stay behind these reads)
+          __builtin_amdgcn_wave_barrier();
+        }
+      }
+#else
       // (the row's part is scalar; the tail lands in the row padding)
-      if (yy >= y0 + 3 && active) *reinterpret_cast<unsigned *>(dst + blur_tiled_off(0, yy - 3, Lpitch)) = outw;
+      if (yy >= y0 + 3 && active) *reinterpret_cast<unsigned *>(dst + (long long)(yy - 3) * Lpitch) = outw;
+#endif
     }
   }
 }
