@@ -136,6 +136,8 @@ __global__ __launch_bounds__(256) void k_resize(const uint8_t *src, long long s_
 // a0 | a1 << 16) gives tap0*a0 + tap1*a1 in one instruction.
 typedef short short2_t __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ int dot2_i16(unsigned taps, unsigned coef) {
+  // (the compiler emits v_mov_b32 0 + the two-operand v_dot2c_i32_i16 for the zero accumulator; the three-operand form with
+  //  an inline 0 saves the 32 moves per thread and not a microsecond: 0.496 ms either way, round 4)
   return __builtin_amdgcn_sdot2(__builtin_bit_cast(short2_t, taps), __builtin_bit_cast(short2_t, coef), 0, false);
 }
 
@@ -144,6 +146,15 @@ __device__ __forceinline__ int dot2_i16(unsigned taps, unsigned coef) {
 #endif
 #ifndef VO_FAST_ARC16
 #define VO_FAST_ARC16 1
+#endif
+#ifndef VO_OCT_WAVES
+#define VO_OCT_WAVES 7
+#endif
+#ifndef VO_BLUR_PACK
+#define VO_BLUR_PACK 1
+#endif
+#ifndef VO_RZ_REUSE
+#define VO_RZ_REUSE 1
 #endif
 #ifndef VO_RZ_ABLATE
 #define VO_RZ_ABLATE 0  // developer ablation switch (tools/rz_ablate.py); 0 in the product build
@@ -233,6 +244,49 @@ __global__ __launch_bounds__(256) void k_resize4(const uint8_t *src, long long s
   __syncthreads();
   const int dyw = dy0 + wave * R;
   uint8_t *orow = Dst + (long long)dyw * d_pitch + dx;
+#if VO_RZ_REUSE && !VO_RZ_ABLATE
+  // Round 4: (i) consecutive output rows share a source row four times out of five at scale 1.2 (row r + 1's upper row
+  // is row r's lower one: the row indices are wave-uniform, so the test is a scalar branch) -- its horizontal sums are
+  // kept instead of being read and formed again; (ii) no clamp: the weights are non-negative and sum to 2048 in both
+  // directions, so the value is <= (255 * 4 + 2) >> 2 = 255 by construction.  23.6 -> ~18 instructions per output pixel.
+  int hp[4] = {0, 0, 0, 0}, prev_row = -1;
+#pragma unroll
+  for (int r = 0; r < R; r++) {
+    if (dyw + r >= dh) break;  // uniform per wave
+    const int sy0 = min(max(sy_[r], 0), sh - 1) - r0, sy1 = min(max(sy_[r] + 1, 0), sh - 1) - r0;
+    const int b0 = (short)(bb_[r] & 0xffff), b1 = bb_[r] >> 16;
+    int g0[4], g1[4];  // horizontal sums >> 4 of the upper / lower source row
+    if (sy0 == prev_row) {  // uniform
+#pragma unroll
+      for (int q = 0; q < 4; q++) g0[q] = hp[q];
+    } else {
+      const uint8_t *R0 = rz_tile + __mul24(sy0 * kRzF, kRzPitch);
+      const unsigned p0 = *reinterpret_cast<const unsigned *>(R0 + o0), p1 = *reinterpret_cast<const unsigned *>(R0 + o1),
+                     p2 = *reinterpret_cast<const unsigned *>(R0 + o2);
+      const unsigned pl = __builtin_amdgcn_alignbyte(p1, p0, woff), ph = __builtin_amdgcn_alignbyte(p2, p1, woff);
+#pragma unroll
+      for (int q = 0; q < 4; q++) g0[q] = dot2_i16(__builtin_amdgcn_perm(ph, pl, sel[q]), ab[q]) >> 4;
+    }
+    {
+      const uint8_t *R1 = rz_tile + __mul24(sy1 * kRzF, kRzPitch);
+      const unsigned q0 = *reinterpret_cast<const unsigned *>(R1 + o0), q1 = *reinterpret_cast<const unsigned *>(R1 + o1),
+                     q2 = *reinterpret_cast<const unsigned *>(R1 + o2);
+      const unsigned ql = __builtin_amdgcn_alignbyte(q1, q0, woff), qh = __builtin_amdgcn_alignbyte(q2, q1, woff);
+#pragma unroll
+      for (int q = 0; q < 4; q++) g1[q] = dot2_i16(__builtin_amdgcn_perm(qh, ql, sel[q]), ab[q]) >> 4;
+    }
+    unsigned outw = 0;
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+      // 24-bit multiplies are exact here: |b| <= 2048, |h >> 4| <= 255 * 2048 / 16
+      const int val = ((__mul24(b0, g0[q]) >> 16) + (__mul24(b1, g1[q]) >> 16) + 2) >> 2;
+      outw |= (unsigned)val << (8 * q);
+      hp[q] = g1[q];
+    }
+    prev_row = sy1;
+    if (store_ok) *reinterpret_cast<unsigned *>(orow + (long long)r * d_pitch) = outw;  // the tail lands in the row padding
+  }
+#else
 #pragma unroll
   for (int r = 0; r < R; r++) {
     if (dyw + r >= dh) break;  // uniform per wave
@@ -265,6 +319,7 @@ __global__ __launch_bounds__(256) void k_resize4(const uint8_t *src, long long s
 #endif
     if (store_ok) *reinterpret_cast<unsigned *>(orow + (long long)r * d_pitch) = outw;  // the tail lands in the row padding
   }
+#endif
 }
 
 // ------------------------------------------------------------------------------------------
@@ -712,7 +767,7 @@ __device__ __forceinline__ int quadrant_of(int kx, int ky, int x0, int y0, int x
 // (7 waves per SIMD = 7 workgroups per CU: the kernel is a chain of latencies, co-resident workgroups are its
 // throughput; 0.326 -> 0.283 ms per 1024 frames against the compiler's own choice of 88 registers / 5 waves)
 template <int CAP>
-__attribute__((amdgpu_waves_per_eu(7, 7))) __global__ __launch_bounds__(256) void k_octree(OrbDev P, const uint32_t *cell_slots,
+__attribute__((amdgpu_waves_per_eu(VO_OCT_WAVES, VO_OCT_WAVES))) __global__ __launch_bounds__(256) void k_octree(OrbDev P, const uint32_t *cell_slots,
                                                 long long slots_frame_stride, const int *cell_count,
                                                 int cells_per_frame, uint32_t *key_data,
                                                 unsigned short *key_label, int keys_per_frame,
@@ -1250,6 +1305,9 @@ __global__ __launch_bounds__(256) void k_blur_groups(FrameSrc src, int lv0_gener
       hn[2] = __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(Cw, Lw, 3), K0, __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(Rw, Cw, 3), K1, 0u, false), false);
       hn[3] = __builtin_amdgcn_udot4(Cw, K0, __builtin_amdgcn_udot4(Rw, K1, 0u, false), false);
       unsigned outw = 0;
+#if VO_BLUR_PACK
+      unsigned a4[4];
+#endif
 #pragma unroll
       for (int q = 0; q < 4; q++) {
         pr[(u + 6) % 7][q] = prev[q] | (hn[q] << 16);  // rows (u - 1, u)
@@ -1259,8 +1317,16 @@ __global__ __launch_bounds__(256) void k_blur_groups(FrameSrc src, int lv0_gener
         acc = __builtin_amdgcn_udot2(__builtin_bit_cast(u16x2, pr[(u + 5) % 7][q]), W45, acc, false);
         acc = __builtin_amdgcn_udot2(__builtin_bit_cast(u16x2, pr[(u + 3) % 7][q]), W23, acc, false);
         acc = __builtin_amdgcn_udot2(__builtin_bit_cast(u16x2, pr[(u + 1) % 7][q]), W01, acc, false);
+#if VO_BLUR_PACK
+        a4[q] = min(acc, 0x00ffffffu);  // byte 2 = min(acc >> 16, 255)
+#else
         outw |= min(acc >> 16, 255u) << (8 * q);
+#endif
       }
+#if VO_BLUR_PACK
+      // the four saturated bytes (byte 2 of each sum) by two byte permutes and an OR: 7 instructions per group instead of 12
+      outw = __builtin_amdgcn_perm(a4[1], a4[0], 0x0c0c0602u) | __builtin_amdgcn_perm(a4[3], a4[2], 0x06020c0cu);
+#endif
 #if VO_BLUR_TILED
       // Tiled plane: a row's dword per lane would be a 4-byte piece in each of sixteen 128-byte lines (measured: the blur
       // 50 % slower).  Four output rows are transposed through LDS instead -- lane (tile t, column group j) then holds the
