@@ -32,6 +32,8 @@ for line in open(pmc):
     if not m or "SQ_INSTS_VALU" not in m.group(2):
         continue
     d = ast.literal_eval(m.group(2))
+    if d["SQ_INSTS_VALU"] < valu.get(m.group(1), 0):
+        continue  # several instantiations of one kernel (k_guided_cand<8> / <16>: the retry pass leaves every frame out): keep the working one
     valu[m.group(1)], salu[m.group(1)], lds[m.group(1)] = d["SQ_INSTS_VALU"], d.get("SQ_INSTS_SALU", 0), d.get("SQ_INSTS_LDS", 0)
 dur = {}
 for r in csv.DictReader(open(stats)):
