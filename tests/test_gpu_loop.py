@@ -160,7 +160,8 @@ def test_rgb_to_gray(vo, orc):
     assert np.abs(vo.rgb_to_gray(img, True).astype(float) - y).max() <= 1.0   # the fixed-point weights of cv::cvtColor
 
 
-def _write_dbow3_binary(path, k, L, parent, weight, word_id, desc, children=None, compressed=False, truncate=None, bad_parent=False):
+def _write_dbow3_binary(path, k, L, parent, weight, word_id, desc, children=None, compressed=False, truncate=None, bad_parent=False,
+                        child_first=False):
     """DBoW3 Vocabulary::toStream as published (the library is not vendored under the reference): magic, bool compressed,
     uint32 nnodes, k, L, scoring, weighting; nnodes - 1 node records -- NO root record -- in the writer's depth-first
     order (a stack of parents; the children of a popped parent are written in order, non-leaf children pushed): id,
@@ -171,15 +172,18 @@ def _write_dbow3_binary(path, k, L, parent, weight, word_id, desc, children=None
         for i in range(1, n):
             children[int(parent[i])].append(i)
     body = struct.pack("<iiii", k, L, 0, 0)
-    stack, written = [0], 0
+    stack, written, recs = [0], 0, []
     while stack:
         pid = stack.pop()
         for c in children[pid]:
             par = n + 5 if (bad_parent and written == 3) else pid
-            body += struct.pack("<IId", c, par, float(weight[c])) + struct.pack("<iii", 32, 1, 0) + bytes(desc[c])
+            recs.append(struct.pack("<IId", c, par, float(weight[c])) + struct.pack("<iii", 32, 1, 0) + bytes(desc[c]))
             written += 1
             if children[c]:
                 stack.append(c)
+    if child_first:  # a foreign / malformed file: a grandchild's record ahead of its parent's
+        recs.insert(0, recs.pop())
+    body += b"".join(recs)
     words = [i for i in range(n) if word_id[i] >= 0]
     body += struct.pack("<I", len(words))
     for i in words:
@@ -264,7 +268,8 @@ def test_vocabulary_file_loader(vo, orc, fmt, tmp_path):
             vo.load_vocabulary(tmp_path / "bad.yml")
     if fmt == "binary":  # malformed streams are refused, not trusted: compressed, truncated, a parent id out of range
         args = (6, 3, parent, V["node_weight"], V["word_id"], V["node_desc"])
-        for name, kw in (("z", dict(compressed=True)), ("t", dict(truncate=1000)), ("p", dict(bad_parent=True))):
+        for name, kw in (("z", dict(compressed=True)), ("t", dict(truncate=1000)), ("p", dict(bad_parent=True)),
+                         ("c", dict(child_first=True))):   # (a child before its parent would lose the parent's subtree: ADVICE r3)
             _write_dbow3_binary(tmp_path / name, *args, **kw)
             with pytest.raises(vo.VoError):
                 vo.load_vocabulary(tmp_path / name)

@@ -253,9 +253,12 @@ int load_dbow3_yaml(const char *path, const std::string &t, std::vector<VocNode>
       return VO_ERR_INVALID;
     }
     const long id = strtol(sid->c_str(), nullptr, 10), pid = strtol(spid->c_str(), nullptr, 10);
-    if (id <= 0 || (size_t)id >= nn || pid < 0 || (size_t)pid >= nn || seen[id]) {
+    // a parent must be defined before its children (DBoW3's writers emit parent first): a later record for the parent would
+    // overwrite the children collected so far, and a node may never be its own ancestor
+    if (id <= 0 || (size_t)id >= nn || pid < 0 || (size_t)pid >= nn || seen[id] || pid == id || !seen[pid]) {
       vo::set_error("%s: record %zu names node %ld / parent %ld (of %zu nodes%s)", path, r, id, pid, nn,
-                    id > 0 && (size_t)id < nn && seen[id] ? ", twice" : "");
+                    id > 0 && (size_t)id < nn && seen[id] ? ", twice"
+                    : (pid >= 0 && (size_t)pid < nn && !seen[pid]) ? "; the parent is not defined before its child" : "");
       return VO_ERR_INVALID;
     }
     VocNode n;
@@ -487,9 +490,10 @@ int vo_vocab_load(const char *path, vo_vocab **out, int *n_nodes, int *n_words, 
       f.read(reinterpret_cast<char *>(&rows), 4);
       f.read(reinterpret_cast<char *>(&type), 4);
       if (!f) break;
-      if (n.id == 0 || n.id >= nn || n.parent >= nn || seen[n.id]) {
+      if (n.id == 0 || n.id >= nn || n.parent >= nn || seen[n.id] || n.parent == n.id || !seen[n.parent]) {
         vo::set_error("%s: record %u names node %u / parent %u (of %u nodes%s)", path, i, n.id, n.parent, nn,
-                      n.id < nn && seen[n.id] ? ", twice" : "");
+                      n.id < nn && seen[n.id] ? ", twice"
+                      : (n.parent < nn && !seen[n.parent]) ? "; the parent is not defined before its child" : "");
         return VO_ERR_INVALID;
       }
       memset(n.desc, 0, 32);
