@@ -427,9 +427,14 @@ __host__ __device__ __forceinline__ int fast_align16(int v) { return (v + 15) & 
 //    whose margin does not exceed the threshold cannot score above it); the rare second round at minThFAST and
 //    the rare overflow path recompute the margins instead of reading them back;
 // Results are bit-identical to round 2's kernel and to the oracle (tests/test_gpu_orb.py); 0.253 -> 0.210 ms per 256
-// frames.  Early-exit builds split the 0.213 ms into staging 0.074, margin walk 0.048, arc scores 0.057, NMS + output
-// 0.035: the phases add up, i.e. the staging latency (table entry, then the tile: two dependent memory round trips
-// of ~3 us per cell with 32 waves per CU in flight) is not hidden by the other waves' compute.
+// frames.  Early-exit builds (1024 frames, round 4: 0.72 ms) return after staging at 0.275, after the first margin walk
+// at 0.45, after the arc scores at 0.65; the minThFAST round costs 0.05.  The 0.275 is NOT a latency that the full
+// kernel leaves exposed: a form of this kernel in which a wave takes 2 / 4 / 8 consecutive cells and fetches the next
+// cell's tile into registers while it works on the current one (tools/attic/k_fast_cell_prefetch_r04.diff.txt) ran
+// at 0.76 / 0.76 / 0.77 ms with 7 waves per SIMD (71 registers), 0.80 with 6 and 1.11 with 8 (spills) -- no
+// dependence on the cells per wave, ~5 % per resident wave.  An early-exit build of 860 k four-line waves measures
+// the dispatcher; in the full kernel the staging is covered and what is left is instruction issue (VALU + LDS,
+// DESIGN.md section 7) with the dependent LDS round trips that the resident waves overlap.
 // ------------------------------------------------------------------------------------------
 #define VO_OP16(name, ins)                                                   \
   __device__ __forceinline__ unsigned name(unsigned a, unsigned b) {          \
@@ -1997,7 +2002,7 @@ int configure(vo_orb *h, int w, int h_img, int n_frames) {
       int mcap = 0;
       for (int l = 0; l < h->nlevels; l++) mcap = std::max(mcap, std::max(D.lv[l].capSel, D.lv[l].nIni));
       h->oct_small = mcap <= 256 - 4;
-      h->fast_tp = mw + 9 <= 48 ? 48 : kTileP;
+      h->fast_tp = mw + 9 <= 48 && mh + 6 <= 64 ? 48 : kTileP;  // 48: three 16-byte chunks per row, <= 192 chunks per tile
       h->fast_rows = mh + 6;
       h->fast_interior = std::max(128, (mw * mh + 1) / 2);  // survivor-list entries: half the cell's pixels (see k_fast_cell)
       h->fast_lds = 4 * (size_t)fast_cell_lds(h->fast_tp, h->fast_rows, h->fast_interior);
