@@ -673,6 +673,14 @@ int vo_sim3_reanchor_points(int n_points, const double *points_in, const int32_t
  * vo_pose_graph_solve): A row-major, lower triangle read and overwritten by its factor, b -> x. */
 int vo_chol_solve(int n, double *A_rowmajor_lower, double *b);
 
+/* The same solve through the split (per-rank segment) form that a sharded global BA uses (vo_ba_set_shard +
+ * vo_ba_set_allreduce on a reduced system with a nested-dissection order), with the n_ranks shards
+ * emulated one after the other on this GPU -- a test entry: the 64-column tile columns [0, c0_tiles) hold segments that
+ * are independent of each other (col_part[j] = the segment of tile column j, owned by rank col_part[j] % n_ranks), the
+ * remaining tile columns the separators.  Per rank: eliminate the own segments into the separator block; the separator
+ * blocks are summed (the all-reduce); every rank solves the separators and substitutes back into its segments.  b -> x. */
+int vo_chol_solve_split(int n, const double *A_rowmajor_lower, double *b, int c0_tiles, const int32_t *col_part, int n_ranks);
+
 /* Bundle-adjustment problem handle (the arrays Optimizer::solveLocalBAPoseAndPoint gathers at
  * optimizer_ceres.cpp:446-592).  Edges may be given in any order; they are grouped by point
  * internally (stable).  cam_fixed[c] != 0 <=> SetParameterBlockConstant (:578-579). */

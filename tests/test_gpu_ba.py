@@ -338,6 +338,39 @@ def test_device_cholesky_random_plans(vo, seed):
     assert np.abs(x - np.linalg.solve(A, b)).max() < 1e-10 * max(1.0, np.abs(x).max())
 
 
+@pytest.mark.parametrize("seed", range(10))
+@pytest.mark.parametrize("n_ranks", [1, 2, 3])
+def test_split_segment_solve_matches_numpy(vo, seed, n_ranks):
+    """the per-rank segment form of the factorisation (sharded global BA): independent segments of 1..4 tile columns, a
+    separator block of 1..5 tile columns (banded or full, so that its Schur complement has fill), a ragged last tile; every
+    emulated rank eliminates its own segments, the separator blocks are summed, every rank solves the separators and
+    substitutes back: x against numpy"""
+    rng = np.random.default_rng(7000 + seed)
+    n_parts = int(rng.integers(2, 6))
+    lens = [int(rng.integers(1, 5)) for _ in range(n_parts)]
+    n_sep = int(rng.integers(1, 6))
+    c0 = sum(lens)
+    m = c0 + n_sep
+    n = 64 * (m - 1) + int(rng.integers(1, 65))
+    col_part = np.concatenate([np.full(l, g) for g, l in enumerate(lens)]).astype(np.int32)
+    keep = np.zeros((m, m), bool)
+    at = 0
+    for l in lens:  # inside a segment: a band (seed-dependent width), towards the separators: random tiles
+        for i in range(at, at + l):
+            keep[i, max(at, i - int(rng.integers(0, 3))):i + 1] = True
+        keep[c0:, at:at + l] = rng.random((n_sep, l)) < 0.6
+        at += l
+    keep[c0:, c0:] = (rng.random((n_sep, n_sep)) < 0.5) if seed % 2 else np.tril(np.ones((n_sep, n_sep), bool))
+    keep = keep | keep.T | np.eye(m, dtype=bool)
+    M = rng.normal(size=(n, n))
+    A = (M + M.T) * np.kron(keep, np.ones((64, 64)))[:n, :n]
+    A += (np.abs(A).sum(1).max() + 1.0) * np.eye(n)
+    b = rng.normal(size=n)
+    x = vo.chol_solve_split(A, b, c0, col_part, n_ranks)
+    xr = np.linalg.solve(A, b)
+    assert np.abs(x - xr).max() < 1e-10 * max(1.0, np.abs(xr).max())
+
+
 def test_device_cholesky_rejects_indefinite(vo):
     A = np.eye(70)
     A[40, 40] = -1.0

@@ -55,7 +55,7 @@ SYMBOLS = [
     "vo_match_frame_projection", "vo_match_local_map", "vo_match_frame_keyframe", "vo_match_bow",
     "vo_match_triangulation", "vo_match_bow_batch", "vo_match_triangulation_batch", "vo_match_fuse", "vo_match_area_best", "vo_match_sim3_projection",
     "vo_match_sim3_mutual", "vo_vocab_create", "vo_vocab_destroy", "vo_bow_transform",
-    "vo_pose_only_solve", "vo_sim3_solve", "vo_pose_graph_solve", "vo_sim3_reanchor_points", "vo_chol_solve", "vo_pose_only_solve_dev",
+    "vo_pose_only_solve", "vo_sim3_solve", "vo_pose_graph_solve", "vo_sim3_reanchor_points", "vo_chol_solve", "vo_chol_solve_split", "vo_pose_only_solve_dev",
     "vo_ba_create", "vo_ba_destroy", "vo_ba_set_stream", "vo_ba_set_shard", "vo_ba_set_allreduce", "vo_ba_set_state",
     "vo_ba_get_state", "vo_ba_n_free_cams", "vo_ba_local_ba", "vo_ba_local_ba_enqueue",
     "vo_ba_local_ba_finish", "vo_ba_solve", "vo_ba_lm_begin",
@@ -871,6 +871,15 @@ def chol_solve(A, b):
     x = np.ascontiguousarray(b, np.float64).copy()
     check(lib().vo_chol_solve(len(x), _p(A), _p(x)), "vo_chol_solve")
     return x, np.tril(A)
+
+
+def chol_solve_split(A, b, c0_tiles, col_part, n_ranks):
+    """the split (per-rank segment) solve of a sharded global BA, its ranks emulated on one GPU -> x"""
+    A = np.ascontiguousarray(A, np.float64)
+    x = np.ascontiguousarray(b, np.float64).copy()
+    cp = np.ascontiguousarray(col_part, np.int32)
+    check(lib().vo_chol_solve_split(len(x), _p(A), _p(x), int(c0_tiles), _p(cp), int(n_ranks)), "vo_chol_solve_split")
+    return x
 
 
 def sim3_reanchor_points(points, ref, S_rw, S_wr):

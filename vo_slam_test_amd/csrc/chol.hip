@@ -386,7 +386,8 @@ __global__ __launch_bounds__(256) void k_chol_tiles(CholCtx C) {
       // (store + flag + load: ~2.5 us of every column's ~17).
       const int j = task.z;
       const int i = task.y;                                  // j <= i <= m  (i == m: right-hand-side rows)
-      const bool fused = task.w != 0;
+      const bool fused = task.w == 1;
+      const bool update_only = task.w == 2;  // split plans: a separator tile takes this rank's segments' updates and stays unfactored
       const int R0 = i < m ? NB * i : ld, C0 = NB * j;
       const int qr = (wave >> 1) * 32, qc = (wave & 1) * 32;
       double4_t acc[2][2], accd[2][2];
@@ -452,6 +453,19 @@ __global__ __launch_bounds__(256) void k_chol_tiles(CholCtx C) {
         __syncthreads();
       }
       if (!alive) return;
+      if (update_only) {
+        // A(i,j) - sum over this rank's segment columns: what the ranks' all-reduce turns into the Schur complement on the
+        // separators (plain stores: the next reader is another launch, behind the collective)
+#pragma unroll
+        for (int a = 0; a < 2; a++)
+#pragma unroll
+          for (int b = 0; b < 2; b++) {
+            double *p = C.A + (long long)(R0 + qr + 16 * a + q4) * ld + C0 + qc + 16 * b + i16;
+            p[0] = acc[a][b][0], p[4LL * ld] = acc[a][b][1], p[8LL * ld] = acc[a][b][2], p[12LL * ld] = acc[a][b][3];
+          }
+        if (tid == 0) atomicAdd(C.done, 1);
+        continue;
+      }
       if (stamp_slot >= 0) CSTAMP(stamp_slot, 2);
       // accumulators -> LDS working tile
 #pragma unroll
@@ -849,79 +863,101 @@ void vo::chol_symbolic(int m, const unsigned long long *pattern, unsigned long l
   if (n_tiles) *n_tiles = nt;
 }
 
-vo::CholPlan *vo::chol_plan_create(int m, const unsigned long long *pattern) {
+// The general builder.  role[j] of tile column j: 0 = not part of this plan, 1 = factored (and, with `back`, solved) by it,
+// 2 = update only (its tiles (i, j), i >= j, take the products over the columns in `kcols` and stay unfactored).  `kcols`:
+// the columns whose tiles may be waited for / multiplied (bit k).  The whole matrix: role = 1 everywhere, kcols = all.
+static vo::CholPlan *build_plan(int m, const unsigned long long *pattern, const std::vector<uint8_t> &role, unsigned long long kcols,
+                                bool front, bool back) {
   if (m < 1 || m > 64) return nullptr;
   std::vector<unsigned long long> lm((size_t)m + 1);
   int depth = 0, nt = 0;
   vo::chol_symbolic(m, pattern, lm.data(), &depth, &nt);
   lm[m] = m == 64 ? ~0ull : ((1ull << m) - 1ull);  // the right-hand-side row
   auto has = [&](int i, int j) { return ((lm[i] >> j) & 1ull) != 0; };
+  auto below = [](int j) { return (1ull << j) - 1ull; };
   std::vector<int4> tasks;
   int n_factor = 0;
   // Ticket order (see the kernel): tile columns by their level in the dependency graph, so that the first columns of
   // independent parts of the matrix are handed out together.  Everything column j waits for lies in columns of a lower
   // level: tiles (i, k) and (j, k) both exist only if row j has a tile in column k, i.e. level(k) < level(j).
-  std::vector<int> level((size_t)m, 1), seq((size_t)m);
+  std::vector<int> level((size_t)m, 1), seq;
   for (int j = 0; j < m; j++) {
+    if (role[j] != 1) continue;
     for (int k = 0; k < j; k++)
-      if (has(j, k)) level[j] = std::max(level[j], level[k] + 1);
-    seq[j] = j;
+      if (role[k] == 1 && ((kcols >> k) & 1ull) && has(j, k)) level[j] = std::max(level[j], level[k] + 1);
+    seq.push_back(j);
   }
   std::stable_sort(seq.begin(), seq.end(), [&](int a, int b) { return level[a] < level[b]; });
-  for (int p = 0; p < m; p++) {
-    const int j = seq[p];
-    for (int i = j; i <= m; i++) {
-      if (!has(i, j)) continue;
-      n_factor++;
-      if (i == j && j > 0 && has(j, j - 1)) continue;  // this diagonal tile belongs to the task of tile (j, j - 1)
-      tasks.push_back(make_int4(0, i, j, (i == j + 1 && i < m) ? 1 : 0));
+  const int ns = (int)seq.size();
+  if (front) {
+    for (int p = 0; p < ns; p++) {
+      const int j = seq[p];
+      for (int i = j; i <= m; i++) {
+        if (!has(i, j)) continue;
+        n_factor++;
+        if (i == j && j > 0 && has(j, j - 1) && role[j - 1] == 1) continue;  // this diagonal tile belongs to the task of tile (j, j - 1)
+        tasks.push_back(make_int4(0, i, j, (i == j + 1 && i < m && role[i] == 1) ? 1 : 0));
+      }
+      if (p >= 2) tasks.push_back(make_int4(1, 0, seq[p - 2], 0));
     }
-    if (p >= 2) tasks.push_back(make_int4(1, 0, seq[p - 2], 0));
+    for (int p = std::max(0, ns - 2); p < ns; p++) tasks.push_back(make_int4(1, 0, seq[p], 0));
+    // update-only tiles: behind every column they read
+    for (int j = 0; j < m; j++) {
+      if (role[j] != 2) continue;
+      for (int i = j; i <= m; i++)
+        if (has(i, j) && (lm[i] & lm[j] & kcols & below(j)) != 0ull) tasks.push_back(make_int4(0, i, j, 2)), n_factor++;
+    }
   }
-  for (int p = std::max(0, m - 2); p < m; p++) tasks.push_back(make_int4(1, 0, seq[p], 0));
   const int n_front = (int)tasks.size();
   // Backward substitution.  A chain = a run of columns j_hi .. j_lo joined by their sub-diagonal tiles; it walks them
   // with the tiles (j + 1, j) and (j + 2, j) of its own columns in registers.  Where the sub-diagonal tile is missing
   // (the first column of a nested-dissection segment) a new chain starts: the segments' chains run concurrently once
   // the separators' unknowns are there.  Every other tile (i, j) is a far link: S_j += L(i,j)^T x_i by whichever
   // workgroup takes it, in the order i descending (a running sum: deterministic).
-  std::vector<int> chain_top((size_t)m);
-  for (int j = m - 1; j >= 0; j--) chain_top[j] = (j == m - 1 || !has(j + 1, j)) ? j : chain_top[j + 1];
-  for (int j = m - 1; j >= 0; j--)
-    if (chain_top[j] == j) {
-      int lo = j;
-      while (lo > 0 && chain_top[lo - 1] == j) lo--;
-      tasks.push_back(make_int4(2, j, lo, 0));
+  std::vector<int> chain_top((size_t)m, -1);
+  std::vector<int2> colinfo((size_t)m, make_int2(0, 0));
+  if (back) {
+    for (int j = m - 1; j >= 0; j--)
+      if (role[j] == 1) chain_top[j] = (j == m - 1 || !has(j + 1, j) || role[j + 1] != 1) ? j : chain_top[j + 1];
+    for (int j = m - 1; j >= 0; j--)
+      if (role[j] == 1 && chain_top[j] == j) {
+        int lo = j;
+        while (lo > 0 && role[lo - 1] == 1 && chain_top[lo - 1] == j) lo--;
+        tasks.push_back(make_int4(2, j, lo, 0));
+      }
+    auto is_near = [&](int i, int j) { return i - j <= 2 && i <= chain_top[j]; };
+    for (int j = 0; j < m; j++) {
+      if (role[j] != 1) continue;
+      int far = 0, near = 0;
+      for (int i = j + 1; i < m; i++) {
+        if (!has(i, j)) continue;
+        if (is_near(i, j)) near |= 1 << (i - j - 1);
+        else far++;
+      }
+      colinfo[j] = make_int2(far, near);
     }
-  std::vector<int2> colinfo((size_t)m);
-  auto is_near = [&](int i, int j) { return i - j <= 2 && i <= chain_top[j]; };
-  for (int j = 0; j < m; j++) {
-    int far = 0, near = 0;
-    for (int i = j + 1; i < m; i++) {
-      if (!has(i, j)) continue;
-      if (is_near(i, j)) near |= 1 << (i - j - 1);
-      else far++;
-    }
-    colinfo[j] = make_int2(far, near);
+    for (int i = m - 1; i >= 1; i--)      // far links: i descending, then j descending (closest to the chain first);
+      for (int j = i - 1; j >= 0; j--) {  // aux = the far links of column j with a larger i (its turn in the sum)
+        if (role[j] != 1 || !has(i, j) || is_near(i, j)) continue;
+        int before = 0;
+        for (int r = i + 1; r < m; r++) before += (has(r, j) && !is_near(r, j)) ? 1 : 0;
+        tasks.push_back(make_int4(3, i, j, before));
+      }
   }
-  for (int i = m - 1; i >= 1; i--)      // far links: i descending, then j descending (closest to the chain first);
-    for (int j = i - 1; j >= 0; j--) {  // aux = the far links of column j with a larger i (its turn in the sum)
-      if (!has(i, j) || is_near(i, j)) continue;
-      int before = 0;
-      for (int r = i + 1; r < m; r++) before += (has(r, j) && !is_near(r, j)) ? 1 : 0;
-      tasks.push_back(make_int4(3, i, j, before));
-    }
+  std::vector<unsigned long long> rowmask((size_t)m + 1);
+  for (int i = 0; i <= m; i++) rowmask[i] = lm[i] & kcols;
   int n_updates = 0;  // tile products L(i,k) L(j,k)^T of the factorisation (2 x 64^3 flop each)
   for (int i = 0; i < m; i++)
     for (int j = 0; j <= i; j++)
-      if (has(i, j)) n_updates += __builtin_popcountll(lm[i] & lm[j] & ((1ull << j) - 1ull));
+      if (role[j] != 0 && has(i, j)) n_updates += __builtin_popcountll(rowmask[i] & rowmask[j] & below(j));
   vo::CholPlan *P = new vo::CholPlan();
   P->n_updates = n_updates;
   P->m = m, P->n_tasks = (int)tasks.size(), P->n_factor = n_factor, P->n_front = n_front, P->n_tiles = nt, P->depth = depth;
+  if (tasks.empty()) tasks.push_back(make_int4(-1, 0, 0, 0));  // (never handed out: n_tasks = 0)
   const size_t o_mask = tasks.size() * sizeof(int4), o_col = o_mask + (size_t)(m + 1) * 8, total = o_col + (size_t)m * sizeof(int2);
   std::vector<uint8_t> img(total);
   memcpy(img.data(), tasks.data(), o_mask);
-  memcpy(img.data() + o_mask, lm.data(), (size_t)(m + 1) * 8);
+  memcpy(img.data() + o_mask, rowmask.data(), (size_t)(m + 1) * 8);
   memcpy(img.data() + o_col, colinfo.data(), (size_t)m * sizeof(int2));
   if (P->dev.reserve(total) != VO_OK || hipMemcpy(P->dev.p, img.data(), total, hipMemcpyHostToDevice) != hipSuccess) {
     P->dev.release();
@@ -932,6 +968,32 @@ vo::CholPlan *vo::chol_plan_create(int m, const unsigned long long *pattern) {
   P->rowmask = reinterpret_cast<const unsigned long long *>(reinterpret_cast<uint8_t *>(P->dev.p) + o_mask);
   P->colinfo = reinterpret_cast<const int2 *>(reinterpret_cast<uint8_t *>(P->dev.p) + o_col);
   return P;
+}
+
+vo::CholPlan *vo::chol_plan_create(int m, const unsigned long long *pattern) {
+  if (m < 1 || m > 64) return nullptr;
+  return build_plan(m, pattern, std::vector<uint8_t>((size_t)m, 1), ~0ull, true, true);
+}
+
+// Split plans of a nested-dissection order whose segments fill the tile columns [0, c0) and whose separators fill [c0, m):
+// `own` = the segment columns this rank eliminates (bit j).
+//   phase 1  this rank's segments: factor their columns (separator rows and the right-hand-side row included) and subtract
+//            their products from the separator block, which stays unfactored (its sum over the ranks is the Schur complement)
+//   phase 2  the separator block on its own: factor + backward substitution (the same on every rank)
+//   phase 3  backward substitution of this rank's segment columns from the separators' solution
+vo::CholPlan *vo::chol_plan_create_split(int m, const unsigned long long *pattern, int c0, unsigned long long own, int phase) {
+  if (m < 1 || m > 64 || c0 < 1 || c0 >= m || phase < 1 || phase > 3) return nullptr;
+  const unsigned long long seg = (1ull << c0) - 1ull, all = m == 64 ? ~0ull : ((1ull << m) - 1ull);
+  own &= seg;
+  std::vector<uint8_t> role((size_t)m, 0);
+  for (int j = 0; j < m; j++) {
+    const bool mine = ((own >> j) & 1ull) != 0;
+    if (phase == 1) role[j] = mine ? 1 : (j >= c0 ? 2 : 0);
+    else if (phase == 2) role[j] = j >= c0 ? 1 : 0;
+    else role[j] = mine ? 1 : 0;
+  }
+  const unsigned long long kcols = phase == 2 ? (all & ~seg) : own;
+  return build_plan(m, pattern, role, kcols, phase != 3, phase != 1);
 }
 
 void vo::chol_plan_destroy(vo::CholPlan *p) {
@@ -1055,10 +1117,12 @@ vo::CholOrder vo::chol_choose_order(int nf, int bs, const std::vector<std::pair<
           vo::CholOrder o;
           o.parts = P, o.cyclic = cyclic, o.sep = w;
           o.slot_of.assign((size_t)nf, -1);
+          o.part_of.assign((size_t)nf, -1);
+          o.seg_slots = in_segs;
           int next_seg = 0, pos = 0;
           for (int g = 0; g < P; g++) {
             const int len = g < P - 1 ? base : last;
-            for (int q = 0; q < len; q++) o.slot_of[pos++] = next_seg++;
+            for (int q = 0; q < len; q++) o.part_of[next_seg] = g, o.slot_of[pos++] = next_seg++;
             if (g < n_sep)
               for (int q = 0; q < sep_len[g]; q++) o.slot_of[pos++] = sep_start[g] + q;
           }
@@ -1079,14 +1143,11 @@ size_t vo::chol_workspace_bytes(int ld) {
   return ints + ((size_t)m * m * NB + (size_t)m * NB + (size_t)m * NB * NB) * 8 + (size_t)2 * m * 16 * 8;
 }
 
-void vo::chol_factor_solve(double *A, int ld, void *workspace, hipStream_t st, const vo::CholPlan *plan) {
+namespace {
+// which = 1: the factorisation launch, 2: the backward launch, 3: both.  xready_from < m: the unknowns of the tile columns
+// [xready_from, m) are already in the solution row (split plans, phase 3).
+void chol_launch(double *A, int ld, void *workspace, hipStream_t st, const vo::CholPlan *plan, int which, int xready_from) {
   const int m = ld / NB;
-  if (!plan || plan->m != m) plan = dense_plan(m);
-  if (!plan) {  // no plan (allocation failure, m outside 1..64): raise the caller's fail flag -- never a silent no-op
-    static const int abandoned = 2;
-    (void)hipMemcpyAsync(workspace, &abandoned, 4, hipMemcpyHostToDevice, st);
-    return;
-  }
   int *wsI = reinterpret_cast<int *>(workspace);
   const size_t ints = ((size_t)chol_ws_ints(m) * 4 + 255) & ~(size_t)255;
   // everything but the fail flag (word 0, owned by the caller) starts at zero
@@ -1094,6 +1155,7 @@ void vo::chol_factor_solve(double *A, int ld, void *workspace, hipStream_t st, c
   CholCtx C;
   C.A = A, C.ld = ld, C.m = m;
   C.fail = wsI, C.ticket = wsI + 1, C.done = wsI + 2, C.ticket2 = wsI + 3, C.ready = wsI + 16, C.xready = C.ready + (m + 1) * m, C.pcount = C.xready + m, C.invready = C.pcount + m;
+  if (xready_from < m) (void)hipMemsetD32Async((hipDeviceptr_t)(C.xready + xready_from), 1, (size_t)(m - xready_from), st);
   C.partial = reinterpret_cast<double *>(reinterpret_cast<uint8_t *>(workspace) + ints);
   C.linv = C.partial + (size_t)m * m * NB + (size_t)m * NB;
   C.stamps = reinterpret_cast<unsigned long long *>(C.linv + (size_t)m * NB * NB);
@@ -1114,6 +1176,33 @@ void vo::chol_factor_solve(double *A, int ld, void *workspace, hipStream_t st, c
   }
   C.tasks = plan->tasks, C.rowmask = plan->rowmask, C.colinfo = plan->colinfo;
   C.n_tasks = plan->n_tasks, C.n_factor = plan->n_factor, C.n_front = plan->n_front;
-  hipLaunchKernelGGL(k_chol_tiles, dim3(std::max(1, std::min(plan->n_front, 2 * n_cu))), dim3(256), lds, st, C);
-  hipLaunchKernelGGL(k_chol_back, dim3(std::max(1, std::min(plan->n_tasks - plan->n_front, 2 * n_cu))), dim3(256), lds, st, C);
+  if ((which & 1) && plan->n_front > 0)
+    hipLaunchKernelGGL(k_chol_tiles, dim3(std::max(1, std::min(plan->n_front, 2 * n_cu))), dim3(256), lds, st, C);
+  if ((which & 2) && plan->n_tasks > plan->n_front)
+    hipLaunchKernelGGL(k_chol_back, dim3(std::max(1, std::min(plan->n_tasks - plan->n_front, 2 * n_cu))), dim3(256), lds, st, C);
+}
+}  // namespace
+
+void vo::chol_factor_solve(double *A, int ld, void *workspace, hipStream_t st, const vo::CholPlan *plan) {
+  const int m = ld / NB;
+  if (!plan || plan->m != m) plan = dense_plan(m);
+  if (!plan) {  // no plan (allocation failure, m outside 1..64): raise the caller's fail flag -- never a silent no-op
+    static const int abandoned = 2;
+    (void)hipMemcpyAsync(workspace, &abandoned, 4, hipMemcpyHostToDevice, st);
+    return;
+  }
+  chol_launch(A, ld, workspace, st, plan, 3, m);
+}
+
+// One phase of a split solve (plans of chol_plan_create_split; the caller sums the separator block over the ranks between
+// phases 1 and 2 and the solution row after phase 3).  The inverses of the diagonal tiles and their reciprocal diagonals
+// (phase 1) stay in the workspace for phase 3; every phase starts from fresh flags.
+void vo::chol_split_phase(double *A, int ld, void *workspace, hipStream_t st, const vo::CholPlan *plan, int phase, int c0) {
+  const int m = ld / NB;
+  if (!plan || plan->m != m) {
+    static const int abandoned = 2;
+    (void)hipMemcpyAsync(workspace, &abandoned, 4, hipMemcpyHostToDevice, st);
+    return;
+  }
+  chol_launch(A, ld, workspace, st, plan, phase == 1 ? 1 : (phase == 2 ? 3 : 2), phase == 3 ? c0 : m);
 }

@@ -280,9 +280,9 @@ extern "C" {
 
 // the 64 x 64 tiles that hold a non-zero: a matrix with empty tiles is factored on its sparse plan (the plans of the
 // large reduced camera systems go through the same code; this entry point is how the tests reach them).  NULL = dense.
-static vo::CholPlan *plan_of_matrix(const std::vector<double> &Ap, int ld) {
+static bool pattern_of_matrix(const std::vector<double> &Ap, int ld, std::vector<unsigned long long> &pattern) {
   const int m = ld / NB;
-  std::vector<unsigned long long> pattern((size_t)m, 0ull);
+  pattern.assign((size_t)m, 0ull);
   bool dense = true;
   for (int ti = 0; ti < m; ti++)
     for (int tj = 0; tj <= ti; tj++) {
@@ -296,7 +296,91 @@ static vo::CholPlan *plan_of_matrix(const std::vector<double> &Ap, int ld) {
       if (nz) pattern[ti] |= 1ull << tj;
       else dense = false;
     }
-  return dense ? nullptr : vo::chol_plan_create(m, pattern.data());
+  return dense;
+}
+static vo::CholPlan *plan_of_matrix(const std::vector<double> &Ap, int ld) {
+  std::vector<unsigned long long> pattern;
+  return pattern_of_matrix(Ap, ld, pattern) ? nullptr : vo::chol_plan_create(ld / NB, pattern.data());
+}
+
+// Test entry of the split (per-rank segment) solve, csrc/chol.hip: the n_ranks shards are emulated one after the other on
+// this GPU.  The tile columns [0, c0) hold independent segments -- col_part[j] = the segment of tile column j, owned by rank
+// col_part[j] % n_ranks --, the rest the separators.  Every "rank" gets the segment columns it owns; the separator block
+// and its part of the right-hand side go to rank 0 alone (the sum over the ranks is the matrix).  Phase 1 per rank, the
+// separator blocks summed (the all-reduce), phase 2 and 3 per rank; x is collected from the owners.
+int vo_chol_solve_split(int n, const double *A_rowmajor_lower, double *b, int c0, const int32_t *col_part, int n_ranks) {
+  if (n <= 0 || !A_rowmajor_lower || !b || !col_part || n_ranks < 1) return VO_ERR_INVALID;
+  VO_CHECK(vo::ensure_device());
+  const int ld = (n + NB - 1) / NB * NB, m = ld / NB;
+  if (ld > 4096 || c0 < 1 || c0 >= m) return VO_ERR_INVALID;
+  std::vector<double> Ap((size_t)(ld + NB) * ld, 0.0);
+  for (int i = 0; i < ld; i++) {
+    if (i < n) {
+      for (int j = 0; j <= i; j++) Ap[(size_t)i * ld + j] = A_rowmajor_lower[(size_t)i * n + j];
+      Ap[(size_t)ld * ld + i] = b[i];
+    } else {
+      Ap[(size_t)i * ld + i] = 1.0;
+    }
+  }
+  std::vector<unsigned long long> pattern;
+  pattern_of_matrix(Ap, ld, pattern);
+  hipStream_t st = vo::thread_stream();
+  const int s0 = NB * c0;
+  std::vector<vo::DevBuf> dA((size_t)n_ranks), dws((size_t)n_ranks);
+  std::vector<unsigned long long> own((size_t)n_ranks, 0ull);
+  for (int j = 0; j < c0; j++) own[(size_t)(col_part[j] % n_ranks)] |= 1ull << j;
+  std::vector<vo::CholPlan *> plans;
+  auto cleanup = [&](int rc) {
+    for (auto *p : plans) vo::chol_plan_destroy(p);
+    for (auto &d : dA) d.release();
+    for (auto &d : dws) d.release();
+    return rc;
+  };
+  std::vector<double> sum((size_t)(ld + NB) * ld, 0.0), tmp(sum.size());
+  int failed = 0;
+  for (int r = 0; r < n_ranks; r++) {
+    std::vector<double> Ar(Ap);
+    if (r != 0)  // the separator block and its right-hand side: rank 0's contribution only
+      for (int i = s0; i <= ld; i++)
+        for (int j = s0; j < ld; j++) Ar[(size_t)i * ld + j] = 0.0;
+    if (upload(dA[r], Ar.data(), Ar.size() * 8, st) != VO_OK || dws[r].reserve(vo::chol_workspace_bytes(ld)) != VO_OK) return cleanup(VO_ERR_HIP);
+    (void)hipMemsetAsync(dws[r].p, 0, 4, st);
+    vo::CholPlan *p1 = vo::chol_plan_create_split(m, pattern.data(), c0, own[r], 1);
+    plans.push_back(p1);
+    vo::chol_split_phase(dA[r].as<double>(), ld, dws[r].p, st, p1, 1, c0);
+    if (vo::copy_d2h(tmp.data(), dA[r].p, tmp.size() * 8, st, "vo_chol_solve_split") != VO_OK || vo::stream_sync(st, "vo_chol_solve_split") != VO_OK)
+      return cleanup(VO_ERR_HIP);
+    for (int i = s0; i <= ld; i++)
+      for (int j = s0; j < ld; j++) sum[(size_t)i * ld + j] += tmp[(size_t)i * ld + j];
+  }
+  std::vector<double> x((size_t)ld, 0.0);
+  for (int r = 0; r < n_ranks; r++) {
+    // the "all-reduced" separator block into this rank's storage (row by row: the block is not contiguous)
+    for (int i = s0; i <= ld; i++)
+      (void)hipMemcpyAsync(dA[r].as<double>() + (size_t)i * ld + s0, sum.data() + (size_t)i * ld + s0, (size_t)(ld - s0) * 8, hipMemcpyHostToDevice, st);
+    vo::CholPlan *p2 = vo::chol_plan_create_split(m, pattern.data(), c0, own[r], 2);
+    vo::CholPlan *p3 = vo::chol_plan_create_split(m, pattern.data(), c0, own[r], 3);
+    plans.push_back(p2), plans.push_back(p3);
+    vo::chol_split_phase(dA[r].as<double>(), ld, dws[r].p, st, p2, 2, c0);
+    vo::chol_split_phase(dA[r].as<double>(), ld, dws[r].p, st, p3, 3, c0);
+    int f = 0;
+    if (vo::copy_d2h(&f, dws[r].p, 4, st, "vo_chol_solve_split") != VO_OK ||
+        vo::copy_d2h(tmp.data(), dA[r].as<double>() + (size_t)(ld + 1) * ld, (size_t)ld * 8, st, "vo_chol_solve_split") != VO_OK ||
+        vo::stream_sync(st, "vo_chol_solve_split") != VO_OK)
+      return cleanup(VO_ERR_HIP);
+    failed = std::max(failed, f);
+    for (int i = 0; i < ld; i++) {
+      const int tj = i / NB;
+      const bool mine = tj < c0 ? ((own[r] >> tj) & 1ull) != 0 : r == 0;
+      if (mine) x[i] = tmp[i];
+    }
+  }
+  if (failed) {
+    vo::set_error(failed == 1 ? "vo_chol_solve_split: matrix is not positive definite" : "vo_chol_solve_split: the factorisation kernel abandoned a wait");
+    return cleanup(failed == 1 ? VO_ERR_INVALID : VO_ERR_HIP);
+  }
+  for (int i = 0; i < n; i++) b[i] = x[i];
+  return cleanup(VO_OK);
 }
 
 int vo_chol_solve(int n, double *A_rowmajor_lower, double *b) {

@@ -115,6 +115,11 @@ void chol_plan_destroy(CholPlan *p);
 void chol_plan_info(const CholPlan *p, int *n_tiles, int *depth, int *n_updates = nullptr);
 void chol_symbolic(int m, const unsigned long long *pattern, unsigned long long *lmask, int *depth, int *n_tiles);
 void chol_factor_solve(double *A, int ld, void *workspace, hipStream_t st, const CholPlan *plan = nullptr);
+// Split solve over the ranks of a sharded system (chol.hip): the segments of a nested-dissection order occupy the tile
+// columns [0, c0), the separators [c0, m); `own` = this rank's segment columns.  Phase 1 eliminates them into the separator
+// block, phase 2 solves the (rank-summed) separator block, phase 3 substitutes back into the rank's segments.
+CholPlan *chol_plan_create_split(int m, const unsigned long long *pattern, int c0, unsigned long long own, int phase);
+void chol_split_phase(double *A, int ld, void *workspace, hipStream_t st, const CholPlan *plan, int phase, int c0);
 // Order of the nf diagonal blocks (bs rows each; pairs = the off-diagonal blocks (hi, lo) that are non-zero) of a system
 // with m tile rows: natural, or a nested dissection of a (cyclic) band when that shortens the chain of dependent tile
 // columns by a quarter or more (chol.hip).  force_parts: -1 = choose, 1 = natural, P > 1 = P segments.
@@ -122,6 +127,8 @@ struct CholOrder {
   std::vector<int> slot_of;  // natural block index -> position
   int parts = 1, cyclic = 0, sep = 0, depth = 0, tiles = 0;
   std::vector<unsigned long long> pattern;  // tile pattern in the chosen order (chol_plan_create's input)
+  std::vector<int> part_of;  // position -> segment index, -1 = separator (empty: natural order, no segments)
+  int seg_slots = 0;         // positions [0, seg_slots) are the segments', the rest the separators'
 };
 CholOrder chol_choose_order(int nf, int bs, const std::vector<std::pair<int, int>> &pairs, int m, int force_parts = -1);
 
