@@ -36,15 +36,16 @@ def test_two_process_sharded_local_ba_through_the_c_abi():
 @pytest.mark.timeout(900)
 def test_two_process_sharded_global_ba_500_keyframes():
     """BASELINE config 4's reduced system (500 key-frames, 3000 x 3000) sharded over two ranks: both derive the same
-    nested-dissection key-frame order, sum their parts of the reduced system in the Cholesky storage, and reproduce the
-    unsharded solve (same LM decisions, cost within 1e-9, poses within 1e-8)"""
+    nested-dissection key-frame order and reproduce the unsharded solve (same LM decisions, cost within 1e-9, poses within
+    1e-8) both ways: with the per-rank segment factorisation (each rank eliminates its own segments, the separator block
+    is all-reduced) and with the replicated factorisation of the all-reduced packed system (VO_BA_SEGMENTS=0)"""
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", OMP_NUM_THREADS="2")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
            "--master-port", str(_free_port()), str(ROOT / "tests" / "dist_worker.py"), "--backend", "gloo", "--case", "gba500"]
     r = subprocess.run(cmd, capture_output=True, text=True, timeout=840, env=env, cwd=str(ROOT))
     out = r.stdout + r.stderr
     assert r.returncode == 0, out[-4000:]
-    assert out.count("-> OK") == 2 and "MISMATCH" not in out, out[-4000:]
+    assert out.count("-> OK") == 4 and "MISMATCH" not in out, out[-4000:]  # 2 ranks x (segments, replicated)
 
 
 @pytest.mark.timeout(1500)

@@ -1013,6 +1013,12 @@ class BundleAdjuster:
         check(lib().vo_ba_debug_order(self._h, out), "vo_ba_debug_order")
         return dict(zip(("parts", "cyclic", "sep", "depth", "tiles", "tile_rows", "tile_products"), list(out)[:7]))
 
+    def segment_c0(self):
+        """first separator tile column when this (sharded) handle runs the per-rank segment factorisation, else 0"""
+        out = (C.c_int * 8)()
+        check(lib().vo_ba_debug_order(self._h, out), "vo_ba_debug_order")
+        return int(out[7])
+
     def debug_schur(self, huber=(0.0, 0.0), edge_active=None):
         n = 6 * self.n_free_cams()
         S, b, cost = np.zeros((n, n)), np.zeros(n), C.c_double()

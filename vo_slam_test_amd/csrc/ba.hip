@@ -973,9 +973,15 @@ struct BaDev {
   int pair_diag_blocks;     // leading workgroups (4 pairs each) that hold the (c, c) pairs
   const int *pair_cc;       // [n_pairs][2] camera slots (c <= c')
   const int4 *pair_e;       // [..] (edge of c, edge of c', point, 0) at a shared point, in point order
-  const int2 *ltiles;       // large systems: the 64 x 64 tiles (row, column) of the factor that exist (the plan's, fill included)
+  const int2 *ltiles;       // large systems: the 64 x 64 tiles (row, column | partial << 16) of the factor that exist (the plan's, fill included)
   int n_ltiles;
   int n_pairs;
+  // per-rank segment factorisation of a sharded large system (build_device / run_lm_eager): points are owned by the rank
+  // of the nested-dissection segment they touch, so a rank's segment columns are complete and only the separator block
+  // [seg_row0, ld) is a partial sum; the replicated terms of that block (camera blocks, LM diagonal, padding identity,
+  // gradient) are added by one rank (seg_lead)
+  int seg_mode, seg_row0, seg_lead;
+  unsigned long long seg_own;  // bit j: tile column j belongs to one of this rank's segments
 };
 
 // large path: what rides along with the reduced system in the same buffer (so that one all-reduce carries
@@ -2206,6 +2212,49 @@ __global__ __launch_bounds__(256) void k_ba_pack_large(BaDev B, const int2 *tile
   }
 }
 
+// Segment solve, the two collectives around the separator phase (dir 0: storage -> payload, 1: payload -> storage).
+//  what 1: the separator block -- the tiles of the factor with both indices behind the segments (Schur fill included) and
+//          the right-hand side from seg_row0 on;
+//  what 2: the solution row: a rank contributes the unknowns of its own segment columns (the lead rank also the
+//          separators'), zeros elsewhere, so that the sum is the whole step; one more slot carries the ranks' fail flags
+//          (a rank whose segment was not positive definite must fail the step on every rank).
+__global__ __launch_bounds__(256) void k_ba_pack_seg(BaDev B, const int2 *tiles, int n_tiles, double *payload, int dir, int what) {
+  const BaState st = *B.st;
+  if (st.done) return;
+  const int tid = threadIdx.x, blk = blockIdx.x;
+  constexpr int T = vo::kCholPanel;
+  if (what == 1) {
+    if (blk < n_tiles) {
+      const int2 t = tiles[blk];
+      double *pk = payload + (long long)blk * T * T;
+      for (int i = tid; i < T * T; i += 256) {
+        double *a = B.Sd + (long long)(T * t.x + i / T) * B.ld + T * t.y + (i % T);
+        if (dir == 0) pk[i] = *a;
+        else *a = pk[i];
+      }
+      return;
+    }
+    double *pk = payload + (long long)n_tiles * T * T, *rhs = B.Sd + (long long)B.ld * B.ld + B.seg_row0;
+    for (int i = (blk - n_tiles) * 256 + tid; i < B.ld - B.seg_row0; i += (gridDim.x - n_tiles) * 256) {
+      if (dir == 0) pk[i] = rhs[i];
+      else rhs[i] = pk[i];
+    }
+    return;
+  }
+  double *x = B.Sd + (long long)(B.ld + 1) * B.ld;
+  for (int i = blk * 256 + tid; i <= B.ld; i += gridDim.x * 256) {
+    if (i == B.ld) {
+      if (dir == 0) payload[i] = *B.chol_fail != 0 ? 1.0 : 0.0;
+      else if (payload[i] != 0.0) *B.chol_fail = 1;
+      continue;
+    }
+    const int tj = i / T;
+    const bool mine = i < B.seg_row0 ? ((B.seg_own >> tj) & 1ull) != 0 : B.seg_lead != 0;
+    if (dir == 0) payload[i] = mine ? x[i] : 0.0;
+    else x[i] = payload[i];
+  }
+}
+
 // one workgroup: Jacobi scale, LM diagonal, cost / gradient-max bookkeeping from the (all-reduced) extras
 __global__ __launch_bounds__(256) void k_ba_prestep_large(BaDev B) {
   __shared__ double red[4];
@@ -2262,7 +2311,8 @@ __global__ __launch_bounds__(256) void k_ba_zero_large(BaDev B) {
   constexpr int T = vo::kCholPanel;
   const int tid = threadIdx.x, blk = blockIdx.x;
   if (blk < B.n_ltiles) {
-    const int2 t = B.ltiles[blk];
+    int2 t = B.ltiles[blk];
+    t.y &= 0xffff;
     for (int i = tid; i < T * T / 2; i += 256) {
       const int r = i / (T / 2), c2 = i - r * (T / 2);
       *reinterpret_cast<double2 *>(B.Sd + (long long)(T * t.x + r) * B.ld + T * t.y + 2 * c2) = make_double2(0.0, 0.0);
@@ -2281,11 +2331,14 @@ __global__ __launch_bounds__(256) void k_ba_assemble_large(BaDev B) {
   if (blk >= B.n_ltiles) {  // right-hand side, row ld: in place on this shard-summed -(Y gl'')
     for (int r = (blk - B.n_ltiles) * 256 + tid; r < B.ld; r += (gridDim.x - B.n_ltiles) * 256) {
       double *rh = B.Sd + (long long)B.ld * B.ld + r;
-      *rh = r < n ? B.gpp_v[r] + B.sc_v[r] * *rh : 0.0;
+      const bool whole = !B.seg_mode || r < B.seg_row0 || B.seg_lead;  // (separator rows of a segment solve: one rank adds g'')
+      *rh = r < n ? (whole ? B.gpp_v[r] : 0.0) + B.sc_v[r] * *rh : 0.0;
     }
     return;
   }
-  const int2 t = B.ltiles[blk];
+  int2 t = B.ltiles[blk];
+  const bool partial = (t.y >> 16) != 0;  // segment solve: a separator tile on a rank that does not add the replicated terms
+  t.y &= 0xffff;
   for (int i = tid; i < T * T; i += 256) {
     const int r = T * t.x + i / T, c = T * t.y + (i % T);
     if (c > r) continue;
@@ -2293,16 +2346,16 @@ __global__ __launch_bounds__(256) void k_ba_assemble_large(BaDev B) {
     double v;
     if (r < n) {
       v = B.Sd[idx];
-      if (r / 6 == c / 6) {
+      if (r / 6 == c / 6 && !partial) {
         const int slot = r / 6, a = c % 6, b = r % 6;  // a <= b
         int q0 = 0;
         for (int q = 0; q < a; q++) q0 += 6 - q;
         v += hp[slot * 27 + q0 + (b - a)];
       }
       v *= B.sc_v[r] * B.sc_v[c];
-      if (r == c) v += B.Dd_v[r];
+      if (r == c && !partial) v += B.Dd_v[r];
     } else {
-      v = r == c ? 1.0 : 0.0;
+      v = (r == c && !partial) ? 1.0 : 0.0;
     }
     B.Sd[idx] = v;
   }
@@ -2719,6 +2772,12 @@ struct vo_ba {
   vo::DevBuf b_ltiles;                   // large systems: tiles of the factor (zeroed / assembled every iteration)
   vo::DevBuf b_packtiles, b_pack;        // sharded large systems: tiles of the matrix that exist, packed all-reduce payload
   int n_pack_tiles = 0;
+  std::vector<int> pt_owner;             // shard of every point (p % n_shards; by nested-dissection segment in a segment solve)
+  bool seg_mode = false;                 // sharded large system: per-rank segment factorisation
+  int seg_c0 = 0;                        // first separator tile column
+  vo::CholPlan *seg_plan[3] = {nullptr, nullptr, nullptr};  // chol_plan_create_split phases 1..3
+  vo::DevBuf b_segtiles, b_segpack;      // separator tiles of the factor; payload of the separator / solution collectives
+  int n_seg_tiles = 0;
   int order_parts = 1, order_cyclic = 0, order_sep = 0, order_depth = 0, order_tiles = 0;  // what choose_camera_order picked
 };
 
@@ -2784,17 +2843,89 @@ int build_device(vo_ba *h) {
       vo::set_error("BA: could not create the factorisation plan");
       return VO_ERR_HIP;
     }
+    std::vector<unsigned long long> lmask((size_t)m);
+    vo::chol_symbolic(m, o.pattern.data(), lmask.data(), nullptr, nullptr);
+    h->pt_owner.resize((size_t)h->n_pts);
+    for (int j = 0; j < h->n_pts; j++) h->pt_owner[j] = j % h->n_shards;
+    // ---- per-rank segment factorisation (sharded, all-reduce callback registered, a nested-dissection order whose
+    // segments end on a tile boundary).  A point is owned by the rank of the segment it touches -- the separators are as
+    // wide as the covisibility band, so no point touches two segments (checked) --, points seen by separator key-frames
+    // only are dealt out to even the load.  Then a rank's segment columns (separator rows included) are complete without
+    // any exchange, and what has to be summed over the ranks is the separator block after the segments' elimination.
     {
-      std::vector<unsigned long long> lmask((size_t)m);
-      vo::chol_symbolic(m, o.pattern.data(), lmask.data(), nullptr, nullptr);
+      const char *e = getenv("VO_BA_SEGMENTS");  // developer knob: 0 = replicated factorisation of the all-reduced system
+      bool seg = h->n_shards > 1 && h->allreduce && !h->ext_payload && !(e && e[0] == '0') && o.parts >= 2 &&
+                 (int)o.part_of.size() == h->nf && o.seg_slots > 0 && (6 * o.seg_slots) % vo::kCholPanel == 0 &&
+                 6 * o.seg_slots / vo::kCholPanel < m;
+      std::vector<int> part_rank, pt_part;
+      if (seg) {
+        part_rank.resize((size_t)o.parts);
+        for (int g = 0; g < o.parts; g++) part_rank[g] = g % h->n_shards;
+        pt_part.assign((size_t)h->n_pts, -1);
+        for (int j = 0; j < h->n_pts && seg; j++)
+          for (int a = h->pt_start[j]; a < h->pt_start[j + 1]; a++) {
+            const int sl = h->cam_slot[h->e_cam[a]];
+            if (sl < 0 || sl >= o.seg_slots) continue;
+            const int g = o.part_of[sl];
+            if (pt_part[j] >= 0 && pt_part[j] != g) seg = false;  // (cannot happen with separators as wide as the band)
+            pt_part[j] = g;
+          }
+        // a segment's tile columns: whole tiles (segment lengths are multiples of 32 key-frames, the end was checked)
+        for (int sl = 0; sl + 1 < o.seg_slots && seg; sl++)
+          if (o.part_of[sl] != o.part_of[sl + 1] && (6 * (sl + 1)) % vo::kCholPanel != 0) seg = false;
+      }
+      if (seg) {
+        std::vector<long long> load((size_t)h->n_shards, 0);
+        for (int j = 0; j < h->n_pts; j++)
+          if (pt_part[j] >= 0) {
+            h->pt_owner[j] = part_rank[pt_part[j]];
+            load[h->pt_owner[j]] += h->pt_start[j + 1] - h->pt_start[j];
+          }
+        for (int j = 0; j < h->n_pts; j++)
+          if (pt_part[j] < 0) {
+            int best = 0;
+            for (int r = 1; r < h->n_shards; r++)
+              if (load[r] < load[best]) best = r;
+            h->pt_owner[j] = best;
+            load[best] += h->pt_start[j + 1] - h->pt_start[j];
+          }
+        h->seg_mode = true;
+        h->seg_c0 = 6 * o.seg_slots / vo::kCholPanel;
+        unsigned long long own = 0;
+        for (int sl = 0; sl < o.seg_slots; sl++)
+          if (part_rank[o.part_of[sl]] == h->shard) own |= (1ull << (6 * sl / vo::kCholPanel)) | (1ull << ((6 * sl + 5) / vo::kCholPanel));
+        for (int ph = 0; ph < 3; ph++) {
+          h->seg_plan[ph] = vo::chol_plan_create_split(m, o.pattern.data(), h->seg_c0, own, ph + 1);
+          if (!h->seg_plan[ph]) {
+            vo::set_error("BA: could not create the segment factorisation plans");
+            return VO_ERR_HIP;
+          }
+        }
+        D.seg_mode = 1, D.seg_row0 = vo::kCholPanel * h->seg_c0, D.seg_lead = h->shard == 0 ? 1 : 0, D.seg_own = own;
+        std::vector<int2> st;
+        for (int i = h->seg_c0; i < m; i++)
+          for (int j = h->seg_c0; j <= i; j++)
+            if ((lmask[i] >> j) & 1ull) st.push_back(make_int2(i, j));
+        h->n_seg_tiles = (int)st.size();
+        VO_CHECK(upload(h->b_segtiles, st.data(), st.size() * sizeof(int2)));
+        VO_CHECK(h->b_segpack.reserve(((size_t)st.size() * vo::kCholPanel * vo::kCholPanel + (size_t)D.ld + 8) * 8));
+      }
+    }
+    {
+      // the tiles this handle zeroes and assembles: all of the factor's -- or, in a segment solve, its own segments'
+      // columns and the separator block (flagged partial where another rank adds the replicated terms)
       std::vector<int2> lt;
       for (int i = 0; i < m; i++)
-        for (int j = 0; j <= i; j++)
-          if ((lmask[i] >> j) & 1ull) lt.push_back(make_int2(i, j));
+        for (int j = 0; j <= i; j++) {
+          if (!((lmask[i] >> j) & 1ull)) continue;
+          if (h->seg_mode && j < h->seg_c0 && !((D.seg_own >> j) & 1ull)) continue;
+          const int partial = h->seg_mode && j >= h->seg_c0 && !D.seg_lead ? 1 : 0;
+          lt.push_back(make_int2(i, j | (partial << 16)));
+        }
       VO_CHECK(upload(h->b_ltiles, lt.data(), lt.size() * sizeof(int2)));
       D.n_ltiles = (int)lt.size();
     }
-    if (h->n_shards > 1) {
+    if (h->n_shards > 1 && !h->seg_mode) {
       std::vector<int2> tiles;
       for (int i = 0; i < m; i++)
         for (int j = 0; j <= i; j++)
@@ -2804,9 +2935,13 @@ int build_device(vo_ba *h) {
       VO_CHECK(h->b_pack.reserve(((size_t)tiles.size() * vo::kCholPanel * vo::kCholPanel + D.ld + (size_t)h->nf * 27 + 1 + h->n_shards) * 8));
     }
   }
+  if (h->pt_owner.empty()) {
+    h->pt_owner.resize((size_t)h->n_pts);
+    for (int j = 0; j < h->n_pts; j++) h->pt_owner[j] = j % h->n_shards;
+  }
   std::vector<int> local;
   for (int j = 0; j < h->n_pts; j++)
-    if (j % h->n_shards == h->shard) local.push_back(j);
+    if (h->pt_owner[j] == h->shard) local.push_back(j);
   D.n_local = (int)local.size();
   // per-camera edge lists restricted to this shard's points
   std::vector<int> cstart(h->nf + 1, 0), cedges;
@@ -2814,7 +2949,7 @@ int build_device(vo_ba *h) {
     std::vector<std::vector<int>> lists(h->nf);
     for (int e = 0; e < h->n_edges; e++) {
       const int s = h->cam_slot[h->e_cam[e]];
-      if (s >= 0 && h->e_pt[e] % h->n_shards == h->shard) lists[s].push_back(e);
+      if (s >= 0 && h->pt_owner[h->e_pt[e]] == h->shard) lists[s].push_back(e);
     }
     int mx = 0;
     for (int s = 0; s < h->nf; s++) {
@@ -3050,12 +3185,33 @@ int launch_linearize_large(vo_ba *h) {
   return VO_OK;
 }
 // second half: damped system, factorisation, step, candidate poses (k_ba_backsub follows)
+int shard_allreduce(vo_ba *h, double *buf, size_t n);
 int launch_step_large(vo_ba *h) {
   BaDev &D = h->D;
   hipStream_t st = h->stream;
   hipLaunchKernelGGL(k_ba_prestep_large, dim3(1), dim3(256), 0, st, D);
   hipLaunchKernelGGL(k_ba_assemble_large, dim3(D.n_ltiles + 8), dim3(256), 0, st, D);
-  vo::chol_factor_solve(D.Sd, D.ld, D.chol_fail, st, h->chol_plan);
+  if (h->seg_mode) {
+    // Per-rank segment factorisation (csrc/chol.hip, split plans): this rank's segments are eliminated into the separator
+    // block; the separator block -- the only part of the reduced system that is a sum over the ranks -- is all-reduced and
+    // solved by every rank; the segments' unknowns follow by back-substitution and the step is gathered by a second,
+    // small all-reduce (zeros outside the own columns).  DESIGN.md section 6.
+    constexpr int T = vo::kCholPanel;
+    double *pk = h->b_segpack.as<double>();
+    const int2 *tiles = h->b_segtiles.as<int2>();
+    const size_t n_sep = (size_t)h->n_seg_tiles * T * T + (size_t)(D.ld - D.seg_row0);
+    vo::chol_split_phase(D.Sd, D.ld, D.chol_fail, st, h->seg_plan[0], 1, h->seg_c0);
+    hipLaunchKernelGGL(k_ba_pack_seg, dim3(h->n_seg_tiles + 4), dim3(256), 0, st, D, tiles, h->n_seg_tiles, pk, 0, 1);
+    VO_CHECK(shard_allreduce(h, pk, n_sep));
+    hipLaunchKernelGGL(k_ba_pack_seg, dim3(h->n_seg_tiles + 4), dim3(256), 0, st, D, tiles, h->n_seg_tiles, pk, 1, 1);
+    vo::chol_split_phase(D.Sd, D.ld, D.chol_fail, st, h->seg_plan[1], 2, h->seg_c0);
+    vo::chol_split_phase(D.Sd, D.ld, D.chol_fail, st, h->seg_plan[2], 3, h->seg_c0);
+    hipLaunchKernelGGL(k_ba_pack_seg, dim3(16), dim3(256), 0, st, D, tiles, 0, pk, 0, 2);
+    VO_CHECK(shard_allreduce(h, pk, (size_t)D.ld + 1));
+    hipLaunchKernelGGL(k_ba_pack_seg, dim3(16), dim3(256), 0, st, D, tiles, 0, pk, 1, 2);
+  } else {
+    vo::chol_factor_solve(D.Sd, D.ld, D.chol_fail, st, h->chol_plan);
+  }
   hipLaunchKernelGGL(k_ba_poststep_large, dim3(1), dim3(256), 0, st, D);
   VO_HIP_CHECK(hipGetLastError());
   return VO_OK;
@@ -3144,6 +3300,10 @@ int run_lm_eager(vo_ba *h, int max_it) {
       VO_CHECK(shard_allreduce(h, h->b_pack.as<double>(), n_pack));
       hipLaunchKernelGGL(k_ba_pack_large, grid, dim3(256), 0, h->stream, h->D, h->b_packtiles.as<int2>(), h->n_pack_tiles, h->b_pack.as<double>(), 1);
       VO_HIP_CHECK(hipGetLastError());
+    } else if (sharded && h->seg_mode) {
+      // segment solve: only the camera-block extras (per key-frame 27 sums, the cost, the gradient maxima) are summed
+      // here; the separator block and the step follow inside launch_step_large
+      VO_CHECK(shard_allreduce(h, h->D.Sd + large_ext_off(h->D.ld), (size_t)h->nf * 27 + 1 + h->n_shards));
     } else if (sharded) {
       VO_CHECK(shard_allreduce(h, p1, n1));
     }
@@ -3409,9 +3569,11 @@ void vo_ba_destroy(vo_ba *h) {
                         &h->b_dl, &h->b_wt, &h->b_wt1, &h->b_hll0, &h->b_hll1, &h->b_spt1, &h->b_sgemm, &h->b_scam, &h->b_spt, &h->b_payload, &h->b_zc,
                         &h->b_sbs, &h->b_payload2, &h->b_state, &h->b_out, &h->b_dbg, &h->b_cnt, &h->b_we0, &h->b_we1,
                         &h->b_glsc0, &h->b_glsc1, &h->b_Sd, &h->b_scv, &h->b_ddv, &h->b_gppv, &h->b_cholfail,
-                        &h->b_pairstart, &h->b_paircc, &h->b_paire, &h->b_merge, &h->b_packtiles, &h->b_pack, &h->b_ltiles})
+                        &h->b_pairstart, &h->b_paircc, &h->b_paire, &h->b_merge, &h->b_packtiles, &h->b_pack, &h->b_ltiles,
+                        &h->b_segtiles, &h->b_segpack})
     b->release();
   vo::chol_plan_destroy(h->chol_plan);
+  for (auto *sp : h->seg_plan) vo::chol_plan_destroy(sp);
   if (h->pin.p) (void)hipHostFree(h->pin.p);
   if (h->own_stream) (void)hipStreamDestroy(h->stream);
   delete h;
@@ -3443,7 +3605,8 @@ int vo_ba_debug_order(vo_ba *h, int out[8]) {
   VO_CHECK(build_device(h));
   out[0] = h->order_parts, out[1] = h->order_cyclic, out[2] = h->order_sep, out[3] = h->order_depth, out[4] = h->order_tiles;
   out[5] = h->D.large ? h->D.ld / vo::kCholPanel : 0;
-  out[6] = out[7] = 0;
+  out[6] = 0;
+  out[7] = h->seg_mode ? h->seg_c0 : 0;  // per-rank segment factorisation: first separator tile column (0: replicated)
   vo::chol_plan_info(h->chol_plan, nullptr, nullptr, &out[6]);
   return VO_OK;
 }
@@ -3462,17 +3625,17 @@ int vo_ba_set_state(vo_ba *h, const double *poses, const double *points) {
 // (and classifies ITS edges only).  One more collective -- outside the LM loop -- leaves the full point array
 // (and the full erase mask) on every rank: owners contribute their values, everybody else zeros.
 static int merge_shards(vo_ba *h, int cur, uint8_t *erase_sorted /*n_edges, in/out, or NULL*/) {
-  if (h->n_shards <= 1 || !h->allreduce) return VO_OK;
+  if (h->n_shards <= 1 || !h->allreduce || !h->built) return VO_OK;
   const size_t np3 = (size_t)h->n_pts * 3, n = np3 + (erase_sorted ? (size_t)h->n_edges : 0);
   if (n == 0) return VO_OK;
   std::vector<double> buf(n, 0.0);
   VO_HIP_CHECK(hipStreamSynchronize(h->stream));
   if (np3) VO_HIP_CHECK(hipMemcpy(buf.data(), h->D.Xp[cur], np3 * 8, hipMemcpyDeviceToHost));
   for (int j = 0; j < h->n_pts; j++)
-    if (j % h->n_shards != h->shard) buf[3 * j] = buf[3 * j + 1] = buf[3 * j + 2] = 0.0;
+    if (h->pt_owner[j] != h->shard) buf[3 * j] = buf[3 * j + 1] = buf[3 * j + 2] = 0.0;
   if (erase_sorted)
     for (int e = 0; e < h->n_edges; e++)
-      buf[np3 + e] = (h->e_pt[e] % h->n_shards == h->shard && erase_sorted[e]) ? 1.0 : 0.0;
+      buf[np3 + e] = (h->pt_owner[h->e_pt[e]] == h->shard && erase_sorted[e]) ? 1.0 : 0.0;
   VO_CHECK(h->b_merge.reserve(n * 8));
   VO_HIP_CHECK(hipMemcpyAsync(h->b_merge.p, buf.data(), n * 8, hipMemcpyHostToDevice, h->stream));
   VO_CHECK(shard_allreduce(h, h->b_merge.as<double>(), n));
@@ -3499,8 +3662,26 @@ int vo_ba_lm_begin(vo_ba *h, double hm, double hs, int max_it, const uint8_t *ed
   if (!h || max_it < 0) return VO_ERR_INVALID;
   return lm_begin(h, hm, hs, max_it, edge_active, false);
 }
-int vo_ba_linearize(vo_ba *h) { return h && h->built ? launch_linearize(h) : VO_ERR_INVALID; }
-int vo_ba_step(vo_ba *h) { return h && h->built ? launch_step(h) : VO_ERR_INVALID; }
+// (a handle in segment mode sums three things per iteration in its own order; the split-phase interface, whose caller sums the
+//  whole reduced system between linearize and step, is for handles without a callback)
+static int reject_segment_mode(const vo_ba *h, const char *fn) {
+  if (h->seg_mode) {
+    vo::set_error("%s: the handle runs the per-rank segment factorisation through its all-reduce callback; drive it with vo_ba_solve "
+                  "(or set VO_BA_SEGMENTS=0)", fn);
+    return VO_ERR_INVALID;
+  }
+  return VO_OK;
+}
+int vo_ba_linearize(vo_ba *h) {
+  if (!h || !h->built) return VO_ERR_INVALID;
+  VO_CHECK(reject_segment_mode(h, "vo_ba_linearize"));
+  return launch_linearize(h);
+}
+int vo_ba_step(vo_ba *h) {
+  if (!h || !h->built) return VO_ERR_INVALID;
+  VO_CHECK(reject_segment_mode(h, "vo_ba_step"));
+  return launch_step(h);
+}
 int vo_ba_update(vo_ba *h) { return h && h->built ? launch_update(h) : VO_ERR_INVALID; }
 int vo_ba_lm_end(vo_ba *h, vo_lm_summary *s) { return h && h->built ? lm_end(h, s) : VO_ERR_INVALID; }
 
