@@ -565,31 +565,47 @@ def main():
             # all-reduced once per LM iteration (+ 6 scalars) through the same callback; every rank factors the summed system
             gb = synth.make_global_ba_problem(0)
             hm, hs = float(np.sqrt(np.float32(5.991))), float(np.sqrt(np.float32(7.815)))
-            gsh = vo.BundleAdjuster(gb, shard=rank, n_shards=world, stream=torch.cuda.current_stream().cuda_stream)
-            gsh.set_allreduce(_allreduce)
-            gsh.solve(hm, hs, 1)                                   # builds the device structures
-            ar_stats["calls"], ar_stats["max_doubles"] = 0, 0
-            g_s, g_it = [], 0
-            for _ in range(5):
-                gsh.set_state(gb["poses"], gb["points"])
-                barrier()
-                tg0 = time.perf_counter()
-                gs = gsh.solve(hm, hs, 10)
-                barrier()
-                g_s.append(time.perf_counter() - tg0)
-                g_it = gs.iterations
-            g_order = gsh.debug_order()
-            gsh.close()
-            _same_on_all_ranks(g_it, "global BA")
-            tg = float(np.median(g_s))
+
+            def _sharded_global_ba(segments):
+                # segments: the per-rank segment factorisation (points owned by the rank of their nested-dissection segment,
+                # own segments eliminated locally, separator block / extras / step all-reduced) instead of the replicated one
+                os.environ["VO_BA_SEGMENTS"] = "1" if segments else "0"
+                gsh = vo.BundleAdjuster(gb, shard=rank, n_shards=world, stream=torch.cuda.current_stream().cuda_stream)
+                gsh.set_allreduce(_allreduce)
+                gsh.solve(hm, hs, 1)                                   # builds the device structures
+                ar_stats["calls"], ar_stats["max_doubles"] = 0, 0
+                g_s, g_it = [], 0
+                for _ in range(5):
+                    gsh.set_state(gb["poses"], gb["points"])
+                    barrier()
+                    tg0 = time.perf_counter()
+                    gs = gsh.solve(hm, hs, 10)
+                    barrier()
+                    g_s.append(time.perf_counter() - tg0)
+                    g_it = gs.iterations
+                g_order, c0 = gsh.debug_order(), gsh.segment_c0()
+                gsh.close()
+                _same_on_all_ranks(g_it, "global BA")
+                os.environ.pop("VO_BA_SEGMENTS", None)
+                return float(np.median(g_s)), g_it, g_order, c0, ar_stats["max_doubles"] * 8 / 1e6, ar_stats["calls"] / len(g_s)
+
+            tg, g_it, g_order, _, g_mb, g_calls = _sharded_global_ba(False)
             out["global_ba"] = {"workload": f"{len(gb['poses'])} KF x {len(gb['points'])} pts, {len(gb['e_cam'])} edges, "
                                             f"{6 * (len(gb['poses']) - 1)}-wide reduced system, 10 LM iterations",
                                 "lm_iters_per_s": round(g_it / tg, 1), "ms_per_iter": round(tg / max(g_it, 1) * 1e3, 3), "dtype": "f64",
-                                "timing": f"median of {len(g_s)} solves",
+                                "timing": "median of 5 solves",
                                 "sharding": f"points % {world}; per LM iteration one all-reduce of the packed reduced system "
-                                            f"({ar_stats['max_doubles'] * 8 / 1e6:.1f} MB) and one of 6 scalars; factorisation replicated",
-                                "allreduce_payload_MB": round(ar_stats["max_doubles"] * 8 / 1e6, 2),
-                                "allreduce_calls_per_solve": ar_stats["calls"] / len(g_s), "key_frame_order": g_order}
+                                            f"({g_mb:.1f} MB) and one of 6 scalars; factorisation replicated",
+                                "allreduce_payload_MB": round(g_mb, 2),
+                                "allreduce_calls_per_solve": g_calls, "key_frame_order": g_order}
+            ts, s_it, _, s_c0, s_mb, s_calls = _sharded_global_ba(True)
+            out["global_ba"]["segment_factorisation"] = {
+                "lm_iters_per_s": round(s_it / ts, 1), "ms_per_iter": round(ts / max(s_it, 1) * 1e3, 3), "first_separator_tile_column": s_c0,
+                "sharding": "points by nested-dissection segment; per LM iteration the camera-block extras, the separator block after the "
+                            f"segments' elimination ({s_mb:.1f} MB), the step and 6 scalars are all-reduced; separators factored on every rank",
+                "allreduce_payload_MB": round(s_mb, 2), "allreduce_calls_per_solve": s_calls,
+                "note": "opt-in (VO_BA_SEGMENTS=1): on one GPU with emulated ranks it computes more per rank than the replicated form "
+                        "(profiles/r04_segment_factorisation.txt)"}
         if world == 1:
             # aggregate throughput: independent problems (one handle + stream each) overlapped on the GPU
             nconc = 8

@@ -371,6 +371,58 @@ def test_split_segment_solve_matches_numpy(vo, seed, n_ranks):
     assert np.abs(x - xr).max() < 1e-10 * max(1.0, np.abs(xr).max())
 
 
+@pytest.mark.timeout(900)
+@pytest.mark.parametrize("world", [2, 3, 4, 8])
+def test_segment_factorisation_over_thread_ranks(vo, world, monkeypatch):
+    """the per-rank segment factorisation of a sharded global BA at world sizes a one-GPU box cannot host as processes
+    (tests/thread_ranks.py: one thread per rank, barrier all-reduce): 4 segments on 2, 3, 4 ranks and on 8 (four ranks
+    without a segment: they only hold separator points) -- LM decisions, cost and state equal the unsharded solve, four
+    collectives per LM iteration, the largest one the separator block"""
+    import thread_ranks
+    from vo_slam_test_amd import synth
+    monkeypatch.setenv("VO_BA_SEGMENTS", "1")
+    prob = synth.make_global_ba_problem(0, n_kf=500, n_pts=8000)
+    hm, hs = float(np.sqrt(np.float32(5.991))), float(np.sqrt(np.float32(7.815)))
+    ref = vo.BundleAdjuster(prob)
+    s0 = ref.solve(hm, hs, 3)
+    p0, x0 = ref.state()
+    o0 = ref.debug_order()
+    ref.close()
+    assert o0["parts"] == 4
+
+    def solve(h, rank):
+        s = h.solve(hm, hs, 3)
+        c0 = h.segment_c0()
+        p, x = h.state()
+        return (s.iterations, s.accepted, s.termination, s.final_cost), c0, p, x
+
+    res, stats = thread_ranks.run_ranks(vo, prob, world, solve)
+    for (its, c0, p, x) in res:
+        assert c0 == 24  # 4 x 64 key-frames x 6 = 24 tile columns of segments
+        assert its[:3] == (s0.iterations, s0.accepted, s0.termination) and abs(its[3] - s0.final_cost) <= 1e-9 * s0.final_cost
+        assert np.abs(p - p0).max() < 1e-8 and np.abs(x - x0).max() < 1e-6
+    sizes = np.array(stats["sizes"][:4 * s0.iterations]).reshape(-1, 4)
+    n_free = 499
+    assert np.all(sizes[:, 0] == n_free * 27 + 1 + world) and np.all(sizes[:, 2] == 3008 + 1) and np.all(sizes[:, 3] == 6)
+    assert np.all(sizes[:, 1] * 8 < 8e6) and np.all(sizes[:, 1] > sizes[:, 0])  # the separator block: < 8 MB (replicated form: 9.5)
+
+
+def test_segment_mode_refuses_the_split_phase_interface(vo, monkeypatch):
+    """a handle in segment mode owns its collectives: vo_ba_linearize / vo_ba_step (whose caller sums the whole system) refuse"""
+    import thread_ranks
+    from vo_slam_test_amd import synth
+    monkeypatch.setenv("VO_BA_SEGMENTS", "1")
+    prob = synth.make_global_ba_problem(1, n_kf=500, n_pts=3000)
+
+    def solve(h, rank):
+        h.solve(0.0, 0.0, 1)
+        return vo.lib().vo_ba_linearize(h._h), vo.lib().vo_ba_step(h._h), vo.lib().vo_last_error().decode()
+
+    res, _ = thread_ranks.run_ranks(vo, prob, 2, solve)
+    for rc1, rc2, msg in res:
+        assert rc1 == -1 and rc2 == -1 and "segment" in msg
+
+
 def test_device_cholesky_rejects_indefinite(vo):
     A = np.eye(70)
     A[40, 40] = -1.0

@@ -67,4 +67,7 @@ def test_bench_gpus_2_starts_two_ranks_and_reports_the_sharded_legs():
     assert "replicas" in d["local_ba"] and "sharding" in d["local_ba"] and d["local_ba"]["lm_iters_per_s"] > 0
     g = d["global_ba"]
     assert g["lm_iters_per_s"] > 0 and 1.0 < g["allreduce_payload_MB"] < 15.0 and g["key_frame_order"]["parts"] > 1
+    sg = g["segment_factorisation"]  # the same solve through the per-rank segment factorisation (opt-in form)
+    assert sg["lm_iters_per_s"] > 0 and sg["first_separator_tile_column"] == 24 and sg["allreduce_payload_MB"] < g["allreduce_payload_MB"]
+    assert sg["allreduce_calls_per_solve"] == 2 * g["allreduce_calls_per_solve"]
     assert "cpu_baseline" not in d  # rank 0 at N = 1 only

@@ -2853,8 +2853,13 @@ int build_device(vo_ba *h) {
     // only are dealt out to even the load.  Then a rank's segment columns (separator rows included) are complete without
     // any exchange, and what has to be summed over the ranks is the separator block after the segments' elimination.
     {
-      const char *e = getenv("VO_BA_SEGMENTS");  // developer knob: 0 = replicated factorisation of the all-reduced system
-      bool seg = h->n_shards > 1 && h->allreduce && !h->ext_payload && !(e && e[0] == '0') && o.parts >= 2 &&
+      // Opt-in (VO_BA_SEGMENTS=1): measured with emulated ranks on one MI355X (tools/gba_seg_run.py) a
+      // rank computes MORE per LM iteration this way than with the replicated factorisation of the all-reduced system
+      // (config 4: 1.05 / 0.98 / 1.03 ms against 0.94 / 0.86 / 0.85 at 2 / 4 / 8 ranks) -- the separators' chain of dependent
+      // tile columns, which every rank still runs, is three quarters of the factorisation, and the split adds launches,
+      // flag resets and two small collectives.
+      const char *e = getenv("VO_BA_SEGMENTS");
+      bool seg = h->n_shards > 1 && h->allreduce && !h->ext_payload && e && e[0] == '1' && o.parts >= 2 &&
                  (int)o.part_of.size() == h->nf && o.seg_slots > 0 && (6 * o.seg_slots) % vo::kCholPanel == 0 &&
                  6 * o.seg_slots / vo::kCholPanel < m;
       std::vector<int> part_rank, pt_part;
@@ -3667,7 +3672,7 @@ int vo_ba_lm_begin(vo_ba *h, double hm, double hs, int max_it, const uint8_t *ed
 static int reject_segment_mode(const vo_ba *h, const char *fn) {
   if (h->seg_mode) {
     vo::set_error("%s: the handle runs the per-rank segment factorisation through its all-reduce callback; drive it with vo_ba_solve "
-                  "(or set VO_BA_SEGMENTS=0)", fn);
+                  "(VO_BA_SEGMENTS=1 selected this form)", fn);
     return VO_ERR_INVALID;
   }
   return VO_OK;
