@@ -673,8 +673,8 @@ int vo_sim3_reanchor_points(int n_points, const double *points_in, const int32_t
  * vo_pose_graph_solve): A row-major, lower triangle read and overwritten by its factor, b -> x. */
 int vo_chol_solve(int n, double *A_rowmajor_lower, double *b);
 
-/* The same solve through the split (per-rank segment) form that a sharded global BA uses (vo_ba_set_shard +
- * vo_ba_set_allreduce on a reduced system with a nested-dissection order), with the n_ranks shards
+/* The same solve through the split (per-rank segment) form that a sharded global BA can use (vo_ba_set_shard +
+ * vo_ba_set_allreduce with VO_BA_SEGMENTS=1), with the n_ranks shards
  * emulated one after the other on this GPU -- a test entry: the 64-column tile columns [0, c0_tiles) hold segments that
  * are independent of each other (col_part[j] = the segment of tile column j, owned by rank col_part[j] % n_ranks), the
  * remaining tile columns the separators.  Per rank: eliminate the own segments into the separator block; the separator
@@ -692,7 +692,9 @@ int vo_ba_create(vo_ba **out, int n_cams, const double *poses, const uint8_t *ca
 void vo_ba_destroy(vo_ba *h);
 int vo_ba_set_stream(vo_ba *h, void *hip_stream);
 /* restrict this handle to the points p with p % n_shards == shard (multi-GPU: one process per
- * GPU, each owning a shard; cameras replicated).  Must precede any solve. */
+ * GPU, each owning a shard; cameras replicated).  Must precede any solve.
+ * (With VO_BA_SEGMENTS=1 in the environment, an all-reduce callback and a large reduced system whose key-frame order has
+ * nested-dissection segments, a point belongs to the rank of the segment it touches instead -- see vo_ba_set_allreduce.) */
 int vo_ba_set_shard(vo_ba *h, int shard, int n_shards);
 /* Multi-GPU from C/C++: the all-reduce the sharded LM loop needs (sum of n doubles at dev_buf over all
  * shards, in place, ordered on hip_stream; returns 0).  With RCCL this is
@@ -700,7 +702,11 @@ int vo_ba_set_shard(vo_ba *h, int shard, int n_shards);
  * over xGMI.  Once set, vo_ba_solve / vo_ba_local_ba[_enqueue] on a sharded handle run the whole LM
  * schedule with exactly two calls of it per iteration (the reduced camera system, 6 scalars); every
  * rank must make the same calls.  Without it those entry points reject a sharded handle
- * (VO_ERR_INVALID) instead of solving from partial sums. */
+ * (VO_ERR_INVALID) instead of solving from partial sums.
+ * Per-rank segment factorisation (opt-in, VO_BA_SEGMENTS=1; large reduced systems only): every rank eliminates the
+ * nested-dissection segments it owns, and the calls per iteration become four -- the camera-block extras, the separator
+ * block after the elimination, the step, 6 scalars; vo_ba_linearize / vo_ba_step refuse such a handle.  Measured with
+ * emulated ranks it does more work per rank than the default, which is why it is not the default. */
 typedef int (*vo_allreduce_fn)(void *user, double *dev_buf, size_t n_doubles, void *hip_stream);
 int vo_ba_set_allreduce(vo_ba *h, vo_allreduce_fn fn, void *user);
 int vo_ba_set_state(vo_ba *h, const double *poses, const double *points);
@@ -708,7 +714,8 @@ int vo_ba_get_state(vo_ba *h, double *poses, double *points);
 int vo_ba_n_free_cams(const vo_ba *h);
 /* The key-frame order a large reduced system (6 nf + 1 > 128) is factored in, chosen when the handle is first used:
  * out = {parts, cyclic, separator key-frames, dependent tile columns on the longest chain, tiles of L, tile rows,
- * tile products L(i,k) L(j,k)^T of the factorisation (2 x 64^3 flop each), 0}; parts == 1: the natural order.
+ * tile products L(i,k) L(j,k)^T of the factorisation (2 x 64^3 flop each), first separator tile column of a handle in
+ * segment mode or 0}; parts == 1: the natural order.
  * (Tests and tools; all zero tile rows for LDS-sized systems.) */
 int vo_ba_debug_order(vo_ba *h, int out[8]);
 
