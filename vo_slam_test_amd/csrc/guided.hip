@@ -784,9 +784,11 @@ __global__ __launch_bounds__(64) void k_guided_replay(FramesDev F, Queries Q, Gu
               hist[bin]++;
             }
           }
-          cnt++;
-          if (rot_on) npush++;
         }
+        // (plain sums: `cnt++; if (rot_on) npush++;` inside the branch made the compiler keep both counters in scratch
+        //  memory and select between their addresses)
+        cnt += a_r ? 1 : 0;
+        npush += (a_r && rot_on) ? 1 : 0;
         pending &= ~(1u << r);
       }
       lds_handoff();

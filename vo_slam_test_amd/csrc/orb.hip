@@ -147,6 +147,9 @@ __device__ __forceinline__ int dot2_i16(unsigned taps, unsigned coef) {
 #ifndef VO_FAST_ARC16
 #define VO_FAST_ARC16 1
 #endif
+#ifndef VO_OCT_LEVEL_MAJOR
+#define VO_OCT_LEVEL_MAJOR 1
+#endif
 #ifndef VO_OCT_WAVES
 #define VO_OCT_WAVES 7
 #endif
@@ -780,7 +783,11 @@ __attribute__((amdgpu_waves_per_eu(VO_OCT_WAVES, VO_OCT_WAVES))) __global__ __la
                                                 int *nk, int *err_flag) {
   __shared__ OctLds<CAP> S;
   const int tid = threadIdx.x;
+#if VO_OCT_LEVEL_MAJOR
+  const int l = blockIdx.y, f = blockIdx.x;  // every frame's level 0 first: the longest workgroups start first, the short ones fill the tail
+#else
   const int l = blockIdx.x, f = blockIdx.y;
+#endif
   const LevelGeom &L = P.lv[l];
   uint32_t *kd = key_data + (long long)f * keys_per_frame + L.candBase;
   unsigned short *kl = key_label + (long long)f * keys_per_frame + L.candBase;
@@ -2132,12 +2139,12 @@ int run_pipeline(vo_orb *h, const uint8_t *dev_images, int n_frames, int w, int 
   }
   VO_STAGE_MARK(2);
   if (h->oct_small)
-    hipLaunchKernelGGL(k_octree<256>, dim3(D.nlevels, n_frames), dim3(256), 0, st, D, h->slots.as<uint32_t>(),
+    hipLaunchKernelGGL(k_octree<256>, VO_OCT_LEVEL_MAJOR ? dim3(n_frames, D.nlevels) : dim3(D.nlevels, n_frames), dim3(256), 0, st, D, h->slots.as<uint32_t>(),
                        h->slots_frame, h->cellcnt.as<int>(), h->cells_frame, h->keydata.as<uint32_t>(),
                        h->keylabel.as<unsigned short>(), h->keys_frame, h->candcnt.as<int>(),
                        h->sel.as<uint32_t>(), h->sel_frame, h->nk.as<int>(), h->err.as<int>());
   else
-    hipLaunchKernelGGL(k_octree<kMaxList>, dim3(D.nlevels, n_frames), dim3(256), 0, st, D, h->slots.as<uint32_t>(),
+    hipLaunchKernelGGL(k_octree<kMaxList>, VO_OCT_LEVEL_MAJOR ? dim3(n_frames, D.nlevels) : dim3(D.nlevels, n_frames), dim3(256), 0, st, D, h->slots.as<uint32_t>(),
                        h->slots_frame, h->cellcnt.as<int>(), h->cells_frame, h->keydata.as<uint32_t>(),
                        h->keylabel.as<unsigned short>(), h->keys_frame, h->candcnt.as<int>(),
                        h->sel.as<uint32_t>(), h->sel_frame, h->nk.as<int>(), h->err.as<int>());
