@@ -222,7 +222,8 @@ def main():
     # The trackers: vo_tracker runs the whole tracked-frame path behind the C-ABI (csrc/tracker.hip).  n_pipe of them share
     # the extraction stream; their searches and pose solves run on high-priority streams of their own.
     trks = [vo.Tracker(B, cam5, synth.DIST, W, H, max_last=1100, max_local=2200, inv_depth_scale=inv_depth,
-                       extract_stream=stream.cuda_stream if n_pipe > 1 else None, single_stream=(n_pipe == 1))
+                       extract_stream=stream.cuda_stream if (n_pipe > 1 and not os.environ.get("VO_BENCH_OWN_EXT_STREAMS")) else None,
+                       single_stream=(n_pipe == 1))
             for _ in range(n_pipe)]
     trk = trks[0]
     exts = [t.extractor() for t in trks]
