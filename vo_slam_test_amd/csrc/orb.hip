@@ -159,6 +159,14 @@ __device__ __forceinline__ int dot2_i16(unsigned taps, unsigned coef) {
 #ifndef VO_RZ_REUSE
 #define VO_RZ_REUSE 1
 #endif
+#ifndef VO_RZ_MULHI
+#define VO_RZ_MULHI 1
+#endif
+#if VO_RZ_MULHI
+#define VO_RZ_H(h) ((h) & ~15)
+#else
+#define VO_RZ_H(h) ((h) >> 4)
+#endif
 #ifndef VO_RZ_ABLATE
 #define VO_RZ_ABLATE 0  // developer ablation switch (tools/rz_ablate.py); 0 in the product build
 #endif
@@ -268,7 +276,7 @@ __global__ __launch_bounds__(256) void k_resize4(const uint8_t *src, long long s
                      p2 = *reinterpret_cast<const unsigned *>(R0 + o2);
       const unsigned pl = __builtin_amdgcn_alignbyte(p1, p0, woff), ph = __builtin_amdgcn_alignbyte(p2, p1, woff);
 #pragma unroll
-      for (int q = 0; q < 4; q++) g0[q] = dot2_i16(__builtin_amdgcn_perm(ph, pl, sel[q]), ab[q]) >> 4;
+      for (int q = 0; q < 4; q++) g0[q] = VO_RZ_H(dot2_i16(__builtin_amdgcn_perm(ph, pl, sel[q]), ab[q]));
     }
     {
       const uint8_t *R1 = rz_tile + __mul24(sy1 * kRzF, kRzPitch);
@@ -276,9 +284,26 @@ __global__ __launch_bounds__(256) void k_resize4(const uint8_t *src, long long s
                      q2 = *reinterpret_cast<const unsigned *>(R1 + o2);
       const unsigned ql = __builtin_amdgcn_alignbyte(q1, q0, woff), qh = __builtin_amdgcn_alignbyte(q2, q1, woff);
 #pragma unroll
-      for (int q = 0; q < 4; q++) g1[q] = dot2_i16(__builtin_amdgcn_perm(qh, ql, sel[q]), ab[q]) >> 4;
+      for (int q = 0; q < 4; q++) g1[q] = VO_RZ_H(dot2_i16(__builtin_amdgcn_perm(qh, ql, sel[q]), ab[q]));
     }
     unsigned outw = 0;
+#if VO_RZ_MULHI
+    // (b * (h >> 4)) >> 16 in ONE instruction: v_mul_hi_u32_u24(b << 12, h & ~15) = (b 2^12 (h >> 4) 2^4) >> 32; both factors
+    // are non-negative and below 2^24 (b <= 2048, h <= 255 * 2048), so the 24-bit form is exact.  g0 / g1 hold h & ~15.
+    {
+      const unsigned b0s = (unsigned)b0 << 12, b1s = (unsigned)b1 << 12;  // uniform
+      unsigned v4[4];
+#pragma unroll
+      for (int q = 0; q < 4; q++) {
+        unsigned t0, t1;
+        asm("v_mul_hi_u32_u24 %0, %1, %2" : "=v"(t0) : "s"(b0s), "v"(g0[q]));
+        asm("v_mul_hi_u32_u24 %0, %1, %2" : "=v"(t1) : "s"(b1s), "v"(g1[q]));
+        v4[q] = (t0 + t1 + 2u) >> 2;
+        hp[q] = g1[q];
+      }
+      outw = v4[0] | (v4[1] << 8) | (v4[2] << 16) | (v4[3] << 24);
+    }
+#else
 #pragma unroll
     for (int q = 0; q < 4; q++) {
       // 24-bit multiplies are exact here: |b| <= 2048, |h >> 4| <= 255 * 2048 / 16
@@ -286,6 +311,7 @@ __global__ __launch_bounds__(256) void k_resize4(const uint8_t *src, long long s
       outw |= (unsigned)val << (8 * q);
       hp[q] = g1[q];
     }
+#endif
     prev_row = sy1;
     if (store_ok) *reinterpret_cast<unsigned *>(orow + (long long)r * d_pitch) = outw;  // the tail lands in the row padding
   }
