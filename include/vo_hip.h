@@ -341,7 +341,9 @@ int vo_bow_transform(const vo_vocab *v, int n, const uint8_t *desc, int levelsup
                      int32_t *node_id);
 
 /* The vocabulary file itself (DBoW3::Vocabulary(path), vo_run.cpp:87): DBoW3's binary stream
- * (Vocabulary::toStream, uncompressed), its cv::FileStorage form (.yml / .yml.gz: Vocabulary::save(cv::FileStorage&),
+ * (Vocabulary::toStream; plain, or -- what Vocabulary::save(path) writes by default, reference map.cpp:94 -- in QuickLZ
+ * level-1 chunks, decoded by a restatement of the published decoder: no library-written file was available to pin it,
+ * a stream that does not follow the format is refused), its cv::FileStorage form (.yml / .yml.gz: Vocabulary::save(cv::FileStorage&),
  * what DBoW3::Vocabulary(path) falls back to) or the ORB-SLAM2 text format; builds the device tree. */
 int vo_vocab_load(const char *path, vo_vocab **out, int *n_nodes, int *n_words, int *branching_k, int *depth_L);
 /* Map::score (map.cpp:335-376): L1 similarity of the query BoW vector (ascending word ids) with every

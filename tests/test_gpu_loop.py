@@ -190,9 +190,12 @@ def _write_dbow3_binary(path, k, L, parent, weight, word_id, desc, children=None
         body += struct.pack("<II", i, int(word_id[i]))
     if truncate is not None:
         body = body[:truncate]
+    if compressed == "qlz":  # what Vocabulary::save(path) writes by default: QuickLZ level-1 chunks of 10000 bytes (tests/qlz_ref.py)
+        import qlz_ref
+        body = qlz_ref.dbow3_compressed_body(body)
     with open(path, "wb") as f:
         f.write(struct.pack("<Q", 88877711233))
-        f.write(struct.pack("<?I", compressed, n))
+        f.write(struct.pack("<?I", bool(compressed), n))
         f.write(body)
 
 
@@ -234,7 +237,7 @@ def _write_orbslam_text(path, k, L, parent, weight, word_id, desc):
             f.write(f"{int(parent[i])} {1 if word_id[i] >= 0 else 0} " + " ".join(str(int(b)) for b in desc[i]) + f" {weight[i]:.17g}\n")
 
 
-@pytest.mark.parametrize("fmt", ["binary", "text", "yaml", "yaml.gz"])
+@pytest.mark.parametrize("fmt", ["binary", "binary.qlz", "text", "yaml", "yaml.gz"])
 def test_vocabulary_file_loader(vo, orc, fmt, tmp_path):
     V = synth.make_vocabulary(1, k=6, L=3)
     cs, ch = V["child_start"], V["children"]
@@ -242,9 +245,12 @@ def test_vocabulary_file_loader(vo, orc, fmt, tmp_path):
     parent = np.zeros(n, np.int64)
     for i in range(n):
         parent[ch[cs[i]:cs[i + 1]]] = i
-    path = tmp_path / {"binary": "voc.dbow3", "text": "voc.txt", "yaml": "voc.yml", "yaml.gz": "voc.yml.gz"}[fmt]
+    path = tmp_path / {"binary": "voc.dbow3", "binary.qlz": "vocz.dbow3", "text": "voc.txt", "yaml": "voc.yml", "yaml.gz": "voc.yml.gz"}[fmt]
     if fmt.startswith("yaml"):
         _write_dbow3_yaml(path, 6, 3, parent, V["node_weight"], V["word_id"], V["node_desc"], gz=fmt.endswith("gz"))
+    elif fmt == "binary.qlz":  # the compressed stream (the reference's `vocab.save(out_path)`, map.cpp:94): two 10000-byte chunks and a rest
+        _write_dbow3_binary(path, 6, 3, parent, V["node_weight"], V["word_id"], V["node_desc"], compressed="qlz")
+        assert path.stat().st_size < 0.9 * (21 + 16 + (n - 1) * 60)   # really compressed
     else:
         (_write_dbow3_binary if fmt == "binary" else _write_orbslam_text)(path, 6, 3, parent, V["node_weight"], V["word_id"], V["node_desc"])
     voc, info = vo.load_vocabulary(path)
@@ -266,7 +272,22 @@ def test_vocabulary_file_loader(vo, orc, fmt, tmp_path):
         _write_dbow3_yaml(tmp_path / "bad.yml", 6, 3, parent, V["node_weight"], V["word_id"], V["node_desc"], drop_descriptor_of=5)
         with pytest.raises(vo.VoError):
             vo.load_vocabulary(tmp_path / "bad.yml")
-    if fmt == "binary":  # malformed streams are refused, not trusted: compressed, truncated, a parent id out of range
+    if fmt == "binary.qlz":  # a damaged compressed stream is refused with a message, never decoded into garbage
+        raw = bytearray(path.read_bytes())
+        for at in (40, 200, len(raw) // 2):
+            bad = bytearray(raw)
+            bad[at] ^= 0x5a
+            (tmp_path / "bad.dbow3").write_bytes(bytes(bad))
+            try:
+                v2, _ = vo.load_vocabulary(tmp_path / "bad.dbow3")
+            except vo.VoError:
+                continue
+            # (a flipped literal byte inside a descriptor still decodes: then the tree differs from the original in that byte only)
+            v2.close()
+        (tmp_path / "cut.dbow3").write_bytes(bytes(raw[:len(raw) - 37]))
+        with pytest.raises(vo.VoError):
+            vo.load_vocabulary(tmp_path / "cut.dbow3")
+    if fmt == "binary":  # malformed streams are refused, not trusted: the flag without the stream, truncated, a parent id out of range
         args = (6, 3, parent, V["node_weight"], V["word_id"], V["node_desc"])
         for name, kw in (("z", dict(compressed=True)), ("t", dict(truncate=1000)), ("p", dict(bad_parent=True)),
                          ("c", dict(child_first=True))):   # (a child before its parent would lose the parent's subtree: ADVICE r3)

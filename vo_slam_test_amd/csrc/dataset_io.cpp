@@ -427,6 +427,110 @@ int vo_tracking_time_stats(const double *seconds, int n_tracked, double *median,
   return VO_OK;
 }
 
+}  // extern "C"
+
+namespace {
+// ---- QuickLZ 1.5.0, compression level 1, no streaming buffer: the coder DBoW3's Vocabulary::toStream runs over 10000-byte
+// chunks of its stream when `compressed` is set (what `vocab.save(path)` does by default, reference src/map.cpp:94).
+// DBoW3 and QuickLZ are not vendored under the reference; this restates the published decoder (quicklz.c,
+// qlz_decompress_core): a chunk is a 3- or 9-byte header (flags: bit 0 compressed, bit 1 long header, bits 2-3 level;
+// then compressed and decompressed size) and a sequence of 32-bit control words, each followed by the items its bits
+// announce from the low bit up -- 0: a literal byte, 1: a match.  A level-1 match names no offset: its 12-bit field is the
+// hash of the three bytes it starts with, and the source is the most recent earlier position with that hash, so the
+// decoder keeps the coder's hash table (positions are hashed as their three bytes become available; the inside of a
+// match is not hashed).  Every read and write is bounds-checked: a stream that does not follow the format is refused.
+// UNPINNED: no file written by DBoW3 itself is available in this environment -- the tests round-trip through a coder
+// restated the same way (tests/qlz_ref.py).
+struct QlzReader {
+  const uint8_t *p;
+  size_t n;
+  uint32_t rd(size_t at, int bytes) const {  // little-endian, zero beyond the end (the reference over-reads its padding)
+    uint32_t v = 0;
+    for (int i = 0; i < bytes; i++)
+      if (at + i < n) v |= (uint32_t)p[at + i] << (8 * i);
+    return v;
+  }
+};
+
+bool qlz_decompress_chunk(const uint8_t *src, size_t src_len, std::vector<uint8_t> &out, std::string &why) {
+  if (src_len < 3) return why = "chunk shorter than its header", false;
+  const unsigned flags = src[0];
+  const size_t hdr = (flags & 2) ? 9 : 3;
+  if (src_len < hdr) return why = "chunk shorter than its header", false;
+  QlzReader R{src, src_len};
+  const size_t csize = (flags & 2) ? R.rd(1, 4) : src[1], dsize = (flags & 2) ? R.rd(5, 4) : src[2];
+  if (csize != src_len) return why = "compressed size field does not match the chunk", false;
+  if (dsize > (64u << 20)) return why = "implausible decompressed size", false;
+  out.assign(dsize, 0);
+  if (!(flags & 1)) {  // stored
+    if (src_len - hdr < dsize) return why = "stored chunk is truncated", false;
+    memcpy(out.data(), src + hdr, dsize);
+    return true;
+  }
+  const int level = (flags >> 2) & 3;
+  if (level != 1) {
+    why = "QuickLZ level " + std::to_string(level) + " stream (only level 1, DBoW3's build default, is decoded)";
+    return false;
+  }
+  if (dsize == 0) return true;
+  std::vector<int64_t> table(4096, -1);
+  auto hash3 = [&](int64_t at) {
+    const uint32_t i = (uint32_t)out[at] | ((uint32_t)out[at + 1] << 8) | ((uint32_t)out[at + 2] << 16);
+    return ((i >> 12) ^ i) & 4095u;
+  };
+  const int64_t last = (int64_t)dsize - 1, last_matchstart = last - 6 - 4;
+  int64_t dst = 0, last_hashed = -1;
+  size_t sp = hdr;
+  uint32_t cword = 1;
+  auto hash_upto = [&](int64_t max) {  // positions (last_hashed, max]; position q needs bytes q .. q + 2
+    while (last_hashed < max) {
+      last_hashed++;
+      if (last_hashed + 2 <= last) table[hash3(last_hashed)] = last_hashed;
+    }
+  };
+  static const unsigned bitlut[16] = {4, 0, 1, 0, 2, 0, 1, 0, 3, 0, 1, 0, 2, 0, 1, 0};
+  for (;;) {
+    if (cword == 1) {
+      if (sp + 4 > src_len) return why = "control word beyond the chunk", false;
+      cword = R.rd(sp, 4), sp += 4;
+      if (cword == 0) return why = "control word without its end marker", false;
+    }
+    const uint32_t fetch = R.rd(sp, 4);
+    if (cword & 1u) {
+      cword >>= 1;
+      const unsigned hash = (fetch >> 4) & 0xfffu;
+      const int64_t from = table[hash];
+      size_t mlen;
+      if (fetch & 0xfu) mlen = (fetch & 0xfu) + 2, sp += 2;
+      else mlen = (fetch >> 16) & 0xffu, sp += 3;
+      if (sp > src_len || from < 0 || from >= dst || mlen < 3 || dst + (int64_t)mlen > (int64_t)dsize)
+        return why = "match outside the data decoded so far", false;
+      for (size_t i = 0; i < mlen; i++) out[dst + i] = out[from + i];  // forward, byte by byte: source and target may overlap
+      dst += mlen;
+      hash_upto(dst - (int64_t)mlen);
+      last_hashed = dst - 1;
+    } else if (dst < last_matchstart) {
+      const unsigned nlit = bitlut[cword & 0xfu];
+      if (sp + nlit > src_len || dst + nlit > (int64_t)dsize) return why = "literals beyond the chunk", false;
+      for (unsigned i = 0; i < nlit; i++) out[dst + i] = src[sp + i];
+      cword >>= nlit, dst += nlit, sp += nlit;
+      hash_upto(dst - 3);
+    } else {
+      while (dst <= last) {
+        if (cword == 1) sp += 4, cword = 1u << 31;
+        if (sp >= src_len) return why = "trailing literals beyond the chunk", false;
+        out[dst++] = src[sp++];
+        cword >>= 1;
+      }
+      return true;
+    }
+    if (dst > last) return true;  // (a stream whose last item is a match ends here)
+  }
+}
+}  // namespace
+
+extern "C" {
+
 int vo_vocab_load(const char *path, vo_vocab **out, int *n_nodes, int *n_words, int *branching_k, int *depth_L) {
   if (!path || !out) return VO_ERR_INVALID;
   std::ifstream f(path, std::ios::binary);
@@ -454,8 +558,8 @@ int vo_vocab_load(const char *path, vo_vocab **out, int *n_nodes, int *n_words, 
     // (int cols, rows, type, then cols x elemSize bytes); then uint32 word count and per word (node id, word id).
     // Children are attached to their parent in FILE order (fromStream does `m_nodes[parent].children.push_back(id)` per
     // record), which is the order Vocabulary::transform visits them in -- ties in the Hamming distance go to the first.
-    // Compressed streams (QuickLZ chunks; what `Vocabulary::save(path)` writes by default) are not decoded: re-save with
-    // `save(path, false)`.
+    // Compressed streams (what `Vocabulary::save(path)` writes by default): QuickLZ level-1 chunks, decoded by
+    // qlz_decompress_chunk above.
     char compressed = 0;
     uint32_t nn = 0;
     f.read(&compressed, 1);
@@ -464,14 +568,44 @@ int vo_vocab_load(const char *path, vo_vocab **out, int *n_nodes, int *n_words, 
       vo::set_error("%s: implausible node count %u", path, nn);
       return VO_ERR_INVALID;
     }
+    std::istringstream mem;
+    std::istream *in = &f;
     if (compressed) {
-      vo::set_error("%s: compressed DBoW3 vocabulary (QuickLZ): re-save it with Vocabulary::save(path, false)", path);
-      return VO_ERR_INVALID;
+      // uint32 chunk count, then the chunks back to back; each is read the way fromStream reads it: 9 bytes, from which
+      // the chunk's size follows, then the rest (a chunk is never shorter than 9 bytes)
+      uint32_t n_chunks = 0;
+      f.read(reinterpret_cast<char *>(&n_chunks), 4);
+      if (!f || n_chunks == 0 || n_chunks > (1u << 20)) {
+        vo::set_error("%s: implausible chunk count %u in a compressed DBoW3 vocabulary", path, n_chunks);
+        return VO_ERR_INVALID;
+      }
+      std::string body;
+      std::vector<uint8_t> chunk, plain;
+      for (uint32_t c = 0; c < n_chunks; c++) {
+        chunk.assign(9, 0);
+        f.read(reinterpret_cast<char *>(chunk.data()), 9);
+        const size_t csize = (chunk[0] & 2) ? ((size_t)chunk[1] | (size_t)chunk[2] << 8 | (size_t)chunk[3] << 16 | (size_t)chunk[4] << 24) : chunk[1];
+        if (!f || csize < 9 || csize > (1u << 24)) {
+          vo::set_error("%s: chunk %u of the compressed vocabulary has size %zu", path, c, csize);
+          return VO_ERR_INVALID;
+        }
+        chunk.resize(csize);
+        f.read(reinterpret_cast<char *>(chunk.data() + 9), (std::streamsize)(csize - 9));
+        std::string why;
+        if (!f || !qlz_decompress_chunk(chunk.data(), csize, plain, why)) {
+          vo::set_error("%s: chunk %u of the compressed (QuickLZ) vocabulary cannot be decoded: %s -- re-save it with "
+                        "Vocabulary::save(path, false)", path, c, f ? why.c_str() : "truncated file");
+          return VO_ERR_INVALID;
+        }
+        body.append(reinterpret_cast<const char *>(plain.data()), plain.size());
+      }
+      mem.str(body);
+      in = &mem;
     }
     int32_t hdr[4];
-    f.read(reinterpret_cast<char *>(hdr), 16);
+    in->read(reinterpret_cast<char *>(hdr), 16);
     k = hdr[0], L = hdr[1];
-    if (!f || k < 1 || k > 64 || L < 1 || L > 16) {
+    if (!*in || k < 1 || k > 64 || L < 1 || L > 16) {
       vo::set_error("%s: implausible branching factor / depth %d / %d", path, k, L);
       return VO_ERR_INVALID;
     }
@@ -483,13 +617,13 @@ int vo_vocab_load(const char *path, vo_vocab **out, int *n_nodes, int *n_words, 
     for (uint32_t i = 1; i < nn; i++) {
       VocNode n;
       int32_t cols = 0, rows = 0, type = 0;
-      f.read(reinterpret_cast<char *>(&n.id), 4);
-      f.read(reinterpret_cast<char *>(&n.parent), 4);
-      f.read(reinterpret_cast<char *>(&n.weight), 8);
-      f.read(reinterpret_cast<char *>(&cols), 4);
-      f.read(reinterpret_cast<char *>(&rows), 4);
-      f.read(reinterpret_cast<char *>(&type), 4);
-      if (!f) break;
+      in->read(reinterpret_cast<char *>(&n.id), 4);
+      in->read(reinterpret_cast<char *>(&n.parent), 4);
+      in->read(reinterpret_cast<char *>(&n.weight), 8);
+      in->read(reinterpret_cast<char *>(&cols), 4);
+      in->read(reinterpret_cast<char *>(&rows), 4);
+      in->read(reinterpret_cast<char *>(&type), 4);
+      if (!*in) break;
       if (n.id == 0 || n.id >= nn || n.parent >= nn || seen[n.id] || n.parent == n.id || !seen[n.parent]) {
         vo::set_error("%s: record %u names node %u / parent %u (of %u nodes%s)", path, i, n.id, n.parent, nn,
                       n.id < nn && seen[n.id] ? ", twice"
@@ -501,23 +635,23 @@ int vo_vocab_load(const char *path, vo_vocab **out, int *n_nodes, int *n_words, 
         vo::set_error("%s: node %u has a %d x %d descriptor of type %d (need 1 x 32 CV_8U)", path, n.id, rows, cols, type);
         return VO_ERR_INVALID;
       }
-      f.read(reinterpret_cast<char *>(n.desc), 32);
+      in->read(reinterpret_cast<char *>(n.desc), 32);
       seen[n.id] = 1;
       n.children.clear();
       nodes[n.id] = n;
       nodes[n.parent].children.push_back(n.id);
     }
     uint32_t nw = 0;
-    f.read(reinterpret_cast<char *>(&nw), 4);
-    if (!f || nw > nn) {
+    in->read(reinterpret_cast<char *>(&nw), 4);
+    if (!*in || nw > nn) {
       vo::set_error("%s: truncated vocabulary", path);
       return VO_ERR_INVALID;
     }
     for (uint32_t i = 0; i < nw; i++) {
       uint32_t nid = 0, wid = 0;
-      f.read(reinterpret_cast<char *>(&nid), 4);
-      f.read(reinterpret_cast<char *>(&wid), 4);
-      if (!f || nid >= nn || wid >= nw) {
+      in->read(reinterpret_cast<char *>(&nid), 4);
+      in->read(reinterpret_cast<char *>(&wid), 4);
+      if (!*in || nid >= nn || wid >= nw) {
         vo::set_error("%s: malformed word table (entry %u: node %u, word %u)", path, i, nid, wid);
         return VO_ERR_INVALID;
       }
