@@ -359,8 +359,9 @@ def main():
         "scaling": "weak", "vs_baseline": None, "dtype": "u8", "data": "synthetic",
         "collective_backend": (args.backend if world > 1 else None),
         "rccl_note": ("this line's all-reduces went through RCCL (torch.distributed nccl backend)" if (world > 1 and args.backend == "nccl") else
-                      "RCCL has not been exercised by this run: the sharded-BA all-reduce path is covered by gloo tests and an RCCL "
-                      "C++ host that compiles and links (examples/rccl_sharded_ba.cpp); no SCALE record exists yet"),
+                      "RCCL has not been exercised by this run: the sharded-BA all-reduce path is covered by gloo tests and by an RCCL "
+                      "C++ host (examples/rccl_sharded_ba.cpp) that has run the loop's collectives on an MI355X as a single rank only "
+                      "(tests/test_gpu_rccl.py); nothing has crossed xGMI and no SCALE record exists yet"),
         "config": {"workload": "tracked frame: ORB extract (640x480, 8-level pyramid, 1000 kpts) + undistort/depth/grid + "
                                "searchByProjection vs last frame + solvePoseOnlySE3 + cullingOutliersBeforeLocalMap + "
                                "isInFrame (refined pose) + searchByProjection vs local map + solvePoseOnlySE3; frames, depth "

@@ -8,6 +8,11 @@
 //
 //   for r in 0 1 2 3 4 5 6 7; do RANK=$r WORLD_SIZE=8 ./rccl_sharded_ba problem.bin & done; wait
 //
+// On a box with ONE GPU (RCCL refuses two ranks on one device) the same program runs as a single rank with
+// VO_BA_COLLECTIVES_AT_ONE_RANK=1: the library then runs the sharded form of its LM loop on the one shard, so every
+// collective of the loop is a real ncclAllReduce on the handle's stream (a sum over one rank) -- what
+// tests/test_gpu_rccl.py does.
+//
 // problem.bin: tools/dump_ba_problem.py (int32 n_cams, n_points, n_edges; poses [n_cams][6] f64; fixed [n_cams] u8;
 // points [n_points][3] f64; edge_cam, edge_point [n_edges] i32; edge_obs [n_edges][3] f64; inv_sigma [n_edges] f64;
 // cam[5] f64).  Every rank prints its wall time; rank 0 also solves the unsharded problem and reports the largest pose
@@ -139,13 +144,44 @@ int main(int argc, char **argv) {
   NCCL_OK(ncclCommInitRank(&comm, world, id, rank));
   hipStream_t st;
   HIP_OK(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
+  {
+    // self-check of the collective on the stream the LM loop will use: every rank contributes (rank + 1) * i
+    const int N = 4096;
+    std::vector<double> hbuf(N);
+    for (int i = 0; i < N; i++) hbuf[i] = (double)(rank + 1) * i;
+    double *dbuf = nullptr;
+    HIP_OK(hipMalloc(&dbuf, N * sizeof(double)));
+    HIP_OK(hipMemcpyAsync(dbuf, hbuf.data(), N * sizeof(double), hipMemcpyHostToDevice, st));
+    if (allreduce(&comm, dbuf, N, st) != 0) {
+      fprintf(stderr, "ncclAllReduce failed\n");
+      return 1;
+    }
+    HIP_OK(hipMemcpyAsync(hbuf.data(), dbuf, N * sizeof(double), hipMemcpyDeviceToHost, st));
+    HIP_OK(hipStreamSynchronize(st));
+    HIP_OK(hipFree(dbuf));
+    const double tri = 0.5 * world * (world + 1);
+    for (int i = 0; i < N; i++)
+      if (hbuf[i] != tri * i) {
+        fprintf(stderr, "rank %d: RCCL all-reduce self-check failed at %d: %g != %g\n", rank, i, hbuf[i], tri * i);
+        return 1;
+      }
+    printf("rank %d / %d: RCCL all-reduce self-check on the BA stream ok (%d doubles)\n", rank, world, N);
+  }
+  static int n_calls = 0;  // collectives the LM loops asked for
+  struct Counting {
+    ncclComm_t *comm;
+  } counting{&comm};
+  auto counted = +[](void *user, double *buf, size_t n, void *stream) -> int {
+    n_calls++;
+    return allreduce(static_cast<Counting *>(user)->comm, buf, n, stream);
+  };
 
   vo_ba *h = nullptr;
   VO_OK_OR_DIE(vo_ba_create(&h, P.n_cams, P.poses.data(), P.fixed.data(), P.n_points, P.points.data(), P.n_edges, P.ecam.data(),
                             P.ept.data(), P.obs.data(), P.isg.data(), P.cam));
   VO_OK_OR_DIE(vo_ba_set_stream(h, st));
   VO_OK_OR_DIE(vo_ba_set_shard(h, rank, world));
-  VO_OK_OR_DIE(vo_ba_set_allreduce(h, allreduce, &comm));
+  VO_OK_OR_DIE(vo_ba_set_allreduce(h, counted, &counting));
   std::vector<uint8_t> erase(P.n_edges);
   vo_lm_summary sums[2];
   double best = 1e30;
@@ -160,8 +196,8 @@ int main(int argc, char **argv) {
   std::vector<double> poses((size_t)6 * P.n_cams), points((size_t)3 * P.n_points);
   VO_OK_OR_DIE(vo_ba_get_state(h, poses.data(), points.data()));
   const int iters = sums[0].iterations + sums[1].iterations;
-  printf("rank %d / %d: %d LM iterations in %.3f ms (%.1f iterations/s), final cost %.6e\n", rank, world, iters, best,
-         iters / best * 1e3, sums[1].final_cost);
+  printf("rank %d / %d: %d LM iterations in %.3f ms (%.1f iterations/s), final cost %.6e, %d RCCL all-reduces in 3 solves\n", rank,
+         world, iters, best, iters / best * 1e3, sums[1].final_cost, n_calls);
   vo_ba_destroy(h);
   if (rank == 0) {
     vo_ba *u = nullptr;

@@ -2773,6 +2773,8 @@ struct vo_ba {
   vo::DevBuf b_packtiles, b_pack;        // sharded large systems: tiles of the matrix that exist, packed all-reduce payload
   int n_pack_tiles = 0;
   std::vector<int> pt_owner;             // shard of every point (p % n_shards; by nested-dissection segment in a segment solve)
+  bool collectives = false;              // the LM loop runs its sharded form: n_shards > 1, or ONE shard with a callback and
+                                         // VO_BA_COLLECTIVES_AT_ONE_RANK=1 (the callback path end to end on a one-GPU box)
   bool seg_mode = false;                 // sharded large system: per-rank segment factorisation
   int seg_c0 = 0;                        // first separator tile column
   vo::CholPlan *seg_plan[3] = {nullptr, nullptr, nullptr};  // chol_plan_create_split phases 1..3
@@ -2821,6 +2823,10 @@ int build_device(vo_ba *h) {
   BaDev &D = h->D;
   D.n_cams = h->n_cams, D.n_pts = h->n_pts, D.n_edges = h->n_edges, D.nf = h->nf;
   D.n_shards = h->n_shards, D.shard = h->shard;
+  {
+    const char *e = getenv("VO_BA_COLLECTIVES_AT_ONE_RANK");
+    h->collectives = h->n_shards > 1 || (h->allreduce && e && e[0] == '1');
+  }
   D.K = Cam{h->cam[0], h->cam[1], h->cam[2], h->cam[3], h->cam[4]};
   D.large = 6 * h->nf + 1 > kMaxN ? 1 : 0;
   D.ld = (6 * h->nf + vo::kCholPanel - 1) / vo::kCholPanel * vo::kCholPanel;
@@ -2930,7 +2936,7 @@ int build_device(vo_ba *h) {
       VO_CHECK(upload(h->b_ltiles, lt.data(), lt.size() * sizeof(int2)));
       D.n_ltiles = (int)lt.size();
     }
-    if (h->n_shards > 1 && !h->seg_mode) {
+    if (h->collectives && !h->seg_mode) {
       std::vector<int2> tiles;
       for (int i = 0; i < m; i++)
         for (int j = 0; j <= i; j++)
@@ -3108,7 +3114,7 @@ int build_device(vo_ba *h) {
   VO_CHECK(h->b_cnt.reserve(4096));
   VO_HIP_CHECK(hipMemsetAsync(h->b_cnt.p, 0, 4096, h->stream));
   D.counters = h->b_cnt.as<unsigned int>();
-  D.fused = h->n_shards == 1 ? 1 : 0;
+  D.fused = h->collectives ? 0 : 1;
   D.div_np1 = (unsigned)((0x100000000ull + (unsigned)(6 * h->nf)) / (unsigned)(6 * h->nf + 1));
   D.dbg = h->b_dbg.as<unsigned long long>();
   VO_HIP_CHECK(hipMemsetAsync(h->b_state.p, 0, 3 * sizeof(BaState), h->stream));
@@ -3244,7 +3250,7 @@ int launch_step(vo_ba *h) {
   else
     hipLaunchKernelGGL(k_ba_solve, dim3(1), dim3(kSolveThreads), h->solve_lds, st, D);
   hipLaunchKernelGGL(k_ba_backsub, dim3(D.n_pblocks), dim3(256), 0, st, D);
-  if (h->n_shards > 1) hipLaunchKernelGGL(k_ba_reduce2, dim3(1), dim3(64), 0, st, D);
+  if (h->collectives) hipLaunchKernelGGL(k_ba_reduce2, dim3(1), dim3(64), 0, st, D);
   VO_HIP_CHECK(hipGetLastError());
   return VO_OK;
 }
@@ -3287,7 +3293,7 @@ int shard_allreduce(vo_ba *h, double *buf, size_t n) {
 }
 
 int run_lm_eager(vo_ba *h, int max_it) {
-  const bool sharded = h->n_shards > 1;
+  const bool sharded = h->collectives;
   double *p1 = nullptr, *p2 = nullptr;
   size_t n1 = 0, n2 = 0;
   if (sharded) {  // exactly two collectives per LM iteration; every control decision is a
@@ -3330,7 +3336,7 @@ int run_lm(vo_ba *h, int max_it) {
     const char *e = getenv("VO_BA_GRAPH");
     return e && e[0] == '1';
   }();
-  if (!use_graph || !h->own_stream || max_it < 1 || h->n_shards > 1) return run_lm_eager(h, max_it);
+  if (!use_graph || !h->own_stream || max_it < 1 || h->collectives) return run_lm_eager(h, max_it);
   auto it = h->graphs.find(max_it);
   if (it == h->graphs.end()) {
     hipGraph_t graph = nullptr;
