@@ -760,14 +760,16 @@ def main():
                 out["pose_only_ba"]["speedup_vs_cpu_port"] = round(out["pose_only_ba"]["device_resident"]["solves_per_s"] / (nps / tq), 1)
             if "global_ba" in out:
                 gp, gpt = gb["poses"].copy(), gb["points"].copy()
-                gsum = orc.make_summary(1)
+                gsum = orc.make_summary(8)
                 tgc0 = time.perf_counter()
+                n_git = 4  # (one call: the linearisation of the start point is paid once, as in the device's 10-iteration solves)
                 orc.lib().orc_ba_lm(len(gp), gp, gb["fixed"], len(gpt), gpt, len(gb["e_cam"]), gb["e_cam"], gb["e_pt"],
-                                    gb["e_obs"], gb["e_inv_sigma"], None, gb["cam"], hm, hs, 1,
+                                    gb["e_obs"], gb["e_inv_sigma"], None, gb["cam"], hm, hs, n_git,
                                     ctypes.cast(ctypes.pointer(gsum), ctypes.c_void_p))
-                tgc = time.perf_counter() - tgc0
+                tgc = (time.perf_counter() - tgc0) / max(int(gsum.iterations), 1)
                 cpu["global_ba_lm_iters_per_s"] = round(1.0 / tgc, 3)
-                cpu["global_ba_sample"] = f"1 LM iteration of the same 500-KF problem, {tgc:.1f} s, 1 thread"
+                cpu["global_ba_sample"] = (f"{int(gsum.iterations)} LM iterations of the same 500-KF problem, {tgc * int(gsum.iterations):.1f} s, "
+                                           "1 thread")
                 out["global_ba"]["speedup_vs_cpu_port"] = round(out["global_ba"]["lm_iters_per_s"] * tgc, 1)
         # the same port on all host cores at once, one frame stream per core (so the 1-core figure is no strawman)
         try:
