@@ -835,7 +835,7 @@ __global__ __launch_bounds__(64) void k_guided_replay(FramesDev F, Queries Q, Gu
     lds_handoff();
   }
   for (int i = lane; i < nf; i += 64) assigned[i] = (int)asg[i] - 1;
-  if (lane == 0) O.n_matches[f] = cnt;
+  if (lane == 0) O.n_matches[f] = cnt, O.ovf_used[f] = 0;  // (the cursor is back at zero for the next search: guided_launch)
 }
 
 // number of accepted queries of the searches without a claim step
@@ -946,14 +946,19 @@ int guided_launch(vo_frames *h, int slot0, int n_frames, const Queries &Q, const
       VO_CHECK(h->b_ovfr.reserve((size_t)n_frames * pool_per_frame * 2 + 64));
     }
     VO_CHECK(h->b_qrec.reserve((size_t)n_frames * Q.stride * 8 + 64));
-    VO_CHECK(h->b_used.reserve((size_t)n_frames * 4 + 64));
+    {
+      // overflow cursors: zero when allocated, and k_guided_replay leaves a frame's cursor at zero again (one fill kernel
+      // fewer per search in a chain where every dispatch costs ~4 us)
+      void *before = h->b_used.p;
+      VO_CHECK(h->b_used.reserve((size_t)h->max_frames * 4 + 64));
+      if (h->b_used.p != before) VO_HIP_CHECK(hipMemsetAsync(h->b_used.p, 0, (size_t)h->max_frames * 4 + 64, st));
+    }
     VO_CHECK(h->b_push.reserve((size_t)n_frames * Q.stride * 4 + 64));
     O.pool = h->b_pool.as<unsigned>(), O.ovf = h->b_ovf.as<unsigned>();
     O.rank = c.mode == kModeSim3 ? h->b_rank.as<unsigned short>() : nullptr;
     O.ovf_rank = c.mode == kModeSim3 ? h->b_ovfr.as<unsigned short>() : nullptr;
     O.qrec = h->b_qrec.as<uint2>(), O.ovf_used = h->b_used.as<int>(), O.pushes = h->b_push.as<unsigned>();
     O.ovf_stride = (int)pool_per_frame;
-    VO_HIP_CHECK(hipMemsetAsync(O.ovf_used, 0, (size_t)n_frames * 4, st));
   }
   const int nq_max = Q.nq_all;
   if (nq_max > 0) {

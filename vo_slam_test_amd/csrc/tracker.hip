@@ -34,8 +34,9 @@ using namespace vo::ba;
 // motion-model pose -- one launch instead of four memsets and a copy (a launch or a copy costs ~5 us of a 0.7 ms frame
 // when one camera stream is tracked at a time).
 __global__ __launch_bounds__(256) void k_track_prep(int cap, int last_stride, int *assigned, uint8_t *fhas, uint8_t *fobs,
-                                                    uint8_t *last_matched, const double *pose0, double *pose) {
+                                                    uint8_t *last_matched, const double *pose0, double *pose, int *zero_counter) {
   const int f = blockIdx.x, tid = threadIdx.x;
+  if (f == 0 && tid == 0 && zero_counter) *zero_counter = 0;  // the retry pass's counter (k_track_retry_prep adds to it)
   const long long o = (long long)f * cap;
   for (int i = tid; i < cap; i += 256) assigned[o + i] = -1, fhas[o + i] = 0, fobs[o + i] = 0;
   for (int i = tid; i < last_stride; i += 256) last_matched[(long long)f * last_stride + i] = 0;
@@ -450,7 +451,8 @@ int stage_motion(vo_tracker *t, const vo_tracker_params &P) {
                                 cam4, 0, c.width, 0, c.height, t->q0_flags.as<uint8_t>(), t->q0_u.as<float>(),
                                 t->q0_v.as<float>(), t->q0_aux.as<float>(), st));
   hipLaunchKernelGGL(k_track_prep, dim3(B), dim3(256), 0, st, t->cap, t->n_last, t->assigned.as<int>(), t->fhas.as<uint8_t>(),
-                     t->fobs.as<uint8_t>(), t->last_matched.as<uint8_t>(), t->pose0.as<double>(), t->pose.as<double>());
+                     t->fobs.as<uint8_t>(), t->last_matched.as<uint8_t>(), t->pose0.as<double>(), t->pose.as<double>(),
+                     P.no_retry ? (int *)nullptr : t->retry_nq.as<int>() + B);
   q.n_queries = t->nq_last, q.stride = t->n_last, q.flags = t->q0_flags.as<uint8_t>(), q.u = t->q0_u.as<float>();
   q.v = t->q0_v.as<float>(), q.aux = t->q0_aux.as<float>(), q.level = t->q0_level.as<int32_t>();
   q.angle = t->q0_angle.as<float>(), q.desc = t->q0_desc.as<uint8_t>();
@@ -460,8 +462,7 @@ int stage_motion(vo_tracker *t, const vo_tracker_params &P) {
   if (!P.no_retry) {
     // `if (match_num < 20) { fill(mappoints_, nullptr); match_num = searchByProjection(..., 2*radius); }` (:241-245) for
     // the frames that need it, on the device: the second call leaves every other frame out (n_per_frame < 0)
-    int *rq = t->retry_nq.as<int>();
-    VO_HIP_CHECK(hipMemsetAsync(rq + B, 0, 4, st));
+    int *rq = t->retry_nq.as<int>();  // (rq[B], the count of retried frames, was zeroed by k_track_prep)
     hipLaunchKernelGGL(k_track_retry_prep, dim3(B), dim3(256), 0, st, t->cap, t->nq_last, t->nm_first.as<int>(),
                        t->assigned.as<int>(), rq, rq + B);
     q.n_per_frame = rq;
@@ -487,7 +488,7 @@ int stage_ref_keyframe(vo_tracker *t, const vo_tracker_params &P) {
     return VO_ERR_INVALID;
   }
   hipLaunchKernelGGL(k_track_prep, dim3(B), dim3(256), 0, st, t->cap, t->n_last, t->assigned.as<int>(), t->fhas.as<uint8_t>(),
-                     t->fobs.as<uint8_t>(), t->last_matched.as<uint8_t>(), t->pose0.as<double>(), t->pose.as<double>());
+                     t->fobs.as<uint8_t>(), t->last_matched.as<uint8_t>(), t->pose0.as<double>(), t->pose.as<double>(), (int *)nullptr);
   std::vector<vo::RefKeyFrame> kfs((size_t)B);
   for (int f = 0; f < B; f++) {
     const RefKfHost &k = t->ref_kf[f];
