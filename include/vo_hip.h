@@ -707,7 +707,8 @@ int vo_ba_set_shard(vo_ba *h, int shard, int n_shards);
  * (VO_ERR_INVALID) instead of solving from partial sums.
  * Per-rank segment factorisation (opt-in, VO_BA_SEGMENTS=1; large reduced systems only): every rank eliminates the
  * nested-dissection segments it owns, and the calls per iteration become four -- the camera-block extras, the separator
- * block after the elimination, the step, 6 scalars; vo_ba_linearize / vo_ba_step refuse such a handle.  Measured with
+ * block after the elimination, the step, 6 scalars; vo_ba_linearize / vo_ba_step refuse such a handle.  The variable is
+ * read when the handle is first used (after vo_ba_set_allreduce) and must be the same on every rank.  Measured with
  * emulated ranks it does more work per rank than the default, which is why it is not the default.
  * VO_BA_COLLECTIVES_AT_ONE_RANK=1: a handle of ONE shard with a callback runs the same sharded form of the loop (for
  * bringing a collective up on a one-GPU machine: every call is a sum over one rank; tests/test_gpu_rccl.py). */
