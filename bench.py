@@ -571,8 +571,8 @@ def main():
             def _sharded_global_ba(segments):
                 # segments: the per-rank segment factorisation (points owned by the rank of their nested-dissection segment,
                 # own segments eliminated locally, separator block / extras / step all-reduced) instead of the replicated one
-                os.environ["VO_BA_SEGMENTS"] = "1" if segments else "0"
-                gsh = vo.BundleAdjuster(gb, shard=rank, n_shards=world, stream=torch.cuda.current_stream().cuda_stream)
+                gsh = vo.BundleAdjuster(gb, shard=rank, n_shards=world, stream=torch.cuda.current_stream().cuda_stream,
+                                        options={"segments": int(segments)})
                 gsh.set_allreduce(_allreduce)
                 gsh.solve(hm, hs, 1)                                   # builds the device structures
                 ar_stats["calls"], ar_stats["max_doubles"] = 0, 0
@@ -588,7 +588,6 @@ def main():
                 g_order, c0 = gsh.debug_order(), gsh.segment_c0()
                 gsh.close()
                 _same_on_all_ranks(g_it, "global BA")
-                os.environ.pop("VO_BA_SEGMENTS", None)
                 return float(np.median(g_s)), g_it, g_order, c0, ar_stats["max_doubles"] * 8 / 1e6, ar_stats["calls"] / len(g_s)
 
             tg, g_it, g_order, _, g_mb, g_calls = _sharded_global_ba(False)
@@ -606,7 +605,7 @@ def main():
                 "sharding": "points by nested-dissection segment; per LM iteration the camera-block extras, the separator block after the "
                             f"segments' elimination ({s_mb:.1f} MB), the step and 6 scalars are all-reduced; separators factored on every rank",
                 "allreduce_payload_MB": round(s_mb, 2), "allreduce_calls_per_solve": s_calls,
-                "note": "opt-in (VO_BA_SEGMENTS=1): on one GPU with emulated ranks it computes more per rank than the replicated form "
+                "note": "opt-in (vo_ba_set_option(h, VO_BA_OPT_SEGMENTS, 1)): on one GPU with emulated ranks it computes more per rank than the replicated form "
                         "(profiles/r04_segment_factorisation.txt)"}
         if world == 1:
             # aggregate throughput: independent problems (one handle + stream each) overlapped on the GPU

@@ -9,7 +9,7 @@
 //   for r in 0 1 2 3 4 5 6 7; do RANK=$r WORLD_SIZE=8 ./rccl_sharded_ba problem.bin & done; wait
 //
 // On a box with ONE GPU (RCCL refuses two ranks on one device) the same program runs as a single rank with
-// VO_BA_COLLECTIVES_AT_ONE_RANK=1: the library then runs the sharded form of its LM loop on the one shard, so every
+// `--collectives-at-one-rank` (vo_ba_set_option(h, VO_BA_OPT_COLLECTIVES_AT_ONE_RANK, 1)): the library then runs the sharded form of its LM loop on the one shard, so every
 // collective of the loop is a real ncclAllReduce on the handle's stream (a sum over one rank) -- what
 // tests/test_gpu_rccl.py does.
 //
@@ -102,7 +102,7 @@ static int env_int(const char *a, const char *b, int dflt) {
 
 int main(int argc, char **argv) {
   if (argc < 2) {
-    fprintf(stderr, "usage: %s problem.bin\n", argv[0]);
+    fprintf(stderr, "usage: %s problem.bin [--collectives-at-one-rank] [--segments]\n", argv[0]);
     return 2;
   }
   const int rank = env_int("RANK", "OMPI_COMM_WORLD_RANK", 0), world = env_int("WORLD_SIZE", "OMPI_COMM_WORLD_SIZE", 1);
@@ -181,6 +181,10 @@ int main(int argc, char **argv) {
                             P.ept.data(), P.obs.data(), P.isg.data(), P.cam));
   VO_OK_OR_DIE(vo_ba_set_stream(h, st));
   VO_OK_OR_DIE(vo_ba_set_shard(h, rank, world));
+  for (int a = 2; a < argc; a++) {  // protocol options: the same flags on every rank (the library checks it by a handshake)
+    if (!strcmp(argv[a], "--collectives-at-one-rank")) VO_OK_OR_DIE(vo_ba_set_option(h, VO_BA_OPT_COLLECTIVES_AT_ONE_RANK, 1));
+    if (!strcmp(argv[a], "--segments")) VO_OK_OR_DIE(vo_ba_set_option(h, VO_BA_OPT_SEGMENTS, 1));
+  }
   VO_OK_OR_DIE(vo_ba_set_allreduce(h, counted, &counting));
   std::vector<uint8_t> erase(P.n_edges);
   vo_lm_summary sums[2];

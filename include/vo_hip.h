@@ -676,7 +676,7 @@ int vo_sim3_reanchor_points(int n_points, const double *points_in, const int32_t
 int vo_chol_solve(int n, double *A_rowmajor_lower, double *b);
 
 /* The same solve through the split (per-rank segment) form that a sharded global BA can use (vo_ba_set_shard +
- * vo_ba_set_allreduce with VO_BA_SEGMENTS=1), with the n_ranks shards
+ * vo_ba_set_allreduce with VO_BA_OPT_SEGMENTS), with the n_ranks shards
  * emulated one after the other on this GPU -- a test entry: the 64-column tile columns [0, c0_tiles) hold segments that
  * are independent of each other (col_part[j] = the segment of tile column j, owned by rank col_part[j] % n_ranks), the
  * remaining tile columns the separators.  Per rank: eliminate the own segments into the separator block; the separator
@@ -695,9 +695,25 @@ void vo_ba_destroy(vo_ba *h);
 int vo_ba_set_stream(vo_ba *h, void *hip_stream);
 /* restrict this handle to the points p with p % n_shards == shard (multi-GPU: one process per
  * GPU, each owning a shard; cameras replicated).  Must precede any solve.
- * (With VO_BA_SEGMENTS=1 in the environment, an all-reduce callback and a large reduced system whose key-frame order has
+ * (With VO_BA_OPT_SEGMENTS set, an all-reduce callback and a large reduced system whose key-frame order has
  * nested-dissection segments, a point belongs to the rank of the segment it touches instead -- see vo_ba_set_allreduce.) */
 int vo_ba_set_shard(vo_ba *h, int shard, int n_shards);
+/* Per-handle options; must precede the first use of the handle (any solve, vo_ba_set_state, vo_ba_debug_order) and be the
+ * same on every rank of a sharded solve.  A sharded handle with an all-reduce callback checks that with one small
+ * handshake all-reduce when it is first used: ranks that disagree on the options, the shard count or the problem fail
+ * with VO_ERR_INVALID instead of waiting for each other in mismatched collectives.
+ *   VO_BA_OPT_SEGMENTS                 1: per-rank segment factorisation (see vo_ba_set_allreduce); default 0
+ *   VO_BA_OPT_COLLECTIVES_AT_ONE_RANK  1: a handle of ONE shard with a callback runs the sharded form of the loop (for
+ *                                      bringing a collective up on a one-GPU machine: every call is a sum over one rank)
+ *   VO_BA_OPT_ORDER_PARTS              force the number of nested-dissection parts of a large system's key-frame order
+ *                                      (1 = natural order; -1 = choose, the default) */
+enum { VO_BA_OPT_SEGMENTS = 1, VO_BA_OPT_COLLECTIVES_AT_ONE_RANK = 2, VO_BA_OPT_ORDER_PARTS = 3 };
+int vo_ba_set_option(vo_ba *h, int option, int value);
+/* Process-wide developer knobs: VO_OPT_BA_GRAPH 1 = replay the LM iteration sequence of an unsharded solve from a
+ * hipGraph (default 0: eager launches are faster on this stack); VO_OPT_POSE_BLOCK = threads per
+ * frame of the pose-only solver (0 = automatic, 64, 128, 256). */
+enum { VO_OPT_BA_GRAPH = 1, VO_OPT_POSE_BLOCK = 2 };
+int vo_set_option(int option, int value);
 /* Multi-GPU from C/C++: the all-reduce the sharded LM loop needs (sum of n doubles at dev_buf over all
  * shards, in place, ordered on hip_stream; returns 0).  With RCCL this is
  *   ncclAllReduce(buf, buf, n, ncclDouble, ncclSum, comm, (hipStream_t)stream)
@@ -705,12 +721,12 @@ int vo_ba_set_shard(vo_ba *h, int shard, int n_shards);
  * schedule with exactly two calls of it per iteration (the reduced camera system, 6 scalars); every
  * rank must make the same calls.  Without it those entry points reject a sharded handle
  * (VO_ERR_INVALID) instead of solving from partial sums.
- * Per-rank segment factorisation (opt-in, VO_BA_SEGMENTS=1; large reduced systems only): every rank eliminates the
+ * Per-rank segment factorisation (opt-in, vo_ba_set_option(h, VO_BA_OPT_SEGMENTS, 1); large reduced systems only): every rank eliminates the
  * nested-dissection segments it owns, and the calls per iteration become four -- the camera-block extras, the separator
- * block after the elimination, the step, 6 scalars; vo_ba_linearize / vo_ba_step refuse such a handle.  The variable is
- * read when the handle is first used (after vo_ba_set_allreduce) and must be the same on every rank.  Measured with
+ * block after the elimination, the step, 6 scalars; vo_ba_linearize / vo_ba_step refuse such a handle.  The option
+ * takes effect when the handle is first used and must be the same on every rank (checked by a handshake).  Measured with
  * emulated ranks it does more work per rank than the default, which is why it is not the default.
- * VO_BA_COLLECTIVES_AT_ONE_RANK=1: a handle of ONE shard with a callback runs the same sharded form of the loop (for
+ * VO_BA_OPT_COLLECTIVES_AT_ONE_RANK: a handle of ONE shard with a callback runs the same sharded form of the loop (for
  * bringing a collective up on a one-GPU machine: every call is a sum over one rank; tests/test_gpu_rccl.py). */
 typedef int (*vo_allreduce_fn)(void *user, double *dev_buf, size_t n_doubles, void *hip_stream);
 int vo_ba_set_allreduce(vo_ba *h, vo_allreduce_fn fn, void *user);

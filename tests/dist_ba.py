@@ -51,7 +51,7 @@ class ShardedBundleAdjuster:
 
     def __init__(self, prob, rank: int, world_size: int):
         import torch
-        from . import _lib
+        from vo_slam_test_amd import _lib
         self.torch = torch
         self.rank, self.world = rank, world_size
         self.stream = torch.cuda.current_stream()

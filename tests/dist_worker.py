@@ -65,11 +65,10 @@ def main():
         good_all = True
         # (a) per-rank segment factorisation: points owned by the rank of their nested-dissection segment; per LM iteration
         #     the camera-block extras, the separator block after the segments' elimination, the step and 6 scalars are summed;
-        # (b) VO_BA_SEGMENTS=0: points p % world, the packed reduced system summed, every rank factors all of it
+        # (b) the default: points p % world, the packed reduced system summed, every rank factors all of it
         for mode in ("segments", "replicated"):
-            os.environ["VO_BA_SEGMENTS"] = "1" if mode == "segments" else "0"
             calls["n"], calls["max_doubles"] = 0, 0
-            sh = vo.BundleAdjuster(prob, shard=rank, n_shards=world, stream=st)
+            sh = vo.BundleAdjuster(prob, shard=rank, n_shards=world, stream=st, options={"segments": int(mode == "segments")})
             sh.set_allreduce(allreduce)
             s1 = sh.solve(hm, hs, 3)
             p1, x1 = sh.state()

@@ -1,5 +1,5 @@
 """World-size-2 test of the N>1 path on CPU (gloo): the sharding rule and the all-reduce payload
-handling of vo_slam_test_amd.dist_ba, with the CPU oracle standing in for the per-shard HIP
+handling of tests/dist_ba.py, with the CPU oracle standing in for the per-shard HIP
 linearisation (the oracle is the checker here, never the product path)."""
 import os
 import pathlib
@@ -27,7 +27,8 @@ def _worker(rank, world, port, q):
     import torch
     import torch.distributed as dist
     import oracle_lib as orc
-    from vo_slam_test_amd import dist_ba, synth
+    import dist_ba
+    from vo_slam_test_amd import synth
     dist.init_process_group("gloo", rank=rank, world_size=world)
     pr = synth.make_lba_problem(12, n_kf=4, n_pts=120, n_fixed=1)
     mask = dist_ba.shard_edge_mask(pr["e_pt"], rank, world)
@@ -48,7 +49,8 @@ def _worker(rank, world, port, q):
 @pytest.mark.timeout(180)
 def test_two_rank_gloo_allreduce_of_shard_partials(orc):
     import torch.multiprocessing as mp
-    from vo_slam_test_amd import dist_ba, synth
+    import dist_ba
+    from vo_slam_test_amd import synth
     world, port = 2, _free_port()
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
@@ -72,7 +74,7 @@ def test_two_rank_gloo_allreduce_of_shard_partials(orc):
 
 
 def test_sharding_rule():
-    from vo_slam_test_amd import dist_ba
+    import dist_ba
     e_pt = np.arange(20) % 7
     masks = [dist_ba.shard_edge_mask(e_pt, r, 3) for r in range(3)]
     assert (np.sum(masks, 0) == 1).all()

@@ -1,7 +1,7 @@
 """RCCL carrying the collectives of the sharded LM loop on a real GPU -- as far as a ONE-GPU box allows: RCCL refuses two
 ranks on one device, so examples/rccl_sharded_ba.cpp (the C++ host a deployment would use: ncclCommInitRank,
 vo_ba_set_allreduce with ncclAllReduce(ncclDouble, ncclSum) on the handle's stream) runs as a single rank with
-VO_BA_COLLECTIVES_AT_ONE_RANK=1.  The library then runs the sharded form of its loop (partial-sum payloads, k_ba_reduce,
+`--collectives-at-one-rank` (vo_ba_set_option(h, VO_BA_OPT_COLLECTIVES_AT_ONE_RANK, 1)).  The library then runs the sharded form of its loop (partial-sum payloads, k_ba_reduce,
 two callbacks per LM iteration, the closing merge) on the one shard, every collective is a real ncclAllReduce enqueued
 on the BA stream between the loop's kernels, and the result must equal the plain one-GPU solve.  What this does NOT show:
 bytes crossing xGMI (world > 1) -- that is the driver's multi-GPU run."""
@@ -35,8 +35,8 @@ def test_rccl_host_runs_the_sharded_loop_on_one_rank(tmp_path):
     r = subprocess.run([sys.executable, str(ROOT / "tools" / "dump_ba_problem.py"), str(prob)], capture_output=True, text=True, cwd=str(ROOT))
     assert r.returncode == 0 and prob.exists(), r.stderr[-2000:]
     env = dict(os.environ, RANK="0", WORLD_SIZE="1", LOCAL_RANK="0", VO_NCCL_ID_FILE=str(tmp_path / "id"),
-               VO_BA_COLLECTIVES_AT_ONE_RANK="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
-    r = subprocess.run([str(exe), str(prob)], capture_output=True, text=True, env=env, timeout=600)
+               HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run([str(exe), str(prob), "--collectives-at-one-rank"], capture_output=True, text=True, env=env, timeout=600)
     out = r.stdout + r.stderr
     assert r.returncode == 0, out[-3000:]
     assert "RCCL all-reduce self-check on the BA stream ok" in out

@@ -13,7 +13,7 @@ class _DevView:
         self.__cuda_array_interface__ = {"shape": (int(n),), "typestr": "<f8", "data": (int(ptr), False), "version": 2}
 
 
-def run_ranks(vo, prob, world, solve, streams=None, serial=False):
+def run_ranks(vo, prob, world, solve, streams=None, serial=False, options=None):
     """solve(handle, rank) -> result, on `world` sharded handles of `prob`; returns (results, stats) with
     stats = dict(calls per rank, payload sizes in doubles per call of rank 0, and -- serial=True: the ranks take turns
     between collectives, so that a rank's GPU work runs alone -- per rank the wall time of every stretch between two
@@ -22,7 +22,7 @@ def run_ranks(vo, prob, world, solve, streams=None, serial=False):
     import torch
     barrier = threading.Barrier(world)
     slots = [None] * world
-    stats = {"calls": [0] * world, "sizes": [], "stretch_ms": [[] for _ in range(world)]}
+    stats = {"calls": [0] * world, "sizes": [], "stretch_ms": [[] for _ in range(world)], "handshake": [False] * world}
     results, errors = [None] * world, []
     streams = streams or [torch.cuda.Stream() for _ in range(world)]
     arrived = [threading.Semaphore(0) for _ in range(world)]  # rank r has finished the stretch before its next collective
@@ -31,9 +31,13 @@ def run_ranks(vo, prob, world, solve, streams=None, serial=False):
     def worker(rank):
         try:
             def allreduce(ptr, n, stream):
-                stats["calls"][rank] += 1
-                if rank == 0:
-                    stats["sizes"].append(int(n))
+                handshake = int(n) == 4 and stats["calls"][rank] == 0 and not stats["handshake"][rank]
+                if handshake:   # the protocol handshake of a sharded handle's first use (4 doubles): not part of the LM loop's schedule
+                    stats["handshake"][rank] = True
+                else:
+                    stats["calls"][rank] += 1
+                    if rank == 0:
+                        stats["sizes"].append(int(n))
                 with torch.cuda.stream(streams[rank]):
                     t = torch.as_tensor(_DevView(ptr, n), device="cuda")
                     streams[rank].synchronize()
@@ -56,7 +60,7 @@ def run_ranks(vo, prob, world, solve, streams=None, serial=False):
                 return 0
 
             with torch.cuda.stream(streams[rank]):
-                h = vo.BundleAdjuster(prob, shard=rank, n_shards=world, stream=streams[rank].cuda_stream)
+                h = vo.BundleAdjuster(prob, shard=rank, n_shards=world, stream=streams[rank].cuda_stream, options=options)
                 h.set_allreduce(allreduce)
                 if serial:
                     if rank > 0:

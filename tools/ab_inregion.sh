@@ -1,4 +1,5 @@
-cd ${GRAFT_REPO_ROOT:-/root/repo}
+#!/bin/bash
+cd "$(dirname "$0")/.."
 one() {
   python bench.py --steps 20 --warmup 3 --no-ba --no-bruteforce --no-single-stream --no-cpu-baseline 2>/dev/null | tail -1 | python -c "
 import json,sys

@@ -5,11 +5,20 @@
 set -e
 cd "$(dirname "$0")/.."
 name=$1; unit=$2; srcfile=$3; shift 3
+python -m vo_slam_test_amd.build >/dev/null   # the other units' objects must be current
 mkdir -p vo_slam_test_amd/_variants vo_slam_test_amd/_obj/variants
-C="-O3 -std=c++17 --offload-arch=gfx950 -fPIC -Wall -Wno-unused-function -Ivo_slam_test_amd/csrc"
+C="-O3 -std=c++17 --offload-arch=gfx950 -fPIC -Wall -Wno-unused-function -Wno-pass-failed -Ivo_slam_test_amd/csrc"
 contract=off
 case $unit in ba|pose_graph|chol) contract=fast;; esac
-/opt/rocm/bin/hipcc $C -ffp-contract=$contract "$@" -c $srcfile -o vo_slam_test_amd/_obj/variants/${unit}_$name.o 2>/dev/null
-others=$(ls vo_slam_test_amd/_obj/*.o | grep -v "/${unit}\.o")
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o vo_slam_test_amd/_variants/libvo_$name.so $others vo_slam_test_amd/_obj/variants/${unit}_$name.o -lz
+obj=vo_slam_test_amd/_obj/variants/${unit}_$name.o
+if ! /opt/rocm/bin/hipcc $C -ffp-contract=$contract "$@" -c $srcfile -o $obj 2>/tmp/variant_$name.err; then
+  cat /tmp/variant_$name.err >&2; echo "variant $name FAILED to compile" >&2; exit 1
+fi
+# the link list comes from build.py's SOURCES (not a glob of _obj/: stale objects of earlier variants live there)
+others=$(python - <<PY
+from vo_slam_test_amd import build as b
+print(" ".join(str(b.PKG / "_obj" / (s.rsplit(".", 1)[0] + ".o")) for s, _ in b.SOURCES if s.rsplit(".", 1)[0] != "$unit"))
+PY
+)
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o vo_slam_test_amd/_variants/libvo_$name.so $others $obj -lz
 echo built vo_slam_test_amd/_variants/libvo_$name.so

@@ -39,7 +39,6 @@ out = {"unsharded_ms_per_iter": float(np.median(times)), "worlds": {}}
 import os  # noqa: E402
 for world in worlds:
     for mode in ("segments", "replicated"):
-        os.environ["VO_BA_SEGMENTS"] = "1" if mode == "segments" else "0"
         ncol = 4 if mode == "segments" else 2
 
         def solve(h, rank):

@@ -1,5 +1,5 @@
 """Developer tool: ONE pose-only problem on the device with 1000 / 500 / 250 / 125 / 64 of its observations, per block width
-(VO_POSE_BLOCK = 64, 128, 256 via the environment of a child process): time per launch and LM iterations -- how much of
+(vo_set_option(VO_OPT_POSE_BLOCK, 64 / 128 / 256) in a child process): time per launch and LM iterations -- how much of
 an LM iteration is the per-observation work and how much the fixed part (reduction, 6 x 6 solve, exp / log, tests)."""
 import ctypes, os, pathlib, subprocess, sys
 ROOT = pathlib.Path(__file__).resolve().parent.parent
@@ -7,6 +7,7 @@ sys.path.insert(0, str(ROOT))
 if len(sys.argv) > 1 and sys.argv[1] == "child":
     import numpy as np, torch
     from vo_slam_test_amd import _lib as vo, synth
+    vo.set_option("pose_block", int(sys.argv[2]))
     pr = synth.make_pose_problem(3)
     cs = torch.cuda.current_stream()
     for n in (1000, 500, 250, 125, 64):
@@ -33,6 +34,6 @@ if len(sys.argv) > 1 and sys.argv[1] == "child":
         print(f"   n = {n:4d}: {t:7.1f} us per launch, {its} LM iterations -> {t / max(its, 1):5.2f} us per iteration")
     sys.exit(0)
 for bw in (64, 128, 256):
-    print("VO_POSE_BLOCK =", bw)
-    r = subprocess.run([sys.executable, __file__, "child"], env=dict(os.environ, VO_POSE_BLOCK=str(bw)), capture_output=True, text=True)
+    print("pose block =", bw)
+    r = subprocess.run([sys.executable, __file__, "child", str(bw)], capture_output=True, text=True)
     print(r.stdout.rstrip() or r.stderr[-1500:])

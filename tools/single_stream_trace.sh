@@ -1,5 +1,6 @@
+#!/bin/bash
 cd /tmp && export TMPDIR=/tmp
-R=${GRAFT_REPO_ROOT:-/root/repo}
+R="$(cd "$(dirname "$0")/.." && pwd)"
 python3 $R/tools/latency_probe.py 2>&1 | grep -v amdgpu.ids | tail -4
 d=$R/gpurun_out/sstrace; rm -rf $d; mkdir -p $d
 rocprofv3 --kernel-trace -d $d --output-format csv -- python3 $R/tools/latency_probe.py > $d/log.txt 2>&1

@@ -56,7 +56,7 @@ SYMBOLS = [
     "vo_match_triangulation", "vo_match_bow_batch", "vo_match_triangulation_batch", "vo_match_fuse", "vo_match_area_best", "vo_match_sim3_projection",
     "vo_match_sim3_mutual", "vo_vocab_create", "vo_vocab_destroy", "vo_bow_transform",
     "vo_pose_only_solve", "vo_sim3_solve", "vo_pose_graph_solve", "vo_sim3_reanchor_points", "vo_chol_solve", "vo_chol_solve_split", "vo_pose_only_solve_dev",
-    "vo_ba_create", "vo_ba_destroy", "vo_ba_set_stream", "vo_ba_set_shard", "vo_ba_set_allreduce", "vo_ba_set_state",
+    "vo_ba_create", "vo_ba_destroy", "vo_ba_set_stream", "vo_ba_set_shard", "vo_ba_set_option", "vo_set_option", "vo_ba_set_allreduce", "vo_ba_set_state",
     "vo_ba_get_state", "vo_ba_n_free_cams", "vo_ba_local_ba", "vo_ba_local_ba_enqueue",
     "vo_ba_local_ba_finish", "vo_ba_solve", "vo_ba_lm_begin",
     "vo_ba_linearize", "vo_ba_step", "vo_ba_update", "vo_ba_lm_end", "vo_ba_reduced_system",
@@ -892,10 +892,18 @@ def sim3_reanchor_points(points, ref, S_rw, S_wr):
     return out
 
 
+def set_option(option, value):
+    """vo_set_option: 'ba_graph' (1: hipGraph replay of unsharded LM loops) / 'pose_block' (0, 64, 128, 256)."""
+    code = {"ba_graph": 1, "pose_block": 2}.get(option, option)
+    check(lib().vo_set_option(int(code), int(value)), "vo_set_option")
+
+
 class BundleAdjuster:
     """Handle over vo_ba_* (the arrays Optimizer::solveLocalBAPoseAndPoint gathers)."""
 
-    def __init__(self, prob, shard=0, n_shards=1, stream=None):
+    OPT_SEGMENTS, OPT_COLLECTIVES_AT_ONE_RANK, OPT_ORDER_PARTS = 1, 2, 3
+
+    def __init__(self, prob, shard=0, n_shards=1, stream=None, options=None):
         self.prob = prob
         self.n_cams, self.n_pts, self.n_edges = len(prob["poses"]), len(prob["points"]), len(prob["e_cam"])
         self._h = C.c_void_p()
@@ -907,6 +915,14 @@ class BundleAdjuster:
             check(lib().vo_ba_set_shard(self._h, shard, n_shards), "vo_ba_set_shard")
         if stream is not None:
             check(lib().vo_ba_set_stream(self._h, C.c_void_p(stream)))
+        for k, v in (options or {}).items():
+            self.set_option(k, v)
+
+    def set_option(self, option, value):
+        """vo_ba_set_option: 'segments' / 'collectives_at_one_rank' / 'order_parts' (or the integer codes); before the
+        first use of the handle, the same on every rank."""
+        code = {"segments": 1, "collectives_at_one_rank": 2, "order_parts": 3}.get(option, option)
+        check(lib().vo_ba_set_option(self._h, int(code), int(value)), "vo_ba_set_option")
 
     def close(self):
         if getattr(self, "_h", None) and self._h.value and _lib is not None:

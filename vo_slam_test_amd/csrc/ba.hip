@@ -25,6 +25,7 @@
 #include "vo_common.h"
 
 #include <algorithm>
+#include <atomic>
 #include <cmath>
 #include <map>
 #include <numeric>
@@ -2741,6 +2742,9 @@ __global__ __launch_bounds__(256) void k_ba_setup(BaDev B, int set_active, uint8
 // ============================================================================================
 // host
 // ============================================================================================
+// process-wide developer knobs (vo_set_option)
+static std::atomic<int> g_opt_ba_graph{0}, g_opt_pose_block{0};
+
 struct vo_ba {
   int n_cams = 0, n_pts = 0, n_edges = 0, nf = 0;
   std::vector<double> poses, points;
@@ -2781,6 +2785,11 @@ struct vo_ba {
   vo::DevBuf b_segtiles, b_segpack;      // separator tiles of the factor; payload of the separator / solution collectives
   int n_seg_tiles = 0;
   int order_parts = 1, order_cyclic = 0, order_sep = 0, order_depth = 0, order_tiles = 0;  // what choose_camera_order picked
+  // vo_ba_set_option (before the first use of the handle; the same on every rank of a sharded solve -- checked by the
+  // handshake all-reduce of build_device)
+  int opt_segments = 0;       // VO_BA_OPT_SEGMENTS: per-rank segment factorisation
+  int opt_collectives_1 = 0;  // VO_BA_OPT_COLLECTIVES_AT_ONE_RANK: one shard + callback runs the sharded form of the loop
+  int opt_order_parts = -1;   // VO_BA_OPT_ORDER_PARTS: force the number of nested-dissection parts (1 = natural order)
 };
 
 namespace {
@@ -2810,9 +2819,7 @@ vo::CholOrder choose_camera_order(const vo_ba *h, int m) {
         if (!seen[(size_t)hi * nf + lo]) seen[(size_t)hi * nf + lo] = 1, pairs.push_back({hi, lo});
       }
     }
-  int force_parts = -1;
-  if (const char *e = getenv("VO_BA_ORDER_PARTS")) force_parts = atoi(e);  // developer knob (tools/gba_run.py): 1 = natural
-  return vo::chol_choose_order(nf, 6, pairs, m, force_parts);
+  return vo::chol_choose_order(nf, 6, pairs, m, h->opt_order_parts);  // (-1: choose; vo_ba_set_option(VO_BA_OPT_ORDER_PARTS))
 }
 
 // Every device-side initialisation below is enqueued on the handle's own (non-blocking) stream: a hipMemset on the NULL
@@ -2823,10 +2830,7 @@ int build_device(vo_ba *h) {
   BaDev &D = h->D;
   D.n_cams = h->n_cams, D.n_pts = h->n_pts, D.n_edges = h->n_edges, D.nf = h->nf;
   D.n_shards = h->n_shards, D.shard = h->shard;
-  {
-    const char *e = getenv("VO_BA_COLLECTIVES_AT_ONE_RANK");
-    h->collectives = h->n_shards > 1 || (h->allreduce && e && e[0] == '1');
-  }
+  h->collectives = h->n_shards > 1 || (h->allreduce && h->opt_collectives_1);
   D.K = Cam{h->cam[0], h->cam[1], h->cam[2], h->cam[3], h->cam[4]};
   D.large = 6 * h->nf + 1 > kMaxN ? 1 : 0;
   D.ld = (6 * h->nf + vo::kCholPanel - 1) / vo::kCholPanel * vo::kCholPanel;
@@ -2859,13 +2863,12 @@ int build_device(vo_ba *h) {
     // only are dealt out to even the load.  Then a rank's segment columns (separator rows included) are complete without
     // any exchange, and what has to be summed over the ranks is the separator block after the segments' elimination.
     {
-      // Opt-in (VO_BA_SEGMENTS=1): measured with emulated ranks on one MI355X (tools/gba_seg_run.py) a
+      // Opt-in (vo_ba_set_option(h, VO_BA_OPT_SEGMENTS, 1)): measured with emulated ranks on one MI355X (tools/gba_seg_run.py) a
       // rank computes MORE per LM iteration this way than with the replicated factorisation of the all-reduced system
       // (config 4: 1.05 / 0.98 / 1.03 ms against 0.94 / 0.86 / 0.85 at 2 / 4 / 8 ranks) -- the separators' chain of dependent
       // tile columns, which every rank still runs, is three quarters of the factorisation, and the split adds launches,
       // flag resets and two small collectives.
-      const char *e = getenv("VO_BA_SEGMENTS");
-      bool seg = h->n_shards > 1 && h->allreduce && !h->ext_payload && e && e[0] == '1' && o.parts >= 2 &&
+      bool seg = h->n_shards > 1 && h->allreduce && !h->ext_payload && h->opt_segments && o.parts >= 2 &&
                  (int)o.part_of.size() == h->nf && o.seg_slots > 0 && (6 * o.seg_slots) % vo::kCholPanel == 0 &&
                  6 * o.seg_slots / vo::kCholPanel < m;
       std::vector<int> part_rank, pt_part;
@@ -3149,6 +3152,33 @@ int build_device(vo_ba *h) {
   if (h->gemm_lds > 64 * 1024)
     VO_HIP_CHECK(hipFuncSetAttribute((const void *)k_ba_gemm, hipFuncAttributeMaxDynamicSharedMemorySize,
                                      (int)h->gemm_lds));
+  if (h->collectives && h->allreduce) {
+    // Handshake: the collective schedule of the LM loop (how many all-reduces per iteration, of how many doubles) follows
+    // from the options and the problem, and ranks that disagree would wait for each other forever.  One tiny all-reduce
+    // before any solve: every rank contributes (c, c^2, 1) with c = its protocol word; the sums tell every rank -- the
+    // same way -- whether all words are equal (n sum(c^2) == sum(c)^2, exact in doubles for c < 2^20) and whether the
+    // number of ranks is the one it was configured with.
+    const unsigned proto = 1u + (h->seg_mode ? 1u : 0u) + (D.large ? 2u : 0u) + 4u * (unsigned)(h->n_shards & 0xff) +
+                           1024u * (unsigned)((h->n_edges * 31 + h->n_pts * 7 + h->nf) & 0x3ff);
+    const double c = (double)proto;
+    double hs[4] = {c, c * c, 1.0, 0.0};
+    VO_CHECK(h->b_merge.reserve(64));
+    VO_HIP_CHECK(hipMemcpyAsync(h->b_merge.p, hs, sizeof(hs), hipMemcpyHostToDevice, h->stream));
+    const int rc = h->allreduce(h->allreduce_user, h->b_merge.as<double>(), 4, (void *)h->stream);
+    if (rc != 0) {
+      vo::set_error("BA all-reduce callback failed with status %d (handshake)", rc);
+      return VO_ERR_HIP;
+    }
+    VO_HIP_CHECK(hipMemcpyAsync(hs, h->b_merge.p, sizeof(hs), hipMemcpyDeviceToHost, h->stream));
+    VO_HIP_CHECK(hipStreamSynchronize(h->stream));
+    const double nr = hs[2];
+    if (nr != (double)h->n_shards || nr * hs[1] != hs[0] * hs[0]) {
+      vo::set_error("sharded BA: the ranks disagree on the collective protocol (options / shard count / problem): %g ranks answered, "
+                    "%d configured, protocol word %u here (vo_ba_set_option and vo_ba_set_shard must be the same on every rank)",
+                    nr, h->n_shards, proto);
+      return VO_ERR_INVALID;
+    }
+  }
   h->built = true;
   return VO_OK;
 }
@@ -3331,11 +3361,8 @@ int run_lm_eager(vo_ba *h, int max_it) {
 int run_lm(vo_ba *h, int max_it) {
   // Measured on MI355X / ROCm 7.2: replaying a 30-45 node graph costs ~100-200 us of host time before
   // the first node starts, while eager launches (~4 us each) stay ahead of ~20 us kernels.  Graph
-  // replay is therefore opt-in (VO_BA_GRAPH=1), for hosts whose launch path is the bottleneck.
-  static const bool use_graph = [] {
-    const char *e = getenv("VO_BA_GRAPH");
-    return e && e[0] == '1';
-  }();
+  // replay is therefore opt-in (vo_set_option(VO_OPT_BA_GRAPH, 1)), for hosts whose launch path is the bottleneck.
+  const bool use_graph = g_opt_ba_graph.load(std::memory_order_relaxed) != 0;
   if (!use_graph || !h->own_stream || max_it < 1 || h->collectives) return run_lm_eager(h, max_it);
   auto it = h->graphs.find(max_it);
   if (it == h->graphs.end()) {
@@ -3377,10 +3404,7 @@ extern "C" {
 // fastest with four wavefronts sharing its observations; a batch is fastest with ONE wavefront per frame, so that a
 // CU works on four frames at once instead of four times on one (1024 frames x 1000 observations: 1.45 -> see DESIGN).
 static inline int pose_block_width(int n_problems) {
-  static const int forced = [] {
-    const char *e = getenv("VO_POSE_BLOCK");
-    return e ? atoi(e) : 0;
-  }();
+  const int forced = g_opt_pose_block.load(std::memory_order_relaxed);  // vo_set_option(VO_OPT_POSE_BLOCK, ...)
   if (forced == 64 || forced == 128 || forced == 256) return forced;
   return n_problems >= 512 ? 64 : 256;
 }
@@ -3609,6 +3633,33 @@ int vo_ba_set_shard(vo_ba *h, int shard, int n_shards) {
   return VO_OK;
 }
 
+int vo_ba_set_option(vo_ba *h, int option, int value) {
+  if (!h || h->built) {
+    vo::set_error("vo_ba_set_option: null handle or called after the first use of the handle");
+    return VO_ERR_INVALID;
+  }
+  switch (option) {
+    case VO_BA_OPT_SEGMENTS: h->opt_segments = value != 0; return VO_OK;
+    case VO_BA_OPT_COLLECTIVES_AT_ONE_RANK: h->opt_collectives_1 = value != 0; return VO_OK;
+    case VO_BA_OPT_ORDER_PARTS: h->opt_order_parts = value; return VO_OK;
+    default: vo::set_error("vo_ba_set_option: unknown option %d", option); return VO_ERR_INVALID;
+  }
+}
+
+int vo_set_option(int option, int value) {
+  switch (option) {
+    case VO_OPT_BA_GRAPH: g_opt_ba_graph.store(value != 0); return VO_OK;
+    case VO_OPT_POSE_BLOCK:
+      if (value != 0 && value != 64 && value != 128 && value != 256) {
+        vo::set_error("vo_set_option(VO_OPT_POSE_BLOCK): 0 (automatic), 64, 128 or 256");
+        return VO_ERR_INVALID;
+      }
+      g_opt_pose_block.store(value);
+      return VO_OK;
+    default: vo::set_error("vo_set_option: unknown option %d", option); return VO_ERR_INVALID;
+  }
+}
+
 int vo_ba_n_free_cams(const vo_ba *h) { return h ? h->nf : 0; }
 
 int vo_ba_debug_order(vo_ba *h, int out[8]) {
@@ -3678,7 +3729,7 @@ int vo_ba_lm_begin(vo_ba *h, double hm, double hs, int max_it, const uint8_t *ed
 static int reject_segment_mode(const vo_ba *h, const char *fn) {
   if (h->seg_mode) {
     vo::set_error("%s: the handle runs the per-rank segment factorisation through its all-reduce callback; drive it with vo_ba_solve "
-                  "(VO_BA_SEGMENTS=1 selected this form)", fn);
+                  "(VO_BA_OPT_SEGMENTS selected this form)", fn);
     return VO_ERR_INVALID;
   }
   return VO_OK;

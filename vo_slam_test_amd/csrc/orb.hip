@@ -6,9 +6,6 @@
 // Compiled with -ffp-contract=off: the float expressions that decide integer results
 // (fastAtan2 polynomial, x*b + y*a sample coordinates, pt *= scale) must round exactly like the
 // x86-64 reference build, which has no FMA.
-#ifndef VO_BLUR_TILED
-#define VO_BLUR_TILED 1  // 0: blurred planes row-major (rounds 1-3)
-#endif
 #include "vo_common.h"
 
 #include <cmath>
@@ -75,11 +72,7 @@ struct FrameSrc {  // where level 0 lives (caller memory) and where levels >= 1 
 // 128-byte line each (tile rows of pitch / 16 tiles; the plane's height is padded to 8 rows): a window then touches
 // 3-4 x 5-6 = 15-24 lines.  The blur kernels only change their store address; vo_orb_get_level un-tiles on the host.
 __host__ __device__ __forceinline__ long long blur_tiled_off(int x, int y, int pitch) {
-#if VO_BLUR_TILED
   return (long long)(y >> 3) * pitch * 8 + (x >> 4) * 128 + (y & 7) * 16 + (x & 15);
-#else
-  return (long long)y * pitch + x;
-#endif
 }
 
 __device__ __forceinline__ const uint8_t *level_plane(const OrbDev &P, const FrameSrc &S, int l, int f,
@@ -141,35 +134,8 @@ __device__ __forceinline__ int dot2_i16(unsigned taps, unsigned coef) {
   return __builtin_amdgcn_sdot2(__builtin_bit_cast(short2_t, taps), __builtin_bit_cast(short2_t, coef), 0, false);
 }
 
-#ifndef VO_FAST_REFINE
-#define VO_FAST_REFINE 2  // developer A/B switches (tools/ab_orb.sh): 0 off, 1 every round, 2 = product: the minThFAST round only
-#endif
-#ifndef VO_FAST_ARC16
-#define VO_FAST_ARC16 1
-#endif
-#ifndef VO_OCT_LEVEL_MAJOR
-#define VO_OCT_LEVEL_MAJOR 1
-#endif
-#ifndef VO_OCT_WAVES
-#define VO_OCT_WAVES 7
-#endif
-#ifndef VO_BLUR_PACK
-#define VO_BLUR_PACK 1
-#endif
-#ifndef VO_RZ_REUSE
-#define VO_RZ_REUSE 1
-#endif
-#ifndef VO_RZ_MULHI
-#define VO_RZ_MULHI 1
-#endif
-#if VO_RZ_MULHI
-#define VO_RZ_H(h) ((h) & ~15)
-#else
-#define VO_RZ_H(h) ((h) >> 4)
-#endif
-#ifndef VO_RZ_ABLATE
-#define VO_RZ_ABLATE 0  // developer ablation switch (tools/rz_ablate.py); 0 in the product build
-#endif
+#define VO_OCT_WAVES 7  // waves per SIMD the oct-tree is compiled for (6: +7 %, 8: +2.5 %, round 4)
+__device__ __forceinline__ int rz_h16(int h) { return h & ~15; }  // horizontal sum with the low four bits dropped (see the vertical blend)
 constexpr int kRzL = 16;               // lanes (four-pixel groups) per tile row
 constexpr int kRzF = 64 / kRzL;        // frames a wavefront works on side by side
 constexpr int kRzW = 4 * kRzL, kRzH = 16;  // output tile of k_resize4: 64 x 16 pixels of kRzF frames
@@ -241,12 +207,7 @@ __global__ __launch_bounds__(256) void k_resize4(const uint8_t *src, long long s
       if (q < nq) {  // uniform
         // source row 2 q + (tr >> 2), clamped to the image: both candidates are scalar
         const int ra = __mul24(min(2 * q, ymax), s_pitch), rb = __mul24(min(2 * q + 1, ymax), s_pitch);
-#if VO_RZ_ABLATE == 2
-        v[q] = (unsigned)(ra + rb);
-        (void)g0;
-#else
         v[q] = *reinterpret_cast<const unsigned *>(g0 + (hi ? rb : ra));
-#endif
       }
 #pragma unroll
     for (int q = 0; q < kRzNQ; q++)
@@ -255,7 +216,6 @@ __global__ __launch_bounds__(256) void k_resize4(const uint8_t *src, long long s
   __syncthreads();
   const int dyw = dy0 + wave * R;
   uint8_t *orow = Dst + (long long)dyw * d_pitch + dx;
-#if VO_RZ_REUSE && !VO_RZ_ABLATE
   // Round 4: (i) consecutive output rows share a source row four times out of five at scale 1.2 (row r + 1's upper row
   // is row r's lower one: the row indices are wave-uniform, so the test is a scalar branch) -- its horizontal sums are
   // kept instead of being read and formed again; (ii) no clamp: the weights are non-negative and sum to 2048 in both
@@ -276,7 +236,7 @@ __global__ __launch_bounds__(256) void k_resize4(const uint8_t *src, long long s
                      p2 = *reinterpret_cast<const unsigned *>(R0 + o2);
       const unsigned pl = __builtin_amdgcn_alignbyte(p1, p0, woff), ph = __builtin_amdgcn_alignbyte(p2, p1, woff);
 #pragma unroll
-      for (int q = 0; q < 4; q++) g0[q] = VO_RZ_H(dot2_i16(__builtin_amdgcn_perm(ph, pl, sel[q]), ab[q]));
+      for (int q = 0; q < 4; q++) g0[q] = rz_h16(dot2_i16(__builtin_amdgcn_perm(ph, pl, sel[q]), ab[q]));
     }
     {
       const uint8_t *R1 = rz_tile + __mul24(sy1 * kRzF, kRzPitch);
@@ -284,10 +244,9 @@ __global__ __launch_bounds__(256) void k_resize4(const uint8_t *src, long long s
                      q2 = *reinterpret_cast<const unsigned *>(R1 + o2);
       const unsigned ql = __builtin_amdgcn_alignbyte(q1, q0, woff), qh = __builtin_amdgcn_alignbyte(q2, q1, woff);
 #pragma unroll
-      for (int q = 0; q < 4; q++) g1[q] = VO_RZ_H(dot2_i16(__builtin_amdgcn_perm(qh, ql, sel[q]), ab[q]));
+      for (int q = 0; q < 4; q++) g1[q] = rz_h16(dot2_i16(__builtin_amdgcn_perm(qh, ql, sel[q]), ab[q]));
     }
     unsigned outw = 0;
-#if VO_RZ_MULHI
     // (b * (h >> 4)) >> 16 in ONE instruction: v_mul_hi_u32_u24(b << 12, h & ~15) = (b 2^12 (h >> 4) 2^4) >> 32; both factors
     // are non-negative and below 2^24 (b <= 2048, h <= 255 * 2048), so the 24-bit form is exact.  g0 / g1 hold h & ~15.
     {
@@ -303,52 +262,9 @@ __global__ __launch_bounds__(256) void k_resize4(const uint8_t *src, long long s
       }
       outw = v4[0] | (v4[1] << 8) | (v4[2] << 16) | (v4[3] << 24);
     }
-#else
-#pragma unroll
-    for (int q = 0; q < 4; q++) {
-      // 24-bit multiplies are exact here: |b| <= 2048, |h >> 4| <= 255 * 2048 / 16
-      const int val = ((__mul24(b0, g0[q]) >> 16) + (__mul24(b1, g1[q]) >> 16) + 2) >> 2;
-      outw |= (unsigned)val << (8 * q);
-      hp[q] = g1[q];
-    }
-#endif
     prev_row = sy1;
     if (store_ok) *reinterpret_cast<unsigned *>(orow + (long long)r * d_pitch) = outw;  // the tail lands in the row padding
   }
-#else
-#pragma unroll
-  for (int r = 0; r < R; r++) {
-    if (dyw + r >= dh) break;  // uniform per wave
-    const int sy0 = min(max(sy_[r], 0), sh - 1) - r0, sy1 = min(max(sy_[r] + 1, 0), sh - 1) - r0;
-    const int b0 = (short)(bb_[r] & 0xffff), b1 = bb_[r] >> 16;
-    const uint8_t *R0 = rz_tile + __mul24(sy0 * kRzF, kRzPitch), *R1 = rz_tile + __mul24(sy1 * kRzF, kRzPitch);
-    const unsigned p0 = *reinterpret_cast<const unsigned *>(R0 + o0), p1 = *reinterpret_cast<const unsigned *>(R0 + o1),
-                   p2 = *reinterpret_cast<const unsigned *>(R0 + o2);
-    const unsigned q0 = *reinterpret_cast<const unsigned *>(R1 + o0), q1 = *reinterpret_cast<const unsigned *>(R1 + o1),
-                   q2 = *reinterpret_cast<const unsigned *>(R1 + o2);
-    unsigned outw = 0;
-#if VO_RZ_ABLATE == 1
-    outw = p0 ^ p1 ^ p2 ^ q0 ^ q1 ^ q2 ^ (unsigned)(b0 + b1);
-#else
-    // the 8 bytes from column sx[0] on, of both source rows
-    const unsigned pl = __builtin_amdgcn_alignbyte(p1, p0, woff), ph = __builtin_amdgcn_alignbyte(p2, p1, woff);
-    const unsigned ql = __builtin_amdgcn_alignbyte(q1, q0, woff), qh = __builtin_amdgcn_alignbyte(q2, q1, woff);
-#pragma unroll
-    for (int q = 0; q < 4; q++) {
-      const int h0 = dot2_i16(__builtin_amdgcn_perm(ph, pl, sel[q]), ab[q]);
-      const int h1 = dot2_i16(__builtin_amdgcn_perm(qh, ql, sel[q]), ab[q]);
-      // 24-bit multiplies are exact here: |b| <= 2048, |h >> 4| <= 255 * 2048 / 16
-      int val = ((__mul24(b0, h0 >> 4) >> 16) + (__mul24(b1, h1 >> 4) >> 16) + 2) >> 2;
-      val = min(max(val, 0), 255);
-      outw |= (unsigned)val << (8 * q);
-    }
-#endif
-#if VO_RZ_ABLATE == 3
-    if (outw == 0x12345678u)
-#endif
-    if (store_ok) *reinterpret_cast<unsigned *>(orow + (long long)r * d_pitch) = outw;  // the tail lands in the row padding
-  }
-#endif
 }
 
 // ------------------------------------------------------------------------------------------
@@ -403,13 +319,6 @@ __device__ __forceinline__ int fast_arc_score(const lds_u8 *ring, int min_th) {
   // three-extrema of consecutive ring pixels on the 16-bit VOP2 min / max (the class that issues at ~2.2 cycles, section 7
   // of DESIGN.md; the compiler's own v_min_u32 / v_max_u32 issue at 4.2): four ring positions per asm block, 12 operations
   unsigned mn3[16], mx3[16];
-#if !VO_FAST_ARC16
-#pragma unroll
-  for (int k = 0; k < 16; k++) {
-    mn3[k] = (unsigned)min(r[k], min(r[(k + 1) & 15], r[(k + 2) & 15]));
-    mx3[k] = (unsigned)max(r[k], max(r[(k + 1) & 15], r[(k + 2) & 15]));
-  }
-#else
 #pragma unroll
   for (int k = 0; k < 16; k += 4) {
     unsigned t0, t1;
@@ -430,7 +339,6 @@ __device__ __forceinline__ int fast_arc_score(const lds_u8 *ring, int min_th) {
         : "v"((unsigned)r[k]), "v"((unsigned)r[(k + 1) & 15]), "v"((unsigned)r[(k + 2) & 15]), "v"((unsigned)r[(k + 3) & 15]),
           "v"((unsigned)r[(k + 4) & 15]), "v"((unsigned)r[(k + 5) & 15]));
   }
-#endif
   unsigned Au = max(mx3[0], max(mx3[3], mx3[6])), Bu = min(mn3[0], min(mn3[3], mn3[6]));
 #pragma unroll
   for (int k = 1; k < 16; k++) {
@@ -483,6 +391,9 @@ __host__ __device__ __forceinline__ int fast_cell_lds(int tp, int tile_rows, int
 // TP: tile row pitch in bytes (48: three 16-byte chunks, the LDS-DMA path; 72: the largest legal cell, staged
 // through registers).  BYTEWISE: the caller's level-0 rows are not 4-byte aligned (copied byte by byte).
 template <int TP, bool BYTEWISE>
+#ifdef VO_FAST_CPW
+__attribute__((amdgpu_waves_per_eu(8, 8)))
+#endif
 __global__ __launch_bounds__(256) void k_fast_cell(OrbDev P, FrameSrc src, uint32_t *cell_slots,
                                                    long long slots_frame_stride, int *cell_count,
                                                    int cells_per_frame, int tile_rows, int list_cap,
@@ -490,8 +401,16 @@ __global__ __launch_bounds__(256) void k_fast_cell(OrbDev P, FrameSrc src, uint3
   extern __shared__ __attribute__((aligned(16))) uint8_t fast_lds[];
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
-  const int cell = blockIdx.x * 4 + wave, f = blockIdx.y;
+  const int f = blockIdx.y;
+#ifdef VO_FAST_CPW  // developer A/B (round 5): a wave takes VO_FAST_CPW consecutive cells in a plain loop, no prefetch
+  for (int cpw = 0; cpw < VO_FAST_CPW; cpw++) {
+  const int cell = (blockIdx.x * 4 + wave) * VO_FAST_CPW + cpw;
+  if (cell >= cells_per_frame) return;
+  if (cpw) wave_sync();
+#else
+  const int cell = blockIdx.x * 4 + wave;
   if (cell >= cells_per_frame) return;  // wave-uniform; the kernel has no workgroup barrier
+#endif
   const int tile_bytes = fast_align16(TP * tile_rows);  // uniform
   lds_u8 *tile_raw = (lds_u8 *)fast_lds + wave * fast_cell_lds(TP, tile_rows, list_cap);
   lds_u16 *plist = (lds_u16 *)(tile_raw + 2 * tile_bytes);
@@ -502,7 +421,11 @@ __global__ __launch_bounds__(256) void k_fast_cell(OrbDev P, FrameSrc src, uint3
   const int iw = cw - 6, ih = ch - 6;
   if (iw <= 0 || ih <= 0) {  // :801, :811 (cw = 0 in the table), or no interior pixel
     if (lane == 0) *out_count = 0;
+#ifdef VO_FAST_CPW
+    continue;
+#else
     return;
+#endif
   }
   int pitch;
   const uint8_t *img;
@@ -708,15 +631,13 @@ __global__ __launch_bounds__(256) void k_fast_cell(OrbDev P, FrameSrc src, uint3
     wave_sync();
     int np = np0;
     if (np <= list_cap - 64) {  // uniform, the usual case (the walk's appends clamp their base 64 entries before the end)
-#if VO_FAST_REFINE
       // (only in the minThFAST round: at iniThFAST the further bounds reject ~15 % of a list -- three passes for nothing,
       //  measured +3 % on the kernel -- while they take a minThFAST list from ~170 entries to ~55)
-      if (VO_FAST_REFINE == 1 || round == 1) {
+      if (round == 1) {
         if (np > 64) np = refine_list(np, th, ring_k2);
         if (np > 64) np = refine_list(np, th, ring_k1);
         if (np > 64) np = refine_list(np, th, ring_k3);
       }
-#endif
       score_list(np);
       wave_sync();
       running = nms_list(np, th, 0);
@@ -743,6 +664,9 @@ __global__ __launch_bounds__(256) void k_fast_cell(OrbDev P, FrameSrc src, uint3
     wave_sync();
   }
   if (lane == 0) *out_count = min(running, cap_cell);
+#ifdef VO_FAST_CPW
+  }
+#endif
 }
 
 // ------------------------------------------------------------------------------------------
@@ -809,11 +733,7 @@ __attribute__((amdgpu_waves_per_eu(VO_OCT_WAVES, VO_OCT_WAVES))) __global__ __la
                                                 int *nk, int *err_flag) {
   __shared__ OctLds<CAP> S;
   const int tid = threadIdx.x;
-#if VO_OCT_LEVEL_MAJOR
   const int l = blockIdx.y, f = blockIdx.x;  // every frame's level 0 first: the longest workgroups start first, the short ones fill the tail
-#else
-  const int l = blockIdx.x, f = blockIdx.y;
-#endif
   const LevelGeom &L = P.lv[l];
   uint32_t *kd = key_data + (long long)f * keys_per_frame + L.candBase;
   unsigned short *kl = key_label + (long long)f * keys_per_frame + L.candBase;
@@ -1243,7 +1163,6 @@ __global__ __launch_bounds__(256) void k_blur_groups(FrameSrc src, int lv0_gener
   const bool fvalid = f0 + fo < n_frames;
   const int fl = fvalid ? fo : 0;  // lanes past the batch repeat its first frame (not stored)
   const int G = min(cb * kBlurB + (lane & (kBlurB - 1)), ngroups - 1), x = 4 * G;
-  const bool active = fvalid && cb * kBlurB + (lane & (kBlurB - 1)) < ngroups;
   int pitch;
   const uint8_t *img;
   unsigned fsrc;
@@ -1256,7 +1175,6 @@ __global__ __launch_bounds__(256) void k_blur_groups(FrameSrc src, int lv0_gener
     img = src.pyr + (long long)f0 * src.pyr_frame_stride + (((long long)sd[10] << 32) | (unsigned)sd[9]);
     fsrc = (unsigned)(fl * src.pyr_frame_stride);
   }
-#if VO_BLUR_TILED
   // the lane's part of the store address: its frame and the tile column of its quad (lanes 4 t .. 4 t + 3 = the four column
   // groups of one 16-pixel tile; lanes past the row end keep their own tile column: what they store is row padding)
   const int Gu = cb * kBlurB + (lane & (kBlurB - 1));
@@ -1265,10 +1183,6 @@ __global__ __launch_bounds__(256) void k_blur_groups(FrameSrc src, int lv0_gener
                  (long long)fl * src.blur_frame_stride + (Gu >> 2) * 128;
   __shared__ __attribute__((aligned(16))) unsigned tr_all[4][4][64];
   unsigned (*tr)[64] = tr_all[threadIdx.x >> 6];
-#else
-  uint8_t *dst = src.blur + (long long)f0 * src.blur_frame_stride + (((long long)sd[7] << 32) | (unsigned)sd[6]) +
-                 (long long)fl * src.blur_frame_stride + x;
-#endif
   // the three dwords of the lane: columns x-4.., x.., x+4..; at the row ends the neighbour is replaced by the
   // group itself (never read outside the row) and rebuilt below
   const unsigned vC = fsrc + (unsigned)x, vL = vC - (G > 0 ? 4u : 0u), vR = vC + (x + 4 < pitch ? 4u : 0u);
@@ -1343,9 +1257,7 @@ __global__ __launch_bounds__(256) void k_blur_groups(FrameSrc src, int lv0_gener
       hn[2] = __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(Cw, Lw, 3), K0, __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(Rw, Cw, 3), K1, 0u, false), false);
       hn[3] = __builtin_amdgcn_udot4(Cw, K0, __builtin_amdgcn_udot4(Rw, K1, 0u, false), false);
       unsigned outw = 0;
-#if VO_BLUR_PACK
       unsigned a4[4];
-#endif
 #pragma unroll
       for (int q = 0; q < 4; q++) {
         pr[(u + 6) % 7][q] = prev[q] | (hn[q] << 16);  // rows (u - 1, u)
@@ -1355,17 +1267,10 @@ __global__ __launch_bounds__(256) void k_blur_groups(FrameSrc src, int lv0_gener
         acc = __builtin_amdgcn_udot2(__builtin_bit_cast(u16x2, pr[(u + 5) % 7][q]), W45, acc, false);
         acc = __builtin_amdgcn_udot2(__builtin_bit_cast(u16x2, pr[(u + 3) % 7][q]), W23, acc, false);
         acc = __builtin_amdgcn_udot2(__builtin_bit_cast(u16x2, pr[(u + 1) % 7][q]), W01, acc, false);
-#if VO_BLUR_PACK
         a4[q] = min(acc, 0x00ffffffu);  // byte 2 = min(acc >> 16, 255)
-#else
-        outw |= min(acc >> 16, 255u) << (8 * q);
-#endif
       }
-#if VO_BLUR_PACK
       // the four saturated bytes (byte 2 of each sum) by two byte permutes and an OR: 7 instructions per group instead of 12
       outw = __builtin_amdgcn_perm(a4[1], a4[0], 0x0c0c0602u) | __builtin_amdgcn_perm(a4[3], a4[2], 0x06020c0cu);
-#endif
-#if VO_BLUR_TILED
       // Tiled plane: a row's dword per lane would be a 4-byte piece in each of sixteen 128-byte lines (measured: the blur
       // 50 % slower).  Four output rows are transposed through LDS instead -- lane (tile t, column group j) then holds the
       // four dwords of row j of its tile and stores them as ONE 16-byte tile row: as many line touches per row as the
@@ -1383,10 +1288,6 @@ __global__ __launch_bounds__(256) void k_blur_groups(FrameSrc src, int lv0_gener
           __builtin_amdgcn_wave_barrier();
         }
       }
-#else
-      // (the row's part is scalar; the tail lands in the row padding)
-      if (yy >= y0 + 3 && active) *reinterpret_cast<unsigned *>(dst + (long long)(yy - 3) * Lpitch) = outw;
-#endif
     }
   }
 }
@@ -1607,13 +1508,8 @@ __global__ __launch_bounds__(256) void k_describe(OrbDev P, FrameSrc src, const 
     const uint8_t *bl = src.blur + (long long)f * src.blur_frame_stride + L.blur_off;
     DescRec r;
     r.disc_base = (unsigned long long)(uintptr_t)(img + (long long)(py - kHalfPatch) * pitch + (px - kHalfPatch));
-#if VO_BLUR_TILED
     r.blur_base = (unsigned long long)(uintptr_t)bl;  // the plane; the window's origin (px - 19, py - 19) rides in `pad`
     r.pad = (px - kEdge) | ((py - kEdge) << 16);
-#else
-    r.blur_base = (unsigned long long)(uintptr_t)(bl + (long long)(py - kEdge) * bp + (px - kEdge));
-    r.pad = 0;
-#endif
     r.pitch = pitch, r.bpitch = bp;
     r.m10 = r.m01 = 0;
     r.a = r.b = 0.f;
@@ -1710,7 +1606,6 @@ __global__ __launch_bounds__(256) void k_describe(OrbDev P, FrameSrc src, const 
     for (int s = 0; s < NK; s++) {
       const int kk = min(k + s, k1 - 1);
       const unsigned long long bb = rec[kk].blur_base;
-#if VO_BLUR_TILED
       const int xy0 = rec[kk].pad;
       narrow[s] = uni_i32(xy0 & 15) <= 48 - (2 * kEdge + 1);  // uniform: three chunks per row suffice
       if (narrow[s]) {
@@ -1720,16 +1615,6 @@ __global__ __launch_bounds__(256) void k_describe(OrbDev P, FrameSrc src, const 
       } else {
         window_issue_tiled<2 * kEdge + 1, 4>(bb, uni_i32(rec[kk].bpitch), xy0, lane, wv[s], ox[s]);
       }
-#else
-      narrow[s] = uni_i32((int)(unsigned)bb & 15) <= 48 - (2 * kEdge + 1);  // uniform: three chunks per row suffice
-      if (narrow[s]) {
-        u32x4 w2[2];
-        window_issue<2 * kEdge + 1, 3>(bb, uni_i32(rec[kk].bpitch), lane, w2, ox[s]);
-        wv[s][0] = w2[0], wv[s][1] = w2[1];
-      } else {
-        window_issue<2 * kEdge + 1, 4>(bb, uni_i32(rec[kk].bpitch), lane, wv[s], ox[s]);
-      }
-#endif
     }
 #pragma unroll
     for (int s = 0; s < NK; s++) {
@@ -2156,7 +2041,11 @@ int run_pipeline(vo_orb *h, const uint8_t *dev_images, int n_frames, int w, int 
     VO_HIP_CHECK(hipEventRecord(h->ev_join, h->side));
   }
   if (h->cells_frame > 0) {
+#ifdef VO_FAST_CPW
+    const dim3 grid((h->cells_frame + 4 * VO_FAST_CPW - 1) / (4 * VO_FAST_CPW), n_frames);
+#else
     const dim3 grid((h->cells_frame + 3) / 4, n_frames);
+#endif
     auto fast = h->fast_tp == 48 ? (lv0_unaligned ? k_fast_cell<48, true> : k_fast_cell<48, false>)
                                  : (lv0_unaligned ? k_fast_cell<kTileP, true> : k_fast_cell<kTileP, false>);
     hipLaunchKernelGGL(fast, grid, dim3(256), h->fast_lds, st, D, S, h->slots.as<uint32_t>(), h->slots_frame,
@@ -2165,12 +2054,12 @@ int run_pipeline(vo_orb *h, const uint8_t *dev_images, int n_frames, int w, int 
   }
   VO_STAGE_MARK(2);
   if (h->oct_small)
-    hipLaunchKernelGGL(k_octree<256>, VO_OCT_LEVEL_MAJOR ? dim3(n_frames, D.nlevels) : dim3(D.nlevels, n_frames), dim3(256), 0, st, D, h->slots.as<uint32_t>(),
+    hipLaunchKernelGGL(k_octree<256>, dim3(n_frames, D.nlevels), dim3(256), 0, st, D, h->slots.as<uint32_t>(),
                        h->slots_frame, h->cellcnt.as<int>(), h->cells_frame, h->keydata.as<uint32_t>(),
                        h->keylabel.as<unsigned short>(), h->keys_frame, h->candcnt.as<int>(),
                        h->sel.as<uint32_t>(), h->sel_frame, h->nk.as<int>(), h->err.as<int>());
   else
-    hipLaunchKernelGGL(k_octree<kMaxList>, VO_OCT_LEVEL_MAJOR ? dim3(n_frames, D.nlevels) : dim3(D.nlevels, n_frames), dim3(256), 0, st, D, h->slots.as<uint32_t>(),
+    hipLaunchKernelGGL(k_octree<kMaxList>, dim3(n_frames, D.nlevels), dim3(256), 0, st, D, h->slots.as<uint32_t>(),
                        h->slots_frame, h->cellcnt.as<int>(), h->cells_frame, h->keydata.as<uint32_t>(),
                        h->keylabel.as<unsigned short>(), h->keys_frame, h->candcnt.as<int>(),
                        h->sel.as<uint32_t>(), h->sel_frame, h->nk.as<int>(), h->err.as<int>());
@@ -2438,7 +2327,7 @@ int vo_orb_get_level(vo_orb *h, int frame, int level, int blurred, uint8_t *dst,
     sp = h->last_src.pyr + (long long)frame * h->last_src.pyr_frame_stride + L.pyr_off;
     pitch = L.pitch;
   }
-  if (blurred && VO_BLUR_TILED) {  // the blurred planes are stored in 16 x 8 tiles: fetch the plane, un-tile on the host
+  if (blurred) {  // the blurred planes are stored in 16 x 8 tiles: fetch the plane, un-tile on the host
     std::vector<uint8_t> tmp((size_t)pitch * align_up(L.h, 8));
     VO_HIP_CHECK(hipMemcpy(tmp.data(), sp, tmp.size(), hipMemcpyDeviceToHost));
     for (int y = 0; y < L.h; y++)
