@@ -67,6 +67,16 @@ int vo_orb_create(vo_orb **out, int nfeatures, float scale_factor, int nlevels, 
 void vo_orb_destroy(vo_orb *h);
 /* run on a caller-owned hipStream_t instead of the handle's own stream (NULL = default stream) */
 int vo_orb_set_stream(vo_orb *h, void *hip_stream);
+/* VO_ORB_OPT_FUSED_LEVEL_PASS (default 0): 1 = every pyramid level whose geometry allows it is processed by ONE kernel that
+ * stages a tile once and produces the level's FAST cell results, its blurred tiles and the next level's rows from it
+ * (csrc/orb_level_pass.inc); 0 = the three separate kernels per level.  The results are bit-identical; on MI355X the fused
+ * pass measures 6 % slower than the three kernels (profiles/r05_ab_fused.txt: more vector instructions and three workgroup
+ * barriers), which is why it is opt-in. */
+enum { VO_ORB_OPT_FUSED_LEVEL_PASS = 1 };
+int vo_orb_set_option(vo_orb *h, int option, int value);
+/* (tests and tools) the fused pass's plan for one level of a width x height image: out = {takes the fused pass, tile pitch,
+ * tile rows, score rows, workgroups per frame, LDS bytes per workgroup, survivor-list entries, 0} */
+int vo_orb_debug_level_pass(vo_orb *h, int width, int height, int level, int out[8]);
 
 /* GetLevels / GetScaleFactor / GetScaleFactors / GetInverseScaleFactors (ORBextractor.h:61-76) */
 int vo_orb_levels(const vo_orb *h);
@@ -107,7 +117,8 @@ int vo_orb_get_level_counts(vo_orb *h, int frame, int32_t *counts /*nlevels*/);
 /* Per-stage timing with HIP events recorded on the handle's stream around each stage of every
  * subsequent call (bench.py's live roofline measurement).  Stages: 0 pyramid (all resize launches),
  * 1 FAST cells, 2 oct-tree, 3 offsets (always 0: folded into the descriptor kernel), 4 blur,
- * 5 orientation+descriptor.  vo_orb_get_timing
+ * 5 orientation+descriptor.  With the fused level pass (vo_orb_set_option) stage 0 carries the whole chain of level passes
+ * -- pyramid + FAST + blur -- and stages 1 and 4 are empty.  vo_orb_get_timing
  * synchronises, adds the elapsed times of the calls since the last reset to ms[VO_ORB_STAGES],
  * returns the number of timed calls in *n_calls and resets the accumulators. */
 #define VO_ORB_STAGES 6

@@ -7,11 +7,28 @@ from vo_slam_test_amd import synth
 pytestmark = pytest.mark.gpu
 
 
-@pytest.fixture(scope="module")
-def ext(vo):
+@pytest.fixture(scope="module", params=["fused", "separate"])
+def ext(vo, request):
+    """both forms of the level pipeline: the fused per-level pass (default) and the three separate kernels"""
     e = vo.OrbExtractor(1000, 1.2, 8, 20, 7)
+    e.set_fused(request.param == "fused")
     yield e
     e.close()
+
+
+@pytest.fixture(params=["fused", "separate"])
+def make_ext(vo, request):
+    made = []
+
+    def make(*args):
+        e = vo.OrbExtractor(*args)
+        e.set_fused(request.param == "fused")
+        made.append(e)
+        return e
+
+    yield make
+    for e in made:
+        e.close()
 
 
 def test_tables_match_oracle(ext, orc):
@@ -53,25 +70,24 @@ def test_extract_bit_exact(ext, orc, idx):
     assert np.array_equal(desc, odesc)
 
 
-def test_other_sizes_and_params(vo, orc):
+def test_other_sizes_and_params(make_ext, orc):
     """ragged sizes (non-multiple-of-64 widths, tiny top levels) and a different feature budget"""
     for (w, h, nf, nl) in [(320, 240, 500, 8), (752, 480, 1500, 8), (401, 301, 300, 5), (128, 96, 200, 4)]:
         img = synth.make_frame(11, w=w, h=h, n_rect=200, n_blob=60)
-        e = vo.OrbExtractor(nf, 1.2, nl, 20, 7)
+        e = make_ext(nf, 1.2, nl, 20, 7)
         p = orc.orb_params(nf, 1.2, nl, 20, 7)
         okp, odesc, _ = orc.extract(p, img, cap=nf + 64)
         kps, desc = e(img)
-        e.close()
         assert len(kps) == len(okp), (w, h)
         assert np.array_equal(kps, okp) and np.array_equal(desc, odesc), (w, h)
 
 
 @pytest.mark.parametrize("w,h", [(96, 80), (80, 64), (77, 61)])
-def test_tiny_pyramid_levels(vo, orc, w, h):
+def test_tiny_pyramid_levels(make_ext, orc, w, h):
     """top levels narrower than 24 px take the generic blur kernel, levels without a FAST cell yield nothing:
     every level's pyramid and blurred plane, and the final key-points, still match"""
     img = synth.make_frame(11, w=w, h=h, n_rect=40, n_blob=10)
-    e = vo.OrbExtractor(100, 1.2, 8, 20, 7)
+    e = make_ext(100, 1.2, 8, 20, 7)
     p = orc.orb_params(100, 1.2, 8, 20, 7)
     okp, odesc, _ = orc.extract(p, img, cap=164)
     kps, desc = e(img)
@@ -79,12 +95,11 @@ def test_tiny_pyramid_levels(vo, orc, w, h):
     for l in range(8):
         assert np.array_equal(e.get_level(0, l), lev[l]), f"pyramid level {l}"
         assert np.array_equal(e.get_level(0, l, blurred=True), orc.blur(lev[l])), f"blur level {l}"
-    e.close()
     assert np.array_equal(kps, okp) and np.array_equal(desc, odesc)
 
 
 @pytest.mark.parametrize("kind", ["uniform", "salt"])
-def test_noise_images_overflow_the_survivor_list(vo, orc, kind):
+def test_noise_images_overflow_the_survivor_list(make_ext, orc, kind):
     """white noise: most pixels pass the FAST pre-test, far more than the per-cell survivor list holds, so
     the cells take the chunked path; sparse salt noise mixes both paths"""
     rng = np.random.default_rng(5)
@@ -95,7 +110,7 @@ def test_noise_images_overflow_the_survivor_list(vo, orc, kind):
         m = rng.random((240, 320)) < 0.08
         img[m] = rng.integers(150, 256, int(m.sum()), dtype=np.uint8)
         img[:, 160:] = rng.integers(0, 256, (240, 160), dtype=np.uint8)
-    e = vo.OrbExtractor(800, 1.2, 8, 20, 7)
+    e = make_ext(800, 1.2, 8, 20, 7)
     p = orc.orb_params(800, 1.2, 8, 20, 7)
     okp, odesc, _ = orc.extract(p, img, cap=800 + 256)
     kps, desc = e(img)
@@ -105,7 +120,6 @@ def test_noise_images_overflow_the_survivor_list(vo, orc, kind):
         gx, gy, gr = e.get_candidates(0, l)
         assert len(gx) == len(cx), f"candidate count level {l}: {len(gx)} vs {len(cx)}"
         assert np.array_equal(gx, cx) and np.array_equal(gy, cy) and np.array_equal(gr, cr), f"candidates {l}"
-    e.close()
     assert len(kps) == len(okp) > 0
     assert np.array_equal(kps, okp) and np.array_equal(desc, odesc)
 
@@ -187,15 +201,14 @@ def test_batch_device_unaligned_rows(ext, orc):
 
 @pytest.mark.parametrize("w,h,nf,sf,nl", [(1280, 720, 2000, 1.2, 8), (640, 480, 1000, 1.1, 8), (640, 480, 800, 1.5, 5),
                                          (500, 375, 600, 1.33, 6), (640, 480, 700, 2.0, 4), (203, 151, 150, 1.25, 3)])
-def test_scale_factors_and_large_images(vo, orc, w, h, nf, sf, nl):
+def test_scale_factors_and_large_images(make_ext, orc, w, h, nf, sf, nl):
     """other pyramid scale factors (the tiled resize covers ratios below 2, the generic kernel the rest),
     a 720p frame, and odd small sizes"""
     img = synth.make_frame(21, w=w, h=h, n_rect=max(150, w * h // 600), n_blob=80)
-    e = vo.OrbExtractor(nf, sf, nl, 20, 7)
+    e = make_ext(nf, sf, nl, 20, 7)
     p = orc.orb_params(nf, sf, nl, 20, 7)
     okp, odesc, _ = orc.extract(p, img, cap=nf + 256)
     kps, desc = e(img)
-    e.close()
     assert len(kps) == len(okp) > 0, (w, h, sf)
     assert np.array_equal(kps, okp) and np.array_equal(desc, odesc), (w, h, sf)
 

@@ -36,7 +36,7 @@ _lib = None
 # every symbol include/vo_hip.h declares (tests check the .so exports all of them)
 SYMBOLS = [
     "vo_last_error", "vo_device_count", "vo_version", "vo_release_thread_scratch",
-    "vo_orb_create", "vo_orb_destroy", "vo_orb_set_stream", "vo_orb_levels", "vo_orb_scale_factor",
+    "vo_orb_create", "vo_orb_destroy", "vo_orb_set_stream", "vo_orb_set_option", "vo_orb_debug_level_pass", "vo_orb_levels", "vo_orb_scale_factor",
     "vo_orb_scale_factors", "vo_orb_features_per_level", "vo_orb_max_keypoints", "vo_orb_extract",
     "vo_orb_extract_batch_dev", "vo_orb_sync", "vo_orb_get_level", "vo_orb_get_candidates",
     "vo_orb_get_level_counts", "vo_orb_set_timing", "vo_orb_get_timing",
@@ -178,6 +178,19 @@ class OrbExtractor:
 
     def set_stream(self, stream_ptr: int):
         check(lib().vo_orb_set_stream(self._h, C.c_void_p(stream_ptr)))
+
+    def set_fused(self, on: bool):
+        """vo_orb_set_option(VO_ORB_OPT_FUSED_LEVEL_PASS): the fused per-level pass (default) or the three separate kernels"""
+        check(lib().vo_orb_set_option(self._h, 1, int(bool(on))), "vo_orb_set_option")
+
+    def level_pass_plan(self, width, height):
+        """per level: dict(fused, tile_pitch, tile_rows, score_rows, blocks, lds_bytes, list_cap) of the fused pass"""
+        out = []
+        for l in range(self.nlevels):
+            v = (C.c_int * 8)()
+            check(lib().vo_orb_debug_level_pass(self._h, int(width), int(height), l, v), "vo_orb_debug_level_pass")
+            out.append(dict(zip(("fused", "tile_pitch", "tile_rows", "score_rows", "blocks", "lds_bytes", "list_cap"), list(v)[:7])))
+        return out
 
     def __call__(self, image: np.ndarray, mask=None):
         """operator()(image, mask, keypoints, descriptors): host image -> (keypoints, descriptors)."""

@@ -21,6 +21,7 @@ constexpr int kEdge = 19;          // EDGE_THRESHOLD  ORBextractor.cpp:76
 constexpr int kBorder = kEdge - 3; // minBorderX/Y    :778-779
 constexpr int kHalfPatch = 15;     // HALF_PATCH_SIZE :75
 constexpr int kTileP = 72;         // LDS pitch of a FAST cell tile (cell <= 66 px incl. 6 px overlap)
+constexpr int kFastCpw = 4;        // cells a wavefront of k_fast_cell takes one after the other
 constexpr int kMaxList = 1024;     // oct-tree node list capacity per level (quota <= kMaxList-4)
 
 // Per-lane constants of k_describe, lane-major so that a lane fetches them with nine 16-byte loads:
@@ -388,29 +389,196 @@ __host__ __device__ __forceinline__ int fast_cell_lds(int tp, int tile_rows, int
   return 2 * fast_align16(tp * tile_rows) + fast_align16(2 * list_cap);
 }
 
+// FAST-9-16 + NMS of ONE cell by ONE wavefront on a tile that is already in LDS (k_fast_cell stages a private tile per
+// wave, k_level_pass a tile shared by the workgroup).  `tile`: the cell's pixel (iniX, iniY), row pitch TP; the score
+// entry of a pixel lives `sdelta` bytes behind its image byte (a zeroed region of the same pitch whose entries around
+// the cell's interior are never written); `plist`: the wave's survivor list.  Everything else as described above.
+template <int TP>
+__device__ __forceinline__ void fast_cell_body(lds_u8 *tile, int sdelta, lds_u16 *plist, int list_cap, int iw, int ih,
+                                               int ini_th, int min_th, uint32_t *slot, int cap_cell, int xoff, int yoff,
+                                               int *out_count, int lane) {
+  // ---- margin walk.  A 9-arc always contains two neighbouring compass pixels (ring 0, 4, 8, 12), so the arc
+  // score S is bounded by the compass margin m = max(mb - v, v - md), mb = min(max(p0,p8), max(p4,p12)),
+  // md = max(min(p0,p8), min(p4,p12)): a pixel can only be a corner at threshold t if m > t.  Pixels with m > th
+  // are compacted IN RASTER ORDER into the wave's LDS list as the LDS address of their (-3, -3) neighbour.
+  // Lane mapping: 32 columns x 2 rows per step (64 x 1 for cells wider than 32).
+  const int lw = iw <= 32 ? 5 : 6;  // uniform
+  const int lx = lane & ((1 << lw) - 1), ly = lane >> lw, ri = 64 >> lw;
+  lds_u8 *const b0 = tile + ly * TP + lx;
+  struct Ring5 { unsigned v, p0, p4, p8, p12; };
+  auto load5 = [&](const lds_u8 *b) { return Ring5{b[3 * TP + 3], b[6 * TP + 3], b[3 * TP + 6], b[3], b[3 * TP]}; };
+  // lanes with m > th as a wave mask: nine 16-bit VOP2 instructions and the compare, in one block (no register
+  // moves, no hazard padding between the dependent instructions: none of them writes a partial register)
+  auto margin_gt = [&](const Ring5 &r, unsigned thv) {
+    unsigned long long mask;
+    unsigned t0, t1, t2, t3;
+    asm("v_max_u16 %1, %6, %8\n\t"
+        "v_max_u16 %2, %7, %9\n\t"
+        "v_min_u16 %3, %6, %8\n\t"
+        "v_min_u16 %4, %7, %9\n\t"
+        "v_min_u16 %1, %1, %2\n\t"
+        "v_max_u16 %3, %3, %4\n\t"
+        "v_sub_u16 %1, %1, %5\n\t"
+        "v_sub_u16 %3, %5, %3\n\t"
+        "v_max_i16 %1, %1, %3\n\t"
+        "v_cmp_gt_i16 %0, %1, %10"
+        : "=s"(mask), "=&v"(t0), "=&v"(t1), "=&v"(t2), "=&v"(t3)
+        : "v"(r.v), "v"(r.p0), "v"(r.p4), "v"(r.p8), "v"(r.p12), "v"(thv));
+    return mask;
+  };
+  // rows [r0, r1) of the interior; returns the number of survivors (uniform); entries past the list's capacity
+  // pile up on its last 64 slots and the count tells the caller to take the chunked path
+  auto walk = [&](int th, int r0, int r1) {
+    int n = 0;
+    const unsigned thv = (unsigned)th;
+    if (lx < iw) {
+      lds_u8 *b = b0 + r0 * TP;
+      asm("" : "+v"(b));
+      int row = r0;
+      auto append = [&](unsigned long long mask, lds_u8 *bb) {
+        const int base = min(n, list_cap - 64);  // scalar
+        const int pos = (int)__builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mask, (unsigned)base));
+        if (__builtin_amdgcn_inverse_ballot_w64(mask)) plist[pos] = (unsigned short)(unsigned)(uintptr_t)bb;
+        n += __popcll(mask);
+      };
+      for (; row + 2 * ri <= r1; row += 2 * ri, b += 2 * ri * TP) {
+        lds_u8 *b1 = b + ri * TP;
+        const Ring5 va = load5(b), vb = load5(b1);
+        const unsigned long long ma = margin_gt(va, thv), mb = margin_gt(vb, thv);
+        append(ma, b);
+        append(mb, b1);
+      }
+      if (row + ri <= r1) {
+        append(margin_gt(load5(b), thv), b);
+        row += ri, b += ri * TP;
+      }
+      if (row < r1) {  // odd last row of a two-row step: the lanes of the first row only
+        const unsigned long long m = margin_gt(load5(b), thv);
+        append(ly == 0 ? m & 0xffffffffull : 0ull, b);
+      }
+    }
+    return __builtin_amdgcn_readlane(n, 0);  // lane 0 always takes part
+  };
+  // Second-level bound for long lists (a cell redone at minThFAST lists ~1/5 of its pixels, noise for the most part):
+  // the compass argument holds for ANY four ring pixels a quarter turn apart, so S is also bounded by the margin of the
+  // rings (K, K + 4, K + 8, K + 12), K = 1, 2, 3.  Entries whose bound does not exceed th cannot be corners at th and, as
+  // neighbours, score below every kept pixel (S - 1 < th): dropping them -- score entry left at 0 -- changes nothing.
+  // The list is compacted in place, order preserved (a lane writes at or before its own position, after every lane of
+  // the batch has read; LDS operations of one wavefront execute in order).  ~14 fast-class instructions per 64 entries
+  // against ~105 for their arc scores; the second bound halves a minThFAST list, the third takes another third.
+  auto refine_list = [&](int n, int th, auto load_ring) {
+    int kept = 0;
+    const unsigned thv = (unsigned)th;
+    for (int base = 0; base < n; base += 64) {
+      // lanes past the list repeat its last entry (no divergence around the asm block); their mask bits are cleared
+      const unsigned short e = plist[min(base + lane, n - 1)];
+      const int rem = n - base;  // uniform
+      const unsigned long long valid = rem >= 64 ? ~0ull : ((1ull << rem) - 1ull);
+      const unsigned long long mask = margin_gt(load_ring((const lds_u8 *)(uintptr_t)(unsigned)e), thv) & valid;
+      const int pos = (int)__builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mask, (unsigned)kept));
+      if (__builtin_amdgcn_inverse_ballot_w64(mask)) plist[pos] = e;
+      kept += __popcll(mask);
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // LDS operations of one wavefront execute in order: the next batch
+      __builtin_amdgcn_wave_barrier();                    // reads behind these writes (no memory fence needed)
+    }
+    return kept;
+  };
+  auto ring_k2 = [&](const lds_u8 *b) { return Ring5{b[3 * TP + 3], b[5 * TP + 5], b[TP + 5], b[TP + 1], b[5 * TP + 1]}; };
+  auto ring_k1 = [&](const lds_u8 *b) { return Ring5{b[3 * TP + 3], b[6 * TP + 4], b[2 * TP + 6], b[2], b[4 * TP]}; };
+  auto ring_k3 = [&](const lds_u8 *b) { return Ring5{b[3 * TP + 3], b[4 * TP + 6], b[4], b[2 * TP], b[6 * TP + 2]}; };
+  auto score_list = [&](int n) {
+    for (int i = lane; i < n; i += 64) {
+      lds_u8 *b = (lds_u8 *)(uintptr_t)(unsigned)plist[i];
+      b[sdelta + 3 * TP + 3] = (uint8_t)fast_arc_score<TP>(b, min_th);  // cornerScore, defined from minThFAST up
+    }
+  };
+  // 3x3 non-maximum suppression at threshold th over the raster-ordered list; kept pixels go out in the same
+  // order behind the `kept` already written.  Entries that are not survivors are 0, as OpenCV reads them.
+  auto nms_list = [&](int n, int th, int kept) {
+    for (int base = 0; base < n; base += 64) {
+      const int i = base + lane;
+      bool keep = false;
+      int pos = 0, sc0 = 0;
+      if (i < n) {
+        const lds_u8 *b = (const lds_u8 *)(uintptr_t)(unsigned)plist[i];
+        pos = (int)(b - tile);
+        const lds_u8 *c = b + sdelta + 2 * TP + 2;  // score entry (-1, -1) from the pixel
+        sc0 = c[TP + 1];
+        const unsigned nb = max_u16(max_u16(max_u16(c[0], c[1]), max_u16(c[2], c[TP])),
+                                    max_u16(max_u16(c[TP + 2], c[2 * TP]), max_u16(c[2 * TP + 1], c[2 * TP + 2])));
+        keep = sc0 >= th && sc0 > (int)nb;
+      }
+      const unsigned long long mask = __builtin_amdgcn_ballot_w64(keep);
+      const int off = kept + __builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0u));
+      if (keep && off < cap_cell) {
+        const int y = pos / TP, x = pos - y * TP;  // interior coordinates; the cell-local ones are +3
+        slot[off] = (uint32_t)(x + 3 + xoff) | ((uint32_t)(y + 3 + yoff) << 12) | ((uint32_t)sc0 << 24);
+      }
+      kept += __popcll(mask);
+    }
+    return kept;
+  };
+  int running = 0;
+  for (int round = 0; round < 2; round++) {
+    // a cell with no key-point at iniThFAST is redone at minThFAST (:820-824)
+    const int th = round == 0 ? ini_th : min_th;
+    const int np0 = walk(th, 0, ih);
+    wave_sync();
+    int np = np0;
+    if (np <= list_cap - 64) {  // uniform, the usual case (the walk's appends clamp their base 64 entries before the end)
+      // (only in the minThFAST round: at iniThFAST the further bounds reject ~15 % of a list -- three passes for nothing,
+      //  measured +3 % on the kernel -- while they take a minThFAST list from ~170 entries to ~55)
+      if (round == 1) {
+        if (np > 64) np = refine_list(np, th, ring_k2);
+        if (np > 64) np = refine_list(np, th, ring_k1);
+        if (np > 64) np = refine_list(np, th, ring_k3);
+      }
+      score_list(np);
+      wave_sync();
+      running = nms_list(np, th, 0);
+    } else {
+      // Rare: more survivors than the list holds (noise-like texture).  Chunks of as many rows as fit the list
+      // even if every pixel hits are scored one after the other, then -- all scores final -- suppressed one after
+      // the other; chunks follow each other in raster order.
+      const int chunk_rows = max((list_cap - 64) / 64, 1) * ri;
+      for (int r0 = 0; r0 < ih; r0 += chunk_rows) {
+        const int n = walk(th, r0, min(r0 + chunk_rows, ih));
+        wave_sync();
+        score_list(n);
+        wave_sync();
+      }
+      running = 0;
+      for (int r0 = 0; r0 < ih; r0 += chunk_rows) {
+        const int n = walk(th, r0, min(r0 + chunk_rows, ih));
+        wave_sync();
+        running = nms_list(n, th, running);
+        wave_sync();
+      }
+    }
+    if (running > 0) break;  // :820 `if(vKeysCell.empty())` retry with minThFAST
+    wave_sync();
+  }
+  if (lane == 0) *out_count = min(running, cap_cell);
+}
+
 // TP: tile row pitch in bytes (48: three 16-byte chunks, the LDS-DMA path; 72: the largest legal cell, staged
 // through registers).  BYTEWISE: the caller's level-0 rows are not 4-byte aligned (copied byte by byte).
 template <int TP, bool BYTEWISE>
-#ifdef VO_FAST_CPW
-__attribute__((amdgpu_waves_per_eu(8, 8)))
-#endif
-__global__ __launch_bounds__(256) void k_fast_cell(OrbDev P, FrameSrc src, uint32_t *cell_slots,
+__attribute__((amdgpu_waves_per_eu(8, 8))) __global__ __launch_bounds__(256) void k_fast_cell(OrbDev P, FrameSrc src, uint32_t *cell_slots,
                                                    long long slots_frame_stride, int *cell_count,
                                                    int cells_per_frame, int tile_rows, int list_cap,
-                                                   const int *__restrict__ cell_tab) {
+                                                   const int *__restrict__ cell_tab, int cell_begin, int cell_end) {
   extern __shared__ __attribute__((aligned(16))) uint8_t fast_lds[];
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
   const int f = blockIdx.y;
-#ifdef VO_FAST_CPW  // developer A/B (round 5): a wave takes VO_FAST_CPW consecutive cells in a plain loop, no prefetch
-  for (int cpw = 0; cpw < VO_FAST_CPW; cpw++) {
-  const int cell = (blockIdx.x * 4 + wave) * VO_FAST_CPW + cpw;
-  if (cell >= cells_per_frame) return;
+  // A wave takes kFastCpw consecutive cells in a plain loop (round 5, profiles/r05_ab_fused.txt: 0.72 -> 0.70 / 0.685 / 0.71 ms
+  // per 1024 frames at 2 / 4 / 8 cells per wave -- the dispatch of 835 k one-cell waves was worth 5 %, not the 38 % an
+  // early-exit build of the one-cell kernel suggested).
+  for (int cpw = 0; cpw < kFastCpw; cpw++) {
+  const int cell = cell_begin + (blockIdx.x * 4 + wave) * kFastCpw + cpw;  // (a level's cells, or all of them)
+  if (cell >= cell_end) return;  // wave-uniform; the kernel has no workgroup barrier
   if (cpw) wave_sync();
-#else
-  const int cell = blockIdx.x * 4 + wave;
-  if (cell >= cells_per_frame) return;  // wave-uniform; the kernel has no workgroup barrier
-#endif
   const int tile_bytes = fast_align16(TP * tile_rows);  // uniform
   lds_u8 *tile_raw = (lds_u8 *)fast_lds + wave * fast_cell_lds(TP, tile_rows, list_cap);
   lds_u16 *plist = (lds_u16 *)(tile_raw + 2 * tile_bytes);
@@ -421,11 +589,7 @@ __global__ __launch_bounds__(256) void k_fast_cell(OrbDev P, FrameSrc src, uint3
   const int iw = cw - 6, ih = ch - 6;
   if (iw <= 0 || ih <= 0) {  // :801, :811 (cw = 0 in the table), or no interior pixel
     if (lane == 0) *out_count = 0;
-#ifdef VO_FAST_CPW
     continue;
-#else
-    return;
-#endif
   }
   int pitch;
   const uint8_t *img;
@@ -501,172 +665,9 @@ __global__ __launch_bounds__(256) void k_fast_cell(OrbDev P, FrameSrc src, uint3
     *(__attribute__((address_space(3))) u32x4_t *)(tile_raw + tile_bytes + 16 * i) = u32x4_t{0u, 0u, 0u, 0u};
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   wave_sync();
-  // ---- margin walk.  A 9-arc always contains two neighbouring compass pixels (ring 0, 4, 8, 12), so the arc
-  // score S is bounded by the compass margin m = max(mb - v, v - md), mb = min(max(p0,p8), max(p4,p12)),
-  // md = max(min(p0,p8), min(p4,p12)): a pixel can only be a corner at threshold t if m > t.  Pixels with m > th
-  // are compacted IN RASTER ORDER into the wave's LDS list as the LDS address of their (-3, -3) neighbour.
-  // Lane mapping: 32 columns x 2 rows per step (64 x 1 for cells wider than 32).
-  const int lw = iw <= 32 ? 5 : 6;  // uniform
-  const int lx = lane & ((1 << lw) - 1), ly = lane >> lw, ri = 64 >> lw;
-  lds_u8 *const b0 = tile + ly * TP + lx;
-  struct Ring5 { unsigned v, p0, p4, p8, p12; };
-  auto load5 = [&](const lds_u8 *b) { return Ring5{b[3 * TP + 3], b[6 * TP + 3], b[3 * TP + 6], b[3], b[3 * TP]}; };
-  // lanes with m > th as a wave mask: nine 16-bit VOP2 instructions and the compare, in one block (no register
-  // moves, no hazard padding between the dependent instructions: none of them writes a partial register)
-  auto margin_gt = [&](const Ring5 &r, unsigned thv) {
-    unsigned long long mask;
-    unsigned t0, t1, t2, t3;
-    asm("v_max_u16 %1, %6, %8\n\t"
-        "v_max_u16 %2, %7, %9\n\t"
-        "v_min_u16 %3, %6, %8\n\t"
-        "v_min_u16 %4, %7, %9\n\t"
-        "v_min_u16 %1, %1, %2\n\t"
-        "v_max_u16 %3, %3, %4\n\t"
-        "v_sub_u16 %1, %1, %5\n\t"
-        "v_sub_u16 %3, %5, %3\n\t"
-        "v_max_i16 %1, %1, %3\n\t"
-        "v_cmp_gt_i16 %0, %1, %10"
-        : "=s"(mask), "=&v"(t0), "=&v"(t1), "=&v"(t2), "=&v"(t3)
-        : "v"(r.v), "v"(r.p0), "v"(r.p4), "v"(r.p8), "v"(r.p12), "v"(thv));
-    return mask;
-  };
-  // rows [r0, r1) of the interior; returns the number of survivors (uniform); entries past the list's capacity
-  // pile up on its last 64 slots and the count tells the caller to take the chunked path
-  auto walk = [&](int th, int r0, int r1) {
-    int n = 0;
-    const unsigned thv = (unsigned)th;
-    if (lx < iw) {
-      lds_u8 *b = b0 + r0 * TP;
-      asm("" : "+v"(b));
-      int row = r0;
-      auto append = [&](unsigned long long mask, lds_u8 *bb) {
-        const int base = min(n, list_cap - 64);  // scalar
-        const int pos = (int)__builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mask, (unsigned)base));
-        if (__builtin_amdgcn_inverse_ballot_w64(mask)) plist[pos] = (unsigned short)(unsigned)(uintptr_t)bb;
-        n += __popcll(mask);
-      };
-      for (; row + 2 * ri <= r1; row += 2 * ri, b += 2 * ri * TP) {
-        lds_u8 *b1 = b + ri * TP;
-        const Ring5 va = load5(b), vb = load5(b1);
-        const unsigned long long ma = margin_gt(va, thv), mb = margin_gt(vb, thv);
-        append(ma, b);
-        append(mb, b1);
-      }
-      if (row + ri <= r1) {
-        append(margin_gt(load5(b), thv), b);
-        row += ri, b += ri * TP;
-      }
-      if (row < r1) {  // odd last row of a two-row step: the lanes of the first row only
-        const unsigned long long m = margin_gt(load5(b), thv);
-        append(ly == 0 ? m & 0xffffffffull : 0ull, b);
-      }
-    }
-    return __builtin_amdgcn_readlane(n, 0);  // lane 0 always takes part
-  };
-  uint32_t *slot = cell_slots + (long long)f * slots_frame_stride + slot_off;
-  // Second-level bound for long lists (a cell redone at minThFAST lists ~1/5 of its pixels, noise for the most part):
-  // the compass argument holds for ANY four ring pixels a quarter turn apart, so S is also bounded by the margin of the
-  // rings (K, K + 4, K + 8, K + 12), K = 1, 2, 3.  Entries whose bound does not exceed th cannot be corners at th and, as
-  // neighbours, score below every kept pixel (S - 1 < th): dropping them -- score entry left at 0 -- changes nothing.
-  // The list is compacted in place, order preserved (a lane writes at or before its own position, after every lane of
-  // the batch has read; LDS operations of one wavefront execute in order).  ~14 fast-class instructions per 64 entries
-  // against ~105 for their arc scores; the second bound halves a minThFAST list, the third takes another third.
-  auto refine_list = [&](int n, int th, auto load_ring) {
-    int kept = 0;
-    const unsigned thv = (unsigned)th;
-    for (int base = 0; base < n; base += 64) {
-      // lanes past the list repeat its last entry (no divergence around the asm block); their mask bits are cleared
-      const unsigned short e = plist[min(base + lane, n - 1)];
-      const int rem = n - base;  // uniform
-      const unsigned long long valid = rem >= 64 ? ~0ull : ((1ull << rem) - 1ull);
-      const unsigned long long mask = margin_gt(load_ring((const lds_u8 *)(uintptr_t)(unsigned)e), thv) & valid;
-      const int pos = (int)__builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mask, (unsigned)kept));
-      if (__builtin_amdgcn_inverse_ballot_w64(mask)) plist[pos] = e;
-      kept += __popcll(mask);
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // LDS operations of one wavefront execute in order: the next batch
-      __builtin_amdgcn_wave_barrier();                    // reads behind these writes (no memory fence needed)
-    }
-    return kept;
-  };
-  auto ring_k2 = [&](const lds_u8 *b) { return Ring5{b[3 * TP + 3], b[5 * TP + 5], b[TP + 5], b[TP + 1], b[5 * TP + 1]}; };
-  auto ring_k1 = [&](const lds_u8 *b) { return Ring5{b[3 * TP + 3], b[6 * TP + 4], b[2 * TP + 6], b[2], b[4 * TP]}; };
-  auto ring_k3 = [&](const lds_u8 *b) { return Ring5{b[3 * TP + 3], b[4 * TP + 6], b[4], b[2 * TP], b[6 * TP + 2]}; };
-  auto score_list = [&](int n) {
-    for (int i = lane; i < n; i += 64) {
-      lds_u8 *b = (lds_u8 *)(uintptr_t)(unsigned)plist[i];
-      b[tile_bytes + 3 * TP + 3] = (uint8_t)fast_arc_score<TP>(b, P.min_th);  // cornerScore, defined from minThFAST up
-    }
-  };
-  // 3x3 non-maximum suppression at threshold th over the raster-ordered list; kept pixels go out in the same
-  // order behind the `kept` already written.  Entries that are not survivors are 0, as OpenCV reads them.
-  auto nms_list = [&](int n, int th, int kept) {
-    for (int base = 0; base < n; base += 64) {
-      const int i = base + lane;
-      bool keep = false;
-      int pos = 0, sc0 = 0;
-      if (i < n) {
-        const lds_u8 *b = (const lds_u8 *)(uintptr_t)(unsigned)plist[i];
-        pos = (int)(b - tile);
-        const lds_u8 *c = b + tile_bytes + 2 * TP + 2;  // score entry (-1, -1) from the pixel
-        sc0 = c[TP + 1];
-        const unsigned nb = max_u16(max_u16(max_u16(c[0], c[1]), max_u16(c[2], c[TP])),
-                                    max_u16(max_u16(c[TP + 2], c[2 * TP]), max_u16(c[2 * TP + 1], c[2 * TP + 2])));
-        keep = sc0 >= th && sc0 > (int)nb;
-      }
-      const unsigned long long mask = __builtin_amdgcn_ballot_w64(keep);
-      const int off = kept + __builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0u));
-      if (keep && off < cap_cell) {
-        const int y = pos / TP, x = pos - y * TP;  // interior coordinates; the cell-local ones are +3
-        slot[off] = (uint32_t)(x + 3 + xoff) | ((uint32_t)(y + 3 + yoff) << 12) | ((uint32_t)sc0 << 24);
-      }
-      kept += __popcll(mask);
-    }
-    return kept;
-  };
-  int running = 0;
-  for (int round = 0; round < 2; round++) {
-    // a cell with no key-point at iniThFAST is redone at minThFAST (:820-824)
-    const int th = round == 0 ? P.ini_th : P.min_th;
-    const int np0 = walk(th, 0, ih);
-    wave_sync();
-    int np = np0;
-    if (np <= list_cap - 64) {  // uniform, the usual case (the walk's appends clamp their base 64 entries before the end)
-      // (only in the minThFAST round: at iniThFAST the further bounds reject ~15 % of a list -- three passes for nothing,
-      //  measured +3 % on the kernel -- while they take a minThFAST list from ~170 entries to ~55)
-      if (round == 1) {
-        if (np > 64) np = refine_list(np, th, ring_k2);
-        if (np > 64) np = refine_list(np, th, ring_k1);
-        if (np > 64) np = refine_list(np, th, ring_k3);
-      }
-      score_list(np);
-      wave_sync();
-      running = nms_list(np, th, 0);
-    } else {
-      // Rare: more survivors than the list holds (noise-like texture).  Chunks of as many rows as fit the list
-      // even if every pixel hits are scored one after the other, then -- all scores final -- suppressed one after
-      // the other; chunks follow each other in raster order.
-      const int chunk_rows = max((list_cap - 64) / 64, 1) * ri;
-      for (int r0 = 0; r0 < ih; r0 += chunk_rows) {
-        const int n = walk(th, r0, min(r0 + chunk_rows, ih));
-        wave_sync();
-        score_list(n);
-        wave_sync();
-      }
-      running = 0;
-      for (int r0 = 0; r0 < ih; r0 += chunk_rows) {
-        const int n = walk(th, r0, min(r0 + chunk_rows, ih));
-        wave_sync();
-        running = nms_list(n, th, running);
-        wave_sync();
-      }
-    }
-    if (running > 0) break;  // :820 `if(vKeysCell.empty())` retry with minThFAST
-    wave_sync();
+  fast_cell_body<TP>(tile, tile_bytes, plist, list_cap, iw, ih, P.ini_th, P.min_th,
+                     cell_slots + (long long)f * slots_frame_stride + slot_off, cap_cell, xoff, yoff, out_count, lane);
   }
-  if (lane == 0) *out_count = min(running, cap_cell);
-#ifdef VO_FAST_CPW
-  }
-#endif
 }
 
 // ------------------------------------------------------------------------------------------
@@ -1292,6 +1293,8 @@ __global__ __launch_bounds__(256) void k_blur_groups(FrameSrc src, int lv0_gener
   }
 }
 
+#include "orb_level_pass.inc"
+
 // ------------------------------------------------------------------------------------------
 // K3 + K5  IC_Angle (:79-107) + computeOrbDescriptor (:110-151) + the coordinate bookkeeping of
 // :845-855 and :1102-1108.  One wavefront per key-point: the 749-pixel disc is reduced with
@@ -1688,6 +1691,15 @@ struct vo_orb {
   bool rz_tiled[kMaxLevels] = {false};                             // the level's tiles fit k_resize4's LDS layout
   int rz_gtab_off[kMaxLevels] = {0}, rz_btab_off[kMaxLevels] = {0};  // its column tables (ints into `tables`)
   int blur_jobs = 0;               // k_blur_groups jobs per frame quad
+  int blur_job0[kMaxLevels + 1] = {0};  // first job of every level (per-level launches next to fused levels)
+  // k_level_pass (orb_level_pass.inc): per level whether it takes the fused pass, its tile pitch / rows, block table, LDS bytes
+  bool fused = false;              // vo_orb_set_option(VO_ORB_OPT_FUSED_LEVEL_PASS): opt-in, measured 6 % slower than the three kernels (profiles/r05_ab_fused.txt)
+  bool lp_ok[kMaxLevels] = {false};
+  int lp_tp[kMaxLevels] = {0}, lp_tile_rows[kMaxLevels] = {0}, lp_score_rows[kMaxLevels] = {0}, lp_blocks[kMaxLevels] = {0};
+  int lp_tab_off[kMaxLevels] = {0}, lp_list_cap[kMaxLevels] = {0};
+  size_t lp_lds[kMaxLevels] = {0};
+  int lp_redge_x[kMaxLevels] = {0}, lp_redge_j0[kMaxLevels] = {0};
+  unsigned lp_selA[kMaxLevels] = {0}, lp_selB[kMaxLevels] = {0}, lp_selP[kMaxLevels] = {0};
   unsigned blur_generic_mask = 0;  // levels blurred by the generic kernel
   std::vector<int> tab_off;  // per level: offsets of xofs,xab,yofs,yab in tables
   vo::DevBuf tables, pyr, blur, slots, cellcnt, keydata, keylabel, candcnt, sel, nk, err;
@@ -1740,6 +1752,161 @@ void orb_resize_tables(int sw, int sh, int dw, int dh, std::vector<int> &xofs, s
 
 int align_up(int v, int a) { return (v + a - 1) / a * a; }
 
+// ---- k_level_pass geometry of level l (orb_level_pass.inc): block table appended to `tables`; false: the level keeps the
+// separate kernels.  xo / yo: source column / row of every column / row of level l + 1 (empty for the last level).
+bool plan_level_pass(vo_orb *h, int l, const std::vector<int> &xo, const std::vector<int> &yo, std::vector<int> &tables) {
+  const LevelGeom &L = h->dev.lv[l];
+  h->lp_ok[l] = false;
+  if (L.nCols < 1 || L.nRows < 1 || L.w < 48 || L.h < 24 || (L.pitch & 15)) return false;
+  const int w = L.w, hh = L.h, wal = align_up(w, 16), hal = align_up(hh, 8);
+  const bool has_next = !xo.empty();
+  const int dw = has_next ? (int)xo.size() : 0, dh = has_next ? (int)yo.size() : 0;
+  struct Span { int b0, b1, t0, c0, nc, f0, f1; };  // owned [b0, b1), tile origin, first cell column / row, cells, FAST range
+  for (int TP : {96, 112, 128}) {
+    // ---- columns
+    std::vector<Span> cols;
+    bool ok = true;
+    const int nBX = (L.nCols + 1) / 2;
+    auto fx0 = [&](int k) { return kBorder + 2 * k * L.wCell; };
+    auto fx1 = [&](int k) { return std::min(kBorder + (2 * k + std::min(2, L.nCols - 2 * k)) * L.wCell + 6, L.maxBX); };
+    int B = 0;
+    for (int k = 0; k < nBX && ok; k++) {
+      const int t0 = std::max(0, B - 16);
+      if (fx0(k) < t0 || fx1(k) + 2 > t0 + TP) { ok = false; break; }  // (+2: the score entries of the block's second cell column sit one byte further)
+      int hi = std::min(t0 + TP - 12, B + 96), nb;
+      if (k + 1 < nBX) {
+        hi = std::min(hi, fx0(k + 1) + 16);
+        hi = std::min(hi, w - 8);
+        nb = hi & ~15;
+        if (nb < std::max(fx1(k + 1) + 2 - TP + 16, B + 16)) { ok = false; break; }
+      } else {
+        nb = wal <= hi ? wal : (std::min(hi, w - 8) & ~15);
+        if (nb < B + 16) { ok = false; break; }
+      }
+      cols.push_back({B, nb, t0, 2 * k, std::min(2, L.nCols - 2 * k), fx0(k), fx1(k)});
+      B = nb;
+    }
+    while (ok && B < wal) {  // what is left of the plane behind the last cell column
+      const int t0 = std::max(0, B - 16), hi = std::min(t0 + TP - 12, B + 96);
+      const int nb = wal <= hi ? wal : (std::min(hi, w - 8) & ~15);
+      if (nb < B + 16) { ok = false; break; }
+      cols.push_back({B, nb, t0, 0, 0, 0, 0});
+      B = nb;
+    }
+    if (!ok) continue;
+    // ---- rows
+    std::vector<Span> rows;
+    const int nBY = (L.nRows + 1) / 2;
+    auto fy0 = [&](int i) { return kBorder + 2 * i * L.hCell; };
+    auto fy1 = [&](int i) { return std::min(kBorder + (2 * i + std::min(2, L.nRows - 2 * i)) * L.hCell + 6, L.maxBY); };
+    const int rows_cap = 2 * L.hCell + 16;
+    B = 0;
+    for (int i = 0; i < nBY; i++) {
+      const int t0 = std::min(fy0(i), std::max(0, B - 4));
+      int nb;
+      if (i + 1 < nBY) nb = std::min((fy0(i + 1) + 4) & ~7, hal);
+      else nb = std::min(hal, (t0 + rows_cap - 4) & ~7);
+      if (nb < B + 8) { ok = false; break; }
+      rows.push_back({B, nb, t0, 2 * i, std::min(2, L.nRows - 2 * i), fy0(i), fy1(i)});
+      B = nb;
+    }
+    while (ok && B < hal) {
+      const int t0 = std::max(0, B - 4);
+      const int nb = std::min(hal, (t0 + rows_cap - 4) & ~7);
+      if (nb < B + 8) { ok = false; break; }
+      rows.push_back({B, nb, t0, 0, 0, 0, 0});
+      B = nb;
+    }
+    if (!ok) continue;
+    // ---- blocks
+    int TR = 0, SR = 4, max_segs = 1;
+    std::vector<int> tab;
+    for (const Span &r : rows)
+      for (const Span &c : cols) {
+        int e[LP_INTS] = {0};
+        const bool cells = r.nc > 0 && c.nc > 0;
+        int t0y = r.t0;
+        const bool bottom = r.b1 + 4 > hh;
+        if (bottom) t0y = std::max(0, std::min(t0y, 2 * hh - 2 - (r.b1 + 3)));  // the rows the mirrored apron reads
+        if (!cells) t0y = std::max(0, std::min(t0y, r.b0 - 4));
+        const int yend = std::min(hh, std::max(cells ? r.f1 : 0, r.b1 + 4));
+        e[LP_TX0] = c.t0, e[LP_TY0] = t0y, e[LP_TH] = yend - t0y;
+        e[LP_BX0] = c.b0, e[LP_BX1] = c.b1, e[LP_BY0] = r.b0, e[LP_BY1] = r.b1;
+        TR = std::max(TR, e[LP_TH]);
+        int nc = 0;
+        for (int q = 0; q < 4; q++) e[LP_CELL0 + q] = -1;
+        if (cells)
+          for (int ci = 0; ci < r.nc; ci++)
+            for (int cj = 0; cj < c.nc; cj++) {
+              e[LP_CELL0 + nc] = L.cellBase + (r.c0 + ci) * L.nCols + (c.c0 + cj);
+              e[LP_CPOS0 + nc] = cj | (ci << 8);
+              nc++;
+            }
+        e[LP_NCELLS] = nc;
+        e[LP_FY0] = r.f0;
+        if (cells) SR = std::max(SR, r.f1 - r.f0 + 4);
+        if (has_next) {
+          auto first_ge = [](const std::vector<int> &v, int step, int n, int bound) {  // first index i (of n, stride `step` in v) with v >= bound
+            int i = 0;
+            while (i < n && std::max(v[std::min((size_t)i * step, v.size() - 1)], 0) < bound) i++;
+            return i;
+          };
+          const int ngr = (dw + 3) / 4;
+          e[LP_G0] = first_ge(xo, 4, ngr, c.b0), e[LP_G1] = c.b1 >= wal ? ngr : first_ge(xo, 4, ngr, c.b1);
+          e[LP_D0] = first_ge(yo, 1, dh, r.b0), e[LP_D1] = r.b1 >= hal ? dh : first_ge(yo, 1, dh, r.b1);
+          if (e[LP_G1] - e[LP_G0] > 32) ok = false;
+          // (every source row / column these read lies in the tile: sy + 1 <= by1 <= tile end, base + 11 <= bx1 + 10 < tx0 + TP)
+          if (e[LP_D1] > e[LP_D0] && std::min(std::max(yo[e[LP_D1] - 1] + 1, 0), hh - 1) >= t0y + e[LP_TH]) ok = false;
+        }
+        e[LP_EDGE] = (c.b0 == 0 ? LP_EDGE_L : 0) | (c.b1 > ((w - 1) & ~7) ? LP_EDGE_R : 0) | (r.b0 == 0 ? LP_EDGE_T : 0) |
+                     (bottom ? LP_EDGE_B : 0);
+        const int segs = (c.b1 - c.b0) / 8;
+        e[LP_SEGS] = segs, e[LP_R] = std::min(12, 64 / segs), e[LP_INV] = (65536 + segs - 1) / segs;
+        for (int ln = 0; ln < 64; ln++)
+          if ((int)(((unsigned)ln * (unsigned)e[LP_INV]) >> 16) != ln / segs) ok = false;
+        max_segs = std::max(max_segs, segs);
+        if (c.b1 - c.t0 + 12 > TP && !(c.b1 >= wal && wal - c.t0 + 4 <= TP && w + 11 <= c.t0 + TP)) ok = false;
+        tab.insert(tab.end(), e, e + LP_INTS);
+      }
+    if (!ok) continue;
+    const int list_cap = std::max(128, (L.wCell * L.hCell + 1) / 2);
+    const size_t tile_bytes = (size_t)TP * TR, score = (size_t)fast_align16(TP * SR), lists = 4 * (size_t)fast_align16(2 * list_cap),
+                 rings = 2 * (size_t)kLpRing * lp_ring_stride(kLpColSplit ? (max_segs + 1) / 2 : max_segs);
+    const size_t lds = tile_bytes + std::max(score + lists, rings);
+    if (lds > 64 * 1024 || (tile_bytes & 15)) continue;
+    while (tables.size() % 4) tables.push_back(0);
+    h->lp_tab_off[l] = (int)tables.size();
+    tables.insert(tables.end(), tab.begin(), tab.end());
+    h->lp_ok[l] = true, h->lp_tp[l] = TP, h->lp_tile_rows[l] = TR, h->lp_score_rows[l] = SR, h->lp_blocks[l] = (int)(rows.size() * cols.size());
+    h->lp_list_cap[l] = list_cap, h->lp_lds[l] = lds;
+    // right plane edge: window byte offset of column w - 1 in its segment, the dwords to rebuild and their byte selectors
+    const int cW = ((w - 1) & 7) + 4, j0 = (cW + 1) >> 2;
+    unsigned sel[2] = {0, 0};
+    for (int j = j0; j <= j0 + 1; j++)
+      for (int t = 0; t < 4; t++) {
+        const int kk = 4 * j + t;
+        int o = kk <= cW ? kk : 2 * cW - kk;
+        o = std::min(std::max(o, 4 * (j0 - 1)), 4 * j0 + 3);
+        sel[j - j0] |= (unsigned)(o - 4 * (j0 - 1)) << (8 * t);
+      }
+    h->lp_redge_x[l] = (w - 1) & ~7, h->lp_redge_j0[l] = j0, h->lp_selA[l] = sel[0], h->lp_selB[l] = sel[1];
+    // the segment in front: column w - 1 sits at its window offset c = 12 + (w - 1) % 8; only offsets 13..15 can lie behind it
+    h->lp_selP[l] = 0;
+    if (((w - 1) & 7) < 3) {
+      const int c = 12 + ((w - 1) & 7);
+      unsigned sp = 0;
+      for (int t = 0; t < 4; t++) {
+        const int kk = 12 + t;
+        const int o = std::min(std::max(kk <= c ? kk : 2 * c - kk, 8), 15);
+        sp |= (unsigned)(o - 8) << (8 * t);
+      }
+      h->lp_selP[l] = sp;  // (never 0: byte 0 selects offset 12 = value 4)
+    }
+    return true;
+  }
+  return false;
+}
+
 int configure(vo_orb *h, int w, int h_img, int n_frames) {
   if (w != h->cfg_w || h_img != h->cfg_h) {
     // kernels of the previous call may still be reading the tables on the (non-blocking) handle stream
@@ -1753,6 +1920,7 @@ int configure(vo_orb *h, int w, int h_img, int n_frames) {
     long long pyr = 0, blur = 0, slots = 0;
     int cells = 0, keys = 0, sel = 0, tiles = 0, maxkp = 0;
     std::vector<int> tables;
+    std::vector<std::vector<int>> lv_xo(h->nlevels + 1), lv_yo(h->nlevels + 1);  // source column / row of level l's columns / rows
     h->tab_off.assign(h->nlevels * 4, 0);
     int pw = w, ph = h_img;
     for (int l = 0; l < h->nlevels; l++) {
@@ -1820,6 +1988,7 @@ int configure(vo_orb *h, int w, int h_img, int n_frames) {
       if (l > 0) {
         std::vector<int> xo, xa, yo, ya;
         orb_resize_tables(pw, ph, L.w, L.h, xo, xa, yo, ya);
+        lv_xo[l] = xo, lv_yo[l] = yo;
         h->tab_off[l * 4 + 0] = (int)tables.size();
         tables.insert(tables.end(), xo.begin(), xo.end());
         h->tab_off[l * 4 + 1] = (int)tables.size();
@@ -1879,6 +2048,7 @@ int configure(vo_orb *h, int w, int h_img, int n_frames) {
       h->blur_generic_mask = 0;
       for (int l = 0; l < h->nlevels; l++) {
         const LevelGeom &L = D.lv[l];
+        h->blur_job0[l] = h->blur_job0[l + 1] = h->blur_jobs;
         if (L.w < kBlurMinW || L.h < kBlurMinH) {
           h->blur_generic_mask |= 1u << l;
           continue;
@@ -1892,6 +2062,7 @@ int configure(vo_orb *h, int w, int h_img, int n_frames) {
             tables.insert(tables.end(), e, e + 16);
             h->blur_jobs++;
           }
+        h->blur_job0[l + 1] = h->blur_jobs;
       }
       h->cell_tab_off = (int)tables.size();
       for (int l = 0; l < h->nlevels; l++) {
@@ -1911,6 +2082,17 @@ int configure(vo_orb *h, int w, int h_img, int n_frames) {
                              0, 0, 0, 0};
           tables.insert(tables.end(), e, e + 16);
         }
+      }
+    }
+    for (int l = 0; l < h->nlevels; l++) {
+      // the next level is produced by the fused pass only if k_resize4's column-group table exists for it
+      const bool next = l + 1 < h->nlevels;
+      const bool next_ok = !next || (h->rz_tiled[l + 1] && (double)D.lv[l].w / D.lv[l + 1].w < 1.99 && D.lv[l + 1].pitch >= ((D.lv[l + 1].w + 3) & ~3));
+      static const std::vector<int> none;
+      if (!next_ok || !plan_level_pass(h, l, next ? lv_xo[l + 1] : none, next ? lv_yo[l + 1] : none, tables)) h->lp_ok[l] = false;
+      if (h->lp_ok[l] && h->lp_lds[l] > 48 * 1024) {
+        const void *fn = h->lp_tp[l] == 96 ? (const void *)k_level_pass<96> : h->lp_tp[l] == 112 ? (const void *)k_level_pass<112> : (const void *)k_level_pass<128>;
+        VO_HIP_CHECK(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->lp_lds[l]));
       }
     }
     {
@@ -1998,13 +2180,13 @@ int run_pipeline(vo_orb *h, const uint8_t *dev_images, int n_frames, int w, int 
 #define VO_STAGE_MARK(i) \
   if (ev) VO_HIP_CHECK(hipEventRecord(ev[i], st))
   VO_STAGE_MARK(0);
-  // pyramid: level l from level l-1 (sequential by construction, :1129)
-  for (int l = 1; l < D.nlevels; l++) {
+  const int *T = h->tables.as<int>();
+  // level l from level l - 1 (sequential by construction, :1129)
+  auto launch_resize = [&](int l) {
     const LevelGeom &L = D.lv[l], &Pv = D.lv[l - 1];
     const uint8_t *sp = l == 1 ? dev_images : S.pyr + Pv.pyr_off;
     const long long sfs = l == 1 ? (long long)frame_stride : h->pyr_frame;
     const int spitch = l == 1 ? stride : Pv.pitch;
-    const int *T = h->tables.as<int>();
     // 4 outputs span <= 3*scale + 2 source columns; with the aligned start that fits 12 bytes for
     // scale factors below 2 and needs 4-byte aligned source rows with readable padding to the pitch
     const bool aligned = ((reinterpret_cast<uintptr_t>(sp) | (uintptr_t)spitch | (uintptr_t)sfs) & 3) == 0 &&
@@ -2020,37 +2202,75 @@ int run_pipeline(vo_orb *h, const uint8_t *dev_images, int n_frames, int w, int 
                          (long long)h->pyr_frame, L.pitch, L.w, L.h, T + h->tab_off[l * 4 + 0],
                          T + h->tab_off[l * 4 + 1], T + h->tab_off[l * 4 + 2], T + h->tab_off[l * 4 + 3]);
     }
-  }
-  VO_STAGE_MARK(1);
-  // The blur reads the pyramid only; FAST -> oct-tree -> offsets do not touch the blurred planes.  Outside
-  // the instrumented mode the blur therefore runs on a side stream next to them (the oct-tree kernel is
-  // latency-bound and leaves most of the machine idle) and joins before the descriptors.
-  const bool overlap = !ev && h->side != nullptr;
-  auto launch_blur = [&](hipStream_t bs) {
-    const int lv0_generic = lv0_unaligned;
-    if (h->blur_jobs > 0)
-      hipLaunchKernelGGL(k_blur_groups, dim3((h->blur_jobs + 3) / 4, (n_frames + kBlurF - 1) / kBlurF), dim3(256), 0, bs, S,
-                         lv0_generic, h->tables.as<int>() + h->strip_tab_off, h->blur_jobs, n_frames);
-    const unsigned gmask = h->blur_generic_mask | (lv0_generic ? 1u : 0u);
-    if (gmask) hipLaunchKernelGGL(k_blur, dim3(h->tiles_frame, n_frames), dim3(256), 0, bs, D, S, gmask);
   };
-  if (overlap) {
-    VO_HIP_CHECK(hipEventRecord(h->ev_fork, st));
-    VO_HIP_CHECK(hipStreamWaitEvent(h->side, h->ev_fork, 0));
-    launch_blur(h->side);
-    VO_HIP_CHECK(hipEventRecord(h->ev_join, h->side));
-  }
-  if (h->cells_frame > 0) {
-#ifdef VO_FAST_CPW
-    const dim3 grid((h->cells_frame + 4 * VO_FAST_CPW - 1) / (4 * VO_FAST_CPW), n_frames);
-#else
-    const dim3 grid((h->cells_frame + 3) / 4, n_frames);
-#endif
+  auto launch_fast = [&](int cell_begin, int cell_end) {
+    if (cell_end <= cell_begin) return;
+    const dim3 grid((cell_end - cell_begin + 4 * kFastCpw - 1) / (4 * kFastCpw), n_frames);
     auto fast = h->fast_tp == 48 ? (lv0_unaligned ? k_fast_cell<48, true> : k_fast_cell<48, false>)
                                  : (lv0_unaligned ? k_fast_cell<kTileP, true> : k_fast_cell<kTileP, false>);
     hipLaunchKernelGGL(fast, grid, dim3(256), h->fast_lds, st, D, S, h->slots.as<uint32_t>(), h->slots_frame,
-                       h->cellcnt.as<int>(), h->cells_frame, h->fast_rows, h->fast_interior,
-                       h->tables.as<int>() + h->cell_tab_off);
+                       h->cellcnt.as<int>(), h->cells_frame, h->fast_rows, h->fast_interior, T + h->cell_tab_off, cell_begin, cell_end);
+  };
+  // (the strip kernel reads aligned dwords; a caller image that is not 4-byte aligned falls back to the generic LDS
+  // kernel for level 0 only)
+  auto launch_blur = [&](hipStream_t bs, int job_begin, int job_end, unsigned level_mask) {
+    const int lv0_generic = lv0_unaligned;
+    if (job_end > job_begin)
+      hipLaunchKernelGGL(k_blur_groups, dim3((job_end - job_begin + 3) / 4, (n_frames + kBlurF - 1) / kBlurF), dim3(256), 0, bs, S,
+                         lv0_generic, T + h->strip_tab_off + 16 * job_begin, job_end - job_begin, n_frames);
+    const unsigned gmask = (h->blur_generic_mask | (lv0_generic ? 1u : 0u)) & level_mask;
+    if (gmask) hipLaunchKernelGGL(k_blur, dim3(h->tiles_frame, n_frames), dim3(256), 0, bs, D, S, gmask);
+  };
+  // One fused pass per level (orb_level_pass.inc) where the level's geometry takes it: its FAST cells, its blurred tiles and the
+  // next level's rows from ONE staged tile.  Level 0 needs 16-byte aligned caller rows for the LDS-DMA chunks.
+  bool any_fused = false;
+  if (h->fused)
+    for (int l = 0; l < D.nlevels; l++) any_fused = any_fused || (h->lp_ok[l] && !(l == 0 && lv0_not16));
+  const bool overlap = !ev && h->side != nullptr && !any_fused;
+  if (any_fused) {
+    for (int l = 0; l < D.nlevels; l++) {
+      const LevelGeom &L = D.lv[l];
+      if (h->lp_ok[l] && !(l == 0 && lv0_not16)) {
+        LevelPassArgs A{};
+        A.src = l == 0 ? dev_images : S.pyr + L.pyr_off;
+        A.s_frame_stride = l == 0 ? (long long)frame_stride : h->pyr_frame;
+        A.s_pitch = l == 0 ? stride : L.pitch, A.sw = L.w, A.sh = L.h;
+        A.blur = S.blur + L.blur_off, A.b_frame_stride = h->blur_frame, A.b_pitch = L.pitch;
+        if (l + 1 < D.nlevels) {
+          const LevelGeom &N = D.lv[l + 1];
+          A.dst = S.pyr + N.pyr_off, A.d_frame_stride = h->pyr_frame, A.d_pitch = N.pitch, A.dw = N.w, A.dh = N.h;
+          A.gtab = T + h->rz_gtab_off[l + 1], A.yofs = T + h->tab_off[(l + 1) * 4 + 2], A.yab = T + h->tab_off[(l + 1) * 4 + 3];
+        }
+        A.blk_tab = T + h->lp_tab_off[l], A.cell_tab = T + h->cell_tab_off;
+        A.cell_slots = h->slots.as<uint32_t>(), A.slots_frame_stride = h->slots_frame, A.cell_count = h->cellcnt.as<int>();
+        A.cells_per_frame = h->cells_frame;
+        A.tile_rows = h->lp_tile_rows[l], A.score_rows = h->lp_score_rows[l], A.list_cap = h->lp_list_cap[l];
+        A.ini_th = D.ini_th, A.min_th = D.min_th;
+        A.redge_x = h->lp_redge_x[l], A.redge_j0 = h->lp_redge_j0[l], A.redge_selA = h->lp_selA[l], A.redge_selB = h->lp_selB[l], A.redge_selP = h->lp_selP[l];
+        const dim3 grid(h->lp_blocks[l], n_frames);
+        if (h->lp_tp[l] == 96) hipLaunchKernelGGL(k_level_pass<96>, grid, dim3(256), h->lp_lds[l], st, A);
+        else if (h->lp_tp[l] == 112) hipLaunchKernelGGL(k_level_pass<112>, grid, dim3(256), h->lp_lds[l], st, A);
+        else hipLaunchKernelGGL(k_level_pass<128>, grid, dim3(256), h->lp_lds[l], st, A);
+      } else {  // this level through the separate kernels
+        if (l + 1 < D.nlevels) launch_resize(l + 1);
+        launch_fast(L.cellBase, L.cellBase + L.nCells);
+        launch_blur(st, h->blur_job0[l], h->blur_job0[l + 1], 1u << l);
+      }
+    }
+    VO_STAGE_MARK(1);  // (instrumented mode: stage 0 carries the whole chain of level passes, stages 1 and 4 are empty)
+  } else {
+    for (int l = 1; l < D.nlevels; l++) launch_resize(l);
+    VO_STAGE_MARK(1);
+    // The blur reads the pyramid only; FAST -> oct-tree -> offsets do not touch the blurred planes.  Outside
+    // the instrumented mode the blur therefore runs on a side stream next to them (the oct-tree kernel is
+    // latency-bound and leaves most of the machine idle) and joins before the descriptors.
+    if (overlap) {
+      VO_HIP_CHECK(hipEventRecord(h->ev_fork, st));
+      VO_HIP_CHECK(hipStreamWaitEvent(h->side, h->ev_fork, 0));
+      launch_blur(h->side, 0, h->blur_jobs, ~0u);
+      VO_HIP_CHECK(hipEventRecord(h->ev_join, h->side));
+    }
+    launch_fast(0, h->cells_frame);
   }
   VO_STAGE_MARK(2);
   if (h->oct_small)
@@ -2065,12 +2285,10 @@ int run_pipeline(vo_orb *h, const uint8_t *dev_images, int n_frames, int w, int 
                        h->sel.as<uint32_t>(), h->sel_frame, h->nk.as<int>(), h->err.as<int>());
   VO_STAGE_MARK(3);
   // (stage 3, the per-frame offsets and counts, is computed by k_describe itself: no launch and no event here)
-  // (the strip kernel reads aligned dwords; a caller image that is not 4-byte aligned falls back to the
-  // generic LDS kernel for level 0 only)
   if (overlap)
     VO_HIP_CHECK(hipStreamWaitEvent(st, h->ev_join, 0));
-  else
-    launch_blur(st);
+  else if (!any_fused)
+    launch_blur(st, 0, h->blur_jobs, ~0u);
   VO_STAGE_MARK(5);
   const int kp_blocks = (std::min(capacity, h->max_kp) + 63) / 64;
   if (kp_blocks == 0 && dcounts) VO_HIP_CHECK(hipMemsetAsync(dcounts, 0, (size_t)n_frames * sizeof(int), st));
@@ -2198,6 +2416,24 @@ int vo_orb_set_stream(vo_orb *h, void *s) {
   if (h->own_stream) (void)hipStreamDestroy(h->stream);
   h->own_stream = false;
   h->stream = (hipStream_t)s;
+  return VO_OK;
+}
+
+int vo_orb_set_option(vo_orb *h, int option, int value) {
+  if (!h) return VO_ERR_INVALID;
+  if (option == VO_ORB_OPT_FUSED_LEVEL_PASS) {
+    h->fused = value != 0;
+    return VO_OK;
+  }
+  vo::set_error("vo_orb_set_option: unknown option %d", option);
+  return VO_ERR_INVALID;
+}
+
+int vo_orb_debug_level_pass(vo_orb *h, int width, int height, int level, int out[8]) {
+  if (!h || !out || level < 0 || level >= h->nlevels || width <= 0 || height <= 0) return VO_ERR_INVALID;
+  VO_CHECK(configure(h, width, height, 1));
+  out[0] = h->fused && h->lp_ok[level] ? 1 : 0, out[1] = h->lp_tp[level], out[2] = h->lp_tile_rows[level], out[3] = h->lp_score_rows[level];
+  out[4] = h->lp_blocks[level], out[5] = (int)h->lp_lds[level], out[6] = h->lp_list_cap[level], out[7] = 0;
   return VO_OK;
 }
 
