@@ -127,7 +127,8 @@ int main(int argc, char **argv) {
   }
   const double *cam5 = in["cam"].as<double>();
   Camera camera = make_camera(cam5, 0.08f);
-  camera.distCoef_.create(5, 1, CV_32F);  // zeros: no distortion
+  camera.distCoef_.create(5, 1, CV_32F);
+  for (int i = 0; i < 5; i++) camera.distCoef_.at<float>(i) = in["dist"].as<float>()[i];
 
   // ---- 1: ORBextractor::operator() and Frame::Frame on a gray image + metric depth image
   ORB_SLAM2::ORBextractor orb(1000, 1.2f, 8, 20, 7);

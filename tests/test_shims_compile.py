@@ -30,3 +30,18 @@ def test_header_is_plain_c():
     r = subprocess.run([gcc, "-std=c99", "-pedantic", "-Wall", "-Werror", "-fsyntax-only", f"-I{ROOT / 'include'}", "-x", "c", "-"],
                        input=src, capture_output=True, text=True)
     assert r.returncode == 0, r.stderr[-3000:]
+
+
+def test_shim_run_driver_builds_here():
+    """tests/shim_run/shim_run.cpp (the driver that EXECUTES the shims on the GPU box, tests/test_gpu_shims_run.py) compiles
+    against its functional stand-ins and links with libvo_hip.so in this container too -- no GPU needed for that"""
+    import tempfile
+    from vo_slam_test_amd import build
+    gxx = shutil.which("g++")
+    so = build.build()
+    run = ROOT / "tests" / "shim_run"
+    with tempfile.TemporaryDirectory() as d:
+        r = subprocess.run([gxx, "-std=gnu++14", "-O0", "-Wall", "-Werror", f"-I{run}", f"-I{run / 'thirdparty'}", f"-I{ROOT / 'include'}",
+                            str(run / "shim_run.cpp"), f"-L{so.parent}", "-lvo_hip", f"-Wl,-rpath,{so.parent}", "-L/opt/rocm/lib",
+                            "-Wl,-rpath,/opt/rocm/lib", "-lpthread", "-o", f"{d}/shim_run"], capture_output=True, text=True)
+        assert r.returncode == 0, r.stderr[-3000:]
