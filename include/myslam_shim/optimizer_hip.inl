@@ -108,22 +108,24 @@ void Optimizer::solveLocalBAPoseAndPoint(KeyFrame *keyframe, bool &stopFlag, Map
   }
   Camera *c = keyframe->camera_;
   const double cam[5] = {c->fx_, c->fy_, c->cx_, c->cy_, c->bf_};
-  vo_ba *h = nullptr;
-  if (vo_ba_create(&h, (int)cams.size(), poses.data(), fixed.data(), (int)points.size(), pts.data(),
-                   (int)edges.size(), e_cam.data(), e_pt.data(), e_obs.data(), e_is.data(), cam) != VO_OK)
-    return;
+  // ONE handle per calling thread, re-used for every key-frame's problem (vo_ba_reset): LocalMapping::run builds a new local
+  // window per key-frame (localMapping.cpp:38), and a create / destroy pair per call would put hipMalloc, a stream and a
+  // device-synchronising hipFree on the mapping thread's hot path (2.5 ms against 1.1 ms per call at 10 key-frames x 3000
+  // points, bench.py local_ba.end_to_end).  Never destroyed: thread-exit order against the HIP runtime's teardown.
+  static thread_local vo_ba *h = nullptr;
+  const int rc_new = h ? vo_ba_reset(h, (int)cams.size(), poses.data(), fixed.data(), (int)points.size(), pts.data(), (int)edges.size(),
+                                     e_cam.data(), e_pt.data(), e_obs.data(), e_is.data(), cam)
+                       : vo_ba_create(&h, (int)cams.size(), poses.data(), fixed.data(), (int)points.size(), pts.data(),
+                                      (int)edges.size(), e_cam.data(), e_pt.data(), e_obs.data(), e_is.data(), cam);
+  if (rc_new != VO_OK) return;
   // ---- solve (problem 1, chi2, problem 2, chi2) with the reference's stopFlag polling points: the library
   // reads the caller's LIVE flag (a bool written by the tracking thread, localMapping.cpp:72,540) as a byte at
   // :594 and again at :612, so a stop raised while problem 1 is being queued is still seen
   std::vector<uint8_t> erase(edges.size() + 1, 0);
   static_assert(sizeof(bool) == 1, "stopFlag is polled as a byte");
   const int rc = vo_ba_local_ba(h, reinterpret_cast<const volatile unsigned char *>(&stopFlag), erase.data(), nullptr);
-  if (rc != VO_OK) {  // VO_ERR_STOPPED mirrors the early return at :594-595 (no write-back)
-    vo_ba_destroy(h);
-    return;
-  }
-  vo_ba_get_state(h, poses.data(), pts.data());
-  vo_ba_destroy(h);
+  if (rc != VO_OK) return;  // VO_ERR_STOPPED mirrors the early return at :594-595 (no write-back)
+  vo_ba_get_state(h, poses.data(), pts.data());  // (the state came back with the results: no round trip of its own)
   // ---- write-back (:757-804)
   unique_lock<mutex> lock(map_curr->mutexMapUpdate_);
   for (size_t e = 0; e < edges.size(); e++)

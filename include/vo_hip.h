@@ -703,6 +703,13 @@ int vo_ba_create(vo_ba **out, int n_cams, const double *poses, const uint8_t *ca
                  const int32_t *edge_point, const double *edge_obs, const double *edge_inv_sigma,
                  const double cam[5]);
 void vo_ba_destroy(vo_ba *h);
+/* A NEW problem in an existing handle: the per-key-frame caller (localMapping.cpp:38 builds a different local window every
+ * time) keeps ONE handle per thread and resets it instead of create / destroy -- stream, device buffers (grow-only, with
+ * headroom), page-locked staging, shard / callback / options stay, so that nothing is allocated or freed on the hot path
+ * (hipFree synchronises the whole device, the tracking thread's streams included).  Arguments as vo_ba_create. */
+int vo_ba_reset(vo_ba *h, int n_cams, const double *poses, const uint8_t *cam_fixed, int n_points, const double *points,
+                int n_edges, const int32_t *edge_cam, const int32_t *edge_point, const double *edge_obs,
+                const double *edge_inv_sigma, const double cam[5]);
 int vo_ba_set_stream(vo_ba *h, void *hip_stream);
 /* restrict this handle to the points p with p % n_shards == shard (multi-GPU: one process per
  * GPU, each owning a shard; cameras replicated).  Must precede any solve.

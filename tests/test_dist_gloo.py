@@ -4,6 +4,7 @@ linearisation (the oracle is the checker here, never the product path)."""
 import os
 import pathlib
 import socket
+import subprocess
 import sys
 
 import numpy as np
@@ -79,3 +80,40 @@ def test_sharding_rule():
     masks = [dist_ba.shard_edge_mask(e_pt, r, 3) for r in range(3)]
     assert (np.sum(masks, 0) == 1).all()
     assert np.array_equal(dist_ba.shard_of_point(np.arange(6), 1), np.zeros(6, int))
+
+
+def test_collective_watchdog_ends_a_stuck_rank(tmp_path):
+    """a rank whose peer never arrives must END with a non-zero status, not hang: two gloo ranks are started,
+    rank 1 exits before its first barrier; rank 0's watchdog (bench.py --collective-timeout) gives up within the deadline."""
+    script = tmp_path / "stuck.py"
+    script.write_text(
+        "import os, sys, time, datetime, threading\n"
+        "import torch.distributed as dist\n"
+        "rank = int(os.environ['RANK'])\n"
+        "dist.init_process_group('gloo', timeout=datetime.timedelta(seconds=8))\n"
+        "if rank == 1:\n"
+        "    os._exit(0)\n"
+        "progress = {'t': time.time()}\n"
+        "def wd():\n"
+        "    while True:\n"
+        "        time.sleep(0.5)\n"
+        "        if time.time() - progress['t'] > 10:\n"
+        "            os._exit(70)\n"
+        "threading.Thread(target=wd, daemon=True).start()\n"
+        "try:\n"
+        "    dist.barrier()\n"
+        "except Exception as e:\n"
+        "    sys.stderr.write('barrier failed: %r\\n' % (e,))\n"
+        "    os._exit(71)\n"
+        "os._exit(0)\n")
+    import socket
+    sk = socket.socket()
+    sk.bind(("127.0.0.1", 0))
+    port = sk.getsockname()[1]
+    sk.close()
+    procs = []
+    for rk in (0, 1):
+        env = dict(os.environ, RANK=str(rk), WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        procs.append(subprocess.Popen([sys.executable, str(script)], env=env, stderr=subprocess.PIPE))
+    rcs = [p.wait(timeout=60) for p in procs]
+    assert rcs[1] == 0 and rcs[0] in (70, 71), rcs  # the stuck rank ended by its deadline, with a non-zero status

@@ -127,6 +127,45 @@ def test_local_ba_matches_oracle(vo, orc, seed):
     assert (erase != oerase).sum() == 0
 
 
+def test_one_handle_reset_over_twenty_problems(vo, orc):
+    """vo_ba_reset: twenty problems of different sizes -- growing, shrinking, with and without fixed key-frames --
+    through ONE handle, each equal to the oracle; a problem is also solved on a fresh handle to show that nothing of its
+    predecessors leaks into it"""
+    rng = np.random.default_rng(11)
+    ba = None
+    for k in range(20):
+        n_kf, n_pts, n_fixed = int(rng.integers(3, 9)), int(rng.integers(80, 500)), int(rng.integers(0, 3))
+        pr = synth.make_lba_problem(100 + k, n_kf=n_kf, n_pts=n_pts, n_fixed=n_fixed)
+        if ba is None:
+            ba = vo.BundleAdjuster(pr)
+        else:
+            ba.reset(pr)
+        erase, sums, rc = ba.local_ba()
+        gposes, gpts = ba.state()
+        oposes, opts, oerase, osums, orc_rc = orc.local_ba(pr)
+        assert rc == 0 and orc_rc == 0, k
+        for q in range(2):
+            assert (sums[q].iterations, sums[q].accepted) == (osums[q].iterations, osums[q].accepted), (k, q)
+        assert np.abs(gposes - oposes).max() < 1e-7 and np.array_equal(erase, oerase), k
+        deg = np.bincount(pr["e_pt"], minlength=len(opts))
+        if (deg >= 4).any():
+            assert np.abs(gpts[deg >= 4] - opts[deg >= 4]).max() < 1e-5, k
+        if k in (7, 15):
+            fresh = vo.BundleAdjuster(pr)
+            e2, _, _ = fresh.local_ba()
+            p2, x2 = fresh.state()
+            fresh.close()
+            assert np.array_equal(e2, erase) and np.array_equal(p2, gposes) and np.array_equal(x2, gpts), k
+        if k == 9:  # the split-phase getters still work on a re-used handle, and a stopped call leaves the new state untouched
+            pr2 = synth.make_lba_problem(300, n_kf=4, n_pts=120, n_fixed=1)
+            ba.reset(pr2)
+            flag = C.c_int(1)
+            _, _, rc_s = ba.local_ba(stop=C.byref(flag))
+            p_s, x_s = ba.state()
+            assert rc_s == -5 and np.array_equal(p_s, pr2["poses"]) and np.array_equal(x_s, pr2["points"])
+    ba.close()
+
+
 def test_local_ba_stop_flag(vo, orc):
     pr = synth.make_lba_problem(3, n_kf=4, n_pts=200, n_fixed=1)
     ba = vo.BundleAdjuster(pr)

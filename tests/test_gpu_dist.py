@@ -71,3 +71,30 @@ def test_bench_gpus_2_starts_two_ranks_and_reports_the_sharded_legs():
     assert sg["lm_iters_per_s"] > 0 and sg["first_separator_tile_column"] == 24 and sg["allreduce_payload_MB"] < g["allreduce_payload_MB"]
     assert sg["allreduce_calls_per_solve"] == 2 * g["allreduce_calls_per_solve"]
     assert "cpu_baseline" not in d  # rank 0 at N = 1 only
+    sc = d["ba_scaling"]  # the SCALE question answered inside the run: node aggregate over rank 0 alone, plus the sharded forms
+    assert sc["n_gpus"] == 2 and sc["replicas"]["x_one_gpu"] > 0 and sc["replicas"]["one_gpu_lm_iters_per_s"] > 0
+    for k in ("sharded_local_ba", "sharded_global_ba_replicated", "sharded_global_ba_segments"):
+        assert sc[k]["x_one_gpu"] > 0, k
+
+
+@pytest.mark.timeout(900)
+def test_bench_rccl_process_group_of_one():
+    """torch.distributed with the **nccl** backend (= RCCL) on the hardware, as a process group of ONE rank:
+    `bench.py --dist-at-one-rank` runs the SHARDED forms of the config-3 and config-4 legs on handles with
+    VO_BA_OPT_COLLECTIVES_AT_ONE_RANK, so that every collective of the LM loop is a real dist.all_reduce on RCCL through the
+    `_allreduce` callback the multi-GPU run uses -- the torch-RCCL path has then run on the hardware before the 8-GPU run."""
+    import json
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", OMP_NUM_THREADS="2")
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK"):
+        env.pop(k, None)
+    cmd = [sys.executable, str(ROOT / "bench.py"), "--gpus", "1", "--backend", "nccl", "--dist-at-one-rank", "--steps", "2", "--warmup", "1",
+           "--batch", "64", "--no-bruteforce", "--no-single-stream", "--no-cpu-baseline", "--collective-timeout", "120"]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=800, env=env, cwd=str(ROOT))
+    assert r.returncode == 0, (r.stdout[-2000:], r.stderr[-4000:])
+    d = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+    assert d["n_gpus"] == 1
+    s3 = d["local_ba"]["sharded_at_one_rank"]
+    assert s3["backend"] == "nccl" and s3["allreduce_calls_per_solve"] >= 2 * d["local_ba"]["iterations_per_solve"]
+    assert 0 < s3["ms_per_solve"] < 20 * d["local_ba"]["ms_per_solve"]
+    g = d["global_ba_sharded_at_one_rank"]
+    assert g["lm_iters_per_s"] > 0 and g["allreduce_calls_per_solve"] >= 2 and 1.0 < g["allreduce_payload_MB"] < 15.0

@@ -56,7 +56,7 @@ SYMBOLS = [
     "vo_match_triangulation", "vo_match_bow_batch", "vo_match_triangulation_batch", "vo_match_fuse", "vo_match_area_best", "vo_match_sim3_projection",
     "vo_match_sim3_mutual", "vo_vocab_create", "vo_vocab_destroy", "vo_bow_transform",
     "vo_pose_only_solve", "vo_sim3_solve", "vo_pose_graph_solve", "vo_sim3_reanchor_points", "vo_chol_solve", "vo_chol_solve_split", "vo_pose_only_solve_dev",
-    "vo_ba_create", "vo_ba_destroy", "vo_ba_set_stream", "vo_ba_set_shard", "vo_ba_set_option", "vo_set_option", "vo_ba_set_allreduce", "vo_ba_set_state",
+    "vo_ba_create", "vo_ba_reset", "vo_ba_destroy", "vo_ba_set_stream", "vo_ba_set_shard", "vo_ba_set_option", "vo_set_option", "vo_ba_set_allreduce", "vo_ba_set_state",
     "vo_ba_get_state", "vo_ba_n_free_cams", "vo_ba_local_ba", "vo_ba_local_ba_enqueue",
     "vo_ba_local_ba_finish", "vo_ba_solve", "vo_ba_lm_begin",
     "vo_ba_linearize", "vo_ba_step", "vo_ba_update", "vo_ba_lm_end", "vo_ba_reduced_system",
@@ -930,6 +930,14 @@ class BundleAdjuster:
             check(lib().vo_ba_set_stream(self._h, C.c_void_p(stream)))
         for k, v in (options or {}).items():
             self.set_option(k, v)
+
+    def reset(self, prob):
+        """vo_ba_reset: a new problem in this handle (buffers, stream, options kept)"""
+        self.prob = prob
+        self.n_cams, self.n_pts, self.n_edges = len(prob["poses"]), len(prob["points"]), len(prob["e_cam"])
+        a = {k: np.ascontiguousarray(v) for k, v in prob.items() if isinstance(v, np.ndarray)}
+        check(lib().vo_ba_reset(self._h, self.n_cams, _p(a["poses"]), _p(a["fixed"]), self.n_pts, _p(a["points"]), self.n_edges,
+                                _p(a["e_cam"]), _p(a["e_pt"]), _p(a["e_obs"]), _p(a["e_inv_sigma"]), _p(a["cam"])), "vo_ba_reset")
 
     def set_option(self, option, value):
         """vo_ba_set_option: 'segments' / 'collectives_at_one_rank' / 'order_parts' (or the integer codes); before the

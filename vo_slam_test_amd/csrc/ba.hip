@@ -2758,6 +2758,14 @@ struct vo_ba {
   bool own_stream = false;
   bool built = false;
   vo::PinnedBuf pin;  // page-locked landing block of vo_ba_local_ba_finish (results of a solve)
+  vo::PinnedBuf up_pin;   // page-locked staging of build_device's uploads: ONE block ...
+  size_t up_used = 0;
+  vo::DevBuf b_up_arena;  // ... mirrored by ONE device block: the uploaded buffers are views into it, one copy per build
+  vo::DevBuf b_zero_arena;  // the buffers a build starts at zero, views into one block: one memset per build
+  size_t zero_used = 0;
+  bool arenas = false;    // this build uses the two arenas (LDS-sized systems; large ones keep separate buffers)
+  bool state_cached = false;           // pin holds the final poses / points of the last vo_ba_local_ba (vo_ba_get_state without a round trip)
+  size_t cache_xc_off = 0, cache_xp_off = 0;
   BaDev D{};
   vo::DevBuf b_ecam, b_ept, b_eobs, b_eis, b_eact, b_ptstart, b_local, b_camslot, b_slotcam, b_camstart,
       b_camedges, b_ptin, b_camin, b_xc0, b_xc1, b_xp0, b_xp1, b_pc0, b_pc1, b_sc, b_sp, b_hinv, b_gl2, b_dl, b_wt, b_wt1, b_hll0, b_hll1, b_spt1,
@@ -2799,7 +2807,40 @@ int upload(vo::DevBuf &b, const void *src, size_t bytes) {
   if (bytes) VO_HIP_CHECK(hipMemcpy(b.p, src, bytes, hipMemcpyHostToDevice));
   return VO_OK;
 }
-
+// A device buffer that grows with headroom: a handle that is re-used for problem after problem (vo_ba_reset) stops
+// allocating after the first few (hipMalloc costs tens of microseconds, the hipFree behind a growth synchronises the device).
+int reserve_grow(vo::DevBuf &b, size_t bytes) {
+  if (bytes <= b.bytes) return VO_OK;
+  return b.reserve(bytes + bytes / 2 + 256);
+}
+// build_device's uploads of a handle: through ONE page-locked staging block (reserved by build_device for the whole build,
+// so that it never moves under a copy in flight) and asynchronous on the handle's stream -- a hipMemcpy from pageable memory
+// is a synchronous round trip of 10-30 us apiece, fourteen of them per handle
+int upload(vo_ba *h, vo::DevBuf &b, const void *src, size_t bytes) {
+  const size_t off = (h->up_used + 255) & ~(size_t)255;
+  if (!h->arenas || off + std::max<size_t>(bytes, 64) > h->up_pin.bytes) {  // large systems; or more than build_device reserved
+    VO_CHECK(reserve_grow(b, std::max<size_t>(bytes, 64)));
+    if (bytes) VO_HIP_CHECK(hipMemcpy(b.p, src, bytes, hipMemcpyHostToDevice));
+    return VO_OK;
+  }
+  if (bytes) memcpy(h->up_pin.data() + off, src, bytes);
+  h->up_used = off + std::max<size_t>(bytes, 64);
+  b.set_view(static_cast<uint8_t *>(h->b_up_arena.p) + off, std::max<size_t>(bytes, 64));  // (the one copy follows at the end of the build)
+  return VO_OK;
+}
+// a buffer that starts the build at zero: a view into the zero arena where this build uses it (one memset for all of them)
+int zalloc(vo_ba *h, vo::DevBuf &b, size_t bytes) {
+  bytes = std::max<size_t>(bytes, 64);
+  const size_t off = (h->zero_used + 255) & ~(size_t)255;
+  if (!h->arenas || off + bytes > h->b_zero_arena.bytes) {
+    VO_CHECK(reserve_grow(b, bytes));
+    VO_HIP_CHECK(hipMemsetAsync(b.p, 0, bytes, h->stream));
+    return VO_OK;
+  }
+  h->zero_used = off + bytes;
+  b.set_view(static_cast<uint8_t *>(h->b_zero_arena.p) + off, bytes);
+  return VO_OK;
+}
 
 // ---- key-frame order of a large reduced system: vo::chol_choose_order (chol.hip) over the covisibility graph ------
 vo::CholOrder choose_camera_order(const vo_ba *h, int m) {
@@ -2828,6 +2869,10 @@ vo::CholOrder choose_camera_order(const vo_ba *h, int m) {
 int build_device(vo_ba *h) {
   if (h->built) return VO_OK;
   BaDev &D = h->D;
+  // staging for every upload of this build (never moved while copies are in flight: reserved once, before the first)
+  VO_HIP_CHECK(hipStreamSynchronize(h->stream));  // (a previous build's copies out of the block have landed)
+  VO_CHECK(h->up_pin.reserve(65536 + (size_t)h->n_edges * 56 + (size_t)h->n_pts * 64 + (size_t)h->n_cams * 256));
+  h->up_used = 0;
   D.n_cams = h->n_cams, D.n_pts = h->n_pts, D.n_edges = h->n_edges, D.nf = h->nf;
   D.n_shards = h->n_shards, D.shard = h->shard;
   h->collectives = h->n_shards > 1 || (h->allreduce && h->opt_collectives_1);
@@ -2839,6 +2884,17 @@ int build_device(vo_ba *h) {
     return VO_ERR_CAPACITY;
   }
   D.Mpad = D.large ? 16 : std::max(16, (6 * h->nf + 1 + 15) / 16 * 16);  // large: no dense operand matrix
+  // LDS-sized systems (the per-key-frame local BA): the uploaded buffers are views into ONE device block filled by one copy
+  // from the page-locked staging, the zero-initialised ones views into another cleared by one memset -- fourteen copies and
+  // nine memsets otherwise, each a dependent ~3-5 us step in front of the first LM kernel
+  h->arenas = !D.large;
+  h->zero_used = 0;
+  if (h->arenas) {
+    VO_CHECK(reserve_grow(h->b_up_arena, h->up_pin.bytes));
+    const size_t np_ = (size_t)std::max(1, h->n_pts);
+    VO_CHECK(reserve_grow(h->b_zero_arena, np_ + (size_t)h->n_cams + 2 * np_ * 48 + 2 * 3 * np_ * D.Mpad * 8 +
+                                               33 * (size_t)D.Mpad * D.Mpad * 8 + 4096 + 3 * sizeof(BaState) + 16 * 256 + 1024));
+  }
   if (D.large) {
     const int m = D.ld / vo::kCholPanel;
     const vo::CholOrder o = choose_camera_order(h, m);
@@ -2921,8 +2977,8 @@ int build_device(vo_ba *h) {
           for (int j = h->seg_c0; j <= i; j++)
             if ((lmask[i] >> j) & 1ull) st.push_back(make_int2(i, j));
         h->n_seg_tiles = (int)st.size();
-        VO_CHECK(upload(h->b_segtiles, st.data(), st.size() * sizeof(int2)));
-        VO_CHECK(h->b_segpack.reserve(((size_t)st.size() * vo::kCholPanel * vo::kCholPanel + (size_t)D.ld + 8) * 8));
+        VO_CHECK(upload(h, h->b_segtiles, st.data(), st.size() * sizeof(int2)));
+        VO_CHECK(reserve_grow(h->b_segpack, ((size_t)st.size() * vo::kCholPanel * vo::kCholPanel + (size_t)D.ld + 8) * 8));
       }
     }
     {
@@ -2936,7 +2992,7 @@ int build_device(vo_ba *h) {
           const int partial = h->seg_mode && j >= h->seg_c0 && !D.seg_lead ? 1 : 0;
           lt.push_back(make_int2(i, j | (partial << 16)));
         }
-      VO_CHECK(upload(h->b_ltiles, lt.data(), lt.size() * sizeof(int2)));
+      VO_CHECK(upload(h, h->b_ltiles, lt.data(), lt.size() * sizeof(int2)));
       D.n_ltiles = (int)lt.size();
     }
     if (h->collectives && !h->seg_mode) {
@@ -2945,8 +3001,8 @@ int build_device(vo_ba *h) {
         for (int j = 0; j <= i; j++)
           if ((o.pattern[i] >> j) & 1ull) tiles.push_back(make_int2(i, j));
       h->n_pack_tiles = (int)tiles.size();
-      VO_CHECK(upload(h->b_packtiles, tiles.data(), tiles.size() * sizeof(int2)));
-      VO_CHECK(h->b_pack.reserve(((size_t)tiles.size() * vo::kCholPanel * vo::kCholPanel + D.ld + (size_t)h->nf * 27 + 1 + h->n_shards) * 8));
+      VO_CHECK(upload(h, h->b_packtiles, tiles.data(), tiles.size() * sizeof(int2)));
+      VO_CHECK(reserve_grow(h->b_pack, ((size_t)tiles.size() * vo::kCholPanel * vo::kCholPanel + D.ld + (size_t)h->nf * 27 + 1 + h->n_shards) * 8));
     }
   }
   if (h->pt_owner.empty()) {
@@ -2960,16 +3016,18 @@ int build_device(vo_ba *h) {
   // per-camera edge lists restricted to this shard's points
   std::vector<int> cstart(h->nf + 1, 0), cedges;
   {
-    std::vector<std::vector<int>> lists(h->nf);
+    // counting sort of this shard's edges by free-camera slot (edge order within a camera = sorted edge order)
     for (int e = 0; e < h->n_edges; e++) {
-      const int s = h->cam_slot[h->e_cam[e]];
-      if (s >= 0 && h->pt_owner[h->e_pt[e]] == h->shard) lists[s].push_back(e);
+      const int sl = h->cam_slot[h->e_cam[e]];
+      if (sl >= 0 && h->pt_owner[h->e_pt[e]] == h->shard) cstart[sl + 1]++;
     }
     int mx = 0;
-    for (int s = 0; s < h->nf; s++) {
-      cstart[s + 1] = cstart[s] + (int)lists[s].size();
-      cedges.insert(cedges.end(), lists[s].begin(), lists[s].end());
-      mx = std::max(mx, (int)lists[s].size());
+    for (int sl = 0; sl < h->nf; sl++) mx = std::max(mx, cstart[sl + 1]), cstart[sl + 1] += cstart[sl];
+    cedges.resize((size_t)cstart[h->nf]);
+    std::vector<int> fill(cstart.begin(), cstart.end() - 1);
+    for (int e = 0; e < h->n_edges; e++) {
+      const int sl = h->cam_slot[h->e_cam[e]];
+      if (sl >= 0 && h->pt_owner[h->e_pt[e]] == h->shard) cedges[(size_t)fill[sl]++] = e;
     }
     D.n_cchunks = std::max(1, (mx + kCamChunk - 1) / kCamChunk);
   }
@@ -2986,47 +3044,40 @@ int build_device(vo_ba *h) {
                   h->n_pts, kChunkPts);
     return VO_ERR_CAPACITY;
   }
-  VO_CHECK(upload(h->b_ecam, h->e_cam.data(), h->e_cam.size() * 4));
-  VO_CHECK(upload(h->b_ept, h->e_pt.data(), h->e_pt.size() * 4));
-  VO_CHECK(upload(h->b_eobs, h->e_obs.data(), h->e_obs.size() * 8));
-  VO_CHECK(upload(h->b_eis, h->e_is.data(), h->e_is.size() * 8));
-  VO_CHECK(h->b_eact.reserve(std::max<size_t>(h->n_edges, 64)));
-  VO_CHECK(h->b_out.reserve(std::max<size_t>(h->n_edges, 64)));
-  VO_CHECK(upload(h->b_ptstart, h->pt_start.data(), h->pt_start.size() * 4));
-  VO_CHECK(upload(h->b_local, local.data(), local.size() * 4));
-  VO_CHECK(upload(h->b_camslot, h->cam_slot.data(), h->cam_slot.size() * 4));
-  VO_CHECK(upload(h->b_slotcam, h->slot_cam.data(), h->slot_cam.size() * 4));
-  VO_CHECK(upload(h->b_camstart, cstart.data(), cstart.size() * 4));
-  VO_CHECK(upload(h->b_camedges, cedges.data(), cedges.size() * 4));
-  VO_CHECK(h->b_ptin.reserve(std::max<size_t>(h->n_pts, 64)));
-  VO_CHECK(h->b_camin.reserve(std::max<size_t>(h->n_cams, 64)));
-  VO_HIP_CHECK(hipMemsetAsync(h->b_ptin.p, 0, std::max<size_t>(h->n_pts, 64), h->stream));  // epoch stamps start below epoch 1
-  VO_HIP_CHECK(hipMemsetAsync(h->b_camin.p, 0, std::max<size_t>(h->n_cams, 64), h->stream));
+  VO_CHECK(upload(h, h->b_ecam, h->e_cam.data(), h->e_cam.size() * 4));
+  VO_CHECK(upload(h, h->b_ept, h->e_pt.data(), h->e_pt.size() * 4));
+  VO_CHECK(upload(h, h->b_eobs, h->e_obs.data(), h->e_obs.size() * 8));
+  VO_CHECK(upload(h, h->b_eis, h->e_is.data(), h->e_is.size() * 8));
+  VO_CHECK(reserve_grow(h->b_eact, std::max<size_t>(h->n_edges, 64)));
+  VO_CHECK(reserve_grow(h->b_out, std::max<size_t>(h->n_edges, 64)));
+  VO_CHECK(upload(h, h->b_ptstart, h->pt_start.data(), h->pt_start.size() * 4));
+  VO_CHECK(upload(h, h->b_local, local.data(), local.size() * 4));
+  VO_CHECK(upload(h, h->b_camslot, h->cam_slot.data(), h->cam_slot.size() * 4));
+  VO_CHECK(upload(h, h->b_slotcam, h->slot_cam.data(), h->slot_cam.size() * 4));
+  VO_CHECK(upload(h, h->b_camstart, cstart.data(), cstart.size() * 4));
+  VO_CHECK(upload(h, h->b_camedges, cedges.data(), cedges.size() * 4));
+  VO_CHECK(zalloc(h, h->b_ptin, std::max<size_t>(h->n_pts, 64)));  // epoch stamps start below epoch 1
+  VO_CHECK(zalloc(h, h->b_camin, std::max<size_t>(h->n_cams, 64)));
   D.epoch = 0;
-  VO_CHECK(upload(h->b_xc0, h->poses.data(), h->poses.size() * 8));
-  VO_CHECK(upload(h->b_xc1, h->poses.data(), h->poses.size() * 8));
-  VO_CHECK(upload(h->b_xp0, h->points.data(), h->points.size() * 8));
-  VO_CHECK(upload(h->b_xp1, h->points.data(), h->points.size() * 8));
-  VO_CHECK(h->b_pc0.reserve((size_t)h->n_cams * 12 * 8));
-  VO_CHECK(h->b_pc1.reserve((size_t)h->n_cams * 12 * 8));
-  VO_CHECK(h->b_sc.reserve((size_t)std::max(1, h->n_cams) * 6 * 8));
-  VO_CHECK(h->b_sp.reserve((size_t)std::max(1, h->n_pts) * 3 * 8));
-  VO_CHECK(h->b_hinv.reserve((size_t)std::max(1, h->n_pts) * 6 * 8));
-  VO_CHECK(h->b_gl2.reserve((size_t)std::max(1, h->n_pts) * 3 * 8));
-  VO_CHECK(h->b_dl.reserve((size_t)std::max(1, h->n_pts) * 3 * 8));
+  VO_CHECK(upload(h, h->b_xc0, h->poses.data(), h->poses.size() * 8));
+  VO_CHECK(upload(h, h->b_xc1, h->poses.data(), h->poses.size() * 8));
+  VO_CHECK(upload(h, h->b_xp0, h->points.data(), h->points.size() * 8));
+  VO_CHECK(upload(h, h->b_xp1, h->points.data(), h->points.size() * 8));
+  VO_CHECK(reserve_grow(h->b_pc0, (size_t)h->n_cams * 12 * 8));
+  VO_CHECK(reserve_grow(h->b_pc1, (size_t)h->n_cams * 12 * 8));
+  VO_CHECK(reserve_grow(h->b_sc, (size_t)std::max(1, h->n_cams) * 6 * 8));
+  VO_CHECK(reserve_grow(h->b_sp, (size_t)std::max(1, h->n_pts) * 3 * 8));
+  VO_CHECK(reserve_grow(h->b_hinv, (size_t)std::max(1, h->n_pts) * 6 * 8));
+  VO_CHECK(reserve_grow(h->b_gl2, (size_t)std::max(1, h->n_pts) * 3 * 8));
+  VO_CHECK(reserve_grow(h->b_dl, (size_t)std::max(1, h->n_pts) * 3 * 8));
   const size_t wt_rows = D.large ? 1 : (size_t)std::max(1, K);
-  VO_CHECK(h->b_wt.reserve(wt_rows * D.Mpad * 8));
-  VO_CHECK(h->b_wt1.reserve(wt_rows * D.Mpad * 8));
-  VO_CHECK(h->b_hll0.reserve((size_t)std::max(1, h->n_pts) * 6 * 8));
-  VO_CHECK(h->b_hll1.reserve((size_t)std::max(1, h->n_pts) * 6 * 8));
-  VO_HIP_CHECK(hipMemsetAsync(h->b_hll0.p, 0, (size_t)std::max(1, h->n_pts) * 6 * 8, h->stream));
-  VO_HIP_CHECK(hipMemsetAsync(h->b_hll1.p, 0, (size_t)std::max(1, h->n_pts) * 6 * 8, h->stream));
   // operand matrices start out all-zero; only (point, camera) pairs that have an edge are ever written
-  VO_HIP_CHECK(hipMemsetAsync(h->b_wt.p, 0, wt_rows * D.Mpad * 8, h->stream));
-  VO_HIP_CHECK(hipMemsetAsync(h->b_wt1.p, 0, wt_rows * D.Mpad * 8, h->stream));
+  VO_CHECK(zalloc(h, h->b_wt, wt_rows * D.Mpad * 8));
+  VO_CHECK(zalloc(h, h->b_wt1, wt_rows * D.Mpad * 8));
+  VO_CHECK(zalloc(h, h->b_hll0, (size_t)std::max(1, h->n_pts) * 6 * 8));
+  VO_CHECK(zalloc(h, h->b_hll1, (size_t)std::max(1, h->n_pts) * 6 * 8));
   if (D.large) D.ksplit = 1;
-  VO_CHECK(h->b_sgemm.reserve((size_t)(D.ksplit + 1) * D.Mpad * D.Mpad * 8));  // + one all-zero slab
-  VO_HIP_CHECK(hipMemsetAsync(h->b_sgemm.as<double>() + (size_t)D.ksplit * D.Mpad * D.Mpad, 0, (size_t)D.Mpad * D.Mpad * 8, h->stream));
+  VO_CHECK(zalloc(h, h->b_sgemm, (size_t)(D.ksplit + 1) * D.Mpad * D.Mpad * 8));  // (the slab behind the last one must be all-zero)
   if (D.large) {
     // covisible camera pairs (c <= c') and, per pair, the (edge of c, edge of c') couples at their shared
     // points in point order: the gather lists of k_ba_pairs
@@ -3079,23 +3130,23 @@ int build_device(vo_ba *h) {
       pcc.push_back((int)(cp[first[w]].key / h->nf)), pcc.push_back((int)(cp[first[w]].key % h->nf));
     }
     if (pe.empty()) pe.assign(4, 0);
-    VO_CHECK(upload(h->b_pairstart, pstart.data(), pstart.size() * 4));
-    VO_CHECK(upload(h->b_paircc, pcc.data(), pcc.size() * 4));
-    VO_CHECK(upload(h->b_paire, pe.data(), pe.size() * 4));
-    VO_CHECK(h->b_we0.reserve((size_t)std::max(1, h->n_edges) * 18 * 8));
-    VO_CHECK(h->b_we1.reserve((size_t)std::max(1, h->n_edges) * 18 * 8));
+    VO_CHECK(upload(h, h->b_pairstart, pstart.data(), pstart.size() * 4));
+    VO_CHECK(upload(h, h->b_paircc, pcc.data(), pcc.size() * 4));
+    VO_CHECK(upload(h, h->b_paire, pe.data(), pe.size() * 4));
+    VO_CHECK(reserve_grow(h->b_we0, (size_t)std::max(1, h->n_edges) * 18 * 8));
+    VO_CHECK(reserve_grow(h->b_we1, (size_t)std::max(1, h->n_edges) * 18 * 8));
     VO_HIP_CHECK(hipMemsetAsync(h->b_we0.p, 0, (size_t)std::max(1, h->n_edges) * 18 * 8, h->stream));
     VO_HIP_CHECK(hipMemsetAsync(h->b_we1.p, 0, (size_t)std::max(1, h->n_edges) * 18 * 8, h->stream));
-    VO_CHECK(h->b_glsc0.reserve((size_t)std::max(1, h->n_pts) * 3 * 8));
-    VO_CHECK(h->b_glsc1.reserve((size_t)std::max(1, h->n_pts) * 3 * 8));
-    VO_CHECK(h->b_Sd.reserve((size_t)(D.ld + vo::kCholPanel) * D.ld * 8));  // + right-hand side / solution rows
+    VO_CHECK(reserve_grow(h->b_glsc0, (size_t)std::max(1, h->n_pts) * 3 * 8));
+    VO_CHECK(reserve_grow(h->b_glsc1, (size_t)std::max(1, h->n_pts) * 3 * 8));
+    VO_CHECK(reserve_grow(h->b_Sd, (size_t)(D.ld + vo::kCholPanel) * D.ld * 8));  // + right-hand side / solution rows
     // (once: the tiles outside the plan are never written again, and a caller's all-reduce of the whole storage -- the
     // split-phase interface -- must not sum uninitialised memory)
     VO_HIP_CHECK(hipMemsetAsync(h->b_Sd.p, 0, (size_t)(D.ld + vo::kCholPanel) * D.ld * 8, h->stream));
-    VO_CHECK(h->b_scv.reserve((size_t)D.ld * 8));
-    VO_CHECK(h->b_ddv.reserve((size_t)D.ld * 8));
-    VO_CHECK(h->b_gppv.reserve((size_t)D.ld * 8));
-    VO_CHECK(h->b_cholfail.reserve(vo::chol_workspace_bytes(D.ld)));
+    VO_CHECK(reserve_grow(h->b_scv, (size_t)D.ld * 8));
+    VO_CHECK(reserve_grow(h->b_ddv, (size_t)D.ld * 8));
+    VO_CHECK(reserve_grow(h->b_gppv, (size_t)D.ld * 8));
+    VO_CHECK(reserve_grow(h->b_cholfail, vo::chol_workspace_bytes(D.ld)));
     D.We[0] = h->b_we0.as<double>(), D.We[1] = h->b_we1.as<double>();
     D.glsc[0] = h->b_glsc0.as<double>(), D.glsc[1] = h->b_glsc1.as<double>();
     D.Sd = h->ext_payload ? h->ext_payload : h->b_Sd.as<double>();
@@ -3105,22 +3156,24 @@ int build_device(vo_ba *h) {
     D.pair_start = h->b_pairstart.as<int>(), D.pair_cc = h->b_paircc.as<int>(), D.pair_e = h->b_paire.as<int4>();
     D.ltiles = h->b_ltiles.as<int2>();
   }
-  VO_CHECK(h->b_scam.reserve((size_t)std::max(1, h->nf) * D.n_cchunks * 27 * 8));
-  VO_CHECK(h->b_spt.reserve((size_t)D.n_pblocks * 2 * 8));
-  VO_CHECK(h->b_spt1.reserve((size_t)D.n_pblocks * 2 * 8));
-  VO_CHECK(h->b_payload.reserve(((size_t)D.Mpad * D.Mpad + (size_t)h->nf * 27 + 1 + h->n_shards) * 8));
-  VO_CHECK(h->b_zc.reserve((size_t)std::max(1, 6 * h->nf) * 8));
-  VO_CHECK(h->b_sbs.reserve((size_t)D.n_pblocks * 6 * 8));
-  VO_CHECK(h->b_payload2.reserve(64));
-  VO_CHECK(h->b_state.reserve(3 * sizeof(BaState)));
-  VO_CHECK(h->b_dbg.reserve(64 * 8));
-  VO_CHECK(h->b_cnt.reserve(4096));
-  VO_HIP_CHECK(hipMemsetAsync(h->b_cnt.p, 0, 4096, h->stream));
+  VO_CHECK(reserve_grow(h->b_scam, (size_t)std::max(1, h->nf) * D.n_cchunks * 27 * 8));
+  VO_CHECK(reserve_grow(h->b_spt, (size_t)D.n_pblocks * 2 * 8));
+  VO_CHECK(reserve_grow(h->b_spt1, (size_t)D.n_pblocks * 2 * 8));
+  VO_CHECK(reserve_grow(h->b_payload, ((size_t)D.Mpad * D.Mpad + (size_t)h->nf * 27 + 1 + h->n_shards) * 8));
+  VO_CHECK(reserve_grow(h->b_zc, (size_t)std::max(1, 6 * h->nf) * 8));
+  VO_CHECK(reserve_grow(h->b_sbs, (size_t)D.n_pblocks * 6 * 8));
+  VO_CHECK(reserve_grow(h->b_payload2, 64));
+  VO_CHECK(zalloc(h, h->b_state, 3 * sizeof(BaState)));
+  VO_CHECK(reserve_grow(h->b_dbg, 64 * 8));
+  VO_CHECK(zalloc(h, h->b_cnt, 4096));
   D.counters = h->b_cnt.as<unsigned int>();
   D.fused = h->collectives ? 0 : 1;
   D.div_np1 = (unsigned)((0x100000000ull + (unsigned)(6 * h->nf)) / (unsigned)(6 * h->nf + 1));
   D.dbg = h->b_dbg.as<unsigned long long>();
-  VO_HIP_CHECK(hipMemsetAsync(h->b_state.p, 0, 3 * sizeof(BaState), h->stream));
+  if (h->arenas) {  // everything this build uploads: one copy; everything that starts at zero: one memset
+    if (h->up_used) VO_HIP_CHECK(hipMemcpyAsync(h->b_up_arena.p, h->up_pin.p, h->up_used, hipMemcpyHostToDevice, h->stream));
+    if (h->zero_used) VO_HIP_CHECK(hipMemsetAsync(h->b_zero_arena.p, 0, h->zero_used, h->stream));
+  }
   D.e_cam = h->b_ecam.as<int>(), D.e_pt = h->b_ept.as<int>();
   D.e_obs = h->b_eobs.as<double>(), D.e_is = h->b_eis.as<double>();
   D.e_active = h->b_eact.as<uint8_t>();
@@ -3162,7 +3215,7 @@ int build_device(vo_ba *h) {
                            1024u * (unsigned)((h->n_edges * 31 + h->n_pts * 7 + h->nf) & 0x3ff);
     const double c = (double)proto;
     double hs[4] = {c, c * c, 1.0, 0.0};
-    VO_CHECK(h->b_merge.reserve(64));
+    VO_CHECK(reserve_grow(h->b_merge, 64));
     VO_HIP_CHECK(hipMemcpyAsync(h->b_merge.p, hs, sizeof(hs), hipMemcpyHostToDevice, h->stream));
     const int rc = h->allreduce(h->allreduce_user, h->b_merge.as<double>(), 4, (void *)h->stream);
     if (rc != 0) {
@@ -3186,6 +3239,7 @@ int build_device(vo_ba *h) {
 int lm_begin(vo_ba *h, double hm, double hs, int max_it, const uint8_t *active_caller, bool keep_device_mask,
              uint8_t *classify0_out = nullptr) {
   VO_CHECK(build_device(h));
+  h->state_cached = false;  // a solve is about to move the state
   BaDev &D = h->D;
   hipStream_t st = h->stream;
   int set_active = 0;
@@ -3544,46 +3598,64 @@ int vo_sim3_solve(int n_problems, const int32_t *offsets, const double *cam_matc
   return vo::stream_sync(st, "vo_sim3_solve");
 }
 
-int vo_ba_create(vo_ba **out, int n_cams, const double *poses, const uint8_t *cam_fixed, int n_points,
-                 const double *points, int n_edges, const int32_t *edge_cam, const int32_t *edge_point,
-                 const double *edge_obs, const double *edge_inv_sigma, const double cam[5]) {
-  if (!out || n_cams < 1 || n_points < 0 || n_edges < 0 || !poses || !cam_fixed || !cam ||
-      (n_points > 0 && !points) || (n_edges > 0 && (!edge_cam || !edge_point || !edge_obs || !edge_inv_sigma))) {
-    vo::set_error("vo_ba_create: invalid argument");
+// the host part of a problem: validation, stable grouping of the edges by point (the order Ceres' Schur eliminator walks its
+// chunks) by a counting sort, free-camera slots
+static int ba_check_args(int n_cams, const double *poses, const uint8_t *cam_fixed, int n_points, const double *points, int n_edges,
+                         const int32_t *edge_cam, const int32_t *edge_point, const double *edge_obs, const double *edge_inv_sigma,
+                         const double *cam, const char *fn) {
+  if (n_cams < 1 || n_points < 0 || n_edges < 0 || !poses || !cam_fixed || !cam || (n_points > 0 && !points) ||
+      (n_edges > 0 && (!edge_cam || !edge_point || !edge_obs || !edge_inv_sigma))) {
+    vo::set_error("%s: invalid argument", fn);
     return VO_ERR_INVALID;
   }
   for (int e = 0; e < n_edges; e++)
     if (edge_cam[e] < 0 || edge_cam[e] >= n_cams || edge_point[e] < 0 || edge_point[e] >= n_points) {
-      vo::set_error("vo_ba_create: edge %d references camera %d / point %d out of range", e, edge_cam[e],
-                    edge_point[e]);
+      vo::set_error("%s: edge %d references camera %d / point %d out of range", fn, e, edge_cam[e], edge_point[e]);
       return VO_ERR_INVALID;
     }
-  VO_CHECK(vo::ensure_device());
-  vo_ba *h = new vo_ba();
-  h->n_cams = n_cams, h->n_pts = n_points, h->n_edges = n_edges;
+  return VO_OK;
+}
+static void ba_fill_problem(vo_ba *h, int n_cams, const double *poses, const uint8_t *cam_fixed, int n_points, const double *points,
+                            int n_edges, const int32_t *edge_cam, const int32_t *edge_point, const double *edge_obs,
+                            const double *edge_inv_sigma, const double cam[5]) {
+  h->n_cams = n_cams, h->n_pts = n_points, h->n_edges = n_edges, h->nf = 0;
   h->poses.assign(poses, poses + 6 * (size_t)n_cams);
   h->points.assign(points, points + 3 * (size_t)n_points);
   h->cam_fixed.assign(cam_fixed, cam_fixed + n_cams);
   memcpy(h->cam, cam, sizeof(h->cam));
-  // stable grouping of the edges by point (the order Ceres' Schur eliminator walks its chunks)
   h->perm.resize(n_edges);
-  std::iota(h->perm.begin(), h->perm.end(), 0);
-  std::stable_sort(h->perm.begin(), h->perm.end(), [&](int a, int b) { return edge_point[a] < edge_point[b]; });
   h->e_cam.resize(n_edges), h->e_pt.resize(n_edges), h->e_obs.resize(3 * (size_t)n_edges), h->e_is.resize(n_edges);
   h->pt_start.assign(n_points + 1, 0);
-  for (int s = 0; s < n_edges; s++) {
-    const int e = h->perm[s];
-    h->e_cam[s] = edge_cam[e], h->e_pt[s] = edge_point[e], h->e_is[s] = edge_inv_sigma[e];
-    for (int k = 0; k < 3; k++) h->e_obs[3 * (size_t)s + k] = edge_obs[3 * (size_t)e + k];
-    h->pt_start[edge_point[e] + 1]++;
-  }
+  for (int e = 0; e < n_edges; e++) h->pt_start[edge_point[e] + 1]++;
   for (int j = 0; j < n_points; j++) h->pt_start[j + 1] += h->pt_start[j];
+  std::vector<int> fill(h->pt_start.begin(), h->pt_start.end() - 1);
+  for (int e = 0; e < n_edges; e++) {  // counting sort: stable, caller order within a point
+    const int sidx = fill[edge_point[e]]++;
+    h->perm[sidx] = e;
+    h->e_cam[sidx] = edge_cam[e], h->e_pt[sidx] = edge_point[e], h->e_is[sidx] = edge_inv_sigma[e];
+    h->e_obs[3 * (size_t)sidx] = edge_obs[3 * (size_t)e], h->e_obs[3 * (size_t)sidx + 1] = edge_obs[3 * (size_t)e + 1];
+    h->e_obs[3 * (size_t)sidx + 2] = edge_obs[3 * (size_t)e + 2];
+  }
   h->cam_slot.assign(n_cams, -1);
+  h->slot_cam.clear();
   for (int c = 0; c < n_cams; c++)
     if (!cam_fixed[c]) {
       h->cam_slot[c] = h->nf++;
       h->slot_cam.push_back(c);
     }
+}
+
+int vo_ba_create(vo_ba **out, int n_cams, const double *poses, const uint8_t *cam_fixed, int n_points,
+                 const double *points, int n_edges, const int32_t *edge_cam, const int32_t *edge_point,
+                 const double *edge_obs, const double *edge_inv_sigma, const double cam[5]) {
+  if (!out) {
+    vo::set_error("vo_ba_create: invalid argument");
+    return VO_ERR_INVALID;
+  }
+  VO_CHECK(ba_check_args(n_cams, poses, cam_fixed, n_points, points, n_edges, edge_cam, edge_point, edge_obs, edge_inv_sigma, cam, "vo_ba_create"));
+  VO_CHECK(vo::ensure_device());
+  vo_ba *h = new vo_ba();
+  ba_fill_problem(h, n_cams, poses, cam_fixed, n_points, points, n_edges, edge_cam, edge_point, edge_obs, edge_inv_sigma, cam);
   if (hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking) != hipSuccess) {
     delete h;
     vo::set_error("hipStreamCreate failed");
@@ -3591,6 +3663,31 @@ int vo_ba_create(vo_ba **out, int n_cams, const double *poses, const uint8_t *ca
   }
   h->own_stream = true;
   *out = h;
+  return VO_OK;
+}
+
+// A NEW problem in an existing handle (localMapping.cpp:38 solves a different local window per key-frame): stream, device
+// buffers (grow-only, with headroom), page-locked staging and options stay; nothing is allocated or freed unless the new
+// problem is larger than every one before it.  Shard, all-reduce callback and options are kept.
+int vo_ba_reset(vo_ba *h, int n_cams, const double *poses, const uint8_t *cam_fixed, int n_points, const double *points,
+                int n_edges, const int32_t *edge_cam, const int32_t *edge_point, const double *edge_obs,
+                const double *edge_inv_sigma, const double cam[5]) {
+  if (!h) {
+    vo::set_error("vo_ba_reset: null handle");
+    return VO_ERR_INVALID;
+  }
+  VO_CHECK(ba_check_args(n_cams, poses, cam_fixed, n_points, points, n_edges, edge_cam, edge_point, edge_obs, edge_inv_sigma, cam, "vo_ba_reset"));
+  VO_HIP_CHECK(hipStreamSynchronize(h->stream));  // nothing of the previous problem is in flight
+  drop_graphs(h);
+  ba_fill_problem(h, n_cams, poses, cam_fixed, n_points, points, n_edges, edge_cam, edge_point, edge_obs, edge_inv_sigma, cam);
+  vo::chol_plan_destroy(h->chol_plan);
+  h->chol_plan = nullptr;
+  for (auto *&sp : h->seg_plan) vo::chol_plan_destroy(sp), sp = nullptr;
+  h->built = false, h->state_cached = false;
+  h->D = BaDev{};
+  h->lm_max_it = 0, h->archive_slot = -1, h->lba_second = false;
+  h->n_pack_tiles = 0, h->pt_owner.clear(), h->collectives = false, h->seg_mode = false, h->seg_c0 = 0, h->n_seg_tiles = 0;
+  h->order_parts = 1, h->order_cyclic = 0, h->order_sep = 0, h->order_depth = 0, h->order_tiles = 0;
   return VO_OK;
 }
 
@@ -3605,11 +3702,12 @@ void vo_ba_destroy(vo_ba *h) {
                         &h->b_sbs, &h->b_payload2, &h->b_state, &h->b_out, &h->b_dbg, &h->b_cnt, &h->b_we0, &h->b_we1,
                         &h->b_glsc0, &h->b_glsc1, &h->b_Sd, &h->b_scv, &h->b_ddv, &h->b_gppv, &h->b_cholfail,
                         &h->b_pairstart, &h->b_paircc, &h->b_paire, &h->b_merge, &h->b_packtiles, &h->b_pack, &h->b_ltiles,
-                        &h->b_segtiles, &h->b_segpack})
+                        &h->b_segtiles, &h->b_segpack, &h->b_up_arena, &h->b_zero_arena})
     b->release();
   vo::chol_plan_destroy(h->chol_plan);
   for (auto *sp : h->seg_plan) vo::chol_plan_destroy(sp);
   if (h->pin.p) (void)hipHostFree(h->pin.p);
+  if (h->up_pin.p) (void)hipHostFree(h->up_pin.p);
   if (h->own_stream) (void)hipStreamDestroy(h->stream);
   delete h;
 }
@@ -3676,6 +3774,7 @@ int vo_ba_debug_order(vo_ba *h, int out[8]) {
 int vo_ba_set_state(vo_ba *h, const double *poses, const double *points) {
   if (!h) return VO_ERR_INVALID;
   VO_CHECK(build_device(h));
+  h->state_cached = false;
   int cur;
   VO_CHECK(current_index(h, &cur));
   if (poses) VO_HIP_CHECK(hipMemcpy(h->D.Xc[cur], poses, (size_t)h->n_cams * 48, hipMemcpyHostToDevice));
@@ -3711,6 +3810,11 @@ static int merge_shards(vo_ba *h, int cur, uint8_t *erase_sorted /*n_edges, in/o
 
 int vo_ba_get_state(vo_ba *h, double *poses, double *points) {
   if (!h) return VO_ERR_INVALID;
+  if (h->built && h->state_cached) {  // the state vo_ba_local_ba_finish brought back with its results
+    if (poses) memcpy(poses, h->pin.data() + h->cache_xc_off, (size_t)h->n_cams * 48);
+    if (points && h->n_pts) memcpy(points, h->pin.data() + h->cache_xp_off, (size_t)h->n_pts * 24);
+    return VO_OK;
+  }
   VO_CHECK(build_device(h));
   int cur;
   VO_CHECK(current_index(h, &cur));
@@ -3849,12 +3953,24 @@ int vo_ba_local_ba_finish(vo_ba *h, uint8_t *edge_erase, vo_lm_summary *sums) {
   if (!h || !edge_erase || !h->built) return VO_ERR_INVALID;
   // both results land in one page-locked block: a copy into pageable memory costs ~20 us apiece
   const size_t st_off = ((size_t)std::max(1, h->n_edges) + 15) & ~(size_t)15;
-  VO_CHECK(h->pin.reserve(st_off + 3 * sizeof(BaState)));
+  // ... and, for an unsharded handle, both ping-pong copies of the poses and points ride along (a few hundred KB): the caller's
+  // vo_ba_get_state then needs no round trip of its own (which of the two is current is known only after the wait)
+  const bool cache = h->n_shards <= 1 && !h->D.large;
+  const size_t xc_bytes = (size_t)h->n_cams * 48, xp_bytes = (size_t)h->n_pts * 24;
+  const size_t xc_off = (st_off + 3 * sizeof(BaState) + 63) & ~(size_t)63, xp_off = (xc_off + 2 * xc_bytes + 63) & ~(size_t)63;
+  VO_CHECK(h->pin.reserve(cache ? xp_off + 2 * xp_bytes + 64 : st_off + 3 * sizeof(BaState)));
   uint8_t *tmp = h->pin.data();
   BaState *st = reinterpret_cast<BaState *>(tmp + st_off);
   VO_HIP_CHECK(hipMemcpyAsync(tmp, h->b_out.p, h->n_edges, hipMemcpyDeviceToHost, h->stream));
   VO_HIP_CHECK(hipMemcpyAsync(st, h->D.st, 3 * sizeof(BaState), hipMemcpyDeviceToHost, h->stream));
+  if (cache)
+    for (int k = 0; k < 2; k++) {
+      VO_HIP_CHECK(hipMemcpyAsync(tmp + xc_off + k * xc_bytes, h->D.Xc[k], xc_bytes, hipMemcpyDeviceToHost, h->stream));
+      if (xp_bytes) VO_HIP_CHECK(hipMemcpyAsync(tmp + xp_off + k * xp_bytes, h->D.Xp[k], xp_bytes, hipMemcpyDeviceToHost, h->stream));
+    }
   VO_HIP_CHECK(hipStreamSynchronize(h->stream));
+  h->state_cached = cache;
+  h->cache_xc_off = xc_off + (size_t)st[0].cur * xc_bytes, h->cache_xp_off = xp_off + (size_t)st[0].cur * xp_bytes;
   VO_CHECK(merge_shards(h, st[0].cur, tmp));  // no-op for an unsharded handle
   for (int s = 0; s < h->n_edges; s++) edge_erase[h->perm[s]] = tmp[s];
   if (sums) {

@@ -35,7 +35,9 @@ int ensure_device();  // VO_OK or VO_ERR_NO_DEVICE
 struct DevBuf {
   void *p = nullptr;
   size_t bytes = 0;
+  bool view = false;  // p points into another DevBuf (an arena): never freed through this object
   int reserve(size_t n) {
+    if (view) p = nullptr, bytes = 0, view = false;
     if (n <= bytes) return VO_OK;
     if (p) (void)hipFree(p);
     p = nullptr;
@@ -45,9 +47,14 @@ struct DevBuf {
     return VO_OK;
   }
   void release() {
-    if (p) (void)hipFree(p);
+    if (p && !view) (void)hipFree(p);
     p = nullptr;
     bytes = 0;
+    view = false;
+  }
+  void set_view(void *ptr, size_t n) {  // (an owned allocation is kept aside by the caller or released first)
+    if (p && !view) (void)hipFree(p);
+    p = ptr, bytes = n, view = true;
   }
   template <class T>
   T *as() const {
