@@ -59,8 +59,11 @@ Sophus::Sim3 Sim3Solver::iterate(int iterations_req, bool &stopFlag, bool &empty
   for (int k0 = 0; k0 < trips; k0 += chunk) {
     const int nk = std::min(chunk, trips - k0);
     for (int k = 0; k < nk; k++) draw(&triplets[3 * k]);
-    if (vo_sim3_ransac_eval(n, pc1.data(), pc2.data(), px1.data(), px2.data(), me1.data(), me2.data(), cam4, nk, triplets.data(),
-                            fixScale_ ? 1 : 0, counts.data(), flags.data(), sims.data()) != VO_OK) {
+    // the correspondences go to the device with the first trip of this call and stay there for the others (NULL arrays)
+    const bool first = k0 == 0;
+    if (vo_sim3_ransac_eval(n, first ? pc1.data() : nullptr, first ? pc2.data() : nullptr, first ? px1.data() : nullptr,
+                            first ? px2.data() : nullptr, first ? me1.data() : nullptr, first ? me2.data() : nullptr, cam4, nk,
+                            triplets.data(), fixScale_ ? 1 : 0, counts.data(), flags.data(), sims.data()) != VO_OK) {
       stopFlag = true;  // no error channel in the reference: report "nothing found, stop"
       emptyFlag = true;
       return Sophus::Sim3();

@@ -369,7 +369,10 @@ int vo_bow_score(int n_query, const int32_t *query_words, const double *query_va
  * reference draws them with rand(), :119-137), as does the sequential pick "first hypothesis whose
  * inlier count beats the threshold" (:141-160).  max_err = the reference's INTEGER thresholds
  * (vector<int>, 9.210 sigma^2 truncated).  Per hypothesis: counts[k], inlier_flags[k * n ..] (or NULL),
- * sims[13 k ..] = R12 row-major (9), t12 (3), s12. */
+ * sims[13 k ..] = R12 row-major (9), t12 (3), s12.
+ * All six correspondence arrays NULL: the correspondences the calling host thread passed with its previous call (same n)
+ * are still on the device and are used again -- a caller that evaluates one hypothesis per call (to keep its random
+ * generator in step with the reference's) uploads them once per Sim3Solver::iterate, not once per trip. */
 int vo_sim3_ransac_eval(int n, const double *cam1_points, const double *cam2_points, const double *pixels1,
                         const double *pixels2, const int32_t *max_err1, const int32_t *max_err2,
                         const float cam4[4], int n_hypotheses, const int32_t *triplets, int fix_scale,

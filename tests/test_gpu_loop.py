@@ -39,6 +39,13 @@ def test_sim3_ransac_hypotheses(vo, orc, fix_scale, scale):
                                    np.ascontiguousarray(px2), me1, me2, cam, K, tri, int(fix_scale), oc, of, osim)
     assert np.abs(sims - osim).max() < 1e-11                      # same Jacobi rotations, FP64
     assert np.array_equal(counts, oc) and np.array_equal(flags, of)
+    # one hypothesis per call against the correspondences the previous call left on the device (what the shim of
+    # Sim3Solver::iterate does to keep rand() in step): the same answers; a size nobody uploaded is refused
+    for k in (0, 7, 123):
+        c1, f1, s1 = vo.sim3_ransac_eval(None, None, None, None, None, None, cam, tri[k:k + 1], fix_scale, resident_n=n)
+        assert c1[0] == counts[k] and np.array_equal(f1[0], flags[k]) and np.array_equal(s1[0], sims[k])
+    with pytest.raises(vo.VoError):
+        vo.sim3_ransac_eval(None, None, None, None, None, None, cam, tri[:1], fix_scale, resident_n=n + 1)
     # the sequential pick of Sim3Solver::iterate: first hypothesis whose count beats the threshold (:141-160)
     first = int(np.argmax(counts > 0.5 * n))
     assert counts[first] > 0.5 * n
@@ -161,7 +168,7 @@ def test_rgb_to_gray(vo, orc):
 
 
 def _write_dbow3_binary(path, k, L, parent, weight, word_id, desc, children=None, compressed=False, truncate=None, bad_parent=False,
-                        child_first=False):
+                        child_first=False, qlz_chunk=None):
     """DBoW3 Vocabulary::toStream as published (the library is not vendored under the reference): magic, bool compressed,
     uint32 nnodes, k, L, scoring, weighting; nnodes - 1 node records -- NO root record -- in the writer's depth-first
     order (a stack of parents; the children of a popped parent are written in order, non-leaf children pushed): id,
@@ -192,7 +199,7 @@ def _write_dbow3_binary(path, k, L, parent, weight, word_id, desc, children=None
         body = body[:truncate]
     if compressed == "qlz":  # what Vocabulary::save(path) writes by default: QuickLZ level-1 chunks of 10000 bytes (tests/qlz_ref.py)
         import qlz_ref
-        body = qlz_ref.dbow3_compressed_body(body)
+        body = qlz_ref.dbow3_compressed_body(body, chunk_size=qlz_chunk or 10000)
     with open(path, "wb") as f:
         f.write(struct.pack("<Q", 88877711233))
         f.write(struct.pack("<?I", bool(compressed), n))
@@ -287,6 +294,16 @@ def test_vocabulary_file_loader(vo, orc, fmt, tmp_path):
         (tmp_path / "cut.dbow3").write_bytes(bytes(raw[:len(raw) - 37]))
         with pytest.raises(vo.VoError):
             vo.load_vocabulary(tmp_path / "cut.dbow3")
+        # a stream whose LAST chunk carries three bytes: QuickLZ's short header (3 bytes, inputs below 216) makes it a 6-byte
+        # chunk -- shorter than the 9 bytes a long header takes (such files were refused)
+        blen = 16 + (n - 1) * 60 + 4 + 8 * int((V["word_id"] >= 0).sum())
+        _write_dbow3_binary(tmp_path / "tail.dbow3", 6, 3, parent, V["node_weight"], V["word_id"], V["node_desc"], compressed="qlz",
+                            qlz_chunk=(blen - 3 + 1) // 2)
+        v3, info3 = vo.load_vocabulary(tmp_path / "tail.dbow3")
+        assert info3["n_nodes"] == n
+        w3, wt3, nd3 = v3.transform(feats)
+        v3.close()
+        assert np.array_equal(nd3, nd1) and np.array_equal(w3, w1)
     if fmt == "binary":  # malformed streams are refused, not trusted: the flag without the stream, truncated, a parent id out of range
         args = (6, 3, parent, V["node_weight"], V["word_id"], V["node_desc"])
         for name, kw in (("z", dict(compressed=True)), ("t", dict(truncate=1000)), ("p", dict(bad_parent=True)),

@@ -1080,13 +1080,18 @@ def se3_log(R, t):
 
 
 # ----------------------------------------------------------------------------- loop closing / local mapping / harness I/O
-def sim3_ransac_eval(pc1, pc2, px1, px2, maxerr1, maxerr2, cam4, triplets, fix_scale=True, want_flags=True):
-    """Sim3Solver hypotheses (sim3Solver.cpp:98-280) in one launch -> (counts [K], flags [K, n], sims [K, 13])."""
-    a = [np.ascontiguousarray(v, np.float64) for v in (pc1, pc2, px1, px2)]
-    e1, e2 = np.ascontiguousarray(maxerr1, np.int32), np.ascontiguousarray(maxerr2, np.int32)
+def sim3_ransac_eval(pc1, pc2, px1, px2, maxerr1, maxerr2, cam4, triplets, fix_scale=True, want_flags=True, resident_n=None):
+    """Sim3Solver hypotheses (sim3Solver.cpp:98-280) in one launch -> (counts [K], flags [K, n], sims [K, 13]).
+    resident_n: pass None arrays and the previous call's n to evaluate against the correspondences that call uploaded."""
     tr = np.ascontiguousarray(triplets, np.int32).reshape(-1, 3)
     cam = np.ascontiguousarray(cam4, np.float32)
-    n, K = len(a[0]), len(tr)
+    if resident_n is not None:
+        a, e1, e2, n = [None] * 4, None, None, int(resident_n)
+    else:
+        a = [np.ascontiguousarray(v, np.float64) for v in (pc1, pc2, px1, px2)]
+        e1, e2 = np.ascontiguousarray(maxerr1, np.int32), np.ascontiguousarray(maxerr2, np.int32)
+        n = len(a[0])
+    K = len(tr)
     counts, flags, sims = np.zeros(K, np.int32), np.zeros((K, max(n, 1)), np.uint8), np.zeros((K, 13))
     check(lib().vo_sim3_ransac_eval(n, _p(a[0]), _p(a[1]), _p(a[2]), _p(a[3]), _p(e1), _p(e2), _p(cam), K, _p(tr),
                                     int(bool(fix_scale)), _p(counts), _p(flags) if want_flags else None, _p(sims)),

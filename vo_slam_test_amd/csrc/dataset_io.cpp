@@ -582,15 +582,24 @@ int vo_vocab_load(const char *path, vo_vocab **out, int *n_nodes, int *n_words, 
       std::string body;
       std::vector<uint8_t> chunk, plain;
       for (uint32_t c = 0; c < n_chunks; c++) {
+        // a chunk's header is 3 bytes (flags, compressed size, decompressed size: inputs below 216 bytes) or 9 (32-bit sizes,
+        // flag bit 1); the last chunk of a stream can be as short as 4 bytes, so only what the header form needs is read
+        // before the size is known (reading 9 bytes up front refused such files)
         chunk.assign(9, 0);
-        f.read(reinterpret_cast<char *>(chunk.data()), 9);
-        const size_t csize = (chunk[0] & 2) ? ((size_t)chunk[1] | (size_t)chunk[2] << 8 | (size_t)chunk[3] << 16 | (size_t)chunk[4] << 24) : chunk[1];
-        if (!f || csize < 9 || csize > (1u << 24)) {
+        f.read(reinterpret_cast<char *>(chunk.data()), 3);
+        const bool long_hdr = (chunk[0] & 2) != 0;
+        size_t have = 3;
+        if (long_hdr) {
+          f.read(reinterpret_cast<char *>(chunk.data() + 3), 6);
+          have = 9;
+        }
+        const size_t csize = long_hdr ? ((size_t)chunk[1] | (size_t)chunk[2] << 8 | (size_t)chunk[3] << 16 | (size_t)chunk[4] << 24) : chunk[1];
+        if (!f || csize < have + 1 || csize > (1u << 24)) {
           vo::set_error("%s: chunk %u of the compressed vocabulary has size %zu", path, c, csize);
           return VO_ERR_INVALID;
         }
-        chunk.resize(csize);
-        f.read(reinterpret_cast<char *>(chunk.data() + 9), (std::streamsize)(csize - 9));
+        chunk.resize(std::max<size_t>(csize, 9));
+        f.read(reinterpret_cast<char *>(chunk.data() + have), (std::streamsize)(csize - have));
         std::string why;
         if (!f || !qlz_decompress_chunk(chunk.data(), csize, plain, why)) {
           vo::set_error("%s: chunk %u of the compressed (QuickLZ) vocabulary cannot be decoded: %s -- re-save it with "

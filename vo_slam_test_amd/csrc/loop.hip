@@ -209,8 +209,12 @@ int vo_sim3_ransac_eval(int n, const double *cam1_points, const double *cam2_poi
                         const double *pixels2, const int32_t *max_err1, const int32_t *max_err2, const float cam4[4],
                         int n_hypotheses, const int32_t *triplets, int fix_scale, int32_t *counts, uint8_t *inlier_flags,
                         double *sims) {
+  // all six correspondence arrays NULL: the correspondences this host thread uploaded with its previous call stay in place
+  // (Sim3Solver::iterate evaluates one hypothesis per trip to keep rand() in step with the reference: five trips per call
+  // of the loop closer, one upload -- ADVICE r4)
+  const bool resident = !cam1_points && !cam2_points && !pixels1 && !pixels2 && !max_err1 && !max_err2;
   if (n < 0 || n_hypotheses < 0 || !cam4 || (n_hypotheses > 0 && (!triplets || !counts || !sims)) ||
-      (n > 0 && (!cam1_points || !cam2_points || !pixels1 || !pixels2 || !max_err1 || !max_err2)))
+      (n > 0 && !resident && (!cam1_points || !cam2_points || !pixels1 || !pixels2 || !max_err1 || !max_err2)))
     return VO_ERR_INVALID;
   if (n_hypotheses == 0) return VO_OK;
   for (int k = 0; k < 3 * n_hypotheses; k++)
@@ -220,14 +224,24 @@ int vo_sim3_ransac_eval(int n, const double *cam1_points, const double *cam2_poi
     }
   VO_CHECK(vo::ensure_device());
   thread_local vo::ScratchBuf d1, d2, p1, p2, e1, e2, tr, cn, fl, sm;
+  thread_local int resident_n = -1;
   hipStream_t st = vo::thread_stream();
   const char *W = "vo_sim3_ransac_eval";
-  VO_CHECK(vo::upload(d1, cam1_points, (size_t)n * 24, st, W));
-  VO_CHECK(vo::upload(d2, cam2_points, (size_t)n * 24, st, W));
-  VO_CHECK(vo::upload(p1, pixels1, (size_t)n * 16, st, W));
-  VO_CHECK(vo::upload(p2, pixels2, (size_t)n * 16, st, W));
-  VO_CHECK(vo::upload(e1, max_err1, (size_t)n * 4, st, W));
-  VO_CHECK(vo::upload(e2, max_err2, (size_t)n * 4, st, W));
+  if (resident && n > 0) {
+    if (resident_n != n) {
+      vo::set_error("vo_sim3_ransac_eval: no correspondences of this size are resident for this thread (%d requested, %d held)", n, resident_n);
+      return VO_ERR_INVALID;
+    }
+  } else {
+    resident_n = -1;
+    VO_CHECK(vo::upload(d1, cam1_points, (size_t)n * 24, st, W));
+    VO_CHECK(vo::upload(d2, cam2_points, (size_t)n * 24, st, W));
+    VO_CHECK(vo::upload(p1, pixels1, (size_t)n * 16, st, W));
+    VO_CHECK(vo::upload(p2, pixels2, (size_t)n * 16, st, W));
+    VO_CHECK(vo::upload(e1, max_err1, (size_t)n * 4, st, W));
+    VO_CHECK(vo::upload(e2, max_err2, (size_t)n * 4, st, W));
+    resident_n = n;
+  }
   VO_CHECK(vo::upload(tr, triplets, (size_t)n_hypotheses * 12, st, W));
   VO_CHECK(cn.reserve((size_t)n_hypotheses * 4));
   VO_CHECK(fl.reserve(std::max<size_t>((size_t)n_hypotheses * n, 64)));

@@ -328,7 +328,13 @@ int vo_chol_solve_split(int n, const double *A_rowmajor_lower, double *b, int c0
   const int s0 = NB * c0;
   std::vector<vo::DevBuf> dA((size_t)n_ranks), dws((size_t)n_ranks);
   std::vector<unsigned long long> own((size_t)n_ranks, 0ull);
-  for (int j = 0; j < c0; j++) own[(size_t)(col_part[j] % n_ranks)] |= 1ull << j;
+  for (int j = 0; j < c0; j++) {
+    if (col_part[j] < 0) {  // (a negative segment number would index in front of `own`: ADVICE r4)
+      vo::set_error("vo_chol_solve_split: col_part[%d] = %d", j, col_part[j]);
+      return VO_ERR_INVALID;
+    }
+    own[(size_t)(col_part[j] % n_ranks)] |= 1ull << j;
+  }
   std::vector<vo::CholPlan *> plans;
   auto cleanup = [&](int rc) {
     for (auto *p : plans) vo::chol_plan_destroy(p);

@@ -34,9 +34,8 @@ using namespace vo::ba;
 // motion-model pose -- one launch instead of four memsets and a copy (a launch or a copy costs ~5 us of a 0.7 ms frame
 // when one camera stream is tracked at a time).
 __global__ __launch_bounds__(256) void k_track_prep(int cap, int last_stride, int *assigned, uint8_t *fhas, uint8_t *fobs,
-                                                    uint8_t *last_matched, const double *pose0, double *pose, int *zero_counter) {
+                                                    uint8_t *last_matched, const double *pose0, double *pose) {
   const int f = blockIdx.x, tid = threadIdx.x;
-  if (f == 0 && tid == 0 && zero_counter) *zero_counter = 0;  // the retry pass's counter (k_track_retry_prep adds to it)
   const long long o = (long long)f * cap;
   for (int i = tid; i < cap; i += 256) assigned[o + i] = -1, fhas[o + i] = 0, fobs[o + i] = 0;
   for (int i = tid; i < last_stride; i += 256) last_matched[(long long)f * last_stride + i] = 0;
@@ -46,13 +45,11 @@ __global__ __launch_bounds__(256) void k_track_prep(int cap, int last_stride, in
 // trackWithMotion's retry (visualOdometry.cpp:241-245): a frame whose first search found fewer than 20 matches has its
 // map-point slots cleared (`fill(mappoints_, nullptr)`) and is searched again at twice the radius.  Per frame: the query
 // count of the second guided call (negative = the frame is left out of it, include/vo_hip.h) and the cleared assignments.
-__global__ __launch_bounds__(256) void k_track_retry_prep(int cap, int nq_last, const int *nm_first, int *assigned, int *retry_nq,
-                                                          int *n_retried) {
+__global__ __launch_bounds__(256) void k_track_retry_prep(int cap, int nq_last, const int *nm_first, int *assigned, int *retry_nq) {
   const int f = blockIdx.x, tid = threadIdx.x;
   const bool retry = nm_first[f] < 20;
   if (tid == 0) {
     retry_nq[f] = retry ? nq_last : -1;
-    if (retry) atomicAdd(n_retried, 1);
   }
   if (!retry) return;
   const long long o = (long long)f * cap;
@@ -256,7 +253,7 @@ struct vo_tracker {
   DevBuf kps, desc, cnt, images, depth;
   DevBuf q0_flags, q0_u, q0_v, q0_aux, q0_level, q0_angle, q0_desc, p0, pf0, last_matched;
   DevBuf q1_flags, q1_u, q1_v, q1_aux, q1_level, q1_viewcos, q1_desc, p1, nrm1, mind1, maxd1, pf1, link1;
-  DevBuf Tcw, pose0, pose, pose_first, resblk, retry_nq, foutl;  // retry_nq: [B] + the retried-frames counter  // resblk: k_track_pack's block (72 bytes per frame + 2 flags)
+  DevBuf Tcw, pose0, pose, pose_first, resblk, retry_nq, foutl;  // retry_nq: [B] query counts of the retry pass  // resblk: k_track_pack's block (72 bytes per frame + 2 flags)
   DevBuf assigned, assigned_first, nm, nm_first, fpoint, fhas, fobs, pts, obs, isg, ranges, index, outlier, ninl, ninl_first,
       nobs_first, ntracked, status;
   PinnedBuf stage;
@@ -451,8 +448,7 @@ int stage_motion(vo_tracker *t, const vo_tracker_params &P) {
                                 cam4, 0, c.width, 0, c.height, t->q0_flags.as<uint8_t>(), t->q0_u.as<float>(),
                                 t->q0_v.as<float>(), t->q0_aux.as<float>(), st));
   hipLaunchKernelGGL(k_track_prep, dim3(B), dim3(256), 0, st, t->cap, t->n_last, t->assigned.as<int>(), t->fhas.as<uint8_t>(),
-                     t->fobs.as<uint8_t>(), t->last_matched.as<uint8_t>(), t->pose0.as<double>(), t->pose.as<double>(),
-                     P.no_retry ? (int *)nullptr : t->retry_nq.as<int>() + B);
+                     t->fobs.as<uint8_t>(), t->last_matched.as<uint8_t>(), t->pose0.as<double>(), t->pose.as<double>());
   q.n_queries = t->nq_last, q.stride = t->n_last, q.flags = t->q0_flags.as<uint8_t>(), q.u = t->q0_u.as<float>();
   q.v = t->q0_v.as<float>(), q.aux = t->q0_aux.as<float>(), q.level = t->q0_level.as<int32_t>();
   q.angle = t->q0_angle.as<float>(), q.desc = t->q0_desc.as<uint8_t>();
@@ -462,9 +458,11 @@ int stage_motion(vo_tracker *t, const vo_tracker_params &P) {
   if (!P.no_retry) {
     // `if (match_num < 20) { fill(mappoints_, nullptr); match_num = searchByProjection(..., 2*radius); }` (:241-245) for
     // the frames that need it, on the device: the second call leaves every other frame out (n_per_frame < 0)
-    int *rq = t->retry_nq.as<int>();  // (rq[B], the count of retried frames, was zeroed by k_track_prep)
+    // (three short dispatches -- this one, a candidate grid whose workgroups return at once for frames that are left out, a
+    //  replay -- even when no frame needs them: ~12 us per batch, inside bench.py's `match_last_frame` stage)
+    int *rq = t->retry_nq.as<int>();
     hipLaunchKernelGGL(k_track_retry_prep, dim3(B), dim3(256), 0, st, t->cap, t->nq_last, t->nm_first.as<int>(),
-                       t->assigned.as<int>(), rq, rq + B);
+                       t->assigned.as<int>(), rq);
     q.n_per_frame = rq;
     gp.radius = 2.f * P.radius;
     VO_CHECK(vo_match_guided_dev(t->frames, 0, B, &q, &gp, nullptr, t->assigned.as<int32_t>(), nullptr,
@@ -488,7 +486,7 @@ int stage_ref_keyframe(vo_tracker *t, const vo_tracker_params &P) {
     return VO_ERR_INVALID;
   }
   hipLaunchKernelGGL(k_track_prep, dim3(B), dim3(256), 0, st, t->cap, t->n_last, t->assigned.as<int>(), t->fhas.as<uint8_t>(),
-                     t->fobs.as<uint8_t>(), t->last_matched.as<uint8_t>(), t->pose0.as<double>(), t->pose.as<double>(), (int *)nullptr);
+                     t->fobs.as<uint8_t>(), t->last_matched.as<uint8_t>(), t->pose0.as<double>(), t->pose.as<double>());
   std::vector<vo::RefKeyFrame> kfs((size_t)B);
   for (int f = 0; f < B; f++) {
     const RefKfHost &k = t->ref_kf[f];
@@ -820,6 +818,31 @@ int vo_tracker_set_ref_keyframe(vo_tracker *t, const vo_vocab *vocab, int n, con
   if (!t || !vocab || n < 0 || n > t->n_last || !Tcw12 || !nodes || (n > 0 && (!points || !flags || !angle || !desc)))
     return VO_ERR_INVALID;
   const int B = t->B;
+  // every view is validated BEFORE anything is enqueued or any tracker state changes: a DBoW3::FeatureVector as CSR
+  // has start[0] == 0, non-decreasing offsets, every feature index below n; an empty view may carry null arrays
+  for (int f = 0; f < B; f++) {
+    const vo_bow_view *v = nodes[f];
+    if (!v || v->n_nodes < 0 || (v->n_nodes > 0 && (!v->node_id || !v->start || !v->feat))) {
+      vo::set_error("vo_tracker_set_ref_keyframe: frame %d has no usable vocabulary-node view", f);
+      return VO_ERR_INVALID;
+    }
+    if (v->n_nodes == 0) continue;
+    if (v->start[0] != 0) {
+      vo::set_error("vo_tracker_set_ref_keyframe: frame %d: start[0] = %d", f, v->start[0]);
+      return VO_ERR_INVALID;
+    }
+    for (int j = 0; j < v->n_nodes; j++)
+      if (v->start[j + 1] < v->start[j]) {
+        vo::set_error("vo_tracker_set_ref_keyframe: frame %d: node offsets decrease at node %d", f, j);
+        return VO_ERR_INVALID;
+      }
+    const int nf = v->start[v->n_nodes];
+    for (int i = 0; i < nf; i++)
+      if ((int)v->feat[i] < 0 || (int)v->feat[i] >= n) {
+        vo::set_error("vo_tracker_set_ref_keyframe: frame %d names feature %u of %d", f, v->feat[i], n);
+        return VO_ERR_INVALID;
+      }
+  }
   std::vector<double> p6((size_t)B * 6);
   for (int f = 0; f < B; f++) VO_CHECK(vo_se3_log(Tcw12 + 12 * f, Tcw12 + 12 * f + 9, p6.data() + 6 * f));
   VO_CHECK(t->stage.reserve((size_t)B * 144));
@@ -832,27 +855,29 @@ int vo_tracker_set_ref_keyframe(vo_tracker *t, const vo_vocab *vocab, int n, con
   VO_CHECK(put_rows(t, t->p0, points, n, t->n_last, 24, "points"));
   VO_CHECK(put_rows(t, t->pf0, flags, n, t->n_last, 1, "flags"));
   VO_CHECK(put_rows(t, t->q0_flags, flags, n, t->n_last, 1, "flags"));
-  t->ref_vocab = vocab;
-  t->ref_kf.assign((size_t)B, RefKfHost{});
+  std::vector<RefKfHost> kfs((size_t)B);
   for (int f = 0; f < B; f++) {
-    RefKfHost &k = t->ref_kf[f];
+    RefKfHost &k = kfs[f];
     const vo_bow_view *v = nodes[f];
-    if (!v || v->n_nodes < 0 || (v->n_nodes > 0 && (!v->node_id || !v->start || !v->feat))) return VO_ERR_INVALID;
     k.n = n;
     k.valid.resize((size_t)n), k.angle.assign(angle + (size_t)f * n, angle + (size_t)(f + 1) * n);
     for (int i = 0; i < n; i++) k.valid[i] = flags[(size_t)f * n + i] & 1;
     k.desc.assign(desc + (size_t)f * n * 32, desc + (size_t)(f + 1) * n * 32);
-    k.node_id.assign(v->node_id, v->node_id + v->n_nodes);
-    k.start.assign(v->start, v->start + v->n_nodes + 1);
-    const int nf = v->n_nodes > 0 ? v->start[v->n_nodes] : 0;
-    k.feat.assign(v->feat, v->feat + nf);
-    for (int i = 0; i < nf; i++)
-      if ((int)k.feat[i] >= n) return VO_ERR_INVALID;
+    if (v->n_nodes > 0) {
+      k.node_id.assign(v->node_id, v->node_id + v->n_nodes);
+      k.start.assign(v->start, v->start + v->n_nodes + 1);
+      k.feat.assign(v->feat, v->feat + v->start[v->n_nodes]);
+    } else {
+      k.start.assign(1, 0);
+    }
     k.view.n_nodes = v->n_nodes, k.view.node_id = reinterpret_cast<const uint32_t *>(k.node_id.data()), k.view.start = k.start.data(),
     k.view.feat = k.feat.data();
   }
+  VO_HIP_CHECK(hipStreamSynchronize(t->st));  // (the staging block may be reused by the next call)
+  t->ref_vocab = vocab;  // only now: a call that failed above leaves the tracker's reference key-frame as it was
+  t->ref_kf.swap(kfs);
+  // the views point into the vectors' heap blocks, which the swap moved along with their owners
   t->nq_last = n;
-  VO_HIP_CHECK(hipStreamSynchronize(t->st));
   return VO_OK;
 }
 
