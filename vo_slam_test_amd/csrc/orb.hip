@@ -366,13 +366,15 @@ __host__ __device__ __forceinline__ int fast_align16(int v) { return (v + 15) & 
 //    the rare overflow path recompute the margins instead of reading them back;
 // Results are bit-identical to round 2's kernel and to the oracle (tests/test_gpu_orb.py); 0.253 -> 0.210 ms per 256
 // frames.  Early-exit builds (1024 frames, round 4: 0.72 ms) return after staging at 0.275, after the first margin walk
-// at 0.45, after the arc scores at 0.65; the minThFAST round costs 0.05.  The 0.275 is NOT a latency that the full
-// kernel leaves exposed: a form of this kernel in which a wave takes 2 / 4 / 8 consecutive cells and fetches the next
-// cell's tile into registers while it works on the current one (tools/attic/k_fast_cell_prefetch_r04.diff.txt) ran
-// at 0.76 / 0.76 / 0.77 ms with 7 waves per SIMD (71 registers), 0.80 with 6 and 1.11 with 8 (spills) -- no
-// dependence on the cells per wave, ~5 % per resident wave.  An early-exit build of 860 k four-line waves measures
-// the dispatcher; in the full kernel the staging is covered and what is left is instruction issue (VALU + LDS,
-// DESIGN.md section 7) with the dependent LDS round trips that the resident waves overlap.
+// at 0.45, after the arc scores at 0.65; the minThFAST round costs 0.05 -- the phases are ADDITIVE (0.275 + 0.17 + 0.20 +
+// 0.07 = 0.715).  What the first 0.275 is was settled in round 5 (profiles/r05_ab_fused.txt): a wave that takes 2 / 4 / 8
+// cells in a PLAIN loop (no register prefetch: 63 registers, still 8 waves per SIMD) runs at 0.70 / 0.685 / 0.71 ms -- the
+// dispatch of 835 k one-cell waves is worth 5 %, and 4 cells per wave is what the kernel does now (kFastCpw).  The rest of
+// the 0.275 is the latency of the tile's LDS-DMA as seen by a kernel that does nothing else: the fused level pass, which
+// stages 2.2x larger tiles with a quarter of the workgroups, measures the same 0.45 ms for "staging only" -- ~8 workgroups
+// per CU each waiting ~3 us for its tile.  In the full kernel that wait is overlapped by the other resident waves' walks
+// and scores; the multi-cell forms of round 4 that tried to hide it by a register prefetch paid more in occupancy (71
+// registers, 7 waves: 0.76 ms) than there was to win.
 // ------------------------------------------------------------------------------------------
 #define VO_OP16(name, ins)                                                   \
   __device__ __forceinline__ unsigned name(unsigned a, unsigned b) {          \
