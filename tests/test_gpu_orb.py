@@ -11,7 +11,7 @@ pytestmark = pytest.mark.gpu
 def ext(vo, request):
     """both forms of the level pipeline: the fused per-level pass (default) and the three separate kernels"""
     e = vo.OrbExtractor(1000, 1.2, 8, 20, 7)
-    e.set_fused(request.param == "fused")
+    e.set_fused(int(request.param == "fused"))
     yield e
     e.close()
 
@@ -22,7 +22,7 @@ def make_ext(vo, request):
 
     def make(*args):
         e = vo.OrbExtractor(*args)
-        e.set_fused(request.param == "fused")
+        e.set_fused(int(request.param == "fused"))
         made.append(e)
         return e
 

@@ -181,7 +181,7 @@ class OrbExtractor:
 
     def set_fused(self, on: bool):
         """vo_orb_set_option(VO_ORB_OPT_FUSED_LEVEL_PASS): the fused per-level pass (default) or the three separate kernels"""
-        check(lib().vo_orb_set_option(self._h, 1, int(bool(on))), "vo_orb_set_option")
+        check(lib().vo_orb_set_option(self._h, 1, int(on)), "vo_orb_set_option")  # 0 / False: separate kernels; 1 / True: k_level_pass; 2: k_level_pass2
 
     def level_pass_plan(self, width, height):
         """per level: dict(fused, tile_pitch, tile_rows, score_rows, blocks, lds_bytes, list_cap) of the fused pass"""

@@ -1695,7 +1695,7 @@ struct vo_orb {
   int blur_jobs = 0;               // k_blur_groups jobs per frame quad
   int blur_job0[kMaxLevels + 1] = {0};  // first job of every level (per-level launches next to fused levels)
   // k_level_pass (orb_level_pass.inc): per level whether it takes the fused pass, its tile pitch / rows, block table, LDS bytes
-  bool fused = false;              // vo_orb_set_option(VO_ORB_OPT_FUSED_LEVEL_PASS): opt-in, measured 6 % slower than the three kernels (profiles/r05_ab_fused.txt)
+  int fused = 0;                   // vo_orb_set_option(VO_ORB_OPT_FUSED_LEVEL_PASS): 0 the three kernels (default), 1 k_level_pass (profiles/r05_ab_fused.txt)
   bool lp_ok[kMaxLevels] = {false};
   int lp_tp[kMaxLevels] = {0}, lp_tile_rows[kMaxLevels] = {0}, lp_score_rows[kMaxLevels] = {0}, lp_blocks[kMaxLevels] = {0};
   int lp_tab_off[kMaxLevels] = {0}, lp_list_cap[kMaxLevels] = {0};
@@ -2424,7 +2424,7 @@ int vo_orb_set_stream(vo_orb *h, void *s) {
 int vo_orb_set_option(vo_orb *h, int option, int value) {
   if (!h) return VO_ERR_INVALID;
   if (option == VO_ORB_OPT_FUSED_LEVEL_PASS) {
-    h->fused = value != 0;
+    h->fused = value != 0 ? 1 : 0;
     return VO_OK;
   }
   vo::set_error("vo_orb_set_option: unknown option %d", option);
