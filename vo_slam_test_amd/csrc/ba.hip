@@ -173,6 +173,9 @@ struct PoseLm {
 #ifndef VO_POSE_ND
 #define VO_POSE_ND 4
 #endif
+#ifndef VO_POSE_PINGPONG
+#define VO_POSE_PINGPONG 1
+#endif
 struct ObsView {
   const VO_GLOBAL double *pts, *obs, *isg;
   VO_GLOBAL uint8_t *outlier;  // the result, and the skip mask of a pass
@@ -184,6 +187,61 @@ struct ObsView {
 };
 
 // One observation's contribution to H (upper 21), g (6) and the cost; unscaled, loss-corrected.
+//
+// The pose Jacobian of edge_eval factors as J = A [I | X]: A = d r / d pc (rows u [a 0 c], v [0 b d], uR [a 0 e]) and
+// X = -[pc]x, so with M = rho1 A^T A (3 x 3, M01 = 0) and m = rho1 A^T r
+//     H += [ M    M X   ]      g += [ m     ]
+//          [ .  X^T M X ]           [ X^T m ]
+// and every column of X has two non-zeros: 15 + 14 + 12 multiply-adds and 14 adds for H (the dense row products of the
+// 2-3 x 6 Jacobian: 60 + 15), the rotation half of J is never formed.  (Round 5: 0.271 -> see DESIGN section 5.)
+#ifndef VO_POSE_FACTORED
+#define VO_POSE_FACTORED 1
+#endif
+#if VO_POSE_FACTORED
+__device__ __forceinline__ void pose_obs_term(const PoseCache &P, const double (&pw)[3], double ou, double ov, double our,
+                                              double is, const Cam &K, double hm, double hs, double (&acc)[28]) {
+  // R p + t as three multiply-add chains that start from t (trans_point adds t last: a multiply and an add more per row)
+  const double x = __builtin_fma(P.R[0], pw[0], __builtin_fma(P.R[1], pw[1], __builtin_fma(P.R[2], pw[2], P.t[0])));
+  const double y = __builtin_fma(P.R[3], pw[0], __builtin_fma(P.R[4], pw[1], __builtin_fma(P.R[5], pw[2], P.t[1])));
+  const double z = __builtin_fma(P.R[6], pw[0], __builtin_fma(P.R[7], pw[1], __builtin_fma(P.R[8], pw[2], P.t[2])));
+  const double invz = inv_fast(z), invz2 = invz * invz;
+  const bool stereo = !(our < 0);
+  const double uhat = K.fx * x * invz + K.cx;
+  const double r0 = (ou - uhat) * is;
+  const double r1 = (ov - (K.fy * y * invz + K.cy)) * is;
+  const double r2 = stereo ? (our - (uhat - K.bf * invz)) * is : 0.0;
+  const double a = -invz * K.fx, b = -invz * K.fy, c = x * invz2 * K.fx, d = y * invz2 * K.fy;  // Jp[0], [7], [2], [8]
+  const double a2 = stereo ? a : 0.0, e = stereo ? c - K.bf * invz2 : 0.0;                        // Jp[12], [14]
+  const double s = r0 * r0 + r1 * r1 + r2 * r2;
+  double rho0, rho1;
+  huber(stereo ? hs : hm, s, rho0, rho1);
+  acc[27] += 0.5 * rho0;
+  const double wa = rho1 * a, wa2 = rho1 * a2, wb = rho1 * b, wc = rho1 * c, wd = rho1 * d, we = rho1 * e;
+  const double M00 = __builtin_fma(wa, a, wa2 * a2), M02 = __builtin_fma(wa, c, wa2 * e), M11 = wb * b, M12 = wb * d;
+  const double M22 = __builtin_fma(wc, c, __builtin_fma(wd, d, we * e));
+  const double m0 = __builtin_fma(wa, r0, wa2 * r2), m1 = wb * r1, m2 = __builtin_fma(wc, r0, __builtin_fma(wd, r1, we * r2));
+  // M X, X = [[0 z -y] [-z 0 x] [y -x 0]]
+  const double X00 = y * M02, X10 = __builtin_fma(y, M12, -(z * M11)), X20 = __builtin_fma(y, M22, -(z * M12));
+  const double X01 = __builtin_fma(z, M00, -(x * M02)), X11 = -(x * M12), X21 = __builtin_fma(z, M02, -(x * M22));
+  const double X02 = -(y * M00), X12 = x * M11, X22 = __builtin_fma(x, M12, -(y * M02));
+  // packed upper triangle, row by row: (0,b) 0..5, (1,b) 6..10, (2,b) 11..14, (3,b) 15..17, (4,b) 18..19, (5,5) 20
+  acc[0] += M00, acc[2] += M02, acc[6] += M11, acc[7] += M12, acc[11] += M22;
+  acc[3] += X00, acc[4] += X01, acc[5] += X02;
+  acc[8] += X10, acc[9] += X11, acc[10] += X12;
+  acc[12] += X20, acc[13] += X21, acc[14] += X22;
+  // X^T (M X): column a of X against column b of M X
+  acc[15] = __builtin_fma(y, X20, __builtin_fma(-z, X10, acc[15]));
+  acc[16] = __builtin_fma(y, X21, __builtin_fma(-z, X11, acc[16]));
+  acc[17] = __builtin_fma(y, X22, __builtin_fma(-z, X12, acc[17]));
+  acc[18] = __builtin_fma(z, X01, __builtin_fma(-x, X21, acc[18]));
+  acc[19] = __builtin_fma(z, X02, __builtin_fma(-x, X22, acc[19]));
+  acc[20] = __builtin_fma(x, X12, __builtin_fma(-y, X02, acc[20]));
+  acc[21] += m0, acc[22] += m1, acc[23] += m2;
+  acc[24] = __builtin_fma(y, m2, __builtin_fma(-z, m1, acc[24]));
+  acc[25] = __builtin_fma(z, m0, __builtin_fma(-x, m2, acc[25]));
+  acc[26] = __builtin_fma(x, m1, __builtin_fma(-y, m0, acc[26]));
+}
+#else
 __device__ __forceinline__ void pose_obs_term(const PoseCache &P, const double (&pw)[3], double ou, double ov, double our,
                                               double is, const Cam &K, double hm, double hs, double (&acc)[28]) {
   double r[3], J[18];
@@ -221,6 +279,7 @@ __device__ __forceinline__ void pose_obs_term(const PoseCache &P, const double (
   for (int a = 2; a < 6; a++)
     acc[21 + a] = __builtin_fma(w0[a], r[0], __builtin_fma(w1[a], r[1], __builtin_fma(w2[a], r[2], acc[21 + a])));
 }
+#endif
 
 // One linearisation pass over the observations that are not flagged.  WAVE (one wavefront per frame, nothing else on
 // its SIMD to run while a load is in flight): observations are requested in batches of four trips, one batch ahead
@@ -230,6 +289,46 @@ __device__ __forceinline__ void pose_accumulate(const PoseCache &P, int n, const
                                                 double (&acc)[28]) {
 #pragma unroll
   for (int i = 0; i < 28; i++) acc[i] = 0;
+#if VO_POSE_PINGPONG
+  if (WAVE) {
+    // Round 5: (i) the loads take the wave-uniform base from scalar registers and a 32-bit byte offset per lane (the int
+    // index cost twelve 64-bit address operations per observation); (ii) two register sets that swap roles in a loop
+    // unrolled by two, so the "next batch becomes the current one" copies -- 14 moves per observation -- are gone.
+    const unsigned lane = threadIdx.x, last = (unsigned)(n - 1);
+    constexpr int ND = VO_POSE_ND;
+    struct Ob { double pw[3], ou, ov, our, is; unsigned skip; };
+    const VO_GLOBAL char *bp = (const VO_GLOBAL char *)V.pts, *bo = (const VO_GLOBAL char *)V.obs, *bi = (const VO_GLOBAL char *)V.isg;
+    const VO_GLOBAL uint8_t *bs = V.outlier;
+    auto request = [&](unsigned base, Ob (&o)[ND]) {
+#pragma unroll
+      for (int k = 0; k < ND; k++) {
+        const unsigned i = min(base + 64u * k + lane, last);  // past the end: a harmless re-read
+        const unsigned o24 = __umul24(i, 24u), o8 = i * 8u;  // (v_mul_lo_u32 is a quarter-rate instruction)
+        o[k].pw[0] = *(const VO_GLOBAL double *)(bp + o24), o[k].pw[1] = *(const VO_GLOBAL double *)(bp + o24 + 8);
+        o[k].pw[2] = *(const VO_GLOBAL double *)(bp + o24 + 16);
+        o[k].ou = *(const VO_GLOBAL double *)(bo + o24), o[k].ov = *(const VO_GLOBAL double *)(bo + o24 + 8);
+        o[k].our = *(const VO_GLOBAL double *)(bo + o24 + 16);
+        o[k].is = *(const VO_GLOBAL double *)(bi + o8);
+        o[k].skip = bs[i];
+      }
+    };
+    auto eval = [&](unsigned base, const Ob (&o)[ND]) {
+#pragma unroll
+      for (int k = 0; k < ND; k++)
+        if (base + 64u * k + lane <= last && !o[k].skip) pose_obs_term(P, o[k].pw, o[k].ou, o[k].ov, o[k].our, o[k].is, K, hm, hs, acc);
+    };
+    Ob A[ND], B[ND];
+    request(0, A);
+#pragma unroll 1
+    for (unsigned base = 0; base <= last; base += 2 * ND * 64) {
+      request(base + ND * 64, B);
+      eval(base, A);
+      request(base + 2 * ND * 64, A);
+      eval(base + ND * 64, B);  // (a batch wholly past the end evaluates nothing: every lane fails the range test)
+    }
+    return;
+  }
+#endif
   if (WAVE) {
     const int lane = threadIdx.x;
     constexpr int ND = VO_POSE_ND;
