@@ -19,9 +19,6 @@
 //                 single GPU: the last block also runs the trust-region update
 //   k_ba_reduce2 / k_ba_update  (sharded) second payload and trust-region bookkeeping
 #include "ba_math.h"
-#ifndef VO_POSE_V
-#define VO_POSE_V 1  // developer A/B switches (tools/ab_pose.sh): 1 value-major scratch (product: 0.284 -> 0.280 ms), 2 LDS-only hand-offs (no effect), 4 no prefetch behind the last batch (+6 %: the branch breaks the software pipeline)
-#endif
 #include "vo_common.h"
 
 #include <algorithm>
@@ -347,7 +344,7 @@ __device__ __forceinline__ void pose_accumulate(const PoseCache &P, int n, const
     for (int base = 0; base < n; base += ND * 64) {
       Ob nxt[ND];
       // the next batch travels while this one is evaluated (none behind the last one: those loads would only be waited for)
-      if (!(VO_POSE_V & 4) || base + ND * 64 < n) request(base + ND * 64, nxt);
+      request(base + ND * 64, nxt);
 #pragma unroll
       for (int k = 0; k < ND; k++)
         if (base + 64 * k + lane < n && !cur[k].skip)
@@ -412,31 +409,52 @@ __device__ __forceinline__ void wave_lds_sync() {  // LDS hand-off between lanes
   __builtin_amdgcn_wave_barrier();
 }
 
-// 64 lanes x 28 partial sums -> 28 totals at dst (LDS), in a fixed order.  Two passes of 14 values through a
-// [64][15] scratch: lane l stores its 14 values as row l, lane 4 v + q sums rows q, q + 4, ... of column v, the four
-// quarter sums meet by two quad permutes.  About 110 instructions for what 28 DPP / readlane wave sums did in 1000
-// (a third of the instructions the round-2 kernel executed per LM iteration).
-// Layout (round 4): value-major at a pitch of 68 doubles -- scratch[k][lane].  A lane's stores of one value land on
-// consecutive doubles across the wavefront, and the column reads of lane 4 v + q (rows 4 j + q of value v) fall on banks
-// 8 v + 2 q + 8 j (mod 64): distinct inside each half-wave, where the lane-major [64][15] layout of round 3 read two-way
-// conflicted (49 % of the kernel's LDS cycles).  The hand-offs wait for LDS only: a wavefront-scope fence also waits for
-// vmcnt(0), i.e. for whatever the observation prefetch still has in flight.
-constexpr int kPoseRedPitch = 68;
-constexpr int kPoseRedScratch = (VO_POSE_V & 1) ? 14 * kPoseRedPitch : 64 * 15;
-__device__ __forceinline__ void wave_lds_handoff() {
-#if VO_POSE_V & 2
-  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-  __builtin_amdgcn_wave_barrier();
-#else
-  wave_lds_sync();
-#endif
-}
+// 64 lanes x 28 partial sums -> 28 totals at dst (LDS), in a fixed order: a transpose through LDS instead of 28 x 6
+// DPP / readlane steps (about 110 instructions for what those did in 1000).  Layout: value-major, scratch[k][lane] at a
+// pitch of kPoseRedPitch doubles -- a lane's stores of one value land on consecutive doubles across the wavefront.
+//   ONE_PASS (the one-wavefront kernel, round 5): all 28 values in one trip: lane 2 v + h sums rows h, h + 2, ... of value v
+//   (32 loads in flight, a pairwise tree), the halves meet by one quad permute.  Pitch 66: the reads of a half-wave fall on
+//   banks 4 v + 4 j + 2 h (mod 64), all distinct.  One store / hand-off / load / hand-off chain per linearisation instead of two.
+//   Two passes of 14 values (the 256-thread form: four scratch areas must fit next to each other): lane 4 v + q sums rows
+//   q, q + 4, ..., two quad permutes; pitch 68: banks 8 v + 2 q + 8 j, distinct inside each half-wave (the lane-major
+//   [64][15] layout of round 3 read two-way conflicted: 49 % of the kernel's LDS cycles).
+// The hand-offs wait for LDS only where it matters: a wavefront-scope fence also waits for vmcnt(0).
+template <bool ONE_PASS>
+struct PoseRed {
+  static constexpr int kPitch = ONE_PASS ? 66 : 68;
+  static constexpr int kScratch = (ONE_PASS ? 28 : 14) * kPitch;
+};
+__device__ __forceinline__ void wave_lds_handoff() { wave_lds_sync(); }
+template <bool ONE_PASS>
 __device__ __forceinline__ void wave_reduce28(const double (&v)[28], double *scratch, double *dst) {
-  const int lane = threadIdx.x & 63, vi = lane >> 2, q = lane & 3;
+  constexpr int P = PoseRed<ONE_PASS>::kPitch;
+  const int lane = threadIdx.x & 63;
+  if (ONE_PASS) {
+    const int vi = lane >> 1, h = lane & 1;
+#pragma unroll
+    for (int k = 0; k < 28; k++) scratch[k * P + lane] = v[k];
+    wave_lds_handoff();
+    double t = 0;
+    if (lane < 56) {
+      double u[32];
+#pragma unroll
+      for (int j = 0; j < 32; j++) u[j] = scratch[vi * P + 2 * j + h];
+#pragma unroll
+      for (int w = 16; w >= 1; w >>= 1)
+#pragma unroll
+        for (int j = 0; j < w; j++) u[j] += u[j + w];
+      t = u[0];
+    }
+    t += dpp_f64<0xB1>(t);  // quad_perm [1,0,3,2]
+    if (lane < 56 && h == 0) dst[vi] = t;
+    wave_lds_handoff();
+    return;
+  }
+  const int vi = lane >> 2, q = lane & 3;
 #pragma unroll
   for (int c = 0; c < 2; c++) {
 #pragma unroll
-    for (int k = 0; k < 14; k++) scratch[(VO_POSE_V & 1) ? k * kPoseRedPitch + lane : lane * 15 + k] = v[14 * c + k];
+    for (int k = 0; k < 14; k++) scratch[k * P + lane] = v[14 * c + k];
     wave_lds_handoff();
     double t = 0;
     if (lane < 56) {
@@ -444,7 +462,7 @@ __device__ __forceinline__ void wave_reduce28(const double (&v)[28], double *scr
       // summed pairwise in a fixed order
       double u[16];
 #pragma unroll
-      for (int j = 0; j < 16; j++) u[j] = scratch[(VO_POSE_V & 1) ? vi * kPoseRedPitch + 4 * j + q : (4 * j + q) * 15 + vi];
+      for (int j = 0; j < 16; j++) u[j] = scratch[vi * P + 4 * j + q];
 #pragma unroll
       for (int w = 8; w >= 1; w >>= 1)
 #pragma unroll
@@ -462,7 +480,8 @@ __device__ __forceinline__ void wave_reduce28(const double (&v)[28], double *scr
 // and at the candidate
 template <bool WAVE>
 struct PoseLds {
-  static constexpr int kRed = WAVE ? kPoseRedScratch : 4 * kPoseRedScratch + 4 * 28;  // per-wave scratch, then the wave totals
+  static constexpr int kScratch = PoseRed<WAVE>::kScratch;
+  static constexpr int kRed = WAVE ? kScratch : 4 * kScratch + 4 * 28;  // per-wave scratch, then the wave totals
   double red[kRed];
   double acc[28];   // linearisation at x: 21 + 6 + 1 sums, uniform over the workgroup
   double cand[28];  // ... at the trial point
@@ -483,15 +502,16 @@ __device__ void pose_lm(double x[6], int n, const ObsView &V, const Cam &K, doub
     double v[28];
     pose_accumulate<WAVE>(pose_cache_se3(T), n, V, K, hm, hs, v);
     if (WAVE) {
-      wave_reduce28(v, S.red, dst);
+      wave_reduce28<true>(v, S.red, dst);
     } else {
       // every wavefront reduces its lanes through its own scratch (the same transpose as the one-wavefront kernel: a
       // tenth of the instructions of 28 DPP / readlane sums -- this path is the latency of ONE frame), then 28 threads add
       // the wave totals in wave order
       const int wave = threadIdx.x >> 6, nw = (int)blockDim.x >> 6;
-      double *tot = S.red + 4 * kPoseRedScratch;
+      constexpr int kS = PoseLds<WAVE>::kScratch;
+      double *tot = S.red + 4 * kS;
       __syncthreads();  // the previous pass's totals have been read
-      wave_reduce28(v, S.red + wave * kPoseRedScratch, tot + wave * 28);
+      wave_reduce28<false>(v, S.red + wave * kS, tot + wave * 28);
       __syncthreads();
       if (threadIdx.x < 28) {
         double t = 0;
@@ -501,13 +521,26 @@ __device__ void pose_lm(double x[6], int n, const ObsView &V, const Cam &K, doub
       __syncthreads();
     }
   };
-  linearize(Tx, S.acc);
+  // the linearisation at x and the one at the candidate swap roles when a step is accepted (no copy)
+  double *cur = S.acc, *cnd = S.cand;
+  linearize(Tx, cur);
   double scale[6];
 #pragma unroll
-  for (int a = 0; a < 6; a++) scale[a] = 1.0 / (1.0 + sqrt(S.acc[tri_u(a, a)]));
-  double radius = 1e4, decrease = 2.0, x_cost = S.acc[27];
+  for (int a = 0; a < 6; a++) scale[a] = 1.0 / (1.0 + sqrt(cur[tri_u(a, a)]));
+  // The trust-region scalars: radius and decrease with their reciprocals next to them (decrease is a power of two, so
+  // radius * inv_decrease is the quotient exactly; 1 / radius is refreshed when an accepted step changes the radius) --
+  // the damping of an iteration is six multiplications, not six IEEE divisions in front of the factorisation.
+  double radius = 1e4, inv_radius = 1e-4, decrease = 2.0, inv_decrease = 0.5, x_cost = cur[27];
   const double initial_cost = x_cost;
-  double x_norm = sqrt(x[0] * x[0] + x[1] * x[1] + x[2] * x[2] + x[3] * x[3] + x[4] * x[4] + x[5] * x[5]);
+  auto norm6 = [](const double (&v)[6]) {
+    const double s2 = v[0] * v[0] + v[1] * v[1] + v[2] * v[2] + v[3] * v[3] + v[4] * v[4] + v[5] * v[5];
+    return s2 > 0.0 ? s2 * rsqrt_fast(s2) : 0.0;
+  };
+  double x_norm;
+  {
+    const double xv[6] = {x[0], x[1], x[2], x[3], x[4], x[5]};
+    x_norm = norm6(xv);
+  }
   int iterations = 0, accepted = 0, termination = 0, invalid = 0;
   bool last_ok = false;
   for (int it = 1;; it++) {
@@ -515,12 +548,13 @@ __device__ void pose_lm(double x[6], int n, const ObsView &V, const Cam &K, doub
       termination = 0;
       break;
     }
+    double h[27];  // one batch of LDS reads: the gradient test and the normal equations use the same values
+#pragma unroll
+    for (int i = 0; i < 27; i++) h[i] = cur[i];
     if (last_ok) {
-      double gm = 0, gr[6];
+      double gm = 0;
 #pragma unroll
-      for (int a = 0; a < 6; a++) gr[a] = S.acc[21 + a];
-#pragma unroll
-      for (int a = 0; a < 6; a++) gm = fmax(gm, fabs(gr[a]));
+      for (int a = 0; a < 6; a++) gm = fmax(gm, fabs(h[21 + a]));
       if (gm <= 1e-10) {
         termination = 3;
         break;
@@ -534,17 +568,12 @@ __device__ void pose_lm(double x[6], int n, const ObsView &V, const Cam &K, doub
     last_ok = false;
     // scaled normal equations  H'' = S H S, g'' = S g ; LM diagonal from clamp(diag H'')/radius
     double L[21], g[6], y[6];
-    {
-      double h[27];  // one batch of LDS reads
 #pragma unroll
-      for (int i = 0; i < 27; i++) h[i] = S.acc[i];
+    for (int a = 0; a < 6; a++) {
 #pragma unroll
-      for (int a = 0; a < 6; a++) {
-#pragma unroll
-        for (int b2 = 0; b2 <= a; b2++) L[tri_l(a, b2)] = h[tri_u(b2, a)] * scale[b2] * scale[a];
-        g[a] = h[21 + a] * scale[a];
-        y[a] = g[a];
-      }
+      for (int b2 = 0; b2 <= a; b2++) L[tri_l(a, b2)] = h[tri_u(b2, a)] * scale[b2] * scale[a];
+      g[a] = h[21 + a] * scale[a];
+      y[a] = g[a];
     }
     double model = 0, delta[6];
     {
@@ -553,7 +582,7 @@ __device__ void pose_lm(double x[6], int n, const ObsView &V, const Cam &K, doub
 #pragma unroll
       for (int i = 0; i < 21; i++) Hs[i] = L[i];
 #pragma unroll
-      for (int a = 0; a < 6; a++) L[tri_l(a, a)] += fmin(fmax(L[tri_l(a, a)], 1e-6), 1e32) / radius;
+      for (int a = 0; a < 6; a++) L[tri_l(a, a)] += fmin(fmax(L[tri_l(a, a)], 1e-6), 1e32) * inv_radius;
       bool ok = chol6_packed(L, y);
       if (ok) {
         double gs = 0, sHs = 0;
@@ -576,8 +605,8 @@ __device__ void pose_lm(double x[6], int n, const ObsView &V, const Cam &K, doub
           termination = 4;
           break;
         }
-        radius /= decrease;
-        decrease *= 2.0;
+        radius *= inv_decrease, inv_radius *= decrease;
+        decrease *= 2.0, inv_decrease *= 0.5;
         continue;
       }
     }
@@ -587,40 +616,42 @@ __device__ void pose_lm(double x[6], int n, const ObsView &V, const Cam &K, doub
     se3_plus_keep(Tx, delta, xc, Tc);
     // The candidate is linearised completely in the same pass (its cost is one of the 28 sums): an
     // accepted step -- the common case -- then needs no second sweep over the observations.
-    linearize(Tc, S.cand);
-    double cand = S.cand[27];
+    linearize(Tc, cnd);
+    double cand = cnd[27];
     if (!isfinite(cand)) cand = 1.7976931348623157e308;
     double sn = 0;
 #pragma unroll
     for (int a = 0; a < 6; a++) sn += (x[a] - xc[a]) * (x[a] - xc[a]);
-    if (sqrt(sn) <= 1e-8 * (x_norm + 1e-8)) {
-      termination = 2;
-      break;
+    {
+      const double tol = 1e-8 * (x_norm + 1e-8);  // |step| <= tol, compared as squares (no square root)
+      if (sn <= tol * tol) {
+        termination = 2;
+        break;
+      }
     }
     const double change = x_cost - cand;
     if (fabs(change) <= 1e-6 * x_cost) {
       termination = 1;
       break;
     }
-    const double rel = change / model;
+    const double rel = change * inv_fast(model);
     if (rel > 1e-3) {
 #pragma unroll
       for (int a = 0; a < 6; a++) x[a] = xc[a];
       Tx = Tc;
-      x_norm = sqrt(x[0] * x[0] + x[1] * x[1] + x[2] * x[2] + x[3] * x[3] + x[4] * x[4] + x[5] * x[5]);
-      // the candidate's linearisation becomes the current one
-      if (WAVE) wave_lds_sync(); else __syncthreads();
-      if (threadIdx.x < 28) S.acc[threadIdx.x] = S.cand[threadIdx.x];
-      if (WAVE) wave_lds_sync(); else __syncthreads();
+      x_norm = norm6(xc);
+      double *t = cur;
+      cur = cnd, cnd = t;  // the candidate's linearisation becomes the current one
       x_cost = cand;
       const double t2 = 2.0 * rel - 1.0;
-      radius = fmin(radius / fmax(1.0 / 3.0, 1.0 - t2 * t2 * t2), 1e16);
-      decrease = 2.0;
+      radius = fmin(radius * inv_fast(fmax(1.0 / 3.0, 1.0 - t2 * t2 * t2)), 1e16);
+      inv_radius = inv_fast(radius);
+      decrease = 2.0, inv_decrease = 0.5;
       accepted++;
       last_ok = true;
     } else {
-      radius /= decrease;
-      decrease *= 2.0;
+      radius *= inv_decrease, inv_radius *= decrease;
+      decrease *= 2.0, inv_decrease *= 0.5;
     }
   }
   if (sum && threadIdx.x == 0) {

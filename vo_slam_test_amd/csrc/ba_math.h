@@ -80,7 +80,9 @@ template <bool FAST = false>
 VO_HD Se3 se3_exp(const double xi[6]) {
   Se3 T;
   const double wx = xi[3], wy = xi[4], wz = xi[5];
-  const double theta = sqrt(wx * wx + wy * wy + wz * wz);
+  const double th2 = wx * wx + wy * wy + wz * wz;
+  const double rth = (FAST && th2 > 0.0) ? rsqrt_fast(th2) : 0.0;  // FAST: 1 / theta, and theta = theta^2 / theta
+  const double theta = FAST ? th2 * rth : sqrt(th2);
   const double half = 0.5 * theta;
   double sh, ch;
   if (FAST)
@@ -92,7 +94,7 @@ VO_HD Se3 se3_exp(const double xi[6]) {
     const double t2 = theta * theta;
     imag = 0.5 - 0.0208333 * t2 + 0.000260417 * t2 * t2;
   } else {
-    imag = FAST ? sh * inv_fast(theta) : sh / theta;
+    imag = FAST ? sh * rth : sh / theta;
   }
   T.q[0] = ch, T.q[1] = imag * wx, T.q[2] = imag * wy, T.q[3] = imag * wz;
   if (FAST) {
@@ -111,8 +113,8 @@ VO_HD Se3 se3_exp(const double xi[6]) {
     const double t2 = theta * theta;
     double a, b;  // 1-cos = 2 sin^2(t/2)
     if (FAST) {
-      const double it2 = inv_fast(t2);
-      a = (2.0 * sh * sh) * it2, b = (theta - 2.0 * sh * ch) * (it2 * inv_fast(theta));
+      const double it2 = rth * rth;
+      a = (2.0 * sh * sh) * it2, b = (theta - 2.0 * sh * ch) * (it2 * rth);
     } else {
       a = (2.0 * sh * sh) / t2, b = (theta - 2.0 * sh * ch) / (t2 * theta);
     }
@@ -145,6 +147,34 @@ VO_HD void se3_log(const Se3 &T, double xi[6]) {
   xi[3] = wx, xi[4] = wy, xi[5] = wz;
 }
 
+// The same with the Newton-refined reciprocals of the FAST forms (pose-only LM: one log per iteration, in a dependent
+// chain that nothing overlaps): 1 / n is the rsqrt that forms n, theta w / (2 n) = f w / 2.  The degenerate inputs
+// (rotation below 1e-10, w = 0) take the plain function.
+VO_HD void se3_log_fast(const Se3 &T, double xi[6]) {
+#ifdef __HIP_DEVICE_COMPILE__
+  const double n2 = T.q[1] * T.q[1] + T.q[2] * T.q[2] + T.q[3] * T.q[3];
+  const double w = T.q[0];
+  if (!(n2 >= 1e-18) || !(fabs(w) > 1e-8)) {
+    se3_log(T, xi);
+    return;
+  }
+  const double rn = rsqrt_fast(n2), n = n2 * rn;
+  const double f = 2 * atan(n * inv_fast(w)) * rn;
+  const double theta = f * n;
+  const double wx = f * T.q[1], wy = f * T.q[2], wz = f * T.q[3];
+  const double c = (theta < kSmallEps) ? (1. / 12.) : (1 - 0.5 * f * w) * inv_fast(theta * theta);
+  const double *t = T.t;
+  const double wxt[3] = {wy * t[2] - wz * t[1], wz * t[0] - wx * t[2], wx * t[1] - wy * t[0]};
+  const double wwxt[3] = {wy * wxt[2] - wz * wxt[1], wz * wxt[0] - wx * wxt[2], wx * wxt[1] - wy * wxt[0]};
+  xi[0] = t[0] - 0.5 * wxt[0] + c * wwxt[0];
+  xi[1] = t[1] - 0.5 * wxt[1] + c * wwxt[1];
+  xi[2] = t[2] - 0.5 * wxt[2] + c * wwxt[2];
+  xi[3] = wx, xi[4] = wy, xi[5] = wz;
+#else
+  se3_log(T, xi);
+#endif
+}
+
 // PoseLocalParameterization::Plus (optimizer_ceres.cpp:44-53): log(exp(delta) * exp(x)).
 // The two-argument form takes exp(x) ready-made: the solve kernel forms it while the reduced
 // system is still in flight, off the critical path behind the factorisation.
@@ -175,7 +205,7 @@ VO_HD void se3_plus_keep(const Se3 &B, const double d[6], double out[6], Se3 &C)
   C.q[3] = A.q[0] * B.q[3] + A.q[3] * B.q[0] + A.q[1] * B.q[2] - A.q[2] * B.q[1];
   const double rn = rsqrt_fast(C.q[0] * C.q[0] + C.q[1] * C.q[1] + C.q[2] * C.q[2] + C.q[3] * C.q[3]);
   C.q[0] *= rn, C.q[1] *= rn, C.q[2] *= rn, C.q[3] *= rn;
-  se3_log(C, out);
+  se3_log_fast(C, out);
 }
 
 // Optimizer::se3TransPoint<double> (optimizer_ceres.h:29-95) plus the rotation matrix of
