@@ -170,8 +170,8 @@ struct PoseLm {
 #ifndef VO_POSE_ND
 #define VO_POSE_ND 4
 #endif
-#ifndef VO_POSE_PINGPONG
-#define VO_POSE_PINGPONG 1
+#ifndef VO_POSE_WRAP
+#define VO_POSE_WRAP 1  // developer A/B: 0 = every pass requests its first batch itself (and the hand-offs of the reduction wait for it)
 #endif
 struct ObsView {
   const VO_GLOBAL double *pts, *obs, *isg;
@@ -190,11 +190,7 @@ struct ObsView {
 //     H += [ M    M X   ]      g += [ m     ]
 //          [ .  X^T M X ]           [ X^T m ]
 // and every column of X has two non-zeros: 15 + 14 + 12 multiply-adds and 14 adds for H (the dense row products of the
-// 2-3 x 6 Jacobian: 60 + 15), the rotation half of J is never formed.  (Round 5: 0.271 -> see DESIGN section 5.)
-#ifndef VO_POSE_FACTORED
-#define VO_POSE_FACTORED 1
-#endif
-#if VO_POSE_FACTORED
+// 2-3 x 6 Jacobian: 60 + 15), the rotation half of J is never formed.
 __device__ __forceinline__ void pose_obs_term(const PoseCache &P, const double (&pw)[3], double ou, double ov, double our,
                                               double is, const Cam &K, double hm, double hs, double (&acc)[28]) {
   // R p + t as three multiply-add chains that start from t (trans_point adds t last: a multiply and an add more per row)
@@ -238,119 +234,58 @@ __device__ __forceinline__ void pose_obs_term(const PoseCache &P, const double (
   acc[25] = __builtin_fma(z, m0, __builtin_fma(-x, m2, acc[25]));
   acc[26] = __builtin_fma(x, m1, __builtin_fma(-y, m0, acc[26]));
 }
-#else
-__device__ __forceinline__ void pose_obs_term(const PoseCache &P, const double (&pw)[3], double ou, double ov, double our,
-                                              double is, const Cam &K, double hm, double hs, double (&acc)[28]) {
-  double r[3], J[18];
-  const int m = edge_eval<true, false>(P, pw, ou, ov, our, is, K, r, J, nullptr);
-  const double s = r[0] * r[0] + r[1] * r[1] + r[2] * r[2];
-  double rho0, rho1;
-  huber(m == 2 ? hm : hs, s, rho0, rho1);
-  acc[27] += 0.5 * rho0;
-  // J' = sqrt(rho1) J, r' = sqrt(rho1) r  =>  J'^T J' = rho1 J^T J, J'^T r' = rho1 J^T r.  The rows of edge_eval's pose
-  // Jacobian have fixed zeros -- u row [a0 0 a2 a3 a4 a5], v row [0 b1 b2 b3 b4 b5], uR row [c0 0 c2 c3 c4 c5] (all
-  // zero for a monocular observation) -- so the products that involve them are left out (60 multiply-adds and 15
-  // scalings per observation instead of 108).  acc: packed upper triangle row by row (00 01 02 03 04 05 11 12 ...),
-  // then the gradient, then the cost.  Every sum is one chain of multiply-adds onto its accumulator
-  // (acc += a b + c d + e f costs a multiply, two multiply-adds and an add).
-  double w0[6], w1[6], w2[6];
+
+// A batch of observations of the one-wavefront form: ND trips of 64, in registers.
+struct PoseOb { double pw[3], ou, ov, our, is; unsigned skip; };
+constexpr int kPoseNd = VO_POSE_ND;
+// The loads take the wave-uniform bases from scalar registers and a 32-bit byte offset per lane (an int index costs
+// twelve 64-bit address operations per observation); unconditional, the raw flag byte included: a bool would be
+// compared, i.e. waited for, where it is loaded.
+__device__ __forceinline__ void pose_request(const ObsView &V, unsigned base, unsigned last, PoseOb (&o)[kPoseNd]) {
+  const unsigned lane = threadIdx.x;
+  const VO_GLOBAL char *bp = (const VO_GLOBAL char *)V.pts, *bo = (const VO_GLOBAL char *)V.obs, *bi = (const VO_GLOBAL char *)V.isg;
+  const VO_GLOBAL uint8_t *bs = V.outlier;
 #pragma unroll
-  for (int k = 0; k < 6; k++) w0[k] = rho1 * J[k], w1[k] = rho1 * J[6 + k], w2[k] = rho1 * J[12 + k];
-  acc[0] = __builtin_fma(w0[0], J[0], __builtin_fma(w2[0], J[12], acc[0]));  // (0,0); (0,1) is identically zero
-#pragma unroll
-  for (int b = 2; b < 6; b++) acc[b] = __builtin_fma(w0[0], J[b], __builtin_fma(w2[0], J[12 + b], acc[b]));  // (0,b)
-  acc[6] = __builtin_fma(w1[1], J[7], acc[6]);                                                               // (1,1)
-#pragma unroll
-  for (int b = 2; b < 6; b++) acc[5 + b] = __builtin_fma(w1[1], J[6 + b], acc[5 + b]);  // (1,b): index 6 + (b - 1)
-  {
-    int t = 11;  // (2,2)
-#pragma unroll
-    for (int a = 2; a < 6; a++)
-#pragma unroll
-      for (int b = a; b < 6; b++, t++)
-        acc[t] = __builtin_fma(w0[a], J[b], __builtin_fma(w1[a], J[6 + b], __builtin_fma(w2[a], J[12 + b], acc[t])));
+  for (int k = 0; k < kPoseNd; k++) {
+    const unsigned i = min(base + 64u * k + lane, last);  // past the end: a harmless re-read
+    const unsigned o24 = __umul24(i, 24u), o8 = i * 8u;  // (v_mul_lo_u32 is a quarter-rate instruction)
+    o[k].pw[0] = *(const VO_GLOBAL double *)(bp + o24), o[k].pw[1] = *(const VO_GLOBAL double *)(bp + o24 + 8);
+    o[k].pw[2] = *(const VO_GLOBAL double *)(bp + o24 + 16);
+    o[k].ou = *(const VO_GLOBAL double *)(bo + o24), o[k].ov = *(const VO_GLOBAL double *)(bo + o24 + 8);
+    o[k].our = *(const VO_GLOBAL double *)(bo + o24 + 16);
+    o[k].is = *(const VO_GLOBAL double *)(bi + o8);
+    o[k].skip = bs[i];
   }
-  acc[21] = __builtin_fma(w0[0], r[0], __builtin_fma(w2[0], r[2], acc[21]));
-  acc[22] = __builtin_fma(w1[1], r[1], acc[22]);
-#pragma unroll
-  for (int a = 2; a < 6; a++)
-    acc[21 + a] = __builtin_fma(w0[a], r[0], __builtin_fma(w1[a], r[1], __builtin_fma(w2[a], r[2], acc[21 + a])));
 }
-#endif
 
 // One linearisation pass over the observations that are not flagged.  WAVE (one wavefront per frame, nothing else on
-// its SIMD to run while a load is in flight): observations are requested in batches of four trips, one batch ahead
-// of their use -- the raw flag byte included: a bool would be compared, i.e. waited for, where it is loaded.
+// its SIMD to run while a load is in flight): observations travel in batches of four trips, one batch ahead of their
+// use, into two register sets that swap roles in a loop unrolled by two (no "next becomes current" copies: 14 moves
+// per observation).  `first` holds batch 0 on entry -- requested by the previous pass behind its last trip, so that it
+// travels during the reduction and the 6 x 6 solve (the observations of a round do not change; a pass that requests
+// its own first batch waits for it once per LM iteration) -- and again on exit.
 template <bool WAVE>
 __device__ __forceinline__ void pose_accumulate(const PoseCache &P, int n, const ObsView &V, const Cam &K, double hm, double hs,
-                                                double (&acc)[28]) {
+                                                double (&acc)[28], PoseOb (&first)[kPoseNd]) {
 #pragma unroll
   for (int i = 0; i < 28; i++) acc[i] = 0;
-#if VO_POSE_PINGPONG
   if (WAVE) {
-    // Round 5: (i) the loads take the wave-uniform base from scalar registers and a 32-bit byte offset per lane (the int
-    // index cost twelve 64-bit address operations per observation); (ii) two register sets that swap roles in a loop
-    // unrolled by two, so the "next batch becomes the current one" copies -- 14 moves per observation -- are gone.
     const unsigned lane = threadIdx.x, last = (unsigned)(n - 1);
-    constexpr int ND = VO_POSE_ND;
-    struct Ob { double pw[3], ou, ov, our, is; unsigned skip; };
-    const VO_GLOBAL char *bp = (const VO_GLOBAL char *)V.pts, *bo = (const VO_GLOBAL char *)V.obs, *bi = (const VO_GLOBAL char *)V.isg;
-    const VO_GLOBAL uint8_t *bs = V.outlier;
-    auto request = [&](unsigned base, Ob (&o)[ND]) {
-#pragma unroll
-      for (int k = 0; k < ND; k++) {
-        const unsigned i = min(base + 64u * k + lane, last);  // past the end: a harmless re-read
-        const unsigned o24 = __umul24(i, 24u), o8 = i * 8u;  // (v_mul_lo_u32 is a quarter-rate instruction)
-        o[k].pw[0] = *(const VO_GLOBAL double *)(bp + o24), o[k].pw[1] = *(const VO_GLOBAL double *)(bp + o24 + 8);
-        o[k].pw[2] = *(const VO_GLOBAL double *)(bp + o24 + 16);
-        o[k].ou = *(const VO_GLOBAL double *)(bo + o24), o[k].ov = *(const VO_GLOBAL double *)(bo + o24 + 8);
-        o[k].our = *(const VO_GLOBAL double *)(bo + o24 + 16);
-        o[k].is = *(const VO_GLOBAL double *)(bi + o8);
-        o[k].skip = bs[i];
-      }
-    };
-    auto eval = [&](unsigned base, const Ob (&o)[ND]) {
+    constexpr int ND = kPoseNd;
+    auto eval = [&](unsigned base, const PoseOb (&o)[ND]) {
 #pragma unroll
       for (int k = 0; k < ND; k++)
         if (base + 64u * k + lane <= last && !o[k].skip) pose_obs_term(P, o[k].pw, o[k].ou, o[k].ov, o[k].our, o[k].is, K, hm, hs, acc);
     };
-    Ob A[ND], B[ND];
-    request(0, A);
+    PoseOb B[ND];
+    if (!VO_POSE_WRAP) pose_request(V, 0, last, first);
 #pragma unroll 1
     for (unsigned base = 0; base <= last; base += 2 * ND * 64) {
-      request(base + ND * 64, B);
-      eval(base, A);
-      request(base + 2 * ND * 64, A);
+      pose_request(V, base + ND * 64, last, B);
+      eval(base, first);
+      const unsigned nb = base + 2 * ND * 64;
+      pose_request(V, (VO_POSE_WRAP && nb > last) ? 0u : nb, last, first);  // behind the last trip: batch 0 for the next pass
       eval(base + ND * 64, B);  // (a batch wholly past the end evaluates nothing: every lane fails the range test)
-    }
-    return;
-  }
-#endif
-  if (WAVE) {
-    const int lane = threadIdx.x;
-    constexpr int ND = VO_POSE_ND;
-    struct Ob { double pw[3], ou, ov, our, is; unsigned skip; };
-    auto request = [&](int base, Ob (&o)[ND]) {
-#pragma unroll
-      for (int k = 0; k < ND; k++) {
-        const int i = min(base + 64 * k + lane, n - 1);  // past the end: a harmless re-read
-        V.get(i, o[k].pw, o[k].ou, o[k].ov, o[k].our, o[k].is);
-        o[k].skip = V.outlier[i];
-      }
-    };
-    Ob cur[ND];
-    request(0, cur);
-#pragma unroll 1
-    for (int base = 0; base < n; base += ND * 64) {
-      Ob nxt[ND];
-      // the next batch travels while this one is evaluated (none behind the last one: those loads would only be waited for)
-      request(base + ND * 64, nxt);
-#pragma unroll
-      for (int k = 0; k < ND; k++)
-        if (base + 64 * k + lane < n && !cur[k].skip)
-          pose_obs_term(P, cur[k].pw, cur[k].ou, cur[k].ov, cur[k].our, cur[k].is, K, hm, hs, acc);
-#pragma unroll
-      for (int k = 0; k < ND; k++) cur[k] = nxt[k];
     }
     return;
   }
@@ -424,7 +359,14 @@ struct PoseRed {
   static constexpr int kPitch = ONE_PASS ? 66 : 68;
   static constexpr int kScratch = (ONE_PASS ? 28 : 14) * kPitch;
 };
-__device__ __forceinline__ void wave_lds_handoff() { wave_lds_sync(); }
+__device__ __forceinline__ void wave_lds_handoff() {
+#if VO_POSE_WRAP
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // LDS only: the next pass's first batch stays in flight
+  __builtin_amdgcn_wave_barrier();
+#else
+  wave_lds_sync();
+#endif
+}
 template <bool ONE_PASS>
 __device__ __forceinline__ void wave_reduce28(const double (&v)[28], double *scratch, double *dst) {
   constexpr int P = PoseRed<ONE_PASS>::kPitch;
@@ -487,6 +429,21 @@ struct PoseLds {
   double cand[28];  // ... at the trial point
 };
 
+// -DVO_POSE_STAMPS (tools/pose_stamps.py): shader-clock cycles per phase of the LM loop, summed over the iterations and
+// handed back in the summary's fields (initial_cost = solve, final_cost = plus, final_radius = pass, reserved = reduction,
+// accepted = tests) -- a developer build, never the product.
+#ifdef VO_POSE_STAMPS
+#define POSE_STAMP(slot, dep)                                                                            \
+  do {                                                                                                   \
+    unsigned long long t_;                                                                               \
+    asm volatile("s_memtime %0\n s_waitcnt lgkmcnt(0)" : "=s"(t_), "+v"(dep)::"memory");                 \
+    if ((slot) >= 0) st_[(slot) < 0 ? 0 : (slot)] += t_ - tp_;                                           \
+    tp_ = t_;                                                                                            \
+  } while (0)
+#else
+#define POSE_STAMP(slot, dep) do { } while (0)
+#endif
+
 // Ceres-style LM on one 6-dof pose.  The linearisations -- 21 + 6 + 1 sums each -- live in LDS, not in registers: a
 // trial step accumulates the candidate's sums while the solve's temporaries are dead and vice versa (round 2 kept
 // two sets of 28 accumulators next to a 6 x 6 system in every lane: 256 VGPR + 251 AGPR).  Every thread carries the
@@ -498,9 +455,16 @@ __device__ void pose_lm(double x[6], int n, const ObsView &V, const Cam &K, doub
   // residuals are evaluated from it: rotation matrix from the unit quaternion, t = V * upsilon -- what
   // se3TransPoint(x) computes through sin / cos of |omega|, up to rounding; no trigonometry per evaluation.
   Se3 Tx = se3_exp<true>(x);
+#ifdef VO_POSE_STAMPS
+  unsigned long long st_[5] = {0, 0, 0, 0, 0}, tp_ = 0;
+#endif
+  bool in_loop_ = false;  // (stamps)
+  PoseOb first[kPoseNd];  // batch 0 of the next pass (one-wavefront form)
+  if (WAVE && VO_POSE_WRAP) pose_request(V, 0, (unsigned)(n - 1), first);
   auto linearize = [&](const Se3 &T, double *dst) {  // sums of the linearisation at T -> dst (LDS)
     double v[28];
-    pose_accumulate<WAVE>(pose_cache_se3(T), n, V, K, hm, hs, v);
+    pose_accumulate<WAVE>(pose_cache_se3(T), n, V, K, hm, hs, v, first);
+    POSE_STAMP(in_loop_ ? 2 : -1, v[27]);
     if (WAVE) {
       wave_reduce28<true>(v, S.red, dst);
     } else {
@@ -548,6 +512,8 @@ __device__ void pose_lm(double x[6], int n, const ObsView &V, const Cam &K, doub
       termination = 0;
       break;
     }
+    in_loop_ = true;
+    POSE_STAMP(-1, x_cost);
     double h[27];  // one batch of LDS reads: the gradient test and the normal equations use the same values
 #pragma unroll
     for (int i = 0; i < 27; i++) h[i] = cur[i];
@@ -611,13 +577,16 @@ __device__ void pose_lm(double x[6], int n, const ObsView &V, const Cam &K, doub
       }
     }
     invalid = 0;
+    POSE_STAMP(0, model);
     double xc[6];
     Se3 Tc;
     se3_plus_keep(Tx, delta, xc, Tc);
+    POSE_STAMP(1, xc[0]);
     // The candidate is linearised completely in the same pass (its cost is one of the 28 sums): an
     // accepted step -- the common case -- then needs no second sweep over the observations.
     linearize(Tc, cnd);
     double cand = cnd[27];
+    POSE_STAMP(3, cand);
     if (!isfinite(cand)) cand = 1.7976931348623157e308;
     double sn = 0;
 #pragma unroll
@@ -653,6 +622,7 @@ __device__ void pose_lm(double x[6], int n, const ObsView &V, const Cam &K, doub
       radius *= inv_decrease, inv_radius *= decrease;
       decrease *= 2.0, inv_decrease *= 0.5;
     }
+    POSE_STAMP(4, radius);
   }
   if (sum && threadIdx.x == 0) {
     sum->iterations = iterations;
@@ -662,6 +632,10 @@ __device__ void pose_lm(double x[6], int n, const ObsView &V, const Cam &K, doub
     sum->initial_cost = initial_cost;
     sum->final_cost = x_cost;
     sum->final_radius = radius;
+#ifdef VO_POSE_STAMPS
+    sum->initial_cost = (double)st_[0], sum->final_cost = (double)st_[1], sum->final_radius = (double)st_[2];
+    sum->reserved = (int)st_[3], sum->accepted = (int)st_[4];
+#endif
   }
 }
 
