@@ -508,6 +508,14 @@ int vo_track_gather_dev(vo_frames *h, int slot0, int n_frames, const double *dev
                         const uint8_t *dev_feature_has, const float *scale_factors, int n_levels,
                         double *dev_points, double *dev_obs, double *dev_inv_sigma, int32_t *dev_ranges,
                         int32_t *dev_index, void *hip_stream);
+/* vo_track_scatter_dev followed by vo_track_gather_dev in one launch (same outputs, bit for bit): what the
+ * tracker runs between a search and the pose solve that consumes its matches. */
+int vo_track_scatter_gather_dev(vo_frames *h, int slot0, int n_frames, const int32_t *dev_assigned,
+                                const double *dev_query_points, const uint8_t *dev_query_flags, int stride,
+                                double *dev_feature_points, uint8_t *dev_feature_has,
+                                uint8_t *dev_feature_observed, const float *scale_factors, int n_levels,
+                                double *dev_points, double *dev_obs, double *dev_inv_sigma,
+                                int32_t *dev_ranges, int32_t *dev_index, void *hip_stream);
 
 /* ------------------------------------------------------------------------------------------
  * The tracked-frame pipeline as one object  --  VisualOdometry::trackWithMotion + trackLocalMap
@@ -516,7 +524,7 @@ int vo_track_gather_dev(vo_frames *h, int slot0, int n_frames, const double *dev
  * frame's map points (radius 15), solvePoseOnlySE3, cullingOutliersBeforeLocalMap, Frame::isInFrame +
  * MapPoint::predictScale for the local map points WITH THE REFINED POSE, searchByProjection against
  * them (thRadius 3, ratio 0.8), solvePoseOnlySE3, inlier count.  One call enqueues the whole sequence
- * (29 kernel launches) without host synchronisation; batch = 1 with host images is the single-stream form
+ * (27 kernel launches) without host synchronisation; batch = 1 with host images is the single-stream form
  * (Frame construction to pose in one call).
  *
  * Streams: the searches and pose solves run on `stream` (NULL: a high-priority stream of the tracker),

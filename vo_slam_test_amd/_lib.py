@@ -46,7 +46,7 @@ SYMBOLS = [
     "vo_vocab_load", "vo_bow_score", "vo_sim3_ransac_eval", "vo_triangulate", "vo_rgb_to_gray", "vo_rgb_to_gray_dev",
     "vo_dataset_open", "vo_dataset_size", "vo_dataset_entry", "vo_dataset_close", "vo_png_info", "vo_png_read",
     "vo_trajectory_write", "vo_tracking_time_stats",
-    "vo_track_project_dev", "vo_track_scatter_dev", "vo_track_gather_dev", "vo_pose_only_solve_ranges_dev",
+    "vo_track_project_dev", "vo_track_scatter_dev", "vo_track_gather_dev", "vo_track_scatter_gather_dev", "vo_pose_only_solve_ranges_dev",
     "vo_tracker_track_first", "vo_tracker_track_first_dev", "vo_tracker_track_local_map", "vo_tracker_set_ref_keyframe",
     "vo_tracker_track_ref_keyframe", "vo_tracker_track_ref_keyframe_dev",
     "vo_tracker_create", "vo_tracker_destroy", "vo_tracker_info", "vo_tracker_extractor", "vo_tracker_frames",

@@ -865,6 +865,10 @@ void track_scatter_launch(int n_frames, int cap, int stride, const int *fn, int 
 void track_gather_launch(int n_frames, int cap, const int *fn, int slot0, const float *X, const float *Y, const float *UR,
                          const int *OCT, const double *fpoint, const uint8_t *fhas, const float *sf, double *pts, double *obs,
                          double *isg, int *ranges, int *index, hipStream_t st);
+void track_scatter_gather_launch(int n_frames, int cap, int stride, const int *fn, int slot0, const int *assigned,
+                                 const double *qpoints, const uint8_t *qflags, double *fpoint, uint8_t *fhas, uint8_t *fobserved,
+                                 const float *X, const float *Y, const float *UR, const int *OCT, const float *sf, double *pts,
+                                 double *obs, double *isg, int *ranges, int *index, hipStream_t st);
 }  // namespace vo
 
 struct vo_frames {
@@ -1189,6 +1193,27 @@ int vo_track_gather_dev(vo_frames *h, int slot0, int n_frames, const double *dev
   }
   vo::track_gather_launch(n_frames, h->cap, h->D.n, slot0, h->D.x, h->D.y, h->D.uright, h->D.octave, dev_feature_points,
                           dev_feature_has, h->b_sf.as<float>(), dev_points, dev_obs, dev_inv_sigma, dev_ranges, dev_index, st);
+  VO_HIP_CHECK(hipGetLastError());
+  return VO_OK;
+}
+
+int vo_track_scatter_gather_dev(vo_frames *h, int slot0, int n_frames, const int32_t *dev_assigned, const double *dev_query_points,
+                                const uint8_t *dev_query_flags, int stride, double *dev_feature_points, uint8_t *dev_feature_has,
+                                uint8_t *dev_feature_observed, const float *scale_factors, int n_levels, double *dev_points,
+                                double *dev_obs, double *dev_inv_sigma, int32_t *dev_ranges, int32_t *dev_index, void *hip_stream) {
+  if (!h || slot0 < 0 || n_frames < 1 || slot0 + n_frames > h->max_frames || !dev_assigned || !dev_query_points ||
+      !dev_query_flags || stride < 1 || !dev_feature_points || !dev_feature_has || !scale_factors || n_levels < 1 ||
+      n_levels > 16 || !dev_points || !dev_obs || !dev_inv_sigma || !dev_ranges)
+    return VO_ERR_INVALID;
+  hipStream_t st = (hipStream_t)hip_stream;
+  if (!h->b_sf.p) VO_CHECK(h->b_sf.reserve(64));
+  if (memcmp(h->sf_host, scale_factors, (size_t)n_levels * 4) != 0) {  // uploaded when it changes (once per extractor)
+    memcpy(h->sf_host, scale_factors, (size_t)n_levels * 4);
+    VO_HIP_CHECK(hipMemcpyAsync(h->b_sf.p, h->sf_host, 64, hipMemcpyHostToDevice, st));
+  }
+  vo::track_scatter_gather_launch(n_frames, h->cap, stride, h->D.n, slot0, dev_assigned, dev_query_points, dev_query_flags,
+                                  dev_feature_points, dev_feature_has, dev_feature_observed, h->D.x, h->D.y, h->D.uright,
+                                  h->D.octave, h->b_sf.as<float>(), dev_points, dev_obs, dev_inv_sigma, dev_ranges, dev_index, st);
   VO_HIP_CHECK(hipGetLastError());
   return VO_OK;
 }

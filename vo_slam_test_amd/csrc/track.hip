@@ -88,6 +88,60 @@ __global__ __launch_bounds__(256) void k_track_gather(int cap, const int *fn, in
   if (tid == 0) ranges[2 * f] = (int)o, ranges[2 * f + 1] = s_base;
 }
 
+// k_track_scatter followed by k_track_gather in ONE launch (the tracker's use: a search's matches go into the frame's
+// slots right before the pose solve that reads them): a feature that a query claimed takes the query's point -- written
+// to its slot exactly as the scatter does -- and enters the observation list with it; a feature that held a point before
+// enters with that one.  Same outputs, bit for bit, as the two kernels one after the other.
+__global__ __launch_bounds__(256) void k_track_scatter_gather(int cap, int stride, const int *fn, int slot0, const int *assigned,
+                                                              const double *qpoints, const uint8_t *qflags, double *fpoint,
+                                                              uint8_t *fhas, uint8_t *fobserved, const float *X, const float *Y,
+                                                              const float *UR, const int *OCT, const float *sf, double *pts,
+                                                              double *obs, double *isg, int *ranges, int *index) {
+  __shared__ int wsum[4];
+  __shared__ int s_base;
+  const int f = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int n = fn[slot0 + f];
+  const long long so = (long long)(slot0 + f) * cap, o = (long long)f * cap;
+  if (tid == 0) s_base = 0;
+  __syncthreads();
+  for (int b = 0; b < n; b += 256) {
+    const int i = b + tid;
+    bool has = false;
+    double p0 = 0, p1 = 0, p2 = 0;
+    if (i < n) {
+      const int a = assigned[o + i];
+      if (a >= 0) {
+        const long long qo = (long long)f * stride + a;
+        p0 = qpoints[3 * qo], p1 = qpoints[3 * qo + 1], p2 = qpoints[3 * qo + 2];
+        fpoint[3 * (o + i)] = p0, fpoint[3 * (o + i) + 1] = p1, fpoint[3 * (o + i) + 2] = p2;
+        fhas[o + i] = 1;
+        if (fobserved) fobserved[o + i] = (qflags[qo] >> 1) & 1u;
+        has = true;
+      } else if (fhas[o + i]) {
+        p0 = fpoint[3 * (o + i)], p1 = fpoint[3 * (o + i) + 1], p2 = fpoint[3 * (o + i) + 2];
+        has = true;
+      }
+    }
+    const unsigned long long m = __builtin_amdgcn_ballot_w64(has);
+    const int within = (int)__builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
+    if (lane == 0) wsum[wave] = __popcll(m);
+    __syncthreads();
+    int pre = s_base;
+    for (int w = 0; w < wave; w++) pre += wsum[w];
+    if (has) {
+      const long long d = o + pre + within;
+      pts[3 * d] = p0, pts[3 * d + 1] = p1, pts[3 * d + 2] = p2;
+      obs[3 * d] = (double)X[so + i], obs[3 * d + 1] = (double)Y[so + i], obs[3 * d + 2] = (double)UR[so + i];
+      isg[d] = 1.0 / (double)sf[OCT[so + i]];  // :190
+      if (index) index[d] = i;
+    }
+    __syncthreads();
+    if (tid == 0) s_base += wsum[0] + wsum[1] + wsum[2] + wsum[3];
+    __syncthreads();
+  }
+  if (tid == 0) ranges[2 * f] = (int)o, ranges[2 * f + 1] = s_base;
+}
+
 }  // namespace
 
 extern "C" {
@@ -122,5 +176,12 @@ void track_gather_launch(int n_frames, int cap, const int *fn, int slot0, const 
                          double *isg, int *ranges, int *index, hipStream_t st) {
   hipLaunchKernelGGL(k_track_gather, dim3(n_frames), dim3(256), 0, st, cap, fn, slot0, X, Y, UR, OCT, fpoint, fhas, sf, pts,
                      obs, isg, ranges, index);
+}
+void track_scatter_gather_launch(int n_frames, int cap, int stride, const int *fn, int slot0, const int *assigned,
+                                 const double *qpoints, const uint8_t *qflags, double *fpoint, uint8_t *fhas, uint8_t *fobserved,
+                                 const float *X, const float *Y, const float *UR, const int *OCT, const float *sf, double *pts,
+                                 double *obs, double *isg, int *ranges, int *index, hipStream_t st) {
+  hipLaunchKernelGGL(k_track_scatter_gather, dim3(n_frames), dim3(256), 0, st, cap, stride, fn, slot0, assigned, qpoints, qflags,
+                     fpoint, fhas, fobserved, X, Y, UR, OCT, sf, pts, obs, isg, ranges, index);
 }
 }  // namespace vo

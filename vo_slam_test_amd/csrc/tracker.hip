@@ -4,15 +4,18 @@
 //
 //   ORB extraction (frame.cpp:22)                    vo_orb_extract_batch_dev          extraction stream
 //   Frame::Frame post-processing, grid (:27-32)      vo_frames_build_dev               tracking stream from here on
-//   searchByProjection(frame, last frame, 15)        k_track_project + vo_match_guided_dev mode 0 + k_track_scatter
-//   solvePoseOnlySE3                                 k_track_gather + k_pose_only
+//   searchByProjection(frame, last frame, 15)        k_track_project_prep + vo_match_guided_dev mode 0 (+ the 2 x radius retry)
+//   solvePoseOnlySE3                                 k_track_scatter_gather (the matches into the frame's slots, the
+//                                                    observation list) + k_pose_only
 //   cullingOutliersBeforeLocalMap (:864-886)         k_track_cull: outliers of the solve lose their map point
 //   searchLocalMapPoints: Frame::isInFrame (frame.cpp:145-190, with the REFINED pose) + MapPoint::predictScale
-//                                                    k_track_in_frame
-//   searchByProjection(frame, local points, 3)       vo_match_guided_dev mode 1 + k_track_scatter
-//   solvePoseOnlySE3, inlier count (:289-300)        k_track_gather + k_pose_only + k_track_count
+//                                                    k_track_in_frame (batches: one launch with the culling,
+//                                                    k_track_cull_in_frame)
+//   searchByProjection(frame, local points, 3)       vo_match_guided_dev mode 1
+//   solvePoseOnlySE3, inlier count (:289-300)        k_track_scatter_gather + k_pose_only + k_track_count (which also
+//                                                    writes the frame's record of the result block)
 //
-// 29 kernel launches per batch, no host synchronisation in between.  The extraction may run on a stream shared by several
+// 27 kernel launches per batch (28 for fewer than 32 frames; round 4: 33), no host synchronisation in between.  The extraction may run on a stream shared by several
 // trackers (vo_tracker_config.extract_stream): batch i + 1's extraction then overlaps batch i's searches and pose
 // solves (two events order them).  Round 2 kept this sequence in Python (vo_slam_test_amd/tracking.py) without the
 // culling step and with the local-map projections fixed before the first solve; host code is now C++
@@ -42,6 +45,43 @@ __global__ __launch_bounds__(256) void k_track_prep(int cap, int last_stride, in
   if (tid < 6) pose[6 * f + tid] = pose0[6 * f + tid];
 }
 
+// k_track_prep and the projection prologue of searchByProjection(Frame*, Frame*) (k_track_project, csrc/track.hip: the
+// same arithmetic, matcher.cpp:41-64) in one launch: the two touch disjoint arrays.  Block (x, f) projects queries
+// [256 x, 256 x + 256) of frame f and clears the slice of the per-feature state that the blocks of a frame share out.
+__global__ __launch_bounds__(256) void k_track_project_prep(int nq, int stride, const double *Tcw, const double *points,
+                                                            const uint8_t *pflags, float fx, float fy, float cx, float cy, int xmin,
+                                                            int xmax, int ymin, int ymax, uint8_t *qflags, float *qu, float *qv,
+                                                            float *qinvz, int cap, int *assigned, uint8_t *fhas, uint8_t *fobs,
+                                                            uint8_t *last_matched, const double *pose0, double *pose) {
+  const int f = blockIdx.y, tid = threadIdx.x, q = blockIdx.x * 256 + tid;
+  {
+    const long long o = (long long)f * cap;
+    const int step = (int)gridDim.x * 256;
+    for (int i = q; i < cap; i += step) assigned[o + i] = -1, fhas[o + i] = 0, fobs[o + i] = 0;
+    for (int i = q; i < stride; i += step) last_matched[(long long)f * stride + i] = 0;
+    if (blockIdx.x == 0 && tid < 6) pose[6 * f + tid] = pose0[6 * f + tid];
+  }
+  if (q >= nq) return;
+  const long long o = (long long)f * stride + q;
+  const double *T = Tcw + 12 * (long long)f, *p = points + 3 * o;
+  const unsigned pf = pflags[o];
+  uint8_t out = 0;
+  float u = 0.f, v = 0.f, invz = 0.f;
+  if (pf & 1u) {
+    const double x = T[0] * p[0] + T[1] * p[1] + T[2] * p[2] + T[9];
+    const double y = T[3] * p[0] + T[4] * p[1] + T[5] * p[2] + T[10];
+    const double zc = T[6] * p[0] + T[7] * p[1] + T[8] * p[2] + T[11];
+    const float z = (float)zc;
+    if (!(z < 0.0f)) {  // :52-53
+      invz = 1.0f / z;
+      u = (float)((double)fx * x / zc + (double)cx);  // Camera::camera2pixel, camera.cpp:72-75 (float members widened)
+      v = (float)((double)fy * y / zc + (double)cy);
+      if (!(u < xmin || u > xmax) && !(v < ymin || v > ymax)) out = (uint8_t)(1u | (pf & 2u));  // :61-64
+    }
+  }
+  qflags[o] = out, qu[o] = u, qv[o] = v, qinvz[o] = invz;
+}
+
 // trackWithMotion's retry (visualOdometry.cpp:241-245): a frame whose first search found fewer than 20 matches has its
 // map-point slots cleared (`fill(mappoints_, nullptr)`) and is searched again at twice the radius.  Per frame: the query
 // count of the second guided call (negative = the frame is left out of it, include/vo_hip.h) and the cleared assignments.
@@ -60,21 +100,27 @@ __global__ __launch_bounds__(256) void k_track_retry_prep(int cap, int nq_last, 
 // two stages' sticky overflow flags -- in one block, so that the host needs ONE download (it was eight small ones and
 // three synchronisations: ~60 us of a 0.7 ms frame).  Record: [pose 6 doubles | n_tracked, n_inliers, n_matches_last,
 // n_matches_local, status, 0] = 72 bytes; the flags follow the records.
-__global__ __launch_bounds__(256) void k_track_pack(int B, const double *pose, const int *ntracked, const int *ninl, const int *nm_first,
-                                                    const int *nm, const int *status, const int *orb_err, const int *guided_err,
-                                                    uint8_t *out) {
-  const int f = blockIdx.x * 256 + threadIdx.x;
-  if (f < B) {
-    double *pd = reinterpret_cast<double *>(out + (size_t)f * 72);
-    for (int k = 0; k < 6; k++) pd[k] = pose[6 * f + k];
-    int *pi = reinterpret_cast<int *>(out + (size_t)f * 72 + 48);
-    pi[0] = ntracked[f], pi[1] = ninl[f], pi[2] = nm_first[f], pi[3] = nm[f], pi[4] = status[f], pi[5] = 0;
-  }
+struct PackArgs {
+  int B;
+  const double *pose;
+  const int *ninl, *nm_first, *nm, *orb_err, *guided_err;
+  uint8_t *out;
+};
+__device__ __forceinline__ void pack_record(const PackArgs &K, int f, int ntracked, int status) {
+  double *pd = reinterpret_cast<double *>(K.out + (size_t)f * 72);
+  for (int k = 0; k < 6; k++) pd[k] = K.pose[6 * f + k];
+  int *pi = reinterpret_cast<int *>(K.out + (size_t)f * 72 + 48);
+  pi[0] = ntracked, pi[1] = K.ninl[f], pi[2] = K.nm_first[f], pi[3] = K.nm[f], pi[4] = status, pi[5] = 0;
   if (f == 0) {
-    int *fl = reinterpret_cast<int *>(out + (size_t)B * 72);
-    fl[0] = orb_err ? *orb_err : 0;
-    fl[1] = guided_err ? *guided_err : 0;
+    int *fl = reinterpret_cast<int *>(K.out + (size_t)K.B * 72);
+    fl[0] = K.orb_err ? *K.orb_err : 0;
+    fl[1] = K.guided_err ? *K.guided_err : 0;
   }
+}
+// (on its own: the first frame of a sequence, whose counts are memsets)
+__global__ __launch_bounds__(256) void k_track_pack(PackArgs K, const int *ntracked, const int *status) {
+  const int f = blockIdx.x * 256 + threadIdx.x;
+  if (f < K.B) pack_record(K, f, ntracked[f], status[f]);
 }
 
 // cullingOutliersBeforeLocalMap (visualOdometry.cpp:864-886) on the pose solver's observation list: an outlier's
@@ -84,101 +130,139 @@ __global__ __launch_bounds__(256) void k_track_pack(int B, const double *pose, c
 // visualIdxOfFrame_ == frame id (:752, :881) and are skipped by searchLocalMapPoints (:765).
 // It also keeps the first search's assignments, pose and inlier count for the caller (VO_TRACKER_*_FIRST) and hands
 // `assigned` to the second search cleared -- three copies and a memset less per batch.
-__global__ __launch_bounds__(256) void k_track_cull(int cap, const int *ranges, const int *index, const uint8_t *outlier,
-                                                    int *assigned, int last_stride, uint8_t *fhas, uint8_t *fobs,
-                                                    uint8_t *last_matched, int *n_observed_inliers, int *assigned_first,
-                                                    const double *pose, double *pose_first, const int *ninl, int *ninl_first) {
-  __shared__ int s_cnt[4];
-  const int f = blockIdx.x, tid = threadIdx.x;
-  const long long o = (long long)f * cap;
-  const int start = ranges[2 * f], count = ranges[2 * f + 1];
-  for (int i = tid; i < cap; i += 256) {
-    const int a = assigned[o + i];
-    if (a >= 0) last_matched[(long long)f * last_stride + a] = 1;
-    assigned_first[o + i] = a;
-    assigned[o + i] = -1;
+struct CullArgs {
+  int cap;
+  const int *ranges, *index;
+  const uint8_t *outlier;
+  int *assigned;
+  int last_stride;
+  uint8_t *fhas, *fobs, *last_matched;
+  int *n_observed_inliers, *assigned_first;
+  const double *pose;
+  double *pose_first;
+  const int *ninl;
+  int *ninl_first;
+};
+__device__ __forceinline__ void cull_frame(const CullArgs &C, int f, int *s_cnt) {
+  const int tid = threadIdx.x;
+  const long long o = (long long)f * C.cap;
+  const int start = C.ranges[2 * f], count = C.ranges[2 * f + 1];
+  for (int i = tid; i < C.cap; i += 256) {
+    const int a = C.assigned[o + i];
+    if (a >= 0) C.last_matched[(long long)f * C.last_stride + a] = 1;
+    C.assigned_first[o + i] = a;
+    C.assigned[o + i] = -1;
   }
-  if (tid < 6) pose_first[6 * f + tid] = pose[6 * f + tid];
-  if (tid == 6) ninl_first[f] = ninl[f];
+  if (tid < 6) C.pose_first[6 * f + tid] = C.pose[6 * f + tid];
+  if (tid == 6) C.ninl_first[f] = C.ninl[f];
   int local = 0;
   for (int d = tid; d < count; d += 256) {
-    const int i = index[start + d];
-    if (outlier[start + d]) {
-      fhas[o + i] = 0;
-      fobs[o + i] = 0;
-    } else if (fobs[o + i]) {
+    const int i = C.index[start + d];
+    if (C.outlier[start + d]) {
+      C.fhas[o + i] = 0;
+      C.fobs[o + i] = 0;
+    } else if (C.fobs[o + i]) {
       local++;
     }
   }
   for (int s = 32; s >= 1; s >>= 1) local += __shfl_xor(local, s);
   if ((tid & 63) == 0) s_cnt[tid >> 6] = local;
   __syncthreads();
-  if (tid == 0) n_observed_inliers[f] = s_cnt[0] + s_cnt[1] + s_cnt[2] + s_cnt[3];
+  if (tid == 0) C.n_observed_inliers[f] = s_cnt[0] + s_cnt[1] + s_cnt[2] + s_cnt[3];
 }
-
+__global__ __launch_bounds__(256) void k_track_cull(CullArgs C) {
+  __shared__ int s_cnt[4];
+  cull_frame(C, blockIdx.x, s_cnt);
+}
 // Frame::isInFrame (frame.cpp:145-190) and MapPoint::predictScale (mappoint.cpp:182-196) for the local map points of
 // every frame, with Tcw = exp(pose) of the first solve (frame->setPose, optimizer_ceres.cpp:311).  Arithmetic as the
 // reference has it: the transform in double (Sophus SE3 * Vector3d = Eigen's quaternion rotation), z, u, v, the
 // distance and the view cosine narrowed to float where the reference narrows them, logf as the correctly rounded
 // float of the double logarithm (the reference calls glibc's logf: DESIGN section 3).
 // pflags bit 0: the point exists, is not bad and is not already in the frame; bit 1: it has observations.
-__global__ __launch_bounds__(256) void k_track_in_frame(int nq, int stride, const double *pose6, const double *points,
-                                                        const double *normals, const float *min_dist, const float *max_dist,
-                                                        const uint8_t *pflags, const int *link, const uint8_t *last_matched,
-                                                        int last_stride, float fx, float fy, float cx, float cy, float bf,
-                                                        float xmin, float xmax, float ymin, float ymax, float log_sf1,
-                                                        int n_levels, uint8_t *qflags, float *qu, float *qv, float *qur,
-                                                        int *qlevel, float *qviewcos) {
-  __shared__ double s_T[10];  // q (w, x, y, z), t, Ow
-  const int f = blockIdx.y, q = blockIdx.x * 256 + threadIdx.x;
-  if (threadIdx.x == 0) {
-    const Se3 T = se3_exp(pose6 + 6 * (long long)f);
-    // Ow_ = Tcw.inverse().translation() (frame.cpp:103): the conjugate rotation of -t
-    const double qc[4] = {T.q[0], -T.q[1], -T.q[2], -T.q[3]}, nt[3] = {-T.t[0], -T.t[1], -T.t[2]};
-    double ow[3];
-    quat_rotate(qc, nt, ow);
-    for (int k = 0; k < 4; k++) s_T[k] = T.q[k];
-    for (int k = 0; k < 3; k++) s_T[4 + k] = T.t[k], s_T[7 + k] = ow[k];
-  }
-  __syncthreads();
-  if (q >= nq) return;
-  const long long o = (long long)f * stride + q;
-  const unsigned pf = pflags[o];
+struct InFrameArgs {
+  int nq, stride;
+  const double *pose6, *points, *normals;
+  const float *min_dist, *max_dist;
+  const uint8_t *pflags;
+  const int *link;
+  const uint8_t *last_matched;
+  int last_stride;
+  float fx, fy, cx, cy, bf, xmin, xmax, ymin, ymax, log_sf1;
+  int n_levels;
+  uint8_t *qflags;
+  float *qu, *qv, *qur;
+  int *qlevel;
+  float *qviewcos;
+};
+// s_T: q (w, x, y, z), t, Ow of the frame's pose (in_frame_pose), set by one thread before a barrier
+__device__ __forceinline__ void in_frame_pose(const InFrameArgs &A, int f, double *s_T) {
+  const Se3 T = se3_exp(A.pose6 + 6 * (long long)f);
+  // Ow_ = Tcw.inverse().translation() (frame.cpp:103): the conjugate rotation of -t
+  const double qc[4] = {T.q[0], -T.q[1], -T.q[2], -T.q[3]}, nt[3] = {-T.t[0], -T.t[1], -T.t[2]};
+  double ow[3];
+  quat_rotate(qc, nt, ow);
+  for (int k = 0; k < 4; k++) s_T[k] = T.q[k];
+  for (int k = 0; k < 3; k++) s_T[4 + k] = T.t[k], s_T[7 + k] = ow[k];
+}
+__device__ __forceinline__ void in_frame_query(const InFrameArgs &A, int f, int q, const double *s_T) {
+  const long long o = (long long)f * A.stride + q;
+  const unsigned pf = A.pflags[o];
   uint8_t out = 0;
   float u = 0.f, v = 0.f, ur = 0.f, vc = 0.f;
   int level = 0;
-  const int lk = link ? link[o] : -1;
-  const bool in_frame_already = lk >= 0 && last_matched[(long long)f * last_stride + lk] != 0;  // :765
+  const int lk = A.link ? A.link[o] : -1;
+  const bool in_frame_already = lk >= 0 && A.last_matched[(long long)f * A.last_stride + lk] != 0;  // :765
   if ((pf & 1u) && !in_frame_already) {
-    const double *p = points + 3 * o, *nv = normals + 3 * o;
+    const double *p = A.points + 3 * o, *nv = A.normals + 3 * o;
     const double qq[4] = {s_T[0], s_T[1], s_T[2], s_T[3]};
     double rp[3];
     quat_rotate(qq, p, rp);
     const double x = rp[0] + s_T[4], y = rp[1] + s_T[5], zc = rp[2] + s_T[6];
     const float z = (float)zc;
     if (!(z < 0.0f)) {  // :153-154
-      u = (float)((double)fx * x / zc + (double)cx);  // Camera::camera2pixel, camera.cpp:72-75 (float members widened)
-      v = (float)((double)fy * y / zc + (double)cy);
-      if (!(u < xmin || u > xmax) && !(v < ymin || v > ymax)) {  // :159-164
+      u = (float)((double)A.fx * x / zc + (double)A.cx);  // Camera::camera2pixel, camera.cpp:72-75 (float members widened)
+      v = (float)((double)A.fy * y / zc + (double)A.cy);
+      if (!(u < A.xmin || u > A.xmax) && !(v < A.ymin || v > A.ymax)) {  // :159-164
         const double l0 = p[0] - s_T[7], l1 = p[1] - s_T[8], l2 = p[2] - s_T[9];
         const float dist = (float)sqrt(l0 * l0 + l1 * l1 + l2 * l2);  // :167
-        const float mind = 0.8f * min_dist[o], maxd = 1.2f * max_dist[o];  // mappoint.cpp:391-401
+        const float mind = 0.8f * A.min_dist[o], maxd = 1.2f * A.max_dist[o];  // mappoint.cpp:391-401
         if (!(dist < mind || dist > maxd)) {
           vc = (float)(l0 * nv[0] + l1 * nv[1] + l2 * nv[2]) / dist;  // :176
           if (!(vc < 0.5f)) {
             out = (uint8_t)(1u | (pf & 2u));
-            ur = u - bf / z;  // :184
-            const float ratio = max_dist[o] / dist;  // mappoint.cpp:187
+            ur = u - A.bf / z;  // :184
+            const float ratio = A.max_dist[o] / dist;  // mappoint.cpp:187
             const float lg = (float)log((double)ratio);
-            const int s = (int)ceilf(lg / log_sf1);
-            level = s < 0 ? 0 : (s >= n_levels ? n_levels - 1 : s);
+            const int s = (int)ceilf(lg / A.log_sf1);
+            level = s < 0 ? 0 : (s >= A.n_levels ? A.n_levels - 1 : s);
           }
         }
       }
     }
   }
   if (!out) u = v = ur = vc = 0.f, level = 0;
-  qflags[o] = out, qu[o] = u, qv[o] = v, qur[o] = ur, qlevel[o] = level, qviewcos[o] = vc;
+  A.qflags[o] = out, A.qu[o] = u, A.qv[o] = v, A.qur[o] = ur, A.qlevel[o] = level, A.qviewcos[o] = vc;
+}
+__global__ __launch_bounds__(256) void k_track_in_frame(InFrameArgs A) {
+  __shared__ double s_T[10];
+  const int f = blockIdx.y, q = blockIdx.x * 256 + threadIdx.x;
+  if (threadIdx.x == 0) in_frame_pose(A, f, s_T);
+  __syncthreads();
+  if (q < A.nq) in_frame_query(A, f, q, s_T);
+}
+// k_track_cull followed by k_track_in_frame in ONE launch, one workgroup per frame (the second reads the
+// last-frame-matched marks the first writes: a workgroup barrier orders them for the frame; the queries of the frame are
+// walked 256 at a time)
+__global__ __launch_bounds__(256) void k_track_cull_in_frame(CullArgs C, InFrameArgs A) {
+  __shared__ int s_cnt[4];
+  __shared__ double s_T[10];
+  const int f = blockIdx.x;
+  if (threadIdx.x == 0) in_frame_pose(A, f, s_T);
+  cull_frame(C, f, s_cnt);
+  __threadfence_block();
+  __syncthreads();
+  for (int q = threadIdx.x; q < A.nq; q += 256) in_frame_query(A, f, q, s_T);
 }
 
 // trackLocalMap's inlier count (visualOdometry.cpp:289-300): features that hold a map point with observations and are
@@ -186,7 +270,7 @@ __global__ __launch_bounds__(256) void k_track_in_frame(int nq, int stride, cons
 __global__ __launch_bounds__(256) void k_track_count(int cap, const int *ranges, const int *index, const uint8_t *outlier,
                                                      const uint8_t *fobs, const int *n_first, const int *n_observed_first,
                                                      const int *ninl_first, int *n_tracked, int *status, int min_matches,
-                                                     uint8_t *feature_outlier) {
+                                                     uint8_t *feature_outlier, PackArgs K) {
   __shared__ int s_cnt[4];
   const int f = blockIdx.x, tid = threadIdx.x;
   const long long o = (long long)f * cap;
@@ -210,13 +294,14 @@ __global__ __launch_bounds__(256) void k_track_count(int cap, const int *ranges,
     if (n_observed_first[f] < 10) st |= VO_TRACK_FEW_INLIERS;      // :253
     (void)ninl_first;
     status[f] = st;
+    pack_record(K, f, n, st);  // the frame's record of the result block (was a launch of its own)
   }
 }
 
 // status word and counts after the first stage alone (vo_tracker_track_first): what trackWithMotion / trackRefKeyFrame
 // return -- enough matches, and at least 10 observed inliers after the culling (:247-253, :268-275)
 __global__ __launch_bounds__(256) void k_track_first_status(int B, const int *n_first, const int *n_observed_first, int *n_tracked,
-                                                            int *status, int min_matches) {
+                                                            int *status, int min_matches, PackArgs K) {
   const int f = blockIdx.x * 256 + threadIdx.x;
   if (f >= B) return;
   int st = 0;
@@ -224,6 +309,7 @@ __global__ __launch_bounds__(256) void k_track_first_status(int B, const int *n_
   if (n_observed_first[f] < 10) st |= VO_TRACK_FEW_INLIERS;
   n_tracked[f] = n_observed_first[f];
   status[f] = st;
+  pack_record(K, f, n_observed_first[f], st);
 }
 
 constexpr int kStages = VO_TRACKER_STAGES;
@@ -258,6 +344,9 @@ struct vo_tracker {
       nobs_first, ntracked, status;
   PinnedBuf stage;
   bool have_link = false;
+  // a search's matches that the next solve_pose writes into the frame's slots (k_track_scatter_gather)
+  struct { const int32_t *assigned = nullptr; const double *qpoints = nullptr; const uint8_t *qflags = nullptr; int stride = 0; } pend;
+  bool in_frame_done = false;  // k_track_cull_in_frame has produced the local-map queries of this call
   int first_min_matches = 20;
   // trackRefKeyFrame's reference key-frame per frame of the batch (host copies: the common-node walk is host work)
   const vo_vocab *ref_vocab = nullptr;
@@ -384,9 +473,17 @@ int begin_timed_call(vo_tracker *t) {
 }
 
 int solve_pose(vo_tracker *t) {
-  VO_CHECK(vo_track_gather_dev(t->frames, 0, t->B, t->fpoint.as<double>(), t->fhas.as<uint8_t>(), t->sf, t->n_levels,
-                               t->pts.as<double>(), t->obs.as<double>(), t->isg.as<double>(), t->ranges.as<int32_t>(),
-                               t->index.as<int32_t>(), t->st));
+  if (t->pend.assigned) {
+    VO_CHECK(vo_track_scatter_gather_dev(t->frames, 0, t->B, t->pend.assigned, t->pend.qpoints, t->pend.qflags, t->pend.stride,
+                                         t->fpoint.as<double>(), t->fhas.as<uint8_t>(), t->fobs.as<uint8_t>(), t->sf, t->n_levels,
+                                         t->pts.as<double>(), t->obs.as<double>(), t->isg.as<double>(), t->ranges.as<int32_t>(),
+                                         t->index.as<int32_t>(), t->st));
+    t->pend.assigned = nullptr;
+  } else {
+    VO_CHECK(vo_track_gather_dev(t->frames, 0, t->B, t->fpoint.as<double>(), t->fhas.as<uint8_t>(), t->sf, t->n_levels,
+                                 t->pts.as<double>(), t->obs.as<double>(), t->isg.as<double>(), t->ranges.as<int32_t>(),
+                                 t->index.as<int32_t>(), t->st));
+  }
   return vo_pose_only_solve_ranges_dev(t->B, t->ranges.as<int32_t>(), t->pts.as<double>(), t->obs.as<double>(),
                                        t->isg.as<double>(), t->Tcw.as<double>() + (size_t)t->B * 12, t->pose.as<double>(),
                                        t->outlier.as<uint8_t>(), t->ninl.as<int32_t>(), nullptr, t->st);
@@ -423,12 +520,17 @@ int stage_front(vo_tracker *t, const uint8_t *dev_images, int img_pitch, size_t 
   return VO_OK;
 }
 
+// everything k_track_count / k_track_first_status / k_track_pack need to write the result block
+int pack_args(vo_tracker *t, PackArgs &K) {
+  VO_CHECK(t->resblk.reserve((size_t)t->B * 72 + 64));
+  K = PackArgs{t->B, t->pose.as<double>(), t->ninl.as<int>(), t->nm_first.as<int>(), t->nm.as<int>(), vo::orb_error_flag(t->orb),
+               vo::guided_error_flag(t->frames), t->resblk.as<uint8_t>()};
+  return VO_OK;
+}
 int launch_pack(vo_tracker *t) {
-  const int B = t->B;
-  VO_CHECK(t->resblk.reserve((size_t)B * 72 + 64));
-  hipLaunchKernelGGL(k_track_pack, dim3((B + 255) / 256), dim3(256), 0, t->st, B, t->pose.as<double>(), t->ntracked.as<int>(),
-                     t->ninl.as<int>(), t->nm_first.as<int>(), t->nm.as<int>(), t->status.as<int>(), vo::orb_error_flag(t->orb),
-                     vo::guided_error_flag(t->frames), t->resblk.as<uint8_t>());
+  PackArgs K;
+  VO_CHECK(pack_args(t, K));
+  hipLaunchKernelGGL(k_track_pack, dim3((t->B + 255) / 256), dim3(256), 0, t->st, K, t->ntracked.as<int>(), t->status.as<int>());
   VO_HIP_CHECK(hipGetLastError());
   return VO_OK;
 }
@@ -444,11 +546,13 @@ int stage_motion(vo_tracker *t, const vo_tracker_params &P) {
   gp.n_levels = t->n_levels, gp.scale_factors = t->sf;
   StageTimer tm(t, 2, st);
   const float cam4[4] = {c.intrinsics[0], c.intrinsics[1], c.intrinsics[2], c.intrinsics[3]};
-  VO_CHECK(vo_track_project_dev(B, t->nq_last, t->n_last, t->Tcw.as<double>(), t->p0.as<double>(), t->pf0.as<uint8_t>(),
-                                cam4, 0, c.width, 0, c.height, t->q0_flags.as<uint8_t>(), t->q0_u.as<float>(),
-                                t->q0_v.as<float>(), t->q0_aux.as<float>(), st));
-  hipLaunchKernelGGL(k_track_prep, dim3(B), dim3(256), 0, st, t->cap, t->n_last, t->assigned.as<int>(), t->fhas.as<uint8_t>(),
-                     t->fobs.as<uint8_t>(), t->last_matched.as<uint8_t>(), t->pose0.as<double>(), t->pose.as<double>());
+  // (nq_last > 0 here: run_pipeline takes the first-frame route otherwise)
+  hipLaunchKernelGGL(k_track_project_prep, dim3((t->nq_last + 255) / 256, B), dim3(256), 0, st, t->nq_last, t->n_last,
+                     t->Tcw.as<double>(), t->p0.as<double>(), t->pf0.as<uint8_t>(), cam4[0], cam4[1], cam4[2], cam4[3], 0, c.width, 0,
+                     c.height, t->q0_flags.as<uint8_t>(), t->q0_u.as<float>(), t->q0_v.as<float>(), t->q0_aux.as<float>(), t->cap,
+                     t->assigned.as<int>(), t->fhas.as<uint8_t>(), t->fobs.as<uint8_t>(), t->last_matched.as<uint8_t>(),
+                     t->pose0.as<double>(), t->pose.as<double>());
+  VO_HIP_CHECK(hipGetLastError());
   q.n_queries = t->nq_last, q.stride = t->n_last, q.flags = t->q0_flags.as<uint8_t>(), q.u = t->q0_u.as<float>();
   q.v = t->q0_v.as<float>(), q.aux = t->q0_aux.as<float>(), q.level = t->q0_level.as<int32_t>();
   q.angle = t->q0_angle.as<float>(), q.desc = t->q0_desc.as<uint8_t>();
@@ -468,8 +572,9 @@ int stage_motion(vo_tracker *t, const vo_tracker_params &P) {
     VO_CHECK(vo_match_guided_dev(t->frames, 0, B, &q, &gp, nullptr, t->assigned.as<int32_t>(), nullptr,
                                  t->nm_first.as<int32_t>(), 0, st));
   }
-  VO_CHECK(vo_track_scatter_dev(t->frames, 0, B, t->assigned.as<int32_t>(), t->p0.as<double>(), t->q0_flags.as<uint8_t>(),
-                                t->n_last, t->fpoint.as<double>(), t->fhas.as<uint8_t>(), t->fobs.as<uint8_t>(), st));
+  // the matches go into the frame's slots in the launch that gathers the pose problem (solve_pose)
+  t->pend.assigned = t->assigned.as<int32_t>(), t->pend.qpoints = t->p0.as<double>(), t->pend.qflags = t->q0_flags.as<uint8_t>();
+  t->pend.stride = t->n_last;
   return VO_OK;
 }
 
@@ -494,20 +599,41 @@ int stage_ref_keyframe(vo_tracker *t, const vo_tracker_params &P) {
   }
   VO_CHECK(vo::bow_search_resident(t->ref_vocab, t->frames, 0, B, kfs.data(), P.ref_ratio > 0.f ? P.ref_ratio : 0.7f, 1, 3,
                                    t->assigned.as<int32_t>(), t->cap, t->nm_first.as<int32_t>(), st));
-  VO_CHECK(vo_track_scatter_dev(t->frames, 0, B, t->assigned.as<int32_t>(), t->p0.as<double>(), t->q0_flags.as<uint8_t>(),
-                                t->n_last, t->fpoint.as<double>(), t->fhas.as<uint8_t>(), t->fobs.as<uint8_t>(), st));
+  // the matches go into the frame's slots in the launch that gathers the pose problem (solve_pose)
+  t->pend.assigned = t->assigned.as<int32_t>(), t->pend.qpoints = t->p0.as<double>(), t->pend.qflags = t->q0_flags.as<uint8_t>();
+  t->pend.stride = t->n_last;
   return VO_OK;
 }
 
-// solvePoseOnlySE3 + cullingOutliersBeforeLocalMap (:249-250 / :271-272)
-int stage_solve_cull(vo_tracker *t) {
+InFrameArgs in_frame_args(vo_tracker *t) {
+  const vo_tracker_config &c = t->cfg;
+  return InFrameArgs{t->nq_local, t->n_local, t->pose.as<double>(), t->p1.as<double>(), t->nrm1.as<double>(), t->mind1.as<float>(),
+                     t->maxd1.as<float>(), t->pf1.as<uint8_t>(), t->have_link ? t->link1.as<int>() : (const int *)nullptr,
+                     t->last_matched.as<uint8_t>(), t->n_last, c.intrinsics[0], c.intrinsics[1], c.intrinsics[2], c.intrinsics[3],
+                     c.intrinsics[4], 0.f, (float)c.width, 0.f, (float)c.height, (float)log((double)t->sf[1]), t->n_levels,
+                     t->q1_flags.as<uint8_t>(), t->q1_u.as<float>(), t->q1_v.as<float>(), t->q1_aux.as<float>(), t->q1_level.as<int>(),
+                     t->q1_viewcos.as<float>()};
+}
+
+// solvePoseOnlySE3 + cullingOutliersBeforeLocalMap (:249-250 / :271-272); with_in_frame: the local-map stage follows in
+// the same call, and its isInFrame pass (which needs this stage's pose and marks) rides in the culling launch
+int stage_solve_cull(vo_tracker *t, bool with_in_frame) {
   hipStream_t st = t->st;
   StageTimer tm(t, 3, st);
   VO_CHECK(solve_pose(t));
-  hipLaunchKernelGGL(k_track_cull, dim3(t->B), dim3(256), 0, st, t->cap, t->ranges.as<int>(), t->index.as<int>(),
-                     t->outlier.as<uint8_t>(), t->assigned.as<int>(), t->n_last, t->fhas.as<uint8_t>(), t->fobs.as<uint8_t>(),
-                     t->last_matched.as<uint8_t>(), t->nobs_first.as<int>(), t->assigned_first.as<int>(), t->pose.as<double>(),
-                     t->pose_first.as<double>(), t->ninl.as<int>(), t->ninl_first.as<int>());
+  const CullArgs C{t->cap, t->ranges.as<int>(), t->index.as<int>(), t->outlier.as<uint8_t>(), t->assigned.as<int>(), t->n_last,
+                   t->fhas.as<uint8_t>(), t->fobs.as<uint8_t>(), t->last_matched.as<uint8_t>(), t->nobs_first.as<int>(),
+                   t->assigned_first.as<int>(), t->pose.as<double>(), t->pose_first.as<double>(), t->ninl.as<int>(),
+                   t->ninl_first.as<int>()};
+  t->in_frame_done = false;
+  // (a few frames: one workgroup per frame walks its ~2000 queries in 8 trips, 15.6 us against 4.1 + 4.5 for the two launches)
+  if (with_in_frame && t->nq_local > 0 && t->B >= 32) {
+    hipLaunchKernelGGL(k_track_cull_in_frame, dim3(t->B), dim3(256), 0, st, C, in_frame_args(t));
+    t->in_frame_done = true;
+  } else {
+    hipLaunchKernelGGL(k_track_cull, dim3(t->B), dim3(256), 0, st, C);
+  }
+  VO_HIP_CHECK(hipGetLastError());
   return VO_OK;
 }
 
@@ -523,13 +649,9 @@ int stage_local(vo_tracker *t, const vo_tracker_params &P) {
   {
     StageTimer tm(t, 4, st);
     if (t->nq_local > 0) {
-      hipLaunchKernelGGL(k_track_in_frame, dim3((t->nq_local + 255) / 256, B), dim3(256), 0, st, t->nq_local, t->n_local,
-                         t->pose.as<double>(), t->p1.as<double>(), t->nrm1.as<double>(), t->mind1.as<float>(),
-                         t->maxd1.as<float>(), t->pf1.as<uint8_t>(), t->have_link ? t->link1.as<int>() : (const int *)nullptr,
-                         t->last_matched.as<uint8_t>(), t->n_last, c.intrinsics[0], c.intrinsics[1], c.intrinsics[2],
-                         c.intrinsics[3], c.intrinsics[4], 0.f, (float)c.width, 0.f, (float)c.height,
-                         (float)log((double)t->sf[1]), t->n_levels, t->q1_flags.as<uint8_t>(), t->q1_u.as<float>(),
-                         t->q1_v.as<float>(), t->q1_aux.as<float>(), t->q1_level.as<int>(), t->q1_viewcos.as<float>());
+      if (!t->in_frame_done)  // (the local-map stage on its own: vo_tracker_track_local_map)
+        hipLaunchKernelGGL(k_track_in_frame, dim3((t->nq_local + 255) / 256, B), dim3(256), 0, st, in_frame_args(t));
+      t->in_frame_done = false;
       // (`assigned` was cleared by k_track_cull)
       q.n_queries = t->nq_local, q.stride = t->n_local, q.flags = t->q1_flags.as<uint8_t>(), q.u = t->q1_u.as<float>();
       q.v = t->q1_v.as<float>(), q.aux = t->q1_aux.as<float>(), q.level = t->q1_level.as<int32_t>();
@@ -537,8 +659,8 @@ int stage_local(vo_tracker *t, const vo_tracker_params &P) {
       gp.mode = 1, gp.radius = P.th_radius, gp.ratio = P.ratio, gp.bf = 0.f, gp.direction = 0, gp.check_rot = 0;
       VO_CHECK(vo_match_guided_dev(t->frames, 0, B, &q, &gp, t->fobs.as<uint8_t>(), t->assigned.as<int32_t>(), nullptr,
                                    t->nm.as<int32_t>(), 0, st));
-      VO_CHECK(vo_track_scatter_dev(t->frames, 0, B, t->assigned.as<int32_t>(), t->p1.as<double>(), t->q1_flags.as<uint8_t>(),
-                                    t->n_local, t->fpoint.as<double>(), t->fhas.as<uint8_t>(), t->fobs.as<uint8_t>(), st));
+      t->pend.assigned = t->assigned.as<int32_t>(), t->pend.qpoints = t->p1.as<double>(), t->pend.qflags = t->q1_flags.as<uint8_t>();
+      t->pend.stride = t->n_local;
     } else {
       VO_HIP_CHECK(hipMemsetAsync(t->nm.p, 0, (size_t)B * 4, st));
     }
@@ -547,10 +669,13 @@ int stage_local(vo_tracker *t, const vo_tracker_params &P) {
   {
     StageTimer tm(t, 5, st);
     VO_CHECK(solve_pose(t));
+    PackArgs K;
+    VO_CHECK(pack_args(t, K));
     hipLaunchKernelGGL(k_track_count, dim3(B), dim3(256), 0, st, t->cap, t->ranges.as<int>(), t->index.as<int>(),
                        t->outlier.as<uint8_t>(), t->fobs.as<uint8_t>(), t->nm_first.as<int>(), t->nobs_first.as<int>(),
                        t->ninl_first.as<int>(), t->ntracked.as<int>(), t->status.as<int>(), t->first_min_matches,
-                       t->foutl.as<uint8_t>());
+                       t->foutl.as<uint8_t>(), K);
+    VO_HIP_CHECK(hipGetLastError());
   }
   return VO_OK;
 }
@@ -591,16 +716,19 @@ int run_pipeline(vo_tracker *t, const uint8_t *dev_images, int img_pitch, size_t
     t->first_min_matches = 15;  // :268
     VO_CHECK(stage_ref_keyframe(t, P));
   }
-  if (run & (kRunMotion | kRunRefKeyFrame)) VO_CHECK(stage_solve_cull(t));
+  if (run & (kRunMotion | kRunRefKeyFrame)) VO_CHECK(stage_solve_cull(t, (run & kRunLocal) != 0));
+  // (the result block is written by the last kernel of either route: k_track_count / k_track_first_status)
   if (run & kRunLocal) {
     VO_CHECK(stage_local(t, P));
   } else {
     // first stage only: the status word and the counts of trackWithMotion / trackRefKeyFrame
     VO_HIP_CHECK(hipMemsetAsync(t->nm.p, 0, (size_t)B * 4, st));
+    PackArgs K;
+    VO_CHECK(pack_args(t, K));
     hipLaunchKernelGGL(k_track_first_status, dim3((B + 255) / 256), dim3(256), 0, st, B, t->nm_first.as<int>(),
-                       t->nobs_first.as<int>(), t->ntracked.as<int>(), t->status.as<int>(), t->first_min_matches);
+                       t->nobs_first.as<int>(), t->ntracked.as<int>(), t->status.as<int>(), t->first_min_matches, K);
+    VO_HIP_CHECK(hipGetLastError());
   }
-  VO_CHECK(launch_pack(t));
   if (t->tslot >= 0) t->tissued++, t->tslot = -1;
   return VO_OK;
 }
