@@ -139,14 +139,22 @@ __global__ __launch_bounds__(256) void k_frame_post(FramesDev F, CamDev C, const
 
 // assignFeaturesToGrid (frame.cpp:72-89) as CSR: one workgroup per frame.  Cell lists keep feature-index order
 // (push_back order): slots are handed out by LDS atomics, then every cell with more than one item is sorted.
+// LDS_ITEMS (the frame's slots fit kGridLdsCap): every feature's cell and the item list stay in LDS until the list is
+// final -- the insertion sort of a cell was a chain of dependent global loads and stores (25 of the 0.59 ms of a
+// single-stream frame, 0.11 ms per 1024 frames: the kernel ran at 7 % of the issue rate).
+constexpr int kGridLdsCap = 4096;
+template <bool LDS_ITEMS>
 __global__ __launch_bounds__(256) void k_frame_grid(FramesDev F, int slot0) {
   __shared__ int cnt[kCells];
   __shared__ int wsum[4];
+  __shared__ unsigned short s_items[LDS_ITEMS ? kGridLdsCap : 1];
+  __shared__ short s_cell[LDS_ITEMS ? kGridLdsCap : 1];
   const int s = slot0 + blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int n = F.n[s];
   const float *X = F.x + (long long)s * F.cap, *Y = F.y + (long long)s * F.cap;
   int *start = F.cell_start + (long long)s * (kCells + 1);
-  unsigned short *items = F.cell_items + (long long)s * F.cap;
+  unsigned short *gitems = F.cell_items + (long long)s * F.cap;
+  unsigned short *items = LDS_ITEMS ? s_items : gitems;
   for (int c = tid; c < kCells; c += 256) cnt[c] = 0;
   __syncthreads();
   auto cell_of = [&](int i) {
@@ -155,6 +163,7 @@ __global__ __launch_bounds__(256) void k_frame_grid(FramesDev F, int slot0) {
   };
   for (int i = tid; i < n; i += 256) {
     const int c = cell_of(i);
+    if (LDS_ITEMS) s_cell[i] = (short)c;
     if (c >= 0) atomicAdd(&cnt[c], 1);
   }
   __syncthreads();
@@ -174,8 +183,10 @@ __global__ __launch_bounds__(256) void k_frame_grid(FramesDev F, int slot0) {
   int base = incl - sum;
   for (int w = 0; w < wave; w++) base += wsum[w];
   __syncthreads();
+  int first[PER];
 #pragma unroll
   for (int k = 0; k < PER; k++) {
+    first[k] = base;
     start[tid * PER + k] = base;
     cnt[tid * PER + k] = base;  // fill cursor
     base += loc[k];
@@ -183,29 +194,30 @@ __global__ __launch_bounds__(256) void k_frame_grid(FramesDev F, int slot0) {
   if (tid == 255) start[kCells] = base;
   __syncthreads();
   for (int i = tid; i < n; i += 256) {
-    const int c = cell_of(i);
+    const int c = LDS_ITEMS ? (int)s_cell[i] : cell_of(i);
     if (c >= 0) items[atomicAdd(&cnt[c], 1)] = (unsigned short)i;
   }
   __syncthreads();
-  __threadfence_block();
-  for (int c = tid; c < kCells; c += 256) {
-    const int e = cnt[c];
-    // s0 = start of the cell: the exclusive offset written above
-    const int s0 = start[c];
-    for (int a = s0 + 1; a < e; a++) {  // insertion sort, lists of a handful of entries
-      const unsigned short v = items[a];
-      int b = a - 1;
-      while (b >= s0 && items[b] > v) items[b + 1] = items[b], b--;
-      items[b + 1] = v;
+  if (!LDS_ITEMS) __threadfence_block();
+  // a thread sorts the cells whose counts it scanned (it still holds their extents)
+#pragma unroll
+  for (int k = 0; k < PER; k++) {
+    const int s0 = first[k], e = s0 + loc[k];
+    for (int a2 = s0 + 1; a2 < e; a2++) {  // insertion sort, lists of a handful of entries
+      const unsigned short v = items[a2];
+      int b2 = a2 - 1;
+      while (b2 >= s0 && items[b2] > v) items[b2 + 1] = items[b2], b2--;
+      items[b2 + 1] = v;
     }
   }
   __syncthreads();
-  __threadfence_block();
-  // cell-ordered copies for the matcher
-  const int total = start[kCells];
+  if (!LDS_ITEMS) __threadfence_block();
+  // the list, and the cell-ordered copies for the matcher
+  const int total = wsum[0] + wsum[1] + wsum[2] + wsum[3];  // = start[kCells]
   const long long fo = (long long)s * F.cap;
   for (int t = tid; t < total; t += 256) {
     const int i = items[t];
+    if (LDS_ITEMS) gitems[t] = (unsigned short)i;
     F.srec[fo + t] = make_uint4(__float_as_uint(X[i]), __float_as_uint(Y[i]), __float_as_uint(F.uright[fo + i]),
                                 (unsigned)(F.octave[fo + i] & 0xff) | ((unsigned)i << 8));
     const uint4 *d = reinterpret_cast<const uint4 *>(F.desc + (fo + i) * 32);
@@ -1061,7 +1073,7 @@ int vo_frames_build_dev(vo_frames *h, int slot0, int n_frames, const vo_keypoint
   hipLaunchKernelGGL(k_frame_post, dim3((nmax + 255) / 256, n_frames), dim3(256), 0, st, h->D, h->cam, dev_keypoints,
                      dev_descriptors, dev_counts, capacity, dev_depth, depth_kind, (long long)depth_frame_stride_bytes,
                      depth_pitch_bytes, inv_depth_scale, (int)h->width, (int)h->height, slot0, h->b_err.as<int>());
-  hipLaunchKernelGGL(k_frame_grid, dim3(n_frames), dim3(256), 0, st, h->D, slot0);
+  hipLaunchKernelGGL(h->cap <= kGridLdsCap ? k_frame_grid<true> : k_frame_grid<false>, dim3(n_frames), dim3(256), 0, st, h->D, slot0);
   VO_HIP_CHECK(hipGetLastError());
   return VO_OK;
 }
@@ -1089,7 +1101,7 @@ int vo_frames_upload(vo_frames *h, int slot, const vo_frame_view *view, const fl
     VO_CHECK(vo::copy_h2d(h->D.desc + o * 32, view->desc, (size_t)n * 32, st, "vo_frames_upload"));
   }
   VO_CHECK(vo::copy_h2d(h->D.n + slot, &n, 4, st, "vo_frames_upload"));
-  hipLaunchKernelGGL(k_frame_grid, dim3(1), dim3(256), 0, st, h->D, slot);
+  hipLaunchKernelGGL(h->cap <= kGridLdsCap ? k_frame_grid<true> : k_frame_grid<false>, dim3(1), dim3(256), 0, st, h->D, slot);
   VO_HIP_CHECK(hipGetLastError());
   // `n` lives on this stack frame: the copy above must have left it before we return
   return vo::stream_sync(st, "vo_frames_upload");
@@ -1322,7 +1334,7 @@ int guided_host(const vo_frame_view *cur, const HostQueries &hq, const GuidedCal
   VO_CHECK(d2d(D.uright, o_ur, (size_t)nf * 4));
   VO_CHECK(d2d(D.desc, o_fd, (size_t)nf * 32));
   VO_CHECK(d2d(D.n, o_n, 4));
-  hipLaunchKernelGGL(k_frame_grid, dim3(1), dim3(256), 0, st, D, 0);
+  hipLaunchKernelGGL(D.cap <= kGridLdsCap ? k_frame_grid<true> : k_frame_grid<false>, dim3(1), dim3(256), 0, st, D, 0);
   Queries Q{};
   Q.flags = d + o_qf, Q.u = reinterpret_cast<const float *>(d + o_qu), Q.v = reinterpret_cast<const float *>(d + o_qv);
   Q.aux = reinterpret_cast<const float *>(d + o_qa), Q.level = reinterpret_cast<const int *>(d + o_ql);
