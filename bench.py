@@ -448,7 +448,7 @@ def main():
         out["single_stream"] = {"ms_per_frame": round(float(np.median(lat[5:])) * 1e3, 4),
                                 "frames_per_s": round(1.0 / float(np.median(lat[5:])), 1),
                                 "note": "batch 1, host image + raw depth in, pose out, one C call + results (PCIe and "
-                                        "launch latency of 28 kernels included)"}
+                                        "launch latency of 27 kernels included)"}
         h_all = np.ascontiguousarray(frames_np)
         h_dall = np.ascontiguousarray(np.stack([uniq_depth[i % n_unique] for i in range(B)])).view(np.uint16)
         ing = []

@@ -249,6 +249,12 @@ typedef struct {
   float radius, bf, ratio, dist_threshold;
   int32_t direction, check_rot, n_levels, max_dist;
   const float *scale_factors; /* host, n_levels entries */
+  /* mode 0 only, or NULL: trackWithMotion's retry (visualOdometry.cpp:241-245) decided on the device.  A frame that ends
+   * the call with fewer than retry_below matches has its dev_assigned entries set back to -1 and
+   * retry_n_per_frame[f] = its query count; every other frame gets -1 -- the n_per_frame array of a second call
+   * (same queries, wider radius) that then looks at those frames only. */
+  int32_t retry_below;
+  int32_t *retry_n_per_frame; /* device [n_frames] */
 } vo_guided_params;
 int vo_match_guided_dev(vo_frames *h, int slot0, int n_frames, const vo_guided_queries *q,
                         const vo_guided_params *p, const uint8_t *dev_feature_mask, int32_t *dev_assigned,
@@ -524,7 +530,7 @@ int vo_track_scatter_gather_dev(vo_frames *h, int slot0, int n_frames, const int
  * frame's map points (radius 15), solvePoseOnlySE3, cullingOutliersBeforeLocalMap, Frame::isInFrame +
  * MapPoint::predictScale for the local map points WITH THE REFINED POSE, searchByProjection against
  * them (thRadius 3, ratio 0.8), solvePoseOnlySE3, inlier count.  One call enqueues the whole sequence
- * (27 kernel launches) without host synchronisation; batch = 1 with host images is the single-stream form
+ * (26 kernel launches) without host synchronisation; batch = 1 with host images is the single-stream form
  * (Frame construction to pose in one call).
  *
  * Streams: the searches and pose solves run on `stream` (NULL: a high-priority stream of the tracker),

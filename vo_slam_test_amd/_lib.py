@@ -288,7 +288,8 @@ class GuidedQueries(C.Structure):
 class GuidedParams(C.Structure):
     _fields_ = [("mode", C.c_int32), ("radius", C.c_float), ("bf", C.c_float), ("ratio", C.c_float),
                 ("dist_threshold", C.c_float), ("direction", C.c_int32), ("check_rot", C.c_int32),
-                ("n_levels", C.c_int32), ("max_dist", C.c_int32), ("scale_factors", C.c_void_p)]
+                ("n_levels", C.c_int32), ("max_dist", C.c_int32), ("scale_factors", C.c_void_p),
+                ("retry_below", C.c_int32), ("retry_n_per_frame", C.c_void_p)]
 
 
 class Frames:

@@ -243,6 +243,7 @@ struct GuidedParams {
   float radius, bf, ratio, dist_threshold;
   int direction, check_rot, n_levels, max_dist;
   float sf[16];
+  int retry_below;  // with GuidedOut::retry_nq: frames that end with fewer matches are cleared and queued for a second call
 };
 
 constexpr float kNarrowRadius = 20.f;  // search radius (before the level scale) up to which a query gets 8 lanes, not 16
@@ -261,6 +262,7 @@ struct GuidedOut {
   const uint8_t *fmask;     // [frames][cap] or NULL: blocked / has-map-point / occupied on entry
   unsigned *pushes;         // [frames][stride] rotation-histogram entries idx | bin << 16
   int *n_matches;           // [frames]
+  int *retry_nq;            // [frames] or NULL: the n_per_frame array of a retry call (vo_guided_params::retry_n_per_frame)
   int *err;                 // bit 0: overflow area exhausted (bit 1: the frame store dropped key-points, k_frame_post)
 };
 
@@ -846,8 +848,15 @@ __global__ __launch_bounds__(64) void k_guided_replay(FramesDev F, Queries Q, Gu
     }
     lds_handoff();
   }
-  for (int i = lane; i < nf; i += 64) assigned[i] = (int)asg[i] - 1;
-  if (lane == 0) O.n_matches[f] = cnt, O.ovf_used[f] = 0;  // (the cursor is back at zero for the next search: guided_launch)
+  // trackWithMotion's retry (visualOdometry.cpp:241-245) decided where the count is known: a frame with fewer than
+  // retry_below matches gives its assignments back (`fill(mappoints_, nullptr)`) and is the only kind of frame the second,
+  // wider call looks at
+  const bool retry = O.retry_nq && cnt < P.retry_below;
+  for (int i = lane; i < nf; i += 64) assigned[i] = retry ? -1 : (int)asg[i] - 1;
+  if (lane == 0) {
+    O.n_matches[f] = cnt, O.ovf_used[f] = 0;  // (the cursor is back at zero for the next search: guided_launch)
+    if (O.retry_nq) O.retry_nq[f] = retry ? nq : -1;
+  }
 }
 
 // number of accepted queries of the searches without a claim step
@@ -933,6 +942,8 @@ struct GuidedCall {
   int direction, check_rot, n_levels, max_dist;
   const float *scale_factors;
   int n_scale;
+  int retry_below = 0;
+  int *retry_nq = nullptr;
 };
 
 // Enqueue the matcher kernels for frames [slot0, slot0 + n_frames) on `st`.  All pointers are device memory.
@@ -945,6 +956,7 @@ int guided_launch(vo_frames *h, int slot0, int n_frames, const Queries &Q, const
   const bool claims = c.mode == kModeFrame || c.mode == kModeLocalMap || c.mode == kModeKeyFrame || c.mode == kModeSim3;
   GuidedOut O{};
   O.best_idx = best_idx, O.assigned = assigned, O.fmask = fmask, O.n_matches = n_matches;
+  P.retry_below = c.retry_below, O.retry_nq = c.retry_nq;
   // the overflow flag is sticky (like the extractor's): kernels only ever set it, vo_match_guided_status reads and clears
   // it -- two searches launched back to back on one handle (the tracked path) cannot erase each other's report
   if (!h->b_err.p) {
@@ -1174,6 +1186,13 @@ int vo_match_guided_dev(vo_frames *h, int slot0, int n_frames, const vo_guided_q
   Q.viewcos = q->viewcos, Q.desc = q->desc, Q.nq = q->n_per_frame, Q.nq_all = q->n_queries, Q.stride = q->stride;
   GuidedCall c{p->mode, p->radius, p->bf, p->ratio, p->dist_threshold, p->direction, p->check_rot, p->n_levels,
                p->max_dist, p->scale_factors, p->n_levels};
+  if (p->retry_n_per_frame) {
+    if (p->mode != kModeFrame) {
+      vo::set_error("vo_match_guided_dev: retry_n_per_frame is for mode 0 (trackWithMotion's retry)");
+      return VO_ERR_INVALID;
+    }
+    c.retry_below = p->retry_below, c.retry_nq = p->retry_n_per_frame;
+  }
   if (pool_per_frame == 0) pool_per_frame = (size_t)std::max(q->n_queries, 1) * 16;
   return guided_launch(h, slot0, n_frames, Q, c, dev_feature_mask, dev_assigned, dev_best_idx, dev_n_matches,
                        pool_per_frame, (hipStream_t)hip_stream);

@@ -15,7 +15,7 @@
 //   solvePoseOnlySE3, inlier count (:289-300)        k_track_scatter_gather + k_pose_only + k_track_count (which also
 //                                                    writes the frame's record of the result block)
 //
-// 27 kernel launches per batch (28 for fewer than 32 frames; round 4: 33), no host synchronisation in between.  The extraction may run on a stream shared by several
+// 26 kernel launches per batch (27 for fewer than 32 frames; round 4: 33), no host synchronisation in between.  The extraction may run on a stream shared by several
 // trackers (vo_tracker_config.extract_stream): batch i + 1's extraction then overlaps batch i's searches and pose
 // solves (two events order them).  Round 2 kept this sequence in Python (vo_slam_test_amd/tracking.py) without the
 // culling step and with the local-map projections fixed before the first solve; host code is now C++
@@ -80,20 +80,6 @@ __global__ __launch_bounds__(256) void k_track_project_prep(int nq, int stride, 
     }
   }
   qflags[o] = out, qu[o] = u, qv[o] = v, qinvz[o] = invz;
-}
-
-// trackWithMotion's retry (visualOdometry.cpp:241-245): a frame whose first search found fewer than 20 matches has its
-// map-point slots cleared (`fill(mappoints_, nullptr)`) and is searched again at twice the radius.  Per frame: the query
-// count of the second guided call (negative = the frame is left out of it, include/vo_hip.h) and the cleared assignments.
-__global__ __launch_bounds__(256) void k_track_retry_prep(int cap, int nq_last, const int *nm_first, int *assigned, int *retry_nq) {
-  const int f = blockIdx.x, tid = threadIdx.x;
-  const bool retry = nm_first[f] < 20;
-  if (tid == 0) {
-    retry_nq[f] = retry ? nq_last : -1;
-  }
-  if (!retry) return;
-  const long long o = (long long)f * cap;
-  for (int i = tid; i < cap; i += 256) assigned[o + i] = -1;
 }
 
 // End of a batch: everything vo_tracker_results hands back -- pose, the four counts, the status word per frame, and the
@@ -557,18 +543,18 @@ int stage_motion(vo_tracker *t, const vo_tracker_params &P) {
   q.v = t->q0_v.as<float>(), q.aux = t->q0_aux.as<float>(), q.level = t->q0_level.as<int32_t>();
   q.angle = t->q0_angle.as<float>(), q.desc = t->q0_desc.as<uint8_t>();
   gp.mode = 0, gp.radius = P.radius, gp.bf = c.intrinsics[4], gp.direction = P.direction, gp.check_rot = 1;
+  // `if (match_num < 20) { fill(mappoints_, nullptr); match_num = searchByProjection(..., 2*radius); }` (:241-245): the
+  // first search's replay decides per frame (it knows the count), clears the assignments of the frames that need the
+  // second look and writes their query counts; the second call leaves every other frame out (n_per_frame < 0) -- two
+  // short dispatches (a candidate grid whose workgroups return at once, a replay) even when no frame needs them: ~8 us
+  // per batch inside bench.py's `match_last_frame` stage
+  int *rq = t->retry_nq.as<int>();
+  if (!P.no_retry) gp.retry_below = 20, gp.retry_n_per_frame = rq;
   VO_CHECK(vo_match_guided_dev(t->frames, 0, B, &q, &gp, nullptr, t->assigned.as<int32_t>(), nullptr,
                                t->nm_first.as<int32_t>(), 0, st));
   if (!P.no_retry) {
-    // `if (match_num < 20) { fill(mappoints_, nullptr); match_num = searchByProjection(..., 2*radius); }` (:241-245) for
-    // the frames that need it, on the device: the second call leaves every other frame out (n_per_frame < 0)
-    // (three short dispatches -- this one, a candidate grid whose workgroups return at once for frames that are left out, a
-    //  replay -- even when no frame needs them: ~12 us per batch, inside bench.py's `match_last_frame` stage)
-    int *rq = t->retry_nq.as<int>();
-    hipLaunchKernelGGL(k_track_retry_prep, dim3(B), dim3(256), 0, st, t->cap, t->nq_last, t->nm_first.as<int>(),
-                       t->assigned.as<int>(), rq);
     q.n_per_frame = rq;
-    gp.radius = 2.f * P.radius;
+    gp.radius = 2.f * P.radius, gp.retry_n_per_frame = nullptr;
     VO_CHECK(vo_match_guided_dev(t->frames, 0, B, &q, &gp, nullptr, t->assigned.as<int32_t>(), nullptr,
                                  t->nm_first.as<int32_t>(), 0, st));
   }
