@@ -13,17 +13,27 @@ namespace {
 
 using namespace vo;
 
-// K6: D[i][j] = popcount(A_i xor B_j) over 256 bits.  A workgroup owns 512 columns x 128 rows: each thread
-// keeps two B descriptors in registers (fetched as four 16-byte loads: a wavefront reads 4 KB contiguous) and
-// streams the 128-row A tile from LDS (all lanes read the same address: a broadcast, no bank conflict);
-// results leave as one 4-byte store per lane per row, i.e. 256 contiguous bytes per wavefront -- the kernel
-// is bound by the 2 bytes/pair it writes and by the 16 vector instructions a distance costs.
+// K6: D[i][j] = popcount(A_i xor B_j) over 256 bits.  Each thread keeps its B descriptors in registers (16-byte loads:
+// a wavefront reads whole lines) and streams the 128-row A tile from LDS (all lanes read the same address: a broadcast,
+// no bank conflict); results leave as one packed store per lane per row -- the kernel is bound by the 2 bytes/pair it
+// writes and by the 16 vector instructions a distance costs.
+#ifndef VO_HAM_NC
+#define VO_HAM_NC 4  // developer A/B: B descriptors (columns) per thread, 2 or 4
+#endif
 constexpr int kHamRows = 128;
+constexpr int kHamNc = VO_HAM_NC;
 typedef uint32_t ham_u32x4 __attribute__((ext_vector_type(4)));
+typedef uint32_t ham_u32x2 __attribute__((ext_vector_type(2)));
 
-__global__ __launch_bounds__(256) void k_hamming(const uint32_t *A, int na, long long a_stride,
-                                                 const uint32_t *B, int nb, long long b_stride,
-                                                 uint16_t *D, long long d_stride) {
+// NC columns per thread: a workgroup owns 256 NC columns x 128 rows.  NC = 4 (round 5): at <= 1024 columns a workgroup
+// writes WHOLE rows, one after the other -- every 128-byte line of the matrix is filled by one workgroup within a few
+// hundred cycles (rows are 2 nb bytes apart, not a multiple of the line: with two workgroups per row the lines at the
+// row's start, middle and end were written in two parts at different times) -- and a row of A read from LDS serves four
+// distances instead of two.
+template <int NC>
+__global__ __launch_bounds__(256) void k_hamming(const uint32_t *__restrict__ A, int na, long long a_stride,
+                                                 const uint32_t *__restrict__ B, int nb, long long b_stride,
+                                                 uint16_t *__restrict__ D, long long d_stride) {
   __shared__ __attribute__((aligned(16))) uint32_t a[kHamRows][8];
   const int tid = threadIdx.x;
   const long long p = blockIdx.z;
@@ -31,7 +41,7 @@ __global__ __launch_bounds__(256) void k_hamming(const uint32_t *A, int na, long
   B += p * b_stride * 8;
   D += p * d_stride;
   const int i0 = blockIdx.y * kHamRows;
-  const int j0 = (blockIdx.x * 256 + tid) * 2;
+  const int j0 = (blockIdx.x * 256 + tid) * NC;
   const bool wide = ((reinterpret_cast<uintptr_t>(A) | reinterpret_cast<uintptr_t>(B)) & 15) == 0;  // uniform
   for (int c = tid; c < kHamRows * 2; c += 256) {  // 16-byte chunk c of the tile: row c / 2, half c & 1
     const int r = c >> 1;
@@ -45,39 +55,48 @@ __global__ __launch_bounds__(256) void k_hamming(const uint32_t *A, int na, long
     }
     *reinterpret_cast<ham_u32x4 *>(&a[r][4 * (c & 1)]) = v;
   }
-  uint32_t b0[8], b1[8];
+  uint32_t b[NC][8];
   {
-    ham_u32x4 q[4] = {{0u, 0u, 0u, 0u}, {0u, 0u, 0u, 0u}, {0u, 0u, 0u, 0u}, {0u, 0u, 0u, 0u}};
-    // the last column of an odd nb is clamped, not predicated (a predicated load becomes a branch)
-    const uint32_t *s0 = B + (long long)min(j0, nb - 1) * 8, *s1 = B + (long long)min(j0 + 1, nb - 1) * 8;
-    if (wide) {
-      q[0] = reinterpret_cast<const ham_u32x4 *>(s0)[0], q[1] = reinterpret_cast<const ham_u32x4 *>(s0)[1];
-      q[2] = reinterpret_cast<const ham_u32x4 *>(s1)[0], q[3] = reinterpret_cast<const ham_u32x4 *>(s1)[1];
-    } else {
+    // columns past the end are clamped, not predicated (a predicated load becomes a branch)
 #pragma unroll
-      for (int w = 0; w < 4; w++) q[0][w] = s0[w], q[1][w] = s0[4 + w], q[2][w] = s1[w], q[3][w] = s1[4 + w];
+    for (int k = 0; k < NC; k++) {
+      const uint32_t *s0 = B + (long long)min(j0 + k, nb - 1) * 8;
+      if (wide) {
+        const ham_u32x4 q0 = reinterpret_cast<const ham_u32x4 *>(s0)[0], q1 = reinterpret_cast<const ham_u32x4 *>(s0)[1];
+#pragma unroll
+        for (int w = 0; w < 4; w++) b[k][w] = q0[w], b[k][4 + w] = q1[w];
+      } else {
+#pragma unroll
+        for (int w = 0; w < 8; w++) b[k][w] = s0[w];
+      }
     }
-#pragma unroll
-    for (int w = 0; w < 4; w++) b0[w] = q[0][w], b0[4 + w] = q[1][w], b1[w] = q[2][w], b1[4 + w] = q[3][w];
   }
   __syncthreads();
   if (j0 >= nb) return;
-  const bool pair_store = ((nb & 1) == 0);
+  const bool vec_store = (nb % NC) == 0;  // whole groups, and every row start is 2 NC-byte aligned relative to D
   const int rows = min(kHamRows, na - i0);
   uint16_t *o = D + (long long)i0 * nb + j0;
   for (int r = 0; r < rows; r++, o += nb) {
-    int d0 = 0, d1 = 0;
+    int d[NC];
+#pragma unroll
+    for (int k = 0; k < NC; k++) d[k] = 0;
 #pragma unroll
     for (int w = 0; w < 8; w++) {
       const uint32_t av = a[r][w];
-      d0 += __popc(av ^ b0[w]);
-      d1 += __popc(av ^ b1[w]);
+#pragma unroll
+      for (int k = 0; k < NC; k++) d[k] += __popc(av ^ b[k][w]);
     }
-    if (pair_store) {
-      *reinterpret_cast<uint32_t *>(o) = (uint32_t)d0 | ((uint32_t)d1 << 16);
+    if (vec_store) {
+      if (NC == 2) {
+        *reinterpret_cast<uint32_t *>(o) = (uint32_t)d[0] | ((uint32_t)d[1] << 16);
+      } else {
+        *reinterpret_cast<ham_u32x2 *>(o) =
+            ham_u32x2{(uint32_t)d[0] | ((uint32_t)d[1] << 16), (uint32_t)d[NC == 2 ? 0 : 2] | ((uint32_t)d[NC == 2 ? 1 : 3] << 16)};
+      }
     } else {
-      o[0] = (uint16_t)d0;
-      if (j0 + 1 < nb) o[1] = (uint16_t)d1;
+#pragma unroll
+      for (int k = 0; k < NC; k++)
+        if (j0 + k < nb) o[k] = (uint16_t)d[k];
     }
   }
 }
@@ -85,9 +104,17 @@ __global__ __launch_bounds__(256) void k_hamming(const uint32_t *A, int na, long
 int launch_hamming(const uint8_t *a, int na, size_t as, const uint8_t *b, int nb, size_t bs, uint16_t *d,
                    size_t ds, int n_pairs, hipStream_t st) {
   if (na <= 0 || nb <= 0 || n_pairs <= 0) return VO_OK;
-  dim3 grid((nb + 511) / 512, (na + kHamRows - 1) / kHamRows, n_pairs);
-  hipLaunchKernelGGL(k_hamming, grid, dim3(256), 0, st, reinterpret_cast<const uint32_t *>(a), na, (long long)as,
-                     reinterpret_cast<const uint32_t *>(b), nb, (long long)bs, d, (long long)ds);
+  // the 8-byte stores of the 4-column form need 8-byte aligned rows: D itself and the pair stride
+  const bool al8 = (reinterpret_cast<uintptr_t>(d) & 7) == 0 && (ds & 3) == 0;
+  if (kHamNc == 4 && al8) {
+    dim3 grid((nb + 1023) / 1024, (na + kHamRows - 1) / kHamRows, n_pairs);
+    hipLaunchKernelGGL(k_hamming<4>, grid, dim3(256), 0, st, reinterpret_cast<const uint32_t *>(a), na, (long long)as,
+                       reinterpret_cast<const uint32_t *>(b), nb, (long long)bs, d, (long long)ds);
+  } else {
+    dim3 grid((nb + 511) / 512, (na + kHamRows - 1) / kHamRows, n_pairs);
+    hipLaunchKernelGGL(k_hamming<2>, grid, dim3(256), 0, st, reinterpret_cast<const uint32_t *>(a), na, (long long)as,
+                       reinterpret_cast<const uint32_t *>(b), nb, (long long)bs, d, (long long)ds);
+  }
   VO_HIP_CHECK(hipGetLastError());
   return VO_OK;
 }
