@@ -180,8 +180,12 @@ class OrbExtractor:
         check(lib().vo_orb_set_stream(self._h, C.c_void_p(stream_ptr)))
 
     def set_fused(self, on: bool):
-        """vo_orb_set_option(VO_ORB_OPT_FUSED_LEVEL_PASS): the fused per-level pass (default) or the three separate kernels"""
-        check(lib().vo_orb_set_option(self._h, 1, int(on)), "vo_orb_set_option")  # 0 / False: separate kernels; 1 / True: k_level_pass; 2: k_level_pass2
+        """vo_orb_set_option(VO_ORB_OPT_FUSED_LEVEL_PASS): the fused per-level pass, or the three separate kernels (default)"""
+        check(lib().vo_orb_set_option(self._h, 1, int(on)), "vo_orb_set_option")
+
+    def set_early_level0(self, on: bool):
+        """vo_orb_set_option(VO_ORB_OPT_EARLY_LEVEL0): level 0's FAST cells and blur next to the resize chain (default on)"""
+        check(lib().vo_orb_set_option(self._h, 2, int(on)), "vo_orb_set_option")
 
     def level_pass_plan(self, width, height):
         """per level: dict(fused, tile_pitch, tile_rows, score_rows, blocks, lds_bytes, list_cap) of the fused pass"""

@@ -1679,7 +1679,8 @@ struct vo_orb {
   hipStream_t stream = nullptr;
   bool own_stream = false;
   hipStream_t side = nullptr;          // blur runs here, concurrently with FAST / oct-tree (no data dependence)
-  hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+  hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_fork0 = nullptr, ev_fast0 = nullptr;
+  int early_level0 = 1;  // vo_orb_set_option(VO_ORB_OPT_EARLY_LEVEL0)
   // geometry (valid for cfg_w x cfg_h)
   int cfg_w = 0, cfg_h = 0;
   OrbDev dev;
@@ -2149,7 +2150,7 @@ int run_pipeline(vo_orb *h, const uint8_t *dev_images, int n_frames, int w, int 
                  size_t frame_stride, vo_keypoint *dkp, uint8_t *ddesc, int capacity, int32_t *dcounts) {
   VO_CHECK(configure(h, w, hh, n_frames));
   const OrbDev &D = h->dev;
-  hipStream_t st = h->stream;
+  hipStream_t st = h->stream;  // (not const: the early level-0 launches borrow the launch lambdas for the side stream)
   FrameSrc S;
   S.img0 = dev_images;
   S.img0_frame_stride = (long long)frame_stride;
@@ -2261,18 +2262,37 @@ int run_pipeline(vo_orb *h, const uint8_t *dev_images, int n_frames, int w, int 
     }
     VO_STAGE_MARK(1);  // (instrumented mode: stage 0 carries the whole chain of level passes, stages 1 and 4 are empty)
   } else {
+    // Outside the instrumented mode the work that needs the caller's image only -- FAST on the cells of level 0 (a third of
+    // all cells) and level 0's blur -- starts on the side stream at once, next to the resize chain (seven dependent
+    // launches, the small ones latency-bound); the blur of the other levels follows there when the pyramid is complete.
+    // FAST -> oct-tree -> offsets do not touch the blurred planes: the side stream joins before the descriptors, level 0's
+    // cells before the oct-tree.
+    const bool early0 = overlap && h->early_level0 && D.nlevels > 1 && D.lv[0].nCells > 0;
+    if (early0) {
+      VO_HIP_CHECK(hipEventRecord(h->ev_fork0, st));
+      VO_HIP_CHECK(hipStreamWaitEvent(h->side, h->ev_fork0, 0));
+      hipStream_t keep = st;
+      st = h->side;  // (launch_fast launches on `st`)
+      launch_fast(D.lv[0].cellBase, D.lv[0].cellBase + D.lv[0].nCells);
+      st = keep;
+      VO_HIP_CHECK(hipEventRecord(h->ev_fast0, h->side));
+      launch_blur(h->side, h->blur_job0[0], h->blur_job0[1], 1u);
+    }
     for (int l = 1; l < D.nlevels; l++) launch_resize(l);
     VO_STAGE_MARK(1);
-    // The blur reads the pyramid only; FAST -> oct-tree -> offsets do not touch the blurred planes.  Outside
-    // the instrumented mode the blur therefore runs on a side stream next to them (the oct-tree kernel is
-    // latency-bound and leaves most of the machine idle) and joins before the descriptors.
     if (overlap) {
       VO_HIP_CHECK(hipEventRecord(h->ev_fork, st));
       VO_HIP_CHECK(hipStreamWaitEvent(h->side, h->ev_fork, 0));
-      launch_blur(h->side, 0, h->blur_jobs, ~0u);
+      if (early0) launch_blur(h->side, h->blur_job0[1], h->blur_jobs, ~1u);
+      else launch_blur(h->side, 0, h->blur_jobs, ~0u);
       VO_HIP_CHECK(hipEventRecord(h->ev_join, h->side));
     }
-    launch_fast(0, h->cells_frame);
+    if (early0) {
+      launch_fast(D.lv[1].cellBase, h->cells_frame);
+      VO_HIP_CHECK(hipStreamWaitEvent(st, h->ev_fast0, 0));
+    } else {
+      launch_fast(0, h->cells_frame);
+    }
   }
   VO_STAGE_MARK(2);
   if (h->oct_small)
@@ -2389,7 +2409,9 @@ int vo_orb_create(vo_orb **out, int nfeatures, float scale_factor, int nlevels, 
   h->own_stream = true;
   if (hipStreamCreateWithFlags(&h->side, hipStreamNonBlocking) != hipSuccess ||
       hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming) != hipSuccess ||
-      hipEventCreateWithFlags(&h->ev_join, hipEventDisableTiming) != hipSuccess) {
+      hipEventCreateWithFlags(&h->ev_join, hipEventDisableTiming) != hipSuccess ||
+      hipEventCreateWithFlags(&h->ev_fork0, hipEventDisableTiming) != hipSuccess ||
+      hipEventCreateWithFlags(&h->ev_fast0, hipEventDisableTiming) != hipSuccess) {
     (void)hipGetLastError();
     h->side = nullptr;  // no overlap then
   }
@@ -2407,6 +2429,8 @@ void vo_orb_destroy(vo_orb *h) {
   for (hipEvent_t e : h->ev) (void)hipEventDestroy(e);
   if (h->ev_fork) (void)hipEventDestroy(h->ev_fork);
   if (h->ev_join) (void)hipEventDestroy(h->ev_join);
+  if (h->ev_fork0) (void)hipEventDestroy(h->ev_fork0);
+  if (h->ev_fast0) (void)hipEventDestroy(h->ev_fast0);
   if (h->side) (void)hipStreamDestroy(h->side);
   if (h->own_stream) (void)hipStreamDestroy(h->stream);
   delete h;
@@ -2425,6 +2449,10 @@ int vo_orb_set_option(vo_orb *h, int option, int value) {
   if (!h) return VO_ERR_INVALID;
   if (option == VO_ORB_OPT_FUSED_LEVEL_PASS) {
     h->fused = value != 0 ? 1 : 0;
+    return VO_OK;
+  }
+  if (option == VO_ORB_OPT_EARLY_LEVEL0) {
+    h->early_level0 = value ? 1 : 0;
     return VO_OK;
   }
   vo::set_error("vo_orb_set_option: unknown option %d", option);
