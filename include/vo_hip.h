@@ -72,9 +72,11 @@ int vo_orb_set_stream(vo_orb *h, void *hip_stream);
  * (csrc/orb_level_pass.inc); 0 = the three separate kernels per level.  The results are bit-identical; on MI355X the fused
  * pass measures 6 % slower than the three kernels (profiles/r05_ab_fused.txt: more vector instructions and three workgroup
  * barriers), which is why it is opt-in. */
-/* VO_ORB_OPT_EARLY_LEVEL0 (default 1): outside the instrumented mode (vo_orb_set_timing) FAST on the cells of level 0 and level
- * 0's blur -- the work that needs the caller's image only -- start on the extractor's side stream next to the resize chain; 0 =
- * round 4's order (FAST on all cells behind the pyramid, the whole blur on the side stream next to it).  Results are identical. */
+/* VO_ORB_OPT_EARLY_LEVEL0 (default 0): 1 = outside the instrumented mode (vo_orb_set_timing) FAST on the cells of level 0 and
+ * level 0's blur -- the work that needs the caller's image only -- start on the extractor's side stream next to the resize chain;
+ * 0 = FAST on all cells behind the pyramid, the whole blur on the side stream next to it.  Results are identical; measured
+ * (tools/ext_schedule_ab.py): 2.482 against 2.499 ms per 1024 frames for the extraction alone, no difference for the tracked
+ * step (every kernel involved is bound by instruction issue: there is nothing to overlap), hence opt-in. */
 enum { VO_ORB_OPT_FUSED_LEVEL_PASS = 1, VO_ORB_OPT_EARLY_LEVEL0 = 2 };
 int vo_orb_set_option(vo_orb *h, int option, int value);
 /* (tests and tools) the fused pass's plan for one level of a width x height image: out = {takes the fused pass, tile pitch,

@@ -1,5 +1,5 @@
 """Developer tool (GPU box): the extractor's launch order outside the instrumented mode -- level 0's FAST cells and blur next to
-the resize chain (VO_ORB_OPT_EARLY_LEVEL0 = 1, default) against round 4's order (0) -- interleaved; extraction alone and
+the resize chain (VO_ORB_OPT_EARLY_LEVEL0 = 1) against the default order (0) -- interleaved; extraction alone and
 extraction + all-pairs Hamming, 1024 frames per step.  Also checks that both orders give identical key-points / descriptors."""
 import pathlib, sys, time
 sys.path.insert(0, str(pathlib.Path(__file__).resolve().parent.parent))

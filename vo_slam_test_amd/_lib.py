@@ -184,7 +184,7 @@ class OrbExtractor:
         check(lib().vo_orb_set_option(self._h, 1, int(on)), "vo_orb_set_option")
 
     def set_early_level0(self, on: bool):
-        """vo_orb_set_option(VO_ORB_OPT_EARLY_LEVEL0): level 0's FAST cells and blur next to the resize chain (default on)"""
+        """vo_orb_set_option(VO_ORB_OPT_EARLY_LEVEL0): level 0's FAST cells and blur next to the resize chain (default off)"""
         check(lib().vo_orb_set_option(self._h, 2, int(on)), "vo_orb_set_option")
 
     def level_pass_plan(self, width, height):
