@@ -535,7 +535,7 @@ int vo_track_scatter_gather_dev(vo_frames *h, int slot0, int n_frames, const int
  * frame's map points (radius 15), solvePoseOnlySE3, cullingOutliersBeforeLocalMap, Frame::isInFrame +
  * MapPoint::predictScale for the local map points WITH THE REFINED POSE, searchByProjection against
  * them (thRadius 3, ratio 0.8), solvePoseOnlySE3, inlier count.  One call enqueues the whole sequence
- * (26 kernel launches) without host synchronisation; batch = 1 with host images is the single-stream form
+ * (27 kernel launches) without host synchronisation; batch = 1 with host images is the single-stream form
  * (Frame construction to pose in one call).
  *
  * Streams: the searches and pose solves run on `stream` (NULL: a high-priority stream of the tracker),

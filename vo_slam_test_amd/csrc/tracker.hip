@@ -9,13 +9,12 @@
 //                                                    observation list) + k_pose_only
 //   cullingOutliersBeforeLocalMap (:864-886)         k_track_cull: outliers of the solve lose their map point
 //   searchLocalMapPoints: Frame::isInFrame (frame.cpp:145-190, with the REFINED pose) + MapPoint::predictScale
-//                                                    k_track_in_frame (batches: one launch with the culling,
-//                                                    k_track_cull_in_frame)
+//                                                    k_track_in_frame
 //   searchByProjection(frame, local points, 3)       vo_match_guided_dev mode 1
 //   solvePoseOnlySE3, inlier count (:289-300)        k_track_scatter_gather + k_pose_only + k_track_count (which also
 //                                                    writes the frame's record of the result block)
 //
-// 26 kernel launches per batch (27 for fewer than 32 frames; round 4: 33), no host synchronisation in between.  The extraction may run on a stream shared by several
+// 27 kernel launches per batch (round 4: 33), no host synchronisation in between.  The extraction may run on a stream shared by several
 // trackers (vo_tracker_config.extract_stream): batch i + 1's extraction then overlaps batch i's searches and pose
 // solves (two events order them).  Round 2 kept this sequence in Python (vo_slam_test_amd/tracking.py) without the
 // culling step and with the local-map projections fixed before the first solve; host code is now C++
@@ -237,20 +236,6 @@ __global__ __launch_bounds__(256) void k_track_in_frame(InFrameArgs A) {
   __syncthreads();
   if (q < A.nq) in_frame_query(A, f, q, s_T);
 }
-// k_track_cull followed by k_track_in_frame in ONE launch, one workgroup per frame (the second reads the
-// last-frame-matched marks the first writes: a workgroup barrier orders them for the frame; the queries of the frame are
-// walked 256 at a time)
-__global__ __launch_bounds__(256) void k_track_cull_in_frame(CullArgs C, InFrameArgs A) {
-  __shared__ int s_cnt[4];
-  __shared__ double s_T[10];
-  const int f = blockIdx.x;
-  if (threadIdx.x == 0) in_frame_pose(A, f, s_T);
-  cull_frame(C, f, s_cnt);
-  __threadfence_block();
-  __syncthreads();
-  for (int q = threadIdx.x; q < A.nq; q += 256) in_frame_query(A, f, q, s_T);
-}
-
 // trackLocalMap's inlier count (visualOdometry.cpp:289-300): features that hold a map point with observations and are
 // no outlier of the second solve; and the per-frame status word.
 __global__ __launch_bounds__(256) void k_track_count(int cap, const int *ranges, const int *index, const uint8_t *outlier,
@@ -332,7 +317,6 @@ struct vo_tracker {
   bool have_link = false;
   // a search's matches that the next solve_pose writes into the frame's slots (k_track_scatter_gather)
   struct { const int32_t *assigned = nullptr; const double *qpoints = nullptr; const uint8_t *qflags = nullptr; int stride = 0; } pend;
-  bool in_frame_done = false;  // k_track_cull_in_frame has produced the local-map queries of this call
   int first_min_matches = 20;
   // trackRefKeyFrame's reference key-frame per frame of the batch (host copies: the common-node walk is host work)
   const vo_vocab *ref_vocab = nullptr;
@@ -601,9 +585,11 @@ InFrameArgs in_frame_args(vo_tracker *t) {
                      t->q1_viewcos.as<float>()};
 }
 
-// solvePoseOnlySE3 + cullingOutliersBeforeLocalMap (:249-250 / :271-272); with_in_frame: the local-map stage follows in
-// the same call, and its isInFrame pass (which needs this stage's pose and marks) rides in the culling launch
-int stage_solve_cull(vo_tracker *t, bool with_in_frame) {
+// solvePoseOnlySE3 + cullingOutliersBeforeLocalMap (:249-250 / :271-272)
+// (Round 5 tried the culling and the isInFrame pass of the local-map stage in ONE launch, one workgroup per frame with a barrier
+//  between the two: 172 us per 1024 frames against 24 + 50 for the two launches -- a frame's ~1900 queries walked by 256 threads
+//  in 8 dependent trips leave one wavefront per SIMD, where the separate kernel runs 8 workgroups per frame side by side.)
+int stage_solve_cull(vo_tracker *t) {
   hipStream_t st = t->st;
   StageTimer tm(t, 3, st);
   VO_CHECK(solve_pose(t));
@@ -611,14 +597,7 @@ int stage_solve_cull(vo_tracker *t, bool with_in_frame) {
                    t->fhas.as<uint8_t>(), t->fobs.as<uint8_t>(), t->last_matched.as<uint8_t>(), t->nobs_first.as<int>(),
                    t->assigned_first.as<int>(), t->pose.as<double>(), t->pose_first.as<double>(), t->ninl.as<int>(),
                    t->ninl_first.as<int>()};
-  t->in_frame_done = false;
-  // (a few frames: one workgroup per frame walks its ~2000 queries in 8 trips, 15.6 us against 4.1 + 4.5 for the two launches)
-  if (with_in_frame && t->nq_local > 0 && t->B >= 32) {
-    hipLaunchKernelGGL(k_track_cull_in_frame, dim3(t->B), dim3(256), 0, st, C, in_frame_args(t));
-    t->in_frame_done = true;
-  } else {
-    hipLaunchKernelGGL(k_track_cull, dim3(t->B), dim3(256), 0, st, C);
-  }
+  hipLaunchKernelGGL(k_track_cull, dim3(t->B), dim3(256), 0, st, C);
   VO_HIP_CHECK(hipGetLastError());
   return VO_OK;
 }
@@ -635,9 +614,7 @@ int stage_local(vo_tracker *t, const vo_tracker_params &P) {
   {
     StageTimer tm(t, 4, st);
     if (t->nq_local > 0) {
-      if (!t->in_frame_done)  // (the local-map stage on its own: vo_tracker_track_local_map)
-        hipLaunchKernelGGL(k_track_in_frame, dim3((t->nq_local + 255) / 256, B), dim3(256), 0, st, in_frame_args(t));
-      t->in_frame_done = false;
+      hipLaunchKernelGGL(k_track_in_frame, dim3((t->nq_local + 255) / 256, B), dim3(256), 0, st, in_frame_args(t));
       // (`assigned` was cleared by k_track_cull)
       q.n_queries = t->nq_local, q.stride = t->n_local, q.flags = t->q1_flags.as<uint8_t>(), q.u = t->q1_u.as<float>();
       q.v = t->q1_v.as<float>(), q.aux = t->q1_aux.as<float>(), q.level = t->q1_level.as<int32_t>();
@@ -702,7 +679,7 @@ int run_pipeline(vo_tracker *t, const uint8_t *dev_images, int img_pitch, size_t
     t->first_min_matches = 15;  // :268
     VO_CHECK(stage_ref_keyframe(t, P));
   }
-  if (run & (kRunMotion | kRunRefKeyFrame)) VO_CHECK(stage_solve_cull(t, (run & kRunLocal) != 0));
+  if (run & (kRunMotion | kRunRefKeyFrame)) VO_CHECK(stage_solve_cull(t));
   // (the result block is written by the last kernel of either route: k_track_count / k_track_first_status)
   if (run & kRunLocal) {
     VO_CHECK(stage_local(t, P));
