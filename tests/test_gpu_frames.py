@@ -420,3 +420,83 @@ def test_frame_construct_in_one_call(vo, orc, depth_kind):
         orc.lib().orc_find_depth(n, x, y, ux, dimg, W, H, W, float(cam5[4]), ur, dep)
     assert np.array_equal(got["uright"], ur) and np.array_equal(got["depth"], dep)
     fr.close(), ext.close()
+
+
+def test_scatter_gather_in_one_launch_equals_the_two_launches(vo, orc):
+    """vo_track_scatter_gather_dev (what the tracker runs between a search and the pose solve) against
+    vo_track_scatter_dev followed by vo_track_gather_dev on the same state: every output array bit for bit --
+    features claimed by a query, features that held a point before, features with neither, a frame without any."""
+    import torch
+    B, stride = 3, 700
+    imgs = synth.make_frames(B, start=40)
+    ext, kps, desc, cnt = _extract_dev(vo, imgs)
+    raw = np.stack([synth.make_depth(40 + i) for i in range(B)])
+    inv = np.float32(1.0) / np.float32(synth.DEPTH_SCALE)
+    fr = vo.Frames(B, 2048, synth.CAM.astype(np.float32), None)
+    st = torch.cuda.current_stream().cuda_stream
+    fr.build_dev(kps, desc, cnt, torch.from_numpy(raw.view(np.int16)).cuda(), float(inv), stream=st)
+    torch.cuda.synchronize()
+    cap, n = fr.cap, cnt.cpu().numpy()
+    rng = np.random.default_rng(5)
+    assigned = np.full((B, cap), -1, np.int32)
+    fhas0 = np.zeros((B, cap), np.uint8)
+    fpoint0 = rng.normal(size=(B, cap, 3))
+    for f in range(2):  # frame 2: nothing assigned, nothing held
+        idx = rng.permutation(n[f])
+        claimed, held = idx[: n[f] // 3], idx[n[f] // 3: n[f] // 2]
+        assigned[f, claimed] = rng.permutation(stride)[: len(claimed)]
+        fhas0[f, held] = 1
+    qpts = rng.normal(size=(B, stride, 3))
+    qfl = rng.integers(0, 4, size=(B, stride)).astype(np.uint8)
+    sf = _sf(orc)
+    L = vo.lib()
+
+    def dev(a):
+        return torch.from_numpy(np.ascontiguousarray(a)).cuda()
+
+    def run(fused):
+        d = dict(assigned=dev(assigned), qp=dev(qpts), qf=dev(qfl), fpoint=dev(fpoint0), fhas=dev(fhas0),
+                 fobs=dev(np.zeros((B, cap), np.uint8)), pts=dev(np.zeros((B, cap, 3))), obs=dev(np.zeros((B, cap, 3))),
+                 isg=dev(np.zeros((B, cap))), ranges=dev(np.zeros((B, 2), np.int32)), index=dev(np.full((B, cap), -7, np.int32)))
+        p = lambda k: C.c_void_p(d[k].data_ptr())
+        if fused:
+            vo.check(L.vo_track_scatter_gather_dev(fr._h, 0, B, p("assigned"), p("qp"), p("qf"), stride, p("fpoint"), p("fhas"),
+                                                   p("fobs"), vo._p(sf), len(sf), p("pts"), p("obs"), p("isg"), p("ranges"),
+                                                   p("index"), C.c_void_p(st)), "vo_track_scatter_gather_dev")
+        else:
+            vo.check(L.vo_track_scatter_dev(fr._h, 0, B, p("assigned"), p("qp"), p("qf"), stride, p("fpoint"), p("fhas"),
+                                            p("fobs"), C.c_void_p(st)), "vo_track_scatter_dev")
+            vo.check(L.vo_track_gather_dev(fr._h, 0, B, p("fpoint"), p("fhas"), vo._p(sf), len(sf), p("pts"), p("obs"), p("isg"),
+                                           p("ranges"), p("index"), C.c_void_p(st)), "vo_track_gather_dev")
+        torch.cuda.synchronize()
+        return {k: v.cpu().numpy() for k, v in d.items()}
+
+    a, b = run(False), run(True)
+    counts = a["ranges"][:, 1]
+    assert counts[0] > 100 and counts[1] > 100 and counts[2] == 0
+    for k in a:
+        assert np.array_equal(a[k], b[k]), k
+    ext.close()
+    fr.close()
+
+
+def test_extractor_launch_order_option_changes_nothing(vo, orc):
+    """VO_ORB_OPT_EARLY_LEVEL0: level 0's FAST cells and blur next to the resize chain -- same key-points and descriptors."""
+    import torch
+    imgs = synth.make_frames(4, start=7)
+    outs = []
+    for early in (False, True):
+        ext = vo.OrbExtractor(1000, 1.2, 8, 20, 7)
+        ext.set_early_level0(early)
+        cap, B = ext.max_keypoints(), len(imgs)
+        t = torch.from_numpy(np.ascontiguousarray(imgs)).cuda()
+        kps = torch.zeros((B, cap, 28), dtype=torch.uint8, device="cuda")
+        desc = torch.zeros((B, cap, 32), dtype=torch.uint8, device="cuda")
+        cnt = torch.zeros(B, dtype=torch.int32, device="cuda")
+        ext.extract_batch_dev(t, kps, desc, cnt)
+        ext.sync()
+        outs.append((kps.cpu().numpy(), desc.cpu().numpy(), cnt.cpu().numpy()))
+        ext.close()
+    assert outs[0][2].min() > 500
+    for x, y in zip(outs[0], outs[1]):
+        assert np.array_equal(x, y)
