@@ -61,6 +61,27 @@ def test_pose_only_batch_and_edge_cases(vo, orc):
         assert np.abs(poses[i] - opose).max() < 1e-8, i
 
 
+@pytest.mark.parametrize("block", [64, 128])
+def test_pose_only_one_wavefront_form_on_ragged_sizes(vo, orc, block):
+    """The batched (one wavefront per frame) kernel, forced through vo_set_option(VO_OPT_POSE_BLOCK) on a handful of
+    problems: observation counts around the edges of its batches of 4 x 64 (two register sets, the first batch of the
+    next pass requested behind the last trip) and beyond them."""
+    sizes = [1, 63, 64, 65, 255, 256, 257, 511, 513, 768, 1000, 1024, 1025, 1300, 2049]
+    probs = [synth.make_pose_problem(40 + i, n=n) for i, n in enumerate(sizes)]
+    vo.set_option("pose_block", block)
+    try:
+        poses, masks, ninl, sums = vo.Optimizer.solvePoseOnlySE3(probs, summaries=True)
+    finally:
+        vo.set_option("pose_block", 0)
+    for i, pr in enumerate(probs):
+        opose, ooutl, oninl, osums, _ = orc.pose_only(pr)
+        assert ninl[i] == oninl, (sizes[i], ninl[i], oninl)
+        assert np.array_equal(masks[i], ooutl), sizes[i]
+        assert np.abs(poses[i] - opose).max() < 1e-8, sizes[i]
+        for r in range(2):
+            assert sums[2 * i + r].iterations == osums[r].iterations, (sizes[i], r)
+
+
 def _good_problem(seed, **kw):
     pr = synth.make_lba_problem(seed, **kw)
     return pr
