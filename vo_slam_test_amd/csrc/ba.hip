@@ -498,7 +498,7 @@ __device__ void pose_lm(double x[6], int n, const ObsView &V, const Cam &K, doub
   const double initial_cost = x_cost;
   auto norm6 = [](const double (&v)[6]) {
     const double s2 = v[0] * v[0] + v[1] * v[1] + v[2] * v[2] + v[3] * v[3] + v[4] * v[4] + v[5] * v[5];
-    return s2 > 0.0 ? s2 * rsqrt_fast(s2) : 0.0;
+    return s2 > 1e-280 ? s2 * rsqrt_fast(s2) : 0.0;  // (|x| below 1e-140 counts as zero: the test adds 1e-8 to it)
   };
   double x_norm;
   {

@@ -81,7 +81,7 @@ VO_HD Se3 se3_exp(const double xi[6]) {
   Se3 T;
   const double wx = xi[3], wy = xi[4], wz = xi[5];
   const double th2 = wx * wx + wy * wy + wz * wz;
-  const double rth = (FAST && th2 > 0.0) ? rsqrt_fast(th2) : 0.0;  // FAST: 1 / theta, and theta = theta^2 / theta
+  const double rth = (FAST && th2 > 1e-280) ? rsqrt_fast(th2) : 0.0;  // FAST: 1 / theta, and theta = theta^2 / theta (below 1e-140: the zero rotation -- v_rsq_f64 of a denormal is not to be relied on)
   const double theta = FAST ? th2 * rth : sqrt(th2);
   const double half = 0.5 * theta;
   double sh, ch;
