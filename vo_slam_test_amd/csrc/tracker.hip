@@ -646,6 +646,7 @@ int stage_local(vo_tracker *t, const vo_tracker_params &P) {
 int run_pipeline(vo_tracker *t, const uint8_t *dev_images, int img_pitch, size_t img_frame_stride, const void *dev_depth,
                  int depth_kind, size_t depth_frame_stride, int depth_pitch, const vo_tracker_params *prm, unsigned run) {
   VO_CHECK(begin_timed_call(t));
+  t->pend.assigned = nullptr;  // (a call that failed half-way must not leave its matches to the next one)
   if (!(run == (kRunFront | kRunMotion | kRunLocal))) t->tslot = -1;  // the six stage timers describe the one-call tracked frame
   const int B = t->B;
   hipStream_t st = t->st;
