@@ -167,12 +167,7 @@ struct PoseLm {
 // four trips ahead of its use the plain reads are as fast (0.284 against 0.286 ms per 1024 frames), and the 148 KB of
 // LDS per CU the cache took go to the extraction kernels that run next to the solve (tracked step 4.39 -> 4.14 ms).
 #define VO_GLOBAL __attribute__((address_space(1)))
-#ifndef VO_POSE_ND
-#define VO_POSE_ND 4
-#endif
-#ifndef VO_POSE_WRAP
-#define VO_POSE_WRAP 1  // developer A/B: 0 = every pass requests its first batch itself (and the hand-offs of the reduction wait for it)
-#endif
+constexpr int kPoseNd = 4;  // trips of 64 observations per register set of the one-wavefront pass (5 / 6: spills, round 3)
 struct ObsView {
   const VO_GLOBAL double *pts, *obs, *isg;
   VO_GLOBAL uint8_t *outlier;  // the result, and the skip mask of a pass
@@ -237,7 +232,6 @@ __device__ __forceinline__ void pose_obs_term(const PoseCache &P, const double (
 
 // A batch of observations of the one-wavefront form: ND trips of 64, in registers.
 struct PoseOb { double pw[3], ou, ov, our, is; unsigned skip; };
-constexpr int kPoseNd = VO_POSE_ND;
 // The loads take the wave-uniform bases from scalar registers and a 32-bit byte offset per lane (an int index costs
 // twelve 64-bit address operations per observation); unconditional, the raw flag byte included: a bool would be
 // compared, i.e. waited for, where it is loaded.
@@ -278,13 +272,12 @@ __device__ __forceinline__ void pose_accumulate(const PoseCache &P, int n, const
         if (base + 64u * k + lane <= last && !o[k].skip) pose_obs_term(P, o[k].pw, o[k].ou, o[k].ov, o[k].our, o[k].is, K, hm, hs, acc);
     };
     PoseOb B[ND];
-    if (!VO_POSE_WRAP) pose_request(V, 0, last, first);
 #pragma unroll 1
     for (unsigned base = 0; base <= last; base += 2 * ND * 64) {
       pose_request(V, base + ND * 64, last, B);
       eval(base, first);
       const unsigned nb = base + 2 * ND * 64;
-      pose_request(V, (VO_POSE_WRAP && nb > last) ? 0u : nb, last, first);  // behind the last trip: batch 0 for the next pass
+      pose_request(V, nb > last ? 0u : nb, last, first);  // behind the last trip: batch 0 for the next pass (0.2275 -> 0.2235 ms)
       eval(base + ND * 64, B);  // (a batch wholly past the end evaluates nothing: every lane fails the range test)
     }
     return;
@@ -360,12 +353,8 @@ struct PoseRed {
   static constexpr int kScratch = (ONE_PASS ? 28 : 14) * kPitch;
 };
 __device__ __forceinline__ void wave_lds_handoff() {
-#if VO_POSE_WRAP
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // LDS only: the next pass's first batch stays in flight
   __builtin_amdgcn_wave_barrier();
-#else
-  wave_lds_sync();
-#endif
 }
 template <bool ONE_PASS>
 __device__ __forceinline__ void wave_reduce28(const double (&v)[28], double *scratch, double *dst) {
@@ -460,7 +449,7 @@ __device__ void pose_lm(double x[6], int n, const ObsView &V, const Cam &K, doub
 #endif
   bool in_loop_ = false;  // (stamps)
   PoseOb first[kPoseNd];  // batch 0 of the next pass (one-wavefront form)
-  if (WAVE && VO_POSE_WRAP) pose_request(V, 0, (unsigned)(n - 1), first);
+  if (WAVE) pose_request(V, 0, (unsigned)(n - 1), first);
   auto linearize = [&](const Se3 &T, double *dst) {  // sums of the linearisation at T -> dst (LDS)
     double v[28];
     pose_accumulate<WAVE>(pose_cache_se3(T), n, V, K, hm, hs, v, first);

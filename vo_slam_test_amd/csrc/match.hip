@@ -17,11 +17,7 @@ using namespace vo;
 // a wavefront reads whole lines) and streams the 128-row A tile from LDS (all lanes read the same address: a broadcast,
 // no bank conflict); results leave as one packed store per lane per row -- the kernel is bound by the 2 bytes/pair it
 // writes and by the 16 vector instructions a distance costs.
-#ifndef VO_HAM_NC
-#define VO_HAM_NC 4  // developer A/B: B descriptors (columns) per thread, 2 or 4
-#endif
 constexpr int kHamRows = 128;
-constexpr int kHamNc = VO_HAM_NC;
 typedef uint32_t ham_u32x4 __attribute__((ext_vector_type(4)));
 typedef uint32_t ham_u32x2 __attribute__((ext_vector_type(2)));
 
@@ -106,7 +102,7 @@ int launch_hamming(const uint8_t *a, int na, size_t as, const uint8_t *b, int nb
   if (na <= 0 || nb <= 0 || n_pairs <= 0) return VO_OK;
   // the 8-byte stores of the 4-column form need 8-byte aligned rows: D itself and the pair stride
   const bool al8 = (reinterpret_cast<uintptr_t>(d) & 7) == 0 && (ds & 3) == 0;
-  if (kHamNc == 4 && al8) {
+  if (al8) {
     dim3 grid((nb + 1023) / 1024, (na + kHamRows - 1) / kHamRows, n_pairs);
     hipLaunchKernelGGL(k_hamming<4>, grid, dim3(256), 0, st, reinterpret_cast<const uint32_t *>(a), na, (long long)as,
                        reinterpret_cast<const uint32_t *>(b), nb, (long long)bs, d, (long long)ds);
