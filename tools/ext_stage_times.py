@@ -11,7 +11,7 @@ stream = torch.cuda.Stream()
 ext = vo.OrbExtractor(1000, 1.2, 8, 20, 7)
 ext.set_stream(stream.cuda_stream)
 if hasattr(ext, 'set_fused'):
-    ext.set_fused(int(os.environ.get('VO_EXT_FUSED', '1')))  # 0: the three separate kernels per level
+    ext.set_fused(int(os.environ.get('VO_EXT_FUSED', '0')))  # 0: the three separate kernels per level
 cap = ext.max_keypoints()
 with torch.cuda.stream(stream):
     frames = torch.from_numpy(synth.make_frames(32)).cuda().repeat(B // 32, 1, 1).contiguous()
