@@ -779,7 +779,7 @@ void vo_tracker_destroy(vo_tracker *t) {
                     &t->q1_level, &t->q1_viewcos, &t->q1_desc, &t->p1, &t->nrm1, &t->mind1, &t->maxd1, &t->pf1, &t->link1, &t->Tcw,
                     &t->pose0, &t->pose, &t->pose_first, &t->resblk, &t->assigned, &t->assigned_first, &t->nm, &t->nm_first, &t->fpoint,
                     &t->fhas, &t->fobs, &t->pts, &t->obs, &t->isg, &t->ranges, &t->index, &t->outlier, &t->ninl, &t->ninl_first,
-                    &t->nobs_first, &t->ntracked, &t->status})
+                    &t->nobs_first, &t->ntracked, &t->status, &t->retry_nq, &t->foutl})
     b->release();
   if (t->own_st && t->st) (void)hipStreamDestroy(t->st);
   if (t->own_est && t->est) (void)hipStreamDestroy(t->est);
