@@ -751,8 +751,10 @@ enum { VO_BA_OPT_SEGMENTS = 1, VO_BA_OPT_COLLECTIVES_AT_ONE_RANK = 2, VO_BA_OPT_
 int vo_ba_set_option(vo_ba *h, int option, int value);
 /* Process-wide developer knobs: VO_OPT_BA_GRAPH 1 = replay the LM iteration sequence of an unsharded solve from a
  * hipGraph (default 0: eager launches are faster on this stack); VO_OPT_POSE_BLOCK = threads per
- * frame of the pose-only solver (0 = automatic, 64, 128, 256). */
-enum { VO_OPT_BA_GRAPH = 1, VO_OPT_POSE_BLOCK = 2 };
+ * frame of the pose-only solver (0 = automatic, 64, 128, 256); VO_OPT_HAMMING_KERNEL = which form of the all-pairs Hamming
+ * kernel vo_hamming_matrix* launch: 0 (default) = int8 matrix-core dot products, 1 = the xor / popcount VALU form (identical
+ * results). */
+enum { VO_OPT_BA_GRAPH = 1, VO_OPT_POSE_BLOCK = 2, VO_OPT_HAMMING_KERNEL = 3 };
 int vo_set_option(int option, int value);
 /* Multi-GPU from C/C++: the all-reduce the sharded LM loop needs (sum of n doubles at dev_buf over all
  * shards, in place, ordered on hip_stream; returns 0).  With RCCL this is

@@ -7,8 +7,17 @@ from vo_slam_test_amd import synth
 pytestmark = pytest.mark.gpu
 
 
-@pytest.mark.parametrize("na,nb", [(1, 1), (7, 13), (1000, 1000), (1003, 999), (33, 2049), (0, 5)])
-def test_hamming_matrix(vo, orc, na, nb):
+@pytest.fixture(params=[0, 1], ids=["mfma", "valu"])
+def ham_kernel(vo, request):
+    """both forms of K6 (vo_set_option(VO_OPT_HAMMING_KERNEL)): int8 matrix-core dot products (default) / xor + popcount"""
+    vo.set_option("hamming_kernel", request.param)
+    yield request.param
+    vo.set_option("hamming_kernel", 0)
+
+
+@pytest.mark.parametrize("na,nb", [(1, 1), (7, 13), (1000, 1000), (1003, 999), (33, 2049), (0, 5), (129, 8), (31, 1024),
+                                   (128, 136), (257, 127)])
+def test_hamming_matrix(vo, orc, ham_kernel, na, nb):
     a, b = synth.random_descriptors(na, 1), synth.random_descriptors(nb, 2)
     d = vo.hamming_matrix(a, b)
     assert d.shape == (na, nb)
@@ -18,12 +27,21 @@ def test_hamming_matrix(vo, orc, na, nb):
         assert np.array_equal(d[:5, :7], bits[:, :min(7, nb)])
 
 
-def test_hamming_extremes(vo):
+def test_hamming_extremes(vo, ham_kernel):
+    """all-zero / all-one descriptors (popcounts 0 and 256: the byte-sized pieces of the matrix-core form's ninth K-step) and
+    sparse / dense ones in between"""
     z, o = np.zeros((3, 32), np.uint8), np.full((2, 32), 255, np.uint8)
     assert (vo.hamming_matrix(z, o) == 256).all() and (vo.hamming_matrix(z, z) == 0).all()
+    assert (vo.hamming_matrix(o, z) == 256).all() and (vo.hamming_matrix(o, o) == 0).all()
+    rng = np.random.default_rng(5)
+    dens = rng.random((40, 1, 1)) ** 3
+    a = np.packbits(rng.random((40, 32, 8)) < dens, axis=2).reshape(40, 32)
+    b = np.packbits(rng.random((40, 32, 8)) < 1 - dens, axis=2).reshape(40, 32)
+    want = np.unpackbits(a[:, None, :] ^ b[None, :, :], axis=2).sum(2)
+    assert np.array_equal(vo.hamming_matrix(a, b), want)
 
 
-def test_hamming_batch_dev(vo, orc):
+def test_hamming_batch_dev(vo, orc, ham_kernel):
     import torch
     P, n = 5, 1000
     a = np.stack([synth.random_descriptors(n, 10 + p) for p in range(P)])
@@ -35,6 +53,24 @@ def test_hamming_batch_dev(vo, orc):
     got = td.cpu().numpy().view(np.uint16)
     for p in range(P):
         assert np.array_equal(got[p], orc.hamming_matrix(a[p], b[p]))
+
+
+def test_hamming_unaligned_views(vo, orc, ham_kernel):
+    """descriptor arrays at 4-byte (not 16-byte) aligned addresses, an odd column count and a matrix at a 2-byte aligned
+    address: the dword-load / u16-store paths of both kernels"""
+    import torch
+    na, nb = 77, 203
+    a, b = synth.random_descriptors(na, 3), synth.random_descriptors(nb, 4)
+    ta = torch.zeros(na * 32 + 4, dtype=torch.uint8, device="cuda")
+    tb = torch.zeros(nb * 32 + 12, dtype=torch.uint8, device="cuda")
+    ta[4:].copy_(torch.from_numpy(a).reshape(-1))
+    tb[12:].copy_(torch.from_numpy(b).reshape(-1))
+    td = torch.full((na * nb + 1,), -1, dtype=torch.int16, device="cuda")
+    vo.hamming_matrix_dev(ta[4:].view(na, 32), tb[12:].view(nb, 32), td[1:], stream=torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    got = td.cpu().numpy().view(np.uint16)
+    assert got[0] == 0xFFFF
+    assert np.array_equal(got[1:].reshape(na, nb), orc.hamming_matrix(a, b))
 
 
 def _frame_pair(orc, idx):

@@ -911,8 +911,9 @@ def sim3_reanchor_points(points, ref, S_rw, S_wr):
 
 
 def set_option(option, value):
-    """vo_set_option: 'ba_graph' (1: hipGraph replay of unsharded LM loops) / 'pose_block' (0, 64, 128, 256)."""
-    code = {"ba_graph": 1, "pose_block": 2}.get(option, option)
+    """vo_set_option: 'ba_graph' (1: hipGraph replay of unsharded LM loops) / 'pose_block' (0, 64, 128, 256) /
+    'hamming_kernel' (0: int8 matrix cores, 1: xor + popcount on the VALU)."""
+    code = {"ba_graph": 1, "pose_block": 2, "hamming_kernel": 3}.get(option, option)
     check(lib().vo_set_option(int(code), int(value)), "vo_set_option")
 
 

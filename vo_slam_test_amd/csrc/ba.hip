@@ -3847,6 +3847,13 @@ int vo_set_option(int option, int value) {
       }
       g_opt_pose_block.store(value);
       return VO_OK;
+    case VO_OPT_HAMMING_KERNEL:
+      if (value != 0 && value != 1) {
+        vo::set_error("vo_set_option(VO_OPT_HAMMING_KERNEL): 0 (matrix cores) or 1 (VALU)");
+        return VO_ERR_INVALID;
+      }
+      vo::set_hamming_kernel(value);
+      return VO_OK;
     default: vo::set_error("vo_set_option: unknown option %d", option); return VO_ERR_INVALID;
   }
 }

@@ -6,6 +6,7 @@
 #include "vo_common.h"
 
 #include <algorithm>
+#include <atomic>
 #include <cmath>
 #include <vector>
 
@@ -97,9 +98,227 @@ __global__ __launch_bounds__(256) void k_hamming(const uint32_t *__restrict__ A,
   }
 }
 
+// K6 on the matrix cores (round 6).  The VALU form above costs 16 vector instructions per distance and is bound by their
+// issue (262 M wave-instructions per 1024 pairs of 1000 x 1000), not by the 2 bytes per distance it writes.  A Hamming
+// distance is an integer dot product: with p_i = |A_i|, q_j = |B_j| and a' the complemented bits of A_i,
+//     ham(i, j) = p_i - q_j + sum_k (2 a'_ik) b_jk,
+// so v_mfma_i32_32x32x32_i8 computes 32 x 32 distances in 8 K-steps of 32 bits on operands unpacked to bytes
+// (b -> {0, 1}, a' -> {0, 2}) plus a ninth step whose operands carry (p_i in four byte-sized pieces | 1 1 1 1) and
+// (1 1 1 1 | -q_j in four pieces): the accumulator holds the distance itself, exact in int32.  Unpacking 4 bits to the 4
+// bytes of a dword is v_bfe + v_mul_u32_u24 (t * 0x00204081 puts bit i at bit 8 i, no carries) + v_and.  (The order of the
+// bits along K is whatever the unpacking makes it -- the same for both operands, which is all a dot product needs.)
+//   workgroup = 4 wavefronts = 128 rows x ALL columns, in chunks of 128 columns: every wavefront unpacks one 32-column
+// tile of the chunk into LDS (the MFMA "A" operand, 9 x 16 bytes per lane), keeps its own 32 rows (the "B" operand) in
+// registers, and runs 4 x 9 MFMAs per chunk; M = column, N = row, so a lane ends up with 4 consecutive columns of one row
+// per accumulator group: packed to u16 they go through a wave-private LDS image and leave as 16-byte stores (see
+// "Emission" in the kernel: whole 128-byte lines only, which is what decides the speed of this kernel).
+// Per 1024 distances: 9 MFMAs (288 of the SIMD's cycles, a third of what the 2 KB of stores leave room for at HBM
+// rate) and ~45 vector instructions instead of 256.  1024 pairs of 1000 x 1000: 0.41 ms against 0.505 (in bench.py's
+// extract + match leg, interleaved on one box; a linear fill of the same 2.05 GB takes 0.36-0.38).
+typedef int ham_i32x4 __attribute__((ext_vector_type(4)));
+typedef int ham_i32x16 __attribute__((ext_vector_type(16)));
+constexpr int kHmRows = 128;       // rows per workgroup (32 per wavefront)
+constexpr int kHmChunkTiles = 4;   // 32-column tiles per chunk
+constexpr int kHmSteps = 9;        // 8 K-steps of 32 descriptor bits + the popcount step
+constexpr int kHmXBytes = kHmChunkTiles * kHmSteps * 64 * 16;
+constexpr int kHmTBytes = 32 * 256;  // a wavefront's store image: 32 rows x one chunk of 128 columns
+
+// the 16 bits [16 h, 16 h + 16) of q as 16 bytes: bit b -> byte b = (mask's byte) if set
+__device__ __forceinline__ ham_i32x4 ham_unpack16(uint32_t q, uint32_t sh, uint32_t mul, uint32_t mask) {
+  ham_i32x4 r;
+#pragma unroll
+  for (int n = 0; n < 4; n++) r[n] = (int)(__umul24(__builtin_amdgcn_ubfe(q, sh + 4 * n, 4), mul) & mask);
+  return r;
+}
+
+__device__ __forceinline__ void ham_load_desc(const uint32_t *src, bool wide, uint32_t q[8]) {
+  if (wide) {
+    const ham_u32x4 q0 = reinterpret_cast<const ham_u32x4 *>(src)[0], q1 = reinterpret_cast<const ham_u32x4 *>(src)[1];
+#pragma unroll
+    for (int w = 0; w < 4; w++) q[w] = q0[w], q[4 + w] = q1[w];
+  } else {
+#pragma unroll
+    for (int w = 0; w < 8; w++) q[w] = src[w];
+  }
+}
+
+// halfword h of each of the descriptor's 8 dwords, two per register (sel: v_perm_b32 selector of the lane's half)
+__device__ __forceinline__ void ham_compress(const uint32_t q[8], uint32_t sel, uint32_t out[4], uint32_t &pop) {
+  pop = 0;
+#pragma unroll
+  for (int k = 0; k < 4; k++) {
+    pop += __popc(q[2 * k]) + __popc(q[2 * k + 1]);
+    out[k] = __builtin_amdgcn_perm(q[2 * k + 1], q[2 * k], sel);
+  }
+}
+
+constexpr int kHmSuper = 8;  // chunks whose column tiles a wavefront fetches at once (1024 columns)
+
+template <bool VEC_STORE>
+__global__ __launch_bounds__(256, 2) void k_hamming_mfma(const uint32_t *__restrict__ A, int na, long long a_stride,
+                                                         const uint32_t *__restrict__ B, int nb, long long b_stride,
+                                                         uint16_t *__restrict__ D, long long d_stride) {
+  __shared__ __attribute__((aligned(16))) uint8_t lds[kHmXBytes + 4 * kHmTBytes];
+  ham_i32x4 *X = reinterpret_cast<ham_i32x4 *>(lds);
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, m = lane & 31, h = lane >> 5;
+  uint8_t *T = lds + kHmXBytes + wave * kHmTBytes;
+  const long long p = blockIdx.z;
+  A += p * a_stride * 8;
+  B += p * b_stride * 8;
+  D += p * d_stride;
+  const bool wide = ((reinterpret_cast<uintptr_t>(A) | reinterpret_cast<uintptr_t>(B)) & 15) == 0;  // uniform
+  const int i0 = blockIdx.x * kHmRows + wave * 32;
+  const uint32_t sel = h ? 0x07060302u : 0x05040100u;
+
+  // this wavefront's rows: 2 x complemented bits, and (p pieces | ones) in the ninth step (lanes 0-31 only)
+  ham_i32x4 Y[kHmSteps];
+  {
+    uint32_t q[8], c4[4], pc;
+    ham_load_desc(A + (long long)min(i0 + m, na - 1) * 8, wide, q);
+    ham_compress(q, sel, c4, pc);
+#pragma unroll
+    for (int s = 0; s < 8; s++) Y[s] = ham_unpack16(~c4[s >> 1], 16 * (s & 1), 0x00408102u, 0x02020202u);
+    const uint32_t pieces = (pc >> 2) | (((pc + 1) >> 2) << 8) | (((pc + 2) >> 2) << 16) | (((pc + 3) >> 2) << 24);
+    Y[8] = h ? ham_i32x4{0, 0, 0, 0} : ham_i32x4{(int)pieces, 0x01010101, 0, 0};
+  }
+
+  // Emission (VEC_STORE): a row leaves in 128-byte windows on the 128-byte LINES of memory, 8 lanes x 16 bytes per row, 8 rows
+  // per instruction.  The rows are 2 nb bytes apart (2000: not a multiple of the line), so row r's windows are shifted by
+  // s_r = (address of the row) mod 128 against its columns; the store image T is a ring of 256 bytes per row (the two halves
+  // of a chunk), from which window k = bytes [128 k - s_r, 128 k + 128 - s_r) of the row is read once half-chunk k is in.
+  // The piece in front of a row's first line boundary shares its line with the previous row's tail: it is kept in registers
+  // and stored in the last step, next to that tail.  Measured on the bare store pattern (tools/microbench/write_pattern.hip,
+  // 2.05 GB): 256-byte pieces at fixed column offsets 0.56-0.60 ms, whole lines 0.48-0.51, whole lines with head and tail
+  // written together 0.38 = a linear fill (a partial line whose other part arrives microseconds later is what costs).
+  const int erow = lane >> 3, ep = lane & 7;
+  uint8_t *eline[4];  // the line the row starts in
+  int elo[4], ehi[4];  // the row's bytes are [elo, ehi) from there
+  ham_u32x4 ehead[4];
+#pragma unroll
+  for (int it = 0; it < 4; it++) {
+    const int r = i0 + 8 * it + erow;
+    uint8_t *rowp = reinterpret_cast<uint8_t *>(D + (long long)min(r, na - 1) * nb);
+    const int s = (int)(reinterpret_cast<uintptr_t>(rowp) & 127);
+    eline[it] = rowp - s;
+    elo[it] = s;
+    ehi[it] = r < na ? s + 2 * nb : s;
+    ehead[it] = ham_u32x4{0u, 0u, 0u, 0u};
+  }
+  // window k of the wavefront's 32 rows: T -> memory (4 instructions)
+  auto emit = [&](int k, bool first, bool heads_now) {
+#pragma unroll
+    for (int it = 0; it < 4; it++) {
+      const int rr = 8 * it + erow, e = 128 * k + 16 * ep;
+      const ham_u32x4 v =
+          *reinterpret_cast<const ham_u32x4 *>(T + rr * 256 + (((((e - elo[it]) >> 4) & 15) ^ (rr & 15)) << 4));
+      const bool in = e >= elo[it] && e < ehi[it];
+      if (first && elo[it] != 0) {
+        ehead[it] = v;  // (k = 0: everything in front of the first line boundary)
+      } else if (in) {
+        *reinterpret_cast<ham_u32x4 *>(eline[it] + e) = v;
+      }
+      if (heads_now) {
+        const int e0 = 16 * ep;
+        if (elo[it] != 0 && e0 >= elo[it] && e0 < ehi[it]) *reinterpret_cast<ham_u32x4 *>(eline[it] + e0) = ehead[it];
+      }
+    }
+  };
+
+  int k_half = 0;  // half-chunks (64 columns) emitted so far
+  for (int sc = 0; sc < nb; sc += 32 * kHmChunkTiles * kHmSuper) {
+    // No load inside the chunk loop: vmcnt counts loads and stores in one queue, and a wavefront that waited for the next
+    // chunk's descriptors waited for this chunk's stores as well (measured: compute 0.39 ms + stores 0.39 ms, not
+    // overlapped).  The column tiles this wavefront unpacks in the next 8 chunks (tile 4 c + wave of chunk c) are fetched
+    // here, all loads in flight at once, and kept as the lane's half of each dword: 4 registers + the popcount per tile.
+    uint32_t Bc[kHmSuper][4], Bp[kHmSuper];
+#pragma unroll
+    for (int k = 0; k < kHmSuper; k++) {
+      uint32_t q[8];
+      ham_load_desc(B + (long long)min(sc + (k * kHmChunkTiles + wave) * 32 + m, nb - 1) * 8, wide, q);
+      ham_compress(q, sel, Bc[k], Bp[k]);
+    }
+    const int n_chunks = min(kHmSuper, (nb - sc + 32 * kHmChunkTiles - 1) / (32 * kHmChunkTiles));
+#pragma nounroll
+    for (int c = 0; c < n_chunks; c++) {
+      {  // column tile 4 c + wave -> X[wave]: bits as {0, 1}, (ones | -q pieces) in the ninth step
+        ham_i32x4 *x = X + wave * kHmSteps * 64 + lane;
+#pragma unroll
+        for (int s = 0; s < 8; s++) x[s * 64] = ham_unpack16(Bc[0][s >> 1], 16 * (s & 1), 0x00204081u, 0x01010101u);
+        const uint32_t pc = Bp[0];
+        const uint32_t neg = ((0u - (pc >> 2)) & 255u) | (((0u - ((pc + 1) >> 2)) & 255u) << 8) |
+                             (((0u - ((pc + 2) >> 2)) & 255u) << 16) | (((0u - ((pc + 3) >> 2)) & 255u) << 24);
+        x[8 * 64] = h ? ham_i32x4{0, 0, 0, 0} : ham_i32x4{0x01010101, (int)neg, 0, 0};
+#pragma unroll
+        for (int k = 0; k + 1 < kHmSuper; k++) {  // the next chunk's tile moves to slot 0 (v_mov: the fast class)
+#pragma unroll
+          for (int w = 0; w < 4; w++) Bc[k][w] = Bc[k + 1][w];
+          Bp[k] = Bp[k + 1];
+        }
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");  // LDS only: stores stay in flight
+      if (i0 < na) {  // wave-uniform
+        const int col0 = sc + c * 32 * kHmChunkTiles;
+#pragma unroll
+        for (int hc = 0; hc < 2; hc++) {
+          if (col0 + hc * 64 < nb) {  // uniform
+#pragma unroll
+            for (int t = 2 * hc; t < 2 * hc + 2; t++) {
+              const ham_i32x4 *x = X + t * kHmSteps * 64 + lane;
+              ham_i32x16 acc = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+              for (int s = 0; s < kHmSteps; s++) acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(x[s * 64], Y[s], acc, 0, 0, 0);
+              // lane (m, h), registers 4 g .. 4 g + 3: row i0 + m, columns 32 t + 8 g + 4 h + 0..3 of the chunk; the 16-byte
+              // pieces of a row are stored at (piece ^ row): the 256-byte pitch alone would put every row in the same banks
+#pragma unroll
+              for (int g = 0; g < 4; g++) {
+                ham_u32x2 v = {(uint32_t)acc[4 * g] | ((uint32_t)acc[4 * g + 1] << 16),
+                               (uint32_t)acc[4 * g + 2] | ((uint32_t)acc[4 * g + 3] << 16)};
+                *reinterpret_cast<ham_u32x2 *>(T + m * 256 + (((4 * t + g) ^ (m & 15)) << 4) + h * 8) = v;
+              }
+            }
+            // the image is this wavefront's own: LDS operations of a wavefront complete in order, no workgroup barrier
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_wave_barrier();
+            if (VEC_STORE) {
+              if (k_half == 0) emit(0, true, false); else emit(k_half, false, false);
+            } else {
+              for (int e = lane; e < 32 * 64; e += 64) {
+                const int rr = e >> 6, cc = hc * 64 + (e & 63);
+                if (i0 + rr < na && col0 + cc < nb)
+                  D[(long long)(i0 + rr) * nb + col0 + cc] =
+                      *reinterpret_cast<const uint16_t *>(T + rr * 256 + ((((cc >> 3) ^ (rr & 15)) << 4) | ((cc & 7) << 1)));
+              }
+            }
+            k_half++;
+          }
+        }
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");  // X is rewritten by the next chunk
+    }
+  }
+  if (VEC_STORE && i0 < na) emit(k_half, false, true);  // the rows' last pieces, and the heads of the rows behind them
+}
+
+
+// vo_set_option(VO_OPT_HAMMING_KERNEL): 0 = the matrix-core form (default), 1 = the VALU form
+std::atomic<int> g_hamming_kernel{0};
+
 int launch_hamming(const uint8_t *a, int na, size_t as, const uint8_t *b, int nb, size_t bs, uint16_t *d,
                    size_t ds, int n_pairs, hipStream_t st) {
   if (na <= 0 || nb <= 0 || n_pairs <= 0) return VO_OK;
+  if (g_hamming_kernel.load(std::memory_order_relaxed) == 0) {
+    // 16-byte stores: D, the pair stride and every row start 16-byte aligned
+    const bool al16 = (reinterpret_cast<uintptr_t>(d) & 15) == 0 && (ds & 7) == 0 && (nb & 7) == 0;
+    dim3 grid((na + kHmRows - 1) / kHmRows, 1, n_pairs);
+    if (al16)
+      hipLaunchKernelGGL(k_hamming_mfma<true>, grid, dim3(256), 0, st, reinterpret_cast<const uint32_t *>(a), na,
+                         (long long)as, reinterpret_cast<const uint32_t *>(b), nb, (long long)bs, d, (long long)ds);
+    else
+      hipLaunchKernelGGL(k_hamming_mfma<false>, grid, dim3(256), 0, st, reinterpret_cast<const uint32_t *>(a), na,
+                         (long long)as, reinterpret_cast<const uint32_t *>(b), nb, (long long)bs, d, (long long)ds);
+    VO_HIP_CHECK(hipGetLastError());
+    return VO_OK;
+  }
   // the 8-byte stores of the 4-column form need 8-byte aligned rows: D itself and the pair stride
   const bool al8 = (reinterpret_cast<uintptr_t>(d) & 7) == 0 && (ds & 3) == 0;
   if (al8) {
@@ -486,6 +705,10 @@ int node_search_batch(int mode, int n_pairs, const NodePair *pairs, bool a_flag_
 }
 
 }  // namespace
+
+namespace vo {
+void set_hamming_kernel(int v) { g_hamming_kernel.store(v, std::memory_order_relaxed); }
+}  // namespace vo
 
 extern "C" {
 

@@ -162,6 +162,9 @@ struct FrameStoreView {
 };
 FrameStoreView frame_store_view(const vo_frames *h);
 
+// vo_set_option(VO_OPT_HAMMING_KERNEL) (match.hip): 0 = matrix-core form, 1 = VALU form
+void set_hamming_kernel(int v);
+
 // Device addresses of the handles' sticky error flags (NULL before the first use): vo_tracker copies them into its
 // result block so that one download answers "pose + counts + did anything overflow" (orb.hip, guided.hip).
 const int *orb_error_flag(const vo_orb *h);
