@@ -77,7 +77,10 @@ int vo_orb_set_stream(vo_orb *h, void *hip_stream);
  * 0 = FAST on all cells behind the pyramid, the whole blur on the side stream next to it.  Results are identical; measured
  * (tools/ext_schedule_ab.py): 2.482 against 2.499 ms per 1024 frames for the extraction alone, no difference for the tracked
  * step (every kernel involved is bound by instruction issue: there is nothing to overlap), hence opt-in. */
-enum { VO_ORB_OPT_FUSED_LEVEL_PASS = 1, VO_ORB_OPT_EARLY_LEVEL0 = 2 };
+/* VO_ORB_OPT_BLUR_KERNEL (default 0): which kernel blurs the levels (identical planes either way): 0 = k_blur_mfma, both passes
+ * of the 7x7 filter as int8 matrix-core products with banded weight matrices (levels of at least 64 x 16 pixels with 16-byte
+ * aligned rows; the others fall back by themselves), 1 = k_blur_groups, the dot-product form on the VALU. */
+enum { VO_ORB_OPT_FUSED_LEVEL_PASS = 1, VO_ORB_OPT_EARLY_LEVEL0 = 2, VO_ORB_OPT_BLUR_KERNEL = 3 };
 int vo_orb_set_option(vo_orb *h, int option, int value);
 /* (tests and tools) the fused pass's plan for one level of a width x height image: out = {takes the fused pass, tile pitch,
  * tile rows, score rows, workgroups per frame, LDS bytes per workgroup, survivor-list entries, 0} */
@@ -127,6 +130,13 @@ int vo_orb_get_level_counts(vo_orb *h, int frame, int32_t *counts /*nlevels*/);
  * synchronises, adds the elapsed times of the calls since the last reset to ms[VO_ORB_STAGES],
  * returns the number of timed calls in *n_calls and resets the accumulators. */
 #define VO_ORB_STAGES 6
+/* Stage hook: `hook(stage, hip_stream, user)` is called on the calling host thread inside vo_orb_extract* each time the launches
+ * of a stage (numbering of vo_orb_get_timing: 0 pyramid, 1 FAST, 2 oct-tree, 4 blur, 5 descriptors) have been enqueued on
+ * `hip_stream` -- the place to record an event or to make another stream wait, e.g. to start the all-pairs matching of the
+ * PREVIOUS batch (matrix cores + HBM writes) on a second stream exactly when this batch's FAST (vector-issue bound) starts:
+ * bench.py's extract + match leg does that.  The hook must not synchronise.  NULL removes it. */
+typedef void (*vo_orb_stage_hook)(int stage, void *hip_stream, void *user);
+int vo_orb_set_stage_hook(vo_orb *h, vo_orb_stage_hook hook, void *user);
 int vo_orb_set_timing(vo_orb *h, int enabled);
 int vo_orb_get_timing(vo_orb *h, double *ms /*VO_ORB_STAGES*/, int *n_calls);
 

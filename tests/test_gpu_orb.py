@@ -7,22 +7,31 @@ from vo_slam_test_amd import synth
 pytestmark = pytest.mark.gpu
 
 
-@pytest.fixture(scope="module", params=["fused", "separate"])
+MODES = ["separate", "separate-valu-blur", "fused"]
+
+
+def _set_mode(e, mode):
+    """the forms of the level pipeline: the three separate kernels with the blur on the matrix cores (the default), the same with
+    the VALU blur (VO_ORB_OPT_BLUR_KERNEL = 1), and the opt-in fused per-level pass (VO_ORB_OPT_FUSED_LEVEL_PASS)"""
+    e.set_fused(int(mode == "fused"))
+    e.set_blur_kernel(1 if mode == "separate-valu-blur" else 0)
+
+
+@pytest.fixture(scope="module", params=MODES)
 def ext(vo, request):
-    """both forms of the level pipeline: the fused per-level pass (default) and the three separate kernels"""
     e = vo.OrbExtractor(1000, 1.2, 8, 20, 7)
-    e.set_fused(int(request.param == "fused"))
+    _set_mode(e, request.param)
     yield e
     e.close()
 
 
-@pytest.fixture(params=["fused", "separate"])
+@pytest.fixture(params=MODES)
 def make_ext(vo, request):
     made = []
 
     def make(*args):
         e = vo.OrbExtractor(*args)
-        e.set_fused(int(request.param == "fused"))
+        _set_mode(e, request.param)
         made.append(e)
         return e
 

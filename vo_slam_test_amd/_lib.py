@@ -36,7 +36,7 @@ _lib = None
 # every symbol include/vo_hip.h declares (tests check the .so exports all of them)
 SYMBOLS = [
     "vo_last_error", "vo_device_count", "vo_version", "vo_release_thread_scratch",
-    "vo_orb_create", "vo_orb_destroy", "vo_orb_set_stream", "vo_orb_set_option", "vo_orb_debug_level_pass", "vo_orb_levels", "vo_orb_scale_factor",
+    "vo_orb_create", "vo_orb_destroy", "vo_orb_set_stream", "vo_orb_set_option", "vo_orb_set_stage_hook", "vo_orb_debug_level_pass", "vo_orb_levels", "vo_orb_scale_factor",
     "vo_orb_scale_factors", "vo_orb_features_per_level", "vo_orb_max_keypoints", "vo_orb_extract",
     "vo_orb_extract_batch_dev", "vo_orb_sync", "vo_orb_get_level", "vo_orb_get_candidates",
     "vo_orb_get_level_counts", "vo_orb_set_timing", "vo_orb_get_timing",
@@ -186,6 +186,20 @@ class OrbExtractor:
     def set_early_level0(self, on: bool):
         """vo_orb_set_option(VO_ORB_OPT_EARLY_LEVEL0): level 0's FAST cells and blur next to the resize chain (default off)"""
         check(lib().vo_orb_set_option(self._h, 2, int(on)), "vo_orb_set_option")
+
+    def set_stage_hook(self, fn):
+        """vo_orb_set_stage_hook: fn(stage, stream_ptr) is called when a stage's launches have been enqueued (None removes it)"""
+        if fn is None:
+            self._hook = None
+            check(lib().vo_orb_set_stage_hook(self._h, None, None), "vo_orb_set_stage_hook")
+            return
+        HOOK = C.CFUNCTYPE(None, C.c_int, C.c_void_p, C.c_void_p)
+        self._hook = HOOK(lambda stage, stream, user: fn(stage, stream))  # (kept alive with the handle)
+        check(lib().vo_orb_set_stage_hook(self._h, self._hook, None), "vo_orb_set_stage_hook")
+
+    def set_blur_kernel(self, kind: int):
+        """vo_orb_set_option(VO_ORB_OPT_BLUR_KERNEL): 0 = int8 matrix-core products (default), 1 = the VALU form"""
+        check(lib().vo_orb_set_option(self._h, 3, int(kind)), "vo_orb_set_option")
 
     def level_pass_plan(self, width, height):
         """per level: dict(fused, tile_pitch, tile_rows, score_rows, blocks, lds_bytes, list_cap) of the fused pass"""

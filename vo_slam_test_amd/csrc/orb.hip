@@ -1295,6 +1295,160 @@ __global__ __launch_bounds__(256) void k_blur_groups(FrameSrc src, int lv0_gener
   }
 }
 
+
+// K4 on the matrix cores (round 6).  k_blur_groups runs at two thirds of the VALU issue rate (227 M vector instructions per
+// 1024 frames, ~15 per pixel) with the matrix pipe idle; both passes of the filter are products with a banded Toeplitz matrix
+// of 8-bit weights {18,34,49,55,49,34,18}, and integer MFMA is exact, so the result stays bit-identical:
+//   row pass     H[y][x] = sum_k P[y][k] Wh[k][x]: v_mfma_i32_32x32x32_i8, A = 32 rows x 16 consecutive pixels per lane -- a
+//                16-byte load, xor 0x80 = (p - 128) as int8 --, B = the band (a constant operand: per strip from a table built
+//                with the handle, BORDER_REFLECT_101 at the left / right edge folded into its entries), K = the 64 source
+//                columns [x0 - 16, x0 + 48) in two steps, C = 128 * 257 so that the accumulator is the unsigned 16-bit row sum;
+//   hand-over    the accumulator of that product has its COLUMN on the lane and 16 rows in its registers -- exactly the A
+//                operand of the next product if the order of its K slots is chosen to match (slot 4 g + j of lane half h = row
+//                8 g + 4 h + j; the band operand is permuted accordingly): no lane movement, no LDS.  The 16-bit sums are
+//                split into a high and a low byte plane (4 v_perm per 4 values, xor 0x80 for the sign);
+//   column pass  V^T[x][y] = sum_k H[k][x] Wv[k][y] for both planes, against the tile's own 32 rows and the first six of the
+//                next tile; value = acc_hi * 256 + acc_lo with the rounding and the three offsets riding in acc_lo's C operand;
+//   store        M = x lands in the registers and N = y on the lanes, so a lane holds 4 x 4 consecutive pixels of ONE row:
+//                (v >> 16) saturated by v_sat_pk_u8_i16, two v_permlane32_swap give every lane a whole 16-byte row of a 16 x 8
+//                tile of the blurred plane, and 8 consecutive lanes write one 128-byte tile: whole lines, no LDS transpose.
+// A wavefront walks a strip of 32 columns downwards, 32 rows per step (rows beyond the top / bottom are the reflected rows
+// themselves, fetched by address); 6 MFMAs and ~90 vector instructions per 1024 pixels instead of ~240.
+typedef int bm_i32x4 __attribute__((ext_vector_type(4)));
+typedef int bm_i32x16 __attribute__((ext_vector_type(16)));
+constexpr int kBmMinW = 64, kBmMinH = 16;  // smaller levels keep the other kernels
+constexpr int kBmSegRows = 160;            // output rows per job (5 tiles of 32; one extra row-pass tile per job)
+
+__device__ __forceinline__ unsigned bm_sat_pk(unsigned v) {
+  unsigned r;
+  asm("v_sat_pk_u8_i16 %0, %1" : "=v"(r) : "v"(v));
+  return r;
+}
+
+// (4 waves per SIMD declared: with a register budget of at most 256 the compiler keeps the accumulators in VGPRs; at the default
+//  it put them in AGPRs and paid a v_accvgpr_read per result register and 16 v_accvgpr_mov per product for its C operand)
+__global__ __launch_bounds__(256, 4) void k_blur_mfma(FrameSrc src, const int *__restrict__ job_tab, int n_jobs,
+                                                   const int *__restrict__ tab, int bv_off) {
+  const int lane = threadIdx.x & 63;
+  const int job = blockIdx.x * 4 + __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
+  if (job >= n_jobs) return;
+  const int *sd = job_tab + 16 * job;  // wave-uniform: scalar loads
+  const int l = sd[0], x0 = sd[1], r0 = sd[2], n_vt = sd[3], cmax = sd[5], Lh = sd[6], y_end = sd[13], Lpitch = sd[11];
+  const int f = blockIdx.y, m = lane & 31, kg = lane >> 5;
+  int pitch;
+  const uint8_t *img;
+  if (l == 0) {
+    pitch = src.img0_pitch;
+    img = src.img0 + (long long)f * src.img0_frame_stride;
+  } else {
+    pitch = sd[4];
+    img = src.pyr + (long long)f * src.pyr_frame_stride + (((long long)sd[10] << 32) | (unsigned)sd[9]);
+  }
+  uint8_t *dst = src.blur + (long long)f * src.blur_frame_stride + (((long long)sd[8] << 32) | (unsigned)sd[7]);
+  // the band operands: row pass (this strip's, two K steps), column pass (against the tile itself / the next tile)
+  const bm_i32x4 *bh = reinterpret_cast<const bm_i32x4 *>(tab + sd[12]);
+  const bm_i32x4 Bh0 = bh[lane], Bh1 = bh[64 + lane];
+  const bm_i32x4 *bv = reinterpret_cast<const bm_i32x4 *>(tab + bv_off);
+  const bm_i32x4 Bv1 = bv[lane], Bv2 = bv[64 + lane];
+  // Source tiles (32 rows x the 64 bytes [x0 - 16, x0 + 48) of each) travel HBM -> LDS by LDS-DMA, two instructions of 16 rows x
+  // 4 pieces of 16 bytes (LDS address = 16 * lane): a lane's operand -- 16 bytes of each of 32 DIFFERENT rows per instruction --
+  // fetched straight into registers touched 32 lines per instruction and the texture-address path became the bound (measured:
+  // products alone 0.25 ms, + loads 0.22, + stores 0.16 per 1024 frames).  Pieces are kept inside the row (clamped; the band
+  // table was built with the same clamp: a slot that holds a duplicate or an unused column has weight 0) and stored at
+  // (piece ^ row bits 2-3) so that the operand reads -- lanes = rows, 64 bytes apart -- spread over the banks.
+  __shared__ __attribute__((aligned(16))) uint8_t stage_all[4][2][2048];
+  lds_u8 *stage = (lds_u8 *)stage_all[threadIdx.x >> 6];
+  const int drow = lane >> 2;                                  // row of the lane's piece within a half tile
+  const int dcol = min(max(x0 - 16 + 16 * ((lane & 3) ^ ((drow >> 2) & 3)), 0), cmax);
+  bm_i32x16 CH, CV;
+#pragma unroll
+  for (int i = 0; i < 16; i++) CH[i] = 128 * 257, CV[i] = 257 * (128 * 257) + (1 << 15);
+  const bm_i32x16 Z = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+
+  auto dma_tile = [&](int k) {
+#pragma unroll
+    for (int i = 0; i < 2; i++) {
+      const int y = min(r0 + 32 * k + 16 * i + drow, Lh + 2);
+      const uint8_t *g = img + (long long)reflect101_near(y, Lh) * pitch + dcol;
+      __builtin_amdgcn_global_load_lds((gmem_u8 *)g, stage + 2048 * (k & 1) + 1024 * i, 16, 0, 0);
+    }
+  };
+  // the lane's operand pieces of tile k: row m, pieces kg and 2 + kg (one asm block with its own wait: the compiler does not
+  // see these reads, so it does not put a vmcnt(0) -- which would also wait for the tile just requested -- in front of them)
+  const unsigned rd0 = (unsigned)(m * 64 + ((kg ^ ((m >> 2) & 3)) << 4)), rd1 = (unsigned)(m * 64 + (((2 + kg) ^ ((m >> 2) & 3)) << 4));
+  auto read_tile = [&](int k, bm_i32x4 &a0, bm_i32x4 &a1) {
+    const unsigned base = (unsigned)(uintptr_t)(stage + 2048 * (k & 1));
+    asm volatile("ds_read_b128 %0, %2\n\tds_read_b128 %1, %3\n\ts_waitcnt lgkmcnt(0)"
+                 : "=&v"(a0), "=&v"(a1)
+                 : "v"(base + rd0), "v"(base + rd1)
+                 : "memory");
+  };
+  // row pass of one tile -> the two byte planes as the column pass's A operand
+  auto row_pass = [&](bm_i32x4 a0, bm_i32x4 a1, bm_i32x4 &lo, bm_i32x4 &hi) {
+#pragma unroll
+    for (int i = 0; i < 4; i++) a0[i] ^= (int)0x80808080, a1[i] ^= (int)0x80808080;
+    bm_i32x16 acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(a0, Bh0, CH, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(a1, Bh1, acc, 0, 0, 0);
+#pragma unroll
+    for (int g = 0; g < 4; g++) {
+      const unsigned t01 = __builtin_amdgcn_perm((unsigned)acc[4 * g + 1], (unsigned)acc[4 * g], 0x05010400u);
+      const unsigned t23 = __builtin_amdgcn_perm((unsigned)acc[4 * g + 3], (unsigned)acc[4 * g + 2], 0x05010400u);
+      lo[g] = (int)(__builtin_amdgcn_perm(t23, t01, 0x05040100u) ^ 0x80808080u);
+      hi[g] = (int)(__builtin_amdgcn_perm(t23, t01, 0x07060302u) ^ 0x80808080u);
+    }
+  };
+
+  // the band operands have arrived before the loop: inside it the compiler would otherwise wait for them -- and with them for
+  // the tile it has just requested -- at their first use of every iteration
+  asm volatile("" ::"v"(Bh0), "v"(Bh1), "v"(Bv1), "v"(Bv2));
+  bm_i32x4 p0, p1, lo, hi;
+  dma_tile(0);
+  dma_tile(1);
+  asm volatile("s_waitcnt vmcnt(2)" ::: "memory");  // tile 0 has landed (vmcnt counts in issue order: tile 1's two stay out)
+  read_tile(0, p0, p1);
+  row_pass(p0, p1, lo, hi);
+  const int xt_ok = x0 + 16 * kg < Lpitch;
+  for (int k = 0; k < n_vt; k++) {
+    // outstanding, in issue order: tile k + 1 (two DMAs), the previous iteration's store -> all but the youngest one
+    if (k == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
+    bm_i32x4 n0, n1;
+    read_tile(k + 1, n0, n1);
+#ifndef BM_NOLOAD
+    if (k + 1 < n_vt) dma_tile(k + 2);  // uniform; into the buffer tile k left; in flight during this tile's products
+#endif
+    bm_i32x4 lo2, hi2;
+    row_pass(n0, n1, lo2, hi2);
+    bm_i32x16 al = __builtin_amdgcn_mfma_i32_32x32x32_i8(lo, Bv1, CV, 0, 0, 0);
+    bm_i32x16 ah = __builtin_amdgcn_mfma_i32_32x32x32_i8(hi, Bv1, Z, 0, 0, 0);
+    al = __builtin_amdgcn_mfma_i32_32x32x32_i8(lo2, Bv2, al, 0, 0, 0);
+    ah = __builtin_amdgcn_mfma_i32_32x32x32_i8(hi2, Bv2, ah, 0, 0, 0);
+    lo = lo2, hi = hi2;
+    // lane (y = m, kg): registers 4 g + j = column x0 + 8 g + 4 kg + j of row y
+    unsigned d[4];
+#pragma unroll
+    for (int g = 0; g < 4; g++) {
+      unsigned v[4];
+#pragma unroll
+      for (int j = 0; j < 4; j++) v[j] = ((unsigned)ah[4 * g + j] << 8) + (unsigned)al[4 * g + j];
+      const unsigned s01 = bm_sat_pk(__builtin_amdgcn_perm(v[1], v[0], 0x07060302u));
+      const unsigned s23 = bm_sat_pk(__builtin_amdgcn_perm(v[3], v[2], 0x07060302u));
+      d[g] = s01 | (s23 << 16);
+    }
+    // lane halves exchange so that lane (y, kg) holds the 16 bytes of row y of tile column x0 / 16 + kg: d0 d2 d1 d3
+    const auto w02 = __builtin_amdgcn_permlane32_swap(d[0], d[2], false, false);
+    const auto w13 = __builtin_amdgcn_permlane32_swap(d[1], d[3], false, false);
+    const int y = r0 + 3 + 32 * k + m;
+#ifdef BM_NOSTORE
+    if (w02[0] == 0x12345678u && w13[1] == 0x9abcdef1u)
+#endif
+    if (xt_ok && y < y_end) {
+      const u32x4_t out = {w02[0], w02[1], w13[0], w13[1]};
+      *reinterpret_cast<u32x4_t *>(dst + blur_tiled_off(x0 + 16 * kg, y, Lpitch)) = out;
+    }
+  }
+}
+
 #include "orb_level_pass.inc"
 
 // ------------------------------------------------------------------------------------------
@@ -1680,6 +1834,8 @@ struct vo_orb {
   bool own_stream = false;
   hipStream_t side = nullptr;          // blur runs here, concurrently with FAST / oct-tree (no data dependence)
   hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_fork0 = nullptr, ev_fast0 = nullptr;
+  vo_orb_stage_hook hook = nullptr;    // vo_orb_set_stage_hook: called when a stage's launches have been enqueued
+  void *hook_user = nullptr;
   int early_level0 = 0;  // vo_orb_set_option(VO_ORB_OPT_EARLY_LEVEL0): measured -0.6 % on the extraction alone, nothing on the tracked step
   // geometry (valid for cfg_w x cfg_h)
   int cfg_w = 0, cfg_h = 0;
@@ -1704,6 +1860,12 @@ struct vo_orb {
   int lp_redge_x[kMaxLevels] = {0}, lp_redge_j0[kMaxLevels] = {0};
   unsigned lp_selA[kMaxLevels] = {0}, lp_selB[kMaxLevels] = {0}, lp_selP[kMaxLevels] = {0};
   unsigned blur_generic_mask = 0;  // levels blurred by the generic kernel
+  // k_blur_mfma: job table (16 ints per job: a strip of 32 columns x <= kBmSegRows rows), the column pass's band operands, the
+  // levels it takes (the others keep k_blur_groups / k_blur)
+  int blur_mfma = 0;               // vo_orb_set_option(VO_ORB_OPT_BLUR_KERNEL): 0 = matrix cores (default), 1 = k_blur_groups
+  int bm_tab_off = 0, bm_bv_off = 0, bm_jobs = 0;
+  int bm_job0[kMaxLevels + 1] = {0};
+  unsigned bm_mask = 0;
   std::vector<int> tab_off;  // per level: offsets of xofs,xab,yofs,yab in tables
   vo::DevBuf tables, pyr, blur, slots, cellcnt, keydata, keylabel, candcnt, sel, nk, err;
   vo::DevBuf in_img, out_kp, out_desc, out_cnt;
@@ -2067,6 +2229,90 @@ int configure(vo_orb *h, int w, int h_img, int n_frames) {
           }
         h->blur_job0[l + 1] = h->blur_jobs;
       }
+      {
+        // k_blur_mfma: band operands and jobs.  Row pass, strip x0 of a level of width w: K slot (step s, lane half kg, byte
+        // b) holds source column clamp(x0 - 16 + 32 s + 16 kg) + b (the kernel clamps its 16-byte pieces the same way); entry
+        // [slot][n] = the weight with which that column enters output column x0 + n, BORDER_REFLECT_101 folded in (a column
+        // that several slots hold is given to the first).  Column pass: slot (kg, b) = row 8 (b >> 2) + 4 kg + (b & 3) of the
+        // row-pass tile (the order its accumulator registers have), against the tile itself (Bv1) and the next one (Bv2).
+        static const int kw[7] = {18, 34, 49, 55, 49, 34, 18};
+        while (tables.size() % 4) tables.push_back(0);
+        h->bm_bv_off = (int)tables.size();
+        for (int which = 0; which < 2; which++)
+          for (int lane = 0; lane < 64; lane++)
+            for (int q = 0; q < 4; q++) {
+              unsigned wd = 0;
+              for (int j = 0; j < 4; j++) {
+                const int n = lane & 31, kg = lane >> 5, ys = 8 * q + 4 * kg + j + 32 * which, t = ys - n;
+                if (t >= 0 && t <= 6) wd |= (unsigned)kw[t] << (8 * j);
+              }
+              tables.push_back((int)wd);
+            }
+        std::vector<std::pair<std::vector<int>, int>> seen;  // distinct row-pass operands of this handle
+        std::vector<int> jobs;
+        h->bm_jobs = 0, h->bm_mask = 0;
+        for (int l = 0; l < h->nlevels; l++) {
+          const LevelGeom &L = D.lv[l];
+          h->bm_job0[l] = h->bm_job0[l + 1] = h->bm_jobs;
+          if (L.w < kBmMinW || L.h < kBmMinH) continue;
+          h->bm_mask |= 1u << l;
+          const int cmax = align_up(L.w, 16) - 16;
+          std::vector<int> strip_off;
+          for (int x0 = 0; x0 < L.w; x0 += 32) {
+            std::vector<int> mat(2 * 64 * 4, 0);
+            for (int n = 0; n < 32 && x0 + n < L.w; n++) {
+              int wcol[7], wval[7], nw = 0;  // the columns output x0 + n reads, reflected, with their summed weights
+              for (int d = -3; d <= 3; d++) {
+                int c = x0 + n + d;
+                if (L.w == 1) c = 0;
+                else while (c < 0 || c >= L.w) c = c < 0 ? -c : 2 * L.w - 2 - c;
+                int i = 0;
+                while (i < nw && wcol[i] != c) i++;
+                if (i == nw) wcol[nw] = c, wval[nw] = 0, nw++;
+                wval[i] += kw[d + 3];
+              }
+              for (int sstep = 0; sstep < 2; sstep++)
+                for (int kg = 0; kg < 2; kg++) {
+                  const int cb = std::min(std::max(x0 - 16 + 32 * sstep + 16 * kg, 0), cmax);
+                  for (int b = 0; b < 16; b++)
+                    for (int i = 0; i < nw; i++)
+                      if (wcol[i] == cb + b && wval[i] != 0) {
+                        mat[(sstep * 64 + kg * 32 + n) * 4 + (b >> 2)] |= wval[i] << (8 * (b & 3));
+                        wval[i] = 0;  // given to the first slot that holds the column
+                      }
+                }
+              for (int i = 0; i < nw; i++)
+                if (wval[i] != 0) {
+                  vo::set_error("k_blur_mfma: column %d of level %d is outside the strip window at x0 = %d", wcol[i], l, x0);
+                  return VO_ERR_INVALID;
+                }
+            }
+            int off = -1;
+            for (auto &e : seen)
+              if (e.first == mat) off = e.second;
+            if (off < 0) {
+              off = (int)tables.size();
+              tables.insert(tables.end(), mat.begin(), mat.end());
+              seen.emplace_back(std::move(mat), off);
+            }
+            strip_off.push_back(off);
+          }
+          for (int ys = 0; ys < L.h; ys += kBmSegRows) {
+            const int ye = std::min(L.h, ys + kBmSegRows);
+            for (int x0 = 0, si = 0; x0 < L.w; x0 += 32, si++) {
+              const int e[16] = {l, x0, ys - 3, (ye - ys + 31) / 32, L.pitch, cmax, L.h,
+                                 (int)(unsigned)(L.blur_off & 0xffffffffLL), (int)(L.blur_off >> 32),
+                                 (int)(unsigned)(L.pyr_off & 0xffffffffLL), (int)(L.pyr_off >> 32), L.pitch, strip_off[si], ye, 0, 0};
+              jobs.insert(jobs.end(), e, e + 16);
+              h->bm_jobs++;
+            }
+          }
+          h->bm_job0[l + 1] = h->bm_jobs;
+        }
+        while (tables.size() % 16) tables.push_back(0);
+        h->bm_tab_off = (int)tables.size();
+        tables.insert(tables.end(), jobs.begin(), jobs.end());
+      }
       h->cell_tab_off = (int)tables.size();
       for (int l = 0; l < h->nlevels; l++) {
         const LevelGeom &L = D.lv[l];
@@ -2180,8 +2426,11 @@ int run_pipeline(vo_orb *h, const uint8_t *dev_images, int n_frames, int w, int 
     ev = h->ev.data() + (size_t)h->timed_calls * (VO_ORB_STAGES + 1);
     h->timed_calls++;
   }
-#define VO_STAGE_MARK(i) \
-  if (ev) VO_HIP_CHECK(hipEventRecord(ev[i], st))
+#define VO_STAGE_MARK(i)                               \
+  do {                                                 \
+    if (ev) VO_HIP_CHECK(hipEventRecord(ev[i], st));   \
+    if (h->hook && (i) > 0) h->hook((i)-1, st, h->hook_user); \
+  } while (0)
   VO_STAGE_MARK(0);
   const int *T = h->tables.as<int>();
   // level l from level l - 1 (sequential by construction, :1129)
@@ -2214,14 +2463,34 @@ int run_pipeline(vo_orb *h, const uint8_t *dev_images, int n_frames, int w, int 
     hipLaunchKernelGGL(fast, grid, dim3(256), h->fast_lds, st, D, S, h->slots.as<uint32_t>(), h->slots_frame,
                        h->cellcnt.as<int>(), h->cells_frame, h->fast_rows, h->fast_interior, T + h->cell_tab_off, cell_begin, cell_end);
   };
-  // (the strip kernel reads aligned dwords; a caller image that is not 4-byte aligned falls back to the generic LDS
-  // kernel for level 0 only)
-  auto launch_blur = [&](hipStream_t bs, int job_begin, int job_end, unsigned level_mask) {
-    const int lv0_generic = lv0_unaligned;
-    if (job_end > job_begin)
-      hipLaunchKernelGGL(k_blur_groups, dim3((job_end - job_begin + 3) / 4, (n_frames + kBlurF - 1) / kBlurF), dim3(256), 0, bs, S,
-                         lv0_generic, T + h->strip_tab_off + 16 * job_begin, job_end - job_begin, n_frames);
-    const unsigned gmask = (h->blur_generic_mask | (lv0_generic ? 1u : 0u)) & level_mask;
+  // The blur of levels [l0, l1): k_blur_mfma where the level takes it (16-byte aligned rows: our own planes always, the caller's
+  // image if it is), else k_blur_groups (aligned dwords), else -- levels too small for either, a caller image that is not
+  // 4-byte aligned -- the generic LDS kernel.
+  const bool lv0_rows16 = !lv0_not16 && stride >= ((D.lv[0].w + 15) & ~15);
+  auto launch_blur = [&](hipStream_t bs, int l0, int l1) {
+    if (l1 <= l0) return;
+    const unsigned lmask = (l1 >= 32 ? ~0u : (1u << l1) - 1u) & ~((1u << l0) - 1u);
+    unsigned mf = h->blur_mfma == 0 ? (h->bm_mask & lmask) : 0u;
+    if (!lv0_rows16) mf &= ~1u;
+    // (the jobs of consecutive levels are consecutive: one launch per run of levels of the same kind)
+    for (int l = l0; l < l1;) {
+      const bool is_mf = (mf >> l) & 1u;
+      int e = l + 1;
+      while (e < l1 && (((mf >> e) & 1u) != 0) == is_mf) e++;
+      if (is_mf) {
+        const int jb = h->bm_job0[l], je = h->bm_job0[e];
+        if (je > jb)
+          hipLaunchKernelGGL(k_blur_mfma, dim3((je - jb + 3) / 4, n_frames), dim3(256), 0, bs, S, T + h->bm_tab_off + 16 * jb,
+                             je - jb, T, h->bm_bv_off);
+      } else {
+        const int jb = h->blur_job0[l], je = h->blur_job0[e];
+        if (je > jb)
+          hipLaunchKernelGGL(k_blur_groups, dim3((je - jb + 3) / 4, (n_frames + kBlurF - 1) / kBlurF), dim3(256), 0, bs, S,
+                             lv0_unaligned, T + h->strip_tab_off + 16 * jb, je - jb, n_frames);
+      }
+      l = e;
+    }
+    const unsigned gmask = (h->blur_generic_mask | (lv0_unaligned ? 1u : 0u)) & lmask & ~mf;
     if (gmask) hipLaunchKernelGGL(k_blur, dim3(h->tiles_frame, n_frames), dim3(256), 0, bs, D, S, gmask);
   };
   // One fused pass per level (orb_level_pass.inc) where the level's geometry takes it: its FAST cells, its blurred tiles and the
@@ -2257,7 +2526,7 @@ int run_pipeline(vo_orb *h, const uint8_t *dev_images, int n_frames, int w, int 
       } else {  // this level through the separate kernels
         if (l + 1 < D.nlevels) launch_resize(l + 1);
         launch_fast(L.cellBase, L.cellBase + L.nCells);
-        launch_blur(st, h->blur_job0[l], h->blur_job0[l + 1], 1u << l);
+        launch_blur(st, l, l + 1);
       }
     }
     VO_STAGE_MARK(1);  // (instrumented mode: stage 0 carries the whole chain of level passes, stages 1 and 4 are empty)
@@ -2276,15 +2545,14 @@ int run_pipeline(vo_orb *h, const uint8_t *dev_images, int n_frames, int w, int 
       launch_fast(D.lv[0].cellBase, D.lv[0].cellBase + D.lv[0].nCells);
       st = keep;
       VO_HIP_CHECK(hipEventRecord(h->ev_fast0, h->side));
-      launch_blur(h->side, h->blur_job0[0], h->blur_job0[1], 1u);
+      launch_blur(h->side, 0, 1);
     }
     for (int l = 1; l < D.nlevels; l++) launch_resize(l);
     VO_STAGE_MARK(1);
     if (overlap) {
       VO_HIP_CHECK(hipEventRecord(h->ev_fork, st));
       VO_HIP_CHECK(hipStreamWaitEvent(h->side, h->ev_fork, 0));
-      if (early0) launch_blur(h->side, h->blur_job0[1], h->blur_jobs, ~1u);
-      else launch_blur(h->side, 0, h->blur_jobs, ~0u);
+      launch_blur(h->side, early0 ? 1 : 0, D.nlevels);
       VO_HIP_CHECK(hipEventRecord(h->ev_join, h->side));
     }
     if (early0) {
@@ -2310,7 +2578,7 @@ int run_pipeline(vo_orb *h, const uint8_t *dev_images, int n_frames, int w, int 
   if (overlap)
     VO_HIP_CHECK(hipStreamWaitEvent(st, h->ev_join, 0));
   else if (!any_fused)
-    launch_blur(st, 0, h->blur_jobs, ~0u);
+    launch_blur(st, 0, D.nlevels);
   VO_STAGE_MARK(5);
   const int kp_blocks = (std::min(capacity, h->max_kp) + 63) / 64;
   if (kp_blocks == 0 && dcounts) VO_HIP_CHECK(hipMemsetAsync(dcounts, 0, (size_t)n_frames * sizeof(int), st));
@@ -2455,8 +2723,22 @@ int vo_orb_set_option(vo_orb *h, int option, int value) {
     h->early_level0 = value ? 1 : 0;
     return VO_OK;
   }
+  if (option == VO_ORB_OPT_BLUR_KERNEL) {
+    if (value != 0 && value != 1) {
+      vo::set_error("vo_orb_set_option(VO_ORB_OPT_BLUR_KERNEL): 0 (matrix cores) or 1 (VALU)");
+      return VO_ERR_INVALID;
+    }
+    h->blur_mfma = value;
+    return VO_OK;
+  }
   vo::set_error("vo_orb_set_option: unknown option %d", option);
   return VO_ERR_INVALID;
+}
+
+int vo_orb_set_stage_hook(vo_orb *h, vo_orb_stage_hook hook, void *user) {
+  if (!h) return VO_ERR_INVALID;
+  h->hook = hook, h->hook_user = user;
+  return VO_OK;
 }
 
 int vo_orb_debug_level_pass(vo_orb *h, int width, int height, int level, int out[8]) {
