@@ -2838,13 +2838,31 @@ __global__ __launch_bounds__(256) void k_ba_setup(BaDev B, int set_active, uint8
 // process-wide developer knobs (vo_set_option)
 static std::atomic<int> g_opt_ba_graph{0}, g_opt_pose_block{0};
 
+// A host array that lives either in its own vector or -- the sorted edge arrays of an LDS-sized problem -- directly in the
+// page-locked block build_device uploads from (ba_fill_problem writes them once, where the DMA reads them: at config 3 the
+// intermediate copy of 1.1 MB was ~0.05 ms of every vo_ba_reset -> vo_ba_local_ba call).
+template <class T>
+struct HostArr {
+  T *p = nullptr;
+  size_t n = 0;
+  std::vector<T> own;
+  void resize(size_t m) { own.resize(m), p = own.data(), n = m; }
+  void bind(T *ext, size_t m) { p = ext, n = m; }
+  T *data() { return p; }
+  const T *data() const { return p; }
+  size_t size() const { return n; }
+  T &operator[](size_t i) { return p[i]; }
+  const T &operator[](size_t i) const { return p[i]; }
+};
+
 struct vo_ba {
   int n_cams = 0, n_pts = 0, n_edges = 0, nf = 0;
   std::vector<double> poses, points;
   std::vector<uint8_t> cam_fixed;
-  std::vector<int> e_cam, e_pt, perm;  // sorted by point; perm[sorted] = caller index
-  std::vector<double> e_obs, e_is;
-  std::vector<int> pt_start, cam_slot, slot_cam;
+  HostArr<int> e_cam, e_pt;  // sorted by point
+  std::vector<int> perm;     // perm[sorted] = caller index
+  HostArr<double> e_obs, e_is;
+  std::vector<int> pt_start, cam_slot, slot_cam, fill_tmp, cam_count;  // (cam_count: edges per free-camera slot, all points)
   double cam[5];
   int shard = 0, n_shards = 1;
   hipStream_t stream = nullptr;
@@ -2909,6 +2927,9 @@ int reserve_grow(vo::DevBuf &b, size_t bytes) {
 // build_device's uploads of a handle: through ONE page-locked staging block (reserved by build_device for the whole build,
 // so that it never moves under a copy in flight) and asynchronous on the handle's stream -- a hipMemcpy from pageable memory
 // is a synchronous round trip of 10-30 us apiece, fourteen of them per handle
+static size_t up_pin_bytes(int n_edges, int n_pts, int n_cams) {
+  return 65536 + (size_t)n_edges * 56 + (size_t)n_pts * 64 + (size_t)n_cams * 256;
+}
 int upload(vo_ba *h, vo::DevBuf &b, const void *src, size_t bytes) {
   const size_t off = (h->up_used + 255) & ~(size_t)255;
   if (!h->arenas || off + std::max<size_t>(bytes, 64) > h->up_pin.bytes) {  // large systems; or more than build_device reserved
@@ -2916,7 +2937,7 @@ int upload(vo_ba *h, vo::DevBuf &b, const void *src, size_t bytes) {
     if (bytes) VO_HIP_CHECK(hipMemcpy(b.p, src, bytes, hipMemcpyHostToDevice));
     return VO_OK;
   }
-  if (bytes) memcpy(h->up_pin.data() + off, src, bytes);
+  if (bytes && src != h->up_pin.data() + off) memcpy(h->up_pin.data() + off, src, bytes);  // (ba_fill_problem may have put it there)
   h->up_used = off + std::max<size_t>(bytes, 64);
   b.set_view(static_cast<uint8_t *>(h->b_up_arena.p) + off, std::max<size_t>(bytes, 64));  // (the one copy follows at the end of the build)
   return VO_OK;
@@ -2964,7 +2985,7 @@ int build_device(vo_ba *h) {
   BaDev &D = h->D;
   // staging for every upload of this build (never moved while copies are in flight: reserved once, before the first)
   VO_HIP_CHECK(hipStreamSynchronize(h->stream));  // (a previous build's copies out of the block have landed)
-  VO_CHECK(h->up_pin.reserve(65536 + (size_t)h->n_edges * 56 + (size_t)h->n_pts * 64 + (size_t)h->n_cams * 256));
+  VO_CHECK(h->up_pin.reserve(up_pin_bytes(h->n_edges, h->n_pts, h->n_cams)));  // (no-op when ba_fill_problem placed the edge arrays)
   h->up_used = 0;
   D.n_cams = h->n_cams, D.n_pts = h->n_pts, D.n_edges = h->n_edges, D.nf = h->nf;
   D.n_shards = h->n_shards, D.shard = h->shard;
@@ -3102,25 +3123,43 @@ int build_device(vo_ba *h) {
     h->pt_owner.resize((size_t)h->n_pts);
     for (int j = 0; j < h->n_pts; j++) h->pt_owner[j] = j % h->n_shards;
   }
+  const bool all_local = h->n_shards == 1;  // (every point is this shard's: no owner look-ups, and ba_fill_problem has counted the cameras' edges)
   std::vector<int> local;
-  for (int j = 0; j < h->n_pts; j++)
-    if (h->pt_owner[j] == h->shard) local.push_back(j);
+  if (all_local) {
+    local.resize((size_t)h->n_pts);
+    std::iota(local.begin(), local.end(), 0);
+  } else {
+    for (int j = 0; j < h->n_pts; j++)
+      if (h->pt_owner[j] == h->shard) local.push_back(j);
+  }
   D.n_local = (int)local.size();
   // per-camera edge lists restricted to this shard's points
   std::vector<int> cstart(h->nf + 1, 0), cedges;
   {
     // counting sort of this shard's edges by free-camera slot (edge order within a camera = sorted edge order)
-    for (int e = 0; e < h->n_edges; e++) {
-      const int sl = h->cam_slot[h->e_cam[e]];
-      if (sl >= 0 && h->pt_owner[h->e_pt[e]] == h->shard) cstart[sl + 1]++;
+    if (all_local && !D.large && (int)h->cam_count.size() == h->nf + 1) {  // (a large system has re-ordered its camera slots above)
+      for (int sl = 0; sl < h->nf; sl++) cstart[sl + 1] = h->cam_count[sl];
+    } else {
+      for (int e = 0; e < h->n_edges; e++) {
+        const int sl = h->cam_slot[h->e_cam[e]];
+        if (sl >= 0 && h->pt_owner[h->e_pt[e]] == h->shard) cstart[sl + 1]++;
+      }
     }
     int mx = 0;
     for (int sl = 0; sl < h->nf; sl++) mx = std::max(mx, cstart[sl + 1]), cstart[sl + 1] += cstart[sl];
     cedges.resize((size_t)cstart[h->nf]);
     std::vector<int> fill(cstart.begin(), cstart.end() - 1);
-    for (int e = 0; e < h->n_edges; e++) {
-      const int sl = h->cam_slot[h->e_cam[e]];
-      if (sl >= 0 && h->pt_owner[h->e_pt[e]] == h->shard) cedges[(size_t)fill[sl]++] = e;
+    const int *slot = h->cam_slot.data(), *ec = h->e_cam.data();
+    if (all_local) {
+      for (int e = 0; e < h->n_edges; e++) {
+        const int sl = slot[ec[e]];
+        if (sl >= 0) cedges[(size_t)fill[sl]++] = e;
+      }
+    } else {
+      for (int e = 0; e < h->n_edges; e++) {
+        const int sl = slot[ec[e]];
+        if (sl >= 0 && h->pt_owner[h->e_pt[e]] == h->shard) cedges[(size_t)fill[sl]++] = e;
+      }
     }
     D.n_cchunks = std::max(1, (mx + kCamChunk - 1) / kCamChunk);
   }
@@ -3701,34 +3740,35 @@ static int ba_check_args(int n_cams, const double *poses, const uint8_t *cam_fix
     vo::set_error("%s: invalid argument", fn);
     return VO_ERR_INVALID;
   }
-  for (int e = 0; e < n_edges; e++)
-    if (edge_cam[e] < 0 || edge_cam[e] >= n_cams || edge_point[e] < 0 || edge_point[e] >= n_points) {
-      vo::set_error("%s: edge %d references camera %d / point %d out of range", fn, e, edge_cam[e], edge_point[e]);
-      return VO_ERR_INVALID;
-    }
   return VO_OK;
 }
-static void ba_fill_problem(vo_ba *h, int n_cams, const double *poses, const uint8_t *cam_fixed, int n_points, const double *points,
-                            int n_edges, const int32_t *edge_cam, const int32_t *edge_point, const double *edge_obs,
-                            const double *edge_inv_sigma, const double cam[5]) {
+// Two passes over the caller's edges: (1) range check + edges per point (into a scratch vector: a rejected problem leaves the
+// handle as it was), (2) the stable scatter into point order -- straight into the page-locked upload block when the problem is
+// LDS-sized (the offsets are the ones build_device's first four uploads compute) -- which also counts the edges per free camera.
+static int ba_fill_problem(vo_ba *h, int n_cams, const double *poses, const uint8_t *cam_fixed, int n_points, const double *points,
+                           int n_edges, const int32_t *edge_cam, const int32_t *edge_point, const double *edge_obs,
+                           const double *edge_inv_sigma, const double cam[5], const char *fn) {
+  std::vector<int> &cnt = h->fill_tmp;
+  cnt.assign((size_t)n_points + 1, 0);
+  {
+    int *c1 = cnt.data() + 1;
+    unsigned bad = 0;
+    for (int e = 0; e < n_edges; e++) {
+      const unsigned pc = (unsigned)edge_cam[e], pp = (unsigned)edge_point[e];
+      if (pc >= (unsigned)n_cams || pp >= (unsigned)n_points) {
+        bad = 1;
+        vo::set_error("%s: edge %d references camera %d / point %d out of range", fn, e, edge_cam[e], edge_point[e]);
+        break;
+      }
+      c1[pp]++;
+    }
+    if (bad) return VO_ERR_INVALID;
+  }
   h->n_cams = n_cams, h->n_pts = n_points, h->n_edges = n_edges, h->nf = 0;
   h->poses.assign(poses, poses + 6 * (size_t)n_cams);
   h->points.assign(points, points + 3 * (size_t)n_points);
   h->cam_fixed.assign(cam_fixed, cam_fixed + n_cams);
   memcpy(h->cam, cam, sizeof(h->cam));
-  h->perm.resize(n_edges);
-  h->e_cam.resize(n_edges), h->e_pt.resize(n_edges), h->e_obs.resize(3 * (size_t)n_edges), h->e_is.resize(n_edges);
-  h->pt_start.assign(n_points + 1, 0);
-  for (int e = 0; e < n_edges; e++) h->pt_start[edge_point[e] + 1]++;
-  for (int j = 0; j < n_points; j++) h->pt_start[j + 1] += h->pt_start[j];
-  std::vector<int> fill(h->pt_start.begin(), h->pt_start.end() - 1);
-  for (int e = 0; e < n_edges; e++) {  // counting sort: stable, caller order within a point
-    const int sidx = fill[edge_point[e]]++;
-    h->perm[sidx] = e;
-    h->e_cam[sidx] = edge_cam[e], h->e_pt[sidx] = edge_point[e], h->e_is[sidx] = edge_inv_sigma[e];
-    h->e_obs[3 * (size_t)sidx] = edge_obs[3 * (size_t)e], h->e_obs[3 * (size_t)sidx + 1] = edge_obs[3 * (size_t)e + 1];
-    h->e_obs[3 * (size_t)sidx + 2] = edge_obs[3 * (size_t)e + 2];
-  }
   h->cam_slot.assign(n_cams, -1);
   h->slot_cam.clear();
   for (int c = 0; c < n_cams; c++)
@@ -3736,6 +3776,44 @@ static void ba_fill_problem(vo_ba *h, int n_cams, const double *poses, const uin
       h->cam_slot[c] = h->nf++;
       h->slot_cam.push_back(c);
     }
+  h->perm.resize(n_edges);
+  bool placed = false;
+  if (6 * h->nf + 1 <= kMaxN && n_edges > 0 && h->up_pin.reserve(up_pin_bytes(n_edges, n_points, n_cams)) == VO_OK) {
+    // the staging offsets of build_device's uploads of e_cam, e_pt, e_obs, e_is (in that order, from offset 0)
+    auto al = [](size_t v) { return (v + 255) & ~(size_t)255; };
+    const size_t o0 = 0, o1 = al(o0 + std::max<size_t>((size_t)n_edges * 4, 64)), o2 = al(o1 + std::max<size_t>((size_t)n_edges * 4, 64)),
+                 o3 = al(o2 + std::max<size_t>((size_t)n_edges * 24, 64));
+    if (o3 + (size_t)n_edges * 8 <= h->up_pin.bytes) {
+      uint8_t *pb = h->up_pin.data();
+      h->e_cam.bind(reinterpret_cast<int *>(pb + o0), n_edges), h->e_pt.bind(reinterpret_cast<int *>(pb + o1), n_edges);
+      h->e_obs.bind(reinterpret_cast<double *>(pb + o2), 3 * (size_t)n_edges), h->e_is.bind(reinterpret_cast<double *>(pb + o3), n_edges);
+      placed = true;
+    }
+  }
+  if (!placed) h->e_cam.resize(n_edges), h->e_pt.resize(n_edges), h->e_obs.resize(3 * (size_t)n_edges), h->e_is.resize(n_edges);
+  h->pt_start.resize((size_t)n_points + 1);
+  {
+    int run = 0;
+    for (int j = 0; j < n_points; j++) {  // cnt[j + 1] = edges of point j -> cnt[j] = next free position of point j
+      const int c = cnt[j + 1];
+      h->pt_start[j] = run, cnt[j] = run, run += c;
+    }
+    h->pt_start[n_points] = run;
+  }
+  h->cam_count.assign((size_t)h->nf + 1, 0);
+  int *ec = h->e_cam.data(), *ep = h->e_pt.data(), *pm = h->perm.data(), *fl = cnt.data(), *cc = h->cam_count.data();
+  const int *slot = h->cam_slot.data();
+  double *eo = h->e_obs.data(), *ei = h->e_is.data();
+  for (int e = 0; e < n_edges; e++) {  // counting sort: stable, caller order within a point
+    const int pp = edge_point[e], pc = edge_cam[e];
+    const int sidx = fl[pp]++;
+    pm[sidx] = e, ec[sidx] = pc, ep[sidx] = pp, ei[sidx] = edge_inv_sigma[e];
+    eo[3 * (size_t)sidx] = edge_obs[3 * (size_t)e], eo[3 * (size_t)sidx + 1] = edge_obs[3 * (size_t)e + 1];
+    eo[3 * (size_t)sidx + 2] = edge_obs[3 * (size_t)e + 2];
+    const int sl = slot[pc];
+    cc[sl < 0 ? h->nf : sl]++;
+  }
+  return VO_OK;
 }
 
 int vo_ba_create(vo_ba **out, int n_cams, const double *poses, const uint8_t *cam_fixed, int n_points,
@@ -3748,7 +3826,12 @@ int vo_ba_create(vo_ba **out, int n_cams, const double *poses, const uint8_t *ca
   VO_CHECK(ba_check_args(n_cams, poses, cam_fixed, n_points, points, n_edges, edge_cam, edge_point, edge_obs, edge_inv_sigma, cam, "vo_ba_create"));
   VO_CHECK(vo::ensure_device());
   vo_ba *h = new vo_ba();
-  ba_fill_problem(h, n_cams, poses, cam_fixed, n_points, points, n_edges, edge_cam, edge_point, edge_obs, edge_inv_sigma, cam);
+  const int frc = ba_fill_problem(h, n_cams, poses, cam_fixed, n_points, points, n_edges, edge_cam, edge_point, edge_obs, edge_inv_sigma, cam, "vo_ba_create");
+  if (frc != VO_OK) {
+    if (h->up_pin.p) (void)hipHostFree(h->up_pin.p);
+    delete h;
+    return frc;
+  }
   if (hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking) != hipSuccess) {
     delete h;
     vo::set_error("hipStreamCreate failed");
@@ -3772,7 +3855,8 @@ int vo_ba_reset(vo_ba *h, int n_cams, const double *poses, const uint8_t *cam_fi
   VO_CHECK(ba_check_args(n_cams, poses, cam_fixed, n_points, points, n_edges, edge_cam, edge_point, edge_obs, edge_inv_sigma, cam, "vo_ba_reset"));
   VO_HIP_CHECK(hipStreamSynchronize(h->stream));  // nothing of the previous problem is in flight
   drop_graphs(h);
-  ba_fill_problem(h, n_cams, poses, cam_fixed, n_points, points, n_edges, edge_cam, edge_point, edge_obs, edge_inv_sigma, cam);
+  // (a problem that fails the range check leaves the handle's previous problem in place, still built)
+  VO_CHECK(ba_fill_problem(h, n_cams, poses, cam_fixed, n_points, points, n_edges, edge_cam, edge_point, edge_obs, edge_inv_sigma, cam, "vo_ba_reset"));
   vo::chol_plan_destroy(h->chol_plan);
   h->chol_plan = nullptr;
   for (auto *&sp : h->seg_plan) vo::chol_plan_destroy(sp), sp = nullptr;
