@@ -178,10 +178,9 @@ def main():
     # Every wait on another rank has a deadline: the process group's own timeout (the NCCL watchdog aborts the process, gloo
     # raises) and, above it, a watchdog thread that ends THIS process with status 70 when no barrier / all-reduce has
     # completed for --collective-timeout seconds.  (os._exit: the process ends, nothing is exec'ed.)
-    progress = {"t": time.time(), "what": "start", "armed": False}
-
-    def _mark(what):
-        progress["t"], progress["what"] = time.time(), what
+    from vo_slam_test_amd.watchdog import CollectiveWatchdog
+    wd = CollectiveWatchdog(args.collective_timeout, rank)   # (started below when there are other ranks to wait for)
+    _mark = wd.mark
 
     if world > 1 or dist_one:
         import datetime
@@ -202,27 +201,16 @@ def main():
         else:
             dist.init_process_group(args.backend, timeout=tmo, **init)
 
-        def _watchdog():
-            while True:
-                time.sleep(2.0)
-                if progress["armed"] and time.time() - progress["t"] > args.collective_timeout:
-                    sys.stderr.write(f"bench.py rank {rank}: no collective completed for {args.collective_timeout:.0f} s "
-                                     f"(last: {progress['what']}) -- giving up\n")
-                    sys.stderr.flush()
-                    os._exit(70)
-
-        threading.Thread(target=_watchdog, daemon=True).start()
+        wd.start()
 
     from vo_slam_test_amd import _lib as vo
     from vo_slam_test_amd import synth
 
     def barrier():
         if dist is not None:
-            progress["armed"] = True
-            _mark("barrier (waiting)")
+            wd.arm("barrier (waiting)")
             dist.barrier()
-            _mark("barrier")
-            progress["armed"] = False
+            wd.disarm("barrier")
         torch.cuda.synchronize()
 
     W, H, B = 640, 480, args.batch
@@ -535,7 +523,8 @@ def main():
             # the exchange of the sharded LM loop (vo_ba_set_allreduce): RCCL over xGMI with the nccl backend
             ar_stats["calls"] += 1
             ar_stats["max_doubles"] = max(ar_stats["max_doubles"], int(n))
-            _mark(f"all-reduce of {int(n)} doubles")
+            # (armed: this is called from inside vo_ba_solve's LM loop -- a peer that never arrives must end this rank too)
+            wd.arm(f"all-reduce of {int(n)} doubles (waiting)")
             t = torch.as_tensor(_DevView(ptr, n), device="cuda")
             if args.backend == "nccl":
                 dist.all_reduce(t)
@@ -543,6 +532,7 @@ def main():
                 hbuf = t.cpu()
                 dist.all_reduce(hbuf)
                 t.copy_(hbuf)
+            wd.disarm(f"all-reduce of {int(n)} doubles")
             return 0
 
         def _same_on_all_ranks(v, what):

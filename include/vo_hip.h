@@ -738,7 +738,9 @@ void vo_ba_destroy(vo_ba *h);
 /* A NEW problem in an existing handle: the per-key-frame caller (localMapping.cpp:38 builds a different local window every
  * time) keeps ONE handle per thread and resets it instead of create / destroy -- stream, device buffers (grow-only, with
  * headroom), page-locked staging, shard / callback / options stay, so that nothing is allocated or freed on the hot path
- * (hipFree synchronises the whole device, the tracking thread's streams included).  Arguments as vo_ba_create. */
+ * (hipFree synchronises the whole device, the tracking thread's streams included).  Arguments as vo_ba_create.  Caller-owned
+ * reduce buffers (vo_ba_set_reduce_buffers) were sized for the previous problem: the reset forgets them, set them again.  A
+ * problem that is rejected (VO_ERR_INVALID: an edge out of range) leaves the handle's previous problem in place. */
 int vo_ba_reset(vo_ba *h, int n_cams, const double *poses, const uint8_t *cam_fixed, int n_points, const double *points,
                 int n_edges, const int32_t *edge_cam, const int32_t *edge_point, const double *edge_obs,
                 const double *edge_inv_sigma, const double cam[5]);
@@ -826,7 +828,7 @@ int vo_ba_update(vo_ba *h);
 int vo_ba_lm_end(vo_ba *h, vo_lm_summary *summary);
 /* let the caller own the two all-reduce payload buffers (e.g. torch tensors handed to
  * torch.distributed); sizes as reported by vo_ba_reduced_system / vo_ba_reduced_cost.
- * Must precede vo_ba_lm_begin. */
+ * Must precede vo_ba_lm_begin; vo_ba_reset forgets them (they are sized by the problem). */
 int vo_ba_set_reduce_buffers(vo_ba *h, double *dev_system, double *dev_cost);
 /* device pointers + element counts of the two all-reduce payloads */
 int vo_ba_reduced_system(vo_ba *h, double **dev_ptr, size_t *n_doubles);

@@ -83,28 +83,28 @@ def test_sharding_rule():
 
 
 def test_collective_watchdog_ends_a_stuck_rank(tmp_path):
-    """a rank whose peer never arrives must END with a non-zero status, not hang: two gloo ranks are started,
-    rank 1 exits before its first barrier; rank 0's watchdog (bench.py --collective-timeout) gives up within the deadline."""
+    """a rank whose peer never arrives must END with a non-zero status, not hang.  Two gloo ranks are
+    started, rank 1 exits before its first barrier; rank 0 waits in a barrier guarded by bench.py's OWN watchdog
+    (vo_slam_test_amd.watchdog.CollectiveWatchdog -- the class bench.py arms around its barriers and around the all-reduce
+    callback of the sharded LM loop), which gives up within the deadline."""
     script = tmp_path / "stuck.py"
     script.write_text(
-        "import os, sys, time, datetime, threading\n"
+        "import os, sys, datetime\n"
+        f"sys.path.insert(0, {str(ROOT)!r})\n"
         "import torch.distributed as dist\n"
+        "from vo_slam_test_amd.watchdog import CollectiveWatchdog\n"
         "rank = int(os.environ['RANK'])\n"
         "dist.init_process_group('gloo', timeout=datetime.timedelta(seconds=8))\n"
         "if rank == 1:\n"
         "    os._exit(0)\n"
-        "progress = {'t': time.time()}\n"
-        "def wd():\n"
-        "    while True:\n"
-        "        time.sleep(0.5)\n"
-        "        if time.time() - progress['t'] > 10:\n"
-        "            os._exit(70)\n"
-        "threading.Thread(target=wd, daemon=True).start()\n"
+        "wd = CollectiveWatchdog(10.0, rank, poll=0.5).start()\n"
+        "wd.arm('barrier (waiting)')\n"
         "try:\n"
         "    dist.barrier()\n"
         "except Exception as e:\n"
         "    sys.stderr.write('barrier failed: %r\\n' % (e,))\n"
         "    os._exit(71)\n"
+        "wd.disarm('barrier')\n"
         "os._exit(0)\n")
     import socket
     sk = socket.socket()
@@ -117,3 +117,35 @@ def test_collective_watchdog_ends_a_stuck_rank(tmp_path):
         procs.append(subprocess.Popen([sys.executable, str(script)], env=env, stderr=subprocess.PIPE))
     rcs = [p.wait(timeout=60) for p in procs]
     assert rcs[1] == 0 and rcs[0] in (70, 71), rcs  # the stuck rank ended by its deadline, with a non-zero status
+
+
+def test_watchdog_fires_only_while_armed():
+    """the deadline runs between arm() and disarm() only, mark() restarts it, and expiry calls the exit function with status 70
+    (here a recording stand-in for os._exit)"""
+    import time
+    from vo_slam_test_amd.watchdog import CollectiveWatchdog
+    fired = []
+    wd = CollectiveWatchdog(0.3, rank=3, poll=0.05, exit_fn=fired.append).start()
+    time.sleep(0.5)
+    assert not fired and not wd.expired()          # never armed: idle time does not count
+    wd.arm("all-reduce of 8 doubles (waiting)")
+    time.sleep(0.15)
+    wd.mark("still waiting")                        # progress restarts the clock
+    time.sleep(0.2)
+    assert not fired
+    wd.disarm("all-reduce of 8 doubles")
+    time.sleep(0.5)
+    assert not fired                                # disarmed: a long compute phase between collectives is fine
+    wd.arm("barrier (waiting)")
+    time.sleep(0.6)
+    assert fired == [70] and wd.what == "barrier (waiting)"
+
+
+def test_bench_uses_the_importable_watchdog():
+    """bench.py arms the watchdog around its barriers AND around the all-reduce callback of the sharded LM loop (the
+    callback only marked progress, so a collective that hung inside vo_ba_solve was not ended by --collective-timeout)"""
+    src = (ROOT / "bench.py").read_text()
+    assert "from vo_slam_test_amd.watchdog import CollectiveWatchdog" in src
+    cb = src[src.index("def _allreduce("):]
+    cb = cb[:cb.index("return 0")]
+    assert "wd.arm(" in cb and "wd.disarm(" in cb and cb.index("wd.arm(") < cb.index("dist.all_reduce") < cb.index("wd.disarm(")

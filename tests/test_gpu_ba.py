@@ -146,6 +146,18 @@ def test_local_ba_matches_oracle(vo, orc, seed):
     rel = np.abs(gpts[well] - opts[well]).max()
     assert rel < 1e-5
     assert (erase != oerase).sum() == 0
+    _check_every_written_back_point(pr, gpts, opts, deg)
+
+
+def _check_every_written_back_point(pr, gpts, opts, deg):
+    """The reference writes EVERY local map point back (optimizer_ceres.cpp:793-803), also the ones two or three key-frames see:
+    their blocks are nearly singular, the solve moves them by up to thousands of units, and an absolute bound means nothing for
+    them.  Stated bound for every point, whatever its degree: |device - oracle| <= 1e-8 * max(|X_oracle|, 1) per coordinate
+    (measured over 24 problems, tools/weak_points_probe.py: 1.0e-10 at degree 1, 9.5e-11 at 2, 6.4e-11 at 3, <= 1.1e-12 from 4
+    on); a point no edge refers to is returned bit for bit."""
+    scale = np.maximum(np.linalg.norm(opts, axis=1), 1.0)[:, None]
+    assert (np.abs(gpts - opts) <= 1e-8 * scale).all(), float((np.abs(gpts - opts) / scale).max())
+    assert np.array_equal(gpts[deg == 0], pr["points"][deg == 0])
 
 
 def test_one_handle_reset_over_twenty_problems(vo, orc):
@@ -171,6 +183,7 @@ def test_one_handle_reset_over_twenty_problems(vo, orc):
         deg = np.bincount(pr["e_pt"], minlength=len(opts))
         if (deg >= 4).any():
             assert np.abs(gpts[deg >= 4] - opts[deg >= 4]).max() < 1e-5, k
+        _check_every_written_back_point(pr, gpts, opts, deg)
         if k in (7, 15):
             fresh = vo.BundleAdjuster(pr)
             e2, _, _ = fresh.local_ba()

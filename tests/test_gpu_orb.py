@@ -255,3 +255,49 @@ def test_large_batch_is_deterministic_and_matches_oracle(ext, orc):
         assert n == len(okp)
         assert np.array_equal(np.frombuffer(kps[f, :n].tobytes(), dtype=_lib.KP_DTYPE), okp)
         assert np.array_equal(desc[f, :n], odesc)
+
+
+def test_stage_hook_order_and_second_stream(vo, orc):
+    """vo_orb_set_stage_hook: called once per stage, in pipeline order, with the stream the stage was enqueued on; work launched
+    from it on another stream behind an event of that stream (here: the all-pairs matching of the PREVIOUS extraction's
+    descriptors, the use bench.py's schedule experiment made of it) leaves both results as they are without it"""
+    import torch
+    B = 8
+    frames = torch.from_numpy(synth.make_frames(B)).cuda()
+    s1, s2 = torch.cuda.Stream(), torch.cuda.Stream()
+    e = vo.OrbExtractor(1000, 1.2, 8, 20, 7)
+    e.set_stream(s1.cuda_stream)
+    cap = e.max_keypoints()
+    kps = torch.zeros((B, cap, 28), dtype=torch.uint8, device="cuda")
+    desc = [torch.zeros((B, cap, 32), dtype=torch.uint8, device="cuda") for _ in range(2)]
+    cnt = torch.zeros(B, dtype=torch.int32, device="cuda")
+    dm = [torch.zeros((B - 1, 600, 600), dtype=torch.int16, device="cuda") for _ in range(2)]
+    torch.cuda.synchronize()
+    with torch.cuda.stream(s1):
+        e.extract_batch_dev(frames, kps, desc[0], cnt)
+    torch.cuda.synchronize()
+    vo.hamming_matrix_batch_dev(desc[0][:-1, :600], desc[0][1:, :600], dm[0], stream=s1.cuda_stream)
+    torch.cuda.synchronize()
+    want_desc, want_dm = desc[0].cpu().numpy().copy(), dm[0].cpu().numpy().copy()
+    seen = []
+
+    def hook(stage, stream):
+        seen.append((stage, stream))
+        if stage == 0:  # behind this extraction's pyramid: the matching of the previous extraction's descriptors, on s2
+            ev = torch.cuda.Event()
+            ev.record(s1)
+            s2.wait_event(ev)
+            vo.hamming_matrix_batch_dev(desc[0][:-1, :600], desc[0][1:, :600], dm[1], stream=s2.cuda_stream)
+
+    e.set_stage_hook(hook)
+    with torch.cuda.stream(s1):
+        e.extract_batch_dev(frames, kps, desc[1], cnt)
+    torch.cuda.synchronize()
+    e.set_stage_hook(None)
+    with torch.cuda.stream(s1):
+        e.extract_batch_dev(frames, kps, desc[1], cnt)  # (no calls any more)
+    torch.cuda.synchronize()
+    e.close()
+    assert [st for st, _ in seen] == [0, 1, 2, 4, 5], seen
+    assert all(sp == s1.cuda_stream for _, sp in seen)
+    assert np.array_equal(desc[1].cpu().numpy(), want_desc) and np.array_equal(dm[1].cpu().numpy(), want_dm)

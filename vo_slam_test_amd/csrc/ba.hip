@@ -2921,6 +2921,7 @@ int upload(vo::DevBuf &b, const void *src, size_t bytes) {
 // A device buffer that grows with headroom: a handle that is re-used for problem after problem (vo_ba_reset) stops
 // allocating after the first few (hipMalloc costs tens of microseconds, the hipFree behind a growth synchronises the device).
 int reserve_grow(vo::DevBuf &b, size_t bytes) {
+  if (b.view) b.release();  // a view into an earlier build's arena is not this buffer's storage (it kept aliasing the old offset)
   if (bytes <= b.bytes) return VO_OK;
   return b.reserve(bytes + bytes / 2 + 256);
 }
@@ -3340,13 +3341,16 @@ int build_device(vo_ba *h) {
   if (h->collectives && h->allreduce) {
     // Handshake: the collective schedule of the LM loop (how many all-reduces per iteration, of how many doubles) follows
     // from the options and the problem, and ranks that disagree would wait for each other forever.  One tiny all-reduce
-    // before any solve: every rank contributes (c, c^2, 1) with c = its protocol word; the sums tell every rank -- the
-    // same way -- whether all words are equal (n sum(c^2) == sum(c)^2, exact in doubles for c < 2^20) and whether the
-    // number of ranks is the one it was configured with.
-    const unsigned proto = 1u + (h->seg_mode ? 1u : 0u) + (D.large ? 2u : 0u) + 4u * (unsigned)(h->n_shards & 0xff) +
-                           1024u * (unsigned)((h->n_edges * 31 + h->n_pts * 7 + h->nf) & 0x3ff);
-    const double c = (double)proto;
-    double hs[4] = {c, c * c, 1.0, 0.0};
+    // before any solve: every rank contributes (c, c^2, 1, g) -- c = its 16-bit protocol word (protocol bits, shard count,
+    // five bits of a hash of the problem sizes), g = twenty more bits of that hash (64-bit arithmetic).  All words are
+    // equal iff n sum(c^2) == sum(c)^2, exact in doubles up to 2^10 ranks (with the former 20-bit word it was
+    // exact up to ~90); sum(g) == n g catches a different problem in all but one case in 2^20; sum(1) is the number of
+    // ranks that answered.
+    const unsigned long long hash = (unsigned long long)h->n_edges * 31ull + (unsigned long long)h->n_pts * 7ull + (unsigned long long)h->nf;
+    const unsigned proto = (1u + (h->seg_mode ? 1u : 0u) + (D.large ? 2u : 0u)) | ((unsigned)(h->n_shards & 0xff) << 3) |
+                           ((unsigned)(hash & 31ull) << 11);
+    const double c = (double)proto, g = (double)((hash >> 5) & 0xfffffull);
+    double hs[4] = {c, c * c, 1.0, g};
     VO_CHECK(reserve_grow(h->b_merge, 64));
     VO_HIP_CHECK(hipMemcpyAsync(h->b_merge.p, hs, sizeof(hs), hipMemcpyHostToDevice, h->stream));
     const int rc = h->allreduce(h->allreduce_user, h->b_merge.as<double>(), 4, (void *)h->stream);
@@ -3357,7 +3361,7 @@ int build_device(vo_ba *h) {
     VO_HIP_CHECK(hipMemcpyAsync(hs, h->b_merge.p, sizeof(hs), hipMemcpyDeviceToHost, h->stream));
     VO_HIP_CHECK(hipStreamSynchronize(h->stream));
     const double nr = hs[2];
-    if (nr != (double)h->n_shards || nr * hs[1] != hs[0] * hs[0]) {
+    if (nr != (double)h->n_shards || nr * hs[1] != hs[0] * hs[0] || hs[3] != nr * g) {
       vo::set_error("sharded BA: the ranks disagree on the collective protocol (options / shard count / problem): %g ranks answered, "
                     "%d configured, protocol word %u here (vo_ba_set_option and vo_ba_set_shard must be the same on every rank)",
                     nr, h->n_shards, proto);
@@ -3861,6 +3865,8 @@ int vo_ba_reset(vo_ba *h, int n_cams, const double *poses, const uint8_t *cam_fi
   h->chol_plan = nullptr;
   for (auto *&sp : h->seg_plan) vo::chol_plan_destroy(sp), sp = nullptr;
   h->built = false, h->state_cached = false;
+  // caller-owned reduce buffers were sized for the previous problem (vo_ba_set_reduce_buffers): they must be set again
+  h->ext_payload = nullptr, h->ext_payload2 = nullptr;
   h->D = BaDev{};
   h->lm_max_it = 0, h->archive_slot = -1, h->lba_second = false;
   h->n_pack_tiles = 0, h->pt_owner.clear(), h->collectives = false, h->seg_mode = false, h->seg_c0 = 0, h->n_seg_tiles = 0;

@@ -49,19 +49,11 @@ namespace {
 using namespace vo;
 
 constexpr int NB = vo::kCholPanel;  // 64
-#ifndef VO_CHOL_PIVOT_WIDTH
-#define VO_CHOL_PIVOT_WIDTH 16
-#endif
-#ifndef VO_CHOL_SUBFLAG_PANEL
-#define VO_CHOL_SUBFLAG_PANEL 0
-#endif
-#ifndef VO_CHOL_POLL_DEPTH
-#define VO_CHOL_POLL_DEPTH 1
-#endif
-#ifndef VO_CHOL_NEWTON
-#define VO_CHOL_NEWTON 3
-#endif
-constexpr int kNewton = VO_CHOL_NEWTON;  // v_rsq_f64 is good to ~2^-26: 1, 2 = Newton steps (~1e-15, full precision); 3 = one third-order step (full)
+// decided in rounds 3-4 (8-wide pivot sub-panels, flagging the sub-diagonal tile with a later panel, four
+// polls in flight and plain Newton steps were each measured and lost)
+constexpr int kPivotWidth = 16;   // pivot sub-panel = the 16-column panel
+constexpr int kSubflagPanel = 0;  // the panel step behind which the sub-diagonal tile's stores are drained and flagged
+constexpr int kNewton = 3;  // v_rsq_f64 is good to ~2^-26: 1, 2 = Newton steps (~1e-15, full precision); 3 = one third-order step (full)
 constexpr int LP = NB + 1;          // LDS pitch of a staged tile (conflict-free column and row walks)
 typedef double double4_t __attribute__((ext_vector_type(4)));
 
@@ -109,33 +101,13 @@ struct CholCtx {
 };
 
 // workgroup-wide wait for a flag (bounded).  Returns false when the kernel is being abandoned.  A poll is a trip to
-// memory (~1 us: the loads bypass the caches), so four are kept in flight, a quarter of that apart -- the hand-offs
-// on the factorisation's critical path see a flag ~0.4 us sooner than with one poll at a time; `seen` (optional)
-// receives the value read, which may be ahead of `want` (panel counters: no need to ask again).
+// memory (~1 us: the loads bypass the caches); ONE poll at a time (four in flight, a quarter of a trip apart, saw a flag
+// ~0.4 us sooner and cost the chain more in flag traffic: 470 -> 523 us, round 3); `seen` (optional) receives the value
+// read, which may be ahead of `want` (panel counters: no need to ask again).
 __device__ __forceinline__ bool wait_flag(const CholCtx &C, const int *flag, int want, int *s_state, int *seen = nullptr) {
   if (threadIdx.x == 0) {
     int ok = 1;
     int v0 = ld_flag(flag);
-#if VO_CHOL_POLL_DEPTH == 4
-    if (v0 < want) {
-      __builtin_amdgcn_s_sleep(4);
-      int v1 = ld_flag(flag);
-      __builtin_amdgcn_s_sleep(4);
-      int v2 = ld_flag(flag);
-      __builtin_amdgcn_s_sleep(4);
-      int v3 = ld_flag(flag);
-      for (int n = 0; v0 < want; n++) {
-        if (n > C.spin_limit || ld_flag(C.fail) != 0) {
-          if (n > C.spin_limit) atomicMax(C.fail, 2);  // dependency never arrived: give up loudly instead of hanging
-          ok = 0;
-          break;
-        }
-        v0 = v1, v1 = v2, v2 = v3;
-        __builtin_amdgcn_s_sleep(4);
-        v3 = ld_flag(flag);
-      }
-    }
-#else
     for (int n = 0; v0 < want; n++) {
       if (n > C.spin_limit || ld_flag(C.fail) != 0) {
         if (n > C.spin_limit) atomicMax(C.fail, 2);  // dependency never arrived: give up loudly instead of hanging
@@ -145,7 +117,6 @@ __device__ __forceinline__ bool wait_flag(const CholCtx &C, const int *flag, int
       __builtin_amdgcn_s_sleep(2);
       v0 = ld_flag(flag);
     }
-#endif
     s_state[0] = ok;
     s_state[1] = v0;
   }
@@ -212,7 +183,7 @@ __device__ __forceinline__ bool tile_chol(double (*T)[LP], double *rdiag /*[NB]*
   // measured: 11.2 against 10.4 us per diagonal tile -- the pivot loop is bound by the latency of its dependent chain
   // (~300 cycles per pivot), not by the updates issued next to it; so was forming the next diagonal ahead of the column
   // (d' = a' - x^2 / d through v_rcp_f64: 2.28 against 2.05 us per 16 pivots).  PW = 16 is the product.
-  constexpr int PW = VO_CHOL_PIVOT_WIDTH, NSP = 16 / PW;
+  constexpr int PW = kPivotWidth, NSP = 16 / PW;
 #pragma unroll
   for (int sp = 0; sp < 4 * NSP; sp++) {
     const int c0 = PW * sp, b = sp / NSP;
@@ -508,7 +479,7 @@ __global__ __launch_bounds__(256) void k_chol_tiles(CholCtx C) {
               if (b == 1 && dslot >= 0) CSTAMP(dslot, 13);
             },
             [&](int b) {
-              if (b != VO_CHOL_SUBFLAG_PANEL || !sub) return;
+              if (b != kSubflagPanel || !sub) return;
               asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // (this wavefront's share of the sub-diagonal tile's stores)
               if (lane == 0 && atomicAdd(&s_stored, 1) == 2) {
                 s_stored = 0;

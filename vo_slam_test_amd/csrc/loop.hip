@@ -228,8 +228,14 @@ int vo_sim3_ransac_eval(int n, const double *cam1_points, const double *cam2_poi
   hipStream_t st = vo::thread_stream();
   const char *W = "vo_sim3_ransac_eval";
   if (resident && n > 0) {
-    if (resident_n != n) {
-      vo::set_error("vo_sim3_ransac_eval: no correspondences of this size are resident for this thread (%d requested, %d held)", n, resident_n);
+    // (the buffers themselves are checked, not only the count: vo_release_thread_scratch() on this thread frees them, and a
+    //  failed upload leaves them short -- a launch with null or short pointers is a GPU memory fault, not an error code)
+    const bool held = d1.p && d2.p && p1.p && p2.p && e1.p && e2.p && d1.bytes >= (size_t)n * 24 && d2.bytes >= (size_t)n * 24 &&
+                      p1.bytes >= (size_t)n * 16 && p2.bytes >= (size_t)n * 16 && e1.bytes >= (size_t)n * 4 && e2.bytes >= (size_t)n * 4;
+    if (resident_n != n || !held) {
+      vo::set_error("vo_sim3_ransac_eval: no correspondences of this size are resident for this thread (%d requested, %d held%s)", n,
+                    resident_n, held ? "" : ", buffers released");
+      resident_n = -1;
       return VO_ERR_INVALID;
     }
   } else {

@@ -135,7 +135,7 @@ __device__ __forceinline__ int dot2_i16(unsigned taps, unsigned coef) {
   return __builtin_amdgcn_sdot2(__builtin_bit_cast(short2_t, taps), __builtin_bit_cast(short2_t, coef), 0, false);
 }
 
-#define VO_OCT_WAVES 7  // waves per SIMD the oct-tree is compiled for (6: +7 %, 8: +2.5 %, round 4)
+constexpr int kOctWaves = 7;  // waves per SIMD the oct-tree is compiled for (6: +7 %, 8: +2.5 %, round 4)
 __device__ __forceinline__ int rz_h16(int h) { return h & ~15; }  // horizontal sum with the low four bits dropped (see the vertical blend)
 constexpr int kRzL = 16;               // lanes (four-pixel groups) per tile row
 constexpr int kRzF = 64 / kRzL;        // frames a wavefront works on side by side
@@ -728,7 +728,7 @@ __device__ __forceinline__ int quadrant_of(int kx, int ky, int x0, int y0, int x
 // (7 waves per SIMD = 7 workgroups per CU: the kernel is a chain of latencies, co-resident workgroups are its
 // throughput; 0.326 -> 0.283 ms per 1024 frames against the compiler's own choice of 88 registers / 5 waves)
 template <int CAP>
-__attribute__((amdgpu_waves_per_eu(VO_OCT_WAVES, VO_OCT_WAVES))) __global__ __launch_bounds__(256) void k_octree(OrbDev P, const uint32_t *cell_slots,
+__attribute__((amdgpu_waves_per_eu(kOctWaves, kOctWaves))) __global__ __launch_bounds__(256) void k_octree(OrbDev P, const uint32_t *cell_slots,
                                                 long long slots_frame_stride, const int *cell_count,
                                                 int cells_per_frame, uint32_t *key_data,
                                                 unsigned short *key_label, int keys_per_frame,
@@ -1414,9 +1414,7 @@ __global__ __launch_bounds__(256, 4) void k_blur_mfma(FrameSrc src, const int *_
     else asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
     bm_i32x4 n0, n1;
     read_tile(k + 1, n0, n1);
-#ifndef BM_NOLOAD
     if (k + 1 < n_vt) dma_tile(k + 2);  // uniform; into the buffer tile k left; in flight during this tile's products
-#endif
     bm_i32x4 lo2, hi2;
     row_pass(n0, n1, lo2, hi2);
     bm_i32x16 al = __builtin_amdgcn_mfma_i32_32x32x32_i8(lo, Bv1, CV, 0, 0, 0);
@@ -1439,9 +1437,6 @@ __global__ __launch_bounds__(256, 4) void k_blur_mfma(FrameSrc src, const int *_
     const auto w02 = __builtin_amdgcn_permlane32_swap(d[0], d[2], false, false);
     const auto w13 = __builtin_amdgcn_permlane32_swap(d[1], d[3], false, false);
     const int y = r0 + 3 + 32 * k + m;
-#ifdef BM_NOSTORE
-    if (w02[0] == 0x12345678u && w13[1] == 0x9abcdef1u)
-#endif
     if (xt_ok && y < y_end) {
       const u32x4_t out = {w02[0], w02[1], w13[0], w13[1]};
       *reinterpret_cast<u32x4_t *>(dst + blur_tiled_off(x0 + 16 * kg, y, Lpitch)) = out;
@@ -1599,9 +1594,7 @@ __device__ __forceinline__ void window_store(lds_u8 *slot, int lane, const u32x4
   }
 }
 
-#ifndef VO_DESC_NK
-#define VO_DESC_NK 2
-#endif
+constexpr int kDescNK = 2;  // key-points in flight per wavefront of k_describe (1 and 4 measured slower, round 2)
 
 // One workgroup per batch of 64 key-points of a frame, four phases separated by workgroup barriers:
 //  0  lane = key-point: level search, selected key, plane addresses -> LDS records
@@ -2583,7 +2576,7 @@ int run_pipeline(vo_orb *h, const uint8_t *dev_images, int n_frames, int w, int 
   const int kp_blocks = (std::min(capacity, h->max_kp) + 63) / 64;
   if (kp_blocks == 0 && dcounts) VO_HIP_CHECK(hipMemsetAsync(dcounts, 0, (size_t)n_frames * sizeof(int), st));
   if (kp_blocks > 0)
-    hipLaunchKernelGGL(k_describe<VO_DESC_NK>, dim3(kp_blocks * ((n_frames + 7) / 8) * 8), dim3(256), 0, st, D, S,
+    hipLaunchKernelGGL(k_describe<kDescNK>, dim3(kp_blocks * ((n_frames + 7) / 8) * 8), dim3(256), 0, st, D, S,
                        h->sel.as<uint32_t>(), h->sel_frame, h->nk.as<int>(), dcounts, capacity, dkp, ddesc, lv0_not16, kp_blocks,
                        n_frames, h->err.as<int>());
   VO_STAGE_MARK(6);
