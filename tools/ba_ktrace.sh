@@ -4,7 +4,7 @@ cd /tmp && export TMPDIR=/tmp
 R=${GRAFT_REPO_ROOT:-/root/repo}
 python3 $R/tools/ba_run.py 20 2>&1 | grep -v amdgpu.ids
 d=$R/gpurun_out/ba_ktrace; rm -rf $d; mkdir -p $d
-rocprofv3 --kernel-trace -d $d --output-format csv -- python3 $R/tools/ba_run.py 10 > $d/log.txt 2>&1
+timeout 300 rocprofv3 --kernel-trace -d $d --output-format csv -- python3 $R/tools/ba_run.py 10 > $d/log.txt 2>&1
 python3 - <<PY
 import csv, glob, collections
 f = glob.glob("$d/**/*kernel_trace.csv", recursive=True)[0]

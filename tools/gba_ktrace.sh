@@ -3,7 +3,7 @@
 cd /tmp && export TMPDIR=/tmp
 R=${GRAFT_REPO_ROOT:-/root/repo}
 d=$R/gpurun_out/gba_ktrace; rm -rf $d; mkdir -p $d
-rocprofv3 --kernel-trace -d $d --output-format csv -- python3 $R/tools/gba_run.py "$@" > $d/log.txt 2>&1
+timeout 300 rocprofv3 --kernel-trace -d $d --output-format csv -- python3 $R/tools/gba_run.py "$@" > $d/log.txt 2>&1
 tail -3 $d/log.txt
 python3 - <<PY
 import csv, glob, collections

@@ -15,7 +15,7 @@ for so in "" $R/vo_slam_test_amd/_variants/libvo_*.so; do
     i=$((i+1))
     d=$R/gpurun_out/pmcs_lp/g$i
     rm -rf $d; mkdir -p $d
-    rocprofv3 --pmc $grp -d $d --output-format csv -- python3 $R/tools/ext_stage_times.py > $d/log.txt 2>&1
+    timeout 300 rocprofv3 --pmc $grp -d $d --output-format csv -- python3 $R/tools/ext_stage_times.py > $d/log.txt 2>&1
     python3 $R/tools/pmc_summary.py $d $filt 2>&1 | grep -v "^at::\|elementwise\|vectorized\|rocclr\|fill_\|copy" | head -12
   done <<'GROUPS'
 SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY

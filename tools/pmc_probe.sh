@@ -10,7 +10,7 @@ while read -r grp; do
   i=$((i+1))
   d=$R/gpurun_out/pmcp/g$i
   rm -rf $d; mkdir -p $d
-  rocprofv3 --pmc $grp -d $d --output-format csv -- python3 "$@" > $d/log.txt 2>&1
+  timeout 300 rocprofv3 --pmc $grp -d $d --output-format csv -- python3 "$@" > $d/log.txt 2>&1
   echo "== $grp"
   python3 $R/tools/pmc_summary.py $d $filt 2>&1 | head -6
 done <<'GROUPS'

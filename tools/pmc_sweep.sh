@@ -10,7 +10,7 @@ while read -r grp; do
   i=$((i+1))
   d=$R/gpurun_out/pmcs/g$i
   rm -rf $d; mkdir -p $d
-  rocprofv3 --pmc $grp -d $d --output-format csv -- python3 $R/bench.py --steps 2 --warmup 1 --no-ba --no-cpu-baseline --no-bruteforce --no-single-stream > $d/log.txt 2>&1
+  timeout 300 rocprofv3 --pmc $grp -d $d --output-format csv -- python3 $R/bench.py --steps 2 --warmup 1 --no-ba --no-cpu-baseline --no-bruteforce --no-single-stream > $d/log.txt 2>&1
   echo "== $grp"
   python3 $R/tools/pmc_summary.py $d $filt 2>&1 | grep -v "^at::\|elementwise\|vectorized\|rocclr\|fill_\|copy" | head -24
 done <<'GROUPS'

@@ -8,13 +8,13 @@ O=$R/gpurun_out/refresh
 rm -rf $O; mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
 # 1. kernel trace + stats of the bench command
-rocprofv3 --kernel-trace --stats -d $O/kt --output-format csv -- python3 $R/bench.py --steps 20 --warmup 2 --no-cpu-baseline --no-single-stream > $O/kt.log 2>&1
+timeout 600 rocprofv3 --kernel-trace --stats -d $O/kt --output-format csv -- python3 $R/bench.py --steps 20 --warmup 2 --no-cpu-baseline --no-single-stream > $O/kt.log 2>&1
 f=$(find $O/kt -name "*kernel_stats.csv" | head -1)
 cp "$f" $O/r${NN}_kernel_stats.csv
 python3 $R/tools/prof_summary.py $O/kt 40 > $O/r${NN}_kernel_stats_summary.txt 2>&1
 # 2. HBM-side traffic: separate passes per counter (never combined with trace domains)
-rocprofv3 --pmc FETCH_SIZE -d $O/fetch --output-format csv -- python3 $R/bench.py --steps 2 --warmup 1 --no-ba --no-cpu-baseline --no-bruteforce --no-single-stream > $O/fetch.log 2>&1
-rocprofv3 --pmc WRITE_SIZE -d $O/write --output-format csv -- python3 $R/bench.py --steps 2 --warmup 1 --no-ba --no-cpu-baseline --no-bruteforce --no-single-stream > $O/write.log 2>&1
+timeout 300 rocprofv3 --pmc FETCH_SIZE -d $O/fetch --output-format csv -- python3 $R/bench.py --steps 2 --warmup 1 --no-ba --no-cpu-baseline --no-bruteforce --no-single-stream > $O/fetch.log 2>&1
+timeout 300 rocprofv3 --pmc WRITE_SIZE -d $O/write --output-format csv -- python3 $R/bench.py --steps 2 --warmup 1 --no-ba --no-cpu-baseline --no-bruteforce --no-single-stream > $O/write.log 2>&1
 python3 $R/tools/make_traffic_json.py $O/fetch $O/write $O/r${NN}_traffic_pmc.json > $O/traffic.log 2>&1
 # 3. instruction-mix / LDS / texture-path / L2 counters per kernel (one --pmc pass per group)
 bash $R/tools/pmc_sweep.sh > $O/r${NN}_pmc_summary.txt 2>&1

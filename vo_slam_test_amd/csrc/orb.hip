@@ -1302,11 +1302,11 @@ __global__ __launch_bounds__(256) void k_blur_groups(FrameSrc src, int lv0_gener
 //   row pass     H[y][x] = sum_k P[y][k] Wh[k][x]: v_mfma_i32_32x32x32_i8, A = 32 rows x 16 consecutive pixels per lane -- a
 //                16-byte load, xor 0x80 = (p - 128) as int8 --, B = the band (a constant operand: per strip from a table built
 //                with the handle, BORDER_REFLECT_101 at the left / right edge folded into its entries), K = the 64 source
-//                columns [x0 - 16, x0 + 48) in two steps, C = 128 * 257 so that the accumulator is the unsigned 16-bit row sum;
+//                columns [x0 - 16, x0 + 48) in two steps, C = 128 so that the accumulator is the row sum - 2^15, a signed 16-bit number;
 //   hand-over    the accumulator of that product has its COLUMN on the lane and 16 rows in its registers -- exactly the A
 //                operand of the next product if the order of its K slots is chosen to match (slot 4 g + j of lane half h = row
 //                8 g + 4 h + j; the band operand is permuted accordingly): no lane movement, no LDS.  The 16-bit sums are
-//                split into a high and a low byte plane (4 v_perm per 4 values, xor 0x80 for the sign);
+//                split into a high and a low byte plane (4 v_perm per 4 values; the low plane xor 0x80: byte - 128);
 //   column pass  V^T[x][y] = sum_k H[k][x] Wv[k][y] for both planes, against the tile's own 32 rows and the first six of the
 //                next tile; value = acc_hi * 256 + acc_lo with the rounding and the three offsets riding in acc_lo's C operand;
 //   store        M = x lands in the registers and N = y on the lanes, so a lane holds 4 x 4 consecutive pixels of ONE row:
@@ -1325,9 +1325,10 @@ __device__ __forceinline__ unsigned bm_sat_pk(unsigned v) {
   return r;
 }
 
-// (4 waves per SIMD declared: with a register budget of at most 256 the compiler keeps the accumulators in VGPRs; at the default
-//  it put them in AGPRs and paid a v_accvgpr_read per result register and 16 v_accvgpr_mov per product for its C operand)
-__global__ __launch_bounds__(256, 4) void k_blur_mfma(FrameSrc src, const int *__restrict__ job_tab, int n_jobs,
+// (4 waves per SIMD: with a register budget of at most 256 the compiler keeps the accumulators in VGPRs -- at the default it put
+//  them in AGPRs and paid a v_accvgpr_read per result register --, and FOUR is also what the kernel runs fastest at: 0.66 / 0.53 /
+//  0.507 / 0.524 / 0.55 ms per 1024 frames at 2 / 3 / 4 / 5 / 6 resident waves per SIMD, the register count allows 6)
+__attribute__((amdgpu_waves_per_eu(4, 4))) __global__ __launch_bounds__(256, 4) void k_blur_mfma(FrameSrc src, const int *__restrict__ job_tab, int n_jobs,
                                                    const int *__restrict__ tab, int bv_off) {
   const int lane = threadIdx.x & 63;
   const int job = blockIdx.x * 4 + __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
@@ -1360,10 +1361,18 @@ __global__ __launch_bounds__(256, 4) void k_blur_mfma(FrameSrc src, const int *_
   lds_u8 *stage = (lds_u8 *)stage_all[threadIdx.x >> 6];
   const int drow = lane >> 2;                                  // row of the lane's piece within a half tile
   const int dcol = min(max(x0 - 16 + 16 * ((lane & 3) ^ ((drow >> 2) & 3)), 0), cmax);
-  bm_i32x16 CH, CV;
-#pragma unroll
-  for (int i = 0; i < 16; i++) CH[i] = 128 * 257, CV[i] = 257 * (128 * 257) + (1 << 15);
   const bm_i32x16 Z = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+  // The C operands of the two chains are constants (row pass: 128, so that the accumulator is the row sum minus 2^15, a signed
+  // 16-bit number whose high byte is its own signed byte and whose low byte needs the xor only; column pass: the three offsets
+  // and the rounding).  They are rebuilt from one register per product (16 v_mov of the fast class): kept as loop-invariant
+  // 16-register tuples they cost 32 registers -- a wavefront per SIMD -- and the same moves, because the product overwrites C.
+  auto splat = [](int v) {
+    asm volatile("" : "+v"(v));
+    bm_i32x16 c;
+#pragma unroll
+    for (int i = 0; i < 16; i++) c[i] = v;
+    return c;
+  };
 
   auto dma_tile = [&](int k) {
 #pragma unroll
@@ -1387,14 +1396,14 @@ __global__ __launch_bounds__(256, 4) void k_blur_mfma(FrameSrc src, const int *_
   auto row_pass = [&](bm_i32x4 a0, bm_i32x4 a1, bm_i32x4 &lo, bm_i32x4 &hi) {
 #pragma unroll
     for (int i = 0; i < 4; i++) a0[i] ^= (int)0x80808080, a1[i] ^= (int)0x80808080;
-    bm_i32x16 acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(a0, Bh0, CH, 0, 0, 0);
+    bm_i32x16 acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(a0, Bh0, splat(128), 0, 0, 0);
     acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(a1, Bh1, acc, 0, 0, 0);
 #pragma unroll
     for (int g = 0; g < 4; g++) {
       const unsigned t01 = __builtin_amdgcn_perm((unsigned)acc[4 * g + 1], (unsigned)acc[4 * g], 0x05010400u);
       const unsigned t23 = __builtin_amdgcn_perm((unsigned)acc[4 * g + 3], (unsigned)acc[4 * g + 2], 0x05010400u);
       lo[g] = (int)(__builtin_amdgcn_perm(t23, t01, 0x05040100u) ^ 0x80808080u);
-      hi[g] = (int)(__builtin_amdgcn_perm(t23, t01, 0x07060302u) ^ 0x80808080u);
+      hi[g] = (int)__builtin_amdgcn_perm(t23, t01, 0x07060302u);
     }
   };
 
@@ -1417,7 +1426,7 @@ __global__ __launch_bounds__(256, 4) void k_blur_mfma(FrameSrc src, const int *_
     if (k + 1 < n_vt) dma_tile(k + 2);  // uniform; into the buffer tile k left; in flight during this tile's products
     bm_i32x4 lo2, hi2;
     row_pass(n0, n1, lo2, hi2);
-    bm_i32x16 al = __builtin_amdgcn_mfma_i32_32x32x32_i8(lo, Bv1, CV, 0, 0, 0);
+    bm_i32x16 al = __builtin_amdgcn_mfma_i32_32x32x32_i8(lo, Bv1, splat(257 * (128 * 257) + (1 << 15)), 0, 0, 0);
     bm_i32x16 ah = __builtin_amdgcn_mfma_i32_32x32x32_i8(hi, Bv1, Z, 0, 0, 0);
     al = __builtin_amdgcn_mfma_i32_32x32x32_i8(lo2, Bv2, al, 0, 0, 0);
     ah = __builtin_amdgcn_mfma_i32_32x32x32_i8(hi2, Bv2, ah, 0, 0, 0);
