@@ -133,6 +133,10 @@ def main():
     ap.add_argument("--pipeline", type=int, default=2, help="batches in flight: the issue-bound extraction of one batch runs on a "
                     "shared stream next to the latency-bound searches / pose solves (one wavefront per frame, high-priority "
                     "streams) of the previous ones; 1 = everything on one stream")
+    ap.add_argument("--unique-frames", type=int, default=32, help="distinct synthetic frames the batch is built from (repeated to --batch; "
+                    "every copy is its own HBM buffer either way).  32 keeps the set-up short; --unique-frames 1024 gives the "
+                    "data-dependent kernels -- FAST survivor lists, oct-tree depth, the claim replays -- 1024 different cases "
+                    "(set-up takes ~1 min longer; measured once per round, DESIGN.md section 7)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-ba", action="store_true")
     ap.add_argument("--no-bruteforce", action="store_true", help="skip the extract + all-pairs Hamming measurement (configs[1] as written)")
@@ -214,7 +218,7 @@ def main():
         torch.cuda.synchronize()
 
     W, H, B = 640, 480, args.batch
-    n_unique = min(B, 32)
+    n_unique = max(1, min(B, args.unique_frames))
     uniq = synth.make_frames(n_unique, start=rank * 1000)
     uniq_depth = np.stack([synth.make_depth(rank * 1000 + i) for i in range(n_unique)])
     frames_np = np.stack([uniq[i % n_unique] for i in range(B)])
@@ -257,6 +261,9 @@ def main():
             for _ in range(n_pipe)]
     trk = trks[0]
     exts = [t.extractor() for t in trks]
+    if os.environ.get("VO_BENCH_BLUR"):   # developer A/B: 1 = the VALU blur in the trackers' extractors
+        for e in exts:
+            e.set_blur_kernel(int(os.environ["VO_BENCH_BLUR"]))
     all_maps = [maps[f % n_unique] for f in range(B)]
     for t in trks:
         load_maps(t, all_maps, 1100, 2200)
@@ -277,7 +284,7 @@ def main():
     for t in trks:
         res = t.results()   # synchronises; raises on dropped key-points / exhausted candidate pools
         counts = t.get(t.KEYPOINT_COUNTS)
-        assert counts.min() >= NM, f"synthetic frames must yield >= {NM} key-points, got {counts.min()}"
+        assert counts.min() >= (NM if n_unique <= 32 else 900), f"synthetic frames must yield >= {NM} key-points, got {counts.min()}"
         ninl = res["n_inliers"]
         assert ninl.min() >= 100, f"tracking must keep >= 100 pose inliers per frame, got {ninl.min()}"
         assert not res["status"].any(), "every synthetic frame must be tracked (status 0)"
@@ -370,6 +377,24 @@ def main():
             "alone_ms": round(serial_stage_ms[k], 4),
             "alone_frac": round(sb[k] * B / (serial_stage_ms[k] * 1e-3) / 1e9 / HBM_PEAK_GBS, 5)}
         for k in kernel_stages if stage_ms.get(k, 0.0) > 0 and serial_stage_ms[k] > 0}
+    # The binding unit next to the HBM fraction (VERDICT r5 #1c): vector instructions per launch from the committed PMC pass
+    # (profiles/valu_counts.json: SQ_INSTS_VALU per 1024 frames, collected with rocprofv3 --pmc on this workload) x the calibrated
+    # issue cost (4.2 cycles per wave64 instruction per SIMD, profiles/r03_valu_issue_calibration.txt) / the launch time measured
+    # HERE with one batch in flight.  A kernel near 1 is bound by instruction issue whatever its HBM fraction says.
+    vc = None
+    try:
+        vc = json.loads((ROOT / "profiles" / "valu_counts.json").read_text())
+    except Exception:
+        vc = None
+    if vc:
+        cyc, simds, clk = float(vc["cycles_per_valu"]), float(vc["simds"]), float(vc["clock_GHz"]) * 1e9
+        for k, d in roofline["per_kernel"].items():
+            n = vc["valu_per_1024_frames"].get(k)
+            if n:
+                d["valu_issue_frac"] = round(n * (B / 1024.0) * cyc / (simds * clk) / (serial_stage_ms[k] * 1e-3), 4)
+                d["judged_on"] = "valu_issue" if d["valu_issue_frac"] > d["alone_frac"] else "hbm"
+        roofline["valu_issue_note"] = ("valu_issue_frac = SQ_INSTS_VALU (profiles/valu_counts.json, " + vc.get("source", "") + ") x " +
+                                       f"{cyc} cycles / ({int(simds)} SIMDs x {vc['clock_GHz']} GHz) / alone_ms")
     stage_gbs = {k: round(sb[k] * B / (serial_stage_ms[k] * 1e-3) / 1e9, 1) for k in kernel_stages if serial_stage_ms[k] > 0}
     stage_gbs_region = {k: round(sb[k] * B / (stage_ms[k] * 1e-3) / 1e9, 1) for k in stage_ms
                         if k in sb and stage_ms[k] > 0}
@@ -498,6 +523,15 @@ def main():
             "workload": "BASELINE configs[1]: extract + all-pairs 1000x1000 Hamming vs next frame (u16 matrix written)",
             "frames_per_s": round(B * nbf / tbf, 1), "ms_per_step": round(tbf / nbf * 1e3, 4),
             "stage_ms_per_launch": {k: round(v, 4) for k, v in bms.items() if k != "offsets"},
+            "kernels": {"hamming": "k_hamming_mfma (int8 matrix-core dot products; vo_set_option(VO_OPT_HAMMING_KERNEL, 1) = the VALU form)",
+                        "blur": "k_blur_mfma (int8 matrix-core band products; VO_ORB_OPT_BLUR_KERNEL = 1: k_blur_groups)"},
+            "hamming_roofline": {"bound": "hbm (write stream)", "bytes_per_launch": 2064000 * B,
+                                 "achieved": round(2064000 * B / (bms["hamming"] * 1e-3) / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                 "frac": round(2064000 * B / (bms["hamming"] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                                 "valu_issue_frac": (round(vc["valu_per_1024_frames"]["hamming"] * (B / 1024.0) * float(vc["cycles_per_valu"]) /
+                                                           (float(vc["simds"]) * float(vc["clock_GHz"]) * 1e9) / (bms["hamming"] * 1e-3), 4)
+                                                     if vc and vc["valu_per_1024_frames"].get("hamming") else None),
+                                 "note": "a linear fill of the same 2.05 GB takes 0.36-0.38 ms on this chip (tools/microbench/write_pattern.hip)"},
             "survey_8d_bytes_per_frame": sb8,
             "end_to_end_algorithmic_GBps_per_gpu": round(sb8 * B * nbf / tbf / 1e9, 1),
             "frac_of_hbm_peak": round(sb8 * B * nbf / tbf / 1e9 / HBM_PEAK_GBS, 4),
@@ -749,12 +783,22 @@ def main():
 
             keep = vo.BundleAdjuster(lb)
             keep.local_ba()
+            # (b) as the C++ shim calls it: the three C entry points on arguments marshalled ONCE -- a ctypes call builds a dozen
+            # pointer objects and numpy allocates the result arrays per call, ~0.03 ms that no C++ caller pays
+            L_ = vo.lib()
+            a_ = {k_: np.ascontiguousarray(v_) for k_, v_ in lb.items() if isinstance(v_, np.ndarray)}
+            rargs_ = (keep._h, len(lb["poses"]), vo._p(a_["poses"]), vo._p(a_["fixed"]), len(lb["points"]), vo._p(a_["points"]),
+                      len(lb["e_cam"]), vo._p(a_["e_cam"]), vo._p(a_["e_pt"]), vo._p(a_["e_obs"]), vo._p(a_["e_inv_sigma"]), vo._p(a_["cam"]))
+            erase_ = np.zeros(len(lb["e_cam"]), np.uint8)
+            sums_ = (vo.LmSummary * 2)()
+            po_, px_ = np.zeros((len(lb["poses"]), 6)), np.zeros((len(lb["points"]), 3))
+            largs_ = (keep._h, None, vo._p(erase_), ctypes.byref(sums_))
+            gargs_ = (keep._h, vo._p(po_), vo._p(px_))
 
             def _e2e_reuse():
-                keep.reset(lb)
-                _, s_, _ = keep.local_ba()
-                keep.state()
-                return s_[0].iterations + s_[1].iterations
+                if L_.vo_ba_reset(*rargs_) != 0 or L_.vo_ba_local_ba(*largs_) != 0 or L_.vo_ba_get_state(*gargs_) != 0:
+                    raise RuntimeError(L_.vo_last_error())
+                return sums_[0].iterations + sums_[1].iterations
 
             e2e = {}
             for name, fn in (("create_destroy_per_call", _e2e_fresh), ("one_handle_reset_per_call", _e2e_reuse)):
@@ -769,7 +813,10 @@ def main():
                              "x_solve_only": round(float(np.median(ts_)) / (tb / reps), 3)}
             keep.close()
             e2e["note"] = ("from host arrays to the written-back state, median of 30; the shim of Optimizer::solveLocalBAPoseAndPoint keeps one "
-                           "handle per thread and calls vo_ba_reset (no hipMalloc / hipFree / stream creation per key-frame)")
+                           "handle per thread and calls vo_ba_reset (no hipMalloc / hipFree / stream creation per key-frame); "
+                           "one_handle_reset_per_call = vo_ba_reset + vo_ba_local_ba + vo_ba_get_state through the C-ABI on arguments "
+                           "marshalled once (what the C++ shim does), create_destroy_per_call through the Python wrapper")
+            assert np.isfinite(po_).all() and sums_[0].iterations > 0
             out["local_ba"]["end_to_end"] = e2e
             # aggregate throughput: independent problems (one handle + stream each) overlapped on the GPU
             nconc = 8

@@ -37,20 +37,35 @@ def run():
     ba.local_ba()
     st = np.zeros(64, np.uint64)
     L.vo_ba_debug_stamps(ba._h, st.ctypes.data_as(C.c_void_p))
+    # the eight phase stamps of k_ba_solve and the two kernel-entry stamps are REQUIRED: an unwritten one (0) means the stamp
+    # build and this script have drifted apart -- fail loudly instead of printing differences against zero (VERDICT r5 #4:
+    # round 5's committed file carried -3.1e10 us in five places)
+    required = list(range(8)) + [16, 36]
+    missing = [i for i in required if int(st[i]) == 0]
+    if missing:
+        raise SystemExit(f"ba_stamps: stamp slot(s) {missing} were not written by this build -- refusing to report")
     d = np.diff(st[:8].astype(np.int64)) / 100.0  # s_memrealtime ticks at 100 MHz -> us
-    rel = lambda i: (int(st[i]) - int(st[16])) / 100.0
-    print("gemm block 0 (us from its entry): hinv table %.2f, MFMA loop done %.2f, end %.2f; solve kernel starts at %.2f"
-          % (rel(17), rel(18), rel(20), rel(0)))
-    print("  gemm, latest over all tile blocks (us from block 0 entry): MFMA loop done %.2f, last-arriver ticket %.2f, slab sums stored %.2f" % (rel(23), rel(22), rel(21)))
-    print("  camera role, latest block end %.2f; solve kernel end %.2f; backsub block 0 entry %.2f (all from gemm block 0 entry)" % (rel(35), rel(7), rel(36)))
-    print("  camera role, latest block start %.2f, latest wave edges done %.2f, latest block sum done %.2f" % (rel(42), rel(43), rel(44)))
-    print("  camera role, first block (us from gemm block 0 entry): start %.2f, edges done %.2f, block sum done %.2f" % (rel(32), rel(33), rel(34)))
-    rb = lambda i: (int(st[i]) - int(st[36])) / 100.0
-    print("  back-substitution kernel, block 0 (us from its entry): point steps %.2f, candidate linearised %.2f, block sums %.2f; last block: ticket %.2f, update done %.2f" % (rb(37), rb(38), rb(39), rb(40), rb(41)))
-    print("  shader clock during the solve: %.0f MHz" % ((int(st[31]) - int(st[30])) / ((int(st[7]) - int(st[0])) / 100.0)))
+
+    def rel(i, base=16):
+        return None if int(st[i]) == 0 else (int(st[i]) - int(st[base])) / 100.0
+
+    def f(v):
+        return "n/a" if v is None else "%.2f" % v
+
+    print("gemm block 0 entry = 0; solve kernel starts at %s us" % f(rel(0)))
+    print("  gemm, latest over all tile blocks (us from block 0 entry): MFMA loop done %s, last-arriver ticket %s, slab sums stored %s"
+          % (f(rel(23)), f(rel(22)), f(rel(21))))
+    print("  camera role, latest block end %s; solve kernel end %s; backsub block 0 entry %s (all from gemm block 0 entry)"
+          % (f(rel(35)), f(rel(7)), f(rel(36))))
+    print("  camera role, latest block start %s, latest wave edges done %s; first block: start %s, edges done %s"
+          % (f(rel(42)), f(rel(43)), f(rel(32)), f(rel(33))))
+    print("  back-substitution kernel, block 0 (us from its entry): point steps %s, candidate linearised %s, block sums %s; last block: "
+          "ticket %s, update done %s" % tuple(f(rel(i, 36)) for i in (37, 38, 39, 40, 41)))
+    if int(st[30]) and int(st[31]):
+        print("  shader clock during the solve: %.0f MHz" % ((int(st[31]) - int(st[30])) / ((int(st[7]) - int(st[0])) / 100.0)))
     print("  LDLt phases summed over the block columns (us): diag loads %.2f, ldl6 %.2f, panel %.2f, barriers %.2f, trailing %.2f" % tuple(int(st[48 + i]) / 100.0 for i in range(5)))
-    print("  G prefetch +%.2f, pose prefetch +%.2f" % ((int(st[10]) - int(st[0])) / 100.0, (int(st[11]) - int(st[0])) / 100.0))
-    print(f"  prefetch drained at +{(int(st[8]) - int(st[0])) / 100.0:.2f} us, slab sums done at +{(int(st[9]) - int(st[0])) / 100.0:.2f} us")
+    print("  G prefetch +%s, pose prefetch +%s; prefetch drained at +%s us, slab sums done at +%s us"
+          % tuple(f(rel(i, 0)) for i in (10, 11, 8, 9)))
     names = ["slab sums+scale", "assemble+gmax", "LDLt", "back-subst", "dots", "cand poses", "block_sum"]
     for nm, v in zip(names, d):
         print(f"{nm:18s} {v:8.2f} us")

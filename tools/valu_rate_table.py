@@ -22,7 +22,7 @@ if len(sys.argv) > 3:
     import json
     st = json.loads(open(sys.argv[3]).read().strip().splitlines()[-1])["one_batch_in_flight"]["stage_ms_per_launch"]
     # stage -> (kernel, launches per stage)
-    for stage, (k, n) in {"pyramid": ("k_resize4", 7), "fast": ("k_fast_cell", 1), "octree": ("k_octree", 1), "blur": ("k_blur_groups", 1),
+    for stage, (k, n) in {"pyramid": ("k_resize4", 7), "fast": ("k_fast_cell", 1), "octree": ("k_octree", 1), "blur": ("k_blur_mfma", 1),
                           "describe": ("k_describe", 1)}.items():
         alone[k] = st[stage] * 1e-3 / n
 CLK, SIMDS = 2.38e9, 1024

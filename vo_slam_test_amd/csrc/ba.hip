@@ -2871,6 +2871,7 @@ struct vo_ba {
   vo::PinnedBuf pin;  // page-locked landing block of vo_ba_local_ba_finish (results of a solve)
   vo::PinnedBuf up_pin;   // page-locked staging of build_device's uploads: ONE block ...
   size_t up_used = 0;
+  size_t pre_copied = 0;  // bytes at the start of the staging block whose copy to the device ba_fill_problem has already enqueued
   vo::DevBuf b_up_arena;  // ... mirrored by ONE device block: the uploaded buffers are views into it, one copy per build
   vo::DevBuf b_zero_arena;  // the buffers a build starts at zero, views into one block: one memset per build
   size_t zero_used = 0;
@@ -2985,7 +2986,9 @@ int build_device(vo_ba *h) {
   if (h->built) return VO_OK;
   BaDev &D = h->D;
   // staging for every upload of this build (never moved while copies are in flight: reserved once, before the first)
-  VO_HIP_CHECK(hipStreamSynchronize(h->stream));  // (a previous build's copies out of the block have landed)
+  // (a previous build's copies out of the block have landed -- unless ba_fill_problem has just synchronised, filled the edge
+  //  arrays and started THEIR copy, which this build neither touches nor has to wait for)
+  if (!h->pre_copied) VO_HIP_CHECK(hipStreamSynchronize(h->stream));
   VO_CHECK(h->up_pin.reserve(up_pin_bytes(h->n_edges, h->n_pts, h->n_cams)));  // (no-op when ba_fill_problem placed the edge arrays)
   h->up_used = 0;
   D.n_cams = h->n_cams, D.n_pts = h->n_pts, D.n_edges = h->n_edges, D.nf = h->nf;
@@ -3003,6 +3006,7 @@ int build_device(vo_ba *h) {
   // from the page-locked staging, the zero-initialised ones views into another cleared by one memset -- fourteen copies and
   // nine memsets otherwise, each a dependent ~3-5 us step in front of the first LM kernel
   h->arenas = !D.large;
+  if (!h->arenas) h->pre_copied = 0;
   h->zero_used = 0;
   if (h->arenas) {
     VO_CHECK(reserve_grow(h->b_up_arena, h->up_pin.bytes));
@@ -3304,7 +3308,10 @@ int build_device(vo_ba *h) {
   D.div_np1 = (unsigned)((0x100000000ull + (unsigned)(6 * h->nf)) / (unsigned)(6 * h->nf + 1));
   D.dbg = h->b_dbg.as<unsigned long long>();
   if (h->arenas) {  // everything this build uploads: one copy; everything that starts at zero: one memset
-    if (h->up_used) VO_HIP_CHECK(hipMemcpyAsync(h->b_up_arena.p, h->up_pin.p, h->up_used, hipMemcpyHostToDevice, h->stream));
+    const size_t done = std::min(h->pre_copied, h->up_used);  // the edge arrays are already on their way (ba_fill_problem)
+    if (h->up_used > done)
+      VO_HIP_CHECK(hipMemcpyAsync(static_cast<uint8_t *>(h->b_up_arena.p) + done, h->up_pin.data() + done, h->up_used - done,
+                                  hipMemcpyHostToDevice, h->stream));
     if (h->zero_used) VO_HIP_CHECK(hipMemsetAsync(h->b_zero_arena.p, 0, h->zero_used, h->stream));
   }
   D.e_cam = h->b_ecam.as<int>(), D.e_pt = h->b_ept.as<int>();
@@ -3782,7 +3789,10 @@ static int ba_fill_problem(vo_ba *h, int n_cams, const double *poses, const uint
     }
   h->perm.resize(n_edges);
   bool placed = false;
-  if (6 * h->nf + 1 <= kMaxN && n_edges > 0 && h->up_pin.reserve(up_pin_bytes(n_edges, n_points, n_cams)) == VO_OK) {
+  h->pre_copied = 0;
+  size_t edge_bytes = 0;
+  if (6 * h->nf + 1 <= kMaxN && n_edges > 0 && h->stream && h->up_pin.reserve(up_pin_bytes(n_edges, n_points, n_cams)) == VO_OK &&
+      reserve_grow(h->b_up_arena, h->up_pin.bytes) == VO_OK) {
     // the staging offsets of build_device's uploads of e_cam, e_pt, e_obs, e_is (in that order, from offset 0)
     auto al = [](size_t v) { return (v + 255) & ~(size_t)255; };
     const size_t o0 = 0, o1 = al(o0 + std::max<size_t>((size_t)n_edges * 4, 64)), o2 = al(o1 + std::max<size_t>((size_t)n_edges * 4, 64)),
@@ -3792,6 +3802,7 @@ static int ba_fill_problem(vo_ba *h, int n_cams, const double *poses, const uint
       h->e_cam.bind(reinterpret_cast<int *>(pb + o0), n_edges), h->e_pt.bind(reinterpret_cast<int *>(pb + o1), n_edges);
       h->e_obs.bind(reinterpret_cast<double *>(pb + o2), 3 * (size_t)n_edges), h->e_is.bind(reinterpret_cast<double *>(pb + o3), n_edges);
       placed = true;
+      edge_bytes = o3 + (size_t)n_edges * 8;
     }
   }
   if (!placed) h->e_cam.resize(n_edges), h->e_pt.resize(n_edges), h->e_obs.resize(3 * (size_t)n_edges), h->e_is.resize(n_edges);
@@ -3817,6 +3828,11 @@ static int ba_fill_problem(vo_ba *h, int n_cams, const double *poses, const uint
     const int sl = slot[pc];
     cc[sl < 0 ? h->nf : sl]++;
   }
+  // The edge arrays (1.1 of the 1.4 MB a config-3 build uploads) start their trip now: the copy runs while build_device does
+  // the rest of the host work (camera lists, small tables) instead of behind it.
+  if (placed && edge_bytes > 0 &&
+      hipMemcpyAsync(h->b_up_arena.p, h->up_pin.p, edge_bytes, hipMemcpyHostToDevice, h->stream) == hipSuccess)
+    h->pre_copied = edge_bytes;
   return VO_OK;
 }
 
@@ -3830,18 +3846,17 @@ int vo_ba_create(vo_ba **out, int n_cams, const double *poses, const uint8_t *ca
   VO_CHECK(ba_check_args(n_cams, poses, cam_fixed, n_points, points, n_edges, edge_cam, edge_point, edge_obs, edge_inv_sigma, cam, "vo_ba_create"));
   VO_CHECK(vo::ensure_device());
   vo_ba *h = new vo_ba();
-  const int frc = ba_fill_problem(h, n_cams, poses, cam_fixed, n_points, points, n_edges, edge_cam, edge_point, edge_obs, edge_inv_sigma, cam, "vo_ba_create");
-  if (frc != VO_OK) {
-    if (h->up_pin.p) (void)hipHostFree(h->up_pin.p);
-    delete h;
-    return frc;
-  }
   if (hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking) != hipSuccess) {
     delete h;
     vo::set_error("hipStreamCreate failed");
     return VO_ERR_HIP;
   }
   h->own_stream = true;
+  const int frc = ba_fill_problem(h, n_cams, poses, cam_fixed, n_points, points, n_edges, edge_cam, edge_point, edge_obs, edge_inv_sigma, cam, "vo_ba_create");
+  if (frc != VO_OK) {
+    vo_ba_destroy(h);
+    return frc;
+  }
   *out = h;
   return VO_OK;
 }

@@ -1317,7 +1317,8 @@ __global__ __launch_bounds__(256) void k_blur_groups(FrameSrc src, int lv0_gener
 typedef int bm_i32x4 __attribute__((ext_vector_type(4)));
 typedef int bm_i32x16 __attribute__((ext_vector_type(16)));
 constexpr int kBmMinW = 64, kBmMinH = 16;  // smaller levels keep the other kernels
-constexpr int kBmSegRows = 160;            // output rows per job (5 tiles of 32; one extra row-pass tile per job)
+constexpr int kBmSegRows = 160;            // output rows per job (5 tiles of 32; one extra row-pass tile per job): 96 / 160 / 256 / 480
+                                           // rows measured 0.546 / 0.516 / 0.624 / 0.548 ms per 1024 frames (level 0 = three equal jobs)
 
 __device__ __forceinline__ unsigned bm_sat_pk(unsigned v) {
   unsigned r;
