@@ -301,3 +301,20 @@ def test_stage_hook_order_and_second_stream(vo, orc):
     assert [st for st, _ in seen] == [0, 1, 2, 4, 5], seen
     assert all(sp == s1.cuda_stream for _, sp in seen)
     assert np.array_equal(desc[1].cpu().numpy(), want_desc) and np.array_equal(dm[1].cpu().numpy(), want_dm)
+
+
+@pytest.mark.parametrize("w,h", [(642, 481), (641, 480), (672, 497), (99, 83), (65, 17), (1026, 770)])
+def test_blurred_planes_at_awkward_sizes(make_ext, orc, w, h):
+    """every level's blurred plane at widths that put the right image edge 1, 2, ... columns into the last 32-column strip of
+    k_blur_mfma (the strip before it then needs reflected columns too), at heights that are not multiples of the 32-row tiles or
+    of the 160-row jobs, at sizes just above its 64 x 16 minimum and below it (the other blur kernels), and at a width beyond
+    1024 -- against the oracle's blur of the oracle's pyramid, in all three extractor modes"""
+    nl = 8 if w >= 300 else 3
+    e = make_ext(300, 1.2, nl, 20, 7)
+    img = synth.make_frame(23, w=w, h=h, n_rect=max(20, w * h // 600), n_blob=max(5, w * h // 3000))
+    e(img)
+    p = orc.orb_params(nfeatures=300, nlevels=nl)
+    lev = orc.pyramid(p, img)
+    for l in range(nl):
+        assert np.array_equal(e.get_level(0, l), lev[l]), f"pyramid level {l} of {w} x {h}"
+        assert np.array_equal(e.get_level(0, l, blurred=True), orc.blur(lev[l])), f"blur level {l} of {w} x {h}"
