@@ -458,10 +458,23 @@ def main():
             lat.append(time.perf_counter() - tq)
         assert r1["n_inliers"][0] >= 100
         t1.close()
+        # the floor under a chain of dependent launches on this stack: 200 one-element kernels back to back on one stream
+        # (27 launches per tracked frame, most of them at this floor)
+        tiny = torch.zeros(64, device="cuda")
+        for _ in range(20):
+            tiny.add_(1.0)
+        torch.cuda.synchronize()
+        tq = time.perf_counter()
+        for _ in range(200):
+            tiny.add_(1.0)
+        torch.cuda.synchronize()
+        floor_us = (time.perf_counter() - tq) / 200 * 1e6
         out["single_stream"] = {"ms_per_frame": round(float(np.median(lat[5:])) * 1e3, 4),
                                 "frames_per_s": round(1.0 / float(np.median(lat[5:])), 1),
+                                "launches_per_frame": 27, "dependent_dispatch_floor_us": round(floor_us, 2),
                                 "note": "batch 1, host image + raw depth in, pose out, one C call + results (PCIe and "
-                                        "launch latency of 27 kernels included)"}
+                                        "launch latency of 27 kernels included; dependent_dispatch_floor_us = one trivial kernel "
+                                        "behind another on one stream, host-paired, the least any of the 27 can cost)"}
         h_all = np.ascontiguousarray(frames_np)
         h_dall = np.ascontiguousarray(np.stack([uniq_depth[i % n_unique] for i in range(B)])).view(np.uint16)
         ing = []
