@@ -15,6 +15,8 @@
 //                  rows) are both written in the last step
 //  10 seg256a2     256-byte windows on 128-byte boundaries, heads deferred to the last step
 //  11 seg128a2     128-byte windows on 128-byte boundaries (8 rows per instruction), heads deferred
+//  12 gridstride   the whole grid sweeps memory front to back, 16 bytes per thread per trip (a fill kernel)
+//  13 linear_nt    as 0 with non-temporal stores
 // Prints ms and TB/s per mode.   hipcc -O3 --offload-arch=gfx950 tools/microbench/write_pattern.hip -o /tmp/wp && /tmp/wp
 #include <hip/hip_runtime.h>
 #include <cstdio>
@@ -84,6 +86,13 @@ __global__ __launch_bounds__(256, 2) void k_write(unsigned char *D, unsigned val
       }
       __builtin_amdgcn_s_sleep(MODE == 10 ? 8 : 4);
     }
+  } else if (MODE == 12) {  // the whole grid sweeps memory front to back (what a fill kernel does)
+    const long long total = (long long)kPairs * kPairBytes, nthreads = (long long)gridDim.x * gridDim.z * 256;
+    const long long tid0 = ((long long)blockIdx.z * gridDim.x + blockIdx.x) * 256 + threadIdx.x;
+    for (long long o = tid0 * 16; o < total; o += nthreads * 16) *reinterpret_cast<u32x4 *>(D + o) = v;
+  } else if (MODE == 13) {  // as 0 with non-temporal stores
+    const long long lo = (long long)i0 * PITCH, hi = std::min<long long>((long long)(i0 + 128) * PITCH, kPairBytes);
+    for (long long o = lo + threadIdx.x * 16; o < hi; o += 4096) __builtin_nontemporal_store(v, reinterpret_cast<u32x4 *>(base + o));
   } else if (MODE == 8) {
     const int r0 = i0 + wave * 32;
     for (int c = 0; c < 5; c++) {
@@ -169,7 +178,7 @@ int main() {
   CK(hipMalloc(&D, kPairs * kPairBytes + 4096));
   printf("pitch %d\n", PITCH);
   run<0>("linear", D); run<1>("rows8", D); run<2>("seg256", D); run<3>("seg256a", D); run<4>("seg512a", D);
-  run<5>("rowblock32", D); run<6>("seg128a", D); run<7>("seg256b", D); run<8>("seg512b", D); run<9>("seg256b2", D); run<10>("seg256a2", D); run<11>("seg128a2", D);
+  run<5>("rowblock32", D); run<6>("seg128a", D); run<7>("seg256b", D); run<8>("seg512b", D); run<9>("seg256b2", D); run<10>("seg256a2", D); run<11>("seg128a2", D); run<12>("gridstride", D); run<13>("linear_nt", D);
   run<0>("linear", D);
   return 0;
 }

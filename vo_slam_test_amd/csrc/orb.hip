@@ -1419,7 +1419,9 @@ __attribute__((amdgpu_waves_per_eu(4, 4))) __global__ __launch_bounds__(256, 4) 
   row_pass(p0, p1, lo, hi);
   const int xt_ok = x0 + 16 * kg < Lpitch;
   for (int k = 0; k < n_vt; k++) {
-    // outstanding, in issue order: tile k + 1 (two DMAs), the previous iteration's store -> all but the youngest one
+    // outstanding, in issue order: tile k + 1 (two DMAs), the previous iteration's store -> all but the youngest one.  (Every
+    // iteration DOES issue its store: a job has ceil(rows / 32) tiles, so each tile holds a row below y_end, and the lanes of
+    // lane half 0 always own an existing tile column -- the count below relies on it.)
     if (k == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     else asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
     bm_i32x4 n0, n1;
