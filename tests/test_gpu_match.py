@@ -55,6 +55,25 @@ def test_hamming_batch_dev(vo, orc, ham_kernel):
         assert np.array_equal(got[p], orc.hamming_matrix(a[p], b[p]))
 
 
+def test_hamming_random_shapes(vo, ham_kernel):
+    """40 seeded random shapes (1 .. 1500 rows / columns: row blocks, column chunks and super-chunks of the matrix-core form
+    cut at every kind of remainder) against numpy, with descriptors of every density"""
+    rng = np.random.default_rng(2026)
+    for k in range(40):
+        na, nb = int(rng.integers(1, 1500)), int(rng.integers(1, 1500))
+        if k % 5 == 0:
+            nb = int(rng.integers(1, 180)) * 8   # the 16-byte store path
+        if k % 7 == 0:
+            nb = 1024 + int(rng.integers(1, 400))  # a second super-chunk of column tiles
+        da, db = rng.random((na, 1, 1)), rng.random((nb, 1, 1))
+        a = np.packbits(rng.random((na, 32, 8)) < da, axis=2).reshape(na, 32)
+        b = np.packbits(rng.random((nb, 32, 8)) < db, axis=2).reshape(nb, 32)
+        got = vo.hamming_matrix(a, b)
+        ca, cb = np.unpackbits(a, axis=1).astype(np.int32), np.unpackbits(b, axis=1).astype(np.int32)
+        want = ca.sum(1)[:, None] + cb.sum(1)[None, :] - 2 * (ca @ cb.T)
+        assert np.array_equal(got, want.astype(np.uint16)), (k, na, nb)
+
+
 def test_hamming_unaligned_views(vo, orc, ham_kernel):
     """descriptor arrays at 4-byte (not 16-byte) aligned addresses, an odd column count and a matrix at a 2-byte aligned
     address: the dword-load / u16-store paths of both kernels"""
