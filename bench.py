@@ -290,22 +290,37 @@ def main():
         assert not res["status"].any(), "every synthetic frame must be tracked (status 0)"
     # FAST candidates per frame: the mean over the batch's distinct frames (the byte counts of the FAST / oct-tree stages use it)
     ncand = float(np.mean([sum(len(exts[0].get_candidates(f, l)[0]) for l in range(8)) for f in range(n_unique)]))
-    # reference point: the same step with nothing overlapped (one batch in flight)
+    # reference point: the same step with nothing overlapped -- ONE batch in flight on ONE stream (a tracker of its own in
+    # single-stream mode when the timed region pipelines), its steps back to back with one synchronisation at the end.  (Until
+    # round 5 this leg synchronised the host after every batch: the clock drops in the idle gaps and every kernel read 5-10 %
+    # longer than in the kernel trace of the same launches -- FAST 0.72 against 0.655 ms; profiles/README.md, round 6.)
     barrier()
-    exts[0].set_timing(True)
-    trk.set_timing(True)
+    if n_pipe == 1:
+        trk_one = trk
+    else:
+        trk_one = vo.Tracker(B, cam5, synth.DIST, W, H, max_last=1100, max_local=2200, inv_depth_scale=inv_depth, single_stream=True)
+        load_maps(trk_one, all_maps, 1100, 2200)
+    ext_one = trk_one.extractor()
+    for _ in range(2):
+        trk_one.track_dev(frames, depth)
+    trk_one.sync()
+    ext_one.set_timing(True)
+    trk_one.set_timing(True)
+    n_serial = max(4, args.steps // 3)
     ts0 = time.perf_counter()
-    n_serial = max(3, args.steps // 4)
     for _ in range(n_serial):
-        step(only=trk)
-        trk.sync()
+        trk_one.track_dev(frames, depth)
+    trk_one.sync()
     serial_ms = (time.perf_counter() - ts0) / n_serial * 1e3
-    sm, nc = exts[0].get_timing()
-    exts[0].set_timing(False)
+    sm, nc = ext_one.get_timing()
+    ext_one.set_timing(False)
     serial_stage_ms = {k: v / max(nc, 1) for k, v in sm.items()}
-    tm, tc = trk.get_timing()
+    tm, tc = trk_one.get_timing()
+    trk_one.set_timing(False)
     for name in ("frame_post", "match_last_frame", "pose_only_1", "match_local_map", "pose_only_2"):
         serial_stage_ms[name] = tm[name] / max(tc, 1)
+    if trk_one is not trk:
+        trk_one.close()
     # timed region: instrumented as well (per-kernel HIP events on the launching stream; the un-instrumented extractor,
     # whose blur runs on a side stream, measured the same step time with two batches in flight: 4.74 ms either way)
     for e in exts:
@@ -429,7 +444,7 @@ def main():
                    "batches_in_flight": n_pipe},
         "one_batch_in_flight": {"ms_per_step": round(serial_ms, 4), "frames_per_s": round(B / serial_ms * 1e3, 1),
                                 "stage_ms_per_launch": {k: round(v, 4) for k, v in serial_stage_ms.items()},
-                                "note": "the same step with a host synchronisation after every batch (nothing overlapped); "
+                                "note": "the same step on ONE stream, batches back to back, one synchronisation at the end (nothing overlapped); "
                                         "stage_ms_per_launch at the top level is measured inside the timed region, i.e. with the "
                                         "other batch's kernels running next to each launch when batches_in_flight > 1"},
         "roofline": roofline,
