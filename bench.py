@@ -261,6 +261,8 @@ def main():
             for _ in range(n_pipe)]
     trk = trks[0]
     exts = [t.extractor() for t in trks]
+    if os.environ.get("VO_BENCH_POSE_BLOCK"):   # developer A/B: threads per frame of the pose-only solver (0 auto, 64, 128, 256)
+        vo.set_option("pose_block", int(os.environ["VO_BENCH_POSE_BLOCK"]))
     if os.environ.get("VO_BENCH_BLUR"):   # developer A/B: 1 = the VALU blur in the trackers' extractors
         for e in exts:
             e.set_blur_kernel(int(os.environ["VO_BENCH_BLUR"]))
