@@ -263,6 +263,10 @@ def main():
     exts = [t.extractor() for t in trks]
     if os.environ.get("VO_BENCH_POSE_BLOCK"):   # developer A/B: threads per frame of the pose-only solver (0 auto, 64, 128, 256)
         vo.set_option("pose_block", int(os.environ["VO_BENCH_POSE_BLOCK"]))
+    if os.environ.get("VO_BENCH_DESCBLUR"):   # developer A/B: 1 = blurred planes instead of the descriptor kernel's own window blur
+        for e in exts:
+            e.set_describe_blur(int(os.environ["VO_BENCH_DESCBLUR"]))
+        ext.set_describe_blur(int(os.environ["VO_BENCH_DESCBLUR"]))
     if os.environ.get("VO_BENCH_BLUR"):   # developer A/B: 1 = the VALU blur in the trackers' extractors
         for e in exts:
             e.set_blur_kernel(int(os.environ["VO_BENCH_BLUR"]))

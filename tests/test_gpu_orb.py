@@ -7,13 +7,15 @@ from vo_slam_test_amd import synth
 pytestmark = pytest.mark.gpu
 
 
-MODES = ["separate", "separate-valu-blur", "fused"]
+MODES = ["on-demand-blur", "separate", "separate-valu-blur", "fused"]
 
 
 def _set_mode(e, mode):
-    """the forms of the level pipeline: the three separate kernels with the blur on the matrix cores (the default), the same with
-    the VALU blur (VO_ORB_OPT_BLUR_KERNEL = 1), and the opt-in fused per-level pass (VO_ORB_OPT_FUSED_LEVEL_PASS)"""
+    """the forms of the level pipeline: no blurred planes at all -- the descriptor kernel blurs the windows it reads (the default,
+    VO_ORB_OPT_DESCRIBE_BLUR = 0) --, blurred planes by the matrix-core kernel, the same with the VALU blur
+    (VO_ORB_OPT_BLUR_KERNEL = 1), and the opt-in fused per-level pass (VO_ORB_OPT_FUSED_LEVEL_PASS)"""
     e.set_fused(int(mode == "fused"))
+    e.set_describe_blur(0 if mode == "on-demand-blur" else 1)
     e.set_blur_kernel(1 if mode == "separate-valu-blur" else 0)
 
 

@@ -2,7 +2,7 @@
 for every combination of the process-wide / per-handle options named on the command line, interleaved and repeated so that
 clock drift and box-to-box differences cancel.  Prints ms per step (uninstrumented = the library's default launch order; and the
 instrumented per-stage times) and the share of the 8 TB/s HBM peak that the SURVEY 8d bytes (7 187 128 per frame) make.
-usage: [VO_HIP_LIB=...] python tools/ebm_probe.py [ham=0,1] [blur=0,1] [reps=3] [stages=1]"""
+usage: [VO_HIP_LIB=...] python tools/ebm_probe.py [ham=0,1] [blur=0,1] [db=0,1] [reps=3] [stages=1]"""
 import pathlib, sys, time
 sys.path.insert(0, str(pathlib.Path(__file__).resolve().parent.parent))
 import numpy as np, torch  # noqa: E402
@@ -11,6 +11,7 @@ from vo_slam_test_amd import _lib as vo, synth  # noqa: E402
 kw = dict(a.split("=") for a in sys.argv[1:])
 hams = [int(x) for x in kw.get("ham", "0,1").split(",")]
 blurs = [int(x) for x in kw.get("blur", "0").split(",")]
+dbs = [int(x) for x in kw.get("db", "0").split(",")]  # VO_ORB_OPT_DESCRIBE_BLUR: 0 on demand, 1 blurred planes
 reps = int(kw.get("reps", "3"))
 B, NM = 1024, 1000
 stream = torch.cuda.Stream()
@@ -51,12 +52,13 @@ def timed(n=10):
 
 SB8 = 5123128 + 2064000
 for rep in range(reps):
-    for ham, blur in [(a, b) for a in hams for b in blurs]:
+    for ham, blur, db in [(a, b, c) for a in hams for b in blurs for c in dbs]:
         vo.set_option("hamming_kernel", ham)
         ext.set_blur_kernel(blur)
+        ext.set_describe_blur(db)
         ext.set_timing(False)
         t, th = timed()
-        line = f"ham={ham} blur={blur}: default order {t:.3f} ms = {SB8 * B / t / 1e6 / 8000 * 100:.1f} % of HBM peak (hamming in it {th:.3f})"
+        line = f"ham={ham} blur={blur} db={db}: default order {t:.3f} ms = {SB8 * B / t / 1e6 / 8000 * 100:.1f} % of HBM peak (hamming in it {th:.3f})"
         if kw.get("stages", "1") == "1":
             ext.set_timing(True)
             ti, thi = timed()

@@ -12,6 +12,8 @@ ext = vo.OrbExtractor(1000, 1.2, 8, 20, 7)
 ext.set_stream(stream.cuda_stream)
 if hasattr(ext, 'set_fused'):
     ext.set_fused(int(os.environ.get('VO_EXT_FUSED', '0')))  # 0: the three separate kernels per level
+if hasattr(ext, 'set_describe_blur'):
+    ext.set_describe_blur(int(os.environ.get('VO_EXT_DESCBLUR', '0')))  # 0: the descriptor kernel blurs its windows itself
 cap = ext.max_keypoints()
 with torch.cuda.stream(stream):
     frames = torch.from_numpy(synth.make_frames(32)).cuda().repeat(B // 32, 1, 1).contiguous()

@@ -197,6 +197,10 @@ class OrbExtractor:
         self._hook = HOOK(lambda stage, stream, user: fn(stage, stream))  # (kept alive with the handle)
         check(lib().vo_orb_set_stage_hook(self._h, self._hook, None), "vo_orb_set_stage_hook")
 
+    def set_describe_blur(self, kind: int):
+        """vo_orb_set_option(VO_ORB_OPT_DESCRIBE_BLUR): 0 = the descriptor kernel blurs its windows itself (default), 1 = blurred planes"""
+        check(lib().vo_orb_set_option(self._h, 4, int(kind)), "vo_orb_set_option")
+
     def set_blur_kernel(self, kind: int):
         """vo_orb_set_option(VO_ORB_OPT_BLUR_KERNEL): 0 = int8 matrix-core products (default), 1 = the VALU form"""
         check(lib().vo_orb_set_option(self._h, 3, int(kind)), "vo_orb_set_option")

@@ -1528,6 +1528,7 @@ struct DescRec {
   int m10, m01;                  // intensity-centroid moments
   float a, b;                    // cos, sin of the steering angle
   int bytewise, pad;             // level-0 rows of the caller's image are not 16-byte aligned
+  int wh, pad2;                  // on-demand blur (OD): level width | height << 16; blur_base = the level plane, bpitch = its bytes
 };
 
 // LDS values every lane reads from the same address, moved to scalar registers
@@ -1553,7 +1554,10 @@ typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 // all 32 banks instead of 16 -- against VERDICT r3's reading of the 48 % bank-conflict cycles: 0.746 / 0.747 / 0.749 ms per
 // 1024 frames for 64 / 80 / 96, i.e. no effect: the LDS pipe is not what the kernel waits for, its window fetches are.)
 constexpr int kWinPitch = 64;
-constexpr int kWinBytes = 40 * 64;  // 39 rows, rounded up to a multiple of 4 lanes x 16 bytes
+constexpr int kOdPitch = 80;         // on-demand blur: row pitch of the staged raw window and of the blurred window written over it
+                                     // (20 dwords: 16 rows at this pitch start in 16 different banks; at 64 bytes every fourth row
+                                     // shared its banks with the operand reads and the blurred stores 8-way)
+constexpr int kWinBytes = 48 * kOdPitch;  // 39 rows at 64 bytes (blurred planes) / 45 + 3 rows at kOdPitch (on-demand blur)
 
 // Stage the ROWS x (<= 64 - 15) byte window whose top-left pixel is `origin` (row pitch `pitch`, rows 16-byte
 // aligned) into LDS with 16-byte loads: lane + 64 j -> row (lane >> 2) + 16 j, chunk lane & 3, so the LDS
@@ -1620,11 +1624,25 @@ constexpr int kDescNK = 2;  // key-points in flight per wavefront of k_describe 
 //     scatter over it); lane t rotates the pattern points of tests t, t+64, t+128, t+192 (packed FP32
 //     multiplies and adds, rounding by the 1.5 * 2^23 constant so that the integer falls out of the mantissa
 //     and feeds the address arithmetic), eight LDS byte gathers, four 64-bit ballots are the descriptor.
-template <int NK>  // key-points a wave keeps in flight in phases 1 and 3
-__global__ __launch_bounds__(256) void k_describe(OrbDev P, FrameSrc src, const uint32_t *sel,
+// OD ("on demand", round 6): the blurred planes are never made.  Phase 3 stages the 45 x 45 RAW window around the key-point
+// (buffer loads with hardware range checking at the exact origin px - 22: byte-aligned 16-byte loads are legal on gfx950,
+// tools/microbench/unaligned_load.hip) and blurs it in place into the 39 x 39 window the tests read, with the int8
+// matrix-core scheme of k_blur_mfma on v_mfma_i32_16x16x64_i8: row pass = 3 x 3 products (16 rows x 64 source columns against
+// the band of 16 output columns; the accumulator -- column on the lane, four rows per 16-row tile in its registers -- is the
+// A operand of the column pass as it stands: K slot 4 T + r of lane quarter q = row 16 T + 4 q + r), column pass = 3 x 3 x 2
+// byte planes; all constants ride in spare K slots (two bytes 0x81 per staged row against weight 64 give the +128 of the row
+// pass; the fourth dword of the column pass's A operand is a per-lane constant against weights 16 / 127: +128 on the low
+// plane, +33152 on the high one = the three offsets and the rounding), so no accumulator is ever initialised.  BORDER_REFLECT_101:
+// rows by address, columns by a byte fix-up of the staged rows (key-points within 22 px of the left / right edge only).
+// The blur of a whole pyramid (1.9 GB of traffic, 0.51 ms per 1024 frames) becomes ~1.5 M blurred pixels per frame computed
+// where they are read.
+template <int NK, bool OD>  // key-points a wave keeps in flight in phases 1 and 3; on-demand blur
+// (4 waves per SIMD declared: the register budget <= 256 keeps the MFMA results in VGPRs; at the default they land in AGPRs and
+//  every result register costs a v_accvgpr_read -- 108 per key-point)
+__global__ __launch_bounds__(256, 4) void k_describe(OrbDev P, FrameSrc src, const uint32_t *sel,
                                                   int sel_per_frame, const int *nk, int *counts, int capacity,
                                                   vo_keypoint *kps, uint8_t *desc, int lv0_bytewise,
-                                                  int batches_per_frame, int n_frames, int *err_flag) {
+                                                  int batches_per_frame, int n_frames, int *err_flag, const int *od_tab) {
   __shared__ DescRec rec[64];
   __shared__ __attribute__((aligned(16))) uint8_t win_lds[4][NK][kWinBytes];
   const int tid = threadIdx.x, lane = tid & 63;
@@ -1675,6 +1693,11 @@ __global__ __launch_bounds__(256) void k_describe(OrbDev P, FrameSrc src, const 
     r.blur_base = (unsigned long long)(uintptr_t)bl;  // the plane; the window's origin (px - 19, py - 19) rides in `pad`
     r.pad = (px - kEdge) | ((py - kEdge) << 16);
     r.pitch = pitch, r.bpitch = bp;
+    r.wh = L.w | (L.h << 16), r.pad2 = 0;
+    if (OD) {  // the raw level plane of this frame and its size in bytes (the range the buffer loads check)
+      r.blur_base = (unsigned long long)(uintptr_t)img;
+      r.bpitch = L.h * pitch;
+    }
     r.m10 = r.m01 = 0;
     r.a = r.b = 0.f;
     r.bytewise = l == 0 && lv0_bytewise;
@@ -1762,7 +1785,141 @@ __global__ __launch_bounds__(256) void k_describe(OrbDev P, FrameSrc src, const 
   __syncthreads();
   // ---- phase 3: descriptors
   constexpr float kMagic = 12582912.f;  // 1.5 * 2^23: x + kMagic has rint(x) + 0x400000 in its low 24 bits
-  for (int k = k0; k < k1; k += NK) {
+  // the band operands of the on-demand blur (per-lane constants: 6 x 4 registers + 2) from the table built with the handle
+  typedef int od_i32x4 __attribute__((ext_vector_type(4)));
+  od_i32x4 Bh[3], Bv[3];
+  int A3lo = 0, A3hi = 0;
+  if (OD) {
+    const od_i32x4 *tb = reinterpret_cast<const od_i32x4 *>(od_tab);
+#pragma unroll
+    for (int X = 0; X < 3; X++) Bh[X] = tb[64 * X + lane], Bv[X] = tb[64 * (3 + X) + lane];
+    const int kq = lane >> 4;
+    A3lo = kq < 2 ? 0x01010101 : 0;           // 8 slots x 1 x 16 = 128
+    A3hi = kq < 2 ? 0x05050505 : 0x20202020;  // 8 x 5 x 16 + 8 x 32 x 127 = 33152 = (257 * 128 * 257 + 2^15 - 128) / 256
+    // columns 48..63 of every staged row are never loaded: bytes 0x80 (= 0 after the operand's xor), the last two 0x81 (= +1:
+    // against weights 64 + 64 they add the row pass's 128).  Written once per wavefront for its NK slots (phase 1 used the same
+    // memory at another pitch); neither a stage nor a blurred window touches them afterwards.
+    const u32x4 cst = {0x80808080u, 0x80808080u, 0x80808080u, 0x81818080u};
+    if (lane < 48) {
+#pragma unroll
+      for (int s = 0; s < NK; s++) *(__attribute__((address_space(3))) u32x4 *)((lds_u8 *)win_lds[wave][s] + kOdPitch * lane + 48) = cst;
+    }
+    wave_sync();
+  }
+  for (int k = k0; OD && k < k1; k += NK) {
+    u32x4 wv[NK][3];
+    int pxs[NK], pys[NK], wls[NK];
+#pragma unroll
+    for (int s = 0; s < NK; s++) {
+      const int kk = min(k + s, k1 - 1);
+      const int xy0 = uni_i32(rec[kk].pad), wh = uni_i32(rec[kk].wh), pitch = uni_i32(rec[kk].pitch);
+      const int px = (xy0 & 0xffff) + kEdge, py = (xy0 >> 16) + kEdge, Lh = wh >> 16;
+      pxs[s] = px, pys[s] = py, wls[s] = wh & 0xffff;
+      const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void *)uni_ptr(rec[kk].blur_base), 0, uni_i32(rec[kk].bpitch), 0x00020000);
+#pragma unroll
+      for (int j = 0; j < 3; j++) {
+        const int idx = lane + 64 * j, row = min(idx / 3, 44), chunk = idx % 3;
+        const int y = reflect101_near(py - 22 + row, Lh);
+        // (an offset in front of the plane is a huge unsigned one: the range check returns zeros, as it does behind the plane)
+        wv[s][j] = __builtin_amdgcn_raw_buffer_load_b128(rs, y * pitch + (px - 22) + 16 * chunk, 0, 0);
+      }
+    }
+#pragma unroll
+    for (int s = 0; s < NK; s++)
+#pragma unroll
+      for (int j = 0; j < 3; j++) {
+        const int idx = lane + 64 * j, row = idx / 3, chunk = idx % 3;
+        if (row < 48) *(__attribute__((address_space(3))) u32x4 *)((lds_u8 *)win_lds[wave][s] + kOdPitch * row + 16 * chunk) = wv[s][j];
+      }
+    wave_sync();
+    uint32_t t[NK][8];
+#pragma unroll
+    for (int s = 0; s < NK; s++) {
+      lds_u8 *R = (lds_u8 *)win_lds[wave][s];
+      const int px = pxs[s], Lw = wls[s];
+      if (px < 22 || px + 22 > Lw - 1) {  // uniform: BORDER_REFLECT_101 of the columns beyond the plane (at most six a side)
+        if (px < 22 && pys[s] <= 22) {
+          // a window over the plane's first pixel: the first chunk of raw row 0 starts in front of the plane, and the range check
+          // drops the WHOLE 16-byte load, its in-plane bytes included -- they are fetched one by one (staged row 22 - py)
+          const int kk = min(k + s, k1 - 1);
+          const __amdgpu_buffer_rsrc_t rs0 = __builtin_amdgcn_make_buffer_rsrc((void *)uni_ptr(rec[kk].blur_base), 0, uni_i32(rec[kk].bpitch), 0x00020000);
+          if (lane >= 22 - px && lane < 16) R[kOdPitch * (22 - pys[s]) + lane] = __builtin_amdgcn_raw_buffer_load_b8(rs0, lane - (22 - px), 0, 0);
+          wave_sync();
+        }
+        if (lane < 48) {
+          for (int c = 0; c < 22 - px; c++) R[kOdPitch * lane + c] = R[kOdPitch * lane + 2 * (22 - px) - c];
+          for (int c = Lw - (px - 22); c < 45; c++) R[kOdPitch * lane + c] = R[kOdPitch * lane + 2 * (Lw - 1 - (px - 22)) - c];
+        }
+        wave_sync();
+      }
+      // row pass: A = 16 staged rows x 64 columns (the lane's quarter: 16 bytes), xor 0x80 = pixel - 128
+      const int m = lane & 15, kq = lane >> 4;
+      od_i32x4 a[3];
+#pragma unroll
+      for (int T = 0; T < 3; T++) {
+        const u32x4 v = *(const __attribute__((address_space(3))) u32x4 *)(R + kOdPitch * (16 * T + m) + 16 * kq);
+        a[T] = od_i32x4{(int)(v.x ^ 0x80808080u), (int)(v.y ^ 0x80808080u), (int)(v.z ^ 0x80808080u), (int)(v.w ^ 0x80808080u)};
+      }
+      wave_sync();  // (every lane has its rows: the blurred window may now overwrite the stage)
+      const od_i32x4 Z = {0, 0, 0, 0};
+#pragma unroll
+      for (int X = 0; X < 3; X++) {
+        od_i32x4 lo, hi;
+#pragma unroll
+        for (int T = 0; T < 3; T++) {
+          const od_i32x4 acc = __builtin_amdgcn_mfma_i32_16x16x64_i8(a[T], Bh[X], Z, 0, 0, 0);  // row sums - 2^15, rows 16 T + 4 q + r
+          const unsigned t01 = __builtin_amdgcn_perm((unsigned)acc[1], (unsigned)acc[0], 0x05010400u);
+          const unsigned t23 = __builtin_amdgcn_perm((unsigned)acc[3], (unsigned)acc[2], 0x05010400u);
+          lo[T] = (int)(__builtin_amdgcn_perm(t23, t01, 0x05040100u) ^ 0x80808080u);
+          hi[T] = (int)__builtin_amdgcn_perm(t23, t01, 0x07060302u);
+        }
+        lo[3] = A3lo, hi[3] = A3hi;
+#pragma unroll
+        for (int Y = 0; Y < 3; Y++) {
+          const od_i32x4 al = __builtin_amdgcn_mfma_i32_16x16x64_i8(lo, Bv[Y], Z, 0, 0, 0);
+          const od_i32x4 ah = __builtin_amdgcn_mfma_i32_16x16x64_i8(hi, Bv[Y], Z, 0, 0, 0);
+          unsigned v[4];
+#pragma unroll
+          for (int j = 0; j < 4; j++) v[j] = ((unsigned)ah[j] << 8) + (unsigned)al[j];
+          const unsigned s01 = bm_sat_pk(__builtin_amdgcn_perm(v[1], v[0], 0x07060302u));
+          const unsigned s23 = bm_sat_pk(__builtin_amdgcn_perm(v[3], v[2], 0x07060302u));
+          // lane (row 16 Y + m, quarter kq): blurred columns 16 X + 4 kq .. + 3 of that row
+          *(__attribute__((address_space(3))) unsigned *)(R + kOdPitch * (16 * Y + m) + 16 * X + 4 * kq) = s01 | (s23 << 16);
+        }
+      }
+    }
+    wave_sync();
+#pragma unroll
+    for (int s = 0; s < NK; s++) {
+      const int kk = min(k + s, k1 - 1);
+      const float a = uni_f32(rec[kk].a), b = uni_f32(rec[kk].b);
+      // (r + 19) * 80 + (q + 19) from the raw bit patterns: v_mad_u32_u24 takes the low 24 bits of rint(x)'s pattern, 0x400000 + r
+      const unsigned fold = (unsigned)(kEdge * kOdPitch + kEdge) - (0x400000u * (unsigned)kOdPitch + 0x4B400000u);
+      const lds_u8 *wl = (const lds_u8 *)win_lds[wave][s];
+      const v2f ba = {b, a}, anb = {a, -b}, mg = {kMagic, kMagic};
+#pragma unroll
+      for (int w = 0; w < 4; w++)
+#pragma unroll
+        for (int e = 0; e < 2; e++) {
+          const int c = 18 + 4 * w + 2 * e;
+          const float x = __uint_as_float(tab[c >> 2][c & 3]), y = __uint_as_float(tab[(c + 1) >> 2][(c + 1) & 3]);
+          const v2f xx = {x, x}, yy = {y, y};
+          const v2f rq = (xx * ba + yy * anb) + mg;
+          const unsigned o = __umul24(__float_as_uint(rq.x), (unsigned)kOdPitch) + __float_as_uint(rq.y) + fold;
+          t[s][2 * w + e] = wl[o];
+        }
+    }
+#pragma unroll
+    for (int s = 0; s < NK; s++) {
+      unsigned long long wd[4];
+#pragma unroll
+      for (int w = 0; w < 4; w++) wd[w] = __builtin_amdgcn_ballot_w64(t[s][2 * w] < t[s][2 * w + 1]);
+      const unsigned long long mine = lane == 0 ? wd[0] : lane == 1 ? wd[1] : lane == 2 ? wd[2] : wd[3];
+      if (lane < 4 && k + s < k1) reinterpret_cast<unsigned long long *>(desc + ((long long)f * capacity + g0 + k + s) * 32)[lane] = mine;
+    }
+    wave_sync();  // the windows are overwritten by the next group
+  }
+  for (int k = k0; !OD && k < k1; k += NK) {
     u32x4 wv[NK][3];
     int ox[NK];
     bool narrow[NK];
@@ -1857,6 +2014,11 @@ struct vo_orb {
   int blur_jobs = 0;               // k_blur_groups jobs per frame quad
   int blur_job0[kMaxLevels + 1] = {0};  // first job of every level (per-level launches next to fused levels)
   // k_level_pass (orb_level_pass.inc): per level whether it takes the fused pass, its tile pitch / rows, block table, LDS bytes
+  int od_tab_off = 0;              // band operands of k_describe's on-demand blur (6 x 64 x 4 ints into `tables`)
+  int desc_blur = 0;               // vo_orb_set_option(VO_ORB_OPT_DESCRIBE_BLUR): 0 k_describe blurs its windows itself (default), 1 blurred planes
+  bool blur_valid = false;         // the blurred planes of the last call exist (vo_orb_get_level(blurred) makes them on demand)
+  bool last_lv0_rows16 = false;
+  int last_lv0_unaligned = 0;
   int fused = 0;                   // vo_orb_set_option(VO_ORB_OPT_FUSED_LEVEL_PASS): 0 the three kernels (default), 1 k_level_pass (profiles/r05_ab_fused.txt)
   bool lp_ok[kMaxLevels] = {false};
   int lp_tp[kMaxLevels] = {0}, lp_tile_rows[kMaxLevels] = {0}, lp_score_rows[kMaxLevels] = {0}, lp_blocks[kMaxLevels] = {0};
@@ -1921,6 +2083,39 @@ void orb_resize_tables(int sw, int sh, int dw, int dh, std::vector<int> &xofs, s
 }
 
 int align_up(int v, int a) { return (v + a - 1) / a * a; }
+
+// The blur of levels [l0, l1) of `n_frames` frames: k_blur_mfma where the level takes it (16-byte aligned rows: our own planes
+// always, the caller's image if it is), else k_blur_groups (aligned dwords), else -- levels too small for either, a caller image
+// that is not 4-byte aligned -- the generic LDS kernel.
+void launch_blur_levels(vo_orb *h, const FrameSrc &S, int n_frames, bool lv0_rows16, int lv0_unaligned, hipStream_t bs, int l0, int l1) {
+  const OrbDev &D = h->dev;
+  const int *T = h->tables.as<int>();
+  if (l1 <= l0) return;
+  const unsigned lmask = (l1 >= 32 ? ~0u : (1u << l1) - 1u) & ~((1u << l0) - 1u);
+  unsigned mf = h->blur_mfma == 0 ? (h->bm_mask & lmask) : 0u;
+  if (!lv0_rows16) mf &= ~1u;
+  // (the jobs of consecutive levels are consecutive: one launch per run of levels of the same kind)
+  for (int l = l0; l < l1;) {
+    const bool is_mf = (mf >> l) & 1u;
+    int e = l + 1;
+    while (e < l1 && (((mf >> e) & 1u) != 0) == is_mf) e++;
+    if (is_mf) {
+      const int jb = h->bm_job0[l], je = h->bm_job0[e];
+      if (je > jb)
+        hipLaunchKernelGGL(k_blur_mfma, dim3((je - jb + 3) / 4, n_frames), dim3(256), 0, bs, S, T + h->bm_tab_off + 16 * jb, je - jb, T,
+                           h->bm_bv_off);
+    } else {
+      const int jb = h->blur_job0[l], je = h->blur_job0[e];
+      if (je > jb)
+        hipLaunchKernelGGL(k_blur_groups, dim3((je - jb + 3) / 4, (n_frames + kBlurF - 1) / kBlurF), dim3(256), 0, bs, S, lv0_unaligned,
+                           T + h->strip_tab_off + 16 * jb, je - jb, n_frames);
+    }
+    l = e;
+  }
+  const unsigned gmask = (h->blur_generic_mask | (lv0_unaligned ? 1u : 0u)) & lmask & ~mf;
+  if (gmask) hipLaunchKernelGGL(k_blur, dim3(h->tiles_frame, n_frames), dim3(256), 0, bs, D, S, gmask);
+}
+
 
 // ---- k_level_pass geometry of level l (orb_level_pass.inc): block table appended to `tables`; false: the level keeps the
 // separate kernels.  xo / yo: source column / row of every column / row of level l + 1 (empty for the last level).
@@ -2318,6 +2513,36 @@ int configure(vo_orb *h, int w, int h_img, int n_frames) {
         h->bm_tab_off = (int)tables.size();
         tables.insert(tables.end(), jobs.begin(), jobs.end());
       }
+      {
+        // k_describe<., true>: band operands of its window blur on v_mfma_i32_16x16x64_i8, lane (n = lane & 15, kq = lane >> 4),
+        // byte b of the lane's 16.  Row pass X = 0..2 (16 output columns each): slot (kq, b) = staged column 16 kq + b, which enters
+        // output column 16 X + n with weight w[16 kq + b - (16 X + n)]; slots 62 and 63 (the two 0x81 bytes) weigh 64.  Column
+        // pass Y = 0..2: slot (kq, 4 T + r) = row 16 T + 4 kq + r of the row-pass result (the order its accumulator registers have),
+        // weight w[row - (16 Y + n)]; T = 3: the constant slots (16 for the lane quarters 0 and 1, 127 for 2 and 3).
+        static const int kw[7] = {18, 34, 49, 55, 49, 34, 18};
+        while (tables.size() % 4) tables.push_back(0);
+        h->od_tab_off = (int)tables.size();
+        for (int which = 0; which < 2; which++)
+          for (int X = 0; X < 3; X++)
+            for (int lane = 0; lane < 64; lane++)
+              for (int d = 0; d < 4; d++) {
+                unsigned wd = 0;
+                for (int j = 0; j < 4; j++) {
+                  const int n = lane & 15, kq = lane >> 4, b = 4 * d + j;
+                  int v;
+                  if (which == 0) {
+                    const int t = 16 * kq + b - (16 * X + n);
+                    v = (t >= 0 && t <= 6) ? kw[t] : 0;
+                    if (kq == 3 && b >= 14) v = 64;
+                  } else {
+                    const int T = b >> 2, r = b & 3, t = 16 * T + 4 * kq + r - (16 * X + n);
+                    v = T < 3 ? ((t >= 0 && t <= 6) ? kw[t] : 0) : (kq < 2 ? 16 : 127);
+                  }
+                  wd |= (unsigned)v << (8 * j);
+                }
+                tables.push_back((int)wd);
+              }
+      }
       h->cell_tab_off = (int)tables.size();
       for (int l = 0; l < h->nlevels; l++) {
         const LevelGeom &L = D.lv[l];
@@ -2468,42 +2693,19 @@ int run_pipeline(vo_orb *h, const uint8_t *dev_images, int n_frames, int w, int 
     hipLaunchKernelGGL(fast, grid, dim3(256), h->fast_lds, st, D, S, h->slots.as<uint32_t>(), h->slots_frame,
                        h->cellcnt.as<int>(), h->cells_frame, h->fast_rows, h->fast_interior, T + h->cell_tab_off, cell_begin, cell_end);
   };
-  // The blur of levels [l0, l1): k_blur_mfma where the level takes it (16-byte aligned rows: our own planes always, the caller's
-  // image if it is), else k_blur_groups (aligned dwords), else -- levels too small for either, a caller image that is not
-  // 4-byte aligned -- the generic LDS kernel.
+  // (launch_blur_levels: k_blur_mfma where the level takes it, else k_blur_groups, else the generic LDS kernel)
   const bool lv0_rows16 = !lv0_not16 && stride >= ((D.lv[0].w + 15) & ~15);
-  auto launch_blur = [&](hipStream_t bs, int l0, int l1) {
-    if (l1 <= l0) return;
-    const unsigned lmask = (l1 >= 32 ? ~0u : (1u << l1) - 1u) & ~((1u << l0) - 1u);
-    unsigned mf = h->blur_mfma == 0 ? (h->bm_mask & lmask) : 0u;
-    if (!lv0_rows16) mf &= ~1u;
-    // (the jobs of consecutive levels are consecutive: one launch per run of levels of the same kind)
-    for (int l = l0; l < l1;) {
-      const bool is_mf = (mf >> l) & 1u;
-      int e = l + 1;
-      while (e < l1 && (((mf >> e) & 1u) != 0) == is_mf) e++;
-      if (is_mf) {
-        const int jb = h->bm_job0[l], je = h->bm_job0[e];
-        if (je > jb)
-          hipLaunchKernelGGL(k_blur_mfma, dim3((je - jb + 3) / 4, n_frames), dim3(256), 0, bs, S, T + h->bm_tab_off + 16 * jb,
-                             je - jb, T, h->bm_bv_off);
-      } else {
-        const int jb = h->blur_job0[l], je = h->blur_job0[e];
-        if (je > jb)
-          hipLaunchKernelGGL(k_blur_groups, dim3((je - jb + 3) / 4, (n_frames + kBlurF - 1) / kBlurF), dim3(256), 0, bs, S,
-                             lv0_unaligned, T + h->strip_tab_off + 16 * jb, je - jb, n_frames);
-      }
-      l = e;
-    }
-    const unsigned gmask = (h->blur_generic_mask | (lv0_unaligned ? 1u : 0u)) & lmask & ~mf;
-    if (gmask) hipLaunchKernelGGL(k_blur, dim3(h->tiles_frame, n_frames), dim3(256), 0, bs, D, S, gmask);
-  };
+  h->last_lv0_rows16 = lv0_rows16, h->last_lv0_unaligned = lv0_unaligned;
+  auto launch_blur = [&](hipStream_t bs, int l0, int l1) { launch_blur_levels(h, S, n_frames, lv0_rows16, lv0_unaligned, bs, l0, l1); };
   // One fused pass per level (orb_level_pass.inc) where the level's geometry takes it: its FAST cells, its blurred tiles and the
   // next level's rows from ONE staged tile.  Level 0 needs 16-byte aligned caller rows for the LDS-DMA chunks.
   bool any_fused = false;
   if (h->fused)
     for (int l = 0; l < D.nlevels; l++) any_fused = any_fused || (h->lp_ok[l] && !(l == 0 && lv0_not16));
-  const bool overlap = !ev && h->side != nullptr && !any_fused;
+  // on-demand blur: k_describe blurs the windows it reads; no blurred plane is made (the fused pass makes its own tiles)
+  const bool od = h->desc_blur == 0 && !any_fused;
+  h->blur_valid = !od;
+  const bool overlap = !ev && h->side != nullptr && !any_fused && !od;
   if (any_fused) {
     for (int l = 0; l < D.nlevels; l++) {
       const LevelGeom &L = D.lv[l];
@@ -2582,15 +2784,16 @@ int run_pipeline(vo_orb *h, const uint8_t *dev_images, int n_frames, int w, int 
   // (stage 3, the per-frame offsets and counts, is computed by k_describe itself: no launch and no event here)
   if (overlap)
     VO_HIP_CHECK(hipStreamWaitEvent(st, h->ev_join, 0));
-  else if (!any_fused)
+  else if (!any_fused && !od)
     launch_blur(st, 0, D.nlevels);
   VO_STAGE_MARK(5);
   const int kp_blocks = (std::min(capacity, h->max_kp) + 63) / 64;
   if (kp_blocks == 0 && dcounts) VO_HIP_CHECK(hipMemsetAsync(dcounts, 0, (size_t)n_frames * sizeof(int), st));
-  if (kp_blocks > 0)
-    hipLaunchKernelGGL(k_describe<kDescNK>, dim3(kp_blocks * ((n_frames + 7) / 8) * 8), dim3(256), 0, st, D, S,
-                       h->sel.as<uint32_t>(), h->sel_frame, h->nk.as<int>(), dcounts, capacity, dkp, ddesc, lv0_not16, kp_blocks,
-                       n_frames, h->err.as<int>());
+  if (kp_blocks > 0) {
+    auto kd = od ? k_describe<kDescNK, true> : k_describe<kDescNK, false>;
+    hipLaunchKernelGGL(kd, dim3(kp_blocks * ((n_frames + 7) / 8) * 8), dim3(256), 0, st, D, S, h->sel.as<uint32_t>(), h->sel_frame,
+                       h->nk.as<int>(), dcounts, capacity, dkp, ddesc, lv0_not16, kp_blocks, n_frames, h->err.as<int>(), T + h->od_tab_off);
+  }
   VO_STAGE_MARK(6);
 #undef VO_STAGE_MARK
   VO_HIP_CHECK(hipGetLastError());
@@ -2726,6 +2929,14 @@ int vo_orb_set_option(vo_orb *h, int option, int value) {
   }
   if (option == VO_ORB_OPT_EARLY_LEVEL0) {
     h->early_level0 = value ? 1 : 0;
+    return VO_OK;
+  }
+  if (option == VO_ORB_OPT_DESCRIBE_BLUR) {
+    if (value != 0 && value != 1) {
+      vo::set_error("vo_orb_set_option(VO_ORB_OPT_DESCRIBE_BLUR): 0 (on demand, inside the descriptor kernel) or 1 (blurred planes)");
+      return VO_ERR_INVALID;
+    }
+    h->desc_blur = value;
     return VO_OK;
   }
   if (option == VO_ORB_OPT_BLUR_KERNEL) {
@@ -2871,6 +3082,12 @@ int vo_orb_get_level(vo_orb *h, int frame, int level, int blurred, uint8_t *dst,
   const uint8_t *sp;
   int pitch;
   if (blurred) {
+    if (!h->blur_valid) {  // on-demand mode: the extraction did not make the planes; make them now (all levels of the last batch)
+      launch_blur_levels(h, h->last_src, h->last_frames, h->last_lv0_rows16, h->last_lv0_unaligned, h->stream, 0, h->nlevels);
+      VO_HIP_CHECK(hipGetLastError());
+      VO_HIP_CHECK(hipStreamSynchronize(h->stream));
+      h->blur_valid = true;
+    }
     sp = h->last_src.blur + (long long)frame * h->last_src.blur_frame_stride + L.blur_off;
     pitch = L.pitch;
   } else if (level == 0) {
