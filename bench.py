@@ -374,7 +374,9 @@ def main():
     # The dominant kernel: the longest single-kernel stage of the path in the timed region (HIP events on the launching
     # stream around every kernel; with two batches in flight the other batch's kernels share the CUs with it, which
     # stretches every launch while the step gets shorter -- the same kernel with one batch in flight is under "alone")
-    kernel_stages = [k for k in serial_stage_ms if k not in ("offsets", "pose_only_1", "pose_only_2")]
+    # (a stage that launches nothing -- the blur when the descriptor kernel blurs its own windows, VO_ORB_OPT_DESCRIBE_BLUR = 0 --
+    #  reads a few microseconds of event overhead: it is not a kernel)
+    kernel_stages = [k for k in serial_stage_ms if k not in ("offsets", "pose_only_1", "pose_only_2") and serial_stage_ms[k] > 0.02]
     # ranked by the durations INSIDE the timed region (the undisturbed ranking picked describe over FAST on a
     # 0.1 % margin); every kernel's fraction is in `per_kernel` below either way
     dom = max(kernel_stages, key=lambda k: stage_ms.get(k, 0.0))
@@ -418,7 +420,7 @@ def main():
                                        f"{cyc} cycles / ({int(simds)} SIMDs x {vc['clock_GHz']} GHz) / alone_ms")
     stage_gbs = {k: round(sb[k] * B / (serial_stage_ms[k] * 1e-3) / 1e9, 1) for k in kernel_stages if serial_stage_ms[k] > 0}
     stage_gbs_region = {k: round(sb[k] * B / (stage_ms[k] * 1e-3) / 1e9, 1) for k in stage_ms
-                        if k in sb and stage_ms[k] > 0}
+                        if k in sb and stage_ms[k] > 0.02}
     # pose-only stages are bound by FP64 instruction issue: report their flop rate (~270 flop per observation and iteration)
     po_iters = 20.0
     pose_flops = 270.0 * n_obs2 * po_iters
@@ -558,7 +560,8 @@ def main():
             "frames_per_s": round(B * nbf / tbf, 1), "ms_per_step": round(tbf / nbf * 1e3, 4),
             "stage_ms_per_launch": {k: round(v, 4) for k, v in bms.items() if k != "offsets"},
             "kernels": {"hamming": "k_hamming_mfma (int8 matrix-core dot products; vo_set_option(VO_OPT_HAMMING_KERNEL, 1) = the VALU form)",
-                        "blur": "k_blur_mfma (int8 matrix-core band products; VO_ORB_OPT_BLUR_KERNEL = 1: k_blur_groups)"},
+                        "blur": "none: k_describe<., true> blurs the 45 x 45 window of every key-point itself (int8 matrix cores; "
+                                "VO_ORB_OPT_DESCRIBE_BLUR = 1: blurred planes by k_blur_mfma, VO_ORB_OPT_BLUR_KERNEL = 1: by k_blur_groups)"},
             "hamming_roofline": {"bound": "hbm (write stream)", "bytes_per_launch": 2064000 * B,
                                  "achieved": round(2064000 * B / (bms["hamming"] * 1e-3) / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                  "frac": round(2064000 * B / (bms["hamming"] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),

@@ -1821,7 +1821,7 @@ __global__ __launch_bounds__(256, 4) void k_describe(OrbDev P, FrameSrc src, con
         const int idx = lane + 64 * j, row = min(idx / 3, 44), chunk = idx % 3;
         const int y = reflect101_near(py - 22 + row, Lh);
         // (an offset in front of the plane is a huge unsigned one: the range check returns zeros, as it does behind the plane)
-        wv[s][j] = __builtin_amdgcn_raw_buffer_load_b128(rs, y * pitch + (px - 22) + 16 * chunk, 0, 0);
+        wv[s][j] = __builtin_amdgcn_raw_buffer_load_b128(rs, __mul24(y, pitch) + (px - 22) + 16 * chunk, 0, 0);
       }
     }
 #pragma unroll
