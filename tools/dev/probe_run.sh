@@ -1,0 +1,18 @@
+#!/bin/bash
+# usage: probe_run.sh kernel_substr variant...
+cd /tmp && export TMPDIR=/tmp
+R=${GRAFT_REPO_ROOT:-/root/repo}
+K=$1; shift
+for v in "$@"; do
+  if [ "$v" = product ]; then unset VO_HIP_LIB; else export VO_HIP_LIB=$R/vo_slam_test_amd/_variants/libvo_$v.so; fi
+  d=$R/gpurun_out/probe_$v; rm -rf $d; mkdir -p $d
+  timeout 300 rocprofv3 --kernel-trace -d $d --output-format csv -- python3 $R/tools/gba_run.py > $d/log.txt 2>&1
+  echo "=== $v: $(grep 'LM it' $d/log.txt | tail -1)"
+  python3 - <<PY
+import csv, glob
+f = glob.glob("$d/**/*kernel_trace.csv", recursive=True)[0]
+v = sorted((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1000.0 for r in csv.DictReader(open(f)) if "$K" in r["Kernel_Name"])
+print("$K n=%d" % len(v), " ".join("%.0f" % x for x in v))
+PY
+  rm -rf $d
+done

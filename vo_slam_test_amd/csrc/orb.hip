@@ -1981,6 +1981,261 @@ __global__ __launch_bounds__(256, 4) void k_describe(OrbDev P, FrameSrc src, con
   }
 }
 
+
+// ------------------------------------------------------------------------------------------
+// K3 + K4 + K5 in one visit of the window (round 6, second form of the on-demand blur): the 45 x 45 RAW window of a key-point
+// is brought into LDS ONCE -- k_describe<., true> fetched the 31 x 31 orientation window in phase 1 and the 45 x 45 window,
+// which contains it, again in phase 3: five 1 KB loads per key-point where three do -- and stays there from the moments to
+// the tests.  A wavefront owns kDwKpw = 4 key-points from start to end (no workgroup barrier, no key-point records in LDS):
+//  0  every lane derives the data of key-point (lane & 3) of its wavefront (level, position, plane); the per-key-point
+//     values move to scalar registers by v_readlane
+//  1  the four windows are requested together, straight into LDS (buffer_load_dwordx4 ... lds: lane + 64 j <-> 16-byte chunk
+//     idx % 3 of window row idx / 3, LDS address 16 idx = 48 row + 16 chunk, i.e. row pitch 48; hardware range checking
+//     and row reflection by address exactly as in k_describe<., true>); the moments are byte reads of the disc at
+//     (22 + v, 22 + u) of the staged window
+//  2  lanes 0..3: fastAtan2, cos / sin, key-point record
+//  3  blur in place (v_mfma_i32_16x16x64_i8, the arithmetic and operand tables of k_describe<., true>; the constant K slots
+//     48..63 of the row pass are one 16-byte chunk behind each window instead of a fourth chunk per row), then the tests
+// LDS: 4 x 4 windows of 48 x 48 + 16 bytes = 36.3 KB per workgroup, four workgroups per CU.
+// ------------------------------------------------------------------------------------------
+constexpr int kDwKpw = 4;
+constexpr int kDwPitch = 48;
+constexpr int kDwWin = 48 * kDwPitch + 16;
+// the lane's 12 disc pixels as byte offsets (22 + v) * 48 + (22 + u) in such a window (vo_orb_create)
+__constant__ __attribute__((aligned(16))) uint32_t c_disc48[64][12];
+
+template <bool DMA>
+__global__ __launch_bounds__(256, 4) void k_describe_win(OrbDev P, FrameSrc src, const uint32_t *sel, int sel_per_frame, const int *nk,
+                                                      int *counts, int capacity, vo_keypoint *kps, uint8_t *desc,
+                                                      int groups_per_frame, int n_frames, int *err_flag, const int *od_tab) {
+  __shared__ __attribute__((aligned(16))) uint8_t win_lds[4][kDwKpw][kDwWin];
+  typedef int od_i32x4 __attribute__((ext_vector_type(4)));
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  // all groups of a frame on one XCD (their windows overlap line by line: one L2 serves them)
+  const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+  const int f = (slot / groups_per_frame) * 8 + xcd, g0 = (slot % groups_per_frame) * (4 * kDwKpw);
+  if (f >= n_frames) return;
+  int op[kMaxLevels + 1];
+  {
+    const int *nkp = nk + f * P.nlevels;
+    int acc = 0;
+#pragma unroll
+    for (int i = 0; i < kMaxLevels; i++) {
+      op[i] = acc;
+      if (i < P.nlevels) acc += nkp[i];
+    }
+    op[kMaxLevels] = acc;
+  }
+  const int total = min(op[kMaxLevels], capacity);
+  if (g0 == 0 && tid == 0 && counts) counts[f] = total;
+  if (g0 == 0 && tid == 0 && op[kMaxLevels] > capacity) atomicExch(err_flag, 3);  // key-points dropped: reported by vo_orb_sync
+  const int k0 = g0 + wave * kDwKpw;
+  const int nv = min(total - k0, kDwKpw);  // key-points of this wavefront (uniform)
+  if (nv <= 0) return;                      // (the kernel has no workgroup barrier)
+  // ---- phase 0: key-point (lane & 3) of the wavefront on every lane (past the end: the last one again, never stored)
+  const int g = k0 + min(lane & 3, nv - 1);
+  int l = 0, obase = 0;
+#pragma unroll
+  for (int i = 1; i < kMaxLevels; i++)
+    if (i < P.nlevels && g >= op[i]) l = i, obase = op[i];
+  const LevelGeom &L = P.lv[l];
+  const uint32_t kv = sel[(long long)f * sel_per_frame + L.selBase + (g - obase)];
+  const int px_v = (int)(kv & 0xfff) + kBorder, py_v = (int)((kv >> 12) & 0xfff) + kBorder;  // :849-850
+  int pitch_v;
+  const unsigned long long img_v = (unsigned long long)(uintptr_t)level_plane(P, src, l, f, pitch_v);
+  const int wh_v = L.w | (L.h << 16);
+  // per-lane constants: disc offsets / weights, pattern, band operands, window chunk of the lane
+  u32x4 dof[3], tab[6];
+#pragma unroll
+  for (int i = 0; i < 3; i++) dof[i] = reinterpret_cast<const u32x4 *>(c_disc48[lane])[i];
+#pragma unroll
+  for (int i = 0; i < 6; i++) tab[i] = reinterpret_cast<const u32x4 *>(c_desc_tab[lane])[3 + i];  // [0..1]: weights, [1.5..5]: pattern
+  od_i32x4 Bh[3], Bv[3];
+  {
+    const od_i32x4 *tb = reinterpret_cast<const od_i32x4 *>(od_tab);
+#pragma unroll
+    for (int X = 0; X < 3; X++) Bh[X] = tb[64 * X + lane], Bv[X] = tb[64 * (3 + X) + lane];
+  }
+  const int m = lane & 15, kq = lane >> 4;
+  const int A3lo = kq < 2 ? 0x01010101 : 0;           // (k_describe<., true>: the constants of the column pass)
+  const int A3hi = kq < 2 ? 0x05050505 : 0x20202020;
+  lds_u8 *const W0 = (lds_u8 *)win_lds[wave][0];
+  // K slots 48..63 of the row pass: bytes 0x80 (= 0 after the operand's xor), the last two 0x81 (+1 against weights 64 + 64 = the
+  // row pass's 128); written once, never overwritten
+  if (lane < kDwKpw) *(__attribute__((address_space(3))) u32x4 *)(W0 + kDwWin * lane + 48 * kDwPitch) = u32x4{0x80808080u, 0x80808080u, 0x80808080u, 0x81818080u};
+  int px[kDwKpw], py[kDwKpw], Lw[kDwKpw], Lh[kDwKpw];
+  __amdgpu_buffer_rsrc_t rs[kDwKpw];
+  // ---- phase 1: the four windows
+  u32x4 wv[DMA ? 1 : kDwKpw][3];
+#pragma unroll
+  for (int s = 0; s < kDwKpw; s++) {
+    px[s] = __builtin_amdgcn_readlane(px_v, s), py[s] = __builtin_amdgcn_readlane(py_v, s);
+    const int wh = __builtin_amdgcn_readlane(wh_v, s), pitch = __builtin_amdgcn_readlane(pitch_v, s);
+    Lw[s] = wh & 0xffff, Lh[s] = wh >> 16;
+    const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)img_v, s), hi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(img_v >> 32), s);
+    rs[s] = __builtin_amdgcn_make_buffer_rsrc((void *)(uintptr_t)(((unsigned long long)hi << 32) | lo), 0, Lh[s] * pitch, 0x00020000);
+#pragma unroll
+    for (int j = 0; j < 3; j++) {
+      const int idx = lane + 64 * j, row = min(idx / 3, 44), chunk = idx % 3;
+      const int y = reflect101_near(py[s] - 22 + row, Lh[s]);
+      // (an offset in front of the plane is a huge unsigned one: the range check returns zeros, as it does behind the plane)
+      const int off = __mul24(y, pitch) + (px[s] - 22) + 16 * chunk;
+      if (DMA) {
+        if (j < 2 || lane < 16) __builtin_amdgcn_raw_ptr_buffer_load_lds(rs[s], (__attribute__((address_space(3))) void *)(W0 + kDwWin * s + 1024 * j), 16, off, 0, 0, 0);
+      } else {
+        wv[s][j] = __builtin_amdgcn_raw_buffer_load_b128(rs[s], off, 0, 0);
+      }
+    }
+  }
+  if (!DMA) {
+#pragma unroll
+    for (int s = 0; s < kDwKpw; s++)
+#pragma unroll
+      for (int j = 0; j < 3; j++)
+        if (j < 2 || lane < 16) *(__attribute__((address_space(3))) u32x4 *)(W0 + kDwWin * s + 1024 * j + 16 * lane) = wv[s][j];
+  } else {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  }
+  wave_sync();
+#pragma unroll
+  for (int s = 0; s < kDwKpw; s++) {
+    lds_u8 *R = W0 + kDwWin * s;
+    if (px[s] < 22 || px[s] + 22 > Lw[s] - 1) {  // uniform: BORDER_REFLECT_101 of the columns beyond the plane (at most six a side)
+      if (px[s] < 22 && py[s] <= 22) {
+        // a window over the plane's first pixel: the first chunk of raw row 0 starts in front of the plane, and the range check
+        // drops the WHOLE 16-byte load, its in-plane bytes included -- they are fetched one by one (staged row 22 - py)
+        if (lane >= 22 - px[s] && lane < 16) R[kDwPitch * (22 - py[s]) + lane] = __builtin_amdgcn_raw_buffer_load_b8(rs[s], lane - (22 - px[s]), 0, 0);
+        wave_sync();
+      }
+      if (lane < 48) {
+        for (int c = 0; c < 22 - px[s]; c++) R[kDwPitch * lane + c] = R[kDwPitch * lane + 2 * (22 - px[s]) - c];
+        for (int c = Lw[s] - (px[s] - 22); c < 45; c++) R[kDwPitch * lane + c] = R[kDwPitch * lane + 2 * (Lw[s] - 1 - (px[s] - 22)) - c];
+      }
+      wave_sync();
+    }
+  }
+  // moments (:79-107): the disc is rows / columns 7..37 of the window, which no fix-up touches
+  int m10_v = 0, m01_v = 0;
+  {
+    uint32_t va[kDwKpw][12];
+#pragma unroll
+    for (int s = 0; s < kDwKpw; s++)
+#pragma unroll
+      for (int i = 0; i < 12; i++) va[s][i] = (W0 + kDwWin * s)[dof[i >> 2][i & 3]];
+#pragma unroll
+    for (int s = 0; s < kDwKpw; s++) {
+      int s10 = 0, s01 = 0;
+#pragma unroll
+      for (int j = 0; j < 3; j++) {
+        const uint32_t w = (__builtin_amdgcn_perm(va[s][4 * j + 1], va[s][4 * j], 0x0c0c0400u) |
+                            __builtin_amdgcn_perm(va[s][4 * j + 3], va[s][4 * j + 2], 0x04000c0cu)) ^ 0x80808080u;
+        s10 = __builtin_amdgcn_sdot4((int)tab[0][j], (int)w, s10, false);
+        s01 = __builtin_amdgcn_sdot4((int)(j == 0 ? tab[0][3] : tab[1][j - 1]), (int)w, s01, false);
+      }
+      const int m10 = wave_sum_i32(s10), m01 = wave_sum_i32(s01);
+      if ((lane & 3) == s) m10_v = m10, m01_v = m01;
+    }
+  }
+  // ---- phase 2: angle, cos / sin, key-point record (lanes 0..3; the other lanes repeat them)
+  float ca_v, sb_v;
+  {
+    const float angle = fast_atan2_deg((float)m01_v, (float)m10_v);
+    const float factorPI = (float)(3.14159265358979323846 / 180.f);  // :109
+    cos_sin_f(angle * factorPI, ca_v, sb_v);
+    if (lane < nv) {
+      vo_keypoint kp;
+      float fx = (float)px_v, fy = (float)py_v;
+      if (l != 0) {  // :1102-1108
+        fx *= L.scale;
+        fy *= L.scale;
+      }
+      kp.x = fx;
+      kp.y = fy;
+      kp.size = (float)L.patchSize;
+      kp.angle = angle;
+      kp.response = (float)(kv >> 24);
+      kp.octave = l;
+      kp.class_id = -1;
+      kps[(long long)f * capacity + k0 + lane] = kp;
+    }
+  }
+  // ---- phase 3: blur in place, tests
+  int aoff[3];
+#pragma unroll
+  for (int T = 0; T < 3; T++) aoff[T] = kq < 3 ? kDwPitch * (16 * T + m) + 16 * kq : 48 * kDwPitch;
+  od_i32x4 a[kDwKpw][3];
+#pragma unroll
+  for (int s = 0; s < kDwKpw; s++)
+#pragma unroll
+    for (int T = 0; T < 3; T++) {
+      const u32x4 v = *(const __attribute__((address_space(3))) u32x4 *)(W0 + kDwWin * s + aoff[T]);
+      a[s][T] = od_i32x4{(int)(v.x ^ 0x80808080u), (int)(v.y ^ 0x80808080u), (int)(v.z ^ 0x80808080u), (int)(v.w ^ 0x80808080u)};
+    }
+  wave_sync();  // (every lane has its rows: the blurred windows may now overwrite the raw ones)
+  const od_i32x4 Z = {0, 0, 0, 0};
+#pragma unroll
+  for (int s = 0; s < kDwKpw; s++) {
+    lds_u8 *R = W0 + kDwWin * s;
+#pragma unroll
+    for (int X = 0; X < 3; X++) {
+      od_i32x4 lo, hi;
+#pragma unroll
+      for (int T = 0; T < 3; T++) {
+        const od_i32x4 acc = __builtin_amdgcn_mfma_i32_16x16x64_i8(a[s][T], Bh[X], Z, 0, 0, 0);  // row sums - 2^15, rows 16 T + 4 q + r
+        const unsigned t01 = __builtin_amdgcn_perm((unsigned)acc[1], (unsigned)acc[0], 0x05010400u);
+        const unsigned t23 = __builtin_amdgcn_perm((unsigned)acc[3], (unsigned)acc[2], 0x05010400u);
+        lo[T] = (int)(__builtin_amdgcn_perm(t23, t01, 0x05040100u) ^ 0x80808080u);
+        hi[T] = (int)__builtin_amdgcn_perm(t23, t01, 0x07060302u);
+      }
+      lo[3] = A3lo, hi[3] = A3hi;
+#pragma unroll
+      for (int Y = 0; Y < 3; Y++) {
+        const od_i32x4 al = __builtin_amdgcn_mfma_i32_16x16x64_i8(lo, Bv[Y], Z, 0, 0, 0);
+        const od_i32x4 ah = __builtin_amdgcn_mfma_i32_16x16x64_i8(hi, Bv[Y], Z, 0, 0, 0);
+        unsigned v[4];
+#pragma unroll
+        for (int j = 0; j < 4; j++) v[j] = ((unsigned)ah[j] << 8) + (unsigned)al[j];
+        const unsigned s01 = bm_sat_pk(__builtin_amdgcn_perm(v[1], v[0], 0x07060302u));
+        const unsigned s23 = bm_sat_pk(__builtin_amdgcn_perm(v[3], v[2], 0x07060302u));
+        // lane (row 16 Y + m, quarter kq): blurred columns 16 X + 4 kq .. + 3 of that row
+        *(__attribute__((address_space(3))) unsigned *)(R + kDwPitch * (16 * Y + m) + 16 * X + 4 * kq) = s01 | (s23 << 16);
+      }
+    }
+  }
+  wave_sync();
+  constexpr float kMagic = 12582912.f;  // 1.5 * 2^23: x + kMagic has rint(x) + 0x400000 in its low 24 bits
+  uint32_t t[kDwKpw][8];
+#pragma unroll
+  for (int s = 0; s < kDwKpw; s++) {
+    const float ca = __uint_as_float((unsigned)__builtin_amdgcn_readlane((int)__float_as_uint(ca_v), s));
+    const float sb = __uint_as_float((unsigned)__builtin_amdgcn_readlane((int)__float_as_uint(sb_v), s));
+    // (r + 19) * 48 + (q + 19) from the raw bit patterns: v_mad_u32_u24 takes the low 24 bits of rint(x)'s pattern, 0x400000 + r
+    const unsigned fold = (unsigned)(kEdge * kDwPitch + kEdge) - (0x400000u * (unsigned)kDwPitch + 0x4B400000u);
+    const lds_u8 *wl = W0 + kDwWin * s;
+    const v2f ba = {sb, ca}, anb = {ca, -sb}, mg = {kMagic, kMagic};
+#pragma unroll
+    for (int w = 0; w < 4; w++)
+#pragma unroll
+      for (int e = 0; e < 2; e++) {
+        const int c = 6 + 4 * w + 2 * e;  // (pattern floats: entries 18.. of the lane's table row = tab[1.5..])
+        const float x = __uint_as_float(tab[c >> 2][c & 3]), y = __uint_as_float(tab[(c + 1) >> 2][(c + 1) & 3]);
+        const v2f xx = {x, x}, yy = {y, y};
+        const v2f rq = (xx * ba + yy * anb) + mg;  // (x b + y a, x a - y b), each rounded to nearest even
+        const unsigned o = __umul24(__float_as_uint(rq.x), (unsigned)kDwPitch) + __float_as_uint(rq.y) + fold;
+        t[s][2 * w + e] = wl[o];
+      }
+  }
+#pragma unroll
+  for (int s = 0; s < kDwKpw; s++) {
+    unsigned long long wd[4];
+#pragma unroll
+    for (int w = 0; w < 4; w++) wd[w] = __builtin_amdgcn_ballot_w64(t[s][2 * w] < t[s][2 * w + 1]);
+    const unsigned long long mine = lane == 0 ? wd[0] : lane == 1 ? wd[1] : lane == 2 ? wd[2] : wd[3];
+    if (lane < 4 && s < nv) reinterpret_cast<unsigned long long *>(desc + ((long long)f * capacity + k0 + s) * 32)[lane] = mine;
+  }
+}
+
 }  // namespace
 
 // ============================================================================================
@@ -2703,7 +2958,7 @@ int run_pipeline(vo_orb *h, const uint8_t *dev_images, int n_frames, int w, int 
   if (h->fused)
     for (int l = 0; l < D.nlevels; l++) any_fused = any_fused || (h->lp_ok[l] && !(l == 0 && lv0_not16));
   // on-demand blur: k_describe blurs the windows it reads; no blurred plane is made (the fused pass makes its own tiles)
-  const bool od = h->desc_blur == 0 && !any_fused;
+  const bool od = h->desc_blur != 1 && !any_fused;  // (2, 3: developer A/B forms of the on-demand kernel)
   h->blur_valid = !od;
   const bool overlap = !ev && h->side != nullptr && !any_fused && !od;
   if (any_fused) {
@@ -2789,7 +3044,12 @@ int run_pipeline(vo_orb *h, const uint8_t *dev_images, int n_frames, int w, int 
   VO_STAGE_MARK(5);
   const int kp_blocks = (std::min(capacity, h->max_kp) + 63) / 64;
   if (kp_blocks == 0 && dcounts) VO_HIP_CHECK(hipMemsetAsync(dcounts, 0, (size_t)n_frames * sizeof(int), st));
-  if (kp_blocks > 0) {
+  if (kp_blocks > 0 && od && h->desc_blur != 2) {
+    const int groups = (std::min(capacity, h->max_kp) + 4 * kDwKpw - 1) / (4 * kDwKpw);
+    auto kd = h->desc_blur == 3 ? k_describe_win<false> : k_describe_win<true>;
+    hipLaunchKernelGGL(kd, dim3(groups * ((n_frames + 7) / 8) * 8), dim3(256), 0, st, D, S, h->sel.as<uint32_t>(), h->sel_frame,
+                       h->nk.as<int>(), dcounts, capacity, dkp, ddesc, groups, n_frames, h->err.as<int>(), T + h->od_tab_off);
+  } else if (kp_blocks > 0) {
     auto kd = od ? k_describe<kDescNK, true> : k_describe<kDescNK, false>;
     hipLaunchKernelGGL(kd, dim3(kp_blocks * ((n_frames + 7) / 8) * 8), dim3(256), 0, st, D, S, h->sel.as<uint32_t>(), h->sel_frame,
                        h->nk.as<int>(), dcounts, capacity, dkp, ddesc, lv0_not16, kp_blocks, n_frames, h->err.as<int>(), T + h->od_tab_off);
@@ -2871,7 +3131,14 @@ int vo_orb_create(vo_orb **out, int nfeatures, float scale_factor, int nlevels, 
           memcpy(&tab[ln][18 + 4 * k + c], &fv, 4);
         }
     }
-    if (hipMemcpyToSymbol(HIP_SYMBOL(c_desc_tab), tab, sizeof(tab)) != hipSuccess) {
+    static uint32_t tab48[64][12];
+    for (int ln = 0; ln < 64; ln++)
+      for (int i = 0; i < 12; i++) {
+        const int u = disc[2 * (ln + 64 * i)], v = disc[2 * (ln + 64 * i) + 1];
+        tab48[ln][i] = (uint32_t)((v + 22) * kDwPitch + (u + 22));
+      }
+    if (hipMemcpyToSymbol(HIP_SYMBOL(c_desc_tab), tab, sizeof(tab)) != hipSuccess ||
+        hipMemcpyToSymbol(HIP_SYMBOL(c_disc48), tab48, sizeof(tab48)) != hipSuccess) {
       vo::set_error("hipMemcpyToSymbol(orientation / pattern table) failed");
       delete h;
       return VO_ERR_HIP;
@@ -2932,7 +3199,7 @@ int vo_orb_set_option(vo_orb *h, int option, int value) {
     return VO_OK;
   }
   if (option == VO_ORB_OPT_DESCRIBE_BLUR) {
-    if (value != 0 && value != 1) {
+    if (value < 0 || value > 3) {
       vo::set_error("vo_orb_set_option(VO_ORB_OPT_DESCRIBE_BLUR): 0 (on demand, inside the descriptor kernel) or 1 (blurred planes)");
       return VO_ERR_INVALID;
     }
