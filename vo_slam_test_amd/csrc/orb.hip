@@ -2004,7 +2004,21 @@ constexpr int kDwWin = 48 * kDwPitch + 16;
 // the lane's 12 disc pixels as byte offsets (22 + v) * 48 + (22 + u) in such a window (vo_orb_create)
 __constant__ __attribute__((aligned(16))) uint32_t c_disc48[64][12];
 
-template <bool DMA>
+// 64-lane sum whose total lands in lane 63 (DPP row reductions, then row_bcast:15 / row_bcast:31): uniform result
+__device__ __forceinline__ int wave_sum63_i32(int x) {
+  x += __builtin_amdgcn_update_dpp(0, x, 0xB1, 0xf, 0xf, false);   // quad_perm [1,0,3,2]
+  x += __builtin_amdgcn_update_dpp(0, x, 0x4E, 0xf, 0xf, false);   // quad_perm [2,3,0,1]
+  x += __builtin_amdgcn_update_dpp(0, x, 0x141, 0xf, 0xf, false);  // row_half_mirror
+  x += __builtin_amdgcn_update_dpp(0, x, 0x140, 0xf, 0xf, false);  // row_mirror: every lane holds its row's sum
+  x += __builtin_amdgcn_update_dpp(0, x, 0x142, 0xa, 0xf, false);  // row_bcast:15 into rows 1 and 3
+  x += __builtin_amdgcn_update_dpp(0, x, 0x143, 0xc, 0xf, false);  // row_bcast:31 into rows 2 and 3
+  return __builtin_amdgcn_readlane(x, 63);
+}
+
+// Workgroup -> (frame, level, 16 key-point slots of that level's selection): the level is uniform, so everything a window's
+// address needs except the key-point itself comes from scalar registers, and the key-points' load does not wait for the level
+// counts (their prefix sum is only needed for the output position): the chain in front of the window loads is ONE round trip
+// (selection entry) instead of three (counts -> level record -> selection entry).
 __global__ __launch_bounds__(256, 4) void k_describe_win(OrbDev P, FrameSrc src, const uint32_t *sel, int sel_per_frame, const int *nk,
                                                       int *counts, int capacity, vo_keypoint *kps, uint8_t *desc,
                                                       int groups_per_frame, int n_frames, int *err_flag, const int *od_tab) {
@@ -2014,37 +2028,46 @@ __global__ __launch_bounds__(256, 4) void k_describe_win(OrbDev P, FrameSrc src,
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   // all groups of a frame on one XCD (their windows overlap line by line: one L2 serves them)
   const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
-  const int f = (slot / groups_per_frame) * 8 + xcd, g0 = (slot % groups_per_frame) * (4 * kDwKpw);
+  const int f = (slot / groups_per_frame) * 8 + xcd, gb = slot % groups_per_frame;
   if (f >= n_frames) return;
-  int op[kMaxLevels + 1];
+  int l = 0, gstart = 0;
   {
-    const int *nkp = nk + f * P.nlevels;
     int acc = 0;
 #pragma unroll
-    for (int i = 0; i < kMaxLevels; i++) {
-      op[i] = acc;
-      if (i < P.nlevels) acc += nkp[i];
-    }
-    op[kMaxLevels] = acc;
+    for (int i = 0; i < kMaxLevels; i++)
+      if (i < P.nlevels) {
+        if (gb >= acc) l = i, gstart = acc;
+        acc += (P.lv[i].capSel + 4 * kDwKpw - 1) / (4 * kDwKpw);
+      }
   }
-  const int total = min(op[kMaxLevels], capacity);
-  if (g0 == 0 && tid == 0 && counts) counts[f] = total;
-  if (g0 == 0 && tid == 0 && op[kMaxLevels] > capacity) atomicExch(err_flag, 3);  // key-points dropped: reported by vo_orb_sync
-  const int k0 = g0 + wave * kDwKpw;
-  const int nv = min(total - k0, kDwKpw);  // key-points of this wavefront (uniform)
-  if (nv <= 0) return;                      // (the kernel has no workgroup barrier)
-  // ---- phase 0: key-point (lane & 3) of the wavefront on every lane (past the end: the last one again, never stored)
-  const int g = k0 + min(lane & 3, nv - 1);
-  int l = 0, obase = 0;
-#pragma unroll
-  for (int i = 1; i < kMaxLevels; i++)
-    if (i < P.nlevels && g >= op[i]) l = i, obase = op[i];
+  l = __builtin_amdgcn_readfirstlane(l);
   const LevelGeom &L = P.lv[l];
-  const uint32_t kv = sel[(long long)f * sel_per_frame + L.selBase + (g - obase)];
+  const int idx0 = (gb - gstart) * (4 * kDwKpw) + wave * kDwKpw;  // the wavefront's first slot in the level's selection
+  // the key-points: requested before anything that depends on the counts (slots past the level's count hold stale entries:
+  // never used; the index stays inside the level's block)
+  const uint32_t kv = sel[(long long)f * sel_per_frame + L.selBase + min(idx0 + (lane & 3), L.capSel - 1)];
+  int op_l = 0, total = 0;
+  {
+    const int *nkp = nk + f * P.nlevels;
+#pragma unroll
+    for (int i = 0; i < kMaxLevels; i++)
+      if (i < P.nlevels) {
+        const int c = nkp[i];
+        if (i < l) op_l += c;
+        total += c;
+      }
+  }
+  const int nkl = nk[f * P.nlevels + l];
+  if (gb == 0 && tid == 0 && counts) counts[f] = min(total, capacity);
+  if (gb == 0 && tid == 0 && total > capacity) atomicExch(err_flag, 3);  // key-points dropped: reported by vo_orb_sync
+  total = min(total, capacity);
+  const int k0 = op_l + idx0;                                  // output position of the wavefront's first key-point
+  const int nv = min(min(nkl - idx0, total - k0), kDwKpw);     // key-points of this wavefront (uniform)
+  if (nv <= 0) return;                                         // (the kernel has no workgroup barrier)
+  int pitch;
+  const uint8_t *img = level_plane(P, src, l, f, pitch);
+  const int LW = L.w, LH = L.h;
   const int px_v = (int)(kv & 0xfff) + kBorder, py_v = (int)((kv >> 12) & 0xfff) + kBorder;  // :849-850
-  int pitch_v;
-  const unsigned long long img_v = (unsigned long long)(uintptr_t)level_plane(P, src, l, f, pitch_v);
-  const int wh_v = L.w | (L.h << 16);
   // per-lane constants: disc offsets / weights, pattern, band operands, window chunk of the lane
   u32x4 dof[3], tab[6];
 #pragma unroll
@@ -2064,53 +2087,49 @@ __global__ __launch_bounds__(256, 4) void k_describe_win(OrbDev P, FrameSrc src,
   // K slots 48..63 of the row pass: bytes 0x80 (= 0 after the operand's xor), the last two 0x81 (+1 against weights 64 + 64 = the
   // row pass's 128); written once, never overwritten
   if (lane < kDwKpw) *(__attribute__((address_space(3))) u32x4 *)(W0 + kDwWin * lane + 48 * kDwPitch) = u32x4{0x80808080u, 0x80808080u, 0x80808080u, 0x81818080u};
-  int px[kDwKpw], py[kDwKpw], Lw[kDwKpw], Lh[kDwKpw];
-  __amdgpu_buffer_rsrc_t rs[kDwKpw];
-  // ---- phase 1: the four windows
-  u32x4 wv[DMA ? 1 : kDwKpw][3];
+  // ---- phase 1: the four windows (slots past the wavefront's count repeat its last key-point; never stored)
+  int px[kDwKpw], py[kDwKpw];
+  const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void *)img, 0, LH * pitch, 0x00020000);
+  int wrow[3], wch[3];  // the lane's chunk of load j: window row, 16 x chunk
+#pragma unroll
+  for (int j = 0; j < 3; j++) {
+    const int idx = lane + 64 * j;
+    wrow[j] = min(idx / 3, 44), wch[j] = 16 * (idx % 3);
+  }
 #pragma unroll
   for (int s = 0; s < kDwKpw; s++) {
-    px[s] = __builtin_amdgcn_readlane(px_v, s), py[s] = __builtin_amdgcn_readlane(py_v, s);
-    const int wh = __builtin_amdgcn_readlane(wh_v, s), pitch = __builtin_amdgcn_readlane(pitch_v, s);
-    Lw[s] = wh & 0xffff, Lh[s] = wh >> 16;
-    const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)img_v, s), hi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(img_v >> 32), s);
-    rs[s] = __builtin_amdgcn_make_buffer_rsrc((void *)(uintptr_t)(((unsigned long long)hi << 32) | lo), 0, Lh[s] * pitch, 0x00020000);
+    const int ss = min(s, nv - 1);
+    px[s] = __builtin_amdgcn_readlane(px_v, ss), py[s] = __builtin_amdgcn_readlane(py_v, ss);
+    const bool inside = py[s] >= 22 && py[s] + 22 < LH;  // uniform: no row of the window is reflected
+    const int base = (py[s] - 22) * pitch + (px[s] - 22);
 #pragma unroll
     for (int j = 0; j < 3; j++) {
-      const int idx = lane + 64 * j, row = min(idx / 3, 44), chunk = idx % 3;
-      const int y = reflect101_near(py[s] - 22 + row, Lh[s]);
+      int off;
       // (an offset in front of the plane is a huge unsigned one: the range check returns zeros, as it does behind the plane)
-      const int off = __mul24(y, pitch) + (px[s] - 22) + 16 * chunk;
-      if (DMA) {
-        if (j < 2 || lane < 16) __builtin_amdgcn_raw_ptr_buffer_load_lds(rs[s], (__attribute__((address_space(3))) void *)(W0 + kDwWin * s + 1024 * j), 16, off, 0, 0, 0);
+      if (inside) {
+        off = (int)__umul24((unsigned)wrow[j], (unsigned)pitch) + (wch[j] + base);
       } else {
-        wv[s][j] = __builtin_amdgcn_raw_buffer_load_b128(rs[s], off, 0, 0);
+        const int y = reflect101_near(py[s] - 22 + wrow[j], LH);
+        off = __mul24(y, pitch) + (px[s] - 22) + wch[j];
       }
+      if (j < 2 || lane < 16) __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (__attribute__((address_space(3))) void *)(W0 + kDwWin * s + 1024 * j), 16, off, 0, 0, 0);
     }
   }
-  if (!DMA) {
-#pragma unroll
-    for (int s = 0; s < kDwKpw; s++)
-#pragma unroll
-      for (int j = 0; j < 3; j++)
-        if (j < 2 || lane < 16) *(__attribute__((address_space(3))) u32x4 *)(W0 + kDwWin * s + 1024 * j + 16 * lane) = wv[s][j];
-  } else {
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   wave_sync();
 #pragma unroll
   for (int s = 0; s < kDwKpw; s++) {
     lds_u8 *R = W0 + kDwWin * s;
-    if (px[s] < 22 || px[s] + 22 > Lw[s] - 1) {  // uniform: BORDER_REFLECT_101 of the columns beyond the plane (at most six a side)
+    if (px[s] < 22 || px[s] + 22 > LW - 1) {  // uniform: BORDER_REFLECT_101 of the columns beyond the plane (at most six a side)
       if (px[s] < 22 && py[s] <= 22) {
         // a window over the plane's first pixel: the first chunk of raw row 0 starts in front of the plane, and the range check
         // drops the WHOLE 16-byte load, its in-plane bytes included -- they are fetched one by one (staged row 22 - py)
-        if (lane >= 22 - px[s] && lane < 16) R[kDwPitch * (22 - py[s]) + lane] = __builtin_amdgcn_raw_buffer_load_b8(rs[s], lane - (22 - px[s]), 0, 0);
+        if (lane >= 22 - px[s] && lane < 16) R[kDwPitch * (22 - py[s]) + lane] = __builtin_amdgcn_raw_buffer_load_b8(rs, lane - (22 - px[s]), 0, 0);
         wave_sync();
       }
       if (lane < 48) {
         for (int c = 0; c < 22 - px[s]; c++) R[kDwPitch * lane + c] = R[kDwPitch * lane + 2 * (22 - px[s]) - c];
-        for (int c = Lw[s] - (px[s] - 22); c < 45; c++) R[kDwPitch * lane + c] = R[kDwPitch * lane + 2 * (Lw[s] - 1 - (px[s] - 22)) - c];
+        for (int c = LW - (px[s] - 22); c < 45; c++) R[kDwPitch * lane + c] = R[kDwPitch * lane + 2 * (LW - 1 - (px[s] - 22)) - c];
       }
       wave_sync();
     }
@@ -2133,7 +2152,7 @@ __global__ __launch_bounds__(256, 4) void k_describe_win(OrbDev P, FrameSrc src,
         s10 = __builtin_amdgcn_sdot4((int)tab[0][j], (int)w, s10, false);
         s01 = __builtin_amdgcn_sdot4((int)(j == 0 ? tab[0][3] : tab[1][j - 1]), (int)w, s01, false);
       }
-      const int m10 = wave_sum_i32(s10), m01 = wave_sum_i32(s01);
+      const int m10 = wave_sum63_i32(s10), m01 = wave_sum63_i32(s01);
       if ((lane & 3) == s) m10_v = m10, m01_v = m01;
     }
   }
@@ -3045,8 +3064,9 @@ int run_pipeline(vo_orb *h, const uint8_t *dev_images, int n_frames, int w, int 
   const int kp_blocks = (std::min(capacity, h->max_kp) + 63) / 64;
   if (kp_blocks == 0 && dcounts) VO_HIP_CHECK(hipMemsetAsync(dcounts, 0, (size_t)n_frames * sizeof(int), st));
   if (kp_blocks > 0 && od && h->desc_blur != 2) {
-    const int groups = (std::min(capacity, h->max_kp) + 4 * kDwKpw - 1) / (4 * kDwKpw);
-    auto kd = h->desc_blur == 3 ? k_describe_win<false> : k_describe_win<true>;
+    int groups = 0;  // 16-slot groups of the levels' selections
+    for (int l = 0; l < D.nlevels; l++) groups += (D.lv[l].capSel + 4 * kDwKpw - 1) / (4 * kDwKpw);
+    auto kd = k_describe_win;
     hipLaunchKernelGGL(kd, dim3(groups * ((n_frames + 7) / 8) * 8), dim3(256), 0, st, D, S, h->sel.as<uint32_t>(), h->sel_frame,
                        h->nk.as<int>(), dcounts, capacity, dkp, ddesc, groups, n_frames, h->err.as<int>(), T + h->od_tab_off);
   } else if (kp_blocks > 0) {
@@ -3199,7 +3219,7 @@ int vo_orb_set_option(vo_orb *h, int option, int value) {
     return VO_OK;
   }
   if (option == VO_ORB_OPT_DESCRIBE_BLUR) {
-    if (value < 0 || value > 3) {
+    if (value < 0 || value > 2) {
       vo::set_error("vo_orb_set_option(VO_ORB_OPT_DESCRIBE_BLUR): 0 (on demand, inside the descriptor kernel) or 1 (blurred planes)");
       return VO_ERR_INVALID;
     }
