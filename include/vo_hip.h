@@ -770,8 +770,10 @@ int vo_ba_set_option(vo_ba *h, int option, int value);
  * hipGraph (default 0: eager launches are faster on this stack); VO_OPT_POSE_BLOCK = threads per
  * frame of the pose-only solver (0 = automatic, 64, 128, 256); VO_OPT_HAMMING_KERNEL = which form of the all-pairs Hamming
  * kernel vo_hamming_matrix* launch: 0 (default) = int8 matrix-core dot products, 1 = the xor / popcount VALU form (identical
- * results). */
-enum { VO_OPT_BA_GRAPH = 1, VO_OPT_POSE_BLOCK = 2, VO_OPT_HAMMING_KERNEL = 3 };
+ * results); VO_OPT_BA_PAIRS_KERNEL = which kernel gathers the reduced camera system of a LARGE problem
+ * (more than 21 free key-frames): 0 (default) = k_ba_pairs_lds, blocks staged through LDS, 1 = k_ba_pairs, lane = couple (the two
+ * agree to rounding, not bitwise: the order of the sums differs). */
+enum { VO_OPT_BA_GRAPH = 1, VO_OPT_POSE_BLOCK = 2, VO_OPT_HAMMING_KERNEL = 3, VO_OPT_BA_PAIRS_KERNEL = 4 };
 int vo_set_option(int option, int value);
 /* Multi-GPU from C/C++: the all-reduce the sharded LM loop needs (sum of n doubles at dev_buf over all
  * shards, in place, ordered on hip_stream; returns 0).  With RCCL this is

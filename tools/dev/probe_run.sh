@@ -1,12 +1,12 @@
 #!/bin/bash
-# usage: probe_run.sh kernel_substr variant...
+# Developer tool (GPU box): per-launch durations of one kernel of the config-4 global BA (tools/gba_run.py) for a list of settings
+#   tools/dev/probe_run.sh k_ba_pairs "VO_PAIRS=0" "VO_PAIRS=1"
 cd /tmp && export TMPDIR=/tmp
 R=${GRAFT_REPO_ROOT:-/root/repo}
 K=$1; shift
 for v in "$@"; do
-  if [ "$v" = product ]; then unset VO_HIP_LIB; else export VO_HIP_LIB=$R/vo_slam_test_amd/_variants/libvo_$v.so; fi
-  d=$R/gpurun_out/probe_$v; rm -rf $d; mkdir -p $d
-  timeout 300 rocprofv3 --kernel-trace -d $d --output-format csv -- python3 $R/tools/gba_run.py > $d/log.txt 2>&1
+  d=$R/gpurun_out/probe; rm -rf $d; mkdir -p $d
+  env $v timeout 300 rocprofv3 --kernel-trace -d $d --output-format csv -- python3 $R/tools/gba_run.py > $d/log.txt 2>&1
   echo "=== $v: $(grep 'LM it' $d/log.txt | tail -1)"
   python3 - <<PY
 import csv, glob

@@ -10,6 +10,9 @@ import torch  # noqa: F401,E402
 
 from vo_slam_test_amd import _lib, synth  # noqa: E402
 
+import os  # noqa: E402
+if os.environ.get('VO_PAIRS'):
+    _lib.set_option(4, int(os.environ['VO_PAIRS']))  # VO_OPT_BA_PAIRS_KERNEL
 n_kf = int(sys.argv[1]) if len(sys.argv) > 1 else 500
 n_pts = int(sys.argv[2]) if len(sys.argv) > 2 else 50000
 t0 = time.perf_counter()

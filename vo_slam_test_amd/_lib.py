@@ -930,8 +930,8 @@ def sim3_reanchor_points(points, ref, S_rw, S_wr):
 
 def set_option(option, value):
     """vo_set_option: 'ba_graph' (1: hipGraph replay of unsharded LM loops) / 'pose_block' (0, 64, 128, 256) /
-    'hamming_kernel' (0: int8 matrix cores, 1: xor + popcount on the VALU)."""
-    code = {"ba_graph": 1, "pose_block": 2, "hamming_kernel": 3}.get(option, option)
+    'hamming_kernel' (0: int8 matrix cores, 1: xor + popcount on the VALU) / 'ba_pairs_kernel' (0: blocks staged through LDS, 1: lane = couple)."""
+    code = {"ba_graph": 1, "pose_block": 2, "hamming_kernel": 3, "ba_pairs_kernel": 4}.get(option, option)
     check(lib().vo_set_option(int(code), int(value)), "vo_set_option")
 
 

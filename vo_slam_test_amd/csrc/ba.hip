@@ -2245,6 +2245,147 @@ __global__ __launch_bounds__(256) void k_ba_pairs(BaDev B) {
   }
 }
 
+// k_ba_pairs_lds -- the same sums with the blocks staged through LDS (round 6).  k_ba_pairs' lane = couple mapping makes every one
+// of its 21 loads per couple touch 64 different cache lines (9 + 9 + 3 instructions of 16 bytes per lane, each lane in another
+// block), holds the 42 loaded doubles of the couple in flight in registers (208 registers, two wavefronts per SIMD) and walks a
+// pair as a chain of dependent round trips.  Here a wavefront takes 32 couples per step and
+//  * fetches their blocks COOPERATIVELY by global_load_dwordx4 ... lds: nine consecutive lanes read one 144-byte W block (seven
+//    blocks per instruction, ~14 lines instead of 64), three lanes one 48-byte point block; the data never pass through registers,
+//    the block indices reach the fetching lanes by ds_bpermute from the lanes that hold the couple records;
+//  * computes with lane = (couple, half): lanes l and l + 32 share a couple and produce rows 0..2 / 3..5 of its 6 x 6 product from
+//    LDS reads (stride 144 / 48 bytes: conflict-free for 16-byte reads), 18 accumulators each;
+//  * ends with a reduce-scatter butterfly over the 32 couples' lanes (20 exchanges; entry bitreverse5(l & 31) of the half).
+// ~100 registers: three workgroups per CU by LDS (4 x 10.5 KB each).  Deterministic; the order of the sum differs from
+// k_ba_pairs', so the two agree to rounding (1e-16 relative), not bitwise.
+constexpr int kPrStep = 32;                       // couples per step
+constexpr int kPrLds = kPrStep * (144 + 144 + 48);  // 10752 bytes per wavefront
+
+__device__ __forceinline__ double reduce_scatter18(const double (&v0)[18], int r, int &index) {
+  auto level = [&](auto nin, const double *in, double *out, int bit, int width) {
+    constexpr int N = decltype(nin)::value;
+#pragma unroll
+    for (int i = 0; i < (N + 1) / 2; i++) {
+      const double lo = in[2 * i], hi = 2 * i + 1 < N ? in[2 * i + 1] : 0.0;
+      const double keep = bit ? hi : lo, send = bit ? lo : hi;
+      out[i] = keep + __shfl_xor(send, width);
+    }
+  };
+  double v1[9], v2[5], v3[3], v4[2], v5[1];
+  level(std::integral_constant<int, 18>{}, v0, v1, r & 16, 16);
+  level(std::integral_constant<int, 9>{}, v1, v2, r & 8, 8);
+  level(std::integral_constant<int, 5>{}, v2, v3, r & 4, 4);
+  level(std::integral_constant<int, 3>{}, v3, v4, r & 2, 2);
+  level(std::integral_constant<int, 2>{}, v4, v5, r & 1, 1);
+  index = (int)(__brev((unsigned)r) >> 27);
+  return v5[0];
+}
+
+__global__ __launch_bounds__(256) void k_ba_pairs_lds(BaDev B) {
+  __shared__ __attribute__((aligned(16))) unsigned char pr_lds[4][kPrLds];
+  typedef __attribute__((address_space(3))) unsigned char lds_u8;
+  typedef const __attribute__((address_space(1))) unsigned char gmem_u8;
+  const BaState st = *B.st;
+  if (st.done) return;
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
+  int blk = blockIdx.x;  // (XCD split as in k_ba_pairs)
+  if (blk >= B.pair_diag_blocks) {
+    const int q = blk - B.pair_diag_blocks, per_xcd = ((int)gridDim.x - B.pair_diag_blocks) >> 3;
+    blk = B.pair_diag_blocks + (q & 7) * per_xcd + (q >> 3);
+  }
+  const int pr = blk * 4 + wave;
+  const int c = B.pair_cc[2 * pr], cp = B.pair_cc[2 * pr + 1];
+  const int t0 = B.pair_start[2 * pr], t1 = B.pair_start[2 * pr + 1];
+  if (t1 <= t0) return;  // padding (the kernel has no workgroup barrier)
+  gmem_u8 *We = (gmem_u8 *)B.We[st.cur], *Hi = (gmem_u8 *)B.hinv;
+  const double *gls = B.glsc[st.cur];
+  lds_u8 *const LW = (lds_u8 *)pr_lds[wave], *const LP = LW + kPrStep * 144, *const LH = LP + kPrStep * 144;
+  const int r = lane & 31, half = lane >> 5;
+  // roles in the fetch: lane = 9 block + chunk for the W blocks (7 blocks per instruction), 3 block + chunk for the point blocks (21)
+  const int c7 = lane / 9, ch9 = (lane - 9 * c7) * 16, c21 = lane / 3, ch3 = (lane - 3 * c21) * 16;
+  double acc[18], rh[3] = {0, 0, 0};
+#pragma unroll
+  for (int i = 0; i < 18; i++) acc[i] = 0;
+  const bool diag = c == cp;
+  int4 rec = B.pair_e[min(t0 + r, t1 - 1)];  // (couple of lanes r and r + 32; past the end: the last one, its sums are zeroed)
+  for (int t = t0; t < t1; t += kPrStep) {
+    const int4 nxt = B.pair_e[min(t + kPrStep + r, t1 - 1)];
+    double g0 = 0, g1 = 0, g2 = 0;
+    if (diag) g0 = gls[3 * rec.z], g1 = gls[3 * rec.z + 1], g2 = gls[3 * rec.z + 2];
+#pragma unroll
+    for (int q = 0; q < 5; q++) {
+      const int ci = min(7 * q + c7, kPrStep - 1);
+      const unsigned e = (unsigned)__builtin_amdgcn_ds_bpermute(4 * ci, rec.x), ep = (unsigned)__builtin_amdgcn_ds_bpermute(4 * ci, rec.y);
+      if (c7 < 7 && 7 * q + c7 < kPrStep) {
+        __builtin_amdgcn_global_load_lds(We + (e * 144u + (unsigned)ch9), LW + 1008 * q, 16, 0, 0);
+        __builtin_amdgcn_global_load_lds(We + (ep * 144u + (unsigned)ch9), LP + 1008 * q, 16, 0, 0);
+      }
+    }
+#pragma unroll
+    for (int q = 0; q < 2; q++) {
+      const int ci = min(21 * q + c21, kPrStep - 1);
+      const unsigned j = (unsigned)__builtin_amdgcn_ds_bpermute(4 * ci, rec.z);
+      if (c21 < 21 && 21 * q + c21 < kPrStep) __builtin_amdgcn_global_load_lds(Hi + (j * 48u + (unsigned)ch3), LH + 1008 * q, 16, 0, 0);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    const bool ok = t + r < t1;
+    typedef __attribute__((address_space(3))) double2_t lds_d2;
+    typedef __attribute__((address_space(3))) double lds_d;
+    const lds_d2 *hv = (const lds_d2 *)(LH + 48 * r);
+    const double2_t ha = hv[0], hb = hv[1], hc = hv[2];
+    const double h00 = ok ? ha.x : 0.0, h01 = ok ? ha.y : 0.0, h02 = ok ? hb.x : 0.0, h11 = ok ? hb.y : 0.0, h12 = ok ? hc.x : 0.0,
+                 h22 = ok ? hc.y : 0.0;
+    const lds_d *wl = (const lds_d *)(LW + 144 * r) + 3 * half;  // W_e[a][k] = w[6 k + a], rows a = 3 half + i
+    double Y[3][3];
+#pragma unroll
+    for (int i = 0; i < 3; i++) {
+      const double w0 = wl[i], w1 = wl[6 + i], w2 = wl[12 + i];
+      Y[i][0] = w0 * h00 + w1 * h01 + w2 * h02;
+      Y[i][1] = w0 * h01 + w1 * h11 + w2 * h12;
+      Y[i][2] = w0 * h02 + w1 * h12 + w2 * h22;
+    }
+    const lds_d2 *wp2 = (const lds_d2 *)(LP + 144 * r);
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+#pragma unroll
+      for (int bb = 0; bb < 3; bb++) {
+        const double2_t p = wp2[3 * k + bb];  // W_e'[2 bb][k], W_e'[2 bb + 1][k]
+#pragma unroll
+        for (int i = 0; i < 3; i++) {
+          acc[6 * i + 2 * bb] += Y[i][k] * p.x;
+          acc[6 * i + 2 * bb + 1] += Y[i][k] * p.y;
+        }
+      }
+    }
+    if (diag) {  // the camera's own edges -> its part of the right-hand side
+#pragma unroll
+      for (int i = 0; i < 3; i++) rh[i] += Y[i][0] * g0 + Y[i][1] * g1 + Y[i][2] * g2;
+    }
+    rec = nxt;
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");  // (the next step's blocks overwrite these)
+    __builtin_amdgcn_wave_barrier();
+  }
+  // block (row c', column c) of the lower triangle: entry (6c'+b, 6c+a) = -G[a][b]
+  int idx;
+  const double mine = reduce_scatter18(acc, r, idx);
+  if (idx < 18) {
+    const int i = idx / 6, b = idx - 6 * i, a = 3 * half + i;
+    B.Sd[(long long)(6 * cp + b) * B.ld + 6 * c + a] = -mine;
+  }
+  if (diag) {
+#pragma unroll
+    for (int o = 16; o >= 1; o >>= 1) {
+#pragma unroll
+      for (int i = 0; i < 3; i++) rh[i] += __shfl_xor(rh[i], o);
+    }
+    double r1 = 0;
+#pragma unroll
+    for (int i = 0; i < 3; i++) r1 = (r == i) ? rh[i] : r1;
+    if (r < 3) B.Sd[(long long)B.ld * B.ld + 6 * c + 3 * half + r] = -r1;  // row ld: -(sum_e Y_e gl''_j); completed by k_ba_assemble_large
+  }
+}
+
 __global__ __launch_bounds__(256) void k_ba_partials_large(BaDev B) {
   __shared__ double red[8];
   const BaState st0 = *B.st;
@@ -2836,7 +2977,7 @@ __global__ __launch_bounds__(256) void k_ba_setup(BaDev B, int set_active, uint8
 // host
 // ============================================================================================
 // process-wide developer knobs (vo_set_option)
-static std::atomic<int> g_opt_ba_graph{0}, g_opt_pose_block{0};
+static std::atomic<int> g_opt_ba_graph{0}, g_opt_pose_block{0}, g_opt_pairs_kernel{0};
 
 // A host array that lives either in its own vector or -- the sorted edge arrays of an LDS-sized problem -- directly in the
 // page-locked block build_device uploads from (ba_fill_problem writes them once, where the DMA reads them: at config 3 the
@@ -3417,7 +3558,12 @@ int launch_linearize_large(vo_ba *h) {
   hipLaunchKernelGGL(k_ba_hinv_large, dim3((D.n_local + 255) / 256), dim3(256), 0, st, D);
   hipLaunchKernelGGL(k_ba_cams_large, dim3(std::max(1, h->nf * D.n_cchunks)), dim3(kCamChunk), 0, st, D);
   hipLaunchKernelGGL(k_ba_zero_large, dim3(D.n_ltiles + 8), dim3(256), 0, st, D);
-  if (D.n_pairs > 0) hipLaunchKernelGGL(k_ba_pairs, dim3(D.n_pairs / 4), dim3(256), 0, st, D);  // n_pairs: a multiple of 32
+  if (D.n_pairs > 0) {  // n_pairs: a multiple of 32
+    if (g_opt_pairs_kernel.load(std::memory_order_relaxed) == 0)
+      hipLaunchKernelGGL(k_ba_pairs_lds, dim3(D.n_pairs / 4), dim3(256), 0, st, D);
+    else
+      hipLaunchKernelGGL(k_ba_pairs, dim3(D.n_pairs / 4), dim3(256), 0, st, D);
+  }
   hipLaunchKernelGGL(k_ba_partials_large, dim3(std::max(1, (h->nf * 27 + 255) / 256)), dim3(256), 0, st, D);
   VO_HIP_CHECK(hipGetLastError());
   return VO_OK;
@@ -3951,6 +4097,13 @@ int vo_set_option(int option, int value) {
         return VO_ERR_INVALID;
       }
       g_opt_pose_block.store(value);
+      return VO_OK;
+    case VO_OPT_BA_PAIRS_KERNEL:
+      if (value != 0 && value != 1) {
+        vo::set_error("vo_set_option(VO_OPT_BA_PAIRS_KERNEL): 0 (blocks staged through LDS) or 1 (lane = couple, register loads)");
+        return VO_ERR_INVALID;
+      }
+      g_opt_pairs_kernel.store(value);
       return VO_OK;
     case VO_OPT_HAMMING_KERNEL:
       if (value != 0 && value != 1) {
