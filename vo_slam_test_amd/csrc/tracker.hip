@@ -303,6 +303,13 @@ struct vo_tracker {
   hipStream_t st = nullptr, est = nullptr;
   bool own_st = false, own_est = false;
   hipEvent_t ev_extract = nullptr, ev_build = nullptr;
+  // host-buffer calls: the depth image is first read BEHIND the extraction (vo_frames_build_dev), so its upload goes on a copy
+  // stream of its own, issued after the extraction has been enqueued: the key-points are being extracted while the host (pageable
+  // memory: the runtime stages it synchronously) and the copy engine move the depth -- two thirds of the bytes of a frame
+  hipStream_t cst = nullptr;
+  hipEvent_t ev_depth = nullptr;
+  const void *pend_depth = nullptr;
+  size_t pend_depth_bytes = 0;
   bool have_build = false;
   int B = 0, kcap = 0, cap = 0, n_levels = 0, n_last = 0, n_local = 0, nq_last = 0, nq_local = 0;
   float sf[16] = {0};
@@ -477,16 +484,22 @@ int stage_front(vo_tracker *t, const uint8_t *dev_images, int img_pitch, size_t 
   }
   VO_HIP_CHECK(hipEventRecord(t->ev_extract, est));
   if (est != st) VO_HIP_CHECK(hipStreamWaitEvent(st, t->ev_extract, 0));
+  if (t->pend_depth) {  // (see vo_tracker::cst)
+    if (t->have_build) VO_HIP_CHECK(hipStreamWaitEvent(t->cst, t->ev_build, 0));  // the last call's depth has been consumed
+    const void *src = t->pend_depth;
+    t->pend_depth = nullptr;
+    VO_HIP_CHECK(hipMemcpyAsync(t->depth.p, src, t->pend_depth_bytes, hipMemcpyHostToDevice, t->cst));
+    VO_HIP_CHECK(hipEventRecord(t->ev_depth, t->cst));
+    VO_HIP_CHECK(hipStreamWaitEvent(st, t->ev_depth, 0));
+  }
   // ---- Frame::Frame post-processing
   {
     StageTimer tm(t, 1, st);
     VO_CHECK(vo_frames_build_dev(t->frames, 0, B, t->kps.as<vo_keypoint>(), t->desc.as<uint8_t>(), t->cnt.as<int32_t>(),
                                  t->kcap, dev_depth, depth_kind, depth_frame_stride, depth_pitch, c.inv_depth_scale, st));
   }
-  if (est != st) {
-    VO_HIP_CHECK(hipEventRecord(t->ev_build, st));
-    t->have_build = true;
-  }
+  VO_HIP_CHECK(hipEventRecord(t->ev_build, st));
+  t->have_build = true;
   return VO_OK;
 }
 
@@ -741,7 +754,9 @@ int vo_tracker_create(vo_tracker **out, const vo_tracker_config *cfg) {
   }
   if ((rc = vo_orb_set_stream(t->orb, t->est)) != VO_OK) return fail(rc);
   if (hipEventCreateWithFlags(&t->ev_extract, hipEventDisableTiming) != hipSuccess ||
-      hipEventCreateWithFlags(&t->ev_build, hipEventDisableTiming) != hipSuccess)
+      hipEventCreateWithFlags(&t->ev_build, hipEventDisableTiming) != hipSuccess ||
+      hipEventCreateWithFlags(&t->ev_depth, hipEventDisableTiming) != hipSuccess ||
+      hipStreamCreateWithFlags(&t->cst, hipStreamNonBlocking) != hipSuccess)
     return fail(VO_ERR_HIP);
   t->n_levels = vo_orb_levels(t->orb);
   if ((rc = vo_orb_scale_factors(t->orb, t->sf, nullptr)) != VO_OK) return fail(rc);
@@ -768,10 +783,12 @@ void vo_tracker_destroy(vo_tracker *t) {
   if (!t) return;
   if (t->st) (void)hipStreamSynchronize(t->st);
   if (t->est && t->est != t->st) (void)hipStreamSynchronize(t->est);
+  if (t->cst) (void)hipStreamSynchronize(t->cst);
   for (hipEvent_t e : t->tev)
     if (e) (void)hipEventDestroy(e);
   if (t->ev_extract) (void)hipEventDestroy(t->ev_extract);
   if (t->ev_build) (void)hipEventDestroy(t->ev_build);
+  if (t->ev_depth) (void)hipEventDestroy(t->ev_depth);
   if (t->frames) vo_frames_destroy(t->frames);
   if (t->orb) vo_orb_destroy(t->orb);
   for (DevBuf *b : {&t->kps, &t->desc, &t->cnt, &t->images, &t->depth, &t->q0_flags, &t->q0_u, &t->q0_v, &t->q0_aux, &t->q0_level,
@@ -783,6 +800,7 @@ void vo_tracker_destroy(vo_tracker *t) {
     b->release();
   if (t->own_st && t->st) (void)hipStreamDestroy(t->st);
   if (t->own_est && t->est) (void)hipStreamDestroy(t->est);
+  if (t->cst) (void)hipStreamDestroy(t->cst);
   delete t;
 }
 
@@ -855,7 +873,8 @@ static int upload_host_frames(vo_tracker *t, const uint8_t *images, const void *
   // uploads on the extraction stream (the depth is first read behind the extraction, which the tracking stream waits for)
   if (t->est != t->st && t->have_build) VO_HIP_CHECK(hipStreamWaitEvent(t->est, t->ev_build, 0));
   VO_HIP_CHECK(hipMemcpyAsync(t->images.p, images, B * npx, hipMemcpyHostToDevice, t->est));
-  if (dsz) VO_HIP_CHECK(hipMemcpyAsync(t->depth.p, depth, B * npx * dsz, hipMemcpyHostToDevice, t->est));
+  // (the depth follows behind the extraction's launches, on the copy stream: stage_front)
+  t->pend_depth = dsz ? depth : nullptr, t->pend_depth_bytes = B * npx * dsz;
   *npx_out = npx, *dsz_out = dsz;
   return VO_OK;
 }
