@@ -371,6 +371,15 @@ def main():
     sb.update(tracking_bytes_per_frame(nkp, n_q0, n_q1, n_obs2))
     ext_keys = ("pyramid", "fast", "octree", "blur", "describe")
     sb["extract"] = sum(sb[k] for k in ext_keys)
+    # With the blur inside the descriptor kernel (VO_ORB_OPT_DESCRIBE_BLUR = 0, the default) there is no blur launch: the `describe`
+    # stage then does the work of BOTH rows of SURVEY 8d -- "read for blur + write blurred" (2 x 950 532 B per frame) and the
+    # orientation / descriptor gathers + outputs ((749 + 512 + 60) B per key-point) -- and is priced with their sum, so that the
+    # stages still add up to B_ext; `describe_gathers_only_frac` below is the same kernel against the gather row alone.
+    describe_covers_blur = serial_stage_ms.get("blur", 0.0) <= 0.02
+    sb_describe_gathers = sb["describe"]
+    if describe_covers_blur:
+        sb["describe"] += sb["blur"]
+        sb["blur"] = 0
     # The dominant kernel: the longest single-kernel stage of the path in the timed region (HIP events on the launching
     # stream around every kernel; with two batches in flight the other batch's kernels share the CUs with it, which
     # stretches every launch while the step gets shorter -- the same kernel with one batch in flight is under "alone")
@@ -394,6 +403,11 @@ def main():
                 "bytes_per_launch": sb[dom] * B, "avg_launch_ms": round(stage_ms[dom], 4),
                 "alone": {"avg_launch_ms": round(serial_stage_ms[dom], 4), "achieved": round(alone, 2),
                           "frac": round(alone / HBM_PEAK_GBS, 5), "note": "the same kernel with one batch in flight"}}
+    if describe_covers_blur:
+        roofline["describe_bytes_note"] = ("describe = k_describe_win, blur included: priced with SURVEY 8d's blur row (2 x 950 532 B per "
+                                           "frame) + gather / output row ((749 + 512 + 60) B per key-point); against the gather row alone "
+                                           "its alone_frac is " + str(round(sb_describe_gathers * B / (serial_stage_ms["describe"] * 1e-3) / 1e9
+                                                                            / HBM_PEAK_GBS, 5)))
     roofline["per_kernel"] = {
         k: {"bytes_per_launch": sb[k] * B, "avg_launch_ms": round(stage_ms[k], 4),
             "frac": round(sb[k] * B / (stage_ms[k] * 1e-3) / 1e9 / HBM_PEAK_GBS, 5),
@@ -560,7 +574,7 @@ def main():
             "frames_per_s": round(B * nbf / tbf, 1), "ms_per_step": round(tbf / nbf * 1e3, 4),
             "stage_ms_per_launch": {k: round(v, 4) for k, v in bms.items() if k != "offsets"},
             "kernels": {"hamming": "k_hamming_mfma (int8 matrix-core dot products; vo_set_option(VO_OPT_HAMMING_KERNEL, 1) = the VALU form)",
-                        "blur": "none: k_describe<., true> blurs the 45 x 45 window of every key-point itself (int8 matrix cores; "
+                        "blur": "none: k_describe_win stages the 45 x 45 raw window of a key-point once and blurs it in place (int8 matrix cores; "
                                 "VO_ORB_OPT_DESCRIBE_BLUR = 1: blurred planes by k_blur_mfma, VO_ORB_OPT_BLUR_KERNEL = 1: by k_blur_groups)"},
             "hamming_roofline": {"bound": "hbm (write stream)", "bytes_per_launch": 2064000 * B,
                                  "achieved": round(2064000 * B / (bms["hamming"] * 1e-3) / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",

@@ -80,11 +80,12 @@ int vo_orb_set_stream(vo_orb *h, void *hip_stream);
 /* VO_ORB_OPT_BLUR_KERNEL (default 0): which kernel blurs the levels (identical planes either way): 0 = k_blur_mfma, both passes
  * of the 7x7 filter as int8 matrix-core products with banded weight matrices (levels of at least 64 x 16 pixels with 16-byte
  * aligned rows; the others fall back by themselves), 1 = k_blur_groups, the dot-product form on the VALU. */
-/* VO_ORB_OPT_DESCRIBE_BLUR (default 0): 0 = no blurred pyramid is made: the descriptor kernel stages the 45 x 45 raw window of a
- * key-point and blurs it itself (int8 matrix-core products, the arithmetic of the plane kernels: identical descriptors);
+/* VO_ORB_OPT_DESCRIBE_BLUR (default 0): 0 = no blurred pyramid is made: the descriptor kernel (k_describe_win) brings the
+ * 45 x 45 raw window of a key-point into LDS once, takes the orientation moments from it, blurs it in place (int8 matrix-core
+ * products, the arithmetic of the plane kernels: identical descriptors) and runs the tests on it;
  * vo_orb_get_level(blurred = 1) then makes the planes when it is asked for them.  1 = the blurred planes are made for every
- * level of every frame (VO_ORB_OPT_BLUR_KERNEL picks the kernel) and the descriptor kernel reads its windows from them.  The
- * fused level pass (VO_ORB_OPT_FUSED_LEVEL_PASS) makes its own blurred tiles: with it the planes are always used. */
+ * level of every frame (VO_ORB_OPT_BLUR_KERNEL picks the kernel) and the descriptor kernel (k_describe) reads its windows from
+ * them.  The fused level pass (VO_ORB_OPT_FUSED_LEVEL_PASS) makes its own blurred tiles: with it the planes are always used. */
 enum { VO_ORB_OPT_FUSED_LEVEL_PASS = 1, VO_ORB_OPT_EARLY_LEVEL0 = 2, VO_ORB_OPT_BLUR_KERNEL = 3, VO_ORB_OPT_DESCRIBE_BLUR = 4 };
 int vo_orb_set_option(vo_orb *h, int option, int value);
 /* (tests and tools) the fused pass's plan for one level of a width x height image: out = {takes the fused pass, tile pitch,

@@ -572,8 +572,16 @@ def test_pose_graph_config4_size_properties(vo):
 
 # ------------------------------------------------------------------ large reduced systems (global-BA path)
 
+@pytest.fixture(params=[0, 1], ids=["pairs-lds", "pairs-lane-per-couple"])
+def pairs_kernel(vo, request):
+    """both gather kernels of the large path (vo_set_option(VO_OPT_BA_PAIRS_KERNEL)): k_ba_pairs_lds (default), k_ba_pairs"""
+    vo.set_option("ba_pairs_kernel", request.param)
+    yield request.param
+    vo.set_option("ba_pairs_kernel", 0)
+
+
 @pytest.mark.parametrize("n_kf,n_pts,seed", [(23, 600, 3), (30, 900, 4)])
-def test_large_system_local_ba_matches_oracle(vo, orc, n_kf, n_pts, seed):
+def test_large_system_local_ba_matches_oracle(vo, orc, pairs_kernel, n_kf, n_pts, seed):
     """more than 21 free key-frames: per-edge W blocks, pair-gathered Schur complement, HBM-resident
     reduced system through the blocked Cholesky -- same schedule and tolerances as the LDS path"""
     from vo_slam_test_amd import synth
@@ -592,7 +600,7 @@ def test_large_system_local_ba_matches_oracle(vo, orc, n_kf, n_pts, seed):
     assert np.allclose([sums[0].final_cost, sums[1].final_cost], [osums[0].final_cost, osums[1].final_cost], rtol=1e-8)
 
 
-def test_large_system_with_an_isolated_straddling_camera(vo, orc):
+def test_large_system_with_an_isolated_straddling_camera(vo, orc, pairs_kernel):
     """64 is not a multiple of 6, so the 6x6 diagonal block of slot 10 (rows 60..65) lies in tiles (0,0), (1,0)
     and (1,1).  Here slot 10 is covisible with slot 30 only and no pair joins tiles 0 and 1 otherwise: tile (1,0) must be
     in the plan all the same, or rows 64-65 x cols 60-63 of that camera block are dropped silently."""

@@ -105,10 +105,12 @@ def test_g8_sim3_and_loop_searches(vo):
     assert cnt == int(g["sim3proj_n"]) and np.array_equal(assigned, g["sim3proj"])
 
 
-def test_g9_global_ba_config4(vo):
+@pytest.mark.parametrize("pairs", [0, 1], ids=["pairs-lds", "pairs-lane-per-couple"])
+def test_g9_global_ba_config4(vo, pairs):
     """BASELINE config 4 size (500 key-frames, 50 000 points, ~620 k edges, 2994 x 2994 reduced system):
-    two LM iterations against the CPU oracle's result (tests/golden/make_g9_global_ba.py)."""
+    two LM iterations against the CPU oracle's result (tests/golden/make_g9_global_ba.py), with either gather kernel."""
     from vo_slam_test_amd import synth
+    vo.set_option("ba_pairs_kernel", pairs)
     g = np.load(G / "g9_global_ba.npz")
     pr = synth.make_global_ba_problem(0)
     assert len(pr["e_cam"]) == int(g["n_edges"])
@@ -117,6 +119,7 @@ def test_g9_global_ba_config4(vo):
     s = ba.solve(float(np.sqrt(np.float32(5.991))), float(np.sqrt(np.float32(7.815))), int(g["iters"]))
     poses, pts = ba.state()
     ba.close()
+    vo.set_option("ba_pairs_kernel", 0)
     assert (s.iterations, s.accepted) == (int(g["iters"]), int(g["accepted"])), (s.iterations, s.accepted, s.termination, s.initial_cost, s.final_cost, s.final_radius, vo.lib().vo_last_error())
     assert abs(s.initial_cost - float(g["initial_cost"])) <= 1e-10 * float(g["initial_cost"])
     assert abs(s.final_cost - float(g["final_cost"])) <= 1e-8 * float(g["final_cost"])

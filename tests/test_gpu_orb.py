@@ -7,7 +7,7 @@ from vo_slam_test_amd import synth
 pytestmark = pytest.mark.gpu
 
 
-MODES = ["on-demand-blur", "on-demand-blur-2", "separate", "separate-valu-blur", "fused"]
+MODES = ["on-demand-blur", "separate", "separate-valu-blur", "fused"]
 
 
 def _set_mode(e, mode):
@@ -15,7 +15,7 @@ def _set_mode(e, mode):
     VO_ORB_OPT_DESCRIBE_BLUR = 0) --, blurred planes by the matrix-core kernel, the same with the VALU blur
     (VO_ORB_OPT_BLUR_KERNEL = 1), and the opt-in fused per-level pass (VO_ORB_OPT_FUSED_LEVEL_PASS)"""
     e.set_fused(int(mode == "fused"))
-    e.set_describe_blur({"on-demand-blur": 0, "on-demand-blur-2": 2}.get(mode, 1))
+    e.set_describe_blur(0 if mode == "on-demand-blur" else 1)
     e.set_blur_kernel(1 if mode == "separate-valu-blur" else 0)
 
 

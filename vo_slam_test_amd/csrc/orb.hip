@@ -1528,7 +1528,7 @@ struct DescRec {
   int m10, m01;                  // intensity-centroid moments
   float a, b;                    // cos, sin of the steering angle
   int bytewise, pad;             // level-0 rows of the caller's image are not 16-byte aligned
-  int wh, pad2;                  // on-demand blur (OD): level width | height << 16; blur_base = the level plane, bpitch = its bytes
+  int wh, pad2;                  // level width | height << 16 (unused by this kernel)
 };
 
 // LDS values every lane reads from the same address, moved to scalar registers
@@ -1554,10 +1554,7 @@ typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 // all 32 banks instead of 16 -- against VERDICT r3's reading of the 48 % bank-conflict cycles: 0.746 / 0.747 / 0.749 ms per
 // 1024 frames for 64 / 80 / 96, i.e. no effect: the LDS pipe is not what the kernel waits for, its window fetches are.)
 constexpr int kWinPitch = 64;
-constexpr int kOdPitch = 80;         // on-demand blur: row pitch of the staged raw window and of the blurred window written over it
-                                     // (20 dwords: 16 rows at this pitch start in 16 different banks; at 64 bytes every fourth row
-                                     // shared its banks with the operand reads and the blurred stores 8-way)
-constexpr int kWinBytes = 48 * kOdPitch;  // 39 rows at 64 bytes (blurred planes) / 45 + 3 rows at kOdPitch (on-demand blur)
+constexpr int kWinBytes = 40 * kWinPitch;  // 39 rows
 
 // Stage the ROWS x (<= 64 - 15) byte window whose top-left pixel is `origin` (row pitch `pitch`, rows 16-byte
 // aligned) into LDS with 16-byte loads: lane + 64 j -> row (lane >> 2) + 16 j, chunk lane & 3, so the LDS
@@ -1624,25 +1621,13 @@ constexpr int kDescNK = 2;  // key-points in flight per wavefront of k_describe 
 //     scatter over it); lane t rotates the pattern points of tests t, t+64, t+128, t+192 (packed FP32
 //     multiplies and adds, rounding by the 1.5 * 2^23 constant so that the integer falls out of the mantissa
 //     and feeds the address arithmetic), eight LDS byte gathers, four 64-bit ballots are the descriptor.
-// OD ("on demand", round 6): the blurred planes are never made.  Phase 3 stages the 45 x 45 RAW window around the key-point
-// (buffer loads with hardware range checking at the exact origin px - 22: byte-aligned 16-byte loads are legal on gfx950,
-// tools/microbench/unaligned_load.hip) and blurs it in place into the 39 x 39 window the tests read, with the int8
-// matrix-core scheme of k_blur_mfma on v_mfma_i32_16x16x64_i8: row pass = 3 x 3 products (16 rows x 64 source columns against
-// the band of 16 output columns; the accumulator -- column on the lane, four rows per 16-row tile in its registers -- is the
-// A operand of the column pass as it stands: K slot 4 T + r of lane quarter q = row 16 T + 4 q + r), column pass = 3 x 3 x 2
-// byte planes; all constants ride in spare K slots (two bytes 0x81 per staged row against weight 64 give the +128 of the row
-// pass; the fourth dword of the column pass's A operand is a per-lane constant against weights 16 / 127: +128 on the low
-// plane, +33152 on the high one = the three offsets and the rounding), so no accumulator is ever initialised.  BORDER_REFLECT_101:
-// rows by address, columns by a byte fix-up of the staged rows (key-points within 22 px of the left / right edge only).
-// The blur of a whole pyramid (1.9 GB of traffic, 0.51 ms per 1024 frames) becomes ~1.5 M blurred pixels per frame computed
-// where they are read.
-template <int NK, bool OD>  // key-points a wave keeps in flight in phases 1 and 3; on-demand blur
-// (4 waves per SIMD declared: the register budget <= 256 keeps the MFMA results in VGPRs; at the default they land in AGPRs and
-//  every result register costs a v_accvgpr_read -- 108 per key-point)
+// (The blur-on-demand form of this kernel -- phase 3 on the 45 x 45 RAW window -- was round 6's first step and is superseded by
+//  k_describe_win below, which visits the window once; tools/attic/k_describe_od_r06.hip.txt.)
+template <int NK>  // key-points a wave keeps in flight in phases 1 and 3
 __global__ __launch_bounds__(256, 4) void k_describe(OrbDev P, FrameSrc src, const uint32_t *sel,
                                                   int sel_per_frame, const int *nk, int *counts, int capacity,
                                                   vo_keypoint *kps, uint8_t *desc, int lv0_bytewise,
-                                                  int batches_per_frame, int n_frames, int *err_flag, const int *od_tab) {
+                                                  int batches_per_frame, int n_frames, int *err_flag) {
   __shared__ DescRec rec[64];
   __shared__ __attribute__((aligned(16))) uint8_t win_lds[4][NK][kWinBytes];
   const int tid = threadIdx.x, lane = tid & 63;
@@ -1694,10 +1679,6 @@ __global__ __launch_bounds__(256, 4) void k_describe(OrbDev P, FrameSrc src, con
     r.pad = (px - kEdge) | ((py - kEdge) << 16);
     r.pitch = pitch, r.bpitch = bp;
     r.wh = L.w | (L.h << 16), r.pad2 = 0;
-    if (OD) {  // the raw level plane of this frame and its size in bytes (the range the buffer loads check)
-      r.blur_base = (unsigned long long)(uintptr_t)img;
-      r.bpitch = L.h * pitch;
-    }
     r.m10 = r.m01 = 0;
     r.a = r.b = 0.f;
     r.bytewise = l == 0 && lv0_bytewise;
@@ -1785,141 +1766,7 @@ __global__ __launch_bounds__(256, 4) void k_describe(OrbDev P, FrameSrc src, con
   __syncthreads();
   // ---- phase 3: descriptors
   constexpr float kMagic = 12582912.f;  // 1.5 * 2^23: x + kMagic has rint(x) + 0x400000 in its low 24 bits
-  // the band operands of the on-demand blur (per-lane constants: 6 x 4 registers + 2) from the table built with the handle
-  typedef int od_i32x4 __attribute__((ext_vector_type(4)));
-  od_i32x4 Bh[3], Bv[3];
-  int A3lo = 0, A3hi = 0;
-  if (OD) {
-    const od_i32x4 *tb = reinterpret_cast<const od_i32x4 *>(od_tab);
-#pragma unroll
-    for (int X = 0; X < 3; X++) Bh[X] = tb[64 * X + lane], Bv[X] = tb[64 * (3 + X) + lane];
-    const int kq = lane >> 4;
-    A3lo = kq < 2 ? 0x01010101 : 0;           // 8 slots x 1 x 16 = 128
-    A3hi = kq < 2 ? 0x05050505 : 0x20202020;  // 8 x 5 x 16 + 8 x 32 x 127 = 33152 = (257 * 128 * 257 + 2^15 - 128) / 256
-    // columns 48..63 of every staged row are never loaded: bytes 0x80 (= 0 after the operand's xor), the last two 0x81 (= +1:
-    // against weights 64 + 64 they add the row pass's 128).  Written once per wavefront for its NK slots (phase 1 used the same
-    // memory at another pitch); neither a stage nor a blurred window touches them afterwards.
-    const u32x4 cst = {0x80808080u, 0x80808080u, 0x80808080u, 0x81818080u};
-    if (lane < 48) {
-#pragma unroll
-      for (int s = 0; s < NK; s++) *(__attribute__((address_space(3))) u32x4 *)((lds_u8 *)win_lds[wave][s] + kOdPitch * lane + 48) = cst;
-    }
-    wave_sync();
-  }
-  for (int k = k0; OD && k < k1; k += NK) {
-    u32x4 wv[NK][3];
-    int pxs[NK], pys[NK], wls[NK];
-#pragma unroll
-    for (int s = 0; s < NK; s++) {
-      const int kk = min(k + s, k1 - 1);
-      const int xy0 = uni_i32(rec[kk].pad), wh = uni_i32(rec[kk].wh), pitch = uni_i32(rec[kk].pitch);
-      const int px = (xy0 & 0xffff) + kEdge, py = (xy0 >> 16) + kEdge, Lh = wh >> 16;
-      pxs[s] = px, pys[s] = py, wls[s] = wh & 0xffff;
-      const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void *)uni_ptr(rec[kk].blur_base), 0, uni_i32(rec[kk].bpitch), 0x00020000);
-#pragma unroll
-      for (int j = 0; j < 3; j++) {
-        const int idx = lane + 64 * j, row = min(idx / 3, 44), chunk = idx % 3;
-        const int y = reflect101_near(py - 22 + row, Lh);
-        // (an offset in front of the plane is a huge unsigned one: the range check returns zeros, as it does behind the plane)
-        wv[s][j] = __builtin_amdgcn_raw_buffer_load_b128(rs, __mul24(y, pitch) + (px - 22) + 16 * chunk, 0, 0);
-      }
-    }
-#pragma unroll
-    for (int s = 0; s < NK; s++)
-#pragma unroll
-      for (int j = 0; j < 3; j++) {
-        const int idx = lane + 64 * j, row = idx / 3, chunk = idx % 3;
-        if (row < 48) *(__attribute__((address_space(3))) u32x4 *)((lds_u8 *)win_lds[wave][s] + kOdPitch * row + 16 * chunk) = wv[s][j];
-      }
-    wave_sync();
-    uint32_t t[NK][8];
-#pragma unroll
-    for (int s = 0; s < NK; s++) {
-      lds_u8 *R = (lds_u8 *)win_lds[wave][s];
-      const int px = pxs[s], Lw = wls[s];
-      if (px < 22 || px + 22 > Lw - 1) {  // uniform: BORDER_REFLECT_101 of the columns beyond the plane (at most six a side)
-        if (px < 22 && pys[s] <= 22) {
-          // a window over the plane's first pixel: the first chunk of raw row 0 starts in front of the plane, and the range check
-          // drops the WHOLE 16-byte load, its in-plane bytes included -- they are fetched one by one (staged row 22 - py)
-          const int kk = min(k + s, k1 - 1);
-          const __amdgpu_buffer_rsrc_t rs0 = __builtin_amdgcn_make_buffer_rsrc((void *)uni_ptr(rec[kk].blur_base), 0, uni_i32(rec[kk].bpitch), 0x00020000);
-          if (lane >= 22 - px && lane < 16) R[kOdPitch * (22 - pys[s]) + lane] = __builtin_amdgcn_raw_buffer_load_b8(rs0, lane - (22 - px), 0, 0);
-          wave_sync();
-        }
-        if (lane < 48) {
-          for (int c = 0; c < 22 - px; c++) R[kOdPitch * lane + c] = R[kOdPitch * lane + 2 * (22 - px) - c];
-          for (int c = Lw - (px - 22); c < 45; c++) R[kOdPitch * lane + c] = R[kOdPitch * lane + 2 * (Lw - 1 - (px - 22)) - c];
-        }
-        wave_sync();
-      }
-      // row pass: A = 16 staged rows x 64 columns (the lane's quarter: 16 bytes), xor 0x80 = pixel - 128
-      const int m = lane & 15, kq = lane >> 4;
-      od_i32x4 a[3];
-#pragma unroll
-      for (int T = 0; T < 3; T++) {
-        const u32x4 v = *(const __attribute__((address_space(3))) u32x4 *)(R + kOdPitch * (16 * T + m) + 16 * kq);
-        a[T] = od_i32x4{(int)(v.x ^ 0x80808080u), (int)(v.y ^ 0x80808080u), (int)(v.z ^ 0x80808080u), (int)(v.w ^ 0x80808080u)};
-      }
-      wave_sync();  // (every lane has its rows: the blurred window may now overwrite the stage)
-      const od_i32x4 Z = {0, 0, 0, 0};
-#pragma unroll
-      for (int X = 0; X < 3; X++) {
-        od_i32x4 lo, hi;
-#pragma unroll
-        for (int T = 0; T < 3; T++) {
-          const od_i32x4 acc = __builtin_amdgcn_mfma_i32_16x16x64_i8(a[T], Bh[X], Z, 0, 0, 0);  // row sums - 2^15, rows 16 T + 4 q + r
-          const unsigned t01 = __builtin_amdgcn_perm((unsigned)acc[1], (unsigned)acc[0], 0x05010400u);
-          const unsigned t23 = __builtin_amdgcn_perm((unsigned)acc[3], (unsigned)acc[2], 0x05010400u);
-          lo[T] = (int)(__builtin_amdgcn_perm(t23, t01, 0x05040100u) ^ 0x80808080u);
-          hi[T] = (int)__builtin_amdgcn_perm(t23, t01, 0x07060302u);
-        }
-        lo[3] = A3lo, hi[3] = A3hi;
-#pragma unroll
-        for (int Y = 0; Y < 3; Y++) {
-          const od_i32x4 al = __builtin_amdgcn_mfma_i32_16x16x64_i8(lo, Bv[Y], Z, 0, 0, 0);
-          const od_i32x4 ah = __builtin_amdgcn_mfma_i32_16x16x64_i8(hi, Bv[Y], Z, 0, 0, 0);
-          unsigned v[4];
-#pragma unroll
-          for (int j = 0; j < 4; j++) v[j] = ((unsigned)ah[j] << 8) + (unsigned)al[j];
-          const unsigned s01 = bm_sat_pk(__builtin_amdgcn_perm(v[1], v[0], 0x07060302u));
-          const unsigned s23 = bm_sat_pk(__builtin_amdgcn_perm(v[3], v[2], 0x07060302u));
-          // lane (row 16 Y + m, quarter kq): blurred columns 16 X + 4 kq .. + 3 of that row
-          *(__attribute__((address_space(3))) unsigned *)(R + kOdPitch * (16 * Y + m) + 16 * X + 4 * kq) = s01 | (s23 << 16);
-        }
-      }
-    }
-    wave_sync();
-#pragma unroll
-    for (int s = 0; s < NK; s++) {
-      const int kk = min(k + s, k1 - 1);
-      const float a = uni_f32(rec[kk].a), b = uni_f32(rec[kk].b);
-      // (r + 19) * 80 + (q + 19) from the raw bit patterns: v_mad_u32_u24 takes the low 24 bits of rint(x)'s pattern, 0x400000 + r
-      const unsigned fold = (unsigned)(kEdge * kOdPitch + kEdge) - (0x400000u * (unsigned)kOdPitch + 0x4B400000u);
-      const lds_u8 *wl = (const lds_u8 *)win_lds[wave][s];
-      const v2f ba = {b, a}, anb = {a, -b}, mg = {kMagic, kMagic};
-#pragma unroll
-      for (int w = 0; w < 4; w++)
-#pragma unroll
-        for (int e = 0; e < 2; e++) {
-          const int c = 18 + 4 * w + 2 * e;
-          const float x = __uint_as_float(tab[c >> 2][c & 3]), y = __uint_as_float(tab[(c + 1) >> 2][(c + 1) & 3]);
-          const v2f xx = {x, x}, yy = {y, y};
-          const v2f rq = (xx * ba + yy * anb) + mg;
-          const unsigned o = __umul24(__float_as_uint(rq.x), (unsigned)kOdPitch) + __float_as_uint(rq.y) + fold;
-          t[s][2 * w + e] = wl[o];
-        }
-    }
-#pragma unroll
-    for (int s = 0; s < NK; s++) {
-      unsigned long long wd[4];
-#pragma unroll
-      for (int w = 0; w < 4; w++) wd[w] = __builtin_amdgcn_ballot_w64(t[s][2 * w] < t[s][2 * w + 1]);
-      const unsigned long long mine = lane == 0 ? wd[0] : lane == 1 ? wd[1] : lane == 2 ? wd[2] : wd[3];
-      if (lane < 4 && k + s < k1) reinterpret_cast<unsigned long long *>(desc + ((long long)f * capacity + g0 + k + s) * 32)[lane] = mine;
-    }
-    wave_sync();  // the windows are overwritten by the next group
-  }
-  for (int k = k0; !OD && k < k1; k += NK) {
+  for (int k = k0; k < k1; k += NK) {
     u32x4 wv[NK][3];
     int ox[NK];
     bool narrow[NK];
@@ -1983,20 +1830,30 @@ __global__ __launch_bounds__(256, 4) void k_describe(OrbDev P, FrameSrc src, con
 
 
 // ------------------------------------------------------------------------------------------
-// K3 + K4 + K5 in one visit of the window (round 6, second form of the on-demand blur): the 45 x 45 RAW window of a key-point
-// is brought into LDS ONCE -- k_describe<., true> fetched the 31 x 31 orientation window in phase 1 and the 45 x 45 window,
-// which contains it, again in phase 3: five 1 KB loads per key-point where three do -- and stays there from the moments to
-// the tests.  A wavefront owns kDwKpw = 4 key-points from start to end (no workgroup barrier, no key-point records in LDS):
-//  0  every lane derives the data of key-point (lane & 3) of its wavefront (level, position, plane); the per-key-point
-//     values move to scalar registers by v_readlane
+// K3 + K4 + K5 in one visit of the window (round 6; the default, VO_ORB_OPT_DESCRIBE_BLUR = 0).  No blurred pyramid is made:
+// the 45 x 45 RAW window of a key-point -- the 39 x 39 window of the tests plus the blur's three pixels a side; it contains the
+// 31 x 31 orientation window -- is brought into LDS ONCE and stays there from the moments to the tests; the blur of a whole
+// pyramid (1.9 GB of traffic per 1024 frames) becomes ~1.5 M blurred pixels per frame computed where they are read.
+// A wavefront owns kDwKpw = 4 key-points of ONE level from start to end (no workgroup barrier, no key-point records in LDS):
+//  0  scalar: level of the workgroup, plane, one buffer descriptor; the lanes' key-point (lane & 3) moves to scalar registers
+//     by v_readlane
 //  1  the four windows are requested together, straight into LDS (buffer_load_dwordx4 ... lds: lane + 64 j <-> 16-byte chunk
-//     idx % 3 of window row idx / 3, LDS address 16 idx = 48 row + 16 chunk, i.e. row pitch 48; hardware range checking
-//     and row reflection by address exactly as in k_describe<., true>); the moments are byte reads of the disc at
-//     (22 + v, 22 + u) of the staged window
+//     idx % 3 of window row idx / 3, LDS address 16 idx = 48 row + 16 chunk, i.e. row pitch 48) at the exact origin px - 22
+//     (byte-aligned 16-byte loads are legal on gfx950, tools/microbench/unaligned_load.hip) with hardware range checking;
+//     BORDER_REFLECT_101: rows by address, columns by a byte fix-up of the staged rows (key-points within 22 px of the left /
+//     right edge only); the moments are byte reads of the disc at (22 + v, 22 + u) of the staged window, signed byte dot
+//     products (pixel - 128: the disc's u and v sum to zero, so the offset cancels), DPP wave sums
 //  2  lanes 0..3: fastAtan2, cos / sin, key-point record
-//  3  blur in place (v_mfma_i32_16x16x64_i8, the arithmetic and operand tables of k_describe<., true>; the constant K slots
-//     48..63 of the row pass are one 16-byte chunk behind each window instead of a fourth chunk per row), then the tests
-// LDS: 4 x 4 windows of 48 x 48 + 16 bytes = 36.3 KB per workgroup, four workgroups per CU.
+//  3  blur IN PLACE with the int8 matrix-core scheme of k_blur_mfma on v_mfma_i32_16x16x64_i8: row pass = 3 x 3 products (16
+//     rows x 64 source columns against the band of 16 output columns; the accumulator -- column on the lane, four rows per
+//     16-row tile in its registers -- is the A operand of the column pass as it stands: K slot 4 T + r of lane quarter q = row
+//     16 T + 4 q + r), column pass = 3 x 3 x 2 byte planes; all constants ride in spare K slots (K slots 48..63 of the row pass
+//     are one 16-byte chunk behind each window: two bytes 0x81 against weight 64 give its +128; the fourth dword of the column
+//     pass's A operand is a per-lane constant against weights 16 / 127: +128 on the low plane, +33152 on the high one = the three
+//     offsets and the rounding), so no accumulator is ever initialised; then the tests: lane t rotates the pattern points of
+//     tests t, t + 64, t + 128, t + 192 (packed FP32, rounding by the 1.5 * 2^23 constant), eight LDS byte gathers, four ballots
+// LDS: 4 x 4 windows of 48 x 48 + 16 bytes = 36.3 KB per workgroup, four workgroups per CU; <= 128 registers keeps the MFMA
+// results in VGPRs.  profiles/r06_ab_describe.txt: 0.82 ms per 1024 frames against 1.17 for blurred planes + k_describe.
 // ------------------------------------------------------------------------------------------
 constexpr int kDwKpw = 4;
 constexpr int kDwPitch = 48;
@@ -2081,7 +1938,7 @@ __global__ __launch_bounds__(256, 4) void k_describe_win(OrbDev P, FrameSrc src,
     for (int X = 0; X < 3; X++) Bh[X] = tb[64 * X + lane], Bv[X] = tb[64 * (3 + X) + lane];
   }
   const int m = lane & 15, kq = lane >> 4;
-  const int A3lo = kq < 2 ? 0x01010101 : 0;           // (k_describe<., true>: the constants of the column pass)
+  const int A3lo = kq < 2 ? 0x01010101 : 0;           // (the constants of the column pass: the low plane's 128, the high plane's 33152 = the three offsets and the rounding)
   const int A3hi = kq < 2 ? 0x05050505 : 0x20202020;
   lds_u8 *const W0 = (lds_u8 *)win_lds[wave][0];
   // K slots 48..63 of the row pass: bytes 0x80 (= 0 after the operand's xor), the last two 0x81 (+1 against weights 64 + 64 = the
@@ -2288,7 +2145,7 @@ struct vo_orb {
   int blur_jobs = 0;               // k_blur_groups jobs per frame quad
   int blur_job0[kMaxLevels + 1] = {0};  // first job of every level (per-level launches next to fused levels)
   // k_level_pass (orb_level_pass.inc): per level whether it takes the fused pass, its tile pitch / rows, block table, LDS bytes
-  int od_tab_off = 0;              // band operands of k_describe's on-demand blur (6 x 64 x 4 ints into `tables`)
+  int od_tab_off = 0;              // band operands of k_describe_win's window blur (6 x 64 x 4 ints into `tables`)
   int desc_blur = 0;               // vo_orb_set_option(VO_ORB_OPT_DESCRIBE_BLUR): 0 k_describe blurs its windows itself (default), 1 blurred planes
   bool blur_valid = false;         // the blurred planes of the last call exist (vo_orb_get_level(blurred) makes them on demand)
   bool last_lv0_rows16 = false;
@@ -2788,7 +2645,7 @@ int configure(vo_orb *h, int w, int h_img, int n_frames) {
         tables.insert(tables.end(), jobs.begin(), jobs.end());
       }
       {
-        // k_describe<., true>: band operands of its window blur on v_mfma_i32_16x16x64_i8, lane (n = lane & 15, kq = lane >> 4),
+        // k_describe_win: band operands of its window blur on v_mfma_i32_16x16x64_i8, lane (n = lane & 15, kq = lane >> 4),
         // byte b of the lane's 16.  Row pass X = 0..2 (16 output columns each): slot (kq, b) = staged column 16 kq + b, which enters
         // output column 16 X + n with weight w[16 kq + b - (16 X + n)]; slots 62 and 63 (the two 0x81 bytes) weigh 64.  Column
         // pass Y = 0..2: slot (kq, 4 T + r) = row 16 T + 4 kq + r of the row-pass result (the order its accumulator registers have),
@@ -2977,7 +2834,7 @@ int run_pipeline(vo_orb *h, const uint8_t *dev_images, int n_frames, int w, int 
   if (h->fused)
     for (int l = 0; l < D.nlevels; l++) any_fused = any_fused || (h->lp_ok[l] && !(l == 0 && lv0_not16));
   // on-demand blur: k_describe blurs the windows it reads; no blurred plane is made (the fused pass makes its own tiles)
-  const bool od = h->desc_blur != 1 && !any_fused;  // (2, 3: developer A/B forms of the on-demand kernel)
+  const bool od = h->desc_blur == 0 && !any_fused;
   h->blur_valid = !od;
   const bool overlap = !ev && h->side != nullptr && !any_fused && !od;
   if (any_fused) {
@@ -3063,16 +2920,15 @@ int run_pipeline(vo_orb *h, const uint8_t *dev_images, int n_frames, int w, int 
   VO_STAGE_MARK(5);
   const int kp_blocks = (std::min(capacity, h->max_kp) + 63) / 64;
   if (kp_blocks == 0 && dcounts) VO_HIP_CHECK(hipMemsetAsync(dcounts, 0, (size_t)n_frames * sizeof(int), st));
-  if (kp_blocks > 0 && od && h->desc_blur != 2) {
+  if (kp_blocks > 0 && od) {
     int groups = 0;  // 16-slot groups of the levels' selections
     for (int l = 0; l < D.nlevels; l++) groups += (D.lv[l].capSel + 4 * kDwKpw - 1) / (4 * kDwKpw);
     auto kd = k_describe_win;
     hipLaunchKernelGGL(kd, dim3(groups * ((n_frames + 7) / 8) * 8), dim3(256), 0, st, D, S, h->sel.as<uint32_t>(), h->sel_frame,
                        h->nk.as<int>(), dcounts, capacity, dkp, ddesc, groups, n_frames, h->err.as<int>(), T + h->od_tab_off);
   } else if (kp_blocks > 0) {
-    auto kd = od ? k_describe<kDescNK, true> : k_describe<kDescNK, false>;
-    hipLaunchKernelGGL(kd, dim3(kp_blocks * ((n_frames + 7) / 8) * 8), dim3(256), 0, st, D, S, h->sel.as<uint32_t>(), h->sel_frame,
-                       h->nk.as<int>(), dcounts, capacity, dkp, ddesc, lv0_not16, kp_blocks, n_frames, h->err.as<int>(), T + h->od_tab_off);
+    hipLaunchKernelGGL(k_describe<kDescNK>, dim3(kp_blocks * ((n_frames + 7) / 8) * 8), dim3(256), 0, st, D, S, h->sel.as<uint32_t>(),
+                       h->sel_frame, h->nk.as<int>(), dcounts, capacity, dkp, ddesc, lv0_not16, kp_blocks, n_frames, h->err.as<int>());
   }
   VO_STAGE_MARK(6);
 #undef VO_STAGE_MARK
@@ -3219,7 +3075,7 @@ int vo_orb_set_option(vo_orb *h, int option, int value) {
     return VO_OK;
   }
   if (option == VO_ORB_OPT_DESCRIBE_BLUR) {
-    if (value < 0 || value > 2) {
+    if (value != 0 && value != 1) {
       vo::set_error("vo_orb_set_option(VO_ORB_OPT_DESCRIBE_BLUR): 0 (on demand, inside the descriptor kernel) or 1 (blurred planes)");
       return VO_ERR_INVALID;
     }
