@@ -616,8 +616,10 @@ int vo_tracker_set_local_map(vo_tracker *t, int n, const double *points, const d
                              const int32_t *link, const uint8_t *desc);
 /* One batch.  _dev: 8-bit grey images [batch] in device memory (row pitch, frame stride in bytes), depth as
  * in vo_frames_build_dev (depth_kind 0 none, 1 float32 metres, 2 uint16 raw).  vo_tracker_track: the same
- * from host memory (width x height, tightly packed; uploads included).  Asynchronous; params NULL: 15,
- * 3, 0.8, 0. */
+ * from host memory (width x height, tightly packed; uploads included: the image ahead of the extraction, the depth -- first
+ * read by the frame build -- on a copy stream of the tracker behind the extraction's launches.  Page-locked host buffers must
+ * stay untouched until vo_tracker_results or a synchronisation; pageable ones are read before the call returns).
+ * Asynchronous; params NULL: 15, 3, 0.8, 0. */
 int vo_tracker_track_dev(vo_tracker *t, const uint8_t *dev_images, int image_pitch, size_t image_frame_stride,
                          const void *dev_depth, int depth_kind, size_t depth_frame_stride, int depth_pitch,
                          const vo_tracker_params *params);
