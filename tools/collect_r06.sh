@@ -1,7 +1,7 @@
 #!/bin/bash
 # GPU box: what profiles/r06_* is made from.  Every rocprofv3 pass has its own timeout (a counter group the profiler does not
 # like ended one gpurun call after 20 minutes this round).  Stages are selected by argument so that a call stays short:
-#   tools/collect_r06.sh trace | traffic | pmc | ebm | gba | pose | bench
+#   tools/collect_r06.sh trace | traffic | pmc | mfma | gba | pose | bench
 R=${GRAFT_REPO_ROOT:-/root/repo}
 O=$R/gpurun_out/r06; mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
@@ -29,11 +29,16 @@ traffic)
   rm -rf $O/FETCH_SIZE $O/WRITE_SIZE $O/hFETCH_SIZE $O/hWRITE_SIZE ;;
 pmc)
   bash $R/tools/pmc_sweep.sh > $O/r06_pmc_summary.txt 2>&1
-  # the matrix-pipe counters of the two kernels that moved there (VERDICT r5 #1b: record SQ_VALU_MFMA_BUSY_CYCLES)
+  rm -rf $R/gpurun_out/pmcs ;;
+mfma)
+  # the matrix-pipe counters of the kernels that use it (VERDICT r5 #1b: record SQ_VALU_MFMA_BUSY_CYCLES): k_hamming_mfma, k_describe_win
+  # (default extraction) and k_blur_mfma (VO_ORB_OPT_DESCRIBE_BLUR = 1)
   { for grp in "SQ_INSTS_VALU SQ_INSTS_MFMA SQ_INSTS_LDS SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR" "SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU_MFMA_MOPS_I8 SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_BUSY_CYCLES" "SQ_WAVES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY"; do
       rm -rf $O/pm; VO_HAM_NOCHECK=1 timeout 200 rocprofv3 --pmc $grp -d $O/pm --output-format csv -- python3 $R/tools/ham_probe.py 1024 0 > $O/pm.log 2>&1
       echo "== $grp"; python3 $R/tools/pmc_summary.py $O/pm k_hamming
       rm -rf $O/pm; VO_EXT_REPS=3 timeout 200 rocprofv3 --pmc $grp -d $O/pm --output-format csv -- python3 $R/tools/ext_stage_times.py > $O/pm.log 2>&1
+      python3 $R/tools/pmc_summary.py $O/pm k_describe
+      rm -rf $O/pm; VO_EXT_DESCBLUR=1 VO_EXT_REPS=3 timeout 200 rocprofv3 --pmc $grp -d $O/pm --output-format csv -- python3 $R/tools/ext_stage_times.py > $O/pm.log 2>&1
       python3 $R/tools/pmc_summary.py $O/pm k_blur
     done; } > $O/r06_pmc_mfma_kernels.txt 2>&1
   rm -rf $O/pm $R/gpurun_out/pmcs ;;

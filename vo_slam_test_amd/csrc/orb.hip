@@ -1856,6 +1856,7 @@ __global__ __launch_bounds__(256, 4) void k_describe(OrbDev P, FrameSrc src, con
 // results in VGPRs.  profiles/r06_ab_describe.txt: 0.82 ms per 1024 frames against 1.17 for blurred planes + k_describe.
 // ------------------------------------------------------------------------------------------
 constexpr int kDwKpw = 4;
+constexpr int kDwWaves = 4;  // wavefronts per workgroup (they do not interact; 1 / 2 measured 0.88 / 0.89 ms against 0.81)
 constexpr int kDwPitch = 48;
 constexpr int kDwWin = 48 * kDwPitch + 16;
 // the lane's 12 disc pixels as byte offsets (22 + v) * 48 + (22 + u) in such a window (vo_orb_create)
@@ -1876,10 +1877,10 @@ __device__ __forceinline__ int wave_sum63_i32(int x) {
 // address needs except the key-point itself comes from scalar registers, and the key-points' load does not wait for the level
 // counts (their prefix sum is only needed for the output position): the chain in front of the window loads is ONE round trip
 // (selection entry) instead of three (counts -> level record -> selection entry).
-__global__ __launch_bounds__(256, 4) void k_describe_win(OrbDev P, FrameSrc src, const uint32_t *sel, int sel_per_frame, const int *nk,
+__global__ __launch_bounds__(64 * kDwWaves, 16 / kDwWaves) void k_describe_win(OrbDev P, FrameSrc src, const uint32_t *sel, int sel_per_frame, const int *nk,
                                                       int *counts, int capacity, vo_keypoint *kps, uint8_t *desc,
                                                       int groups_per_frame, int n_frames, int *err_flag, const int *od_tab) {
-  __shared__ __attribute__((aligned(16))) uint8_t win_lds[4][kDwKpw][kDwWin];
+  __shared__ __attribute__((aligned(16))) uint8_t win_lds[kDwWaves][kDwKpw][kDwWin];
   typedef int od_i32x4 __attribute__((ext_vector_type(4)));
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -1894,12 +1895,12 @@ __global__ __launch_bounds__(256, 4) void k_describe_win(OrbDev P, FrameSrc src,
     for (int i = 0; i < kMaxLevels; i++)
       if (i < P.nlevels) {
         if (gb >= acc) l = i, gstart = acc;
-        acc += (P.lv[i].capSel + 4 * kDwKpw - 1) / (4 * kDwKpw);
+        acc += (P.lv[i].capSel + kDwWaves * kDwKpw - 1) / (kDwWaves * kDwKpw);
       }
   }
   l = __builtin_amdgcn_readfirstlane(l);
   const LevelGeom &L = P.lv[l];
-  const int idx0 = (gb - gstart) * (4 * kDwKpw) + wave * kDwKpw;  // the wavefront's first slot in the level's selection
+  const int idx0 = (gb - gstart) * (kDwWaves * kDwKpw) + wave * kDwKpw;  // the wavefront's first slot in the level's selection
   // the key-points: requested before anything that depends on the counts (slots past the level's count hold stale entries:
   // never used; the index stays inside the level's block)
   const uint32_t kv = sel[(long long)f * sel_per_frame + L.selBase + min(idx0 + (lane & 3), L.capSel - 1)];
@@ -2922,9 +2923,9 @@ int run_pipeline(vo_orb *h, const uint8_t *dev_images, int n_frames, int w, int 
   if (kp_blocks == 0 && dcounts) VO_HIP_CHECK(hipMemsetAsync(dcounts, 0, (size_t)n_frames * sizeof(int), st));
   if (kp_blocks > 0 && od) {
     int groups = 0;  // 16-slot groups of the levels' selections
-    for (int l = 0; l < D.nlevels; l++) groups += (D.lv[l].capSel + 4 * kDwKpw - 1) / (4 * kDwKpw);
+    for (int l = 0; l < D.nlevels; l++) groups += (D.lv[l].capSel + kDwWaves * kDwKpw - 1) / (kDwWaves * kDwKpw);
     auto kd = k_describe_win;
-    hipLaunchKernelGGL(kd, dim3(groups * ((n_frames + 7) / 8) * 8), dim3(256), 0, st, D, S, h->sel.as<uint32_t>(), h->sel_frame,
+    hipLaunchKernelGGL(kd, dim3(groups * ((n_frames + 7) / 8) * 8), dim3(64 * kDwWaves), 0, st, D, S, h->sel.as<uint32_t>(), h->sel_frame,
                        h->nk.as<int>(), dcounts, capacity, dkp, ddesc, groups, n_frames, h->err.as<int>(), T + h->od_tab_off);
   } else if (kp_blocks > 0) {
     hipLaunchKernelGGL(k_describe<kDescNK>, dim3(kp_blocks * ((n_frames + 7) / 8) * 8), dim3(256), 0, st, D, S, h->sel.as<uint32_t>(),
