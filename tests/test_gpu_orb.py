@@ -135,6 +135,40 @@ def test_noise_images_overflow_the_survivor_list(make_ext, orc, kind):
     assert np.array_equal(kps, okp) and np.array_equal(desc, odesc)
 
 
+@pytest.mark.parametrize("w,h", [(642, 481), (333, 257), (131, 99), (88, 70)])
+def test_border_windows_at_awkward_sizes(make_ext, orc, w, h):
+    """noise everywhere: key-points sit on the 19-px margin of every level on all four sides and in the corners, so the
+    descriptor kernel's windows reach 3 px beyond the plane left / right / above / below (reflected rows by address, reflected
+    columns by the fix-up, the first chunk of plane row 0 in front of the plane) at row pitches that are no multiple of 16"""
+    rng = np.random.default_rng(w * 1000 + h)
+    img = rng.integers(0, 256, (h, w), dtype=np.uint8)
+    img[h // 3:h // 2, :] = (img[h // 3:h // 2, :] // 8) * 8  # a band with ties in the FAST scores
+    # a bright square with a vertex 20 px from each image corner on a dark surround: strong corners whose windows cover the
+    # plane's first / last pixels (the one case in which a whole 16-byte chunk in front of the plane is dropped)
+    for (cx, cy, sx, sy) in [(20, 20, 1, 1), (w - 21, 20, -1, 1), (20, h - 21, 1, -1), (w - 21, h - 21, -1, -1)]:
+        x0, x1 = sorted((cx - 12 * sx, cx + 14 * sx))
+        y0, y1 = sorted((cy - 12 * sy, cy + 14 * sy))
+        img[max(y0, 0):y1 + 1, max(x0, 0):x1 + 1] = 20
+        xa, xb = sorted((cx, cx + 14 * sx))
+        ya, yb = sorted((cy, cy + 14 * sy))
+        img[ya:yb + 1, xa:xb + 1] = 235
+        img[cy, cx] = 255  # (a perfect vertex ties with its neighbour in the non-maximum suppression and both are dropped)
+    nf = 1500 if w > 300 else 400
+    e = make_ext(nf, 1.2, 8, 20, 7)
+    p = orc.orb_params(nf, 1.2, 8, 20, 7)
+    okp, odesc, _ = orc.extract(p, img, cap=nf + 256)
+    kps, desc = e(img)
+    assert len(kps) == len(okp) > 0
+    assert np.array_equal(kps, okp) and np.array_equal(desc, odesc)
+    # the margins really are populated: level coordinates within 22 px of a side (the window then reaches beyond the plane)
+    sc = np.float32(1.2) ** okp["octave"].astype(np.float32)
+    lx, ly = okp["x"] / sc, okp["y"] / sc
+    lw, lh = np.float32(w) / sc, np.float32(h) / sc
+    assert (lx < 22).any() and (ly < 22).any() and (lx > lw - 23).any() and (ly > lh - 23).any()
+    assert ((lx < 22) & (ly <= 22)).any(), "no window over a plane's first pixel"
+    assert ((lx > lw - 23) & (ly > lh - 23)).any(), "no window over a plane's last pixel"
+
+
 def test_flat_image_gives_no_keypoints(ext):
     kps, desc = ext(np.full((480, 640), 100, np.uint8))
     assert len(kps) == 0 and desc.shape == (0, 32)
