@@ -953,6 +953,10 @@ def main():
             f_chol = g_order["tile_products"] * 2 * 64 ** 3 + (g_order["tiles"] - g_order["tile_rows"]) * 64 ** 3 + g_order["tile_rows"] * 64 ** 3 / 3
             f_gba = f_gba_dense - nc6 ** 3 / 3 + f_chol
             out["global_ba"]["key_frame_order"] = g_order
+            out["global_ba"]["kernels"] = {"gather": "k_ba_pairs_lds (W / point blocks staged through LDS; vo_set_option(VO_OPT_BA_PAIRS_KERNEL, 1) = "
+                                                     "k_ba_pairs, lane = couple)",
+                                           "per_iteration_us": "profiles/r06_global_ba_kernels.txt: k_chol_tiles 504, k_ba_pairs_lds 219, k_ba_backsub 96, "
+                                                               "k_chol_back 63, k_ba_cams_large 39, seven small kernels 70"}
             out["global_ba"]["roofline"] = {"bound": "fp64 mfma (tile Cholesky on a nested-dissection plan: the serial chain of dependent tile columns bounds it)",
                                             "flops_per_iteration": round(f_gba), "flops_per_iteration_dense_survey_8d": round(f_gba_dense),
                                             "achieved": round(f_gba * gs.iterations / tg / 1e12, 3),
