@@ -2319,15 +2319,15 @@ __global__ __launch_bounds__(256) void k_ba_pairs_lds(BaDev B) {
       const int ci = min(7 * q + c7, kPrStep - 1);
       const unsigned e = (unsigned)__builtin_amdgcn_ds_bpermute(4 * ci, rec.x), ep = (unsigned)__builtin_amdgcn_ds_bpermute(4 * ci, rec.y);
       if (c7 < 7 && 7 * q + c7 < kPrStep) {
-        __builtin_amdgcn_global_load_lds(We + (e * 144u + (unsigned)ch9), LW + 1008 * q, 16, 0, 0);
-        __builtin_amdgcn_global_load_lds(We + (ep * 144u + (unsigned)ch9), LP + 1008 * q, 16, 0, 0);
+        __builtin_amdgcn_global_load_lds(We + ((unsigned long long)e * 144u + (unsigned)ch9), LW + 1008 * q, 16, 0, 0);
+        __builtin_amdgcn_global_load_lds(We + ((unsigned long long)ep * 144u + (unsigned)ch9), LP + 1008 * q, 16, 0, 0);
       }
     }
 #pragma unroll
     for (int q = 0; q < 2; q++) {
       const int ci = min(21 * q + c21, kPrStep - 1);
       const unsigned j = (unsigned)__builtin_amdgcn_ds_bpermute(4 * ci, rec.z);
-      if (c21 < 21 && 21 * q + c21 < kPrStep) __builtin_amdgcn_global_load_lds(Hi + (j * 48u + (unsigned)ch3), LH + 1008 * q, 16, 0, 0);
+      if (c21 < 21 && 21 * q + c21 < kPrStep) __builtin_amdgcn_global_load_lds(Hi + ((unsigned long long)j * 48u + (unsigned)ch3), LH + 1008 * q, 16, 0, 0);
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
