@@ -600,6 +600,39 @@ def test_large_system_local_ba_matches_oracle(vo, orc, pairs_kernel, n_kf, n_pts
     assert np.allclose([sums[0].final_cost, sums[1].final_cost], [osums[0].final_cost, osums[1].final_cost], rtol=1e-8)
 
 
+@pytest.mark.parametrize("n_kf,n_pts,seed", [(26, 500, 11), (40, 3000, 12), (64, 1500, 13)])
+def test_gather_kernels_agree_on_the_reduced_system(vo, n_kf, n_pts, seed):
+    """k_ba_pairs_lds (32 couples per step, blocks staged through LDS) against k_ba_pairs (lane = couple) on the same
+    linearisation: the reduced camera system, entry by entry.  The sums run in different orders, so the bound is rounding
+    (1e-12 of the largest entry); the problems give pairs of 1 ... several hundred couples, i.e. partial, whole and many steps."""
+    import torch
+    pr = synth.make_lba_problem(seed, n_kf=n_kf, n_pts=n_pts, n_fixed=1)
+    stream = torch.cuda.current_stream().cuda_stream
+    got = []
+    try:
+        for kernel in (0, 1):
+            vo.set_option("ba_pairs_kernel", kernel)
+            ba = vo.BundleAdjuster(pr, stream=stream)
+            assert 6 * ba.n_free_cams() + 1 > 128
+            _, n1 = ba.reduced_system()
+            _, n2 = ba.reduced_cost()
+            t1 = torch.zeros(n1, dtype=torch.float64, device="cuda")
+            t2 = torch.zeros(n2, dtype=torch.float64, device="cuda")
+            ba.set_reduce_buffers(t1, t2)
+            ba.lm_begin(HM, HS, 3)
+            ba.linearize()
+            torch.cuda.synchronize()
+            got.append(t1.cpu().numpy().copy())
+            ba.lm_end()
+            ba.close()
+    finally:
+        vo.set_option("ba_pairs_kernel", 0)
+    a, b = got
+    assert a.shape == b.shape and np.isfinite(a).all() and np.abs(a).max() > 0
+    assert np.abs(a - b).max() <= 1e-12 * np.abs(b).max()
+    assert np.array_equal(a != 0, b != 0)  # the same entries are written
+
+
 def test_large_system_with_an_isolated_straddling_camera(vo, orc, pairs_kernel):
     """64 is not a multiple of 6, so the 6x6 diagonal block of slot 10 (rows 60..65) lies in tiles (0,0), (1,0)
     and (1,1).  Here slot 10 is covisible with slot 30 only and no pair joins tiles 0 and 1 otherwise: tile (1,0) must be
