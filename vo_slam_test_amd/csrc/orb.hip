@@ -1891,12 +1891,10 @@ __global__ __launch_bounds__(64 * kDwWaves, 16 / kDwWaves) void k_describe_win(O
   int l = 0, gstart = 0;
   {
     int acc = 0;
-#pragma unroll
-    for (int i = 0; i < kMaxLevels; i++)
-      if (i < P.nlevels) {
-        if (gb >= acc) l = i, gstart = acc;
-        acc += (P.lv[i].capSel + kDwWaves * kDwKpw - 1) / (kDwWaves * kDwKpw);
-      }
+    for (int i = 0; i < P.nlevels; i++) {
+      if (gb >= acc) l = i, gstart = acc;
+      acc += (P.lv[i].capSel + kDwWaves * kDwKpw - 1) / (kDwWaves * kDwKpw);
+    }
   }
   l = __builtin_amdgcn_readfirstlane(l);
   const LevelGeom &L = P.lv[l];
@@ -1907,13 +1905,11 @@ __global__ __launch_bounds__(64 * kDwWaves, 16 / kDwWaves) void k_describe_win(O
   int op_l = 0, total = 0;
   {
     const int *nkp = nk + f * P.nlevels;
-#pragma unroll
-    for (int i = 0; i < kMaxLevels; i++)
-      if (i < P.nlevels) {
-        const int c = nkp[i];
-        if (i < l) op_l += c;
-        total += c;
-      }
+    for (int i = 0; i < P.nlevels; i++) {
+      const int c = nkp[i];
+      if (i < l) op_l += c;
+      total += c;
+    }
   }
   const int nkl = nk[f * P.nlevels + l];
   if (gb == 0 && tid == 0 && counts) counts[f] = min(total, capacity);
