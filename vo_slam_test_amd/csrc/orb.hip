@@ -1950,23 +1950,33 @@ __global__ __launch_bounds__(64 * kDwWaves, 16 / kDwWaves) void k_describe_win(O
     const int idx = lane + 64 * j;
     wrow[j] = min(idx / 3, 44), wch[j] = 16 * (idx % 3);
   }
+  // (the level is uniform: row x pitch + chunk of the lane's three loads once per group; a window strictly inside the plane's
+  //  rows then needs no vector instruction per load -- its origin rides in the load's scalar offset)
+  int wro[3];
+#pragma unroll
+  for (int j = 0; j < 3; j++) wro[j] = (int)__umul24((unsigned)wrow[j], (unsigned)pitch) + wch[j];
 #pragma unroll
   for (int s = 0; s < kDwKpw; s++) {
     const int ss = min(s, nv - 1);
     px[s] = __builtin_amdgcn_readlane(px_v, ss), py[s] = __builtin_amdgcn_readlane(py_v, ss);
     const bool inside = py[s] >= 22 && py[s] + 22 < LH;  // uniform: no row of the window is reflected
+    // strictly inside: not even the plane's first or last row is touched, so every byte of the window is in the plane or in the
+    // bytes that follow a row inside it -- nothing for the range check to catch (the scalar offset is not part of that check)
+    const bool strictly = py[s] >= 23 && py[s] + 23 < LH;
     const int base = (py[s] - 22) * pitch + (px[s] - 22);
 #pragma unroll
     for (int j = 0; j < 3; j++) {
-      int off;
+      int off, soff = 0;
       // (an offset in front of the plane is a huge unsigned one: the range check returns zeros, as it does behind the plane)
-      if (inside) {
-        off = (int)__umul24((unsigned)wrow[j], (unsigned)pitch) + (wch[j] + base);
+      if (strictly) {
+        off = wro[j], soff = base;
+      } else if (inside) {
+        off = wro[j] + base;
       } else {
         const int y = reflect101_near(py[s] - 22 + wrow[j], LH);
         off = __mul24(y, pitch) + (px[s] - 22) + wch[j];
       }
-      if (j < 2 || lane < 16) __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (__attribute__((address_space(3))) void *)(W0 + kDwWin * s + 1024 * j), 16, off, 0, 0, 0);
+      if (j < 2 || lane < 16) __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (__attribute__((address_space(3))) void *)(W0 + kDwWin * s + 1024 * j), 16, off, soff, 0, 0);
     }
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
