@@ -1932,7 +1932,12 @@ __global__ __launch_bounds__(64 * kDwWaves, 16 / kDwWaves) void k_describe_win(O
   {
     const od_i32x4 *tb = reinterpret_cast<const od_i32x4 *>(od_tab);
 #pragma unroll
-    for (int X = 0; X < 3; X++) Bh[X] = tb[64 * X + lane], Bv[X] = tb[64 * (3 + X) + lane];
+    for (int X = 0; X < 3; X++) Bh[X] = tb[64 * X + lane];
+    // the column pass's band for output tile Y is the one for tile 0 moved down by Y row tiles (K slot 4 T + r = row 16 T + 4 q + r:
+    // the tile index is the dword index; dword 3 = the constant slots, the same for every Y): one load instead of three
+    Bv[0] = tb[64 * 3 + lane];
+    Bv[1] = od_i32x4{0, Bv[0].x, Bv[0].y, Bv[0].w};
+    Bv[2] = od_i32x4{0, 0, Bv[0].x, Bv[0].w};
   }
   const int m = lane & 15, kq = lane >> 4;
   const int A3lo = kq < 2 ? 0x01010101 : 0;           // (the constants of the column pass: the low plane's 128, the high plane's 33152 = the three offsets and the rounding)
