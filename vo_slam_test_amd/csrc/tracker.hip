@@ -471,7 +471,7 @@ int solve_pose(vo_tracker *t) {
 enum : unsigned { kRunFront = 1u, kRunMotion = 2u, kRunRefKeyFrame = 4u, kRunLocal = 8u };
 
 int stage_front(vo_tracker *t, const uint8_t *dev_images, int img_pitch, size_t img_frame_stride, const void *dev_depth,
-                int depth_kind, size_t depth_frame_stride, int depth_pitch) {
+                int depth_kind, size_t depth_frame_stride, int depth_pitch, const void *host_depth) {
   const int B = t->B;
   hipStream_t st = t->st, est = t->est;
   const vo_tracker_config &c = t->cfg;
@@ -484,11 +484,9 @@ int stage_front(vo_tracker *t, const uint8_t *dev_images, int img_pitch, size_t 
   }
   VO_HIP_CHECK(hipEventRecord(t->ev_extract, est));
   if (est != st) VO_HIP_CHECK(hipStreamWaitEvent(st, t->ev_extract, 0));
-  if (t->pend_depth) {  // (see vo_tracker::cst)
+  if (host_depth) {  // (see vo_tracker::cst)
     if (t->have_build) VO_HIP_CHECK(hipStreamWaitEvent(t->cst, t->ev_build, 0));  // the last call's depth has been consumed
-    const void *src = t->pend_depth;
-    t->pend_depth = nullptr;
-    VO_HIP_CHECK(hipMemcpyAsync(t->depth.p, src, t->pend_depth_bytes, hipMemcpyHostToDevice, t->cst));
+    VO_HIP_CHECK(hipMemcpyAsync(t->depth.p, host_depth, t->pend_depth_bytes, hipMemcpyHostToDevice, t->cst));
     VO_HIP_CHECK(hipEventRecord(t->ev_depth, t->cst));
     VO_HIP_CHECK(hipStreamWaitEvent(st, t->ev_depth, 0));
   }
@@ -658,6 +656,10 @@ int stage_local(vo_tracker *t, const vo_tracker_params &P) {
 
 int run_pipeline(vo_tracker *t, const uint8_t *dev_images, int img_pitch, size_t img_frame_stride, const void *dev_depth,
                  int depth_kind, size_t depth_frame_stride, int depth_pitch, const vo_tracker_params *prm, unsigned run) {
+  // (the host depth image of THIS call, if any: taken off the handle before anything can fail, so that a call that ends early never
+  //  leaves a host pointer behind for the next one)
+  const void *host_depth = t->pend_depth;
+  t->pend_depth = nullptr;
   VO_CHECK(begin_timed_call(t));
   t->pend.assigned = nullptr;  // (a call that failed half-way must not leave its matches to the next one)
   if (!(run == (kRunFront | kRunMotion | kRunLocal))) t->tslot = -1;  // the six stage timers describe the one-call tracked frame
@@ -670,7 +672,7 @@ int run_pipeline(vo_tracker *t, const uint8_t *dev_images, int img_pitch, size_t
     P.radius = 15.f, P.th_radius = 3.f, P.ratio = 0.8f, P.direction = 0, P.no_retry = 0, P.ref_ratio = 0.7f;
   }
   if (run & kRunFront)
-    VO_CHECK(stage_front(t, dev_images, img_pitch, img_frame_stride, dev_depth, depth_kind, depth_frame_stride, depth_pitch));
+    VO_CHECK(stage_front(t, dev_images, img_pitch, img_frame_stride, dev_depth, depth_kind, depth_frame_stride, depth_pitch, host_depth));
   const size_t capB = (size_t)B * t->cap;
   if ((run & kRunMotion) && t->nq_last == 0) {
     // no last frame (the first frame of a sequence, visualOdometry.cpp:170-214): Frame construction only; the pose is
