@@ -141,9 +141,8 @@ constexpr int kRzL = 16;               // lanes (four-pixel groups) per tile row
 constexpr int kRzF = 64 / kRzL;        // frames a wavefront works on side by side
 constexpr int kRzW = 4 * kRzL, kRzH = 16;  // output tile of k_resize4: 64 x 16 pixels of kRzF frames
 constexpr int kRzMaxDw = 32;           // dwords per source row of a tile (scale factors up to ~1.8)
-constexpr int kRzPitch = 4 * kRzMaxDw + 4;  // LDS row pitch: constant, so staged rows sit at immediate offsets
+constexpr int kRzPitch = 4 * kRzMaxDw;  // LDS row pitch (128 bytes: eight 16-byte chunks, what a lane group of the LDS-DMA staging fills)
 constexpr int kRzMaxRows = 32;         // source rows of a tile
-constexpr int kRzNQ = kRzMaxRows * kRzF / 8;  // staging loads per thread: 8 stacked rows (2 source rows x 4 frames) each
 
 // One workgroup per 64 x 16 output tile of four consecutive frames; lane = frame * 16 + four-pixel group: a
 // 256-pixel-wide tile wastes up to half of its lanes on the narrow levels, a 64-pixel one at most a fifth, and
@@ -151,8 +150,10 @@ constexpr int kRzNQ = kRzMaxRows * kRzF / 8;  // staging loads per thread: 8 sta
 // Everything that depends only on the output column is precomputed per level with the handle (`gtab`: per
 // four-pixel group the aligned source column, the byte offset of its 8-byte window, the four tap selectors and
 // coefficient pairs; `btab`: per column block the first source dword and the dwords per row), and the source
-// rectangles are staged without index arithmetic: thread (x = tid & 31, tr = tid >> 5) copies dword x of
-// stacked row 8 q + tr (source row 2 q + (tr >> 2) of frame tr & 3) for q = 0, 1, ... into LDS row 8 q + tr.
+// rectangles are staged by LDS-DMA (round 6; buffer_load_dwordx4 ... lds, dword-aligned source, hardware range check):
+// LDS row 8 Q + s (128 bytes) = source row 2 Q + (s >> 2) of frame s & 3, one wave-instruction per group Q of eight
+// stacked rows, lane = 8 s + 16-byte chunk -- no registers, no LDS stores (the round-2 form, a dword per lane through
+// registers into rows of 132 bytes: 0.492 against 0.477 ms per 1024 frames).
 // One tile per workgroup measured fastest (0.196 ms per 256 frames against 0.214 / 0.221 / 0.240 with 2 / 4 /
 // 8 vertically consecutive tiles software-pipelined in one workgroup): many small workgroups overlap their
 // loads and arithmetic across each other better than an in-kernel pipeline does.
@@ -197,22 +198,22 @@ __global__ __launch_bounds__(256) void k_resize4(const uint8_t *src, long long s
     bb_[r] = yab[dy];
   }
   {
-    const int x = min(tid & 31, ndw - 1), tr = tid >> 5;  // lanes past the row's last dword repeat it
-    const int ymax = sh - 1 - r0;
-    const uint8_t *g0 = S + (long long)r0 * s_pitch + c0 + (long long)min(tr & 3, nfr - 1) * s_frame_stride + 4 * x;
-    uint8_t *lt = rz_tile + tr * kRzPitch + 4 * x;
-    const bool hi = (tr >> 2) != 0;
-    unsigned v[kRzNQ];
-#pragma unroll
-    for (int q = 0; q < kRzNQ; q++)
-      if (q < nq) {  // uniform
-        // source row 2 q + (tr >> 2), clamped to the image: both candidates are scalar
-        const int ra = __mul24(min(2 * q, ymax), s_pitch), rb = __mul24(min(2 * q + 1, ymax), s_pitch);
-        v[q] = *reinterpret_cast<const unsigned *>(g0 + (hi ? rb : ra));
-      }
-#pragma unroll
-    for (int q = 0; q < kRzNQ; q++)
-      if (q < nq) *reinterpret_cast<unsigned *>(lt + q * 8 * kRzPitch) = v[q];
+    // staging by LDS-DMA: lane = 8 x row slot + 16-byte chunk; a wave-instruction fills the 8 stacked rows 8 Q .. 8 Q + 7 (source rows
+    // 2 Q and 2 Q + 1 of the four frames) at 128 bytes each -- the same stacking as above with the dwords of a chunk fetched together,
+    // no registers, no LDS stores, two vector instructions of address arithmetic per 1 KB
+    const int lane = tid & 63, rs = lane >> 3, c = lane & 7;
+    const int nch = (ndw + 3) >> 2, ymax = sh - 1 - r0;
+    const __amdgpu_buffer_rsrc_t rsb = __builtin_amdgcn_make_buffer_rsrc((void *)S, 0, (int)((nfr - 1) * s_frame_stride) + sh * s_pitch, 0x00020000);
+    // (the four frames' rows of a source row sit 128 bytes apart, i.e. in the same banks; an xor swizzle of the chunk position by the
+    //  frame that spreads them over the 32 banks changed nothing: 0.477-0.479 ms either way -- the kernel does not wait for LDS)
+    const int lane_off = min(rs & 3, nfr - 1) * (int)s_frame_stride + r0 * s_pitch + c0 + 16 * min(c, nch - 1);
+    const bool hi = (rs >> 2) != 0;
+    for (int Q = wave; Q < nq; Q += 4) {  // uniform per wavefront
+      const int ra = __mul24(min(2 * Q, ymax), s_pitch), rb = __mul24(min(2 * Q + 1, ymax), s_pitch);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsb, (__attribute__((address_space(3))) void *)((__attribute__((address_space(3))) uint8_t *)rz_tile + Q * 8 * kRzPitch), 16,
+                                               lane_off + (hi ? rb : ra), 0, 0, 0);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   }
   __syncthreads();
   const int dyw = dy0 + wave * R;
